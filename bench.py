@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the seed-and-extend hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): batched banded Smith-Waterman/Gotoh, 10 M x 100 bp
+reads vs 150 bp reference windows per GPU, band 15, LOCAL, scheme (2,-1,-2,-1); inputs are
+generated on the device and are resident in HBM before the timed region.  A "step" is one
+pass of the extension kernel over the whole batch (for N>1: over every rank's shard, plus the
+gather of the result records to rank 0 over RCCL/xGMI, overlapped with the next step).
+
+Also measured in the same run (not part of `value`): the FM-index rank() point-query kernel
+on a 3 Gbp-sized index (the second half of BASELINE.json's metric), reported as `rank_roofline`,
+and the CPU oracle timed on the host cores (`cpu_baseline`).
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+import nvbio_amd as nvb
+from nvbio_amd import workloads as W
+
+# MI355X peaks (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12      # int32 lane-ops/s: 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6 T
+
+READ_LEN, REF_LEN, BAND = 100, 150, 15
+SCHEME = (2, -1, -2, -1)
+# algorithmic figures per alignment
+CELLS_PER_ALN = READ_LEN * BAND                    # 1500 band cells
+NOMINAL_OPS_PER_CELL = 14                          # reference recurrence, int ops per cell
+BYTES_PER_ALN = 50 + 29 + 12 + 8                   # packed read + text window + sink record + offsets = 99 B
+RANK_BYTES_PER_QUERY = 40                          # 32 B record + 4 B query + 4 B result
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
+    ap.add_argument("--rank-genome", type=float, default=3.0e9, help="BWT length of the rank leg (symbols)")
+    ap.add_argument("--rank-queries", type=int, default=1 << 28)
+    ap.add_argument("--no-rank", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2_000_000)
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local])
+        torch.cuda.synchronize()
+
+    # ---------------------------------------------------------------- inputs (resident before timing)
+    n = a.reads
+    patterns, texts = W.make_sw_batch(n, READ_LEN, REF_LEN, seed=0x5EED0002 + rank, device=dev)
+    aligner = nvb.make_gotoh_aligner(nvb.LOCAL, nvb.SimpleGotohScheme(*SCHEME))
+    batch = nvb.BatchedBandedAlignmentScore(BAND)
+    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+
+    def launch(buf):
+        batch.enact(aligner, patterns, texts, buf[0], buf[1])
+
+    # result records: score[n] + sink[n,2] = 12 B per read, double-buffered so that the gather
+    # of step k (side stream) overlaps the kernel of step k+1
+    outs = [(torch.empty(n, dtype=torch.int32, device=dev), torch.empty((n, 2), dtype=torch.int32, device=dev)) for _ in range(2)]
+    g_scores = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    g_sinks = [torch.empty((n, 2), dtype=torch.int32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    pending = [None, None]
+
+    def step(i, events=None):
+        b = i & 1
+        if world > 1 and pending[b] is not None:
+            torch.cuda.current_stream().wait_event(pending[b])        # gather of step i-2 done: buffer b is free
+        if events is not None:
+            events[0].record()
+        launch(outs[b])
+        if events is not None:
+            events[1].record()
+        if world > 1:
+            comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(comm_stream):
+                dist.gather(outs[b][0], g_scores, dst=0)
+                dist.gather(outs[b][1], g_sinks, dst=0)
+                pending[b] = torch.cuda.Event()
+                pending[b].record(comm_stream)
+
+    # ---------------------------------------------------------------- parity gate (sample vs oracle)
+    parity = None
+    if rank == 0:
+        from oracle import pyoracle as O          # checker only
+        import numpy as np
+        launch(outs[0])
+        torch.cuda.synchronize()
+        m = min(n, 100_000)
+        sub_p = nvb.PackedStringSet(patterns.words, 4, True, patterns.begin[:m].contiguous(), None, READ_LEN)
+        sub_t = nvb.PackedStringSet(texts.words, 2, False, texts.begin[:m].contiguous(), None, REF_LEN)
+        es, ek = O.batch_banded_gotoh_score(BAND, O.LOCAL, SCHEME, O.StringSet.from_device(sub_p), O.StringSet.from_device(sub_t))
+        ok = bool((outs[0][0][:m].cpu().numpy() == es).all() and (outs[0][1][:m].cpu().numpy().view(np.uint32) == ek).all())
+        parity = {"checked": m, "bit_exact": ok}
+        if not ok:
+            raise SystemExit("parity gate failed: HIP scores differ from the oracle")
+
+    # ---------------------------------------------------------------- timed region
+    for i in range(a.warmup):
+        step(i)
+    barrier()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i, evs[i])
+    if world > 1:
+        torch.cuda.current_stream().wait_stream(comm_stream)
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(a.steps, 1)
+
+    out = None
+    if rank == 0:
+        total_reads = n * world * a.steps
+        value = total_reads / elapsed
+        kt = kern_ms * 1e-3
+        roofline = {
+            "kernel": "banded_gotoh_score_kernel<15,LOCAL>",
+            "bound": "valu",
+            "achieved": n * CELLS_PER_ALN * NOMINAL_OPS_PER_CELL / kt / 1e12,
+            "peak": VALU_PEAK_TOPS,
+            "unit": "Tint-op/s",
+            "frac": n * CELLS_PER_ALN * NOMINAL_OPS_PER_CELL / kt / 1e12 / VALU_PEAK_TOPS,
+            "traffic": None,
+            "kernel_ms": kern_ms,
+            "gcups": n * CELLS_PER_ALN / kt / 1e9,
+            "hbm_GBs": n * BYTES_PER_ALN / kt / 1e9,
+            "hbm_frac": n * BYTES_PER_ALN / kt / 1e9 / HBM_PEAK_GBS,
+            "note": "integer DP: neither HBM nor MFMA binds it; peak = int32 VALU lane-ops/s, achieved = cells x 14 nominal ops (SURVEY 8d)",
+        }
+        out = {
+            "metric": "aligned reads/s (100 bp, band=15)", "value": value, "unit": "reads/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": "nvbio::aln batched banded SW (configs[1]): %d x 100 bp reads vs 150 bp windows per GPU, band=15, LOCAL Gotoh (2,-1,-2,-1)" % n,
+                       "reads_per_gpu": n, "read_len": READ_LEN, "band": BAND, "type": "LOCAL", "parallelism": "read-shard x%d, gather to rank 0" % world},
+            "roofline": roofline, "parity": parity,
+        }
+
+    # ---------------------------------------------------------------- FM-index rank leg (rank 0, N == 1 only)
+    if rank == 0 and world == 1 and not a.no_rank:
+        out["rank_roofline"] = rank_leg(a, dev)
+    if rank == 0 and world == 1 and not a.no_cpu:
+        out["cpu_baseline"] = cpu_leg(a, patterns, texts)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def rank_leg(a, dev):
+    """rank(i,c) point queries at uniform random i on a 3 Gbp-sized index (random BWT string with a
+    device-built occurrence table): algorithmic 40 B per query."""
+    ng = int(a.rank_genome)
+    words = W.make_random_bwt(ng, device=dev)
+    bwt_occ, L2 = nvb.build_bwt_occ(ng, words)
+    del words
+    fmi = nvb.FMIndexDevice(ng, ng, L2, bwt_occ)
+    q = a.rank_queries
+    g = torch.Generator(device=dev)
+    g.manual_seed(0x5EED0003)
+    k = torch.randint(0, ng, (q,), dtype=torch.int64, generator=g, device=dev).to(torch.int32)
+    c = torch.randint(0, 4, (q,), dtype=torch.uint8, generator=g, device=dev)
+    r = nvb.rank(fmi, k, c)          # warm-up + property check: rank <= k+1, and sums over c
+    torch.cuda.synchronize()
+    kk = (k.to(torch.int64) & 0xFFFFFFFF)
+    assert bool(((r.to(torch.int64) & 0xFFFFFFFF) <= kk + 1).all())
+    reps = 5
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for e0, e1 in evs:
+        e0.record()
+        nvb.rank(fmi, k, c)
+        e1.record()
+    torch.cuda.synchronize()
+    ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / reps
+    gbs = q * RANK_BYTES_PER_QUERY / (ms * 1e-3) / 1e9
+    return {"kernel": "fm_rank_kernel", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gbs / HBM_PEAK_GBS, "traffic": None, "kernel_ms": ms, "queries": q, "index_symbols": ng,
+            "index_bytes": int(bwt_occ.numel()) * 4, "Mqueries_per_s": q / (ms * 1e-3) / 1e6}
+
+
+def cpu_leg(a, patterns, texts):
+    """The CPU oracle (the reference host path's arithmetic, OpenMP like HostThreadScheduler) on a
+    bounded sample of the same workload, all host cores."""
+    from oracle import pyoracle as O
+    m = min(len(patterns), a.cpu_sample)
+    sub_p = nvb.PackedStringSet(patterns.words, 4, True, patterns.begin[:m].contiguous(), None, READ_LEN)
+    sub_t = nvb.PackedStringSet(texts.words, 2, False, texts.begin[:m].contiguous(), None, REF_LEN)
+    hp, ht = O.StringSet.from_device(sub_p), O.StringSet.from_device(sub_t)
+    cores = os.cpu_count() or 1
+    O.batch_banded_gotoh_score(BAND, O.LOCAL, SCHEME, hp, ht, n_threads=cores, native=True)      # warm-up
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        O.batch_banded_gotoh_score(BAND, O.LOCAL, SCHEME, hp, ht, n_threads=cores, native=True)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return {"value": m / best, "unit": "reads/s", "cores": cores, "kind": "port",
+            "sample": "%d of the same reads, band 15 LOCAL, OpenMP static over jobs, gcc -O3 -march=native, best of 3" % m}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,165 @@
+/*
+ * nvbio_hip.h -- C-ABI of the MI355X (gfx950) seed-and-extend hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types.
+ * Every pointer is a DEVICE pointer into caller-owned HBM unless stated
+ * otherwise; nothing is allocated, retained or freed by the library except
+ * where a `temp` buffer is passed in explicitly.  All entry points enqueue work
+ * on `stream` (a hipStream_t passed as void*; NULL = the null stream) and
+ * return immediately with 0 or a hipError_t value; they never throw and never
+ * fall back to the CPU.
+ *
+ * The reference (NVlabs/nvbio) has no ABI for this path -- it is C++ templates
+ * (SURVEY.md 8b).  Each entry point below names the reference interface it
+ * replaces; nvbio_amd/include/nvbio_hip/ *.h holds the C++ host layer that
+ * mirrors those template names on top of this ABI.
+ */
+#ifndef NVBIO_HIP_H
+#define NVBIO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NVBIO_HIP_ABI_VERSION 1
+
+/* nvbio::aln::AlignmentType (nvbio/alignment/alignment_base.h:54) */
+enum { NVBIO_HIP_GLOBAL = 0, NVBIO_HIP_LOCAL = 1, NVBIO_HIP_SEMI_GLOBAL = 2 };
+
+/* A set of strings stored in one packed word stream, i.e. what the reference
+ * expresses as a string-set over nvbio::PackedStream<const uint32*,uint8,BITS,
+ * BIG_ENDIAN> (nvbio/basic/packedstream.h, packedstream_inl.h:336-400):
+ * string i = symbols [begin[i], begin[i]+length[i]) of the stream.
+ *   words      the stream's uint32 words (device)
+ *   n_words    number of words allocated; the kernels read whole 16-symbol
+ *              groups and clamp every word load to [0,n_words), so a string may
+ *              end anywhere in the stream without padding
+ *   bits       2 or 4 (the production read / genome formats; 8-bit strings
+ *              are packed by the host layer first)
+ *   big_endian PackedStream's BIG_ENDIAN_T
+ *   begin      n symbol offsets (uint64, device)
+ *   length     n lengths (device), or NULL -> every string has `fixed_length` symbols */
+typedef struct nvbio_hip_string_set {
+    const uint32_t* words;
+    uint64_t        n_words;
+    uint32_t        bits;
+    uint32_t        big_endian;
+    const uint64_t* begin;
+    const uint32_t* length;
+    uint32_t        fixed_length;
+    uint32_t        _pad;
+} nvbio_hip_string_set;
+
+/* nvbio::aln::SimpleGotohScheme (nvbio/alignment/utils.h:114-134) */
+typedef struct nvbio_hip_gotoh_scheme {
+    int32_t match, mismatch, gap_open, gap_ext;
+} nvbio_hip_gotoh_scheme;
+
+/* nvbio::aln::BestSink<int32> (nvbio/alignment/sink.h:68-89) is returned as
+ * two arrays: score[n] and sink[2n] = {sink.x, sink.y}. */
+
+/*
+ * Replaces  BatchedBandedAlignmentScore<BAND_LEN, stream_type,
+ *           DeviceThreadBlockScheduler<128,1>>::enact(stream)
+ *           (nvbio/alignment/batched.h:333-353, batched_banded_inl.h:135-162) and
+ *           batch_banded_alignment_score<BAND_LEN>(aligner, patterns, texts, sinks, ...)
+ *           (nvbio/alignment/batched_inl.h:1074-1101)
+ * for aligner = GotohAligner<TYPE, SimpleGotohScheme>, trivial qualities:
+ * job i scores patterns[i] against texts[i] exactly as
+ * priv::banded::gotoh_alignment_score_dispatch<BAND_LEN,TYPE>::run
+ * (nvbio/alignment/gotoh/gotoh_banded_inl.h:415-658) into a fresh BestSink.
+ * band_len in {3,5,7,15,31}.  A job whose text is shorter than its pattern
+ * leaves the sink invalid (score = -(1<<30), sink = (0xFFFFFFFF,0xFFFFFFFF)).
+ */
+int nvbio_hip_banded_gotoh_score(
+    const nvbio_hip_gotoh_scheme* scheme /* host */, int32_t type, uint32_t band_len,
+    const nvbio_hip_string_set* patterns /* host struct, device arrays */,
+    const nvbio_hip_string_set* texts    /* host struct, device arrays */,
+    uint32_t n, int32_t* out_score, uint32_t* out_sink, void* stream);
+
+/* nvbio::fm_index<rank_dictionary<2,64,PackedStream<.,uint8,2,true>,.,.>, SSA_index_multiple_context<SA_INT>, const uint32*>
+ * (nvbio/fmindex/fmindex.h:341-387) in the production interleaved layout
+ * (nvbio/io/fmindex/fmindex.h:159-174, fmindex_impl.cu:305-327):
+ *   bwt_occ  8 x uint32 per 64 BWT symbols: 4 words of big-endian 2-bit BWT,
+ *            then #A,#C,#G,#T before the block
+ *   ssa      ssa[k] = SA[k*sa_int], ssa[0] = 0xFFFFFFFF (nvbio/fmindex/ssa_inl.h:263-309)
+ * This struct lives on the host; bwt_occ / ssa point to device memory. */
+typedef struct nvbio_hip_fmindex {
+    uint32_t        length;
+    uint32_t        primary;
+    uint32_t        L2[5];
+    uint32_t        sa_int;
+    const uint32_t* bwt_occ;
+    const uint32_t* ssa;
+} nvbio_hip_fmindex;
+
+/* Replaces nvbio::rank(fmi, k, c) (nvbio/fmindex/fmindex_inl.h:36-57) over n
+ * independent point queries: out[i] = rank(fmi, k[i], c[i]). */
+int nvbio_hip_fm_rank(const nvbio_hip_fmindex* fmi, const uint32_t* k, const uint8_t* c,
+                      uint32_t n, uint32_t* out, void* stream);
+
+/* Replaces nvbio::rank4(fmi, k) (fmindex_inl.h:111-135): out[4i..4i+3]. */
+int nvbio_hip_fm_rank4(const nvbio_hip_fmindex* fmi, const uint32_t* k,
+                       uint32_t n, uint32_t* out, void* stream);
+
+/* Replaces nvbio::rank(fmi, range, c) (fmindex_inl.h:66-99): range/out are uint2 arrays. */
+int nvbio_hip_fm_rank_range(const nvbio_hip_fmindex* fmi, const uint32_t* range, const uint8_t* c,
+                            uint32_t n, uint32_t* out, void* stream);
+
+/* Replaces nvbio::match(fmi, pattern, len) (fmindex_inl.h:280-341) and
+ * nvBowtie's match_range (nvBowtie/bowtie2/cuda/mapping_inl.h:83-97) over a
+ * string-set: out_range[2i..2i+1] = inclusive SA range of seeds[i], (1,0) if
+ * the seed holds a symbol > 3. */
+int nvbio_hip_fm_match(const nvbio_hip_fmindex* fmi, const nvbio_hip_string_set* seeds,
+                       uint32_t n, uint32_t* out_range, void* stream);
+
+/* Replaces nvbio::locate(fmi, i) (fmindex_inl.h:466-501) and nvBowtie's
+ * locate_kernel (nvBowtie/bowtie2/cuda/locate_inl.h:122-148). */
+int nvbio_hip_fm_locate(const nvbio_hip_fmindex* fmi, const uint32_t* sa_rows,
+                        uint32_t n, uint32_t* out_pos, void* stream);
+
+/* Two-pass form: locate_ssa_iterator / lookup_ssa_iterator (fmindex_inl.h:511-569;
+ * nvBowtie locate_init_kernel / locate_lookup_kernel, locate_inl.h:153-208).
+ * out_it / it are uint2 arrays {sampled row, steps}. */
+int nvbio_hip_fm_locate_ssa_iterator(const nvbio_hip_fmindex* fmi, const uint32_t* sa_rows,
+                                     uint32_t n, uint32_t* out_it, void* stream);
+int nvbio_hip_fm_lookup_ssa_iterator(const nvbio_hip_fmindex* fmi, const uint32_t* it,
+                                     uint32_t n, uint32_t* out_pos, void* stream);
+
+/* Replaces FMIndexFilter<device_tag,fm_index>::rank(index, string_set)
+ * (nvbio/fmindex/filter.h:139-170, filter_inl.h:268-300): out_range = match of
+ * every seed, out_slots = inclusive scan of the range sizes (uint64).
+ * temp: device scratch of nvbio_hip_fm_filter_temp_bytes(n) bytes.
+ * The total number of hits is out_slots[n-1] (left on the device). */
+uint64_t nvbio_hip_fm_filter_temp_bytes(uint32_t n);
+int nvbio_hip_fm_filter_rank(const nvbio_hip_fmindex* fmi, const nvbio_hip_string_set* seeds,
+                             uint32_t n, uint32_t* out_range, uint64_t* out_slots,
+                             void* temp, uint64_t temp_bytes, void* stream);
+
+/* Replaces FMIndexFilter<device_tag,fm_index>::locate(begin, end, hits)
+ * (filter_inl.h:306-402): hits[2(h-begin)..] = {text position, seed id} for the
+ * global hit indices h in [begin,end). */
+int nvbio_hip_fm_filter_locate(const nvbio_hip_fmindex* fmi, const uint32_t* range, const uint64_t* slots,
+                               uint32_t n_queries, uint64_t begin, uint64_t end,
+                               uint32_t* out_hits, void* stream);
+
+/* Replaces build_occurrence_table<2,64> (nvbio/fmindex/rank_dictionary_inl.h:42-77)
+ * fused with the bwt|occ interleave of the loader (fmindex_impl.cu:305-327):
+ * bwt_words = big-endian 2-bit BWT, 4*ceil(n/64) words (zero padded);
+ * out_bwt_occ = 8*ceil(n/64) words; out_L2 = 5 device words.
+ * temp: device scratch of nvbio_hip_build_bwt_occ_temp_bytes(n) bytes. */
+uint64_t nvbio_hip_build_bwt_occ_temp_bytes(uint32_t n);
+int nvbio_hip_build_bwt_occ(uint32_t n, const uint32_t* bwt_words, uint32_t* out_bwt_occ, uint32_t* out_L2,
+                            void* temp, uint64_t temp_bytes, void* stream);
+
+/* Library / device introspection (host). */
+int         nvbio_hip_abi_version(void);
+const char* nvbio_hip_arch(void);           /* "gfx950" */
+const char* nvbio_hip_last_kernel(void);    /* name of the last kernel variant launched by this thread */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NVBIO_HIP_H */

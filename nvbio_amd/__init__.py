@@ -1,0 +1,14 @@
+"""nvbio_amd -- MI355X (gfx950) native seed-and-extend hot path with nvbio's interface.
+
+The product is the C-ABI library `lib/libnvbio_hip.so` (hand-written HIP kernels,
+declared in include/nvbio_hip.h).  This Python package is a thin host layer over
+that ABI which mirrors the reference's names (nvbio::aln / nvbio::fm_index /
+FMIndexFilter) and uses torch only for device memory and streams.  There is no
+CPU fallback: importing the package without the built library raises.
+"""
+from ._lib import lib, LIB_PATH, check  # noqa: F401
+from .strings import PackedStringSet, pack_symbols  # noqa: F401
+from .alignment import (GLOBAL, LOCAL, SEMI_GLOBAL, SimpleGotohScheme, GotohAligner,  # noqa: F401
+                        make_gotoh_aligner, BatchedBandedAlignmentScore, batch_banded_alignment_score)
+from .fmindex import FMIndexDevice, FMIndexFilter, rank, rank4, rank_range, match, locate, \
+    locate_ssa_iterator, lookup_ssa_iterator, build_bwt_occ  # noqa: F401

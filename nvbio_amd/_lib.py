@@ -1,0 +1,83 @@
+"""ctypes binding of include/nvbio_hip.h.  Fails loudly when the HIP library is missing."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libnvbio_hip.so")
+
+# every symbol include/nvbio_hip.h declares
+SYMBOLS = [
+    "nvbio_hip_banded_gotoh_score",
+    "nvbio_hip_fm_rank", "nvbio_hip_fm_rank4", "nvbio_hip_fm_rank_range",
+    "nvbio_hip_fm_match", "nvbio_hip_fm_locate",
+    "nvbio_hip_fm_locate_ssa_iterator", "nvbio_hip_fm_lookup_ssa_iterator",
+    "nvbio_hip_fm_filter_temp_bytes", "nvbio_hip_fm_filter_rank", "nvbio_hip_fm_filter_locate",
+    "nvbio_hip_build_bwt_occ_temp_bytes", "nvbio_hip_build_bwt_occ",
+    "nvbio_hip_abi_version", "nvbio_hip_arch", "nvbio_hip_last_kernel",
+]
+
+
+class StringSetStruct(C.Structure):      # nvbio_hip_string_set
+    _fields_ = [("words", C.c_void_p), ("n_words", C.c_uint64), ("bits", C.c_uint32), ("big_endian", C.c_uint32),
+                ("begin", C.c_void_p), ("length", C.c_void_p), ("fixed_length", C.c_uint32), ("_pad", C.c_uint32)]
+
+
+class GotohSchemeStruct(C.Structure):    # nvbio_hip_gotoh_scheme
+    _fields_ = [("match", C.c_int32), ("mismatch", C.c_int32), ("gap_open", C.c_int32), ("gap_ext", C.c_int32)]
+
+
+class FMIndexStruct(C.Structure):        # nvbio_hip_fmindex
+    _fields_ = [("length", C.c_uint32), ("primary", C.c_uint32), ("L2", C.c_uint32 * 5), ("sa_int", C.c_uint32),
+                ("bwt_occ", C.c_void_p), ("ssa", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library.  No fallback: a missing build is an error."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "nvbio_amd: %s is missing -- build it with `python -m nvbio_amd.build` "
+                "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for s in SYMBOLS:
+            getattr(L, s)   # AttributeError if the library does not export the ABI
+        vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
+        P = C.POINTER
+        L.nvbio_hip_banded_gotoh_score.argtypes = [P(GotohSchemeStruct), i32, u32, P(StringSetStruct), P(StringSetStruct), u32, vp, vp, vp]
+        L.nvbio_hip_fm_rank.argtypes = [P(FMIndexStruct), vp, vp, u32, vp, vp]
+        L.nvbio_hip_fm_rank4.argtypes = [P(FMIndexStruct), vp, u32, vp, vp]
+        L.nvbio_hip_fm_rank_range.argtypes = [P(FMIndexStruct), vp, vp, u32, vp, vp]
+        L.nvbio_hip_fm_match.argtypes = [P(FMIndexStruct), P(StringSetStruct), u32, vp, vp]
+        L.nvbio_hip_fm_locate.argtypes = [P(FMIndexStruct), vp, u32, vp, vp]
+        L.nvbio_hip_fm_locate_ssa_iterator.argtypes = [P(FMIndexStruct), vp, u32, vp, vp]
+        L.nvbio_hip_fm_lookup_ssa_iterator.argtypes = [P(FMIndexStruct), vp, u32, vp, vp]
+        L.nvbio_hip_fm_filter_temp_bytes.argtypes = [u32]
+        L.nvbio_hip_fm_filter_temp_bytes.restype = u64
+        L.nvbio_hip_fm_filter_rank.argtypes = [P(FMIndexStruct), P(StringSetStruct), u32, vp, vp, vp, u64, vp]
+        L.nvbio_hip_fm_filter_locate.argtypes = [P(FMIndexStruct), vp, vp, u32, u64, u64, vp, vp]
+        L.nvbio_hip_build_bwt_occ_temp_bytes.argtypes = [u32]
+        L.nvbio_hip_build_bwt_occ_temp_bytes.restype = u64
+        L.nvbio_hip_build_bwt_occ.argtypes = [u32, vp, vp, vp, vp, u64, vp]
+        L.nvbio_hip_abi_version.restype = C.c_int
+        L.nvbio_hip_arch.restype = C.c_char_p
+        L.nvbio_hip_last_kernel.restype = C.c_char_p
+        for s in SYMBOLS:
+            f = getattr(L, s)
+            if f.restype is C.c_int and s not in ("nvbio_hip_abi_version",):
+                pass
+        _lib = L
+    return _lib
+
+
+def check(err, what):
+    if err != 0:
+        raise RuntimeError("nvbio_amd: %s failed with hipError %d" % (what, err))
+
+
+def current_stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,149 @@
+"""Host layer mirroring nvbio::fm_index free functions and FMIndexFilter.
+
+Reference names: rank / rank4 / match / locate / locate_ssa_iterator / lookup_ssa_iterator
+(nvbio/fmindex/fmindex_inl.h), FMIndexFilter<device_tag,...>::rank / locate
+(nvbio/fmindex/filter.h:139-203), FMIndexDataDevice (nvbio/io/fmindex/fmindex.h:294-362).
+All compute happens in libnvbio_hip.so.
+"""
+import ctypes as C
+
+import torch
+
+from ._lib import lib, check, FMIndexStruct, current_stream_ptr
+
+
+def _vp(t):
+    return C.c_void_p(t.data_ptr())
+
+
+class FMIndexDevice:
+    """Device-resident FM-index in the reference's interleaved bwt|occ layout."""
+
+    def __init__(self, length, primary, L2, bwt_occ, ssa=None, sa_int=16):
+        assert bwt_occ.dtype == torch.int32 and bwt_occ.is_contiguous()
+        assert bwt_occ.data_ptr() % 32 == 0
+        self.length, self.primary, self.L2 = int(length), int(primary), [int(x) for x in L2]
+        self.bwt_occ, self.ssa, self.sa_int = bwt_occ, ssa, int(sa_int)
+
+    def struct(self):
+        s = FMIndexStruct()
+        s.length, s.primary, s.sa_int = self.length, self.primary, self.sa_int
+        for i in range(5):
+            s.L2[i] = self.L2[i]
+        s.bwt_occ = self.bwt_occ.data_ptr()
+        s.ssa = self.ssa.data_ptr() if self.ssa is not None else None
+        return s
+
+    @staticmethod
+    def from_host(host_index, device="cuda"):
+        """host_index: any object with length, primary, L2, bwt_occ (uint32 np), ssa (uint32 np), sa_int."""
+        import numpy as np
+        bo = torch.from_numpy(np.ascontiguousarray(host_index.bwt_occ).view(np.int32)).to(device)
+        ssa = torch.from_numpy(np.ascontiguousarray(host_index.ssa).view(np.int32)).to(device)
+        return FMIndexDevice(host_index.length, host_index.primary, host_index.L2, bo, ssa, host_index.sa_int)
+
+
+def rank(fmi, k, c):
+    n = k.numel()
+    out = torch.empty(n, dtype=torch.int32, device=k.device)
+    s = fmi.struct()
+    check(lib().nvbio_hip_fm_rank(C.byref(s), _vp(k), _vp(c), n, _vp(out), current_stream_ptr()), "nvbio_hip_fm_rank")
+    return out
+
+
+def rank4(fmi, k):
+    n = k.numel()
+    out = torch.empty((n, 4), dtype=torch.int32, device=k.device)
+    s = fmi.struct()
+    check(lib().nvbio_hip_fm_rank4(C.byref(s), _vp(k), n, _vp(out), current_stream_ptr()), "nvbio_hip_fm_rank4")
+    return out
+
+
+def rank_range(fmi, ranges, c):
+    n = ranges.numel() // 2
+    out = torch.empty((n, 2), dtype=torch.int32, device=ranges.device)
+    s = fmi.struct()
+    check(lib().nvbio_hip_fm_rank_range(C.byref(s), _vp(ranges), _vp(c), n, _vp(out), current_stream_ptr()), "nvbio_hip_fm_rank_range")
+    return out
+
+
+def match(fmi, seeds, out=None):
+    n = len(seeds)
+    if out is None:
+        out = torch.empty((n, 2), dtype=torch.int32, device=seeds.words.device)
+    s, ss = fmi.struct(), seeds.struct()
+    check(lib().nvbio_hip_fm_match(C.byref(s), C.byref(ss), n, _vp(out), current_stream_ptr()), "nvbio_hip_fm_match")
+    return out
+
+
+def locate(fmi, rows, out=None):
+    n = rows.numel()
+    if out is None:
+        out = torch.empty(n, dtype=torch.int32, device=rows.device)
+    s = fmi.struct()
+    check(lib().nvbio_hip_fm_locate(C.byref(s), _vp(rows), n, _vp(out), current_stream_ptr()), "nvbio_hip_fm_locate")
+    return out
+
+
+def locate_ssa_iterator(fmi, rows):
+    n = rows.numel()
+    out = torch.empty((n, 2), dtype=torch.int32, device=rows.device)
+    s = fmi.struct()
+    check(lib().nvbio_hip_fm_locate_ssa_iterator(C.byref(s), _vp(rows), n, _vp(out), current_stream_ptr()), "nvbio_hip_fm_locate_ssa_iterator")
+    return out
+
+
+def lookup_ssa_iterator(fmi, its):
+    n = its.numel() // 2
+    out = torch.empty(n, dtype=torch.int32, device=its.device)
+    s = fmi.struct()
+    check(lib().nvbio_hip_fm_lookup_ssa_iterator(C.byref(s), _vp(its), n, _vp(out), current_stream_ptr()), "nvbio_hip_fm_lookup_ssa_iterator")
+    return out
+
+
+class FMIndexFilter:
+    """FMIndexFilter<device_tag, fm_index> (nvbio/fmindex/filter.h:139-203)."""
+
+    def __init__(self):
+        self.n_queries = 0
+        self.n_occurrences = 0
+        self.ranges = None
+        self.slots = None
+        self.index = None
+
+    def rank(self, index, string_set):
+        n = len(string_set)
+        dev = string_set.words.device
+        self.index, self.n_queries = index, n
+        self.ranges = torch.empty((n, 2), dtype=torch.int32, device=dev)
+        self.slots = torch.empty(n, dtype=torch.int64, device=dev)
+        tb = int(lib().nvbio_hip_fm_filter_temp_bytes(n))
+        temp = torch.empty(tb, dtype=torch.uint8, device=dev)
+        s, ss = index.struct(), string_set.struct()
+        check(lib().nvbio_hip_fm_filter_rank(C.byref(s), C.byref(ss), n, _vp(self.ranges), _vp(self.slots),
+                                            _vp(temp), tb, current_stream_ptr()), "nvbio_hip_fm_filter_rank")
+        self.n_occurrences = int(self.slots[n - 1].item()) if n else 0
+        return self.n_occurrences
+
+    def locate(self, begin, end, hits=None):
+        if hits is None:
+            hits = torch.empty((end - begin, 2), dtype=torch.int32, device=self.ranges.device)
+        s = self.index.struct()
+        check(lib().nvbio_hip_fm_filter_locate(C.byref(s), _vp(self.ranges), _vp(self.slots), self.n_queries,
+                                              begin, end, _vp(hits), current_stream_ptr()), "nvbio_hip_fm_filter_locate")
+        return hits
+
+
+def build_bwt_occ(n, bwt_words):
+    """Device build_occurrence_table<2,64> + interleave.  bwt_words: int32 tensor, 4*ceil(n/64) words,
+    big-endian 2-bit BWT.  Returns (bwt_occ int32[8*ceil(n/64)], L2 list of 5 ints)."""
+    n_blocks = (n + 63) // 64
+    assert bwt_words.numel() >= 4 * n_blocks and bwt_words.data_ptr() % 16 == 0
+    dev = bwt_words.device
+    out = torch.empty(8 * n_blocks, dtype=torch.int32, device=dev)
+    L2 = torch.empty(5, dtype=torch.int32, device=dev)
+    tb = int(lib().nvbio_hip_build_bwt_occ_temp_bytes(n))
+    temp = torch.empty(tb, dtype=torch.uint8, device=dev)
+    check(lib().nvbio_hip_build_bwt_occ(n, _vp(bwt_words), _vp(out), _vp(L2), _vp(temp), tb, current_stream_ptr()), "nvbio_hip_build_bwt_occ")
+    L2h = [int(x) & 0xFFFFFFFF for x in L2.cpu().tolist()]
+    return out, L2h

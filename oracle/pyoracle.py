@@ -1,0 +1,322 @@
+"""ctypes/numpy front-end of the CPU oracle (oracle/nvbio_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product package (nvbio_amd) never imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SRC = os.path.join(_HERE, "nvbio_oracle.c")
+_LIB = os.path.join(_HERE, "libnvbio_oracle.so")
+
+GLOBAL, LOCAL, SEMI_GLOBAL = 0, 1, 2   # nvbio/alignment/alignment_base.h:54
+
+_CFLAGS = ["-O3", "-fopenmp", "-fPIC", "-std=c99", "-fvisibility=hidden"]
+
+
+def build(native=False, out=None):
+    """Compile the oracle.  native=True adds -march=native (used for the
+    cpu_baseline timing on the box it is timed on) and writes next to `out`."""
+    out = out or _LIB
+    flags = list(_CFLAGS) + (["-march=native"] if native else ["-march=x86-64-v2"])
+    subprocess.check_call(["gcc"] + flags + ["-shared", "-o", out, _SRC])
+    return out
+
+
+class _Fmi(C.Structure):
+    _fields_ = [("length", C.c_uint32), ("primary", C.c_uint32), ("L2", C.c_uint32 * 5),
+                ("bwt_occ", C.c_void_p), ("ssa", C.c_void_p), ("sa_int", C.c_uint32)]
+
+
+def _load(path):
+    lib = C.CDLL(path)
+    u32p, u64p, i32p, u8p = (C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.POINTER(C.c_uint8))
+    lib.oracle_banded_gotoh_score.restype = C.c_int
+    lib.oracle_ref_banded_sw.restype = C.c_int32
+    lib.oracle_bwt_from_sa.restype = C.c_uint32
+    lib.oracle_filter_rank.restype = C.c_uint64
+    lib.oracle_num_threads.restype = C.c_int
+    return lib
+
+
+_lib = None
+_lib_native = None
+
+
+def lib(native=False):
+    global _lib, _lib_native
+    if native:
+        if _lib_native is not None:
+            return _lib_native
+        import tempfile
+        try:
+            path = build(native=True, out=os.path.join(tempfile.gettempdir(), "libnvbio_oracle_native_%d.so" % os.getpid()))
+            _lib_native = _load(path)
+            return _lib_native
+        except Exception as e:  # fall back to the portable build
+            print("oracle: native rebuild failed (%s), using portable build" % e, file=sys.stderr)
+    if _lib is None:
+        if not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(_SRC):
+            build()
+        _lib = _load(_LIB)
+    return _lib
+
+
+def _p(a, ty=None):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+# ----------------------------------------------------------------------------
+# packed streams
+# ----------------------------------------------------------------------------
+def words_for(n_symbols, bits):
+    per = 32 // bits
+    return (int(n_symbols) + per - 1) // per
+
+
+def pack(sym, bits, big_endian, pad_words=4):
+    """Pack uint8 symbols into uint32 words (PackedStream layout)."""
+    sym = np.ascontiguousarray(sym, dtype=np.uint8)
+    n = sym.size
+    per = 32 // bits
+    nw = words_for(n, bits) + pad_words
+    s = np.zeros(nw * per, dtype=np.uint32)
+    s[:n] = sym & ((1 << bits) - 1)
+    s = s.reshape(nw, per)
+    k = np.arange(per, dtype=np.uint32)
+    sh = (32 - bits - k * bits) if big_endian else (k * bits)
+    return np.bitwise_or.reduce(s << sh.astype(np.uint32), axis=1).astype(np.uint32)
+
+
+def unpack(words, begin, n, bits, big_endian):
+    out = np.zeros(n, dtype=np.uint8)
+    w = _u32(words)
+    lib().oracle_unpack(_p(w), C.c_uint64(begin), C.c_uint64(n), C.c_uint32(bits), C.c_uint32(big_endian), _p(out))
+    return out
+
+
+class StringSet:
+    """A set of strings inside one packed word stream:
+    string i = symbols [begin[i], begin[i]+length[i])."""
+
+    def __init__(self, words, bits, big_endian, begin, length):
+        self.words = _u32(words)
+        self.bits = int(bits)
+        self.big_endian = int(bool(big_endian))
+        self.begin = _u64(begin)
+        self.length = _u32(length)
+        assert self.begin.size == self.length.size
+
+    def __len__(self):
+        return self.begin.size
+
+    @staticmethod
+    def from_device(ps):
+        """Copy a device-side packed string set (any object with words/bits/big_endian/begin/
+        length/fixed_length tensors, e.g. nvbio_amd.PackedStringSet) to the host."""
+        n = len(ps)
+        length = (ps.length.cpu().numpy().view(np.uint32) if ps.length is not None
+                  else np.full(n, ps.fixed_length, dtype=np.uint32))
+        return StringSet(ps.words.cpu().numpy().view(np.uint32), ps.bits, ps.big_endian,
+                         ps.begin.cpu().numpy().view(np.uint64), length)
+
+    @staticmethod
+    def from_lists(strings, bits, big_endian):
+        lens = np.array([len(s) for s in strings], dtype=np.uint32)
+        begin = np.zeros(len(strings), dtype=np.uint64)
+        if len(strings):
+            begin[1:] = np.cumsum(lens[:-1], dtype=np.uint64)
+        cat = np.concatenate([np.asarray(s, dtype=np.uint8) for s in strings]) if len(strings) else np.zeros(0, np.uint8)
+        return StringSet(pack(cat, bits, big_endian), bits, big_endian, begin, lens)
+
+
+# ----------------------------------------------------------------------------
+# alignment
+# ----------------------------------------------------------------------------
+def _scheme(s):
+    return np.ascontiguousarray(s, dtype=np.int32)
+
+
+def banded_gotoh_score(band, aln_type, scheme, pattern, text, pat_bits=8, txt_bits=8, pat_be=False, txt_be=False):
+    """Single alignment of two uint8 symbol arrays -> (ok, score, sink_x, sink_y)."""
+    pw = pack(pattern, pat_bits, pat_be)
+    tw = pack(text, txt_bits, txt_be)
+    out = np.zeros(3, dtype=np.int32)
+    sc = _scheme(scheme)
+    ok = lib().oracle_banded_gotoh_score(
+        C.c_uint32(band), C.c_int(aln_type), _p(sc),
+        _p(pw), C.c_uint32(pat_bits), C.c_uint32(pat_be), C.c_uint64(0), C.c_uint32(len(pattern)),
+        _p(tw), C.c_uint32(txt_bits), C.c_uint32(txt_be), C.c_uint64(0), C.c_uint32(len(text)),
+        _p(out))
+    return bool(ok), int(out[0]), int(np.uint32(out[1])), int(np.uint32(out[2]))
+
+
+def batch_banded_gotoh_score(band, aln_type, scheme, patterns, texts, n_threads=0, native=False):
+    """HostThreadScheduler semantics over two StringSets -> (score[n] int32, sink[n,2] uint32)."""
+    n = len(patterns)
+    assert len(texts) == n
+    score = np.empty(n, dtype=np.int32)
+    sink = np.empty((n, 2), dtype=np.uint32)
+    sc = _scheme(scheme)
+    lib(native).oracle_batch_banded_gotoh_score(
+        C.c_uint32(band), C.c_int(aln_type), _p(sc),
+        _p(patterns.words), C.c_uint32(patterns.bits), C.c_uint32(patterns.big_endian), _p(patterns.begin), _p(patterns.length),
+        _p(texts.words), C.c_uint32(texts.bits), C.c_uint32(texts.big_endian), _p(texts.begin), _p(texts.length),
+        C.c_uint32(n), _p(score), _p(sink), C.c_int(n_threads))
+    return score, sink
+
+
+def ref_banded_sw(band, aln_type, scheme, pattern, text, pos=0):
+    p = np.ascontiguousarray(pattern, dtype=np.uint8)
+    t = np.ascontiguousarray(text, dtype=np.uint8)
+    assert len(t) >= pos + len(p) + band - 1
+    sc = _scheme(scheme)
+    return int(lib().oracle_ref_banded_sw(C.c_uint32(band), C.c_int(aln_type), _p(sc), _p(p), C.c_uint32(len(p)), _p(t), C.c_uint32(pos)))
+
+
+# ----------------------------------------------------------------------------
+# FM-index
+# ----------------------------------------------------------------------------
+def suffix_array(text):
+    """SA of text (symbols 0..3) with the reference's padding convention
+    (nvbio/fmindex/bwt.h:36-45): n+1 rows, SA[0] = n (the empty '$' suffix).
+    Prefix doubling in numpy -- test tooling for small n."""
+    t = np.ascontiguousarray(text, dtype=np.uint8)
+    n = t.size
+    K = 12
+    s = np.zeros(n + 1 + K, dtype=np.int64)
+    s[:n] = t.astype(np.int64) + 1
+    key = np.zeros(n + 1, dtype=np.int64)
+    for k in range(K):
+        key = key * 5 + s[k:k + n + 1]
+    h = K
+    while True:
+        order = np.argsort(key, kind="stable")
+        sk = key[order]
+        newr = np.zeros(n + 1, dtype=np.int64)
+        newr[1:] = np.cumsum(sk[1:] != sk[:-1])
+        rank = np.empty(n + 1, dtype=np.int64)
+        rank[order] = newr
+        if newr[-1] == n:
+            return order.astype(np.uint32)
+        nxt = np.zeros(n + 1, dtype=np.int64)
+        if h <= n:
+            nxt[:n + 1 - h] = rank[h:] + 1
+        key = rank * (n + 2) + nxt
+        h *= 2
+
+
+class FMIndex:
+    """Host FM-index in the reference's production layout (interleaved bwt|occ
+    records, nvbio/io/fmindex/fmindex_impl.cu:305-327; SSA every sa_int rows)."""
+
+    def __init__(self, text=None, sa_int=16, parts=None):
+        if parts is not None:
+            self.length, self.primary, self.L2, self.bwt_occ, self.ssa, self.sa_int = parts
+        else:
+            t = np.ascontiguousarray(text, dtype=np.uint8)
+            n = t.size
+            sa = suffix_array(t)
+            bwt = np.zeros(n + 1, dtype=np.uint8)
+            primary = lib().oracle_bwt_from_sa(C.c_uint32(n), _p(t), _p(sa), _p(bwt))
+            n_blocks = (n + 63) // 64
+            bw = np.zeros(n_blocks * 4 + 4, dtype=np.uint32)
+            pw = pack(bwt[:n], 2, True, pad_words=0)
+            bw[:pw.size] = pw
+            bwt_occ = np.zeros(max(n_blocks, 1) * 8, dtype=np.uint32)
+            L2 = np.zeros(5, dtype=np.uint32)
+            lib().oracle_build_bwt_occ(C.c_uint32(n), _p(bw), _p(bwt_occ), _p(L2))
+            ssa = np.zeros((n + 1 + sa_int - 1) // sa_int, dtype=np.uint32)
+            lib().oracle_build_ssa(C.c_uint32(n), _p(sa), C.c_uint32(sa_int), _p(ssa))
+            self.length, self.primary, self.L2, self.bwt_occ, self.ssa, self.sa_int = n, int(primary), L2, bwt_occ, ssa, sa_int
+            self.sa = sa
+            self.bwt = bwt[:n]
+        self._c = _Fmi()
+        self._c.length = self.length
+        self._c.primary = self.primary
+        for i in range(5):
+            self._c.L2[i] = int(self.L2[i])
+        self._c.bwt_occ = self.bwt_occ.ctypes.data
+        self._c.ssa = self.ssa.ctypes.data if self.ssa is not None else None
+        self._c.sa_int = self.sa_int
+
+    def _ref(self):
+        return C.byref(self._c)
+
+    def rank(self, k, c):
+        k = _u32(k); c = np.ascontiguousarray(c, dtype=np.uint8)
+        out = np.empty(k.size, dtype=np.uint32)
+        lib().oracle_fm_rank(self._ref(), _p(k), _p(c), C.c_uint32(k.size), _p(out))
+        return out
+
+    def rank4(self, k):
+        k = _u32(k)
+        out = np.empty((k.size, 4), dtype=np.uint32)
+        lib().oracle_fm_rank4(self._ref(), _p(k), C.c_uint32(k.size), _p(out))
+        return out
+
+    def rank_range(self, ranges, c):
+        r = _u32(ranges).reshape(-1, 2); c = np.ascontiguousarray(c, dtype=np.uint8)
+        out = np.empty_like(r)
+        lib().oracle_fm_rank_range(self._ref(), _p(r), _p(c), C.c_uint32(r.shape[0]), _p(out))
+        return out
+
+    def match(self, seeds, n_threads=0, native=False, want_bytes=False):
+        n = len(seeds)
+        out = np.empty((n, 2), dtype=np.uint32)
+        nbytes = C.c_uint64(0)
+        lib(native).oracle_fm_match(self._ref(), _p(seeds.words), C.c_uint32(seeds.bits), C.c_uint32(seeds.big_endian),
+                                    _p(seeds.begin), _p(seeds.length), C.c_uint32(n), _p(out), C.byref(nbytes), C.c_int(n_threads))
+        return (out, int(nbytes.value)) if want_bytes else out
+
+    def locate(self, rows, n_threads=0, native=False, want_steps=False):
+        rows = _u32(rows)
+        out = np.empty(rows.size, dtype=np.uint32)
+        steps = C.c_uint64(0)
+        lib(native).oracle_fm_locate(self._ref(), _p(rows), C.c_uint32(rows.size), _p(out), C.byref(steps), C.c_int(n_threads))
+        return (out, int(steps.value)) if want_steps else out
+
+    def locate_ssa_iterator(self, rows):
+        rows = _u32(rows)
+        out = np.empty((rows.size, 2), dtype=np.uint32)
+        lib().oracle_fm_locate_ssa_iterator(self._ref(), _p(rows), C.c_uint32(rows.size), _p(out))
+        return out
+
+    def lookup_ssa_iterator(self, its):
+        its = _u32(its).reshape(-1, 2)
+        out = np.empty(its.shape[0], dtype=np.uint32)
+        lib().oracle_fm_lookup_ssa_iterator(self._ref(), _p(its), C.c_uint32(its.shape[0]), _p(out))
+        return out
+
+    def filter_rank(self, seeds):
+        n = len(seeds)
+        ranges = np.empty((n, 2), dtype=np.uint32)
+        slots = np.empty(n, dtype=np.uint64)
+        total = lib().oracle_filter_rank(self._ref(), _p(seeds.words), C.c_uint32(seeds.bits), C.c_uint32(seeds.big_endian),
+                                         _p(seeds.begin), _p(seeds.length), C.c_uint32(n), _p(ranges), _p(slots))
+        return int(total), ranges, slots
+
+    def filter_locate(self, ranges, slots, begin, end):
+        hits = np.empty((end - begin, 2), dtype=np.uint32)
+        lib().oracle_filter_locate(self._ref(), _p(_u32(ranges)), _p(_u64(slots)), C.c_uint32(len(slots)),
+                                   C.c_uint64(begin), C.c_uint64(end), _p(hits))
+        return hits
+
+
+def num_threads():
+    return int(lib().oracle_num_threads())

@@ -1,0 +1,165 @@
+"""Parity of the HIP banded Gotoh kernel (through the C-ABI) with the CPU oracle: bit-exact
+scores and sinks.  Mirrors what the reference's alignment tests check (KATs, the differential
+ref_banded_sw check) plus the edge cases of the reference semantics."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import nvbio_amd as nvb
+from nvbio_amd import workloads as W
+from oracle import pyoracle as O
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+KAT = json.load(open(os.path.join(HERE, "golden", "kat.json")))
+SCHEMES = [(2, -1, -2, -1), (0, -5, -8, -3), (2, -1, -1, -1)]
+
+
+def dna(s):
+    return np.array(["ACGT".index(c) for c in s], dtype=np.uint8)
+
+
+def run_gpu(band, ty, scheme, hp, ht, dev):
+    """hp/ht: oracle StringSets (host) -> run the same data through the HIP path."""
+    p = nvb.PackedStringSet.from_host(hp.words, hp.bits, hp.big_endian, hp.begin, hp.length, device=dev)
+    t = nvb.PackedStringSet.from_host(ht.words, ht.bits, ht.big_endian, ht.begin, ht.length, device=dev)
+    score, sink = nvb.batch_banded_alignment_score(band, nvb.make_gotoh_aligner(ty, nvb.SimpleGotohScheme(*scheme)), p, t)
+    torch.cuda.synchronize()
+    return score.cpu().numpy(), sink.cpu().numpy().view(np.uint32)
+
+
+def check(band, ty, scheme, hp, ht, dev):
+    es, ek = O.batch_banded_gotoh_score(band, ty, scheme, hp, ht)
+    gs, gk = run_gpu(band, ty, scheme, hp, ht, dev)
+    bad = np.nonzero((es != gs) | (ek != gk).any(1))[0]
+    assert bad.size == 0, "band %d type %d scheme %s: %d mismatches, first %d: cpu (%d,%s) gpu (%d,%s)" % (
+        band, ty, scheme, bad.size, bad[0], es[bad[0]], ek[bad[0]], gs[bad[0]], gk[bad[0]])
+    return es, ek
+
+
+def test_kats_on_gpu(cuda):
+    for case in KAT["gotoh"]:
+        p, t = dna(KAT["strings"][case["p"]]), dna(KAT["strings"][case["t"]])
+        for pb, pbe, tbe in ((4, True, False), (4, False, True), (2, True, True), (2, False, False)):
+            hp = O.StringSet.from_lists([p], pb, pbe)
+            ht = O.StringSet.from_lists([t], 2, tbe)
+            gs, gk = run_gpu(case["band"], case["type"], case["scheme"], hp, ht, cuda)
+            assert int(gs[0]) == case["score"] and gk[0].tolist() == case["sink"], case
+
+
+def random_pairs(rng, n, band, max_len=160, ragged=True):
+    pats, txts = [], []
+    for i in range(n):
+        M = int(rng.integers(0 if ragged else 100, max_len)) if ragged else 100
+        kind = i % 6
+        if kind == 0:   N = M + band - 1 + int(rng.integers(0, 40))      # text covers the band
+        elif kind == 1: N = M + int(rng.integers(0, band))               # text ends inside the band (255s)
+        elif kind == 2: N = M                                            # shortest legal text
+        elif kind == 3: N = max(0, M - int(rng.integers(1, 5)))          # text shorter than pattern
+        elif kind == 4: N = M + band // 2
+        else:           N = M + band + 50
+        t = rng.integers(0, 4, N, dtype=np.uint8)
+        off = int(rng.integers(0, band))
+        p = np.resize(t[off:off + M], M) if N > off else rng.integers(0, 4, M, dtype=np.uint8)
+        if p.size != M:
+            p = rng.integers(0, 4, M, dtype=np.uint8)
+        p = p.copy()
+        mut = rng.random(M) < 0.08
+        p[mut] = rng.integers(0, 5, int(mut.sum()), dtype=np.uint8)      # includes N=4
+        if M > 20 and i % 3 == 0:                                        # an indel
+            cut = int(rng.integers(5, M - 5))
+            p = np.concatenate([p[:cut], p[cut + 2:], rng.integers(0, 4, 2, dtype=np.uint8)])
+        pats.append(p); txts.append(t)
+    return pats, txts
+
+
+@pytest.mark.parametrize("band", [3, 5, 7, 15, 31])
+@pytest.mark.parametrize("ty", [nvb.GLOBAL, nvb.LOCAL, nvb.SEMI_GLOBAL])
+def test_random_ragged_pairs(cuda, band, ty):
+    rng = np.random.default_rng(1000 + band * 3 + ty)
+    pats, txts = random_pairs(rng, 3000, band)
+    for (pb, pbe, tbe) in ((4, True, False), (4, False, True), (2, True, True), (2, False, False)):
+        if pb == 2:
+            pp = [np.minimum(p, 3) for p in pats]
+        else:
+            pp = pats
+        hp = O.StringSet.from_lists(pp, pb, pbe)
+        ht = O.StringSet.from_lists(txts, 2, tbe)
+        for scheme in SCHEMES:
+            check(band, ty, scheme, hp, ht, cuda)
+
+
+def test_empty_and_tiny_batches(cuda):
+    sc = nvb.make_gotoh_aligner(nvb.LOCAL, nvb.SimpleGotohScheme(2, -1, -2, -1))
+    p, t = W.make_sw_batch(0, device=cuda)
+    s, k = nvb.batch_banded_alignment_score(15, sc, p, t)
+    assert s.numel() == 0 and k.numel() == 0
+    for n in (1, 2, 63, 64, 65, 255, 256, 257):
+        p, t = W.make_sw_batch(n, device=cuda, seed=n)
+        hp, ht = O.StringSet.from_device(p), O.StringSet.from_device(t)
+        for ty in (0, 1, 2):
+            check(15, ty, (2, -1, -2, -1), hp, ht, cuda)
+
+
+def test_text_shorter_than_pattern_leaves_sink_invalid(cuda):
+    exp = KAT["text_shorter_than_pattern"]
+    hp = O.StringSet.from_lists([dna(KAT["strings"]["real_p"])[:100]], 4, True)
+    ht = O.StringSet.from_lists([dna(KAT["strings"]["real_t"])[:50]], 2, False)
+    for ty in (0, 1, 2):
+        gs, gk = run_gpu(15, ty, (2, -1, -2, -1), hp, ht, cuda)
+        assert int(gs[0]) == exp["score"] and gk[0].tolist() == exp["sink"]
+
+
+def test_large_negative_scores_cross_infimum(cuda):
+    """mismatch costs large enough that H drops below the reference's short-based infimum
+    (gotoh_banded_inl.h:446-448): the F[BAND-2] = max(infimum+G_e, ...) path must match."""
+    rng = np.random.default_rng(5)
+    pats = [rng.integers(0, 4, 150, dtype=np.uint8) for _ in range(500)]
+    txts = [rng.integers(0, 4, 181, dtype=np.uint8) for _ in range(500)]
+    hp, ht = O.StringSet.from_lists(pats, 4, True), O.StringSet.from_lists(txts, 2, False)
+    for band in (15, 31):
+        for ty in (0, 2):
+            check(band, ty, (1, -900, -700, -600), hp, ht, cuda)
+
+
+def test_config1_workload_100k(cuda):
+    """BASELINE config 1 inputs (100 k x 100 bp vs 150 bp, band 15, LOCAL and SEMI_GLOBAL)."""
+    p, t = W.make_sw_batch(100_000, device=cuda, seed=0x5EED0001)
+    hp, ht = O.StringSet.from_device(p), O.StringSet.from_device(t)
+    for ty in (nvb.LOCAL, nvb.SEMI_GLOBAL):
+        es, ek = check(15, ty, (2, -1, -2, -1), hp, ht, cuda)
+        assert es.min() > 100 and len(np.unique(es)) > 30      # non-trivial scores
+
+
+def test_config5_shape_150bp_band31(cuda):
+    p, t = W.make_sw_batch(50_000, read_len=150, ref_len=200, device=cuda, seed=0x5EED0005)
+    hp, ht = O.StringSet.from_device(p), O.StringSet.from_device(t)
+    check(31, nvb.LOCAL, (2, -1, -2, -1), hp, ht, cuda)
+
+
+def test_full_size_properties_10m(cuda):
+    """BASELINE config 2 at full size (10 M pairs): size-independent properties plus an exact
+    check of a strided sample against the oracle."""
+    n = 10_000_000
+    p, t = W.make_sw_batch(n, device=cuda, seed=0x5EED0002)
+    al = nvb.make_gotoh_aligner(nvb.LOCAL, nvb.SimpleGotohScheme(2, -1, -2, -1))
+    s1, k1 = nvb.batch_banded_alignment_score(15, al, p, t)
+    s2, k2 = nvb.batch_banded_alignment_score(15, al, p, t)
+    torch.cuda.synchronize()
+    assert torch.equal(s1, s2) and torch.equal(k1, k2)                  # deterministic / idempotent
+    assert int(s1.min()) >= 0 and int(s1.max()) <= 200                  # LOCAL: 0 <= score <= 2*M
+    assert bool((k1[:, 1] >= 1).all()) and bool((k1[:, 1] <= 100).all())
+    assert bool((k1[:, 0] >= k1[:, 1]).all()) and bool((k1[:, 0] <= k1[:, 1] + 14).all())   # sink inside the band
+    # permuting the jobs permutes the results
+    perm = torch.randperm(n, device=cuda, generator=torch.Generator(device=cuda).manual_seed(1))[:200_000]
+    pp = nvb.PackedStringSet(p.words, 4, True, p.begin[perm].contiguous(), None, 100)
+    tp = nvb.PackedStringSet(t.words, 2, False, t.begin[perm].contiguous(), None, 150)
+    s3, k3 = nvb.batch_banded_alignment_score(15, al, pp, tp)
+    assert torch.equal(s3, s1[perm]) and torch.equal(k3, k1[perm])
+    # exact check of that sample against the oracle
+    hp, ht = O.StringSet.from_device(pp), O.StringSet.from_device(tp)
+    es, ek = O.batch_banded_gotoh_score(15, nvb.LOCAL, (2, -1, -2, -1), hp, ht)
+    assert (s3.cpu().numpy() == es).all() and (k3.cpu().numpy().view(np.uint32) == ek).all()

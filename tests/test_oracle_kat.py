@@ -1,0 +1,192 @@
+"""Pins the CPU oracle (oracle/nvbio_oracle.c) to the known answers the reference's own
+tests hold for this path, and to the reference tests' own property checks.  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KAT = json.load(open(os.path.join(HERE, "golden", "kat.json")))
+
+
+def dna(s):
+    return np.array(["ACGT".index(c) for c in s], dtype=np.uint8)
+
+
+def rescore_cigar(cigar, pattern, text, text_start, scheme):
+    """What the reference's TestBacktracker::score does (alignment_test_utils.h:628-): walk the
+    alignment and apply the Gotoh scheme (first gap symbol gap_open, further ones gap_ext)."""
+    match, mismatch, gap_open, gap_ext = scheme
+    import re
+    i, j, score = 0, text_start, 0
+    # the test's backtracker pushes ops end-to-start and scores them reversed
+    # (alignment_test_utils.h:656-658), so its RLE literal reads right-to-left
+    for cnt, op in reversed(re.findall(r"(\d+)([MID])", cigar)):
+        cnt = int(cnt)
+        if op == "M":
+            for _ in range(cnt):
+                score += match if pattern[i] == text[j] else mismatch
+                i += 1; j += 1
+        elif op == "D":      # consumes text
+            score += gap_open + (cnt - 1) * gap_ext
+            j += cnt
+        else:                # I: consumes pattern
+            score += gap_open + (cnt - 1) * gap_ext
+            i += cnt
+    return score, i, j
+
+
+@pytest.mark.parametrize("case", KAT["gotoh"], ids=lambda c: "%s-b%d-t%d" % (c["p"], c["band"], c["type"]))
+def test_gotoh_kat(case):
+    p, t = dna(KAT["strings"][case["p"]]), dna(KAT["strings"][case["t"]])
+    for pb, tb in ((8, 8), (4, 2), (2, 2)):
+        for be in (False, True):
+            ok, score, sx, sy = O.banded_gotoh_score(case["band"], case["type"], case["scheme"], p, t,
+                                                     pat_bits=pb, txt_bits=tb, pat_be=be, txt_be=not be)
+            assert ok
+            assert (score, [sx, sy]) == (case["score"], case["sink"])
+    # the reference test's differential oracle (alignment_test.cu:310-326)
+    if len(t) >= len(p) + case["band"] - 1:
+        assert O.ref_banded_sw(case["band"], case["type"], case["scheme"], p, t) == case["score"]
+    if "cigar" in case:
+        # the CIGAR literal held by the reference test, re-scored as the test does
+        text_used = sum(int(n) for n, op in __import__("re").findall(r"(\d+)([MID])", case["cigar"]) if op in "MD")
+        start = case["sink"][0] - text_used
+        s, i, j = rescore_cigar(case["cigar"], p, t, start, case["scheme"])
+        assert (i, j) == (len(p), case["sink"][0])
+        assert s == case["score"]
+
+
+def test_text_shorter_than_pattern():
+    exp = KAT["text_shorter_than_pattern"]
+    p, t = dna(KAT["strings"]["real_p"])[:100], dna(KAT["strings"]["real_t"])[:50]
+    for ty in (0, 1, 2):
+        ok, score, sx, sy = O.banded_gotoh_score(15, ty, (2, -1, -2, -1), p, t)
+        assert ok == exp["returns"] and score == exp["score"] and [sx, sy] == exp["sink"]
+
+
+def test_banded_edit_distance_kats():
+    grp = KAT["banded_edit_distance_band5_semi_global"]
+    for c in grp["cases"]:
+        p = np.frombuffer(c["pattern"].encode(), dtype=np.uint8)
+        t = np.frombuffer(c["text"].encode(), dtype=np.uint8)
+        ok, score, _, _ = O.banded_gotoh_score(5, O.SEMI_GLOBAL, grp["scheme"], p, t)
+        assert ok and score == c["score"], c
+
+
+@pytest.mark.parametrize("band", [3, 5, 7, 15, 31])
+@pytest.mark.parametrize("aln_type", [O.GLOBAL, O.LOCAL, O.SEMI_GLOBAL])
+def test_differential_vs_ref_banded_sw(band, aln_type):
+    """banded_alignment_score == ref_banded_sw on random pairs, as alignment_test.cu:310-326
+    asserts (valid where the text covers the whole band: N >= M + BAND - 1)."""
+    rng = np.random.default_rng(band * 10 + aln_type)
+    for scheme in [(2, -1, -2, -1), (0, -5, -8, -3), (2, -1, -1, -1), (1, -3, -5, -2)]:
+        for _ in range(40):
+            M = int(rng.integers(1, 120))
+            N = M + band - 1 + int(rng.integers(0, 5))
+            t = rng.integers(0, 4, N, dtype=np.uint8)
+            p = t[band // 2: band // 2 + M].copy()
+            mut = rng.random(M) < 0.1
+            p[mut] = rng.integers(0, 4, int(mut.sum()), dtype=np.uint8)
+            ok, score, sx, sy = O.banded_gotoh_score(band, aln_type, scheme, p, t, pat_bits=4, txt_bits=2)
+            assert ok
+            assert score == O.ref_banded_sw(band, aln_type, scheme, p, t)
+
+
+def test_band31_cache_truncation_quirk():
+    """Reference_cache<31> is a 2-bit PackedStream (alignment_base_inl.h:75-98): an out-of-range
+    text symbol (255) re-read from the cache is 3 ('T').  With a pattern of T's and a text that
+    ends early the score therefore differs from a 'true mismatch' model."""
+    p = np.full(40, 3, dtype=np.uint8)
+    t = np.full(45, 3, dtype=np.uint8)       # N < M + BAND - 1 -> 255s enter the band
+    ok, s31, _, _ = O.banded_gotoh_score(31, O.LOCAL, (2, -1, -2, -1), p, t, pat_bits=4, txt_bits=2)
+    ok, s15, _, _ = O.banded_gotoh_score(15, O.LOCAL, (2, -1, -2, -1), p, t, pat_bits=4, txt_bits=2)
+    assert s31 == 80 and s15 == 80
+
+
+# ---------------------------------------------------------------------------- FM-index
+@pytest.fixture(scope="module")
+def fmi():
+    rng = np.random.default_rng(7)
+    n = 50021
+    text = rng.integers(0, 4, n, dtype=np.uint8)
+    return text, O.FMIndex(text)
+
+
+def test_suffix_array_is_sorted(fmi):
+    text, f = fmi
+    s = bytes(text)
+    sa = f.sa
+    assert sa[0] == f.length and sorted(sa.tolist()) == list(range(f.length + 1))
+    rng = np.random.default_rng(1)
+    for i in rng.integers(1, f.length, 3000):
+        assert s[int(sa[i]):] < s[int(sa[i + 1]):]
+
+
+def test_rank_equals_naive_count(fmi):
+    """nvbio-test/rank_test.cu:55-86 and fmindex_test.cu: rank == running naive count."""
+    text, f = fmi
+    n = f.length
+    sa = f.sa.astype(np.int64)
+    col = np.where(sa == 0, 9, text[(sa - 1) % n])      # the BWT column with '$' at `primary`
+    cum = np.stack([np.cumsum(col == c) for c in range(4)], 1)
+    k = np.arange(n + 1, dtype=np.uint32)
+    for c in range(4):
+        assert (f.rank(k, np.full(n + 1, c, np.uint8)) == cum[:, c]).all()
+    assert (f.rank4(k) == cum).all()
+    assert (f.rank(np.array([0xFFFFFFFF], np.uint32), np.array([2], np.uint8)) == 0).all()
+    # range form == two point queries
+    rng = np.random.default_rng(3)
+    x = rng.integers(0, n + 1, 5000).astype(np.int64) - 1
+    y = np.minimum(x + rng.integers(0, 300, 5000), n)
+    c = rng.integers(0, 4, 5000).astype(np.uint8)
+    rr = f.rank_range(np.stack([x.astype(np.uint32), y.astype(np.uint32)], 1), c)
+    ex = np.where(x < 0, 0, cum[np.maximum(x, 0), c])
+    assert (rr[:, 0] == ex).all() and (rr[:, 1] == cum[y, c]).all()
+
+
+def test_match_and_locate_find_the_pattern(fmi):
+    """fmindex_test.cu:610-664: every located position of a matched pattern holds the pattern."""
+    text, f = fmi
+    s = bytes(text)
+    rng = np.random.default_rng(5)
+    seeds = [text[p:p + 8].copy() for p in rng.integers(0, f.length - 8, 300)]
+    seeds += [rng.integers(0, 4, 11, dtype=np.uint8) for _ in range(100)]
+    seeds += [np.array([0, 1, 4, 2], np.uint8)]                    # holds an N
+    ss = O.StringSet.from_lists(seeds, 4, True)
+    rg = f.match(ss)
+    assert rg[-1].tolist() == [1, 0]
+    for i, sd in enumerate(seeds[:-1]):
+        pat = bytes(sd)
+        cnt = sum(1 for j in range(len(s) - len(pat) + 1) if s.startswith(pat, j)) if i % 25 == 0 else None
+        x, y = int(rg[i, 0]), int(rg[i, 1])
+        if cnt is not None:
+            assert (y - x + 1 if x <= y else 0) == cnt
+        if x <= y:
+            pos = f.locate(np.arange(x, min(y, x + 10) + 1, dtype=np.uint32))
+            for q in pos:
+                assert s[int(q):int(q) + len(pat)] == pat
+    # locate of every row reproduces the suffix array (ssa check, fmindex_test.cu:582-592)
+    rows = np.arange(1, f.length + 1, dtype=np.uint32)
+    pos, steps = f.locate(rows, want_steps=True)
+    assert (pos == f.sa[1:]).all() and steps > 0
+    it = f.locate_ssa_iterator(rows)
+    assert (f.lookup_ssa_iterator(it) == pos).all()
+
+
+def test_filter_rank_locate(fmi):
+    text, f = fmi
+    rng = np.random.default_rng(9)
+    seeds = [text[p:p + 10].copy() for p in rng.integers(0, f.length - 10, 200)]
+    ss = O.StringSet.from_lists(seeds, 2, True)
+    total, ranges, slots = f.filter_rank(ss)
+    sizes = np.where(ranges[:, 0] <= ranges[:, 1], ranges[:, 1].astype(np.int64) - ranges[:, 0] + 1, 0)
+    assert total == sizes.sum() and (slots == np.cumsum(sizes)).all()
+    hits = f.filter_locate(ranges, slots, 0, total)
+    s = bytes(text)
+    for pos, sid in hits:
+        pat = bytes(seeds[int(sid)])
+        assert s[int(pos):int(pos) + len(pat)] == pat
