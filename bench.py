@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--rank-genome", type=float, default=3.0e9, help="BWT length of the rank leg (symbols)")
     ap.add_argument("--rank-queries", type=int, default=1 << 28)
     ap.add_argument("--no-rank", action="store_true")
+    ap.add_argument("--only", choices=["dp", "rank"], default=None, help="profiling aid: run just one leg, print its object")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
     return ap.parse_args()
@@ -76,6 +77,12 @@ def main():
         if world > 1:
             dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
+
+    if a.only == "rank":
+        print(json.dumps({"rank_roofline": rank_leg(a, dev)}))
+        return
+    if a.only == "dp":
+        a.no_rank = a.no_cpu = True
 
     # ---------------------------------------------------------------- inputs (resident before timing)
     n = a.reads

@@ -253,10 +253,11 @@ NVB_API int nvbio_hip_banded_gotoh_score(
     uint32_t n, int32_t* out_score, uint32_t* out_sink, void* stream)
 {
     using namespace nvb;
-    if (!scheme || !patterns || !texts || !out_score || !out_sink) return hipErrorInvalidValue;
+    if (!scheme || !patterns || !texts) return hipErrorInvalidValue;
     if (type < 0 || type > 2) return hipErrorInvalidValue;
     if (!(patterns->bits == 2 || patterns->bits == 4) || texts->bits != 2) return hipErrorNotSupported;
-    if (n == 0) return hipSuccess;
+    if (n == 0) return hipSuccess;                 // an empty batch is legal and touches nothing
+    if (!out_score || !out_sink) return hipErrorInvalidValue;
     if (!patterns->words || !texts->words || !patterns->begin || !texts->begin ||
         patterns->n_words == 0 || texts->n_words == 0) return hipErrorInvalidValue;
 

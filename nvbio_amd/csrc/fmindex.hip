@@ -325,8 +325,8 @@ using namespace nvb;
 NVB_API int nvbio_hip_fm_rank(const nvbio_hip_fmindex* fmi, const uint32_t* k, const uint8_t* c,
                               uint32_t n, uint32_t* out, void* stream)
 {
+    if (n == 0 && fmi) return hipSuccess;
     if (!fmi || !fmi->bwt_occ || !k || !c || !out) return hipErrorInvalidValue;
-    if (n == 0) return hipSuccess;
     g_last_kernel = "fm_rank_kernel";
     hipLaunchKernelGGL(fm_rank_kernel, grid_for(n), dim3(256), 0, to_stream(stream), make_fmi(fmi), k, c, n, out);
     return hipGetLastError();
@@ -334,8 +334,8 @@ NVB_API int nvbio_hip_fm_rank(const nvbio_hip_fmindex* fmi, const uint32_t* k, c
 
 NVB_API int nvbio_hip_fm_rank4(const nvbio_hip_fmindex* fmi, const uint32_t* k, uint32_t n, uint32_t* out, void* stream)
 {
+    if (n == 0 && fmi) return hipSuccess;
     if (!fmi || !fmi->bwt_occ || !k || !out) return hipErrorInvalidValue;
-    if (n == 0) return hipSuccess;
     g_last_kernel = "fm_rank4_kernel";
     hipLaunchKernelGGL(fm_rank4_kernel, grid_for(n), dim3(256), 0, to_stream(stream), make_fmi(fmi), k, n, reinterpret_cast<uint4*>(out));
     return hipGetLastError();
@@ -344,8 +344,8 @@ NVB_API int nvbio_hip_fm_rank4(const nvbio_hip_fmindex* fmi, const uint32_t* k, 
 NVB_API int nvbio_hip_fm_rank_range(const nvbio_hip_fmindex* fmi, const uint32_t* range, const uint8_t* c,
                                     uint32_t n, uint32_t* out, void* stream)
 {
+    if (n == 0 && fmi) return hipSuccess;
     if (!fmi || !fmi->bwt_occ || !range || !c || !out) return hipErrorInvalidValue;
-    if (n == 0) return hipSuccess;
     g_last_kernel = "fm_rank_range_kernel";
     hipLaunchKernelGGL(fm_rank_range_kernel, grid_for(n), dim3(256), 0, to_stream(stream), make_fmi(fmi),
                        reinterpret_cast<const uint2*>(range), c, n, reinterpret_cast<uint2*>(out));
@@ -362,8 +362,8 @@ static int check_seeds(const nvbio_hip_string_set* s)
 NVB_API int nvbio_hip_fm_match(const nvbio_hip_fmindex* fmi, const nvbio_hip_string_set* seeds,
                                uint32_t n, uint32_t* out_range, void* stream)
 {
+    if (n == 0 && fmi) return hipSuccess;
     if (!fmi || !fmi->bwt_occ || !out_range) return hipErrorInvalidValue;
-    if (n == 0) return hipSuccess;
     if (int e = check_seeds(seeds)) return e;
     g_last_kernel = "fm_match_kernel";
     hipLaunchKernelGGL(fm_match_kernel, grid_for(n), dim3(256), 0, to_stream(stream), make_fmi(fmi),
@@ -380,9 +380,9 @@ static int check_locate(const nvbio_hip_fmindex* fmi)
 
 NVB_API int nvbio_hip_fm_locate(const nvbio_hip_fmindex* fmi, const uint32_t* sa_rows, uint32_t n, uint32_t* out_pos, void* stream)
 {
+    if (n == 0 && fmi) return hipSuccess;
     if (int e = check_locate(fmi)) return e;
     if (!sa_rows || !out_pos) return hipErrorInvalidValue;
-    if (n == 0) return hipSuccess;
     g_last_kernel = "fm_locate_kernel";
     hipLaunchKernelGGL(fm_locate_kernel, grid_for(n), dim3(256), 0, to_stream(stream), make_fmi(fmi), sa_rows, n, out_pos);
     return hipGetLastError();
