@@ -77,6 +77,9 @@ int nvbio_hip_banded_gotoh_score(
     const nvbio_hip_gotoh_scheme* scheme /* host */, int32_t type, uint32_t band_len,
     const nvbio_hip_string_set* patterns /* host struct, device arrays */,
     const nvbio_hip_string_set* texts    /* host struct, device arrays */,
+    uint32_t max_pattern_len, uint32_t max_text_len /* the reference's max_pattern_length /
+        max_text_length arguments (batched.h:217-231); 0 = unknown.  Only used to pick the
+        arithmetic width: results never depend on them. */,
     uint32_t n, int32_t* out_score, uint32_t* out_sink, void* stream);
 
 /* nvbio::fm_index<rank_dictionary<2,64,PackedStream<.,uint8,2,true>,.,.>, SSA_index_multiple_context<SA_INT>, const uint32*>
@@ -153,6 +156,15 @@ int nvbio_hip_fm_filter_locate(const nvbio_hip_fmindex* fmi, const uint32_t* ran
 uint64_t nvbio_hip_build_bwt_occ_temp_bytes(uint32_t n);
 int nvbio_hip_build_bwt_occ(uint32_t n, const uint32_t* bwt_words, uint32_t* out_bwt_occ, uint32_t* out_L2,
                             void* temp, uint64_t temp_bytes, void* stream);
+
+/* Device-memory helpers for host code that has no HIP headers (the C++ host layer in
+ * include/nvbio_hip/ uses them where the reference uses thrust::device_vector).
+ * kind: 1 = host->device, 2 = device->host, 3 = device->device. */
+int nvbio_hip_device_malloc(void** ptr, uint64_t bytes);
+int nvbio_hip_device_free(void* ptr);
+int nvbio_hip_memcpy(void* dst, const void* src, uint64_t bytes, int kind, void* stream);
+int nvbio_hip_memset(void* dst, int value, uint64_t bytes, void* stream);
+int nvbio_hip_stream_synchronize(void* stream);
 
 /* Library / device introspection (host). */
 int         nvbio_hip_abi_version(void);

@@ -1,0 +1,118 @@
+// nvbio_hip/alignment.h -- nvbio::aln batch interface of the banded Gotoh score on MI355X.
+//
+// Mirrors, name for name:
+//   AlignmentType, GotohAligner, make_gotoh_aligner        nvbio/alignment/alignment_base.h:54,255-298
+//   SimpleGotohScheme                                      nvbio/alignment/utils.h:114-134
+//   BestSink<int32>                                        nvbio/alignment/sink.h:68-89
+//   DeviceThreadScheduler / DeviceThreadBlockScheduler     nvbio/alignment/batched.h:51-76
+//   batch_banded_alignment_score<BAND_LEN>(...)            nvbio/alignment/batched.h:217-231
+//   BatchedBandedAlignmentScore<BAND_LEN,stream,scheduler> nvbio/alignment/batched.h:333-353
+// Work is done by nvbio_hip_banded_gotoh_score (include/nvbio_hip.h); like the reference's
+// enact(), calls are asynchronous on the current (null) stream and return nothing.
+#pragma once
+#include "strings.h"
+
+namespace nvbio {
+namespace aln {
+
+enum AlignmentType { GLOBAL = 0, LOCAL = 1, SEMI_GLOBAL = 2 };
+
+struct SimpleGotohScheme
+{
+    SimpleGotohScheme() : m_match(0), m_mismatch(0), m_gap_open(0), m_gap_ext(0) {}
+    SimpleGotohScheme(const int32 match, const int32 mm, const int32 gap_open, const int32 gap_ext)
+        : m_match(match), m_mismatch(mm), m_gap_open(gap_open), m_gap_ext(gap_ext) {}
+    int32 match(const uint8 = 0) const { return m_match; }
+    int32 mismatch(const uint8 = 0) const { return m_mismatch; }
+    int32 pattern_gap_open() const { return m_gap_open; }
+    int32 pattern_gap_extension() const { return m_gap_ext; }
+    int32 text_gap_open() const { return m_gap_open; }
+    int32 text_gap_extension() const { return m_gap_ext; }
+    int32 m_match, m_mismatch, m_gap_open, m_gap_ext;
+};
+
+struct GotohTag {};
+
+template <AlignmentType T, typename scoring_scheme_type>
+struct GotohAligner
+{
+    static const AlignmentType TYPE = T;
+    typedef GotohTag            aligner_tag;
+    typedef scoring_scheme_type scoring_scheme;
+    GotohAligner(const scoring_scheme_type _scheme) : scheme(_scheme) {}
+    scoring_scheme_type scheme;
+};
+template <AlignmentType TYPE, typename scoring_scheme_type>
+GotohAligner<TYPE, scoring_scheme_type> make_gotoh_aligner(const scoring_scheme_type& scheme) { return GotohAligner<TYPE, scoring_scheme_type>(scheme); }
+
+/// BestSink<int32> in device memory is {int32 score; uint2 sink}
+template <typename ScoreType> struct BestSink { ScoreType score; uint2 sink; };
+
+/// structure-of-arrays iterator over device BestSink storage: what the C-ABI writes
+struct BestSinkArrays { int32* score; uint32* sink; };
+
+struct HostThreadScheduler {};
+template <uint32 BLOCKDIM, uint32 MINBLOCKS> struct DeviceThreadBlockScheduler {};
+typedef DeviceThreadBlockScheduler<128, 1> DeviceThreadScheduler;
+
+/// The stream of alignment jobs handed to BatchedBandedAlignmentScore::enact.  The reference's
+/// stream concept (batched.h:239-296) is a user functor bundle evaluated per thread; across a
+/// C-ABI the kernels need its data instead, so this stream exposes the same accessors
+/// (aligner(), size(), max_pattern_length(), max_text_length()) plus the string sets and sinks.
+template <typename t_aligner_type, typename pattern_set_type, typename text_set_type>
+struct PackedAlignmentStream
+{
+    typedef t_aligner_type aligner_type;
+    PackedAlignmentStream(aligner_type _aligner, pattern_set_type _patterns, text_set_type _texts, BestSinkArrays _sinks,
+                          uint32 _max_pattern_len = 0, uint32 _max_text_len = 0)
+        : m_aligner(_aligner), m_patterns(_patterns), m_texts(_texts), m_sinks(_sinks),
+          m_max_pattern_len(_max_pattern_len), m_max_text_len(_max_text_len) {}
+    const aligner_type& aligner() const { return m_aligner; }
+    uint32 size() const { return m_patterns.size(); }
+    uint32 max_pattern_length() const { return m_max_pattern_len; }
+    uint32 max_text_length() const { return m_max_text_len; }
+    aligner_type m_aligner; pattern_set_type m_patterns; text_set_type m_texts; BestSinkArrays m_sinks;
+    uint32 m_max_pattern_len, m_max_text_len;
+};
+
+template <uint32 BAND_LEN, typename stream_type, typename algorithm_type = DeviceThreadScheduler>
+struct BatchedBandedAlignmentScore
+{
+    typedef typename stream_type::aligner_type aligner_type;
+    static uint64 min_temp_storage(const uint32, const uint32, const uint32) { return 0u; }   // batched_banded_inl.h:143-147
+    static uint64 max_temp_storage(const uint32, const uint32, const uint32) { return 0u; }
+
+    void enact(stream_type stream, uint64 temp_size = 0u, uint8* temp = nullptr, void* hip_stream = nullptr)
+    {
+        (void)temp_size; (void)temp;
+        static_assert(BAND_LEN == 3 || BAND_LEN == 5 || BAND_LEN == 7 || BAND_LEN == 15 || BAND_LEN == 31, "unsupported BAND_LEN");
+        const nvbio_hip_gotoh_scheme sc = { stream.aligner().scheme.m_match, stream.aligner().scheme.m_mismatch,
+                                            stream.aligner().scheme.m_gap_open, stream.aligner().scheme.m_gap_ext };
+        const nvbio_hip_string_set p = stream.m_patterns.abi(), t = stream.m_texts.abi();
+        hip_check(nvbio_hip_banded_gotoh_score(&sc, int32(aligner_type::TYPE), BAND_LEN, &p, &t,
+                                               stream.max_pattern_length(), stream.max_text_length(),
+                                               stream.size(), stream.m_sinks.score, stream.m_sinks.sink, hip_stream),
+                  "nvbio_hip_banded_gotoh_score");
+    }
+};
+
+/// batch_banded_alignment_score<BAND_LEN>(aligner, patterns, texts, sinks, scheduler, maxP, maxT)
+template <uint32 BAND_LEN, typename aligner_type, typename pattern_set_type, typename text_set_type, typename scheduler_type>
+void batch_banded_alignment_score(
+    const aligner_type      aligner,
+    const pattern_set_type  patterns,
+    const text_set_type     texts,
+          BestSinkArrays    sinks,
+    const scheduler_type    scheduler,
+    const uint32            max_pattern_length,
+    const uint32            max_text_length)
+{
+    (void)scheduler;
+    typedef PackedAlignmentStream<aligner_type, pattern_set_type, text_set_type> stream_type;
+    stream_type stream(aligner, patterns, texts, sinks, max_pattern_length, max_text_length);
+    BatchedBandedAlignmentScore<BAND_LEN, stream_type, scheduler_type> batch;
+    batch.enact(stream);
+}
+
+} // namespace aln
+} // namespace nvbio

@@ -13,6 +13,8 @@ SYMBOLS = [
     "nvbio_hip_fm_locate_ssa_iterator", "nvbio_hip_fm_lookup_ssa_iterator",
     "nvbio_hip_fm_filter_temp_bytes", "nvbio_hip_fm_filter_rank", "nvbio_hip_fm_filter_locate",
     "nvbio_hip_build_bwt_occ_temp_bytes", "nvbio_hip_build_bwt_occ",
+    "nvbio_hip_device_malloc", "nvbio_hip_device_free", "nvbio_hip_memcpy", "nvbio_hip_memset",
+    "nvbio_hip_stream_synchronize",
     "nvbio_hip_abi_version", "nvbio_hip_arch", "nvbio_hip_last_kernel",
 ]
 
@@ -47,7 +49,7 @@ def lib():
             getattr(L, s)   # AttributeError if the library does not export the ABI
         vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
         P = C.POINTER
-        L.nvbio_hip_banded_gotoh_score.argtypes = [P(GotohSchemeStruct), i32, u32, P(StringSetStruct), P(StringSetStruct), u32, vp, vp, vp]
+        L.nvbio_hip_banded_gotoh_score.argtypes = [P(GotohSchemeStruct), i32, u32, P(StringSetStruct), P(StringSetStruct), u32, u32, u32, vp, vp, vp]
         L.nvbio_hip_fm_rank.argtypes = [P(FMIndexStruct), vp, vp, u32, vp, vp]
         L.nvbio_hip_fm_rank4.argtypes = [P(FMIndexStruct), vp, u32, vp, vp]
         L.nvbio_hip_fm_rank_range.argtypes = [P(FMIndexStruct), vp, vp, u32, vp, vp]
@@ -65,10 +67,6 @@ def lib():
         L.nvbio_hip_abi_version.restype = C.c_int
         L.nvbio_hip_arch.restype = C.c_char_p
         L.nvbio_hip_last_kernel.restype = C.c_char_p
-        for s in SYMBOLS:
-            f = getattr(L, s)
-            if f.restype is C.c_int and s not in ("nvbio_hip_abi_version",):
-                pass
         _lib = L
     return _lib
 

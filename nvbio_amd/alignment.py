@@ -50,20 +50,26 @@ class BatchedBandedAlignmentScore:
 
     max_temp_storage = min_temp_storage
 
-    def enact(self, aligner, patterns, texts, out_score, out_sink):
+    def enact(self, aligner, patterns, texts, out_score, out_sink, max_pattern_length=0, max_text_length=0):
         n = len(patterns)
+        if patterns.length is None:
+            max_pattern_length = max_pattern_length or patterns.fixed_length
+        if texts.length is None:
+            max_text_length = max_text_length or texts.fixed_length
         assert len(texts) == n
         assert out_score.dtype == torch.int32 and out_score.numel() >= n and out_score.is_cuda
         assert out_sink.dtype == torch.int32 and out_sink.numel() >= 2 * n and out_sink.is_cuda
         sc = aligner.scheme.struct()
         ps, ts = patterns.struct(), texts.struct()
         err = lib().nvbio_hip_banded_gotoh_score(
-            C.byref(sc), aligner.type, self.band_len, C.byref(ps), C.byref(ts), n,
+            C.byref(sc), aligner.type, self.band_len, C.byref(ps), C.byref(ts),
+            int(max_pattern_length), int(max_text_length), n,
             C.c_void_p(out_score.data_ptr()), C.c_void_p(out_sink.data_ptr()), current_stream_ptr())
         check(err, "nvbio_hip_banded_gotoh_score")
 
 
-def batch_banded_alignment_score(band_len, aligner, patterns, texts, out_score=None, out_sink=None):
+def batch_banded_alignment_score(band_len, aligner, patterns, texts, out_score=None, out_sink=None,
+                                 max_pattern_length=0, max_text_length=0):
     """batch_banded_alignment_score<BAND_LEN>(aligner, patterns, texts, sinks, DeviceThreadScheduler()).
     Returns (score[n] int32, sink[n,2] int32 holding the uint32 bit patterns)."""
     n = len(patterns)
@@ -72,5 +78,6 @@ def batch_banded_alignment_score(band_len, aligner, patterns, texts, out_score=N
         out_score = torch.empty(n, dtype=torch.int32, device=dev)
     if out_sink is None:
         out_sink = torch.empty((n, 2), dtype=torch.int32, device=dev)
-    BatchedBandedAlignmentScore(band_len).enact(aligner, patterns, texts, out_score, out_sink)
+    BatchedBandedAlignmentScore(band_len).enact(aligner, patterns, texts, out_score, out_sink,
+                                                max_pattern_length, max_text_length)
     return out_score, out_sink

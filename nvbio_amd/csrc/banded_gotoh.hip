@@ -250,8 +250,10 @@ static hipError_t launch_band(const GotohParams& p, int type, hipStream_t stream
 NVB_API int nvbio_hip_banded_gotoh_score(
     const nvbio_hip_gotoh_scheme* scheme, int32_t type, uint32_t band_len,
     const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len,
     uint32_t n, int32_t* out_score, uint32_t* out_sink, void* stream)
 {
+    (void)max_pattern_len; (void)max_text_len;
     using namespace nvb;
     if (!scheme || !patterns || !texts) return hipErrorInvalidValue;
     if (type < 0 || type > 2) return hipErrorInvalidValue;
@@ -278,6 +280,19 @@ NVB_API int nvbio_hip_banded_gotoh_score(
     default: return hipErrorNotSupported;
     }
 }
+
+NVB_API int nvbio_hip_device_malloc(void** ptr, uint64_t bytes) { return ptr ? hipMalloc(ptr, bytes ? bytes : 1) : hipErrorInvalidValue; }
+NVB_API int nvbio_hip_device_free(void* ptr) { return hipFree(ptr); }
+NVB_API int nvbio_hip_memcpy(void* dst, const void* src, uint64_t bytes, int kind, void* stream)
+{
+    const hipMemcpyKind k = kind == 1 ? hipMemcpyHostToDevice : kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    if (bytes == 0) return hipSuccess;
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, k, nvb::to_stream(stream));
+    if (e != hipSuccess) return e;
+    return kind == 2 ? hipStreamSynchronize(nvb::to_stream(stream)) : hipSuccess;
+}
+NVB_API int nvbio_hip_memset(void* dst, int value, uint64_t bytes, void* stream) { return bytes ? hipMemsetAsync(dst, value, bytes, nvb::to_stream(stream)) : hipSuccess; }
+NVB_API int nvbio_hip_stream_synchronize(void* stream) { return hipStreamSynchronize(nvb::to_stream(stream)); }
 
 NVB_API int         nvbio_hip_abi_version(void) { return NVBIO_HIP_ABI_VERSION; }
 NVB_API const char* nvbio_hip_arch(void)        { return "gfx950"; }

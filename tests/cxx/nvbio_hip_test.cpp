@@ -1,0 +1,266 @@
+// nvbio_hip_test.cpp -- C++ parity driver for the hot path, written against the host layer in
+// include/nvbio_hip/ the way the reference's own suites are written against nvbio
+// (nvbio-test/alignment_test.cu, rank_test.cu, fmindex_test.cu): synthetic data, run the device
+// path, compare with an independent host computation, exit(1) on the first mismatch.
+// The host computation is the CPU oracle (oracle/nvbio_oracle.c), linked here as the checker.
+//
+//   nvbio_hip_test [-aln] [-rank] [-fm-index]      (no flag = all)
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <nvbio_hip/alignment.h>
+#include <nvbio_hip/fmindex.h>
+
+using namespace nvbio;
+
+// ---- the oracle's C entry points (oracle/nvbio_oracle.c) --------------------------------------
+extern "C" {
+typedef struct { uint32_t length, primary, L2[5]; const uint32_t* bwt_occ; const uint32_t* ssa; uint32_t sa_int; } oracle_fmi_t;
+void oracle_batch_banded_gotoh_score(uint32_t band, int type, const int32_t* scheme,
+    const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, const uint64_t* pat_begin, const uint32_t* pat_len,
+    const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, const uint64_t* txt_begin, const uint32_t* txt_len,
+    uint32_t n, int32_t* out_score, uint32_t* out_sink, int n_threads);
+uint32_t oracle_bwt_from_sa(uint32_t n, const uint8_t* T, const uint32_t* SA, uint8_t* bwt);
+void oracle_build_bwt_occ(uint32_t n, const uint32_t* bwt_words, uint32_t* bwt_occ, uint32_t* L2);
+void oracle_build_ssa(uint32_t n, const uint32_t* SA, uint32_t K, uint32_t* ssa);
+void oracle_fm_rank(const oracle_fmi_t* f, const uint32_t* k, const uint8_t* c, uint32_t n, uint32_t* out);
+void oracle_fm_rank4(const oracle_fmi_t* f, const uint32_t* k, uint32_t n, uint32_t* out);
+void oracle_fm_match(const oracle_fmi_t* f, const uint32_t* w, uint32_t bits, uint32_t be, const uint64_t* begin, const uint32_t* len,
+    uint32_t n, uint32_t* out_range, uint64_t* algo_bytes, int n_threads);
+void oracle_fm_locate(const oracle_fmi_t* f, const uint32_t* rows, uint32_t n, uint32_t* out_pos, uint64_t* total_steps, int n_threads);
+uint64_t oracle_filter_rank(const oracle_fmi_t* f, const uint32_t* w, uint32_t bits, uint32_t be, const uint64_t* begin, const uint32_t* len,
+    uint32_t n, uint32_t* ranges, uint64_t* slots);
+void oracle_filter_locate(const oracle_fmi_t* f, const uint32_t* ranges, const uint64_t* slots, uint32_t n_queries,
+    uint64_t begin, uint64_t end, uint32_t* hits);
+}
+
+#define FAIL(...) do { fprintf(stderr, "  error: " __VA_ARGS__); fprintf(stderr, "\n"); exit(1); } while (0)
+
+// the reference's LCG (nvbio/basic/numbers.h:610-621); its low bits are periodic, so symbols are
+// drawn from the high bits here
+struct LCG_random { uint32 m_s; LCG_random(uint32 s = 0) : m_s(s) {} uint32 next() { m_s = m_s * 1664525u + 1013904223u; return m_s; } uint32 sym() { return next() >> 30; } };
+
+static std::vector<uint8> string_to_dna(const char* s) { std::vector<uint8> r; for (; *s; ++s) r.push_back(*s == 'A' ? 0 : *s == 'C' ? 1 : *s == 'G' ? 2 : 3); return r; }
+
+// ----------------------------------------------------------------------------------- alignment
+template <uint32 BAND_LEN, aln::AlignmentType TYPE, uint32 PBITS, bool PBE, bool TBE>
+static void run_batch(const char* name, const aln::SimpleGotohScheme scoring,
+                      const std::vector<std::vector<uint8> >& patterns, const std::vector<std::vector<uint8> >& texts,
+                      std::vector<int32>* out_score = nullptr, std::vector<uint32>* out_sink = nullptr)
+{
+    const uint32 n = uint32(patterns.size());
+    PackedStringSetDevice<PBITS, PBE> d_patterns(patterns);
+    PackedStringSetDevice<2, TBE>     d_texts(texts);
+    hip::device_vector<int32>  d_score(n);
+    hip::device_vector<uint32> d_sink(2 * size_t(n));
+    aln::BestSinkArrays sinks = { d_score.data(), d_sink.data() };
+
+    aln::batch_banded_alignment_score<BAND_LEN>(
+        aln::make_gotoh_aligner<TYPE>(scoring), d_patterns.view(), d_texts.view(), sinks,
+        aln::DeviceThreadScheduler(), 0u, 0u);
+    hip::synchronize();
+    const std::vector<int32>  score = d_score.to_host();
+    const std::vector<uint32> sink  = d_sink.to_host();
+
+    // host reference: HostThreadScheduler semantics
+    std::vector<uint8> pc, tc; std::vector<uint64> pb(n), tb(n); std::vector<uint32> pl(n), tl(n);
+    for (uint32 i = 0; i < n; ++i) { pb[i] = pc.size(); pl[i] = uint32(patterns[i].size()); pc.insert(pc.end(), patterns[i].begin(), patterns[i].end());
+                                     tb[i] = tc.size(); tl[i] = uint32(texts[i].size());    tc.insert(tc.end(), texts[i].begin(), texts[i].end()); }
+    const std::vector<uint32> pw = pack_symbols<PBITS, PBE>(pc.data(), pc.size()), tw = pack_symbols<2, TBE>(tc.data(), tc.size());
+    std::vector<int32> hs(n); std::vector<uint32> hk(2 * size_t(n));
+    const int32 sc[4] = { scoring.m_match, scoring.m_mismatch, scoring.m_gap_open, scoring.m_gap_ext };
+    oracle_batch_banded_gotoh_score(BAND_LEN, int(TYPE), sc, pw.data(), PBITS, PBE, pb.data(), pl.data(), tw.data(), 2, TBE, tb.data(), tl.data(), n, hs.data(), hk.data(), 0);
+    for (uint32 i = 0; i < n; ++i)
+        if (score[i] != hs[i] || sink[2 * i] != hk[2 * i] || sink[2 * i + 1] != hk[2 * i + 1])
+            FAIL("%s: job %u: device (%d, %u,%u) != host (%d, %u,%u)", name, i, score[i], sink[2 * i], sink[2 * i + 1], hs[i], hk[2 * i], hk[2 * i + 1]);
+    if (out_score) *out_score = score;
+    if (out_sink)  *out_sink = sink;
+    fprintf(stderr, "    %-44s : %u jobs ok\n", name, n);
+}
+
+template <uint32 BAND_LEN, aln::AlignmentType TYPE>
+static void expect_single(const char* name, aln::SimpleGotohScheme sc, const char* p, const char* t, int32 score, uint32 sx, uint32 sy)
+{
+    std::vector<int32> s; std::vector<uint32> k;
+    run_batch<BAND_LEN, TYPE, 4, true, false>(name, sc, { string_to_dna(p) }, { string_to_dna(t) }, &s, &k);
+    if (s[0] != score || k[0] != sx || k[1] != sy) FAIL("%s: expected %d @ (%u,%u), got %d @ (%u,%u)", name, score, sx, sy, s[0], k[0], k[1]);
+}
+
+static int alignment_test()
+{
+    fprintf(stderr, "testing alignment... started\n");
+    // known answers (tests/golden/kat.json; strings of nvbio-test/alignment_test.cu:749-826)
+    const char* P1 = "ACAACTA"; const char* T1 = "AAACACCCTAACACACTAAA";
+    expect_single<7,  aln::SEMI_GLOBAL>("kat banded-semi-global 7", aln::SimpleGotohScheme(2, -1, -1, -1), P1, T1, 10, 10, 7);
+    expect_single<7,  aln::LOCAL>      ("kat banded-local 7",       aln::SimpleGotohScheme(2, -1, -1, -1), P1, T1, 10, 10, 7);
+    expect_single<7,  aln::GLOBAL>     ("kat banded-global 7",      aln::SimpleGotohScheme(2, -1, -1, -1), P1, T1, 5, 13, 7);
+    expect_single<15, aln::SEMI_GLOBAL>("kat banded-semi-global 15",aln::SimpleGotohScheme(2, -1, -1, -1), P1, T1, 13, 18, 7);
+    const char* P2 = "TTATGTAGGTGGTCTGGTTTTTGCCTTTTAAGCTTCTGCAAAAAACAACAACAAACTTGTGGTATTACACTGACTCTACAGATCAATTTGGGGACAACTTCCATGTGTTCCACCACCAATACTGAATCTTTCAATCGACTGACGTGGTAT";
+    const char* T2 = "ATCGGATTCTTTCTTACTTGTAGGTGGTCTGGTTTTTGCCTTTTAAGCTTCTGCAAAAAACAACAACAAACTTGTGGTATTACACTGACTCTACAGATCAATTTGGGGACAACTTCCATGTGTTCCACCACCAATACTGAATCTTTCAATCGACTGACGTGGTATCTCTCTCTCCATCTAT";
+    expect_single<31, aln::SEMI_GLOBAL>("kat real banded Gotoh 31", aln::SimpleGotohScheme(0, -5, -8, -3), P2, T2, -11, 165, 150);
+    expect_single<15, aln::SEMI_GLOBAL>("kat real banded Gotoh 15", aln::SimpleGotohScheme(0, -5, -8, -3), P2, T2, -403, 160, 150);
+    expect_single<31, aln::LOCAL>      ("kat real banded local 31", aln::SimpleGotohScheme(2, -1, -2, -1), P2, T2, 297, 165, 150);
+
+    // the throughput configuration of alignment_test.cu:1071-1194 (BAND=15, M=150, N=M+15), with
+    // planted substitutions so that scores are not trivial; reads 4-bit LE, refs 2-bit LE as there
+    const uint32 N_TASKS = 32768, M = 150, N = M + 15;
+    LCG_random rnd(7);
+    std::vector<std::vector<uint8> > pats(N_TASKS), txts(N_TASKS);
+    for (uint32 i = 0; i < N_TASKS; ++i) {
+        txts[i].resize(N); for (uint32 j = 0; j < N; ++j) txts[i][j] = uint8(rnd.sym());
+        pats[i].assign(txts[i].begin() + 7, txts[i].begin() + 7 + M);
+        for (uint32 j = 0; j < M; ++j) if ((rnd.next() >> 16) % 100 < 5) pats[i][j] = uint8(rnd.sym());
+        if (i % 3 == 0) pats[i].erase(pats[i].begin() + 40 + (i % 50), pats[i].begin() + 42 + (i % 50));    // ragged: a deletion
+        if (i % 97 == 0) pats[i][i % pats[i].size()] = 4;                                                   // an N
+        if (i % 211 == 0) txts[i].resize(pats[i].size() - 3);                                               // text shorter than pattern
+    }
+    const aln::SimpleGotohScheme s1(2, -1, -1, -1), s2(2, -1, -2, -1), s3(0, -5, -8, -3);
+    run_batch<15, aln::GLOBAL,      4, false, false>("batch gotoh-banded global 15",      s1, pats, txts);
+    run_batch<15, aln::SEMI_GLOBAL, 4, false, false>("batch gotoh-banded semi-global 15", s1, pats, txts);
+    run_batch<15, aln::LOCAL,       4, false, false>("batch gotoh-banded local 15",       s1, pats, txts);
+    run_batch<15, aln::LOCAL,       4, true,  false>("batch local 15, BE reads (sw-benchmark fmt)", s2, pats, txts);
+    run_batch<15, aln::LOCAL,       4, true,  true >("batch local 15, BE reads + BE genome (nvBowtie fmt)", s2, pats, txts);
+    run_batch<31, aln::SEMI_GLOBAL, 4, true,  true >("batch semi-global 31",              s3, pats, txts);
+    run_batch<31, aln::LOCAL,       4, true,  false>("batch local 31",                    s2, pats, txts);
+    run_batch<7,  aln::SEMI_GLOBAL, 4, true,  false>("batch semi-global 7",               s3, pats, txts);
+    run_batch<3,  aln::LOCAL,       4, true,  false>("batch local 3",                     s2, pats, txts);
+    run_batch<5,  aln::GLOBAL,      4, true,  false>("batch global 5",                    s2, pats, txts);
+    fprintf(stderr, "testing alignment... done\n");
+    return 0;
+}
+
+// ----------------------------------------------------------------------------------- FM-index
+struct HostIndex {
+    uint32 n, primary; uint32 L2[5];
+    std::vector<uint8> text, bwt; std::vector<uint32> sa, bwt_words, bwt_occ, ssa;
+    oracle_fmi_t ofmi;
+};
+
+static void build_host_index(HostIndex& h, uint32 n, uint32 seed)
+{
+    h.n = n; h.text.resize(n);
+    LCG_random rnd(seed);
+    for (uint32 i = 0; i < n; ++i) h.text[i] = uint8(rnd.sym());
+    // suffix array by prefix doubling; SA[0] = n (the '$' suffix) as gen_sa pads it (bwt.h:36-45)
+    std::vector<uint32> sa(n + 1), rk(n + 1), tmp(n + 1);
+    std::iota(sa.begin(), sa.end(), 0u);
+    for (uint32 i = 0; i <= n; ++i) rk[i] = i < n ? h.text[i] + 1u : 0u;
+    for (uint32 k = 1;; k <<= 1) {
+        auto key = [&](uint32 i) { return std::make_pair(rk[i], i + k <= n ? rk[i + k] + 1u : 0u); };
+        std::sort(sa.begin(), sa.end(), [&](uint32 a, uint32 b) { return key(a) < key(b); });
+        tmp[sa[0]] = 0;
+        for (uint32 i = 1; i <= n; ++i) tmp[sa[i]] = tmp[sa[i - 1]] + (key(sa[i - 1]) < key(sa[i]) ? 1u : 0u);
+        rk = tmp;
+        if (rk[sa[n]] == n) break;
+    }
+    h.sa = sa;
+    h.bwt.resize(n + 1);
+    h.primary = oracle_bwt_from_sa(n, h.text.data(), h.sa.data(), h.bwt.data());
+    const uint32 n_blocks = (n + 63) / 64;
+    h.bwt_words.assign(size_t(n_blocks) * 4, 0u);
+    { const std::vector<uint32> w = pack_symbols<2, true>(h.bwt.data(), n, 0); std::copy(w.begin(), w.end(), h.bwt_words.begin()); }
+    h.bwt_occ.resize(size_t(n_blocks) * 8);
+    oracle_build_bwt_occ(n, h.bwt_words.data(), h.bwt_occ.data(), h.L2);
+    h.ssa.resize((n + 16) / 16);
+    oracle_build_ssa(n, h.sa.data(), 16, h.ssa.data());
+    h.ofmi.length = n; h.ofmi.primary = h.primary; memcpy(h.ofmi.L2, h.L2, sizeof h.L2);
+    h.ofmi.bwt_occ = h.bwt_occ.data(); h.ofmi.ssa = h.ssa.data(); h.ofmi.sa_int = 16;
+}
+
+static int rank_test()
+{
+    fprintf(stderr, "rank test... started\n");
+    HostIndex h; build_host_index(h, 100000, 3);
+    // device-built occurrence table == host build_occurrence_table<2,64> + interleave
+    hip::device_vector<uint32> d_bwt(h.bwt_words), d_bwt_occ(h.bwt_occ.size());
+    uint32 L2[5];
+    build_bwt_occ(h.n, d_bwt.data(), d_bwt_occ.data(), L2);
+    if (d_bwt_occ.to_host() != h.bwt_occ || memcmp(L2, h.L2, sizeof L2)) FAIL("device occurrence table differs from the host one");
+    // rank(dict, i, c) against a running naive count, every i and c (rank_test.cu:55-86).
+    // primary = n keeps the fm_index '$' adjustment out of the way: this is the rank dictionary alone.
+    fm_index_device fmi(h.n, h.n, h.L2, d_bwt_occ.data(), nullptr);
+    std::vector<uint32> k(h.n); std::iota(k.begin(), k.end(), 0u);
+    hip::device_vector<uint32> d_k(k); hip::device_vector<uint4> d_r4(h.n);
+    rank4(fmi, h.n, d_k.data(), d_r4.data());
+    const std::vector<uint4> r4 = d_r4.to_host();
+    uint32 cnt[4] = { 0, 0, 0, 0 };
+    for (uint32 i = 0; i < h.n; ++i) {
+        ++cnt[h.bwt[i]];
+        if (r4[i].x != cnt[0] || r4[i].y != cnt[1] || r4[i].z != cnt[2] || r4[i].w != cnt[3]) FAIL("rank4 mismatch at %u", i);
+    }
+    for (uint32 c = 0; c < 4; ++c) {
+        std::vector<uint8> cc(h.n, uint8(c)); hip::device_vector<uint8> d_c(cc); hip::device_vector<uint32> d_r(h.n);
+        rank(fmi, h.n, d_k.data(), d_c.data(), d_r.data());
+        const std::vector<uint32> r = d_r.to_host();
+        uint32 run = 0;
+        for (uint32 i = 0; i < h.n; ++i) { run += (h.bwt[i] == c); if (r[i] != run) FAIL("rank mismatch at %u, c=%u: %u != %u", i, c, r[i], run); }
+    }
+    fprintf(stderr, "rank test... done\n");
+    return 0;
+}
+
+static int fmindex_test()
+{
+    fprintf(stderr, "FM-index test... started\n");
+    HostIndex h; build_host_index(h, 1u << 18, 11);
+    hip::device_vector<uint32> d_bwt_occ(h.bwt_occ), d_ssa(h.ssa);
+    fm_index_device fmi(h.n, h.primary, h.L2, d_bwt_occ.data(), d_ssa.data(), 16);
+
+    // ssa check (fmindex_test.cu:582-592): locate of every row == SA
+    {
+        std::vector<uint32> rows(h.n); std::iota(rows.begin(), rows.end(), 1u);
+        hip::device_vector<uint32> d_rows(rows), d_pos(h.n);
+        locate(fmi, h.n, d_rows.data(), d_pos.data());
+        const std::vector<uint32> pos = d_pos.to_host();
+        for (uint32 i = 0; i < h.n; ++i) if (pos[i] != h.sa[i + 1]) FAIL("locate(%u) = %u != SA = %u", i + 1, pos[i], h.sa[i + 1]);
+    }
+    // match 8-mers, then locate every row of the range and compare the text there (fmindex_test.cu:610-664)
+    LCG_random rnd(5);
+    const uint32 Q = 65536, LEN = 8;
+    std::vector<std::vector<uint8> > seeds(Q);
+    for (uint32 q = 0; q < Q; ++q) { const uint32 p = rnd.next() % (h.n - LEN); seeds[q].assign(h.text.begin() + p, h.text.begin() + p + LEN); if (q % 7 == 0) seeds[q][q % LEN] = uint8(rnd.sym()); }
+    for (int shuffled = 0; shuffled < 2; ++shuffled) {       // sorted and shuffled orders (fmindex_test.cu:666-716)
+        if (!shuffled) std::sort(seeds.begin(), seeds.end());
+        else for (uint32 q = Q - 1; q > 0; --q) std::swap(seeds[q], seeds[rnd.next() % (q + 1)]);
+        PackedStringSetDevice<2, true> d_seeds(seeds);
+        hip::device_vector<uint2> d_ranges(Q);
+        match(fmi, d_seeds.view(), d_ranges.data());
+        const std::vector<uint2> ranges = d_ranges.to_host();
+        // host oracle
+        std::vector<uint8> cat; std::vector<uint64> b(Q); std::vector<uint32> l(Q, LEN);
+        for (uint32 q = 0; q < Q; ++q) { b[q] = cat.size(); cat.insert(cat.end(), seeds[q].begin(), seeds[q].end()); }
+        const std::vector<uint32> w = pack_symbols<2, true>(cat.data(), cat.size());
+        std::vector<uint32> hr(2 * size_t(Q));
+        oracle_fm_match(&h.ofmi, w.data(), 2, 1, b.data(), l.data(), Q, hr.data(), nullptr, 0);
+        for (uint32 q = 0; q < Q; ++q) if (ranges[q].x != hr[2 * q] || ranges[q].y != hr[2 * q + 1]) FAIL("match %u: device (%u,%u) host (%u,%u)", q, ranges[q].x, ranges[q].y, hr[2 * q], hr[2 * q + 1]);
+        // the filter: rank + locate, every hit must hold its seed in the text
+        FMIndexFilterDevice filter;
+        const uint64 n_hits = filter.rank(fmi, d_seeds.view());
+        hip::device_vector<uint2> d_hits(n_hits);
+        filter.locate(0, n_hits, d_hits.data());
+        const std::vector<uint2> hits = d_hits.to_host();
+        uint64 expect = 0;
+        for (uint32 q = 0; q < Q; ++q) expect += uint32(1u + hr[2 * q + 1] - hr[2 * q]);
+        if (expect != n_hits) FAIL("filter.rank: %llu hits, expected %llu", (unsigned long long)n_hits, (unsigned long long)expect);
+        for (uint64 i = 0; i < n_hits; ++i)
+            if (memcmp(h.text.data() + hits[i].x, seeds[hits[i].y].data(), LEN)) FAIL("hit %llu: text at %u does not hold seed %u", (unsigned long long)i, hits[i].x, hits[i].y);
+    }
+    fprintf(stderr, "FM-index test... done\n");
+    return 0;
+}
+
+int main(int argc, char** argv)
+{
+    bool aln_t = false, rank_t = false, fm_t = false;
+    for (int i = 1; i < argc; ++i) { aln_t |= !strcmp(argv[i], "-aln"); rank_t |= !strcmp(argv[i], "-rank"); fm_t |= !strcmp(argv[i], "-fm-index"); }
+    if (!aln_t && !rank_t && !fm_t) aln_t = rank_t = fm_t = true;
+    try {
+        if (aln_t)  alignment_test();
+        if (rank_t) rank_test();
+        if (fm_t)   fmindex_test();
+    } catch (const nvbio::hip_error& e) { fprintf(stderr, "caught a nvbio::hip_error exception:\n  %s\n", e.what()); return 1; }
+    fprintf(stderr, "nvbio_hip_test: all passed\n");
+    return 0;
+}

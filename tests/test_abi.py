@@ -41,13 +41,13 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     ps, ts = _lib.StringSetStruct(), _lib.StringSetStruct()
     ps.bits, ts.bits = 4, 2
     # null outputs -> hipErrorInvalidValue (1); nothing is launched
-    assert L.nvbio_hip_banded_gotoh_score(ctypes.byref(sc), 1, 15, ctypes.byref(ps), ctypes.byref(ts), 10, None, None, None) == 1
+    assert L.nvbio_hip_banded_gotoh_score(ctypes.byref(sc), 1, 15, ctypes.byref(ps), ctypes.byref(ts), 0, 0, 10, None, None, None) == 1
     # an 8-bit stream is outside the ABI's contract -> hipErrorNotSupported (801)
     ps.bits = 8
-    assert L.nvbio_hip_banded_gotoh_score(ctypes.byref(sc), 1, 15, ctypes.byref(ps), ctypes.byref(ts), 10, None, None, None) == 801
+    assert L.nvbio_hip_banded_gotoh_score(ctypes.byref(sc), 1, 15, ctypes.byref(ps), ctypes.byref(ts), 0, 0, 10, None, None, None) == 801
     # an empty batch is legal
     ps.bits = 4
-    assert L.nvbio_hip_banded_gotoh_score(ctypes.byref(sc), 1, 15, ctypes.byref(ps), ctypes.byref(ts), 0, None, None, None) == 0
+    assert L.nvbio_hip_banded_gotoh_score(ctypes.byref(sc), 1, 15, ctypes.byref(ps), ctypes.byref(ts), 0, 0, 0, None, None, None) == 0
     f = _lib.FMIndexStruct()
     assert L.nvbio_hip_fm_rank(ctypes.byref(f), None, None, 10, None, None) == 1
     assert L.nvbio_hip_fm_filter_temp_bytes(1000) > 8000
