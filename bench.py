@@ -30,6 +30,7 @@ import torch.distributed as dist
 
 import nvbio_amd as nvb
 from nvbio_amd import workloads as W
+from nvbio_amd.distributed import ResultGather
 
 # MI355X peaks (/opt/skills/guides/MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
@@ -97,8 +98,7 @@ def main():
     # result records: score[n] + sink[n,2] = 12 B per read, double-buffered so that the gather
     # of step k (side stream) overlaps the kernel of step k+1
     outs = [(torch.empty(n, dtype=torch.int32, device=dev), torch.empty((n, 2), dtype=torch.int32, device=dev)) for _ in range(2)]
-    g_scores = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
-    g_sinks = [torch.empty((n, 2), dtype=torch.int32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gatherers = [ResultGather(n * world, dst=0, device=dev) for _ in range(2)] if world > 1 else None
 
     pending = [None, None]
 
@@ -114,8 +114,7 @@ def main():
         if world > 1:
             comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(comm_stream):
-                dist.gather(outs[b][0], g_scores, dst=0)
-                dist.gather(outs[b][1], g_sinks, dst=0)
+                gatherers[b].gather(outs[b][0], outs[b][1])       # 12 B/read to rank 0 over RCCL/xGMI
                 pending[b] = torch.cuda.Event()
                 pending[b].record(comm_stream)
 

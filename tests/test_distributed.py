@@ -1,0 +1,66 @@
+"""world_size-2 test (gloo, CPU) of the multi-GPU layout: contiguous read sharding and the
+gather of result records to rank 0.  The per-rank 'compute' here is the CPU oracle (this is a
+test of the sharding / gather logic, not of a kernel)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from nvbio_amd import workloads as W
+from nvbio_amd.distributed import ResultGather, shard_range, shard_sizes
+from oracle import pyoracle as O
+
+
+def test_shard_ranges_cover_everything():
+    for n in (0, 1, 7, 100, 1001):
+        for world in (1, 2, 3, 8):
+            r = [shard_range(n, g, world) for g in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[i][1] == r[i + 1][0] for i in range(world - 1))
+            assert sum(shard_sizes(n, world)) == n
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        patterns, texts = W.make_sw_batch(n, seed=77, device="cpu")        # same batch on every rank
+        hp, ht = O.StringSet.from_device(patterns), O.StringSet.from_device(texts)
+        lo, hi = shard_range(n, rank, world)
+        sub_p = O.StringSet(hp.words, hp.bits, hp.big_endian, hp.begin[lo:hi], hp.length[lo:hi])
+        sub_t = O.StringSet(ht.words, ht.bits, ht.big_endian, ht.begin[lo:hi], ht.length[lo:hi])
+        s, k = O.batch_banded_gotoh_score(15, O.LOCAL, (2, -1, -2, -1), sub_p, sub_t, n_threads=1)
+        g = ResultGather(n, dst=0, device="cpu")
+        for _ in range(2):                                                   # buffers are reusable
+            out = g.gather(torch.from_numpy(s), torch.from_numpy(k.view(np.int32)))
+        if rank == 0:
+            es, ek = O.batch_banded_gotoh_score(15, O.LOCAL, (2, -1, -2, -1), hp, ht, n_threads=1)
+            ok = bool((out[0].numpy() == es).all() and (out[1].numpy().view(np.uint32) == ek).all())
+            q.put(ok)
+        else:
+            assert out is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [1001, 64])
+def test_two_rank_shard_and_gather(n):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
