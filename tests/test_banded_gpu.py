@@ -22,22 +22,46 @@ def dna(s):
     return np.array(["ACGT".index(c) for c in s], dtype=np.uint8)
 
 
-def run_gpu(band, ty, scheme, hp, ht, dev):
-    """hp/ht: oracle StringSets (host) -> run the same data through the HIP path."""
+def run_gpu(band, ty, scheme, hp, ht, dev, force32=False):
+    """hp/ht: oracle StringSets (host) -> run the same data through the HIP path.
+    force32: disable the 16-bit kernels so the 32-bit ones are exercised on the same data."""
     p = nvb.PackedStringSet.from_host(hp.words, hp.bits, hp.big_endian, hp.begin, hp.length, device=dev)
     t = nvb.PackedStringSet.from_host(ht.words, ht.bits, ht.big_endian, ht.begin, ht.length, device=dev)
-    score, sink = nvb.batch_banded_alignment_score(band, nvb.make_gotoh_aligner(ty, nvb.SimpleGotohScheme(*scheme)), p, t)
-    torch.cuda.synchronize()
+    os.environ["NVBIO_HIP_FORCE_32BIT"] = "1" if force32 else "0"
+    try:
+        score, sink = nvb.batch_banded_alignment_score(band, nvb.make_gotoh_aligner(ty, nvb.SimpleGotohScheme(*scheme)), p, t)
+        torch.cuda.synchronize()
+    finally:
+        os.environ["NVBIO_HIP_FORCE_32BIT"] = "0"
     return score.cpu().numpy(), sink.cpu().numpy().view(np.uint32)
 
 
 def check(band, ty, scheme, hp, ht, dev):
     es, ek = O.batch_banded_gotoh_score(band, ty, scheme, hp, ht)
-    gs, gk = run_gpu(band, ty, scheme, hp, ht, dev)
-    bad = np.nonzero((es != gs) | (ek != gk).any(1))[0]
-    assert bad.size == 0, "band %d type %d scheme %s: %d mismatches, first %d: cpu (%d,%s) gpu (%d,%s)" % (
-        band, ty, scheme, bad.size, bad[0], es[bad[0]], ek[bad[0]], gs[bad[0]], gk[bad[0]])
+    for force32 in (False, True):
+        gs, gk = run_gpu(band, ty, scheme, hp, ht, dev, force32)
+        bad = np.nonzero((es != gs) | (ek != gk).any(1))[0]
+        assert bad.size == 0, "band %d type %d scheme %s force32=%s: %d mismatches, first %d: cpu (%d,%s) gpu (%d,%s)" % (
+            band, ty, scheme, force32, bad.size, bad[0], es[bad[0]], ek[bad[0]], gs[bad[0]], gk[bad[0]])
     return es, ek
+
+
+def test_kernel_width_selection(cuda):
+    """Jobs longer than the 16-bit exactness limit of their scheme go to the 32-bit kernel, per job:
+    LOCAL (2,-1,-2,-1) is exact in 16 bits up to 511 symbols; mix lengths across that limit."""
+    rng = np.random.default_rng(42)
+    pats, txts = [], []
+    for L in [10, 100, 510, 511, 512, 513, 700, 1200, 30, 511, 512]:
+        t = rng.integers(0, 4, L + 40, dtype=np.uint8)
+        p = t[7:7 + L].copy()
+        mut = rng.random(L) < 0.03
+        p[mut] = rng.integers(0, 4, int(mut.sum()), dtype=np.uint8)
+        pats.append(p); txts.append(t)
+    hp, ht = O.StringSet.from_lists(pats, 4, True), O.StringSet.from_lists(txts, 2, False)
+    for band in (15, 31):
+        for ty in (0, 1, 2):
+            es, _ = check(band, ty, (2, -1, -2, -1), hp, ht, cuda)
+    assert es.max() > 1022          # scores beyond the 16-bit LOCAL range are present and exact
 
 
 def test_kats_on_gpu(cuda):
