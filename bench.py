@@ -45,16 +45,28 @@ BYTES_PER_ALN = 50 + 29 + 12 + 8                   # packed read + text window +
 RANK_BYTES_PER_QUERY = 40                          # 32 B record + 4 B query + 4 B result
 
 
+def measured_traffic(kernel):
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same command
+    (profiles/traffic.json: TCC_EA0_RDREQ x request size + TCC_EA0_WRREQ x 64 B); None if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
-    ap.add_argument("--rank-genome", type=float, default=3.0e9, help="BWT length of the rank leg (symbols)")
+    ap.add_argument("--genome", type=float, default=3.0e9, help="synthetic genome length of the FM-index legs (a true index is built on the device)")
     ap.add_argument("--rank-queries", type=int, default=1 << 28)
     ap.add_argument("--no-rank", action="store_true")
-    ap.add_argument("--only", choices=["dp", "rank"], default=None, help="profiling aid: run just one leg, print its object")
+    ap.add_argument("--only", choices=["dp", "rank", "seed"], default=None, help="profiling aid: run just one leg, print its object")
+    ap.add_argument("--seeds", type=int, default=50_000_000)
+    ap.add_argument("--no-seed", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
     return ap.parse_args()
@@ -79,11 +91,13 @@ def main():
             dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
-    if a.only == "rank":
-        print(json.dumps({"rank_roofline": rank_leg(a, dev)}))
+    if a.only in ("rank", "seed"):
+        a.no_seed = a.only == "rank"
+        a.no_rank = a.only == "seed"
+        print(json.dumps(fm_legs(a, dev)))
         return
     if a.only == "dp":
-        a.no_rank = a.no_cpu = True
+        a.no_rank = a.no_cpu = a.no_seed = True
 
     # ---------------------------------------------------------------- inputs (resident before timing)
     n = a.reads
@@ -165,7 +179,7 @@ def main():
             "peak": VALU_PEAK_TOPS,
             "unit": "Tint-op/s",
             "frac": n * CELLS_PER_ALN * NOMINAL_OPS_PER_CELL / kt / 1e12 / VALU_PEAK_TOPS,
-            "traffic": None,
+            "traffic": measured_traffic("banded_gotoh_score_kernel"),
             "kernel_ms": kern_ms,
             "gcups": n * CELLS_PER_ALN / kt / 1e9,
             "hbm_GBs": n * BYTES_PER_ALN / kt / 1e9,
@@ -182,24 +196,42 @@ def main():
         }
 
     # ---------------------------------------------------------------- FM-index rank leg (rank 0, N == 1 only)
-    if rank == 0 and world == 1 and not a.no_rank:
-        out["rank_roofline"] = rank_leg(a, dev)
+    if rank == 0 and world == 1 and not (a.no_rank and a.no_seed):
+        del patterns, texts, outs
+        torch.cuda.empty_cache()
+        out.update(fm_legs(a, dev))
     if rank == 0 and world == 1 and not a.no_cpu:
-        out["cpu_baseline"] = cpu_leg(a, patterns, texts)
+        out["cpu_baseline"] = cpu_leg(a, *W.make_sw_batch(min(n, a.cpu_sample), READ_LEN, REF_LEN, seed=0x5EED0002, device=dev))
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
 
-def rank_leg(a, dev):
-    """rank(i,c) point queries at uniform random i on a 3 Gbp-sized index (random BWT string with a
-    device-built occurrence table): algorithmic 40 B per query."""
-    ng = int(a.rank_genome)
-    words = W.make_random_bwt(ng, device=dev)
-    bwt_occ, L2 = nvb.build_bwt_occ(ng, words)
-    del words
-    fmi = nvb.FMIndexDevice(ng, ng, L2, bwt_occ)
+def fm_legs(a, dev):
+    """The FM-index half of the metric on ONE true index of a synthetic i.i.d. genome (BASELINE
+    config 3: 3 Gbp), built on the device: rank() point queries (`rank_roofline`) and
+    match + locate of 22-bp seeds (`seed_leg`)."""
+    ng = int(a.genome)
+    g = torch.Generator(device=dev)
+    g.manual_seed(0x5EED0003)
+    text = torch.randint(0, 4, (ng,), dtype=torch.uint8, generator=g, device=dev)
+    t0 = time.perf_counter()
+    fmi = W.build_fm_index(text)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t0
+    out = {}
+    if not a.no_rank:
+        out["rank_roofline"] = rank_leg(a, dev, fmi)
+    if not a.no_seed:
+        out["seed_leg"] = seed_leg(a, dev, fmi, text, build_s)
+    return out
+
+
+def rank_leg(a, dev, fmi):
+    """rank(i,c) point queries at uniform random i: algorithmic 40 B per query."""
+    ng = fmi.length
+    bwt_occ = fmi.bwt_occ
     q = a.rank_queries
     g = torch.Generator(device=dev)
     g.manual_seed(0x5EED0003)
@@ -219,8 +251,59 @@ def rank_leg(a, dev):
     ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / reps
     gbs = q * RANK_BYTES_PER_QUERY / (ms * 1e-3) / 1e9
     return {"kernel": "fm_rank_kernel", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": gbs / HBM_PEAK_GBS, "traffic": None, "kernel_ms": ms, "queries": q, "index_symbols": ng,
+            "frac": gbs / HBM_PEAK_GBS, "traffic": measured_traffic("fm_rank_kernel"), "kernel_ms": ms, "queries": q, "index_symbols": ng,
             "index_bytes": int(bwt_occ.numel()) * 4, "Mqueries_per_s": q / (ms * 1e-3) / 1e6}
+
+
+def seed_leg(a, dev, fmi, text, build_s):
+    """Backward search (match) of 22-bp seeds and locate of their first SA row (SURVEY.md 8d config
+    3-ii).  A sample is checked bit-exactly against the oracle run on a host copy of the same
+    index; the oracle also counts the algorithmic index bytes per seed."""
+    import numpy as np
+    from oracle import pyoracle as O
+    ng = fmi.length
+    seeds = W.make_seeds(text, a.seeds, 22)
+    ranges = nvb.match(fmi, seeds)
+    torch.cuda.synchronize()
+    reps = 5
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for e0, e1 in evs:
+        e0.record(); nvb.match(fmi, seeds, out=ranges); e1.record()
+    torch.cuda.synchronize()
+    match_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / reps
+    # locate the first row of every non-empty range
+    ok = (ranges[:, 0].to(torch.int64) & 0xFFFFFFFF) <= (ranges[:, 1].to(torch.int64) & 0xFFFFFFFF)
+    rows = ranges[:, 0][ok].contiguous()
+    pos = nvb.locate(fmi, rows)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for e0, e1 in evs:
+        e0.record(); nvb.locate(fmi, rows, out=pos); e1.record()
+    torch.cuda.synchronize()
+    locate_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / reps
+    # parity + algorithmic bytes on a sample, by the oracle on a host copy of the same index
+    m = min(a.seeds, 1_000_000)
+    host = O.FMIndex(parts=(fmi.length, fmi.primary, np.array(fmi.L2, dtype=np.uint32),
+                            fmi.bwt_occ.cpu().numpy().view(np.uint32), fmi.ssa.cpu().numpy().view(np.uint32), fmi.sa_int))
+    sub = nvb.PackedStringSet(seeds.words, seeds.bits, seeds.big_endian, seeds.begin[:m].contiguous(), None, 22)
+    er, nbytes = host.match(O.StringSet.from_device(sub), want_bytes=True)
+    exact = bool((ranges[:m].cpu().numpy().view(np.uint32) == er).all())
+    mr = min(int(rows.numel()), 1_000_000)
+    ep, steps = host.locate(rows[:mr].cpu().numpy().view(np.uint32), want_steps=True)
+    exact = exact and bool((pos[:mr].cpu().numpy().view(np.uint32) == ep).all())
+    if not exact:
+        raise SystemExit("parity gate failed: FM-index match/locate differ from the oracle")
+    bytes_per_seed = nbytes / m + 6 + 8
+    bytes_per_loc = 32.0 * steps / mr + 4 + 8
+    mgbs = a.seeds * bytes_per_seed / (match_ms * 1e-3) / 1e9
+    lgbs = rows.numel() * bytes_per_loc / (locate_ms * 1e-3) / 1e9
+    return {"genome_symbols": ng, "index_build_s": build_s, "seeds": a.seeds, "seed_len": 22,
+            "match": {"kernel": "fm_match_kernel", "kernel_ms": match_ms, "Mseeds_per_s": a.seeds / (match_ms * 1e-3) / 1e6,
+                      "algorithmic_bytes_per_seed": bytes_per_seed, "achieved_GBs": mgbs, "frac_of_hbm_peak": mgbs / HBM_PEAK_GBS},
+            "locate": {"kernel": "fm_locate_kernel", "rows": int(rows.numel()), "kernel_ms": locate_ms,
+                       "Mrows_per_s": rows.numel() / (locate_ms * 1e-3) / 1e6, "mean_lf_steps": steps / mr,
+                       "algorithmic_bytes_per_row": bytes_per_loc, "achieved_GBs": lgbs, "frac_of_hbm_peak": lgbs / HBM_PEAK_GBS},
+            "parity": {"checked_seeds": m, "checked_rows": mr, "bit_exact": exact}}
 
 
 def cpu_leg(a, patterns, texts):

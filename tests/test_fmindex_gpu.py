@@ -160,3 +160,20 @@ def test_random_bwt_rank_property_large(cuda):
         assert np.bincount(sym, minlength=4).tolist() == [int(x) for x in nvb.rank4(f, torch.tensor([int(q)], device=cuda, dtype=torch.int32)).cpu()[0]]
         if q > 3_000_000:
             break
+
+
+def test_device_built_index_equals_host_index(cuda):
+    """The device index builder used by the FM-index bench configs (torch prefix-doubling SA +
+    the build_occurrence_table kernel) reproduces the host oracle's index bit for bit."""
+    rng = np.random.default_rng(21)
+    n = 300007
+    text = rng.integers(0, 4, n, dtype=np.uint8)
+    text[1000:3000] = 2
+    host = O.FMIndex(text)
+    fmi, sa = W.build_fm_index(torch.from_numpy(text).to(cuda), keep_sa=True)
+    assert fmi.length == n and fmi.primary == host.primary and fmi.L2 == [int(x) for x in host.L2]
+    assert (sa.cpu().numpy().astype(np.uint32) == host.sa).all()
+    assert (u32(fmi.bwt_occ) == host.bwt_occ[: fmi.bwt_occ.numel()]).all()
+    assert (u32(fmi.ssa) == host.ssa).all()
+    seeds = W.make_seeds(torch.from_numpy(text).to(cuda), 20000, 22)
+    assert (u32(nvb.match(fmi, seeds)) == host.match(O.StringSet.from_device(seeds))).all()
