@@ -93,9 +93,17 @@ typedef struct nvbio_hip_fmindex {
     uint32_t        length;
     uint32_t        primary;
     uint32_t        L2[5];
-    uint32_t        sa_int;
+    uint32_t        sa_int;     /* any power of two; 16 in the reference's files.  With 288 GB of HBM
+                                   a denser SSA (down to 1 = the full SA) is affordable and shortens
+                                   locate's LF walk from ~sa_int steps to none; results are identical */
     const uint32_t* bwt_occ;
     const uint32_t* ssa;
+    const uint32_t* ktab;       /* optional accelerator, NULL = none: the match range (uint2) of every
+                                   k-mer, built by nvbio_hip_fm_build_ktab; match() then resolves a
+                                   seed's last ktab_k symbols with one lookup instead of ktab_k
+                                   backward-search steps -- same ranges, bit for bit */
+    uint32_t        ktab_k;
+    uint32_t        _pad;
 } nvbio_hip_fmindex;
 
 /* Replaces nvbio::rank(fmi, k, c) (nvbio/fmindex/fmindex_inl.h:36-57) over n
@@ -117,6 +125,11 @@ int nvbio_hip_fm_rank_range(const nvbio_hip_fmindex* fmi, const uint32_t* range,
  * the seed holds a symbol > 3. */
 int nvbio_hip_fm_match(const nvbio_hip_fmindex* fmi, const nvbio_hip_string_set* seeds,
                        uint32_t n, uint32_t* out_range, void* stream);
+
+/* Builds the optional k-mer table for `fmi` (fmi->ktab is ignored): out_ktab[2c..2c+1] =
+ * match(fmi, kmer c), where kmer c has symbol t (0 = first) at bits [2t,2t+2) of c, for all
+ * 4^k codes; 1 <= k <= 14; out_ktab holds 2*4^k words (k=12: 128 MiB). */
+int nvbio_hip_fm_build_ktab(const nvbio_hip_fmindex* fmi, uint32_t k, uint32_t* out_ktab, void* stream);
 
 /* Replaces nvbio::locate(fmi, i) (fmindex_inl.h:466-501) and nvBowtie's
  * locate_kernel (nvBowtie/bowtie2/cuda/locate_inl.h:122-148). */

@@ -16,9 +16,12 @@ struct fm_index_device
     typedef uint2  range_type;
     nvbio_hip_fmindex m;
 
-    fm_index_device() { m.length = m.primary = 0; m.sa_int = 16; m.bwt_occ = nullptr; m.ssa = nullptr; for (int i = 0; i < 5; ++i) m.L2[i] = 0; }
+    fm_index_device() { m.length = m.primary = 0; m.sa_int = 16; m.bwt_occ = nullptr; m.ssa = nullptr; m.ktab = nullptr; m.ktab_k = 0; m._pad = 0; for (int i = 0; i < 5; ++i) m.L2[i] = 0; }
     fm_index_device(uint32 length, uint32 primary, const uint32* L2, const uint32* bwt_occ, const uint32* ssa, uint32 sa_int = 16)
-    { m.length = length; m.primary = primary; for (int i = 0; i < 5; ++i) m.L2[i] = L2[i]; m.bwt_occ = bwt_occ; m.ssa = ssa; m.sa_int = sa_int; }
+    { m.length = length; m.primary = primary; for (int i = 0; i < 5; ++i) m.L2[i] = L2[i]; m.bwt_occ = bwt_occ; m.ssa = ssa; m.sa_int = sa_int; m.ktab = nullptr; m.ktab_k = 0; m._pad = 0; }
+
+    /// attach the optional k-mer table built by build_ktab() (caller keeps the storage alive)
+    void set_ktab(const uint32* ktab, uint32 k) { m.ktab = ktab; m.ktab_k = k; }
 
     index_type length() const { return m.length; }
     index_type primary() const { return m.primary; }
@@ -41,6 +44,9 @@ inline void rank(const fm_index_device& fmi, uint32 n, const uint2* range, const
 template <typename string_set_type>
 inline void match(const fm_index_device& fmi, const string_set_type& string_set, uint2* ranges, void* stream = nullptr)
 { const nvbio_hip_string_set s = string_set.abi(); hip_check(nvbio_hip_fm_match(&fmi.m, &s, string_set.size(), reinterpret_cast<uint32*>(ranges), stream), "nvbio_hip_fm_match"); }
+/// builds the k-mer table accelerator of match(): 2*4^k words into d_ktab
+inline void build_ktab(const fm_index_device& fmi, uint32 k, uint32* d_ktab, void* stream = nullptr)
+{ hip_check(nvbio_hip_fm_build_ktab(&fmi.m, k, d_ktab, stream), "nvbio_hip_fm_build_ktab"); }
 /// out[i] = locate(fmi, rows[i])                                   fmindex_inl.h:466-501
 inline void locate(const fm_index_device& fmi, uint32 n, const uint32* rows, uint32* out, void* stream = nullptr)
 { hip_check(nvbio_hip_fm_locate(&fmi.m, rows, n, out, stream), "nvbio_hip_fm_locate"); }

@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libnvbio_hip.so")
 SYMBOLS = [
     "nvbio_hip_banded_gotoh_score",
     "nvbio_hip_fm_rank", "nvbio_hip_fm_rank4", "nvbio_hip_fm_rank_range",
-    "nvbio_hip_fm_match", "nvbio_hip_fm_locate",
+    "nvbio_hip_fm_match", "nvbio_hip_fm_build_ktab", "nvbio_hip_fm_locate",
     "nvbio_hip_fm_locate_ssa_iterator", "nvbio_hip_fm_lookup_ssa_iterator",
     "nvbio_hip_fm_filter_temp_bytes", "nvbio_hip_fm_filter_rank", "nvbio_hip_fm_filter_locate",
     "nvbio_hip_build_bwt_occ_temp_bytes", "nvbio_hip_build_bwt_occ",
@@ -30,7 +30,7 @@ class GotohSchemeStruct(C.Structure):    # nvbio_hip_gotoh_scheme
 
 class FMIndexStruct(C.Structure):        # nvbio_hip_fmindex
     _fields_ = [("length", C.c_uint32), ("primary", C.c_uint32), ("L2", C.c_uint32 * 5), ("sa_int", C.c_uint32),
-                ("bwt_occ", C.c_void_p), ("ssa", C.c_void_p)]
+                ("bwt_occ", C.c_void_p), ("ssa", C.c_void_p), ("ktab", C.c_void_p), ("ktab_k", C.c_uint32), ("_pad", C.c_uint32)]
 
 
 _lib = None
@@ -54,6 +54,7 @@ def lib():
         L.nvbio_hip_fm_rank4.argtypes = [P(FMIndexStruct), vp, u32, vp, vp]
         L.nvbio_hip_fm_rank_range.argtypes = [P(FMIndexStruct), vp, vp, u32, vp, vp]
         L.nvbio_hip_fm_match.argtypes = [P(FMIndexStruct), P(StringSetStruct), u32, vp, vp]
+        L.nvbio_hip_fm_build_ktab.argtypes = [P(FMIndexStruct), u32, vp, vp]
         L.nvbio_hip_fm_locate.argtypes = [P(FMIndexStruct), vp, u32, vp, vp]
         L.nvbio_hip_fm_locate_ssa_iterator.argtypes = [P(FMIndexStruct), vp, u32, vp, vp]
         L.nvbio_hip_fm_lookup_ssa_iterator.argtypes = [P(FMIndexStruct), vp, u32, vp, vp]

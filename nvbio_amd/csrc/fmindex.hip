@@ -32,6 +32,8 @@ struct Fmi {
     uint32_t        sa_int;
     const uint4*    rec;        // 2 x uint4 per block: bwt words, occ counters
     const uint32_t* ssa;
+    const uint2*    ktab;       // optional: match range of every ktab_k-mer
+    uint32_t        ktab_k;
 };
 
 inline Fmi make_fmi(const nvbio_hip_fmindex* h)
@@ -42,6 +44,8 @@ inline Fmi make_fmi(const nvbio_hip_fmindex* h)
     f.sa_int = h->sa_int;
     f.rec = reinterpret_cast<const uint4*>(h->bwt_occ);
     f.ssa = h->ssa;
+    f.ktab = reinterpret_cast<const uint2*>(h->ktab);
+    f.ktab_k = h->ktab ? h->ktab_k : 0u;
     return f;
 }
 
@@ -166,11 +170,9 @@ fm_rank_range_kernel(const Fmi f, const uint2* __restrict__ range, const uint8_t
 
 // ------------------------------------------------------------------ backward search
 // match (fmindex_inl.h:307-341) with nvBowtie's symbol test (mapping_inl.h:83-97).
-// One lane = one seed; the seed (<= 32 symbols per fetch) is pulled 16 symbols at a time.
-__device__ __forceinline__ uint2 fm_match(const Fmi& f, const Stream& s, uint64_t begin, uint32_t len)
+// One lane = one seed; the seed is pulled 16 symbols per fetch.
+__device__ __forceinline__ uint2 fm_match_from(const Fmi& f, const Stream& s, uint64_t begin, int32_t i, uint32_t x, uint32_t y)
 {
-    uint32_t x = 0, y = f.length;
-    int32_t  i = int32_t(len) - 1;
     while (i >= 0 && x <= y)
     {
         // symbols [g0, g0+16) of the seed, g0 = 16-aligned group holding i
@@ -188,6 +190,53 @@ __device__ __forceinline__ uint2 fm_match(const Fmi& f, const Stream& s, uint64_
         }
     }
     return make_uint2(x, y);
+}
+
+// pack the low k nibbles (each <= 3) of v into k 2-bit fields
+__device__ __forceinline__ uint32_t nibbles_to_2bit(uint64_t v)
+{
+    v = (v | (v >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+    v = (v | (v >> 4)) & 0x00FF00FF00FF00FFull;
+    v = (v | (v >> 8)) & 0x0000FFFF0000FFFFull;
+    v = (v | (v >> 16)) & 0x00000000FFFFFFFFull;
+    return uint32_t(v);
+}
+
+__device__ __forceinline__ uint2 fm_match(const Fmi& f, const Stream& s, uint64_t begin, uint32_t len)
+{
+    const uint32_t k = f.ktab_k;
+    if (k != 0u && len >= k)
+    {
+        // the last k symbols of the seed: one table lookup replaces the first k steps.  The table
+        // entry IS match(k-mer), i.e. the state in which the reference's loop leaves those steps
+        // (including an empty range at the step where it became empty).
+        uint64_t tail = (s.bits == 2) ? expand_2to4(fetch16_2bit(s, begin + len - k)) : fetch16_4bit(s, begin + len - k);
+        tail &= (k == 16u) ? ~0ull : ((1ull << (4u * k)) - 1ull);
+        if ((tail & 0xCCCCCCCCCCCCCCCCull) == 0ull)          // no N among them (else: plain search)
+        {
+            const uint2 r = f.ktab[nibbles_to_2bit(tail)];
+            if (r.x > r.y) return r;
+            return fm_match_from(f, s, begin, int32_t(len - k) - 1, r.x, r.y);
+        }
+    }
+    return fm_match_from(f, s, begin, int32_t(len) - 1, 0u, f.length);
+}
+
+// one lane = one k-mer code: its match range, by the plain search (the table is ignored)
+__global__ void __launch_bounds__(256)
+fm_build_ktab_kernel(const Fmi f, uint32_t k, uint32_t n_codes, uint2* __restrict__ out)
+{
+    const uint32_t code = blockIdx.x * 256u + threadIdx.x;
+    if (code >= n_codes) return;
+    uint32_t x = 0, y = f.length;
+    for (int32_t t = int32_t(k) - 1; t >= 0 && x <= y; --t)
+    {
+        const uint32_t c = (code >> (2u * uint32_t(t))) & 3u;
+        const uint2 r = fm_rank2(f, x - 1u, y, c);
+        x = f.L2[c] + r.x + 1u;
+        y = f.L2[c] + r.y;
+    }
+    out[code] = make_uint2(x, y);
 }
 
 __global__ void __launch_bounds__(256)
@@ -368,6 +417,17 @@ NVB_API int nvbio_hip_fm_match(const nvbio_hip_fmindex* fmi, const nvbio_hip_str
     g_last_kernel = "fm_match_kernel";
     hipLaunchKernelGGL(fm_match_kernel, grid_for(n), dim3(256), 0, to_stream(stream), make_fmi(fmi),
                        make_string_set(seeds), n, reinterpret_cast<uint2*>(out_range));
+    return hipGetLastError();
+}
+
+NVB_API int nvbio_hip_fm_build_ktab(const nvbio_hip_fmindex* fmi, uint32_t k, uint32_t* out_ktab, void* stream)
+{
+    if (!fmi || !fmi->bwt_occ || !out_ktab || k < 1 || k > 14) return hipErrorInvalidValue;
+    Fmi f = make_fmi(fmi);
+    f.ktab = nullptr; f.ktab_k = 0;
+    const uint32_t n_codes = 1u << (2u * k);
+    g_last_kernel = "fm_build_ktab_kernel";
+    hipLaunchKernelGGL(fm_build_ktab_kernel, grid_for(n_codes), dim3(256), 0, to_stream(stream), f, k, n_codes, reinterpret_cast<uint2*>(out_ktab));
     return hipGetLastError();
 }
 

@@ -19,11 +19,27 @@ def _vp(t):
 class FMIndexDevice:
     """Device-resident FM-index in the reference's interleaved bwt|occ layout."""
 
-    def __init__(self, length, primary, L2, bwt_occ, ssa=None, sa_int=16):
+    def __init__(self, length, primary, L2, bwt_occ, ssa=None, sa_int=16, ktab=None, ktab_k=0):
         assert bwt_occ.dtype == torch.int32 and bwt_occ.is_contiguous()
         assert bwt_occ.data_ptr() % 32 == 0
         self.length, self.primary, self.L2 = int(length), int(primary), [int(x) for x in L2]
         self.bwt_occ, self.ssa, self.sa_int = bwt_occ, ssa, int(sa_int)
+        self.ktab, self.ktab_k = ktab, int(ktab_k)
+
+    def with_ktab(self, k=12):
+        """A copy of this index carrying the k-mer table accelerator (4^k uint2 entries in HBM)."""
+        tab = torch.empty((4 ** k, 2), dtype=torch.int32, device=self.bwt_occ.device)
+        s = self.struct()
+        check(lib().nvbio_hip_fm_build_ktab(C.byref(s), k, _vp(tab), current_stream_ptr()), "nvbio_hip_fm_build_ktab")
+        return FMIndexDevice(self.length, self.primary, self.L2, self.bwt_occ, self.ssa, self.sa_int, tab, k)
+
+    def with_dense_ssa(self, sa_int):
+        """A copy of this index with the suffix array sampled every `sa_int` rows (power of two,
+        1 = full SA), derived on the device by locating the sampled rows with the current SSA."""
+        assert sa_int >= 1 and (sa_int & (sa_int - 1)) == 0
+        rows = torch.arange(0, self.length + 1, sa_int, dtype=torch.int64, device=self.bwt_occ.device).to(torch.int32)
+        ssa = locate(self, rows)
+        return FMIndexDevice(self.length, self.primary, self.L2, self.bwt_occ, ssa, sa_int, self.ktab, self.ktab_k)
 
     def struct(self):
         s = FMIndexStruct()
@@ -32,6 +48,8 @@ class FMIndexDevice:
             s.L2[i] = self.L2[i]
         s.bwt_occ = self.bwt_occ.data_ptr()
         s.ssa = self.ssa.data_ptr() if self.ssa is not None else None
+        s.ktab = self.ktab.data_ptr() if self.ktab is not None else None
+        s.ktab_k = self.ktab_k if self.ktab is not None else 0
         return s
 
     @staticmethod

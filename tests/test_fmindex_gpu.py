@@ -177,3 +177,39 @@ def test_device_built_index_equals_host_index(cuda):
     assert (u32(fmi.ssa) == host.ssa).all()
     seeds = W.make_seeds(torch.from_numpy(text).to(cuda), 20000, 22)
     assert (u32(nvb.match(fmi, seeds)) == host.match(O.StringSet.from_device(seeds))).all()
+
+
+@pytest.mark.parametrize("k", [1, 5, 8, 12])
+def test_ktab_accelerated_match_is_identical(cuda, index, k):
+    """The optional k-mer table must not change a single range: seeds shorter than k, seeds with an
+    N inside / outside the tabulated tail, absent seeds (empty ranges frozen at their stop state)."""
+    text, host, dev = index
+    rng = np.random.default_rng(100 + k)
+    fk = dev.with_ktab(k)
+    tab = u32(fk.ktab)
+    # the table itself == match of every k-mer (code: symbol t at bits 2t)
+    codes = rng.integers(0, 4 ** k, 2000)
+    kmers = [np.array([(c >> (2 * t)) & 3 for t in range(k)], dtype=np.uint8) for c in codes]
+    assert (tab[codes] == host.match(O.StringSet.from_lists(kmers, 2, True))).all()
+    for bits, be in ((2, True), (4, True), (4, False), (2, False)):
+        for length in (22, 0):
+            hs = make_seeds(rng, text, 20000, length, bits, be, with_n=True)
+            ds = nvb.PackedStringSet.from_host(hs.words, bits, be, hs.begin, hs.length, device=cuda)
+            exp = host.match(hs)
+            assert (u32(nvb.match(fk, ds)) == exp).all()
+            assert (u32(nvb.match(dev, ds)) == exp).all()
+
+
+@pytest.mark.parametrize("sa_int", [1, 4, 64])
+def test_dense_ssa_locate_is_identical(cuda, index, sa_int):
+    text, host, dev = index
+    n = host.length
+    fd = dev.with_dense_ssa(sa_int)
+    rng = np.random.default_rng(sa_int)
+    rows = rng.integers(0, n + 1, 100000).astype(np.uint32)
+    exp = host.locate(rows)
+    assert (u32(nvb.locate(fd, i32(rows, cuda))) == exp).all()
+    it = nvb.locate_ssa_iterator(fd, i32(rows, cuda))
+    assert (u32(nvb.lookup_ssa_iterator(fd, it)) == exp).all()
+    if sa_int == 1:
+        assert (u32(fd.ssa)[1:] == host.sa[1:]).all()
