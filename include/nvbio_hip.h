@@ -82,6 +82,28 @@ int nvbio_hip_banded_gotoh_score(
         arithmetic width: results never depend on them. */,
     uint32_t n, int32_t* out_score, uint32_t* out_sink, void* stream);
 
+/* nvBowtie's SmithWatermanScoringScheme<QualCost,ConstantCost> as the Gotoh aligner sees it
+ * (nvBowtie/bowtie2/cuda/scoring.h:283-293): substitution(r,q,qq) = (r == q) ? match : mismatch[qq],
+ * with mismatch[qq] = -m_mmp(qq) tabulated by the host for every quality byte (the float->int
+ * truncation of QualCost, scoring.h:86-104, stays on the host), and the four gap accessors. */
+typedef struct nvbio_hip_gotoh_qual_scheme {
+    int32_t match;
+    int32_t pattern_gap_open, pattern_gap_ext, text_gap_open, text_gap_ext;   /* as returned by the accessors (<= 0) */
+    int32_t mismatch[256];
+} nvbio_hip_gotoh_qual_scheme;
+
+/* As nvbio_hip_banded_gotoh_score, for GotohAligner<TYPE, SmithWatermanScoringScheme<...>> with a
+ * quality string per pattern: replaces the instantiation in nvBowtie's extension stage
+ * (nvBowtie/bowtie2/cuda/score_best_inl.h:153-201).  quals[b + i] is the quality of symbol i of the
+ * pattern that begins at stream index b (nvBowtie stores read qualities at the reads' own offsets);
+ * n_quals = bytes allocated. */
+int nvbio_hip_banded_gotoh_score_qual(
+    const nvbio_hip_gotoh_qual_scheme* scheme /* host */, int32_t type, uint32_t band_len,
+    const nvbio_hip_string_set* patterns, const uint8_t* quals, uint64_t n_quals,
+    const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len,
+    uint32_t n, int32_t* out_score, uint32_t* out_sink, void* stream);
+
 /* nvbio::fm_index<rank_dictionary<2,64,PackedStream<.,uint8,2,true>,.,.>, SSA_index_multiple_context<SA_INT>, const uint32*>
  * (nvbio/fmindex/fmindex.h:341-387) in the production interleaved layout
  * (nvbio/io/fmindex/fmindex.h:159-174, fmindex_impl.cu:305-327):

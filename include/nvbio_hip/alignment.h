@@ -31,6 +31,38 @@ struct SimpleGotohScheme
     int32 m_match, m_mismatch, m_gap_open, m_gap_ext;
 };
 
+/// nvBowtie's SmithWatermanScoringScheme<QualCost<int>,ConstantCost<int>> restricted to what the
+/// Gotoh aligner reads (nvBowtie/bowtie2/cuda/scoring.h:206-356): same member names.
+struct SmithWatermanScoringScheme
+{
+    SmithWatermanScoringScheme() : m_read_gap_const(5), m_read_gap_coeff(3), m_ref_gap_const(5), m_ref_gap_coeff(3),
+                                   m_match(0), m_mmp_min(2), m_mmp_max(6), m_mmp_constant(false) {}
+    static SmithWatermanScoringScheme local() { SmithWatermanScoringScheme s; s.m_match = 2; return s; }
+
+    /// QualCost<int>::operator() (scoring.h:96-100), single precision with truncation as written there
+    int32 mmp(const int q) const {
+        if (m_mmp_constant) return m_mmp_max;
+        const float frac = (float)((q < 40 ? q : 40) / 40.0f);
+        return m_mmp_min + int32(frac * (m_mmp_max - m_mmp_min));
+    }
+    int32 match(const uint8 = 0) const { return m_match; }
+    int32 mismatch(const uint8 q = 0) const { return -mmp(q); }
+    int32 pattern_gap_open() const { return -m_read_gap_const - m_read_gap_coeff; }
+    int32 pattern_gap_extension() const { return -m_read_gap_coeff; }
+    int32 text_gap_open() const { return -m_ref_gap_const - m_ref_gap_coeff; }
+    int32 text_gap_extension() const { return -m_ref_gap_coeff; }
+
+    nvbio_hip_gotoh_qual_scheme abi() const {
+        nvbio_hip_gotoh_qual_scheme s;
+        s.match = match(); s.pattern_gap_open = pattern_gap_open(); s.pattern_gap_ext = pattern_gap_extension();
+        s.text_gap_open = text_gap_open(); s.text_gap_ext = text_gap_extension();
+        for (int q = 0; q < 256; ++q) s.mismatch[q] = mismatch(uint8(q));
+        return s;
+    }
+    int m_read_gap_const, m_read_gap_coeff, m_ref_gap_const, m_ref_gap_coeff;
+    int m_match, m_mmp_min, m_mmp_max; bool m_mmp_constant;
+};
+
 struct GotohTag {};
 
 template <AlignmentType T, typename scoring_scheme_type>
@@ -95,6 +127,26 @@ struct BatchedBandedAlignmentScore
                   "nvbio_hip_banded_gotoh_score");
     }
 };
+
+/// The quality-aware form used by nvBowtie's extension stage (score_best_inl.h:153-201): aligner =
+/// GotohAligner<TYPE, SmithWatermanScoringScheme>, one quality byte per read symbol at the reads' offsets.
+template <uint32 BAND_LEN, AlignmentType TYPE, typename pattern_set_type, typename text_set_type>
+void batch_banded_alignment_score(
+    const GotohAligner<TYPE, SmithWatermanScoringScheme> aligner,
+    const pattern_set_type  patterns,
+    const uint8*            quals,
+    const uint64            n_quals,
+    const text_set_type     texts,
+          BestSinkArrays    sinks,
+    const uint32            max_pattern_length,
+    const uint32            max_text_length,
+    void*                   hip_stream = nullptr)
+{
+    const nvbio_hip_gotoh_qual_scheme sc = aligner.scheme.abi();
+    const nvbio_hip_string_set p = patterns.abi(), t = texts.abi();
+    hip_check(nvbio_hip_banded_gotoh_score_qual(&sc, int32(TYPE), BAND_LEN, &p, quals, n_quals, &t, max_pattern_length, max_text_length,
+                                                patterns.size(), sinks.score, sinks.sink, hip_stream), "nvbio_hip_banded_gotoh_score_qual");
+}
 
 /// batch_banded_alignment_score<BAND_LEN>(aligner, patterns, texts, sinks, scheduler, maxP, maxT)
 template <uint32 BAND_LEN, typename aligner_type, typename pattern_set_type, typename text_set_type, typename scheduler_type>

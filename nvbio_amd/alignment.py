@@ -10,7 +10,9 @@ import ctypes as C
 
 import torch
 
-from ._lib import lib, check, GotohSchemeStruct, current_stream_ptr
+import numpy as np
+
+from ._lib import lib, check, GotohSchemeStruct, GotohQualSchemeStruct, current_stream_ptr
 
 GLOBAL, LOCAL, SEMI_GLOBAL = 0, 1, 2
 
@@ -21,6 +23,48 @@ class SimpleGotohScheme:
 
     def struct(self):
         return GotohSchemeStruct(self.m_match, self.m_mismatch, self.m_gap_open, self.m_gap_ext)
+
+
+class SmithWatermanScoringScheme:
+    """nvBowtie's scoring scheme as its Gotoh aligner sees it (nvBowtie/bowtie2/cuda/scoring.h:206-356):
+    constant match bonus, quality-dependent mismatch penalty QualCost(min,max) (scoring.h:86-104) or a
+    constant one, affine read / reference gap costs.  Defaults are bowtie2's end-to-end values."""
+
+    def __init__(self, match=0, mmp_min=2, mmp_max=6, read_gap_const=5, read_gap_coeff=3,
+                 ref_gap_const=5, ref_gap_coeff=3, mm_cost="qual"):
+        self.m_match = int(match)
+        self.m_mmp_min, self.m_mmp_max, self.mm_cost = int(mmp_min), int(mmp_max), mm_cost
+        self.m_read_gap_const, self.m_read_gap_coeff = int(read_gap_const), int(read_gap_coeff)
+        self.m_ref_gap_const, self.m_ref_gap_coeff = int(ref_gap_const), int(ref_gap_coeff)
+
+    @staticmethod
+    def local():
+        return SmithWatermanScoringScheme(match=2)
+
+    def mmp(self, q):
+        """m_mmp(q).  QualCost: min + int(frac * (max - min)), frac = float(min(q,40) / 40.0f), in
+        single precision with truncation, exactly as the reference writes it."""
+        if self.mm_cost == "constant":
+            return self.m_mmp_max                                  # ConstantCost(min,max) keeps max
+        frac = np.float32(np.float32(min(int(q), 40)) / np.float32(40.0))
+        return self.m_mmp_min + int(np.float32(frac * np.float32(self.m_mmp_max - self.m_mmp_min)))
+
+    # the aln::GotohAligner interface (scoring.h:283-293)
+    def match(self, q=0): return self.m_match
+    def mismatch(self, q=0): return -self.mmp(q)
+    def pattern_gap_open(self): return -self.m_read_gap_const - self.m_read_gap_coeff
+    def pattern_gap_extension(self): return -self.m_read_gap_coeff
+    def text_gap_open(self): return -self.m_ref_gap_const - self.m_ref_gap_coeff
+    def text_gap_extension(self): return -self.m_ref_gap_coeff
+
+    def struct(self):
+        s = GotohQualSchemeStruct()
+        s.match = self.match()
+        s.pattern_gap_open, s.pattern_gap_ext = self.pattern_gap_open(), self.pattern_gap_extension()
+        s.text_gap_open, s.text_gap_ext = self.text_gap_open(), self.text_gap_extension()
+        for q in range(256):
+            s.mismatch[q] = self.mismatch(q)
+        return s
 
 
 class GotohAligner:
@@ -50,7 +94,9 @@ class BatchedBandedAlignmentScore:
 
     max_temp_storage = min_temp_storage
 
-    def enact(self, aligner, patterns, texts, out_score, out_sink, max_pattern_length=0, max_text_length=0):
+    def enact(self, aligner, patterns, texts, out_score, out_sink, max_pattern_length=0, max_text_length=0, quals=None):
+        """quals: uint8 device tensor indexed like the pattern stream's symbols -- required by (and only
+        used with) a SmithWatermanScoringScheme aligner, as nvBowtie's read qualities are."""
         n = len(patterns)
         if patterns.length is None:
             max_pattern_length = max_pattern_length or patterns.fixed_length
@@ -61,6 +107,14 @@ class BatchedBandedAlignmentScore:
         assert out_sink.dtype == torch.int32 and out_sink.numel() >= 2 * n and out_sink.is_cuda
         sc = aligner.scheme.struct()
         ps, ts = patterns.struct(), texts.struct()
+        if isinstance(aligner.scheme, SmithWatermanScoringScheme):
+            assert quals is not None and quals.dtype == torch.uint8 and quals.is_cuda and quals.is_contiguous()
+            err = lib().nvbio_hip_banded_gotoh_score_qual(
+                C.byref(sc), aligner.type, self.band_len, C.byref(ps), C.c_void_p(quals.data_ptr()), quals.numel(), C.byref(ts),
+                int(max_pattern_length), int(max_text_length), n,
+                C.c_void_p(out_score.data_ptr()), C.c_void_p(out_sink.data_ptr()), current_stream_ptr())
+            check(err, "nvbio_hip_banded_gotoh_score_qual")
+            return
         err = lib().nvbio_hip_banded_gotoh_score(
             C.byref(sc), aligner.type, self.band_len, C.byref(ps), C.byref(ts),
             int(max_pattern_length), int(max_text_length), n,
@@ -69,7 +123,7 @@ class BatchedBandedAlignmentScore:
 
 
 def batch_banded_alignment_score(band_len, aligner, patterns, texts, out_score=None, out_sink=None,
-                                 max_pattern_length=0, max_text_length=0):
+                                 max_pattern_length=0, max_text_length=0, quals=None):
     """batch_banded_alignment_score<BAND_LEN>(aligner, patterns, texts, sinks, DeviceThreadScheduler()).
     Returns (score[n] int32, sink[n,2] int32 holding the uint32 bit patterns)."""
     n = len(patterns)
@@ -79,5 +133,5 @@ def batch_banded_alignment_score(band_len, aligner, patterns, texts, out_score=N
     if out_sink is None:
         out_sink = torch.empty((n, 2), dtype=torch.int32, device=dev)
     BatchedBandedAlignmentScore(band_len).enact(aligner, patterns, texts, out_score, out_sink,
-                                                max_pattern_length, max_text_length)
+                                                max_pattern_length, max_text_length, quals)
     return out_score, out_sink

@@ -36,342 +36,27 @@
 //    to that length run the 16-bit kernel, longer ones the 32-bit kernel.
 //    Both produce the reference's int32 results bit for bit.
 //
-#include "common.h"
-#include <limits.h>
-#include <algorithm>
-#include <stdlib.h>
+#include "banded_gotoh_impl.h"
 
 namespace nvb {
 
 thread_local const char* g_last_kernel = "";
 
-struct GotohParams {
-    StringSet pat, txt;
-    int32_t   match, mismatch, gap_open, gap_ext;
-    uint32_t  n;
-    uint32_t  len_lo, len_hi;     // this launch handles jobs with len_lo <= pattern_len <= len_hi
-    int32_t*  out_score;
-    uint32_t* out_sink;
-};
+#define NVB_DECL(B) \
+    extern template hipError_t launch_band_width<B, NoQual>(const GotohParams&, const NoQual&, int, bool, hipStream_t); \
+    extern template hipError_t launch_band_width<B, QualArgs>(const GotohParams&, const QualArgs&, int, bool, hipStream_t);
+NVB_DECL(3) NVB_DECL(5) NVB_DECL(7) NVB_DECL(15) NVB_DECL(31)
+#undef NVB_DECL
 
-template <int BAND> struct BandTraits {
-    // bands 3,5,7,15: the reference's text cache is a plain uint32 array; any other band uses a
-    // 2-bit PackedStream cache which truncates what it stores to 2 bits
-    // (nvbio/alignment/alignment_base_inl.h:75-98, packedstream_inl.h:352-369)
-    static constexpr bool QUIRK = !(BAND == 3 || BAND == 5 || BAND == 7 || BAND == 15);
-    static constexpr bool RING  = (BAND <= 16);
-    static constexpr int  ROWS  = RING ? 16 : 8;
-    static constexpr int  NTC   = RING ? 16 : BAND - 1;
-};
-
-// ---------------------------------------------------------------------------
-// arithmetic policies.  A value is an int32 (A32) or an int16 kept in the low
-// half of a VGPR (A16; gfx9 16-bit VOP2 ops zero the high half).
-// ---------------------------------------------------------------------------
-struct A32 {
-    typedef int32_t T;
-    static __device__ __forceinline__ T   add(T a, T b)        { return a + b; }
-    static __device__ __forceinline__ T   mx(T a, T b)         { return max(a, b); }
-    static __device__ __forceinline__ T   mx3(T a, T b, T c)   { return max(max(a, b), c); }
-    static __device__ __forceinline__ T   clamp0(T a)          { return max(a, 0); }
-    template <int J> static __device__ __forceinline__ T key(T hi) { return hi + J; }      // hi is a multiple of 32
-    static __device__ __forceinline__ T   cnst(int32_t v)      { return v; }
-    static __device__ __forceinline__ int32_t to_int(T a)      { return a; }
-    static __device__ __forceinline__ uint32_t bits(T a)       { return uint32_t(a); }
-    static __device__ __forceinline__ T   min_value()          { return INT_MIN; }
-
-    // one interior band cell (gotoh_banded_inl.h:520-577): F, H, E and (LOCAL) the row's sink key
-    template <int TYPE, int J>
-    static __device__ __forceinline__ void cell(T& Fj, const T Fnext, const T HGnext, T& HGj, T& E, T& rowkey,
-                                                const uint32_t g, const uint32_t q, const T Go, const T Ge, const T sM, const T sX)
-    {
-        Fj = max(Fnext + Ge, HGnext);
-        const T diag = HGj + (g == q ? sM : sX);
-        T hi = max(max(Fj, E), diag);
-        if (TYPE == NVBIO_HIP_LOCAL) { hi = max(hi, 0); rowkey = max(rowkey, hi + J); }
-        HGj = hi + Go;
-        E = max(E + Ge, HGj);
-    }
-};
-struct A16 {
-    typedef uint32_t T;
-    static __device__ __forceinline__ T add(T a, T b)      { T r; asm("v_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-    static __device__ __forceinline__ T mx(T a, T b)       { T r; asm("v_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-    static __device__ __forceinline__ T mx3(T a, T b, T c) { return mx(mx(a, b), c); }
-    static __device__ __forceinline__ T clamp0(T a)        { T r; asm("v_max_i16 %0, 0, %1" : "=v"(r) : "v"(a)); return r; }
-    template <int J> static __device__ __forceinline__ T key(T hi) { T r; asm("v_add_u16 %0, %2, %1" : "=v"(r) : "v"(hi), "s"(J)); return r; }
-    static __device__ __forceinline__ T cnst(int32_t v)    { return uint32_t(v) & 0xFFFFu; }
-    static __device__ __forceinline__ int32_t to_int(T a)  { return int32_t(int16_t(a & 0xFFFFu)); }
-    static __device__ __forceinline__ uint32_t bits(T a)   { return a & 0xFFFFu; }
-
-    // The same cell as one hand-scheduled instruction block: 2-cycle 16-bit VOP2 ops only (plus the
-    // compare/select of the substitution score), ordered so that the serial E -> H -> HG -> E chain
-    // (5 ops) is interleaved with the independent F / diagonal / key work.
-    template <int TYPE, int J>
-    static __device__ __forceinline__ void cell(T& Fj, const T Fnext, const T HGnext, T& HGj, T& E, T& rowkey,
-                                                const uint32_t g, const uint32_t q, const T Go, const T Ge, const T sM, const T sX)
-    {
-        T d, h, e2;
-        if (TYPE == NVBIO_HIP_LOCAL)
-            asm("v_cmp_eq_u32 vcc, %[g], %[q]\n\t"
-                "v_add_u16 %[f], %[fn], %[ge]\n\t"
-                "v_cndmask_b32 %[d], %[sx], %[sm], vcc\n\t"
-                "v_max_i16 %[f], %[f], %[hgn]\n\t"
-                "v_add_u16 %[d], %[hg], %[d]\n\t"
-                "v_max_i16 %[h], %[f], %[e]\n\t"
-                "v_add_u16 %[e2], %[e], %[ge]\n\t"
-                "v_max_i16 %[h], %[h], %[d]\n\t"
-                "v_max_i16 %[h], 0, %[h]\n\t"
-                "v_add_u16 %[hg], %[h], %[go]\n\t"
-                "v_add_u16 %[d], %[sj], %[h]\n\t"
-                "v_max_i16 %[e], %[e2], %[hg]\n\t"
-                "v_max_i16 %[rk], %[rk], %[d]"
-                : [f] "=&v"(Fj), [d] "=&v"(d), [h] "=&v"(h), [e2] "=&v"(e2), [hg] "+v"(HGj), [e] "+v"(E), [rk] "+v"(rowkey)
-                : [g] "v"(g), [q] "v"(q), [fn] "v"(Fnext), [ge] "v"(Ge), [sx] "v"(sX), [sm] "v"(sM), [hgn] "v"(HGnext), [go] "v"(Go), [sj] "s"(J)
-                : "vcc");
-        else
-            asm("v_cmp_eq_u32 vcc, %[g], %[q]\n\t"
-                "v_add_u16 %[f], %[fn], %[ge]\n\t"
-                "v_cndmask_b32 %[d], %[sx], %[sm], vcc\n\t"
-                "v_max_i16 %[f], %[f], %[hgn]\n\t"
-                "v_add_u16 %[d], %[hg], %[d]\n\t"
-                "v_max_i16 %[h], %[f], %[e]\n\t"
-                "v_add_u16 %[e2], %[e], %[ge]\n\t"
-                "v_max_i16 %[h], %[h], %[d]\n\t"
-                "v_add_u16 %[hg], %[h], %[go]\n\t"
-                "v_max_i16 %[e], %[e2], %[hg]"
-                : [f] "=&v"(Fj), [d] "=&v"(d), [h] "=&v"(h), [e2] "=&v"(e2), [hg] "+v"(HGj), [e] "+v"(E)
-                : [g] "v"(g), [q] "v"(q), [fn] "v"(Fnext), [ge] "v"(Ge), [sx] "v"(sX), [sm] "v"(sM), [hgn] "v"(HGnext), [go] "v"(Go)
-                : "vcc");
-    }
-    static __device__ __forceinline__ T min_value()        { return 0x8000u; }
-};
-
-template <int BAND, typename A>
-struct DPState {
-    typename A::T HG[BAND];                  // (H + G_o) of the previous row  [x32 for LOCAL]
-    typename A::T F[BAND - 1];               // F[BAND-1] is always `infimum`
-    uint32_t      tc[BandTraits<BAND>::NTC]; // text symbols of the band
-    typename A::T bestkey;                   // LOCAL: score*32 + j of the best cell so far
-    uint32_t      besti;                     //        and its row
-};
-
-template <typename A>
-struct DPConsts {
-    typename A::T Go, Ge, sM, sX, inf;       // sM/sX = match/mismatch - G_o ; inf = the infimum sentinel
-};
-
-template <int BAND, int TYPE, typename A, int R>
-__device__ __forceinline__ void dp_row(DPState<BAND, A>& st, const DPConsts<A>& k,
-                                       const uint32_t i, const uint32_t q, const uint32_t g_new)
-{
-    typedef BandTraits<BAND> BT;
-    typedef typename A::T T;
-    T rowkey = A::min_value();
-    T E;
-
-    // j == 0  (gotoh_banded_inl.h:483-517)
-    {
-        const T fnext = A::add((1 == BAND - 1) ? k.inf : st.F[1 < BAND - 1 ? 1 : 0], k.Ge);
-        st.F[0] = A::mx(fnext, st.HG[1]);
-        const uint32_t g = st.tc[BT::RING ? (R & 15) : 0];
-        const T diag = A::add(st.HG[0], g == q ? k.sM : k.sX);
-        T hi = A::mx(st.F[0], diag);
-        if (TYPE == NVBIO_HIP_LOCAL) { hi = A::clamp0(hi); rowkey = hi; }
-        st.HG[0] = A::add(hi, k.Go);
-        E = st.HG[0];
-    }
-    // 1 <= j <= BAND-2  (:520-577)
-    #pragma unroll
-    for (int j = 1; j < BAND - 1; ++j)
-    {
-        const uint32_t g = st.tc[BT::RING ? ((R + j) & 15) : j];
-        if (!BT::RING) st.tc[j - 1] = g;                                   // :542
-        // F[BAND-1] is `infimum` at every row (:586), so the cell next to the band edge sees it as F[j+1]
-        const T fnext = (j + 1 == BAND - 1) ? k.inf : st.F[j + 1 < BAND - 1 ? j + 1 : 0];
-        switch (j) {   // the sink key's column is an instruction constant
-            #define NVB_CELL(J) case J: A::template cell<TYPE, J>(st.F[j], fnext, st.HG[j + 1], st.HG[j], E, rowkey, g, q, k.Go, k.Ge, k.sM, k.sX); break;
-            NVB_CELL(1) NVB_CELL(2) NVB_CELL(3) NVB_CELL(4) NVB_CELL(5) NVB_CELL(6) NVB_CELL(7) NVB_CELL(8) NVB_CELL(9) NVB_CELL(10)
-            NVB_CELL(11) NVB_CELL(12) NVB_CELL(13) NVB_CELL(14) NVB_CELL(15) NVB_CELL(16) NVB_CELL(17) NVB_CELL(18) NVB_CELL(19) NVB_CELL(20)
-            NVB_CELL(21) NVB_CELL(22) NVB_CELL(23) NVB_CELL(24) NVB_CELL(25) NVB_CELL(26) NVB_CELL(27) NVB_CELL(28) NVB_CELL(29)
-            #undef NVB_CELL
-            default: break;
-        }
-    }
-    // the new text symbol enters the band (:580-581); the cached copy is what later rows see
-    {
-        const uint32_t stored = BT::QUIRK ? (g_new & 3u) : g_new;
-        if (BT::RING) st.tc[(R + BAND - 1) & 15] = stored;
-        else          st.tc[BAND - 2] = stored;
-    }
-    // j == BAND-1  (:584-614) -- compares against the raw symbol
-    {
-        const T diag = A::add(st.HG[BAND - 1], g_new == q ? k.sM : k.sX);
-        T hi = A::mx(E, diag);
-        if (TYPE == NVBIO_HIP_LOCAL) { hi = A::clamp0(hi); rowkey = A::mx(rowkey, A::template key<BAND - 1>(hi)); }
-        st.HG[BAND - 1] = A::add(hi, k.Go);
-    }
-    if (TYPE == NVBIO_HIP_LOCAL)
-    {
-        // BestSink::report uses '<=' (sink_inl.h:57-68): a later cell with an equal score wins.
-        // LOCAL keys are non-negative, so the comparison is the same in either width.
-        const uint32_t rk = A::bits(rowkey), bk = A::bits(st.bestkey);
-        const bool upd = (rk | 31u) >= bk;
-        st.bestkey = upd ? rowkey : st.bestkey;
-        st.besti   = upd ? i : st.besti;
-    }
-}
-
-template <int BAND, int TYPE, typename A, int R, int END>
-struct RowUnrollN {
-    __device__ __forceinline__ static void run(DPState<BAND, A>& st, const DPConsts<A>& k,
-        const uint32_t i0, const uint32_t M, const uint32_t N, const uint64_t P, const uint32_t T)
-    {
-        const uint32_t i = i0 + R;
-        if (i < M)
-        {
-            const uint32_t q = uint32_t(P >> (4 * R)) & 15u;
-            uint32_t g = (T >> (2 * R)) & 3u;
-            if (i + BAND - 1 >= N) g = 255u;
-            dp_row<BAND, TYPE, A, R>(st, k, i, q, g);
-        }
-        RowUnrollN<BAND, TYPE, A, R + 1, END>::run(st, k, i0, M, N, P, T);
-    }
-};
-template <int BAND, int TYPE, typename A, int END> struct RowUnrollN<BAND, TYPE, A, END, END> {
-    __device__ __forceinline__ static void run(DPState<BAND, A>&, const DPConsts<A>&, uint32_t, uint32_t, uint32_t, uint64_t, uint32_t) {}
-};
-
-__device__ __forceinline__ uint64_t fetch_pattern16(const Stream& s, uint64_t sym)
-{
-    return (s.bits == 4) ? fetch16_4bit(s, sym) : expand_2to4(fetch16_2bit(s, sym));
-}
-
-// the sentinel standing in for the reference's infimum (-32768 - max(G_o,G_e), :446-448).
-// 32-bit: the reference's own number (scaled for LOCAL).  16-bit: the lowest value whose
-// G_e step is still representable; the host only selects the 16-bit kernel when every reachable
-// DP value stays far above it, in which case either sentinel loses every max it takes part in.
-template <typename A> struct Sentinel {};
-template <> struct Sentinel<A32> {
-    static __device__ __forceinline__ int32_t get(int32_t Go, int32_t Ge, int sh) { return (-32768 - max(Go, Ge)) * (1 << sh); }
-};
-template <> struct Sentinel<A16> {   // infimum + G_e == -32768 exactly: the add cannot wrap
-    static __device__ __forceinline__ uint32_t get(int32_t Go, int32_t Ge, int sh) { return A16::cnst(-32768 - Ge * (1 << sh)); }
-};
-
-template <int BAND, int TYPE, typename A>
-__global__ void __launch_bounds__(256)
-banded_gotoh_score_kernel(const GotohParams p)
-{
-    typedef BandTraits<BAND> BT;
-    typedef typename A::T T;
-    constexpr int SH = (TYPE == NVBIO_HIP_LOCAL) ? 5 : 0;      // LOCAL carries scores x32 (see header)
-    const uint32_t id = blockIdx.x * 256u + threadIdx.x;
-    if (id >= p.n) return;
-
-    const uint32_t M  = p.pat.length ? p.pat.length[id] : p.pat.fixed_length;
-    if (M < p.len_lo || M > p.len_hi) return;                   // the other arithmetic width owns this job
-    const uint64_t pb = p.pat.begin[id];
-    const uint64_t tb = p.txt.begin[id];
-    const uint32_t N  = p.txt.length ? p.txt.length[id] : p.txt.fixed_length;
-
-    int32_t  score = -(1 << 30);                 // BestSink<int32>() : numbers.h:832-835
-    uint32_t sx = 0xFFFFFFFFu, sy = 0xFFFFFFFFu;
-
-    if (N >= M)                                  // gotoh_banded_inl.h:431-432
-    {
-        DPConsts<A> k;
-        k.Go = A::cnst(p.gap_open * (1 << SH)); k.Ge = A::cnst(p.gap_ext * (1 << SH));
-        k.sM = A::cnst((p.match - p.gap_open) * (1 << SH)); k.sX = A::cnst((p.mismatch - p.gap_open) * (1 << SH));
-        k.inf = Sentinel<A>::get(p.gap_open, p.gap_ext, SH);
-        const T infimum = k.inf;
-
-        DPState<BAND, A> st;
-        // init_row_zero (:46-77), stored as H + G_o
-        st.HG[0] = k.Go;
-        #pragma unroll
-        for (int j = 1; j < BAND; ++j)
-            st.HG[j] = A::cnst(((TYPE == NVBIO_HIP_GLOBAL ? p.gap_open + (j - 1) * p.gap_ext : 0) + p.gap_open) * (1 << SH));
-        #pragma unroll
-        for (int j = 0; j < BAND - 1; ++j) st.F[j] = infimum;
-        st.bestkey = A::cnst(0); st.besti = 0;
-
-        // first band of text (:441-442): symbols 0..BAND-2, no bounds check in the reference either
-        {
-            #pragma unroll
-            for (int b = 0; b < BAND - 1; b += 16)
-            {
-                const uint32_t T0 = fetch16_2bit(p.txt.s, tb + b);
-                #pragma unroll
-                for (int j = b; j < BAND - 1 && j < b + 16; ++j)
-                    st.tc[BT::RING ? (j & 15) : j] = (T0 >> (2 * (j - b))) & 3u;
-            }
-        }
-
-        uint64_t P  = fetch_pattern16(p.pat.s, pb);
-        uint32_t Tx = fetch16_2bit(p.txt.s, tb + BAND - 1);
-        for (uint32_t i0 = 0; i0 < M; i0 += BT::ROWS)
-        {
-            // prefetch the next block's symbols while this one computes
-            const uint64_t Pn = fetch_pattern16(p.pat.s, pb + i0 + BT::ROWS);
-            const uint32_t Tn = fetch16_2bit(p.txt.s, tb + i0 + BT::ROWS + BAND - 1);
-            RowUnrollN<BAND, TYPE, A, 0, BT::ROWS>::run(st, k, i0, M, N, P, Tx);
-            P = Pn; Tx = Tn;
-        }
-
-        if (TYPE == NVBIO_HIP_LOCAL)
-        {
-            if (M > 0) {
-                const uint32_t key = uint32_t(A::to_int(st.bestkey));          // >= 0
-                const uint32_t j = key & 31u;
-                score = int32_t(key >> 5);
-                sx = st.besti + j + 1; sy = st.besti + 1;
-            }
-        }
-        else if (TYPE == NVBIO_HIP_GLOBAL)
-        {
-            score = A::to_int(st.HG[BAND - 1]) - p.gap_open;      // :641-642
-            sx = M + BAND - 1; sy = M;
-        }
-        else
-        {
-            // :643-655
-            const uint32_t a = M + BAND - 1u;
-            const uint32_t m = (a < N ? a : N) - (M - 1u);
-            #pragma unroll
-            for (int j = 0; j < BAND; ++j)
-            {
-                const int32_t h = A::to_int(st.HG[j]) - p.gap_open;
-                if ((j == 0 || uint32_t(j) < m) && score <= h) { score = h; sx = M + j; sy = M; }
-            }
-        }
-    }
-    p.out_score[id] = score;
-    reinterpret_cast<uint2*>(p.out_sink)[id] = make_uint2(sx, sy);
-}
-
-template <int BAND, typename A>
-static hipError_t launch_band(const GotohParams& p, int type, hipStream_t stream)
-{
-    const dim3 grid((p.n + 255u) / 256u), block(256);
-    switch (type) {
-    case NVBIO_HIP_GLOBAL:      hipLaunchKernelGGL((banded_gotoh_score_kernel<BAND, NVBIO_HIP_GLOBAL, A>),      grid, block, 0, stream, p); break;
-    case NVBIO_HIP_LOCAL:       hipLaunchKernelGGL((banded_gotoh_score_kernel<BAND, NVBIO_HIP_LOCAL, A>),       grid, block, 0, stream, p); break;
-    case NVBIO_HIP_SEMI_GLOBAL: hipLaunchKernelGGL((banded_gotoh_score_kernel<BAND, NVBIO_HIP_SEMI_GLOBAL, A>), grid, block, 0, stream, p); break;
-    default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
-
-template <typename A>
-static hipError_t launch(const GotohParams& p, int type, uint32_t band, hipStream_t s)
+template <typename QA>
+static hipError_t launch(const GotohParams& p, const QA& qa, int type, uint32_t band, bool width16, hipStream_t s)
 {
     switch (band) {
-    case 3:  return launch_band<3, A>(p, type, s);
-    case 5:  return launch_band<5, A>(p, type, s);
-    case 7:  return launch_band<7, A>(p, type, s);
-    case 15: return launch_band<15, A>(p, type, s);
-    case 31: return launch_band<31, A>(p, type, s);
+    case 3:  return launch_band_width<3, QA>(p, qa, type, width16, s);
+    case 5:  return launch_band_width<5, QA>(p, qa, type, width16, s);
+    case 7:  return launch_band_width<7, QA>(p, qa, type, width16, s);
+    case 15: return launch_band_width<15, QA>(p, qa, type, width16, s);
+    case 31: return launch_band_width<31, QA>(p, qa, type, width16, s);
     default: return hipErrorNotSupported;
     }
 }
@@ -383,22 +68,63 @@ static hipError_t launch(const GotohParams& p, int type, uint32_t band, hipStrea
 //                        far above the sentinel.
 //   GLOBAL/SEMI_GLOBAL:  |value| <= (M + BAND + 2) * max|cost|; need that below 15000 so that
 //                        no real value comes within a band's worth of gap steps of the sentinel.
-static uint32_t max_len_16bit(const nvbio_hip_gotoh_scheme& sc, int type, uint32_t band)
+static uint32_t max_len_16bit(int32_t match, int64_t A /* max |cost| */, int32_t gap_open, int32_t gap_ext, int type, uint32_t band)
 {
-    auto iabs = [](int32_t v) { return v < 0 ? -int64_t(v) : int64_t(v); };
-    if (sc.gap_open > 0 || sc.gap_ext > 0) return 0;
-    const int64_t A = std::max(std::max(iabs(sc.match), iabs(sc.mismatch)), std::max(iabs(sc.gap_open), iabs(sc.gap_ext)));
+    if (gap_open > 0 || gap_ext > 0) return 0;
     if (A == 0) return 0xFFFFFFFFu;
     if (type == NVBIO_HIP_LOCAL) {
-        if (sc.match < 0 || A > 100) return 0;                       // 32*4*A stays far above -32768
-        if (sc.match == 0) return 0xFFFFFFFFu;
-        return uint32_t(1022 / sc.match);
+        if (match < 0 || A > 100) return 0;                          // 32*4*A stays far above -32768
+        if (match == 0) return 0xFFFFFFFFu;
+        return uint32_t(1022 / match);
     }
     const int64_t lim = 15000 / A - int64_t(band) - 2;
     return lim <= 0 ? 0u : uint32_t(lim);
 }
 
 } // namespace nvb
+
+template <typename QA>
+static int banded_gotoh_dispatch(nvb::GotohParams& p, const QA& qa, int64_t max_abs_cost, int32_t type, uint32_t band_len,
+                                 const nvbio_hip_string_set* patterns, hipStream_t s, const char* tag16, const char* tag32)
+{
+    using namespace nvb;
+    // NVBIO_HIP_FORCE_32BIT=1 disables the 16-bit kernels (used by the tests to cover both widths)
+    const char* force32 = getenv("NVBIO_HIP_FORCE_32BIT");
+    const uint32_t lim16 = (force32 && force32[0] == '1') ? 0u
+                         : max_len_16bit(p.match, max_abs_cost, std::max(p.gap_open, p.txt_gap_open), std::max(p.gap_ext, p.txt_gap_ext), type, band_len);
+    const bool fixed = (patterns->length == nullptr);
+    hipError_t e = hipSuccess;
+    // jobs with pattern_len <= lim16 : 16-bit arithmetic;  longer ones : 32-bit arithmetic
+    if (lim16 > 0 && (!fixed || patterns->fixed_length <= lim16)) {
+        p.len_lo = 0; p.len_hi = lim16;
+        g_last_kernel = tag16;
+        e = launch<QA>(p, qa, type, band_len, true, s);
+        if (e != hipSuccess) return e;
+    }
+    if (lim16 != 0xFFFFFFFFu && (!fixed || patterns->fixed_length > lim16)) {
+        p.len_lo = lim16 > 0 ? lim16 + 1 : 0; p.len_hi = 0xFFFFFFFFu;
+        if (fixed || lim16 == 0) g_last_kernel = tag32;
+        e = launch<QA>(p, qa, type, band_len, false, s);
+    }
+    return e;
+}
+
+static int check_banded_args(int32_t type, uint32_t band_len, const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts)
+{
+    if (!patterns || !texts) return hipErrorInvalidValue;
+    if (type < 0 || type > 2) return hipErrorInvalidValue;
+    if (!(patterns->bits == 2 || patterns->bits == 4) || texts->bits != 2) return hipErrorNotSupported;
+    if (!(band_len == 3 || band_len == 5 || band_len == 7 || band_len == 15 || band_len == 31)) return hipErrorNotSupported;
+    return hipSuccess;
+}
+static int check_banded_ptrs(const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts, const int32_t* out_score, const uint32_t* out_sink)
+{
+    if (!out_score || !out_sink) return hipErrorInvalidValue;
+    if (!patterns->words || !texts->words || !patterns->begin || !texts->begin ||
+        patterns->n_words == 0 || texts->n_words == 0) return hipErrorInvalidValue;
+    return hipSuccess;
+}
+static inline int64_t iabs64(int32_t v) { return v < 0 ? -int64_t(v) : int64_t(v); }
 
 NVB_API int nvbio_hip_banded_gotoh_score(
     const nvbio_hip_gotoh_scheme* scheme, int32_t type, uint32_t band_len,
@@ -408,41 +134,52 @@ NVB_API int nvbio_hip_banded_gotoh_score(
 {
     (void)max_pattern_len; (void)max_text_len;     // kernel selection is made per job from its own length
     using namespace nvb;
-    if (!scheme || !patterns || !texts) return hipErrorInvalidValue;
-    if (type < 0 || type > 2) return hipErrorInvalidValue;
-    if (!(patterns->bits == 2 || patterns->bits == 4) || texts->bits != 2) return hipErrorNotSupported;
-    if (!(band_len == 3 || band_len == 5 || band_len == 7 || band_len == 15 || band_len == 31)) return hipErrorNotSupported;
+    if (!scheme) return hipErrorInvalidValue;
+    if (int e = check_banded_args(type, band_len, patterns, texts)) return e;
     if (n == 0) return hipSuccess;                 // an empty batch is legal and touches nothing
-    if (!out_score || !out_sink) return hipErrorInvalidValue;
-    if (!patterns->words || !texts->words || !patterns->begin || !texts->begin ||
-        patterns->n_words == 0 || texts->n_words == 0) return hipErrorInvalidValue;
+    if (int e = check_banded_ptrs(patterns, texts, out_score, out_sink)) return e;
 
     GotohParams p;
     p.pat = make_string_set(patterns);
     p.txt = make_string_set(texts);
     p.match = scheme->match; p.mismatch = scheme->mismatch;
     p.gap_open = scheme->gap_open; p.gap_ext = scheme->gap_ext;
+    p.txt_gap_open = scheme->gap_open; p.txt_gap_ext = scheme->gap_ext;      // SimpleGotohScheme: utils.h:128-131
     p.n = n; p.out_score = out_score; p.out_sink = out_sink;
+    const int64_t A = std::max(std::max(iabs64(scheme->match), iabs64(scheme->mismatch)), std::max(iabs64(scheme->gap_open), iabs64(scheme->gap_ext)));
+    return banded_gotoh_dispatch(p, NoQual(), A, type, band_len, patterns, to_stream(stream),
+                                 "banded_gotoh_score_kernel<A16>", "banded_gotoh_score_kernel<A32>");
+}
 
-    hipStream_t s = to_stream(stream);
-    // NVBIO_HIP_FORCE_32BIT=1 disables the 16-bit kernels (used by the tests to cover both widths)
-    const char* force32 = getenv("NVBIO_HIP_FORCE_32BIT");
-    const uint32_t lim16 = (force32 && force32[0] == '1') ? 0u : max_len_16bit(*scheme, type, band_len);
-    const bool fixed = (patterns->length == nullptr);
-    hipError_t e = hipSuccess;
-    // jobs with pattern_len <= lim16 : 16-bit arithmetic;  longer ones : 32-bit arithmetic
-    if (lim16 > 0 && (!fixed || patterns->fixed_length <= lim16)) {
-        p.len_lo = 0; p.len_hi = lim16;
-        g_last_kernel = "banded_gotoh_score_kernel<A16>";
-        e = launch<A16>(p, type, band_len, s);
-        if (e != hipSuccess) return e;
-    }
-    if (lim16 != 0xFFFFFFFFu && (!fixed || patterns->fixed_length > lim16)) {
-        p.len_lo = lim16 > 0 ? lim16 + 1 : 0; p.len_hi = 0xFFFFFFFFu;
-        if (fixed || lim16 == 0) g_last_kernel = "banded_gotoh_score_kernel<A32>";
-        e = launch<A32>(p, type, band_len, s);
-    }
-    return e;
+NVB_API int nvbio_hip_banded_gotoh_score_qual(
+    const nvbio_hip_gotoh_qual_scheme* scheme, int32_t type, uint32_t band_len,
+    const nvbio_hip_string_set* patterns, const uint8_t* quals, uint64_t n_quals,
+    const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len,
+    uint32_t n, int32_t* out_score, uint32_t* out_sink, void* stream)
+{
+    (void)max_pattern_len; (void)max_text_len;
+    using namespace nvb;
+    if (!scheme) return hipErrorInvalidValue;
+    if (int e = check_banded_args(type, band_len, patterns, texts)) return e;
+    if (n == 0) return hipSuccess;
+    if (int e = check_banded_ptrs(patterns, texts, out_score, out_sink)) return e;
+    if (!quals || n_quals < 4) return hipErrorInvalidValue;
+
+    GotohParams p;
+    p.pat = make_string_set(patterns);
+    p.txt = make_string_set(texts);
+    p.match = scheme->match; p.mismatch = 0;
+    p.gap_open = scheme->pattern_gap_open; p.gap_ext = scheme->pattern_gap_ext;
+    p.txt_gap_open = scheme->text_gap_open; p.txt_gap_ext = scheme->text_gap_ext;
+    p.n = n; p.out_score = out_score; p.out_sink = out_sink;
+    QualArgs qa;
+    qa.quals = quals; qa.n_quals = n_quals;
+    int64_t A = std::max(std::max(iabs64(scheme->match), iabs64(scheme->pattern_gap_open)), std::max(iabs64(scheme->pattern_gap_ext),
+                std::max(iabs64(scheme->text_gap_open), iabs64(scheme->text_gap_ext))));
+    for (int i = 0; i < 256; ++i) { qa.lut[i] = scheme->mismatch[i]; A = std::max(A, iabs64(scheme->mismatch[i])); }
+    return banded_gotoh_dispatch(p, qa, A, type, band_len, patterns, to_stream(stream),
+                                 "banded_gotoh_score_kernel<A16,qual>", "banded_gotoh_score_kernel<A32,qual>");
 }
 
 NVB_API int nvbio_hip_device_malloc(void** ptr, uint64_t bytes) { return ptr ? hipMalloc(ptr, bytes ? bytes : 1) : hipErrorInvalidValue; }

@@ -1,0 +1,3 @@
+// explicit instantiation: band 31, NoQual
+#include "banded_gotoh_impl.h"
+namespace nvb { template hipError_t launch_band_width<31, NoQual>(const GotohParams&, const NoQual&, int, bool, hipStream_t); }

@@ -1,0 +1,3 @@
+// explicit instantiation: band 31, QualArgs
+#include "banded_gotoh_impl.h"
+namespace nvb { template hipError_t launch_band_width<31, QualArgs>(const GotohParams&, const QualArgs&, int, bool, hipStream_t); }

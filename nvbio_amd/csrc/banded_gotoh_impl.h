@@ -1,0 +1,385 @@
+// banded_gotoh_impl.h -- kernel templates of the banded Gotoh score (see banded_gotoh.hip for the design notes)
+#pragma once
+#include "common.h"
+#include <limits.h>
+#include <algorithm>
+#include <stdlib.h>
+
+namespace nvb {
+
+struct GotohParams {
+    StringSet pat, txt;
+    int32_t   match, mismatch, gap_open, gap_ext;   // gap_* = the scheme's pattern_gap_open / _extension
+    int32_t   txt_gap_open, txt_gap_ext;            // text_gap_* : GLOBAL row-zero init and the infimum only
+    uint32_t  n;
+    uint32_t  len_lo, len_hi;     // this launch handles jobs with len_lo <= pattern_len <= len_hi
+    int32_t*  out_score;
+    uint32_t* out_sink;
+};
+
+// nvBowtie's quality-aware scheme (nvBowtie/bowtie2/cuda/scoring.h:283-293): the mismatch score is a
+// function of the read symbol's quality byte, tabulated by the host for all 256 bytes.
+struct QualArgs {
+    const uint8_t* quals;        // quality of the pattern symbol at stream index begin + i
+    uint64_t       n_quals;      // bytes allocated (loads are clamped)
+    int32_t        lut[256];     // mismatch(q)
+};
+struct NoQual {};
+
+template <int BAND> struct BandTraits {
+    // bands 3,5,7,15: the reference's text cache is a plain uint32 array; any other band uses a
+    // 2-bit PackedStream cache which truncates what it stores to 2 bits
+    // (nvbio/alignment/alignment_base_inl.h:75-98, packedstream_inl.h:352-369)
+    static constexpr bool QUIRK = !(BAND == 3 || BAND == 5 || BAND == 7 || BAND == 15);
+    static constexpr bool RING  = (BAND <= 16);
+    static constexpr int  ROWS  = RING ? 16 : 8;
+    static constexpr int  NTC   = RING ? 16 : BAND - 1;
+};
+
+// ---------------------------------------------------------------------------
+// arithmetic policies.  A value is an int32 (A32) or an int16 kept in the low
+// half of a VGPR (A16; gfx9 16-bit VOP2 ops zero the high half).
+// ---------------------------------------------------------------------------
+struct A32 {
+    typedef int32_t T;
+    static __device__ __forceinline__ T   add(T a, T b)        { return a + b; }
+    static __device__ __forceinline__ T   mx(T a, T b)         { return max(a, b); }
+    static __device__ __forceinline__ T   mx3(T a, T b, T c)   { return max(max(a, b), c); }
+    static __device__ __forceinline__ T   clamp0(T a)          { return max(a, 0); }
+    template <int J> static __device__ __forceinline__ T key(T hi) { return hi + J; }      // hi is a multiple of 32
+    static __device__ __forceinline__ T   cnst(int32_t v)      { return v; }
+    static __device__ __forceinline__ int32_t to_int(T a)      { return a; }
+    static __device__ __forceinline__ uint32_t bits(T a)       { return uint32_t(a); }
+    static __device__ __forceinline__ T   min_value()          { return INT_MIN; }
+
+    // one interior band cell (gotoh_banded_inl.h:520-577): F, H, E and (LOCAL) the row's sink key
+    template <int TYPE, int J>
+    static __device__ __forceinline__ void cell(T& Fj, const T Fnext, const T HGnext, T& HGj, T& E, T& rowkey,
+                                                const uint32_t g, const uint32_t q, const T Go, const T Ge, const T sM, const T sX)
+    {
+        Fj = max(Fnext + Ge, HGnext);
+        const T diag = HGj + (g == q ? sM : sX);
+        T hi = max(max(Fj, E), diag);
+        if (TYPE == NVBIO_HIP_LOCAL) { hi = max(hi, 0); rowkey = max(rowkey, hi + J); }
+        HGj = hi + Go;
+        E = max(E + Ge, HGj);
+    }
+};
+struct A16 {
+    typedef uint32_t T;
+    static __device__ __forceinline__ T add(T a, T b)      { T r; asm("v_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+    static __device__ __forceinline__ T mx(T a, T b)       { T r; asm("v_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+    static __device__ __forceinline__ T mx3(T a, T b, T c) { return mx(mx(a, b), c); }
+    static __device__ __forceinline__ T clamp0(T a)        { T r; asm("v_max_i16 %0, 0, %1" : "=v"(r) : "v"(a)); return r; }
+    template <int J> static __device__ __forceinline__ T key(T hi) { T r; asm("v_add_u16 %0, %2, %1" : "=v"(r) : "v"(hi), "s"(J)); return r; }
+    static __device__ __forceinline__ T cnst(int32_t v)    { return uint32_t(v) & 0xFFFFu; }
+    static __device__ __forceinline__ int32_t to_int(T a)  { return int32_t(int16_t(a & 0xFFFFu)); }
+    static __device__ __forceinline__ uint32_t bits(T a)   { return a & 0xFFFFu; }
+
+    // The same cell as one hand-scheduled instruction block: 2-cycle 16-bit VOP2 ops only (plus the
+    // compare/select of the substitution score), ordered so that the serial E -> H -> HG -> E chain
+    // (5 ops) is interleaved with the independent F / diagonal / key work.
+    template <int TYPE, int J>
+    static __device__ __forceinline__ void cell(T& Fj, const T Fnext, const T HGnext, T& HGj, T& E, T& rowkey,
+                                                const uint32_t g, const uint32_t q, const T Go, const T Ge, const T sM, const T sX)
+    {
+        T d, h, e2;
+        if (TYPE == NVBIO_HIP_LOCAL)
+            asm("v_cmp_eq_u32 vcc, %[g], %[q]\n\t"
+                "v_add_u16 %[f], %[fn], %[ge]\n\t"
+                "v_cndmask_b32 %[d], %[sx], %[sm], vcc\n\t"
+                "v_max_i16 %[f], %[f], %[hgn]\n\t"
+                "v_add_u16 %[d], %[hg], %[d]\n\t"
+                "v_max_i16 %[h], %[f], %[e]\n\t"
+                "v_add_u16 %[e2], %[e], %[ge]\n\t"
+                "v_max_i16 %[h], %[h], %[d]\n\t"
+                "v_max_i16 %[h], 0, %[h]\n\t"
+                "v_add_u16 %[hg], %[h], %[go]\n\t"
+                "v_add_u16 %[d], %[sj], %[h]\n\t"
+                "v_max_i16 %[e], %[e2], %[hg]\n\t"
+                "v_max_i16 %[rk], %[rk], %[d]"
+                : [f] "=&v"(Fj), [d] "=&v"(d), [h] "=&v"(h), [e2] "=&v"(e2), [hg] "+v"(HGj), [e] "+v"(E), [rk] "+v"(rowkey)
+                : [g] "v"(g), [q] "v"(q), [fn] "v"(Fnext), [ge] "v"(Ge), [sx] "v"(sX), [sm] "v"(sM), [hgn] "v"(HGnext), [go] "v"(Go), [sj] "s"(J)
+                : "vcc");
+        else
+            asm("v_cmp_eq_u32 vcc, %[g], %[q]\n\t"
+                "v_add_u16 %[f], %[fn], %[ge]\n\t"
+                "v_cndmask_b32 %[d], %[sx], %[sm], vcc\n\t"
+                "v_max_i16 %[f], %[f], %[hgn]\n\t"
+                "v_add_u16 %[d], %[hg], %[d]\n\t"
+                "v_max_i16 %[h], %[f], %[e]\n\t"
+                "v_add_u16 %[e2], %[e], %[ge]\n\t"
+                "v_max_i16 %[h], %[h], %[d]\n\t"
+                "v_add_u16 %[hg], %[h], %[go]\n\t"
+                "v_max_i16 %[e], %[e2], %[hg]"
+                : [f] "=&v"(Fj), [d] "=&v"(d), [h] "=&v"(h), [e2] "=&v"(e2), [hg] "+v"(HGj), [e] "+v"(E)
+                : [g] "v"(g), [q] "v"(q), [fn] "v"(Fnext), [ge] "v"(Ge), [sx] "v"(sX), [sm] "v"(sM), [hgn] "v"(HGnext), [go] "v"(Go)
+                : "vcc");
+    }
+    static __device__ __forceinline__ T min_value()        { return 0x8000u; }
+};
+
+template <int BAND, typename A>
+struct DPState {
+    typename A::T HG[BAND];                  // (H + G_o) of the previous row  [x32 for LOCAL]
+    typename A::T F[BAND - 1];               // F[BAND-1] is always `infimum`
+    uint32_t      tc[BandTraits<BAND>::NTC]; // text symbols of the band
+    typename A::T bestkey;                   // LOCAL: score*32 + j of the best cell so far
+    uint32_t      besti;                     //        and its row
+};
+
+template <typename A>
+struct DPConsts {
+    typename A::T Go, Ge, sM, sX, inf;       // sM/sX = match/mismatch - G_o ; inf = the infimum sentinel
+};
+
+template <int BAND, int TYPE, typename A, int R>
+__device__ __forceinline__ void dp_row(DPState<BAND, A>& st, const DPConsts<A>& k, const typename A::T sX,
+                                       const uint32_t i, const uint32_t q, const uint32_t g_new)
+{
+    typedef BandTraits<BAND> BT;
+    typedef typename A::T T;
+    T rowkey = A::min_value();
+    T E;
+
+    // j == 0  (gotoh_banded_inl.h:483-517)
+    {
+        const T fnext = A::add((1 == BAND - 1) ? k.inf : st.F[1 < BAND - 1 ? 1 : 0], k.Ge);
+        st.F[0] = A::mx(fnext, st.HG[1]);
+        const uint32_t g = st.tc[BT::RING ? (R & 15) : 0];
+        const T diag = A::add(st.HG[0], g == q ? k.sM : sX);
+        T hi = A::mx(st.F[0], diag);
+        if (TYPE == NVBIO_HIP_LOCAL) { hi = A::clamp0(hi); rowkey = hi; }
+        st.HG[0] = A::add(hi, k.Go);
+        E = st.HG[0];
+    }
+    // 1 <= j <= BAND-2  (:520-577)
+    #pragma unroll
+    for (int j = 1; j < BAND - 1; ++j)
+    {
+        const uint32_t g = st.tc[BT::RING ? ((R + j) & 15) : j];
+        if (!BT::RING) st.tc[j - 1] = g;                                   // :542
+        // F[BAND-1] is `infimum` at every row (:586), so the cell next to the band edge sees it as F[j+1]
+        const T fnext = (j + 1 == BAND - 1) ? k.inf : st.F[j + 1 < BAND - 1 ? j + 1 : 0];
+        switch (j) {   // the sink key's column is an instruction constant
+            #define NVB_CELL(J) case J: A::template cell<TYPE, J>(st.F[j], fnext, st.HG[j + 1], st.HG[j], E, rowkey, g, q, k.Go, k.Ge, k.sM, sX); break;
+            NVB_CELL(1) NVB_CELL(2) NVB_CELL(3) NVB_CELL(4) NVB_CELL(5) NVB_CELL(6) NVB_CELL(7) NVB_CELL(8) NVB_CELL(9) NVB_CELL(10)
+            NVB_CELL(11) NVB_CELL(12) NVB_CELL(13) NVB_CELL(14) NVB_CELL(15) NVB_CELL(16) NVB_CELL(17) NVB_CELL(18) NVB_CELL(19) NVB_CELL(20)
+            NVB_CELL(21) NVB_CELL(22) NVB_CELL(23) NVB_CELL(24) NVB_CELL(25) NVB_CELL(26) NVB_CELL(27) NVB_CELL(28) NVB_CELL(29)
+            #undef NVB_CELL
+            default: break;
+        }
+    }
+    // the new text symbol enters the band (:580-581); the cached copy is what later rows see
+    {
+        const uint32_t stored = BT::QUIRK ? (g_new & 3u) : g_new;
+        if (BT::RING) st.tc[(R + BAND - 1) & 15] = stored;
+        else          st.tc[BAND - 2] = stored;
+    }
+    // j == BAND-1  (:584-614) -- compares against the raw symbol
+    {
+        const T diag = A::add(st.HG[BAND - 1], g_new == q ? k.sM : sX);
+        T hi = A::mx(E, diag);
+        if (TYPE == NVBIO_HIP_LOCAL) { hi = A::clamp0(hi); rowkey = A::mx(rowkey, A::template key<BAND - 1>(hi)); }
+        st.HG[BAND - 1] = A::add(hi, k.Go);
+    }
+    if (TYPE == NVBIO_HIP_LOCAL)
+    {
+        // BestSink::report uses '<=' (sink_inl.h:57-68): a later cell with an equal score wins.
+        // LOCAL keys are non-negative, so the comparison is the same in either width.
+        const uint32_t rk = A::bits(rowkey), bk = A::bits(st.bestkey);
+        const bool upd = (rk | 31u) >= bk;
+        st.bestkey = upd ? rowkey : st.bestkey;
+        st.besti   = upd ? i : st.besti;
+    }
+}
+
+template <int BAND, int TYPE, typename A, bool QUAL, int R, int END>
+struct RowUnrollN {
+    __device__ __forceinline__ static void run(DPState<BAND, A>& st, const DPConsts<A>& k,
+        const uint32_t i0, const uint32_t M, const uint32_t N, const uint64_t P, const uint32_t T,
+        const uint4 Q, const typename A::T* lut)
+    {
+        const uint32_t i = i0 + R;
+        if (i < M)
+        {
+            const uint32_t q = uint32_t(P >> (4 * R)) & 15u;
+            uint32_t g = (T >> (2 * R)) & 3u;
+            if (i + BAND - 1 >= N) g = 255u;
+            typename A::T sX = k.sX;
+            if (QUAL) {
+                const uint32_t w = (R >> 2) == 0 ? Q.x : (R >> 2) == 1 ? Q.y : (R >> 2) == 2 ? Q.z : Q.w;
+                sX = lut[(w >> (8 * (R & 3))) & 255u];          // mismatch(quality of row i), LDS
+            }
+            dp_row<BAND, TYPE, A, R>(st, k, sX, i, q, g);
+        }
+        RowUnrollN<BAND, TYPE, A, QUAL, R + 1, END>::run(st, k, i0, M, N, P, T, Q, lut);
+    }
+};
+template <int BAND, int TYPE, typename A, bool QUAL, int END> struct RowUnrollN<BAND, TYPE, A, QUAL, END, END> {
+    __device__ __forceinline__ static void run(DPState<BAND, A>&, const DPConsts<A>&, uint32_t, uint32_t, uint32_t, uint64_t, uint32_t,
+                                               uint4, const typename A::T*) {}
+};
+
+// 16 quality bytes starting at byte `off` (unaligned dword loads, clamped to the array)
+__device__ __forceinline__ uint32_t ld_qual_word(const QualArgs& qa, uint64_t off)
+{
+    const uint64_t last = qa.n_quals - 4u;
+    const uint64_t lo = off < last ? off : last;
+    const uint32_t sh = uint32_t(off - lo) * 8u;
+    uint32_t w;
+    __builtin_memcpy(&w, qa.quals + lo, 4);
+    return sh >= 32u ? 0u : (w >> sh);
+}
+__device__ __forceinline__ uint4 fetch_quals16(const QualArgs& qa, uint64_t off)
+{
+    return make_uint4(ld_qual_word(qa, off), ld_qual_word(qa, off + 4), ld_qual_word(qa, off + 8), ld_qual_word(qa, off + 12));
+}
+__device__ __forceinline__ uint4 fetch_quals16(const NoQual&, uint64_t) { return make_uint4(0, 0, 0, 0); }
+
+__device__ __forceinline__ uint64_t fetch_pattern16(const Stream& s, uint64_t sym)
+{
+    return (s.bits == 4) ? fetch16_4bit(s, sym) : expand_2to4(fetch16_2bit(s, sym));
+}
+
+// the sentinel standing in for the reference's infimum (-32768 - max(G_o,G_e), :446-448).
+// 32-bit: the reference's own number (scaled for LOCAL).  16-bit: the lowest value whose
+// G_e step is still representable; the host only selects the 16-bit kernel when every reachable
+// DP value stays far above it, in which case either sentinel loses every max it takes part in.
+template <typename A> struct Sentinel {};
+template <> struct Sentinel<A32> {
+    static __device__ __forceinline__ int32_t get(int32_t Go, int32_t Ge, int32_t tGo, int32_t tGe, int sh)
+    { return (-32768 - max(max(Go, Ge), max(tGo, tGe))) * (1 << sh); }
+};
+template <> struct Sentinel<A16> {   // infimum + G_e == -32768 exactly: the add cannot wrap
+    static __device__ __forceinline__ uint32_t get(int32_t, int32_t Ge, int32_t, int32_t, int sh) { return A16::cnst(-32768 - Ge * (1 << sh)); }
+};
+
+template <typename QA> struct IsQual { static constexpr bool value = false; };
+template <> struct IsQual<QualArgs> { static constexpr bool value = true; };
+
+template <typename A> __device__ __forceinline__ void fill_lut(typename A::T* lut, const QualArgs& qa, int32_t Go, int sh)
+{
+    lut[threadIdx.x] = A::cnst((qa.lut[threadIdx.x] - Go) * (1 << sh));       // pre-biased by -G_o like sX
+    __syncthreads();
+}
+template <typename A> __device__ __forceinline__ void fill_lut(typename A::T*, const NoQual&, int32_t, int) {}
+
+template <int BAND, int TYPE, typename A, typename QA>
+__global__ void __launch_bounds__(256)
+banded_gotoh_score_kernel(const GotohParams p, const QA qa)
+{
+    typedef BandTraits<BAND> BT;
+    typedef typename A::T T;
+    constexpr bool QUAL = IsQual<QA>::value;
+    constexpr int SH = (TYPE == NVBIO_HIP_LOCAL) ? 5 : 0;      // LOCAL carries scores x32 (see header)
+    __shared__ T s_lut[QUAL ? 256 : 1];
+    fill_lut<A>(s_lut, qa, p.gap_open, SH);
+    const uint32_t id = blockIdx.x * 256u + threadIdx.x;
+    if (id >= p.n) return;
+
+    const uint32_t M  = p.pat.length ? p.pat.length[id] : p.pat.fixed_length;
+    if (M < p.len_lo || M > p.len_hi) return;                   // the other arithmetic width owns this job
+    const uint64_t pb = p.pat.begin[id];
+    const uint64_t tb = p.txt.begin[id];
+    const uint32_t N  = p.txt.length ? p.txt.length[id] : p.txt.fixed_length;
+
+    int32_t  score = -(1 << 30);                 // BestSink<int32>() : numbers.h:832-835
+    uint32_t sx = 0xFFFFFFFFu, sy = 0xFFFFFFFFu;
+
+    if (N >= M)                                  // gotoh_banded_inl.h:431-432
+    {
+        DPConsts<A> k;
+        k.Go = A::cnst(p.gap_open * (1 << SH)); k.Ge = A::cnst(p.gap_ext * (1 << SH));
+        k.sM = A::cnst((p.match - p.gap_open) * (1 << SH)); k.sX = A::cnst((p.mismatch - p.gap_open) * (1 << SH));
+        k.inf = Sentinel<A>::get(p.gap_open, p.gap_ext, p.txt_gap_open, p.txt_gap_ext, SH);
+        const T infimum = k.inf;
+
+        DPState<BAND, A> st;
+        // init_row_zero (:46-77), stored as H + G_o
+        st.HG[0] = k.Go;
+        #pragma unroll
+        for (int j = 1; j < BAND; ++j)
+            st.HG[j] = A::cnst(((TYPE == NVBIO_HIP_GLOBAL ? p.txt_gap_open + (j - 1) * p.txt_gap_ext : 0) + p.gap_open) * (1 << SH));
+        #pragma unroll
+        for (int j = 0; j < BAND - 1; ++j) st.F[j] = infimum;
+        st.bestkey = A::cnst(0); st.besti = 0;
+
+        // first band of text (:441-442): symbols 0..BAND-2, no bounds check in the reference either
+        {
+            #pragma unroll
+            for (int b = 0; b < BAND - 1; b += 16)
+            {
+                const uint32_t T0 = fetch16_2bit(p.txt.s, tb + b);
+                #pragma unroll
+                for (int j = b; j < BAND - 1 && j < b + 16; ++j)
+                    st.tc[BT::RING ? (j & 15) : j] = (T0 >> (2 * (j - b))) & 3u;
+            }
+        }
+
+        uint64_t P  = fetch_pattern16(p.pat.s, pb);
+        uint32_t Tx = fetch16_2bit(p.txt.s, tb + BAND - 1);
+        uint4    Q  = fetch_quals16(qa, pb);
+        for (uint32_t i0 = 0; i0 < M; i0 += BT::ROWS)
+        {
+            // prefetch the next block's symbols while this one computes
+            const uint64_t Pn = fetch_pattern16(p.pat.s, pb + i0 + BT::ROWS);
+            const uint32_t Tn = fetch16_2bit(p.txt.s, tb + i0 + BT::ROWS + BAND - 1);
+            const uint4    Qn = fetch_quals16(qa, pb + i0 + BT::ROWS);
+            RowUnrollN<BAND, TYPE, A, QUAL, 0, BT::ROWS>::run(st, k, i0, M, N, P, Tx, Q, s_lut);
+            P = Pn; Tx = Tn; Q = Qn;
+        }
+
+        if (TYPE == NVBIO_HIP_LOCAL)
+        {
+            if (M > 0) {
+                const uint32_t key = uint32_t(A::to_int(st.bestkey));          // >= 0
+                const uint32_t j = key & 31u;
+                score = int32_t(key >> 5);
+                sx = st.besti + j + 1; sy = st.besti + 1;
+            }
+        }
+        else if (TYPE == NVBIO_HIP_GLOBAL)
+        {
+            score = A::to_int(st.HG[BAND - 1]) - p.gap_open;      // :641-642
+            sx = M + BAND - 1; sy = M;
+        }
+        else
+        {
+            // :643-655
+            const uint32_t a = M + BAND - 1u;
+            const uint32_t m = (a < N ? a : N) - (M - 1u);
+            #pragma unroll
+            for (int j = 0; j < BAND; ++j)
+            {
+                const int32_t h = A::to_int(st.HG[j]) - p.gap_open;
+                if ((j == 0 || uint32_t(j) < m) && score <= h) { score = h; sx = M + j; sy = M; }
+            }
+        }
+    }
+    p.out_score[id] = score;
+    reinterpret_cast<uint2*>(p.out_sink)[id] = make_uint2(sx, sy);
+}
+
+template <int BAND, typename A, typename QA>
+hipError_t launch_band(const GotohParams& p, const QA& qa, int type, hipStream_t stream)
+{
+    const dim3 grid((p.n + 255u) / 256u), block(256);
+    switch (type) {
+    case NVBIO_HIP_GLOBAL:      hipLaunchKernelGGL((banded_gotoh_score_kernel<BAND, NVBIO_HIP_GLOBAL, A, QA>),      grid, block, 0, stream, p, qa); break;
+    case NVBIO_HIP_LOCAL:       hipLaunchKernelGGL((banded_gotoh_score_kernel<BAND, NVBIO_HIP_LOCAL, A, QA>),       grid, block, 0, stream, p, qa); break;
+    case NVBIO_HIP_SEMI_GLOBAL: hipLaunchKernelGGL((banded_gotoh_score_kernel<BAND, NVBIO_HIP_SEMI_GLOBAL, A, QA>), grid, block, 0, stream, p, qa); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// One explicit instantiation per (band, scheme kind) lives in its own translation unit
+// (banded_gotoh_inst.hip.inc) so that the 60 kernels build in parallel.
+template <int BAND, typename QA>
+hipError_t launch_band_width(const GotohParams& p, const QA& qa, int type, bool width16, hipStream_t s)
+{
+    return width16 ? launch_band<BAND, A16, QA>(p, qa, type, s) : launch_band<BAND, A32, QA>(p, qa, type, s);
+}
+
+} // namespace nvb

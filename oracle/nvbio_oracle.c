@@ -123,15 +123,41 @@ static inline uint32_t cache_store(uint32_t band, uint32_t g)
     return (band == 3 || band == 5 || band == 7 || band == 15) ? g : (g & 3u);
 }
 
-/* generic substitution callback: SimpleGotohScheme (utils.h:125) */
-static inline int32_t subst_simple(int32_t match, int32_t mismatch, uint8_t r, uint8_t q)
-{
-    return q == r ? match : mismatch;
-}
+
+/* Scoring scheme as the DP sees it (the GotohAligner interface, nvbio/alignment/utils.h:114-134 and
+ * nvBowtie/bowtie2/cuda/scoring.h:283-293): substitution(r,q,qq) = (r == q) ? match : mismatch(qq);
+ * mm_lut == NULL: SimpleGotohScheme (constant mismatch).  mm_lut != NULL: nvBowtie's
+ * SmithWatermanScoringScheme, mismatch(qq) = -m_mmp(qq) tabulated for the 256 quality bytes. */
+typedef struct {
+    int32_t match, mismatch;
+    int32_t pat_gap_open, pat_gap_ext, txt_gap_open, txt_gap_ext;
+    const int32_t* mm_lut;
+    const uint8_t* quals;          /* quality of pattern symbol at stream index pat_begin + i */
+} scheme_t;
+
+static int banded_gotoh_score_x(uint32_t band, int type, const scheme_t* sc,
+    const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, uint64_t pat_begin, uint32_t pattern_len,
+    const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, uint64_t txt_begin, uint32_t text_len,
+    best_sink_t* sink);
 
 static int banded_gotoh_score(
     uint32_t band, int type,
     int32_t s_match, int32_t s_mismatch, int32_t s_gap_open, int32_t s_gap_ext,
+    const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, uint64_t pat_begin, uint32_t pattern_len,
+    const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, uint64_t txt_begin, uint32_t text_len,
+    best_sink_t* sink)
+{
+    scheme_t sc = { s_match, s_mismatch, s_gap_open, s_gap_ext, s_gap_open, s_gap_ext, NULL, NULL };
+    return banded_gotoh_score_x(band, type, &sc, pat_w, pat_bits, pat_be, pat_begin, pattern_len,
+                                txt_w, txt_bits, txt_be, txt_begin, text_len, sink);
+}
+
+static inline int32_t subst(const scheme_t* sc, uint8_t r, uint8_t q, uint8_t qq)
+{
+    return q == r ? sc->match : (sc->mm_lut ? sc->mm_lut[qq] : sc->mismatch);
+}
+
+static int banded_gotoh_score_x(uint32_t band, int type, const scheme_t* sc,
     const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, uint64_t pat_begin, uint32_t pattern_len,
     const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, uint64_t txt_begin, uint32_t text_len,
     best_sink_t* sink)
@@ -145,20 +171,21 @@ static int banded_gotoh_score(
     for (uint32_t j = 0; j + 1 < band; ++j)
         text_cache[j] = cache_store(band, ps_get(txt_w, txt_bits, txt_be, txt_begin + j));
 
-    const int32_t G_o = s_gap_open;                              /* pattern_gap_open      :444 */
-    const int32_t G_e = s_gap_ext;                               /* pattern_gap_extension :445 */
-    const int32_t infimum = -32768 - imax(imax(G_o, G_e), imax(s_gap_open, s_gap_ext)); /* :446-448 */
+    const int32_t G_o = sc->pat_gap_open;                        /* pattern_gap_open      :444 */
+    const int32_t G_e = sc->pat_gap_ext;                         /* pattern_gap_extension :445 */
+    const int32_t infimum = -32768 - imax(imax(G_o, G_e), imax(sc->txt_gap_open, sc->txt_gap_ext)); /* :446-448 */
 
     /* init_row_zero :46-77 */
     H_band[0] = 0;
     for (uint32_t j = 1; j < band; ++j)
-        H_band[j] = (type == ALN_GLOBAL) ? s_gap_open + (int32_t)(j - 1) * s_gap_ext : 0;
+        H_band[j] = (type == ALN_GLOBAL) ? sc->txt_gap_open + (int32_t)(j - 1) * sc->txt_gap_ext : 0;   /* :57 */
     for (uint32_t j = 0; j < band; ++j)
         F_band[j] = infimum;
 
     for (uint32_t i = 0; i < pattern_len; ++i)                  /* :463 */
     {
-        const uint8_t q = (uint8_t)ps_get(pat_w, pat_bits, pat_be, pat_begin + i);
+        const uint8_t q  = (uint8_t)ps_get(pat_w, pat_bits, pat_be, pat_begin + i);
+        const uint8_t qq = sc->quals ? sc->quals[pat_begin + i] : 0;       /* :470 */
 
         /* j == 0 (:483-515) */
         {
@@ -166,7 +193,7 @@ static int banded_gotoh_score(
             const int32_t htop = H_band[1] + G_o;
             F_band[0] = imax(ftop, htop);
             const uint8_t g = (uint8_t)text_cache[0];
-            const int32_t S_ij     = subst_simple(s_match, s_mismatch, g, q);
+            const int32_t S_ij     = subst(sc, g, q, qq);
             const int32_t diagonal = H_band[0] + S_ij;
             const int32_t top      = F_band[0];
             int32_t hi = imax(top, diagonal);
@@ -185,7 +212,7 @@ static int banded_gotoh_score(
             F_band[j] = imax(ftop, htop);
 
             const uint32_t g = text_cache[j]; text_cache[j - 1] = g;      /* :542 */
-            const int32_t S_ij     = subst_simple(s_match, s_mismatch, (uint8_t)g, q);
+            const int32_t S_ij     = subst(sc, (uint8_t)g, q, qq);
             const int32_t diagonal = H_band[j] + S_ij;
             const int32_t top      = F_band[j];
             const int32_t left     = E_j;
@@ -208,7 +235,7 @@ static int banded_gotoh_score(
         /* j == BAND_LEN-1 (:584-614) -- uses the raw g, not the cached copy */
         {
             F_band[band - 1] = infimum;
-            const int32_t S_ij     = subst_simple(s_match, s_mismatch, g, q);
+            const int32_t S_ij     = subst(sc, g, q, qq);
             const int32_t diagonal = H_band[band - 1] + S_ij;
             const int32_t left     = E_j;
             int32_t hi = imax(left, diagonal);
@@ -270,6 +297,39 @@ ORACLE_API void oracle_batch_banded_gotoh_score(
             pat_w, pat_bits, pat_be, pat_begin[i], pat_len[i],
             txt_w, txt_bits, txt_be, txt_begin[i], txt_len[i], &s);
         out_score[i] = s.score; out_sink[2 * i] = s.sink_x; out_sink[2 * i + 1] = s.sink_y;
+    }
+}
+
+/* The same batch with nvBowtie's quality-aware scheme (scoring.h:283-293): scheme6 = {match,
+ * pattern_gap_open, pattern_gap_ext, text_gap_open, text_gap_ext, unused}; mm_lut[256] = mismatch(q);
+ * quals[] indexed like the pattern stream's symbols. */
+ORACLE_API void oracle_batch_banded_gotoh_score_qual(
+    uint32_t band, int type, const int32_t* scheme6, const int32_t* mm_lut, const uint8_t* quals,
+    const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, const uint64_t* pat_begin, const uint32_t* pat_len,
+    const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, const uint64_t* txt_begin, const uint32_t* txt_len,
+    uint32_t n, int32_t* out_score, uint32_t* out_sink, int n_threads)
+{
+    scheme_t sc = { scheme6[0], 0, scheme6[1], scheme6[2], scheme6[3], scheme6[4], mm_lut, quals };
+#if defined(_OPENMP)
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+    #pragma omp parallel for schedule(static)
+#endif
+    for (int64_t i = 0; i < (int64_t)n; ++i)
+    {
+        best_sink_t s; sink_init(&s);
+        banded_gotoh_score_x(band, type, &sc, pat_w, pat_bits, pat_be, pat_begin[i], pat_len[i],
+            txt_w, txt_bits, txt_be, txt_begin[i], txt_len[i], &s);
+        out_score[i] = s.score; out_sink[2 * i] = s.sink_x; out_sink[2 * i + 1] = s.sink_y;
+    }
+}
+
+/* QualCost<int>::operator() (nvBowtie/bowtie2/cuda/scoring.h:86-104): the float -> int truncation
+ * is part of the reference's arithmetic, so the table is produced here exactly as written there. */
+ORACLE_API void oracle_qual_cost_lut(int32_t min_val, int32_t max_val, int32_t* lut256)
+{
+    for (int i = 0; i < 256; ++i) {
+        const float frac = (float)((i < 40 ? i : 40) / 40.0f);
+        lut256[i] = min_val + (int32_t)(frac * (max_val - min_val));
     }
 }
 

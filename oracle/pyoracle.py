@@ -181,6 +181,30 @@ def batch_banded_gotoh_score(band, aln_type, scheme, patterns, texts, n_threads=
     return score, sink
 
 
+def qual_cost_lut(min_val, max_val):
+    """QualCost<int>(min,max)(q) for q in 0..255 (nvBowtie scoring.h:86-104), computed in C floats."""
+    lut = np.zeros(256, dtype=np.int32)
+    lib().oracle_qual_cost_lut(C.c_int32(min_val), C.c_int32(max_val), _p(lut))
+    return lut
+
+
+def batch_banded_gotoh_score_qual(band, aln_type, scheme6, mm_lut, quals, patterns, texts, n_threads=0):
+    """As batch_banded_gotoh_score with nvBowtie's quality-aware scheme: scheme6 = (match,
+    pattern_gap_open, pattern_gap_ext, text_gap_open, text_gap_ext, 0), mm_lut[256] = mismatch(q)."""
+    n = len(patterns)
+    score = np.empty(n, dtype=np.int32)
+    sink = np.empty((n, 2), dtype=np.uint32)
+    sc = np.ascontiguousarray(scheme6, dtype=np.int32)
+    lut = np.ascontiguousarray(mm_lut, dtype=np.int32)
+    q = np.ascontiguousarray(quals, dtype=np.uint8)
+    lib().oracle_batch_banded_gotoh_score_qual(
+        C.c_uint32(band), C.c_int(aln_type), _p(sc), _p(lut), _p(q),
+        _p(patterns.words), C.c_uint32(patterns.bits), C.c_uint32(patterns.big_endian), _p(patterns.begin), _p(patterns.length),
+        _p(texts.words), C.c_uint32(texts.bits), C.c_uint32(texts.big_endian), _p(texts.begin), _p(texts.length),
+        C.c_uint32(n), _p(score), _p(sink), C.c_int(n_threads))
+    return score, sink
+
+
 def ref_banded_sw(band, aln_type, scheme, pattern, text, pos=0):
     p = np.ascontiguousarray(pattern, dtype=np.uint8)
     t = np.ascontiguousarray(text, dtype=np.uint8)

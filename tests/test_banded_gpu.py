@@ -187,3 +187,38 @@ def test_full_size_properties_10m(cuda):
     hp, ht = O.StringSet.from_device(pp), O.StringSet.from_device(tp)
     es, ek = O.batch_banded_gotoh_score(15, nvb.LOCAL, (2, -1, -2, -1), hp, ht)
     assert (s3.cpu().numpy() == es).all() and (k3.cpu().numpy().view(np.uint32) == ek).all()
+
+
+@pytest.mark.parametrize("band", [7, 15, 31])
+@pytest.mark.parametrize("ty", [nvb.LOCAL, nvb.SEMI_GLOBAL, nvb.GLOBAL])
+def test_quality_aware_scheme(cuda, band, ty):
+    """nvBowtie's SmithWatermanScoringScheme (quality-dependent mismatch penalty, separate read /
+    reference gap costs) through nvbio_hip_banded_gotoh_score_qual, vs the oracle."""
+    rng = np.random.default_rng(500 + band + ty)
+    pats, txts = random_pairs(rng, 2000, band)
+    hp, ht = O.StringSet.from_lists(pats, 4, True), O.StringSet.from_lists(txts, 2, True)
+    total = int(hp.begin[-1] + hp.length[-1])
+    quals = rng.integers(0, 60, total + 3, dtype=np.uint8)          # phred bytes, some above the 40 cap
+    quals[::97] = 255
+    for scheme in (nvb.SmithWatermanScoringScheme(), nvb.SmithWatermanScoringScheme.local(),
+                   nvb.SmithWatermanScoringScheme(match=1, mmp_min=1, mmp_max=9, read_gap_const=4, read_gap_coeff=2, ref_gap_const=7, ref_gap_coeff=1),
+                   nvb.SmithWatermanScoringScheme(match=2, mm_cost="constant")):
+        st = scheme.struct()
+        lut = np.array([st.mismatch[q] for q in range(256)], dtype=np.int32)
+        if scheme.mm_cost == "qual":      # the host layer's table == the reference's float arithmetic in C
+            assert (-lut == O.qual_cost_lut(scheme.m_mmp_min, scheme.m_mmp_max)).all()
+        s6 = (st.match, st.pattern_gap_open, st.pattern_gap_ext, st.text_gap_open, st.text_gap_ext, 0)
+        es, ek = O.batch_banded_gotoh_score_qual(band, ty, s6, lut, quals, hp, ht)
+        p = nvb.PackedStringSet.from_host(hp.words, 4, True, hp.begin, hp.length, device=cuda)
+        t = nvb.PackedStringSet.from_host(ht.words, 2, True, ht.begin, ht.length, device=cuda)
+        dq = torch.from_numpy(quals).to(cuda)
+        for force32 in ("0", "1"):
+            os.environ["NVBIO_HIP_FORCE_32BIT"] = force32
+            try:
+                gs, gk = nvb.batch_banded_alignment_score(band, nvb.make_gotoh_aligner(ty, scheme), p, t, quals=dq)
+                torch.cuda.synchronize()
+            finally:
+                os.environ["NVBIO_HIP_FORCE_32BIT"] = "0"
+            gs, gk = gs.cpu().numpy(), gk.cpu().numpy().view(np.uint32)
+            bad = np.nonzero((es != gs) | (ek != gk).any(1))[0]
+            assert bad.size == 0, (band, ty, force32, bad[:5], es[bad[:3]], gs[bad[:3]])
