@@ -153,6 +153,30 @@ int nvbio_hip_fm_match(const nvbio_hip_fmindex* fmi, const nvbio_hip_string_set*
  * 4^k codes; 1 <= k <= 14; out_ktab holds 2*4^k words (k=12: 128 MiB). */
 int nvbio_hip_fm_build_ktab(const nvbio_hip_fmindex* fmi, uint32_t k, uint32_t* out_ktab, void* stream);
 
+/* nvBowtie's seeding parameters as map_queues_kernel reads them (nvBowtie/bowtie2/cuda/params.h:100-120). */
+typedef struct nvbio_hip_map_params {
+    uint32_t seed_len;       /* params.seed_len (22 end-to-end / 20 local)                       */
+    uint32_t min_read_len;   /* shorter reads get no hits                                        */
+    uint32_t max_hits;       /* per-read cap: beyond it the largest SA ranges are dropped (100)  */
+    uint32_t max_reseed;     /* retry_stride = seed_freq / (max_reseed + 1)                      */
+    uint32_t retry;          /* re-seeding round: seeds start at retry * retry_stride            */
+    uint32_t rep_seeds;      /* reseed[] = no hit, or mean range size >= rep_seeds               */
+    uint32_t fw, rc;         /* strands to map                                                   */
+} nvbio_hip_map_params;
+
+/* Replaces nvBowtie's exact seed mapping stage, map_queues_kernel<EXACT_MAPPING>
+ * (nvBowtie/bowtie2/cuda/mapping_inl.h:511-592 with seed_mapper<EXACT_MAPPING>, :229-312, and
+ * match_range, :83-97): for queue entry id (read in_queue[id], or id if in_queue is NULL) every seed
+ * window of the read is searched on both strands and each non-empty SA range is stored as a SeedHit
+ * word pair {range_begin; range_delta:20, pos_in_read:10, rc:1, index_dir:1} (seed_hit.h:54-223,
+ * exclusive range) at out_hits[read * hits_stride + k], k < out_counts[read].  seed_freq_by_len[L] is
+ * the host-tabulated params.seed_freq(L) (SimpleFunc, func.h:39-70) for every read length L that
+ * occurs.  out_reseed (nullable) receives the reference's re-seeding predicate per queue entry. */
+int nvbio_hip_map_exact(const nvbio_hip_fmindex* fmi, const nvbio_hip_string_set* reads,
+                        const uint32_t* in_queue, uint32_t n, const nvbio_hip_map_params* params /* host */,
+                        const uint32_t* seed_freq_by_len /* device */,
+                        uint64_t* out_hits, uint32_t hits_stride, uint32_t* out_counts, uint8_t* out_reseed, void* stream);
+
 /* Replaces nvbio::locate(fmi, i) (fmindex_inl.h:466-501) and nvBowtie's
  * locate_kernel (nvBowtie/bowtie2/cuda/locate_inl.h:122-148). */
 int nvbio_hip_fm_locate(const nvbio_hip_fmindex* fmi, const uint32_t* sa_rows,

@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libnvbio_hip.so")
 SYMBOLS = [
     "nvbio_hip_banded_gotoh_score", "nvbio_hip_banded_gotoh_score_qual",
     "nvbio_hip_fm_rank", "nvbio_hip_fm_rank4", "nvbio_hip_fm_rank_range",
-    "nvbio_hip_fm_match", "nvbio_hip_fm_build_ktab", "nvbio_hip_fm_locate",
+    "nvbio_hip_fm_match", "nvbio_hip_fm_build_ktab", "nvbio_hip_map_exact", "nvbio_hip_fm_locate",
     "nvbio_hip_fm_locate_ssa_iterator", "nvbio_hip_fm_lookup_ssa_iterator",
     "nvbio_hip_fm_filter_temp_bytes", "nvbio_hip_fm_filter_rank", "nvbio_hip_fm_filter_locate",
     "nvbio_hip_build_bwt_occ_temp_bytes", "nvbio_hip_build_bwt_occ",
@@ -31,6 +31,10 @@ class GotohSchemeStruct(C.Structure):    # nvbio_hip_gotoh_scheme
 class GotohQualSchemeStruct(C.Structure):  # nvbio_hip_gotoh_qual_scheme
     _fields_ = [("match", C.c_int32), ("pattern_gap_open", C.c_int32), ("pattern_gap_ext", C.c_int32),
                 ("text_gap_open", C.c_int32), ("text_gap_ext", C.c_int32), ("mismatch", C.c_int32 * 256)]
+
+
+class MapParamsStruct(C.Structure):       # nvbio_hip_map_params
+    _fields_ = [(k, C.c_uint32) for k in ("seed_len", "min_read_len", "max_hits", "max_reseed", "retry", "rep_seeds", "fw", "rc")]
 
 
 class FMIndexStruct(C.Structure):        # nvbio_hip_fmindex
@@ -61,6 +65,7 @@ def lib():
         L.nvbio_hip_fm_rank_range.argtypes = [P(FMIndexStruct), vp, vp, u32, vp, vp]
         L.nvbio_hip_fm_match.argtypes = [P(FMIndexStruct), P(StringSetStruct), u32, vp, vp]
         L.nvbio_hip_fm_build_ktab.argtypes = [P(FMIndexStruct), u32, vp, vp]
+        L.nvbio_hip_map_exact.argtypes = [P(FMIndexStruct), P(StringSetStruct), vp, u32, P(MapParamsStruct), vp, vp, u32, vp, vp, vp]
         L.nvbio_hip_fm_locate.argtypes = [P(FMIndexStruct), vp, u32, vp, vp]
         L.nvbio_hip_fm_locate_ssa_iterator.argtypes = [P(FMIndexStruct), vp, u32, vp, vp]
         L.nvbio_hip_fm_lookup_ssa_iterator.argtypes = [P(FMIndexStruct), vp, u32, vp, vp]

@@ -733,6 +733,96 @@ ORACLE_API void oracle_filter_locate(const oracle_fmi_t* f,
     }
 }
 
+/* ------------------------------------------------------------------------ */
+/* nvBowtie exact seed mapping: what a "seed hit set" is    */
+/*   match_range                nvBowtie/bowtie2/cuda/mapping_inl.h:83-97    */
+/*   seed_mapper<EXACT_MAPPING> mapping_inl.h:229-312 (USE_REVERSE_INDEX 0)  */
+/*   map_queues_kernel          mapping_inl.h:511-592                        */
+/*   SeedHit                    seed_hit.h:54-223                            */
+/*   complement_functor<4>      nvbio/basic/numbers.h:1338-1352              */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+    uint32_t seed_len, min_read_len, max_hits, max_reseed, retry, rep_seeds, fw, rc;
+} oracle_map_params_t;
+
+/* SeedHit: {uint32 range_begin; uint32 range_delta:20, pos:10, rc:1, indexdir:1}, exclusive range */
+static inline uint64_t seed_hit_pack(uint32_t begin, uint32_t delta, uint32_t pos, uint32_t rc, uint32_t indexdir)
+{
+    const uint32_t w1 = (delta & 0xFFFFFu) | ((pos & 0x3FFu) << 20) | ((rc & 1u) << 30) | ((indexdir & 1u) << 31);
+    return ((uint64_t)w1 << 32) | begin;
+}
+
+/* match_range over a transformed seed: symbol t of the scan = comp(seed[reverse ? len-1-t : t]) */
+static void match_range_x(const oracle_fmi_t* f, const uint32_t* w, uint32_t bits, uint32_t be, uint64_t begin, uint32_t len,
+                          int reverse, int complement, uint32_t* ox, uint32_t* oy)
+{
+    uint32_t rx = 0, ry = f->length;
+    for (uint32_t t = 0; t < len && rx <= ry; ++t) {
+        uint32_t c = ps_get(w, bits, be, begin + (reverse ? len - 1 - t : t));
+        if (complement) c = (c >= 4) ? c : 3u - c;
+        if (c > 3) { rx = 1; ry = 0; break; }
+        uint32_t a, b;
+        fm_rank2(f, rx - 1, ry, c, &a, &b);
+        rx = f->L2[c] + a + 1;
+        ry = f->L2[c] + b;
+    }
+    *ox = rx; *oy = ry;
+}
+
+/* one read -> its seed hits, in generation order; when a hit arrives with max_hits already held,
+ * one hit of largest range size is dropped first (priority_deque::pop_bottom with hit_compare).
+ * Returns the number of hits kept; *reseed as map_queues_kernel computes it. */
+ORACLE_API void oracle_map_exact(const oracle_fmi_t* f,
+    const uint32_t* w, uint32_t bits, uint32_t be, const uint64_t* read_begin, const uint32_t* read_len,
+    const uint32_t* in_queue /* nullable */, uint32_t n, const oracle_map_params_t* p, const uint32_t* seed_freq_by_len,
+    uint64_t* out_hits, uint32_t hits_stride, uint32_t* out_counts, uint8_t* out_reseed /* nullable */)
+{
+    for (uint32_t id = 0; id < n; ++id)
+    {
+        const uint32_t read_id = in_queue ? in_queue[id] : id;
+        const uint64_t rx = read_begin[read_id];
+        const uint32_t rlen = read_len[read_id];
+        uint64_t* hits = out_hits + (uint64_t)read_id * hits_stride;
+        uint32_t nh = 0, range_sum = 0, range_count = 0;
+        if (rlen < p->min_read_len) { out_counts[read_id] = 0; continue; }   /* reseed[id] is left untouched, as in :542-546 */
+        const uint32_t seed_len = p->seed_len < rlen ? p->seed_len : rlen;
+        const uint32_t seed_freq = seed_freq_by_len[rlen];
+        const uint32_t retry_stride = seed_freq / (p->max_reseed + 1);
+        for (uint64_t pos = rx + (uint64_t)p->retry * retry_stride; pos + seed_len <= rx + rlen; pos += seed_freq)
+        {
+            int has_n = 0;
+            for (uint32_t i = 0; i < seed_len; ++i) has_n |= (ps_get(w, bits, be, pos + i) == 4u);   /* count_occurrences(...,4u,1u) :258 */
+            if (has_n) continue;
+            for (int strand = 0; strand < 2; ++strand)
+            {
+                if (strand == 0 ? !p->fw : !p->rc) continue;
+                uint32_t x, y;
+                match_range_x(f, w, bits, be, pos, seed_len, strand, strand, &x, &y);
+                if (x > y) continue;
+                const uint32_t pir = strand == 0 ? (uint32_t)(rx + rlen - pos - seed_len) : (uint32_t)(pos - rx);
+                if (nh == p->max_hits || nh == hits_stride) {            /* pop_bottom: drop a largest range */
+                    uint32_t worst = 0;
+                    for (uint32_t h = 1; h < nh; ++h)
+                        if (((hits[h] >> 32) & 0xFFFFFu) > ((hits[worst] >> 32) & 0xFFFFFu)) worst = h;
+                    hits[worst] = hits[--nh];
+                }
+                hits[nh++] = seed_hit_pack(x, y + 1u - x, pir, strand, 0);
+                range_sum += y - x + 1u; range_count++;
+            }
+        }
+        out_counts[read_id] = nh;
+        if (out_reseed) out_reseed[id] = (range_count == 0 || range_sum >= p->rep_seeds * range_count);
+    }
+}
+
+/* SimpleFunc (nvBowtie/bowtie2/cuda/func.h:39-70) tabulated for x in [0,n): type 0 linear, 1 log, 2 sqrt */
+#include <math.h>
+ORACLE_API void oracle_simple_func_table(int type, float k, float m, uint32_t n, uint32_t* out)
+{
+    for (uint32_t x = 0; x < n; ++x)
+        out[x] = (uint32_t)(int32_t)(k + m * (type == 1 ? logf((float)x) : type == 2 ? sqrtf((float)x) : (float)x));
+}
+
 ORACLE_API int oracle_num_threads(void)
 {
 #if defined(_OPENMP)

@@ -24,7 +24,7 @@ def build(native=False, out=None):
     cpu_baseline timing on the box it is timed on) and writes next to `out`."""
     out = out or _LIB
     flags = list(_CFLAGS) + (["-march=native"] if native else ["-march=x86-64-v2"])
-    subprocess.check_call(["gcc"] + flags + ["-shared", "-o", out, _SRC])
+    subprocess.check_call(["gcc"] + flags + ["-shared", "-o", out, _SRC, "-lm"])
     return out
 
 
@@ -340,6 +340,32 @@ class FMIndex:
         lib().oracle_filter_locate(self._ref(), _p(_u32(ranges)), _p(_u64(slots)), C.c_uint32(len(slots)),
                                    C.c_uint64(begin), C.c_uint64(end), _p(hits))
         return hits
+
+
+class MapParams(C.Structure):
+    _fields_ = [(k, C.c_uint32) for k in ("seed_len", "min_read_len", "max_hits", "max_reseed", "retry", "rep_seeds", "fw", "rc")]
+
+
+def simple_func_table(ftype, k, m, n):
+    """nvBowtie's SimpleFunc(type,k,m)(x) for x in [0,n) (func.h:39-70), in C floats."""
+    out = np.zeros(n, dtype=np.uint32)
+    lib().oracle_simple_func_table(C.c_int(ftype), C.c_float(k), C.c_float(m), C.c_uint32(n), _p(out))
+    return out
+
+
+def map_exact(fmi, reads, params, seed_freq_by_len, hits_stride, in_queue=None):
+    """nvBowtie exact seed mapping of a read StringSet -> (hits uint64[n_reads,stride], counts, reseed)."""
+    n_reads = len(reads)
+    q = _u32(in_queue) if in_queue is not None else None
+    n = q.size if q is not None else n_reads
+    hits = np.zeros((n_reads, hits_stride), dtype=np.uint64)
+    counts = np.zeros(n_reads, dtype=np.uint32)
+    reseed = np.zeros(n, dtype=np.uint8)
+    sf = _u32(seed_freq_by_len)
+    mp = MapParams(**params)
+    lib().oracle_map_exact(fmi._ref(), _p(reads.words), C.c_uint32(reads.bits), C.c_uint32(reads.big_endian), _p(reads.begin), _p(reads.length),
+                           _p(q), C.c_uint32(n), C.byref(mp), _p(sf), _p(hits), C.c_uint32(hits_stride), _p(counts), _p(reseed))
+    return hits, counts, reseed
 
 
 def num_threads():

@@ -1,0 +1,69 @@
+"""nvBowtie exact seed mapping (seed hit sets) through the C-ABI vs the oracle's restatement of
+map_queues_kernel<EXACT_MAPPING>.  Hit sets are compared per read after sorting, as the reference's
+own order-independent checksum does (nvBowtie/bowtie2/cuda/checksums.h)."""
+import numpy as np
+import pytest
+import torch
+
+import nvbio_amd as nvb
+from nvbio_amd import mapping as M
+from oracle import pyoracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def make_reads(rng, text, n, ragged):
+    reads = []
+    for i in range(n):
+        L = int(rng.integers(8, 160)) if ragged else 100
+        p = int(rng.integers(0, text.size - L))
+        r = text[p:p + L].copy()
+        if i % 2 == 0:                                   # reverse-complement strand reads
+            r = (3 - r)[::-1].copy()
+        mut = rng.random(L) < 0.03
+        r[mut] = rng.integers(0, 4, int(mut.sum()), dtype=np.uint8)
+        if i % 17 == 0:
+            r[int(rng.integers(0, L))] = 4               # an N
+        reads.append(r[::-1].copy())                     # nvBowtie stores reads reversed (io::REVERSE)
+    return reads
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_seed_hit_sets(cuda, ragged):
+    rng = np.random.default_rng(11 + ragged)
+    text = rng.integers(0, 4, 1 << 18, dtype=np.uint8)
+    text[5000:5600] = np.tile(np.array([0, 1], dtype=np.uint8), 300)      # a repeat: wide SA ranges
+    host = O.FMIndex(text)
+    fmi = nvb.FMIndexDevice.from_host(host, cuda)
+    reads = make_reads(rng, text, 4000, ragged)
+    hr = O.StringSet.from_lists(reads, 4, True)
+    dr = nvb.PackedStringSet.from_host(hr.words, 4, True, hr.begin, hr.length, device=cuda)
+    params = nvb.MappingParams()
+    max_len = 160
+    sf = O.simple_func_table(2, 1.0, 1.15, max_len + 1)
+    assert (params.seed_freq_table(max_len, "cpu").numpy().view(np.uint32)[1:] == sf[1:]).all()   # host table == C float arithmetic
+    for retry, fw, rc, max_hits, queue in ((0, 1, 1, 100, None), (1, 1, 1, 100, None), (2, 1, 0, 100, None), (0, 0, 1, 100, None),
+                                           (0, 1, 1, 3, None), (0, 1, 1, 100, rng.permutation(4000)[:1500].astype(np.uint32))):
+        params.max_hits = max_hits
+        stride = 40
+        pd = dict(seed_len=params.seed_len, min_read_len=params.min_read_len, max_hits=max_hits, max_reseed=params.max_reseed,
+                  retry=retry, rep_seeds=params.rep_seeds, fw=fw, rc=rc)
+        eh, ec, er = O.map_exact(host, hr, pd, sf, stride, in_queue=queue)
+        dq = torch.from_numpy(queue.view(np.int32)).to(cuda) if queue is not None else None
+        gh, gc, gr = nvb.map_exact(fmi, dr, params, max_len, retry=retry, fw=bool(fw), rc=bool(rc), in_queue=dq, hits_stride=stride)
+        torch.cuda.synchronize()
+        gh, gc, gr = gh.cpu().numpy().view(np.uint64), gc.cpu().numpy().view(np.uint32), gr.cpu().numpy()
+        ids = queue if queue is not None else np.arange(4000)
+        assert (gc[ids] == ec[ids]).all()
+        assert (gr == er).all()
+        assert gc.max() > 4 or max_hits == 3
+        for r in ids:
+            a, b = np.sort(gh[r, :gc[r]]), np.sort(eh[r, :ec[r]])
+            if max_hits == 3 and ec[r] == 3:
+                # at the cap the kept sizes are determined (ties among equal largest ranges are not)
+                assert (np.sort((a >> 32) & 0xFFFFF) == np.sort((b >> 32) & 0xFFFFF)).all()
+            else:
+                assert (a == b).all(), (r, a, b)
+    # the hits decode to seeds that really occur: fw hit rows locate to text positions holding the seed
+    u = nvb.unpack_seed_hits(torch.from_numpy(gh.view(np.int64)))
+    assert int(u["index_dir"].max()) == 0
