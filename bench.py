@@ -64,9 +64,11 @@ def parse():
     ap.add_argument("--genome", type=float, default=3.0e9, help="synthetic genome length of the FM-index legs (a true index is built on the device)")
     ap.add_argument("--rank-queries", type=int, default=1 << 28)
     ap.add_argument("--no-rank", action="store_true")
-    ap.add_argument("--only", choices=["dp", "rank", "seed"], default=None, help="profiling aid: run just one leg, print its object")
+    ap.add_argument("--only", choices=["dp", "rank", "seed", "e2e"], default=None, help="profiling aid: run just one leg, print its object")
     ap.add_argument("--seeds", type=int, default=50_000_000)
     ap.add_argument("--no-seed", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--e2e-reads", type=int, default=10_000_000, help="reads per batch of the end-to-end seed+locate+extend leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
     return ap.parse_args()
@@ -91,13 +93,14 @@ def main():
             dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
-    if a.only in ("rank", "seed"):
-        a.no_seed = a.only == "rank"
-        a.no_rank = a.only == "seed"
+    if a.only in ("rank", "seed", "e2e"):
+        a.no_seed = a.only != "seed"
+        a.no_rank = a.only != "rank"
+        a.no_e2e = a.only != "e2e"
         print(json.dumps(fm_legs(a, dev)))
         return
     if a.only == "dp":
-        a.no_rank = a.no_cpu = a.no_seed = True
+        a.no_rank = a.no_cpu = a.no_seed = a.no_e2e = True
 
     # ---------------------------------------------------------------- inputs (resident before timing)
     n = a.reads
@@ -196,7 +199,7 @@ def main():
         }
 
     # ---------------------------------------------------------------- FM-index rank leg (rank 0, N == 1 only)
-    if rank == 0 and world == 1 and not (a.no_rank and a.no_seed):
+    if rank == 0 and world == 1 and not (a.no_rank and a.no_seed and a.no_e2e):
         del patterns, texts, outs
         torch.cuda.empty_cache()
         out.update(fm_legs(a, dev))
@@ -225,7 +228,61 @@ def fm_legs(a, dev):
         out["rank_roofline"] = rank_leg(a, dev, fmi)
     if not a.no_seed:
         out["seed_leg"] = seed_leg(a, dev, fmi, text, build_s)
+    if not a.no_e2e:
+        out["e2e_leg"] = e2e_leg(a, dev, fmi, text)
     return out
+
+
+def e2e_leg(a, dev, fmi, text):
+    """BASELINE config 4's shape: single-end 100-bp reads against the 3 Gbp index through the composed
+    driver nvbio_amd.pipeline (map_exact -> locate -> banded extend, band 15, -> best per read).  The
+    select / reduce glue between the kernels is torch tensor code, not nvBowtie's policy; a sample is
+    checked exactly against the same glue over the oracle."""
+    import numpy as np
+    from nvbio_amd import pipeline as P
+    from oracle import pyoracle as O
+    ng, n = fmi.length, a.e2e_reads
+    genome_words = W._pack_chunked(text, 2, True)
+    sym, pos, _ = P.make_reads(text, n, READ_LEN, seed=0x5EED0004)
+    mp = nvb.MappingParams()
+    packed = P.pack_read_streams(sym)                  # inputs resident in HBM before the timed region
+    res = {}
+    for name, idx in (("reference_layout", fmi), ("hbm_rich_ssa1", None)):
+        if idx is None:
+            idx = fmi.with_dense_ssa(1)
+        be = P.HipBackend(idx, None, mp, READ_LEN)
+        P.seed_and_extend(be, sym, genome_words, ng, packed=packed)        # warm-up
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        score, bpos, n_jobs = P.seed_and_extend(be, sym, genome_words, ng, packed=packed)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        found = bpos >= 0
+        res[name] = {"ms_per_batch": ms, "Mreads_per_s": n / (ms * 1e-3) / 1e6, "extension_jobs": n_jobs,
+                     "reads_with_hit": float(found.float().mean().item()),
+                     "hit_at_true_position": float(((bpos == torch.clamp(pos - BAND // 2, min=0)) & found).float().mean().item())}
+        if name == "reference_layout":
+            ref_score, ref_pos = score, bpos
+        else:
+            res[name]["identical_to_reference_layout"] = bool(torch.equal(score, ref_score) and torch.equal(bpos, ref_pos))
+        del idx, be
+    # exact check of a sample against the same glue over the oracle
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_pipeline_gpu import OracleBackend
+    m = 20_000
+    host = O.FMIndex(parts=(fmi.length, fmi.primary, np.array(fmi.L2, dtype=np.uint32),
+                            fmi.bwt_occ.cpu().numpy().view(np.uint32), fmi.ssa.cpu().numpy().view(np.uint32), fmi.sa_int))
+    es, ep, _ = P.seed_and_extend(OracleBackend(host, mp, READ_LEN), sym[:m].cpu(), genome_words.cpu(), ng)
+    gs, gp, _ = P.seed_and_extend(P.HipBackend(fmi, None, mp, READ_LEN), sym[:m].contiguous(), genome_words, ng)
+    ok = bool(torch.equal(gs.cpu(), es) and torch.equal(gp.cpu(), ep))
+    if not ok:
+        raise SystemExit("parity gate failed: end-to-end driver differs from the oracle")
+    res["parity"] = {"checked_reads": m, "bit_exact": ok}
+    res["reads"] = n
+    res["genome_symbols"] = ng
+    return res
 
 
 def rank_leg(a, dev, fmi):

@@ -1,0 +1,99 @@
+"""A minimal single-end seed-and-extend driver over the hot-path entry points: map_exact -> (take up
+to `rows_per_hit` SA rows of every seed hit) -> locate -> banded Gotoh extension of the read against
+the genome window around each located seed -> best score per read.
+
+This is glue (torch tensor ops), not part of the hot path and not nvBowtie's selection / reduction
+policy (out of scope); it exists to exercise and time the composed kernels on
+BASELINE config 4's shape.  `backend` supplies the three hot-path calls so that the tests can run
+the identical glue over the CPU oracle."""
+import torch
+
+from .strings import PackedStringSet
+from .workloads import _pack_chunked
+
+
+class HipBackend:
+    """The product path: every call goes to libnvbio_hip.so."""
+
+    def __init__(self, fmi, genome, map_params, max_read_len):
+        from . import mapping, fmindex, alignment
+        self._m, self._f, self._a = mapping, fmindex, alignment
+        self.fmi, self.genome, self.map_params, self.max_read_len = fmi, genome, map_params, max_read_len
+
+    def map_exact(self, reads_rev, hits_stride):
+        return self._m.map_exact(self.fmi, reads_rev, self.map_params, self.max_read_len, hits_stride=hits_stride)[:2]
+
+    def locate(self, rows):
+        return self._f.locate(self.fmi, rows)
+
+    def score(self, band, aligner, patterns, texts):
+        return self._a.batch_banded_alignment_score(band, aligner, patterns, texts)
+
+
+def make_reads(text, n, read_len=100, seed=0x5EED0004, sub_rate=0.04):
+    """Single-end reads sampled from the genome, half of them from the reverse strand, with
+    substitutions.  Returns (fw symbols [n,L] uint8, true position int64[n], is_rc bool[n])."""
+    dev = text.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    pos = torch.randint(0, text.numel() - read_len, (n,), generator=g, device=dev)
+    sym = text[pos.unsqueeze(1) + torch.arange(read_len, device=dev).unsqueeze(0)]
+    sub = torch.rand((n, read_len), generator=g, device=dev) < sub_rate
+    delta = torch.randint(1, 4, (n, read_len), dtype=torch.uint8, generator=g, device=dev)
+    sym = torch.where(sub, (sym + delta) & 3, sym)
+    is_rc = torch.rand(n, generator=g, device=dev) < 0.5
+    rc_sym = (3 - sym).flip(1)
+    sym = torch.where(is_rc.unsqueeze(1), rc_sym, sym)
+    return sym, pos, is_rc
+
+
+def pack_read_streams(sym):
+    """The three orientations the stages need, all 4-bit big-endian (nvBowtie's read format):
+    reversed (what the mapping stage scans, io::REVERSE), forward and reverse-complement (patterns of
+    the extension stage for STANDARD / COMPLEMENT hits)."""
+    n, L = sym.shape
+    dev = sym.device
+    idx = torch.arange(n, dtype=torch.int64, device=dev) * L
+    rev = PackedStringSet(_pack_chunked(sym.flip(1).reshape(-1), 4, True), 4, True, idx, None, L)
+    both = torch.cat([sym.reshape(-1), (3 - sym).flip(1).reshape(-1)])
+    ext_words = _pack_chunked(both, 4, True)
+    return rev, ext_words
+
+
+def seed_and_extend(backend, sym, genome_words, genome_len, band=15, rows_per_hit=2, hits_stride=16, aligner=None, packed=None):
+    """Returns (best_score int32[n], best_pos int64[n] (window begin of the best job, -1 if none),
+    n_jobs).  `packed` = pack_read_streams(sym) when the caller keeps the packed reads resident."""
+    from .alignment import make_gotoh_aligner, SimpleGotohScheme, SEMI_GLOBAL
+    n, L = sym.shape
+    dev = sym.device
+    reads_rev, ext_words = packed if packed is not None else pack_read_streams(sym)
+    hits, counts = backend.map_exact(reads_rev, hits_stride)
+    # flatten the hits, expand each into up to rows_per_hit SA rows
+    k = torch.arange(hits.shape[1], device=dev).unsqueeze(0)
+    valid = k < (counts.to(torch.int64) & 0xFFFFFFFF).unsqueeze(1)
+    read_id = torch.arange(n, device=dev).unsqueeze(1).expand_as(hits)[valid]
+    w = hits[valid]
+    lo, hi = w & 0xFFFFFFFF, (w >> 32) & 0xFFFFFFFF
+    delta, pir, rc = hi & 0xFFFFF, (hi >> 20) & 0x3FF, (hi >> 30) & 1
+    take = torch.clamp(delta, max=rows_per_hit)
+    rep = torch.repeat_interleave(torch.arange(w.numel(), device=dev), take)
+    first = torch.cumsum(take, 0) - take
+    row = lo[rep] + (torch.arange(rep.numel(), device=dev) - first[rep])
+    gpos = backend.locate(row.to(torch.int32)).to(torch.int64) & 0xFFFFFFFF
+    # window of the read around the located seed (the arithmetic of score_best_inl.h:95-126)
+    jr, jrc = read_id[rep], rc[rep]
+    wbeg = torch.clamp(gpos - pir[rep] - band // 2, min=0)
+    wend = torch.clamp(wbeg + L + band, max=genome_len)
+    patterns = PackedStringSet(ext_words, 4, True, (jr * L + jrc * (n * L)).contiguous(), None, L)
+    texts = PackedStringSet(genome_words, 2, True, wbeg.contiguous(), (wend - wbeg).to(torch.int32).contiguous(), 0)
+    if aligner is None:
+        aligner = make_gotoh_aligner(SEMI_GLOBAL, SimpleGotohScheme(0, -6, -8, -3))
+    score, _ = backend.score(band, aligner, patterns, texts)
+    # best job per read; ties broken toward the smallest window begin so that the result is order-free
+    key = (score.to(torch.int64) + (1 << 31)) * (1 << 32) + ((1 << 32) - 1 - wbeg)
+    best = torch.full((n,), -1, dtype=torch.int64, device=dev)
+    best = best.scatter_reduce(0, jr, key, reduce="amax", include_self=True)
+    has = best >= 0
+    best_score = torch.where(has, (best >> 32) - (1 << 31), torch.full_like(best, -(1 << 30))).to(torch.int32)
+    best_pos = torch.where(has, (1 << 32) - 1 - (best & 0xFFFFFFFF), torch.full_like(best, -1))
+    return best_score, best_pos, int(rep.numel())
