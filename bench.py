@@ -247,9 +247,9 @@ def e2e_leg(a, dev, fmi, text):
     mp = nvb.MappingParams()
     packed = P.pack_read_streams(sym)                  # inputs resident in HBM before the timed region
     res = {}
-    for name, idx in (("reference_layout", fmi), ("hbm_rich_ssa1", None)):
+    for name, idx in (("reference_layout", fmi), ("hbm_rich_ktab12_ssa1", None)):
         if idx is None:
-            idx = fmi.with_dense_ssa(1)
+            idx = fmi.with_ktab(12).with_dense_ssa(1)
         be = P.HipBackend(idx, None, mp, READ_LEN)
         P.seed_and_extend(be, sym, genome_words, ng, packed=packed)        # warm-up
         torch.cuda.synchronize()

@@ -30,7 +30,27 @@ struct MapParams {
 __device__ __forceinline__ uint2 match_range_x(const Fmi& f, const Stream& s, uint64_t begin, uint32_t len, bool reverse, bool complement, bool& has_n)
 {
     uint32_t x = 0, y = f.length;
-    for (uint32_t t0 = 0; t0 < len && x <= y; t0 += 16u)
+    uint32_t t_start = 0;
+    const uint32_t k = f.ktab_k;
+    if (k != 0u && len >= k)
+    {
+        // the first k scan symbols through the k-mer table (entry = match of that k-mer; code has the
+        // symbol consumed LAST at bits [0,2) -- see nvbio_hip_fm_build_ktab)
+        uint64_t grp = (s.bits == 2) ? expand_2to4(fetch16_2bit(s, reverse ? begin + len - k : begin))
+                                     : fetch16_4bit(s, reverse ? begin + len - k : begin);
+        grp &= (k == 16u) ? ~0ull : ((1ull << (4u * k)) - 1ull);
+        if ((grp & 0xCCCCCCCCCCCCCCCCull) != 0ull) { has_n = true; return make_uint2(1u, 0u); }
+        const uint32_t packed = nibbles_to_2bit(grp);                         // group symbol j at bits 2j
+        const uint32_t mask = (k == 16u) ? 0xFFFFFFFFu : ((1u << (2u * k)) - 1u);
+        // forward scan: scan symbol i = group symbol i, consumed first -> highest field: reverse the fields.
+        // reverse scan: scan symbol i = group symbol k-1-i -> already in table order; complement = ~.
+        uint32_t code = reverse ? packed : (rev2(packed) >> (32u - 2u * k));
+        if (complement) code = ~code & mask;
+        const uint2 r = f.ktab[code];
+        if (r.x > r.y) return r;
+        x = r.x; y = r.y; t_start = k;
+    }
+    for (uint32_t t0 = t_start; t0 < len && x <= y; t0 += 16u)
     {
         // the 16-symbol group holding scan symbols [t0, t0+16)
         const uint32_t cnt = (len - t0) < 16u ? (len - t0) : 16u;
@@ -129,7 +149,6 @@ NVB_API int nvbio_hip_map_exact(const nvbio_hip_fmindex* fmi, const nvbio_hip_st
     p.max_reseed = params->max_reseed; p.retry = params->retry; p.rep_seeds = params->rep_seeds;
     p.fw = params->fw; p.rc = params->rc;
     Fmi f = make_fmi(fmi);
-    f.ktab = nullptr; f.ktab_k = 0;
     g_last_kernel = "map_exact_kernel";
     hipLaunchKernelGGL(map_exact_kernel, dim3((n + 255u) / 256u), dim3(256), 0, to_stream(stream), f, make_string_set(reads), in_queue, n, p,
                        seed_freq_by_len, reinterpret_cast<uint2*>(out_hits), hits_stride, out_counts, out_reseed);

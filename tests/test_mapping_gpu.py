@@ -51,6 +51,10 @@ def test_seed_hit_sets(cuda, ragged):
         eh, ec, er = O.map_exact(host, hr, pd, sf, stride, in_queue=queue)
         dq = torch.from_numpy(queue.view(np.int32)).to(cuda) if queue is not None else None
         gh, gc, gr = nvb.map_exact(fmi, dr, params, max_len, retry=retry, fw=bool(fw), rc=bool(rc), in_queue=dq, hits_stride=stride)
+        # the k-mer table accelerator must not change anything
+        for kk in (9, 12):
+            kh, kc, kr = nvb.map_exact(fmi.with_ktab(kk), dr, params, max_len, retry=retry, fw=bool(fw), rc=bool(rc), in_queue=dq, hits_stride=stride)
+            assert torch.equal(kh, gh) and torch.equal(kc, gc) and torch.equal(kr, gr), kk
         torch.cuda.synchronize()
         gh, gc, gr = gh.cpu().numpy().view(np.uint64), gc.cpu().numpy().view(np.uint32), gr.cpu().numpy()
         ids = queue if queue is not None else np.arange(4000)
