@@ -70,7 +70,7 @@ def parse():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--e2e-reads", type=int, default=10_000_000, help="reads per batch of the end-to-end seed+locate+extend leg")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=2_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=10_000_000)
     return ap.parse_args()
 
 
@@ -131,7 +131,7 @@ def main():
         if world > 1:
             comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(comm_stream):
-                gatherers[b].gather(outs[b][0], outs[b][1])       # 12 B/read to rank 0 over RCCL/xGMI
+                gatherers[b].gather(outs[b][0], outs[b][1], concat=False)   # 12 B/read to rank 0 over RCCL/xGMI
                 pending[b] = torch.cuda.Event()
                 pending[b].record(comm_stream)
 

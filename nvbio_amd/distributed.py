@@ -42,8 +42,10 @@ class ResultGather:
             self.bufs = [torch.empty((self.pad, 3), dtype=torch.int32, device=device) for _ in range(self.world)]
         self.send = torch.empty((self.pad, 3), dtype=torch.int32, device=device) if self.world > 1 else None
 
-    def gather(self, score, sink):
-        """Returns (score[n_total], sink[n_total,2]) on dst, None elsewhere."""
+    def gather(self, score, sink, concat=True):
+        """Returns (score[n_total], sink[n_total,2]) on dst, None elsewhere.  concat=False leaves the
+        records in the per-rank receive buffers (`self.bufs[r][:self.sizes[r]]`) and returns True on dst:
+        no extra copy, for callers that consume them in place."""
         n = score.numel()
         assert n == self.sizes[self.rank]
         if self.world == 1:
@@ -53,5 +55,7 @@ class ResultGather:
         dist.gather(self.send, self.bufs if self.rank == self.dst else None, dst=self.dst, group=self.group)
         if self.rank != self.dst:
             return None
+        if not concat:
+            return True
         rec = torch.cat([self.bufs[r][: self.sizes[r]] for r in range(self.world)], dim=0)
         return rec[:, 0].contiguous(), rec[:, 1:].contiguous()

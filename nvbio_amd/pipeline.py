@@ -5,7 +5,7 @@ the genome window around each located seed -> best score per read.
 This is glue (torch tensor ops), not part of the hot path and not nvBowtie's selection / reduction
 policy (out of scope); it exists to exercise and time the composed kernels on
 BASELINE config 4's shape.  `backend` supplies the three hot-path calls so that the tests can run
-the identical glue over the CPU oracle."""
+the identical glue over a host checker."""
 import torch
 
 from .strings import PackedStringSet
