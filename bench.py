@@ -112,7 +112,7 @@ def main():
     def launch(buf):
         batch.enact(aligner, patterns, texts, buf[0], buf[1])
 
-    # result records: score[n] + sink[n,2] = 12 B per read, double-buffered so that the gather
+    # result records: score[n] + sink[n,2], gathered as 8 B per read; double-buffered so that the gather
     # of step k (side stream) overlaps the kernel of step k+1
     outs = [(torch.empty(n, dtype=torch.int32, device=dev), torch.empty((n, 2), dtype=torch.int32, device=dev)) for _ in range(2)]
     gatherers = [ResultGather(n * world, dst=0, device=dev) for _ in range(2)] if world > 1 else None
@@ -131,7 +131,7 @@ def main():
         if world > 1:
             comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(comm_stream):
-                gatherers[b].gather(outs[b][0], outs[b][1], concat=False)   # 12 B/read to rank 0 over RCCL/xGMI
+                gatherers[b].gather(outs[b][0], outs[b][1], concat=False)   # 8 B/read to rank 0 over RCCL/xGMI
                 pending[b] = torch.cuda.Event()
                 pending[b].record(comm_stream)
 

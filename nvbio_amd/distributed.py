@@ -26,21 +26,23 @@ class ResultGather:
 
     xGMI is point-to-point, so this is a gather (send/recv to the root over its 7 links), not a
     ring all-gather: the root receives (G-1)/G of the bytes once, nobody else receives anything.
-    Buffers are allocated once; `gather()` can be enqueued on a side stream to overlap the next
-    batch's kernel."""
+    compact=True (sinks below 65536, i.e. any short-read batch) packs a record into 8 bytes
+    {score, sink.x << 16 | sink.y} -- at 3 G reads/s per GPU the root of an 8-GPU node then takes in
+    ~190 GB/s instead of ~280 GB/s.  Buffers are allocated once; `gather()` can be enqueued on a side
+    stream to overlap the next batch's kernel."""
 
-    def __init__(self, n_total, dst=0, device=None, group=None):
-        self.group, self.dst = group, dst
+    def __init__(self, n_total, dst=0, device=None, group=None, compact=True):
+        self.group, self.dst, self.compact = group, dst, compact
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.sizes = shard_sizes(n_total, self.world)
         self.n_total = n_total
         self.pad = max(self.sizes) if self.sizes else 0
+        self.width = 2 if compact else 3
         self.bufs = None
         if self.world > 1 and self.rank == dst:
-            # one [pad,3] record buffer per rank: {score, sink.x, sink.y} = 12 B per read
-            self.bufs = [torch.empty((self.pad, 3), dtype=torch.int32, device=device) for _ in range(self.world)]
-        self.send = torch.empty((self.pad, 3), dtype=torch.int32, device=device) if self.world > 1 else None
+            self.bufs = [torch.empty((self.pad, self.width), dtype=torch.int32, device=device) for _ in range(self.world)]
+        self.send = torch.empty((self.pad, self.width), dtype=torch.int32, device=device) if self.world > 1 else None
 
     def gather(self, score, sink, concat=True):
         """Returns (score[n_total], sink[n_total,2]) on dst, None elsewhere.  concat=False leaves the
@@ -50,12 +52,24 @@ class ResultGather:
         assert n == self.sizes[self.rank]
         if self.world == 1:
             return score, sink
+        sink = sink.view(-1, 2)
         self.send[:n, 0] = score
-        self.send[:n, 1:] = sink.view(-1, 2)
+        if self.compact:
+            self.send[:n, 1] = (sink[:, 0] << 16) | (sink[:, 1] & 0xFFFF)
+        else:
+            self.send[:n, 1:] = sink
         dist.gather(self.send, self.bufs if self.rank == self.dst else None, dst=self.dst, group=self.group)
         if self.rank != self.dst:
             return None
         if not concat:
             return True
         rec = torch.cat([self.bufs[r][: self.sizes[r]] for r in range(self.world)], dim=0)
+        if self.compact:
+            sx = (rec[:, 1] >> 16) & 0xFFFF
+            sy = rec[:, 1] & 0xFFFF
+            # an invalid sink (0xFFFFFFFF, 0xFFFFFFFF) round-trips as (0xFFFF, 0xFFFF): restore it
+            bad = (sx == 0xFFFF) & (sy == 0xFFFF)
+            sx = torch.where(bad, torch.full_like(sx, -1), sx)
+            sy = torch.where(bad, torch.full_like(sy, -1), sy)
+            return rec[:, 0].contiguous(), torch.stack([sx, sy], dim=1).contiguous()
         return rec[:, 0].contiguous(), rec[:, 1:].contiguous()

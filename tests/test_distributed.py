@@ -28,7 +28,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, n, q):
+def _worker(rank, world, port, n, q, compact=True):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -39,7 +39,7 @@ def _worker(rank, world, port, n, q):
         sub_p = O.StringSet(hp.words, hp.bits, hp.big_endian, hp.begin[lo:hi], hp.length[lo:hi])
         sub_t = O.StringSet(ht.words, ht.bits, ht.big_endian, ht.begin[lo:hi], ht.length[lo:hi])
         s, k = O.batch_banded_gotoh_score(15, O.LOCAL, (2, -1, -2, -1), sub_p, sub_t, n_threads=1)
-        g = ResultGather(n, dst=0, device="cpu")
+        g = ResultGather(n, dst=0, device="cpu", compact=compact)
         for _ in range(2):                                                   # buffers are reusable
             out = g.gather(torch.from_numpy(s), torch.from_numpy(k.view(np.int32)))
         if rank == 0:
@@ -52,12 +52,12 @@ def _worker(rank, world, port, n, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [1001, 64])
-def test_two_rank_shard_and_gather(n):
+@pytest.mark.parametrize("n,compact", [(1001, True), (64, False)])
+def test_two_rank_shard_and_gather(n, compact):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q, compact)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
