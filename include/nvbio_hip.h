@@ -78,8 +78,9 @@ int nvbio_hip_banded_gotoh_score(
     const nvbio_hip_string_set* patterns /* host struct, device arrays */,
     const nvbio_hip_string_set* texts    /* host struct, device arrays */,
     uint32_t max_pattern_len, uint32_t max_text_len /* the reference's max_pattern_length /
-        max_text_length arguments (batched.h:217-231); 0 = unknown.  Only used to pick the
-        arithmetic width: results never depend on them. */,
+        max_text_length arguments (batched.h:217-231); 0 = unknown.  max_pattern_len only sizes
+        the per-lane LDS staging of the strings (longer jobs read HBM directly): results never
+        depend on either. */,
     uint32_t n, int32_t* out_score, uint32_t* out_sink, void* stream);
 
 /* nvBowtie's SmithWatermanScoringScheme<QualCost,ConstantCost> as the Gotoh aligner sees it

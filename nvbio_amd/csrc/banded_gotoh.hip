@@ -94,6 +94,18 @@ static int banded_gotoh_dispatch(nvb::GotohParams& p, const QA& qa, int64_t max_
                          : max_len_16bit(p.match, max_abs_cost, std::max(p.gap_open, p.txt_gap_open), std::max(p.gap_ext, p.txt_gap_ext), type, band_len);
     const bool fixed = (patterns->length == nullptr);
     hipError_t e = hipSuccess;
+    // LDS staging of each lane's words, sized from the longest pattern the caller announces
+    // (max_pattern_length, or the fixed length); unknown or too long for 32 KiB per block -> off
+    {
+        const uint32_t maxM = fixed ? patterns->fixed_length : p.stage_pw /* carries the hint */;
+        p.stage_pw = p.stage_tw = 0;
+        const char* nostage = getenv("NVBIO_HIP_NO_STAGING");
+        if (maxM != 0 && !(nostage && nostage[0] == '1')) {
+            const uint32_t pw = (stage_words_pattern(32u / patterns->bits - 1u, maxM, patterns->bits) + 3u) & ~3u;
+            const uint32_t tw = (stage_words_text(15u, maxM, band_len) + 3u) & ~3u;
+            if ((pw + tw) * 1024u <= 32768u) { p.stage_pw = pw; p.stage_tw = tw; }
+        }
+    }
     // jobs with pattern_len <= lim16 : 16-bit arithmetic;  longer ones : 32-bit arithmetic
     if (lim16 > 0 && (!fixed || patterns->fixed_length <= lim16)) {
         p.len_lo = 0; p.len_hi = lim16;
@@ -132,7 +144,7 @@ NVB_API int nvbio_hip_banded_gotoh_score(
     uint32_t max_pattern_len, uint32_t max_text_len,
     uint32_t n, int32_t* out_score, uint32_t* out_sink, void* stream)
 {
-    (void)max_pattern_len; (void)max_text_len;     // kernel selection is made per job from its own length
+    (void)max_text_len;     // arithmetic width is chosen per job from its own length; max_pattern_len only sizes the LDS staging
     using namespace nvb;
     if (!scheme) return hipErrorInvalidValue;
     if (int e = check_banded_args(type, band_len, patterns, texts)) return e;
@@ -146,6 +158,7 @@ NVB_API int nvbio_hip_banded_gotoh_score(
     p.gap_open = scheme->gap_open; p.gap_ext = scheme->gap_ext;
     p.txt_gap_open = scheme->gap_open; p.txt_gap_ext = scheme->gap_ext;      // SimpleGotohScheme: utils.h:128-131
     p.n = n; p.out_score = out_score; p.out_sink = out_sink;
+    p.stage_pw = max_pattern_len; p.stage_tw = 0;       // the hint, consumed by banded_gotoh_dispatch
     const int64_t A = std::max(std::max(iabs64(scheme->match), iabs64(scheme->mismatch)), std::max(iabs64(scheme->gap_open), iabs64(scheme->gap_ext)));
     return banded_gotoh_dispatch(p, NoQual(), A, type, band_len, patterns, to_stream(stream),
                                  "banded_gotoh_score_kernel<A16>", "banded_gotoh_score_kernel<A32>");
@@ -158,7 +171,7 @@ NVB_API int nvbio_hip_banded_gotoh_score_qual(
     uint32_t max_pattern_len, uint32_t max_text_len,
     uint32_t n, int32_t* out_score, uint32_t* out_sink, void* stream)
 {
-    (void)max_pattern_len; (void)max_text_len;
+    (void)max_text_len;
     using namespace nvb;
     if (!scheme) return hipErrorInvalidValue;
     if (int e = check_banded_args(type, band_len, patterns, texts)) return e;
@@ -173,6 +186,7 @@ NVB_API int nvbio_hip_banded_gotoh_score_qual(
     p.gap_open = scheme->pattern_gap_open; p.gap_ext = scheme->pattern_gap_ext;
     p.txt_gap_open = scheme->text_gap_open; p.txt_gap_ext = scheme->text_gap_ext;
     p.n = n; p.out_score = out_score; p.out_sink = out_sink;
+    p.stage_pw = max_pattern_len; p.stage_tw = 0;       // the hint, consumed by banded_gotoh_dispatch
     QualArgs qa;
     qa.quals = quals; qa.n_quals = n_quals;
     int64_t A = std::max(std::max(iabs64(scheme->match), iabs64(scheme->pattern_gap_open)), std::max(iabs64(scheme->pattern_gap_ext),

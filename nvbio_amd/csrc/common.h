@@ -38,16 +38,26 @@ __device__ __forceinline__ uint32_t funnel(uint32_t lo, uint32_t hi, uint32_t sh
     return __builtin_amdgcn_alignbit(hi, lo, sh);
 }
 
+typedef const uint32_t __attribute__((address_space(3)))* lds_words_t;   // LDS pointer: ds_read, not flat
+
 struct Stream {
     const uint32_t* words;
     uint64_t        n_words;     // loads are clamped to [0, n_words)
     uint32_t        bits;
     uint32_t        big_endian;
+    // optional per-lane LDS copy of words [kb, kb + staged words): lane-interleaved, this lane's
+    // word w at lds[w * 256] (the pointer already includes the lane's slot).  NULL = read HBM.
+    lds_words_t     lds;
+    uint64_t        kb;
 };
 
-__device__ __forceinline__ uint32_t ld_word(const Stream& s, uint64_t k)
+__device__ __forceinline__ uint32_t ld_word_global(const Stream& s, uint64_t k)
 {
     return s.words[k < s.n_words ? k : s.n_words - 1];
+}
+__device__ __forceinline__ uint32_t ld_word(const Stream& s, uint64_t k)
+{
+    return s.lds ? s.lds[(k - s.kb) * 256u] : ld_word_global(s, k);
 }
 
 // 16 symbols of a 2-bit stream starting at symbol index `sym`, canonical order
@@ -105,6 +115,7 @@ inline StringSet make_string_set(const nvbio_hip_string_set* h)
 {
     StringSet d;
     d.s.words = h->words; d.s.n_words = h->n_words; d.s.bits = h->bits; d.s.big_endian = h->big_endian;
+    d.s.lds = nullptr; d.s.kb = 0;
     d.begin = h->begin; d.length = h->length; d.fixed_length = h->fixed_length;
     return d;
 }

@@ -22,14 +22,23 @@ def dna(s):
     return np.array(["ACGT".index(c) for c in s], dtype=np.uint8)
 
 
+_hint_cycle = [0]
+
+
 def run_gpu(band, ty, scheme, hp, ht, dev, force32=False):
     """hp/ht: oracle StringSets (host) -> run the same data through the HIP path.
-    force32: disable the 16-bit kernels so the 32-bit ones are exercised on the same data."""
+    force32: disable the 16-bit kernels so the 32-bit ones are exercised on the same data.
+    The max_pattern_length hint (which only sizes the LDS staging) cycles through unknown / exact /
+    too small, so staged lanes, unstaged launches and per-lane fall-backs are all exercised."""
     p = nvb.PackedStringSet.from_host(hp.words, hp.bits, hp.big_endian, hp.begin, hp.length, device=dev)
     t = nvb.PackedStringSet.from_host(ht.words, ht.bits, ht.big_endian, ht.begin, ht.length, device=dev)
     os.environ["NVBIO_HIP_FORCE_32BIT"] = "1" if force32 else "0"
+    maxlen = int(hp.length.max()) if hp.length.size else 0
+    _hint_cycle[0] += 1
+    hint = (0, maxlen, max(maxlen // 2, 1))[_hint_cycle[0] % 3]
     try:
-        score, sink = nvb.batch_banded_alignment_score(band, nvb.make_gotoh_aligner(ty, nvb.SimpleGotohScheme(*scheme)), p, t)
+        score, sink = nvb.batch_banded_alignment_score(band, nvb.make_gotoh_aligner(ty, nvb.SimpleGotohScheme(*scheme)), p, t,
+                                                       max_pattern_length=hint)
         torch.cuda.synchronize()
     finally:
         os.environ["NVBIO_HIP_FORCE_32BIT"] = "0"
