@@ -83,6 +83,23 @@ int nvbio_hip_banded_gotoh_score(
         depend on either. */,
     uint32_t n, int32_t* out_score, uint32_t* out_sink, void* stream);
 
+/*
+ * Full-matrix (unbanded) Gotoh score.  Replaces
+ *   BatchedAlignmentScore<stream, DeviceThreadScheduler>::enact (nvbio/alignment/batched.h:310-329,
+ *   batched_inl.h:383-460) and batch_alignment_score(...) (batched.h:160-190)
+ * for aligner = GotohAligner<TYPE, SimpleGotohScheme, TextBlockingTag> -- the instantiation of
+ * sw-benchmark (sw-benchmark/sw-benchmark.cu:604-631): job i scores patterns[i] against the whole of
+ * texts[i] exactly as priv::gotoh_alignment_score_dispatch<8,TYPE,TextBlockingTag,.>::run
+ * (nvbio/alignment/gotoh/gotoh_inl.h:969-1489) does into a fresh BestSink, including its int16
+ * boundary column, its tie order and its early exit against min_score[i] (NULL = never).
+ * out_ok (nullable) receives that function's bool (0 = early-exited).  Patterns up to 256 symbols
+ * (max_pattern_len / max_text_len are required for ragged sets: they select the register layout). */
+int nvbio_hip_gotoh_score(
+    const nvbio_hip_gotoh_scheme* scheme /* host */, int32_t type,
+    const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len, const int32_t* min_score /* device, nullable */,
+    uint32_t n, int32_t* out_score, uint32_t* out_sink, uint8_t* out_ok, void* stream);
+
 /* nvBowtie's SmithWatermanScoringScheme<QualCost,ConstantCost> as the Gotoh aligner sees it
  * (nvBowtie/bowtie2/cuda/scoring.h:283-293): substitution(r,q,qq) = (r == q) ? match : mismatch[qq],
  * with mismatch[qq] = -m_mmp(qq) tabulated by the host for every quality byte (the float->int

@@ -135,3 +135,37 @@ def batch_banded_alignment_score(band_len, aligner, patterns, texts, out_score=N
     BatchedBandedAlignmentScore(band_len).enact(aligner, patterns, texts, out_score, out_sink,
                                                 max_pattern_length, max_text_length, quals)
     return out_score, out_sink
+
+
+class BatchedAlignmentScore:
+    """BatchedAlignmentScore<stream, DeviceThreadScheduler> (batched.h:310-329) for the full-matrix Gotoh
+    score with the text-blocking aligner sw-benchmark instantiates (sw-benchmark.cu:604-631)."""
+
+    def enact(self, aligner, patterns, texts, out_score, out_sink, max_pattern_length=0, max_text_length=0,
+              min_score=None, out_ok=None):
+        n = len(patterns)
+        assert len(texts) == n and isinstance(aligner.scheme, SimpleGotohScheme)
+        if patterns.length is None:
+            max_pattern_length = max_pattern_length or patterns.fixed_length
+        if texts.length is None:
+            max_text_length = max_text_length or texts.fixed_length
+        sc = aligner.scheme.struct()
+        ps, ts = patterns.struct(), texts.struct()
+        err = lib().nvbio_hip_gotoh_score(
+            C.byref(sc), aligner.type, C.byref(ps), C.byref(ts), int(max_pattern_length), int(max_text_length),
+            C.c_void_p(min_score.data_ptr()) if min_score is not None else None, n,
+            C.c_void_p(out_score.data_ptr()), C.c_void_p(out_sink.data_ptr()),
+            C.c_void_p(out_ok.data_ptr()) if out_ok is not None else None, current_stream_ptr())
+        check(err, "nvbio_hip_gotoh_score")
+
+
+def batch_alignment_score(aligner, patterns, texts, max_pattern_length=0, max_text_length=0, min_score=None):
+    """batch_alignment_score(aligner, patterns, texts, sinks, DeviceThreadScheduler(), maxP, maxT)
+    (batched.h:160-190).  Returns (score[n], sink[n,2], ok[n] uint8)."""
+    n = len(patterns)
+    dev = patterns.words.device
+    score = torch.empty(n, dtype=torch.int32, device=dev)
+    sink = torch.empty((n, 2), dtype=torch.int32, device=dev)
+    ok = torch.empty(n, dtype=torch.uint8, device=dev)
+    BatchedAlignmentScore().enact(aligner, patterns, texts, score, sink, max_pattern_length, max_text_length, min_score, ok)
+    return score, sink, ok

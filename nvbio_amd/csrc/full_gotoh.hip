@@ -1,0 +1,305 @@
+// full_gotoh.hip -- batched full-matrix Gotoh / Smith-Waterman score for gfx950.
+//
+// Computes, per job, what the reference's text-blocking full DP
+//   priv::gotoh_alignment_score_dispatch<8,TYPE,TextBlockingTag,symbol>::run
+//   (nvbio/alignment/gotoh/gotoh_inl.h:969-1489; BAND_LEN = 8 text columns per block, :1491-1495)
+// reports into a fresh BestSink<int32>, as instantiated by sw-benchmark
+// (make_gotoh_aligner<TYPE,TextBlockingTag>, sw-benchmark/sw-benchmark.cu:604-631) through
+//   BatchedAlignmentScore<stream,DeviceThreadScheduler>::enact (nvbio/alignment/batched_inl.h:383-460).
+//
+// The reference runs one thread per alignment and keeps a boundary column of short2 {H,E} per
+// pattern row in local / global memory, sweeping the text in blocks of 8 columns.  That mapping
+// needs O(pattern) private memory per lane.  Here ONE WAVE owns one alignment and sweeps the text
+// as a systolic array: lane l holds R consecutive pattern rows in registers (H and E of the
+// previous column), processes text column c = step - l, and hands its bottom row's H and F, the
+// column's text symbol and the running column maximum to lane l+1 with four wave_shr:1 DPP moves
+// per step -- no column storage at all, text symbols are read once per wave.  (This is the
+// "wavefront / shuffle sweep" shape; the banded kernel does not use it because a 15-wide band
+// leaves 3/4 of a wave idle.)
+//
+// What the reference's blocking makes observable is reproduced exactly:
+//  * LOCAL ties: BestSink keeps the LAST maximal cell in the reference's visiting order
+//    (block of 8 columns, then row, then column) -- each lane tracks (score, order key) pairs and
+//    the wave reduces them;
+//  * the boundary column is stored as int16: H and E crossing a block boundary are truncated
+//    (gotoh_inl.h:1065, 1476-1477) -- the TRUNC variants do the same, and are selected whenever
+//    the host cannot prove the values stay inside int16;
+//  * the early exit after each full block, max_i H(i, block end) + missing_cols * match < min_score
+//    (:1212-1214): the column maximum flows down the lanes with the data; when the test fires the
+//    wave recomputes the prefix it covers, so the sink holds exactly what the reference's holds.
+#include "common.h"
+#include <algorithm>
+
+namespace nvb {
+
+struct FullParams {
+    StringSet      pat, txt;
+    int32_t        match, mismatch, gap_open, gap_ext;
+    const int32_t* min_score;      // nullable: no early exit
+    uint32_t       n;
+    int32_t*       out_score;
+    uint32_t*      out_sink;
+    uint8_t*       out_ok;         // nullable: the reference's per-job bool
+};
+
+__device__ __forceinline__ int32_t dpp_shr1(int32_t first_lane_value, int32_t x)
+{
+    // lane l receives x of lane l-1; lane 0 keeps first_lane_value   (wave_shr:1 = 0x138 on gfx9)
+    return __builtin_amdgcn_update_dpp(first_lane_value, x, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int32_t sext16(int32_t v) { return int32_t(int16_t(v)); }
+
+struct SweepResult { int32_t score; uint32_t sx, sy; uint32_t exit_col; };   // exit_col = 0xFFFFFFFF: ran to the end
+
+// One sweep of the wave over text columns [0, Ncols).  CHECK: evaluate the early-exit test.
+template <int TYPE, int R, bool TRUNC>
+__device__ __forceinline__ SweepResult sweep(const FullParams& p, const uint64_t pb, const uint64_t tb,
+                                             const uint32_t M, const uint32_t Ncols, const uint32_t Nfull,
+                                             const bool check, const int32_t min_score)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const int32_t  Go = p.gap_open, Ge = p.gap_ext;
+    const int32_t  infimum = -32768 - min(Go, Ge);                               // :1153
+    const uint32_t lane_last = (M - 1u) / uint32_t(R);
+    const uint32_t KM = 8u * 64u * uint32_t(R);                                  // order-key stride per block
+
+    // this lane's rows
+    uint32_t q[R]; int32_t Hleft[R], E[R];
+    #pragma unroll
+    for (int k = 0; k < R; ++k)
+    {
+        const uint32_t r = lane * R + k;
+        q[k] = r < M ? get_symbol(p.pat.s, pb + r) : 255u;
+        // context.init (:69-93): the column left of the matrix, kept as short2
+        int32_t h0 = (TYPE != NVBIO_HIP_LOCAL) ? p.gap_open + p.gap_ext * int32_t(r) : 0;
+        int32_t e0 = (TYPE == NVBIO_HIP_LOCAL) ? 0 : infimum;
+        Hleft[k] = TRUNC ? sext16(h0) : h0;
+        E[k]     = TRUNC ? sext16(e0) : e0;
+    }
+
+    // values handed down the lanes (produced in the previous step)
+    int32_t out_h = 0, out_f = 0, out_ch = 0, out_cm = 0;
+    int32_t prev_in_h = 0;          // H(row above this lane, c-1): the first row's diagonal
+    uint64_t best64 = 0;            // LOCAL: (score << 32 | order key) of the best cell of this lane
+    bool     have = false;
+    int32_t  sg_score = -(1 << 30); uint32_t sg_col = 0;     // SEMI_GLOBAL / GLOBAL, last-row lane
+    uint32_t exit_col = 0xFFFFFFFFu;
+    uint32_t grp = 0;
+
+    const uint32_t n_steps = Ncols + lane_last;
+    for (uint32_t s = 0; s < n_steps; ++s)
+    {
+        if ((s & 15u) == 0u && s < Ncols) grp = fetch16_2bit(p.txt.s, tb + s);   // wave-uniform
+        const int32_t  c_signed = int32_t(s) - int32_t(lane);
+        const uint32_t c = uint32_t(c_signed);
+        const bool active = c_signed >= 0 && c < Ncols && lane <= lane_last;
+
+        // inputs from the lane above (its outputs of the previous step = same column c)
+        // row -1 for lane 0: H(-1,c) = GLOBAL ? G_o + G_e*c : 0 ; F = infimum ; (:1172-1176)
+        const int32_t top_h  = (TYPE == NVBIO_HIP_GLOBAL) ? Go + Ge * int32_t(s) : 0;
+        const int32_t ch0    = int32_t((grp >> (2u * (s & 15u))) & 3u);
+        int32_t in_h  = dpp_shr1(top_h, out_h);
+        int32_t in_f  = dpp_shr1(infimum, out_f);
+        int32_t in_ch = dpp_shr1(ch0, out_ch);
+        int32_t in_cm = dpp_shr1(-(1 << 30), out_cm);
+        // diagonal of the first row: H(row above, c-1); for lane 0: H(-1,-1) = 0, else G_o + G_e*(c-1)
+        int32_t diag = prev_in_h;
+        if (lane == 0u) diag = (TYPE == NVBIO_HIP_GLOBAL && s > 0u) ? Go + Ge * int32_t(s - 1u) : 0;
+        else if (c_signed == 0)
+        {
+            // first column: the diagonal is the init column's entry of the row above (context.init)
+            const int32_t h0 = (TYPE != NVBIO_HIP_LOCAL) ? p.gap_open + p.gap_ext * int32_t(lane * R - 1u) : 0;
+            diag = TRUNC ? sext16(h0) : h0;
+        }
+        if (TRUNC && lane != 0u && (c & 7u) == 0u && c_signed > 0) diag = sext16(diag);   // crossed a block boundary via temp[]
+        prev_in_h = in_h;
+
+        int32_t habove = in_h, fabove = in_f, cm = in_cm;
+        const bool crossing = TRUNC && (c & 7u) == 0u && c_signed > 0;      // column c starts a block: left values came through temp[]
+        #pragma unroll
+        for (int k = 0; k < R; ++k)
+        {
+            const uint32_t r = lane * R + k;
+            int32_t hl = Hleft[k], e = E[k];
+            if (crossing) { hl = sext16(hl); e = sext16(e); }
+            const int32_t f  = max(fabove + Ge, habove + Go);
+            e = max(e + Ge, hl + Go);
+            const int32_t d  = diag + ((uint32_t(in_ch) == q[k]) ? p.match : p.mismatch);
+            int32_t h = max(max(e, f), d);
+            if (TYPE == NVBIO_HIP_LOCAL) h = max(h, 0);
+            diag = hl;                  // H(r, c-1) is the next row's diagonal (already truncated if crossing)
+            if (active)
+            {
+                Hleft[k] = h; E[k] = e;
+                if (r < M)
+                {
+                    cm = max(cm, h);
+                    if (TYPE == NVBIO_HIP_LOCAL)
+                    {
+                        // order key: block-major, then row, then column within the block
+                        const uint32_t key = (c >> 3) * KM + r * 8u + (c & 7u);
+                        const uint64_t cand = (uint64_t(uint32_t(h)) << 32) | key;
+                        if (!have || cand >= best64) { best64 = cand; have = true; }
+                    }
+                }
+            }
+            habove = h; fabove = f;
+        }
+        if (active)
+        {
+            out_h = habove; out_f = fabove; out_ch = in_ch; out_cm = cm;
+        }
+        // the lane holding the last pattern row: semi-global / global reports and the early-exit test
+        if (active && lane == lane_last)
+        {
+            const uint32_t klast = (M - 1u) - lane_last * uint32_t(R);
+            int32_t hlast = Hleft[0];
+            #pragma unroll
+            for (int k = 1; k < R; ++k) if (uint32_t(k) == klast) hlast = Hleft[k];
+            if (TYPE == NVBIO_HIP_SEMI_GLOBAL) { if (sg_score <= hlast) { sg_score = hlast; sg_col = c; } }
+            if (TYPE == NVBIO_HIP_GLOBAL && c + 1u == Nfull) { sg_score = hlast; sg_col = c; }
+            // early exit (:1212-1214): only after blocks that are not the last one
+            if (check && (c & 7u) == 7u && exit_col == 0xFFFFFFFFu)
+            {
+                const uint32_t nb = 8u * ((Nfull + 7u) / 8u);
+                const uint32_t end_block = nb > 8u ? nb : 8u;
+                const uint32_t block = c - 7u;
+                if (block + 8u < end_block)
+                {
+                    const int32_t missing = int32_t(Nfull - block - 8u);
+                    if (cm + missing * p.match < min_score) exit_col = c;
+                }
+            }
+        }
+    }
+
+    // gather the result in every lane
+    SweepResult res;
+    res.exit_col = uint32_t(__shfl(int32_t(exit_col), int32_t(lane_last)));
+    res.score = -(1 << 30); res.sx = res.sy = 0xFFFFFFFFu;
+    if (TYPE == NVBIO_HIP_LOCAL)
+    {
+        uint64_t b = have ? best64 : 0ull; uint32_t hv = have ? 1u : 0u;
+        #pragma unroll
+        for (int off = 32; off >= 1; off >>= 1)
+        {
+            const uint32_t olo = uint32_t(__shfl_xor(int32_t(uint32_t(b)), off));
+            const uint32_t ohi = uint32_t(__shfl_xor(int32_t(uint32_t(b >> 32)), off));
+            const uint32_t ohv = uint32_t(__shfl_xor(int32_t(hv), off));
+            const uint64_t o = (uint64_t(ohi) << 32) | olo;
+            if (ohv && (!hv || o > b)) { b = o; hv = 1u; }
+        }
+        if (hv) {
+            const uint32_t key = uint32_t(b);
+            const uint32_t col = (key / KM) * 8u + (key & 7u), row = (key % KM) >> 3;
+            res.score = int32_t(uint32_t(b >> 32)); res.sx = col + 1u; res.sy = row + 1u;
+        }
+    }
+    else
+    {
+        const int32_t  sc  = __shfl(sg_score, int32_t(lane_last));
+        const uint32_t col = uint32_t(__shfl(int32_t(sg_col), int32_t(lane_last)));
+        const bool reported = (TYPE == NVBIO_HIP_SEMI_GLOBAL) ? (Ncols > 0u) : (Ncols == Nfull && Nfull > 0u);
+        if (reported) { res.score = sc; res.sx = col + 1u; res.sy = M; }
+    }
+    return res;
+}
+
+template <int TYPE, int R, bool TRUNC>
+__global__ void __launch_bounds__(256)
+full_gotoh_score_kernel(const FullParams p)
+{
+    const uint32_t job  = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (job >= p.n) return;
+    const uint32_t M  = p.pat.length ? p.pat.length[job] : p.pat.fixed_length;
+    const uint32_t N  = p.txt.length ? p.txt.length[job] : p.txt.fixed_length;
+    const uint64_t pb = p.pat.begin[job], tb = p.txt.begin[job];
+    const bool     check = p.min_score != nullptr;
+    const int32_t  min_score = check ? p.min_score[job] : -(1 << 30);
+
+    int32_t score = -(1 << 30); uint32_t sx = 0xFFFFFFFFu, sy = 0xFFFFFFFFu; uint32_t ok = 1u;
+    if (M == 0u)
+    {
+        // no rows: only the row above the matrix is ever reported (:1203-1207, :1404-1421)
+        const uint32_t nb = 8u * ((N + 7u) / 8u);
+        const bool has_full_block = nb > 8u;
+        const bool exits = check && has_full_block && (-(1 << 30) + int32_t(N - 8u) * p.match < min_score);
+        if (exits) { ok = 0u; if (TYPE == NVBIO_HIP_SEMI_GLOBAL) { score = 0; sx = 8u; sy = 0u; } }
+        else if (N > 0u) {
+            if (TYPE == NVBIO_HIP_SEMI_GLOBAL) { score = 0; sx = N; sy = 0u; }
+            if (TYPE == NVBIO_HIP_GLOBAL)      { score = p.gap_open + p.gap_ext * int32_t(N - 1u); sx = N; sy = 0u; }
+        }
+    }
+    else
+    {
+        SweepResult r = sweep<TYPE, R, TRUNC>(p, pb, tb, M, N, N, check, min_score);
+        if (r.exit_col != 0xFFFFFFFFu)
+        {
+            // the reference returned false after this block: its sink saw columns [0, exit_col] only
+            ok = 0u;
+            r = sweep<TYPE, R, TRUNC>(p, pb, tb, M, r.exit_col + 1u, N, false, min_score);
+        }
+        score = r.score; sx = r.sx; sy = r.sy;
+    }
+    if (lane == 0u)
+    {
+        p.out_score[job] = score;
+        reinterpret_cast<uint2*>(p.out_sink)[job] = make_uint2(sx, sy);
+        if (p.out_ok) p.out_ok[job] = uint8_t(ok);
+    }
+}
+
+template <int R, bool TRUNC>
+static hipError_t launch_full(const FullParams& p, int type, hipStream_t s)
+{
+    const dim3 grid((uint64_t(p.n) * 64u + 255u) / 256u), block(256);
+    switch (type) {
+    case NVBIO_HIP_GLOBAL:      hipLaunchKernelGGL((full_gotoh_score_kernel<NVBIO_HIP_GLOBAL, R, TRUNC>),      grid, block, 0, s, p); break;
+    case NVBIO_HIP_LOCAL:       hipLaunchKernelGGL((full_gotoh_score_kernel<NVBIO_HIP_LOCAL, R, TRUNC>),       grid, block, 0, s, p); break;
+    case NVBIO_HIP_SEMI_GLOBAL: hipLaunchKernelGGL((full_gotoh_score_kernel<NVBIO_HIP_SEMI_GLOBAL, R, TRUNC>), grid, block, 0, s, p); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+} // namespace nvb
+
+using namespace nvb;
+
+NVB_API int nvbio_hip_gotoh_score(
+    const nvbio_hip_gotoh_scheme* scheme, int32_t type,
+    const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len, const int32_t* min_score,
+    uint32_t n, int32_t* out_score, uint32_t* out_sink, uint8_t* out_ok, void* stream)
+{
+    if (!scheme || !patterns || !texts) return hipErrorInvalidValue;
+    if (type < 0 || type > 2) return hipErrorInvalidValue;
+    if (!(patterns->bits == 2 || patterns->bits == 4) || texts->bits != 2) return hipErrorNotSupported;
+    if (n == 0) return hipSuccess;
+    if (!out_score || !out_sink || !patterns->words || !texts->words || !patterns->begin || !texts->begin ||
+        patterns->n_words == 0 || texts->n_words == 0) return hipErrorInvalidValue;
+    // the systolic mapping holds the whole pattern in one wave's registers: the caller states its bound
+    const uint32_t maxM = patterns->length ? max_pattern_len : patterns->fixed_length;
+    const uint32_t maxN = texts->length ? max_text_len : texts->fixed_length;
+    if (maxM == 0 || maxM > 256u) return hipErrorNotSupported;
+    if (maxN == 0 || uint64_t(maxN) * 64u * 4u >= (1ull << 32)) return hipErrorNotSupported;    // LOCAL order keys are 32-bit
+
+    FullParams p;
+    p.pat = make_string_set(patterns); p.txt = make_string_set(texts);
+    p.match = scheme->match; p.mismatch = scheme->mismatch; p.gap_open = scheme->gap_open; p.gap_ext = scheme->gap_ext;
+    p.min_score = min_score; p.n = n; p.out_score = out_score; p.out_sink = out_sink; p.out_ok = out_ok;
+
+    // can any H / E leave int16?  |value| <= (maxM + maxN + 2) * max|cost| (+ the short-based infimum)
+    auto iabs = [](int32_t v) { return v < 0 ? -int64_t(v) : int64_t(v); };
+    const int64_t A = std::max(std::max(iabs(scheme->match), iabs(scheme->mismatch)), std::max(iabs(scheme->gap_open), iabs(scheme->gap_ext)));
+    const bool trunc = !(scheme->gap_open <= 0 && scheme->gap_ext <= 0 && (int64_t(maxM) + maxN + 2) * A < 30000);
+    hipStream_t s = to_stream(stream);
+    g_last_kernel = "full_gotoh_score_kernel";
+    const int R = maxM <= 64u ? 1 : maxM <= 128u ? 2 : 4;
+    if (trunc) {
+        switch (R) { case 1: return launch_full<1, true>(p, type, s); case 2: return launch_full<2, true>(p, type, s); default: return launch_full<4, true>(p, type, s); }
+    } else {
+        switch (R) { case 1: return launch_full<1, false>(p, type, s); case 2: return launch_full<2, false>(p, type, s); default: return launch_full<4, false>(p, type, s); }
+    }
+}

@@ -333,6 +333,142 @@ ORACLE_API void oracle_qual_cost_lut(int32_t min_val, int32_t max_val, int32_t* 
     }
 }
 
+/* ------------------------------------------------------------------------ */
+/* Full-matrix Gotoh score, text-blocking: gotoh_inl.h:969-1489              */
+/*   (the form sw-benchmark instantiates: make_gotoh_aligner<TYPE,           */
+/*    TextBlockingTag>, sw-benchmark.cu:604-631; BAND_LEN = 8 text columns   */
+/*    per block, gotoh_inl.h:1491-1495; boundary column kept as short2       */
+/*    {H,E} per pattern row, gotoh_inl.h:1476-1477)                          */
+/* ------------------------------------------------------------------------ */
+#define FULL_BAND 8
+static int gotoh_score_text_blocking(int type, const scheme_t* sc,
+    const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, uint64_t pat_begin, uint32_t M,
+    const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, uint64_t txt_begin, uint32_t N,
+    int32_t min_score, best_sink_t* sink, int16_t* temp /* 2*M scratch */)
+{
+    int32_t H_band[FULL_BAND + 1], F_band[FULL_BAND + 1];
+    uint8_t r_cache[FULL_BAND];
+    memset(r_cache, 0, sizeof r_cache);
+    const int32_t G_o = sc->pat_gap_open, G_e = sc->pat_gap_ext, zero = 0;
+    const int32_t infimum = -32768 - (G_o < G_e ? G_o : G_e);                    /* :1153 */
+    /* context.init, GotohScoringContext (:69-93), TextBlockingTag branch */
+    for (uint32_t i = 0; i < M; ++i) {
+        temp[2 * i]     = (int16_t)(type != ALN_LOCAL ? sc->txt_gap_open + sc->txt_gap_ext * (int32_t)i : zero);
+        temp[2 * i + 1] = (int16_t)(type == ALN_LOCAL ? zero : infimum);
+    }
+    const uint32_t nb = FULL_BAND * ((N + FULL_BAND - 1) / FULL_BAND);
+    const uint32_t end_block = nb > FULL_BAND ? nb : FULL_BAND;                  /* :1160-1162, window_end == N */
+    for (uint32_t block = 0; block + FULL_BAND <= end_block; block += FULL_BAND)
+    {
+        const int last = (block + FULL_BAND == end_block);                       /* the CHECK_N block (:1219-) */
+        const uint32_t block_end = (block + FULL_BAND < N) ? block + FULL_BAND : N;
+        for (uint32_t t = 0; t < FULL_BAND; ++t)
+            if (!last || block + t < block_end) r_cache[t] = (uint8_t)ps_get(txt_w, txt_bits, txt_be, txt_begin + block + t);
+        for (uint32_t j = 0; j <= FULL_BAND; ++j) {
+            H_band[j] = (type == ALN_GLOBAL) ? (block + j > 0 ? G_o + G_e * (int32_t)(block + j - 1u) : zero) : zero;
+            F_band[j] = infimum;
+        }
+        int32_t max_score = -(1 << 30);
+        int32_t temp_i = H_band[0];
+        for (uint32_t i = 0; i < M; ++i)
+        {
+            const uint8_t q_i  = (uint8_t)ps_get(pat_w, pat_bits, pat_be, pat_begin + i);
+            const uint8_t qq_i = sc->quals ? sc->quals[pat_begin + i] : 0;
+            /* update_row (:974-1098) */
+            int32_t H_diag = temp_i;
+            H_band[0] = temp_i = temp[2 * i];
+            int32_t E = temp[2 * i + 1];
+            for (uint32_t j = 1; j <= FULL_BAND; ++j)
+            {
+                F_band[j] = imax(F_band[j] + G_e, H_band[j] + G_o);
+                E = imax(E + G_e, H_band[j - 1] + G_o);
+                const int32_t diagonal = H_diag + subst(sc, r_cache[j - 1], q_i, qq_i);
+                int32_t hi = imax(imax(E, F_band[j]), diagonal);
+                if (type == ALN_LOCAL) hi = imax(hi, zero);
+                H_diag = H_band[j];
+                H_band[j] = hi;
+            }
+            temp[2 * i] = (int16_t)H_band[FULL_BAND]; temp[2 * i + 1] = (int16_t)E;      /* make_vector<short> :1065 */
+            max_score = imax(max_score, H_band[FULL_BAND]);
+            if (type == ALN_LOCAL)
+                for (uint32_t j = 1; j <= FULL_BAND; ++j)
+                    if (!last || block + j <= N) sink_report(sink, H_band[j], block + j, i + 1);
+        }
+        if (!last)
+        {
+            if (type == ALN_SEMI_GLOBAL)
+                for (uint32_t j = 1; j <= FULL_BAND; ++j) sink_report(sink, H_band[j], block + j, M);
+            const int32_t missing_cols = (int32_t)(N - block - FULL_BAND);
+            if (max_score + missing_cols * sc->match < min_score) return 0;         /* :1212-1214 (match(255)) */
+        }
+        else
+        {
+            if (type == ALN_SEMI_GLOBAL) {
+                for (uint32_t j = 1; j <= FULL_BAND; ++j) if (block + j <= N) sink_report(sink, H_band[j], block + j, M);
+            } else if (type == ALN_GLOBAL) {
+                for (uint32_t j = 1; j <= FULL_BAND; ++j) if (block + j == N) sink_report(sink, H_band[j], block + j, M);
+            }
+        }
+    }
+    return 1;
+}
+
+/* BatchedAlignmentScore<stream,HostThreadScheduler> over GotohAligner<TYPE,SimpleGotohScheme,TextBlockingTag>
+ * (nvbio/alignment/batched_inl.h:236-300): out_ok[i] = the per-job bool (0 = early-exited). */
+ORACLE_API void oracle_batch_gotoh_score(
+    int type, const int32_t* scheme,
+    const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, const uint64_t* pat_begin, const uint32_t* pat_len,
+    const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, const uint64_t* txt_begin, const uint32_t* txt_len,
+    const int32_t* min_score /* nullable: -(1<<30) */, uint32_t n, int32_t* out_score, uint32_t* out_sink, uint8_t* out_ok, int n_threads)
+{
+    scheme_t sc = { scheme[0], scheme[1], scheme[2], scheme[3], scheme[2], scheme[3], NULL, NULL };
+#if defined(_OPENMP)
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+    #pragma omp parallel for schedule(dynamic, 16)
+#endif
+    for (int64_t i = 0; i < (int64_t)n; ++i)
+    {
+        best_sink_t s; sink_init(&s);
+        int16_t* temp = (int16_t*)malloc(sizeof(int16_t) * 2 * (size_t)(pat_len[i] + 1));
+        const int ok = gotoh_score_text_blocking(type, &sc, pat_w, pat_bits, pat_be, pat_begin[i], pat_len[i],
+            txt_w, txt_bits, txt_be, txt_begin[i], txt_len[i], min_score ? min_score[i] : -(1 << 30), &s, temp);
+        free(temp);
+        out_score[i] = s.score; out_sink[2 * i] = s.sink_x; out_sink[2 * i + 1] = s.sink_y;
+        if (out_ok) out_ok[i] = (uint8_t)ok;
+    }
+}
+
+/* ref_sw for the Gotoh aligner: nvbio-test/alignment_test_utils.h:536-624, the independent
+ * full-matrix checker the reference's alignment test compares alignment_score() with
+ * (alignment_test.cu:247-265).  i runs over the text, j over the pattern. */
+ORACLE_API int32_t oracle_ref_sw_gotoh(int type, const int32_t* scheme, const uint8_t* str, uint32_t M, const uint8_t* ref, uint32_t N)
+{
+    const int32_t V = scheme[0], S = scheme[1], G_o = scheme[2], G_e = scheme[3];
+    const size_t W = (size_t)M + 1;
+    int32_t* H = (int32_t*)malloc(sizeof(int32_t) * 3 * W * ((size_t)N + 1));
+    int32_t* E = H + W * ((size_t)N + 1);
+    int32_t* F = E + W * ((size_t)N + 1);
+    const int32_t ninf = (type != ALN_LOCAL) ? -100000 : 0;
+    H[0] = 0; E[0] = F[0] = ninf;
+    for (uint32_t j = 1; j <= M; ++j) { H[j] = (type != ALN_LOCAL) ? G_o + G_e * (int32_t)(j - 1) : 0; E[j] = F[j] = ninf; }
+    for (uint32_t i = 1; i <= N; ++i) { H[i * W] = (type == ALN_GLOBAL) ? G_o + G_e * (int32_t)(i - 1) : 0; E[i * W] = F[i * W] = ninf; }
+    int32_t best = -(1 << 30);
+    for (uint32_t i = 1; i <= N; ++i) {
+        for (uint32_t j = 1; j <= M; ++j) {
+            const int32_t S_ij = (ref[i - 1] == str[j - 1]) ? V : S;
+            E[i * W + j] = imax(E[i * W + j - 1] + G_e, H[i * W + j - 1] + G_o);
+            F[i * W + j] = imax(F[(i - 1) * W + j] + G_e, H[(i - 1) * W + j] + G_o);
+            int32_t h = imax(imax(H[(i - 1) * W + j - 1] + S_ij, E[i * W + j]), F[i * W + j]);
+            if (type == ALN_LOCAL) { h = imax(h, 0); if (best < h) best = h; }
+            H[i * W + j] = h;
+        }
+        if (type == ALN_SEMI_GLOBAL && best < H[i * W + M]) best = H[i * W + M];
+    }
+    const int32_t r = (type == ALN_GLOBAL) ? H[(size_t)N * W + M] : best;
+    free(H);
+    return r;
+}
+
 /* ref_banded_sw: nvbio-test/alignment_test_utils.h:314-460.  The reference's
  * test-suite asserts  banded_alignment_score(...) == ref_banded_sw(...)
  * (alignment_test.cu:310-326); restated here so our tests can make the same

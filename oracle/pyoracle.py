@@ -38,6 +38,7 @@ def _load(path):
     u32p, u64p, i32p, u8p = (C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.POINTER(C.c_uint8))
     lib.oracle_banded_gotoh_score.restype = C.c_int
     lib.oracle_ref_banded_sw.restype = C.c_int32
+    lib.oracle_ref_sw_gotoh.restype = C.c_int32
     lib.oracle_bwt_from_sa.restype = C.c_uint32
     lib.oracle_filter_rank.restype = C.c_uint64
     lib.oracle_num_threads.restype = C.c_int
@@ -179,6 +180,30 @@ def batch_banded_gotoh_score(band, aln_type, scheme, patterns, texts, n_threads=
         _p(texts.words), C.c_uint32(texts.bits), C.c_uint32(texts.big_endian), _p(texts.begin), _p(texts.length),
         C.c_uint32(n), _p(score), _p(sink), C.c_int(n_threads))
     return score, sink
+
+
+def batch_gotoh_score(aln_type, scheme, patterns, texts, min_score=None, n_threads=0, native=False):
+    """Full-matrix Gotoh score, text-blocking form (gotoh_inl.h:969-1489), HostThreadScheduler semantics
+    -> (score[n], sink[n,2], ok[n])."""
+    n = len(patterns)
+    score = np.empty(n, dtype=np.int32)
+    sink = np.empty((n, 2), dtype=np.uint32)
+    ok = np.empty(n, dtype=np.uint8)
+    sc = _scheme(scheme)
+    ms = np.ascontiguousarray(min_score, dtype=np.int32) if min_score is not None else None
+    lib(native).oracle_batch_gotoh_score(
+        C.c_int(aln_type), _p(sc),
+        _p(patterns.words), C.c_uint32(patterns.bits), C.c_uint32(patterns.big_endian), _p(patterns.begin), _p(patterns.length),
+        _p(texts.words), C.c_uint32(texts.bits), C.c_uint32(texts.big_endian), _p(texts.begin), _p(texts.length),
+        _p(ms), C.c_uint32(n), _p(score), _p(sink), _p(ok), C.c_int(n_threads))
+    return score, sink, ok
+
+
+def ref_sw_gotoh(aln_type, scheme, pattern, text):
+    p = np.ascontiguousarray(pattern, dtype=np.uint8)
+    t = np.ascontiguousarray(text, dtype=np.uint8)
+    sc = _scheme(scheme)
+    return int(lib().oracle_ref_sw_gotoh(C.c_int(aln_type), _p(sc), _p(p), C.c_uint32(p.size), _p(t), C.c_uint32(t.size)))
 
 
 def qual_cost_lut(min_val, max_val):

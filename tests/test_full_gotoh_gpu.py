@@ -1,0 +1,104 @@
+"""Full-matrix Gotoh score (text-blocking form, the aligner sw-benchmark instantiates) through the
+C-ABI vs the oracle's restatement of gotoh_inl.h:969-1489: bit-exact score, sink and ok flag,
+including the LOCAL tie order, the int16 boundary column and the early exit."""
+import numpy as np
+import pytest
+import torch
+
+import nvbio_amd as nvb
+from oracle import pyoracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def dna(s):
+    return np.array(["ACGT".index(c) for c in s], dtype=np.uint8)
+
+
+def run(ty, scheme, pats, txts, dev, min_score=None, maxM=None, maxN=None, pbits=4, pbe=True, tbe=False):
+    hp, ht = O.StringSet.from_lists(pats, pbits, pbe), O.StringSet.from_lists(txts, 2, tbe)
+    es, ek, eo = O.batch_gotoh_score(ty, scheme, hp, ht, min_score=min_score)
+    p = nvb.PackedStringSet.from_host(hp.words, pbits, pbe, hp.begin, hp.length, device=dev)
+    t = nvb.PackedStringSet.from_host(ht.words, 2, tbe, ht.begin, ht.length, device=dev)
+    ms = torch.from_numpy(np.ascontiguousarray(min_score, dtype=np.int32)).to(dev) if min_score is not None else None
+    maxM = maxM or max(1, max(len(x) for x in pats))
+    maxN = maxN or max(1, max(len(x) for x in txts))
+    gs, gk, go = nvb.batch_alignment_score(nvb.make_gotoh_aligner(ty, nvb.SimpleGotohScheme(*scheme)), p, t, maxM, maxN, ms)
+    torch.cuda.synchronize()
+    gs, gk, go = gs.cpu().numpy(), gk.cpu().numpy().view(np.uint32), go.cpu().numpy()
+    bad = np.nonzero((es != gs) | (ek != gk).any(1) | (eo != go))[0]
+    assert bad.size == 0, "type %d scheme %s: %d mismatches; first %d: M=%d N=%d cpu (%d,%s,%d) gpu (%d,%s,%d)" % (
+        ty, scheme, bad.size, bad[0], len(pats[bad[0]]), len(txts[bad[0]]), es[bad[0]], ek[bad[0]], eo[bad[0]], gs[bad[0]], gk[bad[0]], go[bad[0]])
+    return es, ek, eo
+
+
+def test_kats(cuda):
+    """alignment_test.cu:749-795: ACAACTA vs AAACACCCTAACACACTAAA, Gotoh (2,-1,-1,-1); the scores are what
+    the test's CIGARs (1M2D3M1D3M10D, 4M1D3M, 4M1D3M) re-score to."""
+    p, t = dna("ACAACTA"), dna("AAACACCCTAACACACTAAA")
+    for ty, score in ((nvb.GLOBAL, 1), (nvb.LOCAL, 13), (nvb.SEMI_GLOBAL, 13)):
+        es, ek, _ = run(ty, (2, -1, -1, -1), [p], [t], cuda)
+        assert es[0] == score and O.ref_sw_gotoh(ty, (2, -1, -1, -1), p, t) == score
+
+
+def make_pairs(rng, n, max_m, max_n):
+    pats, txts = [], []
+    for i in range(n):
+        M = int(rng.integers(0 if i % 50 == 0 else 1, max_m + 1))
+        N = int(rng.integers(0 if i % 40 == 0 else 1, max_n + 1))
+        t = rng.integers(0, 4, N, dtype=np.uint8)
+        if N > M + 4 and M > 0:
+            off = int(rng.integers(0, N - M))
+            p = t[off:off + M].copy()
+            mut = rng.random(M) < 0.08
+            p[mut] = rng.integers(0, 5, int(mut.sum()), dtype=np.uint8)
+            if M > 12 and i % 3 == 0:
+                cut = int(rng.integers(3, M - 3)); p = np.concatenate([p[:cut], p[cut + 2:]])
+        else:
+            p = rng.integers(0, 4, M, dtype=np.uint8)
+        if i % 7 == 0 and N > 20:        # low-complexity text: many tied maxima
+            t[:] = np.tile(np.array([0, 1], dtype=np.uint8), N)[:N]
+            p = np.tile(np.array([0, 1], dtype=np.uint8), M + 1)[:len(p)]
+        pats.append(p); txts.append(t)
+    return pats, txts
+
+
+@pytest.mark.parametrize("ty", [nvb.GLOBAL, nvb.LOCAL, nvb.SEMI_GLOBAL])
+@pytest.mark.parametrize("max_m", [64, 128, 256])
+def test_random_pairs(cuda, ty, max_m):
+    rng = np.random.default_rng(ty * 10 + max_m)
+    pats, txts = make_pairs(rng, 1500, max_m, 400)
+    for scheme in ((2, -1, -2, -1), (0, -5, -8, -3), (2, -1, -1, -1)):
+        es, ek, eo = run(ty, scheme, pats, txts, cuda, maxM=max_m, maxN=400)
+    for i in range(0, 1500, 97):            # and the oracle agrees with the reference test's own checker
+        if len(txts[i]) > 0 and len(pats[i]) > 0:
+            s, _, _ = O.batch_gotoh_score(ty, (2, -1, -1, -1), O.StringSet.from_lists([pats[i]], 4, True), O.StringSet.from_lists([txts[i]], 2, False))
+            assert s[0] == O.ref_sw_gotoh(ty, (2, -1, -1, -1), np.minimum(pats[i], 9), txts[i])
+
+
+@pytest.mark.parametrize("ty", [nvb.GLOBAL, nvb.LOCAL, nvb.SEMI_GLOBAL])
+def test_early_exit_against_min_score(cuda, ty):
+    rng = np.random.default_rng(77 + ty)
+    pats, txts = make_pairs(rng, 1200, 100, 300)
+    ms = rng.integers(-60, 220, 1200).astype(np.int32)
+    for scheme in ((2, -1, -2, -1), (0, -5, -8, -3)):
+        es, ek, eo = run(ty, scheme, pats, txts, cuda, min_score=ms, maxM=100, maxN=300)
+    assert 0 < eo.sum() < 1200          # both outcomes occur
+
+
+@pytest.mark.parametrize("ty", [nvb.GLOBAL, nvb.LOCAL, nvb.SEMI_GLOBAL])
+def test_int16_boundary_column_truncation(cuda, ty):
+    """Costs large enough that H / E crossing a block boundary do not fit the reference's short2
+    boundary column (gotoh_inl.h:1065): the wrap-around is part of the reference's results."""
+    rng = np.random.default_rng(5 + ty)
+    pats, txts = make_pairs(rng, 600, 100, 300)
+    run(ty, (700, -900, -1100, -800), pats, txts, cuda, maxM=100, maxN=300)
+    run(ty, (2, -1, -2, -1), pats, txts, cuda, maxM=100, maxN=40000)     # bound unknown -> TRUNC variant, same results
+
+
+def test_packings(cuda):
+    rng = np.random.default_rng(9)
+    pats, txts = make_pairs(rng, 400, 90, 200)
+    p2 = [np.minimum(p, 3) for p in pats]
+    for (pb, pbe, tbe, pp) in ((4, False, True, pats), (2, True, True, p2), (2, False, False, p2)):
+        run(nvb.LOCAL, (2, -1, -2, -1), pp, txts, cuda, pbits=pb, pbe=pbe, tbe=tbe)
