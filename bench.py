@@ -64,10 +64,13 @@ def parse():
     ap.add_argument("--genome", type=float, default=3.0e9, help="synthetic genome length of the FM-index legs (a true index is built on the device)")
     ap.add_argument("--rank-queries", type=int, default=1 << 28)
     ap.add_argument("--no-rank", action="store_true")
-    ap.add_argument("--only", choices=["dp", "rank", "seed", "e2e"], default=None, help="profiling aid: run just one leg, print its object")
+    ap.add_argument("--only", choices=["dp", "rank", "seed", "e2e", "full"], default=None, help="profiling aid: run just one leg, print its object")
     ap.add_argument("--seeds", type=int, default=50_000_000)
     ap.add_argument("--no-seed", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--no-full", action="store_true")
+    ap.add_argument("--full-reads", type=int, default=65536)
+    ap.add_argument("--full-ref", type=int, default=16384)
     ap.add_argument("--e2e-reads", type=int, default=10_000_000, help="reads per batch of the end-to-end seed+locate+extend leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000)
@@ -93,6 +96,9 @@ def main():
             dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
+    if a.only == "full":
+        print(json.dumps({"full_dp_leg": full_dp_leg(a, dev)}))
+        return
     if a.only in ("rank", "seed", "e2e"):
         a.no_seed = a.only != "seed"
         a.no_rank = a.only != "rank"
@@ -100,7 +106,7 @@ def main():
         print(json.dumps(fm_legs(a, dev)))
         return
     if a.only == "dp":
-        a.no_rank = a.no_cpu = a.no_seed = a.no_e2e = True
+        a.no_rank = a.no_cpu = a.no_seed = a.no_e2e = a.no_full = True
 
     # ---------------------------------------------------------------- inputs (resident before timing)
     n = a.reads
@@ -203,6 +209,8 @@ def main():
         del patterns, texts, outs
         torch.cuda.empty_cache()
         out.update(fm_legs(a, dev))
+    if rank == 0 and world == 1 and not a.no_full:
+        out["full_dp_leg"] = full_dp_leg(a, dev)
     if rank == 0 and world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_leg(a, *W.make_sw_batch(min(n, a.cpu_sample), READ_LEN, REF_LEN, seed=0x5EED0002, device=dev))
     if rank == 0:
@@ -391,6 +399,48 @@ def seed_leg(a, dev, fmi, text, build_s):
                        "algorithmic_bytes_per_row": bytes_per_loc, "achieved_GBs": lgbs, "frac_of_hbm_peak": lgbs / HBM_PEAK_GBS},
             "hbm_capacity_options": options,
             "parity": {"checked_seeds": m, "checked_rows": mr, "bit_exact": exact}}
+
+
+def full_dp_leg(a, dev):
+    """sw-benchmark's shape (sw-benchmark.cu:557-657): every read is aligned against the WHOLE reference
+    with the full-matrix text-blocking Gotoh aligner, scoring (2,-1,-2,-1); 150-bp reads, one shared
+    reference.  GCUPS = reads x read_len x ref_len / time, as sw-benchmark prints it (:380,441)."""
+    import numpy as np
+    from oracle import pyoracle as O
+    n, L, N = a.full_reads, 150, a.full_ref
+    g = torch.Generator(device=dev)
+    g.manual_seed(0x5EED0006)
+    ref = torch.randint(0, 4, (N,), dtype=torch.uint8, generator=g, device=dev)
+    pos = torch.randint(0, N - L, (n,), generator=g, device=dev)
+    sym = ref[pos.unsqueeze(1) + torch.arange(L, device=dev).unsqueeze(0)]
+    sub = torch.rand((n, L), generator=g, device=dev) < 0.05
+    sym = torch.where(sub, (sym + torch.randint(1, 4, (n, L), dtype=torch.uint8, generator=g, device=dev)) & 3, sym)
+    idx = torch.arange(n, dtype=torch.int64, device=dev)
+    patterns = nvb.PackedStringSet(W._pack_chunked(sym.reshape(-1), 4, True), 4, True, idx * L, None, L)
+    texts = nvb.PackedStringSet(W._pack_chunked(ref, 2, False), 2, False, torch.zeros(n, dtype=torch.int64, device=dev), None, N)
+    res = {"reads": n, "read_len": L, "ref_len": N, "scheme": list(SCHEME)}
+    score = torch.empty(n, dtype=torch.int32, device=dev)
+    sink = torch.empty((n, 2), dtype=torch.int32, device=dev)
+    for name, ty in (("local", nvb.LOCAL), ("semi_global", nvb.SEMI_GLOBAL), ("global", nvb.GLOBAL)):
+        al = nvb.make_gotoh_aligner(ty, nvb.SimpleGotohScheme(*SCHEME))
+        batch = nvb.BatchedAlignmentScore()
+        batch.enact(al, patterns, texts, score, sink)
+        torch.cuda.synchronize()
+        reps = 3
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for e0, e1 in evs:
+            e0.record(); batch.enact(al, patterns, texts, score, sink); e1.record()
+        torch.cuda.synchronize()
+        ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / reps
+        m = 256
+        sub_p = nvb.PackedStringSet(patterns.words, 4, True, patterns.begin[:m].contiguous(), None, L)
+        sub_t = nvb.PackedStringSet(texts.words, 2, False, texts.begin[:m].contiguous(), None, N)
+        es, ek, _ = O.batch_gotoh_score(ty, SCHEME, O.StringSet.from_device(sub_p), O.StringSet.from_device(sub_t), n_threads=os.cpu_count() or 1)
+        ok = bool((score[:m].cpu().numpy() == es).all() and (sink[:m].cpu().numpy().view(np.uint32) == ek).all())
+        if not ok:
+            raise SystemExit("parity gate failed: full-matrix Gotoh differs from the oracle")
+        res[name] = {"kernel_ms": ms, "GCUPS": n * L * N / (ms * 1e-3) / 1e9, "Mreads_per_s": n / (ms * 1e-3) / 1e6, "parity_checked": m, "bit_exact": ok}
+    return res
 
 
 def cpu_leg(a, patterns, texts):

@@ -29,6 +29,7 @@
 //    wave recomputes the prefix it covers, so the sink holds exactly what the reference's holds.
 #include "common.h"
 #include <algorithm>
+#include <stdlib.h>
 
 namespace nvb {
 
@@ -205,7 +206,253 @@ __device__ __forceinline__ SweepResult sweep(const FullParams& p, const uint64_t
     return res;
 }
 
-template <int TYPE, int R, bool TRUNC>
+// ---------------------------------------------------------------------------------------------
+// Fast sweep: used when the host has proved that no DP value can leave int16 (so the boundary
+// column's truncation is the identity), scores stay below 2048 and texts below 2^20 symbols.
+// Everything a cell needs is a 2-cycle 16-bit VOP2 op (profiles/r01/valu_probe.txt) plus the
+// compare/select of the substitution score; H is carried as HG = H + G_o exactly as in the banded
+// kernel, which serves the E of the next column, the F of the next row and, with the substitution
+// scores pre-biased by -G_o, the diagonal.  LOCAL: each ROW keeps max(score << 20 | column) -- for
+// one row the reference's visiting order is the column order, so a per-row maximum with the column
+// in the low bits IS "last maximal cell of the row"; rows and lanes are merged once at the end with
+// the full (block, row, column) order key.
+// ---------------------------------------------------------------------------------------------
+template <int TYPE>
+__device__ __forceinline__ void cell16(uint32_t& e, uint32_t& hlg, uint32_t& hab_g, uint32_t& fab, uint32_t& diag_g,
+                                       const uint32_t ch, const uint32_t q, const uint32_t go, const uint32_t ge,
+                                       const uint32_t sM, const uint32_t sX, uint32_t& h_out)
+{
+    // in : e = E(r,c-1), hlg = HG(r,c-1), hab_g = HG(r-1,c), fab = F(r-1,c), diag_g = HG(r-1,c-1)
+    // out: e = E(r,c),   hlg = HG(r,c),   hab_g = HG(r,c),   fab = F(r,c),   diag_g = HG(r,c-1), h_out = H(r,c)
+    uint32_t f, d, h, t;
+    if (TYPE == NVBIO_HIP_LOCAL)
+        asm("v_cmp_eq_u32 vcc, %[ch], %[q]\n\t"
+            "v_add_u16 %[f], %[fab], %[ge]\n\t"
+            "v_cndmask_b32 %[d], %[sx], %[sm], vcc\n\t"
+            "v_add_u16 %[e], %[e], %[ge]\n\t"
+            "v_max_i16 %[f], %[f], %[hab]\n\t"
+            "v_add_u16 %[d], %[dg], %[d]\n\t"
+            "v_max_i16 %[e], %[e], %[hl]\n\t"
+            "v_max_i16 %[h], %[f], %[d]\n\t"
+            "v_max_i16 %[h], %[h], %[e]\n\t"
+            "v_max_i16 %[h], 0, %[h]\n\t"
+            "v_add_u16 %[t], %[h], %[go]"
+            : [f] "=&v"(f), [d] "=&v"(d), [h] "=&v"(h), [t] "=&v"(t), [e] "+v"(e)
+            : [ch] "v"(ch), [q] "v"(q), [fab] "v"(fab), [ge] "v"(ge), [sx] "v"(sX), [sm] "v"(sM), [hab] "v"(hab_g), [dg] "v"(diag_g), [go] "v"(go), [hl] "v"(hlg)
+            : "vcc");
+    else
+        asm("v_cmp_eq_u32 vcc, %[ch], %[q]\n\t"
+            "v_add_u16 %[f], %[fab], %[ge]\n\t"
+            "v_cndmask_b32 %[d], %[sx], %[sm], vcc\n\t"
+            "v_add_u16 %[e], %[e], %[ge]\n\t"
+            "v_max_i16 %[f], %[f], %[hab]\n\t"
+            "v_add_u16 %[d], %[dg], %[d]\n\t"
+            "v_max_i16 %[e], %[e], %[hl]\n\t"
+            "v_max_i16 %[h], %[f], %[d]\n\t"
+            "v_max_i16 %[h], %[h], %[e]\n\t"
+            "v_add_u16 %[t], %[h], %[go]"
+            : [f] "=&v"(f), [d] "=&v"(d), [h] "=&v"(h), [t] "=&v"(t), [e] "+v"(e)
+            : [ch] "v"(ch), [q] "v"(q), [fab] "v"(fab), [ge] "v"(ge), [sx] "v"(sX), [sm] "v"(sM), [hab] "v"(hab_g), [dg] "v"(diag_g), [go] "v"(go), [hl] "v"(hlg)
+            : "vcc");
+    diag_g = hlg; hlg = t; hab_g = t; fab = f; h_out = h;      // old HG(r,c-1) is the next row's diagonal: a renaming
+}
+
+__device__ __forceinline__ uint32_t c16(int32_t v) { return uint32_t(v) & 0xFFFFu; }
+__device__ __forceinline__ uint32_t max16u(uint32_t a, uint32_t b) { uint32_t r; asm("v_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+template <int TYPE, int R, bool CHECK>
+struct Sweep16
+{
+    const FullParams& p;
+    uint32_t lane, lane_last, klast, M, Ncols, Nfull;
+    int32_t  Go, Ge, min_score;
+    uint32_t go, ge, sM, sX, inf16, init_above_g;
+    uint64_t tb;
+    uint32_t q[R], HLG[R], E[R], bestk[R];
+    uint32_t out_hg, out_f, out_ch, out_cm, prev_in_hg;
+    int32_t  sg_score; uint32_t sg_col, exit_col, grp;
+    uint32_t sg_hg16;                     // SEMI_GLOBAL: best HG of this lane's last row so far (16-bit), its column in sg_col
+    uint32_t top_hg, top_prev_hg;         // GLOBAL: HG(-1,s), HG(-1,s-1)
+    uint32_t kl;                          // this lane's last valid row (for the last-row reports)
+
+    __device__ __forceinline__ Sweep16(const FullParams& _p) : p(_p) {}
+
+    __device__ __forceinline__ void init(const uint64_t pb, const uint64_t _tb, uint32_t _M, uint32_t _Ncols, uint32_t _Nfull, int32_t _min_score)
+    {
+        lane = threadIdx.x & 63u; M = _M; Ncols = _Ncols; Nfull = _Nfull; min_score = _min_score; tb = _tb;
+        Go = p.gap_open; Ge = p.gap_ext;
+        const int32_t infimum = -32768 - min(Go, Ge);
+        lane_last = (M - 1u) / uint32_t(R);
+        klast = (M - 1u) - lane_last * uint32_t(R);
+        kl = lane < lane_last ? uint32_t(R - 1) : (lane == lane_last ? klast : 0u);
+        go = c16(Go); ge = c16(Ge); sM = c16(p.match - Go); sX = c16(p.mismatch - Go); inf16 = c16(infimum);
+        #pragma unroll
+        for (int k = 0; k < R; ++k)
+        {
+            const uint32_t r = lane * R + k;
+            q[k] = r < M ? get_symbol(p.pat.s, pb + r) : 255u;
+            HLG[k] = c16(((TYPE != NVBIO_HIP_LOCAL) ? Go + Ge * int32_t(r) : 0) + Go);
+            E[k]   = c16((TYPE == NVBIO_HIP_LOCAL) ? 0 : infimum);
+            bestk[k] = 0u;
+        }
+        out_hg = out_f = out_ch = out_cm = prev_in_hg = 0;
+        sg_score = -(1 << 30); sg_col = 0; exit_col = 0xFFFFFFFFu; grp = 0; sg_hg16 = 0x8000u;
+        top_hg = c16(Go + Go); top_prev_hg = go;
+        init_above_g = c16(((TYPE != NVBIO_HIP_LOCAL) ? Go + Ge * int32_t(lane * R - 1u) : 0) + Go);
+    }
+
+    // the last-row lane's reports and the early-exit test for column c (cm = full column maximum)
+    __device__ __forceinline__ void last_row(const uint32_t c, const uint32_t cm)
+    {
+        uint32_t hg_last = HLG[0];
+        #pragma unroll
+        for (int k = 1; k < R; ++k) if (uint32_t(k) == kl) hg_last = HLG[k];
+        const int32_t hlast = int32_t(int16_t(hg_last)) - Go;
+        if (TYPE == NVBIO_HIP_SEMI_GLOBAL) { if (int16_t(hg_last) >= int16_t(sg_hg16)) { sg_hg16 = hg_last; sg_col = c; } }
+        if (TYPE == NVBIO_HIP_GLOBAL && c + 1u == Nfull) { sg_score = hlast; sg_col = c; }
+        early_exit_test(c, cm);
+    }
+    __device__ __forceinline__ void early_exit_test(const uint32_t c, const uint32_t cm)
+    {
+        if (CHECK && (c & 7u) == 7u && exit_col == 0xFFFFFFFFu)
+        {
+            const uint32_t nb = 8u * ((Nfull + 7u) / 8u);
+            const uint32_t end_block = nb > 8u ? nb : 8u;
+            const uint32_t block = c - 7u;
+            if (block + 8u < end_block && int32_t(int16_t(cm)) + int32_t(Nfull - block - 8u) * p.match < min_score) exit_col = c;
+        }
+    }
+
+    // one step; PRED = lanes may be outside the matrix (ramp-up / ramp-down)
+    template <bool PRED>
+    __device__ __forceinline__ void step(const uint32_t s, const uint32_t ch0)
+    {
+        const uint32_t c = s - lane;
+        const uint32_t th = (TYPE == NVBIO_HIP_GLOBAL) ? top_hg : go;          // HG(-1,c) for lane 0
+        const uint32_t in_hg = uint32_t(dpp_shr1(int32_t(th), int32_t(out_hg)));
+        const uint32_t in_f  = uint32_t(dpp_shr1(int32_t(inf16), int32_t(out_f)));
+        const uint32_t in_ch = uint32_t(dpp_shr1(int32_t(ch0), int32_t(out_ch)));
+        const uint32_t in_cm = CHECK ? uint32_t(dpp_shr1(int32_t(0x8000u), int32_t(out_cm))) : 0u;
+        uint32_t diag_g = prev_in_hg;
+        if (lane == 0u) diag_g = (TYPE == NVBIO_HIP_GLOBAL) ? top_prev_hg : go;
+        else if (c == 0u) diag_g = init_above_g;
+        prev_in_hg = in_hg;
+        if (TYPE == NVBIO_HIP_GLOBAL) { top_prev_hg = top_hg; uint32_t t; asm("v_add_u16 %0, %1, %2" : "=v"(t) : "v"(top_hg), "v"(ge)); top_hg = t; }
+
+        const bool active = !PRED || (int32_t(c) >= 0 && c < Ncols && lane <= lane_last);
+        if (active)
+        {
+            uint32_t hab_g = in_hg, fab = in_f, cm = in_cm, h = 0;
+            #pragma unroll
+            for (int k = 0; k < R; ++k)
+            {
+                cell16<TYPE>(E[k], HLG[k], hab_g, fab, diag_g, in_ch, q[k], go, ge, sM, sX, h);
+                if (TYPE == NVBIO_HIP_LOCAL) bestk[k] = max(bestk[k], (h << 20) | c);
+                if (CHECK) { if (uint32_t(k) <= kl) cm = max16u(cm, h); }
+            }
+            out_hg = hab_g; out_f = fab; out_ch = in_ch; out_cm = cm;
+            if (PRED)
+            {
+                if (TYPE != NVBIO_HIP_LOCAL || CHECK) { if (lane == lane_last) last_row(c, cm); }
+            }
+            else
+            {
+                // steady state: no branch.  Every lane follows its own last row (only the last-row
+                // lane's record is read at the end); the final column never falls in this phase.
+                if (TYPE == NVBIO_HIP_SEMI_GLOBAL)
+                {
+                    uint32_t hg_last = HLG[0];
+                    #pragma unroll
+                    for (int k = 1; k < R; ++k) hg_last = (uint32_t(k) == kl) ? HLG[k] : hg_last;
+                    const bool upd = int16_t(hg_last) >= int16_t(sg_hg16);
+                    sg_hg16 = upd ? hg_last : sg_hg16;
+                    sg_col  = upd ? c : sg_col;
+                }
+                if (CHECK) { if (lane == lane_last) early_exit_test(c, cm); }
+            }
+        }
+    }
+
+    __device__ __forceinline__ SweepResult run()
+    {
+        const uint32_t n_steps = Ncols + lane_last;
+        uint32_t s = 0;
+        // ramp-up, up to the first 16-aligned step at which every row-holding lane is inside the matrix
+        const uint32_t s_fast = (lane_last + 15u) & ~15u;
+        for (; s < n_steps && s < s_fast; ++s)
+        {
+            if ((s & 15u) == 0u && s < Ncols) grp = fetch16_2bit(p.txt.s, tb + s);
+            step<true>(s, (grp >> (2u * (s & 15u))) & 3u);
+        }
+        // steady state: 16 unpredicated steps per text group (lanes past the last row compute harmlessly)
+        for (; s + 16u < Ncols; s += 16u)        // strict: the last column is always handled by the tail
+        {
+            grp = fetch16_2bit(p.txt.s, tb + s);
+            #pragma unroll
+            for (int u = 0; u < 16; ++u) step<false>(s + u, (grp >> (2 * u)) & 3u);
+        }
+        // tail and ramp-down
+        for (; s < n_steps; ++s)
+        {
+            if ((s & 15u) == 0u && s < Ncols) grp = fetch16_2bit(p.txt.s, tb + s);
+            step<true>(s, (grp >> (2u * (s & 15u))) & 3u);
+        }
+
+        SweepResult res;
+        res.exit_col = uint32_t(__shfl(int32_t(exit_col), int32_t(lane_last)));
+        res.score = -(1 << 30); res.sx = res.sy = 0xFFFFFFFFu;
+        const uint32_t KM = 8u * 64u * uint32_t(R);
+        if (TYPE == NVBIO_HIP_LOCAL)
+        {
+            // merge this lane's rows, then the lanes, with the reference's order key
+            uint64_t b = 0; uint32_t hv = 0;
+            const uint32_t nvalid = lane > lane_last ? 0u : (lane == lane_last ? klast + 1u : uint32_t(R));
+            #pragma unroll
+            for (int k = 0; k < R; ++k)
+            {
+                if (uint32_t(k) < nvalid && Ncols > 0u) {
+                    const uint32_t hh = bestk[k] >> 20, cc = bestk[k] & 0xFFFFFu, r = lane * R + k;
+                    const uint64_t cand = (uint64_t(hh) << 32) | ((cc >> 3) * KM + r * 8u + (cc & 7u));
+                    if (!hv || cand > b) { b = cand; hv = 1u; }
+                }
+            }
+            #pragma unroll
+            for (int off = 32; off >= 1; off >>= 1)
+            {
+                const uint32_t olo = uint32_t(__shfl_xor(int32_t(uint32_t(b)), off));
+                const uint32_t ohi = uint32_t(__shfl_xor(int32_t(uint32_t(b >> 32)), off));
+                const uint32_t ohv = uint32_t(__shfl_xor(int32_t(hv), off));
+                const uint64_t o = (uint64_t(ohi) << 32) | olo;
+                if (ohv && (!hv || o > b)) { b = o; hv = 1u; }
+            }
+            if (hv) {
+                const uint32_t key = uint32_t(b);
+                const uint32_t col = (key / KM) * 8u + (key & 7u), row = (key % KM) >> 3;
+                res.score = int32_t(uint32_t(b >> 32)); res.sx = col + 1u; res.sy = row + 1u;
+            }
+        }
+        else
+        {
+            if (TYPE == NVBIO_HIP_SEMI_GLOBAL) sg_score = int32_t(int16_t(sg_hg16)) - Go;
+            const int32_t  sc  = __shfl(sg_score, int32_t(lane_last));
+            const uint32_t col = uint32_t(__shfl(int32_t(sg_col), int32_t(lane_last)));
+            const bool reported = (TYPE == NVBIO_HIP_SEMI_GLOBAL) ? (Ncols > 0u) : (Ncols == Nfull && Nfull > 0u);
+            if (reported) { res.score = sc; res.sx = col + 1u; res.sy = M; }
+        }
+        return res;
+    }
+};
+
+template <int TYPE, int R, bool CHECK>
+__device__ __forceinline__ SweepResult sweep16(const FullParams& p, const uint64_t pb, const uint64_t tb,
+                                               const uint32_t M, const uint32_t Ncols, const uint32_t Nfull, const int32_t min_score)
+{
+    Sweep16<TYPE, R, CHECK> sw(p);
+    sw.init(pb, tb, M, Ncols, Nfull, min_score);
+    return sw.run();
+}
+
+template <int TYPE, int R, bool TRUNC, bool FAST>
 __global__ void __launch_bounds__(256)
 full_gotoh_score_kernel(const FullParams p)
 {
@@ -233,12 +480,15 @@ full_gotoh_score_kernel(const FullParams p)
     }
     else
     {
-        SweepResult r = sweep<TYPE, R, TRUNC>(p, pb, tb, M, N, N, check, min_score);
+        SweepResult r = FAST ? (check ? sweep16<TYPE, R, true>(p, pb, tb, M, N, N, min_score)
+                                      : sweep16<TYPE, R, false>(p, pb, tb, M, N, N, min_score))
+                             : sweep<TYPE, R, TRUNC>(p, pb, tb, M, N, N, check, min_score);
         if (r.exit_col != 0xFFFFFFFFu)
         {
             // the reference returned false after this block: its sink saw columns [0, exit_col] only
             ok = 0u;
-            r = sweep<TYPE, R, TRUNC>(p, pb, tb, M, r.exit_col + 1u, N, false, min_score);
+            r = FAST ? sweep16<TYPE, R, false>(p, pb, tb, M, r.exit_col + 1u, N, min_score)
+                     : sweep<TYPE, R, TRUNC>(p, pb, tb, M, r.exit_col + 1u, N, false, min_score);
         }
         score = r.score; sx = r.sx; sy = r.sy;
     }
@@ -250,14 +500,14 @@ full_gotoh_score_kernel(const FullParams p)
     }
 }
 
-template <int R, bool TRUNC>
+template <int R, bool TRUNC, bool FAST>
 static hipError_t launch_full(const FullParams& p, int type, hipStream_t s)
 {
     const dim3 grid((uint64_t(p.n) * 64u + 255u) / 256u), block(256);
     switch (type) {
-    case NVBIO_HIP_GLOBAL:      hipLaunchKernelGGL((full_gotoh_score_kernel<NVBIO_HIP_GLOBAL, R, TRUNC>),      grid, block, 0, s, p); break;
-    case NVBIO_HIP_LOCAL:       hipLaunchKernelGGL((full_gotoh_score_kernel<NVBIO_HIP_LOCAL, R, TRUNC>),       grid, block, 0, s, p); break;
-    case NVBIO_HIP_SEMI_GLOBAL: hipLaunchKernelGGL((full_gotoh_score_kernel<NVBIO_HIP_SEMI_GLOBAL, R, TRUNC>), grid, block, 0, s, p); break;
+    case NVBIO_HIP_GLOBAL:      hipLaunchKernelGGL((full_gotoh_score_kernel<NVBIO_HIP_GLOBAL, R, TRUNC, FAST>),      grid, block, 0, s, p); break;
+    case NVBIO_HIP_LOCAL:       hipLaunchKernelGGL((full_gotoh_score_kernel<NVBIO_HIP_LOCAL, R, TRUNC, FAST>),       grid, block, 0, s, p); break;
+    case NVBIO_HIP_SEMI_GLOBAL: hipLaunchKernelGGL((full_gotoh_score_kernel<NVBIO_HIP_SEMI_GLOBAL, R, TRUNC, FAST>), grid, block, 0, s, p); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -290,16 +540,30 @@ NVB_API int nvbio_hip_gotoh_score(
     p.match = scheme->match; p.mismatch = scheme->mismatch; p.gap_open = scheme->gap_open; p.gap_ext = scheme->gap_ext;
     p.min_score = min_score; p.n = n; p.out_score = out_score; p.out_sink = out_sink; p.out_ok = out_ok;
 
-    // can any H / E leave int16?  |value| <= (maxM + maxN + 2) * max|cost| (+ the short-based infimum)
+    // can any H / E leave int16?  LOCAL: 0 <= H <= M*match, E/F a few gap costs below.  SEMI_GLOBAL (pattern
+    // global, text free): every cell is reachable from the zero row above its column, so values stay within
+    // (M+2) * max|cost| whatever the text length.  GLOBAL: the row above the matrix itself reaches G_o + G_e*N.
     auto iabs = [](int32_t v) { return v < 0 ? -int64_t(v) : int64_t(v); };
     const int64_t A = std::max(std::max(iabs(scheme->match), iabs(scheme->mismatch)), std::max(iabs(scheme->gap_open), iabs(scheme->gap_ext)));
-    const bool trunc = !(scheme->gap_open <= 0 && scheme->gap_ext <= 0 && (int64_t(maxM) + maxN + 2) * A < 30000);
+    const int64_t span = (type == NVBIO_HIP_GLOBAL) ? int64_t(maxM) + maxN + 4 : int64_t(maxM) + 4;
+    const bool trunc = !(scheme->gap_open <= 0 && scheme->gap_ext <= 0 && span * A < 30000);
     hipStream_t s = to_stream(stream);
     g_last_kernel = "full_gotoh_score_kernel";
-    const int R = maxM <= 64u ? 1 : maxM <= 128u ? 2 : 4;
+    const int R = maxM <= 64u ? 1 : maxM <= 128u ? 2 : maxM <= 192u ? 3 : 4;
+    // the 16-bit sweep needs: values inside int16 (= !trunc), LOCAL scores < 2048 and columns < 2^20 for its packed row maxima
+    const char* nofast = getenv("NVBIO_HIP_FULL_GENERIC");
+    const bool fast = !trunc && maxN < (1u << 20) && (type != NVBIO_HIP_LOCAL || (scheme->match >= 0 && int64_t(maxM) * scheme->match < 2048))
+                      && !(nofast && nofast[0] == '1');
+    if (fast) {
+        g_last_kernel = "full_gotoh_score_kernel<16-bit>";
+        switch (R) { case 1: return launch_full<1, false, true>(p, type, s); case 2: return launch_full<2, false, true>(p, type, s);
+                     case 3: return launch_full<3, false, true>(p, type, s); default: return launch_full<4, false, true>(p, type, s); }
+    }
     if (trunc) {
-        switch (R) { case 1: return launch_full<1, true>(p, type, s); case 2: return launch_full<2, true>(p, type, s); default: return launch_full<4, true>(p, type, s); }
+        switch (R) { case 1: return launch_full<1, true, false>(p, type, s); case 2: return launch_full<2, true, false>(p, type, s);
+                     case 3: return launch_full<3, true, false>(p, type, s); default: return launch_full<4, true, false>(p, type, s); }
     } else {
-        switch (R) { case 1: return launch_full<1, false>(p, type, s); case 2: return launch_full<2, false>(p, type, s); default: return launch_full<4, false>(p, type, s); }
+        switch (R) { case 1: return launch_full<1, false, false>(p, type, s); case 2: return launch_full<2, false, false>(p, type, s);
+                     case 3: return launch_full<3, false, false>(p, type, s); default: return launch_full<4, false, false>(p, type, s); }
     }
 }

@@ -1,6 +1,8 @@
 """Full-matrix Gotoh score (text-blocking form, the aligner sw-benchmark instantiates) through the
 C-ABI vs the oracle's restatement of gotoh_inl.h:969-1489: bit-exact score, sink and ok flag,
 including the LOCAL tie order, the int16 boundary column and the early exit."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -23,12 +25,17 @@ def run(ty, scheme, pats, txts, dev, min_score=None, maxM=None, maxN=None, pbits
     ms = torch.from_numpy(np.ascontiguousarray(min_score, dtype=np.int32)).to(dev) if min_score is not None else None
     maxM = maxM or max(1, max(len(x) for x in pats))
     maxN = maxN or max(1, max(len(x) for x in txts))
-    gs, gk, go = nvb.batch_alignment_score(nvb.make_gotoh_aligner(ty, nvb.SimpleGotohScheme(*scheme)), p, t, maxM, maxN, ms)
-    torch.cuda.synchronize()
-    gs, gk, go = gs.cpu().numpy(), gk.cpu().numpy().view(np.uint32), go.cpu().numpy()
-    bad = np.nonzero((es != gs) | (ek != gk).any(1) | (eo != go))[0]
-    assert bad.size == 0, "type %d scheme %s: %d mismatches; first %d: M=%d N=%d cpu (%d,%s,%d) gpu (%d,%s,%d)" % (
-        ty, scheme, bad.size, bad[0], len(pats[bad[0]]), len(txts[bad[0]]), es[bad[0]], ek[bad[0]], eo[bad[0]], gs[bad[0]], gk[bad[0]], go[bad[0]])
+    for generic in ("0", "1"):          # the 16-bit systolic sweep (when eligible) and the generic 32-bit one
+        os.environ["NVBIO_HIP_FULL_GENERIC"] = generic
+        try:
+            gs, gk, go = nvb.batch_alignment_score(nvb.make_gotoh_aligner(ty, nvb.SimpleGotohScheme(*scheme)), p, t, maxM, maxN, ms)
+            torch.cuda.synchronize()
+        finally:
+            os.environ["NVBIO_HIP_FULL_GENERIC"] = "0"
+        gs, gk, go = gs.cpu().numpy(), gk.cpu().numpy().view(np.uint32), go.cpu().numpy()
+        bad = np.nonzero((es != gs) | (ek != gk).any(1) | (eo != go))[0]
+        assert bad.size == 0, "type %d scheme %s generic=%s: %d mismatches; first %d: M=%d N=%d cpu (%d,%s,%d) gpu (%d,%s,%d)" % (
+            ty, scheme, generic, bad.size, bad[0], len(pats[bad[0]]), len(txts[bad[0]]), es[bad[0]], ek[bad[0]], eo[bad[0]], gs[bad[0]], gk[bad[0]], go[bad[0]])
     return es, ek, eo
 
 
@@ -64,7 +71,7 @@ def make_pairs(rng, n, max_m, max_n):
 
 
 @pytest.mark.parametrize("ty", [nvb.GLOBAL, nvb.LOCAL, nvb.SEMI_GLOBAL])
-@pytest.mark.parametrize("max_m", [64, 128, 256])
+@pytest.mark.parametrize("max_m", [64, 128, 192, 256])
 def test_random_pairs(cuda, ty, max_m):
     rng = np.random.default_rng(ty * 10 + max_m)
     pats, txts = make_pairs(rng, 1500, max_m, 400)
