@@ -148,6 +148,51 @@ void batch_banded_alignment_score(
                                                 patterns.size(), sinks.score, sinks.sink, hip_stream), "nvbio_hip_banded_gotoh_score_qual");
 }
 
+/// algorithm tags (alignment_base.h:72-79); the full-matrix path implements the text-blocking form
+struct PatternBlockingTag {};
+struct TextBlockingTag {};
+
+/// BatchedAlignmentScore<stream, scheduler> (batched.h:310-329) for the full-matrix Gotoh score with
+/// the text-blocking aligner, as sw-benchmark instantiates it (sw-benchmark.cu:604-631)
+template <typename stream_type, typename algorithm_type = DeviceThreadScheduler>
+struct BatchedAlignmentScore
+{
+    typedef typename stream_type::aligner_type aligner_type;
+    static uint64 min_temp_storage(const uint32, const uint32, const uint32) { return 0u; }   // no column storage: the
+    static uint64 max_temp_storage(const uint32, const uint32, const uint32) { return 0u; }   // pattern lives in a wave's registers
+
+    /// min_score / ok: optional device arrays (the reference's context.min_score and per-job bool)
+    void enact(stream_type stream, uint64 temp_size = 0u, uint8* temp = nullptr,
+               const int32* min_score = nullptr, uint8* ok = nullptr, void* hip_stream = nullptr)
+    {
+        (void)temp_size; (void)temp;
+        const nvbio_hip_gotoh_scheme sc = { stream.aligner().scheme.m_match, stream.aligner().scheme.m_mismatch,
+                                            stream.aligner().scheme.m_gap_open, stream.aligner().scheme.m_gap_ext };
+        const nvbio_hip_string_set p = stream.m_patterns.abi(), t = stream.m_texts.abi();
+        hip_check(nvbio_hip_gotoh_score(&sc, int32(aligner_type::TYPE), &p, &t, stream.max_pattern_length(), stream.max_text_length(),
+                                        min_score, stream.size(), stream.m_sinks.score, stream.m_sinks.sink, ok, hip_stream),
+                  "nvbio_hip_gotoh_score");
+    }
+};
+
+/// batch_alignment_score(aligner, patterns, texts, sinks, scheduler, maxP, maxT)   (batched.h:160-190)
+template <typename aligner_type, typename pattern_set_type, typename text_set_type, typename scheduler_type>
+void batch_alignment_score(
+    const aligner_type      aligner,
+    const pattern_set_type  patterns,
+    const text_set_type     texts,
+          BestSinkArrays    sinks,
+    const scheduler_type    scheduler,
+    const uint32            max_pattern_length,
+    const uint32            max_text_length)
+{
+    (void)scheduler;
+    typedef PackedAlignmentStream<aligner_type, pattern_set_type, text_set_type> stream_type;
+    stream_type stream(aligner, patterns, texts, sinks, max_pattern_length, max_text_length);
+    BatchedAlignmentScore<stream_type, scheduler_type> batch;
+    batch.enact(stream);
+}
+
 /// batch_banded_alignment_score<BAND_LEN>(aligner, patterns, texts, sinks, scheduler, maxP, maxT)
 template <uint32 BAND_LEN, typename aligner_type, typename pattern_set_type, typename text_set_type, typename scheduler_type>
 void batch_banded_alignment_score(

@@ -302,11 +302,8 @@ struct Sweep16
     }
 
     // the last-row lane's reports and the early-exit test for column c (cm = full column maximum)
-    __device__ __forceinline__ void last_row(const uint32_t c, const uint32_t cm)
+    __device__ __forceinline__ void last_row(const uint32_t c, const uint32_t cm, const uint32_t hg_last)
     {
-        uint32_t hg_last = HLG[0];
-        #pragma unroll
-        for (int k = 1; k < R; ++k) if (uint32_t(k) == kl) hg_last = HLG[k];
         const int32_t hlast = int32_t(int16_t(hg_last)) - Go;
         if (TYPE == NVBIO_HIP_SEMI_GLOBAL) { if (int16_t(hg_last) >= int16_t(sg_hg16)) { sg_hg16 = hg_last; sg_col = c; } }
         if (TYPE == NVBIO_HIP_GLOBAL && c + 1u == Nfull) { sg_score = hlast; sg_col = c; }
@@ -342,18 +339,19 @@ struct Sweep16
         const bool active = !PRED || (int32_t(c) >= 0 && c < Ncols && lane <= lane_last);
         if (active)
         {
-            uint32_t hab_g = in_hg, fab = in_f, cm = in_cm, h = 0;
+            uint32_t hab_g = in_hg, fab = in_f, cm = in_cm, h = 0, hg_last = 0;
             #pragma unroll
             for (int k = 0; k < R; ++k)
             {
                 cell16<TYPE>(E[k], HLG[k], hab_g, fab, diag_g, in_ch, q[k], go, ge, sM, sX, h);
                 if (TYPE == NVBIO_HIP_LOCAL) bestk[k] = max(bestk[k], (h << 20) | c);
                 if (CHECK) { if (uint32_t(k) <= kl) cm = max16u(cm, h); }
+                if (TYPE != NVBIO_HIP_LOCAL) hg_last = (uint32_t(k) == kl) ? hab_g : hg_last;   // HG of this lane's last valid row
             }
             out_hg = hab_g; out_f = fab; out_ch = in_ch; out_cm = cm;
             if (PRED)
             {
-                if (TYPE != NVBIO_HIP_LOCAL || CHECK) { if (lane == lane_last) last_row(c, cm); }
+                if (TYPE != NVBIO_HIP_LOCAL || CHECK) { if (lane == lane_last) last_row(c, cm, hg_last); }
             }
             else
             {
@@ -361,9 +359,6 @@ struct Sweep16
                 // lane's record is read at the end); the final column never falls in this phase.
                 if (TYPE == NVBIO_HIP_SEMI_GLOBAL)
                 {
-                    uint32_t hg_last = HLG[0];
-                    #pragma unroll
-                    for (int k = 1; k < R; ++k) hg_last = (uint32_t(k) == kl) ? HLG[k] : hg_last;
                     const bool upd = int16_t(hg_last) >= int16_t(sg_hg16);
                     sg_hg16 = upd ? hg_last : sg_hg16;
                     sg_col  = upd ? c : sg_col;

@@ -18,6 +18,10 @@ using namespace nvbio;
 // ---- the oracle's C entry points (oracle/nvbio_oracle.c) --------------------------------------
 extern "C" {
 typedef struct { uint32_t length, primary, L2[5]; const uint32_t* bwt_occ; const uint32_t* ssa; uint32_t sa_int; } oracle_fmi_t;
+void oracle_batch_gotoh_score(int type, const int32_t* scheme,
+    const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, const uint64_t* pat_begin, const uint32_t* pat_len,
+    const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, const uint64_t* txt_begin, const uint32_t* txt_len,
+    const int32_t* min_score, uint32_t n, int32_t* out_score, uint32_t* out_sink, uint8_t* out_ok, int n_threads);
 void oracle_batch_banded_gotoh_score(uint32_t band, int type, const int32_t* scheme,
     const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, const uint64_t* pat_begin, const uint32_t* pat_len,
     const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, const uint64_t* txt_begin, const uint32_t* txt_len,
@@ -80,6 +84,35 @@ static void run_batch(const char* name, const aln::SimpleGotohScheme scoring,
     fprintf(stderr, "    %-44s : %u jobs ok\n", name, n);
 }
 
+// full-matrix Gotoh through batch_alignment_score (sw-benchmark's instantiation), device vs host
+template <aln::AlignmentType TYPE>
+static void run_full_batch(const char* name, const aln::SimpleGotohScheme scoring,
+                           const std::vector<std::vector<uint8> >& patterns, const std::vector<std::vector<uint8> >& texts)
+{
+    const uint32 n = uint32(patterns.size());
+    PackedStringSetDevice<4, true>  d_patterns(patterns);
+    PackedStringSetDevice<2, false> d_texts(texts);
+    hip::device_vector<int32>  d_score(n);
+    hip::device_vector<uint32> d_sink(2 * size_t(n));
+    aln::BestSinkArrays sinks = { d_score.data(), d_sink.data() };
+    uint32 maxP = 1, maxT = 1;
+    for (uint32 i = 0; i < n; ++i) { maxP = std::max(maxP, uint32(patterns[i].size())); maxT = std::max(maxT, uint32(texts[i].size())); }
+    aln::batch_alignment_score(aln::make_gotoh_aligner<TYPE>(scoring), d_patterns.view(), d_texts.view(), sinks, aln::DeviceThreadScheduler(), maxP, maxT);
+    hip::synchronize();
+    const std::vector<int32> score = d_score.to_host(); const std::vector<uint32> sink = d_sink.to_host();
+    std::vector<uint8> pc, tc; std::vector<uint64> pb(n), tb(n); std::vector<uint32> pl(n), tl(n);
+    for (uint32 i = 0; i < n; ++i) { pb[i] = pc.size(); pl[i] = uint32(patterns[i].size()); pc.insert(pc.end(), patterns[i].begin(), patterns[i].end());
+                                     tb[i] = tc.size(); tl[i] = uint32(texts[i].size());    tc.insert(tc.end(), texts[i].begin(), texts[i].end()); }
+    const std::vector<uint32> pw = pack_symbols<4, true>(pc.data(), pc.size()), tw = pack_symbols<2, false>(tc.data(), tc.size());
+    std::vector<int32> hs(n); std::vector<uint32> hk(2 * size_t(n));
+    const int32 sc[4] = { scoring.m_match, scoring.m_mismatch, scoring.m_gap_open, scoring.m_gap_ext };
+    oracle_batch_gotoh_score(int(TYPE), sc, pw.data(), 4, 1, pb.data(), pl.data(), tw.data(), 2, 0, tb.data(), tl.data(), nullptr, n, hs.data(), hk.data(), nullptr, 0);
+    for (uint32 i = 0; i < n; ++i)
+        if (score[i] != hs[i] || sink[2 * i] != hk[2 * i] || sink[2 * i + 1] != hk[2 * i + 1])
+            FAIL("%s: job %u: device (%d, %u,%u) != host (%d, %u,%u)", name, i, score[i], sink[2 * i], sink[2 * i + 1], hs[i], hk[2 * i], hk[2 * i + 1]);
+    fprintf(stderr, "    %-44s : %u jobs ok\n", name, n);
+}
+
 template <uint32 BAND_LEN, aln::AlignmentType TYPE>
 static void expect_single(const char* name, aln::SimpleGotohScheme sc, const char* p, const char* t, int32 score, uint32 sx, uint32 sy)
 {
@@ -127,6 +160,19 @@ static int alignment_test()
     run_batch<7,  aln::SEMI_GLOBAL, 4, true,  false>("batch semi-global 7",               s3, pats, txts);
     run_batch<3,  aln::LOCAL,       4, true,  false>("batch local 3",                     s2, pats, txts);
     run_batch<5,  aln::GLOBAL,      4, true,  false>("batch global 5",                    s2, pats, txts);
+    // full-matrix Gotoh (the sw-benchmark instantiation): reads against longer references
+    {
+        std::vector<std::vector<uint8> > fp(2048), ft(2048);
+        for (uint32 i = 0; i < 2048; ++i) {
+            ft[i].resize(300 + i % 200); for (size_t j = 0; j < ft[i].size(); ++j) ft[i][j] = uint8(rnd.sym());
+            const uint32 L = 30 + i % 120, off = i % 100;
+            fp[i].assign(ft[i].begin() + off, ft[i].begin() + off + L);
+            for (uint32 j = 0; j < L; ++j) if ((rnd.next() >> 16) % 100 < 6) fp[i][j] = uint8(rnd.sym());
+        }
+        run_full_batch<aln::LOCAL>      ("batch gotoh full local",       s2, fp, ft);
+        run_full_batch<aln::SEMI_GLOBAL>("batch gotoh full semi-global", s2, fp, ft);
+        run_full_batch<aln::GLOBAL>     ("batch gotoh full global",      s3, fp, ft);
+    }
     fprintf(stderr, "testing alignment... done\n");
     return 0;
 }
