@@ -122,6 +122,42 @@ int nvbio_hip_banded_gotoh_score_qual(
     uint32_t max_pattern_len, uint32_t max_text_len,
     uint32_t n, int32_t* out_score, uint32_t* out_sink, void* stream);
 
+/* Batched banded Gotoh traceback.  Replaces
+ *   BatchedBandedAlignmentTraceback<BAND_LEN, CHECKPOINTS, stream, DeviceThreadScheduler>::enact
+ *   (nvbio/alignment/batched.h:460-476, batched_banded_inl.h:250-420)
+ * for aligner = GotohAligner<TYPE, scheme> and the CIGAR-forming backtracer nvBowtie passes
+ * (Backtracker<io::Cigar*>, nvBowtie/bowtie2/cuda/alignment_utils.h:125-168), the instantiation of
+ * nvBowtie's traceback stage (traceback_inl.h:205-262).  Job i re-scores patterns[i] in the band of
+ * texts[i] (banded_alignment_traceback, nvbio/alignment/banded_inl.h:352-423) and walks the flow flags
+ * back (gotoh_banded_inl.h:878-960):
+ *   out_score[i], out_sink[2i..]     Alignment::score / ::sink   (== nvbio_hip_banded_gotoh_score's)
+ *   out_source[2i..]                 Alignment::source           ((-1,-1) when there is no valid sink)
+ *   out_cigar[i*cigar_stride + k]    io::Cigar as a uint16: type | len << 2 (nvbio/io/alignments.h:57-75;
+ *                                    0 = M, 1 = I, 2 = D, 3 = soft clip), in the backtracer's order, i.e.
+ *                                    the END of the alignment first, exactly what context->cigar holds
+ *   out_cigar_len[i]                 backtracer.size; entries beyond cigar_stride are counted, not written
+ * CHECKPOINTS has no equivalent: the flow flags of the whole band are kept in `temp`
+ * (nvbio_hip_banded_gotoh_traceback_temp_bytes), which reproduces the reference for every interval
+ * as long as the DP values fit its int16 checkpoints; schemes/lengths with
+ * (max_pattern_len + band_len + 2) * max|cost| >= 32000 are refused with 801.
+ * max_pattern_len is required for ragged pattern sets. */
+uint64_t nvbio_hip_banded_gotoh_traceback_temp_bytes(uint32_t band_len, uint32_t max_pattern_len, uint32_t n);
+int nvbio_hip_banded_gotoh_traceback(
+    const nvbio_hip_gotoh_scheme* scheme /* host */, int32_t type, uint32_t band_len,
+    const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len, uint32_t n,
+    int32_t* out_score, uint32_t* out_sink, uint32_t* out_source,
+    uint16_t* out_cigar, uint32_t cigar_stride, uint32_t* out_cigar_len,
+    void* temp, uint64_t temp_bytes, void* stream);
+int nvbio_hip_banded_gotoh_traceback_qual(
+    const nvbio_hip_gotoh_qual_scheme* scheme /* host */, int32_t type, uint32_t band_len,
+    const nvbio_hip_string_set* patterns, const uint8_t* quals, uint64_t n_quals,
+    const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len, uint32_t n,
+    int32_t* out_score, uint32_t* out_sink, uint32_t* out_source,
+    uint16_t* out_cigar, uint32_t cigar_stride, uint32_t* out_cigar_len,
+    void* temp, uint64_t temp_bytes, void* stream);
+
 /* nvbio::fm_index<rank_dictionary<2,64,PackedStream<.,uint8,2,true>,.,.>, SSA_index_multiple_context<SA_INT>, const uint32*>
  * (nvbio/fmindex/fmindex.h:341-387) in the production interleaved layout
  * (nvbio/io/fmindex/fmindex.h:159-174, fmindex_impl.cu:305-327):

@@ -148,6 +148,88 @@ void batch_banded_alignment_score(
                                                 patterns.size(), sinks.score, sinks.sink, hip_stream), "nvbio_hip_banded_gotoh_score_qual");
 }
 
+} // namespace aln
+
+/// io::Cigar (nvbio/io/alignments.h:57-75): what nvBowtie's Backtracker writes
+namespace io {
+struct Cigar
+{
+    enum Operation { SUBSTITUTION = 0, INSERTION = 1, DELETION = 2, SOFT_CLIPPING = 3 };
+    Cigar() {}
+    Cigar(const uint8 type, const uint16 len) : m_type(type), m_len(len) {}
+    uint16 m_type:2, m_len:14;
+};
+} // namespace io
+
+namespace aln {
+
+/// Alignment<int32> (alignment.h: score, source, sink) as device structure-of-arrays + the CIGARs the
+/// backtracer formed: job i's entries are cigar[i*cigar_stride .. + cigar_len[i]), end of the alignment
+/// first (the Backtracker stores them backwards, alignment_utils.h:121-123)
+struct AlignmentArrays { int32* score; uint32* source; uint32* sink; };
+struct CigarArrays     { io::Cigar* cigar; uint32 cigar_stride; uint32* cigar_len; };
+
+/// The stream handed to BatchedBandedAlignmentTraceback::enact: the score stream's data plus the
+/// traceback outputs (and, for nvBowtie's quality-aware scheme, the read qualities).
+template <typename t_aligner_type, typename pattern_set_type, typename text_set_type>
+struct PackedTracebackStream
+{
+    typedef t_aligner_type aligner_type;
+    PackedTracebackStream(aligner_type _aligner, pattern_set_type _patterns, text_set_type _texts,
+                          AlignmentArrays _alignments, CigarArrays _cigars, uint32 _max_pattern_len, uint32 _max_text_len = 0,
+                          const uint8* _quals = nullptr, uint64 _n_quals = 0)
+        : m_aligner(_aligner), m_patterns(_patterns), m_texts(_texts), m_alignments(_alignments), m_cigars(_cigars),
+          m_max_pattern_len(_max_pattern_len), m_max_text_len(_max_text_len), m_quals(_quals), m_n_quals(_n_quals) {}
+    const aligner_type& aligner() const { return m_aligner; }
+    uint32 size() const { return m_patterns.size(); }
+    uint32 max_pattern_length() const { return m_max_pattern_len; }
+    uint32 max_text_length() const { return m_max_text_len; }
+    aligner_type m_aligner; pattern_set_type m_patterns; text_set_type m_texts;
+    AlignmentArrays m_alignments; CigarArrays m_cigars;
+    uint32 m_max_pattern_len, m_max_text_len; const uint8* m_quals; uint64 m_n_quals;
+};
+
+/// BatchedBandedAlignmentTraceback<BAND_LEN, CHECKPOINTS, stream, scheduler> (batched.h:460-476).
+/// CHECKPOINTS is kept for signature parity; the temp storage holds the flow flags of the whole band
+/// (min_temp_storage == max_temp_storage, and enact requires it).
+template <uint32 BAND_LEN, uint32 CHECKPOINTS, typename stream_type, typename algorithm_type = DeviceThreadScheduler>
+struct BatchedBandedAlignmentTraceback
+{
+    typedef typename stream_type::aligner_type aligner_type;
+    static uint64 min_temp_storage(const uint32 max_pattern_len, const uint32, const uint32 stream_size)
+    { return nvbio_hip_banded_gotoh_traceback_temp_bytes(BAND_LEN, max_pattern_len, stream_size); }
+    static uint64 max_temp_storage(const uint32 max_pattern_len, const uint32 max_text_len, const uint32 stream_size)
+    { return min_temp_storage(max_pattern_len, max_text_len, stream_size); }
+
+    void enact(stream_type stream, uint64 temp_size, uint8* temp, void* hip_stream = nullptr)
+    {
+        static_assert(BAND_LEN == 3 || BAND_LEN == 5 || BAND_LEN == 7 || BAND_LEN == 15 || BAND_LEN == 31, "unsupported BAND_LEN");
+        static_assert(sizeof(io::Cigar) == 2, "io::Cigar must be a uint16 bit-field");
+        call(stream.aligner().scheme, stream, temp_size, temp, hip_stream);
+    }
+private:
+    static void call(const SimpleGotohScheme& scheme, stream_type& stream, uint64 temp_size, uint8* temp, void* hip_stream)
+    {
+        const nvbio_hip_gotoh_scheme sc = { scheme.m_match, scheme.m_mismatch, scheme.m_gap_open, scheme.m_gap_ext };
+        const nvbio_hip_string_set p = stream.m_patterns.abi(), t = stream.m_texts.abi();
+        hip_check(nvbio_hip_banded_gotoh_traceback(&sc, int32(aligner_type::TYPE), BAND_LEN, &p, &t,
+                      stream.max_pattern_length(), stream.max_text_length(), stream.size(),
+                      stream.m_alignments.score, stream.m_alignments.sink, stream.m_alignments.source,
+                      reinterpret_cast<uint16*>(stream.m_cigars.cigar), stream.m_cigars.cigar_stride, stream.m_cigars.cigar_len,
+                      temp, temp_size, hip_stream), "nvbio_hip_banded_gotoh_traceback");
+    }
+    static void call(const SmithWatermanScoringScheme& scheme, stream_type& stream, uint64 temp_size, uint8* temp, void* hip_stream)
+    {
+        const nvbio_hip_gotoh_qual_scheme sc = scheme.abi();
+        const nvbio_hip_string_set p = stream.m_patterns.abi(), t = stream.m_texts.abi();
+        hip_check(nvbio_hip_banded_gotoh_traceback_qual(&sc, int32(aligner_type::TYPE), BAND_LEN, &p, stream.m_quals, stream.m_n_quals, &t,
+                      stream.max_pattern_length(), stream.max_text_length(), stream.size(),
+                      stream.m_alignments.score, stream.m_alignments.sink, stream.m_alignments.source,
+                      reinterpret_cast<uint16*>(stream.m_cigars.cigar), stream.m_cigars.cigar_stride, stream.m_cigars.cigar_len,
+                      temp, temp_size, hip_stream), "nvbio_hip_banded_gotoh_traceback_qual");
+    }
+};
+
 /// algorithm tags (alignment_base.h:72-79); the full-matrix path implements the text-blocking form
 struct PatternBlockingTag {};
 struct TextBlockingTag {};

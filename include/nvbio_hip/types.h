@@ -14,6 +14,7 @@
 namespace nvbio {
 
 typedef uint8_t  uint8;
+typedef uint16_t uint16;
 typedef int32_t  int32;
 typedef uint32_t uint32;
 typedef int64_t  int64;

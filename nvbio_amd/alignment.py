@@ -137,6 +137,74 @@ def batch_banded_alignment_score(band_len, aligner, patterns, texts, out_score=N
     return out_score, out_sink
 
 
+class BatchedBandedAlignmentTraceback:
+    """BatchedBandedAlignmentTraceback<BAND_LEN, CHECKPOINTS, stream, DeviceThreadScheduler> (batched.h:460-476)
+    with nvBowtie's CIGAR-forming backtracer (alignment_utils.h:125-168).  CHECKPOINTS is accepted for
+    signature parity and ignored: the whole band's flow flags live in the temp storage."""
+
+    def __init__(self, band_len, checkpoints=32):
+        if band_len not in (3, 5, 7, 15, 31):
+            raise ValueError("unsupported BAND_LEN %d" % band_len)
+        self.band_len = band_len
+        self.checkpoints = checkpoints
+
+    def min_temp_storage(self, max_pattern_len, max_text_len, stream_size):
+        return int(lib().nvbio_hip_banded_gotoh_traceback_temp_bytes(self.band_len, int(max_pattern_len), int(stream_size)))
+
+    max_temp_storage = min_temp_storage
+
+    def enact(self, aligner, patterns, texts, out_score, out_sink, out_source, out_cigar, out_cigar_len,
+              max_pattern_length=0, max_text_length=0, quals=None, temp=None):
+        """out_cigar: int16 [n, cigar_stride] device tensor holding the io::Cigar uint16 bit patterns."""
+        n = len(patterns)
+        assert len(texts) == n
+        if patterns.length is None:
+            max_pattern_length = max_pattern_length or patterns.fixed_length
+        if texts.length is None:
+            max_text_length = max_text_length or texts.fixed_length
+        for t, k in ((out_score, 1), (out_sink, 2), (out_source, 2), (out_cigar_len, 1)):
+            assert t.dtype == torch.int32 and t.is_cuda and t.is_contiguous() and t.numel() >= k * n
+        assert out_cigar.dtype == torch.int16 and out_cigar.is_cuda and out_cigar.is_contiguous() and out_cigar.dim() == 2 and out_cigar.shape[0] >= n
+        need = self.min_temp_storage(max_pattern_length, max_text_length, n)
+        if temp is None:
+            temp = torch.empty(max(need, 8), dtype=torch.uint8, device=patterns.words.device)
+        assert temp.is_cuda and temp.numel() * temp.element_size() >= need
+        sc = aligner.scheme.struct()
+        ps, ts = patterns.struct(), texts.struct()
+        tail = (int(max_pattern_length), int(max_text_length), n,
+                C.c_void_p(out_score.data_ptr()), C.c_void_p(out_sink.data_ptr()), C.c_void_p(out_source.data_ptr()),
+                C.c_void_p(out_cigar.data_ptr()), int(out_cigar.shape[1]), C.c_void_p(out_cigar_len.data_ptr()),
+                C.c_void_p(temp.data_ptr()), temp.numel() * temp.element_size(), current_stream_ptr())
+        if isinstance(aligner.scheme, SmithWatermanScoringScheme):
+            assert quals is not None and quals.dtype == torch.uint8 and quals.is_cuda and quals.is_contiguous()
+            err = lib().nvbio_hip_banded_gotoh_traceback_qual(
+                C.byref(sc), aligner.type, self.band_len, C.byref(ps), C.c_void_p(quals.data_ptr()), quals.numel(), C.byref(ts), *tail)
+            check(err, "nvbio_hip_banded_gotoh_traceback_qual")
+        else:
+            err = lib().nvbio_hip_banded_gotoh_traceback(C.byref(sc), aligner.type, self.band_len, C.byref(ps), C.byref(ts), *tail)
+            check(err, "nvbio_hip_banded_gotoh_traceback")
+        # the kernel reads `temp` asynchronously: keep it alive until the stream has passed it
+        temp.record_stream(torch.cuda.current_stream())
+
+
+def batch_banded_alignment_traceback(band_len, aligner, patterns, texts, max_pattern_length=0, max_text_length=0,
+                                     quals=None, cigar_stride=None):
+    """One call form: returns dict(score[n], sink[n,2], source[n,2], cigar[n,stride] int16, cigar_len[n])."""
+    n = len(patterns)
+    dev = patterns.words.device
+    maxM = max_pattern_length or patterns.fixed_length
+    if cigar_stride is None:
+        cigar_stride = min(int(maxM) + band_len + 2, 64)
+    out = dict(score=torch.empty(n, dtype=torch.int32, device=dev),
+               sink=torch.empty((n, 2), dtype=torch.int32, device=dev),
+               source=torch.empty((n, 2), dtype=torch.int32, device=dev),
+               cigar=torch.zeros((max(n, 1), cigar_stride), dtype=torch.int16, device=dev),
+               cigar_len=torch.empty(n, dtype=torch.int32, device=dev))
+    BatchedBandedAlignmentTraceback(band_len).enact(aligner, patterns, texts, out["score"], out["sink"], out["source"],
+                                                    out["cigar"], out["cigar_len"], max_pattern_length, max_text_length, quals)
+    return out
+
+
 class BatchedAlignmentScore:
     """BatchedAlignmentScore<stream, DeviceThreadScheduler> (batched.h:310-329) for the full-matrix Gotoh
     score with the text-blocking aligner sw-benchmark instantiates (sw-benchmark.cu:604-631)."""

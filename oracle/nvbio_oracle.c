@@ -469,6 +469,156 @@ ORACLE_API int32_t oracle_ref_sw_gotoh(int type, const int32_t* scheme, const ui
     return r;
 }
 
+/* ------------------------------------------------------------------------ */
+/* Banded Gotoh traceback                                                     */
+/*   driver            nvbio/alignment/banded_inl.h:352-489                   */
+/*   flow flags        gotoh_banded_inl.h:479-614 (the dir/edir/fdir handed to */
+/*                     new_cell) and :323-336 (GotohSubmatrixContext)         */
+/*   backtracking      gotoh_banded_inl.h:878-960                             */
+/* The reference recomputes the flags window by window from short2 checkpoints */
+/* (:205-262); whenever the DP values fit int16 that is the same as one dense  */
+/* forward pass, which is what is restated here.                              */
+/* ------------------------------------------------------------------------ */
+enum { DIR_SUBSTITUTION = 0, DIR_INSERTION = 1, DIR_DELETION = 2, DIR_SINK = 3, DIR_INSERTION_EXT = 4, DIR_DELETION_EXT = 8 };   /* alignment_base.h:139-150 */
+
+/* forward pass of gotoh_alignment_score_dispatch::run recording new_cell()'s cdir per cell; flags: M x band bytes */
+static int banded_gotoh_flow(uint32_t band, int type, const scheme_t* sc,
+    const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, uint64_t pat_begin, uint32_t pattern_len,
+    const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, uint64_t txt_begin, uint32_t text_len,
+    best_sink_t* sink, uint8_t* flags)
+{
+    if (text_len < pattern_len) return 0;
+    uint32_t text_cache[MAX_BAND];
+    int32_t  H_band[MAX_BAND], F_band[MAX_BAND];
+    for (uint32_t j = 0; j + 1 < band; ++j)
+        text_cache[j] = cache_store(band, ps_get(txt_w, txt_bits, txt_be, txt_begin + j));
+    const int32_t G_o = sc->pat_gap_open, G_e = sc->pat_gap_ext;
+    const int32_t infimum = -32768 - imax(imax(G_o, G_e), imax(sc->txt_gap_open, sc->txt_gap_ext));
+    H_band[0] = 0;
+    for (uint32_t j = 1; j < band; ++j) H_band[j] = (type == ALN_GLOBAL) ? sc->txt_gap_open + (int32_t)(j - 1) * sc->txt_gap_ext : 0;
+    for (uint32_t j = 0; j < band; ++j) F_band[j] = infimum;
+    for (uint32_t i = 0; i < pattern_len; ++i)
+    {
+        const uint8_t q  = (uint8_t)ps_get(pat_w, pat_bits, pat_be, pat_begin + i);
+        const uint8_t qq = sc->quals ? sc->quals[pat_begin + i] : 0;
+        uint8_t* row = flags + (size_t)i * band;
+        uint8_t edir = DIR_SUBSTITUTION;
+        {   /* j == 0 (:483-515) */
+            const int32_t ftop = F_band[1] + G_e, htop = H_band[1] + G_o;
+            F_band[0] = imax(ftop, htop);
+            const uint8_t fdir = ftop > htop ? DIR_DELETION_EXT : DIR_SUBSTITUTION;
+            const int32_t diagonal = H_band[0] + subst(sc, (uint8_t)text_cache[0], q, qq);
+            const int32_t top = F_band[0];
+            int32_t hi = imax(top, diagonal);
+            uint8_t hdir = (top > diagonal) ? DIR_INSERTION : DIR_SUBSTITUTION;
+            if (type == ALN_LOCAL) { hi = imax(hi, 0); if (hi == 0) hdir = DIR_SINK; sink_report(sink, hi, i + 1, i + 1); }
+            H_band[0] = hi;
+            row[0] = (uint8_t)(hdir | DIR_SUBSTITUTION | fdir);
+        }
+        int32_t E_j = H_band[0] + G_o;
+        for (uint32_t j = 1; j + 1 < band; ++j)
+        {
+            const int32_t ftop = F_band[j + 1] + G_e, htop = H_band[j + 1] + G_o;
+            F_band[j] = imax(ftop, htop);
+            const uint8_t fdir = ftop > htop ? DIR_DELETION_EXT : DIR_SUBSTITUTION;
+            const uint32_t g = text_cache[j]; text_cache[j - 1] = g;
+            const int32_t diagonal = H_band[j] + subst(sc, (uint8_t)g, q, qq);
+            const int32_t top = F_band[j], left = E_j;
+            int32_t hi = imax(imax(top, left), diagonal);
+            uint8_t hdir = top > left ? (top > diagonal ? DIR_INSERTION : DIR_SUBSTITUTION) : (left > diagonal ? DIR_DELETION : DIR_SUBSTITUTION);
+            if (type == ALN_LOCAL) { hi = imax(hi, 0); if (hi == 0) hdir = DIR_SINK; sink_report(sink, hi, i + j + 1, i + 1); }
+            H_band[j] = hi;
+            row[j] = (uint8_t)(hdir | edir | fdir);
+            const int32_t eleft = E_j + G_e, ediagonal = hi + G_o;
+            edir = (eleft > ediagonal) ? DIR_INSERTION_EXT : DIR_SUBSTITUTION;
+            E_j = imax(ediagonal, eleft);
+        }
+        const uint8_t g = (i + band - 1 < text_len) ? (uint8_t)ps_get(txt_w, txt_bits, txt_be, txt_begin + i + band - 1) : 255u;
+        text_cache[band - 2] = cache_store(band, g);
+        {   /* j == BAND_LEN-1 (:584-614) */
+            F_band[band - 1] = infimum;
+            const int32_t diagonal = H_band[band - 1] + subst(sc, g, q, qq);
+            const int32_t left = E_j;
+            int32_t hi = imax(left, diagonal);
+            uint8_t hdir = (left > diagonal) ? DIR_DELETION : DIR_SUBSTITUTION;
+            if (type == ALN_LOCAL) { hi = imax(hi, 0); if (hi == 0) hdir = DIR_SINK; sink_report(sink, hi, i + band, i + 1); }
+            H_band[band - 1] = hi;
+            row[band - 1] = (uint8_t)(hdir | edir | DIR_SUBSTITUTION);
+        }
+    }
+    if (type == ALN_GLOBAL)
+        sink_report(sink, H_band[band - 1], pattern_len + band - 1, pattern_len);
+    else if (type == ALN_SEMI_GLOBAL) {
+        const uint32_t a = pattern_len + band - 1u;
+        const uint32_t m = (a < text_len ? a : text_len) - (pattern_len - 1u);
+        sink_report(sink, H_band[0], pattern_len, pattern_len);
+        for (uint32_t j = 1; j < band; ++j) if (j < m) sink_report(sink, H_band[j], pattern_len + j, pattern_len);
+    }
+    return 1;
+}
+
+/* banded_alignment_traceback (banded_inl.h:352-423 + gotoh_banded_inl.h:878-960).
+ * out: res[0] = score, res[1..2] = source (x,y), res[3..4] = sink (x,y), res[5] = number of ops,
+ *      res[6] = clip pushed first (pattern_len - sink.y), res[7] = clip pushed last (source.y);
+ * ops[] = the backtracer's pushes in order (end of the alignment first): 0 = M, 1 = I, 2 = D.
+ * flags: scratch of pattern_len * band bytes. */
+static void banded_gotoh_traceback_x(
+    uint32_t band, int type, const scheme_t* scp,
+    const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, uint64_t pat_begin, uint32_t pat_len,
+    const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, uint64_t txt_begin, uint32_t txt_len,
+    int32_t* res, uint8_t* ops, uint32_t ops_capacity, uint8_t* flags)
+{
+    const scheme_t sc = *scp;
+    best_sink_t best; sink_init(&best);
+    banded_gotoh_flow(band, type, &sc, pat_w, pat_bits, pat_be, pat_begin, pat_len, txt_w, txt_bits, txt_be, txt_begin, txt_len, &best, flags);
+    res[0] = best.score; res[3] = (int32_t)best.sink_x; res[4] = (int32_t)best.sink_y; res[5] = 0; res[6] = res[7] = 0;
+    if (best.sink_x == 0xFFFFFFFFu || best.sink_y == 0xFFFFFFFFu) { res[1] = res[2] = -1; return; }      /* :383-385 */
+    uint32_t n = 0;
+    res[6] = (int32_t)(pat_len - best.sink_y);                                                          /* clip :387 */
+    int32_t entry = (int32_t)(best.sink_x - best.sink_y), row = (int32_t)best.sink_y - 1;
+    uint8_t state = 0;   /* HSTATE */
+    uint32_t sx, sy;
+    int stopped = 0;
+    while (row >= 0)
+    {
+        const uint8_t op = flags[(size_t)row * band + entry], h_op = op & 3u;
+        if (type == ALN_LOCAL && state == 0 && h_op == DIR_SINK) { sy = (uint32_t)row + 1u; sx = (uint32_t)entry + sy; stopped = 1; break; }
+        if (state == 1) {            /* ESTATE */
+            if ((op & DIR_INSERTION_EXT) == 0u) state = 0;
+            --entry; if (n < ops_capacity) ops[n] = DIR_DELETION; ++n;
+        } else if (state == 2) {     /* FSTATE */
+            if ((op & DIR_DELETION_EXT) == 0u) state = 0;
+            ++entry; --row; if (n < ops_capacity) ops[n] = DIR_INSERTION; ++n;
+        } else {
+            if (h_op == DIR_DELETION) state = 1;
+            else if (h_op == DIR_INSERTION) state = 2;
+            else { --row; if (n < ops_capacity) ops[n] = DIR_SUBSTITUTION; ++n; }
+        }
+    }
+    if (!stopped) { sy = 0; sx = (uint32_t)entry; }
+    res[1] = (int32_t)sx; res[2] = (int32_t)sy; res[5] = (int32_t)n; res[7] = (int32_t)sy;              /* clip :418 */
+}
+
+ORACLE_API void oracle_banded_gotoh_traceback(
+    uint32_t band, int type, const int32_t* scheme,
+    const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, uint64_t pat_begin, uint32_t pat_len,
+    const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, uint64_t txt_begin, uint32_t txt_len,
+    int32_t* res, uint8_t* ops, uint32_t ops_capacity, uint8_t* flags)
+{
+    const scheme_t sc = { scheme[0], scheme[1], scheme[2], scheme[3], scheme[2], scheme[3], NULL, NULL };
+    banded_gotoh_traceback_x(band, type, &sc, pat_w, pat_bits, pat_be, pat_begin, pat_len, txt_w, txt_bits, txt_be, txt_begin, txt_len, res, ops, ops_capacity, flags);
+}
+/* quality-aware scheme: qscheme = {match, pattern_gap_open, pattern_gap_ext, text_gap_open, text_gap_ext} */
+ORACLE_API void oracle_banded_gotoh_traceback_qual(
+    uint32_t band, int type, const int32_t* qscheme, const int32_t* mm_lut, const uint8_t* quals,
+    const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, uint64_t pat_begin, uint32_t pat_len,
+    const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, uint64_t txt_begin, uint32_t txt_len,
+    int32_t* res, uint8_t* ops, uint32_t ops_capacity, uint8_t* flags)
+{
+    const scheme_t sc = { qscheme[0], 0, qscheme[1], qscheme[2], qscheme[3], qscheme[4], mm_lut, quals };
+    banded_gotoh_traceback_x(band, type, &sc, pat_w, pat_bits, pat_be, pat_begin, pat_len, txt_w, txt_bits, txt_be, txt_begin, txt_len, res, ops, ops_capacity, flags);
+}
+
 /* ref_banded_sw: nvbio-test/alignment_test_utils.h:314-460.  The reference's
  * test-suite asserts  banded_alignment_score(...) == ref_banded_sw(...)
  * (alignment_test.cu:310-326); restated here so our tests can make the same

@@ -199,6 +199,77 @@ def batch_gotoh_score(aln_type, scheme, patterns, texts, min_score=None, n_threa
     return score, sink, ok
 
 
+def banded_gotoh_traceback(band, aln_type, scheme, patterns, texts, i=0, mm_lut=None, quals=None):
+    """banded_alignment_traceback of job i of two StringSets -> dict(score, source, sink, ops (end first:
+    0=M 1=I 2=D), clip_end, clip_begin, cigar).  With mm_lut/quals: scheme = (match, pattern_gap_open,
+    pattern_gap_ext, text_gap_open, text_gap_ext) (nvBowtie's quality-aware scheme).
+    cigar = what nvBowtie's Backtracker (alignment_utils.h:125-168) leaves in its io::Cigar vector:
+    uint16 = type | len << 2 (type:2, len:14 bit-field), stored end of the alignment first,
+    soft clips (type 3) at both ends."""
+    M, N = int(patterns.length[i]), int(texts.length[i])
+    res = np.zeros(8, dtype=np.int32)
+    cap = 2 * M + band + 8        # deletions <= band - 1 + insertions
+    ops = np.zeros(cap, dtype=np.uint8)
+    flags = np.zeros(max(1, M * band), dtype=np.uint8)
+    tail = (_p(patterns.words), C.c_uint32(patterns.bits), C.c_uint32(patterns.big_endian), C.c_uint64(int(patterns.begin[i])), C.c_uint32(M),
+            _p(texts.words), C.c_uint32(texts.bits), C.c_uint32(texts.big_endian), C.c_uint64(int(texts.begin[i])), C.c_uint32(N),
+            _p(res), _p(ops), C.c_uint32(cap), _p(flags))
+    if mm_lut is None:
+        sc = _scheme(scheme)
+        lib().oracle_banded_gotoh_traceback(C.c_uint32(band), C.c_int(aln_type), _p(sc), *tail)
+    else:
+        sc = np.ascontiguousarray(scheme, dtype=np.int32)
+        lut = np.ascontiguousarray(mm_lut, dtype=np.int32)
+        q = np.ascontiguousarray(quals, dtype=np.uint8)
+        lib().oracle_banded_gotoh_traceback_qual(C.c_uint32(band), C.c_int(aln_type), _p(sc), _p(lut), _p(q), *tail)
+    n = int(res[5])
+    o = ops[:n].copy()
+    cig = []
+    if res[6]:
+        cig.append(3 | (int(res[6]) << 2))
+    k = 0
+    while k < n:
+        e = k
+        while e < n and o[e] == o[k]:
+            e += 1
+        cig.append(int(o[k]) | ((e - k) << 2))
+        k = e
+    if res[7]:
+        cig.append(3 | (int(res[7]) << 2))
+    return dict(score=int(res[0]), source=(int(np.uint32(res[1])), int(np.uint32(res[2]))), sink=(int(np.uint32(res[3])), int(np.uint32(res[4]))),
+                ops=o, clip_end=int(res[6]), clip_begin=int(res[7]), cigar=np.array(cig, dtype=np.uint16))
+
+
+def batch_banded_gotoh_traceback(band, aln_type, scheme, patterns, texts, cigar_stride, mm_lut=None, quals=None):
+    """banded_gotoh_traceback over two StringSets -> dict of arrays laid out like the C-ABI's outputs."""
+    n = len(patterns)
+    out = dict(score=np.empty(n, np.int32), sink=np.empty((n, 2), np.uint32), source=np.empty((n, 2), np.uint32),
+               cigar=np.zeros((max(n, 1), cigar_stride), np.uint16), cigar_len=np.empty(n, np.uint32))
+    for i in range(n):
+        r = banded_gotoh_traceback(band, aln_type, scheme, patterns, texts, i, mm_lut, quals)
+        out["score"][i] = r["score"]; out["sink"][i] = r["sink"]; out["source"][i] = r["source"]
+        c = r["cigar"]
+        out["cigar_len"][i] = c.size
+        out["cigar"][i, :min(c.size, cigar_stride)] = c[:cigar_stride]
+    return out
+
+
+def cigar_rle(ops_end_first):
+    """Run-length encode the backtracer's pushes in push order, as the reference test prints them
+    (alignment_test_utils.h: rle(backtracker.aln))."""
+    out, prev, cnt = [], None, 0
+    for o in ops_end_first:
+        if o == prev:
+            cnt += 1
+        else:
+            if prev is not None:
+                out.append("%d%s" % (cnt, "MID"[prev]))
+            prev, cnt = int(o), 1
+    if prev is not None:
+        out.append("%d%s" % (cnt, "MID"[prev]))
+    return "".join(out)
+
+
 def ref_sw_gotoh(aln_type, scheme, pattern, text):
     p = np.ascontiguousarray(pattern, dtype=np.uint8)
     t = np.ascontiguousarray(text, dtype=np.uint8)

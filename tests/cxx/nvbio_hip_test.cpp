@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <string>
 #include <nvbio_hip/alignment.h>
 #include <nvbio_hip/fmindex.h>
 
@@ -26,6 +27,10 @@ void oracle_batch_banded_gotoh_score(uint32_t band, int type, const int32_t* sch
     const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, const uint64_t* pat_begin, const uint32_t* pat_len,
     const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, const uint64_t* txt_begin, const uint32_t* txt_len,
     uint32_t n, int32_t* out_score, uint32_t* out_sink, int n_threads);
+void oracle_banded_gotoh_traceback(uint32_t band, int type, const int32_t* scheme,
+    const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, uint64_t pat_begin, uint32_t pat_len,
+    const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, uint64_t txt_begin, uint32_t txt_len,
+    int32_t* res, uint8_t* ops, uint32_t ops_capacity, uint8_t* flags);
 uint32_t oracle_bwt_from_sa(uint32_t n, const uint8_t* T, const uint32_t* SA, uint8_t* bwt);
 void oracle_build_bwt_occ(uint32_t n, const uint32_t* bwt_words, uint32_t* bwt_occ, uint32_t* L2);
 void oracle_build_ssa(uint32_t n, const uint32_t* SA, uint32_t K, uint32_t* ssa);
@@ -113,6 +118,73 @@ static void run_full_batch(const char* name, const aln::SimpleGotohScheme scorin
     fprintf(stderr, "    %-44s : %u jobs ok\n", name, n);
 }
 
+// run-length string of a backwards io::Cigar vector, as the reference test prints it (rle(backtracker.aln))
+static std::string cigar_string(const io::Cigar* c, const uint32 n)
+{
+    std::string r; char buf[32];
+    for (uint32 i = 0; i < n; ++i) { snprintf(buf, sizeof(buf), "%u%c", uint32(c[i].m_len), "MIDS"[c[i].m_type]); r += buf; }
+    return r;
+}
+
+// BatchedBandedAlignmentTraceback vs the oracle's banded_alignment_traceback, job by job
+template <uint32 BAND_LEN, aln::AlignmentType TYPE>
+static void run_traceback_batch(const char* name, const aln::SimpleGotohScheme scoring,
+                                const std::vector<std::vector<uint8> >& patterns, const std::vector<std::vector<uint8> >& texts,
+                                const char* expect_cigar = nullptr)
+{
+    const uint32 n = uint32(patterns.size()), STRIDE = 48;
+    uint32 maxP = 0; for (uint32 i = 0; i < n; ++i) maxP = std::max(maxP, uint32(patterns[i].size()));
+    PackedStringSetDevice<4, true> d_patterns(patterns);
+    PackedStringSetDevice<2, true> d_texts(texts);
+    hip::device_vector<int32>  d_score(n);
+    hip::device_vector<uint32> d_sink(2 * size_t(n)), d_source(2 * size_t(n)), d_len(n);
+    hip::device_vector<io::Cigar> d_cigar(size_t(n) * STRIDE);
+    typedef aln::GotohAligner<TYPE, aln::SimpleGotohScheme> aligner_type;
+    typedef aln::PackedTracebackStream<aligner_type, PackedStringSetView<4, true>, PackedStringSetView<2, true> > stream_type;
+    typedef aln::BatchedBandedAlignmentTraceback<BAND_LEN, 32u, stream_type> batch_type;
+    const uint64 temp_size = batch_type::max_temp_storage(maxP, maxP + BAND_LEN, n);
+    hip::device_vector<uint8> d_temp(temp_size ? temp_size : 1);
+    aln::AlignmentArrays alns = { d_score.data(), d_source.data(), d_sink.data() };
+    aln::CigarArrays cigs = { d_cigar.data(), STRIDE, d_len.data() };
+    batch_type batch;
+    batch.enact(stream_type(aln::make_gotoh_aligner<TYPE>(scoring), d_patterns.view(), d_texts.view(), alns, cigs, maxP, maxP + BAND_LEN), temp_size, d_temp.data());
+    hip::synchronize();
+    const std::vector<int32> score = d_score.to_host();
+    const std::vector<uint32> sink = d_sink.to_host(), source = d_source.to_host(), len = d_len.to_host();
+    const std::vector<io::Cigar> cigar = d_cigar.to_host();
+
+    std::vector<uint8> pc, tc; std::vector<uint64> pb(n), tb(n);
+    for (uint32 i = 0; i < n; ++i) { pb[i] = pc.size(); pc.insert(pc.end(), patterns[i].begin(), patterns[i].end());
+                                     tb[i] = tc.size(); tc.insert(tc.end(), texts[i].begin(), texts[i].end()); }
+    tc.insert(tc.end(), 64, 0);            // the device set is zero padded past its last string as well
+    const std::vector<uint32> pw = pack_symbols<4, true>(pc.data(), pc.size()), tw = pack_symbols<2, true>(tc.data(), tc.size());
+    const int32 sc[4] = { scoring.m_match, scoring.m_mismatch, scoring.m_gap_open, scoring.m_gap_ext };
+    std::vector<uint8> ops(2 * maxP + BAND_LEN + 8), flags(size_t(maxP + 1) * BAND_LEN);
+    for (uint32 i = 0; i < n; ++i)
+    {
+        int32 res[8];
+        oracle_banded_gotoh_traceback(BAND_LEN, int(TYPE), sc, pw.data(), 4, 1, pb[i], uint32(patterns[i].size()),
+                                      tw.data(), 2, 1, tb[i], uint32(texts[i].size()), res, ops.data(), uint32(ops.size()), flags.data());
+        std::vector<io::Cigar> h;
+        if (res[1] != -1 || res[2] != -1) {
+            if (res[6]) h.push_back(io::Cigar(io::Cigar::SOFT_CLIPPING, uint16(res[6])));
+            for (int32 k = 0; k < res[5]; ) { int32 e = k; while (e < res[5] && ops[e] == ops[k]) ++e; h.push_back(io::Cigar(ops[k], uint16(e - k))); k = e; }
+            if (res[7]) h.push_back(io::Cigar(io::Cigar::SOFT_CLIPPING, uint16(res[7])));
+        }
+        bool ok = score[i] == res[0] && source[2 * i] == uint32(res[1]) && source[2 * i + 1] == uint32(res[2]) &&
+                  sink[2 * i] == uint32(res[3]) && sink[2 * i + 1] == uint32(res[4]) && len[i] == h.size();
+        for (uint32 k = 0; ok && k < std::min<uint32>(len[i], STRIDE); ++k)
+            ok = cigar[size_t(i) * STRIDE + k].m_type == h[k].m_type && cigar[size_t(i) * STRIDE + k].m_len == h[k].m_len;
+        if (!ok)
+            FAIL("%s: job %u: device %d [%u,%u]->[%u,%u] %s != host %d [%u,%u]->[%u,%u] %s", name, i,
+                 score[i], source[2 * i], source[2 * i + 1], sink[2 * i], sink[2 * i + 1], cigar_string(&cigar[size_t(i) * STRIDE], std::min<uint32>(len[i], STRIDE)).c_str(),
+                 res[0], uint32(res[1]), uint32(res[2]), uint32(res[3]), uint32(res[4]), cigar_string(h.data(), uint32(h.size())).c_str());
+    }
+    if (expect_cigar && cigar_string(&cigar[0], len[0]) != expect_cigar)
+        FAIL("%s: expected %s, got %s", name, expect_cigar, cigar_string(&cigar[0], len[0]).c_str());
+    fprintf(stderr, "    %-44s : %u jobs ok%s%s\n", name, n, expect_cigar ? "  " : "", expect_cigar ? expect_cigar : "");
+}
+
 template <uint32 BAND_LEN, aln::AlignmentType TYPE>
 static void expect_single(const char* name, aln::SimpleGotohScheme sc, const char* p, const char* t, int32 score, uint32 sx, uint32 sy)
 {
@@ -135,6 +207,10 @@ static int alignment_test()
     expect_single<31, aln::SEMI_GLOBAL>("kat real banded Gotoh 31", aln::SimpleGotohScheme(0, -5, -8, -3), P2, T2, -11, 165, 150);
     expect_single<15, aln::SEMI_GLOBAL>("kat real banded Gotoh 15", aln::SimpleGotohScheme(0, -5, -8, -3), P2, T2, -403, 160, 150);
     expect_single<31, aln::LOCAL>      ("kat real banded local 31", aln::SimpleGotohScheme(2, -1, -2, -1), P2, T2, 297, 165, 150);
+
+    // the CIGAR literals of the reference's banded traceback tests (alignment_test.cu:793, :825)
+    run_traceback_batch<7,  aln::SEMI_GLOBAL>("kat traceback banded-semi-global 7", aln::SimpleGotohScheme(2, -1, -1, -1), { string_to_dna(P1) }, { string_to_dna(T1) }, "4M1D3M");
+    run_traceback_batch<31, aln::SEMI_GLOBAL>("kat traceback real banded Gotoh 31", aln::SimpleGotohScheme(0, -5, -8, -3), { string_to_dna(P2) }, { string_to_dna(T2) }, "147M2D3M");
 
     // the throughput configuration of alignment_test.cu:1071-1194 (BAND=15, M=150, N=M+15), with
     // planted substitutions so that scores are not trivial; reads 4-bit LE, refs 2-bit LE as there
@@ -160,6 +236,11 @@ static int alignment_test()
     run_batch<7,  aln::SEMI_GLOBAL, 4, true,  false>("batch semi-global 7",               s3, pats, txts);
     run_batch<3,  aln::LOCAL,       4, true,  false>("batch local 3",                     s2, pats, txts);
     run_batch<5,  aln::GLOBAL,      4, true,  false>("batch global 5",                    s2, pats, txts);
+    // banded traceback -> CIGAR over the same ragged batch (nvBowtie's traceback stage shape)
+    run_traceback_batch<15, aln::LOCAL>      ("batch traceback local 15",       s2, pats, txts);
+    run_traceback_batch<15, aln::SEMI_GLOBAL>("batch traceback semi-global 15", s3, pats, txts);
+    run_traceback_batch<31, aln::GLOBAL>     ("batch traceback global 31",      s1, pats, txts);
+    run_traceback_batch<7,  aln::LOCAL>      ("batch traceback local 7",        s1, pats, txts);
     // full-matrix Gotoh (the sw-benchmark instantiation): reads against longer references
     {
         std::vector<std::vector<uint8> > fp(2048), ft(2048);

@@ -60,6 +60,93 @@ def test_gotoh_kat(case):
         assert s == case["score"]
 
 
+@pytest.mark.parametrize("case", [c for c in KAT["gotoh"] if "cigar" in c], ids=lambda c: "%s-b%d" % (c["cigar"], c["band"]))
+def test_traceback_cigar_kat(case):
+    """banded_alignment_traceback against the CIGAR literals of the reference's own test
+    (alignment_test.cu:793, :825; rle(backtracker.aln) at :280)."""
+    p, t = dna(KAT["strings"][case["p"]]), dna(KAT["strings"][case["t"]])
+    for pb, be in ((4, True), (2, False)):
+        hp = O.StringSet.from_lists([p], pb, be)
+        ht = O.StringSet.from_lists([t], 2, not be)
+        r = O.banded_gotoh_traceback(case["band"], case["type"], case["scheme"], hp, ht)
+        assert O.cigar_rle(r["ops"]) == case["cigar"]
+        assert r["score"] == case["score"] and list(r["sink"]) == case["sink"]
+        assert r["source"][1] == 0 and r["clip_end"] == 0 and r["clip_begin"] == 0
+
+
+def _first(ss):
+    """the first string of a StringSet, over the same words"""
+    return O.StringSet(ss.words, ss.bits, ss.big_endian, ss.begin[:1], ss.length[:1])
+
+
+def walk_alignment(r, pattern, text, scheme, mm_lut=None, quals=None):
+    """TestBacktracker::score generalised: replay the ops (stored end first) from the source cell."""
+    match, mismatch, go, ge = scheme[:4]
+    i, j = r["source"][1], r["source"][0]
+    score, prev = 0, None
+    for op in r["ops"][::-1]:
+        if op == 0:
+            mm = mismatch if mm_lut is None else int(mm_lut[quals[i]])
+            score += match if pattern[i] == text[j] else mm
+            i += 1; j += 1
+        elif op == 2:
+            score += ge if prev == 2 else go
+            j += 1
+        else:
+            score += ge if prev == 1 else go
+            i += 1
+        prev = op
+    return score, i, j
+
+
+@pytest.mark.parametrize("band", [3, 5, 7, 15, 31])
+@pytest.mark.parametrize("aln_type", [0, 1, 2])
+def test_traceback_properties(band, aln_type):
+    """What the reference test asserts of every traceback (alignment_test.cu:277-355): the replayed
+    alignment scores exactly the banded score, starts at `source` and ends at `sink`."""
+    rng = np.random.default_rng(100 * band + aln_type)
+    scheme = (2, -1, -2, -1)
+    for it in range(60):
+        M = int(rng.integers(1, 60))
+        N = M + band - 1 + int(rng.integers(0, 4)) if it % 3 else M + int(rng.integers(0, band))
+        t = rng.integers(0, 4, N).astype(np.uint8)
+        p = t[band // 2: band // 2 + M].copy() if N >= band // 2 + M else rng.integers(0, 4, M).astype(np.uint8)
+        p = p[:M] if len(p) == M else rng.integers(0, 4, M).astype(np.uint8)
+        for _ in range(int(rng.integers(0, 4))):       # a few substitutions / indels
+            k = int(rng.integers(0, M))
+            kind = rng.integers(0, 3)
+            if kind == 0:
+                p[k] = rng.integers(0, 4)
+            elif kind == 1 and M > 2:
+                p = np.concatenate([p[:k], p[k + 1:], rng.integers(0, 4, 1).astype(np.uint8)])
+            else:
+                p = np.concatenate([p[:k], rng.integers(0, 4, 1).astype(np.uint8), p[k:]])[:M]
+        hp = O.StringSet.from_lists([p], 4, True)
+        ht = O.StringSet.from_lists([t, np.zeros(64, np.uint8)], 2, True)     # a second string = defined padding
+        r = O.banded_gotoh_traceback(band, aln_type, scheme, hp, _first(ht))
+        sc_b, sk_b = O.batch_banded_gotoh_score(band, aln_type, scheme, hp, _first(ht))
+        assert (r["score"], r["sink"]) == (int(sc_b[0]), (int(sk_b[0, 0]), int(sk_b[0, 1])))
+        score, (sx, sy) = r["score"], r["sink"]
+        if band == 31:
+            continue          # the 2-bit text cache of this band (see test_band31_cache_truncation_quirk) breaks replay near the text end
+        # what the DP saw past the end of the text: the band's preload reads the stream unchecked
+        # (gotoh_banded_inl.h:437-441; zero padding here), later fetches see 255 (:580-582)
+        seen = np.concatenate([t, np.zeros(max(0, band - 1 - N), np.uint8), np.full(band, 255, np.uint8)])
+        s, i, j = walk_alignment(r, p, seen, scheme)
+        assert (j, i) == r["sink"]
+        if aln_type == 0 and r["source"][0] > 0:
+            # GLOBAL: row zero of the band is initialised with the cost of the leading text gap
+            # (gotoh_banded_inl.h:46-77); the walk ends at row 0 without pushing those deletions
+            s += scheme[2] + (r["source"][0] - 1) * scheme[3]
+        assert s == score
+        assert r["clip_end"] == M - sy and r["clip_begin"] == r["source"][1]
+        if aln_type != 1:
+            assert r["source"][1] == 0 and sy == M
+        # the packed CIGAR consumes exactly the pattern (nvBowtie's assert, traceback_inl.h:168-171)
+        cig = r["cigar"]
+        assert sum(int(c) >> 2 for c in cig if (int(c) & 3) != 2) == M
+
+
 def test_text_shorter_than_pattern():
     exp = KAT["text_shorter_than_pattern"]
     p, t = dna(KAT["strings"]["real_p"])[:100], dna(KAT["strings"]["real_t"])[:50]

@@ -1,0 +1,127 @@
+"""Parity of the HIP banded Gotoh traceback (through the C-ABI) with the CPU oracle: bit-exact score,
+sink, source and CIGAR (nvBowtie's io::Cigar encoding, end of the alignment first)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import nvbio_amd as nvb
+from oracle import pyoracle as O
+from test_banded_gpu import random_pairs, dna
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+KAT = json.load(open(os.path.join(HERE, "golden", "kat.json")))
+
+
+def to_dev(hs, dev):
+    return nvb.PackedStringSet.from_host(hs.words, hs.bits, hs.big_endian, hs.begin, hs.length, device=dev)
+
+
+def compare(exp, got, tag):
+    g = {k: v.cpu().numpy() for k, v in got.items()}
+    n = exp["score"].size
+    assert (exp["score"] == g["score"][:n]).all(), tag
+    assert (exp["sink"] == g["sink"].view(np.uint32)[:n]).all(), tag
+    bad = np.nonzero((exp["source"] != g["source"].view(np.uint32)[:n]).any(1))[0]
+    assert bad.size == 0, (tag, bad[:5], exp["source"][bad[:3]], g["source"].view(np.uint32)[bad[:3]])
+    assert (exp["cigar_len"] == g["cigar_len"].view(np.uint32)[:n]).all(), tag
+    gc = g["cigar"].view(np.uint16)[:n]
+    stride = gc.shape[1]
+    mask = np.arange(stride)[None, :] < np.minimum(exp["cigar_len"], stride)[:, None]
+    bad = np.nonzero(((exp["cigar"][:n] != gc) & mask).any(1))[0]
+    assert bad.size == 0, (tag, bad[:5], exp["cigar"][bad[0]], gc[bad[0]])
+
+
+def test_cigar_kats_on_gpu(cuda):
+    """the CIGAR literals of the reference's own test (alignment_test.cu:793, :825)"""
+    for case in (c for c in KAT["gotoh"] if "cigar" in c):
+        p, t = dna(KAT["strings"][case["p"]]), dna(KAT["strings"][case["t"]])
+        hp, ht = O.StringSet.from_lists([p], 4, True), O.StringSet.from_lists([t], 2, False)
+        aligner = nvb.make_gotoh_aligner(case["type"], nvb.SimpleGotohScheme(*case["scheme"]))
+        got = nvb.batch_banded_alignment_traceback(case["band"], aligner, to_dev(hp, cuda), to_dev(ht, cuda), max_pattern_length=len(p))
+        torch.cuda.synchronize()
+        k = int(got["cigar_len"][0])
+        cig = got["cigar"][0, :k].cpu().numpy().view(np.uint16)
+        assert "".join("%d%s" % (c >> 2, "MIDS"[c & 3]) for c in cig) == case["cigar"]
+        assert int(got["score"][0]) == case["score"]
+        assert got["sink"][0].tolist() == case["sink"]
+
+
+@pytest.mark.parametrize("band", [3, 5, 7, 15, 31])
+@pytest.mark.parametrize("ty", [nvb.GLOBAL, nvb.LOCAL, nvb.SEMI_GLOBAL])
+def test_random_ragged_pairs(cuda, band, ty):
+    rng = np.random.default_rng(7000 + band * 3 + ty)
+    pats, txts = random_pairs(rng, 1500, band)
+    longest = 0
+    for pbits, pbe, tbe in ((4, True, True), (2, False, False)):
+        pp = [np.minimum(p, 3) for p in pats] if pbits == 2 else pats
+        hp, ht = O.StringSet.from_lists(pp, pbits, pbe), O.StringSet.from_lists(txts + [np.zeros(64, np.uint8)], 2, tbe)
+        ht = O.StringSet(ht.words, 2, tbe, ht.begin[:-1], ht.length[:-1])       # defined padding after the last text
+        maxM = int(hp.length.max())
+        for scheme in ((2, -1, -2, -1), (0, -5, -8, -3)):
+            stride = 24 if scheme[0] else 40          # small enough that some CIGARs overflow and are only counted
+            exp = O.batch_banded_gotoh_traceback(band, ty, scheme, hp, ht, stride)
+            got = nvb.batch_banded_alignment_traceback(band, nvb.make_gotoh_aligner(ty, nvb.SimpleGotohScheme(*scheme)),
+                                                       to_dev(hp, cuda), to_dev(ht, cuda), max_pattern_length=maxM, cigar_stride=stride)
+            torch.cuda.synchronize()
+            compare(exp, got, (band, ty, scheme, pbits))
+            longest = max(longest, int(exp["cigar_len"].max()))
+    assert longest > 3
+
+
+@pytest.mark.parametrize("ty", [nvb.LOCAL, nvb.SEMI_GLOBAL])
+def test_quality_aware_scheme(cuda, ty):
+    """nvBowtie's traceback instantiation: SmithWatermanScoringScheme + read qualities (traceback_inl.h:205-262)"""
+    band = 15
+    rng = np.random.default_rng(7100 + ty)
+    pats, txts = random_pairs(rng, 1500, band)
+    hp, ht = O.StringSet.from_lists(pats, 4, True), O.StringSet.from_lists(txts + [np.zeros(64, np.uint8)], 2, True)
+    ht = O.StringSet(ht.words, 2, True, ht.begin[:-1], ht.length[:-1])
+    total = int(hp.begin[-1] + hp.length[-1])
+    quals = rng.integers(0, 60, total + 3, dtype=np.uint8)
+    quals[::97] = 255
+    for scheme in (nvb.SmithWatermanScoringScheme(), nvb.SmithWatermanScoringScheme.local()):
+        st = scheme.struct()
+        lut = np.array([st.mismatch[q] for q in range(256)], dtype=np.int32)
+        s5 = (st.match, st.pattern_gap_open, st.pattern_gap_ext, st.text_gap_open, st.text_gap_ext)
+        exp = O.batch_banded_gotoh_traceback(band, ty, s5, hp, ht, 48, lut, quals)
+        got = nvb.batch_banded_alignment_traceback(band, nvb.make_gotoh_aligner(ty, scheme), to_dev(hp, cuda), to_dev(ht, cuda),
+                                                   max_pattern_length=int(hp.length.max()), quals=torch.from_numpy(quals).to(cuda), cigar_stride=48)
+        torch.cuda.synchronize()
+        compare(exp, got, (ty, "qual"))
+
+
+def test_fixed_length_batch_and_score_agreement(cuda):
+    """100 bp reads against band-15 windows (the extension stage's shape): traceback score/sink equal the
+    score kernel's, every CIGAR consumes exactly the read (nvBowtie's assert, traceback_inl.h:168-171)."""
+    from nvbio_amd import workloads as W
+    n, M, band = 200_000, 100, 15
+    p, t = W.make_sw_batch(n, M, M + band, device=cuda, seed=5)
+    aligner = nvb.make_gotoh_aligner(nvb.LOCAL, nvb.SimpleGotohScheme(2, -1, -2, -1))
+    score, sink = nvb.batch_banded_alignment_score(band, aligner, p, t)
+    got = nvb.batch_banded_alignment_traceback(band, aligner, p, t, cigar_stride=32)
+    torch.cuda.synchronize()
+    assert torch.equal(score, got["score"]) and torch.equal(sink, got["sink"])
+    cig = got["cigar"].to(torch.int32) & 0xFFFF
+    k = torch.arange(cig.shape[1], device=cuda)[None, :] < got["cigar_len"][:, None]
+    consumed = (((cig >> 2) * ((cig & 3) != 2)) * k).sum(1)
+    assert int(got["cigar_len"].max()) <= 32
+    assert bool((consumed == M).all())
+    # spot-check a sample against the oracle
+    hp, ht = O.StringSet.from_device(p), O.StringSet.from_device(t)
+    idx = np.arange(0, n, 997)
+    sub = lambda s: O.StringSet(s.words, s.bits, s.big_endian, s.begin[idx], s.length[idx])
+    exp = O.batch_banded_gotoh_traceback(band, nvb.LOCAL, (2, -1, -2, -1), sub(hp), sub(ht), 32)
+    compare(exp, {k2: v[torch.from_numpy(idx).to(cuda)] for k2, v in got.items()}, "fixed")
+
+
+def test_refusals(cuda):
+    hp, ht = O.StringSet.from_lists([np.zeros(10, np.uint8)], 4, True), O.StringSet.from_lists([np.zeros(30, np.uint8)], 2, True)
+    big = nvb.make_gotoh_aligner(nvb.LOCAL, nvb.SimpleGotohScheme(2000, -1000, -2000, -1000))
+    with pytest.raises(RuntimeError):          # outside the int16 checkpoint range of the reference: refused, not approximated
+        nvb.batch_banded_alignment_traceback(15, big, to_dev(hp, cuda), to_dev(ht, cuda), max_pattern_length=10)
+    with pytest.raises(ValueError):
+        nvb.BatchedBandedAlignmentTraceback(9)
