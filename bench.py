@@ -82,18 +82,26 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("NVBIO_BENCH_SHARE_GPU") == "1":
+        local = 0          # debugging aid: all ranks on one GPU (exercises the N>1 control flow on a 1-GPU box)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if os.environ.get("NVBIO_BENCH_SHARE_GPU") == "1":
+            dist.init_process_group("gloo")       # RCCL refuses two ranks on one device; gloo stages the gather through the host
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node == --gpus"
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local])
+            if dist.get_backend() == "nccl":
+                dist.barrier(device_ids=[local])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     if a.only == "full":
@@ -118,10 +126,10 @@ def main():
     def launch(buf):
         batch.enact(aligner, patterns, texts, buf[0], buf[1])
 
-    # result records: score[n] + sink[n,2], gathered as 8 B per read; double-buffered so that the gather
+    # result records: score[n] + sink[n,2], gathered as 4 B per read (score:16, sink.x:8, sink.y:8 -- 100 bp reads); double-buffered so that the gather
     # of step k (side stream) overlaps the kernel of step k+1
     outs = [(torch.empty(n, dtype=torch.int32, device=dev), torch.empty((n, 2), dtype=torch.int32, device=dev)) for _ in range(2)]
-    gatherers = [ResultGather(n * world, dst=0, device=dev) for _ in range(2)] if world > 1 else None
+    gatherers = [ResultGather(n * world, dst=0, device=dev, record_bytes=4) for _ in range(2)] if world > 1 else None
 
     pending = [None, None]
 
@@ -137,7 +145,7 @@ def main():
         if world > 1:
             comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(comm_stream):
-                gatherers[b].gather(outs[b][0], outs[b][1], concat=False)   # 8 B/read to rank 0 over RCCL/xGMI
+                gatherers[b].gather(outs[b][0], outs[b][1], concat=False)   # 4 B/read to rank 0 over RCCL/xGMI
                 pending[b] = torch.cuda.Event()
                 pending[b].record(comm_stream)
 
@@ -171,7 +179,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(a.steps, 1)

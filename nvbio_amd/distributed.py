@@ -26,19 +26,26 @@ class ResultGather:
 
     xGMI is point-to-point, so this is a gather (send/recv to the root over its 7 links), not a
     ring all-gather: the root receives (G-1)/G of the bytes once, nobody else receives anything.
-    compact=True (sinks below 65536, i.e. any short-read batch) packs a record into 8 bytes
-    {score, sink.x << 16 | sink.y} -- at 3 G reads/s per GPU the root of an 8-GPU node then takes in
-    ~190 GB/s instead of ~280 GB/s.  Buffers are allocated once; `gather()` can be enqueued on a side
-    stream to overlap the next batch's kernel."""
+    Record sizes (`record_bytes`):
+      12  {score, sink.x, sink.y}                          any batch
+       8  {score, sink.x << 16 | sink.y}                   sinks below 65535 (any short-read batch)
+       4  {score:int16 << 16 | sink.x:8 << 8 | sink.y:8}   sinks below 255 and |score| < 32767, e.g. 100 bp
+          reads in band-15 windows: at 3.3 G reads/s per GPU the root of an 8-GPU node takes in ~93 GB/s
+    An untouched sink (score -2^30, sink (-1,-1): text shorter than pattern) round-trips in every format.
+    Buffers are allocated once; `gather()` can be enqueued on a side stream to overlap the next
+    batch's kernel."""
 
-    def __init__(self, n_total, dst=0, device=None, group=None, compact=True):
-        self.group, self.dst, self.compact = group, dst, compact
+    def __init__(self, n_total, dst=0, device=None, group=None, compact=True, record_bytes=None):
+        if record_bytes is None:
+            record_bytes = 8 if compact else 12
+        assert record_bytes in (4, 8, 12)
+        self.group, self.dst, self.record_bytes = group, dst, record_bytes
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.sizes = shard_sizes(n_total, self.world)
         self.n_total = n_total
         self.pad = max(self.sizes) if self.sizes else 0
-        self.width = 2 if compact else 3
+        self.width = record_bytes // 4
         self.bufs = None
         if self.world > 1 and self.rank == dst:
             self.bufs = [torch.empty((self.pad, self.width), dtype=torch.int32, device=device) for _ in range(self.world)]
@@ -53,23 +60,41 @@ class ResultGather:
         if self.world == 1:
             return score, sink
         sink = sink.view(-1, 2)
-        self.send[:n, 0] = score
-        if self.compact:
+        if self.record_bytes == 4:
+            s16 = torch.clamp(score, min=-32768)          # only the untouched-sink score lies below
+            self.send[:n, 0] = (s16 << 16) | ((sink[:, 0] & 0xFF) << 8) | (sink[:, 1] & 0xFF)
+        elif self.record_bytes == 8:
+            self.send[:n, 0] = score
             self.send[:n, 1] = (sink[:, 0] << 16) | (sink[:, 1] & 0xFFFF)
         else:
+            self.send[:n, 0] = score
             self.send[:n, 1:] = sink
-        dist.gather(self.send, self.bufs if self.rank == self.dst else None, dst=self.dst, group=self.group)
+        if self.send.is_cuda and dist.get_backend(self.group) != "nccl":
+            # gloo cannot gather device tensors: stage through the host (debug / CPU-test configurations only)
+            host = [torch.empty(b.shape, dtype=b.dtype) for b in self.bufs] if self.rank == self.dst else None
+            dist.gather(self.send.cpu(), host, dst=self.dst, group=self.group)
+            if host is not None:
+                for b, h in zip(self.bufs, host):
+                    b.copy_(h)
+        else:
+            dist.gather(self.send, self.bufs if self.rank == self.dst else None, dst=self.dst, group=self.group)
         if self.rank != self.dst:
             return None
         if not concat:
             return True
         rec = torch.cat([self.bufs[r][: self.sizes[r]] for r in range(self.world)], dim=0)
-        if self.compact:
-            sx = (rec[:, 1] >> 16) & 0xFFFF
-            sy = rec[:, 1] & 0xFFFF
-            # an invalid sink (0xFFFFFFFF, 0xFFFFFFFF) round-trips as (0xFFFF, 0xFFFF): restore it
-            bad = (sx == 0xFFFF) & (sy == 0xFFFF)
-            sx = torch.where(bad, torch.full_like(sx, -1), sx)
-            sy = torch.where(bad, torch.full_like(sy, -1), sy)
-            return rec[:, 0].contiguous(), torch.stack([sx, sy], dim=1).contiguous()
-        return rec[:, 0].contiguous(), rec[:, 1:].contiguous()
+        if self.record_bytes == 12:
+            return rec[:, 0].contiguous(), rec[:, 1:].contiguous()
+        if self.record_bytes == 8:
+            sc = rec[:, 0].contiguous()
+            sx, sy, none = (rec[:, 1] >> 16) & 0xFFFF, rec[:, 1] & 0xFFFF, 0xFFFF
+        else:
+            sc = rec[:, 0] >> 16                            # arithmetic shift: sign-extends the int16 score
+            sx, sy, none = (rec[:, 0] >> 8) & 0xFF, rec[:, 0] & 0xFF, 0xFF
+        # an untouched sink (0xFFFFFFFF, 0xFFFFFFFF) round-trips as all-ones fields: restore it
+        bad = (sx == none) & (sy == none)
+        sx = torch.where(bad, torch.full_like(sx, -1), sx)
+        sy = torch.where(bad, torch.full_like(sy, -1), sy)
+        if self.record_bytes == 4:
+            sc = torch.where(bad & (sc == -32768), torch.full_like(sc, -(1 << 30)), sc)
+        return sc.contiguous(), torch.stack([sx, sy], dim=1).contiguous()

@@ -28,18 +28,19 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, n, q, compact=True):
+def _worker(rank, world, port, n, q, record_bytes=8):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         patterns, texts = W.make_sw_batch(n, seed=77, device="cpu")        # same batch on every rank
         hp, ht = O.StringSet.from_device(patterns), O.StringSet.from_device(texts)
+        ht.length[5::7] = 60                                               # some texts shorter than their pattern: untouched sinks
         lo, hi = shard_range(n, rank, world)
         sub_p = O.StringSet(hp.words, hp.bits, hp.big_endian, hp.begin[lo:hi], hp.length[lo:hi])
         sub_t = O.StringSet(ht.words, ht.bits, ht.big_endian, ht.begin[lo:hi], ht.length[lo:hi])
         s, k = O.batch_banded_gotoh_score(15, O.LOCAL, (2, -1, -2, -1), sub_p, sub_t, n_threads=1)
-        g = ResultGather(n, dst=0, device="cpu", compact=compact)
+        g = ResultGather(n, dst=0, device="cpu", record_bytes=record_bytes)
         for _ in range(2):                                                   # buffers are reusable
             out = g.gather(torch.from_numpy(s), torch.from_numpy(k.view(np.int32)))
         if rank == 0:
@@ -52,12 +53,12 @@ def _worker(rank, world, port, n, q, compact=True):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,compact", [(1001, True), (64, False)])
-def test_two_rank_shard_and_gather(n, compact):
+@pytest.mark.parametrize("n,record_bytes", [(1001, 8), (64, 12), (1001, 4)])
+def test_two_rank_shard_and_gather(n, record_bytes):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q, compact)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q, record_bytes)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
