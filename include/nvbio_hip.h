@@ -231,6 +231,25 @@ int nvbio_hip_map_exact(const nvbio_hip_fmindex* fmi, const nvbio_hip_string_set
                         const uint32_t* seed_freq_by_len /* device */,
                         uint64_t* out_hits, uint32_t hits_stride, uint32_t* out_counts, uint8_t* out_reseed, void* stream);
 
+/* nvBowtie's seed mapping algorithms (mapping_inl.h:118-123; chosen by map_t, :809-843, from
+ * params.allow_sub / params.subseed_len). */
+enum { NVBIO_HIP_EXACT_MAPPING = 0, NVBIO_HIP_APPROX_MAPPING = 1, NVBIO_HIP_CASE_PRUNING_MAPPING = 2 };
+
+/* Replaces map_queues_kernel<ALGO> for all three algorithms (mapping_inl.h:511-592):
+ *   EXACT         as nvbio_hip_map_exact (rfmi, subseed_len ignored)
+ *   APPROX        seed_mapper<APPROX_MAPPING> (:318-365): per seed, map<CHECK_EXACT> of the stored seed and
+ *                 map<IGNORE_EXACT> of its reversed complement on the forward index -- exact in the first
+ *                 subseed_len scan symbols, one substitution (enumerated with rank4) in the rest
+ *   CASE_PRUNING  seed_mapper<CASE_PRUNING_MAPPING> (:372-428): the four half-exact / half-one-mismatch
+ *                 searches over the forward index fmi and the index of the reversed genome rfmi
+ * with map<> as in mapping_inl.h:124-223 (N handling included).  Hits are SeedHit word pairs as in
+ * nvbio_hip_map_exact, index_dir (bit 31) = 1 for hits found on rfmi.  Seeds up to 32 symbols. */
+int nvbio_hip_map(int32_t algorithm, uint32_t subseed_len,
+                  const nvbio_hip_fmindex* fmi, const nvbio_hip_fmindex* rfmi /* CASE_PRUNING only */,
+                  const nvbio_hip_string_set* reads, const uint32_t* in_queue, uint32_t n,
+                  const nvbio_hip_map_params* params /* host */, const uint32_t* seed_freq_by_len /* device */,
+                  uint64_t* out_hits, uint32_t hits_stride, uint32_t* out_counts, uint8_t* out_reseed, void* stream);
+
 /* Replaces nvbio::locate(fmi, i) (fmindex_inl.h:466-501) and nvBowtie's
  * locate_kernel (nvBowtie/bowtie2/cuda/locate_inl.h:122-148). */
 int nvbio_hip_fm_locate(const nvbio_hip_fmindex* fmi, const uint32_t* sa_rows,

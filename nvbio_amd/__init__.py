@@ -14,4 +14,4 @@ from .alignment import (GLOBAL, LOCAL, SEMI_GLOBAL, SimpleGotohScheme, SmithWate
                         BatchedBandedAlignmentTraceback, batch_banded_alignment_traceback)
 from .fmindex import FMIndexDevice, FMIndexFilter, rank, rank4, rank_range, match, locate, \
     locate_ssa_iterator, lookup_ssa_iterator, build_bwt_occ  # noqa: F401
-from .mapping import MappingParams, map_exact, unpack_seed_hits  # noqa: F401
+from .mapping import MappingParams, map_exact, map_seeds, unpack_seed_hits  # noqa: F401

@@ -10,7 +10,7 @@ SYMBOLS = [
     "nvbio_hip_banded_gotoh_score", "nvbio_hip_banded_gotoh_score_qual", "nvbio_hip_gotoh_score",
     "nvbio_hip_banded_gotoh_traceback_temp_bytes", "nvbio_hip_banded_gotoh_traceback", "nvbio_hip_banded_gotoh_traceback_qual",
     "nvbio_hip_fm_rank", "nvbio_hip_fm_rank4", "nvbio_hip_fm_rank_range",
-    "nvbio_hip_fm_match", "nvbio_hip_fm_build_ktab", "nvbio_hip_map_exact", "nvbio_hip_fm_locate",
+    "nvbio_hip_fm_match", "nvbio_hip_fm_build_ktab", "nvbio_hip_map_exact", "nvbio_hip_map", "nvbio_hip_fm_locate",
     "nvbio_hip_fm_locate_ssa_iterator", "nvbio_hip_fm_lookup_ssa_iterator",
     "nvbio_hip_fm_filter_temp_bytes", "nvbio_hip_fm_filter_rank", "nvbio_hip_fm_filter_locate",
     "nvbio_hip_build_bwt_occ_temp_bytes", "nvbio_hip_build_bwt_occ",
@@ -74,6 +74,7 @@ def lib():
         L.nvbio_hip_fm_match.argtypes = [P(FMIndexStruct), P(StringSetStruct), u32, vp, vp]
         L.nvbio_hip_fm_build_ktab.argtypes = [P(FMIndexStruct), u32, vp, vp]
         L.nvbio_hip_map_exact.argtypes = [P(FMIndexStruct), P(StringSetStruct), vp, u32, P(MapParamsStruct), vp, vp, u32, vp, vp, vp]
+        L.nvbio_hip_map.argtypes = [i32, u32, P(FMIndexStruct), P(FMIndexStruct), P(StringSetStruct), vp, u32, P(MapParamsStruct), vp, vp, u32, vp, vp, vp]
         L.nvbio_hip_fm_locate.argtypes = [P(FMIndexStruct), vp, u32, vp, vp]
         L.nvbio_hip_fm_locate_ssa_iterator.argtypes = [P(FMIndexStruct), vp, u32, vp, vp]
         L.nvbio_hip_fm_lookup_ssa_iterator.argtypes = [P(FMIndexStruct), vp, u32, vp, vp]

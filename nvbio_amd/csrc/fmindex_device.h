@@ -124,6 +124,33 @@ __device__ __forceinline__ uint4 fm_rank4(const Fmi& f, uint32_t k)
     return o;
 }
 
+// rank4 over a range (fmindex_inl.h:148-186): both ends resolved independently, one record load when
+// they share a block
+__device__ __forceinline__ void fm_rank4_range(const Fmi& f, uint32_t x, uint32_t y, uint4& lo, uint4& hi)
+{
+    const uint4 all = make_uint4(f.L2[1] - f.L2[0], f.L2[2] - f.L2[1], f.L2[3] - f.L2[2], f.L2[4] - f.L2[3]);
+    bool nx = !(x == 0xFFFFFFFFu || x == f.length);
+    bool ny = !(y == 0xFFFFFFFFu || y == f.length);
+    uint32_t ax = x, ay = y;
+    if (nx && ax >= f.primary) --ax;
+    if (ny && ay >= f.primary) --ay;
+    if (nx && ax == 0xFFFFFFFFu) nx = false;
+    if (ny && ay == 0xFFFFFFFFu) ny = false;
+    Record rx, ry;
+    if (nx) rx = load_record(f, ax >> 6);
+    if (ny) { if (nx && (ax >> 6) == (ay >> 6)) ry = rx; else ry = load_record(f, ay >> 6); }
+    auto count4 = [](const Record& r, const uint32_t cnt) {
+        uint4 o = r.occ;
+        o.x += block_count(r.bwt, cnt, 0);
+        o.y += block_count(r.bwt, cnt, 1);
+        o.z += block_count(r.bwt, cnt, 2);
+        o.w = r.occ.w + cnt - (o.x - r.occ.x) - (o.y - r.occ.y) - (o.z - r.occ.z);
+        return o;
+    };
+    lo = nx ? count4(rx, (ax & 63u) + 1u) : (x == f.length ? all : make_uint4(0, 0, 0, 0));
+    hi = ny ? count4(ry, (ay & 63u) + 1u) : (y == f.length ? all : make_uint4(0, 0, 0, 0));
+}
+
 // ------------------------------------------------------------------ backward search
 // match (fmindex_inl.h:307-341) with nvBowtie's symbol test (mapping_inl.h:83-97).
 // One lane = one seed; the seed is pulled 16 symbols per fetch.

@@ -56,6 +56,31 @@ def map_exact(fmi, reads, params, max_read_len, retry=0, fw=True, rc=True, in_qu
     return hits, counts, reseed
 
 
+EXACT_MAPPING, APPROX_MAPPING, CASE_PRUNING_MAPPING = 0, 1, 2      # MappingAlgorithm (mapping_inl.h:118-123)
+
+
+def map_seeds(fmi, rfmi, reads, params, max_read_len, allow_sub=0, subseed_len=0, retry=0, fw=True, rc=True, in_queue=None, hits_stride=64):
+    """nvBowtie's map() with the algorithm choice of map_t (mapping_inl.h:809-843): allow_sub == 0 -> exact;
+    allow_sub and subseed_len == 0 -> case pruning (uses rfmi, the index of the reversed genome);
+    allow_sub and subseed_len > 0 -> exact subseed + one mismatch in the rest.  Returns (hits, counts, reseed)
+    as map_exact does; index_dir = 1 marks hits found on rfmi."""
+    algorithm = EXACT_MAPPING if not allow_sub else (CASE_PRUNING_MAPPING if subseed_len == 0 else APPROX_MAPPING)
+    dev = reads.words.device
+    n_reads = len(reads)
+    n = in_queue.numel() if in_queue is not None else n_reads
+    sf = params.seed_freq_table(max_read_len, dev)
+    hits = torch.zeros((n_reads, hits_stride), dtype=torch.int64, device=dev)
+    counts = torch.zeros(n_reads, dtype=torch.int32, device=dev)
+    reseed = torch.zeros(n, dtype=torch.uint8, device=dev)
+    s, rs, mp = fmi.struct(), reads.struct(), params.struct(retry, fw, rc)
+    r = rfmi.struct() if rfmi is not None else None
+    q = C.c_void_p(in_queue.data_ptr()) if in_queue is not None else None
+    check(lib().nvbio_hip_map(algorithm, int(subseed_len), C.byref(s), C.byref(r) if r is not None else None, C.byref(rs), q, n, C.byref(mp),
+                              C.c_void_p(sf.data_ptr()), C.c_void_p(hits.data_ptr()), hits_stride, C.c_void_p(counts.data_ptr()),
+                              C.c_void_p(reseed.data_ptr()), current_stream_ptr()), "nvbio_hip_map")
+    return hits, counts, reseed
+
+
 def unpack_seed_hits(words):
     """SeedHit word pairs (int64, little-endian: low word = range_begin) -> dict of int64 arrays."""
     w = words.to(torch.int64)

@@ -1101,6 +1101,119 @@ ORACLE_API void oracle_map_exact(const oracle_fmi_t* f,
     }
 }
 
+/* ------------------------------------------------------------------------ */
+/* nvBowtie seed mapping with one mismatch                                    */
+/*   map<find_exact>                   mapping_inl.h:124-223                  */
+/*   seed_mapper<APPROX_MAPPING>       mapping_inl.h:318-365                  */
+/*   seed_mapper<CASE_PRUNING_MAPPING> mapping_inl.h:372-428                  */
+/*   map_queues_kernel<ALGO>           mapping_inl.h:511-592                  */
+/*   map_t (algorithm choice)          mapping_inl.h:809-843                  */
+/* ------------------------------------------------------------------------ */
+typedef struct { const uint32_t* w; uint32_t bits, be; uint64_t begin; uint32_t len; int reverse, complement; } seed_reader_t;
+
+static inline uint32_t seed_sym(const seed_reader_t* r, uint32_t t)
+{
+    uint32_t c = ps_get(r->w, r->bits, r->be, r->begin + (r->reverse ? r->len - 1 - t : t));
+    if (r->complement) c = (c >= 4) ? c : 3u - c;            /* complement_functor<4> */
+    return c;
+}
+
+/* match_range (mapping_inl.h:80-96): inclusive range in/out */
+static void match_range_span(const oracle_fmi_t* f, const seed_reader_t* q, uint32_t begin, uint32_t end, uint32_t* rx, uint32_t* ry)
+{
+    for (uint32_t i = begin; i < end && *rx <= *ry; ++i) {
+        const uint32_t c = seed_sym(q, i);
+        if (c > 3) { *rx = 1; *ry = 0; return; }
+        uint32_t a, b;
+        fm_rank2(f, *rx - 1, *ry, c, &a, &b);
+        *rx = f->L2[c] + a + 1;
+        *ry = f->L2[c] + b;
+    }
+}
+
+typedef struct { uint64_t* hits; uint32_t nh, cap, range_sum, range_count; } hit_heap_t;
+
+static void heap_push(hit_heap_t* h, uint32_t x, uint32_t y /* inclusive */, uint32_t pos, uint32_t rc, uint32_t indexdir)
+{
+    if (h->nh == h->cap) {                                   /* pop_bottom: drop a largest range */
+        uint32_t worst = 0;
+        for (uint32_t k = 1; k < h->nh; ++k)
+            if (((h->hits[k] >> 32) & 0xFFFFFu) > ((h->hits[worst] >> 32) & 0xFFFFFu)) worst = k;
+        h->hits[worst] = h->hits[--h->nh];
+    }
+    h->hits[h->nh++] = seed_hit_pack(x, y + 1u - x, pos, rc, indexdir);
+    h->range_sum += y - x + 1u; h->range_count++;
+}
+
+static void map_one_mismatch(int find_exact, const seed_reader_t* q, uint32_t len1, uint32_t len2, const oracle_fmi_t* f,
+                             uint32_t pos, uint32_t rc, uint32_t indexdir, hit_heap_t* heap)
+{
+    /* a read shorter than subseed_len makes the reference index outside its seed (query[i], i >= len2, and
+     * ReverseXform wraps below zero): undefined there, defined here as an all-exact search of the seed */
+    if (len1 > len2) len1 = len2;
+    uint32_t N_pos = 0, N_cnt = 0;
+    for (uint32_t i = 0; i < len2; ++i)
+        if (seed_sym(q, i) > 3) { if (i < len1 || N_cnt) return; N_pos = i; N_cnt++; }
+    len1 = N_cnt ? N_pos : len1;
+    uint32_t bx = 0, by = f->length;
+    match_range_span(f, q, 0, len1, &bx, &by);
+    for (uint32_t i = len1; i < len2 && bx <= by; ++i)
+    {
+        const uint32_t c = seed_sym(q, i);
+        uint32_t lo[4], hi[4];
+        fm_rank4(f, bx - 1, lo); fm_rank4(f, by, hi);
+        for (uint32_t sub = 0; sub < 4; ++sub)
+            if (sub != c && hi[sub] > lo[sub]) {
+                uint32_t x = f->L2[sub] + lo[sub] + 1, y = f->L2[sub] + hi[sub];
+                match_range_span(f, q, i + 1, len2, &x, &y);
+                if (x <= y) heap_push(heap, x, y, pos, rc, indexdir);
+            }
+        if (c < 4) { bx = f->L2[c] + lo[c] + 1; by = f->L2[c] + hi[c]; }
+        else { bx = 1; by = 0; break; }
+    }
+    if (find_exact && bx <= by) heap_push(heap, bx, by, pos, rc, indexdir);
+}
+
+/* algorithm: 0 exact, 1 approx (subseed_len exact + 1 mismatch in the rest), 2 case pruning (needs rf = index of the reversed text) */
+ORACLE_API void oracle_map(int algorithm, uint32_t subseed_len, const oracle_fmi_t* f, const oracle_fmi_t* rf,
+    const uint32_t* w, uint32_t bits, uint32_t be, const uint64_t* read_begin, const uint32_t* read_len,
+    const uint32_t* in_queue /* nullable */, uint32_t n, const oracle_map_params_t* p, const uint32_t* seed_freq_by_len,
+    uint64_t* out_hits, uint32_t hits_stride, uint32_t* out_counts, uint8_t* out_reseed /* nullable */)
+{
+    if (algorithm == 0) { oracle_map_exact(f, w, bits, be, read_begin, read_len, in_queue, n, p, seed_freq_by_len, out_hits, hits_stride, out_counts, out_reseed); return; }
+    for (uint32_t id = 0; id < n; ++id)
+    {
+        const uint32_t read_id = in_queue ? in_queue[id] : id;
+        const uint64_t rx = read_begin[read_id];
+        const uint32_t rlen = read_len[read_id];
+        hit_heap_t heap = { out_hits + (uint64_t)read_id * hits_stride, 0, p->max_hits < hits_stride ? p->max_hits : hits_stride, 0, 0 };
+        if (rlen < p->min_read_len) { out_counts[read_id] = 0; continue; }
+        const uint32_t seed_len = p->seed_len < rlen ? p->seed_len : rlen;
+        const uint32_t seed_freq = seed_freq_by_len[rlen];
+        const uint32_t retry_stride = seed_freq / (p->max_reseed + 1);
+        for (uint64_t pos = rx + (uint64_t)p->retry * retry_stride; pos + seed_len <= rx + rlen; pos += seed_freq)
+        {
+            const seed_reader_t fr  = { w, bits, be, pos, seed_len, 0, 0 }, rr  = { w, bits, be, pos, seed_len, 1, 0 };
+            const seed_reader_t cfr = { w, bits, be, pos, seed_len, 0, 1 }, crr = { w, bits, be, pos, seed_len, 1, 1 };
+            const uint32_t rel = (uint32_t)(pos - rx);
+            if (algorithm == 1) {
+                uint32_t nN = 0;
+                for (uint32_t i = 0; i < seed_len; ++i) nN += (seed_sym(&fr, i) == 4u);
+                if (nN >= 2) continue;                                                           /* :346 */
+                if (p->fw) map_one_mismatch(1, &fr,  subseed_len, seed_len, f, rlen - rel - seed_len, 0, 0, &heap);
+                if (p->rc) map_one_mismatch(0, &crr, subseed_len, seed_len, f, rel,                   1, 0, &heap);
+            } else {
+                if (p->fw) map_one_mismatch(1, &fr,  seed_len / 2,       seed_len, f,  rlen - rel - seed_len, 0, 0, &heap);
+                if (p->fw) map_one_mismatch(0, &rr,  (seed_len + 1) / 2, seed_len, rf, rlen - rel - 1,        0, 1, &heap);
+                if (p->rc) map_one_mismatch(1, &cfr, seed_len / 2,       seed_len, rf, rel + seed_len - 1,    1, 1, &heap);
+                if (p->rc) map_one_mismatch(0, &crr, (seed_len + 1) / 2, seed_len, f,  rel,                   1, 0, &heap);
+            }
+        }
+        out_counts[read_id] = heap.nh;
+        if (out_reseed) out_reseed[id] = (heap.range_count == 0 || heap.range_sum >= p->rep_seeds * heap.range_count);
+    }
+}
+
 /* SimpleFunc (nvBowtie/bowtie2/cuda/func.h:39-70) tabulated for x in [0,n): type 0 linear, 1 log, 2 sqrt */
 #include <math.h>
 ORACLE_API void oracle_simple_func_table(int type, float k, float m, uint32_t n, uint32_t* out)

@@ -464,5 +464,22 @@ def map_exact(fmi, reads, params, seed_freq_by_len, hits_stride, in_queue=None):
     return hits, counts, reseed
 
 
+def map_seeds(algorithm, subseed_len, fmi, rfmi, reads, params, seed_freq_by_len, hits_stride, in_queue=None):
+    """nvBowtie seed mapping (map_queues_kernel<ALGO>): algorithm 0 exact, 1 approx (exact subseed + one
+    mismatch in the rest, forward index), 2 case pruning (needs rfmi = the index of the reversed text)."""
+    n_reads = len(reads)
+    q = _u32(in_queue) if in_queue is not None else None
+    n = q.size if q is not None else n_reads
+    hits = np.zeros((n_reads, hits_stride), dtype=np.uint64)
+    counts = np.zeros(n_reads, dtype=np.uint32)
+    reseed = np.zeros(n, dtype=np.uint8)
+    sf = _u32(seed_freq_by_len)
+    mp = MapParams(**params)
+    lib().oracle_map(C.c_int(algorithm), C.c_uint32(subseed_len), fmi._ref(), rfmi._ref() if rfmi is not None else None,
+                     _p(reads.words), C.c_uint32(reads.bits), C.c_uint32(reads.big_endian), _p(reads.begin), _p(reads.length),
+                     _p(q), C.c_uint32(n), C.byref(mp), _p(sf), _p(hits), C.c_uint32(hits_stride), _p(counts), _p(reseed))
+    return hits, counts, reseed
+
+
 def num_threads():
     return int(lib().oracle_num_threads())

@@ -13,6 +13,7 @@
 #include <string>
 #include <nvbio_hip/alignment.h>
 #include <nvbio_hip/fmindex.h>
+#include <nvbio_hip/mapping.h>
 
 using namespace nvbio;
 
@@ -39,6 +40,11 @@ void oracle_fm_rank4(const oracle_fmi_t* f, const uint32_t* k, uint32_t n, uint3
 void oracle_fm_match(const oracle_fmi_t* f, const uint32_t* w, uint32_t bits, uint32_t be, const uint64_t* begin, const uint32_t* len,
     uint32_t n, uint32_t* out_range, uint64_t* algo_bytes, int n_threads);
 void oracle_fm_locate(const oracle_fmi_t* f, const uint32_t* rows, uint32_t n, uint32_t* out_pos, uint64_t* total_steps, int n_threads);
+typedef struct { uint32_t seed_len, min_read_len, max_hits, max_reseed, retry, rep_seeds, fw, rc; } oracle_map_params_t;
+void oracle_map(int algorithm, uint32_t subseed_len, const oracle_fmi_t* f, const oracle_fmi_t* rf,
+    const uint32_t* w, uint32_t bits, uint32_t be, const uint64_t* read_begin, const uint32_t* read_len,
+    const uint32_t* in_queue, uint32_t n, const oracle_map_params_t* p, const uint32_t* seed_freq_by_len,
+    uint64_t* out_hits, uint32_t hits_stride, uint32_t* out_counts, uint8_t* out_reseed);
 uint64_t oracle_filter_rank(const oracle_fmi_t* f, const uint32_t* w, uint32_t bits, uint32_t be, const uint64_t* begin, const uint32_t* len,
     uint32_t n, uint32_t* ranges, uint64_t* slots);
 void oracle_filter_locate(const oracle_fmi_t* f, const uint32_t* ranges, const uint64_t* slots, uint32_t n_queries,
@@ -265,11 +271,12 @@ struct HostIndex {
     oracle_fmi_t ofmi;
 };
 
-static void build_host_index(HostIndex& h, uint32 n, uint32 seed)
+static void build_host_index(HostIndex& h, uint32 n, uint32 seed, bool reversed = false)
 {
     h.n = n; h.text.resize(n);
     LCG_random rnd(seed);
     for (uint32 i = 0; i < n; ++i) h.text[i] = uint8(rnd.sym());
+    if (reversed) std::reverse(h.text.begin(), h.text.end());      // the index of the reversed genome (rfmi)
     // suffix array by prefix doubling; SA[0] = n (the '$' suffix) as gen_sa pads it (bwt.h:36-45)
     std::vector<uint32> sa(n + 1), rk(n + 1), tmp(n + 1);
     std::iota(sa.begin(), sa.end(), 0u);
@@ -373,6 +380,52 @@ static int fmindex_test()
         if (expect != n_hits) FAIL("filter.rank: %llu hits, expected %llu", (unsigned long long)n_hits, (unsigned long long)expect);
         for (uint64 i = 0; i < n_hits; ++i)
             if (memcmp(h.text.data() + hits[i].x, seeds[hits[i].y].data(), LEN)) FAIL("hit %llu: text at %u does not hold seed %u", (unsigned long long)i, hits[i].x, hits[i].y);
+    }
+    // nvBowtie's seed mapping stage: the three algorithms of map_t vs the oracle, hit sets compared sorted
+    {
+        HostIndex rh; build_host_index(rh, h.n, 11, /*reversed=*/true);
+        hip::device_vector<uint32> d_rbwt_occ(rh.bwt_occ), d_rssa(rh.ssa);
+        fm_index_device rfmi(rh.n, rh.primary, rh.L2, d_rbwt_occ.data(), d_rssa.data(), 16);
+        const uint32 R = 8192, STRIDE = 128;
+        std::vector<std::vector<uint8> > reads(R);
+        for (uint32 r = 0; r < R; ++r) {
+            const uint32 L = 30 + r % 100, p = rnd.next() % (h.n - L);
+            reads[r].assign(h.text.begin() + p, h.text.begin() + p + L);
+            if (r & 1) { std::reverse(reads[r].begin(), reads[r].end()); for (auto& c : reads[r]) c = uint8(3 - c); }
+            for (uint32 j = 0; j < L; ++j) if ((rnd.next() >> 16) % 100 < 3) reads[r][j] = uint8(rnd.sym());
+            if (r % 19 == 0) reads[r][r % L] = 4;
+            std::reverse(reads[r].begin(), reads[r].end());          // io::REVERSE storage
+        }
+        PackedStringSetDevice<4, true> d_reads(reads);
+        std::vector<uint8> cat; std::vector<uint64> rb(R); std::vector<uint32> rl(R);
+        for (uint32 r = 0; r < R; ++r) { rb[r] = cat.size(); rl[r] = uint32(reads[r].size()); cat.insert(cat.end(), reads[r].begin(), reads[r].end()); }
+        const std::vector<uint32> rw = pack_symbols<4, true>(cat.data(), cat.size());
+        for (int mode = 0; mode < 3; ++mode) {
+            bowtie2::cuda::ParamsPOD params;
+            params.allow_sub = mode > 0; params.subseed_len = mode == 1 ? 12u : 0u; params.max_hits = 120;
+            const std::vector<uint32> sf = params.seed_freq_table(130);
+            hip::device_vector<uint32> d_sf(sf), d_counts(R);
+            hip::device_vector<bowtie2::cuda::SeedHit> d_hits(size_t(R) * STRIDE);
+            hip::device_vector<uint8> d_reseed(R);
+            bowtie2::cuda::SeedHitDequeArrayDeviceView hits = { d_hits.data(), STRIDE, d_counts.data() };
+            const bowtie2::cuda::PingPongQueuesView queues = { R, nullptr };
+            bowtie2::cuda::map(d_reads.view(), fmi, rfmi, 0u, queues, d_reseed.data(), hits, params, d_sf.data(), true, true);
+            hip::synchronize();
+            const std::vector<bowtie2::cuda::SeedHit> gh = d_hits.to_host(); const std::vector<uint32> gc = d_counts.to_host(); const std::vector<uint8> gr = d_reseed.to_host();
+            const oracle_map_params_t op = { params.seed_len, params.min_read_len, params.max_hits, params.max_reseed, 0u, params.rep_seeds, 1u, 1u };
+            std::vector<uint64> eh(size_t(R) * STRIDE); std::vector<uint32> ec(R); std::vector<uint8> er(R);
+            oracle_map(mode, params.subseed_len, &h.ofmi, &rh.ofmi, rw.data(), 4, 1, rb.data(), rl.data(), nullptr, R, &op, sf.data(), eh.data(), STRIDE, ec.data(), er.data());
+            uint64 total = 0;
+            for (uint32 r = 0; r < R; ++r) {
+                if (gc[r] != ec[r] || gr[r] != er[r]) FAIL("map mode %d read %u: %u hits (reseed %u), expected %u (%u)", mode, r, gc[r], gr[r], ec[r], er[r]);
+                std::vector<uint64> a(gc[r]), b(eh.begin() + size_t(r) * STRIDE, eh.begin() + size_t(r) * STRIDE + ec[r]);
+                memcpy(a.data(), &gh[size_t(r) * STRIDE], sizeof(uint64) * gc[r]);
+                std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
+                if (a != b) FAIL("map mode %d read %u: hit sets differ", mode, r);
+                total += gc[r];
+            }
+            fprintf(stderr, "    %-44s : %u reads, %llu seed hits ok\n", mode == 0 ? "map exact" : mode == 1 ? "map approx (subseed 12)" : "map case-pruning (fwd + rev index)", R, (unsigned long long)total);
+        }
     }
     fprintf(stderr, "FM-index test... done\n");
     return 0;

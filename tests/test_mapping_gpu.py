@@ -71,3 +71,47 @@ def test_seed_hit_sets(cuda, ragged):
     # the hits decode to seeds that really occur: fw hit rows locate to text positions holding the seed
     u = nvb.unpack_seed_hits(torch.from_numpy(gh.view(np.int64)))
     assert int(u["index_dir"].max()) == 0
+
+
+@pytest.mark.parametrize("allow_sub,subseed", [(1, 10), (1, 16), (1, 0)])
+def test_one_mismatch_seed_hit_sets(cuda, allow_sub, subseed):
+    """map_queues_kernel<APPROX_MAPPING / CASE_PRUNING_MAPPING> (params.allow_sub, params.subseed_len) vs the
+    oracle's restatement; per-read hit sets compared sorted."""
+    rng = np.random.default_rng(300 + subseed)
+    text = rng.integers(0, 4, 1 << 17, dtype=np.uint8)
+    text[5000:5600] = np.tile(np.array([0, 1], dtype=np.uint8), 300)
+    host, rhost = O.FMIndex(text), O.FMIndex(text[::-1].copy())
+    fmi, rfmi = nvb.FMIndexDevice.from_host(host, cuda), nvb.FMIndexDevice.from_host(rhost, cuda)
+    n = 3000
+    reads = make_reads(rng, text, n, ragged=True)
+    for i in range(0, n, 29):                            # a second N in some reads
+        reads[i][int(rng.integers(0, reads[i].size))] = 4
+    hr = O.StringSet.from_lists(reads, 4, True)
+    dr = nvb.PackedStringSet.from_host(hr.words, 4, True, hr.begin, hr.length, device=cuda)
+    max_len, stride, most = 160, 200, 0
+    for seed_len, retry, fw, rc, max_hits in ((22, 0, 1, 1, 200), (20, 1, 1, 1, 200), (32, 0, 1, 0, 200), (13, 2, 0, 1, 200), (22, 0, 1, 1, 5)):
+        if subseed > seed_len:
+            continue
+        params = nvb.MappingParams(seed_len=seed_len, max_hits=max_hits)
+        sf = O.simple_func_table(2, 1.0, 1.15, max_len + 1)
+        pd = dict(seed_len=seed_len, min_read_len=params.min_read_len, max_hits=max_hits, max_reseed=params.max_reseed,
+                  retry=retry, rep_seeds=params.rep_seeds, fw=fw, rc=rc)
+        algo = 2 if subseed == 0 else 1
+        eh, ec, er = O.map_seeds(algo, subseed, host, rhost, hr, pd, sf, stride)
+        for f_dev, rf_dev in ((fmi, rfmi), (fmi.with_ktab(8), rfmi.with_ktab(8))):       # the k-mer table must not change anything
+            gh, gc, gr = nvb.map_seeds(f_dev, rf_dev, dr, params, max_len, allow_sub=allow_sub, subseed_len=subseed, retry=retry,
+                                       fw=bool(fw), rc=bool(rc), hits_stride=stride)
+            torch.cuda.synchronize()
+            gh, gc, gr = gh.cpu().numpy().view(np.uint64), gc.cpu().numpy().view(np.uint32), gr.cpu().numpy()
+            assert (gc == ec).all(), (seed_len, np.nonzero(gc != ec)[0][:5])
+            assert (gr == er).all()
+            for r in range(n):
+                a, b = np.sort(gh[r, :gc[r]]), np.sort(eh[r, :ec[r]])
+                if max_hits == 5 and ec[r] == 5:
+                    assert (np.sort((a >> 32) & 0xFFFFF) == np.sort((b >> 32) & 0xFFFFF)).all()
+                else:
+                    assert (a == b).all(), (seed_len, r, a, b)
+        most = max(most, int(ec.max()))
+    assert most > 10
+    if subseed == 0:
+        assert int(nvb.unpack_seed_hits(torch.from_numpy(gh.view(np.int64)))["index_dir"].max()) == 1

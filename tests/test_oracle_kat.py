@@ -277,3 +277,81 @@ def test_filter_rank_locate(fmi):
     for pos, sid in hits:
         pat = bytes(seeds[int(sid)])
         assert s[int(pos):int(pos) + len(pat)] == pat
+
+
+# ---------------------------------------------------------------------------- one-mismatch seed mapping
+def _brute_hits(text, scan, len1, find_exact):
+    """Text positions whose substring equals the scan sequence (consumed back to front by the FM-index:
+    text[p + L-1-t] == scan[t]) with the mismatch pattern map<find_exact> accepts (mapping_inl.h:124-223):
+    exact in scan[0,len1), exactly one substitution in scan[len1,L) (or none, if find_exact);
+    a single N in [len1,L) is the forced mismatch position."""
+    L = len(scan)
+    n_pos = [i for i in range(L) if scan[i] > 3]
+    if len(n_pos) > 1 or (n_pos and n_pos[0] < len1):
+        return set()
+    if n_pos:
+        len1 = n_pos[0]
+    want = np.array(scan[::-1], dtype=np.int16)          # text order
+    win = np.lib.stride_tricks.sliding_window_view(text, L).astype(np.int16)
+    mism = win != want[None, :]
+    n_mism = mism.sum(1)
+    in_exact = mism[:, L - len1:].any(1) if len1 else np.zeros(len(win), bool)     # scan index t <-> text offset L-1-t
+    ok = ((n_mism == 1) & ~in_exact)
+    if n_pos:
+        ok = (n_mism == 1) & ~in_exact                   # the N position always mismatches
+    elif find_exact:
+        ok |= (n_mism == 0)
+    return set(np.nonzero(ok)[0].tolist())
+
+
+@pytest.mark.parametrize("algorithm,subseed", [(1, 8), (1, 14), (2, 0)])
+def test_one_mismatch_mappers_find_exactly_the_allowed_occurrences(algorithm, subseed):
+    rng = np.random.default_rng(31 + algorithm + subseed)
+    text = rng.integers(0, 4, 6000, dtype=np.uint8)
+    text[1000:1200] = np.tile(np.array([0, 1, 2], dtype=np.uint8), 67)[:200]
+    f, rf = O.FMIndex(text), O.FMIndex(text[::-1].copy())
+    L = 20
+    reads = []
+    for i in range(150):
+        p = int(rng.integers(0, text.size - L))
+        r = text[p:p + L].copy()
+        if i % 2:
+            r = (3 - r)[::-1].copy()
+        if i % 3 == 0:
+            r[int(rng.integers(0, L))] = rng.integers(0, 4)
+        if i % 11 == 0:
+            r[int(rng.integers(0, L))] = 4
+        if i % 37 == 0:
+            r[[2, 15]] = 4
+        reads.append(r[::-1].copy())                     # stored reversed (io::REVERSE)
+    hr = O.StringSet.from_lists(reads, 4, True)
+    sf = np.full(L + 1, 7, np.uint32)
+    pd = dict(seed_len=L, min_read_len=12, max_hits=1000, max_reseed=2, retry=0, rep_seeds=1000, fw=1, rc=1)
+    hits, counts, reseed = O.map_seeds(algorithm, subseed, f, rf, hr, pd, sf, 400)
+    rtext = text[::-1].copy()
+    n_with_mismatch_hits = 0
+    for i, stored in enumerate(reads):
+        got = {}
+        for h in hits[i, :counts[i]]:
+            begin, w1 = int(h & 0xFFFFFFFF), int(h >> 32)
+            delta, pos, rc, idir = w1 & 0xFFFFF, (w1 >> 20) & 0x3FF, (w1 >> 30) & 1, (w1 >> 31) & 1
+            sa = (rf if idir else f).sa
+            got.setdefault((rc, idir), set()).update(int(x) for x in sa[begin:begin + delta])
+            assert pos == {(0, 0): 0, (1, 0): 0, (0, 1): L - 1, (1, 1): L - 1}[(rc, idir)]     # one seed per read at pos 0 here
+        fwd = list(stored)                               # f_reader: scan t = stored[t]
+        rev = fwd[::-1]
+        comp = lambda q: [c if c > 3 else 3 - c for c in q]
+        if algorithm == 1:
+            nN = sum(c == 4 for c in fwd)
+            exp = {} if nN >= 2 else {(0, 0): _brute_hits(text, fwd, subseed, True), (1, 0): _brute_hits(text, comp(rev), subseed, False)}
+        else:
+            exp = {(0, 0): _brute_hits(text, fwd, L // 2, True), (0, 1): _brute_hits(rtext, rev, (L + 1) // 2, False),
+                   (1, 1): _brute_hits(rtext, comp(fwd), L // 2, True), (1, 0): _brute_hits(text, comp(rev), (L + 1) // 2, False)}
+        exp = {k: v for k, v in exp.items() if v}
+        assert got == exp, (i, got, exp)
+        n_with_mismatch_hits += (i % 3 == 0 and i % 11 != 0 and len(got) > 0)      # substituted reads that were still found
+    assert n_with_mismatch_hits > 5
+    # algorithm 0 through the same entry point == the exact mapper
+    h0, c0, r0 = O.map_seeds(0, 0, f, None, hr, pd, sf, 400)
+    h1, c1, r1 = O.map_exact(f, hr, pd, sf, 400)
+    assert (h0 == h1).all() and (c0 == c1).all() and (r0 == r1).all()
