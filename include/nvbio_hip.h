@@ -100,6 +100,28 @@ int nvbio_hip_gotoh_score(
     uint32_t max_pattern_len, uint32_t max_text_len, const int32_t* min_score /* device, nullable */,
     uint32_t n, int32_t* out_score, uint32_t* out_sink, uint8_t* out_ok, void* stream);
 
+/* nvbio::aln::SimpleSmithWatermanScheme (nvbio/alignment/utils.h:92-109): linear gap costs.
+ * EditDistanceAligner is this scheme with {0,-1,-1,-1} (ed/ed_utils.h:44-51). */
+typedef struct nvbio_hip_sw_scheme { int32_t match, mismatch, deletion, insertion; } nvbio_hip_sw_scheme;
+
+/* As nvbio_hip_banded_gotoh_score / nvbio_hip_gotoh_score, for
+ *   aligner = SmithWatermanAligner<TYPE, SimpleSmithWatermanScheme>  (sw/sw_banded_inl.h:340-520; sw/sw_inl.h:881-1222,
+ *             TextBlockingTag, 16-column blocks, int16 boundary column, no early exit)
+ *   aligner = EditDistanceAligner<TYPE>                              (ed/ed_banded_inl.h, ed/ed_inl.h:85-99: the same
+ *             code with EditDistanceSWScheme) -- the second leg of sw-benchmark (sw-benchmark.cu:641-657).
+ * Schemes with deletion != insertion are refused (801); the full-matrix form also refuses schemes/lengths whose
+ * values could leave int16 ((M [+ N for GLOBAL] + 4) * max|cost| >= 30000). */
+int nvbio_hip_banded_sw_score(
+    const nvbio_hip_sw_scheme* scheme /* host */, int32_t type, uint32_t band_len,
+    const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len,
+    uint32_t n, int32_t* out_score, uint32_t* out_sink, void* stream);
+int nvbio_hip_sw_score(
+    const nvbio_hip_sw_scheme* scheme /* host */, int32_t type,
+    const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len,
+    uint32_t n, int32_t* out_score, uint32_t* out_sink, void* stream);
+
 /* nvBowtie's SmithWatermanScoringScheme<QualCost,ConstantCost> as the Gotoh aligner sees it
  * (nvBowtie/bowtie2/cuda/scoring.h:283-293): substitution(r,q,qq) = (r == q) ? match : mismatch[qq],
  * with mismatch[qq] = -m_mmp(qq) tabulated by the host for every quality byte (the float->int

@@ -17,6 +17,25 @@ namespace aln {
 
 enum AlignmentType { GLOBAL = 0, LOCAL = 1, SEMI_GLOBAL = 2 };
 
+/// algorithm tags (alignment_base.h:72-79).  The banded aligners ignore them; the full-matrix batch
+/// implements the text-blocking form (its visiting order decides LOCAL ties).
+struct PatternBlockingTag {};
+struct TextBlockingTag {};
+
+/// SimpleSmithWatermanScheme (utils.h:92-109): linear gap costs
+struct SimpleSmithWatermanScheme
+{
+    SimpleSmithWatermanScheme() : m_match(0), m_mismatch(0), m_deletion(0), m_insertion(0) {}
+    SimpleSmithWatermanScheme(const int32 match, const int32 mm, const int32 del, const int32 ins)
+        : m_match(match), m_mismatch(mm), m_deletion(del), m_insertion(ins) {}
+    int32 match(const uint8 = 0) const { return m_match; }
+    int32 mismatch(const uint8 = 0) const { return m_mismatch; }
+    int32 mismatch(const uint8, const uint8, const uint8 = 0) const { return m_mismatch; }
+    int32 deletion() const { return m_deletion; }
+    int32 insertion() const { return m_insertion; }
+    int32 m_match, m_mismatch, m_deletion, m_insertion;
+};
+
 struct SimpleGotohScheme
 {
     SimpleGotohScheme() : m_match(0), m_mismatch(0), m_gap_open(0), m_gap_ext(0) {}
@@ -64,18 +83,77 @@ struct SmithWatermanScoringScheme
 };
 
 struct GotohTag {};
+struct SmithWatermanTag {};
+struct EditDistanceTag {};
 
-template <AlignmentType T, typename scoring_scheme_type>
+template <AlignmentType T, typename scoring_scheme_type, typename algorithm_tag = PatternBlockingTag>
 struct GotohAligner
 {
     static const AlignmentType TYPE = T;
     typedef GotohTag            aligner_tag;
+    typedef algorithm_tag       algorithm_type;
     typedef scoring_scheme_type scoring_scheme;
     GotohAligner(const scoring_scheme_type _scheme) : scheme(_scheme) {}
     scoring_scheme_type scheme;
 };
 template <AlignmentType TYPE, typename scoring_scheme_type>
 GotohAligner<TYPE, scoring_scheme_type> make_gotoh_aligner(const scoring_scheme_type& scheme) { return GotohAligner<TYPE, scoring_scheme_type>(scheme); }
+template <AlignmentType TYPE, typename algorithm_tag, typename scoring_scheme_type>
+GotohAligner<TYPE, scoring_scheme_type, algorithm_tag> make_gotoh_aligner(const scoring_scheme_type& scheme) { return GotohAligner<TYPE, scoring_scheme_type, algorithm_tag>(scheme); }
+
+/// SmithWatermanAligner<TYPE, scheme, algorithm_tag> (alignment_base.h): linear-gap DP
+template <AlignmentType T, typename scoring_scheme_type, typename algorithm_tag = PatternBlockingTag>
+struct SmithWatermanAligner
+{
+    static const AlignmentType TYPE = T;
+    typedef SmithWatermanTag    aligner_tag;
+    typedef algorithm_tag       algorithm_type;
+    typedef scoring_scheme_type scoring_scheme;
+    SmithWatermanAligner(const scoring_scheme_type _scheme) : scheme(_scheme) {}
+    scoring_scheme_type scheme;
+};
+template <AlignmentType TYPE, typename scoring_scheme_type>
+SmithWatermanAligner<TYPE, scoring_scheme_type> make_smith_waterman_aligner(const scoring_scheme_type& scheme) { return SmithWatermanAligner<TYPE, scoring_scheme_type>(scheme); }
+template <AlignmentType TYPE, typename algorithm_tag, typename scoring_scheme_type>
+SmithWatermanAligner<TYPE, scoring_scheme_type, algorithm_tag> make_smith_waterman_aligner(const scoring_scheme_type& scheme) { return SmithWatermanAligner<TYPE, scoring_scheme_type, algorithm_tag>(scheme); }
+
+/// EditDistanceAligner<TYPE, algorithm_tag>: the SW code with EditDistanceSWScheme (ed_utils.h:44-51)
+template <AlignmentType T, typename algorithm_tag = PatternBlockingTag>
+struct EditDistanceAligner
+{
+    static const AlignmentType TYPE = T;
+    typedef EditDistanceTag           aligner_tag;
+    typedef algorithm_tag             algorithm_type;
+    typedef SimpleSmithWatermanScheme scoring_scheme;
+    EditDistanceAligner() : scheme(0, -1, -1, -1) {}
+    SimpleSmithWatermanScheme scheme;
+};
+template <AlignmentType TYPE> EditDistanceAligner<TYPE> make_edit_distance_aligner() { return EditDistanceAligner<TYPE>(); }
+template <AlignmentType TYPE, typename algorithm_tag> EditDistanceAligner<TYPE, algorithm_tag> make_edit_distance_aligner() { return EditDistanceAligner<TYPE, algorithm_tag>(); }
+
+namespace priv {
+inline nvbio_hip_gotoh_scheme abi_scheme(const SimpleGotohScheme& s) { const nvbio_hip_gotoh_scheme r = { s.m_match, s.m_mismatch, s.m_gap_open, s.m_gap_ext }; return r; }
+inline nvbio_hip_sw_scheme    abi_scheme(const SimpleSmithWatermanScheme& s) { const nvbio_hip_sw_scheme r = { s.m_match, s.m_mismatch, s.m_deletion, s.m_insertion }; return r; }
+/// the C-ABI entry for each scheme kind: Gotoh / linear-gap (SW, ED)
+inline int banded_score(const nvbio_hip_gotoh_scheme& sc, int32 type, uint32 band, const nvbio_hip_string_set& p, const nvbio_hip_string_set& t,
+                        uint32 maxP, uint32 maxT, uint32 n, int32* score, uint32* sink, void* stream)
+{ return nvbio_hip_banded_gotoh_score(&sc, type, band, &p, &t, maxP, maxT, n, score, sink, stream); }
+inline int banded_score(const nvbio_hip_sw_scheme& sc, int32 type, uint32 band, const nvbio_hip_string_set& p, const nvbio_hip_string_set& t,
+                        uint32 maxP, uint32 maxT, uint32 n, int32* score, uint32* sink, void* stream)
+{ return nvbio_hip_banded_sw_score(&sc, type, band, &p, &t, maxP, maxT, n, score, sink, stream); }
+inline int full_score(const nvbio_hip_gotoh_scheme& sc, int32 type, const nvbio_hip_string_set& p, const nvbio_hip_string_set& t,
+                      uint32 maxP, uint32 maxT, const int32* min_score, uint32 n, int32* score, uint32* sink, uint8* ok, void* stream)
+{ return nvbio_hip_gotoh_score(&sc, type, &p, &t, maxP, maxT, min_score, n, score, sink, ok, stream); }
+inline int full_score(const nvbio_hip_sw_scheme& sc, int32 type, const nvbio_hip_string_set& p, const nvbio_hip_string_set& t,
+                      uint32 maxP, uint32 maxT, const int32*, uint32 n, int32* score, uint32* sink, uint8* ok, void* stream)
+{   // the text-blocking SW / ED form never exits early (sw_inl.h:1075-1222): every job returns true
+    const int e = nvbio_hip_sw_score(&sc, type, &p, &t, maxP, maxT, n, score, sink, stream);
+    if (e == 0 && ok && n) return nvbio_hip_memset(ok, 1, n, stream);
+    return e;
+}
+template <typename A, typename B> struct same_type { static const bool value = false; };
+template <typename A> struct same_type<A, A> { static const bool value = true; };
+} // namespace priv
 
 /// BestSink<int32> in device memory is {int32 score; uint2 sink}
 template <typename ScoreType> struct BestSink { ScoreType score; uint2 sink; };
@@ -118,13 +196,11 @@ struct BatchedBandedAlignmentScore
     {
         (void)temp_size; (void)temp;
         static_assert(BAND_LEN == 3 || BAND_LEN == 5 || BAND_LEN == 7 || BAND_LEN == 15 || BAND_LEN == 31, "unsupported BAND_LEN");
-        const nvbio_hip_gotoh_scheme sc = { stream.aligner().scheme.m_match, stream.aligner().scheme.m_mismatch,
-                                            stream.aligner().scheme.m_gap_open, stream.aligner().scheme.m_gap_ext };
         const nvbio_hip_string_set p = stream.m_patterns.abi(), t = stream.m_texts.abi();
-        hip_check(nvbio_hip_banded_gotoh_score(&sc, int32(aligner_type::TYPE), BAND_LEN, &p, &t,
-                                               stream.max_pattern_length(), stream.max_text_length(),
-                                               stream.size(), stream.m_sinks.score, stream.m_sinks.sink, hip_stream),
-                  "nvbio_hip_banded_gotoh_score");
+        hip_check(priv::banded_score(priv::abi_scheme(stream.aligner().scheme), int32(aligner_type::TYPE), BAND_LEN, p, t,
+                                     stream.max_pattern_length(), stream.max_text_length(),
+                                     stream.size(), stream.m_sinks.score, stream.m_sinks.sink, hip_stream),
+                  "nvbio_hip_banded_{gotoh,sw}_score");
     }
 };
 
@@ -230,10 +306,6 @@ private:
     }
 };
 
-/// algorithm tags (alignment_base.h:72-79); the full-matrix path implements the text-blocking form
-struct PatternBlockingTag {};
-struct TextBlockingTag {};
-
 /// BatchedAlignmentScore<stream, scheduler> (batched.h:310-329) for the full-matrix Gotoh score with
 /// the text-blocking aligner, as sw-benchmark instantiates it (sw-benchmark.cu:604-631)
 template <typename stream_type, typename algorithm_type = DeviceThreadScheduler>
@@ -248,12 +320,12 @@ struct BatchedAlignmentScore
                const int32* min_score = nullptr, uint8* ok = nullptr, void* hip_stream = nullptr)
     {
         (void)temp_size; (void)temp;
-        const nvbio_hip_gotoh_scheme sc = { stream.aligner().scheme.m_match, stream.aligner().scheme.m_mismatch,
-                                            stream.aligner().scheme.m_gap_open, stream.aligner().scheme.m_gap_ext };
+        static_assert(priv::same_type<typename aligner_type::algorithm_type, TextBlockingTag>::value,
+                      "the full-matrix batch implements the TextBlockingTag aligners (make_*_aligner<TYPE,TextBlockingTag>)");
         const nvbio_hip_string_set p = stream.m_patterns.abi(), t = stream.m_texts.abi();
-        hip_check(nvbio_hip_gotoh_score(&sc, int32(aligner_type::TYPE), &p, &t, stream.max_pattern_length(), stream.max_text_length(),
-                                        min_score, stream.size(), stream.m_sinks.score, stream.m_sinks.sink, ok, hip_stream),
-                  "nvbio_hip_gotoh_score");
+        hip_check(priv::full_score(priv::abi_scheme(stream.aligner().scheme), int32(aligner_type::TYPE), p, t, stream.max_pattern_length(), stream.max_text_length(),
+                                   min_score, stream.size(), stream.m_sinks.score, stream.m_sinks.sink, ok, hip_stream),
+                  "nvbio_hip_{gotoh,sw}_score");
     }
 };
 

@@ -11,7 +11,9 @@ from .strings import PackedStringSet, pack_symbols  # noqa: F401
 from .alignment import (GLOBAL, LOCAL, SEMI_GLOBAL, SimpleGotohScheme, SmithWatermanScoringScheme, GotohAligner,  # noqa: F401
                         make_gotoh_aligner, BatchedBandedAlignmentScore, batch_banded_alignment_score,
                         BatchedAlignmentScore, batch_alignment_score,
-                        BatchedBandedAlignmentTraceback, batch_banded_alignment_traceback)
+                        BatchedBandedAlignmentTraceback, batch_banded_alignment_traceback,
+                        SimpleSmithWatermanScheme, SmithWatermanAligner, EditDistanceAligner,
+                        make_smith_waterman_aligner, make_edit_distance_aligner)
 from .fmindex import FMIndexDevice, FMIndexFilter, rank, rank4, rank_range, match, locate, \
     locate_ssa_iterator, lookup_ssa_iterator, build_bwt_occ  # noqa: F401
 from .mapping import MappingParams, map_exact, map_seeds, unpack_seed_hits  # noqa: F401

@@ -77,6 +77,39 @@ def make_gotoh_aligner(aln_type, scheme):
     return GotohAligner(aln_type, scheme)
 
 
+class SimpleSmithWatermanScheme:
+    """nvbio::aln::SimpleSmithWatermanScheme (utils.h:92-109): linear gap costs."""
+
+    def __init__(self, match, mismatch, deletion, insertion):
+        self.m_match, self.m_mismatch, self.m_deletion, self.m_insertion = int(match), int(mismatch), int(deletion), int(insertion)
+
+    def struct(self):      # nvbio_hip_sw_scheme has the layout of four int32
+        return GotohSchemeStruct(self.m_match, self.m_mismatch, self.m_deletion, self.m_insertion)
+
+
+class SmithWatermanAligner:
+    """SmithWatermanAligner<TYPE, scheme> (alignment_base.h): linear-gap DP."""
+
+    def __init__(self, aln_type, scheme):
+        assert aln_type in (GLOBAL, LOCAL, SEMI_GLOBAL)
+        self.type, self.scheme = aln_type, scheme
+
+
+class EditDistanceAligner(SmithWatermanAligner):
+    """EditDistanceAligner<TYPE>: the SW code with EditDistanceSWScheme (ed_utils.h:44-51)."""
+
+    def __init__(self, aln_type):
+        super().__init__(aln_type, SimpleSmithWatermanScheme(0, -1, -1, -1))
+
+
+def make_smith_waterman_aligner(aln_type, scheme):
+    return SmithWatermanAligner(aln_type, scheme)
+
+
+def make_edit_distance_aligner(aln_type):
+    return EditDistanceAligner(aln_type)
+
+
 class BatchedBandedAlignmentScore:
     """BatchedBandedAlignmentScore<BAND_LEN, stream, DeviceThreadBlockScheduler>.
 
@@ -107,6 +140,13 @@ class BatchedBandedAlignmentScore:
         assert out_sink.dtype == torch.int32 and out_sink.numel() >= 2 * n and out_sink.is_cuda
         sc = aligner.scheme.struct()
         ps, ts = patterns.struct(), texts.struct()
+        if isinstance(aligner, SmithWatermanAligner):
+            err = lib().nvbio_hip_banded_sw_score(
+                C.byref(sc), aligner.type, self.band_len, C.byref(ps), C.byref(ts),
+                int(max_pattern_length), int(max_text_length), n,
+                C.c_void_p(out_score.data_ptr()), C.c_void_p(out_sink.data_ptr()), current_stream_ptr())
+            check(err, "nvbio_hip_banded_sw_score")
+            return
         if isinstance(aligner.scheme, SmithWatermanScoringScheme):
             assert quals is not None and quals.dtype == torch.uint8 and quals.is_cuda and quals.is_contiguous()
             err = lib().nvbio_hip_banded_gotoh_score_qual(
@@ -212,13 +252,22 @@ class BatchedAlignmentScore:
     def enact(self, aligner, patterns, texts, out_score, out_sink, max_pattern_length=0, max_text_length=0,
               min_score=None, out_ok=None):
         n = len(patterns)
-        assert len(texts) == n and isinstance(aligner.scheme, SimpleGotohScheme)
+        assert len(texts) == n and isinstance(aligner.scheme, (SimpleGotohScheme, SimpleSmithWatermanScheme))
         if patterns.length is None:
             max_pattern_length = max_pattern_length or patterns.fixed_length
         if texts.length is None:
             max_text_length = max_text_length or texts.fixed_length
         sc = aligner.scheme.struct()
         ps, ts = patterns.struct(), texts.struct()
+        if isinstance(aligner, SmithWatermanAligner):
+            # the text-blocking SW / ED form never exits early (sw_inl.h:1075-1222): min_score is not consulted
+            err = lib().nvbio_hip_sw_score(
+                C.byref(sc), aligner.type, C.byref(ps), C.byref(ts), int(max_pattern_length), int(max_text_length), n,
+                C.c_void_p(out_score.data_ptr()), C.c_void_p(out_sink.data_ptr()), current_stream_ptr())
+            check(err, "nvbio_hip_sw_score")
+            if out_ok is not None:
+                out_ok.fill_(1)
+            return
         err = lib().nvbio_hip_gotoh_score(
             C.byref(sc), aligner.type, C.byref(ps), C.byref(ts), int(max_pattern_length), int(max_text_length),
             C.c_void_p(min_score.data_ptr()) if min_score is not None else None, n,

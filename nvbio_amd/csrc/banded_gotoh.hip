@@ -196,6 +196,20 @@ NVB_API int nvbio_hip_banded_gotoh_score_qual(
                                  "banded_gotoh_score_kernel<A16,qual>", "banded_gotoh_score_kernel<A32,qual>");
 }
 
+// SmithWatermanAligner / EditDistanceAligner in the band (sw_banded_inl.h:340-520): with deletion == insertion the
+// recurrence is the Gotoh one with gap_open == gap_ext cell for cell (H >= E, F), same band geometry, same reports.
+NVB_API int nvbio_hip_banded_sw_score(
+    const nvbio_hip_sw_scheme* scheme, int32_t type, uint32_t band_len,
+    const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len,
+    uint32_t n, int32_t* out_score, uint32_t* out_sink, void* stream)
+{
+    if (!scheme) return hipErrorInvalidValue;
+    if (scheme->deletion != scheme->insertion) return hipErrorNotSupported;
+    const nvbio_hip_gotoh_scheme g = { scheme->match, scheme->mismatch, scheme->deletion, scheme->deletion };
+    return nvbio_hip_banded_gotoh_score(&g, type, band_len, patterns, texts, max_pattern_len, max_text_len, n, out_score, out_sink, stream);
+}
+
 NVB_API int nvbio_hip_device_malloc(void** ptr, uint64_t bytes) { return ptr ? hipMalloc(ptr, bytes ? bytes : 1) : hipErrorInvalidValue; }
 NVB_API int nvbio_hip_device_free(void* ptr) { return hipFree(ptr); }
 NVB_API int nvbio_hip_memcpy(void* dst, const void* src, uint64_t bytes, int kind, void* stream)

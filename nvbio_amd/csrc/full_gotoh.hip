@@ -41,6 +41,7 @@ struct FullParams {
     int32_t*       out_score;
     uint32_t*      out_sink;
     uint8_t*       out_ok;         // nullable: the reference's per-job bool
+    uint32_t       blk_log2;       // log2 of the reference's block width: fixes the LOCAL tie order (3 = Gotoh, 4 = SW / ED)
 };
 
 __device__ __forceinline__ int32_t dpp_shr1(int32_t first_lane_value, int32_t x)
@@ -62,7 +63,8 @@ __device__ __forceinline__ SweepResult sweep(const FullParams& p, const uint64_t
     const int32_t  Go = p.gap_open, Ge = p.gap_ext;
     const int32_t  infimum = -32768 - min(Go, Ge);                               // :1153
     const uint32_t lane_last = (M - 1u) / uint32_t(R);
-    const uint32_t KM = 8u * 64u * uint32_t(R);                                  // order-key stride per block
+    const uint32_t BS = p.blk_log2, BLK = 1u << BS;                              // columns per reference block (8 Gotoh, 16 SW/ED)
+    const uint32_t KM = BLK * 64u * uint32_t(R);                                 // order-key stride per block
 
     // this lane's rows
     uint32_t q[R]; int32_t Hleft[R], E[R];
@@ -138,7 +140,7 @@ __device__ __forceinline__ SweepResult sweep(const FullParams& p, const uint64_t
                     if (TYPE == NVBIO_HIP_LOCAL)
                     {
                         // order key: block-major, then row, then column within the block
-                        const uint32_t key = (c >> 3) * KM + r * 8u + (c & 7u);
+                        const uint32_t key = (c >> BS) * KM + r * BLK + (c & (BLK - 1u));
                         const uint64_t cand = (uint64_t(uint32_t(h)) << 32) | key;
                         if (!have || cand >= best64) { best64 = cand; have = true; }
                     }
@@ -192,7 +194,7 @@ __device__ __forceinline__ SweepResult sweep(const FullParams& p, const uint64_t
         }
         if (hv) {
             const uint32_t key = uint32_t(b);
-            const uint32_t col = (key / KM) * 8u + (key & 7u), row = (key % KM) >> 3;
+            const uint32_t col = (key / KM) * BLK + (key & (BLK - 1u)), row = (key % KM) >> BS;
             res.score = int32_t(uint32_t(b >> 32)); res.sx = col + 1u; res.sy = row + 1u;
         }
     }
@@ -396,7 +398,7 @@ struct Sweep16
         SweepResult res;
         res.exit_col = uint32_t(__shfl(int32_t(exit_col), int32_t(lane_last)));
         res.score = -(1 << 30); res.sx = res.sy = 0xFFFFFFFFu;
-        const uint32_t KM = 8u * 64u * uint32_t(R);
+        const uint32_t BS = p.blk_log2, BLK = 1u << BS, KM = BLK * 64u * uint32_t(R);
         if (TYPE == NVBIO_HIP_LOCAL)
         {
             // merge this lane's rows, then the lanes, with the reference's order key
@@ -407,7 +409,7 @@ struct Sweep16
             {
                 if (uint32_t(k) < nvalid && Ncols > 0u) {
                     const uint32_t hh = bestk[k] >> 20, cc = bestk[k] & 0xFFFFFu, r = lane * R + k;
-                    const uint64_t cand = (uint64_t(hh) << 32) | ((cc >> 3) * KM + r * 8u + (cc & 7u));
+                    const uint64_t cand = (uint64_t(hh) << 32) | ((cc >> BS) * KM + r * BLK + (cc & (BLK - 1u)));
                     if (!hv || cand > b) { b = cand; hv = 1u; }
                 }
             }
@@ -422,7 +424,7 @@ struct Sweep16
             }
             if (hv) {
                 const uint32_t key = uint32_t(b);
-                const uint32_t col = (key / KM) * 8u + (key & 7u), row = (key % KM) >> 3;
+                const uint32_t col = (key / KM) * BLK + (key & (BLK - 1u)), row = (key % KM) >> BS;
                 res.score = int32_t(uint32_t(b >> 32)); res.sx = col + 1u; res.sy = row + 1u;
             }
         }
@@ -512,8 +514,8 @@ static hipError_t launch_full(const FullParams& p, int type, hipStream_t s)
 
 using namespace nvb;
 
-NVB_API int nvbio_hip_gotoh_score(
-    const nvbio_hip_gotoh_scheme* scheme, int32_t type,
+static int full_score_core(
+    const nvbio_hip_gotoh_scheme* scheme, int32_t type, uint32_t blk_log2,
     const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts,
     uint32_t max_pattern_len, uint32_t max_text_len, const int32_t* min_score,
     uint32_t n, int32_t* out_score, uint32_t* out_sink, uint8_t* out_ok, void* stream)
@@ -534,6 +536,7 @@ NVB_API int nvbio_hip_gotoh_score(
     p.pat = make_string_set(patterns); p.txt = make_string_set(texts);
     p.match = scheme->match; p.mismatch = scheme->mismatch; p.gap_open = scheme->gap_open; p.gap_ext = scheme->gap_ext;
     p.min_score = min_score; p.n = n; p.out_score = out_score; p.out_sink = out_sink; p.out_ok = out_ok;
+    p.blk_log2 = blk_log2;
 
     // can any H / E leave int16?  LOCAL: 0 <= H <= M*match, E/F a few gap costs below.  SEMI_GLOBAL (pattern
     // global, text free): every cell is reachable from the zero row above its column, so values stay within
@@ -554,6 +557,7 @@ NVB_API int nvbio_hip_gotoh_score(
         switch (R) { case 1: return launch_full<1, false, true>(p, type, s); case 2: return launch_full<2, false, true>(p, type, s);
                      case 3: return launch_full<3, false, true>(p, type, s); default: return launch_full<4, false, true>(p, type, s); }
     }
+    if (trunc && blk_log2 != 3u) return hipErrorNotSupported;     // the int16 boundary column of the SW form is not modelled beyond its exact range
     if (trunc) {
         switch (R) { case 1: return launch_full<1, true, false>(p, type, s); case 2: return launch_full<2, true, false>(p, type, s);
                      case 3: return launch_full<3, true, false>(p, type, s); default: return launch_full<4, true, false>(p, type, s); }
@@ -561,4 +565,30 @@ NVB_API int nvbio_hip_gotoh_score(
         switch (R) { case 1: return launch_full<1, false, false>(p, type, s); case 2: return launch_full<2, false, false>(p, type, s);
                      case 3: return launch_full<3, false, false>(p, type, s); default: return launch_full<4, false, false>(p, type, s); }
     }
+}
+
+NVB_API int nvbio_hip_gotoh_score(
+    const nvbio_hip_gotoh_scheme* scheme, int32_t type,
+    const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len, const int32_t* min_score,
+    uint32_t n, int32_t* out_score, uint32_t* out_sink, uint8_t* out_ok, void* stream)
+{
+    return full_score_core(scheme, type, 3u, patterns, texts, max_pattern_len, max_text_len, min_score, n, out_score, out_sink, out_ok, stream);
+}
+
+// SmithWatermanAligner / EditDistanceAligner, full matrix, text blocking (sw_inl.h:881-1222): linear gaps with
+// deletion == insertion are Gotoh with gap_open == gap_ext cell for cell (H >= E, F always), the boundary column
+// is exact while values fit int16, this variant never exits early, and its blocks are 16 columns wide.
+NVB_API int nvbio_hip_sw_score(
+    const nvbio_hip_sw_scheme* scheme, int32_t type,
+    const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len,
+    uint32_t n, int32_t* out_score, uint32_t* out_sink, void* stream)
+{
+    if (!scheme) return hipErrorInvalidValue;
+    if (scheme->deletion != scheme->insertion) return hipErrorNotSupported;
+    const nvbio_hip_gotoh_scheme g = { scheme->match, scheme->mismatch, scheme->deletion, scheme->deletion };
+    const int e = full_score_core(&g, type, 4u, patterns, texts, max_pattern_len, max_text_len, nullptr, n, out_score, out_sink, nullptr, stream);
+    if (e == hipSuccess && n) g_last_kernel = "full_gotoh_score_kernel<16-bit,sw>";
+    return e;
 }

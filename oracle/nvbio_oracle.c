@@ -438,6 +438,140 @@ ORACLE_API void oracle_batch_gotoh_score(
     }
 }
 
+/* ------------------------------------------------------------------------ */
+/* Smith-Waterman (linear gaps) and edit-distance aligners                    */
+/*   banded score     nvbio/alignment/sw/sw_banded_inl.h:47-58, 340-520       */
+/*   full, text-block nvbio/alignment/sw/sw_inl.h:55-81 (init), 881-1222      */
+/*                    BAND_LEN = 16 columns per block (:1330-1334), boundary   */
+/*                    column kept as int16, no early exit in this variant     */
+/*   edit distance    = the same code with EditDistanceSWScheme (0,-1,-1,-1): */
+/*                    ed/ed_utils.h:44-51, ed/ed_inl.h:85-99, ed_banded_inl.h */
+/* scheme = {match, mismatch, deletion, insertion}                            */
+/* ------------------------------------------------------------------------ */
+static int banded_sw_score_x(uint32_t band, int type, const int32_t* sw,
+    const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, uint64_t pat_begin, uint32_t pattern_len,
+    const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, uint64_t txt_begin, uint32_t text_len,
+    best_sink_t* sink)
+{
+    if (text_len < pattern_len) return 0;
+    uint32_t text_cache[MAX_BAND];
+    int32_t  B[MAX_BAND];
+    for (uint32_t j = 0; j + 1 < band; ++j)
+        text_cache[j] = cache_store(band, ps_get(txt_w, txt_bits, txt_be, txt_begin + j));
+    const int32_t V = sw[0], X = sw[1], G = sw[2], I = sw[3];
+    for (uint32_t j = 0; j < band; ++j) B[j] = (type == ALN_GLOBAL) ? (int32_t)j * G : 0;       /* init_row_zero :47-58 */
+    for (uint32_t i = 0; i < pattern_len; ++i)
+    {
+        const uint8_t q = (uint8_t)ps_get(pat_w, pat_bits, pat_be, pat_begin + i);
+        {
+            const uint8_t g = (uint8_t)text_cache[0];
+            const int32_t diagonal = B[0] + (g == q ? V : X), top = B[1] + G;
+            int32_t hi = imax(top, diagonal);
+            if (type == ALN_LOCAL) { hi = imax(hi, 0); sink_report(sink, hi, i + 1, i + 1); }
+            B[0] = hi;
+        }
+        for (uint32_t j = 1; j + 1 < band; ++j)
+        {
+            const uint32_t g = text_cache[j]; text_cache[j - 1] = g;
+            const int32_t diagonal = B[j] + ((uint8_t)g == q ? V : X), top = B[j + 1] + G, left = B[j - 1] + I;
+            int32_t hi = imax(imax(top, left), diagonal);
+            if (type == ALN_LOCAL) { hi = imax(hi, 0); sink_report(sink, hi, i + j + 1, i + 1); }
+            B[j] = hi;
+        }
+        const uint8_t g = (i + band - 1 < text_len) ? (uint8_t)ps_get(txt_w, txt_bits, txt_be, txt_begin + i + band - 1) : 255u;
+        text_cache[band - 2] = cache_store(band, g);
+        {
+            const int32_t diagonal = B[band - 1] + (g == q ? V : X), left = B[band - 2] + I;
+            int32_t hi = imax(left, diagonal);
+            if (type == ALN_LOCAL) { hi = imax(hi, 0); sink_report(sink, hi, i + band, i + 1); }
+            B[band - 1] = hi;
+        }
+    }
+    if (type == ALN_GLOBAL)
+        sink_report(sink, B[band - 1], pattern_len + band - 1, pattern_len);
+    else if (type == ALN_SEMI_GLOBAL) {
+        const uint32_t a = pattern_len + band - 1u;
+        const uint32_t m = (a < text_len ? a : text_len) - (pattern_len - 1u);
+        sink_report(sink, B[0], pattern_len, pattern_len);
+        for (uint32_t j = 1; j < band; ++j) if (j < m) sink_report(sink, B[j], pattern_len + j, pattern_len);
+    }
+    return 1;
+}
+
+#define SW_FULL_BAND 16
+static int sw_score_text_blocking(int type, const int32_t* sw,
+    const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, uint64_t pat_begin, uint32_t M,
+    const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, uint64_t txt_begin, uint32_t N,
+    best_sink_t* sink, int16_t* temp /* M scratch */)
+{
+    int32_t band[SW_FULL_BAND + 1];
+    uint8_t r_cache[SW_FULL_BAND];
+    memset(r_cache, 0, sizeof r_cache);
+    const int32_t V = sw[0], X = sw[1], G = sw[2], I = sw[3], zero = 0;
+    for (uint32_t i = 0; i < M; ++i) temp[i] = (int16_t)(type != ALN_LOCAL ? I * (int32_t)(i + 1) : zero);     /* SWScoringContext::init :67-81 */
+    const uint32_t nb = SW_FULL_BAND * ((N + SW_FULL_BAND - 1) / SW_FULL_BAND);
+    const uint32_t end_block = nb > SW_FULL_BAND ? nb : SW_FULL_BAND;
+    for (uint32_t block = 0; block + SW_FULL_BAND <= end_block; block += SW_FULL_BAND)
+    {
+        const int last = (block + SW_FULL_BAND == end_block);
+        const uint32_t block_end = (block + SW_FULL_BAND < N) ? block + SW_FULL_BAND : N;
+        for (uint32_t j = 0; j <= SW_FULL_BAND; ++j) band[j] = (type == ALN_GLOBAL) ? G * (int32_t)(block + j) : zero;
+        for (uint32_t t = 0; t < SW_FULL_BAND; ++t)
+            if (!last || block + t < block_end) r_cache[t] = (uint8_t)ps_get(txt_w, txt_bits, txt_be, txt_begin + block + t);
+        int32_t temp_i = band[0];
+        for (uint32_t i = 0; i < M; ++i)
+        {
+            const uint8_t q_i = (uint8_t)ps_get(pat_w, pat_bits, pat_be, pat_begin + i);
+            int32_t prev = temp_i;                                      /* update_row :884-960 */
+            band[0] = temp_i = temp[i];
+            for (uint32_t j = 1; j <= SW_FULL_BAND; ++j)
+            {
+                const int32_t diagonal = prev + (r_cache[j - 1] == q_i ? V : X);
+                const int32_t top = band[j] + I, left = band[j - 1] + G;
+                int32_t hi = imax(imax(top, left), diagonal);
+                if (type == ALN_LOCAL) hi = imax(hi, zero);
+                prev = band[j];
+                band[j] = hi;
+            }
+            temp[i] = (int16_t)band[SW_FULL_BAND];
+            if (type == ALN_LOCAL)
+                for (uint32_t j = 1; j <= SW_FULL_BAND; ++j)
+                    if (!last || block + j <= N) sink_report(sink, band[j], block + j, i + 1);
+        }
+        if (type == ALN_SEMI_GLOBAL) {
+            for (uint32_t j = 1; j <= SW_FULL_BAND; ++j) if (!last || block + j <= N) sink_report(sink, band[j], block + j, M);
+        } else if (type == ALN_GLOBAL && last) {
+            for (uint32_t j = 1; j <= SW_FULL_BAND; ++j) if (block + j == N) sink_report(sink, band[j], block + j, M);
+        }
+    }
+    return 1;
+}
+
+/* banded: BatchedBandedAlignmentScore over SmithWatermanAligner / EditDistanceAligner;
+ * full (band == 0): BatchedAlignmentScore over the TextBlockingTag forms */
+ORACLE_API void oracle_batch_sw_score(
+    uint32_t band /* 0 = full matrix */, int type, const int32_t* scheme,
+    const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, const uint64_t* pat_begin, const uint32_t* pat_len,
+    const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, const uint64_t* txt_begin, const uint32_t* txt_len,
+    uint32_t n, int32_t* out_score, uint32_t* out_sink, int n_threads)
+{
+#if defined(_OPENMP)
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+    #pragma omp parallel for schedule(dynamic, 16)
+#endif
+    for (int64_t i = 0; i < (int64_t)n; ++i)
+    {
+        best_sink_t s; sink_init(&s);
+        if (band) banded_sw_score_x(band, type, scheme, pat_w, pat_bits, pat_be, pat_begin[i], pat_len[i], txt_w, txt_bits, txt_be, txt_begin[i], txt_len[i], &s);
+        else {
+            int16_t* temp = (int16_t*)malloc(sizeof(int16_t) * (size_t)(pat_len[i] + 1));
+            sw_score_text_blocking(type, scheme, pat_w, pat_bits, pat_be, pat_begin[i], pat_len[i], txt_w, txt_bits, txt_be, txt_begin[i], txt_len[i], &s, temp);
+            free(temp);
+        }
+        out_score[i] = s.score; out_sink[2 * i] = s.sink_x; out_sink[2 * i + 1] = s.sink_y;
+    }
+}
+
 /* ref_sw for the Gotoh aligner: nvbio-test/alignment_test_utils.h:536-624, the independent
  * full-matrix checker the reference's alignment test compares alignment_score() with
  * (alignment_test.cu:247-265).  i runs over the text, j over the pattern. */

@@ -270,6 +270,21 @@ def cigar_rle(ops_end_first):
     return "".join(out)
 
 
+def batch_sw_score(band, aln_type, scheme, patterns, texts, n_threads=0):
+    """SmithWatermanAligner (scheme = match, mismatch, deletion, insertion; edit distance = (0,-1,-1,-1)):
+    banded score for band > 0, full-matrix text-blocking score for band == 0."""
+    n = len(patterns)
+    score = np.empty(n, dtype=np.int32)
+    sink = np.empty((n, 2), dtype=np.uint32)
+    sc = _scheme(scheme)
+    lib().oracle_batch_sw_score(
+        C.c_uint32(band), C.c_int(aln_type), _p(sc),
+        _p(patterns.words), C.c_uint32(patterns.bits), C.c_uint32(patterns.big_endian), _p(patterns.begin), _p(patterns.length),
+        _p(texts.words), C.c_uint32(texts.bits), C.c_uint32(texts.big_endian), _p(texts.begin), _p(texts.length),
+        C.c_uint32(n), _p(score), _p(sink), C.c_int(n_threads))
+    return score, sink
+
+
 def ref_sw_gotoh(aln_type, scheme, pattern, text):
     p = np.ascontiguousarray(pattern, dtype=np.uint8)
     t = np.ascontiguousarray(text, dtype=np.uint8)

@@ -32,6 +32,10 @@ void oracle_banded_gotoh_traceback(uint32_t band, int type, const int32_t* schem
     const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, uint64_t pat_begin, uint32_t pat_len,
     const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, uint64_t txt_begin, uint32_t txt_len,
     int32_t* res, uint8_t* ops, uint32_t ops_capacity, uint8_t* flags);
+void oracle_batch_sw_score(uint32_t band, int type, const int32_t* scheme,
+    const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, const uint64_t* pat_begin, const uint32_t* pat_len,
+    const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, const uint64_t* txt_begin, const uint32_t* txt_len,
+    uint32_t n, int32_t* out_score, uint32_t* out_sink, int n_threads);
 uint32_t oracle_bwt_from_sa(uint32_t n, const uint8_t* T, const uint32_t* SA, uint8_t* bwt);
 void oracle_build_bwt_occ(uint32_t n, const uint32_t* bwt_words, uint32_t* bwt_occ, uint32_t* L2);
 void oracle_build_ssa(uint32_t n, const uint32_t* SA, uint32_t K, uint32_t* ssa);
@@ -108,7 +112,7 @@ static void run_full_batch(const char* name, const aln::SimpleGotohScheme scorin
     aln::BestSinkArrays sinks = { d_score.data(), d_sink.data() };
     uint32 maxP = 1, maxT = 1;
     for (uint32 i = 0; i < n; ++i) { maxP = std::max(maxP, uint32(patterns[i].size())); maxT = std::max(maxT, uint32(texts[i].size())); }
-    aln::batch_alignment_score(aln::make_gotoh_aligner<TYPE>(scoring), d_patterns.view(), d_texts.view(), sinks, aln::DeviceThreadScheduler(), maxP, maxT);
+    aln::batch_alignment_score(aln::make_gotoh_aligner<TYPE, aln::TextBlockingTag>(scoring), d_patterns.view(), d_texts.view(), sinks, aln::DeviceThreadScheduler(), maxP, maxT);
     hip::synchronize();
     const std::vector<int32> score = d_score.to_host(); const std::vector<uint32> sink = d_sink.to_host();
     std::vector<uint8> pc, tc; std::vector<uint64> pb(n), tb(n); std::vector<uint32> pl(n), tl(n);
@@ -118,6 +122,37 @@ static void run_full_batch(const char* name, const aln::SimpleGotohScheme scorin
     std::vector<int32> hs(n); std::vector<uint32> hk(2 * size_t(n));
     const int32 sc[4] = { scoring.m_match, scoring.m_mismatch, scoring.m_gap_open, scoring.m_gap_ext };
     oracle_batch_gotoh_score(int(TYPE), sc, pw.data(), 4, 1, pb.data(), pl.data(), tw.data(), 2, 0, tb.data(), tl.data(), nullptr, n, hs.data(), hk.data(), nullptr, 0);
+    for (uint32 i = 0; i < n; ++i)
+        if (score[i] != hs[i] || sink[2 * i] != hk[2 * i] || sink[2 * i + 1] != hk[2 * i + 1])
+            FAIL("%s: job %u: device (%d, %u,%u) != host (%d, %u,%u)", name, i, score[i], sink[2 * i], sink[2 * i + 1], hs[i], hk[2 * i], hk[2 * i + 1]);
+    fprintf(stderr, "    %-44s : %u jobs ok\n", name, n);
+}
+
+// SmithWatermanAligner / EditDistanceAligner batches (banded: BAND_LEN > 0; full matrix, text blocking: BAND_LEN == 0)
+template <uint32 BAND_LEN, typename aligner_type>
+static void run_sw_batch(const char* name, const aligner_type aligner,
+                         const std::vector<std::vector<uint8> >& patterns, const std::vector<std::vector<uint8> >& texts)
+{
+    const uint32 n = uint32(patterns.size());
+    uint32 maxP = 0, maxT = 0;
+    for (uint32 i = 0; i < n; ++i) { maxP = std::max(maxP, uint32(patterns[i].size())); maxT = std::max(maxT, uint32(texts[i].size())); }
+    PackedStringSetDevice<4, true>  d_patterns(patterns);
+    PackedStringSetDevice<2, false> d_texts(texts);
+    hip::device_vector<int32>  d_score(n);
+    hip::device_vector<uint32> d_sink(2 * size_t(n));
+    aln::BestSinkArrays sinks = { d_score.data(), d_sink.data() };
+    if constexpr (BAND_LEN != 0) aln::batch_banded_alignment_score<BAND_LEN ? BAND_LEN : 15>(aligner, d_patterns.view(), d_texts.view(), sinks, aln::DeviceThreadScheduler(), maxP, maxT);
+    else          aln::batch_alignment_score(aligner, d_patterns.view(), d_texts.view(), sinks, aln::DeviceThreadScheduler(), maxP, maxT);
+    hip::synchronize();
+    const std::vector<int32> score = d_score.to_host(); const std::vector<uint32> sink = d_sink.to_host();
+    std::vector<uint8> pc, tc; std::vector<uint64> pb(n), tb(n); std::vector<uint32> pl(n), tl(n);
+    for (uint32 i = 0; i < n; ++i) { pb[i] = pc.size(); pl[i] = uint32(patterns[i].size()); pc.insert(pc.end(), patterns[i].begin(), patterns[i].end());
+                                     tb[i] = tc.size(); tl[i] = uint32(texts[i].size());    tc.insert(tc.end(), texts[i].begin(), texts[i].end()); }
+    tc.insert(tc.end(), 64, 0);
+    const std::vector<uint32> pw = pack_symbols<4, true>(pc.data(), pc.size()), tw = pack_symbols<2, false>(tc.data(), tc.size());
+    std::vector<int32> hs(n); std::vector<uint32> hk(2 * size_t(n));
+    const int32 sc[4] = { aligner.scheme.m_match, aligner.scheme.m_mismatch, aligner.scheme.m_deletion, aligner.scheme.m_insertion };
+    oracle_batch_sw_score(BAND_LEN, int(aligner_type::TYPE), sc, pw.data(), 4, 1, pb.data(), pl.data(), tw.data(), 2, 0, tb.data(), tl.data(), n, hs.data(), hk.data(), 0);
     for (uint32 i = 0; i < n; ++i)
         if (score[i] != hs[i] || sink[2 * i] != hk[2 * i] || sink[2 * i + 1] != hk[2 * i + 1])
             FAIL("%s: job %u: device (%d, %u,%u) != host (%d, %u,%u)", name, i, score[i], sink[2 * i], sink[2 * i + 1], hs[i], hk[2 * i], hk[2 * i + 1]);
@@ -242,6 +277,10 @@ static int alignment_test()
     run_batch<7,  aln::SEMI_GLOBAL, 4, true,  false>("batch semi-global 7",               s3, pats, txts);
     run_batch<3,  aln::LOCAL,       4, true,  false>("batch local 3",                     s2, pats, txts);
     run_batch<5,  aln::GLOBAL,      4, true,  false>("batch global 5",                    s2, pats, txts);
+    // linear-gap aligners in the band (nvbio-test's ed-banded / sw-banded cases)
+    run_sw_batch<15>("batch ed-banded semi-global 15", aln::make_edit_distance_aligner<aln::SEMI_GLOBAL>(), pats, txts);
+    run_sw_batch<15>("batch sw-banded local 15",       aln::make_smith_waterman_aligner<aln::LOCAL>(aln::SimpleSmithWatermanScheme(2, -1, -1, -1)), pats, txts);
+    run_sw_batch<7> ("batch sw-banded global 7",       aln::make_smith_waterman_aligner<aln::GLOBAL>(aln::SimpleSmithWatermanScheme(2, -1, -1, -1)), pats, txts);
     // banded traceback -> CIGAR over the same ragged batch (nvBowtie's traceback stage shape)
     run_traceback_batch<15, aln::LOCAL>      ("batch traceback local 15",       s2, pats, txts);
     run_traceback_batch<15, aln::SEMI_GLOBAL>("batch traceback semi-global 15", s3, pats, txts);
@@ -256,6 +295,8 @@ static int alignment_test()
             fp[i].assign(ft[i].begin() + off, ft[i].begin() + off + L);
             for (uint32 j = 0; j < L; ++j) if ((rnd.next() >> 16) % 100 < 6) fp[i][j] = uint8(rnd.sym());
         }
+        run_sw_batch<0>("batch ed full semi-global (sw-benchmark leg)", aln::make_edit_distance_aligner<aln::SEMI_GLOBAL, aln::TextBlockingTag>(), fp, ft);
+        run_sw_batch<0>("batch sw full local", aln::make_smith_waterman_aligner<aln::LOCAL, aln::TextBlockingTag>(aln::SimpleSmithWatermanScheme(2, -1, -1, -1)), fp, ft);
         run_full_batch<aln::LOCAL>      ("batch gotoh full local",       s2, fp, ft);
         run_full_batch<aln::SEMI_GLOBAL>("batch gotoh full semi-global", s2, fp, ft);
         run_full_batch<aln::GLOBAL>     ("batch gotoh full global",      s3, fp, ft);

@@ -162,6 +162,11 @@ def test_banded_edit_distance_kats():
         t = np.frombuffer(c["text"].encode(), dtype=np.uint8)
         ok, score, _, _ = O.banded_gotoh_score(5, O.SEMI_GLOBAL, grp["scheme"], p, t)
         assert ok and score == c["score"], c
+        # ... and on the restatement of the code path the reference test really runs: the banded
+        # Smith-Waterman recurrence with EditDistanceSWScheme (ed_banded_inl.h -> sw_banded_inl.h)
+        hp, ht = O.StringSet.from_lists([p], 8, False), O.StringSet.from_lists([t], 8, False)
+        s2, _ = O.batch_sw_score(5, O.SEMI_GLOBAL, (0, -1, -1, -1), hp, ht)
+        assert int(s2[0]) == c["score"], c
 
 
 @pytest.mark.parametrize("band", [3, 5, 7, 15, 31])
@@ -355,3 +360,43 @@ def test_one_mismatch_mappers_find_exactly_the_allowed_occurrences(algorithm, su
     h0, c0, r0 = O.map_seeds(0, 0, f, None, hr, pd, sf, 400)
     h1, c1, r1 = O.map_exact(f, hr, pd, sf, 400)
     assert (h0 == h1).all() and (c0 == c1).all() and (r0 == r1).all()
+
+
+# ---------------------------------------------------------------------------- SW / edit-distance aligners
+@pytest.mark.parametrize("scheme", [(0, -1, -1, -1), (2, -1, -1, -1), (1, -3, -2, -2)])
+def test_linear_gap_aligners_equal_gotoh_with_open_eq_ext(scheme):
+    """SmithWatermanAligner / EditDistanceAligner (linear gaps, deletion == insertion) compute the same H
+    matrix as GotohAligner with gap_open == gap_ext -- the reference's own functional test expects the
+    same alignments from both (alignment_test.cu:769-793).  Checked restatement against restatement:
+    banded for every band and type (scores and sinks); full matrix: scores for every type, sinks for
+    GLOBAL / SEMI_GLOBAL (LOCAL ties resolve by the visiting order, 16-column blocks vs 8)."""
+    rng = np.random.default_rng(sum(scheme) + 50)
+    g = (scheme[0], scheme[1], scheme[2], scheme[2])
+    pats, txts = [], []
+    for i in range(400):
+        M = int(rng.integers(1, 70))
+        N = M + int(rng.integers(0, 60)) if i % 5 else max(1, M - int(rng.integers(0, 3)))
+        t = rng.integers(0, 4, N).astype(np.uint8)
+        off = int(rng.integers(0, max(1, N - M + 1)))
+        p = np.resize(t[off:off + M], M).copy()
+        mut = rng.random(M) < 0.1
+        p[mut] = rng.integers(0, 5, int(mut.sum()))
+        pats.append(p); txts.append(t)
+    hp, ht = O.StringSet.from_lists(pats, 4, True), O.StringSet.from_lists(txts + [np.zeros(64, np.uint8)], 2, True)
+    ht = O.StringSet(ht.words, 2, True, ht.begin[:-1], ht.length[:-1])
+    for ty in (O.GLOBAL, O.LOCAL, O.SEMI_GLOBAL):
+        for band in (3, 5, 7, 15, 31):
+            a, ak = O.batch_sw_score(band, ty, scheme, hp, ht)
+            b, bk = O.batch_banded_gotoh_score(band, ty, g, hp, ht)
+            assert (a == b).all() and (ak == bk).all(), (ty, band)
+        a, ak = O.batch_sw_score(0, ty, scheme, hp, ht)
+        b, bk, ok = O.batch_gotoh_score(ty, g, hp, ht)
+        assert (a == b).all(), ty
+        if ty != O.LOCAL:
+            assert (ak == bk).all(), ty
+    # the full-matrix SW / Gotoh KAT strings of the functional test: same scores from both aligners
+    p, t = dna(KAT["strings"]["short_p"]), dna(KAT["strings"]["short_t"])
+    hp1, ht1 = O.StringSet.from_lists([p], 4, True), O.StringSet.from_lists([t], 2, False)
+    for ty in (O.GLOBAL, O.LOCAL, O.SEMI_GLOBAL):
+        a, ak = O.batch_sw_score(0, ty, (2, -1, -1, -1), hp1, ht1)
+        assert int(a[0]) == O.ref_sw_gotoh(ty, (2, -1, -1, -1), p, t)

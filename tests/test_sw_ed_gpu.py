@@ -1,0 +1,113 @@
+"""SmithWatermanAligner / EditDistanceAligner (linear gaps) through the C-ABI vs the oracle's restatement of
+sw_banded_inl.h and of the text-blocking sw_inl.h (16-column blocks): bit-exact scores and sinks, banded
+and full matrix -- sw-benchmark's edit-distance leg and nvbio-test's ed / sw cases."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import nvbio_amd as nvb
+from oracle import pyoracle as O
+from test_banded_gpu import random_pairs
+from test_full_gotoh_gpu import make_pairs, dna
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+KAT = json.load(open(os.path.join(HERE, "golden", "kat.json")))
+SCHEMES = [(0, -1, -1, -1), (2, -1, -1, -1), (1, -3, -2, -2)]
+
+
+def to_dev(hs, dev):
+    return nvb.PackedStringSet.from_host(hs.words, hs.bits, hs.big_endian, hs.begin, hs.length, device=dev)
+
+
+def aligner_for(ty, scheme):
+    return nvb.make_edit_distance_aligner(ty) if scheme == (0, -1, -1, -1) else nvb.make_smith_waterman_aligner(ty, nvb.SimpleSmithWatermanScheme(*scheme))
+
+
+@pytest.mark.parametrize("band", [3, 5, 7, 15, 31])
+@pytest.mark.parametrize("ty", [nvb.GLOBAL, nvb.LOCAL, nvb.SEMI_GLOBAL])
+def test_banded(cuda, band, ty):
+    rng = np.random.default_rng(9000 + band * 3 + ty)
+    pats, txts = random_pairs(rng, 2000, band)
+    hp, ht = O.StringSet.from_lists(pats, 4, True), O.StringSet.from_lists(txts, 2, True)
+    for scheme in SCHEMES:
+        es, ek = O.batch_sw_score(band, ty, scheme, hp, ht)
+        gs, gk = nvb.batch_banded_alignment_score(band, aligner_for(ty, scheme), to_dev(hp, cuda), to_dev(ht, cuda),
+                                                  max_pattern_length=int(hp.length.max()))
+        torch.cuda.synchronize()
+        gs, gk = gs.cpu().numpy(), gk.cpu().numpy().view(np.uint32)
+        bad = np.nonzero((es != gs) | (ek != gk).any(1))[0]
+        assert bad.size == 0, (band, ty, scheme, bad[:5], es[bad[:3]], gs[bad[:3]])
+
+
+def test_banded_edit_distance_kats(cuda):
+    """alignment_test.cu:677-747: banded_alignment_score<5>(make_edit_distance_aligner<SEMI_GLOBAL>()) literals;
+    the test's strings are ASCII, mapped to DNA codes here (only equality of symbols matters)."""
+    grp = KAT["banded_edit_distance_band5_semi_global"]
+    code = {c: i for i, c in enumerate("ACGT")}
+    pats = [np.array([code[c] for c in k["pattern"]], np.uint8) for k in grp["cases"]]
+    txts = [np.array([code[c] for c in k["text"]], np.uint8) for k in grp["cases"]]
+    hp, ht = O.StringSet.from_lists(pats, 4, True), O.StringSet.from_lists(txts + [np.zeros(64, np.uint8)], 2, False)
+    ht = O.StringSet(ht.words, 2, False, ht.begin[:-1], ht.length[:-1])
+    gs, _ = nvb.batch_banded_alignment_score(5, nvb.make_edit_distance_aligner(nvb.SEMI_GLOBAL), to_dev(hp, cuda), to_dev(ht, cuda), max_pattern_length=16)
+    assert gs.cpu().tolist() == [k["score"] for k in grp["cases"]]
+
+
+@pytest.mark.parametrize("ty", [nvb.GLOBAL, nvb.LOCAL, nvb.SEMI_GLOBAL])
+def test_full_matrix(cuda, ty):
+    rng = np.random.default_rng(9100 + ty)
+    pats, txts = make_pairs(rng, 1500, 200, 400)
+    pats = [p if len(p) else np.zeros(1, np.uint8) for p in pats]
+    txts = [t if len(t) else np.zeros(1, np.uint8) for t in txts]
+    hp, ht = O.StringSet.from_lists(pats, 4, True), O.StringSet.from_lists(txts, 2, False)
+    for scheme in SCHEMES:
+        es, ek = O.batch_sw_score(0, ty, scheme, hp, ht)
+        for generic in ("0", "1"):
+            os.environ["NVBIO_HIP_FULL_GENERIC"] = generic
+            try:
+                gs, gk, go = nvb.batch_alignment_score(aligner_for(ty, scheme), to_dev(hp, cuda), to_dev(ht, cuda), 200, 400)
+                torch.cuda.synchronize()
+            finally:
+                os.environ["NVBIO_HIP_FULL_GENERIC"] = "0"
+            gs, gk = gs.cpu().numpy(), gk.cpu().numpy().view(np.uint32)
+            bad = np.nonzero((es != gs) | (ek != gk).any(1))[0]
+            assert bad.size == 0, (ty, scheme, generic, bad[:5], es[bad[:3]], gs[bad[:3]], ek[bad[:3]], gk[bad[:3]])
+            assert bool(go.all())
+    if ty == nvb.LOCAL:
+        # the 16-column visiting order is observable: some ties resolve differently from the Gotoh (8-column) form
+        _, bk, _ = O.batch_gotoh_score(ty, (2, -1, -1, -1), hp, ht)
+        _, ak = O.batch_sw_score(0, ty, (2, -1, -1, -1), hp, ht)
+        assert (ak != bk).any()
+
+
+def test_sw_benchmark_edit_distance_leg(cuda):
+    """sw-benchmark.cu:641-657: every read against the whole reference, edit distance, SEMI_GLOBAL"""
+    rng = np.random.default_rng(5)
+    ref = rng.integers(0, 4, 4096, dtype=np.uint8)
+    reads = []
+    for i in range(512):
+        p = int(rng.integers(0, ref.size - 150))
+        r = ref[p:p + 150].copy()
+        mut = rng.random(150) < 0.04
+        r[mut] = rng.integers(0, 4, int(mut.sum()))
+        reads.append(r)
+    hp = O.StringSet.from_lists(reads, 4, True)
+    hr = O.StringSet.from_lists([ref], 2, False)
+    ht = O.StringSet(hr.words, 2, False, np.zeros(512, np.uint64), np.full(512, ref.size, np.uint32))      # every job: the same text
+    es, ek = O.batch_sw_score(0, nvb.SEMI_GLOBAL, (0, -1, -1, -1), hp, ht)
+    gs, gk, _ = nvb.batch_alignment_score(nvb.make_edit_distance_aligner(nvb.SEMI_GLOBAL), to_dev(hp, cuda), to_dev(ht, cuda), 150, ref.size)
+    torch.cuda.synchronize()
+    assert (gs.cpu().numpy() == es).all() and (gk.cpu().numpy().view(np.uint32) == ek).all()
+    assert es.max() <= 0 and es.min() < -2
+
+
+def test_asymmetric_costs_are_refused(cuda):
+    hp, ht = O.StringSet.from_lists([np.zeros(10, np.uint8)], 4, True), O.StringSet.from_lists([np.zeros(30, np.uint8)], 2, True)
+    al = nvb.make_smith_waterman_aligner(nvb.LOCAL, nvb.SimpleSmithWatermanScheme(2, -1, -2, -1))
+    with pytest.raises(RuntimeError):
+        nvb.batch_banded_alignment_score(15, al, to_dev(hp, cuda), to_dev(ht, cuda))
+    with pytest.raises(RuntimeError):
+        nvb.batch_alignment_score(al, to_dev(hp, cuda), to_dev(ht, cuda), 10, 30)
