@@ -1,0 +1,169 @@
+"""On-disk formats either side of the hot path, as the reference reads / writes them:
+
+  <prefix>.bwt / .rbwt   [uint32 primary][uint32 cumFreq x4][uint32 BWT words: 2-bit big-endian, '$' removed]
+                         load_bwt (nvbio/io/fmindex/fmindex_impl.cu:119-178), save_bwt (nvBWT/nvBWT.cu:312-331)
+  <prefix>.sa / .rsa     [primary][cumFreq x4][sa_intv][seq_length][uint32 ssa[1..]]   (ssa[0] = -1 is implied)
+                         load_sa (fmindex_impl.cu:180-262), save_ssa (nvBWT.cu:336-353)
+  <prefix>.wpac          [uint64 seq_length][uint32 words: 2-bit big-endian genome]      (nvBWT.cu:222-248, sequence_pac.cpp:94-145)
+  <prefix>.pac           BWA's byte-packed genome, 4 symbols per byte big-endian, trailing length byte
+                         (nvBWT.cu:253-298, sequence_pac.cpp:147-190)
+
+File parsing is host work (numpy); the occurrence table is built on the device by libnvbio_hip.so
+(nvbio_hip_build_bwt_occ), as FMIndexDataHost::load does on the host (fmindex_impl.cu:264-328)."""
+import os
+
+import numpy as np
+import torch
+
+from .fmindex import FMIndexDevice, build_bwt_occ
+
+FORWARD, REVERSE, SA = 0x02, 0x04, 0x10          # FMIndexData flags (nvbio/io/fmindex/fmindex.h:86-88)
+SA_INT, OCC_INT = 16, 64
+
+
+class FileMismatch(RuntimeError):
+    pass
+
+
+def read_bwt(path):
+    """-> (primary, cum_freq[4], seq_length, bwt_words uint32[4*ceil(n/64)] zero padded)"""
+    raw = np.fromfile(path, dtype=np.uint32)
+    if raw.size < 5:
+        raise IOError("failed reading bwt \"%s\"" % path)
+    primary, cum = int(raw[0]), raw[1:5].copy()
+    n = int(cum[3])                                   # the sum of the frequencies gives the total length
+    seq_words = (n + 15) // 16
+    padded = (seq_words + 3) // 4 * 4
+    body = raw[5:]
+    if (body.size + 3) // 4 * 4 != padded:
+        raise IOError("failed reading bwt \"%s\"" % path)
+    words = np.zeros(max(padded, 4 * ((n + 63) // 64)), dtype=np.uint32)
+    words[:body.size] = body
+    return primary, cum, n, words
+
+
+def write_bwt(path, primary, cum_freq, bwt_words, seq_length):
+    with open(path, "wb") as f:
+        np.array([primary], dtype=np.uint32).tofile(f)
+        np.asarray(cum_freq, dtype=np.uint32)[:4].tofile(f)
+        np.asarray(bwt_words, dtype=np.uint32)[:(seq_length + 15) // 16].tofile(f)
+
+
+def read_sa(path, seq_length, primary, sa_int=SA_INT):
+    """-> ssa uint32[(n + sa_int) / sa_int] with ssa[0] = 0xFFFFFFFF"""
+    raw = np.fromfile(path, dtype=np.uint32)
+    if raw.size < 7:
+        raise IOError("failed reading SSA \"%s\"" % path)
+    if int(raw[0]) != primary:
+        raise FileMismatch("SA file mismatch \"%s\": expected primary %u, got %u" % (path, primary, int(raw[0])))
+    if int(raw[5]) != sa_int:
+        raise FileMismatch("unsupported SA interval (found %u, expected %u)" % (int(raw[5]), sa_int))
+    if int(raw[6]) != seq_length:
+        raise FileMismatch("SA file mismatch \"%s\": expected length %u, got %u" % (path, seq_length, int(raw[6])))
+    size = (seq_length + sa_int) // sa_int
+    if raw.size - 7 < size - 1:
+        raise IOError("failed reading SSA \"%s\"" % path)
+    ssa = np.empty(size, dtype=np.uint32)
+    ssa[0] = 0xFFFFFFFF
+    ssa[1:] = raw[7:7 + size - 1]
+    return ssa
+
+
+def write_sa(path, primary, cum_freq, ssa, seq_length, sa_int=SA_INT):
+    with open(path, "wb") as f:
+        np.array([primary], dtype=np.uint32).tofile(f)
+        np.asarray(cum_freq, dtype=np.uint32)[:4].tofile(f)
+        np.array([sa_int, seq_length], dtype=np.uint32).tofile(f)
+        np.asarray(ssa, dtype=np.uint32)[1:].tofile(f)
+
+
+def read_wpac(path):
+    """-> (seq_length, uint32 words, 2-bit big-endian)"""
+    with open(path, "rb") as f:
+        n = int(np.fromfile(f, dtype=np.uint64, count=1)[0])
+        words = np.fromfile(f, dtype=np.uint32, count=(n + 15) // 16)
+    if words.size != (n + 15) // 16:
+        raise IOError("failed reading %s" % path)
+    return n, words
+
+
+def write_wpac(path, seq_length, words):
+    with open(path, "wb") as f:
+        np.array([seq_length], dtype=np.uint64).tofile(f)
+        np.asarray(words, dtype=np.uint32)[:(seq_length + 15) // 16].tofile(f)
+
+
+def read_pac(path):
+    """BWA .pac -> (seq_length, uint32 words, 2-bit big-endian: the layout of the .wpac words)"""
+    raw = np.fromfile(path, dtype=np.uint8)
+    if raw.size < 2:
+        raise IOError("failed reading %s" % path)
+    n = (raw.size - 2) * 4 + int(raw[-1])
+    nbytes = (n + 3) // 4
+    body = np.zeros((nbytes + 3) // 4 * 4, dtype=np.uint8)
+    body[:nbytes] = raw[:nbytes]
+    # byte b holds symbols 4b..4b+3 from its top bits down; a big-endian word is the same order over 4 bytes
+    words = body.view(">u4").astype(np.uint32)
+    return n, words
+
+
+def write_pac(path, seq_length, words):
+    w = np.asarray(words, dtype=np.uint32)[:(seq_length + 15) // 16]
+    body = w.astype(">u4").view(np.uint8)[:(seq_length + 3) // 4]
+    with open(path, "wb") as f:
+        body.tofile(f)
+        if seq_length % 4 == 0:                       # the file size is always l_pac/4 + 1 + 1 (nvBWT.cu:285-294)
+            np.array([0], dtype=np.uint8).tofile(f)
+        np.array([seq_length % 4], dtype=np.uint8).tofile(f)
+
+
+def load_genome(prefix):
+    """sequence_pac.cpp:68-80: <prefix>.wpac if present, else <prefix>.pac"""
+    if os.path.exists(prefix + ".wpac"):
+        return read_wpac(prefix + ".wpac")
+    return read_pac(prefix + ".pac")
+
+
+class FMIndexDataDevice:
+    """io::FMIndexDataHost::load + io::FMIndexDataDevice (nvbio/io/fmindex/fmindex.h:200-362): reads
+    <prefix>.bwt/.sa (FORWARD) and .rbwt/.rsa (REVERSE), builds the interleaved bwt|occ records on the device
+    and exposes `index()` / `rindex()` as FMIndexDevice objects."""
+
+    def __init__(self, prefix, flags=FORWARD | REVERSE | SA, device="cuda"):
+        self.flags = flags
+        self._fwd = self._load(prefix + ".bwt", prefix + ".sa", flags, device) if flags & FORWARD else None
+        self._rev = self._load(prefix + ".rbwt", prefix + ".rsa", flags, device) if flags & REVERSE else None
+        one = self._fwd or self._rev
+        self.seq_length = one.length if one else 0
+
+    @staticmethod
+    def _load(bwt_path, sa_path, flags, device):
+        primary, _, n, words = read_bwt(bwt_path)
+        d_words = torch.from_numpy(words.view(np.int32)).to(device)
+        bwt_occ, L2 = build_bwt_occ(n, d_words)
+        ssa = None
+        if (flags & SA) and os.path.exists(sa_path):
+            try:
+                ssa = torch.from_numpy(read_sa(sa_path, n, primary).view(np.int32)).to(device)
+            except FileMismatch:
+                ssa = None                             # "just skip the ssa file" (fmindex_impl.cu:253-256)
+        return FMIndexDevice(n, primary, L2, bwt_occ, ssa, SA_INT)
+
+    def index(self):
+        return self._fwd
+
+    def rindex(self):
+        return self._rev
+
+    def genome_length(self):
+        return self.seq_length
+
+
+def save_fmindex(prefix, host_index, reverse=False):
+    """Writes a host index (an object with length, primary, bwt (symbols), ssa, sa_int) the way nvBWT does."""
+    from .strings import pack_symbols
+    n = host_index.length
+    words = pack_symbols(torch.from_numpy(np.ascontiguousarray(host_index.bwt, dtype=np.uint8)), 2, True, pad_words=0).numpy().view(np.uint32)
+    cum = np.cumsum(np.bincount(np.asarray(host_index.bwt, dtype=np.uint8), minlength=4)[:4]).astype(np.uint32)
+    write_bwt(prefix + (".rbwt" if reverse else ".bwt"), host_index.primary, cum, words, n)
+    write_sa(prefix + (".rsa" if reverse else ".sa"), host_index.primary, cum, host_index.ssa, n, host_index.sa_int)

@@ -14,6 +14,8 @@
 #include <nvbio_hip/alignment.h>
 #include <nvbio_hip/fmindex.h>
 #include <nvbio_hip/mapping.h>
+#include <nvbio_hip/io.h>
+#include <unistd.h>
 
 using namespace nvbio;
 
@@ -421,6 +423,34 @@ static int fmindex_test()
         if (expect != n_hits) FAIL("filter.rank: %llu hits, expected %llu", (unsigned long long)n_hits, (unsigned long long)expect);
         for (uint64 i = 0; i < n_hits; ++i)
             if (memcmp(h.text.data() + hits[i].x, seeds[hits[i].y].data(), LEN)) FAIL("hit %llu: text at %u does not hold seed %u", (unsigned long long)i, hits[i].x, hits[i].y);
+    }
+    // on-disk formats: write <prefix>.bwt/.sa the way nvBWT does, load them through io::FMIndexDataHost /
+    // io::FMIndexDataDevice (occurrence table built on the device) and compare with the index built in memory
+    {
+        char prefix[256]; snprintf(prefix, sizeof(prefix), "/tmp/nvbio_hip_test_%d", int(getpid()));
+        const std::string bwt_name = std::string(prefix) + ".bwt", sa_name = std::string(prefix) + ".sa";
+        uint32 cum[4] = { h.L2[1], h.L2[2], h.L2[3], h.L2[4] };
+        FILE* f = fopen(bwt_name.c_str(), "wb");
+        fwrite(&h.primary, 4, 1, f); fwrite(cum, 4, 4, f); fwrite(h.bwt_words.data(), 4, (h.n + 15) / 16, f); fclose(f);
+        f = fopen(sa_name.c_str(), "wb");
+        const uint32 sa_int = 16;
+        fwrite(&h.primary, 4, 1, f); fwrite(cum, 4, 4, f); fwrite(&sa_int, 4, 1, f); fwrite(&h.n, 4, 1, f); fwrite(h.ssa.data() + 1, 4, h.ssa.size() - 1, f); fclose(f);
+        io::FMIndexDataHost host_data;
+        if (!host_data.load(prefix, io::FMIndexDataCore::FORWARD | io::FMIndexDataCore::SA)) FAIL("FMIndexDataHost::load failed");
+        io::FMIndexDataDevice dev_data(host_data, io::FMIndexDataCore::FORWARD);
+        const fm_index_device& lf = dev_data.index();
+        if (lf.length() != h.n || lf.primary() != h.primary) FAIL("loaded index: length/primary mismatch");
+        for (int c = 0; c < 5; ++c) if (lf.m.L2[c] != h.L2[c]) FAIL("loaded index: L2[%d] = %u != %u", c, lf.m.L2[c], h.L2[c]);
+        std::vector<uint32> got(h.bwt_occ.size());
+        hip_check(nvbio_hip_memcpy(got.data(), lf.m.bwt_occ, got.size() * 4, 2, nullptr), "memcpy");
+        if (got != h.bwt_occ) FAIL("loaded index: bwt_occ differs from the host-built table");
+        std::vector<uint32> rows(1000), pos0, pos1; for (uint32 i = 0; i < 1000; ++i) rows[i] = 1u + (i * 257u) % h.n;
+        hip::device_vector<uint32> d_rows(rows), d_pos(1000);
+        locate(lf, 1000, d_rows.data(), d_pos.data());
+        pos0 = d_pos.to_host();
+        for (uint32 i = 0; i < 1000; ++i) if (pos0[i] != h.sa[rows[i]]) FAIL("loaded index: locate(%u) = %u != %u", rows[i], pos0[i], h.sa[rows[i]]);
+        remove(bwt_name.c_str()); remove(sa_name.c_str());
+        fprintf(stderr, "    %-44s : ok\n", "io::FMIndexDataHost/Device (.bwt/.sa)");
     }
     // nvBowtie's seed mapping stage: the three algorithms of map_t vs the oracle, hit sets compared sorted
     {

@@ -1,0 +1,90 @@
+"""On-disk formats: byte layouts of .bwt/.sa/.wpac/.pac as the reference's loaders and
+nvBWT's writers define them (fmindex_impl.cu:119-262, nvBWT.cu:222-353, sequence_pac.cpp:94-190)."""
+import os
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+from nvbio_amd import io as nio
+from oracle import pyoracle as O
+
+
+def test_bwt_and_sa_byte_layout(tmp_path):
+    rng = np.random.default_rng(1)
+    text = rng.integers(0, 4, 1000, dtype=np.uint8)
+    h = O.FMIndex(text)
+    prefix = str(tmp_path / "g")
+    nio.save_fmindex(prefix, h)
+    raw = open(prefix + ".bwt", "rb").read()
+    primary, c0, c1, c2, c3 = struct.unpack("<5I", raw[:20])
+    assert primary == h.primary and c3 == 1000                          # the last cumulative frequency is the length
+    assert [c0, c1, c2, c3] == np.cumsum(np.bincount(h.bwt, minlength=4)).tolist()
+    assert len(raw) == 20 + 4 * ((1000 + 15) // 16)                      # BWT without '$', 16 symbols per word
+    w0 = struct.unpack("<I", raw[20:24])[0]
+    assert [(w0 >> (30 - 2 * k)) & 3 for k in range(16)] == h.bwt[:16].tolist()      # big-endian 2-bit symbols
+    raw = open(prefix + ".sa", "rb").read()
+    f = struct.unpack("<7I", raw[:28])
+    assert f[0] == h.primary and f[5] == 16 and f[6] == 1000
+    n_ssa = (1000 + 16) // 16
+    assert len(raw) == 28 + 4 * (n_ssa - 1)                              # ssa[0] (= -1) is not stored
+    assert struct.unpack("<I", raw[28:32])[0] == h.sa[16]
+    # readers
+    p2, cum, n, words = nio.read_bwt(prefix + ".bwt")
+    assert (p2, n) == (h.primary, 1000) and words.size % 4 == 0 and words.size >= 4 * ((n + 63) // 64)
+    assert (nio.read_sa(prefix + ".sa", n, p2) == h.ssa).all()
+    with pytest.raises(nio.FileMismatch):
+        nio.read_sa(prefix + ".sa", n, p2 + 1)
+    with pytest.raises(nio.FileMismatch):
+        nio.read_sa(prefix + ".sa", n, p2, sa_int=32)
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 16, 17, 64, 1001, 1004])
+def test_pac_and_wpac(tmp_path, n):
+    rng = np.random.default_rng(n)
+    sym = rng.integers(0, 4, n, dtype=np.uint8)
+    words = O.pack(sym, 2, True)
+    p, w = str(tmp_path / "x.pac"), str(tmp_path / "x.wpac")
+    nio.write_pac(p, n, words)
+    nio.write_wpac(w, n, words)
+    assert os.path.getsize(p) == n // 4 + 2 if n % 4 == 0 else os.path.getsize(p) == (n + 3) // 4 + 1      # BWA's size rule
+    raw = np.fromfile(p, dtype=np.uint8)
+    assert raw[-1] == n % 4
+    assert [(int(raw[i // 4]) >> (6 - 2 * (i % 4))) & 3 for i in range(n)] == sym.tolist()
+    assert struct.unpack("<Q", open(w, "rb").read(8))[0] == n
+    for loader in (nio.read_pac, nio.read_wpac):
+        n2, w2 = loader(p if loader is nio.read_pac else w)
+        assert n2 == n
+        assert [(int(w2[i // 16]) >> (30 - 2 * (i % 16))) & 3 for i in range(n)] == sym.tolist()
+    os.remove(w)
+    assert nio.load_genome(str(tmp_path / "x"))[0] == n                  # falls back to .pac
+
+
+@pytest.mark.gpu
+def test_index_round_trip_through_files(tmp_path, cuda):
+    """write forward + reverse index files, load them with FMIndexDataDevice (occurrence table built on the
+    device), and search: identical to the index uploaded directly."""
+    import nvbio_amd as nvb
+    rng = np.random.default_rng(2)
+    text = rng.integers(0, 4, 50_000, dtype=np.uint8)
+    h, rh = O.FMIndex(text), O.FMIndex(text[::-1].copy())
+    prefix = str(tmp_path / "genome")
+    nio.save_fmindex(prefix, h)
+    nio.save_fmindex(prefix, rh, reverse=True)
+    data = nio.FMIndexDataDevice(prefix, device=cuda)
+    for loaded, host in ((data.index(), h), (data.rindex(), rh)):
+        assert (loaded.length, loaded.primary) == (host.length, host.primary)
+        assert loaded.L2 == [int(x) for x in host.L2]
+        assert (loaded.bwt_occ.cpu().numpy().view(np.uint32) == host.bwt_occ).all()
+        assert (loaded.ssa.cpu().numpy().view(np.uint32) == host.ssa).all()
+    seeds = [text[i:i + 20] for i in rng.integers(0, text.size - 20, 500)]
+    hs = O.StringSet.from_lists(seeds, 2, True)
+    ds = nvb.PackedStringSet.from_host(hs.words, 2, True, hs.begin, hs.length, device=cuda)
+    r = nvb.match(data.index(), ds).cpu().numpy().view(np.uint32)
+    assert (r == h.match(hs)).all()
+    pos = nvb.locate(data.index(), torch.from_numpy(r[:, 0].astype(np.int64)).to(cuda).to(torch.int32)).cpu().numpy().view(np.uint32)
+    assert all((text[p:p + 20] == s).all() for p, s in zip(pos, seeds))
+    # SA-less load
+    d2 = nio.FMIndexDataDevice(prefix, flags=nio.FORWARD, device=cuda)
+    assert d2.index().ssa is None and d2.rindex() is None
