@@ -272,6 +272,34 @@ int nvbio_hip_map(int32_t algorithm, uint32_t subseed_len,
                   const nvbio_hip_map_params* params /* host */, const uint32_t* seed_freq_by_len /* device */,
                   uint64_t* out_hits, uint32_t hits_stride, uint32_t* out_counts, uint8_t* out_reseed, void* stream);
 
+/* nvBowtie's reduction of extension results to the best two alignments per read: score_reduce_kernel
+ * (nvBowtie/bowtie2/cuda/reduce_inl.h:71-160).  An io::Alignment (nvbio/io/alignments.h:80-131) is a uint64:
+ * low word {score_sgn:1, score:17, ed:10, rc:1, mate:1, paired:1, discordant:1}, high word m_align;
+ * best_alignments[read] is the best, best_alignments[read + best_stride] the second best (initialised by
+ * nvbio_hip_init_alignments).  Active read t (read id read_ids[t], or t) owns the extension results
+ * [hit_begin[t], hit_begin[t+1]) of hit_score / hit_loc / hit_rc, walked in that order: results at an already
+ * recorded location are skipped, a higher score becomes the best (the old best the second), and a score above
+ * the second best replaces it only if distinct_alignments(best, hit, read_len/2) (alignments_inl.h:35-47).
+ * The context hooks of the reference (hit statistics / extension give-up counters) are not part of it. */
+uint64_t nvbio_hip_alignment_invalid(void);
+/* init_alignments (nvBowtie/bowtie2/cuda/aligner.h:323-366): best and second best of every read start unaligned
+ * (pos -1, ed 255) with score worst_score_by_len[read length] = the scheme's threshold score (device table). */
+int nvbio_hip_init_alignments(uint32_t n_reads, const uint32_t* read_len /* nullable */, uint32_t fixed_read_len,
+                              const int32_t* worst_score_by_len /* device */, uint32_t mate,
+                              uint64_t* best_alignments, uint32_t best_stride, void* stream);
+int nvbio_hip_score_reduce(uint32_t n_active, const uint32_t* read_ids /* nullable */, const uint64_t* hit_begin,
+                           const int32_t* hit_score, const uint32_t* hit_loc, const uint8_t* hit_rc,
+                           const uint32_t* read_len /* by read id, nullable */, uint32_t fixed_read_len,
+                           uint64_t* best_alignments, uint32_t best_stride, void* stream);
+
+/* BowtieMapq2 / BowtieMapq3 (nvBowtie/bowtie2/cuda/mapq.h:42-330) for single-end reads:
+ * out_mapq[r] from the best / second-best alignment of read r; perfect_score(len) = len * match,
+ * min_score(len) = min_score_by_len[len] (the scheme's SimpleFunc tabulated by the host, scoring.h:272-281),
+ * monotone = scheme.m_monotone (match bonus == 0).  Unaligned reads get 0.  version: 2 or 3. */
+int nvbio_hip_mapq(int32_t version, int32_t match, int32_t monotone, const int32_t* min_score_by_len /* device */,
+                   uint32_t n_reads, const uint64_t* best_alignments, uint32_t best_stride,
+                   const uint32_t* read_len /* nullable */, uint32_t fixed_read_len, uint8_t* out_mapq, void* stream);
+
 /* Replaces nvbio::locate(fmi, i) (fmindex_inl.h:466-501) and nvBowtie's
  * locate_kernel (nvBowtie/bowtie2/cuda/locate_inl.h:122-148). */
 int nvbio_hip_fm_locate(const nvbio_hip_fmindex* fmi, const uint32_t* sa_rows,

@@ -17,3 +17,4 @@ from .alignment import (GLOBAL, LOCAL, SEMI_GLOBAL, SimpleGotohScheme, SmithWate
 from .fmindex import FMIndexDevice, FMIndexFilter, rank, rank4, rank_range, match, locate, \
     locate_ssa_iterator, lookup_ssa_iterator, build_bwt_occ  # noqa: F401
 from .mapping import MappingParams, map_exact, map_seeds, unpack_seed_hits  # noqa: F401
+from .reduce import BestAlignments, score_reduce, mapq  # noqa: F401

@@ -31,15 +31,25 @@ class SmithWatermanScoringScheme:
     constant one, affine read / reference gap costs.  Defaults are bowtie2's end-to-end values."""
 
     def __init__(self, match=0, mmp_min=2, mmp_max=6, read_gap_const=5, read_gap_coeff=3,
-                 ref_gap_const=5, ref_gap_coeff=3, mm_cost="qual"):
+                 ref_gap_const=5, ref_gap_coeff=3, mm_cost="qual", score_min=(0, -0.6, -0.6)):
         self.m_match = int(match)
+        self.m_score_min = score_min                               # SimpleFunc (type, k, m): LinearFunc -0.6 -0.6 (scoring_inl.h:108)
+        self.m_monotone = int(match) == 0                          # scoring_inl.h:143
         self.m_mmp_min, self.m_mmp_max, self.mm_cost = int(mmp_min), int(mmp_max), mm_cost
         self.m_read_gap_const, self.m_read_gap_coeff = int(read_gap_const), int(read_gap_coeff)
         self.m_ref_gap_const, self.m_ref_gap_coeff = int(ref_gap_const), int(ref_gap_coeff)
 
     @staticmethod
     def local():
-        return SmithWatermanScoringScheme(match=2)
+        """SmithWatermanScoringScheme::local() (scoring_inl.h:81-101): match 2, score-min = log, 0 + 10 ln(len)"""
+        return SmithWatermanScoringScheme(match=2, score_min=(1, 0.0, 10.0))
+
+    def perfect_score(self, read_len):                             # scoring.h:281
+        return int(read_len) * self.m_match
+
+    def min_score(self, read_len):                                 # scoring.h:272
+        from .mapping import simple_func
+        return simple_func(*self.m_score_min, read_len)
 
     def mmp(self, q):
         """m_mmp(q).  QualCost: min + int(frac * (max - min)), frac = float(min(q,40) / 40.0f), in

@@ -1,0 +1,200 @@
+// reduce.hip -- nvBowtie's score reduction and mapping-quality stages on gfx950.
+//   score_reduce_kernel   nvBowtie/bowtie2/cuda/reduce_inl.h:71-160   (best / second-best per read)
+//   BowtieMapq2 / Mapq3   nvBowtie/bowtie2/cuda/mapq.h:42-330
+//   io::Alignment         nvbio/io/alignments.h:80-131 ; distinct_alignments alignments_inl.h:35-47
+// Both are thin, HBM-streaming stages: one lane per read, a sequential walk over the read's extension
+// results (the update rule is order dependent), 16 B of state per read.
+#include "common.h"
+
+namespace nvb {
+
+struct IoAln { uint32_t w, align; };      // {score_sgn:1, score:17, ed:10, rc:1, mate:1, paired:1, discordant:1}, m_align
+
+__device__ __forceinline__ IoAln io_aln_make(uint32_t pos, uint32_t ed, int32_t score, uint32_t rc)
+{
+    const uint32_t mag = score < 0 ? uint32_t(-score) : uint32_t(score);
+    IoAln a;
+    a.w = (score < 0 ? 1u : 0u) | ((mag & 0x1FFFFu) << 1) | ((ed & 0x3FFu) << 18) | ((rc & 1u) << 28);
+    a.align = pos;
+    return a;
+}
+__device__ __forceinline__ int32_t  io_aln_score(const IoAln a) { const int32_t m = int32_t((a.w >> 1) & 0x1FFFFu); return (a.w & 1u) ? -m : m; }
+__device__ __forceinline__ uint32_t io_aln_rc(const IoAln a) { return (a.w >> 28) & 1u; }
+__device__ __forceinline__ bool     distinct_alignments(uint32_t pos1, uint32_t rc1, uint32_t pos2, uint32_t rc2, uint32_t dist)
+{
+    if (rc1 != rc2) return true;
+    return !(pos1 >= pos2 - min(pos2, dist) && pos1 <= pos2 + dist);
+}
+
+__global__ void __launch_bounds__(256)
+score_reduce_kernel(uint32_t n_active, const uint32_t* __restrict__ read_ids, const uint64_t* __restrict__ hit_begin,
+                    const int32_t* __restrict__ hit_score, const uint32_t* __restrict__ hit_loc, const uint8_t* __restrict__ hit_rc,
+                    const uint32_t* __restrict__ read_len, uint32_t fixed_len, uint2* __restrict__ best, uint32_t best_stride)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_active) return;
+    const uint32_t read_id = read_ids ? read_ids[t] : t;
+    const uint2 b1 = best[read_id], b2 = best[read_id + best_stride];
+    IoAln a1 = { b1.x, b1.y }, a2 = { b2.x, b2.y };
+    const uint32_t len = read_len ? read_len[read_id] : fixed_len;
+    const uint64_t hb = hit_begin[t], he = hit_begin[t + 1];
+    for (uint64_t i = hb; i < he; ++i)
+    {
+        const int32_t score = hit_score[i]; const uint32_t g_pos = hit_loc[i], rc = hit_rc[i];
+        // locations already visited are skipped (reduce_inl.h:111-114)
+        if ((rc == io_aln_rc(a1) && g_pos == a1.align) || (rc == io_aln_rc(a2) && g_pos == a2.align)) continue;
+        if (score > io_aln_score(a1)) { a2 = a1; a1 = io_aln_make(g_pos, 0u, score, rc); }
+        else if (score > io_aln_score(a2) && distinct_alignments(a1.align, io_aln_rc(a1), g_pos, rc, len / 2u)) a2 = io_aln_make(g_pos, 0u, score, rc);
+    }
+    best[read_id] = make_uint2(a1.w, a1.align);
+    best[read_id + best_stride] = make_uint2(a2.w, a2.align);
+}
+
+// init_alignments_kernel (nvBowtie/bowtie2/cuda/aligner.h:323-346): both slots unaligned (pos -1, ed max) with the
+// read's worst acceptable score, so that only extensions above the threshold are ever recorded.  The reference
+// passes `mate` in the constructor's rc position (aligner.h:342-343); kept.
+__global__ void __launch_bounds__(256)
+init_alignments_kernel(uint32_t n_reads, const uint32_t* __restrict__ read_len, uint32_t fixed_len,
+                       const int32_t* __restrict__ worst_score_by_len, uint32_t mate, uint2* __restrict__ best, uint32_t best_stride)
+{
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint32_t len = read_len ? read_len[r] : fixed_len;
+    const IoAln a = io_aln_make(0xFFFFFFFFu, 255u, worst_score_by_len[len], mate);
+    best[r] = make_uint2(a.w, a.align);
+    best[r + best_stride] = make_uint2(a.w, a.align);
+}
+
+// single-precision arithmetic without contraction, so the thresholds fall where the host code puts them
+__device__ __forceinline__ float fmul(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float fadd(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ int clamp10(int v) { return v < 0 ? 0 : v > 10 ? 10 : v; }
+
+__constant__ int8_t c_unpaired_one[11] = { 43, 42, 41, 36, 32, 27, 20, 11, 4, 1, 0 };
+__constant__ int8_t c_unpaired_two_perfect[11] = { 2, 16, 23, 30, 31, 32, 34, 36, 38, 40, 42 };
+__constant__ int8_t c_unpaired_two[11][11] = {
+    {  2,  2,  2,  1,  1, 0, 0, 0, 0, 0, 0 }, { 20, 14,  7,  3,  2, 1, 0, 0, 0, 0, 0 }, { 20, 16, 10,  6,  3, 1, 0, 0, 0, 0, 0 },
+    { 20, 17, 13,  9,  3, 1, 1, 0, 0, 0, 0 }, { 21, 19, 15,  9,  5, 2, 2, 0, 0, 0, 0 }, { 22, 21, 16, 11, 10, 5, 0, 0, 0, 0, 0 },
+    { 23, 22, 19, 16, 11, 0, 0, 0, 0, 0, 0 }, { 24, 25, 21, 30,  0, 0, 0, 0, 0, 0, 0 }, { 30, 26, 29,  0,  0, 0, 0, 0, 0, 0, 0 },
+    { 30, 27,  0,  0,  0, 0, 0, 0, 0, 0, 0 }, { 30,  0,  0,  0,  0, 0, 0, 0, 0, 0, 0 } };
+
+__device__ uint32_t mapq_v3(int32_t best_score, bool has_second, int32_t second_score, float max_score, float min_score)
+{
+    const float norm_factor = __fdiv_rn(10.0f, fadd(max_score, -min_score));
+    if (float(best_score) < min_score) return 0u;
+    const int best = max(int(max_score) - best_score, 0);
+    const int best_bin = clamp10(int(fadd(fmul(float(best), norm_factor), 0.5f)));
+    if (has_second) {
+        const int diff = best_score - second_score;
+        const int diff_bin = clamp10(int(fadd(fmul(float(diff), norm_factor), 0.5f)));
+        return (float(best) == max_score) ? uint32_t(c_unpaired_two_perfect[best_bin]) : uint32_t(c_unpaired_two[diff_bin][best_bin]);
+    }
+    return (float(best) == max_score) ? 44u : uint32_t(c_unpaired_one[best_bin]);
+}
+__device__ uint32_t mapq_v2(int32_t best_score, bool has_second, int32_t second_score, float max_score, float min_score, bool monotone)
+{
+    const float diff = fadd(max_score, -min_score), best = float(best_score);
+    if (best < min_score) return 0u;
+    const float best_over = fadd(best, -min_score);
+    #define GE(x, f) ((x) >= fmul(diff, f))
+    if (monotone) {
+        if (!has_second) {
+            if (GE(best_over, 0.8f)) return 42; if (GE(best_over, 0.7f)) return 40; if (GE(best_over, 0.6f)) return 24;
+            if (GE(best_over, 0.5f)) return 23; if (GE(best_over, 0.4f)) return 8;  if (GE(best_over, 0.3f)) return 3;
+            return 0;
+        }
+        const float best_diff = fabsf(fadd(fabsf(best), -fabsf(float(second_score))));
+        if (GE(best_diff, 0.9f)) return (best_over == diff) ? 39 : 33;
+        if (GE(best_diff, 0.8f)) return (best_over == diff) ? 38 : 27;
+        if (GE(best_diff, 0.7f)) return (best_over == diff) ? 37 : 26;
+        if (GE(best_diff, 0.6f)) return (best_over == diff) ? 36 : 22;
+        if (GE(best_diff, 0.5f)) { if (best_over == diff) return 35; if (GE(best_over, 0.84f)) return 25; if (GE(best_over, 0.68f)) return 16; return 5; }
+        if (GE(best_diff, 0.4f)) { if (best_over == diff) return 34; if (GE(best_over, 0.84f)) return 21; if (GE(best_over, 0.68f)) return 14; return 4; }
+        if (GE(best_diff, 0.3f)) { if (best_over == diff) return 32; if (GE(best_over, 0.88f)) return 18; if (GE(best_over, 0.67f)) return 15; return 3; }
+        if (GE(best_diff, 0.2f)) { if (best_over == diff) return 31; if (GE(best_over, 0.88f)) return 17; if (GE(best_over, 0.67f)) return 11; return 0; }
+        if (GE(best_diff, 0.1f)) { if (best_over == diff) return 30; if (GE(best_over, 0.88f)) return 12; if (GE(best_over, 0.67f)) return 7;  return 0; }
+        if (best_diff > 0) return GE(best_over, 0.67f) ? 6 : 2;
+        return GE(best_over, 0.67f) ? 1 : 0;
+    }
+    if (!has_second) {
+        if (GE(best_over, 0.8f)) return 44; if (GE(best_over, 0.7f)) return 42; if (GE(best_over, 0.6f)) return 41;
+        if (GE(best_over, 0.5f)) return 36; if (GE(best_over, 0.4f)) return 28; if (GE(best_over, 0.3f)) return 24;
+        return 22;
+    }
+    const float best_diff = fabsf(fadd(fabsf(best), -fabsf(float(second_score))));
+    if (GE(best_diff, 0.9f)) return 40; if (GE(best_diff, 0.8f)) return 39; if (GE(best_diff, 0.7f)) return 38; if (GE(best_diff, 0.6f)) return 37;
+    if (GE(best_diff, 0.5f)) { if (best_over == diff) return 35; return GE(best_over, 0.50f) ? 25 : 20; }
+    if (GE(best_diff, 0.4f)) { if (best_over == diff) return 34; return GE(best_over, 0.50f) ? 21 : 19; }
+    if (GE(best_diff, 0.3f)) { if (best_over == diff) return 33; return GE(best_over, 0.5f) ? 18 : 16; }
+    if (GE(best_diff, 0.2f)) { if (best_over == diff) return 32; return GE(best_over, 0.5f) ? 17 : 12; }
+    if (GE(best_diff, 0.1f)) { if (best_over == diff) return 31; return GE(best_over, 0.5f) ? 14 : 9; }
+    if (best_diff > 0) return GE(best_over, 0.5f) ? 11 : 2;
+    return GE(best_over, 0.5f) ? 1 : 0;
+    #undef GE
+}
+
+__global__ void __launch_bounds__(256)
+mapq_kernel(int32_t version, int32_t match, int32_t monotone, uint32_t n_reads, const uint2* __restrict__ best, uint32_t best_stride,
+            const uint32_t* __restrict__ read_len, uint32_t fixed_len, const int32_t* __restrict__ min_score_by_len, uint8_t* __restrict__ out)
+{
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint2 b1 = best[r], b2 = best[r + best_stride];
+    const IoAln a1 = { b1.x, b1.y }, a2 = { b2.x, b2.y };
+    if (a1.align == 0xFFFFFFFFu) { out[r] = 0; return; }
+    const uint32_t len = read_len ? read_len[r] : fixed_len;
+    const float max_score = float(int32_t(len) * match), min_score = float(min_score_by_len[len]);
+    const bool has_second = a2.align != 0xFFFFFFFFu;
+    out[r] = uint8_t(version == 3 ? mapq_v3(io_aln_score(a1), has_second, io_aln_score(a2), max_score, min_score)
+                                  : mapq_v2(io_aln_score(a1), has_second, io_aln_score(a2), max_score, min_score, monotone != 0));
+}
+
+} // namespace nvb
+
+using namespace nvb;
+
+NVB_API uint64_t nvbio_hip_alignment_invalid(void)
+{   // io::Alignment::invalid(): pos -1, ed 255, score 2^17-1 (alignments.h:127-128)
+    return (uint64_t(0xFFFFFFFFu) << 32) | (uint64_t(0x1FFFFu) << 1) | (uint64_t(255u) << 18);
+}
+
+NVB_API int nvbio_hip_init_alignments(uint32_t n_reads, const uint32_t* read_len, uint32_t fixed_read_len,
+                                      const int32_t* worst_score_by_len, uint32_t mate,
+                                      uint64_t* best_alignments, uint32_t best_stride, void* stream)
+{
+    if (n_reads == 0) return hipSuccess;
+    if (!worst_score_by_len || !best_alignments || best_stride < n_reads) return hipErrorInvalidValue;
+    if (!read_len && fixed_read_len == 0) return hipErrorInvalidValue;
+    g_last_kernel = "init_alignments_kernel";
+    hipLaunchKernelGGL(init_alignments_kernel, dim3((n_reads + 255u) / 256u), dim3(256), 0, to_stream(stream), n_reads, read_len, fixed_read_len,
+                       worst_score_by_len, mate, reinterpret_cast<uint2*>(best_alignments), best_stride);
+    return hipGetLastError();
+}
+
+NVB_API int nvbio_hip_score_reduce(uint32_t n_active, const uint32_t* read_ids, const uint64_t* hit_begin,
+                                   const int32_t* hit_score, const uint32_t* hit_loc, const uint8_t* hit_rc,
+                                   const uint32_t* read_len, uint32_t fixed_read_len,
+                                   uint64_t* best_alignments, uint32_t best_stride, void* stream)
+{
+    if (n_active == 0) return hipSuccess;
+    if (!hit_begin || !hit_score || !hit_loc || !hit_rc || !best_alignments || best_stride == 0) return hipErrorInvalidValue;
+    if (!read_len && fixed_read_len == 0) return hipErrorInvalidValue;
+    g_last_kernel = "score_reduce_kernel";
+    hipLaunchKernelGGL(score_reduce_kernel, dim3((n_active + 255u) / 256u), dim3(256), 0, to_stream(stream), n_active, read_ids, hit_begin,
+                       hit_score, hit_loc, hit_rc, read_len, fixed_read_len, reinterpret_cast<uint2*>(best_alignments), best_stride);
+    return hipGetLastError();
+}
+
+NVB_API int nvbio_hip_mapq(int32_t version, int32_t match, int32_t monotone, const int32_t* min_score_by_len,
+                           uint32_t n_reads, const uint64_t* best_alignments, uint32_t best_stride,
+                           const uint32_t* read_len, uint32_t fixed_read_len, uint8_t* out_mapq, void* stream)
+{
+    if (version != 2 && version != 3) return hipErrorInvalidValue;
+    if (n_reads == 0) return hipSuccess;
+    if (!min_score_by_len || !best_alignments || !out_mapq || best_stride == 0) return hipErrorInvalidValue;
+    if (!read_len && fixed_read_len == 0) return hipErrorInvalidValue;
+    g_last_kernel = "mapq_kernel";
+    hipLaunchKernelGGL(mapq_kernel, dim3((n_reads + 255u) / 256u), dim3(256), 0, to_stream(stream), version, match, monotone, n_reads,
+                       reinterpret_cast<const uint2*>(best_alignments), best_stride, read_len, fixed_read_len, min_score_by_len, out_mapq);
+    return hipGetLastError();
+}

@@ -29,6 +29,27 @@ class HipBackend:
     def score(self, band, aligner, patterns, texts):
         return self._a.batch_banded_alignment_score(band, aligner, patterns, texts)
 
+    # the stages after scoring (align_single_end)
+    def init_best(self, n, scheme, read_len):
+        from . import reduce
+        return reduce.BestAlignments(n, scheme, fixed_read_len=read_len, device=self.fmi.bwt_occ.device).data
+
+    def reduce(self, best, hit_begin, score, loc, rc, read_len):
+        from . import reduce
+        b = reduce.BestAlignments.__new__(reduce.BestAlignments)
+        b.n, b.stride, b.data = best.shape[1], best.shape[1], best
+        reduce.score_reduce(b, hit_begin, score, loc, rc, fixed_read_len=read_len)
+        return best
+
+    def mapq(self, best, scheme, read_len, version=2):
+        from . import reduce
+        b = reduce.BestAlignments.__new__(reduce.BestAlignments)
+        b.n, b.stride, b.data = best.shape[1], best.shape[1], best
+        return reduce.mapq(b, scheme, fixed_read_len=read_len, version=version)
+
+    def traceback(self, band, aligner, patterns, texts, cigar_stride):
+        return self._a.batch_banded_alignment_traceback(band, aligner, patterns, texts, cigar_stride=cigar_stride)
+
 
 def make_reads(text, n, read_len=100, seed=0x5EED0004, sub_rate=0.04):
     """Single-end reads sampled from the genome, half of them from the reverse strand, with
@@ -97,3 +118,66 @@ def seed_and_extend(backend, sym, genome_words, genome_len, band=15, rows_per_hi
     best_score = torch.where(has, (best >> 32) - (1 << 31), torch.full_like(best, -(1 << 30))).to(torch.int32)
     best_pos = torch.where(has, (1 << 32) - 1 - (best & 0xFFFFFFFF), torch.full_like(best, -1))
     return best_score, best_pos, int(rep.numel())
+
+
+def align_single_end(backend, sym, genome_words, genome_len, band=15, rows_per_hit=2, hits_stride=16, aligner=None,
+                     mapq_scheme=None, packed=None, cigar_stride=32):
+    """seed -> locate -> extend -> score_reduce (best / second best, nvBowtie's rule) -> MAPQ (BowtieMapq2) ->
+    banded traceback of the best alignment: the single-end stages of nvBowtie's best-approx driver
+    (aligner_best_approx.h:522-840) minus its hit-selection heuristics -- every located row is extended, in
+    (read, sorted hit, row) order.  Returns dict(best int64[2,n] io::Alignment words, mapq uint8[n],
+    cigar int16[n,stride], cigar_len int32[n], source int32[n,2], sink int32[n,2], n_jobs)."""
+    from .alignment import make_gotoh_aligner, SimpleGotohScheme, SmithWatermanScoringScheme, SEMI_GLOBAL
+    n, L = sym.shape
+    dev = sym.device
+    reads_rev, ext_words = packed if packed is not None else pack_read_streams(sym)
+    if aligner is None:
+        aligner = make_gotoh_aligner(SEMI_GLOBAL, SimpleGotohScheme(0, -6, -8, -3))
+    if mapq_scheme is None:
+        mapq_scheme = SmithWatermanScoringScheme()              # end-to-end: perfect score 0, min score -0.6 - 0.6 L
+    hits, counts = backend.map_exact(reads_rev, hits_stride)
+    k = torch.arange(hits.shape[1], device=dev).unsqueeze(0)
+    valid = k < (counts.to(torch.int64) & 0xFFFFFFFF).unsqueeze(1)
+    # a deterministic extension order: each read's hits sorted by their words (the reference's order is run dependent)
+    hits = torch.where(valid, hits, torch.full_like(hits, (1 << 63) - 1))
+    hits, _ = torch.sort(hits, dim=1)
+    read_id = torch.arange(n, device=dev).unsqueeze(1).expand_as(hits)[valid.sum(1, keepdim=True) > k]
+    w = hits[valid.sum(1, keepdim=True) > k]
+    lo, hi = w & 0xFFFFFFFF, (w >> 32) & 0xFFFFFFFF
+    delta, pir, rc = hi & 0xFFFFF, (hi >> 20) & 0x3FF, (hi >> 30) & 1
+    take = torch.clamp(delta, max=rows_per_hit)
+    rep = torch.repeat_interleave(torch.arange(w.numel(), device=dev), take)
+    first = torch.cumsum(take, 0) - take
+    row = lo[rep] + (torch.arange(rep.numel(), device=dev) - first[rep])
+    gpos = backend.locate(row.to(torch.int32)).to(torch.int64) & 0xFFFFFFFF
+    jr, jrc = read_id[rep], rc[rep]
+    wbeg = torch.clamp(gpos - pir[rep] - band // 2, min=0)
+    wend = torch.clamp(wbeg + L + band, max=genome_len)
+    pat_begin = (jr * L + jrc * (n * L)).contiguous()
+    patterns = PackedStringSet(ext_words, 4, True, pat_begin, None, L)
+    texts = PackedStringSet(genome_words, 2, True, wbeg.contiguous(), (wend - wbeg).to(torch.int32).contiguous(), 0)
+    score, _ = backend.score(band, aligner, patterns, texts)
+    # reduce: jobs are grouped by read (jr is non-decreasing); results below the threshold never beat the initial worst score
+    per_read = torch.bincount(jr, minlength=n)
+    hit_begin = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    hit_begin[1:] = torch.cumsum(per_read, 0)
+    best = backend.init_best(n, mapq_scheme, L)
+    best = backend.reduce(best, hit_begin, score.contiguous(), wbeg.to(torch.int32).contiguous(), jrc.to(torch.uint8).contiguous(), L)
+    mapq = backend.mapq(best, mapq_scheme, L)
+    # traceback of the best alignment of every aligned read (traceback_inl.h: window = the scored window)
+    b_align = (best[0] >> 32) & 0xFFFFFFFF
+    aligned = b_align != 0xFFFFFFFF
+    b_rc = (best[0] >> 28) & 1
+    ids = torch.nonzero(aligned).squeeze(1)
+    tb_begin = b_align[ids]
+    tb_end = torch.clamp(tb_begin + L + band, max=genome_len)
+    tb_pat = PackedStringSet(ext_words, 4, True, (ids * L + b_rc[ids] * (n * L)).contiguous(), None, L)
+    tb_txt = PackedStringSet(genome_words, 2, True, tb_begin.contiguous(), (tb_end - tb_begin).to(torch.int32).contiguous(), 0)
+    tb = backend.traceback(band, aligner, tb_pat, tb_txt, cigar_stride)
+    cigar = torch.zeros((n, cigar_stride), dtype=torch.int16, device=dev)
+    cigar_len = torch.zeros(n, dtype=torch.int32, device=dev)
+    source = torch.full((n, 2), -1, dtype=torch.int32, device=dev)
+    sink = torch.full((n, 2), -1, dtype=torch.int32, device=dev)
+    cigar[ids] = tb["cigar"][: ids.numel()]; cigar_len[ids] = tb["cigar_len"]; source[ids] = tb["source"]; sink[ids] = tb["sink"]
+    return dict(best=best, mapq=mapq, cigar=cigar, cigar_len=cigar_len, source=source, sink=sink, tb_score=tb["score"], aligned_ids=ids,
+                n_jobs=int(rep.numel()))

@@ -1356,6 +1356,153 @@ ORACLE_API void oracle_simple_func_table(int type, float k, float m, uint32_t n,
         out[x] = (uint32_t)(int32_t)(k + m * (type == 1 ? logf((float)x) : type == 2 ? sqrtf((float)x) : (float)x));
 }
 
+/* ------------------------------------------------------------------------ */
+/* nvBowtie score reduction and mapping quality                               */
+/*   io::Alignment / BestAlignments   nvbio/io/alignments.h:80-176            */
+/*   io::distinct_alignments          nvbio/io/alignments_inl.h:35-47         */
+/*   score_reduce_kernel              nvBowtie/bowtie2/cuda/reduce_inl.h:71-160 */
+/*   BowtieMapq2 / BowtieMapq3        nvBowtie/bowtie2/cuda/mapq.h:42-330     */
+/* io::Alignment is two words: {score_sgn:1, score:17, ed:10, rc:1, mate:1,    */
+/* paired:1, discordant:1} (first bit-field in the low bits) and m_align.      */
+/* ------------------------------------------------------------------------ */
+static int32_t simple_func(int type, float k, float m, int32_t x);
+typedef struct { uint32_t w, align; } io_aln_t;
+static inline io_aln_t io_aln_make(uint32_t pos, uint32_t ed, int32_t score, uint32_t rc)
+{
+    io_aln_t a;
+    const uint32_t mag = score < 0 ? (uint32_t)(-score) : (uint32_t)score;
+    a.w = (score < 0 ? 1u : 0u) | ((mag & 0x1FFFFu) << 1) | ((ed & 0x3FFu) << 18) | ((rc & 1u) << 28);
+    a.align = pos;
+    return a;
+}
+static inline int32_t  io_aln_score(io_aln_t a) { const int32_t m = (int32_t)((a.w >> 1) & 0x1FFFFu); return (a.w & 1u) ? -m : m; }
+static inline uint32_t io_aln_rc(io_aln_t a) { return (a.w >> 28) & 1u; }
+static inline int      io_aln_aligned(io_aln_t a) { return a.align != 0xFFFFFFFFu; }
+ORACLE_API uint64_t oracle_alignment_invalid(void)
+{   /* Alignment::invalid() = Alignment(uint32(-1), max_ed() = 255, max_score() = 2^17-1, 0) */
+    const io_aln_t a = io_aln_make(0xFFFFFFFFu, 255u, (1 << 17) - 1, 0u);
+    return ((uint64_t)a.align << 32) | a.w;
+}
+static inline int distinct_alignments(uint32_t pos1, uint32_t rc1, uint32_t pos2, uint32_t rc2, uint32_t dist)
+{
+    if (rc1 != rc2) return 1;
+    return (pos1 >= pos2 - (pos2 < dist ? pos2 : dist) && pos1 <= pos2 + dist) ? 0 : 1;
+}
+
+/* init_alignments_kernel (aligner.h:323-346); `mate` lands in the constructor's rc slot there */
+ORACLE_API void oracle_init_alignments(uint32_t n_reads, const uint32_t* read_len, int min_type, float min_k, float min_m, uint32_t mate,
+    uint64_t* best, uint32_t best_stride)
+{
+    for (uint32_t r = 0; r < n_reads; ++r) {
+        const io_aln_t a = io_aln_make(0xFFFFFFFFu, 255u, simple_func(min_type, min_k, min_m, (int32_t)read_len[r]), mate);
+        best[r] = best[r + best_stride] = ((uint64_t)a.align << 32) | a.w;
+    }
+}
+
+/* best: [2][best_stride] words pairs {w, align} (best at read_id, second best at read_id + best_stride);
+ * hits of active read t: [hit_begin[t], hit_begin[t+1]) in extension order */
+ORACLE_API void oracle_score_reduce(uint32_t n_active, const uint32_t* read_ids /* nullable */, const uint64_t* hit_begin,
+    const int32_t* hit_score, const uint32_t* hit_loc, const uint8_t* hit_rc, const uint32_t* read_len /* by read id */,
+    uint64_t* best, uint32_t best_stride)
+{
+    for (uint32_t t = 0; t < n_active; ++t)
+    {
+        const uint32_t read_id = read_ids ? read_ids[t] : t;
+        io_aln_t a1 = { (uint32_t)best[read_id], (uint32_t)(best[read_id] >> 32) };
+        io_aln_t a2 = { (uint32_t)best[read_id + best_stride], (uint32_t)(best[read_id + best_stride] >> 32) };
+        const uint32_t len = read_len[read_id];
+        for (uint64_t i = hit_begin[t]; i < hit_begin[t + 1]; ++i)
+        {
+            const int32_t score = hit_score[i]; const uint32_t g_pos = hit_loc[i], rc = hit_rc[i];
+            if ((rc == io_aln_rc(a1) && g_pos == a1.align) || (rc == io_aln_rc(a2) && g_pos == a2.align)) continue;
+            if (score > io_aln_score(a1)) { a2 = a1; a1 = io_aln_make(g_pos, 0u, score, rc); }
+            else if (score > io_aln_score(a2) && distinct_alignments(a1.align, io_aln_rc(a1), g_pos, rc, len / 2)) a2 = io_aln_make(g_pos, 0u, score, rc);
+        }
+        best[read_id] = ((uint64_t)a1.align << 32) | a1.w;
+        best[read_id + best_stride] = ((uint64_t)a2.align << 32) | a2.w;
+    }
+}
+
+static int32_t simple_func(int type, float k, float m, int32_t x)
+{
+    return (int32_t)(k + m * (type == 1 ? logf((float)x) : type == 2 ? sqrtf((float)x) : (float)x));
+}
+static inline int clamp10(int v) { return v < 0 ? 0 : v > 10 ? 10 : v; }
+
+static uint32_t mapq_v3(int32_t best_score, int has_second, int32_t second_score, float max_score, float min_score)
+{
+    static const int unpaired_one[11] = { 43, 42, 41, 36, 32, 27, 20, 11, 4, 1, 0 };
+    static const int unpaired_two_perfect[11] = { 2, 16, 23, 30, 31, 32, 34, 36, 38, 40, 42 };
+    static const int unpaired_two[11][11] = {
+        {  2,  2,  2,  1,  1, 0, 0, 0, 0, 0, 0 }, { 20, 14,  7,  3,  2, 1, 0, 0, 0, 0, 0 }, { 20, 16, 10,  6,  3, 1, 0, 0, 0, 0, 0 },
+        { 20, 17, 13,  9,  3, 1, 1, 0, 0, 0, 0 }, { 21, 19, 15,  9,  5, 2, 2, 0, 0, 0, 0 }, { 22, 21, 16, 11, 10, 5, 0, 0, 0, 0, 0 },
+        { 23, 22, 19, 16, 11, 0, 0, 0, 0, 0, 0 }, { 24, 25, 21, 30,  0, 0, 0, 0, 0, 0, 0 }, { 30, 26, 29,  0,  0, 0, 0, 0, 0, 0, 0 },
+        { 30, 27,  0,  0,  0, 0, 0, 0, 0, 0, 0 }, { 30,  0,  0,  0,  0, 0, 0, 0, 0, 0, 0 } };
+    const float norm_factor = 10.0f / (max_score - min_score);
+    if ((float)best_score < min_score) return 0;
+    const int best = ((int)max_score - best_score) > 0 ? ((int)max_score - best_score) : 0;
+    const int best_bin = clamp10((int)((float)best * norm_factor + 0.5f));
+    if (has_second) {
+        const int diff = best_score - second_score;
+        const int diff_bin = clamp10((int)((float)diff * norm_factor + 0.5f));
+        return ((float)best == max_score) ? (uint32_t)unpaired_two_perfect[best_bin] : (uint32_t)unpaired_two[diff_bin][best_bin];
+    }
+    return ((float)best == max_score) ? 44u : (uint32_t)unpaired_one[best_bin];
+}
+static uint32_t mapq_v2(int32_t best_score, int has_second, int32_t second_score, float max_score, float min_score, int monotone)
+{
+    const float diff = max_score - min_score, best = (float)best_score;
+    if (best < min_score) return 0;
+    const float best_over = best - min_score;
+    if (monotone) {
+        if (!has_second) {
+            if (best_over >= diff * 0.8f) return 42; if (best_over >= diff * 0.7f) return 40; if (best_over >= diff * 0.6f) return 24;
+            if (best_over >= diff * 0.5f) return 23; if (best_over >= diff * 0.4f) return 8;  if (best_over >= diff * 0.3f) return 3;
+            return 0;
+        }
+        const float best_diff = fabsf(fabsf(best) - fabsf((float)second_score));
+        if (best_diff >= diff * 0.9f) return (best_over == diff) ? 39 : 33;
+        if (best_diff >= diff * 0.8f) return (best_over == diff) ? 38 : 27;
+        if (best_diff >= diff * 0.7f) return (best_over == diff) ? 37 : 26;
+        if (best_diff >= diff * 0.6f) return (best_over == diff) ? 36 : 22;
+        if (best_diff >= diff * 0.5f) { if (best_over == diff) return 35; if (best_over >= diff * 0.84f) return 25; if (best_over >= diff * 0.68f) return 16; return 5; }
+        if (best_diff >= diff * 0.4f) { if (best_over == diff) return 34; if (best_over >= diff * 0.84f) return 21; if (best_over >= diff * 0.68f) return 14; return 4; }
+        if (best_diff >= diff * 0.3f) { if (best_over == diff) return 32; if (best_over >= diff * 0.88f) return 18; if (best_over >= diff * 0.67f) return 15; return 3; }
+        if (best_diff >= diff * 0.2f) { if (best_over == diff) return 31; if (best_over >= diff * 0.88f) return 17; if (best_over >= diff * 0.67f) return 11; return 0; }
+        if (best_diff >= diff * 0.1f) { if (best_over == diff) return 30; if (best_over >= diff * 0.88f) return 12; if (best_over >= diff * 0.67f) return 7;  return 0; }
+        if (best_diff > 0) return (best_over >= diff * 0.67f) ? 6 : 2;
+        return (best_over >= diff * 0.67f) ? 1 : 0;
+    }
+    if (!has_second) {
+        if (best_over >= diff * 0.8f) return 44; if (best_over >= diff * 0.7f) return 42; if (best_over >= diff * 0.6f) return 41;
+        if (best_over >= diff * 0.5f) return 36; if (best_over >= diff * 0.4f) return 28; if (best_over >= diff * 0.3f) return 24;
+        return 22;
+    }
+    const float best_diff = fabsf(fabsf(best) - fabsf((float)second_score));
+    if (best_diff >= diff * 0.9f) return 40; if (best_diff >= diff * 0.8f) return 39; if (best_diff >= diff * 0.7f) return 38; if (best_diff >= diff * 0.6f) return 37;
+    if (best_diff >= diff * 0.5f) { if (best_over == diff) return 35; return (best_over >= diff * 0.50f) ? 25 : 20; }
+    if (best_diff >= diff * 0.4f) { if (best_over == diff) return 34; return (best_over >= diff * 0.50f) ? 21 : 19; }
+    if (best_diff >= diff * 0.3f) { if (best_over == diff) return 33; return (best_over >= diff * 0.5f) ? 18 : 16; }
+    if (best_diff >= diff * 0.2f) { if (best_over == diff) return 32; return (best_over >= diff * 0.5f) ? 17 : 12; }
+    if (best_diff >= diff * 0.1f) { if (best_over == diff) return 31; return (best_over >= diff * 0.5f) ? 14 : 9; }
+    if (best_diff > 0) return (best_over >= diff * 0.5f) ? 11 : 2;
+    return (best_over >= diff * 0.5f) ? 1 : 0;
+}
+/* single-end reads: out[r] = mapq(BestPairedAlignments(best of read r), read_len[r]); unaligned reads get 0.
+ * scheme: match bonus, min-score SimpleFunc (type,k,m), monotone flag (scoring.h:272-281,347) */
+ORACLE_API void oracle_mapq(int version, int32_t match, int min_type, float min_k, float min_m, int monotone,
+    uint32_t n_reads, const uint64_t* best, uint32_t best_stride, const uint32_t* read_len, uint8_t* out)
+{
+    for (uint32_t r = 0; r < n_reads; ++r)
+    {
+        const io_aln_t a1 = { (uint32_t)best[r], (uint32_t)(best[r] >> 32) }, a2 = { (uint32_t)best[r + best_stride], (uint32_t)(best[r + best_stride] >> 32) };
+        if (!io_aln_aligned(a1)) { out[r] = 0; continue; }
+        const float max_score = (float)((int32_t)read_len[r] * match), min_score = (float)simple_func(min_type, min_k, min_m, (int32_t)read_len[r]);
+        out[r] = (uint8_t)(version == 3 ? mapq_v3(io_aln_score(a1), io_aln_aligned(a2), io_aln_score(a2), max_score, min_score)
+                                        : mapq_v2(io_aln_score(a1), io_aln_aligned(a2), io_aln_score(a2), max_score, min_score, monotone));
+    }
+}
+
 ORACLE_API int oracle_num_threads(void)
 {
 #if defined(_OPENMP)

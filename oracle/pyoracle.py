@@ -16,7 +16,7 @@ _LIB = os.path.join(_HERE, "libnvbio_oracle.so")
 
 GLOBAL, LOCAL, SEMI_GLOBAL = 0, 1, 2   # nvbio/alignment/alignment_base.h:54
 
-_CFLAGS = ["-O3", "-fopenmp", "-fPIC", "-std=c99", "-fvisibility=hidden"]
+_CFLAGS = ["-O3", "-ffp-contract=off", "-fopenmp", "-fPIC", "-std=c99", "-fvisibility=hidden"]
 
 
 def build(native=False, out=None):
@@ -494,6 +494,36 @@ def map_seeds(algorithm, subseed_len, fmi, rfmi, reads, params, seed_freq_by_len
                      _p(reads.words), C.c_uint32(reads.bits), C.c_uint32(reads.big_endian), _p(reads.begin), _p(reads.length),
                      _p(q), C.c_uint32(n), C.byref(mp), _p(sf), _p(hits), C.c_uint32(hits_stride), _p(counts), _p(reseed))
     return hits, counts, reseed
+
+
+def alignment_invalid():
+    lib().oracle_alignment_invalid.restype = C.c_uint64
+    return int(lib().oracle_alignment_invalid())
+
+
+def init_alignments(read_len, score_min, mate=0):
+    rl = _u32(read_len)
+    best = np.zeros((2, rl.size), dtype=np.uint64)
+    lib().oracle_init_alignments(C.c_uint32(rl.size), _p(rl), C.c_int(score_min[0]), C.c_float(score_min[1]), C.c_float(score_min[2]), C.c_uint32(mate),
+                                 _p(best), C.c_uint32(rl.size))
+    return best
+
+
+def score_reduce(best, hit_begin, hit_score, hit_loc, hit_rc, read_len, read_ids=None):
+    """score_reduce_kernel over uint64 best[2, stride] (in place)."""
+    hb = _u64(hit_begin); n = hb.size - 1
+    rid = _u32(read_ids) if read_ids is not None else None
+    lib().oracle_score_reduce(C.c_uint32(n), _p(rid), _p(hb), _p(np.ascontiguousarray(hit_score, dtype=np.int32)), _p(_u32(hit_loc)),
+                              _p(np.ascontiguousarray(hit_rc, dtype=np.uint8)), _p(_u32(read_len)), _p(best), C.c_uint32(best.shape[1]))
+    return best
+
+
+def mapq(version, match, score_min, monotone, best, read_len):
+    n = best.shape[1]
+    out = np.zeros(n, dtype=np.uint8)
+    lib().oracle_mapq(C.c_int(version), C.c_int32(match), C.c_int(score_min[0]), C.c_float(score_min[1]), C.c_float(score_min[2]), C.c_int(int(monotone)),
+                      C.c_uint32(n), _p(best), C.c_uint32(n), _p(_u32(read_len)), _p(out))
+    return out
 
 
 def num_threads():

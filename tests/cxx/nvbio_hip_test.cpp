@@ -15,6 +15,7 @@
 #include <nvbio_hip/fmindex.h>
 #include <nvbio_hip/mapping.h>
 #include <nvbio_hip/io.h>
+#include <nvbio_hip/reduce.h>
 #include <unistd.h>
 
 using namespace nvbio;
@@ -497,6 +498,31 @@ static int fmindex_test()
             }
             fprintf(stderr, "    %-44s : %u reads, %llu seed hits ok\n", mode == 0 ? "map exact" : mode == 1 ? "map approx (subseed 12)" : "map case-pruning (fwd + rev index)", R, (unsigned long long)total);
         }
+    }
+    // io::Alignment's bit layout as the kernels write it: invalid() == nvbio_hip_alignment_invalid(), and a reduce + mapq smoke
+    {
+        const io::Alignment inv = io::Alignment::invalid(); uint64 w; memcpy(&w, &inv, 8);
+        if (w != nvbio_hip_alignment_invalid()) FAIL("io::Alignment layout: invalid() = %llx, library %llx", (unsigned long long)w, (unsigned long long)nvbio_hip_alignment_invalid());
+        const uint32 R = 4, L = 100;
+        bowtie2::cuda::ScoreLimits sc;                         // end-to-end defaults
+        hip::device_vector<int32> d_tab(sc.min_score_table(L));
+        hip::device_vector<io::Alignment> d_best(2 * R);
+        bowtie2::cuda::init_alignments(R, nullptr, L, d_tab.data(), d_best.data(), R);
+        // read 0: two distinct hits; read 1: the same location twice; read 2: below the threshold; read 3: none
+        const std::vector<uint64> hb = { 0, 2, 4, 5, 5 };
+        const std::vector<int32>  hs = { -12, -30, -6, -6, -200 };
+        const std::vector<uint32> hl = { 1000, 5000, 777, 777, 42 };
+        const std::vector<uint8>  hr = { 0, 1, 0, 0, 0 };
+        hip::device_vector<uint64> d_hb(hb); hip::device_vector<int32> d_hs(hs); hip::device_vector<uint32> d_hl(hl); hip::device_vector<uint8> d_hr(hr), d_mq(R);
+        bowtie2::cuda::score_reduce(R, nullptr, d_hb.data(), d_hs.data(), d_hl.data(), d_hr.data(), nullptr, L, d_best.data(), R);
+        bowtie2::cuda::mapq(2, sc, d_tab.data(), R, d_best.data(), R, nullptr, L, d_mq.data());
+        hip::synchronize();
+        const std::vector<io::Alignment> b = d_best.to_host(); const std::vector<uint8> mq = d_mq.to_host();
+        if (!(b[0].score() == -12 && b[0].alignment() == 1000 && b[R + 0].score() == -30 && b[R + 0].is_rc())) FAIL("score_reduce: read 0");
+        if (!(b[1].score() == -6 && !b[R + 1].is_aligned())) FAIL("score_reduce: read 1 (a revisited location must not become the second best)");
+        if (b[2].is_aligned() || b[3].is_aligned()) FAIL("score_reduce: reads 2/3 must stay unaligned");
+        if (!(mq[1] == 42 && mq[2] == 0 && mq[3] == 0 && mq[0] > 0 && mq[0] < 42)) FAIL("mapq: got %u %u %u %u", mq[0], mq[1], mq[2], mq[3]);
+        fprintf(stderr, "    %-44s : ok (mapq %u %u %u %u)\n", "init_alignments / score_reduce / mapq", mq[0], mq[1], mq[2], mq[3]);
     }
     fprintf(stderr, "FM-index test... done\n");
     return 0;
