@@ -71,7 +71,7 @@ def make_pairs(rng, n, max_m, max_n):
 
 
 @pytest.mark.parametrize("ty", [nvb.GLOBAL, nvb.LOCAL, nvb.SEMI_GLOBAL])
-@pytest.mark.parametrize("max_m", [64, 128, 192, 256])
+@pytest.mark.parametrize("max_m", [64, 128, 192, 256, 400, 512])
 def test_random_pairs(cuda, ty, max_m):
     rng = np.random.default_rng(ty * 10 + max_m)
     pats, txts = make_pairs(rng, 1500, max_m, 400)
