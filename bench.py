@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--genome", type=float, default=3.0e9, help="synthetic genome length of the FM-index legs (a true index is built on the device)")
     ap.add_argument("--rank-queries", type=int, default=1 << 28)
     ap.add_argument("--no-rank", action="store_true")
-    ap.add_argument("--only", choices=["dp", "rank", "seed", "e2e", "full"], default=None, help="profiling aid: run just one leg, print its object")
+    ap.add_argument("--only", choices=["dp", "rank", "seed", "e2e", "full", "extras"], default=None, help="profiling aid: run just one leg, print its object")
     ap.add_argument("--seeds", type=int, default=50_000_000)
     ap.add_argument("--no-seed", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
@@ -104,6 +104,9 @@ def main():
                 dist.barrier()
         torch.cuda.synchronize()
 
+    if a.only == "extras":
+        print(json.dumps({"extras_leg": extras_leg(a, dev)}))
+        return
     if a.only == "full":
         print(json.dumps({"full_dp_leg": full_dp_leg(a, dev)}))
         return
@@ -449,6 +452,101 @@ def full_dp_leg(a, dev):
             raise SystemExit("parity gate failed: full-matrix Gotoh differs from the oracle")
         res[name] = {"kernel_ms": ms, "GCUPS": n * L * N / (ms * 1e-3) / 1e9, "Mreads_per_s": n / (ms * 1e-3) / 1e6, "parity_checked": m, "bit_exact": ok}
     return res
+
+
+def _timed(fn, reps=3):
+    fn(); torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for e0, e1 in evs:
+        e0.record(); fn(); e1.record()
+    torch.cuda.synchronize()
+    return sum(e0.elapsed_time(e1) for e0, e1 in evs) / reps
+
+
+def extras_leg(a, dev):
+    """Throughput of the kernels built around the hot path: banded traceback -> CIGAR, the
+    one-mismatch seed mappers, edit-distance full-matrix scoring (sw-benchmark's second leg), score reduction
+    + MAPQ, and the composed single-end aligner.  Each with a sample checked exactly against the oracle.
+    Opt-in (`--only extras`): not part of the default line."""
+    import numpy as np
+    from oracle import pyoracle as O
+    from nvbio_amd import pipeline as P
+    out = {}
+    # ---- banded traceback, 100 bp x band 15 LOCAL (the read shape of config 2)
+    n = 2_000_000
+    p, t = W.make_sw_batch(n, READ_LEN, REF_LEN, seed=0x5EED0005, device=dev)
+    al = nvb.make_gotoh_aligner(nvb.LOCAL, nvb.SimpleGotohScheme(*SCHEME))
+    tb = nvb.BatchedBandedAlignmentTraceback(BAND)
+    o = dict(score=torch.empty(n, dtype=torch.int32, device=dev), sink=torch.empty((n, 2), dtype=torch.int32, device=dev),
+             source=torch.empty((n, 2), dtype=torch.int32, device=dev), cigar=torch.zeros((n, 32), dtype=torch.int16, device=dev),
+             cigar_len=torch.empty(n, dtype=torch.int32, device=dev))
+    temp = torch.empty(tb.min_temp_storage(READ_LEN, 0, n), dtype=torch.uint8, device=dev)
+    ms = _timed(lambda: tb.enact(al, p, t, o["score"], o["sink"], o["source"], o["cigar"], o["cigar_len"], temp=temp))
+    m = 20_000
+    sub = lambda s_: O.StringSet(s_.words, s_.bits, s_.big_endian, s_.begin[:m], s_.length[:m])
+    e = O.batch_banded_gotoh_traceback(BAND, O.LOCAL, SCHEME, sub(O.StringSet.from_device(p)), sub(O.StringSet.from_device(t)), 32)
+    ok = all(bool((o[k][:m].cpu().numpy().view(e[k].dtype) == e[k]).all()) for k in ("score", "sink", "source", "cigar_len", "cigar"))
+    out["banded_traceback"] = {"alignments": n, "kernel_ms": ms, "Malignments_per_s": n / ms / 1e3, "flag_bytes_per_alignment": READ_LEN * 8,
+                               "flag_GBs_write_plus_read": 2 * n * READ_LEN * 8 / (ms * 1e-3) / 1e9, "parity_checked": m, "bit_exact": ok}
+    del p, t, o, temp
+    # ---- edit distance, full matrix, SEMI_GLOBAL (sw-benchmark.cu:641-657)
+    nr, ref_len = 65536, 16384
+    g = torch.Generator(device=dev); g.manual_seed(0x5EED0006)
+    ref = torch.randint(0, 4, (ref_len,), dtype=torch.uint8, generator=g, device=dev)
+    st = torch.randint(0, ref_len - 150, (nr,), generator=g, device=dev)
+    reads = ref[st.unsqueeze(1) + torch.arange(150, device=dev).unsqueeze(0)]
+    mut = torch.rand((nr, 150), generator=g, device=dev) < 0.04
+    reads = torch.where(mut, (reads + 1) & 3, reads)
+    rp = nvb.PackedStringSet(W._pack_chunked(reads.reshape(-1), 4, True), 4, True, torch.arange(nr, dtype=torch.int64, device=dev) * 150, None, 150)
+    rt = nvb.PackedStringSet(W._pack_chunked(ref, 2, False), 2, False, torch.zeros(nr, dtype=torch.int64, device=dev), None, ref_len)
+    ed = nvb.make_edit_distance_aligner(nvb.SEMI_GLOBAL)
+    ms = _timed(lambda: nvb.batch_alignment_score(ed, rp, rt, 150, ref_len))
+    gs, gk, _ = nvb.batch_alignment_score(ed, rp, rt, 150, ref_len)
+    m = 256
+    hp, ht = O.StringSet.from_device(rp), O.StringSet.from_device(rt)
+    es, ek = O.batch_sw_score(0, O.SEMI_GLOBAL, (0, -1, -1, -1), O.StringSet(hp.words, 4, True, hp.begin[:m], hp.length[:m]), O.StringSet(ht.words, 2, False, ht.begin[:m], ht.length[:m]))
+    ok = bool((gs[:m].cpu().numpy() == es).all() and (gk[:m].cpu().numpy().view(np.uint32) == ek).all())
+    out["edit_distance_full"] = {"reads": nr, "read_len": 150, "ref_len": ref_len, "kernel_ms": ms, "GCUPS": nr * 150 * ref_len / ms / 1e6, "parity_checked": m, "bit_exact": ok}
+    del rp, rt, reads
+    # ---- one-mismatch seed mappers + composed aligner on a forward + reverse index
+    ng = int(min(a.genome, 1_000_000_000))
+    g.manual_seed(0x5EED0003)
+    text = torch.randint(0, 4, (ng,), dtype=torch.uint8, generator=g, device=dev)
+    fmi = W.build_fm_index(text)
+    rfmi = W.build_fm_index(text.flip(0).contiguous())
+    nreads = 2_000_000
+    sym, pos, _ = P.make_reads(text, nreads, READ_LEN, seed=0x5EED0004)
+    reads_rev, ext_words = P.pack_read_streams(sym)
+    mp = nvb.MappingParams()
+    res = {}
+    for name, kw in (("exact", dict(allow_sub=0)), ("approx_subseed12", dict(allow_sub=1, subseed_len=12)), ("case_pruning", dict(allow_sub=1, subseed_len=0))):
+        ms = _timed(lambda: nvb.map_seeds(fmi, rfmi, reads_rev, mp, READ_LEN, hits_stride=64, **kw))
+        h, c, _ = nvb.map_seeds(fmi, rfmi, reads_rev, mp, READ_LEN, hits_stride=64, **kw)
+        res[name] = {"kernel_ms": ms, "Mreads_per_s": nreads / ms / 1e3, "seed_hits_per_read": float(c.float().mean().item())}
+    m = 2000
+    hostf = O.FMIndex(parts=(fmi.length, fmi.primary, np.array(fmi.L2, dtype=np.uint32), fmi.bwt_occ.cpu().numpy().view(np.uint32), fmi.ssa.cpu().numpy().view(np.uint32), fmi.sa_int))
+    hostr = O.FMIndex(parts=(rfmi.length, rfmi.primary, np.array(rfmi.L2, dtype=np.uint32), rfmi.bwt_occ.cpu().numpy().view(np.uint32), rfmi.ssa.cpu().numpy().view(np.uint32), rfmi.sa_int))
+    hr = O.StringSet.from_device(reads_rev)
+    hr = O.StringSet(hr.words, 4, True, hr.begin[:m], hr.length[:m])
+    sf = O.simple_func_table(2, 1.0, 1.15, READ_LEN + 1)
+    pd = dict(seed_len=mp.seed_len, min_read_len=mp.min_read_len, max_hits=mp.max_hits, max_reseed=mp.max_reseed, retry=0, rep_seeds=mp.rep_seeds, fw=1, rc=1)
+    eh, ec, _ = O.map_seeds(2, 0, hostf, hostr, hr, pd, sf, 64)
+    gh, gc = h[:m].cpu().numpy().view(np.uint64), c[:m].cpu().numpy().view(np.uint32)
+    ok = bool((gc == ec).all()) and all((np.sort(gh[r, :gc[r]]) == np.sort(eh[r, :ec[r]])).all() for r in range(m))
+    res["parity"] = {"checked_reads": m, "algorithm": "case_pruning", "hit_sets_equal": ok}
+    res["genome_symbols"] = ng; res["reads"] = nreads
+    out["seed_mappers"] = res
+    genome_words = W._pack_chunked(text, 2, True)
+    be = P.HipBackend(fmi, None, mp, READ_LEN)
+    ms = _timed(lambda: P.align_single_end(be, sym, genome_words, ng, packed=(reads_rev, ext_words)), reps=2)
+    r = P.align_single_end(be, sym, genome_words, ng, packed=(reads_rev, ext_words))
+    aligned = ((r["best"][0] >> 32) & 0xFFFFFFFF) != 0xFFFFFFFF
+    at_true = (((r["best"][0] >> 32) & 0xFFFFFFFF) == torch.clamp(pos - BAND // 2, min=0)) & aligned
+    out["align_single_end"] = {"reads": nreads, "ms_per_batch": ms, "Mreads_per_s": nreads / ms / 1e3, "extension_jobs": r["n_jobs"],
+                               "aligned": float(aligned.float().mean().item()), "best_at_true_position": float(at_true.float().mean().item()),
+                               "mapq_ge_23": float((r["mapq"] >= 23).float().mean().item()),
+                               "stages": "map_exact, locate, banded extend, score_reduce, BowtieMapq2, banded traceback (glue in torch)"}
+    return out
 
 
 def cpu_leg(a, patterns, texts):
