@@ -508,6 +508,49 @@ def extras_leg(a, dev):
     ok = bool((gs[:m].cpu().numpy() == es).all() and (gk[:m].cpu().numpy().view(np.uint32) == ek).all())
     out["edit_distance_full"] = {"reads": nr, "read_len": 150, "ref_len": ref_len, "kernel_ms": ms, "GCUPS": nr * 150 * ref_len / ms / 1e6, "parity_checked": m, "bit_exact": ok}
     del rp, rt, reads
+    # ---- the two extension kernels at the paired-end shape of BASELINE config 5: 2 x 150 bp, LOCAL, band 31
+    # anchor mate: banded LOCAL band 31 with nvBowtie's quality-aware local scheme; opposite mate: full-matrix LOCAL
+    # of the 150-bp mate against a 650-bp insert window with a min_score (score_opposite_inl.h:266)
+    n = 4_000_000
+    p, t = W.make_sw_batch(n, 150, 150 + 31, seed=0x5EED0007, device=dev)
+    q = torch.randint(2, 41, (n * 150 + 8,), dtype=torch.uint8, generator=g, device=dev)
+    loc = nvb.SmithWatermanScoringScheme.local()
+    al31 = nvb.make_gotoh_aligner(nvb.LOCAL, loc)
+    sc31 = torch.empty(n, dtype=torch.int32, device=dev); sk31 = torch.empty((n, 2), dtype=torch.int32, device=dev)
+    b31 = nvb.BatchedBandedAlignmentScore(31)
+    ms = _timed(lambda: b31.enact(al31, p, t, sc31, sk31, quals=q))
+    m = 20_000
+    st = loc.struct()
+    lut = np.array([st.mismatch[k] for k in range(256)], dtype=np.int32)
+    s6 = (st.match, st.pattern_gap_open, st.pattern_gap_ext, st.text_gap_open, st.text_gap_ext, 0)
+    hp, ht = O.StringSet.from_device(p), O.StringSet.from_device(t)
+    es, ek = O.batch_banded_gotoh_score_qual(31, O.LOCAL, s6, lut, q.cpu().numpy(), O.StringSet(hp.words, 4, True, hp.begin[:m], hp.length[:m]),
+                                             O.StringSet(ht.words, 2, False, ht.begin[:m], ht.length[:m]))
+    ok = bool((sc31[:m].cpu().numpy() == es).all() and (sk31[:m].cpu().numpy().view(np.uint32) == ek).all())
+    pe = {"anchor_banded_local_31": {"alignments": n, "read_len": 150, "kernel_ms": ms, "Malignments_per_s": n / ms / 1e3, "GCUPS": n * 150 * 31 / ms / 1e6,
+                                     "kernel": nvb.lib().nvbio_hip_last_kernel().decode(), "parity_checked": m, "bit_exact": ok}}
+    del p, t, q
+    nw, wl = 1_000_000, 650
+    g.manual_seed(0x5EED0008)
+    win = torch.randint(0, 4, (nw, wl), dtype=torch.uint8, generator=g, device=dev)
+    off = torch.randint(0, wl - 150, (nw,), generator=g, device=dev)
+    mate = win.gather(1, off.unsqueeze(1) + torch.arange(150, device=dev).unsqueeze(0))
+    mate = torch.where(torch.rand((nw, 150), generator=g, device=dev) < 0.04, (mate + 1) & 3, mate)
+    mp_ = nvb.PackedStringSet(W._pack_chunked(mate.reshape(-1), 4, True), 4, True, torch.arange(nw, dtype=torch.int64, device=dev) * 150, None, 150)
+    wt = nvb.PackedStringSet(W._pack_chunked(win.reshape(-1), 2, True), 2, True, torch.arange(nw, dtype=torch.int64, device=dev) * wl, None, wl)
+    alo = nvb.make_gotoh_aligner(nvb.LOCAL, nvb.SimpleGotohScheme(2, -6, -8, -3))
+    msc = torch.full((nw,), 100, dtype=torch.int32, device=dev)
+    ms = _timed(lambda: nvb.batch_alignment_score(alo, mp_, wt, 150, wl, msc))
+    gs, gk, go = nvb.batch_alignment_score(alo, mp_, wt, 150, wl, msc)
+    m = 2000
+    hp, ht = O.StringSet.from_device(mp_), O.StringSet.from_device(wt)
+    es, ek, eo = O.batch_gotoh_score(O.LOCAL, (2, -6, -8, -3), O.StringSet(hp.words, 4, True, hp.begin[:m], hp.length[:m]),
+                                     O.StringSet(ht.words, 2, True, ht.begin[:m], ht.length[:m]), min_score=np.full(m, 100, np.int32))
+    ok = bool((gs[:m].cpu().numpy() == es).all() and (gk[:m].cpu().numpy().view(np.uint32) == ek).all() and (go[:m].cpu().numpy() == eo).all())
+    pe["opposite_mate_full_local"] = {"pairs": nw, "mate_len": 150, "window": wl, "kernel_ms": ms, "Mpairs_per_s": nw / ms / 1e3, "GCUPS": nw * 150 * wl / ms / 1e6,
+                                      "parity_checked": m, "bit_exact": ok}
+    out["paired_end_shapes"] = pe
+    del win, mate, mp_, wt
     # ---- one-mismatch seed mappers + composed aligner on a forward + reverse index
     ng = int(min(a.genome, 1_000_000_000))
     g.manual_seed(0x5EED0003)

@@ -134,6 +134,25 @@ struct DPConsts {
     typename A::T Go, Ge, sM, sX, inf;       // sM/sX = match/mismatch - G_o ; inf = the infimum sentinel
 };
 
+template <int BAND, int TYPE, typename A, int R, int J, int END>
+struct CellLoop {
+    __device__ __forceinline__ static void run(DPState<BAND, A>& st, const DPConsts<A>& k, const typename A::T sX,
+                                               typename A::T& E, typename A::T& rowkey, const uint32_t q)
+    {
+        typedef BandTraits<BAND> BT;
+        typedef typename A::T T;
+        const uint32_t g = st.tc[BT::RING ? ((R + J) & 15) : J];
+        if (!BT::RING) st.tc[J - 1] = g;                                   // :542
+        const T fnext = (J + 1 == BAND - 1) ? k.inf : st.F[J + 1 < BAND - 1 ? J + 1 : 0];
+        A::template cell<TYPE, J>(st.F[J], fnext, st.HG[J + 1], st.HG[J], E, rowkey, g, q, k.Go, k.Ge, k.sM, sX);
+        CellLoop<BAND, TYPE, A, R, J + 1, END>::run(st, k, sX, E, rowkey, q);
+    }
+};
+template <int BAND, int TYPE, typename A, int R, int END>
+struct CellLoop<BAND, TYPE, A, R, END, END> {
+    __device__ __forceinline__ static void run(DPState<BAND, A>&, const DPConsts<A>&, const typename A::T, typename A::T&, typename A::T&, const uint32_t) {}
+};
+
 template <int BAND, int TYPE, typename A, int R>
 __device__ __forceinline__ void dp_row(DPState<BAND, A>& st, const DPConsts<A>& k, const typename A::T sX,
                                        const uint32_t i, const uint32_t q, const uint32_t g_new)
@@ -155,6 +174,15 @@ __device__ __forceinline__ void dp_row(DPState<BAND, A>& st, const DPConsts<A>& 
         E = st.HG[0];
     }
     // 1 <= j <= BAND-2  (:520-577)
+    if constexpr (BAND > 16)
+    {
+        // wide bands: compile-time recursion over the cells.  (A `#pragma unroll` loop whose body is a 29-way switch of
+        // asm blocks is not unrolled by the compiler at this size; the band state would then be indexed dynamically and
+        // live in scratch memory.)
+        CellLoop<BAND, TYPE, A, R, 1, BAND - 1>::run(st, k, sX, E, rowkey, q);
+    }
+    else
+    {
     #pragma unroll
     for (int j = 1; j < BAND - 1; ++j)
     {
@@ -165,11 +193,11 @@ __device__ __forceinline__ void dp_row(DPState<BAND, A>& st, const DPConsts<A>& 
         switch (j) {   // the sink key's column is an instruction constant
             #define NVB_CELL(J) case J: A::template cell<TYPE, J>(st.F[j], fnext, st.HG[j + 1], st.HG[j], E, rowkey, g, q, k.Go, k.Ge, k.sM, sX); break;
             NVB_CELL(1) NVB_CELL(2) NVB_CELL(3) NVB_CELL(4) NVB_CELL(5) NVB_CELL(6) NVB_CELL(7) NVB_CELL(8) NVB_CELL(9) NVB_CELL(10)
-            NVB_CELL(11) NVB_CELL(12) NVB_CELL(13) NVB_CELL(14) NVB_CELL(15) NVB_CELL(16) NVB_CELL(17) NVB_CELL(18) NVB_CELL(19) NVB_CELL(20)
-            NVB_CELL(21) NVB_CELL(22) NVB_CELL(23) NVB_CELL(24) NVB_CELL(25) NVB_CELL(26) NVB_CELL(27) NVB_CELL(28) NVB_CELL(29)
+            NVB_CELL(11) NVB_CELL(12) NVB_CELL(13) NVB_CELL(14)
             #undef NVB_CELL
             default: break;
         }
+    }
     }
     // the new text symbol enters the band (:580-581); the cached copy is what later rows see
     {
