@@ -122,6 +122,22 @@ int nvbio_hip_sw_score(
     uint32_t max_pattern_len, uint32_t max_text_len,
     uint32_t n, int32_t* out_score, uint32_t* out_sink, void* stream);
 
+/* The general full-matrix score: aligner kind x algorithm tag (alignment_base.h:72-79), i.e.
+ *   BatchedAlignmentScore<stream,...>::enact for GotohAligner / SmithWatermanAligner / EditDistanceAligner with
+ *   PatternBlockingTag (the default of make_*_aligner<TYPE>(...); gotoh_inl.h:459-900, sw_inl.h:417-760) or TextBlockingTag.
+ * scheme4 = {match, mismatch, gap_open, gap_ext} (Gotoh) or {match, mismatch, deletion, insertion} (SW; ED = {0,-1,-1,-1}).
+ * The two tags compute the same matrix; they differ in the visiting order (which of several equal LOCAL maxima the sink
+ * keeps), and in the early exit against min_score[i]: per block of 8 (16) pattern symbols for PatternBlockingTag
+ * (max_i H[i][block end] + (M - block end) * match < min_score), per block of text columns for TextBlockingTag.
+ * PatternBlockingTag runs on the 16-bit sweep only (values within int16, else 801) and needs patterns of >= 1 symbol. */
+enum { NVBIO_HIP_GOTOH_ALIGNER = 0, NVBIO_HIP_SW_ALIGNER = 1 };
+enum { NVBIO_HIP_PATTERN_BLOCKING = 0, NVBIO_HIP_TEXT_BLOCKING = 1 };
+int nvbio_hip_alignment_score(
+    int32_t aligner, int32_t algorithm, const int32_t* scheme4 /* host */, int32_t type,
+    const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len, const int32_t* min_score /* device, nullable */,
+    uint32_t n, int32_t* out_score, uint32_t* out_sink, uint8_t* out_ok /* nullable */, void* stream);
+
 /* nvBowtie's SmithWatermanScoringScheme<QualCost,ConstantCost> as the Gotoh aligner sees it
  * (nvBowtie/bowtie2/cuda/scoring.h:283-293): substitution(r,q,qq) = (r == q) ? match : mismatch[qq],
  * with mismatch[qq] = -m_mmp(qq) tabulated by the host for every quality byte (the float->int

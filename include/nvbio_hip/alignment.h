@@ -151,6 +151,11 @@ inline int full_score(const nvbio_hip_sw_scheme& sc, int32 type, const nvbio_hip
     if (e == 0 && ok && n) return nvbio_hip_memset(ok, 1, n, stream);
     return e;
 }
+struct int4_scheme { int32 v[4]; };
+inline int4_scheme scheme4(const SimpleGotohScheme& s) { const int4_scheme r = { { s.m_match, s.m_mismatch, s.m_gap_open, s.m_gap_ext } }; return r; }
+inline int4_scheme scheme4(const SimpleSmithWatermanScheme& s) { const int4_scheme r = { { s.m_match, s.m_mismatch, s.m_deletion, s.m_insertion } }; return r; }
+inline int32 aligner_kind(const SimpleGotohScheme&) { return NVBIO_HIP_GOTOH_ALIGNER; }
+inline int32 aligner_kind(const SimpleSmithWatermanScheme&) { return NVBIO_HIP_SW_ALIGNER; }
 template <typename A, typename B> struct same_type { static const bool value = false; };
 template <typename A> struct same_type<A, A> { static const bool value = true; };
 } // namespace priv
@@ -320,12 +325,13 @@ struct BatchedAlignmentScore
                const int32* min_score = nullptr, uint8* ok = nullptr, void* hip_stream = nullptr)
     {
         (void)temp_size; (void)temp;
-        static_assert(priv::same_type<typename aligner_type::algorithm_type, TextBlockingTag>::value,
-                      "the full-matrix batch implements the TextBlockingTag aligners (make_*_aligner<TYPE,TextBlockingTag>)");
         const nvbio_hip_string_set p = stream.m_patterns.abi(), t = stream.m_texts.abi();
-        hip_check(priv::full_score(priv::abi_scheme(stream.aligner().scheme), int32(aligner_type::TYPE), p, t, stream.max_pattern_length(), stream.max_text_length(),
-                                   min_score, stream.size(), stream.m_sinks.score, stream.m_sinks.sink, ok, hip_stream),
-                  "nvbio_hip_{gotoh,sw}_score");
+        const bool text_blocking = priv::same_type<typename aligner_type::algorithm_type, TextBlockingTag>::value;
+        hip_check(nvbio_hip_alignment_score(priv::aligner_kind(stream.aligner().scheme), text_blocking ? NVBIO_HIP_TEXT_BLOCKING : NVBIO_HIP_PATTERN_BLOCKING,
+                                            priv::scheme4(stream.aligner().scheme).v, int32(aligner_type::TYPE), &p, &t,
+                                            stream.max_pattern_length(), stream.max_text_length(),
+                                            min_score, stream.size(), stream.m_sinks.score, stream.m_sinks.sink, ok, hip_stream),
+                  "nvbio_hip_alignment_score");
     }
 };
 

@@ -8,7 +8,7 @@ CPU fallback: importing the package without the built library raises.
 """
 from ._lib import lib, LIB_PATH, check  # noqa: F401
 from .strings import PackedStringSet, pack_symbols  # noqa: F401
-from .alignment import (GLOBAL, LOCAL, SEMI_GLOBAL, SimpleGotohScheme, SmithWatermanScoringScheme, GotohAligner,  # noqa: F401
+from .alignment import (GLOBAL, LOCAL, SEMI_GLOBAL, PATTERN_BLOCKING, TEXT_BLOCKING, SimpleGotohScheme, SmithWatermanScoringScheme, GotohAligner,  # noqa: F401
                         make_gotoh_aligner, BatchedBandedAlignmentScore, batch_banded_alignment_score,
                         BatchedAlignmentScore, batch_alignment_score,
                         BatchedBandedAlignmentTraceback, batch_banded_alignment_traceback,

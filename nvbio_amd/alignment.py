@@ -77,14 +77,19 @@ class SmithWatermanScoringScheme:
         return s
 
 
+PATTERN_BLOCKING, TEXT_BLOCKING = 0, 1      # algorithm tags (alignment_base.h:72-79); only the full-matrix batch looks at them
+
+
 class GotohAligner:
-    def __init__(self, aln_type, scheme):
-        assert aln_type in (GLOBAL, LOCAL, SEMI_GLOBAL)
-        self.type, self.scheme = aln_type, scheme
+    def __init__(self, aln_type, scheme, algorithm=TEXT_BLOCKING):
+        assert aln_type in (GLOBAL, LOCAL, SEMI_GLOBAL) and algorithm in (PATTERN_BLOCKING, TEXT_BLOCKING)
+        self.type, self.scheme, self.algorithm = aln_type, scheme, algorithm
 
 
-def make_gotoh_aligner(aln_type, scheme):
-    return GotohAligner(aln_type, scheme)
+def make_gotoh_aligner(aln_type, scheme, algorithm=TEXT_BLOCKING):
+    """make_gotoh_aligner<TYPE, algorithm_tag>(scheme).  NOTE: this layer defaults to the text-blocking form (what
+    sw-benchmark instantiates); the reference's C++ default tag is PatternBlockingTag -- pass PATTERN_BLOCKING for it."""
+    return GotohAligner(aln_type, scheme, algorithm)
 
 
 class SimpleSmithWatermanScheme:
@@ -100,24 +105,24 @@ class SimpleSmithWatermanScheme:
 class SmithWatermanAligner:
     """SmithWatermanAligner<TYPE, scheme> (alignment_base.h): linear-gap DP."""
 
-    def __init__(self, aln_type, scheme):
-        assert aln_type in (GLOBAL, LOCAL, SEMI_GLOBAL)
-        self.type, self.scheme = aln_type, scheme
+    def __init__(self, aln_type, scheme, algorithm=TEXT_BLOCKING):
+        assert aln_type in (GLOBAL, LOCAL, SEMI_GLOBAL) and algorithm in (PATTERN_BLOCKING, TEXT_BLOCKING)
+        self.type, self.scheme, self.algorithm = aln_type, scheme, algorithm
 
 
 class EditDistanceAligner(SmithWatermanAligner):
     """EditDistanceAligner<TYPE>: the SW code with EditDistanceSWScheme (ed_utils.h:44-51)."""
 
-    def __init__(self, aln_type):
-        super().__init__(aln_type, SimpleSmithWatermanScheme(0, -1, -1, -1))
+    def __init__(self, aln_type, algorithm=TEXT_BLOCKING):
+        super().__init__(aln_type, SimpleSmithWatermanScheme(0, -1, -1, -1), algorithm)
 
 
-def make_smith_waterman_aligner(aln_type, scheme):
-    return SmithWatermanAligner(aln_type, scheme)
+def make_smith_waterman_aligner(aln_type, scheme, algorithm=TEXT_BLOCKING):
+    return SmithWatermanAligner(aln_type, scheme, algorithm)
 
 
-def make_edit_distance_aligner(aln_type):
-    return EditDistanceAligner(aln_type)
+def make_edit_distance_aligner(aln_type, algorithm=TEXT_BLOCKING):
+    return EditDistanceAligner(aln_type, algorithm)
 
 
 class BatchedBandedAlignmentScore:
@@ -269,6 +274,15 @@ class BatchedAlignmentScore:
             max_text_length = max_text_length or texts.fixed_length
         sc = aligner.scheme.struct()
         ps, ts = patterns.struct(), texts.struct()
+        if getattr(aligner, "algorithm", TEXT_BLOCKING) == PATTERN_BLOCKING:
+            s4 = (C.c_int32 * 4)(*[getattr(sc, f) for f, _ in sc._fields_])
+            err = lib().nvbio_hip_alignment_score(
+                1 if isinstance(aligner, SmithWatermanAligner) else 0, PATTERN_BLOCKING, s4, aligner.type, C.byref(ps), C.byref(ts),
+                int(max_pattern_length), int(max_text_length), C.c_void_p(min_score.data_ptr()) if min_score is not None else None, n,
+                C.c_void_p(out_score.data_ptr()), C.c_void_p(out_sink.data_ptr()),
+                C.c_void_p(out_ok.data_ptr()) if out_ok is not None else None, current_stream_ptr())
+            check(err, "nvbio_hip_alignment_score")
+            return
         if isinstance(aligner, SmithWatermanAligner):
             # the text-blocking SW / ED form never exits early (sw_inl.h:1075-1222): min_score is not consulted
             err = lib().nvbio_hip_sw_score(

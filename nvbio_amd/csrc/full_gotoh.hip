@@ -42,6 +42,7 @@ struct FullParams {
     uint32_t*      out_sink;
     uint8_t*       out_ok;         // nullable: the reference's per-job bool
     uint32_t       blk_log2;       // log2 of the reference's block width: fixes the LOCAL tie order (3 = Gotoh, 4 = SW / ED)
+    uint32_t       pattern_blocking;   // 0: blocks of text columns (TextBlockingTag); 1: blocks of pattern rows (PatternBlockingTag)
 };
 
 __device__ __forceinline__ int32_t dpp_shr1(int32_t first_lane_value, int32_t x)
@@ -51,7 +52,7 @@ __device__ __forceinline__ int32_t dpp_shr1(int32_t first_lane_value, int32_t x)
 }
 __device__ __forceinline__ int32_t sext16(int32_t v) { return int32_t(int16_t(v)); }
 
-struct SweepResult { int32_t score; uint32_t sx, sy; uint32_t exit_col; };   // exit_col = 0xFFFFFFFF: ran to the end
+struct SweepResult { int32_t score; uint32_t sx, sy; uint32_t exit_col; uint32_t pb_exit_row; };   // exit_col / pb_exit_row = 0xFFFFFFFF: ran to the end
 
 // One sweep of the wave over text columns [0, Ncols).  CHECK: evaluate the early-exit test.
 template <int TYPE, int R, bool TRUNC>
@@ -179,7 +180,7 @@ __device__ __forceinline__ SweepResult sweep(const FullParams& p, const uint64_t
     // gather the result in every lane
     SweepResult res;
     res.exit_col = uint32_t(__shfl(int32_t(exit_col), int32_t(lane_last)));
-    res.score = -(1 << 30); res.sx = res.sy = 0xFFFFFFFFu;
+    res.score = -(1 << 30); res.sx = res.sy = 0xFFFFFFFFu; res.pb_exit_row = 0xFFFFFFFFu;
     if (TYPE == NVBIO_HIP_LOCAL)
     {
         uint64_t b = have ? best64 : 0ull; uint32_t hv = have ? 1u : 0u;
@@ -262,7 +263,7 @@ __device__ __forceinline__ void cell16(uint32_t& e, uint32_t& hlg, uint32_t& hab
 __device__ __forceinline__ uint32_t c16(int32_t v) { return uint32_t(v) & 0xFFFFu; }
 __device__ __forceinline__ uint32_t max16u(uint32_t a, uint32_t b) { uint32_t r; asm("v_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
-template <int TYPE, int R, bool CHECK>
+template <int TYPE, int R, bool CHECK, bool PBX = false>      // PBX: keep every row's maximum over the text (pattern-blocking early exit, non-LOCAL types)
 struct Sweep16
 {
     const FullParams& p;
@@ -270,18 +271,19 @@ struct Sweep16
     int32_t  Go, Ge, min_score;
     uint32_t go, ge, sM, sX, inf16, init_above_g;
     uint64_t tb;
-    uint32_t q[R], HLG[R], E[R], bestk[R];
+    uint32_t q[R], HLG[R], E[R], bestk[R], rmax[PBX ? R : 1];
     uint32_t out_hg, out_f, out_ch, out_cm, prev_in_hg;
     int32_t  sg_score; uint32_t sg_col, exit_col, grp;
     uint32_t sg_hg16;                     // SEMI_GLOBAL: best HG of this lane's last row so far (16-bit), its column in sg_col
     uint32_t top_hg, top_prev_hg;         // GLOBAL: HG(-1,s), HG(-1,s-1)
     uint32_t kl;                          // this lane's last valid row (for the last-row reports)
+    bool     pb_check;                    // pattern blocking with a min_score: evaluate its early exit after the sweep
 
     __device__ __forceinline__ Sweep16(const FullParams& _p) : p(_p) {}
 
     __device__ __forceinline__ void init(const uint64_t pb, const uint64_t _tb, uint32_t _M, uint32_t _Ncols, uint32_t _Nfull, int32_t _min_score)
     {
-        lane = threadIdx.x & 63u; M = _M; Ncols = _Ncols; Nfull = _Nfull; min_score = _min_score; tb = _tb;
+        lane = threadIdx.x & 63u; M = _M; Ncols = _Ncols; Nfull = _Nfull; min_score = _min_score; tb = _tb; pb_check = false;
         Go = p.gap_open; Ge = p.gap_ext;
         const int32_t infimum = -32768 - min(Go, Ge);
         lane_last = (M - 1u) / uint32_t(R);
@@ -296,6 +298,7 @@ struct Sweep16
             HLG[k] = c16(((TYPE != NVBIO_HIP_LOCAL) ? Go + Ge * int32_t(r) : 0) + Go);
             E[k]   = c16((TYPE == NVBIO_HIP_LOCAL) ? 0 : infimum);
             bestk[k] = 0u;
+            if (PBX) rmax[k] = 0x8000u;
         }
         out_hg = out_f = out_ch = out_cm = prev_in_hg = 0;
         sg_score = -(1 << 30); sg_col = 0; exit_col = 0xFFFFFFFFu; grp = 0; sg_hg16 = 0x8000u;
@@ -347,6 +350,7 @@ struct Sweep16
             {
                 cell16<TYPE>(E[k], HLG[k], hab_g, fab, diag_g, in_ch, q[k], go, ge, sM, sX, h);
                 if (TYPE == NVBIO_HIP_LOCAL) bestk[k] = max(bestk[k], (h << 20) | c);
+                if (PBX) rmax[k] = max16u(rmax[k], h);
                 if (CHECK) { if (uint32_t(k) <= kl) cm = max16u(cm, h); }
                 if (TYPE != NVBIO_HIP_LOCAL) hg_last = (uint32_t(k) == kl) ? hab_g : hg_last;   // HG of this lane's last valid row
             }
@@ -398,18 +402,42 @@ struct Sweep16
         SweepResult res;
         res.exit_col = uint32_t(__shfl(int32_t(exit_col), int32_t(lane_last)));
         res.score = -(1 << 30); res.sx = res.sy = 0xFFFFFFFFu;
+        res.pb_exit_row = 0xFFFFFFFFu;
         const uint32_t BS = p.blk_log2, BLK = 1u << BS, KM = BLK * 64u * uint32_t(R);
+        const bool PB = p.pattern_blocking != 0u;
+        const uint32_t nvalid = lane > lane_last ? 0u : (lane == lane_last ? klast + 1u : uint32_t(R));
+        if (pb_check)
+        {
+            // pattern blocking: after every non-final block of BLK pattern rows the reference tests
+            // max_i H[i][block end] + (M - block end) * match < min_score (gotoh_inl.h:826-830, sw_inl.h:697-701)
+            uint32_t first = 0xFFFFFFFFu;
+            #pragma unroll
+            for (int k = 0; k < R; ++k)
+            {
+                const uint32_t r = lane * R + k;
+                if (uint32_t(k) < nvalid && ((r + 1u) & (BLK - 1u)) == 0u && r + 1u < M)
+                {
+                    const int32_t rm = (TYPE == NVBIO_HIP_LOCAL) ? int32_t(bestk[k] >> 20) : int32_t(int16_t(rmax[PBX ? k : 0]));
+                    if (rm + int32_t(M - (r + 1u)) * p.match < min_score) first = min(first, r);
+                }
+            }
+            #pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) first = min(first, uint32_t(__shfl_xor(int32_t(first), off)));
+            res.pb_exit_row = first;
+        }
         if (TYPE == NVBIO_HIP_LOCAL)
         {
             // merge this lane's rows, then the lanes, with the reference's order key
             uint64_t b = 0; uint32_t hv = 0;
-            const uint32_t nvalid = lane > lane_last ? 0u : (lane == lane_last ? klast + 1u : uint32_t(R));
             #pragma unroll
             for (int k = 0; k < R; ++k)
             {
                 if (uint32_t(k) < nvalid && Ncols > 0u) {
                     const uint32_t hh = bestk[k] >> 20, cc = bestk[k] & 0xFFFFFu, r = lane * R + k;
-                    const uint64_t cand = (uint64_t(hh) << 32) | ((cc >> BS) * KM + r * BLK + (cc & (BLK - 1u)));
+                    // text blocking: block of columns -> row -> column in block; pattern blocking: block of rows -> column -> row in block
+                    const uint32_t key = PB ? (((r >> BS) << (20u + BS)) | (cc << BS) | (r & (BLK - 1u)))
+                                            : ((cc >> BS) * KM + r * BLK + (cc & (BLK - 1u)));
+                    const uint64_t cand = (uint64_t(hh) << 32) | key;
                     if (!hv || cand > b) { b = cand; hv = 1u; }
                 }
             }
@@ -424,7 +452,8 @@ struct Sweep16
             }
             if (hv) {
                 const uint32_t key = uint32_t(b);
-                const uint32_t col = (key / KM) * BLK + (key & (BLK - 1u)), row = (key % KM) >> BS;
+                const uint32_t col = PB ? ((key >> BS) & 0xFFFFFu) : ((key / KM) * BLK + (key & (BLK - 1u)));
+                const uint32_t row = PB ? ((key >> (20u + BS)) * BLK + (key & (BLK - 1u))) : ((key % KM) >> BS);
                 res.score = int32_t(uint32_t(b >> 32)); res.sx = col + 1u; res.sy = row + 1u;
             }
         }
@@ -446,6 +475,16 @@ __device__ __forceinline__ SweepResult sweep16(const FullParams& p, const uint64
 {
     Sweep16<TYPE, R, CHECK> sw(p);
     sw.init(pb, tb, M, Ncols, Nfull, min_score);
+    return sw.run();
+}
+// pattern blocking with a min_score: one sweep that also yields the reference's exit row (0xFFFFFFFF = none)
+template <int TYPE, int R>
+__device__ __forceinline__ SweepResult sweep16_pb(const FullParams& p, const uint64_t pb, const uint64_t tb,
+                                                  const uint32_t M, const uint32_t N, const int32_t min_score)
+{
+    Sweep16<TYPE, R, false, (TYPE != NVBIO_HIP_LOCAL)> sw(p);
+    sw.init(pb, tb, M, N, N, min_score);
+    sw.pb_check = true;
     return sw.run();
 }
 
@@ -475,6 +514,29 @@ full_gotoh_score_kernel(const FullParams p)
             if (TYPE == NVBIO_HIP_GLOBAL)      { score = p.gap_open + p.gap_ext * int32_t(N - 1u); sx = N; sy = 0u; }
         }
     }
+    else if (FAST && p.pattern_blocking != 0u && check)
+    {
+        // PatternBlockingTag with a min_score: the exit test runs per block of pattern rows (gotoh_inl.h:826-830)
+        const uint32_t BLK = 1u << p.blk_log2;
+        const uint32_t n_blocks = (M + BLK - 1u) / BLK;
+        if (N == 0u)
+        {
+            // no text row was visited: max_score is still its minimum, so the first non-final block exits
+            if (n_blocks > 1u) ok = 0u;
+            else if (TYPE == NVBIO_HIP_GLOBAL) { score = p.gap_open + p.gap_ext * int32_t(M - 1u); sx = 0u; sy = M; }
+        }
+        else
+        {
+            SweepResult r = sweep16_pb<TYPE, R>(p, pb, tb, M, N, min_score);
+            if (r.pb_exit_row != 0xFFFFFFFFu)
+            {
+                ok = 0u;
+                // the sink saw pattern rows [0, exit row] only: LOCAL reports of those blocks, nothing for the other types
+                if (TYPE == NVBIO_HIP_LOCAL) { r = sweep16<TYPE, R, false>(p, pb, tb, r.pb_exit_row + 1u, N, N, min_score); score = r.score; sx = r.sx; sy = r.sy; }
+            }
+            else { score = r.score; sx = r.sx; sy = r.sy; }
+        }
+    }
     else
     {
         SweepResult r = FAST ? (check ? sweep16<TYPE, R, true>(p, pb, tb, M, N, N, min_score)
@@ -488,6 +550,8 @@ full_gotoh_score_kernel(const FullParams p)
                      : sweep<TYPE, R, TRUNC>(p, pb, tb, M, r.exit_col + 1u, N, false, min_score);
         }
         score = r.score; sx = r.sx; sy = r.sy;
+        // pattern blocking, GLOBAL, empty text: save_Mth reports the initial row (gotoh_inl.h:896-897)
+        if (FAST && p.pattern_blocking != 0u && TYPE == NVBIO_HIP_GLOBAL && N == 0u) { score = p.gap_open + p.gap_ext * int32_t(M - 1u); sx = 0u; sy = M; }
     }
     if (lane == 0u)
     {
@@ -515,7 +579,7 @@ static hipError_t launch_full(const FullParams& p, int type, hipStream_t s)
 using namespace nvb;
 
 static int full_score_core(
-    const nvbio_hip_gotoh_scheme* scheme, int32_t type, uint32_t blk_log2,
+    const nvbio_hip_gotoh_scheme* scheme, int32_t type, uint32_t blk_log2, uint32_t pattern_blocking,
     const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts,
     uint32_t max_pattern_len, uint32_t max_text_len, const int32_t* min_score,
     uint32_t n, int32_t* out_score, uint32_t* out_sink, uint8_t* out_ok, void* stream)
@@ -536,7 +600,7 @@ static int full_score_core(
     p.pat = make_string_set(patterns); p.txt = make_string_set(texts);
     p.match = scheme->match; p.mismatch = scheme->mismatch; p.gap_open = scheme->gap_open; p.gap_ext = scheme->gap_ext;
     p.min_score = min_score; p.n = n; p.out_score = out_score; p.out_sink = out_sink; p.out_ok = out_ok;
-    p.blk_log2 = blk_log2;
+    p.blk_log2 = blk_log2; p.pattern_blocking = pattern_blocking;
 
     // can any H / E leave int16?  LOCAL: 0 <= H <= M*match, E/F a few gap costs below.  SEMI_GLOBAL (pattern
     // global, text free): every cell is reachable from the zero row above its column, so values stay within
@@ -559,6 +623,7 @@ static int full_score_core(
                      default: return launch_full<8, false, true>(p, type, s); }
     }
     if (trunc && blk_log2 != 3u) return hipErrorNotSupported;     // the int16 boundary column of the SW form is not modelled beyond its exact range
+    if (pattern_blocking && !fast) return hipErrorNotSupported;   // pattern blocking is implemented on the 16-bit sweep only
     if (trunc) {
         switch (R) { case 1: return launch_full<1, true, false>(p, type, s); case 2: return launch_full<2, true, false>(p, type, s);
                      case 3: return launch_full<3, true, false>(p, type, s); case 4: return launch_full<4, true, false>(p, type, s);
@@ -576,7 +641,7 @@ NVB_API int nvbio_hip_gotoh_score(
     uint32_t max_pattern_len, uint32_t max_text_len, const int32_t* min_score,
     uint32_t n, int32_t* out_score, uint32_t* out_sink, uint8_t* out_ok, void* stream)
 {
-    return full_score_core(scheme, type, 3u, patterns, texts, max_pattern_len, max_text_len, min_score, n, out_score, out_sink, out_ok, stream);
+    return full_score_core(scheme, type, 3u, 0u, patterns, texts, max_pattern_len, max_text_len, min_score, n, out_score, out_sink, out_ok, stream);
 }
 
 // SmithWatermanAligner / EditDistanceAligner, full matrix, text blocking (sw_inl.h:881-1222): linear gaps with
@@ -591,7 +656,25 @@ NVB_API int nvbio_hip_sw_score(
     if (!scheme) return hipErrorInvalidValue;
     if (scheme->deletion != scheme->insertion) return hipErrorNotSupported;
     const nvbio_hip_gotoh_scheme g = { scheme->match, scheme->mismatch, scheme->deletion, scheme->deletion };
-    const int e = full_score_core(&g, type, 4u, patterns, texts, max_pattern_len, max_text_len, nullptr, n, out_score, out_sink, nullptr, stream);
+    const int e = full_score_core(&g, type, 4u, 0u, patterns, texts, max_pattern_len, max_text_len, nullptr, n, out_score, out_sink, nullptr, stream);
     if (e == hipSuccess && n) g_last_kernel = "full_gotoh_score_kernel<16-bit,sw>";
+    return e;
+}
+
+// The general full-matrix entry: aligner kind x algorithm tag.
+NVB_API int nvbio_hip_alignment_score(
+    int32_t aligner /* 0 Gotoh, 1 Smith-Waterman / edit distance */, int32_t algorithm /* 0 PatternBlockingTag, 1 TextBlockingTag */,
+    const int32_t* scheme4, int32_t type,
+    const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len, const int32_t* min_score,
+    uint32_t n, int32_t* out_score, uint32_t* out_sink, uint8_t* out_ok, void* stream)
+{
+    if (!scheme4 || aligner < 0 || aligner > 1 || algorithm < 0 || algorithm > 1) return hipErrorInvalidValue;
+    if (aligner == 1 && scheme4[2] != scheme4[3]) return hipErrorNotSupported;         // deletion != insertion
+    const nvbio_hip_gotoh_scheme g = { scheme4[0], scheme4[1], scheme4[2], aligner == 1 ? scheme4[2] : scheme4[3] };
+    if (algorithm == 1 && aligner == 1) min_score = nullptr;                            // the text-blocking SW form never exits early
+    const int e = full_score_core(&g, type, aligner == 1 ? 4u : 3u, algorithm == 0 ? 1u : 0u, patterns, texts, max_pattern_len, max_text_len,
+                                  min_score, n, out_score, out_sink, (algorithm == 1 && aligner == 1) ? nullptr : out_ok, stream);
+    if (e == hipSuccess && n && algorithm == 1 && aligner == 1 && out_ok) return hipMemsetAsync(out_ok, 1, n, to_stream(stream));
     return e;
 }

@@ -547,6 +547,124 @@ static int sw_score_text_blocking(int type, const int32_t* sw,
     return 1;
 }
 
+/* ------------------------------------------------------------------------ */
+/* Full-matrix scores, PATTERN blocking (the default algorithm tag):          */
+/*   Gotoh  gotoh_inl.h:459-900 (8 pattern symbols per block, short2 column   */
+/*          over the text), init :69-93, save_boundary/save_Mth utils_inl.h   */
+/*          :206-226,279-299                                                  */
+/*   SW/ED  sw_inl.h:417-760 (16 pattern symbols per block, int16 column)     */
+/* Same DP as the text-blocking forms; what differs is the visiting order     */
+/* (block of pattern symbols -> text position -> symbol in block: it decides   */
+/* LOCAL ties), where the int16 column cuts, and the early exit: after each    */
+/* non-final block, max_i H[i][block end] + (M - block end) * match < min_score */
+/* returns false (sink as reported so far).  M >= 1 (M == 0 reads              */
+/* uninitialised cells in the reference).                                     */
+/* linear != 0: SW recurrences with scheme {match, mismatch, deletion,        */
+/* insertion}; else Gotoh with scheme_t.                                      */
+/* ------------------------------------------------------------------------ */
+static int score_pattern_blocking(int linear, int type, const scheme_t* sc, const int32_t* sw,
+    const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, uint64_t pat_begin, uint32_t M,
+    const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, uint64_t txt_begin, uint32_t N,
+    int32_t min_score, best_sink_t* sink, int16_t* temp /* 2*N scratch */)
+{
+    const uint32_t BL = linear ? 16u : 8u;
+    int32_t H_band[17], F_band[17];
+    uint8_t q_cache[16], qq_cache[16];
+    memset(q_cache, 0, sizeof q_cache); memset(qq_cache, 0, sizeof qq_cache);
+    const int32_t zero = 0;
+    const int32_t G_o = linear ? 0 : sc->pat_gap_open, G_e = linear ? 0 : sc->pat_gap_ext;
+    const int32_t V = linear ? sw[0] : 0, X = linear ? sw[1] : 0, G = linear ? sw[2] : 0, I = linear ? sw[3] : 0;
+    const int32_t infimum = -32768 - (G_o < G_e ? G_o : G_e);
+    const int32_t match255 = linear ? V : sc->match;
+    for (uint32_t i = 0; i < N; ++i) {                       /* context.init, PatternBlockingTag branch */
+        if (linear) temp[i] = (int16_t)(type == ALN_GLOBAL ? G * (int32_t)(i + 1) : zero);          /* sw_inl.h:76-79 */
+        else { temp[2 * i] = (int16_t)(type == ALN_GLOBAL ? sc->txt_gap_open + sc->txt_gap_ext * (int32_t)i : zero);
+               temp[2 * i + 1] = (int16_t)(type == ALN_LOCAL ? zero : infimum); }                   /* gotoh_inl.h:82-88 */
+    }
+    const uint32_t nb = BL * ((M + BL - 1) / BL);
+    const uint32_t end_block = nb > BL ? nb : BL;
+    for (uint32_t block = 0; block + BL <= end_block; block += BL)
+    {
+        const int last = (block + BL == end_block);
+        const uint32_t block_end = (block + BL < M) ? block + BL : M;
+        for (uint32_t t = 0; t < BL; ++t)
+            if (!last || block + t < block_end) {
+                q_cache[t]  = (uint8_t)ps_get(pat_w, pat_bits, pat_be, pat_begin + block + t);
+                qq_cache[t] = (!linear && sc->quals) ? sc->quals[pat_begin + block + t] : 0;
+            }
+        for (uint32_t j = 0; j <= BL; ++j) {
+            if (linear) H_band[j] = (type != ALN_LOCAL) ? I * (int32_t)(block + j) : zero;
+            else { H_band[j] = (type != ALN_LOCAL) ? (block + j > 0 ? G_o + G_e * (int32_t)(block + j - 1u) : zero) : zero; F_band[j] = infimum; }
+        }
+        int32_t max_score = (-2147483647 - 1);               /* Field_traits<int32>::min() */
+        int32_t temp_i = H_band[0];
+        for (uint32_t i = 0; i < N; ++i)
+        {
+            const uint8_t r_i = (uint8_t)ps_get(txt_w, txt_bits, txt_be, txt_begin + i);
+            int32_t H_diag = temp_i, E = 0;
+            if (linear) { H_band[0] = temp_i = temp[i]; }
+            else        { H_band[0] = temp_i = temp[2 * i]; E = temp[2 * i + 1]; }
+            for (uint32_t j = 1; j <= BL; ++j)
+            {
+                int32_t hi;
+                if (linear) {
+                    const int32_t diagonal = H_diag + (r_i == q_cache[j - 1] ? V : X);
+                    const int32_t top = H_band[j] + G, left = H_band[j - 1] + I;
+                    hi = imax(imax(top, left), diagonal);
+                } else {
+                    F_band[j] = imax(F_band[j] + G_e, H_band[j] + G_o);
+                    E = imax(E + G_e, H_band[j - 1] + G_o);
+                    const int32_t diagonal = H_diag + subst(sc, r_i, q_cache[j - 1], qq_cache[j - 1]);
+                    hi = imax(imax(E, F_band[j]), diagonal);
+                }
+                if (type == ALN_LOCAL) hi = imax(hi, zero);
+                H_diag = H_band[j];
+                H_band[j] = hi;
+            }
+            if (linear) temp[i] = (int16_t)H_band[BL];
+            else { temp[2 * i] = (int16_t)H_band[BL]; temp[2 * i + 1] = (int16_t)E; }
+            max_score = imax(max_score, H_band[BL]);
+            if (type == ALN_LOCAL) {
+                for (uint32_t j = 1; j <= BL; ++j)
+                    if (!last || block + j <= M) sink_report(sink, H_band[j], i + 1, block + j);
+            } else if (last && type == ALN_SEMI_GLOBAL) {
+                if (block + BL >= M) sink_report(sink, H_band[((M - 1) & (BL - 1)) + 1], i + 1, M);     /* save_boundary -> save_Mth */
+            }
+        }
+        if (!last) {
+            const int32_t missing_cols = (int32_t)(M - block - BL);
+            if ((int64_t)max_score + (int64_t)missing_cols * match255 < (int64_t)min_score) return 0;
+        }
+    }
+    if (type == ALN_GLOBAL)
+        sink_report(sink, H_band[((M - 1) & (BL - 1)) + 1], N, M);          /* save_Mth(M, band, N-1, sink): (i+1, M) with i = N-1 */
+    return 1;
+}
+
+/* kind: 0 Gotoh {match,mismatch,gap_open,gap_ext}, 1 SW / ED {match,mismatch,deletion,insertion} */
+ORACLE_API void oracle_batch_score_pattern_blocking(
+    int kind, int type, const int32_t* scheme,
+    const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, const uint64_t* pat_begin, const uint32_t* pat_len,
+    const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, const uint64_t* txt_begin, const uint32_t* txt_len,
+    const int32_t* min_score /* nullable */, uint32_t n, int32_t* out_score, uint32_t* out_sink, uint8_t* out_ok, int n_threads)
+{
+    scheme_t sc = { scheme[0], scheme[1], scheme[2], scheme[3], scheme[2], scheme[3], NULL, NULL };
+#if defined(_OPENMP)
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+    #pragma omp parallel for schedule(dynamic, 16)
+#endif
+    for (int64_t i = 0; i < (int64_t)n; ++i)
+    {
+        best_sink_t s; sink_init(&s);
+        int16_t* temp = (int16_t*)malloc(sizeof(int16_t) * 2 * (size_t)(txt_len[i] + 1));
+        const int ok = score_pattern_blocking(kind, type, &sc, scheme, pat_w, pat_bits, pat_be, pat_begin[i], pat_len[i],
+            txt_w, txt_bits, txt_be, txt_begin[i], txt_len[i], min_score ? min_score[i] : (-2147483647 - 1) /* never exits */, &s, temp);
+        free(temp);
+        out_score[i] = s.score; out_sink[2 * i] = s.sink_x; out_sink[2 * i + 1] = s.sink_y;
+        if (out_ok) out_ok[i] = (uint8_t)ok;
+    }
+}
+
 /* banded: BatchedBandedAlignmentScore over SmithWatermanAligner / EditDistanceAligner;
  * full (band == 0): BatchedAlignmentScore over the TextBlockingTag forms */
 ORACLE_API void oracle_batch_sw_score(

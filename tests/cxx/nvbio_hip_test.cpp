@@ -35,6 +35,10 @@ void oracle_banded_gotoh_traceback(uint32_t band, int type, const int32_t* schem
     const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, uint64_t pat_begin, uint32_t pat_len,
     const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, uint64_t txt_begin, uint32_t txt_len,
     int32_t* res, uint8_t* ops, uint32_t ops_capacity, uint8_t* flags);
+void oracle_batch_score_pattern_blocking(int kind, int type, const int32_t* scheme,
+    const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, const uint64_t* pat_begin, const uint32_t* pat_len,
+    const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, const uint64_t* txt_begin, const uint32_t* txt_len,
+    const int32_t* min_score, uint32_t n, int32_t* out_score, uint32_t* out_sink, uint8_t* out_ok, int n_threads);
 void oracle_batch_sw_score(uint32_t band, int type, const int32_t* scheme,
     const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, const uint64_t* pat_begin, const uint32_t* pat_len,
     const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, const uint64_t* txt_begin, const uint32_t* txt_len,
@@ -144,6 +148,7 @@ static void run_sw_batch(const char* name, const aligner_type aligner,
     hip::device_vector<int32>  d_score(n);
     hip::device_vector<uint32> d_sink(2 * size_t(n));
     aln::BestSinkArrays sinks = { d_score.data(), d_sink.data() };
+    constexpr bool PATTERN_BLOCKING = !aln::priv::same_type<typename aligner_type::algorithm_type, aln::TextBlockingTag>::value;
     if constexpr (BAND_LEN != 0) aln::batch_banded_alignment_score<BAND_LEN ? BAND_LEN : 15>(aligner, d_patterns.view(), d_texts.view(), sinks, aln::DeviceThreadScheduler(), maxP, maxT);
     else          aln::batch_alignment_score(aligner, d_patterns.view(), d_texts.view(), sinks, aln::DeviceThreadScheduler(), maxP, maxT);
     hip::synchronize();
@@ -155,7 +160,10 @@ static void run_sw_batch(const char* name, const aligner_type aligner,
     const std::vector<uint32> pw = pack_symbols<4, true>(pc.data(), pc.size()), tw = pack_symbols<2, false>(tc.data(), tc.size());
     std::vector<int32> hs(n); std::vector<uint32> hk(2 * size_t(n));
     const int32 sc[4] = { aligner.scheme.m_match, aligner.scheme.m_mismatch, aligner.scheme.m_deletion, aligner.scheme.m_insertion };
-    oracle_batch_sw_score(BAND_LEN, int(aligner_type::TYPE), sc, pw.data(), 4, 1, pb.data(), pl.data(), tw.data(), 2, 0, tb.data(), tl.data(), n, hs.data(), hk.data(), 0);
+    if (BAND_LEN == 0 && PATTERN_BLOCKING)     // the reference's default algorithm tag
+        oracle_batch_score_pattern_blocking(1, int(aligner_type::TYPE), sc, pw.data(), 4, 1, pb.data(), pl.data(), tw.data(), 2, 0, tb.data(), tl.data(), nullptr, n, hs.data(), hk.data(), nullptr, 0);
+    else
+        oracle_batch_sw_score(BAND_LEN, int(aligner_type::TYPE), sc, pw.data(), 4, 1, pb.data(), pl.data(), tw.data(), 2, 0, tb.data(), tl.data(), n, hs.data(), hk.data(), 0);
     for (uint32 i = 0; i < n; ++i)
         if (score[i] != hs[i] || sink[2 * i] != hk[2 * i] || sink[2 * i + 1] != hk[2 * i + 1])
             FAIL("%s: job %u: device (%d, %u,%u) != host (%d, %u,%u)", name, i, score[i], sink[2 * i], sink[2 * i + 1], hs[i], hk[2 * i], hk[2 * i + 1]);
@@ -300,6 +308,8 @@ static int alignment_test()
         }
         run_sw_batch<0>("batch ed full semi-global (sw-benchmark leg)", aln::make_edit_distance_aligner<aln::SEMI_GLOBAL, aln::TextBlockingTag>(), fp, ft);
         run_sw_batch<0>("batch sw full local", aln::make_smith_waterman_aligner<aln::LOCAL, aln::TextBlockingTag>(aln::SimpleSmithWatermanScheme(2, -1, -1, -1)), fp, ft);
+        run_sw_batch<0>("batch sw full local (default tag: pattern blocking)", aln::make_smith_waterman_aligner<aln::LOCAL>(aln::SimpleSmithWatermanScheme(2, -1, -1, -1)), fp, ft);
+        run_sw_batch<0>("batch ed full global (default tag)", aln::make_edit_distance_aligner<aln::GLOBAL>(), fp, ft);
         run_full_batch<aln::LOCAL>      ("batch gotoh full local",       s2, fp, ft);
         run_full_batch<aln::SEMI_GLOBAL>("batch gotoh full semi-global", s2, fp, ft);
         run_full_batch<aln::GLOBAL>     ("batch gotoh full global",      s3, fp, ft);

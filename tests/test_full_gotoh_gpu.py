@@ -109,3 +109,34 @@ def test_packings(cuda):
     p2 = [np.minimum(p, 3) for p in pats]
     for (pb, pbe, tbe, pp) in ((4, False, True, pats), (2, True, True, p2), (2, False, False, p2)):
         run(nvb.LOCAL, (2, -1, -2, -1), pp, txts, cuda, pbits=pb, pbe=pbe, tbe=tbe)
+
+
+# ---------------------------------------------------------------------------- PatternBlockingTag (the default algorithm tag)
+@pytest.mark.parametrize("ty", [nvb.GLOBAL, nvb.LOCAL, nvb.SEMI_GLOBAL])
+@pytest.mark.parametrize("kind", [0, 1])
+def test_pattern_blocking(cuda, ty, kind):
+    """Gotoh (8-symbol blocks) and SW / ED (16-symbol blocks) in the pattern-blocking form, vs the oracle's restatement of
+    gotoh_inl.h:459-900 / sw_inl.h:417-760: scores, sinks (LOCAL ties follow the pattern-block order) and the per-block
+    early exit against min_score."""
+    rng = np.random.default_rng(300 + 10 * kind + ty)
+    for max_m in (60, 130, 200, 256, 400):
+        pats, txts = make_pairs(rng, 800, max_m, 350)
+        pats = [p if len(p) else np.zeros(1, np.uint8) for p in pats]            # M >= 1 (M == 0 is undefined in the reference)
+        hp, ht = O.StringSet.from_lists(pats, 4, True), O.StringSet.from_lists(txts, 2, False)
+        dp = nvb.PackedStringSet.from_host(hp.words, 4, True, hp.begin, hp.length, device=cuda)
+        dt = nvb.PackedStringSet.from_host(ht.words, 2, False, ht.begin, ht.length, device=cuda)
+        ms = rng.integers(-80, 260, 800).astype(np.int32)
+        for scheme in (((2, -1, -2, -1), (0, -5, -8, -3)) if kind == 0 else ((2, -1, -1, -1), (0, -1, -1, -1))):
+            mk = (lambda s_: nvb.make_gotoh_aligner(ty, nvb.SimpleGotohScheme(*s_), nvb.PATTERN_BLOCKING)) if kind == 0 else \
+                 (lambda s_: nvb.make_smith_waterman_aligner(ty, nvb.SimpleSmithWatermanScheme(*s_), nvb.PATTERN_BLOCKING))
+            for min_score in (None, ms):
+                es, ek, eo = O.batch_score_pattern_blocking(kind, ty, scheme, hp, ht, min_score=min_score)
+                gs, gk, go = nvb.batch_alignment_score(mk(scheme), dp, dt, max_m, 350,
+                                                       torch.from_numpy(min_score).to(cuda) if min_score is not None else None)
+                torch.cuda.synchronize()
+                gs, gk, go = gs.cpu().numpy(), gk.cpu().numpy().view(np.uint32), go.cpu().numpy()
+                bad = np.nonzero((es != gs) | (ek != gk).any(1) | (eo != go))[0]
+                assert bad.size == 0, (kind, ty, scheme, max_m, min_score is not None, bad[:5], len(pats[bad[0]]), len(txts[bad[0]]),
+                                       (es[bad[0]], ek[bad[0]], eo[bad[0]]), (gs[bad[0]], gk[bad[0]], go[bad[0]]))
+                if min_score is not None and scheme[0] > 0:
+                    assert 0 < eo.sum() < 800          # both outcomes occur

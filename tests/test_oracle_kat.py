@@ -400,3 +400,29 @@ def test_linear_gap_aligners_equal_gotoh_with_open_eq_ext(scheme):
     for ty in (O.GLOBAL, O.LOCAL, O.SEMI_GLOBAL):
         a, ak = O.batch_sw_score(0, ty, (2, -1, -1, -1), hp1, ht1)
         assert int(a[0]) == O.ref_sw_gotoh(ty, (2, -1, -1, -1), p, t)
+
+
+def test_pattern_blocking_and_text_blocking_restatements_agree():
+    """Two independent restatements (gotoh_inl.h:459-900 vs :969-1489, sw_inl.h:417-760 vs :881-1222) of the same
+    matrix: scores agree everywhere, sinks agree for GLOBAL / SEMI_GLOBAL; LOCAL sinks differ only where several
+    cells hold the maximum (the visiting order picks the survivor)."""
+    rng = np.random.default_rng(8)
+    pats, txts = [], []
+    for i in range(500):
+        M, N = int(rng.integers(1, 90)), int(rng.integers(1, 200))
+        t = rng.integers(0, 4, N).astype(np.uint8)
+        p = t[:M].copy() if N >= M else rng.integers(0, 4, M).astype(np.uint8)
+        p = np.resize(p, M); mut = rng.random(M) < 0.1; p[mut] = rng.integers(0, 4, int(mut.sum()))
+        pats.append(p); txts.append(t)
+    hp, ht = O.StringSet.from_lists(pats, 4, True), O.StringSet.from_lists(txts, 2, False)
+    differs = 0
+    for ty in (O.GLOBAL, O.LOCAL, O.SEMI_GLOBAL):
+        for kind, scheme in ((0, (2, -1, -2, -1)), (1, (2, -1, -1, -1)), (1, (0, -1, -1, -1))):
+            a, ak, aok = O.batch_score_pattern_blocking(kind, ty, scheme, hp, ht)
+            b, bk = (O.batch_gotoh_score(ty, scheme, hp, ht)[:2]) if kind == 0 else O.batch_sw_score(0, ty, scheme, hp, ht)
+            assert (a == b).all() and aok.all()
+            if ty != O.LOCAL:
+                assert (ak == bk).all()
+            else:
+                differs += int((ak != bk).any(1).sum())
+    assert differs > 0
