@@ -326,9 +326,20 @@ def rank_leg(a, dev, fmi):
     torch.cuda.synchronize()
     ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / reps
     gbs = q * RANK_BYTES_PER_QUERY / (ms * 1e-3) / 1e9
-    return {"kernel": "fm_rank_kernel", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": gbs / HBM_PEAK_GBS, "traffic": measured_traffic("fm_rank_kernel"), "kernel_ms": ms, "queries": q, "index_symbols": ng,
-            "index_bytes": int(bwt_occ.numel()) * 4, "Mqueries_per_s": q / (ms * 1e-3) / 1e6}
+    traffic = measured_traffic("fm_rank_kernel")
+    res = {"kernel": "fm_rank_kernel", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": ms, "queries": q, "index_symbols": ng,
+           "index_bytes": int(bwt_occ.numel()) * 4, "Mqueries_per_s": q / (ms * 1e-3) / 1e6}
+    if traffic:
+        # what the memory system actually moved (PMC, profiles/traffic.json, measured at the default query count): every query
+        # misses to a 128-byte fabric request although it needs 32 bytes of it
+        scale = q / 268435456.0
+        res["traffic_GBs"] = traffic * scale / (ms * 1e-3) / 1e9
+        res["traffic_frac_of_hbm_peak"] = res["traffic_GBs"] / HBM_PEAK_GBS
+    res["random_lines_per_s_G"] = q / (ms * 1e-3) / 1e9
+    res["random_line_limit_G"] = 53.0          # tools/gather_probe.hip (profiles/r01/gather_probe.txt): the chip's random 128-B line rate
+    res["note"] = "uniform random point queries: one 128-B line per query is the floor; frac counts 40 algorithmic bytes per query"
+    return res
 
 
 def seed_leg(a, dev, fmi, text, build_s):
