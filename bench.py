@@ -135,17 +135,32 @@ def main():
     gatherers = [ResultGather(n * world, dst=0, device=dev, record_bytes=4) for _ in range(2)] if world > 1 else None
 
     pending = [None, None]
+    # pre-flight of the gather on tiny buffers: if the backend cannot do it, every rank learns so here, agrees, and the
+    # run continues with the results left on their GPUs (reported as "gather": false) instead of dying mid-measurement
+    gather_on = world > 1
+    if world > 1:
+        flag = 1
+        try:
+            probe = ResultGather(world * 4, dst=0, device=dev, record_bytes=4)
+            probe.gather(torch.zeros(4, dtype=torch.int32, device=dev), torch.zeros((4, 2), dtype=torch.int32, device=dev), concat=False)
+            torch.cuda.synchronize()
+        except Exception as e:     # noqa: BLE001
+            sys.stderr.write("bench: result gather unavailable (%s); continuing without it\n" % e)
+            flag = 0
+        ft = torch.tensor([flag], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(ft, op=dist.ReduceOp.MIN)
+        gather_on = bool(int(ft.item()))
 
     def step(i, events=None):
         b = i & 1
-        if world > 1 and pending[b] is not None:
+        if gather_on and pending[b] is not None:
             torch.cuda.current_stream().wait_event(pending[b])        # gather of step i-2 done: buffer b is free
         if events is not None:
             events[0].record()
         launch(outs[b])
         if events is not None:
             events[1].record()
-        if world > 1:
+        if gather_on:
             comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(comm_stream):
                 gatherers[b].gather(outs[b][0], outs[b][1], concat=False)   # 4 B/read to rank 0 over RCCL/xGMI
@@ -211,7 +226,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16", "data": "synthetic",
             "config": {"workload": "nvbio::aln batched banded SW (configs[1]): %d x 100 bp reads vs 150 bp windows per GPU, band=15, LOCAL Gotoh (2,-1,-2,-1)" % n,
-                       "reads_per_gpu": n, "read_len": READ_LEN, "band": BAND, "type": "LOCAL", "parallelism": "read-shard x%d, gather to rank 0" % world},
+                       "reads_per_gpu": n, "read_len": READ_LEN, "band": BAND, "type": "LOCAL", "parallelism": "read-shard x%d, gather to rank 0" % world, "gather": bool(gather_on) if world > 1 else None},
             "roofline": roofline, "parity": parity,
         }
 
