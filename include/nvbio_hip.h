@@ -196,6 +196,23 @@ int nvbio_hip_banded_gotoh_traceback_qual(
     uint16_t* out_cigar, uint32_t cigar_stride, uint32_t* out_cigar_len,
     void* temp, uint64_t temp_bytes, void* stream);
 
+/* Batched full-matrix Gotoh traceback.  Replaces
+ *   BatchedAlignmentTraceback<CHECKPOINTS, stream, DeviceThreadScheduler>::enact (nvbio/alignment/batched.h:432-452)
+ * for aligner = GotohAligner<TYPE, SimpleGotohScheme> with nvBowtie's CIGAR-forming backtracer: alignment_traceback
+ * (alignment_inl.h:365-480) -- the sink of the pattern-blocking score pass, the flow flags of gotoh_inl.h:512-560 /
+ * :407-425, the walk of gotoh_inl.h:1806-1870 and the driver's completion along the first row / column (:443-466).
+ * Outputs as nvbio_hip_banded_gotoh_traceback (source/sink: x = text position, y = pattern position).
+ * The flow flags of the whole matrix live in `temp` (nvbio_hip_gotoh_traceback_temp_bytes: 4 bytes per 8 cells + 4 bytes
+ * per text symbol, per job); CHECKPOINTS has no equivalent.  Requires the int16-exact range of the full-matrix scorer. */
+uint64_t nvbio_hip_gotoh_traceback_temp_bytes(uint32_t max_pattern_len, uint32_t max_text_len, uint32_t n);
+int nvbio_hip_gotoh_traceback(
+    const nvbio_hip_gotoh_scheme* scheme /* host */, int32_t type,
+    const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len, uint32_t n,
+    int32_t* out_score, uint32_t* out_sink, uint32_t* out_source,
+    uint16_t* out_cigar, uint32_t cigar_stride, uint32_t* out_cigar_len,
+    void* temp, uint64_t temp_bytes, void* stream);
+
 /* nvbio::fm_index<rank_dictionary<2,64,PackedStream<.,uint8,2,true>,.,.>, SSA_index_multiple_context<SA_INT>, const uint32*>
  * (nvbio/fmindex/fmindex.h:341-387) in the production interleaved layout
  * (nvbio/io/fmindex/fmindex.h:159-174, fmindex_impl.cu:305-327):

@@ -335,6 +335,29 @@ struct BatchedAlignmentScore
     }
 };
 
+/// BatchedAlignmentTraceback<CHECKPOINTS, stream, scheduler> (batched.h:432-452): full-matrix Gotoh traceback with
+/// nvBowtie's CIGAR-forming backtracer; the stream is the PackedTracebackStream of the banded form.
+template <uint32 CHECKPOINTS, typename stream_type, typename algorithm_type = DeviceThreadScheduler>
+struct BatchedAlignmentTraceback
+{
+    typedef typename stream_type::aligner_type aligner_type;
+    static uint64 min_temp_storage(const uint32 max_pattern_len, const uint32 max_text_len, const uint32 stream_size)
+    { return nvbio_hip_gotoh_traceback_temp_bytes(max_pattern_len, max_text_len, stream_size); }
+    static uint64 max_temp_storage(const uint32 max_pattern_len, const uint32 max_text_len, const uint32 stream_size)
+    { return min_temp_storage(max_pattern_len, max_text_len, stream_size); }
+
+    void enact(stream_type stream, uint64 temp_size, uint8* temp, void* hip_stream = nullptr)
+    {
+        static_assert(sizeof(io::Cigar) == 2, "io::Cigar must be a uint16 bit-field");
+        const nvbio_hip_gotoh_scheme sc = priv::abi_scheme(stream.aligner().scheme);
+        const nvbio_hip_string_set p = stream.m_patterns.abi(), t = stream.m_texts.abi();
+        hip_check(nvbio_hip_gotoh_traceback(&sc, int32(aligner_type::TYPE), &p, &t, stream.max_pattern_length(), stream.max_text_length(), stream.size(),
+                      stream.m_alignments.score, stream.m_alignments.sink, stream.m_alignments.source,
+                      reinterpret_cast<uint16*>(stream.m_cigars.cigar), stream.m_cigars.cigar_stride, stream.m_cigars.cigar_len,
+                      temp, temp_size, hip_stream), "nvbio_hip_gotoh_traceback");
+    }
+};
+
 /// batch_alignment_score(aligner, patterns, texts, sinks, scheduler, maxP, maxT)   (batched.h:160-190)
 template <typename aligner_type, typename pattern_set_type, typename text_set_type, typename scheduler_type>
 void batch_alignment_score(

@@ -11,7 +11,7 @@ from .strings import PackedStringSet, pack_symbols  # noqa: F401
 from .alignment import (GLOBAL, LOCAL, SEMI_GLOBAL, PATTERN_BLOCKING, TEXT_BLOCKING, SimpleGotohScheme, SmithWatermanScoringScheme, GotohAligner,  # noqa: F401
                         make_gotoh_aligner, BatchedBandedAlignmentScore, batch_banded_alignment_score,
                         BatchedAlignmentScore, batch_alignment_score,
-                        BatchedBandedAlignmentTraceback, batch_banded_alignment_traceback,
+                        BatchedBandedAlignmentTraceback, batch_banded_alignment_traceback, batch_alignment_traceback,
                         SimpleSmithWatermanScheme, SmithWatermanAligner, EditDistanceAligner,
                         make_smith_waterman_aligner, make_edit_distance_aligner)
 from .fmindex import FMIndexDevice, FMIndexFilter, rank, rank4, rank_range, match, locate, \

@@ -260,6 +260,30 @@ def batch_banded_alignment_traceback(band_len, aligner, patterns, texts, max_pat
     return out
 
 
+def batch_alignment_traceback(aligner, patterns, texts, max_pattern_length=0, max_text_length=0, cigar_stride=64):
+    """BatchedAlignmentTraceback<CHECKPOINTS, stream>::enact (batched.h:432-452) for the full-matrix Gotoh aligner with
+    nvBowtie's backtracer: returns dict(score, sink, source, cigar int16[n,stride], cigar_len) as the banded form does."""
+    n = len(patterns)
+    assert len(texts) == n and isinstance(aligner.scheme, SimpleGotohScheme)
+    dev = patterns.words.device
+    maxM = max_pattern_length or patterns.fixed_length
+    maxN = max_text_length or texts.fixed_length
+    need = int(lib().nvbio_hip_gotoh_traceback_temp_bytes(int(maxM), int(maxN), n))
+    temp = torch.empty(max(need, 8), dtype=torch.uint8, device=dev)
+    out = dict(score=torch.empty(n, dtype=torch.int32, device=dev), sink=torch.empty((n, 2), dtype=torch.int32, device=dev),
+               source=torch.empty((n, 2), dtype=torch.int32, device=dev), cigar=torch.zeros((max(n, 1), cigar_stride), dtype=torch.int16, device=dev),
+               cigar_len=torch.empty(n, dtype=torch.int32, device=dev))
+    sc = aligner.scheme.struct()
+    ps, ts = patterns.struct(), texts.struct()
+    err = lib().nvbio_hip_gotoh_traceback(C.byref(sc), aligner.type, C.byref(ps), C.byref(ts), int(maxM), int(maxN), n,
+                                          C.c_void_p(out["score"].data_ptr()), C.c_void_p(out["sink"].data_ptr()), C.c_void_p(out["source"].data_ptr()),
+                                          C.c_void_p(out["cigar"].data_ptr()), cigar_stride, C.c_void_p(out["cigar_len"].data_ptr()),
+                                          C.c_void_p(temp.data_ptr()), temp.numel(), current_stream_ptr())
+    check(err, "nvbio_hip_gotoh_traceback")
+    temp.record_stream(torch.cuda.current_stream())
+    return out
+
+
 class BatchedAlignmentScore:
     """BatchedAlignmentScore<stream, DeviceThreadScheduler> (batched.h:310-329) for the full-matrix Gotoh
     score with the text-blocking aligner sw-benchmark instantiates (sw-benchmark.cu:604-631)."""

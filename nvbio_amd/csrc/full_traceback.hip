@@ -1,0 +1,215 @@
+// full_traceback.hip -- batched full-matrix Gotoh traceback -> CIGAR, gfx950.
+//
+// Replaces, for GotohAligner<TYPE, SimpleGotohScheme>:
+//   aln::BatchedAlignmentTraceback<CHECKPOINTS, stream>::enact (nvbio/alignment/batched.h:432-452) = per job
+//   alignment_traceback (alignment_inl.h:365-480): the pattern-blocking score pass with checkpoints every CHECKPOINTS
+//   pattern symbols (its sink decides where the walk starts), then per checkpoint the flow submatrix
+//   (gotoh_inl.h:512-560, GotohSubmatrixContext::new_cell :407-425) and the walk (gotoh_inl.h:1806-1870), with
+//   nvBowtie's CIGAR-forming backtracer (nvBowtie/bowtie2/cuda/alignment_utils.h:125-168).
+//
+// As in the banded kernel the checkpoint/recompute scheme is replaced by keeping the flow flags of the whole matrix in
+// HBM: a lane walks the matrix exactly in the reference's pattern-blocking order (blocks of 8 pattern symbols in
+// registers, the {H,E} boundary column over the text as int16 pairs in HBM), writes 8 flag nibbles = one dword per
+// (block, text row), lane-interleaved, then walks them back.  150 x 650 (nvBowtie's opposite-mate window) is
+// 49 KB of flags per alignment.  Exact while the DP values fit the reference's int16 columns; the host refuses
+// schemes / lengths that could leave that range.
+#include "common.h"
+#include <algorithm>
+
+namespace nvb {
+
+enum : uint32_t { T_SUBSTITUTION = 0, T_INSERTION = 1, T_DELETION = 2, T_SINK = 3, T_INSERTION_EXT = 4, T_DELETION_EXT = 8 };
+
+struct FullTbParams {
+    StringSet pat, txt;
+    int32_t   match, mismatch, gap_open, gap_ext;
+    uint32_t  n, max_text_len;
+    int32_t*  out_score; uint2* out_sink; uint2* out_source;
+    uint16_t* out_cigar; uint32_t cigar_stride; uint32_t* out_cigar_len;
+    uint32_t* flags;      // [block][text row][job]: 8 nibbles, pattern column (block*8 + k) at bits 4k
+    uint32_t* column;     // [text row][job]: {int16 H, int16 E} of the last pattern column of the previous block
+};
+
+template <int TYPE>
+__global__ void __launch_bounds__(256) full_gotoh_traceback_kernel(const FullTbParams p)
+{
+    const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
+    if (tid >= p.n) return;
+    const uint64_t pb = p.pat.begin[tid], tb = p.txt.begin[tid];
+    const uint32_t M  = p.pat.length ? p.pat.length[tid] : p.pat.fixed_length;
+    const uint32_t N  = p.txt.length ? p.txt.length[tid] : p.txt.fixed_length;
+    const uint64_t n  = p.n;
+
+    int32_t  best = -(1 << 30);
+    uint32_t bx = 0xFFFFFFFFu, by = 0xFFFFFFFFu;
+    auto report = [&](const int32_t s, const uint32_t x, const uint32_t y) { if (best <= s) { best = s; bx = x; by = y; } };
+
+    const int32_t G_o = p.gap_open, G_e = p.gap_ext;
+    const int32_t infimum = -32768 - min(G_o, G_e);
+    constexpr uint32_t BL = 8u;
+    const uint32_t n_blocks = max(1u, (M + BL - 1u) / BL);
+    int32_t H_band[BL + 1], F_band[BL + 1];
+    uint32_t q_cache[BL];
+    #pragma unroll
+    for (uint32_t t = 0; t < BL; ++t) q_cache[t] = 255u;
+
+    // ---- forward pass in the reference's visiting order (gotoh_inl.h:640-900), flags kept
+    for (uint32_t blk = 0; blk < n_blocks; ++blk)
+    {
+        const uint32_t block = blk * BL;
+        const bool last = (blk + 1u == n_blocks);
+        #pragma unroll
+        for (uint32_t t = 0; t < BL; ++t) if (block + t < M) q_cache[t] = get_symbol(p.pat.s, pb + block + t);
+        #pragma unroll
+        for (uint32_t j = 0; j <= BL; ++j) {
+            H_band[j] = (TYPE != NVBIO_HIP_LOCAL) ? (block + j > 0u ? G_o + G_e * int32_t(block + j - 1u) : 0) : 0;
+            F_band[j] = infimum;
+        }
+        int32_t temp_i = H_band[0];
+        for (uint32_t i = 0; i < N; ++i)
+        {
+            const uint32_t r_i = get_symbol(p.txt.s, tb + i);
+            int32_t H_diag = temp_i, E;
+            if (blk == 0u) {        // context.init (:275-279)
+                temp_i = (TYPE == NVBIO_HIP_GLOBAL) ? G_o + G_e * int32_t(i) : 0;
+                E      = (TYPE == NVBIO_HIP_LOCAL) ? 0 : infimum;
+            } else {
+                const uint32_t c = p.column[uint64_t(i) * n + tid];
+                temp_i = int32_t(int16_t(c & 0xFFFFu));
+                E      = int32_t(int16_t(c >> 16));
+            }
+            H_band[0] = temp_i;
+            uint32_t word = 0;
+            #pragma unroll
+            for (uint32_t j = 1; j <= BL; ++j)
+            {
+                const int32_t ftop = F_band[j] + G_e, htop = H_band[j] + G_o;
+                F_band[j] = max(ftop, htop);
+                const uint32_t fdir = ftop > htop ? T_DELETION_EXT : T_SUBSTITUTION;
+                const int32_t eleft = E + G_e, hleft = H_band[j - 1] + G_o;
+                E = max(eleft, hleft);
+                const uint32_t edir = eleft > hleft ? T_INSERTION_EXT : T_SUBSTITUTION;
+                const int32_t diagonal = H_diag + (r_i == q_cache[j - 1] ? p.match : p.mismatch);
+                const int32_t top = F_band[j], left = E;
+                int32_t hi = max(max(left, top), diagonal);
+                if (TYPE == NVBIO_HIP_LOCAL) hi = max(hi, 0);
+                uint32_t hdir = top > left ? (top > diagonal ? T_DELETION : T_SUBSTITUTION) : (left > diagonal ? T_INSERTION : T_SUBSTITUTION);
+                if (TYPE == NVBIO_HIP_LOCAL && hi == 0) hdir = T_SINK;
+                H_diag = H_band[j];
+                H_band[j] = hi;
+                word |= (hdir | edir | fdir) << (4u * (j - 1u));
+                if (TYPE == NVBIO_HIP_LOCAL) { if (block + j <= M) report(hi, i + 1u, block + j); }
+            }
+            p.column[uint64_t(i) * n + tid] = (uint32_t(H_band[BL]) & 0xFFFFu) | (uint32_t(E) << 16);     // make_vector<short> (:565)
+            __builtin_nontemporal_store(word, p.flags + (uint64_t(blk) * p.max_text_len + i) * n + tid);
+            if (TYPE == NVBIO_HIP_SEMI_GLOBAL && last)
+            {
+                // save_boundary -> save_Mth: H[i][M] (utils_inl.h:206-226,279-299)
+                const uint32_t jm = ((M - 1u) & (BL - 1u)) + 1u;
+                int32_t v = 0;
+                #pragma unroll
+                for (uint32_t j = 1; j <= BL; ++j) if (j == jm) v = H_band[j];
+                report(v, i + 1u, M);
+            }
+        }
+    }
+    if (TYPE == NVBIO_HIP_GLOBAL)
+    {
+        const uint32_t jm = ((M - 1u) & (BL - 1u)) + 1u;
+        int32_t v = 0;
+        #pragma unroll
+        for (uint32_t j = 1; j <= BL; ++j) if (j == jm) v = H_band[j];
+        report(v, N, M);
+    }
+
+    p.out_score[tid] = best;
+    p.out_sink[tid]  = make_uint2(bx, by);
+
+    // ---- walk back: gotoh_inl.h:1806-1870 over all checkpoints, then alignment_inl.h:443-466; Backtracker::clip / push
+    uint16_t* cigar = p.out_cigar + uint64_t(tid) * p.cigar_stride;
+    uint32_t  size = 0, run_type = 255u, run_len = 0;
+    auto flush = [&]() { if (run_len) { if (size < p.cigar_stride) cigar[size] = uint16_t(run_type | (run_len << 2)); ++size; run_len = 0; } };
+    auto clip  = [&](const uint32_t l) { if (l) { if (size < p.cigar_stride) cigar[size] = uint16_t(3u | (l << 2)); ++size; } };
+    auto push  = [&](const uint32_t t) { if (t != run_type) { flush(); run_type = t; } ++run_len; };
+
+    if (bx == 0xFFFFFFFFu || by == 0xFFFFFFFFu) {
+        p.out_source[tid]    = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        p.out_cigar_len[tid] = 0;
+        return;
+    }
+    clip(M - by);
+    int32_t  row = int32_t(bx), col = int32_t(by) - 1;
+    uint32_t state = 0;     // 0 = H, 1 = E, 2 = F
+    while (row > 0 && col >= 0)
+    {
+        const uint32_t w  = p.flags[(uint64_t(uint32_t(col) >> 3) * p.max_text_len + uint32_t(row - 1)) * n + tid];
+        const uint32_t op = (w >> ((uint32_t(col) & 7u) * 4u)) & 15u, h_op = op & 3u;
+        if (TYPE == NVBIO_HIP_LOCAL && state == 0 && h_op == T_SINK) break;
+        if (state == 1)      { if ((op & T_INSERTION_EXT) == 0u) state = 0; --col; push(T_INSERTION); }
+        else if (state == 2) { if ((op & T_DELETION_EXT)  == 0u) state = 0; --row; push(T_DELETION); }
+        else if (h_op == T_INSERTION) state = 1;
+        else if (h_op == T_DELETION)  state = 2;
+        else { --col; --row; push(T_SUBSTITUTION); }
+    }
+    uint32_t sx = uint32_t(row), sy = uint32_t(col + 1);
+    if (TYPE == NVBIO_HIP_SEMI_GLOBAL || TYPE == NVBIO_HIP_GLOBAL) { if (sx == 0u) for (; sy > 0u; --sy) push(T_INSERTION); }
+    if (TYPE == NVBIO_HIP_GLOBAL)                                   { if (sy == 0u) for (; sx > 0u; --sx) push(T_DELETION); }
+    flush();
+    clip(sy);
+    p.out_source[tid]    = make_uint2(sx, sy);
+    p.out_cigar_len[tid] = size;
+}
+
+} // namespace nvb
+
+using namespace nvb;
+
+NVB_API uint64_t nvbio_hip_gotoh_traceback_temp_bytes(uint32_t max_pattern_len, uint32_t max_text_len, uint32_t n)
+{
+    const uint64_t blocks = std::max<uint64_t>(1u, (uint64_t(max_pattern_len) + 7u) / 8u);
+    return (blocks + 1u) * uint64_t(max_text_len) * uint64_t(n) * 4u;      // flags + the boundary column
+}
+
+NVB_API int nvbio_hip_gotoh_traceback(
+    const nvbio_hip_gotoh_scheme* scheme, int32_t type,
+    const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len, uint32_t n,
+    int32_t* out_score, uint32_t* out_sink, uint32_t* out_source,
+    uint16_t* out_cigar, uint32_t cigar_stride, uint32_t* out_cigar_len,
+    void* temp, uint64_t temp_bytes, void* stream)
+{
+    if (!scheme || !patterns || !texts) return hipErrorInvalidValue;
+    if (type < 0 || type > 2) return hipErrorInvalidValue;
+    if (!(patterns->bits == 2 || patterns->bits == 4) || texts->bits != 2) return hipErrorNotSupported;
+    if (n == 0) return hipSuccess;
+    if (!out_score || !out_sink || !out_source || !out_cigar || !out_cigar_len || cigar_stride == 0) return hipErrorInvalidValue;
+    if (!patterns->words || !texts->words || !patterns->begin || !texts->begin || patterns->n_words == 0 || texts->n_words == 0) return hipErrorInvalidValue;
+    const uint32_t maxM = patterns->length ? max_pattern_len : patterns->fixed_length;
+    const uint32_t maxN = texts->length ? max_text_len : texts->fixed_length;
+    if (maxM == 0 || maxN == 0) return hipErrorInvalidValue;
+    if (maxM >= (1u << 14) || maxN >= (1u << 14)) return hipErrorNotSupported;       // io::Cigar::m_len is 14 bits
+    auto iabs = [](int32_t v) { return v < 0 ? -int64_t(v) : int64_t(v); };
+    const int64_t A = std::max(std::max(iabs(scheme->match), iabs(scheme->mismatch)), std::max(iabs(scheme->gap_open), iabs(scheme->gap_ext)));
+    const int64_t span = (type == NVBIO_HIP_GLOBAL) ? int64_t(maxM) + maxN + 4 : int64_t(maxM) + 4;
+    if (!(scheme->gap_open <= 0 && scheme->gap_ext <= 0 && span * A < 30000)) return hipErrorNotSupported;   // int16 checkpoints / columns exact only here
+    const uint64_t need = nvbio_hip_gotoh_traceback_temp_bytes(maxM, maxN, n);
+    if (!temp || temp_bytes < need) return hipErrorInvalidValue;
+
+    FullTbParams p;
+    p.pat = make_string_set(patterns); p.txt = make_string_set(texts);
+    p.match = scheme->match; p.mismatch = scheme->mismatch; p.gap_open = scheme->gap_open; p.gap_ext = scheme->gap_ext;
+    p.n = n; p.max_text_len = maxN;
+    p.out_score = out_score; p.out_sink = reinterpret_cast<uint2*>(out_sink); p.out_source = reinterpret_cast<uint2*>(out_source);
+    p.out_cigar = out_cigar; p.cigar_stride = cigar_stride; p.out_cigar_len = out_cigar_len;
+    p.column = static_cast<uint32_t*>(temp);
+    p.flags  = p.column + uint64_t(maxN) * n;
+    g_last_kernel = "full_gotoh_traceback_kernel";
+    const dim3 grid((n + 255u) / 256u), block(256);
+    hipStream_t s = to_stream(stream);
+    switch (type) {
+    case NVBIO_HIP_LOCAL:       hipLaunchKernelGGL(full_gotoh_traceback_kernel<NVBIO_HIP_LOCAL>,       grid, block, 0, s, p); break;
+    case NVBIO_HIP_SEMI_GLOBAL: hipLaunchKernelGGL(full_gotoh_traceback_kernel<NVBIO_HIP_SEMI_GLOBAL>, grid, block, 0, s, p); break;
+    default:                    hipLaunchKernelGGL(full_gotoh_traceback_kernel<NVBIO_HIP_GLOBAL>,      grid, block, 0, s, p); break;
+    }
+    return hipGetLastError();
+}

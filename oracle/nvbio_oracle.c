@@ -109,6 +109,8 @@ static inline void sink_report(best_sink_t* s, int32_t score, uint32_t x, uint32
     if (s->score <= score) { s->score = score; s->sink_x = x; s->sink_y = y; }
 }
 static inline int32_t imax(int32_t a, int32_t b) { return a > b ? a : b; }
+/* DirectionVector */
+enum { DIR_SUBSTITUTION = 0, DIR_INSERTION = 1, DIR_DELETION = 2, DIR_SINK = 3, DIR_INSERTION_EXT = 4, DIR_DELETION_EXT = 8 };   /* alignment_base.h:139-150 */
 
 #define MAX_BAND 64
 
@@ -665,6 +667,93 @@ ORACLE_API void oracle_batch_score_pattern_blocking(
     }
 }
 
+/* ------------------------------------------------------------------------ */
+/* Full-matrix Gotoh traceback                                                */
+/*   driver      nvbio/alignment/alignment_inl.h:365-480 (score with           */
+/*               checkpoints every CHECKPOINTS pattern symbols, then per       */
+/*               checkpoint: recompute the flow submatrix, walk it back)       */
+/*   flow flags  gotoh_inl.h:512-560 (update_row's new_cell arguments) and     */
+/*               GotohSubmatrixContext::new_cell (:407-425)                    */
+/*   walk        gotoh_inl.h:1806-1870                                         */
+/* The sink is the one of the pattern-blocking score pass; the flags are        */
+/* restated densely (the checkpoints are exact while values fit int16).        */
+/* res: [0] score, [1..2] source (x = text, y = pattern), [3..4] sink,          */
+/*      [5] ops pushed, [6] clip pushed first (M - sink.y), [7] clip pushed    */
+/*      last (source.y);  ops: 0 = M, 1 = I, 2 = D, end of the alignment first */
+/* flags: scratch of M*N bytes, hrow / frow: scratch of M+1 int32 each.        */
+/* ------------------------------------------------------------------------ */
+ORACLE_API void oracle_gotoh_traceback(int type, const int32_t* scheme,
+    const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, uint64_t pat_begin, uint32_t M,
+    const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, uint64_t txt_begin, uint32_t N,
+    int32_t* res, uint8_t* ops, uint32_t ops_capacity, uint8_t* flags, int32_t* hrow, int32_t* frow)
+{
+    const scheme_t sc = { scheme[0], scheme[1], scheme[2], scheme[3], scheme[2], scheme[3], NULL, NULL };
+    best_sink_t best; sink_init(&best);
+    {
+        int16_t* temp = (int16_t*)malloc(sizeof(int16_t) * 2 * (size_t)(N + 1));
+        score_pattern_blocking(0, type, &sc, scheme, pat_w, pat_bits, pat_be, pat_begin, M, txt_w, txt_bits, txt_be, txt_begin, N, (-2147483647 - 1), &best, temp);
+        free(temp);
+    }
+    res[0] = best.score; res[3] = (int32_t)best.sink_x; res[4] = (int32_t)best.sink_y; res[5] = res[6] = res[7] = 0;
+    if (best.sink_x == 0xFFFFFFFFu || best.sink_y == 0xFFFFFFFFu) { res[1] = res[2] = -1; return; }
+    /* dense flow flags: cell (i, j) = text row i, pattern column j */
+    const int32_t G_o = sc.pat_gap_open, G_e = sc.pat_gap_ext;
+    const int32_t infimum = -32768 - (G_o < G_e ? G_o : G_e);
+    for (uint32_t j = 0; j <= M; ++j) {                      /* the row above the text: H_band init (:693-697), F = infimum */
+        hrow[j] = (type != ALN_LOCAL) ? (j > 0 ? G_o + G_e * (int32_t)(j - 1u) : 0) : 0;
+        frow[j] = infimum;
+    }
+    for (uint32_t i = 0; i < N; ++i)
+    {
+        const uint8_t r_i = (uint8_t)ps_get(txt_w, txt_bits, txt_be, txt_begin + i);
+        int32_t H_diag = hrow[0];
+        hrow[0] = (type == ALN_GLOBAL) ? sc.txt_gap_open + sc.txt_gap_ext * (int32_t)i : 0;       /* context.init (:275-279) */
+        int32_t E = (type == ALN_LOCAL) ? 0 : infimum;
+        for (uint32_t j = 1; j <= M; ++j)
+        {
+            const int32_t ftop = frow[j] + G_e, htop = hrow[j] + G_o;
+            frow[j] = imax(ftop, htop);
+            const uint8_t fdir = ftop > htop ? DIR_DELETION_EXT : DIR_SUBSTITUTION;
+            const int32_t eleft = E + G_e, hleft = hrow[j - 1] + G_o;
+            E = imax(eleft, hleft);
+            const uint8_t edir = eleft > hleft ? DIR_INSERTION_EXT : DIR_SUBSTITUTION;
+            const uint8_t q_j = (uint8_t)ps_get(pat_w, pat_bits, pat_be, pat_begin + j - 1);
+            const int32_t diagonal = H_diag + subst(&sc, r_i, q_j, 0);
+            const int32_t top = frow[j], left = E;
+            int32_t hi = imax(imax(left, top), diagonal);
+            if (type == ALN_LOCAL) hi = imax(hi, 0);
+            uint8_t hdir = top > left ? (top > diagonal ? DIR_DELETION : DIR_SUBSTITUTION) : (left > diagonal ? DIR_INSERTION : DIR_SUBSTITUTION);
+            if (type == ALN_LOCAL && hi == 0) hdir = DIR_SINK;
+            H_diag = hrow[j];
+            hrow[j] = hi;
+            flags[(size_t)i * M + (j - 1)] = (uint8_t)(hdir | edir | fdir);
+        }
+    }
+    /* walk back (:1806-1870 across all checkpoints, then alignment_inl.h:443-466) */
+    uint32_t n = 0;
+    res[6] = (int32_t)(M - best.sink_y);
+    int32_t row = (int32_t)best.sink_x, col = (int32_t)best.sink_y - 1;
+    uint8_t state = 0;     /* HSTATE */
+    int found = 0;
+    #define PUSH(o) do { if (n < ops_capacity) ops[n] = (o); ++n; } while (0)
+    while (row > 0 && col >= 0)
+    {
+        const uint8_t op = flags[(size_t)(row - 1) * M + col], h_op = op & 3u;
+        if (type == ALN_LOCAL && state == 0 && h_op == DIR_SINK) { found = 1; break; }
+        if (state == 1)      { if ((op & DIR_INSERTION_EXT) == 0u) state = 0; --col; PUSH(DIR_INSERTION); }
+        else if (state == 2) { if ((op & DIR_DELETION_EXT)  == 0u) state = 0; --row; PUSH(DIR_DELETION); }
+        else if (h_op == DIR_INSERTION) state = 1;
+        else if (h_op == DIR_DELETION)  state = 2;
+        else { --col; --row; PUSH(DIR_SUBSTITUTION); }
+    }
+    (void)found;
+    uint32_t sx = (uint32_t)row, sy = (uint32_t)(col + 1);
+    if (type == ALN_SEMI_GLOBAL || type == ALN_GLOBAL) { if (sx == 0) for (; sy > 0; --sy) PUSH(DIR_INSERTION); }
+    if (type == ALN_GLOBAL)                            { if (sy == 0) for (; sx > 0; --sx) PUSH(DIR_DELETION); }
+    #undef PUSH
+    res[1] = (int32_t)sx; res[2] = (int32_t)sy; res[5] = (int32_t)n; res[7] = (int32_t)sy;
+}
+
 /* banded: BatchedBandedAlignmentScore over SmithWatermanAligner / EditDistanceAligner;
  * full (band == 0): BatchedAlignmentScore over the TextBlockingTag forms */
 ORACLE_API void oracle_batch_sw_score(
@@ -731,7 +820,6 @@ ORACLE_API int32_t oracle_ref_sw_gotoh(int type, const int32_t* scheme, const ui
 /* (:205-262); whenever the DP values fit int16 that is the same as one dense  */
 /* forward pass, which is what is restated here.                              */
 /* ------------------------------------------------------------------------ */
-enum { DIR_SUBSTITUTION = 0, DIR_INSERTION = 1, DIR_DELETION = 2, DIR_SINK = 3, DIR_INSERTION_EXT = 4, DIR_DELETION_EXT = 8 };   /* alignment_base.h:139-150 */
 
 /* forward pass of gotoh_alignment_score_dispatch::run recording new_cell()'s cdir per cell; flags: M x band bytes */
 static int banded_gotoh_flow(uint32_t band, int type, const scheme_t* sc,

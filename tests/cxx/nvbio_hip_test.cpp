@@ -264,6 +264,27 @@ static int alignment_test()
     run_traceback_batch<7,  aln::SEMI_GLOBAL>("kat traceback banded-semi-global 7", aln::SimpleGotohScheme(2, -1, -1, -1), { string_to_dna(P1) }, { string_to_dna(T1) }, "4M1D3M");
     run_traceback_batch<31, aln::SEMI_GLOBAL>("kat traceback real banded Gotoh 31", aln::SimpleGotohScheme(0, -5, -8, -3), { string_to_dna(P2) }, { string_to_dna(T2) }, "147M2D3M");
 
+    // the full-matrix Gotoh CIGARs of the same functional test (alignment_test.cu:788-792)
+    {
+        const struct { aln::AlignmentType type; const char* cigar; } cases[3] = { { aln::GLOBAL, "1M2D3M1D3M10D" }, { aln::LOCAL, "4M1D3M" }, { aln::SEMI_GLOBAL, "4M1D3M" } };
+        PackedStringSetDevice<4, true> d_p(std::vector<std::vector<uint8> >(1, string_to_dna(P1)));
+        PackedStringSetDevice<2, true> d_t(std::vector<std::vector<uint8> >(1, string_to_dna(T1)));
+        hip::device_vector<int32> d_score(1); hip::device_vector<uint32> d_sink(2), d_source(2), d_len(1); hip::device_vector<io::Cigar> d_cigar(32);
+        const uint64 tsz = nvbio_hip_gotoh_traceback_temp_bytes(7, 20, 1);
+        hip::device_vector<uint8> d_temp(tsz);
+        aln::AlignmentArrays alns = { d_score.data(), d_source.data(), d_sink.data() };
+        aln::CigarArrays cigs = { d_cigar.data(), 32u, d_len.data() };
+        for (int c = 0; c < 3; ++c) {
+            const nvbio_hip_gotoh_scheme sc = { 2, -1, -1, -1 };
+            const nvbio_hip_string_set p = d_p.view().abi(), t = d_t.view().abi();
+            hip_check(nvbio_hip_gotoh_traceback(&sc, int32(cases[c].type), &p, &t, 7, 20, 1, alns.score, alns.sink, alns.source,
+                                                reinterpret_cast<uint16*>(cigs.cigar), 32u, cigs.cigar_len, d_temp.data(), tsz, nullptr), "nvbio_hip_gotoh_traceback");
+            hip::synchronize();
+            const std::vector<io::Cigar> cg = d_cigar.to_host(); const uint32 len = d_len.to_host()[0];
+            if (cigar_string(cg.data(), len) != cases[c].cigar) FAIL("full traceback type %d: expected %s, got %s", int(cases[c].type), cases[c].cigar, cigar_string(cg.data(), len).c_str());
+        }
+        fprintf(stderr, "    %-44s : 1M2D3M1D3M10D / 4M1D3M / 4M1D3M ok\n", "kat full-matrix traceback (global/local/semi)");
+    }
     // the throughput configuration of alignment_test.cu:1071-1194 (BAND=15, M=150, N=M+15), with
     // planted substitutions so that scores are not trivial; reads 4-bit LE, refs 2-bit LE as there
     const uint32 N_TASKS = 32768, M = 150, N = M + 15;

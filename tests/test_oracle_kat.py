@@ -426,3 +426,43 @@ def test_pattern_blocking_and_text_blocking_restatements_agree():
             else:
                 differs += int((ak != bk).any(1).sum())
     assert differs > 0
+
+
+def test_full_matrix_traceback_kats_and_properties():
+    """alignment_traceback (full matrix, Gotoh): the three CIGAR literals of the reference's functional test
+    (alignment_test.cu:788-792), and on random pairs the replayed alignment re-scores to the reported score."""
+    p, t = dna(KAT["strings"]["short_p"]), dna(KAT["strings"]["short_t"])
+    hp, ht = O.StringSet.from_lists([p], 4, True), O.StringSet.from_lists([t], 2, False)
+    for ty, lit in ((O.GLOBAL, "1M2D3M1D3M10D"), (O.LOCAL, "4M1D3M"), (O.SEMI_GLOBAL, "4M1D3M")):
+        r = O.gotoh_traceback(ty, (2, -1, -1, -1), hp, ht)
+        assert O.cigar_rle(r["ops"]) == lit
+        assert r["score"] == O.ref_sw_gotoh(ty, (2, -1, -1, -1), p, t)
+    rng = np.random.default_rng(12)
+    scheme = (2, -1, -2, -1)
+    for it in range(150):
+        M, N = int(rng.integers(1, 50)), int(rng.integers(1, 90))
+        t = rng.integers(0, 4, N).astype(np.uint8)
+        p = np.resize(t[int(rng.integers(0, N)):], M).copy()
+        mut = rng.random(M) < 0.15
+        p[mut] = rng.integers(0, 4, int(mut.sum()))
+        hp, ht = O.StringSet.from_lists([p], 4, True), O.StringSet.from_lists([t], 2, True)
+        for ty in (O.GLOBAL, O.LOCAL, O.SEMI_GLOBAL):
+            r = O.gotoh_traceback(ty, scheme, hp, ht)
+            sc_pb, sk_pb, _ = O.batch_score_pattern_blocking(0, ty, scheme, hp, ht)
+            assert r["score"] == int(sc_pb[0]) and r["sink"] == (int(sk_pb[0, 0]), int(sk_pb[0, 1]))
+            # replay from the source: x walks the text, y the pattern
+            x, y = r["source"]
+            s, prev = 0, None
+            for op in r["ops"][::-1]:
+                if op == 0:
+                    s += scheme[0] if p[y] == t[x] else scheme[1]; x += 1; y += 1
+                elif op == 2:
+                    s += scheme[3] if prev == 2 else scheme[2]; x += 1
+                else:
+                    s += scheme[3] if prev == 1 else scheme[2]; y += 1
+                prev = op
+            assert (x, y) == r["sink"] and s == r["score"], (ty, it)
+            if ty == O.GLOBAL:
+                assert r["source"] == (0, 0) and r["sink"] == (N, M)
+            if ty != O.LOCAL:
+                assert r["source"][1] == 0 and r["sink"][1] == M

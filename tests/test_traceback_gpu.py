@@ -125,3 +125,48 @@ def test_refusals(cuda):
         nvb.batch_banded_alignment_traceback(15, big, to_dev(hp, cuda), to_dev(ht, cuda), max_pattern_length=10)
     with pytest.raises(ValueError):
         nvb.BatchedBandedAlignmentTraceback(9)
+
+
+# ---------------------------------------------------------------------------- full-matrix traceback
+def test_full_matrix_cigar_kats_on_gpu(cuda):
+    """alignment_test.cu:788-792: the full-matrix Gotoh CIGARs"""
+    p, t = dna(KAT["strings"]["short_p"]), dna(KAT["strings"]["short_t"])
+    hp, ht = O.StringSet.from_lists([p], 4, True), O.StringSet.from_lists([t], 2, False)
+    for ty, lit in ((nvb.GLOBAL, "1M2D3M1D3M10D"), (nvb.LOCAL, "4M1D3M"), (nvb.SEMI_GLOBAL, "4M1D3M")):
+        got = nvb.batch_alignment_traceback(nvb.make_gotoh_aligner(ty, nvb.SimpleGotohScheme(2, -1, -1, -1)), to_dev(hp, cuda), to_dev(ht, cuda), len(p), len(t))
+        torch.cuda.synchronize()
+        k = int(got["cigar_len"][0])
+        cig = got["cigar"][0, :k].cpu().numpy().view(np.uint16)
+        assert "".join("%d%s" % (c >> 2, "MIDS"[c & 3]) for c in cig) == lit
+
+
+@pytest.mark.parametrize("ty", [nvb.GLOBAL, nvb.LOCAL, nvb.SEMI_GLOBAL])
+def test_full_matrix_traceback(cuda, ty):
+    """random pairs incl. the opposite-mate shape (150 bp in a 650-bp window): score, sink (pattern-blocking order),
+    source and CIGAR equal to the oracle's restatement of alignment_traceback"""
+    rng = np.random.default_rng(8100 + ty)
+    pats, txts = [], []
+    for i in range(600):
+        if i % 4 == 0:
+            M, N = 150, 650
+        else:
+            M, N = int(rng.integers(1, 140)), int(rng.integers(1, 300))
+        t = rng.integers(0, 4, N).astype(np.uint8)
+        off = int(rng.integers(0, max(1, N - M)))
+        p = np.resize(t[off:off + M] if N > off + 3 else rng.integers(0, 4, M).astype(np.uint8), M).copy()
+        mut = rng.random(M) < 0.06
+        p[mut] = rng.integers(0, 5, int(mut.sum()))
+        if M > 30 and i % 3 == 0:
+            cut = int(rng.integers(5, M - 5))
+            p = np.concatenate([p[:cut], p[cut + 3:], rng.integers(0, 4, 3).astype(np.uint8)])
+        pats.append(p); txts.append(t)
+    hp, ht = O.StringSet.from_lists(pats, 4, True), O.StringSet.from_lists(txts, 2, True)
+    for scheme in ((2, -1, -2, -1), (0, -6, -8, -3), (2, -6, -8, -3)):
+        stride = 40
+        exp = O.batch_gotoh_traceback(ty, scheme, hp, ht, stride)
+        got = nvb.batch_alignment_traceback(nvb.make_gotoh_aligner(ty, nvb.SimpleGotohScheme(*scheme)), to_dev(hp, cuda), to_dev(ht, cuda), 150, 650, cigar_stride=stride)
+        torch.cuda.synchronize()
+        compare(exp, got, (ty, scheme))
+        # the score pass of the same aligner (pattern blocking) agrees
+        gs, gk, _ = nvb.batch_alignment_score(nvb.make_gotoh_aligner(ty, nvb.SimpleGotohScheme(*scheme), nvb.PATTERN_BLOCKING), to_dev(hp, cuda), to_dev(ht, cuda), 150, 650)
+        assert torch.equal(gs, got["score"]) and torch.equal(gk, got["sink"])
