@@ -564,17 +564,28 @@ def extras_leg(a, dev):
     mate = torch.where(torch.rand((nw, 150), generator=g, device=dev) < 0.04, (mate + 1) & 3, mate)
     mp_ = nvb.PackedStringSet(W._pack_chunked(mate.reshape(-1), 4, True), 4, True, torch.arange(nw, dtype=torch.int64, device=dev) * 150, None, 150)
     wt = nvb.PackedStringSet(W._pack_chunked(win.reshape(-1), 2, True), 2, True, torch.arange(nw, dtype=torch.int64, device=dev) * wl, None, wl)
-    alo = nvb.make_gotoh_aligner(nvb.LOCAL, nvb.SimpleGotohScheme(2, -6, -8, -3))
+    alo = nvb.make_gotoh_aligner(nvb.LOCAL, nvb.SimpleGotohScheme(2, -6, -8, -3), nvb.PATTERN_BLOCKING)      # nvBowtie's aligners carry the default tag
     msc = torch.full((nw,), 100, dtype=torch.int32, device=dev)
     ms = _timed(lambda: nvb.batch_alignment_score(alo, mp_, wt, 150, wl, msc))
     gs, gk, go = nvb.batch_alignment_score(alo, mp_, wt, 150, wl, msc)
     m = 2000
     hp, ht = O.StringSet.from_device(mp_), O.StringSet.from_device(wt)
-    es, ek, eo = O.batch_gotoh_score(O.LOCAL, (2, -6, -8, -3), O.StringSet(hp.words, 4, True, hp.begin[:m], hp.length[:m]),
-                                     O.StringSet(ht.words, 2, True, ht.begin[:m], ht.length[:m]), min_score=np.full(m, 100, np.int32))
+    es, ek, eo = O.batch_score_pattern_blocking(0, O.LOCAL, (2, -6, -8, -3), O.StringSet(hp.words, 4, True, hp.begin[:m], hp.length[:m]),
+                                                O.StringSet(ht.words, 2, True, ht.begin[:m], ht.length[:m]), min_score=np.full(m, 100, np.int32))
     ok = bool((gs[:m].cpu().numpy() == es).all() and (gk[:m].cpu().numpy().view(np.uint32) == ek).all() and (go[:m].cpu().numpy() == eo).all())
     pe["opposite_mate_full_local"] = {"pairs": nw, "mate_len": 150, "window": wl, "kernel_ms": ms, "Mpairs_per_s": nw / ms / 1e3, "GCUPS": nw * 150 * wl / ms / 1e6,
                                       "parity_checked": m, "bit_exact": ok}
+    # opposite-mate traceback: full-matrix Gotoh traceback of the 150-bp mate in its 650-bp window
+    ntb = 200_000
+    tbp = nvb.PackedStringSet(mp_.words, 4, True, mp_.begin[:ntb].contiguous(), None, 150)
+    tbt = nvb.PackedStringSet(wt.words, 2, True, wt.begin[:ntb].contiguous(), None, wl)
+    ms = _timed(lambda: nvb.batch_alignment_traceback(alo, tbp, tbt, 150, wl, cigar_stride=32), reps=2)
+    got = nvb.batch_alignment_traceback(alo, tbp, tbt, 150, wl, cigar_stride=32)
+    m = 300
+    e = O.batch_gotoh_traceback(O.LOCAL, (2, -6, -8, -3), O.StringSet(hp.words, 4, True, hp.begin[:m], hp.length[:m]), O.StringSet(ht.words, 2, True, ht.begin[:m], ht.length[:m]), 32)
+    ok = all(bool((got[k][:m].cpu().numpy().view(e[k].dtype) == e[k][:m]).all()) for k in ("score", "sink", "source", "cigar_len", "cigar"))
+    pe["opposite_mate_full_traceback"] = {"pairs": ntb, "kernel_ms": ms, "Mpairs_per_s": ntb / ms / 1e3, "flag_bytes_per_pair": ((150 + 7) // 8 + 1) * wl * 4,
+                                          "parity_checked": m, "bit_exact": ok}
     out["paired_end_shapes"] = pe
     del win, mate, mp_, wt
     # ---- one-mismatch seed mappers + composed aligner on a forward + reverse index

@@ -262,6 +262,7 @@ __device__ __forceinline__ void cell16(uint32_t& e, uint32_t& hlg, uint32_t& hab
 
 __device__ __forceinline__ uint32_t c16(int32_t v) { return uint32_t(v) & 0xFFFFu; }
 __device__ __forceinline__ uint32_t max16u(uint32_t a, uint32_t b) { uint32_t r; asm("v_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ uint32_t min16u(uint32_t a, uint32_t b) { uint32_t r; asm("v_min_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 template <int TYPE, int R, bool CHECK, bool PBX = false>      // PBX: keep every row's maximum over the text (pattern-blocking early exit, non-LOCAL types)
 struct Sweep16
@@ -272,6 +273,7 @@ struct Sweep16
     uint32_t go, ge, sM, sX, inf16, init_above_g;
     uint64_t tb;
     uint32_t q[R], HLG[R], E[R], bestk[R], rmax[PBX ? R : 1];
+    uint32_t lim[CHECK ? R : 1];          // CHECK: 0x7FFF for this lane's valid rows, 0x8000 for rows past the pattern (they drop out of the column maximum)
     uint32_t out_hg, out_f, out_ch, out_cm, prev_in_hg;
     int32_t  sg_score; uint32_t sg_col, exit_col, grp;
     uint32_t sg_hg16;                     // SEMI_GLOBAL: best HG of this lane's last row so far (16-bit), its column in sg_col
@@ -299,6 +301,7 @@ struct Sweep16
             E[k]   = c16((TYPE == NVBIO_HIP_LOCAL) ? 0 : infimum);
             bestk[k] = 0u;
             if (PBX) rmax[k] = 0x8000u;
+            if (CHECK) lim[k] = (uint32_t(k) <= kl) ? 0x7FFFu : 0x8000u;
         }
         out_hg = out_f = out_ch = out_cm = prev_in_hg = 0;
         sg_score = -(1 << 30); sg_col = 0; exit_col = 0xFFFFFFFFu; grp = 0; sg_hg16 = 0x8000u;
@@ -310,7 +313,7 @@ struct Sweep16
     __device__ __forceinline__ void last_row(const uint32_t c, const uint32_t cm, const uint32_t hg_last)
     {
         const int32_t hlast = int32_t(int16_t(hg_last)) - Go;
-        if (TYPE == NVBIO_HIP_SEMI_GLOBAL) { if (int16_t(hg_last) >= int16_t(sg_hg16)) { sg_hg16 = hg_last; sg_col = c; } }
+        if (TYPE == NVBIO_HIP_SEMI_GLOBAL) { if (int16_t(hg_last) >= int16_t(sg_hg16) && (!CHECK || exit_col == 0xFFFFFFFFu)) { sg_hg16 = hg_last; sg_col = c; } }
         if (TYPE == NVBIO_HIP_GLOBAL && c + 1u == Nfull) { sg_score = hlast; sg_col = c; }
         early_exit_test(c, cm);
     }
@@ -351,7 +354,7 @@ struct Sweep16
                 cell16<TYPE>(E[k], HLG[k], hab_g, fab, diag_g, in_ch, q[k], go, ge, sM, sX, h);
                 if (TYPE == NVBIO_HIP_LOCAL) bestk[k] = max(bestk[k], (h << 20) | c);
                 if (PBX) rmax[k] = max16u(rmax[k], h);
-                if (CHECK) { if (uint32_t(k) <= kl) cm = max16u(cm, h); }
+                if (CHECK) cm = max16u(cm, min16u(h, lim[k]));
                 if (TYPE != NVBIO_HIP_LOCAL) hg_last = (uint32_t(k) == kl) ? hab_g : hg_last;   // HG of this lane's last valid row
             }
             out_hg = hab_g; out_f = fab; out_ch = in_ch; out_cm = cm;
@@ -365,11 +368,12 @@ struct Sweep16
                 // lane's record is read at the end); the final column never falls in this phase.
                 if (TYPE == NVBIO_HIP_SEMI_GLOBAL)
                 {
-                    const bool upd = int16_t(hg_last) >= int16_t(sg_hg16);
+                    // (after the reference's early exit the last row's record is frozen: its sink saw columns <= exit only)
+                    const bool upd = int16_t(hg_last) >= int16_t(sg_hg16) && (!CHECK || exit_col == 0xFFFFFFFFu);
                     sg_hg16 = upd ? hg_last : sg_hg16;
                     sg_col  = upd ? c : sg_col;
                 }
-                if (CHECK) { if (lane == lane_last) early_exit_test(c, cm); }
+                if (CHECK) { if (((s - lane_last) & 7u) == 7u) { if (lane == lane_last) early_exit_test(c, cm); } }   // wave-uniform outer test
             }
         }
     }
@@ -546,8 +550,18 @@ full_gotoh_score_kernel(const FullParams p)
         {
             // the reference returned false after this block: its sink saw columns [0, exit_col] only
             ok = 0u;
-            r = FAST ? sweep16<TYPE, R, false>(p, pb, tb, M, r.exit_col + 1u, N, min_score)
-                     : sweep<TYPE, R, TRUNC>(p, pb, tb, M, r.exit_col + 1u, N, false, min_score);
+            if (!FAST)
+                r = sweep<TYPE, R, TRUNC>(p, pb, tb, M, r.exit_col + 1u, N, false, min_score);
+            else if (TYPE == NVBIO_HIP_GLOBAL)
+                { r.score = -(1 << 30); r.sx = r.sy = 0xFFFFFFFFu; }            // the only report is at the last column
+            else if (TYPE == NVBIO_HIP_LOCAL)
+            {
+                // if the best cell of the whole matrix lies at or before the exit column it is also the best of the
+                // columns the reference visited (same total order); only otherwise sweep the truncated text again
+                if (!(r.sx != 0xFFFFFFFFu && r.sx - 1u <= r.exit_col))
+                    r = sweep16<TYPE, R, false>(p, pb, tb, M, r.exit_col + 1u, N, min_score);
+            }
+            // SEMI_GLOBAL: the last row's record was frozen at the exit column inside the sweep
         }
         score = r.score; sx = r.sx; sy = r.sy;
         // pattern blocking, GLOBAL, empty text: save_Mth reports the initial row (gotoh_inl.h:896-897)

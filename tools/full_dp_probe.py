@@ -1,0 +1,25 @@
+import torch, nvbio_amd as nvb
+from nvbio_amd import workloads as W
+dev = "cuda"
+def timed(fn, reps=3):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+g = torch.Generator(device=dev); g.manual_seed(8)
+for nw, wl in ((1_000_000, 650), (200_000, 650), (100_000, 4096)):
+    win = torch.randint(0, 4, (nw, wl), dtype=torch.uint8, generator=g, device=dev)
+    off = torch.randint(0, wl - 150, (nw,), generator=g, device=dev)
+    mate = win.gather(1, off.unsqueeze(1) + torch.arange(150, device=dev).unsqueeze(0))
+    mp_ = nvb.PackedStringSet(W._pack_chunked(mate.reshape(-1), 4, True), 4, True, torch.arange(nw, dtype=torch.int64, device=dev) * 150, None, 150)
+    wt = nvb.PackedStringSet(W._pack_chunked(win.reshape(-1), 2, True), 2, True, torch.arange(nw, dtype=torch.int64, device=dev) * wl, None, wl)
+    msc = torch.full((nw,), 100, dtype=torch.int32, device=dev)
+    for scheme in ((2, -6, -8, -3), (2, -1, -2, -1)):
+        for algo in (nvb.TEXT_BLOCKING, nvb.PATTERN_BLOCKING):
+            al = nvb.make_gotoh_aligner(nvb.LOCAL, nvb.SimpleGotohScheme(*scheme), algo)
+            for ms_t, nm in ((None, "no min_score"), (msc, "min_score=100")):
+                ms = timed(lambda: nvb.batch_alignment_score(al, mp_, wt, 150, wl, ms_t))
+                print("n %7d N %4d scheme %s algo %d %-13s: %7.2f ms %6.0f GCUPS [%s]" % (nw, wl, scheme, algo, nm, ms, nw * 150 * wl / ms / 1e6, nvb.lib().nvbio_hip_last_kernel().decode()))
+    del win, mate, mp_, wt
