@@ -62,3 +62,94 @@ def test_hip_path_reproduces_golden_vectors(cuda):
     assert (cc == G["map_counts"]).all() and (r.cpu().numpy() == G["map_reseed"]).all()
     for i in range(cc.size):
         assert (np.sort(hh[i, :cc[i]]) == np.sort(G["map_hits"][i, :cc[i]])).all()
+
+
+# ---------------------------------------------------------------------------- the rows built around the path
+E = np.load(os.path.join(HERE, "golden", "extension_vectors.npz"))
+MM_PARAMS = dict(seed_len=22, min_read_len=12, max_hits=100, max_reseed=2, retry=0, rep_seeds=300, fw=1, rc=1)
+TB_KEYS = ("score", "sink", "source", "cigar", "cigar_len")
+
+
+def _sorted_hits(h, c, stride):
+    return np.sort(np.where(np.arange(stride)[None, :] < c[:, None], h, np.uint64(2**64 - 1)), axis=1)
+
+
+def test_oracle_reproduces_extension_vectors():
+    hp = O.StringSet(E["tb_pw"], 4, True, E["tb_pb"], E["tb_pl"]); ht = O.StringSet(E["tb_tw"], 2, True, E["tb_tb"], E["tb_tl"])
+    for ty in (0, 1, 2):
+        r = O.batch_banded_gotoh_traceback(15, ty, (2, -1, -2, -1), hp, ht, 48)
+        for k in TB_KEYS:
+            assert (r[k] == E["tb_t%d_%s" % (ty, k)]).all(), (ty, k)
+    hp = O.StringSet(E["fu_pw"], 4, True, E["fu_pb"], E["fu_pl"]); ht = O.StringSet(E["fu_tw"], 2, False, E["fu_tb"], E["fu_tl"])
+    ms = E["fu_min_score"]
+    for ty in (0, 1, 2):
+        for tag, fn in (("tb", lambda: O.batch_gotoh_score(ty, (2, -1, -2, -1), hp, ht, min_score=ms)),
+                        ("pb", lambda: O.batch_score_pattern_blocking(0, ty, (2, -1, -2, -1), hp, ht, min_score=ms))):
+            s, k, ok = fn()
+            assert (s == E["fu_%s_t%d_score" % (tag, ty)]).all() and (k == E["fu_%s_t%d_sink" % (tag, ty)]).all() and (ok == E["fu_%s_t%d_ok" % (tag, ty)]).all()
+        s, k = O.batch_sw_score(0, ty, (0, -1, -1, -1), hp, ht)
+        assert (s == E["fu_ed_t%d_score" % ty]).all() and (k == E["fu_ed_t%d_sink" % ty]).all()
+        r = O.batch_gotoh_traceback(ty, (2, -1, -2, -1), hp, ht, 48)
+        for kk in TB_KEYS:
+            assert (r[kk] == E["fu_tr_t%d_%s" % (ty, kk)]).all(), (ty, kk)
+    f, rf = O.FMIndex(E["mm_text"]), O.FMIndex(E["mm_text"][::-1].copy())
+    hr = O.StringSet(E["mm_rw"], 4, True, E["mm_rb"], E["mm_rl"])
+    for algo, sub in ((1, 12), (2, 0)):
+        h, c, rs = O.map_seeds(algo, sub, f, rf, hr, MM_PARAMS, E["mm_sf"], 96)
+        assert (c == E["mm_a%d_counts" % algo]).all() and (rs == E["mm_a%d_reseed" % algo]).all() and (_sorted_hits(h, c, 96) == E["mm_a%d_hits" % algo]).all()
+    best = O.init_alignments(E["rd_read_len"], (0, -0.6, -0.6))
+    O.score_reduce(best, E["rd_hit_begin"], E["rd_score"], E["rd_loc"], E["rd_rc"], E["rd_read_len"])
+    assert (best == E["rd_best"]).all()
+    assert (O.mapq(2, 0, (0, -0.6, -0.6), True, best, E["rd_read_len"]) == E["rd_mapq2"]).all()
+    assert (O.mapq(3, 0, (0, -0.6, -0.6), True, best, E["rd_read_len"]) == E["rd_mapq3"]).all()
+
+
+@pytest.mark.gpu
+def test_hip_path_reproduces_extension_vectors(cuda):
+    import torch
+    import nvbio_amd as nvb
+
+    def dev_set(w, bits, be, b, ln):
+        return nvb.PackedStringSet.from_host(w, bits, be, b, ln, device=cuda)
+
+    def same(got, key, exp):
+        g = got[key].cpu().numpy()
+        n = exp.shape[0]
+        return (g.view(exp.dtype)[:n] == exp).all()
+
+    p, t = dev_set(E["tb_pw"], 4, True, E["tb_pb"], E["tb_pl"]), dev_set(E["tb_tw"], 2, True, E["tb_tb"], E["tb_tl"])
+    gotoh = lambda ty, algo=nvb.TEXT_BLOCKING: nvb.make_gotoh_aligner(ty, nvb.SimpleGotohScheme(2, -1, -2, -1), algo)
+    for ty in (0, 1, 2):
+        got = nvb.batch_banded_alignment_traceback(15, gotoh(ty), p, t, max_pattern_length=int(E["tb_pl"].max()), cigar_stride=48)
+        for k in TB_KEYS:
+            assert same(got, k, E["tb_t%d_%s" % (ty, k)]), (ty, k)
+    p, t = dev_set(E["fu_pw"], 4, True, E["fu_pb"], E["fu_pl"]), dev_set(E["fu_tw"], 2, False, E["fu_tb"], E["fu_tl"])
+    maxM, maxN = int(E["fu_pl"].max()), int(E["fu_tl"].max())
+    ms = torch.from_numpy(E["fu_min_score"]).to(cuda)
+    for ty in (0, 1, 2):
+        for tag, algo in (("tb", nvb.TEXT_BLOCKING), ("pb", nvb.PATTERN_BLOCKING)):
+            s, k, ok = nvb.batch_alignment_score(gotoh(ty, algo), p, t, maxM, maxN, ms)
+            assert (s.cpu().numpy() == E["fu_%s_t%d_score" % (tag, ty)]).all() and (k.cpu().numpy().view(np.uint32) == E["fu_%s_t%d_sink" % (tag, ty)]).all()
+            assert (ok.cpu().numpy() == E["fu_%s_t%d_ok" % (tag, ty)]).all()
+        s, k, _ = nvb.batch_alignment_score(nvb.make_edit_distance_aligner(ty), p, t, maxM, maxN)
+        assert (s.cpu().numpy() == E["fu_ed_t%d_score" % ty]).all() and (k.cpu().numpy().view(np.uint32) == E["fu_ed_t%d_sink" % ty]).all()
+        got = nvb.batch_alignment_traceback(gotoh(ty), p, t, maxM, maxN, cigar_stride=48)
+        for kk in TB_KEYS:
+            assert same(got, kk, E["fu_tr_t%d_%s" % (ty, kk)]), (ty, kk)
+    fmi = nvb.FMIndexDevice.from_host(O.FMIndex(E["mm_text"]), cuda)
+    rfmi = nvb.FMIndexDevice.from_host(O.FMIndex(E["mm_text"][::-1].copy()), cuda)
+    reads = dev_set(E["mm_rw"], 4, True, E["mm_rb"], E["mm_rl"])
+    for algo, sub in ((1, 12), (2, 0)):
+        h, c, rs = nvb.map_seeds(fmi, rfmi, reads, nvb.MappingParams(), 79, allow_sub=1, subseed_len=sub, hits_stride=96)
+        cc = c.cpu().numpy().view(np.uint32)
+        assert (cc == E["mm_a%d_counts" % algo]).all() and (rs.cpu().numpy() == E["mm_a%d_reseed" % algo]).all()
+        assert (_sorted_hits(h.cpu().numpy().view(np.uint64), cc, 96) == E["mm_a%d_hits" % algo]).all()
+    i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(cuda)
+    sch = nvb.SmithWatermanScoringScheme()
+    rl = i32(E["rd_read_len"])
+    best = nvb.BestAlignments(E["rd_read_len"].size, sch, read_len=rl, max_read_len=200, device=cuda)
+    nvb.score_reduce(best, torch.from_numpy(E["rd_hit_begin"].view(np.int64)).to(cuda), i32(E["rd_score"]), i32(E["rd_loc"]),
+                     torch.from_numpy(E["rd_rc"]).to(cuda), read_len=rl)
+    assert (best.data.cpu().numpy().view(np.uint64) == E["rd_best"]).all()
+    assert (nvb.mapq(best, sch, read_len=rl, version=2, max_read_len=200).cpu().numpy() == E["rd_mapq2"]).all()
+    assert (nvb.mapq(best, sch, read_len=rl, version=3, max_read_len=200).cpu().numpy() == E["rd_mapq3"]).all()
