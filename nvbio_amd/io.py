@@ -167,3 +167,82 @@ def save_fmindex(prefix, host_index, reverse=False):
     cum = np.cumsum(np.bincount(np.asarray(host_index.bwt, dtype=np.uint8), minlength=4)[:4]).astype(np.uint32)
     write_bwt(prefix + (".rbwt" if reverse else ".bwt"), host_index.primary, cum, words, n)
     write_sa(prefix + (".rsa" if reverse else ".sa"), host_index.primary, cum, host_index.ssa, n, host_index.sa_int)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# reads: FASTQ -> the packed SequenceData layout (nvbio/io/sequence/sequence_fastq.cpp, sequence_encoder.cpp:118-230)
+# ----------------------------------------------------------------------------------------------------------------------
+SEQ_FORWARD, SEQ_REVERSE, SEQ_FORWARD_COMPLEMENT, SEQ_REVERSE_COMPLEMENT = 0x1, 0x2, 0x4, 0x8     # SequenceEncoding (sequence.h:172-178)
+PHRED, PHRED33, PHRED64, SOLEXA = 0, 1, 2, 3                                                       # QualityEncoding (sequence.h:163-169)
+
+_NT4 = np.full(256, 4, dtype=np.uint8)                     # nst_nt4_encode: ACGT (either case) -> 0..3, anything else -> 4
+for _c, _v in zip("ACGTacgt", (0, 1, 2, 3, 0, 1, 2, 3)):
+    _NT4[ord(_c)] = _v
+_SOLEXA_TO_PHRED = np.array([0, 1, 1, 1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 7, 8, 9, 10] + list(range(10, 246)), dtype=np.uint8)
+
+
+class SequenceDataHost:
+    """io::SequenceDataHost for DNA_N reads: symbols 4-bit big-endian packed (sequence_traits.h), `sequence_index`
+    (n+1 symbol offsets), one phred byte per symbol, names."""
+
+    def __init__(self, symbols, index, quals, names):
+        self.symbols, self.sequence_index, self.quals, self.names = symbols, index, quals, names
+
+    def size(self):
+        return self.sequence_index.size - 1
+
+    def bps(self):
+        return int(self.sequence_index[-1])
+
+    def max_sequence_len(self):
+        return int(np.diff(self.sequence_index).max()) if self.size() else 0
+
+    def to_device(self, device="cuda"):
+        """-> (PackedStringSet over the 4-bit big-endian stream, quals uint8 tensor)"""
+        from .strings import PackedStringSet, pack_symbols
+        words = pack_symbols(torch.from_numpy(self.symbols), 4, True).to(device)
+        begin = torch.from_numpy(self.sequence_index[:-1].astype(np.int64)).to(device)
+        length = torch.from_numpy(np.diff(self.sequence_index).astype(np.int32)).to(device)
+        return PackedStringSet(words, 4, True, begin, length, 0), torch.from_numpy(self.quals).to(device)
+
+
+def _convert_quality(q, encoding):
+    if encoding == PHRED33:
+        return (q - 33).astype(np.uint8)
+    if encoding == PHRED64:
+        return (q - 64).astype(np.uint8)
+    if encoding == SOLEXA:
+        return _SOLEXA_TO_PHRED[q]
+    return q.astype(np.uint8)
+
+
+def read_fastq(path, max_reads=None, flags=SEQ_FORWARD, quality_encoding=PHRED33):
+    """Loads a (plain-text, 4-line-record) FASTQ file the way the reference's loader encodes it: each strand
+    requested in `flags` is appended per read in the order FORWARD, REVERSE, FORWARD_COMPLEMENT, REVERSE_COMPLEMENT
+    (sequence_encoder.cpp:265-300); bases through nst_nt4_encode; qualities converted to phred and reversed with the
+    read.  nvBowtie loads its reads with io::REVERSE (nvBowtie.cpp:579)."""
+    syms, quals, names, lens = [], [], [], []
+    with open(path, "rb") as f:
+        while max_reads is None or len(names) < max_reads:
+            h = f.readline()
+            if not h:
+                break
+            if not h.startswith(b"@"):
+                raise IOError("FASTQ: record does not start with '@' at read %d" % len(names))
+            seq = f.readline().rstrip(b"\r\n")
+            plus = f.readline()
+            ql = f.readline().rstrip(b"\r\n")
+            if not plus.startswith(b"+") or len(ql) != len(seq):
+                raise IOError("FASTQ: malformed record %d" % len(names))
+            bp = _NT4[np.frombuffer(seq, dtype=np.uint8)]
+            q = _convert_quality(np.frombuffer(ql, dtype=np.uint8), quality_encoding)
+            comp = np.where(bp < 4, 3 - bp, 4).astype(np.uint8)
+            for flag, s_, q_ in ((SEQ_FORWARD, bp, q), (SEQ_REVERSE, bp[::-1], q[::-1]),
+                                 (SEQ_FORWARD_COMPLEMENT, comp, q), (SEQ_REVERSE_COMPLEMENT, comp[::-1], q[::-1])):
+                if flags & flag:
+                    syms.append(s_); quals.append(q_); lens.append(len(seq))
+            names.append(h[1:].split()[0].decode() if len(h) > 1 else "")
+    index = np.zeros(len(lens) + 1, dtype=np.uint32)
+    index[1:] = np.cumsum(lens)
+    cat = lambda xs: np.concatenate(xs).astype(np.uint8) if xs else np.zeros(0, np.uint8)
+    return SequenceDataHost(cat(syms), index, cat(quals), names)

@@ -88,3 +88,63 @@ def test_index_round_trip_through_files(tmp_path, cuda):
     # SA-less load
     d2 = nio.FMIndexDataDevice(prefix, flags=nio.FORWARD, device=cuda)
     assert d2.index().ssa is None and d2.rindex() is None
+
+
+def test_fastq_to_sequence_data(tmp_path):
+    """FASTQ -> SequenceData (sequence_encoder.cpp): base codes, phred conversion, strand encodings and 4-bit BE packing"""
+    fq = tmp_path / "r.fastq"
+    fq.write_text("@r1 extra\nACGTNacgtn\n+\nIIII#5555!\n@r2\nTTGCA\n+r2\nABCDE\n")
+    d = nio.read_fastq(str(fq))
+    assert d.size() == 2 and d.names == ["r1", "r2"] and d.sequence_index.tolist() == [0, 10, 15]
+    assert d.symbols.tolist() == [0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 3, 3, 2, 1, 0]
+    assert d.quals[:10].tolist() == [40, 40, 40, 40, 2, 20, 20, 20, 20, 0] and d.quals[10:].tolist() == [32, 33, 34, 35, 36]
+    r = nio.read_fastq(str(fq), flags=nio.SEQ_REVERSE)                       # what nvBowtie loads
+    assert r.symbols[:10].tolist() == [4, 3, 2, 1, 0, 4, 3, 2, 1, 0] and r.quals[:10].tolist() == [0, 20, 20, 20, 20, 2, 40, 40, 40, 40]
+    both = nio.read_fastq(str(fq), flags=nio.SEQ_FORWARD | nio.SEQ_REVERSE_COMPLEMENT, max_reads=1)
+    assert both.size() == 2 and both.symbols[10:].tolist() == [4, 0, 1, 2, 3, 4, 0, 1, 2, 3]     # rc: N stays N
+    p64 = nio.read_fastq(str(fq), quality_encoding=nio.PHRED64)
+    assert p64.quals[10] == (ord("A") - 64)
+    # the packed stream is what the kernels read: symbol i of the set at bits 28 - 4*(i % 8) of word i / 8
+    import torch
+    from nvbio_amd.strings import pack_symbols
+    w = pack_symbols(torch.from_numpy(d.symbols), 4, True).numpy().view(np.uint32)
+    assert [(int(w[i // 8]) >> (28 - 4 * (i % 8))) & 15 for i in range(15)] == d.symbols.tolist()
+    with pytest.raises(IOError):
+        bad = tmp_path / "bad.fastq"; bad.write_text("@x\nACGT\n+\nII\n"); nio.read_fastq(str(bad))
+
+
+@pytest.mark.gpu
+def test_files_to_sam_example(tmp_path, cuda):
+    """index files + genome + FASTQ -> SAM through tools/align_fastq.py: reads come back at the positions they were drawn
+    from, on the right strand, with CIGARs that consume the read"""
+    import io as _io, sys, re
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import align_fastq
+    rng = np.random.default_rng(3)
+    text = rng.integers(0, 4, 200_000, dtype=np.uint8)
+    prefix = str(tmp_path / "g")
+    nio.save_fmindex(prefix, O.FMIndex(text))
+    nio.write_wpac(prefix + ".wpac", text.size, O.pack(text, 2, True))
+    L, n = 100, 300
+    pos = rng.integers(0, text.size - L, n)
+    with open(prefix + ".fastq", "w") as f:
+        for i, p in enumerate(pos):
+            r = text[p:p + L].copy()
+            mut = rng.random(L) < 0.03
+            r[mut] = (r[mut] + 1) & 3
+            if i % 2:
+                r = (3 - r)[::-1]
+            f.write("@read%d\n%s\n+\n%s\n" % (i, "".join("ACGT"[c] for c in r), "I" * L))
+    buf = _io.StringIO()
+    align_fastq.main(prefix, prefix + ".fastq", buf, device=cuda)
+    lines = [ln.split("\t") for ln in buf.getvalue().splitlines() if not ln.startswith("@")]
+    assert len(lines) == n
+    aligned = [ln for ln in lines if ln[1] != "4"]
+    assert len(aligned) > 0.9 * n
+    good = 0
+    for ln in aligned:
+        i = int(ln[0][4:])
+        consumed = sum(int(k) for k, op in re.findall(r"(\d+)([MIDS])", ln[5]) if op in "MIS")
+        assert consumed == L
+        good += (int(ln[3]) - 1 == pos[i]) and (ln[1] == ("16" if i % 2 else "0"))
+    assert good > 0.95 * len(aligned)

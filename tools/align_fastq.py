@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Real-data flow through the library: <prefix>.bwt/.sa (+ .wpac/.pac genome) and a FASTQ file of equal-length reads ->
+SAM lines (seed, locate, extend, reduce, MAPQ, traceback: nvbio_amd.pipeline.align_single_end).  A usage example, not
+nvBowtie's CLI: mandatory SAM fields + AS:i / XS:i only, single reference sequence, no read groups.
+
+    python tools/align_fastq.py <index prefix> <reads.fastq> [out.sam]"""
+import sys
+
+import numpy as np
+import torch
+
+import nvbio_amd as nvb
+from nvbio_amd import io as nio, pipeline as P
+
+
+def cigar_string(words, length):
+    """io::Cigar words are stored end-first; SAM wants them start-first"""
+    ops = [(int(w) & 3, (int(w) & 0xFFFF) >> 2) for w in words[:length]][::-1]
+    return "".join("%d%s" % (n, "MIDS"[t]) for t, n in ops) or "*"
+
+
+def main(prefix, fastq, out=sys.stdout, device="cuda", ref_name="ref"):
+    data = nio.FMIndexDataDevice(prefix, flags=nio.FORWARD | nio.SA, device=device)
+    n_genome, g_words = nio.load_genome(prefix)
+    genome_words = torch.from_numpy(np.concatenate([g_words, np.zeros(8, np.uint32)]).view(np.int32)).to(device)
+    reads = nio.read_fastq(fastq)
+    lens = np.diff(reads.sequence_index)
+    if reads.size() == 0 or (lens != lens[0]).any():
+        raise SystemExit("align_fastq: this example needs equal-length reads")
+    L = int(lens[0])
+    sym = torch.from_numpy(reads.symbols.reshape(reads.size(), L)).to(device)
+    mp = nvb.MappingParams()
+    be = P.HipBackend(data.index(), None, mp, L)
+    r = P.align_single_end(be, sym, genome_words, n_genome, cigar_stride=64)
+    torch.cuda.synchronize()
+    best = r["best"].cpu().numpy().view(np.uint64)
+    mapq, cig, clen = r["mapq"].cpu().numpy(), r["cigar"].cpu().numpy().view(np.uint16), r["cigar_len"].cpu().numpy()
+    source = r["source"].cpu().numpy()
+    out.write("@HD\tVN:1.0\tSO:unsorted\n@SQ\tSN:%s\tLN:%d\n@PG\tID:nvbio_amd\tPN:nvbio_amd\n" % (ref_name, n_genome))
+    quals = reads.quals.reshape(reads.size(), L)
+    for i in range(reads.size()):
+        w, pos = int(best[0, i] & 0xFFFFFFFF), int(best[0, i] >> 32)
+        seq = reads.symbols[i * L:(i + 1) * L]
+        if pos == 0xFFFFFFFF:
+            out.write("%s\t4\t*\t0\t0\t*\t*\t0\t0\t%s\t%s\n" % (reads.names[i], "".join("ACGTN"[c] for c in seq), "".join(chr(int(q) + 33) for q in quals[i])))
+            continue
+        rc = (w >> 28) & 1
+        score = ((w >> 1) & 0x1FFFF) * (-1 if w & 1 else 1)
+        s, q = (np.where(seq < 4, 3 - seq, 4)[::-1], quals[i][::-1]) if rc else (seq, quals[i])
+        tags = "AS:i:%d" % score
+        w2 = int(best[1, i] & 0xFFFFFFFF)
+        if int(best[1, i] >> 32) != 0xFFFFFFFF:
+            tags += "\tXS:i:%d" % (((w2 >> 1) & 0x1FFFF) * (-1 if w2 & 1 else 1))
+        out.write("%s\t%d\t%s\t%d\t%d\t%s\t*\t0\t0\t%s\t%s\t%s\n" % (
+            reads.names[i], 16 if rc else 0, ref_name, pos + int(source[i, 0]) + 1, int(mapq[i]), cigar_string(cig[i], int(clen[i])),
+            "".join("ACGTN"[c] for c in s), "".join(chr(int(x) + 33) for x in q), tags))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) < 3:
+        raise SystemExit(__doc__)
+    if len(sys.argv) > 3:
+        with open(sys.argv[3], "w") as f:
+            main(sys.argv[1], sys.argv[2], f)
+    else:
+        main(sys.argv[1], sys.argv[2])
