@@ -213,6 +213,24 @@ int nvbio_hip_gotoh_traceback(
     uint16_t* out_cigar, uint32_t cigar_stride, uint32_t* out_cigar_len,
     void* temp, uint64_t temp_bytes, void* stream);
 
+/* The tracebacks for SmithWatermanAligner / EditDistanceAligner (deletion == insertion), banded (sw_banded_inl.h:405-470,
+ * 748-800) and full matrix (sw_inl.h:389-396, 475-500, 1660-1700): arguments and temp sizes as the Gotoh forms.  The banded
+ * reference context does not mark zero cells, so its LOCAL walk always reaches the first pattern row; reproduced. */
+int nvbio_hip_banded_sw_traceback(
+    const nvbio_hip_sw_scheme* scheme /* host */, int32_t type, uint32_t band_len,
+    const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len, uint32_t n,
+    int32_t* out_score, uint32_t* out_sink, uint32_t* out_source,
+    uint16_t* out_cigar, uint32_t cigar_stride, uint32_t* out_cigar_len,
+    void* temp, uint64_t temp_bytes, void* stream);
+int nvbio_hip_sw_traceback(
+    const nvbio_hip_sw_scheme* scheme /* host */, int32_t type,
+    const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len, uint32_t n,
+    int32_t* out_score, uint32_t* out_sink, uint32_t* out_source,
+    uint16_t* out_cigar, uint32_t cigar_stride, uint32_t* out_cigar_len,
+    void* temp, uint64_t temp_bytes, void* stream);
+
 /* nvbio::fm_index<rank_dictionary<2,64,PackedStream<.,uint8,2,true>,.,.>, SSA_index_multiple_context<SA_INT>, const uint32*>
  * (nvbio/fmindex/fmindex.h:341-387) in the production interleaved layout
  * (nvbio/io/fmindex/fmindex.h:159-174, fmindex_impl.cu:305-327):

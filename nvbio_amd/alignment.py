@@ -230,7 +230,10 @@ class BatchedBandedAlignmentTraceback:
                 C.c_void_p(out_score.data_ptr()), C.c_void_p(out_sink.data_ptr()), C.c_void_p(out_source.data_ptr()),
                 C.c_void_p(out_cigar.data_ptr()), int(out_cigar.shape[1]), C.c_void_p(out_cigar_len.data_ptr()),
                 C.c_void_p(temp.data_ptr()), temp.numel() * temp.element_size(), current_stream_ptr())
-        if isinstance(aligner.scheme, SmithWatermanScoringScheme):
+        if isinstance(aligner, SmithWatermanAligner):
+            err = lib().nvbio_hip_banded_sw_traceback(C.byref(sc), aligner.type, self.band_len, C.byref(ps), C.byref(ts), *tail)
+            check(err, "nvbio_hip_banded_sw_traceback")
+        elif isinstance(aligner.scheme, SmithWatermanScoringScheme):
             assert quals is not None and quals.dtype == torch.uint8 and quals.is_cuda and quals.is_contiguous()
             err = lib().nvbio_hip_banded_gotoh_traceback_qual(
                 C.byref(sc), aligner.type, self.band_len, C.byref(ps), C.c_void_p(quals.data_ptr()), quals.numel(), C.byref(ts), *tail)
@@ -264,7 +267,7 @@ def batch_alignment_traceback(aligner, patterns, texts, max_pattern_length=0, ma
     """BatchedAlignmentTraceback<CHECKPOINTS, stream>::enact (batched.h:432-452) for the full-matrix Gotoh aligner with
     nvBowtie's backtracer: returns dict(score, sink, source, cigar int16[n,stride], cigar_len) as the banded form does."""
     n = len(patterns)
-    assert len(texts) == n and isinstance(aligner.scheme, SimpleGotohScheme)
+    assert len(texts) == n and isinstance(aligner.scheme, (SimpleGotohScheme, SimpleSmithWatermanScheme))
     dev = patterns.words.device
     maxM = max_pattern_length or patterns.fixed_length
     maxN = max_text_length or texts.fixed_length
@@ -275,11 +278,12 @@ def batch_alignment_traceback(aligner, patterns, texts, max_pattern_length=0, ma
                cigar_len=torch.empty(n, dtype=torch.int32, device=dev))
     sc = aligner.scheme.struct()
     ps, ts = patterns.struct(), texts.struct()
-    err = lib().nvbio_hip_gotoh_traceback(C.byref(sc), aligner.type, C.byref(ps), C.byref(ts), int(maxM), int(maxN), n,
+    fn = lib().nvbio_hip_sw_traceback if isinstance(aligner, SmithWatermanAligner) else lib().nvbio_hip_gotoh_traceback
+    err = fn(C.byref(sc), aligner.type, C.byref(ps), C.byref(ts), int(maxM), int(maxN), n,
                                           C.c_void_p(out["score"].data_ptr()), C.c_void_p(out["sink"].data_ptr()), C.c_void_p(out["source"].data_ptr()),
                                           C.c_void_p(out["cigar"].data_ptr()), cigar_stride, C.c_void_p(out["cigar_len"].data_ptr()),
                                           C.c_void_p(temp.data_ptr()), temp.numel(), current_stream_ptr())
-    check(err, "nvbio_hip_gotoh_traceback")
+    check(err, "nvbio_hip_{gotoh,sw}_traceback")
     temp.record_stream(torch.cuda.current_stream())
     return out
 

@@ -34,6 +34,7 @@ struct TracebackParams {
     uint32_t        cigar_stride;
     uint32_t*       out_cigar_len;
     uint64_t*       flags;          // [row][word][job]
+    uint32_t        no_sink;        // SW / ED aligners: the banded submatrix context stores the direction only (sw_banded_inl.h:269-279)
 };
 
 template <uint32_t BAND>
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void banded_gotoh_traceback_kernel(const Trace
                 const int32_t top = F[0];
                 int32_t  hi   = max(top, diagonal);
                 uint32_t hdir = top > diagonal ? INSERTION : SUBSTITUTION;
-                if (TYPE == NVBIO_HIP_LOCAL) { hi = max(hi, 0); if (hi == 0) hdir = SINK; report(hi, i + 1, i + 1); }
+                if (TYPE == NVBIO_HIP_LOCAL) { hi = max(hi, 0); if (hi == 0 && !p.no_sink) hdir = SINK; report(hi, i + 1, i + 1); }
                 H[0] = hi;
                 row.set(0, hdir | fdir);
             }
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void banded_gotoh_traceback_kernel(const Trace
                 const int32_t top = F[j], left = E;
                 int32_t  hi   = max(max(top, left), diagonal);
                 uint32_t hdir = top > left ? (top > diagonal ? INSERTION : SUBSTITUTION) : (left > diagonal ? DELETION : SUBSTITUTION);
-                if (TYPE == NVBIO_HIP_LOCAL) { hi = max(hi, 0); if (hi == 0) hdir = SINK; report(hi, i + j + 1, i + 1); }
+                if (TYPE == NVBIO_HIP_LOCAL) { hi = max(hi, 0); if (hi == 0 && !p.no_sink) hdir = SINK; report(hi, i + j + 1, i + 1); }
                 H[j] = hi;
                 row.set(j, hdir | edir | fdir);
                 const int32_t eleft = E + G_e, ediagonal = hi + G_o;
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void banded_gotoh_traceback_kernel(const Trace
                 const int32_t left = E;
                 int32_t  hi   = max(left, diagonal);
                 uint32_t hdir = left > diagonal ? DELETION : SUBSTITUTION;
-                if (TYPE == NVBIO_HIP_LOCAL) { hi = max(hi, 0); if (hi == 0) hdir = SINK; report(hi, i + BAND, i + 1); }
+                if (TYPE == NVBIO_HIP_LOCAL) { hi = max(hi, 0); if (hi == 0 && !p.no_sink) hdir = SINK; report(hi, i + BAND, i + 1); }
                 H[BAND - 1] = hi;
                 row.set(BAND - 1, hdir | edir);
             }
@@ -255,7 +256,7 @@ NVB_API int nvbio_hip_banded_gotoh_traceback(
     using namespace nvb;
     if (!scheme) return hipErrorInvalidValue;
     TracebackParams p;
-    p.quals = nullptr; p.n_quals = 0;
+    p.quals = nullptr; p.n_quals = 0; p.no_sink = 0;
     p.match = scheme->match;
     p.gap_open = scheme->gap_open; p.gap_ext = scheme->gap_ext;
     p.txt_gap_open = scheme->gap_open; p.txt_gap_ext = scheme->gap_ext;
@@ -279,13 +280,38 @@ NVB_API int nvbio_hip_banded_gotoh_traceback_qual(
     if (!scheme) return hipErrorInvalidValue;
     if (n != 0 && (!quals || n_quals == 0)) return hipErrorInvalidValue;
     TracebackParams p;
-    p.quals = quals; p.n_quals = n_quals;
+    p.quals = quals; p.n_quals = n_quals; p.no_sink = 0;
     p.match = scheme->match;
     p.gap_open = scheme->pattern_gap_open; p.gap_ext = scheme->pattern_gap_ext;
     p.txt_gap_open = scheme->text_gap_open; p.txt_gap_ext = scheme->text_gap_ext;
     int64_t A = std::max(std::max(tb_abs(scheme->match), tb_abs(scheme->pattern_gap_open)), std::max(tb_abs(scheme->pattern_gap_ext),
                 std::max(tb_abs(scheme->text_gap_open), tb_abs(scheme->text_gap_ext))));
     for (int i = 0; i < 256; ++i) { p.mismatch[i] = scheme->mismatch[i]; A = std::max(A, tb_abs(scheme->mismatch[i])); }
+    return traceback_common(p, A, type, band_len, patterns, texts, max_pattern_len, n, out_score, out_sink, out_source,
+                            out_cigar, cigar_stride, out_cigar_len, temp, temp_bytes, to_stream(stream));
+}
+
+// SmithWatermanAligner / EditDistanceAligner in the band (sw_banded_inl.h:405-470, 748-800): with deletion == insertion the
+// directions are those of the Gotoh recurrence with gap_open == gap_ext; the reference's banded SW context does not mark
+// zero cells as SINK, so a LOCAL walk runs to the first pattern row -- kept.
+NVB_API int nvbio_hip_banded_sw_traceback(
+    const nvbio_hip_sw_scheme* scheme, int32_t type, uint32_t band_len,
+    const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len, uint32_t n,
+    int32_t* out_score, uint32_t* out_sink, uint32_t* out_source,
+    uint16_t* out_cigar, uint32_t cigar_stride, uint32_t* out_cigar_len,
+    void* temp, uint64_t temp_bytes, void* stream)
+{
+    (void)max_text_len;
+    using namespace nvb;
+    if (!scheme) return hipErrorInvalidValue;
+    if (scheme->deletion != scheme->insertion) return hipErrorNotSupported;
+    TracebackParams p;
+    p.quals = nullptr; p.n_quals = 0; p.no_sink = 1;
+    p.match = scheme->match;
+    p.gap_open = p.gap_ext = p.txt_gap_open = p.txt_gap_ext = scheme->deletion;
+    for (int i = 0; i < 256; ++i) p.mismatch[i] = scheme->mismatch;
+    const int64_t A = std::max(std::max(tb_abs(scheme->match), tb_abs(scheme->mismatch)), tb_abs(scheme->deletion));
     return traceback_common(p, A, type, band_len, patterns, texts, max_pattern_len, n, out_score, out_sink, out_source,
                             out_cigar, cigar_stride, out_cigar_len, temp, temp_bytes, to_stream(stream));
 }

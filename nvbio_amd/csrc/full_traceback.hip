@@ -30,7 +30,7 @@ struct FullTbParams {
     uint32_t* column;     // [text row][job]: {int16 H, int16 E} of the last pattern column of the previous block
 };
 
-template <int TYPE>
+template <int TYPE, uint32_t BL>      // BL: pattern symbols per block of the reference's score pass (8 Gotoh, 16 SW / ED): fixes the sink's tie order
 __global__ void __launch_bounds__(256) full_gotoh_traceback_kernel(const FullTbParams p)
 {
     const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
@@ -46,7 +46,6 @@ __global__ void __launch_bounds__(256) full_gotoh_traceback_kernel(const FullTbP
 
     const int32_t G_o = p.gap_open, G_e = p.gap_ext;
     const int32_t infimum = -32768 - min(G_o, G_e);
-    constexpr uint32_t BL = 8u;
     const uint32_t n_blocks = max(1u, (M + BL - 1u) / BL);
     int32_t H_band[BL + 1], F_band[BL + 1];
     uint32_t q_cache[BL];
@@ -79,7 +78,9 @@ __global__ void __launch_bounds__(256) full_gotoh_traceback_kernel(const FullTbP
                 E      = int32_t(int16_t(c >> 16));
             }
             H_band[0] = temp_i;
-            uint32_t word = 0;
+            uint32_t word[BL / 8u];
+            #pragma unroll
+            for (uint32_t w8 = 0; w8 < BL / 8u; ++w8) word[w8] = 0;
             #pragma unroll
             for (uint32_t j = 1; j <= BL; ++j)
             {
@@ -97,11 +98,13 @@ __global__ void __launch_bounds__(256) full_gotoh_traceback_kernel(const FullTbP
                 if (TYPE == NVBIO_HIP_LOCAL && hi == 0) hdir = T_SINK;
                 H_diag = H_band[j];
                 H_band[j] = hi;
-                word |= (hdir | edir | fdir) << (4u * (j - 1u));
+                word[(j - 1u) >> 3] |= (hdir | edir | fdir) << (4u * ((j - 1u) & 7u));
                 if (TYPE == NVBIO_HIP_LOCAL) { if (block + j <= M) report(hi, i + 1u, block + j); }
             }
             p.column[uint64_t(i) * n + tid] = (uint32_t(H_band[BL]) & 0xFFFFu) | (uint32_t(E) << 16);     // make_vector<short> (:565)
-            __builtin_nontemporal_store(word, p.flags + (uint64_t(blk) * p.max_text_len + i) * n + tid);
+            #pragma unroll
+            for (uint32_t w8 = 0; w8 < BL / 8u; ++w8)
+                __builtin_nontemporal_store(word[w8], p.flags + (uint64_t(blk * (BL / 8u) + w8) * p.max_text_len + i) * n + tid);
             if (TYPE == NVBIO_HIP_SEMI_GLOBAL && last)
             {
                 // save_boundary -> save_Mth: H[i][M] (utils_inl.h:206-226,279-299)
@@ -166,12 +169,12 @@ using namespace nvb;
 
 NVB_API uint64_t nvbio_hip_gotoh_traceback_temp_bytes(uint32_t max_pattern_len, uint32_t max_text_len, uint32_t n)
 {
-    const uint64_t blocks = std::max<uint64_t>(1u, (uint64_t(max_pattern_len) + 7u) / 8u);
+    const uint64_t blocks = 2u * std::max<uint64_t>(1u, (uint64_t(max_pattern_len) + 15u) / 16u);     // 8-column flag words, whole 16-column blocks
     return (blocks + 1u) * uint64_t(max_text_len) * uint64_t(n) * 4u;      // flags + the boundary column
 }
 
-NVB_API int nvbio_hip_gotoh_traceback(
-    const nvbio_hip_gotoh_scheme* scheme, int32_t type,
+static int full_traceback_core(
+    const nvbio_hip_gotoh_scheme* scheme, int32_t type, uint32_t block_len,
     const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts,
     uint32_t max_pattern_len, uint32_t max_text_len, uint32_t n,
     int32_t* out_score, uint32_t* out_sink, uint32_t* out_source,
@@ -206,10 +209,48 @@ NVB_API int nvbio_hip_gotoh_traceback(
     g_last_kernel = "full_gotoh_traceback_kernel";
     const dim3 grid((n + 255u) / 256u), block(256);
     hipStream_t s = to_stream(stream);
-    switch (type) {
-    case NVBIO_HIP_LOCAL:       hipLaunchKernelGGL(full_gotoh_traceback_kernel<NVBIO_HIP_LOCAL>,       grid, block, 0, s, p); break;
-    case NVBIO_HIP_SEMI_GLOBAL: hipLaunchKernelGGL(full_gotoh_traceback_kernel<NVBIO_HIP_SEMI_GLOBAL>, grid, block, 0, s, p); break;
-    default:                    hipLaunchKernelGGL(full_gotoh_traceback_kernel<NVBIO_HIP_GLOBAL>,      grid, block, 0, s, p); break;
+    if (block_len == 16u) {
+        switch (type) {
+        case NVBIO_HIP_LOCAL:       hipLaunchKernelGGL((full_gotoh_traceback_kernel<NVBIO_HIP_LOCAL, 16u>),       grid, block, 0, s, p); break;
+        case NVBIO_HIP_SEMI_GLOBAL: hipLaunchKernelGGL((full_gotoh_traceback_kernel<NVBIO_HIP_SEMI_GLOBAL, 16u>), grid, block, 0, s, p); break;
+        default:                    hipLaunchKernelGGL((full_gotoh_traceback_kernel<NVBIO_HIP_GLOBAL, 16u>),      grid, block, 0, s, p); break;
+        }
+    } else {
+        switch (type) {
+        case NVBIO_HIP_LOCAL:       hipLaunchKernelGGL((full_gotoh_traceback_kernel<NVBIO_HIP_LOCAL, 8u>),       grid, block, 0, s, p); break;
+        case NVBIO_HIP_SEMI_GLOBAL: hipLaunchKernelGGL((full_gotoh_traceback_kernel<NVBIO_HIP_SEMI_GLOBAL, 8u>), grid, block, 0, s, p); break;
+        default:                    hipLaunchKernelGGL((full_gotoh_traceback_kernel<NVBIO_HIP_GLOBAL, 8u>),      grid, block, 0, s, p); break;
+        }
     }
     return hipGetLastError();
+}
+
+NVB_API int nvbio_hip_gotoh_traceback(
+    const nvbio_hip_gotoh_scheme* scheme, int32_t type,
+    const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len, uint32_t n,
+    int32_t* out_score, uint32_t* out_sink, uint32_t* out_source,
+    uint16_t* out_cigar, uint32_t cigar_stride, uint32_t* out_cigar_len,
+    void* temp, uint64_t temp_bytes, void* stream)
+{
+    return full_traceback_core(scheme, type, 8u, patterns, texts, max_pattern_len, max_text_len, n, out_score, out_sink, out_source,
+                               out_cigar, cigar_stride, out_cigar_len, temp, temp_bytes, stream);
+}
+
+// SmithWatermanAligner / EditDistanceAligner (sw_inl.h:389-396, 475-500, 1660-1700): with deletion == insertion the matrix, the
+// flow directions and the walk are those of Gotoh with gap_open == gap_ext (the extension flags never fire); the sink comes
+// from the 16-column pattern-blocking score pass.
+NVB_API int nvbio_hip_sw_traceback(
+    const nvbio_hip_sw_scheme* scheme, int32_t type,
+    const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len, uint32_t n,
+    int32_t* out_score, uint32_t* out_sink, uint32_t* out_source,
+    uint16_t* out_cigar, uint32_t cigar_stride, uint32_t* out_cigar_len,
+    void* temp, uint64_t temp_bytes, void* stream)
+{
+    if (!scheme) return hipErrorInvalidValue;
+    if (scheme->deletion != scheme->insertion) return hipErrorNotSupported;
+    const nvbio_hip_gotoh_scheme g = { scheme->match, scheme->mismatch, scheme->deletion, scheme->deletion };
+    return full_traceback_core(&g, type, 16u, patterns, texts, max_pattern_len, max_text_len, n, out_score, out_sink, out_source,
+                               out_cigar, cigar_stride, out_cigar_len, temp, temp_bytes, stream);
 }

@@ -754,6 +754,132 @@ ORACLE_API void oracle_gotoh_traceback(int type, const int32_t* scheme,
     res[1] = (int32_t)sx; res[2] = (int32_t)sy; res[5] = (int32_t)n; res[7] = (int32_t)sy;
 }
 
+/* ------------------------------------------------------------------------ */
+/* Smith-Waterman / edit-distance tracebacks (linear gaps)                    */
+/*   banded  flags: sw_banded_inl.h:405-470 (new_cell's dir) stored as is by  */
+/*           SmithWatermanSubmatrixContext (:269-279) -- NOTE no SINK marking */
+/*           even for LOCAL, so its walk (:748-800) only ends at row zero;    */
+/*           driver banded_inl.h:352-423                                      */
+/*   full    flags: sw_inl.h:475-500 with `score ? dir : SINK` for LOCAL      */
+/*           (:389-396); walk :1660-1700; driver alignment_inl.h:365-480;     */
+/*           sink = the 16-column pattern-blocking score pass                 */
+/* scheme = {match, mismatch, deletion, insertion}; res / ops as the Gotoh    */
+/* tracebacks; flags: M*band (banded) or M*N (full) bytes; row: M+1 int32.     */
+/* ------------------------------------------------------------------------ */
+ORACLE_API void oracle_sw_traceback(uint32_t band /* 0 = full matrix */, int type, const int32_t* sw,
+    const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, uint64_t pat_begin, uint32_t M,
+    const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, uint64_t txt_begin, uint32_t N,
+    int32_t* res, uint8_t* ops, uint32_t ops_capacity, uint8_t* flags, int32_t* row)
+{
+    const int32_t V = sw[0], X = sw[1], G = sw[2], I = sw[3];
+    best_sink_t best; sink_init(&best);
+    uint32_t n = 0;
+    #define PUSH(o) do { if (n < ops_capacity) ops[n] = (o); ++n; } while (0)
+    res[5] = res[6] = res[7] = 0;
+    if (band)
+    {
+        /* forward pass = banded_sw_score_x with the direction of every cell kept */
+        if (N >= M)
+        {
+            uint32_t text_cache[MAX_BAND]; int32_t B[MAX_BAND];
+            for (uint32_t j = 0; j + 1 < band; ++j) text_cache[j] = cache_store(band, ps_get(txt_w, txt_bits, txt_be, txt_begin + j));
+            for (uint32_t j = 0; j < band; ++j) B[j] = (type == ALN_GLOBAL) ? (int32_t)j * G : 0;
+            for (uint32_t i = 0; i < M; ++i)
+            {
+                const uint8_t q = (uint8_t)ps_get(pat_w, pat_bits, pat_be, pat_begin + i);
+                uint8_t* fr = flags + (size_t)i * band;
+                {
+                    const int32_t diagonal = B[0] + ((uint8_t)text_cache[0] == q ? V : X), top = B[1] + G;
+                    int32_t hi = imax(top, diagonal);
+                    if (type == ALN_LOCAL) { hi = imax(hi, 0); sink_report(&best, hi, i + 1, i + 1); }
+                    B[0] = hi; fr[0] = top > diagonal ? DIR_INSERTION : DIR_SUBSTITUTION;
+                }
+                for (uint32_t j = 1; j + 1 < band; ++j)
+                {
+                    const uint32_t g = text_cache[j]; text_cache[j - 1] = g;
+                    const int32_t diagonal = B[j] + ((uint8_t)g == q ? V : X), top = B[j + 1] + G, left = B[j - 1] + I;
+                    int32_t hi = imax(imax(top, left), diagonal);
+                    if (type == ALN_LOCAL) { hi = imax(hi, 0); sink_report(&best, hi, i + j + 1, i + 1); }
+                    B[j] = hi;
+                    fr[j] = top > left ? (top > diagonal ? DIR_INSERTION : DIR_SUBSTITUTION) : (left > diagonal ? DIR_DELETION : DIR_SUBSTITUTION);
+                }
+                const uint8_t g = (i + band - 1 < N) ? (uint8_t)ps_get(txt_w, txt_bits, txt_be, txt_begin + i + band - 1) : 255u;
+                text_cache[band - 2] = cache_store(band, g);
+                {
+                    const int32_t diagonal = B[band - 1] + (g == q ? V : X), left = B[band - 2] + I;
+                    int32_t hi = imax(left, diagonal);
+                    if (type == ALN_LOCAL) { hi = imax(hi, 0); sink_report(&best, hi, i + band, i + 1); }
+                    B[band - 1] = hi; fr[band - 1] = left > diagonal ? DIR_DELETION : DIR_SUBSTITUTION;
+                }
+            }
+            if (type == ALN_GLOBAL) sink_report(&best, B[band - 1], M + band - 1, M);
+            else if (type == ALN_SEMI_GLOBAL) {
+                const uint32_t a = M + band - 1u, m = (a < N ? a : N) - (M - 1u);
+                sink_report(&best, B[0], M, M);
+                for (uint32_t j = 1; j < band; ++j) if (j < m) sink_report(&best, B[j], M + j, M);
+            }
+        }
+        res[0] = best.score; res[3] = (int32_t)best.sink_x; res[4] = (int32_t)best.sink_y;
+        if (best.sink_x == 0xFFFFFFFFu || best.sink_y == 0xFFFFFFFFu) { res[1] = res[2] = -1; return; }
+        res[6] = (int32_t)(M - best.sink_y);
+        int32_t entry = (int32_t)(best.sink_x - best.sink_y), r = (int32_t)best.sink_y - 1;
+        while (r >= 0)
+        {
+            const uint8_t op = flags[(size_t)r * band + entry];
+            /* (TYPE == LOCAL && op == SINK) can never hold: the context stores `dir` only */
+            if (op == DIR_DELETION)       { --entry; PUSH(DIR_DELETION); }
+            else if (op == DIR_INSERTION) { ++entry; --r; PUSH(DIR_INSERTION); }
+            else                          { --r; PUSH(DIR_SUBSTITUTION); }
+        }
+        res[1] = entry; res[2] = 0; res[5] = (int32_t)n; res[7] = 0;
+        #undef PUSH
+        return;
+    }
+    /* full matrix */
+    {
+        int16_t* temp = (int16_t*)malloc(sizeof(int16_t) * 2 * (size_t)(N + 1));
+        const scheme_t dummy = { 0, 0, 0, 0, 0, 0, NULL, NULL };
+        score_pattern_blocking(1, type, &dummy, sw, pat_w, pat_bits, pat_be, pat_begin, M, txt_w, txt_bits, txt_be, txt_begin, N, (-2147483647 - 1), &best, temp);
+        free(temp);
+    }
+    res[0] = best.score; res[3] = (int32_t)best.sink_x; res[4] = (int32_t)best.sink_y;
+    if (best.sink_x == 0xFFFFFFFFu || best.sink_y == 0xFFFFFFFFu) { res[1] = res[2] = -1; return; }
+    for (uint32_t j = 0; j <= M; ++j) row[j] = (type != ALN_LOCAL) ? I * (int32_t)j : 0;          /* band init: sw_inl.h:648-649 */
+    for (uint32_t i = 0; i < N; ++i)
+    {
+        const uint8_t r_i = (uint8_t)ps_get(txt_w, txt_bits, txt_be, txt_begin + i);
+        int32_t prev = row[0];
+        row[0] = (type == ALN_GLOBAL) ? G * (int32_t)(i + 1) : 0;                                  /* context.init: :76-79 */
+        for (uint32_t j = 1; j <= M; ++j)
+        {
+            const uint8_t q_j = (uint8_t)ps_get(pat_w, pat_bits, pat_be, pat_begin + j - 1);
+            const int32_t diagonal = prev + (r_i == q_j ? V : X), top = row[j] + G, left = row[j - 1] + I;
+            int32_t hi = imax(imax(top, left), diagonal);
+            if (type == ALN_LOCAL) hi = imax(hi, 0);
+            uint8_t dir = top > left ? (top > diagonal ? DIR_DELETION : DIR_SUBSTITUTION) : (left > diagonal ? DIR_INSERTION : DIR_SUBSTITUTION);
+            if (type == ALN_LOCAL && hi == 0) dir = DIR_SINK;
+            prev = row[j]; row[j] = hi;
+            flags[(size_t)i * M + (j - 1)] = dir;
+        }
+    }
+    #define PUSH(o) do { if (n < ops_capacity) ops[n] = (o); ++n; } while (0)
+    res[6] = (int32_t)(M - best.sink_y);
+    int32_t r = (int32_t)best.sink_x, c = (int32_t)best.sink_y - 1;
+    while (r > 0 && c >= 0)
+    {
+        const uint8_t op = flags[(size_t)(r - 1) * M + c];
+        if (type == ALN_LOCAL && op == DIR_SINK) break;
+        if (op != DIR_DELETION)  --c;
+        if (op != DIR_INSERTION) --r;
+        PUSH(op);
+    }
+    uint32_t sx = (uint32_t)r, sy = (uint32_t)(c + 1);
+    if (type == ALN_SEMI_GLOBAL || type == ALN_GLOBAL) { if (sx == 0) for (; sy > 0; --sy) PUSH(DIR_INSERTION); }
+    if (type == ALN_GLOBAL)                            { if (sy == 0) for (; sx > 0; --sx) PUSH(DIR_DELETION); }
+    #undef PUSH
+    res[1] = (int32_t)sx; res[2] = (int32_t)sy; res[5] = (int32_t)n; res[7] = (int32_t)sy;
+}
+
 /* banded: BatchedBandedAlignmentScore over SmithWatermanAligner / EditDistanceAligner;
  * full (band == 0): BatchedAlignmentScore over the TextBlockingTag forms */
 ORACLE_API void oracle_batch_sw_score(

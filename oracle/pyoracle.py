@@ -286,6 +286,51 @@ def gotoh_traceback(aln_type, scheme, patterns, texts, i=0):
                 ops=o, clip_end=int(res[6]), clip_begin=int(res[7]), cigar=np.array(cig, dtype=np.uint16))
 
 
+def sw_traceback(band, aln_type, scheme, patterns, texts, i=0):
+    """SmithWatermanAligner / EditDistanceAligner traceback of job i (band > 0: banded; 0: full matrix)."""
+    M, N = int(patterns.length[i]), int(texts.length[i])
+    res = np.zeros(8, dtype=np.int32)
+    cap = 2 * M + N + band + 8
+    ops = np.zeros(cap, dtype=np.uint8)
+    flags = np.zeros(max(1, M * (band if band else N)), dtype=np.uint8)
+    row = np.zeros(M + 1, dtype=np.int32)
+    sc = _scheme(scheme)
+    lib().oracle_sw_traceback(
+        C.c_uint32(band), C.c_int(aln_type), _p(sc),
+        _p(patterns.words), C.c_uint32(patterns.bits), C.c_uint32(patterns.big_endian), C.c_uint64(int(patterns.begin[i])), C.c_uint32(M),
+        _p(texts.words), C.c_uint32(texts.bits), C.c_uint32(texts.big_endian), C.c_uint64(int(texts.begin[i])), C.c_uint32(N),
+        _p(res), _p(ops), C.c_uint32(cap), _p(flags), _p(row))
+    n = int(res[5])
+    o = ops[:n].copy()
+    cig = []
+    if res[6]:
+        cig.append(3 | (int(res[6]) << 2))
+    k = 0
+    while k < n:
+        e = k
+        while e < n and o[e] == o[k]:
+            e += 1
+        cig.append(int(o[k]) | ((e - k) << 2))
+        k = e
+    if res[7]:
+        cig.append(3 | (int(res[7]) << 2))
+    return dict(score=int(res[0]), source=(int(np.uint32(res[1])), int(np.uint32(res[2]))), sink=(int(np.uint32(res[3])), int(np.uint32(res[4]))),
+                ops=o, clip_end=int(res[6]), clip_begin=int(res[7]), cigar=np.array(cig, dtype=np.uint16))
+
+
+def batch_sw_traceback(band, aln_type, scheme, patterns, texts, cigar_stride):
+    n = len(patterns)
+    out = dict(score=np.empty(n, np.int32), sink=np.empty((n, 2), np.uint32), source=np.empty((n, 2), np.uint32),
+               cigar=np.zeros((max(n, 1), cigar_stride), np.uint16), cigar_len=np.empty(n, np.uint32))
+    for i in range(n):
+        r = sw_traceback(band, aln_type, scheme, patterns, texts, i)
+        out["score"][i] = r["score"]; out["sink"][i] = r["sink"]; out["source"][i] = r["source"]
+        c = r["cigar"]
+        out["cigar_len"][i] = c.size
+        out["cigar"][i, :min(c.size, cigar_stride)] = c[:cigar_stride]
+    return out
+
+
 def batch_gotoh_traceback(aln_type, scheme, patterns, texts, cigar_stride):
     n = len(patterns)
     out = dict(score=np.empty(n, np.int32), sink=np.empty((n, 2), np.uint32), source=np.empty((n, 2), np.uint32),

@@ -466,3 +466,36 @@ def test_full_matrix_traceback_kats_and_properties():
                 assert r["source"] == (0, 0) and r["sink"] == (N, M)
             if ty != O.LOCAL:
                 assert r["source"][1] == 0 and r["sink"][1] == M
+
+
+def test_sw_tracebacks_kats_and_relation_to_gotoh():
+    """SW / ED tracebacks: the reference's three full-matrix SW CIGAR literals (alignment_test.cu:776-780); and against the Gotoh
+    restatement with gap_open == gap_ext: identical in the band for GLOBAL / SEMI_GLOBAL and in the full matrix whenever the sinks
+    coincide, different for banded LOCAL (the SW band context never marks a sink, sw_banded_inl.h:269-279)."""
+    p, t = dna(KAT["strings"]["short_p"]), dna(KAT["strings"]["short_t"])
+    hp, ht = O.StringSet.from_lists([p], 4, True), O.StringSet.from_lists([t], 2, False)
+    for ty, lit in ((O.GLOBAL, "1M2D3M1D3M10D"), (O.LOCAL, "4M1D3M"), (O.SEMI_GLOBAL, "4M1D3M")):
+        assert O.cigar_rle(O.sw_traceback(0, ty, (2, -1, -1, -1), hp, ht)["ops"]) == lit
+    rng = np.random.default_rng(3)
+    key = lambda r: (r["score"], r["sink"], r["source"], r["cigar"].tolist())
+    local_differs = 0
+    for it in range(200):
+        M = int(rng.integers(1, 50)); N = M + int(rng.integers(0, 40))
+        t = rng.integers(0, 4, N).astype(np.uint8)
+        p = np.resize(t[int(rng.integers(0, max(1, N - M + 1))):], M).copy()
+        mut = rng.random(M) < 0.12
+        p[mut] = rng.integers(0, 4, int(mut.sum()))
+        hp = O.StringSet.from_lists([p], 4, True)
+        ht = O.StringSet.from_lists([t, np.zeros(64, np.uint8)], 2, True); ht = O.StringSet(ht.words, 2, True, ht.begin[:1], ht.length[:1])
+        for ty in (O.GLOBAL, O.LOCAL, O.SEMI_GLOBAL):
+            a, b = O.sw_traceback(15, ty, (2, -1, -1, -1), hp, ht), O.banded_gotoh_traceback(15, ty, (2, -1, -1, -1), hp, ht)
+            if ty == O.LOCAL:
+                local_differs += key(a) != key(b)
+                assert a["source"][1] == 0 and (a["score"], a["sink"]) == (b["score"], b["sink"])
+            else:
+                assert key(a) == key(b)
+            a, b = O.sw_traceback(0, ty, (2, -1, -1, -1), hp, ht), O.gotoh_traceback(ty, (2, -1, -1, -1), hp, ht)
+            assert a["score"] == b["score"]
+            if a["sink"] == b["sink"]:
+                assert key(a) == key(b)
+    assert local_differs > 0

@@ -170,3 +170,43 @@ def test_full_matrix_traceback(cuda, ty):
         # the score pass of the same aligner (pattern blocking) agrees
         gs, gk, _ = nvb.batch_alignment_score(nvb.make_gotoh_aligner(ty, nvb.SimpleGotohScheme(*scheme), nvb.PATTERN_BLOCKING), to_dev(hp, cuda), to_dev(ht, cuda), 150, 650)
         assert torch.equal(gs, got["score"]) and torch.equal(gk, got["sink"])
+
+
+# ---------------------------------------------------------------------------- SW / edit-distance tracebacks
+@pytest.mark.parametrize("ty", [nvb.GLOBAL, nvb.LOCAL, nvb.SEMI_GLOBAL])
+def test_sw_and_ed_tracebacks(cuda, ty):
+    """SmithWatermanAligner / EditDistanceAligner tracebacks, banded (incl. the reference's LOCAL walk that never stops at a zero
+    cell) and full matrix (sink of the 16-column pattern-blocking pass), vs the oracle's restatement of sw_banded_inl.h / sw_inl.h;
+    and the reference's three full-matrix SW CIGAR literals (alignment_test.cu:776-780)."""
+    rng = np.random.default_rng(8300 + ty)
+    pats, txts = random_pairs(rng, 800, 15)
+    hp, ht = O.StringSet.from_lists(pats, 4, True), O.StringSet.from_lists(txts + [np.zeros(64, np.uint8)], 2, True)
+    ht = O.StringSet(ht.words, 2, True, ht.begin[:-1], ht.length[:-1])
+    maxM = int(hp.length.max())
+    for scheme in ((2, -1, -1, -1), (0, -1, -1, -1)):
+        al = nvb.make_edit_distance_aligner(ty) if scheme[0] == 0 else nvb.make_smith_waterman_aligner(ty, nvb.SimpleSmithWatermanScheme(*scheme))
+        for band in (7, 15, 31):
+            exp = O.batch_sw_traceback(band, ty, scheme, hp, ht, 40)
+            got = nvb.batch_banded_alignment_traceback(band, al, to_dev(hp, cuda), to_dev(ht, cuda), max_pattern_length=maxM, cigar_stride=40)
+            torch.cuda.synchronize()
+            compare(exp, got, (ty, scheme, band))
+    fp, ft = [], []
+    for i in range(400):
+        M, N = int(rng.integers(1, 120)), int(rng.integers(1, 260))
+        t = rng.integers(0, 4, N).astype(np.uint8)
+        p = np.resize(t[int(rng.integers(0, N)):], M).copy()
+        mut = rng.random(M) < 0.08
+        p[mut] = rng.integers(0, 4, int(mut.sum()))
+        fp.append(p); ft.append(t)
+    hp, ht = O.StringSet.from_lists(fp, 4, True), O.StringSet.from_lists(ft, 2, False)
+    for scheme in ((2, -1, -1, -1), (0, -1, -1, -1)):
+        al = nvb.make_edit_distance_aligner(ty) if scheme[0] == 0 else nvb.make_smith_waterman_aligner(ty, nvb.SimpleSmithWatermanScheme(*scheme))
+        exp = O.batch_sw_traceback(0, ty, scheme, hp, ht, 48)
+        got = nvb.batch_alignment_traceback(al, to_dev(hp, cuda), to_dev(ht, cuda), 120, 260, cigar_stride=48)
+        torch.cuda.synchronize()
+        compare(exp, got, (ty, scheme, "full"))
+    p, t = dna(KAT["strings"]["short_p"]), dna(KAT["strings"]["short_t"])
+    h1, h2 = O.StringSet.from_lists([p], 4, True), O.StringSet.from_lists([t], 2, False)
+    got = nvb.batch_alignment_traceback(nvb.make_smith_waterman_aligner(ty, nvb.SimpleSmithWatermanScheme(2, -1, -1, -1)), to_dev(h1, cuda), to_dev(h2, cuda), 7, 20)
+    cig = got["cigar"][0, :int(got["cigar_len"][0])].cpu().numpy().view(np.uint16)
+    assert "".join("%d%s" % (c >> 2, "MIDS"[c & 3]) for c in cig) == {nvb.GLOBAL: "1M2D3M1D3M10D", nvb.LOCAL: "4M1D3M", nvb.SEMI_GLOBAL: "4M1D3M"}[ty]
