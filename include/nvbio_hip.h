@@ -231,6 +231,17 @@ int nvbio_hip_sw_traceback(
     uint16_t* out_cigar, uint32_t cigar_stride, uint32_t* out_cigar_len,
     void* temp, uint64_t temp_bytes, void* stream);
 
+/* nvbio_hip_alignment_score for GotohAligner<TYPE, SmithWatermanScoringScheme<...>, algorithm_tag>: nvBowtie's full-matrix
+ * scoring of the opposite mate (score_opposite_inl.h:266-269).  Mismatch penalties come from the quality bytes (as in
+ * nvbio_hip_banded_gotoh_score_qual); the recurrences use the pattern gap costs, and one boundary line of the matrix is
+ * initialised with the text gap costs -- which one depends on the tag, exactly as gotoh_inl.h:82-88 / :693-697 / :1171-1175
+ * have it.  16-bit sweep only (801 otherwise). */
+int nvbio_hip_alignment_score_qual(
+    const nvbio_hip_gotoh_qual_scheme* scheme /* host */, int32_t algorithm, int32_t type,
+    const nvbio_hip_string_set* patterns, const uint8_t* quals, uint64_t n_quals, const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len, const int32_t* min_score /* device, nullable */,
+    uint32_t n, int32_t* out_score, uint32_t* out_sink, uint8_t* out_ok /* nullable */, void* stream);
+
 /* nvbio::fm_index<rank_dictionary<2,64,PackedStream<.,uint8,2,true>,.,.>, SSA_index_multiple_context<SA_INT>, const uint32*>
  * (nvbio/fmindex/fmindex.h:341-387) in the production interleaved layout
  * (nvbio/io/fmindex/fmindex.h:159-174, fmindex_impl.cu:305-327):

@@ -293,15 +293,24 @@ class BatchedAlignmentScore:
     score with the text-blocking aligner sw-benchmark instantiates (sw-benchmark.cu:604-631)."""
 
     def enact(self, aligner, patterns, texts, out_score, out_sink, max_pattern_length=0, max_text_length=0,
-              min_score=None, out_ok=None):
+              min_score=None, out_ok=None, quals=None):
         n = len(patterns)
-        assert len(texts) == n and isinstance(aligner.scheme, (SimpleGotohScheme, SimpleSmithWatermanScheme))
+        assert len(texts) == n and isinstance(aligner.scheme, (SimpleGotohScheme, SimpleSmithWatermanScheme, SmithWatermanScoringScheme))
         if patterns.length is None:
             max_pattern_length = max_pattern_length or patterns.fixed_length
         if texts.length is None:
             max_text_length = max_text_length or texts.fixed_length
         sc = aligner.scheme.struct()
         ps, ts = patterns.struct(), texts.struct()
+        if isinstance(aligner.scheme, SmithWatermanScoringScheme):
+            assert quals is not None and quals.dtype == torch.uint8 and quals.is_cuda and quals.is_contiguous()
+            err = lib().nvbio_hip_alignment_score_qual(
+                C.byref(sc), getattr(aligner, "algorithm", TEXT_BLOCKING), aligner.type, C.byref(ps), C.c_void_p(quals.data_ptr()), quals.numel(), C.byref(ts),
+                int(max_pattern_length), int(max_text_length), C.c_void_p(min_score.data_ptr()) if min_score is not None else None, n,
+                C.c_void_p(out_score.data_ptr()), C.c_void_p(out_sink.data_ptr()),
+                C.c_void_p(out_ok.data_ptr()) if out_ok is not None else None, current_stream_ptr())
+            check(err, "nvbio_hip_alignment_score_qual")
+            return
         if getattr(aligner, "algorithm", TEXT_BLOCKING) == PATTERN_BLOCKING:
             s4 = (C.c_int32 * 4)(*[getattr(sc, f) for f, _ in sc._fields_])
             err = lib().nvbio_hip_alignment_score(
@@ -328,7 +337,7 @@ class BatchedAlignmentScore:
         check(err, "nvbio_hip_gotoh_score")
 
 
-def batch_alignment_score(aligner, patterns, texts, max_pattern_length=0, max_text_length=0, min_score=None):
+def batch_alignment_score(aligner, patterns, texts, max_pattern_length=0, max_text_length=0, min_score=None, quals=None):
     """batch_alignment_score(aligner, patterns, texts, sinks, DeviceThreadScheduler(), maxP, maxT)
     (batched.h:160-190).  Returns (score[n], sink[n,2], ok[n] uint8)."""
     n = len(patterns)
@@ -336,5 +345,5 @@ def batch_alignment_score(aligner, patterns, texts, max_pattern_length=0, max_te
     score = torch.empty(n, dtype=torch.int32, device=dev)
     sink = torch.empty((n, 2), dtype=torch.int32, device=dev)
     ok = torch.empty(n, dtype=torch.uint8, device=dev)
-    BatchedAlignmentScore().enact(aligner, patterns, texts, score, sink, max_pattern_length, max_text_length, min_score, ok)
+    BatchedAlignmentScore().enact(aligner, patterns, texts, score, sink, max_pattern_length, max_text_length, min_score, ok, quals)
     return score, sink, ok

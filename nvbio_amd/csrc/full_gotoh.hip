@@ -43,6 +43,12 @@ struct FullParams {
     uint8_t*       out_ok;         // nullable: the reference's per-job bool
     uint32_t       blk_log2;       // log2 of the reference's block width: fixes the LOCAL tie order (3 = Gotoh, 4 = SW / ED)
     uint32_t       pattern_blocking;   // 0: blocks of text columns (TextBlockingTag); 1: blocks of pattern rows (PatternBlockingTag)
+    // quality-aware scheme (nvBowtie): mismatch by the quality byte of the pattern symbol; nullptr = constant `mismatch`
+    const uint8_t* quals; uint64_t n_quals;
+    int32_t        mm_lut[256];
+    // gap costs of the two boundary lines (they are the text / pattern gap costs, which line gets which depends on the tag)
+    int32_t        col_go, col_ge;     // column before the text:  H(r, -1) = col_go + col_ge * r      (non-LOCAL)
+    int32_t        row_go, row_ge;     // row above the pattern:   H(-1, c) = row_go + row_ge * c      (GLOBAL)
 };
 
 __device__ __forceinline__ int32_t dpp_shr1(int32_t first_lane_value, int32_t x)
@@ -270,7 +276,8 @@ struct Sweep16
     const FullParams& p;
     uint32_t lane, lane_last, klast, M, Ncols, Nfull;
     int32_t  Go, Ge, min_score;
-    uint32_t go, ge, sM, sX, inf16, init_above_g;
+    uint32_t go, ge, rge, sM, sX, inf16, init_above_g;
+    uint32_t sXk[R];                      // per-row mismatch score (quality-aware schemes), pre-biased like sX
     uint64_t tb;
     uint32_t q[R], HLG[R], E[R], bestk[R], rmax[PBX ? R : 1];
     uint32_t lim[CHECK ? R : 1];          // CHECK: 0x7FFF for this lane's valid rows, 0x8000 for rows past the pattern (they drop out of the column maximum)
@@ -291,13 +298,14 @@ struct Sweep16
         lane_last = (M - 1u) / uint32_t(R);
         klast = (M - 1u) - lane_last * uint32_t(R);
         kl = lane < lane_last ? uint32_t(R - 1) : (lane == lane_last ? klast : 0u);
-        go = c16(Go); ge = c16(Ge); sM = c16(p.match - Go); sX = c16(p.mismatch - Go); inf16 = c16(infimum);
+        go = c16(Go); ge = c16(Ge); rge = c16(p.row_ge); sM = c16(p.match - Go); sX = c16(p.mismatch - Go); inf16 = c16(infimum);
         #pragma unroll
         for (int k = 0; k < R; ++k)
         {
             const uint32_t r = lane * R + k;
             q[k] = r < M ? get_symbol(p.pat.s, pb + r) : 255u;
-            HLG[k] = c16(((TYPE != NVBIO_HIP_LOCAL) ? Go + Ge * int32_t(r) : 0) + Go);
+            HLG[k] = c16(((TYPE != NVBIO_HIP_LOCAL) ? p.col_go + p.col_ge * int32_t(r) : 0) + Go);
+            sXk[k] = (p.quals && r < M) ? c16(p.mm_lut[p.quals[min(pb + r, p.n_quals - 1u)]] - Go) : sX;
             E[k]   = c16((TYPE == NVBIO_HIP_LOCAL) ? 0 : infimum);
             bestk[k] = 0u;
             if (PBX) rmax[k] = 0x8000u;
@@ -305,8 +313,8 @@ struct Sweep16
         }
         out_hg = out_f = out_ch = out_cm = prev_in_hg = 0;
         sg_score = -(1 << 30); sg_col = 0; exit_col = 0xFFFFFFFFu; grp = 0; sg_hg16 = 0x8000u;
-        top_hg = c16(Go + Go); top_prev_hg = go;
-        init_above_g = c16(((TYPE != NVBIO_HIP_LOCAL) ? Go + Ge * int32_t(lane * R - 1u) : 0) + Go);
+        top_hg = c16(p.row_go + Go); top_prev_hg = go;
+        init_above_g = c16(((TYPE != NVBIO_HIP_LOCAL) ? p.col_go + p.col_ge * int32_t(lane * R - 1u) : 0) + Go);
     }
 
     // the last-row lane's reports and the early-exit test for column c (cm = full column maximum)
@@ -342,7 +350,7 @@ struct Sweep16
         if (lane == 0u) diag_g = (TYPE == NVBIO_HIP_GLOBAL) ? top_prev_hg : go;
         else if (c == 0u) diag_g = init_above_g;
         prev_in_hg = in_hg;
-        if (TYPE == NVBIO_HIP_GLOBAL) { top_prev_hg = top_hg; uint32_t t; asm("v_add_u16 %0, %1, %2" : "=v"(t) : "v"(top_hg), "v"(ge)); top_hg = t; }
+        if (TYPE == NVBIO_HIP_GLOBAL) { top_prev_hg = top_hg; uint32_t t; asm("v_add_u16 %0, %1, %2" : "=v"(t) : "v"(top_hg), "v"(rge)); top_hg = t; }
 
         const bool active = !PRED || (int32_t(c) >= 0 && c < Ncols && lane <= lane_last);
         if (active)
@@ -351,7 +359,7 @@ struct Sweep16
             #pragma unroll
             for (int k = 0; k < R; ++k)
             {
-                cell16<TYPE>(E[k], HLG[k], hab_g, fab, diag_g, in_ch, q[k], go, ge, sM, sX, h);
+                cell16<TYPE>(E[k], HLG[k], hab_g, fab, diag_g, in_ch, q[k], go, ge, sM, sXk[k], h);
                 if (TYPE == NVBIO_HIP_LOCAL) bestk[k] = max(bestk[k], (h << 20) | c);
                 if (PBX) rmax[k] = max16u(rmax[k], h);
                 if (CHECK) cm = max16u(cm, min16u(h, lim[k]));
@@ -515,7 +523,7 @@ full_gotoh_score_kernel(const FullParams p)
         if (exits) { ok = 0u; if (TYPE == NVBIO_HIP_SEMI_GLOBAL) { score = 0; sx = 8u; sy = 0u; } }
         else if (N > 0u) {
             if (TYPE == NVBIO_HIP_SEMI_GLOBAL) { score = 0; sx = N; sy = 0u; }
-            if (TYPE == NVBIO_HIP_GLOBAL)      { score = p.gap_open + p.gap_ext * int32_t(N - 1u); sx = N; sy = 0u; }
+            if (TYPE == NVBIO_HIP_GLOBAL)      { score = p.row_go + p.row_ge * int32_t(N - 1u); sx = N; sy = 0u; }
         }
     }
     else if (FAST && p.pattern_blocking != 0u && check)
@@ -527,7 +535,7 @@ full_gotoh_score_kernel(const FullParams p)
         {
             // no text row was visited: max_score is still its minimum, so the first non-final block exits
             if (n_blocks > 1u) ok = 0u;
-            else if (TYPE == NVBIO_HIP_GLOBAL) { score = p.gap_open + p.gap_ext * int32_t(M - 1u); sx = 0u; sy = M; }
+            else if (TYPE == NVBIO_HIP_GLOBAL) { score = p.col_go + p.col_ge * int32_t(M - 1u); sx = 0u; sy = M; }
         }
         else
         {
@@ -565,7 +573,7 @@ full_gotoh_score_kernel(const FullParams p)
         }
         score = r.score; sx = r.sx; sy = r.sy;
         // pattern blocking, GLOBAL, empty text: save_Mth reports the initial row (gotoh_inl.h:896-897)
-        if (FAST && p.pattern_blocking != 0u && TYPE == NVBIO_HIP_GLOBAL && N == 0u) { score = p.gap_open + p.gap_ext * int32_t(M - 1u); sx = 0u; sy = M; }
+        if (FAST && p.pattern_blocking != 0u && TYPE == NVBIO_HIP_GLOBAL && N == 0u) { score = p.col_go + p.col_ge * int32_t(M - 1u); sx = 0u; sy = M; }
     }
     if (lane == 0u)
     {
@@ -592,8 +600,10 @@ static hipError_t launch_full(const FullParams& p, int type, hipStream_t s)
 
 using namespace nvb;
 
+struct QualPart { const uint8_t* quals; uint64_t n_quals; const int32_t* mismatch; int32_t text_gap_open, text_gap_ext; };
+
 static int full_score_core(
-    const nvbio_hip_gotoh_scheme* scheme, int32_t type, uint32_t blk_log2, uint32_t pattern_blocking,
+    const nvbio_hip_gotoh_scheme* scheme, const QualPart* qual, int32_t type, uint32_t blk_log2, uint32_t pattern_blocking,
     const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts,
     uint32_t max_pattern_len, uint32_t max_text_len, const int32_t* min_score,
     uint32_t n, int32_t* out_score, uint32_t* out_sink, uint8_t* out_ok, void* stream)
@@ -615,12 +625,19 @@ static int full_score_core(
     p.match = scheme->match; p.mismatch = scheme->mismatch; p.gap_open = scheme->gap_open; p.gap_ext = scheme->gap_ext;
     p.min_score = min_score; p.n = n; p.out_score = out_score; p.out_sink = out_sink; p.out_ok = out_ok;
     p.blk_log2 = blk_log2; p.pattern_blocking = pattern_blocking;
+    p.quals = qual ? qual->quals : nullptr; p.n_quals = qual ? qual->n_quals : 0;
+    for (int i = 0; i < 256; ++i) p.mm_lut[i] = qual ? qual->mismatch[i] : scheme->mismatch;
+    // which boundary line is initialised with which gap costs depends on the tag (gotoh_inl.h:82-88 vs :693-697 / :1171-1175)
+    const int32_t tgo = qual ? qual->text_gap_open : scheme->gap_open, tge = qual ? qual->text_gap_ext : scheme->gap_ext;
+    p.col_go = pattern_blocking ? scheme->gap_open : tgo; p.col_ge = pattern_blocking ? scheme->gap_ext : tge;
+    p.row_go = pattern_blocking ? tgo : scheme->gap_open; p.row_ge = pattern_blocking ? tge : scheme->gap_ext;
 
     // can any H / E leave int16?  LOCAL: 0 <= H <= M*match, E/F a few gap costs below.  SEMI_GLOBAL (pattern
     // global, text free): every cell is reachable from the zero row above its column, so values stay within
     // (M+2) * max|cost| whatever the text length.  GLOBAL: the row above the matrix itself reaches G_o + G_e*N.
     auto iabs = [](int32_t v) { return v < 0 ? -int64_t(v) : int64_t(v); };
-    const int64_t A = std::max(std::max(iabs(scheme->match), iabs(scheme->mismatch)), std::max(iabs(scheme->gap_open), iabs(scheme->gap_ext)));
+    int64_t A = std::max(std::max(iabs(scheme->match), iabs(scheme->mismatch)), std::max(iabs(scheme->gap_open), iabs(scheme->gap_ext)));
+    if (qual) { for (int i = 0; i < 256; ++i) A = std::max(A, iabs(qual->mismatch[i])); A = std::max(A, std::max(iabs(qual->text_gap_open), iabs(qual->text_gap_ext))); }
     const int64_t span = (type == NVBIO_HIP_GLOBAL) ? int64_t(maxM) + maxN + 4 : int64_t(maxM) + 4;
     const bool trunc = !(scheme->gap_open <= 0 && scheme->gap_ext <= 0 && span * A < 30000);
     hipStream_t s = to_stream(stream);
@@ -638,6 +655,7 @@ static int full_score_core(
     }
     if (trunc && blk_log2 != 3u) return hipErrorNotSupported;     // the int16 boundary column of the SW form is not modelled beyond its exact range
     if (pattern_blocking && !fast) return hipErrorNotSupported;   // pattern blocking is implemented on the 16-bit sweep only
+    if (qual && !fast) return hipErrorNotSupported;               // so is the quality-aware scheme
     if (trunc) {
         switch (R) { case 1: return launch_full<1, true, false>(p, type, s); case 2: return launch_full<2, true, false>(p, type, s);
                      case 3: return launch_full<3, true, false>(p, type, s); case 4: return launch_full<4, true, false>(p, type, s);
@@ -655,7 +673,7 @@ NVB_API int nvbio_hip_gotoh_score(
     uint32_t max_pattern_len, uint32_t max_text_len, const int32_t* min_score,
     uint32_t n, int32_t* out_score, uint32_t* out_sink, uint8_t* out_ok, void* stream)
 {
-    return full_score_core(scheme, type, 3u, 0u, patterns, texts, max_pattern_len, max_text_len, min_score, n, out_score, out_sink, out_ok, stream);
+    return full_score_core(scheme, nullptr, type, 3u, 0u, patterns, texts, max_pattern_len, max_text_len, min_score, n, out_score, out_sink, out_ok, stream);
 }
 
 // SmithWatermanAligner / EditDistanceAligner, full matrix, text blocking (sw_inl.h:881-1222): linear gaps with
@@ -670,7 +688,7 @@ NVB_API int nvbio_hip_sw_score(
     if (!scheme) return hipErrorInvalidValue;
     if (scheme->deletion != scheme->insertion) return hipErrorNotSupported;
     const nvbio_hip_gotoh_scheme g = { scheme->match, scheme->mismatch, scheme->deletion, scheme->deletion };
-    const int e = full_score_core(&g, type, 4u, 0u, patterns, texts, max_pattern_len, max_text_len, nullptr, n, out_score, out_sink, nullptr, stream);
+    const int e = full_score_core(&g, nullptr, type, 4u, 0u, patterns, texts, max_pattern_len, max_text_len, nullptr, n, out_score, out_sink, nullptr, stream);
     if (e == hipSuccess && n) g_last_kernel = "full_gotoh_score_kernel<16-bit,sw>";
     return e;
 }
@@ -687,8 +705,25 @@ NVB_API int nvbio_hip_alignment_score(
     if (aligner == 1 && scheme4[2] != scheme4[3]) return hipErrorNotSupported;         // deletion != insertion
     const nvbio_hip_gotoh_scheme g = { scheme4[0], scheme4[1], scheme4[2], aligner == 1 ? scheme4[2] : scheme4[3] };
     if (algorithm == 1 && aligner == 1) min_score = nullptr;                            // the text-blocking SW form never exits early
-    const int e = full_score_core(&g, type, aligner == 1 ? 4u : 3u, algorithm == 0 ? 1u : 0u, patterns, texts, max_pattern_len, max_text_len,
+    const int e = full_score_core(&g, nullptr, type, aligner == 1 ? 4u : 3u, algorithm == 0 ? 1u : 0u, patterns, texts, max_pattern_len, max_text_len,
                                   min_score, n, out_score, out_sink, (algorithm == 1 && aligner == 1) ? nullptr : out_ok, stream);
     if (e == hipSuccess && n && algorithm == 1 && aligner == 1 && out_ok) return hipMemsetAsync(out_ok, 1, n, to_stream(stream));
     return e;
+}
+
+// GotohAligner<TYPE, SmithWatermanScoringScheme<...>> (nvBowtie's opposite-mate scoring, score_opposite_inl.h:266-269): per-symbol
+// mismatch penalties from the read qualities, pattern gap costs in the recurrences, text gap costs on one boundary line.
+NVB_API int nvbio_hip_alignment_score_qual(
+    const nvbio_hip_gotoh_qual_scheme* scheme, int32_t algorithm, int32_t type,
+    const nvbio_hip_string_set* patterns, const uint8_t* quals, uint64_t n_quals, const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len, const int32_t* min_score,
+    uint32_t n, int32_t* out_score, uint32_t* out_sink, uint8_t* out_ok, void* stream)
+{
+    if (!scheme || algorithm < 0 || algorithm > 1) return hipErrorInvalidValue;
+    if (n != 0 && (!quals || n_quals == 0)) return hipErrorInvalidValue;
+    int32_t worst = 0;
+    for (int i = 0; i < 256; ++i) worst = std::min(worst, scheme->mismatch[i]);
+    const nvbio_hip_gotoh_scheme g = { scheme->match, worst, scheme->pattern_gap_open, scheme->pattern_gap_ext };
+    const QualPart q = { quals, n_quals, scheme->mismatch, scheme->text_gap_open, scheme->text_gap_ext };
+    return full_score_core(&g, &q, type, 3u, algorithm == 0 ? 1u : 0u, patterns, texts, max_pattern_len, max_text_len, min_score, n, out_score, out_sink, out_ok, stream);
 }

@@ -667,6 +667,35 @@ ORACLE_API void oracle_batch_score_pattern_blocking(
     }
 }
 
+/* the full-matrix score for nvBowtie's quality-aware scheme: qscheme = {match, pattern_gap_open, pattern_gap_ext,
+ * text_gap_open, text_gap_ext}; algorithm 0 = pattern blocking, 1 = text blocking */
+ORACLE_API void oracle_batch_gotoh_score_qual(
+    int algorithm, int type, const int32_t* qscheme, const int32_t* mm_lut, const uint8_t* quals,
+    const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, const uint64_t* pat_begin, const uint32_t* pat_len,
+    const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, const uint64_t* txt_begin, const uint32_t* txt_len,
+    const int32_t* min_score /* nullable */, uint32_t n, int32_t* out_score, uint32_t* out_sink, uint8_t* out_ok, int n_threads)
+{
+    const scheme_t sc = { qscheme[0], 0, qscheme[1], qscheme[2], qscheme[3], qscheme[4], mm_lut, quals };
+#if defined(_OPENMP)
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+    #pragma omp parallel for schedule(dynamic, 16)
+#endif
+    for (int64_t i = 0; i < (int64_t)n; ++i)
+    {
+        best_sink_t s; sink_init(&s);
+        const size_t len = (algorithm ? pat_len[i] : txt_len[i]) + 1;
+        int16_t* temp = (int16_t*)malloc(sizeof(int16_t) * 2 * len);
+        const int ok = algorithm
+            ? gotoh_score_text_blocking(type, &sc, pat_w, pat_bits, pat_be, pat_begin[i], pat_len[i], txt_w, txt_bits, txt_be, txt_begin[i], txt_len[i],
+                                        min_score ? min_score[i] : -(1 << 30), &s, temp)
+            : score_pattern_blocking(0, type, &sc, NULL, pat_w, pat_bits, pat_be, pat_begin[i], pat_len[i], txt_w, txt_bits, txt_be, txt_begin[i], txt_len[i],
+                                     min_score ? min_score[i] : (-2147483647 - 1), &s, temp);
+        free(temp);
+        out_score[i] = s.score; out_sink[2 * i] = s.sink_x; out_sink[2 * i + 1] = s.sink_y;
+        if (out_ok) out_ok[i] = (uint8_t)ok;
+    }
+}
+
 /* ------------------------------------------------------------------------ */
 /* Full-matrix Gotoh traceback                                                */
 /*   driver      nvbio/alignment/alignment_inl.h:365-480 (score with           */

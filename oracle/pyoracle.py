@@ -375,6 +375,21 @@ def batch_sw_score(band, aln_type, scheme, patterns, texts, n_threads=0):
     return score, sink
 
 
+def batch_gotoh_score_qual(algorithm, aln_type, scheme5, mm_lut, quals, patterns, texts, min_score=None, n_threads=0):
+    """Full-matrix Gotoh score with nvBowtie's quality-aware scheme: scheme5 = (match, pattern_gap_open, pattern_gap_ext,
+    text_gap_open, text_gap_ext); algorithm 0 = pattern blocking, 1 = text blocking -> (score, sink, ok)."""
+    n = len(patterns)
+    score = np.empty(n, dtype=np.int32); sink = np.empty((n, 2), dtype=np.uint32); ok = np.empty(n, dtype=np.uint8)
+    sc = np.ascontiguousarray(scheme5, dtype=np.int32); lut = np.ascontiguousarray(mm_lut, dtype=np.int32); q = np.ascontiguousarray(quals, dtype=np.uint8)
+    ms = np.ascontiguousarray(min_score, dtype=np.int32) if min_score is not None else None
+    lib().oracle_batch_gotoh_score_qual(
+        C.c_int(algorithm), C.c_int(aln_type), _p(sc), _p(lut), _p(q),
+        _p(patterns.words), C.c_uint32(patterns.bits), C.c_uint32(patterns.big_endian), _p(patterns.begin), _p(patterns.length),
+        _p(texts.words), C.c_uint32(texts.bits), C.c_uint32(texts.big_endian), _p(texts.begin), _p(texts.length),
+        _p(ms), C.c_uint32(n), _p(score), _p(sink), _p(ok), C.c_int(n_threads))
+    return score, sink, ok
+
+
 def batch_score_pattern_blocking(kind, aln_type, scheme, patterns, texts, min_score=None, n_threads=0):
     """Full-matrix score, pattern-blocking form (the default algorithm tag): kind 0 = Gotoh (gotoh_inl.h:459-900),
     kind 1 = SW / edit distance (sw_inl.h:417-760) -> (score[n], sink[n,2], ok[n])."""

@@ -140,3 +140,34 @@ def test_pattern_blocking(cuda, ty, kind):
                                        (es[bad[0]], ek[bad[0]], eo[bad[0]]), (gs[bad[0]], gk[bad[0]], go[bad[0]]))
                 if min_score is not None and scheme[0] > 0:
                     assert 0 < eo.sum() < 800          # both outcomes occur
+
+
+@pytest.mark.parametrize("ty", [nvb.GLOBAL, nvb.LOCAL, nvb.SEMI_GLOBAL])
+@pytest.mark.parametrize("algo", [nvb.PATTERN_BLOCKING, nvb.TEXT_BLOCKING])
+def test_quality_aware_scheme_full_matrix(cuda, ty, algo):
+    """nvBowtie's opposite-mate scoring: GotohAligner<TYPE, SmithWatermanScoringScheme> over the full matrix, both tags, with
+    min_score; asymmetric read / reference gap costs exercise the tag-dependent boundary initialisation."""
+    rng = np.random.default_rng(600 + 10 * algo + ty)
+    pats, txts = make_pairs(rng, 900, 150, 400)
+    pats = [p if len(p) else np.zeros(1, np.uint8) for p in pats]
+    hp, ht = O.StringSet.from_lists(pats, 4, True), O.StringSet.from_lists(txts, 2, True)
+    total = int(hp.begin[-1] + hp.length[-1])
+    quals = rng.integers(0, 60, total + 3, dtype=np.uint8); quals[::89] = 255
+    dp = nvb.PackedStringSet.from_host(hp.words, 4, True, hp.begin, hp.length, device=cuda)
+    dt = nvb.PackedStringSet.from_host(ht.words, 2, True, ht.begin, ht.length, device=cuda)
+    dq = torch.from_numpy(quals).to(cuda)
+    ms = rng.integers(-60, 200, 900).astype(np.int32)
+    for scheme in (nvb.SmithWatermanScoringScheme(), nvb.SmithWatermanScoringScheme.local(),
+                   nvb.SmithWatermanScoringScheme(match=1, mmp_min=1, mmp_max=9, read_gap_const=4, read_gap_coeff=2, ref_gap_const=7, ref_gap_coeff=1)):
+        st = scheme.struct()
+        lut = np.array([st.mismatch[q] for q in range(256)], dtype=np.int32)
+        s5 = (st.match, st.pattern_gap_open, st.pattern_gap_ext, st.text_gap_open, st.text_gap_ext)
+        for min_score in (None, ms):
+            es, ek, eo = O.batch_gotoh_score_qual(algo, ty, s5, lut, quals, hp, ht, min_score=min_score)
+            gs, gk, go = nvb.batch_alignment_score(nvb.make_gotoh_aligner(ty, scheme, algo), dp, dt, 150, 400,
+                                                   torch.from_numpy(min_score).to(cuda) if min_score is not None else None, quals=dq)
+            torch.cuda.synchronize()
+            gs, gk, go = gs.cpu().numpy(), gk.cpu().numpy().view(np.uint32), go.cpu().numpy()
+            bad = np.nonzero((es != gs) | (ek != gk).any(1) | (eo != go))[0]
+            assert bad.size == 0, (ty, algo, st.match, min_score is not None, bad[:5], len(pats[bad[0]]), len(txts[bad[0]]),
+                                   (es[bad[0]], ek[bad[0]], eo[bad[0]]), (gs[bad[0]], gk[bad[0]], go[bad[0]]))
