@@ -213,6 +213,16 @@ int nvbio_hip_gotoh_traceback(
     uint16_t* out_cigar, uint32_t cigar_stride, uint32_t* out_cigar_len,
     void* temp, uint64_t temp_bytes, void* stream);
 
+/* nvbio_hip_gotoh_traceback with nvBowtie's quality-aware scheme (its opposite-mate traceback, traceback_inl.h): mismatch
+ * penalties from the quality bytes, pattern gap costs in the recurrences, text gap costs on the column before the pattern. */
+int nvbio_hip_gotoh_traceback_qual(
+    const nvbio_hip_gotoh_qual_scheme* scheme /* host */, int32_t type,
+    const nvbio_hip_string_set* patterns, const uint8_t* quals, uint64_t n_quals, const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len, uint32_t n,
+    int32_t* out_score, uint32_t* out_sink, uint32_t* out_source,
+    uint16_t* out_cigar, uint32_t cigar_stride, uint32_t* out_cigar_len,
+    void* temp, uint64_t temp_bytes, void* stream);
+
 /* The tracebacks for SmithWatermanAligner / EditDistanceAligner (deletion == insertion), banded (sw_banded_inl.h:405-470,
  * 748-800) and full matrix (sw_inl.h:389-396, 475-500, 1660-1700): arguments and temp sizes as the Gotoh forms.  The banded
  * reference context does not mark zero cells, so its LOCAL walk always reaches the first pattern row; reproduced. */

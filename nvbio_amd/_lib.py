@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libnvbio_hip.so")
 SYMBOLS = [
     "nvbio_hip_banded_gotoh_score", "nvbio_hip_banded_gotoh_score_qual", "nvbio_hip_gotoh_score", "nvbio_hip_banded_sw_score", "nvbio_hip_sw_score", "nvbio_hip_alignment_score", "nvbio_hip_alignment_score_qual",
     "nvbio_hip_banded_gotoh_traceback_temp_bytes", "nvbio_hip_banded_gotoh_traceback", "nvbio_hip_banded_gotoh_traceback_qual",
-    "nvbio_hip_gotoh_traceback_temp_bytes", "nvbio_hip_gotoh_traceback", "nvbio_hip_banded_sw_traceback", "nvbio_hip_sw_traceback",
+    "nvbio_hip_gotoh_traceback_temp_bytes", "nvbio_hip_gotoh_traceback", "nvbio_hip_gotoh_traceback_qual", "nvbio_hip_banded_sw_traceback", "nvbio_hip_sw_traceback",
     "nvbio_hip_fm_rank", "nvbio_hip_fm_rank4", "nvbio_hip_fm_rank_range",
     "nvbio_hip_fm_match", "nvbio_hip_fm_build_ktab", "nvbio_hip_map_exact", "nvbio_hip_map",
     "nvbio_hip_alignment_invalid", "nvbio_hip_init_alignments", "nvbio_hip_score_reduce", "nvbio_hip_mapq", "nvbio_hip_fm_locate",
@@ -76,6 +76,8 @@ def lib():
         L.nvbio_hip_gotoh_traceback_temp_bytes.restype = u64
         L.nvbio_hip_gotoh_traceback.argtypes = [P(GotohSchemeStruct), i32, P(StringSetStruct), P(StringSetStruct), u32, u32, u32,
                                                 vp, vp, vp, vp, u32, vp, vp, u64, vp]
+        L.nvbio_hip_gotoh_traceback_qual.argtypes = [P(GotohQualSchemeStruct), i32, P(StringSetStruct), vp, u64, P(StringSetStruct), u32, u32, u32,
+                                                     vp, vp, vp, vp, u32, vp, vp, u64, vp]
         L.nvbio_hip_banded_sw_traceback.argtypes = [P(GotohSchemeStruct), i32, u32, P(StringSetStruct), P(StringSetStruct), u32, u32, u32,
                                                     vp, vp, vp, vp, u32, vp, vp, u64, vp]
         L.nvbio_hip_sw_traceback.argtypes = [P(GotohSchemeStruct), i32, P(StringSetStruct), P(StringSetStruct), u32, u32, u32,

@@ -263,11 +263,11 @@ def batch_banded_alignment_traceback(band_len, aligner, patterns, texts, max_pat
     return out
 
 
-def batch_alignment_traceback(aligner, patterns, texts, max_pattern_length=0, max_text_length=0, cigar_stride=64):
+def batch_alignment_traceback(aligner, patterns, texts, max_pattern_length=0, max_text_length=0, cigar_stride=64, quals=None):
     """BatchedAlignmentTraceback<CHECKPOINTS, stream>::enact (batched.h:432-452) for the full-matrix Gotoh aligner with
     nvBowtie's backtracer: returns dict(score, sink, source, cigar int16[n,stride], cigar_len) as the banded form does."""
     n = len(patterns)
-    assert len(texts) == n and isinstance(aligner.scheme, (SimpleGotohScheme, SimpleSmithWatermanScheme))
+    assert len(texts) == n and isinstance(aligner.scheme, (SimpleGotohScheme, SimpleSmithWatermanScheme, SmithWatermanScoringScheme))
     dev = patterns.words.device
     maxM = max_pattern_length or patterns.fixed_length
     maxN = max_text_length or texts.fixed_length
@@ -278,6 +278,15 @@ def batch_alignment_traceback(aligner, patterns, texts, max_pattern_length=0, ma
                cigar_len=torch.empty(n, dtype=torch.int32, device=dev))
     sc = aligner.scheme.struct()
     ps, ts = patterns.struct(), texts.struct()
+    tail = (int(maxM), int(maxN), n, C.c_void_p(out["score"].data_ptr()), C.c_void_p(out["sink"].data_ptr()), C.c_void_p(out["source"].data_ptr()),
+            C.c_void_p(out["cigar"].data_ptr()), cigar_stride, C.c_void_p(out["cigar_len"].data_ptr()),
+            C.c_void_p(temp.data_ptr()), temp.numel(), current_stream_ptr())
+    if isinstance(aligner.scheme, SmithWatermanScoringScheme):
+        assert quals is not None and quals.dtype == torch.uint8 and quals.is_cuda and quals.is_contiguous()
+        check(lib().nvbio_hip_gotoh_traceback_qual(C.byref(sc), aligner.type, C.byref(ps), C.c_void_p(quals.data_ptr()), quals.numel(), C.byref(ts), *tail),
+              "nvbio_hip_gotoh_traceback_qual")
+        temp.record_stream(torch.cuda.current_stream())
+        return out
     fn = lib().nvbio_hip_sw_traceback if isinstance(aligner, SmithWatermanAligner) else lib().nvbio_hip_gotoh_traceback
     err = fn(C.byref(sc), aligner.type, C.byref(ps), C.byref(ts), int(maxM), int(maxN), n,
                                           C.c_void_p(out["score"].data_ptr()), C.c_void_p(out["sink"].data_ptr()), C.c_void_p(out["source"].data_ptr()),

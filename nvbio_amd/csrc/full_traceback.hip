@@ -28,6 +28,9 @@ struct FullTbParams {
     uint16_t* out_cigar; uint32_t cigar_stride; uint32_t* out_cigar_len;
     uint32_t* flags;      // [block][text row][job]: 8 nibbles, pattern column (block*8 + k) at bits 4k
     uint32_t* column;     // [text row][job]: {int16 H, int16 E} of the last pattern column of the previous block
+    const uint8_t* quals; uint64_t n_quals;      // quality-aware scheme: mismatch = mm_lut[quality of the pattern symbol]; nullptr = `mismatch`
+    int32_t   mm_lut[256];
+    int32_t   txt_gap_open, txt_gap_ext;         // the column before the pattern (GLOBAL) is initialised with the text gap costs (gotoh_inl.h:275-279)
 };
 
 template <int TYPE, uint32_t BL>      // BL: pattern symbols per block of the reference's score pass (8 Gotoh, 16 SW / ED): fixes the sink's tie order
@@ -49,8 +52,9 @@ __global__ void __launch_bounds__(256) full_gotoh_traceback_kernel(const FullTbP
     const uint32_t n_blocks = max(1u, (M + BL - 1u) / BL);
     int32_t H_band[BL + 1], F_band[BL + 1];
     uint32_t q_cache[BL];
+    int32_t  x_cache[BL];
     #pragma unroll
-    for (uint32_t t = 0; t < BL; ++t) q_cache[t] = 255u;
+    for (uint32_t t = 0; t < BL; ++t) { q_cache[t] = 255u; x_cache[t] = p.mismatch; }
 
     // ---- forward pass in the reference's visiting order (gotoh_inl.h:640-900), flags kept
     for (uint32_t blk = 0; blk < n_blocks; ++blk)
@@ -58,7 +62,10 @@ __global__ void __launch_bounds__(256) full_gotoh_traceback_kernel(const FullTbP
         const uint32_t block = blk * BL;
         const bool last = (blk + 1u == n_blocks);
         #pragma unroll
-        for (uint32_t t = 0; t < BL; ++t) if (block + t < M) q_cache[t] = get_symbol(p.pat.s, pb + block + t);
+        for (uint32_t t = 0; t < BL; ++t) if (block + t < M) {
+            q_cache[t] = get_symbol(p.pat.s, pb + block + t);
+            if (p.quals) x_cache[t] = p.mm_lut[p.quals[min(pb + block + t, p.n_quals - 1u)]];
+        }
         #pragma unroll
         for (uint32_t j = 0; j <= BL; ++j) {
             H_band[j] = (TYPE != NVBIO_HIP_LOCAL) ? (block + j > 0u ? G_o + G_e * int32_t(block + j - 1u) : 0) : 0;
@@ -70,7 +77,7 @@ __global__ void __launch_bounds__(256) full_gotoh_traceback_kernel(const FullTbP
             const uint32_t r_i = get_symbol(p.txt.s, tb + i);
             int32_t H_diag = temp_i, E;
             if (blk == 0u) {        // context.init (:275-279)
-                temp_i = (TYPE == NVBIO_HIP_GLOBAL) ? G_o + G_e * int32_t(i) : 0;
+                temp_i = (TYPE == NVBIO_HIP_GLOBAL) ? p.txt_gap_open + p.txt_gap_ext * int32_t(i) : 0;
                 E      = (TYPE == NVBIO_HIP_LOCAL) ? 0 : infimum;
             } else {
                 const uint32_t c = p.column[uint64_t(i) * n + tid];
@@ -90,7 +97,7 @@ __global__ void __launch_bounds__(256) full_gotoh_traceback_kernel(const FullTbP
                 const int32_t eleft = E + G_e, hleft = H_band[j - 1] + G_o;
                 E = max(eleft, hleft);
                 const uint32_t edir = eleft > hleft ? T_INSERTION_EXT : T_SUBSTITUTION;
-                const int32_t diagonal = H_diag + (r_i == q_cache[j - 1] ? p.match : p.mismatch);
+                const int32_t diagonal = H_diag + (r_i == q_cache[j - 1] ? p.match : x_cache[j - 1]);
                 const int32_t top = F_band[j], left = E;
                 int32_t hi = max(max(left, top), diagonal);
                 if (TYPE == NVBIO_HIP_LOCAL) hi = max(hi, 0);
@@ -173,8 +180,10 @@ NVB_API uint64_t nvbio_hip_gotoh_traceback_temp_bytes(uint32_t max_pattern_len, 
     return (blocks + 1u) * uint64_t(max_text_len) * uint64_t(n) * 4u;      // flags + the boundary column
 }
 
+struct TbQualPart { const uint8_t* quals; uint64_t n_quals; const int32_t* mismatch; int32_t text_gap_open, text_gap_ext; };
+
 static int full_traceback_core(
-    const nvbio_hip_gotoh_scheme* scheme, int32_t type, uint32_t block_len,
+    const nvbio_hip_gotoh_scheme* scheme, const TbQualPart* qual, int32_t type, uint32_t block_len,
     const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts,
     uint32_t max_pattern_len, uint32_t max_text_len, uint32_t n,
     int32_t* out_score, uint32_t* out_sink, uint32_t* out_source,
@@ -192,7 +201,8 @@ static int full_traceback_core(
     if (maxM == 0 || maxN == 0) return hipErrorInvalidValue;
     if (maxM >= (1u << 14) || maxN >= (1u << 14)) return hipErrorNotSupported;       // io::Cigar::m_len is 14 bits
     auto iabs = [](int32_t v) { return v < 0 ? -int64_t(v) : int64_t(v); };
-    const int64_t A = std::max(std::max(iabs(scheme->match), iabs(scheme->mismatch)), std::max(iabs(scheme->gap_open), iabs(scheme->gap_ext)));
+    int64_t A = std::max(std::max(iabs(scheme->match), iabs(scheme->mismatch)), std::max(iabs(scheme->gap_open), iabs(scheme->gap_ext)));
+    if (qual) { for (int i = 0; i < 256; ++i) A = std::max(A, iabs(qual->mismatch[i])); A = std::max(A, std::max(iabs(qual->text_gap_open), iabs(qual->text_gap_ext))); }
     const int64_t span = (type == NVBIO_HIP_GLOBAL) ? int64_t(maxM) + maxN + 4 : int64_t(maxM) + 4;
     if (!(scheme->gap_open <= 0 && scheme->gap_ext <= 0 && span * A < 30000)) return hipErrorNotSupported;   // int16 checkpoints / columns exact only here
     const uint64_t need = nvbio_hip_gotoh_traceback_temp_bytes(maxM, maxN, n);
@@ -202,6 +212,9 @@ static int full_traceback_core(
     p.pat = make_string_set(patterns); p.txt = make_string_set(texts);
     p.match = scheme->match; p.mismatch = scheme->mismatch; p.gap_open = scheme->gap_open; p.gap_ext = scheme->gap_ext;
     p.n = n; p.max_text_len = maxN;
+    p.quals = qual ? qual->quals : nullptr; p.n_quals = qual ? qual->n_quals : 0;
+    for (int i = 0; i < 256; ++i) p.mm_lut[i] = qual ? qual->mismatch[i] : scheme->mismatch;
+    p.txt_gap_open = qual ? qual->text_gap_open : scheme->gap_open; p.txt_gap_ext = qual ? qual->text_gap_ext : scheme->gap_ext;
     p.out_score = out_score; p.out_sink = reinterpret_cast<uint2*>(out_sink); p.out_source = reinterpret_cast<uint2*>(out_source);
     p.out_cigar = out_cigar; p.cigar_stride = cigar_stride; p.out_cigar_len = out_cigar_len;
     p.column = static_cast<uint32_t*>(temp);
@@ -233,7 +246,7 @@ NVB_API int nvbio_hip_gotoh_traceback(
     uint16_t* out_cigar, uint32_t cigar_stride, uint32_t* out_cigar_len,
     void* temp, uint64_t temp_bytes, void* stream)
 {
-    return full_traceback_core(scheme, type, 8u, patterns, texts, max_pattern_len, max_text_len, n, out_score, out_sink, out_source,
+    return full_traceback_core(scheme, nullptr, type, 8u, patterns, texts, max_pattern_len, max_text_len, n, out_score, out_sink, out_source,
                                out_cigar, cigar_stride, out_cigar_len, temp, temp_bytes, stream);
 }
 
@@ -251,6 +264,25 @@ NVB_API int nvbio_hip_sw_traceback(
     if (!scheme) return hipErrorInvalidValue;
     if (scheme->deletion != scheme->insertion) return hipErrorNotSupported;
     const nvbio_hip_gotoh_scheme g = { scheme->match, scheme->mismatch, scheme->deletion, scheme->deletion };
-    return full_traceback_core(&g, type, 16u, patterns, texts, max_pattern_len, max_text_len, n, out_score, out_sink, out_source,
+    return full_traceback_core(&g, nullptr, type, 16u, patterns, texts, max_pattern_len, max_text_len, n, out_score, out_sink, out_source,
+                               out_cigar, cigar_stride, out_cigar_len, temp, temp_bytes, stream);
+}
+
+// nvBowtie's opposite-mate traceback: GotohAligner<TYPE, SmithWatermanScoringScheme<...>> over the full matrix
+NVB_API int nvbio_hip_gotoh_traceback_qual(
+    const nvbio_hip_gotoh_qual_scheme* scheme, int32_t type,
+    const nvbio_hip_string_set* patterns, const uint8_t* quals, uint64_t n_quals, const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len, uint32_t n,
+    int32_t* out_score, uint32_t* out_sink, uint32_t* out_source,
+    uint16_t* out_cigar, uint32_t cigar_stride, uint32_t* out_cigar_len,
+    void* temp, uint64_t temp_bytes, void* stream)
+{
+    if (!scheme) return hipErrorInvalidValue;
+    if (n != 0 && (!quals || n_quals == 0)) return hipErrorInvalidValue;
+    int32_t worst = 0;
+    for (int i = 0; i < 256; ++i) worst = std::min(worst, scheme->mismatch[i]);
+    const nvbio_hip_gotoh_scheme g = { scheme->match, worst, scheme->pattern_gap_open, scheme->pattern_gap_ext };
+    const TbQualPart q = { quals, n_quals, scheme->mismatch, scheme->text_gap_open, scheme->text_gap_ext };
+    return full_traceback_core(&g, &q, type, 8u, patterns, texts, max_pattern_len, max_text_len, n, out_score, out_sink, out_source,
                                out_cigar, cigar_stride, out_cigar_len, temp, temp_bytes, stream);
 }

@@ -711,16 +711,16 @@ ORACLE_API void oracle_batch_gotoh_score_qual(
 /*      last (source.y);  ops: 0 = M, 1 = I, 2 = D, end of the alignment first */
 /* flags: scratch of M*N bytes, hrow / frow: scratch of M+1 int32 each.        */
 /* ------------------------------------------------------------------------ */
-ORACLE_API void oracle_gotoh_traceback(int type, const int32_t* scheme,
+static void gotoh_traceback_x(int type, const scheme_t* scp,
     const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, uint64_t pat_begin, uint32_t M,
     const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, uint64_t txt_begin, uint32_t N,
     int32_t* res, uint8_t* ops, uint32_t ops_capacity, uint8_t* flags, int32_t* hrow, int32_t* frow)
 {
-    const scheme_t sc = { scheme[0], scheme[1], scheme[2], scheme[3], scheme[2], scheme[3], NULL, NULL };
+    const scheme_t sc = *scp;
     best_sink_t best; sink_init(&best);
     {
         int16_t* temp = (int16_t*)malloc(sizeof(int16_t) * 2 * (size_t)(N + 1));
-        score_pattern_blocking(0, type, &sc, scheme, pat_w, pat_bits, pat_be, pat_begin, M, txt_w, txt_bits, txt_be, txt_begin, N, (-2147483647 - 1), &best, temp);
+        score_pattern_blocking(0, type, &sc, NULL, pat_w, pat_bits, pat_be, pat_begin, M, txt_w, txt_bits, txt_be, txt_begin, N, (-2147483647 - 1), &best, temp);
         free(temp);
     }
     res[0] = best.score; res[3] = (int32_t)best.sink_x; res[4] = (int32_t)best.sink_y; res[5] = res[6] = res[7] = 0;
@@ -747,7 +747,7 @@ ORACLE_API void oracle_gotoh_traceback(int type, const int32_t* scheme,
             E = imax(eleft, hleft);
             const uint8_t edir = eleft > hleft ? DIR_INSERTION_EXT : DIR_SUBSTITUTION;
             const uint8_t q_j = (uint8_t)ps_get(pat_w, pat_bits, pat_be, pat_begin + j - 1);
-            const int32_t diagonal = H_diag + subst(&sc, r_i, q_j, 0);
+            const int32_t diagonal = H_diag + subst(&sc, r_i, q_j, sc.quals ? sc.quals[pat_begin + j - 1] : 0);
             const int32_t top = frow[j], left = E;
             int32_t hi = imax(imax(left, top), diagonal);
             if (type == ALN_LOCAL) hi = imax(hi, 0);
@@ -781,6 +781,24 @@ ORACLE_API void oracle_gotoh_traceback(int type, const int32_t* scheme,
     if (type == ALN_GLOBAL)                            { if (sy == 0) for (; sx > 0; --sx) PUSH(DIR_DELETION); }
     #undef PUSH
     res[1] = (int32_t)sx; res[2] = (int32_t)sy; res[5] = (int32_t)n; res[7] = (int32_t)sy;
+}
+
+ORACLE_API void oracle_gotoh_traceback(int type, const int32_t* scheme,
+    const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, uint64_t pat_begin, uint32_t M,
+    const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, uint64_t txt_begin, uint32_t N,
+    int32_t* res, uint8_t* ops, uint32_t ops_capacity, uint8_t* flags, int32_t* hrow, int32_t* frow)
+{
+    const scheme_t sc = { scheme[0], scheme[1], scheme[2], scheme[3], scheme[2], scheme[3], NULL, NULL };
+    gotoh_traceback_x(type, &sc, pat_w, pat_bits, pat_be, pat_begin, M, txt_w, txt_bits, txt_be, txt_begin, N, res, ops, ops_capacity, flags, hrow, frow);
+}
+/* quality-aware scheme: qscheme = {match, pattern_gap_open, pattern_gap_ext, text_gap_open, text_gap_ext} */
+ORACLE_API void oracle_gotoh_traceback_qual(int type, const int32_t* qscheme, const int32_t* mm_lut, const uint8_t* quals,
+    const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, uint64_t pat_begin, uint32_t M,
+    const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, uint64_t txt_begin, uint32_t N,
+    int32_t* res, uint8_t* ops, uint32_t ops_capacity, uint8_t* flags, int32_t* hrow, int32_t* frow)
+{
+    const scheme_t sc = { qscheme[0], 0, qscheme[1], qscheme[2], qscheme[3], qscheme[4], mm_lut, quals };
+    gotoh_traceback_x(type, &sc, pat_w, pat_bits, pat_be, pat_begin, M, txt_w, txt_bits, txt_be, txt_begin, N, res, ops, ops_capacity, flags, hrow, frow);
 }
 
 /* ------------------------------------------------------------------------ */

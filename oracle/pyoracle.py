@@ -254,8 +254,9 @@ def batch_banded_gotoh_traceback(band, aln_type, scheme, patterns, texts, cigar_
     return out
 
 
-def gotoh_traceback(aln_type, scheme, patterns, texts, i=0):
-    """alignment_traceback (full matrix, Gotoh) of job i -> dict like banded_gotoh_traceback."""
+def gotoh_traceback(aln_type, scheme, patterns, texts, i=0, mm_lut=None, quals=None):
+    """alignment_traceback (full matrix, Gotoh) of job i -> dict like banded_gotoh_traceback.  With mm_lut / quals:
+    scheme = (match, pattern_gap_open, pattern_gap_ext, text_gap_open, text_gap_ext)."""
     M, N = int(patterns.length[i]), int(texts.length[i])
     res = np.zeros(8, dtype=np.int32)
     cap = M + N + 8
@@ -263,11 +264,13 @@ def gotoh_traceback(aln_type, scheme, patterns, texts, i=0):
     flags = np.zeros(max(1, M * N), dtype=np.uint8)
     hrow, frow = np.zeros(M + 1, dtype=np.int32), np.zeros(M + 1, dtype=np.int32)
     sc = _scheme(scheme)
-    lib().oracle_gotoh_traceback(
-        C.c_int(aln_type), _p(sc),
-        _p(patterns.words), C.c_uint32(patterns.bits), C.c_uint32(patterns.big_endian), C.c_uint64(int(patterns.begin[i])), C.c_uint32(M),
-        _p(texts.words), C.c_uint32(texts.bits), C.c_uint32(texts.big_endian), C.c_uint64(int(texts.begin[i])), C.c_uint32(N),
-        _p(res), _p(ops), C.c_uint32(cap), _p(flags), _p(hrow), _p(frow))
+    tail = (_p(patterns.words), C.c_uint32(patterns.bits), C.c_uint32(patterns.big_endian), C.c_uint64(int(patterns.begin[i])), C.c_uint32(M),
+            _p(texts.words), C.c_uint32(texts.bits), C.c_uint32(texts.big_endian), C.c_uint64(int(texts.begin[i])), C.c_uint32(N),
+            _p(res), _p(ops), C.c_uint32(cap), _p(flags), _p(hrow), _p(frow))
+    if mm_lut is None:
+        lib().oracle_gotoh_traceback(C.c_int(aln_type), _p(sc), *tail)
+    else:
+        lib().oracle_gotoh_traceback_qual(C.c_int(aln_type), _p(sc), _p(np.ascontiguousarray(mm_lut, dtype=np.int32)), _p(np.ascontiguousarray(quals, dtype=np.uint8)), *tail)
     n = int(res[5])
     o = ops[:n].copy()
     cig = []
@@ -331,12 +334,12 @@ def batch_sw_traceback(band, aln_type, scheme, patterns, texts, cigar_stride):
     return out
 
 
-def batch_gotoh_traceback(aln_type, scheme, patterns, texts, cigar_stride):
+def batch_gotoh_traceback(aln_type, scheme, patterns, texts, cigar_stride, mm_lut=None, quals=None):
     n = len(patterns)
     out = dict(score=np.empty(n, np.int32), sink=np.empty((n, 2), np.uint32), source=np.empty((n, 2), np.uint32),
                cigar=np.zeros((max(n, 1), cigar_stride), np.uint16), cigar_len=np.empty(n, np.uint32))
     for i in range(n):
-        r = gotoh_traceback(aln_type, scheme, patterns, texts, i)
+        r = gotoh_traceback(aln_type, scheme, patterns, texts, i, mm_lut, quals)
         out["score"][i] = r["score"]; out["sink"][i] = r["sink"]; out["source"][i] = r["source"]
         c = r["cigar"]
         out["cigar_len"][i] = c.size

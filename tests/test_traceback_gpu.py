@@ -210,3 +210,29 @@ def test_sw_and_ed_tracebacks(cuda, ty):
     got = nvb.batch_alignment_traceback(nvb.make_smith_waterman_aligner(ty, nvb.SimpleSmithWatermanScheme(2, -1, -1, -1)), to_dev(h1, cuda), to_dev(h2, cuda), 7, 20)
     cig = got["cigar"][0, :int(got["cigar_len"][0])].cpu().numpy().view(np.uint16)
     assert "".join("%d%s" % (c >> 2, "MIDS"[c & 3]) for c in cig) == {nvb.GLOBAL: "1M2D3M1D3M10D", nvb.LOCAL: "4M1D3M", nvb.SEMI_GLOBAL: "4M1D3M"}[ty]
+
+
+@pytest.mark.parametrize("ty", [nvb.LOCAL, nvb.SEMI_GLOBAL, nvb.GLOBAL])
+def test_full_matrix_traceback_quality_aware(cuda, ty):
+    """nvBowtie's opposite-mate traceback: quality-aware scheme over the full matrix (asymmetric gap costs included)"""
+    rng = np.random.default_rng(8500 + ty)
+    pats, txts = [], []
+    for i in range(300):
+        M, N = int(rng.integers(1, 150)), int(rng.integers(1, 400))
+        t = rng.integers(0, 4, N).astype(np.uint8)
+        p = np.resize(t[int(rng.integers(0, N)):], M).copy()
+        mut = rng.random(M) < 0.06
+        p[mut] = rng.integers(0, 5, int(mut.sum()))
+        pats.append(p); txts.append(t)
+    hp, ht = O.StringSet.from_lists(pats, 4, True), O.StringSet.from_lists(txts, 2, True)
+    quals = rng.integers(0, 60, int(hp.begin[-1] + hp.length[-1]) + 3, dtype=np.uint8)
+    for scheme in (nvb.SmithWatermanScoringScheme.local(),
+                   nvb.SmithWatermanScoringScheme(match=1, mmp_min=1, mmp_max=9, read_gap_const=4, read_gap_coeff=2, ref_gap_const=7, ref_gap_coeff=1)):
+        st = scheme.struct()
+        lut = np.array([st.mismatch[q] for q in range(256)], dtype=np.int32)
+        s5 = (st.match, st.pattern_gap_open, st.pattern_gap_ext, st.text_gap_open, st.text_gap_ext)
+        exp = O.batch_gotoh_traceback(ty, s5, hp, ht, 48, lut, quals)
+        got = nvb.batch_alignment_traceback(nvb.make_gotoh_aligner(ty, scheme), to_dev(hp, cuda), to_dev(ht, cuda), 150, 400, cigar_stride=48,
+                                            quals=torch.from_numpy(quals).to(cuda))
+        torch.cuda.synchronize()
+        compare(exp, got, (ty, st.match))
