@@ -364,6 +364,18 @@ int nvbio_hip_score_reduce(uint32_t n_active, const uint32_t* read_ids /* nullab
                            const uint32_t* read_len /* by read id, nullable */, uint32_t fixed_read_len,
                            uint64_t* best_alignments, uint32_t best_stride, void* stream);
 
+/* The paired-end form: score_reduce_paired_kernel (reduce_inl.h:355-500).  Per extension result the anchor mate's
+ * {loc, sink (genome end), score, rc} and the opposite mate's {loc, sink, sink2, score, score2} (the stream's hit.* fields,
+ * score_opposite_inl.h:203-235); the pair is `paired` when the opposite score exceeds score_limit.  best_alignments holds
+ * the anchor (or, while no pair was found and pe_unpaired, mate 1) entries, best_alignments_o the opposite (mate 2) ones.
+ * anchor: 0 / 1; pe_policy: io::PairedEndPolicy (FF 0, FR 1, RF 2, RR 3). */
+int nvbio_hip_score_reduce_paired(uint32_t n_active, const uint32_t* read_ids /* nullable */, const uint64_t* hit_begin,
+    const uint32_t* hit_loc, const uint32_t* hit_sink, const int32_t* hit_score, const uint8_t* hit_rc,
+    const uint32_t* opposite_loc, const uint32_t* opposite_sink, const uint32_t* opposite_sink2,
+    const int32_t* opposite_score, const int32_t* opposite_score2,
+    const uint32_t* read_len /* nullable */, uint32_t fixed_read_len, uint32_t anchor, int32_t pe_policy, int32_t pe_unpaired, int32_t score_limit,
+    uint64_t* best_alignments, uint64_t* best_alignments_o, uint32_t best_stride, void* stream);
+
 /* BowtieMapq2 / BowtieMapq3 (nvBowtie/bowtie2/cuda/mapq.h:42-330) for single-end reads:
  * out_mapq[r] from the best / second-best alignment of read r; perfect_score(len) = len * match,
  * min_score(len) = min_score_by_len[len] (the scheme's SimpleFunc tabulated by the host, scoring.h:272-281),
@@ -371,6 +383,13 @@ int nvbio_hip_score_reduce(uint32_t n_active, const uint32_t* read_ids /* nullab
 int nvbio_hip_mapq(int32_t version, int32_t match, int32_t monotone, const int32_t* min_score_by_len /* device */,
                    uint32_t n_reads, const uint64_t* best_alignments, uint32_t best_stride,
                    const uint32_t* read_len /* nullable */, uint32_t fixed_read_len, uint8_t* out_mapq, void* stream);
+
+/* The same calculators over BestPairedAlignments(anchor pair, opposite pair) (mapq.h:56-58, 156-166): when the best alignment
+ * is paired, scores and the score range are the sums over both mates (version 2) / the quality is 44 (version 3). */
+int nvbio_hip_mapq_paired(int32_t version, int32_t match, int32_t monotone, const int32_t* min_score_by_len /* device */,
+                          uint32_t n_reads, const uint64_t* best_alignments, const uint64_t* best_alignments_o, uint32_t best_stride,
+                          const uint32_t* read_len /* nullable */, const uint32_t* o_read_len /* nullable */,
+                          uint32_t fixed_read_len, uint32_t o_fixed_read_len, uint8_t* out_mapq, void* stream);
 
 /* Replaces nvbio::locate(fmi, i) (fmindex_inl.h:466-501) and nvBowtie's
  * locate_kernel (nvBowtie/bowtie2/cuda/locate_inl.h:122-148). */

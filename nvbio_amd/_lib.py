@@ -12,7 +12,7 @@ SYMBOLS = [
     "nvbio_hip_gotoh_traceback_temp_bytes", "nvbio_hip_gotoh_traceback", "nvbio_hip_gotoh_traceback_qual", "nvbio_hip_banded_sw_traceback", "nvbio_hip_sw_traceback",
     "nvbio_hip_fm_rank", "nvbio_hip_fm_rank4", "nvbio_hip_fm_rank_range",
     "nvbio_hip_fm_match", "nvbio_hip_fm_build_ktab", "nvbio_hip_map_exact", "nvbio_hip_map",
-    "nvbio_hip_alignment_invalid", "nvbio_hip_init_alignments", "nvbio_hip_score_reduce", "nvbio_hip_mapq", "nvbio_hip_fm_locate",
+    "nvbio_hip_alignment_invalid", "nvbio_hip_init_alignments", "nvbio_hip_score_reduce", "nvbio_hip_score_reduce_paired", "nvbio_hip_mapq", "nvbio_hip_mapq_paired", "nvbio_hip_fm_locate",
     "nvbio_hip_fm_locate_ssa_iterator", "nvbio_hip_fm_lookup_ssa_iterator",
     "nvbio_hip_fm_filter_temp_bytes", "nvbio_hip_fm_filter_rank", "nvbio_hip_fm_filter_locate",
     "nvbio_hip_build_bwt_occ_temp_bytes", "nvbio_hip_build_bwt_occ",
@@ -95,7 +95,9 @@ def lib():
         L.nvbio_hip_alignment_invalid.restype = u64
         L.nvbio_hip_init_alignments.argtypes = [u32, vp, u32, vp, u32, vp, u32, vp]
         L.nvbio_hip_score_reduce.argtypes = [u32, vp, vp, vp, vp, vp, vp, u32, vp, u32, vp]
+        L.nvbio_hip_score_reduce_paired.argtypes = [u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, i32, i32, i32, vp, vp, u32, vp]
         L.nvbio_hip_mapq.argtypes = [i32, i32, i32, vp, u32, vp, u32, vp, u32, vp, vp]
+        L.nvbio_hip_mapq_paired.argtypes = [i32, i32, i32, vp, u32, vp, vp, u32, vp, vp, u32, u32, vp, vp]
         L.nvbio_hip_fm_locate.argtypes = [P(FMIndexStruct), vp, u32, vp, vp]
         L.nvbio_hip_fm_locate_ssa_iterator.argtypes = [P(FMIndexStruct), vp, u32, vp, vp]
         L.nvbio_hip_fm_lookup_ssa_iterator.argtypes = [P(FMIndexStruct), vp, u32, vp, vp]

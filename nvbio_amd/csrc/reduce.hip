@@ -65,6 +65,104 @@ init_alignments_kernel(uint32_t n_reads, const uint32_t* __restrict__ read_len, 
     best[r + best_stride] = make_uint2(a.w, a.align);
 }
 
+// ------------------------------------------------------------------ paired-end reduction
+// score_reduce_paired_kernel (reduce_inl.h:355-500) with try_update / update_* / replace_best (:160-350),
+// frame_opposite_mate (alignment_utils.h:61-98), the paired distinct_alignments (alignments_inl.h:66-80,121-136)
+__device__ __forceinline__ IoAln io_aln_make_full(uint32_t pos, uint32_t ed, int32_t score, uint32_t rc, uint32_t mate, bool paired)
+{
+    IoAln a = io_aln_make(pos, ed, score, rc);
+    a.w |= ((mate & 1u) << 29) | ((paired ? 1u : 0u) << 30);
+    return a;
+}
+__device__ __forceinline__ uint32_t io_aln_sink(const IoAln a)   { return (a.w >> 18) & 0x3FFu; }
+__device__ __forceinline__ uint32_t io_aln_mate(const IoAln a)   { return (a.w >> 29) & 1u; }
+__device__ __forceinline__ bool     io_aln_paired(const IoAln a) { return ((a.w >> 30) & 1u) != 0u && a.align != 0xFFFFFFFFu; }
+struct IoPair { IoAln a, o; };
+struct IoBestPairs { IoAln a1, a2, o1, o2; };
+__device__ __forceinline__ IoAln   pair_mate(const IoPair& p, uint32_t m) { return m == io_aln_mate(p.a) ? p.a : p.o; }
+__device__ __forceinline__ int32_t pair_score(const IoPair& p) { return io_aln_score(p.a) + io_aln_score(p.o); }
+__device__ __forceinline__ int32_t bp_best_score(const IoBestPairs& b)   { return io_aln_score(b.a1) + (io_aln_paired(b.a1) ? io_aln_score(b.o1) : 0); }
+__device__ __forceinline__ int32_t bp_second_score(const IoBestPairs& b) { return io_aln_score(b.a2) + (io_aln_paired(b.a2) ? io_aln_score(b.o2) : 0); }
+__device__ __forceinline__ bool distinct_pairs(const IoPair& p1, const IoPair& p2, uint32_t dist)
+{
+    const IoAln a1 = pair_mate(p1, 0), o1 = pair_mate(p1, 1), a2 = pair_mate(p2, 0), o2 = pair_mate(p2, 1);
+    const uint32_t apos1 = a1.align + io_aln_sink(a1), opos1 = o1.align + io_aln_sink(o1);
+    const uint32_t apos2 = a2.align + io_aln_sink(a2), opos2 = o2.align + io_aln_sink(o2);
+    if (io_aln_rc(a1) != io_aln_rc(a2) || io_aln_rc(o1) != io_aln_rc(o2)) return true;
+    return !((apos1 >= apos2 - min(apos2, dist) && apos1 <= apos2 + dist) && (opos1 >= opos2 - min(opos2, dist) && opos1 <= opos2 + dist));
+}
+__device__ __forceinline__ bool distinct_alns(const IoAln p1, const IoAln p2, uint32_t dist)
+{
+    return distinct_alignments(p1.align + io_aln_sink(p1), io_aln_rc(p1), p2.align + io_aln_sink(p2), io_aln_rc(p2), dist);
+}
+__device__ __forceinline__ void try_update_pair(IoBestPairs& b, const IoPair& pair, uint32_t min_distance)
+{
+    const int32_t score = pair_score(pair);
+    const IoPair p0 = { b.a1, b.o1 }, p1 = { b.a2, b.o2 };
+    if (!distinct_pairs(p0, pair, min_distance)) { if (score > bp_best_score(b)) { b.a1 = pair.a; b.o1 = pair.o; } }
+    else if (!distinct_pairs(p1, pair, min_distance)) {
+        if (score > bp_best_score(b)) { b.a2 = b.a1; b.o2 = b.o1; b.a1 = pair.a; b.o1 = pair.o; }
+        else if (score > bp_second_score(b)) { b.a2 = pair.a; b.o2 = pair.o; }
+    }
+    else if (!io_aln_paired(b.a1) || score > bp_best_score(b)) { b.a2 = b.a1; b.o2 = b.o1; b.a1 = pair.a; b.o1 = pair.o; }
+    else if (!io_aln_paired(b.a2) || score > bp_second_score(b)) { b.a2 = pair.a; b.o2 = pair.o; }
+}
+__device__ __forceinline__ void try_update_single(IoAln& a1, IoAln& a2, const IoAln a, uint32_t min_distance)
+{
+    if (!distinct_alns(a1, a, min_distance)) { if (io_aln_score(a) > io_aln_score(a1)) a1 = a; }
+    else if (!distinct_alns(a2, a, min_distance)) {
+        if (io_aln_score(a) > io_aln_score(a1)) { a2 = a1; a1 = a; }
+        else if (io_aln_score(a) > io_aln_score(a2)) a2 = a;
+    }
+    else if (io_aln_score(a) > io_aln_score(a1)) { a2 = a1; a1 = a; }
+    else if (io_aln_score(a) > io_aln_score(a2)) a2 = a;
+}
+
+struct PairedReduceParams {
+    uint32_t n_active; const uint32_t* read_ids; const uint64_t* hit_begin;
+    const uint32_t* hit_loc; const uint32_t* hit_sink; const int32_t* hit_score; const uint8_t* hit_rc;
+    const uint32_t* o_loc; const uint32_t* o_sink; const uint32_t* o_sink2; const int32_t* o_score; const int32_t* o_score2;
+    const uint32_t* read_len; uint32_t fixed_len;
+    uint32_t anchor; int32_t pe_policy, pe_unpaired, score_limit;
+    uint2* best; uint2* best_o; uint32_t best_stride;
+};
+
+__global__ void __launch_bounds__(256) score_reduce_paired_kernel(const PairedReduceParams p)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= p.n_active) return;
+    const uint32_t read_id = p.read_ids ? p.read_ids[t] : t;
+    auto ld = [](const uint2* q, uint32_t i) { const uint2 v = q[i]; IoAln a = { v.x, v.y }; return a; };
+    IoBestPairs b = { ld(p.best, read_id), ld(p.best, read_id + p.best_stride), ld(p.best_o, read_id), ld(p.best_o, read_id + p.best_stride) };
+    const uint32_t min_distance = (p.read_len ? p.read_len[read_id] : p.fixed_len) / 4u;
+    for (uint64_t i = p.hit_begin[t]; i < p.hit_begin[t + 1]; ++i)
+    {
+        const uint32_t rc = p.hit_rc[i];
+        const bool anchor_fw = !rc, anchor_1 = (p.anchor == 0u);
+        bool o_fw;      // frame_opposite_mate: only the orientation is needed here
+        switch (p.pe_policy) {
+        case 0: case 3: o_fw = anchor_fw; break;         // FF, RR
+        default:        o_fw = !anchor_fw; break;        // FR, RF
+        }
+        (void)anchor_1;
+        const uint32_t o_rc = !o_fw;
+        const IoPair pair  = { io_aln_make_full(p.hit_loc[i], p.hit_sink[i] - p.hit_loc[i], p.hit_score[i], rc, p.anchor, p.o_score[i] > p.score_limit),
+                               io_aln_make_full(p.o_loc[i], p.o_sink[i] - p.o_loc[i], p.o_score[i], o_rc, p.anchor ^ 1u, p.o_score[i] > p.score_limit) };
+        const IoPair pair2 = { io_aln_make_full(p.hit_loc[i], p.hit_sink[i] - p.hit_loc[i], p.hit_score[i], rc, p.anchor, p.o_score2[i] > p.score_limit),
+                               io_aln_make_full(p.o_loc[i], p.o_sink2[i] - p.o_loc[i], p.o_score2[i], o_rc, p.anchor ^ 1u, p.o_score2[i] > p.score_limit) };
+        if (io_aln_paired(pair.a)) {
+            try_update_pair(b, pair, min_distance);
+            if (io_aln_paired(pair2.a)) try_update_pair(b, pair2, min_distance);
+        } else if (p.pe_unpaired && !io_aln_paired(b.a1)) {
+            // no paired alignment yet: best two of mate 1 live in m_a*, of mate 2 in m_o*
+            if (p.anchor) try_update_single(b.o1, b.o2, pair.a, min_distance);
+            else          try_update_single(b.a1, b.a2, pair.a, min_distance);
+        }
+    }
+    p.best[read_id] = make_uint2(b.a1.w, b.a1.align); p.best[read_id + p.best_stride] = make_uint2(b.a2.w, b.a2.align);
+    p.best_o[read_id] = make_uint2(b.o1.w, b.o1.align); p.best_o[read_id + p.best_stride] = make_uint2(b.o2.w, b.o2.align);
+}
+
 // single-precision arithmetic without contraction, so the thresholds fall where the host code puts them
 __device__ __forceinline__ float fmul(float a, float b) { return __fmul_rn(a, b); }
 __device__ __forceinline__ float fadd(float a, float b) { return __fadd_rn(a, b); }
@@ -78,8 +176,9 @@ __constant__ int8_t c_unpaired_two[11][11] = {
     { 23, 22, 19, 16, 11, 0, 0, 0, 0, 0, 0 }, { 24, 25, 21, 30,  0, 0, 0, 0, 0, 0, 0 }, { 30, 26, 29,  0,  0, 0, 0, 0, 0, 0, 0 },
     { 30, 27,  0,  0,  0, 0, 0, 0, 0, 0, 0 }, { 30,  0,  0,  0,  0, 0, 0, 0, 0, 0, 0 } };
 
-__device__ uint32_t mapq_v3(int32_t best_score, bool has_second, int32_t second_score, float max_score, float min_score)
+__device__ uint32_t mapq_v3(int32_t best_score, bool has_second, int32_t second_score, float max_score, float min_score, bool is_paired = false)
 {
+    if (is_paired) return 44u;          // paired_one_perfect (mapq.h:96-102)
     const float norm_factor = __fdiv_rn(10.0f, fadd(max_score, -min_score));
     if (float(best_score) < min_score) return 0u;
     const int best = max(int(max_score) - best_score, 0);
@@ -149,6 +248,28 @@ mapq_kernel(int32_t version, int32_t match, int32_t monotone, uint32_t n_reads, 
                                   : mapq_v2(io_aln_score(a1), has_second, io_aln_score(a2), max_score, min_score, monotone != 0));
 }
 
+__global__ void __launch_bounds__(256)
+mapq_paired_kernel(int32_t version, int32_t match, int32_t monotone, uint32_t n_reads, const uint2* __restrict__ best, const uint2* __restrict__ best_o,
+                   uint32_t best_stride, const uint32_t* __restrict__ read_len, const uint32_t* __restrict__ o_read_len, uint32_t fixed_len, uint32_t o_fixed_len,
+                   const int32_t* __restrict__ min_score_by_len, uint8_t* __restrict__ out)
+{
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= n_reads) return;
+    auto ld = [](const uint2* q, uint32_t i) { const uint2 v = q[i]; IoAln a = { v.x, v.y }; return a; };
+    const IoBestPairs b = { ld(best, r), ld(best, r + best_stride), ld(best_o, r), ld(best_o, r + best_stride) };
+    if (b.a1.align == 0xFFFFFFFFu) { out[r] = 0; return; }
+    const bool paired = io_aln_paired(b.a1);
+    const bool has_second = paired ? io_aln_paired(b.a2) : (b.a2.align != 0xFFFFFFFFu);
+    const uint32_t len = read_len ? read_len[r] : fixed_len, olen = o_read_len ? o_read_len[r] : o_fixed_len;
+    if (version == 3) {
+        out[r] = uint8_t(mapq_v3(bp_best_score(b), has_second, bp_second_score(b), float(int32_t(len) * match), float(min_score_by_len[len]), paired));
+    } else {
+        const float max_score = fadd(float(int32_t(len) * match), paired ? float(int32_t(olen) * match) : 0.0f);
+        const float min_score = fadd(float(min_score_by_len[len]), paired ? float(min_score_by_len[olen]) : 0.0f);
+        out[r] = uint8_t(mapq_v2(bp_best_score(b), has_second, bp_second_score(b), max_score, min_score, monotone != 0));
+    }
+}
+
 } // namespace nvb
 
 using namespace nvb;
@@ -196,5 +317,40 @@ NVB_API int nvbio_hip_mapq(int32_t version, int32_t match, int32_t monotone, con
     g_last_kernel = "mapq_kernel";
     hipLaunchKernelGGL(mapq_kernel, dim3((n_reads + 255u) / 256u), dim3(256), 0, to_stream(stream), version, match, monotone, n_reads,
                        reinterpret_cast<const uint2*>(best_alignments), best_stride, read_len, fixed_read_len, min_score_by_len, out_mapq);
+    return hipGetLastError();
+}
+
+NVB_API int nvbio_hip_score_reduce_paired(uint32_t n_active, const uint32_t* read_ids, const uint64_t* hit_begin,
+    const uint32_t* hit_loc, const uint32_t* hit_sink, const int32_t* hit_score, const uint8_t* hit_rc,
+    const uint32_t* opposite_loc, const uint32_t* opposite_sink, const uint32_t* opposite_sink2,
+    const int32_t* opposite_score, const int32_t* opposite_score2,
+    const uint32_t* read_len, uint32_t fixed_read_len, uint32_t anchor, int32_t pe_policy, int32_t pe_unpaired, int32_t score_limit,
+    uint64_t* best_alignments, uint64_t* best_alignments_o, uint32_t best_stride, void* stream)
+{
+    if (n_active == 0) return hipSuccess;
+    if (!hit_begin || !hit_loc || !hit_sink || !hit_score || !hit_rc || !opposite_loc || !opposite_sink || !opposite_sink2 || !opposite_score || !opposite_score2 ||
+        !best_alignments || !best_alignments_o || best_stride == 0 || anchor > 1u || pe_policy < 0 || pe_policy > 3) return hipErrorInvalidValue;
+    if (!read_len && fixed_read_len == 0) return hipErrorInvalidValue;
+    PairedReduceParams p = { n_active, read_ids, hit_begin, hit_loc, hit_sink, hit_score, hit_rc, opposite_loc, opposite_sink, opposite_sink2, opposite_score, opposite_score2,
+                             read_len, fixed_read_len, anchor, pe_policy, pe_unpaired, score_limit,
+                             reinterpret_cast<uint2*>(best_alignments), reinterpret_cast<uint2*>(best_alignments_o), best_stride };
+    g_last_kernel = "score_reduce_paired_kernel";
+    hipLaunchKernelGGL(score_reduce_paired_kernel, dim3((n_active + 255u) / 256u), dim3(256), 0, to_stream(stream), p);
+    return hipGetLastError();
+}
+
+NVB_API int nvbio_hip_mapq_paired(int32_t version, int32_t match, int32_t monotone, const int32_t* min_score_by_len,
+                                  uint32_t n_reads, const uint64_t* best_alignments, const uint64_t* best_alignments_o, uint32_t best_stride,
+                                  const uint32_t* read_len, const uint32_t* o_read_len, uint32_t fixed_read_len, uint32_t o_fixed_read_len,
+                                  uint8_t* out_mapq, void* stream)
+{
+    if (version != 2 && version != 3) return hipErrorInvalidValue;
+    if (n_reads == 0) return hipSuccess;
+    if (!min_score_by_len || !best_alignments || !best_alignments_o || !out_mapq || best_stride == 0) return hipErrorInvalidValue;
+    if ((!read_len && fixed_read_len == 0) || (!o_read_len && o_fixed_read_len == 0)) return hipErrorInvalidValue;
+    g_last_kernel = "mapq_paired_kernel";
+    hipLaunchKernelGGL(mapq_paired_kernel, dim3((n_reads + 255u) / 256u), dim3(256), 0, to_stream(stream), version, match, monotone, n_reads,
+                       reinterpret_cast<const uint2*>(best_alignments), reinterpret_cast<const uint2*>(best_alignments_o), best_stride,
+                       read_len, o_read_len, fixed_read_len, o_fixed_read_len, min_score_by_len, out_mapq);
     return hipGetLastError();
 }

@@ -63,3 +63,30 @@ def mapq(best, scheme, read_len=None, fixed_read_len=0, version=2, max_read_len=
                                _vp(read_len), int(fixed_read_len), _vp(out), current_stream_ptr()), "nvbio_hip_mapq")
     table.record_stream(torch.cuda.current_stream())      # read asynchronously by the kernel
     return out
+
+
+PE_POLICY_FF, PE_POLICY_FR, PE_POLICY_RF, PE_POLICY_RR = 0, 1, 2, 3      # io::PairedEndPolicy (sequence.h:190-196)
+
+
+def score_reduce_paired(best, best_o, hit_begin, hit_loc, hit_sink, hit_score, hit_rc, o_loc, o_sink, o_sink2, o_score, o_score2,
+                        anchor, pe_policy=PE_POLICY_FR, pe_unpaired=True, score_limit=-(1 << 17) + 1, read_len=None, fixed_read_len=0, read_ids=None):
+    """score_reduce_paired (reduce_inl.h:355-500): fold the paired extension results of every active read into
+    best (anchor / mate-1 entries) and best_o (opposite / mate-2 entries)."""
+    n_active = hit_begin.numel() - 1
+    check(lib().nvbio_hip_score_reduce_paired(n_active, _vp(read_ids), _vp(hit_begin), _vp(hit_loc), _vp(hit_sink), _vp(hit_score), _vp(hit_rc),
+                                              _vp(o_loc), _vp(o_sink), _vp(o_sink2), _vp(o_score), _vp(o_score2), _vp(read_len), int(fixed_read_len),
+                                              int(anchor), int(pe_policy), int(bool(pe_unpaired)), int(score_limit),
+                                              _vp(best.data), _vp(best_o.data), best.stride, current_stream_ptr()), "nvbio_hip_score_reduce_paired")
+    return best, best_o
+
+
+def mapq_paired(best, best_o, scheme, read_len=None, o_read_len=None, fixed_read_len=0, o_fixed_read_len=0, version=2, max_read_len=None):
+    """BowtieMapq2 / BowtieMapq3 over BestPairedAlignments(best, best_o) -> uint8[n]."""
+    dev = best.data.device
+    max_len = int(max_read_len or max(fixed_read_len, o_fixed_read_len) or max(int(read_len.max()), int(o_read_len.max())))
+    table = torch.tensor([scheme.min_score(L) if L > 0 else 0 for L in range(max_len + 1)], dtype=torch.int32, device=dev)
+    out = torch.empty(best.n, dtype=torch.uint8, device=dev)
+    check(lib().nvbio_hip_mapq_paired(int(version), int(scheme.m_match), int(bool(scheme.m_monotone)), _vp(table), best.n, _vp(best.data), _vp(best_o.data), best.stride,
+                                      _vp(read_len), _vp(o_read_len), int(fixed_read_len), int(o_fixed_read_len), _vp(out), current_stream_ptr()), "nvbio_hip_mapq_paired")
+    table.record_stream(torch.cuda.current_stream())
+    return out

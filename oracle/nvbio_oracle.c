@@ -1802,14 +1802,132 @@ ORACLE_API void oracle_score_reduce(uint32_t n_active, const uint32_t* read_ids 
     }
 }
 
+/* ------------------------------------------------------------------------ */
+/* paired-end reduction: score_reduce_paired_kernel (reduce_inl.h:355-500),   */
+/* try_update / update_best / replace_best / update_second (:160-350),        */
+/* frame_opposite_mate (alignment_utils.h:61-98), io::PairedAlignments /      */
+/* BestPairedAlignments (alignments.h:180-330), the paired                    */
+/* distinct_alignments (alignments_inl.h:66-80,121-136)                       */
+/* ------------------------------------------------------------------------ */
+static inline io_aln_t io_aln_make_full(uint32_t pos, uint32_t ed, int32_t score, uint32_t rc, uint32_t mate, int paired)
+{
+    io_aln_t a = io_aln_make(pos, ed, score, rc);
+    a.w |= ((mate & 1u) << 29) | ((paired ? 1u : 0u) << 30);
+    return a;
+}
+static inline uint32_t io_aln_sink(io_aln_t a)   { return (a.w >> 18) & 0x3FFu; }
+static inline uint32_t io_aln_mate(io_aln_t a)   { return (a.w >> 29) & 1u; }
+static inline int      io_aln_paired(io_aln_t a) { return ((a.w >> 30) & 1u) && io_aln_aligned(a); }       /* is_paired() */
+static inline int      io_aln_unpaired(io_aln_t a) { return !((a.w >> 30) & 1u) && io_aln_aligned(a); }
+typedef struct { io_aln_t a, o; } io_pair_t;
+typedef struct { io_aln_t a1, a2, o1, o2; } io_best_pairs_t;
+static inline io_aln_t pair_mate(const io_pair_t* p, uint32_t m) { return m == io_aln_mate(p->a) ? p->a : p->o; }
+static inline int32_t  pair_score(const io_pair_t* p) { return io_aln_score(p->a) + io_aln_score(p->o); }
+static inline int      bp_is_paired(const io_best_pairs_t* b) { return io_aln_paired(b->a1); }
+static inline int      bp_has_second_paired(const io_best_pairs_t* b) { return io_aln_paired(b->a2); }
+static inline int32_t  bp_best_score(const io_best_pairs_t* b) { return io_aln_score(b->a1) + (bp_is_paired(b) ? io_aln_score(b->o1) : 0); }
+static inline int32_t  bp_second_score(const io_best_pairs_t* b) { return io_aln_score(b->a2) + (bp_has_second_paired(b) ? io_aln_score(b->o2) : 0); }
+static int distinct_pairs(const io_pair_t* p1, const io_pair_t* p2, uint32_t dist)
+{
+    const io_aln_t a1 = pair_mate(p1, 0), o1 = pair_mate(p1, 1), a2 = pair_mate(p2, 0), o2 = pair_mate(p2, 1);
+    const uint32_t apos1 = a1.align + io_aln_sink(a1), opos1 = o1.align + io_aln_sink(o1);
+    const uint32_t apos2 = a2.align + io_aln_sink(a2), opos2 = o2.align + io_aln_sink(o2);
+    if (io_aln_rc(a1) != io_aln_rc(a2) || io_aln_rc(o1) != io_aln_rc(o2)) return 1;
+    return ((apos1 >= apos2 - (apos2 < dist ? apos2 : dist) && apos1 <= apos2 + dist) &&
+            (opos1 >= opos2 - (opos2 < dist ? opos2 : dist) && opos1 <= opos2 + dist)) ? 0 : 1;
+}
+static int distinct_alns(io_aln_t p1, io_aln_t p2, uint32_t dist)
+{
+    return distinct_alignments(p1.align + io_aln_sink(p1), io_aln_rc(p1), p2.align + io_aln_sink(p2), io_aln_rc(p2), dist);
+}
+static int try_update_pair(io_best_pairs_t* b, const io_pair_t* pair, uint32_t min_distance)
+{
+    const int32_t score = pair_score(pair);
+    const io_pair_t p0 = { b->a1, b->o1 }, p1 = { b->a2, b->o2 };
+    if (!distinct_pairs(&p0, pair, min_distance)) {
+        if (score > bp_best_score(b)) { b->a1 = pair->a; b->o1 = pair->o; }                         /* replace_best */
+        return 1;
+    } else if (!distinct_pairs(&p1, pair, min_distance)) {
+        if (score > bp_best_score(b)) { b->a2 = b->a1; b->o2 = b->o1; b->a1 = pair->a; b->o1 = pair->o; }     /* update_best */
+        else if (score > bp_second_score(b)) { b->a2 = pair->a; b->o2 = pair->o; }                  /* update_second */
+        return 1;
+    } else if (!bp_is_paired(b) || score > bp_best_score(b)) {
+        b->a2 = b->a1; b->o2 = b->o1; b->a1 = pair->a; b->o1 = pair->o; return 1;
+    } else if (!bp_has_second_paired(b) || score > bp_second_score(b)) {
+        b->a2 = pair->a; b->o2 = pair->o; return 1;
+    }
+    return 0;
+}
+static int try_update_single(io_aln_t* a1, io_aln_t* a2, io_aln_t a, uint32_t min_distance)
+{
+    if (!distinct_alns(*a1, a, min_distance)) { if (io_aln_score(a) > io_aln_score(*a1)) *a1 = a; return 1; }
+    else if (!distinct_alns(*a2, a, min_distance)) {
+        if (io_aln_score(a) > io_aln_score(*a1)) { *a2 = *a1; *a1 = a; }
+        else if (io_aln_score(a) > io_aln_score(*a2)) *a2 = a;
+        return 1;
+    }
+    else if (io_aln_score(a) > io_aln_score(*a1)) { *a2 = *a1; *a1 = a; return 1; }
+    else if (io_aln_score(a) > io_aln_score(*a2)) { *a2 = a; return 1; }
+    return 0;
+}
+static void frame_opposite_mate(int policy, uint32_t anchor, int anchor_fw, int* left, int* fw)
+{   /* io::PairedEndPolicy: FF = 0, FR = 1, RF = 2, RR = 3 (nvbio/io/sequence/sequence.h:190-196) */
+    const int anchor_1 = (anchor == 0);
+    switch (policy) {
+    case 0:  *left = (anchor_1 != anchor_fw); *fw = anchor_fw;  break;     /* FF */
+    case 3:  *left = (anchor_1 == anchor_fw); *fw = anchor_fw;  break;     /* RR */
+    case 1:  *left = !anchor_fw;              *fw = !anchor_fw; break;     /* FR */
+    default: *left = anchor_fw;               *fw = !anchor_fw; break;     /* RF */
+    }
+}
+/* hit arrays per extension result: loc, sink (genome end of the anchor), score, rc, opposite_loc, opposite_sink,
+ * opposite_sink2, opposite_score, opposite_score2; best / best_o: [2][best_stride] io::Alignment words */
+ORACLE_API void oracle_score_reduce_paired(uint32_t n_active, const uint32_t* read_ids, const uint64_t* hit_begin,
+    const uint32_t* hit_loc, const uint32_t* hit_sink, const int32_t* hit_score, const uint8_t* hit_rc,
+    const uint32_t* o_loc, const uint32_t* o_sink, const uint32_t* o_sink2, const int32_t* o_score, const int32_t* o_score2,
+    const uint32_t* read_len, uint32_t anchor, int pe_policy, int pe_unpaired, int32_t score_limit,
+    uint64_t* best, uint64_t* best_o, uint32_t best_stride)
+{
+    #define LD(p, i) ((io_aln_t){ (uint32_t)(p)[i], (uint32_t)((p)[i] >> 32) })
+    #define ST(p, i, a) ((p)[i] = ((uint64_t)(a).align << 32) | (a).w)
+    for (uint32_t t = 0; t < n_active; ++t)
+    {
+        const uint32_t read_id = read_ids ? read_ids[t] : t;
+        io_best_pairs_t b = { LD(best, read_id), LD(best, read_id + best_stride), LD(best_o, read_id), LD(best_o, read_id + best_stride) };
+        const uint32_t min_distance = read_len[read_id] / 4;
+        for (uint64_t i = hit_begin[t]; i < hit_begin[t + 1]; ++i)
+        {
+            const uint32_t rc = hit_rc[i];
+            int o_left, o_fw;
+            frame_opposite_mate(pe_policy, anchor, !rc, &o_left, &o_fw);
+            const uint32_t o_rc = !o_fw;
+            const io_pair_t pair  = { io_aln_make_full(hit_loc[i], hit_sink[i] - hit_loc[i], hit_score[i], rc, anchor, o_score[i] > score_limit),
+                                      io_aln_make_full(o_loc[i], o_sink[i] - o_loc[i], o_score[i], o_rc, !anchor, o_score[i] > score_limit) };
+            const io_pair_t pair2 = { io_aln_make_full(hit_loc[i], hit_sink[i] - hit_loc[i], hit_score[i], rc, anchor, o_score2[i] > score_limit),
+                                      io_aln_make_full(o_loc[i], o_sink2[i] - o_loc[i], o_score2[i], o_rc, !anchor, o_score2[i] > score_limit) };
+            if (io_aln_paired(pair.a)) {
+                try_update_pair(&b, &pair, min_distance);
+                if (io_aln_paired(pair2.a)) try_update_pair(&b, &pair2, min_distance);
+            } else if (pe_unpaired && !bp_is_paired(&b)) {
+                if (anchor) try_update_single(&b.o1, &b.o2, pair.a, min_distance);
+                else        try_update_single(&b.a1, &b.a2, pair.a, min_distance);
+            }
+        }
+        ST(best, read_id, b.a1); ST(best, read_id + best_stride, b.a2); ST(best_o, read_id, b.o1); ST(best_o, read_id + best_stride, b.o2);
+    }
+    #undef LD
+    #undef ST
+}
+
 static int32_t simple_func(int type, float k, float m, int32_t x)
 {
     return (int32_t)(k + m * (type == 1 ? logf((float)x) : type == 2 ? sqrtf((float)x) : (float)x));
 }
 static inline int clamp10(int v) { return v < 0 ? 0 : v > 10 ? 10 : v; }
 
-static uint32_t mapq_v3(int32_t best_score, int has_second, int32_t second_score, float max_score, float min_score)
+static uint32_t mapq_v3(int32_t best_score, int has_second, int32_t second_score, float max_score, float min_score, int is_paired)
 {
+    if (is_paired) return 44;        /* paired_one_perfect: mapq.h:96-102 (before any threshold test) */
     static const int unpaired_one[11] = { 43, 42, 41, 36, 32, 27, 20, 11, 4, 1, 0 };
     static const int unpaired_two_perfect[11] = { 2, 16, 23, 30, 31, 32, 34, 36, 38, 40, 42 };
     static const int unpaired_two[11][11] = {
@@ -1877,8 +1995,30 @@ ORACLE_API void oracle_mapq(int version, int32_t match, int min_type, float min_
         const io_aln_t a1 = { (uint32_t)best[r], (uint32_t)(best[r] >> 32) }, a2 = { (uint32_t)best[r + best_stride], (uint32_t)(best[r + best_stride] >> 32) };
         if (!io_aln_aligned(a1)) { out[r] = 0; continue; }
         const float max_score = (float)((int32_t)read_len[r] * match), min_score = (float)simple_func(min_type, min_k, min_m, (int32_t)read_len[r]);
-        out[r] = (uint8_t)(version == 3 ? mapq_v3(io_aln_score(a1), io_aln_aligned(a2), io_aln_score(a2), max_score, min_score)
+        out[r] = (uint8_t)(version == 3 ? mapq_v3(io_aln_score(a1), io_aln_aligned(a2), io_aln_score(a2), max_score, min_score, 0)
                                         : mapq_v2(io_aln_score(a1), io_aln_aligned(a2), io_aln_score(a2), max_score, min_score, monotone));
+    }
+}
+
+/* paired-end reads: mapq(BestPairedAlignments(anchor best pair, opposite best pair), read_len, o_read_len) (mapq.h:56-58,150-166) */
+ORACLE_API void oracle_mapq_paired(int version, int32_t match, int min_type, float min_k, float min_m, int monotone,
+    uint32_t n_reads, const uint64_t* best, const uint64_t* best_o, uint32_t best_stride, const uint32_t* read_len, const uint32_t* o_read_len, uint8_t* out)
+{
+    for (uint32_t r = 0; r < n_reads; ++r)
+    {
+        const io_best_pairs_t b = { { (uint32_t)best[r], (uint32_t)(best[r] >> 32) }, { (uint32_t)best[r + best_stride], (uint32_t)(best[r + best_stride] >> 32) },
+                                    { (uint32_t)best_o[r], (uint32_t)(best_o[r] >> 32) }, { (uint32_t)best_o[r + best_stride], (uint32_t)(best_o[r + best_stride] >> 32) } };
+        if (!io_aln_aligned(b.a1)) { out[r] = 0; continue; }
+        const int paired = bp_is_paired(&b);
+        const int has_second = paired ? bp_has_second_paired(&b) : io_aln_aligned(b.a2);
+        if (version == 3) {
+            const float max_score = (float)((int32_t)read_len[r] * match), min_score = (float)simple_func(min_type, min_k, min_m, (int32_t)read_len[r]);
+            out[r] = (uint8_t)mapq_v3(bp_best_score(&b), has_second, bp_second_score(&b), max_score, min_score, paired);
+        } else {
+            const float max_score = (float)((int32_t)read_len[r] * match) + (paired ? (float)((int32_t)o_read_len[r] * match) : 0.0f);
+            const float min_score = (float)simple_func(min_type, min_k, min_m, (int32_t)read_len[r]) + (paired ? (float)simple_func(min_type, min_k, min_m, (int32_t)o_read_len[r]) : 0.0f);
+            out[r] = (uint8_t)mapq_v2(bp_best_score(&b), has_second, bp_second_score(&b), max_score, min_score, monotone);
+        }
     }
 }
 

@@ -643,11 +643,30 @@ def score_reduce(best, hit_begin, hit_score, hit_loc, hit_rc, read_len, read_ids
     return best
 
 
+def score_reduce_paired(best, best_o, hit_begin, hit_loc, hit_sink, hit_score, hit_rc, o_loc, o_sink, o_sink2, o_score, o_score2,
+                        read_len, anchor, pe_policy, pe_unpaired, score_limit, read_ids=None):
+    hb = _u64(hit_begin); n = hb.size - 1
+    rid = _u32(read_ids) if read_ids is not None else None
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    lib().oracle_score_reduce_paired(C.c_uint32(n), _p(rid), _p(hb), _p(_u32(hit_loc)), _p(_u32(hit_sink)), _p(i32(hit_score)), _p(np.ascontiguousarray(hit_rc, dtype=np.uint8)),
+                                     _p(_u32(o_loc)), _p(_u32(o_sink)), _p(_u32(o_sink2)), _p(i32(o_score)), _p(i32(o_score2)), _p(_u32(read_len)),
+                                     C.c_uint32(anchor), C.c_int(pe_policy), C.c_int(int(pe_unpaired)), C.c_int32(score_limit), _p(best), _p(best_o), C.c_uint32(best.shape[1]))
+    return best, best_o
+
+
 def mapq(version, match, score_min, monotone, best, read_len):
     n = best.shape[1]
     out = np.zeros(n, dtype=np.uint8)
     lib().oracle_mapq(C.c_int(version), C.c_int32(match), C.c_int(score_min[0]), C.c_float(score_min[1]), C.c_float(score_min[2]), C.c_int(int(monotone)),
                       C.c_uint32(n), _p(best), C.c_uint32(n), _p(_u32(read_len)), _p(out))
+    return out
+
+
+def mapq_paired(version, match, score_min, monotone, best, best_o, read_len, o_read_len):
+    n = best.shape[1]
+    out = np.zeros(n, dtype=np.uint8)
+    lib().oracle_mapq_paired(C.c_int(version), C.c_int32(match), C.c_int(score_min[0]), C.c_float(score_min[1]), C.c_float(score_min[2]), C.c_int(int(monotone)),
+                             C.c_uint32(n), _p(best), _p(best_o), C.c_uint32(n), _p(_u32(read_len)), _p(_u32(o_read_len)), _p(out))
     return out
 
 

@@ -77,3 +77,56 @@ def test_score_reduce_and_mapq(cuda, ragged):
             bad = np.nonzero(gm != em)[0]
             assert bad.size == 0, (version, scheme.m_match, bad[:5], gm[bad[:5]], em[bad[:5]])
             assert len(set(em.tolist())) > 5               # a spread of qualities, not one constant
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("anchor", [0, 1])
+@pytest.mark.parametrize("policy", [0, 1, 2, 3])
+def test_score_reduce_paired(cuda, anchor, policy):
+    """score_reduce_paired_kernel (reduce_inl.h:355-500): paired / unpaired updates of the four best slots, both anchors, all
+    pairing policies; several rounds accumulate; bit-exact io::Alignment words vs the oracle."""
+    rng = np.random.default_rng(900 + 10 * anchor + policy)
+    n_reads, n_active = 6000, 5000
+    sch = nvb.SmithWatermanScoringScheme()
+    read_len = rng.integers(50, 251, n_reads).astype(np.uint32)
+    d = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(cuda)
+    rl = d(read_len, np.int32)
+    best = nvb.BestAlignments(n_reads, sch, read_len=rl, max_read_len=250, device=cuda, mate=0)
+    best_o = nvb.BestAlignments(n_reads, sch, read_len=rl, max_read_len=250, device=cuda, mate=1)
+    e = O.init_alignments(read_len, sch.m_score_min, 0)
+    eo = O.init_alignments(read_len, sch.m_score_min, 1)
+    assert (best_o.data.cpu().numpy().view(np.uint64) == eo).all()
+    score_limit = -200
+    for rnd in range(3):
+        a = anchor if rnd < 2 else 1 - anchor                 # the second anchor pass of the reference comes after the first
+        read_ids = rng.permutation(n_reads)[:n_active].astype(np.uint32)
+        counts = rng.integers(0, 6, n_active)
+        hb = np.zeros(n_active + 1, np.uint64); hb[1:] = np.cumsum(counts)
+        tot = int(hb[-1])
+        owner = np.repeat(np.arange(n_active), counts)
+        locus = rng.integers(1000, 1 << 28, n_active)
+        loc = (locus[owner] + rng.choice([0, 0, 2, 30, 70, 900, 50000], tot)).astype(np.uint32)
+        sink = (loc + rng.integers(40, 260, tot)).astype(np.uint32)
+        score = (-rng.integers(0, 60, tot)).astype(np.int32)
+        rc = (rng.random(tot) < 0.4).astype(np.uint8)
+        o_loc = (loc + rng.integers(-400, 400, tot)).astype(np.uint32)
+        o_sink = (o_loc + rng.integers(40, 260, tot)).astype(np.uint32)
+        o_sink2 = (o_loc + rng.integers(40, 260, tot)).astype(np.uint32)
+        o_score = np.where(rng.random(tot) < 0.6, -rng.integers(0, 60, tot), -100000).astype(np.int32)     # -100000 = scheme_type::worst_score stand-in
+        o_score2 = np.where(rng.random(tot) < 0.2, -rng.integers(0, 60, tot), -100000).astype(np.int32)
+        O.score_reduce_paired(e, eo, hb, loc, sink, score, rc, o_loc, o_sink, o_sink2, o_score, o_score2, read_len, a, policy, True, score_limit, read_ids)
+        nvb.score_reduce_paired(best, best_o, d(hb, np.int64), d(loc, np.int32), d(sink, np.int32), d(score, np.int32), d(rc, np.uint8),
+                                d(o_loc, np.int32), d(o_sink, np.int32), d(o_sink2, np.int32), d(o_score, np.int32), d(o_score2, np.int32),
+                                anchor=a, pe_policy=policy, pe_unpaired=True, score_limit=score_limit, read_len=rl, read_ids=d(read_ids, np.int32))
+        torch.cuda.synchronize()
+        g, go = best.data.cpu().numpy().view(np.uint64), best_o.data.cpu().numpy().view(np.uint64)
+        bad = np.nonzero((g != e).any(0) | (go != eo).any(0))[0]
+        assert bad.size == 0, (rnd, bad[:5], [hex(x) for x in g[:, bad[0]]], [hex(x) for x in e[:, bad[0]]], [hex(x) for x in go[:, bad[0]]], [hex(x) for x in eo[:, bad[0]]])
+    paired = (e[0] >> np.uint64(30)) & np.uint64(1)
+    assert 0 < int(paired.sum()) < n_reads                   # both paired and unpaired outcomes occur
+    o_len = rng.integers(50, 251, n_reads).astype(np.uint32)
+    for version in (2, 3):
+        em = O.mapq_paired(version, sch.m_match, sch.m_score_min, sch.m_monotone, e, eo, read_len, o_len)
+        gm = nvb.mapq_paired(best, best_o, sch, read_len=rl, o_read_len=d(o_len, np.int32), version=version, max_read_len=250).cpu().numpy()
+        assert (gm == em).all(), (version, np.nonzero(gm != em)[0][:5])
+        assert len(set(em.tolist())) > 3
