@@ -376,6 +376,24 @@ int nvbio_hip_score_reduce_paired(uint32_t n_active, const uint32_t* read_ids /*
     const uint32_t* read_len /* nullable */, uint32_t fixed_read_len, uint32_t anchor, int32_t pe_policy, int32_t pe_unpaired, int32_t score_limit,
     uint64_t* best_alignments, uint64_t* best_alignments_o, uint32_t best_stride, void* stream);
 
+/* The paired-end parameters the opposite-mate stage reads (nvBowtie/bowtie2/cuda/params.h: pe_policy, min_frag_len,
+ * max_frag_len, pe_overlap) plus the pipeline's score_limit, anchor (0 / 1) and genome_length. */
+typedef struct nvbio_hip_pe_params {
+    int32_t  pe_policy, min_frag_len, max_frag_len, pe_overlap, score_limit;
+    uint32_t anchor, genome_length;
+} nvbio_hip_pe_params;
+
+/* BestOppositeScoreStream::init_context (nvBowtie/bowtie2/cuda/score_opposite_inl.h:92-200) for every scored anchor hit:
+ * the opposite mate's score threshold (compute_target_score, alignment_utils.h:100-111, clamped by the mate's own worst score
+ * and score_limit), its strand (frame_opposite_mate), and the genome window [begin, end) allowed by the fragment-length limits
+ * and max_text_gaps (utils_inl.h:181-204).  out_valid = the function's bool (threshold reachable, window inside the genome and
+ * non-empty, location not already recorded in the best pairs).  The windows + thresholds feed nvbio_hip_alignment_score_qual. */
+int nvbio_hip_opposite_mate_windows(uint32_t n_hits, const uint32_t* hit_read_id, const uint8_t* hit_rc, const uint32_t* hit_loc, const int32_t* hit_score,
+    const uint32_t* a_read_len /* nullable */, const uint32_t* o_read_len /* nullable */, uint32_t a_fixed_len, uint32_t o_fixed_len,
+    const uint64_t* best_alignments, const uint64_t* best_alignments_o, uint32_t best_stride,
+    int32_t match, const int32_t* min_score_by_len /* device */, int32_t text_gap_open, int32_t text_gap_ext, const nvbio_hip_pe_params* params /* host */,
+    uint8_t* out_valid, int32_t* out_min_score, uint8_t* out_read_rc, uint32_t* out_genome_begin, uint32_t* out_genome_end, void* stream);
+
 /* BowtieMapq2 / BowtieMapq3 (nvBowtie/bowtie2/cuda/mapq.h:42-330) for single-end reads:
  * out_mapq[r] from the best / second-best alignment of read r; perfect_score(len) = len * match,
  * min_score(len) = min_score_by_len[len] (the scheme's SimpleFunc tabulated by the host, scoring.h:272-281),

@@ -17,4 +17,4 @@ from .alignment import (GLOBAL, LOCAL, SEMI_GLOBAL, PATTERN_BLOCKING, TEXT_BLOCK
 from .fmindex import FMIndexDevice, FMIndexFilter, rank, rank4, rank_range, match, locate, \
     locate_ssa_iterator, lookup_ssa_iterator, build_bwt_occ  # noqa: F401
 from .mapping import MappingParams, map_exact, map_seeds, unpack_seed_hits  # noqa: F401
-from .reduce import BestAlignments, score_reduce, score_reduce_paired, mapq, mapq_paired  # noqa: F401
+from .reduce import BestAlignments, score_reduce, score_reduce_paired, mapq, mapq_paired, opposite_mate_windows  # noqa: F401

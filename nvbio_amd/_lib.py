@@ -12,7 +12,7 @@ SYMBOLS = [
     "nvbio_hip_gotoh_traceback_temp_bytes", "nvbio_hip_gotoh_traceback", "nvbio_hip_gotoh_traceback_qual", "nvbio_hip_banded_sw_traceback", "nvbio_hip_sw_traceback",
     "nvbio_hip_fm_rank", "nvbio_hip_fm_rank4", "nvbio_hip_fm_rank_range",
     "nvbio_hip_fm_match", "nvbio_hip_fm_build_ktab", "nvbio_hip_map_exact", "nvbio_hip_map",
-    "nvbio_hip_alignment_invalid", "nvbio_hip_init_alignments", "nvbio_hip_score_reduce", "nvbio_hip_score_reduce_paired", "nvbio_hip_mapq", "nvbio_hip_mapq_paired", "nvbio_hip_fm_locate",
+    "nvbio_hip_alignment_invalid", "nvbio_hip_init_alignments", "nvbio_hip_score_reduce", "nvbio_hip_score_reduce_paired", "nvbio_hip_opposite_mate_windows", "nvbio_hip_mapq", "nvbio_hip_mapq_paired", "nvbio_hip_fm_locate",
     "nvbio_hip_fm_locate_ssa_iterator", "nvbio_hip_fm_lookup_ssa_iterator",
     "nvbio_hip_fm_filter_temp_bytes", "nvbio_hip_fm_filter_rank", "nvbio_hip_fm_filter_locate",
     "nvbio_hip_build_bwt_occ_temp_bytes", "nvbio_hip_build_bwt_occ",
@@ -20,6 +20,11 @@ SYMBOLS = [
     "nvbio_hip_stream_synchronize",
     "nvbio_hip_abi_version", "nvbio_hip_arch", "nvbio_hip_last_kernel",
 ]
+
+
+class PeParamsStruct(C.Structure):       # nvbio_hip_pe_params
+    _fields_ = [("pe_policy", C.c_int32), ("min_frag_len", C.c_int32), ("max_frag_len", C.c_int32), ("pe_overlap", C.c_int32),
+                ("score_limit", C.c_int32), ("anchor", C.c_uint32), ("genome_length", C.c_uint32)]
 
 
 class StringSetStruct(C.Structure):      # nvbio_hip_string_set
@@ -96,6 +101,8 @@ def lib():
         L.nvbio_hip_init_alignments.argtypes = [u32, vp, u32, vp, u32, vp, u32, vp]
         L.nvbio_hip_score_reduce.argtypes = [u32, vp, vp, vp, vp, vp, vp, u32, vp, u32, vp]
         L.nvbio_hip_score_reduce_paired.argtypes = [u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, i32, i32, i32, vp, vp, u32, vp]
+        L.nvbio_hip_opposite_mate_windows.argtypes = [u32, vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, u32, i32, vp, i32, i32, P(PeParamsStruct),
+                                                      vp, vp, vp, vp, vp, vp]
         L.nvbio_hip_mapq.argtypes = [i32, i32, i32, vp, u32, vp, u32, vp, u32, vp, vp]
         L.nvbio_hip_mapq_paired.argtypes = [i32, i32, i32, vp, u32, vp, vp, u32, vp, vp, u32, u32, vp, vp]
         L.nvbio_hip_fm_locate.argtypes = [P(FMIndexStruct), vp, u32, vp, vp]

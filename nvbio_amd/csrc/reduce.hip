@@ -163,6 +163,85 @@ __global__ void __launch_bounds__(256) score_reduce_paired_kernel(const PairedRe
     p.best_o[read_id] = make_uint2(b.o1.w, b.o1.align); p.best_o[read_id + p.best_stride] = make_uint2(b.o2.w, b.o2.align);
 }
 
+// ------------------------------------------------------------------ opposite-mate windows
+// BestOppositeScoreStream::init_context (score_opposite_inl.h:92-200), compute_target_score (alignment_utils.h:100-111),
+// frame_opposite_mate (:61-98), max_text_gaps for the Gotoh aligner (nvbio/alignment/utils_inl.h:181-204)
+struct OppositeParams {
+    uint32_t n_hits; const uint32_t* hit_read_id; const uint8_t* hit_rc; const uint32_t* hit_loc; const int32_t* hit_score;
+    const uint32_t* a_read_len; const uint32_t* o_read_len; uint32_t a_fixed_len, o_fixed_len;
+    const uint2* best; const uint2* best_o; uint32_t best_stride;
+    int32_t match; const int32_t* min_score_by_len; int32_t text_gap_open, text_gap_ext;
+    int32_t pe_policy, min_frag_len, max_frag_len, pe_overlap, score_limit; uint32_t anchor, genome_length;
+    uint8_t* out_valid; int32_t* out_min_score; uint8_t* out_read_rc; uint32_t* out_genome_begin; uint32_t* out_genome_end;
+};
+
+__global__ void __launch_bounds__(256) opposite_windows_kernel(const OppositeParams p)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= p.n_hits) return;
+    const uint32_t read_rc = p.hit_rc[i], read_id = p.hit_read_id[i], g_pos = p.hit_loc[i];
+    const uint32_t a_len = p.a_read_len ? p.a_read_len[read_id] : p.a_fixed_len, o_len = p.o_read_len ? p.o_read_len[read_id] : p.o_fixed_len;
+    const int32_t a_optimal = int32_t(a_len) * p.match, a_worst = p.min_score_by_len[a_len];
+    const int32_t o_optimal = int32_t(o_len) * p.match, o_worst = p.min_score_by_len[o_len];
+    auto ld = [](const uint2* q, uint32_t k) { const uint2 v = q[k]; IoAln a = { v.x, v.y }; return a; };
+    const IoBestPairs b = { ld(p.best, read_id), ld(p.best, read_id + p.best_stride), ld(p.best_o, read_id), ld(p.best_o, read_id + p.best_stride) };
+    int32_t target;
+    if (!io_aln_paired(b.a2)) target = a_worst + o_worst;
+    else { const int32_t delta = bp_best_score(b) - bp_second_score(b); target = bp_second_score(b) + (delta * 3) / 4; }      // bowtie2's 'tighten = 3'
+    const int32_t target_pair = min(target + 1, a_optimal + o_optimal);
+    const int32_t target_mate = max(target_pair - p.hit_score[i], o_worst);
+    const int32_t min_score = max(target_mate, p.score_limit);
+    p.out_min_score[i] = min_score;
+    uint32_t valid = 0, o_rc = 0, gb = 0, ge = 0;
+    if (min_score <= o_optimal)
+    {
+        const bool anchor_fw = !read_rc, anchor_1 = (p.anchor == 0u);
+        bool o_left, o_fw;
+        switch (p.pe_policy) {
+        case 0:  o_left = (anchor_1 != anchor_fw); o_fw = anchor_fw;  break;    // FF
+        case 3:  o_left = (anchor_1 == anchor_fw); o_fw = anchor_fw;  break;    // RR
+        case 1:  o_left = !anchor_fw;              o_fw = !anchor_fw; break;    // FR
+        default: o_left = anchor_fw;               o_fw = !anchor_fw; break;    // RF
+        }
+        o_rc = o_fw ? 0u : 1u;
+        int32_t max_ref_gaps;
+        {
+            int32_t score = int32_t(o_len) * p.match;
+            if (score < min_score) max_ref_gaps = 0;
+            else {
+                score += p.text_gap_open;
+                uint32_t n = 0;
+                while (score >= min_score && n < o_len) { score += p.text_gap_ext; ++n; }
+                max_ref_gaps = int32_t(n - 1u);             // (n == 0 wraps, as in the reference)
+            }
+        }
+        const uint32_t o_gapped_len = o_len + uint32_t(max_ref_gaps);
+        const uint32_t min_frag = uint32_t(p.min_frag_len), max_frag = uint32_t(p.max_frag_len);
+        if (o_left) {
+            const uint32_t max_end = g_pos + a_len + o_gapped_len > min_frag ? g_pos + a_len + o_gapped_len - min_frag : 0u;
+            gb = g_pos + a_len > max_frag ? (g_pos + a_len) - max_frag : 0u;
+            ge = p.pe_overlap ? g_pos + a_len : g_pos;
+            ge = min(ge, max_end);
+        } else {
+            const uint32_t min_begin = g_pos + min_frag > o_gapped_len ? g_pos + min_frag - o_gapped_len : 0u;
+            ge = g_pos + max_frag;
+            gb = p.pe_overlap ? g_pos : g_pos + a_len;
+            gb = max(gb, min_begin);
+        }
+        ge = min(ge, p.genome_length);
+        if (gb < p.genome_length)
+        {
+            const uint32_t mate = p.anchor ? 0u : 1u;
+            const bool skip = (mate == io_aln_mate(b.a1) && o_rc == io_aln_rc(b.a1) && g_pos == b.a1.align) ||
+                              (mate == io_aln_mate(b.o1) && o_rc == io_aln_rc(b.o1) && g_pos == b.o1.align) ||
+                              (mate == io_aln_mate(b.a2) && o_rc == io_aln_rc(b.a2) && g_pos == b.a2.align) ||
+                              (mate == io_aln_mate(b.o2) && o_rc == io_aln_rc(b.o2) && g_pos == b.o2.align) || (gb == ge);
+            valid = skip ? 0u : 1u;
+        }
+    }
+    p.out_valid[i] = uint8_t(valid); p.out_read_rc[i] = uint8_t(o_rc); p.out_genome_begin[i] = gb; p.out_genome_end[i] = ge;
+}
+
 // single-precision arithmetic without contraction, so the thresholds fall where the host code puts them
 __device__ __forceinline__ float fmul(float a, float b) { return __fmul_rn(a, b); }
 __device__ __forceinline__ float fadd(float a, float b) { return __fadd_rn(a, b); }
@@ -352,5 +431,25 @@ NVB_API int nvbio_hip_mapq_paired(int32_t version, int32_t match, int32_t monoto
     hipLaunchKernelGGL(mapq_paired_kernel, dim3((n_reads + 255u) / 256u), dim3(256), 0, to_stream(stream), version, match, monotone, n_reads,
                        reinterpret_cast<const uint2*>(best_alignments), reinterpret_cast<const uint2*>(best_alignments_o), best_stride,
                        read_len, o_read_len, fixed_read_len, o_fixed_read_len, min_score_by_len, out_mapq);
+    return hipGetLastError();
+}
+
+NVB_API int nvbio_hip_opposite_mate_windows(uint32_t n_hits, const uint32_t* hit_read_id, const uint8_t* hit_rc, const uint32_t* hit_loc, const int32_t* hit_score,
+    const uint32_t* a_read_len, const uint32_t* o_read_len, uint32_t a_fixed_len, uint32_t o_fixed_len,
+    const uint64_t* best_alignments, const uint64_t* best_alignments_o, uint32_t best_stride,
+    int32_t match, const int32_t* min_score_by_len, int32_t text_gap_open, int32_t text_gap_ext, const nvbio_hip_pe_params* params,
+    uint8_t* out_valid, int32_t* out_min_score, uint8_t* out_read_rc, uint32_t* out_genome_begin, uint32_t* out_genome_end, void* stream)
+{
+    if (n_hits == 0) return hipSuccess;
+    if (!hit_read_id || !hit_rc || !hit_loc || !hit_score || !best_alignments || !best_alignments_o || best_stride == 0 || !min_score_by_len || !params ||
+        !out_valid || !out_min_score || !out_read_rc || !out_genome_begin || !out_genome_end) return hipErrorInvalidValue;
+    if ((!a_read_len && a_fixed_len == 0) || (!o_read_len && o_fixed_len == 0) || params->anchor > 1u || params->pe_policy < 0 || params->pe_policy > 3) return hipErrorInvalidValue;
+    OppositeParams p = { n_hits, hit_read_id, hit_rc, hit_loc, hit_score, a_read_len, o_read_len, a_fixed_len, o_fixed_len,
+                         reinterpret_cast<const uint2*>(best_alignments), reinterpret_cast<const uint2*>(best_alignments_o), best_stride,
+                         match, min_score_by_len, text_gap_open, text_gap_ext,
+                         params->pe_policy, params->min_frag_len, params->max_frag_len, params->pe_overlap, params->score_limit, params->anchor, params->genome_length,
+                         out_valid, out_min_score, out_read_rc, out_genome_begin, out_genome_end };
+    g_last_kernel = "opposite_windows_kernel";
+    hipLaunchKernelGGL(opposite_windows_kernel, dim3((n_hits + 255u) / 256u), dim3(256), 0, to_stream(stream), p);
     return hipGetLastError();
 }

@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from ._lib import lib, check, current_stream_ptr
+from ._lib import lib, check, current_stream_ptr, PeParamsStruct
 
 
 def _vp(t):
@@ -88,5 +88,27 @@ def mapq_paired(best, best_o, scheme, read_len=None, o_read_len=None, fixed_read
     out = torch.empty(best.n, dtype=torch.uint8, device=dev)
     check(lib().nvbio_hip_mapq_paired(int(version), int(scheme.m_match), int(bool(scheme.m_monotone)), _vp(table), best.n, _vp(best.data), _vp(best_o.data), best.stride,
                                       _vp(read_len), _vp(o_read_len), int(fixed_read_len), int(o_fixed_read_len), _vp(out), current_stream_ptr()), "nvbio_hip_mapq_paired")
+    table.record_stream(torch.cuda.current_stream())
+    return out
+
+
+def opposite_mate_windows(hit_read_id, hit_rc, hit_loc, hit_score, best, best_o, scheme, anchor, genome_length,
+                          a_read_len=None, o_read_len=None, a_fixed_len=0, o_fixed_len=0, pe_policy=PE_POLICY_FR,
+                          min_frag_len=0, max_frag_len=500, pe_overlap=True, score_limit=-(1 << 17) + 1, max_read_len=None):
+    """BestOppositeScoreStream::init_context (score_opposite_inl.h:92-200) over all scored anchor hits ->
+    dict(valid uint8, min_score int32, read_rc uint8, genome_begin int32, genome_end int32)."""
+    dev = hit_loc.device
+    n = hit_loc.numel()
+    max_len = int(max_read_len or max(a_fixed_len, o_fixed_len) or max(int(a_read_len.max()), int(o_read_len.max())))
+    table = torch.tensor([scheme.min_score(L) if L > 0 else 0 for L in range(max_len + 1)], dtype=torch.int32, device=dev)
+    out = dict(valid=torch.empty(n, dtype=torch.uint8, device=dev), min_score=torch.empty(n, dtype=torch.int32, device=dev),
+               read_rc=torch.empty(n, dtype=torch.uint8, device=dev), genome_begin=torch.empty(n, dtype=torch.int32, device=dev),
+               genome_end=torch.empty(n, dtype=torch.int32, device=dev))
+    pp = PeParamsStruct(int(pe_policy), int(min_frag_len), int(max_frag_len), int(bool(pe_overlap)), int(score_limit), int(anchor), int(genome_length))
+    check(lib().nvbio_hip_opposite_mate_windows(n, _vp(hit_read_id), _vp(hit_rc), _vp(hit_loc), _vp(hit_score), _vp(a_read_len), _vp(o_read_len),
+                                                int(a_fixed_len), int(o_fixed_len), _vp(best.data), _vp(best_o.data), best.stride,
+                                                int(scheme.m_match), _vp(table), int(scheme.text_gap_open()), int(scheme.text_gap_extension()), C.byref(pp),
+                                                _vp(out["valid"]), _vp(out["min_score"]), _vp(out["read_rc"]), _vp(out["genome_begin"]), _vp(out["genome_end"]),
+                                                current_stream_ptr()), "nvbio_hip_opposite_mate_windows")
     table.record_stream(torch.cuda.current_stream())
     return out

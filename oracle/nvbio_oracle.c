@@ -1919,6 +1919,73 @@ ORACLE_API void oracle_score_reduce_paired(uint32_t n_active, const uint32_t* re
     #undef ST
 }
 
+/* BestOppositeScoreStream::init_context (score_opposite_inl.h:92-200): for every anchor hit, the opposite mate's strand,
+ * genome window and score threshold; compute_target_score (alignment_utils.h:100-111); max_text_gaps (utils_inl.h:181-204).
+ * limits: {match, min_type, text_gap_open, text_gap_ext}, min_k / min_m the threshold function's coefficients */
+typedef struct { int32_t pe_policy, min_frag_len, max_frag_len, pe_overlap, score_limit; uint32_t anchor, genome_length; } oracle_pe_params_t;
+ORACLE_API void oracle_opposite_windows(uint32_t n_hits, const uint32_t* hit_read_id, const uint8_t* hit_rc, const uint32_t* hit_loc, const int32_t* hit_score,
+    const uint32_t* a_read_len, const uint32_t* o_read_len, const uint64_t* best, const uint64_t* best_o, uint32_t best_stride,
+    int32_t match, int min_type, float min_k, float min_m, int32_t text_gap_open, int32_t text_gap_ext, const oracle_pe_params_t* pp,
+    uint8_t* out_valid, int32_t* out_min_score, uint8_t* out_read_rc, uint32_t* out_genome_begin, uint32_t* out_genome_end)
+{
+    for (uint32_t i = 0; i < n_hits; ++i)
+    {
+        const uint32_t read_rc = hit_rc[i], read_id = hit_read_id[i], g_pos = hit_loc[i];
+        const uint32_t a_len = a_read_len[read_id], o_len = o_read_len[read_id];
+        const int32_t a_optimal = (int32_t)a_len * match, a_worst = simple_func(min_type, min_k, min_m, (int32_t)a_len);
+        const int32_t o_optimal = (int32_t)o_len * match, o_worst = simple_func(min_type, min_k, min_m, (int32_t)o_len);
+        const io_best_pairs_t b = { { (uint32_t)best[read_id], (uint32_t)(best[read_id] >> 32) }, { (uint32_t)best[read_id + best_stride], (uint32_t)(best[read_id + best_stride] >> 32) },
+                                    { (uint32_t)best_o[read_id], (uint32_t)(best_o[read_id] >> 32) }, { (uint32_t)best_o[read_id + best_stride], (uint32_t)(best_o[read_id + best_stride] >> 32) } };
+        int32_t target;                                                         /* compute_target_score */
+        if (!bp_has_second_paired(&b)) target = a_worst + o_worst;
+        else { const int32_t delta = bp_best_score(&b) - bp_second_score(&b); target = bp_second_score(&b) + (delta * 3) / 4; }
+        int32_t target_pair = target + 1; if (a_optimal + o_optimal < target_pair) target_pair = a_optimal + o_optimal;
+        int32_t target_mate = target_pair - hit_score[i];
+        if (target_mate < o_worst) target_mate = o_worst;
+        const int32_t min_score = target_mate > pp->score_limit ? target_mate : pp->score_limit;
+        out_min_score[i] = min_score;
+        out_valid[i] = 0; out_read_rc[i] = 0; out_genome_begin[i] = out_genome_end[i] = 0;
+        if (min_score > o_optimal) continue;
+        int o_left, o_fw;
+        frame_opposite_mate(pp->pe_policy, pp->anchor, !read_rc, &o_left, &o_fw);
+        out_read_rc[i] = (uint8_t)!o_fw;
+        int32_t max_ref_gaps;                                                   /* max_text_gaps, uint32 result taken as int32 */
+        {
+            int32_t score = (int32_t)o_len * match;
+            if (score < min_score) max_ref_gaps = 0;
+            else {
+                score += text_gap_open;
+                uint32_t n = 0;
+                while (score >= min_score && n < o_len) { score += text_gap_ext; ++n; }
+                max_ref_gaps = (int32_t)(n - 1u);
+            }
+        }
+        const uint32_t o_gapped_len = o_len + (uint32_t)max_ref_gaps;
+        const uint32_t min_frag = (uint32_t)pp->min_frag_len, max_frag = (uint32_t)pp->max_frag_len;
+        uint32_t gb, ge;
+        if (o_left) {
+            const uint32_t max_end = g_pos + a_len + o_gapped_len > min_frag ? g_pos + a_len + o_gapped_len - min_frag : 0u;
+            gb = g_pos + a_len > max_frag ? (g_pos + a_len) - max_frag : 0u;
+            ge = pp->pe_overlap ? g_pos + a_len : g_pos;
+            if (max_end < ge) ge = max_end;
+        } else {
+            const uint32_t min_begin = g_pos + min_frag > o_gapped_len ? g_pos + min_frag - o_gapped_len : 0u;
+            ge = g_pos + max_frag;
+            gb = pp->pe_overlap ? g_pos : g_pos + a_len;
+            if (min_begin > gb) gb = min_begin;
+        }
+        if (ge > pp->genome_length) ge = pp->genome_length;
+        out_genome_begin[i] = gb; out_genome_end[i] = ge;
+        if (gb >= pp->genome_length) continue;
+        const uint32_t mate = pp->anchor ? 0u : 1u, rrc = (uint32_t)!o_fw;
+        const int skip = (mate == io_aln_mate(b.a1) && rrc == io_aln_rc(b.a1) && g_pos == b.a1.align) ||
+                         (mate == io_aln_mate(b.o1) && rrc == io_aln_rc(b.o1) && g_pos == b.o1.align) ||
+                         (mate == io_aln_mate(b.a2) && rrc == io_aln_rc(b.a2) && g_pos == b.a2.align) ||
+                         (mate == io_aln_mate(b.o2) && rrc == io_aln_rc(b.o2) && g_pos == b.o2.align) || (gb == ge);
+        out_valid[i] = (uint8_t)!skip;
+    }
+}
+
 static int32_t simple_func(int type, float k, float m, int32_t x)
 {
     return (int32_t)(k + m * (type == 1 ? logf((float)x) : type == 2 ? sqrtf((float)x) : (float)x));

@@ -662,6 +662,23 @@ def mapq(version, match, score_min, monotone, best, read_len):
     return out
 
 
+class _PeParams(C.Structure):
+    _fields_ = [("pe_policy", C.c_int32), ("min_frag_len", C.c_int32), ("max_frag_len", C.c_int32), ("pe_overlap", C.c_int32),
+                ("score_limit", C.c_int32), ("anchor", C.c_uint32), ("genome_length", C.c_uint32)]
+
+
+def opposite_windows(hit_read_id, hit_rc, hit_loc, hit_score, a_read_len, o_read_len, best, best_o, match, score_min, text_gap_open, text_gap_ext,
+                     pe_policy, min_frag_len, max_frag_len, pe_overlap, score_limit, anchor, genome_length):
+    n = len(hit_loc)
+    out = dict(valid=np.zeros(n, np.uint8), min_score=np.zeros(n, np.int32), read_rc=np.zeros(n, np.uint8), genome_begin=np.zeros(n, np.uint32), genome_end=np.zeros(n, np.uint32))
+    pp = _PeParams(pe_policy, min_frag_len, max_frag_len, int(pe_overlap), score_limit, anchor, genome_length)
+    lib().oracle_opposite_windows(C.c_uint32(n), _p(_u32(hit_read_id)), _p(np.ascontiguousarray(hit_rc, dtype=np.uint8)), _p(_u32(hit_loc)), _p(np.ascontiguousarray(hit_score, dtype=np.int32)),
+                                  _p(_u32(a_read_len)), _p(_u32(o_read_len)), _p(best), _p(best_o), C.c_uint32(best.shape[1]),
+                                  C.c_int32(match), C.c_int(score_min[0]), C.c_float(score_min[1]), C.c_float(score_min[2]), C.c_int32(text_gap_open), C.c_int32(text_gap_ext), C.byref(pp),
+                                  _p(out["valid"]), _p(out["min_score"]), _p(out["read_rc"]), _p(out["genome_begin"]), _p(out["genome_end"]))
+    return out
+
+
 def mapq_paired(version, match, score_min, monotone, best, best_o, read_len, o_read_len):
     n = best.shape[1]
     out = np.zeros(n, dtype=np.uint8)

@@ -130,3 +130,46 @@ def test_score_reduce_paired(cuda, anchor, policy):
         gm = nvb.mapq_paired(best, best_o, sch, read_len=rl, o_read_len=d(o_len, np.int32), version=version, max_read_len=250).cpu().numpy()
         assert (gm == em).all(), (version, np.nonzero(gm != em)[0][:5])
         assert len(set(em.tolist())) > 3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("anchor", [0, 1])
+def test_opposite_mate_windows(cuda, anchor):
+    """BestOppositeScoreStream::init_context: thresholds, strands and genome windows of the opposite mates, all pairing policies,
+    fragment-length limits incl. the genome ends, best pairs with and without a paired second best"""
+    rng = np.random.default_rng(950 + anchor)
+    n_reads, n_hits, G = 3000, 20000, 1_000_000
+    d = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(cuda)
+    a_len = rng.integers(50, 251, n_reads).astype(np.uint32); o_len = rng.integers(50, 251, n_reads).astype(np.uint32)
+    for sch in (nvb.SmithWatermanScoringScheme(), nvb.SmithWatermanScoringScheme.local()):
+        # some best pairs from a reduce round, so that compute_target_score sees paired seconds and the skip rule fires
+        e, eo = O.init_alignments(a_len, sch.m_score_min, 0), O.init_alignments(o_len, sch.m_score_min, 1)
+        counts = rng.integers(0, 4, n_reads); hb = np.zeros(n_reads + 1, np.uint64); hb[1:] = np.cumsum(counts); tot = int(hb[-1])
+        loc = rng.integers(0, G - 300, tot).astype(np.uint32); sink = (loc + 100).astype(np.uint32)
+        sgn = 1 if sch.m_match else -1
+        sc = (sgn * rng.integers(0, 60, tot)).astype(np.int32); rc = (rng.random(tot) < 0.5).astype(np.uint8)
+        ol = (loc + 200).astype(np.uint32); osk = (ol + 100).astype(np.uint32)
+        os1 = np.where(rng.random(tot) < 0.7, sgn * rng.integers(0, 60, tot), -100000).astype(np.int32)
+        O.score_reduce_paired(e, eo, hb, loc, sink, sc, rc, ol, osk, osk, os1, np.full(tot, -100000, np.int32), a_len, anchor, 1, True, -1000)
+        best = nvb.BestAlignments(n_reads, sch, read_len=d(a_len, np.int32), max_read_len=250, device=cuda)
+        best_o = nvb.BestAlignments(n_reads, sch, read_len=d(o_len, np.int32), max_read_len=250, device=cuda, mate=1)
+        best.data.copy_(d(e, np.int64)); best_o.data.copy_(d(eo, np.int64))
+        h_read = rng.integers(0, n_reads, n_hits).astype(np.uint32); h_rc = (rng.random(n_hits) < 0.5).astype(np.uint8)
+        h_loc = rng.choice([0, 5, 300, G - 10, G - 400], n_hits).astype(np.uint32) + rng.integers(0, 5, n_hits).astype(np.uint32) * 1000
+        h_loc = np.where(rng.random(n_hits) < 0.7, rng.integers(0, G - 1, n_hits), h_loc).astype(np.uint32)
+        revisit = rng.random(n_hits) < 0.05                   # hits at an already recorded location
+        h_loc[revisit] = (e[0, h_read[revisit]] >> np.uint64(32)).astype(np.uint32)
+        h_score = (sgn * rng.integers(0, 80, n_hits)).astype(np.int32)
+        for policy in (0, 1, 2, 3):
+            for (mn, mx, ov) in ((0, 500, True), (150, 400, False), (0, 1 << 20, True)):
+                exp = O.opposite_windows(h_read, h_rc, h_loc, h_score, a_len, o_len, e, eo, sch.m_match, sch.m_score_min, sch.text_gap_open(), sch.text_gap_extension(),
+                                         policy, mn, mx, ov, -1000, anchor, G)
+                got = nvb.opposite_mate_windows(d(h_read, np.int32), d(h_rc, np.uint8), d(h_loc, np.int32), d(h_score, np.int32), best, best_o, sch, anchor, G,
+                                                a_read_len=d(a_len, np.int32), o_read_len=d(o_len, np.int32), pe_policy=policy, min_frag_len=mn, max_frag_len=mx,
+                                                pe_overlap=ov, score_limit=-1000, max_read_len=250)
+                torch.cuda.synchronize()
+                for k in exp:
+                    g = got[k].cpu().numpy().view(exp[k].dtype)
+                    bad = np.nonzero(g != exp[k])[0]
+                    assert bad.size == 0, (sch.m_match, policy, mn, mx, ov, k, bad[:5], g[bad[:5]], exp[k][bad[:5]])
+                assert 0 < exp["valid"].sum() < n_hits
