@@ -626,6 +626,19 @@ def extras_leg(a, dev):
                                "aligned": float(aligned.float().mean().item()), "best_at_true_position": float(at_true.float().mean().item()),
                                "mapq_ge_23": float((r["mapq"] >= 23).float().mean().item()),
                                "stages": "map_exact, locate, banded extend, score_reduce, BowtieMapq2, banded traceback (glue in torch)"}
+    # ---- BASELINE config 5's shape on one GPU: 2 x 150 bp FR pairs, LOCAL band 31 in nvBowtie's local scheme
+    npairs = 500_000
+    s1, s2, ppos, pflen = P.make_read_pairs(text, npairs, 150, seed=0x5EED0009)
+    mp20 = nvb.MappingParams(seed_len=20)                                    # nvBowtie --local: 20-bp seeds
+    be2 = P.HipBackend(fmi, None, mp20, 150)
+    ms = _timed(lambda: P.align_paired_end(be2, s1, s2, genome_words, ng), reps=2)
+    r = P.align_paired_end(be2, s1, s2, genome_words, ng)
+    paired = ((r["best"][0] >> 30) & 1) != 0
+    a_pos = (r["best"][0] >> 32) & 0xFFFFFFFF
+    ok_pos = (((a_pos - ppos).abs() <= 3) | ((a_pos - (ppos + pflen - 150)).abs() <= 3)) & paired
+    out["align_paired_end"] = {"pairs": npairs, "ms_per_batch": ms, "Mpairs_per_s": npairs / ms / 1e3, "extension_jobs": r["n_jobs"], "opposite_mate_jobs": r["n_opposite"],
+                               "paired": float(paired.float().mean().item()), "anchor_at_fragment_end": float(ok_pos.float().mean().item()),
+                               "stages": "per anchor mate: map_exact, locate, banded LOCAL 31 (quality-aware), opposite windows, full-matrix LOCAL (pattern blocking, min_score), score_reduce_paired; then BowtieMapq2 paired (glue in torch)"}
     return out
 
 

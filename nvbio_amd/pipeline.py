@@ -50,6 +50,37 @@ class HipBackend:
     def traceback(self, band, aligner, patterns, texts, cigar_stride):
         return self._a.batch_banded_alignment_traceback(band, aligner, patterns, texts, cigar_stride=cigar_stride)
 
+    # the paired-end stages (align_paired_end)
+    def _best(self, data):
+        from . import reduce
+        b = reduce.BestAlignments.__new__(reduce.BestAlignments)
+        b.n, b.stride, b.data = data.shape[1], data.shape[1], data
+        return b
+
+    def init_best_mate(self, n, scheme, read_len, mate):
+        from . import reduce
+        return reduce.BestAlignments(n, scheme, fixed_read_len=read_len, device=self.fmi.bwt_occ.device, mate=mate).data
+
+    def score_qual(self, band, aligner, patterns, texts, quals):
+        return self._a.batch_banded_alignment_score(band, aligner, patterns, texts, quals=quals)
+
+    def opposite_windows(self, read_id, rc, loc, score, best, best_o, scheme, anchor, genome_len, read_len, **kw):
+        from . import reduce
+        return reduce.opposite_mate_windows(read_id, rc, loc, score, self._best(best), self._best(best_o), scheme, anchor, genome_len,
+                                            a_fixed_len=read_len, o_fixed_len=read_len, **kw)
+
+    def full_score_qual(self, aligner, patterns, texts, max_m, max_n, min_score, quals):
+        return self._a.batch_alignment_score(aligner, patterns, texts, max_m, max_n, min_score, quals=quals)
+
+    def reduce_paired(self, best, best_o, hit_begin, loc, sink, score, rc, o_loc, o_sink, o_sink2, o_score, o_score2, anchor, read_len, **kw):
+        from . import reduce
+        reduce.score_reduce_paired(self._best(best), self._best(best_o), hit_begin, loc, sink, score, rc, o_loc, o_sink, o_sink2, o_score, o_score2,
+                                   anchor, fixed_read_len=read_len, **kw)
+
+    def mapq_paired(self, best, best_o, scheme, read_len):
+        from . import reduce
+        return reduce.mapq_paired(self._best(best), self._best(best_o), scheme, fixed_read_len=read_len, o_fixed_read_len=read_len)
+
 
 def make_reads(text, n, read_len=100, seed=0x5EED0004, sub_rate=0.04):
     """Single-end reads sampled from the genome, half of them from the reverse strand, with
@@ -181,3 +212,98 @@ def align_single_end(backend, sym, genome_words, genome_len, band=15, rows_per_h
     cigar[ids] = tb["cigar"][: ids.numel()]; cigar_len[ids] = tb["cigar_len"]; source[ids] = tb["source"]; sink[ids] = tb["sink"]
     return dict(best=best, mapq=mapq, cigar=cigar, cigar_len=cigar_len, source=source, sink=sink, tb_score=tb["score"], aligned_ids=ids,
                 n_jobs=int(rep.numel()))
+
+
+def make_read_pairs(text, n, read_len=150, seed=0x5EED0005, sub_rate=0.03, frag=(250, 450)):
+    """FR pairs: mate 1 = the fragment's first read_len bases (forward strand), mate 2 = the reverse complement of its last
+    read_len bases; half of the fragments come from the reverse strand.  -> (sym1, sym2 [n,L] uint8, frag_pos int64[n], frag_len)"""
+    dev = text.device
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    flen = torch.randint(frag[0], frag[1] + 1, (n,), generator=g, device=dev)
+    pos = torch.randint(0, text.numel() - frag[1] - 1, (n,), generator=g, device=dev)
+    ar = torch.arange(read_len, device=dev).unsqueeze(0)
+    left = text[pos.unsqueeze(1) + ar]
+    right = text[(pos + flen - read_len).unsqueeze(1) + ar]
+    def mutate(x):
+        sub = torch.rand(x.shape, generator=g, device=dev) < sub_rate
+        return torch.where(sub, (x + torch.randint(1, 4, x.shape, dtype=torch.uint8, generator=g, device=dev)) & 3, x)
+    m1, m2 = mutate(left), mutate((3 - right).flip(1))
+    swap = torch.rand(n, generator=g, device=dev) < 0.5          # fragment from the reverse strand: the mates trade places
+    sym1 = torch.where(swap.unsqueeze(1), m2, m1)
+    sym2 = torch.where(swap.unsqueeze(1), m1, m2)
+    return sym1, sym2, pos, flen
+
+
+def align_paired_end(backend, sym1, sym2, genome_words, genome_len, scheme=None, band=31, rows_per_hit=2, hits_stride=16,
+                     min_frag_len=0, max_frag_len=500, qual_value=30):
+    """BASELINE config 5's stage sequence for FR pairs, per anchor mate (aligner_best_approx_paired.h): seed + locate the anchor,
+    banded LOCAL extension in nvBowtie's quality-aware scheme, opposite-mate windows and thresholds, full-matrix scoring of the
+    opposite mate, paired reduction; then paired MAPQ.  Hit selection is not the reference's (every located row is extended, in
+    (read, sorted hit, row) order).  Returns dict(best, best_o int64[2,n] io::Alignment words, mapq uint8[n], n_jobs, n_opposite)."""
+    from .alignment import make_gotoh_aligner, SmithWatermanScoringScheme, LOCAL, PATTERN_BLOCKING
+    n, L = sym1.shape
+    dev = sym1.device
+    scheme = scheme or SmithWatermanScoringScheme.local()
+    banded_aligner = make_gotoh_aligner(LOCAL, scheme)
+    full_aligner = make_gotoh_aligner(LOCAL, scheme, PATTERN_BLOCKING)
+    worst = -(1 << 16)                                            # scheme_type::worst_score (scoring.h:226-227)
+    score_limit = worst
+    mates = (sym1, sym2)
+    packed = [pack_read_streams(m) for m in mates]                # (reversed reads for mapping, fw + rc extension words) per mate
+    quals = torch.full((2 * n * L + 8,), qual_value, dtype=torch.uint8, device=dev)
+    best = backend.init_best_mate(n, scheme, L, 0)
+    best_o = backend.init_best_mate(n, scheme, L, 1)
+    n_jobs = n_opp = 0
+    for anchor in (0, 1):
+        reads_rev, ext_words = packed[anchor]
+        o_ext_words = packed[1 - anchor][1]
+        hits, counts = backend.map_exact(reads_rev, hits_stride)
+        k = torch.arange(hits.shape[1], device=dev).unsqueeze(0)
+        valid = k < (counts.to(torch.int64) & 0xFFFFFFFF).unsqueeze(1)
+        hits, _ = torch.sort(torch.where(valid, hits, torch.full_like(hits, (1 << 63) - 1)), dim=1)
+        keep = valid.sum(1, keepdim=True) > k
+        read_id = torch.arange(n, device=dev).unsqueeze(1).expand_as(hits)[keep]
+        w = hits[keep]
+        lo, hi = w & 0xFFFFFFFF, (w >> 32) & 0xFFFFFFFF
+        delta, pir, rc = hi & 0xFFFFF, (hi >> 20) & 0x3FF, (hi >> 30) & 1
+        take = torch.clamp(delta, max=rows_per_hit)
+        rep = torch.repeat_interleave(torch.arange(w.numel(), device=dev), take)
+        first = torch.cumsum(take, 0) - take
+        row = lo[rep] + (torch.arange(rep.numel(), device=dev) - first[rep])
+        gpos = backend.locate(row.to(torch.int32)).to(torch.int64) & 0xFFFFFFFF
+        jr, jrc = read_id[rep], rc[rep]
+        loc = torch.clamp(gpos - pir[rep], min=0)                 # hit.loc: where the read starts (locate_inl.h:142)
+        wbeg = torch.clamp(loc - band // 2, min=0)                # score_best_inl.h:112-116
+        wend = torch.clamp(wbeg + L + band, max=genome_len)
+        patterns = PackedStringSet(ext_words, 4, True, (jr * L + jrc * (n * L)).contiguous(), None, L)
+        texts = PackedStringSet(genome_words, 2, True, wbeg.contiguous(), (wend - wbeg).to(torch.int32).contiguous(), 0)
+        a_score, a_sink = backend.score_qual(band, banded_aligner, patterns, texts, quals)
+        a_score = torch.clamp(a_score, min=worst)                 # hit.score = max(sink.score, worst_score) (:139)
+        a_sinkx = (a_sink.view(-1, 2)[:, 0].to(torch.int64) & 0xFFFFFFFF)
+        hit_sink = torch.where(a_sinkx == 0xFFFFFFFF, wbeg, wbeg + a_sinkx)
+        i32 = lambda t: t.to(torch.int32).contiguous()
+        ow = backend.opposite_windows(i32(jr), jrc.to(torch.uint8).contiguous(), i32(loc), i32(a_score), best, best_o, scheme, anchor, genome_len, L,
+                                      min_frag_len=min_frag_len, max_frag_len=max_frag_len, score_limit=score_limit)
+        ok = ow["valid"] != 0
+        idx = torch.nonzero(ok).squeeze(1)
+        ob = ow["genome_begin"].to(torch.int64)[idx] & 0xFFFFFFFF
+        oe = ow["genome_end"].to(torch.int64)[idx] & 0xFFFFFFFF
+        orc = ow["read_rc"].to(torch.int64)[idx]
+        o_pat = PackedStringSet(o_ext_words, 4, True, (jr[idx] * L + orc * (n * L)).contiguous(), None, L)
+        o_txt = PackedStringSet(genome_words, 2, True, ob.contiguous(), (oe - ob).to(torch.int32).contiguous(), 0)
+        ms = ow["min_score"][idx].contiguous()
+        s_o, k_o, _ = backend.full_score_qual(full_aligner, o_pat, o_txt, L, int(max_frag_len) + L, ms, quals)
+        # hit.opposite_* (score_opposite_inl.h:224-235)
+        o_score = torch.full((rep.numel(),), worst, dtype=torch.int32, device=dev)
+        o_score[idx] = torch.where(s_o >= ms, s_o, torch.full_like(s_o, worst))
+        o_loc = torch.zeros(rep.numel(), dtype=torch.int64, device=dev); o_loc[idx] = ob
+        kx = k_o.view(-1, 2)[:, 0].to(torch.int64) & 0xFFFFFFFF
+        o_sink = o_loc.clone(); o_sink[idx] = ob + torch.where(kx == 0xFFFFFFFF, torch.zeros_like(kx), kx)
+        o_score2 = torch.full_like(o_score, worst)
+        per_read = torch.bincount(jr, minlength=n)
+        hit_begin = torch.zeros(n + 1, dtype=torch.int64, device=dev); hit_begin[1:] = torch.cumsum(per_read, 0)
+        backend.reduce_paired(best, best_o, hit_begin, i32(loc), i32(hit_sink), i32(a_score), jrc.to(torch.uint8).contiguous(),
+                              i32(o_loc), i32(o_sink), i32(o_loc), o_score, o_score2, anchor, L, score_limit=score_limit)
+        n_jobs += int(rep.numel()); n_opp += int(idx.numel())
+    mapq = backend.mapq_paired(best, best_o, scheme, L)
+    return dict(best=best, best_o=best_o, mapq=mapq, n_jobs=n_jobs, n_opposite=n_opp)

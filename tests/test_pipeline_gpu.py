@@ -60,6 +60,78 @@ class OracleBackendFull(OracleBackend):
                     cigar=torch.from_numpy(r["cigar"].view(np.int16)), cigar_len=torch.from_numpy(r["cigar_len"].view(np.int32)))
 
 
+class OracleBackendPaired(OracleBackendFull):
+    """... plus the paired-end stages."""
+
+    def init_best_mate(self, n, scheme, read_len, mate):
+        return torch.from_numpy(O.init_alignments(np.full(n, read_len, np.uint32), scheme.m_score_min, mate).view(np.int64))
+
+    @staticmethod
+    def _q(scheme):
+        st = scheme.struct()
+        return st, np.array([st.mismatch[q] for q in range(256)], dtype=np.int32)
+
+    def score_qual(self, band, aligner, patterns, texts, quals):
+        st, lut = self._q(aligner.scheme)
+        s, k = O.batch_banded_gotoh_score_qual(band, aligner.type, (st.match, st.pattern_gap_open, st.pattern_gap_ext, st.text_gap_open, st.text_gap_ext, 0), lut,
+                                               quals.numpy(), O.StringSet.from_device(patterns), O.StringSet.from_device(texts))
+        return torch.from_numpy(s), torch.from_numpy(k.view(np.int32))
+
+    def opposite_windows(self, read_id, rc, loc, score, best, best_o, scheme, anchor, genome_len, read_len, min_frag_len=0, max_frag_len=500, score_limit=0):
+        n = best.shape[1]
+        r = O.opposite_windows(read_id.numpy(), rc.numpy(), loc.numpy().view(np.uint32), score.numpy(), np.full(n, read_len, np.uint32), np.full(n, read_len, np.uint32),
+                               best.numpy().view(np.uint64), best_o.numpy().view(np.uint64), scheme.m_match, scheme.m_score_min, scheme.text_gap_open(), scheme.text_gap_extension(),
+                               1, min_frag_len, max_frag_len, True, score_limit, anchor, genome_len)
+        return dict(valid=torch.from_numpy(r["valid"]), min_score=torch.from_numpy(r["min_score"]), read_rc=torch.from_numpy(r["read_rc"]),
+                    genome_begin=torch.from_numpy(r["genome_begin"].view(np.int32)), genome_end=torch.from_numpy(r["genome_end"].view(np.int32)))
+
+    def full_score_qual(self, aligner, patterns, texts, max_m, max_n, min_score, quals):
+        st, lut = self._q(aligner.scheme)
+        s, k, ok = O.batch_gotoh_score_qual(0, aligner.type, (st.match, st.pattern_gap_open, st.pattern_gap_ext, st.text_gap_open, st.text_gap_ext), lut, quals.numpy(),
+                                            O.StringSet.from_device(patterns), O.StringSet.from_device(texts), min_score=min_score.numpy())
+        return torch.from_numpy(s), torch.from_numpy(k.view(np.int32)), torch.from_numpy(ok)
+
+    def reduce_paired(self, best, best_o, hit_begin, loc, sink, score, rc, o_loc, o_sink, o_sink2, o_score, o_score2, anchor, read_len, score_limit=0):
+        n = best.shape[1]
+        u = lambda t: t.numpy().view(np.uint32)
+        O.score_reduce_paired(best.numpy().view(np.uint64), best_o.numpy().view(np.uint64), hit_begin.numpy().view(np.uint64), u(loc), u(sink), score.numpy(), rc.numpy(),
+                              u(o_loc), u(o_sink), u(o_sink2), o_score.numpy(), o_score2.numpy(), np.full(n, read_len, np.uint32), anchor, 1, True, score_limit)
+
+    def mapq_paired(self, best, best_o, scheme, read_len):
+        n = best.shape[1]
+        return torch.from_numpy(O.mapq_paired(2, scheme.m_match, scheme.m_score_min, scheme.m_monotone, best.numpy().view(np.uint64), best_o.numpy().view(np.uint64),
+                                              np.full(n, read_len, np.uint32), np.full(n, read_len, np.uint32)))
+
+
+def test_align_paired_end_matches_oracle(cuda):
+    """BASELINE config 5's shape at test size: 2 x 150 bp FR pairs, LOCAL band 31 in nvBowtie's local scheme; every stage's
+    output equals the same glue over the oracle, and the pairs come back paired, at their fragment's two ends."""
+    g = torch.Generator().manual_seed(7)
+    n_genome, n_pairs, L = 1 << 20, 600, 150
+    text = torch.randint(0, 4, (n_genome,), dtype=torch.uint8, generator=g)
+    host = O.FMIndex(text.numpy())
+    sym1, sym2, pos, flen = P.make_read_pairs(text, n_pairs, L, seed=11)
+    mp = nvb.MappingParams(seed_len=20)
+    gw_host = W._pack_chunked(text, 2, True)
+    e = P.align_paired_end(OracleBackendPaired(host, mp, L), sym1, sym2, gw_host, n_genome)
+    fmi = nvb.FMIndexDevice.from_host(host, cuda)
+    r = P.align_paired_end(P.HipBackend(fmi, None, mp, L), sym1.to(cuda), sym2.to(cuda), gw_host.to(cuda), n_genome)
+    torch.cuda.synchronize()
+    assert (r["n_jobs"], r["n_opposite"]) == (e["n_jobs"], e["n_opposite"]) and r["n_opposite"] > n_pairs
+    for key in ("best", "best_o", "mapq"):
+        assert torch.equal(r[key].cpu(), e[key]), key
+    b, bo = r["best"].cpu(), r["best_o"].cpu()
+    paired = ((b[0] >> 30) & 1) != 0
+    assert paired.float().mean() > 0.9
+    # the anchor entry holds the anchor mate's start; the opposite entry holds its window begin + the offset of its alignment's end
+    a_pos, o_pos, o_end = (b[0] >> 32) & 0xFFFFFFFF, (bo[0] >> 32) & 0xFFFFFFFF, ((bo[0] >> 32) & 0xFFFFFFFF) + ((bo[0] >> 18) & 0x3FF)
+    left, right = pos, pos + flen - L
+    anchor_ok = ((a_pos - left).abs() <= 3) | ((a_pos - right).abs() <= 3)
+    opp_ok = ((o_end - (left + L)).abs() <= 3) | ((o_end - (right + L)).abs() <= 3)
+    assert ((anchor_ok & opp_ok) | ~paired).float().mean() > 0.97
+    assert int(r["mapq"].cpu()[paired].to(torch.int32).min()) >= 0
+
+
 def test_align_single_end_matches_oracle(cuda):
     """seed -> locate -> extend -> score_reduce -> MAPQ -> traceback: every stage's output identical to the same
     glue over the oracle; reads come back at their true positions with sensible qualities and CIGARs."""
