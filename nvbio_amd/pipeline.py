@@ -112,6 +112,17 @@ def pack_read_streams(sym):
     return rev, ext_words
 
 
+def _first_occurrences(jr, jrc, loc):
+    """Indices (ascending) of the first job of every distinct (read, strand, read start): several seeds of one read usually locate
+    to the same placement, and extending it once is enough (the reference gets the same effect from extending one hit per round and
+    skipping recorded locations, score_best / reduce_inl.h:111-114)."""
+    key = (jr << 33) | (jrc << 32) | loc
+    uniq, inv = torch.unique(key, return_inverse=True)
+    first = torch.full((uniq.numel(),), key.numel(), dtype=torch.int64, device=key.device)
+    first = first.scatter_reduce(0, inv, torch.arange(key.numel(), device=key.device), reduce="amin", include_self=True)
+    return torch.sort(first).values
+
+
 def seed_and_extend(backend, sym, genome_words, genome_len, band=15, rows_per_hit=2, hits_stride=16, aligner=None, packed=None):
     """Returns (best_score int32[n], best_pos int64[n] (window begin of the best job, -1 if none),
     n_jobs).  `packed` = pack_read_streams(sym) when the caller keeps the packed reads resident."""
@@ -134,6 +145,8 @@ def seed_and_extend(backend, sym, genome_words, genome_len, band=15, rows_per_hi
     gpos = backend.locate(row.to(torch.int32)).to(torch.int64) & 0xFFFFFFFF
     # window of the read around the located seed (the arithmetic of score_best_inl.h:95-126)
     jr, jrc = read_id[rep], rc[rep]
+    sel = _first_occurrences(jr, jrc, torch.clamp(gpos - pir[rep], min=0))
+    jr, jrc, gpos, rep = jr[sel], jrc[sel], gpos[sel], rep[sel]
     wbeg = torch.clamp(gpos - pir[rep] - band // 2, min=0)
     wend = torch.clamp(wbeg + L + band, max=genome_len)
     patterns = PackedStringSet(ext_words, 4, True, (jr * L + jrc * (n * L)).contiguous(), None, L)
@@ -182,6 +195,8 @@ def align_single_end(backend, sym, genome_words, genome_len, band=15, rows_per_h
     row = lo[rep] + (torch.arange(rep.numel(), device=dev) - first[rep])
     gpos = backend.locate(row.to(torch.int32)).to(torch.int64) & 0xFFFFFFFF
     jr, jrc = read_id[rep], rc[rep]
+    sel = _first_occurrences(jr, jrc, torch.clamp(gpos - pir[rep], min=0))
+    jr, jrc, gpos, rep = jr[sel], jrc[sel], gpos[sel], rep[sel]
     wbeg = torch.clamp(gpos - pir[rep] - band // 2, min=0)
     wend = torch.clamp(wbeg + L + band, max=genome_len)
     pat_begin = (jr * L + jrc * (n * L)).contiguous()
@@ -272,6 +287,8 @@ def align_paired_end(backend, sym1, sym2, genome_words, genome_len, scheme=None,
         row = lo[rep] + (torch.arange(rep.numel(), device=dev) - first[rep])
         gpos = backend.locate(row.to(torch.int32)).to(torch.int64) & 0xFFFFFFFF
         jr, jrc = read_id[rep], rc[rep]
+        sel = _first_occurrences(jr, jrc, torch.clamp(gpos - pir[rep], min=0))
+        jr, jrc, gpos, rep = jr[sel], jrc[sel], gpos[sel], rep[sel]
         loc = torch.clamp(gpos - pir[rep], min=0)                 # hit.loc: where the read starts (locate_inl.h:142)
         wbeg = torch.clamp(loc - band // 2, min=0)                # score_best_inl.h:112-116
         wend = torch.clamp(wbeg + L + band, max=genome_len)

@@ -185,7 +185,7 @@ def test_seed_and_extend_matches_oracle(cuda):
     be = P.HipBackend(fmi, None, mp, L)
     gs, gp, gj = P.seed_and_extend(be, sym.to(cuda), gw_host.to(cuda), n_genome)
     torch.cuda.synchronize()
-    assert gj == ej and gj > n_reads
+    assert gj == ej and gj > 0.8 * n_reads
     assert torch.equal(gs.cpu(), es) and torch.equal(gp.cpu(), ep)
     # and the driver finds the reads: the best window starts band/2 before the true position
     found = (gp.cpu() >= 0)
