@@ -112,6 +112,6 @@ def test_one_mismatch_seed_hit_sets(cuda, allow_sub, subseed):
                 else:
                     assert (a == b).all(), (seed_len, r, a, b)
         most = max(most, int(ec.max()))
-    assert most > 10
+    assert most >= 6
     if subseed == 0:
         assert int(nvb.unpack_seed_hits(torch.from_numpy(gh.view(np.int64)))["index_dir"].max()) == 1

@@ -76,11 +76,8 @@ def test_full_matrix(cuda, ty):
             bad = np.nonzero((es != gs) | (ek != gk).any(1))[0]
             assert bad.size == 0, (ty, scheme, generic, bad[:5], es[bad[:3]], gs[bad[:3]], ek[bad[:3]], gk[bad[:3]])
             assert bool(go.all())
-    if ty == nvb.LOCAL:
-        # the 16-column visiting order is observable: some ties resolve differently from the Gotoh (8-column) form
-        _, bk, _ = O.batch_gotoh_score(ty, (2, -1, -1, -1), hp, ht)
-        _, ak = O.batch_sw_score(0, ty, (2, -1, -1, -1), hp, ht)
-        assert (ak != bk).any()
+    # (with LOCAL the 16-column visiting order is observable: on most data sets some ties resolve differently from the Gotoh
+    # (8-column) form -- tests/test_oracle_kat.py::test_pattern_blocking_and_text_blocking_restatements_agree counts them)
 
 
 def test_sw_benchmark_edit_distance_leg(cuda):
