@@ -276,7 +276,7 @@ NVB_API int nvbio_hip_fm_lookup_ssa_iterator(const nvbio_hip_fmindex* fmi, const
 NVB_API uint64_t nvbio_hip_fm_filter_temp_bytes(uint32_t n)
 {
     size_t scan = 0;
-    hipcub::DeviceScan::InclusiveSum(nullptr, scan, (const uint64_t*)nullptr, (uint64_t*)nullptr, int(n));
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, scan, (const uint64_t*)nullptr, (uint64_t*)nullptr, int(n));     // size query only
     return align256(uint64_t(n) * 8u) + align256(scan) + 256u;
 }
 
@@ -316,7 +316,7 @@ NVB_API uint64_t nvbio_hip_build_bwt_occ_temp_bytes(uint32_t n)
 {
     const uint64_t n_blocks = (uint64_t(n) + 63u) / 64u;
     size_t scan = 0;
-    hipcub::DeviceScan::ExclusiveScan(nullptr, scan, (const Count4*)nullptr, (Count4*)nullptr, Count4Sum(), Count4{0, 0, 0, 0}, int(n_blocks));
+    (void)hipcub::DeviceScan::ExclusiveScan(nullptr, scan, (const Count4*)nullptr, (Count4*)nullptr, Count4Sum(), Count4{0, 0, 0, 0}, int(n_blocks));     // size query only
     return 2u * align256(n_blocks * 16u) + align256(scan) + 256u;
 }
 
