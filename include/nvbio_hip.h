@@ -337,7 +337,8 @@ enum { NVBIO_HIP_EXACT_MAPPING = 0, NVBIO_HIP_APPROX_MAPPING = 1, NVBIO_HIP_CASE
  *   CASE_PRUNING  seed_mapper<CASE_PRUNING_MAPPING> (:372-428): the four half-exact / half-one-mismatch
  *                 searches over the forward index fmi and the index of the reversed genome rfmi
  * with map<> as in mapping_inl.h:124-223 (N handling included).  Hits are SeedHit word pairs as in
- * nvbio_hip_map_exact, index_dir (bit 31) = 1 for hits found on rfmi.  Seeds up to 32 symbols. */
+ * nvbio_hip_map_exact, index_dir (bit 31) = 1 for hits found on rfmi.  Seeds up to 32 symbols.
+ * A read's hits are stored in the array order of the reference's hit deque (see the selection stage below). */
 int nvbio_hip_map(int32_t algorithm, uint32_t subseed_len,
                   const nvbio_hip_fmindex* fmi, const nvbio_hip_fmindex* rfmi /* CASE_PRUNING only */,
                   const nvbio_hip_string_set* reads, const uint32_t* in_queue, uint32_t n,
@@ -363,6 +364,70 @@ int nvbio_hip_score_reduce(uint32_t n_active, const uint32_t* read_ids /* nullab
                            const int32_t* hit_score, const uint32_t* hit_loc, const uint8_t* hit_rc,
                            const uint32_t* read_len /* by read id, nullable */, uint32_t fixed_read_len,
                            uint64_t* best_alignments, uint32_t best_stride, void* stream);
+
+/* ---- nvBowtie hit selection and the per-round stages of its best-approx extension loop --------------------------
+ * (driver: Aligner::best_approx_score, nvBowtie/bowtie2/cuda/aligner_best_approx.h:522-840.)
+ *
+ * The hit arena written by nvbio_hip_map* IS the reference's SeedHitDequeArray content: a read's SeedHits sit at
+ * hits[read_id * hits_stride] in the array order of its priority_deque (interval heap, nvbio/basic/interval_heap.h;
+ * slot 0 = a largest range, top() = slot 1, or slot 0 when alone), hit_counts[read_id] is the deque size.  The
+ * probability tree of the randomized selection (SumTree<float*>, nvbio/basic/sum_tree.h) of read r lives at
+ * probs[r * probs_stride], probs_stride >= nvbio_hip_sum_tree_node_count(hits_stride).
+ * Active reads are packed_read words (defs.h:152-162: read_id:31, top_flag:1); a selected hit is {read_id, loc, seed}
+ * with seed a packed_seed word (defs.h:171-181: pos_in_read:12, index_dir:1, rc:1, top_flag:1).
+ * Floating point: single precision, every operation rounded separately (the host-compiled arithmetic). */
+uint32_t nvbio_hip_sum_tree_node_count(uint32_t size);
+/* select_init_kernel (select.cu:36-103): trys[r] = max_effort_init (if trys); when randomized, rseeds[r] = hash of the
+ * read's name (names NUL-terminated in read_names at read_names_idx[r]; with read_names NULL rseeds is left as the
+ * caller set it), probs = 1 / range_size^2 per hit (the first 0 if top_seed) and the tree sums. */
+int nvbio_hip_select_init(uint32_t n_reads, const char* read_names, const uint32_t* read_names_idx,
+                          const uint64_t* hits, uint32_t hits_stride, const uint32_t* hit_counts,
+                          float* probs, uint32_t probs_stride, uint32_t* trys /* nullable */, uint32_t* rseeds,
+                          uint32_t max_effort_init, int32_t randomized, int32_t top_seed, void* stream);
+/* select (select_inl.h:74-607; dispatch :744-795): one round of hit selection for the reads of active_in.  Reads whose
+ * try counter is 0 or whose deque is empty leave the queue; the others hand out up to n_multi SA rows each (n_multi == 1:
+ * select_kernel / rand_select_kernel, > 1: the *_multi_kernel forms), from the deque's top range downwards, or -- randomized
+ * -- from hits sampled in proportion to probs with the read's LCG.  Outputs, in the order of active_in (the reference's
+ * slot order is atomic-dependent): active_out[n_out], the selected hits grouped per read with hit_begin[n_out + 1]
+ * offsets, out_sizes = {n_out, n_hits} (device).  active_out / hit_begin need n_active (+1) entries, the hit arrays
+ * n_active * n_multi.  hits / hit_counts / probs / rseeds are updated in place.  n_multi <= 4096. */
+uint64_t nvbio_hip_select_temp_bytes(uint32_t n_active, uint32_t n_multi);
+int nvbio_hip_select(int32_t randomized, uint32_t n_multi, const uint32_t* active_in, uint32_t n_active,
+                     uint64_t* hits, uint32_t hits_stride, uint32_t* hit_counts,
+                     float* probs, uint32_t probs_stride, uint32_t* rseeds, const uint32_t* trys,
+                     uint32_t* active_out, uint64_t* hit_begin, uint32_t* hit_read_id, uint32_t* hit_loc, uint32_t* hit_seed,
+                     uint32_t* out_sizes, void* temp, uint64_t temp_bytes, void* stream);
+/* Diagnostic: runs programs of deque operations (ops[i]: 0 = push vals[i], dropping the bottom first when the deque
+ * holds caps[i] hits; 1 = pop_top; 2 = pop_bottom; program c = [case_start[c], case_start[c+1])) through the device's
+ * hit deque and writes the deque's array after every operation from out_states[state_start[c]] on.  scratch: n_cases *
+ * scratch_stride words.  Used to replay vectors recorded from the reference's interval heap. */
+int nvbio_hip_hit_deque_replay(uint32_t n_cases, const uint32_t* case_start, const uint8_t* ops, const uint64_t* vals, const uint32_t* caps,
+                               const uint64_t* state_start, uint64_t* scratch, uint32_t scratch_stride, uint64_t* out_states, void* stream);
+/* locate_kernel (locate_inl.h:53-143): hit_loc[i] (an SA row of fmi, or of rfmi when the seed's index_dir is REVERSE)
+ * becomes the read's start in genome coordinates: locate - pos_in_read, mirrored (length-1-locate) for rfmi; uint32
+ * arithmetic, so a read hanging over the genome start wraps.  rfmi may be NULL when no hit uses it. */
+int nvbio_hip_locate_hits(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmindex* rfmi, uint32_t n,
+                          uint32_t* hit_loc, const uint32_t* hit_seed, void* stream);
+/* BestScoreStream::init_context (score_best_inl.h:95-126): per hit, the genome window [loc - band/2 (clamped at 0),
+ * + band + read_len (clamped at genome_length)), the threshold max(second best score of the read, score_limit) and
+ * the pattern (read r's forward copy at read_begin[r] -- or r * fixed_read_len -- or its reverse complement rc_offset
+ * symbols further, by the seed's rc bit).  A window beginning at or beyond its end gets length 0 (the reference
+ * would read out of bounds); the alignment then fails like any text shorter than its pattern. */
+int nvbio_hip_score_best_setup(uint32_t n_hits, const uint32_t* hit_read_id, const uint32_t* hit_loc, const uint32_t* hit_seed,
+                               const uint64_t* read_begin /* nullable */, const uint32_t* read_len /* nullable */, uint32_t fixed_read_len,
+                               uint64_t rc_offset, uint32_t band_len, uint32_t genome_length,
+                               const uint64_t* best_alignments, uint32_t best_stride, int32_t score_limit,
+                               uint64_t* pattern_begin, uint32_t* pattern_len /* nullable iff fixed */,
+                               uint64_t* text_begin, uint32_t* text_len, int32_t* min_score, void* stream);
+/* score_reduce_kernel with ReduceBestApproxContext (reduce_inl.h:71-160, reduce.h:63-105): nvbio_hip_score_reduce over
+ * packed active reads and packed seeds, plus the give-up counters: see reduce.hip.  hit_score is the raw DP score
+ * (clamped to worst_score = scheme_type::worst_score here); n_ext = extensions done before this round. */
+int nvbio_hip_score_reduce_best_approx(uint32_t n_active, const uint32_t* active_reads, const uint64_t* hit_begin,
+                                       const int32_t* hit_score, const uint32_t* hit_loc, const uint32_t* hit_seed,
+                                       const uint32_t* read_len /* nullable */, uint32_t fixed_read_len,
+                                       uint64_t* best_alignments, uint32_t best_stride, int32_t worst_score,
+                                       uint32_t* trys, uint32_t* hit_counts,
+                                       uint32_t n_ext, uint32_t min_ext, uint32_t max_ext, uint32_t max_effort, void* stream);
 
 /* The paired-end form: score_reduce_paired_kernel (reduce_inl.h:355-500).  Per extension result the anchor mate's
  * {loc, sink (genome end), score, rc} and the opposite mate's {loc, sink, sink2, score, score2} (the stream's hit.* fields,

@@ -1,0 +1,137 @@
+"""nvBowtie's single-end best-mapping driver over the C-ABI stages: Aligner::best_approx and
+Aligner::best_approx_score (nvBowtie/bowtie2/cuda/aligner_best_approx.h:85-520, :522-840).
+
+Per seeding pass: map the queued reads' seeds into their hit deques, then run extension rounds -- select the next SA
+row(s) of every active read (deterministic or randomized, one or several per round), locate them, score the read
+against the genome window around each, fold the scores into the best / second-best alignments while the
+give-up counters decide which reads stay active -- and queue for re-seeding the reads that are still unaligned or
+whose seeds were too repetitive.  Then MAPQ and the banded traceback of every best alignment.
+
+Only queue bookkeeping lives here (compaction of the re-seed queue, the choice of hits-per-read per round): what
+the reference's driver does on the host between kernel launches.  Every stage is a libnvbio_hip.so call; nothing
+falls back to the CPU."""
+import torch
+
+from . import mapping, reduce, select as sel
+from .alignment import (make_gotoh_aligner, SmithWatermanScoringScheme, SEMI_GLOBAL, LOCAL, batch_banded_alignment_score,
+                        batch_banded_alignment_traceback)
+from .strings import PackedStringSet
+
+WORST_SCORE = -(1 << 16)          # SmithWatermanScoringScheme::worst_score (scoring.h:226-227)
+
+
+class Params:
+    """The fields of nvBowtie's Params this driver reads, with its defaults (params.cpp:116-197; end-to-end)."""
+
+    def __init__(self, **kw):
+        self.max_hits, self.max_dist = 100, 15
+        self.max_effort_init, self.max_effort, self.min_ext, self.max_ext = 15, 15, 30, 400
+        self.max_reseed, self.rep_seeds, self.allow_sub, self.subseed_len = 2, 300, 0, 0
+        self.randomized, self.top_seed, self.no_multi_hits = True, 0, False
+        self.seed_len, self.seed_freq, self.min_read_len = 22, (mapping.SQRT_FUNC, 1.0, 1.15), 12
+        self.local = False
+        self.fw, self.rc = True, True
+        self.batch_size = 1 << 20                      # Aligner::BATCH_SIZE
+        self.hits_stride = None                        # arena slots per read (default min(max_hits, 128))
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise TypeError("unknown parameter %s" % k)
+            setattr(self, k, v)
+        self.max_effort_init = max(self.max_effort_init, self.max_effort)      # params.cpp:197-198
+        self.max_ext = max(self.max_ext, self.max_effort)
+
+    def mapping_params(self):
+        return mapping.MappingParams(self.seed_len, self.seed_freq, self.min_read_len, self.max_hits, self.max_reseed, self.rep_seeds)
+
+
+def band_length(max_dist):
+    """Aligner::band_length (aligner.h:165-174): the smallest 2^k - 1 >= 2 * max_dist + 1"""
+    b = 4
+    while b - 1 < max_dist * 2 + 1:
+        b *= 2
+    return b - 1
+
+
+def hits_per_read(n_active, n_ext, params):
+    """The choice at aligner_best_approx.h:627-650."""
+    if n_active <= params.batch_size // 2 and not params.no_multi_hits:
+        return min(params.batch_size // n_active, min(4096, params.max_ext - n_ext))
+    return 1
+
+
+def best_approx_score(fmi, rfmi, state, seed_queue, best, reads_fw_rc, n_reads, read_len, genome_words, genome_len, aligner, quals,
+                      params, band_len, stats):
+    """Aligner::best_approx_score: the extension rounds of one seeding pass (`state` = select_init's output)."""
+    active = seed_queue.to(torch.int32)                                   # pack_read(params.top_seed), defs.h:185-205
+    if params.top_seed & 1:
+        active = active | torch.tensor(-(1 << 31), dtype=torch.int32, device=active.device)
+    n_ext = 0
+    while active.numel() and n_ext < params.max_ext:
+        n_multi = hits_per_read(active.numel(), n_ext, params)
+        active, hit_begin, rid, loc, seed = sel.select(state, active, n_multi)
+        if active.numel() == 0:
+            break
+        if loc.numel() == 0:
+            continue
+        sel.locate_hits(fmi, rfmi, loc, seed)
+        pb, _, tb, tl, _ = sel.score_best_setup(rid, loc, seed, best, band_len, genome_len, WORST_SCORE, fixed_read_len=read_len,
+                                                rc_offset=n_reads * read_len)
+        patterns = PackedStringSet(reads_fw_rc, 4, True, pb, None, read_len)
+        texts = PackedStringSet(genome_words, 2, True, tb, tl, 0)
+        score, _ = batch_banded_alignment_score(band_len, aligner, patterns, texts, quals=quals)
+        sel.score_reduce_best_approx(best, state, active, hit_begin, score, loc, seed, WORST_SCORE, n_ext, params.min_ext, params.max_ext,
+                                     params.max_effort, fixed_read_len=read_len)
+        stats["extensions"] += int(loc.numel()); stats["rounds"] += 1
+        n_ext += n_multi
+
+
+def best_approx(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=None, names=None, qual_value=30, traceback=True,
+                cigar_stride=None):
+    """Aligner::best_approx for a batch of equal-length reads `sym` (uint8 [n, L], symbols 0..4).  `names`: list of read
+    names (they seed the randomized selection).  Returns dict(best int64[2,n] io::Alignment words, mapq uint8[n], and with
+    traceback: cigar int16[n,stride], cigar_len, source, sink (-1 for unaligned reads), stats)."""
+    from .pipeline import pack_read_streams
+    params = params or Params()
+    n, L = sym.shape
+    dev = sym.device
+    scheme = scheme or (SmithWatermanScoringScheme.local() if params.local else SmithWatermanScoringScheme())
+    aligner = make_gotoh_aligner(LOCAL if params.local else SEMI_GLOBAL, scheme)
+    band_len = band_length(params.max_dist)
+    reads_rev, reads_fw_rc = pack_read_streams(sym)
+    quals = torch.full((2 * n * L + 8,), qual_value, dtype=torch.uint8, device=dev)
+    name_arena = sel.pack_names(names if names is not None else ["%d" % i for i in range(n)], dev) if params.randomized else None
+    mp = params.mapping_params()
+    best = reduce.BestAlignments(n, scheme, fixed_read_len=L, device=dev)           # init_alignments with the threshold score
+    seed_queue = torch.arange(n, dtype=torch.int32, device=dev)
+    hits_stride = params.hits_stride or min(params.max_hits, 128)
+    stats = dict(extensions=0, rounds=0, seeding_passes=0, queue=[])
+    for seeding_pass in range(params.max_reseed + 1):
+        if seed_queue.numel() == 0:
+            break
+        stats["queue"].append(int(seed_queue.numel())); stats["seeding_passes"] += 1
+        hits, counts, reseed = mapping.map_seeds(fmi, rfmi, reads_rev, mp, L, allow_sub=params.allow_sub, subseed_len=params.subseed_len,
+                                                 retry=seeding_pass, fw=params.fw, rc=params.rc, in_queue=seed_queue, hits_stride=hits_stride)
+        state = sel.SelectState(hits, counts, name_arena, params.max_effort_init, params.randomized, params.top_seed)
+        best_approx_score(fmi, rfmi, state, seed_queue, best, reads_fw_rc, n, L, genome_words, genome_len, aligner, quals, params, band_len, stats)
+        # mark_unaligned (aligner_init.cu:421-436) + copy_flagged
+        flag = (reseed != 0) | ~best.is_aligned(0)[seed_queue.to(torch.int64)]
+        seed_queue = seed_queue[flag]
+    out = dict(best=best.data, mapq=reduce.mapq(best, scheme, fixed_read_len=L), stats=stats)
+    if traceback:
+        # banded_traceback_best (traceback_inl.h:104-136): window = alignment - band/2, band + read_len long
+        b_align = best.alignment(0)
+        ids = torch.nonzero(best.is_aligned(0)).squeeze(1)
+        b_rc = best.is_rc(0)
+        tb_begin = torch.clamp(b_align[ids] - band_len // 2, min=0)
+        tb_end = torch.clamp(tb_begin + L + band_len, max=genome_len)
+        pat = PackedStringSet(reads_fw_rc, 4, True, (ids * L + b_rc[ids] * (n * L)).contiguous(), None, L)
+        txt = PackedStringSet(genome_words, 2, True, tb_begin.contiguous(), (tb_end - tb_begin).to(torch.int32).contiguous(), 0)
+        tb = batch_banded_alignment_traceback(band_len, aligner, pat, txt, quals=quals, cigar_stride=cigar_stride)
+        stride = tb["cigar"].shape[1]
+        cigar = torch.zeros((n, stride), dtype=torch.int16, device=dev)
+        cigar_len = torch.zeros(n, dtype=torch.int32, device=dev)
+        source = torch.full((n, 2), -1, dtype=torch.int32, device=dev)
+        sink = torch.full((n, 2), -1, dtype=torch.int32, device=dev)
+        cigar[ids] = tb["cigar"][: ids.numel()]; cigar_len[ids] = tb["cigar_len"]; source[ids] = tb["source"]; sink[ids] = tb["sink"]
+        out.update(cigar=cigar, cigar_len=cigar_len, source=source, sink=sink, tb_score=tb["score"], aligned_ids=ids)
+    return out

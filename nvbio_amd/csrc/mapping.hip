@@ -10,15 +10,15 @@
 // pos_in_read = read_end - pos - seed_len) and the reverse scan of its complement (flags
 // COMPLEMENT/FORWARD, pos_in_read = pos - read_begin); non-empty SA ranges only, stored exclusive.
 //
-// Differences in mechanism, not in the hit sets: the reference keeps a 512-entry interval heap in
-// per-thread local memory and copies it to an arena slot taken with an atomic bump, so the order of
-// a read's hits (heap layout) and the slot order (atomics) are run-dependent, and its own checksum
-// compares the sorted sets (checksums.h).  Here a read's hits are written in generation order to a
-// fixed slot read_id * hits_stride -- no local-memory heap, no atomics, deterministic.  When a read
-// produces more than max_hits hits, a hit of largest range size is dropped per extra hit exactly as
-// priority_deque::pop_bottom does (which of several equal-sized largest hits goes is unspecified in
-// both).
+// Difference in mechanism, not in the result: the reference keeps a 512-entry deque in per-thread local
+// memory and copies it to an arena slot taken with an atomic bump, so the slot order is run-dependent.
+// Here the deque (hit_deque.h: the reference's interval heap, exchange for exchange) is built in place in
+// the fixed slot read_id * hits_stride -- no local-memory copy, no atomics -- and a read's hits come out
+// in exactly the array order the reference's store_deque writes (mapping_inl.h:101-115), which is what the
+// selection stage's top() and randomized sampling act on.  When a read produces more than max_hits hits,
+// the deque's bottom (a hit of largest range size) is dropped per extra hit (:268-270).
 #include "fmindex_device.h"
+#include "hit_deque.h"
 
 namespace nvb {
 
@@ -116,13 +116,10 @@ map_exact_kernel(const Fmi f, const StringSet reads, const uint32_t* __restrict_
             if (has_n) break;
             if (r.x > r.y) continue;
             const uint32_t pir = strand == 0 ? uint32_t(rb + rlen - pos - seed_len) : uint32_t(pos - rb);
-            if (nh == cap)
-            {
-                uint32_t worst = 0, wsize = hits[0].y & 0xFFFFFu;
-                for (uint32_t h = 1; h < nh; ++h) { const uint32_t sz = hits[h].y & 0xFFFFFu; if (sz > wsize) { wsize = sz; worst = h; } }
-                hits[worst] = hits[--nh];
-            }
+            const HitDeque deque = { hits };
+            if (nh == cap) { deque.pop_bottom(int(nh)); --nh; }                  // :268-270
             hits[nh++] = seed_hit_pack(r.x, r.y + 1u - r.x, pir, strand);
+            deque.push(int(nh));
             range_sum += r.y - r.x + 1u; range_count++;
         }
     }
@@ -205,13 +202,10 @@ struct HitHeap {
     uint32_t nh, cap, range_sum, range_count;
     __device__ __forceinline__ void push(const uint2 r /* inclusive */, const uint32_t flags)
     {
-        if (nh == cap)
-        {
-            uint32_t worst = 0, wsize = hits[0].y & 0xFFFFFu;
-            for (uint32_t h = 1; h < nh; ++h) { const uint32_t sz = hits[h].y & 0xFFFFFu; if (sz > wsize) { wsize = sz; worst = h; } }
-            hits[worst] = hits[--nh];
-        }
+        const HitDeque deque = { hits };
+        if (nh == cap) { deque.pop_bottom(int(nh)); --nh; }
         hits[nh++] = make_uint2(r.x, ((r.y + 1u - r.x) & 0xFFFFFu) | flags);
+        deque.push(int(nh));
         range_sum += r.y - r.x + 1u; range_count++;
     }
 };

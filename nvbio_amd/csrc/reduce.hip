@@ -50,6 +50,46 @@ score_reduce_kernel(uint32_t n_active, const uint32_t* __restrict__ read_ids, co
     best[read_id + best_stride] = make_uint2(a2.w, a2.align);
 }
 
+// score_reduce_kernel with ReduceBestApproxContext (reduce.h:63-105): the same walk, plus the extension give-up
+// counters of the best-approx loop.  An update of the best or second best refills the read's try counter with
+// max_effort; any other result, once n_ext + idx reaches min_ext and the hit did not come from the top seed range,
+// burns one try, and the read's hit deque is erased (so the next selection round drops the read) when the tries
+// run out or n_ext + idx reaches max_ext.  hit_score is the raw DP result, clamped to worst_score first as
+// BestScoreStream::output does (score_best_inl.h:139); `active` holds packed_read words.
+__global__ void __launch_bounds__(256)
+score_reduce_best_approx_kernel(uint32_t n_active, const uint32_t* __restrict__ active, const uint64_t* __restrict__ hit_begin,
+                                const int32_t* __restrict__ hit_score, const uint32_t* __restrict__ hit_loc, const uint32_t* __restrict__ hit_seed,
+                                const uint32_t* __restrict__ read_len, uint32_t fixed_len, uint2* __restrict__ best, uint32_t best_stride,
+                                int32_t worst_score, uint32_t* __restrict__ trys, uint32_t* __restrict__ hit_counts,
+                                uint32_t n_ext, uint32_t min_ext, uint32_t max_ext, uint32_t max_effort)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_active) return;
+    const uint32_t read_id = active[t] & 0x7FFFFFFFu;
+    const uint2 b1 = best[read_id], b2 = best[read_id + best_stride];
+    IoAln a1 = { b1.x, b1.y }, a2 = { b2.x, b2.y };
+    const uint32_t len = read_len ? read_len[read_id] : fixed_len;
+    const uint64_t hb = hit_begin[t], he = hit_begin[t + 1];
+    uint32_t tr = trys[read_id];
+    bool erase = false;
+    for (uint64_t i = hb; i < he; ++i)
+    {
+        const int32_t score = max(hit_score[i], worst_score);
+        const uint32_t g_pos = hit_loc[i], seed = hit_seed[i], rc = (seed >> 13) & 1u, top_flag = (seed >> 14) & 1u;
+        if ((rc == io_aln_rc(a1) && g_pos == a1.align) || (rc == io_aln_rc(a2) && g_pos == a2.align)) continue;
+        if (score > io_aln_score(a1)) { tr = max_effort; a2 = a1; a1 = io_aln_make(g_pos, 0u, score, rc); }
+        else if (score > io_aln_score(a2) && distinct_alignments(a1.align, io_aln_rc(a1), g_pos, rc, len / 2u)) { tr = max_effort; a2 = io_aln_make(g_pos, 0u, score, rc); }
+        else if (tr > 0u) {
+            const uint32_t idx = uint32_t(i - hb);
+            if ((n_ext + idx >= min_ext && top_flag == 0u && --tr == 0u) || (n_ext + idx >= max_ext)) erase = true;
+        }
+    }
+    trys[read_id] = tr;
+    if (erase) hit_counts[read_id] = 0u;
+    best[read_id] = make_uint2(a1.w, a1.align);
+    best[read_id + best_stride] = make_uint2(a2.w, a2.align);
+}
+
 // init_alignments_kernel (nvBowtie/bowtie2/cuda/aligner.h:323-346): both slots unaligned (pos -1, ed max) with the
 // read's worst acceptable score, so that only extensions above the threshold are ever recorded.  The reference
 // passes `mate` in the constructor's rc position (aligner.h:342-343); kept.
@@ -382,6 +422,24 @@ NVB_API int nvbio_hip_score_reduce(uint32_t n_active, const uint32_t* read_ids, 
     g_last_kernel = "score_reduce_kernel";
     hipLaunchKernelGGL(score_reduce_kernel, dim3((n_active + 255u) / 256u), dim3(256), 0, to_stream(stream), n_active, read_ids, hit_begin,
                        hit_score, hit_loc, hit_rc, read_len, fixed_read_len, reinterpret_cast<uint2*>(best_alignments), best_stride);
+    return hipGetLastError();
+}
+
+NVB_API int nvbio_hip_score_reduce_best_approx(uint32_t n_active, const uint32_t* active_reads, const uint64_t* hit_begin,
+                                               const int32_t* hit_score, const uint32_t* hit_loc, const uint32_t* hit_seed,
+                                               const uint32_t* read_len, uint32_t fixed_read_len,
+                                               uint64_t* best_alignments, uint32_t best_stride, int32_t worst_score,
+                                               uint32_t* trys, uint32_t* hit_counts,
+                                               uint32_t n_ext, uint32_t min_ext, uint32_t max_ext, uint32_t max_effort, void* stream)
+{
+    if (n_active == 0) return hipSuccess;
+    if (!active_reads || !hit_begin || !hit_score || !hit_loc || !hit_seed || !best_alignments || best_stride == 0 || !trys || !hit_counts)
+        return hipErrorInvalidValue;
+    if (!read_len && fixed_read_len == 0) return hipErrorInvalidValue;
+    g_last_kernel = "score_reduce_best_approx_kernel";
+    hipLaunchKernelGGL(score_reduce_best_approx_kernel, dim3((n_active + 255u) / 256u), dim3(256), 0, to_stream(stream), n_active, active_reads,
+                       hit_begin, hit_score, hit_loc, hit_seed, read_len, fixed_read_len, reinterpret_cast<uint2*>(best_alignments), best_stride,
+                       worst_score, trys, hit_counts, n_ext, min_ext, max_ext, max_effort);
     return hipGetLastError();
 }
 

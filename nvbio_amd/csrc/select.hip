@@ -1,0 +1,395 @@
+// select.hip -- nvBowtie's hit-selection stage and the per-round glue kernels of its best-approx extension
+// loop, on gfx950.
+//   select_init_kernel                     nvBowtie/bowtie2/cuda/select.cu:36-103
+//   select_kernel / rand_select_kernel / select_multi_kernel / rand_select_multi_kernel,
+//   randomized_select                      nvBowtie/bowtie2/cuda/select_inl.h:74-607
+//   SumTree<float*> / sample()             nvbio/basic/sum_tree_inl.h:38-178
+//   locate_kernel (index direction)        nvBowtie/bowtie2/cuda/locate_inl.h:53-143
+//   BestScoreStream::init_context          nvBowtie/bowtie2/cuda/score_best_inl.h:95-126
+//
+// One lane per active read: a read's selection is a short sequential walk over its own deque / probability
+// tree (order dependent: LCG draws, pop_front, tree updates), reads are independent.  Where the reference takes
+// output slots with warp-aggregated atomics (so the order of its output queues changes from run to run), the
+// lanes here stage their picks, one scan turns the per-read counts into offsets, and a second kernel compacts:
+// active reads and their hits come out in input-queue order, every run.  The multi-hit index (ReadHitsIndex
+// links, scoring_queues.h:64-130) becomes a CSR offset array -- a read's hits are contiguous.
+//
+// Single-precision arithmetic is done operation by operation (no contraction), matching the host compile of
+// the reference's HOST_DEVICE code that the oracle restates.
+#include "fmindex_device.h"
+#include "hit_deque.h"
+#include <hipcub/hipcub.hpp>
+
+namespace nvb {
+
+__device__ __forceinline__ uint32_t ilog2(uint32_t n) { return 31u - uint32_t(__clz(int(n | 1u))); }       // nvbio::log2 (floor; log2(0) = 0)
+__device__ __forceinline__ uint32_t st_padded(const uint32_t size) { const uint32_t l = ilog2(size); return (1u << l) < size ? 1u << (l + 1u) : 1u << l; }
+
+struct SumTree
+{
+    float*   c;
+    uint32_t size, padded;
+    __device__ __forceinline__ SumTree(float* cells, const uint32_t n) : c(cells), size(n), padded(st_padded(n)) {}
+    __device__ __forceinline__ float sum() const { return c[padded * 2u - 2u]; }
+    __device__ void setup() const
+    {
+        for (uint32_t i = size; i < padded; ++i) c[i] = 0.0f;
+        uint32_t src = 0;
+        for (uint32_t n = padded; n >= 2u; n >>= 1) {
+            const uint32_t dst = src + n, m = n >> 1;
+            for (uint32_t i = 0; i < m; ++i) c[dst + i] = __fadd_rn(c[src + i * 2u], c[src + i * 2u + 1u]);
+            src += n;
+        }
+    }
+    __device__ void set(const uint32_t i, const float v) const
+    {
+        c[i] = v;
+        uint32_t prev = 0u, base = padded, parent = i >> 1;
+        for (uint32_t m = padded >> 1; base + parent < padded * 2u - 1u; m >>= 1) {
+            c[base + parent] = __fadd_rn(c[prev + parent * 2u], c[prev + parent * 2u + 1u]);
+            prev = base; base += m; parent >>= 1;
+        }
+    }
+    __device__ uint32_t sample(const float value) const
+    {
+        uint32_t base = padded * 2u - 4u, node = 0;
+        float v = value;
+        for (uint32_t m = 2u; m < padded; m *= 2u) {
+            const float l = c[base + node], r = c[base + node + 1u];
+            const float s = __fadd_rn(l, r);
+            if (s == 0.0f) node *= 2u;
+            else {
+                const float vs = __fmul_rn(v, s);
+                if (vs < l || r == 0.0f) { node = node * 2u; const float q = __fdiv_rn(vs, l); v = q < 1.0f ? q : 1.0f; }
+                else { node = (node + 1u) * 2u; const float q = __fdiv_rn(__fsub_rn(vs, l), r); v = q < 1.0f ? q : 1.0f; }
+            }
+            base -= m * 2u;
+        }
+        const float l = node < size ? c[node] : 0.0f, r = node + 1u < size ? c[node + 1u] : 0.0f;
+        const float vs = __fmul_rn(v, __fadd_rn(l, r));
+        node = (vs < l || r == 0.0f) ? node : node + 1u;
+        return node < size ? node : size - 1u;
+    }
+};
+
+__device__ __forceinline__ uint32_t hit_delta(const uint2 h) { return h.y & 0xFFFFFu; }
+__device__ __forceinline__ uint32_t hit_pop_front(uint2* h)              // SeedHit::pop_front (seed_hit.h:136-142)
+{
+    uint2 v = *h;
+    const uint32_t r = v.x;
+    v.x = r + 1u;
+    v.y = (v.y & ~0xFFFFFu) | ((v.y - 1u) & 0xFFFFFu);
+    *h = v;
+    return r;
+}
+__device__ __forceinline__ uint32_t packed_seed_of(const uint2 h, const uint32_t top_flag)      // defs.h:171-181
+{
+    return ((h.y >> 20) & 0x3FFu) | (((h.y >> 31) & 1u) << 12) | (((h.y >> 30) & 1u) << 13) | ((top_flag & 1u) << 14);
+}
+
+__global__ void __launch_bounds__(256)
+select_init_kernel(uint32_t n_reads, const char* __restrict__ names, const uint32_t* __restrict__ names_idx,
+                   const uint2* __restrict__ hits, uint32_t hits_stride, const uint32_t* __restrict__ counts,
+                   float* __restrict__ probs, uint32_t probs_stride, uint32_t* __restrict__ trys, uint32_t* __restrict__ rseeds,
+                   uint32_t max_effort_init, int randomized, int top_seed)
+{
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= n_reads) return;
+    if (trys) trys[r] = max_effort_init;
+    if (!randomized) return;
+    if (names) {
+        const uint32_t off = names_idx[r], len = names_idx[r + 1u] - off;
+        uint32_t hash = 5381u;
+        for (uint32_t i = 0; i < len && names[off + i]; ++i) hash = ((hash << 5) + hash) ^ uint32_t(int32_t((signed char)names[off + i]));
+        rseeds[r] = hash;
+    }
+    const uint32_t n = counts[r];
+    if (n == 0u) return;
+    float* pr = probs + uint64_t(r) * probs_stride;
+    const uint2* h = hits + uint64_t(r) * hits_stride;
+    for (uint32_t i = 0; i < n; ++i) { const float d = __uint2float_rn(hit_delta(h[i])); pr[i] = __fdiv_rn(1.0f, __fmul_rn(d, d)); }
+    if (top_seed) pr[0] = 0.0f;
+    SumTree(pr, n).setup();
+}
+
+__device__ uint32_t randomized_select(const SumTree& tree, const uint2* h, uint32_t* rseed)
+{
+    uint32_t s = *rseed;
+    uint32_t pick = 0u;
+    bool found = false;
+    for (uint32_t i = 0; i < 10u && !found; ++i) {
+        s = 1664525u * s + 1013904223u;
+        const float rf = __fdiv_rn(__uint2float_rn(s), 4294967296.0f);          // float(0xFFFFFFFFu) rounds to 2^32
+        const uint32_t id = tree.sample(rf);
+        if (hit_delta(h[id]) != 0u) { pick = id; found = true; }
+    }
+    *rseed = s;
+    return pick;
+}
+
+// stage 1: every active read makes its picks into its own staging slots
+template <bool RANDOMIZED>
+__global__ void __launch_bounds__(256)
+select_kernel(uint32_t n_multi, const uint32_t* __restrict__ active_in, uint32_t n_active,
+              uint2* __restrict__ hits, uint32_t hits_stride, uint32_t* __restrict__ counts,
+              float* __restrict__ probs, uint32_t probs_stride, uint32_t* __restrict__ rseeds, const uint32_t* __restrict__ trys,
+              uint32_t* __restrict__ stage_read, uint32_t* __restrict__ stage_loc, uint32_t* __restrict__ stage_seed, uint64_t* __restrict__ key)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t > n_active) return;
+    if (t == n_active) { key[t] = 0ull; return; }
+    const uint32_t read_id = active_in[t] & 0x7FFFFFFFu;
+    uint32_t top_flag = active_in[t] >> 31;
+    uint32_t n_sel = 0u;
+    uint32_t n = (trys[read_id] == 0u) ? 0u : counts[read_id];                  // SelectBestApproxContext::stop, empty deque
+    if (n != 0u)
+    {
+        uint2* h = hits + uint64_t(read_id) * hits_stride;
+        uint32_t* out_loc = stage_loc + uint64_t(t) * n_multi;
+        uint32_t* out_seed = stage_seed + uint64_t(t) * n_multi;
+        if (!RANDOMIZED)
+        {
+            const HitDeque deque = { h };
+            for (uint32_t i = 0; i < n_multi; ++i)
+            {
+                uint32_t top = uint32_t(deque.top(int(n)));
+                if (hit_delta(h[top]) == 0u) {                                  // the top range ran out: next one
+                    deque.pop_top(int(n)); --n;
+                    if (n == 0u) break;
+                    top = uint32_t(deque.top(int(n)));
+                    top_flag = 0u;
+                }
+                out_loc[n_sel] = hit_pop_front(&h[top]);
+                out_seed[n_sel] = packed_seed_of(h[top], top_flag);
+                ++n_sel;
+            }
+            counts[read_id] = n;                                                // ~SeedHitDequeReference
+        }
+        else
+        {
+            const SumTree tree(probs + uint64_t(read_id) * probs_stride, n);
+            for (uint32_t i = 0; i < n_multi; ++i)
+            {
+                if (tree.sum() <= 0.0f) break;                                  // (erase() here is undone by the reference's destructor)
+                if (top_flag && hit_delta(h[0]) == 0u) top_flag = 0u;
+                const uint32_t id = top_flag ? 0u : randomized_select(tree, h, &rseeds[read_id]);
+                if (hit_delta(h[id]) == 0u) { if (n_multi > 1u) continue; else break; }
+                out_loc[n_sel] = hit_pop_front(&h[id]);
+                if (hit_delta(h[id]) == 0u) tree.set(id, 0.0f);
+                out_seed[n_sel] = packed_seed_of(h[id], top_flag);
+                ++n_sel;
+            }
+        }
+    }
+    stage_read[t] = read_id | (top_flag << 31);
+    key[t] = (uint64_t(n_sel != 0u ? 1u : 0u) << 32) | n_sel;
+}
+
+// stage 2: compaction in queue order
+__global__ void __launch_bounds__(256)
+select_compact_kernel(uint32_t n_multi, uint32_t n_active, const uint64_t* __restrict__ key, const uint64_t* __restrict__ off,
+                      const uint32_t* __restrict__ stage_read, const uint32_t* __restrict__ stage_loc, const uint32_t* __restrict__ stage_seed,
+                      uint32_t* __restrict__ active_out, uint64_t* __restrict__ hit_begin, uint32_t* __restrict__ hit_read_id,
+                      uint32_t* __restrict__ hit_loc, uint32_t* __restrict__ hit_seed, uint32_t* __restrict__ out_sizes)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t > n_active) return;
+    const uint64_t o = off[t];
+    if (t == n_active) {
+        hit_begin[uint32_t(o >> 32)] = o & 0xFFFFFFFFull;
+        out_sizes[0] = uint32_t(o >> 32); out_sizes[1] = uint32_t(o);
+        return;
+    }
+    const uint32_t n_sel = uint32_t(key[t]);
+    if (n_sel == 0u) return;
+    const uint32_t slot = uint32_t(o >> 32), hb = uint32_t(o);
+    active_out[slot] = stage_read[t];
+    hit_begin[slot] = hb;
+    const uint32_t read_id = stage_read[t] & 0x7FFFFFFFu;
+    for (uint32_t i = 0; i < n_sel; ++i) {
+        hit_read_id[hb + i] = read_id;
+        hit_loc[hb + i] = stage_loc[uint64_t(t) * n_multi + i];
+        hit_seed[hb + i] = stage_seed[uint64_t(t) * n_multi + i];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+locate_hits_kernel(const Fmi f, const Fmi rf, uint32_t n, uint32_t* __restrict__ hit_loc, const uint32_t* __restrict__ hit_seed)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t seed = hit_seed[i], dir = (seed >> 12) & 1u, pir = seed & 0xFFFu;
+    const Fmi& x = dir ? rf : f;
+    const uint2 it = fm_locate_it(x, hit_loc[i]);
+    const uint32_t g = x.ssa[it.x / x.sa_int] + it.y;
+    hit_loc[i] = (dir ? rf.length - 1u - g : g) - pir;
+}
+
+__global__ void __launch_bounds__(256)
+score_best_setup_kernel(uint32_t n, const uint32_t* __restrict__ hit_read_id, const uint32_t* __restrict__ hit_loc, const uint32_t* __restrict__ hit_seed,
+                        const uint64_t* __restrict__ read_begin, const uint32_t* __restrict__ read_len, uint32_t fixed_len, uint64_t rc_offset,
+                        uint32_t band_len, uint32_t genome_len, const uint2* __restrict__ best, uint32_t best_stride, int32_t score_limit,
+                        uint64_t* __restrict__ pat_begin, uint32_t* __restrict__ pat_len,
+                        uint64_t* __restrict__ text_begin, uint32_t* __restrict__ text_len, int32_t* __restrict__ min_score)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = hit_read_id[i], g = hit_loc[i];
+    const uint32_t len = read_len ? read_len[r] : fixed_len;
+    const uint32_t gb = g > band_len / 2u ? g - band_len / 2u : 0u;
+    const uint32_t sum = gb + band_len + len;
+    const uint32_t ge = sum < genome_len ? sum : genome_len;
+    text_begin[i] = gb;
+    text_len[i] = ge > gb ? ge - gb : 0u;                                        // (a wrapped read start: empty window, the alignment fails)
+    pat_begin[i] = (read_begin ? read_begin[r] : uint64_t(r) * fixed_len) + (((hit_seed[i] >> 13) & 1u) ? rc_offset : 0ull);
+    if (pat_len) pat_len[i] = len;
+    const uint32_t w2 = best[r + best_stride].x;
+    const int32_t m2 = int32_t((w2 >> 1) & 0x1FFFFu), s2 = (w2 & 1u) ? -m2 : m2;
+    min_score[i] = s2 > score_limit ? s2 : score_limit;
+}
+
+// one lane per program of deque operations (0 push with the mappers' "full: pop_bottom first" rule, 1 pop_top,
+// 2 pop_bottom), the deque's array written out after every operation: lets a test replay the programs recorded
+// from the reference's heap (tests/golden/hit_deque_vectors.npz) through the device implementation
+__global__ void __launch_bounds__(64)
+hit_deque_replay_kernel(uint32_t n_cases, const uint32_t* __restrict__ case_start, const uint8_t* __restrict__ ops, const uint64_t* __restrict__ vals,
+                        const uint32_t* __restrict__ caps, const uint64_t* __restrict__ state_start, uint2* __restrict__ scratch, uint32_t scratch_stride,
+                        uint64_t* __restrict__ out_states)
+{
+    const uint32_t c = blockIdx.x * 64u + threadIdx.x;
+    if (c >= n_cases) return;
+    const HitDeque d = { scratch + uint64_t(c) * scratch_stride };
+    int n = 0;
+    uint64_t o = state_start[c];
+    for (uint32_t i = case_start[c]; i < case_start[c + 1u]; ++i)
+    {
+        if (ops[i] == 0u) {
+            if (uint32_t(n) == caps[i]) { d.pop_bottom(n); --n; }
+            d.a[n++] = make_uint2(uint32_t(vals[i]), uint32_t(vals[i] >> 32));
+            d.push(n);
+        }
+        else if (ops[i] == 1u) { d.pop_top(n); --n; }
+        else { d.pop_bottom(n); --n; }
+        for (int k = 0; k < n; ++k) out_states[o++] = (uint64_t(d.a[k].y) << 32) | d.a[k].x;
+    }
+}
+
+static inline dim3 grid_for(uint64_t n) { return dim3(uint32_t((n + 255u) / 256u)); }
+static inline uint64_t align256(uint64_t x) { return (x + 255ull) & ~255ull; }
+static size_t select_scan_bytes(uint32_t n)
+{
+    size_t scan = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan, (const uint64_t*)nullptr, (uint64_t*)nullptr, int(n) + 1);    // size query only
+    return scan;
+}
+
+} // namespace nvb
+
+using namespace nvb;
+
+NVB_API uint32_t nvbio_hip_sum_tree_node_count(uint32_t size)
+{
+    uint32_t l = 0; for (uint32_t n = size; n > 1u; n >>= 1) ++l;
+    const uint32_t padded = (1u << l) < size ? 1u << (l + 1u) : 1u << l;
+    return padded * 2u - 1u;
+}
+
+NVB_API int nvbio_hip_select_init(uint32_t n_reads, const char* read_names, const uint32_t* read_names_idx,
+                                  const uint64_t* hits, uint32_t hits_stride, const uint32_t* hit_counts,
+                                  float* probs, uint32_t probs_stride, uint32_t* trys, uint32_t* rseeds,
+                                  uint32_t max_effort_init, int32_t randomized, int32_t top_seed, void* stream)
+{
+    if (n_reads == 0) return hipSuccess;
+    if (randomized) {
+        if (!hits || !hit_counts || !probs || !rseeds || hits_stride == 0) return hipErrorInvalidValue;
+        if (probs_stride < nvbio_hip_sum_tree_node_count(hits_stride)) return hipErrorInvalidValue;
+        if (read_names && !read_names_idx) return hipErrorInvalidValue;
+    }
+    g_last_kernel = "select_init_kernel";
+    hipLaunchKernelGGL(select_init_kernel, grid_for(n_reads), dim3(256), 0, to_stream(stream), n_reads, read_names, read_names_idx,
+                       reinterpret_cast<const uint2*>(hits), hits_stride, hit_counts, probs, probs_stride, trys, rseeds, max_effort_init,
+                       int(randomized), int(top_seed));
+    return hipGetLastError();
+}
+
+NVB_API uint64_t nvbio_hip_select_temp_bytes(uint32_t n_active, uint32_t n_multi)
+{
+    const uint64_t n = n_active, m = n_multi ? n_multi : 1u;
+    return 2u * align256(n * m * 4u) + align256(n * 4u) + 2u * align256((n + 1u) * 8u) + align256(select_scan_bytes(n_active)) + 256u;
+}
+
+NVB_API int nvbio_hip_select(int32_t randomized, uint32_t n_multi, const uint32_t* active_in, uint32_t n_active,
+                             uint64_t* hits, uint32_t hits_stride, uint32_t* hit_counts,
+                             float* probs, uint32_t probs_stride, uint32_t* rseeds, const uint32_t* trys,
+                             uint32_t* active_out, uint64_t* hit_begin, uint32_t* hit_read_id, uint32_t* hit_loc, uint32_t* hit_seed,
+                             uint32_t* out_sizes, void* temp, uint64_t temp_bytes, void* stream)
+{
+    if (!out_sizes || !hit_begin) return hipErrorInvalidValue;
+    if (n_multi == 0 || n_multi > 4096u) return hipErrorInvalidValue;          // the reference encodes the per-read hit index in 12 bits
+    if (n_active != 0 && (!active_in || !hits || !hit_counts || !trys || !active_out || !hit_read_id || !hit_loc || !hit_seed || hits_stride == 0))
+        return hipErrorInvalidValue;
+    if (randomized && n_active != 0 && (!probs || !rseeds || probs_stride < nvbio_hip_sum_tree_node_count(hits_stride))) return hipErrorInvalidValue;
+    if (!temp || temp_bytes < nvbio_hip_select_temp_bytes(n_active, n_multi)) return hipErrorInvalidValue;
+    const uint64_t n = n_active;
+    uint8_t* p = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(temp) + 255u) & ~uintptr_t(255));
+    uint32_t* stage_loc  = reinterpret_cast<uint32_t*>(p); p += align256(n * n_multi * 4u);
+    uint32_t* stage_seed = reinterpret_cast<uint32_t*>(p); p += align256(n * n_multi * 4u);
+    uint32_t* stage_read = reinterpret_cast<uint32_t*>(p); p += align256(n * 4u);
+    uint64_t* key        = reinterpret_cast<uint64_t*>(p); p += align256((n + 1u) * 8u);
+    uint64_t* off        = reinterpret_cast<uint64_t*>(p); p += align256((n + 1u) * 8u);
+    size_t scan_bytes = select_scan_bytes(n_active);
+    hipStream_t s = to_stream(stream);
+    g_last_kernel = randomized ? "select_kernel<rand>" : "select_kernel";
+    if (randomized)
+        hipLaunchKernelGGL(select_kernel<true>, grid_for(n + 1u), dim3(256), 0, s, n_multi, active_in, n_active, reinterpret_cast<uint2*>(hits), hits_stride,
+                           hit_counts, probs, probs_stride, rseeds, trys, stage_read, stage_loc, stage_seed, key);
+    else
+        hipLaunchKernelGGL(select_kernel<false>, grid_for(n + 1u), dim3(256), 0, s, n_multi, active_in, n_active, reinterpret_cast<uint2*>(hits), hits_stride,
+                           hit_counts, probs, probs_stride, rseeds, trys, stage_read, stage_loc, stage_seed, key);
+    if (hipError_t e = hipcub::DeviceScan::ExclusiveSum(p, scan_bytes, key, off, int(n_active) + 1, s)) return e;
+    hipLaunchKernelGGL(select_compact_kernel, grid_for(n + 1u), dim3(256), 0, s, n_multi, n_active, key, off, stage_read, stage_loc, stage_seed,
+                       active_out, hit_begin, hit_read_id, hit_loc, hit_seed, out_sizes);
+    return hipGetLastError();
+}
+
+NVB_API int nvbio_hip_locate_hits(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmindex* rfmi, uint32_t n,
+                                  uint32_t* hit_loc, const uint32_t* hit_seed, void* stream)
+{
+    if (!fmi || !fmi->bwt_occ || !fmi->ssa) return hipErrorInvalidValue;
+    if (fmi->sa_int == 0 || (fmi->sa_int & (fmi->sa_int - 1)) != 0) return hipErrorInvalidValue;
+    if (rfmi && (!rfmi->bwt_occ || !rfmi->ssa || rfmi->sa_int == 0 || (rfmi->sa_int & (rfmi->sa_int - 1)) != 0)) return hipErrorInvalidValue;
+    if (n == 0) return hipSuccess;
+    if (!hit_loc || !hit_seed) return hipErrorInvalidValue;
+    g_last_kernel = "locate_hits_kernel";
+    hipLaunchKernelGGL(locate_hits_kernel, grid_for(n), dim3(256), 0, to_stream(stream), make_fmi(fmi), make_fmi(rfmi ? rfmi : fmi), n, hit_loc, hit_seed);
+    return hipGetLastError();
+}
+
+NVB_API int nvbio_hip_score_best_setup(uint32_t n_hits, const uint32_t* hit_read_id, const uint32_t* hit_loc, const uint32_t* hit_seed,
+                                       const uint64_t* read_begin, const uint32_t* read_len, uint32_t fixed_read_len, uint64_t rc_offset,
+                                       uint32_t band_len, uint32_t genome_length, const uint64_t* best_alignments, uint32_t best_stride,
+                                       int32_t score_limit, uint64_t* pattern_begin, uint32_t* pattern_len,
+                                       uint64_t* text_begin, uint32_t* text_len, int32_t* min_score, void* stream)
+{
+    if (n_hits == 0) return hipSuccess;
+    if (!hit_read_id || !hit_loc || !hit_seed || !best_alignments || best_stride == 0 || !pattern_begin || !text_begin || !text_len || !min_score)
+        return hipErrorInvalidValue;
+    if (!read_len && fixed_read_len == 0) return hipErrorInvalidValue;
+    if (read_len && !pattern_len) return hipErrorInvalidValue;
+    g_last_kernel = "score_best_setup_kernel";
+    hipLaunchKernelGGL(score_best_setup_kernel, grid_for(n_hits), dim3(256), 0, to_stream(stream), n_hits, hit_read_id, hit_loc, hit_seed,
+                       read_begin, read_len, fixed_read_len, rc_offset, band_len, genome_length, reinterpret_cast<const uint2*>(best_alignments),
+                       best_stride, score_limit, pattern_begin, pattern_len, text_begin, text_len, min_score);
+    return hipGetLastError();
+}
+
+NVB_API int nvbio_hip_hit_deque_replay(uint32_t n_cases, const uint32_t* case_start, const uint8_t* ops, const uint64_t* vals, const uint32_t* caps,
+                                       const uint64_t* state_start, uint64_t* scratch, uint32_t scratch_stride, uint64_t* out_states, void* stream)
+{
+    if (n_cases == 0) return hipSuccess;
+    if (!case_start || !ops || !vals || !caps || !state_start || !scratch || !out_states || scratch_stride == 0) return hipErrorInvalidValue;
+    g_last_kernel = "hit_deque_replay_kernel";
+    hipLaunchKernelGGL(hit_deque_replay_kernel, dim3((n_cases + 63u) / 64u), dim3(64), 0, to_stream(stream), n_cases, case_start, ops, vals, caps,
+                       state_start, reinterpret_cast<uint2*>(scratch), scratch_stride, out_states);
+    return hipGetLastError();
+}

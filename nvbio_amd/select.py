@@ -1,0 +1,106 @@
+"""nvBowtie's hit-selection stage and the per-round stages of its best-approx extension loop, over the C-ABI
+(nvBowtie/bowtie2/cuda/select.h, select_inl.h, locate_inl.h, score_best_inl.h, reduce.h).
+
+The hit arena returned by `mapping.map_exact` / `map_seeds` is the reference's SeedHitDequeArray content (a read's
+hits in the array order of its priority deque); `SelectState` adds what `select_init` sets up next to it."""
+import ctypes as C
+
+import torch
+
+from ._lib import lib, check, current_stream_ptr
+
+
+def _vp(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def sum_tree_node_count(size):
+    return int(lib().nvbio_hip_sum_tree_node_count(int(size)))
+
+
+def pack_names(names, device):
+    """NUL-terminated names -> (uint8 arena, int32 index[n+1]) as SequenceData keeps them (name_stream / name_index)."""
+    blob = b"".join(nm.encode() + b"\0" for nm in names)
+    idx = [0]
+    for nm in names:
+        idx.append(idx[-1] + len(nm) + 1)
+    return (torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device),
+            torch.tensor(idx, dtype=torch.int64).to(torch.int32).to(device))
+
+
+class SelectState:
+    """trys / rseeds / probability trees of every read of a batch (BestApproxScoringPipelineState's trys, rseeds
+    and the SeedHitDequeArray's m_probs)."""
+
+    def __init__(self, hits, counts, names=None, max_effort_init=15, randomized=True, top_seed=0, rseeds=None):
+        n, stride = hits.shape
+        dev = hits.device
+        self.hits, self.counts = hits, counts
+        self.randomized = bool(randomized)
+        self.probs_stride = sum_tree_node_count(stride)
+        self.probs = torch.zeros((n, self.probs_stride), dtype=torch.float32, device=dev) if randomized else None
+        self.trys = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.rseeds = (rseeds.clone() if rseeds is not None else torch.zeros(n, dtype=torch.int32, device=dev))
+        arena, idx = names if names is not None else (None, None)
+        check(lib().nvbio_hip_select_init(n, _vp(arena), _vp(idx), _vp(hits), stride, _vp(counts), _vp(self.probs), self.probs_stride,
+                                          _vp(self.trys), _vp(self.rseeds), int(max_effort_init), int(self.randomized), int(top_seed),
+                                          current_stream_ptr()), "nvbio_hip_select_init")
+
+
+def select(state, active_in, n_multi=1):
+    """One selection round.  active_in: int32 packed_read words.  Returns (active_out, hit_begin int64[n_out+1],
+    hit_read_id, hit_loc (SA rows), hit_seed (packed_seed words)), trimmed to their sizes (one host sync, as in the
+    reference, which reads the queue sizes back at this point: aligner_best_approx.h:678-692)."""
+    n = active_in.numel()
+    dev = active_in.device
+    active_out = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    hit_begin = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    cap = max(n * n_multi, 1)
+    rid = torch.empty(cap, dtype=torch.int32, device=dev)
+    loc = torch.empty(cap, dtype=torch.int32, device=dev)
+    seed = torch.empty(cap, dtype=torch.int32, device=dev)
+    sizes = torch.zeros(2, dtype=torch.int32, device=dev)
+    tb = int(lib().nvbio_hip_select_temp_bytes(n, n_multi))
+    temp = torch.empty(tb, dtype=torch.uint8, device=dev)
+    check(lib().nvbio_hip_select(int(state.randomized), int(n_multi), _vp(active_in), n, _vp(state.hits), state.hits.shape[1], _vp(state.counts),
+                                 _vp(state.probs), state.probs_stride, _vp(state.rseeds), _vp(state.trys),
+                                 _vp(active_out), _vp(hit_begin), _vp(rid), _vp(loc), _vp(seed), _vp(sizes), _vp(temp), tb,
+                                 current_stream_ptr()), "nvbio_hip_select")
+    n_out, n_hits = (int(v) for v in sizes.tolist())
+    return active_out[:n_out], hit_begin[:n_out + 1], rid[:n_hits], loc[:n_hits], seed[:n_hits]
+
+
+def locate_hits(fmi, rfmi, hit_loc, hit_seed):
+    """In place: SA rows -> read-start genome coordinates (locate_kernel)."""
+    s = fmi.struct()
+    r = rfmi.struct() if rfmi is not None else None
+    check(lib().nvbio_hip_locate_hits(C.byref(s), C.byref(r) if r is not None else None, hit_loc.numel(), _vp(hit_loc), _vp(hit_seed),
+                                      current_stream_ptr()), "nvbio_hip_locate_hits")
+    return hit_loc
+
+
+def score_best_setup(hit_read_id, hit_loc, hit_seed, best, band_len, genome_len, score_limit, fixed_read_len=0, read_begin=None,
+                     read_len=None, rc_offset=0):
+    """Per hit: (pattern_begin int64, pattern_len int32 | None, text_begin int64, text_len int32, min_score int32)."""
+    n = hit_read_id.numel()
+    dev = hit_read_id.device
+    pb = torch.empty(n, dtype=torch.int64, device=dev)
+    pl = torch.empty(n, dtype=torch.int32, device=dev) if read_len is not None else None
+    tb = torch.empty(n, dtype=torch.int64, device=dev)
+    tl = torch.empty(n, dtype=torch.int32, device=dev)
+    ms = torch.empty(n, dtype=torch.int32, device=dev)
+    data = best.data if hasattr(best, "data") else best
+    check(lib().nvbio_hip_score_best_setup(n, _vp(hit_read_id), _vp(hit_loc), _vp(hit_seed), _vp(read_begin), _vp(read_len), int(fixed_read_len),
+                                           int(rc_offset), int(band_len), int(genome_len), _vp(data), data.shape[1], int(score_limit),
+                                           _vp(pb), _vp(pl), _vp(tb), _vp(tl), _vp(ms), current_stream_ptr()), "nvbio_hip_score_best_setup")
+    return pb, pl, tb, tl, ms
+
+
+def score_reduce_best_approx(best, state, active, hit_begin, hit_score, hit_loc, hit_seed, worst_score, n_ext, min_ext, max_ext, max_effort,
+                             fixed_read_len=0, read_len=None):
+    data = best.data if hasattr(best, "data") else best
+    check(lib().nvbio_hip_score_reduce_best_approx(active.numel(), _vp(active), _vp(hit_begin), _vp(hit_score), _vp(hit_loc), _vp(hit_seed),
+                                                   _vp(read_len), int(fixed_read_len), _vp(data), data.shape[1], int(worst_score),
+                                                   _vp(state.trys), _vp(state.counts), int(n_ext), int(min_ext), int(max_ext), int(max_effort),
+                                                   current_stream_ptr()), "nvbio_hip_score_reduce_best_approx")
+    return best

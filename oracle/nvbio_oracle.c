@@ -1551,6 +1551,88 @@ static inline uint64_t seed_hit_pack(uint32_t begin, uint32_t delta, uint32_t po
     return ((uint64_t)w1 << 32) | begin;
 }
 
+/* ------------------------------------------------------------------------ */
+/* The seed-hit deque: priority_deque<SeedHit, vector_view, hit_compare>       */
+/*   nvbio/basic/priority_deque.h:329-421 over the interval heap of            */
+/*   nvbio/basic/interval_heap.h:195-260,389-533 (N. McClatchey's, Boost SL),  */
+/*   hit_compare nvBowtie/bowtie2/cuda/seed_hit.h:235-244 (larger range first) */
+/* Even slots hold interval lower bounds, odd slots upper bounds; slot 0 is a  */
+/* hit of LARGEST range (pop_bottom drops it), slot 1 (slot 0 when alone) one   */
+/* of SMALLEST range (top()).  The array order decides which of several         */
+/* equal-sized hits the selection stage meets first, so every swap is the       */
+/* reference's.  Pinned against the reference header itself (oracle/_ref).      */
+/* ------------------------------------------------------------------------ */
+static inline int hit_before(uint64_t f, uint64_t s) { return ((f >> 32) & 0xFFFFFu) > ((s >> 32) & 0xFFFFFu); }
+static inline void hit_swap(uint64_t* a, long i, long j) { const uint64_t t = a[i]; a[i] = a[j]; a[j] = t; }
+
+/* interval_heap.h:389-409 */
+static void ih_sift_up(uint64_t* a, long i, int lower, long limit)
+{
+    while (i >= limit) {
+        const long parent = ((i / 2 - 1) | 1) ^ (lower ? 1 : 0);
+        if (!(lower ? hit_before(a[i], a[parent]) : hit_before(a[parent], a[i]))) break;
+        hit_swap(a, i, parent);
+        i = parent;
+    }
+}
+/* :412-429 */
+static void ih_leaf_upper(uint64_t* a, long n, long i, long limit)
+{
+    const long co = (i * 2 < n) ? i * 2 : (i ^ 1);
+    if (hit_before(a[i], a[co])) { hit_swap(a, i, co); ih_sift_up(a, co, 1, limit); }
+    else ih_sift_up(a, i, 0, limit);
+}
+/* :432-455 */
+static void ih_leaf_lower(uint64_t* a, long n, long i, long limit)
+{
+    long co = i | 1;
+    if (co >= n) { if (co == 1) return; co = (co / 2 - 1) | 1; }
+    if (hit_before(a[co], a[i])) { hit_swap(a, i, co); ih_sift_up(a, co, 0, limit); }
+    else ih_sift_up(a, i, 1, limit);
+}
+/* :458-517 */
+static void ih_sift_down(uint64_t* a, long n, long i, int lower, long limit)
+{
+    const long end_parent = n / 2 - ((lower && (n & 3) == 0) ? 2 : 1);
+    while (i < end_parent) {
+        long child = i * 2 + (lower ? 2 : 1);
+        if (lower ? hit_before(a[child + 2], a[child]) : hit_before(a[child], a[child + 2])) child += 2;
+        hit_swap(a, i, child);
+        i = child;
+    }
+    if (i <= end_parent + (lower ? 0 : 1)) {
+        long child = i * 2 + (lower ? 2 : 1);
+        if (child < n) {
+            if (!lower && child + 1 < n && hit_before(a[child], a[child + 1])) {
+                ++child;
+                hit_swap(a, i, child);
+                ih_leaf_lower(a, n, child, limit);
+                return;
+            }
+            hit_swap(a, i, child);
+            i = child;
+        }
+    }
+    if (lower) ih_leaf_lower(a, n, i, limit); else ih_leaf_upper(a, n, i, limit);
+}
+/* push (priority_deque.h:354-357): a[n-1] is the new element */
+static void ih_push(uint64_t* a, long n)
+{
+    if ((n - 1) & 1) ih_leaf_upper(a, n, n - 1, 2); else ih_leaf_lower(a, n, n - 1, 2);
+}
+/* pop_bottom (:397-402): afterwards the heap is a[0..n-1) */
+static void ih_pop_bottom(uint64_t* a, long n) { hit_swap(a, 0, n - 1); ih_sift_down(a, n - 1, 0, 1, 2); }
+/* pop_top (:412-417) */
+static void ih_pop_top(uint64_t* a, long n)
+{
+    if (n <= 2) return;
+    hit_swap(a, 1, n - 1);
+    ih_sift_down(a, n - 1, 1, 0, 2);
+}
+ORACLE_API void oracle_hit_deque_push(uint64_t* a, uint32_t n)       { ih_push(a, n); }
+ORACLE_API void oracle_hit_deque_pop_bottom(uint64_t* a, uint32_t n) { ih_pop_bottom(a, n); }
+ORACLE_API void oracle_hit_deque_pop_top(uint64_t* a, uint32_t n)    { ih_pop_top(a, n); }
+
 /* match_range over a transformed seed: symbol t of the scan = comp(seed[reverse ? len-1-t : t]) */
 static void match_range_x(const oracle_fmi_t* f, const uint32_t* w, uint32_t bits, uint32_t be, uint64_t begin, uint32_t len,
                           int reverse, int complement, uint32_t* ox, uint32_t* oy)
@@ -1568,8 +1650,8 @@ static void match_range_x(const oracle_fmi_t* f, const uint32_t* w, uint32_t bit
     *ox = rx; *oy = ry;
 }
 
-/* one read -> its seed hits, in generation order; when a hit arrives with max_hits already held,
- * one hit of largest range size is dropped first (priority_deque::pop_bottom with hit_compare).
+/* one read -> its seed hits, laid out as the reference's hit deque (interval heap, see above); when a hit
+ * arrives with max_hits already held, the deque's bottom (a hit of largest range size) is dropped first.
  * Returns the number of hits kept; *reseed as map_queues_kernel computes it. */
 ORACLE_API void oracle_map_exact(const oracle_fmi_t* f,
     const uint32_t* w, uint32_t bits, uint32_t be, const uint64_t* read_begin, const uint32_t* read_len,
@@ -1599,13 +1681,9 @@ ORACLE_API void oracle_map_exact(const oracle_fmi_t* f,
                 match_range_x(f, w, bits, be, pos, seed_len, strand, strand, &x, &y);
                 if (x > y) continue;
                 const uint32_t pir = strand == 0 ? (uint32_t)(rx + rlen - pos - seed_len) : (uint32_t)(pos - rx);
-                if (nh == p->max_hits || nh == hits_stride) {            /* pop_bottom: drop a largest range */
-                    uint32_t worst = 0;
-                    for (uint32_t h = 1; h < nh; ++h)
-                        if (((hits[h] >> 32) & 0xFFFFFu) > ((hits[worst] >> 32) & 0xFFFFFu)) worst = h;
-                    hits[worst] = hits[--nh];
-                }
+                if (nh == p->max_hits || nh == hits_stride) { ih_pop_bottom(hits, nh); --nh; }     /* :268-270 */
                 hits[nh++] = seed_hit_pack(x, y + 1u - x, pir, strand, 0);
+                ih_push(hits, nh);
                 range_sum += y - x + 1u; range_count++;
             }
         }
@@ -1648,13 +1726,9 @@ typedef struct { uint64_t* hits; uint32_t nh, cap, range_sum, range_count; } hit
 
 static void heap_push(hit_heap_t* h, uint32_t x, uint32_t y /* inclusive */, uint32_t pos, uint32_t rc, uint32_t indexdir)
 {
-    if (h->nh == h->cap) {                                   /* pop_bottom: drop a largest range */
-        uint32_t worst = 0;
-        for (uint32_t k = 1; k < h->nh; ++k)
-            if (((h->hits[k] >> 32) & 0xFFFFFu) > ((h->hits[worst] >> 32) & 0xFFFFFu)) worst = k;
-        h->hits[worst] = h->hits[--h->nh];
-    }
+    if (h->nh == h->cap) { ih_pop_bottom(h->hits, h->nh); --h->nh; }
     h->hits[h->nh++] = seed_hit_pack(x, y + 1u - x, pos, rc, indexdir);
+    ih_push(h->hits, h->nh);
     h->range_sum += y - x + 1u; h->range_count++;
 }
 
@@ -1796,6 +1870,264 @@ ORACLE_API void oracle_score_reduce(uint32_t n_active, const uint32_t* read_ids 
             if ((rc == io_aln_rc(a1) && g_pos == a1.align) || (rc == io_aln_rc(a2) && g_pos == a2.align)) continue;
             if (score > io_aln_score(a1)) { a2 = a1; a1 = io_aln_make(g_pos, 0u, score, rc); }
             else if (score > io_aln_score(a2) && distinct_alignments(a1.align, io_aln_rc(a1), g_pos, rc, len / 2)) a2 = io_aln_make(g_pos, 0u, score, rc);
+        }
+        best[read_id] = ((uint64_t)a1.align << 32) | a1.w;
+        best[read_id + best_stride] = ((uint64_t)a2.align << 32) | a2.w;
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* nvBowtie hit selection and the best-approx extension loop's per-round stages */
+/*   select_init_kernel            nvBowtie/bowtie2/cuda/select.cu:36-103        */
+/*   select_kernel / rand_select_kernel / select_multi_kernel /                 */
+/*   rand_select_multi_kernel, randomized_select   select_inl.h:74-607          */
+/*   SumTree<float*>, sample()     nvbio/basic/sum_tree_inl.h:38-178             */
+/*   SeedHit::pop_front / empty    seed_hit.h:136-149                            */
+/*   packed_read / packed_seed     defs.h:152-181                                */
+/*   locate (index direction)      locate_inl.h:53-143                           */
+/*   BestScoreStream               score_best_inl.h:54-148                       */
+/*   ReduceBestApproxContext       reduce.h:63-105 ; score_reduce_kernel         */
+/*                                 reduce_inl.h:71-160                           */
+/* Layout here: a read's deque lives at hits[read_id * hits_stride], its size in */
+/* counts[read_id], its probability tree at probs[read_id * probs_stride].       */
+/* Active reads are packed_read words (read_id:31, top_flag:1); a selected hit   */
+/* carries {read_id, loc (SA row), seed = packed_seed word (pos_in_read:12,      */
+/* index_dir:1, rc:1, top_flag:1)}.  The reference allocates output slots with   */
+/* atomics (run-dependent order); here outputs follow the input queue's order.   */
+/* Single precision, every operation rounded on its own (host arithmetic).       */
+/* ------------------------------------------------------------------------ */
+static inline uint32_t ilog2_u32(uint32_t n)       /* nvbio::log2, numbers.h:516-524 */
+{
+    uint32_t c = 0;
+    if (n & 0xffff0000u) { n >>= 16; c |= 16; }
+    if (n & 0xff00) { n >>= 8; c |= 8; }
+    if (n & 0xf0) { n >>= 4; c |= 4; }
+    if (n & 0xc) { n >>= 2; c |= 2; }
+    if (n & 0x2) c |= 1;
+    return c;
+}
+static inline uint32_t st_padded(uint32_t size) { const uint32_t l = ilog2_u32(size); return (1u << l) < size ? 1u << (l + 1u) : 1u << l; }
+ORACLE_API uint32_t oracle_sum_tree_node_count(uint32_t size) { return st_padded(size) * 2u - 1u; }
+static void st_setup(float* c, uint32_t size, uint32_t padded)
+{
+    for (uint32_t i = size; i < padded; ++i) c[i] = 0.0f;
+    uint32_t src = 0;
+    for (uint32_t n = padded; n >= 2; n >>= 1) {
+        const uint32_t dst = src + n, m = n >> 1;
+        for (uint32_t i = 0; i < m; ++i) c[dst + i] = c[src + i * 2] + c[src + i * 2 + 1u];
+        src += n;
+    }
+}
+static void st_set(float* c, uint32_t padded, uint32_t i, float v)
+{
+    c[i] = v;
+    uint32_t prev = 0u, base = padded, parent = i >> 1;
+    for (uint32_t m = padded >> 1; base + parent < padded * 2u - 1u; m >>= 1) {
+        c[base + parent] = c[prev + parent * 2] + c[prev + parent * 2 + 1];
+        prev = base; base += m; parent >>= 1;
+    }
+}
+static inline float st_sum(const float* c, uint32_t padded) { return c[padded * 2u - 2u]; }
+static inline float fmin1(float a) { return a < 1.0f ? a : 1.0f; }          /* nvbio::min(a, 1.0f) */
+static uint32_t st_sample(const float* c, uint32_t size, uint32_t padded, float value)
+{
+    uint32_t base = padded * 2u - 4u, node = 0;
+    float v = value;
+    for (uint32_t m = 2; m < padded; m *= 2) {
+        const float l = c[base + node], r = c[base + node + 1u];
+        const float sum = l + r;
+        if (sum == 0.0f) node *= 2;
+        else {
+            const float vs = v * sum;
+            if (vs < l || r == 0.0f) { node = node * 2u; v = fmin1(vs / l); }
+            else { node = (node + 1u) * 2u; const float d = vs - l; v = fmin1(d / r); }
+        }
+        base -= m * 2;
+    }
+    {
+        const float l = node < size ? c[node] : 0.0f, r = node + 1u < size ? c[node + 1u] : 0.0f;
+        const float sum = l + r;
+        const float vs = v * sum;
+        node = (vs < l || r == 0.0f) ? node : node + 1u;
+    }
+    return node < size ? node : size - 1u;
+}
+/* exposed so the tree can be exercised on its own */
+ORACLE_API void oracle_sum_tree_setup(float* c, uint32_t size) { st_setup(c, size, st_padded(size)); }
+ORACLE_API void oracle_sum_tree_set(float* c, uint32_t size, uint32_t i, float v) { st_set(c, st_padded(size), i, v); }
+ORACLE_API uint32_t oracle_sum_tree_sample(const float* c, uint32_t size, float v) { return st_sample(c, size, st_padded(size), v); }
+
+static inline uint32_t hit_delta(uint64_t h) { return (uint32_t)(h >> 32) & 0xFFFFFu; }
+static inline uint32_t hit_pop_front(uint64_t* h)      /* SeedHit::pop_front: ++range_begin, --range_delta (20-bit field) */
+{
+    const uint32_t r = (uint32_t)*h;
+    const uint32_t hi = (uint32_t)(*h >> 32);
+    const uint32_t nhi = (hi & ~0xFFFFFu) | ((hi - 1u) & 0xFFFFFu);
+    *h = ((uint64_t)nhi << 32) | (uint32_t)(r + 1u);
+    return r;
+}
+static inline uint32_t packed_seed_of(uint64_t h, uint32_t top_flag)
+{
+    const uint32_t hi = (uint32_t)(h >> 32);
+    return ((hi >> 20) & 0x3FFu) | (((hi >> 31) & 1u) << 12) | (((hi >> 30) & 1u) << 13) | ((top_flag & 1u) << 14);
+}
+
+ORACLE_API void oracle_select_init(uint32_t n_reads, const char* names /* nullable */, const uint32_t* names_idx,
+    const uint64_t* hits, uint32_t hits_stride, const uint32_t* counts, float* probs, uint32_t probs_stride,
+    uint32_t* trys /* nullable */, uint32_t* rseeds, uint32_t max_effort_init, int randomized, int top_seed)
+{
+    for (uint32_t r = 0; r < n_reads; ++r)
+    {
+        if (trys) trys[r] = max_effort_init;
+        if (!randomized) continue;
+        if (names) {                                   /* djb2 (xor form) of the read name, select.cu:64-76 */
+            const uint32_t off = names_idx[r], len = names_idx[r + 1] - off;
+            uint32_t hash = 5381;
+            for (uint32_t i = 0; i < len && names[off + i]; ++i) hash = ((hash << 5) + hash) ^ (uint32_t)(int32_t)names[off + i];
+            rseeds[r] = hash;
+        }
+        const uint32_t n = counts[r];
+        if (n == 0) continue;
+        float* pr = probs + (uint64_t)r * probs_stride;
+        const uint64_t* h = hits + (uint64_t)r * hits_stride;
+        for (uint32_t i = 0; i < n; ++i) { const float d = (float)hit_delta(h[i]); pr[i] = 1.0f / (d * d); }
+        if (top_seed) pr[0] = 0.0f;
+        st_setup(pr, n, st_padded(n));
+    }
+}
+
+static uint32_t randomized_select(const float* pr, uint32_t n, uint32_t padded, const uint64_t* h, uint32_t* rseed)
+{
+    for (uint32_t i = 0; i < 10; ++i) {
+        const uint32_t ri = 1664525u * *rseed + 1013904223u;
+        *rseed = ri;
+        const float rf = (float)ri / (float)0xFFFFFFFFu;
+        const uint32_t id = st_sample(pr, n, padded, rf);
+        if (hit_delta(h[id]) != 0) return id;
+    }
+    return 0;
+}
+
+/* one selection round.  out arrays sized for n_active reads / n_active * n_multi hits; out_sizes = {reads kept, hits}.
+ * NOTE erase() inside the reference's selection kernels is undone by ~SeedHitDequeReference (seed_hit_deque_array.h:
+ * 263-268 writes the size captured at construction back after hits.erase()), so a read's count survives; the read
+ * still leaves the active queue because nothing is emitted for it. */
+ORACLE_API void oracle_select(int randomized, uint32_t n_multi, const uint32_t* active_in, uint32_t n_active,
+    uint64_t* hits, uint32_t hits_stride, uint32_t* counts, float* probs, uint32_t probs_stride, uint32_t* rseeds, const uint32_t* trys,
+    uint32_t* active_out, uint64_t* hit_begin, uint32_t* hit_read_id, uint32_t* hit_loc, uint32_t* hit_seed, uint32_t* out_sizes)
+{
+    uint32_t n_out = 0; uint64_t n_hits = 0;
+    for (uint32_t t = 0; t < n_active; ++t)
+    {
+        const uint32_t read_id = active_in[t] & 0x7FFFFFFFu;
+        uint32_t top_flag = active_in[t] >> 31;
+        if (trys[read_id] == 0) continue;                                      /* SelectBestApproxContext::stop */
+        uint32_t n = counts[read_id];
+        if (n == 0) continue;
+        uint64_t* h = hits + (uint64_t)read_id * hits_stride;
+        const uint64_t first = n_hits;
+        if (!randomized)
+        {
+            /* select_kernel (:74-137) and select_multi_kernel (:281-480): walk the deque from its top */
+            for (uint32_t i = 0; i < n_multi; ++i)
+            {
+                uint32_t top = (n == 1) ? 0u : 1u;
+                if (hit_delta(h[top]) == 0) {
+                    ih_pop_top(h, n); --n;
+                    if (n == 0) break;
+                    top = (n == 1) ? 0u : 1u;
+                    top_flag = 0u;
+                }
+                const uint32_t sa_pos = hit_pop_front(&h[top]);
+                hit_read_id[n_hits] = read_id; hit_loc[n_hits] = sa_pos; hit_seed[n_hits] = packed_seed_of(h[top], top_flag);
+                ++n_hits;
+            }
+            counts[read_id] = n;
+        }
+        else
+        {
+            /* rand_select_kernel (:176-264) and rand_select_multi_kernel (:496-607) */
+            float* pr = probs + (uint64_t)read_id * probs_stride;
+            const uint32_t padded = st_padded(n);
+            for (uint32_t i = 0; i < n_multi; ++i)
+            {
+                if (st_sum(pr, padded) <= 0.0f) break;
+                if (top_flag && hit_delta(h[0]) == 0) top_flag = 0;
+                const uint32_t id = top_flag ? 0u : randomized_select(pr, n, padded, h, &rseeds[read_id]);
+                if (hit_delta(h[id]) == 0) { if (n_multi > 1) continue; else break; }
+                const uint32_t sa_pos = hit_pop_front(&h[id]);
+                if (hit_delta(h[id]) == 0) st_set(pr, padded, id, 0.0f);
+                hit_read_id[n_hits] = read_id; hit_loc[n_hits] = sa_pos; hit_seed[n_hits] = packed_seed_of(h[id], top_flag);
+                ++n_hits;
+            }
+        }
+        if (n_hits > first) {
+            hit_begin[n_out] = first;
+            active_out[n_out] = read_id | (top_flag << 31);
+            ++n_out;
+        }
+    }
+    hit_begin[n_out] = n_hits;
+    out_sizes[0] = n_out; out_sizes[1] = (uint32_t)n_hits;
+}
+
+/* locate_kernel (locate_inl.h:122-143): SA row -> read start in genome coordinates (may wrap below zero) */
+ORACLE_API void oracle_locate_hits(const oracle_fmi_t* f, const oracle_fmi_t* rf, uint32_t n, uint32_t* hit_loc, const uint32_t* hit_seed)
+{
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t dir = (hit_seed[i] >> 12) & 1u, pir = hit_seed[i] & 0xFFFu;
+        const uint32_t g = dir ? rf->length - 1u - fm_locate(rf, hit_loc[i], NULL) : fm_locate(f, hit_loc[i], NULL);
+        hit_loc[i] = g - pir;
+    }
+}
+
+/* BestScoreStream::init_context (score_best_inl.h:95-126): the genome window and the score threshold of every hit.
+ * A window that starts at or beyond its end (a wrapped read start) is given length 0 -- the reference would take the
+ * wrapped difference as a length and read out of bounds. */
+ORACLE_API void oracle_score_best_setup(uint32_t n, const uint32_t* hit_read_id, const uint32_t* hit_loc,
+    const uint32_t* read_len, uint32_t band_len, uint32_t genome_len, const uint64_t* best, uint32_t best_stride, int32_t score_limit,
+    uint64_t* text_begin, uint32_t* text_len, int32_t* min_score)
+{
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t r = hit_read_id[i], g = hit_loc[i];
+        const uint32_t gb = g > band_len / 2 ? g - band_len / 2 : 0u;
+        const uint32_t sum = gb + band_len + read_len[r];                      /* uint32 arithmetic as in the reference */
+        const uint32_t ge = sum < genome_len ? sum : genome_len;
+        text_begin[i] = gb; text_len[i] = ge > gb ? ge - gb : 0u;
+        const io_aln_t a2 = { (uint32_t)best[r + best_stride], (uint32_t)(best[r + best_stride] >> 32) };
+        const int32_t s2 = io_aln_score(a2);
+        min_score[i] = s2 > score_limit ? s2 : score_limit;
+    }
+}
+
+/* score_reduce_kernel with ReduceBestApproxContext.  hit_score is the raw DP result: BestScoreStream::output clamps it to
+ * worst_score first (score_best_inl.h:139).  active = packed_read words. */
+ORACLE_API void oracle_score_reduce_best_approx(uint32_t n_active, const uint32_t* active, const uint64_t* hit_begin,
+    const int32_t* hit_score, const uint32_t* hit_loc, const uint32_t* hit_seed, const uint32_t* read_len,
+    uint64_t* best, uint32_t best_stride, int32_t worst_score,
+    uint32_t* trys, uint32_t* counts, uint32_t n_ext, uint32_t min_ext, uint32_t max_ext, uint32_t max_effort)
+{
+    for (uint32_t t = 0; t < n_active; ++t)
+    {
+        const uint32_t read_id = active[t] & 0x7FFFFFFFu;
+        io_aln_t a1 = { (uint32_t)best[read_id], (uint32_t)(best[read_id] >> 32) };
+        io_aln_t a2 = { (uint32_t)best[read_id + best_stride], (uint32_t)(best[read_id + best_stride] >> 32) };
+        const uint32_t len = read_len[read_id];
+        const uint64_t hb = hit_begin[t];
+        for (uint64_t i = hb; i < hit_begin[t + 1]; ++i)
+        {
+            const int32_t score = hit_score[i] > worst_score ? hit_score[i] : worst_score;
+            const uint32_t g_pos = hit_loc[i], rc = (hit_seed[i] >> 13) & 1u, top_flag = (hit_seed[i] >> 14) & 1u;
+            if ((rc == io_aln_rc(a1) && g_pos == a1.align) || (rc == io_aln_rc(a2) && g_pos == a2.align)) continue;
+            if (score > io_aln_score(a1)) { trys[read_id] = max_effort; a2 = a1; a1 = io_aln_make(g_pos, 0u, score, rc); }
+            else if (score > io_aln_score(a2) && distinct_alignments(a1.align, io_aln_rc(a1), g_pos, rc, len / 2)) {
+                trys[read_id] = max_effort; a2 = io_aln_make(g_pos, 0u, score, rc);
+            }
+            else if (trys[read_id] > 0) {                                       /* ReduceBestApproxContext::failure, reduce.h:90-100 */
+                const uint32_t idx = (uint32_t)(i - hb);
+                if (((n_ext + idx >= min_ext) && top_flag == 0 && --trys[read_id] == 0) || (n_ext + idx >= max_ext))
+                    counts[read_id] = 0;                                        /* hits.erase(read_id) */
+            }
         }
         best[read_id] = ((uint64_t)a1.align << 32) | a1.w;
         best[read_id + best_stride] = ((uint64_t)a2.align << 32) | a2.w;

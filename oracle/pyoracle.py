@@ -643,6 +643,93 @@ def score_reduce(best, hit_begin, hit_score, hit_loc, hit_rc, read_len, read_ids
     return best
 
 
+def hit_deque_ops(lib_handle=None):
+    """(push, pop_bottom, pop_top) over uint64 arrays: the restated interval heap of the hit deque."""
+    L = lib()
+    mk = lambda f: (lambda a, n: f(_p(a), C.c_uint32(n)))
+    return mk(L.oracle_hit_deque_push), mk(L.oracle_hit_deque_pop_bottom), mk(L.oracle_hit_deque_pop_top)
+
+
+def sum_tree_node_count(size):
+    lib().oracle_sum_tree_node_count.restype = C.c_uint32
+    return int(lib().oracle_sum_tree_node_count(C.c_uint32(size)))
+
+
+def sum_tree_setup(cells, size):
+    lib().oracle_sum_tree_setup(_p(cells), C.c_uint32(size))
+
+
+def sum_tree_set(cells, size, i, v):
+    lib().oracle_sum_tree_set(_p(cells), C.c_uint32(size), C.c_uint32(i), C.c_float(v))
+
+
+def sum_tree_sample(cells, size, v):
+    lib().oracle_sum_tree_sample.restype = C.c_uint32
+    return int(lib().oracle_sum_tree_sample(_p(cells), C.c_uint32(size), C.c_float(v)))
+
+
+def pack_names(names):
+    """(char arena uint8[], index uint32[n+1]) of NUL-terminated read names, as SequenceData keeps them."""
+    blob = b"".join(nm.encode() + b"\0" for nm in names)
+    idx = np.zeros(len(names) + 1, dtype=np.uint32)
+    idx[1:] = np.cumsum([len(nm) + 1 for nm in names])
+    return np.frombuffer(blob, dtype=np.uint8).copy(), idx
+
+
+def select_init(hits, counts, names, names_idx, max_effort_init, randomized=True, top_seed=0, rseeds=None):
+    """select_init_kernel: returns (probs float32[n, node_count(stride)], trys uint32[n], rseeds uint32[n])."""
+    n, stride = hits.shape
+    ps = sum_tree_node_count(stride)
+    probs = np.zeros((n, ps), dtype=np.float32)
+    trys = np.zeros(n, dtype=np.uint32)
+    rs = np.zeros(n, dtype=np.uint32) if rseeds is None else _u32(rseeds).copy()
+    lib().oracle_select_init(C.c_uint32(n), _p(names), _p(_u32(names_idx)) if names_idx is not None else None, _p(hits), C.c_uint32(stride),
+                             _p(_u32(counts)), _p(probs), C.c_uint32(ps), _p(trys), _p(rs), C.c_uint32(max_effort_init),
+                             C.c_int(int(randomized)), C.c_int(int(top_seed)))
+    return probs, trys, rs
+
+
+def select(randomized, n_multi, active_in, hits, counts, probs, rseeds, trys):
+    """One selection round (in place on hits / counts / probs / rseeds).  Returns (active_out, hit_begin uint64[n_out+1],
+    hit_read_id, hit_loc (SA rows), hit_seed (packed_seed words))."""
+    q = _u32(active_in); n = q.size
+    active_out = np.zeros(n, dtype=np.uint32)
+    hit_begin = np.zeros(n + 1, dtype=np.uint64)
+    cap = max(n * n_multi, 1)
+    rid = np.zeros(cap, dtype=np.uint32); loc = np.zeros(cap, dtype=np.uint32); seed = np.zeros(cap, dtype=np.uint32)
+    sizes = np.zeros(2, dtype=np.uint32)
+    lib().oracle_select(C.c_int(int(randomized)), C.c_uint32(n_multi), _p(q), C.c_uint32(n), _p(hits), C.c_uint32(hits.shape[1]), _p(counts),
+                        _p(probs), C.c_uint32(probs.shape[1]), _p(rseeds), _p(trys), _p(active_out), _p(hit_begin), _p(rid), _p(loc), _p(seed), _p(sizes))
+    no, nh = int(sizes[0]), int(sizes[1])
+    return active_out[:no].copy(), hit_begin[:no + 1].copy(), rid[:nh].copy(), loc[:nh].copy(), seed[:nh].copy()
+
+
+def locate_hits(fmi, rfmi, hit_loc, hit_seed):
+    """locate_kernel: SA rows -> read-start genome coordinates (in a copy)."""
+    loc = _u32(hit_loc).copy()
+    lib().oracle_locate_hits(fmi._ref(), rfmi._ref() if rfmi is not None else fmi._ref(), C.c_uint32(loc.size), _p(loc), _p(_u32(hit_seed)))
+    return loc
+
+
+def score_best_setup(hit_read_id, hit_loc, read_len, band_len, genome_len, best, score_limit):
+    n = _u32(hit_read_id).size
+    tb = np.zeros(n, dtype=np.uint64); tl = np.zeros(n, dtype=np.uint32); ms = np.zeros(n, dtype=np.int32)
+    lib().oracle_score_best_setup(C.c_uint32(n), _p(_u32(hit_read_id)), _p(_u32(hit_loc)), _p(_u32(read_len)), C.c_uint32(band_len),
+                                  C.c_uint32(genome_len), _p(best), C.c_uint32(best.shape[1]), C.c_int32(score_limit), _p(tb), _p(tl), _p(ms))
+    return tb, tl, ms
+
+
+def score_reduce_best_approx(best, active, hit_begin, hit_score, hit_loc, hit_seed, read_len, worst_score, trys, counts,
+                             n_ext, min_ext, max_ext, max_effort):
+    """score_reduce_kernel + ReduceBestApproxContext, in place on best / trys / counts."""
+    hb = _u64(hit_begin); n = hb.size - 1
+    lib().oracle_score_reduce_best_approx(C.c_uint32(n), _p(_u32(active)), _p(hb), _p(np.ascontiguousarray(hit_score, dtype=np.int32)),
+                                          _p(_u32(hit_loc)), _p(_u32(hit_seed)), _p(_u32(read_len)), _p(best), C.c_uint32(best.shape[1]),
+                                          C.c_int32(worst_score), _p(trys), _p(counts), C.c_uint32(n_ext), C.c_uint32(min_ext),
+                                          C.c_uint32(max_ext), C.c_uint32(max_effort))
+    return best
+
+
 def score_reduce_paired(best, best_o, hit_begin, hit_loc, hit_sink, hit_score, hit_rc, o_loc, o_sink, o_sink2, o_score, o_score2,
                         read_len, anchor, pe_policy, pe_unpaired, score_limit, read_ids=None):
     hb = _u64(hit_begin); n = hb.size - 1

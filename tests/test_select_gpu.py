@@ -1,0 +1,215 @@
+"""nvBowtie's hit-selection stage, the per-round stages of its best-approx loop and the composed single-end driver
+through the C-ABI vs the oracle (reference: nvBowtie/bowtie2/cuda/select_inl.h, select.cu, locate_inl.h,
+score_best_inl.h, reduce.h, aligner_best_approx.h)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import nvbio_amd as nvb
+from nvbio_amd import select as S, aligner as A, workloads as W, pipeline as P
+from nvbio_amd._lib import lib, check
+from oracle import pyoracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+import oracle_driver as OD  # noqa: E402
+from test_select_oracle import _random_deques  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def dev_i32(a, cuda):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(cuda)
+
+
+def test_device_hit_deque_replays_reference_vectors(cuda):
+    """The programs recorded from the reference's interval_heap.h, through the device deque: same array after every operation."""
+    import ctypes as C
+    G = np.load(os.path.join(HERE, "golden", "hit_deque_vectors.npz"))
+    cs, sizes = G["case_start"], G["sizes"].astype(np.uint64)
+    per_case = np.add.reduceat(sizes, cs[:-1].astype(np.int64))
+    state_start = np.zeros(cs.size - 1, np.uint64); state_start[1:] = np.cumsum(per_case)[:-1]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8)).to(cuda)
+    d_cs, d_ops, d_vals, d_caps, d_ss = t(cs), t(G["ops"]), t(G["vals"]), t(G["caps"]), t(state_start)
+    scratch = torch.zeros((cs.size - 1) * 64, dtype=torch.int64, device=cuda)
+    out = torch.zeros(G["states"].size, dtype=torch.int64, device=cuda)
+    vp = lambda x: C.c_void_p(x.data_ptr())
+    check(lib().nvbio_hip_hit_deque_replay(cs.size - 1, vp(d_cs), vp(d_ops), vp(d_vals), vp(d_caps), vp(d_ss), vp(scratch), 64, vp(out), None), "replay")
+    torch.cuda.synchronize()
+    assert (out.cpu().numpy().view(np.uint64) == G["states"]).all()
+
+
+@pytest.mark.parametrize("randomized", [False, True])
+@pytest.mark.parametrize("n_multi", [1, 4, 32])
+@pytest.mark.parametrize("top_seed", [0, 1])
+def test_select_rounds_match_oracle(cuda, randomized, n_multi, top_seed):
+    """select_init + repeated select rounds on random deques: queues, selected hits, and the whole mutable state
+    (arena, counts, probability trees bit for bit, LCG states) after every round; some reads give up on the way."""
+    rng = np.random.default_rng(40 + n_multi + 2 * top_seed)
+    n, stride = 3000, 20
+    hits, counts = _random_deques(rng, n, stride, max_size=12)
+    names = ["r%d/%d" % (i, i * 7919 % 13) for i in range(n)]
+    arena, idx = O.pack_names(names)
+    e_probs, e_trys, e_rseeds = O.select_init(hits, counts, arena, idx, 15, randomized, top_seed)
+    d_hits, d_counts = torch.from_numpy(hits.view(np.int64).copy()).to(cuda), dev_i32(counts, cuda)
+    st = S.SelectState(d_hits, d_counts, S.pack_names(names, cuda), 15, randomized, top_seed)
+    torch.cuda.synchronize()
+    assert (st.trys.cpu().numpy().view(np.uint32) == e_trys).all()
+    if randomized:
+        assert (st.rseeds.cpu().numpy().view(np.uint32) == e_rseeds).all()
+        assert (st.probs.cpu().numpy().view(np.uint32) == e_probs.view(np.uint32)).all()
+    e_active = (np.arange(n, dtype=np.uint32) | np.uint32(top_seed << 31))[rng.permutation(n)]
+    d_active = dev_i32(e_active, cuda)
+    rounds = total = 0
+    while e_active.size:
+        if rounds % 3 == 2:                                    # some reads run out of tries between rounds
+            give_up = rng.integers(0, n, 40)
+            e_trys[give_up] = 0
+            st.trys[torch.from_numpy(give_up).to(cuda)] = 0
+        e_active, e_hb, e_rid, e_loc, e_seed = O.select(randomized, n_multi, e_active, hits, counts, e_probs, e_rseeds, e_trys)
+        d_active, d_hb, d_rid, d_loc, d_seed = S.select(st, d_active, n_multi)
+        torch.cuda.synchronize()
+        u = lambda x: x.cpu().numpy().view(np.uint32)
+        assert (u(d_active) == e_active).all() and (d_hb.cpu().numpy().view(np.uint64) == e_hb).all()
+        assert (u(d_rid) == e_rid).all() and (u(d_loc) == e_loc).all() and (u(d_seed) == e_seed).all()
+        assert (st.hits.cpu().numpy().view(np.uint64) == hits).all() and (u(st.counts) == counts).all()
+        if randomized:
+            assert (u(st.rseeds) == e_rseeds).all() and (st.probs.cpu().numpy().view(np.uint32) == e_probs.view(np.uint32)).all()
+        rounds += 1; total += e_loc.size
+        assert rounds < 2000
+    assert rounds > 3 and total > n
+
+
+def _small_index(rng, n_genome=1 << 17):
+    text = rng.integers(0, 4, n_genome, dtype=np.uint8)
+    text[7000:7800] = np.tile(np.array([0, 1, 2], dtype=np.uint8), 267)[:800]
+    text[30000:30400] = text[90000:90400]                       # a 400 bp duplication: two equally good placements
+    return text
+
+
+def test_locate_setup_reduce_match_oracle(cuda):
+    """locate_hits (both index directions), score_best_setup, score_reduce_best_approx on random hits."""
+    rng = np.random.default_rng(9)
+    text = _small_index(rng)
+    host, rhost = O.FMIndex(text), O.FMIndex(text[::-1].copy())
+    fmi, rfmi = nvb.FMIndexDevice.from_host(host, cuda), nvb.FMIndexDevice.from_host(rhost, cuda)
+    n_reads, L, n_hits = 500, 100, 6000
+    rows = rng.integers(0, text.size + 1, n_hits).astype(np.uint32)
+    seed = (rng.integers(0, 80, n_hits) | (rng.integers(0, 2, n_hits) << 12) | (rng.integers(0, 2, n_hits) << 13) | (rng.integers(0, 2, n_hits) << 14)).astype(np.uint32)
+    e_loc = O.locate_hits(host, rhost, rows, seed)
+    d_loc, d_seed = dev_i32(rows, cuda), dev_i32(seed, cuda)
+    S.locate_hits(fmi, rfmi, d_loc, d_seed)
+    torch.cuda.synchronize()
+    assert (d_loc.cpu().numpy().view(np.uint32) == e_loc).all()
+    assert (e_loc > 0xFFFF0000).any()                           # some read starts wrap below zero
+
+    rid = np.sort(rng.integers(0, n_reads, n_hits)).astype(np.uint32)
+    read_len = np.full(n_reads, L, np.uint32)
+    best = O.init_alignments(read_len, (0, -0.6, -0.6))
+    best[1, ::3] = best[1, ::3] & ~np.uint64(0x3FFFF) | np.uint64((20 << 1) | 1)      # some second-best scores: -20
+    e_tb, e_tl, e_ms = O.score_best_setup(rid, e_loc, read_len, 31, text.size, best, -(1 << 16))
+    d_best = torch.from_numpy(best.view(np.int64).copy()).to(cuda)
+    pb, pl, tb, tl, ms = S.score_best_setup(dev_i32(rid, cuda), d_loc, d_seed, d_best, 31, text.size, -(1 << 16), fixed_read_len=L, rc_offset=n_reads * L)
+    torch.cuda.synchronize()
+    assert (tb.cpu().numpy().view(np.uint64) == e_tb).all() and (tl.cpu().numpy().view(np.uint32) == e_tl).all() and (ms.cpu().numpy() == e_ms).all()
+    assert (pb.cpu().numpy() == rid.astype(np.int64) * L + ((seed >> 13) & 1).astype(np.int64) * n_reads * L).all()
+    assert (e_tl == 0).any() and (e_tl == L + 31).any() and (e_ms == -20).any()
+
+    # reduce with the give-up counters: groups of consecutive hits per active read
+    active = np.unique(rid).astype(np.uint32)
+    hb = np.searchsorted(rid, np.append(active, n_reads)).astype(np.uint64)
+    for n_ext in (0, 25, 395):
+        score = rng.integers(-80, 1, n_hits).astype(np.int32)
+        score[rng.random(n_hits) < 0.2] = -(1 << 30)
+        loc2 = (e_loc // 50 * 50).astype(np.uint32)             # collisions with recorded locations
+        trys = rng.integers(0, 4, n_reads).astype(np.uint32); counts = rng.integers(0, 9, n_reads).astype(np.uint32)
+        e_best, e_trys, e_counts = best.copy(), trys.copy(), counts.copy()
+        O.score_reduce_best_approx(e_best, active, hb, score, loc2, seed, read_len, -(1 << 16), e_trys, e_counts, n_ext, 30, 400, 15)
+        st = S.SelectState.__new__(S.SelectState)
+        st.trys, st.counts = dev_i32(trys, cuda), dev_i32(counts, cuda)
+        g_best = torch.from_numpy(best.view(np.int64).copy()).to(cuda)
+        S.score_reduce_best_approx(g_best, st, dev_i32(active, cuda), torch.from_numpy(hb.view(np.int64)).to(cuda), torch.from_numpy(score).to(cuda),
+                                   dev_i32(loc2, cuda), d_seed, -(1 << 16), n_ext, 30, 400, 15, fixed_read_len=L)
+        torch.cuda.synchronize()
+        assert (g_best.cpu().numpy().view(np.uint64) == e_best).all()
+        assert (st.trys.cpu().numpy().view(np.uint32) == e_trys).all() and (st.counts.cpu().numpy().view(np.uint32) == e_counts).all()
+        assert n_ext == 0 or ((e_counts != counts).any() and (e_trys != trys).any())
+        best = e_best
+
+
+def _reads(rng, text, n, L):
+    sym = np.zeros((n, L), np.uint8)
+    pos = rng.integers(0, text.size - L, n)
+    for i in range(n):
+        r = text[pos[i]:pos[i] + L].copy()
+        k = [0, 1, 3, 6, 12][i % 5]
+        for j in rng.integers(0, L, k):
+            r[j] = (r[j] + 1 + rng.integers(0, 3)) & 3
+        if i % 11 == 0:
+            d = int(rng.integers(10, L - 10)); r = np.concatenate([r[:d], r[d + 2:], rng.integers(0, 4, 2, dtype=np.uint8)])      # a 2-base deletion
+        if i % 13 == 0:
+            r[int(rng.integers(0, L))] = 4
+        if i % 2:
+            r = np.where(r > 3, r, 3 - r)[::-1]
+        if i % 19 == 0:
+            r = rng.integers(0, 4, L, dtype=np.uint8)             # unalignable
+        sym[i] = r
+    return sym, pos
+
+
+CONFIGS = {
+    "default": dict(),
+    "no_rand": dict(randomized=False),
+    "top_seed": dict(top_seed=1),
+    "one_hit_rounds": dict(batch_size=1000),                     # n_reads > BATCH_SIZE/2: one hit per read per round
+    "multi_rounds": dict(batch_size=6000),                       # 5 hits per read per round, more as the queue drains
+    "low_effort": dict(max_effort=2, max_effort_init=2, min_ext=3, max_ext=20),
+    "one_mismatch_seeds": dict(allow_sub=1, seed_len=20, max_hits=30),
+    "subseed": dict(allow_sub=1, subseed_len=12, max_reseed=1),
+    "local": dict(local=True, seed_len=20, seed_freq=(2, 1.0, 0.75)),
+}
+
+
+@pytest.mark.parametrize("config", sorted(CONFIGS))
+def test_best_approx_driver_matches_oracle(cuda, config):
+    """Aligner::best_approx end to end -- seeding passes, selection rounds, locate, extension, reduction with give-up
+    counters, re-seeding, MAPQ, traceback -- vs the independent numpy driver over the oracle: identical best / second-best
+    alignments, MAPQs, CIGARs and per-pass queue sizes; and reads land where they were sampled."""
+    rng = np.random.default_rng(123)
+    text = _small_index(rng)
+    host, rhost = O.FMIndex(text), O.FMIndex(text[::-1].copy())
+    fmi, rfmi = nvb.FMIndexDevice.from_host(host, cuda), nvb.FMIndexDevice.from_host(rhost, cuda)
+    n, L = 1200, 100
+    sym, pos = _reads(rng, text, n, L)
+    names = ["sim.%d" % i for i in range(n)]
+    params = A.Params(**CONFIGS[config])
+    scheme = nvb.SmithWatermanScoringScheme.local() if params.local else nvb.SmithWatermanScoringScheme()
+    gw = W._pack_chunked(torch.from_numpy(text), 2, True)
+    e = OD.best_approx(host, rhost, sym, gw.numpy().view(np.uint32), text.size, params, scheme, names, 1 if params.local else 2)
+    r = A.best_approx(fmi, rfmi, torch.from_numpy(sym).to(cuda), gw.to(cuda), text.size, params, scheme, names, cigar_stride=64)
+    torch.cuda.synchronize()
+    assert r["stats"] == e["stats"], (r["stats"], e["stats"])
+    assert (r["best"].cpu().numpy().view(np.uint64) == e["best"]).all()
+    assert (r["mapq"].cpu().numpy() == e["mapq"]).all()
+    ids = r["aligned_ids"].cpu().numpy()
+    assert (ids == e["aligned_ids"]).all()
+    tb = e["tb"]
+    assert (r["cigar_len"].cpu().numpy()[ids].view(np.uint32) == tb["cigar_len"]).all()
+    assert (r["cigar"].cpu().numpy()[ids].view(np.uint16) == tb["cigar"][: ids.size]).all()
+    assert (r["tb_score"].cpu().numpy() == tb["score"]).all()
+    assert (r["sink"].cpu().numpy()[ids].view(np.uint32) == tb["sink"]).all() and (r["source"].cpu().numpy()[ids].view(np.uint32) == tb["source"]).all()
+    # sanity of the result itself: simulated reads (not the random ones) come back at their origin
+    best0 = e["best"][0]
+    loc = (best0 >> np.uint64(32)).astype(np.int64)
+    aligned = loc != 0xFFFFFFFF
+    sim = np.arange(n) % 19 != 0
+    ok = aligned & sim & (np.abs(loc - pos) <= 4)
+    assert ok.sum() >= 0.7 * sim.sum(), (ok.sum(), sim.sum(), aligned.sum())
+    assert e["stats"]["seeding_passes"] >= 2 and e["stats"]["rounds"] >= 2
+    # the traceback re-derives the score the extension stage recorded
+    sc = np.where(best0 & np.uint64(1), -((best0 >> np.uint64(1)) & np.uint64(0x1FFFF)).astype(np.int64), ((best0 >> np.uint64(1)) & np.uint64(0x1FFFF)).astype(np.int64))
+    assert (tb["score"] == sc[ids]).all()
