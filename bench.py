@@ -626,6 +626,39 @@ def extras_leg(a, dev):
                                "aligned": float(aligned.float().mean().item()), "best_at_true_position": float(at_true.float().mean().item()),
                                "mapq_ge_23": float((r["mapq"] >= 23).float().mean().item()),
                                "stages": "map_exact, locate, banded extend, score_reduce, BowtieMapq2, banded traceback (glue in torch)"}
+    # ---- the same batch through nvBowtie's own single-end driver (Aligner::best_approx): seeding passes, randomized hit
+    # selection, locate, quality-aware banded extension (band 31 = band_length(max_dist 15)), reduction with give-up counters,
+    # re-seeding, MAPQ, traceback
+    from nvbio_amd import aligner as AL, select as SEL
+    names = SEL.pack_names(["r%d" % i for i in range(nreads)], dev)
+    ba = {}
+    for cname, kw in (("default", dict()), ("no_rand", dict(randomized=False)), ("one_mismatch_seeds", dict(allow_sub=1))):
+        prm = AL.Params(hits_stride=16 if not kw.get("allow_sub") else 64, batch_size=nreads, **kw)
+        run = lambda st=False: AL.best_approx(fmi, rfmi, sym, genome_words, ng, prm, names=names, packed=(reads_rev, ext_words), stage_times=st)
+        ms = _timed(run, reps=2)
+        r = run(True)
+        loc = (r["best"][0] >> 32) & 0xFFFFFFFF
+        aligned = loc != 0xFFFFFFFF
+        at_true = aligned & ((loc - pos).abs() <= 2)
+        ba[cname] = {"reads": nreads, "ms_per_batch": ms, "Mreads_per_s": nreads / ms / 1e3, "extensions": r["stats"]["extensions"],
+                     "rounds": r["stats"]["rounds"], "queue_per_seeding_pass": r["stats"]["queue"],
+                     "aligned": float(aligned.float().mean().item()), "best_at_true_position": float(at_true.float().mean().item()),
+                     "mapq_ge_23": float((r["mapq"] >= 23).float().mean().item()),
+                     "stage_ms": {k: round(v, 3) for k, v in r["stats"]["ms"].items()}}
+    # parity of the composed driver on a sample: the first 2000 reads as their own batch vs the numpy driver over the oracle
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+    import oracle_driver as OD
+    m = 2000
+    prm = AL.Params(hits_stride=16, batch_size=m)
+    nm = ["r%d" % i for i in range(m)]
+    rs = AL.best_approx(fmi, rfmi, sym[:m].contiguous(), genome_words, ng, prm, names=nm, cigar_stride=64)
+    es = OD.best_approx(hostf, hostr, sym[:m].cpu().numpy(), genome_words.cpu().numpy().view(np.uint32), ng, prm, nvb.SmithWatermanScoringScheme(), nm, 2)
+    ids = rs["aligned_ids"].cpu().numpy()
+    ok = bool((rs["best"].cpu().numpy().view(np.uint64) == es["best"]).all() and (rs["mapq"].cpu().numpy() == es["mapq"]).all()
+              and (rs["cigar"].cpu().numpy()[ids].view(np.uint16) == es["tb"]["cigar"][: ids.size]).all() and rs["stats"] == es["stats"])
+    ba["parity"] = {"checked_reads": m, "best_mapq_cigar_stats_equal": ok}
+    ba["stages"] = "per seeding pass: map -> select_init -> rounds of {select, locate, banded extend (quality-aware scheme), score_reduce + give-up counters}; mark_unaligned / re-seed queue; BowtieMapq2; banded traceback"
+    out["best_approx_single_end"] = ba
     # ---- BASELINE config 5's shape on one GPU: 2 x 150 bp FR pairs, LOCAL band 31 in nvBowtie's local scheme
     npairs = 500_000
     s1, s2, ppos, pflen = P.make_read_pairs(text, npairs, 150, seed=0x5EED0009)

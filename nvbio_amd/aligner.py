@@ -20,6 +20,24 @@ from .strings import PackedStringSet
 WORST_SCORE = -(1 << 16)          # SmithWatermanScoringScheme::worst_score (scoring.h:226-227)
 
 
+class _Stage:
+    """Accumulates a stage's device time into stats["ms"][name] when stats["ms"] exists (as the reference's Stats does with
+    its device timers); otherwise free."""
+
+    def __init__(self, stats, name):
+        self.ms, self.name = stats.get("ms"), name
+
+    def __enter__(self):
+        if self.ms is not None:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if self.ms is not None:
+            self.e1.record(); self.e1.synchronize()
+            self.ms[self.name] = self.ms.get(self.name, 0.0) + self.e0.elapsed_time(self.e1)
+
+
 class Params:
     """The fields of nvBowtie's Params this driver reads, with its defaults (params.cpp:116-197; end-to-end)."""
 
@@ -68,25 +86,29 @@ def best_approx_score(fmi, rfmi, state, seed_queue, best, reads_fw_rc, n_reads, 
     n_ext = 0
     while active.numel() and n_ext < params.max_ext:
         n_multi = hits_per_read(active.numel(), n_ext, params)
-        active, hit_begin, rid, loc, seed = sel.select(state, active, n_multi)
+        with _Stage(stats, "select"):
+            active, hit_begin, rid, loc, seed = sel.select(state, active, n_multi)
         if active.numel() == 0:
             break
         if loc.numel() == 0:
             continue
-        sel.locate_hits(fmi, rfmi, loc, seed)
-        pb, _, tb, tl, _ = sel.score_best_setup(rid, loc, seed, best, band_len, genome_len, WORST_SCORE, fixed_read_len=read_len,
-                                                rc_offset=n_reads * read_len)
-        patterns = PackedStringSet(reads_fw_rc, 4, True, pb, None, read_len)
-        texts = PackedStringSet(genome_words, 2, True, tb, tl, 0)
-        score, _ = batch_banded_alignment_score(band_len, aligner, patterns, texts, quals=quals)
-        sel.score_reduce_best_approx(best, state, active, hit_begin, score, loc, seed, WORST_SCORE, n_ext, params.min_ext, params.max_ext,
-                                     params.max_effort, fixed_read_len=read_len)
+        with _Stage(stats, "locate"):
+            sel.locate_hits(fmi, rfmi, loc, seed)
+        with _Stage(stats, "score"):
+            pb, _, tb, tl, _ = sel.score_best_setup(rid, loc, seed, best, band_len, genome_len, WORST_SCORE, fixed_read_len=read_len,
+                                                    rc_offset=n_reads * read_len)
+            patterns = PackedStringSet(reads_fw_rc, 4, True, pb, None, read_len)
+            texts = PackedStringSet(genome_words, 2, True, tb, tl, 0)
+            score, _ = batch_banded_alignment_score(band_len, aligner, patterns, texts, quals=quals)
+        with _Stage(stats, "reduce"):
+            sel.score_reduce_best_approx(best, state, active, hit_begin, score, loc, seed, WORST_SCORE, n_ext, params.min_ext, params.max_ext,
+                                         params.max_effort, fixed_read_len=read_len)
         stats["extensions"] += int(loc.numel()); stats["rounds"] += 1
         n_ext += n_multi
 
 
 def best_approx(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=None, names=None, qual_value=30, traceback=True,
-                cigar_stride=None):
+                cigar_stride=None, stage_times=False, packed=None):
     """Aligner::best_approx for a batch of equal-length reads `sym` (uint8 [n, L], symbols 0..4).  `names`: list of read
     names (they seed the randomized selection).  Returns dict(best int64[2,n] io::Alignment words, mapq uint8[n], and with
     traceback: cigar int16[n,stride], cigar_len, source, sink (-1 for unaligned reads), stats)."""
@@ -97,26 +119,37 @@ def best_approx(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=No
     scheme = scheme or (SmithWatermanScoringScheme.local() if params.local else SmithWatermanScoringScheme())
     aligner = make_gotoh_aligner(LOCAL if params.local else SEMI_GLOBAL, scheme)
     band_len = band_length(params.max_dist)
-    reads_rev, reads_fw_rc = pack_read_streams(sym)
+    reads_rev, reads_fw_rc = packed if packed is not None else pack_read_streams(sym)
     quals = torch.full((2 * n * L + 8,), qual_value, dtype=torch.uint8, device=dev)
-    name_arena = sel.pack_names(names if names is not None else ["%d" % i for i in range(n)], dev) if params.randomized else None
+    if not params.randomized:
+        name_arena = None
+    elif isinstance(names, tuple):                       # already packed: (uint8 arena, int32 index[n+1]) on the device
+        name_arena = names
+    else:
+        name_arena = sel.pack_names(names if names is not None else ["%d" % i for i in range(n)], dev)
     mp = params.mapping_params()
     best = reduce.BestAlignments(n, scheme, fixed_read_len=L, device=dev)           # init_alignments with the threshold score
     seed_queue = torch.arange(n, dtype=torch.int32, device=dev)
     hits_stride = params.hits_stride or min(params.max_hits, 128)
     stats = dict(extensions=0, rounds=0, seeding_passes=0, queue=[])
+    if stage_times:
+        stats["ms"] = {}
     for seeding_pass in range(params.max_reseed + 1):
         if seed_queue.numel() == 0:
             break
         stats["queue"].append(int(seed_queue.numel())); stats["seeding_passes"] += 1
-        hits, counts, reseed = mapping.map_seeds(fmi, rfmi, reads_rev, mp, L, allow_sub=params.allow_sub, subseed_len=params.subseed_len,
-                                                 retry=seeding_pass, fw=params.fw, rc=params.rc, in_queue=seed_queue, hits_stride=hits_stride)
-        state = sel.SelectState(hits, counts, name_arena, params.max_effort_init, params.randomized, params.top_seed)
+        with _Stage(stats, "map"):
+            hits, counts, reseed = mapping.map_seeds(fmi, rfmi, reads_rev, mp, L, allow_sub=params.allow_sub, subseed_len=params.subseed_len,
+                                                     retry=seeding_pass, fw=params.fw, rc=params.rc, in_queue=seed_queue, hits_stride=hits_stride)
+        with _Stage(stats, "select_init"):
+            state = sel.SelectState(hits, counts, name_arena, params.max_effort_init, params.randomized, params.top_seed)
         best_approx_score(fmi, rfmi, state, seed_queue, best, reads_fw_rc, n, L, genome_words, genome_len, aligner, quals, params, band_len, stats)
         # mark_unaligned (aligner_init.cu:421-436) + copy_flagged
         flag = (reseed != 0) | ~best.is_aligned(0)[seed_queue.to(torch.int64)]
         seed_queue = seed_queue[flag]
-    out = dict(best=best.data, mapq=reduce.mapq(best, scheme, fixed_read_len=L), stats=stats)
+    with _Stage(stats, "mapq"):
+        mapq = reduce.mapq(best, scheme, fixed_read_len=L)
+    out = dict(best=best.data, mapq=mapq, stats=stats)
     if traceback:
         # banded_traceback_best (traceback_inl.h:104-136): window = alignment - band/2, band + read_len long
         b_align = best.alignment(0)
@@ -126,7 +159,8 @@ def best_approx(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=No
         tb_end = torch.clamp(tb_begin + L + band_len, max=genome_len)
         pat = PackedStringSet(reads_fw_rc, 4, True, (ids * L + b_rc[ids] * (n * L)).contiguous(), None, L)
         txt = PackedStringSet(genome_words, 2, True, tb_begin.contiguous(), (tb_end - tb_begin).to(torch.int32).contiguous(), 0)
-        tb = batch_banded_alignment_traceback(band_len, aligner, pat, txt, quals=quals, cigar_stride=cigar_stride)
+        with _Stage(stats, "traceback"):
+            tb = batch_banded_alignment_traceback(band_len, aligner, pat, txt, quals=quals, cigar_stride=cigar_stride)
         stride = tb["cigar"].shape[1]
         cigar = torch.zeros((n, stride), dtype=torch.int16, device=dev)
         cigar_len = torch.zeros(n, dtype=torch.int32, device=dev)

@@ -16,6 +16,7 @@
 #include <nvbio_hip/mapping.h>
 #include <nvbio_hip/io.h>
 #include <nvbio_hip/reduce.h>
+#include <nvbio_hip/select.h>
 #include <unistd.h>
 
 using namespace nvbio;
@@ -56,6 +57,13 @@ void oracle_map(int algorithm, uint32_t subseed_len, const oracle_fmi_t* f, cons
     const uint32_t* w, uint32_t bits, uint32_t be, const uint64_t* read_begin, const uint32_t* read_len,
     const uint32_t* in_queue, uint32_t n, const oracle_map_params_t* p, const uint32_t* seed_freq_by_len,
     uint64_t* out_hits, uint32_t hits_stride, uint32_t* out_counts, uint8_t* out_reseed);
+uint32_t oracle_sum_tree_node_count(uint32_t size);
+void oracle_select_init(uint32_t n_reads, const char* names, const uint32_t* names_idx, const uint64_t* hits, uint32_t hits_stride, const uint32_t* counts,
+    float* probs, uint32_t probs_stride, uint32_t* trys, uint32_t* rseeds, uint32_t max_effort_init, int randomized, int top_seed);
+void oracle_select(int randomized, uint32_t n_multi, const uint32_t* active_in, uint32_t n_active, uint64_t* hits, uint32_t hits_stride, uint32_t* counts,
+    float* probs, uint32_t probs_stride, uint32_t* rseeds, const uint32_t* trys, uint32_t* active_out, uint64_t* hit_begin, uint32_t* hit_read_id,
+    uint32_t* hit_loc, uint32_t* hit_seed, uint32_t* out_sizes);
+void oracle_locate_hits(const oracle_fmi_t* f, const oracle_fmi_t* rf, uint32_t n, uint32_t* hit_loc, const uint32_t* hit_seed);
 uint64_t oracle_filter_rank(const oracle_fmi_t* f, const uint32_t* w, uint32_t bits, uint32_t be, const uint64_t* begin, const uint32_t* len,
     uint32_t n, uint32_t* ranges, uint64_t* slots);
 void oracle_filter_locate(const oracle_fmi_t* f, const uint32_t* ranges, const uint64_t* slots, uint32_t n_queries,
@@ -484,7 +492,7 @@ static int fmindex_test()
         remove(bwt_name.c_str()); remove(sa_name.c_str());
         fprintf(stderr, "    %-44s : ok\n", "io::FMIndexDataHost/Device (.bwt/.sa)");
     }
-    // nvBowtie's seed mapping stage: the three algorithms of map_t vs the oracle, hit sets compared sorted
+    // nvBowtie's seed mapping stage: the three algorithms of map_t vs the oracle, hit deques compared verbatim
     {
         HostIndex rh; build_host_index(rh, h.n, 11, /*reversed=*/true);
         hip::device_vector<uint32> d_rbwt_occ(rh.bwt_occ), d_rssa(rh.ssa);
@@ -523,9 +531,48 @@ static int fmindex_test()
                 if (gc[r] != ec[r] || gr[r] != er[r]) FAIL("map mode %d read %u: %u hits (reseed %u), expected %u (%u)", mode, r, gc[r], gr[r], ec[r], er[r]);
                 std::vector<uint64> a(gc[r]), b(eh.begin() + size_t(r) * STRIDE, eh.begin() + size_t(r) * STRIDE + ec[r]);
                 memcpy(a.data(), &gh[size_t(r) * STRIDE], sizeof(uint64) * gc[r]);
-                std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
-                if (a != b) FAIL("map mode %d read %u: hit sets differ", mode, r);
+                if (a != b) FAIL("map mode %d read %u: hit deques differ", mode, r);          // array order of the reference's deque
                 total += gc[r];
+            }
+            // the selection stage on these deques, through select.h: select_init + rounds of select / locate vs the oracle
+            for (int randomized = 0; randomized < 2; ++randomized) {
+                bowtie2::cuda::SelectParamsPOD sp; sp.randomized = randomized != 0;
+                std::string names; std::vector<uint32> names_idx(R + 1u, 0u);
+                for (uint32 r = 0; r < R; ++r) { char nm[32]; snprintf(nm, sizeof(nm), "read.%u", r * 31u); names += nm; names.push_back('\0'); names_idx[r + 1] = uint32(names.size()); }
+                hip::device_vector<char> d_names(std::vector<char>(names.begin(), names.end())); hip::device_vector<uint32> d_names_idx(names_idx);
+                hip::device_vector<bowtie2::cuda::SeedHit> d_hits2(gh); hip::device_vector<uint32> d_counts2(gc);
+                bowtie2::cuda::SeedHitDequeArrayDeviceView hits2 = { d_hits2.data(), STRIDE, d_counts2.data() };
+                bowtie2::cuda::SelectState state(R, STRIDE);
+                bowtie2::cuda::select_init(R, d_names.data(), d_names_idx.data(), hits2, state, sp);
+                const uint32 ps = oracle_sum_tree_node_count(STRIDE);
+                std::vector<uint64> oh(eh); std::vector<uint32> oc(ec), otrys(R), orseeds(R); std::vector<float> oprobs(size_t(R) * ps);
+                oracle_select_init(R, names.data(), names_idx.data(), oh.data(), STRIDE, oc.data(), oprobs.data(), ps, otrys.data(), orseeds.data(), sp.max_effort_init, randomized, 0);
+                const uint32 N_MULTI = 3;
+                bowtie2::cuda::ScoringQueues queues(R, R * N_MULTI);
+                std::vector<bowtie2::cuda::packed_read> q0(R); std::vector<uint32> oq(R);
+                for (uint32 r = 0; r < R; ++r) { q0[r] = bowtie2::cuda::packed_read(r, 0u); oq[r] = r; }
+                queues.active_in.assign(q0.data(), R); queues.in_size = R;
+                uint64 selected = 0;
+                for (int round = 0; round < 4 && queues.in_size; ++round) {
+                    bowtie2::cuda::select(hits2, state, queues, N_MULTI, sp);
+                    std::vector<uint32> oout(oq.size()), orid(oq.size() * N_MULTI), oloc(oq.size() * N_MULTI), oseed(oq.size() * N_MULTI), osz(2);
+                    std::vector<uint64> ohb(oq.size() + 1);
+                    oracle_select(randomized, N_MULTI, oq.data(), uint32(oq.size()), oh.data(), STRIDE, oc.data(), oprobs.data(), ps, orseeds.data(), otrys.data(),
+                                  oout.data(), ohb.data(), orid.data(), oloc.data(), oseed.data(), osz.data());
+                    if (queues.in_size != osz[0] || queues.hits_size != osz[1]) FAIL("select (rand %d) round %d: %u reads / %u hits, expected %u / %u", randomized, round, queues.in_size, queues.hits_size, osz[0], osz[1]);
+                    bowtie2::cuda::locate(fmi, rfmi, queues);
+                    oracle_locate_hits(&h.ofmi, &rh.ofmi, osz[1], oloc.data(), oseed.data());
+                    hip::synchronize();
+                    const std::vector<bowtie2::cuda::packed_read> ga = queues.active_in.to_host();
+                    const std::vector<uint32> gl = queues.hit_loc.to_host(), gi = queues.hit_read_id.to_host();
+                    const std::vector<bowtie2::cuda::packed_seed> gs = queues.hit_seed.to_host();
+                    const std::vector<uint64> ghb = queues.hit_begin.to_host();
+                    for (uint32 t = 0; t < osz[0]; ++t) { uint32 w; memcpy(&w, &ga[t], 4); if (w != oout[t] || ghb[t] != ohb[t]) FAIL("select (rand %d) round %d: active read %u differs", randomized, round, t); }
+                    for (uint32 i = 0; i < osz[1]; ++i) { uint32 w; memcpy(&w, &gs[i], 4); if (gl[i] != oloc[i] || gi[i] != orid[i] || (w & 0x7FFFu) != oseed[i]) FAIL("select (rand %d) round %d: hit %u differs", randomized, round, i); }
+                    oq.assign(oout.begin(), oout.begin() + osz[0]);
+                    selected += osz[1];
+                }
+                fprintf(stderr, "    %-44s : %llu hits selected + located ok\n", mode == 0 ? (randomized ? "  select (randomized, 3 hits/read)" : "  select (top of deque, 3 hits/read)") : "  select", (unsigned long long)selected);
             }
             fprintf(stderr, "    %-44s : %u reads, %llu seed hits ok\n", mode == 0 ? "map exact" : mode == 1 ? "map approx (subseed 12)" : "map case-pruning (fwd + rev index)", R, (unsigned long long)total);
         }
