@@ -459,6 +459,41 @@ int nvbio_hip_opposite_mate_windows(uint32_t n_hits, const uint32_t* hit_read_id
     int32_t match, const int32_t* min_score_by_len /* device */, int32_t text_gap_open, int32_t text_gap_ext, const nvbio_hip_pe_params* params /* host */,
     uint8_t* out_valid, int32_t* out_min_score, uint8_t* out_read_rc, uint32_t* out_genome_begin, uint32_t* out_genome_end, void* stream);
 
+/* ---- the per-round stages of nvBowtie's PAIRED best-approx loop (Aligner::best_approx_score, aligner_best_approx_paired.h:455-700):
+ * select / locate as in the single-end loop, then
+ *   anchor_score_best    BestAnchorScoreStream (score_paired_inl.h:54-150): nvbio_hip_anchor_score_setup (window, pattern, threshold
+ *                        from the read's best pairs; hits at recorded locations are skipped), the banded scorer, _finish (hit.score =
+ *                        score >= threshold ? score : worst_score; hit.sink = window begin + sink.x)
+ *   opposite_score_best  BestOppositeScoreStream (score_opposite_inl.h:54-235): nvbio_hip_opposite_score_setup = nvbio_hip_opposite_mate_windows
+ *                        over packed seeds, valid only for hits whose anchor score is not worst_score (the opposite queue), the full-matrix
+ *                        scorer over the valid hits, _finish (scatter of hit.opposite_* for those; the caller pre-fills worst_score)
+ *   score_reduce_paired  with ReduceBestApproxContext: nvbio_hip_score_reduce_paired_best_approx
+ * and after the loops nvbio_hip_mark_discordant (aligner_init.cu:457-480).  The reference's skip test of the anchor stream reads
+ * context->min_score before setting it (score_paired_inl.h:128); that term is taken as false here. */
+int nvbio_hip_anchor_score_setup(uint32_t n_hits, const uint32_t* hit_read_id, const uint32_t* hit_loc, const uint32_t* hit_seed,
+    const uint64_t* a_read_begin /* nullable */, const uint32_t* a_read_len /* nullable */, const uint32_t* o_read_len /* nullable */,
+    uint32_t a_fixed_len, uint32_t o_fixed_len, uint64_t rc_offset,
+    uint32_t band_len, uint32_t genome_length, const uint64_t* best_alignments, const uint64_t* best_alignments_o, uint32_t best_stride,
+    int32_t match, const int32_t* min_score_by_len /* device */, int32_t score_limit, uint32_t anchor,
+    uint64_t* pattern_begin, uint32_t* pattern_len /* nullable iff fixed */, uint64_t* text_begin, uint32_t* text_len, int32_t* min_score, void* stream);
+int nvbio_hip_anchor_score_finish(uint32_t n_hits, const int32_t* raw_score, const uint32_t* raw_sink /* uint2[n] */, const uint64_t* text_begin,
+    const int32_t* min_score, int32_t worst_score, int32_t* hit_score, uint32_t* hit_sink, void* stream);
+int nvbio_hip_opposite_score_setup(uint32_t n_hits, const uint32_t* hit_read_id, const uint32_t* hit_seed, const uint32_t* hit_loc, const int32_t* hit_score,
+    int32_t worst_score, const uint32_t* a_read_len, const uint32_t* o_read_len, uint32_t a_fixed_len, uint32_t o_fixed_len,
+    const uint64_t* best_alignments, const uint64_t* best_alignments_o, uint32_t best_stride,
+    int32_t match, const int32_t* min_score_by_len /* device */, int32_t text_gap_open, int32_t text_gap_ext, const nvbio_hip_pe_params* params /* host */,
+    uint8_t* out_valid, int32_t* out_min_score, uint8_t* out_read_rc, uint32_t* out_genome_begin, uint32_t* out_genome_end, void* stream);
+int nvbio_hip_opposite_score_finish(uint32_t n_valid, const uint32_t* valid_idx, const int32_t* raw_score /* [n_valid] */, const uint32_t* raw_sink /* uint2[n_valid] */,
+    const int32_t* min_score /* by hit */, const uint32_t* genome_begin /* by hit */, int32_t worst_score,
+    int32_t* opposite_score, int32_t* opposite_score2, uint32_t* opposite_loc, uint32_t* opposite_sink, uint32_t* opposite_sink2, void* stream);
+int nvbio_hip_score_reduce_paired_best_approx(uint32_t n_active, const uint32_t* active_reads, const uint64_t* hit_begin,
+    const uint32_t* hit_loc, const uint32_t* hit_sink, const int32_t* hit_score, const uint32_t* hit_seed,
+    const uint32_t* opposite_loc, const uint32_t* opposite_sink, const uint32_t* opposite_sink2, const int32_t* opposite_score, const int32_t* opposite_score2,
+    const uint32_t* read_len /* nullable */, uint32_t fixed_read_len, uint32_t anchor, int32_t pe_policy, int32_t pe_unpaired, int32_t score_limit,
+    uint64_t* best_alignments, uint64_t* best_alignments_o, uint32_t best_stride,
+    uint32_t* trys, uint32_t* hit_counts, uint32_t n_ext, uint32_t min_ext, uint32_t max_ext, uint32_t max_effort, void* stream);
+int nvbio_hip_mark_discordant(uint32_t n_reads, uint64_t* best_alignments, uint64_t* best_alignments_o, uint32_t best_stride, void* stream);
+
 /* BowtieMapq2 / BowtieMapq3 (nvBowtie/bowtie2/cuda/mapq.h:42-330) for single-end reads:
  * out_mapq[r] from the best / second-best alignment of read r; perfect_score(len) = len * match,
  * min_score(len) = min_score_by_len[len] (the scheme's SimpleFunc tabulated by the host, scoring.h:272-281),

@@ -15,6 +15,8 @@ SYMBOLS = [
     "nvbio_hip_alignment_invalid", "nvbio_hip_init_alignments", "nvbio_hip_score_reduce", "nvbio_hip_score_reduce_paired", "nvbio_hip_opposite_mate_windows", "nvbio_hip_mapq", "nvbio_hip_mapq_paired", "nvbio_hip_fm_locate",
     "nvbio_hip_sum_tree_node_count", "nvbio_hip_select_init", "nvbio_hip_select_temp_bytes", "nvbio_hip_select", "nvbio_hip_locate_hits", "nvbio_hip_hit_deque_replay",
     "nvbio_hip_score_best_setup", "nvbio_hip_score_reduce_best_approx",
+    "nvbio_hip_anchor_score_setup", "nvbio_hip_anchor_score_finish", "nvbio_hip_opposite_score_setup", "nvbio_hip_opposite_score_finish",
+    "nvbio_hip_score_reduce_paired_best_approx", "nvbio_hip_mark_discordant",
     "nvbio_hip_fm_locate_ssa_iterator", "nvbio_hip_fm_lookup_ssa_iterator",
     "nvbio_hip_fm_filter_temp_bytes", "nvbio_hip_fm_filter_rank", "nvbio_hip_fm_filter_locate",
     "nvbio_hip_build_bwt_occ_temp_bytes", "nvbio_hip_build_bwt_occ",
@@ -110,6 +112,12 @@ def lib():
         L.nvbio_hip_locate_hits.argtypes = [P(FMIndexStruct), P(FMIndexStruct), u32, vp, vp, vp]
         L.nvbio_hip_score_best_setup.argtypes = [u32, vp, vp, vp, vp, vp, u32, u64, u32, u32, vp, u32, i32, vp, vp, vp, vp, vp, vp]
         L.nvbio_hip_score_reduce_best_approx.argtypes = [u32, vp, vp, vp, vp, vp, vp, u32, vp, u32, i32, vp, vp, u32, u32, u32, u32, vp]
+        L.nvbio_hip_anchor_score_setup.argtypes = [u32, vp, vp, vp, vp, vp, vp, u32, u32, u64, u32, u32, vp, vp, u32, i32, vp, i32, u32, vp, vp, vp, vp, vp, vp]
+        L.nvbio_hip_anchor_score_finish.argtypes = [u32, vp, vp, vp, vp, i32, vp, vp, vp]
+        L.nvbio_hip_opposite_score_setup.argtypes = [u32, vp, vp, vp, vp, i32, vp, vp, u32, u32, vp, vp, u32, i32, vp, i32, i32, P(PeParamsStruct), vp, vp, vp, vp, vp, vp]
+        L.nvbio_hip_opposite_score_finish.argtypes = [u32, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]
+        L.nvbio_hip_score_reduce_paired_best_approx.argtypes = [u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, i32, i32, i32, vp, vp, u32, vp, vp, u32, u32, u32, u32, vp]
+        L.nvbio_hip_mark_discordant.argtypes = [u32, vp, vp, u32, vp]
         L.nvbio_hip_score_reduce_paired.argtypes = [u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, i32, i32, i32, vp, vp, u32, vp]
         L.nvbio_hip_opposite_mate_windows.argtypes = [u32, vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, u32, i32, vp, i32, i32, P(PeParamsStruct),
                                                       vp, vp, vp, vp, vp, vp]

@@ -13,8 +13,8 @@ falls back to the CPU."""
 import torch
 
 from . import mapping, reduce, select as sel
-from .alignment import (make_gotoh_aligner, SmithWatermanScoringScheme, SEMI_GLOBAL, LOCAL, batch_banded_alignment_score,
-                        batch_banded_alignment_traceback)
+from .alignment import (make_gotoh_aligner, SmithWatermanScoringScheme, SEMI_GLOBAL, LOCAL, PATTERN_BLOCKING, batch_banded_alignment_score,
+                        batch_banded_alignment_traceback, batch_alignment_score, batch_alignment_traceback)
 from .strings import PackedStringSet
 
 WORST_SCORE = -(1 << 16)          # SmithWatermanScoringScheme::worst_score (scoring.h:226-227)
@@ -49,6 +49,8 @@ class Params:
         self.seed_len, self.seed_freq, self.min_read_len = 22, (mapping.SQRT_FUNC, 1.0, 1.15), 12
         self.local = False
         self.fw, self.rc = True, True
+        # paired-end (params.cpp:165-172; io::PE_POLICY_FR)
+        self.pe_policy, self.pe_overlap, self.pe_unpaired, self.pe_discordant, self.min_frag_len, self.max_frag_len = 1, True, True, True, 0, 500
         self.batch_size = 1 << 20                      # Aligner::BATCH_SIZE
         self.hits_stride = None                        # arena slots per read (default min(max_hits, 128))
         for k, v in kw.items():
@@ -168,4 +170,166 @@ def best_approx(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=No
         sink = torch.full((n, 2), -1, dtype=torch.int32, device=dev)
         cigar[ids] = tb["cigar"][: ids.numel()]; cigar_len[ids] = tb["cigar_len"]; source[ids] = tb["source"]; sink[ids] = tb["sink"]
         out.update(cigar=cigar, cigar_len=cigar_len, source=source, sink=sink, tb_score=tb["score"], aligned_ids=ids)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# paired-end: Aligner::best_approx / best_approx_score of aligner_best_approx_paired.h (:95-453, :455-700)
+# ------------------------------------------------------------------------------------------------------------------
+def best_approx_score_paired(fmi, rfmi, state, seed_queue, anchor, best, best_o, a_words, o_words, n_reads, read_len, genome_words, genome_len,
+                             scheme, banded_aligner, full_aligner, quals, table, params, band_len, stats):
+    """The extension rounds of one seeding pass of one anchor mate: select, locate, anchor_score_best, opposite_score_best over the
+    hits whose anchor scored, score_reduce_paired with the give-up counters."""
+    L = read_len
+    active = seed_queue.to(torch.int32)
+    if params.top_seed & 1:
+        active = active | torch.tensor(-(1 << 31), dtype=torch.int32, device=active.device)
+    n_ext = 0
+    while active.numel() and n_ext < params.max_ext:
+        n_multi = hits_per_read(active.numel(), n_ext, params)
+        with _Stage(stats, "select"):
+            active, hit_begin, rid, loc, seed = sel.select(state, active, n_multi)
+        if active.numel() == 0:
+            break
+        if loc.numel() == 0:
+            continue
+        with _Stage(stats, "locate"):
+            sel.locate_hits(fmi, rfmi, loc, seed)
+        with _Stage(stats, "anchor_score"):
+            pb, tb, tl, ms = sel.anchor_score_setup(rid, loc, seed, best, best_o, scheme, anchor, band_len, genome_len, WORST_SCORE, L, L, n_reads * L, table)
+            raw, raw_sink = batch_banded_alignment_score(band_len, banded_aligner, PackedStringSet(a_words, 4, True, pb, None, L),
+                                                         PackedStringSet(genome_words, 2, True, tb, tl, 0), quals=quals)
+            hit_score, hit_sink = sel.anchor_score_finish(raw, raw_sink, tb, ms, WORST_SCORE)
+        with _Stage(stats, "opposite_score"):
+            ow = sel.opposite_score_setup(rid, seed, loc, hit_score, WORST_SCORE, best, best_o, scheme, anchor, genome_len, L, L, params.pe_policy,
+                                          params.min_frag_len, params.max_frag_len, params.pe_overlap, WORST_SCORE, table)
+            idx = torch.nonzero(ow["valid"]).squeeze(1)                    # the jobs that are actually scored
+            n_valid = int(idx.numel())
+            if n_valid:
+                ob = ow["genome_begin"].to(torch.int64)[idx] & 0xFFFFFFFF
+                oe = ow["genome_end"].to(torch.int64)[idx] & 0xFFFFFFFF
+                o_pat = PackedStringSet(o_words, 4, True, ((rid.to(torch.int64)[idx] & 0xFFFFFFFF) * L + ow["read_rc"].to(torch.int64)[idx] * (n_reads * L)).contiguous(), None, L)
+                o_txt = PackedStringSet(genome_words, 2, True, ob.contiguous(), (oe - ob).to(torch.int32).contiguous(), 0)
+                o_ms = ow["min_score"][idx].contiguous()
+                max_n = int(params.max_frag_len) + L
+                s_o, k_o, _ = batch_alignment_score(full_aligner, o_pat, o_txt, L, max_n, o_ms, quals=quals)
+            else:
+                s_o = torch.empty(0, dtype=torch.int32, device=loc.device); k_o = torch.empty((0, 2), dtype=torch.int32, device=loc.device)
+            o_score, o_score2, o_loc, o_sink, o_sink2 = sel.opposite_score_finish(idx.to(torch.int32), s_o, k_o, ow["min_score"], ow["genome_begin"],
+                                                                                   WORST_SCORE, int(loc.numel()))
+        with _Stage(stats, "reduce"):
+            sel.score_reduce_paired_best_approx(best, best_o, state, active, hit_begin, loc, hit_sink, hit_score, seed, o_loc, o_sink, o_sink2, o_score, o_score2,
+                                                anchor, params.pe_policy, params.pe_unpaired, WORST_SCORE, n_ext, params.min_ext, params.max_ext,
+                                                params.max_effort, L)
+        stats["extensions"] += int(loc.numel()); stats["opposite_extensions"] += n_valid; stats["rounds"] += 1
+        n_ext += n_multi
+
+
+def best_approx_paired(fmi, rfmi, sym1, sym2, genome_words, genome_len, params=None, scheme=None, names=None, qual_value=30, traceback=True,
+                       cigar_stride=64, stage_times=False):
+    """Aligner::best_approx for read pairs (equal-length mates sym1 / sym2, uint8 [n, L]).  Returns dict(best, best_o int64[2,n]
+    io::Alignment words of the anchor / opposite slots, mapq1, mapq2 uint8[n], and with traceback per slot set ("1" = best_data,
+    "2" = best_data_o): cigar, cigar_len, source, sink; stats)."""
+    from .pipeline import pack_read_streams
+    params = params or Params()
+    n, L = sym1.shape
+    assert sym2.shape == sym1.shape
+    dev = sym1.device
+    scheme = scheme or (SmithWatermanScoringScheme.local() if params.local else SmithWatermanScoringScheme())
+    aln_type = LOCAL if params.local else SEMI_GLOBAL
+    banded_aligner = make_gotoh_aligner(aln_type, scheme)
+    full_aligner = make_gotoh_aligner(aln_type, scheme, PATTERN_BLOCKING)            # nvBowtie's aligners carry the default tag
+    band_len = band_length(params.max_dist)
+    packed = [pack_read_streams(sym1), pack_read_streams(sym2)]                       # per mate: (reversed reads, fw + rc words)
+    quals = torch.full((2 * n * L + 8,), qual_value, dtype=torch.uint8, device=dev)
+    if not params.randomized:
+        name_arena = None
+    elif isinstance(names, tuple):
+        name_arena = names
+    else:
+        name_arena = sel.pack_names(names if names is not None else ["%d" % i for i in range(n)], dev)
+    mp = params.mapping_params()
+    table = sel._min_score_table(scheme, L, dev)
+    best = reduce.BestAlignments(n, scheme, fixed_read_len=L, device=dev, mate=0)
+    best_o = reduce.BestAlignments(n, scheme, fixed_read_len=L, device=dev, mate=1)
+    hits_stride = params.hits_stride or min(params.max_hits, 128)
+    stats = dict(extensions=0, opposite_extensions=0, rounds=0, seeding_passes=0, queue=[])
+    if stage_times:
+        stats["ms"] = {}
+    for anchor in (0, 1):
+        seed_queue = torch.arange(n, dtype=torch.int32, device=dev)
+        fw_strand = params.pe_policy in (0, 1) if anchor == 0 else params.pe_policy in (0, 2)      # :168-176
+        fw, rc = (params.fw, params.rc) if fw_strand else (params.rc, params.fw)
+        reads_rev, a_words = packed[anchor]
+        o_words = packed[1 - anchor][1]
+        for seeding_pass in range(params.max_reseed + 1):
+            if seed_queue.numel() == 0:
+                break
+            stats["queue"].append(int(seed_queue.numel())); stats["seeding_passes"] += 1
+            with _Stage(stats, "map"):
+                hits, counts, reseed = mapping.map_seeds(fmi, rfmi, reads_rev, mp, L, allow_sub=params.allow_sub, subseed_len=params.subseed_len,
+                                                         retry=seeding_pass, fw=fw, rc=rc, in_queue=seed_queue, hits_stride=hits_stride)
+            with _Stage(stats, "select_init"):
+                state = sel.SelectState(hits, counts, name_arena, params.max_effort_init, params.randomized, params.top_seed)
+            best_approx_score_paired(fmi, rfmi, state, seed_queue, anchor, best, best_o, a_words, o_words, n, L, genome_words, genome_len, scheme,
+                                     banded_aligner, full_aligner, quals, table, params, band_len, stats)
+            seed_queue = seed_queue[reseed != 0]                                      # copy_flagged (no mark_unaligned in the paired driver)
+    if params.pe_discordant:
+        sel.mark_discordant(best, best_o)
+    with _Stage(stats, "mapq"):
+        mapq1 = reduce.mapq_paired(best, best_o, scheme, fixed_read_len=L, o_fixed_read_len=L)      # MapqFunctorPE(mate 0)
+        mapq2 = reduce.mapq_paired(best_o, best, scheme, fixed_read_len=L, o_fixed_read_len=L)      # MapqFunctorPE(mate 1)
+    out = dict(best=best.data, best_o=best_o.data, mapq1=mapq1, mapq2=mapq2, stats=stats)
+    if traceback:
+        with _Stage(stats, "traceback"):
+            mate_words = (packed[0][1], packed[1][1])
+
+            def banded_tb(data, ids):
+                """banded_traceback_best over reads `ids` of one slot set: the mate comes from the alignment (traceback_inl.h:104-136)"""
+                w = data[0][ids]
+                align, rcb, mate = (w >> 32) & 0xFFFFFFFF, (w >> 28) & 1, (w >> 29) & 1
+                tb_begin = torch.clamp(align - band_len // 2, min=0)
+                tb_end = torch.clamp(tb_begin + L + band_len, max=genome_len)
+                res = {}
+                for m in (0, 1):
+                    k = torch.nonzero(mate == m).squeeze(1)
+                    if k.numel() == 0:
+                        continue
+                    pat = PackedStringSet(mate_words[m], 4, True, (ids[k] * L + rcb[k] * (n * L)).contiguous(), None, L)
+                    txt = PackedStringSet(genome_words, 2, True, tb_begin[k].contiguous(), (tb_end[k] - tb_begin[k]).to(torch.int32).contiguous(), 0)
+                    res[m] = (ids[k], batch_banded_alignment_traceback(band_len, banded_aligner, pat, txt, quals=quals, cigar_stride=cigar_stride))
+                return res
+
+            def full_tb(data, ids):
+                """opposite_traceback_best: the concordant opposite mates, full matrix over [alignment, alignment + sink)"""
+                w = data[0][ids]
+                align, rcb, mate, g_len = (w >> 32) & 0xFFFFFFFF, (w >> 28) & 1, (w >> 29) & 1, (w >> 18) & 0x3FF
+                t_end = torch.clamp(align + g_len, max=genome_len)
+                res = {}
+                for m in (0, 1):
+                    k = torch.nonzero(mate == m).squeeze(1)
+                    if k.numel() == 0:
+                        continue
+                    pat = PackedStringSet(mate_words[m], 4, True, (ids[k] * L + rcb[k] * (n * L)).contiguous(), None, L)
+                    txt = PackedStringSet(genome_words, 2, True, align[k].contiguous(), (t_end[k] - align[k]).to(torch.int32).contiguous(), 0)
+                    res[m] = (ids[k], batch_alignment_traceback(full_aligner, pat, txt, L, 1024, cigar_stride=cigar_stride, quals=quals))
+                return res
+
+            def scatter(parts):
+                cigar = torch.zeros((n, cigar_stride), dtype=torch.int16, device=dev); cigar_len = torch.zeros(n, dtype=torch.int32, device=dev)
+                source = torch.full((n, 2), -1, dtype=torch.int32, device=dev); sink = torch.full((n, 2), -1, dtype=torch.int32, device=dev)
+                score = torch.full((n,), WORST_SCORE, dtype=torch.int32, device=dev)
+                for res in parts:
+                    for ids_m, tbm in res.values():
+                        cigar[ids_m] = tbm["cigar"][: ids_m.numel()]; cigar_len[ids_m] = tbm["cigar_len"]; source[ids_m] = tbm["source"]; sink[ids_m] = tbm["sink"]
+                        score[ids_m] = tbm["score"]
+                return dict(cigar=cigar, cigar_len=cigar_len, source=source, sink=sink, score=score)
+
+            aligned1 = torch.nonzero(best.is_aligned(0)).squeeze(1)
+            out["tb1"] = scatter([banded_tb(best.data, aligned1)])
+            w_o = best_o.data[0]
+            concordant = (((w_o >> 30) & 1) != 0) & (((w_o >> 31) & 1) == 0)
+            ids_c = torch.nonzero(concordant & best_o.is_aligned(0)).squeeze(1)
+            ids_u = torch.nonzero(~concordant & best_o.is_aligned(0)).squeeze(1)
+            out["tb2"] = scatter([full_tb(best_o.data, ids_c), banded_tb(best_o.data, ids_u)])
     return out

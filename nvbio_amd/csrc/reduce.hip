@@ -135,27 +135,35 @@ __device__ __forceinline__ bool distinct_alns(const IoAln p1, const IoAln p2, ui
 {
     return distinct_alignments(p1.align + io_aln_sink(p1), io_aln_rc(p1), p2.align + io_aln_sink(p2), io_aln_rc(p2), dist);
 }
-__device__ __forceinline__ void try_update_pair(IoBestPairs& b, const IoPair& pair, uint32_t min_distance)
+// try_update (reduce_inl.h:204-340): true when the result was absorbed (an update, or a location already recorded); every
+// actual update refills the read's try counter (ReduceBestApproxContext::best_score / second_score) when CTX
+template <bool CTX>
+__device__ __forceinline__ bool try_update_pair(IoBestPairs& b, const IoPair& pair, uint32_t min_distance, uint32_t& tr, uint32_t max_effort)
 {
     const int32_t score = pair_score(pair);
     const IoPair p0 = { b.a1, b.o1 }, p1 = { b.a2, b.o2 };
-    if (!distinct_pairs(p0, pair, min_distance)) { if (score > bp_best_score(b)) { b.a1 = pair.a; b.o1 = pair.o; } }
+    if (!distinct_pairs(p0, pair, min_distance)) { if (score > bp_best_score(b)) { if (CTX) tr = max_effort; b.a1 = pair.a; b.o1 = pair.o; } return true; }
     else if (!distinct_pairs(p1, pair, min_distance)) {
-        if (score > bp_best_score(b)) { b.a2 = b.a1; b.o2 = b.o1; b.a1 = pair.a; b.o1 = pair.o; }
-        else if (score > bp_second_score(b)) { b.a2 = pair.a; b.o2 = pair.o; }
+        if (score > bp_best_score(b)) { if (CTX) tr = max_effort; b.a2 = b.a1; b.o2 = b.o1; b.a1 = pair.a; b.o1 = pair.o; }
+        else if (score > bp_second_score(b)) { if (CTX) tr = max_effort; b.a2 = pair.a; b.o2 = pair.o; }
+        return true;
     }
-    else if (!io_aln_paired(b.a1) || score > bp_best_score(b)) { b.a2 = b.a1; b.o2 = b.o1; b.a1 = pair.a; b.o1 = pair.o; }
-    else if (!io_aln_paired(b.a2) || score > bp_second_score(b)) { b.a2 = pair.a; b.o2 = pair.o; }
+    else if (!io_aln_paired(b.a1) || score > bp_best_score(b)) { if (CTX) tr = max_effort; b.a2 = b.a1; b.o2 = b.o1; b.a1 = pair.a; b.o1 = pair.o; return true; }
+    else if (!io_aln_paired(b.a2) || score > bp_second_score(b)) { if (CTX) tr = max_effort; b.a2 = pair.a; b.o2 = pair.o; return true; }
+    return false;
 }
-__device__ __forceinline__ void try_update_single(IoAln& a1, IoAln& a2, const IoAln a, uint32_t min_distance)
+template <bool CTX>
+__device__ __forceinline__ bool try_update_single(IoAln& a1, IoAln& a2, const IoAln a, uint32_t min_distance, uint32_t& tr, uint32_t max_effort)
 {
-    if (!distinct_alns(a1, a, min_distance)) { if (io_aln_score(a) > io_aln_score(a1)) a1 = a; }
+    if (!distinct_alns(a1, a, min_distance)) { if (io_aln_score(a) > io_aln_score(a1)) { if (CTX) tr = max_effort; a1 = a; } return true; }
     else if (!distinct_alns(a2, a, min_distance)) {
-        if (io_aln_score(a) > io_aln_score(a1)) { a2 = a1; a1 = a; }
-        else if (io_aln_score(a) > io_aln_score(a2)) a2 = a;
+        if (io_aln_score(a) > io_aln_score(a1)) { if (CTX) tr = max_effort; a2 = a1; a1 = a; }
+        else if (io_aln_score(a) > io_aln_score(a2)) { if (CTX) tr = max_effort; a2 = a; }
+        return true;
     }
-    else if (io_aln_score(a) > io_aln_score(a1)) { a2 = a1; a1 = a; }
-    else if (io_aln_score(a) > io_aln_score(a2)) a2 = a;
+    else if (io_aln_score(a) > io_aln_score(a1)) { if (CTX) tr = max_effort; a2 = a1; a1 = a; return true; }
+    else if (io_aln_score(a) > io_aln_score(a2)) { if (CTX) tr = max_effort; a2 = a; return true; }
+    return false;
 }
 
 struct PairedReduceParams {
@@ -165,42 +173,143 @@ struct PairedReduceParams {
     const uint32_t* read_len; uint32_t fixed_len;
     uint32_t anchor; int32_t pe_policy, pe_unpaired, score_limit;
     uint2* best; uint2* best_o; uint32_t best_stride;
+    // CTX (the best-approx loop): read_ids are packed_read words, strands / top flags come from packed seeds, and the
+    // give-up counters of ReduceBestApproxContext (reduce.h:63-105) are maintained
+    const uint32_t* hit_seed; uint32_t* trys; uint32_t* hit_counts; uint32_t n_ext, min_ext, max_ext, max_effort;
 };
 
+template <bool CTX>
 __global__ void __launch_bounds__(256) score_reduce_paired_kernel(const PairedReduceParams p)
 {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= p.n_active) return;
-    const uint32_t read_id = p.read_ids ? p.read_ids[t] : t;
+    const uint32_t read_id = CTX ? (p.read_ids[t] & 0x7FFFFFFFu) : (p.read_ids ? p.read_ids[t] : t);
     auto ld = [](const uint2* q, uint32_t i) { const uint2 v = q[i]; IoAln a = { v.x, v.y }; return a; };
     IoBestPairs b = { ld(p.best, read_id), ld(p.best, read_id + p.best_stride), ld(p.best_o, read_id), ld(p.best_o, read_id + p.best_stride) };
     const uint32_t min_distance = (p.read_len ? p.read_len[read_id] : p.fixed_len) / 4u;
-    for (uint64_t i = p.hit_begin[t]; i < p.hit_begin[t + 1]; ++i)
+    uint32_t tr = CTX ? p.trys[read_id] : 0u;
+    bool erase = false;
+    const uint64_t hb = p.hit_begin[t];
+    for (uint64_t i = hb; i < p.hit_begin[t + 1]; ++i)
     {
-        const uint32_t rc = p.hit_rc[i];
-        const bool anchor_fw = !rc, anchor_1 = (p.anchor == 0u);
+        const uint32_t seed = CTX ? p.hit_seed[i] : 0u;
+        const uint32_t rc = CTX ? ((seed >> 13) & 1u) : p.hit_rc[i];
+        const bool anchor_fw = !rc;
         bool o_fw;      // frame_opposite_mate: only the orientation is needed here
         switch (p.pe_policy) {
         case 0: case 3: o_fw = anchor_fw; break;         // FF, RR
         default:        o_fw = !anchor_fw; break;        // FR, RF
         }
-        (void)anchor_1;
         const uint32_t o_rc = !o_fw;
         const IoPair pair  = { io_aln_make_full(p.hit_loc[i], p.hit_sink[i] - p.hit_loc[i], p.hit_score[i], rc, p.anchor, p.o_score[i] > p.score_limit),
                                io_aln_make_full(p.o_loc[i], p.o_sink[i] - p.o_loc[i], p.o_score[i], o_rc, p.anchor ^ 1u, p.o_score[i] > p.score_limit) };
         const IoPair pair2 = { io_aln_make_full(p.hit_loc[i], p.hit_sink[i] - p.hit_loc[i], p.hit_score[i], rc, p.anchor, p.o_score2[i] > p.score_limit),
                                io_aln_make_full(p.o_loc[i], p.o_sink2[i] - p.o_loc[i], p.o_score2[i], o_rc, p.anchor ^ 1u, p.o_score2[i] > p.score_limit) };
+        bool updated = false;
         if (io_aln_paired(pair.a)) {
-            try_update_pair(b, pair, min_distance);
-            if (io_aln_paired(pair2.a)) try_update_pair(b, pair2, min_distance);
+            updated |= try_update_pair<CTX>(b, pair, min_distance, tr, p.max_effort);
+            if (io_aln_paired(pair2.a)) updated |= try_update_pair<CTX>(b, pair2, min_distance, tr, p.max_effort);
         } else if (p.pe_unpaired && !io_aln_paired(b.a1)) {
             // no paired alignment yet: best two of mate 1 live in m_a*, of mate 2 in m_o*
-            if (p.anchor) try_update_single(b.o1, b.o2, pair.a, min_distance);
-            else          try_update_single(b.a1, b.a2, pair.a, min_distance);
+            if (p.anchor) updated |= try_update_single<CTX>(b.o1, b.o2, pair.a, min_distance, tr, p.max_effort);
+            else          updated |= try_update_single<CTX>(b.a1, b.a2, pair.a, min_distance, tr, p.max_effort);
+        }
+        if (CTX && !updated && tr > 0u) {                  // ReduceBestApproxContext::failure
+            const uint32_t idx = uint32_t(i - hb), top_flag = (seed >> 14) & 1u;
+            if ((p.n_ext + idx >= p.min_ext && top_flag == 0u && --tr == 0u) || (p.n_ext + idx >= p.max_ext)) erase = true;
         }
     }
+    if (CTX) { p.trys[read_id] = tr; if (erase) p.hit_counts[read_id] = 0u; }
     p.best[read_id] = make_uint2(b.a1.w, b.a1.align); p.best[read_id + p.best_stride] = make_uint2(b.a2.w, b.a2.align);
     p.best_o[read_id] = make_uint2(b.o1.w, b.o1.align); p.best_o[read_id + p.best_stride] = make_uint2(b.o2.w, b.o2.align);
+}
+
+// mark_discordant_kernel (aligner_init.cu:457-480): a pair whose mates are both uniquely aligned but not concordant
+__global__ void __launch_bounds__(256) mark_discordant_kernel(uint32_t n_reads, uint2* __restrict__ best, uint2* __restrict__ best_o, uint32_t stride)
+{
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint2 a1 = best[r], o1 = best_o[r];
+    const bool concordant = ((a1.x >> 30) & 1u) && !((a1.x >> 31) & 1u);
+    if (!concordant && a1.y != 0xFFFFFFFFu && best[r + stride].y == 0xFFFFFFFFu && o1.y != 0xFFFFFFFFu && best_o[r + stride].y == 0xFFFFFFFFu) {
+        best[r] = make_uint2(a1.x | 0xC0000000u, a1.y);
+        best_o[r] = make_uint2(o1.x | 0xC0000000u, o1.y);
+    }
+}
+
+// compute_target_score (alignment_utils.h:100-111) bounded by the pair's perfect score
+__device__ __forceinline__ int32_t target_pair_score(const IoBestPairs& b, int32_t a_worst, int32_t o_worst, int32_t a_optimal, int32_t o_optimal)
+{
+    int32_t target;
+    if (!io_aln_paired(b.a2)) target = a_worst + o_worst;
+    else { const int32_t delta = bp_best_score(b) - bp_second_score(b); target = bp_second_score(b) + (delta * 3) / 4; }      // bowtie2's 'tighten = 3'
+    return min(target + 1, a_optimal + o_optimal);
+}
+
+// BestAnchorScoreStream::init_context (score_paired_inl.h:54-135): window, pattern and threshold of every anchor hit.  A hit at a
+// location already recorded in the read's best pairs is skipped: threshold INT32_MAX and an empty window (the DP then fails and
+// the hit scores worst_score, as when the reference does not run it).  The reference's skip test also reads context->min_score
+// before setting it (:128, an uninitialised read); that term is taken as false.
+struct AnchorSetupParams {
+    uint32_t n; const uint32_t* hit_read_id; const uint32_t* hit_loc; const uint32_t* hit_seed;
+    const uint64_t* a_read_begin; const uint32_t* a_read_len; const uint32_t* o_read_len; uint32_t a_fixed_len, o_fixed_len; uint64_t rc_offset;
+    uint32_t band_len, genome_len; const uint2* best; const uint2* best_o; uint32_t best_stride;
+    int32_t match; const int32_t* min_score_by_len; int32_t score_limit; uint32_t anchor;
+    uint64_t* pat_begin; uint32_t* pat_len; uint64_t* text_begin; uint32_t* text_len; int32_t* min_score;
+};
+__global__ void __launch_bounds__(256) anchor_score_setup_kernel(const AnchorSetupParams p)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= p.n) return;
+    const uint32_t read_id = p.hit_read_id[i], g_pos = p.hit_loc[i], read_rc = (p.hit_seed[i] >> 13) & 1u;
+    const uint32_t a_len = p.a_read_len ? p.a_read_len[read_id] : p.a_fixed_len, o_len = p.o_read_len ? p.o_read_len[read_id] : p.o_fixed_len;
+    const int32_t a_optimal = int32_t(a_len) * p.match, a_worst = p.min_score_by_len[a_len];
+    const int32_t o_optimal = int32_t(o_len) * p.match, o_worst = p.min_score_by_len[o_len];
+    auto ld = [](const uint2* q, uint32_t k) { const uint2 v = q[k]; IoAln a = { v.x, v.y }; return a; };
+    const IoBestPairs b = { ld(p.best, read_id), ld(p.best, read_id + p.best_stride), ld(p.best_o, read_id), ld(p.best_o, read_id + p.best_stride) };
+    const int32_t target_mate = max(target_pair_score(b, a_worst, o_worst, a_optimal, o_optimal) - o_optimal, a_worst);
+    const uint32_t gb = g_pos > p.band_len / 2u ? g_pos - p.band_len / 2u : 0u;
+    const uint32_t sum = gb + p.band_len + a_len;
+    const uint32_t ge = sum < p.genome_len ? sum : p.genome_len;
+    const uint32_t mate = p.anchor;
+    const bool skip = (mate == io_aln_mate(b.a1) && read_rc == io_aln_rc(b.a1) && g_pos == b.a1.align) ||
+                      (mate == io_aln_mate(b.o1) && read_rc == io_aln_rc(b.o1) && g_pos == b.o1.align) ||
+                      (mate == io_aln_mate(b.a2) && read_rc == io_aln_rc(b.a2) && g_pos == b.a2.align) ||
+                      (mate == io_aln_mate(b.o2) && read_rc == io_aln_rc(b.o2) && g_pos == b.o2.align);
+    p.text_begin[i] = gb;
+    p.text_len[i] = (skip || ge <= gb) ? 0u : ge - gb;
+    p.min_score[i] = skip ? 0x7FFFFFFF : max(target_mate, p.score_limit);
+    p.pat_begin[i] = (p.a_read_begin ? p.a_read_begin[read_id] : uint64_t(read_id) * p.a_fixed_len) + (read_rc ? p.rc_offset : 0ull);
+    if (p.pat_len) p.pat_len[i] = a_len;
+}
+// BestAnchorScoreStream::output (:137-150)
+__global__ void __launch_bounds__(256)
+anchor_score_finish_kernel(uint32_t n, const int32_t* __restrict__ raw_score, const uint2* __restrict__ raw_sink, const uint64_t* __restrict__ text_begin,
+                           const int32_t* __restrict__ min_score, int32_t worst_score, int32_t* __restrict__ hit_score, uint32_t* __restrict__ hit_sink)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const int32_t s = raw_score[i];
+    hit_score[i] = s >= min_score[i] ? s : worst_score;
+    hit_sink[i] = uint32_t(text_begin[i]) + raw_sink[i].x;
+}
+// BestOppositeScoreStream::output (score_opposite_inl.h:203-235) for the scored (valid) hits idx[k]; all other hits keep the
+// worst score the driver filled in (aligner_best_approx_paired.h:641-645)
+__global__ void __launch_bounds__(256)
+opposite_score_finish_kernel(uint32_t n_valid, const uint32_t* __restrict__ idx, const int32_t* __restrict__ raw_score, const uint2* __restrict__ raw_sink,
+                             const int32_t* __restrict__ min_score, const uint32_t* __restrict__ genome_begin, int32_t worst_score,
+                             int32_t* __restrict__ o_score, int32_t* __restrict__ o_score2, uint32_t* __restrict__ o_loc, uint32_t* __restrict__ o_sink, uint32_t* __restrict__ o_sink2)
+{
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= n_valid) return;
+    const uint32_t h = idx[k];
+    const int32_t s = raw_score[k];
+    const uint32_t gb = genome_begin[h], sx = raw_sink[k].x;
+    o_score[h] = s >= min_score[h] ? s : worst_score;
+    o_score2[h] = worst_score;
+    o_loc[h] = gb;
+    o_sink[h] = gb + (sx != 0xFFFFFFFFu ? sx : 0u);
+    o_sink2[h] = gb;
 }
 
 // ------------------------------------------------------------------ opposite-mate windows
@@ -213,13 +322,16 @@ struct OppositeParams {
     int32_t match; const int32_t* min_score_by_len; int32_t text_gap_open, text_gap_ext;
     int32_t pe_policy, min_frag_len, max_frag_len, pe_overlap, score_limit; uint32_t anchor, genome_length;
     uint8_t* out_valid; int32_t* out_min_score; uint8_t* out_read_rc; uint32_t* out_genome_begin; uint32_t* out_genome_end;
+    // the best-approx loop's form: strands from packed seeds, and only hits whose anchor score is not gate_worst are in the
+    // opposite queue (aligner_best_approx_paired.h:632-640)
+    const uint32_t* hit_seed; int32_t use_gate, gate_worst;
 };
 
 __global__ void __launch_bounds__(256) opposite_windows_kernel(const OppositeParams p)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= p.n_hits) return;
-    const uint32_t read_rc = p.hit_rc[i], read_id = p.hit_read_id[i], g_pos = p.hit_loc[i];
+    const uint32_t read_rc = p.hit_seed ? ((p.hit_seed[i] >> 13) & 1u) : p.hit_rc[i], read_id = p.hit_read_id[i], g_pos = p.hit_loc[i];
     const uint32_t a_len = p.a_read_len ? p.a_read_len[read_id] : p.a_fixed_len, o_len = p.o_read_len ? p.o_read_len[read_id] : p.o_fixed_len;
     const int32_t a_optimal = int32_t(a_len) * p.match, a_worst = p.min_score_by_len[a_len];
     const int32_t o_optimal = int32_t(o_len) * p.match, o_worst = p.min_score_by_len[o_len];
@@ -279,6 +391,7 @@ __global__ void __launch_bounds__(256) opposite_windows_kernel(const OppositePar
             valid = skip ? 0u : 1u;
         }
     }
+    if (p.use_gate && p.hit_score[i] == p.gate_worst) valid = 0u;
     p.out_valid[i] = uint8_t(valid); p.out_read_rc[i] = uint8_t(o_rc); p.out_genome_begin[i] = gb; p.out_genome_end[i] = ge;
 }
 
@@ -472,7 +585,7 @@ NVB_API int nvbio_hip_score_reduce_paired(uint32_t n_active, const uint32_t* rea
                              read_len, fixed_read_len, anchor, pe_policy, pe_unpaired, score_limit,
                              reinterpret_cast<uint2*>(best_alignments), reinterpret_cast<uint2*>(best_alignments_o), best_stride };
     g_last_kernel = "score_reduce_paired_kernel";
-    hipLaunchKernelGGL(score_reduce_paired_kernel, dim3((n_active + 255u) / 256u), dim3(256), 0, to_stream(stream), p);
+    hipLaunchKernelGGL(score_reduce_paired_kernel<false>, dim3((n_active + 255u) / 256u), dim3(256), 0, to_stream(stream), p);
     return hipGetLastError();
 }
 
@@ -509,5 +622,98 @@ NVB_API int nvbio_hip_opposite_mate_windows(uint32_t n_hits, const uint32_t* hit
                          out_valid, out_min_score, out_read_rc, out_genome_begin, out_genome_end };
     g_last_kernel = "opposite_windows_kernel";
     hipLaunchKernelGGL(opposite_windows_kernel, dim3((n_hits + 255u) / 256u), dim3(256), 0, to_stream(stream), p);
+    return hipGetLastError();
+}
+
+NVB_API int nvbio_hip_anchor_score_setup(uint32_t n_hits, const uint32_t* hit_read_id, const uint32_t* hit_loc, const uint32_t* hit_seed,
+    const uint64_t* a_read_begin, const uint32_t* a_read_len, const uint32_t* o_read_len, uint32_t a_fixed_len, uint32_t o_fixed_len, uint64_t rc_offset,
+    uint32_t band_len, uint32_t genome_length, const uint64_t* best_alignments, const uint64_t* best_alignments_o, uint32_t best_stride,
+    int32_t match, const int32_t* min_score_by_len, int32_t score_limit, uint32_t anchor,
+    uint64_t* pattern_begin, uint32_t* pattern_len, uint64_t* text_begin, uint32_t* text_len, int32_t* min_score, void* stream)
+{
+    if (n_hits == 0) return hipSuccess;
+    if (!hit_read_id || !hit_loc || !hit_seed || !best_alignments || !best_alignments_o || best_stride == 0 || !min_score_by_len || anchor > 1u ||
+        !pattern_begin || !text_begin || !text_len || !min_score) return hipErrorInvalidValue;
+    if ((!a_read_len && a_fixed_len == 0) || (!o_read_len && o_fixed_len == 0) || (a_read_len && !pattern_len)) return hipErrorInvalidValue;
+    AnchorSetupParams p = { n_hits, hit_read_id, hit_loc, hit_seed, a_read_begin, a_read_len, o_read_len, a_fixed_len, o_fixed_len, rc_offset,
+                            band_len, genome_length, reinterpret_cast<const uint2*>(best_alignments), reinterpret_cast<const uint2*>(best_alignments_o), best_stride,
+                            match, min_score_by_len, score_limit, anchor, pattern_begin, pattern_len, text_begin, text_len, min_score };
+    g_last_kernel = "anchor_score_setup_kernel";
+    hipLaunchKernelGGL(anchor_score_setup_kernel, dim3((n_hits + 255u) / 256u), dim3(256), 0, to_stream(stream), p);
+    return hipGetLastError();
+}
+
+NVB_API int nvbio_hip_anchor_score_finish(uint32_t n_hits, const int32_t* raw_score, const uint32_t* raw_sink, const uint64_t* text_begin,
+    const int32_t* min_score, int32_t worst_score, int32_t* hit_score, uint32_t* hit_sink, void* stream)
+{
+    if (n_hits == 0) return hipSuccess;
+    if (!raw_score || !raw_sink || !text_begin || !min_score || !hit_score || !hit_sink) return hipErrorInvalidValue;
+    g_last_kernel = "anchor_score_finish_kernel";
+    hipLaunchKernelGGL(anchor_score_finish_kernel, dim3((n_hits + 255u) / 256u), dim3(256), 0, to_stream(stream), n_hits, raw_score,
+                       reinterpret_cast<const uint2*>(raw_sink), text_begin, min_score, worst_score, hit_score, hit_sink);
+    return hipGetLastError();
+}
+
+NVB_API int nvbio_hip_opposite_score_setup(uint32_t n_hits, const uint32_t* hit_read_id, const uint32_t* hit_seed, const uint32_t* hit_loc, const int32_t* hit_score,
+    int32_t worst_score, const uint32_t* a_read_len, const uint32_t* o_read_len, uint32_t a_fixed_len, uint32_t o_fixed_len,
+    const uint64_t* best_alignments, const uint64_t* best_alignments_o, uint32_t best_stride,
+    int32_t match, const int32_t* min_score_by_len, int32_t text_gap_open, int32_t text_gap_ext, const nvbio_hip_pe_params* params,
+    uint8_t* out_valid, int32_t* out_min_score, uint8_t* out_read_rc, uint32_t* out_genome_begin, uint32_t* out_genome_end, void* stream)
+{
+    if (n_hits == 0) return hipSuccess;
+    if (!hit_read_id || !hit_seed || !hit_loc || !hit_score || !best_alignments || !best_alignments_o || best_stride == 0 || !min_score_by_len || !params ||
+        !out_valid || !out_min_score || !out_read_rc || !out_genome_begin || !out_genome_end) return hipErrorInvalidValue;
+    if ((!a_read_len && a_fixed_len == 0) || (!o_read_len && o_fixed_len == 0) || params->anchor > 1u || params->pe_policy < 0 || params->pe_policy > 3) return hipErrorInvalidValue;
+    OppositeParams p = { n_hits, hit_read_id, nullptr, hit_loc, hit_score, a_read_len, o_read_len, a_fixed_len, o_fixed_len,
+                         reinterpret_cast<const uint2*>(best_alignments), reinterpret_cast<const uint2*>(best_alignments_o), best_stride,
+                         match, min_score_by_len, text_gap_open, text_gap_ext,
+                         params->pe_policy, params->min_frag_len, params->max_frag_len, params->pe_overlap, params->score_limit, params->anchor, params->genome_length,
+                         out_valid, out_min_score, out_read_rc, out_genome_begin, out_genome_end, hit_seed, 1, worst_score };
+    g_last_kernel = "opposite_windows_kernel";
+    hipLaunchKernelGGL(opposite_windows_kernel, dim3((n_hits + 255u) / 256u), dim3(256), 0, to_stream(stream), p);
+    return hipGetLastError();
+}
+
+NVB_API int nvbio_hip_opposite_score_finish(uint32_t n_valid, const uint32_t* valid_idx, const int32_t* raw_score, const uint32_t* raw_sink,
+    const int32_t* min_score, const uint32_t* genome_begin, int32_t worst_score,
+    int32_t* opposite_score, int32_t* opposite_score2, uint32_t* opposite_loc, uint32_t* opposite_sink, uint32_t* opposite_sink2, void* stream)
+{
+    if (n_valid == 0) return hipSuccess;
+    if (!valid_idx || !raw_score || !raw_sink || !min_score || !genome_begin || !opposite_score || !opposite_score2 || !opposite_loc || !opposite_sink || !opposite_sink2)
+        return hipErrorInvalidValue;
+    g_last_kernel = "opposite_score_finish_kernel";
+    hipLaunchKernelGGL(opposite_score_finish_kernel, dim3((n_valid + 255u) / 256u), dim3(256), 0, to_stream(stream), n_valid, valid_idx, raw_score,
+                       reinterpret_cast<const uint2*>(raw_sink), min_score, genome_begin, worst_score, opposite_score, opposite_score2, opposite_loc, opposite_sink, opposite_sink2);
+    return hipGetLastError();
+}
+
+NVB_API int nvbio_hip_score_reduce_paired_best_approx(uint32_t n_active, const uint32_t* active_reads, const uint64_t* hit_begin,
+    const uint32_t* hit_loc, const uint32_t* hit_sink, const int32_t* hit_score, const uint32_t* hit_seed,
+    const uint32_t* opposite_loc, const uint32_t* opposite_sink, const uint32_t* opposite_sink2, const int32_t* opposite_score, const int32_t* opposite_score2,
+    const uint32_t* read_len, uint32_t fixed_read_len, uint32_t anchor, int32_t pe_policy, int32_t pe_unpaired, int32_t score_limit,
+    uint64_t* best_alignments, uint64_t* best_alignments_o, uint32_t best_stride,
+    uint32_t* trys, uint32_t* hit_counts, uint32_t n_ext, uint32_t min_ext, uint32_t max_ext, uint32_t max_effort, void* stream)
+{
+    if (n_active == 0) return hipSuccess;
+    if (!active_reads || !hit_begin || !hit_loc || !hit_sink || !hit_score || !hit_seed || !opposite_loc || !opposite_sink || !opposite_sink2 || !opposite_score ||
+        !opposite_score2 || !best_alignments || !best_alignments_o || best_stride == 0 || anchor > 1u || pe_policy < 0 || pe_policy > 3 || !trys || !hit_counts)
+        return hipErrorInvalidValue;
+    if (!read_len && fixed_read_len == 0) return hipErrorInvalidValue;
+    PairedReduceParams p = { n_active, active_reads, hit_begin, hit_loc, hit_sink, hit_score, nullptr, opposite_loc, opposite_sink, opposite_sink2, opposite_score, opposite_score2,
+                             read_len, fixed_read_len, anchor, pe_policy, pe_unpaired, score_limit,
+                             reinterpret_cast<uint2*>(best_alignments), reinterpret_cast<uint2*>(best_alignments_o), best_stride,
+                             hit_seed, trys, hit_counts, n_ext, min_ext, max_ext, max_effort };
+    g_last_kernel = "score_reduce_paired_kernel<ctx>";
+    hipLaunchKernelGGL(score_reduce_paired_kernel<true>, dim3((n_active + 255u) / 256u), dim3(256), 0, to_stream(stream), p);
+    return hipGetLastError();
+}
+
+NVB_API int nvbio_hip_mark_discordant(uint32_t n_reads, uint64_t* best_alignments, uint64_t* best_alignments_o, uint32_t best_stride, void* stream)
+{
+    if (n_reads == 0) return hipSuccess;
+    if (!best_alignments || !best_alignments_o || best_stride == 0) return hipErrorInvalidValue;
+    g_last_kernel = "mark_discordant_kernel";
+    hipLaunchKernelGGL(mark_discordant_kernel, dim3((n_reads + 255u) / 256u), dim3(256), 0, to_stream(stream), n_reads,
+                       reinterpret_cast<uint2*>(best_alignments), reinterpret_cast<uint2*>(best_alignments_o), best_stride);
     return hipGetLastError();
 }

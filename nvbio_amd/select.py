@@ -104,3 +104,76 @@ def score_reduce_best_approx(best, state, active, hit_begin, hit_score, hit_loc,
                                                    _vp(state.trys), _vp(state.counts), int(n_ext), int(min_ext), int(max_ext), int(max_effort),
                                                    current_stream_ptr()), "nvbio_hip_score_reduce_best_approx")
     return best
+
+
+# ---- the paired-end loop's stages (aligner_best_approx_paired.h:455-700) ------------------------------------------------
+def _min_score_table(scheme, max_len, dev):
+    return torch.tensor([scheme.min_score(L) if L > 0 else 0 for L in range(max_len + 1)], dtype=torch.int32, device=dev)
+
+
+def anchor_score_setup(hit_read_id, hit_loc, hit_seed, best, best_o, scheme, anchor, band_len, genome_len, score_limit, fixed_read_len,
+                       o_fixed_read_len, rc_offset, table=None):
+    """BestAnchorScoreStream::init_context -> (pattern_begin, text_begin, text_len, min_score)."""
+    n = hit_read_id.numel()
+    dev = hit_read_id.device
+    table = table if table is not None else _min_score_table(scheme, max(fixed_read_len, o_fixed_read_len), dev)
+    pb = torch.empty(n, dtype=torch.int64, device=dev); tb = torch.empty(n, dtype=torch.int64, device=dev)
+    tl = torch.empty(n, dtype=torch.int32, device=dev); ms = torch.empty(n, dtype=torch.int32, device=dev)
+    check(lib().nvbio_hip_anchor_score_setup(n, _vp(hit_read_id), _vp(hit_loc), _vp(hit_seed), None, None, None, int(fixed_read_len), int(o_fixed_read_len),
+                                             int(rc_offset), int(band_len), int(genome_len), _vp(best.data), _vp(best_o.data), best.stride,
+                                             int(scheme.m_match), _vp(table), int(score_limit), int(anchor), _vp(pb), None, _vp(tb), _vp(tl), _vp(ms),
+                                             current_stream_ptr()), "nvbio_hip_anchor_score_setup")
+    table.record_stream(torch.cuda.current_stream())
+    return pb, tb, tl, ms
+
+
+def anchor_score_finish(raw_score, raw_sink, text_begin, min_score, worst_score):
+    n = raw_score.numel()
+    hs = torch.empty(n, dtype=torch.int32, device=raw_score.device); hk = torch.empty(n, dtype=torch.int32, device=raw_score.device)
+    check(lib().nvbio_hip_anchor_score_finish(n, _vp(raw_score), _vp(raw_sink), _vp(text_begin), _vp(min_score), int(worst_score), _vp(hs), _vp(hk),
+                                              current_stream_ptr()), "nvbio_hip_anchor_score_finish")
+    return hs, hk
+
+
+def opposite_score_setup(hit_read_id, hit_seed, hit_loc, hit_score, worst_score, best, best_o, scheme, anchor, genome_len, fixed_read_len, o_fixed_read_len,
+                         pe_policy, min_frag_len, max_frag_len, pe_overlap, score_limit, table=None):
+    """BestOppositeScoreStream::init_context for the hits of the opposite queue -> dict(valid, min_score, read_rc, genome_begin, genome_end)."""
+    from ._lib import PeParamsStruct
+    n = hit_read_id.numel()
+    dev = hit_read_id.device
+    table = table if table is not None else _min_score_table(scheme, max(fixed_read_len, o_fixed_read_len), dev)
+    out = dict(valid=torch.empty(n, dtype=torch.uint8, device=dev), min_score=torch.empty(n, dtype=torch.int32, device=dev),
+               read_rc=torch.empty(n, dtype=torch.uint8, device=dev), genome_begin=torch.empty(n, dtype=torch.int32, device=dev),
+               genome_end=torch.empty(n, dtype=torch.int32, device=dev))
+    pp = PeParamsStruct(int(pe_policy), int(min_frag_len), int(max_frag_len), int(bool(pe_overlap)), int(score_limit), int(anchor), int(genome_len))
+    check(lib().nvbio_hip_opposite_score_setup(n, _vp(hit_read_id), _vp(hit_seed), _vp(hit_loc), _vp(hit_score), int(worst_score), None, None,
+                                               int(fixed_read_len), int(o_fixed_read_len), _vp(best.data), _vp(best_o.data), best.stride,
+                                               int(scheme.m_match), _vp(table), int(scheme.text_gap_open()), int(scheme.text_gap_extension()), C.byref(pp),
+                                               _vp(out["valid"]), _vp(out["min_score"]), _vp(out["read_rc"]), _vp(out["genome_begin"]), _vp(out["genome_end"]),
+                                               current_stream_ptr()), "nvbio_hip_opposite_score_setup")
+    table.record_stream(torch.cuda.current_stream())
+    return out
+
+
+def opposite_score_finish(valid_idx, raw_score, raw_sink, min_score, genome_begin, worst_score, n_hits):
+    """hit.opposite_* of a round: worst_score everywhere, BestOppositeScoreStream::output for the scored hits."""
+    dev = min_score.device
+    o_score = torch.full((n_hits,), worst_score, dtype=torch.int32, device=dev)
+    o_score2 = torch.full((n_hits,), worst_score, dtype=torch.int32, device=dev)
+    o_loc = torch.zeros(n_hits, dtype=torch.int32, device=dev); o_sink = torch.zeros(n_hits, dtype=torch.int32, device=dev); o_sink2 = torch.zeros(n_hits, dtype=torch.int32, device=dev)
+    check(lib().nvbio_hip_opposite_score_finish(valid_idx.numel(), _vp(valid_idx), _vp(raw_score), _vp(raw_sink), _vp(min_score), _vp(genome_begin), int(worst_score),
+                                                _vp(o_score), _vp(o_score2), _vp(o_loc), _vp(o_sink), _vp(o_sink2), current_stream_ptr()), "nvbio_hip_opposite_score_finish")
+    return o_score, o_score2, o_loc, o_sink, o_sink2
+
+
+def score_reduce_paired_best_approx(best, best_o, state, active, hit_begin, hit_loc, hit_sink, hit_score, hit_seed, o_loc, o_sink, o_sink2, o_score, o_score2,
+                                    anchor, pe_policy, pe_unpaired, score_limit, n_ext, min_ext, max_ext, max_effort, fixed_read_len):
+    check(lib().nvbio_hip_score_reduce_paired_best_approx(active.numel(), _vp(active), _vp(hit_begin), _vp(hit_loc), _vp(hit_sink), _vp(hit_score), _vp(hit_seed),
+                                                          _vp(o_loc), _vp(o_sink), _vp(o_sink2), _vp(o_score), _vp(o_score2), None, int(fixed_read_len),
+                                                          int(anchor), int(pe_policy), int(bool(pe_unpaired)), int(score_limit), _vp(best.data), _vp(best_o.data),
+                                                          best.stride, _vp(state.trys), _vp(state.counts), int(n_ext), int(min_ext), int(max_ext), int(max_effort),
+                                                          current_stream_ptr()), "nvbio_hip_score_reduce_paired_best_approx")
+
+
+def mark_discordant(best, best_o):
+    check(lib().nvbio_hip_mark_discordant(best.n, _vp(best.data), _vp(best_o.data), best.stride, current_stream_ptr()), "nvbio_hip_mark_discordant")

@@ -2172,36 +2172,41 @@ static int distinct_alns(io_aln_t p1, io_aln_t p2, uint32_t dist)
 {
     return distinct_alignments(p1.align + io_aln_sink(p1), io_aln_rc(p1), p2.align + io_aln_sink(p2), io_aln_rc(p2), dist);
 }
-static int try_update_pair(io_best_pairs_t* b, const io_pair_t* pair, uint32_t min_distance)
+/* tr (nullable): the read's try counter -- ReduceBestApproxContext::best_score / second_score refill it on every update */
+static int try_update_pair_ctx(io_best_pairs_t* b, const io_pair_t* pair, uint32_t min_distance, uint32_t* tr, uint32_t max_effort)
 {
     const int32_t score = pair_score(pair);
     const io_pair_t p0 = { b->a1, b->o1 }, p1 = { b->a2, b->o2 };
+    #define HOOK() do { if (tr) *tr = max_effort; } while (0)
     if (!distinct_pairs(&p0, pair, min_distance)) {
-        if (score > bp_best_score(b)) { b->a1 = pair->a; b->o1 = pair->o; }                         /* replace_best */
+        if (score > bp_best_score(b)) { HOOK(); b->a1 = pair->a; b->o1 = pair->o; }                         /* replace_best */
         return 1;
     } else if (!distinct_pairs(&p1, pair, min_distance)) {
-        if (score > bp_best_score(b)) { b->a2 = b->a1; b->o2 = b->o1; b->a1 = pair->a; b->o1 = pair->o; }     /* update_best */
-        else if (score > bp_second_score(b)) { b->a2 = pair->a; b->o2 = pair->o; }                  /* update_second */
+        if (score > bp_best_score(b)) { HOOK(); b->a2 = b->a1; b->o2 = b->o1; b->a1 = pair->a; b->o1 = pair->o; }     /* update_best */
+        else if (score > bp_second_score(b)) { HOOK(); b->a2 = pair->a; b->o2 = pair->o; }                  /* update_second */
         return 1;
     } else if (!bp_is_paired(b) || score > bp_best_score(b)) {
-        b->a2 = b->a1; b->o2 = b->o1; b->a1 = pair->a; b->o1 = pair->o; return 1;
+        HOOK(); b->a2 = b->a1; b->o2 = b->o1; b->a1 = pair->a; b->o1 = pair->o; return 1;
     } else if (!bp_has_second_paired(b) || score > bp_second_score(b)) {
-        b->a2 = pair->a; b->o2 = pair->o; return 1;
+        HOOK(); b->a2 = pair->a; b->o2 = pair->o; return 1;
     }
     return 0;
 }
-static int try_update_single(io_aln_t* a1, io_aln_t* a2, io_aln_t a, uint32_t min_distance)
+static int try_update_single_ctx(io_aln_t* a1, io_aln_t* a2, io_aln_t a, uint32_t min_distance, uint32_t* tr, uint32_t max_effort)
 {
-    if (!distinct_alns(*a1, a, min_distance)) { if (io_aln_score(a) > io_aln_score(*a1)) *a1 = a; return 1; }
+    if (!distinct_alns(*a1, a, min_distance)) { if (io_aln_score(a) > io_aln_score(*a1)) { HOOK(); *a1 = a; } return 1; }
     else if (!distinct_alns(*a2, a, min_distance)) {
-        if (io_aln_score(a) > io_aln_score(*a1)) { *a2 = *a1; *a1 = a; }
-        else if (io_aln_score(a) > io_aln_score(*a2)) *a2 = a;
+        if (io_aln_score(a) > io_aln_score(*a1)) { HOOK(); *a2 = *a1; *a1 = a; }
+        else if (io_aln_score(a) > io_aln_score(*a2)) { HOOK(); *a2 = a; }
         return 1;
     }
-    else if (io_aln_score(a) > io_aln_score(*a1)) { *a2 = *a1; *a1 = a; return 1; }
-    else if (io_aln_score(a) > io_aln_score(*a2)) { *a2 = a; return 1; }
+    else if (io_aln_score(a) > io_aln_score(*a1)) { HOOK(); *a2 = *a1; *a1 = a; return 1; }
+    else if (io_aln_score(a) > io_aln_score(*a2)) { HOOK(); *a2 = a; return 1; }
     return 0;
+    #undef HOOK
 }
+static int try_update_pair(io_best_pairs_t* b, const io_pair_t* pair, uint32_t min_distance) { return try_update_pair_ctx(b, pair, min_distance, NULL, 0); }
+static int try_update_single(io_aln_t* a1, io_aln_t* a2, io_aln_t a, uint32_t min_distance) { return try_update_single_ctx(a1, a2, a, min_distance, NULL, 0); }
 static void frame_opposite_mate(int policy, uint32_t anchor, int anchor_fw, int* left, int* fw)
 {   /* io::PairedEndPolicy: FF = 0, FR = 1, RF = 2, RR = 3 (nvbio/io/sequence/sequence.h:190-196) */
     const int anchor_1 = (anchor == 0);
@@ -2396,6 +2401,117 @@ ORACLE_API void oracle_mapq(int version, int32_t match, int min_type, float min_
         const float max_score = (float)((int32_t)read_len[r] * match), min_score = (float)simple_func(min_type, min_k, min_m, (int32_t)read_len[r]);
         out[r] = (uint8_t)(version == 3 ? mapq_v3(io_aln_score(a1), io_aln_aligned(a2), io_aln_score(a2), max_score, min_score, 0)
                                         : mapq_v2(io_aln_score(a1), io_aln_aligned(a2), io_aln_score(a2), max_score, min_score, monotone));
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* The per-round stages of nvBowtie's PAIRED best-approx loop                  */
+/*   (aligner_best_approx_paired.h:455-700)                                   */
+/*   BestAnchorScoreStream          score_paired_inl.h:54-150                 */
+/*   score_reduce_paired_kernel + ReduceBestApproxContext  reduce_inl.h:355-480 */
+/*   mark_discordant_kernel         aligner_init.cu:457-480                   */
+/* ------------------------------------------------------------------------ */
+static int32_t target_pair_score(const io_best_pairs_t* b, int32_t a_worst, int32_t o_worst, int32_t a_optimal, int32_t o_optimal)
+{
+    int32_t target;                                                             /* compute_target_score, alignment_utils.h:100-111 */
+    if (!bp_has_second_paired(b)) target = a_worst + o_worst;
+    else { const int32_t delta = bp_best_score(b) - bp_second_score(b); target = bp_second_score(b) + (delta * 3) / 4; }
+    const int32_t t1 = target + 1, t2 = a_optimal + o_optimal;
+    return t1 < t2 ? t1 : t2;
+}
+/* BestAnchorScoreStream::init_context: the anchor hit's genome window and score threshold.  A hit at a location already
+ * recorded in the read's best pairs is skipped: threshold INT32_MAX and (here) an empty window, so that the DP fails and
+ * the hit scores worst_score.  The reference's skip test also reads context->min_score before it is set (an
+ * uninitialised read, score_paired_inl.h:128); that term is taken as false. */
+ORACLE_API void oracle_anchor_score_setup(uint32_t n, const uint32_t* hit_read_id, const uint32_t* hit_loc, const uint32_t* hit_seed,
+    const uint32_t* a_read_len, const uint32_t* o_read_len, uint32_t band_len, uint32_t genome_len,
+    const uint64_t* best, const uint64_t* best_o, uint32_t best_stride, int32_t match, int min_type, float min_k, float min_m,
+    int32_t score_limit, uint32_t anchor, uint64_t* text_begin, uint32_t* text_len, int32_t* min_score)
+{
+    for (uint32_t i = 0; i < n; ++i)
+    {
+        const uint32_t read_id = hit_read_id[i], g_pos = hit_loc[i], read_rc = (hit_seed[i] >> 13) & 1u;
+        const uint32_t a_len = a_read_len[read_id], o_len = o_read_len[read_id];
+        const int32_t a_optimal = (int32_t)a_len * match, a_worst = simple_func(min_type, min_k, min_m, (int32_t)a_len);
+        const int32_t o_optimal = (int32_t)o_len * match, o_worst = simple_func(min_type, min_k, min_m, (int32_t)o_len);
+        const io_best_pairs_t b = { { (uint32_t)best[read_id], (uint32_t)(best[read_id] >> 32) }, { (uint32_t)best[read_id + best_stride], (uint32_t)(best[read_id + best_stride] >> 32) },
+                                    { (uint32_t)best_o[read_id], (uint32_t)(best_o[read_id] >> 32) }, { (uint32_t)best_o[read_id + best_stride], (uint32_t)(best_o[read_id + best_stride] >> 32) } };
+        int32_t target_mate = target_pair_score(&b, a_worst, o_worst, a_optimal, o_optimal) - o_optimal;
+        if (target_mate < a_worst) target_mate = a_worst;
+        const uint32_t gb = g_pos > band_len / 2 ? g_pos - band_len / 2 : 0u;
+        const uint32_t sum = gb + band_len + a_len;
+        const uint32_t ge = sum < genome_len ? sum : genome_len;
+        const int skip = (anchor == io_aln_mate(b.a1) && read_rc == io_aln_rc(b.a1) && g_pos == b.a1.align) ||
+                         (anchor == io_aln_mate(b.o1) && read_rc == io_aln_rc(b.o1) && g_pos == b.o1.align) ||
+                         (anchor == io_aln_mate(b.a2) && read_rc == io_aln_rc(b.a2) && g_pos == b.a2.align) ||
+                         (anchor == io_aln_mate(b.o2) && read_rc == io_aln_rc(b.o2) && g_pos == b.o2.align);
+        text_begin[i] = gb;
+        text_len[i] = (skip || ge <= gb) ? 0u : ge - gb;
+        min_score[i] = skip ? INT32_MAX : (target_mate > score_limit ? target_mate : score_limit);
+    }
+}
+/* BestAnchorScoreStream::output */
+ORACLE_API void oracle_anchor_score_finish(uint32_t n, const int32_t* raw_score, const uint32_t* raw_sink /* 2n */, const uint64_t* text_begin,
+    const int32_t* min_score, int32_t worst_score, int32_t* hit_score, uint32_t* hit_sink)
+{
+    for (uint32_t i = 0; i < n; ++i) {
+        hit_score[i] = raw_score[i] >= min_score[i] ? raw_score[i] : worst_score;
+        hit_sink[i] = (uint32_t)text_begin[i] + raw_sink[2 * i];
+    }
+}
+
+ORACLE_API void oracle_score_reduce_paired_best_approx(uint32_t n_active, const uint32_t* active, const uint64_t* hit_begin,
+    const uint32_t* hit_loc, const uint32_t* hit_sink, const int32_t* hit_score, const uint32_t* hit_seed,
+    const uint32_t* o_loc, const uint32_t* o_sink, const uint32_t* o_sink2, const int32_t* o_score, const int32_t* o_score2,
+    const uint32_t* read_len, uint32_t anchor, int pe_policy, int pe_unpaired, int32_t score_limit,
+    uint64_t* best, uint64_t* best_o, uint32_t best_stride,
+    uint32_t* trys, uint32_t* counts, uint32_t n_ext, uint32_t min_ext, uint32_t max_ext, uint32_t max_effort)
+{
+    #define LD(p, i) ((io_aln_t){ (uint32_t)(p)[i], (uint32_t)((p)[i] >> 32) })
+    #define ST(p, i, a) ((p)[i] = ((uint64_t)(a).align << 32) | (a).w)
+    for (uint32_t t = 0; t < n_active; ++t)
+    {
+        const uint32_t read_id = active[t] & 0x7FFFFFFFu;
+        io_best_pairs_t b = { LD(best, read_id), LD(best, read_id + best_stride), LD(best_o, read_id), LD(best_o, read_id + best_stride) };
+        const uint32_t min_distance = read_len[read_id] / 4;
+        const uint64_t hb = hit_begin[t];
+        for (uint64_t i = hb; i < hit_begin[t + 1]; ++i)
+        {
+            const uint32_t rc = (hit_seed[i] >> 13) & 1u, top_flag = (hit_seed[i] >> 14) & 1u;
+            int o_left, o_fw;
+            frame_opposite_mate(pe_policy, anchor, !rc, &o_left, &o_fw);
+            const uint32_t o_rc = !o_fw;
+            const io_pair_t pair  = { io_aln_make_full(hit_loc[i], hit_sink[i] - hit_loc[i], hit_score[i], rc, anchor, o_score[i] > score_limit),
+                                      io_aln_make_full(o_loc[i], o_sink[i] - o_loc[i], o_score[i], o_rc, !anchor, o_score[i] > score_limit) };
+            const io_pair_t pair2 = { io_aln_make_full(hit_loc[i], hit_sink[i] - hit_loc[i], hit_score[i], rc, anchor, o_score2[i] > score_limit),
+                                      io_aln_make_full(o_loc[i], o_sink2[i] - o_loc[i], o_score2[i], o_rc, !anchor, o_score2[i] > score_limit) };
+            int updated = 0;
+            if (io_aln_paired(pair.a)) {
+                if (try_update_pair_ctx(&b, &pair, min_distance, &trys[read_id], max_effort)) updated = 1;
+                if (io_aln_paired(pair2.a)) { if (try_update_pair_ctx(&b, &pair2, min_distance, &trys[read_id], max_effort)) updated = 1; }
+            } else if (pe_unpaired && !bp_is_paired(&b)) {
+                if (anchor ? try_update_single_ctx(&b.o1, &b.o2, pair.a, min_distance, &trys[read_id], max_effort)
+                           : try_update_single_ctx(&b.a1, &b.a2, pair.a, min_distance, &trys[read_id], max_effort)) updated = 1;
+            }
+            if (!updated && trys[read_id] > 0) {
+                const uint32_t idx = (uint32_t)(i - hb);
+                if (((n_ext + idx >= min_ext) && top_flag == 0 && --trys[read_id] == 0) || (n_ext + idx >= max_ext)) counts[read_id] = 0;
+            }
+        }
+        ST(best, read_id, b.a1); ST(best, read_id + best_stride, b.a2); ST(best_o, read_id, b.o1); ST(best_o, read_id + best_stride, b.o2);
+    }
+    #undef LD
+    #undef ST
+}
+
+ORACLE_API void oracle_mark_discordant(uint32_t n_reads, uint64_t* best, uint64_t* best_o, uint32_t stride)
+{
+    for (uint32_t r = 0; r < n_reads; ++r) {
+        const uint32_t w = (uint32_t)best[r];
+        const int concordant = ((w >> 30) & 1u) && !((w >> 31) & 1u);
+        const int aligned = (best[r] >> 32) != 0xFFFFFFFFu, second = (best[r + stride] >> 32) != 0xFFFFFFFFu;
+        const int o_aligned = (best_o[r] >> 32) != 0xFFFFFFFFu, o_second = (best_o[r + stride] >> 32) != 0xFFFFFFFFu;
+        if (!concordant && aligned && !second && o_aligned && !o_second) { best[r] |= 0xC0000000ull; best_o[r] |= 0xC0000000ull; }
     }
 }
 

@@ -730,6 +730,40 @@ def score_reduce_best_approx(best, active, hit_begin, hit_score, hit_loc, hit_se
     return best
 
 
+def anchor_score_setup(hit_read_id, hit_loc, hit_seed, a_read_len, o_read_len, band_len, genome_len, best, best_o, match, score_min, score_limit, anchor):
+    n = _u32(hit_read_id).size
+    tb = np.zeros(n, dtype=np.uint64); tl = np.zeros(n, dtype=np.uint32); ms = np.zeros(n, dtype=np.int32)
+    lib().oracle_anchor_score_setup(C.c_uint32(n), _p(_u32(hit_read_id)), _p(_u32(hit_loc)), _p(_u32(hit_seed)), _p(_u32(a_read_len)), _p(_u32(o_read_len)),
+                                    C.c_uint32(band_len), C.c_uint32(genome_len), _p(best), _p(best_o), C.c_uint32(best.shape[1]), C.c_int32(match),
+                                    C.c_int(score_min[0]), C.c_float(score_min[1]), C.c_float(score_min[2]), C.c_int32(score_limit), C.c_uint32(anchor),
+                                    _p(tb), _p(tl), _p(ms))
+    return tb, tl, ms
+
+
+def anchor_score_finish(raw_score, raw_sink, text_begin, min_score, worst_score):
+    n = raw_score.size
+    hs = np.zeros(n, dtype=np.int32); hk = np.zeros(n, dtype=np.uint32)
+    lib().oracle_anchor_score_finish(C.c_uint32(n), _p(np.ascontiguousarray(raw_score, dtype=np.int32)), _p(_u32(raw_sink)), _p(_u64(text_begin)),
+                                     _p(np.ascontiguousarray(min_score, dtype=np.int32)), C.c_int32(worst_score), _p(hs), _p(hk))
+    return hs, hk
+
+
+def score_reduce_paired_best_approx(best, best_o, active, hit_begin, hit_loc, hit_sink, hit_score, hit_seed, o_loc, o_sink, o_sink2, o_score, o_score2,
+                                    read_len, anchor, pe_policy, pe_unpaired, score_limit, trys, counts, n_ext, min_ext, max_ext, max_effort):
+    hb = _u64(hit_begin); n = hb.size - 1
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    lib().oracle_score_reduce_paired_best_approx(C.c_uint32(n), _p(_u32(active)), _p(hb), _p(_u32(hit_loc)), _p(_u32(hit_sink)), _p(i32(hit_score)), _p(_u32(hit_seed)),
+                                                 _p(_u32(o_loc)), _p(_u32(o_sink)), _p(_u32(o_sink2)), _p(i32(o_score)), _p(i32(o_score2)), _p(_u32(read_len)),
+                                                 C.c_uint32(anchor), C.c_int(pe_policy), C.c_int(int(pe_unpaired)), C.c_int32(score_limit), _p(best), _p(best_o),
+                                                 C.c_uint32(best.shape[1]), _p(trys), _p(counts), C.c_uint32(n_ext), C.c_uint32(min_ext), C.c_uint32(max_ext),
+                                                 C.c_uint32(max_effort))
+    return best, best_o
+
+
+def mark_discordant(best, best_o):
+    lib().oracle_mark_discordant(C.c_uint32(best.shape[1]), _p(best), _p(best_o), C.c_uint32(best.shape[1]))
+
+
 def score_reduce_paired(best, best_o, hit_begin, hit_loc, hit_sink, hit_score, hit_rc, o_loc, o_sink, o_sink2, o_score, o_score2,
                         read_len, anchor, pe_policy, pe_unpaired, score_limit, read_ids=None):
     hb = _u64(hit_begin); n = hb.size - 1

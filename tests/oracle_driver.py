@@ -88,3 +88,108 @@ def best_approx(host_fmi, host_rfmi, sym, genome_words, genome_len, params, sche
         r = O.batch_banded_gotoh_traceback(band, aln_type, sch6[:5], pat, txt, cigar_stride, mm_lut=lut, quals=quals)
         out.update(aligned_ids=ids, tb=r)
     return out
+
+
+def best_approx_paired(host_fmi, host_rfmi, sym1, sym2, genome_words, genome_len, params, scheme, names, aln_type, qual_value=30, cigar_stride=64):
+    """Aligner::best_approx for pairs (aligner_best_approx_paired.h:95-453, :455-700), numpy over the oracle."""
+    n, L = sym1.shape
+    band = band_length(params.max_dist)
+    packed = [pack_reads(sym1), pack_reads(sym2)]
+    quals = np.full(2 * n * L + 8, qual_value, np.uint8)
+    sch6, lut = qual_scheme(scheme)
+    read_len = np.full(n, L, np.uint32)
+    best = O.init_alignments(read_len, scheme.m_score_min, 0)
+    best_o = O.init_alignments(read_len, scheme.m_score_min, 1)
+    mp = params.mapping_params()
+    sf = mp.seed_freq_table(L, "cpu").numpy().view(np.uint32)
+    arena, idx = O.pack_names(names)
+    stride = params.hits_stride or min(params.max_hits, 128)
+    algorithm = 0 if not params.allow_sub else (2 if params.subseed_len == 0 else 1)
+    stats = dict(extensions=0, opposite_extensions=0, rounds=0, seeding_passes=0, queue=[])
+    for anchor in (0, 1):
+        queue = np.arange(n, dtype=np.uint32)
+        fw_strand = params.pe_policy in (0, 1) if anchor == 0 else params.pe_policy in (0, 2)
+        fw, rc = (params.fw, params.rc) if fw_strand else (params.rc, params.fw)
+        reads_rev, a_words = packed[anchor]
+        o_words = packed[1 - anchor][1]
+        for seeding_pass in range(params.max_reseed + 1):
+            if queue.size == 0:
+                break
+            stats["queue"].append(int(queue.size)); stats["seeding_passes"] += 1
+            pd = dict(seed_len=mp.seed_len, min_read_len=mp.min_read_len, max_hits=mp.max_hits, max_reseed=mp.max_reseed, retry=seeding_pass,
+                      rep_seeds=mp.rep_seeds, fw=int(fw), rc=int(rc))
+            hits, counts, reseed = O.map_seeds(algorithm, params.subseed_len, host_fmi, host_rfmi, reads_rev, pd, sf, stride, in_queue=queue)
+            probs, trys, rseeds = O.select_init(hits, counts, arena if params.randomized else None, idx if params.randomized else None,
+                                                params.max_effort_init, params.randomized, params.top_seed)
+            active = queue | np.uint32((params.top_seed & 1) << 31)
+            n_ext = 0
+            while active.size and n_ext < params.max_ext:
+                n_multi = 1
+                if active.size <= params.batch_size // 2 and not params.no_multi_hits:
+                    n_multi = min(params.batch_size // active.size, min(4096, params.max_ext - n_ext))
+                active, hit_begin, rid, loc, seed = O.select(params.randomized, n_multi, active, hits, counts, probs, rseeds, trys)
+                if active.size == 0:
+                    break
+                loc = O.locate_hits(host_fmi, host_rfmi, loc, seed)
+                rcb = ((seed >> 13) & 1).astype(np.uint8)
+                # anchor_score_best
+                tb, tl, ms = O.anchor_score_setup(rid, loc, seed, read_len, read_len, band, genome_len, best, best_o, scheme.m_match, scheme.m_score_min, WORST_SCORE, anchor)
+                pat = O.StringSet(a_words, 4, True, rid.astype(np.uint64) * L + rcb.astype(np.uint64) * (n * L), np.full(rid.size, L, np.uint32))
+                raw, raw_sink = O.batch_banded_gotoh_score_qual(band, aln_type, sch6, lut, quals, pat, O.StringSet(genome_words, 2, True, tb, tl))
+                hit_score, hit_sink = O.anchor_score_finish(raw, raw_sink, tb, ms, WORST_SCORE)
+                # opposite_score_best over the hits whose anchor scored
+                ow = O.opposite_windows(rid, rcb, loc, hit_score, read_len, read_len, best, best_o, scheme.m_match, scheme.m_score_min, scheme.text_gap_open(),
+                                        scheme.text_gap_extension(), params.pe_policy, params.min_frag_len, params.max_frag_len, params.pe_overlap, WORST_SCORE,
+                                        anchor, genome_len)
+                valid = (ow["valid"] != 0) & (hit_score != WORST_SCORE)
+                k = np.nonzero(valid)[0]
+                o_score = np.full(rid.size, WORST_SCORE, np.int32); o_score2 = o_score.copy()
+                o_loc = np.zeros(rid.size, np.uint32); o_sink = np.zeros(rid.size, np.uint32); o_sink2 = np.zeros(rid.size, np.uint32)
+                if k.size:
+                    ob, oe = ow["genome_begin"][k].astype(np.uint64), ow["genome_end"][k].astype(np.uint64)
+                    o_pat = O.StringSet(o_words, 4, True, rid[k].astype(np.uint64) * L + ow["read_rc"][k].astype(np.uint64) * (n * L), np.full(k.size, L, np.uint32))
+                    o_txt = O.StringSet(genome_words, 2, True, ob, (oe - ob).astype(np.uint32))
+                    s_o, k_o, _ = O.batch_gotoh_score_qual(0, aln_type, sch6[:5], lut, quals, o_pat, o_txt, min_score=ow["min_score"][k])
+                    o_score[k] = np.where(s_o >= ow["min_score"][k], s_o, WORST_SCORE)
+                    sx = k_o.reshape(-1, 2)[:, 0]
+                    o_loc[k] = ob.astype(np.uint32)
+                    o_sink[k] = (ob + np.where(sx == 0xFFFFFFFF, 0, sx)).astype(np.uint32)
+                    o_sink2[k] = ob.astype(np.uint32)
+                O.score_reduce_paired_best_approx(best, best_o, active, hit_begin, loc, hit_sink, hit_score, seed, o_loc, o_sink, o_sink2, o_score, o_score2,
+                                                  read_len, anchor, params.pe_policy, params.pe_unpaired, WORST_SCORE, trys, counts, n_ext,
+                                                  params.min_ext, params.max_ext, params.max_effort)
+                stats["extensions"] += int(loc.size); stats["opposite_extensions"] += int(k.size); stats["rounds"] += 1
+                n_ext += n_multi
+            queue = queue[reseed != 0]
+    if params.pe_discordant:
+        O.mark_discordant(best, best_o)
+    mapq1 = O.mapq_paired(2, scheme.m_match, scheme.m_score_min, scheme.m_monotone, best, best_o, read_len, read_len)
+    mapq2 = O.mapq_paired(2, scheme.m_match, scheme.m_score_min, scheme.m_monotone, best_o, best, read_len, read_len)
+    out = dict(best=best, best_o=best_o, mapq1=mapq1, mapq2=mapq2, stats=stats)
+    mate_words = (packed[0][1], packed[1][1])
+
+    def trace(data, ids, full):
+        res = dict(cigar=np.zeros((n, cigar_stride), np.uint16), cigar_len=np.zeros(n, np.uint32), source=np.full((n, 2), 0xFFFFFFFF, np.uint32),
+                   sink=np.full((n, 2), 0xFFFFFFFF, np.uint32), score=np.full(n, WORST_SCORE, np.int32))
+        for i in ids:
+            w = int(data[0][i])
+            align, rcb, mate, g_len = w >> 32, (w >> 28) & 1, (w >> 29) & 1, (w >> 18) & 0x3FF
+            pat = O.StringSet(mate_words[mate], 4, True, np.array([i * L + rcb * n * L], np.uint64), np.array([L], np.uint32))
+            if full(i):
+                tb0, tb1 = align, min(align + g_len, genome_len)
+                r = O.batch_gotoh_traceback(aln_type, sch6[:5], pat, O.StringSet(genome_words, 2, True, np.array([tb0], np.uint64), np.array([tb1 - tb0], np.uint32)),
+                                            cigar_stride, mm_lut=lut, quals=quals)
+            else:
+                tb0 = max(align - band // 2, 0); tb1 = min(tb0 + L + band, genome_len)
+                r = O.batch_banded_gotoh_traceback(band, aln_type, sch6[:5], pat, O.StringSet(genome_words, 2, True, np.array([tb0], np.uint64), np.array([tb1 - tb0], np.uint32)),
+                                                   cigar_stride, mm_lut=lut, quals=quals)
+            for key in ("cigar", "cigar_len", "source", "sink", "score"):
+                res[key][i] = r[key][0]
+        return res
+
+    aligned = lambda d: (d[0] >> np.uint64(32)) != np.uint64(0xFFFFFFFF)
+    out["tb1"] = trace(best, np.nonzero(aligned(best))[0], lambda i: False)
+    w_o = best_o[0]
+    conc = (((w_o >> np.uint64(30)) & np.uint64(1)) != 0) & (((w_o >> np.uint64(31)) & np.uint64(1)) == 0)
+    out["tb2"] = trace(best_o, np.nonzero(aligned(best_o))[0], lambda i: bool(conc[i]))
+    return out

@@ -213,3 +213,83 @@ def test_best_approx_driver_matches_oracle(cuda, config):
     # the traceback re-derives the score the extension stage recorded
     sc = np.where(best0 & np.uint64(1), -((best0 >> np.uint64(1)) & np.uint64(0x1FFFF)).astype(np.int64), ((best0 >> np.uint64(1)) & np.uint64(0x1FFFF)).astype(np.int64))
     assert (tb["score"] == sc[ids]).all()
+
+
+def _pairs(rng, text, n, L, frag=(200, 420)):
+    """FR pairs: mate 1 forward at the fragment's left end, mate 2 reverse-complement at its right end; substitutions, some indels,
+    some pairs with an unalignable or a far-away (discordant) mate"""
+    s1 = np.zeros((n, L), np.uint8); s2 = np.zeros((n, L), np.uint8)
+    pos = np.zeros(n, np.int64); flen = np.zeros(n, np.int64)
+    for i in range(n):
+        f = int(rng.integers(frag[0], frag[1]))
+        p = int(rng.integers(0, text.size - f - 2000))
+        a = text[p:p + L].copy()
+        q = p + f - L if i % 23 else p + 1500                       # every 23rd pair: mate 2 far away (no concordant placement)
+        b = text[q:q + L].copy()
+        for r, k in ((a, [0, 1, 2, 5][i % 4]), (b, [1, 0, 4, 2][i % 4])):
+            for j in rng.integers(0, L, k):
+                r[j] = (r[j] + 1 + rng.integers(0, 3)) & 3
+        if i % 9 == 0:
+            d = int(rng.integers(20, L - 20)); b = np.concatenate([b[:d], b[d + 1:], rng.integers(0, 4, 1, dtype=np.uint8)])
+        if i % 17 == 0:
+            b = rng.integers(0, 4, L, dtype=np.uint8)                  # mate 2 unalignable: mate 1 must still be reported (mixed mode)
+        if i % 31 == 0:
+            a = rng.integers(0, 4, L, dtype=np.uint8); b = rng.integers(0, 4, L, dtype=np.uint8)
+        s1[i] = a; s2[i] = np.where(b > 3, b, 3 - b)[::-1]
+        pos[i] = p; flen[i] = f
+    return s1, s2, pos, flen
+
+
+PAIRED_CONFIGS = {
+    "default": dict(),
+    "no_rand_local": dict(randomized=False, local=True, seed_len=20, seed_freq=(2, 1.0, 0.75)),
+    "one_hit_rounds": dict(batch_size=600),
+    "multi_rounds_no_mixed": dict(batch_size=3000, pe_unpaired=False, pe_discordant=False),
+    "low_effort_subseed": dict(max_effort=3, max_effort_init=3, min_ext=4, max_ext=40, allow_sub=1, subseed_len=12, max_reseed=1),
+    "ff_policy": dict(pe_policy=0, max_frag_len=450),
+}
+
+
+@pytest.mark.parametrize("config", sorted(PAIRED_CONFIGS))
+def test_best_approx_paired_driver_matches_oracle(cuda, config):
+    """Aligner::best_approx for pairs -- per anchor mate: seeding passes, selection rounds, anchor extension with pair-aware thresholds,
+    opposite-mate windows + full-matrix scoring, paired reduction with give-up counters; then discordant marking, both MAPQs and the
+    anchor / opposite tracebacks -- vs the independent numpy driver over the oracle."""
+    rng = np.random.default_rng(321)
+    text = _small_index(rng, 1 << 17)
+    host, rhost = O.FMIndex(text), O.FMIndex(text[::-1].copy())
+    fmi, rfmi = nvb.FMIndexDevice.from_host(host, cuda), nvb.FMIndexDevice.from_host(rhost, cuda)
+    n, L = 700, 100
+    s1, s2, pos, flen = _pairs(rng, text, n, L)
+    if PAIRED_CONFIGS[config].get("pe_policy") == 0:                   # FF: both mates forward
+        s2 = np.where(s2 > 3, s2, 3 - s2)[:, ::-1].copy()
+    names = ["pair.%d" % i for i in range(n)]
+    params = A.Params(**PAIRED_CONFIGS[config])
+    scheme = nvb.SmithWatermanScoringScheme.local() if params.local else nvb.SmithWatermanScoringScheme()
+    gw = W._pack_chunked(torch.from_numpy(text), 2, True)
+    e = OD.best_approx_paired(host, rhost, s1, s2, gw.numpy().view(np.uint32), text.size, params, scheme, names, 1 if params.local else 2)
+    r = A.best_approx_paired(fmi, rfmi, torch.from_numpy(s1).to(cuda), torch.from_numpy(s2).to(cuda), gw.to(cuda), text.size, params, scheme, names)
+    torch.cuda.synchronize()
+    assert r["stats"] == e["stats"], (r["stats"], e["stats"])
+    for key in ("best", "best_o"):
+        assert (r[key].cpu().numpy().view(np.uint64) == e[key]).all(), key
+    assert (r["mapq1"].cpu().numpy() == e["mapq1"]).all() and (r["mapq2"].cpu().numpy() == e["mapq2"]).all()
+    for slot in ("tb1", "tb2"):
+        for key in ("cigar_len", "cigar", "source", "sink", "score"):
+            got = r[slot][key].cpu().numpy()
+            assert (got.view(e[slot][key].dtype) == e[slot][key]).all(), (slot, key)
+    # the result itself: most pairs come back concordant at their fragment's two ends
+    b, bo = e["best"][0], e["best_o"][0]
+    paired = ((b >> np.uint64(30)) & np.uint64(1)) != 0
+    disc = ((b >> np.uint64(31)) & np.uint64(1)) != 0
+    conc = paired & ~disc
+    a_pos = (b >> np.uint64(32)).astype(np.int64)
+    good = conc & ((np.abs(a_pos - pos) <= 4) | (np.abs(a_pos - (pos + flen - L)) <= 4))
+    expect = (np.arange(n) % 23 != 0) & (np.arange(n) % 17 != 0) & (np.arange(n) % 31 != 0)
+    assert good[expect].mean() >= 0.8, (good[expect].mean(), conc.mean())
+    assert e["stats"]["opposite_extensions"] > n // 2
+    if params.pe_unpaired:
+        lone = (np.arange(n) % 17 == 0) & (np.arange(n) % 31 != 0)
+        assert (((b[lone] >> np.uint64(32)) != np.uint64(0xFFFFFFFF)) & ~paired[lone]).mean() >= 0.5     # mate 1 reported alone
+    if params.pe_discordant and params.pe_unpaired:
+        assert disc.sum() >= 1
