@@ -659,9 +659,39 @@ def extras_leg(a, dev):
     ba["parity"] = {"checked_reads": m, "best_mapq_cigar_stats_equal": ok}
     ba["stages"] = "per seeding pass: map -> select_init -> rounds of {select, locate, banded extend (quality-aware scheme), score_reduce + give-up counters}; mark_unaligned / re-seed queue; BowtieMapq2; banded traceback"
     out["best_approx_single_end"] = ba
-    # ---- BASELINE config 5's shape on one GPU: 2 x 150 bp FR pairs, LOCAL band 31 in nvBowtie's local scheme
+    # ---- BASELINE config 5 under nvBowtie's own paired-end driver: 2 x 150 bp FR pairs, --local (20-bp seeds, LOCAL band 31 in the
+    # quality-aware local scheme), opposite mates by full-matrix DP in their fragment windows, paired reduction, discordant marking,
+    # MAPQ per mate, anchor (banded) and opposite (full-matrix) tracebacks
     npairs = 500_000
     s1, s2, ppos, pflen = P.make_read_pairs(text, npairs, 150, seed=0x5EED0009)
+    pnames = SEL.pack_names(["p%d" % i for i in range(npairs)], dev)
+    bp = {}
+    for cname, kw in (("local_default", dict(local=True, seed_len=20, seed_freq=(2, 1.0, 0.75))), ("end_to_end", dict())):
+        prm = AL.Params(hits_stride=32, batch_size=npairs, **kw)
+        run = lambda st=False: AL.best_approx_paired(fmi, rfmi, s1, s2, genome_words, ng, prm, names=pnames, stage_times=st)
+        ms = _timed(run, reps=2)
+        r = run(True)
+        b0 = r["best"][0]
+        paired = ((b0 >> 30) & 1) != 0
+        conc = paired & (((b0 >> 31) & 1) == 0)
+        a_pos = (b0 >> 32) & 0xFFFFFFFF
+        ok_pos = (((a_pos - ppos).abs() <= 3) | ((a_pos - (ppos + pflen - 150)).abs() <= 3)) & conc
+        bp[cname] = {"pairs": npairs, "ms_per_batch": ms, "Mpairs_per_s": npairs / ms / 1e3, "anchor_extensions": r["stats"]["extensions"],
+                     "opposite_extensions": r["stats"]["opposite_extensions"], "rounds": r["stats"]["rounds"], "queue_per_seeding_pass": r["stats"]["queue"],
+                     "concordant": float(conc.float().mean().item()), "concordant_at_fragment_end": float(ok_pos.float().mean().item()),
+                     "mapq1_ge_23": float((r["mapq1"] >= 23).float().mean().item()), "stage_ms": {k: round(v, 3) for k, v in r["stats"]["ms"].items()}}
+    m = 600
+    prm = AL.Params(hits_stride=32, batch_size=m, local=True, seed_len=20, seed_freq=(2, 1.0, 0.75))
+    nm = ["p%d" % i for i in range(m)]
+    rs = AL.best_approx_paired(fmi, rfmi, s1[:m].contiguous(), s2[:m].contiguous(), genome_words, ng, prm, names=nm)
+    es = OD.best_approx_paired(hostf, hostr, s1[:m].cpu().numpy(), s2[:m].cpu().numpy(), genome_words.cpu().numpy().view(np.uint32), ng, prm,
+                               nvb.SmithWatermanScoringScheme.local(), nm, 1)
+    ok = bool(all((rs[k].cpu().numpy().view(np.uint64) == es[k]).all() for k in ("best", "best_o")) and (rs["mapq1"].cpu().numpy() == es["mapq1"]).all()
+              and (rs["mapq2"].cpu().numpy() == es["mapq2"]).all() and rs["stats"] == es["stats"]
+              and all((rs[sl]["cigar"].cpu().numpy().view(np.uint16) == es[sl]["cigar"]).all() for sl in ("tb1", "tb2")))
+    bp["parity"] = {"checked_pairs": m, "best_mapq_cigar_stats_equal": ok}
+    out["best_approx_paired_end"] = bp
+    # ---- the same shape through the earlier stage composition (every located placement extended, no selection policy)
     mp20 = nvb.MappingParams(seed_len=20)                                    # nvBowtie --local: 20-bp seeds
     be2 = P.HipBackend(fmi, None, mp20, 150)
     ms = _timed(lambda: P.align_paired_end(be2, s1, s2, genome_words, ng), reps=2)
