@@ -302,6 +302,28 @@ def e2e_leg(a, dev, fmi, text):
         else:
             res[name]["identical_to_reference_layout"] = bool(torch.equal(score, ref_score) and torch.equal(bpos, ref_pos))
         del idx, be
+    # the same batch through nvBowtie's own single-end driver (Aligner::best_approx: seeding passes, randomized hit selection,
+    # band-31 quality-aware extension, give-up counters, re-seeding, MAPQ, traceback) -- the reference's policy end to end
+    from nvbio_amd import aligner as AL, select as SEL
+    names = SEL.pack_names(["r%d" % i for i in range(n)], dev)
+    prm = AL.Params(hits_stride=16, batch_size=n)
+    for name, idx in (("nvbowtie_best_approx", fmi), ("nvbowtie_best_approx_ktab12_ssa1", None)):
+        if idx is None:
+            idx = fmi.with_ktab(12).with_dense_ssa(1)
+        run = lambda st=False: AL.best_approx(idx, None, sym, genome_words, ng, prm, names=names, packed=packed, stage_times=st)
+        ms = _timed(run, reps=2)
+        r = run(True)
+        loc = (r["best"][0] >> 32) & 0xFFFFFFFF
+        aligned = loc != 0xFFFFFFFF
+        res[name] = {"ms_per_batch": ms, "Mreads_per_s": n / ms / 1e3, "extensions": r["stats"]["extensions"], "rounds": r["stats"]["rounds"],
+                     "queue_per_seeding_pass": r["stats"]["queue"], "aligned": float(aligned.float().mean().item()),
+                     "best_at_true_position": float((aligned & ((loc - pos).abs() <= 2)).float().mean().item()),
+                     "mapq_ge_23": float((r["mapq"] >= 23).float().mean().item()), "stage_ms": {k: round(v, 3) for k, v in r["stats"]["ms"].items()}}
+        if name == "nvbowtie_best_approx":
+            ref_best, ref_mapq, ref_cigar = r["best"], r["mapq"], r["cigar"]
+        else:
+            res[name]["identical_to_reference_layout"] = bool(torch.equal(r["best"], ref_best) and torch.equal(r["mapq"], ref_mapq) and torch.equal(r["cigar"], ref_cigar))
+        del idx, r
     # exact check of a sample against the same glue over the oracle
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_pipeline_gpu import OracleBackend
@@ -314,6 +336,19 @@ def e2e_leg(a, dev, fmi, text):
     if not ok:
         raise SystemExit("parity gate failed: end-to-end driver differs from the oracle")
     res["parity"] = {"checked_reads": m, "bit_exact": ok}
+    # ... and of the nvBowtie driver: 2000 reads as their own batch vs the independent numpy driver over the oracle
+    import oracle_driver as OD
+    m2 = 2000
+    prm2 = AL.Params(hits_stride=16, batch_size=m2)
+    nm = ["r%d" % i for i in range(m2)]
+    rs = AL.best_approx(fmi, None, sym[:m2].contiguous(), genome_words, ng, prm2, names=nm, cigar_stride=64)
+    es2 = OD.best_approx(host, None, sym[:m2].cpu().numpy(), genome_words.cpu().numpy().view(np.uint32), ng, prm2, nvb.SmithWatermanScoringScheme(), nm, 2)
+    ids = rs["aligned_ids"].cpu().numpy()
+    ok2 = bool((rs["best"].cpu().numpy().view(np.uint64) == es2["best"]).all() and (rs["mapq"].cpu().numpy() == es2["mapq"]).all()
+               and (rs["cigar"].cpu().numpy()[ids].view(np.uint16) == es2["tb"]["cigar"][: ids.size]).all() and rs["stats"] == es2["stats"])
+    if not ok2:
+        raise SystemExit("parity gate failed: nvBowtie single-end driver differs from the oracle driver")
+    res["parity"]["nvbowtie_driver"] = {"checked_reads": m2, "best_mapq_cigar_stats_equal": ok2}
     res["reads"] = n
     res["genome_symbols"] = ng
     return res

@@ -109,8 +109,16 @@ def best_approx_score(fmi, rfmi, state, seed_queue, best, reads_fw_rc, n_reads, 
         n_ext += n_multi
 
 
+def _qual_stream(n, L, qual_value, quals, dev):
+    """One quality byte per pattern symbol, laid out like the fw + rc pattern words (the rc copy's qualities reversed)."""
+    if quals is None:
+        return torch.full((2 * n * L + 8,), qual_value, dtype=torch.uint8, device=dev)
+    q = quals.to(dev).to(torch.uint8).reshape(n, L)
+    return torch.cat([q.reshape(-1), q.flip(1).reshape(-1), torch.zeros(8, dtype=torch.uint8, device=dev)])
+
+
 def best_approx(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=None, names=None, qual_value=30, traceback=True,
-                cigar_stride=None, stage_times=False, packed=None):
+                cigar_stride=None, stage_times=False, packed=None, quals=None):
     """Aligner::best_approx for a batch of equal-length reads `sym` (uint8 [n, L], symbols 0..4).  `names`: list of read
     names (they seed the randomized selection).  Returns dict(best int64[2,n] io::Alignment words, mapq uint8[n], and with
     traceback: cigar int16[n,stride], cigar_len, source, sink (-1 for unaligned reads), stats)."""
@@ -122,7 +130,7 @@ def best_approx(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=No
     aligner = make_gotoh_aligner(LOCAL if params.local else SEMI_GLOBAL, scheme)
     band_len = band_length(params.max_dist)
     reads_rev, reads_fw_rc = packed if packed is not None else pack_read_streams(sym)
-    quals = torch.full((2 * n * L + 8,), qual_value, dtype=torch.uint8, device=dev)
+    quals = _qual_stream(n, L, qual_value, quals, dev)                      # `quals`: uint8 [n, L] Phred values, or None
     if not params.randomized:
         name_arena = None
     elif isinstance(names, tuple):                       # already packed: (uint8 arena, int32 index[n+1]) on the device

@@ -20,12 +20,13 @@ def sum_tree_node_count(size):
 
 def pack_names(names, device):
     """NUL-terminated names -> (uint8 arena, int32 index[n+1]) as SequenceData keeps them (name_stream / name_index)."""
-    blob = b"".join(nm.encode() + b"\0" for nm in names)
-    idx = [0]
-    for nm in names:
-        idx.append(idx[-1] + len(nm) + 1)
-    return (torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device),
-            torch.tensor(idx, dtype=torch.int64).to(torch.int32).to(device))
+    import numpy as np
+    blob = ("\0".join(names) + "\0").encode() if len(names) else b""
+    idx = np.zeros(len(names) + 1, dtype=np.int64)
+    if len(names):
+        idx[1:] = np.cumsum(np.fromiter((len(nm.encode()) if not nm.isascii() else len(nm) for nm in names), dtype=np.int64, count=len(names)) + 1)
+    return (torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device) if blob else torch.zeros(0, dtype=torch.uint8, device=device),
+            torch.from_numpy(idx).to(torch.int32).to(device))
 
 
 class SelectState:

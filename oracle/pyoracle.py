@@ -672,7 +672,7 @@ def pack_names(names):
     """(char arena uint8[], index uint32[n+1]) of NUL-terminated read names, as SequenceData keeps them."""
     blob = b"".join(nm.encode() + b"\0" for nm in names)
     idx = np.zeros(len(names) + 1, dtype=np.uint32)
-    idx[1:] = np.cumsum([len(nm) + 1 for nm in names])
+    idx[1:] = np.cumsum([len(nm.encode()) + 1 for nm in names])
     return np.frombuffer(blob, dtype=np.uint8).copy(), idx
 
 

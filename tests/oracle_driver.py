@@ -31,11 +31,15 @@ def qual_scheme(scheme):
     return (st.match, st.pattern_gap_open, st.pattern_gap_ext, st.text_gap_open, st.text_gap_ext, 0), np.array([st.mismatch[q] for q in range(256)], np.int32)
 
 
-def best_approx(host_fmi, host_rfmi, sym, genome_words, genome_len, params, scheme, names, aln_type, qual_value=30, traceback=True, cigar_stride=64):
+def best_approx(host_fmi, host_rfmi, sym, genome_words, genome_len, params, scheme, names, aln_type, qual_value=30, traceback=True, cigar_stride=64,
+                read_quals=None):
     n, L = sym.shape
     band = band_length(params.max_dist)
     reads_rev, ext_words = pack_reads(sym)
     quals = np.full(2 * n * L + 8, qual_value, np.uint8)
+    if read_quals is not None:
+        q = np.asarray(read_quals, np.uint8).reshape(n, L)
+        quals = np.concatenate([q.reshape(-1), q[:, ::-1].reshape(-1), np.zeros(8, np.uint8)])
     sch6, lut = qual_scheme(scheme)
     read_len = np.full(n, L, np.uint32)
     best = O.init_alignments(read_len, scheme.m_score_min)

@@ -171,6 +171,7 @@ CONFIGS = {
     "one_mismatch_seeds": dict(allow_sub=1, seed_len=20, max_hits=30),
     "subseed": dict(allow_sub=1, subseed_len=12, max_reseed=1),
     "local": dict(local=True, seed_len=20, seed_freq=(2, 1.0, 0.75)),
+    "read_quals": dict(),                                        # per-base Phred qualities instead of a constant
 }
 
 
@@ -189,8 +190,10 @@ def test_best_approx_driver_matches_oracle(cuda, config):
     params = A.Params(**CONFIGS[config])
     scheme = nvb.SmithWatermanScoringScheme.local() if params.local else nvb.SmithWatermanScoringScheme()
     gw = W._pack_chunked(torch.from_numpy(text), 2, True)
-    e = OD.best_approx(host, rhost, sym, gw.numpy().view(np.uint32), text.size, params, scheme, names, 1 if params.local else 2)
-    r = A.best_approx(fmi, rfmi, torch.from_numpy(sym).to(cuda), gw.to(cuda), text.size, params, scheme, names, cigar_stride=64)
+    rq = rng.integers(2, 42, (n, L)).astype(np.uint8) if config == "read_quals" else None
+    e = OD.best_approx(host, rhost, sym, gw.numpy().view(np.uint32), text.size, params, scheme, names, 1 if params.local else 2, read_quals=rq)
+    r = A.best_approx(fmi, rfmi, torch.from_numpy(sym).to(cuda), gw.to(cuda), text.size, params, scheme, names, cigar_stride=64,
+                      quals=torch.from_numpy(rq) if rq is not None else None)
     torch.cuda.synchronize()
     assert r["stats"] == e["stats"], (r["stats"], e["stats"])
     assert (r["best"].cpu().numpy().view(np.uint64) == e["best"]).all()

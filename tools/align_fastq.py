@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Real-data flow through the library: <prefix>.bwt/.sa (+ .wpac/.pac genome) and a FASTQ file of equal-length reads ->
-SAM lines (seed, locate, extend, reduce, MAPQ, traceback: nvbio_amd.pipeline.align_single_end).  A usage example, not
-nvBowtie's CLI: mandatory SAM fields + AS:i / XS:i only, single reference sequence, no read groups.
+SAM lines through nvBowtie's single-end best-mapping driver (nvbio_amd.aligner.best_approx = Aligner::best_approx: seeding
+passes, randomized hit selection seeded by the read names, quality-aware extension, give-up counters, MAPQ, traceback).
+A usage example, not nvBowtie's CLI: mandatory SAM fields + AS:i / XS:i only, single reference sequence, no read groups.
 
     python tools/align_fastq.py <index prefix> <reads.fastq> [out.sam]"""
 import sys
@@ -10,7 +11,7 @@ import numpy as np
 import torch
 
 import nvbio_amd as nvb
-from nvbio_amd import io as nio, pipeline as P
+from nvbio_amd import io as nio, aligner as A
 
 
 def cigar_string(words, length):
@@ -29,9 +30,10 @@ def main(prefix, fastq, out=sys.stdout, device="cuda", ref_name="ref"):
         raise SystemExit("align_fastq: this example needs equal-length reads")
     L = int(lens[0])
     sym = torch.from_numpy(reads.symbols.reshape(reads.size(), L)).to(device)
-    mp = nvb.MappingParams()
-    be = P.HipBackend(data.index(), None, mp, L)
-    r = P.align_single_end(be, sym, genome_words, n_genome, cigar_stride=64)
+    params = A.Params(hits_stride=32)
+    band = A.band_length(params.max_dist)
+    r = A.best_approx(data.index(), None, sym, genome_words, n_genome, params, names=list(reads.names), cigar_stride=64,
+                      quals=torch.from_numpy(reads.quals.reshape(reads.size(), L)))
     torch.cuda.synchronize()
     best = r["best"].cpu().numpy().view(np.uint64)
     mapq, cig, clen = r["mapq"].cpu().numpy(), r["cigar"].cpu().numpy().view(np.uint16), r["cigar_len"].cpu().numpy()
@@ -52,7 +54,7 @@ def main(prefix, fastq, out=sys.stdout, device="cuda", ref_name="ref"):
         if int(best[1, i] >> 32) != 0xFFFFFFFF:
             tags += "\tXS:i:%d" % (((w2 >> 1) & 0x1FFFF) * (-1 if w2 & 1 else 1))
         out.write("%s\t%d\t%s\t%d\t%d\t%s\t*\t0\t0\t%s\t%s\t%s\n" % (
-            reads.names[i], 16 if rc else 0, ref_name, pos + int(source[i, 0]) + 1, int(mapq[i]), cigar_string(cig[i], int(clen[i])),
+            reads.names[i], 16 if rc else 0, ref_name, max(pos - band // 2, 0) + int(source[i, 0]) + 1, int(mapq[i]), cigar_string(cig[i], int(clen[i])),
             "".join("ACGTN"[c] for c in s), "".join(chr(int(x) + 33) for x in q), tags))
 
 
