@@ -494,6 +494,26 @@ int nvbio_hip_score_reduce_paired_best_approx(uint32_t n_active, const uint32_t*
     uint32_t* trys, uint32_t* hit_counts, uint32_t n_ext, uint32_t min_ext, uint32_t max_ext, uint32_t max_effort, void* stream);
 int nvbio_hip_mark_discordant(uint32_t n_reads, uint64_t* best_alignments, uint64_t* best_alignments_o, uint32_t best_stride, void* stream);
 
+/* ---- what nvBowtie's host drivers do between the stages (they use thrust / nvbio primitives for it) ----
+ * mark_unaligned (aligner_init.cu:421-444): reseed[t] = 1 for every queued read whose best alignment is still unaligned.
+ * copy_flagged (nvbio/basic/primitives.h, used at aligner_best_approx.h:273-280): out = the in[i] with flags[i] != 0, in
+ * order; *out_count (device) = how many.
+ * traceback_best_setup = BestTracebackStream::init_context (traceback_inl.h:104-136) over best_alignments[idx[i]] (or [i]):
+ * want 0: every aligned entry, banded window [alignment - band/2, + band + read_len); want 1: concordant entries, the
+ * opposite mate's window [alignment, alignment + sink) (opposite_traceback_best); want 2: aligned, not concordant, banded
+ * window.  Patterns: the read's copy at read_begin[r] (or r * fixed_read_len), + rc_offset for reverse-complement
+ * alignments, + mate_offset when the alignment's mate bit is set.  Entries that do not qualify get out_valid 0 and an
+ * empty window. */
+int nvbio_hip_mark_unaligned(uint32_t n_active, const uint32_t* active_reads, const uint64_t* best_alignments, uint8_t* reseed, void* stream);
+uint64_t nvbio_hip_copy_flagged_temp_bytes(uint32_t n);
+int nvbio_hip_copy_flagged(uint32_t n, const uint32_t* in, const uint8_t* flags, uint32_t* out, uint32_t* out_count /* device */,
+                           void* temp, uint64_t temp_bytes, void* stream);
+int nvbio_hip_traceback_best_setup(uint32_t n, const uint32_t* idx /* nullable */, const uint64_t* best_alignments, uint32_t band_len, uint32_t genome_length,
+                                   const uint64_t* read_begin /* nullable */, const uint32_t* read_len /* nullable */, uint32_t fixed_read_len,
+                                   uint64_t rc_offset, uint64_t mate_offset, int32_t want,
+                                   uint8_t* out_valid, uint64_t* pattern_begin, uint32_t* pattern_len /* nullable iff fixed */,
+                                   uint64_t* text_begin, uint32_t* text_len, void* stream);
+
 /* BowtieMapq2 / BowtieMapq3 (nvBowtie/bowtie2/cuda/mapq.h:42-330) for single-end reads:
  * out_mapq[r] from the best / second-best alignment of read r; perfect_score(len) = len * match,
  * min_score(len) = min_score_by_len[len] (the scheme's SimpleFunc tabulated by the host, scoring.h:272-281),

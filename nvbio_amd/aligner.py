@@ -154,30 +154,20 @@ def best_approx(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=No
         with _Stage(stats, "select_init"):
             state = sel.SelectState(hits, counts, name_arena, params.max_effort_init, params.randomized, params.top_seed)
         best_approx_score(fmi, rfmi, state, seed_queue, best, reads_fw_rc, n, L, genome_words, genome_len, aligner, quals, params, band_len, stats)
-        # mark_unaligned (aligner_init.cu:421-436) + copy_flagged
-        flag = (reseed != 0) | ~best.is_aligned(0)[seed_queue.to(torch.int64)]
-        seed_queue = seed_queue[flag]
+        sel.mark_unaligned(seed_queue, best, reseed)                               # aligner_init.cu:421-444
+        seed_queue = sel.copy_flagged(seed_queue, reseed)                          # aligner_best_approx.h:273-283
     with _Stage(stats, "mapq"):
         mapq = reduce.mapq(best, scheme, fixed_read_len=L)
     out = dict(best=best.data, mapq=mapq, stats=stats)
     if traceback:
-        # banded_traceback_best (traceback_inl.h:104-136): window = alignment - band/2, band + read_len long
-        b_align = best.alignment(0)
-        ids = torch.nonzero(best.is_aligned(0)).squeeze(1)
-        b_rc = best.is_rc(0)
-        tb_begin = torch.clamp(b_align[ids] - band_len // 2, min=0)
-        tb_end = torch.clamp(tb_begin + L + band_len, max=genome_len)
-        pat = PackedStringSet(reads_fw_rc, 4, True, (ids * L + b_rc[ids] * (n * L)).contiguous(), None, L)
-        txt = PackedStringSet(genome_words, 2, True, tb_begin.contiguous(), (tb_end - tb_begin).to(torch.int32).contiguous(), 0)
+        # banded_traceback_best (traceback_inl.h:104-136) over every read; unaligned reads get an empty window, fail at once and
+        # come back with no CIGAR and source = sink = (-1, -1)
         with _Stage(stats, "traceback"):
-            tb = batch_banded_alignment_traceback(band_len, aligner, pat, txt, quals=quals, cigar_stride=cigar_stride)
-        stride = tb["cigar"].shape[1]
-        cigar = torch.zeros((n, stride), dtype=torch.int16, device=dev)
-        cigar_len = torch.zeros(n, dtype=torch.int32, device=dev)
-        source = torch.full((n, 2), -1, dtype=torch.int32, device=dev)
-        sink = torch.full((n, 2), -1, dtype=torch.int32, device=dev)
-        cigar[ids] = tb["cigar"][: ids.numel()]; cigar_len[ids] = tb["cigar_len"]; source[ids] = tb["source"]; sink[ids] = tb["sink"]
-        out.update(cigar=cigar, cigar_len=cigar_len, source=source, sink=sink, tb_score=tb["score"], aligned_ids=ids)
+            _, pb, tbeg, tlen = sel.traceback_best_setup(best.data, n, band_len, genome_len, L, n * L)
+            tb = batch_banded_alignment_traceback(band_len, aligner, PackedStringSet(reads_fw_rc, 4, True, pb, None, L),
+                                                  PackedStringSet(genome_words, 2, True, tbeg, tlen, 0), quals=quals, cigar_stride=cigar_stride)
+        out.update(cigar=tb["cigar"], cigar_len=tb["cigar_len"], source=tb["source"], sink=tb["sink"], tb_score=tb["score"],
+                   aligned_ids=torch.nonzero(best.is_aligned(0)).squeeze(1))
     return out
 
 

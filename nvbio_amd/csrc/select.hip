@@ -393,3 +393,93 @@ NVB_API int nvbio_hip_hit_deque_replay(uint32_t n_cases, const uint32_t* case_st
                        state_start, reinterpret_cast<uint2*>(scratch), scratch_stride, out_states);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------ driver utilities
+// What the reference's host drivers do with thrust / nvbio primitives between the stages:
+//   mark_unaligned_kernel  aligner_init.cu:421-436 ; nvbio::copy_flagged  (nvbio/basic/primitives.h) -> hipCUB select
+//   BestTracebackStream::init_context  traceback_inl.h:104-136 (window and pattern of every best alignment)
+namespace nvb {
+
+__global__ void __launch_bounds__(256)
+mark_unaligned_kernel(uint32_t n_active, const uint32_t* __restrict__ active, const uint2* __restrict__ best, uint8_t* __restrict__ reseed)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_active) return;
+    if (best[active[t]].y == 0xFFFFFFFFu) reseed[t] = 1u;
+}
+
+// anchor-style tracebacks (banded): window = alignment - band/2 (clamped), band + read_len long; opposite-style (full matrix,
+// concordant opposite mates): [alignment, alignment + sink).  The mate (which read set) and the strand come from the alignment.
+// valid[i] = 0 for unaligned entries (the stream's init_context returns false) or when `want` does not match:
+// want 0: every aligned entry -> banded; 1: concordant entries -> full; 2: aligned, not concordant -> banded
+__global__ void __launch_bounds__(256)
+traceback_best_setup_kernel(uint32_t n, const uint32_t* __restrict__ idx, const uint2* __restrict__ best, uint32_t band_len, uint32_t genome_len,
+                            const uint64_t* __restrict__ read_begin, const uint32_t* __restrict__ read_len, uint32_t fixed_len, uint64_t rc_offset,
+                            uint64_t mate_offset, int want,
+                            uint8_t* __restrict__ valid, uint64_t* __restrict__ pat_begin, uint32_t* __restrict__ pat_len,
+                            uint64_t* __restrict__ text_begin, uint32_t* __restrict__ text_len)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = idx ? idx[i] : i;
+    const uint2 a = best[r];
+    const bool aligned = a.y != 0xFFFFFFFFu;
+    const bool concordant = ((a.x >> 30) & 1u) && !((a.x >> 31) & 1u);
+    const bool ok = aligned && (want == 0 || (want == 1 ? concordant : !concordant));
+    const uint32_t rc = (a.x >> 28) & 1u, mate = (a.x >> 29) & 1u, sink = (a.x >> 18) & 0x3FFu;
+    const uint32_t len = read_len ? read_len[r] : fixed_len;
+    uint32_t gb, ge;
+    if (want == 1) { gb = a.y; ge = gb + sink; }
+    else { gb = a.y > band_len / 2u ? a.y - band_len / 2u : 0u; ge = gb + band_len + len; }
+    ge = ge < genome_len ? ge : genome_len;
+    valid[i] = ok ? 1u : 0u;
+    text_begin[i] = gb;
+    text_len[i] = (ok && ge > gb) ? ge - gb : 0u;
+    pat_begin[i] = (read_begin ? read_begin[r] : uint64_t(r) * fixed_len) + (rc ? rc_offset : 0ull) + (mate ? mate_offset : 0ull);
+    if (pat_len) pat_len[i] = len;
+}
+
+} // namespace nvb
+
+NVB_API int nvbio_hip_mark_unaligned(uint32_t n_active, const uint32_t* active_reads, const uint64_t* best_alignments, uint8_t* reseed, void* stream)
+{
+    if (n_active == 0) return hipSuccess;
+    if (!active_reads || !best_alignments || !reseed) return hipErrorInvalidValue;
+    g_last_kernel = "mark_unaligned_kernel";
+    hipLaunchKernelGGL(mark_unaligned_kernel, grid_for(n_active), dim3(256), 0, to_stream(stream), n_active, active_reads,
+                       reinterpret_cast<const uint2*>(best_alignments), reseed);
+    return hipGetLastError();
+}
+
+NVB_API uint64_t nvbio_hip_copy_flagged_temp_bytes(uint32_t n)
+{
+    size_t bytes = 0;
+    (void)hipcub::DeviceSelect::Flagged(nullptr, bytes, (const uint32_t*)nullptr, (const uint8_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, int(n));   // size query only
+    return align256(bytes) + 256u;
+}
+
+NVB_API int nvbio_hip_copy_flagged(uint32_t n, const uint32_t* in, const uint8_t* flags, uint32_t* out, uint32_t* out_count, void* temp, uint64_t temp_bytes, void* stream)
+{
+    if (!out_count) return hipErrorInvalidValue;
+    if (n == 0) return hipMemsetAsync(out_count, 0, 4, to_stream(stream));
+    if (!in || !flags || !out || !temp || temp_bytes < nvbio_hip_copy_flagged_temp_bytes(n)) return hipErrorInvalidValue;
+    uint8_t* p = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(temp) + 255u) & ~uintptr_t(255));
+    size_t bytes = size_t(temp_bytes - 256u);
+    g_last_kernel = "hipcub::DeviceSelect::Flagged";
+    return hipcub::DeviceSelect::Flagged(p, bytes, in, flags, out, out_count, int(n), to_stream(stream));
+}
+
+NVB_API int nvbio_hip_traceback_best_setup(uint32_t n, const uint32_t* idx, const uint64_t* best_alignments, uint32_t band_len, uint32_t genome_length,
+                                           const uint64_t* read_begin, const uint32_t* read_len, uint32_t fixed_read_len, uint64_t rc_offset, uint64_t mate_offset,
+                                           int32_t want, uint8_t* out_valid, uint64_t* pattern_begin, uint32_t* pattern_len, uint64_t* text_begin, uint32_t* text_len,
+                                           void* stream)
+{
+    if (n == 0) return hipSuccess;
+    if (!best_alignments || !out_valid || !pattern_begin || !text_begin || !text_len || want < 0 || want > 2) return hipErrorInvalidValue;
+    if ((!read_len && fixed_read_len == 0) || (read_len && !pattern_len)) return hipErrorInvalidValue;
+    g_last_kernel = "traceback_best_setup_kernel";
+    hipLaunchKernelGGL(traceback_best_setup_kernel, grid_for(n), dim3(256), 0, to_stream(stream), n, idx, reinterpret_cast<const uint2*>(best_alignments),
+                       band_len, genome_length, read_begin, read_len, fixed_read_len, rc_offset, mate_offset, int(want), out_valid, pattern_begin, pattern_len,
+                       text_begin, text_len);
+    return hipGetLastError();
+}

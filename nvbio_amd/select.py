@@ -178,3 +178,32 @@ def score_reduce_paired_best_approx(best, best_o, state, active, hit_begin, hit_
 
 def mark_discordant(best, best_o):
     check(lib().nvbio_hip_mark_discordant(best.n, _vp(best.data), _vp(best_o.data), best.stride, current_stream_ptr()), "nvbio_hip_mark_discordant")
+
+
+# ---- driver utilities (what the reference's host code does with thrust between the stages) ------------------------------
+def mark_unaligned(active, best, reseed):
+    check(lib().nvbio_hip_mark_unaligned(active.numel(), _vp(active), _vp(best.data), _vp(reseed), current_stream_ptr()), "nvbio_hip_mark_unaligned")
+
+
+def copy_flagged(values, flags):
+    """nvbio::copy_flagged: the values whose flag is set, in order (one host sync for the count, as in the reference)."""
+    n = values.numel()
+    dev = values.device
+    out = torch.empty(max(n, 1), dtype=values.dtype, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    tb = int(lib().nvbio_hip_copy_flagged_temp_bytes(n))
+    temp = torch.empty(tb, dtype=torch.uint8, device=dev)
+    check(lib().nvbio_hip_copy_flagged(n, _vp(values), _vp(flags), _vp(out), _vp(count), _vp(temp), tb, current_stream_ptr()), "nvbio_hip_copy_flagged")
+    return out[: int(count.item())]
+
+
+def traceback_best_setup(best_data, n, band_len, genome_len, fixed_read_len, rc_offset, mate_offset=0, want=0, idx=None):
+    """BestTracebackStream::init_context over best_data[0][idx] -> (valid uint8, pattern_begin, text_begin, text_len)."""
+    dev = best_data.device
+    m = idx.numel() if idx is not None else n
+    valid = torch.empty(m, dtype=torch.uint8, device=dev)
+    pb = torch.empty(m, dtype=torch.int64, device=dev); tb = torch.empty(m, dtype=torch.int64, device=dev); tl = torch.empty(m, dtype=torch.int32, device=dev)
+    check(lib().nvbio_hip_traceback_best_setup(m, _vp(idx), _vp(best_data), int(band_len), int(genome_len), None, None, int(fixed_read_len), int(rc_offset),
+                                               int(mate_offset), int(want), _vp(valid), _vp(pb), None, _vp(tb), _vp(tl), current_stream_ptr()),
+          "nvbio_hip_traceback_best_setup")
+    return valid, pb, tb, tl

@@ -1,0 +1,65 @@
+// aligner_shim.cpp -- a C entry point around the C++ host driver nvbio::bowtie2::cuda::Aligner (include/nvbio_hip/aligner.h)
+// so that the Python GPU tests can run it on the same device-resident inputs as the Python driver and compare both with the
+// oracle driver.  Test infrastructure: built by __graft_entry__.build() into tests/cxx/libaligner_shim.so.
+#include <cstring>
+#include <nvbio_hip/aligner.h>
+
+using namespace nvbio;
+using namespace nvbio::bowtie2::cuda;
+
+struct shim_params
+{
+    uint32_t local, randomized, top_seed, max_effort_init, max_effort, min_ext, max_ext, max_reseed, rep_seeds, max_hits, allow_sub, subseed_len,
+             seed_len, seed_freq_type, min_read_len, max_dist, no_multi_hits, batch_size, hits_stride;
+    float    seed_freq_k, seed_freq_m;
+    int32_t  match, score_min_type; float score_min_k, score_min_m;
+};
+
+extern "C" __attribute__((visibility("default")))
+int nvbio_aligner_best_approx(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmindex* rfmi, uint32_t n, uint32_t L,
+                              const uint32_t* d_rev_words, uint64_t rev_n_words, const uint64_t* d_rev_begin,
+                              const uint32_t* d_fwrc_words, uint64_t fwrc_n_words, const uint8_t* d_quals, uint64_t n_quals,
+                              const char* d_names, const uint32_t* d_names_idx,
+                              const uint32_t* d_genome_words, uint64_t genome_n_words, uint32_t genome_len, const shim_params* sp,
+                              uint64_t* h_best /* 2n */, uint8_t* h_mapq, uint16_t* h_cigar /* n*64 */, uint32_t* h_cigar_len, uint32_t* h_source, uint32_t* h_sink,
+                              int32_t* h_tb_score, uint64_t* h_stats /* extensions, rounds, seeding_passes, n_queue, queue[8] */)
+{
+    try {
+        Params params;
+        params.seed_len = sp->seed_len; params.seed_freq = SimpleFunc(SimpleFunc::Type(sp->seed_freq_type), sp->seed_freq_k, sp->seed_freq_m);
+        params.min_read_len = sp->min_read_len; params.max_hits = sp->max_hits; params.max_reseed = sp->max_reseed; params.rep_seeds = sp->rep_seeds;
+        params.allow_sub = sp->allow_sub; params.subseed_len = sp->subseed_len;
+        params.select.randomized = sp->randomized != 0; params.select.top_seed = sp->top_seed; params.select.max_effort_init = sp->max_effort_init;
+        params.select.max_effort = sp->max_effort; params.select.min_ext = sp->min_ext; params.select.max_ext = sp->max_ext;
+        params.max_dist = sp->max_dist; params.alignment_type = sp->local ? LocalAlignment : EndToEndAlignment;
+        params.no_multi_hits = sp->no_multi_hits != 0; params.hits_stride = sp->hits_stride;
+
+        aln::SmithWatermanScoringScheme scheme = sp->local ? aln::SmithWatermanScoringScheme::local() : aln::SmithWatermanScoringScheme();
+        scheme.m_match = sp->match;
+        const ScoreLimits limits(sp->match, SimpleFunc(SimpleFunc::Type(sp->score_min_type), sp->score_min_k, sp->score_min_m));
+
+        fm_index_device f, rf; f.m = *fmi; rf.m = rfmi ? *rfmi : *fmi;
+        ReadBatch reads;
+        reads.n = n; reads.len = L;
+        reads.reversed = PackedStringSetView<4, true>(n, d_rev_words, rev_n_words, d_rev_begin, nullptr, L);
+        reads.fw_rc_words = d_fwrc_words; reads.fw_rc_n_words = fwrc_n_words; reads.rc_offset = uint64_t(n) * L;
+        reads.quals = d_quals; reads.n_quals = n_quals; reads.names = d_names; reads.names_idx = d_names_idx;
+
+        Aligner aligner;
+        aligner.init(std::max(sp->batch_size, n), sp->batch_size);
+        Stats stats;
+        aligner.best_approx(params, f, rf, scheme, limits, d_genome_words, genome_n_words, genome_len, reads, stats);
+
+        const std::vector<io::Alignment> best = aligner.best_data_dvec.to_host();
+        for (uint32_t i = 0; i < n; ++i) { memcpy(&h_best[i], &best[i], 8); memcpy(&h_best[n + i], &best[aligner.BATCH_SIZE + i], 8); }
+        const std::vector<uint8> mq = aligner.mapq_dvec.to_host();         memcpy(h_mapq, mq.data(), n);
+        const std::vector<io::Cigar> cg = aligner.cigar.to_host();         memcpy(h_cigar, cg.data(), size_t(n) * aligner.cigar_stride * 2u);
+        const std::vector<uint32> cl = aligner.cigar_len.to_host();        memcpy(h_cigar_len, cl.data(), size_t(n) * 4u);
+        const std::vector<uint32> so = aligner.cigar_source.to_host();     memcpy(h_source, so.data(), size_t(n) * 8u);
+        const std::vector<uint32> si = aligner.cigar_sink.to_host();       memcpy(h_sink, si.data(), size_t(n) * 8u);
+        const std::vector<int32> ts = aligner.traceback_score.to_host();   memcpy(h_tb_score, ts.data(), size_t(n) * 4u);
+        h_stats[0] = stats.extensions; h_stats[1] = stats.rounds; h_stats[2] = stats.seeding_passes; h_stats[3] = stats.queue.size();
+        for (size_t k = 0; k < stats.queue.size() && k < 8; ++k) h_stats[4 + k] = stats.queue[k];
+        return 0;
+    } catch (const nvbio::hip_error& e) { fprintf(stderr, "aligner_shim: %s\n", e.what()); return 1; }
+}

@@ -203,7 +203,8 @@ def test_best_approx_driver_matches_oracle(cuda, config):
     tb = e["tb"]
     assert (r["cigar_len"].cpu().numpy()[ids].view(np.uint32) == tb["cigar_len"]).all()
     assert (r["cigar"].cpu().numpy()[ids].view(np.uint16) == tb["cigar"][: ids.size]).all()
-    assert (r["tb_score"].cpu().numpy() == tb["score"]).all()
+    assert (r["tb_score"].cpu().numpy()[ids] == tb["score"]).all()
+    assert (r["cigar_len"].cpu().numpy().sum() == tb["cigar_len"].sum()) and (r["source"].cpu().numpy()[~np.isin(np.arange(n), ids)] == -1).all()
     assert (r["sink"].cpu().numpy()[ids].view(np.uint32) == tb["sink"]).all() and (r["source"].cpu().numpy()[ids].view(np.uint32) == tb["source"]).all()
     # sanity of the result itself: simulated reads (not the random ones) come back at their origin
     best0 = e["best"][0]
@@ -296,3 +297,66 @@ def test_best_approx_paired_driver_matches_oracle(cuda, config):
         assert (((b[lone] >> np.uint64(32)) != np.uint64(0xFFFFFFFF)) & ~paired[lone]).mean() >= 0.5     # mate 1 reported alone
     if params.pe_discordant and params.pe_unpaired:
         assert disc.sum() >= 1
+
+
+import ctypes as _C  # noqa: E402
+
+
+class _ShimParams(_C.Structure):
+    _fields_ = [(k, _C.c_uint32) for k in ("local", "randomized", "top_seed", "max_effort_init", "max_effort", "min_ext", "max_ext", "max_reseed", "rep_seeds",
+                                           "max_hits", "allow_sub", "subseed_len", "seed_len", "seed_freq_type", "min_read_len", "max_dist", "no_multi_hits",
+                                           "batch_size", "hits_stride")] + \
+               [("seed_freq_k", _C.c_float), ("seed_freq_m", _C.c_float), ("match", _C.c_int32), ("score_min_type", _C.c_int32),
+                ("score_min_k", _C.c_float), ("score_min_m", _C.c_float)]
+
+
+@pytest.mark.parametrize("config", ["default", "no_rand", "one_hit_rounds", "multi_rounds", "one_mismatch_seeds", "local", "low_effort"])
+def test_cxx_aligner_driver_matches_oracle(cuda, config):
+    """The C++ host driver (include/nvbio_hip/aligner.h: nvbio::bowtie2::cuda::Aligner::best_approx), called through tests/cxx/aligner_shim.cpp
+    on device-resident inputs: identical to the numpy driver over the oracle (and so to the Python driver)."""
+    import ctypes as C
+    shim_path = os.path.join(HERE, "cxx", "libaligner_shim.so")
+    if not os.path.exists(shim_path):
+        pytest.fail("tests/cxx/libaligner_shim.so is missing: run `python __graft_entry__.py`")
+    shim = C.CDLL(shim_path)
+    rng = np.random.default_rng(123)
+    text = _small_index(rng)
+    host, rhost = O.FMIndex(text), O.FMIndex(text[::-1].copy())
+    fmi, rfmi = nvb.FMIndexDevice.from_host(host, cuda), nvb.FMIndexDevice.from_host(rhost, cuda)
+    n, L = 1200, 100
+    sym, pos = _reads(rng, text, n, L)
+    names = ["sim.%d" % i for i in range(n)]
+    params = A.Params(**CONFIGS[config])
+    scheme = nvb.SmithWatermanScoringScheme.local() if params.local else nvb.SmithWatermanScoringScheme()
+    gw = W._pack_chunked(torch.from_numpy(text), 2, True)
+    e = OD.best_approx(host, rhost, sym, gw.numpy().view(np.uint32), text.size, params, scheme, names, 1 if params.local else 2)
+
+    d_sym = torch.from_numpy(sym).to(cuda)
+    reads_rev, fwrc = P.pack_read_streams(d_sym)
+    quals = torch.full((2 * n * L + 8,), 30, dtype=torch.uint8, device=cuda)
+    arena, idx = S.pack_names(names, cuda)
+    d_gw = gw.to(cuda)
+    sp = _ShimParams(int(params.local), int(params.randomized), params.top_seed, params.max_effort_init, params.max_effort, params.min_ext, params.max_ext,
+                     params.max_reseed, params.rep_seeds, params.max_hits, params.allow_sub, params.subseed_len, params.seed_len, params.seed_freq[0],
+                     params.min_read_len, params.max_dist, int(params.no_multi_hits), params.batch_size, params.hits_stride or 0,
+                     params.seed_freq[1], params.seed_freq[2], scheme.m_match, scheme.m_score_min[0], scheme.m_score_min[1], scheme.m_score_min[2])
+    best = np.zeros((2, n), np.uint64); mapq = np.zeros(n, np.uint8); cigar = np.zeros((n, 64), np.uint16); cigar_len = np.zeros(n, np.uint32)
+    source = np.zeros((n, 2), np.uint32); sink = np.zeros((n, 2), np.uint32); tb_score = np.zeros(n, np.int32); stats = np.zeros(12, np.uint64)
+    fs, rs = fmi.struct(), rfmi.struct()
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    hp = lambda a: a.ctypes.data_as(C.c_void_p)
+    torch.cuda.synchronize()
+    rc = shim.nvbio_aligner_best_approx(C.byref(fs), C.byref(rs), C.c_uint32(n), C.c_uint32(L), vp(reads_rev.words), C.c_uint64(reads_rev.words.numel()),
+                                        vp(reads_rev.begin), vp(fwrc), C.c_uint64(fwrc.numel()), vp(quals), C.c_uint64(quals.numel()), vp(arena), vp(idx),
+                                        vp(d_gw), C.c_uint64(d_gw.numel()), C.c_uint32(text.size), C.byref(sp),
+                                        hp(best), hp(mapq), hp(cigar), hp(cigar_len), hp(source), hp(sink), hp(tb_score), hp(stats))
+    assert rc == 0
+    assert (best == e["best"]).all() and (mapq == e["mapq"]).all()
+    st = e["stats"]
+    assert (int(stats[0]), int(stats[1]), int(stats[2])) == (st["extensions"], st["rounds"], st["seeding_passes"])
+    assert [int(x) for x in stats[4:4 + int(stats[3])]] == st["queue"]
+    ids, tb = e["aligned_ids"], e["tb"]
+    assert (cigar_len[ids] == tb["cigar_len"]).all() and (cigar[ids] == tb["cigar"][: ids.size]).all()
+    assert (source[ids] == tb["source"]).all() and (sink[ids] == tb["sink"]).all() and (tb_score[ids] == tb["score"]).all()
+    rest = ~np.isin(np.arange(n), ids)
+    assert (cigar_len[rest] == 0).all() and (source[rest] == 0xFFFFFFFF).all()
