@@ -35,6 +35,8 @@ struct TracebackParams {
     uint32_t*       out_cigar_len;
     uint64_t*       flags;          // [row][word][job]
     uint32_t        no_sink;        // SW / ED aligners: the banded submatrix context stores the direction only (sw_banded_inl.h:269-279)
+    const uint32_t* pending;        // nullable: the jobs this launch works on (slot -> job), *pending_count of them
+    const uint32_t* pending_count;
 };
 
 template <uint32_t BAND>
@@ -55,8 +57,9 @@ __global__ __launch_bounds__(256) void banded_gotoh_traceback_kernel(const Trace
     mm[threadIdx.x] = p.mismatch[threadIdx.x];
     __syncthreads();
 
-    const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
-    if (tid >= p.n) return;
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;       // where this lane's flags live
+    if (slot >= (p.pending ? *p.pending_count : p.n)) return;
+    const uint32_t tid = p.pending ? p.pending[slot] : slot;      // the job
 
     const uint64_t pb = p.pat.begin[tid], tb = p.txt.begin[tid];
     const uint32_t M  = p.pat.length ? p.pat.length[tid] : p.pat.fixed_length;
@@ -84,9 +87,14 @@ __global__ __launch_bounds__(256) void banded_gotoh_traceback_kernel(const Trace
 #pragma unroll
         for (uint32_t j = 0; j < BAND; ++j) F[j] = infimum;
 
+        uint64_t pq = 0, tg = 0;          // read / new-text symbols of rows [i & ~15, +16), one nibble per row
         for (uint32_t i = 0; i < M; ++i)
         {
-            const uint32_t q  = get_symbol(p.pat.s, pb + i);
+            if ((i & 15u) == 0u) {
+                pq = (p.pat.s.bits == 2) ? expand_2to4(fetch16_2bit(p.pat.s, pb + i)) : fetch16_4bit(p.pat.s, pb + i);
+                tg = expand_2to4(fetch16_2bit(p.txt.s, tb + i + BAND - 1));
+            }
+            const uint32_t q  = uint32_t(pq >> ((i & 15u) * 4u)) & 15u;
             const uint32_t qq = p.quals ? p.quals[min(pb + i, p.n_quals - 1)] : 0u;
             const int32_t  S  = p.match, X = mm[qq];
             FlagRow<BAND> row; row.clear();
@@ -122,7 +130,7 @@ __global__ __launch_bounds__(256) void banded_gotoh_traceback_kernel(const Trace
                 edir = eleft > ediagonal ? INSERTION_EXT : SUBSTITUTION;
                 E = max(ediagonal, eleft);
             }
-            const uint32_t g = (i + BAND - 1 < N) ? get_symbol(p.txt.s, tb + i + BAND - 1) : 255u;
+            const uint32_t g = (i + BAND - 1 < N) ? (uint32_t(tg >> ((i & 15u) * 4u)) & 15u) : 255u;
             tc[BAND - 2] = QUIRK ? (g & 3u) : g;
             {
                 F[BAND - 1] = infimum;
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(256) void banded_gotoh_traceback_kernel(const Trace
             }
 #pragma unroll
             for (uint32_t k = 0; k < W; ++k)
-                __builtin_nontemporal_store(row.w[k], p.flags + (uint64_t(i) * W + k) * p.n + tid);
+                __builtin_nontemporal_store(row.w[k], p.flags + (uint64_t(i) * W + k) * p.n + slot);
         }
         if (TYPE == NVBIO_HIP_GLOBAL)
             report(H[BAND - 1], M + BAND - 1, M);
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(256) void banded_gotoh_traceback_kernel(const Trace
     bool     stopped = false;
     while (row >= 0)
     {
-        const uint64_t w  = p.flags[(uint64_t(row) * W + (uint32_t(entry) >> 4)) * p.n + tid];
+        const uint64_t w  = p.flags[(uint64_t(row) * W + (uint32_t(entry) >> 4)) * p.n + slot];
         const uint32_t op = uint32_t(w >> ((uint32_t(entry) & 15u) * 4u)) & 15u, h_op = op & 3u;
         if (TYPE == NVBIO_HIP_LOCAL && state == 0 && h_op == SINK) { source.y = uint32_t(row) + 1u; source.x = uint32_t(entry) + source.y; stopped = true; break; }
         if (state == 1)      { if ((op & INSERTION_EXT) == 0u) state = 0; --entry; push(DELETION); }
@@ -186,6 +194,85 @@ __global__ __launch_bounds__(256) void banded_gotoh_traceback_kernel(const Trace
     p.out_cigar_len[tid] = size;
 }
 
+// ---- the ungapped fast path ------------------------------------------------------------------------------
+// Most reads align without a gap.  Given the score and sink of a job (from the score kernel, the same DP), walk up the band
+// column of the sink adding the substitution scores exactly as the DP sees them (qualities, N, and the reference's text cache:
+// symbols beyond the text read 255 when first loaded and 3 when re-read from the 2-bit cache of bands other than 3,5,7,15).
+// If the sum from some row t to the sink row equals the score, then every H on that diagonal segment equals its partial sum
+// (H >= partial sum through the diagonal candidate, and H(sink) >= H(k) + rest forces <=), so at each of those cells the
+// diagonal candidate equals H and the reference's direction is SUBSTITUTION (it wins every tie), i.e. the traceback IS that
+// diagonal: GLOBAL / SEMI_GLOBAL need t = 0 (plus the row-zero value of the column), LOCAL takes the largest such t, where
+// H(t-1) = 0 makes the walk stop (SINK) or t = 0.  Such jobs get their CIGAR here; the others are queued for the full kernel.
+template <int TYPE>
+__global__ __launch_bounds__(256) void banded_traceback_diagonal_kernel(const TracebackParams p, const uint32_t band, const uint32_t quirk,
+                                                                        uint32_t* __restrict__ pending, uint32_t* __restrict__ pending_count)
+{
+    __shared__ int32_t mm[256];
+    mm[threadIdx.x] = p.mismatch[threadIdx.x];
+    __syncthreads();
+    const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
+    if (tid >= p.n) return;
+    const uint2 sink = p.out_sink[tid];
+    if (sink.x == 0xFFFFFFFFu || sink.y == 0xFFFFFFFFu) {          // no alignment: what the full kernel reports
+        p.out_source[tid] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        p.out_cigar_len[tid] = 0;
+        return;
+    }
+    const int32_t  best = p.out_score[tid];
+    const uint64_t pb = p.pat.begin[tid], tb = p.txt.begin[tid];
+    const uint32_t M  = p.pat.length ? p.pat.length[tid] : p.pat.fixed_length;
+    const uint32_t N  = p.txt.length ? p.txt.length[tid] : p.txt.fixed_length;
+    const uint32_t by = sink.y, j = sink.x - sink.y;
+    bool     found = false;
+    uint32_t t = 0;
+    if (!(TYPE == NVBIO_HIP_LOCAL && best <= 0))
+    {
+        // 16 rows per fetch (one 64-bit group of read symbols, one of text symbols); quality bytes only where symbols differ
+        int32_t c = 0;
+        for (int32_t c0 = int32_t((by - 1u) & ~15u); c0 >= 0 && !found; c0 -= 16)
+        {
+            const uint64_t pq = (p.pat.s.bits == 2) ? expand_2to4(fetch16_2bit(p.pat.s, pb + uint32_t(c0))) : fetch16_4bit(p.pat.s, pb + uint32_t(c0));
+            const uint64_t tg = expand_2to4(fetch16_2bit(p.txt.s, tb + uint32_t(c0) + j));
+            for (int32_t k = min(15, int32_t(by) - 1 - c0); k >= 0; --k)
+            {
+                const uint32_t i = uint32_t(c0 + k), idx = i + j;
+                const uint32_t q = uint32_t(pq >> (4 * k)) & 15u;
+                uint32_t g = uint32_t(tg >> (4 * k)) & 15u;
+                if (!(idx + 2u <= band || idx < N)) g = (j == band - 1u) ? 255u : (quirk ? 3u : 255u);     // (the initial cache load is not range checked)
+                int32_t sc = p.match;
+                if (g != q) sc = mm[p.quals ? p.quals[min(pb + i, p.n_quals - 1)] : 0u];
+                c += sc;
+                if (TYPE == NVBIO_HIP_LOCAL && c == best) { found = true; t = i; break; }
+            }
+        }
+        if (TYPE != NVBIO_HIP_LOCAL) {
+            const int32_t init = (TYPE == NVBIO_HIP_GLOBAL && j != 0u) ? p.txt_gap_open + int32_t(j - 1u) * p.txt_gap_ext : 0;
+            found = (c + init == best);
+        }
+    }
+    {
+        // queue the jobs that need the full kernel: one atomic per wavefront, slots in lane order
+        const uint64_t need = __ballot(!found);
+        if (!found) {
+            const uint32_t lane = threadIdx.x & 63u, leader = uint32_t(__ffsll((long long)need)) - 1u;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(pending_count, uint32_t(__popcll(need)));
+            base = __shfl(base, int(leader));
+            pending[base + uint32_t(__popcll(need & ((1ull << lane) - 1ull)))] = tid;
+            return;
+        }
+    }
+
+    uint16_t* cigar = p.out_cigar + uint64_t(tid) * p.cigar_stride;
+    uint32_t  size = 0;
+    auto emit = [&](const uint32_t type, const uint32_t len) { if (len) { if (size < p.cigar_stride) cigar[size] = uint16_t(type | (len << 2)); ++size; } };
+    emit(3u, M - by);                      // soft clip at the read's end
+    emit(SUBSTITUTION, by - t);
+    emit(3u, t);                           // ... and at its start
+    p.out_source[tid]    = make_uint2(j + t, t);
+    p.out_cigar_len[tid] = size;
+}
+
 template <uint32_t BAND>
 static hipError_t launch_tb(const TracebackParams& p, const int32_t type, hipStream_t s)
 {
@@ -198,14 +285,22 @@ static hipError_t launch_tb(const TracebackParams& p, const int32_t type, hipStr
     return hipGetLastError();
 }
 
+static inline uint64_t tb_flag_bytes(uint32_t band_len, uint32_t max_pattern_len, uint32_t n)
+{
+    const uint64_t b = uint64_t(max_pattern_len) * ((band_len + 15u) / 16u) * uint64_t(n) * 8u;
+    return (b + 255ull) & ~255ull;
+}
 static inline int64_t tb_abs(int32_t v) { return v < 0 ? -int64_t(v) : int64_t(v); }
+
+typedef int (*score_launch_fn)(const void* scheme, int32_t type, uint32_t band_len, const nvbio_hip_string_set* patterns, const uint8_t* quals, uint64_t n_quals,
+                               const nvbio_hip_string_set* texts, uint32_t max_pattern_len, uint32_t n, int32_t* out_score, uint32_t* out_sink, void* stream);
 
 static int traceback_common(TracebackParams& p, int64_t A, int32_t type, uint32_t band_len,
                             const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts,
                             uint32_t max_pattern_len, uint32_t n,
                             int32_t* out_score, uint32_t* out_sink, uint32_t* out_source,
                             uint16_t* out_cigar, uint32_t cigar_stride, uint32_t* out_cigar_len,
-                            void* temp, uint64_t temp_bytes, hipStream_t s)
+                            void* temp, uint64_t temp_bytes, hipStream_t s, score_launch_fn score_launch = nullptr, const void* score_scheme = nullptr)
 {
     if (!patterns || !texts) return hipErrorInvalidValue;
     if (type < 0 || type > 2) return hipErrorInvalidValue;
@@ -227,6 +322,24 @@ static int traceback_common(TracebackParams& p, int64_t A, int32_t type, uint32_
     p.n = n; p.out_score = out_score; p.out_sink = reinterpret_cast<uint2*>(out_sink); p.out_source = reinterpret_cast<uint2*>(out_source);
     p.out_cigar = out_cigar; p.cigar_stride = cigar_stride; p.out_cigar_len = out_cigar_len;
     p.flags = static_cast<uint64_t*>(temp);
+    p.pending = nullptr; p.pending_count = nullptr;
+    if (score_launch)
+    {
+        // score + sink of every job from the score kernel, CIGARs of the ungapped ones from the diagonal check, the rest queued
+        uint32_t* pending = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(temp) + tb_flag_bytes(band_len, maxM, n));
+        uint32_t* pending_count = pending + n;
+        if (hipError_t e = hipMemsetAsync(pending_count, 0, 4, s)) return e;
+        if (int e = score_launch(score_scheme, type, band_len, patterns, p.quals, p.n_quals, texts, max_pattern_len, n, out_score, out_sink, s)) return e;
+        const uint32_t quirk = !(band_len == 3 || band_len == 5 || band_len == 7 || band_len == 15) ? 1u : 0u;
+        const dim3 grid((n + 255u) / 256u), block(256);
+        switch (type) {
+        case NVBIO_HIP_LOCAL:       hipLaunchKernelGGL(banded_traceback_diagonal_kernel<NVBIO_HIP_LOCAL>,       grid, block, 0, s, p, band_len, quirk, pending, pending_count); break;
+        case NVBIO_HIP_SEMI_GLOBAL: hipLaunchKernelGGL(banded_traceback_diagonal_kernel<NVBIO_HIP_SEMI_GLOBAL>, grid, block, 0, s, p, band_len, quirk, pending, pending_count); break;
+        default:                    hipLaunchKernelGGL(banded_traceback_diagonal_kernel<NVBIO_HIP_GLOBAL>,      grid, block, 0, s, p, band_len, quirk, pending, pending_count); break;
+        }
+        if (hipError_t e = hipGetLastError()) return e;
+        p.pending = pending; p.pending_count = pending_count;
+    }
     g_last_kernel = "banded_gotoh_traceback_kernel";
     switch (band_len) {
     case 3:  return launch_tb<3>(p, type, s);
@@ -241,7 +354,17 @@ static int traceback_common(TracebackParams& p, int64_t A, int32_t type, uint32_
 
 NVB_API uint64_t nvbio_hip_banded_gotoh_traceback_temp_bytes(uint32_t band_len, uint32_t max_pattern_len, uint32_t n)
 {
-    return uint64_t(max_pattern_len) * ((band_len + 15u) / 16u) * uint64_t(n) * 8u;
+    // the flow flags of every job's band + the queue of jobs left to the full kernel and its counter
+    return nvb::tb_flag_bytes(band_len, max_pattern_len, n) + uint64_t(n) * 4u + 256u;
+}
+
+namespace {
+int score_noqual(const void* scheme, int32_t type, uint32_t band_len, const nvbio_hip_string_set* patterns, const uint8_t*, uint64_t,
+                 const nvbio_hip_string_set* texts, uint32_t max_pattern_len, uint32_t n, int32_t* out_score, uint32_t* out_sink, void* stream)
+{ return nvbio_hip_banded_gotoh_score(static_cast<const nvbio_hip_gotoh_scheme*>(scheme), type, band_len, patterns, texts, max_pattern_len, 0, n, out_score, out_sink, stream); }
+int score_qual(const void* scheme, int32_t type, uint32_t band_len, const nvbio_hip_string_set* patterns, const uint8_t* quals, uint64_t n_quals,
+               const nvbio_hip_string_set* texts, uint32_t max_pattern_len, uint32_t n, int32_t* out_score, uint32_t* out_sink, void* stream)
+{ return nvbio_hip_banded_gotoh_score_qual(static_cast<const nvbio_hip_gotoh_qual_scheme*>(scheme), type, band_len, patterns, quals, n_quals, texts, max_pattern_len, 0, n, out_score, out_sink, stream); }
 }
 
 NVB_API int nvbio_hip_banded_gotoh_traceback(
@@ -263,7 +386,7 @@ NVB_API int nvbio_hip_banded_gotoh_traceback(
     for (int i = 0; i < 256; ++i) p.mismatch[i] = scheme->mismatch;
     const int64_t A = std::max(std::max(tb_abs(scheme->match), tb_abs(scheme->mismatch)), std::max(tb_abs(scheme->gap_open), tb_abs(scheme->gap_ext)));
     return traceback_common(p, A, type, band_len, patterns, texts, max_pattern_len, n, out_score, out_sink, out_source,
-                            out_cigar, cigar_stride, out_cigar_len, temp, temp_bytes, to_stream(stream));
+                            out_cigar, cigar_stride, out_cigar_len, temp, temp_bytes, to_stream(stream), score_noqual, scheme);
 }
 
 NVB_API int nvbio_hip_banded_gotoh_traceback_qual(
@@ -288,7 +411,7 @@ NVB_API int nvbio_hip_banded_gotoh_traceback_qual(
                 std::max(tb_abs(scheme->text_gap_open), tb_abs(scheme->text_gap_ext))));
     for (int i = 0; i < 256; ++i) { p.mismatch[i] = scheme->mismatch[i]; A = std::max(A, tb_abs(scheme->mismatch[i])); }
     return traceback_common(p, A, type, band_len, patterns, texts, max_pattern_len, n, out_score, out_sink, out_source,
-                            out_cigar, cigar_stride, out_cigar_len, temp, temp_bytes, to_stream(stream));
+                            out_cigar, cigar_stride, out_cigar_len, temp, temp_bytes, to_stream(stream), score_qual, scheme);
 }
 
 // SmithWatermanAligner / EditDistanceAligner in the band (sw_banded_inl.h:405-470, 748-800): with deletion == insertion the

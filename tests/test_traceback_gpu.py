@@ -236,3 +236,56 @@ def test_full_matrix_traceback_quality_aware(cuda, ty):
                                             quals=torch.from_numpy(quals).to(cuda))
         torch.cuda.synchronize()
         compare(exp, got, (ty, st.match))
+
+
+@pytest.mark.parametrize("band", [3, 5, 7, 15, 31])
+@pytest.mark.parametrize("ty", [nvb.GLOBAL, nvb.LOCAL, nvb.SEMI_GLOBAL])
+def test_ungapped_alignments_every_band_offset(cuda, band, ty):
+    """The bulk case of real reads -- no gap, a few substitutions -- at every band offset, with windows that end inside the band
+    (where the reference's text cache turns out-of-range symbols into 3 for bands other than 3,5,7,15), N's in the reads, leading /
+    trailing junk (LOCAL clipping) and a minority of gapped reads mixed in: the diagonal fast path and the full kernel must agree with
+    the oracle job by job."""
+    rng = np.random.default_rng(7300 + band * 3 + ty)
+    pats, txts = [], []
+    for i in range(900):
+        M = int(rng.integers(4, 120))
+        off = int(rng.integers(0, band))
+        tail = [band + 3, band - 1 - off, 0, int(rng.integers(0, band))][i % 4]          # text beyond the diagonal's end: plenty / flush with the band / none / random
+        t = rng.integers(0, 4, off + M + tail, dtype=np.uint8)
+        p = t[off:off + M].copy()
+        for j in rng.integers(0, M, [0, 0, 1, 2, 4][i % 5]):
+            p[j] = (p[j] + 1 + rng.integers(0, 3)) & 3
+        if i % 11 == 0:
+            p[int(rng.integers(0, M))] = 4
+        if i % 7 == 0 and M > 20:                                                        # junk at both ends: LOCAL clips it
+            p[:3] = rng.integers(0, 4, 3); p[-4:] = rng.integers(0, 4, 4)
+        if i % 13 == 0 and M > 12:                                                       # a deletion in the read: not ungapped
+            d = int(rng.integers(4, M - 4)); p = np.concatenate([p[:d], p[d + 1:]])
+        if i % 17 == 0:
+            p[:] = 3                                                                     # poly-T reads meet the cache quirk's 3s
+        pats.append(p); txts.append(t)
+    hp, ht = O.StringSet.from_lists(pats, 4, True), O.StringSet.from_lists(txts + [np.full(64, 3, np.uint8)], 2, True)
+    ht = O.StringSet(ht.words, 2, True, ht.begin[:-1], ht.length[:-1])                   # what follows the last text is defined (all T)
+    maxM = int(hp.length.max())
+    ungapped = 0
+    for scheme in ((2, -3, -5, -3), (0, -6, -8, -3), (1, -1, -1, -1)):
+        exp = O.batch_banded_gotoh_traceback(band, ty, scheme, hp, ht, 40)
+        got = nvb.batch_banded_alignment_traceback(band, nvb.make_gotoh_aligner(ty, nvb.SimpleGotohScheme(*scheme)), to_dev(hp, cuda), to_dev(ht, cuda),
+                                                   max_pattern_length=maxM, cigar_stride=40)
+        torch.cuda.synchronize()
+        compare(exp, got, (band, ty, scheme))
+        ok = exp["cigar_len"] > 0
+        ungapped += int((((exp["cigar"] & 3) != 1) & ((exp["cigar"] & 3) != 2) | (np.arange(40)[None, :] >= exp["cigar_len"][:, None])).all(1)[ok].sum())
+    assert ungapped > (10 if ty == nvb.GLOBAL else 900)
+    if band == 31 or band == 15:
+        total = int(hp.begin[-1] + hp.length[-1])
+        quals = rng.integers(0, 50, total + 3, dtype=np.uint8)
+        for sch in (nvb.SmithWatermanScoringScheme(), nvb.SmithWatermanScoringScheme.local()):
+            st = sch.struct()
+            lut = np.array([st.mismatch[q] for q in range(256)], dtype=np.int32)
+            s5 = (st.match, st.pattern_gap_open, st.pattern_gap_ext, st.text_gap_open, st.text_gap_ext)
+            exp = O.batch_banded_gotoh_traceback(band, ty, s5, hp, ht, 40, lut, quals)
+            got = nvb.batch_banded_alignment_traceback(band, nvb.make_gotoh_aligner(ty, sch), to_dev(hp, cuda), to_dev(ht, cuda), max_pattern_length=maxM,
+                                                       quals=torch.from_numpy(quals).to(cuda), cigar_stride=40)
+            torch.cuda.synchronize()
+            compare(exp, got, (band, ty, "qual"))
