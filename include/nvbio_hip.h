@@ -514,6 +514,21 @@ int nvbio_hip_traceback_best_setup(uint32_t n, const uint32_t* idx /* nullable *
                                    uint8_t* out_valid, uint64_t* pattern_begin, uint32_t* pattern_len /* nullable iff fixed */,
                                    uint64_t* text_begin, uint32_t* text_len, void* stream);
 
+/* finish_alignment_kernel + BestTracebackStream::finish (nvBowtie/bowtie2/cuda/traceback_inl.h:523-722, :177-189): for job i with
+ * valid[i] != 0, replay its CIGAR (cigar[i * cigar_stride ..], cigar_len[i] words stored end first, first text column
+ * cigar_source[2i] & 0xFFFF) over pattern i and text i (the window of nvbio_hip_traceback_best_setup) and write
+ *   - out_mds[i * mds_stride ..]: the MD string in nvbio's byte code (io::MDS_OP, nvbio/io/alignments.h:46-52): bytes 0-1 its length,
+ *     then {MDS_MATCH 0, run <= 255} / {MDS_MISMATCH 1, read symbol} / {MDS_INSERTION 2 | MDS_DELETION 3, length byte, symbols};
+ *     out_mds_len[i] its length (bytes beyond mds_stride are counted, not stored);
+ *   - the alignment best_alignments[idx ? idx[i] : i] rewritten: m_align = the text's begin, m_ed = mismatches + inserted / deleted
+ *     symbols (soft clips excluded), m_score = sum over the SUBSTITUTION columns of scoring_scheme.score (scoring.h:301-311):
+ *     -n_penalty when the read symbol is N, else match or mismatch_by_quality[q] (host table of -m_mmp(q)).
+ * Jobs with valid 0, no CIGAR, or a CIGAR longer than cigar_stride are skipped (out_mds_len 0, alignment untouched). */
+int nvbio_hip_finish_alignment(uint32_t n, const uint8_t* valid, const nvbio_hip_string_set* patterns, const uint8_t* quals /* nullable */, uint64_t n_quals,
+                               const nvbio_hip_string_set* texts, const uint16_t* cigar, uint32_t cigar_stride, const uint32_t* cigar_len,
+                               const uint32_t* cigar_source /* uint2[n] */, int32_t match, const int32_t* mismatch_by_quality /* host, 256 */, int32_t n_penalty,
+                               const uint32_t* idx /* nullable */, uint64_t* best_alignments, uint8_t* out_mds, uint32_t mds_stride, uint32_t* out_mds_len, void* stream);
+
 /* BowtieMapq2 / BowtieMapq3 (nvBowtie/bowtie2/cuda/mapq.h:42-330) for single-end reads:
  * out_mapq[r] from the best / second-best alignment of read r; perfect_score(len) = len * match,
  * min_score(len) = min_score_by_len[len] (the scheme's SimpleFunc tabulated by the host, scoring.h:272-281),

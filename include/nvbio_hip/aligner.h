@@ -22,9 +22,10 @@ enum AlignmentTypeMode { EndToEndAlignment = 0, LocalAlignment = 1 };           
 /// the fields of nvBowtie's Params the driver reads, with its defaults (params.cpp:116-197)
 struct Params : public ParamsPOD
 {
-    Params() : max_dist(15), alignment_type(EndToEndAlignment), no_multi_hits(false), fw(true), rc(true), hits_stride(0) {}
+    Params() : max_dist(15), alignment_type(EndToEndAlignment), no_multi_hits(false), fw(true), rc(true), hits_stride(0), finish_alignments(true) {}
     SelectParamsPOD select;
     uint32 max_dist; AlignmentTypeMode alignment_type; bool no_multi_hits, fw, rc; uint32 hits_stride;
+    bool   finish_alignments;      ///< run finish_alignment_best (MD strings, edit distances, final scores) as the reference always does
 };
 
 struct Stats { uint64 extensions; uint32 rounds, seeding_passes; std::vector<uint32> queue; Stats() : extensions(0), rounds(0), seeding_passes(0) {} };
@@ -54,8 +55,11 @@ struct Aligner
     hip::device_vector<uint32>        cigar_len, cigar_source, cigar_sink;   // cigar_coords + sinks of the tracebacks
     hip::device_vector<int32>         traceback_score;
     uint32                            cigar_stride;
+    hip::device_vector<uint8>         mds;               // [BATCH_SIZE][mds_stride]: MD strings in nvbio's byte code (finish_alignment)
+    hip::device_vector<uint32>        mds_len;
+    uint32                            mds_stride;
 
-    Aligner() : BATCH_SIZE(0), SCORING_BATCH(0), cigar_stride(64) {}
+    Aligner() : BATCH_SIZE(0), SCORING_BATCH(0), cigar_stride(64), mds_stride(256) {}
 
     /// Aligner::band_length (aligner.h:165-174)
     static uint32 band_length(const uint32 max_dist)
@@ -71,6 +75,7 @@ struct Aligner
         best_data_dvec.resize(size_t(batch_size) * 2u); mapq_dvec.resize(batch_size);
         cigar.resize(size_t(batch_size) * cigar_stride); cigar_len.resize(batch_size);
         cigar_source.resize(size_t(batch_size) * 2u); cigar_sink.resize(size_t(batch_size) * 2u); traceback_score.resize(batch_size);
+        mds.resize(size_t(batch_size) * mds_stride); mds_len.resize(batch_size);
         return true;
     }
 
@@ -161,6 +166,17 @@ private:
                 batch_type().enact(stream, temp.size(), temp.data(), hip_stream);
                 hip::synchronize(hip_stream);                     // temp is released on scope exit
             });
+            // finish_alignment_best: MD strings, edit distances, final scores; best_data then holds what the output stage reads
+            if (params.finish_alignments)
+            {
+                const nvbio_hip_gotoh_qual_scheme sc = scoring_scheme.abi();
+                const nvbio_hip_string_set p = patterns.abi(), t = texts.abi();
+                hip_check(nvbio_hip_finish_alignment(count, valid.data(), &p, reads.quals, reads.n_quals, &t, reinterpret_cast<const uint16*>(cigar.data()), cigar_stride,
+                                                     cigar_len.data(), cigar_source.data(), sc.match, sc.mismatch, 1 /* m_np = ConstantCost(1,1) */, nullptr,
+                                                     reinterpret_cast<uint64*>(best_data_dvec.data()), mds.data(), mds_stride, mds_len.data(), hip_stream),
+                          "nvbio_hip_finish_alignment");
+                hip::synchronize(hip_stream);
+            }
         }
         hip::synchronize(hip_stream);
     }

@@ -118,7 +118,7 @@ def _qual_stream(n, L, qual_value, quals, dev):
 
 
 def best_approx(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=None, names=None, qual_value=30, traceback=True,
-                cigar_stride=None, stage_times=False, packed=None, quals=None):
+                cigar_stride=None, stage_times=False, packed=None, quals=None, finish=False, mds_stride=256):
     """Aligner::best_approx for a batch of equal-length reads `sym` (uint8 [n, L], symbols 0..4).  `names`: list of read
     names (they seed the randomized selection).  Returns dict(best int64[2,n] io::Alignment words, mapq uint8[n], and with
     traceback: cigar int16[n,stride], cigar_len, source, sink (-1 for unaligned reads), stats)."""
@@ -163,11 +163,18 @@ def best_approx(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=No
         # banded_traceback_best (traceback_inl.h:104-136) over every read; unaligned reads get an empty window, fail at once and
         # come back with no CIGAR and source = sink = (-1, -1)
         with _Stage(stats, "traceback"):
-            _, pb, tbeg, tlen = sel.traceback_best_setup(best.data, n, band_len, genome_len, L, n * L)
-            tb = batch_banded_alignment_traceback(band_len, aligner, PackedStringSet(reads_fw_rc, 4, True, pb, None, L),
-                                                  PackedStringSet(genome_words, 2, True, tbeg, tlen, 0), quals=quals, cigar_stride=cigar_stride)
+            valid, pb, tbeg, tlen = sel.traceback_best_setup(best.data, n, band_len, genome_len, L, n * L)
+            pat, txt = PackedStringSet(reads_fw_rc, 4, True, pb, None, L), PackedStringSet(genome_words, 2, True, tbeg, tlen, 0)
+            tb = batch_banded_alignment_traceback(band_len, aligner, pat, txt, quals=quals, cigar_stride=cigar_stride)
         out.update(cigar=tb["cigar"], cigar_len=tb["cigar_len"], source=tb["source"], sink=tb["sink"], tb_score=tb["score"],
                    aligned_ids=torch.nonzero(best.is_aligned(0)).squeeze(1))
+        if finish:
+            # finish_alignment_best (traceback_inl.h:523-760): MD strings, edit distances, final scores; out["best"] becomes what the
+            # reference hands to its output stage (m_align = window begin), the extension-stage words stay in out["best_scored"]
+            out["best_scored"] = best.data.clone()
+            with _Stage(stats, "finish"):
+                out["mds"], out["mds_len"] = sel.finish_alignment(valid, pat, quals, txt, tb["cigar"], tb["cigar_len"], tb["source"], scheme, best.data,
+                                                                  mds_stride=mds_stride)
     return out
 
 
@@ -224,7 +231,7 @@ def best_approx_score_paired(fmi, rfmi, state, seed_queue, anchor, best, best_o,
 
 
 def best_approx_paired(fmi, rfmi, sym1, sym2, genome_words, genome_len, params=None, scheme=None, names=None, qual_value=30, traceback=True,
-                       cigar_stride=64, stage_times=False):
+                       cigar_stride=64, stage_times=False, finish=False, mds_stride=256):
     """Aligner::best_approx for read pairs (equal-length mates sym1 / sym2, uint8 [n, L]).  Returns dict(best, best_o int64[2,n]
     io::Alignment words of the anchor / opposite slots, mapq1, mapq2 uint8[n], and with traceback per slot set ("1" = best_data,
     "2" = best_data_o): cigar, cigar_len, source, sink; stats)."""
@@ -279,55 +286,45 @@ def best_approx_paired(fmi, rfmi, sym1, sym2, genome_words, genome_len, params=N
         mapq2 = reduce.mapq_paired(best_o, best, scheme, fixed_read_len=L, o_fixed_read_len=L)      # MapqFunctorPE(mate 1)
     out = dict(best=best.data, best_o=best_o.data, mapq1=mapq1, mapq2=mapq2, stats=stats)
     if traceback:
+        # both mates' fw + rc patterns in one stream: a traceback picks its read by the alignment's mate bit (traceback_inl.h:117-120)
+        mate_words = torch.cat([packed[0][1], packed[1][1]])
+        mate_offset = int(packed[0][1].numel()) * 8
+        tq = torch.full((mate_offset + 2 * n * L + 8,), qual_value, dtype=torch.uint8, device=dev)
+        sets = lambda pb, tbeg, tlen: (PackedStringSet(mate_words, 4, True, pb, None, L), PackedStringSet(genome_words, 2, True, tbeg, tlen, 0))
         with _Stage(stats, "traceback"):
-            mate_words = (packed[0][1], packed[1][1])
-
-            def banded_tb(data, ids):
-                """banded_traceback_best over reads `ids` of one slot set: the mate comes from the alignment (traceback_inl.h:104-136)"""
-                w = data[0][ids]
-                align, rcb, mate = (w >> 32) & 0xFFFFFFFF, (w >> 28) & 1, (w >> 29) & 1
-                tb_begin = torch.clamp(align - band_len // 2, min=0)
-                tb_end = torch.clamp(tb_begin + L + band_len, max=genome_len)
-                res = {}
-                for m in (0, 1):
-                    k = torch.nonzero(mate == m).squeeze(1)
-                    if k.numel() == 0:
-                        continue
-                    pat = PackedStringSet(mate_words[m], 4, True, (ids[k] * L + rcb[k] * (n * L)).contiguous(), None, L)
-                    txt = PackedStringSet(genome_words, 2, True, tb_begin[k].contiguous(), (tb_end[k] - tb_begin[k]).to(torch.int32).contiguous(), 0)
-                    res[m] = (ids[k], batch_banded_alignment_traceback(band_len, banded_aligner, pat, txt, quals=quals, cigar_stride=cigar_stride))
-                return res
-
-            def full_tb(data, ids):
-                """opposite_traceback_best: the concordant opposite mates, full matrix over [alignment, alignment + sink)"""
-                w = data[0][ids]
-                align, rcb, mate, g_len = (w >> 32) & 0xFFFFFFFF, (w >> 28) & 1, (w >> 29) & 1, (w >> 18) & 0x3FF
-                t_end = torch.clamp(align + g_len, max=genome_len)
-                res = {}
-                for m in (0, 1):
-                    k = torch.nonzero(mate == m).squeeze(1)
-                    if k.numel() == 0:
-                        continue
-                    pat = PackedStringSet(mate_words[m], 4, True, (ids[k] * L + rcb[k] * (n * L)).contiguous(), None, L)
-                    txt = PackedStringSet(genome_words, 2, True, align[k].contiguous(), (t_end[k] - align[k]).to(torch.int32).contiguous(), 0)
-                    res[m] = (ids[k], batch_alignment_traceback(full_aligner, pat, txt, L, 1024, cigar_stride=cigar_stride, quals=quals))
-                return res
-
-            def scatter(parts):
-                cigar = torch.zeros((n, cigar_stride), dtype=torch.int16, device=dev); cigar_len = torch.zeros(n, dtype=torch.int32, device=dev)
-                source = torch.full((n, 2), -1, dtype=torch.int32, device=dev); sink = torch.full((n, 2), -1, dtype=torch.int32, device=dev)
-                score = torch.full((n,), WORST_SCORE, dtype=torch.int32, device=dev)
-                for res in parts:
-                    for ids_m, tbm in res.values():
-                        cigar[ids_m] = tbm["cigar"][: ids_m.numel()]; cigar_len[ids_m] = tbm["cigar_len"]; source[ids_m] = tbm["source"]; sink[ids_m] = tbm["sink"]
-                        score[ids_m] = tbm["score"]
-                return dict(cigar=cigar, cigar_len=cigar_len, source=source, sink=sink, score=score)
-
-            aligned1 = torch.nonzero(best.is_aligned(0)).squeeze(1)
-            out["tb1"] = scatter([banded_tb(best.data, aligned1)])
+            # banded_traceback_best over the anchor slots (every aligned entry)
+            v1, pb, tbeg, tlen = sel.traceback_best_setup(best.data, n, band_len, genome_len, L, n * L, mate_offset, want=0)
+            pat1, txt1 = sets(pb, tbeg, tlen)
+            tb1 = batch_banded_alignment_traceback(band_len, banded_aligner, pat1, txt1, quals=tq, cigar_stride=cigar_stride)
+            # the opposite slots: opposite_traceback_best (full matrix over [alignment, alignment + sink)) for the concordant ones,
+            # banded_traceback_best for the other aligned ones
             w_o = best_o.data[0]
-            concordant = (((w_o >> 30) & 1) != 0) & (((w_o >> 31) & 1) == 0)
-            ids_c = torch.nonzero(concordant & best_o.is_aligned(0)).squeeze(1)
-            ids_u = torch.nonzero(~concordant & best_o.is_aligned(0)).squeeze(1)
-            out["tb2"] = scatter([full_tb(best_o.data, ids_c), banded_tb(best_o.data, ids_u)])
+            concordant = (((w_o >> 30) & 1) != 0) & (((w_o >> 31) & 1) == 0) & best_o.is_aligned(0)
+            ids_c = torch.nonzero(concordant).squeeze(1).to(torch.int32)
+            vu, pb, tbeg, tlen = sel.traceback_best_setup(best_o.data, n, band_len, genome_len, L, n * L, mate_offset, want=2)
+            pat_u, txt_u = sets(pb, tbeg, tlen)
+            tb_u = batch_banded_alignment_traceback(band_len, banded_aligner, pat_u, txt_u, quals=tq, cigar_stride=cigar_stride)
+            if ids_c.numel():
+                vc, pb, tbeg, tlen = sel.traceback_best_setup(best_o.data, n, band_len, genome_len, L, n * L, mate_offset, want=1, idx=ids_c)
+                pat_c, txt_c = sets(pb, tbeg, tlen)
+                tb_c = batch_alignment_traceback(full_aligner, pat_c, txt_c, L, 1024, cigar_stride=cigar_stride, quals=tq)
+        if finish:
+            out["best_scored"], out["best_o_scored"] = best.data.clone(), best_o.data.clone()
+            with _Stage(stats, "finish"):
+                out["mds1"], out["mds1_len"] = sel.finish_alignment(v1, pat1, tq, txt1, tb1["cigar"], tb1["cigar_len"], tb1["source"], scheme, best.data, mds_stride=mds_stride)
+                # the reference evaluates mate 2's MAPQ functor here, after the anchor slots were finished and before the opposite ones
+                # are (aligner_best_approx_paired.h:308-323)
+                out["mapq2"] = reduce.mapq_paired(best_o, best, scheme, fixed_read_len=L, o_fixed_read_len=L)
+                mds2, mds2_len = sel.finish_alignment(vu, pat_u, tq, txt_u, tb_u["cigar"], tb_u["cigar_len"], tb_u["source"], scheme, best_o.data, mds_stride=mds_stride)
+                if ids_c.numel():
+                    mc, mc_len = sel.finish_alignment(vc, pat_c, tq, txt_c, tb_c["cigar"], tb_c["cigar_len"], tb_c["source"], scheme, best_o.data, idx=ids_c,
+                                                      mds_stride=mds_stride)
+                    k = ids_c.to(torch.int64)
+                    mds2[k] = mc[: k.numel()]; mds2_len[k] = mc_len
+                out["mds2"], out["mds2_len"] = mds2, mds2_len
+        if ids_c.numel():                                   # merge the two kinds of opposite-slot tracebacks
+            k = ids_c.to(torch.int64)
+            for key in ("cigar", "cigar_len", "source", "sink", "score"):
+                tb_u[key][k] = tb_c[key][: k.numel()]
+        out["tb1"], out["tb2"] = tb1, tb_u
     return out

@@ -483,3 +483,92 @@ NVB_API int nvbio_hip_traceback_best_setup(uint32_t n, const uint32_t* idx, cons
                        text_begin, text_len);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------ finish_alignment
+// finish_alignment_kernel (traceback_inl.h:523-722) + BestTracebackStream::finish (:177-189): one lane replays its alignment's
+// CIGAR (stored end first) over the read and its genome window and emits the MD string in nvbio's byte code (io::MDS_OP:
+// [len lo, len hi] then {MATCH, run <= 255} / {MISMATCH, read symbol} / {INSERTION | DELETION, length byte, symbols...}), the
+// edit distance (clips not counted) and the final score = scoring_scheme.score() summed over the SUBSTITUTION columns only
+// (scoring.h:301-311), then rewrites the alignment: m_align = window begin, m_ed, m_score.  A streaming pass over ~100 bytes
+// per read.  A CIGAR that overflowed its slots cannot be replayed: skipped (mds_len 0, alignment untouched).
+namespace nvb {
+
+struct FinishParams {
+    uint32_t n; const uint8_t* valid; StringSet pat, txt; const uint8_t* quals; uint64_t n_quals;
+    const uint16_t* cigar; uint32_t cigar_stride; const uint32_t* cigar_len; const uint2* cigar_source;
+    int32_t match, n_penalty; int32_t mismatch[256];
+    const uint32_t* idx; uint2* best; uint8_t* mds; uint32_t mds_stride; uint32_t* mds_len;
+};
+
+__global__ void __launch_bounds__(256) finish_alignment_kernel(const FinishParams p)
+{
+    __shared__ int32_t mm[256];
+    mm[threadIdx.x] = p.mismatch[threadIdx.x];
+    __syncthreads();
+    const uint32_t w = blockIdx.x * 256u + threadIdx.x;
+    if (w >= p.n) return;
+    const uint32_t clen = p.cigar_len[w];
+    if (!p.valid[w] || clen == 0u || clen > p.cigar_stride) { p.mds_len[w] = 0u; return; }
+    const uint16_t* cv = p.cigar + uint64_t(w) * p.cigar_stride;
+    uint8_t* mds = p.mds + uint64_t(w) * p.mds_stride;
+    const uint64_t pb = p.pat.begin[w], tb = p.txt.begin[w];
+    uint32_t mds_len = 2u, mds_op = 4u, ed = 0u, run = 0u /* counter of the open MATCH run (kept in a register) */, run_at = 0u;
+    int32_t  score = 0;
+    uint32_t j = 0u, k = p.cigar_source[w].x & 0xFFFFu;
+    auto push = [&](const uint32_t v) { if (mds_len < p.mds_stride) mds[mds_len] = uint8_t(v); ++mds_len; };
+    auto close_run = [&]() { if (run && run_at < p.mds_stride) mds[run_at] = uint8_t(run); run = 0u; };
+    for (uint32_t i = 0; i < clen; ++i)
+    {
+        const uint32_t word = cv[clen - i - 1u], t = word & 3u, l = word >> 2;
+        if (t != 0u) { close_run(); mds_op = (t == 2u) ? 3u : 2u; push(mds_op); push(l); }
+        for (uint32_t x = 0; x < l; ++x)
+        {
+            j += (t != 2u) ? 1u : 0u;
+            k += (t == 0u || t == 2u) ? 1u : 0u;
+            const uint32_t readc = j > 0u ? get_symbol(p.pat.s, pb + j - 1u) : 255u;
+            const uint32_t refc  = k > 0u ? get_symbol(p.txt.s, tb + k - 1u) : 255u;
+            if (t == 0u) {
+                if (readc == refc) {
+                    if (mds_op == 0u && run < 255u) ++run;
+                    else { close_run(); mds_op = 0u; push(0u); run_at = mds_len; push(1u); run = 1u; }
+                } else { close_run(); mds_op = 1u; push(1u); push(readc); ++ed; }
+                const uint32_t q = p.quals ? p.quals[min(pb + j - 1u, p.n_quals - 1u)] : 0u;
+                const uint32_t ref_mask = (1u << (refc & 31u)) & 0xFFu;
+                score += (readc > 3u || ref_mask > 15u) ? -p.n_penalty : ((ref_mask & (1u << readc)) ? p.match : mm[q]);
+            } else {
+                push(t == 2u ? refc : readc);
+                if (t != 3u) ++ed;
+            }
+        }
+    }
+    close_run();
+    if (p.mds_stride >= 2u) { mds[0] = uint8_t(mds_len & 0xFFu); mds[1] = uint8_t(mds_len >> 8); }
+    p.mds_len[w] = mds_len;
+    const uint32_t r = p.idx ? p.idx[w] : w;
+    const uint32_t mag = score < 0 ? uint32_t(-score) : uint32_t(score);
+    const uint32_t a = (p.best[r].x & 0xF0000000u) | (score < 0 ? 1u : 0u) | ((mag & 0x1FFFFu) << 1) | ((ed & 0x3FFu) << 18);
+    p.best[r] = make_uint2(a, uint32_t(tb));
+}
+
+} // namespace nvb
+
+NVB_API int nvbio_hip_finish_alignment(uint32_t n, const uint8_t* valid, const nvbio_hip_string_set* patterns, const uint8_t* quals, uint64_t n_quals,
+                                       const nvbio_hip_string_set* texts, const uint16_t* cigar, uint32_t cigar_stride, const uint32_t* cigar_len,
+                                       const uint32_t* cigar_source, int32_t match, const int32_t* mismatch_by_quality, int32_t n_penalty,
+                                       const uint32_t* idx, uint64_t* best_alignments, uint8_t* out_mds, uint32_t mds_stride, uint32_t* out_mds_len, void* stream)
+{
+    if (n == 0) return hipSuccess;
+    if (!valid || !patterns || !texts || !cigar || !cigar_len || !cigar_source || !mismatch_by_quality || !best_alignments || !out_mds || !out_mds_len ||
+        cigar_stride == 0 || mds_stride < 2) return hipErrorInvalidValue;
+    if (!(patterns->bits == 2 || patterns->bits == 4) || texts->bits != 2) return hipErrorNotSupported;
+    if (!patterns->words || !patterns->begin || !texts->words || !texts->begin) return hipErrorInvalidValue;
+    FinishParams p;
+    p.n = n; p.valid = valid; p.pat = make_string_set(patterns); p.txt = make_string_set(texts); p.quals = quals; p.n_quals = n_quals;
+    p.cigar = cigar; p.cigar_stride = cigar_stride; p.cigar_len = cigar_len; p.cigar_source = reinterpret_cast<const uint2*>(cigar_source);
+    p.match = match; p.n_penalty = n_penalty;
+    for (int i = 0; i < 256; ++i) p.mismatch[i] = mismatch_by_quality[i];
+    p.idx = idx; p.best = reinterpret_cast<uint2*>(best_alignments); p.mds = out_mds; p.mds_stride = mds_stride; p.mds_len = out_mds_len;
+    g_last_kernel = "finish_alignment_kernel";
+    hipLaunchKernelGGL(finish_alignment_kernel, grid_for(n), dim3(256), 0, to_stream(stream), p);
+    return hipGetLastError();
+}

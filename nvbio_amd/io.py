@@ -246,3 +246,27 @@ def read_fastq(path, max_reads=None, flags=SEQ_FORWARD, quality_encoding=PHRED33
     index[1:] = np.cumsum(lens)
     cat = lambda xs: np.concatenate(xs).astype(np.uint8) if xs else np.zeros(0, np.uint8)
     return SequenceDataHost(cat(syms), index, cat(quals), names)
+
+
+def sam_md_string(mds):
+    """The MD:Z value and the XM / XO / XG counters SamOutput::generate_md_string derives from an alignment's byte-coded MDS
+    (nvbio/io/output/output_sam.cpp:233-314): consecutive MATCH tokens are summed (as a byte, like the reference's uint8 counter), a
+    MISMATCH prints the symbol the MDS holds (finish_alignment stores the READ symbol there, traceback_inl.h:646), a DELETION prints
+    '^' + the reference symbols + '0', an INSERTION prints nothing.  -> (md, mm, gapo, gape)."""
+    n = int(mds[0]) | (int(mds[1]) << 8)
+    out, mm, gapo, gape, i = [], 0, 0, 0, 2
+    while i < n:
+        op = int(mds[i]); i += 1
+        if op == 0:
+            run = int(mds[i]); i += 1
+            while i < n and int(mds[i]) == 0:                      # (the reference adds the next token's OP byte, 0, and then reads that token's
+                run = (run + int(mds[i])) & 0xFF; i += 1           #  count as an op code, which matches no case: runs past 255 are garbled -- kept)
+            out.append(str(run))
+        elif op == 1:
+            out.append("ACGTN"[min(int(mds[i]), 4)]); i += 1; mm += 1
+        elif op == 2:
+            l = int(mds[i]); i += 1 + l; gapo += 1; gape += l - 1
+        elif op == 3:
+            l = int(mds[i]); i += 1
+            out.append("^" + "".join("ACGTN"[min(int(c), 4)] for c in mds[i:i + l]) + "0"); i += l; gapo += 1; gape += l - 1
+    return "".join(out), mm, gapo, gape

@@ -107,7 +107,7 @@ def pack_read_streams(sym):
     dev = sym.device
     idx = torch.arange(n, dtype=torch.int64, device=dev) * L
     rev = PackedStringSet(_pack_chunked(sym.flip(1).reshape(-1), 4, True), 4, True, idx, None, L)
-    both = torch.cat([sym.reshape(-1), (3 - sym).flip(1).reshape(-1)])
+    both = torch.cat([sym.reshape(-1), torch.where(sym > 3, sym, 3 - sym).flip(1).reshape(-1)])       # complement_functor<4>: N stays N
     ext_words = _pack_chunked(both, 4, True)
     return rev, ext_words
 

@@ -207,3 +207,20 @@ def traceback_best_setup(best_data, n, band_len, genome_len, fixed_read_len, rc_
                                                int(mate_offset), int(want), _vp(valid), _vp(pb), None, _vp(tb), _vp(tl), current_stream_ptr()),
           "nvbio_hip_traceback_best_setup")
     return valid, pb, tb, tl
+
+
+def finish_alignment(valid, patterns, quals, texts, cigar, cigar_len, source, scheme, best_data, idx=None, mds_stride=256):
+    """finish_alignment_kernel: MD strings (nvbio byte code) + the alignments of best_data[0] rewritten (window begin, edit distance, final score).
+    Returns (mds uint8[n, stride], mds_len int32[n])."""
+    import numpy as np
+    n = len(patterns)
+    dev = cigar.device
+    mds = torch.zeros((max(n, 1), mds_stride), dtype=torch.uint8, device=dev)
+    mds_len = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
+    st = scheme.struct()
+    lut = (C.c_int32 * 256)(*[st.mismatch[q] for q in range(256)])
+    ps, ts = patterns.struct(), texts.struct()
+    check(lib().nvbio_hip_finish_alignment(n, _vp(valid), C.byref(ps), _vp(quals), quals.numel() if quals is not None else 0, C.byref(ts), _vp(cigar), cigar.shape[1],
+                                           _vp(cigar_len), _vp(source), int(scheme.m_match), lut, int(getattr(scheme, "m_n_penalty", 1)), _vp(idx), _vp(best_data),
+                                           _vp(mds), mds_stride, _vp(mds_len), current_stream_ptr()), "nvbio_hip_finish_alignment")
+    return mds, mds_len[:n]

@@ -2515,6 +2515,74 @@ ORACLE_API void oracle_mark_discordant(uint32_t n_reads, uint64_t* best, uint64_
     }
 }
 
+/* ------------------------------------------------------------------------ */
+/* finish_alignment_kernel (nvBowtie/bowtie2/cuda/traceback_inl.h:523-722):     */
+/* from a best alignment's CIGAR, its MD string in nvbio's byte-coded form       */
+/* (io::MDS_OP, nvbio/io/alignments.h:46-52: [len lo, len hi] then {MATCH, run   */
+/* <= 255} / {MISMATCH, read symbol} / {INSERTION|DELETION, length byte, symbols */
+/* ...}), its edit distance (mismatches + inserted / deleted symbols, clips not   */
+/* counted) and its final score -- the sum of scoring_scheme.score() over the     */
+/* SUBSTITUTION columns only (scoring.h:301-311: N penalty if the read symbol is  */
+/* > 3, else match bonus or the quality's mismatch penalty) -- and the alignment  */
+/* rewritten by BestTracebackStream::finish (:177-189): m_align = window begin,   */
+/* m_ed, m_score.  CIGAR words are stored end first.  A CIGAR that overflowed its */
+/* slots cannot be replayed: the job is skipped (mds_len 0, alignment untouched). */
+/* ------------------------------------------------------------------------ */
+ORACLE_API void oracle_finish_alignment(uint32_t n, const uint8_t* valid,
+    const uint32_t* pw, uint32_t pbits, uint32_t pbe, const uint64_t* pbegin, const uint32_t* plen, const uint8_t* quals, uint64_t n_quals,
+    const uint32_t* tw, uint32_t tbe, const uint64_t* tbegin, const uint32_t* tlen,
+    const uint16_t* cigar, uint32_t cigar_stride, const uint32_t* cigar_len, const uint32_t* cigar_source /* 2n */,
+    int32_t match, const int32_t* mismatch_lut, int32_t n_penalty, const uint32_t* idx /* nullable */, uint64_t* best,
+    uint8_t* out_mds, uint32_t mds_stride, uint32_t* out_mds_len)
+{
+    for (uint32_t w = 0; w < n; ++w)
+    {
+        out_mds_len[w] = 0;
+        if (!valid[w] || cigar_len[w] == 0 || cigar_len[w] > cigar_stride) continue;
+        const uint16_t* cv = cigar + (uint64_t)w * cigar_stride;
+        uint8_t* mds = out_mds + (uint64_t)w * mds_stride;
+        #define MDS_PUSH(v) do { if (mds_len < mds_stride) mds[mds_len] = (uint8_t)(v); ++mds_len; } while (0)
+        uint32_t mds_len = 2, mds_op = 4 /* MDS_INVALID */, ed = 0, last_run = 0 /* index of the open MATCH run's counter */;
+        int32_t score = 0;
+        uint32_t j = 0, k = cigar_source[2 * w] & 0xFFFFu;
+        for (uint32_t i = 0; i < cigar_len[w]; ++i)
+        {
+            const uint32_t word = cv[cigar_len[w] - i - 1u], t = word & 3u, l = word >> 2;
+            if (t != 0u) {                                   /* INSERTION / DELETION / SOFT_CLIPPING header */
+                mds_op = (t == 2u) ? 3u : 2u;
+                MDS_PUSH(mds_op); MDS_PUSH(l);
+            }
+            for (uint32_t x = 0; x < l; ++x)
+            {
+                j += (t != 2u) ? 1u : 0u;
+                k += (t == 0u || t == 2u) ? 1u : 0u;
+                const uint32_t readc = j > 0 ? ps_get(pw, pbits, pbe, pbegin[w] + j - 1) : 255u;
+                const uint32_t refc  = k > 0 ? ps_get(tw, 2, tbe, tbegin[w] + k - 1) : 255u;
+                if (t == 0u) {
+                    if (readc == refc) {
+                        if (mds_op == 0u && last_run < mds_stride && mds[last_run] < 255) mds[last_run]++;
+                        else { mds_op = 0u; MDS_PUSH(0u); last_run = mds_len; MDS_PUSH(1u); }
+                    } else { mds_op = 1u; MDS_PUSH(1u); MDS_PUSH(readc); ++ed; }
+                    const uint32_t q = quals ? quals[(pbegin[w] + j - 1 < n_quals) ? pbegin[w] + j - 1 : n_quals - 1] : 0u;
+                    const uint32_t ref_mask = (1u << (refc & 31u)) & 0xFFu;
+                    score += (readc > 3u || ref_mask > 15u) ? -n_penalty : ((ref_mask & (1u << readc)) ? match : mismatch_lut[q]);
+                } else {
+                    MDS_PUSH(t == 2u ? refc : readc);
+                    if (t != 3u) ++ed;
+                }
+            }
+        }
+        #undef MDS_PUSH
+        if (mds_stride >= 2) { mds[0] = (uint8_t)(mds_len & 0xFF); mds[1] = (uint8_t)(mds_len >> 8); }
+        out_mds_len[w] = mds_len;
+        const uint32_t r = idx ? idx[w] : w;
+        uint32_t a = (uint32_t)best[r];
+        const uint32_t mag = score < 0 ? (uint32_t)(-score) : (uint32_t)score;
+        a = (a & 0xF0000000u) | (score < 0 ? 1u : 0u) | ((mag & 0x1FFFFu) << 1) | ((ed & 0x3FFu) << 18);
+        best[r] = ((uint64_t)(uint32_t)tbegin[w] << 32) | a;
+    }
+}
+
 /* paired-end reads: mapq(BestPairedAlignments(anchor best pair, opposite best pair), read_len, o_read_len) (mapq.h:56-58,150-166) */
 ORACLE_API void oracle_mapq_paired(int version, int32_t match, int min_type, float min_k, float min_m, int monotone,
     uint32_t n_reads, const uint64_t* best, const uint64_t* best_o, uint32_t best_stride, const uint32_t* read_len, const uint32_t* o_read_len, uint8_t* out)

@@ -764,6 +764,35 @@ def mark_discordant(best, best_o):
     lib().oracle_mark_discordant(C.c_uint32(best.shape[1]), _p(best), _p(best_o), C.c_uint32(best.shape[1]))
 
 
+def finish_alignment(valid, patterns, quals, texts, cigar, cigar_len, source, match, mismatch_lut, n_penalty, best_row, idx=None, mds_stride=256):
+    """finish_alignment_kernel over n jobs: returns (mds uint8[n, stride], mds_len uint32[n]) and rewrites best_row[idx[i] | i] in place."""
+    n = len(patterns)
+    mds = np.zeros((max(n, 1), mds_stride), dtype=np.uint8); mds_len = np.zeros(n, dtype=np.uint32)
+    cg = np.ascontiguousarray(cigar, dtype=np.uint16)
+    q = np.ascontiguousarray(quals, dtype=np.uint8) if quals is not None else None
+    lib().oracle_finish_alignment(C.c_uint32(n), _p(np.ascontiguousarray(valid, dtype=np.uint8)), _p(patterns.words), C.c_uint32(patterns.bits), C.c_uint32(patterns.big_endian),
+                                  _p(patterns.begin), _p(patterns.length), _p(q), C.c_uint64(q.size if q is not None else 0),
+                                  _p(texts.words), C.c_uint32(texts.big_endian), _p(texts.begin), _p(texts.length),
+                                  _p(cg), C.c_uint32(cg.shape[1]), _p(_u32(cigar_len)), _p(_u32(source)),
+                                  C.c_int32(match), _p(np.ascontiguousarray(mismatch_lut, dtype=np.int32)), C.c_int32(n_penalty),
+                                  _p(_u32(idx)) if idx is not None else None, _p(best_row), _p(mds), C.c_uint32(mds_stride), _p(mds_len))
+    return mds, mds_len
+
+
+def mds_to_string(mds):
+    """nvbio's byte-coded MDS -> the SAM MD:Z string (match counts, mismatched reference bases are not kept by nvbio: it stores the READ symbol
+    of a mismatch, so the SAM writer re-reads the reference; here the read symbol is shown lower-case) -- a debugging aid for the tests."""
+    n = int(mds[0]) | (int(mds[1]) << 8)
+    out, i = [], 2
+    while i < n:
+        op = int(mds[i])
+        if op == 0: out.append(str(int(mds[i + 1]))); i += 2
+        elif op == 1: out.append("acgtn"[min(int(mds[i + 1]), 4)]); i += 2
+        else:
+            l = int(mds[i + 1]); out.append(("^" if op == 3 else "+") + "".join("ACGTN"[min(int(c), 4)] for c in mds[i + 2:i + 2 + l])); i += 2 + l
+    return "".join(out)
+
+
 def score_reduce_paired(best, best_o, hit_begin, hit_loc, hit_sink, hit_score, hit_rc, o_loc, o_sink, o_sink2, o_score, o_score2,
                         read_len, anchor, pe_policy, pe_unpaired, score_limit, read_ids=None):
     hb = _u64(hit_begin); n = hb.size - 1

@@ -13,6 +13,7 @@ struct shim_params
              seed_len, seed_freq_type, min_read_len, max_dist, no_multi_hits, batch_size, hits_stride;
     float    seed_freq_k, seed_freq_m;
     int32_t  match, score_min_type; float score_min_k, score_min_m;
+    uint32_t finish;
 };
 
 extern "C" __attribute__((visibility("default")))
@@ -22,7 +23,8 @@ int nvbio_aligner_best_approx(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmin
                               const char* d_names, const uint32_t* d_names_idx,
                               const uint32_t* d_genome_words, uint64_t genome_n_words, uint32_t genome_len, const shim_params* sp,
                               uint64_t* h_best /* 2n */, uint8_t* h_mapq, uint16_t* h_cigar /* n*64 */, uint32_t* h_cigar_len, uint32_t* h_source, uint32_t* h_sink,
-                              int32_t* h_tb_score, uint64_t* h_stats /* extensions, rounds, seeding_passes, n_queue, queue[8] */)
+                              int32_t* h_tb_score, uint64_t* h_stats /* extensions, rounds, seeding_passes, n_queue, queue[8] */,
+                              uint8_t* h_mds /* n*256 */, uint32_t* h_mds_len)
 {
     try {
         Params params;
@@ -32,7 +34,7 @@ int nvbio_aligner_best_approx(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmin
         params.select.randomized = sp->randomized != 0; params.select.top_seed = sp->top_seed; params.select.max_effort_init = sp->max_effort_init;
         params.select.max_effort = sp->max_effort; params.select.min_ext = sp->min_ext; params.select.max_ext = sp->max_ext;
         params.max_dist = sp->max_dist; params.alignment_type = sp->local ? LocalAlignment : EndToEndAlignment;
-        params.no_multi_hits = sp->no_multi_hits != 0; params.hits_stride = sp->hits_stride;
+        params.no_multi_hits = sp->no_multi_hits != 0; params.hits_stride = sp->hits_stride; params.finish_alignments = sp->finish != 0;
 
         aln::SmithWatermanScoringScheme scheme = sp->local ? aln::SmithWatermanScoringScheme::local() : aln::SmithWatermanScoringScheme();
         scheme.m_match = sp->match;
@@ -58,6 +60,8 @@ int nvbio_aligner_best_approx(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmin
         const std::vector<uint32> so = aligner.cigar_source.to_host();     memcpy(h_source, so.data(), size_t(n) * 8u);
         const std::vector<uint32> si = aligner.cigar_sink.to_host();       memcpy(h_sink, si.data(), size_t(n) * 8u);
         const std::vector<int32> ts = aligner.traceback_score.to_host();   memcpy(h_tb_score, ts.data(), size_t(n) * 4u);
+        const std::vector<uint8> md = aligner.mds.to_host();               memcpy(h_mds, md.data(), size_t(n) * aligner.mds_stride);
+        const std::vector<uint32> ml = aligner.mds_len.to_host();          memcpy(h_mds_len, ml.data(), size_t(n) * 4u);
         h_stats[0] = stats.extensions; h_stats[1] = stats.rounds; h_stats[2] = stats.seeding_passes; h_stats[3] = stats.queue.size();
         for (size_t k = 0; k < stats.queue.size() && k < 8; ++k) h_stats[4 + k] = stats.queue[k];
         return 0;

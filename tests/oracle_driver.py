@@ -32,7 +32,7 @@ def qual_scheme(scheme):
 
 
 def best_approx(host_fmi, host_rfmi, sym, genome_words, genome_len, params, scheme, names, aln_type, qual_value=30, traceback=True, cigar_stride=64,
-                read_quals=None):
+                read_quals=None, finish=False, mds_stride=256):
     n, L = sym.shape
     band = band_length(params.max_dist)
     reads_rev, ext_words = pack_reads(sym)
@@ -91,10 +91,17 @@ def best_approx(host_fmi, host_rfmi, sym, genome_words, genome_len, params, sche
         txt = O.StringSet(genome_words, 2, True, tbeg.astype(np.uint64), (tend - tbeg).astype(np.uint32))
         r = O.batch_banded_gotoh_traceback(band, aln_type, sch6[:5], pat, txt, cigar_stride, mm_lut=lut, quals=quals)
         out.update(aligned_ids=ids, tb=r)
+        if finish:                                       # finish_alignment_best (traceback_inl.h:523-760)
+            out["best_scored"] = best.copy()
+            mds, mds_len = O.finish_alignment(np.ones(ids.size, np.uint8), pat, quals, txt, r["cigar"][: ids.size], r["cigar_len"], r["source"], scheme.m_match, lut, 1,
+                                              best[0], idx=ids, mds_stride=mds_stride)
+            out["mds"] = np.zeros((n, mds_stride), np.uint8); out["mds"][ids] = mds[: ids.size]
+            out["mds_len"] = np.zeros(n, np.uint32); out["mds_len"][ids] = mds_len
     return out
 
 
-def best_approx_paired(host_fmi, host_rfmi, sym1, sym2, genome_words, genome_len, params, scheme, names, aln_type, qual_value=30, cigar_stride=64):
+def best_approx_paired(host_fmi, host_rfmi, sym1, sym2, genome_words, genome_len, params, scheme, names, aln_type, qual_value=30, cigar_stride=64,
+                       finish=False, mds_stride=256):
     """Aligner::best_approx for pairs (aligner_best_approx_paired.h:95-453, :455-700), numpy over the oracle."""
     n, L = sym1.shape
     band = band_length(params.max_dist)
@@ -172,9 +179,13 @@ def best_approx_paired(host_fmi, host_rfmi, sym1, sym2, genome_words, genome_len
     out = dict(best=best, best_o=best_o, mapq1=mapq1, mapq2=mapq2, stats=stats)
     mate_words = (packed[0][1], packed[1][1])
 
+    if finish:
+        out["best_scored"], out["best_o_scored"] = best.copy(), best_o.copy()
+
     def trace(data, ids, full):
         res = dict(cigar=np.zeros((n, cigar_stride), np.uint16), cigar_len=np.zeros(n, np.uint32), source=np.full((n, 2), 0xFFFFFFFF, np.uint32),
-                   sink=np.full((n, 2), 0xFFFFFFFF, np.uint32), score=np.full(n, WORST_SCORE, np.int32))
+                   sink=np.full((n, 2), 0xFFFFFFFF, np.uint32), score=np.full(n, WORST_SCORE, np.int32),
+                   mds=np.zeros((n, mds_stride), np.uint8), mds_len=np.zeros(n, np.uint32))
         for i in ids:
             w = int(data[0][i])
             align, rcb, mate, g_len = w >> 32, (w >> 28) & 1, (w >> 29) & 1, (w >> 18) & 0x3FF
@@ -189,10 +200,17 @@ def best_approx_paired(host_fmi, host_rfmi, sym1, sym2, genome_words, genome_len
                                                    cigar_stride, mm_lut=lut, quals=quals)
             for key in ("cigar", "cigar_len", "source", "sink", "score"):
                 res[key][i] = r[key][0]
+            if finish:                                   # finish_alignment_best / finish_opposite_alignment_best on this slot
+                txt = O.StringSet(genome_words, 2, True, np.array([tb0], np.uint64), np.array([tb1 - tb0], np.uint32))
+                m, ml = O.finish_alignment(np.ones(1, np.uint8), pat, quals, txt, r["cigar"][:1], r["cigar_len"], r["source"], scheme.m_match, lut, 1, data[0],
+                                           idx=np.array([i], np.uint32), mds_stride=mds_stride)
+                res["mds"][i] = m[0]; res["mds_len"][i] = ml[0]
         return res
 
     aligned = lambda d: (d[0] >> np.uint64(32)) != np.uint64(0xFFFFFFFF)
     out["tb1"] = trace(best, np.nonzero(aligned(best))[0], lambda i: False)
+    if finish:       # mate 2's MAPQ is evaluated after the anchor slots were finished (aligner_best_approx_paired.h:308-323)
+        out["mapq2"] = O.mapq_paired(2, scheme.m_match, scheme.m_score_min, scheme.m_monotone, best_o, best, read_len, read_len)
     w_o = best_o[0]
     conc = (((w_o >> np.uint64(30)) & np.uint64(1)) != 0) & (((w_o >> np.uint64(31)) & np.uint64(1)) == 0)
     out["tb2"] = trace(best_o, np.nonzero(aligned(best_o))[0], lambda i: bool(conc[i]))

@@ -146,5 +146,14 @@ def test_files_to_sam_example(tmp_path, cuda):
         i = int(ln[0][4:])
         consumed = sum(int(k) for k, op in re.findall(r"(\d+)([MIDS])", ln[5]) if op in "MIS")
         assert consumed == L
-        good += (int(ln[3]) - 1 == pos[i]) and (ln[1] == ("16" if i % 2 else "0"))
+        ok = (int(ln[3]) - 1 == pos[i]) and (ln[1] == ("16" if i % 2 else "0"))
+        good += ok
+        tags = dict((t.split(":")[0], t.split(":", 2)[2]) for t in ln[11:])
+        assert set(tags) == {"NM", "AS", "XM", "XO", "XG", "MD"}          # SamOutput's tag set (output_sam.cpp:354-365)
+        if ok and ln[5] == "%dM" % L:
+            # an ungapped placement at the origin: NM = XM = the Hamming distance to the genome, AS = -(sum of the mismatch penalties) = -6 each at Q40
+            seq = np.array(["ACGT".index(c) for c in ln[9]], dtype=np.uint8)
+            ham = int((seq != text[pos[i]:pos[i] + L]).sum())
+            assert int(tags["NM"]) == ham == int(tags["XM"]) and tags["XO"] == tags["XG"] == "0" and int(tags["AS"]) == -6 * ham
+            assert sum(int(x) for x in re.findall(r"\d+", tags["MD"])) + ham == L
     assert good > 0.95 * len(aligned)

@@ -172,6 +172,7 @@ CONFIGS = {
     "subseed": dict(allow_sub=1, subseed_len=12, max_reseed=1),
     "local": dict(local=True, seed_len=20, seed_freq=(2, 1.0, 0.75)),
     "read_quals": dict(),                                        # per-base Phred qualities instead of a constant
+    "finish": dict(),                                            # + finish_alignment: MD strings, edit distances, final scores
 }
 
 
@@ -191,9 +192,21 @@ def test_best_approx_driver_matches_oracle(cuda, config):
     scheme = nvb.SmithWatermanScoringScheme.local() if params.local else nvb.SmithWatermanScoringScheme()
     gw = W._pack_chunked(torch.from_numpy(text), 2, True)
     rq = rng.integers(2, 42, (n, L)).astype(np.uint8) if config == "read_quals" else None
-    e = OD.best_approx(host, rhost, sym, gw.numpy().view(np.uint32), text.size, params, scheme, names, 1 if params.local else 2, read_quals=rq)
+    fin = config == "finish"
+    e = OD.best_approx(host, rhost, sym, gw.numpy().view(np.uint32), text.size, params, scheme, names, 1 if params.local else 2, read_quals=rq, finish=fin)
     r = A.best_approx(fmi, rfmi, torch.from_numpy(sym).to(cuda), gw.to(cuda), text.size, params, scheme, names, cigar_stride=64,
-                      quals=torch.from_numpy(rq) if rq is not None else None)
+                      quals=torch.from_numpy(rq) if rq is not None else None, finish=fin)
+    if fin:
+        assert (r["mds_len"].cpu().numpy().view(np.uint32) == e["mds_len"]).all()
+        m = np.arange(256)[None, :] < np.minimum(e["mds_len"], 256)[:, None]
+        assert ((r["mds"].cpu().numpy() == e["mds"]) | ~m).all()
+        assert (r["best_scored"].cpu().numpy().view(np.uint64) == e["best_scored"]).all()
+        # the finished words: edit distance = mismatches + gap symbols of the CIGAR / MD, score <= 0 end-to-end, position = the window's begin
+        fw = e["best"][0][e["aligned_ids"]]
+        ed = ((fw >> np.uint64(18)) & np.uint64(0x3FF)).astype(np.int64)
+        assert ed.max() > 3 and (ed >= 0).all()
+        k = int(e["aligned_ids"][int(np.argmax(ed))])
+        assert len(O.mds_to_string(e["mds"][k])) > 0
     torch.cuda.synchronize()
     assert r["stats"] == e["stats"], (r["stats"], e["stats"])
     assert (r["best"].cpu().numpy().view(np.uint64) == e["best"]).all()
@@ -207,7 +220,7 @@ def test_best_approx_driver_matches_oracle(cuda, config):
     assert (r["cigar_len"].cpu().numpy().sum() == tb["cigar_len"].sum()) and (r["source"].cpu().numpy()[~np.isin(np.arange(n), ids)] == -1).all()
     assert (r["sink"].cpu().numpy()[ids].view(np.uint32) == tb["sink"]).all() and (r["source"].cpu().numpy()[ids].view(np.uint32) == tb["source"]).all()
     # sanity of the result itself: simulated reads (not the random ones) come back at their origin
-    best0 = e["best"][0]
+    best0 = (e["best_scored"] if fin else e["best"])[0]
     loc = (best0 >> np.uint64(32)).astype(np.int64)
     aligned = loc != 0xFFFFFFFF
     sim = np.arange(n) % 19 != 0
@@ -251,6 +264,7 @@ PAIRED_CONFIGS = {
     "multi_rounds_no_mixed": dict(batch_size=3000, pe_unpaired=False, pe_discordant=False),
     "low_effort_subseed": dict(max_effort=3, max_effort_init=3, min_ext=4, max_ext=40, allow_sub=1, subseed_len=12, max_reseed=1),
     "ff_policy": dict(pe_policy=0, max_frag_len=450),
+    "finish": dict(),                                            # + finish_alignment on both slot sets (MD strings, edit distances, final scores)
 }
 
 
@@ -271,17 +285,27 @@ def test_best_approx_paired_driver_matches_oracle(cuda, config):
     params = A.Params(**PAIRED_CONFIGS[config])
     scheme = nvb.SmithWatermanScoringScheme.local() if params.local else nvb.SmithWatermanScoringScheme()
     gw = W._pack_chunked(torch.from_numpy(text), 2, True)
-    e = OD.best_approx_paired(host, rhost, s1, s2, gw.numpy().view(np.uint32), text.size, params, scheme, names, 1 if params.local else 2)
-    r = A.best_approx_paired(fmi, rfmi, torch.from_numpy(s1).to(cuda), torch.from_numpy(s2).to(cuda), gw.to(cuda), text.size, params, scheme, names)
+    fin = config == "finish"
+    e = OD.best_approx_paired(host, rhost, s1, s2, gw.numpy().view(np.uint32), text.size, params, scheme, names, 1 if params.local else 2, finish=fin)
+    r = A.best_approx_paired(fmi, rfmi, torch.from_numpy(s1).to(cuda), torch.from_numpy(s2).to(cuda), gw.to(cuda), text.size, params, scheme, names, finish=fin)
     torch.cuda.synchronize()
     assert r["stats"] == e["stats"], (r["stats"], e["stats"])
-    for key in ("best", "best_o"):
+    for key in ("best", "best_o") + (("best_scored", "best_o_scored") if fin else ()):
         assert (r[key].cpu().numpy().view(np.uint64) == e[key]).all(), key
     assert (r["mapq1"].cpu().numpy() == e["mapq1"]).all() and (r["mapq2"].cpu().numpy() == e["mapq2"]).all()
-    for slot in ("tb1", "tb2"):
-        for key in ("cigar_len", "cigar", "source", "sink", "score"):
+    for slot, data in (("tb1", "best_scored" if fin else "best"), ("tb2", "best_o_scored" if fin else "best_o")):
+        al = (e[data][0] >> np.uint64(32)) != np.uint64(0xFFFFFFFF)
+        for key in ("cigar_len", "cigar", "source", "sink"):
             got = r[slot][key].cpu().numpy()
             assert (got.view(e[slot][key].dtype) == e[slot][key]).all(), (slot, key)
+        assert (r[slot]["score"].cpu().numpy()[al] == e[slot]["score"][al]).all(), slot
+        if fin:
+            k = "mds1" if slot == "tb1" else "mds2"
+            assert (r[k + "_len"].cpu().numpy().view(np.uint32) == e[slot]["mds_len"]).all(), k
+            m = np.arange(256)[None, :] < np.minimum(e[slot]["mds_len"], 256)[:, None]
+            assert ((r[k].cpu().numpy() == e[slot]["mds"]) | ~m).all(), k
+    if fin:
+        e = dict(e, best=e["best_scored"], best_o=e["best_o_scored"])          # the sanity checks below look at the extension-stage words
     # the result itself: most pairs come back concordant at their fragment's two ends
     b, bo = e["best"][0], e["best_o"][0]
     paired = ((b >> np.uint64(30)) & np.uint64(1)) != 0
@@ -307,10 +331,10 @@ class _ShimParams(_C.Structure):
                                            "max_hits", "allow_sub", "subseed_len", "seed_len", "seed_freq_type", "min_read_len", "max_dist", "no_multi_hits",
                                            "batch_size", "hits_stride")] + \
                [("seed_freq_k", _C.c_float), ("seed_freq_m", _C.c_float), ("match", _C.c_int32), ("score_min_type", _C.c_int32),
-                ("score_min_k", _C.c_float), ("score_min_m", _C.c_float)]
+                ("score_min_k", _C.c_float), ("score_min_m", _C.c_float), ("finish", _C.c_uint32)]
 
 
-@pytest.mark.parametrize("config", ["default", "no_rand", "one_hit_rounds", "multi_rounds", "one_mismatch_seeds", "local", "low_effort"])
+@pytest.mark.parametrize("config", ["default", "no_rand", "one_hit_rounds", "multi_rounds", "one_mismatch_seeds", "local", "low_effort", "finish"])
 def test_cxx_aligner_driver_matches_oracle(cuda, config):
     """The C++ host driver (include/nvbio_hip/aligner.h: nvbio::bowtie2::cuda::Aligner::best_approx), called through tests/cxx/aligner_shim.cpp
     on device-resident inputs: identical to the numpy driver over the oracle (and so to the Python driver)."""
@@ -329,7 +353,8 @@ def test_cxx_aligner_driver_matches_oracle(cuda, config):
     params = A.Params(**CONFIGS[config])
     scheme = nvb.SmithWatermanScoringScheme.local() if params.local else nvb.SmithWatermanScoringScheme()
     gw = W._pack_chunked(torch.from_numpy(text), 2, True)
-    e = OD.best_approx(host, rhost, sym, gw.numpy().view(np.uint32), text.size, params, scheme, names, 1 if params.local else 2)
+    fin = config == "finish"
+    e = OD.best_approx(host, rhost, sym, gw.numpy().view(np.uint32), text.size, params, scheme, names, 1 if params.local else 2, finish=fin)
 
     d_sym = torch.from_numpy(sym).to(cuda)
     reads_rev, fwrc = P.pack_read_streams(d_sym)
@@ -339,7 +364,8 @@ def test_cxx_aligner_driver_matches_oracle(cuda, config):
     sp = _ShimParams(int(params.local), int(params.randomized), params.top_seed, params.max_effort_init, params.max_effort, params.min_ext, params.max_ext,
                      params.max_reseed, params.rep_seeds, params.max_hits, params.allow_sub, params.subseed_len, params.seed_len, params.seed_freq[0],
                      params.min_read_len, params.max_dist, int(params.no_multi_hits), params.batch_size, params.hits_stride or 0,
-                     params.seed_freq[1], params.seed_freq[2], scheme.m_match, scheme.m_score_min[0], scheme.m_score_min[1], scheme.m_score_min[2])
+                     params.seed_freq[1], params.seed_freq[2], scheme.m_match, scheme.m_score_min[0], scheme.m_score_min[1], scheme.m_score_min[2], int(fin))
+    mds = np.zeros((n, 256), np.uint8); mds_len = np.zeros(n, np.uint32)
     best = np.zeros((2, n), np.uint64); mapq = np.zeros(n, np.uint8); cigar = np.zeros((n, 64), np.uint16); cigar_len = np.zeros(n, np.uint32)
     source = np.zeros((n, 2), np.uint32); sink = np.zeros((n, 2), np.uint32); tb_score = np.zeros(n, np.int32); stats = np.zeros(12, np.uint64)
     fs, rs = fmi.struct(), rfmi.struct()
@@ -349,8 +375,12 @@ def test_cxx_aligner_driver_matches_oracle(cuda, config):
     rc = shim.nvbio_aligner_best_approx(C.byref(fs), C.byref(rs), C.c_uint32(n), C.c_uint32(L), vp(reads_rev.words), C.c_uint64(reads_rev.words.numel()),
                                         vp(reads_rev.begin), vp(fwrc), C.c_uint64(fwrc.numel()), vp(quals), C.c_uint64(quals.numel()), vp(arena), vp(idx),
                                         vp(d_gw), C.c_uint64(d_gw.numel()), C.c_uint32(text.size), C.byref(sp),
-                                        hp(best), hp(mapq), hp(cigar), hp(cigar_len), hp(source), hp(sink), hp(tb_score), hp(stats))
+                                        hp(best), hp(mapq), hp(cigar), hp(cigar_len), hp(source), hp(sink), hp(tb_score), hp(stats), hp(mds), hp(mds_len))
     assert rc == 0
+    if fin:
+        assert (mds_len == e["mds_len"]).all()
+        m = np.arange(256)[None, :] < np.minimum(e["mds_len"], 256)[:, None]
+        assert ((mds == e["mds"]) | ~m).all()
     assert (best == e["best"]).all() and (mapq == e["mapq"]).all()
     st = e["stats"]
     assert (int(stats[0]), int(stats[1]), int(stats[2])) == (st["extensions"], st["rounds"], st["seeding_passes"])

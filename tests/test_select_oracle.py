@@ -220,3 +220,17 @@ def test_reduce_best_approx_counters():
     assert trys.tolist() == [3, 3, 3, 3] and counts.tolist() == [9, 9, 9, 9]
     O.score_reduce_best_approx(best, active, hb, np.full(4, -900, np.int32), loc + 9, seed2, read_len, -(1 << 16), trys, counts, 400, 30, 400, 15)
     assert trys.tolist() == [2, 3, 2, 2] and counts.tolist() == [0, 0, 0, 0]
+
+
+def test_sam_md_string_rendering():
+    """SamOutput::generate_md_string over nvbio's byte-coded MDS (output_sam.cpp:233-314), as restated in nvbio_amd.io.sam_md_string"""
+    from nvbio_amd.io import sam_md_string
+    def mds(*tokens):
+        body = [b for t in tokens for b in t]
+        n = len(body) + 2
+        return np.array([n & 0xFF, n >> 8] + body, dtype=np.uint8)
+    assert sam_md_string(mds((0, 60))) == ("60", 0, 0, 0)
+    assert sam_md_string(mds((0, 10), (1, 3), (0, 49))) == ("10T49", 1, 0, 0)                      # the symbol stored with a MISMATCH is printed
+    assert sam_md_string(mds((0, 30), (3, 2, 1, 2), (0, 30))) == ("30^CG030", 0, 1, 1)               # deletion: '^' + symbols + '0'
+    assert sam_md_string(mds((2, 3, 0, 0, 0), (0, 57))) == ("57", 0, 1, 2)                           # insertion (or soft clip): counted, not printed
+    assert sam_md_string(mds((1, 4), (0, 5)))[0] == "N5"

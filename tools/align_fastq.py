@@ -2,7 +2,8 @@
 """Real-data flow through the library: <prefix>.bwt/.sa (+ .wpac/.pac genome) and a FASTQ file of equal-length reads ->
 SAM lines through nvBowtie's single-end best-mapping driver (nvbio_amd.aligner.best_approx = Aligner::best_approx: seeding
 passes, randomized hit selection seeded by the read names, quality-aware extension, give-up counters, MAPQ, traceback).
-A usage example, not nvBowtie's CLI: mandatory SAM fields + AS:i / XS:i only, single reference sequence, no read groups.
+A usage example, not nvBowtie's CLI: the mandatory SAM fields and the tags SamOutput writes (NM, AS, XM, XO, XG, MD from the finished
+alignments; nvbio/io/output/output_sam.cpp:316-366), single reference sequence, no read groups.
 
     python tools/align_fastq.py <index prefix> <reads.fastq> [out.sam]"""
 import sys
@@ -33,11 +34,11 @@ def main(prefix, fastq, out=sys.stdout, device="cuda", ref_name="ref"):
     params = A.Params(hits_stride=32)
     band = A.band_length(params.max_dist)
     r = A.best_approx(data.index(), None, sym, genome_words, n_genome, params, names=list(reads.names), cigar_stride=64,
-                      quals=torch.from_numpy(reads.quals.reshape(reads.size(), L)))
+                      quals=torch.from_numpy(reads.quals.reshape(reads.size(), L)), finish=True)
     torch.cuda.synchronize()
-    best = r["best"].cpu().numpy().view(np.uint64)
+    best = r["best"].cpu().numpy().view(np.uint64)            # finished: m_align = the traceback window's begin, m_ed, final score
     mapq, cig, clen = r["mapq"].cpu().numpy(), r["cigar"].cpu().numpy().view(np.uint16), r["cigar_len"].cpu().numpy()
-    source = r["source"].cpu().numpy()
+    source, mds = r["source"].cpu().numpy(), r["mds"].cpu().numpy()
     out.write("@HD\tVN:1.0\tSO:unsorted\n@SQ\tSN:%s\tLN:%d\n@PG\tID:nvbio_amd\tPN:nvbio_amd\n" % (ref_name, n_genome))
     quals = reads.quals.reshape(reads.size(), L)
     for i in range(reads.size()):
@@ -47,15 +48,12 @@ def main(prefix, fastq, out=sys.stdout, device="cuda", ref_name="ref"):
             out.write("%s\t4\t*\t0\t0\t*\t*\t0\t0\t%s\t%s\n" % (reads.names[i], "".join("ACGTN"[c] for c in seq), "".join(chr(int(q) + 33) for q in quals[i])))
             continue
         rc = (w >> 28) & 1
-        score = ((w >> 1) & 0x1FFFF) * (-1 if w & 1 else 1)
+        score, ed = ((w >> 1) & 0x1FFFF) * (-1 if w & 1 else 1), (w >> 18) & 0x3FF
         s, q = (np.where(seq < 4, 3 - seq, 4)[::-1], quals[i][::-1]) if rc else (seq, quals[i])
-        tags = "AS:i:%d" % score
-        w2 = int(best[1, i] & 0xFFFFFFFF)
-        if int(best[1, i] >> 32) != 0xFFFFFFFF:
-            tags += "\tXS:i:%d" % (((w2 >> 1) & 0x1FFFF) * (-1 if w2 & 1 else 1))
-        out.write("%s\t%d\t%s\t%d\t%d\t%s\t*\t0\t0\t%s\t%s\t%s\n" % (
-            reads.names[i], 16 if rc else 0, ref_name, max(pos - band // 2, 0) + int(source[i, 0]) + 1, int(mapq[i]), cigar_string(cig[i], int(clen[i])),
-            "".join("ACGTN"[c] for c in s), "".join(chr(int(x) + 33) for x in q), tags))
+        md, mm, gapo, gape = nio.sam_md_string(mds[i])
+        out.write("%s\t%d\t%s\t%d\t%d\t%s\t*\t0\t0\t%s\t%s\tNM:i:%d\tAS:i:%d\tXM:i:%d\tXO:i:%d\tXG:i:%d\tMD:Z:%s\n" % (
+            reads.names[i], 16 if rc else 0, ref_name, pos + int(source[i, 0]) + 1, int(mapq[i]), cigar_string(cig[i], int(clen[i])),
+            "".join("ACGTN"[c] for c in s), "".join(chr(int(x) + 33) for x in q), ed, score, mm, gapo, gape, md or "*"))
 
 
 if __name__ == "__main__":
