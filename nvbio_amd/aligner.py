@@ -79,8 +79,7 @@ def hits_per_read(n_active, n_ext, params):
     return 1
 
 
-def best_approx_score(fmi, rfmi, state, seed_queue, best, reads_fw_rc, n_reads, read_len, genome_words, genome_len, aligner, quals,
-                      params, band_len, stats):
+def best_approx_score(fmi, rfmi, state, seed_queue, best, batch, genome_words, genome_len, aligner, params, band_len, stats):
     """Aligner::best_approx_score: the extension rounds of one seeding pass (`state` = select_init's output)."""
     active = seed_queue.to(torch.int32)                                   # pack_read(params.top_seed), defs.h:185-205
     if params.top_seed & 1:
@@ -97,14 +96,14 @@ def best_approx_score(fmi, rfmi, state, seed_queue, best, reads_fw_rc, n_reads, 
         with _Stage(stats, "locate"):
             sel.locate_hits(fmi, rfmi, loc, seed)
         with _Stage(stats, "score"):
-            pb, _, tb, tl, _ = sel.score_best_setup(rid, loc, seed, best, band_len, genome_len, WORST_SCORE, fixed_read_len=read_len,
-                                                    rc_offset=n_reads * read_len)
-            patterns = PackedStringSet(reads_fw_rc, 4, True, pb, None, read_len)
+            pb, pl, tb, tl, _ = sel.score_best_setup(rid, loc, seed, best, band_len, genome_len, WORST_SCORE, fixed_read_len=batch.fixed_len,
+                                                     read_begin=batch.read_begin, read_len=batch.read_len, rc_offset=batch.rc_offset)
+            patterns = PackedStringSet(batch.fw_rc_words, 4, True, pb, pl, batch.fixed_len)
             texts = PackedStringSet(genome_words, 2, True, tb, tl, 0)
-            score, _ = batch_banded_alignment_score(band_len, aligner, patterns, texts, quals=quals)
+            score, _ = batch_banded_alignment_score(band_len, aligner, patterns, texts, max_pattern_length=batch.max_len, quals=batch.quals)
         with _Stage(stats, "reduce"):
             sel.score_reduce_best_approx(best, state, active, hit_begin, score, loc, seed, WORST_SCORE, n_ext, params.min_ext, params.max_ext,
-                                         params.max_effort, fixed_read_len=read_len)
+                                         params.max_effort, fixed_read_len=batch.fixed_len, read_len=batch.read_len)
         stats["extensions"] += int(loc.numel()); stats["rounds"] += 1
         n_ext += n_multi
 
@@ -117,20 +116,58 @@ def _qual_stream(n, L, qual_value, quals, dev):
     return torch.cat([q.reshape(-1), q.flip(1).reshape(-1), torch.zeros(8, dtype=torch.uint8, device=dev)])
 
 
+class ReadBatch:
+    """A batch of reads on the device in the layouts the stages read (io::SequenceDataDevice's role): stored reversed (io::REVERSE: what
+    the mappers scan), forward copies followed rc_offset symbols later by the reverse complements (extension / traceback patterns), one
+    quality byte per pattern symbol.  Equal-length batches keep fixed_len (no per-read arrays); ragged ones carry begin / length."""
+
+    def __init__(self, n, max_len, fixed_len, read_begin, read_len, reversed_set, fw_rc_words, rc_offset, quals):
+        self.n, self.max_len, self.fixed_len, self.read_begin, self.read_len = n, max_len, fixed_len, read_begin, read_len
+        self.reversed, self.fw_rc_words, self.rc_offset, self.quals = reversed_set, fw_rc_words, rc_offset, quals
+
+    @staticmethod
+    def from_matrix(sym, qual_value=30, quals=None, packed=None):
+        from .pipeline import pack_read_streams
+        n, L = sym.shape
+        reads_rev, fw_rc = packed if packed is not None else pack_read_streams(sym)
+        return ReadBatch(n, L, L, None, None, reads_rev, fw_rc, n * L, _qual_stream(n, L, qual_value, quals, sym.device))
+
+    @staticmethod
+    def from_ragged(symbols, index, quals=None, qual_value=30):
+        """symbols: uint8 [total] (0..4), index: int64 [n+1] offsets, quals: uint8 [total] or None"""
+        from .workloads import _pack_chunked
+        dev = symbols.device
+        index = index.to(torch.int64)
+        n, total = index.numel() - 1, int(index[-1])
+        length = (index[1:] - index[:-1])
+        pos = torch.arange(total, device=dev)
+        r = torch.searchsorted(index, pos, right=True) - 1
+        mirror = index[r + 1] - 1 - (pos - index[r])                                  # the same read's symbol counted from its end
+        rev = symbols[mirror]
+        rc = torch.where(rev > 3, rev, 3 - rev)                                       # complement_functor<4>: N stays N
+        begin = index[:-1].contiguous()
+        len32 = length.to(torch.int32).contiguous()
+        reversed_set = PackedStringSet(_pack_chunked(rev, 4, True), 4, True, begin, len32, 0)
+        fw_rc = _pack_chunked(torch.cat([symbols, rc]), 4, True)
+        q = torch.full((total,), qual_value, dtype=torch.uint8, device=dev) if quals is None else quals.to(dev).to(torch.uint8)
+        qs = torch.cat([q, q[mirror], torch.zeros(8, dtype=torch.uint8, device=dev)])
+        return ReadBatch(n, int(length.max()) if n else 0, 0, begin, len32, reversed_set, fw_rc, total, qs)
+
+
 def best_approx(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=None, names=None, qual_value=30, traceback=True,
                 cigar_stride=None, stage_times=False, packed=None, quals=None, finish=False, mds_stride=256):
-    """Aligner::best_approx for a batch of equal-length reads `sym` (uint8 [n, L], symbols 0..4).  `names`: list of read
-    names (they seed the randomized selection).  Returns dict(best int64[2,n] io::Alignment words, mapq uint8[n], and with
-    traceback: cigar int16[n,stride], cigar_len, source, sink (-1 for unaligned reads), stats)."""
-    from .pipeline import pack_read_streams
+    """Aligner::best_approx for a batch of reads: `sym` is a uint8 [n, L] matrix of equal-length reads (symbols 0..4) or a ReadBatch
+    (ReadBatch.from_ragged for reads of different lengths).  `names`: list of read names (they seed the randomized selection).
+    Returns dict(best int64[2,n] io::Alignment words, mapq uint8[n], and with traceback: cigar int16[n,stride], cigar_len, source,
+    sink (-1 for unaligned reads), stats)."""
     params = params or Params()
-    n, L = sym.shape
-    dev = sym.device
+    batch = sym if isinstance(sym, ReadBatch) else ReadBatch.from_matrix(sym, qual_value, quals, packed)
+    n, L = batch.n, batch.max_len                                                    # L: the longest read
+    dev = batch.fw_rc_words.device
     scheme = scheme or (SmithWatermanScoringScheme.local() if params.local else SmithWatermanScoringScheme())
     aligner = make_gotoh_aligner(LOCAL if params.local else SEMI_GLOBAL, scheme)
     band_len = band_length(params.max_dist)
-    reads_rev, reads_fw_rc = packed if packed is not None else pack_read_streams(sym)
-    quals = _qual_stream(n, L, qual_value, quals, dev)                      # `quals`: uint8 [n, L] Phred values, or None
+    reads_rev, reads_fw_rc, quals = batch.reversed, batch.fw_rc_words, batch.quals
     if not params.randomized:
         name_arena = None
     elif isinstance(names, tuple):                       # already packed: (uint8 arena, int32 index[n+1]) on the device
@@ -138,7 +175,7 @@ def best_approx(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=No
     else:
         name_arena = sel.pack_names(names if names is not None else ["%d" % i for i in range(n)], dev)
     mp = params.mapping_params()
-    best = reduce.BestAlignments(n, scheme, fixed_read_len=L, device=dev)           # init_alignments with the threshold score
+    best = reduce.BestAlignments(n, scheme, read_len=batch.read_len, fixed_read_len=batch.fixed_len, max_read_len=L, device=dev)     # init_alignments
     seed_queue = torch.arange(n, dtype=torch.int32, device=dev)
     hits_stride = params.hits_stride or min(params.max_hits, 128)
     stats = dict(extensions=0, rounds=0, seeding_passes=0, queue=[])
@@ -153,19 +190,24 @@ def best_approx(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=No
                                                      retry=seeding_pass, fw=params.fw, rc=params.rc, in_queue=seed_queue, hits_stride=hits_stride)
         with _Stage(stats, "select_init"):
             state = sel.SelectState(hits, counts, name_arena, params.max_effort_init, params.randomized, params.top_seed)
-        best_approx_score(fmi, rfmi, state, seed_queue, best, reads_fw_rc, n, L, genome_words, genome_len, aligner, quals, params, band_len, stats)
+        best_approx_score(fmi, rfmi, state, seed_queue, best, batch, genome_words, genome_len, aligner, params, band_len, stats)
         sel.mark_unaligned(seed_queue, best, reseed)                               # aligner_init.cu:421-444
         seed_queue = sel.copy_flagged(seed_queue, reseed)                          # aligner_best_approx.h:273-283
     with _Stage(stats, "mapq"):
-        mapq = reduce.mapq(best, scheme, fixed_read_len=L)
+        mapq = reduce.mapq(best, scheme, read_len=batch.read_len, fixed_read_len=batch.fixed_len, max_read_len=L)
     out = dict(best=best.data, mapq=mapq, stats=stats)
     if traceback:
         # banded_traceback_best (traceback_inl.h:104-136) over every read; unaligned reads get an empty window, fail at once and
         # come back with no CIGAR and source = sink = (-1, -1)
         with _Stage(stats, "traceback"):
-            valid, pb, tbeg, tlen = sel.traceback_best_setup(best.data, n, band_len, genome_len, L, n * L)
-            pat, txt = PackedStringSet(reads_fw_rc, 4, True, pb, None, L), PackedStringSet(genome_words, 2, True, tbeg, tlen, 0)
-            tb = batch_banded_alignment_traceback(band_len, aligner, pat, txt, quals=quals, cigar_stride=cigar_stride)
+            if batch.read_len is None:
+                valid, pb, tbeg, tlen = sel.traceback_best_setup(best.data, n, band_len, genome_len, L, batch.rc_offset)
+                plen = None
+            else:
+                valid, pb, tbeg, tlen, plen = sel.traceback_best_setup(best.data, n, band_len, genome_len, 0, batch.rc_offset, read_begin=batch.read_begin,
+                                                                      read_len=batch.read_len)
+            pat, txt = PackedStringSet(reads_fw_rc, 4, True, pb, plen, batch.fixed_len), PackedStringSet(genome_words, 2, True, tbeg, tlen, 0)
+            tb = batch_banded_alignment_traceback(band_len, aligner, pat, txt, max_pattern_length=L, quals=quals, cigar_stride=cigar_stride)
         out.update(cigar=tb["cigar"], cigar_len=tb["cigar_len"], source=tb["source"], sink=tb["sink"], tb_score=tb["score"],
                    aligned_ids=torch.nonzero(best.is_aligned(0)).squeeze(1))
         if finish:

@@ -197,16 +197,17 @@ def copy_flagged(values, flags):
     return out[: int(count.item())]
 
 
-def traceback_best_setup(best_data, n, band_len, genome_len, fixed_read_len, rc_offset, mate_offset=0, want=0, idx=None):
-    """BestTracebackStream::init_context over best_data[0][idx] -> (valid uint8, pattern_begin, text_begin, text_len)."""
+def traceback_best_setup(best_data, n, band_len, genome_len, fixed_read_len, rc_offset, mate_offset=0, want=0, idx=None, read_begin=None, read_len=None):
+    """BestTracebackStream::init_context over best_data[0][idx] -> (valid uint8, pattern_begin, text_begin, text_len[, pattern_len when ragged])."""
     dev = best_data.device
     m = idx.numel() if idx is not None else n
     valid = torch.empty(m, dtype=torch.uint8, device=dev)
     pb = torch.empty(m, dtype=torch.int64, device=dev); tb = torch.empty(m, dtype=torch.int64, device=dev); tl = torch.empty(m, dtype=torch.int32, device=dev)
-    check(lib().nvbio_hip_traceback_best_setup(m, _vp(idx), _vp(best_data), int(band_len), int(genome_len), None, None, int(fixed_read_len), int(rc_offset),
-                                               int(mate_offset), int(want), _vp(valid), _vp(pb), None, _vp(tb), _vp(tl), current_stream_ptr()),
+    pl = torch.empty(m, dtype=torch.int32, device=dev) if read_len is not None else None
+    check(lib().nvbio_hip_traceback_best_setup(m, _vp(idx), _vp(best_data), int(band_len), int(genome_len), _vp(read_begin), _vp(read_len), int(fixed_read_len),
+                                               int(rc_offset), int(mate_offset), int(want), _vp(valid), _vp(pb), _vp(pl), _vp(tb), _vp(tl), current_stream_ptr()),
           "nvbio_hip_traceback_best_setup")
-    return valid, pb, tb, tl
+    return (valid, pb, tb, tl) if read_len is None else (valid, pb, tb, tl, pl)
 
 
 def finish_alignment(valid, patterns, quals, texts, cigar, cigar_len, source, scheme, best_data, idx=None, mds_stride=256):

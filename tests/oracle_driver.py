@@ -16,14 +16,15 @@ def band_length(max_dist):
 
 
 def pack_reads(sym):
-    """(reversed reads as a 4-bit BE StringSet for the mapper; fw + rc pattern words)"""
-    n, L = sym.shape
-    begin = np.arange(n, dtype=np.uint64) * L
-    lens = np.full(n, L, np.uint32)
-    rev = O.StringSet(O.pack(sym[:, ::-1].reshape(-1), 4, True), 4, True, begin, lens)
-    rc = np.where(sym > 3, sym, 3 - sym)[:, ::-1]
-    ext = O.pack(np.concatenate([sym.reshape(-1), rc.reshape(-1)]), 4, True)
-    return rev, ext
+    """(reversed reads as a 4-bit BE StringSet for the mapper; fw + rc pattern words; offsets int64[n+1]).  `sym`: uint8 [n, L] matrix
+    or a list of uint8 arrays (reads of different lengths)."""
+    reads = [np.asarray(r, np.uint8) for r in sym]
+    lens = np.array([r.size for r in reads], np.uint32)
+    index = np.zeros(len(reads) + 1, np.int64); index[1:] = np.cumsum(lens)
+    cat = lambda xs: np.concatenate(xs) if len(xs) else np.zeros(0, np.uint8)
+    rev = O.StringSet(O.pack(cat([r[::-1] for r in reads]), 4, True), 4, True, index[:-1].astype(np.uint64), lens)
+    ext = O.pack(np.concatenate([cat(reads), cat([np.where(r > 3, r, 3 - r)[::-1] for r in reads])]), 4, True)
+    return rev, ext, index
 
 
 def qual_scheme(scheme):
@@ -33,15 +34,16 @@ def qual_scheme(scheme):
 
 def best_approx(host_fmi, host_rfmi, sym, genome_words, genome_len, params, scheme, names, aln_type, qual_value=30, traceback=True, cigar_stride=64,
                 read_quals=None, finish=False, mds_stride=256):
-    n, L = sym.shape
     band = band_length(params.max_dist)
-    reads_rev, ext_words = pack_reads(sym)
-    quals = np.full(2 * n * L + 8, qual_value, np.uint8)
-    if read_quals is not None:
-        q = np.asarray(read_quals, np.uint8).reshape(n, L)
-        quals = np.concatenate([q.reshape(-1), q[:, ::-1].reshape(-1), np.zeros(8, np.uint8)])
+    reads_rev, ext_words, index = pack_reads(sym)
+    n, total = index.size - 1, int(index[-1])
+    read_len = np.diff(index).astype(np.uint32)
+    L = int(read_len.max())                                      # the longest read (sizes the seed-frequency table)
+    quals = np.full(2 * total + 8, qual_value, np.uint8)
+    if read_quals is not None:                                   # matrix or list of per-read arrays
+        qs = [np.asarray(q, np.uint8) for q in read_quals]
+        quals = np.concatenate(qs + [q[::-1] for q in qs] + [np.zeros(8, np.uint8)])
     sch6, lut = qual_scheme(scheme)
-    read_len = np.full(n, L, np.uint32)
     best = O.init_alignments(read_len, scheme.m_score_min)
     mp = params.mapping_params()
     sf = mp.seed_freq_table(L, "cpu").numpy().view(np.uint32)
@@ -71,7 +73,7 @@ def best_approx(host_fmi, host_rfmi, sym, genome_words, genome_len, params, sche
             loc = O.locate_hits(host_fmi, host_rfmi, loc, seed)
             tb, tl, _ = O.score_best_setup(rid, loc, read_len, band, genome_len, best, WORST_SCORE)
             rc = (seed >> 13) & 1
-            patterns = O.StringSet(ext_words, 4, True, rid.astype(np.uint64) * L + rc.astype(np.uint64) * (n * L), np.full(rid.size, L, np.uint32))
+            patterns = O.StringSet(ext_words, 4, True, index[rid].astype(np.uint64) + rc.astype(np.uint64) * total, read_len[rid])
             texts = O.StringSet(genome_words, 2, True, tb, tl)
             score, _ = O.batch_banded_gotoh_score_qual(band, aln_type, sch6, lut, quals, patterns, texts)
             O.score_reduce_best_approx(best, active, hit_begin, score, loc, seed, read_len, WORST_SCORE, trys, counts, n_ext,
@@ -86,8 +88,8 @@ def best_approx(host_fmi, host_rfmi, sym, genome_words, genome_len, params, sche
         ids = np.nonzero(align != 0xFFFFFFFF)[0]
         b_rc = ((best[0] >> np.uint64(28)) & np.uint64(1)).astype(np.int64)
         tbeg = np.maximum(align[ids] - band // 2, 0)
-        tend = np.minimum(tbeg + L + band, genome_len)
-        pat = O.StringSet(ext_words, 4, True, (ids * L + b_rc[ids] * (n * L)).astype(np.uint64), np.full(ids.size, L, np.uint32))
+        tend = np.minimum(tbeg + read_len[ids].astype(np.int64) + band, genome_len)
+        pat = O.StringSet(ext_words, 4, True, (index[ids] + b_rc[ids] * total).astype(np.uint64), read_len[ids])
         txt = O.StringSet(genome_words, 2, True, tbeg.astype(np.uint64), (tend - tbeg).astype(np.uint32))
         r = O.batch_banded_gotoh_traceback(band, aln_type, sch6[:5], pat, txt, cigar_stride, mm_lut=lut, quals=quals)
         out.update(aligned_ids=ids, tb=r)
@@ -105,7 +107,7 @@ def best_approx_paired(host_fmi, host_rfmi, sym1, sym2, genome_words, genome_len
     """Aligner::best_approx for pairs (aligner_best_approx_paired.h:95-453, :455-700), numpy over the oracle."""
     n, L = sym1.shape
     band = band_length(params.max_dist)
-    packed = [pack_reads(sym1), pack_reads(sym2)]
+    packed = [pack_reads(sym1)[:2], pack_reads(sym2)[:2]]
     quals = np.full(2 * n * L + 8, qual_value, np.uint8)
     sch6, lut = qual_scheme(scheme)
     read_len = np.full(n, L, np.uint32)

@@ -125,10 +125,12 @@ def test_files_to_sam_example(tmp_path, cuda):
     prefix = str(tmp_path / "g")
     nio.save_fmindex(prefix, O.FMIndex(text))
     nio.write_wpac(prefix + ".wpac", text.size, O.pack(text, 2, True))
-    L, n = 100, 300
-    pos = rng.integers(0, text.size - L, n)
+    n = 300
+    lens = np.where(np.arange(n) % 3 == 0, 76, 100)                      # reads of two lengths in one file
+    pos = rng.integers(0, text.size - 100, n)
     with open(prefix + ".fastq", "w") as f:
         for i, p in enumerate(pos):
+            L = int(lens[i])
             r = text[p:p + L].copy()
             mut = rng.random(L) < 0.03
             r[mut] = (r[mut] + 1) & 3
@@ -144,8 +146,9 @@ def test_files_to_sam_example(tmp_path, cuda):
     good = 0
     for ln in aligned:
         i = int(ln[0][4:])
+        L = int(lens[i])
         consumed = sum(int(k) for k, op in re.findall(r"(\d+)([MIDS])", ln[5]) if op in "MIS")
-        assert consumed == L
+        assert consumed == L == len(ln[9])
         ok = (int(ln[3]) - 1 == pos[i]) and (ln[1] == ("16" if i % 2 else "0"))
         good += ok
         tags = dict((t.split(":")[0], t.split(":", 2)[2]) for t in ln[11:])

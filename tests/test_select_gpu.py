@@ -390,3 +390,53 @@ def test_cxx_aligner_driver_matches_oracle(cuda, config):
     assert (source[ids] == tb["source"]).all() and (sink[ids] == tb["sink"]).all() and (tb_score[ids] == tb["score"]).all()
     rest = ~np.isin(np.arange(n), ids)
     assert (cigar_len[rest] == 0).all() and (source[rest] == 0xFFFFFFFF).all()
+
+
+@pytest.mark.parametrize("config", ["default", "local", "one_mismatch_seeds"])
+def test_best_approx_ragged_reads_matches_oracle(cuda, config):
+    """Reads of different lengths (14 .. 160 bp, per-base qualities) through the driver: per-read seed intervals, thresholds, windows,
+    MAPQ scales, tracebacks and MD strings all follow each read's own length; vs the numpy driver over the oracle."""
+    rng = np.random.default_rng(777)
+    text = _small_index(rng)
+    host, rhost = O.FMIndex(text), O.FMIndex(text[::-1].copy())
+    fmi, rfmi = nvb.FMIndexDevice.from_host(host, cuda), nvb.FMIndexDevice.from_host(rhost, cuda)
+    n = 900
+    reads, quals, pos = [], [], []
+    for i in range(n):
+        L = int(rng.integers(14, 161))
+        p = int(rng.integers(0, text.size - L))
+        r = text[p:p + L].copy()
+        for j in rng.integers(0, L, [0, 1, 2, 3][i % 4] * L // 60):
+            r[j] = (r[j] + 1 + rng.integers(0, 3)) & 3
+        if i % 9 == 0 and L > 40:
+            d = int(rng.integers(10, L - 10)); r = np.concatenate([r[:d], r[d + 1:]])
+        if i % 14 == 0:
+            r[int(rng.integers(0, r.size))] = 4
+        if i % 2:
+            r = np.where(r > 3, r, 3 - r)[::-1].copy()
+        reads.append(r); quals.append(rng.integers(2, 42, r.size).astype(np.uint8)); pos.append(p)
+    names = ["rag.%d" % i for i in range(n)]
+    params = A.Params(**CONFIGS[config])
+    scheme = nvb.SmithWatermanScoringScheme.local() if params.local else nvb.SmithWatermanScoringScheme()
+    gw = W._pack_chunked(torch.from_numpy(text), 2, True)
+    e = OD.best_approx(host, rhost, reads, gw.numpy().view(np.uint32), text.size, params, scheme, names, 1 if params.local else 2, read_quals=quals, finish=True,
+                       cigar_stride=96)
+    index = np.zeros(n + 1, np.int64); index[1:] = np.cumsum([r.size for r in reads])
+    batch = A.ReadBatch.from_ragged(torch.from_numpy(np.concatenate(reads)).to(cuda), torch.from_numpy(index).to(cuda), torch.from_numpy(np.concatenate(quals)).to(cuda))
+    r = A.best_approx(fmi, rfmi, batch, gw.to(cuda), text.size, params, scheme, names, cigar_stride=96, finish=True)
+    torch.cuda.synchronize()
+    assert r["stats"] == e["stats"], (r["stats"], e["stats"])
+    assert (r["best_scored"].cpu().numpy().view(np.uint64) == e["best_scored"]).all() and (r["best"].cpu().numpy().view(np.uint64) == e["best"]).all()
+    assert (r["mapq"].cpu().numpy() == e["mapq"]).all()
+    ids, tb = e["aligned_ids"], e["tb"]
+    assert (r["aligned_ids"].cpu().numpy() == ids).all()
+    assert (r["cigar_len"].cpu().numpy()[ids].view(np.uint32) == tb["cigar_len"]).all()
+    assert (r["cigar"].cpu().numpy()[ids].view(np.uint16) == tb["cigar"][: ids.size]).all()
+    assert (r["source"].cpu().numpy()[ids].view(np.uint32) == tb["source"]).all() and (r["sink"].cpu().numpy()[ids].view(np.uint32) == tb["sink"]).all()
+    assert (r["mds_len"].cpu().numpy().view(np.uint32) == e["mds_len"]).all()
+    m = np.arange(256)[None, :] < np.minimum(e["mds_len"], 256)[:, None]
+    assert ((r["mds"].cpu().numpy() == e["mds"]) | ~m).all()
+    loc = (e["best_scored"][0] >> np.uint64(32)).astype(np.int64)
+    lens = np.array([x.size for x in reads])
+    ok = (loc != 0xFFFFFFFF) & (np.abs(loc - np.array(pos)) <= 4)
+    assert ok[lens >= 40].mean() > 0.75 and (loc != 0xFFFFFFFF)[lens < 22].sum() >= 1          # long reads recovered; some shorter than a seed still align
