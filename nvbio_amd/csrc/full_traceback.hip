@@ -31,13 +31,16 @@ struct FullTbParams {
     const uint8_t* quals; uint64_t n_quals;      // quality-aware scheme: mismatch = mm_lut[quality of the pattern symbol]; nullptr = `mismatch`
     int32_t   mm_lut[256];
     int32_t   txt_gap_open, txt_gap_ext;         // the column before the pattern (GLOBAL) is initialised with the text gap costs (gotoh_inl.h:275-279)
+    const uint32_t* pending;                     // nullable: the jobs this launch works on (slot -> job), *pending_count of them
+    const uint32_t* pending_count;
 };
 
 template <int TYPE, uint32_t BL>      // BL: pattern symbols per block of the reference's score pass (8 Gotoh, 16 SW / ED): fixes the sink's tie order
 __global__ void __launch_bounds__(256) full_gotoh_traceback_kernel(const FullTbParams p)
 {
-    const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
-    if (tid >= p.n) return;
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;          // where this lane's flags / boundary column live
+    if (slot >= (p.pending ? *p.pending_count : p.n)) return;
+    const uint32_t tid = p.pending ? p.pending[slot] : slot;         // the job
     const uint64_t pb = p.pat.begin[tid], tb = p.txt.begin[tid];
     const uint32_t M  = p.pat.length ? p.pat.length[tid] : p.pat.fixed_length;
     const uint32_t N  = p.txt.length ? p.txt.length[tid] : p.txt.fixed_length;
@@ -80,7 +83,7 @@ __global__ void __launch_bounds__(256) full_gotoh_traceback_kernel(const FullTbP
                 temp_i = (TYPE == NVBIO_HIP_GLOBAL) ? p.txt_gap_open + p.txt_gap_ext * int32_t(i) : 0;
                 E      = (TYPE == NVBIO_HIP_LOCAL) ? 0 : infimum;
             } else {
-                const uint32_t c = p.column[uint64_t(i) * n + tid];
+                const uint32_t c = p.column[uint64_t(i) * n + slot];
                 temp_i = int32_t(int16_t(c & 0xFFFFu));
                 E      = int32_t(int16_t(c >> 16));
             }
@@ -108,10 +111,10 @@ __global__ void __launch_bounds__(256) full_gotoh_traceback_kernel(const FullTbP
                 word[(j - 1u) >> 3] |= (hdir | edir | fdir) << (4u * ((j - 1u) & 7u));
                 if (TYPE == NVBIO_HIP_LOCAL) { if (block + j <= M) report(hi, i + 1u, block + j); }
             }
-            p.column[uint64_t(i) * n + tid] = (uint32_t(H_band[BL]) & 0xFFFFu) | (uint32_t(E) << 16);     // make_vector<short> (:565)
+            p.column[uint64_t(i) * n + slot] = (uint32_t(H_band[BL]) & 0xFFFFu) | (uint32_t(E) << 16);     // make_vector<short> (:565)
             #pragma unroll
             for (uint32_t w8 = 0; w8 < BL / 8u; ++w8)
-                __builtin_nontemporal_store(word[w8], p.flags + (uint64_t(blk * (BL / 8u) + w8) * p.max_text_len + i) * n + tid);
+                __builtin_nontemporal_store(word[w8], p.flags + (uint64_t(blk * (BL / 8u) + w8) * p.max_text_len + i) * n + slot);
             if (TYPE == NVBIO_HIP_SEMI_GLOBAL && last)
             {
                 // save_boundary -> save_Mth: H[i][M] (utils_inl.h:206-226,279-299)
@@ -152,7 +155,7 @@ __global__ void __launch_bounds__(256) full_gotoh_traceback_kernel(const FullTbP
     uint32_t state = 0;     // 0 = H, 1 = E, 2 = F
     while (row > 0 && col >= 0)
     {
-        const uint32_t w  = p.flags[(uint64_t(uint32_t(col) >> 3) * p.max_text_len + uint32_t(row - 1)) * n + tid];
+        const uint32_t w  = p.flags[(uint64_t(uint32_t(col) >> 3) * p.max_text_len + uint32_t(row - 1)) * n + slot];
         const uint32_t op = (w >> ((uint32_t(col) & 7u) * 4u)) & 15u, h_op = op & 3u;
         if (TYPE == NVBIO_HIP_LOCAL && state == 0 && h_op == T_SINK) break;
         if (state == 1)      { if ((op & T_INSERTION_EXT) == 0u) state = 0; --col; push(T_INSERTION); }
@@ -170,6 +173,72 @@ __global__ void __launch_bounds__(256) full_gotoh_traceback_kernel(const FullTbP
     p.out_cigar_len[tid] = size;
 }
 
+// ---- the ungapped fast path (LOCAL / SEMI_GLOBAL): as in banded_traceback.hip.  Given score and sink from the score kernel (the same
+// pattern-blocking DP, so the same sink: checked on tie-heavy batches), walk the diagonal up-left from the sink adding substitution
+// scores; when the sum over k cells equals the score, every H on that segment equals its partial sum and each cell's direction is
+// SUBSTITUTION, so the walk of the full kernel is exactly that diagonal: LOCAL stops at the first such k (H = 0 there: SINK, or the
+// matrix edge), SEMI_GLOBAL needs the whole pattern (k = M, free text start).  Other jobs are queued for the full kernel.
+template <int TYPE>
+__global__ void __launch_bounds__(256) full_traceback_diagonal_kernel(const FullTbParams p, uint32_t* __restrict__ pending, uint32_t* __restrict__ pending_count)
+{
+    const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
+    if (tid >= p.n) return;
+    const uint2 sink = p.out_sink[tid];
+    if (sink.x == 0xFFFFFFFFu || sink.y == 0xFFFFFFFFu) {
+        p.out_source[tid] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        p.out_cigar_len[tid] = 0;
+        return;
+    }
+    const int32_t  best = p.out_score[tid];
+    const uint64_t pb = p.pat.begin[tid], tb = p.txt.begin[tid];
+    const uint32_t M  = p.pat.length ? p.pat.length[tid] : p.pat.fixed_length;
+    const uint32_t bx = sink.x, by = sink.y;
+    bool     found = false;
+    uint32_t k_found = 0;
+    const uint32_t kmax = min(bx, by);
+    if (!(TYPE == NVBIO_HIP_LOCAL && best <= 0) && !(TYPE == NVBIO_HIP_SEMI_GLOBAL && bx < by))
+    {
+        int32_t c = 0;
+        // cells k = 0 .. kmax-1: text symbol bx-1-k, pattern symbol by-1-k; 16 per fetch, walking down from the sink
+        for (uint32_t k0 = 0; k0 < kmax && !found; k0 += 16u)
+        {
+            const uint32_t cnt = min(16u, kmax - k0);
+            const uint32_t lo_p = by - k0 - cnt, lo_t = bx - k0 - cnt;                 // lowest symbol index of this group
+            const uint64_t pq = (p.pat.s.bits == 2) ? expand_2to4(fetch16_2bit(p.pat.s, pb + lo_p)) : fetch16_4bit(p.pat.s, pb + lo_p);
+            const uint64_t tg = expand_2to4(fetch16_2bit(p.txt.s, tb + lo_t));
+            for (uint32_t u = 0; u < cnt; ++u)
+            {
+                const uint32_t m = cnt - 1u - u;                                       // nibble of cell k0 + u
+                const uint32_t q = uint32_t(pq >> (4u * m)) & 15u, g = uint32_t(tg >> (4u * m)) & 15u;
+                int32_t sc = p.match;
+                if (g != q) sc = p.quals ? p.mm_lut[p.quals[min(pb + lo_p + m, p.n_quals - 1u)]] : p.mismatch;
+                c += sc;
+                if (TYPE == NVBIO_HIP_LOCAL && c == best) { found = true; k_found = k0 + u + 1u; break; }
+            }
+        }
+        if (TYPE == NVBIO_HIP_SEMI_GLOBAL) { found = (c == best); k_found = by; }
+    }
+    {
+        const uint64_t need = __ballot(!found);
+        if (!found) {
+            const uint32_t lane = threadIdx.x & 63u, leader = uint32_t(__ffsll((long long)need)) - 1u;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(pending_count, uint32_t(__popcll(need)));
+            base = __shfl(base, int(leader));
+            pending[base + uint32_t(__popcll(need & ((1ull << lane) - 1ull)))] = tid;
+            return;
+        }
+    }
+    uint16_t* cigar = p.out_cigar + uint64_t(tid) * p.cigar_stride;
+    uint32_t  size = 0;
+    auto emit = [&](const uint32_t type, const uint32_t len) { if (len) { if (size < p.cigar_stride) cigar[size] = uint16_t(type | (len << 2)); ++size; } };
+    emit(3u, M - by);
+    emit(T_SUBSTITUTION, k_found);
+    emit(3u, by - k_found);
+    p.out_source[tid]    = make_uint2(bx - k_found, by - k_found);
+    p.out_cigar_len[tid] = size;
+}
+
 } // namespace nvb
 
 using namespace nvb;
@@ -177,7 +246,7 @@ using namespace nvb;
 NVB_API uint64_t nvbio_hip_gotoh_traceback_temp_bytes(uint32_t max_pattern_len, uint32_t max_text_len, uint32_t n)
 {
     const uint64_t blocks = 2u * std::max<uint64_t>(1u, (uint64_t(max_pattern_len) + 15u) / 16u);     // 8-column flag words, whole 16-column blocks
-    return (blocks + 1u) * uint64_t(max_text_len) * uint64_t(n) * 4u;      // flags + the boundary column
+    return (blocks + 1u) * uint64_t(max_text_len) * uint64_t(n) * 4u + uint64_t(n) * 4u + 256u;      // flags + the boundary column + the queue of gapped jobs
 }
 
 struct TbQualPart { const uint8_t* quals; uint64_t n_quals; const int32_t* mismatch; int32_t text_gap_open, text_gap_ext; };
@@ -219,9 +288,37 @@ static int full_traceback_core(
     p.out_cigar = out_cigar; p.cigar_stride = cigar_stride; p.out_cigar_len = out_cigar_len;
     p.column = static_cast<uint32_t*>(temp);
     p.flags  = p.column + uint64_t(maxN) * n;
-    g_last_kernel = "full_gotoh_traceback_kernel";
+    p.pending = nullptr; p.pending_count = nullptr;
     const dim3 grid((n + 255u) / 256u), block(256);
     hipStream_t s = to_stream(stream);
+    if (block_len == 8u && type != NVBIO_HIP_GLOBAL && maxM <= 512u)
+    {
+        // score + sink of every job from the (wave-per-alignment, 16-bit) pattern-blocking score kernel, CIGARs of the ungapped ones
+        // from the diagonal check, the rest queued for the full kernel
+        uint32_t* pending = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(temp) + (need - uint64_t(n) * 4u - 256u));
+        uint32_t* pending_count = pending + n;
+        if (hipError_t e = hipMemsetAsync(pending_count, 0, 4, s)) return e;
+        int err;
+        if (qual) {
+            nvbio_hip_gotoh_qual_scheme qs;
+            qs.match = scheme->match; qs.pattern_gap_open = scheme->gap_open; qs.pattern_gap_ext = scheme->gap_ext;
+            qs.text_gap_open = qual->text_gap_open; qs.text_gap_ext = qual->text_gap_ext;
+            for (int i = 0; i < 256; ++i) qs.mismatch[i] = qual->mismatch[i];
+            err = nvbio_hip_alignment_score_qual(&qs, NVBIO_HIP_PATTERN_BLOCKING, type, patterns, qual->quals, qual->n_quals, texts, maxM, maxN, nullptr, n,
+                                                 out_score, out_sink, nullptr, stream);
+        } else {
+            const int32_t s4[4] = { scheme->match, scheme->mismatch, scheme->gap_open, scheme->gap_ext };
+            err = nvbio_hip_alignment_score(NVBIO_HIP_GOTOH_ALIGNER, NVBIO_HIP_PATTERN_BLOCKING, s4, type, patterns, texts, maxM, maxN, nullptr, n,
+                                            out_score, out_sink, nullptr, stream);
+        }
+        if (err == hipSuccess) {
+            if (type == NVBIO_HIP_LOCAL) hipLaunchKernelGGL(full_traceback_diagonal_kernel<NVBIO_HIP_LOCAL>,       grid, block, 0, s, p, pending, pending_count);
+            else                         hipLaunchKernelGGL(full_traceback_diagonal_kernel<NVBIO_HIP_SEMI_GLOBAL>, grid, block, 0, s, p, pending, pending_count);
+            if (hipError_t e = hipGetLastError()) return e;
+            p.pending = pending; p.pending_count = pending_count;
+        } else if (err != hipErrorNotSupported) return err;          // a shape the score kernel does not take: every job goes to the full kernel
+    }
+    g_last_kernel = "full_gotoh_traceback_kernel";
     if (block_len == 16u) {
         switch (type) {
         case NVBIO_HIP_LOCAL:       hipLaunchKernelGGL((full_gotoh_traceback_kernel<NVBIO_HIP_LOCAL, 16u>),       grid, block, 0, s, p); break;

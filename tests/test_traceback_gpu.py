@@ -289,3 +289,32 @@ def test_ungapped_alignments_every_band_offset(cuda, band, ty):
                                                        quals=torch.from_numpy(quals).to(cuda), cigar_stride=40)
             torch.cuda.synchronize()
             compare(exp, got, (band, ty, "qual"))
+
+
+def test_full_matrix_traceback_on_tie_heavy_batches(cuda):
+    """Binary-alphabet texts (many equal-scoring placements): the traceback -- whose ungapped jobs take their sink from the pattern-blocking
+    score kernel -- still equals the oracle's job by job, and score kernel and traceback agree on every sink."""
+    rng = np.random.default_rng(8700)
+    pats, txts = [], []
+    for i in range(1200):
+        M = int(rng.integers(5, 150)); N = int(rng.integers(M, 500))
+        t = rng.integers(0, 2 if i % 2 else 4, N, dtype=np.uint8)
+        o = int(rng.integers(0, N - M + 1))
+        p = t[o:o + M].copy()
+        for j in rng.integers(0, M, int(rng.integers(0, 5))):
+            p[j] = (p[j] + 1) & 3
+        if i % 6 == 0:
+            p = rng.integers(0, 2, M, dtype=np.uint8)
+        pats.append(p); txts.append(t)
+    hp, ht = O.StringSet.from_lists(pats, 4, True), O.StringSet.from_lists(txts + [np.zeros(64, np.uint8)], 2, True)
+    ht = O.StringSet(ht.words, 2, True, ht.begin[:-1], ht.length[:-1])
+    dp, dt = to_dev(hp, cuda), to_dev(ht, cuda)
+    for ty in (nvb.LOCAL, nvb.SEMI_GLOBAL):
+        for scheme in ((2, -6, -8, -3), (1, -1, -2, -1), (0, -6, -8, -3)):
+            al = nvb.make_gotoh_aligner(ty, nvb.SimpleGotohScheme(*scheme), nvb.PATTERN_BLOCKING)
+            exp = O.batch_gotoh_traceback(ty, scheme, hp, ht, 48)
+            got = nvb.batch_alignment_traceback(al, dp, dt, 150, 500, cigar_stride=48)
+            s, k, _ = nvb.batch_alignment_score(al, dp, dt, 150, 500)
+            torch.cuda.synchronize()
+            compare(exp, got, (ty, scheme, "ties"))
+            assert torch.equal(s, got["score"]) and torch.equal(k, got["sink"])
