@@ -440,3 +440,44 @@ def test_best_approx_ragged_reads_matches_oracle(cuda, config):
     lens = np.array([x.size for x in reads])
     ok = (loc != 0xFFFFFFFF) & (np.abs(loc - np.array(pos)) <= 4)
     assert ok[lens >= 40].mean() > 0.75 and (loc != 0xFFFFFFFF)[lens < 22].sum() >= 1          # long reads recovered; some shorter than a seed still align
+
+
+def test_best_approx_edge_cases_match_oracle(cuda):
+    """Reads hanging over both genome ends (the located read start wraps below zero / the window is clipped), all-N and half-N reads,
+    exact duplicates, reads from the repeat, a single-read batch and a batch where nothing aligns: no crash, and the oracle driver's
+    results."""
+    rng = np.random.default_rng(4242)
+    text = _small_index(rng, 1 << 17)
+    host, rhost = O.FMIndex(text), O.FMIndex(text[::-1].copy())
+    fmi, rfmi = nvb.FMIndexDevice.from_host(host, cuda), nvb.FMIndexDevice.from_host(rhost, cuda)
+    L = 100
+    gw = W._pack_chunked(torch.from_numpy(text), 2, True)
+    rc = lambda r: np.where(r > 3, r, 3 - r)[::-1]
+    reads = []
+    for k in (0, 1, 5, 14, 40):                                   # k junk bases hang over the genome start / end
+        reads.append(np.concatenate([rng.integers(0, 4, k, dtype=np.uint8), text[:L - k]]))
+        reads.append(np.concatenate([text[text.size - (L - k):], rng.integers(0, 4, k, dtype=np.uint8)]))
+        reads.append(rc(reads[-2])); reads.append(rc(reads[-2]))
+    reads.append(np.full(L, 4, np.uint8))
+    reads.append(np.concatenate([text[3000:3050], np.full(50, 4, np.uint8)]))
+    reads += [text[20000:20100].copy()] * 3
+    reads += [text[7100:7200].copy(), rc(text[7300:7400])]          # inside the period-3 repeat
+    reads += [rng.integers(0, 4, L, dtype=np.uint8) for _ in range(5)]
+    sym = np.stack(reads).astype(np.uint8)
+    for tag, batch, kw in (("mixed", sym, {}), ("single", sym[:1], {}), ("no_rand", sym, dict(randomized=False)), ("local", sym, dict(local=True, seed_len=20)),
+                           ("unalignable", np.stack([rng.integers(0, 4, L, dtype=np.uint8) for _ in range(8)]).astype(np.uint8), {})):
+        params = A.Params(**kw)
+        scheme = nvb.SmithWatermanScoringScheme.local() if params.local else nvb.SmithWatermanScoringScheme()
+        names = ["e%d" % i for i in range(batch.shape[0])]
+        e = OD.best_approx(host, rhost, batch, gw.numpy().view(np.uint32), text.size, params, scheme, names, 1 if params.local else 2, finish=True)
+        r = A.best_approx(fmi, rfmi, torch.from_numpy(batch).to(cuda), gw.to(cuda), text.size, params, scheme, names, cigar_stride=64, finish=True)
+        torch.cuda.synchronize()
+        assert r["stats"] == e["stats"], tag
+        assert (r["best"].cpu().numpy().view(np.uint64) == e["best"]).all() and (r["best_scored"].cpu().numpy().view(np.uint64) == e["best_scored"]).all(), tag
+        assert (r["mapq"].cpu().numpy() == e["mapq"]).all(), tag
+        ids = e["aligned_ids"]
+        assert (r["cigar"].cpu().numpy()[ids].view(np.uint16) == e["tb"]["cigar"][: ids.size]).all() and (r["mds_len"].cpu().numpy().view(np.uint32) == e["mds_len"]).all(), tag
+        if tag == "mixed":
+            assert ids.size >= 15
+        if tag == "unalignable":
+            assert ids.size <= 1
