@@ -482,8 +482,13 @@ int nvbio_hip_opposite_score_setup(uint32_t n_hits, const uint32_t* hit_read_id,
     int32_t worst_score, const uint32_t* a_read_len, const uint32_t* o_read_len, uint32_t a_fixed_len, uint32_t o_fixed_len,
     const uint64_t* best_alignments, const uint64_t* best_alignments_o, uint32_t best_stride,
     int32_t match, const int32_t* min_score_by_len /* device */, int32_t text_gap_open, int32_t text_gap_ext, const nvbio_hip_pe_params* params /* host */,
-    uint8_t* out_valid, int32_t* out_min_score, uint8_t* out_read_rc, uint32_t* out_genome_begin, uint32_t* out_genome_end, void* stream);
-int nvbio_hip_opposite_score_finish(uint32_t n_valid, const uint32_t* valid_idx, const int32_t* raw_score /* [n_valid] */, const uint32_t* raw_sink /* uint2[n_valid] */,
+    uint8_t* out_valid, int32_t* out_min_score, uint8_t* out_read_rc, uint32_t* out_genome_begin, uint32_t* out_genome_end,
+    /* optional (all NULL / 0 to skip): the full-matrix job of every hit -- pattern = the opposite mate's forward copy at o_read_begin[r]
+     * (or r * o_fixed_len), its reverse complement o_rc_offset symbols further; text = the window, empty for invalid hits */
+    const uint64_t* o_read_begin, uint64_t o_rc_offset, uint64_t* out_pattern_begin, uint64_t* out_text_begin, uint32_t* out_text_len, void* stream);
+/* valid_idx != NULL: raw results of the n_valid scored hits valid_idx[k]; valid_idx == NULL: one raw result per hit (n_valid = n_hits) and
+ * valid_flags[h] says whether hit h was scored (the others get worst_score) */
+int nvbio_hip_opposite_score_finish(uint32_t n_valid, const uint32_t* valid_idx, const uint8_t* valid_flags, const int32_t* raw_score /* [n_valid] */, const uint32_t* raw_sink /* uint2[n_valid] */,
     const int32_t* min_score /* by hit */, const uint32_t* genome_begin /* by hit */, int32_t worst_score,
     int32_t* opposite_score, int32_t* opposite_score2, uint32_t* opposite_loc, uint32_t* opposite_sink, uint32_t* opposite_sink2, void* stream);
 int nvbio_hip_score_reduce_paired_best_approx(uint32_t n_active, const uint32_t* active_reads, const uint64_t* hit_begin,
@@ -508,6 +513,7 @@ int nvbio_hip_mark_unaligned(uint32_t n_active, const uint32_t* active_reads, co
 uint64_t nvbio_hip_copy_flagged_temp_bytes(uint32_t n);
 int nvbio_hip_copy_flagged(uint32_t n, const uint32_t* in, const uint8_t* flags, uint32_t* out, uint32_t* out_count /* device */,
                            void* temp, uint64_t temp_bytes, void* stream);
+int nvbio_hip_scatter_rows(uint32_t n, const uint32_t* idx, const void* src, void* dst, uint32_t row_bytes /* multiple of 4 */, void* stream);   /* dst row idx[i] = src row i */
 int nvbio_hip_traceback_best_setup(uint32_t n, const uint32_t* idx /* nullable */, const uint64_t* best_alignments, uint32_t band_len, uint32_t genome_length,
                                    const uint64_t* read_begin /* nullable */, const uint32_t* read_len /* nullable */, uint32_t fixed_read_len,
                                    uint64_t rc_offset, uint64_t mate_offset, int32_t want,

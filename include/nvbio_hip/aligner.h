@@ -42,6 +42,22 @@ struct ReadBatch
     const char*   names;       const uint32* names_idx;
 };
 
+/// the paired-end fields of Params (params.cpp:165-172; io::PairedEndPolicy FF 0, FR 1, RF 2, RR 3)
+struct PairedParams
+{
+    PairedParams() : pe_policy(1), pe_overlap(true), pe_unpaired(true), pe_discordant(true), min_frag_len(0), max_frag_len(500) {}
+    int32 pe_policy; bool pe_overlap, pe_unpaired, pe_discordant; uint32 min_frag_len, max_frag_len;
+};
+
+/// Two mate batches of equal size and read length.  The tracebacks pick a read by the alignment's mate bit, so they read ONE pattern
+/// stream holding both mates: mate m's fw + rc copies start m * mate_offset symbols into `both_words` (qualities likewise).
+struct PairedReadBatch
+{
+    ReadBatch     mate[2];
+    const uint32* both_words; uint64 both_n_words; uint64 mate_offset;
+    const uint8*  both_quals; uint64 both_n_quals;
+};
+
 struct Aligner
 {
     static const int32 worst_score = -(1 << 16);         // SmithWatermanScoringScheme::worst_score (scoring.h:226-227)
@@ -58,6 +74,13 @@ struct Aligner
     hip::device_vector<uint8>         mds;               // [BATCH_SIZE][mds_stride]: MD strings in nvbio's byte code (finish_alignment)
     hip::device_vector<uint32>        mds_len;
     uint32                            mds_stride;
+    // paired-end: the opposite slot set (best_data_dvec_o of the reference) and mate 2's MAPQ
+    hip::device_vector<io::Alignment> best_data_dvec_o;
+    hip::device_vector<uint8>         mapq_dvec_o;
+    hip::device_vector<io::Cigar>     cigar_o;
+    hip::device_vector<uint32>        cigar_len_o, cigar_source_o, cigar_sink_o, mds_len_o;
+    hip::device_vector<int32>         traceback_score_o;
+    hip::device_vector<uint8>         mds_o;
 
     Aligner() : BATCH_SIZE(0), SCORING_BATCH(0), cigar_stride(64), mds_stride(256) {}
 
@@ -77,6 +100,24 @@ struct Aligner
         cigar_source.resize(size_t(batch_size) * 2u); cigar_sink.resize(size_t(batch_size) * 2u); traceback_score.resize(batch_size);
         mds.resize(size_t(batch_size) * mds_stride); mds_len.resize(batch_size);
         return true;
+    }
+
+    /// the additional storage of paired-end runs (Aligner::init with EndType PAIRED_END)
+    bool init_paired()
+    {
+        const uint32 b = BATCH_SIZE;
+        best_data_dvec_o.resize(size_t(b) * 2u); mapq_dvec_o.resize(b); cigar_o.resize(size_t(b) * cigar_stride); cigar_len_o.resize(b);
+        cigar_source_o.resize(size_t(b) * 2u); cigar_sink_o.resize(size_t(b) * 2u); traceback_score_o.resize(b); mds_o.resize(size_t(b) * mds_stride); mds_len_o.resize(b);
+        return true;
+    }
+
+    /// Aligner::best_approx for read pairs (aligner_best_approx_paired.h:95-453)
+    void best_approx(const Params& params, const PairedParams& pe, const fm_index_device& fmi, const fm_index_device& rfmi,
+                     const aln::SmithWatermanScoringScheme& scoring_scheme, const ScoreLimits& limits,
+                     const uint32* genome_words, const uint64 genome_n_words, const uint32 genome_len, const PairedReadBatch& reads, Stats& stats, void* hip_stream = nullptr)
+    {
+        if (params.alignment_type == LocalAlignment) best_approx_paired_t<aln::LOCAL>(params, pe, fmi, rfmi, scoring_scheme, limits, genome_words, genome_n_words, genome_len, reads, stats, hip_stream);
+        else                                         best_approx_paired_t<aln::SEMI_GLOBAL>(params, pe, fmi, rfmi, scoring_scheme, limits, genome_words, genome_n_words, genome_len, reads, stats, hip_stream);
     }
 
     /// Aligner::best_approx (aligner_best_approx.h:85-520)
@@ -177,6 +218,211 @@ private:
                           "nvbio_hip_finish_alignment");
                 hip::synchronize(hip_stream);
             }
+        }
+        hip::synchronize(hip_stream);
+    }
+
+    template <aln::AlignmentType TYPE>
+    void best_approx_paired_t(const Params& params, const PairedParams& pe, const fm_index_device& fmi, const fm_index_device& rfmi,
+                              const aln::SmithWatermanScoringScheme& scoring_scheme, const ScoreLimits& limits,
+                              const uint32* genome_words, const uint64 genome_n_words, const uint32 genome_len, const PairedReadBatch& reads, Stats& stats, void* hip_stream)
+    {
+        const uint32 count = reads.mate[0].n, L = reads.mate[0].len;
+        const uint32 band_len = band_length(params.max_dist);
+        const uint32 hits_stride = params.hits_stride ? params.hits_stride : std::min(params.max_hits, 128u);
+        const aln::GotohAligner<TYPE, aln::SmithWatermanScoringScheme> aligner(scoring_scheme);
+        const nvbio_hip_gotoh_qual_scheme sc = scoring_scheme.abi();
+        uint64* best   = reinterpret_cast<uint64*>(best_data_dvec.data());
+        uint64* best_o = reinterpret_cast<uint64*>(best_data_dvec_o.data());
+
+        hip::device_vector<int32> min_score_table(limits.min_score_table(L));
+        init_alignments(count, nullptr, L, min_score_table.data(), best_data_dvec.data(),   BATCH_SIZE, 0u, hip_stream);
+        init_alignments(count, nullptr, L, min_score_table.data(), best_data_dvec_o.data(), BATCH_SIZE, 1u, hip_stream);
+
+        std::vector<uint32> iota(count); std::iota(iota.begin(), iota.end(), 0u);
+        hip::device_vector<uint32>  d_iota(iota), seed_queue_in(count), seed_queue_out(count), queue_count(1);
+        hip::device_vector<SeedHit> hit_data(size_t(count) * hits_stride);
+        hip::device_vector<uint32>  hit_counts(count);
+        hip::device_vector<uint8>   reseed(count);
+        hip::device_vector<uint32>  seed_freq(params.seed_freq_table(L));
+        SelectState   state(count, hits_stride);
+        const uint32  max_hits_per_round = std::max(SCORING_BATCH, count);
+        ScoringQueues queues(count, max_hits_per_round);
+        hip::device_vector<uint64> pat_begin(max_hits_per_round), txt_begin(max_hits_per_round);
+        hip::device_vector<uint32> txt_len(max_hits_per_round), sinks(size_t(max_hits_per_round) * 2u), hit_sink(max_hits_per_round);
+        hip::device_vector<int32>  min_score(max_hits_per_round), raw_score(max_hits_per_round), hit_score(max_hits_per_round);
+        hip::device_vector<uint8>  o_valid(max_hits_per_round), o_rc(max_hits_per_round);
+        hip::device_vector<uint32> o_gbegin(max_hits_per_round), o_gend(max_hits_per_round), o_loc(max_hits_per_round), o_sink(max_hits_per_round), o_sink2(max_hits_per_round);
+        hip::device_vector<int32>  o_score(max_hits_per_round), o_score2(max_hits_per_round);
+        hip::device_vector<uint8>  flag_temp(nvbio_hip_copy_flagged_temp_bytes(count));
+        SeedHitDequeArrayDeviceView hits = { hit_data.data(), hits_stride, hit_counts.data() };
+        const nvbio_hip_pe_params pp = { pe.pe_policy, int32(pe.min_frag_len), int32(pe.max_frag_len), pe.pe_overlap ? 1 : 0, worst_score, 0u, genome_len };
+
+        for (uint32 anchor = 0; anchor < 2; ++anchor)
+        {
+            const ReadBatch& a_reads = reads.mate[anchor];
+            const ReadBatch& o_reads = reads.mate[1u - anchor];
+            nvbio_hip_pe_params app = pp; app.anchor = anchor;
+            seed_queue_in.assign(iota.data(), count);
+            uint32 seed_queue_size = count;
+            const bool fw_strand = (anchor == 0) ? (pe.pe_policy == 0 || pe.pe_policy == 1) : (pe.pe_policy == 0 || pe.pe_policy == 2);     // :168-176
+            const bool fw = fw_strand ? params.fw : params.rc, rc = fw_strand ? params.rc : params.fw;
+
+            for (uint32 seeding_pass = 0; seeding_pass < params.max_reseed + 1; ++seeding_pass)
+            {
+                if (seed_queue_size == 0) break;
+                stats.queue.push_back(seed_queue_size); ++stats.seeding_passes;
+                hip_check(nvbio_hip_memset(hit_counts.data(), 0, uint64(count) * 4u, hip_stream), "nvbio_hip_memset");
+                const PingPongQueuesView seed_queues = { seed_queue_size, seed_queue_in.data() };
+                map(a_reads.reversed, fmi, rfmi, seeding_pass, seed_queues, reseed.data(), hits, params, seed_freq.data(), fw, rc, hip_stream);
+
+                // best_approx_score (:455-700)
+                {
+                    hip::synchronize(hip_stream);
+                    std::vector<uint32> q(seed_queue_size);
+                    hip_check(nvbio_hip_memcpy(q.data(), seed_queue_in.data(), uint64(seed_queue_size) * 4u, 2, nullptr), "nvbio_hip_memcpy(d2h)");
+                    std::vector<packed_read> packed(seed_queue_size);
+                    for (uint32 i = 0; i < seed_queue_size; ++i) packed[i] = packed_read(q[i], params.select.top_seed & 1u);
+                    hip_check(nvbio_hip_memcpy(queues.active_in.data(), packed.data(), uint64(seed_queue_size) * 4u, 1, nullptr), "nvbio_hip_memcpy(h2d)");
+                    queues.in_size = seed_queue_size;
+                }
+                select_init(count, a_reads.names, a_reads.names_idx, hits, state, params.select, hip_stream);
+                uint32 n_ext = 0;
+                while (queues.in_size && n_ext < params.select.max_ext)
+                {
+                    uint32 n_hits_per_read = 1;
+                    if (queues.in_size <= SCORING_BATCH / 2 && !params.no_multi_hits)
+                        n_hits_per_read = std::min(SCORING_BATCH / queues.in_size, std::min(4096u, params.select.max_ext - n_ext));
+                    select(hits, state, queues, n_hits_per_read, params.select, hip_stream);
+                    if (queues.in_size == 0) break;
+                    if (queues.hits_size == 0) continue;
+                    locate(fmi, rfmi, queues, hip_stream);
+                    const uint32 nh = queues.hits_size;
+                    const uint32* hit_seed = reinterpret_cast<const uint32*>(queues.hit_seed.data());
+
+                    // anchor_score_best
+                    hip_check(nvbio_hip_anchor_score_setup(nh, queues.hit_read_id.data(), queues.hit_loc.data(), hit_seed, nullptr, nullptr, nullptr, L, L, a_reads.rc_offset,
+                                                           band_len, genome_len, best, best_o, BATCH_SIZE, sc.match, min_score_table.data(), worst_score, anchor,
+                                                           pat_begin.data(), nullptr, txt_begin.data(), txt_len.data(), min_score.data(), hip_stream), "nvbio_hip_anchor_score_setup");
+                    {
+                        const PackedStringSetView<4, true> patterns(nh, a_reads.fw_rc_words, a_reads.fw_rc_n_words, pat_begin.data(), nullptr, L);
+                        const PackedStringSetView<2, true> texts(nh, genome_words, genome_n_words, txt_begin.data(), txt_len.data(), 0u);
+                        const aln::BestSinkArrays sink_arrays = { raw_score.data(), sinks.data() };
+                        dispatch_band(band_len, [&](auto band) {
+                            aln::batch_banded_alignment_score<decltype(band)::value>(aligner, patterns, a_reads.quals, a_reads.n_quals, texts, sink_arrays, L, L + band_len, hip_stream);
+                        });
+                    }
+                    hip_check(nvbio_hip_anchor_score_finish(nh, raw_score.data(), sinks.data(), txt_begin.data(), min_score.data(), worst_score, hit_score.data(), hit_sink.data(), hip_stream),
+                              "nvbio_hip_anchor_score_finish");
+
+                    // opposite_score_best over the hits whose anchor scored: every hit gets a job, the invalid ones an empty text
+                    hip_check(nvbio_hip_opposite_score_setup(nh, queues.hit_read_id.data(), hit_seed, queues.hit_loc.data(), hit_score.data(), worst_score, nullptr, nullptr, L, L,
+                                                             best, best_o, BATCH_SIZE, sc.match, min_score_table.data(), sc.text_gap_open, sc.text_gap_ext, &app,
+                                                             o_valid.data(), min_score.data(), o_rc.data(), o_gbegin.data(), o_gend.data(),
+                                                             nullptr, o_reads.rc_offset, pat_begin.data(), txt_begin.data(), txt_len.data(), hip_stream), "nvbio_hip_opposite_score_setup");
+                    {
+                        const PackedStringSetView<4, true> patterns(nh, o_reads.fw_rc_words, o_reads.fw_rc_n_words, pat_begin.data(), nullptr, L);
+                        const PackedStringSetView<2, true> texts(nh, genome_words, genome_n_words, txt_begin.data(), txt_len.data(), 0u);
+                        const nvbio_hip_string_set p = patterns.abi(), t = texts.abi();
+                        hip_check(nvbio_hip_alignment_score_qual(&sc, NVBIO_HIP_PATTERN_BLOCKING, int32(TYPE), &p, o_reads.quals, o_reads.n_quals, &t, L, pe.max_frag_len + L,
+                                                                 min_score.data(), nh, raw_score.data(), sinks.data(), nullptr, hip_stream), "nvbio_hip_alignment_score_qual");
+                    }
+                    hip_check(nvbio_hip_opposite_score_finish(nh, nullptr, o_valid.data(), raw_score.data(), sinks.data(), min_score.data(), o_gbegin.data(), worst_score,
+                                                              o_score.data(), o_score2.data(), o_loc.data(), o_sink.data(), o_sink2.data(), hip_stream), "nvbio_hip_opposite_score_finish");
+
+                    // score_reduce_paired with the give-up counters
+                    hip_check(nvbio_hip_score_reduce_paired_best_approx(queues.in_size, reinterpret_cast<const uint32*>(queues.active_in.data()), queues.hit_begin.data(),
+                                  queues.hit_loc.data(), hit_sink.data(), hit_score.data(), hit_seed, o_loc.data(), o_sink.data(), o_sink2.data(), o_score.data(), o_score2.data(),
+                                  nullptr, L, anchor, pe.pe_policy, pe.pe_unpaired ? 1 : 0, worst_score, best, best_o, BATCH_SIZE,
+                                  state.trys.data(), hit_counts.data(), n_ext, params.select.min_ext, params.select.max_ext, params.select.max_effort, hip_stream),
+                              "nvbio_hip_score_reduce_paired_best_approx");
+                    stats.extensions += nh; ++stats.rounds;
+                    n_ext += n_hits_per_read;
+                }
+
+                // copy the reads that need reseeding (no mark_unaligned in the paired driver)
+                hip_check(nvbio_hip_copy_flagged(seed_queue_size, seed_queue_in.data(), reseed.data(), seed_queue_out.data(), queue_count.data(),
+                                                 flag_temp.data(), flag_temp.size(), hip_stream), "nvbio_hip_copy_flagged");
+                hip::synchronize(hip_stream);
+                seed_queue_size = queue_count.to_host()[0];
+                std::swap(seed_queue_in.m_ptr, seed_queue_out.m_ptr);
+            }
+        }
+
+        if (pe.pe_discordant)
+            hip_check(nvbio_hip_mark_discordant(count, best, best_o, BATCH_SIZE, hip_stream), "nvbio_hip_mark_discordant");
+        // mate 1's MAPQ functor
+        hip_check(nvbio_hip_mapq_paired(2, limits.match, limits.monotone ? 1 : 0, min_score_table.data(), count, best, best_o, BATCH_SIZE, nullptr, nullptr, L, L,
+                                        mapq_dvec.data(), hip_stream), "nvbio_hip_mapq_paired");
+
+        // tracebacks + finish: anchor slots (banded), opposite slots (full matrix for the concordant ones, banded for the others)
+        const uint64 rc_offset = reads.mate[0].rc_offset;
+        hip::device_vector<uint8>  valid(count), valid_c(count);
+        hip::device_vector<uint64> tb_pat(count), tb_txt(count);
+        hip::device_vector<uint32> tb_len(count), idx_c(count);
+        auto banded_tb = [&](const uint64* slots, const int32 want, hip::device_vector<uint8>& v, io::Cigar* cg, uint32* cg_len, uint32* src, uint32* snk, int32* score) {
+            hip_check(nvbio_hip_memset(cg, 0, uint64(count) * cigar_stride * sizeof(io::Cigar), hip_stream), "nvbio_hip_memset");
+            hip_check(nvbio_hip_traceback_best_setup(count, nullptr, slots, band_len, genome_len, nullptr, nullptr, L, rc_offset, reads.mate_offset, want,
+                                                     v.data(), tb_pat.data(), nullptr, tb_txt.data(), tb_len.data(), hip_stream), "nvbio_hip_traceback_best_setup");
+            const PackedStringSetView<4, true> patterns(count, reads.both_words, reads.both_n_words, tb_pat.data(), nullptr, L);
+            const PackedStringSetView<2, true> texts(count, genome_words, genome_n_words, tb_txt.data(), tb_len.data(), 0u);
+            const nvbio_hip_string_set p = patterns.abi(), t = texts.abi();
+            hip::device_vector<uint8> temp(nvbio_hip_banded_gotoh_traceback_temp_bytes(band_len < 4 ? 3u : band_len < 8 ? 7u : band_len < 16 ? 15u : 31u, L, count));
+            hip_check(nvbio_hip_banded_gotoh_traceback_qual(&sc, int32(TYPE), band_len < 4 ? 3u : band_len < 8 ? 7u : band_len < 16 ? 15u : 31u, &p, reads.both_quals, reads.both_n_quals, &t,
+                                                            L, L + band_len, count, score, snk, src, reinterpret_cast<uint16*>(cg), cigar_stride, cg_len, temp.data(), temp.size(), hip_stream),
+                      "nvbio_hip_banded_gotoh_traceback_qual");
+            hip::synchronize(hip_stream);
+        };
+        auto finish = [&](const uint32 n_jobs, const uint8* v, const uint32* idx, uint64* slots, const io::Cigar* cg, const uint32* cg_len, const uint32* src, uint8* md, uint32* md_len) {
+            const PackedStringSetView<4, true> patterns(n_jobs, reads.both_words, reads.both_n_words, tb_pat.data(), nullptr, L);
+            const PackedStringSetView<2, true> texts(n_jobs, genome_words, genome_n_words, tb_txt.data(), tb_len.data(), 0u);
+            const nvbio_hip_string_set p = patterns.abi(), t = texts.abi();
+            hip_check(nvbio_hip_finish_alignment(n_jobs, v, &p, reads.both_quals, reads.both_n_quals, &t, reinterpret_cast<const uint16*>(cg), cigar_stride, cg_len, src,
+                                                 sc.match, sc.mismatch, 1, idx, slots, md, mds_stride, md_len, hip_stream), "nvbio_hip_finish_alignment");
+        };
+
+        banded_tb(best, 0, valid, cigar.data(), cigar_len.data(), cigar_source.data(), cigar_sink.data(), traceback_score.data());
+        if (params.finish_alignments) finish(count, valid.data(), nullptr, best, cigar.data(), cigar_len.data(), cigar_source.data(), mds.data(), mds_len.data());
+        // mate 2's MAPQ functor: after the anchor slots were finished, before the opposite ones are (:308-323)
+        hip_check(nvbio_hip_mapq_paired(2, limits.match, limits.monotone ? 1 : 0, min_score_table.data(), count, best_o, best, BATCH_SIZE, nullptr, nullptr, L, L,
+                                        mapq_dvec_o.data(), hip_stream), "nvbio_hip_mapq_paired");
+
+        // which opposite slots are concordant (their tracebacks run over the full matrix of [alignment, alignment + sink))
+        hip_check(nvbio_hip_traceback_best_setup(count, nullptr, best_o, band_len, genome_len, nullptr, nullptr, L, rc_offset, reads.mate_offset, 1,
+                                                 valid_c.data(), tb_pat.data(), nullptr, tb_txt.data(), tb_len.data(), hip_stream), "nvbio_hip_traceback_best_setup");
+        hip_check(nvbio_hip_copy_flagged(count, d_iota.data(), valid_c.data(), idx_c.data(), queue_count.data(), flag_temp.data(), flag_temp.size(), hip_stream), "nvbio_hip_copy_flagged");
+        hip::synchronize(hip_stream);
+        const uint32 n_conc = queue_count.to_host()[0];
+
+        banded_tb(best_o, 2, valid, cigar_o.data(), cigar_len_o.data(), cigar_source_o.data(), cigar_sink_o.data(), traceback_score_o.data());
+        if (params.finish_alignments) finish(count, valid.data(), nullptr, best_o, cigar_o.data(), cigar_len_o.data(), cigar_source_o.data(), mds_o.data(), mds_len_o.data());
+        if (n_conc)
+        {
+            hip::device_vector<uint8>     v(n_conc), md(size_t(n_conc) * mds_stride);
+            hip::device_vector<io::Cigar> cg(size_t(n_conc) * cigar_stride);
+            hip::device_vector<uint32>    cg_len(n_conc), src(size_t(n_conc) * 2u), snk(size_t(n_conc) * 2u), md_len(n_conc);
+            hip::device_vector<int32>     score(n_conc);
+            hip_check(nvbio_hip_memset(cg.data(), 0, uint64(n_conc) * cigar_stride * sizeof(io::Cigar), hip_stream), "nvbio_hip_memset");
+            hip_check(nvbio_hip_traceback_best_setup(n_conc, idx_c.data(), best_o, band_len, genome_len, nullptr, nullptr, L, rc_offset, reads.mate_offset, 1,
+                                                     v.data(), tb_pat.data(), nullptr, tb_txt.data(), tb_len.data(), hip_stream), "nvbio_hip_traceback_best_setup");
+            const PackedStringSetView<4, true> patterns(n_conc, reads.both_words, reads.both_n_words, tb_pat.data(), nullptr, L);
+            const PackedStringSetView<2, true> texts(n_conc, genome_words, genome_n_words, tb_txt.data(), tb_len.data(), 0u);
+            const nvbio_hip_string_set p = patterns.abi(), t = texts.abi();
+            hip::device_vector<uint8> temp(nvbio_hip_gotoh_traceback_temp_bytes(L, 1024u, n_conc));
+            hip_check(nvbio_hip_gotoh_traceback_qual(&sc, int32(TYPE), &p, reads.both_quals, reads.both_n_quals, &t, L, 1024u, n_conc, score.data(), snk.data(), src.data(),
+                                                     reinterpret_cast<uint16*>(cg.data()), cigar_stride, cg_len.data(), temp.data(), temp.size(), hip_stream), "nvbio_hip_gotoh_traceback_qual");
+            if (params.finish_alignments) finish(n_conc, v.data(), idx_c.data(), best_o, cg.data(), cg_len.data(), src.data(), md.data(), md_len.data());
+            // put the concordant mates' results at their reads
+            hip_check(nvbio_hip_scatter_rows(n_conc, idx_c.data(), cg.data(),     cigar_o.data(),           cigar_stride * 2u, hip_stream), "nvbio_hip_scatter_rows");
+            hip_check(nvbio_hip_scatter_rows(n_conc, idx_c.data(), cg_len.data(), cigar_len_o.data(),       4u, hip_stream), "nvbio_hip_scatter_rows");
+            hip_check(nvbio_hip_scatter_rows(n_conc, idx_c.data(), src.data(),    cigar_source_o.data(),    8u, hip_stream), "nvbio_hip_scatter_rows");
+            hip_check(nvbio_hip_scatter_rows(n_conc, idx_c.data(), snk.data(),    cigar_sink_o.data(),      8u, hip_stream), "nvbio_hip_scatter_rows");
+            hip_check(nvbio_hip_scatter_rows(n_conc, idx_c.data(), score.data(),  traceback_score_o.data(), 4u, hip_stream), "nvbio_hip_scatter_rows");
+            if (params.finish_alignments) {
+                hip_check(nvbio_hip_scatter_rows(n_conc, idx_c.data(), md.data(),     mds_o.data(),     mds_stride, hip_stream), "nvbio_hip_scatter_rows");
+                hip_check(nvbio_hip_scatter_rows(n_conc, idx_c.data(), md_len.data(), mds_len_o.data(), 4u, hip_stream), "nvbio_hip_scatter_rows");
+            }
+            hip::synchronize(hip_stream);
         }
         hip::synchronize(hip_stream);
     }

@@ -297,12 +297,13 @@ anchor_score_finish_kernel(uint32_t n, const int32_t* __restrict__ raw_score, co
 // worst score the driver filled in (aligner_best_approx_paired.h:641-645)
 __global__ void __launch_bounds__(256)
 opposite_score_finish_kernel(uint32_t n_valid, const uint32_t* __restrict__ idx, const int32_t* __restrict__ raw_score, const uint2* __restrict__ raw_sink,
-                             const int32_t* __restrict__ min_score, const uint32_t* __restrict__ genome_begin, int32_t worst_score,
+                             const int32_t* __restrict__ min_score, const uint32_t* __restrict__ genome_begin, int32_t worst_score, const uint8_t* __restrict__ valid_flags,
                              int32_t* __restrict__ o_score, int32_t* __restrict__ o_score2, uint32_t* __restrict__ o_loc, uint32_t* __restrict__ o_sink, uint32_t* __restrict__ o_sink2)
 {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     if (k >= n_valid) return;
-    const uint32_t h = idx[k];
+    const uint32_t h = idx ? idx[k] : k;          // idx == NULL: one raw result per hit, `valid_flags` says which were scored
+    if (!idx && valid_flags && !valid_flags[k]) { o_score[h] = worst_score; o_score2[h] = worst_score; o_loc[h] = 0u; o_sink[h] = 0u; o_sink2[h] = 0u; return; }
     const int32_t s = raw_score[k];
     const uint32_t gb = genome_begin[h], sx = raw_sink[k].x;
     o_score[h] = s >= min_score[h] ? s : worst_score;
@@ -325,6 +326,9 @@ struct OppositeParams {
     // the best-approx loop's form: strands from packed seeds, and only hits whose anchor score is not gate_worst are in the
     // opposite queue (aligner_best_approx_paired.h:632-640)
     const uint32_t* hit_seed; int32_t use_gate, gate_worst;
+    // optional job description of every hit for the full-matrix scorer (an invalid hit gets an empty text: nothing to score):
+    // the opposite mate's pattern (forward copy at o_read_begin[r] | r * o_fixed_len, reverse complement o_rc_offset further)
+    const uint64_t* o_read_begin; uint64_t o_rc_offset; uint64_t* out_pat_begin; uint64_t* out_text_begin; uint32_t* out_text_len;
 };
 
 __global__ void __launch_bounds__(256) opposite_windows_kernel(const OppositeParams p)
@@ -393,6 +397,11 @@ __global__ void __launch_bounds__(256) opposite_windows_kernel(const OppositePar
     }
     if (p.use_gate && p.hit_score[i] == p.gate_worst) valid = 0u;
     p.out_valid[i] = uint8_t(valid); p.out_read_rc[i] = uint8_t(o_rc); p.out_genome_begin[i] = gb; p.out_genome_end[i] = ge;
+    if (p.out_pat_begin) {
+        p.out_pat_begin[i]  = (p.o_read_begin ? p.o_read_begin[read_id] : uint64_t(read_id) * p.o_fixed_len) + (o_rc ? p.o_rc_offset : 0ull);
+        p.out_text_begin[i] = gb;
+        p.out_text_len[i]   = (valid && ge > gb) ? ge - gb : 0u;
+    }
 }
 
 // single-precision arithmetic without contraction, so the thresholds fall where the host code puts them
@@ -658,9 +667,11 @@ NVB_API int nvbio_hip_opposite_score_setup(uint32_t n_hits, const uint32_t* hit_
     int32_t worst_score, const uint32_t* a_read_len, const uint32_t* o_read_len, uint32_t a_fixed_len, uint32_t o_fixed_len,
     const uint64_t* best_alignments, const uint64_t* best_alignments_o, uint32_t best_stride,
     int32_t match, const int32_t* min_score_by_len, int32_t text_gap_open, int32_t text_gap_ext, const nvbio_hip_pe_params* params,
-    uint8_t* out_valid, int32_t* out_min_score, uint8_t* out_read_rc, uint32_t* out_genome_begin, uint32_t* out_genome_end, void* stream)
+    uint8_t* out_valid, int32_t* out_min_score, uint8_t* out_read_rc, uint32_t* out_genome_begin, uint32_t* out_genome_end,
+    const uint64_t* o_read_begin, uint64_t o_rc_offset, uint64_t* out_pattern_begin, uint64_t* out_text_begin, uint32_t* out_text_len, void* stream)
 {
     if (n_hits == 0) return hipSuccess;
+    if (out_pattern_begin && (!out_text_begin || !out_text_len)) return hipErrorInvalidValue;
     if (!hit_read_id || !hit_seed || !hit_loc || !hit_score || !best_alignments || !best_alignments_o || best_stride == 0 || !min_score_by_len || !params ||
         !out_valid || !out_min_score || !out_read_rc || !out_genome_begin || !out_genome_end) return hipErrorInvalidValue;
     if ((!a_read_len && a_fixed_len == 0) || (!o_read_len && o_fixed_len == 0) || params->anchor > 1u || params->pe_policy < 0 || params->pe_policy > 3) return hipErrorInvalidValue;
@@ -668,22 +679,23 @@ NVB_API int nvbio_hip_opposite_score_setup(uint32_t n_hits, const uint32_t* hit_
                          reinterpret_cast<const uint2*>(best_alignments), reinterpret_cast<const uint2*>(best_alignments_o), best_stride,
                          match, min_score_by_len, text_gap_open, text_gap_ext,
                          params->pe_policy, params->min_frag_len, params->max_frag_len, params->pe_overlap, params->score_limit, params->anchor, params->genome_length,
-                         out_valid, out_min_score, out_read_rc, out_genome_begin, out_genome_end, hit_seed, 1, worst_score };
+                         out_valid, out_min_score, out_read_rc, out_genome_begin, out_genome_end, hit_seed, 1, worst_score,
+                         o_read_begin, o_rc_offset, out_pattern_begin, out_text_begin, out_text_len };
     g_last_kernel = "opposite_windows_kernel";
     hipLaunchKernelGGL(opposite_windows_kernel, dim3((n_hits + 255u) / 256u), dim3(256), 0, to_stream(stream), p);
     return hipGetLastError();
 }
 
-NVB_API int nvbio_hip_opposite_score_finish(uint32_t n_valid, const uint32_t* valid_idx, const int32_t* raw_score, const uint32_t* raw_sink,
+NVB_API int nvbio_hip_opposite_score_finish(uint32_t n_valid, const uint32_t* valid_idx, const uint8_t* valid_flags, const int32_t* raw_score, const uint32_t* raw_sink,
     const int32_t* min_score, const uint32_t* genome_begin, int32_t worst_score,
     int32_t* opposite_score, int32_t* opposite_score2, uint32_t* opposite_loc, uint32_t* opposite_sink, uint32_t* opposite_sink2, void* stream)
 {
     if (n_valid == 0) return hipSuccess;
-    if (!valid_idx || !raw_score || !raw_sink || !min_score || !genome_begin || !opposite_score || !opposite_score2 || !opposite_loc || !opposite_sink || !opposite_sink2)
+    if ((!valid_idx && !valid_flags) || !raw_score || !raw_sink || !min_score || !genome_begin || !opposite_score || !opposite_score2 || !opposite_loc || !opposite_sink || !opposite_sink2)
         return hipErrorInvalidValue;
     g_last_kernel = "opposite_score_finish_kernel";
     hipLaunchKernelGGL(opposite_score_finish_kernel, dim3((n_valid + 255u) / 256u), dim3(256), 0, to_stream(stream), n_valid, valid_idx, raw_score,
-                       reinterpret_cast<const uint2*>(raw_sink), min_score, genome_begin, worst_score, opposite_score, opposite_score2, opposite_loc, opposite_sink, opposite_sink2);
+                       reinterpret_cast<const uint2*>(raw_sink), min_score, genome_begin, worst_score, valid_idx ? nullptr : valid_flags, opposite_score, opposite_score2, opposite_loc, opposite_sink, opposite_sink2);
     return hipGetLastError();
 }
 

@@ -572,3 +572,24 @@ NVB_API int nvbio_hip_finish_alignment(uint32_t n, const uint8_t* valid, const n
     hipLaunchKernelGGL(finish_alignment_kernel, grid_for(n), dim3(256), 0, to_stream(stream), p);
     return hipGetLastError();
 }
+
+// copies row i of src (row_bytes bytes, a multiple of 4) to row idx[i] of dst: puts the results of a compacted batch (e.g. the
+// full-matrix tracebacks of the concordant opposite mates) back at their reads
+namespace nvb {
+__global__ void __launch_bounds__(256) scatter_rows_kernel(uint32_t n, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint32_t row_words)
+{
+    const uint64_t t = uint64_t(blockIdx.x) * 256u + threadIdx.x;
+    if (t >= uint64_t(n) * row_words) return;
+    const uint32_t i = uint32_t(t / row_words), w = uint32_t(t % row_words);
+    dst[uint64_t(idx[i]) * row_words + w] = src[t];
+}
+}
+NVB_API int nvbio_hip_scatter_rows(uint32_t n, const uint32_t* idx, const void* src, void* dst, uint32_t row_bytes, void* stream)
+{
+    if (n == 0) return hipSuccess;
+    if (!idx || !src || !dst || row_bytes == 0 || (row_bytes & 3u)) return hipErrorInvalidValue;
+    g_last_kernel = "scatter_rows_kernel";
+    hipLaunchKernelGGL(scatter_rows_kernel, grid_for(uint64_t(n) * (row_bytes / 4u)), dim3(256), 0, to_stream(stream), n, idx,
+                       static_cast<const uint32_t*>(src), static_cast<uint32_t*>(dst), row_bytes / 4u);
+    return hipGetLastError();
+}

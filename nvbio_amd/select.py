@@ -151,7 +151,7 @@ def opposite_score_setup(hit_read_id, hit_seed, hit_loc, hit_score, worst_score,
                                                int(fixed_read_len), int(o_fixed_read_len), _vp(best.data), _vp(best_o.data), best.stride,
                                                int(scheme.m_match), _vp(table), int(scheme.text_gap_open()), int(scheme.text_gap_extension()), C.byref(pp),
                                                _vp(out["valid"]), _vp(out["min_score"]), _vp(out["read_rc"]), _vp(out["genome_begin"]), _vp(out["genome_end"]),
-                                               current_stream_ptr()), "nvbio_hip_opposite_score_setup")
+                                               None, 0, None, None, None, current_stream_ptr()), "nvbio_hip_opposite_score_setup")
     table.record_stream(torch.cuda.current_stream())
     return out
 
@@ -162,7 +162,7 @@ def opposite_score_finish(valid_idx, raw_score, raw_sink, min_score, genome_begi
     o_score = torch.full((n_hits,), worst_score, dtype=torch.int32, device=dev)
     o_score2 = torch.full((n_hits,), worst_score, dtype=torch.int32, device=dev)
     o_loc = torch.zeros(n_hits, dtype=torch.int32, device=dev); o_sink = torch.zeros(n_hits, dtype=torch.int32, device=dev); o_sink2 = torch.zeros(n_hits, dtype=torch.int32, device=dev)
-    check(lib().nvbio_hip_opposite_score_finish(valid_idx.numel(), _vp(valid_idx), _vp(raw_score), _vp(raw_sink), _vp(min_score), _vp(genome_begin), int(worst_score),
+    check(lib().nvbio_hip_opposite_score_finish(valid_idx.numel(), _vp(valid_idx), None, _vp(raw_score), _vp(raw_sink), _vp(min_score), _vp(genome_begin), int(worst_score),
                                                 _vp(o_score), _vp(o_score2), _vp(o_loc), _vp(o_sink), _vp(o_sink2), current_stream_ptr()), "nvbio_hip_opposite_score_finish")
     return o_score, o_score2, o_loc, o_sink, o_sink2
 

@@ -67,3 +67,70 @@ int nvbio_aligner_best_approx(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmin
         return 0;
     } catch (const nvbio::hip_error& e) { fprintf(stderr, "aligner_shim: %s\n", e.what()); return 1; }
 }
+
+struct shim_pe_params { int32_t pe_policy; uint32_t pe_overlap, pe_unpaired, pe_discordant, min_frag_len, max_frag_len; };
+
+// the paired-end driver: per mate {reversed words, begin, fw+rc words, quals, names}, the joint pattern stream of the tracebacks;
+// outputs per slot set: best[2n], mapq[n], cigar[n*64], cigar_len[n], source[2n], sink[2n], mds[n*256], mds_len[n]
+extern "C" __attribute__((visibility("default")))
+int nvbio_aligner_best_approx_paired(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmindex* rfmi, uint32_t n, uint32_t L,
+                                     const uint32_t* const* d_rev_words, const uint64_t* rev_n_words, const uint64_t* const* d_rev_begin,
+                                     const uint32_t* const* d_fwrc_words, const uint64_t* fwrc_n_words, const uint8_t* d_quals, uint64_t n_quals,
+                                     const char* d_names, const uint32_t* d_names_idx,
+                                     const uint32_t* d_both_words, uint64_t both_n_words, uint64_t mate_offset, const uint8_t* d_both_quals, uint64_t both_n_quals,
+                                     const uint32_t* d_genome_words, uint64_t genome_n_words, uint32_t genome_len, const shim_params* sp, const shim_pe_params* pp,
+                                     uint64_t* const* h_best, uint8_t* const* h_mapq, uint16_t* const* h_cigar, uint32_t* const* h_cigar_len, uint32_t* const* h_source,
+                                     uint32_t* const* h_sink, uint8_t* const* h_mds, uint32_t* const* h_mds_len, uint64_t* h_stats)
+{
+    try {
+        Params params;
+        params.seed_len = sp->seed_len; params.seed_freq = SimpleFunc(SimpleFunc::Type(sp->seed_freq_type), sp->seed_freq_k, sp->seed_freq_m);
+        params.min_read_len = sp->min_read_len; params.max_hits = sp->max_hits; params.max_reseed = sp->max_reseed; params.rep_seeds = sp->rep_seeds;
+        params.allow_sub = sp->allow_sub; params.subseed_len = sp->subseed_len;
+        params.select.randomized = sp->randomized != 0; params.select.top_seed = sp->top_seed; params.select.max_effort_init = sp->max_effort_init;
+        params.select.max_effort = sp->max_effort; params.select.min_ext = sp->min_ext; params.select.max_ext = sp->max_ext;
+        params.max_dist = sp->max_dist; params.alignment_type = sp->local ? LocalAlignment : EndToEndAlignment;
+        params.no_multi_hits = sp->no_multi_hits != 0; params.hits_stride = sp->hits_stride; params.finish_alignments = sp->finish != 0;
+        PairedParams pe;
+        pe.pe_policy = pp->pe_policy; pe.pe_overlap = pp->pe_overlap != 0; pe.pe_unpaired = pp->pe_unpaired != 0; pe.pe_discordant = pp->pe_discordant != 0;
+        pe.min_frag_len = pp->min_frag_len; pe.max_frag_len = pp->max_frag_len;
+
+        aln::SmithWatermanScoringScheme scheme = sp->local ? aln::SmithWatermanScoringScheme::local() : aln::SmithWatermanScoringScheme();
+        scheme.m_match = sp->match;
+        const ScoreLimits limits(sp->match, SimpleFunc(SimpleFunc::Type(sp->score_min_type), sp->score_min_k, sp->score_min_m));
+        fm_index_device f, rf; f.m = *fmi; rf.m = rfmi ? *rfmi : *fmi;
+
+        PairedReadBatch reads;
+        for (int m = 0; m < 2; ++m) {
+            ReadBatch& b = reads.mate[m];
+            b.n = n; b.len = L;
+            b.reversed = PackedStringSetView<4, true>(n, d_rev_words[m], rev_n_words[m], d_rev_begin[m], nullptr, L);
+            b.fw_rc_words = d_fwrc_words[m]; b.fw_rc_n_words = fwrc_n_words[m]; b.rc_offset = uint64_t(n) * L;
+            b.quals = d_quals; b.n_quals = n_quals; b.names = d_names; b.names_idx = d_names_idx;
+        }
+        reads.both_words = d_both_words; reads.both_n_words = both_n_words; reads.mate_offset = mate_offset;
+        reads.both_quals = d_both_quals; reads.both_n_quals = both_n_quals;
+
+        Aligner aligner;
+        aligner.init(std::max(sp->batch_size, n), sp->batch_size);
+        aligner.init_paired();
+        Stats stats;
+        aligner.best_approx(params, pe, f, rf, scheme, limits, d_genome_words, genome_n_words, genome_len, reads, stats);
+
+        const uint32_t B = aligner.BATCH_SIZE;
+        for (int slot = 0; slot < 2; ++slot) {
+            const std::vector<io::Alignment> best = (slot ? aligner.best_data_dvec_o : aligner.best_data_dvec).to_host();
+            for (uint32_t i = 0; i < n; ++i) { memcpy(&h_best[slot][i], &best[i], 8); memcpy(&h_best[slot][n + i], &best[B + i], 8); }
+            const std::vector<uint8> mq = (slot ? aligner.mapq_dvec_o : aligner.mapq_dvec).to_host();              memcpy(h_mapq[slot], mq.data(), n);
+            const std::vector<io::Cigar> cg = (slot ? aligner.cigar_o : aligner.cigar).to_host();                   memcpy(h_cigar[slot], cg.data(), size_t(n) * aligner.cigar_stride * 2u);
+            const std::vector<uint32> cl = (slot ? aligner.cigar_len_o : aligner.cigar_len).to_host();              memcpy(h_cigar_len[slot], cl.data(), size_t(n) * 4u);
+            const std::vector<uint32> so = (slot ? aligner.cigar_source_o : aligner.cigar_source).to_host();        memcpy(h_source[slot], so.data(), size_t(n) * 8u);
+            const std::vector<uint32> si = (slot ? aligner.cigar_sink_o : aligner.cigar_sink).to_host();            memcpy(h_sink[slot], si.data(), size_t(n) * 8u);
+            const std::vector<uint8> md = (slot ? aligner.mds_o : aligner.mds).to_host();                           memcpy(h_mds[slot], md.data(), size_t(n) * aligner.mds_stride);
+            const std::vector<uint32> ml = (slot ? aligner.mds_len_o : aligner.mds_len).to_host();                  memcpy(h_mds_len[slot], ml.data(), size_t(n) * 4u);
+        }
+        h_stats[0] = stats.extensions; h_stats[1] = stats.rounds; h_stats[2] = stats.seeding_passes; h_stats[3] = stats.queue.size();
+        for (size_t k = 0; k < stats.queue.size() && k < 8; ++k) h_stats[4 + k] = stats.queue[k];
+        return 0;
+    } catch (const nvbio::hip_error& e) { fprintf(stderr, "aligner_shim: %s\n", e.what()); return 1; }
+}

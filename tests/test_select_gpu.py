@@ -481,3 +481,75 @@ def test_best_approx_edge_cases_match_oracle(cuda):
             assert ids.size >= 15
         if tag == "unalignable":
             assert ids.size <= 1
+
+
+class _ShimPeParams(_C.Structure):
+    _fields_ = [("pe_policy", _C.c_int32)] + [(k, _C.c_uint32) for k in ("pe_overlap", "pe_unpaired", "pe_discordant", "min_frag_len", "max_frag_len")]
+
+
+@pytest.mark.parametrize("config", ["default", "no_rand_local", "one_hit_rounds", "multi_rounds_no_mixed", "ff_policy", "finish"])
+def test_cxx_paired_aligner_driver_matches_oracle(cuda, config):
+    """The C++ paired-end driver (Aligner::best_approx over a PairedReadBatch, include/nvbio_hip/aligner.h) through the shim: both slot sets, both MAPQs,
+    all CIGARs (and MD strings) equal the numpy driver's over the oracle."""
+    import ctypes as C
+    shim_path = os.path.join(HERE, "cxx", "libaligner_shim.so")
+    if not os.path.exists(shim_path):
+        pytest.fail("tests/cxx/libaligner_shim.so is missing: run `python __graft_entry__.py`")
+    shim = C.CDLL(shim_path)
+    rng = np.random.default_rng(321)
+    text = _small_index(rng, 1 << 17)
+    host, rhost = O.FMIndex(text), O.FMIndex(text[::-1].copy())
+    fmi, rfmi = nvb.FMIndexDevice.from_host(host, cuda), nvb.FMIndexDevice.from_host(rhost, cuda)
+    n, L = 700, 100
+    s1, s2, pos, flen = _pairs(rng, text, n, L)
+    if PAIRED_CONFIGS[config].get("pe_policy") == 0:
+        s2 = np.where(s2 > 3, s2, 3 - s2)[:, ::-1].copy()
+    names = ["pair.%d" % i for i in range(n)]
+    params = A.Params(**PAIRED_CONFIGS[config])
+    scheme = nvb.SmithWatermanScoringScheme.local() if params.local else nvb.SmithWatermanScoringScheme()
+    gw = W._pack_chunked(torch.from_numpy(text), 2, True)
+    fin = config == "finish"
+    e = OD.best_approx_paired(host, rhost, s1, s2, gw.numpy().view(np.uint32), text.size, params, scheme, names, 1 if params.local else 2, finish=fin)
+
+    packed = [P.pack_read_streams(torch.from_numpy(s).to(cuda)) for s in (s1, s2)]
+    quals = torch.full((2 * n * L + 8,), 30, dtype=torch.uint8, device=cuda)
+    both = torch.cat([packed[0][1], packed[1][1]]); mate_offset = packed[0][1].numel() * 8
+    both_q = torch.full((mate_offset + 2 * n * L + 8,), 30, dtype=torch.uint8, device=cuda)
+    arena, idx = S.pack_names(names, cuda)
+    d_gw = gw.to(cuda)
+    sp = _ShimParams(int(params.local), int(params.randomized), params.top_seed, params.max_effort_init, params.max_effort, params.min_ext, params.max_ext,
+                     params.max_reseed, params.rep_seeds, params.max_hits, params.allow_sub, params.subseed_len, params.seed_len, params.seed_freq[0],
+                     params.min_read_len, params.max_dist, int(params.no_multi_hits), params.batch_size, params.hits_stride or 0,
+                     params.seed_freq[1], params.seed_freq[2], scheme.m_match, scheme.m_score_min[0], scheme.m_score_min[1], scheme.m_score_min[2], int(fin))
+    pp = _ShimPeParams(params.pe_policy, int(params.pe_overlap), int(params.pe_unpaired), int(params.pe_discordant), params.min_frag_len, params.max_frag_len)
+    out = dict(best=[np.zeros((2, n), np.uint64) for _ in range(2)], mapq=[np.zeros(n, np.uint8) for _ in range(2)], cigar=[np.zeros((n, 64), np.uint16) for _ in range(2)],
+               cigar_len=[np.zeros(n, np.uint32) for _ in range(2)], source=[np.zeros((n, 2), np.uint32) for _ in range(2)], sink=[np.zeros((n, 2), np.uint32) for _ in range(2)],
+               mds=[np.zeros((n, 256), np.uint8) for _ in range(2)], mds_len=[np.zeros(n, np.uint32) for _ in range(2)])
+    stats = np.zeros(12, np.uint64)
+    pair_ptrs = lambda ts: (C.c_void_p * 2)(*[t.data_ptr() for t in ts])
+    pair_host = lambda arrs: (C.c_void_p * 2)(*[a.ctypes.data for a in arrs])
+    u64x2 = lambda v: (C.c_uint64 * 2)(*v)
+    fs, rs = fmi.struct(), rfmi.struct()
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    torch.cuda.synchronize()
+    rc = shim.nvbio_aligner_best_approx_paired(
+        C.byref(fs), C.byref(rs), C.c_uint32(n), C.c_uint32(L),
+        pair_ptrs([packed[0][0].words, packed[1][0].words]), u64x2([packed[0][0].words.numel(), packed[1][0].words.numel()]), pair_ptrs([packed[0][0].begin, packed[1][0].begin]),
+        pair_ptrs([packed[0][1], packed[1][1]]), u64x2([packed[0][1].numel(), packed[1][1].numel()]), vp(quals), C.c_uint64(quals.numel()), vp(arena), vp(idx),
+        vp(both), C.c_uint64(both.numel()), C.c_uint64(mate_offset), vp(both_q), C.c_uint64(both_q.numel()),
+        vp(d_gw), C.c_uint64(d_gw.numel()), C.c_uint32(text.size), C.byref(sp), C.byref(pp),
+        pair_host(out["best"]), pair_host(out["mapq"]), pair_host(out["cigar"]), pair_host(out["cigar_len"]), pair_host(out["source"]), pair_host(out["sink"]),
+        pair_host(out["mds"]), pair_host(out["mds_len"]), stats.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    st = e["stats"]
+    assert (int(stats[0]), int(stats[1]), int(stats[2])) == (st["extensions"], st["rounds"], st["seeding_passes"])
+    assert [int(x) for x in stats[4:4 + int(stats[3])]] == st["queue"]
+    assert (out["best"][0] == e["best"]).all() and (out["best"][1] == e["best_o"]).all()
+    assert (out["mapq"][0] == e["mapq1"]).all() and (out["mapq"][1] == e["mapq2"]).all()
+    for slot, key in ((0, "tb1"), (1, "tb2")):
+        for f in ("cigar_len", "cigar", "source", "sink"):
+            assert (out[f][slot] == e[key][f]).all(), (key, f)
+        if fin:
+            assert (out["mds_len"][slot] == e[key]["mds_len"]).all(), key
+            m = np.arange(256)[None, :] < np.minimum(e[key]["mds_len"], 256)[:, None]
+            assert ((out["mds"][slot] == e[key]["mds"]) | ~m).all(), key
