@@ -160,3 +160,46 @@ def test_files_to_sam_example(tmp_path, cuda):
             assert int(tags["NM"]) == ham == int(tags["XM"]) and tags["XO"] == tags["XG"] == "0" and int(tags["AS"]) == -6 * ham
             assert sum(int(x) for x in re.findall(r"\d+", tags["MD"])) + ham == L
     assert good > 0.95 * len(aligned)
+
+
+@pytest.mark.gpu
+def test_paired_files_to_sam_example(tmp_path, cuda):
+    """index files + two FASTQ files of FR mates -> SAM through the paired-end driver: both records of a pair carry the paired flags, point at each
+    other (PNEXT / TLEN) and sit at the fragment's two ends; a pair whose second mate is junk keeps mate 1 as an unpaired alignment"""
+    import io as _io, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import align_fastq
+    rng = np.random.default_rng(5)
+    text = rng.integers(0, 4, 200_000, dtype=np.uint8)
+    prefix = str(tmp_path / "g")
+    nio.save_fmindex(prefix, O.FMIndex(text))
+    nio.write_wpac(prefix + ".wpac", text.size, O.pack(text, 2, True))
+    L, n = 100, 120
+    pos = rng.integers(0, text.size - 600, n); flen = rng.integers(220, 420, n)
+    with open(prefix + "_1.fastq", "w") as f1, open(prefix + "_2.fastq", "w") as f2:
+        for i in range(n):
+            a = text[pos[i]:pos[i] + L].copy(); b = text[pos[i] + flen[i] - L:pos[i] + flen[i]].copy()
+            a[rng.integers(0, L, 2)] ^= 1; b[rng.integers(0, L, 1)] ^= 2
+            b = (3 - b)[::-1]
+            if i % 10 == 0:
+                b = rng.integers(0, 4, L, dtype=np.uint8)                     # junk mate 2
+            for f, r in ((f1, a), (f2, b)):
+                f.write("@frag%d\n%s\n+\n%s\n" % (i, "".join("ACGT"[c] for c in r), "I" * L))
+    buf = _io.StringIO()
+    align_fastq.main_paired(prefix, prefix + "_1.fastq", prefix + "_2.fastq", buf, device=cuda)
+    lines = [ln.split("\t") for ln in buf.getvalue().splitlines() if not ln.startswith("@")]
+    assert len(lines) == 2 * n
+    proper = 0
+    for i in range(n):
+        a, b = lines[2 * i], lines[2 * i + 1]
+        assert a[0] == b[0] == "frag%d" % i
+        fa, fb = int(a[1]), int(b[1])
+        if i % 10 == 0:
+            assert fb == 4 and (fa & 0x1) and (fa & 0x8) and not (fa & 0x2) and int(a[3]) - 1 == pos[i]          # mate 1 alone, mate flagged unmapped
+            continue
+        if (fa & 0x2) and (fb & 0x2):
+            proper += 1
+            assert (fa & 0x41) == 0x41 and (fb & 0x81) == 0x81 and bool(fa & 0x10) != bool(fb & 0x10) and bool(fa & 0x20) == bool(fb & 0x10)
+            assert int(a[3]) - 1 == pos[i] and int(b[3]) - 1 == pos[i] + flen[i] - L
+            assert int(a[7]) == int(b[3]) and int(b[7]) == int(a[3]) and int(a[8]) == flen[i] == -int(b[8])
+    assert proper >= 0.9 * (n - n // 10)

@@ -5,7 +5,8 @@ passes, randomized hit selection seeded by the read names, quality-aware extensi
 Reads may differ in length.  A usage example, not nvBowtie's CLI: the mandatory SAM fields and the tags SamOutput writes (NM, AS, XM, XO, XG, MD from the finished
 alignments; nvbio/io/output/output_sam.cpp:316-366), single reference sequence, no read groups.
 
-    python tools/align_fastq.py <index prefix> <reads.fastq> [out.sam]"""
+    python tools/align_fastq.py <index prefix> <reads.fastq> [out.sam]
+    python tools/align_fastq.py <index prefix> <mates1.fastq> <mates2.fastq> <out.sam>"""
 import sys
 
 import numpy as np
@@ -53,10 +54,80 @@ def main(prefix, fastq, out=sys.stdout, device="cuda", ref_name="ref"):
             "".join("ACGTN"[c] for c in s), "".join(chr(int(x) + 33) for x in q), ed, score, mm, gapo, gape, md or "*"))
 
 
+def main_paired(prefix, fastq1, fastq2, out=sys.stdout, device="cuda", ref_name="ref", **param_overrides):
+    """Paired-end flow: two FASTQ files of equal-length mates -> SAM through nvbio_amd.aligner.best_approx_paired (Aligner::best_approx of
+    aligner_best_approx_paired.h) with SamOutput's paired fields (output_sam.cpp:372-520): flags READ_1 / READ_2 by the alignment's mate, REVERSE,
+    PAIRED, PROPER_PAIR when the mate's alignment is concordant, MATE_UNMAPPED, MATE_REVERSE; RNEXT '=', PNEXT, TLEN = span of the two alignments,
+    negative for the rightmost one; unaligned reads carry the UNMAPPED flag alone, as the reference writes them."""
+    data = nio.FMIndexDataDevice(prefix, flags=nio.FORWARD | nio.SA, device=device)
+    n_genome, g_words = nio.load_genome(prefix)
+    genome_words = torch.from_numpy(np.concatenate([g_words, np.zeros(8, np.uint32)]).view(np.int32)).to(device)
+    r1, r2 = nio.read_fastq(fastq1), nio.read_fastq(fastq2)
+    n = r1.size()
+    lens = np.concatenate([np.diff(r1.sequence_index), np.diff(r2.sequence_index)])
+    if n == 0 or r2.size() != n or (lens != lens[0]).any():
+        raise SystemExit("align_fastq: the paired example needs two files with the same number of equal-length reads")
+    L = int(lens[0])
+    mats = [torch.from_numpy(r.symbols.reshape(n, L)).to(device) for r in (r1, r2)]
+    params = A.Params(hits_stride=32, **param_overrides)
+    r = A.best_approx_paired(data.index(), None, mats[0], mats[1], genome_words, n_genome, params, names=list(r1.names), finish=True)
+    torch.cuda.synchronize()
+    slots = []
+    for key_best, key_tb, key_mds, key_mapq in (("best", "tb1", "mds1", "mapq1"), ("best_o", "tb2", "mds2", "mapq2")):
+        slots.append(dict(best=r[key_best].cpu().numpy().view(np.uint64)[0], cigar=r[key_tb]["cigar"].cpu().numpy().view(np.uint16),
+                          clen=r[key_tb]["cigar_len"].cpu().numpy(), source=r[key_tb]["source"].cpu().numpy(), mds=r[key_mds].cpu().numpy(), mapq=r[key_mapq].cpu().numpy()))
+    reads = (r1, r2)
+    out.write("@HD\tVN:1.0\tSO:unsorted\n@SQ\tSN:%s\tLN:%d\n@PG\tID:nvbio_amd\tPN:nvbio_amd\n" % (ref_name, n_genome))
+
+    def fields(slot, i):
+        w, pos = int(slot["best"][i] & 0xFFFFFFFF), int(slot["best"][i] >> 32)
+        if pos == 0xFFFFFFFF:
+            return None
+        ops = [(int(c) & 3, int(c) >> 2) for c in slot["cigar"][i][:int(slot["clen"][i])]]
+        ref_len = sum(l for t, l in ops if t in (0, 2))
+        return dict(w=w, pos=pos + int(slot["source"][i, 0]), ref_len=ref_len, rc=(w >> 28) & 1, mate=(w >> 29) & 1,
+                    concordant=bool((w >> 30) & 1) and not bool((w >> 31) & 1))
+
+    for i in range(n):
+        f = [fields(slots[0], i), fields(slots[1], i)]
+        for k in (0, 1):
+            a, m = f[k], f[1 - k]
+            mate = a["mate"] if a else k                              # an unaligned slot k holds mate k
+            rd = reads[mate]
+            seq, qual = rd.symbols[i * L:(i + 1) * L], rd.quals[i * L:(i + 1) * L]
+            if a is None:
+                out.write("%s\t4\t*\t0\t0\t*\t*\t0\t0\t%s\t%s\n" % (rd.names[i], "".join("ACGTN"[c] for c in seq), "".join(chr(int(q) + 33) for q in qual)))
+                continue
+            flags = (0x80 if a["mate"] else 0x40) | (0x10 if a["rc"] else 0) | 0x1
+            if m is not None and m["concordant"]:
+                flags |= 0x2
+            if m is None:
+                flags |= 0x8
+            elif m["rc"]:
+                flags |= 0x20
+            if m is not None:
+                pnext = m["pos"] + 1
+                tlen = max(m["pos"] + m["ref_len"], a["pos"] + a["ref_len"]) - min(m["pos"], a["pos"])
+                if m["pos"] < a["pos"]:
+                    tlen = -tlen
+            else:
+                pnext, tlen = a["pos"] + 1, 0
+            w = a["w"]
+            score, ed = ((w >> 1) & 0x1FFFF) * (-1 if w & 1 else 1), (w >> 18) & 0x3FF
+            s, q = (np.where(seq < 4, 3 - seq, 4)[::-1], qual[::-1]) if a["rc"] else (seq, qual)
+            md, mm, gapo, gape = nio.sam_md_string(slots[k]["mds"][i])
+            out.write("%s\t%d\t%s\t%d\t%d\t%s\t=\t%d\t%d\t%s\t%s\tNM:i:%d\tAS:i:%d\tXM:i:%d\tXO:i:%d\tXG:i:%d\tMD:Z:%s\n" % (
+                rd.names[i], flags, ref_name, a["pos"] + 1, int(slots[k]["mapq"][i]), cigar_string(slots[k]["cigar"][i], int(slots[k]["clen"][i])), pnext, tlen,
+                "".join("ACGTN"[c] for c in s), "".join(chr(int(x) + 33) for x in q), ed, score, mm, gapo, gape, md or "*"))
+
+
 if __name__ == "__main__":
     if len(sys.argv) < 3:
         raise SystemExit(__doc__)
-    if len(sys.argv) > 3:
+    if len(sys.argv) > 4:                       # <prefix> <mates 1> <mates 2> <out.sam>
+        with open(sys.argv[4], "w") as f:
+            main_paired(sys.argv[1], sys.argv[2], sys.argv[3], f)
+    elif len(sys.argv) > 3:
         with open(sys.argv[3], "w") as f:
             main(sys.argv[1], sys.argv[2], f)
     else:
