@@ -270,3 +270,101 @@ def sam_md_string(mds):
             l = int(mds[i]); i += 1
             out.append("^" + "".join("ACGTN"[min(int(c), 4)] for c in mds[i:i + l]) + "0"); i += l; gapo += 1; gape += l - 1
     return "".join(out), mm, gapo, gape
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BAM output (nvbio/io/output/output_bam.cpp): the records the SAM writer prints, in BAM's binary layout inside BGZF blocks.
+# Tag types follow BamOutput::output_alignment (:470-510): NM / XM / XO / XG as 'C' (uint8), AS as 'I' (uint32 of the score's bits),
+# MD as 'Z'; bin is always 0 (:374).
+# ---------------------------------------------------------------------------------------------------------------------
+_BAM_SEQ = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+_BAM_CIGAR = {c: i for i, c in enumerate("MIDNSHP=X")}
+_BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def _bgzf_block(payload):
+    import struct
+    import zlib
+    comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+    data = comp.compress(payload) + comp.flush()
+    bsize = len(data) + 25                      # total block size - 1
+    return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + data +
+            struct.pack("<II", zlib.crc32(payload) & 0xFFFFFFFF, len(payload) & 0xFFFFFFFF))
+
+
+def sam_to_bam(sam_text, path):
+    """Write the SAM text produced by tools/align_fastq.py (header + records over one reference) as a BAM file."""
+    import re
+    import struct
+    header, records = [], []
+    for ln in sam_text.splitlines():
+        (header if ln.startswith("@") else records).append(ln)
+    refs = [(m.group(1), int(m.group(2))) for m in (re.match(r"@SQ\tSN:(\S+)\tLN:(\d+)", h) for h in header) if m]
+    ref_id = {name: i for i, (name, _) in enumerate(refs)}
+    text = ("\n".join(header) + "\n").encode()
+    out = bytearray(b"BAM\x01" + struct.pack("<i", len(text)) + text + struct.pack("<i", len(refs)))
+    for name, ln_ in refs:
+        out += struct.pack("<i", len(name) + 1) + name.encode() + b"\0" + struct.pack("<i", ln_)
+    for ln in records:
+        f = ln.split("\t")
+        qname, flag, rname, pos, mapq, cigar, rnext, pnext, tlen, seq, qual = f[:11]
+        ops = [(int(l), _BAM_CIGAR[o]) for l, o in re.findall(r"(\d+)([MIDNSHP=X])", cigar)] if cigar != "*" else []
+        rid = ref_id.get(rname, -1)
+        nid = rid if rnext == "=" else ref_id.get(rnext, -1)
+        body = struct.pack("<iiBBHHHIiii", rid, int(pos) - 1, len(qname) + 1, int(mapq), 0, len(ops), int(flag), len(seq), nid, int(pnext) - 1, int(tlen))
+        body += qname.encode() + b"\0" + b"".join(struct.pack("<I", (l << 4) | o) for l, o in ops)
+        nib = [_BAM_SEQ[c] for c in seq] + [0]
+        body += bytes((nib[2 * k] << 4) | nib[2 * k + 1] for k in range((len(seq) + 1) // 2))
+        body += bytes(ord(c) - 33 for c in qual)
+        for tag in f[11:]:
+            key, ty, val = tag.split(":", 2)
+            if ty == "Z":
+                body += key.encode() + b"Z" + val.encode() + b"\0"
+            elif key == "AS":
+                body += key.encode() + b"I" + struct.pack("<I", int(val) & 0xFFFFFFFF)
+            else:
+                body += key.encode() + b"C" + struct.pack("<B", int(val) & 0xFF)
+        out += struct.pack("<i", len(body)) + body
+    with open(path, "wb") as fh:
+        for s in range(0, len(out), 0xFF00):
+            fh.write(_bgzf_block(bytes(out[s:s + 0xFF00])))
+        fh.write(_BGZF_EOF)
+
+
+def read_bam(path):
+    """Parse a BAM file back into (header text, [(name, length)], list of record dicts) -- for the tests."""
+    import gzip
+    import struct
+    raw = gzip.open(path, "rb").read()              # BGZF = concatenated gzip members
+    assert raw[:4] == b"BAM\x01"
+    l_text = struct.unpack_from("<i", raw, 4)[0]
+    text = raw[8:8 + l_text].decode()
+    o = 8 + l_text
+    n_ref = struct.unpack_from("<i", raw, o)[0]; o += 4
+    refs = []
+    for _ in range(n_ref):
+        l = struct.unpack_from("<i", raw, o)[0]; o += 4
+        name = raw[o:o + l - 1].decode(); o += l
+        refs.append((name, struct.unpack_from("<i", raw, o)[0])); o += 4
+    recs = []
+    while o < len(raw):
+        bs = struct.unpack_from("<i", raw, o)[0]; o += 4
+        rid, pos, l_name, mapq, _bin, n_cig, flag, l_seq, nid, npos, tlen = struct.unpack_from("<iiBBHHHIiii", raw, o)
+        p = o + 32
+        name = raw[p:p + l_name - 1].decode(); p += l_name
+        cig = "".join("%d%s" % (w >> 4, "MIDNSHP=X"[w & 15]) for w in struct.unpack_from("<%dI" % n_cig, raw, p)); p += 4 * n_cig
+        sq = raw[p:p + (l_seq + 1) // 2]; p += (l_seq + 1) // 2
+        seq = "".join("=ACMGRSVTWYHKDBN"[(sq[k // 2] >> (4 if k % 2 == 0 else 0)) & 15] for k in range(l_seq))
+        qual = "".join(chr(q + 33) for q in raw[p:p + l_seq]); p += l_seq
+        tags = {}
+        while p < o + bs:
+            key, ty = raw[p:p + 2].decode(), chr(raw[p + 2]); p += 3
+            if ty == "Z":
+                e = raw.index(b"\0", p); tags[key] = raw[p:e].decode(); p = e + 1
+            elif ty == "I":
+                tags[key] = struct.unpack_from("<I", raw, p)[0]; p += 4
+            else:
+                tags[key] = raw[p]; p += 1
+        recs.append(dict(name=name, flag=flag, ref=rid, pos=pos + 1, mapq=mapq, cigar=cig or "*", next_ref=nid, pnext=npos + 1, tlen=tlen, seq=seq, qual=qual, tags=tags))
+        o += bs
+    return text, refs, recs

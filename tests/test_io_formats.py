@@ -203,3 +203,33 @@ def test_paired_files_to_sam_example(tmp_path, cuda):
             assert int(a[3]) - 1 == pos[i] and int(b[3]) - 1 == pos[i] + flen[i] - L
             assert int(a[7]) == int(b[3]) and int(b[7]) == int(a[3]) and int(a[8]) == flen[i] == -int(b[8])
     assert proper >= 0.9 * (n - n // 10)
+
+
+def test_bam_round_trip(tmp_path):
+    """SAM records -> BAM (BGZF blocks, binary records with BamOutput's tag types) -> parsed back: every field survives"""
+    rng = np.random.default_rng(9)
+    lines = ["@HD\tVN:1.0\tSO:unsorted", "@SQ\tSN:ref\tLN:200000", "@PG\tID:nvbio_amd\tPN:nvbio_amd"]
+    recs = []
+    for i in range(700):                                       # enough for more than one BGZF block
+        L = int(rng.integers(30, 151))
+        seq = "".join("ACGTN"[c] for c in rng.integers(0, 5, L)); qual = "".join(chr(33 + int(q)) for q in rng.integers(0, 42, L))
+        if i % 7 == 0:
+            recs.append(("u%d" % i, 4, "*", 0, 0, "*", "*", 0, 0, seq, qual, {}))
+            lines.append("u%d\t4\t*\t0\t0\t*\t*\t0\t0\t%s\t%s" % (i, seq, qual))
+            continue
+        cig = "%dS%dM1D%dM" % (3, L - 10, 7) if i % 3 == 0 else "%dM" % L
+        tags = dict(NM=int(rng.integers(0, 20)), AS=-int(rng.integers(0, 300)), XM=int(rng.integers(0, 9)), XO=int(rng.integers(0, 3)), XG=int(rng.integers(0, 3)), MD="12A7^CG030")
+        pos, pn, tl = int(rng.integers(1, 190000)), int(rng.integers(1, 190000)), int(rng.integers(-500, 500))
+        recs.append(("r%d" % i, 99 if i % 2 else 147, "ref", pos, int(rng.integers(0, 43)), cig, "=", pn, tl, seq, qual, tags))
+        r = recs[-1]
+        lines.append("\t".join(str(x) for x in r[:11]) + "\tNM:i:%d\tAS:i:%d\tXM:i:%d\tXO:i:%d\tXG:i:%d\tMD:Z:%s" % tuple(tags[k] for k in ("NM", "AS", "XM", "XO", "XG", "MD")))
+    path = str(tmp_path / "t.bam")
+    nio.sam_to_bam("\n".join(lines) + "\n", path)
+    text, refs, got = nio.read_bam(path)
+    assert refs == [("ref", 200000)] and text.splitlines() == lines[:3] and len(got) == len(recs)
+    for g, r in zip(got, recs):
+        assert (g["name"], g["flag"], g["pos"], g["mapq"], g["cigar"], g["pnext"], g["tlen"], g["seq"], g["qual"]) == (r[0], r[1], r[3], r[4], r[5], r[7], r[8], r[9], r[10])
+        assert g["ref"] == (0 if r[2] == "ref" else -1) and g["next_ref"] == (0 if r[6] == "=" else -1)
+        if r[11]:
+            assert g["tags"]["MD"] == r[11]["MD"] and g["tags"]["NM"] == r[11]["NM"] and g["tags"]["AS"] == r[11]["AS"] & 0xFFFFFFFF
+    assert open(path, "rb").read()[-28:] == bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")      # the BGZF end-of-file block

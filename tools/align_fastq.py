@@ -5,8 +5,8 @@ passes, randomized hit selection seeded by the read names, quality-aware extensi
 Reads may differ in length.  A usage example, not nvBowtie's CLI: the mandatory SAM fields and the tags SamOutput writes (NM, AS, XM, XO, XG, MD from the finished
 alignments; nvbio/io/output/output_sam.cpp:316-366), single reference sequence, no read groups.
 
-    python tools/align_fastq.py <index prefix> <reads.fastq> [out.sam]
-    python tools/align_fastq.py <index prefix> <mates1.fastq> <mates2.fastq> <out.sam>"""
+    python tools/align_fastq.py <index prefix> <reads.fastq> [out.sam | out.bam]
+    python tools/align_fastq.py <index prefix> <mates1.fastq> <mates2.fastq> <out.sam | out.bam>"""
 import sys
 
 import numpy as np
@@ -124,11 +124,19 @@ def main_paired(prefix, fastq1, fastq2, out=sys.stdout, device="cuda", ref_name=
 if __name__ == "__main__":
     if len(sys.argv) < 3:
         raise SystemExit(__doc__)
-    if len(sys.argv) > 4:                       # <prefix> <mates 1> <mates 2> <out.sam>
-        with open(sys.argv[4], "w") as f:
-            main_paired(sys.argv[1], sys.argv[2], sys.argv[3], f)
-    elif len(sys.argv) > 3:
-        with open(sys.argv[3], "w") as f:
-            main(sys.argv[1], sys.argv[2], f)
+    import io as _io
+    paired = len(sys.argv) > 4                  # <prefix> <mates 1> <mates 2> <out.sam|out.bam>
+    if len(sys.argv) > 3:
+        path = sys.argv[4] if paired else sys.argv[3]
+        buf = _io.StringIO()
+        if paired:
+            main_paired(sys.argv[1], sys.argv[2], sys.argv[3], buf)
+        else:
+            main(sys.argv[1], sys.argv[2], buf)
+        if path.endswith(".bam"):
+            nio.sam_to_bam(buf.getvalue(), path)           # the same records in BAM (nvbio/io/output/output_bam.cpp)
+        else:
+            with open(path, "w") as f:
+                f.write(buf.getvalue())
     else:
         main(sys.argv[1], sys.argv[2])
