@@ -361,15 +361,15 @@ def e2e_leg(a, dev, fmi, text):
     from nvbio_amd import aligner as AL, select as SEL
     names = SEL.pack_names(["r%d" % i for i in range(n)], dev)
     prm = AL.Params(hits_stride=16, batch_size=n)
-    for name, idx in (("nvbowtie_best_approx", fmi), ("nvbowtie_best_approx_ktab12_ssa1", None)):
-        if idx is None:
-            idx = fmi.with_ktab(12).with_dense_ssa(1)
+    for name, idx in (("nvbowtie_best_approx", fmi), ("nvbowtie_best_approx_ktab12_ssa1", 12), ("nvbowtie_best_approx_ktab15_ssa1", 15)):
+        if not hasattr(idx, "length"):                 # HBM-capacity options: 4^k-entry k-mer table (0.13 / 8.6 GB) + the full suffix array (12 GB)
+            idx = fmi.with_ktab(idx).with_dense_ssa(1)
         run = lambda st=False: AL.best_approx(idx, None, sym, genome_words, ng, prm, names=names, packed=packed, stage_times=st)
         ms = _timed(run, reps=2)
         r = run(True)
         loc = (r["best"][0] >> 32) & 0xFFFFFFFF
         aligned = loc != 0xFFFFFFFF
-        res[name] = {"ms_per_batch": ms, "Mreads_per_s": n / ms / 1e3, "extensions": r["stats"]["extensions"], "rounds": r["stats"]["rounds"],
+        res[name] = {"ms_per_batch": ms, "Mreads_per_s": n / ms / 1e3, "extensions": r["stats"]["extensions"], "dp_jobs": r.get("dp_jobs"), "rounds": r["stats"]["rounds"],
                      "queue_per_seeding_pass": r["stats"]["queue"], "aligned": float(aligned.float().mean().item()),
                      "best_at_true_position": float((aligned & ((loc - pos).abs() <= 2)).float().mean().item()),
                      "mapq_ge_23": float((r["mapq"] >= 23).float().mean().item()), "stage_ms": {k: round(v, 3) for k, v in r["stats"]["ms"].items()}}
@@ -729,7 +729,7 @@ def extras_leg(a, dev):
         loc = (r["best"][0] >> 32) & 0xFFFFFFFF
         aligned = loc != 0xFFFFFFFF
         at_true = aligned & ((loc - pos).abs() <= 2)
-        ba[cname] = {"reads": nreads, "ms_per_batch": ms, "Mreads_per_s": nreads / ms / 1e3, "extensions": r["stats"]["extensions"],
+        ba[cname] = {"reads": nreads, "ms_per_batch": ms, "Mreads_per_s": nreads / ms / 1e3, "extensions": r["stats"]["extensions"], "dp_jobs": r.get("dp_jobs"),
                      "rounds": r["stats"]["rounds"], "queue_per_seeding_pass": r["stats"]["queue"],
                      "aligned": float(aligned.float().mean().item()), "best_at_true_position": float(at_true.float().mean().item()),
                      "mapq_ge_23": float((r["mapq"] >= 23).float().mean().item()),

@@ -298,7 +298,7 @@ int nvbio_hip_fm_match(const nvbio_hip_fmindex* fmi, const nvbio_hip_string_set*
 
 /* Builds the optional k-mer table for `fmi` (fmi->ktab is ignored): out_ktab[2c..2c+1] =
  * match(fmi, kmer c), where kmer c has symbol t (0 = first) at bits [2t,2t+2) of c, for all
- * 4^k codes; 1 <= k <= 14; out_ktab holds 2*4^k words (k=12: 128 MiB). */
+ * 4^k codes; 1 <= k <= 15; out_ktab holds 2*4^k words (k=12: 128 MiB, k=14: 2 GiB, k=15: 8 GiB). */
 int nvbio_hip_fm_build_ktab(const nvbio_hip_fmindex* fmi, uint32_t k, uint32_t* out_ktab, void* stream);
 
 /* nvBowtie's seeding parameters as map_queues_kernel reads them (nvBowtie/bowtie2/cuda/params.h:100-120). */
@@ -418,7 +418,17 @@ int nvbio_hip_score_best_setup(uint32_t n_hits, const uint32_t* hit_read_id, con
                                uint64_t rc_offset, uint32_t band_len, uint32_t genome_length,
                                const uint64_t* best_alignments, uint32_t best_stride, int32_t score_limit,
                                uint64_t* pattern_begin, uint32_t* pattern_len /* nullable iff fixed */,
-                               uint64_t* text_begin, uint32_t* text_len, int32_t* min_score, void* stream);
+                               uint64_t* text_begin, uint32_t* text_len, int32_t* min_score,
+                               int32_t* known_score /* nullable, see below */,
+                               uint32_t* job_count /* nullable, device */, uint32_t* job_hit /* nullable, n_hits */, void* stream);
+/* known_score (optional, a pure saving): a hit whose (strand, read start) equals one of the read's two recorded alignments would be
+ * scored over the same window again and get the recorded score.  With known_score != NULL such hits get known_score[i] = that score
+ * and an empty window (INT32_MIN marks the others); handing the array to nvbio_hip_score_reduce_best_approx makes the reduction use
+ * it in place of the (absent) DP result, so every output is what the reference computes by re-running the DP.
+ * job_count / job_hit (optional, both or neither, need known_score): compacted jobs.  Only the hits that still need a DP are written,
+ * at slots 0..*job_count-1 of pattern_begin / pattern_len / text_begin / text_len / min_score, with job_hit[slot] = the hit; run the DP
+ * over *job_count jobs, scatter its scores into known_score (nvbio_hip_scatter_rows(n_jobs, job_hit, scores, known_score, 4)) and
+ * hand known_score to the reduction as hit_score.  The slot order is not deterministic; everything indexed by hit is. */
 /* score_reduce_kernel with ReduceBestApproxContext (reduce_inl.h:71-160, reduce.h:63-105): nvbio_hip_score_reduce over
  * packed active reads and packed seeds, plus the give-up counters: see reduce.hip.  hit_score is the raw DP score
  * (clamped to worst_score = scheme_type::worst_score here); n_ext = extensions done before this round. */
@@ -427,7 +437,8 @@ int nvbio_hip_score_reduce_best_approx(uint32_t n_active, const uint32_t* active
                                        const uint32_t* read_len /* nullable */, uint32_t fixed_read_len,
                                        uint64_t* best_alignments, uint32_t best_stride, int32_t worst_score,
                                        uint32_t* trys, uint32_t* hit_counts,
-                                       uint32_t n_ext, uint32_t min_ext, uint32_t max_ext, uint32_t max_effort, void* stream);
+                                       uint32_t n_ext, uint32_t min_ext, uint32_t max_ext, uint32_t max_effort,
+                                       const int32_t* known_score /* nullable: from nvbio_hip_score_best_setup */, void* stream);
 
 /* The paired-end form: score_reduce_paired_kernel (reduce_inl.h:355-500).  Per extension result the anchor mate's
  * {loc, sink (genome end), score, rc} and the opposite mate's {loc, sink, sink2, score, score2} (the stream's hit.* fields,

@@ -28,7 +28,7 @@ struct Params : public ParamsPOD
     bool   finish_alignments;      ///< run finish_alignment_best (MD strings, edit distances, final scores) as the reference always does
 };
 
-struct Stats { uint64 extensions; uint32 rounds, seeding_passes; std::vector<uint32> queue; Stats() : extensions(0), rounds(0), seeding_passes(0) {} };
+struct Stats { uint64 extensions, dp_jobs; uint32 rounds, seeding_passes; std::vector<uint32> queue; Stats() : extensions(0), dp_jobs(0), rounds(0), seeding_passes(0) {} };
 
 /// A batch of equal-length reads on the device in the layouts the stages read (io::SequenceDataDevice's role): the reads
 /// stored reversed (io::REVERSE, what the mappers scan), their forward copies followed rc_offset symbols later by their
@@ -447,8 +447,11 @@ private:
                            hip::device_vector<uint64>& pat_begin, hip::device_vector<uint64>& txt_begin, hip::device_vector<uint32>& txt_len,
                            hip::device_vector<uint32>& sinks, hip::device_vector<int32>& min_score, hip::device_vector<int32>& hit_score,
                            Stats& stats, void* hip_stream)
+    
     {
         const uint32 L = reads.len;
+        hip::device_vector<int32> known_score(pat_begin.size());
+        hip::device_vector<uint32> job_hit(pat_begin.size()), job_count(1);
         // active_read_queues.in_queue = pack_read( params.top_seed ) of the seed queue
         {
             hip::synchronize(hip_stream);
@@ -475,18 +478,29 @@ private:
             locate(fmi, rfmi, queues, hip_stream);
 
             // score_best: BestScoreStream's windows, then the banded scorer in nvBowtie's quality-aware scheme
+            // Hits at a placement the read already recorded keep the recorded score (known_score, see nvbio_hip.h); only the others
+            // become DP jobs, compacted, their scores scattered back at their hits.
             score_best_setup(queues, nullptr, nullptr, L, reads.rc_offset, band_len, genome_len, best_data_dvec.data(), BATCH_SIZE, worst_score,
-                             pat_begin.data(), nullptr, txt_begin.data(), txt_len.data(), min_score.data(), hip_stream);
-            const PackedStringSetView<4, true> patterns(queues.hits_size, reads.fw_rc_words, reads.fw_rc_n_words, pat_begin.data(), nullptr, L);
-            const PackedStringSetView<2, true> texts(queues.hits_size, genome_words, genome_n_words, txt_begin.data(), txt_len.data(), 0u);
-            const aln::BestSinkArrays sink_arrays = { hit_score.data(), sinks.data() };
-            dispatch_band(band_len, [&](auto band) {
-                aln::batch_banded_alignment_score<decltype(band)::value>(aligner, patterns, reads.quals, reads.n_quals, texts, sink_arrays, L, L + band_len, hip_stream);
-            });
+                             pat_begin.data(), nullptr, txt_begin.data(), txt_len.data(), min_score.data(), known_score.data(),
+                             job_count.data(), job_hit.data(), hip_stream);
+            uint32 n_jobs = 0;
+            hip::synchronize(hip_stream);
+            hip_check(nvbio_hip_memcpy(&n_jobs, job_count.data(), 4u, 2, nullptr), "nvbio_hip_memcpy(d2h)");
+            if (n_jobs)
+            {
+                const PackedStringSetView<4, true> patterns(n_jobs, reads.fw_rc_words, reads.fw_rc_n_words, pat_begin.data(), nullptr, L);
+                const PackedStringSetView<2, true> texts(n_jobs, genome_words, genome_n_words, txt_begin.data(), txt_len.data(), 0u);
+                const aln::BestSinkArrays sink_arrays = { hit_score.data(), sinks.data() };
+                dispatch_band(band_len, [&](auto band) {
+                    aln::batch_banded_alignment_score<decltype(band)::value>(aligner, patterns, reads.quals, reads.n_quals, texts, sink_arrays, L, L + band_len, hip_stream);
+                });
+                hip_check(nvbio_hip_scatter_rows(n_jobs, job_hit.data(), hit_score.data(), known_score.data(), 4u, hip_stream), "nvbio_hip_scatter_rows");
+            }
+            stats.dp_jobs += n_jobs;
 
             // score_reduce with the give-up counters
-            score_reduce(ReduceBestApproxContext(state.trys.data(), n_ext), hits, queues, hit_score.data(), nullptr, L, best_data_dvec.data(), BATCH_SIZE,
-                         worst_score, params.select, hip_stream);
+            score_reduce(ReduceBestApproxContext(state.trys.data(), n_ext), hits, queues, known_score.data(), nullptr, L, best_data_dvec.data(), BATCH_SIZE,
+                         worst_score, params.select, nullptr, hip_stream);
             stats.extensions += queues.hits_size; ++stats.rounds;
             n_ext += n_hits_per_read;
         }

@@ -101,12 +101,13 @@ inline void locate(const fm_index_device& fmi, const fm_index_device& rfmi, Scor
 inline void score_best_setup(const ScoringQueues& queues, const uint64* d_read_begin, const uint32* d_read_len, const uint32 fixed_read_len,
                              const uint64 rc_offset, const uint32 band_len, const uint32 genome_length,
                              const io::Alignment* best_data, const uint32 best_stride, const int32 score_limit,
-                             uint64* pattern_begin, uint32* pattern_len, uint64* text_begin, uint32* text_len, int32* min_score, void* hip_stream = nullptr)
+                             uint64* pattern_begin, uint32* pattern_len, uint64* text_begin, uint32* text_len, int32* min_score, int32* known_score = nullptr,
+                             uint32* job_count = nullptr, uint32* job_hit = nullptr, void* hip_stream = nullptr)
 {
     hip_check(nvbio_hip_score_best_setup(queues.hits_size, queues.hit_read_id.data(), queues.hit_loc.data(), reinterpret_cast<const uint32*>(queues.hit_seed.data()),
                                          d_read_begin, d_read_len, fixed_read_len, rc_offset, band_len, genome_length,
                                          reinterpret_cast<const uint64*>(best_data), best_stride, score_limit, pattern_begin, pattern_len,
-                                         text_begin, text_len, min_score, hip_stream), "nvbio_hip_score_best_setup");
+                                         text_begin, text_len, min_score, known_score, job_count, job_hit, hip_stream), "nvbio_hip_score_best_setup");
 }
 
 /// ReduceBestApproxContext (reduce.h:63-105)
@@ -119,12 +120,12 @@ struct ReduceBestApproxContext
 /// score_reduce( context, pipeline, params ) (reduce.h:136-147) over the round's hits; hit_score = the raw DP scores
 inline void score_reduce(const ReduceBestApproxContext context, SeedHitDequeArrayDeviceView hits, const ScoringQueues& queues, const int32* d_hit_score,
                          const uint32* d_read_len, const uint32 fixed_read_len, io::Alignment* best_data, const uint32 best_stride,
-                         const int32 worst_score, const SelectParamsPOD params, void* hip_stream = nullptr)
+                         const int32 worst_score, const SelectParamsPOD params, const int32* d_known_score = nullptr, void* hip_stream = nullptr)
 {
     hip_check(nvbio_hip_score_reduce_best_approx(queues.in_size, reinterpret_cast<const uint32*>(queues.active_in.data()), queues.hit_begin.data(), d_hit_score,
                                                  queues.hit_loc.data(), reinterpret_cast<const uint32*>(queues.hit_seed.data()), d_read_len, fixed_read_len,
                                                  reinterpret_cast<uint64*>(best_data), best_stride, worst_score, context.m_trys, hits.counts,
-                                                 context.m_ext, params.min_ext, params.max_ext, params.max_effort, hip_stream),
+                                                 context.m_ext, params.min_ext, params.max_ext, params.max_effort, d_known_score, hip_stream),
               "nvbio_hip_score_reduce_best_approx");
 }
 

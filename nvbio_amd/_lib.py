@@ -111,8 +111,8 @@ def lib():
         L.nvbio_hip_select.argtypes = [i32, u32, vp, u32, vp, u32, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, vp]
         L.nvbio_hip_hit_deque_replay.argtypes = [u32, vp, vp, vp, vp, vp, vp, u32, vp, vp]
         L.nvbio_hip_locate_hits.argtypes = [P(FMIndexStruct), P(FMIndexStruct), u32, vp, vp, vp]
-        L.nvbio_hip_score_best_setup.argtypes = [u32, vp, vp, vp, vp, vp, u32, u64, u32, u32, vp, u32, i32, vp, vp, vp, vp, vp, vp]
-        L.nvbio_hip_score_reduce_best_approx.argtypes = [u32, vp, vp, vp, vp, vp, vp, u32, vp, u32, i32, vp, vp, u32, u32, u32, u32, vp]
+        L.nvbio_hip_score_best_setup.argtypes = [u32, vp, vp, vp, vp, vp, u32, u64, u32, u32, vp, u32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.nvbio_hip_score_reduce_best_approx.argtypes = [u32, vp, vp, vp, vp, vp, vp, u32, vp, u32, i32, vp, vp, u32, u32, u32, u32, vp, vp]
         L.nvbio_hip_anchor_score_setup.argtypes = [u32, vp, vp, vp, vp, vp, vp, u32, u32, u64, u32, u32, vp, vp, u32, i32, vp, i32, u32, vp, vp, vp, vp, vp, vp]
         L.nvbio_hip_anchor_score_finish.argtypes = [u32, vp, vp, vp, vp, i32, vp, vp, vp]
         L.nvbio_hip_opposite_score_setup.argtypes = [u32, vp, vp, vp, vp, i32, vp, vp, u32, u32, vp, vp, u32, i32, vp, i32, i32, P(PeParamsStruct), vp, vp, vp, vp, vp, vp, u64, vp, vp, vp, vp]

@@ -96,11 +96,16 @@ def best_approx_score(fmi, rfmi, state, seed_queue, best, batch, genome_words, g
         with _Stage(stats, "locate"):
             sel.locate_hits(fmi, rfmi, loc, seed)
         with _Stage(stats, "score"):
-            pb, pl, tb, tl, _ = sel.score_best_setup(rid, loc, seed, best, band_len, genome_len, WORST_SCORE, fixed_read_len=batch.fixed_len,
-                                                     read_begin=batch.read_begin, read_len=batch.read_len, rc_offset=batch.rc_offset)
-            patterns = PackedStringSet(batch.fw_rc_words, 4, True, pb, pl, batch.fixed_len)
-            texts = PackedStringSet(genome_words, 2, True, tb, tl, 0)
-            score, _ = batch_banded_alignment_score(band_len, aligner, patterns, texts, max_pattern_length=batch.max_len, quals=batch.quals)
+            # hits at a placement the read already recorded keep the recorded score; only the others become DP jobs (compacted)
+            pb, pl, tb, tl, _, score, job_hit = sel.score_best_setup(rid, loc, seed, best, band_len, genome_len, WORST_SCORE,
+                                                                     fixed_read_len=batch.fixed_len, read_begin=batch.read_begin,
+                                                                     read_len=batch.read_len, rc_offset=batch.rc_offset, compact=True)
+            if job_hit.numel():
+                patterns = PackedStringSet(batch.fw_rc_words, 4, True, pb, pl, batch.fixed_len)
+                texts = PackedStringSet(genome_words, 2, True, tb, tl, 0)
+                job_score, _ = batch_banded_alignment_score(band_len, aligner, patterns, texts, max_pattern_length=batch.max_len, quals=batch.quals)
+                sel.scatter_scores(job_hit, job_score, score)
+            stats["dp_jobs"] = stats.get("dp_jobs", 0) + int(job_hit.numel())
         with _Stage(stats, "reduce"):
             sel.score_reduce_best_approx(best, state, active, hit_begin, score, loc, seed, WORST_SCORE, n_ext, params.min_ext, params.max_ext,
                                          params.max_effort, fixed_read_len=batch.fixed_len, read_len=batch.read_len)
@@ -195,7 +200,7 @@ def best_approx(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=No
         seed_queue = sel.copy_flagged(seed_queue, reseed)                          # aligner_best_approx.h:273-283
     with _Stage(stats, "mapq"):
         mapq = reduce.mapq(best, scheme, read_len=batch.read_len, fixed_read_len=batch.fixed_len, max_read_len=L)
-    out = dict(best=best.data, mapq=mapq, stats=stats)
+    out = dict(best=best.data, mapq=mapq, dp_jobs=stats.pop("dp_jobs", 0), stats=stats)    # (dp_jobs: the extensions that needed a DP)
     if traceback:
         # banded_traceback_best (traceback_inl.h:104-136) over every read; unaligned reads get an empty window, fail at once and
         # come back with no CIGAR and source = sink = (-1, -1)

@@ -227,7 +227,7 @@ NVB_API int nvbio_hip_fm_match(const nvbio_hip_fmindex* fmi, const nvbio_hip_str
 
 NVB_API int nvbio_hip_fm_build_ktab(const nvbio_hip_fmindex* fmi, uint32_t k, uint32_t* out_ktab, void* stream)
 {
-    if (!fmi || !fmi->bwt_occ || !out_ktab || k < 1 || k > 14) return hipErrorInvalidValue;
+    if (!fmi || !fmi->bwt_occ || !out_ktab || k < 1 || k > 15) return hipErrorInvalidValue;      // 4^15 entries = 8.6 GB; the code space must fit uint32
     Fmi f = make_fmi(fmi);
     f.ktab = nullptr; f.ktab_k = 0;
     const uint32_t n_codes = 1u << (2u * k);

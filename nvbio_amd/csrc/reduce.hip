@@ -5,6 +5,7 @@
 // Both are thin, HBM-streaming stages: one lane per read, a sequential walk over the read's extension
 // results (the update rule is order dependent), 16 B of state per read.
 #include "common.h"
+#include <limits.h>
 
 namespace nvb {
 
@@ -61,7 +62,7 @@ score_reduce_best_approx_kernel(uint32_t n_active, const uint32_t* __restrict__ 
                                 const int32_t* __restrict__ hit_score, const uint32_t* __restrict__ hit_loc, const uint32_t* __restrict__ hit_seed,
                                 const uint32_t* __restrict__ read_len, uint32_t fixed_len, uint2* __restrict__ best, uint32_t best_stride,
                                 int32_t worst_score, uint32_t* __restrict__ trys, uint32_t* __restrict__ hit_counts,
-                                uint32_t n_ext, uint32_t min_ext, uint32_t max_ext, uint32_t max_effort)
+                                uint32_t n_ext, uint32_t min_ext, uint32_t max_ext, uint32_t max_effort, const int32_t* __restrict__ known_score)
 {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= n_active) return;
@@ -74,7 +75,9 @@ score_reduce_best_approx_kernel(uint32_t n_active, const uint32_t* __restrict__ 
     bool erase = false;
     for (uint64_t i = hb; i < he; ++i)
     {
-        const int32_t score = max(hit_score[i], worst_score);
+        // (known_score: the score of a hit whose placement was already recorded, set by score_best_setup instead of re-running its DP)
+        const int32_t known = known_score ? known_score[i] : INT32_MIN;
+        const int32_t score = known != INT32_MIN ? known : max(hit_score[i], worst_score);
         const uint32_t g_pos = hit_loc[i], seed = hit_seed[i], rc = (seed >> 13) & 1u, top_flag = (seed >> 14) & 1u;
         if ((rc == io_aln_rc(a1) && g_pos == a1.align) || (rc == io_aln_rc(a2) && g_pos == a2.align)) continue;
         if (score > io_aln_score(a1)) { tr = max_effort; a2 = a1; a1 = io_aln_make(g_pos, 0u, score, rc); }
@@ -552,7 +555,7 @@ NVB_API int nvbio_hip_score_reduce_best_approx(uint32_t n_active, const uint32_t
                                                const uint32_t* read_len, uint32_t fixed_read_len,
                                                uint64_t* best_alignments, uint32_t best_stride, int32_t worst_score,
                                                uint32_t* trys, uint32_t* hit_counts,
-                                               uint32_t n_ext, uint32_t min_ext, uint32_t max_ext, uint32_t max_effort, void* stream)
+                                               uint32_t n_ext, uint32_t min_ext, uint32_t max_ext, uint32_t max_effort, const int32_t* known_score, void* stream)
 {
     if (n_active == 0) return hipSuccess;
     if (!active_reads || !hit_begin || !hit_score || !hit_loc || !hit_seed || !best_alignments || best_stride == 0 || !trys || !hit_counts)
@@ -561,7 +564,7 @@ NVB_API int nvbio_hip_score_reduce_best_approx(uint32_t n_active, const uint32_t
     g_last_kernel = "score_reduce_best_approx_kernel";
     hipLaunchKernelGGL(score_reduce_best_approx_kernel, dim3((n_active + 255u) / 256u), dim3(256), 0, to_stream(stream), n_active, active_reads,
                        hit_begin, hit_score, hit_loc, hit_seed, read_len, fixed_read_len, reinterpret_cast<uint2*>(best_alignments), best_stride,
-                       worst_score, trys, hit_counts, n_ext, min_ext, max_ext, max_effort);
+                       worst_score, trys, hit_counts, n_ext, min_ext, max_ext, max_effort, known_score);
     return hipGetLastError();
 }
 

@@ -19,6 +19,7 @@
 #include "fmindex_device.h"
 #include "hit_deque.h"
 #include <hipcub/hipcub.hpp>
+#include <limits.h>
 
 namespace nvb {
 
@@ -230,7 +231,8 @@ score_best_setup_kernel(uint32_t n, const uint32_t* __restrict__ hit_read_id, co
                         const uint64_t* __restrict__ read_begin, const uint32_t* __restrict__ read_len, uint32_t fixed_len, uint64_t rc_offset,
                         uint32_t band_len, uint32_t genome_len, const uint2* __restrict__ best, uint32_t best_stride, int32_t score_limit,
                         uint64_t* __restrict__ pat_begin, uint32_t* __restrict__ pat_len,
-                        uint64_t* __restrict__ text_begin, uint32_t* __restrict__ text_len, int32_t* __restrict__ min_score)
+                        uint64_t* __restrict__ text_begin, uint32_t* __restrict__ text_len, int32_t* __restrict__ min_score, int32_t* __restrict__ known_score,
+                        uint32_t* __restrict__ job_count, uint32_t* __restrict__ job_hit)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
@@ -239,13 +241,37 @@ score_best_setup_kernel(uint32_t n, const uint32_t* __restrict__ hit_read_id, co
     const uint32_t gb = g > band_len / 2u ? g - band_len / 2u : 0u;
     const uint32_t sum = gb + band_len + len;
     const uint32_t ge = sum < genome_len ? sum : genome_len;
-    text_begin[i] = gb;
-    text_len[i] = ge > gb ? ge - gb : 0u;                                        // (a wrapped read start: empty window, the alignment fails)
-    pat_begin[i] = (read_begin ? read_begin[r] : uint64_t(r) * fixed_len) + (((hit_seed[i] >> 13) & 1u) ? rc_offset : 0ull);
-    if (pat_len) pat_len[i] = len;
+    // A hit at a placement the read already recorded (same strand, same start) would be scored over the very same window again, and its
+    // score is the recorded one: hand that score to the reduction instead (which usually skips the hit anyway, reduce_inl.h:111-114) and
+    // give the job an empty window.  Most seeds of a read point at one placement, so this removes most of the extension work.
+    int32_t known = INT32_MIN;
+    if (known_score) {
+        const uint32_t rc = (hit_seed[i] >> 13) & 1u;
+        const uint2 a1 = best[r], a2 = best[r + best_stride];
+        if (((a1.x >> 28) & 1u) == rc && a1.y == g)      { const int32_t m = int32_t((a1.x >> 1) & 0x1FFFFu); known = (a1.x & 1u) ? -m : m; }
+        else if (((a2.x >> 28) & 1u) == rc && a2.y == g) { const int32_t m = int32_t((a2.x >> 1) & 0x1FFFFu); known = (a2.x & 1u) ? -m : m; }
+        known_score[i] = known;
+    }
+    // compacted form: only the hits that still need a DP become jobs, job_hit[slot] = the hit (one atomic per wavefront; the slot
+    // order varies from run to run, the scores scattered back through job_hit do not)
+    uint32_t o = i;
+    if (job_hit) {
+        const bool need = known == INT32_MIN;
+        const uint64_t m = __ballot(need);
+        if (!need) return;
+        const uint32_t lane = __lane_id(), leader = uint32_t(__ffsll((long long)m)) - 1u;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(job_count, uint32_t(__popcll(m)));
+        o = __shfl(base, int(leader)) + uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
+        job_hit[o] = i;
+    }
+    text_begin[o] = gb;
+    text_len[o] = (ge > gb && known == INT32_MIN) ? ge - gb : 0u;                // (a wrapped read start: empty window, the alignment fails)
+    pat_begin[o] = (read_begin ? read_begin[r] : uint64_t(r) * fixed_len) + (((hit_seed[i] >> 13) & 1u) ? rc_offset : 0ull);
+    if (pat_len) pat_len[o] = len;
     const uint32_t w2 = best[r + best_stride].x;
     const int32_t m2 = int32_t((w2 >> 1) & 0x1FFFFu), s2 = (w2 & 1u) ? -m2 : m2;
-    min_score[i] = s2 > score_limit ? s2 : score_limit;
+    min_score[o] = s2 > score_limit ? s2 : score_limit;
 }
 
 // one lane per program of deque operations (0 push with the mappers' "full: pop_bottom first" rule, 1 pop_top,
@@ -369,8 +395,11 @@ NVB_API int nvbio_hip_score_best_setup(uint32_t n_hits, const uint32_t* hit_read
                                        const uint64_t* read_begin, const uint32_t* read_len, uint32_t fixed_read_len, uint64_t rc_offset,
                                        uint32_t band_len, uint32_t genome_length, const uint64_t* best_alignments, uint32_t best_stride,
                                        int32_t score_limit, uint64_t* pattern_begin, uint32_t* pattern_len,
-                                       uint64_t* text_begin, uint32_t* text_len, int32_t* min_score, void* stream)
+                                       uint64_t* text_begin, uint32_t* text_len, int32_t* min_score, int32_t* known_score,
+                                       uint32_t* job_count, uint32_t* job_hit, void* stream)
 {
+    if ((job_count != nullptr) != (job_hit != nullptr) || (job_hit && !known_score)) return hipErrorInvalidValue;
+    if (job_count) { const hipError_t e = hipMemsetAsync(job_count, 0, sizeof(uint32_t), to_stream(stream)); if (e != hipSuccess) return e; }
     if (n_hits == 0) return hipSuccess;
     if (!hit_read_id || !hit_loc || !hit_seed || !best_alignments || best_stride == 0 || !pattern_begin || !text_begin || !text_len || !min_score)
         return hipErrorInvalidValue;
@@ -379,7 +408,7 @@ NVB_API int nvbio_hip_score_best_setup(uint32_t n_hits, const uint32_t* hit_read
     g_last_kernel = "score_best_setup_kernel";
     hipLaunchKernelGGL(score_best_setup_kernel, grid_for(n_hits), dim3(256), 0, to_stream(stream), n_hits, hit_read_id, hit_loc, hit_seed,
                        read_begin, read_len, fixed_read_len, rc_offset, band_len, genome_length, reinterpret_cast<const uint2*>(best_alignments),
-                       best_stride, score_limit, pattern_begin, pattern_len, text_begin, text_len, min_score);
+                       best_stride, score_limit, pattern_begin, pattern_len, text_begin, text_len, min_score, known_score, job_count, job_hit);
     return hipGetLastError();
 }
 

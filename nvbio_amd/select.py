@@ -81,8 +81,12 @@ def locate_hits(fmi, rfmi, hit_loc, hit_seed):
 
 
 def score_best_setup(hit_read_id, hit_loc, hit_seed, best, band_len, genome_len, score_limit, fixed_read_len=0, read_begin=None,
-                     read_len=None, rc_offset=0):
-    """Per hit: (pattern_begin int64, pattern_len int32 | None, text_begin int64, text_len int32, min_score int32)."""
+                     read_len=None, rc_offset=0, known=False, compact=False):
+    """Per hit: (pattern_begin int64, pattern_len int32 | None, text_begin int64, text_len int32, min_score int32[, known_score int32 when
+    `known`: the recorded score of hits at an already recorded placement, whose windows come back empty]).
+    compact: only the hits that still need a DP become jobs; returns (pb, pl, tb, tl, ms, known_score, job_hit), the job arrays cut to
+    the job count (one device->host read)."""
+    known = known or compact
     n = hit_read_id.numel()
     dev = hit_read_id.device
     pb = torch.empty(n, dtype=torch.int64, device=dev)
@@ -90,19 +94,32 @@ def score_best_setup(hit_read_id, hit_loc, hit_seed, best, band_len, genome_len,
     tb = torch.empty(n, dtype=torch.int64, device=dev)
     tl = torch.empty(n, dtype=torch.int32, device=dev)
     ms = torch.empty(n, dtype=torch.int32, device=dev)
+    ks = torch.empty(n, dtype=torch.int32, device=dev) if known else None
+    jc = torch.empty(1, dtype=torch.int32, device=dev) if compact else None
+    jh = torch.empty(n, dtype=torch.int32, device=dev) if compact else None
     data = best.data if hasattr(best, "data") else best
     check(lib().nvbio_hip_score_best_setup(n, _vp(hit_read_id), _vp(hit_loc), _vp(hit_seed), _vp(read_begin), _vp(read_len), int(fixed_read_len),
                                            int(rc_offset), int(band_len), int(genome_len), _vp(data), data.shape[1], int(score_limit),
-                                           _vp(pb), _vp(pl), _vp(tb), _vp(tl), _vp(ms), current_stream_ptr()), "nvbio_hip_score_best_setup")
-    return pb, pl, tb, tl, ms
+                                           _vp(pb), _vp(pl), _vp(tb), _vp(tl), _vp(ms), _vp(ks), _vp(jc), _vp(jh), current_stream_ptr()),
+          "nvbio_hip_score_best_setup")
+    if compact:
+        nj = int(jc.item())
+        return pb[:nj], (pl[:nj] if pl is not None else None), tb[:nj], tl[:nj], ms[:nj], ks, jh[:nj]
+    return (pb, pl, tb, tl, ms, ks) if known else (pb, pl, tb, tl, ms)
+
+
+def scatter_scores(job_hit, scores, known_score):
+    """known_score[job_hit[j]] = scores[j]: the DP scores of compacted jobs back at their hits."""
+    check(lib().nvbio_hip_scatter_rows(job_hit.numel(), _vp(job_hit), _vp(scores), _vp(known_score), 4, current_stream_ptr()), "nvbio_hip_scatter_rows")
+    return known_score
 
 
 def score_reduce_best_approx(best, state, active, hit_begin, hit_score, hit_loc, hit_seed, worst_score, n_ext, min_ext, max_ext, max_effort,
-                             fixed_read_len=0, read_len=None):
+                             fixed_read_len=0, read_len=None, known_score=None):
     data = best.data if hasattr(best, "data") else best
     check(lib().nvbio_hip_score_reduce_best_approx(active.numel(), _vp(active), _vp(hit_begin), _vp(hit_score), _vp(hit_loc), _vp(hit_seed),
                                                    _vp(read_len), int(fixed_read_len), _vp(data), data.shape[1], int(worst_score),
-                                                   _vp(state.trys), _vp(state.counts), int(n_ext), int(min_ext), int(max_ext), int(max_effort),
+                                                   _vp(state.trys), _vp(state.counts), int(n_ext), int(min_ext), int(max_ext), int(max_effort), _vp(known_score),
                                                    current_stream_ptr()), "nvbio_hip_score_reduce_best_approx")
     return best
 
