@@ -546,6 +546,41 @@ int nvbio_hip_finish_alignment(uint32_t n, const uint8_t* valid, const nvbio_hip
                                const uint32_t* cigar_source /* uint2[n] */, int32_t match, const int32_t* mismatch_by_quality /* host, 256 */, int32_t n_penalty,
                                const uint32_t* idx /* nullable */, uint64_t* best_alignments, uint8_t* out_mds, uint32_t mds_stride, uint32_t* out_mds_len, void* stream);
 
+/* ---- all-mapping mode (Aligner::all / score_all, nvBowtie/bowtie2/cuda/aligner_all.h:47-694) ----
+ * Every row of every SA range in every read's hit deque is located, de-duplicated, extended, and reported when its score reaches
+ * scoring_scheme.min_score(read_len).  The host driver (nvbio_amd.aligner.all_mapping) does the scans, sorts and compactions the
+ * reference does with thrust; the device stages are:
+ *   gather_ranges (mapping.cu:39-67): out_ranges[t] = the size of SA range t, ranges numbered read by read in deque array order
+ *     (hit_count_scan = inclusive scan of the deque sizes).
+ *   select_all (select.cu:175-219): hit begin + t, numbered through hit_range_scan (inclusive scan of out_ranges) ->
+ *     out_loc = its SA row (range begin + row), out_seed = packed_seed(pos_in_read, index_dir, rc, 0), out_read_id.
+ *   mark_straddling (locate_inl.h:213-244): flags[t] = 0 when hit idx_queue[t]'s seed [loc, loc + seed_len] crosses a boundary of
+ *     sequence_index (n_sequences + 1 offsets) -- the indexing (hit idx_queue[t], flag t) is the reference's.
+ *   score_all_setup (AllScoreStream::init_context, score_all_inl.h:99-127): job i = hit idx[i] (or i): window
+ *     [loc - band/2, + band + read_len) clamped to the genome, pattern = the read's copy (+ rc_offset on the reverse strand).
+ *   score_all_output (AllScoreStream::output, :131-153): out_flags[i] = score[i] >= min_score_by_len[read_len]; out_alignments[i] =
+ *     io::Alignment(loc, 0, score, rc); out_read_id[i] (the reference appends the accepted ones to a ring buffer in atomic order;
+ *     here the caller compacts by the flags, in job order).
+ *   traceback_all_setup (AllTracebackStream::init_context, traceback_inl.h:361-385): the same windows from alignment words. */
+int nvbio_hip_gather_ranges(uint32_t n_ranges, uint32_t n_reads, const uint64_t* hits, uint32_t hits_stride, const uint32_t* hit_count_scan,
+                            uint64_t* out_ranges, void* stream);
+int nvbio_hip_select_all(uint64_t begin, uint32_t count, uint32_t n_reads, uint32_t n_ranges, const uint64_t* hits, uint32_t hits_stride,
+                         const uint32_t* hit_count_scan, const uint64_t* hit_range_scan, uint32_t* out_loc, uint32_t* out_seed, uint32_t* out_read_id,
+                         void* stream);
+int nvbio_hip_mark_straddling(uint32_t n, const uint32_t* idx_queue, uint32_t n_sequences, const uint32_t* sequence_index, const uint32_t* hit_loc,
+                              uint32_t seed_len, uint8_t* flags, void* stream);
+int nvbio_hip_score_all_setup(uint32_t n, const uint32_t* idx /* nullable */, const uint32_t* hit_read_id, const uint32_t* hit_loc, const uint32_t* hit_seed,
+                              const uint64_t* read_begin /* nullable */, const uint32_t* read_len /* nullable */, uint32_t fixed_read_len, uint64_t rc_offset,
+                              uint32_t band_len, uint32_t genome_length,
+                              uint64_t* pattern_begin, uint32_t* pattern_len /* nullable iff fixed */, uint64_t* text_begin, uint32_t* text_len, void* stream);
+int nvbio_hip_score_all_output(uint32_t n, const uint32_t* idx /* nullable */, const uint32_t* hit_read_id, const uint32_t* hit_loc, const uint32_t* hit_seed,
+                               const int32_t* score, const int32_t* min_score_by_len /* device */, const uint32_t* read_len /* nullable */, uint32_t fixed_read_len,
+                               uint8_t* out_flags, uint64_t* out_alignments, uint32_t* out_read_id, void* stream);
+int nvbio_hip_traceback_all_setup(uint32_t n, const uint64_t* alignments, const uint32_t* read_id,
+                                  const uint64_t* read_begin /* nullable */, const uint32_t* read_len /* nullable */, uint32_t fixed_read_len, uint64_t rc_offset,
+                                  uint32_t band_len, uint32_t genome_length,
+                                  uint64_t* pattern_begin, uint32_t* pattern_len /* nullable iff fixed */, uint64_t* text_begin, uint32_t* text_len, void* stream);
+
 /* BowtieMapq2 / BowtieMapq3 (nvBowtie/bowtie2/cuda/mapq.h:42-330) for single-end reads:
  * out_mapq[r] from the best / second-best alignment of read r; perfect_score(len) = len * match,
  * min_score(len) = min_score_by_len[len] (the scheme's SimpleFunc tabulated by the host, scoring.h:272-281),

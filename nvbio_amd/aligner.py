@@ -375,3 +375,100 @@ def best_approx_paired(fmi, rfmi, sym1, sym2, genome_words, genome_len, params=N
                 tb_u[key][k] = tb_c[key][: k.numel()]
         out["tb1"], out["tb2"] = tb1, tb_u
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# all-mapping: Aligner::all / score_all of aligner_all.h (:47-227, :264-694)
+# ------------------------------------------------------------------------------------------------------------------
+def all_mapping(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=None, qual_value=30, quals=None, packed=None, sequence_index=None,
+                cigar_stride=None, mds_stride=256, traceback=True, stage_times=False):
+    """nvBowtie's all-mapping mode: one mapping pass with every seed of every read, then every row of every SA range is located,
+    de-duplicated (within a batch of params.batch_size hits, as in the reference), extended, and reported when its score reaches
+    scheme.min_score(read_len).  The reference streams the accepted alignments through a ring buffer in atomic order and sorts each
+    traceback batch by read; here they come back in batch order, sorted by (read, strand, position) inside a batch.
+    Returns dict(read_id int32[m], alignments int64[m] (finished io::Alignment words: window begin, edit distance, final score),
+    alignments_scored (as accepted: read start, extension score), cigar, cigar_len, source, sink, mds, mds_len, stats)."""
+    params = params or Params()
+    batch = sym if isinstance(sym, ReadBatch) else ReadBatch.from_matrix(sym, qual_value, quals, packed)
+    n, L = batch.n, batch.max_len
+    dev = batch.fw_rc_words.device
+    scheme = scheme or (SmithWatermanScoringScheme.local() if params.local else SmithWatermanScoringScheme())
+    aligner = make_gotoh_aligner(LOCAL if params.local else SEMI_GLOBAL, scheme)
+    band_len = band_length(params.max_dist)
+    mp = params.mapping_params()
+    hits_stride = params.hits_stride or min(params.max_hits, 128)
+    stats = dict(hits=0, ranges=0, unique=0)
+    if stage_times:
+        stats["ms"] = {}
+    # map_kernel (mapping_inl.h:598-687) searches seeds 0 .. max_seeds-1 of the first seeding pattern, max_seeds = max over the read
+    # lengths of uint32(len / seed_freq(len)) (aligner_all.h:93-95); map_seeds(retry 0) searches every seed that fits, which is the
+    # same set whenever the cap does not bind -- checked here, loudly, instead of silently mapping more seeds than the reference
+    lens = [L] if batch.read_len is None else sorted(set(int(x) for x in torch.unique(batch.read_len).tolist()))
+    freq = lambda l: max(mapping.simple_func(*mp.seed_freq, l), 0)
+    max_seeds = max([l // freq(l) for l in range(max(lens[0], 1), lens[-1] + 1) if freq(l) > 0] or [0])
+    for l in lens:
+        if l >= mp.min_read_len and freq(l) > 0 and (l - min(mp.seed_len, l)) // freq(l) + 1 > max_seeds:
+            raise ValueError("all_mapping: the reference's seed cap (%d) would drop seeds of %d-bp reads; this seeding interval is not supported" % (max_seeds, l))
+    with _Stage(stats, "map"):
+        hits, counts, _ = mapping.map_seeds(fmi, rfmi, batch.reversed, mp, L, allow_sub=params.allow_sub, subseed_len=params.subseed_len, retry=0,
+                                            fw=params.fw, rc=params.rc, in_queue=None, hits_stride=hits_stride)
+    empty = dict(read_id=torch.zeros(0, dtype=torch.int32, device=dev), alignments=torch.zeros(0, dtype=torch.int64, device=dev),
+                 alignments_scored=torch.zeros(0, dtype=torch.int64, device=dev), stats=stats)
+    # scans (thrust::inclusive_scan in the reference) and the range sizes
+    count_scan = torch.cumsum(counts.to(torch.int64), 0).to(torch.int32)
+    n_ranges = int(count_scan[-1]) if n else 0
+    if n_ranges == 0:
+        return empty
+    range_scan = torch.cumsum(sel.gather_ranges(hits, counts, count_scan, n_ranges), 0)
+    n_hits = int(range_scan[-1])
+    stats["hits"], stats["ranges"] = n_hits, n_ranges
+    seq_index = torch.tensor(sequence_index if sequence_index is not None else [0, genome_len], dtype=torch.int64, device=dev).to(torch.int32)
+    table = sel._min_score_table(scheme, L, dev)
+    out_aln, out_read = [], []
+    B = params.batch_size
+    for off in range(0, n_hits, B):
+        cnt = min(n_hits - off, B)
+        with _Stage(stats, "select"):
+            loc, seed, rid = sel.select_all(off, cnt, hits, count_scan, range_scan)
+        with _Stage(stats, "locate"):
+            idx_queue = torch.sort((loc.to(torch.int64) & 0xFFFFFFFF) >> 16, stable=True).indices.to(torch.int32)      # sort_hi_bits
+            sel.locate_hits(fmi, rfmi, loc, seed)
+        with _Stage(stats, "sort"):
+            key = (loc.to(torch.int64) & 0xFFFFFFFF) + (rid.to(torch.int64) << 33) + (((seed >> 13) & 1).to(torch.int64) << 32)     # SortingKeys
+            skey, sidx = torch.sort(key, stable=True)
+            flags = torch.ones(cnt, dtype=torch.uint8, device=dev)
+            flags[1:] = (skey[1:] != skey[:-1]).to(torch.uint8)
+            sel.mark_straddling(idx_queue, seq_index, loc, params.seed_len, flags)
+            q = sel.copy_flagged(sidx.to(torch.int32), flags)
+        stats["unique"] += int(q.numel())
+        if q.numel() == 0:
+            continue
+        with _Stage(stats, "score"):
+            pb, pl, tb, tl = sel.score_all_setup(q, rid, loc, seed, band_len, genome_len, fixed_read_len=batch.fixed_len, read_begin=batch.read_begin,
+                                                 read_len=batch.read_len, rc_offset=batch.rc_offset)
+            score, _ = batch_banded_alignment_score(band_len, aligner, PackedStringSet(batch.fw_rc_words, 4, True, pb, pl, batch.fixed_len),
+                                                    PackedStringSet(genome_words, 2, True, tb, tl, 0), max_pattern_length=L, quals=batch.quals)
+            fl, aln, arid = sel.score_all_output(q, rid, loc, seed, score, table, fixed_read_len=batch.fixed_len, read_len=batch.read_len)
+            keep = fl.bool()
+            out_aln.append(aln[keep]); out_read.append(arid[keep])
+    if not out_aln:
+        return empty
+    aln, arid = torch.cat(out_aln), torch.cat(out_read)
+    out = dict(read_id=arid, alignments_scored=aln.clone(), alignments=aln, stats=stats)
+    m = aln.numel()
+    if traceback and m:
+        cig, cl, src, snk, mds, ml = [], [], [], [], [], []
+        for off in range(0, m, B):                     # banded_traceback_all + finish_alignment_all, a batch at a time
+            a, r = aln[off:off + B], arid[off:off + B].contiguous()
+            with _Stage(stats, "traceback"):
+                pb, pl, tb, tl = sel.traceback_all_setup(a, r, band_len, genome_len, fixed_read_len=batch.fixed_len, read_begin=batch.read_begin,
+                                                         read_len=batch.read_len, rc_offset=batch.rc_offset)
+                pat, txt = PackedStringSet(batch.fw_rc_words, 4, True, pb, pl, batch.fixed_len), PackedStringSet(genome_words, 2, True, tb, tl, 0)
+                t = batch_banded_alignment_traceback(band_len, aligner, pat, txt, max_pattern_length=L, quals=batch.quals, cigar_stride=cigar_stride)
+            with _Stage(stats, "finish"):
+                valid = torch.ones(a.numel(), dtype=torch.uint8, device=dev)
+                md, mdl = sel.finish_alignment(valid, pat, batch.quals, txt, t["cigar"], t["cigar_len"], t["source"], scheme, a, mds_stride=mds_stride)
+            cig.append(t["cigar"][: a.numel()]); cl.append(t["cigar_len"][: a.numel()]); src.append(t["source"][: a.numel()]); snk.append(t["sink"][: a.numel()])
+            mds.append(md[: a.numel()]); ml.append(mdl)
+        out.update(cigar=torch.cat(cig), cigar_len=torch.cat(cl), source=torch.cat(src), sink=torch.cat(snk), mds=torch.cat(mds), mds_len=torch.cat(ml))
+    return out

@@ -1,0 +1,197 @@
+// all_mapping.hip -- the device stages of nvBowtie's all-mapping mode (Aligner::all / score_all,
+// nvBowtie/bowtie2/cuda/aligner_all.h:47-694): every row of every seed hit range of every read is located, de-duplicated,
+// extended and -- if its score reaches the scheme's threshold -- traced back and reported.
+//
+//   gather_ranges_kernel     mapping.cu:39-67       the size of every SA range of every read, in deque array order
+//   select_all_kernel        select.cu:175-219      global hit number -> (read, range, row) by two binary searches
+//   mark_straddling_kernel   locate_inl.h:213-244   hits whose seed crosses a reference sequence boundary
+//   all_window_kernel        score_all_inl.h:99-127 / traceback_inl.h:361-385 (the same window rule for scoring and traceback)
+//   score_all_output_kernel  score_all_inl.h:131-153 accepted hits become alignments (the reference appends them to a ring
+//                            buffer with an atomic counter; here every job gets a flag and the host compacts in job order)
+//
+// One lane per hit everywhere: these are streaming passes over the hit arrays (HBM bound, a few bytes per hit); the
+// binary searches run over scans that stay in L2.
+#include "common.h"
+
+namespace nvb {
+
+// first index i in [0, n) with a[i] > key (n if none): nvbio::upper_bound
+template <typename K, typename T>
+__device__ __forceinline__ uint32_t upper_bound_index(const K key, const T* __restrict__ a, const uint32_t n)
+{
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (K(a[mid]) > key) hi = mid; else lo = mid + 1u;
+    }
+    return lo;
+}
+
+__global__ void __launch_bounds__(256)
+gather_ranges_kernel(uint32_t n_ranges, uint32_t n_reads, const uint2* __restrict__ hits, uint32_t hits_stride,
+                     const uint32_t* __restrict__ count_scan, uint64_t* __restrict__ out_ranges)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_ranges) return;
+    const uint32_t read = upper_bound_index<uint32_t>(t, count_scan, n_reads);
+    const uint32_t k = t - (read ? count_scan[read - 1u] : 0u);
+    out_ranges[t] = hits[uint64_t(read) * hits_stride + k].y & 0xFFFFFu;                  // range.y - range.x
+}
+
+__global__ void __launch_bounds__(256)
+select_all_kernel(uint64_t begin, uint32_t count, uint32_t n_reads, uint32_t n_ranges, const uint2* __restrict__ hits, uint32_t hits_stride,
+                  const uint32_t* __restrict__ count_scan, const uint64_t* __restrict__ range_scan,
+                  uint32_t* __restrict__ out_loc, uint32_t* __restrict__ out_seed, uint32_t* __restrict__ out_read)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= count) return;
+    const uint64_t g = begin + t;
+    const uint32_t range = upper_bound_index<uint64_t>(g, range_scan, n_ranges);
+    const uint32_t read = upper_bound_index<uint32_t>(range, count_scan, n_reads);
+    const uint32_t k = range - (read ? count_scan[read - 1u] : 0u);
+    const uint2 h = hits[uint64_t(read) * hits_stride + k];
+    const uint32_t row = uint32_t(g - (range ? range_scan[range - 1u] : 0ull));
+    out_loc[t] = h.x + row;                                                                 // hit->front() + hit_id
+    // packed_seed( pos_in_read, index_dir, rc, top_flag = 0 )
+    out_seed[t] = ((h.y >> 20) & 0x3FFu) | (((h.y >> 31) & 1u) << 12) | (((h.y >> 30) & 1u) << 13);
+    out_read[t] = read;
+}
+
+// NOTE the indexing, kept from the reference: lane t examines hit idx_queue[t] -- the order the hits were located in -- but
+// clears flags[t], which the caller reads in the (read, strand, position) sort order.
+__global__ void __launch_bounds__(256)
+mark_straddling_kernel(uint32_t n, const uint32_t* __restrict__ idx_queue, uint32_t n_seqs, const uint32_t* __restrict__ seq_index,
+                       const uint32_t* __restrict__ hit_loc, uint32_t seed_len, uint8_t* __restrict__ flags)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t g = hit_loc[idx_queue[t]];
+    const uint32_t s0 = upper_bound_index<uint32_t>(g, seq_index, n_seqs + 1u) - 1u;
+    const uint32_t s1 = upper_bound_index<uint32_t>(g + seed_len, seq_index, n_seqs + 1u) - 1u;
+    if (s0 != s1) flags[t] = 0u;
+}
+
+// job i: hit j = idx ? idx[i] : i at (hit_read[j], hit_loc[j], strand bit 13 of hit_seed[j]) -- or, with `alignments`, alignment i of
+// read hit_read[i] -- gets the window [pos - band/2 (clamped at 0), + band + read_len (clamped at the genome's end)) and its pattern
+__global__ void __launch_bounds__(256)
+all_window_kernel(uint32_t n, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ hit_read, const uint32_t* __restrict__ hit_loc,
+                  const uint32_t* __restrict__ hit_seed, const uint2* __restrict__ alignments,
+                  const uint64_t* __restrict__ read_begin, const uint32_t* __restrict__ read_len, uint32_t fixed_len, uint64_t rc_offset,
+                  uint32_t band_len, uint32_t genome_len,
+                  uint64_t* __restrict__ pat_begin, uint32_t* __restrict__ pat_len, uint64_t* __restrict__ text_begin, uint32_t* __restrict__ text_len)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    uint32_t r, pos, rc;
+    if (alignments) { const uint2 a = alignments[i]; r = hit_read[i]; pos = a.y; rc = (a.x >> 28) & 1u; }
+    else            { const uint32_t j = idx ? idx[i] : i; r = hit_read[j]; pos = hit_loc[j]; rc = (hit_seed[j] >> 13) & 1u; }
+    const uint32_t len = read_len ? read_len[r] : fixed_len;
+    const uint32_t gb = pos > band_len / 2u ? pos - band_len / 2u : 0u;
+    const uint32_t sum = gb + band_len + len;                                                // (uint32 arithmetic, as the reference's)
+    const uint32_t ge = sum < genome_len ? sum : genome_len;
+    text_begin[i] = gb;
+    text_len[i] = ge > gb ? ge - gb : 0u;
+    pat_begin[i] = (read_begin ? read_begin[r] : uint64_t(r) * fixed_len) + (rc ? rc_offset : 0ull);
+    if (pat_len) pat_len[i] = len;
+}
+
+__global__ void __launch_bounds__(256)
+score_all_output_kernel(uint32_t n, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ hit_read, const uint32_t* __restrict__ hit_loc,
+                        const uint32_t* __restrict__ hit_seed, const int32_t* __restrict__ score, const int32_t* __restrict__ min_score_by_len,
+                        const uint32_t* __restrict__ read_len, uint32_t fixed_len,
+                        uint8_t* __restrict__ out_flags, uint2* __restrict__ out_alignments, uint32_t* __restrict__ out_read)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t j = idx ? idx[i] : i;
+    const uint32_t r = hit_read[j];
+    const int32_t s = score[i];
+    const bool ok = s >= min_score_by_len[read_len ? read_len[r] : fixed_len];
+    out_flags[i] = ok ? 1u : 0u;
+    // io::Alignment( hit.loc, 0u, sink.score, hit.seed.rc )
+    const uint32_t mag = uint32_t(s < 0 ? -s : s);
+    out_alignments[i] = make_uint2((s < 0 ? 1u : 0u) | ((mag & 0x1FFFFu) << 1) | (((hit_seed[j] >> 13) & 1u) << 28), hit_loc[j]);
+    out_read[i] = r;
+}
+
+} // namespace nvb
+
+using namespace nvb;
+
+static inline dim3 grid_for(uint64_t n) { return dim3(uint32_t((n + 255u) / 256u)); }
+
+NVB_API int nvbio_hip_gather_ranges(uint32_t n_ranges, uint32_t n_reads, const uint64_t* hits, uint32_t hits_stride, const uint32_t* hit_count_scan,
+                                    uint64_t* out_ranges, void* stream)
+{
+    if (n_ranges == 0) return hipSuccess;
+    if (!hits || !hit_count_scan || !out_ranges || hits_stride == 0 || n_reads == 0) return hipErrorInvalidValue;
+    g_last_kernel = "gather_ranges_kernel";
+    hipLaunchKernelGGL(gather_ranges_kernel, grid_for(n_ranges), dim3(256), 0, to_stream(stream), n_ranges, n_reads, reinterpret_cast<const uint2*>(hits),
+                       hits_stride, hit_count_scan, out_ranges);
+    return hipGetLastError();
+}
+
+NVB_API int nvbio_hip_select_all(uint64_t begin, uint32_t count, uint32_t n_reads, uint32_t n_ranges, const uint64_t* hits, uint32_t hits_stride,
+                                 const uint32_t* hit_count_scan, const uint64_t* hit_range_scan, uint32_t* out_loc, uint32_t* out_seed, uint32_t* out_read_id,
+                                 void* stream)
+{
+    if (count == 0) return hipSuccess;
+    if (!hits || !hit_count_scan || !hit_range_scan || !out_loc || !out_seed || !out_read_id || hits_stride == 0 || n_reads == 0 || n_ranges == 0)
+        return hipErrorInvalidValue;
+    g_last_kernel = "select_all_kernel";
+    hipLaunchKernelGGL(select_all_kernel, grid_for(count), dim3(256), 0, to_stream(stream), begin, count, n_reads, n_ranges, reinterpret_cast<const uint2*>(hits),
+                       hits_stride, hit_count_scan, hit_range_scan, out_loc, out_seed, out_read_id);
+    return hipGetLastError();
+}
+
+NVB_API int nvbio_hip_mark_straddling(uint32_t n, const uint32_t* idx_queue, uint32_t n_sequences, const uint32_t* sequence_index, const uint32_t* hit_loc,
+                                      uint32_t seed_len, uint8_t* flags, void* stream)
+{
+    if (n == 0) return hipSuccess;
+    if (!idx_queue || !sequence_index || !hit_loc || !flags || n_sequences == 0) return hipErrorInvalidValue;
+    g_last_kernel = "mark_straddling_kernel";
+    hipLaunchKernelGGL(mark_straddling_kernel, grid_for(n), dim3(256), 0, to_stream(stream), n, idx_queue, n_sequences, sequence_index, hit_loc, seed_len, flags);
+    return hipGetLastError();
+}
+
+NVB_API int nvbio_hip_score_all_setup(uint32_t n, const uint32_t* idx, const uint32_t* hit_read_id, const uint32_t* hit_loc, const uint32_t* hit_seed,
+                                      const uint64_t* read_begin, const uint32_t* read_len, uint32_t fixed_read_len, uint64_t rc_offset,
+                                      uint32_t band_len, uint32_t genome_length,
+                                      uint64_t* pattern_begin, uint32_t* pattern_len, uint64_t* text_begin, uint32_t* text_len, void* stream)
+{
+    if (n == 0) return hipSuccess;
+    if (!hit_read_id || !hit_loc || !hit_seed || !pattern_begin || !text_begin || !text_len) return hipErrorInvalidValue;
+    if ((!read_len && fixed_read_len == 0) || (read_len && !pattern_len)) return hipErrorInvalidValue;
+    g_last_kernel = "all_window_kernel";
+    hipLaunchKernelGGL(all_window_kernel, grid_for(n), dim3(256), 0, to_stream(stream), n, idx, hit_read_id, hit_loc, hit_seed, static_cast<const uint2*>(nullptr),
+                       read_begin, read_len, fixed_read_len, rc_offset, band_len, genome_length, pattern_begin, pattern_len, text_begin, text_len);
+    return hipGetLastError();
+}
+
+NVB_API int nvbio_hip_score_all_output(uint32_t n, const uint32_t* idx, const uint32_t* hit_read_id, const uint32_t* hit_loc, const uint32_t* hit_seed,
+                                       const int32_t* score, const int32_t* min_score_by_len, const uint32_t* read_len, uint32_t fixed_read_len,
+                                       uint8_t* out_flags, uint64_t* out_alignments, uint32_t* out_read_id, void* stream)
+{
+    if (n == 0) return hipSuccess;
+    if (!hit_read_id || !hit_loc || !hit_seed || !score || !min_score_by_len || !out_flags || !out_alignments || !out_read_id) return hipErrorInvalidValue;
+    if (!read_len && fixed_read_len == 0) return hipErrorInvalidValue;
+    g_last_kernel = "score_all_output_kernel";
+    hipLaunchKernelGGL(score_all_output_kernel, grid_for(n), dim3(256), 0, to_stream(stream), n, idx, hit_read_id, hit_loc, hit_seed, score, min_score_by_len,
+                       read_len, fixed_read_len, out_flags, reinterpret_cast<uint2*>(out_alignments), out_read_id);
+    return hipGetLastError();
+}
+
+NVB_API int nvbio_hip_traceback_all_setup(uint32_t n, const uint64_t* alignments, const uint32_t* read_id,
+                                          const uint64_t* read_begin, const uint32_t* read_len, uint32_t fixed_read_len, uint64_t rc_offset,
+                                          uint32_t band_len, uint32_t genome_length,
+                                          uint64_t* pattern_begin, uint32_t* pattern_len, uint64_t* text_begin, uint32_t* text_len, void* stream)
+{
+    if (n == 0) return hipSuccess;
+    if (!alignments || !read_id || !pattern_begin || !text_begin || !text_len) return hipErrorInvalidValue;
+    if ((!read_len && fixed_read_len == 0) || (read_len && !pattern_len)) return hipErrorInvalidValue;
+    g_last_kernel = "all_window_kernel";
+    hipLaunchKernelGGL(all_window_kernel, grid_for(n), dim3(256), 0, to_stream(stream), n, static_cast<const uint32_t*>(nullptr), read_id,
+                       static_cast<const uint32_t*>(nullptr), static_cast<const uint32_t*>(nullptr), reinterpret_cast<const uint2*>(alignments),
+                       read_begin, read_len, fixed_read_len, rc_offset, band_len, genome_length, pattern_begin, pattern_len, text_begin, text_len);
+    return hipGetLastError();
+}

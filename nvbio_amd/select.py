@@ -242,3 +242,63 @@ def finish_alignment(valid, patterns, quals, texts, cigar, cigar_len, source, sc
                                            _vp(cigar_len), _vp(source), int(scheme.m_match), lut, int(getattr(scheme, "m_n_penalty", 1)), _vp(idx), _vp(best_data),
                                            _vp(mds), mds_stride, _vp(mds_len), current_stream_ptr()), "nvbio_hip_finish_alignment")
     return mds, mds_len[:n]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# all-mapping mode (aligner_all.h): device stages
+# ------------------------------------------------------------------------------------------------------------------
+def gather_ranges(hits, counts, count_scan, n_ranges):
+    """gather_ranges (mapping.cu:39-67): the size of every SA range, read by read in deque array order -> int64[n_ranges]."""
+    out = torch.empty(n_ranges, dtype=torch.int64, device=hits.device)
+    check(lib().nvbio_hip_gather_ranges(n_ranges, counts.numel(), _vp(hits), hits.shape[1], _vp(count_scan), _vp(out), current_stream_ptr()),
+          "nvbio_hip_gather_ranges")
+    return out
+
+
+def select_all(begin, count, hits, count_scan, range_scan):
+    """select_all (select.cu:175-219): hits begin .. begin + count of the global numbering -> (SA row, packed seed, read id), int32[count] each."""
+    dev = hits.device
+    loc, seed, rid = (torch.empty(count, dtype=torch.int32, device=dev) for _ in range(3))
+    check(lib().nvbio_hip_select_all(int(begin), int(count), count_scan.numel(), range_scan.numel(), _vp(hits), hits.shape[1], _vp(count_scan), _vp(range_scan),
+                                     _vp(loc), _vp(seed), _vp(rid), current_stream_ptr()), "nvbio_hip_select_all")
+    return loc, seed, rid
+
+
+def mark_straddling(idx_queue, sequence_index, hit_loc, seed_len, flags):
+    """mark_straddling (locate_inl.h:213-244) into flags (uint8, in place)."""
+    check(lib().nvbio_hip_mark_straddling(idx_queue.numel(), _vp(idx_queue), sequence_index.numel() - 1, _vp(sequence_index), _vp(hit_loc), int(seed_len), _vp(flags),
+                                          current_stream_ptr()), "nvbio_hip_mark_straddling")
+    return flags
+
+
+def _window_outputs(m, dev, ragged):
+    pb = torch.empty(m, dtype=torch.int64, device=dev); tb = torch.empty(m, dtype=torch.int64, device=dev); tl = torch.empty(m, dtype=torch.int32, device=dev)
+    return pb, (torch.empty(m, dtype=torch.int32, device=dev) if ragged else None), tb, tl
+
+
+def score_all_setup(idx, hit_read_id, hit_loc, hit_seed, band_len, genome_len, fixed_read_len=0, read_begin=None, read_len=None, rc_offset=0):
+    """AllScoreStream::init_context over the hits idx[i] -> (pattern_begin, pattern_len | None, text_begin, text_len)."""
+    m = idx.numel() if idx is not None else hit_loc.numel()
+    pb, pl, tb, tl = _window_outputs(m, hit_loc.device, read_len is not None)
+    check(lib().nvbio_hip_score_all_setup(m, _vp(idx), _vp(hit_read_id), _vp(hit_loc), _vp(hit_seed), _vp(read_begin), _vp(read_len), int(fixed_read_len), int(rc_offset),
+                                          int(band_len), int(genome_len), _vp(pb), _vp(pl), _vp(tb), _vp(tl), current_stream_ptr()), "nvbio_hip_score_all_setup")
+    return pb, pl, tb, tl
+
+
+def score_all_output(idx, hit_read_id, hit_loc, hit_seed, score, min_score_by_len, fixed_read_len=0, read_len=None):
+    """AllScoreStream::output: (flags uint8, io::Alignment words int64, read ids int32) per job."""
+    m = score.numel()
+    dev = score.device
+    flags = torch.empty(m, dtype=torch.uint8, device=dev); aln = torch.empty(m, dtype=torch.int64, device=dev); rid = torch.empty(m, dtype=torch.int32, device=dev)
+    check(lib().nvbio_hip_score_all_output(m, _vp(idx), _vp(hit_read_id), _vp(hit_loc), _vp(hit_seed), _vp(score), _vp(min_score_by_len), _vp(read_len),
+                                           int(fixed_read_len), _vp(flags), _vp(aln), _vp(rid), current_stream_ptr()), "nvbio_hip_score_all_output")
+    return flags, aln, rid
+
+
+def traceback_all_setup(alignments, read_id, band_len, genome_len, fixed_read_len=0, read_begin=None, read_len=None, rc_offset=0):
+    """AllTracebackStream::init_context -> (pattern_begin, pattern_len | None, text_begin, text_len)."""
+    m = alignments.numel()
+    pb, pl, tb, tl = _window_outputs(m, alignments.device, read_len is not None)
+    check(lib().nvbio_hip_traceback_all_setup(m, _vp(alignments), _vp(read_id), _vp(read_begin), _vp(read_len), int(fixed_read_len), int(rc_offset), int(band_len),
+                                              int(genome_len), _vp(pb), _vp(pl), _vp(tb), _vp(tl), current_stream_ptr()), "nvbio_hip_traceback_all_setup")
+    return pb, pl, tb, tl

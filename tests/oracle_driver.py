@@ -217,3 +217,86 @@ def best_approx_paired(host_fmi, host_rfmi, sym1, sym2, genome_words, genome_len
     conc = (((w_o >> np.uint64(30)) & np.uint64(1)) != 0) & (((w_o >> np.uint64(31)) & np.uint64(1)) == 0)
     out["tb2"] = trace(best_o, np.nonzero(aligned(best_o))[0], lambda i: bool(conc[i]))
     return out
+
+
+def all_mapping(host_fmi, host_rfmi, sym, genome_words, genome_len, params, scheme, aln_type, qual_value=30, cigar_stride=64, mds_stride=256,
+                sequence_index=None, read_quals=None):
+    """Aligner::all / score_all (aligner_all.h:47-694), numpy over the oracle: one mapping pass with every seed, then all rows of all SA
+    ranges in batches of params.batch_size hits -- hi-bits sort, locate, (read, strand, position) sort, de-duplication within the batch,
+    straddling marks (with the reference's indexing), banded extension, acceptance at min_score(read_len), traceback, finish.  Returns
+    the accepted alignments in batch order, sorted by (read, strand, position) inside each batch."""
+    band = band_length(params.max_dist)
+    reads_rev, ext_words, index = pack_reads(sym)
+    n, total = index.size - 1, int(index[-1])
+    read_len = np.diff(index).astype(np.uint32)
+    L = int(read_len.max())
+    quals = np.full(2 * total + 8, qual_value, np.uint8)
+    if read_quals is not None:
+        qs = [np.asarray(q, np.uint8) for q in read_quals]
+        quals = np.concatenate(qs + [q[::-1] for q in qs] + [np.zeros(8, np.uint8)])
+    sch6, lut = qual_scheme(scheme)
+    mp = params.mapping_params()
+    sf = mp.seed_freq_table(L, "cpu").numpy().view(np.uint32)
+    stride = params.hits_stride or min(params.max_hits, 128)
+    algorithm = 0 if not params.allow_sub else (2 if params.subseed_len == 0 else 1)
+    pd = dict(seed_len=mp.seed_len, min_read_len=mp.min_read_len, max_hits=mp.max_hits, max_reseed=mp.max_reseed, retry=0,
+              rep_seeds=mp.rep_seeds, fw=int(params.fw), rc=int(params.rc))
+    hits, counts, _ = O.map_seeds(algorithm, params.subseed_len, host_fmi, host_rfmi, reads_rev, pd, sf, stride)
+    seq_index = np.asarray(sequence_index if sequence_index is not None else [0, genome_len], np.int64)
+    min_score = np.array([scheme.min_score(int(l)) if l else 0 for l in range(L + 1)], np.int64)
+    # every (read, range k, row) in order: the numbering select_all decodes
+    h_read, h_sa, h_seed = [], [], []
+    for r in range(n):
+        for k in range(int(counts[r])):
+            w = int(hits[r, k]); lo, hi = w & 0xFFFFFFFF, w >> 32
+            delta, pos, rcb, idir = hi & 0xFFFFF, (hi >> 20) & 0x3FF, (hi >> 30) & 1, (hi >> 31) & 1
+            h_read.append(np.full(delta, r, np.uint32)); h_sa.append((lo + np.arange(delta, dtype=np.int64)).astype(np.uint32))
+            h_seed.append(np.full(delta, pos | (idir << 12) | (rcb << 13), np.uint32))
+    cat = lambda xs, t: np.concatenate(xs) if xs else np.zeros(0, t)
+    h_read, h_sa, h_seed = cat(h_read, np.uint32), cat(h_sa, np.uint32), cat(h_seed, np.uint32)
+    n_hits = h_read.size
+    out_aln, out_read, stats = [], [], dict(hits=int(n_hits), ranges=int(counts.sum()), unique=0)
+    B = params.batch_size
+    for off in range(0, n_hits, B):
+        rid, sa, seed = h_read[off:off + B], h_sa[off:off + B], h_seed[off:off + B]
+        cnt = rid.size
+        idx_queue = np.argsort(sa >> 16, kind="stable")                               # sort_hi_bits (uint16 keys, stable radix sort)
+        loc = O.locate_hits(host_fmi, host_rfmi, sa.copy(), seed)
+        key = loc.astype(np.uint64) + (rid.astype(np.uint64) << np.uint64(33)) + (((seed >> 13) & 1).astype(np.uint64) << np.uint64(32))
+        sidx = np.argsort(key, kind="stable")
+        skey = key[sidx]
+        flags = np.ones(cnt, bool); flags[1:] = skey[1:] != skey[:-1]
+        g = loc[idx_queue].astype(np.int64)                                            # mark_straddling: hit idx_queue[t], flag t
+        s0 = np.searchsorted(seq_index, g, side="right") - 1
+        s1 = np.searchsorted(seq_index, (g + params.seed_len) & 0xFFFFFFFF, side="right") - 1
+        flags[s0 != s1] = False
+        q = sidx[flags]
+        stats["unique"] += int(q.size)
+        if q.size == 0:
+            continue
+        pos = loc[q].astype(np.int64); rl = read_len[rid[q]].astype(np.int64); rcq = ((seed[q] >> 13) & 1).astype(np.int64)
+        tbeg = np.where(pos > band // 2, pos - band // 2, 0)
+        tend = np.minimum((tbeg + band + rl) & 0xFFFFFFFF, genome_len)
+        tl = np.maximum(tend - tbeg, 0)
+        pat = O.StringSet(ext_words, 4, True, (index[rid[q]] + rcq * total).astype(np.uint64), read_len[rid[q]])
+        txt = O.StringSet(genome_words, 2, True, tbeg.astype(np.uint64), tl.astype(np.uint32))
+        score, _ = O.batch_banded_gotoh_score_qual(band, aln_type, sch6, lut, quals, pat, txt)
+        ok = score.astype(np.int64) >= min_score[rl]
+        s = score[ok].astype(np.int64)
+        w = (s < 0).astype(np.uint64) | ((np.abs(s).astype(np.uint64) & np.uint64(0x1FFFF)) << np.uint64(1)) | (rcq[ok].astype(np.uint64) << np.uint64(28))
+        out_aln.append((pos[ok].astype(np.uint64) << np.uint64(32)) | w); out_read.append(rid[q][ok])
+    aln, arid = cat(out_aln, np.uint64), cat(out_read, np.uint32)
+    out = dict(alignments_scored=aln.copy(), read_id=arid, stats=stats)
+    m = aln.size
+    if m:
+        pos = (aln >> np.uint64(32)).astype(np.int64); rcq = ((aln >> np.uint64(28)) & np.uint64(1)).astype(np.int64); rl = read_len[arid].astype(np.int64)
+        tbeg = np.where(pos > band // 2, pos - band // 2, 0)
+        tend = np.minimum((tbeg + band + rl) & 0xFFFFFFFF, genome_len)
+        pat = O.StringSet(ext_words, 4, True, (index[arid] + rcq * total).astype(np.uint64), read_len[arid])
+        txt = O.StringSet(genome_words, 2, True, tbeg.astype(np.uint64), np.maximum(tend - tbeg, 0).astype(np.uint32))
+        r = O.batch_banded_gotoh_traceback(band, aln_type, sch6[:5], pat, txt, cigar_stride, mm_lut=lut, quals=quals)
+        fin = aln.copy()
+        mds, mds_len = O.finish_alignment(np.ones(m, np.uint8), pat, quals, txt, r["cigar"][:m], r["cigar_len"], r["source"], scheme.m_match, lut, 1, fin,
+                                          mds_stride=mds_stride)
+        out.update(alignments=fin, tb=r, mds=mds[:m], mds_len=mds_len)
+    return out

@@ -1,0 +1,132 @@
+"""nvBowtie's all-mapping mode (Aligner::all / score_all, aligner_all.h) through the C-ABI stages vs the independent numpy driver over
+the oracle: the accepted alignments of every read (all rows of all its seed hit ranges), their tracebacks, MD strings and finished
+alignment words, in the same (batch, read, strand, position) order."""
+import numpy as np
+import pytest
+import torch
+
+import nvbio_amd as nvb
+from nvbio_amd import aligner as A, select as S, workloads as W
+from oracle import pyoracle as O
+from tests import oracle_driver as OD
+
+pytestmark = pytest.mark.gpu
+
+
+def _genome(rng, n=1 << 16):
+    text = rng.integers(0, 4, n, dtype=np.uint8)
+    text[7000:7800] = np.tile(np.array([0, 1, 2], dtype=np.uint8), 267)[:800]       # a tandem repeat: wide SA ranges
+    for k in range(4):                                                               # a 300 bp element, 5 copies with a few differences
+        c = text[20000:20300].copy()
+        c[rng.integers(0, 300, 3)] = rng.integers(0, 4, 3)
+        text[30000 + 7000 * k: 30300 + 7000 * k] = c
+    return text
+
+
+def _reads(rng, text, n, ragged):
+    reads, quals = [], []
+    for i in range(n):
+        L = int(rng.integers(30, 131)) if ragged else 100
+        where = i % 6
+        p = int(rng.integers(20000, 20300 - 30)) if where == 0 else int(rng.integers(7000, 7700)) if where == 1 else \
+            (0 if i % 31 == 2 else text.size - L if i % 31 == 3 else int(rng.integers(0, text.size - L)))
+        p = min(p, text.size - L)
+        r = text[p:p + L].copy()
+        for j in rng.integers(0, L, [0, 1, 2, 4][i % 4]):
+            r[j] = (r[j] + 1 + rng.integers(0, 3)) & 3
+        if i % 10 == 0:
+            d = int(rng.integers(8, L - 8)); r = np.concatenate([r[:d], r[d + 1:], rng.integers(0, 4, 1, dtype=np.uint8)])
+        if i % 13 == 0:
+            r[int(rng.integers(0, L))] = 4
+        if i % 2:
+            r = np.where(r > 3, r, 3 - r)[::-1].copy()
+        if i % 23 == 0:
+            r = rng.integers(0, 4, L, dtype=np.uint8)
+        reads.append(r); quals.append(rng.integers(2, 42, r.size).astype(np.uint8))
+    return reads, quals
+
+
+CONFIGS = {
+    "default": (dict(), False),
+    "small_batches": (dict(batch_size=1500), False),            # the same placement in two batches is reported twice, as in the reference
+    "tiny_batches": (dict(batch_size=97), False),
+    "local": (dict(local=True, seed_len=20, seed_freq=(2, 1.0, 0.75)), False),
+    "one_mismatch_seeds": (dict(allow_sub=1, seed_len=20, max_hits=40, batch_size=4000), False),
+    "ragged": (dict(batch_size=3000), True),
+    "few_hits": (dict(max_hits=4), False),
+    "sequences": (dict(batch_size=2500), False),                # a multi-sequence reference: seeds straddling a boundary are dropped
+}
+
+
+@pytest.mark.parametrize("config", sorted(CONFIGS))
+def test_all_mapping_matches_oracle(cuda, config):
+    rng = np.random.default_rng(4242)
+    text = _genome(rng)
+    host, rhost = O.FMIndex(text), O.FMIndex(text[::-1].copy())
+    fmi, rfmi = nvb.FMIndexDevice.from_host(host, cuda), nvb.FMIndexDevice.from_host(rhost, cuda)
+    kw, ragged = CONFIGS[config]
+    params = A.Params(**kw)
+    n = 600
+    reads, quals = _reads(rng, text, n, ragged)
+    scheme = nvb.SmithWatermanScoringScheme.local() if params.local else nvb.SmithWatermanScoringScheme()
+    gw = W._pack_chunked(torch.from_numpy(text), 2, True)
+    seq_index = [0, 9000, 20100, 41000, text.size] if config == "sequences" else None
+    e = OD.all_mapping(host, rhost, reads, gw.numpy().view(np.uint32), text.size, params, scheme, 1 if params.local else 2, read_quals=quals,
+                       cigar_stride=96, sequence_index=seq_index)
+    if ragged:
+        index = np.zeros(n + 1, np.int64); index[1:] = np.cumsum([r.size for r in reads])
+        batch = A.ReadBatch.from_ragged(torch.from_numpy(np.concatenate(reads)).to(cuda), torch.from_numpy(index).to(cuda), torch.from_numpy(np.concatenate(quals)).to(cuda))
+    else:
+        batch = A.ReadBatch.from_matrix(torch.from_numpy(np.stack(reads)).to(cuda), quals=torch.from_numpy(np.stack(quals)))
+    r = A.all_mapping(fmi, rfmi, batch, gw.to(cuda), text.size, params, scheme, cigar_stride=96, sequence_index=seq_index)
+    torch.cuda.synchronize()
+    assert r["stats"] == e["stats"], (r["stats"], e["stats"])
+    m = e["read_id"].size
+    assert m > n and r["read_id"].numel() == m
+    assert (r["read_id"].cpu().numpy().view(np.uint32) == e["read_id"]).all()
+    assert (r["alignments_scored"].cpu().numpy().view(np.uint64) == e["alignments_scored"]).all()
+    assert (r["alignments"].cpu().numpy().view(np.uint64) == e["alignments"]).all()
+    tb = e["tb"]
+    assert (r["cigar_len"].cpu().numpy().view(np.uint32) == tb["cigar_len"]).all()
+    assert (r["cigar"].cpu().numpy().view(np.uint16) == tb["cigar"][:m]).all()
+    assert (r["source"].cpu().numpy().view(np.uint32) == tb["source"]).all() and (r["sink"].cpu().numpy().view(np.uint32) == tb["sink"]).all()
+    assert (r["mds_len"].cpu().numpy().view(np.uint32) == e["mds_len"]).all()
+    mk = np.arange(256)[None, :] < np.minimum(e["mds_len"], 256)[:, None]
+    assert ((r["mds"].cpu().numpy() == e["mds"]) | ~mk).all()
+    # what the mode is for: reads from the 5-copy element report several placements; within a batch no placement twice
+    per_read = np.bincount(e["read_id"], minlength=n)
+    assert per_read.max() >= 4
+    if config == "default":
+        key = (e["read_id"].astype(np.uint64) << np.uint64(34)) | (e["alignments_scored"] >> np.uint64(32)) | (((e["alignments_scored"] >> np.uint64(28)) & np.uint64(1)) << np.uint64(33))
+        assert np.unique(key).size == m
+    if config == "sequences":
+        assert e["stats"]["unique"] < OD.all_mapping(host, rhost, reads, gw.numpy().view(np.uint32), text.size, params, scheme, 2, read_quals=quals,
+                                                     cigar_stride=96)["stats"]["unique"]
+
+
+def test_all_mapping_stage_kernels(cuda):
+    """gather_ranges / select_all decode the global hit numbering of random deques exactly like a direct enumeration."""
+    rng = np.random.default_rng(5)
+    n, stride = 300, 12
+    counts = rng.integers(0, stride + 1, n).astype(np.uint32)
+    counts[::17] = 0
+    hits = np.zeros((n, stride), np.uint64)
+    exp = []
+    for r in range(n):
+        for k in range(int(counts[r])):
+            begin, delta, pos, rc, idir = int(rng.integers(0, 1 << 30)), int(rng.integers(1, 40)), int(rng.integers(0, 1000)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
+            hits[r, k] = begin | ((delta | (pos << 20) | (rc << 30) | (idir << 31)) << 32)
+            for j in range(delta):
+                exp.append((begin + j, pos | (idir << 12) | (rc << 13), r))
+    exp = np.array(exp, np.int64)
+    d_hits = torch.from_numpy(hits.view(np.int64)).to(cuda)
+    d_counts = torch.from_numpy(counts.view(np.int32)).to(cuda)
+    scan = torch.cumsum(d_counts.to(torch.int64), 0).to(torch.int32)
+    ranges = S.gather_ranges(d_hits, d_counts, scan, int(counts.sum()))
+    rs = torch.cumsum(ranges, 0)
+    assert int(rs[-1]) == exp.shape[0]
+    for off, cnt in ((0, exp.shape[0]), (1234, 777), (exp.shape[0] - 5, 5)):
+        loc, seed, rid = S.select_all(off, cnt, d_hits, scan, rs)
+        torch.cuda.synchronize()
+        assert (loc.cpu().numpy().view(np.uint32) == exp[off:off + cnt, 0]).all()
+        assert (seed.cpu().numpy() == exp[off:off + cnt, 1]).all() and (rid.cpu().numpy() == exp[off:off + cnt, 2]).all()
