@@ -748,6 +748,32 @@ def extras_leg(a, dev):
     ba["parity"] = {"checked_reads": m, "best_mapq_cigar_stats_equal": ok}
     ba["stages"] = "per seeding pass: map -> select_init -> rounds of {select, locate, banded extend (quality-aware scheme), score_reduce + give-up counters}; mark_unaligned / re-seed queue; BowtieMapq2; banded traceback"
     out["best_approx_single_end"] = ba
+    # ---- the same reads through nvBowtie's all-mapping driver (Aligner::all): every row of every seed hit range located,
+    # de-duplicated per batch of BATCH_SIZE hits, extended, accepted at min_score(read_len), traced back, finished
+    am = {}
+    prm = AL.Params(hits_stride=16, batch_size=1 << 22)
+    run = lambda st=False: AL.all_mapping(fmi, rfmi, sym, genome_words, ng, prm, packed=(reads_rev, ext_words), stage_times=st)
+    ms = _timed(run, reps=2)
+    r = run(True)
+    n_aln = int(r["read_id"].numel())
+    first = torch.zeros(nreads, dtype=torch.bool, device=dev); first[r["read_id"].long()] = True
+    at = torch.zeros(nreads, dtype=torch.bool, device=dev)
+    at[r["read_id"].long()[((((r["alignments_scored"] >> 32) & 0xFFFFFFFF) - pos[r["read_id"].long()]).abs() <= 2)]] = True
+    am["default"] = {"reads": nreads, "ms_per_batch": ms, "Mreads_per_s": nreads / ms / 1e3, "seed_hit_rows": r["stats"]["hits"], "unique_placements": r["stats"]["unique"],
+                     "alignments": n_aln, "Malignments_per_s": n_aln / ms / 1e3, "reads_with_alignment": float(first.float().mean().item()),
+                     "true_position_reported": float(at.float().mean().item()), "stage_ms": {k: round(v, 3) for k, v in r["stats"]["ms"].items()}}
+    m = 1500
+    prm = AL.Params(hits_stride=16, batch_size=4096)
+    rs = AL.all_mapping(fmi, rfmi, sym[:m].contiguous(), genome_words, ng, prm, cigar_stride=64)
+    es = OD.all_mapping(hostf, hostr, sym[:m].cpu().numpy(), genome_words.cpu().numpy().view(np.uint32), ng, prm, nvb.SmithWatermanScoringScheme(), 2)
+    k = es["read_id"].size
+    ok = bool(rs["stats"] == es["stats"] and rs["read_id"].numel() == k and (rs["read_id"].cpu().numpy().view(np.uint32) == es["read_id"]).all()
+              and (rs["alignments"].cpu().numpy().view(np.uint64) == es["alignments"]).all()
+              and (rs["cigar"].cpu().numpy().view(np.uint16) == es["tb"]["cigar"][:k]).all()
+              and (rs["mds_len"].cpu().numpy().view(np.uint32) == es["mds_len"]).all())
+    am["parity"] = {"checked_reads": m, "alignments": int(k), "alignments_cigars_md_stats_equal": ok}
+    am["stages"] = "map (all seeds, one pass) -> scans -> batches of {select_all, hi-bits sort, locate, (read, strand, position) sort, dedup + straddling marks, banded extend, accept at min_score}; banded traceback + finish_alignment of every accepted alignment"
+    out["all_mapping_single_end"] = am
     # ---- BASELINE config 5 under nvBowtie's own paired-end driver: 2 x 150 bp FR pairs, --local (20-bp seeds, LOCAL band 31 in the
     # quality-aware local scheme), opposite mates by full-matrix DP in their fragment windows, paired reduction, discordant marking,
     # MAPQ per mate, anchor (banded) and opposite (full-matrix) tracebacks

@@ -545,6 +545,20 @@ __global__ void __launch_bounds__(256) finish_alignment_kernel(const FinishParam
     int32_t  score = 0;
     uint32_t j = 0u, k = p.cigar_source[w].x & 0xFFFFu;
     auto push = [&](const uint32_t v) { if (mds_len < p.mds_stride) mds[mds_len] = uint8_t(v); ++mds_len; };
+    // the walk moves one symbol at a time: keep the packed word under each cursor in a register (one load per 8 / 16 symbols)
+    uint64_t pw_at = ~0ull, tw_at = ~0ull; uint32_t pw = 0u, tw = 0u;
+    const uint32_t pshift = p.pat.s.bits == 2 ? 4u : 3u;
+    auto pat_sym = [&](const uint64_t sym) -> uint32_t {
+        const uint64_t wi = sym >> pshift;
+        if (wi != pw_at) { pw = ld_word_global(p.pat.s, wi); pw_at = wi; }
+        if (p.pat.s.bits == 2) { const uint32_t c = uint32_t(sym) & 15u; return (pw >> (p.pat.s.big_endian ? 30u - 2u * c : 2u * c)) & 3u; }
+        const uint32_t c = uint32_t(sym) & 7u; return (pw >> (p.pat.s.big_endian ? 28u - 4u * c : 4u * c)) & 15u;
+    };
+    auto txt_sym = [&](const uint64_t sym) -> uint32_t {
+        const uint64_t wi = sym >> 4;
+        if (wi != tw_at) { tw = ld_word_global(p.txt.s, wi); tw_at = wi; }
+        const uint32_t c = uint32_t(sym) & 15u; return (tw >> (p.txt.s.big_endian ? 30u - 2u * c : 2u * c)) & 3u;
+    };
     auto close_run = [&]() { if (run && run_at < p.mds_stride) mds[run_at] = uint8_t(run); run = 0u; };
     for (uint32_t i = 0; i < clen; ++i)
     {
@@ -554,16 +568,17 @@ __global__ void __launch_bounds__(256) finish_alignment_kernel(const FinishParam
         {
             j += (t != 2u) ? 1u : 0u;
             k += (t == 0u || t == 2u) ? 1u : 0u;
-            const uint32_t readc = j > 0u ? get_symbol(p.pat.s, pb + j - 1u) : 255u;
-            const uint32_t refc  = k > 0u ? get_symbol(p.txt.s, tb + k - 1u) : 255u;
+            const uint32_t readc = j > 0u ? pat_sym(pb + j - 1u) : 255u;
+            const uint32_t refc  = k > 0u ? txt_sym(tb + k - 1u) : 255u;
             if (t == 0u) {
                 if (readc == refc) {
                     if (mds_op == 0u && run < 255u) ++run;
                     else { close_run(); mds_op = 0u; push(0u); run_at = mds_len; push(1u); run = 1u; }
                 } else { close_run(); mds_op = 1u; push(1u); push(readc); ++ed; }
-                const uint32_t q = p.quals ? p.quals[min(pb + j - 1u, p.n_quals - 1u)] : 0u;
                 const uint32_t ref_mask = (1u << (refc & 31u)) & 0xFFu;
-                score += (readc > 3u || ref_mask > 15u) ? -p.n_penalty : ((ref_mask & (1u << readc)) ? p.match : mm[q]);
+                if (readc > 3u || ref_mask > 15u) score -= p.n_penalty;
+                else if (ref_mask & (1u << readc)) score += p.match;
+                else score += mm[p.quals ? p.quals[min(pb + j - 1u, p.n_quals - 1u)] : 0u];       // the quality matters on a mismatch only
             } else {
                 push(t == 2u ? refc : readc);
                 if (t != 3u) ++ed;

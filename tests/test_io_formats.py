@@ -163,6 +163,40 @@ def test_files_to_sam_example(tmp_path, cuda):
 
 
 @pytest.mark.gpu
+def test_files_to_sam_all_mapping_example(tmp_path, cuda):
+    """tools/align_fastq.py --all: a genome with a 3-copy element; reads from the element come back once per copy (MAPQ 255), unique reads once"""
+    import io as _io, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import align_fastq
+    rng = np.random.default_rng(31)
+    text = rng.integers(0, 4, 120_000, dtype=np.uint8)
+    copies = [10_000, 50_000, 90_000]
+    for c in copies[1:]:
+        text[c:c + 500] = text[10_000:10_500]
+    prefix = str(tmp_path / "g")
+    nio.save_fmindex(prefix, O.FMIndex(text))
+    nio.write_wpac(prefix + ".wpac", text.size, O.pack(text, 2, True))
+    n = 60
+    pos = [int(rng.integers(10_000, 10_400)) if i % 2 == 0 else int(rng.integers(20_000, 40_000)) for i in range(n)]
+    with open(prefix + ".fastq", "w") as f:
+        for i, p in enumerate(pos):
+            r = text[p:p + 100].copy()
+            if i % 4 >= 2:
+                r = (3 - r)[::-1]
+            f.write("@read%d\n%s\n+\n%s\n" % (i, "".join("ACGT"[c] for c in r), "I" * 100))
+    buf = _io.StringIO()
+    align_fastq.main_all(prefix, prefix + ".fastq", buf, device=cuda)
+    lines = [ln.split("\t") for ln in buf.getvalue().splitlines() if not ln.startswith("@")]
+    by_read = {}
+    for ln in lines:
+        assert ln[4] == "255" and ln[5] == "100M" and ln[1] == ("16" if int(ln[0][4:]) % 4 >= 2 else "0")
+        by_read.setdefault(int(ln[0][4:]), []).append(int(ln[3]) - 1)
+    for i, p in enumerate(pos):
+        expect = sorted(c + p - 10_000 for c in copies) if i % 2 == 0 else [p]
+        assert sorted(by_read[i]) == expect, (i, by_read[i], expect)
+
+
+@pytest.mark.gpu
 def test_paired_files_to_sam_example(tmp_path, cuda):
     """index files + two FASTQ files of FR mates -> SAM through the paired-end driver: both records of a pair carry the paired flags, point at each
     other (PNEXT / TLEN) and sit at the fragment's two ends; a pair whose second mate is junk keeps mate 1 as an unpaired alignment"""

@@ -6,6 +6,7 @@ Reads may differ in length.  A usage example, not nvBowtie's CLI: the mandatory 
 alignments; nvbio/io/output/output_sam.cpp:316-366), single reference sequence, no read groups.
 
     python tools/align_fastq.py <index prefix> <reads.fastq> [out.sam | out.bam]
+    python tools/align_fastq.py --all <index prefix> <reads.fastq> [out.sam | out.bam]     (every alignment of every read, Aligner::all)
     python tools/align_fastq.py <index prefix> <mates1.fastq> <mates2.fastq> <out.sam | out.bam>"""
 import sys
 
@@ -51,6 +52,38 @@ def main(prefix, fastq, out=sys.stdout, device="cuda", ref_name="ref"):
         md, mm, gapo, gape = nio.sam_md_string(mds[i])
         out.write("%s\t%d\t%s\t%d\t%d\t%s\t*\t0\t0\t%s\t%s\tNM:i:%d\tAS:i:%d\tXM:i:%d\tXO:i:%d\tXG:i:%d\tMD:Z:%s\n" % (
             reads.names[i], 16 if rc else 0, ref_name, pos + int(source[i, 0]) + 1, int(mapq[i]), cigar_string(cig[i], int(clen[i])),
+            "".join("ACGTN"[c] for c in s), "".join(chr(int(x) + 33) for x in q), ed, score, mm, gapo, gape, md or "*"))
+
+
+def main_all(prefix, fastq, out=sys.stdout, device="cuda", ref_name="ref", **param_overrides):
+    """All-mapping flow (nvBowtie --all = Aligner::all): one SAM record per accepted alignment of every read (MAPQ 255, as the reference fills
+    it, aligner_all.h:82), no record for reads without one.  Needs the reverse index too when one-mismatch seeds are asked for."""
+    data = nio.FMIndexDataDevice(prefix, flags=nio.FORWARD | nio.SA, device=device)
+    n_genome, g_words = nio.load_genome(prefix)
+    genome_words = torch.from_numpy(np.concatenate([g_words, np.zeros(8, np.uint32)]).view(np.int32)).to(device)
+    reads = nio.read_fastq(fastq)
+    if reads.size() == 0:
+        raise SystemExit("align_fastq: no reads")
+    index = np.asarray(reads.sequence_index, dtype=np.int64)
+    batch = A.ReadBatch.from_ragged(torch.from_numpy(reads.symbols).to(device), torch.from_numpy(index).to(device), torch.from_numpy(reads.quals).to(device))
+    r = A.all_mapping(data.index(), None, batch, genome_words, n_genome, A.Params(hits_stride=32, **param_overrides), cigar_stride=64)
+    torch.cuda.synchronize()
+    out.write("@HD\tVN:1.0\tSO:unsorted\n@SQ\tSN:%s\tLN:%d\n@PG\tID:nvbio_amd\tPN:nvbio_amd\n" % (ref_name, n_genome))
+    m = int(r["read_id"].numel())
+    if m == 0:
+        return
+    rid, aln = r["read_id"].cpu().numpy(), r["alignments"].cpu().numpy().view(np.uint64)
+    cig, clen, source, mds = r["cigar"].cpu().numpy().view(np.uint16), r["cigar_len"].cpu().numpy(), r["source"].cpu().numpy(), r["mds"].cpu().numpy()
+    for k in range(m):
+        i = int(rid[k])
+        w, pos = int(aln[k] & 0xFFFFFFFF), int(aln[k] >> 32)
+        seq, qual = reads.symbols[index[i]:index[i + 1]], reads.quals[index[i]:index[i + 1]]
+        rc = (w >> 28) & 1
+        score, ed = ((w >> 1) & 0x1FFFF) * (-1 if w & 1 else 1), (w >> 18) & 0x3FF
+        s, q = (np.where(seq < 4, 3 - seq, 4)[::-1], qual[::-1]) if rc else (seq, qual)
+        md, mm, gapo, gape = nio.sam_md_string(mds[k])
+        out.write("%s\t%d\t%s\t%d\t255\t%s\t*\t0\t0\t%s\t%s\tNM:i:%d\tAS:i:%d\tXM:i:%d\tXO:i:%d\tXG:i:%d\tMD:Z:%s\n" % (
+            reads.names[i], 16 if rc else 0, ref_name, pos + int(source[k, 0]) + 1, cigar_string(cig[k], int(clen[k])),
             "".join("ACGTN"[c] for c in s), "".join(chr(int(x) + 33) for x in q), ed, score, mm, gapo, gape, md or "*"))
 
 
@@ -125,7 +158,14 @@ if __name__ == "__main__":
     if len(sys.argv) < 3:
         raise SystemExit(__doc__)
     import io as _io
+    all_mode = "--all" in sys.argv
+    if all_mode:
+        sys.argv.remove("--all")
     paired = len(sys.argv) > 4                  # <prefix> <mates 1> <mates 2> <out.sam|out.bam>
+    if all_mode and paired:
+        raise SystemExit("align_fastq: --all is single-end (as in nvBowtie)")
+    if all_mode:
+        main, main_best = main_all, main
     if len(sys.argv) > 3:
         path = sys.argv[4] if paired else sys.argv[3]
         buf = _io.StringIO()
