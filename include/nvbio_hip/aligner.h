@@ -447,7 +447,6 @@ private:
                            hip::device_vector<uint64>& pat_begin, hip::device_vector<uint64>& txt_begin, hip::device_vector<uint32>& txt_len,
                            hip::device_vector<uint32>& sinks, hip::device_vector<int32>& min_score, hip::device_vector<int32>& hit_score,
                            Stats& stats, void* hip_stream)
-    
     {
         const uint32 L = reads.len;
         hip::device_vector<int32> known_score(pat_begin.size());
