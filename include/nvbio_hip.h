@@ -525,6 +525,7 @@ uint64_t nvbio_hip_copy_flagged_temp_bytes(uint32_t n);
 int nvbio_hip_copy_flagged(uint32_t n, const uint32_t* in, const uint8_t* flags, uint32_t* out, uint32_t* out_count /* device */,
                            void* temp, uint64_t temp_bytes, void* stream);
 int nvbio_hip_scatter_rows(uint32_t n, const uint32_t* idx, const void* src, void* dst, uint32_t row_bytes /* multiple of 4 */, void* stream);   /* dst row idx[i] = src row i */
+int nvbio_hip_gather_rows(uint32_t n, const uint32_t* idx, const void* src, void* dst, uint32_t row_bytes /* multiple of 4 */, void* stream);    /* dst row i = src row idx[i] */
 int nvbio_hip_traceback_best_setup(uint32_t n, const uint32_t* idx /* nullable */, const uint64_t* best_alignments, uint32_t band_len, uint32_t genome_length,
                                    const uint64_t* read_begin /* nullable */, const uint32_t* read_len /* nullable */, uint32_t fixed_read_len,
                                    uint64_t rc_offset, uint64_t mate_offset, int32_t want,
@@ -580,6 +581,18 @@ int nvbio_hip_traceback_all_setup(uint32_t n, const uint64_t* alignments, const 
                                   const uint64_t* read_begin /* nullable */, const uint32_t* read_len /* nullable */, uint32_t fixed_read_len, uint64_t rc_offset,
                                   uint32_t band_len, uint32_t genome_length,
                                   uint64_t* pattern_begin, uint32_t* pattern_len /* nullable iff fixed */, uint64_t* text_begin, uint32_t* text_len, void* stream);
+
+/* The library primitives score_all calls between those kernels (thrust::inclusive_scan, Aligner::sort_hi_bits / sort_64_bits of
+ * aligner_sort.cu:39-92, the dedup transform of aligner_all.h:498-509), on hipCUB; temp: nvbio_hip_all_mapping_temp_bytes(n) bytes.
+ *   sort_hi_bits: out_idx = the permutation that stably sorts keys[i] >> 16.
+ *   sort_hits: out_idx = the permutation that stably sorts SortingKeys = loc + (read_id << 33) + (rc << 32);
+ *     out_first[i] = 1 when sorted position i holds the first of a run of equal keys (the dedup flags before mark_straddling). */
+uint64_t nvbio_hip_all_mapping_temp_bytes(uint32_t n);
+int nvbio_hip_inclusive_scan_u32(uint32_t n, const uint32_t* in, uint32_t* out, void* temp, uint64_t temp_bytes, void* stream);
+int nvbio_hip_inclusive_scan_u64(uint32_t n, const uint64_t* in, uint64_t* out, void* temp, uint64_t temp_bytes, void* stream);
+int nvbio_hip_sort_hi_bits(uint32_t n, const uint32_t* keys, uint32_t* out_idx, void* temp, uint64_t temp_bytes, void* stream);
+int nvbio_hip_sort_hits(uint32_t n, const uint32_t* hit_read_id, const uint32_t* hit_loc, const uint32_t* hit_seed, uint32_t* out_idx, uint8_t* out_first,
+                        void* temp, uint64_t temp_bytes, void* stream);
 
 /* BowtieMapq2 / BowtieMapq3 (nvBowtie/bowtie2/cuda/mapq.h:42-330) for single-end reads:
  * out_mapq[r] from the best / second-best alignment of read r; perfect_score(len) = len * match,

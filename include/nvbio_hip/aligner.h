@@ -28,7 +28,8 @@ struct Params : public ParamsPOD
     bool   finish_alignments;      ///< run finish_alignment_best (MD strings, edit distances, final scores) as the reference always does
 };
 
-struct Stats { uint64 extensions, dp_jobs; uint32 rounds, seeding_passes; std::vector<uint32> queue; Stats() : extensions(0), dp_jobs(0), rounds(0), seeding_passes(0) {} };
+struct Stats { uint64 extensions, dp_jobs, hits, ranges, unique; uint32 rounds, seeding_passes; std::vector<uint32> queue;
+               Stats() : extensions(0), dp_jobs(0), hits(0), ranges(0), unique(0), rounds(0), seeding_passes(0) {} };
 
 /// A batch of equal-length reads on the device in the layouts the stages read (io::SequenceDataDevice's role): the reads
 /// stored reversed (io::REVERSE, what the mappers scan), their forward copies followed rc_offset symbols later by their
@@ -82,7 +83,14 @@ struct Aligner
     hip::device_vector<int32>         traceback_score_o;
     hip::device_vector<uint8>         mds_o;
 
-    Aligner() : BATCH_SIZE(0), SCORING_BATCH(0), cigar_stride(64), mds_stride(256) {}
+    // all-mapping (Aligner::all): the reported alignments, in batch order, sorted by (read, strand, position) inside a batch;
+    // their CIGARs / MD strings land in cigar, cigar_len, cigar_source, cigar_sink, traceback_score, mds, mds_len (resized to fit)
+    uint64                            n_alignments;
+    hip::device_vector<uint32>        output_read_info_dvec;     // read id of every alignment
+    hip::device_vector<io::Alignment> output_alignments_dvec;    // finished alignments (window begin, edit distance, final score)
+    hip::device_vector<io::Alignment> scored_alignments_dvec;    // as accepted (read start, extension score)
+
+    Aligner() : BATCH_SIZE(0), SCORING_BATCH(0), cigar_stride(64), mds_stride(256), n_alignments(0) {}
 
     /// Aligner::band_length (aligner.h:165-174)
     static uint32 band_length(const uint32 max_dist)
@@ -129,7 +137,162 @@ struct Aligner
         else                                         best_approx_t<aln::SEMI_GLOBAL>(params, fmi, rfmi, scoring_scheme, limits, genome_words, genome_n_words, genome_len, reads, stats, hip_stream);
     }
 
+    /// Aligner::all + score_all (aligner_all.h:47-227, :264-694): every placement of every read that reaches min_score(read_len).
+    /// sequence_index: the offsets of the reference's sequences (n_sequences + 1 entries; {0, genome_len} for one sequence).
+    void all(const Params& params, const fm_index_device& fmi, const fm_index_device& rfmi, const aln::SmithWatermanScoringScheme& scoring_scheme,
+             const ScoreLimits& limits, const uint32* genome_words, const uint64 genome_n_words, const uint32 genome_len,
+             const std::vector<uint32>& sequence_index, const ReadBatch& reads, Stats& stats, void* hip_stream = nullptr)
+    {
+        if (params.alignment_type == LocalAlignment) all_t<aln::LOCAL>(params, fmi, rfmi, scoring_scheme, limits, genome_words, genome_n_words, genome_len, sequence_index, reads, stats, hip_stream);
+        else                                         all_t<aln::SEMI_GLOBAL>(params, fmi, rfmi, scoring_scheme, limits, genome_words, genome_n_words, genome_len, sequence_index, reads, stats, hip_stream);
+    }
+
 private:
+    template <aln::AlignmentType TYPE>
+    void all_t(const Params& params, const fm_index_device& fmi, const fm_index_device& rfmi, const aln::SmithWatermanScoringScheme& scoring_scheme,
+               const ScoreLimits& limits, const uint32* genome_words, const uint64 genome_n_words, const uint32 genome_len,
+               const std::vector<uint32>& sequence_index, const ReadBatch& reads, Stats& stats, void* hip_stream)
+    {
+        const uint32 count = reads.n, L = reads.len, B = SCORING_BATCH;
+        const uint32 band_len = band_length(params.max_dist);
+        const uint32 hits_stride = params.hits_stride ? params.hits_stride : std::min(params.max_hits, 128u);
+        const aln::GotohAligner<TYPE, aln::SmithWatermanScoringScheme> aligner(scoring_scheme);
+        n_alignments = 0;
+        if (count == 0) return;
+
+        // map_kernel searches seeds 0 .. max_seeds-1 (aligner_all.h:93-95, mapping_inl.h:659); map(retry 0) searches every seed that
+        // fits: the same set unless the cap binds, which is refused rather than mapped differently
+        {
+            const int32 f = params.seed_freq(int32(L));
+            const uint32 max_seeds = f > 0 ? L / uint32(f) : 0u;
+            if (L >= params.min_read_len && f > 0 && (L - std::min(params.seed_len, L)) / uint32(f) + 1u > max_seeds)
+                throw std::runtime_error("Aligner::all: the reference's seed cap would drop seeds at this seeding interval (unsupported)");
+        }
+        hip::device_vector<int32>   min_score_table(limits.min_score_table(L));
+        std::vector<uint32> iota(std::max(count, B)); std::iota(iota.begin(), iota.end(), 0u);
+        hip::device_vector<uint32>  d_iota(iota);
+        hip::device_vector<SeedHit> hit_data(size_t(count) * hits_stride);
+        hip::device_vector<uint32>  hit_counts(count), hit_count_scan(count);
+        hip::device_vector<uint8>   reseed(count);
+        hip::device_vector<uint32>  seed_freq(params.seed_freq_table(L));
+        SeedHitDequeArrayDeviceView hits = { hit_data.data(), hits_stride, hit_counts.data() };
+        hip_check(nvbio_hip_memset(hit_counts.data(), 0, uint64(count) * 4u, hip_stream), "nvbio_hip_memset");
+        const PingPongQueuesView seed_queues = { count, d_iota.data() };
+        map(reads.reversed, fmi, rfmi, 0u, seed_queues, reseed.data(), hits, params, seed_freq.data(), params.fw, params.rc, hip_stream);
+
+        // scan the deque sizes, gather and scan the range sizes
+        uint32 n_ranges = 0;
+        {
+            hip::device_vector<uint8> temp(nvbio_hip_all_mapping_temp_bytes(count));
+            hip_check(nvbio_hip_inclusive_scan_u32(count, hit_counts.data(), hit_count_scan.data(), temp.data(), temp.size(), hip_stream), "nvbio_hip_inclusive_scan_u32");
+            hip::synchronize(hip_stream);
+            hip_check(nvbio_hip_memcpy(&n_ranges, hit_count_scan.data() + (count - 1u), 4u, 2, nullptr), "nvbio_hip_memcpy(d2h)");
+        }
+        stats.ranges = n_ranges;
+        if (n_ranges == 0) return;
+        hip::device_vector<uint64> hit_range_scan(n_ranges);
+        uint64 n_hits = 0;
+        {
+            hip::device_vector<uint64> ranges(n_ranges);
+            hip::device_vector<uint8>  temp(nvbio_hip_all_mapping_temp_bytes(n_ranges));
+            hip_check(nvbio_hip_gather_ranges(n_ranges, count, reinterpret_cast<const uint64*>(hit_data.data()), hits_stride, hit_count_scan.data(), ranges.data(), hip_stream), "nvbio_hip_gather_ranges");
+            hip_check(nvbio_hip_inclusive_scan_u64(n_ranges, ranges.data(), hit_range_scan.data(), temp.data(), temp.size(), hip_stream), "nvbio_hip_inclusive_scan_u64");
+            hip::synchronize(hip_stream);
+            hip_check(nvbio_hip_memcpy(&n_hits, hit_range_scan.data() + (n_ranges - 1u), 8u, 2, nullptr), "nvbio_hip_memcpy(d2h)");
+        }
+        stats.hits = n_hits;
+
+        // the hit queues of a batch and the alignment buffer (every row can yield at most one alignment per batch)
+        const uint32 cap = uint32(std::min<uint64>(n_hits, B));
+        hip::device_vector<uint32> hit_loc(cap), hit_seed(cap), hit_read(cap), idx_queue(cap), sort_idx(cap), queue(cap), accepted(cap), counter(1);
+        hip::device_vector<uint8>  flags(cap), sort_temp(nvbio_hip_all_mapping_temp_bytes(cap)), flag_temp(nvbio_hip_copy_flagged_temp_bytes(cap));
+        hip::device_vector<uint64> pat_begin(cap), txt_begin(cap);
+        hip::device_vector<uint32> txt_len(cap), sinks(size_t(cap) * 2u), job_read(cap);
+        hip::device_vector<int32>  hit_score(cap);
+        hip::device_vector<io::Alignment> job_aln(cap);
+        hip::device_vector<uint32> d_seq_index(sequence_index);
+        scored_alignments_dvec.resize(n_hits); output_read_info_dvec.resize(n_hits);
+
+        for (uint64 hit_offset = 0; hit_offset < n_hits; hit_offset += B)
+        {
+            const uint32 hit_count = uint32(std::min<uint64>(n_hits - hit_offset, B));
+            hip_check(nvbio_hip_select_all(hit_offset, hit_count, count, n_ranges, reinterpret_cast<const uint64*>(hit_data.data()), hits_stride, hit_count_scan.data(),
+                                           hit_range_scan.data(), hit_loc.data(), hit_seed.data(), hit_read.data(), hip_stream), "nvbio_hip_select_all");
+            // sort_hi_bits, locate, sort by (read, strand, position), dedup, straddling marks, compaction
+            hip_check(nvbio_hip_sort_hi_bits(hit_count, hit_loc.data(), idx_queue.data(), sort_temp.data(), sort_temp.size(), hip_stream), "nvbio_hip_sort_hi_bits");
+            hip_check(nvbio_hip_locate_hits(&fmi.m, &rfmi.m, hit_count, hit_loc.data(), hit_seed.data(), hip_stream), "nvbio_hip_locate_hits");
+            hip_check(nvbio_hip_sort_hits(hit_count, hit_read.data(), hit_loc.data(), hit_seed.data(), sort_idx.data(), flags.data(), sort_temp.data(), sort_temp.size(), hip_stream),
+                      "nvbio_hip_sort_hits");
+            hip_check(nvbio_hip_mark_straddling(hit_count, idx_queue.data(), uint32(sequence_index.size() - 1u), d_seq_index.data(), hit_loc.data(), params.seed_len, flags.data(), hip_stream),
+                      "nvbio_hip_mark_straddling");
+            hip_check(nvbio_hip_copy_flagged(hit_count, sort_idx.data(), flags.data(), queue.data(), counter.data(), flag_temp.data(), flag_temp.size(), hip_stream), "nvbio_hip_copy_flagged");
+            hip::synchronize(hip_stream);
+            const uint32 queue_size = counter.to_host()[0];
+            stats.unique += queue_size;
+            if (queue_size == 0) continue;
+
+            // score_all: windows, the banded scorer, acceptance at min_score(read_len)
+            hip_check(nvbio_hip_score_all_setup(queue_size, queue.data(), hit_read.data(), hit_loc.data(), hit_seed.data(), nullptr, nullptr, L, reads.rc_offset, band_len, genome_len,
+                                                pat_begin.data(), nullptr, txt_begin.data(), txt_len.data(), hip_stream), "nvbio_hip_score_all_setup");
+            {
+                const PackedStringSetView<4, true> patterns(queue_size, reads.fw_rc_words, reads.fw_rc_n_words, pat_begin.data(), nullptr, L);
+                const PackedStringSetView<2, true> texts(queue_size, genome_words, genome_n_words, txt_begin.data(), txt_len.data(), 0u);
+                const aln::BestSinkArrays sink_arrays = { hit_score.data(), sinks.data() };
+                dispatch_band(band_len, [&](auto band) {
+                    aln::batch_banded_alignment_score<decltype(band)::value>(aligner, patterns, reads.quals, reads.n_quals, texts, sink_arrays, L, L + band_len, hip_stream);
+                });
+            }
+            hip_check(nvbio_hip_score_all_output(queue_size, queue.data(), hit_read.data(), hit_loc.data(), hit_seed.data(), hit_score.data(), min_score_table.data(), nullptr, L,
+                                                 flags.data(), reinterpret_cast<uint64*>(job_aln.data()), job_read.data(), hip_stream), "nvbio_hip_score_all_output");
+            hip_check(nvbio_hip_copy_flagged(queue_size, d_iota.data(), flags.data(), accepted.data(), counter.data(), flag_temp.data(), flag_temp.size(), hip_stream), "nvbio_hip_copy_flagged");
+            hip::synchronize(hip_stream);
+            const uint32 n_accepted = counter.to_host()[0];
+            hip_check(nvbio_hip_gather_rows(n_accepted, accepted.data(), job_aln.data(), scored_alignments_dvec.data() + n_alignments, 8u, hip_stream), "nvbio_hip_gather_rows");
+            hip_check(nvbio_hip_gather_rows(n_accepted, accepted.data(), job_read.data(), output_read_info_dvec.data() + n_alignments, 4u, hip_stream), "nvbio_hip_gather_rows");
+            n_alignments += n_accepted;
+        }
+        hip::synchronize(hip_stream);
+        if (n_alignments == 0) return;
+
+        // banded_traceback_all + finish_alignment_all, BATCH_SIZE alignments at a time
+        const uint64 m = n_alignments;
+        output_alignments_dvec.resize(m);
+        hip_check(nvbio_hip_memcpy(output_alignments_dvec.data(), scored_alignments_dvec.data(), m * 8u, 3, hip_stream), "nvbio_hip_memcpy(d2d)");
+        cigar.resize(size_t(m) * cigar_stride); cigar_len.resize(m); cigar_source.resize(size_t(m) * 2u); cigar_sink.resize(size_t(m) * 2u); traceback_score.resize(m);
+        mds.resize(size_t(m) * mds_stride); mds_len.resize(m);
+        hip_check(nvbio_hip_memset(cigar.data(), 0, m * cigar_stride * sizeof(io::Cigar), hip_stream), "nvbio_hip_memset");
+        hip_check(nvbio_hip_memset(mds.data(), 0, m * mds_stride, hip_stream), "nvbio_hip_memset");
+        const uint32 tcap = uint32(std::min<uint64>(m, B));
+        hip::device_vector<uint64> tb_pat(tcap), tb_txt(tcap);
+        hip::device_vector<uint32> tb_len(tcap);
+        hip::device_vector<uint8>  valid(std::vector<uint8>(tcap, 1u));
+        const nvbio_hip_gotoh_qual_scheme sc = scoring_scheme.abi();
+        for (uint64 off = 0; off < m; off += B)
+        {
+            const uint32 nb = uint32(std::min<uint64>(m - off, B));
+            uint64* a = reinterpret_cast<uint64*>(output_alignments_dvec.data() + off);
+            hip_check(nvbio_hip_traceback_all_setup(nb, a, output_read_info_dvec.data() + off, nullptr, nullptr, L, reads.rc_offset, band_len, genome_len,
+                                                    tb_pat.data(), nullptr, tb_txt.data(), tb_len.data(), hip_stream), "nvbio_hip_traceback_all_setup");
+            const PackedStringSetView<4, true>  patterns(nb, reads.fw_rc_words, reads.fw_rc_n_words, tb_pat.data(), nullptr, L);
+            const PackedStringSetView<2, true>  texts(nb, genome_words, genome_n_words, tb_txt.data(), tb_len.data(), 0u);
+            const aln::AlignmentArrays alignments = { traceback_score.data() + off, cigar_source.data() + 2u * off, cigar_sink.data() + 2u * off };
+            const aln::CigarArrays     cigars     = { cigar.data() + off * cigar_stride, cigar_stride, cigar_len.data() + off };
+            dispatch_band(band_len, [&](auto band) {
+                typedef aln::PackedTracebackStream<aln::GotohAligner<TYPE, aln::SmithWatermanScoringScheme>, PackedStringSetView<4, true>, PackedStringSetView<2, true> > stream_type;
+                const stream_type stream(aligner, patterns, texts, alignments, cigars, L, L + band_len, reads.quals, reads.n_quals);
+                typedef aln::BatchedBandedAlignmentTraceback<decltype(band)::value, 32u, stream_type> batch_type;
+                hip::device_vector<uint8> temp(batch_type::min_temp_storage(L, L + band_len, nb));
+                batch_type().enact(stream, temp.size(), temp.data(), hip_stream);
+                hip::synchronize(hip_stream);
+            });
+            const nvbio_hip_string_set p = patterns.abi(), t = texts.abi();
+            hip_check(nvbio_hip_finish_alignment(nb, valid.data(), &p, reads.quals, reads.n_quals, &t, reinterpret_cast<const uint16*>(cigar.data() + off * cigar_stride), cigar_stride,
+                                                 cigar_len.data() + off, cigar_source.data() + 2u * off, sc.match, sc.mismatch, 1, nullptr, a,
+                                                 mds.data() + off * mds_stride, mds_stride, mds_len.data() + off, hip_stream), "nvbio_hip_finish_alignment");
+            hip::synchronize(hip_stream);
+        }
+    }
+
     template <aln::AlignmentType TYPE>
     void best_approx_t(const Params& params, const fm_index_device& fmi, const fm_index_device& rfmi, const aln::SmithWatermanScoringScheme& scoring_scheme,
                        const ScoreLimits& limits, const uint32* genome_words, const uint64 genome_n_words, const uint32 genome_len,

@@ -415,11 +415,11 @@ def all_mapping(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=No
     empty = dict(read_id=torch.zeros(0, dtype=torch.int32, device=dev), alignments=torch.zeros(0, dtype=torch.int64, device=dev),
                  alignments_scored=torch.zeros(0, dtype=torch.int64, device=dev), stats=stats)
     # scans (thrust::inclusive_scan in the reference) and the range sizes
-    count_scan = torch.cumsum(counts.to(torch.int64), 0).to(torch.int32)
+    count_scan = sel.inclusive_scan(counts)
     n_ranges = int(count_scan[-1]) if n else 0
     if n_ranges == 0:
         return empty
-    range_scan = torch.cumsum(sel.gather_ranges(hits, counts, count_scan, n_ranges), 0)
+    range_scan = sel.inclusive_scan(sel.gather_ranges(hits, counts, count_scan, n_ranges))
     n_hits = int(range_scan[-1])
     stats["hits"], stats["ranges"] = n_hits, n_ranges
     seq_index = torch.tensor(sequence_index if sequence_index is not None else [0, genome_len], dtype=torch.int64, device=dev).to(torch.int32)
@@ -431,15 +431,12 @@ def all_mapping(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=No
         with _Stage(stats, "select"):
             loc, seed, rid = sel.select_all(off, cnt, hits, count_scan, range_scan)
         with _Stage(stats, "locate"):
-            idx_queue = torch.sort((loc.to(torch.int64) & 0xFFFFFFFF) >> 16, stable=True).indices.to(torch.int32)      # sort_hi_bits
+            idx_queue = sel.sort_hi_bits(loc)
             sel.locate_hits(fmi, rfmi, loc, seed)
         with _Stage(stats, "sort"):
-            key = (loc.to(torch.int64) & 0xFFFFFFFF) + (rid.to(torch.int64) << 33) + (((seed >> 13) & 1).to(torch.int64) << 32)     # SortingKeys
-            skey, sidx = torch.sort(key, stable=True)
-            flags = torch.ones(cnt, dtype=torch.uint8, device=dev)
-            flags[1:] = (skey[1:] != skey[:-1]).to(torch.uint8)
+            sidx, flags = sel.sort_hits(rid, loc, seed)                                  # SortingKeys order + first-of-run flags
             sel.mark_straddling(idx_queue, seq_index, loc, params.seed_len, flags)
-            q = sel.copy_flagged(sidx.to(torch.int32), flags)
+            q = sel.copy_flagged(sidx, flags)
         stats["unique"] += int(q.numel())
         if q.numel() == 0:
             continue

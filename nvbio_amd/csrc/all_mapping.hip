@@ -12,6 +12,8 @@
 // One lane per hit everywhere: these are streaming passes over the hit arrays (HBM bound, a few bytes per hit); the
 // binary searches run over scans that stay in L2.
 #include "common.h"
+#include <hipcub/hipcub.hpp>
+#include <algorithm>
 
 namespace nvb {
 
@@ -114,6 +116,33 @@ score_all_output_kernel(uint32_t n, const uint32_t* __restrict__ idx, const uint
     out_read[i] = r;
 }
 
+// ---- the library primitives Aligner::score_all calls between its kernels (thrust::inclusive_scan, sort_enactor.sort over
+// SortBuffers -- aligner_sort.cu:39-92 -- and the dedup transform, aligner_all.h:498-509), on hipCUB
+__global__ void __launch_bounds__(256) iota_kernel(uint32_t n, uint32_t* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) out[i] = i;
+}
+__global__ void __launch_bounds__(256) hi_bits_kernel(uint32_t n, const uint32_t* __restrict__ keys, uint32_t* __restrict__ hi, uint32_t* __restrict__ idx)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) { hi[i] = keys[i] >> 16; idx[i] = i; }                                    // hi_bits_functor<uint16,uint32>
+}
+// SortingKeys (aligner_all.h:229-247): loc + (read_id << 33) + (rc << 32)
+__global__ void __launch_bounds__(256) hit_keys_kernel(uint32_t n, const uint32_t* __restrict__ hit_read, const uint32_t* __restrict__ hit_loc,
+                                                       const uint32_t* __restrict__ hit_seed, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) { keys[i] = uint64_t(hit_loc[i]) + (uint64_t(hit_read[i]) << 33) + (uint64_t((hit_seed[i] >> 13) & 1u) << 32); idx[i] = i; }
+}
+__global__ void __launch_bounds__(256) first_of_run_kernel(uint32_t n, const uint64_t* __restrict__ sorted_keys, uint8_t* __restrict__ flags)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) flags[i] = (i == 0u || sorted_keys[i] != sorted_keys[i - 1u]) ? 1u : 0u;
+}
+
+static inline uint64_t align256(uint64_t x) { return (x + 255u) & ~uint64_t(255); }
+
 } // namespace nvb
 
 using namespace nvb;
@@ -193,5 +222,75 @@ NVB_API int nvbio_hip_traceback_all_setup(uint32_t n, const uint64_t* alignments
     hipLaunchKernelGGL(all_window_kernel, grid_for(n), dim3(256), 0, to_stream(stream), n, static_cast<const uint32_t*>(nullptr), read_id,
                        static_cast<const uint32_t*>(nullptr), static_cast<const uint32_t*>(nullptr), reinterpret_cast<const uint2*>(alignments),
                        read_begin, read_len, fixed_read_len, rc_offset, band_len, genome_length, pattern_begin, pattern_len, text_begin, text_len);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ scans and sorts
+// One scratch size serves every call below over n items: key / value ping-pong buffers + the hipCUB workspace.
+NVB_API uint64_t nvbio_hip_all_mapping_temp_bytes(uint32_t n)
+{
+    size_t a = 0, b = 0, c = 0, d = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, int(n), 0, 64);
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, int(n), 0, 16);
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, c, (const uint64_t*)nullptr, (uint64_t*)nullptr, int(n));
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, d, (const uint32_t*)nullptr, (uint32_t*)nullptr, int(n));
+    const size_t w = std::max(std::max(a, b), std::max(c, d));
+    return align256(w) + 2u * align256(uint64_t(n) * 8u) + align256(uint64_t(n) * 4u) + 256u;
+}
+
+namespace {
+struct Scratch { uint8_t* work; size_t work_bytes; uint64_t* k0; uint64_t* k1; uint32_t* v0; };
+inline bool carve(void* temp, uint64_t temp_bytes, uint32_t n, Scratch& s)
+{
+    if (!temp || temp_bytes < nvbio_hip_all_mapping_temp_bytes(n)) return false;
+    uint8_t* p = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(temp) + 255u) & ~uintptr_t(255));
+    s.k0 = reinterpret_cast<uint64_t*>(p); p += align256(uint64_t(n) * 8u);
+    s.k1 = reinterpret_cast<uint64_t*>(p); p += align256(uint64_t(n) * 8u);
+    s.v0 = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(n) * 4u);
+    s.work = p; s.work_bytes = size_t(temp_bytes - 256u - 2u * align256(uint64_t(n) * 8u) - align256(uint64_t(n) * 4u));
+    return true;
+}
+}
+
+NVB_API int nvbio_hip_inclusive_scan_u32(uint32_t n, const uint32_t* in, uint32_t* out, void* temp, uint64_t temp_bytes, void* stream)
+{
+    if (n == 0) return hipSuccess;
+    Scratch s;
+    if (!in || !out || !carve(temp, temp_bytes, n, s)) return hipErrorInvalidValue;
+    g_last_kernel = "hipcub::DeviceScan::InclusiveSum";
+    return hipcub::DeviceScan::InclusiveSum(s.work, s.work_bytes, in, out, int(n), to_stream(stream));
+}
+
+NVB_API int nvbio_hip_inclusive_scan_u64(uint32_t n, const uint64_t* in, uint64_t* out, void* temp, uint64_t temp_bytes, void* stream)
+{
+    if (n == 0) return hipSuccess;
+    Scratch s;
+    if (!in || !out || !carve(temp, temp_bytes, n, s)) return hipErrorInvalidValue;
+    g_last_kernel = "hipcub::DeviceScan::InclusiveSum";
+    return hipcub::DeviceScan::InclusiveSum(s.work, s.work_bytes, in, out, int(n), to_stream(stream));
+}
+
+NVB_API int nvbio_hip_sort_hi_bits(uint32_t n, const uint32_t* keys, uint32_t* out_idx, void* temp, uint64_t temp_bytes, void* stream)
+{
+    if (n == 0) return hipSuccess;
+    Scratch s;
+    if (!keys || !out_idx || !carve(temp, temp_bytes, n, s)) return hipErrorInvalidValue;
+    uint32_t* h0 = reinterpret_cast<uint32_t*>(s.k0); uint32_t* h1 = reinterpret_cast<uint32_t*>(s.k1);
+    hipLaunchKernelGGL(hi_bits_kernel, grid_for(n), dim3(256), 0, to_stream(stream), n, keys, h0, s.v0);
+    g_last_kernel = "hipcub::DeviceRadixSort::SortPairs";
+    return hipcub::DeviceRadixSort::SortPairs(s.work, s.work_bytes, h0, h1, s.v0, out_idx, int(n), 0, 16, to_stream(stream));       // stable
+}
+
+NVB_API int nvbio_hip_sort_hits(uint32_t n, const uint32_t* hit_read_id, const uint32_t* hit_loc, const uint32_t* hit_seed, uint32_t* out_idx, uint8_t* out_first,
+                                void* temp, uint64_t temp_bytes, void* stream)
+{
+    if (n == 0) return hipSuccess;
+    Scratch s;
+    if (!hit_read_id || !hit_loc || !hit_seed || !out_idx || !out_first || !carve(temp, temp_bytes, n, s)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(hit_keys_kernel, grid_for(n), dim3(256), 0, to_stream(stream), n, hit_read_id, hit_loc, hit_seed, s.k0, s.v0);
+    g_last_kernel = "hipcub::DeviceRadixSort::SortPairs";
+    const hipError_t e = hipcub::DeviceRadixSort::SortPairs(s.work, s.work_bytes, s.k0, s.k1, s.v0, out_idx, int(n), 0, 64, to_stream(stream));   // stable
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(first_of_run_kernel, grid_for(n), dim3(256), 0, to_stream(stream), n, s.k1, out_first);
     return hipGetLastError();
 }

@@ -637,3 +637,23 @@ NVB_API int nvbio_hip_scatter_rows(uint32_t n, const uint32_t* idx, const void* 
                        static_cast<const uint32_t*>(src), static_cast<uint32_t*>(dst), row_bytes / 4u);
     return hipGetLastError();
 }
+
+// dst row i = src row idx[i] (the twin of scatter_rows): compacts accepted alignments through an index list
+namespace nvb {
+__global__ void __launch_bounds__(256) gather_rows_kernel(uint32_t n, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint32_t row_words)
+{
+    const uint64_t t = uint64_t(blockIdx.x) * 256u + threadIdx.x;
+    if (t >= uint64_t(n) * row_words) return;
+    const uint32_t i = uint32_t(t / row_words), w = uint32_t(t % row_words);
+    dst[t] = src[uint64_t(idx[i]) * row_words + w];
+}
+}
+NVB_API int nvbio_hip_gather_rows(uint32_t n, const uint32_t* idx, const void* src, void* dst, uint32_t row_bytes, void* stream)
+{
+    if (n == 0) return hipSuccess;
+    if (!idx || !src || !dst || row_bytes == 0 || (row_bytes & 3u)) return hipErrorInvalidValue;
+    g_last_kernel = "gather_rows_kernel";
+    hipLaunchKernelGGL(gather_rows_kernel, grid_for(uint64_t(n) * (row_bytes / 4u)), dim3(256), 0, to_stream(stream), n, idx,
+                       static_cast<const uint32_t*>(src), static_cast<uint32_t*>(dst), row_bytes / 4u);
+    return hipGetLastError();
+}

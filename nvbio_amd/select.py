@@ -302,3 +302,33 @@ def traceback_all_setup(alignments, read_id, band_len, genome_len, fixed_read_le
     check(lib().nvbio_hip_traceback_all_setup(m, _vp(alignments), _vp(read_id), _vp(read_begin), _vp(read_len), int(fixed_read_len), int(rc_offset), int(band_len),
                                               int(genome_len), _vp(pb), _vp(pl), _vp(tb), _vp(tl), current_stream_ptr()), "nvbio_hip_traceback_all_setup")
     return pb, pl, tb, tl
+
+
+def _all_temp(n, dev):
+    return torch.empty(int(lib().nvbio_hip_all_mapping_temp_bytes(int(n))), dtype=torch.uint8, device=dev)
+
+
+def inclusive_scan(x):
+    """thrust::inclusive_scan over int32 (as uint32) or int64 (as uint64) values."""
+    out = torch.empty_like(x)
+    t = _all_temp(x.numel(), x.device)
+    fn = lib().nvbio_hip_inclusive_scan_u32 if x.dtype == torch.int32 else lib().nvbio_hip_inclusive_scan_u64
+    check(fn(x.numel(), _vp(x), _vp(out), _vp(t), t.numel(), current_stream_ptr()), "nvbio_hip_inclusive_scan")
+    return out
+
+
+def sort_hi_bits(keys):
+    """Aligner::sort_hi_bits (aligner_sort.cu:39-64): the permutation that stably sorts keys >> 16 -> int32[n]."""
+    idx = torch.empty(keys.numel(), dtype=torch.int32, device=keys.device)
+    t = _all_temp(keys.numel(), keys.device)
+    check(lib().nvbio_hip_sort_hi_bits(keys.numel(), _vp(keys), _vp(idx), _vp(t), t.numel(), current_stream_ptr()), "nvbio_hip_sort_hi_bits")
+    return idx
+
+
+def sort_hits(hit_read_id, hit_loc, hit_seed):
+    """Aligner::sort_64_bits over SortingKeys + the dedup flags (aligner_all.h:229-247, :492-509) -> (idx int32[n], first-of-run flags uint8[n])."""
+    n = hit_loc.numel()
+    idx = torch.empty(n, dtype=torch.int32, device=hit_loc.device); first = torch.empty(n, dtype=torch.uint8, device=hit_loc.device)
+    t = _all_temp(n, hit_loc.device)
+    check(lib().nvbio_hip_sort_hits(n, _vp(hit_read_id), _vp(hit_loc), _vp(hit_seed), _vp(idx), _vp(first), _vp(t), t.numel(), current_stream_ptr()), "nvbio_hip_sort_hits")
+    return idx, first

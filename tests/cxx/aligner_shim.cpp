@@ -134,3 +134,50 @@ int nvbio_aligner_best_approx_paired(const nvbio_hip_fmindex* fmi, const nvbio_h
         return 0;
     } catch (const nvbio::hip_error& e) { fprintf(stderr, "aligner_shim: %s\n", e.what()); return 1; }
 }
+
+// the all-mapping driver (Aligner::all): outputs for up to out_cap alignments; *h_n = how many there are
+extern "C" __attribute__((visibility("default")))
+int nvbio_aligner_all(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmindex* rfmi, uint32_t n, uint32_t L,
+                      const uint32_t* d_rev_words, uint64_t rev_n_words, const uint64_t* d_rev_begin,
+                      const uint32_t* d_fwrc_words, uint64_t fwrc_n_words, const uint8_t* d_quals, uint64_t n_quals,
+                      const uint32_t* d_genome_words, uint64_t genome_n_words, uint32_t genome_len, const uint32_t* h_seq_index, uint32_t n_seq_index,
+                      const shim_params* sp, uint64_t out_cap, uint64_t* h_n, uint32_t* h_read_id, uint64_t* h_alignments, uint64_t* h_scored,
+                      uint16_t* h_cigar /* cap*64 */, uint32_t* h_cigar_len, uint32_t* h_source, uint32_t* h_sink, uint8_t* h_mds /* cap*256 */, uint32_t* h_mds_len,
+                      uint64_t* h_stats /* hits, ranges, unique */)
+{
+    try {
+        Params params;
+        params.seed_len = sp->seed_len; params.seed_freq = SimpleFunc(SimpleFunc::Type(sp->seed_freq_type), sp->seed_freq_k, sp->seed_freq_m);
+        params.min_read_len = sp->min_read_len; params.max_hits = sp->max_hits; params.max_reseed = sp->max_reseed; params.rep_seeds = sp->rep_seeds;
+        params.allow_sub = sp->allow_sub; params.subseed_len = sp->subseed_len;
+        params.max_dist = sp->max_dist; params.alignment_type = sp->local ? LocalAlignment : EndToEndAlignment; params.hits_stride = sp->hits_stride;
+        aln::SmithWatermanScoringScheme scheme = sp->local ? aln::SmithWatermanScoringScheme::local() : aln::SmithWatermanScoringScheme();
+        scheme.m_match = sp->match;
+        const ScoreLimits limits(sp->match, SimpleFunc(SimpleFunc::Type(sp->score_min_type), sp->score_min_k, sp->score_min_m));
+        fm_index_device f, rf; f.m = *fmi; rf.m = rfmi ? *rfmi : *fmi;
+        ReadBatch reads;
+        reads.n = n; reads.len = L;
+        reads.reversed = PackedStringSetView<4, true>(n, d_rev_words, rev_n_words, d_rev_begin, nullptr, L);
+        reads.fw_rc_words = d_fwrc_words; reads.fw_rc_n_words = fwrc_n_words; reads.rc_offset = uint64_t(n) * L;
+        reads.quals = d_quals; reads.n_quals = n_quals; reads.names = nullptr; reads.names_idx = nullptr;
+
+        Aligner aligner;
+        aligner.init(std::max(sp->batch_size, n), sp->batch_size);
+        Stats stats;
+        aligner.all(params, f, rf, scheme, limits, d_genome_words, genome_n_words, genome_len, std::vector<uint32>(h_seq_index, h_seq_index + n_seq_index), reads, stats);
+        const uint64_t m = aligner.n_alignments;
+        *h_n = m; h_stats[0] = stats.hits; h_stats[1] = stats.ranges; h_stats[2] = stats.unique;
+        if (m == 0 || m > out_cap) return 0;
+        const uint32_t cs = aligner.cigar_stride, ms = aligner.mds_stride;
+        hip_check(nvbio_hip_memcpy(h_read_id, aligner.output_read_info_dvec.data(), m * 4u, 2, nullptr), "d2h");
+        hip_check(nvbio_hip_memcpy(h_alignments, aligner.output_alignments_dvec.data(), m * 8u, 2, nullptr), "d2h");
+        hip_check(nvbio_hip_memcpy(h_scored, aligner.scored_alignments_dvec.data(), m * 8u, 2, nullptr), "d2h");
+        hip_check(nvbio_hip_memcpy(h_cigar, aligner.cigar.data(), m * cs * 2u, 2, nullptr), "d2h");
+        hip_check(nvbio_hip_memcpy(h_cigar_len, aligner.cigar_len.data(), m * 4u, 2, nullptr), "d2h");
+        hip_check(nvbio_hip_memcpy(h_source, aligner.cigar_source.data(), m * 8u, 2, nullptr), "d2h");
+        hip_check(nvbio_hip_memcpy(h_sink, aligner.cigar_sink.data(), m * 8u, 2, nullptr), "d2h");
+        hip_check(nvbio_hip_memcpy(h_mds, aligner.mds.data(), m * ms, 2, nullptr), "d2h");
+        hip_check(nvbio_hip_memcpy(h_mds_len, aligner.mds_len.data(), m * 4u, 2, nullptr), "d2h");
+        return 0;
+    } catch (const std::exception& e) { fprintf(stderr, "aligner_shim: %s\n", e.what()); return 1; }
+}

@@ -130,3 +130,61 @@ def test_all_mapping_stage_kernels(cuda):
         torch.cuda.synchronize()
         assert (loc.cpu().numpy().view(np.uint32) == exp[off:off + cnt, 0]).all()
         assert (seed.cpu().numpy() == exp[off:off + cnt, 1]).all() and (rid.cpu().numpy() == exp[off:off + cnt, 2]).all()
+
+
+@pytest.mark.parametrize("config", ["default", "small_batches", "local", "one_mismatch_seeds", "sequences"])
+def test_cxx_all_mapping_driver_matches_oracle(cuda, config):
+    """The C++ host driver (include/nvbio_hip/aligner.h: Aligner::all), called through tests/cxx/aligner_shim.cpp on device-resident
+    inputs, vs the numpy driver over the oracle (cigar stride 64, constant Q30)."""
+    import ctypes as C, os
+    from nvbio_amd import pipeline as P
+    from tests.test_select_gpu import _ShimParams
+    shim_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cxx", "libaligner_shim.so")
+    if not os.path.exists(shim_path):
+        pytest.fail("tests/cxx/libaligner_shim.so is missing: run `python __graft_entry__.py`")
+    shim = C.CDLL(shim_path)
+    rng = np.random.default_rng(4242)
+    text = _genome(rng)
+    host, rhost = O.FMIndex(text), O.FMIndex(text[::-1].copy())
+    fmi, rfmi = nvb.FMIndexDevice.from_host(host, cuda), nvb.FMIndexDevice.from_host(rhost, cuda)
+    kw, _ = CONFIGS[config]
+    params = A.Params(**kw)
+    n, L = 600, 100
+    reads, _ = _reads(rng, text, n, False)
+    sym = np.stack(reads)
+    scheme = nvb.SmithWatermanScoringScheme.local() if params.local else nvb.SmithWatermanScoringScheme()
+    gw = W._pack_chunked(torch.from_numpy(text), 2, True)
+    seq_index = [0, 9000, 20100, 41000, text.size] if config == "sequences" else [0, text.size]
+    e = OD.all_mapping(host, rhost, reads, gw.numpy().view(np.uint32), text.size, params, scheme, 1 if params.local else 2, cigar_stride=64, sequence_index=seq_index)
+
+    reads_rev, fwrc = P.pack_read_streams(torch.from_numpy(sym).to(cuda))
+    quals = torch.full((2 * n * L + 8,), 30, dtype=torch.uint8, device=cuda)
+    d_gw = gw.to(cuda)
+    sp = _ShimParams(int(params.local), 0, 0, params.max_effort_init, params.max_effort, params.min_ext, params.max_ext,
+                     params.max_reseed, params.rep_seeds, params.max_hits, params.allow_sub, params.subseed_len, params.seed_len, params.seed_freq[0],
+                     params.min_read_len, params.max_dist, 0, params.batch_size, params.hits_stride or 0,
+                     params.seed_freq[1], params.seed_freq[2], scheme.m_match, scheme.m_score_min[0], scheme.m_score_min[1], scheme.m_score_min[2], 1)
+    m = e["read_id"].size
+    cap = m + 16
+    rid = np.zeros(cap, np.uint32); aln = np.zeros(cap, np.uint64); scored = np.zeros(cap, np.uint64); cigar = np.zeros((cap, 64), np.uint16)
+    cigar_len = np.zeros(cap, np.uint32); source = np.zeros((cap, 2), np.uint32); sink = np.zeros((cap, 2), np.uint32)
+    mds = np.zeros((cap, 256), np.uint8); mds_len = np.zeros(cap, np.uint32); stats = np.zeros(3, np.uint64); count = np.zeros(1, np.uint64)
+    si = np.asarray(seq_index, np.uint32)
+    fs, rs = fmi.struct(), rfmi.struct()
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    hp = lambda a: a.ctypes.data_as(C.c_void_p)
+    torch.cuda.synchronize()
+    rc = shim.nvbio_aligner_all(C.byref(fs), C.byref(rs), C.c_uint32(n), C.c_uint32(L), vp(reads_rev.words), C.c_uint64(reads_rev.words.numel()), vp(reads_rev.begin),
+                                vp(fwrc), C.c_uint64(fwrc.numel()), vp(quals), C.c_uint64(quals.numel()), vp(d_gw), C.c_uint64(d_gw.numel()), C.c_uint32(text.size),
+                                hp(si), C.c_uint32(si.size), C.byref(sp), C.c_uint64(cap), hp(count), hp(rid), hp(aln), hp(scored), hp(cigar), hp(cigar_len), hp(source),
+                                hp(sink), hp(mds), hp(mds_len), hp(stats))
+    assert rc == 0
+    assert (int(stats[0]), int(stats[1]), int(stats[2])) == (e["stats"]["hits"], e["stats"]["ranges"], e["stats"]["unique"])
+    assert int(count[0]) == m
+    assert (rid[:m] == e["read_id"]).all() and (scored[:m] == e["alignments_scored"]).all() and (aln[:m] == e["alignments"]).all()
+    tb = e["tb"]
+    assert (cigar_len[:m] == tb["cigar_len"]).all() and (cigar[:m] == tb["cigar"][:m]).all()
+    assert (source[:m] == tb["source"]).all() and (sink[:m] == tb["sink"]).all()
+    assert (mds_len[:m] == e["mds_len"]).all()
+    mk = np.arange(256)[None, :] < np.minimum(e["mds_len"], 256)[:, None]
+    assert ((mds[:m] == e["mds"]) | ~mk).all()
