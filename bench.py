@@ -791,7 +791,7 @@ def extras_leg(a, dev):
         conc = paired & (((b0 >> 31) & 1) == 0)
         a_pos = (b0 >> 32) & 0xFFFFFFFF
         ok_pos = (((a_pos - ppos).abs() <= 3) | ((a_pos - (ppos + pflen - 150)).abs() <= 3)) & conc
-        bp[cname] = {"pairs": npairs, "ms_per_batch": ms, "Mpairs_per_s": npairs / ms / 1e3, "anchor_extensions": r["stats"]["extensions"],
+        bp[cname] = {"pairs": npairs, "ms_per_batch": ms, "Mpairs_per_s": npairs / ms / 1e3, "anchor_extensions": r["stats"]["extensions"], "opposite_dp_jobs": r.get("opposite_dp_jobs"),
                      "opposite_extensions": r["stats"]["opposite_extensions"], "rounds": r["stats"]["rounds"], "queue_per_seeding_pass": r["stats"]["queue"],
                      "concordant": float(conc.float().mean().item()), "concordant_at_fragment_end": float(ok_pos.float().mean().item()),
                      "mapq1_ge_23": float((r["mapq1"] >= 23).float().mean().item()), "stage_ms": {k: round(v, 3) for k, v in r["stats"]["ms"].items()}}

@@ -508,6 +508,22 @@ int nvbio_hip_score_reduce_paired_best_approx(uint32_t n_active, const uint32_t*
     const uint32_t* read_len /* nullable */, uint32_t fixed_read_len, uint32_t anchor, int32_t pe_policy, int32_t pe_unpaired, int32_t score_limit,
     uint64_t* best_alignments, uint64_t* best_alignments_o, uint32_t best_stride,
     uint32_t* trys, uint32_t* hit_counts, uint32_t n_ext, uint32_t min_ext, uint32_t max_ext, uint32_t max_effort, void* stream);
+/* The opposite-mate memo (optional, a pure saving).  The opposite mate's DP is a pure function of (pair, opposite strand, window,
+ * threshold); the reference re-runs it for every anchor hit landing on a placement it already tried and absorbs the identical result
+ * (in the second anchor pass that is every seed of every read).  memo: 6 words per pair, zero-initialised by the caller, holding the
+ * last scored job and its outputs.
+ *   opposite_memo_lookup (after opposite_score_setup, before the DP): a valid hit whose job equals the pair's entry gets its
+ *     opposite_* outputs from it, valid[i] = 2 and (if text_len != NULL) an empty text; nvbio_hip_opposite_score_finish leaves such
+ *     hits alone (with the valid_idx form, pass only the hits with valid == 1).
+ *   opposite_memo_update (after opposite_score_finish): per active read, the last hit with valid == 1 becomes the pair's entry.
+ * Every output equals what re-running the DP gives; hits of one pair in the SAME round are not matched against each other. */
+int nvbio_hip_opposite_memo_lookup(uint32_t n_hits, const uint32_t* hit_read_id, uint8_t* valid, const uint8_t* read_rc, const uint32_t* genome_begin,
+    const uint32_t* genome_end, const int32_t* min_score, uint32_t anchor, const uint32_t* memo, int32_t worst_score,
+    int32_t* opposite_score, int32_t* opposite_score2, uint32_t* opposite_loc, uint32_t* opposite_sink, uint32_t* opposite_sink2,
+    uint32_t* text_len /* nullable */, void* stream);
+int nvbio_hip_opposite_memo_update(uint32_t n_active, const uint32_t* active_reads, const uint64_t* hit_begin, const uint8_t* valid, const uint8_t* read_rc,
+    const uint32_t* genome_begin, const uint32_t* genome_end, const int32_t* min_score, const int32_t* opposite_score, const uint32_t* opposite_sink,
+    uint32_t anchor, uint32_t* memo, void* stream);
 int nvbio_hip_mark_discordant(uint32_t n_reads, uint64_t* best_alignments, uint64_t* best_alignments_o, uint32_t best_stride, void* stream);
 
 /* ---- what nvBowtie's host drivers do between the stages (they use thrust / nvbio primitives for it) ----

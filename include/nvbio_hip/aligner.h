@@ -420,6 +420,8 @@ private:
         hip::device_vector<uint8>  flag_temp(nvbio_hip_copy_flagged_temp_bytes(count));
         SeedHitDequeArrayDeviceView hits = { hit_data.data(), hits_stride, hit_counts.data() };
         const nvbio_hip_pe_params pp = { pe.pe_policy, int32(pe.min_frag_len), int32(pe.max_frag_len), pe.pe_overlap ? 1 : 0, worst_score, 0u, genome_len };
+        hip::device_vector<uint32> memo(size_t(count) * 6u);                  // the opposite-mate memo, empty
+        hip_check(nvbio_hip_memset(memo.data(), 0, uint64(count) * 24u, hip_stream), "nvbio_hip_memset");
 
         for (uint32 anchor = 0; anchor < 2; ++anchor)
         {
@@ -483,6 +485,10 @@ private:
                                                              best, best_o, BATCH_SIZE, sc.match, min_score_table.data(), sc.text_gap_open, sc.text_gap_ext, &app,
                                                              o_valid.data(), min_score.data(), o_rc.data(), o_gbegin.data(), o_gend.data(),
                                                              nullptr, o_reads.rc_offset, pat_begin.data(), txt_begin.data(), txt_len.data(), hip_stream), "nvbio_hip_opposite_score_setup");
+                    // jobs equal to the pair's last scored job are answered from the memo (nvbio_hip.h: the reference re-runs them)
+                    hip_check(nvbio_hip_opposite_memo_lookup(nh, queues.hit_read_id.data(), o_valid.data(), o_rc.data(), o_gbegin.data(), o_gend.data(), min_score.data(), anchor,
+                                                             memo.data(), worst_score, o_score.data(), o_score2.data(), o_loc.data(), o_sink.data(), o_sink2.data(), txt_len.data(),
+                                                             hip_stream), "nvbio_hip_opposite_memo_lookup");
                     {
                         const PackedStringSetView<4, true> patterns(nh, o_reads.fw_rc_words, o_reads.fw_rc_n_words, pat_begin.data(), nullptr, L);
                         const PackedStringSetView<2, true> texts(nh, genome_words, genome_n_words, txt_begin.data(), txt_len.data(), 0u);
@@ -492,6 +498,9 @@ private:
                     }
                     hip_check(nvbio_hip_opposite_score_finish(nh, nullptr, o_valid.data(), raw_score.data(), sinks.data(), min_score.data(), o_gbegin.data(), worst_score,
                                                               o_score.data(), o_score2.data(), o_loc.data(), o_sink.data(), o_sink2.data(), hip_stream), "nvbio_hip_opposite_score_finish");
+                    hip_check(nvbio_hip_opposite_memo_update(queues.in_size, reinterpret_cast<const uint32*>(queues.active_in.data()), queues.hit_begin.data(), o_valid.data(), o_rc.data(),
+                                                             o_gbegin.data(), o_gend.data(), min_score.data(), o_score.data(), o_sink.data(), anchor, memo.data(), hip_stream),
+                              "nvbio_hip_opposite_memo_update");
 
                     // score_reduce_paired with the give-up counters
                     hip_check(nvbio_hip_score_reduce_paired_best_approx(queues.in_size, reinterpret_cast<const uint32*>(queues.active_in.data()), queues.hit_begin.data(),

@@ -229,7 +229,7 @@ def best_approx(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=No
 # paired-end: Aligner::best_approx / best_approx_score of aligner_best_approx_paired.h (:95-453, :455-700)
 # ------------------------------------------------------------------------------------------------------------------
 def best_approx_score_paired(fmi, rfmi, state, seed_queue, anchor, best, best_o, a_words, o_words, n_reads, read_len, genome_words, genome_len,
-                             scheme, banded_aligner, full_aligner, quals, table, params, band_len, stats):
+                             scheme, banded_aligner, full_aligner, quals, table, params, band_len, stats, memo):
     """The extension rounds of one seeding pass of one anchor mate: select, locate, anchor_score_best, opposite_score_best over the
     hits whose anchor scored, score_reduce_paired with the give-up counters."""
     L = read_len
@@ -255,9 +255,14 @@ def best_approx_score_paired(fmi, rfmi, state, seed_queue, anchor, best, best_o,
         with _Stage(stats, "opposite_score"):
             ow = sel.opposite_score_setup(rid, seed, loc, hit_score, WORST_SCORE, best, best_o, scheme, anchor, genome_len, L, L, params.pe_policy,
                                           params.min_frag_len, params.max_frag_len, params.pe_overlap, WORST_SCORE, table)
-            idx = torch.nonzero(ow["valid"]).squeeze(1)                    # the jobs that are actually scored
-            n_valid = int(idx.numel())
-            if n_valid:
+            # jobs whose (window, threshold, strand) equal the pair's last scored job are answered from the memo: the reference
+            # re-runs them and absorbs the identical result
+            o_out = sel.opposite_outputs(int(loc.numel()), WORST_SCORE, loc.device)
+            sel.opposite_memo_lookup(rid, ow, anchor, memo, WORST_SCORE, o_out)
+            idx = torch.nonzero(ow["valid"] == 1).squeeze(1)               # the jobs that are actually scored
+            n_valid = int(torch.count_nonzero(ow["valid"]))                # what the reference scores (stats)
+            stats["opposite_dp_jobs"] = stats.get("opposite_dp_jobs", 0) + int(idx.numel())
+            if idx.numel():
                 ob = ow["genome_begin"].to(torch.int64)[idx] & 0xFFFFFFFF
                 oe = ow["genome_end"].to(torch.int64)[idx] & 0xFFFFFFFF
                 o_pat = PackedStringSet(o_words, 4, True, ((rid.to(torch.int64)[idx] & 0xFFFFFFFF) * L + ow["read_rc"].to(torch.int64)[idx] * (n_reads * L)).contiguous(), None, L)
@@ -268,7 +273,8 @@ def best_approx_score_paired(fmi, rfmi, state, seed_queue, anchor, best, best_o,
             else:
                 s_o = torch.empty(0, dtype=torch.int32, device=loc.device); k_o = torch.empty((0, 2), dtype=torch.int32, device=loc.device)
             o_score, o_score2, o_loc, o_sink, o_sink2 = sel.opposite_score_finish(idx.to(torch.int32), s_o, k_o, ow["min_score"], ow["genome_begin"],
-                                                                                   WORST_SCORE, int(loc.numel()))
+                                                                                   WORST_SCORE, int(loc.numel()), out=o_out)
+            sel.opposite_memo_update(active, hit_begin, ow, o_out, anchor, memo)
         with _Stage(stats, "reduce"):
             sel.score_reduce_paired_best_approx(best, best_o, state, active, hit_begin, loc, hit_sink, hit_score, seed, o_loc, o_sink, o_sink2, o_score, o_score2,
                                                 anchor, params.pe_policy, params.pe_unpaired, WORST_SCORE, n_ext, params.min_ext, params.max_ext,
@@ -308,6 +314,7 @@ def best_approx_paired(fmi, rfmi, sym1, sym2, genome_words, genome_len, params=N
     stats = dict(extensions=0, opposite_extensions=0, rounds=0, seeding_passes=0, queue=[])
     if stage_times:
         stats["ms"] = {}
+    memo = sel.opposite_memo(n, dev)
     for anchor in (0, 1):
         seed_queue = torch.arange(n, dtype=torch.int32, device=dev)
         fw_strand = params.pe_policy in (0, 1) if anchor == 0 else params.pe_policy in (0, 2)      # :168-176
@@ -324,14 +331,14 @@ def best_approx_paired(fmi, rfmi, sym1, sym2, genome_words, genome_len, params=N
             with _Stage(stats, "select_init"):
                 state = sel.SelectState(hits, counts, name_arena, params.max_effort_init, params.randomized, params.top_seed)
             best_approx_score_paired(fmi, rfmi, state, seed_queue, anchor, best, best_o, a_words, o_words, n, L, genome_words, genome_len, scheme,
-                                     banded_aligner, full_aligner, quals, table, params, band_len, stats)
+                                     banded_aligner, full_aligner, quals, table, params, band_len, stats, memo)
             seed_queue = seed_queue[reseed != 0]                                      # copy_flagged (no mark_unaligned in the paired driver)
     if params.pe_discordant:
         sel.mark_discordant(best, best_o)
     with _Stage(stats, "mapq"):
         mapq1 = reduce.mapq_paired(best, best_o, scheme, fixed_read_len=L, o_fixed_read_len=L)      # MapqFunctorPE(mate 0)
         mapq2 = reduce.mapq_paired(best_o, best, scheme, fixed_read_len=L, o_fixed_read_len=L)      # MapqFunctorPE(mate 1)
-    out = dict(best=best.data, best_o=best_o.data, mapq1=mapq1, mapq2=mapq2, stats=stats)
+    out = dict(best=best.data, best_o=best_o.data, mapq1=mapq1, mapq2=mapq2, opposite_dp_jobs=stats.pop("opposite_dp_jobs", 0), stats=stats)
     if traceback:
         # both mates' fw + rc patterns in one stream: a traceback picks its read by the alignment's mate bit (traceback_inl.h:117-120)
         mate_words = torch.cat([packed[0][1], packed[1][1]])

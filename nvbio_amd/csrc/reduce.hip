@@ -306,6 +306,7 @@ opposite_score_finish_kernel(uint32_t n_valid, const uint32_t* __restrict__ idx,
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     if (k >= n_valid) return;
     const uint32_t h = idx ? idx[k] : k;          // idx == NULL: one raw result per hit, `valid_flags` says which were scored
+    if (!idx && valid_flags && valid_flags[k] == 2u) return;          // answered from the opposite-mate memo (opposite_memo_lookup)
     if (!idx && valid_flags && !valid_flags[k]) { o_score[h] = worst_score; o_score2[h] = worst_score; o_loc[h] = 0u; o_sink[h] = 0u; o_sink2[h] = 0u; return; }
     const int32_t s = raw_score[k];
     const uint32_t gb = genome_begin[h], sx = raw_sink[k].x;
@@ -314,6 +315,45 @@ opposite_score_finish_kernel(uint32_t n_valid, const uint32_t* __restrict__ idx,
     o_loc[h] = gb;
     o_sink[h] = gb + (sx != 0xFFFFFFFFu ? sx : 0u);
     o_sink2[h] = gb;
+}
+
+// ------------------------------------------------------------------ opposite-mate memo
+// The opposite mate's DP is a pure function of (pair, opposite strand, window, threshold).  The reference re-runs it for every
+// anchor hit that lands on a placement it has already tried -- in the second anchor pass that is every seed of every read, because
+// its skip test compares the hit with the recorded *window* begin -- and absorbs the identical result.  One entry
+// per pair remembers the last scored job {window begin, end, threshold, strand, which mate} and its outputs; a later hit with the
+// same job is answered from it.  Written by one lane per pair (opposite_memo_update), read in the next round (opposite_memo_lookup).
+__global__ void __launch_bounds__(256)
+opposite_memo_lookup_kernel(uint32_t n_hits, const uint32_t* __restrict__ hit_read_id, uint8_t* __restrict__ valid, const uint8_t* __restrict__ read_rc,
+                            const uint32_t* __restrict__ gb, const uint32_t* __restrict__ ge, const int32_t* __restrict__ min_score, uint32_t anchor,
+                            const uint32_t* __restrict__ memo, int32_t worst_score,
+                            int32_t* __restrict__ o_score, int32_t* __restrict__ o_score2, uint32_t* __restrict__ o_loc, uint32_t* __restrict__ o_sink, uint32_t* __restrict__ o_sink2,
+                            uint32_t* __restrict__ text_len)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_hits || valid[i] != 1u) return;
+    const uint32_t* m = memo + uint64_t(hit_read_id[i]) * 6u;
+    if (m[3] != (1u | (uint32_t(read_rc[i]) << 1) | (anchor << 2)) || m[0] != gb[i] || m[1] != ge[i] || int32_t(m[2]) != min_score[i]) return;
+    valid[i] = 2u;
+    o_score[i] = int32_t(m[4]); o_score2[i] = worst_score; o_loc[i] = gb[i]; o_sink[i] = m[5]; o_sink2[i] = gb[i];
+    if (text_len) text_len[i] = 0u;
+}
+
+__global__ void __launch_bounds__(256)
+opposite_memo_update_kernel(uint32_t n_active, const uint32_t* __restrict__ active, const uint64_t* __restrict__ hit_begin, const uint8_t* __restrict__ valid,
+                            const uint8_t* __restrict__ read_rc, const uint32_t* __restrict__ gb, const uint32_t* __restrict__ ge, const int32_t* __restrict__ min_score,
+                            const int32_t* __restrict__ o_score, const uint32_t* __restrict__ o_sink, uint32_t anchor, uint32_t* __restrict__ memo)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_active) return;
+    uint32_t* m = memo + uint64_t(active[t] & 0x7FFFFFFFu) * 6u;
+    for (uint64_t i = hit_begin[t + 1]; i > hit_begin[t]; --i)            // the last scored hit of the round
+    {
+        const uint64_t h = i - 1u;
+        if (valid[h] != 1u) continue;
+        m[0] = gb[h]; m[1] = ge[h]; m[2] = uint32_t(min_score[h]); m[3] = 1u | (uint32_t(read_rc[h]) << 1) | (anchor << 2); m[4] = uint32_t(o_score[h]); m[5] = o_sink[h];
+        break;
+    }
 }
 
 // ------------------------------------------------------------------ opposite-mate windows
@@ -699,6 +739,32 @@ NVB_API int nvbio_hip_opposite_score_finish(uint32_t n_valid, const uint32_t* va
     g_last_kernel = "opposite_score_finish_kernel";
     hipLaunchKernelGGL(opposite_score_finish_kernel, dim3((n_valid + 255u) / 256u), dim3(256), 0, to_stream(stream), n_valid, valid_idx, raw_score,
                        reinterpret_cast<const uint2*>(raw_sink), min_score, genome_begin, worst_score, valid_idx ? nullptr : valid_flags, opposite_score, opposite_score2, opposite_loc, opposite_sink, opposite_sink2);
+    return hipGetLastError();
+}
+
+NVB_API int nvbio_hip_opposite_memo_lookup(uint32_t n_hits, const uint32_t* hit_read_id, uint8_t* valid, const uint8_t* read_rc, const uint32_t* genome_begin,
+    const uint32_t* genome_end, const int32_t* min_score, uint32_t anchor, const uint32_t* memo, int32_t worst_score,
+    int32_t* opposite_score, int32_t* opposite_score2, uint32_t* opposite_loc, uint32_t* opposite_sink, uint32_t* opposite_sink2, uint32_t* text_len, void* stream)
+{
+    if (n_hits == 0) return hipSuccess;
+    if (!hit_read_id || !valid || !read_rc || !genome_begin || !genome_end || !min_score || anchor > 1u || !memo || !opposite_score || !opposite_score2 ||
+        !opposite_loc || !opposite_sink || !opposite_sink2) return hipErrorInvalidValue;
+    g_last_kernel = "opposite_memo_lookup_kernel";
+    hipLaunchKernelGGL(opposite_memo_lookup_kernel, dim3((n_hits + 255u) / 256u), dim3(256), 0, to_stream(stream), n_hits, hit_read_id, valid, read_rc, genome_begin,
+                       genome_end, min_score, anchor, memo, worst_score, opposite_score, opposite_score2, opposite_loc, opposite_sink, opposite_sink2, text_len);
+    return hipGetLastError();
+}
+
+NVB_API int nvbio_hip_opposite_memo_update(uint32_t n_active, const uint32_t* active_reads, const uint64_t* hit_begin, const uint8_t* valid, const uint8_t* read_rc,
+    const uint32_t* genome_begin, const uint32_t* genome_end, const int32_t* min_score, const int32_t* opposite_score, const uint32_t* opposite_sink,
+    uint32_t anchor, uint32_t* memo, void* stream)
+{
+    if (n_active == 0) return hipSuccess;
+    if (!active_reads || !hit_begin || !valid || !read_rc || !genome_begin || !genome_end || !min_score || !opposite_score || !opposite_sink || anchor > 1u || !memo)
+        return hipErrorInvalidValue;
+    g_last_kernel = "opposite_memo_update_kernel";
+    hipLaunchKernelGGL(opposite_memo_update_kernel, dim3((n_active + 255u) / 256u), dim3(256), 0, to_stream(stream), n_active, active_reads, hit_begin, valid, read_rc,
+                       genome_begin, genome_end, min_score, opposite_score, opposite_sink, anchor, memo);
     return hipGetLastError();
 }
 

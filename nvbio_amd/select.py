@@ -173,12 +173,38 @@ def opposite_score_setup(hit_read_id, hit_seed, hit_loc, hit_score, worst_score,
     return out
 
 
-def opposite_score_finish(valid_idx, raw_score, raw_sink, min_score, genome_begin, worst_score, n_hits):
-    """hit.opposite_* of a round: worst_score everywhere, BestOppositeScoreStream::output for the scored hits."""
-    dev = min_score.device
+def opposite_outputs(n_hits, worst_score, dev):
+    """hit.opposite_* of a round as the driver initialises them (aligner_best_approx_paired.h:641-645): worst_score, zeros."""
     o_score = torch.full((n_hits,), worst_score, dtype=torch.int32, device=dev)
     o_score2 = torch.full((n_hits,), worst_score, dtype=torch.int32, device=dev)
     o_loc = torch.zeros(n_hits, dtype=torch.int32, device=dev); o_sink = torch.zeros(n_hits, dtype=torch.int32, device=dev); o_sink2 = torch.zeros(n_hits, dtype=torch.int32, device=dev)
+    return o_score, o_score2, o_loc, o_sink, o_sink2
+
+
+def opposite_memo(n_reads, dev):
+    """The opposite-mate memo of a run: 6 words per pair, empty."""
+    return torch.zeros((n_reads, 6), dtype=torch.int32, device=dev)
+
+
+def opposite_memo_lookup(hit_read_id, ow, anchor, memo, worst_score, outputs):
+    """Hits whose opposite-mate job equals their pair's memo entry: outputs filled in, ow["valid"] set to 2 (no DP needed)."""
+    o_score, o_score2, o_loc, o_sink, o_sink2 = outputs
+    check(lib().nvbio_hip_opposite_memo_lookup(hit_read_id.numel(), _vp(hit_read_id), _vp(ow["valid"]), _vp(ow["read_rc"]), _vp(ow["genome_begin"]), _vp(ow["genome_end"]),
+                                               _vp(ow["min_score"]), int(anchor), _vp(memo), int(worst_score), _vp(o_score), _vp(o_score2), _vp(o_loc), _vp(o_sink),
+                                               _vp(o_sink2), None, current_stream_ptr()), "nvbio_hip_opposite_memo_lookup")
+
+
+def opposite_memo_update(active, hit_begin, ow, outputs, anchor, memo):
+    """Per active pair: its last scored hit of the round becomes the memo entry."""
+    check(lib().nvbio_hip_opposite_memo_update(active.numel(), _vp(active), _vp(hit_begin), _vp(ow["valid"]), _vp(ow["read_rc"]), _vp(ow["genome_begin"]),
+                                               _vp(ow["genome_end"]), _vp(ow["min_score"]), _vp(outputs[0]), _vp(outputs[3]), int(anchor), _vp(memo),
+                                               current_stream_ptr()), "nvbio_hip_opposite_memo_update")
+
+
+def opposite_score_finish(valid_idx, raw_score, raw_sink, min_score, genome_begin, worst_score, n_hits, out=None):
+    """hit.opposite_* of a round: worst_score everywhere, BestOppositeScoreStream::output for the scored hits."""
+    dev = min_score.device
+    o_score, o_score2, o_loc, o_sink, o_sink2 = out if out is not None else opposite_outputs(n_hits, worst_score, dev)
     check(lib().nvbio_hip_opposite_score_finish(valid_idx.numel(), _vp(valid_idx), None, _vp(raw_score), _vp(raw_sink), _vp(min_score), _vp(genome_begin), int(worst_score),
                                                 _vp(o_score), _vp(o_score2), _vp(o_loc), _vp(o_sink), _vp(o_sink2), current_stream_ptr()), "nvbio_hip_opposite_score_finish")
     return o_score, o_score2, o_loc, o_sink, o_sink2
