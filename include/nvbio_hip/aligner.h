@@ -211,7 +211,21 @@ private:
         hip::device_vector<int32>  hit_score(cap);
         hip::device_vector<io::Alignment> job_aln(cap);
         hip::device_vector<uint32> d_seq_index(sequence_index);
-        scored_alignments_dvec.resize(n_hits); output_read_info_dvec.resize(n_hits);
+        // the alignment buffer grows as batches report (the reference streams them out through a 2 x BATCH_SIZE ring instead)
+        uint64 capacity = 0;
+        auto reserve = [&](const uint64 need) {
+            if (need <= capacity) return;
+            const uint64 grown = std::max<uint64>(need, std::max<uint64>(2u * capacity, 2u * uint64(B)));
+            hip::device_vector<io::Alignment> a(grown); hip::device_vector<uint32> r(grown);
+            if (n_alignments) {
+                hip_check(nvbio_hip_memcpy(a.data(), scored_alignments_dvec.data(), n_alignments * 8u, 3, hip_stream), "nvbio_hip_memcpy(d2d)");
+                hip_check(nvbio_hip_memcpy(r.data(), output_read_info_dvec.data(), n_alignments * 4u, 3, hip_stream), "nvbio_hip_memcpy(d2d)");
+                hip::synchronize(hip_stream);
+            }
+            std::swap(a.m_ptr, scored_alignments_dvec.m_ptr); std::swap(a.m_size, scored_alignments_dvec.m_size);
+            std::swap(r.m_ptr, output_read_info_dvec.m_ptr);  std::swap(r.m_size, output_read_info_dvec.m_size);
+            capacity = grown;
+        };
 
         for (uint64 hit_offset = 0; hit_offset < n_hits; hit_offset += B)
         {
@@ -247,6 +261,7 @@ private:
             hip_check(nvbio_hip_copy_flagged(queue_size, d_iota.data(), flags.data(), accepted.data(), counter.data(), flag_temp.data(), flag_temp.size(), hip_stream), "nvbio_hip_copy_flagged");
             hip::synchronize(hip_stream);
             const uint32 n_accepted = counter.to_host()[0];
+            reserve(n_alignments + n_accepted);
             hip_check(nvbio_hip_gather_rows(n_accepted, accepted.data(), job_aln.data(), scored_alignments_dvec.data() + n_alignments, 8u, hip_stream), "nvbio_hip_gather_rows");
             hip_check(nvbio_hip_gather_rows(n_accepted, accepted.data(), job_read.data(), output_read_info_dvec.data() + n_alignments, 4u, hip_stream), "nvbio_hip_gather_rows");
             n_alignments += n_accepted;
