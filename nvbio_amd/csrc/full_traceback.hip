@@ -33,6 +33,9 @@ struct FullTbParams {
     int32_t   txt_gap_open, txt_gap_ext;         // the column before the pattern (GLOBAL) is initialised with the text gap costs (gotoh_inl.h:275-279)
     const uint32_t* pending;                     // nullable: the jobs this launch works on (slot -> job), *pending_count of them
     const uint32_t* pending_count;
+    // with `pending`: |cheapest gap open|, |cheapest gap extension| (0 = keep the whole text): lets a queued job drop the text columns
+    // no alignment ending at its sink with its score can reach (see the kernel)
+    int32_t crop_open, crop_ext;
 };
 
 template <int TYPE, uint32_t BL>      // BL: pattern symbols per block of the reference's score pass (8 Gotoh, 16 SW / ED): fixes the sink's tie order
@@ -41,10 +44,28 @@ __global__ void __launch_bounds__(256) full_gotoh_traceback_kernel(const FullTbP
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;          // where this lane's flags / boundary column live
     if (slot >= (p.pending ? *p.pending_count : p.n)) return;
     const uint32_t tid = p.pending ? p.pending[slot] : slot;         // the job
-    const uint64_t pb = p.pat.begin[tid], tb = p.txt.begin[tid];
+    const uint64_t pb = p.pat.begin[tid];
+    uint64_t       tb = p.txt.begin[tid];
     const uint32_t M  = p.pat.length ? p.pat.length[tid] : p.pat.fixed_length;
-    const uint32_t N  = p.txt.length ? p.txt.length[tid] : p.txt.fixed_length;
+    uint32_t       N  = p.txt.length ? p.txt.length[tid] : p.txt.fixed_length;
     const uint64_t n  = p.n;
+
+    // A queued job knows its score and sink (the score pass ran over the whole text).  Any path that ends at the sink with that score
+    // spends at most M * match - score on gaps, so it spans at most M + d text symbols, d = the text gaps that budget buys.  Every
+    // cell the walk visits lies on such a path, and so does every path that ties with it at a visited cell: the values and directions
+    // at the visited cells -- all the walk reads -- are the same whether or not the text left of sink.x - (M + d) is there.  One lane
+    // sweeps the whole matrix here, so dropping those columns (opposite-mate windows are ~4 x the read) shortens the kernel's latency.
+    uint32_t c0 = 0;
+    if (p.pending && TYPE != NVBIO_HIP_GLOBAL && p.crop_ext > 0)
+    {
+        const int32_t  sc = p.out_score[tid];
+        const uint32_t sx = p.out_sink[tid].x;
+        const int64_t  budget = int64_t(M) * max(p.match, 0) - sc - p.crop_open;
+        const uint32_t d = budget < 0 ? 0u : uint32_t(budget / p.crop_ext) + 1u;
+        const uint32_t span = M + d + 2u;
+        if (sx != 0xFFFFFFFFu && sx <= N && sx > span) c0 = sx - span;
+    }
+    tb += c0; N -= c0;
 
     int32_t  best = -(1 << 30);
     uint32_t bx = 0xFFFFFFFFu, by = 0xFFFFFFFFu;
@@ -136,7 +157,7 @@ __global__ void __launch_bounds__(256) full_gotoh_traceback_kernel(const FullTbP
     }
 
     p.out_score[tid] = best;
-    p.out_sink[tid]  = make_uint2(bx, by);
+    p.out_sink[tid]  = make_uint2(bx == 0xFFFFFFFFu ? bx : bx + c0, by);
 
     // ---- walk back: gotoh_inl.h:1806-1870 over all checkpoints, then alignment_inl.h:443-466; Backtracker::clip / push
     uint16_t* cigar = p.out_cigar + uint64_t(tid) * p.cigar_stride;
@@ -169,7 +190,7 @@ __global__ void __launch_bounds__(256) full_gotoh_traceback_kernel(const FullTbP
     if (TYPE == NVBIO_HIP_GLOBAL)                                   { if (sy == 0u) for (; sx > 0u; --sx) push(T_DELETION); }
     flush();
     clip(sy);
-    p.out_source[tid]    = make_uint2(sx, sy);
+    p.out_source[tid]    = make_uint2(sx + c0, sy);
     p.out_cigar_len[tid] = size;
 }
 
@@ -289,6 +310,8 @@ static int full_traceback_core(
     p.column = static_cast<uint32_t*>(temp);
     p.flags  = p.column + uint64_t(maxN) * n;
     p.pending = nullptr; p.pending_count = nullptr;
+    p.crop_open = int32_t(std::min(iabs(scheme->gap_open), qual ? iabs(qual->text_gap_open) : iabs(scheme->gap_open)));
+    p.crop_ext  = int32_t(std::min(iabs(scheme->gap_ext),  qual ? iabs(qual->text_gap_ext)  : iabs(scheme->gap_ext)));
     const dim3 grid((n + 255u) / 256u), block(256);
     hipStream_t s = to_stream(stream);
     if (block_len == 8u && type != NVBIO_HIP_GLOBAL && maxM <= 512u)

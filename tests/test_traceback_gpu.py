@@ -318,3 +318,52 @@ def test_full_matrix_traceback_on_tie_heavy_batches(cuda):
             torch.cuda.synchronize()
             compare(exp, got, (ty, scheme, "ties"))
             assert torch.equal(s, got["score"]) and torch.equal(k, got["sink"])
+
+
+def test_full_matrix_traceback_long_left_context(cuda):
+    """The opposite-mate shape at its extreme: the alignment ends at the end of a text several times the read (the queued, gapped jobs
+    drop the text columns no alignment with their score can reach).  Gapped reads, tandem-repeat texts (equal-scoring paths that
+    slide along the repeat and long gap runs are common there), cheap and expensive gaps, both types, with and without qualities."""
+    rng = np.random.default_rng(8900)
+    pats, txts = [], []
+    for i in range(1500):
+        M = int(rng.integers(30, 151)); N = int(rng.integers(max(M + 40, 200), 651))
+        if i % 3 == 0:
+            unit = rng.integers(0, 4, int(rng.integers(1, 7)), dtype=np.uint8)
+            t = np.resize(unit, N).copy()
+            t[rng.integers(0, N, N // 25)] = rng.integers(0, 4, N // 25)
+        else:
+            t = rng.integers(0, 4, N, dtype=np.uint8)
+        L = M + int(rng.integers(0, 4))
+        p = t[N - L - int(rng.integers(0, 3)):][:L].copy()
+        for j in rng.integers(0, p.size, int(rng.integers(0, 6))):
+            p[j] = (p[j] + 1 + rng.integers(0, 3)) & 3
+        k = i % 5
+        if k == 1:
+            c = int(rng.integers(5, p.size - 5)); p = np.delete(p, slice(c, c + int(rng.integers(1, 9))))
+        elif k == 2:
+            c = int(rng.integers(5, p.size - 5)); p = np.insert(p, c, rng.integers(0, 4, int(rng.integers(1, 6))))
+        elif k == 3:
+            c, d = sorted(rng.integers(5, p.size - 5, 2)); p = np.insert(np.delete(p, slice(c, c + 2)), max(d - 2, 1), rng.integers(0, 4, 3))
+        pats.append(p[:150].astype(np.uint8)); txts.append(t)
+    hp, ht = O.StringSet.from_lists(pats, 4, True), O.StringSet.from_lists(txts + [np.zeros(64, np.uint8)], 2, True)
+    ht = O.StringSet(ht.words, 2, True, ht.begin[:-1], ht.length[:-1])
+    dp, dt = to_dev(hp, cuda), to_dev(ht, cuda)
+    gapped = 0
+    for ty in (nvb.LOCAL, nvb.SEMI_GLOBAL):
+        for scheme in ((2, -6, -8, -3), (1, -2, -1, -1), (0, -6, -5, -3), (3, -1, -4, -1)):
+            exp = O.batch_gotoh_traceback(ty, scheme, hp, ht, 64)
+            got = nvb.batch_alignment_traceback(nvb.make_gotoh_aligner(ty, nvb.SimpleGotohScheme(*scheme), nvb.PATTERN_BLOCKING), dp, dt, 150, 650, cigar_stride=64)
+            torch.cuda.synchronize()
+            compare(exp, got, (ty, scheme, "left context"))
+            gapped += int(((exp["cigar"][:, :8] & 3) % 3 != 0).any(axis=1).sum())
+    assert gapped > 2000
+    quals = rng.integers(0, 45, int(hp.begin[-1] + hp.length[-1]) + 3, dtype=np.uint8)
+    for ty, scheme in ((nvb.LOCAL, nvb.SmithWatermanScoringScheme.local()), (nvb.SEMI_GLOBAL, nvb.SmithWatermanScoringScheme())):
+        st = scheme.struct()
+        lut = np.array([st.mismatch[q] for q in range(256)], dtype=np.int32)
+        s5 = (st.match, st.pattern_gap_open, st.pattern_gap_ext, st.text_gap_open, st.text_gap_ext)
+        exp = O.batch_gotoh_traceback(ty, s5, hp, ht, 64, lut, quals)
+        got = nvb.batch_alignment_traceback(nvb.make_gotoh_aligner(ty, scheme), dp, dt, 150, 650, cigar_stride=64, quals=torch.from_numpy(quals).to(cuda))
+        torch.cuda.synchronize()
+        compare(exp, got, (ty, "qual", "left context"))
