@@ -124,6 +124,68 @@ def load_genome(prefix):
     return read_pac(prefix + ".pac")
 
 
+class BNTSeq:
+    """The .ann / .amb pair of a BWA-style reference (nvbio/basic/bnt.h, bnt.cpp:83-163; format of BWA 0.6.1): sequence names,
+    comments, offsets and lengths in the concatenated genome, and the runs of ambiguous symbols that were replaced when packing."""
+
+    def __init__(self, l_pac, seed, names, annos, gis, offsets, lengths, n_ambs, holes):
+        self.l_pac, self.seed, self.names, self.annos, self.gis = int(l_pac), int(seed), list(names), list(annos), list(gis)
+        self.offsets, self.lengths, self.n_ambs, self.holes = list(offsets), list(lengths), list(n_ambs), list(holes)
+
+    @property
+    def n_seqs(self):
+        return len(self.names)
+
+    def sequence_index(self):
+        """SequenceData's sequence index as BNTLoader builds it (sequence_pac.cpp:214-226): [0, offset_i + len_i ...]"""
+        return [0] + [o + l for o, l in zip(self.offsets, self.lengths)]
+
+    def locate(self, pos):
+        """genome coordinate -> (sequence number, coordinate inside it)"""
+        idx = self.sequence_index()
+        k = int(np.searchsorted(np.asarray(idx, np.int64), pos, side="right")) - 1
+        k = min(max(k, 0), self.n_seqs - 1)
+        return k, int(pos) - idx[k]
+
+
+def read_bns(prefix):
+    """load_bns (bnt.cpp:83-163)"""
+    with open(prefix + ".ann") as f:
+        l_pac, n_seqs, seed = f.readline().split()[:3]
+        names, annos, gis, offsets, lengths, n_ambs = [], [], [], [], [], []
+        for _ in range(int(n_seqs)):
+            head = f.readline().rstrip("\n").split(" ", 2)
+            gis.append(int(head[0])); names.append(head[1]); annos.append(head[2].lstrip(" ") if len(head) > 2 else "")
+            o, l, a = f.readline().split()[:3]
+            offsets.append(int(o)); lengths.append(int(l)); n_ambs.append(int(a))
+    holes = []
+    with open(prefix + ".amb") as f:
+        lp, ns, nh = f.readline().split()[:3]
+        if int(lp) != int(l_pac) or int(ns) != int(n_seqs):
+            raise FileMismatch("%s.ann and %s.amb describe different references" % (prefix, prefix))
+        for _ in range(int(nh)):
+            o, l, c = f.readline().split()[:3]
+            holes.append((int(o), int(l), c))
+    return BNTSeq(l_pac, seed, names, annos, gis, offsets, lengths, n_ambs, holes)
+
+
+def write_bns(prefix, names, lengths, annos=None, holes=(), seed=11):
+    """The .ann / .amb files of sequences laid end to end (what `bwa index` / nvBWT's front end write)."""
+    offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.int64) if len(lengths) else np.zeros(0, np.int64)
+    l_pac = int(np.sum(lengths))
+    annos = annos or [""] * len(names)
+    per_seq = [sum(1 for (o, l, _) in holes if offsets[i] <= o < offsets[i] + lengths[i]) for i in range(len(names))]
+    with open(prefix + ".ann", "w") as f:
+        f.write("%d %d %u\n" % (l_pac, len(names), seed))
+        for i, nm in enumerate(names):
+            f.write("0 %s%s\n" % (nm, (" " + annos[i]) if annos[i] else ""))
+            f.write("%d %d %d\n" % (int(offsets[i]), int(lengths[i]), per_seq[i]))
+    with open(prefix + ".amb", "w") as f:
+        f.write("%d %d %u\n" % (l_pac, len(names), len(holes)))
+        for o, l, c in holes:
+            f.write("%d %d %s\n" % (o, l, c))
+
+
 class FMIndexDataDevice:
     """io::FMIndexDataHost::load + io::FMIndexDataDevice (nvbio/io/fmindex/fmindex.h:200-362): reads
     <prefix>.bwt/.sa (FORWARD) and .rbwt/.rsa (REVERSE), builds the interleaved bwt|occ records on the device

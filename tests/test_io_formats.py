@@ -162,6 +162,60 @@ def test_files_to_sam_example(tmp_path, cuda):
     assert good > 0.95 * len(aligned)
 
 
+def test_bns_files_round_trip(tmp_path):
+    """.ann / .amb (BWA 0.6.1's text format, as bnt.cpp:83-163 reads it): names with and without comments, offsets, holes"""
+    prefix = str(tmp_path / "ref")
+    nio.write_bns(prefix, ["chr1", "chr2", "chrM"], [1000, 2500, 300], annos=["first one", "", "mito genome"], holes=[(10, 5, "N"), (1200, 3, "R")])
+    assert open(prefix + ".ann").read().splitlines()[:3] == ["3800 3 11", "0 chr1 first one", "0 1000 1"]
+    b = nio.read_bns(prefix)
+    assert b.names == ["chr1", "chr2", "chrM"] and b.annos == ["first one", "", "mito genome"] and b.l_pac == 3800
+    assert b.offsets == [0, 1000, 3500] and b.lengths == [1000, 2500, 300] and b.n_ambs == [1, 1, 0] and b.holes == [(10, 5, "N"), (1200, 3, "R")]
+    assert b.sequence_index() == [0, 1000, 3500, 3800]                      # SequenceData's sequence index (sequence_pac.cpp:214-226)
+    assert b.locate(999) == (0, 999) and b.locate(1000) == (1, 0) and b.locate(3799) == (2, 299)
+    with open(prefix + ".amb", "w") as f:
+        f.write("3801 3 0\n")
+    with pytest.raises(nio.FileMismatch):
+        nio.read_bns(prefix)
+
+
+@pytest.mark.gpu
+def test_files_to_sam_multi_sequence_reference(tmp_path, cuda):
+    """a reference of three sequences (.ann / .amb next to the index): @SQ per sequence, RNAME and POS relative to the read's sequence,
+    in the best-mapping and the all-mapping flows; all-mapping drops seeds that straddle two sequences"""
+    import io as _io, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import align_fastq
+    rng = np.random.default_rng(41)
+    lens = [30_000, 50_000, 20_000]
+    text = rng.integers(0, 4, sum(lens), dtype=np.uint8)
+    prefix = str(tmp_path / "g")
+    nio.save_fmindex(prefix, O.FMIndex(text))
+    nio.write_wpac(prefix + ".wpac", text.size, O.pack(text, 2, True))
+    nio.write_bns(prefix, ["chrA", "chrB", "chrC"], lens)
+    starts = [0, 30_000, 80_000]
+    n = 90
+    where = []
+    with open(prefix + ".fastq", "w") as f:
+        for i in range(n):
+            k = i % 3
+            p = int(rng.integers(0, lens[k] - 100))
+            r = text[starts[k] + p: starts[k] + p + 100].copy()
+            if i % 2:
+                r = (3 - r)[::-1]
+            where.append((k, p))
+            f.write("@read%d\n%s\n+\n%s\n" % (i, "".join("ACGT"[c] for c in r), "I" * 100))
+    for flow in (align_fastq.main, align_fastq.main_all):
+        buf = _io.StringIO()
+        flow(prefix, prefix + ".fastq", buf, device=cuda)
+        text_out = buf.getvalue().splitlines()
+        assert [ln for ln in text_out if ln.startswith("@SQ")] == ["@SQ\tSN:chrA\tLN:30000", "@SQ\tSN:chrB\tLN:50000", "@SQ\tSN:chrC\tLN:20000"]
+        recs = [ln.split("\t") for ln in text_out if not ln.startswith("@")]
+        assert len(recs) == n
+        for ln in recs:
+            k, p = where[int(ln[0][4:])]
+            assert ln[2] == "chr" + "ABC"[k] and int(ln[3]) - 1 == p and ln[5] == "100M", ln[:6]
+
+
 @pytest.mark.gpu
 def test_files_to_sam_all_mapping_example(tmp_path, cuda):
     """tools/align_fastq.py --all: a genome with a 3-copy element; reads from the element come back once per copy (MAPQ 255), unique reads once"""

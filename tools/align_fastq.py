@@ -3,7 +3,8 @@
 SAM lines through nvBowtie's single-end best-mapping driver (nvbio_amd.aligner.best_approx = Aligner::best_approx: seeding
 passes, randomized hit selection seeded by the read names, quality-aware extension, give-up counters, MAPQ, traceback).
 Reads may differ in length.  A usage example, not nvBowtie's CLI: the mandatory SAM fields and the tags SamOutput writes (NM, AS, XM, XO, XG, MD from the finished
-alignments; nvbio/io/output/output_sam.cpp:316-366), single reference sequence, no read groups.
+alignments; nvbio/io/output/output_sam.cpp:316-366); the reference's sequences come from <prefix>.ann / .amb when present (else one
+sequence), no read groups.
 
     python tools/align_fastq.py <index prefix> <reads.fastq> [out.sam | out.bam]
     python tools/align_fastq.py --all <index prefix> <reads.fastq> [out.sam | out.bam]     (every alignment of every read, Aligner::all)
@@ -17,10 +18,37 @@ import nvbio_amd as nvb
 from nvbio_amd import io as nio, aligner as A
 
 
+def _rname_pos(ref, pos):
+    """(RNAME, 1-based POS) of a genome coordinate"""
+    name, p = ref.locate(pos)
+    return name, p + 1
+
+
 def cigar_string(words, length):
     """io::Cigar words are stored end-first; SAM wants them start-first"""
     ops = [(int(w) & 3, (int(w) & 0xFFFF) >> 2) for w in words[:length]][::-1]
     return "".join("%d%s" % (n, "MIDS"[t]) for t, n in ops) or "*"
+
+
+class Reference:
+    """Sequence names and offsets of the reference: <prefix>.ann / .amb when they exist (BWA-style, io.read_bns), else one sequence `ref_name`."""
+
+    def __init__(self, prefix, n_genome, ref_name):
+        import os
+        self.bns = nio.read_bns(prefix) if os.path.exists(prefix + ".ann") and os.path.exists(prefix + ".amb") else None
+        self.names = self.bns.names if self.bns else [ref_name]
+        self.index = self.bns.sequence_index() if self.bns else [0, n_genome]
+
+    def header(self):
+        return "@HD\tVN:1.0\tSO:unsorted\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (nm, self.index[k + 1] - self.index[k]) for k, nm in enumerate(self.names)) + \
+               "@PG\tID:nvbio_amd\tPN:nvbio_amd\n"
+
+    def locate(self, pos):
+        """genome coordinate -> (RNAME, 0-based coordinate inside that sequence)"""
+        if self.bns is None:
+            return self.names[0], pos
+        k, p = self.bns.locate(pos)
+        return self.names[k], p
 
 
 def main(prefix, fastq, out=sys.stdout, device="cuda", ref_name="ref"):
@@ -39,7 +67,8 @@ def main(prefix, fastq, out=sys.stdout, device="cuda", ref_name="ref"):
     best = r["best"].cpu().numpy().view(np.uint64)            # finished: m_align = the traceback window's begin, m_ed, final score
     mapq, cig, clen = r["mapq"].cpu().numpy(), r["cigar"].cpu().numpy().view(np.uint16), r["cigar_len"].cpu().numpy()
     source, mds = r["source"].cpu().numpy(), r["mds"].cpu().numpy()
-    out.write("@HD\tVN:1.0\tSO:unsorted\n@SQ\tSN:%s\tLN:%d\n@PG\tID:nvbio_amd\tPN:nvbio_amd\n" % (ref_name, n_genome))
+    ref = Reference(prefix, n_genome, ref_name)
+    out.write(ref.header())
     for i in range(n):
         w, pos = int(best[0, i] & 0xFFFFFFFF), int(best[0, i] >> 32)
         seq, qual = reads.symbols[index[i]:index[i + 1]], reads.quals[index[i]:index[i + 1]]
@@ -51,7 +80,7 @@ def main(prefix, fastq, out=sys.stdout, device="cuda", ref_name="ref"):
         s, q = (np.where(seq < 4, 3 - seq, 4)[::-1], qual[::-1]) if rc else (seq, qual)
         md, mm, gapo, gape = nio.sam_md_string(mds[i])
         out.write("%s\t%d\t%s\t%d\t%d\t%s\t*\t0\t0\t%s\t%s\tNM:i:%d\tAS:i:%d\tXM:i:%d\tXO:i:%d\tXG:i:%d\tMD:Z:%s\n" % (
-            reads.names[i], 16 if rc else 0, ref_name, pos + int(source[i, 0]) + 1, int(mapq[i]), cigar_string(cig[i], int(clen[i])),
+            reads.names[i], 16 if rc else 0, *_rname_pos(ref, pos + int(source[i, 0])), int(mapq[i]), cigar_string(cig[i], int(clen[i])),
             "".join("ACGTN"[c] for c in s), "".join(chr(int(x) + 33) for x in q), ed, score, mm, gapo, gape, md or "*"))
 
 
@@ -66,9 +95,11 @@ def main_all(prefix, fastq, out=sys.stdout, device="cuda", ref_name="ref", **par
         raise SystemExit("align_fastq: no reads")
     index = np.asarray(reads.sequence_index, dtype=np.int64)
     batch = A.ReadBatch.from_ragged(torch.from_numpy(reads.symbols).to(device), torch.from_numpy(index).to(device), torch.from_numpy(reads.quals).to(device))
-    r = A.all_mapping(data.index(), None, batch, genome_words, n_genome, A.Params(hits_stride=32, **param_overrides), cigar_stride=64)
+    ref = Reference(prefix, n_genome, ref_name)
+    r = A.all_mapping(data.index(), None, batch, genome_words, n_genome, A.Params(hits_stride=32, **param_overrides), cigar_stride=64,
+                      sequence_index=ref.index)                       # seeds straddling two sequences are dropped (mark_straddling)
     torch.cuda.synchronize()
-    out.write("@HD\tVN:1.0\tSO:unsorted\n@SQ\tSN:%s\tLN:%d\n@PG\tID:nvbio_amd\tPN:nvbio_amd\n" % (ref_name, n_genome))
+    out.write(ref.header())
     m = int(r["read_id"].numel())
     if m == 0:
         return
@@ -83,7 +114,7 @@ def main_all(prefix, fastq, out=sys.stdout, device="cuda", ref_name="ref", **par
         s, q = (np.where(seq < 4, 3 - seq, 4)[::-1], qual[::-1]) if rc else (seq, qual)
         md, mm, gapo, gape = nio.sam_md_string(mds[k])
         out.write("%s\t%d\t%s\t%d\t255\t%s\t*\t0\t0\t%s\t%s\tNM:i:%d\tAS:i:%d\tXM:i:%d\tXO:i:%d\tXG:i:%d\tMD:Z:%s\n" % (
-            reads.names[i], 16 if rc else 0, ref_name, pos + int(source[k, 0]) + 1, cigar_string(cig[k], int(clen[k])),
+            reads.names[i], 16 if rc else 0, *_rname_pos(ref, pos + int(source[k, 0])), cigar_string(cig[k], int(clen[k])),
             "".join("ACGTN"[c] for c in s), "".join(chr(int(x) + 33) for x in q), ed, score, mm, gapo, gape, md or "*"))
 
 
@@ -110,7 +141,8 @@ def main_paired(prefix, fastq1, fastq2, out=sys.stdout, device="cuda", ref_name=
         slots.append(dict(best=r[key_best].cpu().numpy().view(np.uint64)[0], cigar=r[key_tb]["cigar"].cpu().numpy().view(np.uint16),
                           clen=r[key_tb]["cigar_len"].cpu().numpy(), source=r[key_tb]["source"].cpu().numpy(), mds=r[key_mds].cpu().numpy(), mapq=r[key_mapq].cpu().numpy()))
     reads = (r1, r2)
-    out.write("@HD\tVN:1.0\tSO:unsorted\n@SQ\tSN:%s\tLN:%d\n@PG\tID:nvbio_amd\tPN:nvbio_amd\n" % (ref_name, n_genome))
+    ref = Reference(prefix, n_genome, ref_name)
+    out.write(ref.header())
 
     def fields(slot, i):
         w, pos = int(slot["best"][i] & 0xFFFFFFFF), int(slot["best"][i] >> 32)
@@ -138,19 +170,24 @@ def main_paired(prefix, fastq1, fastq2, out=sys.stdout, device="cuda", ref_name=
                 flags |= 0x8
             elif m["rc"]:
                 flags |= 0x20
+            rname, lpos = ref.locate(a["pos"])
             if m is not None:
-                pnext = m["pos"] + 1
+                m_rname, m_lpos = ref.locate(m["pos"])
+                rnext = "=" if m_rname == rname else m_rname
+                pnext = m_lpos + 1
                 tlen = max(m["pos"] + m["ref_len"], a["pos"] + a["ref_len"]) - min(m["pos"], a["pos"])
                 if m["pos"] < a["pos"]:
                     tlen = -tlen
+                if rnext != "=":
+                    tlen = 0
             else:
-                pnext, tlen = a["pos"] + 1, 0
+                rnext, pnext, tlen = "=", lpos + 1, 0
             w = a["w"]
             score, ed = ((w >> 1) & 0x1FFFF) * (-1 if w & 1 else 1), (w >> 18) & 0x3FF
             s, q = (np.where(seq < 4, 3 - seq, 4)[::-1], qual[::-1]) if a["rc"] else (seq, qual)
             md, mm, gapo, gape = nio.sam_md_string(slots[k]["mds"][i])
-            out.write("%s\t%d\t%s\t%d\t%d\t%s\t=\t%d\t%d\t%s\t%s\tNM:i:%d\tAS:i:%d\tXM:i:%d\tXO:i:%d\tXG:i:%d\tMD:Z:%s\n" % (
-                rd.names[i], flags, ref_name, a["pos"] + 1, int(slots[k]["mapq"][i]), cigar_string(slots[k]["cigar"][i], int(slots[k]["clen"][i])), pnext, tlen,
+            out.write("%s\t%d\t%s\t%d\t%d\t%s\t%s\t%d\t%d\t%s\t%s\tNM:i:%d\tAS:i:%d\tXM:i:%d\tXO:i:%d\tXG:i:%d\tMD:Z:%s\n" % (
+                rd.names[i], flags, rname, lpos + 1, int(slots[k]["mapq"][i]), cigar_string(slots[k]["cigar"][i], int(slots[k]["clen"][i])), rnext, pnext, tlen,
                 "".join("ACGTN"[c] for c in s), "".join(chr(int(x) + 33) for x in q), ed, score, mm, gapo, gape, md or "*"))
 
 
