@@ -195,6 +195,15 @@ int nvbio_hip_banded_gotoh_traceback_qual(
     int32_t* out_score, uint32_t* out_sink, uint32_t* out_source,
     uint16_t* out_cigar, uint32_t cigar_stride, uint32_t* out_cigar_len,
     void* temp, uint64_t temp_bytes, void* stream);
+/* the same, with score[] / sink[] filled by the caller with what nvbio_hip_banded_gotoh_score_qual reports for these jobs (skips the score pass) */
+int nvbio_hip_banded_gotoh_traceback_qual_known(
+    const nvbio_hip_gotoh_qual_scheme* scheme /* host */, int32_t type, uint32_t band_len,
+    const nvbio_hip_string_set* patterns, const uint8_t* quals, uint64_t n_quals,
+    const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len, uint32_t n,
+    int32_t* score /* in/out */, uint32_t* sink /* in/out */, uint32_t* out_source,
+    uint16_t* out_cigar, uint32_t cigar_stride, uint32_t* out_cigar_len,
+    void* temp, uint64_t temp_bytes, void* stream);
 
 /* Batched full-matrix Gotoh traceback.  Replaces
  *   BatchedAlignmentTraceback<CHECKPOINTS, stream, DeviceThreadScheduler>::enact (nvbio/alignment/batched.h:432-452)
@@ -438,7 +447,15 @@ int nvbio_hip_score_reduce_best_approx(uint32_t n_active, const uint32_t* active
                                        uint64_t* best_alignments, uint32_t best_stride, int32_t worst_score,
                                        uint32_t* trys, uint32_t* hit_counts,
                                        uint32_t n_ext, uint32_t min_ext, uint32_t max_ext, uint32_t max_effort,
-                                       const int32_t* known_score /* nullable: from nvbio_hip_score_best_setup */, void* stream);
+                                       const int32_t* known_score /* nullable: from nvbio_hip_score_best_setup */,
+                                       const uint32_t* hit_sink /* nullable uint2[n_hits]: the DP sinks */, uint32_t* best_sink /* nullable uint2[n_reads] */,
+                                       void* stream);
+/* hit_sink / best_sink (optional, both or neither): whenever a hit becomes a read's best alignment its DP sink is kept in best_sink[read].
+ * nvbio_hip_traceback_best_known then lays out, per traceback job, the score and sink the banded scorer would report over the job's
+ * window (the same DP the extension ran; unaligned entries: a failed alignment, score -2^30, sink (-1,-1)), and
+ * nvbio_hip_banded_gotoh_traceback_qual_known starts from them instead of scoring every job again.  Results are the traceback's. */
+int nvbio_hip_traceback_best_known(uint32_t n, const uint32_t* idx /* nullable */, const uint64_t* best_alignments, const uint32_t* best_sink,
+                                   int32_t* out_score, uint32_t* out_sink, void* stream);
 
 /* The paired-end form: score_reduce_paired_kernel (reduce_inl.h:355-500).  Per extension result the anchor mate's
  * {loc, sink (genome end), score, rc} and the opposite mate's {loc, sink, sink2, score, score2} (the stream's hit.* fields,

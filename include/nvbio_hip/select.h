@@ -125,7 +125,7 @@ inline void score_reduce(const ReduceBestApproxContext context, SeedHitDequeArra
     hip_check(nvbio_hip_score_reduce_best_approx(queues.in_size, reinterpret_cast<const uint32*>(queues.active_in.data()), queues.hit_begin.data(), d_hit_score,
                                                  queues.hit_loc.data(), reinterpret_cast<const uint32*>(queues.hit_seed.data()), d_read_len, fixed_read_len,
                                                  reinterpret_cast<uint64*>(best_data), best_stride, worst_score, context.m_trys, hits.counts,
-                                                 context.m_ext, params.min_ext, params.max_ext, params.max_effort, d_known_score, hip_stream),
+                                                 context.m_ext, params.min_ext, params.max_ext, params.max_effort, d_known_score, nullptr, nullptr, hip_stream),
               "nvbio_hip_score_reduce_best_approx");
 }
 

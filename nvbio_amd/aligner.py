@@ -79,7 +79,7 @@ def hits_per_read(n_active, n_ext, params):
     return 1
 
 
-def best_approx_score(fmi, rfmi, state, seed_queue, best, batch, genome_words, genome_len, aligner, params, band_len, stats):
+def best_approx_score(fmi, rfmi, state, seed_queue, best, batch, genome_words, genome_len, aligner, params, band_len, stats, best_sink=None):
     """Aligner::best_approx_score: the extension rounds of one seeding pass (`state` = select_init's output)."""
     active = seed_queue.to(torch.int32)                                   # pack_read(params.top_seed), defs.h:185-205
     if params.top_seed & 1:
@@ -100,15 +100,18 @@ def best_approx_score(fmi, rfmi, state, seed_queue, best, batch, genome_words, g
             pb, pl, tb, tl, _, score, job_hit = sel.score_best_setup(rid, loc, seed, best, band_len, genome_len, WORST_SCORE,
                                                                      fixed_read_len=batch.fixed_len, read_begin=batch.read_begin,
                                                                      read_len=batch.read_len, rc_offset=batch.rc_offset, compact=True)
+            hit_sink = torch.empty((loc.numel(), 2), dtype=torch.int32, device=loc.device) if best_sink is not None else None
             if job_hit.numel():
                 patterns = PackedStringSet(batch.fw_rc_words, 4, True, pb, pl, batch.fixed_len)
                 texts = PackedStringSet(genome_words, 2, True, tb, tl, 0)
-                job_score, _ = batch_banded_alignment_score(band_len, aligner, patterns, texts, max_pattern_length=batch.max_len, quals=batch.quals)
+                job_score, job_sink = batch_banded_alignment_score(band_len, aligner, patterns, texts, max_pattern_length=batch.max_len, quals=batch.quals)
                 sel.scatter_scores(job_hit, job_score, score)
+                if hit_sink is not None:
+                    sel.scatter_sinks(job_hit, job_sink, hit_sink)
             stats["dp_jobs"] = stats.get("dp_jobs", 0) + int(job_hit.numel())
         with _Stage(stats, "reduce"):
             sel.score_reduce_best_approx(best, state, active, hit_begin, score, loc, seed, WORST_SCORE, n_ext, params.min_ext, params.max_ext,
-                                         params.max_effort, fixed_read_len=batch.fixed_len, read_len=batch.read_len)
+                                         params.max_effort, fixed_read_len=batch.fixed_len, read_len=batch.read_len, hit_sink=hit_sink, best_sink=best_sink)
         stats["extensions"] += int(loc.numel()); stats["rounds"] += 1
         n_ext += n_multi
 
@@ -186,6 +189,9 @@ def best_approx(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=No
     stats = dict(extensions=0, rounds=0, seeding_passes=0, queue=[])
     if stage_times:
         stats["ms"] = {}
+    # the DP sink of every read's best alignment, kept by the reduction: the traceback re-scores the very job the extension scored
+    # (same window, pattern, scheme), so it can start from that score and sink instead
+    best_sink = torch.full((n, 2), -1, dtype=torch.int32, device=dev) if traceback else None
     for seeding_pass in range(params.max_reseed + 1):
         if seed_queue.numel() == 0:
             break
@@ -195,7 +201,7 @@ def best_approx(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=No
                                                      retry=seeding_pass, fw=params.fw, rc=params.rc, in_queue=seed_queue, hits_stride=hits_stride)
         with _Stage(stats, "select_init"):
             state = sel.SelectState(hits, counts, name_arena, params.max_effort_init, params.randomized, params.top_seed)
-        best_approx_score(fmi, rfmi, state, seed_queue, best, batch, genome_words, genome_len, aligner, params, band_len, stats)
+        best_approx_score(fmi, rfmi, state, seed_queue, best, batch, genome_words, genome_len, aligner, params, band_len, stats, best_sink)
         sel.mark_unaligned(seed_queue, best, reseed)                               # aligner_init.cu:421-444
         seed_queue = sel.copy_flagged(seed_queue, reseed)                          # aligner_best_approx.h:273-283
     with _Stage(stats, "mapq"):
@@ -212,7 +218,8 @@ def best_approx(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=No
                 valid, pb, tbeg, tlen, plen = sel.traceback_best_setup(best.data, n, band_len, genome_len, 0, batch.rc_offset, read_begin=batch.read_begin,
                                                                       read_len=batch.read_len)
             pat, txt = PackedStringSet(reads_fw_rc, 4, True, pb, plen, batch.fixed_len), PackedStringSet(genome_words, 2, True, tbeg, tlen, 0)
-            tb = batch_banded_alignment_traceback(band_len, aligner, pat, txt, max_pattern_length=L, quals=quals, cigar_stride=cigar_stride)
+            tb = batch_banded_alignment_traceback(band_len, aligner, pat, txt, max_pattern_length=L, quals=quals, cigar_stride=cigar_stride,
+                                                  known=sel.traceback_best_known(best.data, best_sink, n))
         out.update(cigar=tb["cigar"], cigar_len=tb["cigar_len"], source=tb["source"], sink=tb["sink"], tb_score=tb["score"],
                    aligned_ids=torch.nonzero(best.is_aligned(0)).squeeze(1))
         if finish:

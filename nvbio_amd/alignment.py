@@ -209,8 +209,9 @@ class BatchedBandedAlignmentTraceback:
     max_temp_storage = min_temp_storage
 
     def enact(self, aligner, patterns, texts, out_score, out_sink, out_source, out_cigar, out_cigar_len,
-              max_pattern_length=0, max_text_length=0, quals=None, temp=None):
-        """out_cigar: int16 [n, cigar_stride] device tensor holding the io::Cigar uint16 bit patterns."""
+              max_pattern_length=0, max_text_length=0, quals=None, temp=None, known=False):
+        """out_cigar: int16 [n, cigar_stride] device tensor holding the io::Cigar uint16 bit patterns.  known: out_score / out_sink hold on
+        entry what the banded scorer reports for these jobs (quality-aware scheme only): the score pass is skipped."""
         n = len(patterns)
         assert len(texts) == n
         if patterns.length is None:
@@ -235,8 +236,8 @@ class BatchedBandedAlignmentTraceback:
             check(err, "nvbio_hip_banded_sw_traceback")
         elif isinstance(aligner.scheme, SmithWatermanScoringScheme):
             assert quals is not None and quals.dtype == torch.uint8 and quals.is_cuda and quals.is_contiguous()
-            err = lib().nvbio_hip_banded_gotoh_traceback_qual(
-                C.byref(sc), aligner.type, self.band_len, C.byref(ps), C.c_void_p(quals.data_ptr()), quals.numel(), C.byref(ts), *tail)
+            fn = lib().nvbio_hip_banded_gotoh_traceback_qual_known if known else lib().nvbio_hip_banded_gotoh_traceback_qual
+            err = fn(C.byref(sc), aligner.type, self.band_len, C.byref(ps), C.c_void_p(quals.data_ptr()), quals.numel(), C.byref(ts), *tail)
             check(err, "nvbio_hip_banded_gotoh_traceback_qual")
         else:
             err = lib().nvbio_hip_banded_gotoh_traceback(C.byref(sc), aligner.type, self.band_len, C.byref(ps), C.byref(ts), *tail)
@@ -246,20 +247,21 @@ class BatchedBandedAlignmentTraceback:
 
 
 def batch_banded_alignment_traceback(band_len, aligner, patterns, texts, max_pattern_length=0, max_text_length=0,
-                                     quals=None, cigar_stride=None):
-    """One call form: returns dict(score[n], sink[n,2], source[n,2], cigar[n,stride] int16, cigar_len[n])."""
+                                     quals=None, cigar_stride=None, known=None):
+    """One call form: returns dict(score[n], sink[n,2], source[n,2], cigar[n,stride] int16, cigar_len[n]).  known = (score int32[n],
+    sink int32[n,2]) of every job as the banded scorer reports them, when the caller has them already (taken over as outputs)."""
     n = len(patterns)
     dev = patterns.words.device
     maxM = max_pattern_length or patterns.fixed_length
     if cigar_stride is None:
         cigar_stride = min(int(maxM) + band_len + 2, 64)
-    out = dict(score=torch.empty(n, dtype=torch.int32, device=dev),
-               sink=torch.empty((n, 2), dtype=torch.int32, device=dev),
+    out = dict(score=known[0] if known else torch.empty(n, dtype=torch.int32, device=dev),
+               sink=known[1] if known else torch.empty((n, 2), dtype=torch.int32, device=dev),
                source=torch.empty((n, 2), dtype=torch.int32, device=dev),
                cigar=torch.zeros((max(n, 1), cigar_stride), dtype=torch.int16, device=dev),
                cigar_len=torch.empty(n, dtype=torch.int32, device=dev))
     BatchedBandedAlignmentTraceback(band_len).enact(aligner, patterns, texts, out["score"], out["sink"], out["source"],
-                                                    out["cigar"], out["cigar_len"], max_pattern_length, max_text_length, quals)
+                                                    out["cigar"], out["cigar_len"], max_pattern_length, max_text_length, quals, known=bool(known))
     return out
 
 

@@ -362,6 +362,9 @@ namespace {
 int score_noqual(const void* scheme, int32_t type, uint32_t band_len, const nvbio_hip_string_set* patterns, const uint8_t*, uint64_t,
                  const nvbio_hip_string_set* texts, uint32_t max_pattern_len, uint32_t n, int32_t* out_score, uint32_t* out_sink, void* stream)
 { return nvbio_hip_banded_gotoh_score(static_cast<const nvbio_hip_gotoh_scheme*>(scheme), type, band_len, patterns, texts, max_pattern_len, 0, n, out_score, out_sink, stream); }
+// the caller filled out_score / out_sink with what the scorer reports for every job (nvbio_hip_banded_gotoh_traceback_qual_known)
+int score_prefilled(const void*, int32_t, uint32_t, const nvbio_hip_string_set*, const uint8_t*, uint64_t, const nvbio_hip_string_set*, uint32_t, uint32_t, int32_t*, uint32_t*, void*)
+{ return hipSuccess; }
 int score_qual(const void* scheme, int32_t type, uint32_t band_len, const nvbio_hip_string_set* patterns, const uint8_t* quals, uint64_t n_quals,
                const nvbio_hip_string_set* texts, uint32_t max_pattern_len, uint32_t n, int32_t* out_score, uint32_t* out_sink, void* stream)
 { return nvbio_hip_banded_gotoh_score_qual(static_cast<const nvbio_hip_gotoh_qual_scheme*>(scheme), type, band_len, patterns, quals, n_quals, texts, max_pattern_len, 0, n, out_score, out_sink, stream); }
@@ -389,14 +392,14 @@ NVB_API int nvbio_hip_banded_gotoh_traceback(
                             out_cigar, cigar_stride, out_cigar_len, temp, temp_bytes, to_stream(stream), score_noqual, scheme);
 }
 
-NVB_API int nvbio_hip_banded_gotoh_traceback_qual(
+static int banded_traceback_qual(
     const nvbio_hip_gotoh_qual_scheme* scheme, int32_t type, uint32_t band_len,
     const nvbio_hip_string_set* patterns, const uint8_t* quals, uint64_t n_quals,
     const nvbio_hip_string_set* texts,
     uint32_t max_pattern_len, uint32_t max_text_len, uint32_t n,
     int32_t* out_score, uint32_t* out_sink, uint32_t* out_source,
     uint16_t* out_cigar, uint32_t cigar_stride, uint32_t* out_cigar_len,
-    void* temp, uint64_t temp_bytes, void* stream)
+    void* temp, uint64_t temp_bytes, void* stream, bool known)
 {
     (void)max_text_len;
     using namespace nvb;
@@ -411,7 +414,7 @@ NVB_API int nvbio_hip_banded_gotoh_traceback_qual(
                 std::max(tb_abs(scheme->text_gap_open), tb_abs(scheme->text_gap_ext))));
     for (int i = 0; i < 256; ++i) { p.mismatch[i] = scheme->mismatch[i]; A = std::max(A, tb_abs(scheme->mismatch[i])); }
     return traceback_common(p, A, type, band_len, patterns, texts, max_pattern_len, n, out_score, out_sink, out_source,
-                            out_cigar, cigar_stride, out_cigar_len, temp, temp_bytes, to_stream(stream), score_qual, scheme);
+                            out_cigar, cigar_stride, out_cigar_len, temp, temp_bytes, to_stream(stream), known ? score_prefilled : score_qual, scheme);
 }
 
 // SmithWatermanAligner / EditDistanceAligner in the band (sw_banded_inl.h:405-470, 748-800): with deletion == insertion the
@@ -437,4 +440,26 @@ NVB_API int nvbio_hip_banded_sw_traceback(
     const int64_t A = std::max(std::max(tb_abs(scheme->match), tb_abs(scheme->mismatch)), tb_abs(scheme->deletion));
     return traceback_common(p, A, type, band_len, patterns, texts, max_pattern_len, n, out_score, out_sink, out_source,
                             out_cigar, cigar_stride, out_cigar_len, temp, temp_bytes, to_stream(stream));
+}
+
+NVB_API int nvbio_hip_banded_gotoh_traceback_qual(
+    const nvbio_hip_gotoh_qual_scheme* scheme, int32_t type, uint32_t band_len,
+    const nvbio_hip_string_set* patterns, const uint8_t* quals, uint64_t n_quals, const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len, uint32_t n, int32_t* out_score, uint32_t* out_sink, uint32_t* out_source,
+    uint16_t* out_cigar, uint32_t cigar_stride, uint32_t* out_cigar_len, void* temp, uint64_t temp_bytes, void* stream)
+{
+    return banded_traceback_qual(scheme, type, band_len, patterns, quals, n_quals, texts, max_pattern_len, max_text_len, n, out_score, out_sink, out_source,
+                                 out_cigar, cigar_stride, out_cigar_len, temp, temp_bytes, stream, false);
+}
+
+// The same with score and sink of every job known beforehand (out_score / out_sink filled by the caller with what
+// nvbio_hip_banded_gotoh_score_qual reports for these very jobs: the extension stage already ran that DP): skips the score pass.
+NVB_API int nvbio_hip_banded_gotoh_traceback_qual_known(
+    const nvbio_hip_gotoh_qual_scheme* scheme, int32_t type, uint32_t band_len,
+    const nvbio_hip_string_set* patterns, const uint8_t* quals, uint64_t n_quals, const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len, uint32_t n, int32_t* score, uint32_t* sink, uint32_t* out_source,
+    uint16_t* out_cigar, uint32_t cigar_stride, uint32_t* out_cigar_len, void* temp, uint64_t temp_bytes, void* stream)
+{
+    return banded_traceback_qual(scheme, type, band_len, patterns, quals, n_quals, texts, max_pattern_len, max_text_len, n, score, sink, out_source,
+                                 out_cigar, cigar_stride, out_cigar_len, temp, temp_bytes, stream, true);
 }

@@ -62,11 +62,13 @@ score_reduce_best_approx_kernel(uint32_t n_active, const uint32_t* __restrict__ 
                                 const int32_t* __restrict__ hit_score, const uint32_t* __restrict__ hit_loc, const uint32_t* __restrict__ hit_seed,
                                 const uint32_t* __restrict__ read_len, uint32_t fixed_len, uint2* __restrict__ best, uint32_t best_stride,
                                 int32_t worst_score, uint32_t* __restrict__ trys, uint32_t* __restrict__ hit_counts,
-                                uint32_t n_ext, uint32_t min_ext, uint32_t max_ext, uint32_t max_effort, const int32_t* __restrict__ known_score)
+                                uint32_t n_ext, uint32_t min_ext, uint32_t max_ext, uint32_t max_effort, const int32_t* __restrict__ known_score,
+                                const uint2* __restrict__ hit_sink, uint2* __restrict__ best_sink)
 {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= n_active) return;
     const uint32_t read_id = active[t] & 0x7FFFFFFFu;
+    uint2 s1 = make_uint2(0u, 0u); bool s1_new = false;      // the DP sink of a new best alignment (kept for the traceback, which can then skip its score pass)
     const uint2 b1 = best[read_id], b2 = best[read_id + best_stride];
     IoAln a1 = { b1.x, b1.y }, a2 = { b2.x, b2.y };
     const uint32_t len = read_len ? read_len[read_id] : fixed_len;
@@ -80,7 +82,7 @@ score_reduce_best_approx_kernel(uint32_t n_active, const uint32_t* __restrict__ 
         const int32_t score = known != INT32_MIN ? known : max(hit_score[i], worst_score);
         const uint32_t g_pos = hit_loc[i], seed = hit_seed[i], rc = (seed >> 13) & 1u, top_flag = (seed >> 14) & 1u;
         if ((rc == io_aln_rc(a1) && g_pos == a1.align) || (rc == io_aln_rc(a2) && g_pos == a2.align)) continue;
-        if (score > io_aln_score(a1)) { tr = max_effort; a2 = a1; a1 = io_aln_make(g_pos, 0u, score, rc); }
+        if (score > io_aln_score(a1)) { tr = max_effort; a2 = a1; a1 = io_aln_make(g_pos, 0u, score, rc); if (best_sink) { s1 = hit_sink[i]; s1_new = true; } }
         else if (score > io_aln_score(a2) && distinct_alignments(a1.align, io_aln_rc(a1), g_pos, rc, len / 2u)) { tr = max_effort; a2 = io_aln_make(g_pos, 0u, score, rc); }
         else if (tr > 0u) {
             const uint32_t idx = uint32_t(i - hb);
@@ -91,6 +93,23 @@ score_reduce_best_approx_kernel(uint32_t n_active, const uint32_t* __restrict__ 
     if (erase) hit_counts[read_id] = 0u;
     best[read_id] = make_uint2(a1.w, a1.align);
     best[read_id + best_stride] = make_uint2(a2.w, a2.align);
+    if (s1_new) best_sink[read_id] = s1;
+}
+
+// score and sink of every best alignment as the banded scorer reports them over the traceback's window (the same window and pattern
+// as the extension that found it): what nvbio_hip_banded_gotoh_traceback_qual_known takes.  Unaligned entries: a failed alignment.
+__global__ void __launch_bounds__(256)
+traceback_best_known_kernel(uint32_t n, const uint32_t* __restrict__ idx, const uint2* __restrict__ best, const uint2* __restrict__ best_sink,
+                            int32_t* __restrict__ out_score, uint2* __restrict__ out_sink)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = idx ? idx[i] : i;
+    const uint2 a = best[r];
+    const bool aligned = a.y != 0xFFFFFFFFu;
+    const int32_t m = int32_t((a.x >> 1) & 0x1FFFFu);
+    out_score[i] = aligned ? ((a.x & 1u) ? -m : m) : -(1 << 30);
+    out_sink[i]  = aligned ? best_sink[r] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
 }
 
 // init_alignments_kernel (nvBowtie/bowtie2/cuda/aligner.h:323-346): both slots unaligned (pos -1, ed max) with the
@@ -595,8 +614,10 @@ NVB_API int nvbio_hip_score_reduce_best_approx(uint32_t n_active, const uint32_t
                                                const uint32_t* read_len, uint32_t fixed_read_len,
                                                uint64_t* best_alignments, uint32_t best_stride, int32_t worst_score,
                                                uint32_t* trys, uint32_t* hit_counts,
-                                               uint32_t n_ext, uint32_t min_ext, uint32_t max_ext, uint32_t max_effort, const int32_t* known_score, void* stream)
+                                               uint32_t n_ext, uint32_t min_ext, uint32_t max_ext, uint32_t max_effort, const int32_t* known_score,
+                                               const uint32_t* hit_sink, uint32_t* best_sink, void* stream)
 {
+    if ((hit_sink != nullptr) != (best_sink != nullptr)) return hipErrorInvalidValue;
     if (n_active == 0) return hipSuccess;
     if (!active_reads || !hit_begin || !hit_score || !hit_loc || !hit_seed || !best_alignments || best_stride == 0 || !trys || !hit_counts)
         return hipErrorInvalidValue;
@@ -604,7 +625,19 @@ NVB_API int nvbio_hip_score_reduce_best_approx(uint32_t n_active, const uint32_t
     g_last_kernel = "score_reduce_best_approx_kernel";
     hipLaunchKernelGGL(score_reduce_best_approx_kernel, dim3((n_active + 255u) / 256u), dim3(256), 0, to_stream(stream), n_active, active_reads,
                        hit_begin, hit_score, hit_loc, hit_seed, read_len, fixed_read_len, reinterpret_cast<uint2*>(best_alignments), best_stride,
-                       worst_score, trys, hit_counts, n_ext, min_ext, max_ext, max_effort, known_score);
+                       worst_score, trys, hit_counts, n_ext, min_ext, max_ext, max_effort, known_score, reinterpret_cast<const uint2*>(hit_sink),
+                       reinterpret_cast<uint2*>(best_sink));
+    return hipGetLastError();
+}
+
+NVB_API int nvbio_hip_traceback_best_known(uint32_t n, const uint32_t* idx, const uint64_t* best_alignments, const uint32_t* best_sink,
+                                           int32_t* out_score, uint32_t* out_sink, void* stream)
+{
+    if (n == 0) return hipSuccess;
+    if (!best_alignments || !best_sink || !out_score || !out_sink) return hipErrorInvalidValue;
+    g_last_kernel = "traceback_best_known_kernel";
+    hipLaunchKernelGGL(traceback_best_known_kernel, dim3((n + 255u) / 256u), dim3(256), 0, to_stream(stream), n, idx, reinterpret_cast<const uint2*>(best_alignments),
+                       reinterpret_cast<const uint2*>(best_sink), out_score, reinterpret_cast<uint2*>(out_sink));
     return hipGetLastError();
 }
 

@@ -108,6 +108,12 @@ def score_best_setup(hit_read_id, hit_loc, hit_seed, best, band_len, genome_len,
     return (pb, pl, tb, tl, ms, ks) if known else (pb, pl, tb, tl, ms)
 
 
+def scatter_sinks(job_hit, sinks, hit_sink):
+    """hit_sink[job_hit[j]] = sinks[j] (uint2 rows)."""
+    check(lib().nvbio_hip_scatter_rows(job_hit.numel(), _vp(job_hit), _vp(sinks), _vp(hit_sink), 8, current_stream_ptr()), "nvbio_hip_scatter_rows")
+    return hit_sink
+
+
 def scatter_scores(job_hit, scores, known_score):
     """known_score[job_hit[j]] = scores[j]: the DP scores of compacted jobs back at their hits."""
     check(lib().nvbio_hip_scatter_rows(job_hit.numel(), _vp(job_hit), _vp(scores), _vp(known_score), 4, current_stream_ptr()), "nvbio_hip_scatter_rows")
@@ -115,12 +121,12 @@ def scatter_scores(job_hit, scores, known_score):
 
 
 def score_reduce_best_approx(best, state, active, hit_begin, hit_score, hit_loc, hit_seed, worst_score, n_ext, min_ext, max_ext, max_effort,
-                             fixed_read_len=0, read_len=None, known_score=None):
+                             fixed_read_len=0, read_len=None, known_score=None, hit_sink=None, best_sink=None):
     data = best.data if hasattr(best, "data") else best
     check(lib().nvbio_hip_score_reduce_best_approx(active.numel(), _vp(active), _vp(hit_begin), _vp(hit_score), _vp(hit_loc), _vp(hit_seed),
                                                    _vp(read_len), int(fixed_read_len), _vp(data), data.shape[1], int(worst_score),
                                                    _vp(state.trys), _vp(state.counts), int(n_ext), int(min_ext), int(max_ext), int(max_effort), _vp(known_score),
-                                                   current_stream_ptr()), "nvbio_hip_score_reduce_best_approx")
+                                                   _vp(hit_sink), _vp(best_sink), current_stream_ptr()), "nvbio_hip_score_reduce_best_approx")
     return best
 
 
@@ -358,3 +364,13 @@ def sort_hits(hit_read_id, hit_loc, hit_seed):
     t = _all_temp(n, hit_loc.device)
     check(lib().nvbio_hip_sort_hits(n, _vp(hit_read_id), _vp(hit_loc), _vp(hit_seed), _vp(idx), _vp(first), _vp(t), t.numel(), current_stream_ptr()), "nvbio_hip_sort_hits")
     return idx, first
+
+
+def traceback_best_known(best_data, best_sink, n, idx=None):
+    """Score and sink of every best alignment as the banded scorer reports them over the traceback's window (kept by the reduction):
+    (score int32[m], sink int32[m, 2]) for batch_banded_alignment_traceback(known=...)."""
+    m = idx.numel() if idx is not None else n
+    dev = best_data.device
+    score = torch.empty(m, dtype=torch.int32, device=dev); sink = torch.empty((m, 2), dtype=torch.int32, device=dev)
+    check(lib().nvbio_hip_traceback_best_known(m, _vp(idx), _vp(best_data), _vp(best_sink), _vp(score), _vp(sink), current_stream_ptr()), "nvbio_hip_traceback_best_known")
+    return score, sink
