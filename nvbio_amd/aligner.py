@@ -438,7 +438,7 @@ def all_mapping(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=No
     stats["hits"], stats["ranges"] = n_hits, n_ranges
     seq_index = torch.tensor(sequence_index if sequence_index is not None else [0, genome_len], dtype=torch.int64, device=dev).to(torch.int32)
     table = sel._min_score_table(scheme, L, dev)
-    out_aln, out_read = [], []
+    out_aln, out_read, out_known = [], [], []
     B = params.batch_size
     for off in range(0, n_hits, B):
         cnt = min(n_hits - off, B)
@@ -457,14 +457,16 @@ def all_mapping(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=No
         with _Stage(stats, "score"):
             pb, pl, tb, tl = sel.score_all_setup(q, rid, loc, seed, band_len, genome_len, fixed_read_len=batch.fixed_len, read_begin=batch.read_begin,
                                                  read_len=batch.read_len, rc_offset=batch.rc_offset)
-            score, _ = batch_banded_alignment_score(band_len, aligner, PackedStringSet(batch.fw_rc_words, 4, True, pb, pl, batch.fixed_len),
-                                                    PackedStringSet(genome_words, 2, True, tb, tl, 0), max_pattern_length=L, quals=batch.quals)
+            score, sink = batch_banded_alignment_score(band_len, aligner, PackedStringSet(batch.fw_rc_words, 4, True, pb, pl, batch.fixed_len),
+                                                       PackedStringSet(genome_words, 2, True, tb, tl, 0), max_pattern_length=L, quals=batch.quals)
             fl, aln, arid = sel.score_all_output(q, rid, loc, seed, score, table, fixed_read_len=batch.fixed_len, read_len=batch.read_len)
             keep = fl.bool()
             out_aln.append(aln[keep]); out_read.append(arid[keep])
+            out_known.append((score[keep], sink[keep]))              # the traceback re-scores these very jobs: it starts from their sinks instead
     if not out_aln:
         return empty
     aln, arid = torch.cat(out_aln), torch.cat(out_read)
+    k_score, k_sink = torch.cat([k[0] for k in out_known]), torch.cat([k[1] for k in out_known])
     out = dict(read_id=arid, alignments_scored=aln.clone(), alignments=aln, stats=stats)
     m = aln.numel()
     if traceback and m:
@@ -475,7 +477,8 @@ def all_mapping(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=No
                 pb, pl, tb, tl = sel.traceback_all_setup(a, r, band_len, genome_len, fixed_read_len=batch.fixed_len, read_begin=batch.read_begin,
                                                          read_len=batch.read_len, rc_offset=batch.rc_offset)
                 pat, txt = PackedStringSet(batch.fw_rc_words, 4, True, pb, pl, batch.fixed_len), PackedStringSet(genome_words, 2, True, tb, tl, 0)
-                t = batch_banded_alignment_traceback(band_len, aligner, pat, txt, max_pattern_length=L, quals=batch.quals, cigar_stride=cigar_stride)
+                t = batch_banded_alignment_traceback(band_len, aligner, pat, txt, max_pattern_length=L, quals=batch.quals, cigar_stride=cigar_stride,
+                                                     known=(k_score[off:off + B].contiguous(), k_sink[off:off + B].contiguous()))
             with _Stage(stats, "finish"):
                 valid = torch.ones(a.numel(), dtype=torch.uint8, device=dev)
                 md, mdl = sel.finish_alignment(valid, pat, batch.quals, txt, t["cigar"], t["cigar_len"], t["source"], scheme, a, mds_stride=mds_stride)
