@@ -338,6 +338,10 @@ private:
         hip::device_vector<int32>  min_score(max_hits_per_round), hit_score(max_hits_per_round);
         hip::device_vector<uint8>  flag_temp(nvbio_hip_copy_flagged_temp_bytes(count));
         SeedHitDequeArrayDeviceView hits = { hit_data.data(), hits_stride, hit_counts.data() };
+        // the DP sink of every read's best alignment, kept by the reduction: the traceback re-scores the very job the extension scored,
+        // so it starts from that score and sink instead (nvbio_hip.h)
+        hip::device_vector<uint32> best_sink(size_t(count) * 2u);
+        hip_check(nvbio_hip_memset(best_sink.data(), 0xFF, uint64(count) * 8u, hip_stream), "nvbio_hip_memset");
 
         for (uint32 seeding_pass = 0; seeding_pass < params.max_reseed + 1; ++seeding_pass)
         {
@@ -350,7 +354,7 @@ private:
             map(reads.reversed, fmi, rfmi, seeding_pass, seed_queues, reseed.data(), hits, params, seed_freq.data(), params.fw, params.rc, hip_stream);
 
             best_approx_score<TYPE>(params, fmi, rfmi, aligner, genome_words, genome_n_words, genome_len, reads, band_len, seed_queue_size, seed_queue_in.data(),
-                                    hits, state, queues, pat_begin, txt_begin, txt_len, sinks, min_score, hit_score, stats, hip_stream);
+                                    hits, state, queues, pat_begin, txt_begin, txt_len, sinks, min_score, hit_score, stats, hip_stream, best_sink.data());
 
             // mark unaligned reads, copy the reads that need reseeding, swap the queues
             hip_check(nvbio_hip_mark_unaligned(seed_queue_size, seed_queue_in.data(), reinterpret_cast<const uint64*>(best_data_dvec.data()), reseed.data(), hip_stream), "nvbio_hip_mark_unaligned");
@@ -377,12 +381,15 @@ private:
             const PackedStringSetView<2, true>  texts(count, genome_words, genome_n_words, tb_txt.data(), tb_len.data(), 0u);
             const aln::AlignmentArrays alignments = { traceback_score.data(), cigar_source.data(), cigar_sink.data() };
             const aln::CigarArrays     cigars     = { cigar.data(), cigar_stride, cigar_len.data() };
+            hip_check(nvbio_hip_traceback_best_known(count, nullptr, reinterpret_cast<const uint64*>(best_data_dvec.data()), best_sink.data(), traceback_score.data(),
+                                                     cigar_sink.data(), hip_stream), "nvbio_hip_traceback_best_known");
             dispatch_band(band_len, [&](auto band) {
                 typedef aln::PackedTracebackStream<aln::GotohAligner<TYPE, aln::SmithWatermanScoringScheme>, PackedStringSetView<4, true>, PackedStringSetView<2, true> > stream_type;
                 const stream_type stream(aligner, patterns, texts, alignments, cigars, L, L + band_len, reads.quals, reads.n_quals);
                 typedef aln::BatchedBandedAlignmentTraceback<decltype(band)::value, 32u, stream_type> batch_type;
                 hip::device_vector<uint8> temp(batch_type::min_temp_storage(L, L + band_len, count));
-                batch_type().enact(stream, temp.size(), temp.data(), hip_stream);
+                batch_type batch; batch.known_sinks = true;       // traceback_score / cigar_sink hold the extension's results (below)
+                batch.enact(stream, temp.size(), temp.data(), hip_stream);
                 hip::synchronize(hip_stream);                     // temp is released on scope exit
             });
             // finish_alignment_best: MD strings, edit distances, final scores; best_data then holds what the output stage reads
@@ -633,10 +640,11 @@ private:
                            SeedHitDequeArrayDeviceView hits, SelectState& state, ScoringQueues& queues,
                            hip::device_vector<uint64>& pat_begin, hip::device_vector<uint64>& txt_begin, hip::device_vector<uint32>& txt_len,
                            hip::device_vector<uint32>& sinks, hip::device_vector<int32>& min_score, hip::device_vector<int32>& hit_score,
-                           Stats& stats, void* hip_stream)
+                           Stats& stats, void* hip_stream, uint32* best_sink = nullptr)
     {
         const uint32 L = reads.len;
         hip::device_vector<int32> known_score(pat_begin.size());
+        hip::device_vector<uint32> hit_sink(best_sink ? pat_begin.size() * 2u : 0u);       // the DP sinks, per hit (kept for the traceback)
         hip::device_vector<uint32> job_hit(pat_begin.size()), job_count(1);
         // active_read_queues.in_queue = pack_read( params.top_seed ) of the seed queue
         {
@@ -681,12 +689,13 @@ private:
                     aln::batch_banded_alignment_score<decltype(band)::value>(aligner, patterns, reads.quals, reads.n_quals, texts, sink_arrays, L, L + band_len, hip_stream);
                 });
                 hip_check(nvbio_hip_scatter_rows(n_jobs, job_hit.data(), hit_score.data(), known_score.data(), 4u, hip_stream), "nvbio_hip_scatter_rows");
+                if (best_sink) hip_check(nvbio_hip_scatter_rows(n_jobs, job_hit.data(), sinks.data(), hit_sink.data(), 8u, hip_stream), "nvbio_hip_scatter_rows");
             }
             stats.dp_jobs += n_jobs;
 
             // score_reduce with the give-up counters
             score_reduce(ReduceBestApproxContext(state.trys.data(), n_ext), hits, queues, known_score.data(), nullptr, L, best_data_dvec.data(), BATCH_SIZE,
-                         worst_score, params.select, nullptr, hip_stream);
+                         worst_score, params.select, nullptr, hip_stream, best_sink ? hit_sink.data() : nullptr, best_sink);
             stats.extensions += queues.hits_size; ++stats.rounds;
             n_ext += n_hits_per_read;
         }

@@ -282,14 +282,19 @@ struct BatchedBandedAlignmentTraceback
     static uint64 max_temp_storage(const uint32 max_pattern_len, const uint32 max_text_len, const uint32 stream_size)
     { return min_temp_storage(max_pattern_len, max_text_len, stream_size); }
 
+    /// known_sinks (not in the reference; nvBowtie's scheme only): the stream's score / sink arrays already hold what the banded scorer
+    /// reports for these jobs (the extension stage ran that DP), so the score pass is skipped
+    bool known_sinks;
+    BatchedBandedAlignmentTraceback() : known_sinks(false) {}
+
     void enact(stream_type stream, uint64 temp_size, uint8* temp, void* hip_stream = nullptr)
     {
         static_assert(BAND_LEN == 3 || BAND_LEN == 5 || BAND_LEN == 7 || BAND_LEN == 15 || BAND_LEN == 31, "unsupported BAND_LEN");
         static_assert(sizeof(io::Cigar) == 2, "io::Cigar must be a uint16 bit-field");
-        call(stream.aligner().scheme, stream, temp_size, temp, hip_stream);
+        call(stream.aligner().scheme, stream, temp_size, temp, hip_stream, known_sinks);
     }
 private:
-    static void call(const SimpleGotohScheme& scheme, stream_type& stream, uint64 temp_size, uint8* temp, void* hip_stream)
+    static void call(const SimpleGotohScheme& scheme, stream_type& stream, uint64 temp_size, uint8* temp, void* hip_stream, bool)
     {
         const nvbio_hip_gotoh_scheme sc = { scheme.m_match, scheme.m_mismatch, scheme.m_gap_open, scheme.m_gap_ext };
         const nvbio_hip_string_set p = stream.m_patterns.abi(), t = stream.m_texts.abi();
@@ -299,11 +304,11 @@ private:
                       reinterpret_cast<uint16*>(stream.m_cigars.cigar), stream.m_cigars.cigar_stride, stream.m_cigars.cigar_len,
                       temp, temp_size, hip_stream), "nvbio_hip_banded_gotoh_traceback");
     }
-    static void call(const SmithWatermanScoringScheme& scheme, stream_type& stream, uint64 temp_size, uint8* temp, void* hip_stream)
+    static void call(const SmithWatermanScoringScheme& scheme, stream_type& stream, uint64 temp_size, uint8* temp, void* hip_stream, bool known)
     {
         const nvbio_hip_gotoh_qual_scheme sc = scheme.abi();
         const nvbio_hip_string_set p = stream.m_patterns.abi(), t = stream.m_texts.abi();
-        hip_check(nvbio_hip_banded_gotoh_traceback_qual(&sc, int32(aligner_type::TYPE), BAND_LEN, &p, stream.m_quals, stream.m_n_quals, &t,
+        hip_check((known ? nvbio_hip_banded_gotoh_traceback_qual_known : nvbio_hip_banded_gotoh_traceback_qual)(&sc, int32(aligner_type::TYPE), BAND_LEN, &p, stream.m_quals, stream.m_n_quals, &t,
                       stream.max_pattern_length(), stream.max_text_length(), stream.size(),
                       stream.m_alignments.score, stream.m_alignments.sink, stream.m_alignments.source,
                       reinterpret_cast<uint16*>(stream.m_cigars.cigar), stream.m_cigars.cigar_stride, stream.m_cigars.cigar_len,

@@ -120,12 +120,13 @@ struct ReduceBestApproxContext
 /// score_reduce( context, pipeline, params ) (reduce.h:136-147) over the round's hits; hit_score = the raw DP scores
 inline void score_reduce(const ReduceBestApproxContext context, SeedHitDequeArrayDeviceView hits, const ScoringQueues& queues, const int32* d_hit_score,
                          const uint32* d_read_len, const uint32 fixed_read_len, io::Alignment* best_data, const uint32 best_stride,
-                         const int32 worst_score, const SelectParamsPOD params, const int32* d_known_score = nullptr, void* hip_stream = nullptr)
+                         const int32 worst_score, const SelectParamsPOD params, const int32* d_known_score = nullptr, void* hip_stream = nullptr,
+                         const uint32* d_hit_sink = nullptr, uint32* d_best_sink = nullptr)
 {
     hip_check(nvbio_hip_score_reduce_best_approx(queues.in_size, reinterpret_cast<const uint32*>(queues.active_in.data()), queues.hit_begin.data(), d_hit_score,
                                                  queues.hit_loc.data(), reinterpret_cast<const uint32*>(queues.hit_seed.data()), d_read_len, fixed_read_len,
                                                  reinterpret_cast<uint64*>(best_data), best_stride, worst_score, context.m_trys, hits.counts,
-                                                 context.m_ext, params.min_ext, params.max_ext, params.max_effort, d_known_score, nullptr, nullptr, hip_stream),
+                                                 context.m_ext, params.min_ext, params.max_ext, params.max_effort, d_known_score, d_hit_sink, d_best_sink, hip_stream),
               "nvbio_hip_score_reduce_best_approx");
 }
 
