@@ -244,6 +244,7 @@ def best_approx_score_paired(fmi, rfmi, state, seed_queue, anchor, best, best_o,
     if params.top_seed & 1:
         active = active | torch.tensor(-(1 << 31), dtype=torch.int32, device=active.device)
     n_ext = 0
+    n_valid_dev = torch.zeros((), dtype=torch.int64, device=active.device)
     while active.numel() and n_ext < params.max_ext:
         n_multi = hits_per_read(active.numel(), n_ext, params)
         with _Stage(stats, "select"):
@@ -267,7 +268,7 @@ def best_approx_score_paired(fmi, rfmi, state, seed_queue, anchor, best, best_o,
             o_out = sel.opposite_outputs(int(loc.numel()), WORST_SCORE, loc.device)
             sel.opposite_memo_lookup(rid, ow, anchor, memo, WORST_SCORE, o_out)
             idx = torch.nonzero(ow["valid"] == 1).squeeze(1)               # the jobs that are actually scored
-            n_valid = int(torch.count_nonzero(ow["valid"]))                # what the reference scores (stats)
+            n_valid_dev = n_valid_dev + torch.count_nonzero(ow["valid"])   # what the reference scores (stats; read once, after the rounds)
             stats["opposite_dp_jobs"] = stats.get("opposite_dp_jobs", 0) + int(idx.numel())
             if idx.numel():
                 ob = ow["genome_begin"].to(torch.int64)[idx] & 0xFFFFFFFF
@@ -286,8 +287,9 @@ def best_approx_score_paired(fmi, rfmi, state, seed_queue, anchor, best, best_o,
             sel.score_reduce_paired_best_approx(best, best_o, state, active, hit_begin, loc, hit_sink, hit_score, seed, o_loc, o_sink, o_sink2, o_score, o_score2,
                                                 anchor, params.pe_policy, params.pe_unpaired, WORST_SCORE, n_ext, params.min_ext, params.max_ext,
                                                 params.max_effort, L)
-        stats["extensions"] += int(loc.numel()); stats["opposite_extensions"] += n_valid; stats["rounds"] += 1
+        stats["extensions"] += int(loc.numel()); stats["rounds"] += 1
         n_ext += n_multi
+    stats["opposite_extensions"] += int(n_valid_dev)
 
 
 def best_approx_paired(fmi, rfmi, sym1, sym2, genome_words, genome_len, params=None, scheme=None, names=None, qual_value=30, traceback=True,
