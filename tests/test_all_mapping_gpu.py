@@ -188,3 +188,26 @@ def test_cxx_all_mapping_driver_matches_oracle(cuda, config):
     assert (mds_len[:m] == e["mds_len"]).all()
     mk = np.arange(256)[None, :] < np.minimum(e["mds_len"], 256)[:, None]
     assert ((mds[:m] == e["mds"]) | ~mk).all()
+
+
+@pytest.mark.parametrize("bs", [1 << 20, 257])
+def test_all_mapping_matches_committed_vectors(cuda, bs):
+    """The HIP path against the committed fixture (tests/golden/all_mapping_vectors.npz): no oracle call at run time."""
+    import os
+    from tests.golden import make_all_mapping_vectors as G
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "all_mapping_vectors.npz"))
+    text, reads, quals = G.case()
+    host, rhost = O.FMIndex(text), O.FMIndex(text[::-1].copy())                     # (index construction only)
+    fmi, rfmi = nvb.FMIndexDevice.from_host(host, cuda), nvb.FMIndexDevice.from_host(rhost, cuda)
+    gw = W._pack_chunked(torch.from_numpy(text), 2, True).to(cuda)
+    index = np.zeros(len(reads) + 1, np.int64); index[1:] = np.cumsum([r.size for r in reads])
+    batch = A.ReadBatch.from_ragged(torch.from_numpy(np.concatenate(reads)).to(cuda), torch.from_numpy(index).to(cuda), torch.from_numpy(np.concatenate(quals)).to(cuda))
+    r = A.all_mapping(fmi, rfmi, batch, gw, text.size, A.Params(batch_size=bs), nvb.SmithWatermanScoringScheme(), cigar_stride=64, sequence_index=[0, 5000, text.size])
+    torch.cuda.synchronize()
+    m = g["read_id_%d" % bs].size
+    assert r["read_id"].numel() == m
+    assert (r["read_id"].cpu().numpy().view(np.uint32) == g["read_id_%d" % bs]).all()
+    assert (r["alignments_scored"].cpu().numpy().view(np.uint64) == g["scored_%d" % bs]).all() and (r["alignments"].cpu().numpy().view(np.uint64) == g["finished_%d" % bs]).all()
+    assert (r["cigar_len"].cpu().numpy().view(np.uint32) == g["cigar_len_%d" % bs]).all()
+    assert (r["cigar"].cpu().numpy().view(np.uint16)[:, :12] == g["cigar_%d" % bs]).all() and (r["mds_len"].cpu().numpy().view(np.uint32) == g["mds_len_%d" % bs]).all()
+    assert [r["stats"]["hits"], r["stats"]["ranges"], r["stats"]["unique"]] == g["stats_%d" % bs].tolist()

@@ -41,3 +41,20 @@ def test_all_mapping_oracle_reports_every_copy():
     fscore = np.where(fw & np.uint64(1), -1, 1) * ((fw >> np.uint64(1)) & np.uint64(0x1FFFF)).astype(np.int64)
     assert (fscore == score).all()
     assert e["stats"]["hits"] >= e["stats"]["unique"] >= rid.size == 9
+
+
+def test_all_mapping_oracle_matches_committed_vectors():
+    """The checker itself is pinned: tests/golden/all_mapping_vectors.npz (written by tests/golden/make_all_mapping_vectors.py) holds its
+    output on a seeded case -- one batch and 257-row batches, a two-sequence reference, ragged reads with qualities."""
+    import os
+    from tests.golden import make_all_mapping_vectors as G
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "all_mapping_vectors.npz"))
+    text, reads, quals = G.case()
+    for bs in (1 << 20, 257):
+        e = G.run(text, reads, quals, bs)
+        m = e["read_id"].size
+        assert m == g["read_id_%d" % bs].size and m > 200
+        assert (e["read_id"] == g["read_id_%d" % bs]).all() and (e["alignments_scored"] == g["scored_%d" % bs]).all() and (e["alignments"] == g["finished_%d" % bs]).all()
+        assert (e["tb"]["cigar_len"] == g["cigar_len_%d" % bs]).all() and (e["tb"]["cigar"][:m, :12] == g["cigar_%d" % bs]).all() and (e["mds_len"] == g["mds_len_%d" % bs]).all()
+        assert [e["stats"]["hits"], e["stats"]["ranges"], e["stats"]["unique"]] == g["stats_%d" % bs].tolist()
+    assert g["read_id_257"].size > g["read_id_%d" % (1 << 20)].size                      # de-duplication is per batch
