@@ -283,6 +283,14 @@ typedef struct nvbio_hip_fmindex {
                                    backward-search steps -- same ranges, bit for bit */
     uint32_t        ktab_k;
     uint32_t        _pad;
+    const uint32_t* dimer;      /* optional, NULL = none: the MI355X line-native index built by
+                                   nvbio_hip_fm_build_dimer_index (128-byte records holding a two-symbol BWT).
+                                   When attached, match / the seed mappers / locate consume two symbols
+                                   (two text positions) per 128-byte HBM line instead of one -- same SA ranges,
+                                   iterators and positions, bit for bit.  Set by nvbio_hip_fm_attach_dimer_index,
+                                   which also fills the constants below from the buffer's header */
+    uint32_t        dimer_p1, dimer_fill1;
+    uint32_t        dimer_S[4], dimer_T[4];
 } nvbio_hip_fmindex;
 
 /* Replaces nvbio::rank(fmi, k, c) (nvbio/fmindex/fmindex_inl.h:36-57) over n
@@ -304,6 +312,20 @@ int nvbio_hip_fm_rank_range(const nvbio_hip_fmindex* fmi, const uint32_t* range,
  * the seed holds a symbol > 3. */
 int nvbio_hip_fm_match(const nvbio_hip_fmindex* fmi, const nvbio_hip_string_set* seeds,
                        uint32_t n, uint32_t* out_range, void* stream);
+
+/* The line-native two-symbol index (layout: nvbio_amd/csrc/fmindex_dimer.h).  The reference's index spends one
+ * 32-byte record per symbol and range end (nvbio/io/fmindex/fmindex_impl.cu:305-322), which on MI355X is one
+ * 128-byte fabric request each; this one answers a backward-search step for TWO pattern symbols, or two LF steps
+ * of locate, from one 128-byte record.  Built on the device from `fmi` (its bwt_occ; dimer/ktab fields ignored):
+ *   out_dimer  nvbio_hip_fm_dimer_index_bytes(length) bytes, 128-byte aligned  (128 B header + 1 B per SA row)
+ *   temp       nvbio_hip_fm_build_dimer_index_temp_bytes(length) bytes
+ * nvbio_hip_fm_attach_dimer_index copies the header's constants into *fmi and sets fmi->dimer (synchronises
+ * `stream` once; pass dimer = NULL to detach); it fails with hipErrorInvalidValue if the buffer was built
+ * from a different index. */
+uint64_t nvbio_hip_fm_dimer_index_bytes(uint32_t length);
+uint64_t nvbio_hip_fm_build_dimer_index_temp_bytes(uint32_t length);
+int nvbio_hip_fm_build_dimer_index(const nvbio_hip_fmindex* fmi, uint32_t* out_dimer, void* temp, uint64_t temp_bytes, void* stream);
+int nvbio_hip_fm_attach_dimer_index(nvbio_hip_fmindex* fmi, const uint32_t* dimer, void* stream);
 
 /* Builds the optional k-mer table for `fmi` (fmi->ktab is ignored): out_ktab[2c..2c+1] =
  * match(fmi, kmer c), where kmer c has symbol t (0 = first) at bits [2t,2t+2) of c, for all

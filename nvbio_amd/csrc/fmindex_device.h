@@ -3,6 +3,7 @@
 // layout and design notes.
 #pragma once
 #include "common.h"
+#include "fmindex_dimer.h"
 
 namespace nvb {
 
@@ -14,6 +15,7 @@ struct Fmi {
     const uint32_t* ssa;
     const uint2*    ktab;       // optional: match range of every ktab_k-mer
     uint32_t        ktab_k;
+    Dimer           dm;         // optional: the line-native two-symbol index (fmindex_dimer.h); base == nullptr = none
 };
 
 inline Fmi make_fmi(const nvbio_hip_fmindex* h)
@@ -26,6 +28,14 @@ inline Fmi make_fmi(const nvbio_hip_fmindex* h)
     f.ssa = h->ssa;
     f.ktab = reinterpret_cast<const uint2*>(h->ktab);
     f.ktab_k = h->ktab ? h->ktab_k : 0u;
+    f.dm.base = h->dimer;
+    {   // the per-dimer arrays follow the plane records (fmindex_dimer.h); both counts derive from the length
+        const uint32_t n_rec = uint32_t((uint64_t(h->length) + 1u) >> 7) + 1u;
+        f.dm.pd_stride = uint32_t((uint64_t(h->length) + 1u) / 96u) + 1u;
+        f.dm.pd = h->dimer ? reinterpret_cast<const uint4*>(h->dimer + 32u + 32ull * n_rec) : nullptr;
+    }
+    f.dm.primary = h->primary; f.dm.p1 = h->dimer_p1; f.dm.fill1 = h->dimer_fill1;
+    for (int i = 0; i < 4; ++i) { f.dm.S[i] = h->dimer_S[i]; f.dm.T[i] = h->dimer_T[i]; }
     return f;
 }
 
@@ -152,10 +162,27 @@ __device__ __forceinline__ void fm_rank4_range(const Fmi& f, uint32_t x, uint32_
 }
 
 // ------------------------------------------------------------------ backward search
+// one step of the reference's loop body (fmindex_inl.h:333-339): the range of "cP" from the range [x,y] of P
+__device__ __forceinline__ uint2 fm_step(const Fmi& f, const uint32_t x, const uint32_t y, const uint32_t c)
+{
+    if (f.dm.base) return dm_step1(f.dm, x, y, c);
+    const uint2 r = fm_rank2(f, x - 1u, y, c);
+    return make_uint2(f.L2[c] + r.x + 1u, f.L2[c] + r.y);
+}
+// rank4 of both ends of the step from [x,y] (counts without L2), as the one-mismatch mappers use it
+__device__ __forceinline__ void fm_step4(const Fmi& f, const uint32_t x, const uint32_t y, uint4& lo, uint4& hi)
+{
+    if (f.dm.base) { lo = dm_rank4(f.dm, x); hi = dm_rank4(f.dm, y + 1u); }
+    else fm_rank4_range(f, x - 1u, y, lo, hi);
+}
+
 // match (fmindex_inl.h:307-341) with nvBowtie's symbol test (mapping_inl.h:83-97).
-// One lane = one seed; the seed is pulled 16 symbols per fetch.
+// One lane = one seed; the seed is pulled 16 symbols per fetch.  With the two-symbol index attached the
+// loop consumes symbol pairs: a non-empty range after a pair is the range after its two single steps; an
+// empty one is replayed singly, because the reference returns the raw (x,y) of the step that emptied it.
 __device__ __forceinline__ uint2 fm_match_from(const Fmi& f, const Stream& s, uint64_t begin, int32_t i, uint32_t x, uint32_t y)
 {
+    bool pairs = f.dm.base != nullptr;
     while (i >= 0 && x <= y)
     {
         // symbols [g0, g0+16) of the seed, g0 = 16-aligned group holding i
@@ -163,13 +190,22 @@ __device__ __forceinline__ uint2 fm_match_from(const Fmi& f, const Stream& s, ui
         uint64_t grp;   // 4 bits per symbol
         if (s.bits == 2)      grp = expand_2to4(fetch16_2bit(s, begin + g0));
         else                  grp = fetch16_4bit(s, begin + g0);
-        for (; i >= int32_t(g0) && x <= y; --i)
+        while (i >= int32_t(g0) && x <= y)
         {
             const uint32_t c = uint32_t(grp >> (4u * (uint32_t(i) - g0))) & 15u;
             if (c > 3u) return make_uint2(1u, 0u);
-            const uint2 r = fm_rank2(f, x - 1u, y, c);
-            x = f.L2[c] + r.x + 1u;
-            y = f.L2[c] + r.y;
+            if (pairs && i > int32_t(g0))
+            {
+                const uint32_t a = uint32_t(grp >> (4u * (uint32_t(i) - 1u - g0))) & 15u;
+                if (a <= 3u)
+                {
+                    const uint2 r = dm_step2(f.dm, x, y, a, c);
+                    if (r.x <= r.y) { x = r.x; y = r.y; i -= 2; continue; }
+                    pairs = false;
+                }
+            }
+            const uint2 r = fm_step(f, x, y, c);
+            x = r.x; y = r.y; --i;
         }
     }
     return make_uint2(x, y);
@@ -209,6 +245,7 @@ __device__ __forceinline__ uint2 fm_match(const Fmi& f, const Stream& s, uint64_
 // locate_ssa_iterator (fmindex_inl.h:511-545): LF-walk to the next sampled row.
 __device__ __forceinline__ uint2 fm_locate_it(const Fmi& f, uint32_t j)
 {
+    if (f.dm.base) return dm_locate_it(f.dm, j, f.sa_int - 1u);
     uint32_t t = 0;
     const uint32_t mask = f.sa_int - 1u;
     while ((j & mask) != 0u)

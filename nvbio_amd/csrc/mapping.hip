@@ -31,6 +31,7 @@ __device__ __forceinline__ uint2 match_range_x(const Fmi& f, const Stream& s, ui
 {
     uint32_t x = 0, y = f.length;
     uint32_t t_start = 0;
+    bool pairs = f.dm.base != nullptr;
     const uint32_t k = f.ktab_k;
     if (k != 0u && len >= k)
     {
@@ -56,14 +57,26 @@ __device__ __forceinline__ uint2 match_range_x(const Fmi& f, const Stream& s, ui
         const uint32_t cnt = (len - t0) < 16u ? (len - t0) : 16u;
         const uint64_t g0  = reverse ? begin + len - t0 - cnt : begin + t0;
         const uint64_t grp = (s.bits == 2) ? expand_2to4(fetch16_2bit(s, g0)) : fetch16_4bit(s, g0);
-        for (uint32_t u = 0; u < cnt && x <= y; ++u)
+        uint32_t u = 0;
+        while (u < cnt && x <= y)
         {
             uint32_t c = uint32_t(grp >> (4u * (reverse ? cnt - 1u - u : u))) & 15u;
             if (c > 3u) { has_n = true; return make_uint2(1u, 0u); }
             if (complement) c = 3u - c;
-            const uint2 r = fm_rank2(f, x - 1u, y, c);
-            x = f.L2[c] + r.x + 1u;
-            y = f.L2[c] + r.y;
+            if (pairs && u + 1u < cnt)
+            {
+                // two scan symbols per line fetch on the two-symbol index (see fm_match_from)
+                uint32_t a = uint32_t(grp >> (4u * (reverse ? cnt - 2u - u : u + 1u))) & 15u;
+                if (a <= 3u)
+                {
+                    if (complement) a = 3u - a;
+                    const uint2 r = dm_step2(f.dm, x, y, a, c);
+                    if (r.x <= r.y) { x = r.x; y = r.y; u += 2u; continue; }
+                    pairs = false;
+                }
+            }
+            const uint2 r = fm_step(f, x, y, c);
+            x = r.x; y = r.y; ++u;
         }
     }
     return make_uint2(x, y);
@@ -186,13 +199,24 @@ __device__ __forceinline__ SeedVec sv_complement(const SeedVec& q, const uint32_
 // match_range (mapping_inl.h:80-96) over scan symbols [a,b) of q
 __device__ __forceinline__ uint2 match_span(const Fmi& f, const SeedVec& q, const uint32_t a, const uint32_t b, uint2 r)
 {
-    for (uint32_t i = a; i < b && r.x <= r.y; ++i)
+    bool pairs = f.dm.base != nullptr;
+    uint32_t i = a;
+    while (i < b && r.x <= r.y)
     {
         const uint32_t c = sv_sym(q, i);
         if (c > 3u) return make_uint2(1u, 0u);
-        const uint2 k = fm_rank2(f, r.x - 1u, r.y, c);
-        r.x = f.L2[c] + k.x + 1u;
-        r.y = f.L2[c] + k.y;
+        if (pairs && i + 1u < b)
+        {
+            const uint32_t c2 = sv_sym(q, i + 1u);
+            if (c2 <= 3u)
+            {
+                const uint2 k = dm_step2(f.dm, r.x, r.y, c2, c);
+                if (k.x <= k.y) { r = k; i += 2u; continue; }
+                pairs = false;
+            }
+        }
+        r = fm_step(f, r.x, r.y, c);
+        ++i;
     }
     return r;
 }
@@ -242,7 +266,7 @@ __device__ __forceinline__ void map_one_mismatch(const SeedVec& q, uint32_t len1
     {
         const uint32_t c = sv_sym(q, i);
         uint4 lo, hi;
-        fm_rank4_range(f, base.x - 1u, base.y, lo, hi);
+        fm_step4(f, base.x, base.y, lo, hi);
         #pragma unroll 1
         for (uint32_t sub = 0; sub < 4u; ++sub)
         {

@@ -19,19 +19,48 @@ def _vp(t):
 class FMIndexDevice:
     """Device-resident FM-index in the reference's interleaved bwt|occ layout."""
 
-    def __init__(self, length, primary, L2, bwt_occ, ssa=None, sa_int=16, ktab=None, ktab_k=0):
+    def __init__(self, length, primary, L2, bwt_occ, ssa=None, sa_int=16, ktab=None, ktab_k=0, dimer=None, dimer_consts=None):
         assert bwt_occ.dtype == torch.int32 and bwt_occ.is_contiguous()
         assert bwt_occ.data_ptr() % 32 == 0
         self.length, self.primary, self.L2 = int(length), int(primary), [int(x) for x in L2]
         self.bwt_occ, self.ssa, self.sa_int = bwt_occ, ssa, int(sa_int)
         self.ktab, self.ktab_k = ktab, int(ktab_k)
+        self.dimer, self.dimer_consts = dimer, dimer_consts     # line-native two-symbol index + its header constants
+
+    def _copy(self, **kw):
+        d = dict(length=self.length, primary=self.primary, L2=self.L2, bwt_occ=self.bwt_occ, ssa=self.ssa, sa_int=self.sa_int,
+                 ktab=self.ktab, ktab_k=self.ktab_k, dimer=self.dimer, dimer_consts=self.dimer_consts)
+        d.update(kw)
+        return FMIndexDevice(**d)
+
+    def with_dimer(self):
+        """A copy of this index carrying the MI355X line-native two-symbol index (128-byte records, 1 byte per SA
+        row; nvbio_amd/csrc/fmindex_dimer.h), built on the device: match / the seed mappers / locate then consume
+        two symbols per HBM line.  Results are bit-identical."""
+        L = lib()
+        dev = self.bwt_occ.device
+        nbytes = int(L.nvbio_hip_fm_dimer_index_bytes(self.length))
+        buf = torch.empty(nbytes // 4 + 32, dtype=torch.int32, device=dev)
+        off = (-buf.data_ptr() % 128) // 4
+        dimer = buf[off:off + nbytes // 4]
+        tb = int(L.nvbio_hip_fm_build_dimer_index_temp_bytes(self.length))
+        temp = torch.empty(tb, dtype=torch.uint8, device=dev)
+        s = self._copy(dimer=None, dimer_consts=None, ktab=None, ktab_k=0).struct()
+        check(L.nvbio_hip_fm_build_dimer_index(C.byref(s), _vp(dimer), _vp(temp), tb, current_stream_ptr()), "nvbio_hip_fm_build_dimer_index")
+        check(L.nvbio_hip_fm_attach_dimer_index(C.byref(s), _vp(dimer), current_stream_ptr()), "nvbio_hip_fm_attach_dimer_index")
+        consts = (int(s.dimer_p1), int(s.dimer_fill1), [int(x) for x in s.dimer_S], [int(x) for x in s.dimer_T])
+        del temp
+        return self._copy(dimer=dimer, dimer_consts=consts)
+
+    def without_dimer(self):
+        return self._copy(dimer=None, dimer_consts=None)
 
     def with_ktab(self, k=12):
         """A copy of this index carrying the k-mer table accelerator (4^k uint2 entries in HBM)."""
         tab = torch.empty((4 ** k, 2), dtype=torch.int32, device=self.bwt_occ.device)
         s = self.struct()
         check(lib().nvbio_hip_fm_build_ktab(C.byref(s), k, _vp(tab), current_stream_ptr()), "nvbio_hip_fm_build_ktab")
-        return FMIndexDevice(self.length, self.primary, self.L2, self.bwt_occ, self.ssa, self.sa_int, tab, k)
+        return self._copy(ktab=tab, ktab_k=k)
 
     def with_dense_ssa(self, sa_int):
         """A copy of this index with the suffix array sampled every `sa_int` rows (power of two,
@@ -39,7 +68,7 @@ class FMIndexDevice:
         assert sa_int >= 1 and (sa_int & (sa_int - 1)) == 0
         rows = torch.arange(0, self.length + 1, sa_int, dtype=torch.int64, device=self.bwt_occ.device).to(torch.int32)
         ssa = locate(self, rows)
-        return FMIndexDevice(self.length, self.primary, self.L2, self.bwt_occ, ssa, sa_int, self.ktab, self.ktab_k)
+        return self._copy(ssa=ssa, sa_int=sa_int)
 
     def struct(self):
         s = FMIndexStruct()
@@ -50,6 +79,13 @@ class FMIndexDevice:
         s.ssa = self.ssa.data_ptr() if self.ssa is not None else None
         s.ktab = self.ktab.data_ptr() if self.ktab is not None else None
         s.ktab_k = self.ktab_k if self.ktab is not None else 0
+        if self.dimer is not None:
+            s.dimer = self.dimer.data_ptr()
+            s.dimer_p1, s.dimer_fill1 = self.dimer_consts[0], self.dimer_consts[1]
+            for i in range(4):
+                s.dimer_S[i], s.dimer_T[i] = self.dimer_consts[2][i], self.dimer_consts[3][i]
+        else:
+            s.dimer = None
         return s
 
     @staticmethod

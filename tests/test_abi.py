@@ -29,10 +29,11 @@ def test_library_exports_every_symbol():
 
 
 def test_struct_layouts_match_header():
-    # sizes the C compiler gives the ABI structs (LP64): 8+8+4+4+8+8+4+4 / 16 / 4+4+20+4+8+8
+    # sizes the C compiler gives the ABI structs (LP64): 8+8+4+4+8+8+4+4 / 16 / 4+4+20+4 +8+8+8 +4+4 +8 +4+4+16+16
     assert ctypes.sizeof(_lib.StringSetStruct) == 48
     assert ctypes.sizeof(_lib.GotohSchemeStruct) == 16
-    assert ctypes.sizeof(_lib.FMIndexStruct) == 64
+    assert ctypes.sizeof(_lib.FMIndexStruct) == 112
+    assert _lib.FMIndexStruct.dimer.offset == 64 and _lib.FMIndexStruct.dimer_S.offset == 80
 
 
 def test_invalid_arguments_are_rejected_without_a_gpu():

@@ -213,3 +213,91 @@ def test_dense_ssa_locate_is_identical(cuda, index, sa_int):
     assert (u32(nvb.lookup_ssa_iterator(fd, it)) == exp).all()
     if sa_int == 1:
         assert (u32(fd.ssa)[1:] == host.sa[1:]).all()
+
+
+# ------------------------------------------------------------------ the line-native two-symbol index
+def test_dimer_index_layout_equals_model(cuda, index):
+    """The device builder writes exactly the buffer the layout model describes (header constants, folded
+    counters, bit-planes, fillers at primary and at the SA = 1 row)."""
+    from tests import dimer_model as DM
+    text, host, dev = index
+    fd = dev.with_dimer()
+    got = u32(fd.dimer)
+    exp = DM.build(text, host.sa, host.L2)
+    assert got.size == exp.size
+    assert (got[:32] == exp[:32]).all(), (got[:32], exp[:32])
+    assert (got == exp).all()
+    p1, fill1, S, T = fd.dimer_consts
+    assert [p1, fill1] == [int(exp[3]), int(exp[4])] and S == [int(x) for x in exp[8:12]] and T == [int(x) for x in exp[12:16]]
+
+
+@pytest.mark.parametrize("bits,be", [(2, True), (2, False), (4, True), (4, False)])
+def test_dimer_match_is_identical(cuda, index, bits, be):
+    """Two symbols per step must not change a single range: odd and even lengths, seeds shorter than a pair,
+    N inside a pair (either half), absent seeds (the raw (x,y) of the emptying step), with and without the k-mer table."""
+    text, host, dev = index
+    rng = np.random.default_rng(40 + bits * 2 + be)
+    fd = dev.with_dimer()
+    variants = [fd, fd.with_ktab(5), fd.with_ktab(8)]
+    for length in (22, 21, 0, 1, 2, 33):
+        hs = make_seeds(rng, text, 20000, length, bits, be, with_n=True)
+        exp = host.match(hs)
+        ds = nvb.PackedStringSet.from_host(hs.words, bits, be, hs.begin, hs.length, device=cuda)
+        for f in variants:
+            got = u32(nvb.match(f, ds))
+            bad = np.nonzero((got != exp).any(1))[0]
+            assert bad.size == 0, (length, f.ktab_k, bad[:5], got[bad[:5]], exp[bad[:5]])
+    hs = make_seeds(rng, text, 5000, 22, bits, be)
+    ds = nvb.PackedStringSet.from_host(hs.words, bits, be, hs.begin, None, 22, device=cuda)
+    assert (u32(nvb.match(fd, ds)) == host.match(hs)).all()
+
+
+@pytest.mark.parametrize("sa_int", [16, 1, 4, 64])
+def test_dimer_locate_is_identical(cuda, index, sa_int):
+    """Two LF steps per record: same iterators (row, steps) and positions for every SA row, the rows around
+    primary and the SA = 1 row included."""
+    text, host, dev = index
+    n = host.length
+    base = dev if sa_int == 16 else dev.with_dense_ssa(sa_int)
+    fd = base.with_dimer()
+    rows = np.arange(0, n + 1, dtype=np.uint32)
+    if n > 200000:
+        rng = np.random.default_rng(5)
+        rows = np.concatenate([rng.integers(0, n + 1, 200000).astype(np.uint32),
+                               np.arange(max(host.primary, 5) - 5, min(host.primary + 5, n) + 1, dtype=np.uint32)])
+    exp_it = u32(nvb.locate_ssa_iterator(base, i32(rows, cuda)))
+    if sa_int == 16:
+        assert (exp_it == host.locate_ssa_iterator(rows)).all()
+    got_it = nvb.locate_ssa_iterator(fd, i32(rows, cuda))
+    bad = np.nonzero((u32(got_it) != exp_it).any(1))[0]
+    assert bad.size == 0, (bad[:5], rows[bad[:5]], u32(got_it)[bad[:5]], exp_it[bad[:5]], host.primary)
+    exp = host.locate(rows)
+    assert (u32(nvb.locate(fd, i32(rows, cuda))) == exp).all()
+    assert (u32(nvb.lookup_ssa_iterator(fd, got_it)) == exp).all()
+
+
+def test_dimer_filter_is_identical(cuda, index):
+    text, host, dev = index
+    rng = np.random.default_rng(8)
+    fd = dev.with_dimer()
+    hs = make_seeds(rng, text, 4000, 12 if host.length > 1000 else 3, 2, True)
+    total, eranges, eslots = host.filter_rank(hs)
+    ds = nvb.PackedStringSet.from_host(hs.words, 2, True, hs.begin, hs.length, device=cuda)
+    flt = nvb.FMIndexFilter()
+    assert flt.rank(fd, ds) == total
+    assert (u32(flt.ranges) == eranges).all()
+    if total:
+        e = min(total, 50000)
+        assert (u32(flt.locate(0, e)) == host.filter_locate(eranges, eslots, 0, e)).all()
+
+
+def test_dimer_attach_rejects_a_foreign_buffer(cuda, index):
+    import ctypes as C
+    from nvbio_amd._lib import lib
+    text, host, dev = index
+    fd = dev.with_dimer()
+    other = nvb.FMIndexDevice(dev.length, dev.primary ^ 1, dev.L2, dev.bwt_occ, dev.ssa, dev.sa_int)
+    s = other.struct()
+    assert lib().nvbio_hip_fm_attach_dimer_index(C.byref(s), C.c_void_p(fd.dimer.data_ptr()), None) == 1      # hipErrorInvalidValue
+    s = dev.struct()
+    assert lib().nvbio_hip_fm_attach_dimer_index(C.byref(s), C.c_void_p(fd.dimer.data_ptr()), None) == 0 and s.dimer == fd.dimer.data_ptr()

@@ -35,6 +35,7 @@ def test_seed_hit_sets(cuda, ragged):
     text[5000:5600] = np.tile(np.array([0, 1], dtype=np.uint8), 300)      # a repeat: wide SA ranges
     host = O.FMIndex(text)
     fmi = nvb.FMIndexDevice.from_host(host, cuda)
+    fdim = fmi.with_dimer()
     reads = make_reads(rng, text, 4000, ragged)
     hr = O.StringSet.from_lists(reads, 4, True)
     dr = nvb.PackedStringSet.from_host(hr.words, 4, True, hr.begin, hr.length, device=cuda)
@@ -55,6 +56,11 @@ def test_seed_hit_sets(cuda, ragged):
         for kk in (9, 12):
             kh, kc, kr = nvb.map_exact(fmi.with_ktab(kk), dr, params, max_len, retry=retry, fw=bool(fw), rc=bool(rc), in_queue=dq, hits_stride=stride)
             assert torch.equal(kh, gh) and torch.equal(kc, gc) and torch.equal(kr, gr), kk
+        # nor may the line-native two-symbol index (alone, and under the k-mer table)
+        for fv in (fdim, fdim.with_ktab(9)):
+            kh, kc, kr = nvb.map_exact(fv, dr, params, max_len, retry=retry, fw=bool(fw), rc=bool(rc), in_queue=dq, hits_stride=stride)
+            assert torch.equal(kc, gc) and torch.equal(kr, gr), fv.ktab_k
+            assert torch.equal(kh, gh), fv.ktab_k
         torch.cuda.synchronize()
         gh, gc, gr = gh.cpu().numpy().view(np.uint64), gc.cpu().numpy().view(np.uint32), gr.cpu().numpy()
         ids = queue if queue is not None else np.arange(4000)
@@ -94,7 +100,9 @@ def test_one_mismatch_seed_hit_sets(cuda, allow_sub, subseed):
                   retry=retry, rep_seeds=params.rep_seeds, fw=fw, rc=rc)
         algo = 2 if subseed == 0 else 1
         eh, ec, er = O.map_seeds(algo, subseed, host, rhost, hr, pd, sf, stride)
-        for f_dev, rf_dev in ((fmi, rfmi), (fmi.with_ktab(8), rfmi.with_ktab(8))):       # the k-mer table must not change anything
+        # neither the k-mer table nor the line-native two-symbol index may change anything
+        for f_dev, rf_dev in ((fmi, rfmi), (fmi.with_ktab(8), rfmi.with_ktab(8)), (fmi.with_dimer(), rfmi.with_dimer()),
+                              (fmi.with_dimer().with_ktab(8), rfmi.with_dimer())):
             gh, gc, gr = nvb.map_seeds(f_dev, rf_dev, dr, params, max_len, allow_sub=allow_sub, subseed_len=subseed, retry=retry,
                                        fw=bool(fw), rc=bool(rc), hits_stride=stride)
             torch.cuda.synchronize()

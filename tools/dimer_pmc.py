@@ -1,0 +1,28 @@
+"""A short match-only run for PMC passes: 3 Gbp index, 20 M seeds, two launches per index flavour
+(reference layout, then the two-symbol index).  The dispatches appear in that order in the counter CSV."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import nvbio_amd as nvb
+from nvbio_amd import workloads as W
+
+ng = int(float(os.environ.get("GENOME", "3e9")))
+ns = int(float(os.environ.get("SEEDS", "2e7")))
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev); g.manual_seed(0x5EED0003)
+text = torch.randint(0, 4, (ng,), dtype=torch.uint8, generator=g, device=dev)
+fmi = W.build_fm_index(text)
+fd = fmi.with_dimer()
+seeds = W.make_seeds(text, ns, 22)
+out = nvb.match(fmi, seeds)
+for f in (fmi, fmi, fd, fd):
+    nvb.match(f, seeds, out=out)
+torch.cuda.synchronize()
+rows = out[:, 0].contiguous()
+for f in (fmi, fd):
+    nvb.locate(f, rows)
+torch.cuda.synchronize()
+print("done")
