@@ -242,28 +242,34 @@ __device__ __forceinline__ uint2 fm_match(const Fmi& f, const Stream& s, uint64_
 }
 
 // ------------------------------------------------------------------ locate
-// locate_ssa_iterator (fmindex_inl.h:511-545): LF-walk to the next sampled row.
+// One iteration of locate_ssa_iterator's LF walk (fmindex_inl.h:511-545) from an unsampled row j: one text
+// position on the reference layout, up to two on the two-symbol index.
+__device__ __forceinline__ void fm_locate_step(const Fmi& f, uint32_t& j, uint32_t& t)
+{
+    if (f.dm.base) { dm_locate_step(f.dm, j, t, f.sa_int - 1u); return; }
+    if (j != f.primary)
+    {
+        // the BWT symbol of row j and its occurrence counters live in the same record
+        const uint32_t k = (j < f.primary) ? j : j - 1u;
+        const Record r = load_record(f, k >> 6);
+        const uint32_t w = comp(r.bwt, (k & 63u) >> 4);
+        const uint32_t c = (w >> (30u - ((k & 15u) << 1))) & 3u;
+        j = f.L2[c] + comp(r.occ, c) + block_count(r.bwt, (k & 63u) + 1u, c);
+    }
+    else j = 0u;
+    ++t;
+}
+
 __device__ __forceinline__ uint2 fm_locate_it(const Fmi& f, uint32_t j)
 {
-    if (f.dm.base) return dm_locate_it(f.dm, j, f.sa_int - 1u);
     uint32_t t = 0;
     const uint32_t mask = f.sa_int - 1u;
-    while ((j & mask) != 0u)
-    {
-        if (j != f.primary)
-        {
-            // the BWT symbol of row j and its occurrence counters live in the same record
-            const uint32_t k = (j < f.primary) ? j : j - 1u;
-            const Record r = load_record(f, k >> 6);
-            const uint32_t w = comp(r.bwt, (k & 63u) >> 4);
-            const uint32_t c = (w >> (30u - ((k & 15u) << 1))) & 3u;
-            j = f.L2[c] + comp(r.occ, c) + block_count(r.bwt, (k & 63u) + 1u, c);
-        }
-        else j = 0u;
-        ++t;
-    }
+    while ((j & mask) != 0u) fm_locate_step(f, j, t);
     return make_uint2(j, t);
 }
 
+// (A lane-refill form of the batched walk -- a finished lane takes the wave's next row -- was measured and dropped:
+// the reference-layout walk is already at the chip's random-line rate, and on the plane records it ran 12 % slower than
+// one row per lane, profiles/r02/locate_refill.txt.)
 
 } // namespace nvb

@@ -222,36 +222,33 @@ __device__ __forceinline__ uint32_t dm_sel4v(const uint4 q, const uint32_t i)
 // positions per record: the row's own nibble gives both symbols; the single step's landing row j1 is
 // computed from the same record and tested against the sampling mask exactly where the reference tests
 // it, so the iterator (row, steps) is the reference's.
-__device__ __forceinline__ uint2 dm_locate_it(const Dimer& d, uint32_t j, const uint32_t sa_mask)
+// One iteration from an unsampled row j ((j & sa_mask) != 0): afterwards j is either sampled (the walk is over)
+// or two text positions further.
+__device__ __forceinline__ void dm_locate_step(const Dimer& d, uint32_t& j, uint32_t& t, const uint32_t sa_mask)
 {
-    uint32_t t = 0;
-    while ((j & sa_mask) != 0u)
-    {
-        if (j == d.primary) { j = 0u; ++t; break; }          // fmindex_inl.h:534-538: SA = 0 wraps to row 0 (always sampled)
-        const uint32_t* r = d.rec(j >> 7);
-        Planes P;
-        dm_load_planes(r, P, 0, 3);
-        const uint32_t rr = j & 127u;
-        const uint32_t sh = rr & 63u;
-        const bool up = rr >= 64u;
-        const uint32_t b = uint32_t(((up ? P.hi[0] : P.lo[0]) >> sh) & 1u) | (uint32_t(((up ? P.hi[1] : P.lo[1]) >> sh) & 1u) << 1);
-        const uint32_t a = uint32_t(((up ? P.hi[2] : P.lo[2]) >> sh) & 1u) | (uint32_t(((up ? P.hi[3] : P.lo[3]) >> sh) & 1u) << 1);
-        // the four counters of b -- among them the dimer's own -- are one uint4 of the line just fetched
-        const uint4 kb = reinterpret_cast<const uint4*>(r)[b];
-        const uint32_t w = rr + 1u;                            // rows <= j of this block
-        uint64_t mlo, mhi;
-        // single step: j1 = L2[b] + #{rows <= j, != primary : b}
-        dm_match_b(P, b, mlo, mhi);
-        const uint32_t j1 = dm_sel4(d.S, b) + kb.x + kb.y + kb.z + kb.w + dm_prefix_count(mlo, mhi, w) - ((b == 0u && j > d.primary) ? 1u : 0u);
-        if ((j1 & sa_mask) == 0u) { j = j1; ++t; break; }
-        if (j1 == d.primary) { j = 0u; t += 2u; break; }      // SA[j] = 1: the next step is the wrap
-        // second step folded in: j2 = C2[ab] + #{rows <= j holding (a,b)} - fillers
-        const uint32_t v = a * 4u + b;
-        dm_match_ab(P, v, mlo, mhi);
-        j = dm_sel4v(kb, a) + dm_prefix_count(mlo, mhi, w) - dm_filler(d, j + 1u, v);
-        t += 2u;
-    }
-    return make_uint2(j, t);
+    if (j == d.primary) { j = 0u; ++t; return; }             // fmindex_inl.h:534-538: SA = 0 wraps to row 0 (always sampled)
+    const uint32_t* r = d.rec(j >> 7);
+    Planes P;
+    dm_load_planes(r, P, 0, 3);
+    const uint32_t rr = j & 127u;
+    const uint32_t sh = rr & 63u;
+    const bool up = rr >= 64u;
+    const uint32_t b = uint32_t(((up ? P.hi[0] : P.lo[0]) >> sh) & 1u) | (uint32_t(((up ? P.hi[1] : P.lo[1]) >> sh) & 1u) << 1);
+    const uint32_t a = uint32_t(((up ? P.hi[2] : P.lo[2]) >> sh) & 1u) | (uint32_t(((up ? P.hi[3] : P.lo[3]) >> sh) & 1u) << 1);
+    // the four counters of b -- among them the dimer's own -- are one uint4 of the line just fetched
+    const uint4 kb = reinterpret_cast<const uint4*>(r)[b];
+    const uint32_t w = rr + 1u;                                // rows <= j of this block
+    uint64_t mlo, mhi;
+    // single step: j1 = L2[b] + #{rows <= j, != primary : b}
+    dm_match_b(P, b, mlo, mhi);
+    const uint32_t j1 = dm_sel4(d.S, b) + kb.x + kb.y + kb.z + kb.w + dm_prefix_count(mlo, mhi, w) - ((b == 0u && j > d.primary) ? 1u : 0u);
+    if ((j1 & sa_mask) == 0u) { j = j1; ++t; return; }
+    if (j1 == d.primary) { j = 0u; t += 2u; return; }        // SA[j] = 1: the next step is the wrap
+    // second step folded in: j2 = C2[ab] + #{rows <= j holding (a,b)} - fillers
+    const uint32_t v = a * 4u + b;
+    dm_match_ab(P, v, mlo, mhi);
+    j = dm_sel4v(kb, a) + dm_prefix_count(mlo, mhi, w) - dm_filler(d, j + 1u, v);
+    t += 2u;
 }
 
 } // namespace nvb
