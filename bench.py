@@ -72,6 +72,7 @@ def parse():
     ap.add_argument("--full-reads", type=int, default=65536)
     ap.add_argument("--full-ref", type=int, default=16384)
     ap.add_argument("--e2e-reads", type=int, default=10_000_000, help="reads per batch of the end-to-end seed+locate+extend leg")
+    ap.add_argument("--e2e-batches", type=int, default=5, help="batches of the full-size run of BASELINE config 4 (5 x 10 M = 50 M reads)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000)
     return ap.parse_args()
@@ -335,9 +336,11 @@ def e2e_leg(a, dev, fmi, text):
     mp = nvb.MappingParams()
     packed = P.pack_read_streams(sym)                  # inputs resident in HBM before the timed region
     res = {}
-    for name, idx in (("reference_layout", fmi), ("hbm_rich_ktab12_ssa1", None)):
+    for name, idx in (("reference_layout", fmi), ("line_native", "dimer"), ("hbm_rich_ktab12_ssa1", None)):
         if idx is None:
             idx = fmi.with_ktab(12).with_dense_ssa(1)
+        elif idx == "dimer":
+            idx = fmi.with_dimer()
         be = P.HipBackend(idx, None, mp, READ_LEN)
         P.seed_and_extend(be, sym, genome_words, ng, packed=packed)        # warm-up
         torch.cuda.synchronize()
@@ -361,8 +364,13 @@ def e2e_leg(a, dev, fmi, text):
     from nvbio_amd import aligner as AL, select as SEL
     names = SEL.pack_names(["r%d" % i for i in range(n)], dev)
     prm = AL.Params(hits_stride=16, batch_size=n)
-    for name, idx in (("nvbowtie_best_approx", fmi), ("nvbowtie_best_approx_ktab12_ssa1", 12), ("nvbowtie_best_approx_ktab15_ssa1", 15)):
-        if not hasattr(idx, "length"):                 # HBM-capacity options: 4^k-entry k-mer table (0.13 / 8.6 GB) + the full suffix array (12 GB)
+    for name, idx in (("nvbowtie_best_approx", fmi), ("nvbowtie_best_approx_line_native", "dimer"), ("nvbowtie_best_approx_line_native_ktab12_ssa1", "dimer12"),
+                      ("nvbowtie_best_approx_ktab12_ssa1", 12), ("nvbowtie_best_approx_ktab15_ssa1", 15)):
+        if idx == "dimer":                             # the line-native two-symbol index next to the reference layout (11 GB at 3 Gbp)
+            idx = fmi.with_dimer()
+        elif idx == "dimer12":
+            idx = fmi.with_dimer().with_ktab(12).with_dense_ssa(1)
+        elif not hasattr(idx, "length"):               # HBM-capacity options: 4^k-entry k-mer table (0.13 / 8.6 GB) + the full suffix array (12 GB)
             idx = fmi.with_ktab(idx).with_dense_ssa(1)
         run = lambda st=False: AL.best_approx(idx, None, sym, genome_words, ng, prm, names=names, packed=packed, stage_times=st)
         ms = _timed(run, reps=2)
@@ -403,6 +411,29 @@ def e2e_leg(a, dev, fmi, text):
     if not ok2:
         raise SystemExit("parity gate failed: nvBowtie single-end driver differs from the oracle driver")
     res["parity"]["nvbowtie_driver"] = {"checked_reads": m2, "best_mapq_cigar_stats_equal": ok2}
+    # BASELINE config 4 at its full size: 50 M reads = e2e_batches batches of n reads through the single-end driver on the
+    # line-native index (fresh reads per batch; inputs packed before each batch's timed region, as above)
+    if a.e2e_batches > 1:
+        idx = fmi.with_dimer()
+        tot_ms, aligned_n, true_n = 0.0, 0, 0
+        for b in range(a.e2e_batches):
+            symb, posb, _ = P.make_reads(text, n, READ_LEN, seed=0x5EED0040 + b)
+            packedb = P.pack_read_streams(symb)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rb = AL.best_approx(idx, None, symb, genome_words, ng, prm, names=names, packed=packedb)
+            e1.record()
+            torch.cuda.synchronize()
+            tot_ms += e0.elapsed_time(e1)
+            locb = (rb["best"][0] >> 32) & 0xFFFFFFFF
+            al = locb != 0xFFFFFFFF
+            aligned_n += int(al.sum().item()); true_n += int((al & ((locb - posb).abs() <= 2)).sum().item())
+            del symb, posb, packedb, rb
+        tot = n * a.e2e_batches
+        res["config4_full_size"] = {"reads": tot, "batches": a.e2e_batches, "index": "line_native", "ms_total": tot_ms, "Mreads_per_s": tot / tot_ms / 1e3,
+                                    "aligned": aligned_n / tot, "best_at_true_position": true_n / tot}
+        del idx
     res["reads"] = n
     res["genome_symbols"] = ng
     return res
@@ -442,7 +473,26 @@ def rank_leg(a, dev, fmi):
         res["traffic_frac_of_hbm_peak"] = res["traffic_GBs"] / HBM_PEAK_GBS
     res["random_lines_per_s_G"] = q / (ms * 1e-3) / 1e9
     res["random_line_limit_G"] = 53.0          # tools/gather_probe.hip (profiles/r01/gather_probe.txt): the chip's random 128-B line rate
-    res["note"] = "uniform random point queries: one 128-B line per query is the floor; frac counts 40 algorithmic bytes per query"
+    res["order"] = "shuffled"
+    res["note"] = ("uniform random point queries, shuffled: one 128-B fabric request per query is the floor (~53 G/s on this chip), so 40 "
+                   "algorithmic bytes per query cannot exceed ~0.27 of HBM peak in this order; `sorted_order` is the same query set sorted by row, the "
+                   "other order the reference's own test runs (fmindex_test.cu:666-716), where neighbouring queries share lines")
+    # the same queries sorted by row (same kernel, same results up to the permutation)
+    ks, perm = torch.sort(k.to(torch.int64) & 0xFFFFFFFF)
+    ks, cs = ks.to(torch.int32), c[perm].contiguous()
+    rs = nvb.rank(fmi, ks, cs)
+    torch.cuda.synchronize()
+    assert bool(torch.equal(rs, r[perm]))
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for e0, e1 in evs:
+        e0.record()
+        nvb.rank(fmi, ks, cs)
+        e1.record()
+    torch.cuda.synchronize()
+    ms_s = sum(e0.elapsed_time(e1) for e0, e1 in evs) / reps
+    gbs_s = q * RANK_BYTES_PER_QUERY / (ms_s * 1e-3) / 1e9
+    res["sorted_order"] = {"kernel_ms": ms_s, "achieved": gbs_s, "frac": gbs_s / HBM_PEAK_GBS, "Mqueries_per_s": q / (ms_s * 1e-3) / 1e6,
+                           "identical_to_shuffled": True}
     return res
 
 
@@ -495,6 +545,31 @@ def seed_leg(a, dev, fmi, text, build_s):
         torch.cuda.synchronize()
         return sum(e0.elapsed_time(e1) for e0, e1 in ev) / reps
     options = {}
+    # the line-native two-symbol index (nvbio_amd/csrc/fmindex_dimer.h): two symbols per backward-search step and two text
+    # positions per locate step; ranges and positions must be bit-identical
+    t0 = time.perf_counter()
+    fdim = fmi.with_dimer()
+    torch.cuda.synchronize()
+    dimer_s = time.perf_counter() - t0
+    r2 = torch.empty_like(ranges)
+    p2 = torch.empty_like(pos)
+    dm_ms = timed(lambda: nvb.match(fdim, seeds, out=r2))
+    dl_ms = timed(lambda: nvb.locate(fdim, rows, out=p2))
+    srt = torch.sort(rows.to(torch.int64) & 0xFFFFFFFF).values.to(torch.int32)
+    ps = torch.empty_like(pos)
+    line_native = {"index_bytes": int(fdim.dimer.numel()) * 4, "build_s": dimer_s,
+                   "match": {"kernel": "fm_match_kernel", "kernel_ms": dm_ms, "Mseeds_per_s": a.seeds / (dm_ms * 1e-3) / 1e6,
+                             "identical": bool(torch.equal(r2, ranges))},
+                   "locate": {"kernel": "fm_locate_kernel", "kernel_ms": dl_ms, "Mrows_per_s": rows.numel() / (dl_ms * 1e-3) / 1e6,
+                              "identical": bool(torch.equal(p2, pos)),
+                              "sorted_rows_kernel_ms": timed(lambda: nvb.locate(fdim, srt, out=ps))}}
+    fdk = fdim.with_ktab(12)
+    dk_ms = timed(lambda: nvb.match(fdk, seeds, out=r2))
+    line_native["match_ktab12"] = {"kernel_ms": dk_ms, "Mseeds_per_s": a.seeds / (dk_ms * 1e-3) / 1e6, "identical": bool(torch.equal(r2, ranges))}
+    ref_sorted_ms = timed(lambda: nvb.locate(fmi, srt, out=ps))
+    del fdk, fdim, r2, p2, ps, srt
+    if not (line_native["match"]["identical"] and line_native["locate"]["identical"] and line_native["match_ktab12"]["identical"]):
+        raise SystemExit("parity gate failed: the line-native index changes match/locate results")
     fk = fmi.with_ktab(12)
     r2 = torch.empty_like(ranges)
     options["match_ktab12"] = {"kernel_ms": timed(lambda: nvb.match(fk, seeds, out=r2)), "table_bytes": int(fk.ktab.numel()) * 4}
@@ -517,12 +592,24 @@ def seed_leg(a, dev, fmi, text, build_s):
     bytes_per_loc = 32.0 * steps / mr + 4 + 8
     mgbs = a.seeds * bytes_per_seed / (match_ms * 1e-3) / 1e9
     lgbs = rows.numel() * bytes_per_loc / (locate_ms * 1e-3) / 1e9
+    # the line-native figures priced in the SAME algorithmic bytes (what the reference's walk would touch): the index does the
+    # job in fewer, fuller lines, so the fraction says how close the seeding stage is to what 8 TB/s could do for that walk
+    for leg, nunits, bpu in (("match", a.seeds, bytes_per_seed), ("locate", rows.numel(), bytes_per_loc)):
+        g = nunits * bpu / (line_native[leg]["kernel_ms"] * 1e-3) / 1e9
+        line_native[leg]["achieved_GBs"] = g
+        line_native[leg]["frac_of_hbm_peak"] = g / HBM_PEAK_GBS
+    for leg, kern in (("match", "fm_match_kernel<dimer>"), ("locate", "fm_locate_kernel<dimer>")):
+        t = measured_traffic(kern)
+        if t:
+            line_native[leg]["traffic"] = t
     return {"genome_symbols": ng, "index_build_s": build_s, "seeds": a.seeds, "seed_len": 22,
             "match": {"kernel": "fm_match_kernel", "kernel_ms": match_ms, "Mseeds_per_s": a.seeds / (match_ms * 1e-3) / 1e6,
                       "algorithmic_bytes_per_seed": bytes_per_seed, "achieved_GBs": mgbs, "frac_of_hbm_peak": mgbs / HBM_PEAK_GBS},
             "locate": {"kernel": "fm_locate_kernel", "rows": int(rows.numel()), "kernel_ms": locate_ms,
                        "Mrows_per_s": rows.numel() / (locate_ms * 1e-3) / 1e6, "mean_lf_steps": steps / mr,
-                       "algorithmic_bytes_per_row": bytes_per_loc, "achieved_GBs": lgbs, "frac_of_hbm_peak": lgbs / HBM_PEAK_GBS},
+                       "algorithmic_bytes_per_row": bytes_per_loc, "achieved_GBs": lgbs, "frac_of_hbm_peak": lgbs / HBM_PEAK_GBS,
+                       "sorted_rows_kernel_ms": ref_sorted_ms},
+            "line_native_index": line_native,
             "hbm_capacity_options": options,
             "parity": {"checked_seeds": m, "checked_rows": mr, "bit_exact": exact}}
 
