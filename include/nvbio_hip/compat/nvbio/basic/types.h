@@ -1,0 +1,107 @@
+// compat/nvbio/basic/types.h -- the vocabulary types and qualifiers a caller written against nvbio expects
+// (nvbio/basic/types.h, numbers.h), for translation units compiled by hipcc (device + host) or by a host
+// compiler (host only).  Part of the drop-in template layer: `-I include/nvbio_hip/compat` makes the reference's
+// own include lines (<nvbio/alignment/alignment.h>, <nvbio/fmindex/fmindex.h>, ...) resolve here.
+#pragma once
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define NVBIO_HOST_DEVICE __host__ __device__
+#define NVBIO_HOST        __host__
+#define NVBIO_DEVICE      __device__
+#define NVBIO_FORCEINLINE __forceinline__
+#else
+#define NVBIO_HOST_DEVICE
+#define NVBIO_HOST
+#define NVBIO_DEVICE
+#define NVBIO_FORCEINLINE inline __attribute__((always_inline))
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NVBIO_DEVICE_COMPILATION 1
+#endif
+#define NVBIO_CUDA_DEBUG_ASSERT(...)
+#define NVBIO_CUDA_ASSERT(...)
+#define NVBIO_VAR_UNUSED __attribute__((unused))
+
+#include <stdint.h>
+#include <stddef.h>
+#include <iterator>
+#include <limits>
+
+namespace nvbio {
+
+typedef uint8_t  uint8;   typedef int8_t  int8;
+typedef uint16_t uint16;  typedef int16_t int16;
+typedef uint32_t uint32;  typedef int32_t int32;
+typedef uint64_t uint64;  typedef int64_t int64;
+
+#if !defined(__HIPCC__)
+struct uint2 { uint32 x, y; };
+struct uint4 { uint32 x, y, z, w; };
+struct ulonglong2 { unsigned long long x, y; };
+struct ulonglong4 { unsigned long long x, y, z, w; };
+inline uint2 make_uint2(uint32 x, uint32 y) { uint2 r = { x, y }; return r; }
+inline uint4 make_uint4(uint32 x, uint32 y, uint32 z, uint32 w) { uint4 r = { x, y, z, w }; return r; }
+inline ulonglong2 make_ulonglong2(unsigned long long x, unsigned long long y) { ulonglong2 r = { x, y }; return r; }
+inline ulonglong4 make_ulonglong4(unsigned long long x, unsigned long long y, unsigned long long z, unsigned long long w) { ulonglong4 r = { x, y, z, w }; return r; }
+#else
+using ::uint2; using ::uint4; using ::ulonglong2; using ::ulonglong4;
+using ::make_uint2; using ::make_uint4; using ::make_ulonglong2; using ::make_ulonglong4;
+#endif
+typedef ulonglong2 uint64_2;
+typedef ulonglong4 uint64_4;
+
+struct host_tag {};
+struct device_tag {};
+struct null_type {};
+
+/// vector_type<T,N>::type and make_vector (nvbio/basic/types.h): uint32 -> uint2/uint4, uint64 -> ulonglong2/4
+template <typename T, uint32 N> struct vector_type {};
+template <> struct vector_type<uint32, 2> { typedef uint2 type; };
+template <> struct vector_type<uint32, 4> { typedef uint4 type; };
+template <> struct vector_type<uint64, 2> { typedef ulonglong2 type; };
+template <> struct vector_type<uint64, 4> { typedef ulonglong4 type; };
+NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint2 make_vector(const uint32 x, const uint32 y) { return make_uint2(x, y); }
+NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint4 make_vector(const uint32 x, const uint32 y, const uint32 z, const uint32 w) { return make_uint4(x, y, z, w); }
+NVBIO_FORCEINLINE NVBIO_HOST_DEVICE ulonglong2 make_vector(const uint64 x, const uint64 y) { return make_ulonglong2(x, y); }
+NVBIO_FORCEINLINE NVBIO_HOST_DEVICE ulonglong4 make_vector(const uint64 x, const uint64 y, const uint64 z, const uint64 w) { return make_ulonglong4(x, y, z, w); }
+
+template <typename T> struct signed_type {};
+template <> struct signed_type<uint32> { typedef int32 type; };
+template <> struct signed_type<int32>  { typedef int32 type; };
+template <> struct signed_type<uint64> { typedef int64 type; };
+template <> struct signed_type<int64>  { typedef int64 type; };
+template <typename T> struct unsigned_type {};
+template <> struct unsigned_type<uint32> { typedef uint32 type; };
+template <> struct unsigned_type<int32>  { typedef uint32 type; };
+template <> struct unsigned_type<uint64> { typedef uint64 type; };
+template <> struct unsigned_type<int64>  { typedef uint64 type; };
+
+template <typename A, typename B> struct equal { static const bool pred = false; };
+template <typename A>             struct equal<A, A> { static const bool pred = true; };
+
+/// Field_traits<T>::min() / max() with the reference's values (numbers.h:795-850): the 32- and 64-bit signed extremes are
+/// +-2^30 and +-2^62, not the type limits -- BestSink starts at -2^30 and streams use it as "no threshold"
+template <typename T> struct Field_traits {};
+template <> struct Field_traits<int8>   { NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static int8   min() { return int8(-128); }        NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static int8   max() { return int8(127); } };
+template <> struct Field_traits<int16>  { NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static int16  min() { return int16(-32768); }     NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static int16  max() { return int16(32767); } };
+template <> struct Field_traits<int32>  { NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static int32  min() { return -(1 << 30); }        NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static int32  max() { return (1 << 30); } };
+template <> struct Field_traits<int64>  { NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static int64  min() { return -(int64(1) << 62); } NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static int64  max() { return int64(1) << 62; } };
+template <> struct Field_traits<uint8>  { NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static uint8  min() { return 0; } NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static uint8  max() { return uint8(255); } };
+template <> struct Field_traits<uint16> { NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static uint16 min() { return 0; } NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static uint16 max() { return uint16(0xFFFF); } };
+template <> struct Field_traits<uint32> { NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static uint32 min() { return 0; } NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static uint32 max() { return 0xFFFFFFFFu; } };
+template <> struct Field_traits<uint64> { NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static uint64 min() { return 0; } NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static uint64 max() { return ~uint64(0); } };
+
+template <typename T> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE T min(const T a, const T b) { return a < b ? a : b; }
+template <typename T> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE T max(const T a, const T b) { return a < b ? b : a; }
+template <typename T> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE T max3(const T a, const T b, const T c) { return nvbio::max(nvbio::max(a, b), c); }
+template <typename T> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE T min3(const T a, const T b, const T c) { return nvbio::min(nvbio::min(a, b), c); }
+NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 divide_ri(const uint32 a, const uint32 b) { return (a + b - 1u) / b; }
+NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 popc(const uint32 x) { return uint32(__builtin_popcount(x)); }
+NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 popc(const uint64 x) { return uint32(__builtin_popcountll(x)); }
+
+/// string_traits<Iterator>::value_type
+template <typename T> struct string_traits { typedef typename T::value_type value_type; typedef uint32 index_type; };
+template <typename T> struct string_traits<T*> { typedef T value_type; typedef uint32 index_type; };
+template <typename T> struct string_traits<const T*> { typedef T value_type; typedef uint32 index_type; };
+
+} // namespace nvbio

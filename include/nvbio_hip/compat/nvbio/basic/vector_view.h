@@ -1,0 +1,47 @@
+// compat/nvbio/basic/vector_view.h -- vector_view<Iterator,IndexType> (nvbio/basic/vector_view.h:80-230): a sized
+// view over any random-access iterator; the string type the alignment functions take.
+#pragma once
+#include "types.h"
+
+namespace nvbio {
+
+template <typename Iterator, typename IndexType = uint32>
+struct vector_view
+{
+    typedef Iterator                                                iterator;
+    typedef Iterator                                                const_iterator;
+    typedef typename std::iterator_traits<Iterator>::value_type     value_type;
+    typedef typename std::iterator_traits<Iterator>::reference      reference;
+    typedef value_type                                              const_reference;
+    typedef IndexType                                               index_type;
+    typedef IndexType                                               size_type;
+
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE vector_view() : m_size(0) {}
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE vector_view(const IndexType size, Iterator vec) : m_size(size), m_vec(vec) {}
+
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void      resize(const uint32 sz) { m_size = sz; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void      clear() { m_size = 0; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE IndexType size() const { return m_size; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE IndexType length() const { return m_size; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool      empty() const { return m_size == 0; }
+
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE const_reference operator[](const IndexType i) const { return m_vec[i]; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE reference       operator[](const IndexType i)       { return m_vec[i]; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE const_reference front() const { return m_vec[0]; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE const_reference back()  const { return m_vec[m_size - 1]; }
+
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE Iterator begin() const { return m_vec; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE Iterator end()   const { return m_vec + m_size; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE Iterator base()  const { return m_vec; }
+
+    IndexType m_size;
+    Iterator  m_vec;
+};
+
+template <typename Iterator, typename I> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 length(const vector_view<Iterator, I>& v) { return uint32(v.length()); }
+template <typename T> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 length(const T& s) { return uint32(s.length()); }
+template <typename Iterator, typename I> struct string_traits< vector_view<Iterator, I> > {
+    typedef typename vector_view<Iterator, I>::value_type value_type; typedef I index_type;
+};
+
+} // namespace nvbio

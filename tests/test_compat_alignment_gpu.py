@@ -1,0 +1,255 @@
+"""The drop-in template layer (include/nvbio_hip/compat): a caller TU written against the reference's stream concept
+(tests/compat/aln_callers.hip -- user stream classes with init_context / load_strings / output functors, byte strings,
+a user scoring scheme, Best2Sink, HostThreadScheduler) compiled by hipcc with `-I include/nvbio_hip/compat`, its
+results compared bit for bit with the CPU oracle.  Recognised packed streams must run on the tuned kernels, everything
+else on the generic per-lane templates."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pyoracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GLOBAL, LOCAL, SEMI = 0, 1, 2
+
+
+@pytest.fixture(scope="module")
+def callers():
+    path = os.path.join(ROOT, "tests", "compat", "libaln_callers.so")
+    assert os.path.exists(path), "build with python -c 'import __graft_entry__ as g; g.build()'"
+    L = C.CDLL(path)
+    vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
+    L.compat_banded_score.argtypes = [i32, i32, i32, i32, i32, vp, u32, vp, vp, vp, u32, vp, vp, u32, vp, vp, C.c_char_p]
+    L.compat_full_score.argtypes = [i32, i32, i32, i32, i32, vp, u32, vp, vp, vp, u32, vp, vp, u32, vp, vp, vp, C.c_char_p]
+    L.compat_per_thread_score.argtypes = [vp, u32, vp, vp, vp, vp, vp]
+    return L
+
+
+def make_jobs(seed, n, max_read=150, band=31, max_sym=4, short_text_every=53, full=False):
+    """ragged reads (empty ones included) next to reference windows they mostly derive from (substitutions, indels, Ns)."""
+    rng = np.random.default_rng(seed)
+    reads, quals, wins = [], [], []
+    for i in range(n):
+        L = int(rng.integers(0, max_read + 1)) if i % 7 else int(rng.integers(0, 4))
+        W = L + band + int(rng.integers(0, 12)) if not full else int(rng.integers(L, 3 * L + 40))
+        w = rng.integers(0, 4, W, dtype=np.uint8)
+        off = int(rng.integers(0, band // 2 + 1)) if W >= L + band // 2 else 0
+        r = w[off:off + L].copy()
+        if r.size < L:
+            r = np.concatenate([r, rng.integers(0, 4, L - r.size, dtype=np.uint8)])
+        mut = rng.random(L) < 0.06
+        r[mut] = rng.integers(0, 4, int(mut.sum()), dtype=np.uint8)
+        if L > 20 and i % 3 == 0:
+            p = int(rng.integers(5, L - 5))
+            r = np.concatenate([r[:p], r[p + 2:], rng.integers(0, 4, 2, dtype=np.uint8)]) if i % 2 else np.concatenate([r[:p], rng.integers(0, 4, 2, dtype=np.uint8), r[p:-2]])
+        if max_sym > 3 and L and i % 11 == 0:
+            r[int(rng.integers(0, L))] = max_sym
+        if i % short_text_every == short_text_every - 1 and L > 3:
+            w = w[:L - 2]                                     # a text shorter than its pattern: the job is refused
+        reads.append(r.astype(np.uint8)); quals.append(rng.integers(0, 60, L, dtype=np.uint8)); wins.append(w)
+    return reads, quals, wins
+
+
+def offsets(strings):
+    o = np.zeros(len(strings) + 1, dtype=np.uint32)
+    o[1:] = np.cumsum([len(s) for s in strings])
+    return o
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+class Batch:
+    def __init__(self, reads, quals, wins, packed, on_device):
+        self.n = len(reads)
+        self.ro, self.wo = offsets(reads), offsets(wins)
+        cat_r = np.concatenate(reads) if reads else np.zeros(0, np.uint8)
+        cat_w = np.concatenate(wins) if wins else np.zeros(0, np.uint8)
+        self.cat_q = np.concatenate(quals)
+        self.longest_read = int(max(len(r) for r in reads))
+        self.longest_win = int(max(len(w) for w in wins))
+        if packed:
+            self.hr = O.StringSet(O.pack(cat_r, 4, True), 4, True, self.ro[:-1].astype(np.uint64), np.diff(self.ro))
+            self.hw = O.StringSet(O.pack(cat_w, 2, False), 2, False, self.wo[:-1].astype(np.uint64), np.diff(self.wo))
+            rd, wd = self.hr.words, self.hw.words
+        else:
+            pad = np.zeros(8, np.uint8)
+            rb, wb = np.concatenate([cat_r, pad]), np.concatenate([cat_w, pad])
+            self.hr = O.StringSet(np.frombuffer(np.concatenate([rb, np.zeros(-rb.size % 4, np.uint8)]).tobytes(), dtype=np.uint32), 8, False,
+                                  self.ro[:-1].astype(np.uint64), np.diff(self.ro))
+            self.hw = O.StringSet(np.frombuffer(np.concatenate([wb, np.zeros(-wb.size % 4, np.uint8)]).tobytes(), dtype=np.uint32), 8, False,
+                                  self.wo[:-1].astype(np.uint64), np.diff(self.wo))
+            rd, wd = rb, wb
+        mk = dev if on_device else (lambda a: torch.from_numpy(np.ascontiguousarray(a).copy()))
+        self.t = dict(ro=mk(self.ro.view(np.int32)), wo=mk(self.wo.view(np.int32)), r=mk(rd.view(np.int32) if packed else rd), w=mk(wd.view(np.int32) if packed else wd),
+                      q=mk(np.concatenate([self.cat_q, np.zeros(8, np.uint8)])))
+        self.score = mk(np.full(self.n, 12345, np.int32))
+        self.sink = mk(np.full((self.n, 2), 777, np.int32))
+
+    def ptr(self, k):
+        return C.c_void_p(self.t[k].data_ptr())
+
+    def results(self):
+        return self.score.cpu().numpy(), self.sink.cpu().numpy().view(np.uint32)
+
+
+def run_banded(L, b, strings, where, kind, typ, band, scheme):
+    sc = np.array(scheme, dtype=np.int32)
+    path = C.create_string_buffer(16)
+    rc = L.compat_banded_score(strings, where, kind, typ, band, sc.ctypes.data, b.n, b.ptr("ro"), b.ptr("r"), b.ptr("q"), b.longest_read,
+                               b.ptr("wo"), b.ptr("w"), b.longest_win, C.c_void_p(b.score.data_ptr()), C.c_void_p(b.sink.data_ptr()), path)
+    assert rc == 0, (rc, path.value)
+    return path.value.decode()
+
+
+def expect_banded(b, kind, typ, band, scheme):
+    if kind == 0:
+        return O.batch_banded_gotoh_score(band, typ, scheme, b.hr, b.hw)
+    if kind in (1, 2):
+        return O.batch_sw_score(band, typ, scheme if kind == 1 else (0, -1, -1, -1), b.hr, b.hw)
+    lut = np.array([-(2 + min(q, 40) // 10) for q in range(256)], dtype=np.int32)
+    return O.batch_banded_gotoh_score_qual(band, typ, (2, -8, -3, -6, -2, 0), lut, np.concatenate([b.cat_q, np.zeros(8, np.uint8)]), b.hr, b.hw)
+
+
+@pytest.mark.parametrize("typ", [GLOBAL, LOCAL, SEMI])
+@pytest.mark.parametrize("kind,scheme", [(0, (2, -1, -2, -1)), (0, (0, -5, -8, -3)), (1, (2, -2, -3, -3)), (2, (0, -1, -1, -1))])
+@pytest.mark.parametrize("band", [15, 31])
+def test_packed_stream_runs_on_the_tuned_kernels(callers, typ, kind, scheme, band):
+    reads, quals, wins = make_jobs(100 + band + typ, 3000, band=band)
+    b = Batch(reads, quals, wins, packed=True, on_device=True)
+    path = run_banded(callers, b, 0, 0, kind, typ, band, scheme)
+    assert path == "tuned"
+    es, ek = expect_banded(b, kind, typ, band, scheme)
+    gs, gk = b.results()
+    assert (gs == es).all() and (gk == ek).all()
+    assert (es == -(1 << 30)).sum() > 10          # refused jobs reach output() with the untouched sink
+
+
+def test_packed_stream_outside_the_tuned_contract_falls_to_the_generic_lanes(callers):
+    reads, quals, wins = make_jobs(7, 2000, band=15)
+    b = Batch(reads, quals, wins, packed=True, on_device=True)
+    # asymmetric linear gap costs: the tuned kernels refuse them, the generic templates compute them
+    assert run_banded(callers, b, 0, 0, 1, LOCAL, 15, (2, -2, -4, -1)) == "generic"
+    es, ek = O.batch_sw_score(15, LOCAL, (2, -2, -4, -1), b.hr, b.hw)
+    gs, gk = b.results()
+    assert (gs == es).all() and (gk == ek).all()
+    # a band the tuned kernels are not instantiated for
+    for typ in (GLOBAL, LOCAL, SEMI):
+        reads, quals, wins = make_jobs(9 + typ, 1500, band=9)
+        b = Batch(reads, quals, wins, packed=True, on_device=True)
+        assert run_banded(callers, b, 0, 0, 0, typ, 9, (2, -1, -2, -1)) == "generic"
+        es, ek = O.batch_banded_gotoh_score(9, typ, (2, -1, -2, -1), b.hr, b.hw)
+        gs, gk = b.results()
+        assert (gs == es).all() and (gk == ek).all()
+
+
+@pytest.mark.parametrize("typ", [GLOBAL, LOCAL, SEMI])
+@pytest.mark.parametrize("kind,scheme", [(0, (2, -1, -2, -1)), (1, (2, -2, -4, -1)), (2, None), (3, None)])
+@pytest.mark.parametrize("band", [15, 31])
+def test_byte_strings_user_scheme_and_declined_jobs(callers, typ, kind, scheme, band):
+    """uint8 strings (symbols up to 5: band 31's 2-bit window cache truncates them, as in the reference), per-base
+    qualities, a user-defined scheme, Best2Sink, jobs whose init_context declines."""
+    reads, quals, wins = make_jobs(300 + band + typ + kind, 2500, band=band, max_sym=5)
+    b = Batch(reads, quals, wins, packed=False, on_device=True)
+    assert run_banded(callers, b, 1, 0, kind, typ, band, scheme or (0, 0, 0, 0)) == "generic"
+    es, ek = expect_banded(b, kind, typ, band, scheme)
+    gs, gk = b.results()
+    declined = (np.arange(b.n) % 97) == 96
+    assert (gs[declined] == 12345).all() and (gk[declined] == 777).all()
+    assert (gs[~declined] == es[~declined]).all() and (gk[~declined] == ek[~declined]).all()
+
+
+def run_full(L, b, strings, where, kind, typ, tag, scheme, thresholds):
+    sc = np.array(scheme, dtype=np.int32)
+    path = C.create_string_buffer(16)
+    th = None
+    if thresholds is not None:
+        th = dev(thresholds) if where == 0 else torch.from_numpy(np.ascontiguousarray(thresholds).copy())
+    rc = L.compat_full_score(strings, where, kind, typ, tag, sc.ctypes.data, b.n, b.ptr("ro"), b.ptr("r"), b.ptr("q"), b.longest_read,
+                             b.ptr("wo"), b.ptr("w"), b.longest_win, C.c_void_p(th.data_ptr()) if th is not None else None,
+                             C.c_void_p(b.score.data_ptr()), C.c_void_p(b.sink.data_ptr()), path)
+    assert rc == 0, (rc, path.value)
+    return path.value.decode()
+
+
+def expect_full(b, kind, typ, tag, scheme, thresholds):
+    if kind == 3:
+        lut = np.array([-(2 + min(q, 40) // 10) for q in range(256)], dtype=np.int32)
+        s, k, _ = O.batch_gotoh_score_qual(tag, typ, (2, -8, -3, -6, -2), lut, np.concatenate([b.cat_q, np.zeros(8, np.uint8)]), b.hr, b.hw, min_score=thresholds)
+        return s, k
+    if tag == 0:
+        s, k, _ = O.batch_score_pattern_blocking(0 if kind == 0 else 1, typ, scheme if kind != 2 else (0, -1, -1, -1), b.hr, b.hw, min_score=thresholds)
+        return s, k
+    if kind == 0:
+        s, k, _ = O.batch_gotoh_score(typ, scheme, b.hr, b.hw, min_score=thresholds)
+        return s, k
+    return O.batch_sw_score(0, typ, scheme if kind == 1 else (0, -1, -1, -1), b.hr, b.hw)
+
+
+@pytest.mark.parametrize("typ", [GLOBAL, LOCAL, SEMI])
+@pytest.mark.parametrize("tag", [0, 1])
+@pytest.mark.parametrize("kind,scheme", [(0, (2, -1, -2, -1)), (1, (2, -2, -3, -3)), (2, None)])
+def test_full_matrix_packed_stream(callers, typ, tag, kind, scheme):
+    reads, quals, wins = make_jobs(500 + typ + 3 * tag + kind, 1200, max_read=120, full=True, short_text_every=10 ** 9)
+    reads = [r if len(r) else np.array([1], np.uint8) for r in reads]          # the reference reads uninitialised cells for M == 0
+    quals = [q if len(q) else np.array([0], np.uint8) for q in quals]
+    b = Batch(reads, quals, wins, packed=True, on_device=True)
+    th = None
+    if kind == 0:
+        rng = np.random.default_rng(5)
+        th = np.where(rng.random(b.n) < 0.5, -(1 << 30), rng.integers(-40, 160, b.n)).astype(np.int32)
+    assert run_full(callers, b, 0, 0, kind, typ, tag, scheme or (0, -1, -1, -1), th) == "tuned"
+    es, ek = expect_full(b, kind, typ, tag, scheme, th)
+    gs, gk = b.results()
+    assert (gs == es).all() and (gk == ek).all()
+
+
+@pytest.mark.parametrize("typ", [GLOBAL, LOCAL, SEMI])
+@pytest.mark.parametrize("tag", [0, 1])
+@pytest.mark.parametrize("kind,scheme", [(0, (2, -1, -2, -1)), (1, (2, -2, -4, -1)), (3, None)])
+def test_full_matrix_generic_lanes(callers, typ, tag, kind, scheme):
+    """byte strings, asymmetric linear gaps, the user scheme, thresholds with early exits: the generic full-matrix templates"""
+    reads, quals, wins = make_jobs(700 + typ + 3 * tag + kind, 800, max_read=90, full=True, short_text_every=10 ** 9, max_sym=5)
+    reads = [r if len(r) else np.array([1], np.uint8) for r in reads]
+    quals = [q if len(q) else np.array([0], np.uint8) for q in quals]
+    b = Batch(reads, quals, wins, packed=False, on_device=True)
+    rng = np.random.default_rng(6)
+    th = np.where(rng.random(b.n) < 0.5, -(1 << 30), rng.integers(-40, 120, b.n)).astype(np.int32) if kind != 1 else None
+    assert run_full(callers, b, 1, 0, kind, typ, tag, scheme or (0, 0, 0, 0), th) == "generic"
+    es, ek = expect_full(b, kind, typ, tag, scheme, th)
+    gs, gk = b.results()
+    declined = (np.arange(b.n) % 97) == 96
+    assert (gs[~declined] == es[~declined]).all() and (gk[~declined] == ek[~declined]).all()
+
+
+def test_full_matrix_long_patterns_and_host(callers):
+    """patterns beyond the tuned sweep's 512 rows run on the generic lanes; HostThreadScheduler on the host"""
+    rng = np.random.default_rng(8)
+    reads = [rng.integers(0, 4, int(rng.integers(400, 900)), dtype=np.uint8) for _ in range(60)]
+    wins = [np.concatenate([rng.integers(0, 4, 30, dtype=np.uint8), r, rng.integers(0, 4, 30, dtype=np.uint8)]) for r in reads]
+    quals = [np.zeros(len(r), np.uint8) for r in reads]
+    b = Batch(reads, quals, wins, packed=True, on_device=True)
+    assert run_full(callers, b, 0, 0, 0, LOCAL, 0, (2, -1, -2, -1), None) == "generic"
+    es, ek, _ = O.batch_score_pattern_blocking(0, LOCAL, (2, -1, -2, -1), b.hr, b.hw)
+    gs, gk = b.results()
+    assert (gs == es).all() and (gk == ek).all()
+    bh = Batch(reads, quals, wins, packed=True, on_device=False)
+    assert run_full(callers, bh, 0, 1, 0, SEMI, 1, (2, -1, -2, -1), None) == "host"
+    es, ek, _ = O.batch_gotoh_score(SEMI, (2, -1, -2, -1), bh.hr, bh.hw)
+    gs, gk = bh.results()
+    assert (gs == es).all() and (gk == ek).all()
+
+
+def test_per_thread_function_in_a_user_kernel(callers):
+    """aln::banded_alignment_score<7>(aligner, pattern, text, min_score) called from a user kernel on byte strings"""
+    reads, quals, wins = make_jobs(77, 3000, max_read=60, band=7, max_sym=5)
+    b = Batch(reads, quals, wins, packed=False, on_device=True)
+    sc = np.array((2, -1, -1, -1), dtype=np.int32)
+    assert callers.compat_per_thread_score(sc.ctypes.data, b.n, b.ptr("ro"), b.ptr("r"), b.ptr("wo"), b.ptr("w"), C.c_void_p(b.score.data_ptr())) == 0
+    es, _ = O.batch_banded_gotoh_score(7, SEMI, (2, -1, -1, -1), b.hr, b.hw)
+    assert (b.score.cpu().numpy() == es).all()

@@ -26,3 +26,13 @@ for f in (fmi, fd):
     nvb.locate(f, rows)
 torch.cuda.synchronize()
 print("done")
+if os.environ.get("MAP"):
+    from nvbio_amd import pipeline as P
+    nr = int(float(os.environ.get("READS", "4e6")))
+    sym, pos, _ = P.make_reads(text, nr, 100, seed=0x5EED0004)
+    reads, _ = P.pack_read_streams(sym)
+    mp = nvb.MappingParams()
+    for f in (fmi, fd, fd):
+        nvb.map_exact(f, reads, mp, 100)
+    torch.cuda.synchronize()
+    print("map done")
