@@ -1,0 +1,158 @@
+// compat/nvbio/fmindex/fmindex.h -- fm_index<TRankDictionary,TSuffixArray,TL2> and its free functions
+// (nvbio/fmindex/fmindex.h:330-390, fmindex_inl.h:36-570) as host-device templates a caller kernel can invoke per thread:
+// rank / rank4, match / match_reverse (backward search), basic_inv_psi, locate and the two-pass ssa iterators.
+// Conventions kept from the reference: the '$' row `primary` is not stored in the BWT (rows >= primary read k-1),
+// rank(-1) = 0, rank(length) = count, match returns the raw (l,r) of the step that emptied the range, and (1,0) on a
+// symbol outside the alphabet.  (The reference tests `c > symbol_count()`, which lets the symbol equal to the alphabet size
+// -- N = 4 over DNA -- through to L2[4] and a counter of the next block; here that symbol is "no match" too, as in
+// nvBowtie's own match_range, mapping_inl.h:90.)
+#pragma once
+#include "rank_dictionary.h"
+#include "ssa.h"
+
+namespace nvbio {
+
+template <typename A, typename B, typename T, typename F> struct if_equal { typedef F type; };
+template <typename A, typename T, typename F> struct if_equal<A, A, T, F> { typedef T type; };
+
+template <typename TRankDictionary, typename TSuffixArray, typename TL2 = null_type>
+struct fm_index
+{
+    typedef TRankDictionary                         rank_dictionary_type;
+    typedef typename TRankDictionary::text_type     bwt_type;
+    typedef TSuffixArray                            suffix_array_type;
+    typedef typename TRankDictionary::index_type    index_type;
+    typedef typename TRankDictionary::range_type    range_type;
+    typedef typename TRankDictionary::vector_type   vector_type;
+    typedef typename if_equal<TL2, null_type, const index_type*, TL2>::type L2_iterator;
+
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE index_type      length() const { return m_length; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE index_type      primary() const { return m_primary; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE index_type      count(const uint32 c) const { return m_L2[c + 1] - m_L2[c]; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE index_type      L2(const uint32 c) const { return m_L2[c]; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE TRankDictionary rank_dict() const { return m_rank_dict; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE TSuffixArray    sa() const { return m_sa; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bwt_type        bwt() const { return m_rank_dict.text(); }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32          symbol_count() const { return m_rank_dict.symbol_count(); }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32          symbol_size()  const { return m_rank_dict.symbol_size(); }
+
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE fm_index() {}
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE fm_index(const index_type length, const index_type primary, const L2_iterator L2,
+                                                 const TRankDictionary rank_dict, const TSuffixArray sa)
+        : m_length(length), m_primary(primary), m_L2(L2), m_rank_dict(rank_dict), m_sa(sa) {}
+
+    index_type      m_length;
+    index_type      m_primary;
+    L2_iterator     m_L2;
+    TRankDictionary m_rank_dict;
+    TSuffixArray    m_sa;
+};
+
+#define NVBIO_FMI_T template <typename R, typename S, typename L>
+#define NVBIO_FMI   fm_index<R, S, L>
+
+/// occurrences of c in BWT rows [0, k]   (fmindex_inl.h:36-57)
+NVBIO_FMI_T NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
+typename NVBIO_FMI::index_type rank(const NVBIO_FMI& fmi, typename NVBIO_FMI::index_type k, uint8 c)
+{
+    typedef typename NVBIO_FMI::index_type index_type;
+    if (k == index_type(-1)) return 0;
+    if (k == fmi.length())   return fmi.count(c);
+    if (k >= fmi.primary())  --k;
+    return rank(fmi.m_rank_dict, k, uint32(c));
+}
+/// ... for both ends of a range   (fmindex_inl.h:66-99)
+NVBIO_FMI_T NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
+typename NVBIO_FMI::range_type rank(const NVBIO_FMI& fmi, typename NVBIO_FMI::range_type range, uint8 c)
+{
+    return make_vector(rank(fmi, range.x, c), rank(fmi, range.y, c));
+}
+/// all four symbols at once   (fmindex_inl.h:111-135)
+NVBIO_FMI_T NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
+typename R::vec4_type rank4(const NVBIO_FMI& fmi, typename NVBIO_FMI::index_type k)
+{
+    typedef typename NVBIO_FMI::index_type index_type;
+    if (k == index_type(-1)) return make_vector(index_type(0), index_type(0), index_type(0), index_type(0));
+    if (k == fmi.length())   return make_vector(fmi.count(0), fmi.count(1), fmi.count(2), fmi.count(3));
+    if (k >= fmi.primary())  --k;
+    return rank4(fmi.m_rank_dict, k);
+}
+
+/// backward search from a given range   (fmindex_inl.h:307-341)
+template <typename R, typename S, typename L, typename Iterator> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
+typename NVBIO_FMI::range_type match(const NVBIO_FMI& fmi, const Iterator pattern, const uint32 pattern_len, const typename NVBIO_FMI::range_type in_range)
+{
+    typedef typename NVBIO_FMI::index_type index_type;
+    typename NVBIO_FMI::range_type range = in_range;
+    for (int32 i = int32(pattern_len) - 1; i >= 0 && range.x <= range.y; --i)
+    {
+        const uint32 c = uint32(pattern[i]);
+        if (c >= fmi.symbol_count()) return make_vector(index_type(1), index_type(0));
+        const index_type lo = rank(fmi, index_type(range.x - 1), uint8(c)), hi = rank(fmi, range.y, uint8(c));
+        range.x = fmi.L2(c) + lo + 1;
+        range.y = fmi.L2(c) + hi;
+    }
+    return range;
+}
+template <typename R, typename S, typename L, typename Iterator> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
+typename NVBIO_FMI::range_type match(const NVBIO_FMI& fmi, const Iterator pattern, const uint32 pattern_len)
+{
+    typedef typename NVBIO_FMI::index_type index_type;
+    return match(fmi, pattern, pattern_len, make_vector(index_type(0), fmi.length()));
+}
+/// the pattern walked front to back, i.e. a search for its reverse   (fmindex_inl.h:349-382)
+template <typename R, typename S, typename L, typename Iterator> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
+typename NVBIO_FMI::range_type match_reverse(const NVBIO_FMI& fmi, const Iterator pattern, const uint32 pattern_len)
+{
+    typedef typename NVBIO_FMI::index_type index_type;
+    typename NVBIO_FMI::range_type range = make_vector(index_type(0), fmi.length());
+    for (uint32 i = 0; i < pattern_len && range.x <= range.y; ++i)
+    {
+        const uint32 c = uint32(pattern[i]);
+        if (c >= fmi.symbol_count()) return make_vector(index_type(1), index_type(0));
+        const index_type lo = rank(fmi, index_type(range.x - 1), uint8(c)), hi = rank(fmi, range.y, uint8(c));
+        range.x = fmi.L2(c) + lo + 1;
+        range.y = fmi.L2(c) + hi;
+    }
+    return range;
+}
+
+/// one LF step (fmindex_inl.h:390-414): the row of the suffix one text position earlier; the SA = 0 row wraps to row 0
+NVBIO_FMI_T NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
+typename NVBIO_FMI::index_type basic_inv_psi(const NVBIO_FMI& fmi, const typename NVBIO_FMI::index_type i)
+{
+    typedef typename NVBIO_FMI::index_type index_type;
+    if (i == fmi.primary()) return 0;
+    const index_type k = i < fmi.primary() ? i : i - 1;
+    const uint8 c = fmi.m_rank_dict.m_text[k];
+    return fmi.L2(c) + rank(fmi.m_rank_dict, k, uint32(c));
+}
+
+/// LF-walk to the next sampled row: (row, steps)   (fmindex_inl.h:511-545)
+NVBIO_FMI_T NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
+typename NVBIO_FMI::range_type locate_ssa_iterator(const NVBIO_FMI& fmi, const typename NVBIO_FMI::index_type i)
+{
+    typedef typename NVBIO_FMI::index_type index_type;
+    index_type j = i, t = 0;
+    while (!fmi.m_sa.has(j)) { j = basic_inv_psi(fmi, j); ++t; }
+    return make_vector(j, t);
+}
+/// the sampled value of an iterator plus its steps   (fmindex_inl.h:553-569)
+NVBIO_FMI_T NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
+typename NVBIO_FMI::index_type lookup_ssa_iterator(const NVBIO_FMI& fmi, const typename NVBIO_FMI::range_type it)
+{
+    typename NVBIO_FMI::index_type suffix = 0;
+    fmi.m_sa.fetch(it.x, suffix);
+    return suffix + it.y;
+}
+/// text position of SA row i   (fmindex_inl.h:466-501)
+NVBIO_FMI_T NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
+typename NVBIO_FMI::index_type locate(const NVBIO_FMI& fmi, const typename NVBIO_FMI::index_type i)
+{
+    return lookup_ssa_iterator(fmi, locate_ssa_iterator(fmi, i));
+}
+
+#undef NVBIO_FMI_T
+#undef NVBIO_FMI
+
+} // namespace nvbio

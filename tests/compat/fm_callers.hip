@@ -1,0 +1,143 @@
+// tests/compat/fm_callers.hip -- caller kernels of the FM-index written against the reference's template interface
+// (the way nvbio-test/fmindex_test.cu:63-92 and rank_test.cu:55-86 use it): a kernel that backward-searches a slice of
+// the packed genome with match() and locates the first row of its range, and one that issues rank / rank4 point queries;
+// over 32- and 64-bit indices, with separate bwt / occ arrays and with the interleaved uint4 production layout seen
+// through deinterleaved_iterator (nvbio/io/fmindex/fmindex.h:159-174).  Compiled with `hipcc -I include/nvbio_hip/compat`.
+#include <nvbio/basic/types.h>
+#include <nvbio/basic/cached_iterator.h>
+#include <nvbio/basic/packedstream.h>
+#include <nvbio/basic/deinterleaved_iterator.h>
+#include <nvbio/basic/cuda/ldg.h>
+#include <nvbio/fmindex/bwt.h>
+#include <nvbio/fmindex/ssa.h>
+#include <nvbio/fmindex/fmindex.h>
+
+using namespace nvbio;
+
+template <typename FMIndexType, typename word_type>
+__global__ void search_and_locate_kernel(const uint32 n_queries, const uint32 query_len, const word_type* genome_words, const FMIndexType fmi,
+                                         const uint32* starts, typename FMIndexType::index_type* ranges, typename FMIndexType::index_type* positions,
+                                         typename FMIndexType::index_type* reverse_ranges)
+{
+    typedef typename FMIndexType::index_type index_type;
+    typedef typename FMIndexType::range_type range_type;
+    const uint32 q = threadIdx.x + blockIdx.x * blockDim.x;
+    if (q >= n_queries) return;
+
+    typedef const_cached_iterator<const word_type*>                    cached_words;
+    typedef PackedStream<cached_words, uint8, 2, true, index_type>     genome_string;
+    const genome_string genome((cached_words(genome_words)));
+
+    const range_type range = match(fmi, genome + starts[q], query_len);
+    ranges[2 * q] = range.x; ranges[2 * q + 1] = range.y;
+    positions[q] = (range.x <= range.y) ? locate(fmi, range.x) : index_type(-1);
+    if (range.x <= range.y)
+    {
+        // the two-pass form must agree with locate()
+        const range_type it = locate_ssa_iterator(fmi, range.y);
+        if (lookup_ssa_iterator(fmi, it) != locate(fmi, range.y)) positions[q] = index_type(-2);
+    }
+    const range_type rrange = match_reverse(fmi, genome + starts[q], query_len);
+    reverse_ranges[2 * q] = rrange.x; reverse_ranges[2 * q + 1] = rrange.y;
+}
+
+template <typename FMIndexType>
+__global__ void rank_kernel(const uint32 n, const FMIndexType fmi, const typename FMIndexType::index_type* rows, const uint8* symbols,
+                            typename FMIndexType::index_type* out, typename FMIndexType::index_type* out4)
+{
+    typedef typename FMIndexType::index_type index_type;
+    const uint32 q = threadIdx.x + blockIdx.x * blockDim.x;
+    if (q >= n) return;
+    out[q] = rank(fmi, rows[q], symbols[q]);
+    const typename FMIndexType::rank_dictionary_type::vec4_type r4 = rank4(fmi, rows[q]);
+    out4[4 * q] = r4.x; out4[4 * q + 1] = r4.y; out4[4 * q + 2] = r4.z; out4[4 * q + 3] = r4.w;
+    // the range form resolves both ends like two point queries
+    const typename FMIndexType::range_type rr = rank(fmi, make_vector(index_type(rows[q] - 1), rows[q]), symbols[q]);
+    if (rr.y != out[q] || rr.x != rank(fmi, index_type(rows[q] - 1), symbols[q])) out[q] = index_type(-7);
+}
+
+// separate arrays, as the reference's synthetic tests build them (fmindex_test.cu:418-600)
+template <typename index_type>
+struct SeparateLayout
+{
+    typedef PackedStream<const index_type*, uint8, 2, true, index_type>                 bwt_type;
+    typedef rank_dictionary<2, 64, bwt_type, const index_type*, const uint32*>          rank_dict_type;
+    typedef SSA_index_multiple_context<16, const index_type*>                           ssa_type;
+    typedef fm_index<rank_dict_type, ssa_type>                                          fm_index_type;
+    static fm_index_type make(index_type n, index_type primary, const index_type* L2, const void* bwt, const void* occ, const uint32* count_table, const index_type* ssa)
+    {
+        return fm_index_type(n, primary, L2, rank_dict_type(bwt_type((const index_type*)bwt), (const index_type*)occ, count_table), ssa_type(ssa));
+    }
+};
+// the production layout: one uint4 of bwt words and one uint4 of counters per 64 symbols, interleaved
+struct InterleavedLayout
+{
+    typedef cuda::ldg_pointer<uint4>                                bwt_occ_type;
+    typedef deinterleaved_iterator<2, 0, bwt_occ_type>              bwt_words;
+    typedef deinterleaved_iterator<2, 1, bwt_occ_type>              occ_type;
+    typedef PackedStream<bwt_words, uint8, 2, true>                 bwt_type;
+    typedef rank_dictionary<2, 64, bwt_type, occ_type, cuda::ldg_pointer<uint32> >     rank_dict_type;
+    typedef SSA_index_multiple_context<16, cuda::ldg_pointer<uint32> >                  ssa_type;
+    typedef fm_index<rank_dict_type, ssa_type>                      fm_index_type;
+    static fm_index_type make(uint32 n, uint32 primary, const uint32* L2, const void* bwt_occ, const void*, const uint32* count_table, const uint32* ssa)
+    {
+        const bwt_occ_type base((const uint4*)bwt_occ);
+        return fm_index_type(n, primary, L2, rank_dict_type(bwt_type(bwt_words(base)), occ_type(base), cuda::ldg_pointer<uint32>(count_table)),
+                             ssa_type(cuda::ldg_pointer<uint32>(ssa)));
+    }
+};
+
+#define API extern "C" __attribute__((visibility("default")))
+
+template <typename Layout, typename index_type>
+static int run_search(index_type n, index_type primary, const index_type* L2, const void* bwt, const void* occ, const uint32* count_table, const index_type* ssa,
+                      uint32 n_queries, uint32 query_len, const void* genome_words, const uint32* starts, index_type* ranges, index_type* positions, index_type* rranges)
+{
+    const typename Layout::fm_index_type fmi = Layout::make(n, primary, L2, bwt, occ, count_table, ssa);
+    hipLaunchKernelGGL((search_and_locate_kernel<typename Layout::fm_index_type, index_type>), dim3((n_queries + 127u) / 128u), dim3(128), 0, 0,
+                       n_queries, query_len, (const index_type*)genome_words, fmi, starts, ranges, positions, rranges);
+    return int(hipDeviceSynchronize());
+}
+template <typename Layout, typename index_type>
+static int run_rank(index_type n, index_type primary, const index_type* L2, const void* bwt, const void* occ, const uint32* count_table,
+                    uint32 n_queries, const index_type* rows, const uint8* symbols, index_type* out, index_type* out4)
+{
+    const typename Layout::fm_index_type fmi = Layout::make(n, primary, L2, bwt, occ, count_table, (const index_type*)NULL);
+    hipLaunchKernelGGL((rank_kernel<typename Layout::fm_index_type>), dim3((n_queries + 127u) / 128u), dim3(128), 0, 0, n_queries, fmi, rows, symbols, out, out4);
+    return int(hipDeviceSynchronize());
+}
+
+// layout: 0 = separate arrays with 32-bit words / indices, 1 = separate arrays with 64-bit words / indices, 2 = interleaved uint4 (32-bit)
+API int compat_fm_search(int layout, unsigned long long n, unsigned long long primary, const void* L2, const void* bwt, const void* occ, const unsigned* count_table,
+                         const void* ssa, unsigned n_queries, unsigned query_len, const void* genome_words, const unsigned* starts, void* ranges, void* positions, void* rranges)
+{
+    if (layout == 0) return run_search< SeparateLayout<uint32>, uint32 >(uint32(n), uint32(primary), (const uint32*)L2, bwt, occ, count_table, (const uint32*)ssa, n_queries, query_len, genome_words, starts, (uint32*)ranges, (uint32*)positions, (uint32*)rranges);
+    if (layout == 1) return run_search< SeparateLayout<uint64>, uint64 >(uint64(n), uint64(primary), (const uint64*)L2, bwt, occ, count_table, (const uint64*)ssa, n_queries, query_len, genome_words, starts, (uint64*)ranges, (uint64*)positions, (uint64*)rranges);
+    if (layout == 2) return run_search< InterleavedLayout, uint32 >(uint32(n), uint32(primary), (const uint32*)L2, bwt, occ, count_table, (const uint32*)ssa, n_queries, query_len, genome_words, starts, (uint32*)ranges, (uint32*)positions, (uint32*)rranges);
+    return -1;
+}
+API int compat_fm_rank(int layout, unsigned long long n, unsigned long long primary, const void* L2, const void* bwt, const void* occ, const unsigned* count_table,
+                       unsigned n_queries, const void* rows, const unsigned char* symbols, void* out, void* out4)
+{
+    if (layout == 0) return run_rank< SeparateLayout<uint32>, uint32 >(uint32(n), uint32(primary), (const uint32*)L2, bwt, occ, count_table, n_queries, (const uint32*)rows, symbols, (uint32*)out, (uint32*)out4);
+    if (layout == 1) return run_rank< SeparateLayout<uint64>, uint64 >(uint64(n), uint64(primary), (const uint64*)L2, bwt, occ, count_table, n_queries, (const uint64*)rows, symbols, (uint64*)out, (uint64*)out4);
+    if (layout == 2) return run_rank< InterleavedLayout, uint32 >(uint32(n), uint32(primary), (const uint32*)L2, bwt, occ, count_table, n_queries, (const uint32*)rows, symbols, (uint32*)out, (uint32*)out4);
+    return -1;
+}
+
+// the same templates on the host (fmindex_test.cu:376-413 runs its cpu alignment loop this way)
+API int compat_fm_search_host(unsigned n, unsigned primary, const unsigned* L2, const unsigned* bwt, const unsigned* occ, const unsigned* ssa,
+                              unsigned n_queries, unsigned query_len, const unsigned* genome_words, const unsigned* starts, unsigned* ranges, unsigned* positions)
+{
+    uint32 count_table[256];
+    gen_bwt_count_table(count_table);
+    const SeparateLayout<uint32>::fm_index_type fmi = SeparateLayout<uint32>::make(n, primary, L2, bwt, occ, count_table, ssa);
+    const PackedStream<const uint32*, uint8, 2, true> genome(genome_words);
+    for (uint32 q = 0; q < n_queries; ++q)
+    {
+        const uint2 range = match(fmi, genome + starts[q], query_len);
+        ranges[2 * q] = range.x; ranges[2 * q + 1] = range.y;
+        positions[q] = range.x <= range.y ? locate(fmi, range.x) : 0xFFFFFFFFu;
+    }
+    return 0;
+}

@@ -1,0 +1,140 @@
+"""FM-index half of the drop-in template layer: caller kernels written against the reference's fm_index<> / rank_dictionary<>
+templates (tests/compat/fm_callers.hip, in the shape of nvbio-test/fmindex_test.cu:63-92 and rank_test.cu) compiled with
+`hipcc -I include/nvbio_hip/compat`: match / match_reverse / locate / ssa iterators / rank / rank4 per thread, over separate
+bwt + occ arrays with 32- and 64-bit indices and over the interleaved uint4 production layout -- against the oracle.
+The host instantiation of the same templates runs on the CPU suite."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "tests", "compat", "libfm_callers.so")
+
+
+@pytest.fixture(scope="module")
+def fm():
+    assert os.path.exists(LIB), "build with python -c 'import __graft_entry__ as g; g.build()'"
+    L = C.CDLL(LIB)
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+    L.compat_fm_search.argtypes = [i32, u64, u64, vp, vp, vp, vp, vp, u32, u32, vp, vp, vp, vp, vp]
+    L.compat_fm_rank.argtypes = [i32, u64, u64, vp, vp, vp, vp, u32, vp, vp, vp, vp]
+    L.compat_fm_search_host.argtypes = [u32, u32, vp, vp, vp, vp, u32, u32, vp, vp, vp, vp]
+    return L
+
+
+@pytest.fixture(scope="module")
+def index():
+    rng = np.random.default_rng(17)
+    n = 60001
+    text = rng.integers(0, 4, n, dtype=np.uint8)
+    text[2000:2600] = np.tile(np.array([0, 1, 1], np.uint8), 200)
+    host = O.FMIndex(text)
+    nb = (n + 63) // 64 + 1
+    occ = np.zeros(nb * 4, dtype=np.uint32)
+    cum = np.zeros((n + 1, 4), dtype=np.int64)
+    for c in range(4):
+        cum[1:, c] = np.cumsum(host.bwt == c)
+    for k in range(nb):
+        occ[4 * k: 4 * k + 4] = cum[min(64 * k, n)]
+    bw = np.concatenate([O.pack(host.bwt, 2, True, pad_words=0), np.zeros(8, np.uint32)])
+    bw = bw[: (bw.size // 2) * 2]
+    gw = np.concatenate([O.pack(text, 2, True, pad_words=0), np.zeros(8, np.uint32)])
+    gw = gw[: (gw.size // 2) * 2]
+    to64 = lambda w: (w[0::2].astype(np.uint64) << np.uint64(32)) | w[1::2].astype(np.uint64)
+    ssa64 = host.ssa.astype(np.uint64)
+    ssa64[0] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    d = dict(text=text, host=host, n=n, occ32=occ, bwt32=bw, genome32=gw, L2_32=host.L2.astype(np.uint32), ssa32=host.ssa,
+             occ64=occ.astype(np.uint64), bwt64=to64(bw), genome64=to64(gw), L2_64=host.L2.astype(np.uint64), ssa64=ssa64)
+    ct = np.zeros(256, np.uint32)
+    d["count_table"] = ct
+    return d
+
+
+def queries(d, nq, qlen, seed):
+    rng = np.random.default_rng(seed)
+    starts = rng.integers(0, d["n"] - qlen + 1, nq).astype(np.uint32)
+    starts[:4] = [0, d["n"] - qlen, 2000, 2301]
+    pats = [d["text"][s:s + qlen] for s in starts]
+    exp = d["host"].match(O.StringSet.from_lists(pats, 2, True))
+    rexp = d["host"].match(O.StringSet.from_lists([p[::-1] for p in pats], 2, True))
+    pos = d["host"].locate(exp[:, 0])
+    return starts, exp, rexp, pos
+
+
+def test_host_instantiation_matches_oracle(fm, index):
+    d = index
+    starts, exp, _, pos = queries(d, 3000, 22, 1)
+    ranges = np.zeros((starts.size, 2), np.uint32)
+    positions = np.zeros(starts.size, np.uint32)
+    p = lambda a: a.ctypes.data
+    assert fm.compat_fm_search_host(d["n"], d["host"].primary, p(d["L2_32"]), p(d["bwt32"]), p(d["occ32"]), p(d["ssa32"]),
+                                    starts.size, 22, p(d["genome32"]), p(starts), p(ranges), p(positions)) == 0
+    assert (ranges == exp).all()
+    assert (positions == pos).all()
+    assert (d["text"][positions[0]:positions[0] + 22] == d["text"][starts[0]:starts[0] + 22]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", [0, 1, 2], ids=["separate32", "separate64", "interleaved_uint4"])
+@pytest.mark.parametrize("qlen", [22, 7, 33])
+def test_caller_kernel_match_locate(fm, index, layout, qlen):
+    import torch
+    d = index
+    starts, exp, rexp, pos = queries(d, 20000, qlen, 2 + qlen)
+    dt = np.uint64 if layout == 1 else np.uint32
+    sfx = "64" if layout == 1 else "32"
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64 if a.dtype == np.uint64 else np.int32 if a.dtype == np.uint32 else a.dtype)).cuda()
+    L2, ssa, genome = dev(d["L2_" + sfx]), dev(d["ssa" + sfx]), dev(d["genome" + sfx])
+    if layout == 2:
+        bwt, occ = dev(d["host"].bwt_occ), None
+    else:
+        bwt, occ = dev(d["bwt" + sfx]), dev(d["occ" + sfx])
+    ct, st = dev(d["count_table"]), dev(starts)
+    tdt = torch.int64 if layout == 1 else torch.int32
+    ranges = torch.zeros((starts.size, 2), dtype=tdt, device="cuda")
+    rranges = torch.zeros((starts.size, 2), dtype=tdt, device="cuda")
+    positions = torch.zeros(starts.size, dtype=tdt, device="cuda")
+    vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    assert fm.compat_fm_search(layout, d["n"], d["host"].primary, vp(L2), vp(bwt), vp(occ), vp(ct), vp(ssa), starts.size, qlen, vp(genome), vp(st),
+                               vp(ranges), vp(positions), vp(rranges)) == 0
+    got = ranges.cpu().numpy().view(dt)
+    assert (got == exp.astype(dt)).all()
+    assert (positions.cpu().numpy().view(dt) == pos.astype(dt)).all()
+    grr = rranges.cpu().numpy().view(dt)
+    empty = rexp[:, 0] > rexp[:, 1]
+    assert (grr[~empty] == rexp[~empty].astype(dt)).all()
+    # an empty range is the raw (l, r) of the step that emptied it: the same 32-bit values, computed in the index's own width
+    if layout != 1:
+        assert (grr[empty] == rexp[empty]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", [0, 1, 2], ids=["separate32", "separate64", "interleaved_uint4"])
+def test_caller_kernel_rank(fm, index, layout):
+    import torch
+    d = index
+    rng = np.random.default_rng(9)
+    n = d["n"]
+    rows = np.concatenate([rng.integers(0, n + 1, 30000), [0, n, d["host"].primary, d["host"].primary - 1, d["host"].primary + 1, 63, 64, 65]]).astype(np.uint32)
+    syms = rng.integers(0, 4, rows.size).astype(np.uint8)
+    exp, exp4 = d["host"].rank(rows, syms), d["host"].rank4(rows)
+    dt = np.uint64 if layout == 1 else np.uint32
+    sfx = "64" if layout == 1 else "32"
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64 if a.dtype == np.uint64 else np.int32 if a.dtype == np.uint32 else a.dtype)).cuda()
+    L2 = dev(d["L2_" + sfx])
+    if layout == 2:
+        bwt, occ = dev(d["host"].bwt_occ), None
+    else:
+        bwt, occ = dev(d["bwt" + sfx]), dev(d["occ" + sfx])
+    ct, r, s = dev(d["count_table"]), dev(rows.astype(dt)), dev(syms)
+    tdt = torch.int64 if layout == 1 else torch.int32
+    out = torch.zeros(rows.size, dtype=tdt, device="cuda")
+    out4 = torch.zeros((rows.size, 4), dtype=tdt, device="cuda")
+    vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    assert fm.compat_fm_rank(layout, n, d["host"].primary, vp(L2), vp(bwt), vp(occ), vp(ct), rows.size, vp(r), vp(s), vp(out), vp(out4)) == 0
+    assert (out.cpu().numpy().view(dt) == exp.astype(dt)).all()
+    assert (out4.cpu().numpy().view(dt) == exp4.astype(dt)).all()
