@@ -327,6 +327,23 @@ uint64_t nvbio_hip_fm_build_dimer_index_temp_bytes(uint32_t length);
 int nvbio_hip_fm_build_dimer_index(const nvbio_hip_fmindex* fmi, uint32_t* out_dimer, void* temp, uint64_t temp_bytes, void* stream);
 int nvbio_hip_fm_attach_dimer_index(nvbio_hip_fmindex* fmi, const uint32_t* dimer, void* stream);
 
+/* ---- `_host` twins: the reference's HostThreadScheduler / host paths (batched_banded_inl.h:97-128,
+ * batched_inl.h:236-300, the host fm_index functions) behind the same argument lists with HOST pointers everywhere and a
+ * thread count (0 = OpenMP's default) instead of a stream.  Strings may be 2-, 4- or 8-bit packed.  Explicit entry points
+ * for CPU-side callers; the device entry points never fall back to them. */
+int nvbio_hip_banded_gotoh_score_host(const nvbio_hip_gotoh_scheme* scheme, int32_t type, uint32_t band_len,
+                                      const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts,
+                                      uint32_t n, int32_t* out_score, uint32_t* out_sink, int32_t n_threads);
+int nvbio_hip_banded_sw_score_host(const nvbio_hip_sw_scheme* scheme, int32_t type, uint32_t band_len,
+                                   const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts,
+                                   uint32_t n, int32_t* out_score, uint32_t* out_sink, int32_t n_threads);
+int nvbio_hip_alignment_score_host(int32_t aligner, int32_t algorithm, const int32_t* scheme4, int32_t type,
+                                   const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts, const int32_t* min_score /* nullable */,
+                                   uint32_t n, int32_t* out_score, uint32_t* out_sink, uint8_t* out_ok /* nullable */, int32_t n_threads);
+int nvbio_hip_fm_rank_host(const nvbio_hip_fmindex* fmi, const uint32_t* k, const uint8_t* c, uint32_t n, uint32_t* out, int32_t n_threads);
+int nvbio_hip_fm_match_host(const nvbio_hip_fmindex* fmi, const nvbio_hip_string_set* seeds, uint32_t n, uint32_t* out_range, int32_t n_threads);
+int nvbio_hip_fm_locate_host(const nvbio_hip_fmindex* fmi, const uint32_t* sa_rows, uint32_t n, uint32_t* out_pos, int32_t n_threads);
+
 /* Builds the optional k-mer table for `fmi` (fmi->ktab is ignored): out_ktab[2c..2c+1] =
  * match(fmi, kmer c), where kmer c has symbol t (0 = first) at bits [2t,2t+2) of c, for all
  * 4^k codes; 1 <= k <= 15; out_ktab holds 2*4^k words (k=12: 128 MiB, k=14: 2 GiB, k=15: 8 GiB). */

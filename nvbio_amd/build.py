@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libnvbio_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fopenmp",
          "-Wno-unused-result", "-Wno-deprecated-declarations"]
 
 
@@ -24,6 +24,8 @@ def sources():
 def _deps():
     d = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     d.append(os.path.join(HERE, "..", "include", "nvbio_hip.h"))
+    compat = os.path.join(HERE, "..", "include", "nvbio_hip", "compat")       # host_twins.hip instantiates the drop-in templates
+    d += [os.path.join(r, f) for r, _, fs in os.walk(compat) for f in fs]
     return d
 
 
@@ -56,7 +58,7 @@ def build(force=False, verbose=False):
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
             list(ex.map(run, jobs))
     if jobs or force or _stale(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-fopenmp", "-o", LIB] + objs)
     return LIB
 
 
