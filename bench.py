@@ -58,7 +58,7 @@ def measured_traffic(kernel):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20 on one GPU, 200 when --gpus > 1: the gather needs a longer region)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
     ap.add_argument("--genome", type=float, default=3.0e9, help="synthetic genome length of the FM-index legs (a true index is built on the device)")
@@ -81,6 +81,8 @@ def parse():
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.steps is None:
+        a.steps = 20 if world == 1 else 200
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("NVBIO_BENCH_SHARE_GPU") == "1":
@@ -202,6 +204,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(a.steps, 1)
+    if gather_on and rank == 0 and any(g.overflowed() for g in gatherers):
+        raise SystemExit("result gather: records did not fit the 4-byte format")
 
     out = None
     if rank == 0:
@@ -259,6 +263,7 @@ def e2e_sharded_leg(a, dev, rank, world, barrier):
     headline: barrier + synchronize on both sides, maximum over ranks.  Ranks first agree that set-up and a warm-up run succeeded
     everywhere, so that a local failure cannot leave the others waiting in the timed region."""
     from nvbio_amd import aligner as AL, select as SEL, pipeline as P
+    from nvbio_amd.distributed import RecordGather, alignment_records
     cpu = dist.get_backend() != "nccl"
     state, err = {}, ""
     try:
@@ -266,16 +271,20 @@ def e2e_sharded_leg(a, dev, rank, world, barrier):
         g = torch.Generator(device=dev)
         g.manual_seed(0x5EED0003)
         text = torch.randint(0, 4, (ng,), dtype=torch.uint8, generator=g, device=dev)
-        fmi = W.build_fm_index(text)
+        fmi = W.build_fm_index(text).with_dimer()            # the line-native index next to the reference layout
         genome_words = W._pack_chunked(text, 2, True)
         sym, pos, _ = P.make_reads(text, n, READ_LEN, seed=0x5EED0004 + rank)
         del text
         packed = P.pack_read_streams(sym)
         names = SEL.pack_names(["r%d.%d" % (rank, i) for i in range(n)], dev)
         prm = AL.Params(hits_stride=16, batch_size=n)
-        run = lambda: AL.best_approx(fmi, None, sym, genome_words, ng, prm, names=names, packed=packed)
+        gat = RecordGather(n * world, 4, dst=0, device=dev)       # 16 B per read to rank 0: alignment word, position, MAPQ, read id
+        def run():
+            r = AL.best_approx(fmi, None, sym, genome_words, ng, prm, names=names, packed=packed)
+            r["table"] = gat.gather(alignment_records(r["best"][0], r["mapq"], rank * n), concat=False)
+            return r
         run(); torch.cuda.synchronize()
-        state = dict(run=run, n=n, ng=ng, pos=pos)
+        state = dict(run=run, n=n, ng=ng, pos=pos, gat=gat)
     except Exception as e:          # noqa: BLE001 -- reported, and agreed on below
         err = "%s: %s" % (type(e).__name__, e)
     ok = torch.tensor([0 if err else 1], dtype=torch.int32, device="cpu" if cpu else dev)
@@ -294,10 +303,19 @@ def e2e_sharded_leg(a, dev, rank, world, barrier):
                         dtype=torch.float64, device="cpu" if cpu else dev)
     dist.all_reduce(frac, op=dist.ReduceOp.SUM)
     n, el = state["n"], float(elapsed.item())
+    gathered_ok = None
+    if rank == 0:
+        # the root's receive buffers hold every rank's records in rank order: its own shard must equal what it sent, and
+        # the read ids of the other shards must be theirs
+        gat = state["gat"]
+        own = alignment_records(r["best"][0], r["mapq"], 0)
+        gathered_ok = bool(torch.equal(gat.bufs[0][:n], own)) and all(
+            bool((gat.bufs[k][:n, 3] == torch.arange(k * n, (k + 1) * n, device=dev, dtype=torch.int64).to(torch.int32)).all()) for k in range(1, world))
     return {"driver": "nvbio_amd.aligner.best_approx (Aligner::best_approx: seeding passes, randomized selection, band-31 extension, reduce, MAPQ, traceback)",
+            "index": "line_native (two-symbol index attached)", "gather": True, "gather_record_bytes": 16, "gathered_records_verified": gathered_ok,
             "genome_symbols": state["ng"], "reads_per_gpu": n, "n_gpus": world, "ms_per_batch": el * 1e3, "Mreads_per_s": n * world / el / 1e6,
             "aligned": float(frac[0].item()) / world, "best_at_true_position": float(frac[1].item()) / world,
-            "sharding": "reads block-sharded, index replicated, no collective inside the pipeline (results stay on their GPU; the headline leg measures the gather)"}
+            "sharding": "reads block-sharded, index replicated, no collective inside the pipeline; one gather of 16-byte alignment records to rank 0 per batch, inside the timed region"}
 
 
 def fm_legs(a, dev):

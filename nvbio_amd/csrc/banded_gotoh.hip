@@ -63,19 +63,19 @@ static hipError_t launch(const GotohParams& p, const QA& qa, int type, uint32_t 
 
 // Longest pattern for which the 16-bit kernel is exact, from the scheme, band and type alone
 // (0 = never).  Reachable DP values:
-//   LOCAL (scores x32):  0 <= H <= M*match;  E, F, diagonal >= -(|G_o| + |G_e| + |mismatch|);
-//                        keys add j < 32.  Need 32*(M*match) + 31 <= 32767 and the negative side
-//                        far above the sentinel.
+//   LOCAL (scores x32):  0 <= H <= M*S, S = the largest substitution score (match -- or a mismatch / quality-LUT
+//                        entry above it: the scheme is arbitrary ints);  E, F, diagonal >= -(|G_o| + |G_e| + |mismatch|);
+//                        keys add j < 32.  Need 32*(M*S) + 31 <= 32767 and the negative side far above the sentinel.
 //   GLOBAL/SEMI_GLOBAL:  |value| <= (M + BAND + 2) * max|cost|; need that below 15000 so that
 //                        no real value comes within a band's worth of gap steps of the sentinel.
-static uint32_t max_len_16bit(int32_t match, int64_t A /* max |cost| */, int32_t gap_open, int32_t gap_ext, int type, uint32_t band)
+static uint32_t max_len_16bit(int32_t match, int32_t best_pair /* max substitution score */, int64_t A /* max |cost| */, int32_t gap_open, int32_t gap_ext, int type, uint32_t band)
 {
     if (gap_open > 0 || gap_ext > 0) return 0;
     if (A == 0) return 0xFFFFFFFFu;
     if (type == NVBIO_HIP_LOCAL) {
         if (match < 0 || A > 100) return 0;                          // 32*4*A stays far above -32768
-        if (match == 0) return 0xFFFFFFFFu;
-        return uint32_t(1022 / match);
+        if (best_pair <= 0) return 0xFFFFFFFFu;
+        return uint32_t(1022 / best_pair);
     }
     const int64_t lim = 15000 / A - int64_t(band) - 2;
     return lim <= 0 ? 0u : uint32_t(lim);
@@ -84,14 +84,14 @@ static uint32_t max_len_16bit(int32_t match, int64_t A /* max |cost| */, int32_t
 } // namespace nvb
 
 template <typename QA>
-static int banded_gotoh_dispatch(nvb::GotohParams& p, const QA& qa, int64_t max_abs_cost, int32_t type, uint32_t band_len,
+static int banded_gotoh_dispatch(nvb::GotohParams& p, const QA& qa, int64_t max_abs_cost, int32_t best_pair, int32_t type, uint32_t band_len,
                                  const nvbio_hip_string_set* patterns, hipStream_t s, const char* tag16, const char* tag32)
 {
     using namespace nvb;
     // NVBIO_HIP_FORCE_32BIT=1 disables the 16-bit kernels (used by the tests to cover both widths)
     const char* force32 = getenv("NVBIO_HIP_FORCE_32BIT");
     const uint32_t lim16 = (force32 && force32[0] == '1') ? 0u
-                         : max_len_16bit(p.match, max_abs_cost, std::max(p.gap_open, p.txt_gap_open), std::max(p.gap_ext, p.txt_gap_ext), type, band_len);
+                         : max_len_16bit(p.match, best_pair, max_abs_cost, std::max(p.gap_open, p.txt_gap_open), std::max(p.gap_ext, p.txt_gap_ext), type, band_len);
     const bool fixed = (patterns->length == nullptr);
     hipError_t e = hipSuccess;
     // LDS staging of each lane's words, sized from the longest pattern the caller announces
@@ -160,7 +160,7 @@ NVB_API int nvbio_hip_banded_gotoh_score(
     p.n = n; p.out_score = out_score; p.out_sink = out_sink;
     p.stage_pw = max_pattern_len; p.stage_tw = 0;       // the hint, consumed by banded_gotoh_dispatch
     const int64_t A = std::max(std::max(iabs64(scheme->match), iabs64(scheme->mismatch)), std::max(iabs64(scheme->gap_open), iabs64(scheme->gap_ext)));
-    return banded_gotoh_dispatch(p, NoQual(), A, type, band_len, patterns, to_stream(stream),
+    return banded_gotoh_dispatch(p, NoQual(), A, std::max(scheme->match, scheme->mismatch), type, band_len, patterns, to_stream(stream),
                                  "banded_gotoh_score_kernel<A16>", "banded_gotoh_score_kernel<A32>");
 }
 
@@ -191,8 +191,9 @@ NVB_API int nvbio_hip_banded_gotoh_score_qual(
     qa.quals = quals; qa.n_quals = n_quals;
     int64_t A = std::max(std::max(iabs64(scheme->match), iabs64(scheme->pattern_gap_open)), std::max(iabs64(scheme->pattern_gap_ext),
                 std::max(iabs64(scheme->text_gap_open), iabs64(scheme->text_gap_ext))));
-    for (int i = 0; i < 256; ++i) { qa.lut[i] = scheme->mismatch[i]; A = std::max(A, iabs64(scheme->mismatch[i])); }
-    return banded_gotoh_dispatch(p, qa, A, type, band_len, patterns, to_stream(stream),
+    int32_t best_pair = scheme->match;
+    for (int i = 0; i < 256; ++i) { qa.lut[i] = scheme->mismatch[i]; A = std::max(A, iabs64(scheme->mismatch[i])); best_pair = std::max(best_pair, scheme->mismatch[i]); }
+    return banded_gotoh_dispatch(p, qa, A, best_pair, type, band_len, patterns, to_stream(stream),
                                  "banded_gotoh_score_kernel<A16,qual>", "banded_gotoh_score_kernel<A32,qual>");
 }
 

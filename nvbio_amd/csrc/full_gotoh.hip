@@ -41,6 +41,7 @@ struct FullParams {
     int32_t*       out_score;
     uint32_t*      out_sink;
     uint8_t*       out_ok;         // nullable: the reference's per-job bool
+    uint32_t       max_m, max_n;   // the bounds the register layout and the key packing were chosen for
     uint32_t       blk_log2;       // log2 of the reference's block width: fixes the LOCAL tie order (3 = Gotoh, 4 = SW / ED)
     uint32_t       pattern_blocking;   // 0: blocks of text columns (TextBlockingTag); 1: blocks of pattern rows (PatternBlockingTag)
     // quality-aware scheme (nvBowtie): mismatch by the quality byte of the pattern symbol; nullptr = constant `mismatch`
@@ -514,7 +515,13 @@ full_gotoh_score_kernel(const FullParams p)
     const int32_t  min_score = check ? p.min_score[job] : -(1 << 30);
 
     int32_t score = -(1 << 30); uint32_t sx = 0xFFFFFFFFu, sy = 0xFFFFFFFFu; uint32_t ok = 1u;
-    if (M == 0u)
+    if (M > p.max_m || N > p.max_n)
+    {
+        // a job longer than the caller stated: its rows would not fit the lanes' registers (or its columns the packed
+        // keys).  Never a plausible number: the failed-alignment record with ok = 0.
+        ok = 0u;
+    }
+    else if (M == 0u)
     {
         // no rows: only the row above the matrix is ever reported (:1203-1207, :1404-1421)
         const uint32_t nb = 8u * ((N + 7u) / 8u);
@@ -625,6 +632,7 @@ static int full_score_core(
     p.match = scheme->match; p.mismatch = scheme->mismatch; p.gap_open = scheme->gap_open; p.gap_ext = scheme->gap_ext;
     p.min_score = min_score; p.n = n; p.out_score = out_score; p.out_sink = out_sink; p.out_ok = out_ok;
     p.blk_log2 = blk_log2; p.pattern_blocking = pattern_blocking;
+    p.max_m = maxM; p.max_n = maxN;
     p.quals = qual ? qual->quals : nullptr; p.n_quals = qual ? qual->n_quals : 0;
     for (int i = 0; i < 256; ++i) p.mm_lut[i] = qual ? qual->mismatch[i] : scheme->mismatch;
     // which boundary line is initialised with which gap costs depends on the tag (gotoh_inl.h:82-88 vs :693-697 / :1171-1175)
@@ -639,13 +647,18 @@ static int full_score_core(
     int64_t A = std::max(std::max(iabs(scheme->match), iabs(scheme->mismatch)), std::max(iabs(scheme->gap_open), iabs(scheme->gap_ext)));
     if (qual) { for (int i = 0; i < 256; ++i) A = std::max(A, iabs(qual->mismatch[i])); A = std::max(A, std::max(iabs(qual->text_gap_open), iabs(qual->text_gap_ext))); }
     const int64_t span = (type == NVBIO_HIP_GLOBAL) ? int64_t(maxM) + maxN + 4 : int64_t(maxM) + 4;
-    const bool trunc = !(scheme->gap_open <= 0 && scheme->gap_ext <= 0 && span * A < 30000);
+    // the 16-bit sweep's sentinel and range reasoning assume that no gap move earns score, on either string
+    const bool gaps_cost = scheme->gap_open <= 0 && scheme->gap_ext <= 0 && (!qual || (qual->text_gap_open <= 0 && qual->text_gap_ext <= 0));
+    const bool trunc = !(gaps_cost && span * A < 30000);
+    // the largest score one aligned pair can add: LOCAL's H is bounded by M times it, not by M * match
+    int32_t best_pair = std::max(scheme->match, scheme->mismatch);
+    if (qual) for (int i = 0; i < 256; ++i) best_pair = std::max(best_pair, qual->mismatch[i]);
     hipStream_t s = to_stream(stream);
     g_last_kernel = "full_gotoh_score_kernel";
     const int R = maxM <= 64u ? 1 : maxM <= 128u ? 2 : maxM <= 192u ? 3 : maxM <= 256u ? 4 : 8;
     // the 16-bit sweep needs: values inside int16 (= !trunc), LOCAL scores < 2048 and columns < 2^20 for its packed row maxima
     const char* nofast = getenv("NVBIO_HIP_FULL_GENERIC");
-    const bool fast = !trunc && maxN < (1u << 20) && (type != NVBIO_HIP_LOCAL || (scheme->match >= 0 && int64_t(maxM) * scheme->match < 2048))
+    const bool fast = !trunc && maxN < (1u << 20) && (type != NVBIO_HIP_LOCAL || (scheme->match >= 0 && int64_t(maxM) * best_pair < 2048))
                       && !(nofast && nofast[0] == '1');
     if (fast) {
         g_last_kernel = "full_gotoh_score_kernel<16-bit>";

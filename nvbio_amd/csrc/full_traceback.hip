@@ -294,7 +294,8 @@ static int full_traceback_core(
     int64_t A = std::max(std::max(iabs(scheme->match), iabs(scheme->mismatch)), std::max(iabs(scheme->gap_open), iabs(scheme->gap_ext)));
     if (qual) { for (int i = 0; i < 256; ++i) A = std::max(A, iabs(qual->mismatch[i])); A = std::max(A, std::max(iabs(qual->text_gap_open), iabs(qual->text_gap_ext))); }
     const int64_t span = (type == NVBIO_HIP_GLOBAL) ? int64_t(maxM) + maxN + 4 : int64_t(maxM) + 4;
-    if (!(scheme->gap_open <= 0 && scheme->gap_ext <= 0 && span * A < 30000)) return hipErrorNotSupported;   // int16 checkpoints / columns exact only here
+    const bool gaps_cost = scheme->gap_open <= 0 && scheme->gap_ext <= 0 && (!qual || (qual->text_gap_open <= 0 && qual->text_gap_ext <= 0));
+    if (!(gaps_cost && span * A < 30000)) return hipErrorNotSupported;   // int16 checkpoints / columns exact only here (no gap move may earn score)
     const uint64_t need = nvbio_hip_gotoh_traceback_temp_bytes(maxM, maxN, n);
     if (!temp || temp_bytes < need) return hipErrorInvalidValue;
 

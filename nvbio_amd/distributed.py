@@ -21,35 +21,80 @@ def shard_sizes(n_total, world):
     return [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
 
 
-class ResultGather:
-    """Gathers per-rank (score[n_r], sink[n_r,2]) records to `dst` in rank order.
+class RecordGather:
+    """Gathers fixed-width int32 records [n_r, width] from every rank to `dst`, in rank order -- the collective of the
+    path (16 B per read single-end, 32 B per pair).  xGMI is point-to-point, so this is a gather (the root
+    receives (G-1)/G of the bytes once over its 7 links, nobody else receives anything), not a ring all-gather.
+    Buffers are allocated once; `gather()` can be enqueued on a side stream to overlap the next batch's kernels.
+    One extra row per rank carries a status word (see ResultGather)."""
 
-    xGMI is point-to-point, so this is a gather (send/recv to the root over its 7 links), not a
-    ring all-gather: the root receives (G-1)/G of the bytes once, nobody else receives anything.
-    Record sizes (`record_bytes`):
-      12  {score, sink.x, sink.y}                          any batch
-       8  {score, sink.x << 16 | sink.y}                   sinks below 65535 (any short-read batch)
-       4  {score:int16 << 16 | sink.x:8 << 8 | sink.y:8}   sinks below 255 and |score| < 32767, e.g. 100 bp
-          reads in band-15 windows: at 3.3 G reads/s per GPU the root of an 8-GPU node takes in ~93 GB/s
-    An untouched sink (score -2^30, sink (-1,-1): text shorter than pattern) round-trips in every format.
-    Buffers are allocated once; `gather()` can be enqueued on a side stream to overlap the next
-    batch's kernel."""
-
-    def __init__(self, n_total, dst=0, device=None, group=None, compact=True, record_bytes=None):
-        if record_bytes is None:
-            record_bytes = 8 if compact else 12
-        assert record_bytes in (4, 8, 12)
-        self.group, self.dst, self.record_bytes = group, dst, record_bytes
+    def __init__(self, n_total, width, dst=0, device=None, group=None):
+        self.group, self.dst, self.width = group, dst, int(width)
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.sizes = shard_sizes(n_total, self.world)
         self.n_total = n_total
         self.pad = max(self.sizes) if self.sizes else 0
-        self.width = record_bytes // 4
         self.bufs = None
         if self.world > 1 and self.rank == dst:
-            self.bufs = [torch.empty((self.pad, self.width), dtype=torch.int32, device=device) for _ in range(self.world)]
-        self.send = torch.empty((self.pad, self.width), dtype=torch.int32, device=device) if self.world > 1 else None
+            self.bufs = [torch.empty((self.pad + 1, self.width), dtype=torch.int32, device=device) for _ in range(self.world)]
+        self.send = torch.zeros((self.pad + 1, self.width), dtype=torch.int32, device=device) if self.world > 1 else None
+
+    def _exchange(self):
+        if self.send.is_cuda and dist.get_backend(self.group) != "nccl":
+            # gloo cannot gather device tensors: stage through the host (debug / CPU-test configurations only)
+            host = [torch.empty(b.shape, dtype=b.dtype) for b in self.bufs] if self.rank == self.dst else None
+            dist.gather(self.send.cpu(), host, dst=self.dst, group=self.group)
+            if host is not None:
+                for b, h in zip(self.bufs, host):
+                    b.copy_(h)
+        else:
+            dist.gather(self.send, self.bufs if self.rank == self.dst else None, dst=self.dst, group=self.group)
+
+    def status(self):
+        """On dst: the per-rank status words of the last gather (one host read)."""
+        return [int(b[self.pad, 0].item()) for b in self.bufs] if self.bufs is not None else []
+
+    def gather(self, records, concat=True, status=None):
+        """records: int32 [n_r, width] of this rank.  Returns the [n_total, width] table on dst (None elsewhere);
+        concat=False leaves the records in `self.bufs[r][:self.sizes[r]]` and returns True on dst."""
+        n = records.shape[0]
+        assert n == self.sizes[self.rank] and records.shape[1] == self.width
+        if self.world == 1:
+            return records
+        self.send[:n] = records
+        if status is not None:
+            self.send[self.pad, 0] = status
+        self._exchange()
+        if self.rank != self.dst:
+            return None
+        if not concat:
+            return True
+        return torch.cat([self.bufs[r][: self.sizes[r]] for r in range(self.world)], dim=0)
+
+
+class ResultGather(RecordGather):
+    """Gathers per-rank (score[n_r], sink[n_r,2]) records -- BestSink<int32> -- to `dst` in rank order.
+
+    Record sizes (`record_bytes`):
+      12  {score, sink.x, sink.y}                          lossless, the default
+       8  {score, sink.x << 16 | sink.y}                   sinks below 65535 (any short-read batch)
+       4  {score:int16 << 16 | sink.x:8 << 8 | sink.y:8}   sinks below 255 and |score| < 32767, e.g. 100 bp
+          reads in band-15 windows: at 3.3 G reads/s per GPU the root of an 8-GPU node takes in ~93 GB/s
+    An untouched sink (score -2^30, sink (-1,-1): text shorter than pattern) travels as all-ones fields in the compact
+    formats.  Every rank checks on the device that its records fit the chosen format (no host sync) and ships the verdict
+    in the status row; the root raises OverflowError instead of returning truncated values (`concat=False` callers ask
+    `overflowed()`)."""
+
+    def __init__(self, n_total, dst=0, device=None, group=None, compact=False, record_bytes=None):
+        if record_bytes is None:
+            record_bytes = 8 if compact else 12
+        assert record_bytes in (4, 8, 12)
+        self.record_bytes = record_bytes
+        super().__init__(n_total, record_bytes // 4, dst=dst, device=device, group=group)
+
+    def overflowed(self):
+        return any(self.status())
 
     def gather(self, score, sink, concat=True):
         """Returns (score[n_total], sink[n_total,2]) on dst, None elsewhere.  concat=False leaves the
@@ -60,28 +105,30 @@ class ResultGather:
         if self.world == 1:
             return score, sink
         sink = sink.view(-1, 2)
+        untouched = (sink[:, 0] == -1) & (sink[:, 1] == -1)
+        status = None
         if self.record_bytes == 4:
+            fits = untouched | ((sink[:, 0] >= 0) & (sink[:, 0] < 0xFF) & (sink[:, 1] >= 0) & (sink[:, 1] < 0xFF) & (score > -32768) & (score < 32768))
+            status = (~fits).any().to(torch.int32)
             s16 = torch.clamp(score, min=-32768)          # only the untouched-sink score lies below
             self.send[:n, 0] = (s16 << 16) | ((sink[:, 0] & 0xFF) << 8) | (sink[:, 1] & 0xFF)
         elif self.record_bytes == 8:
+            fits = untouched | ((sink[:, 0] >= 0) & (sink[:, 0] < 0xFFFF) & (sink[:, 1] >= 0) & (sink[:, 1] < 0xFFFF))
+            status = (~fits).any().to(torch.int32)
             self.send[:n, 0] = score
             self.send[:n, 1] = (sink[:, 0] << 16) | (sink[:, 1] & 0xFFFF)
         else:
             self.send[:n, 0] = score
             self.send[:n, 1:] = sink
-        if self.send.is_cuda and dist.get_backend(self.group) != "nccl":
-            # gloo cannot gather device tensors: stage through the host (debug / CPU-test configurations only)
-            host = [torch.empty(b.shape, dtype=b.dtype) for b in self.bufs] if self.rank == self.dst else None
-            dist.gather(self.send.cpu(), host, dst=self.dst, group=self.group)
-            if host is not None:
-                for b, h in zip(self.bufs, host):
-                    b.copy_(h)
-        else:
-            dist.gather(self.send, self.bufs if self.rank == self.dst else None, dst=self.dst, group=self.group)
+        if status is not None:
+            self.send[self.pad, 0] = status
+        self._exchange()
         if self.rank != self.dst:
             return None
         if not concat:
             return True
+        if self.overflowed():
+            raise OverflowError("ResultGather: a rank holds sinks / scores that do not fit %d-byte records; use record_bytes=12" % self.record_bytes)
         rec = torch.cat([self.bufs[r][: self.sizes[r]] for r in range(self.world)], dim=0)
         if self.record_bytes == 12:
             return rec[:, 0].contiguous(), rec[:, 1:].contiguous()
@@ -91,10 +138,23 @@ class ResultGather:
         else:
             sc = rec[:, 0] >> 16                            # arithmetic shift: sign-extends the int16 score
             sx, sy, none = (rec[:, 0] >> 8) & 0xFF, rec[:, 0] & 0xFF, 0xFF
-        # an untouched sink (0xFFFFFFFF, 0xFFFFFFFF) round-trips as all-ones fields: restore it
+        # an untouched sink (0xFFFFFFFF, 0xFFFFFFFF) travels as all-ones fields (no fitting sink has them): restore it
         bad = (sx == none) & (sy == none)
         sx = torch.where(bad, torch.full_like(sx, -1), sx)
         sy = torch.where(bad, torch.full_like(sy, -1), sy)
         if self.record_bytes == 4:
             sc = torch.where(bad & (sc == -32768), torch.full_like(sc, -(1 << 30)), sc)
         return sc.contiguous(), torch.stack([sx, sy], dim=1).contiguous()
+
+
+def alignment_records(best, mapq, first_read_id):
+    """nvBowtie's per-read result as the 16-byte record the ranks gather (SURVEY.md 8e): {io::Alignment low word (score, edit
+    distance, strand / mate / pairing flags), alignment position, MAPQ, global read id}.  best: int64 [n] io::Alignment words
+    of the best alignments, mapq: uint8 [n]."""
+    n = best.numel()
+    rec = torch.empty((n, 4), dtype=torch.int32, device=best.device)
+    rec[:, 0] = (best & 0xFFFFFFFF).to(torch.int32)
+    rec[:, 1] = ((best >> 32) & 0xFFFFFFFF).to(torch.int32)
+    rec[:, 2] = mapq.to(torch.int32)
+    rec[:, 3] = torch.arange(first_read_id, first_read_id + n, device=best.device, dtype=torch.int64).to(torch.int32)
+    return rec

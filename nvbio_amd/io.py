@@ -354,6 +354,15 @@ def _bgzf_block(payload):
             struct.pack("<II", zlib.crc32(payload) & 0xFFFFFFFF, len(payload) & 0xFFFFFFFF))
 
 
+def _bam_bin(beg, end):
+    """The UCSC binning index of the 0-based half-open interval [beg, end) (SAM spec 5.3, reg2bin)."""
+    end -= 1
+    for shift, offset in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        if beg >> shift == end >> shift:
+            return offset + (beg >> shift)
+    return 0
+
+
 def sam_to_bam(sam_text, path):
     """Write the SAM text produced by tools/align_fastq.py (header + records over one reference) as a BAM file."""
     import re
@@ -373,11 +382,17 @@ def sam_to_bam(sam_text, path):
         ops = [(int(l), _BAM_CIGAR[o]) for l, o in re.findall(r"(\d+)([MIDNSHP=X])", cigar)] if cigar != "*" else []
         rid = ref_id.get(rname, -1)
         nid = rid if rnext == "=" else ref_id.get(rnext, -1)
-        body = struct.pack("<iiBBHHHIiii", rid, int(pos) - 1, len(qname) + 1, int(mapq), 0, len(ops), int(flag), len(seq), nid, int(pnext) - 1, int(tlen))
+        # SEQ '*' = no sequence stored (l_seq 0, no SEQ / QUAL bytes); QUAL '*' = l_seq bytes of 0xFF (SAM spec 4.2.3)
+        l_seq = 0 if seq == "*" else len(seq)
+        ref_len = sum(l for l, o in ops if o in (0, 2, 3, 7, 8))                  # M D N = X consume the reference
+        beg = int(pos) - 1
+        body = struct.pack("<iiBBHHHIiii", rid, beg, len(qname) + 1, int(mapq), _bam_bin(max(beg, 0), max(beg, 0) + max(ref_len, 1)), len(ops), int(flag),
+                           l_seq, nid, int(pnext) - 1, int(tlen))
         body += qname.encode() + b"\0" + b"".join(struct.pack("<I", (l << 4) | o) for l, o in ops)
-        nib = [_BAM_SEQ[c] for c in seq] + [0]
-        body += bytes((nib[2 * k] << 4) | nib[2 * k + 1] for k in range((len(seq) + 1) // 2))
-        body += bytes(ord(c) - 33 for c in qual)
+        if l_seq:
+            nib = [_BAM_SEQ[c] for c in seq] + [0]
+            body += bytes((nib[2 * k] << 4) | nib[2 * k + 1] for k in range((l_seq + 1) // 2))
+            body += b"\xff" * l_seq if qual == "*" else bytes(ord(c) - 33 for c in qual)
         for tag in f[11:]:
             key, ty, val = tag.split(":", 2)
             if ty == "Z":

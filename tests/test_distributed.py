@@ -11,7 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from nvbio_amd import workloads as W
-from nvbio_amd.distributed import ResultGather, shard_range, shard_sizes
+from nvbio_amd.distributed import RecordGather, ResultGather, alignment_records, shard_range, shard_sizes
 from oracle import pyoracle as O
 
 
@@ -43,12 +43,33 @@ def _worker(rank, world, port, n, q, record_bytes=8):
         g = ResultGather(n, dst=0, device="cpu", record_bytes=record_bytes)
         for _ in range(2):                                                   # buffers are reusable
             out = g.gather(torch.from_numpy(s), torch.from_numpy(k.view(np.int32)))
+        # sinks that do not fit a compact format must be reported, not truncated (a legitimate sink of (0xFF, 0xFF) or
+        # (0xFFFF, 0xFFFF) would otherwise come back as "untouched")
+        overflow_seen = True
+        if record_bytes != 12:
+            big = k.copy()
+            if rank == 1:
+                big[0] = (0xFF, 0xFF) if record_bytes == 4 else (0xFFFF, 0xFFFF)
+            try:
+                g.gather(torch.from_numpy(s), torch.from_numpy(big.view(np.int32)))
+                overflow_seen = rank != 0
+            except OverflowError:
+                overflow_seen = rank == 0
+        # the 16-byte alignment records of the end-to-end drivers
+        best = torch.from_numpy(((np.arange(lo, hi, dtype=np.int64) * 977) << 32) | (np.arange(lo, hi, dtype=np.int64) & 0xFFFF))
+        mapq = torch.from_numpy((np.arange(lo, hi) % 43).astype(np.uint8))
+        rg = RecordGather(n, 4, dst=0, device="cpu")
+        table = rg.gather(alignment_records(best, mapq, lo))
         if rank == 0:
             es, ek = O.batch_banded_gotoh_score(15, O.LOCAL, (2, -1, -2, -1), hp, ht, n_threads=1)
-            ok = bool((out[0].numpy() == es).all() and (out[1].numpy().view(np.uint32) == ek).all())
+            ok = bool((out[0].numpy() == es).all() and (out[1].numpy().view(np.uint32) == ek).all()) and overflow_seen
+            ids = np.arange(n, dtype=np.int64)
+            t = table.numpy()
+            ok = ok and bool((t[:, 3] == ids).all() and (t[:, 2] == ids % 43).all() and (t[:, 1].view(np.uint32) == ((ids * 977) & 0xFFFFFFFF)).all()
+                             and (t[:, 0] == (ids & 0xFFFF)).all())
             q.put(ok)
         else:
-            assert out is None
+            assert out is None and table is None and overflow_seen
     finally:
         dist.destroy_process_group()
 

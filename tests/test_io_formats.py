@@ -302,6 +302,12 @@ def test_bam_round_trip(tmp_path):
         L = int(rng.integers(30, 151))
         seq = "".join("ACGTN"[c] for c in rng.integers(0, 5, L)); qual = "".join(chr(33 + int(q)) for q in rng.integers(0, 42, L))
         if i % 7 == 0:
+            # unmapped records, some without stored sequence ('*') or qualities ('*' = 0xFF bytes): the forms secondary /
+            # unmapped lines of tools/align_fastq.py may take
+            if i % 21 == 0:
+                seq, qual = "*", "*"
+            elif i % 14 == 0:
+                qual = "*"
             recs.append(("u%d" % i, 4, "*", 0, 0, "*", "*", 0, 0, seq, qual, {}))
             lines.append("u%d\t4\t*\t0\t0\t*\t*\t0\t0\t%s\t%s" % (i, seq, qual))
             continue
@@ -316,8 +322,31 @@ def test_bam_round_trip(tmp_path):
     text, refs, got = nio.read_bam(path)
     assert refs == [("ref", 200000)] and text.splitlines() == lines[:3] and len(got) == len(recs)
     for g, r in zip(got, recs):
-        assert (g["name"], g["flag"], g["pos"], g["mapq"], g["cigar"], g["pnext"], g["tlen"], g["seq"], g["qual"]) == (r[0], r[1], r[3], r[4], r[5], r[7], r[8], r[9], r[10])
+        want_seq = "" if r[9] == "*" else r[9]
+        want_qual = "" if r[9] == "*" else (chr(255 + 33) * len(r[9]) if r[10] == "*" else r[10])
+        assert (g["name"], g["flag"], g["pos"], g["mapq"], g["cigar"], g["pnext"], g["tlen"], g["seq"], g["qual"]) == (r[0], r[1], r[3], r[4], r[5], r[7], r[8], want_seq, want_qual)
         assert g["ref"] == (0 if r[2] == "ref" else -1) and g["next_ref"] == (0 if r[6] == "=" else -1)
         if r[11]:
             assert g["tags"]["MD"] == r[11]["MD"] and g["tags"]["NM"] == r[11]["NM"] and g["tags"]["AS"] == r[11]["AS"] & 0xFFFFFFFF
+    # the record layout again, by an independent walk over the raw bytes: block sizes chain exactly to the end of the
+    # stream, l_seq / n_cigar / l_read_name locate every field, and the bin is reg2bin of the aligned interval
+    import gzip, struct
+    raw = gzip.open(path, "rb").read()
+    o = 12 + struct.unpack_from("<i", raw, 4)[0]
+    for _ in range(struct.unpack_from("<i", raw, o - 4)[0]):
+        o += 8 + struct.unpack_from("<i", raw, o)[0]
+    for r in recs:
+        bs = struct.unpack_from("<i", raw, o)[0]
+        rid, pos0, l_name, mapq, bin_, n_cig, flag, l_seq = struct.unpack_from("<iiBBHHHI", raw, o + 4)
+        assert raw[o + 36:o + 36 + l_name] == r[0].encode() + b"\0" and l_seq == (0 if r[9] == "*" else len(r[9]))
+        fixed = 32 + l_name + 4 * n_cig + (l_seq + 1) // 2 + l_seq
+        assert fixed <= bs
+        if r[5] != "*":
+            import re
+            span = sum(int(l) for l, op in re.findall(r"(\d+)([MIDNSHP=X])", r[5]) if op in "MDN=X")
+            b0, e0 = pos0, pos0 + span - 1
+            want = next((off + (b0 >> sh) for sh, off in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)) if b0 >> sh == e0 >> sh), 0)
+            assert bin_ == want
+        o += 4 + bs
+    assert o == len(raw)
     assert open(path, "rb").read()[-28:] == bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")      # the BGZF end-of-file block
