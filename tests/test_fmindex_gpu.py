@@ -301,3 +301,75 @@ def test_dimer_attach_rejects_a_foreign_buffer(cuda, index):
     assert lib().nvbio_hip_fm_attach_dimer_index(C.byref(s), C.c_void_p(fd.dimer.data_ptr()), None) == 1      # hipErrorInvalidValue
     s = dev.struct()
     assert lib().nvbio_hip_fm_attach_dimer_index(C.byref(s), C.c_void_p(fd.dimer.data_ptr()), None) == 0 and s.dimer == fd.dimer.data_ptr()
+
+
+# ------------------------------------------------------------------ BASELINE configs 3 / 4 at their own size
+@pytest.fixture(scope="module")
+def genome_3gbp(cuda):
+    """A true FM-index of a 3 * 10^9-symbol i.i.d. genome built on the device (row indices above 2^31, the regime the
+    3 Gbp configurations live in), its host copy for the oracle, and the line-native index next to it."""
+    ng = 3_000_000_000
+    g = torch.Generator(device=cuda)
+    g.manual_seed(0x5EED0003)
+    text = torch.randint(0, 4, (ng,), dtype=torch.uint8, generator=g, device=cuda)
+    fmi = W.build_fm_index(text)
+    host = O.FMIndex(parts=(fmi.length, fmi.primary, np.array(fmi.L2, dtype=np.uint32),
+                            fmi.bwt_occ.cpu().numpy().view(np.uint32), fmi.ssa.cpu().numpy().view(np.uint32), fmi.sa_int))
+    yield text, fmi, host
+    del text, fmi, host
+    torch.cuda.empty_cache()
+
+
+def test_full_size_rank_properties(cuda, genome_3gbp):
+    text, fmi, host = genome_3gbp
+    n = fmi.length
+    assert n == 3_000_000_000 and fmi.L2[4] == n
+    # sorted rows spread over the whole index, most of them above 2^31: all symbols accounted for, monotone, ends exact
+    k = torch.sort(torch.randint(0, n, (1 << 21,), device=cuda, dtype=torch.int64)).values
+    k[-1] = n - 1
+    k32 = k.to(torch.int32)
+    r4 = nvb.rank4(fmi, k32).to(torch.int64) & 0xFFFFFFFF
+    below_primary = (k < fmi.primary).to(torch.int64)
+    assert bool((r4.sum(1) == k + below_primary).all())                  # rows [0,k] hold k+1 entries, one of them '$' once k >= primary
+    assert bool((r4[1:] >= r4[:-1]).all())
+    assert int((k >= (1 << 31)).sum()) > (1 << 19)
+    # point ranks == the matching rank4 component, and a sample against the oracle on the host copy
+    c = torch.randint(0, 4, (k.numel(),), device=cuda, dtype=torch.uint8)
+    r = nvb.rank(fmi, k32, c).to(torch.int64) & 0xFFFFFFFF
+    assert bool((r == r4.gather(1, c.to(torch.int64).unsqueeze(1)).squeeze(1)).all())
+    m = 200000
+    kk, cc = k32[:: k.numel() // m][:m].contiguous(), c[:: k.numel() // m][:m].contiguous()
+    assert (u32(nvb.rank(fmi, kk, cc)) == host.rank(kk.cpu().numpy().view(np.uint32), cc.cpu().numpy())).all()
+    last = nvb.rank4(fmi, torch.tensor([n], device=cuda, dtype=torch.int64).to(torch.int32)).to(torch.int64)[0] & 0xFFFFFFFF
+    assert [int(x) for x in last] == [fmi.L2[i + 1] - fmi.L2[i] for i in range(4)]
+
+
+@pytest.mark.parametrize("flavour", ["reference_layout", "line_native", "line_native_ktab12"])
+def test_full_size_match_and_locate(cuda, genome_3gbp, flavour):
+    """BASELINE config 3-ii at its own size: >= 1 M 22-bp seeds (90 % drawn from the genome) on the 3 Gbp index, match ranges
+    and located positions against the oracle on a host copy -- for the reference layout and for the line-native index."""
+    text, fmi, host = genome_3gbp
+    idx = fmi if flavour == "reference_layout" else fmi.with_dimer()
+    if flavour.endswith("ktab12"):
+        idx = idx.with_ktab(12)
+    seeds = W.make_seeds(text, 1_200_000, 22)
+    ranges = nvb.match(idx, seeds)
+    exp = host.match(O.StringSet.from_device(seeds), n_threads=0)
+    got = u32(ranges)
+    assert (got == exp).all()
+    ok = exp[:, 0] <= exp[:, 1]
+    assert 0.85 < ok.mean() < 0.95
+    assert int((exp[ok, 0] >= np.uint32(1 << 31)).sum()) > 100000           # rows beyond 2^31 are exercised
+    rows = ranges[:, 0][torch.from_numpy(ok).to(cuda)].contiguous()
+    pos = nvb.locate(idx, rows)
+    epos = host.locate(exp[ok, 0], n_threads=0)
+    assert (u32(pos) == epos).all()
+    # and the property the reference's own test checks (fmindex_test.cu:636-657): the text at a located position is the seed
+    sample = torch.arange(0, rows.numel(), max(rows.numel() // 4096, 1), device=cuda)
+    p = pos[sample].to(torch.int64) & 0xFFFFFFFF
+    hs = O.StringSet.from_device(seeds)
+    okidx = np.nonzero(ok)[0][sample.cpu().numpy()]
+    for j, q in zip(okidx[:512], p[:512].cpu().numpy()):
+        assert (text[int(q):int(q) + 22].cpu().numpy() == O.unpack(hs.words, int(hs.begin[j]), 22, hs.bits, hs.big_endian)).all()
+    del idx
+    torch.cuda.empty_cache()
