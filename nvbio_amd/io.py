@@ -363,7 +363,7 @@ def _bam_bin(beg, end):
     return 0
 
 
-def sam_to_bam(sam_text, path):
+def sam_to_bam(sam_text, path, spec_bins=False):
     """Write the SAM text produced by tools/align_fastq.py (header + records over one reference) as a BAM file."""
     import re
     import struct
@@ -386,7 +386,10 @@ def sam_to_bam(sam_text, path):
         l_seq = 0 if seq == "*" else len(seq)
         ref_len = sum(l for l, o in ops if o in (0, 2, 3, 7, 8))                  # M D N = X consume the reference
         beg = int(pos) - 1
-        body = struct.pack("<iiBBHHHIiii", rid, beg, len(qname) + 1, int(mapq), _bam_bin(max(beg, 0), max(beg, 0) + max(ref_len, 1)), len(ops), int(flag),
+        # bin: BamOutput leaves it 0 ("BAM alignment bin is always 0", output_bam.cpp:374); bam_bin() below gives the
+        # spec's value for callers that want an indexable file (sam_to_bam(..., spec_bins=True))
+        bin_ = _bam_bin(max(beg, 0), max(beg, 0) + max(ref_len, 1)) if (spec_bins and beg >= 0) else (4680 if spec_bins else 0)
+        body = struct.pack("<iiBBHHHIiii", rid, beg, len(qname) + 1, int(mapq), bin_, len(ops), int(flag),
                            l_seq, nid, int(pnext) - 1, int(tlen))
         body += qname.encode() + b"\0" + b"".join(struct.pack("<I", (l << 4) | o) for l, o in ops)
         if l_seq:

@@ -153,3 +153,63 @@ def test_hip_path_reproduces_extension_vectors(cuda):
     assert (best.data.cpu().numpy().view(np.uint64) == E["rd_best"]).all()
     assert (nvb.mapq(best, sch, read_len=rl, version=2, max_read_len=200).cpu().numpy() == E["rd_mapq2"]).all()
     assert (nvb.mapq(best, sch, read_len=rl, version=3, max_read_len=200).cpu().numpy() == E["rd_mapq3"]).all()
+
+
+def test_reference_compiled_vectors_pin_the_oracle():
+    """tests/golden/ref_basic_vectors.npz holds outputs of REFERENCE code compiled from its own sources (popcount.h, bwt.h +
+    sais, priority_deque.h; generator: tests/golden/make_ref_basic_vectors.py).  The oracle's index construction, rank and
+    hit deque must reproduce them."""
+    v = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_basic_vectors.npz"))
+    host = O.FMIndex(v["text"])
+    assert (host.sa == v["sa"].astype(np.uint32)).all() and host.primary == int(v["primary"]) and (host.bwt == v["bwt"]).all()
+    assert (host.bwt_occ[: v["bwt_occ"].size] == v["bwt_occ"]).all() and (host.L2 == v["L2"]).all()
+    idx, sym = v["rank_idx"], v["rank_sym"]
+    k = np.where(idx == 0xFFFFFFFF, idx, np.where(idx >= host.primary, idx + 1, idx)).astype(np.uint32)
+    assert (host.rank(k, sym) == v["rank"]).all()
+    push, pop_bottom, pop_top = O.hit_deque_ops()
+    a = np.zeros(v["deque_ops"].size + 1, np.uint64)
+    size = 0
+    for i, op in enumerate(v["deque_ops"]):
+        if op == 0:
+            a[size] = v["deque_values"][i]; size += 1; push(a, size)
+        elif op == 1 and size:
+            pop_top(a, size); size -= 1
+        elif op == 2 and size:
+            pop_bottom(a, size); size -= 1
+        assert size == v["deque_sizes"][i]
+        if size:
+            assert a[0] == v["deque_bottoms"][i] and (a[1] if size > 1 else a[0]) == v["deque_tops"][i]
+    assert (a[:size] == v["deque_final"]).all()
+
+
+@pytest.mark.gpu
+def test_hip_rank_and_hit_deque_reproduce_reference_compiled_vectors(cuda):
+    """the HIP rank kernels (reference layout and through the line-native index's plane records) and the device hit deque against
+    outputs of the reference's own compiled code -- no oracle call in between"""
+    import ctypes as C
+    import torch
+    import nvbio_amd as nvb
+    from nvbio_amd._lib import lib
+    v = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_basic_vectors.npz"))
+    n, primary = int(v["text"].size), int(v["primary"])
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32 if a.dtype == np.uint32 else a.dtype)).to(cuda)
+    fmi = nvb.FMIndexDevice(n, primary, [int(x) for x in v["L2"]], dev(np.concatenate([v["bwt_occ"], np.zeros(8, np.uint32)])))
+    idx, sym = v["rank_idx"], v["rank_sym"]
+    k = np.where(idx == 0xFFFFFFFF, idx, np.where(idx >= primary, idx + 1, idx)).astype(np.uint32)
+    got = nvb.rank(fmi, dev(k), dev(sym)).cpu().numpy().view(np.uint32)
+    assert (got == v["rank"]).all()
+    r4 = nvb.rank4(fmi, dev(k)).cpu().numpy().view(np.uint32)
+    assert (r4[np.arange(k.size), sym] == v["rank"]).all()
+    # one backward-search step per symbol on the line-native index = L2 + rank + 1 of the same counts
+    fd = fmi.with_dimer()
+    one = [np.array([c], np.uint8) for c in range(4)]
+    from oracle import pyoracle as O
+    hs = O.StringSet.from_lists(one, 2, True)
+    ds = nvb.PackedStringSet.from_host(hs.words, 2, True, hs.begin, hs.length, device=cuda)
+    rg = nvb.match(fd, ds).cpu().numpy().view(np.uint32)
+    for c in range(4):
+        assert int(rg[c, 0]) == int(v["L2"][c]) + 1 and int(rg[c, 1]) == int(v["L2"][c + 1])
+    # the device hit deque replays the reference priority_deque's program: the same array after every operation
+    from tests.test_select_gpu import device_hit_deque_replay
+    states = device_hit_deque_replay(cuda, v["deque_ops"], v["deque_values"], v["deque_sizes"])
+    assert (states == v["deque_states"]).all()

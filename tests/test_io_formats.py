@@ -318,7 +318,7 @@ def test_bam_round_trip(tmp_path):
         r = recs[-1]
         lines.append("\t".join(str(x) for x in r[:11]) + "\tNM:i:%d\tAS:i:%d\tXM:i:%d\tXO:i:%d\tXG:i:%d\tMD:Z:%s" % tuple(tags[k] for k in ("NM", "AS", "XM", "XO", "XG", "MD")))
     path = str(tmp_path / "t.bam")
-    nio.sam_to_bam("\n".join(lines) + "\n", path)
+    nio.sam_to_bam("\n".join(lines) + "\n", path, spec_bins=True)
     text, refs, got = nio.read_bam(path)
     assert refs == [("ref", 200000)] and text.splitlines() == lines[:3] and len(got) == len(recs)
     for g, r in zip(got, recs):

@@ -43,6 +43,22 @@ def test_device_hit_deque_replays_reference_vectors(cuda):
     assert (out.cpu().numpy().view(np.uint64) == G["states"]).all()
 
 
+def device_hit_deque_replay(cuda, ops, vals, sizes):
+    """One program through the device deque: the array after every operation, concatenated (sizes = the expected sizes)."""
+    import ctypes as C
+    n_ops = int(ops.size)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8)).to(cuda)
+    stride = int(sizes.max()) + 2
+    d_cs, d_ops, d_vals = t(np.array([0, n_ops], np.uint32)), t(ops.astype(np.uint8)), t(vals.astype(np.uint64))
+    d_caps, d_ss = t(np.full(n_ops, stride - 1, np.uint32)), t(np.zeros(1, np.uint64))
+    scratch = torch.zeros(stride, dtype=torch.int64, device=cuda)
+    out = torch.zeros(int(sizes.astype(np.int64).sum()), dtype=torch.int64, device=cuda)
+    vp = lambda x: C.c_void_p(x.data_ptr())
+    check(lib().nvbio_hip_hit_deque_replay(1, vp(d_cs), vp(d_ops), vp(d_vals), vp(d_caps), vp(d_ss), vp(scratch), stride, vp(out), None), "replay")
+    torch.cuda.synchronize()
+    return out.cpu().numpy().view(np.uint64)
+
+
 @pytest.mark.parametrize("randomized", [False, True])
 @pytest.mark.parametrize("n_multi", [1, 4, 32])
 @pytest.mark.parametrize("top_seed", [0, 1])
