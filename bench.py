@@ -404,6 +404,10 @@ def e2e_leg(a, dev, fmi, text):
         else:
             res[name]["identical_to_reference_layout"] = bool(torch.equal(r["best"], ref_best) and torch.equal(r["mapq"], ref_mapq) and torch.equal(r["cigar"], ref_cigar))
         del idx, r
+    # the same batch through the C++ host driver (include/nvbio_hip/aligner.h: nvbio::bowtie2::cuda::Aligner::best_approx, the
+    # north star's "host code stays C++"), entered through tests/cxx/aligner_shim.cpp: no torch between the kernels
+    res["cxx_best_approx"] = cxx_driver_leg(a, dev, fmi.with_dimer(), sym, packed, genome_words, ng, names, prm, ref_best, ref_mapq)
+
     # exact check of a sample against the same glue over the oracle
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_pipeline_gpu import OracleBackend
@@ -455,6 +459,48 @@ def e2e_leg(a, dev, fmi, text):
     res["reads"] = n
     res["genome_symbols"] = ng
     return res
+
+
+def cxx_driver_leg(a, dev, idx, sym, packed, genome_words, ng, names, prm, ref_best, ref_mapq):
+    """nvbio::bowtie2::cuda::Aligner::best_approx (C++ over the C-ABI) on the e2e batch: mean wall time per batch of `reps` batches
+    with one Aligner object, per-stage device times from one more batch, and its results compared with the Python driver's."""
+    import ctypes as C
+    shim_path = os.path.join(ROOT, "tests", "cxx", "libaligner_shim.so")
+    if not os.path.exists(shim_path):
+        return {"error": "tests/cxx/libaligner_shim.so is missing (python __graft_entry__.py builds it)"}
+    shim = C.CDLL(shim_path)
+    n, L = sym.shape
+    reads_rev, fwrc = packed
+    quals = torch.full((2 * n * L + 8,), 30, dtype=torch.uint8, device=dev)
+    arena, nidx = names
+    scheme = nvb.SmithWatermanScoringScheme()
+
+    class ShimParams(C.Structure):
+        _fields_ = [(k, C.c_uint32) for k in ("local", "randomized", "top_seed", "max_effort_init", "max_effort", "min_ext", "max_ext", "max_reseed", "rep_seeds",
+                                              "max_hits", "allow_sub", "subseed_len", "seed_len", "seed_freq_type", "min_read_len", "max_dist", "no_multi_hits",
+                                              "batch_size", "hits_stride")] + \
+                   [("seed_freq_k", C.c_float), ("seed_freq_m", C.c_float), ("match", C.c_int32), ("score_min_type", C.c_int32),
+                    ("score_min_k", C.c_float), ("score_min_m", C.c_float), ("finish", C.c_uint32)]
+    p = prm
+    sp = ShimParams(int(p.local), int(p.randomized), p.top_seed, p.max_effort_init, p.max_effort, p.min_ext, p.max_ext, p.max_reseed, p.rep_seeds, p.max_hits,
+                    p.allow_sub, p.subseed_len, p.seed_len, p.seed_freq[0], p.min_read_len, p.max_dist, int(p.no_multi_hits), p.batch_size, p.hits_stride or 0,
+                    p.seed_freq[1], p.seed_freq[2], scheme.m_match, scheme.m_score_min[0], scheme.m_score_min[1], scheme.m_score_min[2], 0)
+    fs = idx.struct()
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    best = torch.zeros((2, n), dtype=torch.int64, device=dev)
+    mapq = torch.zeros(n, dtype=torch.uint8, device=dev)
+    ms, stage, stats = (C.c_double * 1)(), (C.c_double * 9)(), (C.c_uint64 * 4)()
+    torch.cuda.synchronize()
+    rc = shim.nvbio_aligner_best_approx_timed(C.byref(fs), None, C.c_uint32(n), C.c_uint32(L), vp(reads_rev.words), C.c_uint64(reads_rev.words.numel()), vp(reads_rev.begin),
+                                              vp(fwrc), C.c_uint64(fwrc.numel()), vp(quals), C.c_uint64(quals.numel()), vp(arena), vp(nidx),
+                                              vp(genome_words), C.c_uint64(genome_words.numel()), C.c_uint32(ng), C.byref(sp), C.c_uint32(3), ms, stage, vp(best), vp(mapq), stats)
+    if rc != 0:
+        return {"error": "nvbio_aligner_best_approx_timed returned %d" % rc}
+    names9 = ("map", "select_init", "select", "locate", "score", "reduce", "mapq", "traceback", "finish")
+    return {"driver": "nvbio::bowtie2::cuda::Aligner::best_approx (include/nvbio_hip/aligner.h), index: line_native", "ms_per_batch": ms[0], "Mreads_per_s": n / ms[0] / 1e3,
+            "extensions": int(stats[0]), "rounds": int(stats[1]), "dp_jobs": int(stats[3]),
+            "stage_ms": {k: round(stage[i], 3) for i, k in enumerate(names9)},
+            "identical_to_python_driver": bool(torch.equal(best, ref_best) and torch.equal(mapq, ref_mapq))}
 
 
 def rank_leg(a, dev, fmi):

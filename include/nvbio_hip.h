@@ -582,6 +582,11 @@ int nvbio_hip_opposite_memo_update(uint32_t n_active, const uint32_t* active_rea
     uint32_t anchor, uint32_t* memo, void* stream);
 int nvbio_hip_mark_discordant(uint32_t n_reads, uint64_t* best_alignments, uint64_t* best_alignments_o, uint32_t best_stride, void* stream);
 
+/* pack_read(top_seed) over a read queue (nvBowtie/bowtie2/cuda/defs.h:185-205): out[i] = {read_id:31 = queue[i], top_flag:1},
+ * the form the active-read queues of the extension rounds hold.  queue == NULL stands for the identity queue 0 .. n-1 (with
+ * top_flag 0: the initial seed queue of a batch, written on the device). */
+int nvbio_hip_pack_read_queue(uint32_t n, const uint32_t* queue, uint32_t top_flag, uint32_t* out, void* stream);
+
 /* ---- what nvBowtie's host drivers do between the stages (they use thrust / nvbio primitives for it) ----
  * mark_unaligned (aligner_init.cu:421-444): reseed[t] = 1 for every queued read whose best alignment is still unaligned.
  * copy_flagged (nvbio/basic/primitives.h, used at aligner_best_approx.h:273-280): out = the in[i] with flags[i] != 0, in

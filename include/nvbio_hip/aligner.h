@@ -6,7 +6,10 @@
 // banded_traceback_best.  Inputs are device resident (the reference's io::SequenceDataDevice / FMIndexDataDevice).
 #pragma once
 #include <algorithm>
+#include <chrono>
+#include <map>
 #include <numeric>
+#include <string>
 #include <vector>
 #include "alignment.h"
 #include "mapping.h"
@@ -28,7 +31,20 @@ struct Params : public ParamsPOD
     bool   finish_alignments;      ///< run finish_alignment_best (MD strings, edit distances, final scores) as the reference always does
 };
 
-struct Stats { uint64 extensions, dp_jobs, hits, ranges, unique; uint32 rounds, seeding_passes; std::vector<uint32> queue;
+/// per-stage device times (the reference's stats.map / select / locate / score ... timers, aligner_best_approx.h): off by default,
+/// since a stage boundary costs two stream synchronisations
+struct StageClock
+{
+    StageClock() : enabled(false) {}
+    bool enabled;
+    std::map<std::string, double> ms;
+    std::chrono::steady_clock::time_point t0;
+    void begin(const char*, void* s) { if (!enabled) return; hip::synchronize(s); t0 = std::chrono::steady_clock::now(); }
+    void end(const char* name, void* s) { if (!enabled) return; hip::synchronize(s); ms[name] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+    template <typename F> void run(const char* name, void* s, F f) { begin(name, s); f(); end(name, s); }
+};
+
+struct Stats { uint64 extensions, dp_jobs, hits, ranges, unique; uint32 rounds, seeding_passes; std::vector<uint32> queue; StageClock clock;
                Stats() : extensions(0), dp_jobs(0), hits(0), ranges(0), unique(0), rounds(0), seeding_passes(0) {} };
 
 /// A batch of equal-length reads on the device in the layouts the stages read (io::SequenceDataDevice's role): the reads
@@ -89,6 +105,8 @@ struct Aligner
     hip::device_vector<uint32>        output_read_info_dvec;     // read id of every alignment
     hip::device_vector<io::Alignment> output_alignments_dvec;    // finished alignments (window begin, edit distance, final score)
     hip::device_vector<io::Alignment> scored_alignments_dvec;    // as accepted (read start, extension score)
+
+    hip::device_arena                 workspace;                 // the per-batch queues and temporaries of the best-mapping drivers
 
     Aligner() : BATCH_SIZE(0), SCORING_BATCH(0), cigar_stride(64), mds_stride(256), n_alignments(0) {}
 
@@ -317,14 +335,16 @@ private:
         const uint32 band_len = band_length(params.max_dist);
         const uint32 hits_stride = params.hits_stride ? params.hits_stride : std::min(params.max_hits, 128u);
         const aln::GotohAligner<TYPE, aln::SmithWatermanScoringScheme> aligner(scoring_scheme);
+        hip::synchronize(hip_stream);                                   // nothing of the previous batch may still read the workspace
+        const hip::arena_scope scope(workspace);                        // every vector below lives in the Aligner's workspace
 
         // initialize best-alignments with the threshold score
         hip::device_vector<int32> min_score_table(limits.min_score_table(L));
         init_alignments(count, nullptr, L, min_score_table.data(), best_data_dvec.data(), BATCH_SIZE, 0u, hip_stream);
 
         // the seed queue, hit deques, selection state and scoring queues of the pipeline
-        std::vector<uint32> iota(count); std::iota(iota.begin(), iota.end(), 0u);
-        hip::device_vector<uint32> seed_queue_in(iota), seed_queue_out(count), queue_count(1);
+        hip::device_vector<uint32> seed_queue_in(count), seed_queue_out(count), queue_count(1);
+        hip_check(nvbio_hip_pack_read_queue(count, nullptr, 0u, seed_queue_in.data(), hip_stream), "nvbio_hip_pack_read_queue");      // 0 .. count-1
         uint32 seed_queue_size = count;
         hip::device_vector<SeedHit> hit_data(size_t(count) * hits_stride);
         hip::device_vector<uint32>  hit_counts(count);
@@ -351,7 +371,7 @@ private:
             // hit_deques.clear_deques() + map
             hip_check(nvbio_hip_memset(hit_counts.data(), 0, uint64(count) * 4u, hip_stream), "nvbio_hip_memset");
             const PingPongQueuesView seed_queues = { seed_queue_size, seed_queue_in.data() };
-            map(reads.reversed, fmi, rfmi, seeding_pass, seed_queues, reseed.data(), hits, params, seed_freq.data(), params.fw, params.rc, hip_stream);
+            stats.clock.run("map", hip_stream, [&] { map(reads.reversed, fmi, rfmi, seeding_pass, seed_queues, reseed.data(), hits, params, seed_freq.data(), params.fw, params.rc, hip_stream); });
 
             best_approx_score<TYPE>(params, fmi, rfmi, aligner, genome_words, genome_n_words, genome_len, reads, band_len, seed_queue_size, seed_queue_in.data(),
                                     hits, state, queues, pat_begin, txt_begin, txt_len, sinks, min_score, hit_score, stats, hip_stream, best_sink.data());
@@ -366,9 +386,10 @@ private:
         }
 
         // compute mapq (BowtieMapq2)
-        mapq(2, limits, min_score_table.data(), count, best_data_dvec.data(), BATCH_SIZE, nullptr, L, mapq_dvec.data(), hip_stream);
+        stats.clock.run("mapq", hip_stream, [&] { mapq(2, limits, min_score_table.data(), count, best_data_dvec.data(), BATCH_SIZE, nullptr, L, mapq_dvec.data(), hip_stream); });
 
         // banded_traceback_best over every read (unaligned ones get an empty window and no CIGAR)
+        stats.clock.begin("traceback", hip_stream);
         {
             hip::device_vector<uint8>  valid(count);
             hip::device_vector<uint64> tb_pat(count), tb_txt(count);
@@ -392,9 +413,11 @@ private:
                 batch.enact(stream, temp.size(), temp.data(), hip_stream);
                 hip::synchronize(hip_stream);                     // temp is released on scope exit
             });
+            stats.clock.end("traceback", hip_stream);
             // finish_alignment_best: MD strings, edit distances, final scores; best_data then holds what the output stage reads
             if (params.finish_alignments)
             {
+                stats.clock.begin("finish", hip_stream);
                 const nvbio_hip_gotoh_qual_scheme sc = scoring_scheme.abi();
                 const nvbio_hip_string_set p = patterns.abi(), t = texts.abi();
                 hip_check(nvbio_hip_finish_alignment(count, valid.data(), &p, reads.quals, reads.n_quals, &t, reinterpret_cast<const uint16*>(cigar.data()), cigar_stride,
@@ -402,6 +425,7 @@ private:
                                                      reinterpret_cast<uint64*>(best_data_dvec.data()), mds.data(), mds_stride, mds_len.data(), hip_stream),
                           "nvbio_hip_finish_alignment");
                 hip::synchronize(hip_stream);
+                stats.clock.end("finish", hip_stream);
             }
         }
         hip::synchronize(hip_stream);
@@ -419,6 +443,8 @@ private:
         const nvbio_hip_gotoh_qual_scheme sc = scoring_scheme.abi();
         uint64* best   = reinterpret_cast<uint64*>(best_data_dvec.data());
         uint64* best_o = reinterpret_cast<uint64*>(best_data_dvec_o.data());
+        hip::synchronize(hip_stream);
+        const hip::arena_scope scope(workspace);                        // the per-batch vectors below live in the Aligner's workspace
 
         hip::device_vector<int32> min_score_table(limits.min_score_table(L));
         init_alignments(count, nullptr, L, min_score_table.data(), best_data_dvec.data(),   BATCH_SIZE, 0u, hip_stream);
@@ -464,15 +490,9 @@ private:
                 map(a_reads.reversed, fmi, rfmi, seeding_pass, seed_queues, reseed.data(), hits, params, seed_freq.data(), fw, rc, hip_stream);
 
                 // best_approx_score (:455-700)
-                {
-                    hip::synchronize(hip_stream);
-                    std::vector<uint32> q(seed_queue_size);
-                    hip_check(nvbio_hip_memcpy(q.data(), seed_queue_in.data(), uint64(seed_queue_size) * 4u, 2, nullptr), "nvbio_hip_memcpy(d2h)");
-                    std::vector<packed_read> packed(seed_queue_size);
-                    for (uint32 i = 0; i < seed_queue_size; ++i) packed[i] = packed_read(q[i], params.select.top_seed & 1u);
-                    hip_check(nvbio_hip_memcpy(queues.active_in.data(), packed.data(), uint64(seed_queue_size) * 4u, 1, nullptr), "nvbio_hip_memcpy(h2d)");
-                    queues.in_size = seed_queue_size;
-                }
+                hip_check(nvbio_hip_pack_read_queue(seed_queue_size, seed_queue_in.data(), params.select.top_seed & 1u, reinterpret_cast<uint32*>(queues.active_in.data()), hip_stream),
+                          "nvbio_hip_pack_read_queue");
+                queues.in_size = seed_queue_size;
                 select_init(count, a_reads.names, a_reads.names_idx, hits, state, params.select, hip_stream);
                 uint32 n_ext = 0;
                 while (queues.in_size && n_ext < params.select.max_ext)
@@ -647,16 +667,10 @@ private:
         hip::device_vector<uint32> hit_sink(best_sink ? pat_begin.size() * 2u : 0u);       // the DP sinks, per hit (kept for the traceback)
         hip::device_vector<uint32> job_hit(pat_begin.size()), job_count(1);
         // active_read_queues.in_queue = pack_read( params.top_seed ) of the seed queue
-        {
-            hip::synchronize(hip_stream);
-            std::vector<uint32> q(seed_queue_size);
-            hip_check(nvbio_hip_memcpy(q.data(), seed_queue, uint64(seed_queue_size) * 4u, 2, nullptr), "nvbio_hip_memcpy(d2h)");
-            std::vector<packed_read> packed(seed_queue_size);
-            for (uint32 i = 0; i < seed_queue_size; ++i) packed[i] = packed_read(q[i], params.select.top_seed & 1u);
-            hip_check(nvbio_hip_memcpy(queues.active_in.data(), packed.data(), uint64(seed_queue_size) * 4u, 1, nullptr), "nvbio_hip_memcpy(h2d)");
-            queues.in_size = seed_queue_size;
-        }
-        select_init(reads.n, reads.names, reads.names_idx, hits, state, params.select, hip_stream);
+        hip_check(nvbio_hip_pack_read_queue(seed_queue_size, seed_queue, params.select.top_seed & 1u, reinterpret_cast<uint32*>(queues.active_in.data()), hip_stream),
+                  "nvbio_hip_pack_read_queue");
+        queues.in_size = seed_queue_size;
+        stats.clock.run("select_init", hip_stream, [&] { select_init(reads.n, reads.names, reads.names_idx, hits, state, params.select, hip_stream); });
 
         uint32 n_ext = 0;
         while (queues.in_size && n_ext < params.select.max_ext)
@@ -666,10 +680,11 @@ private:
             if (queues.in_size <= SCORING_BATCH / 2 && !params.no_multi_hits)
                 n_hits_per_read = std::min(SCORING_BATCH / queues.in_size, std::min(4096u, params.select.max_ext - n_ext));
 
-            select(hits, state, queues, n_hits_per_read, params.select, hip_stream);
+            stats.clock.run("select", hip_stream, [&] { select(hits, state, queues, n_hits_per_read, params.select, hip_stream); });
             if (queues.in_size == 0) break;
             if (queues.hits_size == 0) continue;
-            locate(fmi, rfmi, queues, hip_stream);
+            stats.clock.run("locate", hip_stream, [&] { locate(fmi, rfmi, queues, hip_stream); });
+            stats.clock.begin("score", hip_stream);
 
             // score_best: BestScoreStream's windows, then the banded scorer in nvBowtie's quality-aware scheme
             // Hits at a placement the read already recorded keep the recorded score (known_score, see nvbio_hip.h); only the others
@@ -692,10 +707,13 @@ private:
                 if (best_sink) hip_check(nvbio_hip_scatter_rows(n_jobs, job_hit.data(), sinks.data(), hit_sink.data(), 8u, hip_stream), "nvbio_hip_scatter_rows");
             }
             stats.dp_jobs += n_jobs;
+            stats.clock.end("score", hip_stream);
 
             // score_reduce with the give-up counters
-            score_reduce(ReduceBestApproxContext(state.trys.data(), n_ext), hits, queues, known_score.data(), nullptr, L, best_data_dvec.data(), BATCH_SIZE,
-                         worst_score, params.select, nullptr, hip_stream, best_sink ? hit_sink.data() : nullptr, best_sink);
+            stats.clock.run("reduce", hip_stream, [&] {
+                score_reduce(ReduceBestApproxContext(state.trys.data(), n_ext), hits, queues, known_score.data(), nullptr, L, best_data_dvec.data(), BATCH_SIZE,
+                             worst_score, params.select, nullptr, hip_stream, best_sink ? hit_sink.data() : nullptr, best_sink);
+            });
             stats.extensions += queues.hits_size; ++stats.rounds;
             n_ext += n_hits_per_read;
         }

@@ -6,8 +6,10 @@
 // that a caller written against nvbio keeps its names and argument order.
 #pragma once
 #include <stdint.h>
+#include <algorithm>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 #include "../nvbio_hip.h"
 
@@ -43,23 +45,76 @@ inline void hip_check(int err, const char* what) { if (err != 0) throw hip_error
 
 namespace hip {
 
+/// A grow-only device arena for a driver's per-batch working set.  The reference's Aligner allocates its queues once in
+/// init(); a driver written with scoped vectors would instead allocate and free gigabytes per batch (a 10 M-read batch needs
+/// a 16 GB traceback buffer), and neither hipMalloc (~0.1 s per GB-sized block) nor the stream-ordered pool (which splits the
+/// big block among the small requests of the next batch) makes that cheap.  Vectors built while an arena_scope is active take
+/// their storage from the arena and never free it; reset() rewinds, and after the first batch the arena is one block.
+struct device_arena
+{
+    device_arena() : used(0) {}
+    ~device_arena() { for (size_t i = 0; i < blocks.size(); ++i) nvbio_hip_device_free(blocks[i].first); }
+    device_arena(const device_arena&) = delete;
+    device_arena& operator=(const device_arena&) = delete;
+    void* take(uint64 bytes)
+    {
+        bytes = (bytes + 255u) & ~uint64(255);
+        if (blocks.empty() || used + bytes > blocks.back().second)
+        {
+            uint64 total = 0; for (size_t i = 0; i < blocks.size(); ++i) total += blocks[i].second;
+            const uint64 want = std::max<uint64>(bytes, std::max<uint64>(total, uint64(64) << 20));
+            void* p = nullptr;
+            hip_check(nvbio_hip_device_malloc(&p, want), "nvbio_hip_device_malloc");
+            blocks.push_back(std::make_pair(p, want)); used = 0;
+        }
+        void* r = static_cast<uint8*>(blocks.back().first) + used;
+        used += bytes;
+        return r;
+    }
+    /// rewind; several blocks (the arena grew during the last batch) are replaced by one of their total size
+    void reset()
+    {
+        if (blocks.size() > 1)
+        {
+            uint64 total = 0; for (size_t i = 0; i < blocks.size(); ++i) { total += blocks[i].second; nvbio_hip_device_free(blocks[i].first); }
+            blocks.clear();
+            void* p = nullptr;
+            hip_check(nvbio_hip_device_malloc(&p, total), "nvbio_hip_device_malloc");
+            blocks.push_back(std::make_pair(p, total));
+        }
+        used = 0;
+    }
+    std::vector<std::pair<void*, uint64> > blocks;
+    uint64 used;
+};
+inline device_arena*& current_arena() { static thread_local device_arena* a = nullptr; return a; }
+struct arena_scope
+{
+    arena_scope(device_arena& a) : prev(current_arena()) { a.reset(); current_arena() = &a; }
+    ~arena_scope() { current_arena() = prev; }
+    device_arena* prev;
+};
+
 /// a minimal device vector (the reference's callers use thrust::device_vector here)
 template <typename T>
 struct device_vector {
     T*     m_ptr;
     size_t m_size;
-    device_vector() : m_ptr(nullptr), m_size(0) {}
-    explicit device_vector(size_t n) : m_ptr(nullptr), m_size(0) { resize(n); }
-    device_vector(const std::vector<T>& h) : m_ptr(nullptr), m_size(0) { assign(h.data(), h.size()); }
+    bool   m_in_arena;
+    device_vector() : m_ptr(nullptr), m_size(0), m_in_arena(false) {}
+    explicit device_vector(size_t n) : m_ptr(nullptr), m_size(0), m_in_arena(false) { resize(n); }
+    device_vector(const std::vector<T>& h) : m_ptr(nullptr), m_size(0), m_in_arena(false) { assign(h.data(), h.size()); }
     device_vector(const device_vector&) = delete;
     device_vector& operator=(const device_vector&) = delete;
-    ~device_vector() { if (m_ptr) nvbio_hip_device_free(m_ptr); }
+    ~device_vector() { if (m_ptr && !m_in_arena) nvbio_hip_device_free(m_ptr); }
     void resize(size_t n) {
         if (n == m_size) return;
-        if (m_ptr) { nvbio_hip_device_free(m_ptr); m_ptr = nullptr; }
+        if (m_ptr && !m_in_arena) nvbio_hip_device_free(m_ptr);
+        m_ptr = nullptr;
+        if (current_arena() && (m_in_arena || m_size == 0)) { m_ptr = static_cast<T*>(current_arena()->take(uint64(n ? n : 1) * sizeof(T))); m_in_arena = true; m_size = n; return; }
         void* p = nullptr;
         hip_check(nvbio_hip_device_malloc(&p, uint64(n) * sizeof(T)), "nvbio_hip_device_malloc");
-        m_ptr = static_cast<T*>(p); m_size = n;
+        m_ptr = static_cast<T*>(p); m_size = n; m_in_arena = false;
     }
     void assign(const T* h, size_t n) {
         resize(n);

@@ -37,6 +37,7 @@
 //    Both produce the reference's int32 results bit for bit.
 //
 #include "banded_gotoh_impl.h"
+#include <chrono>
 
 namespace nvb {
 
@@ -211,8 +212,40 @@ NVB_API int nvbio_hip_banded_sw_score(
     return nvbio_hip_banded_gotoh_score(&g, type, band_len, patterns, texts, max_pattern_len, max_text_len, n, out_score, out_sink, stream);
 }
 
-NVB_API int nvbio_hip_device_malloc(void** ptr, uint64_t bytes) { return ptr ? hipMalloc(ptr, bytes ? bytes : 1) : hipErrorInvalidValue; }
-NVB_API int nvbio_hip_device_free(void* ptr) { return hipFree(ptr); }
+// Device memory for the C++ host layer's containers.  Stream-ordered on the null stream out of the device's default pool, with the
+// pool told to keep what it is given back: a driver that builds and drops its queues every batch (the reference's drivers hold
+// thrust vectors the same way) then pays for hipMalloc once, not per batch.
+static void keep_pool_memory()
+{
+    static thread_local int done_for = -1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev == done_for) return;
+    hipMemPool_t pool;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+        uint64_t keep = ~0ull;
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
+    done_for = dev;
+}
+static double g_alloc_ms = 0.0; static uint64_t g_alloc_calls = 0;
+extern "C" __attribute__((visibility("default"))) void nvb_debug_alloc_stats(double* ms, uint64_t* calls) { *ms = g_alloc_ms; *calls = g_alloc_calls; }
+NVB_API int nvbio_hip_device_malloc(void** ptr, uint64_t bytes)
+{
+    if (!ptr) return hipErrorInvalidValue;
+    keep_pool_memory();
+    const auto t0 = std::chrono::steady_clock::now();
+    const int e = hipMallocAsync(ptr, bytes ? bytes : 1, nullptr);
+    g_alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); ++g_alloc_calls;
+    return e;
+}
+NVB_API int nvbio_hip_device_free(void* ptr)
+{
+    if (!ptr) return hipSuccess;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int e = hipFreeAsync(ptr, nullptr);
+    g_alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); ++g_alloc_calls;
+    return e;
+}
 NVB_API int nvbio_hip_memcpy(void* dst, const void* src, uint64_t bytes, int kind, void* stream)
 {
     const hipMemcpyKind k = kind == 1 ? hipMemcpyHostToDevice : kind == 2 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;

@@ -468,7 +468,24 @@ traceback_best_setup_kernel(uint32_t n, const uint32_t* __restrict__ idx, const 
     if (pat_len) pat_len[i] = len;
 }
 
+// active_read_queues.in_queue = pack_read(top_seed) of the seed queue (defs.h:185-205): read id in the low 31 bits, the flag on top
+__global__ void __launch_bounds__(256)
+pack_read_queue_kernel(uint32_t n, const uint32_t* __restrict__ queue, uint32_t top_flag, uint32_t* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) out[i] = ((queue ? queue[i] : i) & 0x7FFFFFFFu) | (top_flag << 31);
+}
+
 } // namespace nvb
+
+NVB_API int nvbio_hip_pack_read_queue(uint32_t n, const uint32_t* queue, uint32_t top_flag, uint32_t* out, void* stream)
+{
+    if (n == 0) return hipSuccess;
+    if (!out) return hipErrorInvalidValue;
+    g_last_kernel = "pack_read_queue_kernel";
+    hipLaunchKernelGGL(pack_read_queue_kernel, grid_for(n), dim3(256), 0, to_stream(stream), n, queue, top_flag & 1u, out);
+    return hipGetLastError();
+}
 
 NVB_API int nvbio_hip_mark_unaligned(uint32_t n_active, const uint32_t* active_reads, const uint64_t* best_alignments, uint8_t* reseed, void* stream)
 {

@@ -1,11 +1,14 @@
 // aligner_shim.cpp -- a C entry point around the C++ host driver nvbio::bowtie2::cuda::Aligner (include/nvbio_hip/aligner.h)
 // so that the Python GPU tests can run it on the same device-resident inputs as the Python driver and compare both with the
 // oracle driver.  Test infrastructure: built by __graft_entry__.build() into tests/cxx/libaligner_shim.so.
+#include <chrono>
 #include <cstring>
 #include <nvbio_hip/aligner.h>
 
 using namespace nvbio;
 using namespace nvbio::bowtie2::cuda;
+
+extern "C" void nvb_debug_alloc_stats(double*, uint64_t*);      // libnvbio_hip.so: time spent in nvbio_hip_device_malloc / _free (tracing aid)
 
 struct shim_params
 {
@@ -66,6 +69,71 @@ int nvbio_aligner_best_approx(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmin
         for (size_t k = 0; k < stats.queue.size() && k < 8; ++k) h_stats[4 + k] = stats.queue[k];
         return 0;
     } catch (const nvbio::hip_error& e) { fprintf(stderr, "aligner_shim: %s\n", e.what()); return 1; }
+}
+
+// The same driver for timing (bench.py's e2e_leg.cxx_best_approx): one Aligner kept across `reps` batches, wall time per batch
+// between device synchronisations, then one more batch with the stage clock on.  out_ms[0] = mean ms per batch,
+// out_stage_ms = {map, select_init, select, locate, score, reduce, mapq, traceback, finish}; h_best / h_mapq as above.
+extern "C" __attribute__((visibility("default")))
+int nvbio_aligner_best_approx_timed(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmindex* rfmi, uint32_t n, uint32_t L,
+                                    const uint32_t* d_rev_words, uint64_t rev_n_words, const uint64_t* d_rev_begin,
+                                    const uint32_t* d_fwrc_words, uint64_t fwrc_n_words, const uint8_t* d_quals, uint64_t n_quals,
+                                    const char* d_names, const uint32_t* d_names_idx,
+                                    const uint32_t* d_genome_words, uint64_t genome_n_words, uint32_t genome_len, const shim_params* sp,
+                                    uint32_t reps, double* out_ms, double* out_stage_ms /* 9 */, uint64_t* d_best /* device, 2n */, uint8_t* d_mapq /* device */,
+                                    uint64_t* h_stats)
+{
+    try {
+        Params params;
+        params.seed_len = sp->seed_len; params.seed_freq = SimpleFunc(SimpleFunc::Type(sp->seed_freq_type), sp->seed_freq_k, sp->seed_freq_m);
+        params.min_read_len = sp->min_read_len; params.max_hits = sp->max_hits; params.max_reseed = sp->max_reseed; params.rep_seeds = sp->rep_seeds;
+        params.allow_sub = sp->allow_sub; params.subseed_len = sp->subseed_len;
+        params.select.randomized = sp->randomized != 0; params.select.top_seed = sp->top_seed; params.select.max_effort_init = sp->max_effort_init;
+        params.select.max_effort = sp->max_effort; params.select.min_ext = sp->min_ext; params.select.max_ext = sp->max_ext;
+        params.max_dist = sp->max_dist; params.alignment_type = sp->local ? LocalAlignment : EndToEndAlignment;
+        params.no_multi_hits = sp->no_multi_hits != 0; params.hits_stride = sp->hits_stride; params.finish_alignments = sp->finish != 0;
+        aln::SmithWatermanScoringScheme scheme = sp->local ? aln::SmithWatermanScoringScheme::local() : aln::SmithWatermanScoringScheme();
+        scheme.m_match = sp->match;
+        const ScoreLimits limits(sp->match, SimpleFunc(SimpleFunc::Type(sp->score_min_type), sp->score_min_k, sp->score_min_m));
+        fm_index_device f, rf; f.m = *fmi; rf.m = rfmi ? *rfmi : *fmi;
+        ReadBatch reads;
+        reads.n = n; reads.len = L;
+        reads.reversed = PackedStringSetView<4, true>(n, d_rev_words, rev_n_words, d_rev_begin, nullptr, L);
+        reads.fw_rc_words = d_fwrc_words; reads.fw_rc_n_words = fwrc_n_words; reads.rc_offset = uint64_t(n) * L;
+        reads.quals = d_quals; reads.n_quals = n_quals; reads.names = d_names; reads.names_idx = d_names_idx;
+
+        Aligner aligner;
+        aligner.init(std::max(sp->batch_size, n), sp->batch_size);
+        // two warm-up batches: the first sizes the Aligner's workspace, the second finds it in one block
+        for (int w = 0; w < 2; ++w) { Stats warm; aligner.best_approx(params, f, rf, scheme, limits, d_genome_words, genome_n_words, genome_len, reads, warm); }
+        hip::synchronize();
+        double total = 0.0;
+        Stats stats;
+        for (uint32_t r = 0; r < reps; ++r)
+        {
+            stats = Stats();
+            const auto t0 = std::chrono::steady_clock::now();
+            aligner.best_approx(params, f, rf, scheme, limits, d_genome_words, genome_n_words, genome_len, reads, stats);
+            hip::synchronize();
+            total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
+        out_ms[0] = reps ? total / reps : 0.0;
+        if (getenv("NVBIO_SHIM_TRACE")) {
+            double ams = 0; uint64_t calls = 0; nvb_debug_alloc_stats(&ams, &calls);
+            fprintf(stderr, "aligner_shim: %.1f ms per batch; device malloc/free so far: %.1f ms in %llu calls (%u batches incl. warm-up)\n", out_ms[0], ams, (unsigned long long)calls, reps + 2u);
+        }
+        Stats timed; timed.clock.enabled = true;
+        aligner.best_approx(params, f, rf, scheme, limits, d_genome_words, genome_n_words, genome_len, reads, timed);
+        hip::synchronize();
+        const char* names[9] = { "map", "select_init", "select", "locate", "score", "reduce", "mapq", "traceback", "finish" };
+        for (int k = 0; k < 9; ++k) out_stage_ms[k] = timed.clock.ms.count(names[k]) ? timed.clock.ms[names[k]] : 0.0;
+        hip_check(nvbio_hip_memcpy(d_best, aligner.best_data_dvec.data(), uint64_t(n) * 8u, 3, nullptr), "d2d");
+        hip_check(nvbio_hip_memcpy(d_best + n, aligner.best_data_dvec.data() + aligner.BATCH_SIZE, uint64_t(n) * 8u, 3, nullptr), "d2d");
+        hip_check(nvbio_hip_memcpy(d_mapq, aligner.mapq_dvec.data(), n, 3, nullptr), "d2d");
+        hip::synchronize();
+        h_stats[0] = stats.extensions; h_stats[1] = stats.rounds; h_stats[2] = stats.seeding_passes; h_stats[3] = stats.dp_jobs;
+        return 0;
+    } catch (const std::exception& e) { fprintf(stderr, "aligner_shim: %s\n", e.what()); return 1; }
 }
 
 struct shim_pe_params { int32_t pe_policy; uint32_t pe_overlap, pe_unpaired, pe_discordant, min_frag_len, max_frag_len; };
