@@ -291,6 +291,9 @@ typedef struct nvbio_hip_fmindex {
                                    which also fills the constants below from the buffer's header */
     uint32_t        dimer_p1, dimer_fill1;
     uint32_t        dimer_S[4], dimer_T[4];
+    const uint32_t* trimer;     /* optional, NULL = none; needs `dimer`: the three-symbol rank arrays built by
+                                   nvbio_hip_fm_build_trimer_index (10.7 B per SA row).  Backward search then consumes three
+                                   symbols per step -- same ranges, bit for bit */
 } nvbio_hip_fmindex;
 
 /* Replaces nvbio::rank(fmi, k, c) (nvbio/fmindex/fmindex_inl.h:36-57) over n
@@ -326,6 +329,15 @@ uint64_t nvbio_hip_fm_dimer_index_bytes(uint32_t length);
 uint64_t nvbio_hip_fm_build_dimer_index_temp_bytes(uint32_t length);
 int nvbio_hip_fm_build_dimer_index(const nvbio_hip_fmindex* fmi, uint32_t* out_dimer, void* temp, uint64_t temp_bytes, void* stream);
 int nvbio_hip_fm_attach_dimer_index(nvbio_hip_fmindex* fmi, const uint32_t* dimer, void* stream);
+
+/* The three-symbol rank arrays on top of the two-symbol index: for each of the 64 trimers "abc" an array of 16-byte records
+ * {C3[abc] + #rows before the record whose three preceding text symbols are abc, 96-bit mask of the record's rows holding abc},
+ * so that one backward-search step consumes three pattern symbols for one 16-byte load per range end.  Built on the device
+ * from `fmi`'s bwt_occ; out_trimer: nvbio_hip_fm_trimer_index_bytes(length) bytes, 128-byte aligned (a 128-byte header, then the
+ * arrays); temp: nvbio_hip_fm_build_trimer_index_temp_bytes(length).  Attach by setting fmi->trimer (fmi->dimer must be set). */
+uint64_t nvbio_hip_fm_trimer_index_bytes(uint32_t length);
+uint64_t nvbio_hip_fm_build_trimer_index_temp_bytes(uint32_t length);
+int nvbio_hip_fm_build_trimer_index(const nvbio_hip_fmindex* fmi, uint32_t* out_trimer, void* temp, uint64_t temp_bytes, void* stream);
 
 /* ---- `_host` twins: the reference's HostThreadScheduler / host paths (batched_banded_inl.h:97-128,
  * batched_inl.h:236-300, the host fm_index functions) behind the same argument lists with HOST pointers everywhere and a

@@ -16,14 +16,15 @@ struct fm_index_device
     typedef uint2  range_type;
     nvbio_hip_fmindex m;
 
-    fm_index_device() { m.length = m.primary = 0; m.sa_int = 16; m.bwt_occ = nullptr; m.ssa = nullptr; m.ktab = nullptr; m.ktab_k = 0; m._pad = 0; m.dimer = nullptr; m.dimer_p1 = m.dimer_fill1 = 0; for (int i = 0; i < 5; ++i) m.L2[i] = 0; for (int i = 0; i < 4; ++i) m.dimer_S[i] = m.dimer_T[i] = 0; }
+    fm_index_device() { m.length = m.primary = 0; m.sa_int = 16; m.bwt_occ = nullptr; m.ssa = nullptr; m.ktab = nullptr; m.ktab_k = 0; m._pad = 0; m.dimer = nullptr; m.trimer = nullptr; m.dimer_p1 = m.dimer_fill1 = 0; for (int i = 0; i < 5; ++i) m.L2[i] = 0; for (int i = 0; i < 4; ++i) m.dimer_S[i] = m.dimer_T[i] = 0; }
     fm_index_device(uint32 length, uint32 primary, const uint32* L2, const uint32* bwt_occ, const uint32* ssa, uint32 sa_int = 16)
-    { m.length = length; m.primary = primary; for (int i = 0; i < 5; ++i) m.L2[i] = L2[i]; m.bwt_occ = bwt_occ; m.ssa = ssa; m.sa_int = sa_int; m.ktab = nullptr; m.ktab_k = 0; m._pad = 0; m.dimer = nullptr; m.dimer_p1 = m.dimer_fill1 = 0; for (int i = 0; i < 4; ++i) m.dimer_S[i] = m.dimer_T[i] = 0; }
+    { m.length = length; m.primary = primary; for (int i = 0; i < 5; ++i) m.L2[i] = L2[i]; m.bwt_occ = bwt_occ; m.ssa = ssa; m.sa_int = sa_int; m.ktab = nullptr; m.ktab_k = 0; m._pad = 0; m.dimer = nullptr; m.trimer = nullptr; m.dimer_p1 = m.dimer_fill1 = 0; for (int i = 0; i < 4; ++i) m.dimer_S[i] = m.dimer_T[i] = 0; }
 
     /// attach the optional k-mer table built by build_ktab() (caller keeps the storage alive)
     void set_ktab(const uint32* ktab, uint32 k) { m.ktab = ktab; m.ktab_k = k; }
     // attach the line-native two-symbol index built by nvbio_hip_fm_build_dimer_index (NULL detaches)
     int  set_dimer(const uint32* dimer, void* stream = nullptr) { return nvbio_hip_fm_attach_dimer_index(&m, dimer, stream); }
+    void set_trimer(const uint32* trimer) { m.trimer = trimer; }
 
     index_type length() const { return m.length; }
     index_type primary() const { return m.primary; }

@@ -14,7 +14,8 @@ SYMBOLS = [
     "nvbio_hip_fm_match", "nvbio_hip_fm_build_ktab",
     "nvbio_hip_banded_gotoh_score_host", "nvbio_hip_banded_sw_score_host", "nvbio_hip_alignment_score_host",
     "nvbio_hip_fm_rank_host", "nvbio_hip_fm_match_host", "nvbio_hip_fm_locate_host",
-    "nvbio_hip_fm_dimer_index_bytes", "nvbio_hip_fm_build_dimer_index_temp_bytes", "nvbio_hip_fm_build_dimer_index", "nvbio_hip_fm_attach_dimer_index", "nvbio_hip_map_exact", "nvbio_hip_map",
+    "nvbio_hip_fm_dimer_index_bytes", "nvbio_hip_fm_build_dimer_index_temp_bytes", "nvbio_hip_fm_build_dimer_index", "nvbio_hip_fm_attach_dimer_index",
+    "nvbio_hip_fm_trimer_index_bytes", "nvbio_hip_fm_build_trimer_index_temp_bytes", "nvbio_hip_fm_build_trimer_index", "nvbio_hip_map_exact", "nvbio_hip_map",
     "nvbio_hip_alignment_invalid", "nvbio_hip_init_alignments", "nvbio_hip_score_reduce", "nvbio_hip_score_reduce_paired", "nvbio_hip_opposite_mate_windows", "nvbio_hip_mapq", "nvbio_hip_mapq_paired", "nvbio_hip_fm_locate",
     "nvbio_hip_sum_tree_node_count", "nvbio_hip_select_init", "nvbio_hip_select_temp_bytes", "nvbio_hip_select", "nvbio_hip_locate_hits", "nvbio_hip_hit_deque_replay",
     "nvbio_hip_score_best_setup", "nvbio_hip_score_reduce_best_approx",
@@ -60,7 +61,7 @@ class FMIndexStruct(C.Structure):        # nvbio_hip_fmindex
     _fields_ = [("length", C.c_uint32), ("primary", C.c_uint32), ("L2", C.c_uint32 * 5), ("sa_int", C.c_uint32),
                 ("bwt_occ", C.c_void_p), ("ssa", C.c_void_p), ("ktab", C.c_void_p), ("ktab_k", C.c_uint32), ("_pad", C.c_uint32),
                 ("dimer", C.c_void_p), ("dimer_p1", C.c_uint32), ("dimer_fill1", C.c_uint32),
-                ("dimer_S", C.c_uint32 * 4), ("dimer_T", C.c_uint32 * 4)]
+                ("dimer_S", C.c_uint32 * 4), ("dimer_T", C.c_uint32 * 4), ("trimer", C.c_void_p)]
 
 
 _lib = None
@@ -119,6 +120,9 @@ def lib():
         L.nvbio_hip_fm_build_dimer_index_temp_bytes.argtypes = [u32]; L.nvbio_hip_fm_build_dimer_index_temp_bytes.restype = u64
         L.nvbio_hip_fm_build_dimer_index.argtypes = [P(FMIndexStruct), vp, vp, u64, vp]
         L.nvbio_hip_fm_attach_dimer_index.argtypes = [P(FMIndexStruct), vp, vp]
+        L.nvbio_hip_fm_trimer_index_bytes.argtypes = [u32]; L.nvbio_hip_fm_trimer_index_bytes.restype = u64
+        L.nvbio_hip_fm_build_trimer_index_temp_bytes.argtypes = [u32]; L.nvbio_hip_fm_build_trimer_index_temp_bytes.restype = u64
+        L.nvbio_hip_fm_build_trimer_index.argtypes = [P(FMIndexStruct), vp, vp, u64, vp]
         L.nvbio_hip_map_exact.argtypes = [P(FMIndexStruct), P(StringSetStruct), vp, u32, P(MapParamsStruct), vp, vp, u32, vp, vp, vp]
         L.nvbio_hip_map.argtypes = [i32, u32, P(FMIndexStruct), P(FMIndexStruct), P(StringSetStruct), vp, u32, P(MapParamsStruct), vp, vp, u32, vp, vp, vp]
         L.nvbio_hip_alignment_invalid.argtypes = []

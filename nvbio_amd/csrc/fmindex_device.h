@@ -16,6 +16,7 @@ struct Fmi {
     const uint2*    ktab;       // optional: match range of every ktab_k-mer
     uint32_t        ktab_k;
     Dimer           dm;         // optional: the line-native two-symbol index (fmindex_dimer.h); base == nullptr = none
+    Trimer          tm;         // optional: the three-symbol rank arrays on top of it; pk == nullptr = none
 };
 
 inline Fmi make_fmi(const nvbio_hip_fmindex* h)
@@ -36,6 +37,9 @@ inline Fmi make_fmi(const nvbio_hip_fmindex* h)
     }
     f.dm.primary = h->primary; f.dm.p1 = h->dimer_p1; f.dm.fill1 = h->dimer_fill1;
     for (int i = 0; i < 4; ++i) { f.dm.S[i] = h->dimer_S[i]; f.dm.T[i] = h->dimer_T[i]; }
+    // the trimer arrays ride on the dimer index (leftover symbols and empty-range replays use its steps)
+    f.tm.pk = (h->dimer && h->trimer) ? reinterpret_cast<const uint4*>(h->trimer + 128u) : nullptr;      // past the 512-byte header
+    f.tm.stride = f.dm.pd_stride;
     return f;
 }
 
@@ -183,6 +187,7 @@ __device__ __forceinline__ void fm_step4(const Fmi& f, const uint32_t x, const u
 __device__ __forceinline__ uint2 fm_match_from(const Fmi& f, const Stream& s, uint64_t begin, int32_t i, uint32_t x, uint32_t y)
 {
     bool pairs = f.dm.base != nullptr;
+    bool triples = pairs && f.tm.pk != nullptr;
     while (i >= 0 && x <= y)
     {
         // symbols [g0, g0+16) of the seed, g0 = 16-aligned group holding i
@@ -192,16 +197,27 @@ __device__ __forceinline__ uint2 fm_match_from(const Fmi& f, const Stream& s, ui
         else                  grp = fetch16_4bit(s, begin + g0);
         while (i >= int32_t(g0) && x <= y)
         {
-            const uint32_t c = uint32_t(grp >> (4u * (uint32_t(i) - g0))) & 15u;
+            const uint32_t k = uint32_t(i) - g0;
+            const uint32_t c = uint32_t(grp >> (4u * k)) & 15u;
             if (c > 3u) return make_uint2(1u, 0u);
-            if (pairs && i > int32_t(g0))
+            if (pairs && k >= 1u)
             {
-                const uint32_t a = uint32_t(grp >> (4u * (uint32_t(i) - 1u - g0))) & 15u;
-                if (a <= 3u)
+                const uint32_t b = uint32_t(grp >> (4u * (k - 1u))) & 15u;
+                if (b <= 3u)
                 {
-                    const uint2 r = dm_step2(f.dm, x, y, a, c);
+                    if (triples && k >= 2u)
+                    {
+                        const uint32_t a = uint32_t(grp >> (4u * (k - 2u))) & 15u;
+                        if (a <= 3u)
+                        {
+                            const uint2 r = tm_step3(f.tm, x, y, a, b, c);
+                            if (r.x <= r.y) { x = r.x; y = r.y; i -= 3; continue; }
+                            triples = false;          // empty: replay with smaller steps for the reference's raw values
+                        }
+                    }
+                    const uint2 r = dm_step2(f.dm, x, y, b, c);
                     if (r.x <= r.y) { x = r.x; y = r.y; i -= 2; continue; }
-                    pairs = false;
+                    pairs = false; triples = false;
                 }
             }
             const uint2 r = fm_step(f, x, y, c);

@@ -189,13 +189,12 @@ __device__ __forceinline__ uint32_t pd_prefix_count(const uint4 r, const uint32_
     return __popcll(lo & klo) + __popc(r.w & khi);
 }
 
-// one backward-search step by the dimer (a,b): pattern "abP" from the range [x,y] of P.  One 16-byte load per
-// range end (one in all when the wave's ranges are narrow enough to share a record).
-__device__ __forceinline__ uint2 dm_step2(const Dimer& d, const uint32_t x, const uint32_t y, const uint32_t a, const uint32_t b)
+// one backward-search step by a k-mer whose rank array is `arr` (records of {counter, 96-bit mask}): the range of "kP" from
+// the range [x,y] of P.  One 16-byte load per range end (one in all when the wave's ranges are narrow enough to share a record).
+__device__ __forceinline__ uint2 dm_step_array(const uint4* arr, const uint32_t x, const uint32_t y)
 {
     const uint32_t ex = x, ey = y + 1u;
     const uint32_t qx = __umulhi(ex, 0xAAAAAAABu) >> 6, qy = __umulhi(ey, 0xAAAAAAABu) >> 6;       // e / 96
-    const uint4* arr = d.pd + uint64_t(a * 4u + b) * d.pd_stride;
     uint32_t rx, ry;
     if (__builtin_amdgcn_ballot_w64(qx != qy) == 0ull)
     {
@@ -210,6 +209,24 @@ __device__ __forceinline__ uint2 dm_step2(const Dimer& d, const uint32_t x, cons
         ry = r1.x + pd_prefix_count(r1, ey - qy * 96u);
     }
     return make_uint2(rx + 1u, ry);
+}
+// by the dimer (a,b): pattern "abP"
+__device__ __forceinline__ uint2 dm_step2(const Dimer& d, const uint32_t x, const uint32_t y, const uint32_t a, const uint32_t b)
+{
+    return dm_step_array(d.pd + uint64_t(a * 4u + b) * d.pd_stride, x, y);
+}
+
+// ---------------------------------------------------------------------------- three symbols per step
+// The same per-k-mer rank arrays for the 64 trimers (10.7 bytes per row: 32 GB at 3 Gbp -- a ninth of one MI355X's HBM): a
+// 22-bp seed is 7 trimer steps + 1 symbol instead of 11 dimer steps, and what bounds the search is L2 misses per seed
+// (fmindex_trimer.hip builds them; trimer (a,b,c) = pattern "abcP", code a*16 + b*4 + c, C3 folded into the counters).
+struct Trimer {
+    const uint4* pk;         // pk[code * stride + r]; nullptr = not attached
+    uint32_t     stride;
+};
+__device__ __forceinline__ uint2 tm_step3(const Trimer& t, const uint32_t x, const uint32_t y, const uint32_t a, const uint32_t b, const uint32_t c)
+{
+    return dm_step_array(t.pk + uint64_t(a * 16u + b * 4u + c) * t.stride, x, y);
 }
 
 __device__ __forceinline__ uint32_t dm_sel4v(const uint4 q, const uint32_t i)

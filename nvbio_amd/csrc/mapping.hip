@@ -32,6 +32,7 @@ __device__ __forceinline__ uint2 match_range_x(const Fmi& f, const Stream& s, ui
     uint32_t x = 0, y = f.length;
     uint32_t t_start = 0;
     bool pairs = f.dm.base != nullptr;
+    bool triples = pairs && f.tm.pk != nullptr;
     const uint32_t k = f.ktab_k;
     if (k != 0u && len >= k)
     {
@@ -65,14 +66,25 @@ __device__ __forceinline__ uint2 match_range_x(const Fmi& f, const Stream& s, ui
             if (complement) c = 3u - c;
             if (pairs && u + 1u < cnt)
             {
-                // two scan symbols per line fetch on the two-symbol index (see fm_match_from)
-                uint32_t a = uint32_t(grp >> (4u * (reverse ? cnt - 2u - u : u + 1u))) & 15u;
-                if (a <= 3u)
+                // two (three) scan symbols per line fetch on the two- (three-) symbol index (see fm_match_from)
+                uint32_t b = uint32_t(grp >> (4u * (reverse ? cnt - 2u - u : u + 1u))) & 15u;
+                if (b <= 3u)
                 {
-                    if (complement) a = 3u - a;
-                    const uint2 r = dm_step2(f.dm, x, y, a, c);
+                    if (complement) b = 3u - b;
+                    if (triples && u + 2u < cnt)
+                    {
+                        uint32_t a = uint32_t(grp >> (4u * (reverse ? cnt - 3u - u : u + 2u))) & 15u;
+                        if (a <= 3u)
+                        {
+                            if (complement) a = 3u - a;
+                            const uint2 r = tm_step3(f.tm, x, y, a, b, c);
+                            if (r.x <= r.y) { x = r.x; y = r.y; u += 3u; continue; }
+                            triples = false;
+                        }
+                    }
+                    const uint2 r = dm_step2(f.dm, x, y, b, c);
                     if (r.x <= r.y) { x = r.x; y = r.y; u += 2u; continue; }
-                    pairs = false;
+                    pairs = false; triples = false;
                 }
             }
             const uint2 r = fm_step(f, x, y, c);
@@ -200,6 +212,7 @@ __device__ __forceinline__ SeedVec sv_complement(const SeedVec& q, const uint32_
 __device__ __forceinline__ uint2 match_span(const Fmi& f, const SeedVec& q, const uint32_t a, const uint32_t b, uint2 r)
 {
     bool pairs = f.dm.base != nullptr;
+    bool triples = pairs && f.tm.pk != nullptr;
     uint32_t i = a;
     while (i < b && r.x <= r.y)
     {
@@ -210,9 +223,19 @@ __device__ __forceinline__ uint2 match_span(const Fmi& f, const SeedVec& q, cons
             const uint32_t c2 = sv_sym(q, i + 1u);
             if (c2 <= 3u)
             {
+                if (triples && i + 2u < b)
+                {
+                    const uint32_t c3 = sv_sym(q, i + 2u);
+                    if (c3 <= 3u)
+                    {
+                        const uint2 k = tm_step3(f.tm, r.x, r.y, c3, c2, c);
+                        if (k.x <= k.y) { r = k; i += 3u; continue; }
+                        triples = false;
+                    }
+                }
                 const uint2 k = dm_step2(f.dm, r.x, r.y, c2, c);
                 if (k.x <= k.y) { r = k; i += 2u; continue; }
-                pairs = false;
+                pairs = false; triples = false;
             }
         }
         r = fm_step(f, r.x, r.y, c);

@@ -19,17 +19,18 @@ def _vp(t):
 class FMIndexDevice:
     """Device-resident FM-index in the reference's interleaved bwt|occ layout."""
 
-    def __init__(self, length, primary, L2, bwt_occ, ssa=None, sa_int=16, ktab=None, ktab_k=0, dimer=None, dimer_consts=None):
+    def __init__(self, length, primary, L2, bwt_occ, ssa=None, sa_int=16, ktab=None, ktab_k=0, dimer=None, dimer_consts=None, trimer=None):
         assert bwt_occ.dtype == torch.int32 and bwt_occ.is_contiguous()
         assert bwt_occ.data_ptr() % 32 == 0
         self.length, self.primary, self.L2 = int(length), int(primary), [int(x) for x in L2]
         self.bwt_occ, self.ssa, self.sa_int = bwt_occ, ssa, int(sa_int)
         self.ktab, self.ktab_k = ktab, int(ktab_k)
         self.dimer, self.dimer_consts = dimer, dimer_consts     # line-native two-symbol index + its header constants
+        self.trimer = trimer                                    # three-symbol rank arrays on top of it
 
     def _copy(self, **kw):
         d = dict(length=self.length, primary=self.primary, L2=self.L2, bwt_occ=self.bwt_occ, ssa=self.ssa, sa_int=self.sa_int,
-                 ktab=self.ktab, ktab_k=self.ktab_k, dimer=self.dimer, dimer_consts=self.dimer_consts)
+                 ktab=self.ktab, ktab_k=self.ktab_k, dimer=self.dimer, dimer_consts=self.dimer_consts, trimer=self.trimer)
         d.update(kw)
         return FMIndexDevice(**d)
 
@@ -53,7 +54,25 @@ class FMIndexDevice:
         return self._copy(dimer=dimer, dimer_consts=consts)
 
     def without_dimer(self):
-        return self._copy(dimer=None, dimer_consts=None)
+        return self._copy(dimer=None, dimer_consts=None, trimer=None)
+
+    def with_trimer(self):
+        """A copy carrying, on top of the two-symbol index (built if absent), the three-symbol rank arrays (10.7 bytes per SA
+        row): backward search then consumes three symbols per step.  Results are bit-identical."""
+        base = self if self.dimer is not None else self.with_dimer()
+        L = lib()
+        dev = self.bwt_occ.device
+        nbytes = int(L.nvbio_hip_fm_trimer_index_bytes(self.length))
+        buf = torch.empty(nbytes // 4 + 32, dtype=torch.int32, device=dev)
+        off = (-buf.data_ptr() % 128) // 4
+        tri = buf[off:off + nbytes // 4]
+        tb = int(L.nvbio_hip_fm_build_trimer_index_temp_bytes(self.length))
+        temp = torch.empty(tb, dtype=torch.uint8, device=dev)
+        s = base._copy(dimer=None, dimer_consts=None, ktab=None, ktab_k=0, trimer=None).struct()
+        check(L.nvbio_hip_fm_build_trimer_index(C.byref(s), _vp(tri), _vp(temp), tb, current_stream_ptr()), "nvbio_hip_fm_build_trimer_index")
+        torch.cuda.current_stream().synchronize()
+        del temp
+        return base._copy(trimer=tri)
 
     def with_ktab(self, k=12):
         """A copy of this index carrying the k-mer table accelerator (4^k uint2 entries in HBM)."""
@@ -86,6 +105,7 @@ class FMIndexDevice:
                 s.dimer_S[i], s.dimer_T[i] = self.dimer_consts[2][i], self.dimer_consts[3][i]
         else:
             s.dimer = None
+        s.trimer = self.trimer.data_ptr() if (self.trimer is not None and self.dimer is not None) else None
         return s
 
     @staticmethod

@@ -87,9 +87,43 @@ def build(text, sa, L2):
     return out
 
 
+TRIMER_MAGIC = 0x54724D33
+
+
+def build_trimer(text, sa, L2):
+    """-> uint32 array: 128-dword header (C3 at dword 64), then pk[code][record] of 4 dwords (fmindex_trimer.hip)."""
+    t = np.asarray(text, dtype=np.int64)
+    sa = np.asarray(sa, dtype=np.int64)
+    n = t.size
+    R = pd_records(n)
+    code = np.where(sa >= 3, t[np.maximum(sa - 3, 0)] * 16 + t[np.maximum(sa - 2, 0)] * 4 + t[np.maximum(sa - 1, 0)], -1)
+    rows = np.zeros(R * 96, dtype=np.int64) - 1
+    rows[:n + 1] = code
+    tb = rows.reshape(R, 96)
+    out = np.zeros(128 + 64 * 4 * R, dtype=np.uint32)
+    out[0], out[1], out[2], out[3] = TRIMER_MAGIC, n, int(np.nonzero(sa == 0)[0][0]), R
+    # C3[abc] = (first row whose suffix starts with "abc") - 1: rows are sorted by suffix, so count the suffixes below "abc"
+    # (shorter suffixes that are proper prefixes of "abc" sort before it)
+    sfx = [tuple(t[p:p + 3]) for p in range(n)] + [()]
+    pk = out[128:].reshape(64, R, 4)
+    for c in range(64):
+        key = (c >> 4, (c >> 2) & 3, c & 3)
+        out[64 + c] = (sum(1 for s_ in sfx if s_ < key) - 1) & M32
+        m = (tb == c)
+        cnt = np.count_nonzero(m, axis=1)
+        pk[c, :, 0] = ((np.cumsum(cnt) - cnt + int(out[64 + c])) & M32).astype(np.uint32)
+        for w in range(3):
+            word = np.zeros(R, dtype=np.uint64)
+            for r in range(32):
+                word |= m[:, 32 * w + r].astype(np.uint64) << np.uint64(r)
+            pk[c, :, 1 + w] = word.astype(np.uint32)
+    return out
+
+
 class Model:
-    def __init__(self, buf):
+    def __init__(self, buf, trimer=None):
         self.buf = buf
+        self.tri = trimer
         h = buf[:32]
         assert int(h[0]) == MAGIC
         self.n, self.primary, self.p1, self.fill1 = int(h[1]), int(h[2]), int(h[3]), int(h[4])
@@ -135,6 +169,19 @@ class Model:
         self.lines += 1 if x // 768 == (y + 1) // 768 else 2
         return (self.D(x, a, b) + 1) & M32, self.D((y + 1) & M32, a, b)
 
+    def D3(self, e, code):
+        q = e // 96
+        R = int(self.tri[3])
+        o = 128 + 4 * (code * R + q)
+        r = self.tri[o:o + 4]
+        m = int(r[1]) | int(r[2]) << 32 | int(r[3]) << 64
+        return (int(r[0]) + self._prefix(m, e - 96 * q)) & M32
+
+    def step3(self, x, y, a, b, c):
+        self.lines += 1 if x // 768 == (y + 1) // 768 else 2
+        code = a * 16 + b * 4 + c
+        return (self.D3(x, code) + 1) & M32, self.D3((y + 1) & M32, code)
+
     def step1(self, x, y, c):
         self.lines += 1 if (x >> 7) == ((y + 1) >> 7) else 2
         return (self.R(x, c) + 1) & M32, self.R((y + 1) & M32, c)
@@ -144,6 +191,7 @@ class Model:
         x, y = 0, self.n
         i = len(seed) - 1
         pairs = True
+        triples = self.tri is not None
         while i >= 0 and x <= y:
             g0 = i & ~15
             while i >= g0 and x <= y:
@@ -151,13 +199,21 @@ class Model:
                 if c > 3:
                     return 1, 0
                 if pairs and i > g0:
-                    a = int(seed[i - 1])
-                    if a <= 3:
-                        nx, ny = self.step2(x, y, a, c)
+                    b = int(seed[i - 1])
+                    if b <= 3:
+                        if triples and i - 2 >= g0:
+                            a = int(seed[i - 2])
+                            if a <= 3:
+                                nx, ny = self.step3(x, y, a, b, c)
+                                if nx <= ny:
+                                    x, y, i = nx, ny, i - 3
+                                    continue
+                                triples = False
+                        nx, ny = self.step2(x, y, b, c)
                         if nx <= ny:
                             x, y, i = nx, ny, i - 2
                             continue
-                        pairs = False
+                        pairs = triples = False
                 x, y = self.step1(x, y, c)
                 i -= 1
         return x, y

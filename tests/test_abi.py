@@ -32,7 +32,7 @@ def test_struct_layouts_match_header():
     # sizes the C compiler gives the ABI structs (LP64): 8+8+4+4+8+8+4+4 / 16 / 4+4+20+4 +8+8+8 +4+4 +8 +4+4+16+16
     assert ctypes.sizeof(_lib.StringSetStruct) == 48
     assert ctypes.sizeof(_lib.GotohSchemeStruct) == 16
-    assert ctypes.sizeof(_lib.FMIndexStruct) == 112
+    assert ctypes.sizeof(_lib.FMIndexStruct) == 120
     assert _lib.FMIndexStruct.dimer.offset == 64 and _lib.FMIndexStruct.dimer_S.offset == 80
 
 

@@ -19,6 +19,7 @@ def test_model_matches_oracle(n, sa_int):
         text[10:40] = np.tile([0, 1], 15)
     host = O.FMIndex(text, sa_int=sa_int)
     m = DM.Model(DM.build(text, host.sa, host.L2))
+    m3 = DM.Model(DM.build(text, host.sa, host.L2), DM.build_trimer(text, host.sa, host.L2)) if n <= 5000 else None
     seeds = []
     for i in range(600):
         L = int(rng.integers(1, 40))
@@ -36,6 +37,8 @@ def test_model_matches_oracle(n, sa_int):
     exp = host.match(ss)
     for s, e in zip(seeds, exp):
         assert m.match(s) == (int(e[0]), int(e[1])), (s, e)
+        if m3 is not None:
+            assert m3.match(s) == (int(e[0]), int(e[1])), (s, e)        # three symbols per step: same ranges
     rows = np.arange(n + 1, dtype=np.uint32)
     its = host.locate_ssa_iterator(rows)
     for j in range(n + 1):

@@ -373,3 +373,35 @@ def test_full_size_match_and_locate(cuda, genome_3gbp, flavour):
         assert (text[int(q):int(q) + 22].cpu().numpy() == O.unpack(hs.words, int(hs.begin[j]), 22, hs.bits, hs.big_endian)).all()
     del idx
     torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------ three symbols per step
+def test_trimer_arrays_equal_model(cuda, index):
+    from tests import dimer_model as DM
+    text, host, dev = index
+    if host.length > 200000:
+        pytest.skip("the model enumerates suffixes in Python")
+    ft = dev.with_trimer()
+    got = u32(ft.trimer)
+    exp = DM.build_trimer(text, host.sa, host.L2)
+    assert got.size == exp.size
+    assert (got[:4] == exp[:4]).all() and (got[64:128] == exp[64:128]).all(), (got[:4], exp[:4])
+    assert (got[128:] == exp[128:]).all()
+
+
+@pytest.mark.parametrize("bits,be", [(2, True), (4, True), (4, False)])
+def test_trimer_match_is_identical(cuda, index, bits, be):
+    """three symbols per step: every length mod 3, seeds shorter than a triple, an N in any of the three places, absent seeds
+    (the raw (x,y) of the emptying step through the smaller-step replay), with and without the k-mer table"""
+    text, host, dev = index
+    rng = np.random.default_rng(60 + bits * 2 + be)
+    ft = dev.with_trimer()
+    variants = [ft, ft.with_ktab(5), ft.with_ktab(8)]
+    for length in (22, 21, 20, 0, 1, 2, 3, 33):
+        hs = make_seeds(rng, text, 20000, length, bits, be, with_n=True)
+        exp = host.match(hs)
+        ds = nvb.PackedStringSet.from_host(hs.words, bits, be, hs.begin, hs.length, device=cuda)
+        for f in variants:
+            got = u32(nvb.match(f, ds))
+            bad = np.nonzero((got != exp).any(1))[0]
+            assert bad.size == 0, (length, f.ktab_k, bad[:5], got[bad[:5]], exp[bad[:5]])

@@ -36,6 +36,7 @@ def test_seed_hit_sets(cuda, ragged):
     host = O.FMIndex(text)
     fmi = nvb.FMIndexDevice.from_host(host, cuda)
     fdim = fmi.with_dimer()
+    ftri = fdim.with_trimer()
     reads = make_reads(rng, text, 4000, ragged)
     hr = O.StringSet.from_lists(reads, 4, True)
     dr = nvb.PackedStringSet.from_host(hr.words, 4, True, hr.begin, hr.length, device=cuda)
@@ -57,7 +58,7 @@ def test_seed_hit_sets(cuda, ragged):
             kh, kc, kr = nvb.map_exact(fmi.with_ktab(kk), dr, params, max_len, retry=retry, fw=bool(fw), rc=bool(rc), in_queue=dq, hits_stride=stride)
             assert torch.equal(kh, gh) and torch.equal(kc, gc) and torch.equal(kr, gr), kk
         # nor may the line-native two-symbol index (alone, and under the k-mer table)
-        for fv in (fdim, fdim.with_ktab(9)):
+        for fv in (fdim, fdim.with_ktab(9), ftri, ftri.with_ktab(9)):
             kh, kc, kr = nvb.map_exact(fv, dr, params, max_len, retry=retry, fw=bool(fw), rc=bool(rc), in_queue=dq, hits_stride=stride)
             assert torch.equal(kc, gc) and torch.equal(kr, gr), fv.ktab_k
             assert torch.equal(kh, gh), fv.ktab_k
@@ -102,7 +103,7 @@ def test_one_mismatch_seed_hit_sets(cuda, allow_sub, subseed):
         eh, ec, er = O.map_seeds(algo, subseed, host, rhost, hr, pd, sf, stride)
         # neither the k-mer table nor the line-native two-symbol index may change anything
         for f_dev, rf_dev in ((fmi, rfmi), (fmi.with_ktab(8), rfmi.with_ktab(8)), (fmi.with_dimer(), rfmi.with_dimer()),
-                              (fmi.with_dimer().with_ktab(8), rfmi.with_dimer())):
+                              (fmi.with_dimer().with_ktab(8), rfmi.with_dimer()), (fmi.with_trimer(), rfmi.with_trimer())):
             gh, gc, gr = nvb.map_seeds(f_dev, rf_dev, dr, params, max_len, allow_sub=allow_sub, subseed_len=subseed, retry=retry,
                                        fw=bool(fw), rc=bool(rc), hits_stride=stride)
             torch.cuda.synchronize()

@@ -18,7 +18,11 @@ fmi = W.build_fm_index(text)
 fd = fmi.with_dimer()
 seeds = W.make_seeds(text, ns, 22)
 out = nvb.match(fmi, seeds)
-for f in (fmi, fmi, fd, fd):
+flavours = (fmi, fmi, fd, fd)
+if os.environ.get("TRIMER"):
+    ft = fd.with_trimer()
+    flavours = (fd, fd, ft, ft)
+for f in flavours:
     nvb.match(f, seeds, out=out)
 torch.cuda.synchronize()
 rows = out[:, 0].contiguous()

@@ -42,6 +42,15 @@ def main():
     m2 = timed(lambda: nvb.match(fk, seeds, out=r2))
     print("match  dimer + ktab12 %.2f ms (%.2f G/s) identical %s" % (m2, ns / m2 / 1e6, bool(torch.equal(r0, r2))), flush=True)
     del fk, r2
+    t0 = time.perf_counter(); ft = fd.with_trimer(); torch.cuda.synchronize()
+    print("trimer build %.3f s, %.2f GB" % (time.perf_counter() - t0, ft.trimer.numel() * 4 / 1e9), flush=True)
+    r3 = nvb.match(ft, seeds)
+    m3 = timed(lambda: nvb.match(ft, seeds, out=r3))
+    print("match  trimer %.2f ms (%.2f G/s) identical %s" % (m3, ns / m3 / 1e6, bool(torch.equal(r0, r3))), flush=True)
+    fk3 = ft.with_ktab(12)
+    m4 = timed(lambda: nvb.match(fk3, seeds, out=r3))
+    print("match  trimer + ktab12 %.2f ms (%.2f G/s) identical %s" % (m4, ns / m4 / 1e6, bool(torch.equal(r0, r3))), flush=True)
+    del fk3, r3
     ok = (r0[:, 0].to(torch.int64) & 0xFFFFFFFF) <= (r0[:, 1].to(torch.int64) & 0xFFFFFFFF)
     rows = r0[:, 0][ok].contiguous()
     p0 = nvb.locate(fmi, rows); p1 = nvb.locate(fd, rows)
@@ -59,8 +68,11 @@ def main():
     h0, c0, q0 = nvb.map_exact(fmi, reads, mp, 100)
     h1, c1, q1 = nvb.map_exact(fd, reads, mp, 100)
     print("map_exact identical:", bool(torch.equal(h0, h1) and torch.equal(c0, c1) and torch.equal(q0, q1)), flush=True)
+    h2, c2, q2 = nvb.map_exact(ft, reads, mp, 100)
+    print("map_exact trimer identical:", bool(torch.equal(h0, h2) and torch.equal(c0, c2) and torch.equal(q0, q2)), flush=True)
     t0 = timed(lambda: nvb.map_exact(fmi, reads, mp, 100), 3); t1 = timed(lambda: nvb.map_exact(fd, reads, mp, 100), 3)
-    print("map_exact %d reads: reference %.2f ms | dimer %.2f ms" % (nr, t0, t1), flush=True)
+    t2 = timed(lambda: nvb.map_exact(ft, reads, mp, 100), 3)
+    print("map_exact %d reads: reference %.2f ms | dimer %.2f ms | trimer %.2f ms" % (nr, t0, t1, t2), flush=True)
 
 
 if __name__ == "__main__":
