@@ -45,6 +45,29 @@ BYTES_PER_ALN = 50 + 29 + 12 + 8                   # packed read + text window +
 RANK_BYTES_PER_QUERY = 40                          # 32 B record + 4 B query + 4 B result
 
 
+def measured_counter(kernel, key):
+    """Another per-launch counter of the same PMC passes (profiles/traffic.json), None if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f).get(kernel, {}).get(key)
+    except Exception:
+        return None
+
+
+def physical_cores():
+    """Physical cores of the host (distinct (package, core) pairs in /proc/cpuinfo), None if it cannot be read."""
+    try:
+        pairs, pkg = set(), None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pkg = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                pairs.add((pkg, line.split(":")[1].strip()))
+        return len(pairs) or None
+    except OSError:
+        return None
+
+
 def measured_traffic(kernel):
     """HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same command
     (profiles/traffic.json: TCC_EA0_RDREQ x request size + TCC_EA0_WRREQ x 64 B); None if absent."""
@@ -204,6 +227,18 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(a.steps, 1)
+    # the same launch on the all-int32 kernel (what runs when the host cannot prove the 16-bit form exact)
+    a32_ms = None
+    if rank == 0 and world == 1:
+        os.environ["NVBIO_HIP_FORCE_32BIT"] = "1"
+        launch(outs[1]); torch.cuda.synchronize()
+        ev32 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+        for e0, e1 in ev32:
+            e0.record(); launch(outs[1]); e1.record()
+        torch.cuda.synchronize()
+        del os.environ["NVBIO_HIP_FORCE_32BIT"]
+        a32_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev32) / len(ev32)
+        a32_same = bool(torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][1], outs[0][1]))
     if gather_on and rank == 0 and any(g.overflowed() for g in gatherers):
         raise SystemExit("result gather: records did not fit the 4-byte format")
 
@@ -226,6 +261,17 @@ def main():
             "hbm_frac": n * BYTES_PER_ALN / kt / 1e9 / HBM_PEAK_GBS,
             "note": "integer DP: neither HBM nor MFMA binds it; peak = VALU lane-ops/s at 32 lanes/clk (the rate of the 16-bit ops the kernel is built from), achieved = cells x 14 nominal ops (SURVEY 8d); results are the reference's int32 scores, computed in int16 where provably exact",
         }
+        # executed instructions (SQ_INSTS_VALU of the committed PMC pass, wave instructions x 64 lanes) next to the nominal-op count
+        iv = measured_counter("banded_gotoh_score_kernel", "insts_valu_per_launch")
+        if iv is not None:
+            iv_reads = measured_counter("banded_gotoh_score_kernel", "insts_valu_reads") or n
+            roofline["executed"] = {"valu_lane_ops_per_cell": iv * 64.0 / iv_reads / CELLS_PER_ALN, "nominal_ops_per_cell": NOMINAL_OPS_PER_CELL,
+                                    "achieved": iv / iv_reads * n * 64 / kt / 1e12, "unit": "T lane-op/s",
+                                    "frac": iv / iv_reads * n * 64 / kt / 1e12 / VALU_PEAK_TOPS, "source": "SQ_INSTS_VALU, profiles/traffic.json"}
+        if a32_ms is not None:
+            roofline["a32"] = {"kernel": "banded_gotoh_score_kernel<15,LOCAL,A32>", "kernel_ms": a32_ms, "gcups": n * CELLS_PER_ALN / (a32_ms * 1e-3) / 1e9,
+                               "reads_per_s": n / (a32_ms * 1e-3), "frac": n * CELLS_PER_ALN * NOMINAL_OPS_PER_CELL / (a32_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS,
+                               "identical_results": a32_same}
         out = {
             "metric": "aligned reads/s (100 bp, band=15)", "value": value, "unit": "reads/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
@@ -382,10 +428,13 @@ def e2e_leg(a, dev, fmi, text):
     from nvbio_amd import aligner as AL, select as SEL
     names = SEL.pack_names(["r%d" % i for i in range(n)], dev)
     prm = AL.Params(hits_stride=16, batch_size=n)
-    for name, idx in (("nvbowtie_best_approx", fmi), ("nvbowtie_best_approx_line_native", "dimer"), ("nvbowtie_best_approx_line_native_ktab12_ssa1", "dimer12"),
+    for name, idx in (("nvbowtie_best_approx", fmi), ("nvbowtie_best_approx_line_native", "dimer"), ("nvbowtie_best_approx_line_native_ktab8", "dimer8"),
+                      ("nvbowtie_best_approx_line_native_ktab12_ssa1", "dimer12"),
                       ("nvbowtie_best_approx_ktab12_ssa1", 12), ("nvbowtie_best_approx_ktab15_ssa1", 15)):
         if idx == "dimer":                             # the line-native two-symbol index next to the reference layout (11 GB at 3 Gbp)
             idx = fmi.with_dimer()
+        elif idx == "dimer8":                          # + the 512 KB prefix table that lives in L2
+            idx = fmi.with_dimer().with_ktab(8)
         elif idx == "dimer12":
             idx = fmi.with_dimer().with_ktab(12).with_dense_ssa(1)
         elif not hasattr(idx, "length"):               # HBM-capacity options: 4^k-entry k-mer table (0.13 / 8.6 GB) + the full suffix array (12 GB)
@@ -627,12 +676,32 @@ def seed_leg(a, dev, fmi, text, build_s):
                    "locate": {"kernel": "fm_locate_kernel", "kernel_ms": dl_ms, "Mrows_per_s": rows.numel() / (dl_ms * 1e-3) / 1e6,
                               "identical": bool(torch.equal(p2, pos)),
                               "sorted_rows_kernel_ms": timed(lambda: nvb.locate(fdim, srt, out=ps))}}
+    # what the reference's SA-row sort before locate (aligner_best_approx.h:735-741: sort_hi_bits) would cost here, to set against
+    # the gain of sorted rows above: the drivers do not sort, because the gain is smaller than the sort
+    from nvbio_amd import select as SEL
+    line_native["locate"]["sort_hi_bits_ms"] = timed(lambda: SEL.sort_hi_bits(rows))
     fdk = fdim.with_ktab(12)
     dk_ms = timed(lambda: nvb.match(fdk, seeds, out=r2))
     line_native["match_ktab12"] = {"kernel_ms": dk_ms, "Mseeds_per_s": a.seeds / (dk_ms * 1e-3) / 1e6, "identical": bool(torch.equal(r2, ranges))}
+    del fdk
+    # a 4^8-entry table is 512 KB: resident in every XCD's L2, it replaces the four widest pair steps (8 line requests) of a seed
+    fd8 = fdim.with_ktab(8)
+    d8_ms = timed(lambda: nvb.match(fd8, seeds, out=r2))
+    line_native["match_ktab8_l2_resident"] = {"kernel_ms": d8_ms, "Mseeds_per_s": a.seeds / (d8_ms * 1e-3) / 1e6, "table_bytes": int(fd8.ktab.numel()) * 4,
+                                              "identical": bool(torch.equal(r2, ranges))}
+    del fd8
+    # three symbols per step on the 64 per-trimer rank arrays (32 GB at 3 Gbp: an HBM-capacity option)
+    t0 = time.perf_counter()
+    ftri = fdim.with_trimer()
+    torch.cuda.synchronize()
+    tri_s = time.perf_counter() - t0
+    t3_ms = timed(lambda: nvb.match(ftri, seeds, out=r2))
+    line_native["match_trimer"] = {"kernel_ms": t3_ms, "Mseeds_per_s": a.seeds / (t3_ms * 1e-3) / 1e6, "index_bytes": int(ftri.trimer.numel()) * 4, "build_s": tri_s,
+                                   "identical": bool(torch.equal(r2, ranges))}
+    del ftri
     ref_sorted_ms = timed(lambda: nvb.locate(fmi, srt, out=ps))
-    del fdk, fdim, r2, p2, ps, srt
-    if not (line_native["match"]["identical"] and line_native["locate"]["identical"] and line_native["match_ktab12"]["identical"]):
+    del fdim, r2, p2, ps, srt
+    if not all(v["identical"] for v in line_native.values() if isinstance(v, dict)):
         raise SystemExit("parity gate failed: the line-native index changes match/locate results")
     fk = fmi.with_ktab(12)
     r2 = torch.empty_like(ranges)
@@ -1013,7 +1082,7 @@ def cpu_leg(a, patterns, texts):
     exact = bool((gs.cpu().numpy() == es).all() and (gk.cpu().numpy().view(np.uint32) == ek).all())
     if not exact:
         raise SystemExit("parity gate failed: HIP scores differ from the oracle on the CPU-baseline sample")
-    return {"value": m / best, "unit": "reads/s", "cores": cores, "kind": "port",
+    return {"value": m / best, "unit": "reads/s", "cores": cores, "host_physical_cores": physical_cores(), "host_hardware_threads": os.cpu_count(), "kind": "port",
             "sample": "%d of the same reads, band 15 LOCAL, OpenMP over jobs with %d threads (the container's CPU quota; the host has %d hardware threads), gcc -O3 -march=native, best of 3" % (m, cores, os.cpu_count() or 0),
             "gpu_vs_cpu_on_sample": {"compared": m, "bit_exact": exact}}
 
