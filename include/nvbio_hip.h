@@ -232,6 +232,27 @@ int nvbio_hip_gotoh_traceback_qual(
     uint16_t* out_cigar, uint32_t cigar_stride, uint32_t* out_cigar_len,
     void* temp, uint64_t temp_bytes, void* stream);
 
+/* The two full-matrix tracebacks for callers that know, per job, the score of the best alignment over the job's text AND that it ends
+ * at the text's last symbol -- nvBowtie's opposite-mate tracebacks, whose windows are [alignment, alignment + sink) of a scoring pass
+ * (traceback_inl.h:833-905).  The text rows no alignment of that score can reach (all but the last M + gaps-the-score-allows) are
+ * dropped before any DP runs; score, sink, source and CIGAR are those of the plain forms (argument: full_traceback.hip,
+ * crop_windows_kernel).  known_score: device int32[n].  A job for which the premise does not hold gets the traceback of the cropped
+ * window.  GLOBAL: same as the plain forms. */
+int nvbio_hip_gotoh_traceback_known_score(
+    const nvbio_hip_gotoh_scheme* scheme /* host */, int32_t type,
+    const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts, const int32_t* known_score,
+    uint32_t max_pattern_len, uint32_t max_text_len, uint32_t n,
+    int32_t* out_score, uint32_t* out_sink, uint32_t* out_source,
+    uint16_t* out_cigar, uint32_t cigar_stride, uint32_t* out_cigar_len,
+    void* temp, uint64_t temp_bytes, void* stream);
+int nvbio_hip_gotoh_traceback_qual_known_score(
+    const nvbio_hip_gotoh_qual_scheme* scheme /* host */, int32_t type,
+    const nvbio_hip_string_set* patterns, const uint8_t* quals, uint64_t n_quals, const nvbio_hip_string_set* texts, const int32_t* known_score,
+    uint32_t max_pattern_len, uint32_t max_text_len, uint32_t n,
+    int32_t* out_score, uint32_t* out_sink, uint32_t* out_source,
+    uint16_t* out_cigar, uint32_t cigar_stride, uint32_t* out_cigar_len,
+    void* temp, uint64_t temp_bytes, void* stream);
+
 /* The tracebacks for SmithWatermanAligner / EditDistanceAligner (deletion == insertion), banded (sw_banded_inl.h:405-470,
  * 748-800) and full matrix (sw_inl.h:389-396, 475-500, 1660-1700): arguments and temp sizes as the Gotoh forms.  The banded
  * reference context does not mark zero cells, so its LOCAL walk always reaches the first pattern row; reproduced. */
@@ -505,8 +526,8 @@ int nvbio_hip_score_reduce_best_approx(uint32_t n_active, const uint32_t* active
  * nvbio_hip_traceback_best_known then lays out, per traceback job, the score and sink the banded scorer would report over the job's
  * window (the same DP the extension ran; unaligned entries: a failed alignment, score -2^30, sink (-1,-1)), and
  * nvbio_hip_banded_gotoh_traceback_qual_known starts from them instead of scoring every job again.  Results are the traceback's. */
-int nvbio_hip_traceback_best_known(uint32_t n, const uint32_t* idx /* nullable */, const uint64_t* best_alignments, const uint32_t* best_sink,
-                                   int32_t* out_score, uint32_t* out_sink, void* stream);
+int nvbio_hip_traceback_best_known(uint32_t n, const uint32_t* idx /* nullable */, const uint64_t* best_alignments, const uint32_t* best_sink /* nullable */,
+                                   int32_t* out_score, uint32_t* out_sink /* nullable with best_sink: scores only */, void* stream);
 
 /* The paired-end form: score_reduce_paired_kernel (reduce_inl.h:355-500).  Per extension result the anchor mate's
  * {loc, sink (genome end), score, rc} and the opposite mate's {loc, sink, sink2, score, score2} (the stream's hit.* fields,

@@ -623,8 +623,12 @@ private:
             const PackedStringSetView<2, true> texts(n_conc, genome_words, genome_n_words, tb_txt.data(), tb_len.data(), 0u);
             const nvbio_hip_string_set p = patterns.abi(), t = texts.abi();
             hip::device_vector<uint8> temp(nvbio_hip_gotoh_traceback_temp_bytes(L, 1024u, n_conc));
-            hip_check(nvbio_hip_gotoh_traceback_qual(&sc, int32(TYPE), &p, reads.both_quals, reads.both_n_quals, &t, L, 1024u, n_conc, score.data(), snk.data(), src.data(),
-                                                     reinterpret_cast<uint16*>(cg.data()), cigar_stride, cg_len.data(), temp.data(), temp.size(), hip_stream), "nvbio_hip_gotoh_traceback_qual");
+            // each window ends at the sink of the scoring pass whose score the slot holds: the rows no alignment of that score can reach are dropped
+            hip::device_vector<int32> known(n_conc);
+            hip_check(nvbio_hip_traceback_best_known(n_conc, idx_c.data(), best_o, nullptr, known.data(), nullptr, hip_stream), "nvbio_hip_traceback_best_known");
+            hip_check(nvbio_hip_gotoh_traceback_qual_known_score(&sc, int32(TYPE), &p, reads.both_quals, reads.both_n_quals, &t, known.data(), L, 1024u, n_conc, score.data(), snk.data(),
+                                                                 src.data(), reinterpret_cast<uint16*>(cg.data()), cigar_stride, cg_len.data(), temp.data(), temp.size(), hip_stream),
+                      "nvbio_hip_gotoh_traceback_qual_known_score");
             if (params.finish_alignments) finish(n_conc, v.data(), idx_c.data(), best_o, cg.data(), cg_len.data(), src.data(), md.data(), md_len.data());
             // put the concordant mates' results at their reads
             hip_check(nvbio_hip_scatter_rows(n_conc, idx_c.data(), cg.data(),     cigar_o.data(),           cigar_stride * 2u, hip_stream), "nvbio_hip_scatter_rows");

@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libnvbio_hip.so")
 SYMBOLS = [
     "nvbio_hip_banded_gotoh_score", "nvbio_hip_banded_gotoh_score_qual", "nvbio_hip_gotoh_score", "nvbio_hip_banded_sw_score", "nvbio_hip_sw_score", "nvbio_hip_alignment_score", "nvbio_hip_alignment_score_qual",
     "nvbio_hip_banded_gotoh_traceback_temp_bytes", "nvbio_hip_banded_gotoh_traceback", "nvbio_hip_banded_gotoh_traceback_qual",
-    "nvbio_hip_gotoh_traceback_temp_bytes", "nvbio_hip_gotoh_traceback", "nvbio_hip_gotoh_traceback_qual", "nvbio_hip_banded_sw_traceback", "nvbio_hip_sw_traceback",
+    "nvbio_hip_gotoh_traceback_temp_bytes", "nvbio_hip_gotoh_traceback", "nvbio_hip_gotoh_traceback_qual", "nvbio_hip_gotoh_traceback_known_score", "nvbio_hip_gotoh_traceback_qual_known_score", "nvbio_hip_banded_sw_traceback", "nvbio_hip_sw_traceback",
     "nvbio_hip_fm_rank", "nvbio_hip_fm_rank4", "nvbio_hip_fm_rank_range",
     "nvbio_hip_fm_match", "nvbio_hip_fm_build_ktab",
     "nvbio_hip_banded_gotoh_score_host", "nvbio_hip_banded_sw_score_host", "nvbio_hip_alignment_score_host",
@@ -99,6 +99,10 @@ def lib():
                                                 vp, vp, vp, vp, u32, vp, vp, u64, vp]
         L.nvbio_hip_gotoh_traceback_qual.argtypes = [P(GotohQualSchemeStruct), i32, P(StringSetStruct), vp, u64, P(StringSetStruct), u32, u32, u32,
                                                      vp, vp, vp, vp, u32, vp, vp, u64, vp]
+        L.nvbio_hip_gotoh_traceback_known_score.argtypes = [P(GotohSchemeStruct), i32, P(StringSetStruct), P(StringSetStruct), vp, u32, u32, u32,
+                                                            vp, vp, vp, vp, u32, vp, vp, u64, vp]
+        L.nvbio_hip_gotoh_traceback_qual_known_score.argtypes = [P(GotohQualSchemeStruct), i32, P(StringSetStruct), vp, u64, P(StringSetStruct), vp, u32, u32, u32,
+                                                                 vp, vp, vp, vp, u32, vp, vp, u64, vp]
         L.nvbio_hip_banded_sw_traceback.argtypes = [P(GotohSchemeStruct), i32, u32, P(StringSetStruct), P(StringSetStruct), u32, u32, u32,
                                                     vp, vp, vp, vp, u32, vp, vp, u64, vp]
         L.nvbio_hip_sw_traceback.argtypes = [P(GotohSchemeStruct), i32, P(StringSetStruct), P(StringSetStruct), u32, u32, u32,

@@ -356,21 +356,27 @@ def best_approx_paired(fmi, rfmi, sym1, sym2, genome_words, genome_len, params=N
         sets = lambda pb, tbeg, tlen: (PackedStringSet(mate_words, 4, True, pb, None, L), PackedStringSet(genome_words, 2, True, tbeg, tlen, 0))
         with _Stage(stats, "traceback"):
             # banded_traceback_best over the anchor slots (every aligned entry)
-            v1, pb, tbeg, tlen = sel.traceback_best_setup(best.data, n, band_len, genome_len, L, n * L, mate_offset, want=0)
-            pat1, txt1 = sets(pb, tbeg, tlen)
-            tb1 = batch_banded_alignment_traceback(band_len, banded_aligner, pat1, txt1, quals=tq, cigar_stride=cigar_stride)
+            with _Stage(stats, "traceback.anchor"):
+                v1, pb, tbeg, tlen = sel.traceback_best_setup(best.data, n, band_len, genome_len, L, n * L, mate_offset, want=0)
+                pat1, txt1 = sets(pb, tbeg, tlen)
+                tb1 = batch_banded_alignment_traceback(band_len, banded_aligner, pat1, txt1, quals=tq, cigar_stride=cigar_stride)
             # the opposite slots: opposite_traceback_best (full matrix over [alignment, alignment + sink)) for the concordant ones,
             # banded_traceback_best for the other aligned ones
             w_o = best_o.data[0]
             concordant = (((w_o >> 30) & 1) != 0) & (((w_o >> 31) & 1) == 0) & best_o.is_aligned(0)
             ids_c = torch.nonzero(concordant).squeeze(1).to(torch.int32)
-            vu, pb, tbeg, tlen = sel.traceback_best_setup(best_o.data, n, band_len, genome_len, L, n * L, mate_offset, want=2)
-            pat_u, txt_u = sets(pb, tbeg, tlen)
-            tb_u = batch_banded_alignment_traceback(band_len, banded_aligner, pat_u, txt_u, quals=tq, cigar_stride=cigar_stride)
+            with _Stage(stats, "traceback.opposite_banded"):
+                vu, pb, tbeg, tlen = sel.traceback_best_setup(best_o.data, n, band_len, genome_len, L, n * L, mate_offset, want=2)
+                pat_u, txt_u = sets(pb, tbeg, tlen)
+                tb_u = batch_banded_alignment_traceback(band_len, banded_aligner, pat_u, txt_u, quals=tq, cigar_stride=cigar_stride)
             if ids_c.numel():
-                vc, pb, tbeg, tlen = sel.traceback_best_setup(best_o.data, n, band_len, genome_len, L, n * L, mate_offset, want=1, idx=ids_c)
-                pat_c, txt_c = sets(pb, tbeg, tlen)
-                tb_c = batch_alignment_traceback(full_aligner, pat_c, txt_c, L, 1024, cigar_stride=cigar_stride, quals=tq)
+                with _Stage(stats, "traceback.opposite_full"):
+                    vc, pb, tbeg, tlen = sel.traceback_best_setup(best_o.data, n, band_len, genome_len, L, n * L, mate_offset, want=1, idx=ids_c)
+                    pat_c, txt_c = sets(pb, tbeg, tlen)
+                    # these windows end at the sink of the opposite-mate scoring pass, whose score the slot holds: the traceback drops
+                    # the rows of the window no alignment with that score can reach
+                    known = sel.traceback_best_known(best_o.data, None, n, idx=ids_c)[0]
+                    tb_c = batch_alignment_traceback(full_aligner, pat_c, txt_c, L, 1024, cigar_stride=cigar_stride, quals=tq, known_score=known)
         if finish:
             out["best_scored"], out["best_o_scored"] = best.data.clone(), best_o.data.clone()
             with _Stage(stats, "finish"):

@@ -265,9 +265,11 @@ def batch_banded_alignment_traceback(band_len, aligner, patterns, texts, max_pat
     return out
 
 
-def batch_alignment_traceback(aligner, patterns, texts, max_pattern_length=0, max_text_length=0, cigar_stride=64, quals=None):
+def batch_alignment_traceback(aligner, patterns, texts, max_pattern_length=0, max_text_length=0, cigar_stride=64, quals=None, known_score=None):
     """BatchedAlignmentTraceback<CHECKPOINTS, stream>::enact (batched.h:432-452) for the full-matrix Gotoh aligner with
-    nvBowtie's backtracer: returns dict(score, sink, source, cigar int16[n,stride], cigar_len) as the banded form does."""
+    nvBowtie's backtracer: returns dict(score, sink, source, cigar int16[n,stride], cigar_len) as the banded form does.
+    known_score (int32[n], Gotoh aligners): the caller knows every job's best score and that its alignment ends at the last text symbol
+    (opposite-mate tracebacks); same results, the unreachable text rows are dropped first (nvbio_hip_gotoh_traceback*_known_score)."""
     n = len(patterns)
     assert len(texts) == n and isinstance(aligner.scheme, (SimpleGotohScheme, SimpleSmithWatermanScheme, SmithWatermanScoringScheme))
     dev = patterns.words.device
@@ -283,10 +285,21 @@ def batch_alignment_traceback(aligner, patterns, texts, max_pattern_length=0, ma
     tail = (int(maxM), int(maxN), n, C.c_void_p(out["score"].data_ptr()), C.c_void_p(out["sink"].data_ptr()), C.c_void_p(out["source"].data_ptr()),
             C.c_void_p(out["cigar"].data_ptr()), cigar_stride, C.c_void_p(out["cigar_len"].data_ptr()),
             C.c_void_p(temp.data_ptr()), temp.numel(), current_stream_ptr())
+    if known_score is not None:
+        assert known_score.dtype == torch.int32 and known_score.numel() == n and known_score.is_contiguous() and not isinstance(aligner, SmithWatermanAligner)
     if isinstance(aligner.scheme, SmithWatermanScoringScheme):
         assert quals is not None and quals.dtype == torch.uint8 and quals.is_cuda and quals.is_contiguous()
-        check(lib().nvbio_hip_gotoh_traceback_qual(C.byref(sc), aligner.type, C.byref(ps), C.c_void_p(quals.data_ptr()), quals.numel(), C.byref(ts), *tail),
-              "nvbio_hip_gotoh_traceback_qual")
+        if known_score is not None:
+            check(lib().nvbio_hip_gotoh_traceback_qual_known_score(C.byref(sc), aligner.type, C.byref(ps), C.c_void_p(quals.data_ptr()), quals.numel(), C.byref(ts),
+                                                                   C.c_void_p(known_score.data_ptr()), *tail), "nvbio_hip_gotoh_traceback_qual_known_score")
+        else:
+            check(lib().nvbio_hip_gotoh_traceback_qual(C.byref(sc), aligner.type, C.byref(ps), C.c_void_p(quals.data_ptr()), quals.numel(), C.byref(ts), *tail),
+                  "nvbio_hip_gotoh_traceback_qual")
+        temp.record_stream(torch.cuda.current_stream())
+        return out
+    if known_score is not None:
+        check(lib().nvbio_hip_gotoh_traceback_known_score(C.byref(sc), aligner.type, C.byref(ps), C.byref(ts), C.c_void_p(known_score.data_ptr()), *tail),
+              "nvbio_hip_gotoh_traceback_known_score")
         temp.record_stream(torch.cuda.current_stream())
         return out
     fn = lib().nvbio_hip_sw_traceback if isinstance(aligner, SmithWatermanAligner) else lib().nvbio_hip_gotoh_traceback

@@ -109,7 +109,7 @@ traceback_best_known_kernel(uint32_t n, const uint32_t* __restrict__ idx, const 
     const bool aligned = a.y != 0xFFFFFFFFu;
     const int32_t m = int32_t((a.x >> 1) & 0x1FFFFu);
     out_score[i] = aligned ? ((a.x & 1u) ? -m : m) : -(1 << 30);
-    out_sink[i]  = aligned ? best_sink[r] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+    if (out_sink) out_sink[i] = aligned ? best_sink[r] : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
 }
 
 // init_alignments_kernel (nvBowtie/bowtie2/cuda/aligner.h:323-346): both slots unaligned (pos -1, ed max) with the
@@ -634,7 +634,7 @@ NVB_API int nvbio_hip_traceback_best_known(uint32_t n, const uint32_t* idx, cons
                                            int32_t* out_score, uint32_t* out_sink, void* stream)
 {
     if (n == 0) return hipSuccess;
-    if (!best_alignments || !best_sink || !out_score || !out_sink) return hipErrorInvalidValue;
+    if (!best_alignments || !out_score || (best_sink == nullptr) != (out_sink == nullptr)) return hipErrorInvalidValue;      // sinks: both or neither
     g_last_kernel = "traceback_best_known_kernel";
     hipLaunchKernelGGL(traceback_best_known_kernel, dim3((n + 255u) / 256u), dim3(256), 0, to_stream(stream), n, idx, reinterpret_cast<const uint2*>(best_alignments),
                        reinterpret_cast<const uint2*>(best_sink), out_score, reinterpret_cast<uint2*>(out_sink));

@@ -368,9 +368,9 @@ def sort_hits(hit_read_id, hit_loc, hit_seed):
 
 def traceback_best_known(best_data, best_sink, n, idx=None):
     """Score and sink of every best alignment as the banded scorer reports them over the traceback's window (kept by the reduction):
-    (score int32[m], sink int32[m, 2]) for batch_banded_alignment_traceback(known=...)."""
+    (score int32[m], sink int32[m, 2]) for batch_banded_alignment_traceback(known=...).  best_sink None: the scores alone (sink None)."""
     m = idx.numel() if idx is not None else n
     dev = best_data.device
-    score = torch.empty(m, dtype=torch.int32, device=dev); sink = torch.empty((m, 2), dtype=torch.int32, device=dev)
+    score = torch.empty(m, dtype=torch.int32, device=dev); sink = torch.empty((m, 2), dtype=torch.int32, device=dev) if best_sink is not None else None
     check(lib().nvbio_hip_traceback_best_known(m, _vp(idx), _vp(best_data), _vp(best_sink), _vp(score), _vp(sink), current_stream_ptr()), "nvbio_hip_traceback_best_known")
     return score, sink

@@ -128,7 +128,18 @@ def test_refusals(cuda):
 
 
 # ---------------------------------------------------------------------------- full-matrix traceback
-def test_full_matrix_cigar_kats_on_gpu(cuda):
+@pytest.fixture(params=["wave", "lanes"])
+def tb_kernel(request, monkeypatch):
+    """Both executions of the full-matrix traceback: one job per wave segment (the default where a job's pattern blocks fit a wave)
+    and one job per lane (NVBIO_HIP_TRACEBACK_LANES=1; what longer patterns get)."""
+    if request.param == "lanes":
+        monkeypatch.setenv("NVBIO_HIP_TRACEBACK_LANES", "1")
+    else:
+        monkeypatch.delenv("NVBIO_HIP_TRACEBACK_LANES", raising=False)
+    return request.param
+
+
+def test_full_matrix_cigar_kats_on_gpu(cuda, tb_kernel):
     """alignment_test.cu:788-792: the full-matrix Gotoh CIGARs"""
     p, t = dna(KAT["strings"]["short_p"]), dna(KAT["strings"]["short_t"])
     hp, ht = O.StringSet.from_lists([p], 4, True), O.StringSet.from_lists([t], 2, False)
@@ -141,7 +152,7 @@ def test_full_matrix_cigar_kats_on_gpu(cuda):
 
 
 @pytest.mark.parametrize("ty", [nvb.GLOBAL, nvb.LOCAL, nvb.SEMI_GLOBAL])
-def test_full_matrix_traceback(cuda, ty):
+def test_full_matrix_traceback(cuda, ty, tb_kernel):
     """random pairs incl. the opposite-mate shape (150 bp in a 650-bp window): score, sink (pattern-blocking order),
     source and CIGAR equal to the oracle's restatement of alignment_traceback"""
     rng = np.random.default_rng(8100 + ty)
@@ -174,7 +185,7 @@ def test_full_matrix_traceback(cuda, ty):
 
 # ---------------------------------------------------------------------------- SW / edit-distance tracebacks
 @pytest.mark.parametrize("ty", [nvb.GLOBAL, nvb.LOCAL, nvb.SEMI_GLOBAL])
-def test_sw_and_ed_tracebacks(cuda, ty):
+def test_sw_and_ed_tracebacks(cuda, ty, tb_kernel):
     """SmithWatermanAligner / EditDistanceAligner tracebacks, banded (incl. the reference's LOCAL walk that never stops at a zero
     cell) and full matrix (sink of the 16-column pattern-blocking pass), vs the oracle's restatement of sw_banded_inl.h / sw_inl.h;
     and the reference's three full-matrix SW CIGAR literals (alignment_test.cu:776-780)."""
@@ -213,7 +224,7 @@ def test_sw_and_ed_tracebacks(cuda, ty):
 
 
 @pytest.mark.parametrize("ty", [nvb.LOCAL, nvb.SEMI_GLOBAL, nvb.GLOBAL])
-def test_full_matrix_traceback_quality_aware(cuda, ty):
+def test_full_matrix_traceback_quality_aware(cuda, ty, tb_kernel):
     """nvBowtie's opposite-mate traceback: quality-aware scheme over the full matrix (asymmetric gap costs included)"""
     rng = np.random.default_rng(8500 + ty)
     pats, txts = [], []
@@ -291,7 +302,7 @@ def test_ungapped_alignments_every_band_offset(cuda, band, ty):
             compare(exp, got, (band, ty, "qual"))
 
 
-def test_full_matrix_traceback_on_tie_heavy_batches(cuda):
+def test_full_matrix_traceback_on_tie_heavy_batches(cuda, tb_kernel):
     """Binary-alphabet texts (many equal-scoring placements): the traceback -- whose ungapped jobs take their sink from the pattern-blocking
     score kernel -- still equals the oracle's job by job, and score kernel and traceback agree on every sink."""
     rng = np.random.default_rng(8700)
@@ -320,7 +331,7 @@ def test_full_matrix_traceback_on_tie_heavy_batches(cuda):
             assert torch.equal(s, got["score"]) and torch.equal(k, got["sink"])
 
 
-def test_full_matrix_traceback_long_left_context(cuda):
+def test_full_matrix_traceback_long_left_context(cuda, tb_kernel):
     """The opposite-mate shape at its extreme: the alignment ends at the end of a text several times the read (the queued, gapped jobs
     drop the text columns no alignment with their score can reach).  Gapped reads, tandem-repeat texts (equal-scoring paths that
     slide along the repeat and long gap runs are common there), cheap and expensive gaps, both types, with and without qualities."""
@@ -367,3 +378,94 @@ def test_full_matrix_traceback_long_left_context(cuda):
         got = nvb.batch_alignment_traceback(nvb.make_gotoh_aligner(ty, scheme), dp, dt, 150, 650, cigar_stride=64, quals=torch.from_numpy(quals).to(cuda))
         torch.cuda.synchronize()
         compare(exp, got, (ty, "qual", "left context"))
+
+
+@pytest.mark.parametrize("ty", [nvb.GLOBAL, nvb.LOCAL, nvb.SEMI_GLOBAL])
+def test_full_matrix_traceback_block_counts(cuda, ty):
+    """Patterns from 1 symbol to 700: every lanes-per-job width of the wave kernel (1 ... 64 blocks, several jobs per wave and one),
+    and past 512 symbols (Gotoh) the one-job-per-lane kernel; Gotoh (8-symbol blocks) and SW (16-symbol blocks)."""
+    rng = np.random.default_rng(9100 + ty)
+    for maxM, n in ((7, 200), (16, 200), (33, 150), (100, 120), (257, 60), (512, 40), (700, 24)):
+        pats, txts = [], []
+        for i in range(n):
+            M = maxM if i % 3 == 0 else int(rng.integers(1, maxM + 1))
+            N = int(rng.integers(max(1, M // 2), M + 120))
+            t = rng.integers(0, 4, N).astype(np.uint8)
+            p = np.resize(t[int(rng.integers(0, max(1, N - M))):], M).copy()
+            mut = rng.random(M) < 0.05
+            p[mut] = rng.integers(0, 4, int(mut.sum()))
+            if M > 20 and i % 2:
+                c = int(rng.integers(3, M - 8)); p = np.concatenate([p[:c], p[c + 4:], rng.integers(0, 4, 4).astype(np.uint8)])
+            pats.append(p.astype(np.uint8)); txts.append(t)
+        hp, ht = O.StringSet.from_lists(pats, 4, True), O.StringSet.from_lists(txts + [np.zeros(64, np.uint8)], 2, True)
+        ht = O.StringSet(ht.words, 2, True, ht.begin[:-1], ht.length[:-1])
+        dp, dt = to_dev(hp, cuda), to_dev(ht, cuda)
+        maxN = int(ht.length.max())
+        stride = 96
+        exp = O.batch_gotoh_traceback(ty, (2, -3, -5, -2), hp, ht, stride)
+        got = nvb.batch_alignment_traceback(nvb.make_gotoh_aligner(ty, nvb.SimpleGotohScheme(2, -3, -5, -2)), dp, dt, maxM, maxN, cigar_stride=stride)
+        torch.cuda.synchronize()
+        compare(exp, got, (ty, maxM, "gotoh"))
+        exp = O.batch_sw_traceback(0, ty, (2, -1, -1, -1), hp, ht, stride)
+        got = nvb.batch_alignment_traceback(nvb.make_smith_waterman_aligner(ty, nvb.SimpleSmithWatermanScheme(2, -1, -1, -1)), dp, dt, maxM, maxN, cigar_stride=stride)
+        torch.cuda.synchronize()
+        compare(exp, got, (ty, maxM, "sw"))
+
+
+@pytest.mark.parametrize("ty", [nvb.LOCAL, nvb.SEMI_GLOBAL])
+def test_full_matrix_traceback_known_score_windows(cuda, ty, tb_kernel):
+    """nvBowtie's opposite-mate traceback windows: [window begin, sink of the scoring pass), the score known.  The _known_score forms
+    (which drop the text rows no alignment of that score can reach before any DP runs) must return what the plain traceback -- and the
+    oracle -- return over the whole window: gapped reads at the far end of windows several reads long, repeats, with and without
+    qualities."""
+    rng = np.random.default_rng(9300 + ty)
+    pats, txts = [], []
+    for i in range(1200):
+        M = int(rng.integers(30, 151)); N = int(rng.integers(max(M + 40, 200), 651))
+        if i % 3 == 0:
+            unit = rng.integers(0, 4, int(rng.integers(1, 7)), dtype=np.uint8)
+            t = np.resize(unit, N).copy()
+            t[rng.integers(0, N, N // 25)] = rng.integers(0, 4, N // 25)
+        else:
+            t = rng.integers(0, 4, N, dtype=np.uint8)
+        o = int(rng.integers(0, N - M))
+        p = t[o:o + M + 3].copy()
+        for j in rng.integers(0, p.size, int(rng.integers(0, 6))):
+            p[j] = (p[j] + 1 + rng.integers(0, 3)) & 3
+        k = i % 4
+        if k == 1:
+            c = int(rng.integers(5, p.size - 5)); p = np.delete(p, slice(c, c + int(rng.integers(1, 9))))
+        elif k == 2:
+            c = int(rng.integers(5, p.size - 5)); p = np.insert(p, c, rng.integers(0, 4, int(rng.integers(1, 6))))
+        pats.append(p[:150].astype(np.uint8)); txts.append(t)
+    hp, ht = O.StringSet.from_lists(pats, 4, True), O.StringSet.from_lists(txts + [np.zeros(64, np.uint8)], 2, True)
+    ht = O.StringSet(ht.words, 2, True, ht.begin[:-1], ht.length[:-1])
+    quals = rng.integers(0, 60, int(hp.begin[-1] + hp.length[-1]) + 3, dtype=np.uint8)
+    dq = torch.from_numpy(quals).to(cuda)
+    checked = cropped = 0
+    for scheme in ((2, -6, -8, -3), (1, -2, -1, -1), "qual"):
+        if scheme == "qual":
+            sch = nvb.SmithWatermanScoringScheme.local() if ty == nvb.LOCAL else nvb.SmithWatermanScoringScheme()
+            st = sch.struct()
+            lut = np.array([st.mismatch[q] for q in range(256)], dtype=np.int32)
+            okw = dict(lut=lut, quals=quals, s=(st.match, st.pattern_gap_open, st.pattern_gap_ext, st.text_gap_open, st.text_gap_ext))
+            al, kw = nvb.make_gotoh_aligner(ty, sch), dict(quals=dq)
+            first = O.batch_gotoh_traceback(ty, okw["s"], hp, ht, 64, lut, quals)
+        else:
+            al, kw = nvb.make_gotoh_aligner(ty, nvb.SimpleGotohScheme(*scheme)), {}
+            first = O.batch_gotoh_traceback(ty, scheme, hp, ht, 64)
+        # the scoring pass's verdict: windows end at its sinks
+        ok = first["sink"][:, 0].view(np.int32) > 0
+        keep = np.nonzero(ok)[0]
+        wl = first["sink"][keep, 0].astype(np.uint32)
+        sub_p = O.StringSet(hp.words, 4, True, hp.begin[keep], hp.length[keep])
+        sub_t = O.StringSet(ht.words, 2, True, ht.begin[keep], wl)
+        exp = O.batch_gotoh_traceback(ty, okw["s"], sub_p, sub_t, 64, lut, quals) if scheme == "qual" else O.batch_gotoh_traceback(ty, scheme, sub_p, sub_t, 64)
+        assert (exp["score"] == first["score"][keep]).all() and (exp["sink"][:, 0] == wl).all()        # the premise
+        known = torch.from_numpy(first["score"][keep].astype(np.int32)).to(cuda)
+        got = nvb.batch_alignment_traceback(al, to_dev(sub_p, cuda), to_dev(sub_t, cuda), 150, 650, cigar_stride=64, known_score=known, **kw)
+        torch.cuda.synchronize()
+        compare(exp, got, (ty, scheme, "known score"))
+        checked += keep.size
+        cropped += int((wl > sub_p.length + 40).sum())
+    assert checked > 2500 and cropped > 1000
