@@ -649,7 +649,23 @@ static int full_score_core(
     const int64_t span = (type == NVBIO_HIP_GLOBAL) ? int64_t(maxM) + maxN + 4 : int64_t(maxM) + 4;
     // the 16-bit sweep's sentinel and range reasoning assume that no gap move earns score, on either string
     const bool gaps_cost = scheme->gap_open <= 0 && scheme->gap_ext <= 0 && (!qual || (qual->text_gap_open <= 0 && qual->text_gap_ext <= 0));
-    const bool trunc = !(gaps_cost && span * A < 30000);
+    bool trunc = !(gaps_cost && span * A < 30000);
+    if (trunc && gaps_cost && type == NVBIO_HIP_GLOBAL)
+    {
+        // GLOBAL, tighter: (M + N) * max|cost| overestimates badly when the expensive costs are not the gap extensions.  What the sweep
+        // holds: the two boundary lines themselves, H(r,-1) = col_go + col_ge*r and H(-1,c) = row_go + row_ge*c; interior H, each at
+        // least the value of reaching it by one gap run from either boundary line (H is a maximum over paths, those paths included) and
+        // at most M times the best pair score; E, F, H + G_o and the diagonal sum within one gap open + one extension + one substitution
+        // of an H.  All inside int16 => the 16-bit sweep and the reference's int16 boundary column are both exact.
+        const int64_t row_line = iabs(p.row_go) + iabs(p.row_ge) * int64_t(maxN), col_line = iabs(p.col_go) + iabs(p.col_ge) * int64_t(maxM);
+        const int64_t via_top  = row_line + iabs(scheme->gap_open) + iabs(scheme->gap_ext) * int64_t(maxM);
+        const int64_t via_left = col_line + iabs(scheme->gap_open) + iabs(scheme->gap_ext) * int64_t(maxN);
+        int64_t worst_sub = std::max(iabs(scheme->match), iabs(scheme->mismatch));
+        if (qual) for (int i = 0; i < 256; ++i) worst_sub = std::max(worst_sub, iabs(qual->mismatch[i]));
+        const int64_t low  = std::max(std::max(row_line, col_line), std::min(via_top, via_left)) + iabs(scheme->gap_open) + iabs(scheme->gap_ext) + worst_sub + 8;
+        const int64_t high = int64_t(maxM) * std::max<int64_t>(0, std::max(scheme->match, scheme->mismatch)) + worst_sub + 8;
+        if (low < 32000 && high < 32000) trunc = false;
+    }
     // the largest score one aligned pair can add: LOCAL's H is bounded by M times it, not by M * match
     int32_t best_pair = std::max(scheme->match, scheme->mismatch);
     if (qual) for (int i = 0; i < 256; ++i) best_pair = std::max(best_pair, qual->mismatch[i]);

@@ -103,6 +103,33 @@ def test_int16_boundary_column_truncation(cuda, ty):
     run(ty, (2, -1, -2, -1), pats, txts, cuda, maxM=100, maxN=40000)     # bound unknown -> TRUNC variant, same results
 
 
+def test_global_long_texts_on_the_16bit_sweep(cuda):
+    """GLOBAL against texts of thousands of symbols (sw-benchmark's shape: 150 x 16384): (M + N) * max|cost| exceeds int16 there, but
+    the values the sweep holds do not when the expensive costs are not the gap extensions -- the host's tighter proof puts these
+    batches on the 16-bit sweep (checked through nvbio_hip_last_kernel), up to where the boundary row itself nears -32000."""
+    from nvbio_amd._lib import lib
+    rng = np.random.default_rng(611)
+    for maxN, scheme, sweep16 in ((16384, (2, -1, -2, -1), True), (16384, (1, -3, -5, -1), True), (31000, (2, -1, -2, -1), True),
+                                  (16384, (2, -3, -5, -2), False), (33000, (2, -1, -2, -1), False)):
+        pats, txts = [], []
+        for i in range(48):
+            M = int(rng.integers(1, 151)) if i % 3 else 150
+            N = maxN if i % 4 == 0 else int(rng.integers(1, maxN + 1))
+            t = rng.integers(0, 4, N, dtype=np.uint8)
+            o = int(rng.integers(0, max(1, N - M)))
+            pp = np.resize(t[o:o + M], M).copy()
+            mut = rng.random(M) < 0.08
+            pp[mut] = rng.integers(0, 5, int(mut.sum()), dtype=np.uint8)
+            pats.append(pp); txts.append(t)
+        run(nvb.GLOBAL, scheme, pats, txts, cuda, maxM=150, maxN=maxN)
+        hp, ht = O.StringSet.from_lists(pats, 4, True), O.StringSet.from_lists(txts, 2, False)
+        p = nvb.PackedStringSet.from_host(hp.words, 4, True, hp.begin, hp.length, device=cuda)
+        t = nvb.PackedStringSet.from_host(ht.words, 2, False, ht.begin, ht.length, device=cuda)
+        nvb.batch_alignment_score(nvb.make_gotoh_aligner(nvb.GLOBAL, nvb.SimpleGotohScheme(*scheme)), p, t, 150, maxN, None)
+        torch.cuda.synchronize()
+        assert (b"16-bit" in lib().nvbio_hip_last_kernel()) == sweep16, (maxN, scheme, lib().nvbio_hip_last_kernel())
+
+
 def test_packings(cuda):
     rng = np.random.default_rng(9)
     pats, txts = make_pairs(rng, 400, 90, 200)
