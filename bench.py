@@ -725,6 +725,15 @@ def seed_leg(a, dev, fmi, text, build_s):
     bytes_per_loc = 32.0 * steps / mr + 4 + 8
     mgbs = a.seeds * bytes_per_seed / (match_ms * 1e-3) / 1e9
     lgbs = rows.numel() * bytes_per_loc / (locate_ms * 1e-3) / 1e9
+    # counter traffic of the line-native kernels: fabric requests per unit from the committed PMC pass x this launch's units
+    rq = measured_counter("fm_match_kernel<line_native>", "rdreq_128B_per_seed")
+    if rq is not None:
+        line_native["match"]["traffic"] = int(a.seeds * (rq * 128 + 8))
+        line_native["match"]["traffic_over_algorithmic"] = (rq * 128 + 8) / bytes_per_seed
+    rq = measured_counter("fm_locate_kernel<line_native>", "rdreq_128B_per_row")
+    if rq is not None:
+        line_native["locate"]["traffic"] = int(rows.numel() * (rq * 128 + 4))
+        line_native["locate"]["traffic_over_algorithmic"] = (rq * 128 + 4) / bytes_per_loc
     # the line-native figures priced in the SAME algorithmic bytes (what the reference's walk would touch): the index does the
     # job in fewer, fuller lines, so the fraction says how close the seeding stage is to what 8 TB/s could do for that walk
     for leg, nunits, bpu in (("match", a.seeds, bytes_per_seed), ("locate", rows.numel(), bytes_per_loc)):

@@ -92,7 +92,7 @@ int nvbio_hip_banded_gotoh_score(
  * texts[i] exactly as priv::gotoh_alignment_score_dispatch<8,TYPE,TextBlockingTag,.>::run
  * (nvbio/alignment/gotoh/gotoh_inl.h:969-1489) does into a fresh BestSink, including its int16
  * boundary column, its tie order and its early exit against min_score[i] (NULL = never).
- * out_ok (nullable) receives that function's bool (0 = early-exited).  Patterns up to 512 symbols
+ * out_ok (nullable) receives that function's bool (0 = early-exited).  Patterns up to 1024 symbols
  * (max_pattern_len / max_text_len are required for ragged sets: they select the register layout). */
 int nvbio_hip_gotoh_score(
     const nvbio_hip_gotoh_scheme* scheme /* host */, int32_t type,

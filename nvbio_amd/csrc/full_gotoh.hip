@@ -624,8 +624,8 @@ static int full_score_core(
     // the systolic mapping holds the whole pattern in one wave's registers: the caller states its bound
     const uint32_t maxM = patterns->length ? max_pattern_len : patterns->fixed_length;
     const uint32_t maxN = texts->length ? max_text_len : texts->fixed_length;
-    if (maxM == 0 || maxM > 512u) return hipErrorNotSupported;
-    if (maxN == 0 || uint64_t(maxN) * 64u * 8u >= (1ull << 32)) return hipErrorNotSupported;    // LOCAL order keys are 32-bit
+    if (maxM == 0 || maxM > 1024u) return hipErrorNotSupported;        // 64 lanes x 16 rows
+    if (maxN == 0 || uint64_t(maxN) * 64u * (maxM <= 512u ? 8u : 16u) >= (1ull << 32)) return hipErrorNotSupported;    // LOCAL order keys are 32-bit
 
     FullParams p;
     p.pat = make_string_set(patterns); p.txt = make_string_set(texts);
@@ -671,7 +671,7 @@ static int full_score_core(
     if (qual) for (int i = 0; i < 256; ++i) best_pair = std::max(best_pair, qual->mismatch[i]);
     hipStream_t s = to_stream(stream);
     g_last_kernel = "full_gotoh_score_kernel";
-    const int R = maxM <= 64u ? 1 : maxM <= 128u ? 2 : maxM <= 192u ? 3 : maxM <= 256u ? 4 : 8;
+    const int R = maxM <= 64u ? 1 : maxM <= 128u ? 2 : maxM <= 192u ? 3 : maxM <= 256u ? 4 : maxM <= 512u ? 8 : 16;
     // the 16-bit sweep needs: values inside int16 (= !trunc), LOCAL scores < 2048 and columns < 2^20 for its packed row maxima
     const char* nofast = getenv("NVBIO_HIP_FULL_GENERIC");
     const bool fast = !trunc && maxN < (1u << 20) && (type != NVBIO_HIP_LOCAL || (scheme->match >= 0 && int64_t(maxM) * best_pair < 2048))
@@ -680,7 +680,8 @@ static int full_score_core(
         g_last_kernel = "full_gotoh_score_kernel<16-bit>";
         switch (R) { case 1: return launch_full<1, false, true>(p, type, s); case 2: return launch_full<2, false, true>(p, type, s);
                      case 3: return launch_full<3, false, true>(p, type, s); case 4: return launch_full<4, false, true>(p, type, s);
-                     default: return launch_full<8, false, true>(p, type, s); }
+                     case 8: return launch_full<8, false, true>(p, type, s);
+                     default: return launch_full<16, false, true>(p, type, s); }
     }
     if (trunc && blk_log2 != 3u) return hipErrorNotSupported;     // the int16 boundary column of the SW form is not modelled beyond its exact range
     if (pattern_blocking && !fast) return hipErrorNotSupported;   // pattern blocking is implemented on the 16-bit sweep only
@@ -688,11 +689,13 @@ static int full_score_core(
     if (trunc) {
         switch (R) { case 1: return launch_full<1, true, false>(p, type, s); case 2: return launch_full<2, true, false>(p, type, s);
                      case 3: return launch_full<3, true, false>(p, type, s); case 4: return launch_full<4, true, false>(p, type, s);
-                     default: return launch_full<8, true, false>(p, type, s); }
+                     case 8: return launch_full<8, true, false>(p, type, s);
+                     default: return launch_full<16, true, false>(p, type, s); }
     } else {
         switch (R) { case 1: return launch_full<1, false, false>(p, type, s); case 2: return launch_full<2, false, false>(p, type, s);
                      case 3: return launch_full<3, false, false>(p, type, s); case 4: return launch_full<4, false, false>(p, type, s);
-                     default: return launch_full<8, false, false>(p, type, s); }
+                     case 8: return launch_full<8, false, false>(p, type, s);
+                     default: return launch_full<16, false, false>(p, type, s); }
     }
 }
 
