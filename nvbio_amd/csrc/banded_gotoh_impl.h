@@ -52,11 +52,17 @@ struct A32 {
     static __device__ __forceinline__ int32_t to_int(T a)      { return a; }
     static __device__ __forceinline__ uint32_t bits(T a)       { return uint32_t(a); }
     static __device__ __forceinline__ T   min_value()          { return INT_MIN; }
+    // how text / pattern symbols are held for the substitution test: as they are
+    static constexpr bool TABLE = false;
+    static __device__ __forceinline__ uint32_t enc(uint32_t g)      { return g; }
+    static __device__ __forceinline__ uint32_t enc_none()           { return 255u; }
+    static __device__ __forceinline__ T subst(uint32_t, uint32_t, uint32_t) { return 0; }
 
     // one interior band cell (gotoh_banded_inl.h:520-577): F, H, E and (LOCAL) the row's sink key
-    template <int TYPE, int J>
+    template <int TYPE, int J, bool FAST>
     static __device__ __forceinline__ void cell(T& Fj, const T Fnext, const T HGnext, T& HGj, T& E, T& rowkey,
-                                                const uint32_t g, const uint32_t q, const T Go, const T Ge, const T sM, const T sX)
+                                                const uint32_t g, const uint32_t q, const T Go, const T Ge, const T sM, const T sX,
+                                                const uint32_t, const uint32_t)
     {
         Fj = max(Fnext + Ge, HGnext);
         const T diag = HGj + (g == q ? sM : sX);
@@ -76,16 +82,54 @@ struct A16 {
     static __device__ __forceinline__ T cnst(int32_t v)    { return uint32_t(v) & 0xFFFFu; }
     static __device__ __forceinline__ int32_t to_int(T a)  { return int32_t(int16_t(a & 0xFFFFu)); }
     static __device__ __forceinline__ uint32_t bits(T a)   { return a & 0xFFFFu; }
+    // The substitution score without a compare.  v_cmp + v_cndmask cost 6.6 issue cycles of a cell's 32 (VOPC runs at the 32-bit
+    // rate, profiles/r02/valu_probe.txt); one v_perm_b32 costs 4.3 and needs no VCC.  A symbol is held as the byte selector that
+    // picks ITS 16-bit entry out of an 8-byte table: 0x0C0C0100 + 0x0202 * g = {byte 2g, byte 2g+1, zero, zero}; the row's table
+    // {lo, hi} holds entry v = (v == q ? sM : sX), built once per row for the band's cells.  A symbol past the end of the text (the
+    // reference's 255, equal to nothing) has no entry: it is held as 0x0C0C0C0C, and a block of rows that can see one runs the
+    // compare form below on the same selectors (pattern symbols encoded alike; N codes 4..15 give selectors no text symbol has).
+    static constexpr bool TABLE = true;
+    static __device__ __forceinline__ uint32_t enc(uint32_t g)      { uint32_t r; asm("v_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(g), "v"(0x0202u)); return r | 0x0C0C0100u; }
+    static __device__ __forceinline__ uint32_t enc_none()           { return 0x0C0C0C0Cu; }
+    static __device__ __forceinline__ T subst(uint32_t tlo, uint32_t thi, uint32_t sel) { return __builtin_amdgcn_perm(thi, tlo, sel); }
 
     // The same cell as one hand-scheduled instruction block: 2-cycle 16-bit VOP2 ops only (plus the
     // compare/select of the substitution score), ordered so that the serial E -> H -> HG -> E chain
     // (5 ops) is interleaved with the independent F / diagonal / key work.
-    template <int TYPE, int J>
+    template <int TYPE, int J, bool FAST>
     static __device__ __forceinline__ void cell(T& Fj, const T Fnext, const T HGnext, T& HGj, T& E, T& rowkey,
-                                                const uint32_t g, const uint32_t q, const T Go, const T Ge, const T sM, const T sX)
+                                                const uint32_t g, const uint32_t q, const T Go, const T Ge, const T sM, const T sX,
+                                                const uint32_t tlo, const uint32_t thi)
     {
         T d, h, e2;
-        if (TYPE == NVBIO_HIP_LOCAL)
+        if (FAST && TYPE == NVBIO_HIP_LOCAL)
+            asm("v_perm_b32 %[d], %[thi], %[tlo], %[g]\n\t"
+                "v_add_u16 %[f], %[fn], %[ge]\n\t"
+                "v_max_i16 %[f], %[f], %[hgn]\n\t"
+                "v_add_u16 %[d], %[hg], %[d]\n\t"
+                "v_max_i16 %[h], %[f], %[e]\n\t"
+                "v_add_u16 %[e2], %[e], %[ge]\n\t"
+                "v_max_i16 %[h], %[h], %[d]\n\t"
+                "v_max_i16 %[h], 0, %[h]\n\t"
+                "v_add_u16 %[hg], %[h], %[go]\n\t"
+                "v_add_u16 %[d], %[sj], %[h]\n\t"
+                "v_max_i16 %[e], %[e2], %[hg]\n\t"
+                "v_max_i16 %[rk], %[rk], %[d]"
+                : [f] "=&v"(Fj), [d] "=&v"(d), [h] "=&v"(h), [e2] "=&v"(e2), [hg] "+v"(HGj), [e] "+v"(E), [rk] "+v"(rowkey)
+                : [g] "v"(g), [tlo] "v"(tlo), [thi] "v"(thi), [fn] "v"(Fnext), [ge] "v"(Ge), [hgn] "v"(HGnext), [go] "v"(Go), [sj] "s"(J));
+        else if (FAST)
+            asm("v_perm_b32 %[d], %[thi], %[tlo], %[g]\n\t"
+                "v_add_u16 %[f], %[fn], %[ge]\n\t"
+                "v_max_i16 %[f], %[f], %[hgn]\n\t"
+                "v_add_u16 %[d], %[hg], %[d]\n\t"
+                "v_max_i16 %[h], %[f], %[e]\n\t"
+                "v_add_u16 %[e2], %[e], %[ge]\n\t"
+                "v_max_i16 %[h], %[h], %[d]\n\t"
+                "v_add_u16 %[hg], %[h], %[go]\n\t"
+                "v_max_i16 %[e], %[e2], %[hg]"
+                : [f] "=&v"(Fj), [d] "=&v"(d), [h] "=&v"(h), [e2] "=&v"(e2), [hg] "+v"(HGj), [e] "+v"(E)
+                : [g] "v"(g), [tlo] "v"(tlo), [thi] "v"(thi), [fn] "v"(Fnext), [ge] "v"(Ge), [hgn] "v"(HGnext), [go] "v"(Go));
+        else if (TYPE == NVBIO_HIP_LOCAL)
             asm("v_cmp_eq_u32 vcc, %[g], %[q]\n\t"
                 "v_add_u16 %[f], %[fn], %[ge]\n\t"
                 "v_cndmask_b32 %[d], %[sx], %[sm], vcc\n\t"
@@ -132,30 +176,35 @@ struct DPState {
 template <typename A>
 struct DPConsts {
     typename A::T Go, Ge, sM, sX, inf;       // sM/sX = match/mismatch - G_o ; inf = the infimum sentinel
+    uint32_t sMM, sXX;                       // table arithmetic: sM / sX in both halves of a dword
 };
 
-template <int BAND, int TYPE, typename A, int R, int J, int END>
+template <int BAND, int TYPE, typename A, bool FAST, int R, int J, int END>
 struct CellLoop {
     __device__ __forceinline__ static void run(DPState<BAND, A>& st, const DPConsts<A>& k, const typename A::T sX,
-                                               typename A::T& E, typename A::T& rowkey, const uint32_t q)
+                                               typename A::T& E, typename A::T& rowkey, const uint32_t q, const uint32_t tlo, const uint32_t thi)
     {
         typedef BandTraits<BAND> BT;
         typedef typename A::T T;
         const uint32_t g = st.tc[BT::RING ? ((R + J) & 15) : J];
         if (!BT::RING) st.tc[J - 1] = g;                                   // :542
         const T fnext = (J + 1 == BAND - 1) ? k.inf : st.F[J + 1 < BAND - 1 ? J + 1 : 0];
-        A::template cell<TYPE, J>(st.F[J], fnext, st.HG[J + 1], st.HG[J], E, rowkey, g, q, k.Go, k.Ge, k.sM, sX);
-        CellLoop<BAND, TYPE, A, R, J + 1, END>::run(st, k, sX, E, rowkey, q);
+        A::template cell<TYPE, J, FAST>(st.F[J], fnext, st.HG[J + 1], st.HG[J], E, rowkey, g, q, k.Go, k.Ge, k.sM, sX, tlo, thi);
+        CellLoop<BAND, TYPE, A, FAST, R, J + 1, END>::run(st, k, sX, E, rowkey, q, tlo, thi);
     }
 };
-template <int BAND, int TYPE, typename A, int R, int END>
-struct CellLoop<BAND, TYPE, A, R, END, END> {
-    __device__ __forceinline__ static void run(DPState<BAND, A>&, const DPConsts<A>&, const typename A::T, typename A::T&, typename A::T&, const uint32_t) {}
+template <int BAND, int TYPE, typename A, bool FAST, int R, int END>
+struct CellLoop<BAND, TYPE, A, FAST, R, END, END> {
+    __device__ __forceinline__ static void run(DPState<BAND, A>&, const DPConsts<A>&, const typename A::T, typename A::T&, typename A::T&, const uint32_t,
+                                               const uint32_t, const uint32_t) {}
 };
 
-template <int BAND, int TYPE, typename A, int R>
+// q, g_new, g_store and the cached symbols are in A's encoding (A::enc); FAST rows take substitution scores from the row's table
+// {tlo, thi} and must not see a symbol past the text's end; g_store is what later rows read back for the entering symbol.
+template <int BAND, int TYPE, typename A, bool FAST, int R>
 __device__ __forceinline__ void dp_row(DPState<BAND, A>& st, const DPConsts<A>& k, const typename A::T sX,
-                                       const uint32_t i, const uint32_t q, const uint32_t g_new)
+                                       const uint32_t i, const uint32_t q, const uint32_t g_new, const uint32_t g_store,
+                                       const uint32_t tlo, const uint32_t thi)
 {
     typedef BandTraits<BAND> BT;
     typedef typename A::T T;
@@ -167,7 +216,7 @@ __device__ __forceinline__ void dp_row(DPState<BAND, A>& st, const DPConsts<A>& 
         const T fnext = A::add((1 == BAND - 1) ? k.inf : st.F[1 < BAND - 1 ? 1 : 0], k.Ge);
         st.F[0] = A::mx(fnext, st.HG[1]);
         const uint32_t g = st.tc[BT::RING ? (R & 15) : 0];
-        const T diag = A::add(st.HG[0], g == q ? k.sM : sX);
+        const T diag = A::add(st.HG[0], FAST ? A::subst(tlo, thi, g) : (g == q ? k.sM : sX));
         T hi = A::mx(st.F[0], diag);
         if (TYPE == NVBIO_HIP_LOCAL) { hi = A::clamp0(hi); rowkey = hi; }
         st.HG[0] = A::add(hi, k.Go);
@@ -179,7 +228,7 @@ __device__ __forceinline__ void dp_row(DPState<BAND, A>& st, const DPConsts<A>& 
         // wide bands: compile-time recursion over the cells.  (A `#pragma unroll` loop whose body is a 29-way switch of
         // asm blocks is not unrolled by the compiler at this size; the band state would then be indexed dynamically and
         // live in scratch memory.)
-        CellLoop<BAND, TYPE, A, R, 1, BAND - 1>::run(st, k, sX, E, rowkey, q);
+        CellLoop<BAND, TYPE, A, FAST, R, 1, BAND - 1>::run(st, k, sX, E, rowkey, q, tlo, thi);
     }
     else
     {
@@ -191,7 +240,7 @@ __device__ __forceinline__ void dp_row(DPState<BAND, A>& st, const DPConsts<A>& 
         // F[BAND-1] is `infimum` at every row (:586), so the cell next to the band edge sees it as F[j+1]
         const T fnext = (j + 1 == BAND - 1) ? k.inf : st.F[j + 1 < BAND - 1 ? j + 1 : 0];
         switch (j) {   // the sink key's column is an instruction constant
-            #define NVB_CELL(J) case J: A::template cell<TYPE, J>(st.F[j], fnext, st.HG[j + 1], st.HG[j], E, rowkey, g, q, k.Go, k.Ge, k.sM, sX); break;
+            #define NVB_CELL(J) case J: A::template cell<TYPE, J, FAST>(st.F[j], fnext, st.HG[j + 1], st.HG[j], E, rowkey, g, q, k.Go, k.Ge, k.sM, sX, tlo, thi); break;
             NVB_CELL(1) NVB_CELL(2) NVB_CELL(3) NVB_CELL(4) NVB_CELL(5) NVB_CELL(6) NVB_CELL(7) NVB_CELL(8) NVB_CELL(9) NVB_CELL(10)
             NVB_CELL(11) NVB_CELL(12) NVB_CELL(13) NVB_CELL(14)
             #undef NVB_CELL
@@ -201,13 +250,12 @@ __device__ __forceinline__ void dp_row(DPState<BAND, A>& st, const DPConsts<A>& 
     }
     // the new text symbol enters the band (:580-581); the cached copy is what later rows see
     {
-        const uint32_t stored = BT::QUIRK ? (g_new & 3u) : g_new;
-        if (BT::RING) st.tc[(R + BAND - 1) & 15] = stored;
-        else          st.tc[BAND - 2] = stored;
+        if (BT::RING) st.tc[(R + BAND - 1) & 15] = g_store;
+        else          st.tc[BAND - 2] = g_store;
     }
     // j == BAND-1  (:584-614) -- compares against the raw symbol
     {
-        const T diag = A::add(st.HG[BAND - 1], g_new == q ? k.sM : sX);
+        const T diag = A::add(st.HG[BAND - 1], FAST ? A::subst(tlo, thi, g_new) : (g_new == q ? k.sM : sX));
         T hi = A::mx(E, diag);
         if (TYPE == NVBIO_HIP_LOCAL) { hi = A::clamp0(hi); rowkey = A::mx(rowkey, A::template key<BAND - 1>(hi)); }
         st.HG[BAND - 1] = A::add(hi, k.Go);
@@ -223,31 +271,44 @@ __device__ __forceinline__ void dp_row(DPState<BAND, A>& st, const DPConsts<A>& 
     }
 }
 
-template <int BAND, int TYPE, typename A, bool QUAL, int R, int END>
+// FAST (table arithmetic only): the caller has checked that no row of this block lets a symbol past the text's end into the band
+template <int BAND, int TYPE, typename A, bool QUAL, bool FAST, int R, int END>
 struct RowUnrollN {
     __device__ __forceinline__ static void run(DPState<BAND, A>& st, const DPConsts<A>& k,
         const uint32_t i0, const uint32_t M, const uint32_t N, const uint64_t P, const uint32_t T,
-        const uint4 Q, const typename A::T* lut)
+        const uint4 Q, const typename A::T* lut, const uint2* masks)
     {
+        typedef BandTraits<BAND> BT;
         const uint32_t i = i0 + R;
         if (i < M)
         {
-            const uint32_t q = uint32_t(P >> (4 * R)) & 15u;
-            uint32_t g = (T >> (2 * R)) & 3u;
-            if (i + BAND - 1 >= N) g = 255u;
+            const uint32_t qr = uint32_t(P >> (4 * R)) & 15u;
+            const uint32_t gr = (T >> (2 * R)) & 3u;
+            const bool past = !FAST && (i + BAND - 1 >= N);
+            // the entering symbol as this row compares it, and as later rows read it back from the reference's text cache
+            const uint32_t g       = past ? A::enc_none() : A::enc(gr);
+            const uint32_t g_store = past ? (BT::QUIRK ? A::enc(3u) : A::enc_none()) : g;        // the 2-bit cache keeps 255 & 3
             typename A::T sX = k.sX;
             if (QUAL) {
                 const uint32_t w = (R >> 2) == 0 ? Q.x : (R >> 2) == 1 ? Q.y : (R >> 2) == 2 ? Q.z : Q.w;
                 sX = lut[(w >> (8 * (R & 3))) & 255u];          // mismatch(quality of row i), LDS
             }
-            dp_row<BAND, TYPE, A, R>(st, k, sX, i, q, g);
+            uint32_t tlo = 0, thi = 0;
+            if (FAST) {
+                // entry v of the row's table: sM where v is the row's symbol, sX elsewhere (masks[q]: which 16-bit halves take sM)
+                const uint2 m = masks[qr];
+                const uint32_t xx = QUAL ? (uint32_t(sX) | (uint32_t(sX) << 16)) : k.sXX;
+                tlo = (k.sMM & m.x) | (xx & ~m.x);
+                thi = (k.sMM & m.y) | (xx & ~m.y);
+            }
+            dp_row<BAND, TYPE, A, FAST, R>(st, k, sX, i, FAST ? 0u : A::enc(qr), g, g_store, tlo, thi);
         }
-        RowUnrollN<BAND, TYPE, A, QUAL, R + 1, END>::run(st, k, i0, M, N, P, T, Q, lut);
+        RowUnrollN<BAND, TYPE, A, QUAL, FAST, R + 1, END>::run(st, k, i0, M, N, P, T, Q, lut, masks);
     }
 };
-template <int BAND, int TYPE, typename A, bool QUAL, int END> struct RowUnrollN<BAND, TYPE, A, QUAL, END, END> {
+template <int BAND, int TYPE, typename A, bool QUAL, bool FAST, int END> struct RowUnrollN<BAND, TYPE, A, QUAL, FAST, END, END> {
     __device__ __forceinline__ static void run(DPState<BAND, A>&, const DPConsts<A>&, uint32_t, uint32_t, uint32_t, uint64_t, uint32_t,
-                                               uint4, const typename A::T*) {}
+                                               uint4, const typename A::T*, const uint2*) {}
 };
 
 // 16 quality bytes starting at byte `off` (unaligned dword loads, clamped to the array)
@@ -317,6 +378,11 @@ banded_gotoh_score_kernel(const GotohParams p, const QA qa)
     constexpr bool QUAL = IsQual<QA>::value;
     constexpr int SH = (TYPE == NVBIO_HIP_LOCAL) ? 5 : 0;      // LOCAL carries scores x32 (see header)
     __shared__ T s_lut[QUAL ? 256 : 1];
+    __shared__ uint2 s_masks[16];            // table arithmetic: which halves of the row's {lo, hi} hold the match score, by pattern symbol
+    if (A::TABLE && threadIdx.x < 16u)
+        s_masks[threadIdx.x] = make_uint2(threadIdx.x == 0u ? 0x0000FFFFu : threadIdx.x == 1u ? 0xFFFF0000u : 0u,
+                                          threadIdx.x == 2u ? 0x0000FFFFu : threadIdx.x == 3u ? 0xFFFF0000u : 0u);
+    if (A::TABLE && !QUAL) __syncthreads();
     extern __shared__ __attribute__((aligned(16))) uint32_t s_stage[];    // [stage_pw + stage_tw][256]
     fill_lut<A>(s_lut, qa, p.gap_open, SH);
     const uint32_t id = blockIdx.x * 256u + threadIdx.x;
@@ -369,6 +435,7 @@ banded_gotoh_score_kernel(const GotohParams p, const QA qa)
         k.Go = A::cnst(p.gap_open * (1 << SH)); k.Ge = A::cnst(p.gap_ext * (1 << SH));
         k.sM = A::cnst((p.match - p.gap_open) * (1 << SH)); k.sX = A::cnst((p.mismatch - p.gap_open) * (1 << SH));
         k.inf = Sentinel<A>::get(p.gap_open, p.gap_ext, p.txt_gap_open, p.txt_gap_ext, SH);
+        k.sMM = (uint32_t(k.sM) & 0xFFFFu) * 0x10001u; k.sXX = (uint32_t(k.sX) & 0xFFFFu) * 0x10001u;
         const T infimum = k.inf;
 
         DPState<BAND, A> st;
@@ -389,7 +456,7 @@ banded_gotoh_score_kernel(const GotohParams p, const QA qa)
                 const uint32_t T0 = fetch16_2bit(ts, tb + b);
                 #pragma unroll
                 for (int j = b; j < BAND - 1 && j < b + 16; ++j)
-                    st.tc[BT::RING ? (j & 15) : j] = (T0 >> (2 * (j - b))) & 3u;
+                    st.tc[BT::RING ? (j & 15) : j] = A::enc((T0 >> (2 * (j - b))) & 3u);
             }
         }
 
@@ -402,7 +469,11 @@ banded_gotoh_score_kernel(const GotohParams p, const QA qa)
             const uint64_t Pn = fetch_pattern16(ps, pb + i0 + BT::ROWS);
             const uint32_t Tn = fetch16_2bit(ts, tb + i0 + BT::ROWS + BAND - 1);
             const uint4    Qn = fetch_quals16(qa, pb + i0 + BT::ROWS);
-            RowUnrollN<BAND, TYPE, A, QUAL, 0, BT::ROWS>::run(st, k, i0, M, N, P, Tx, Q, s_lut);
+            // a block none of whose rows lets a symbol past the text's end into the band runs on table arithmetic
+            if (A::TABLE && i0 + BT::ROWS - 1u + BAND - 1u < N)
+                RowUnrollN<BAND, TYPE, A, QUAL, true, 0, BT::ROWS>::run(st, k, i0, M, N, P, Tx, Q, s_lut, s_masks);
+            else
+                RowUnrollN<BAND, TYPE, A, QUAL, false, 0, BT::ROWS>::run(st, k, i0, M, N, P, Tx, Q, s_lut, s_masks);
             P = Pn; Tx = Tn; Q = Qn;
         }
 

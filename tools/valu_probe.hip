@@ -43,7 +43,20 @@
   X(sub_u16_clamp,"v_sub_u16_e64 %0, %0, %1 clamp") \
   X(max_i16_sdwa, "v_max_i16_sdwa %0, %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1") \
   X(add_u16_sdwa, "v_add_u16_sdwa %0, %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1") \
-  X(pk_max_i16,   "v_pk_max_i16 %0, %0, %1")
+  X(pk_max_i16,   "v_pk_max_i16 %0, %0, %1") \
+  X(perm_b32,     "v_perm_b32 %0, %0, %1, %1") \
+  X(bfe_u32,      "v_bfe_u32 %0, %0, %1, 8") \
+  X(bfe_i32,      "v_bfe_i32 %0, %0, %1, 8") \
+  X(xor_b32,      "v_xor_b32 %0, %0, %1") \
+  X(and_b32,      "v_and_b32 %0, %0, %1") \
+  X(alignbit_b32, "v_alignbit_b32 %0, %0, %1, %1") \
+  X(alignbyte_b32,"v_alignbyte_b32 %0, %0, %1, %1") \
+  X(lshrrev_b16,  "v_lshrrev_b16 %0, %1, %0") \
+  X(lshrrev_b32v, "v_lshrrev_b32 %0, %1, %0") \
+  X(perm_add_pair,"v_perm_b32 %0, %0, %1, %1\n v_add_u16 %0, %0, %1") \
+  X(cmp_cnd_add,  "v_cmp_eq_u32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc\n v_add_u16 %0, %0, %1") \
+  X(mov_dpp,      "v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf") \
+  X(xor_subclamp, "v_xor_b32 %0, %0, %1\n v_sub_u16_e64 %0, %1, %0 clamp")
 
 #define X(name, str) \
 __global__ void __launch_bounds__(256) k_##name(uint32_t* out, int iters) { \
