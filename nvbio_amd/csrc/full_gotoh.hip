@@ -229,16 +229,18 @@ __device__ __forceinline__ SweepResult sweep(const FullParams& p, const uint64_t
 // ---------------------------------------------------------------------------------------------
 template <int TYPE>
 __device__ __forceinline__ void cell16(uint32_t& e, uint32_t& hlg, uint32_t& hab_g, uint32_t& fab, uint32_t& diag_g,
-                                       const uint32_t ch, const uint32_t q, const uint32_t go, const uint32_t ge,
-                                       const uint32_t sM, const uint32_t sX, uint32_t& h_out)
+                                       const uint32_t ch, const uint32_t tlo, const uint32_t thi, const uint32_t go, const uint32_t ge,
+                                       uint32_t& h_out)
 {
     // in : e = E(r,c-1), hlg = HG(r,c-1), hab_g = HG(r-1,c), fab = F(r-1,c), diag_g = HG(r-1,c-1)
     // out: e = E(r,c),   hlg = HG(r,c),   hab_g = HG(r,c),   fab = F(r,c),   diag_g = HG(r,c-1), h_out = H(r,c)
+    // The substitution score is a table lookup, not a compare + select (6.6 issue cycles -> 4.3, no VCC; profiles/r02/valu_probe.txt):
+    // ch is the text symbol as the byte selector of its 16-bit entry (0x0C0C0100 + 0x0202 * g), {tlo, thi} the row's four entries
+    // (match score - G_o where the entry's symbol is the row's, its mismatch score - G_o elsewhere; a row past the pattern: all mismatch).
     uint32_t f, d, h, t;
     if (TYPE == NVBIO_HIP_LOCAL)
-        asm("v_cmp_eq_u32 vcc, %[ch], %[q]\n\t"
+        asm("v_perm_b32 %[d], %[thi], %[tlo], %[ch]\n\t"
             "v_add_u16 %[f], %[fab], %[ge]\n\t"
-            "v_cndmask_b32 %[d], %[sx], %[sm], vcc\n\t"
             "v_add_u16 %[e], %[e], %[ge]\n\t"
             "v_max_i16 %[f], %[f], %[hab]\n\t"
             "v_add_u16 %[d], %[dg], %[d]\n\t"
@@ -248,12 +250,10 @@ __device__ __forceinline__ void cell16(uint32_t& e, uint32_t& hlg, uint32_t& hab
             "v_max_i16 %[h], 0, %[h]\n\t"
             "v_add_u16 %[t], %[h], %[go]"
             : [f] "=&v"(f), [d] "=&v"(d), [h] "=&v"(h), [t] "=&v"(t), [e] "+v"(e)
-            : [ch] "v"(ch), [q] "v"(q), [fab] "v"(fab), [ge] "v"(ge), [sx] "v"(sX), [sm] "v"(sM), [hab] "v"(hab_g), [dg] "v"(diag_g), [go] "v"(go), [hl] "v"(hlg)
-            : "vcc");
+            : [ch] "v"(ch), [tlo] "v"(tlo), [thi] "v"(thi), [fab] "v"(fab), [ge] "v"(ge), [hab] "v"(hab_g), [dg] "v"(diag_g), [go] "v"(go), [hl] "v"(hlg));
     else
-        asm("v_cmp_eq_u32 vcc, %[ch], %[q]\n\t"
+        asm("v_perm_b32 %[d], %[thi], %[tlo], %[ch]\n\t"
             "v_add_u16 %[f], %[fab], %[ge]\n\t"
-            "v_cndmask_b32 %[d], %[sx], %[sm], vcc\n\t"
             "v_add_u16 %[e], %[e], %[ge]\n\t"
             "v_max_i16 %[f], %[f], %[hab]\n\t"
             "v_add_u16 %[d], %[dg], %[d]\n\t"
@@ -262,8 +262,7 @@ __device__ __forceinline__ void cell16(uint32_t& e, uint32_t& hlg, uint32_t& hab
             "v_max_i16 %[h], %[h], %[e]\n\t"
             "v_add_u16 %[t], %[h], %[go]"
             : [f] "=&v"(f), [d] "=&v"(d), [h] "=&v"(h), [t] "=&v"(t), [e] "+v"(e)
-            : [ch] "v"(ch), [q] "v"(q), [fab] "v"(fab), [ge] "v"(ge), [sx] "v"(sX), [sm] "v"(sM), [hab] "v"(hab_g), [dg] "v"(diag_g), [go] "v"(go), [hl] "v"(hlg)
-            : "vcc");
+            : [ch] "v"(ch), [tlo] "v"(tlo), [thi] "v"(thi), [fab] "v"(fab), [ge] "v"(ge), [hab] "v"(hab_g), [dg] "v"(diag_g), [go] "v"(go), [hl] "v"(hlg));
     diag_g = hlg; hlg = t; hab_g = t; fab = f; h_out = h;      // old HG(r,c-1) is the next row's diagonal: a renaming
 }
 
@@ -277,8 +276,8 @@ struct Sweep16
     const FullParams& p;
     uint32_t lane, lane_last, klast, M, Ncols, Nfull;
     int32_t  Go, Ge, min_score;
-    uint32_t go, ge, rge, sM, sX, inf16, init_above_g;
-    uint32_t sXk[R];                      // per-row mismatch score (quality-aware schemes), pre-biased like sX
+    uint32_t go, ge, rge, inf16, init_above_g;
+    uint32_t tlo[R], thi[R];              // per-row substitution table: four 16-bit entries, scores pre-biased by -G_o (cell16)
     uint64_t tb;
     uint32_t q[R], HLG[R], E[R], bestk[R], rmax[PBX ? R : 1];
     uint32_t lim[CHECK ? R : 1];          // CHECK: 0x7FFF for this lane's valid rows, 0x8000 for rows past the pattern (they drop out of the column maximum)
@@ -299,14 +298,17 @@ struct Sweep16
         lane_last = (M - 1u) / uint32_t(R);
         klast = (M - 1u) - lane_last * uint32_t(R);
         kl = lane < lane_last ? uint32_t(R - 1) : (lane == lane_last ? klast : 0u);
-        go = c16(Go); ge = c16(Ge); rge = c16(p.row_ge); sM = c16(p.match - Go); sX = c16(p.mismatch - Go); inf16 = c16(infimum);
+        go = c16(Go); ge = c16(Ge); rge = c16(p.row_ge); inf16 = c16(infimum);
+        const uint32_t sM = c16(p.match - Go), sX = c16(p.mismatch - Go);
         #pragma unroll
         for (int k = 0; k < R; ++k)
         {
             const uint32_t r = lane * R + k;
             q[k] = r < M ? get_symbol(p.pat.s, pb + r) : 255u;
             HLG[k] = c16(((TYPE != NVBIO_HIP_LOCAL) ? p.col_go + p.col_ge * int32_t(r) : 0) + Go);
-            sXk[k] = (p.quals && r < M) ? c16(p.mm_lut[p.quals[min(pb + r, p.n_quals - 1u)]] - Go) : sX;
+            const uint32_t sXr = (p.quals && r < M) ? c16(p.mm_lut[p.quals[min(pb + r, p.n_quals - 1u)]] - Go) : sX;
+            tlo[k] = (q[k] == 0u ? sM : sXr) | ((q[k] == 1u ? sM : sXr) << 16);
+            thi[k] = (q[k] == 2u ? sM : sXr) | ((q[k] == 3u ? sM : sXr) << 16);
             E[k]   = c16((TYPE == NVBIO_HIP_LOCAL) ? 0 : infimum);
             bestk[k] = 0u;
             if (PBX) rmax[k] = 0x8000u;
@@ -360,7 +362,7 @@ struct Sweep16
             #pragma unroll
             for (int k = 0; k < R; ++k)
             {
-                cell16<TYPE>(E[k], HLG[k], hab_g, fab, diag_g, in_ch, q[k], go, ge, sM, sXk[k], h);
+                cell16<TYPE>(E[k], HLG[k], hab_g, fab, diag_g, in_ch, tlo[k], thi[k], go, ge, h);
                 if (TYPE == NVBIO_HIP_LOCAL) bestk[k] = max(bestk[k], (h << 20) | c);
                 if (PBX) rmax[k] = max16u(rmax[k], h);
                 if (CHECK) cm = max16u(cm, min16u(h, lim[k]));
@@ -393,23 +395,25 @@ struct Sweep16
         uint32_t s = 0;
         // ramp-up, up to the first 16-aligned step at which every row-holding lane is inside the matrix
         const uint32_t s_fast = (lane_last + 15u) & ~15u;
+        // (a wave owns one job: the text group is wave-uniform, so the symbol -> selector arithmetic runs on the scalar unit)
+        auto sel = [](const uint32_t g) { return 0x0C0C0100u + 0x0202u * g; };
         for (; s < n_steps && s < s_fast; ++s)
         {
-            if ((s & 15u) == 0u && s < Ncols) grp = fetch16_2bit(p.txt.s, tb + s);
-            step<true>(s, (grp >> (2u * (s & 15u))) & 3u);
+            if ((s & 15u) == 0u && s < Ncols) grp = uint32_t(__builtin_amdgcn_readfirstlane(int(fetch16_2bit(p.txt.s, tb + s))));
+            step<true>(s, sel((grp >> (2u * (s & 15u))) & 3u));
         }
         // steady state: 16 unpredicated steps per text group (lanes past the last row compute harmlessly)
         for (; s + 16u < Ncols; s += 16u)        // strict: the last column is always handled by the tail
         {
-            grp = fetch16_2bit(p.txt.s, tb + s);
+            grp = uint32_t(__builtin_amdgcn_readfirstlane(int(fetch16_2bit(p.txt.s, tb + s))));
             #pragma unroll
-            for (int u = 0; u < 16; ++u) step<false>(s + u, (grp >> (2 * u)) & 3u);
+            for (int u = 0; u < 16; ++u) step<false>(s + u, sel((grp >> (2 * u)) & 3u));
         }
         // tail and ramp-down
         for (; s < n_steps; ++s)
         {
-            if ((s & 15u) == 0u && s < Ncols) grp = fetch16_2bit(p.txt.s, tb + s);
-            step<true>(s, (grp >> (2u * (s & 15u))) & 3u);
+            if ((s & 15u) == 0u && s < Ncols) grp = uint32_t(__builtin_amdgcn_readfirstlane(int(fetch16_2bit(p.txt.s, tb + s))));
+            step<true>(s, sel((grp >> (2u * (s & 15u))) & 3u));
         }
 
         SweepResult res;
