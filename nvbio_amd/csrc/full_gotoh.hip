@@ -280,6 +280,11 @@ struct Sweep16
     uint32_t tlo[R], thi[R];              // per-row substitution table: four 16-bit entries, scores pre-biased by -G_o (cell16)
     uint64_t tb;
     uint32_t q[R], HLG[R], E[R], bestk[R], rmax[PBX ? R : 1];
+    // LOCAL carries every value x16 (the host admits LOCAL only below 2048) so that "score, then later column" is one 16-bit maximum:
+    // bk16 = max over the current group of 16 steps of H*16 + (step & 15); the groups are folded into bestk = score << 20 | column
+    // at wave-uniform times.  (The 32-bit form, (h << 20 | c) and v_max_u32 per cell, cost 8.6 issue cycles of a cell's 36; this costs 4.6.)
+    static constexpr int SC = (TYPE == NVBIO_HIP_LOCAL) ? 16 : 1;
+    uint32_t bk16[TYPE == NVBIO_HIP_LOCAL ? R : 1];
     uint32_t lim[CHECK ? R : 1];          // CHECK: 0x7FFF for this lane's valid rows, 0x8000 for rows past the pattern (they drop out of the column maximum)
     uint32_t out_hg, out_f, out_ch, out_cm, prev_in_hg;
     int32_t  sg_score; uint32_t sg_col, exit_col, grp;
@@ -294,30 +299,31 @@ struct Sweep16
     {
         lane = threadIdx.x & 63u; M = _M; Ncols = _Ncols; Nfull = _Nfull; min_score = _min_score; tb = _tb; pb_check = false;
         Go = p.gap_open; Ge = p.gap_ext;
-        const int32_t infimum = -32768 - min(Go, Ge);
+        const int32_t infimum = -32768 - min(Go, Ge) * SC;
         lane_last = (M - 1u) / uint32_t(R);
         klast = (M - 1u) - lane_last * uint32_t(R);
         kl = lane < lane_last ? uint32_t(R - 1) : (lane == lane_last ? klast : 0u);
-        go = c16(Go); ge = c16(Ge); rge = c16(p.row_ge); inf16 = c16(infimum);
-        const uint32_t sM = c16(p.match - Go), sX = c16(p.mismatch - Go);
+        go = c16(Go * SC); ge = c16(Ge * SC); rge = c16(p.row_ge); inf16 = c16(infimum);
+        const uint32_t sM = c16((p.match - Go) * SC), sX = c16((p.mismatch - Go) * SC);
         #pragma unroll
         for (int k = 0; k < R; ++k)
         {
             const uint32_t r = lane * R + k;
             q[k] = r < M ? get_symbol(p.pat.s, pb + r) : 255u;
-            HLG[k] = c16(((TYPE != NVBIO_HIP_LOCAL) ? p.col_go + p.col_ge * int32_t(r) : 0) + Go);
-            const uint32_t sXr = (p.quals && r < M) ? c16(p.mm_lut[p.quals[min(pb + r, p.n_quals - 1u)]] - Go) : sX;
+            HLG[k] = c16(((TYPE != NVBIO_HIP_LOCAL) ? p.col_go + p.col_ge * int32_t(r) : 0) + Go * SC);
+            const uint32_t sXr = (p.quals && r < M) ? c16((p.mm_lut[p.quals[min(pb + r, p.n_quals - 1u)]] - Go) * SC) : sX;
             tlo[k] = (q[k] == 0u ? sM : sXr) | ((q[k] == 1u ? sM : sXr) << 16);
             thi[k] = (q[k] == 2u ? sM : sXr) | ((q[k] == 3u ? sM : sXr) << 16);
             E[k]   = c16((TYPE == NVBIO_HIP_LOCAL) ? 0 : infimum);
             bestk[k] = 0u;
+            if (TYPE == NVBIO_HIP_LOCAL) bk16[k] = 0x8000u;
             if (PBX) rmax[k] = 0x8000u;
             if (CHECK) lim[k] = (uint32_t(k) <= kl) ? 0x7FFFu : 0x8000u;
         }
         out_hg = out_f = out_ch = out_cm = prev_in_hg = 0;
         sg_score = -(1 << 30); sg_col = 0; exit_col = 0xFFFFFFFFu; grp = 0; sg_hg16 = 0x8000u;
         top_hg = c16(p.row_go + Go); top_prev_hg = go;
-        init_above_g = c16(((TYPE != NVBIO_HIP_LOCAL) ? p.col_go + p.col_ge * int32_t(lane * R - 1u) : 0) + Go);
+        init_above_g = c16(((TYPE != NVBIO_HIP_LOCAL) ? p.col_go + p.col_ge * int32_t(lane * R - 1u) : 0) + Go * SC);
     }
 
     // the last-row lane's reports and the early-exit test for column c (cm = full column maximum)
@@ -335,13 +341,13 @@ struct Sweep16
             const uint32_t nb = 8u * ((Nfull + 7u) / 8u);
             const uint32_t end_block = nb > 8u ? nb : 8u;
             const uint32_t block = c - 7u;
-            if (block + 8u < end_block && int32_t(int16_t(cm)) + int32_t(Nfull - block - 8u) * p.match < min_score) exit_col = c;
+            if (block + 8u < end_block && int32_t(int16_t(cm)) / SC + int32_t(Nfull - block - 8u) * p.match < min_score) exit_col = c;
         }
     }
 
     // one step; PRED = lanes may be outside the matrix (ramp-up / ramp-down)
     template <bool PRED>
-    __device__ __forceinline__ void step(const uint32_t s, const uint32_t ch0)
+    __device__ __forceinline__ void step(const uint32_t s, const uint32_t ch0, const uint32_t s15)     // s15 = s & 15 (a constant in the unrolled steady state)
     {
         const uint32_t c = s - lane;
         const uint32_t th = (TYPE == NVBIO_HIP_GLOBAL) ? top_hg : go;          // HG(-1,c) for lane 0
@@ -363,7 +369,7 @@ struct Sweep16
             for (int k = 0; k < R; ++k)
             {
                 cell16<TYPE>(E[k], HLG[k], hab_g, fab, diag_g, in_ch, tlo[k], thi[k], go, ge, h);
-                if (TYPE == NVBIO_HIP_LOCAL) bestk[k] = max(bestk[k], (h << 20) | c);
+                if (TYPE == NVBIO_HIP_LOCAL) bk16[k] = max16u(bk16[k], h + s15);       // h < 2^15 and a multiple of 16: no carry out of the low half
                 if (PBX) rmax[k] = max16u(rmax[k], h);
                 if (CHECK) cm = max16u(cm, min16u(h, lim[k]));
                 if (TYPE != NVBIO_HIP_LOCAL) hg_last = (uint32_t(k) == kl) ? hab_g : hg_last;   // HG of this lane's last valid row
@@ -389,6 +395,22 @@ struct Sweep16
         }
     }
 
+    // LOCAL: the finished group of 16 steps [base, base + 16) into the rows' all-time records (every lane at once)
+    __device__ __forceinline__ void fold(const uint32_t base)
+    {
+        if (TYPE == NVBIO_HIP_LOCAL)
+        {
+            #pragma unroll
+            for (int k = 0; k < R; ++k)
+            {
+                const uint32_t t = bk16[k];
+                const uint32_t cand = ((t >> 4) << 20) | ((base + (t & 15u) - lane) & 0xFFFFFu);
+                bestk[k] = (t != 0x8000u) ? max(bestk[k], cand) : bestk[k];      // 0x8000: the lane sat outside the matrix for the whole group
+                bk16[k] = 0x8000u;
+            }
+        }
+    }
+
     __device__ __forceinline__ SweepResult run()
     {
         const uint32_t n_steps = Ncols + lane_last;
@@ -400,21 +422,25 @@ struct Sweep16
         for (; s < n_steps && s < s_fast; ++s)
         {
             if ((s & 15u) == 0u && s < Ncols) grp = uint32_t(__builtin_amdgcn_readfirstlane(int(fetch16_2bit(p.txt.s, tb + s))));
-            step<true>(s, sel((grp >> (2u * (s & 15u))) & 3u));
+            step<true>(s, sel((grp >> (2u * (s & 15u))) & 3u), s & 15u);
+            if ((s & 15u) == 15u) fold(s - 15u);
         }
         // steady state: 16 unpredicated steps per text group (lanes past the last row compute harmlessly)
         for (; s + 16u < Ncols; s += 16u)        // strict: the last column is always handled by the tail
         {
             grp = uint32_t(__builtin_amdgcn_readfirstlane(int(fetch16_2bit(p.txt.s, tb + s))));
             #pragma unroll
-            for (int u = 0; u < 16; ++u) step<false>(s + u, sel((grp >> (2 * u)) & 3u));
+            for (int u = 0; u < 16; ++u) step<false>(s + u, sel((grp >> (2 * u)) & 3u), uint32_t(u));
+            fold(s);
         }
         // tail and ramp-down
         for (; s < n_steps; ++s)
         {
             if ((s & 15u) == 0u && s < Ncols) grp = uint32_t(__builtin_amdgcn_readfirstlane(int(fetch16_2bit(p.txt.s, tb + s))));
-            step<true>(s, sel((grp >> (2u * (s & 15u))) & 3u));
+            step<true>(s, sel((grp >> (2u * (s & 15u))) & 3u), s & 15u);
+            if ((s & 15u) == 15u) fold(s - 15u);
         }
+        if ((s & 15u) != 0u) fold(s & ~15u);
 
         SweepResult res;
         res.exit_col = uint32_t(__shfl(int32_t(exit_col), int32_t(lane_last)));
@@ -678,7 +704,8 @@ static int full_score_core(
     const int R = maxM <= 64u ? 1 : maxM <= 128u ? 2 : maxM <= 192u ? 3 : maxM <= 256u ? 4 : maxM <= 512u ? 8 : 16;
     // the 16-bit sweep needs: values inside int16 (= !trunc), LOCAL scores < 2048 and columns < 2^20 for its packed row maxima
     const char* nofast = getenv("NVBIO_HIP_FULL_GENERIC");
-    const bool fast = !trunc && maxN < (1u << 20) && (type != NVBIO_HIP_LOCAL || (scheme->match >= 0 && int64_t(maxM) * best_pair < 2048))
+    // (LOCAL runs x16: scores below 2048 and every cost below 2048 / 3 keep H, E, F, H + G_o and the diagonal sum inside int16)
+    const bool fast = !trunc && maxN < (1u << 20) && (type != NVBIO_HIP_LOCAL || (scheme->match >= 0 && int64_t(maxM) * best_pair < 2048 && A * 3 < 2000))
                       && !(nofast && nofast[0] == '1');
     if (fast) {
         g_last_kernel = "full_gotoh_score_kernel<16-bit>";
