@@ -18,7 +18,7 @@ from tests import oracle_driver as OD                       # noqa: E402
 
 
 def case(seed=20260927):
-    rng = np.random.default_rng(seed)
+    rng = np.random.default_rng(np.random.SeedSequence(seed))      # (a SeedSequence, not an int: the fuzz campaigns' seed shift must not move a fixture's inputs)
     text = rng.integers(0, 4, 1 << 14, dtype=np.uint8)
     text[3000:3300] = np.tile(np.array([0, 1, 3], dtype=np.uint8), 100)
     for k in range(3):
