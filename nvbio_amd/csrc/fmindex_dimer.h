@@ -253,6 +253,8 @@ __device__ __forceinline__ void dm_locate_step(const Dimer& d, uint32_t& j, uint
     const uint32_t b = uint32_t(((up ? P.hi[0] : P.lo[0]) >> sh) & 1u) | (uint32_t(((up ? P.hi[1] : P.lo[1]) >> sh) & 1u) << 1);
     const uint32_t a = uint32_t(((up ? P.hi[2] : P.lo[2]) >> sh) & 1u) | (uint32_t(((up ? P.hi[3] : P.lo[3]) >> sh) & 1u) << 1);
     // the four counters of b -- among them the dimer's own -- are one uint4 of the line just fetched
+    // (loading all four counter groups up front, to spare the dependent load, is slower -- 12.1 vs 10.5 ms: the step is bound by
+    // its count of scattered load instructions, profiles/r02/locate_refill.txt)
     const uint4 kb = reinterpret_cast<const uint4*>(r)[b];
     const uint32_t w = rr + 1u;                                // rows <= j of this block
     uint64_t mlo, mhi;
