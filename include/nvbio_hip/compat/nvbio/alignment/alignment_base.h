@@ -13,6 +13,15 @@ enum AlignmentType { GLOBAL = 0, LOCAL = 1, SEMI_GLOBAL = 2 };
 /// DP flow directions (alignment_base.h:56-70)
 enum DirectionVector { SUBSTITUTION = 0u, INSERTION = 1u, DELETION = 2u, SINK = 3u };
 
+/// an alignment result: score, start cell and terminal cell, x = text, y = pattern (alignment_base.h:122-135)
+template <typename ScoreType>
+struct Alignment
+{
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE Alignment() {}
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE Alignment(const ScoreType _score, const uint2 _source, const uint2 _sink) : score(_score), source(_source), sink(_sink) {}
+    ScoreType score; uint2 source; uint2 sink;
+};
+
 struct PatternBlockingTag {};
 struct TextBlockingTag {};
 template <typename T> struct transpose_tag {};

@@ -159,6 +159,18 @@ struct recognised
                               simple_aligner<typename stream_type::aligner_type>::ok;
 };
 
+/// the same test for a traceback stream (batched.h:359-420: its context holds a backtracer and an Alignment<int32> instead of a sink)
+template <typename stream_type>
+struct recognised_tb
+{
+    typedef typename stream_type::strings_type strings_type;
+    typedef decltype(strings_type().pattern) pattern_type;
+    typedef decltype(strings_type().text)    text_type;
+    typedef decltype(strings_type().quals)   quals_type;
+    static const bool value = packed_view<pattern_type>::ok && packed_view<text_type>::ok && packed_view<text_type>::BITS == 2u &&
+                              equal<quals_type, trivial_quality_string>::pred && simple_aligner<typename stream_type::aligner_type>::ok;
+};
+
 #if defined(NVBIO_HIP_COMPAT_TUNED)
 /// the job table the tuned kernels consume (structure of arrays in one device buffer)
 struct job_table
@@ -188,10 +200,9 @@ __device__ __forceinline__ unsigned long long wave_max(unsigned long long v)
 __global__ void init_bounds_kernel(unsigned long long* b) { if (threadIdx.x < 4u) b[threadIdx.x] = (threadIdx.x & 1u) ? 0ull : ~0ull; }
 
 /// evaluate the stream's functors per job: where its strings live, how long they are, its min_score
-template <typename stream_type>
+template <typename stream_type, typename R>
 __global__ void __launch_bounds__(128) describe_jobs_kernel(const stream_type stream, const job_table t)
 {
-    typedef recognised<stream_type> R;
     const uint32 i = blockIdx.x * 128u + threadIdx.x;
     unsigned long long plo = ~0ull, phi = 0ull, tlo = ~0ull, thi = 0ull;
     if (i < stream.size())
@@ -238,15 +249,48 @@ __global__ void __launch_bounds__(128) output_jobs_kernel(const stream_type stre
     stream.output(i, &ctx);
 }
 
-/// describe -> (sync: two pointers) -> rebase; fills the C-ABI string sets
+/// hand each traceback to the stream the way the reference's per-job body does (batched_banded_inl.h:248-296, banded_inl.h:383-426):
+/// a declined job is output untouched; a job without a sink gets Alignment(score, (-1,-1), (-1,-1)) and no backtracer call; otherwise
+/// clip(end of the pattern past the sink), the walk's operations from the sink backwards, clip(start of the pattern), the Alignment.
 template <typename stream_type>
-inline void build_job_table(const stream_type& stream, device_buffer& buf, job_table& t, nvbio_hip_string_set& ps, nvbio_hip_string_set& ts, hipStream_t hs)
+__global__ void __launch_bounds__(128) replay_tracebacks_kernel(stream_type stream, const job_table t, const uint32* source, const uint16* cigar,
+                                                                const uint32 cigar_stride, const uint32* cigar_len)
 {
-    typedef recognised<stream_type> R;
+    const uint32 i = blockIdx.x * 128u + threadIdx.x;
+    if (i >= stream.size()) return;
+    typename stream_type::context_type ctx;
+    if (!stream.init_context(i, &ctx)) { stream.output(i, &ctx); return; }
+    const uint2 snk = make_uint2(t.sink[2u * i], t.sink[2u * i + 1u]), src = make_uint2(source[2u * i], source[2u * i + 1u]);
+    if (snk.x == 0xFFFFFFFFu || snk.y == 0xFFFFFFFFu)
+        ctx.alignment = Alignment<int32>(t.score[i], make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu), make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu));
+    else
+    {
+        ctx.backtracer.clip(t.pat_len[i] - snk.y);
+        const uint16* c = cigar + uint64(i) * cigar_stride;
+        const uint32 words = cigar_len[i] < cigar_stride ? cigar_len[i] : cigar_stride;
+        for (uint32 k = 0; k < words; ++k)
+        {
+            const uint32 op = c[k] & 3u, len = uint32(c[k]) >> 2;
+            if (op == 3u) continue;                                   // the two clips are made from sink / source
+            for (uint32 l = 0; l < len; ++l) ctx.backtracer.push(DirectionVector(op));
+        }
+        ctx.backtracer.clip(src.y);
+        ctx.alignment = Alignment<int32>(t.score[i], src, snk);
+    }
+    stream.output(i, &ctx);
+}
+
+/// describe -> (sync: two pointers) -> rebase; fills the C-ABI string sets
+template <typename stream_type, typename R = recognised<stream_type> >
+inline void build_job_table(const stream_type& stream, device_buffer& buf, job_table& t, nvbio_hip_string_set& ps, nvbio_hip_string_set& ts, hipStream_t hs,
+                            const uint64 extra_bytes = 0, uint8** extra = NULL)
+{
     const uint32 n = stream.size();
-    t.carve(buf.reserve(job_table::bytes(n)), n);
+    uint8* base = buf.reserve(job_table::bytes(n) + extra_bytes + 16u);
+    t.carve(base, n);
+    if (extra) *extra = base + ((job_table::bytes(n) + 15u) & ~uint64(15));
     hipLaunchKernelGGL(init_bounds_kernel, dim3(1), dim3(64), 0, hs, t.bounds);
-    hipLaunchKernelGGL((describe_jobs_kernel<stream_type>), dim3((n + 127u) / 128u), dim3(128), 0, hs, stream, t);
+    hipLaunchKernelGGL((describe_jobs_kernel<stream_type, R>), dim3((n + 127u) / 128u), dim3(128), 0, hs, stream, t);
     unsigned long long b[4];
     check(hipMemcpyAsync(b, t.bounds, sizeof(b), hipMemcpyDeviceToHost, hs), "hipMemcpyAsync");
     check(hipStreamSynchronize(hs), "hipStreamSynchronize");
@@ -433,7 +477,7 @@ private:
     {
 #if defined(NVBIO_HIP_COMPAT_TUNED)
         const uint32 n = stream.size();
-        if (stream.max_pattern_length() > 512u) { run_device(stream, temp_size, temp, hs, std::false_type()); return; }     // the tuned sweep keeps <= 512 rows in a wave
+        if (stream.max_pattern_length() > 1024u) { run_device(stream, temp_size, temp, hs, std::false_type()); return; }    // the tuned sweep keeps <= 1024 rows in a wave
         priv::job_table t; nvbio_hip_string_set ps, ts;
         priv::build_job_table(stream, m_jobs, t, ps, ts, hs);
         int32 sc[4];
@@ -455,6 +499,79 @@ private:
 #endif
     const char* m_path;
 };
+
+// ---------------------------------------------------------------------------------------- tracebacks
+// BatchedBandedAlignmentTraceback / BatchedAlignmentTraceback (batched.h:432-476) over the reference's traceback stream concept
+// (context_type {min_score, backtracer, alignment}).  Offered for the streams the tuned kernels recognise -- packed strings in
+// device memory, trivial qualities, the library's Simple*Scheme / edit-distance aligners, any user backtracer with clip(n) /
+// push(op): the C-ABI traceback produces the run-length CIGAR, and a second kernel replays it into the stream's own backtracer
+// and output().  CHECKPOINTS is accepted and ignored (the kernels keep the whole flow matrix).  Other streams and the host
+// scheduler are not offered here: there is no generic per-lane traceback template in this layer.
+#if defined(NVBIO_HIP_COMPAT_TUNED)
+namespace priv {
+template <typename stream_type>
+struct traceback_runner
+{
+    typedef typename stream_type::aligner_type aligner_type;
+    static_assert(recognised_tb<stream_type>::value, "compat tracebacks take packed-string streams with trivial qualities and Simple*Scheme / edit-distance aligners");
+
+    /// band == 0: full matrix
+    void run(const stream_type& stream, const uint32 band, hipStream_t hs)
+    {
+        const uint32 n = stream.size();
+        if (n == 0) return;
+        const uint32 maxP = stream.max_pattern_length(), maxT = stream.max_text_length();
+        const uint32 stride = band ? maxP + band + 4u : maxP + maxT + 4u;          // run-length words never exceed the walk's length
+        const uint64 extra = uint64(n) * (8u + 4u + uint64(stride) * 2u) + 64u;
+        job_table t; nvbio_hip_string_set ps, ts; uint8* x = NULL;
+        build_job_table<stream_type, recognised_tb<stream_type> >(stream, m_jobs, t, ps, ts, hs, extra, &x);
+        uint32* source = reinterpret_cast<uint32*>(x);
+        uint32* cigar_len = source + 2u * uint64(n);
+        uint16* cigar = reinterpret_cast<uint16*>(cigar_len + n);
+        const uint64 tb = band ? nvbio_hip_banded_gotoh_traceback_temp_bytes(band, maxP, n) : nvbio_hip_gotoh_traceback_temp_bytes(maxP, maxT, n);
+        uint8* temp = m_temp.reserve(tb + 16u);
+        int32 sc[4];
+        simple_aligner<aligner_type>::scheme4(stream.aligner(), sc);
+        int err;
+        if (simple_aligner<aligner_type>::KIND == NVBIO_HIP_GOTOH_ALIGNER) {
+            const nvbio_hip_gotoh_scheme g = { sc[0], sc[1], sc[2], sc[3] };
+            err = band ? nvbio_hip_banded_gotoh_traceback(&g, int32(aligner_type::TYPE), band, &ps, &ts, maxP, maxT, n, t.score, t.sink, source, cigar, stride, cigar_len, temp, tb, hs)
+                       : nvbio_hip_gotoh_traceback(&g, int32(aligner_type::TYPE), &ps, &ts, maxP, maxT, n, t.score, t.sink, source, cigar, stride, cigar_len, temp, tb, hs);
+        } else {
+            const nvbio_hip_sw_scheme w = { sc[0], sc[1], sc[2], sc[3] };
+            err = band ? nvbio_hip_banded_sw_traceback(&w, int32(aligner_type::TYPE), band, &ps, &ts, maxP, maxT, n, t.score, t.sink, source, cigar, stride, cigar_len, temp, tb, hs)
+                       : nvbio_hip_sw_traceback(&w, int32(aligner_type::TYPE), &ps, &ts, maxP, maxT, n, t.score, t.sink, source, cigar, stride, cigar_len, temp, tb, hs);
+        }
+        check(err, "nvbio_hip_*_traceback");
+        hipLaunchKernelGGL((replay_tracebacks_kernel<stream_type>), dim3((n + 127u) / 128u), dim3(128), 0, hs, stream, t, source, cigar, stride, cigar_len);
+        check(hipGetLastError(), "replay_tracebacks_kernel");
+    }
+    device_buffer m_jobs, m_temp;
+};
+} // namespace priv
+
+template <uint32 BAND_LEN, uint32 CHECKPOINTS, typename stream_type, typename algorithm_type = DeviceThreadScheduler>
+struct BatchedBandedAlignmentTraceback
+{
+    static_assert(!equal<algorithm_type, HostThreadScheduler>::pred, "compat tracebacks run on the device schedulers");
+    static_assert(priv::tuned_band<BAND_LEN>::value, "bands 3, 5, 7, 15 and 31");
+    static uint64 min_temp_storage(const uint32, const uint32, const uint32) { return 0u; }        // the batch object owns its storage
+    static uint64 max_temp_storage(const uint32, const uint32, const uint32) { return 0u; }
+    void enact(stream_type stream, uint64 = 0u, uint8* = NULL, hipStream_t hip_stream = 0) { m_run.run(stream, BAND_LEN, hip_stream); }
+private:
+    priv::traceback_runner<stream_type> m_run;
+};
+template <uint32 CHECKPOINTS, typename stream_type, typename algorithm_type = DeviceThreadScheduler>
+struct BatchedAlignmentTraceback
+{
+    static_assert(!equal<algorithm_type, HostThreadScheduler>::pred, "compat tracebacks run on the device schedulers");
+    static uint64 min_temp_storage(const uint32, const uint32, const uint32) { return 0u; }
+    static uint64 max_temp_storage(const uint32, const uint32, const uint32) { return 0u; }
+    void enact(stream_type stream, uint64 = 0u, uint8* = NULL, hipStream_t hip_stream = 0) { m_run.run(stream, 0u, hip_stream); }
+private:
+    priv::traceback_runner<stream_type> m_run;
+};
+#endif // NVBIO_HIP_COMPAT_TUNED
 
 // ---------------------------------------------------------------------------------------- convenience functions
 namespace priv {

@@ -295,3 +295,99 @@ API int compat_per_thread_score(const int* sc, unsigned n, const unsigned* ro, c
     hipLaunchKernelGGL(per_thread_kernel<7>, dim3((n + 127u) / 128u), dim3(128), 0, 0, n, ro, reads, wo, windows, aln::SimpleGotohScheme(sc[0], sc[1], sc[2], sc[3]), scores);
     return int(hipDeviceSynchronize());
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// stream 3: a traceback stream (batched.h:359-420): the context carries the caller's backtracer and receives the Alignment.
+// The backtracer below forms a run-length CIGAR the way an aligner's own would (clip -> 'S', push -> M / I / D); output()
+// stores it with the alignment's score, source and sink.
+// ---------------------------------------------------------------------------------------------------------------------
+struct RunLengthBacktracer
+{
+    uint16* words; uint32 capacity, size; uint32 run_op, run_len;
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void clear() { size = 0; run_op = 255u; run_len = 0; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void flush() { if (run_len) { if (size < capacity) words[size] = uint16(run_op | (run_len << 2)); ++size; run_len = 0; } }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void clip(const uint32 len) { flush(); run_op = 255u; if (len) { if (size < capacity) words[size] = uint16(3u | (len << 2)); ++size; } }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void push(const uint8 op) { if (op != run_op) { flush(); run_op = op; } ++run_len; }
+};
+template <typename t_aligner_type>
+struct PackedTracebackStream
+{
+    typedef t_aligner_type aligner_type;
+    typedef cuda::ldg_pointer<uint32> word_iterator;
+    typedef PackedStringLoader<word_iterator, 4, true, uncached_tag>  read_loader_type;
+    typedef PackedStringLoader<word_iterator, 2, false, uncached_tag> window_loader_type;
+    typedef vector_view<typename read_loader_type::iterator>   read_string;
+    typedef vector_view<typename window_loader_type::iterator> window_string;
+    struct context_type { int32 min_score; RunLengthBacktracer backtracer; aln::Alignment<int32> alignment; };
+    struct strings_type { read_loader_type read_loader; window_loader_type window_loader; read_string pattern; aln::trivial_quality_string quals; window_string text; };
+
+    PackedTracebackStream(aligner_type aligner, uint32 count, const uint32* read_offsets, const uint32* read_words, uint32 longest_read,
+                          const uint32* window_offsets, const uint32* window_words, uint32 longest_window,
+                          int32* scores, uint2* sinks, uint2* sources, uint16* cigars, uint32 cigar_stride, uint32* cigar_lens)
+        : m_aligner(aligner), m_count(count), m_read_offsets(read_offsets), m_reads(word_iterator(read_words)), m_longest_read(longest_read),
+          m_window_offsets(window_offsets), m_windows(word_iterator(window_words)), m_longest_window(longest_window),
+          m_scores(scores), m_sinks(sinks), m_sources(sources), m_cigars(cigars), m_cigar_stride(cigar_stride), m_cigar_lens(cigar_lens) {}
+
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE const aligner_type& aligner() const { return m_aligner; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 max_pattern_length() const { return m_longest_read; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 max_text_length() const { return m_longest_window; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 size() const { return m_count; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 pattern_length(const uint32 i, context_type*) const { return m_read_offsets[i + 1] - m_read_offsets[i]; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 text_length(const uint32 i, context_type*) const { return m_window_offsets[i + 1] - m_window_offsets[i]; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool init_context(const uint32 i, context_type* context) const
+    {
+        context->min_score = Field_traits<int32>::min();
+        context->backtracer.words = m_cigars + uint64(i) * m_cigar_stride; context->backtracer.capacity = m_cigar_stride; context->backtracer.clear();
+        context->alignment = aln::Alignment<int32>(-77, make_uint2(7u, 7u), make_uint2(7u, 7u));         // what a declined job leaves behind
+        return (i % 53u) != 52u;               // some jobs are declined: they are output as they are
+    }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void load_strings(const uint32 i, const uint32 window_begin, const uint32 window_end, const context_type*, strings_type* strings) const
+    {
+        const uint32 r0 = m_read_offsets[i],   rn = m_read_offsets[i + 1] - r0;
+        const uint32 w0 = m_window_offsets[i], wn = m_window_offsets[i + 1] - w0;
+        strings->text    = window_string(wn, strings->window_loader.load(m_windows + w0, wn, make_uint2(window_begin, window_end), false));
+        strings->pattern = read_string(rn, strings->read_loader.load(m_reads + r0, rn));
+    }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void output(const uint32 i, context_type* context) const
+    {
+        context->backtracer.flush();
+        m_scores[i] = context->alignment.score;
+        m_sinks[i]  = context->alignment.sink;
+        m_sources[i] = context->alignment.source;
+        m_cigar_lens[i] = context->backtracer.size;
+    }
+    aligner_type m_aligner; uint32 m_count;
+    const uint32* m_read_offsets; typename read_loader_type::input_iterator m_reads; uint32 m_longest_read;
+    const uint32* m_window_offsets; typename window_loader_type::input_iterator m_windows; uint32 m_longest_window;
+    int32* m_scores; uint2* m_sinks; uint2* m_sources; uint16* m_cigars; uint32 m_cigar_stride; uint32* m_cigar_lens;
+};
+
+// band: 0 = full matrix; kind as above (0 Gotoh, 1 Smith-Waterman, 2 edit distance)
+extern "C" __attribute__((visibility("default")))
+int compat_traceback(int kind, int type, int band, const int* sc, unsigned n, const unsigned* read_offsets, const unsigned* reads, unsigned longest_read,
+                     const unsigned* window_offsets, const unsigned* windows, unsigned longest_window,
+                     int* scores, unsigned* sinks, unsigned* sources, unsigned short* cigars, unsigned cigar_stride, unsigned* cigar_lens)
+{
+    try {
+        const int rc = [&]() -> int {
+            #define RUN(ALIGNER) { \
+                auto al = ALIGNER; typedef PackedTracebackStream<decltype(al)> stream_type; \
+                const stream_type st(al, n, read_offsets, reads, longest_read, window_offsets, windows, longest_window, scores, \
+                                     reinterpret_cast<uint2*>(sinks), reinterpret_cast<uint2*>(sources), cigars, cigar_stride, cigar_lens); \
+                if (band == 0)       { aln::BatchedAlignmentTraceback<64, stream_type> b; b.enact(st); } \
+                else if (band == 15) { aln::BatchedBandedAlignmentTraceback<15, 64, stream_type> b; b.enact(st); } \
+                else if (band == 31) { aln::BatchedBandedAlignmentTraceback<31, 64, stream_type> b; b.enact(st); } \
+                else return 1; \
+                return hipDeviceSynchronize() == hipSuccess ? 0 : 3; }
+            #define TYPED(TYPE) \
+                if (kind == 0) RUN(aln::make_gotoh_aligner<TYPE>(aln::SimpleGotohScheme(sc[0], sc[1], sc[2], sc[3]))) \
+                if (kind == 1) RUN(aln::make_smith_waterman_aligner<TYPE>(aln::SimpleSmithWatermanScheme(sc[0], sc[1], sc[2], sc[3]))) \
+                if (kind == 2) RUN(aln::make_edit_distance_aligner<TYPE>())
+            if (type == 0) { TYPED(aln::GLOBAL) } else if (type == 1) { TYPED(aln::LOCAL) } else { TYPED(aln::SEMI_GLOBAL) }
+            #undef TYPED
+            #undef RUN
+            return 1;
+        }();
+        return rc;
+    } catch (const std::exception&) { return 2; }
+}

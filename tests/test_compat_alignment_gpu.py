@@ -228,16 +228,17 @@ def test_full_matrix_generic_lanes(callers, typ, tag, kind, scheme):
 
 
 def test_full_matrix_long_patterns_and_host(callers):
-    """patterns beyond the tuned sweep's 512 rows run on the generic lanes; HostThreadScheduler on the host"""
+    """patterns to 1024 symbols run on the tuned sweep (16 rows per lane), longer ones on the generic lanes; HostThreadScheduler on the host"""
     rng = np.random.default_rng(8)
-    reads = [rng.integers(0, 4, int(rng.integers(400, 900)), dtype=np.uint8) for _ in range(60)]
-    wins = [np.concatenate([rng.integers(0, 4, 30, dtype=np.uint8), r, rng.integers(0, 4, 30, dtype=np.uint8)]) for r in reads]
-    quals = [np.zeros(len(r), np.uint8) for r in reads]
-    b = Batch(reads, quals, wins, packed=True, on_device=True)
-    assert run_full(callers, b, 0, 0, 0, LOCAL, 0, (2, -1, -2, -1), None) == "generic"
-    es, ek, _ = O.batch_score_pattern_blocking(0, LOCAL, (2, -1, -2, -1), b.hr, b.hw)
-    gs, gk = b.results()
-    assert (gs == es).all() and (gk == ek).all()
+    for lo, hi, path in ((400, 900, "tuned"), (1030, 1300, "generic")):
+        reads = [rng.integers(0, 4, int(rng.integers(lo, hi)), dtype=np.uint8) for _ in range(60)]
+        wins = [np.concatenate([rng.integers(0, 4, 30, dtype=np.uint8), r, rng.integers(0, 4, 30, dtype=np.uint8)]) for r in reads]
+        quals = [np.zeros(len(r), np.uint8) for r in reads]
+        b = Batch(reads, quals, wins, packed=True, on_device=True)
+        assert run_full(callers, b, 0, 0, 0, LOCAL, 0, (2, -1, -2, -1), None) == path
+        es, ek, _ = O.batch_score_pattern_blocking(0, LOCAL, (2, -1, -2, -1), b.hr, b.hw)
+        gs, gk = b.results()
+        assert (gs == es).all() and (gk == ek).all()
     bh = Batch(reads, quals, wins, packed=True, on_device=False)
     assert run_full(callers, bh, 0, 1, 0, SEMI, 1, (2, -1, -2, -1), None) == "host"
     es, ek, _ = O.batch_gotoh_score(SEMI, (2, -1, -2, -1), bh.hr, bh.hw)
@@ -253,3 +254,43 @@ def test_per_thread_function_in_a_user_kernel(callers):
     assert callers.compat_per_thread_score(sc.ctypes.data, b.n, b.ptr("ro"), b.ptr("r"), b.ptr("wo"), b.ptr("w"), C.c_void_p(b.score.data_ptr())) == 0
     es, _ = O.batch_banded_gotoh_score(7, SEMI, (2, -1, -1, -1), b.hr, b.hw)
     assert (b.score.cpu().numpy() == es).all()
+
+
+# ---------------------------------------------------------------------------- traceback streams
+@pytest.mark.parametrize("typ", [GLOBAL, LOCAL, SEMI])
+@pytest.mark.parametrize("band", [15, 31, 0])
+def test_traceback_stream_with_a_user_backtracer(callers, typ, band):
+    """BatchedBandedAlignmentTraceback / BatchedAlignmentTraceback over a stream written to the reference's traceback concept
+    (context {min_score, backtracer, alignment}): the caller's own backtracer must receive clip / push / clip exactly as the
+    reference's per-job body issues them, so the run-length CIGAR it forms, and the Alignment handed to output(), equal the
+    oracle's; declined jobs are output untouched; jobs whose text is shorter than the pattern get no backtracer call."""
+    callers.compat_traceback.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    reads, quals, wins = make_jobs(4100 + 10 * typ + band, 900, max_read=120, band=band or 31, max_sym=3, full=(band == 0))
+    b = Batch(reads, quals, wins, packed=True, on_device=True)
+    stride = 200
+    for kind, scheme in ((0, (2, -2, -4, -1)), (1, (2, -1, -1, -1)), (2, (0, -1, -1, -1))):
+        sc = np.array(scheme, dtype=np.int32)
+        score = dev(np.full(b.n, 12345, np.int32)); sink = dev(np.full((b.n, 2), 777, np.int32)); source = dev(np.full((b.n, 2), 777, np.int32))
+        cigar = dev(np.zeros((b.n, stride), np.int16)); clen = dev(np.full(b.n, 999, np.int32))
+        rc = callers.compat_traceback(kind, typ, band, sc.ctypes.data, b.n, b.ptr("ro"), b.ptr("r"), b.longest_read, b.ptr("wo"), b.ptr("w"), b.longest_win,
+                                      C.c_void_p(score.data_ptr()), C.c_void_p(sink.data_ptr()), C.c_void_p(source.data_ptr()), C.c_void_p(cigar.data_ptr()), stride,
+                                      C.c_void_p(clen.data_ptr()))
+        assert rc == 0
+        if kind == 0:
+            exp = O.batch_banded_gotoh_traceback(band, typ, scheme, b.hr, b.hw, stride) if band else O.batch_gotoh_traceback(typ, scheme, b.hr, b.hw, stride)
+        else:
+            exp = O.batch_sw_traceback(band, typ, scheme, b.hr, b.hw, stride)
+        gs, gk, gsrc = score.cpu().numpy(), sink.cpu().numpy().view(np.uint32), source.cpu().numpy().view(np.uint32)
+        gc, gl = cigar.cpu().numpy().view(np.uint16), clen.cpu().numpy().view(np.uint32)
+        declined = (np.arange(b.n) % 53) == 52
+        # (an empty pattern makes the reference's full-matrix pattern-blocking pass read uninitialised cells -- oracle/nvbio_oracle.c,
+        # score_pattern_blocking: nothing to compare there)
+        live = ~declined & ((np.diff(b.ro) > 0) | (band != 0))
+        assert (gs[declined] == -77).all() and (gk[declined] == 7).all() and (gl[declined] == 0).all()
+        assert (gs[live] == exp["score"][live]).all(), (typ, band, kind)
+        assert (gk[live] == exp["sink"][live]).all() and (gsrc[live] == exp["source"][live]).all(), (typ, band, kind)
+        assert (gl[live] == exp["cigar_len"][live]).all(), (typ, band, kind)
+        mask = (np.arange(stride)[None, :] < exp["cigar_len"][:, None]) & live[:, None]
+        assert ((gc == exp["cigar"]) | ~mask).all(), (typ, band, kind)
+        assert int(exp["cigar_len"][live].max()) < stride
