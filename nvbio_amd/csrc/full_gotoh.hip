@@ -320,7 +320,8 @@ struct Sweep16
             if (PBX) rmax[k] = 0x8000u;
             if (CHECK) lim[k] = (uint32_t(k) <= kl) ? 0x7FFFu : 0x8000u;
         }
-        out_hg = out_f = out_ch = out_cm = prev_in_hg = 0;
+        out_hg = out_f = out_ch = out_cm = 0;
+        prev_in_hg = (lane == 0u) ? go : 0u;          // lane 0's first diagonal: the corner above the matrix, H(-1,-1) = 0
         sg_score = -(1 << 30); sg_col = 0; exit_col = 0xFFFFFFFFu; grp = 0; sg_hg16 = 0x8000u;
         top_hg = c16(p.row_go + Go); top_prev_hg = go;
         init_above_g = c16(((TYPE != NVBIO_HIP_LOCAL) ? p.col_go + p.col_ge * int32_t(lane * R - 1u) : 0) + Go * SC);
@@ -355,9 +356,11 @@ struct Sweep16
         const uint32_t in_f  = uint32_t(dpp_shr1(int32_t(inf16), int32_t(out_f)));
         const uint32_t in_ch = uint32_t(dpp_shr1(int32_t(ch0), int32_t(out_ch)));
         const uint32_t in_cm = CHECK ? uint32_t(dpp_shr1(int32_t(0x8000u), int32_t(out_cm))) : 0u;
+        // HG(r-1, c-1): what came down the lanes one step ago.  Lane 0 needs no case of its own -- its in_hg is the row above the matrix,
+        // th, so one step ago it was that row's previous column (prev_in_hg starts as the corner) -- and a lane's first column (the
+        // boundary column's value instead) only occurs while lanes are still entering the matrix.
         uint32_t diag_g = prev_in_hg;
-        if (lane == 0u) diag_g = (TYPE == NVBIO_HIP_GLOBAL) ? top_prev_hg : go;
-        else if (c == 0u) diag_g = init_above_g;
+        if (PRED && lane != 0u && c == 0u) diag_g = init_above_g;
         prev_in_hg = in_hg;
         if (TYPE == NVBIO_HIP_GLOBAL) { top_prev_hg = top_hg; uint32_t t; asm("v_add_u16 %0, %1, %2" : "=v"(t) : "v"(top_hg), "v"(rge)); top_hg = t; }
 
@@ -415,8 +418,8 @@ struct Sweep16
     {
         const uint32_t n_steps = Ncols + lane_last;
         uint32_t s = 0;
-        // ramp-up, up to the first 16-aligned step at which every row-holding lane is inside the matrix
-        const uint32_t s_fast = (lane_last + 15u) & ~15u;
+        // ramp-up, up to the first 16-aligned step at which every row-holding lane is inside the matrix and past its first column
+        const uint32_t s_fast = (lane_last + 16u) & ~15u;         // (strictly past every lane's first column: step() tests for that column only while PRED)
         // (a wave owns one job: the text group is wave-uniform, so the symbol -> selector arithmetic runs on the scalar unit)
         auto sel = [](const uint32_t g) { return 0x0C0C0100u + 0x0202u * g; };
         for (; s < n_steps && s < s_fast; ++s)
