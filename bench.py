@@ -89,6 +89,7 @@ def parse():
     ap.add_argument("--no-rank", action="store_true")
     ap.add_argument("--only", choices=["dp", "rank", "seed", "e2e", "full", "extras"], default=None, help="profiling aid: run just one leg, print its object")
     ap.add_argument("--seeds", type=int, default=50_000_000)
+    ap.add_argument("--pairs", type=int, default=500_000, help="read pairs of the paired-end driver leg inside the e2e leg (0 = skip)")
     ap.add_argument("--no-seed", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-full", action="store_true")
@@ -536,6 +537,27 @@ def e2e_leg(a, dev, fmi, text):
         res["config4_full_size"]["two_batches_in_flight"] = {"ms_total_wall": wall, "Mreads_per_s": tot / wall / 1e3,
                                                              "identical_to_serial": all(torch.equal(outs2[b], serial_best[b]) for b in range(a.e2e_batches))}
         del idx, inputs, serial_best, outs2
+    # BASELINE config 5's shape in the default run: nvBowtie's paired-end driver (2 x 150 bp FR pairs, --local: 20-bp seeds, LOCAL band 31
+    # in the quality-aware local scheme, opposite mates by full-matrix DP, paired reduction, MAPQ, tracebacks) on this 3 Gbp index,
+    # line-native.  (Its parity sample against the oracle driver is in the extras leg, on a 1 Gbp index with a reverse index too.)
+    if a.pairs > 0:
+        npairs = a.pairs
+        s1, s2, ppos, pflen = P.make_read_pairs(text, npairs, 150, seed=0x5EED0009)
+        pnames = SEL.pack_names(["p%d" % i for i in range(npairs)], dev)
+        idx = fmi.with_dimer()
+        prm5 = AL.Params(hits_stride=32, batch_size=npairs, local=True, seed_len=20, seed_freq=(2, 1.0, 0.75))
+        runp = lambda st=False: AL.best_approx_paired(idx, None, s1, s2, genome_words, ng, prm5, names=pnames, stage_times=st)
+        msp = _timed(runp, reps=2)
+        r = runp(True)
+        b0 = r["best"][0]
+        conc = (((b0 >> 30) & 1) != 0) & (((b0 >> 31) & 1) == 0)
+        a_pos = (b0 >> 32) & 0xFFFFFFFF
+        ok_pos = (((a_pos - ppos).abs() <= 3) | ((a_pos - (ppos + pflen - 150)).abs() <= 3)) & conc
+        res["config5_shape_paired_end"] = {"pairs": npairs, "index": "line_native", "ms_per_batch": msp, "Mpairs_per_s": npairs / msp / 1e3,
+                                           "anchor_extensions": r["stats"]["extensions"], "opposite_dp_jobs": r.get("opposite_dp_jobs"),
+                                           "concordant": float(conc.float().mean().item()), "concordant_at_fragment_end": float(ok_pos.float().mean().item()),
+                                           "stage_ms": {k: round(v, 3) for k, v in r["stats"]["ms"].items()}}
+        del idx, r, s1, s2
     res["reads"] = n
     res["genome_symbols"] = ng
     return res
