@@ -557,10 +557,61 @@ def e2e_leg(a, dev, fmi, text):
                                            "anchor_extensions": r["stats"]["extensions"], "opposite_dp_jobs": r.get("opposite_dp_jobs"),
                                            "concordant": float(conc.float().mean().item()), "concordant_at_fragment_end": float(ok_pos.float().mean().item()),
                                            "stage_ms": {k: round(v, 3) for k, v in r["stats"]["ms"].items()}}
+        res["config5_shape_paired_end"]["cxx"] = cxx_paired_leg(dev, idx, s1, s2, genome_words, ng, pnames, prm5, b0)
         del idx, r, s1, s2
     res["reads"] = n
     res["genome_symbols"] = ng
     return res
+
+
+def cxx_paired_leg(dev, idx, s1, s2, genome_words, ng, names, prm, ref_best0):
+    """The C++ paired-end driver (Aligner::best_approx over a PairedReadBatch, include/nvbio_hip/aligner.h) on the same pairs: mean wall
+    time of 3 batches with one Aligner object (tests/cxx/aligner_shim.cpp: nvbio_aligner_best_approx_paired_timed)."""
+    import ctypes as C
+    from nvbio_amd import pipeline as P
+    shim_path = os.path.join(ROOT, "tests", "cxx", "libaligner_shim.so")
+    if not os.path.exists(shim_path):
+        return {"error": "tests/cxx/libaligner_shim.so is missing (python __graft_entry__.py builds it)"}
+    shim = C.CDLL(shim_path)
+    n, L = s1.shape
+    packed = [P.pack_read_streams(s) for s in (s1, s2)]
+    quals = torch.full((2 * n * L + 8,), 30, dtype=torch.uint8, device=dev)
+    both = torch.cat([packed[0][1], packed[1][1]]); mate_offset = packed[0][1].numel() * 8
+    both_q = torch.full((mate_offset + 2 * n * L + 8,), 30, dtype=torch.uint8, device=dev)
+    arena, nidx = names
+    scheme = nvb.SmithWatermanScoringScheme.local() if prm.local else nvb.SmithWatermanScoringScheme()
+
+    class ShimParams(C.Structure):
+        _fields_ = [(k, C.c_uint32) for k in ("local", "randomized", "top_seed", "max_effort_init", "max_effort", "min_ext", "max_ext", "max_reseed", "rep_seeds",
+                                              "max_hits", "allow_sub", "subseed_len", "seed_len", "seed_freq_type", "min_read_len", "max_dist", "no_multi_hits",
+                                              "batch_size", "hits_stride")] + \
+                   [("seed_freq_k", C.c_float), ("seed_freq_m", C.c_float), ("match", C.c_int32), ("score_min_type", C.c_int32),
+                    ("score_min_k", C.c_float), ("score_min_m", C.c_float), ("finish", C.c_uint32)]
+
+    class ShimPeParams(C.Structure):
+        _fields_ = [("pe_policy", C.c_int32)] + [(k, C.c_uint32) for k in ("pe_overlap", "pe_unpaired", "pe_discordant", "min_frag_len", "max_frag_len")]
+    p = prm
+    sp = ShimParams(int(p.local), int(p.randomized), p.top_seed, p.max_effort_init, p.max_effort, p.min_ext, p.max_ext, p.max_reseed, p.rep_seeds, p.max_hits,
+                    p.allow_sub, p.subseed_len, p.seed_len, p.seed_freq[0], p.min_read_len, p.max_dist, int(p.no_multi_hits), p.batch_size, p.hits_stride or 0,
+                    p.seed_freq[1], p.seed_freq[2], scheme.m_match, scheme.m_score_min[0], scheme.m_score_min[1], scheme.m_score_min[2], 0)
+    pp = ShimPeParams(p.pe_policy, int(p.pe_overlap), int(p.pe_unpaired), int(p.pe_discordant), p.min_frag_len, p.max_frag_len)
+    pair_ptrs = lambda ts: (C.c_void_p * 2)(*[t.data_ptr() for t in ts])
+    u64x2 = lambda v: (C.c_uint64 * 2)(*v)
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    fs = idx.struct()
+    ms, stage, stats = (C.c_double * 1)(), (C.c_double * 10)(), (C.c_uint64 * 12)()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()                   # the C++ driver allocates its own workspace: give it what torch's allocator has cached
+    rc = shim.nvbio_aligner_best_approx_paired_timed(
+        C.byref(fs), None, C.c_uint32(n), C.c_uint32(L),
+        pair_ptrs([packed[0][0].words, packed[1][0].words]), u64x2([packed[0][0].words.numel(), packed[1][0].words.numel()]), pair_ptrs([packed[0][0].begin, packed[1][0].begin]),
+        pair_ptrs([packed[0][1], packed[1][1]]), u64x2([packed[0][1].numel(), packed[1][1].numel()]), vp(quals), C.c_uint64(quals.numel()), vp(arena), vp(nidx),
+        vp(both), C.c_uint64(both.numel()), C.c_uint64(mate_offset), vp(both_q), C.c_uint64(both_q.numel()),
+        vp(genome_words), C.c_uint64(genome_words.numel()), C.c_uint32(ng), C.byref(sp), C.byref(pp), C.c_uint32(3), ms, stage, stats)
+    if rc != 0:
+        return {"error": "nvbio_aligner_best_approx_paired_timed returned %d" % rc}
+    return {"driver": "nvbio::bowtie2::cuda::Aligner::best_approx(PairedReadBatch) (include/nvbio_hip/aligner.h)", "ms_per_batch": ms[0], "Mpairs_per_s": n / ms[0] / 1e3,
+            "anchor_extensions": int(stats[0]), "rounds": int(stats[1])}
 
 
 def cxx_driver_leg(a, dev, idx, sym, packed, genome_words, ng, names, prm, ref_best, ref_mapq):

@@ -140,15 +140,15 @@ struct shim_pe_params { int32_t pe_policy; uint32_t pe_overlap, pe_unpaired, pe_
 
 // the paired-end driver: per mate {reversed words, begin, fw+rc words, quals, names}, the joint pattern stream of the tracebacks;
 // outputs per slot set: best[2n], mapq[n], cigar[n*64], cigar_len[n], source[2n], sink[2n], mds[n*256], mds_len[n]
-extern "C" __attribute__((visibility("default")))
-int nvbio_aligner_best_approx_paired(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmindex* rfmi, uint32_t n, uint32_t L,
+static int paired_impl(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmindex* rfmi, uint32_t n, uint32_t L,
                                      const uint32_t* const* d_rev_words, const uint64_t* rev_n_words, const uint64_t* const* d_rev_begin,
                                      const uint32_t* const* d_fwrc_words, const uint64_t* fwrc_n_words, const uint8_t* d_quals, uint64_t n_quals,
                                      const char* d_names, const uint32_t* d_names_idx,
                                      const uint32_t* d_both_words, uint64_t both_n_words, uint64_t mate_offset, const uint8_t* d_both_quals, uint64_t both_n_quals,
                                      const uint32_t* d_genome_words, uint64_t genome_n_words, uint32_t genome_len, const shim_params* sp, const shim_pe_params* pp,
                                      uint64_t* const* h_best, uint8_t* const* h_mapq, uint16_t* const* h_cigar, uint32_t* const* h_cigar_len, uint32_t* const* h_source,
-                                     uint32_t* const* h_sink, uint8_t* const* h_mds, uint32_t* const* h_mds_len, uint64_t* h_stats)
+                                     uint32_t* const* h_sink, uint8_t* const* h_mds, uint32_t* const* h_mds_len, uint64_t* h_stats,
+                                     uint32_t reps, double* out_ms, double* out_stage_ms /* 10 */)
 {
     try {
         Params params;
@@ -184,9 +184,30 @@ int nvbio_aligner_best_approx_paired(const nvbio_hip_fmindex* fmi, const nvbio_h
         aligner.init_paired();
         Stats stats;
         aligner.best_approx(params, pe, f, rf, scheme, limits, d_genome_words, genome_n_words, genome_len, reads, stats);
+        if (reps)
+        {
+            // timed mode: the batch above sized the workspace; one more warm-up, then `reps` batches on the wall clock, then one with the stage clock
+            { Stats warm; aligner.best_approx(params, pe, f, rf, scheme, limits, d_genome_words, genome_n_words, genome_len, reads, warm); }
+            hip::synchronize();
+            double total = 0.0;
+            for (uint32_t r = 0; r < reps; ++r)
+            {
+                stats = Stats();
+                const auto t0 = std::chrono::steady_clock::now();
+                aligner.best_approx(params, pe, f, rf, scheme, limits, d_genome_words, genome_n_words, genome_len, reads, stats);
+                hip::synchronize();
+                total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            }
+            out_ms[0] = total / reps;
+            Stats timed; timed.clock.enabled = true;
+            aligner.best_approx(params, pe, f, rf, scheme, limits, d_genome_words, genome_n_words, genome_len, reads, timed);
+            hip::synchronize();
+            const char* names[10] = { "map", "select_init", "select", "locate", "anchor_score", "opposite_score", "reduce", "mapq", "traceback", "finish" };
+            for (int k = 0; k < 10; ++k) out_stage_ms[k] = timed.clock.ms.count(names[k]) ? timed.clock.ms[names[k]] : 0.0;
+        }
 
         const uint32_t B = aligner.BATCH_SIZE;
-        for (int slot = 0; slot < 2; ++slot) {
+        for (int slot = 0; slot < 2 && h_best; ++slot) {
             const std::vector<io::Alignment> best = (slot ? aligner.best_data_dvec_o : aligner.best_data_dvec).to_host();
             for (uint32_t i = 0; i < n; ++i) { memcpy(&h_best[slot][i], &best[i], 8); memcpy(&h_best[slot][n + i], &best[B + i], 8); }
             const std::vector<uint8> mq = (slot ? aligner.mapq_dvec_o : aligner.mapq_dvec).to_host();              memcpy(h_mapq[slot], mq.data(), n);
@@ -201,6 +222,36 @@ int nvbio_aligner_best_approx_paired(const nvbio_hip_fmindex* fmi, const nvbio_h
         for (size_t k = 0; k < stats.queue.size() && k < 8; ++k) h_stats[4 + k] = stats.queue[k];
         return 0;
     } catch (const nvbio::hip_error& e) { fprintf(stderr, "aligner_shim: %s\n", e.what()); return 1; }
+}
+
+extern "C" __attribute__((visibility("default")))
+int nvbio_aligner_best_approx_paired(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmindex* rfmi, uint32_t n, uint32_t L,
+                                     const uint32_t* const* d_rev_words, const uint64_t* rev_n_words, const uint64_t* const* d_rev_begin,
+                                     const uint32_t* const* d_fwrc_words, const uint64_t* fwrc_n_words, const uint8_t* d_quals, uint64_t n_quals,
+                                     const char* d_names, const uint32_t* d_names_idx,
+                                     const uint32_t* d_both_words, uint64_t both_n_words, uint64_t mate_offset, const uint8_t* d_both_quals, uint64_t both_n_quals,
+                                     const uint32_t* d_genome_words, uint64_t genome_n_words, uint32_t genome_len, const shim_params* sp, const shim_pe_params* pp,
+                                     uint64_t* const* h_best, uint8_t* const* h_mapq, uint16_t* const* h_cigar, uint32_t* const* h_cigar_len, uint32_t* const* h_source,
+                                     uint32_t* const* h_sink, uint8_t* const* h_mds, uint32_t* const* h_mds_len, uint64_t* h_stats)
+{
+    return paired_impl(fmi, rfmi, n, L, d_rev_words, rev_n_words, d_rev_begin, d_fwrc_words, fwrc_n_words, d_quals, n_quals, d_names, d_names_idx, d_both_words, both_n_words,
+                       mate_offset, d_both_quals, both_n_quals, d_genome_words, genome_n_words, genome_len, sp, pp, h_best, h_mapq, h_cigar, h_cigar_len, h_source, h_sink,
+                       h_mds, h_mds_len, h_stats, 0u, nullptr, nullptr);
+}
+// the same driver on the wall clock (bench.py: e2e_leg.config5_shape_paired_end.cxx): mean of `reps` batches with one Aligner object,
+// stage times from one more; only the best alignments of both slot sets come back (host, 2n words each)
+extern "C" __attribute__((visibility("default")))
+int nvbio_aligner_best_approx_paired_timed(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmindex* rfmi, uint32_t n, uint32_t L,
+                                     const uint32_t* const* d_rev_words, const uint64_t* rev_n_words, const uint64_t* const* d_rev_begin,
+                                     const uint32_t* const* d_fwrc_words, const uint64_t* fwrc_n_words, const uint8_t* d_quals, uint64_t n_quals,
+                                     const char* d_names, const uint32_t* d_names_idx,
+                                     const uint32_t* d_both_words, uint64_t both_n_words, uint64_t mate_offset, const uint8_t* d_both_quals, uint64_t both_n_quals,
+                                     const uint32_t* d_genome_words, uint64_t genome_n_words, uint32_t genome_len, const shim_params* sp, const shim_pe_params* pp,
+                                     uint32_t reps, double* out_ms, double* out_stage_ms, uint64_t* h_stats)
+{
+    return paired_impl(fmi, rfmi, n, L, d_rev_words, rev_n_words, d_rev_begin, d_fwrc_words, fwrc_n_words, d_quals, n_quals, d_names, d_names_idx, d_both_words, both_n_words,
+                       mate_offset, d_both_quals, both_n_quals, d_genome_words, genome_n_words, genome_len, sp, pp, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, h_stats, reps ? reps : 1u, out_ms, out_stage_ms);
 }
 
 // the all-mapping driver (Aligner::all): outputs for up to out_cap alignments; *h_n = how many there are
