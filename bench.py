@@ -611,7 +611,8 @@ def cxx_paired_leg(dev, idx, s1, s2, genome_words, ng, names, prm, ref_best0):
     if rc != 0:
         return {"error": "nvbio_aligner_best_approx_paired_timed returned %d" % rc}
     return {"driver": "nvbio::bowtie2::cuda::Aligner::best_approx(PairedReadBatch) (include/nvbio_hip/aligner.h)", "ms_per_batch": ms[0], "Mpairs_per_s": n / ms[0] / 1e3,
-            "anchor_extensions": int(stats[0]), "rounds": int(stats[1])}
+            "anchor_extensions": int(stats[0]), "rounds": int(stats[1]),
+            "stage_ms": {k: round(stage[i], 3) for i, k in enumerate(("map", "select_init", "select", "locate", "anchor_score", "opposite_score", "reduce", "mapq", "traceback", "finish"))}}
 
 
 def cxx_driver_leg(a, dev, idx, sym, packed, genome_words, ng, names, prm, ref_best, ref_mapq):

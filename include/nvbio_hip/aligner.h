@@ -487,27 +487,28 @@ private:
                 stats.queue.push_back(seed_queue_size); ++stats.seeding_passes;
                 hip_check(nvbio_hip_memset(hit_counts.data(), 0, uint64(count) * 4u, hip_stream), "nvbio_hip_memset");
                 const PingPongQueuesView seed_queues = { seed_queue_size, seed_queue_in.data() };
-                map(a_reads.reversed, fmi, rfmi, seeding_pass, seed_queues, reseed.data(), hits, params, seed_freq.data(), fw, rc, hip_stream);
+                stats.clock.run("map", hip_stream, [&] { map(a_reads.reversed, fmi, rfmi, seeding_pass, seed_queues, reseed.data(), hits, params, seed_freq.data(), fw, rc, hip_stream); });
 
                 // best_approx_score (:455-700)
                 hip_check(nvbio_hip_pack_read_queue(seed_queue_size, seed_queue_in.data(), params.select.top_seed & 1u, reinterpret_cast<uint32*>(queues.active_in.data()), hip_stream),
                           "nvbio_hip_pack_read_queue");
                 queues.in_size = seed_queue_size;
-                select_init(count, a_reads.names, a_reads.names_idx, hits, state, params.select, hip_stream);
+                stats.clock.run("select_init", hip_stream, [&] { select_init(count, a_reads.names, a_reads.names_idx, hits, state, params.select, hip_stream); });
                 uint32 n_ext = 0;
                 while (queues.in_size && n_ext < params.select.max_ext)
                 {
                     uint32 n_hits_per_read = 1;
                     if (queues.in_size <= SCORING_BATCH / 2 && !params.no_multi_hits)
                         n_hits_per_read = std::min(SCORING_BATCH / queues.in_size, std::min(4096u, params.select.max_ext - n_ext));
-                    select(hits, state, queues, n_hits_per_read, params.select, hip_stream);
+                    stats.clock.run("select", hip_stream, [&] { select(hits, state, queues, n_hits_per_read, params.select, hip_stream); });
                     if (queues.in_size == 0) break;
                     if (queues.hits_size == 0) continue;
-                    locate(fmi, rfmi, queues, hip_stream);
+                    stats.clock.run("locate", hip_stream, [&] { locate(fmi, rfmi, queues, hip_stream); });
                     const uint32 nh = queues.hits_size;
                     const uint32* hit_seed = reinterpret_cast<const uint32*>(queues.hit_seed.data());
 
                     // anchor_score_best
+                    stats.clock.begin("anchor_score", hip_stream);
                     hip_check(nvbio_hip_anchor_score_setup(nh, queues.hit_read_id.data(), queues.hit_loc.data(), hit_seed, nullptr, nullptr, nullptr, L, L, a_reads.rc_offset,
                                                            band_len, genome_len, best, best_o, BATCH_SIZE, sc.match, min_score_table.data(), worst_score, anchor,
                                                            pat_begin.data(), nullptr, txt_begin.data(), txt_len.data(), min_score.data(), hip_stream), "nvbio_hip_anchor_score_setup");
@@ -521,8 +522,10 @@ private:
                     }
                     hip_check(nvbio_hip_anchor_score_finish(nh, raw_score.data(), sinks.data(), txt_begin.data(), min_score.data(), worst_score, hit_score.data(), hit_sink.data(), hip_stream),
                               "nvbio_hip_anchor_score_finish");
+                    stats.clock.end("anchor_score", hip_stream);
 
                     // opposite_score_best over the hits whose anchor scored: every hit gets a job, the invalid ones an empty text
+                    stats.clock.begin("opposite_score", hip_stream);
                     hip_check(nvbio_hip_opposite_score_setup(nh, queues.hit_read_id.data(), hit_seed, queues.hit_loc.data(), hit_score.data(), worst_score, nullptr, nullptr, L, L,
                                                              best, best_o, BATCH_SIZE, sc.match, min_score_table.data(), sc.text_gap_open, sc.text_gap_ext, &app,
                                                              o_valid.data(), min_score.data(), o_rc.data(), o_gbegin.data(), o_gend.data(),
@@ -543,13 +546,16 @@ private:
                     hip_check(nvbio_hip_opposite_memo_update(queues.in_size, reinterpret_cast<const uint32*>(queues.active_in.data()), queues.hit_begin.data(), o_valid.data(), o_rc.data(),
                                                              o_gbegin.data(), o_gend.data(), min_score.data(), o_score.data(), o_sink.data(), anchor, memo.data(), hip_stream),
                               "nvbio_hip_opposite_memo_update");
+                    stats.clock.end("opposite_score", hip_stream);
 
                     // score_reduce_paired with the give-up counters
+                    stats.clock.begin("reduce", hip_stream);
                     hip_check(nvbio_hip_score_reduce_paired_best_approx(queues.in_size, reinterpret_cast<const uint32*>(queues.active_in.data()), queues.hit_begin.data(),
                                   queues.hit_loc.data(), hit_sink.data(), hit_score.data(), hit_seed, o_loc.data(), o_sink.data(), o_sink2.data(), o_score.data(), o_score2.data(),
                                   nullptr, L, anchor, pe.pe_policy, pe.pe_unpaired ? 1 : 0, worst_score, best, best_o, BATCH_SIZE,
                                   state.trys.data(), hit_counts.data(), n_ext, params.select.min_ext, params.select.max_ext, params.select.max_effort, hip_stream),
                               "nvbio_hip_score_reduce_paired_best_approx");
+                    stats.clock.end("reduce", hip_stream);
                     stats.extensions += nh; ++stats.rounds;
                     n_ext += n_hits_per_read;
                 }
@@ -570,6 +576,7 @@ private:
                                         mapq_dvec.data(), hip_stream), "nvbio_hip_mapq_paired");
 
         // tracebacks + finish: anchor slots (banded), opposite slots (full matrix for the concordant ones, banded for the others)
+        stats.clock.begin("traceback", hip_stream);
         const uint64 rc_offset = reads.mate[0].rc_offset;
         hip::device_vector<uint8>  valid(count), valid_c(count);
         hip::device_vector<uint64> tb_pat(count), tb_txt(count);
@@ -643,6 +650,7 @@ private:
             hip::synchronize(hip_stream);
         }
         hip::synchronize(hip_stream);
+        stats.clock.end("traceback", hip_stream);
     }
 
     /// the static band of banded_score_best / banded_traceback_best (score_best_inl.h:160-164)
