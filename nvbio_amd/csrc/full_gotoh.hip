@@ -636,6 +636,112 @@ static hipError_t launch_full(const FullParams& p, int type, hipStream_t s)
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Edit distance (EditDistanceAligner: match 0, mismatch -1, deletion = insertion = -1; sw-benchmark's second leg,
+// sw-benchmark.cu:641-657) without the matrix: with unit costs adjacent cells differ by -1, 0 or +1, so a column is two bit-vectors
+// of vertical differences and advancing it by one text symbol is a dozen word operations per 64 pattern rows (Myers 1999, in
+// the block form of Hyyro 2003: a carry h_in / h_out of -1, 0, +1 between the 64-row words).  What the reference reports is a
+// function of the last row only -- SEMI_GLOBAL: every H(i, M) in text order into a BestSink (the last best column wins), GLOBAL:
+// H(N, M) -- which the running value of the last row gives exactly; with no min_score the reference never exits early, and its
+// int16 boundary column is exact in the range the host admits here.  One lane per job; 150 x 16 384: ~100 word operations per
+// column instead of 150 cells.  LOCAL, min_score and other costs stay on the sweep.
+// ---------------------------------------------------------------------------------------------
+template <int TYPE, int W>       // W 64-row words: patterns to 64 * W
+__global__ void __launch_bounds__(256) edit_distance_bitvector_kernel(const FullParams p)
+{
+    const uint32_t job = blockIdx.x * 256u + threadIdx.x;
+    if (job >= p.n) return;
+    const uint32_t M  = p.pat.length ? p.pat.length[job] : p.pat.fixed_length;
+    const uint32_t N  = p.txt.length ? p.txt.length[job] : p.txt.fixed_length;
+    const uint64_t pb = p.pat.begin[job], tb = p.txt.begin[job];
+    int32_t score = -(1 << 30); uint32_t sx = 0xFFFFFFFFu, sy = 0xFFFFFFFFu; uint32_t ok = 1u;
+    if (M > p.max_m || N > p.max_n) ok = 0u;
+    else if (M == 0u)
+    {
+        if (N > 0u) {                                                    // as full_gotoh_score_kernel: only the row above the matrix is reported
+            if (TYPE == NVBIO_HIP_SEMI_GLOBAL) { score = 0; sx = N; sy = 0u; }
+            if (TYPE == NVBIO_HIP_GLOBAL)      { score = p.row_go + p.row_ge * int32_t(N - 1u); sx = N; sy = 0u; }
+        }
+    }
+    else if (N == 0u)
+    {
+        if (p.pattern_blocking != 0u && TYPE == NVBIO_HIP_GLOBAL) { score = p.col_go + p.col_ge * int32_t(M - 1u); sx = 0u; sy = M; }
+    }
+    else
+    {
+        uint64_t Peq[4][W];
+        #pragma unroll
+        for (int w = 0; w < W; ++w) { Peq[0][w] = Peq[1][w] = Peq[2][w] = Peq[3][w] = 0ull; }
+        #pragma unroll
+        for (int w = 0; w < W; ++w)
+        {
+            for (uint32_t g0 = 0; g0 < 64u && uint32_t(w) * 64u + g0 < M; g0 += 16u)
+            {
+                const uint32_t r0 = uint32_t(w) * 64u + g0;
+                const uint64_t grp = (p.pat.s.bits == 4) ? fetch16_4bit(p.pat.s, pb + r0) : expand_2to4(fetch16_2bit(p.pat.s, pb + r0));
+                const uint32_t cnt = min(16u, M - r0);
+                for (uint32_t k = 0; k < cnt; ++k)
+                {
+                    const uint32_t c = uint32_t(grp >> (4u * k)) & 15u;
+                    const uint64_t bit = 1ull << (g0 + k);
+                    Peq[0][w] |= (c == 0u) ? bit : 0ull; Peq[1][w] |= (c == 1u) ? bit : 0ull;
+                    Peq[2][w] |= (c == 2u) ? bit : 0ull; Peq[3][w] |= (c == 3u) ? bit : 0ull;      // N codes match nothing
+                }
+            }
+        }
+        uint64_t Pv[W], Mv[W];
+        #pragma unroll
+        for (int w = 0; w < W; ++w) { Pv[w] = ~0ull; Mv[w] = 0ull; }
+        const uint32_t lw = (M - 1u) >> 6, top = (M - 1u) & 63u;
+        int32_t  d = int32_t(M);                                          // D(M, 0)
+        int32_t  best_d = 0x7FFFFFFF; uint32_t best_i = 0u;
+        for (uint32_t i0 = 0; i0 < N; i0 += 16u)
+        {
+            const uint32_t tg = fetch16_2bit(p.txt.s, tb + i0);
+            const uint32_t cnt = min(16u, N - i0);
+            for (uint32_t u = 0; u < cnt; ++u)
+            {
+                const uint32_t c = (tg >> (2u * u)) & 3u;
+                int32_t hin = (TYPE == NVBIO_HIP_GLOBAL) ? 1 : 0;          // the row above the matrix: D(0, i) = i, or 0 with a free text start
+                int32_t dd = 0;
+                #pragma unroll
+                for (int w = 0; w < W; ++w)
+                {
+                    uint64_t Eq = (c == 0u) ? Peq[0][w] : (c == 1u) ? Peq[1][w] : (c == 2u) ? Peq[2][w] : Peq[3][w];
+                    const uint64_t Xv = Eq | Mv[w];
+                    if (hin < 0) Eq |= 1ull;
+                    const uint64_t Xh = (((Eq & Pv[w]) + Pv[w]) ^ Pv[w]) | Eq;
+                    uint64_t Ph = Mv[w] | ~(Xh | Pv[w]);
+                    uint64_t Mh = Pv[w] & Xh;
+                    if (uint32_t(w) == lw) dd = int32_t((Ph >> top) & 1ull) - int32_t((Mh >> top) & 1ull);
+                    const int32_t hout = int32_t(Ph >> 63) - int32_t(Mh >> 63);
+                    Ph <<= 1; Mh <<= 1;
+                    if (hin < 0) Mh |= 1ull; else if (hin > 0) Ph |= 1ull;
+                    Pv[w] = Mh | ~(Xv | Ph);
+                    Mv[w] = Ph & Xv;
+                    hin = hout;
+                }
+                d += dd;
+                if (TYPE == NVBIO_HIP_SEMI_GLOBAL) { if (d <= best_d) { best_d = d; best_i = i0 + u + 1u; } }
+            }
+        }
+        if (TYPE == NVBIO_HIP_SEMI_GLOBAL) { score = -best_d; sx = best_i; sy = M; }
+        else                               { score = -d;      sx = N;      sy = M; }
+    }
+    p.out_score[job] = score;
+    reinterpret_cast<uint2*>(p.out_sink)[job] = make_uint2(sx, sy);
+    if (p.out_ok) p.out_ok[job] = uint8_t(ok);
+}
+
+template <int W>
+static hipError_t launch_ed(const FullParams& p, int type, hipStream_t s)
+{
+    const dim3 grid((p.n + 255u) / 256u), block(256);
+    if (type == NVBIO_HIP_GLOBAL) hipLaunchKernelGGL((edit_distance_bitvector_kernel<NVBIO_HIP_GLOBAL, W>), grid, block, 0, s, p);
+    else                          hipLaunchKernelGGL((edit_distance_bitvector_kernel<NVBIO_HIP_SEMI_GLOBAL, W>), grid, block, 0, s, p);
+    return hipGetLastError();
+}
+
 } // namespace nvb
 
 using namespace nvb;
@@ -710,6 +816,21 @@ static int full_score_core(
     // (LOCAL runs x16: scores below 2048 and every cost below 2048 / 3 keep H, E, F, H + G_o and the diagonal sum inside int16)
     const bool fast = !trunc && maxN < (1u << 20) && (type != NVBIO_HIP_LOCAL || (scheme->match >= 0 && int64_t(maxM) * best_pair < 2048 && A * 3 < 2000))
                       && !(nofast && nofast[0] == '1');
+    // edit distance, no min_score, non-LOCAL: the bit-vector kernel (NVBIO_HIP_ED_SWEEP=1 keeps the sweep, for the tests)
+    {
+        const char* sweep_ed = getenv("NVBIO_HIP_ED_SWEEP");
+        const bool ed = !qual && blk_log2 == 4u && scheme->match == 0 && scheme->mismatch == -1 && scheme->gap_open == -1 && scheme->gap_ext == -1;
+        if (ed && !trunc && type != NVBIO_HIP_LOCAL && min_score == nullptr && maxM <= 512u && !(sweep_ed && sweep_ed[0] == '1'))
+        {
+            g_last_kernel = "edit_distance_bitvector_kernel";
+            const uint32_t words = (maxM + 63u) / 64u;
+            if (words <= 1u) return launch_ed<1>(p, type, s);
+            if (words <= 2u) return launch_ed<2>(p, type, s);
+            if (words <= 3u) return launch_ed<3>(p, type, s);
+            if (words <= 4u) return launch_ed<4>(p, type, s);
+            return launch_ed<8>(p, type, s);
+        }
+    }
     if (fast) {
         g_last_kernel = "full_gotoh_score_kernel<16-bit>";
         switch (R) { case 1: return launch_full<1, false, true>(p, type, s); case 2: return launch_full<2, false, true>(p, type, s);
@@ -755,7 +876,7 @@ NVB_API int nvbio_hip_sw_score(
     if (scheme->deletion != scheme->insertion) return hipErrorNotSupported;
     const nvbio_hip_gotoh_scheme g = { scheme->match, scheme->mismatch, scheme->deletion, scheme->deletion };
     const int e = full_score_core(&g, nullptr, type, 4u, 0u, patterns, texts, max_pattern_len, max_text_len, nullptr, n, out_score, out_sink, nullptr, stream);
-    if (e == hipSuccess && n) g_last_kernel = "full_gotoh_score_kernel<16-bit,sw>";
+    if (e == hipSuccess && n && g_last_kernel[0] != 'e') g_last_kernel = "full_gotoh_score_kernel<16-bit,sw>";       // ('e': the edit-distance kernel ran)
     return e;
 }
 

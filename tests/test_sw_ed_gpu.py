@@ -108,3 +108,57 @@ def test_asymmetric_costs_are_refused(cuda):
         nvb.batch_banded_alignment_score(15, al, to_dev(hp, cuda), to_dev(ht, cuda))
     with pytest.raises(RuntimeError):
         nvb.batch_alignment_score(al, to_dev(hp, cuda), to_dev(ht, cuda), 10, 30)
+
+
+@pytest.mark.parametrize("ty", [nvb.GLOBAL, nvb.SEMI_GLOBAL])
+@pytest.mark.parametrize("algorithm", ["text_blocking", "pattern_blocking"])
+def test_edit_distance_bitvector_kernel(cuda, ty, algorithm):
+    """The edit-distance aligner without a min_score runs on the bit-vector kernel (one lane per job, 64 pattern rows per word):
+    every word count (patterns to 512), ragged and empty strings, N symbols, texts shorter and much longer than the pattern, both
+    algorithm tags -- scores and sinks equal the oracle's and the sweep kernel's (NVBIO_HIP_ED_SWEEP=1)."""
+    from nvbio_amd._lib import lib
+    rng = np.random.default_rng(9500 + ty)
+    tag = nvb.PATTERN_BLOCKING if algorithm == "pattern_blocking" else nvb.TEXT_BLOCKING
+    for max_m, max_n, n in ((64, 300, 800), (100, 260, 800), (150, 900, 500), (192, 400, 400), (256, 700, 300), (400, 1000, 200), (512, 1500, 160)):
+        pats, txts = [], []
+        for i in range(n):
+            M = max_m if i % 5 == 0 else int(rng.integers(0 if i % 31 == 0 else 1, max_m + 1))
+            N = int(rng.integers(0 if i % 29 == 0 else 1, max_n + 1))
+            t = rng.integers(0, 4, N, dtype=np.uint8)
+            if N > M + 4 and M > 0 and i % 3:
+                o = int(rng.integers(0, N - M)); q = t[o:o + M].copy()
+                mut = rng.random(M) < 0.08
+                q[mut] = rng.integers(0, 5, int(mut.sum()), dtype=np.uint8)               # 4 = N: matches nothing
+                if M > 20 and i % 2:
+                    c = int(rng.integers(3, M - 8)); q = np.concatenate([q[:c], q[c + 3:], rng.integers(0, 4, 3, dtype=np.uint8)])
+            else:
+                q = rng.integers(0, 4, M, dtype=np.uint8)
+            pats.append(q.astype(np.uint8)); txts.append(t)
+        hp, ht = O.StringSet.from_lists(pats, 4, True), O.StringSet.from_lists(txts + [np.zeros(64, np.uint8)], 2, bool(ty == nvb.GLOBAL))
+        ht = O.StringSet(ht.words, 2, ht.big_endian, ht.begin[:-1], ht.length[:-1])
+        if algorithm == "pattern_blocking":
+            es, ek, _ = O.batch_score_pattern_blocking(1, ty, (0, -1, -1, -1), hp, ht)
+        else:
+            es, ek = O.batch_sw_score(0, ty, (0, -1, -1, -1), hp, ht)
+        al = nvb.make_edit_distance_aligner(ty, tag)
+        dp, dt = to_dev(hp, cuda), to_dev(ht, cuda)
+        for sweep in ("0", "1"):
+            os.environ["NVBIO_HIP_ED_SWEEP"] = sweep
+            try:
+                gs, gk, go = nvb.batch_alignment_score(al, dp, dt, max_m, max_n)
+                torch.cuda.synchronize()
+                kernel = lib().nvbio_hip_last_kernel()
+            finally:
+                os.environ["NVBIO_HIP_ED_SWEEP"] = "0"
+            assert (b"edit_distance_bitvector" in kernel) == (sweep == "0"), kernel
+            gs, gk = gs.cpu().numpy(), gk.cpu().numpy().view(np.uint32)
+            # (an empty pattern makes the reference's pattern-blocking pass read uninitialised cells: there the two kernels are only
+            # compared with each other)
+            defined = (hp.length > 0) | (algorithm == "text_blocking")
+            bad = np.nonzero(((es != gs) | (ek != gk).any(1)) & defined)[0]
+            assert bad.size == 0, (ty, algorithm, max_m, sweep, bad[:5], [(len(pats[b]), len(txts[b])) for b in bad[:3]], es[bad[:3]], gs[bad[:3]], ek[bad[:3]], gk[bad[:3]])
+            assert bool(go.all())
+            if sweep == "0":
+                first = (gs, gk)
+            else:
+                assert (first[0] == gs).all() and (first[1] == gk).all()
