@@ -1210,7 +1210,32 @@ def cpu_leg(a, patterns, texts):
     exact = bool((gs.cpu().numpy() == es).all() and (gk.cpu().numpy().view(np.uint32) == ek).all())
     if not exact:
         raise SystemExit("parity gate failed: HIP scores differ from the oracle on the CPU-baseline sample")
+    # the drop-in layer's own host execution (HostThreadScheduler: the per-job template under OpenMP, nvbio_hip_banded_gotoh_score_host)
+    # on the same sample and threads
+    twin = None
+    try:
+        import ctypes as C
+        from nvbio_amd import _lib
+
+        def sset(hs):
+            ss = _lib.StringSetStruct()
+            ss.words, ss.n_words, ss.bits, ss.big_endian = hs.words.ctypes.data, hs.words.size, hs.bits, hs.big_endian
+            ss.begin, ss.length, ss.fixed_length = hs.begin.ctypes.data, hs.length.ctypes.data, 0
+            return ss
+        sp_, st_ = sset(hp), sset(ht)
+        hs_, hk_ = np.zeros(m, np.int32), np.zeros((m, 2), np.uint32)
+        gsch = _lib.GotohSchemeStruct(*SCHEME)
+        tbest = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            rc = nvb.lib().nvbio_hip_banded_gotoh_score_host(C.byref(gsch), int(O.LOCAL), BAND, C.byref(sp_), C.byref(st_), m, hs_.ctypes.data, hk_.ctypes.data, cores)
+            dt = time.perf_counter() - t0
+            tbest = dt if tbest is None else min(tbest, dt)
+        twin = {"value": m / tbest, "unit": "reads/s", "threads": cores, "bit_exact_vs_oracle": bool(rc == 0 and (hs_ == es).all() and (hk_ == ek).all())}
+    except Exception as e:     # noqa: BLE001
+        twin = {"error": str(e)}
     return {"value": m / best, "unit": "reads/s", "cores": cores, "host_physical_cores": physical_cores(), "host_hardware_threads": os.cpu_count(), "kind": "port",
+            "host_scheduler_twin": twin,
             "sample": "%d of the same reads, band 15 LOCAL, OpenMP over jobs with %d threads (the container's CPU quota; the host has %d hardware threads), gcc -O3 -march=native, best of 3" % (m, cores, os.cpu_count() or 0),
             "gpu_vs_cpu_on_sample": {"compared": m, "bit_exact": exact}}
 
