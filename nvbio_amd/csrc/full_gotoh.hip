@@ -375,7 +375,15 @@ struct Sweep16
                 if (TYPE == NVBIO_HIP_LOCAL) bk16[k] = max16u(bk16[k], h + s15);       // h < 2^15 and a multiple of 16: no carry out of the low half
                 if (PBX) rmax[k] = max16u(rmax[k], h);
                 if (CHECK) cm = max16u(cm, min16u(h, lim[k]));
-                if (TYPE != NVBIO_HIP_LOCAL) hg_last = (uint32_t(k) == kl) ? hab_g : hg_last;   // HG of this lane's last valid row
+            }
+            if (TYPE != NVBIO_HIP_LOCAL)
+            {
+                // HG of the pattern's last row, for the lane that holds it: row klast of that lane.  klast is the same number in every
+                // lane, and only the last-row lane's record is ever read, so every lane follows its own row klast: selects on a
+                // wave-uniform condition instead of a compare + select per cell.
+                hg_last = HLG[0];
+                #pragma unroll
+                for (int k = 1; k < R; ++k) hg_last = (klast == uint32_t(k)) ? HLG[k] : hg_last;
             }
             out_hg = hab_g; out_f = fab; out_ch = in_ch; out_cm = cm;
             if (PRED)
