@@ -564,6 +564,21 @@ def e2e_leg(a, dev, fmi, text):
     return res
 
 
+def _shim_params(p, scheme):
+    """tests/cxx/aligner_shim.cpp's shim_params (nvBowtie's Params as the shim takes them) for an nvbio_amd.aligner.Params."""
+    import ctypes as C
+
+    class ShimParams(C.Structure):
+        _fields_ = [(k, C.c_uint32) for k in ("local", "randomized", "top_seed", "max_effort_init", "max_effort", "min_ext", "max_ext", "max_reseed", "rep_seeds",
+                                              "max_hits", "allow_sub", "subseed_len", "seed_len", "seed_freq_type", "min_read_len", "max_dist", "no_multi_hits",
+                                              "batch_size", "hits_stride")] + \
+                   [("seed_freq_k", C.c_float), ("seed_freq_m", C.c_float), ("match", C.c_int32), ("score_min_type", C.c_int32),
+                    ("score_min_k", C.c_float), ("score_min_m", C.c_float), ("finish", C.c_uint32)]
+    return ShimParams(int(p.local), int(p.randomized), p.top_seed, p.max_effort_init, p.max_effort, p.min_ext, p.max_ext, p.max_reseed, p.rep_seeds, p.max_hits,
+                      p.allow_sub, p.subseed_len, p.seed_len, p.seed_freq[0], p.min_read_len, p.max_dist, int(p.no_multi_hits), p.batch_size, p.hits_stride or 0,
+                      p.seed_freq[1], p.seed_freq[2], scheme.m_match, scheme.m_score_min[0], scheme.m_score_min[1], scheme.m_score_min[2], 0)
+
+
 def cxx_paired_leg(dev, idx, s1, s2, genome_words, ng, names, prm, ref_best0):
     """The C++ paired-end driver (Aligner::best_approx over a PairedReadBatch, include/nvbio_hip/aligner.h) on the same pairs: mean wall
     time of 3 batches with one Aligner object (tests/cxx/aligner_shim.cpp: nvbio_aligner_best_approx_paired_timed)."""
@@ -581,19 +596,10 @@ def cxx_paired_leg(dev, idx, s1, s2, genome_words, ng, names, prm, ref_best0):
     arena, nidx = names
     scheme = nvb.SmithWatermanScoringScheme.local() if prm.local else nvb.SmithWatermanScoringScheme()
 
-    class ShimParams(C.Structure):
-        _fields_ = [(k, C.c_uint32) for k in ("local", "randomized", "top_seed", "max_effort_init", "max_effort", "min_ext", "max_ext", "max_reseed", "rep_seeds",
-                                              "max_hits", "allow_sub", "subseed_len", "seed_len", "seed_freq_type", "min_read_len", "max_dist", "no_multi_hits",
-                                              "batch_size", "hits_stride")] + \
-                   [("seed_freq_k", C.c_float), ("seed_freq_m", C.c_float), ("match", C.c_int32), ("score_min_type", C.c_int32),
-                    ("score_min_k", C.c_float), ("score_min_m", C.c_float), ("finish", C.c_uint32)]
-
     class ShimPeParams(C.Structure):
         _fields_ = [("pe_policy", C.c_int32)] + [(k, C.c_uint32) for k in ("pe_overlap", "pe_unpaired", "pe_discordant", "min_frag_len", "max_frag_len")]
     p = prm
-    sp = ShimParams(int(p.local), int(p.randomized), p.top_seed, p.max_effort_init, p.max_effort, p.min_ext, p.max_ext, p.max_reseed, p.rep_seeds, p.max_hits,
-                    p.allow_sub, p.subseed_len, p.seed_len, p.seed_freq[0], p.min_read_len, p.max_dist, int(p.no_multi_hits), p.batch_size, p.hits_stride or 0,
-                    p.seed_freq[1], p.seed_freq[2], scheme.m_match, scheme.m_score_min[0], scheme.m_score_min[1], scheme.m_score_min[2], 0)
+    sp = _shim_params(prm, scheme)
     pp = ShimPeParams(p.pe_policy, int(p.pe_overlap), int(p.pe_unpaired), int(p.pe_discordant), p.min_frag_len, p.max_frag_len)
     pair_ptrs = lambda ts: (C.c_void_p * 2)(*[t.data_ptr() for t in ts])
     u64x2 = lambda v: (C.c_uint64 * 2)(*v)
@@ -629,16 +635,7 @@ def cxx_driver_leg(a, dev, idx, sym, packed, genome_words, ng, names, prm, ref_b
     arena, nidx = names
     scheme = nvb.SmithWatermanScoringScheme()
 
-    class ShimParams(C.Structure):
-        _fields_ = [(k, C.c_uint32) for k in ("local", "randomized", "top_seed", "max_effort_init", "max_effort", "min_ext", "max_ext", "max_reseed", "rep_seeds",
-                                              "max_hits", "allow_sub", "subseed_len", "seed_len", "seed_freq_type", "min_read_len", "max_dist", "no_multi_hits",
-                                              "batch_size", "hits_stride")] + \
-                   [("seed_freq_k", C.c_float), ("seed_freq_m", C.c_float), ("match", C.c_int32), ("score_min_type", C.c_int32),
-                    ("score_min_k", C.c_float), ("score_min_m", C.c_float), ("finish", C.c_uint32)]
-    p = prm
-    sp = ShimParams(int(p.local), int(p.randomized), p.top_seed, p.max_effort_init, p.max_effort, p.min_ext, p.max_ext, p.max_reseed, p.rep_seeds, p.max_hits,
-                    p.allow_sub, p.subseed_len, p.seed_len, p.seed_freq[0], p.min_read_len, p.max_dist, int(p.no_multi_hits), p.batch_size, p.hits_stride or 0,
-                    p.seed_freq[1], p.seed_freq[2], scheme.m_match, scheme.m_score_min[0], scheme.m_score_min[1], scheme.m_score_min[2], 0)
+    sp = _shim_params(prm, scheme)
     fs = idx.struct()
     vp = lambda t: C.c_void_p(t.data_ptr())
     best = torch.zeros((2, n), dtype=torch.int64, device=dev)
