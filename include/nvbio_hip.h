@@ -236,8 +236,11 @@ int nvbio_hip_gotoh_traceback_qual(
  * at the text's last symbol -- nvBowtie's opposite-mate tracebacks, whose windows are [alignment, alignment + sink) of a scoring pass
  * (traceback_inl.h:833-905).  The text rows no alignment of that score can reach (all but the last M + gaps-the-score-allows) are
  * dropped before any DP runs; score, sink, source and CIGAR are those of the plain forms (argument: full_traceback.hip,
- * crop_windows_kernel).  known_score: device int32[n].  A job for which the premise does not hold gets the traceback of the cropped
- * window.  GLOBAL: same as the plain forms. */
+ * crop_windows_kernel).  known_score: device int32[n].  The premise is checked per job on what the cropped DP found (score ==
+ * known_score and the sink on the window's last row); a job that fails the check -- a known_score that is too high cuts the window too
+ * short -- is traced again over its whole window, so its outputs are those of the plain form (one 4-byte read-back per call finds the
+ * count; nvbio_hip_known_score_redone() totals it).  Not detectable: a window whose true best alignment lies in the dropped rows while
+ * the kept rows hold one of exactly known_score ending at the last row.  GLOBAL: same as the plain forms. */
 int nvbio_hip_gotoh_traceback_known_score(
     const nvbio_hip_gotoh_scheme* scheme /* host */, int32_t type,
     const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts, const int32_t* known_score,
@@ -252,6 +255,8 @@ int nvbio_hip_gotoh_traceback_qual_known_score(
     int32_t* out_score, uint32_t* out_sink, uint32_t* out_source,
     uint16_t* out_cigar, uint32_t cigar_stride, uint32_t* out_cigar_len,
     void* temp, uint64_t temp_bytes, void* stream);
+
+uint64_t nvbio_hip_known_score_redone(void);     /* jobs the two forms above traced again since the library was loaded */
 
 /* The tracebacks for SmithWatermanAligner / EditDistanceAligner (deletion == insertion), banded (sw_banded_inl.h:405-470,
  * 748-800) and full matrix (sw_inl.h:389-396, 475-500, 1660-1700): arguments and temp sizes as the Gotoh forms.  The banded
@@ -355,10 +360,12 @@ int nvbio_hip_fm_attach_dimer_index(nvbio_hip_fmindex* fmi, const uint32_t* dime
  * {C3[abc] + #rows before the record whose three preceding text symbols are abc, 96-bit mask of the record's rows holding abc},
  * so that one backward-search step consumes three pattern symbols for one 16-byte load per range end.  Built on the device
  * from `fmi`'s bwt_occ; out_trimer: nvbio_hip_fm_trimer_index_bytes(length) bytes, 128-byte aligned (a 128-byte header, then the
- * arrays); temp: nvbio_hip_fm_build_trimer_index_temp_bytes(length).  Attach by setting fmi->trimer (fmi->dimer must be set). */
+ * arrays); temp: nvbio_hip_fm_build_trimer_index_temp_bytes(length).  Attach with nvbio_hip_fm_attach_trimer_index, which checks the
+ * header against `fmi` (magic, length, primary, stride, L2 check word) and that fmi->dimer is attached; NULL detaches. */
 uint64_t nvbio_hip_fm_trimer_index_bytes(uint32_t length);
 uint64_t nvbio_hip_fm_build_trimer_index_temp_bytes(uint32_t length);
 int nvbio_hip_fm_build_trimer_index(const nvbio_hip_fmindex* fmi, uint32_t* out_trimer, void* temp, uint64_t temp_bytes, void* stream);
+int nvbio_hip_fm_attach_trimer_index(nvbio_hip_fmindex* fmi, const uint32_t* trimer, void* stream);
 
 /* ---- `_host` twins: the reference's HostThreadScheduler / host paths (batched_banded_inl.h:97-128,
  * batched_inl.h:236-300, the host fm_index functions) behind the same argument lists with HOST pointers everywhere and a

@@ -24,7 +24,8 @@ struct fm_index_device
     void set_ktab(const uint32* ktab, uint32 k) { m.ktab = ktab; m.ktab_k = k; }
     // attach the line-native two-symbol index built by nvbio_hip_fm_build_dimer_index (NULL detaches)
     int  set_dimer(const uint32* dimer, void* stream = nullptr) { return nvbio_hip_fm_attach_dimer_index(&m, dimer, stream); }
-    void set_trimer(const uint32* trimer) { m.trimer = trimer; }
+    /// attach the three-symbol arrays built by nvbio_hip_fm_build_trimer_index (validated against this index; NULL detaches)
+    int  set_trimer(const uint32* trimer, void* stream = nullptr) { return nvbio_hip_fm_attach_trimer_index(&m, trimer, stream); }
 
     index_type length() const { return m.length; }
     index_type primary() const { return m.primary; }

@@ -9,13 +9,13 @@ LIB_PATH = os.path.join(HERE, "lib", "libnvbio_hip.so")
 SYMBOLS = [
     "nvbio_hip_banded_gotoh_score", "nvbio_hip_banded_gotoh_score_qual", "nvbio_hip_gotoh_score", "nvbio_hip_banded_sw_score", "nvbio_hip_sw_score", "nvbio_hip_alignment_score", "nvbio_hip_alignment_score_qual",
     "nvbio_hip_banded_gotoh_traceback_temp_bytes", "nvbio_hip_banded_gotoh_traceback", "nvbio_hip_banded_gotoh_traceback_qual",
-    "nvbio_hip_gotoh_traceback_temp_bytes", "nvbio_hip_gotoh_traceback", "nvbio_hip_gotoh_traceback_qual", "nvbio_hip_gotoh_traceback_known_score", "nvbio_hip_gotoh_traceback_qual_known_score", "nvbio_hip_banded_sw_traceback", "nvbio_hip_sw_traceback",
+    "nvbio_hip_gotoh_traceback_temp_bytes", "nvbio_hip_gotoh_traceback", "nvbio_hip_gotoh_traceback_qual", "nvbio_hip_gotoh_traceback_known_score", "nvbio_hip_gotoh_traceback_qual_known_score", "nvbio_hip_known_score_redone", "nvbio_hip_banded_sw_traceback", "nvbio_hip_sw_traceback",
     "nvbio_hip_fm_rank", "nvbio_hip_fm_rank4", "nvbio_hip_fm_rank_range",
     "nvbio_hip_fm_match", "nvbio_hip_fm_build_ktab",
     "nvbio_hip_banded_gotoh_score_host", "nvbio_hip_banded_sw_score_host", "nvbio_hip_alignment_score_host",
     "nvbio_hip_fm_rank_host", "nvbio_hip_fm_match_host", "nvbio_hip_fm_locate_host",
     "nvbio_hip_fm_dimer_index_bytes", "nvbio_hip_fm_build_dimer_index_temp_bytes", "nvbio_hip_fm_build_dimer_index", "nvbio_hip_fm_attach_dimer_index",
-    "nvbio_hip_fm_trimer_index_bytes", "nvbio_hip_fm_build_trimer_index_temp_bytes", "nvbio_hip_fm_build_trimer_index", "nvbio_hip_map_exact", "nvbio_hip_map",
+    "nvbio_hip_fm_trimer_index_bytes", "nvbio_hip_fm_build_trimer_index_temp_bytes", "nvbio_hip_fm_build_trimer_index", "nvbio_hip_fm_attach_trimer_index", "nvbio_hip_map_exact", "nvbio_hip_map",
     "nvbio_hip_alignment_invalid", "nvbio_hip_init_alignments", "nvbio_hip_score_reduce", "nvbio_hip_score_reduce_paired", "nvbio_hip_opposite_mate_windows", "nvbio_hip_mapq", "nvbio_hip_mapq_paired", "nvbio_hip_fm_locate",
     "nvbio_hip_sum_tree_node_count", "nvbio_hip_select_init", "nvbio_hip_select_temp_bytes", "nvbio_hip_select", "nvbio_hip_locate_hits", "nvbio_hip_hit_deque_replay",
     "nvbio_hip_score_best_setup", "nvbio_hip_score_reduce_best_approx",
@@ -103,6 +103,7 @@ def lib():
                                                             vp, vp, vp, vp, u32, vp, vp, u64, vp]
         L.nvbio_hip_gotoh_traceback_qual_known_score.argtypes = [P(GotohQualSchemeStruct), i32, P(StringSetStruct), vp, u64, P(StringSetStruct), vp, u32, u32, u32,
                                                                  vp, vp, vp, vp, u32, vp, vp, u64, vp]
+        L.nvbio_hip_known_score_redone.argtypes = []; L.nvbio_hip_known_score_redone.restype = u64
         L.nvbio_hip_banded_sw_traceback.argtypes = [P(GotohSchemeStruct), i32, u32, P(StringSetStruct), P(StringSetStruct), u32, u32, u32,
                                                     vp, vp, vp, vp, u32, vp, vp, u64, vp]
         L.nvbio_hip_sw_traceback.argtypes = [P(GotohSchemeStruct), i32, P(StringSetStruct), P(StringSetStruct), u32, u32, u32,
@@ -127,6 +128,7 @@ def lib():
         L.nvbio_hip_fm_trimer_index_bytes.argtypes = [u32]; L.nvbio_hip_fm_trimer_index_bytes.restype = u64
         L.nvbio_hip_fm_build_trimer_index_temp_bytes.argtypes = [u32]; L.nvbio_hip_fm_build_trimer_index_temp_bytes.restype = u64
         L.nvbio_hip_fm_build_trimer_index.argtypes = [P(FMIndexStruct), vp, vp, u64, vp]
+        L.nvbio_hip_fm_attach_trimer_index.argtypes = [P(FMIndexStruct), vp, vp]
         L.nvbio_hip_map_exact.argtypes = [P(FMIndexStruct), P(StringSetStruct), vp, u32, P(MapParamsStruct), vp, vp, u32, vp, vp, vp]
         L.nvbio_hip_map.argtypes = [i32, u32, P(FMIndexStruct), P(FMIndexStruct), P(StringSetStruct), vp, u32, P(MapParamsStruct), vp, vp, u32, vp, vp, vp]
         L.nvbio_hip_alignment_invalid.argtypes = []

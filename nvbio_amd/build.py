@@ -21,11 +21,12 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
-def _deps():
+def _deps(src):
     d = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     d.append(os.path.join(HERE, "..", "include", "nvbio_hip.h"))
-    compat = os.path.join(HERE, "..", "include", "nvbio_hip", "compat")       # host_twins.hip instantiates the drop-in templates
-    d += [os.path.join(r, f) for r, _, fs in os.walk(compat) for f in fs]
+    if os.path.basename(src) == "host_twins.hip":       # the only TU that instantiates the drop-in templates
+        compat = os.path.join(HERE, "..", "include", "nvbio_hip", "compat")
+        d += [os.path.join(r, f) for r, _, fs in os.walk(compat) for f in fs]
     return d
 
 
@@ -40,13 +41,12 @@ def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
-    deps = _deps()
     jobs = []
     objs = []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
-        if force or _stale(obj, [src] + deps):
+        if force or _stale(obj, [src] + _deps(src)):
             jobs.append([HIPCC] + FLAGS + ["-c", src, "-o", obj])
 
     def run(cmd):

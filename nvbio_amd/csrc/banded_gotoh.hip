@@ -37,7 +37,7 @@
 //    Both produce the reference's int32 results bit for bit.
 //
 #include "banded_gotoh_impl.h"
-#include <chrono>
+#include <mutex>
 
 namespace nvb {
 
@@ -212,39 +212,53 @@ NVB_API int nvbio_hip_banded_sw_score(
     return nvbio_hip_banded_gotoh_score(&g, type, band_len, patterns, texts, max_pattern_len, max_text_len, n, out_score, out_sink, stream);
 }
 
-// Device memory for the C++ host layer's containers.  Stream-ordered on the null stream out of the device's default pool, with the
-// pool told to keep what it is given back: a driver that builds and drops its queues every batch (the reference's drivers hold
-// thrust vectors the same way) then pays for hipMalloc once, not per batch.
-static void keep_pool_memory()
+// Device memory for the C++ host layer's containers.  A private, per-device stream-ordered pool (the device's default pool and
+// its attributes are left alone: this library shares its process with torch's allocator in bench.py) with a bounded release
+// threshold, so freed blocks above 256 MiB go back to the driver.  nvbio_hip_device_free keeps hipFree's contract -- the block
+// may be in use by ANY stream of the device until the call returns, so the device is synchronised before the block re-enters the
+// pool; a driver's per-batch working set lives in a hip::device_arena (include/nvbio_hip/types.h) and never comes through here.
+namespace nvb {
+static hipMemPool_t private_pool(int dev)
 {
-    static thread_local int done_for = -1;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev == done_for) return;
-    hipMemPool_t pool;
-    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
-        uint64_t keep = ~0ull;
-        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    static std::mutex mtx;
+    static hipMemPool_t pools[64] = {};
+    static bool tried[64] = {};
+    if (dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mtx);
+    if (!tried[dev]) {
+        tried[dev] = true;
+        hipMemPoolProps props = {};
+        props.allocType = hipMemAllocationTypePinned;
+        props.handleTypes = hipMemHandleTypeNone;
+        props.location.type = hipMemLocationTypeDevice;
+        props.location.id = dev;
+        hipMemPool_t pool = nullptr;
+        if (hipMemPoolCreate(&pool, &props) == hipSuccess) {
+            uint64_t keep = uint64_t(256) << 20;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+            pools[dev] = pool;
+        } else (void)hipGetLastError();
     }
-    done_for = dev;
+    return pools[dev];
 }
-static double g_alloc_ms = 0.0; static uint64_t g_alloc_calls = 0;
-extern "C" __attribute__((visibility("default"))) void nvb_debug_alloc_stats(double* ms, uint64_t* calls) { *ms = g_alloc_ms; *calls = g_alloc_calls; }
+} // namespace nvb
 NVB_API int nvbio_hip_device_malloc(void** ptr, uint64_t bytes)
 {
     if (!ptr) return hipErrorInvalidValue;
-    keep_pool_memory();
-    const auto t0 = std::chrono::steady_clock::now();
-    const int e = hipMallocAsync(ptr, bytes ? bytes : 1, nullptr);
-    g_alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); ++g_alloc_calls;
-    return e;
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev)) return e;
+    hipMemPool_t pool = nvb::private_pool(dev);
+    if (!pool) return hipMalloc(ptr, bytes ? bytes : 1);
+    if (hipError_t e = hipMallocFromPoolAsync(ptr, bytes ? bytes : 1, pool, nullptr)) return e;
+    return hipStreamSynchronize(nullptr);          // like hipMalloc: the block is usable from every stream on return
 }
 NVB_API int nvbio_hip_device_free(void* ptr)
 {
     if (!ptr) return hipSuccess;
-    const auto t0 = std::chrono::steady_clock::now();
-    const int e = hipFreeAsync(ptr, nullptr);
-    g_alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); ++g_alloc_calls;
-    return e;
+    if (hipError_t e = hipDeviceSynchronize()) return e;     // hipFree's implicit synchronisation: no stream still uses the block
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && nvb::private_pool(dev)) return hipFreeAsync(ptr, nullptr);
+    return hipFree(ptr);
 }
 NVB_API int nvbio_hip_memcpy(void* dst, const void* src, uint64_t bytes, int kind, void* stream)
 {

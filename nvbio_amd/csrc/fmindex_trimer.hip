@@ -83,7 +83,7 @@ __global__ void trimer_header_kernel(const Fmi f, const uint32_t stride, uint32_
     const uint32_t x2 = f.L2[b] + fm_rank(f, x1 - 1u, b) + 1u;
     const uint32_t x3 = f.L2[a] + fm_rank(f, x2 - 1u, a) + 1u;
     out[64u + t] = x3 - 1u;
-    if (t == 0u) { out[0] = TRIMER_MAGIC; out[1] = f.length; out[2] = f.primary; out[3] = stride; }
+    if (t == 0u) { out[0] = TRIMER_MAGIC; out[1] = f.length; out[2] = f.primary; out[3] = stride; out[4] = f.L2[1] ^ ((f.L2[2] << 11) | (f.L2[2] >> 21)); }
 }
 
 __global__ void __launch_bounds__(256)
@@ -138,4 +138,22 @@ NVB_API int nvbio_hip_fm_build_trimer_index(const nvbio_hip_fmindex* fmi, uint32
     hipLaunchKernelGGL(trimer_header_kernel, dim3(1), dim3(64), 0, s, f, R, out_trimer);
     hipLaunchKernelGGL(trimer_counters_kernel, dim3(uint32_t((64ull * R + 255u) / 256u)), dim3(256), 0, s, R, counts, out_trimer, pk);
     return hipGetLastError();
+}
+
+// Attach with validation, like nvbio_hip_fm_attach_dimer_index: the header written by trimer_header_kernel must describe THIS index
+// (magic, length, primary, the stride the kernels derive from the length, the L2 check word) and the two-symbol index must be attached
+// already (leftover symbols and empty-range replays use its steps).  trimer == NULL detaches.
+NVB_API int nvbio_hip_fm_attach_trimer_index(nvbio_hip_fmindex* fmi, const uint32_t* trimer, void* stream)
+{
+    using namespace nvb;
+    if (!fmi) return hipErrorInvalidValue;
+    if (!trimer) { fmi->trimer = nullptr; return hipSuccess; }
+    if (!fmi->dimer) return hipErrorInvalidValue;
+    uint32_t h[5];
+    if (hipError_t e = hipMemcpyAsync(h, trimer, sizeof(h), hipMemcpyDeviceToHost, to_stream(stream))) return e;
+    if (hipError_t e = hipStreamSynchronize(to_stream(stream))) return e;
+    if (h[0] != uint32_t(TRIMER_MAGIC) || h[1] != fmi->length || h[2] != fmi->primary || h[3] != trimer_stride(fmi->length)) return hipErrorInvalidValue;
+    if (h[4] != (fmi->L2[1] ^ ((fmi->L2[2] << 11) | (fmi->L2[2] >> 21)))) return hipErrorInvalidValue;
+    fmi->trimer = trimer;
+    return hipSuccess;
 }

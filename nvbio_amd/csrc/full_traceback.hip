@@ -15,6 +15,7 @@
 // schemes / lengths that could leave that range.
 #include "common.h"
 #include <algorithm>
+#include <atomic>
 
 namespace nvb {
 
@@ -487,6 +488,40 @@ uncrop_kernel(uint32_t n, const uint32_t* __restrict__ c0, uint2* __restrict__ s
     if (source[tid].x != 0xFFFFFFFFu) source[tid].x += c0[tid];
 }
 
+// The premise of the _known_score forms, checked on what the cropped DP found (cropped coordinates): the best score is the one the
+// caller announced and its alignment ends at the window's last row.  A wrong known_score (too high: the window was cut too short)
+// or a window that does not end at its alignment shows up here; such jobs are queued and traced again over their whole window.
+__global__ void __launch_bounds__(256)
+verify_known_kernel(uint32_t n, const int32_t* __restrict__ known_score, const int32_t* __restrict__ score, const uint2* __restrict__ sink,
+                    const uint32_t* __restrict__ new_len, const uint32_t* __restrict__ c0, uint32_t* __restrict__ bad, uint32_t* __restrict__ bad_count)
+{
+    const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
+    if (tid >= n) return;
+    if (c0[tid] == 0u) return;                                                     // nothing was dropped: this IS the plain traceback
+    if (score[tid] == known_score[tid] && sink[tid].x == new_len[tid]) return;
+    bad[atomicAdd(bad_count, 1u)] = tid;
+}
+__global__ void __launch_bounds__(256)
+gather_jobs_kernel(uint32_t m, const uint32_t* __restrict__ bad, const StringSet pat, const StringSet txt,
+                   uint64_t* __restrict__ pb, uint32_t* __restrict__ pl, uint64_t* __restrict__ tb, uint32_t* __restrict__ tl)
+{
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= m) return;
+    const uint32_t j = bad[k];
+    pb[k] = pat.begin[j]; pl[k] = pat.length ? pat.length[j] : pat.fixed_length;
+    tb[k] = txt.begin[j]; tl[k] = txt.length ? txt.length[j] : txt.fixed_length;
+}
+__global__ void __launch_bounds__(256)
+scatter_tracebacks_kernel(uint32_t m, const uint32_t* __restrict__ bad, const int32_t* __restrict__ score, const uint2* __restrict__ sink, const uint2* __restrict__ source,
+                          const uint16_t* __restrict__ cigar, const uint32_t* __restrict__ cigar_len, uint32_t cigar_stride,
+                          int32_t* __restrict__ out_score, uint2* __restrict__ out_sink, uint2* __restrict__ out_source, uint16_t* __restrict__ out_cigar, uint32_t* __restrict__ out_cigar_len)
+{
+    const uint32_t k = blockIdx.x, j = bad[k];
+    if (threadIdx.x == 0u) { out_score[j] = score[k]; out_sink[j] = sink[k]; out_source[j] = source[k]; out_cigar_len[j] = cigar_len[k]; }
+    const uint32_t words = cigar_len[k] < cigar_stride ? cigar_len[k] : cigar_stride;
+    for (uint32_t w = threadIdx.x; w < words; w += 256u) out_cigar[uint64_t(j) * cigar_stride + w] = cigar[uint64_t(k) * cigar_stride + w];
+}
+
 } // namespace nvb
 
 using namespace nvb;
@@ -495,9 +530,11 @@ NVB_API uint64_t nvbio_hip_gotoh_traceback_temp_bytes(uint32_t max_pattern_len, 
 {
     const uint64_t blocks = 2u * std::max<uint64_t>(1u, (uint64_t(max_pattern_len) + 15u) / 16u);     // 8-column flag words, whole 16-column blocks
     // flags + the boundary column (or, per job of the wave kernel, [step][block] flag words: text rows + blocks steps) + the queue of gapped jobs
-    // ... + the cropped windows of the _known_score forms (begin, length, dropped rows: 16 bytes per job)
-    return ((blocks + 1u) * uint64_t(max_text_len) + blocks * blocks) * uint64_t(n) * 4u + uint64_t(n) * 4u + 256u + 8u + uint64_t(n) * 16u;
+    // ... + the cropped windows of the _known_score forms (begin, length, dropped rows: 16 bytes per job) + their queue of jobs to redo
+    return ((blocks + 1u) * uint64_t(max_text_len) + blocks * blocks) * uint64_t(n) * 4u + uint64_t(n) * 4u + 256u + 8u + uint64_t(n) * 16u + uint64_t(n) * 4u + 8u;
 }
+
+static std::atomic<uint64_t> g_known_score_redone{0};
 
 struct TbQualPart { const uint8_t* quals; uint64_t n_quals; const int32_t* mismatch; int32_t text_gap_open, text_gap_ext; };
 
@@ -545,8 +582,10 @@ static int full_traceback_core(
     const dim3 grid((n + 255u) / 256u), block(256);
     hipStream_t s = to_stream(stream);
     // temp: [job regions | queue of gapped jobs, its counter | cropped windows]
-    const uint64_t queue_off = need - uint64_t(n) * 16u - 8u - 256u - uint64_t(n) * 4u, crop_off = (queue_off + uint64_t(n) * 4u + 256u + 7u) & ~uint64_t(7);
+    const uint64_t redo_off = need - uint64_t(n) * 4u - 8u;
+    const uint64_t queue_off = redo_off - uint64_t(n) * 16u - 8u - 256u - uint64_t(n) * 4u, crop_off = (queue_off + uint64_t(n) * 4u + 256u + 7u) & ~uint64_t(7);
     nvbio_hip_string_set cropped = *texts;
+    const nvbio_hip_string_set* whole_texts = texts;
     uint32_t* c0 = nullptr;
     if (known_score && type != NVBIO_HIP_GLOBAL && p.crop_ext > 0)
     {
@@ -630,9 +669,50 @@ static int full_traceback_core(
     return hipGetLastError();
     }();
     if (rc != hipSuccess || !c0) return rc;
+    // the premise, checked per job on the cropped result; the (normally empty) list of jobs it failed for is traced again uncropped
+    uint32_t* bad = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(temp) + redo_off);
+    uint32_t* bad_count = bad + n;
+    if (hipError_t e = hipMemsetAsync(bad_count, 0, 4, s)) return e;
+    hipLaunchKernelGGL(verify_known_kernel, grid, block, 0, s, n, known_score, out_score, p.out_sink, cropped.length, c0, bad, bad_count);
     hipLaunchKernelGGL(uncrop_kernel, grid, block, 0, s, n, c0, p.out_sink, p.out_source);
-    return hipGetLastError();
+    if (hipError_t e = hipGetLastError()) return e;
+    uint32_t m = 0;
+    if (hipError_t e = hipMemcpyAsync(&m, bad_count, 4, hipMemcpyDeviceToHost, s)) return e;
+    if (hipError_t e = hipStreamSynchronize(s)) return e;
+    if (m == 0) return hipSuccess;
+    g_known_score_redone += m;
+    const uint64_t sub_temp = nvbio_hip_gotoh_traceback_temp_bytes(maxM, maxN, m);
+    const uint64_t row = 8u + 4u + 8u + 4u + 4u + 8u + 8u + 4u + uint64_t(cigar_stride) * 2u;
+    uint8_t* blk = nullptr;
+    if (hipError_t e = hipMalloc(reinterpret_cast<void**>(&blk), sub_temp + uint64_t(m) * row + 256u)) return e;
+    uint8_t* q = blk + ((sub_temp + 15u) & ~uint64_t(15));
+    uint64_t* pb = reinterpret_cast<uint64_t*>(q); q += uint64_t(m) * 8u;
+    uint64_t* tb = reinterpret_cast<uint64_t*>(q); q += uint64_t(m) * 8u;
+    uint2* r_sink = reinterpret_cast<uint2*>(q);   q += uint64_t(m) * 8u;
+    uint2* r_src  = reinterpret_cast<uint2*>(q);   q += uint64_t(m) * 8u;
+    uint32_t* pl = reinterpret_cast<uint32_t*>(q); q += uint64_t(m) * 4u;
+    uint32_t* tl = reinterpret_cast<uint32_t*>(q); q += uint64_t(m) * 4u;
+    int32_t* r_score = reinterpret_cast<int32_t*>(q); q += uint64_t(m) * 4u;
+    uint32_t* r_len = reinterpret_cast<uint32_t*>(q); q += uint64_t(m) * 4u;
+    uint16_t* r_cigar = reinterpret_cast<uint16_t*>(q);
+    const dim3 mgrid((m + 255u) / 256u);
+    hipLaunchKernelGGL(gather_jobs_kernel, mgrid, block, 0, s, m, bad, make_string_set(patterns), make_string_set(whole_texts), pb, pl, tb, tl);
+    nvbio_hip_string_set sp = *patterns, st = *whole_texts;
+    sp.begin = pb; sp.length = pl; sp.fixed_length = 0; st.begin = tb; st.length = tl; st.fixed_length = 0;
+    int e2 = full_traceback_core(scheme, qual, type, block_len, &sp, &st, maxM, maxN, m, r_score, reinterpret_cast<uint32_t*>(r_sink), reinterpret_cast<uint32_t*>(r_src),
+                                 r_cigar, cigar_stride, r_len, blk, sub_temp, stream);
+    if (e2 == hipSuccess) {
+        hipLaunchKernelGGL(scatter_tracebacks_kernel, dim3(m), block, 0, s, m, bad, r_score, r_sink, r_src, r_cigar, r_len, cigar_stride,
+                           out_score, p.out_sink, p.out_source, out_cigar, out_cigar_len);
+        e2 = hipGetLastError();
+    }
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(blk);
+    return e2;
 }
+
+// jobs the _known_score forms had to trace again over their whole window since the library was loaded (a caller whose premise holds sees 0)
+NVB_API uint64_t nvbio_hip_known_score_redone(void) { return g_known_score_redone; }
 
 NVB_API int nvbio_hip_gotoh_traceback(
     const nvbio_hip_gotoh_scheme* scheme, int32_t type,
@@ -684,8 +764,8 @@ NVB_API int nvbio_hip_gotoh_traceback_qual(
 }
 
 // The same two with the callers' knowledge that every job's best alignment has the given score and ends at the last symbol of its text
-// (see crop_windows_kernel): nvBowtie's opposite-mate tracebacks.  Results are those of the plain forms; jobs for which the premise
-// does not hold get the traceback of the cropped window.
+// (see crop_windows_kernel): nvBowtie's opposite-mate tracebacks.  Results are those of the plain forms; a job whose cropped DP does
+// not reproduce the premise (another score, or a sink off the last row) is traced again over its whole window (verify_known_kernel).
 NVB_API int nvbio_hip_gotoh_traceback_known_score(
     const nvbio_hip_gotoh_scheme* scheme, int32_t type,
     const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts, const int32_t* known_score,

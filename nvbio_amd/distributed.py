@@ -52,8 +52,10 @@ class RecordGather:
             dist.gather(self.send, self.bufs if self.rank == self.dst else None, dst=self.dst, group=self.group)
 
     def status(self):
-        """On dst: the per-rank status words of the last gather (one host read)."""
-        return [int(b[self.pad, 0].item()) for b in self.bufs] if self.bufs is not None else []
+        """On dst: the per-rank status words of the last gather (ONE stacked device-to-host copy for all ranks)."""
+        if self.bufs is None:
+            return []
+        return [int(v) for v in torch.stack([b[self.pad, 0] for b in self.bufs]).cpu().tolist()]
 
     def gather(self, records, concat=True, status=None):
         """records: int32 [n_r, width] of this rank.  Returns the [n_total, width] table on dst (None elsewhere);
@@ -63,8 +65,7 @@ class RecordGather:
         if self.world == 1:
             return records
         self.send[:n] = records
-        if status is not None:
-            self.send[self.pad, 0] = status
+        self.send[self.pad, 0] = 0 if status is None else status        # always written: no stale word from an earlier call
         self._exchange()
         if self.rank != self.dst:
             return None
@@ -120,14 +121,14 @@ class ResultGather(RecordGather):
         else:
             self.send[:n, 0] = score
             self.send[:n, 1:] = sink
-        if status is not None:
-            self.send[self.pad, 0] = status
+        self.send[self.pad, 0] = 0 if status is None else status          # always written: no stale word from an earlier call
         self._exchange()
         if self.rank != self.dst:
             return None
         if not concat:
             return True
-        if self.overflowed():
+        # 12-byte records are lossless: their status is always 0 and reading it back would be a host sync for nothing
+        if self.record_bytes != 12 and self.overflowed():
             raise OverflowError("ResultGather: a rank holds sinks / scores that do not fit %d-byte records; use record_bytes=12" % self.record_bytes)
         rec = torch.cat([self.bufs[r][: self.sizes[r]] for r in range(self.world)], dim=0)
         if self.record_bytes == 12:

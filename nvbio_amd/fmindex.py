@@ -72,6 +72,8 @@ class FMIndexDevice:
         check(L.nvbio_hip_fm_build_trimer_index(C.byref(s), _vp(tri), _vp(temp), tb, current_stream_ptr()), "nvbio_hip_fm_build_trimer_index")
         torch.cuda.current_stream().synchronize()
         del temp
+        chk = base.struct()         # the header must describe THIS index (stale / foreign arrays are refused, not silently used)
+        check(L.nvbio_hip_fm_attach_trimer_index(C.byref(chk), _vp(tri), current_stream_ptr()), "nvbio_hip_fm_attach_trimer_index")
         return base._copy(trimer=tri)
 
     def with_ktab(self, k=12):

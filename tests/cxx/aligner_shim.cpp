@@ -8,7 +8,6 @@
 using namespace nvbio;
 using namespace nvbio::bowtie2::cuda;
 
-extern "C" void nvb_debug_alloc_stats(double*, uint64_t*);      // libnvbio_hip.so: time spent in nvbio_hip_device_malloc / _free (tracing aid)
 
 struct shim_params
 {
@@ -119,8 +118,7 @@ int nvbio_aligner_best_approx_timed(const nvbio_hip_fmindex* fmi, const nvbio_hi
         }
         out_ms[0] = reps ? total / reps : 0.0;
         if (getenv("NVBIO_SHIM_TRACE")) {
-            double ams = 0; uint64_t calls = 0; nvb_debug_alloc_stats(&ams, &calls);
-            fprintf(stderr, "aligner_shim: %.1f ms per batch; device malloc/free so far: %.1f ms in %llu calls (%u batches incl. warm-up)\n", out_ms[0], ams, (unsigned long long)calls, reps + 2u);
+            fprintf(stderr, "aligner_shim: %.1f ms per batch (%u batches incl. warm-up)\n", out_ms[0], reps + 2u);
         }
         Stats timed; timed.clock.enabled = true;
         aligner.best_approx(params, f, rf, scheme, limits, d_genome_words, genome_n_words, genome_len, reads, timed);

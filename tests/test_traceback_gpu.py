@@ -466,6 +466,22 @@ def test_full_matrix_traceback_known_score_windows(cuda, ty, tb_kernel):
         got = nvb.batch_alignment_traceback(al, to_dev(sub_p, cuda), to_dev(sub_t, cuda), 150, 650, cigar_stride=64, known_score=known, **kw)
         torch.cuda.synchronize()
         compare(exp, got, (ty, scheme, "known score"))
+        # a caller whose premise is WRONG still gets the plain traceback: scores announced too high (the window is cut too short for
+        # the real alignment's gaps) and windows that do not end at their alignment's sink are found by the check on the cropped DP and
+        # traced again over the whole window (full_traceback.hip, verify_known_kernel)
+        before = int(nvb.lib().nvbio_hip_known_score_redone())
+        wrong = first["score"][keep].astype(np.int32).copy()
+        wrong[::3] += 40; wrong[1::3] -= 7
+        got = nvb.batch_alignment_traceback(al, to_dev(sub_p, cuda), to_dev(sub_t, cuda), 150, 650, cigar_stride=64,
+                                            known_score=torch.from_numpy(wrong).to(cuda), **kw)
+        torch.cuda.synchronize()
+        compare(exp, got, (ty, scheme, "wrong known score"))
+        assert int(nvb.lib().nvbio_hip_known_score_redone()) > before
+        longer = O.StringSet(ht.words, 2, True, ht.begin[keep], np.minimum(wl + 9, ht.length[keep]).astype(np.uint32))
+        exp_l = O.batch_gotoh_traceback(ty, okw["s"], sub_p, longer, 64, lut, quals) if scheme == "qual" else O.batch_gotoh_traceback(ty, scheme, sub_p, longer, 64)
+        got = nvb.batch_alignment_traceback(al, to_dev(sub_p, cuda), to_dev(longer, cuda), 150, 650, cigar_stride=64, known_score=known, **kw)
+        torch.cuda.synchronize()
+        compare(exp_l, got, (ty, scheme, "window past the sink"))
         checked += keep.size
         cropped += int((wl > sub_p.length + 40).sum())
     assert checked > 2500 and cropped > 1000
