@@ -24,7 +24,10 @@ struct Alignment
 
 struct PatternBlockingTag {};
 struct TextBlockingTag {};
+/// the Myers bit-vector algorithm for edit distance (alignment_base.h:86-87): an algorithm choice, the scores are the edit-distance aligner's
+template <uint32 ALPHABET_SIZE_T> struct MyersTag { static const uint32 ALPHABET_SIZE = ALPHABET_SIZE_T; };
 template <typename T> struct transpose_tag {};
+template <uint32 N> struct transpose_tag< MyersTag<N> > { typedef MyersTag<N> type; };
 template <> struct transpose_tag<PatternBlockingTag> { typedef TextBlockingTag type; };
 template <> struct transpose_tag<TextBlockingTag>    { typedef PatternBlockingTag type; };
 

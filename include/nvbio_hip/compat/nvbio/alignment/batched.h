@@ -11,15 +11,24 @@
 //     small kernel evaluates the stream's functors per job into a job table (string offsets, lengths, min_score), the
 //     tuned gfx950 kernels behind the C-ABI (include/nvbio_hip.h) score the table, and a second small kernel hands each
 //     result to stream.output().  init_context() runs in both small kernels; streams are pure functors of i.
+//   * DeviceThreadScheduler, staged stream: the same tuned kernels for streams whose patterns are not plain windows of packed
+//     words or whose scheme reads qualities -- nvBowtie's own streams (nvBowtie/bowtie2/cuda/alignment_utils.h:170-218,
+//     score_best_inl.h:54-148): io::ReadStream patterns (reads stored reversed, viewed forward or reverse-complemented), the
+//     reads' quality strings, SmithWatermanScoringScheme (scoring.h:206-356).  The job-table kernel then also writes each job's
+//     pattern (4 bits per symbol) and qualities (a byte per symbol), read through the stream's OWN iterators, into the batch
+//     object's scratch; the scheme's mismatch(q) is tabulated on the host.  last_path() still says "tuned".
 //   * DeviceThreadScheduler, any other stream: one lane per job runs the generic templates of alignment.h on whatever
-//     iterators the stream hands out (8-bit strings, user schemes, quality strings, other sinks ...).
+//     iterators the stream hands out (8-bit strings, user schemes that are not a function of (equal?, quality), other sinks ...).
 //   * HostThreadScheduler: the same templates over host pointers, OpenMP over jobs (batched_banded_inl.h:97-128).
 // DeviceStagedThreadScheduler / DeviceWarpScheduler are accepted as aliases of the device path (they are alternative
 // schedules of the same computation in the reference, batched.h:51-76).
 #pragma once
 #include "alignment.h"
+#include "traceback.h"
+#include "../io/utils.h"
 #include "../basic/packedstream.h"
 #include "../basic/packedstream_loader.h"
+#include "../basic/packed_view.h"
 #include "../basic/cuda/ldg.h"
 #include "../strings/string_set.h"
 #include <stdexcept>
@@ -107,69 +116,82 @@ struct device_buffer
 #endif
 
 // ---------------------------------------------------------------------------------------- stream recognition
-template <typename It> struct word_pointer { static const bool ok = false; };
-template <> struct word_pointer<const uint32*> { static const bool ok = true; NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static const uint32* get(const uint32* p) { return p; } };
-template <> struct word_pointer<uint32*>       { static const bool ok = true; NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static const uint32* get(uint32* p) { return p; } };
-template <> struct word_pointer< cuda::ldg_pointer<uint32> > { static const bool ok = true; NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static const uint32* get(cuda::ldg_pointer<uint32> p) { return p.base; } };
-template <typename It> struct word_pointer< const_cached_iterator<It> > { static const bool ok = word_pointer<It>::ok;
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static const uint32* get(const_cached_iterator<It> p) { return word_pointer<It>::get(p.base()); } };
+using nvbio::priv::word_pointer;         // basic/packed_view.h: "this iterator is a pointer to 32-bit words in memory"
+using nvbio::priv::packed_view;          //                      "this string is a window of a 2/4-bit PackedStream over such words"
 
-template <typename S> struct packed_view { static const bool ok = false; static const uint32 BITS = 0; static const bool BE = false; };
-template <typename I, uint32 B, bool E, typename VI>
-struct packed_view< vector_view< PackedStream<I, uint8, B, E, uint32>, VI > >
-{
-    static const bool   ok   = word_pointer<I>::ok && (B == 2u || B == 4u);
-    static const uint32 BITS = B;
-    static const bool   BE   = E;
-    typedef vector_view< PackedStream<I, uint8, B, E, uint32>, VI > view_type;
-    /// first word address (in words from address 0) and symbol offset of the view from it
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static void where(const view_type& v, uint64& word0, uint32& first)
+/// sinks the tuned route can fill: BestSink<int32>, and BestSink<int16> (examples/fmmap/fmmap.cu:306) while scores fit it
+template <typename S> struct best_sink { static const bool ok = false; static const bool narrow = false; };
+template <> struct best_sink< BestSink<int32> > { static const bool ok = true; static const bool narrow = false; };
+template <> struct best_sink< BestSink<int16> > { static const bool ok = true; static const bool narrow = true; };
+
+/// nvBowtie's scheme concept (nvBowtie/bowtie2/cuda/scoring.h:206-356): cost functors of the quality byte behind match(q) /
+/// mismatch(q), substitution(.,.,r,q,qq) = r == q ? match(qq) : mismatch(qq), four gap accessors.  Detected by the two nested
+/// cost-function typedefs; the host then CHECKS the concept on the values (quality_scheme_table) before any kernel relies on it.
+template <typename S, typename = void> struct quality_scheme : std::false_type {};
+template <typename S> struct quality_scheme<S, std::void_t<typename S::match_cost_function, typename S::mismatch_cost_function> > : std::true_type {};
+
+template <typename A> struct tuned_aligner { static const bool ok = false; static const bool QUAL = false; };
+#if defined(NVBIO_HIP_COMPAT_TUNED)
+template <AlignmentType T, typename G> struct tuned_aligner< GotohAligner<T, SimpleGotohScheme, G> > {
+    static const bool ok = true; static const bool QUAL = false; static const int32 KIND = NVBIO_HIP_GOTOH_ALIGNER; static const bool TEXT_BLOCKING = equal<G, TextBlockingTag>::pred;
+    static void scheme4(const GotohAligner<T, SimpleGotohScheme, G>& a, int32* v) { v[0] = a.scheme.m_match; v[1] = a.scheme.m_mismatch; v[2] = a.scheme.m_gap_open; v[3] = a.scheme.m_gap_ext; } };
+template <AlignmentType T, typename G> struct tuned_aligner< SmithWatermanAligner<T, SimpleSmithWatermanScheme, G> > {
+    static const bool ok = true; static const bool QUAL = false; static const int32 KIND = NVBIO_HIP_SW_ALIGNER; static const bool TEXT_BLOCKING = equal<G, TextBlockingTag>::pred;
+    static void scheme4(const SmithWatermanAligner<T, SimpleSmithWatermanScheme, G>& a, int32* v) { v[0] = a.scheme.m_match; v[1] = a.scheme.m_mismatch; v[2] = a.scheme.m_deletion; v[3] = a.scheme.m_insertion; } };
+template <AlignmentType T, typename G> struct tuned_aligner< EditDistanceAligner<T, G> > {
+    static const bool ok = true; static const bool QUAL = false; static const int32 KIND = NVBIO_HIP_SW_ALIGNER; static const bool TEXT_BLOCKING = equal<G, TextBlockingTag>::pred;
+    static void scheme4(const EditDistanceAligner<T, G>&, int32* v) { v[0] = 0; v[1] = -1; v[2] = -1; v[3] = -1; } };
+/// a Gotoh aligner over a scheme of nvBowtie's concept: its 256 mismatch penalties are tabulated on the host
+template <AlignmentType T, typename S, typename G> struct tuned_aligner< GotohAligner<T, S, G> > {
+    static const bool ok = quality_scheme<S>::value; static const bool QUAL = true; static const int32 KIND = NVBIO_HIP_GOTOH_ALIGNER; static const bool TEXT_BLOCKING = equal<G, TextBlockingTag>::pred;
+    /// false when the scheme's values do not follow the concept (a match bonus that depends on the quality, a substitution score
+    /// that depends on more than (equal?, quality)): such a stream runs on the generic lane
+    static bool table(const GotohAligner<T, S, G>& a, nvbio_hip_gotoh_qual_scheme& q)
     {
-        const PackedStream<I, uint8, B, E, uint32> ps = v.begin();
-        const uint32 per = 32u / B;
-        word0 = uint64(reinterpret_cast<uintptr_t>(word_pointer<I>::get(ps.stream()))) / 4u + ps.index() / per;
-        first = ps.index() % per;
+        const S& s = a.scheme;
+        q.match = s.match(uint8(0));
+        for (uint32 qq = 0; qq < 256u; ++qq)
+        {
+            q.mismatch[qq] = s.mismatch(uint8(qq));
+            if (s.match(uint8(qq)) != q.match) return false;
+            for (uint32 r = 0; r < 5u; ++r)
+                for (uint32 c = 0; c < 5u; ++c)
+                    if (s.substitution(7u * r, 3u * c, uint8(r), uint8(c), uint8(qq)) != (r == c ? q.match : q.mismatch[qq])) return false;
+        }
+        q.pattern_gap_open = s.pattern_gap_open(); q.pattern_gap_ext = s.pattern_gap_extension();
+        q.text_gap_open = s.text_gap_open();       q.text_gap_ext = s.text_gap_extension();
+        return true;
     }
 };
-
-template <typename A> struct simple_aligner { static const bool ok = false; };
-#if defined(NVBIO_HIP_COMPAT_TUNED)
-template <AlignmentType T, typename G> struct simple_aligner< GotohAligner<T, SimpleGotohScheme, G> > {
-    static const bool ok = true; static const int32 KIND = NVBIO_HIP_GOTOH_ALIGNER; static const bool TEXT_BLOCKING = equal<G, TextBlockingTag>::pred;
-    static void scheme4(const GotohAligner<T, SimpleGotohScheme, G>& a, int32* v) { v[0] = a.scheme.m_match; v[1] = a.scheme.m_mismatch; v[2] = a.scheme.m_gap_open; v[3] = a.scheme.m_gap_ext; } };
-template <AlignmentType T, typename G> struct simple_aligner< SmithWatermanAligner<T, SimpleSmithWatermanScheme, G> > {
-    static const bool ok = true; static const int32 KIND = NVBIO_HIP_SW_ALIGNER; static const bool TEXT_BLOCKING = equal<G, TextBlockingTag>::pred;
-    static void scheme4(const SmithWatermanAligner<T, SimpleSmithWatermanScheme, G>& a, int32* v) { v[0] = a.scheme.m_match; v[1] = a.scheme.m_mismatch; v[2] = a.scheme.m_deletion; v[3] = a.scheme.m_insertion; } };
-template <AlignmentType T, typename G> struct simple_aligner< EditDistanceAligner<T, G> > {
-    static const bool ok = true; static const int32 KIND = NVBIO_HIP_SW_ALIGNER; static const bool TEXT_BLOCKING = equal<G, TextBlockingTag>::pred;
-    static void scheme4(const EditDistanceAligner<T, G>&, int32* v) { v[0] = 0; v[1] = -1; v[2] = -1; v[3] = -1; } };
 #endif
 
-template <typename stream_type>
-struct recognised
-{
-    typedef typename stream_type::strings_type strings_type;
-    typedef typename stream_type::context_type context_type;
-    typedef decltype(strings_type().pattern) pattern_type;
-    typedef decltype(strings_type().text)    text_type;
-    typedef decltype(strings_type().quals)   quals_type;
-    typedef decltype(context_type().sink)    sink_type;
-    static const bool value = packed_view<pattern_type>::ok && packed_view<text_type>::ok && packed_view<text_type>::BITS == 2u &&
-                              equal<quals_type, trivial_quality_string>::pred && equal<sink_type, BestSink<int32> >::pred &&
-                              simple_aligner<typename stream_type::aligner_type>::ok;
-};
+/// how a pattern reaches the tuned kernels: in place (a window of packed words), staged (read through its own operator[] into the
+/// batch's scratch: io::ReadStream views of <= 4-bit symbols), or not at all
+template <typename P> struct pattern_source { static const bool direct = packed_view<P>::ok; static const bool stageable = packed_view<P>::ok; };
+template <typename St, typename Q> struct pattern_source< io::ReadStream<St, Q> >
+{ static const bool direct = false; static const bool stageable = (io::ReadStream<St, Q>::SYMBOL_SIZE <= 4u); };
 
-/// the same test for a traceback stream (batched.h:359-420: its context holds a backtracer and an Alignment<int32> instead of a sink)
-template <typename stream_type>
-struct recognised_tb
+template <typename stream_type, typename sink_like>
+struct recognition
 {
     typedef typename stream_type::strings_type strings_type;
     typedef decltype(strings_type().pattern) pattern_type;
     typedef decltype(strings_type().text)    text_type;
     typedef decltype(strings_type().quals)   quals_type;
-    static const bool value = packed_view<pattern_type>::ok && packed_view<text_type>::ok && packed_view<text_type>::BITS == 2u &&
-                              equal<quals_type, trivial_quality_string>::pred && simple_aligner<typename stream_type::aligner_type>::ok;
+    typedef tuned_aligner<typename stream_type::aligner_type> aligner;
+    static const bool text_ok = packed_view<text_type>::ok && packed_view<text_type>::BITS == 2u;
+    /// patterns in place: the strings are windows of packed words and the scheme ignores qualities
+    static const bool zero_copy = aligner::ok && !aligner::QUAL && text_ok && pattern_source<pattern_type>::direct && sink_like::value;
+    /// patterns (and qualities, for a quality scheme) staged through the stream's own iterators
+    static const bool staged = aligner::ok && text_ok && pattern_source<pattern_type>::stageable && sink_like::value && !zero_copy;
+    static const bool value = zero_copy || staged;
+    static const bool stage_quals = staged && aligner::QUAL;
 };
+template <typename stream_type> struct score_sink_ok { static const bool value = best_sink< decltype(typename stream_type::context_type().sink) >::ok; };
+struct any_sink_ok { static const bool value = true; };
+/// score streams (context holds a sink) and traceback streams (batched.h:359-420: a backtracer and an Alignment<int32> instead)
+template <typename stream_type> struct recognised    : recognition<stream_type, score_sink_ok<stream_type> > {};
+template <typename stream_type> struct recognised_tb : recognition<stream_type, any_sink_ok> {};
 
 #if defined(NVBIO_HIP_COMPAT_TUNED)
 /// the job table the tuned kernels consume (structure of arrays in one device buffer)
@@ -177,7 +199,11 @@ struct job_table
 {
     uint64* pat_begin; uint32* pat_len; uint64* txt_begin; uint32* txt_len; int32* min_score; int32* score; uint32* sink; uint8* ok;
     unsigned long long* bounds;        // [0] lowest pattern word, [1] end pattern word, [2] lowest text word, [3] end text word
+    uint32* stage_words; uint8* stage_quals; uint32 stage_stride;         // staged patterns: job i at symbol i * stage_stride (4-bit, little-endian)
     static uint64 bytes(const uint32 n) { return 64u + uint64(n) * (8u + 4u + 8u + 4u + 4u + 4u + 8u + 1u) + 8u * 16u; }
+    static uint32 stride_for(const uint32 maxP) { const uint32 s = (maxP + 7u) & ~7u; return s ? s : 8u; }
+    static uint64 stage_bytes(const uint32 n, const uint32 maxP, const bool quals)
+    { const uint64 sym = uint64(n) * stride_for(maxP) + 64u; return sym / 2u + (quals ? sym : 0u) + 32u; }
     void carve(uint8* p, const uint32 n)
     {
         bounds = reinterpret_cast<unsigned long long*>(p); p += 64u;
@@ -189,6 +215,7 @@ struct job_table
         min_score = reinterpret_cast<int32*>(p);  p += uint64(n) * 4u;
         score     = reinterpret_cast<int32*>(p);  p += uint64(n) * 4u;
         ok        = p;
+        stage_words = nullptr; stage_quals = nullptr; stage_stride = 0;
     }
 };
 
@@ -199,10 +226,20 @@ __device__ __forceinline__ unsigned long long wave_max(unsigned long long v)
 
 __global__ void init_bounds_kernel(unsigned long long* b) { if (threadIdx.x < 4u) b[threadIdx.x] = (threadIdx.x & 1u) ? 0ull : ~0ull; }
 
-/// evaluate the stream's functors per job: where its strings live, how long they are, its min_score
+/// where a pattern lives (in place), or nothing (staged)
+template <typename P, bool DIRECT> struct pattern_where {
+    static const uint32 BITS = packed_view<P>::BITS; static const bool BE = packed_view<P>::BE;
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static void get(const P& p, uint64& w, uint32& f) { packed_view<P>::where(p, w, f); } };
+template <typename P> struct pattern_where<P, false> {
+    static const uint32 BITS = 4u; static const bool BE = false;
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static void get(const P&, uint64& w, uint32& f) { w = 0; f = 0; } };
+
+/// evaluate the stream's functors per job: where its strings live, how long they are, its min_score; a staged stream also has its
+/// pattern (and qualities) read through its own iterators into the scratch
 template <typename stream_type, typename R>
 __global__ void __launch_bounds__(128) describe_jobs_kernel(const stream_type stream, const job_table t)
 {
+    typedef pattern_where<typename R::pattern_type, !R::staged> pwhere;
     const uint32 i = blockIdx.x * 128u + threadIdx.x;
     unsigned long long plo = ~0ull, phi = 0ull, tlo = ~0ull, thi = 0ull;
     if (i < stream.size())
@@ -214,14 +251,40 @@ __global__ void __launch_bounds__(128) describe_jobs_kernel(const stream_type st
         {
             const uint32 len = stream.pattern_length(i, &ctx);
             stream.load_strings(i, 0u, len, &ctx, &strings);
-            packed_view<typename R::pattern_type>::where(strings.pattern, pw, pf);
+            pwhere::get(strings.pattern, pw, pf);
             packed_view<typename R::text_type>::where(strings.text, tw, tf);
             pl = strings.pattern.length(); tl = strings.text.length(); ms = ctx.min_score;
-            plo = pw; phi = pw + (pf + pl + 32u / packed_view<typename R::pattern_type>::BITS - 1u) / (32u / packed_view<typename R::pattern_type>::BITS);
             tlo = tw; thi = tw + (tf + tl + 15u) / 16u;
+            if (R::staged)
+            {
+                // a job longer than the announced maximum cannot be staged: it is given an empty text, which the kernels refuse like
+                // any text shorter than its pattern (the stream's max_pattern_length() is a contract, batched.h:252-256)
+                if (pl > t.stage_stride) { tl = 0; }
+                else
+                {
+                    uint32* w = t.stage_words + uint64(i) * (t.stage_stride / 8u);
+                    for (uint32 k0 = 0; k0 < pl; k0 += 8u)
+                    {
+                        uint32 word = 0;
+                        for (uint32 k = 0; k < 8u; ++k) if (k0 + k < pl) word |= (uint32(strings.pattern[k0 + k]) & 15u) << (4u * k);
+                        w[k0 / 8u] = word;
+                    }
+                    if (R::stage_quals)
+                    {
+                        uint32* qw = reinterpret_cast<uint32*>(t.stage_quals + uint64(i) * t.stage_stride);
+                        for (uint32 k0 = 0; k0 < pl; k0 += 4u)
+                        {
+                            uint32 word = 0;
+                            for (uint32 k = 0; k < 4u; ++k) if (k0 + k < pl) word |= uint32(uint8(strings.quals[k0 + k])) << (8u * k);
+                            qw[k0 / 4u] = word;
+                        }
+                    }
+                }
+            }
+            else { plo = pw; phi = pw + (pf + pl + 32u / pwhere::BITS - 1u) / (32u / pwhere::BITS); }
         }
         // offsets are kept absolute (symbols from address 0) until the host knows the lowest word
-        t.pat_begin[i] = pw * (32u / packed_view<typename R::pattern_type>::BITS) + pf; t.pat_len[i] = pl;
+        t.pat_begin[i] = R::staged ? uint64(i) * t.stage_stride : pw * (32u / pwhere::BITS) + pf; t.pat_len[i] = pl;
         t.txt_begin[i] = tw * 16u + tf; t.txt_len[i] = tl; t.min_score[i] = ms;
     }
     plo = wave_min(plo); phi = wave_max(phi); tlo = wave_min(tlo); thi = wave_max(thi);
@@ -280,15 +343,27 @@ __global__ void __launch_bounds__(128) replay_tracebacks_kernel(stream_type stre
     stream.output(i, &ctx);
 }
 
-/// describe -> (sync: two pointers) -> rebase; fills the C-ABI string sets
+/// describe (+ stage) -> (sync: the four bounds) -> rebase; fills the C-ABI string sets.  quals / n_quals: the staged qualities.
 template <typename stream_type, typename R = recognised<stream_type> >
 inline void build_job_table(const stream_type& stream, device_buffer& buf, job_table& t, nvbio_hip_string_set& ps, nvbio_hip_string_set& ts, hipStream_t hs,
-                            const uint64 extra_bytes = 0, uint8** extra = NULL)
+                            const uint64 extra_bytes = 0, uint8** extra = NULL, const uint8** quals = NULL, uint64* n_quals = NULL)
 {
     const uint32 n = stream.size();
-    uint8* base = buf.reserve(job_table::bytes(n) + extra_bytes + 16u);
+    const uint32 maxP = stream.max_pattern_length();
+    const uint64 table = (job_table::bytes(n) + 15u) & ~uint64(15);
+    const uint64 stage = R::staged ? ((job_table::stage_bytes(n, maxP, R::stage_quals) + 15u) & ~uint64(15)) : 0u;
+    uint8* base = buf.reserve(table + stage + extra_bytes + 16u);
     t.carve(base, n);
-    if (extra) *extra = base + ((job_table::bytes(n) + 15u) & ~uint64(15));
+    if (R::staged)
+    {
+        const uint64 sym = uint64(n) * job_table::stride_for(maxP) + 64u;
+        t.stage_stride = job_table::stride_for(maxP);
+        t.stage_words  = reinterpret_cast<uint32*>(base + table);
+        t.stage_quals  = R::stage_quals ? base + table + ((sym / 2u + 15u) & ~uint64(15)) : nullptr;
+        if (quals)   *quals   = t.stage_quals;
+        if (n_quals) *n_quals = R::stage_quals ? sym : 0u;
+    }
+    if (extra) *extra = base + table + stage;
     hipLaunchKernelGGL(init_bounds_kernel, dim3(1), dim3(64), 0, hs, t.bounds);
     hipLaunchKernelGGL((describe_jobs_kernel<stream_type, R>), dim3((n + 127u) / 128u), dim3(128), 0, hs, stream, t);
     unsigned long long b[4];
@@ -296,20 +371,94 @@ inline void build_job_table(const stream_type& stream, device_buffer& buf, job_t
     check(hipStreamSynchronize(hs), "hipStreamSynchronize");
     if (b[1] == 0ull) { b[0] = 0ull; b[1] = 1ull; }          // no job has a pattern / text: any valid range will do
     if (b[3] == 0ull) { b[2] = 0ull; b[3] = 1ull; }
-    const uint32 pper = 32u / packed_view<typename R::pattern_type>::BITS;
-    hipLaunchKernelGGL(rebase_jobs_kernel, dim3((n + 255u) / 256u), dim3(256), 0, hs, n, t.pat_begin, uint64(b[0]) * pper, t.txt_begin, uint64(b[2]) * 16u);
-    ps.words = reinterpret_cast<const uint32*>(uintptr_t(b[0]) * 4u); ps.n_words = b[1] - b[0];
-    ps.bits = packed_view<typename R::pattern_type>::BITS; ps.big_endian = packed_view<typename R::pattern_type>::BE ? 1u : 0u;
+    typedef pattern_where<typename R::pattern_type, !R::staged> pwhere;
+    const uint32 pper = 32u / pwhere::BITS;
+    hipLaunchKernelGGL(rebase_jobs_kernel, dim3((n + 255u) / 256u), dim3(256), 0, hs, n, t.pat_begin, R::staged ? uint64(0) : uint64(b[0]) * pper, t.txt_begin, uint64(b[2]) * 16u);
+    if (R::staged) { ps.words = t.stage_words; ps.n_words = (uint64(n) * t.stage_stride + 64u) / 8u; ps.bits = 4u; ps.big_endian = 0u; }
+    else           { ps.words = reinterpret_cast<const uint32*>(uintptr_t(b[0]) * 4u); ps.n_words = b[1] - b[0]; ps.bits = pwhere::BITS; ps.big_endian = pwhere::BE ? 1u : 0u; }
     ps.begin = t.pat_begin; ps.length = t.pat_len; ps.fixed_length = 0; ps._pad = 0;
     ts.words = reinterpret_cast<const uint32*>(uintptr_t(b[2]) * 4u); ts.n_words = b[3] - b[2];
     ts.bits = 2u; ts.big_endian = packed_view<typename R::text_type>::BE ? 1u : 0u;
     ts.begin = t.txt_begin; ts.length = t.txt_len; ts.fixed_length = 0; ts._pad = 0;
 }
+
+/// the largest |cost| of an aligner's scheme (to bound what an int16 sink can hold)
+inline int64 abs64(const int32 v) { return v < 0 ? -int64(v) : int64(v); }
 #endif // NVBIO_HIP_COMPAT_TUNED
 
 template <uint32 BAND_LEN> struct tuned_band { static const bool value = (BAND_LEN == 3u || BAND_LEN == 5u || BAND_LEN == 7u || BAND_LEN == 15u || BAND_LEN == 31u); };
 
 } // namespace priv
+
+#if defined(NVBIO_HIP_COMPAT_TUNED)
+namespace priv {
+/// the scheme of a recognised stream as the C-ABI takes it, and the call of the matching entry point
+template <typename stream_type>
+struct tuned_scheme
+{
+    typedef typename stream_type::aligner_type aligner_type;
+    typedef tuned_aligner<aligner_type>        TA;
+    int32 sc[4]; nvbio_hip_gotoh_qual_scheme q; int64 A;
+
+    /// false: the scheme's values are outside the tuned kernels' contract -> generic lane
+    bool init(const stream_type& stream)
+    {
+        A = 0;
+        if constexpr (TA::QUAL)
+        {
+            if (!TA::table(stream.aligner(), q)) return false;
+            A = std::max(std::max(abs64(q.match), abs64(q.pattern_gap_open)), std::max(abs64(q.pattern_gap_ext), std::max(abs64(q.text_gap_open), abs64(q.text_gap_ext))));
+            for (int i = 0; i < 256; ++i) A = std::max(A, abs64(q.mismatch[i]));
+        }
+        else
+        {
+            TA::scheme4(stream.aligner(), sc);
+            for (int i = 0; i < 4; ++i) A = std::max(A, abs64(sc[i]));
+        }
+        return true;
+    }
+    /// an int16 sink holds every score of the batch (the reference narrows each reported score to the sink's type)
+    template <typename sink_type>
+    bool sink_fits(const stream_type& stream) const
+    { return !best_sink<sink_type>::narrow || (int64(stream.max_pattern_length()) + stream.max_text_length() + 2) * A < 32000; }
+
+    int banded_score(const uint32 band, const stream_type& stream, const job_table& t, const nvbio_hip_string_set& ps, const nvbio_hip_string_set& ts,
+                     const uint8* quals, const uint64 n_quals, hipStream_t hs) const
+    {
+        const uint32 n = stream.size(), maxP = stream.max_pattern_length(), maxT = stream.max_text_length();
+        if constexpr (TA::QUAL) return nvbio_hip_banded_gotoh_score_qual(&q, int32(aligner_type::TYPE), band, &ps, quals, n_quals, &ts, maxP, maxT, n, t.score, t.sink, hs);
+        else if (TA::KIND == NVBIO_HIP_GOTOH_ALIGNER) { const nvbio_hip_gotoh_scheme g = { sc[0], sc[1], sc[2], sc[3] };
+            return nvbio_hip_banded_gotoh_score(&g, int32(aligner_type::TYPE), band, &ps, &ts, maxP, maxT, n, t.score, t.sink, hs); }
+        else { const nvbio_hip_sw_scheme w = { sc[0], sc[1], sc[2], sc[3] };
+            return nvbio_hip_banded_sw_score(&w, int32(aligner_type::TYPE), band, &ps, &ts, maxP, maxT, n, t.score, t.sink, hs); }
+    }
+    int full_score(const stream_type& stream, const job_table& t, const nvbio_hip_string_set& ps, const nvbio_hip_string_set& ts,
+                   const uint8* quals, const uint64 n_quals, hipStream_t hs) const
+    {
+        const uint32 n = stream.size(), maxP = stream.max_pattern_length(), maxT = stream.max_text_length();
+        const int32 algo = TA::TEXT_BLOCKING ? NVBIO_HIP_TEXT_BLOCKING : NVBIO_HIP_PATTERN_BLOCKING;
+        if constexpr (TA::QUAL) return nvbio_hip_alignment_score_qual(&q, algo, int32(aligner_type::TYPE), &ps, quals, n_quals, &ts, maxP, maxT, t.min_score, n, t.score, t.sink, t.ok, hs);
+        else return nvbio_hip_alignment_score(TA::KIND, algo, sc, int32(aligner_type::TYPE), &ps, &ts, maxP, maxT, t.min_score, n, t.score, t.sink, t.ok, hs);
+    }
+    /// band == 0: full matrix
+    int traceback(const uint32 band, const stream_type& stream, const job_table& t, const nvbio_hip_string_set& ps, const nvbio_hip_string_set& ts,
+                  const uint8* quals, const uint64 n_quals, uint32* source, uint16* cigar, const uint32 stride, uint32* cigar_len, uint8* temp, const uint64 tb, hipStream_t hs) const
+    {
+        const uint32 n = stream.size(), maxP = stream.max_pattern_length(), maxT = stream.max_text_length();
+        const int32 ty = int32(aligner_type::TYPE);
+        if constexpr (TA::QUAL)
+            return band ? nvbio_hip_banded_gotoh_traceback_qual(&q, ty, band, &ps, quals, n_quals, &ts, maxP, maxT, n, t.score, t.sink, source, cigar, stride, cigar_len, temp, tb, hs)
+                        : nvbio_hip_gotoh_traceback_qual(&q, ty, &ps, quals, n_quals, &ts, maxP, maxT, n, t.score, t.sink, source, cigar, stride, cigar_len, temp, tb, hs);
+        else if (TA::KIND == NVBIO_HIP_GOTOH_ALIGNER) { const nvbio_hip_gotoh_scheme g = { sc[0], sc[1], sc[2], sc[3] };
+            return band ? nvbio_hip_banded_gotoh_traceback(&g, ty, band, &ps, &ts, maxP, maxT, n, t.score, t.sink, source, cigar, stride, cigar_len, temp, tb, hs)
+                        : nvbio_hip_gotoh_traceback(&g, ty, &ps, &ts, maxP, maxT, n, t.score, t.sink, source, cigar, stride, cigar_len, temp, tb, hs); }
+        else { const nvbio_hip_sw_scheme w = { sc[0], sc[1], sc[2], sc[3] };
+            return band ? nvbio_hip_banded_sw_traceback(&w, ty, band, &ps, &ts, maxP, maxT, n, t.score, t.sink, source, cigar, stride, cigar_len, temp, tb, hs)
+                        : nvbio_hip_sw_traceback(&w, ty, &ps, &ts, maxP, maxT, n, t.score, t.sink, source, cigar, stride, cigar_len, temp, tb, hs); }
+    }
+};
+} // namespace priv
+#endif
 
 // ---------------------------------------------------------------------------------------- BatchedBandedAlignmentScore
 template <uint32 BAND_LEN, typename stream_type, typename algorithm_type = DeviceThreadScheduler>
@@ -377,18 +526,12 @@ private:
     {
 #if defined(NVBIO_HIP_COMPAT_TUNED)
         const uint32 n = stream.size();
-        priv::job_table t; nvbio_hip_string_set ps, ts;
-        priv::build_job_table(stream, m_jobs, t, ps, ts, hs);
-        int32 sc[4];
-        priv::simple_aligner<aligner_type>::scheme4(stream.aligner(), sc);
-        int err;
-        if (priv::simple_aligner<aligner_type>::KIND == NVBIO_HIP_GOTOH_ALIGNER) {
-            const nvbio_hip_gotoh_scheme g = { sc[0], sc[1], sc[2], sc[3] };
-            err = nvbio_hip_banded_gotoh_score(&g, int32(aligner_type::TYPE), BAND_LEN, &ps, &ts, stream.max_pattern_length(), stream.max_text_length(), n, t.score, t.sink, hs);
-        } else {
-            const nvbio_hip_sw_scheme w = { sc[0], sc[1], sc[2], sc[3] };
-            err = nvbio_hip_banded_sw_score(&w, int32(aligner_type::TYPE), BAND_LEN, &ps, &ts, stream.max_pattern_length(), stream.max_text_length(), n, t.score, t.sink, hs);
-        }
+        priv::tuned_scheme<stream_type> scheme;
+        typedef decltype(typename stream_type::context_type().sink) sink_type;
+        if (!scheme.init(stream) || !scheme.template sink_fits<sink_type>(stream)) { run_device(stream, hs, std::false_type()); return; }
+        priv::job_table t; nvbio_hip_string_set ps, ts; const uint8* quals = NULL; uint64 n_quals = 0;
+        priv::build_job_table(stream, m_jobs, t, ps, ts, hs, 0u, NULL, &quals, &n_quals);
+        const int err = scheme.banded_score(BAND_LEN, stream, t, ps, ts, quals, n_quals, hs);
         if (err == 801) { run_device(stream, hs, std::false_type()); return; }       // outside the tuned kernels' contract (e.g. asymmetric linear gaps)
         priv::check(err, "nvbio_hip_banded_score");
         hipLaunchKernelGGL((priv::output_jobs_kernel<stream_type>), dim3((n + 127u) / 128u), dim3(128), 0, hs, stream, t);
@@ -477,15 +620,13 @@ private:
     {
 #if defined(NVBIO_HIP_COMPAT_TUNED)
         const uint32 n = stream.size();
-        if (stream.max_pattern_length() > 1024u) { run_device(stream, temp_size, temp, hs, std::false_type()); return; }    // the tuned sweep keeps <= 1024 rows in a wave
-        priv::job_table t; nvbio_hip_string_set ps, ts;
-        priv::build_job_table(stream, m_jobs, t, ps, ts, hs);
-        int32 sc[4];
-        priv::simple_aligner<aligner_type>::scheme4(stream.aligner(), sc);
-        const int err = nvbio_hip_alignment_score(priv::simple_aligner<aligner_type>::KIND,
-                            priv::simple_aligner<aligner_type>::TEXT_BLOCKING ? NVBIO_HIP_TEXT_BLOCKING : NVBIO_HIP_PATTERN_BLOCKING,
-                            sc, int32(aligner_type::TYPE), &ps, &ts, stream.max_pattern_length(), stream.max_text_length(),
-                            t.min_score, n, t.score, t.sink, t.ok, hs);
+        priv::tuned_scheme<stream_type> scheme;
+        typedef decltype(typename stream_type::context_type().sink) sink_type;
+        // the tuned sweep keeps <= 1024 rows in a wave
+        if (stream.max_pattern_length() > 1024u || !scheme.init(stream) || !scheme.template sink_fits<sink_type>(stream)) { run_device(stream, temp_size, temp, hs, std::false_type()); return; }
+        priv::job_table t; nvbio_hip_string_set ps, ts; const uint8* quals = NULL; uint64 n_quals = 0;
+        priv::build_job_table(stream, m_jobs, t, ps, ts, hs, 0u, NULL, &quals, &n_quals);
+        const int err = scheme.full_score(stream, t, ps, ts, quals, n_quals, hs);
         if (err == 801) { run_device(stream, temp_size, temp, hs, std::false_type()); return; }
         priv::check(err, "nvbio_hip_alignment_score");
         hipLaunchKernelGGL((priv::output_jobs_kernel<stream_type>), dim3((n + 127u) / 128u), dim3(128), 0, hs, stream, t);
@@ -502,76 +643,191 @@ private:
 
 // ---------------------------------------------------------------------------------------- tracebacks
 // BatchedBandedAlignmentTraceback / BatchedAlignmentTraceback (batched.h:432-476) over the reference's traceback stream concept
-// (context_type {min_score, backtracer, alignment}).  Offered for the streams the tuned kernels recognise -- packed strings in
-// device memory, trivial qualities, the library's Simple*Scheme / edit-distance aligners, any user backtracer with clip(n) /
-// push(op): the C-ABI traceback produces the run-length CIGAR, and a second kernel replays it into the stream's own backtracer
-// and output().  CHECKPOINTS is accepted and ignored (the kernels keep the whole flow matrix).  Other streams and the host
-// scheduler are not offered here: there is no generic per-lane traceback template in this layer.
-#if defined(NVBIO_HIP_COMPAT_TUNED)
+// (context_type {min_score, backtracer, alignment}; batched_banded_inl.h:248-451, batched_inl.h:610-850), with the same three
+// executions as the scoring classes:
+//   * tuned   -- recognised streams (packed strings in place, or staged through the stream's own iterators as for scoring; the
+//                library's Simple*Scheme / edit-distance aligners or a scheme of nvBowtie's concept; any backtracer with clip(n) /
+//                push(op)): the C-ABI traceback produces the run-length CIGAR, and a second kernel replays it into the stream's own
+//                backtracer and output();
+//   * generic -- any other stream (8-bit strings, user schemes, asymmetric linear gaps): one lane per job runs the templates of
+//                traceback.h on the stream's iterators, flow flags in the batch object's scratch;
+//   * host    -- HostThreadScheduler: the same templates under OpenMP over host pointers.
+// CHECKPOINTS is accepted and ignored (every execution keeps the whole flow matrix of a job).
 namespace priv {
+
+template <uint32 BAND_LEN, typename stream_type>
+NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void banded_traceback_job(const stream_type& stream, const uint32 i, uint8* flags)
+{
+    typename stream_type::context_type ctx;
+    typename stream_type::strings_type strings;
+    if (!stream.init_context(i, &ctx)) { stream.output(i, &ctx); return; }          // batched_banded_inl.h:262-268: declined jobs are output as they are
+    const uint32 len = stream.pattern_length(i, &ctx);
+    stream.load_strings(i, 0u, len, &ctx, &strings);
+    ctx.alignment = banded_traceback<BAND_LEN>(stream.aligner(), strings.pattern, strings.quals, strings.text, ctx.backtracer, flags);
+    stream.output(i, &ctx);
+}
 template <typename stream_type>
+NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void full_traceback_job(const stream_type& stream, const uint32 i, uint8* scratch, const uint32 maxP, const uint32 maxT)
+{
+    typename stream_type::context_type ctx;
+    typename stream_type::strings_type strings;
+    if (!stream.init_context(i, &ctx)) { stream.output(i, &ctx); return; }
+    const uint32 len = stream.pattern_length(i, &ctx);
+    stream.load_strings(i, 0u, len, &ctx, &strings);
+    uint8* flags = scratch;
+    int32* rows  = reinterpret_cast<int32*>(scratch + full_traceback_flag_bytes(maxP, maxT));
+    int16* col   = reinterpret_cast<int16*>(scratch + full_traceback_flag_bytes(maxP, maxT) + full_traceback_row_bytes(maxP));
+    ctx.alignment = matrix_traceback(stream.aligner(), strings.pattern, strings.quals, strings.text, ctx.backtracer, flags, rows, col);
+    stream.output(i, &ctx);
+}
+
+#if defined(__HIPCC__)
+template <uint32 BAND_LEN, typename stream_type>
+__global__ void __launch_bounds__(128) batched_banded_traceback_kernel(const stream_type stream, uint8* scratch, const uint64 stride)
+{
+    const uint32 i = blockIdx.x * 128u + threadIdx.x;
+    if (i < stream.size()) banded_traceback_job<BAND_LEN>(stream, i, scratch + uint64(i) * stride);
+}
+template <typename stream_type>
+__global__ void __launch_bounds__(128) batched_full_traceback_kernel(const stream_type stream, uint8* scratch, const uint64 stride, const uint32 maxP, const uint32 maxT)
+{
+    const uint32 i = blockIdx.x * 128u + threadIdx.x;
+    if (i < stream.size()) full_traceback_job(stream, i, scratch + uint64(i) * stride, maxP, maxT);
+}
+#endif
+
+/// BAND_LEN == 0: full matrix
+template <uint32 BAND_LEN, typename stream_type>
 struct traceback_runner
 {
     typedef typename stream_type::aligner_type aligner_type;
-    static_assert(recognised_tb<stream_type>::value, "compat tracebacks take packed-string streams with trivial qualities and Simple*Scheme / edit-distance aligners");
+    traceback_runner() : m_path("none") {}
 
-    /// band == 0: full matrix
-    void run(const stream_type& stream, const uint32 band, hipStream_t hs)
+    void run_host(const stream_type& stream)
     {
-        const uint32 n = stream.size();
-        if (n == 0) return;
+        const int64 n = int64(stream.size());
         const uint32 maxP = stream.max_pattern_length(), maxT = stream.max_text_length();
+        const uint64 bytes = BAND_LEN ? banded_traceback_scratch(BAND_LEN ? BAND_LEN : 1u, maxP) : full_traceback_scratch(maxP, maxT);
+        #pragma omp parallel
+        {
+            std::vector<uint64> scratch(bytes / 8u + 2u);
+            #pragma omp for schedule(dynamic, 64)
+            for (int64 i = 0; i < n; ++i) job(stream, uint32(i), reinterpret_cast<uint8*>(scratch.data()), maxP, maxT);
+        }
+        m_path = "host";
+    }
+#if defined(__HIPCC__)
+    void run(const stream_type& stream, hipStream_t hs)
+    {
+        if (stream.size() == 0) return;
+        run_device(stream, hs, std::integral_constant<bool, recognised_tb<stream_type>::value && (BAND_LEN == 0u || tuned_band<BAND_LEN ? BAND_LEN : 3u>::value)>());
+    }
+    void run_device(const stream_type& stream, hipStream_t hs, std::false_type)
+    {
+        const uint32 n = stream.size(), maxP = stream.max_pattern_length(), maxT = stream.max_text_length();
+        const uint64 stride = BAND_LEN ? banded_traceback_scratch(BAND_LEN ? BAND_LEN : 1u, maxP) : full_traceback_scratch(maxP, maxT);
+        uint8* scratch = m_temp.reserve(uint64(n) * stride + 16u);
+        launch_generic(stream, scratch, stride, maxP, maxT, hs, std::integral_constant<bool, BAND_LEN != 0u>());
+        check(hipGetLastError(), "batched_traceback_kernel");
+        m_path = "generic";
+    }
+    void launch_generic(const stream_type& stream, uint8* scratch, const uint64 stride, uint32, uint32, hipStream_t hs, std::true_type)
+    { hipLaunchKernelGGL((batched_banded_traceback_kernel<(BAND_LEN ? BAND_LEN : 3u), stream_type>), dim3((stream.size() + 127u) / 128u), dim3(128), 0, hs, stream, scratch, stride); }
+    void launch_generic(const stream_type& stream, uint8* scratch, const uint64 stride, uint32 maxP, uint32 maxT, hipStream_t hs, std::false_type)
+    { hipLaunchKernelGGL((batched_full_traceback_kernel<stream_type>), dim3((stream.size() + 127u) / 128u), dim3(128), 0, hs, stream, scratch, stride, maxP, maxT); }
+
+    void run_device(const stream_type& stream, hipStream_t hs, std::true_type)
+    {
+#if defined(NVBIO_HIP_COMPAT_TUNED)
+        const uint32 n = stream.size();
+        const uint32 band = BAND_LEN;
+        const uint32 maxP = stream.max_pattern_length(), maxT = stream.max_text_length();
+        tuned_scheme<stream_type> scheme;
+        if (!scheme.init(stream)) { run_device(stream, hs, std::false_type()); return; }
         const uint32 stride = band ? maxP + band + 4u : maxP + maxT + 4u;          // run-length words never exceed the walk's length
         const uint64 extra = uint64(n) * (8u + 4u + uint64(stride) * 2u) + 64u;
-        job_table t; nvbio_hip_string_set ps, ts; uint8* x = NULL;
-        build_job_table<stream_type, recognised_tb<stream_type> >(stream, m_jobs, t, ps, ts, hs, extra, &x);
+        job_table t; nvbio_hip_string_set ps, ts; uint8* x = NULL; const uint8* quals = NULL; uint64 n_quals = 0;
+        build_job_table<stream_type, recognised_tb<stream_type> >(stream, m_jobs, t, ps, ts, hs, extra, &x, &quals, &n_quals);
         uint32* source = reinterpret_cast<uint32*>(x);
         uint32* cigar_len = source + 2u * uint64(n);
         uint16* cigar = reinterpret_cast<uint16*>(cigar_len + n);
         const uint64 tb = band ? nvbio_hip_banded_gotoh_traceback_temp_bytes(band, maxP, n) : nvbio_hip_gotoh_traceback_temp_bytes(maxP, maxT, n);
         uint8* temp = m_temp.reserve(tb + 16u);
-        int32 sc[4];
-        simple_aligner<aligner_type>::scheme4(stream.aligner(), sc);
-        int err;
-        if (simple_aligner<aligner_type>::KIND == NVBIO_HIP_GOTOH_ALIGNER) {
-            const nvbio_hip_gotoh_scheme g = { sc[0], sc[1], sc[2], sc[3] };
-            err = band ? nvbio_hip_banded_gotoh_traceback(&g, int32(aligner_type::TYPE), band, &ps, &ts, maxP, maxT, n, t.score, t.sink, source, cigar, stride, cigar_len, temp, tb, hs)
-                       : nvbio_hip_gotoh_traceback(&g, int32(aligner_type::TYPE), &ps, &ts, maxP, maxT, n, t.score, t.sink, source, cigar, stride, cigar_len, temp, tb, hs);
-        } else {
-            const nvbio_hip_sw_scheme w = { sc[0], sc[1], sc[2], sc[3] };
-            err = band ? nvbio_hip_banded_sw_traceback(&w, int32(aligner_type::TYPE), band, &ps, &ts, maxP, maxT, n, t.score, t.sink, source, cigar, stride, cigar_len, temp, tb, hs)
-                       : nvbio_hip_sw_traceback(&w, int32(aligner_type::TYPE), &ps, &ts, maxP, maxT, n, t.score, t.sink, source, cigar, stride, cigar_len, temp, tb, hs);
-        }
+        const int err = scheme.traceback(band, stream, t, ps, ts, quals, n_quals, source, cigar, stride, cigar_len, temp, tb, hs);
+        if (err == 801) { run_device(stream, hs, std::false_type()); return; }     // e.g. asymmetric linear gaps, values beyond int16
         check(err, "nvbio_hip_*_traceback");
         hipLaunchKernelGGL((replay_tracebacks_kernel<stream_type>), dim3((n + 127u) / 128u), dim3(128), 0, hs, stream, t, source, cigar, stride, cigar_len);
         check(hipGetLastError(), "replay_tracebacks_kernel");
+        m_path = "tuned";
+#else
+        run_device(stream, hs, std::false_type());
+#endif
     }
     device_buffer m_jobs, m_temp;
+#endif
+    const char* m_path;
+
+private:
+    static void job(const stream_type& stream, const uint32 i, uint8* scratch, const uint32 maxP, const uint32 maxT)
+    { job(stream, i, scratch, maxP, maxT, std::integral_constant<bool, BAND_LEN != 0u>()); }
+    static void job(const stream_type& stream, const uint32 i, uint8* scratch, uint32, uint32, std::true_type) { banded_traceback_job<(BAND_LEN ? BAND_LEN : 3u)>(stream, i, scratch); }
+    static void job(const stream_type& stream, const uint32 i, uint8* scratch, uint32 maxP, uint32 maxT, std::false_type) { full_traceback_job(stream, i, scratch, maxP, maxT); }
 };
 } // namespace priv
 
 template <uint32 BAND_LEN, uint32 CHECKPOINTS, typename stream_type, typename algorithm_type = DeviceThreadScheduler>
 struct BatchedBandedAlignmentTraceback
 {
-    static_assert(!equal<algorithm_type, HostThreadScheduler>::pred, "compat tracebacks run on the device schedulers");
-    static_assert(priv::tuned_band<BAND_LEN>::value, "bands 3, 5, 7, 15 and 31");
+    static_assert(BAND_LEN >= 2u, "a band of at least two cells");
     static uint64 min_temp_storage(const uint32, const uint32, const uint32) { return 0u; }        // the batch object owns its storage
     static uint64 max_temp_storage(const uint32, const uint32, const uint32) { return 0u; }
-    void enact(stream_type stream, uint64 = 0u, uint8* = NULL, hipStream_t hip_stream = 0) { m_run.run(stream, BAND_LEN, hip_stream); }
+    void enact(stream_type stream, uint64 = 0u, uint8* = NULL
+#if defined(__HIPCC__)
+               , hipStream_t hip_stream = 0
+#endif
+               )
+    {
+#if defined(__HIPCC__)
+        dispatch(stream, hip_stream, std::integral_constant<bool, equal<algorithm_type, HostThreadScheduler>::pred>());
+#else
+        static_assert(equal<algorithm_type, HostThreadScheduler>::pred, "the device schedulers need a translation unit compiled by hipcc");
+        m_run.run_host(stream);
+#endif
+    }
+    const char* last_path() const { return m_run.m_path; }
 private:
-    priv::traceback_runner<stream_type> m_run;
+#if defined(__HIPCC__)
+    void dispatch(const stream_type& stream, hipStream_t, std::true_type)     { m_run.run_host(stream); }       // only instantiated for host streams
+    void dispatch(const stream_type& stream, hipStream_t hs, std::false_type) { m_run.run(stream, hs); }
+#endif
+    priv::traceback_runner<BAND_LEN, stream_type> m_run;
 };
 template <uint32 CHECKPOINTS, typename stream_type, typename algorithm_type = DeviceThreadScheduler>
 struct BatchedAlignmentTraceback
 {
-    static_assert(!equal<algorithm_type, HostThreadScheduler>::pred, "compat tracebacks run on the device schedulers");
     static uint64 min_temp_storage(const uint32, const uint32, const uint32) { return 0u; }
     static uint64 max_temp_storage(const uint32, const uint32, const uint32) { return 0u; }
-    void enact(stream_type stream, uint64 = 0u, uint8* = NULL, hipStream_t hip_stream = 0) { m_run.run(stream, 0u, hip_stream); }
+    void enact(stream_type stream, uint64 = 0u, uint8* = NULL
+#if defined(__HIPCC__)
+               , hipStream_t hip_stream = 0
+#endif
+               )
+    {
+#if defined(__HIPCC__)
+        dispatch(stream, hip_stream, std::integral_constant<bool, equal<algorithm_type, HostThreadScheduler>::pred>());
+#else
+        static_assert(equal<algorithm_type, HostThreadScheduler>::pred, "the device schedulers need a translation unit compiled by hipcc");
+        m_run.run_host(stream);
+#endif
+    }
+    const char* last_path() const { return m_run.m_path; }
 private:
-    priv::traceback_runner<stream_type> m_run;
+#if defined(__HIPCC__)
+    void dispatch(const stream_type& stream, hipStream_t, std::true_type)     { m_run.run_host(stream); }       // only instantiated for host streams
+    void dispatch(const stream_type& stream, hipStream_t hs, std::false_type) { m_run.run(stream, hs); }
+#endif
+    priv::traceback_runner<0u, stream_type> m_run;
 };
-#endif // NVBIO_HIP_COMPAT_TUNED
 
 // ---------------------------------------------------------------------------------------- convenience functions
 namespace priv {

@@ -1,0 +1,77 @@
+// compat/nvbio/basic/vector.h -- nvbio::vector<system_tag,T> (nvbio/basic/vector.h:60-150): the reference's containers are thrust
+// vectors selected by a system tag, with plain_view() / raw_pointer() to reach the storage.  rocThrust ships with ROCm, so the
+// device flavour is thrust::device_vector (its begin() is what callers hand to FMIndexFilter::locate, batch_*_alignment_score and
+// thrust algorithms); the host flavour is thrust::host_vector.  Needs a translation unit compiled by hipcc.
+#pragma once
+#include "types.h"
+#if defined(__HIPCC__)
+#include <thrust/device_vector.h>
+#include <thrust/host_vector.h>
+
+namespace nvbio {
+
+template <typename system_tag, typename T> struct vector {};
+
+template <typename T>
+struct vector<host_tag, T> : public thrust::host_vector<T>
+{
+    typedef host_tag                                system_tag;
+    typedef thrust::host_vector<T>                  base_type;
+    typedef T*                                      plain_view_type;
+    typedef const T*                                const_plain_view_type;
+    vector(const size_t size = 0, const T val = T()) : base_type(size, val) {}
+    template <typename OtherVector> vector(const OtherVector& v) : base_type(v) {}
+    template <typename OtherVector> vector& operator=(const OtherVector& v) { base_type::operator=(v); return *this; }
+};
+template <typename T>
+struct vector<device_tag, T> : public thrust::device_vector<T>
+{
+    typedef device_tag                              system_tag;
+    typedef thrust::device_vector<T>                base_type;
+    typedef T*                                      plain_view_type;
+    typedef const T*                                const_plain_view_type;
+    vector(const size_t size = 0, const T val = T()) : base_type(size, val) {}
+    template <typename OtherVector> vector(const OtherVector& v) : base_type(v) {}
+    template <typename OtherVector> vector& operator=(const OtherVector& v) { base_type::operator=(v); return *this; }
+};
+
+template <typename T> inline T*       raw_pointer(thrust::device_vector<T>& v)       { return v.empty() ? (T*)0 : thrust::raw_pointer_cast(&v.front()); }
+template <typename T> inline const T* raw_pointer(const thrust::device_vector<T>& v) { return v.empty() ? (const T*)0 : thrust::raw_pointer_cast(&v.front()); }
+template <typename T> inline T*       raw_pointer(thrust::host_vector<T>& v)         { return v.empty() ? (T*)0 : &v.front(); }
+template <typename T> inline const T* raw_pointer(const thrust::host_vector<T>& v)   { return v.empty() ? (const T*)0 : &v.front(); }
+template <typename S, typename T> inline T*       plain_view(vector<S, T>& v)       { return raw_pointer(static_cast<typename vector<S, T>::base_type&>(v)); }
+template <typename S, typename T> inline const T* plain_view(const vector<S, T>& v) { return raw_pointer(static_cast<const typename vector<S, T>::base_type&>(v)); }
+template <typename T> inline T*       plain_view(thrust::device_vector<T>& v)       { return raw_pointer(v); }
+template <typename T> inline const T* plain_view(const thrust::device_vector<T>& v) { return raw_pointer(v); }
+template <typename T> inline T*       plain_view(thrust::host_vector<T>& v)         { return raw_pointer(v); }
+template <typename T> inline const T* plain_view(const thrust::host_vector<T>& v)   { return raw_pointer(v); }
+
+namespace priv {
+/// the raw address behind an iterator that is known to walk plain memory (NULL for anything else)
+template <typename It> struct plain_iterator { static const bool ok = false; typedef void value_type; static void* get(It) { return 0; } };
+template <typename T> struct plain_iterator<T*> { static const bool ok = true; typedef T value_type; static T* get(T* p) { return p; } };
+template <typename T> struct plain_iterator< thrust::device_ptr<T> > { static const bool ok = true; typedef T value_type; static T* get(thrust::device_ptr<T> p) { return thrust::raw_pointer_cast(p); } };
+template <typename T> struct plain_iterator< thrust::detail::normal_iterator< thrust::device_ptr<T> > > { static const bool ok = true; typedef T value_type;
+    static T* get(thrust::detail::normal_iterator< thrust::device_ptr<T> > p) { return thrust::raw_pointer_cast(&*p); } };
+template <typename T> struct plain_iterator< thrust::detail::normal_iterator<T*> > { static const bool ok = true; typedef T value_type;
+    static T* get(thrust::detail::normal_iterator<T*> p) { return &*p; } };
+} // namespace priv
+
+} // namespace nvbio
+#else
+#include <vector>
+namespace nvbio {
+template <typename system_tag, typename T> struct vector {};
+template <typename T> struct vector<host_tag, T> : public std::vector<T>
+{
+    typedef host_tag system_tag; typedef std::vector<T> base_type;
+    vector(const size_t size = 0, const T val = T()) : base_type(size, val) {}
+};
+template <typename T> inline T*       plain_view(std::vector<T>& v)       { return v.data(); }
+template <typename T> inline const T* plain_view(const std::vector<T>& v) { return v.data(); }
+namespace priv {
+template <typename It> struct plain_iterator { static const bool ok = false; typedef void value_type; static void* get(It) { return 0; } };
+template <typename T> struct plain_iterator<T*> { static const bool ok = true; typedef T value_type; static T* get(T* p) { return p; } };
+}
+} // namespace nvbio
+#endif

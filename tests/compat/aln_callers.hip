@@ -391,3 +391,92 @@ int compat_traceback(int kind, int type, int band, const int* sc, unsigned n, co
         return rc;
     } catch (const std::exception&) { return 2; }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// stream 4: a traceback stream over plain byte strings with per-base qualities (the reference's own tests trace uint8 strings
+// with user schemes, nvbio-test/alignment_test.cu:417-426; batched_banded_inl.h:299-326 takes any stream): nothing the tuned
+// kernels know, so the batch classes run the per-lane templates -- on the device, and under HostThreadScheduler on the host.
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename t_aligner_type>
+struct ByteTracebackStream
+{
+    typedef t_aligner_type aligner_type;
+    typedef vector_view<const uint8*> byte_string;
+    struct context_type { int32 min_score; RunLengthBacktracer backtracer; aln::Alignment<int32> alignment; };
+    struct strings_type { byte_string pattern; byte_string quals; byte_string text; };
+
+    ByteTracebackStream(aligner_type aligner, uint32 count, const uint32* read_offsets, const uint8* reads, const uint8* quals, uint32 longest_read,
+                        const uint32* window_offsets, const uint8* windows, uint32 longest_window,
+                        int32* scores, uint2* sinks, uint2* sources, uint16* cigars, uint32 cigar_stride, uint32* cigar_lens)
+        : m_aligner(aligner), m_count(count), m_read_offsets(read_offsets), m_reads(reads), m_quals(quals), m_longest_read(longest_read),
+          m_window_offsets(window_offsets), m_windows(windows), m_longest_window(longest_window),
+          m_scores(scores), m_sinks(sinks), m_sources(sources), m_cigars(cigars), m_cigar_stride(cigar_stride), m_cigar_lens(cigar_lens) {}
+
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE const aligner_type& aligner() const { return m_aligner; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 max_pattern_length() const { return m_longest_read; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 max_text_length() const { return m_longest_window; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 size() const { return m_count; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 pattern_length(const uint32 i, context_type*) const { return m_read_offsets[i + 1] - m_read_offsets[i]; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 text_length(const uint32 i, context_type*) const { return m_window_offsets[i + 1] - m_window_offsets[i]; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool init_context(const uint32 i, context_type* context) const
+    {
+        context->min_score = Field_traits<int32>::min();
+        context->backtracer.words = m_cigars + uint64(i) * m_cigar_stride; context->backtracer.capacity = m_cigar_stride; context->backtracer.clear();
+        context->alignment = aln::Alignment<int32>(-77, make_uint2(7u, 7u), make_uint2(7u, 7u));
+        return (i % 53u) != 52u;
+    }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void load_strings(const uint32 i, const uint32, const uint32, const context_type*, strings_type* strings) const
+    {
+        const uint32 r0 = m_read_offsets[i],   rn = m_read_offsets[i + 1] - r0;
+        const uint32 w0 = m_window_offsets[i], wn = m_window_offsets[i + 1] - w0;
+        strings->pattern = byte_string(rn, m_reads + r0);
+        strings->quals   = byte_string(rn, m_quals + r0);
+        strings->text    = byte_string(wn, m_windows + w0);
+    }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void output(const uint32 i, context_type* context) const
+    {
+        context->backtracer.flush();
+        m_scores[i] = context->alignment.score; m_sinks[i] = context->alignment.sink; m_sources[i] = context->alignment.source;
+        m_cigar_lens[i] = context->backtracer.size;
+    }
+    aligner_type m_aligner; uint32 m_count;
+    const uint32* m_read_offsets; const uint8* m_reads; const uint8* m_quals; uint32 m_longest_read;
+    const uint32* m_window_offsets; const uint8* m_windows; uint32 m_longest_window;
+    int32* m_scores; uint2* m_sinks; uint2* m_sources; uint16* m_cigars; uint32 m_cigar_stride; uint32* m_cigar_lens;
+};
+
+// where: 0 = device pointers + DeviceThreadScheduler, 1 = host pointers + HostThreadScheduler; kind: 0 Gotoh, 1 Smith-Waterman (any
+// deletion / insertion costs), 2 edit distance, 3 Gotoh with the user-defined PhredGotohScheme; band: 0 = full matrix, 15, 31
+extern "C" __attribute__((visibility("default")))
+int compat_traceback_bytes(int where, int kind, int type, int band, const int* sc, unsigned n, const unsigned* read_offsets, const unsigned char* reads, const unsigned char* quals,
+                           unsigned longest_read, const unsigned* window_offsets, const unsigned char* windows, unsigned longest_window,
+                           int* scores, unsigned* sinks, unsigned* sources, unsigned short* cigars, unsigned cigar_stride, unsigned* cigar_lens, char* path)
+{
+    try {
+        const char* p = NULL;
+        const int rc = [&]() -> int {
+            #define RUN_S(ALIGNER, SCHED) { \
+                auto al = ALIGNER; typedef ByteTracebackStream<decltype(al)> stream_type; \
+                const stream_type st(al, n, read_offsets, reads, quals, longest_read, window_offsets, windows, longest_window, scores, \
+                                     reinterpret_cast<uint2*>(sinks), reinterpret_cast<uint2*>(sources), cigars, cigar_stride, cigar_lens); \
+                if (band == 0)       { aln::BatchedAlignmentTraceback<64, stream_type, SCHED> b; b.enact(st); p = b.last_path(); } \
+                else if (band == 15) { aln::BatchedBandedAlignmentTraceback<15, 64, stream_type, SCHED> b; b.enact(st); p = b.last_path(); } \
+                else if (band == 31) { aln::BatchedBandedAlignmentTraceback<31, 64, stream_type, SCHED> b; b.enact(st); p = b.last_path(); } \
+                else return 1; \
+                return (where != 0 || hipDeviceSynchronize() == hipSuccess) ? 0 : 3; }
+            #define RUN(ALIGNER) { if (where == 0) RUN_S(ALIGNER, aln::DeviceThreadScheduler) else RUN_S(ALIGNER, aln::HostThreadScheduler) }
+            #define TYPED(TYPE) \
+                if (kind == 0) RUN(aln::make_gotoh_aligner<TYPE>(aln::SimpleGotohScheme(sc[0], sc[1], sc[2], sc[3]))) \
+                if (kind == 1) RUN(aln::make_smith_waterman_aligner<TYPE>(aln::SimpleSmithWatermanScheme(sc[0], sc[1], sc[2], sc[3]))) \
+                if (kind == 2) RUN(aln::make_edit_distance_aligner<TYPE>()) \
+                if (kind == 3) RUN(aln::make_gotoh_aligner<TYPE>(PhredGotohScheme()))
+            if (type == 0) { TYPED(aln::GLOBAL) } else if (type == 1) { TYPED(aln::LOCAL) } else { TYPED(aln::SEMI_GLOBAL) }
+            #undef TYPED
+            #undef RUN
+            #undef RUN_S
+            return 1;
+        }();
+        if (p) { strncpy(path, p, 15); path[15] = 0; }
+        return rc;
+    } catch (const std::exception&) { return 2; }
+}

@@ -294,3 +294,57 @@ def test_traceback_stream_with_a_user_backtracer(callers, typ, band):
         mask = (np.arange(stride)[None, :] < exp["cigar_len"][:, None]) & live[:, None]
         assert ((gc == exp["cigar"]) | ~mask).all(), (typ, band, kind)
         assert int(exp["cigar_len"][live].max()) < stride
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# generic tracebacks: byte strings, user schemes, asymmetric linear gaps -- streams the tuned kernels do not take
+# ---------------------------------------------------------------------------------------------------------------------
+PHRED_LUT = np.array([-(2 + min(q, 40) // 10) for q in range(256)], dtype=np.int32)
+
+
+def run_byte_tracebacks(L, where, typ, band, n=400, seed=0):
+    """ByteTracebackStream of tests/compat/aln_callers.hip through Batched(Banded)AlignmentTraceback; where 0 = device scheduler,
+    1 = HostThreadScheduler.  Returns the number of jobs compared."""
+    L.compat_traceback_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                         C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_char_p]
+    reads, quals, wins = make_jobs(8100 + 10 * typ + band + seed, n, max_read=90, band=band or 31, max_sym=5, full=(band == 0))
+    b = Batch(reads, quals, wins, packed=False, on_device=(where == 0))
+    mk = dev if where == 0 else (lambda a: torch.from_numpy(np.ascontiguousarray(a).copy()))
+    stride = 200
+    compared = 0
+    for kind, scheme in ((0, (2, -2, -4, -1)), (1, (2, -1, -2, -3)), (1, (1, -1, -3, -1)), (2, (0, -1, -1, -1)), (3, None)):
+        sc = np.array(scheme if scheme else (0, 0, 0, 0), dtype=np.int32)
+        score = mk(np.full(b.n, 12345, np.int32)); sink = mk(np.full((b.n, 2), 777, np.int32)); source = mk(np.full((b.n, 2), 777, np.int32))
+        cigar = mk(np.zeros((b.n, stride), np.int16)); clen = mk(np.full(b.n, 999, np.int32))
+        path = C.create_string_buffer(16)
+        rc = L.compat_traceback_bytes(where, kind, typ, band, sc.ctypes.data, b.n, b.ptr("ro"), b.ptr("r"), b.ptr("q"), b.longest_read, b.ptr("wo"), b.ptr("w"), b.longest_win,
+                                      C.c_void_p(score.data_ptr()), C.c_void_p(sink.data_ptr()), C.c_void_p(source.data_ptr()), C.c_void_p(cigar.data_ptr()), stride,
+                                      C.c_void_p(clen.data_ptr()), path)
+        assert rc == 0
+        assert path.value == (b"generic" if where == 0 else b"host")
+        qbuf = np.concatenate([b.cat_q, np.zeros(8, np.uint8)])
+        if kind == 0:
+            exp = O.batch_banded_gotoh_traceback(band, typ, scheme, b.hr, b.hw, stride) if band else O.batch_gotoh_traceback(typ, scheme, b.hr, b.hw, stride)
+        elif kind == 3:
+            s5 = (2, -8, -3, -6, -2)
+            exp = O.batch_banded_gotoh_traceback(band, typ, s5, b.hr, b.hw, stride, PHRED_LUT, qbuf) if band else O.batch_gotoh_traceback(typ, s5, b.hr, b.hw, stride, PHRED_LUT, qbuf)
+        else:
+            exp = O.batch_sw_traceback(band, typ, scheme, b.hr, b.hw, stride)
+        gs, gk, gsrc = score.cpu().numpy(), sink.cpu().numpy().view(np.uint32), source.cpu().numpy().view(np.uint32)
+        gc, gl = cigar.cpu().numpy().view(np.uint16), clen.cpu().numpy().view(np.uint32)
+        declined = (np.arange(b.n) % 53) == 52
+        live = ~declined & ((np.diff(b.ro) > 0) | (band != 0))
+        assert (gs[declined] == -77).all() and (gk[declined] == 7).all() and (gl[declined] == 0).all()
+        assert (gs[live] == exp["score"][live]).all(), (typ, band, kind)
+        assert (gk[live] == exp["sink"][live]).all() and (gsrc[live] == exp["source"][live]).all(), (typ, band, kind)
+        assert (gl[live] == exp["cigar_len"][live]).all(), (typ, band, kind)
+        mask = (np.arange(stride)[None, :] < exp["cigar_len"][:, None]) & live[:, None]
+        assert ((gc == exp["cigar"]) | ~mask).all(), (typ, band, kind)
+        compared += int(live.sum())
+    return compared
+
+
+@pytest.mark.parametrize("typ", [GLOBAL, LOCAL, SEMI])
+@pytest.mark.parametrize("band", [15, 31, 0])
+def test_generic_traceback_streams_on_the_device(callers, typ, band):
+    assert run_byte_tracebacks(callers, 0, typ, band, n=600) > 2000

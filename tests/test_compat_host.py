@@ -70,3 +70,13 @@ def test_host_full_matrix(callers, typ, tag):
     gs, gk = bb.results()
     declined = (np.arange(bb.n) % 97) == 96
     assert (gs[~declined] == es[~declined]).all() and (gk[~declined] == ek[~declined]).all()
+
+
+@pytest.mark.parametrize("typ", [GLOBAL, LOCAL, SEMI])
+@pytest.mark.parametrize("band", [15, 31, 0])
+def test_host_generic_tracebacks(callers, typ, band):
+    """BatchedBandedAlignmentTraceback / BatchedAlignmentTraceback<..., HostThreadScheduler> over byte strings with Gotoh, asymmetric
+    Smith-Waterman, edit-distance and a user-defined quality scheme: the per-lane templates of compat/nvbio/alignment/traceback.h
+    (batched_banded_inl.h:299-326 takes any stream) against the oracle's tracebacks."""
+    from tests.test_compat_alignment_gpu import run_byte_tracebacks
+    assert run_byte_tracebacks(callers, 1, typ, band, n=250) > 800
