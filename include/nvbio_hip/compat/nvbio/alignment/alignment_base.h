@@ -34,6 +34,7 @@ template <> struct transpose_tag<TextBlockingTag>    { typedef PatternBlockingTa
 struct SmithWatermanTag {};
 struct GotohTag {};
 struct EditDistanceTag {};
+struct HammingDistanceTag {};
 template <typename aligner_type> struct aligner_tag { typedef typename aligner_type::aligner_tag type; };
 
 // ---------------------------------------------------------------------------------------- scoring schemes
@@ -118,6 +119,19 @@ template <AlignmentType TYPE, typename scoring_scheme_type> NVBIO_FORCEINLINE NV
 SmithWatermanAligner<TYPE, scoring_scheme_type> make_smith_waterman_aligner(const scoring_scheme_type& scheme) { return SmithWatermanAligner<TYPE, scoring_scheme_type>(scheme); }
 template <AlignmentType TYPE, typename algorithm_tag, typename scoring_scheme_type> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
 SmithWatermanAligner<TYPE, scoring_scheme_type, algorithm_tag> make_smith_waterman_aligner(const scoring_scheme_type& scheme) { return SmithWatermanAligner<TYPE, scoring_scheme_type, algorithm_tag>(scheme); }
+
+/// ungapped alignment (alignment_base.h:365-393): a value type here -- nvBowtie's scheme names it, no batch function of the hot path takes it
+template <AlignmentType T_TYPE, typename scoring_scheme_type, typename AlgorithmType = PatternBlockingTag>
+struct HammingDistanceAligner
+{
+    static const AlignmentType TYPE = T_TYPE;
+    typedef HammingDistanceTag aligner_tag;
+    typedef AlgorithmType      algorithm_tag;
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE HammingDistanceAligner(const scoring_scheme_type _scheme) : scheme(_scheme) {}
+    scoring_scheme_type scheme;
+};
+template <AlignmentType TYPE, typename scoring_scheme_type> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
+HammingDistanceAligner<TYPE, scoring_scheme_type> make_hamming_distance_aligner(const scoring_scheme_type& scheme) { return HammingDistanceAligner<TYPE, scoring_scheme_type>(scheme); }
 
 template <typename T> struct transpose_aligner {};
 template <AlignmentType T, typename A> struct transpose_aligner< EditDistanceAligner<T, A> > { typedef EditDistanceAligner<T, typename transpose_tag<A>::type> type; };

@@ -656,7 +656,7 @@ private:
 namespace priv {
 
 template <uint32 BAND_LEN, typename stream_type>
-NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void banded_traceback_job(const stream_type& stream, const uint32 i, uint8* flags)
+NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void banded_traceback_job(stream_type& stream, const uint32 i, uint8* flags)
 {
     typename stream_type::context_type ctx;
     typename stream_type::strings_type strings;
@@ -667,7 +667,7 @@ NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void banded_traceback_job(const stream_type&
     stream.output(i, &ctx);
 }
 template <typename stream_type>
-NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void full_traceback_job(const stream_type& stream, const uint32 i, uint8* scratch, const uint32 maxP, const uint32 maxT)
+NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void full_traceback_job(stream_type& stream, const uint32 i, uint8* scratch, const uint32 maxP, const uint32 maxT)
 {
     typename stream_type::context_type ctx;
     typename stream_type::strings_type strings;
@@ -683,13 +683,13 @@ NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void full_traceback_job(const stream_type& s
 
 #if defined(__HIPCC__)
 template <uint32 BAND_LEN, typename stream_type>
-__global__ void __launch_bounds__(128) batched_banded_traceback_kernel(const stream_type stream, uint8* scratch, const uint64 stride)
+__global__ void __launch_bounds__(128) batched_banded_traceback_kernel(stream_type stream, uint8* scratch, const uint64 stride)     // by value, not const: a traceback stream's output() may be non-const (traceback_inl.h:140)
 {
     const uint32 i = blockIdx.x * 128u + threadIdx.x;
     if (i < stream.size()) banded_traceback_job<BAND_LEN>(stream, i, scratch + uint64(i) * stride);
 }
 template <typename stream_type>
-__global__ void __launch_bounds__(128) batched_full_traceback_kernel(const stream_type stream, uint8* scratch, const uint64 stride, const uint32 maxP, const uint32 maxT)
+__global__ void __launch_bounds__(128) batched_full_traceback_kernel(stream_type stream, uint8* scratch, const uint64 stride, const uint32 maxP, const uint32 maxT)
 {
     const uint32 i = blockIdx.x * 128u + threadIdx.x;
     if (i < stream.size()) full_traceback_job(stream, i, scratch + uint64(i) * stride, maxP, maxT);
@@ -703,8 +703,9 @@ struct traceback_runner
     typedef typename stream_type::aligner_type aligner_type;
     traceback_runner() : m_path("none") {}
 
-    void run_host(const stream_type& stream)
+    void run_host(const stream_type& in_stream)
     {
+        stream_type stream(in_stream);
         const int64 n = int64(stream.size());
         const uint32 maxP = stream.max_pattern_length(), maxT = stream.max_text_length();
         const uint64 bytes = BAND_LEN ? banded_traceback_scratch(BAND_LEN ? BAND_LEN : 1u, maxP) : full_traceback_scratch(maxP, maxT);
@@ -768,10 +769,10 @@ struct traceback_runner
     const char* m_path;
 
 private:
-    static void job(const stream_type& stream, const uint32 i, uint8* scratch, const uint32 maxP, const uint32 maxT)
+    static void job(stream_type& stream, const uint32 i, uint8* scratch, const uint32 maxP, const uint32 maxT)
     { job(stream, i, scratch, maxP, maxT, std::integral_constant<bool, BAND_LEN != 0u>()); }
-    static void job(const stream_type& stream, const uint32 i, uint8* scratch, uint32, uint32, std::true_type) { banded_traceback_job<(BAND_LEN ? BAND_LEN : 3u)>(stream, i, scratch); }
-    static void job(const stream_type& stream, const uint32 i, uint8* scratch, uint32 maxP, uint32 maxT, std::false_type) { full_traceback_job(stream, i, scratch, maxP, maxT); }
+    static void job(stream_type& stream, const uint32 i, uint8* scratch, uint32, uint32, std::true_type) { banded_traceback_job<(BAND_LEN ? BAND_LEN : 3u)>(stream, i, scratch); }
+    static void job(stream_type& stream, const uint32 i, uint8* scratch, uint32 maxP, uint32 maxT, std::false_type) { full_traceback_job(stream, i, scratch, maxP, maxT); }
 };
 } // namespace priv
 

@@ -7,6 +7,10 @@
 // sw-benchmark's references 2-bit LE).
 #pragma once
 #include "types.h"
+// <endian.h> defines BIG_ENDIAN as a macro; the reference drops it (packedstream.h:38-40) because PackedStream has a member of that name
+#if defined(BIG_ENDIAN)
+#undef BIG_ENDIAN
+#endif
 
 namespace nvbio {
 
@@ -19,6 +23,7 @@ struct PackedStream
     static const uint32 SYMBOL_SIZE       = SYMBOL_SIZE_T;
     static const uint32 SYMBOL_COUNT      = 1u << SYMBOL_SIZE_T;
     static const uint32 SYMBOL_MASK       = SYMBOL_COUNT - 1u;
+    static const uint32 BIG_ENDIAN        = BIG_ENDIAN_T;            ///< the reference's name for it (packedstream.h:202)
     static const bool   IS_BIG_ENDIAN     = BIG_ENDIAN_T;
     static const uint32 ALPHABET_SIZE     = SYMBOL_COUNT;
 

@@ -6,6 +6,9 @@
 namespace nvbio {
 namespace io {
 
+/// how the mates of a paired-end read are oriented (io/sequence/sequence.h:188-196): F = forward, R = reverse
+enum PairedEndPolicy { PE_POLICY_FF = 0, PE_POLICY_FR = 1, PE_POLICY_RF = 2, PE_POLICY_RR = 3 };
+
 template <Alphabet ALPHABET>
 struct SequenceDataTraits
 {

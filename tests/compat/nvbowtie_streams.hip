@@ -166,7 +166,7 @@ struct AlignmentStrings
     typedef ReadLoader<read_batch_type, lmem_cache_type>        pattern_loader_type;
     typedef typename pattern_loader_type::string_type           pattern_string;
     typedef typename pattern_string::qual_string_type           qual_string;
-    typedef PackedStringLoader<typename genome_iterator::storage_iterator, genome_iterator::SYMBOL_SIZE, genome_iterator::IS_BIG_ENDIAN, lmem_cache_type> text_loader_type;
+    typedef PackedStringLoader<typename genome_iterator::storage_iterator, genome_iterator::SYMBOL_SIZE, genome_iterator::BIG_ENDIAN, lmem_cache_type> text_loader_type;
     typedef typename text_loader_type::iterator                 text_iterator;
     typedef vector_view<text_iterator>                          text_string;
 
