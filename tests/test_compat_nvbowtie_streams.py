@@ -196,7 +196,7 @@ def test_best_score_stream_runs_tuned_and_matches_oracle(lib, cuda, kind, band):
     gb = np.array(ts.begin, dtype=np.uint32)
     assert (out["hit_score"].cpu().numpy() == np.maximum(es, -(1 << 16))).all()
     assert (out["hit_sink"].cpu().numpy().view(np.uint32) == (gb + ek[:, 0]).astype(np.uint32)).all()
-    assert (es > 30).sum() > 3000 and (ek[:, 0] == 0xFFFFFFFF).sum() >= 0
+    assert (es > (30 if kind == "local" else -30)).sum() > 3000
 
 
 def test_generic_lane_gives_the_same_results(lib, cuda):
@@ -248,7 +248,7 @@ def test_opposite_score_stream_runs_tuned_and_matches_oracle(lib, cuda, kind):
     got_k = out["raw_sink"].cpu().numpy().view(np.uint32)
     assert (got_s[valid] == es[valid]).all() and (got_k[valid] == ek[valid]).all()
     assert (got_s[~valid] == 12345).all()                  # declined jobs: outputs untouched
-    assert (es[valid] > 30).sum() > 1000
+    assert (es[valid] > (30 if kind == "local" else -30)).sum() > 1000
 
 
 @pytest.mark.parametrize("kind", ["local", "end_to_end"])
