@@ -81,7 +81,7 @@ def measured_traffic(kernel):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20 on one GPU, 200 when --gpus > 1: the gather needs a longer region)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 200: ~0.6 s of timed region)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
     ap.add_argument("--genome", type=float, default=3.0e9, help="synthetic genome length of the FM-index legs (a true index is built on the device)")
@@ -90,6 +90,7 @@ def parse():
     ap.add_argument("--only", choices=["dp", "rank", "seed", "e2e", "full", "extras"], default=None, help="profiling aid: run just one leg, print its object")
     ap.add_argument("--seeds", type=int, default=50_000_000)
     ap.add_argument("--pairs", type=int, default=500_000, help="read pairs of the paired-end driver leg inside the e2e leg (0 = skip)")
+    ap.add_argument("--share-pairs", type=int, default=25_000_000, help="config 5 at one GPU's share of 200 M pairs over 8 GPUs (0 = skip); runs in batches of --pairs")
     ap.add_argument("--no-seed", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-full", action="store_true")
@@ -106,7 +107,7 @@ def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.steps is None:
-        a.steps = 20 if world == 1 else 200
+        a.steps = 200
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("NVBIO_BENCH_SHARE_GPU") == "1":
@@ -459,6 +460,11 @@ def e2e_leg(a, dev, fmi, text):
     # the same batch through the C++ host driver (include/nvbio_hip/aligner.h: nvbio::bowtie2::cuda::Aligner::best_approx, the
     # north star's "host code stays C++"), entered through tests/cxx/aligner_shim.cpp: no torch between the kernels
     res["cxx_best_approx"] = cxx_driver_leg(a, dev, fmi.with_dimer(), sym, packed, genome_words, ng, names, prm, ref_best, ref_mapq)
+    # ... and on the index this GPU's HBM is there for (the default of the config-4 leg below): same driver, same results
+    rich, rich_desc = hbm_rich(fmi, dev)
+    res["cxx_best_approx_hbm_rich"] = cxx_driver_leg(a, dev, rich, sym, packed, genome_words, ng, names, prm, ref_best, ref_mapq)
+    res["cxx_best_approx_hbm_rich"]["index"] = rich_desc
+    del rich
 
     # exact check of a sample against the same glue over the oracle
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -485,58 +491,42 @@ def e2e_leg(a, dev, fmi, text):
     if not ok2:
         raise SystemExit("parity gate failed: nvBowtie single-end driver differs from the oracle driver")
     res["parity"]["nvbowtie_driver"] = {"checked_reads": m2, "best_mapq_cigar_stats_equal": ok2}
-    # BASELINE config 4 at its full size: 50 M reads = e2e_batches batches of n reads through the single-end driver on the
-    # line-native index (fresh reads per batch; inputs packed before each batch's timed region, as above)
+    # BASELINE config 4 at its full size: 50 M reads = e2e_batches batches of n fresh reads through the C++ single-end driver
+    # (nvbio::bowtie2::cuda::Aligner::best_approx; inputs packed in HBM before the timed region), on the HBM-rich index (the default on
+    # this GPU) and on the lean line-native index, one batch at a time and with two batches in flight: one host thread, one Aligner and
+    # one non-blocking HIP stream per batch in flight, so that one batch's fabric-bound map / locate overlaps the other's VALU-bound
+    # select / extend / traceback (what that buys, and why not more: DESIGN.md section 3.7, profiles/r03/cosched_*.txt).
     if a.e2e_batches > 1:
-        idx = fmi.with_dimer()
-        tot_ms, aligned_n, true_n = 0.0, 0, 0
+        inputs, truth = [], []
         for b in range(a.e2e_batches):
             symb, posb, _ = P.make_reads(text, n, READ_LEN, seed=0x5EED0040 + b)
-            packedb = P.pack_read_streams(symb)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            rb = AL.best_approx(idx, None, symb, genome_words, ng, prm, names=names, packed=packedb)
-            e1.record()
-            torch.cuda.synchronize()
-            tot_ms += e0.elapsed_time(e1)
-            locb = (rb["best"][0] >> 32) & 0xFFFFFFFF
-            al = locb != 0xFFFFFFFF
-            aligned_n += int(al.sum().item()); true_n += int((al & ((locb - posb).abs() <= 2)).sum().item())
-            del symb, posb, packedb, rb
+            inputs.append(P.pack_read_streams(symb)); truth.append(posb)
+            del symb
         tot = n * a.e2e_batches
-        res["config4_full_size"] = {"reads": tot, "batches": a.e2e_batches, "index": "line_native", "ms_total": tot_ms, "Mreads_per_s": tot / tot_ms / 1e3,
-                                    "aligned": aligned_n / tot, "best_at_true_position": true_n / tot}
-        # the same batches two at a time: one host thread and one HIP stream per batch in flight (the reference runs one host thread
-        # per device; here two share the device so that one batch's issue-bound stages overlap the other's fabric-bound ones).
-        # Wall clock over all batches, inputs packed beforehand, bests compared with a serial pass over the same inputs.
-        import threading
-        inputs = []
-        for b in range(a.e2e_batches):
-            symb, _, _ = P.make_reads(text, n, READ_LEN, seed=0x5EED0040 + b)
-            inputs.append((symb, P.pack_read_streams(symb)))
-        runb = lambda b: AL.best_approx(idx, None, inputs[b][0], genome_words, ng, prm, names=names, packed=inputs[b][1], traceback=True)
-        serial_best = [runb(b)["best"].clone() for b in range(a.e2e_batches)]
-        outs2 = [None] * a.e2e_batches
-        streams = [torch.cuda.Stream() for _ in range(2)]
-
-        def worker(k):
-            with torch.cuda.stream(streams[k]):
-                for b in range(k, a.e2e_batches, 2):
-                    outs2[b] = runb(b)["best"]
-                streams[k].synchronize()
-
-        wall = None
-        for rep in range(2):                       # the first pass grows each stream's allocator pool
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            th = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
-            [t.start() for t in th]; [t.join() for t in th]
-            torch.cuda.synchronize()
-            wall = (time.perf_counter() - t0) * 1e3
-        res["config4_full_size"]["two_batches_in_flight"] = {"ms_total_wall": wall, "Mreads_per_s": tot / wall / 1e3,
-                                                             "identical_to_serial": all(torch.equal(outs2[b], serial_best[b]) for b in range(a.e2e_batches))}
-        del idx, inputs, serial_best, outs2
+        c4 = {"reads": tot, "batches": a.e2e_batches, "driver": "nvbio::bowtie2::cuda::Aligner::best_approx (C++, include/nvbio_hip/aligner.h)"}
+        for flavour in ("hbm_rich", "line_native"):
+            if flavour == "hbm_rich":
+                idx, desc = hbm_rich(fmi, dev)
+            else:
+                idx, desc = fmi.with_dimer(), {"line_native": True, "ktab_k": 0, "sa_int": fmi.sa_int}
+            serial, sb, sm = cxx_pipelined(dev, idx, inputs, genome_words, ng, names, prm, 1, 0, False)
+            entry = {"index": desc, "serial": serial}
+            if sb is not None:
+                loc = [(x[0] >> 32) & 0xFFFFFFFF for x in sb]
+                entry["aligned"] = sum(int((l != 0xFFFFFFFF).sum().item()) for l in loc) / tot
+                entry["best_at_true_position"] = sum(int(((l != 0xFFFFFFFF) & ((l - t).abs() <= 2)).sum().item()) for l, t in zip(loc, truth)) / tot
+                co, cb, cm = cxx_pipelined(dev, idx, inputs, genome_words, ng, names, prm, 2, 0, False)
+                if cb is not None:
+                    co["identical_to_serial"] = all(torch.equal(x, y) for x, y in zip(cb, sb)) and all(torch.equal(x, y) for x, y in zip(cm, sm))
+                entry["two_batches_in_flight"] = co
+                del cb, cm
+            c4[flavour] = entry
+            del idx, sb, sm
+            torch.cuda.empty_cache()
+        best_rate = max([v.get("Mreads_per_s", 0.0) for f in ("hbm_rich", "line_native") for v in (c4[f].get("serial", {}), c4[f].get("two_batches_in_flight", {}))])
+        c4["Mreads_per_s"] = best_rate
+        res["config4_full_size"] = c4
+        del inputs, truth
     # BASELINE config 5's shape in the default run: nvBowtie's paired-end driver (2 x 150 bp FR pairs, --local: 20-bp seeds, LOCAL band 31
     # in the quality-aware local scheme, opposite mates by full-matrix DP, paired reduction, MAPQ, tracebacks) on this 3 Gbp index,
     # line-native.  (Its parity sample against the oracle driver is in the extras leg, on a 1 Gbp index with a reverse index too.)
@@ -559,9 +549,122 @@ def e2e_leg(a, dev, fmi, text):
                                            "stage_ms": {k: round(v, 3) for k, v in r["stats"]["ms"].items()}}
         res["config5_shape_paired_end"]["cxx"] = cxx_paired_leg(dev, idx, s1, s2, genome_words, ng, pnames, prm5, b0)
         del idx, r, s1, s2
+        # BASELINE config 5 at one GPU's share: 200 M pairs over 8 GPUs = 25 M pairs per GPU, through the C++ paired-end driver in batches
+        if a.share_pairs > 0:
+            res["config5_per_gpu_share"] = config5_share_leg(a, dev, fmi, text, genome_words, ng, pnames, prm5, npairs)
     res["reads"] = n
     res["genome_symbols"] = ng
     return res
+
+
+def config5_share_leg(a, dev, fmi, text, genome_words, ng, names, prm, batch_pairs):
+    """BASELINE config 5 at the share one of 8 GPUs gets (25 M of 200 M pairs, 2 x 150 bp, LOCAL band 31): the C++ paired-end driver over
+    share_pairs / batch_pairs batches of fresh pairs (inputs resident in HBM), one batch at a time and two in flight; the 32-byte pair
+    records (io::BestPairedAlignments) of every batch are produced on the device.  Host <-> device transfers of one batch (BASELINE.md
+    section 3: reported separately, never inside `value`): packed reads + qualities in, pair records out, through pinned host memory."""
+    import ctypes as C
+    from nvbio_amd import pipeline as P
+    shim = C.CDLL(os.path.join(ROOT, "tests", "cxx", "libaligner_shim.so"))
+    n, L = batch_pairs, 150
+    nb = max(1, a.share_pairs // n)
+    idx, desc = hbm_rich(fmi, dev)
+
+    class PairBatch(C.Structure):
+        _fields_ = [("rev_words", C.c_void_p * 2), ("rev_begin", C.c_void_p * 2), ("fwrc_words", C.c_void_p * 2), ("both_words", C.c_void_p)]
+
+    class ShimPeParams(C.Structure):
+        _fields_ = [("pe_policy", C.c_int32)] + [(k, C.c_uint32) for k in ("pe_overlap", "pe_unpaired", "pe_discordant", "min_frag_len", "max_frag_len")]
+    keep, arr = [], (PairBatch * nb)()
+    conc_at_true = 0
+    truth = []
+    for b in range(nb):
+        s1, s2, ppos, pflen = P.make_read_pairs(text, n, L, seed=0x5EED0100 + b)
+        pk = [P.pack_read_streams(x) for x in (s1, s2)]
+        both = torch.cat([pk[0][1], pk[1][1]])
+        keep.append((pk, both)); truth.append((ppos, pflen))
+        for m in range(2):
+            arr[b].rev_words[m] = pk[m][0].words.data_ptr(); arr[b].rev_begin[m] = pk[m][0].begin.data_ptr(); arr[b].fwrc_words[m] = pk[m][1].data_ptr()
+        arr[b].both_words = both.data_ptr()
+        del s1, s2
+    pk0 = keep[0][0]
+    mate_offset = pk0[0][1].numel() * 8
+    quals = torch.full((2 * n * L + 8,), 30, dtype=torch.uint8, device=dev)
+    both_q = torch.full((mate_offset + 2 * n * L + 8,), 30, dtype=torch.uint8, device=dev)
+    arena, nidx = names
+    scheme = nvb.SmithWatermanScoringScheme.local() if prm.local else nvb.SmithWatermanScoringScheme()
+    sp = _shim_params(prm, scheme)
+    pp = ShimPeParams(prm.pe_policy, int(prm.pe_overlap), int(prm.pe_unpaired), int(prm.pe_discordant), prm.min_frag_len, prm.max_frag_len)
+    u64x2 = lambda v: (C.c_uint64 * 2)(*v)
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    records = [torch.zeros((4, n), dtype=torch.int64, device=dev) for _ in range(nb)]
+    rec_ptrs = (C.c_void_p * nb)(*[t.data_ptr() for t in records])
+    fs = idx.struct()
+    out = {"pairs": n * nb, "batches": nb, "pairs_per_batch": n, "read_len": L, "index": desc,
+           "driver": "nvbio::bowtie2::cuda::Aligner::best_approx(PairedReadBatch) (C++, include/nvbio_hip/aligner.h)", "pair_record_bytes": 32}
+    ref = None
+    for key, workers, limit, token in (("serial", 1, 0, 0), ("two_batches_in_flight", 2, 0, 0)):
+        ms, stats = (C.c_double * 1)(), (C.c_uint64 * 2)()
+        torch.cuda.synchronize()
+        rc = shim.nvbio_aligner_best_approx_paired_pipelined(
+            C.byref(fs), None, C.c_uint32(n), C.c_uint32(L), C.c_uint32(nb), arr,
+            u64x2([pk0[0][0].words.numel(), pk0[1][0].words.numel()]), u64x2([pk0[0][1].numel(), pk0[1][1].numel()]),
+            vp(quals), C.c_uint64(quals.numel()), vp(arena), vp(nidx), C.c_uint64(keep[0][1].numel()), C.c_uint64(mate_offset), vp(both_q), C.c_uint64(both_q.numel()),
+            vp(genome_words), C.c_uint64(genome_words.numel()), C.c_uint32(ng), C.byref(sp), C.byref(pp),
+            C.c_uint32(workers), C.c_uint32(limit), ms, rec_ptrs, stats, C.c_uint32(token))
+        torch.cuda.synchronize()
+        if rc != 0:
+            out[key] = {"error": "nvbio_aligner_best_approx_paired_pipelined returned %d" % rc}
+            continue
+        out[key] = {"host_threads": workers, "seeding_grid_limit": limit, "seeding_token": bool(token), "ms_total": ms[0], "Mpairs_per_s": n * nb / ms[0] / 1e3,
+                    "ms_per_batch": ms[0] / nb, "anchor_extensions": int(stats[0])}
+        if ref is None:
+            ref = [t.clone() for t in records]
+            conc = tru = 0
+            for t, (ppos, pflen) in zip(records, truth):
+                b0 = t[0]
+                c = (((b0 >> 30) & 1) != 0) & (((b0 >> 31) & 1) == 0)
+                apos = (b0 >> 32) & 0xFFFFFFFF
+                conc += int(c.sum().item())
+                tru += int(((((apos - ppos).abs() <= 3) | ((apos - (ppos + pflen - L)).abs() <= 3)) & c).sum().item())
+            out["concordant"] = conc / (n * nb); out["concordant_at_fragment_end"] = tru / (n * nb)
+        else:
+            out[key]["identical_to_serial"] = all(torch.equal(x, y) for x, y in zip(records, ref))
+    # host <-> device traffic of one batch, through pinned memory: 4-bit reads (reversed stream) + a quality byte per base in, 32-byte records out
+    rd = [pk0[m][0].words for m in range(2)]
+    h_reads = [torch.empty(t.shape, dtype=t.dtype).pin_memory() for t in rd]
+    h_quals = torch.empty(2 * n * L, dtype=torch.uint8).pin_memory()
+    h_rec = torch.empty((4, n), dtype=torch.int64).pin_memory()
+    d_reads = [torch.empty_like(t) for t in rd]
+    d_quals = torch.empty(2 * n * L, dtype=torch.uint8, device=dev)
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    for rep in range(2):                                   # the first pass maps the pinned pages
+        e[0].record()
+        for hsrc, d in zip(h_reads, d_reads):
+            d.copy_(hsrc, non_blocking=True)
+        d_quals.copy_(h_quals, non_blocking=True)
+        e[1].record()
+        e[2].record()
+        h_rec.copy_(records[0], non_blocking=True)
+        e[3].record()
+        torch.cuda.synchronize()
+    h2d_b = sum(t.numel() * 4 for t in rd) + 2 * n * L
+    d2h_b = 32 * n
+    h2d_ms, d2h_ms = e[0].elapsed_time(e[1]), e[2].elapsed_time(e[3])
+    # the derived streams the stages read (forward + reverse-complement copies, both mates in one stream) are built on the device
+    t0 = time.perf_counter()
+    s1, s2, _, _ = P.make_read_pairs(text, n, L, seed=0x5EED0100)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    pk = [P.pack_read_streams(x) for x in (s1, s2)]; torch.cat([pk[0][1], pk[1][1]])
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    best = out.get("two_batches_in_flight", out.get("serial", {}))
+    comp_ms = best.get("ms_per_batch")
+    out["host_transfers_per_batch"] = {"h2d_bytes": h2d_b, "h2d_ms": h2d_ms, "h2d_GBs": h2d_b / h2d_ms / 1e6, "d2h_bytes": d2h_b, "d2h_ms": d2h_ms, "d2h_GBs": d2h_b / d2h_ms / 1e6,
+                                       "device_side_repacking_ms": (t2 - t1) * 1e3,
+                                       "note": "pinned host memory, one stream; h2d = both mates' packed reads + a quality byte per base, d2h = the 32-byte pair records"}
+    if comp_ms:
+        out["host_transfers_per_batch"]["Mpairs_per_s_if_transfers_were_serialised_with_compute"] = n / (comp_ms + h2d_ms + d2h_ms) / 1e3
+        out["host_transfers_per_batch"]["Mpairs_per_s_if_transfers_overlap_compute"] = n / max(comp_ms, h2d_ms + d2h_ms) / 1e3
+    return out
 
 
 def _shim_params(p, scheme):
@@ -648,10 +751,52 @@ def cxx_driver_leg(a, dev, idx, sym, packed, genome_words, ng, names, prm, ref_b
     if rc != 0:
         return {"error": "nvbio_aligner_best_approx_timed returned %d" % rc}
     names9 = ("map", "select_init", "select", "locate", "score", "reduce", "mapq", "traceback", "finish")
-    return {"driver": "nvbio::bowtie2::cuda::Aligner::best_approx (include/nvbio_hip/aligner.h), index: line_native", "ms_per_batch": ms[0], "Mreads_per_s": n / ms[0] / 1e3,
+    return {"driver": "nvbio::bowtie2::cuda::Aligner::best_approx (include/nvbio_hip/aligner.h)", "ms_per_batch": ms[0], "Mreads_per_s": n / ms[0] / 1e3,
             "extensions": int(stats[0]), "rounds": int(stats[1]), "dp_jobs": int(stats[3]),
             "stage_ms": {k: round(stage[i], 3) for i, k in enumerate(names9)},
             "identical_to_python_driver": bool(torch.equal(best, ref_best) and torch.equal(mapq, ref_mapq))}
+
+
+def cxx_pipelined(dev, idx, batches, genome_words, ng, names, prm, workers, limit, token, reps=2):
+    """`len(batches)` batches of reads through the C++ single-end driver with `workers` host threads / HIP streams sharing the device
+    (tests/cxx/aligner_shim.cpp: nvbio_aligner_best_approx_pipelined; include/nvbio_hip/aligner.h: Aligner::seeding_token).
+    batches: [pack_read_streams(sym), ...].  Returns (dict, bests, mapqs)."""
+    import ctypes as C
+    shim = C.CDLL(os.path.join(ROOT, "tests", "cxx", "libaligner_shim.so"))
+    nb = len(batches)
+    n = int(batches[0][0].begin.numel()); L = READ_LEN
+    quals = torch.full((2 * n * L + 8,), 30, dtype=torch.uint8, device=dev)
+    arena, nidx = names
+    sp = _shim_params(prm, nvb.SmithWatermanScoringScheme())
+    fs = idx.struct()
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    ptrs = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    best = [torch.zeros((2, n), dtype=torch.int64, device=dev) for _ in range(nb)]
+    mapq = [torch.zeros(n, dtype=torch.uint8, device=dev) for _ in range(nb)]
+    ms = (C.c_double * 1)()
+    torch.cuda.synchronize()
+    rc = shim.nvbio_aligner_best_approx_pipelined(
+        C.byref(fs), None, C.c_uint32(n), C.c_uint32(L), C.c_uint32(nb),
+        ptrs([b[0].words for b in batches]), C.c_uint64(batches[0][0].words.numel()), ptrs([b[0].begin for b in batches]),
+        ptrs([b[1] for b in batches]), C.c_uint64(batches[0][1].numel()), vp(quals), C.c_uint64(quals.numel()), vp(arena), vp(nidx),
+        vp(genome_words), C.c_uint64(genome_words.numel()), C.c_uint32(ng), C.byref(sp),
+        C.c_uint32(workers), C.c_uint32(limit), C.c_uint32(reps), ms, ptrs(best), ptrs(mapq), C.c_uint32(1 if token else 0), C.c_uint32(0), C.c_uint32(1), C.c_uint32(0))
+    torch.cuda.synchronize()
+    if rc != 0:
+        return {"error": "nvbio_aligner_best_approx_pipelined returned %d" % rc}, None, None
+    return {"host_threads": workers, "seeding_grid_limit": limit, "seeding_token": bool(token), "ms_total": ms[0], "Mreads_per_s": n * nb / ms[0] / 1e3}, best, mapq
+
+
+def hbm_rich(fmi, dev):
+    """The index the 288 GB of an MI355X are there for: the line-native two-symbol arrays, the match range of every 15-mer (8.6 GB)
+    and the full suffix array (sa_int = 1, 12 GB at 3 Gbp) -- every result stays bit-identical (checked by the callers).  Falls back to
+    k = 12 / sa_int = 4 when less than 64 GB are free."""
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    big = free_b > (64 << 30) and fmi.length > (1 << 28)
+    k, sa = (15, 1) if big else (12, 1 if free_b > (24 << 30) else 4)
+    idx = fmi.with_dimer().with_ktab(k).with_dense_ssa(sa)
+    desc = {"line_native": True, "ktab_k": k, "ktab_bytes": (4 ** k) * 8, "sa_int": sa, "ssa_bytes": int(idx.ssa.numel()) * 4, "dimer_bytes": int(idx.dimer.numel()) * 4}
+    return idx, desc
 
 
 def rank_leg(a, dev, fmi):
@@ -706,9 +851,34 @@ def rank_leg(a, dev, fmi):
     torch.cuda.synchronize()
     ms_s = sum(e0.elapsed_time(e1) for e0, e1 in evs) / reps
     gbs_s = q * RANK_BYTES_PER_QUERY / (ms_s * 1e-3) / 1e9
-    res["sorted_order"] = {"kernel_ms": ms_s, "achieved": gbs_s, "frac": gbs_s / HBM_PEAK_GBS, "Mqueries_per_s": q / (ms_s * 1e-3) / 1e6,
-                           "identical_to_shuffled": True,
-                           "note": "algorithmic bytes (40 per query) over time: ~11 consecutive queries share a 128-B line and L2 serves the repeats, so the figure can pass the HBM peak; the queries' 8 B of I/O each are the real HBM traffic"}
+    sorted_traffic = measured_traffic("fm_rank_kernel_sorted")
+    res["sorted_order"] = {"kernel_ms": ms_s, "algorithmic_GBs": gbs_s, "Mqueries_per_s": q / (ms_s * 1e-3) / 1e6, "identical_to_shuffled": True,
+                           "traffic": sorted_traffic,
+                           "note": "NOT a roofline figure: ~11 consecutive queries share a 128-B line and L2 serves the repeats, so algorithmic bytes (40 per query) over "
+                                   "time can pass the HBM peak; `traffic` is what the fabric moved for this order (TCC_EA0_RDREQ pass, profiles/traffic.json), "
+                                   "null until that pass has been taken"}
+    if sorted_traffic:
+        res["sorted_order"]["traffic_GBs"] = sorted_traffic * (q / 268435456.0) / (ms_s * 1e-3) / 1e9
+        res["sorted_order"]["traffic_frac_of_hbm_peak"] = res["sorted_order"]["traffic_GBs"] / HBM_PEAK_GBS
+    # the same shuffled point queries on the line-native index (plane records: the row's 128-byte line holds its nibble and its counters)
+    try:
+        fd = fmi.with_dimer()
+        rd = nvb.rank(fd, k, c)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(rd, r))
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for e0, e1 in evs:
+            e0.record()
+            nvb.rank(fd, k, c)
+            e1.record()
+        torch.cuda.synchronize()
+        ms_d = sum(e0.elapsed_time(e1) for e0, e1 in evs) / reps
+        res["line_native"] = {"kernel_ms": ms_d, "achieved": q * RANK_BYTES_PER_QUERY / (ms_d * 1e-3) / 1e9, "frac": q * RANK_BYTES_PER_QUERY / (ms_d * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "Mqueries_per_s": q / (ms_d * 1e-3) / 1e6, "random_lines_per_s_G": q / (ms_d * 1e-3) / 1e9, "identical_to_reference_layout": same,
+                              "note": "a point query is one 128-byte line on either layout; the line-native index pays off where a step needs both ends of a range or two symbols"}
+        del fd, rd
+    except Exception as e:     # noqa: BLE001 -- reported, the leg continues
+        res["line_native"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return res
 
 

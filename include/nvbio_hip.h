@@ -774,6 +774,20 @@ int nvbio_hip_memcpy(void* dst, const void* src, uint64_t bytes, int kind, void*
 int nvbio_hip_memset(void* dst, int value, uint64_t bytes, void* stream);
 int nvbio_hip_stream_synchronize(void* stream);
 
+/* Streams and co-scheduling.  The reference runs one host thread per device on its default stream (nvBowtie.cpp:809-864,
+ * compute_thread.cu:74-117).  An MI355X is better served by SEVERAL batches in flight on one device: seeding (map / locate) is bound by
+ * the fabric's random-line rate with idle VALUs, extension / selection / traceback are VALU-bound with an idle fabric.  A driver object
+ * per host thread, each on its own non-blocking stream (every nvbio_hip_* entry takes the stream), lets the two kinds overlap;
+ * nvbio_hip_set_seeding_grid_limit(blocks) caps the grid of the seeding kernels (they become grid-stride loops over their reads), so
+ * that they leave wave slots, registers and LDS of every CU to the other stream's kernels.  Process-wide, 0 = no limit (the default).
+ * Results never depend on any of this. */
+int nvbio_hip_stream_create(void** stream, uint32_t non_blocking);
+int nvbio_hip_stream_create_with_cu_mask(void** stream, const uint32_t* mask, uint32_t n_words);
+int nvbio_hip_stream_destroy(void* stream);
+int nvbio_hip_device_cu_count(void);
+void     nvbio_hip_set_seeding_grid_limit(uint32_t blocks);
+uint32_t nvbio_hip_get_seeding_grid_limit(void);
+
 /* Library / device introspection (host). */
 int         nvbio_hip_abi_version(void);
 const char* nvbio_hip_arch(void);           /* "gfx950" */

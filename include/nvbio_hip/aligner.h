@@ -5,6 +5,7 @@
 // {select, locate, score_best, score_reduce}, mark_unaligned + copy_flagged into the re-seed queue, BowtieMapq2,
 // banded_traceback_best.  Inputs are device resident (the reference's io::SequenceDataDevice / FMIndexDataDevice).
 #pragma once
+#include <mutex>
 #include <algorithm>
 #include <chrono>
 #include <map>
@@ -108,7 +109,27 @@ struct Aligner
 
     hip::device_arena                 workspace;                 // the per-batch queues and temporaries of the best-mapping drivers
 
-    Aligner() : BATCH_SIZE(0), SCORING_BATCH(0), cigar_stride(64), mds_stride(256), n_alignments(0) {}
+    /// Several Aligner objects, one per host thread and HIP stream, may share one device (include/nvbio_hip.h, "Streams and
+    /// co-scheduling"): seeding (map / locate) is bound by the fabric's random-line rate with idle VALUs, everything else is VALU-bound
+    /// with an idle fabric.  Two seeding kernels resident at once only share the line rate (measured: both slow down ~1.8x,
+    /// profiles/r03/cosched_trace.txt); what pays is ONE batch seeding while the others extend.  Aligners that are given the same token
+    /// take it around their seeding kernels (and wait for them inside), so at most one of them is in a fabric-bound stage at a time.
+    std::mutex*                       seeding_token;
+    /// optional: a second stream for the seeding kernels alone (e.g. one created with a CU mask, nvbio_hip_stream_create_with_cu_mask, so
+    /// that seeding occupies a fixed slice of the chip and leaves the rest to the other batches' kernels); the hand-over is host-side
+    void*                             seeding_stream;
+
+    Aligner() : BATCH_SIZE(0), SCORING_BATCH(0), cigar_stride(64), mds_stride(256), n_alignments(0), seeding_token(nullptr), seeding_stream(nullptr) {}
+
+    /// run a seeding stage: f(stream) queues its kernels on the stream it is given
+    template <typename F> void fabric_bound(void* hip_stream, F f)
+    {
+        if (!seeding_token && !seeding_stream) { f(hip_stream); return; }
+        if (seeding_stream) hip::synchronize(hip_stream);               // what the stage reads has been produced
+        void* s = seeding_stream ? seeding_stream : hip_stream;
+        if (seeding_token) { std::lock_guard<std::mutex> guard(*seeding_token); f(s); hip::synchronize(s); }
+        else               { f(s); hip::synchronize(s); }
+    }
 
     /// Aligner::band_length (aligner.h:165-174)
     static uint32 band_length(const uint32 max_dist)
@@ -204,7 +225,7 @@ private:
             hip::device_vector<uint8> temp(nvbio_hip_all_mapping_temp_bytes(count));
             hip_check(nvbio_hip_inclusive_scan_u32(count, hit_counts.data(), hit_count_scan.data(), temp.data(), temp.size(), hip_stream), "nvbio_hip_inclusive_scan_u32");
             hip::synchronize(hip_stream);
-            hip_check(nvbio_hip_memcpy(&n_ranges, hit_count_scan.data() + (count - 1u), 4u, 2, nullptr), "nvbio_hip_memcpy(d2h)");
+            hip_check(nvbio_hip_memcpy(&n_ranges, hit_count_scan.data() + (count - 1u), 4u, 2, hip_stream), "nvbio_hip_memcpy(d2h)");
         }
         stats.ranges = n_ranges;
         if (n_ranges == 0) return;
@@ -216,7 +237,7 @@ private:
             hip_check(nvbio_hip_gather_ranges(n_ranges, count, reinterpret_cast<const uint64*>(hit_data.data()), hits_stride, hit_count_scan.data(), ranges.data(), hip_stream), "nvbio_hip_gather_ranges");
             hip_check(nvbio_hip_inclusive_scan_u64(n_ranges, ranges.data(), hit_range_scan.data(), temp.data(), temp.size(), hip_stream), "nvbio_hip_inclusive_scan_u64");
             hip::synchronize(hip_stream);
-            hip_check(nvbio_hip_memcpy(&n_hits, hit_range_scan.data() + (n_ranges - 1u), 8u, 2, nullptr), "nvbio_hip_memcpy(d2h)");
+            hip_check(nvbio_hip_memcpy(&n_hits, hit_range_scan.data() + (n_ranges - 1u), 8u, 2, hip_stream), "nvbio_hip_memcpy(d2h)");
         }
         stats.hits = n_hits;
 
@@ -259,7 +280,7 @@ private:
                       "nvbio_hip_mark_straddling");
             hip_check(nvbio_hip_copy_flagged(hit_count, sort_idx.data(), flags.data(), queue.data(), counter.data(), flag_temp.data(), flag_temp.size(), hip_stream), "nvbio_hip_copy_flagged");
             hip::synchronize(hip_stream);
-            const uint32 queue_size = counter.to_host()[0];
+            const uint32 queue_size = counter.to_host(hip_stream)[0];
             stats.unique += queue_size;
             if (queue_size == 0) continue;
 
@@ -278,7 +299,7 @@ private:
                                                  flags.data(), reinterpret_cast<uint64*>(job_aln.data()), job_read.data(), hip_stream), "nvbio_hip_score_all_output");
             hip_check(nvbio_hip_copy_flagged(queue_size, d_iota.data(), flags.data(), accepted.data(), counter.data(), flag_temp.data(), flag_temp.size(), hip_stream), "nvbio_hip_copy_flagged");
             hip::synchronize(hip_stream);
-            const uint32 n_accepted = counter.to_host()[0];
+            const uint32 n_accepted = counter.to_host(hip_stream)[0];
             reserve(n_alignments + n_accepted);
             hip_check(nvbio_hip_gather_rows(n_accepted, accepted.data(), job_aln.data(), scored_alignments_dvec.data() + n_alignments, 8u, hip_stream), "nvbio_hip_gather_rows");
             hip_check(nvbio_hip_gather_rows(n_accepted, accepted.data(), job_read.data(), output_read_info_dvec.data() + n_alignments, 4u, hip_stream), "nvbio_hip_gather_rows");
@@ -371,7 +392,7 @@ private:
             // hit_deques.clear_deques() + map
             hip_check(nvbio_hip_memset(hit_counts.data(), 0, uint64(count) * 4u, hip_stream), "nvbio_hip_memset");
             const PingPongQueuesView seed_queues = { seed_queue_size, seed_queue_in.data() };
-            stats.clock.run("map", hip_stream, [&] { map(reads.reversed, fmi, rfmi, seeding_pass, seed_queues, reseed.data(), hits, params, seed_freq.data(), params.fw, params.rc, hip_stream); });
+            stats.clock.run("map", hip_stream, [&] { fabric_bound(hip_stream, [&](void* ss) { map(reads.reversed, fmi, rfmi, seeding_pass, seed_queues, reseed.data(), hits, params, seed_freq.data(), params.fw, params.rc, ss); }); });
 
             best_approx_score<TYPE>(params, fmi, rfmi, aligner, genome_words, genome_n_words, genome_len, reads, band_len, seed_queue_size, seed_queue_in.data(),
                                     hits, state, queues, pat_begin, txt_begin, txt_len, sinks, min_score, hit_score, stats, hip_stream, best_sink.data());
@@ -381,7 +402,7 @@ private:
             hip_check(nvbio_hip_copy_flagged(seed_queue_size, seed_queue_in.data(), reseed.data(), seed_queue_out.data(), queue_count.data(),
                                              flag_temp.data(), flag_temp.size(), hip_stream), "nvbio_hip_copy_flagged");
             hip::synchronize(hip_stream);
-            seed_queue_size = queue_count.to_host()[0];
+            seed_queue_size = queue_count.to_host(hip_stream)[0];
             std::swap(seed_queue_in.m_ptr, seed_queue_out.m_ptr);
         }
 
@@ -476,7 +497,7 @@ private:
             const ReadBatch& a_reads = reads.mate[anchor];
             const ReadBatch& o_reads = reads.mate[1u - anchor];
             nvbio_hip_pe_params app = pp; app.anchor = anchor;
-            seed_queue_in.assign(iota.data(), count);
+            seed_queue_in.assign(iota.data(), count, hip_stream);
             uint32 seed_queue_size = count;
             const bool fw_strand = (anchor == 0) ? (pe.pe_policy == 0 || pe.pe_policy == 1) : (pe.pe_policy == 0 || pe.pe_policy == 2);     // :168-176
             const bool fw = fw_strand ? params.fw : params.rc, rc = fw_strand ? params.rc : params.fw;
@@ -487,7 +508,7 @@ private:
                 stats.queue.push_back(seed_queue_size); ++stats.seeding_passes;
                 hip_check(nvbio_hip_memset(hit_counts.data(), 0, uint64(count) * 4u, hip_stream), "nvbio_hip_memset");
                 const PingPongQueuesView seed_queues = { seed_queue_size, seed_queue_in.data() };
-                stats.clock.run("map", hip_stream, [&] { map(a_reads.reversed, fmi, rfmi, seeding_pass, seed_queues, reseed.data(), hits, params, seed_freq.data(), fw, rc, hip_stream); });
+                stats.clock.run("map", hip_stream, [&] { fabric_bound(hip_stream, [&](void* ss) { map(a_reads.reversed, fmi, rfmi, seeding_pass, seed_queues, reseed.data(), hits, params, seed_freq.data(), fw, rc, ss); }); });
 
                 // best_approx_score (:455-700)
                 hip_check(nvbio_hip_pack_read_queue(seed_queue_size, seed_queue_in.data(), params.select.top_seed & 1u, reinterpret_cast<uint32*>(queues.active_in.data()), hip_stream),
@@ -503,7 +524,7 @@ private:
                     stats.clock.run("select", hip_stream, [&] { select(hits, state, queues, n_hits_per_read, params.select, hip_stream); });
                     if (queues.in_size == 0) break;
                     if (queues.hits_size == 0) continue;
-                    stats.clock.run("locate", hip_stream, [&] { locate(fmi, rfmi, queues, hip_stream); });
+                    stats.clock.run("locate", hip_stream, [&] { fabric_bound(hip_stream, [&](void* ss) { locate(fmi, rfmi, queues, ss); }); });
                     const uint32 nh = queues.hits_size;
                     const uint32* hit_seed = reinterpret_cast<const uint32*>(queues.hit_seed.data());
 
@@ -564,7 +585,7 @@ private:
                 hip_check(nvbio_hip_copy_flagged(seed_queue_size, seed_queue_in.data(), reseed.data(), seed_queue_out.data(), queue_count.data(),
                                                  flag_temp.data(), flag_temp.size(), hip_stream), "nvbio_hip_copy_flagged");
                 hip::synchronize(hip_stream);
-                seed_queue_size = queue_count.to_host()[0];
+                seed_queue_size = queue_count.to_host(hip_stream)[0];
                 std::swap(seed_queue_in.m_ptr, seed_queue_out.m_ptr);
             }
         }
@@ -613,7 +634,7 @@ private:
                                                  valid_c.data(), tb_pat.data(), nullptr, tb_txt.data(), tb_len.data(), hip_stream), "nvbio_hip_traceback_best_setup");
         hip_check(nvbio_hip_copy_flagged(count, d_iota.data(), valid_c.data(), idx_c.data(), queue_count.data(), flag_temp.data(), flag_temp.size(), hip_stream), "nvbio_hip_copy_flagged");
         hip::synchronize(hip_stream);
-        const uint32 n_conc = queue_count.to_host()[0];
+        const uint32 n_conc = queue_count.to_host(hip_stream)[0];
 
         banded_tb(best_o, 2, valid, cigar_o.data(), cigar_len_o.data(), cigar_source_o.data(), cigar_sink_o.data(), traceback_score_o.data());
         if (params.finish_alignments) finish(count, valid.data(), nullptr, best_o, cigar_o.data(), cigar_len_o.data(), cigar_source_o.data(), mds_o.data(), mds_len_o.data());
@@ -695,7 +716,7 @@ private:
             stats.clock.run("select", hip_stream, [&] { select(hits, state, queues, n_hits_per_read, params.select, hip_stream); });
             if (queues.in_size == 0) break;
             if (queues.hits_size == 0) continue;
-            stats.clock.run("locate", hip_stream, [&] { locate(fmi, rfmi, queues, hip_stream); });
+            stats.clock.run("locate", hip_stream, [&] { fabric_bound(hip_stream, [&](void* ss) { locate(fmi, rfmi, queues, ss); }); });
             stats.clock.begin("score", hip_stream);
 
             // score_best: BestScoreStream's windows, then the banded scorer in nvBowtie's quality-aware scheme
@@ -706,7 +727,7 @@ private:
                              job_count.data(), job_hit.data(), hip_stream);
             uint32 n_jobs = 0;
             hip::synchronize(hip_stream);
-            hip_check(nvbio_hip_memcpy(&n_jobs, job_count.data(), 4u, 2, nullptr), "nvbio_hip_memcpy(d2h)");
+            hip_check(nvbio_hip_memcpy(&n_jobs, job_count.data(), 4u, 2, hip_stream), "nvbio_hip_memcpy(d2h)");
             if (n_jobs)
             {
                 const PackedStringSetView<4, true> patterns(n_jobs, reads.fw_rc_words, reads.fw_rc_n_words, pat_begin.data(), nullptr, L);

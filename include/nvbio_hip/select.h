@@ -84,7 +84,7 @@ inline void select(SeedHitDequeArrayDeviceView hits, SelectState& state, Scoring
                                queues.hit_read_id.data(), queues.hit_loc.data(), reinterpret_cast<uint32*>(queues.hit_seed.data()),
                                queues.sizes.data(), temp.data(), temp_bytes, hip_stream), "nvbio_hip_select");
     hip_check(nvbio_hip_stream_synchronize(hip_stream), "nvbio_hip_stream_synchronize");
-    const std::vector<uint32> s = queues.sizes.to_host();
+    const std::vector<uint32> s = queues.sizes.to_host(hip_stream);
     queues.swap();
     queues.in_size = s[0]; queues.hits_size = s[1];
 }

@@ -116,13 +116,15 @@ struct device_vector {
         hip_check(nvbio_hip_device_malloc(&p, uint64(n) * sizeof(T)), "nvbio_hip_device_malloc");
         m_ptr = static_cast<T*>(p); m_size = n; m_in_arena = false;
     }
-    void assign(const T* h, size_t n) {
+    /// (copies go through `stream`: a driver that shares its device with other host threads must not touch the NULL stream, which
+    /// synchronises with every blocking stream of the device)
+    void assign(const T* h, size_t n, void* stream = nullptr) {
         resize(n);
-        hip_check(nvbio_hip_memcpy(m_ptr, h, uint64(n) * sizeof(T), 1, nullptr), "nvbio_hip_memcpy(h2d)");
+        hip_check(nvbio_hip_memcpy(m_ptr, h, uint64(n) * sizeof(T), 1, stream), "nvbio_hip_memcpy(h2d)");
     }
-    std::vector<T> to_host() const {
+    std::vector<T> to_host(void* stream = nullptr) const {
         std::vector<T> h(m_size);
-        hip_check(nvbio_hip_memcpy(h.data(), m_ptr, uint64(m_size) * sizeof(T), 2, nullptr), "nvbio_hip_memcpy(d2h)");
+        hip_check(nvbio_hip_memcpy(h.data(), m_ptr, uint64(m_size) * sizeof(T), 2, stream), "nvbio_hip_memcpy(d2h)");
         return h;
     }
     T*       data()       { return m_ptr; }

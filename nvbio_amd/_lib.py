@@ -29,7 +29,8 @@ SYMBOLS = [
     "nvbio_hip_fm_filter_temp_bytes", "nvbio_hip_fm_filter_rank", "nvbio_hip_fm_filter_locate",
     "nvbio_hip_build_bwt_occ_temp_bytes", "nvbio_hip_build_bwt_occ",
     "nvbio_hip_device_malloc", "nvbio_hip_device_free", "nvbio_hip_memcpy", "nvbio_hip_memset",
-    "nvbio_hip_stream_synchronize",
+    "nvbio_hip_stream_synchronize", "nvbio_hip_stream_create", "nvbio_hip_stream_create_with_cu_mask", "nvbio_hip_stream_destroy", "nvbio_hip_device_cu_count",
+    "nvbio_hip_set_seeding_grid_limit", "nvbio_hip_get_seeding_grid_limit",
     "nvbio_hip_abi_version", "nvbio_hip_arch", "nvbio_hip_last_kernel",
 ]
 
@@ -186,6 +187,8 @@ def lib():
         L.nvbio_hip_build_bwt_occ_temp_bytes.argtypes = [u32]
         L.nvbio_hip_build_bwt_occ_temp_bytes.restype = u64
         L.nvbio_hip_build_bwt_occ.argtypes = [u32, vp, vp, vp, vp, u64, vp]
+        L.nvbio_hip_set_seeding_grid_limit.argtypes = [u32]; L.nvbio_hip_set_seeding_grid_limit.restype = None
+        L.nvbio_hip_get_seeding_grid_limit.argtypes = []; L.nvbio_hip_get_seeding_grid_limit.restype = u32
         L.nvbio_hip_abi_version.restype = C.c_int
         L.nvbio_hip_arch.restype = C.c_char_p
         L.nvbio_hip_last_kernel.restype = C.c_char_p

@@ -99,13 +99,11 @@ __device__ __forceinline__ uint2 seed_hit_pack(uint32_t begin, uint32_t delta, u
     return make_uint2(begin, (delta & 0xFFFFFu) | ((pos & 0x3FFu) << 20) | ((rc & 1u) << 30));    // indexdir = FORWARD = 0
 }
 
-__global__ void __launch_bounds__(256)
-map_exact_kernel(const Fmi f, const StringSet reads, const uint32_t* __restrict__ in_queue, uint32_t n,
-                 const MapParams p, const uint32_t* __restrict__ seed_freq_by_len,
-                 uint2* __restrict__ out_hits, uint32_t hits_stride, uint32_t* __restrict__ out_counts, uint8_t* __restrict__ out_reseed)
+__device__ __forceinline__ void
+map_exact_one(const uint32_t id, const Fmi& f, const StringSet& reads, const uint32_t* __restrict__ in_queue,
+              const MapParams& p, const uint32_t* __restrict__ seed_freq_by_len,
+              uint2* __restrict__ out_hits, uint32_t hits_stride, uint32_t* __restrict__ out_counts, uint8_t* __restrict__ out_reseed)
 {
-    const uint32_t id = blockIdx.x * 256u + threadIdx.x;
-    if (id >= n) return;
     const uint32_t read_id = in_queue ? in_queue[id] : id;
     const uint64_t rb   = reads.begin[read_id];
     const uint32_t rlen = reads.length ? reads.length[read_id] : reads.fixed_length;
@@ -150,6 +148,16 @@ map_exact_kernel(const Fmi f, const StringSet reads, const uint32_t* __restrict_
     }
     out_counts[read_id] = nh;
     if (out_reseed) out_reseed[id] = (range_count == 0u || range_sum >= p.rep_seeds * range_count) ? 1 : 0;
+}
+// grid-stride: the launch may be limited to fewer blocks than reads / 256 (nvbio_hip_set_seeding_grid_limit), so that this
+// fabric-bound kernel leaves wave slots and registers of every CU to a VALU-bound kernel of another stream
+__global__ void __launch_bounds__(256)
+map_exact_kernel(const Fmi f, const StringSet reads, const uint32_t* __restrict__ in_queue, uint32_t n,
+                 const MapParams p, const uint32_t* __restrict__ seed_freq_by_len,
+                 uint2* __restrict__ out_hits, uint32_t hits_stride, uint32_t* __restrict__ out_counts, uint8_t* __restrict__ out_reseed)
+{
+    for (uint64_t id = uint64_t(blockIdx.x) * 256u + threadIdx.x; id < n; id += uint64_t(gridDim.x) * 256u)
+        map_exact_one(uint32_t(id), f, reads, in_queue, p, seed_freq_by_len, out_hits, hits_stride, out_counts, out_reseed);
 }
 
 // ------------------------------------------------------------------ one-mismatch mappers
@@ -307,13 +315,11 @@ __device__ __forceinline__ void map_one_mismatch(const SeedVec& q, uint32_t len1
 }
 
 template <int ALGO>     // 1 = APPROX_MAPPING, 2 = CASE_PRUNING_MAPPING
-__global__ void __launch_bounds__(256)
-map_mismatch_kernel(const Fmi f, const Fmi rf, const StringSet reads, const uint32_t* __restrict__ in_queue, uint32_t n,
-                    const MapParams p, const uint32_t subseed_len, const uint32_t* __restrict__ seed_freq_by_len,
-                    uint2* __restrict__ out_hits, uint32_t hits_stride, uint32_t* __restrict__ out_counts, uint8_t* __restrict__ out_reseed)
+__device__ __forceinline__ void
+map_mismatch_one(const uint32_t id, const Fmi& f, const Fmi& rf, const StringSet& reads, const uint32_t* __restrict__ in_queue,
+                 const MapParams& p, const uint32_t subseed_len, const uint32_t* __restrict__ seed_freq_by_len,
+                 uint2* __restrict__ out_hits, uint32_t hits_stride, uint32_t* __restrict__ out_counts, uint8_t* __restrict__ out_reseed)
 {
-    const uint32_t id = blockIdx.x * 256u + threadIdx.x;
-    if (id >= n) return;
     const uint32_t read_id = in_queue ? in_queue[id] : id;
     const uint64_t rb   = reads.begin[read_id];
     const uint32_t rlen = reads.length ? reads.length[read_id] : reads.fixed_length;
@@ -349,6 +355,15 @@ map_mismatch_kernel(const Fmi f, const Fmi rf, const StringSet reads, const uint
     out_counts[read_id] = heap.nh;
     if (out_reseed) out_reseed[id] = (heap.range_count == 0u || heap.range_sum >= p.rep_seeds * heap.range_count) ? 1 : 0;
 }
+template <int ALGO>
+__global__ void __launch_bounds__(256)
+map_mismatch_kernel(const Fmi f, const Fmi rf, const StringSet reads, const uint32_t* __restrict__ in_queue, uint32_t n,
+                    const MapParams p, const uint32_t subseed_len, const uint32_t* __restrict__ seed_freq_by_len,
+                    uint2* __restrict__ out_hits, uint32_t hits_stride, uint32_t* __restrict__ out_counts, uint8_t* __restrict__ out_reseed)
+{
+    for (uint64_t id = uint64_t(blockIdx.x) * 256u + threadIdx.x; id < n; id += uint64_t(gridDim.x) * 256u)
+        map_mismatch_one<ALGO>(uint32_t(id), f, rf, reads, in_queue, p, subseed_len, seed_freq_by_len, out_hits, hits_stride, out_counts, out_reseed);
+}
 
 } // namespace nvb
 
@@ -375,7 +390,7 @@ NVB_API int nvbio_hip_map(int32_t algorithm, uint32_t subseed_len, const nvbio_h
     p.max_reseed = params->max_reseed; p.retry = params->retry; p.rep_seeds = params->rep_seeds;
     p.fw = params->fw; p.rc = params->rc;
     const Fmi f = make_fmi(fmi), rf = make_fmi(algorithm == NVBIO_HIP_CASE_PRUNING_MAPPING ? rfmi : fmi);
-    const dim3 grid((n + 255u) / 256u), block(256);
+    const dim3 grid(seeding_grid(n)), block(256);
     uint2* hits = reinterpret_cast<uint2*>(out_hits);
     if (algorithm == NVBIO_HIP_APPROX_MAPPING) {
         g_last_kernel = "map_mismatch_kernel<APPROX>";
@@ -406,7 +421,7 @@ NVB_API int nvbio_hip_map_exact(const nvbio_hip_fmindex* fmi, const nvbio_hip_st
     p.fw = params->fw; p.rc = params->rc;
     Fmi f = make_fmi(fmi);
     g_last_kernel = "map_exact_kernel";
-    hipLaunchKernelGGL(map_exact_kernel, dim3((n + 255u) / 256u), dim3(256), 0, to_stream(stream), f, make_string_set(reads), in_queue, n, p,
+    hipLaunchKernelGGL(map_exact_kernel, dim3(seeding_grid(n)), dim3(256), 0, to_stream(stream), f, make_string_set(reads), in_queue, n, p,
                        seed_freq_by_len, reinterpret_cast<uint2*>(out_hits), hits_stride, out_counts, out_reseed);
     return hipGetLastError();
 }

@@ -217,13 +217,15 @@ select_compact_kernel(uint32_t n_multi, uint32_t n_active, const uint64_t* __res
 __global__ void __launch_bounds__(256)
 locate_hits_kernel(const Fmi f, const Fmi rf, uint32_t n, uint32_t* __restrict__ hit_loc, const uint32_t* __restrict__ hit_seed)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t seed = hit_seed[i], dir = (seed >> 12) & 1u, pir = seed & 0xFFFu;
-    const Fmi& x = dir ? rf : f;
-    const uint2 it = fm_locate_it(x, hit_loc[i]);
-    const uint32_t g = x.ssa[it.x / x.sa_int] + it.y;
-    hit_loc[i] = (dir ? rf.length - 1u - g : g) - pir;
+    // grid-stride: see map_exact_kernel
+    for (uint64_t i = uint64_t(blockIdx.x) * 256u + threadIdx.x; i < n; i += uint64_t(gridDim.x) * 256u)
+    {
+        const uint32_t seed = hit_seed[i], dir = (seed >> 12) & 1u, pir = seed & 0xFFFu;
+        const Fmi& x = dir ? rf : f;
+        const uint2 it = fm_locate_it(x, hit_loc[i]);
+        const uint32_t g = x.ssa[it.x / x.sa_int] + it.y;
+        hit_loc[i] = (dir ? rf.length - 1u - g : g) - pir;
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -387,7 +389,7 @@ NVB_API int nvbio_hip_locate_hits(const nvbio_hip_fmindex* fmi, const nvbio_hip_
     if (n == 0) return hipSuccess;
     if (!hit_loc || !hit_seed) return hipErrorInvalidValue;
     g_last_kernel = "locate_hits_kernel";
-    hipLaunchKernelGGL(locate_hits_kernel, grid_for(n), dim3(256), 0, to_stream(stream), make_fmi(fmi), make_fmi(rfmi ? rfmi : fmi), n, hit_loc, hit_seed);
+    hipLaunchKernelGGL(locate_hits_kernel, dim3(seeding_grid(n)), dim3(256), 0, to_stream(stream), make_fmi(fmi), make_fmi(rfmi ? rfmi : fmi), n, hit_loc, hit_seed);
     return hipGetLastError();
 }
 

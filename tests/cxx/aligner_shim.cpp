@@ -134,6 +134,112 @@ int nvbio_aligner_best_approx_timed(const nvbio_hip_fmindex* fmi, const nvbio_hi
     } catch (const std::exception& e) { fprintf(stderr, "aligner_shim: %s\n", e.what()); return 1; }
 }
 
+// Co-scheduling probe / pipelined driver (bench.py's config-4 leg, tools/cosched_probe.py): `n_batches` batches through the single-end
+// driver with `n_workers` host threads, each owning one Aligner and one non-blocking HIP stream (worker w takes batches w, w + n_workers,
+// ...), the way the reference runs one host thread per device -- here several per device, so that one batch's fabric-bound seeding
+// overlaps another's VALU-bound extension.  seeding_grid_limit: nvbio_hip_set_seeding_grid_limit for the run (0 = none).
+// batch b's reads: d_rev_words[b] / d_rev_begin[b] / d_fwrc_words[b] (device pointers, one set per batch).
+// out_wall_ms = wall time of all batches between two device synchronisations (after one untimed warm-up pass that sizes every worker's
+// workspace); d_best[b] (device, 2n) / d_mapq[b] receive every batch's results.
+#include <thread>
+#include <mutex>
+extern "C" __attribute__((visibility("default")))
+int nvbio_aligner_best_approx_pipelined(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmindex* rfmi, uint32_t n, uint32_t L, uint32_t n_batches,
+                                        const uint32_t* const* d_rev_words, uint64_t rev_n_words, const uint64_t* const* d_rev_begin,
+                                        const uint32_t* const* d_fwrc_words, uint64_t fwrc_n_words, const uint8_t* d_quals, uint64_t n_quals,
+                                        const char* d_names, const uint32_t* d_names_idx,
+                                        const uint32_t* d_genome_words, uint64_t genome_n_words, uint32_t genome_len, const shim_params* sp,
+                                        uint32_t n_workers, uint32_t seeding_grid_limit, uint32_t reps, double* out_wall_ms,
+                                        uint64_t* const* d_best, uint8_t* const* d_mapq, uint32_t seeding_token /* 1: the workers take turns in their seeding stages */,
+                                        uint32_t seeding_cus /* > 0: seeding kernels on a CU-masked stream of this many CUs */, uint32_t cu_stride /* 1 = the first CUs, k = every k-th */,
+                                        uint32_t mask_compute /* 1: the other kernels on the complement */)
+{
+    try {
+        Params params;
+        params.seed_len = sp->seed_len; params.seed_freq = SimpleFunc(SimpleFunc::Type(sp->seed_freq_type), sp->seed_freq_k, sp->seed_freq_m);
+        params.min_read_len = sp->min_read_len; params.max_hits = sp->max_hits; params.max_reseed = sp->max_reseed; params.rep_seeds = sp->rep_seeds;
+        params.allow_sub = sp->allow_sub; params.subseed_len = sp->subseed_len;
+        params.select.randomized = sp->randomized != 0; params.select.top_seed = sp->top_seed; params.select.max_effort_init = sp->max_effort_init;
+        params.select.max_effort = sp->max_effort; params.select.min_ext = sp->min_ext; params.select.max_ext = sp->max_ext;
+        params.max_dist = sp->max_dist; params.alignment_type = sp->local ? LocalAlignment : EndToEndAlignment;
+        params.no_multi_hits = sp->no_multi_hits != 0; params.hits_stride = sp->hits_stride; params.finish_alignments = sp->finish != 0;
+        aln::SmithWatermanScoringScheme scheme = sp->local ? aln::SmithWatermanScoringScheme::local() : aln::SmithWatermanScoringScheme();
+        scheme.m_match = sp->match;
+        const ScoreLimits limits(sp->match, SimpleFunc(SimpleFunc::Type(sp->score_min_type), sp->score_min_k, sp->score_min_m));
+        fm_index_device f, rf; f.m = *fmi; rf.m = rfmi ? *rfmi : *fmi;
+        if (n_workers == 0) n_workers = 1;
+
+        std::mutex token;
+        const uint32_t old_limit = nvbio_hip_get_seeding_grid_limit();
+        nvbio_hip_set_seeding_grid_limit(seeding_grid_limit);
+        std::vector<Aligner*> aligners(n_workers, nullptr);
+        std::vector<void*>    streams(n_workers, nullptr), seed_streams(n_workers, nullptr);
+        for (uint32_t w = 0; w < n_workers; ++w)
+        {
+            aligners[w] = new Aligner();
+            aligners[w]->init(std::max(sp->batch_size, n), sp->batch_size);
+            if (seeding_cus)
+            {
+                const uint32_t n_cu = uint32_t(nvbio_hip_device_cu_count()), words = (n_cu + 31u) / 32u;
+                std::vector<uint32_t> seed_mask(words, 0u), rest_mask(words, 0u);
+                uint32_t taken = 0;
+                for (uint32_t c = 0; c < n_cu; ++c)
+                {
+                    const bool pick = taken < seeding_cus && (c % (cu_stride ? cu_stride : 1u)) == 0u;
+                    if (pick) { seed_mask[c / 32u] |= 1u << (c % 32u); ++taken; } else rest_mask[c / 32u] |= 1u << (c % 32u);
+                }
+                hip_check(nvbio_hip_stream_create_with_cu_mask(&seed_streams[w], seed_mask.data(), words), "nvbio_hip_stream_create_with_cu_mask");
+                aligners[w]->seeding_stream = seed_streams[w];
+                if (mask_compute) hip_check(nvbio_hip_stream_create_with_cu_mask(&streams[w], rest_mask.data(), words), "nvbio_hip_stream_create_with_cu_mask");
+            }
+            if (!streams[w] && (n_workers > 1 || seeding_cus)) hip_check(nvbio_hip_stream_create(&streams[w], 1u), "nvbio_hip_stream_create");
+            if (n_workers > 1 && seeding_token) aligners[w]->seeding_token = &token;
+        }
+        std::vector<int> failed(n_workers, 0);
+        auto worker = [&](const uint32_t w)
+        {
+            try {
+                for (uint32_t b = w; b < n_batches; b += n_workers)
+                {
+                    ReadBatch reads;
+                    reads.n = n; reads.len = L;
+                    reads.reversed = PackedStringSetView<4, true>(n, d_rev_words[b], rev_n_words, d_rev_begin[b], nullptr, L);
+                    reads.fw_rc_words = d_fwrc_words[b]; reads.fw_rc_n_words = fwrc_n_words; reads.rc_offset = uint64_t(n) * L;
+                    reads.quals = d_quals; reads.n_quals = n_quals; reads.names = d_names; reads.names_idx = d_names_idx;
+                    Stats stats;
+                    aligners[w]->best_approx(params, f, rf, scheme, limits, d_genome_words, genome_n_words, genome_len, reads, stats, streams[w]);
+                    hip_check(nvbio_hip_memcpy(d_best[b], aligners[w]->best_data_dvec.data(), uint64_t(n) * 8u, 3, streams[w]), "d2d");
+                    hip_check(nvbio_hip_memcpy(d_best[b] + n, aligners[w]->best_data_dvec.data() + aligners[w]->BATCH_SIZE, uint64_t(n) * 8u, 3, streams[w]), "d2d");
+                    hip_check(nvbio_hip_memcpy(d_mapq[b], aligners[w]->mapq_dvec.data(), n, 3, streams[w]), "d2d");
+                    hip::synchronize(streams[w]);
+                }
+            } catch (const std::exception& e) { fprintf(stderr, "aligner_shim worker %u: %s\n", w, e.what()); failed[w] = 1; }
+        };
+        auto pass = [&]()
+        {
+            if (n_workers == 1) { worker(0); return; }
+            std::vector<std::thread> th;
+            for (uint32_t w = 0; w < n_workers; ++w) th.emplace_back(worker, w);
+            for (auto& t : th) t.join();
+        };
+        pass();                                            // warm-up: every worker's workspace reaches its final size
+        hip::synchronize();
+        double total = 0.0;
+        for (uint32_t r = 0; r < reps; ++r)
+        {
+            const auto t0 = std::chrono::steady_clock::now();
+            pass();
+            hip::synchronize();
+            total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
+        out_wall_ms[0] = reps ? total / reps : 0.0;
+        for (uint32_t w = 0; w < n_workers; ++w) { delete aligners[w]; if (streams[w]) nvbio_hip_stream_destroy(streams[w]); if (seed_streams[w]) nvbio_hip_stream_destroy(seed_streams[w]); }
+        nvbio_hip_set_seeding_grid_limit(old_limit);
+        for (uint32_t w = 0; w < n_workers; ++w) if (failed[w]) return 1;
+        return 0;
+    } catch (const std::exception& e) { fprintf(stderr, "aligner_shim: %s\n", e.what()); return 1; }
+}
+
 struct shim_pe_params { int32_t pe_policy; uint32_t pe_overlap, pe_unpaired, pe_discordant, min_frag_len, max_frag_len; };
 
 // the paired-end driver: per mate {reversed words, begin, fw+rc words, quals, names}, the joint pattern stream of the tracebacks;
@@ -250,6 +356,102 @@ int nvbio_aligner_best_approx_paired_timed(const nvbio_hip_fmindex* fmi, const n
     return paired_impl(fmi, rfmi, n, L, d_rev_words, rev_n_words, d_rev_begin, d_fwrc_words, fwrc_n_words, d_quals, n_quals, d_names, d_names_idx, d_both_words, both_n_words,
                        mate_offset, d_both_quals, both_n_quals, d_genome_words, genome_n_words, genome_len, sp, pp, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                        nullptr, nullptr, h_stats, reps ? reps : 1u, out_ms, out_stage_ms);
+}
+
+// The paired-end driver over many batches (bench.py's config-5 leg at its per-GPU share): `n_batches` batches of n pairs each with one
+// Aligner per worker thread / stream, as nvbio_aligner_best_approx_pipelined.  A batch's inputs: shim_pair_batch (device pointers).
+// d_records[b]: device, 32 bytes per pair = io::BestPairedAlignments {anchor best, anchor second, opposite best, opposite second}
+// (nvbio/io/alignments.h:222-300) -- the record a multi-GPU run gathers.
+struct shim_pair_batch { const uint32_t* rev_words[2]; const uint64_t* rev_begin[2]; const uint32_t* fwrc_words[2]; const uint32_t* both_words; };
+extern "C" __attribute__((visibility("default")))
+int nvbio_aligner_best_approx_paired_pipelined(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmindex* rfmi, uint32_t n, uint32_t L, uint32_t n_batches,
+                                               const shim_pair_batch* batches, const uint64_t* rev_n_words, const uint64_t* fwrc_n_words,
+                                               const uint8_t* d_quals, uint64_t n_quals, const char* d_names, const uint32_t* d_names_idx,
+                                               uint64_t both_n_words, uint64_t mate_offset, const uint8_t* d_both_quals, uint64_t both_n_quals,
+                                               const uint32_t* d_genome_words, uint64_t genome_n_words, uint32_t genome_len, const shim_params* sp, const shim_pe_params* pp,
+                                               uint32_t n_workers, uint32_t seeding_grid_limit, double* out_wall_ms, uint64_t* const* d_records, uint64_t* h_stats /* extensions, rounds */,
+                                               uint32_t seeding_token)
+{
+    try {
+        Params params;
+        params.seed_len = sp->seed_len; params.seed_freq = SimpleFunc(SimpleFunc::Type(sp->seed_freq_type), sp->seed_freq_k, sp->seed_freq_m);
+        params.min_read_len = sp->min_read_len; params.max_hits = sp->max_hits; params.max_reseed = sp->max_reseed; params.rep_seeds = sp->rep_seeds;
+        params.allow_sub = sp->allow_sub; params.subseed_len = sp->subseed_len;
+        params.select.randomized = sp->randomized != 0; params.select.top_seed = sp->top_seed; params.select.max_effort_init = sp->max_effort_init;
+        params.select.max_effort = sp->max_effort; params.select.min_ext = sp->min_ext; params.select.max_ext = sp->max_ext;
+        params.max_dist = sp->max_dist; params.alignment_type = sp->local ? LocalAlignment : EndToEndAlignment;
+        params.no_multi_hits = sp->no_multi_hits != 0; params.hits_stride = sp->hits_stride; params.finish_alignments = sp->finish != 0;
+        PairedParams pe;
+        pe.pe_policy = pp->pe_policy; pe.pe_overlap = pp->pe_overlap != 0; pe.pe_unpaired = pp->pe_unpaired != 0; pe.pe_discordant = pp->pe_discordant != 0;
+        pe.min_frag_len = pp->min_frag_len; pe.max_frag_len = pp->max_frag_len;
+        aln::SmithWatermanScoringScheme scheme = sp->local ? aln::SmithWatermanScoringScheme::local() : aln::SmithWatermanScoringScheme();
+        scheme.m_match = sp->match;
+        const ScoreLimits limits(sp->match, SimpleFunc(SimpleFunc::Type(sp->score_min_type), sp->score_min_k, sp->score_min_m));
+        fm_index_device f, rf; f.m = *fmi; rf.m = rfmi ? *rfmi : *fmi;
+        if (n_workers == 0) n_workers = 1;
+        std::mutex token;
+        const uint32_t old_limit = nvbio_hip_get_seeding_grid_limit();
+        nvbio_hip_set_seeding_grid_limit(seeding_grid_limit);
+        std::vector<Aligner*> aligners(n_workers, nullptr);
+        std::vector<void*>    streams(n_workers, nullptr);
+        for (uint32_t w = 0; w < n_workers; ++w)
+        {
+            aligners[w] = new Aligner();
+            aligners[w]->init(std::max(sp->batch_size, n), sp->batch_size);
+            aligners[w]->init_paired();
+            if (n_workers > 1) hip_check(nvbio_hip_stream_create(&streams[w], 1u), "nvbio_hip_stream_create");
+            if (n_workers > 1 && seeding_token) aligners[w]->seeding_token = &token;
+        }
+        std::vector<int> failed(n_workers, 0);
+        std::vector<uint64_t> ext(n_workers, 0), rounds(n_workers, 0);
+        auto run_batch = [&](const uint32_t w, const uint32_t b)
+        {
+            PairedReadBatch reads;
+            for (int m = 0; m < 2; ++m) {
+                ReadBatch& rb = reads.mate[m];
+                rb.n = n; rb.len = L;
+                rb.reversed = PackedStringSetView<4, true>(n, batches[b].rev_words[m], rev_n_words[m], batches[b].rev_begin[m], nullptr, L);
+                rb.fw_rc_words = batches[b].fwrc_words[m]; rb.fw_rc_n_words = fwrc_n_words[m]; rb.rc_offset = uint64_t(n) * L;
+                rb.quals = d_quals; rb.n_quals = n_quals; rb.names = d_names; rb.names_idx = d_names_idx;
+            }
+            reads.both_words = batches[b].both_words; reads.both_n_words = both_n_words; reads.mate_offset = mate_offset;
+            reads.both_quals = d_both_quals; reads.both_n_quals = both_n_quals;
+            Stats stats;
+            Aligner& al = *aligners[w];
+            al.best_approx(params, pe, f, rf, scheme, limits, d_genome_words, genome_n_words, genome_len, reads, stats, streams[w]);
+            ext[w] += stats.extensions; rounds[w] += stats.rounds;
+            // the 32-byte pair record: [a1 | a2 | o1 | o2] as four planes of n words
+            hip_check(nvbio_hip_memcpy(d_records[b],          al.best_data_dvec.data(),                   uint64_t(n) * 8u, 3, streams[w]), "d2d");
+            hip_check(nvbio_hip_memcpy(d_records[b] + n,      al.best_data_dvec.data() + al.BATCH_SIZE,   uint64_t(n) * 8u, 3, streams[w]), "d2d");
+            hip_check(nvbio_hip_memcpy(d_records[b] + 2u * n, al.best_data_dvec_o.data(),                 uint64_t(n) * 8u, 3, streams[w]), "d2d");
+            hip_check(nvbio_hip_memcpy(d_records[b] + 3u * n, al.best_data_dvec_o.data() + al.BATCH_SIZE, uint64_t(n) * 8u, 3, streams[w]), "d2d");
+            hip::synchronize(streams[w]);
+        };
+        auto worker = [&](const uint32_t w, const uint32_t first, const uint32_t count)
+        {
+            try { for (uint32_t b = first + w; b < first + count; b += n_workers) run_batch(w, b); }
+            catch (const std::exception& e) { fprintf(stderr, "aligner_shim worker %u: %s\n", w, e.what()); failed[w] = 1; }
+        };
+        auto pass = [&](const uint32_t first, const uint32_t count)
+        {
+            if (n_workers == 1) { worker(0, first, count); return; }
+            std::vector<std::thread> th;
+            for (uint32_t w = 0; w < n_workers; ++w) th.emplace_back(worker, w, first, count);
+            for (auto& t : th) t.join();
+        };
+        pass(0, std::min(n_batches, 2u * n_workers));          // warm-up on the first batches: every worker's workspace reaches its size
+        hip::synchronize();
+        for (uint32_t w = 0; w < n_workers; ++w) { ext[w] = 0; rounds[w] = 0; }
+        const auto t0 = std::chrono::steady_clock::now();
+        pass(0, n_batches);
+        hip::synchronize();
+        out_wall_ms[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        h_stats[0] = h_stats[1] = 0;
+        for (uint32_t w = 0; w < n_workers; ++w) { h_stats[0] += ext[w]; h_stats[1] += rounds[w]; delete aligners[w]; if (streams[w]) nvbio_hip_stream_destroy(streams[w]); }
+        nvbio_hip_set_seeding_grid_limit(old_limit);
+        for (uint32_t w = 0; w < n_workers; ++w) if (failed[w]) return 1;
+        return 0;
+    } catch (const std::exception& e) { fprintf(stderr, "aligner_shim: %s\n", e.what()); return 1; }
 }
 
 // the all-mapping driver (Aligner::all): outputs for up to out_cap alignments; *h_n = how many there are
