@@ -605,6 +605,7 @@ def config5_share_leg(a, dev, fmi, text, genome_words, ng, names, prm, batch_pai
     for key, workers, limit, token in (("serial", 1, 0, 0), ("two_batches_in_flight", 2, 0, 0)):
         ms, stats = (C.c_double * 1)(), (C.c_uint64 * 2)()
         torch.cuda.synchronize()
+        torch.cuda.empty_cache()               # the C++ drivers allocate their own workspaces: hand them what torch's allocator has cached
         rc = shim.nvbio_aligner_best_approx_paired_pipelined(
             C.byref(fs), None, C.c_uint32(n), C.c_uint32(L), C.c_uint32(nb), arr,
             u64x2([pk0[0][0].words.numel(), pk0[1][0].words.numel()]), u64x2([pk0[0][1].numel(), pk0[1][1].numel()]),
@@ -775,6 +776,7 @@ def cxx_pipelined(dev, idx, batches, genome_words, ng, names, prm, workers, limi
     mapq = [torch.zeros(n, dtype=torch.uint8, device=dev) for _ in range(nb)]
     ms = (C.c_double * 1)()
     torch.cuda.synchronize()
+    torch.cuda.empty_cache()
     rc = shim.nvbio_aligner_best_approx_pipelined(
         C.byref(fs), None, C.c_uint32(n), C.c_uint32(L), C.c_uint32(nb),
         ptrs([b[0].words for b in batches]), C.c_uint64(batches[0][0].words.numel()), ptrs([b[0].begin for b in batches]),

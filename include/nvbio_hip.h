@@ -788,6 +788,27 @@ int nvbio_hip_device_cu_count(void);
 void     nvbio_hip_set_seeding_grid_limit(uint32_t blocks);
 uint32_t nvbio_hip_get_seeding_grid_limit(void);
 
+/* Multi-GPU.  The reference runs one host thread per device over a replicated index, all writing into one shared
+ * output (nvBowtie/nvBowtie.cpp:809-864, bowtie2/cuda/compute_thread.cu:74-117): no collective.  Here every device aligns a contiguous
+ * block of the reads and the fixed-size result records (16 B per read, 32 B per pair; 4-12 B for the extension stage alone) are gathered
+ * to one rank over RCCL / xGMI with grouped ncclSend / ncclRecv -- the ONLY collective of the path.  RCCL is bound at run time (dlopen);
+ * nvbio_hip_comm_available() = 0 means it could not be, and the comm entries return hipErrorNotSupported (801).
+ *   one process, one host thread per device:  nvbio_hip_comm_init_all(comms, n, devices)   (ncclCommInitAll)
+ *   one process per device (a launcher):      rank 0 makes nvbio_hip_comm_unique_id(id), the launcher ships the 128 bytes to every rank,
+ *                                             each rank calls nvbio_hip_comm_init_rank(&comm, world, rank, id) on its own device
+ * nvbio_hip_gather_records: counts[r] records of record_bytes bytes from rank r (all ranks pass the same counts); the root's recv holds
+ * them in rank order.  Device buffers, queued on `stream`.  RCCL failures are returned as 2000 + ncclResult_t. */
+int nvbio_hip_comm_available(void);
+int nvbio_hip_device_count(void);
+int nvbio_hip_set_device(int device);
+int nvbio_hip_get_device(void);
+int nvbio_hip_comm_unique_id(uint8_t* id128);
+int nvbio_hip_comm_init_rank(void** comm, int world, int rank, const uint8_t* id128);
+int nvbio_hip_comm_init_all(void** comms, int n_devices, const int* devices /* nullable: 0..n-1 */);
+int nvbio_hip_comm_destroy(void* comm);
+int nvbio_hip_comm_rank(void* comm, int* rank, int* world);
+int nvbio_hip_gather_records(void* comm, const void* send, const uint64_t* counts, uint32_t record_bytes, void* recv /* root only */, int root, void* stream);
+
 /* Library / device introspection (host). */
 int         nvbio_hip_abi_version(void);
 const char* nvbio_hip_arch(void);           /* "gfx950" */

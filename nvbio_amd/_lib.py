@@ -31,6 +31,8 @@ SYMBOLS = [
     "nvbio_hip_device_malloc", "nvbio_hip_device_free", "nvbio_hip_memcpy", "nvbio_hip_memset",
     "nvbio_hip_stream_synchronize", "nvbio_hip_stream_create", "nvbio_hip_stream_create_with_cu_mask", "nvbio_hip_stream_destroy", "nvbio_hip_device_cu_count",
     "nvbio_hip_set_seeding_grid_limit", "nvbio_hip_get_seeding_grid_limit",
+    "nvbio_hip_comm_available", "nvbio_hip_device_count", "nvbio_hip_set_device", "nvbio_hip_get_device", "nvbio_hip_comm_unique_id", "nvbio_hip_comm_init_rank",
+    "nvbio_hip_comm_init_all", "nvbio_hip_comm_destroy", "nvbio_hip_comm_rank", "nvbio_hip_gather_records",
     "nvbio_hip_abi_version", "nvbio_hip_arch", "nvbio_hip_last_kernel",
 ]
 
@@ -189,6 +191,13 @@ def lib():
         L.nvbio_hip_build_bwt_occ.argtypes = [u32, vp, vp, vp, vp, u64, vp]
         L.nvbio_hip_set_seeding_grid_limit.argtypes = [u32]; L.nvbio_hip_set_seeding_grid_limit.restype = None
         L.nvbio_hip_get_seeding_grid_limit.argtypes = []; L.nvbio_hip_get_seeding_grid_limit.restype = u32
+        L.nvbio_hip_comm_unique_id.argtypes = [vp]
+        L.nvbio_hip_comm_init_rank.argtypes = [P(vp), C.c_int, C.c_int, vp]
+        L.nvbio_hip_comm_init_all.argtypes = [vp, C.c_int, vp]
+        L.nvbio_hip_comm_destroy.argtypes = [vp]
+        L.nvbio_hip_comm_rank.argtypes = [vp, P(C.c_int), P(C.c_int)]
+        L.nvbio_hip_gather_records.argtypes = [vp, vp, vp, u32, vp, C.c_int, vp]
+        L.nvbio_hip_set_device.argtypes = [C.c_int]
         L.nvbio_hip_abi_version.restype = C.c_int
         L.nvbio_hip_arch.restype = C.c_char_p
         L.nvbio_hip_last_kernel.restype = C.c_char_p

@@ -58,7 +58,7 @@ def build(force=False, verbose=False):
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
             list(ex.map(run, jobs))
     if jobs or force or _stale(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-fopenmp", "-o", LIB] + objs)
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-fopenmp", "-o", LIB] + objs + ["-ldl"])
     return LIB
 
 

@@ -270,11 +270,20 @@ __device__ __forceinline__ uint32_t c16(int32_t v) { return uint32_t(v) & 0xFFFF
 __device__ __forceinline__ uint32_t max16u(uint32_t a, uint32_t b) { uint32_t r; asm("v_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ uint32_t min16u(uint32_t a, uint32_t b) { uint32_t r; asm("v_min_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
-template <int TYPE, int R, bool CHECK, bool PBX = false>      // PBX: keep every row's maximum over the text (pattern-blocking early exit, non-LOCAL types)
+// MULTI: several jobs share the wave (full_gotoh_score_multi_kernel): the wave is cut in segments of `W` lanes, segment j sweeps job j,
+// and `lane` is the lane's index INSIDE its segment.  The last lane of every segment but the last holds no rows: it is the next
+// segment's "row above the matrix" (the feeder): what wave_shr:1 hands the next segment's first lane -- H(-1, c) + G_o, F = infimum, the
+// text symbol of column c of the NEXT job, an empty column maximum -- is what that lane keeps in its out_* registers.  Everything a job
+// owns (M, Ncols, lane_last, klast ...) is then a per-lane value, and the loop bounds are the wave's maxima / minima.
+template <int TYPE, int R, bool CHECK, bool PBX = false, bool MULTI = false>      // PBX: keep every row's maximum over the text (pattern-blocking early exit, non-LOCAL types)
 struct Sweep16
 {
+    static_assert(!MULTI || TYPE != NVBIO_HIP_GLOBAL, "segments carry constants down the feeder lanes: LOCAL and SEMI_GLOBAL only");
     const FullParams& p;
     uint32_t lane, lane_last, klast, M, Ncols, Nfull;
+    uint32_t wlane, seg_base, seg_w; bool feeder, seg_valid;      // MULTI: lane in the wave, first lane / width of the segment, feeder lane, segment holds a job
+    uint64_t tb_feed;                                             // MULTI: text of the job this lane feeds symbols for (lane 0: its own; a feeder: the next job's)
+    uint32_t ncols_feed;
     int32_t  Go, Ge, min_score;
     uint32_t go, ge, rge, inf16, init_above_g;
     uint32_t tlo[R], thi[R];              // per-row substitution table: four 16-bit entries, scores pre-biased by -G_o (cell16)
@@ -295,9 +304,14 @@ struct Sweep16
 
     __device__ __forceinline__ Sweep16(const FullParams& _p) : p(_p) {}
 
-    __device__ __forceinline__ void init(const uint64_t pb, const uint64_t _tb, uint32_t _M, uint32_t _Ncols, uint32_t _Nfull, int32_t _min_score)
+    /// MULTI: _seg_w = lanes per segment; _valid = this lane's segment holds a job; _tb_feed / _ncols_feed = text of the job of lane + 1's segment
+    __device__ __forceinline__ void init(const uint64_t pb, const uint64_t _tb, uint32_t _M, uint32_t _Ncols, uint32_t _Nfull, int32_t _min_score,
+                                         const uint32_t _seg_w = 64u, const bool _valid = true, const uint64_t _tb_feed = 0, const uint32_t _ncols_feed = 0)
     {
-        lane = threadIdx.x & 63u; M = _M; Ncols = _Ncols; Nfull = _Nfull; min_score = _min_score; tb = _tb; pb_check = false;
+        wlane = threadIdx.x & 63u; seg_w = _seg_w; seg_valid = _valid;
+        lane = MULTI ? wlane % seg_w : wlane; seg_base = wlane - lane;
+        tb_feed = MULTI ? _tb_feed : _tb; ncols_feed = MULTI ? _ncols_feed : _Ncols;
+        M = _M; Ncols = _Ncols; Nfull = _Nfull; min_score = _min_score; tb = _tb; pb_check = false;
         Go = p.gap_open; Ge = p.gap_ext;
         const int32_t infimum = -32768 - min(Go, Ge) * SC;
         lane_last = (M - 1u) / uint32_t(R);
@@ -321,6 +335,21 @@ struct Sweep16
             if (CHECK) lim[k] = (uint32_t(k) <= kl) ? 0x7FFFu : 0x8000u;
         }
         out_hg = out_f = out_ch = out_cm = 0;
+        feeder = false;
+        if (MULTI)
+        {
+            // the last lane of a segment that has a successor: it holds no rows (the host sizes R so that lane_last < seg_w - 1)
+            feeder = (lane == seg_w - 1u) && (seg_base + seg_w < 64u);
+            // A lane reads, at step s, what the lane above wrote at step s - 1 (the same column): the feeder stands for the row above the
+            // next job's matrix, i.e. one lane ahead of that job's first lane -- at step s it hands on the symbol of column s + 1
+            if (feeder)
+            {
+                out_hg = go; out_f = inf16; out_cm = 0x8000u;
+                out_ch = 0x0C0C0100u + 0x0202u * (ncols_feed ? get_symbol(p.txt.s, tb_feed) : 0u);
+                tb_feed += 1u;
+            }
+            if (!seg_valid) { Ncols = 0u; }            // lanes of a segment without a job never enter the matrix
+        }
         prev_in_hg = (lane == 0u) ? go : 0u;          // lane 0's first diagonal: the corner above the matrix, H(-1,-1) = 0
         sg_score = -(1 << 30); sg_col = 0; exit_col = 0xFFFFFFFFu; grp = 0; sg_hg16 = 0x8000u;
         top_hg = c16(p.row_go + Go); top_prev_hg = go;
@@ -364,6 +393,7 @@ struct Sweep16
         prev_in_hg = in_hg;
         if (TYPE == NVBIO_HIP_GLOBAL) { top_prev_hg = top_hg; uint32_t t; asm("v_add_u16 %0, %1, %2" : "=v"(t) : "v"(top_hg), "v"(rge)); top_hg = t; }
 
+        if (MULTI && feeder) { out_ch = ch0; return; }         // the next segment's row above the matrix: constants, and its job's text symbol
         const bool active = !PRED || (int32_t(c) >= 0 && c < Ncols && lane <= lane_last);
         if (active)
         {
@@ -422,24 +452,39 @@ struct Sweep16
         }
     }
 
+    __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) const
+    { for (int o = 32; o >= 1; o >>= 1) v = max(v, uint32_t(__shfl_xor(int32_t(v), o))); return uint32_t(__builtin_amdgcn_readfirstlane(int(v))); }
+    __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) const
+    { for (int o = 32; o >= 1; o >>= 1) v = min(v, uint32_t(__shfl_xor(int32_t(v), o))); return uint32_t(__builtin_amdgcn_readfirstlane(int(v))); }
+    /// the text group of 16 symbols starting at column s: the job's own (wave-uniform -> scalar) or, MULTI, per lane of the job the lane feeds
+    __device__ __forceinline__ uint32_t text_group(const uint32_t s) const
+    {
+        if (MULTI) return fetch16_2bit(p.txt.s, tb_feed + s);
+        return uint32_t(__builtin_amdgcn_readfirstlane(int(fetch16_2bit(p.txt.s, tb + s))));
+    }
+
     __device__ __forceinline__ SweepResult run()
     {
-        const uint32_t n_steps = Ncols + lane_last;
+        // MULTI: the wave runs to the longest job's last step; the unpredicated steady state covers the steps at which every job is inside it
+        const bool rows = !MULTI || (seg_valid && !feeder && Ncols > 0u);
+        const uint32_t n_steps = MULTI ? wave_max_u32(rows ? Ncols + lane_last : 0u) : Ncols + lane_last;
+        const uint32_t fetch_cols = MULTI ? wave_max_u32(ncols_feed) : Ncols;
         uint32_t s = 0;
         // ramp-up, up to the first 16-aligned step at which every row-holding lane is inside the matrix and past its first column
-        const uint32_t s_fast = (lane_last + 16u) & ~15u;         // (strictly past every lane's first column: step() tests for that column only while PRED)
-        // (a wave owns one job: the text group is wave-uniform, so the symbol -> selector arithmetic runs on the scalar unit)
+        const uint32_t s_fast = MULTI ? wave_max_u32(rows ? ((lane_last + 16u) & ~15u) : 0u) : ((lane_last + 16u) & ~15u);         // (strictly past every lane's first column: step() tests for that column only while PRED)
+        const uint32_t fast_end = MULTI ? wave_min_u32(rows ? Ncols : 0xFFFFFFFFu) : Ncols;
+        // (a wave that owns one job: the text group is wave-uniform, so the symbol -> selector arithmetic runs on the scalar unit)
         auto sel = [](const uint32_t g) { return 0x0C0C0100u + 0x0202u * g; };
         for (; s < n_steps && s < s_fast; ++s)
         {
-            if ((s & 15u) == 0u && s < Ncols) grp = uint32_t(__builtin_amdgcn_readfirstlane(int(fetch16_2bit(p.txt.s, tb + s))));
+            if ((s & 15u) == 0u && s < fetch_cols) grp = text_group(s);
             step<true>(s, sel((grp >> (2u * (s & 15u))) & 3u), s & 15u);
             if ((s & 15u) == 15u) fold(s - 15u);
         }
         // steady state: 16 unpredicated steps per text group (lanes past the last row compute harmlessly)
-        for (; s + 16u < Ncols; s += 16u)        // strict: the last column is always handled by the tail
+        for (; s + 16u < fast_end && s + 16u < n_steps; s += 16u)        // strict: the last column is always handled by the tail
         {
-            grp = uint32_t(__builtin_amdgcn_readfirstlane(int(fetch16_2bit(p.txt.s, tb + s))));
+            grp = text_group(s);
             #pragma unroll
             for (int u = 0; u < 16; ++u) step<false>(s + u, sel((grp >> (2 * u)) & 3u), uint32_t(u));
             fold(s);
@@ -447,14 +492,18 @@ struct Sweep16
         // tail and ramp-down
         for (; s < n_steps; ++s)
         {
-            if ((s & 15u) == 0u && s < Ncols) grp = uint32_t(__builtin_amdgcn_readfirstlane(int(fetch16_2bit(p.txt.s, tb + s))));
+            if ((s & 15u) == 0u && s < fetch_cols) grp = text_group(s);
             step<true>(s, sel((grp >> (2u * (s & 15u))) & 3u), s & 15u);
             if ((s & 15u) == 15u) fold(s - 15u);
         }
         if ((s & 15u) != 0u) fold(s & ~15u);
 
+        // lane holding a job's last row / partner lane of step `off` of an all-reduce over the job's lanes (MULTI: a rotation inside the
+        // segment -- max / min are idempotent, so windows of 1, 2, 4 ... lanes that wrap around cover any segment width)
+        const int last_lane = int(MULTI ? seg_base + lane_last : lane_last);
+        auto peer = [&](const int off) { return MULTI ? int(seg_base + (lane + uint32_t(off)) % seg_w) : int(wlane ^ uint32_t(off)); };
         SweepResult res;
-        res.exit_col = uint32_t(__shfl(int32_t(exit_col), int32_t(lane_last)));
+        res.exit_col = uint32_t(__shfl(int32_t(exit_col), last_lane));
         res.score = -(1 << 30); res.sx = res.sy = 0xFFFFFFFFu;
         res.pb_exit_row = 0xFFFFFFFFu;
         const uint32_t BS = p.blk_log2, BLK = 1u << BS, KM = BLK * 64u * uint32_t(R);
@@ -476,7 +525,7 @@ struct Sweep16
                 }
             }
             #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) first = min(first, uint32_t(__shfl_xor(int32_t(first), off)));
+            for (int off = 32; off >= 1; off >>= 1) first = min(first, uint32_t(__shfl(int32_t(first), peer(off))));
             res.pb_exit_row = first;
         }
         if (TYPE == NVBIO_HIP_LOCAL)
@@ -498,9 +547,10 @@ struct Sweep16
             #pragma unroll
             for (int off = 32; off >= 1; off >>= 1)
             {
-                const uint32_t olo = uint32_t(__shfl_xor(int32_t(uint32_t(b)), off));
-                const uint32_t ohi = uint32_t(__shfl_xor(int32_t(uint32_t(b >> 32)), off));
-                const uint32_t ohv = uint32_t(__shfl_xor(int32_t(hv), off));
+                const int pr = peer(off);
+                const uint32_t olo = uint32_t(__shfl(int32_t(uint32_t(b)), pr));
+                const uint32_t ohi = uint32_t(__shfl(int32_t(uint32_t(b >> 32)), pr));
+                const uint32_t ohv = uint32_t(__shfl(int32_t(hv), pr));
                 const uint64_t o = (uint64_t(ohi) << 32) | olo;
                 if (ohv && (!hv || o > b)) { b = o; hv = 1u; }
             }
@@ -514,8 +564,8 @@ struct Sweep16
         else
         {
             if (TYPE == NVBIO_HIP_SEMI_GLOBAL) sg_score = int32_t(int16_t(sg_hg16)) - Go;
-            const int32_t  sc  = __shfl(sg_score, int32_t(lane_last));
-            const uint32_t col = uint32_t(__shfl(int32_t(sg_col), int32_t(lane_last)));
+            const int32_t  sc  = __shfl(sg_score, last_lane);
+            const uint32_t col = uint32_t(__shfl(int32_t(sg_col), last_lane));
             const bool reported = (TYPE == NVBIO_HIP_SEMI_GLOBAL) ? (Ncols > 0u) : (Ncols == Nfull && Nfull > 0u);
             if (reported) { res.score = sc; res.sx = col + 1u; res.sy = M; }
         }
@@ -629,6 +679,131 @@ full_gotoh_score_kernel(const FullParams p)
         reinterpret_cast<uint2*>(p.out_sink)[job] = make_uint2(sx, sy);
         if (p.out_ok) p.out_ok[job] = uint8_t(ok);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Several jobs per wave (Sweep16<..., MULTI>): short patterns leave most lanes of a 64-lane systolic sweep idle (150 rows at R = 3:
+// 50 lanes; the four lane-to-lane moves of a step are paid for 3 cells), and their short texts make fill and drain a large share of the
+// steps.  Here the wave is cut into n_seg segments of seg_w lanes (2 x 32, 3 x 21, 4 x 16), each sweeping its own job with R = 5 or 6
+// rows per lane: 150-bp mates run two per wave on 30 + 30 lanes.  LOCAL and SEMI_GLOBAL on the 16-bit sweep.  A job whose early exit
+// fires needs a second sweep over a prefix of its rows / columns (as in full_gotoh_score_kernel): the wave then runs that job alone
+// on the single-job sweep, segment by segment, so every result is the one full_gotoh_score_kernel produces.
+// ---------------------------------------------------------------------------------------------
+template <int TYPE, int R>
+__global__ void __launch_bounds__(256)
+full_gotoh_score_multi_kernel(const FullParams p, const uint32_t n_seg, const uint32_t seg_w)
+{
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    const uint32_t wl   = threadIdx.x & 63u;
+    const uint32_t seg  = wl / seg_w, sl = wl - seg * seg_w;
+    const uint32_t job  = wave * n_seg + seg;
+    const bool has_job  = seg < n_seg && job < p.n;
+    // the job whose text symbols this lane hands on: lane 0 of the wave its own, a segment's last lane the next segment's
+    const uint32_t fseg = (wl + 1u) / seg_w, fjob = wave * n_seg + fseg;
+    const bool has_feed = fseg < n_seg && fjob < p.n;
+    if (wave * n_seg >= p.n) return;
+
+    const uint32_t M  = has_job ? (p.pat.length ? p.pat.length[job] : p.pat.fixed_length) : 0u;
+    const uint32_t N  = has_job ? (p.txt.length ? p.txt.length[job] : p.txt.fixed_length) : 0u;
+    const uint64_t pb = has_job ? p.pat.begin[job] : 0ull, tb = has_job ? p.txt.begin[job] : 0ull;
+    const uint32_t Nf = has_feed ? (p.txt.length ? p.txt.length[fjob] : p.txt.fixed_length) : 0u;
+    const uint64_t tf = has_feed ? p.txt.begin[fjob] : 0ull;
+    const bool     check = p.min_score != nullptr;
+    const int32_t  min_score = (check && has_job) ? p.min_score[job] : -(1 << 30);
+    const bool     PB = p.pattern_blocking != 0u;
+
+    int32_t score = -(1 << 30); uint32_t sx = 0xFFFFFFFFu, sy = 0xFFFFFFFFu; uint32_t ok = 1u;
+    // jobs the sweep does not take (see full_gotoh_score_kernel for each case): they sit out with an empty matrix
+    bool swept = has_job;
+    if (has_job)
+    {
+        if (M > p.max_m || N > p.max_n) { ok = 0u; swept = false; }
+        else if (M == 0u)
+        {
+            swept = false;
+            const uint32_t nb = 8u * ((N + 7u) / 8u);
+            const bool exits = check && nb > 8u && (-(1 << 30) + int32_t(N - 8u) * p.match < min_score);
+            if (exits) { ok = 0u; if (TYPE == NVBIO_HIP_SEMI_GLOBAL) { score = 0; sx = 8u; sy = 0u; } }
+            else if (N > 0u && TYPE == NVBIO_HIP_SEMI_GLOBAL) { score = 0; sx = N; sy = 0u; }
+        }
+        else if (PB && check && N == 0u)
+        {
+            swept = false;
+            const uint32_t BLK = 1u << p.blk_log2;
+            if ((M + BLK - 1u) / BLK > 1u) ok = 0u;
+        }
+    }
+    const bool sweeps = swept;
+    const uint32_t Ms = sweeps ? M : 1u, Ns = sweeps ? N : 0u;
+    // 0 = nothing more to do, 1 = sweep rows [0, arg] again (pattern blocking, LOCAL), 2 = sweep columns [0, arg] again (text blocking, LOCAL)
+    uint32_t redo = 0u, redo_arg = 0u;
+    if (PB && check)
+    {
+        Sweep16<TYPE, R, false, (TYPE != NVBIO_HIP_LOCAL), true> sw(p);
+        sw.init(pb, tb, Ms, Ns, Ns, min_score, seg_w, sweeps, tf, Nf);
+        sw.pb_check = true;
+        const SweepResult r = sw.run();
+        if (sweeps)
+        {
+            if (r.pb_exit_row != 0xFFFFFFFFu) { ok = 0u; if (TYPE == NVBIO_HIP_LOCAL) { redo = 1u; redo_arg = r.pb_exit_row + 1u; } }
+            else { score = r.score; sx = r.sx; sy = r.sy; }
+        }
+    }
+    else
+    {
+        SweepResult r;
+        if (check) { Sweep16<TYPE, R, true,  false, true> sw(p); sw.init(pb, tb, Ms, Ns, Ns, min_score, seg_w, sweeps, tf, Nf); r = sw.run(); }
+        else       { Sweep16<TYPE, R, false, false, true> sw(p); sw.init(pb, tb, Ms, Ns, Ns, min_score, seg_w, sweeps, tf, Nf); r = sw.run(); }
+        if (sweeps)
+        {
+            if (r.exit_col != 0xFFFFFFFFu)
+            {
+                ok = 0u;
+                // LOCAL: the best cell of the whole matrix, if it lies at or before the exit column, is also the best of the columns the
+                // reference visited; only otherwise sweep the truncated text again.  SEMI_GLOBAL: the record froze at the exit column.
+                if (TYPE == NVBIO_HIP_LOCAL && !(r.sx != 0xFFFFFFFFu && r.sx - 1u <= r.exit_col)) { redo = 2u; redo_arg = r.exit_col + 1u; }
+                else { score = r.score; sx = r.sx; sy = r.sy; }
+            }
+            else { score = r.score; sx = r.sx; sy = r.sy; }
+        }
+    }
+    // second sweeps, one job at a time on the whole wave (rare: a job whose early exit fired with its best cell beyond the exit)
+    if (TYPE == NVBIO_HIP_LOCAL)
+    {
+        for (uint32_t g = 0; g < n_seg; ++g)
+        {
+            const int src = int(g * seg_w);                                   // the segment's first lane holds its job's values
+            const uint32_t rd = uint32_t(__shfl(int32_t(redo), src));
+            if (rd == 0u) continue;                                            // wave-uniform
+            const uint32_t arg = uint32_t(__shfl(int32_t(redo_arg), src));
+            const uint32_t gM = uint32_t(__shfl(int32_t(M), src)), gN = uint32_t(__shfl(int32_t(N), src));
+            const uint64_t gpb = (uint64_t(uint32_t(__shfl(int32_t(uint32_t(pb >> 32)), src))) << 32) | uint32_t(__shfl(int32_t(uint32_t(pb)), src));
+            const uint64_t gtb = (uint64_t(uint32_t(__shfl(int32_t(uint32_t(tb >> 32)), src))) << 32) | uint32_t(__shfl(int32_t(uint32_t(tb)), src));
+            const int32_t  gms = __shfl(min_score, src);
+            const SweepResult r2 = (rd == 1u) ? sweep16<TYPE, R, false>(p, gpb, gtb, arg, gN, gN, gms) : sweep16<TYPE, R, false>(p, gpb, gtb, gM, arg, gN, gms);
+            if (seg == g) { score = r2.score; sx = r2.sx; sy = r2.sy; }
+        }
+    }
+    if (has_job && sl == 0u)
+    {
+        p.out_score[job] = score;
+        reinterpret_cast<uint2*>(p.out_sink)[job] = make_uint2(sx, sy);
+        if (p.out_ok) p.out_ok[job] = uint8_t(ok);
+    }
+}
+
+template <int R>
+static hipError_t launch_full_multi(const FullParams& p, int type, uint32_t n_seg, hipStream_t s)
+{
+    const uint32_t seg_w = 64u / n_seg;
+    const uint64_t waves = (uint64_t(p.n) + n_seg - 1u) / n_seg;
+    const dim3 grid(uint32_t((waves * 64u + 255u) / 256u)), block(256);
+    switch (type) {
+    case NVBIO_HIP_LOCAL:       hipLaunchKernelGGL((full_gotoh_score_multi_kernel<NVBIO_HIP_LOCAL, R>),       grid, block, 0, s, p, n_seg, seg_w); break;
+    case NVBIO_HIP_SEMI_GLOBAL: hipLaunchKernelGGL((full_gotoh_score_multi_kernel<NVBIO_HIP_SEMI_GLOBAL, R>), grid, block, 0, s, p, n_seg, seg_w); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 template <int R, bool TRUNC, bool FAST>
@@ -837,6 +1012,28 @@ static int full_score_core(
             if (words <= 3u) return launch_ed<3>(p, type, s);
             if (words <= 4u) return launch_ed<4>(p, type, s);
             return launch_ed<8>(p, type, s);
+        }
+    }
+    if (fast && type != NVBIO_HIP_GLOBAL)
+    {
+        // several jobs per wave when that keeps more lanes busy: n_seg segments of 64 / n_seg lanes, the last lane of each feeding the
+        // next, R = 5 or 6 rows per lane.  Estimated cell throughput: busy lanes x (cell work) / (cell work + per-step overhead).
+        const char* nomulti = getenv("NVBIO_HIP_FULL_SINGLE_JOB");
+        auto eff = [](const double lanes, const double rows, const double overhead) { return lanes / 64.0 * (28.0 * rows) / (28.0 * rows + overhead); };
+        double best = eff(double((maxM + R - 1) / R), double(R), 24.0);
+        uint32_t best_seg = 1u, best_r = 0u;
+        for (uint32_t ns = 2u; ns <= 4u; ++ns)
+            for (uint32_t r = 5u; r <= 6u; ++r)
+            {
+                const uint32_t usable = 64u / ns - 1u;
+                if (uint64_t(usable) * r < maxM) continue;
+                const double e = eff(double(ns * ((maxM + r - 1u) / r)), double(r), 36.0);
+                if (e > best * 1.05) { best = e; best_seg = ns; best_r = r; }
+            }
+        if (best_seg > 1u && !(nomulti && nomulti[0] == '1') && uint64_t(maxN) * 64u * 8u < (1ull << 32))
+        {
+            g_last_kernel = "full_gotoh_score_multi_kernel<16-bit>";
+            return best_r == 5u ? launch_full_multi<5>(p, type, best_seg, s) : launch_full_multi<6>(p, type, best_seg, s);
         }
     }
     if (fast) {

@@ -198,3 +198,41 @@ def test_quality_aware_scheme_full_matrix(cuda, ty, algo):
             bad = np.nonzero((es != gs) | (ek != gk).any(1) | (eo != go))[0]
             assert bad.size == 0, (ty, algo, st.match, min_score is not None, bad[:5], len(pats[bad[0]]), len(txts[bad[0]]),
                                    (es[bad[0]], ek[bad[0]], eo[bad[0]]), (gs[bad[0]], gk[bad[0]], go[bad[0]]))
+
+
+@pytest.mark.parametrize("ty", [nvb.LOCAL, nvb.SEMI_GLOBAL])
+@pytest.mark.parametrize("max_m,max_n", [(150, 520), (100, 300), (75, 200), (170, 400), (40, 90)])
+def test_several_jobs_per_wave(cuda, ty, max_m, max_n, monkeypatch):
+    """Short patterns run two to four jobs per wave (full_gotoh_score_multi_kernel: segments of 32 / 21 / 16 lanes, the last lane of a
+    segment feeding the next).  Ragged M and N inside one wave, job counts that do not fill the last wave, empty patterns / texts,
+    tie-heavy texts, min_score early exits of both blocking orders (the second sweep of an exited job), qualities: the multi-job
+    kernel, the single-job kernel (NVBIO_HIP_FULL_SINGLE_JOB=1) and the oracle must agree bit for bit."""
+    rng = np.random.default_rng(77 + ty * 1000 + max_m)
+    for n in (1, 2, 3, 5, 1501):
+        pats, txts = make_pairs(rng, n, max_m, max_n)
+        hp, ht = O.StringSet.from_lists(pats, 4, True), O.StringSet.from_lists(txts, 2, False)
+        p = nvb.PackedStringSet.from_host(hp.words, 4, True, hp.begin, hp.length, device=cuda)
+        t = nvb.PackedStringSet.from_host(ht.words, 2, False, ht.begin, ht.length, device=cuda)
+        ms_host = np.where(rng.random(n) < 0.4, -(1 << 30), rng.integers(-30, 120, n)).astype(np.int32)
+        for scheme in ((2, -1, -2, -1), (1, -3, -5, -2)):
+            for algo, min_score in ((nvb.TEXT_BLOCKING, None), (nvb.TEXT_BLOCKING, ms_host), (nvb.PATTERN_BLOCKING, None), (nvb.PATTERN_BLOCKING, ms_host)):
+                if algo == nvb.TEXT_BLOCKING:
+                    es, ek, eo = O.batch_gotoh_score(ty, scheme, hp, ht, min_score=min_score)
+                else:
+                    live = hp.length > 0                                     # (the reference reads uninitialised cells for M == 0 under pattern blocking)
+                    es, ek, eo = O.batch_score_pattern_blocking(0, ty, scheme, hp, ht, min_score=min_score)
+                ms = torch.from_numpy(min_score).to(cuda) if min_score is not None else None
+                kernels = []
+                for single in ("0", "1"):
+                    monkeypatch.setenv("NVBIO_HIP_FULL_SINGLE_JOB", single)
+                    al = nvb.make_gotoh_aligner(ty, nvb.SimpleGotohScheme(*scheme), algo)
+                    gs, gk, go = nvb.batch_alignment_score(al, p, t, max_m, max_n, ms)
+                    torch.cuda.synchronize()
+                    kernels.append(nvb.lib().nvbio_hip_last_kernel().decode())
+                    gs, gk, go = gs.cpu().numpy(), gk.cpu().numpy().view(np.uint32), go.cpu().numpy()
+                    sel = np.ones(n, bool) if algo == nvb.TEXT_BLOCKING else live
+                    bad = np.nonzero(((es != gs) | (ek != gk).any(1) | (eo != go)) & sel)[0]
+                    assert bad.size == 0, "type %d scheme %s algo %d single=%s n=%d: %d mismatches; first %d: M=%d N=%d cpu (%d,%s,%d) gpu (%d,%s,%d)" % (
+                        ty, scheme, algo, single, n, bad.size, bad[0], len(pats[bad[0]]), len(txts[bad[0]]), es[bad[0]], ek[bad[0]], eo[bad[0]], gs[bad[0]], gk[bad[0]], go[bad[0]])
+                assert "multi" in kernels[0] and "multi" not in kernels[1], kernels
+    monkeypatch.delenv("NVBIO_HIP_FULL_SINGLE_JOB", raising=False)

@@ -1,3 +1,5 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, nvbio_amd as nvb
 from nvbio_amd import workloads as W
 dev = "cuda"
