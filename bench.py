@@ -163,21 +163,49 @@ def main():
     gatherers = [ResultGather(n * world, dst=0, device=dev, record_bytes=4) for _ in range(2)] if world > 1 else None
 
     pending = [None, None]
-    # pre-flight of the gather on tiny buffers: if the backend cannot do it, every rank learns so here, agrees, and the
-    # run continues with the results left on their GPUs (reported as "gather": false) instead of dying mid-measurement
-    gather_on = world > 1
+    # The gather of the result records.  First choice: the C++ path -- RCCL ncclSend / ncclRecv issued through the C-ABI
+    # (nvbio_hip_gather_records; include/nvbio_hip/multi_device.h), its communicator opened from a unique id that torch.distributed
+    # only ships.  Second choice: torch.distributed.gather.  Every rank tries on tiny buffers first and all agree on the outcome, so a
+    # backend that cannot do it is found here -- the run then continues ("gather_path" says how) instead of dying mid-measurement.
+    gather_on, gather_path, cxx_comm, cxx_g = world > 1, None, None, None
     if world > 1:
+        from nvbio_amd.distributed import CxxComm, CxxRecordGather, pack_result_records
+        on_nccl = dist.get_backend() == "nccl"
+
+        def agree(flag):
+            ft = torch.tensor([flag], dtype=torch.int32, device=dev if on_nccl else "cpu")
+            dist.all_reduce(ft, op=dist.ReduceOp.MIN)
+            return bool(int(ft.item()))
+
         flag = 1
         try:
-            probe = ResultGather(world * 4, dst=0, device=dev, record_bytes=4)
-            probe.gather(torch.zeros(4, dtype=torch.int32, device=dev), torch.zeros((4, 2), dtype=torch.int32, device=dev), concat=False)
+            if not on_nccl or os.environ.get("NVBIO_BENCH_TORCH_GATHER") == "1":
+                raise RuntimeError("C++ gather needs one device per rank")
+            cxx_comm = CxxComm()
+            pg = CxxRecordGather(cxx_comm, world * 4, 1, dst=0, device=dev)
+            pg.gather(torch.full((4, 1), rank, dtype=torch.int32, device=dev))
             torch.cuda.synchronize()
+            if rank == 0 and not all(bool((pg.shard(r) == r).all()) for r in range(world)):
+                raise RuntimeError("C++ gather returned wrong records")
         except Exception as e:     # noqa: BLE001
-            sys.stderr.write("bench: result gather unavailable (%s); continuing without it\n" % e)
+            sys.stderr.write("bench: C++ / RCCL gather unavailable on rank %d (%s); trying torch.distributed\n" % (rank, e))
             flag = 0
-        ft = torch.tensor([flag], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(ft, op=dist.ReduceOp.MIN)
-        gather_on = bool(int(ft.item()))
+        if agree(flag):
+            gather_path = "cxx_rccl (nvbio_hip_gather_records: grouped ncclSend/ncclRecv from C++)"
+            cxx_g = [CxxRecordGather(cxx_comm, n * world, 1, dst=0, device=dev) for _ in range(2)]
+        else:
+            cxx_comm = None
+            flag = 1
+            try:
+                probe = ResultGather(world * 4, dst=0, device=dev, record_bytes=4)
+                probe.gather(torch.zeros(4, dtype=torch.int32, device=dev), torch.zeros((4, 2), dtype=torch.int32, device=dev), concat=False)
+                torch.cuda.synchronize()
+            except Exception as e:     # noqa: BLE001
+                sys.stderr.write("bench: result gather unavailable (%s); continuing without it\n" % e)
+                flag = 0
+            gather_on = agree(flag)
+            gather_path = "torch.distributed.gather" if gather_on else None
+    overflow = [None, None]
 
     def step(i, events=None):
         b = i & 1
@@ -191,7 +219,11 @@ def main():
         if gather_on:
             comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(comm_stream):
-                gatherers[b].gather(outs[b][0], outs[b][1], concat=False)   # 4 B/read to rank 0 over RCCL/xGMI
+                if cxx_g is not None:
+                    rec, overflow[b] = pack_result_records(outs[b][0], outs[b][1], 4)
+                    cxx_g[b].gather(rec, concat=False)                      # 4 B/read to rank 0 over RCCL/xGMI, issued from C++
+                else:
+                    gatherers[b].gather(outs[b][0], outs[b][1], concat=False)   # ... or through torch.distributed
                 pending[b] = torch.cuda.Event()
                 pending[b].record(comm_stream)
 
@@ -241,7 +273,10 @@ def main():
         del os.environ["NVBIO_HIP_FORCE_32BIT"]
         a32_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev32) / len(ev32)
         a32_same = bool(torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][1], outs[0][1]))
-    if gather_on and rank == 0 and any(g.overflowed() for g in gatherers):
+    if gather_on and cxx_g is not None:
+        if any(o is not None and bool(o.item()) for o in overflow):
+            raise SystemExit("result gather: records did not fit the 4-byte format")
+    elif gather_on and rank == 0 and any(g.overflowed() for g in gatherers):
         raise SystemExit("result gather: records did not fit the 4-byte format")
 
     out = None
@@ -279,7 +314,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16", "data": "synthetic",
             "config": {"workload": "nvbio::aln batched banded SW (configs[1]): %d x 100 bp reads vs 150 bp windows per GPU, band=15, LOCAL Gotoh (2,-1,-2,-1)" % n,
-                       "reads_per_gpu": n, "read_len": READ_LEN, "band": BAND, "type": "LOCAL", "parallelism": "read-shard x%d, gather to rank 0" % world, "gather": bool(gather_on) if world > 1 else None},
+                       "reads_per_gpu": n, "read_len": READ_LEN, "band": BAND, "type": "LOCAL", "parallelism": "read-shard x%d, gather to rank 0" % world, "gather": bool(gather_on) if world > 1 else None, "gather_path": gather_path},
             "roofline": roofline, "parity": parity,
         }
 
@@ -296,7 +331,7 @@ def main():
     if world > 1 and not a.no_e2e:
         del patterns, texts, outs
         torch.cuda.empty_cache()
-        leg = e2e_sharded_leg(a, dev, rank, world, barrier)
+        leg = e2e_sharded_leg(a, dev, rank, world, barrier, cxx_comm)
         if rank == 0:
             out["e2e_sharded_leg"] = leg
     if rank == 0:
@@ -305,13 +340,13 @@ def main():
         dist.destroy_process_group()
 
 
-def e2e_sharded_leg(a, dev, rank, world, barrier):
+def e2e_sharded_leg(a, dev, rank, world, barrier, cxx_comm=None):
     """nvBowtie's single-end driver (nvbio_amd.aligner.best_approx) with the read batch sharded across the ranks: every GPU holds the
     whole index (built from the same seed) and aligns its own e2e_reads reads; no collective inside the pipeline.  Timed like the
     headline: barrier + synchronize on both sides, maximum over ranks.  Ranks first agree that set-up and a warm-up run succeeded
     everywhere, so that a local failure cannot leave the others waiting in the timed region."""
     from nvbio_amd import aligner as AL, select as SEL, pipeline as P
-    from nvbio_amd.distributed import RecordGather, alignment_records
+    from nvbio_amd.distributed import RecordGather, CxxRecordGather, alignment_records
     cpu = dist.get_backend() != "nccl"
     state, err = {}, ""
     try:
@@ -326,7 +361,8 @@ def e2e_sharded_leg(a, dev, rank, world, barrier):
         packed = P.pack_read_streams(sym)
         names = SEL.pack_names(["r%d.%d" % (rank, i) for i in range(n)], dev)
         prm = AL.Params(hits_stride=16, batch_size=n)
-        gat = RecordGather(n * world, 4, dst=0, device=dev)       # 16 B per read to rank 0: alignment word, position, MAPQ, read id
+        # 16 B per read to rank 0: alignment word, position, MAPQ, read id -- from C++ over RCCL when the pre-flight found it
+        gat = CxxRecordGather(cxx_comm, n * world, 4, dst=0, device=dev) if cxx_comm is not None else RecordGather(n * world, 4, dst=0, device=dev)
         def run():
             r = AL.best_approx(fmi, None, sym, genome_words, ng, prm, names=names, packed=packed)
             r["table"] = gat.gather(alignment_records(r["best"][0], r["mapq"], rank * n), concat=False)
@@ -357,10 +393,11 @@ def e2e_sharded_leg(a, dev, rank, world, barrier):
         # the read ids of the other shards must be theirs
         gat = state["gat"]
         own = alignment_records(r["best"][0], r["mapq"], 0)
-        gathered_ok = bool(torch.equal(gat.bufs[0][:n], own)) and all(
-            bool((gat.bufs[k][:n, 3] == torch.arange(k * n, (k + 1) * n, device=dev, dtype=torch.int64).to(torch.int32)).all()) for k in range(1, world))
+        part = (lambda k: gat.shard(k)) if cxx_comm is not None else (lambda k: gat.bufs[k][:n])
+        gathered_ok = bool(torch.equal(part(0), own)) and all(
+            bool((part(k)[:, 3] == torch.arange(k * n, (k + 1) * n, device=dev, dtype=torch.int64).to(torch.int32)).all()) for k in range(1, world))
     return {"driver": "nvbio_amd.aligner.best_approx (Aligner::best_approx: seeding passes, randomized selection, band-31 extension, reduce, MAPQ, traceback)",
-            "index": "line_native (two-symbol index attached)", "gather": True, "gather_record_bytes": 16, "gathered_records_verified": gathered_ok,
+            "index": "line_native (two-symbol index attached)", "gather": True, "gather_path": "cxx_rccl" if cxx_comm is not None else "torch.distributed.gather", "gather_record_bytes": 16, "gathered_records_verified": gathered_ok,
             "genome_symbols": state["ng"], "reads_per_gpu": n, "n_gpus": world, "ms_per_batch": el * 1e3, "Mreads_per_s": n * world / el / 1e6,
             "aligned": float(frac[0].item()) / world, "best_at_true_position": float(frac[1].item()) / world,
             "sharding": "reads block-sharded, index replicated, no collective inside the pipeline; one gather of 16-byte alignment records to rank 0 per batch, inside the timed region"}

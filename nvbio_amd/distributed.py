@@ -74,6 +74,89 @@ class RecordGather:
         return torch.cat([self.bufs[r][: self.sizes[r]] for r in range(self.world)], dim=0)
 
 
+def pack_result_records(score, sink, record_bytes):
+    """(score[n], sink[n,2]) -- BestSink<int32> -- as int32 records of 12 / 8 / 4 bytes (see ResultGather) plus a device flag that is
+    non-zero when some record does not fit the compact format."""
+    sink = sink.view(-1, 2)
+    n = score.numel()
+    untouched = (sink[:, 0] == -1) & (sink[:, 1] == -1)
+    status = None
+    rec = torch.empty((n, record_bytes // 4), dtype=torch.int32, device=score.device)
+    if record_bytes == 4:
+        fits = untouched | ((sink[:, 0] >= 0) & (sink[:, 0] < 0xFF) & (sink[:, 1] >= 0) & (sink[:, 1] < 0xFF) & (score > -32768) & (score < 32768))
+        status = (~fits).any().to(torch.int32)
+        s16 = torch.clamp(score, min=-32768)          # only the untouched-sink score lies below
+        rec[:, 0] = (s16 << 16) | ((sink[:, 0] & 0xFF) << 8) | (sink[:, 1] & 0xFF)
+    elif record_bytes == 8:
+        fits = untouched | ((sink[:, 0] >= 0) & (sink[:, 0] < 0xFFFF) & (sink[:, 1] >= 0) & (sink[:, 1] < 0xFFFF))
+        status = (~fits).any().to(torch.int32)
+        rec[:, 0] = score
+        rec[:, 1] = (sink[:, 0] << 16) | (sink[:, 1] & 0xFFFF)
+    else:
+        rec[:, 0] = score
+        rec[:, 1:] = sink
+    return rec, status
+
+
+class CxxComm:
+    """The C++ / RCCL side of a launcher-driven run (include/nvbio_hip/multi_device.h: DeviceGroup::from_unique_id): rank 0 makes the
+    RCCL unique id through the C-ABI, torch.distributed ships its 128 bytes, every rank opens its communicator on its own device.
+    After this torch.distributed takes no part in the data path."""
+
+    def __init__(self, group=None):
+        import ctypes as C
+        from ._lib import lib, check
+        self.L, self.C = lib(), C
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if not self.L.nvbio_hip_comm_available():
+            raise RuntimeError("RCCL could not be bound (librccl.so.1)")
+        ident = (C.c_uint8 * 128)()
+        if self.rank == 0:
+            check(self.L.nvbio_hip_comm_unique_id(ident), "nvbio_hip_comm_unique_id")
+        box = [bytes(ident)]
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+        self.comm = C.c_void_p()
+        check(self.L.nvbio_hip_comm_init_rank(C.byref(self.comm), self.world, self.rank, ident), "nvbio_hip_comm_init_rank")
+
+    def close(self):
+        if self.comm:
+            self.L.nvbio_hip_comm_destroy(self.comm)
+            self.comm = None
+
+
+class CxxRecordGather:
+    """RecordGather's interface over nvbio_hip_gather_records (grouped ncclSend / ncclRecv issued from C++ on the caller's current HIP
+    stream): int32 records [n_r, width] from every rank to `dst`, in rank order, into ONE contiguous [n_total, width] table on the root."""
+
+    def __init__(self, comm, n_total, width, dst=0, device=None):
+        import ctypes as C
+        self.comm, self.dst, self.width = comm, dst, int(width)
+        self.rank, self.world = comm.rank, comm.world
+        self.sizes = shard_sizes(n_total, self.world)
+        self.n_total = n_total
+        self.counts = (C.c_uint64 * self.world)(*self.sizes)
+        self.table = torch.empty((n_total, self.width), dtype=torch.int32, device=device) if self.rank == dst else None
+        self.offsets = [sum(self.sizes[:r]) for r in range(self.world)]
+
+    def gather(self, records, concat=True, status=None):
+        from ._lib import check, current_stream_ptr
+        import ctypes as C
+        assert records.shape[0] == self.sizes[self.rank] and records.shape[1] == self.width and records.dtype == torch.int32 and records.is_contiguous()
+        recv = C.c_void_p(self.table.data_ptr()) if self.table is not None else None
+        check(self.comm.L.nvbio_hip_gather_records(self.comm.comm, C.c_void_p(records.data_ptr()), self.counts, self.width * 4, recv, self.dst, current_stream_ptr()),
+              "nvbio_hip_gather_records")
+        if self.rank != self.dst:
+            return None
+        return self.table if concat else True
+
+    def shard(self, r):
+        """the root's view of rank r's records"""
+        return self.table[self.offsets[r]: self.offsets[r] + self.sizes[r]]
+
+
 class ResultGather(RecordGather):
     """Gathers per-rank (score[n_r], sink[n_r,2]) records -- BestSink<int32> -- to `dst` in rank order.
 
@@ -105,22 +188,8 @@ class ResultGather(RecordGather):
         assert n == self.sizes[self.rank]
         if self.world == 1:
             return score, sink
-        sink = sink.view(-1, 2)
-        untouched = (sink[:, 0] == -1) & (sink[:, 1] == -1)
-        status = None
-        if self.record_bytes == 4:
-            fits = untouched | ((sink[:, 0] >= 0) & (sink[:, 0] < 0xFF) & (sink[:, 1] >= 0) & (sink[:, 1] < 0xFF) & (score > -32768) & (score < 32768))
-            status = (~fits).any().to(torch.int32)
-            s16 = torch.clamp(score, min=-32768)          # only the untouched-sink score lies below
-            self.send[:n, 0] = (s16 << 16) | ((sink[:, 0] & 0xFF) << 8) | (sink[:, 1] & 0xFF)
-        elif self.record_bytes == 8:
-            fits = untouched | ((sink[:, 0] >= 0) & (sink[:, 0] < 0xFFFF) & (sink[:, 1] >= 0) & (sink[:, 1] < 0xFFFF))
-            status = (~fits).any().to(torch.int32)
-            self.send[:n, 0] = score
-            self.send[:n, 1] = (sink[:, 0] << 16) | (sink[:, 1] & 0xFFFF)
-        else:
-            self.send[:n, 0] = score
-            self.send[:n, 1:] = sink
+        rec, status = pack_result_records(score, sink, self.record_bytes)
+        self.send[:n] = rec
         self.send[self.pad, 0] = 0 if status is None else status          # always written: no stale word from an earlier call
         self._exchange()
         if self.rank != self.dst:

@@ -500,3 +500,43 @@ int nvbio_aligner_all(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmindex* rfm
         return 0;
     } catch (const std::exception& e) { fprintf(stderr, "aligner_shim: %s\n", e.what()); return 1; }
 }
+
+// include/nvbio_hip/multi_device.h: n_devices host threads, one per device (the reference's multi-GPU shape, nvBowtie.cpp:809-864), each
+// owning a contiguous block of n_total records of record_words int32 words, gathered to rank 0 over RCCL.  Record i holds {i, rank, i ^ 0x5A5A, ...}.
+// Returns 0 when the root's table is complete and in order; 10 + k on a mismatch at rank k's block.
+#include <nvbio_hip/multi_device.h>
+extern "C" __attribute__((visibility("default")))
+int nvbio_multi_device_selftest(uint32_t n_devices, uint64_t n_total, uint32_t record_words)
+{
+    try {
+        hip::DeviceGroup group;
+        hip::DeviceGroup::local(group, n_devices);
+        const uint32_t world = uint32_t(group.size());
+        const std::vector<uint64> counts = hip::shard_sizes(n_total, world);
+        std::vector<uint32_t> table(size_t(n_total) * record_words, 0u);
+        group.run([&](const hip::DeviceGroup::Rank& r)
+        {
+            const std::pair<uint64, uint64> mine = hip::shard_range(n_total, r.rank, r.world);
+            std::vector<uint32_t> h(size_t(mine.second - mine.first) * record_words);
+            for (uint64 i = mine.first; i < mine.second; ++i)
+                for (uint32_t w = 0; w < record_words; ++w) h[size_t(i - mine.first) * record_words + w] = w == 0 ? uint32_t(i) : w == 1 ? r.rank : uint32_t(i) ^ (0x5A5Au * w);
+            void* stream = nullptr;
+            hip_check(nvbio_hip_stream_create(&stream, 1u), "nvbio_hip_stream_create");
+            hip::device_vector<uint32_t> send(h.size() ? h.size() : 1), recv(r.rank == 0 ? table.size() : 1);
+            if (!h.empty()) hip_check(nvbio_hip_memcpy(send.data(), h.data(), h.size() * 4u, 1, stream), "h2d");
+            r.gather_records(send.data(), counts, record_words * 4u, r.rank == 0 ? recv.data() : nullptr, 0u, stream);
+            hip::synchronize(stream);
+            if (r.rank == 0 && !table.empty()) hip_check(nvbio_hip_memcpy(table.data(), recv.data(), table.size() * 4u, 2, stream), "d2h");
+            hip::synchronize(stream);
+            nvbio_hip_stream_destroy(stream);
+        });
+        for (uint32_t k = 0; k < world; ++k)
+        {
+            const std::pair<uint64, uint64> blk = hip::shard_range(n_total, k, world);
+            for (uint64 i = blk.first; i < blk.second; ++i)
+                for (uint32_t w = 0; w < record_words; ++w)
+                    if (table[size_t(i) * record_words + w] != (w == 0 ? uint32_t(i) : w == 1 ? k : uint32_t(i) ^ (0x5A5Au * w))) return 10 + int(k);
+        }
+        return 0;
+    } catch (const std::exception& e) { fprintf(stderr, "nvbio_multi_device_selftest: %s\n", e.what()); return 1; }
+}
