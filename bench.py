@@ -325,6 +325,7 @@ def main():
         out.update(fm_legs(a, dev))
     if rank == 0 and world == 1 and not a.no_full:
         out["full_dp_leg"] = full_dp_leg(a, dev)
+        out["compat_stream_leg"] = compat_stream_leg(a, dev)
     if rank == 0 and world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_leg(a, *W.make_sw_batch(min(n, a.cpu_sample), READ_LEN, REF_LEN, seed=0x5EED0002, device=dev))
     # ---------------------------------------------------------------- nvBowtie end to end, sharded (N > 1): BASELINE config 4's "1 vs 8 GPU shard"
@@ -1121,6 +1122,93 @@ def full_dp_leg(a, dev):
     res["edit_distance_semi_global"] = {"kernel": "edit_distance_bitvector_kernel", "kernel_ms": ms, "GCUPS": n * L * N / (ms * 1e-3) / 1e9,
                                         "Mreads_per_s": n / (ms * 1e-3) / 1e6, "parity_checked": m, "bit_exact": ok}
     return res
+
+
+def compat_stream_leg(a, dev):
+    """What the source-level drop-in route costs: ONE nvBowtie-shaped score stream -- tests/compat/nvbowtie_streams.hip,
+    written to the shape of alignment_utils.h:170-340 + score_best_inl.h:54-148 + scoring.h:206-356: reads stored reversed and viewed through
+    io::ReadLoader, quality strings, the quality-aware scheme, band 15, LOCAL -- enacted through BatchedBandedAlignmentScore on the tuned
+    (staged) route and forced down the generic one-lane-per-job template.  Same hits, same outputs (compared), a sample against the oracle."""
+    import ctypes as C
+    import numpy as np
+    from nvbio_amd import pipeline as P
+    from oracle import pyoracle as O
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    path = os.path.join(ROOT, "tests", "compat", "libnvbowtie_streams.so")
+    if not os.path.exists(path):
+        return {"error": "tests/compat/libnvbowtie_streams.so is missing (python __graft_entry__.py builds it)"}
+    from test_compat_nvbowtie_streams import Args, SCHEMES, scheme_tables
+    lib = C.CDLL(path)
+    lib.bt2_banded_score.argtypes = [C.POINTER(Args), C.c_char_p]
+    lib.bt2_banded_score_generic.argtypes = [C.POINTER(Args)]
+    n, L, band, ng = min(a.reads, 10_000_000), READ_LEN, 15, 1 << 28
+    g = torch.Generator(device=dev); g.manual_seed(0x5EED0011)
+    text = torch.randint(0, 4, (ng,), dtype=torch.uint8, generator=g, device=dev)
+    sym, pos, is_rc = P.make_reads(text, n, L, seed=0x5EED0012)
+    genome_words = W._pack_chunked(text, 2, True)
+    rev_words = W._pack_chunked(sym.flip(1).reshape(-1), 4, True)                     # nvBowtie stores reads reversed
+    quals = torch.randint(0, 60, (n * L + 8,), dtype=torch.uint8, generator=g, device=dev)
+    index = (torch.arange(n + 1, dtype=torch.int64, device=dev) * L).to(torch.int32)
+    hits = torch.stack([torch.arange(n, dtype=torch.int64, device=dev), pos, is_rc.to(torch.int64)], dim=1).to(torch.int32).contiguous()
+    idx_queue = torch.arange(n, dtype=torch.int32, device=dev)
+    second = torch.full((n,), -40, dtype=torch.int32, device=dev)
+    out = {k: torch.zeros(n if k != "raw_sink" else (n, 2), dtype=torch.int32, device=dev) for k in ("hit_score", "hit_sink", "raw_score", "raw_sink")}
+    args = Args()
+    (args.rdg_c, args.rdg_k, args.rfg_c, args.rfg_k, args.match, args.mmp_min, args.mmp_max, args.local) = SCHEMES["local"]
+    args.band_len = band
+    args.read_words, args.read_quals, args.read_index, args.longest = rev_words.data_ptr(), quals.data_ptr(), index.data_ptr(), L
+    args.mate_words, args.mate_quals, args.mate_index, args.mate_longest = rev_words.data_ptr(), quals.data_ptr(), index.data_ptr(), L
+    args.genome_words, args.genome_length = genome_words.data_ptr(), ng
+    args.idx_queue, args.hits, args.n_hits = idx_queue.data_ptr(), hits.data_ptr(), n
+    args.second_best, args.score_limit = second.data_ptr(), -40
+    for k, t in out.items():
+        setattr(args, k, t.data_ptr())
+    pathbuf = C.create_string_buffer(16)
+
+    def timed(fn, reps=3):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    def tuned():
+        if lib.bt2_banded_score(C.byref(args), pathbuf) != 0:
+            raise SystemExit("compat stream leg: bt2_banded_score failed")
+
+    def generic():
+        if lib.bt2_banded_score_generic(C.byref(args)) != 0:
+            raise SystemExit("compat stream leg: bt2_banded_score_generic failed")
+
+    ms_t = timed(tuned)
+    ts, tk = out["raw_score"].clone(), out["raw_sink"].clone()
+    out["raw_score"].zero_(); out["raw_sink"].zero_()
+    ms_g = timed(generic, reps=1)
+    same = bool(torch.equal(ts, out["raw_score"]) and torch.equal(tk, out["raw_sink"]))
+    # a sample against the oracle
+    m = 20000
+    lut, s5, ty = scheme_tables(SCHEMES["local"])
+    comp = np.array([3, 2, 1, 0, 4], np.uint8)
+    hs, hq = sym[:m].cpu().numpy(), quals[: m * L].cpu().numpy().reshape(m, L)[:, ::-1]        # forward reads, forward qualities
+    rc = is_rc[:m].cpu().numpy()
+    pats = [comp[hs[i]][::-1] if rc[i] else hs[i] for i in range(m)]
+    qs = [hq[i][::-1] if rc[i] else hq[i] for i in range(m)]
+    ps = O.StringSet.from_lists(pats, 4, True)
+    qbuf = np.concatenate(qs + [np.zeros(8, np.uint8)])
+    hp = pos[:m].cpu().numpy()
+    gb = np.where(hp > band // 2, hp - band // 2, 0)
+    tset = O.StringSet(genome_words[: (int(gb.max()) + L + band) // 16 + 4].cpu().numpy().view(np.uint32), 2, True, gb.astype(np.uint64),
+                       (np.minimum(gb + band + L, ng) - gb).astype(np.uint32))
+    es, ek = O.batch_banded_gotoh_score_qual(band, ty, s5 + (0,), lut, qbuf, ps, tset)
+    ok = bool((ts[:m].cpu().numpy() == es).all() and (tk[:m].cpu().numpy().view(np.uint32) == ek).all())
+    if not (same and ok):
+        raise SystemExit("parity gate failed: compat stream routes disagree (tuned vs generic %s, tuned vs oracle %s)" % (same, ok))
+    return {"stream": "nvBowtie-shaped BestScoreStream (ReadLoader views of reversed reads, quality strings, SmithWatermanScoringScheme), band 15, LOCAL, %d hits x %d bp" % (n, L),
+            "tuned_route": {"path": pathbuf.value.decode(), "ms_per_enact": ms_t, "Mreads_per_s": n / ms_t / 1e3,
+                            "includes": "job-table kernel (stream's own init_context / load_strings, staging of patterns and qualities), one host sync, the tuned kernel, the stream's output()"},
+            "generic_lane": {"ms_per_enact": ms_g, "Mreads_per_s": n / ms_g / 1e3},
+            "identical_outputs": same, "oracle_sample": {"checked": m, "bit_exact": ok}}
 
 
 def _timed(fn, reps=3):
