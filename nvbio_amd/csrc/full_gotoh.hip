@@ -230,7 +230,7 @@ __device__ __forceinline__ SweepResult sweep(const FullParams& p, const uint64_t
 template <int TYPE>
 __device__ __forceinline__ void cell16(uint32_t& e, uint32_t& hlg, uint32_t& hab_g, uint32_t& fab, uint32_t& diag_g,
                                        const uint32_t ch, const uint32_t tlo, const uint32_t thi, const uint32_t go, const uint32_t ge,
-                                       uint32_t& h_out)
+                                       uint32_t& h_out, uint32_t& bk, const uint32_t s15)
 {
     // in : e = E(r,c-1), hlg = HG(r,c-1), hab_g = HG(r-1,c), fab = F(r-1,c), diag_g = HG(r-1,c-1)
     // out: e = E(r,c),   hlg = HG(r,c),   hab_g = HG(r,c),   fab = F(r,c),   diag_g = HG(r,c-1), h_out = H(r,c)
@@ -248,9 +248,12 @@ __device__ __forceinline__ void cell16(uint32_t& e, uint32_t& hlg, uint32_t& hab
             "v_max_i16 %[h], %[f], %[d]\n\t"
             "v_max_i16 %[h], %[h], %[e]\n\t"
             "v_max_i16 %[h], 0, %[h]\n\t"
-            "v_add_u16 %[t], %[h], %[go]"
-            : [f] "=&v"(f), [d] "=&v"(d), [h] "=&v"(h), [t] "=&v"(t), [e] "+v"(e)
-            : [ch] "v"(ch), [tlo] "v"(tlo), [thi] "v"(thi), [fab] "v"(fab), [ge] "v"(ge), [hab] "v"(hab_g), [dg] "v"(diag_g), [go] "v"(go), [hl] "v"(hlg));
+            "v_add_u16 %[d], %[s15], %[h]\n\t"
+            "v_add_u16 %[t], %[h], %[go]\n\t"
+            "v_max_i16 %[bk], %[bk], %[d]"
+            : [f] "=&v"(f), [d] "=&v"(d), [h] "=&v"(h), [t] "=&v"(t), [e] "+v"(e), [bk] "+v"(bk)
+            : [ch] "v"(ch), [tlo] "v"(tlo), [thi] "v"(thi), [fab] "v"(fab), [ge] "v"(ge), [hab] "v"(hab_g), [dg] "v"(diag_g), [go] "v"(go), [hl] "v"(hlg),
+              [s15] "s"(s15));
     else
         asm("v_perm_b32 %[d], %[thi], %[tlo], %[ch]\n\t"
             "v_add_u16 %[f], %[fab], %[ge]\n\t"
@@ -271,19 +274,19 @@ __device__ __forceinline__ uint32_t max16u(uint32_t a, uint32_t b) { uint32_t r;
 __device__ __forceinline__ uint32_t min16u(uint32_t a, uint32_t b) { uint32_t r; asm("v_min_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 // MULTI: several jobs share the wave (full_gotoh_score_multi_kernel): the wave is cut in segments of `W` lanes, segment j sweeps job j,
-// and `lane` is the lane's index INSIDE its segment.  The last lane of every segment but the last holds no rows: it is the next
-// segment's "row above the matrix" (the feeder): what wave_shr:1 hands the next segment's first lane -- H(-1, c) + G_o, F = infimum, the
-// text symbol of column c of the NEXT job, an empty column maximum -- is what that lane keeps in its out_* registers.  Everything a job
-// owns (M, Ncols, lane_last, klast ...) is then a per-lane value, and the loop bounds are the wave's maxima / minima.
+// and `lane` is the lane's index INSIDE its segment.  The hand-off between lanes is one instruction per value for every shape:
+// v_cndmask_b32 with a wave_shr:1 DPP source and the mask of the segments' first lanes in VCC -- a first lane takes the row above its
+// matrix (H(-1, c) + G_o, F = infimum, the text symbol of column c of ITS job, an empty column maximum), every other lane what the lane
+// above computed one step ago.  Everything a job owns (M, Ncols, lane_last, klast ...) is a per-lane value, and the loop bounds are the
+// wave's maxima / minima.
 template <int TYPE, int R, bool CHECK, bool PBX = false, bool MULTI = false>      // PBX: keep every row's maximum over the text (pattern-blocking early exit, non-LOCAL types)
 struct Sweep16
 {
-    static_assert(!MULTI || TYPE != NVBIO_HIP_GLOBAL, "segments carry constants down the feeder lanes: LOCAL and SEMI_GLOBAL only");
+    static_assert(!MULTI || TYPE != NVBIO_HIP_GLOBAL, "several jobs per wave: LOCAL and SEMI_GLOBAL only");
     const FullParams& p;
     uint32_t lane, lane_last, klast, M, Ncols, Nfull;
-    uint32_t wlane, seg_base, seg_w; bool feeder, seg_valid;      // MULTI: lane in the wave, first lane / width of the segment, feeder lane, segment holds a job
-    uint64_t tb_feed;                                             // MULTI: text of the job this lane feeds symbols for (lane 0: its own; a feeder: the next job's)
-    uint32_t ncols_feed;
+    uint32_t wlane, seg_base, seg_w; bool seg_valid;              // MULTI: lane in the wave, first lane / width of the segment, segment holds a job
+    uint64_t head_mask;                                           // the first lane of every segment (lane 0 of a wave that sweeps one job)
     int32_t  Go, Ge, min_score;
     uint32_t go, ge, rge, inf16, init_above_g;
     uint32_t tlo[R], thi[R];              // per-row substitution table: four 16-bit entries, scores pre-biased by -G_o (cell16)
@@ -304,13 +307,13 @@ struct Sweep16
 
     __device__ __forceinline__ Sweep16(const FullParams& _p) : p(_p) {}
 
-    /// MULTI: _seg_w = lanes per segment; _valid = this lane's segment holds a job; _tb_feed / _ncols_feed = text of the job of lane + 1's segment
+    /// MULTI: _seg_w = lanes per segment; _valid = this lane's segment holds a job
     __device__ __forceinline__ void init(const uint64_t pb, const uint64_t _tb, uint32_t _M, uint32_t _Ncols, uint32_t _Nfull, int32_t _min_score,
-                                         const uint32_t _seg_w = 64u, const bool _valid = true, const uint64_t _tb_feed = 0, const uint32_t _ncols_feed = 0)
+                                         const uint32_t _seg_w = 64u, const bool _valid = true)
     {
         wlane = threadIdx.x & 63u; seg_w = _seg_w; seg_valid = _valid;
         lane = MULTI ? wlane % seg_w : wlane; seg_base = wlane - lane;
-        tb_feed = MULTI ? _tb_feed : _tb; ncols_feed = MULTI ? _ncols_feed : _Ncols;
+        head_mask = __ballot(lane == 0u);
         M = _M; Ncols = _Ncols; Nfull = _Nfull; min_score = _min_score; tb = _tb; pb_check = false;
         Go = p.gap_open; Ge = p.gap_ext;
         const int32_t infimum = -32768 - min(Go, Ge) * SC;
@@ -335,21 +338,7 @@ struct Sweep16
             if (CHECK) lim[k] = (uint32_t(k) <= kl) ? 0x7FFFu : 0x8000u;
         }
         out_hg = out_f = out_ch = out_cm = 0;
-        feeder = false;
-        if (MULTI)
-        {
-            // the last lane of a segment that has a successor: it holds no rows (the host sizes R so that lane_last < seg_w - 1)
-            feeder = (lane == seg_w - 1u) && (seg_base + seg_w < 64u);
-            // A lane reads, at step s, what the lane above wrote at step s - 1 (the same column): the feeder stands for the row above the
-            // next job's matrix, i.e. one lane ahead of that job's first lane -- at step s it hands on the symbol of column s + 1
-            if (feeder)
-            {
-                out_hg = go; out_f = inf16; out_cm = 0x8000u;
-                out_ch = 0x0C0C0100u + 0x0202u * (ncols_feed ? get_symbol(p.txt.s, tb_feed) : 0u);
-                tb_feed += 1u;
-            }
-            if (!seg_valid) { Ncols = 0u; }            // lanes of a segment without a job never enter the matrix
-        }
+        if (MULTI && !seg_valid) { Ncols = 0u; }       // lanes of a segment without a job never enter the matrix
         prev_in_hg = (lane == 0u) ? go : 0u;          // lane 0's first diagonal: the corner above the matrix, H(-1,-1) = 0
         sg_score = -(1 << 30); sg_col = 0; exit_col = 0xFFFFFFFFu; grp = 0; sg_hg16 = 0x8000u;
         top_hg = c16(p.row_go + Go); top_prev_hg = go;
@@ -380,11 +369,28 @@ struct Sweep16
     __device__ __forceinline__ void step(const uint32_t s, const uint32_t ch0, const uint32_t s15)     // s15 = s & 15 (a constant in the unrolled steady state)
     {
         const uint32_t c = s - lane;
-        const uint32_t th = (TYPE == NVBIO_HIP_GLOBAL) ? top_hg : go;          // HG(-1,c) for lane 0
-        const uint32_t in_hg = uint32_t(dpp_shr1(int32_t(th), int32_t(out_hg)));
-        const uint32_t in_f  = uint32_t(dpp_shr1(int32_t(inf16), int32_t(out_f)));
-        const uint32_t in_ch = uint32_t(dpp_shr1(int32_t(ch0), int32_t(out_ch)));
-        const uint32_t in_cm = CHECK ? uint32_t(dpp_shr1(int32_t(0x8000u), int32_t(out_cm))) : 0u;
+        const uint32_t th = (TYPE == NVBIO_HIP_GLOBAL) ? top_hg : go;          // HG(-1,c) for a first lane
+        // The hand-off: in = first lane ? (row above the matrix) : (the lane above's out).  One VOP2 each -- the DPP source shifts, the
+        // select takes the first lanes' mask from VCC -- where a DPP move into a register preset with the first lane's value costs two and
+        // knows lane 0 only.  out_hg is the register the step before wrote last: it is read last (a DPP source needs two wait states).
+        uint32_t in_hg, in_f, in_ch, in_cm = 0u;
+        if (CHECK)
+            asm("s_mov_b64 vcc, %[m]\n\t"
+                "v_cndmask_b32_dpp %[cm], %[ocm], %[hcm], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                "v_cndmask_b32_dpp %[ch], %[och], %[hch], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                "v_cndmask_b32_dpp %[f], %[of], %[hf], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                "v_cndmask_b32_dpp %[hg], %[ohg], %[hh], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+                : [cm] "=&v"(in_cm), [ch] "=&v"(in_ch), [f] "=&v"(in_f), [hg] "=&v"(in_hg)
+                : [ocm] "v"(out_cm), [och] "v"(out_ch), [of] "v"(out_f), [ohg] "v"(out_hg),
+                  [hcm] "v"(0x8000u), [hch] "v"(ch0), [hf] "v"(inf16), [hh] "v"(th), [m] "s"(head_mask) : "vcc");
+        else
+            asm("s_mov_b64 vcc, %[m]\n\t"
+                "v_cndmask_b32_dpp %[ch], %[och], %[hch], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                "v_cndmask_b32_dpp %[f], %[of], %[hf], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                "v_cndmask_b32_dpp %[hg], %[ohg], %[hh], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+                : [ch] "=&v"(in_ch), [f] "=&v"(in_f), [hg] "=&v"(in_hg)
+                : [och] "v"(out_ch), [of] "v"(out_f), [ohg] "v"(out_hg),
+                  [hch] "v"(ch0), [hf] "v"(inf16), [hh] "v"(th), [m] "s"(head_mask) : "vcc");
         // HG(r-1, c-1): what came down the lanes one step ago.  Lane 0 needs no case of its own -- its in_hg is the row above the matrix,
         // th, so one step ago it was that row's previous column (prev_in_hg starts as the corner) -- and a lane's first column (the
         // boundary column's value instead) only occurs while lanes are still entering the matrix.
@@ -393,7 +399,6 @@ struct Sweep16
         prev_in_hg = in_hg;
         if (TYPE == NVBIO_HIP_GLOBAL) { top_prev_hg = top_hg; uint32_t t; asm("v_add_u16 %0, %1, %2" : "=v"(t) : "v"(top_hg), "v"(rge)); top_hg = t; }
 
-        if (MULTI && feeder) { out_ch = ch0; return; }         // the next segment's row above the matrix: constants, and its job's text symbol
         const bool active = !PRED || (int32_t(c) >= 0 && c < Ncols && lane <= lane_last);
         if (active)
         {
@@ -401,8 +406,8 @@ struct Sweep16
             #pragma unroll
             for (int k = 0; k < R; ++k)
             {
-                cell16<TYPE>(E[k], HLG[k], hab_g, fab, diag_g, in_ch, tlo[k], thi[k], go, ge, h);
-                if (TYPE == NVBIO_HIP_LOCAL) bk16[k] = max16u(bk16[k], h + s15);       // h < 2^15 and a multiple of 16: no carry out of the low half
+                // LOCAL: bk16 = max(bk16, h + s15) inside the cell (h < 2^15 and a multiple of 16: no carry out of the low half)
+                cell16<TYPE>(E[k], HLG[k], hab_g, fab, diag_g, in_ch, tlo[k], thi[k], go, ge, h, bk16[TYPE == NVBIO_HIP_LOCAL ? k : 0], s15);
                 if (PBX) rmax[k] = max16u(rmax[k], h);
                 if (CHECK) cm = max16u(cm, min16u(h, lim[k]));
             }
@@ -459,16 +464,16 @@ struct Sweep16
     /// the text group of 16 symbols starting at column s: the job's own (wave-uniform -> scalar) or, MULTI, per lane of the job the lane feeds
     __device__ __forceinline__ uint32_t text_group(const uint32_t s) const
     {
-        if (MULTI) return fetch16_2bit(p.txt.s, tb_feed + s);
+        if (MULTI) return fetch16_2bit(p.txt.s, tb + s);
         return uint32_t(__builtin_amdgcn_readfirstlane(int(fetch16_2bit(p.txt.s, tb + s))));
     }
 
     __device__ __forceinline__ SweepResult run()
     {
         // MULTI: the wave runs to the longest job's last step; the unpredicated steady state covers the steps at which every job is inside it
-        const bool rows = !MULTI || (seg_valid && !feeder && Ncols > 0u);
+        const bool rows = !MULTI || (seg_valid && Ncols > 0u);
         const uint32_t n_steps = MULTI ? wave_max_u32(rows ? Ncols + lane_last : 0u) : Ncols + lane_last;
-        const uint32_t fetch_cols = MULTI ? wave_max_u32(ncols_feed) : Ncols;
+        const uint32_t fetch_cols = MULTI ? wave_max_u32(Ncols) : Ncols;
         uint32_t s = 0;
         // ramp-up, up to the first 16-aligned step at which every row-holding lane is inside the matrix and past its first column
         const uint32_t s_fast = MULTI ? wave_max_u32(rows ? ((lane_last + 16u) & ~15u) : 0u) : ((lane_last + 16u) & ~15u);         // (strictly past every lane's first column: step() tests for that column only while PRED)
@@ -698,16 +703,11 @@ full_gotoh_score_multi_kernel(const FullParams p, const uint32_t n_seg, const ui
     const uint32_t seg  = wl / seg_w, sl = wl - seg * seg_w;
     const uint32_t job  = wave * n_seg + seg;
     const bool has_job  = seg < n_seg && job < p.n;
-    // the job whose text symbols this lane hands on: lane 0 of the wave its own, a segment's last lane the next segment's
-    const uint32_t fseg = (wl + 1u) / seg_w, fjob = wave * n_seg + fseg;
-    const bool has_feed = fseg < n_seg && fjob < p.n;
     if (wave * n_seg >= p.n) return;
 
     const uint32_t M  = has_job ? (p.pat.length ? p.pat.length[job] : p.pat.fixed_length) : 0u;
     const uint32_t N  = has_job ? (p.txt.length ? p.txt.length[job] : p.txt.fixed_length) : 0u;
     const uint64_t pb = has_job ? p.pat.begin[job] : 0ull, tb = has_job ? p.txt.begin[job] : 0ull;
-    const uint32_t Nf = has_feed ? (p.txt.length ? p.txt.length[fjob] : p.txt.fixed_length) : 0u;
-    const uint64_t tf = has_feed ? p.txt.begin[fjob] : 0ull;
     const bool     check = p.min_score != nullptr;
     const int32_t  min_score = (check && has_job) ? p.min_score[job] : -(1 << 30);
     const bool     PB = p.pattern_blocking != 0u;
@@ -740,7 +740,7 @@ full_gotoh_score_multi_kernel(const FullParams p, const uint32_t n_seg, const ui
     if (PB && check)
     {
         Sweep16<TYPE, R, false, (TYPE != NVBIO_HIP_LOCAL), true> sw(p);
-        sw.init(pb, tb, Ms, Ns, Ns, min_score, seg_w, sweeps, tf, Nf);
+        sw.init(pb, tb, Ms, Ns, Ns, min_score, seg_w, sweeps);
         sw.pb_check = true;
         const SweepResult r = sw.run();
         if (sweeps)
@@ -752,8 +752,8 @@ full_gotoh_score_multi_kernel(const FullParams p, const uint32_t n_seg, const ui
     else
     {
         SweepResult r;
-        if (check) { Sweep16<TYPE, R, true,  false, true> sw(p); sw.init(pb, tb, Ms, Ns, Ns, min_score, seg_w, sweeps, tf, Nf); r = sw.run(); }
-        else       { Sweep16<TYPE, R, false, false, true> sw(p); sw.init(pb, tb, Ms, Ns, Ns, min_score, seg_w, sweeps, tf, Nf); r = sw.run(); }
+        if (check) { Sweep16<TYPE, R, true,  false, true> sw(p); sw.init(pb, tb, Ms, Ns, Ns, min_score, seg_w, sweeps); r = sw.run(); }
+        else       { Sweep16<TYPE, R, false, false, true> sw(p); sw.init(pb, tb, Ms, Ns, Ns, min_score, seg_w, sweeps); r = sw.run(); }
         if (sweeps)
         {
             if (r.exit_col != 0xFFFFFFFFu)
@@ -1016,8 +1016,8 @@ static int full_score_core(
     }
     if (fast && type != NVBIO_HIP_GLOBAL)
     {
-        // several jobs per wave when that keeps more lanes busy: n_seg segments of 64 / n_seg lanes, the last lane of each feeding the
-        // next, R = 5 or 6 rows per lane.  Estimated cell throughput: busy lanes x (cell work) / (cell work + per-step overhead).
+        // several jobs per wave when that keeps more lanes busy: n_seg segments of 64 / n_seg lanes, R = 5 or 6 rows per lane.
+        // Estimated cell throughput: busy lanes x (cell work) / (cell work + per-step overhead).
         const char* nomulti = getenv("NVBIO_HIP_FULL_SINGLE_JOB");
         auto eff = [](const double lanes, const double rows, const double overhead) { return lanes / 64.0 * (28.0 * rows) / (28.0 * rows + overhead); };
         double best = eff(double((maxM + R - 1) / R), double(R), 24.0);
@@ -1025,9 +1025,9 @@ static int full_score_core(
         for (uint32_t ns = 2u; ns <= 4u; ++ns)
             for (uint32_t r = 5u; r <= 6u; ++r)
             {
-                const uint32_t usable = 64u / ns - 1u;
+                const uint32_t usable = 64u / ns;
                 if (uint64_t(usable) * r < maxM) continue;
-                const double e = eff(double(ns * ((maxM + r - 1u) / r)), double(r), 36.0);
+                const double e = eff(double(ns * ((maxM + r - 1u) / r)), double(r), 24.0);
                 if (e > best * 1.05) { best = e; best_seg = ns; best_r = r; }
             }
         if (best_seg > 1u && !(nomulti && nomulti[0] == '1') && uint64_t(maxN) * 64u * 8u < (1ull << 32))

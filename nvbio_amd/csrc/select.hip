@@ -20,6 +20,7 @@
 #include "hit_deque.h"
 #include <hipcub/hipcub.hpp>
 #include <limits.h>
+#include <stdlib.h>
 
 namespace nvb {
 
@@ -92,7 +93,7 @@ __global__ void __launch_bounds__(256)
 select_init_kernel(uint32_t n_reads, const char* __restrict__ names, const uint32_t* __restrict__ names_idx,
                    const uint2* __restrict__ hits, uint32_t hits_stride, const uint32_t* __restrict__ counts,
                    float* __restrict__ probs, uint32_t probs_stride, uint32_t* __restrict__ trys, uint32_t* __restrict__ rseeds,
-                   uint32_t max_effort_init, int randomized, int top_seed)
+                   uint32_t max_effort_init, int randomized, int top_seed, int build_tree)
 {
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
     if (r >= n_reads) return;
@@ -104,6 +105,7 @@ select_init_kernel(uint32_t n_reads, const char* __restrict__ names, const uint3
         for (uint32_t i = 0; i < len && names[off + i]; ++i) hash = ((hash << 5) + hash) ^ uint32_t(int32_t((signed char)names[off + i]));
         rseeds[r] = hash;
     }
+    if (!build_tree) return;
     const uint32_t n = counts[r];
     if (n == 0u) return;
     float* pr = probs + uint64_t(r) * probs_stride;
@@ -111,6 +113,79 @@ select_init_kernel(uint32_t n_reads, const char* __restrict__ names, const uint3
     for (uint32_t i = 0; i < n; ++i) { const float d = __uint2float_rn(hit_delta(h[i])); pr[i] = __fdiv_rn(1.0f, __fmul_rn(d, d)); }
     if (top_seed) pr[0] = 0.0f;
     SumTree(pr, n).setup();
+}
+
+// A read's hit row and probability tree held by a group of G lanes, four hits / leaves per lane (G = 4: rows of <= 16 hits, G = 8: <= 32).
+// Every internal node of a SumTree is the float sum of its two children, left + right (setup() builds it so, set() keeps it so), so the
+// node values are a function of the leaves: blocks of 2 and 4 leaves are sums inside the lane, blocks of 8, 16 and 32 a butterfly over the
+// group -- the same pairwise adds, the same values bit for bit (float add commutes).  A lane then holds every ancestor of its own leaves.
+template <int G>
+struct TreeQuad
+{
+    float lf[4];                    // leaves 4 j .. 4 j + 3
+    float a, b, c, d, e, f;         // the blocks of 2 (left, right), 4, 8, 16, 32 leaves this lane belongs to
+    __device__ __forceinline__ void rebuild()
+    {
+        a = __fadd_rn(lf[0], lf[1]); b = __fadd_rn(lf[2], lf[3]); c = __fadd_rn(a, b);
+        d = __fadd_rn(c, __shfl_xor(c, 1, G));
+        e = __fadd_rn(d, __shfl_xor(d, 2, G));
+        f = G > 4 ? __fadd_rn(e, __shfl_xor(e, 4, G)) : 0.0f;
+    }
+    // the node of level k (blocks of 2^k leaves) that starts at leaf `first` (a multiple of 2^k, the same in every lane of the group)
+    __device__ __forceinline__ float node(const uint32_t k, const uint32_t first) const
+    {
+        const uint32_t q = first & 3u;
+        float v = q == 0u ? lf[0] : q == 1u ? lf[1] : q == 2u ? lf[2] : lf[3];
+        v = k == 1u ? (q ? b : a) : v;
+        v = k == 2u ? c : v; v = k == 3u ? d : v; v = k == 4u ? e : v; v = k == 5u ? f : v;
+        return __shfl(v, int(first >> 2), G);
+    }
+    // this lane's own ancestor of level k >= 1 above its leaf slot q
+    __device__ __forceinline__ float own(const uint32_t k, const uint32_t q) const
+    {
+        return k == 1u ? (q >= 2u ? b : a) : k == 2u ? c : k == 3u ? d : k == 4u ? e : f;
+    }
+};
+
+// The probability trees of select_init, four leaves per lane: leaf = 1 / delta^2, then the levels (SumTree::setup's adds).  A read's hit row
+// is read and its tree row written in contiguous pieces -- where one lane per read walks 16 scattered 8-byte loads and 31 scattered 4-byte
+// stores.  Same tree, bit for bit.
+template <int G>
+__global__ void __launch_bounds__(256)
+select_init_tree_kernel(uint32_t n_reads, const uint2* __restrict__ hits, uint32_t hits_stride, const uint32_t* __restrict__ counts,
+                        float* __restrict__ probs, uint32_t probs_stride, int top_seed)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t r = t / G, j = t % G;
+    if (r >= n_reads) return;                       // (whole groups leave together: 256 % G == 0)
+    const uint32_t n = counts[r];
+    if (n == 0u) return;
+    const uint32_t padded = st_padded(n);
+    float* pr = probs + uint64_t(r) * probs_stride;
+    const uint2* hrow = hits + uint64_t(r) * hits_stride;
+    TreeQuad<G> tq;
+    #pragma unroll
+    for (uint32_t q = 0; q < 4u; ++q)
+    {
+        const uint32_t i = 4u * j + q;
+        float v = 0.0f;
+        if (i < n) { const float dl = __uint2float_rn(hit_delta(hrow[i])); v = __fdiv_rn(1.0f, __fmul_rn(dl, dl)); }
+        if (top_seed && i == 0u) v = 0.0f;
+        tq.lf[q] = v;
+        if (i < padded) pr[i] = v;
+    }
+    tq.rebuild();
+    uint32_t base = padded;                                                          // level 1: padded / 2 nodes
+    if (2u * j      < (padded >> 1)) pr[base + 2u * j]      = tq.a;
+    if (2u * j + 1u < (padded >> 1)) pr[base + 2u * j + 1u] = tq.b;
+    base += padded >> 1;
+    if (j < (padded >> 2)) pr[base + j] = tq.c;
+    base += padded >> 2;
+    if ((j & 1u) == 0u && (j >> 1) < (padded >> 3)) pr[base + (j >> 1)] = tq.d;
+    base += padded >> 3;
+    if ((j & 3u) == 0u && (j >> 2) < (padded >> 4)) pr[base + (j >> 2)] = tq.e;
+    base += padded >> 4;
+    if (G > 4 && (j & 7u) == 0u && (j >> 3) < (padded >> 5)) pr[base + (j >> 3)] = tq.f;
 }
 
 __device__ uint32_t randomized_select(const SumTree& tree, const uint2* h, uint32_t* rseed)
@@ -184,6 +259,130 @@ select_kernel(uint32_t n_multi, const uint32_t* __restrict__ active_in, uint32_t
     }
     stage_read[t] = read_id | (top_flag << 31);
     key[t] = (uint64_t(n_sel != 0u ? 1u : 0u) << 32) | n_sel;
+}
+
+// Randomized selection with a read's hit row and tree in a group of G lanes, four hits / leaves per lane (TreeQuad).  One lane per read
+// walks its tree and row with ~25 scattered 4/8-byte accesses per pick; here the row and the LEAVES are loaded once in contiguous pieces and
+// everything else happens in registers:
+//   * SumTree::sample()'s descent (sum_tree_inl.h:120-178) runs redundantly in the lanes of the group, fetching the two children of the
+//     current node by shuffle; the LCG, the float multiply / divide / min sequence and the 10-try loop of randomized_select are unchanged;
+//   * pop_front touches one slot of the lane that owns the picked hit; an exhausted hit zeroes that lane's leaf, and the lane stores the
+//     hit, the leaf, the leaf's ancestors (all its own values) and the staged pick.
+// Same picks, same state, bit for bit (tests/test_select_gpu.py against the oracle's one-lane restatement; NVBIO_HIP_SELECT_LANES=1 runs
+// the one-lane form, =4 this one).  NOT the default: on config 4 it is slower than one lane per read (586 vs 414 us per call), and so was
+// a form with sixteen lanes per read and one leaf each (536 us): the stage is bound by moving each active read's two rows in and out of
+// HBM, not by the number of requests (profiles/r03/select_coop.txt).
+template <int G>
+__global__ void __launch_bounds__(256)
+select_rand_quad_kernel(uint32_t n_multi, const uint32_t* __restrict__ active_in, uint32_t n_active,
+                        uint2* __restrict__ hits, uint32_t hits_stride, uint32_t* __restrict__ counts,
+                        float* __restrict__ probs, uint32_t probs_stride, uint32_t* __restrict__ rseeds, const uint32_t* __restrict__ trys,
+                        uint32_t* __restrict__ stage_read, uint32_t* __restrict__ stage_loc, uint32_t* __restrict__ stage_seed, uint64_t* __restrict__ key)
+{
+    const uint32_t gt = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t t = gt / G, j = gt % G;
+    if (t > n_active) return;
+    if (t == n_active) { if (j == 0u) key[t] = 0ull; return; }
+    const uint32_t read_id = active_in[t] & 0x7FFFFFFFu;
+    uint32_t top_flag = active_in[t] >> 31;
+    uint32_t n_sel = 0u;
+    const uint32_t n = (trys[read_id] == 0u) ? 0u : counts[read_id];
+    if (n != 0u)
+    {
+        uint2* hrow = hits + uint64_t(read_id) * hits_stride;
+        float* pr = probs + uint64_t(read_id) * probs_stride;
+        const uint32_t padded = st_padded(n), lg = ilog2(padded);
+        uint32_t hx[4], hy[4];
+        TreeQuad<G> tq;
+        #pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q)
+        {
+            const uint32_t i = 4u * j + q;
+            const uint2 h = (i < n) ? hrow[i] : make_uint2(0u, 0u);
+            hx[q] = h.x; hy[q] = h.y;
+            tq.lf[q] = (i < padded) ? pr[i] : 0.0f;
+        }
+        // delta of hit i (the same i in every lane of the group)
+        auto delta_of = [&](const uint32_t i) -> uint32_t {
+            const uint32_t q = i & 3u;
+            const uint32_t y = q == 0u ? hy[0] : q == 1u ? hy[1] : q == 2u ? hy[2] : hy[3];
+            return uint32_t(__shfl(int32_t(y & 0xFFFFFu), int(i >> 2), G));
+        };
+        uint32_t s = rseeds[read_id];
+        const uint32_t s_in = s;
+        tq.rebuild();
+        for (uint32_t i = 0; i < n_multi; ++i)
+        {
+            if (tq.node(lg, 0u) <= 0.0f) break;                                        // tree.sum(): the root
+            if (top_flag && delta_of(0u) == 0u) top_flag = 0u;
+            uint32_t id = 0u;
+            if (!top_flag)
+            {
+                // randomized_select: up to 10 draws, the first whose hit still has rows
+                bool found = false;
+                for (uint32_t tr = 0; tr < 10u && !found; ++tr)
+                {
+                    s = 1664525u * s + 1013904223u;
+                    float v = __fdiv_rn(__uint2float_rn(s), 4294967296.0f);
+                    // SumTree::sample: from the two children of the root down to a pair of leaves
+                    uint32_t nd = 0u;                                                  // the left node of the current pair, index in its level
+                    for (uint32_t k = lg; k >= 2u; --k)                                // nodes of this level cover 2^(k-1) leaves
+                    {
+                        const uint32_t B = 1u << (k - 1u);
+                        const float l = tq.node(k - 1u, nd * B), r = tq.node(k - 1u, (nd + 1u) * B);
+                        const float ss = __fadd_rn(l, r);
+                        if (ss == 0.0f) nd *= 2u;
+                        else {
+                            const float vs = __fmul_rn(v, ss);
+                            if (vs < l || r == 0.0f) { nd = nd * 2u; const float qq = __fdiv_rn(vs, l); v = qq < 1.0f ? qq : 1.0f; }
+                            else { nd = (nd + 1u) * 2u; const float qq = __fdiv_rn(__fsub_rn(vs, l), r); v = qq < 1.0f ? qq : 1.0f; }
+                        }
+                    }
+                    const float l = nd < n ? tq.node(0u, nd) : 0.0f, r = nd + 1u < n ? tq.node(0u, nd + 1u) : 0.0f;
+                    const float vs = __fmul_rn(v, __fadd_rn(l, r));
+                    nd = (vs < l || r == 0.0f) ? nd : nd + 1u;
+                    const uint32_t pick = nd < n ? nd : n - 1u;
+                    if (delta_of(pick) != 0u) { id = pick; found = true; }
+                }
+            }
+            const uint32_t dsel = delta_of(id);
+            if (dsel == 0u) { if (n_multi > 1u) continue; else break; }
+            if (j == (id >> 2))                                                        // the lane that owns the picked hit
+            {
+                const uint32_t q = id & 3u;
+                const uint32_t x = q == 0u ? hx[0] : q == 1u ? hx[1] : q == 2u ? hx[2] : hx[3];
+                uint32_t y = q == 0u ? hy[0] : q == 1u ? hy[1] : q == 2u ? hy[2] : hy[3];
+                y = (y & ~0xFFFFFu) | ((y - 1u) & 0xFFFFFu);                             // pop_front
+                #pragma unroll
+                for (uint32_t w = 0; w < 4u; ++w) if (w == q) { hx[w] = x + 1u; hy[w] = y; }
+                hrow[id] = make_uint2(x + 1u, y);
+                stage_loc[uint64_t(t) * n_multi + n_sel] = x;
+                stage_seed[uint64_t(t) * n_multi + n_sel] = packed_seed_of(make_uint2(0u, y), top_flag);
+                if (dsel == 1u)                                                        // the hit ran out: tree.set(id, 0), leaf first
+                {
+                    #pragma unroll
+                    for (uint32_t w = 0; w < 4u; ++w) if (w == q) tq.lf[w] = 0.0f;
+                    pr[id] = 0.0f;
+                }
+            }
+            if (dsel == 1u)
+            {
+                tq.rebuild();
+                if (j == (id >> 2))                                                    // ... then its ancestors, level by level
+                {
+                    uint32_t base = padded;
+                    for (uint32_t k = 1u; k <= lg; ++k) { pr[base + (id >> k)] = tq.own(k, id & 3u); base += padded >> k; }
+                }
+            }
+            ++n_sel;
+        }
+        if (j == 0u && s != s_in) rseeds[read_id] = s;
+    }
+    if (j == 0u)
+    {
+        stage_read[t] = read_id | (top_flag << 31);
+        key[t] = (uint64_t(n_sel != 0u ? 1u : 0u) << 32) | n_sel;
+    }
 }
 
 // stage 2: compaction in queue order
@@ -334,9 +533,17 @@ NVB_API int nvbio_hip_select_init(uint32_t n_reads, const char* read_names, cons
         if (read_names && !read_names_idx) return hipErrorInvalidValue;
     }
     g_last_kernel = "select_init_kernel";
+    // trees: 4 or 8 lanes per read (four leaves each) when a read's hit slots fit, one lane per read otherwise
+    const char* lanes = getenv("NVBIO_HIP_SELECT_LANES");                  // =1: one lane per read
+    const bool one_lane = lanes && lanes[0] == '1';
+    const int G = (!randomized || one_lane) ? 0 : hits_stride <= 16u ? 4 : hits_stride <= 32u ? 8 : 0;
     hipLaunchKernelGGL(select_init_kernel, grid_for(n_reads), dim3(256), 0, to_stream(stream), n_reads, read_names, read_names_idx,
                        reinterpret_cast<const uint2*>(hits), hits_stride, hit_counts, probs, probs_stride, trys, rseeds, max_effort_init,
-                       int(randomized), int(top_seed));
+                       int(randomized), int(top_seed), G == 0 ? 1 : 0);
+    if (G == 4) hipLaunchKernelGGL(select_init_tree_kernel<4>, grid_for(uint64_t(n_reads) * 4u), dim3(256), 0, to_stream(stream), n_reads,
+                                    reinterpret_cast<const uint2*>(hits), hits_stride, hit_counts, probs, probs_stride, int(top_seed));
+    if (G == 8) hipLaunchKernelGGL(select_init_tree_kernel<8>, grid_for(uint64_t(n_reads) * 8u), dim3(256), 0, to_stream(stream), n_reads,
+                                    reinterpret_cast<const uint2*>(hits), hits_stride, hit_counts, probs, probs_stride, int(top_seed));
     return hipGetLastError();
 }
 
@@ -368,7 +575,18 @@ NVB_API int nvbio_hip_select(int32_t randomized, uint32_t n_multi, const uint32_
     size_t scan_bytes = select_scan_bytes(n_active);
     hipStream_t s = to_stream(stream);
     g_last_kernel = randomized ? "select_kernel<rand>" : "select_kernel";
-    if (randomized)
+    // One lane per read is the default: the stage moves every active read's hit row and tree row in and out of HBM once per call and
+    // sits near that floor; the four-leaves-per-lane form (NVBIO_HIP_SELECT_LANES=4, same results) measured slower on config 4
+    // (profiles/r03/select_coop.txt).
+    const char* lanes = getenv("NVBIO_HIP_SELECT_LANES");
+    const bool quad = randomized && hits_stride <= 32u && lanes && lanes[0] == '4';
+    if (quad && hits_stride <= 16u)
+        hipLaunchKernelGGL(select_rand_quad_kernel<4>, grid_for((uint64_t(n) + 1u) * 4u), dim3(256), 0, s, n_multi, active_in, n_active, reinterpret_cast<uint2*>(hits), hits_stride,
+                           hit_counts, probs, probs_stride, rseeds, trys, stage_read, stage_loc, stage_seed, key);
+    else if (quad)
+        hipLaunchKernelGGL(select_rand_quad_kernel<8>, grid_for((uint64_t(n) + 1u) * 8u), dim3(256), 0, s, n_multi, active_in, n_active, reinterpret_cast<uint2*>(hits), hits_stride,
+                           hit_counts, probs, probs_stride, rseeds, trys, stage_read, stage_loc, stage_seed, key);
+    else if (randomized)
         hipLaunchKernelGGL(select_kernel<true>, grid_for(n + 1u), dim3(256), 0, s, n_multi, active_in, n_active, reinterpret_cast<uint2*>(hits), hits_stride,
                            hit_counts, probs, probs_stride, rseeds, trys, stage_read, stage_loc, stage_seed, key);
     else

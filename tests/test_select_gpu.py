@@ -62,12 +62,28 @@ def device_hit_deque_replay(cuda, ops, vals, sizes):
 @pytest.mark.parametrize("randomized", [False, True])
 @pytest.mark.parametrize("n_multi", [1, 4, 32])
 @pytest.mark.parametrize("top_seed", [0, 1])
-def test_select_rounds_match_oracle(cuda, randomized, n_multi, top_seed):
+@pytest.mark.parametrize("stride", [12, 16, 20, 40])
+def test_select_rounds_match_oracle(cuda, randomized, n_multi, top_seed, stride):
     """select_init + repeated select rounds on random deques: queues, selected hits, and the whole mutable state
-    (arena, counts, probability trees bit for bit, LCG states) after every round; some reads give up on the way."""
-    rng = np.random.default_rng(40 + n_multi + 2 * top_seed)
-    n, stride = 3000, 20
-    hits, counts = _random_deques(rng, n, stride, max_size=12)
+    (arena, counts, probability trees bit for bit, LCG states) after every round; some reads give up on the way.
+    select_init builds the trees with 4 lanes per read (stride <= 16), 8 lanes per read (<= 32) or one lane per read (wider rows)."""
+    _select_rounds(cuda, randomized, n_multi, top_seed, stride)
+
+
+@pytest.mark.parametrize("lanes", ["1", "4"])
+@pytest.mark.parametrize("n_multi", [1, 4])
+@pytest.mark.parametrize("stride", [8, 16, 32])
+def test_select_lane_forms_match_oracle(cuda, monkeypatch, lanes, n_multi, stride):
+    """NVBIO_HIP_SELECT_LANES=1: select_init and select with one lane per read; =4: the randomized select with a read's row and tree
+    in 4 / 8 lanes, four leaves each.  Same picks and state as the oracle either way."""
+    monkeypatch.setenv("NVBIO_HIP_SELECT_LANES", lanes)
+    _select_rounds(cuda, True, n_multi, 1, stride)
+
+
+def _select_rounds(cuda, randomized, n_multi, top_seed, stride):
+    rng = np.random.default_rng(40 + n_multi + 2 * top_seed + 100 * stride)
+    n = 3000
+    hits, counts = _random_deques(rng, n, stride, max_size=min(stride, 16))
     names = ["r%d/%d" % (i, i * 7919 % 13) for i in range(n)]
     arena, idx = O.pack_names(names)
     e_probs, e_trys, e_rseeds = O.select_init(hits, counts, arena, idx, 15, randomized, top_seed)

@@ -58,6 +58,8 @@ def main():
         idx = fmi.with_dimer()
         if flavour == "hbm_rich":
             idx = idx.with_ktab(15 if ng > (1 << 28) else 12).with_dense_ssa(1)
+        if flavour == "hbm_rich_trimer":                     # + the three-symbol rank arrays (32 GB at 3 Gbp)
+            idx = idx.with_trimer().with_ktab(15 if ng > (1 << 28) else 12).with_dense_ssa(1)
         fs = idx.struct()
         best = [torch.zeros((2, n), dtype=torch.int64, device=dev) for _ in range(a.batches)]
         mapq = [torch.zeros(n, dtype=torch.uint8, device=dev) for _ in range(a.batches)]

@@ -56,7 +56,17 @@
   X(perm_add_pair,"v_perm_b32 %0, %0, %1, %1\n v_add_u16 %0, %0, %1") \
   X(cmp_cnd_add,  "v_cmp_eq_u32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc\n v_add_u16 %0, %0, %1") \
   X(mov_dpp,      "v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf") \
-  X(xor_subclamp, "v_xor_b32 %0, %0, %1\n v_sub_u16_e64 %0, %1, %0 clamp")
+  X(xor_subclamp, "v_xor_b32 %0, %0, %1\n v_sub_u16_e64 %0, %1, %0 clamp") \
+  X(cnd_dpp_vcc,  "v_cndmask_b32_dpp %0, %0, %1, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0") \
+  X(smov_cnd_dpp, "s_mov_b64 vcc, s[10:11]\n v_cndmask_b32_dpp %0, %0, %1, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0") \
+  X(smov_3cnd_dpp,"s_mov_b64 vcc, s[10:11]\n v_cndmask_b32_dpp %0, %0, %1, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_cndmask_b32_dpp %0, %0, %1, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_cndmask_b32_dpp %0, %0, %1, vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0") \
+  X(dpp_cnd_sgpr, "v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_cndmask_b32_e64 %0, %0, %1, s[10:11]") \
+  X(add_u16_dpp,  "v_add_u16_dpp %0, %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0") \
+  X(max_i16_dpp,  "v_max_i16_dpp %0, %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0") \
+  X(mad_u32_u24,  "v_mad_u32_u24 %0, %0, %1, %1") \
+  X(s_nop_add,    "s_nop 0\n v_add_u16 %0, %0, %1") \
+  X(add_u16_sgpr, "v_add_u16 %0, s10, %0") \
+  X(smov_add,     "s_mov_b64 vcc, s[10:11]\n v_add_u16 %0, %0, %1")
 
 #define X(name, str) \
 __global__ void __launch_bounds__(256) k_##name(uint32_t* out, int iters) { \
