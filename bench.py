@@ -828,12 +828,12 @@ def cxx_pipelined(dev, idx, batches, genome_words, ng, names, prm, workers, limi
 
 
 def hbm_rich(fmi, dev):
-    """The index the 288 GB of an MI355X are there for: the line-native two-symbol arrays, the match range of every 15-mer (8.6 GB)
-    and the full suffix array (sa_int = 1, 12 GB at 3 Gbp) -- every result stays bit-identical (checked by the callers).  Falls back to
-    k = 12 / sa_int = 4 when less than 64 GB are free."""
+    """The index the 288 GB of an MI355X are there for: the line-native two-symbol arrays, the match range of every 16-mer (34 GB; every
+    15-mer, 8.6 GB, below 120 GB free) and the full suffix array (sa_int = 1, 12 GB at 3 Gbp) -- every result stays bit-identical (checked
+    by the callers).  Falls back to k = 12 / sa_int = 4 when less than 64 GB are free."""
     free_b, _ = torch.cuda.mem_get_info(dev)
     big = free_b > (64 << 30) and fmi.length > (1 << 28)
-    k, sa = (15, 1) if big else (12, 1 if free_b > (24 << 30) else 4)
+    k, sa = (16 if free_b > (120 << 30) else 15, 1) if big else (12, 1 if free_b > (24 << 30) else 4)
     idx = fmi.with_dimer().with_ktab(k).with_dense_ssa(sa)
     desc = {"line_native": True, "ktab_k": k, "ktab_bytes": (4 ** k) * 8, "sa_int": sa, "ssa_bytes": int(idx.ssa.numel()) * 4, "dimer_bytes": int(idx.dimer.numel()) * 4}
     return idx, desc
@@ -1107,7 +1107,22 @@ def full_dp_leg(a, dev):
         ok = bool((score[:m].cpu().numpy() == es).all() and (sink[:m].cpu().numpy().view(np.uint32) == ek).all())
         if not ok:
             raise SystemExit("parity gate failed: full-matrix Gotoh differs from the oracle")
-        res[name] = {"kernel_ms": ms, "GCUPS": n * L * N / (ms * 1e-3) / 1e9, "Mreads_per_s": n / (ms * 1e-3) / 1e6, "parity_checked": m, "bit_exact": ok}
+        res[name] = {"kernel_ms": ms, "GCUPS": n * L * N / (ms * 1e-3) / 1e9, "Mreads_per_s": n / (ms * 1e-3) / 1e6, "parity_checked": m, "bit_exact": ok,
+                     "kernel": nvb.lib().nvbio_hip_last_kernel().decode()}
+        # the same accounting as the headline: cells x 14 nominal ops against the VALU lane-op peak, and the executed count of the committed PMC pass
+        cells = float(n) * L * N
+        roof = {"bound": "valu", "achieved": cells * NOMINAL_OPS_PER_CELL / (ms * 1e-3) / 1e12, "peak": VALU_PEAK_TOPS, "unit": "T lane-op/s",
+                "frac": cells * NOMINAL_OPS_PER_CELL / (ms * 1e-3) / 1e12 / VALU_PEAK_TOPS}
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                pm = json.load(f).get("full_gotoh_score_kernel<%s>" % name)
+        except Exception:
+            pm = None
+        if pm and pm.get("insts_valu_per_launch") and pm.get("cells_per_launch"):
+            per_cell = pm["insts_valu_per_launch"] * 64.0 / pm["cells_per_launch"]
+            roof["executed"] = {"valu_lane_ops_per_cell": per_cell, "achieved": per_cell * cells / (ms * 1e-3) / 1e12,
+                                "frac": per_cell * cells / (ms * 1e-3) / 1e12 / VALU_PEAK_TOPS, "source": "SQ_INSTS_VALU, profiles/traffic.json"}
+        res[name]["roofline"] = roof
     # sw-benchmark's second leg (sw-benchmark.cu:641-657): the same reads, edit distance, SEMI_GLOBAL -- on the bit-vector kernel; "GCUPS" is
     # sw-benchmark's figure (matrix cells / time) although no matrix is filled
     al = nvb.make_edit_distance_aligner(nvb.SEMI_GLOBAL)

@@ -386,7 +386,7 @@ int nvbio_hip_fm_locate_host(const nvbio_hip_fmindex* fmi, const uint32_t* sa_ro
 
 /* Builds the optional k-mer table for `fmi` (fmi->ktab is ignored): out_ktab[2c..2c+1] =
  * match(fmi, kmer c), where kmer c has symbol t (0 = first) at bits [2t,2t+2) of c, for all
- * 4^k codes; 1 <= k <= 15; out_ktab holds 2*4^k words (k=12: 128 MiB, k=14: 2 GiB, k=15: 8 GiB). */
+ * 4^k codes; 1 <= k <= 16; out_ktab holds 2*4^k words (k=12: 128 MiB, k=14: 2 GiB, k=15: 8 GiB, k=16: 32 GiB). */
 int nvbio_hip_fm_build_ktab(const nvbio_hip_fmindex* fmi, uint32_t k, uint32_t* out_ktab, void* stream);
 
 /* nvBowtie's seeding parameters as map_queues_kernel reads them (nvBowtie/bowtie2/cuda/params.h:100-120). */

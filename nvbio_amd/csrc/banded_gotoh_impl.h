@@ -78,7 +78,7 @@ struct A16 {
     static __device__ __forceinline__ T mx(T a, T b)       { T r; asm("v_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
     static __device__ __forceinline__ T mx3(T a, T b, T c) { return mx(mx(a, b), c); }
     static __device__ __forceinline__ T clamp0(T a)        { T r; asm("v_max_i16 %0, 0, %1" : "=v"(r) : "v"(a)); return r; }
-    template <int J> static __device__ __forceinline__ T key(T hi) { T r; asm("v_add_u16 %0, %2, %1" : "=v"(r) : "v"(hi), "s"(J)); return r; }
+    template <int J> static __device__ __forceinline__ T key(T hi) { T r; asm("v_add_u16 %0, %2, %1" : "=v"(r) : "v"(hi), "I"(J)); return r; }
     static __device__ __forceinline__ T cnst(int32_t v)    { return uint32_t(v) & 0xFFFFu; }
     static __device__ __forceinline__ int32_t to_int(T a)  { return int32_t(int16_t(a & 0xFFFFu)); }
     static __device__ __forceinline__ uint32_t bits(T a)   { return a & 0xFFFFu; }
@@ -116,7 +116,7 @@ struct A16 {
                 "v_max_i16 %[e], %[e2], %[hg]\n\t"
                 "v_max_i16 %[rk], %[rk], %[d]"
                 : [f] "=&v"(Fj), [d] "=&v"(d), [h] "=&v"(h), [e2] "=&v"(e2), [hg] "+v"(HGj), [e] "+v"(E), [rk] "+v"(rowkey)
-                : [g] "v"(g), [tlo] "v"(tlo), [thi] "v"(thi), [fn] "v"(Fnext), [ge] "v"(Ge), [hgn] "v"(HGnext), [go] "v"(Go), [sj] "s"(J));
+                : [g] "v"(g), [tlo] "v"(tlo), [thi] "v"(thi), [fn] "v"(Fnext), [ge] "v"(Ge), [hgn] "v"(HGnext), [go] "v"(Go), [sj] "I"(J));
         else if (FAST)
             asm("v_perm_b32 %[d], %[thi], %[tlo], %[g]\n\t"
                 "v_add_u16 %[f], %[fn], %[ge]\n\t"
@@ -144,7 +144,7 @@ struct A16 {
                 "v_max_i16 %[e], %[e2], %[hg]\n\t"
                 "v_max_i16 %[rk], %[rk], %[d]"
                 : [f] "=&v"(Fj), [d] "=&v"(d), [h] "=&v"(h), [e2] "=&v"(e2), [hg] "+v"(HGj), [e] "+v"(E), [rk] "+v"(rowkey)
-                : [g] "v"(g), [q] "v"(q), [fn] "v"(Fnext), [ge] "v"(Ge), [sx] "v"(sX), [sm] "v"(sM), [hgn] "v"(HGnext), [go] "v"(Go), [sj] "s"(J)
+                : [g] "v"(g), [q] "v"(q), [fn] "v"(Fnext), [ge] "v"(Ge), [sx] "v"(sX), [sm] "v"(sM), [hgn] "v"(HGnext), [go] "v"(Go), [sj] "I"(J)
                 : "vcc");
         else
             asm("v_cmp_eq_u32 vcc, %[g], %[q]\n\t"

@@ -52,19 +52,22 @@ fm_rank_range_kernel(const Fmi f, const uint2* __restrict__ range, const uint8_t
 
 // one lane = one k-mer code: its match range, by the plain search (the table is ignored)
 __global__ void __launch_bounds__(256)
-fm_build_ktab_kernel(const Fmi f, uint32_t k, uint32_t n_codes, uint2* __restrict__ out)
+fm_build_ktab_kernel(const Fmi f, uint32_t k, uint64_t n_codes, uint2* __restrict__ out)
 {
-    const uint32_t code = blockIdx.x * 256u + threadIdx.x;
-    if (code >= n_codes) return;
-    uint32_t x = 0, y = f.length;
-    for (int32_t t = int32_t(k) - 1; t >= 0 && x <= y; --t)
+    // (grid-stride: k = 16 has 2^32 codes, more than one launch may hold threads)
+    for (uint64_t code64 = uint64_t(blockIdx.x) * 256u + threadIdx.x; code64 < n_codes; code64 += uint64_t(gridDim.x) * 256u)
     {
-        const uint32_t c = (code >> (2u * uint32_t(t))) & 3u;
-        const uint2 r = fm_rank2(f, x - 1u, y, c);
-        x = f.L2[c] + r.x + 1u;
-        y = f.L2[c] + r.y;
+        const uint32_t code = uint32_t(code64);
+        uint32_t x = 0, y = f.length;
+        for (int32_t t = int32_t(k) - 1; t >= 0 && x <= y; --t)
+        {
+            const uint32_t c = (code >> (2u * uint32_t(t))) & 3u;
+            const uint2 r = fm_rank2(f, x - 1u, y, c);
+            x = f.L2[c] + r.x + 1u;
+            y = f.L2[c] + r.y;
+        }
+        out[code64] = make_uint2(x, y);
     }
-    out[code] = make_uint2(x, y);
 }
 
 __global__ void __launch_bounds__(256)
@@ -227,12 +230,12 @@ NVB_API int nvbio_hip_fm_match(const nvbio_hip_fmindex* fmi, const nvbio_hip_str
 
 NVB_API int nvbio_hip_fm_build_ktab(const nvbio_hip_fmindex* fmi, uint32_t k, uint32_t* out_ktab, void* stream)
 {
-    if (!fmi || !fmi->bwt_occ || !out_ktab || k < 1 || k > 15) return hipErrorInvalidValue;      // 4^15 entries = 8.6 GB; the code space must fit uint32
+    if (!fmi || !fmi->bwt_occ || !out_ktab || k < 1 || k > 16) return hipErrorInvalidValue;      // 4^15 entries = 8.6 GB, 4^16 = 34 GB; a code is a uint32
     Fmi f = make_fmi(fmi);
     f.ktab = nullptr; f.ktab_k = 0;
-    const uint32_t n_codes = 1u << (2u * k);
+    const uint64_t n_codes = 1ull << (2u * k);
     g_last_kernel = "fm_build_ktab_kernel";
-    hipLaunchKernelGGL(fm_build_ktab_kernel, grid_for(n_codes), dim3(256), 0, to_stream(stream), f, k, n_codes, reinterpret_cast<uint2*>(out_ktab));
+    hipLaunchKernelGGL(fm_build_ktab_kernel, grid_for(std::min<uint64_t>(n_codes, 1ull << 30)), dim3(256), 0, to_stream(stream), f, k, n_codes, reinterpret_cast<uint2*>(out_ktab));
     return hipGetLastError();
 }
 

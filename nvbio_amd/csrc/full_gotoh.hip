@@ -253,7 +253,7 @@ __device__ __forceinline__ void cell16(uint32_t& e, uint32_t& hlg, uint32_t& hab
             "v_max_i16 %[bk], %[bk], %[d]"
             : [f] "=&v"(f), [d] "=&v"(d), [h] "=&v"(h), [t] "=&v"(t), [e] "+v"(e), [bk] "+v"(bk)
             : [ch] "v"(ch), [tlo] "v"(tlo), [thi] "v"(thi), [fab] "v"(fab), [ge] "v"(ge), [hab] "v"(hab_g), [dg] "v"(diag_g), [go] "v"(go), [hl] "v"(hlg),
-              [s15] "s"(s15));
+              [s15] "v"(s15));       // (a VGPR: VOP2 with an SGPR source issues at half rate, 4.2 against 2.3 cycles)
     else
         asm("v_perm_b32 %[d], %[thi], %[tlo], %[ch]\n\t"
             "v_add_u16 %[f], %[fab], %[ge]\n\t"
@@ -274,8 +274,8 @@ __device__ __forceinline__ uint32_t max16u(uint32_t a, uint32_t b) { uint32_t r;
 __device__ __forceinline__ uint32_t min16u(uint32_t a, uint32_t b) { uint32_t r; asm("v_min_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 // MULTI: several jobs share the wave (full_gotoh_score_multi_kernel): the wave is cut in segments of `W` lanes, segment j sweeps job j,
-// and `lane` is the lane's index INSIDE its segment.  The hand-off between lanes is one instruction per value for every shape:
-// v_cndmask_b32 with a wave_shr:1 DPP source and the mask of the segments' first lanes in VCC -- a first lane takes the row above its
+// and `lane` is the lane's index INSIDE its segment.  The hand-off between lanes is the same two instructions per value for every shape:
+// a wave_shr:1 DPP move and a select on the mask of the segments' first lanes -- a first lane takes the row above its
 // matrix (H(-1, c) + G_o, F = infimum, the text symbol of column c of ITS job, an empty column maximum), every other lane what the lane
 // above computed one step ago.  Everything a job owns (M, Ncols, lane_last, klast ...) is a per-lane value, and the loop bounds are the
 // wave's maxima / minima.
@@ -372,7 +372,9 @@ struct Sweep16
         const uint32_t th = (TYPE == NVBIO_HIP_GLOBAL) ? top_hg : go;          // HG(-1,c) for a first lane
         // The hand-off: in = first lane ? (row above the matrix) : (the lane above's out).  One VOP2 each -- the DPP source shifts, the
         // select takes the first lanes' mask from VCC -- where a DPP move into a register preset with the first lane's value costs two and
-        // knows lane 0 only.  out_hg is the register the step before wrote last: it is read last (a DPP source needs two wait states).
+        // knows lane 0 only.  (In isolation v_cndmask_b32_dpp on VCC measures 22.7 issue cycles against 6.9 for a DPP move + an e64 select
+        // on an SGPR mask, profiles/r03/valu_probe.txt; inside this sweep the order is the other way round, 3.73 against 3.54 TCUPS.)
+        // out_hg is the register the step before wrote last: it is read last (a DPP source needs two wait states, nothing inserts them here).
         uint32_t in_hg, in_f, in_ch, in_cm = 0u;
         if (CHECK)
             asm("s_mov_b64 vcc, %[m]\n\t"

@@ -222,7 +222,8 @@ int nvbio_aligner_best_approx_pipelined(const nvbio_hip_fmindex* fmi, const nvbi
             for (uint32_t w = 0; w < n_workers; ++w) th.emplace_back(worker, w);
             for (auto& t : th) t.join();
         };
-        pass();                                            // warm-up: every worker's workspace reaches its final size
+        pass();                                            // warm-up: every worker's workspace reaches its final size ...
+        if (n_batches < 2u * n_workers) pass();            // ... and is merged into one block, which happens at a worker's SECOND batch
         hip::synchronize();
         double total = 0.0;
         for (uint32_t r = 0; r < reps; ++r)

@@ -344,7 +344,7 @@ def test_full_size_rank_properties(cuda, genome_3gbp):
     assert [int(x) for x in last] == [fmi.L2[i + 1] - fmi.L2[i] for i in range(4)]
 
 
-@pytest.mark.parametrize("flavour", ["reference_layout", "line_native", "line_native_ktab12"])
+@pytest.mark.parametrize("flavour", ["reference_layout", "line_native", "line_native_ktab12", "line_native_ktab16"])
 def test_full_size_match_and_locate(cuda, genome_3gbp, flavour):
     """BASELINE config 3-ii at its own size: >= 1 M 22-bp seeds (90 % drawn from the genome) on the 3 Gbp index, match ranges
     and located positions against the oracle on a host copy -- for the reference layout and for the line-native index."""
@@ -352,6 +352,10 @@ def test_full_size_match_and_locate(cuda, genome_3gbp, flavour):
     idx = fmi if flavour == "reference_layout" else fmi.with_dimer()
     if flavour.endswith("ktab12"):
         idx = idx.with_ktab(12)
+    if flavour.endswith("ktab16"):                       # 2^32 codes, 34 GB: the largest table (a code is a uint32)
+        if torch.cuda.mem_get_info(cuda)[0] < (48 << 30):
+            pytest.skip("needs 34 GB for the table")
+        idx = idx.with_ktab(16)
     seeds = W.make_seeds(text, 1_200_000, 22)
     ranges = nvb.match(idx, seeds)
     exp = host.match(O.StringSet.from_device(seeds), n_threads=0)

@@ -66,7 +66,17 @@
   X(mad_u32_u24,  "v_mad_u32_u24 %0, %0, %1, %1") \
   X(s_nop_add,    "s_nop 0\n v_add_u16 %0, %0, %1") \
   X(add_u16_sgpr, "v_add_u16 %0, s10, %0") \
-  X(smov_add,     "s_mov_b64 vcc, s[10:11]\n v_add_u16 %0, %0, %1")
+  X(smov_add,     "s_mov_b64 vcc, s[10:11]\n v_add_u16 %0, %0, %1") \
+  X(max_i16_inl0, "v_max_i16 %0, 0, %0") \
+  X(add_u16_inl7, "v_add_u16 %0, 7, %0") \
+  X(max_i16_sgpr, "v_max_i16 %0, s10, %0") \
+  X(perm_sgpr,    "v_perm_b32 %0, %0, %1, s10") \
+  X(mov_dpp_rshl, "v_mov_b32_dpp %0, %1 row_shl:3 row_mask:0xf bank_mask:0xf bound_ctrl:0") \
+  X(and_lit,      "v_and_b32 %0, 0x30000, %0") \
+  X(mul_u32_u24,  "v_mul_u32_u24 %0, %0, %1") \
+  X(lshl_or,      "v_lshl_or_b32 %0, %0, 3, %1") \
+  X(add_lshl,     "v_add_lshl_u32 %0, %0, %1, 1") \
+  X(add3,         "v_add3_u32 %0, %0, %1, %1")
 
 #define X(name, str) \
 __global__ void __launch_bounds__(256) k_##name(uint32_t* out, int iters) { \
