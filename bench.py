@@ -831,6 +831,7 @@ def hbm_rich(fmi, dev):
     """The index the 288 GB of an MI355X are there for: the line-native two-symbol arrays, the match range of every 16-mer (34 GB; every
     15-mer, 8.6 GB, below 120 GB free) and the full suffix array (sa_int = 1, 12 GB at 3 Gbp) -- every result stays bit-identical (checked
     by the callers).  Falls back to k = 12 / sa_int = 4 when less than 64 GB are free."""
+    torch.cuda.empty_cache()                   # (what torch's allocator has cached counts as free)
     free_b, _ = torch.cuda.mem_get_info(dev)
     big = free_b > (64 << 30) and fmi.length > (1 << 28)
     k, sa = (16 if free_b > (120 << 30) else 15, 1) if big else (12, 1 if free_b > (24 << 30) else 4)

@@ -39,8 +39,11 @@ struct SelectParamsPOD
 struct SelectState
 {
     SelectState(const uint32 n_reads, const uint32 hits_stride) :
-        probs_stride(nvbio_hip_sum_tree_node_count(hits_stride)), probs(size_t(n_reads) * nvbio_hip_sum_tree_node_count(hits_stride)),
+        probs_stride(row_pitch(nvbio_hip_sum_tree_node_count(hits_stride))), probs(size_t(n_reads) * row_pitch(nvbio_hip_sum_tree_node_count(hits_stride))),
         trys(n_reads), rseeds(n_reads) {}
+    /// A tree row starts on a 128-byte line: the 31 nodes of a 16-hit deque then sit in ONE line instead of straddling two (the selection
+    /// stage is bound by the lines it moves, profiles/r03/select_coop.txt); larger trees are padded to whole lines alike.
+    static uint32 row_pitch(const uint32 nodes) { return (nodes + 31u) & ~31u; }
     uint32 probs_stride;
     hip::device_vector<float>  probs;
     hip::device_vector<uint32> trys, rseeds;

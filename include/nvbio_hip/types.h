@@ -42,6 +42,8 @@ struct hip_error : public std::runtime_error {
     hip_error(const char* what, int c) : std::runtime_error(std::string(what) + " failed, hipError " + std::to_string(c)), code(c) {}
 };
 inline void hip_check(int err, const char* what) { if (err != 0) throw hip_error(what, err); }
+/// a failed allocation says how much was asked for (an out-of-memory report without the size is useless to whoever sizes the batches)
+inline void hip_check_alloc(int err, unsigned long long bytes) { if (err != 0) throw hip_error(("nvbio_hip_device_malloc(" + std::to_string(bytes) + " bytes)").c_str(), err); }
 
 namespace hip {
 
@@ -52,40 +54,45 @@ namespace hip {
 /// their storage from the arena and never free it; reset() rewinds, and after the first batch the arena is one block.
 struct device_arena
 {
-    device_arena() : used(0) {}
+    device_arena() : used(0), taken(0) {}
     ~device_arena() { for (size_t i = 0; i < blocks.size(); ++i) nvbio_hip_device_free(blocks[i].first); }
     device_arena(const device_arena&) = delete;
     device_arena& operator=(const device_arena&) = delete;
     void* take(uint64 bytes)
     {
         bytes = (bytes + 255u) & ~uint64(255);
+        taken += bytes;
         if (blocks.empty() || used + bytes > blocks.back().second)
         {
+            // a new block: as large as everything so far (few blocks for a large first batch), but never more than 4 GiB beyond the request
             uint64 total = 0; for (size_t i = 0; i < blocks.size(); ++i) total += blocks[i].second;
-            const uint64 want = std::max<uint64>(bytes, std::max<uint64>(total, uint64(64) << 20));
+            const uint64 step = std::min<uint64>(std::max<uint64>(total, uint64(64) << 20), uint64(4) << 30);
+            const uint64 want = std::max<uint64>(bytes, step);
             void* p = nullptr;
-            hip_check(nvbio_hip_device_malloc(&p, want), "nvbio_hip_device_malloc");
+            hip_check_alloc(nvbio_hip_device_malloc(&p, want), want);
             blocks.push_back(std::make_pair(p, want)); used = 0;
         }
         void* r = static_cast<uint8*>(blocks.back().first) + used;
         used += bytes;
         return r;
     }
-    /// rewind; several blocks (the arena grew during the last batch) are replaced by one of their total size
+    /// rewind; several blocks (the arena grew during the last batch) are replaced by ONE sized by what that batch took plus an eighth --
+    /// not by the blocks' capacities, which would double the arena every time a batch needs a little more than the one before
     void reset()
     {
         if (blocks.size() > 1)
         {
-            uint64 total = 0; for (size_t i = 0; i < blocks.size(); ++i) { total += blocks[i].second; nvbio_hip_device_free(blocks[i].first); }
+            for (size_t i = 0; i < blocks.size(); ++i) nvbio_hip_device_free(blocks[i].first);
             blocks.clear();
+            const uint64 size = ((taken + taken / 8u) + (uint64(64) << 20) - 1u) & ~((uint64(64) << 20) - 1u);
             void* p = nullptr;
-            hip_check(nvbio_hip_device_malloc(&p, total), "nvbio_hip_device_malloc");
-            blocks.push_back(std::make_pair(p, total));
+            hip_check_alloc(nvbio_hip_device_malloc(&p, size), size);
+            blocks.push_back(std::make_pair(p, size));
         }
-        used = 0;
+        used = 0; taken = 0;
     }
     std::vector<std::pair<void*, uint64> > blocks;
-    uint64 used;
+    uint64 used, taken;             // bytes handed out of the last block / of all blocks since the last reset
 };
 inline device_arena*& current_arena() { static thread_local device_arena* a = nullptr; return a; }
 struct arena_scope
@@ -113,7 +120,7 @@ struct device_vector {
         m_ptr = nullptr;
         if (current_arena() && (m_in_arena || m_size == 0)) { m_ptr = static_cast<T*>(current_arena()->take(uint64(n ? n : 1) * sizeof(T))); m_in_arena = true; m_size = n; return; }
         void* p = nullptr;
-        hip_check(nvbio_hip_device_malloc(&p, uint64(n) * sizeof(T)), "nvbio_hip_device_malloc");
+        hip_check_alloc(nvbio_hip_device_malloc(&p, uint64(n) * sizeof(T)), uint64(n) * sizeof(T));
         m_ptr = static_cast<T*>(p); m_size = n; m_in_arena = false;
     }
     /// (copies go through `stream`: a driver that shares its device with other host threads must not touch the NULL stream, which
