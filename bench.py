@@ -87,7 +87,7 @@ def parse():
     ap.add_argument("--genome", type=float, default=3.0e9, help="synthetic genome length of the FM-index legs (a true index is built on the device)")
     ap.add_argument("--rank-queries", type=int, default=1 << 28)
     ap.add_argument("--no-rank", action="store_true")
-    ap.add_argument("--only", choices=["dp", "rank", "seed", "e2e", "full", "extras"], default=None, help="profiling aid: run just one leg, print its object")
+    ap.add_argument("--only", choices=["dp", "rank", "seed", "e2e", "full", "extras", "compat"], default=None, help="profiling aid: run just one leg, print its object")
     ap.add_argument("--seeds", type=int, default=50_000_000)
     ap.add_argument("--pairs", type=int, default=500_000, help="read pairs of the paired-end driver leg inside the e2e leg (0 = skip)")
     ap.add_argument("--share-pairs", type=int, default=25_000_000, help="config 5 at one GPU's share of 200 M pairs over 8 GPUs (0 = skip); runs in batches of --pairs")
@@ -137,6 +137,9 @@ def main():
         return
     if a.only == "full":
         print(json.dumps({"full_dp_leg": full_dp_leg(a, dev)}))
+        return
+    if a.only == "compat":
+        print(json.dumps({"compat_stream_leg": compat_stream_leg(a, dev)}))
         return
     if a.only in ("rank", "seed", "e2e"):
         a.no_seed = a.only != "seed"

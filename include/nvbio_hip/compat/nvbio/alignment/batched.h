@@ -234,13 +234,19 @@ template <typename P> struct pattern_where<P, false> {
     static const uint32 BITS = 4u; static const bool BE = false;
     NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static void get(const P&, uint64& w, uint32& f) { w = 0; f = 0; } };
 
-/// evaluate the stream's functors per job: where its strings live, how long they are, its min_score; a staged stream also has its
-/// pattern (and qualities) read through its own iterators into the scratch
+/// evaluate the stream's functors per job: where its strings live, how long they are, its min_score.  A staged stream also has its
+/// pattern (and qualities) read through its own iterators into the scratch, as 4-bit little-endian words and a byte per quality: then
+/// SIXTEEN lanes work on a job, eight symbols = one word per lane and turn, so that a job's row is written in contiguous pieces (one lane
+/// per job writes 38 scattered words per 100-bp read and is bound by exactly that: 12 of 14.7 ms per 10 M jobs).  Every one of the sixteen
+/// evaluates the stream's context -- the same addresses in all of them, so no more lines move; the views a stream hands out may point into
+/// the lane's own context (nvBowtie's loaders cache words there), so they cannot be passed between lanes.
 template <typename stream_type, typename R>
 __global__ void __launch_bounds__(128) describe_jobs_kernel(const stream_type stream, const job_table t)
 {
     typedef pattern_where<typename R::pattern_type, !R::staged> pwhere;
-    const uint32 i = blockIdx.x * 128u + threadIdx.x;
+    constexpr uint32 G = R::staged ? 16u : 1u;                       // lanes per job
+    const uint32 gt = blockIdx.x * 128u + threadIdx.x;
+    const uint32 i = gt / G, j = gt % G;
     unsigned long long plo = ~0ull, phi = 0ull, tlo = ~0ull, thi = 0ull;
     if (i < stream.size())
     {
@@ -263,7 +269,7 @@ __global__ void __launch_bounds__(128) describe_jobs_kernel(const stream_type st
                 else
                 {
                     uint32* w = t.stage_words + uint64(i) * (t.stage_stride / 8u);
-                    for (uint32 k0 = 0; k0 < pl; k0 += 8u)
+                    for (uint32 k0 = 8u * j; k0 < pl; k0 += 8u * G)
                     {
                         uint32 word = 0;
                         for (uint32 k = 0; k < 8u; ++k) if (k0 + k < pl) word |= (uint32(strings.pattern[k0 + k]) & 15u) << (4u * k);
@@ -272,7 +278,7 @@ __global__ void __launch_bounds__(128) describe_jobs_kernel(const stream_type st
                     if (R::stage_quals)
                     {
                         uint32* qw = reinterpret_cast<uint32*>(t.stage_quals + uint64(i) * t.stage_stride);
-                        for (uint32 k0 = 0; k0 < pl; k0 += 4u)
+                        for (uint32 k0 = 4u * j; k0 < pl; k0 += 4u * G)
                         {
                             uint32 word = 0;
                             for (uint32 k = 0; k < 4u; ++k) if (k0 + k < pl) word |= uint32(uint8(strings.quals[k0 + k])) << (8u * k);
@@ -284,14 +290,20 @@ __global__ void __launch_bounds__(128) describe_jobs_kernel(const stream_type st
             else { plo = pw; phi = pw + (pf + pl + 32u / pwhere::BITS - 1u) / (32u / pwhere::BITS); }
         }
         // offsets are kept absolute (symbols from address 0) until the host knows the lowest word
-        t.pat_begin[i] = R::staged ? uint64(i) * t.stage_stride : pw * (32u / pwhere::BITS) + pf; t.pat_len[i] = pl;
-        t.txt_begin[i] = tw * 16u + tf; t.txt_len[i] = tl; t.min_score[i] = ms;
+        if (j == 0u)
+        {
+            t.pat_begin[i] = R::staged ? uint64(i) * t.stage_stride : pw * (32u / pwhere::BITS) + pf; t.pat_len[i] = pl;
+            t.txt_begin[i] = tw * 16u + tf; t.txt_len[i] = tl; t.min_score[i] = ms;
+        }
     }
     plo = wave_min(plo); phi = wave_max(phi); tlo = wave_min(tlo); thi = wave_max(thi);
     if ((threadIdx.x & 63u) == 0u)
     {
-        if (phi) { atomicMin(&t.bounds[0], plo); atomicMax(&t.bounds[1], phi); }
-        if (thi) { atomicMin(&t.bounds[2], tlo); atomicMax(&t.bounds[3], thi); }
+        // (a wave that cannot move a bound skips the atomic: after the first waves almost all can, and 2.5 M waves hammering four
+        // addresses cost 50 ms)
+        const volatile unsigned long long* b = t.bounds;
+        if (phi) { if (plo < b[0]) atomicMin(&t.bounds[0], plo); if (phi > b[1]) atomicMax(&t.bounds[1], phi); }
+        if (thi) { if (tlo < b[2]) atomicMin(&t.bounds[2], tlo); if (thi > b[3]) atomicMax(&t.bounds[3], thi); }
     }
 }
 __global__ void __launch_bounds__(256) rebase_jobs_kernel(const uint32 n, uint64* pat_begin, const uint64 pat_delta, uint64* txt_begin, const uint64 txt_delta)
@@ -365,7 +377,7 @@ inline void build_job_table(const stream_type& stream, device_buffer& buf, job_t
     }
     if (extra) *extra = base + table + stage;
     hipLaunchKernelGGL(init_bounds_kernel, dim3(1), dim3(64), 0, hs, t.bounds);
-    hipLaunchKernelGGL((describe_jobs_kernel<stream_type, R>), dim3((n + 127u) / 128u), dim3(128), 0, hs, stream, t);
+    hipLaunchKernelGGL((describe_jobs_kernel<stream_type, R>), dim3(uint32((uint64(n) * (R::staged ? 16u : 1u) + 127u) / 128u)), dim3(128), 0, hs, stream, t);
     unsigned long long b[4];
     check(hipMemcpyAsync(b, t.bounds, sizeof(b), hipMemcpyDeviceToHost, hs), "hipMemcpyAsync");
     check(hipStreamSynchronize(hs), "hipStreamSynchronize");
