@@ -436,9 +436,10 @@ score_best_setup_kernel(uint32_t n, const uint32_t* __restrict__ hit_read_id, co
                         uint32_t* __restrict__ job_count, uint32_t* __restrict__ job_hit)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t r = hit_read_id[i], g = hit_loc[i];
-    const uint32_t len = read_len ? read_len[r] : fixed_len;
+    __shared__ uint32_t wave_need[4], block_base;
+    const bool live = i < n;
+    const uint32_t r = live ? hit_read_id[i] : 0u, g = live ? hit_loc[i] : 0u;
+    const uint32_t len = live ? (read_len ? read_len[r] : fixed_len) : 0u;
     const uint32_t gb = g > band_len / 2u ? g - band_len / 2u : 0u;
     const uint32_t sum = gb + band_len + len;
     const uint32_t ge = sum < genome_len ? sum : genome_len;
@@ -446,31 +447,43 @@ score_best_setup_kernel(uint32_t n, const uint32_t* __restrict__ hit_read_id, co
     // score is the recorded one: hand that score to the reduction instead (which usually skips the hit anyway, reduce_inl.h:111-114) and
     // give the job an empty window.  Most seeds of a read point at one placement, so this removes most of the extension work.
     int32_t known = INT32_MIN;
-    if (known_score) {
-        const uint32_t rc = (hit_seed[i] >> 13) & 1u;
-        const uint2 a1 = best[r], a2 = best[r + best_stride];
-        if (((a1.x >> 28) & 1u) == rc && a1.y == g)      { const int32_t m = int32_t((a1.x >> 1) & 0x1FFFFu); known = (a1.x & 1u) ? -m : m; }
-        else if (((a2.x >> 28) & 1u) == rc && a2.y == g) { const int32_t m = int32_t((a2.x >> 1) & 0x1FFFFu); known = (a2.x & 1u) ? -m : m; }
-        known_score[i] = known;
+    const uint32_t seed = live ? hit_seed[i] : 0u;
+    uint32_t w2 = 0u;
+    if (live) {
+        const uint2 a2 = best[r + best_stride];
+        w2 = a2.x;
+        if (known_score) {
+            const uint32_t rc = (seed >> 13) & 1u;
+            const uint2 a1 = best[r];
+            if (((a1.x >> 28) & 1u) == rc && a1.y == g)      { const int32_t m = int32_t((a1.x >> 1) & 0x1FFFFu); known = (a1.x & 1u) ? -m : m; }
+            else if (((a2.x >> 28) & 1u) == rc && a2.y == g) { const int32_t m = int32_t((a2.x >> 1) & 0x1FFFFu); known = (a2.x & 1u) ? -m : m; }
+            known_score[i] = known;
+        }
     }
-    // compacted form: only the hits that still need a DP become jobs, job_hit[slot] = the hit (one atomic per wavefront; the slot
-    // order varies from run to run, the scores scattered back through job_hit do not)
+    // compacted form: only the hits that still need a DP become jobs, job_hit[slot] = the hit.  One atomic per BLOCK (the waves' counts
+    // meet in LDS): one per wavefront made 156 k same-address atomics per 10 M hits, which is what the kernel then waited for.  The slot
+    // order varies from run to run, the scores scattered back through job_hit do not.
     uint32_t o = i;
+    bool write = live;
     if (job_hit) {
-        const bool need = known == INT32_MIN;
+        const bool need = live && known == INT32_MIN;
         const uint64_t m = __ballot(need);
-        if (!need) return;
-        const uint32_t lane = __lane_id(), leader = uint32_t(__ffsll((long long)m)) - 1u;
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(job_count, uint32_t(__popcll(m)));
-        o = __shfl(base, int(leader)) + uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
-        job_hit[o] = i;
+        const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+        if (lane == 0u) wave_need[wv] = uint32_t(__popcll(m));
+        __syncthreads();
+        if (threadIdx.x == 0u) { const uint32_t tot = wave_need[0] + wave_need[1] + wave_need[2] + wave_need[3]; block_base = tot ? atomicAdd(job_count, tot) : 0u; }
+        __syncthreads();
+        uint32_t base = block_base;
+        for (uint32_t k = 0; k < wv; ++k) base += wave_need[k];
+        o = base + uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
+        write = need;
+        if (need) job_hit[o] = i;
     }
+    if (!write) return;
     text_begin[o] = gb;
     text_len[o] = (ge > gb && known == INT32_MIN) ? ge - gb : 0u;                // (a wrapped read start: empty window, the alignment fails)
-    pat_begin[o] = (read_begin ? read_begin[r] : uint64_t(r) * fixed_len) + (((hit_seed[i] >> 13) & 1u) ? rc_offset : 0ull);
+    pat_begin[o] = (read_begin ? read_begin[r] : uint64_t(r) * fixed_len) + (((seed >> 13) & 1u) ? rc_offset : 0ull);
     if (pat_len) pat_len[o] = len;
-    const uint32_t w2 = best[r + best_stride].x;
     const int32_t m2 = int32_t((w2 >> 1) & 0x1FFFFu), s2 = (w2 & 1u) ? -m2 : m2;
     min_score[o] = s2 > score_limit ? s2 : score_limit;
 }
