@@ -229,10 +229,9 @@ __global__ __launch_bounds__(256) void banded_traceback_diagonal_kernel(const Tr
     {
         // 16 rows per fetch (one 64-bit group of read symbols, one of text symbols); quality bytes only where symbols differ
         int32_t c = 0;
-        for (int32_t c0 = int32_t((by - 1u) & ~15u); c0 >= 0 && !found; c0 -= 16)
+        // qv = the group's 16 quality bytes when they were fetched ahead (have_q), else they are read where symbols differ
+        auto walk_group = [&](const int32_t c0, const uint64_t pq, const uint64_t tg, const uint4 qv, const bool have_q)
         {
-            const uint64_t pq = (p.pat.s.bits == 2) ? expand_2to4(fetch16_2bit(p.pat.s, pb + uint32_t(c0))) : fetch16_4bit(p.pat.s, pb + uint32_t(c0));
-            const uint64_t tg = expand_2to4(fetch16_2bit(p.txt.s, tb + uint32_t(c0) + j));
             for (int32_t k = min(15, int32_t(by) - 1 - c0); k >= 0; --k)
             {
                 const uint32_t i = uint32_t(c0 + k), idx = i + j;
@@ -240,11 +239,58 @@ __global__ __launch_bounds__(256) void banded_traceback_diagonal_kernel(const Tr
                 uint32_t g = uint32_t(tg >> (4 * k)) & 15u;
                 if (!(idx + 2u <= band || idx < N)) g = (j == band - 1u) ? 255u : (quirk ? 3u : 255u);     // (the initial cache load is not range checked)
                 int32_t sc = p.match;
-                if (g != q) sc = mm[p.quals ? p.quals[min(pb + i, p.n_quals - 1)] : 0u];
+                if (g != q)
+                {
+                    uint32_t qual = 0u;
+                    if (have_q) { const uint32_t w = k < 8 ? (k < 4 ? qv.x : qv.y) : (k < 12 ? qv.z : qv.w); qual = (w >> (8u * (uint32_t(k) & 3u))) & 255u; }
+                    else if (p.quals) qual = p.quals[min(pb + i, p.n_quals - 1)];
+                    sc = mm[qual];
+                }
                 c += sc;
                 if (TYPE == NVBIO_HIP_LOCAL && c == best) { found = true; t = i; break; }
             }
+        };
+        auto load_p = [&](const int32_t c0) { return (p.pat.s.bits == 2) ? expand_2to4(fetch16_2bit(p.pat.s, pb + uint32_t(c0))) : fetch16_4bit(p.pat.s, pb + uint32_t(c0)); };
+        auto load_t = [&](const int32_t c0) { return expand_2to4(fetch16_2bit(p.txt.s, tb + uint32_t(c0) + j)); };
+        const uint4 no_q = make_uint4(0u, 0u, 0u, 0u);
+        if (by <= 128u && p.pat.s.bits == 4u && !p.pat.s.lds && !p.txt.s.lds)
+        {
+            // Reads up to 128 rows (4-bit patterns in HBM): every word the walk will touch -- read symbols, window symbols, quality bytes -- is
+            // requested BEFORE the walk starts, as independent loads with nothing but address arithmetic between them.  Fetching a group per
+            // turn of the walk re-requests the read's and the window's lines once per group (between two turns of a lane the other 500 k
+            // resident lanes have pushed them out of L2: 15 fabric requests per read, 55 G/s), and a quality byte fetched where symbols differ
+            // puts a memory round trip into nearly every row of a wave (some lane of 64 differs in 93 % of the rows at 4 % error).
+            typedef uint4 __attribute__((aligned(1))) uint4_u;
+            const int32_t g_top = int32_t((by - 1u) >> 4);
+            const bool have_q = p.quals != nullptr && pb + 16u * uint64_t(g_top) + 16u <= p.n_quals;
+            const uint64_t pk = pb >> 3, tk = (tb + j) >> 4;
+            const uint32_t psh = (uint32_t(pb) & 7u) << 2, tsh = (uint32_t(tb + j) & 15u) << 1;
+            const uint64_t pn = p.pat.s.n_words - 1u, tn = p.txt.s.n_words - 1u;
+            uint32_t pw[17], tw[9]; uint4 qv[8];
+            #pragma unroll
+            for (int k = 0; k < 17; ++k) { pw[k] = 0u; if (k <= 2 * g_top + 2) pw[k] = p.pat.s.words[min(pk + uint32_t(k), pn)]; }
+            #pragma unroll
+            for (int k = 0; k < 9; ++k)  { tw[k] = 0u; if (k <= g_top + 1) tw[k] = p.txt.s.words[min(tk + uint32_t(k), tn)]; }
+            #pragma unroll
+            for (int gi = 0; gi < 8; ++gi) { qv[gi] = no_q; if (have_q && gi <= g_top) qv[gi] = *reinterpret_cast<const uint4_u*>(p.quals + pb + 16u * uint32_t(gi)); }
+            if (p.pat.s.big_endian) {
+                #pragma unroll
+                for (int k = 0; k < 17; ++k) pw[k] = rev4(pw[k]);
+            }
+            if (p.txt.s.big_endian) {
+                #pragma unroll
+                for (int k = 0; k < 9; ++k) tw[k] = rev2(tw[k]);
+            }
+            #pragma unroll
+            for (int gi = 7; gi >= 0; --gi)
+                if (gi <= g_top && !found)
+                {
+                    const uint64_t pq = (uint64_t(funnel(pw[2 * gi + 1], pw[2 * gi + 2], psh)) << 32) | funnel(pw[2 * gi], pw[2 * gi + 1], psh);
+                    walk_group(gi * 16, pq, expand_2to4(funnel(tw[gi], tw[gi + 1], tsh)), qv[gi], have_q);
+                }
         }
+        else
+            for (int32_t c0 = int32_t((by - 1u) & ~15u); c0 >= 0 && !found; c0 -= 16) walk_group(c0, load_p(c0), load_t(c0), no_q, false);
         if (TYPE != NVBIO_HIP_LOCAL) {
             const int32_t init = (TYPE == NVBIO_HIP_GLOBAL && j != 0u) ? p.txt_gap_open + int32_t(j - 1u) * p.txt_gap_ext : 0;
             found = (c + init == best);

@@ -60,6 +60,8 @@ def main():
             idx = idx.with_ktab(15 if ng > (1 << 28) else 12).with_dense_ssa(1)
         if flavour == "hbm_rich_k16":                        # the match range of every 16-mer (34 GB)
             idx = idx.with_ktab(16).with_dense_ssa(1)
+        if flavour == "hbm_rich_k16_trimer":
+            idx = idx.with_trimer().with_ktab(16).with_dense_ssa(1)
         if flavour == "hbm_rich_trimer":                     # + the three-symbol rank arrays (32 GB at 3 Gbp)
             idx = idx.with_trimer().with_ktab(15 if ng > (1 << 28) else 12).with_dense_ssa(1)
         fs = idx.struct()
