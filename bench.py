@@ -1001,6 +1001,16 @@ def seed_leg(a, dev, fmi, text, build_s):
     dk_ms = timed(lambda: nvb.match(fdk, seeds, out=r2))
     line_native["match_ktab12"] = {"kernel_ms": dk_ms, "Mseeds_per_s": a.seeds / (dk_ms * 1e-3) / 1e6, "identical": bool(torch.equal(r2, ranges))}
     del fdk
+    # the largest table (every 16-mer, 34 GB): a 22-bp seed is one look-up + three two-symbol steps.  A seed is then ~4 fabric requests, so the
+    # figure that says how close the kernel is to the chip is requests/s against the measured random-request rate (~53 G/s), not bytes against HBM
+    torch.cuda.empty_cache()
+    if torch.cuda.mem_get_info(dev)[0] > (48 << 30) and ng > (1 << 28):
+        fdk = fdim.with_ktab(16)
+        dk_ms = timed(lambda: nvb.match(fdk, seeds, out=r2))
+        rate = a.seeds / (dk_ms * 1e-3)
+        line_native["match_ktab16"] = {"kernel_ms": dk_ms, "Mseeds_per_s": rate / 1e6, "table_bytes": int(fdk.ktab.numel()) * 4, "identical": bool(torch.equal(r2, ranges)),
+                                       "fabric_requests_per_seed_model": 4, "G_requests_per_s": 4 * rate / 1e9, "frac_of_random_request_rate": 4 * rate / 53e9}
+        del fdk
     # a 4^8-entry table is 512 KB: resident in every XCD's L2, it replaces the four widest pair steps (8 line requests) of a seed
     fd8 = fdim.with_ktab(8)
     d8_ms = timed(lambda: nvb.match(fd8, seeds, out=r2))
