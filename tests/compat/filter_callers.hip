@@ -134,8 +134,8 @@ API int compat_fmmap(const fmmap_args* a, char* rank_path, char* locate_path, ch
         const uint64 n_hits = fm_filter.rank(fm_index, seed_string_set);
         strncpy(rank_path, fm_filter.last_path(), 15);
         *a->out_n_hits = n_hits;
-        hipMemcpy(a->out_ranges, fm_filter.ranges(), sizeof(uint2) * a->n_seeds, hipMemcpyDeviceToDevice);
-        hipMemcpy(a->out_ranks, fm_filter.ranks(), sizeof(uint64) * a->n_seeds, hipMemcpyDeviceToDevice);
+        (void)hipMemcpy(a->out_ranges, fm_filter.ranges(), sizeof(uint2) * a->n_seeds, hipMemcpyDeviceToDevice);
+        (void)hipMemcpy(a->out_ranks, fm_filter.ranks(), sizeof(uint64) * a->n_seeds, hipMemcpyDeviceToDevice);
 
         nvbio::vector<device_tag, aln::BestSink<int16> > sinks(batch_size);
         nvbio::vector<device_tag, uint2> genome_infix_coords(batch_size);
@@ -148,7 +148,7 @@ API int compat_fmmap(const fmmap_args* a, char* rank_path, char* locate_path, ch
             const uint64 hits_end = nvbio::min(nvbio::min(hits_begin + batch_size, n_hits), uint64(a->out_capacity));
             fm_filter.locate(hits_begin, hits_end, hits.begin());
             strncpy(locate_path, fm_filter.last_path(), 15);
-            hipDeviceSynchronize();
+            (void)hipDeviceSynchronize();
 
             // (index-pos, seed-id) -> diagonals (text-pos = index-pos - seed-pos, read-id)
             thrust::transform(hits.begin(), hits.begin() + (hits_end - hits_begin), hits.begin(), hit_to_diagonal(a->seeds));
@@ -167,15 +167,15 @@ API int compat_fmmap(const fmmap_args* a, char* rank_path, char* locate_path, ch
                 aln::make_edit_distance_aligner<aln::SEMI_GLOBAL, myers_dna5_tag>(),
                 read_infix_set, genome_infix_set, sinks.begin(), aln::DeviceThreadScheduler(),
                 a->max_read_len, a->max_read_len + BAND_LEN);
-            hipDeviceSynchronize();
+            (void)hipDeviceSynchronize();
 
-            hipMemcpy(a->out_diagonals + hits_begin, nvbio::plain_view(hits), sizeof(uint2) * (hits_end - hits_begin), hipMemcpyDeviceToDevice);
+            (void)hipMemcpy(a->out_diagonals + hits_begin, nvbio::plain_view(hits), sizeof(uint2) * (hits_end - hits_begin), hipMemcpyDeviceToDevice);
             // BestSink<int16> = { int16 score; uint2 sink } : unpack on the host side of this shim
             nvbio::vector<host_tag, aln::BestSink<int16> > h_sinks(sinks);
             std::vector<int16> sc(hits_end - hits_begin); std::vector<uint2> sk(hits_end - hits_begin);
             for (uint64 k = 0; k < hits_end - hits_begin; ++k) { sc[k] = h_sinks[k].score; sk[k] = h_sinks[k].sink; }
-            hipMemcpy(a->out_scores + hits_begin, sc.data(), sizeof(int16) * sc.size(), hipMemcpyHostToDevice);
-            hipMemcpy(a->out_sinks + hits_begin, sk.data(), sizeof(uint2) * sk.size(), hipMemcpyHostToDevice);
+            (void)hipMemcpy(a->out_scores + hits_begin, sc.data(), sizeof(int16) * sc.size(), hipMemcpyHostToDevice);
+            (void)hipMemcpy(a->out_sinks + hits_begin, sk.data(), sizeof(uint2) * sk.size(), hipMemcpyHostToDevice);
         }
         return int(hipDeviceSynchronize());
     } catch (const std::exception& e) { fprintf(stderr, "compat_fmmap: %s\n", e.what()); return -1; }
@@ -198,8 +198,8 @@ API int compat_filter64(unsigned long long n, unsigned long long primary, const 
         const SparseStringSet<read_stream, const uint2*> seeds(n_seeds, read_stream(read_words), seed_ranges_dev);
         const uint64 n_hits = filter.rank(fm_index, seeds);
         *out_n_hits = n_hits;
-        hipMemcpy(out_ranges, filter.ranges(), sizeof(ulonglong2) * n_seeds, hipMemcpyDeviceToDevice);
-        hipMemcpy(out_ranks, filter.ranks(), sizeof(uint64) * n_seeds, hipMemcpyDeviceToDevice);
+        (void)hipMemcpy(out_ranges, filter.ranges(), sizeof(ulonglong2) * n_seeds, hipMemcpyDeviceToDevice);
+        (void)hipMemcpy(out_ranks, filter.ranks(), sizeof(uint64) * n_seeds, hipMemcpyDeviceToDevice);
         filter.locate(0, nvbio::min(n_hits, uint64(out_capacity)), out_hits);
         strncpy(path, filter.last_path(), 15);
         return int(hipDeviceSynchronize());
