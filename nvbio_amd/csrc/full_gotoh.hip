@@ -282,7 +282,6 @@ __device__ __forceinline__ uint32_t min16u(uint32_t a, uint32_t b) { uint32_t r;
 template <int TYPE, int R, bool CHECK, bool PBX = false, bool MULTI = false>      // PBX: keep every row's maximum over the text (pattern-blocking early exit, non-LOCAL types)
 struct Sweep16
 {
-    static_assert(!MULTI || TYPE != NVBIO_HIP_GLOBAL, "several jobs per wave: LOCAL and SEMI_GLOBAL only");
     const FullParams& p;
     uint32_t lane, lane_last, klast, M, Ncols, Nfull;
     uint32_t wlane, seg_base, seg_w; bool seg_valid;              // MULTI: lane in the wave, first lane / width of the segment, segment holds a job
@@ -692,7 +691,7 @@ full_gotoh_score_kernel(const FullParams p)
 // Several jobs per wave (Sweep16<..., MULTI>): short patterns leave most lanes of a 64-lane systolic sweep idle (150 rows at R = 3:
 // 50 lanes; the four lane-to-lane moves of a step are paid for 3 cells), and their short texts make fill and drain a large share of the
 // steps.  Here the wave is cut into n_seg segments of seg_w lanes (2 x 32, 3 x 21, 4 x 16), each sweeping its own job with R = 5 or 6
-// rows per lane: 150-bp mates run two per wave on 30 + 30 lanes.  LOCAL and SEMI_GLOBAL on the 16-bit sweep.  A job whose early exit
+// rows per lane: 150-bp mates run two per wave on 30 + 30 lanes.  Every alignment type, on the 16-bit sweep.  A job whose early exit
 // fires needs a second sweep over a prefix of its rows / columns (as in full_gotoh_score_kernel): the wave then runs that job alone
 // on the single-job sweep, segment by segment, so every result is the one full_gotoh_score_kernel produces.
 // ---------------------------------------------------------------------------------------------
@@ -727,12 +726,14 @@ full_gotoh_score_multi_kernel(const FullParams p, const uint32_t n_seg, const ui
             const bool exits = check && nb > 8u && (-(1 << 30) + int32_t(N - 8u) * p.match < min_score);
             if (exits) { ok = 0u; if (TYPE == NVBIO_HIP_SEMI_GLOBAL) { score = 0; sx = 8u; sy = 0u; } }
             else if (N > 0u && TYPE == NVBIO_HIP_SEMI_GLOBAL) { score = 0; sx = N; sy = 0u; }
+            else if (N > 0u && TYPE == NVBIO_HIP_GLOBAL)      { score = p.row_go + p.row_ge * int32_t(N - 1u); sx = N; sy = 0u; }
         }
         else if (PB && check && N == 0u)
         {
             swept = false;
             const uint32_t BLK = 1u << p.blk_log2;
             if ((M + BLK - 1u) / BLK > 1u) ok = 0u;
+            else if (TYPE == NVBIO_HIP_GLOBAL) { score = p.col_go + p.col_ge * int32_t(M - 1u); sx = 0u; sy = M; }
         }
     }
     const bool sweeps = swept;
@@ -764,9 +765,11 @@ full_gotoh_score_multi_kernel(const FullParams p, const uint32_t n_seg, const ui
                 // LOCAL: the best cell of the whole matrix, if it lies at or before the exit column, is also the best of the columns the
                 // reference visited; only otherwise sweep the truncated text again.  SEMI_GLOBAL: the record froze at the exit column.
                 if (TYPE == NVBIO_HIP_LOCAL && !(r.sx != 0xFFFFFFFFu && r.sx - 1u <= r.exit_col)) { redo = 2u; redo_arg = r.exit_col + 1u; }
-                else { score = r.score; sx = r.sx; sy = r.sy; }
+                else if (TYPE != NVBIO_HIP_GLOBAL) { score = r.score; sx = r.sx; sy = r.sy; }      // (GLOBAL: the only report is at the last column)
             }
             else { score = r.score; sx = r.sx; sy = r.sy; }
+            // pattern blocking, GLOBAL, empty text: save_Mth reports the initial row (gotoh_inl.h:896-897)
+            if (PB && TYPE == NVBIO_HIP_GLOBAL && N == 0u) { score = p.col_go + p.col_ge * int32_t(M - 1u); sx = 0u; sy = M; }
         }
     }
     // second sweeps, one job at a time on the whole wave (rare: a job whose early exit fired with its best cell beyond the exit)
@@ -803,6 +806,7 @@ static hipError_t launch_full_multi(const FullParams& p, int type, uint32_t n_se
     switch (type) {
     case NVBIO_HIP_LOCAL:       hipLaunchKernelGGL((full_gotoh_score_multi_kernel<NVBIO_HIP_LOCAL, R>),       grid, block, 0, s, p, n_seg, seg_w); break;
     case NVBIO_HIP_SEMI_GLOBAL: hipLaunchKernelGGL((full_gotoh_score_multi_kernel<NVBIO_HIP_SEMI_GLOBAL, R>), grid, block, 0, s, p, n_seg, seg_w); break;
+    case NVBIO_HIP_GLOBAL:      hipLaunchKernelGGL((full_gotoh_score_multi_kernel<NVBIO_HIP_GLOBAL, R>),      grid, block, 0, s, p, n_seg, seg_w); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -1016,7 +1020,7 @@ static int full_score_core(
             return launch_ed<8>(p, type, s);
         }
     }
-    if (fast && type != NVBIO_HIP_GLOBAL)
+    if (fast)
     {
         // several jobs per wave when that keeps more lanes busy: n_seg segments of 64 / n_seg lanes, R = 5 or 6 rows per lane.
         // Estimated cell throughput: busy lanes x (cell work) / (cell work + per-step overhead).

@@ -200,7 +200,7 @@ def test_quality_aware_scheme_full_matrix(cuda, ty, algo):
                                    (es[bad[0]], ek[bad[0]], eo[bad[0]]), (gs[bad[0]], gk[bad[0]], go[bad[0]]))
 
 
-@pytest.mark.parametrize("ty", [nvb.LOCAL, nvb.SEMI_GLOBAL])
+@pytest.mark.parametrize("ty", [nvb.LOCAL, nvb.SEMI_GLOBAL, nvb.GLOBAL])
 @pytest.mark.parametrize("max_m,max_n", [(150, 520), (100, 300), (75, 200), (170, 400), (40, 90)])
 def test_several_jobs_per_wave(cuda, ty, max_m, max_n, monkeypatch):
     """Short patterns run two to four jobs per wave (full_gotoh_score_multi_kernel: segments of 32 / 21 / 16 lanes, the last lane of a
