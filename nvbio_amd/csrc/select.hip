@@ -420,10 +420,12 @@ locate_hits_kernel(const Fmi f, const Fmi rf, uint32_t n, uint32_t* __restrict__
     for (uint64_t i = uint64_t(blockIdx.x) * 256u + threadIdx.x; i < n; i += uint64_t(gridDim.x) * 256u)
     {
         const uint32_t seed = hit_seed[i], dir = (seed >> 12) & 1u, pir = seed & 0xFFFu;
-        const Fmi& x = dir ? rf : f;
-        const uint2 it = fm_locate_it(x, hit_loc[i]);
-        const uint32_t g = x.ssa[it.x / x.sa_int] + it.y;
-        hit_loc[i] = (dir ? rf.length - 1u - g : g) - pir;
+        // (two code paths, not `const Fmi& x = dir ? rf : f`: a reference picked per lane makes the compiler park both index descriptors in
+        // scratch memory -- 296 bytes written and re-read per lane, three times the kernel's useful traffic)
+        uint32_t g;
+        if (dir) { const uint2 it = fm_locate_it(rf, hit_loc[i]); g = rf.length - 1u - (rf.ssa[it.x / rf.sa_int] + it.y); }
+        else     { const uint2 it = fm_locate_it(f,  hit_loc[i]); g = f.ssa[it.x / f.sa_int] + it.y; }
+        hit_loc[i] = g - pir;
     }
 }
 
