@@ -696,7 +696,7 @@ full_gotoh_score_kernel(const FullParams p)
 // on the single-job sweep, segment by segment, so every result is the one full_gotoh_score_kernel produces.
 // ---------------------------------------------------------------------------------------------
 template <int TYPE, int R>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)       // >= 3 waves per SIMD: left alone the SEMI_GLOBAL instance takes 176 VGPRs (2 waves); 168 + 14 spilled: +8 %
 full_gotoh_score_multi_kernel(const FullParams p, const uint32_t n_seg, const uint32_t seg_w)
 {
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
