@@ -239,8 +239,10 @@ int nvbio_hip_gotoh_traceback_qual(
  * crop_windows_kernel).  known_score: device int32[n].  The premise is checked per job on what the cropped DP found (score ==
  * known_score and the sink on the window's last row); a job that fails the check -- a known_score that is too high cuts the window too
  * short -- is traced again over its whole window, so its outputs are those of the plain form (one 4-byte read-back per call finds the
- * count; nvbio_hip_known_score_redone() totals it).  Not detectable: a window whose true best alignment lies in the dropped rows while
- * the kept rows hold one of exactly known_score ending at the last row.  GLOBAL: same as the plain forms. */
+ * count; nvbio_hip_known_score_redone() totals it).  Under a TRUE premise the result is the plain form's in every case, ties included: a
+ * tied cell the cropped DP visits first lies off the last row, fails the check, and the job is traced again.  Not detectable under a
+ * FALSE premise: a window whose plain-order best alignment (of score known_score, or better in the dropped rows) is not the one the kept
+ * rows hold with exactly known_score ending at the last row -- the caller then gets that other alignment.  GLOBAL: same as the plain forms. */
 int nvbio_hip_gotoh_traceback_known_score(
     const nvbio_hip_gotoh_scheme* scheme /* host */, int32_t type,
     const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts, const int32_t* known_score,
