@@ -474,6 +474,13 @@ int nvbio_hip_select_init(uint32_t n_reads, const char* read_names, const uint32
                           const uint64_t* hits, uint32_t hits_stride, const uint32_t* hit_counts,
                           float* probs, uint32_t probs_stride, uint32_t* trys /* nullable */, uint32_t* rseeds,
                           uint32_t max_effort_init, int32_t randomized, int32_t top_seed, void* stream);
+/* The same for the reads of a queue only (queue: device uint32[n_queue] read ids): a re-seeding pass gives hits to its queue's reads
+ * alone, and no read outside it is selected from before the next select_init reaches it, so the state the reference's whole-batch
+ * kernel writes for the others is never read. */
+int nvbio_hip_select_init_queued(uint32_t n_queue, const uint32_t* queue, const char* read_names, const uint32_t* read_names_idx,
+                                 const uint64_t* hits, uint32_t hits_stride, const uint32_t* hit_counts,
+                                 float* probs, uint32_t probs_stride, uint32_t* trys /* nullable */, uint32_t* rseeds,
+                                 uint32_t max_effort_init, int32_t randomized, int32_t top_seed, void* stream);
 /* select (select_inl.h:74-607; dispatch :744-795): one round of hit selection for the reads of active_in.  Reads whose
  * try counter is 0 or whose deque is empty leave the queue; the others hand out up to n_multi SA rows each (n_multi == 1:
  * select_kernel / rand_select_kernel, > 1: the *_multi_kernel forms), from the deque's top range downwards, or -- randomized

@@ -514,7 +514,10 @@ private:
                 hip_check(nvbio_hip_pack_read_queue(seed_queue_size, seed_queue_in.data(), params.select.top_seed & 1u, reinterpret_cast<uint32*>(queues.active_in.data()), hip_stream),
                           "nvbio_hip_pack_read_queue");
                 queues.in_size = seed_queue_size;
-                stats.clock.run("select_init", hip_stream, [&] { select_init(count, a_reads.names, a_reads.names_idx, hits, state, params.select, hip_stream); });
+                // (a re-seeding pass: only its queue's reads have hits and are selected from -- select.h)
+                stats.clock.run("select_init", hip_stream, [&] {
+                    if (seed_queue_size < count) select_init(seed_queue_size, seed_queue_in.data(), a_reads.names, a_reads.names_idx, hits, state, params.select, hip_stream);
+                    else                         select_init(count, a_reads.names, a_reads.names_idx, hits, state, params.select, hip_stream); });
                 uint32 n_ext = 0;
                 while (queues.in_size && n_ext < params.select.max_ext)
                 {
@@ -703,7 +706,10 @@ private:
         hip_check(nvbio_hip_pack_read_queue(seed_queue_size, seed_queue, params.select.top_seed & 1u, reinterpret_cast<uint32*>(queues.active_in.data()), hip_stream),
                   "nvbio_hip_pack_read_queue");
         queues.in_size = seed_queue_size;
-        stats.clock.run("select_init", hip_stream, [&] { select_init(reads.n, reads.names, reads.names_idx, hits, state, params.select, hip_stream); });
+        // (a re-seeding pass: only its queue's reads have hits and are selected from -- select.h)
+        stats.clock.run("select_init", hip_stream, [&] {
+            if (seed_queue_size < reads.n) select_init(seed_queue_size, seed_queue, reads.names, reads.names_idx, hits, state, params.select, hip_stream);
+            else                           select_init(reads.n, reads.names, reads.names_idx, hits, state, params.select, hip_stream); });
 
         uint32 n_ext = 0;
         while (queues.in_size && n_ext < params.select.max_ext)

@@ -73,6 +73,14 @@ inline void select_init(const uint32 count, const char* d_read_names, const uint
                                     state.probs.data(), state.probs_stride, state.trys.data(), state.rseeds.data(), params.max_effort_init,
                                     params.randomized ? 1 : 0, int32(params.top_seed), hip_stream), "nvbio_hip_select_init");
 }
+/// the same for the reads of a seeding pass's queue only (a re-seeding pass: a few percent of the batch)
+inline void select_init(const uint32 n_queue, const uint32* d_queue, const char* d_read_names, const uint32* d_read_names_idx, const SeedHitDequeArrayDeviceView hits,
+                        SelectState& state, const SelectParamsPOD params, void* hip_stream = nullptr)
+{
+    hip_check(nvbio_hip_select_init_queued(n_queue, d_queue, d_read_names, d_read_names_idx, reinterpret_cast<const uint64*>(hits.hits), hits.stride, hits.counts,
+                                           state.probs.data(), state.probs_stride, state.trys.data(), state.rseeds.data(), params.max_effort_init,
+                                           params.randomized ? 1 : 0, int32(params.top_seed), hip_stream), "nvbio_hip_select_init_queued");
+}
 
 /// select( context, pipeline, params ) (select.h:139-152): one round over queues.active_in[0..in_size); on return the output
 /// queue has been swapped in (in_size = surviving reads, hits_size = selected hits) -- the driver's active_read_queues.swap()

@@ -17,7 +17,7 @@ SYMBOLS = [
     "nvbio_hip_fm_dimer_index_bytes", "nvbio_hip_fm_build_dimer_index_temp_bytes", "nvbio_hip_fm_build_dimer_index", "nvbio_hip_fm_attach_dimer_index",
     "nvbio_hip_fm_trimer_index_bytes", "nvbio_hip_fm_build_trimer_index_temp_bytes", "nvbio_hip_fm_build_trimer_index", "nvbio_hip_fm_attach_trimer_index", "nvbio_hip_map_exact", "nvbio_hip_map",
     "nvbio_hip_alignment_invalid", "nvbio_hip_init_alignments", "nvbio_hip_score_reduce", "nvbio_hip_score_reduce_paired", "nvbio_hip_opposite_mate_windows", "nvbio_hip_mapq", "nvbio_hip_mapq_paired", "nvbio_hip_fm_locate",
-    "nvbio_hip_sum_tree_node_count", "nvbio_hip_select_init", "nvbio_hip_select_temp_bytes", "nvbio_hip_select", "nvbio_hip_locate_hits", "nvbio_hip_hit_deque_replay",
+    "nvbio_hip_sum_tree_node_count", "nvbio_hip_select_init", "nvbio_hip_select_init_queued", "nvbio_hip_select_temp_bytes", "nvbio_hip_select", "nvbio_hip_locate_hits", "nvbio_hip_hit_deque_replay",
     "nvbio_hip_score_best_setup", "nvbio_hip_score_reduce_best_approx",
     "nvbio_hip_anchor_score_setup", "nvbio_hip_anchor_score_finish", "nvbio_hip_opposite_score_setup", "nvbio_hip_opposite_score_finish",
     "nvbio_hip_score_reduce_paired_best_approx", "nvbio_hip_mark_discordant",
@@ -140,6 +140,7 @@ def lib():
         L.nvbio_hip_score_reduce.argtypes = [u32, vp, vp, vp, vp, vp, vp, u32, vp, u32, vp]
         L.nvbio_hip_sum_tree_node_count.argtypes = [u32]; L.nvbio_hip_sum_tree_node_count.restype = u32
         L.nvbio_hip_select_init.argtypes = [u32, vp, vp, vp, u32, vp, vp, u32, vp, vp, u32, i32, i32, vp]
+        L.nvbio_hip_select_init_queued.argtypes = [u32, vp, vp, vp, vp, u32, vp, vp, u32, vp, vp, u32, i32, i32, vp]
         L.nvbio_hip_select_temp_bytes.argtypes = [u32, u32]; L.nvbio_hip_select_temp_bytes.restype = u64
         L.nvbio_hip_select.argtypes = [i32, u32, vp, u32, vp, u32, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, vp]
         L.nvbio_hip_hit_deque_replay.argtypes = [u32, vp, vp, vp, vp, vp, vp, u32, vp, vp]

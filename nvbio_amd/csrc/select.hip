@@ -93,10 +93,11 @@ __global__ void __launch_bounds__(256)
 select_init_kernel(uint32_t n_reads, const char* __restrict__ names, const uint32_t* __restrict__ names_idx,
                    const uint2* __restrict__ hits, uint32_t hits_stride, const uint32_t* __restrict__ counts,
                    float* __restrict__ probs, uint32_t probs_stride, uint32_t* __restrict__ trys, uint32_t* __restrict__ rseeds,
-                   uint32_t max_effort_init, int randomized, int top_seed, int build_tree)
+                   uint32_t max_effort_init, int randomized, int top_seed, int build_tree, const uint32_t* __restrict__ queue)
 {
-    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-    if (r >= n_reads) return;
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_reads) return;
+    const uint32_t r = queue ? queue[t] : t;          // queued form: only the reads of the seeding pass's queue
     if (trys) trys[r] = max_effort_init;
     if (!randomized) return;
     if (names) {
@@ -153,11 +154,12 @@ struct TreeQuad
 template <int G>
 __global__ void __launch_bounds__(256)
 select_init_tree_kernel(uint32_t n_reads, const uint2* __restrict__ hits, uint32_t hits_stride, const uint32_t* __restrict__ counts,
-                        float* __restrict__ probs, uint32_t probs_stride, int top_seed)
+                        float* __restrict__ probs, uint32_t probs_stride, int top_seed, const uint32_t* __restrict__ queue)
 {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t r = t / G, j = t % G;
-    if (r >= n_reads) return;                       // (whole groups leave together: 256 % G == 0)
+    const uint32_t slot = t / G, j = t % G;
+    if (slot >= n_reads) return;                    // (whole groups leave together: 256 % G == 0)
+    const uint32_t r = queue ? queue[slot] : slot;
     const uint32_t n = counts[r];
     if (n == 0u) return;
     const uint32_t padded = st_padded(n);
@@ -536,10 +538,10 @@ NVB_API uint32_t nvbio_hip_sum_tree_node_count(uint32_t size)
     return padded * 2u - 1u;
 }
 
-NVB_API int nvbio_hip_select_init(uint32_t n_reads, const char* read_names, const uint32_t* read_names_idx,
-                                  const uint64_t* hits, uint32_t hits_stride, const uint32_t* hit_counts,
-                                  float* probs, uint32_t probs_stride, uint32_t* trys, uint32_t* rseeds,
-                                  uint32_t max_effort_init, int32_t randomized, int32_t top_seed, void* stream)
+static int select_init_impl(uint32_t n_reads, const uint32_t* queue, const char* read_names, const uint32_t* read_names_idx,
+                            const uint64_t* hits, uint32_t hits_stride, const uint32_t* hit_counts,
+                            float* probs, uint32_t probs_stride, uint32_t* trys, uint32_t* rseeds,
+                            uint32_t max_effort_init, int32_t randomized, int32_t top_seed, void* stream)
 {
     if (n_reads == 0) return hipSuccess;
     if (randomized) {
@@ -554,12 +556,33 @@ NVB_API int nvbio_hip_select_init(uint32_t n_reads, const char* read_names, cons
     const int G = (!randomized || one_lane) ? 0 : hits_stride <= 16u ? 4 : hits_stride <= 32u ? 8 : 0;
     hipLaunchKernelGGL(select_init_kernel, grid_for(n_reads), dim3(256), 0, to_stream(stream), n_reads, read_names, read_names_idx,
                        reinterpret_cast<const uint2*>(hits), hits_stride, hit_counts, probs, probs_stride, trys, rseeds, max_effort_init,
-                       int(randomized), int(top_seed), G == 0 ? 1 : 0);
+                       int(randomized), int(top_seed), G == 0 ? 1 : 0, queue);
     if (G == 4) hipLaunchKernelGGL(select_init_tree_kernel<4>, grid_for(uint64_t(n_reads) * 4u), dim3(256), 0, to_stream(stream), n_reads,
-                                    reinterpret_cast<const uint2*>(hits), hits_stride, hit_counts, probs, probs_stride, int(top_seed));
+                                    reinterpret_cast<const uint2*>(hits), hits_stride, hit_counts, probs, probs_stride, int(top_seed), queue);
     if (G == 8) hipLaunchKernelGGL(select_init_tree_kernel<8>, grid_for(uint64_t(n_reads) * 8u), dim3(256), 0, to_stream(stream), n_reads,
-                                    reinterpret_cast<const uint2*>(hits), hits_stride, hit_counts, probs, probs_stride, int(top_seed));
+                                    reinterpret_cast<const uint2*>(hits), hits_stride, hit_counts, probs, probs_stride, int(top_seed), queue);
     return hipGetLastError();
+}
+
+NVB_API int nvbio_hip_select_init(uint32_t n_reads, const char* read_names, const uint32_t* read_names_idx,
+                                  const uint64_t* hits, uint32_t hits_stride, const uint32_t* hit_counts,
+                                  float* probs, uint32_t probs_stride, uint32_t* trys, uint32_t* rseeds,
+                                  uint32_t max_effort_init, int32_t randomized, int32_t top_seed, void* stream)
+{
+    return select_init_impl(n_reads, nullptr, read_names, read_names_idx, hits, hits_stride, hit_counts, probs, probs_stride, trys, rseeds,
+                            max_effort_init, randomized, top_seed, stream);
+}
+// The same for the reads of a queue only (queue[t] = read id): what a re-seeding pass needs -- every other read has no hits in this pass and
+// is not selected from until the next select_init reaches it.  (The reference's kernel always runs over the whole batch, select.cu:36-103;
+// the state it writes for reads outside the queue is never read.)
+NVB_API int nvbio_hip_select_init_queued(uint32_t n_queue, const uint32_t* queue, const char* read_names, const uint32_t* read_names_idx,
+                                         const uint64_t* hits, uint32_t hits_stride, const uint32_t* hit_counts,
+                                         float* probs, uint32_t probs_stride, uint32_t* trys, uint32_t* rseeds,
+                                         uint32_t max_effort_init, int32_t randomized, int32_t top_seed, void* stream)
+{
+    if (n_queue != 0 && !queue) return hipErrorInvalidValue;
+    return select_init_impl(n_queue, queue, read_names, read_names_idx, hits, hits_stride, hit_counts, probs, probs_stride, trys, rseeds,
+                            max_effort_init, randomized, top_seed, stream);
 }
 
 NVB_API uint64_t nvbio_hip_select_temp_bytes(uint32_t n_active, uint32_t n_multi)

@@ -116,6 +116,44 @@ def _select_rounds(cuda, randomized, n_multi, top_seed, stride):
     assert rounds > 3 and total > n
 
 
+@pytest.mark.parametrize("stride", [16, 24, 40])
+def test_select_init_of_a_queue_only(cuda, stride):
+    """nvbio_hip_select_init_queued: the reads of a queue get exactly what the whole-batch select_init gives them (tries, LCG seed from
+    the name, probability tree), every other read's state is left as it was."""
+    import ctypes as C
+    from nvbio_amd._lib import check
+    rng = np.random.default_rng(4100 + stride)
+    n = 5000
+    hits, counts = _random_deques(rng, n, stride, max_size=min(stride, 16))
+    names = ["q%d/%d" % (i * 31 % 977, i) for i in range(n)]
+    arena, idx = O.pack_names(names)
+    e_probs, e_trys, e_rseeds = O.select_init(hits, counts, arena, idx, 15, True, 1)
+    queue = np.sort(rng.choice(n, 700, replace=False)).astype(np.uint32)
+    d_hits, d_counts = torch.from_numpy(hits.view(np.int64).copy()).to(cuda), dev_i32(counts, cuda)
+    d_arena, d_idx = S.pack_names(names, cuda)
+    ps = S.sum_tree_node_count(stride)
+    probs = torch.full((n, ps), -7.0, dtype=torch.float32, device=cuda)
+    trys = torch.full((n,), 99, dtype=torch.int32, device=cuda)
+    rseeds = torch.full((n,), 12345, dtype=torch.int32, device=cuda)
+    d_queue = dev_i32(queue, cuda)
+    vp = lambda x: C.c_void_p(x.data_ptr())
+    check(lib().nvbio_hip_select_init_queued(queue.size, vp(d_queue), vp(d_arena), vp(d_idx), vp(d_hits), stride, vp(d_counts), vp(probs), ps,
+                                             vp(trys), vp(rseeds), 15, 1, 1, None), "nvbio_hip_select_init_queued")
+    torch.cuda.synchronize()
+    inq = np.zeros(n, bool); inq[queue] = True
+    g_trys, g_rseeds, g_probs = trys.cpu().numpy().view(np.uint32), rseeds.cpu().numpy().view(np.uint32), probs.cpu().numpy()
+    assert (g_trys[inq] == e_trys[inq]).all() and (g_trys[~inq] == 99).all()
+    assert (g_rseeds[inq] == e_rseeds[inq]).all() and (g_rseeds[~inq] == 12345).all()
+    assert (g_probs[~inq] == -7.0).all()
+    # a queued read's tree: its nodes (2 * padded - 1 of them) as the oracle builds them; empty deques are not touched
+    has = inq & (counts > 0)
+    for r in np.nonzero(has)[0][:400]:
+        m = int(counts[r]); padded = 1 << int(np.ceil(np.log2(m))) if m > 1 else 1
+        k = 2 * padded - 1
+        assert (g_probs[r, :k].view(np.uint32) == e_probs[r, :k].view(np.uint32)).all(), (r, m)
+    assert (g_probs[inq & (counts == 0)] == -7.0).all()
+
+
 def _small_index(rng, n_genome=1 << 17):
     text = rng.integers(0, 4, n_genome, dtype=np.uint8)
     text[7000:7800] = np.tile(np.array([0, 1, 2], dtype=np.uint8), 267)[:800]
