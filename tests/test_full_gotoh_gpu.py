@@ -203,8 +203,8 @@ def test_quality_aware_scheme_full_matrix(cuda, ty, algo):
 @pytest.mark.parametrize("ty", [nvb.LOCAL, nvb.SEMI_GLOBAL, nvb.GLOBAL])
 @pytest.mark.parametrize("max_m,max_n", [(150, 520), (100, 300), (75, 200), (170, 400), (40, 90)])
 def test_several_jobs_per_wave(cuda, ty, max_m, max_n, monkeypatch):
-    """Short patterns run two to four jobs per wave (full_gotoh_score_multi_kernel: segments of 32 / 21 / 16 lanes, the last lane of a
-    segment feeding the next).  Ragged M and N inside one wave, job counts that do not fill the last wave, empty patterns / texts,
+    """Short patterns run two to four jobs per wave (full_gotoh_score_multi_kernel: segments of 32 / 21 / 16 lanes, a segment's first lane
+    taking the row above its own matrix).  Ragged M and N inside one wave, job counts that do not fill the last wave, empty patterns / texts,
     tie-heavy texts, min_score early exits of both blocking orders (the second sweep of an exited job), qualities: the multi-job
     kernel, the single-job kernel (NVBIO_HIP_FULL_SINGLE_JOB=1) and the oracle must agree bit for bit."""
     rng = np.random.default_rng(77 + ty * 1000 + max_m)
