@@ -126,6 +126,40 @@ def test_sum_tree():
         assert cells[O.sum_tree_sample(cells, size, 0.0)] > 0 and cells[O.sum_tree_sample(cells, size, 1.0)] > 0
 
 
+def test_sum_tree_reference_literals():
+    """The known answers the reference's own test holds for SumTree (nvbio-test/sum_tree_test.cpp:41-193: int32 trees of 128 and 80
+    leaves, sample() at 0, 0.5 and 1, leaves removed with add() / set()): the oracle's restatement of setup / set / sample
+    (sum_tree_inl.h:38-178) must give them.  sample() casts the cells to float before every operation, and these cell values are small
+    integers, so a float tree holds the same numbers exactly.  (add(i, d) is set(i, cell + d) on exact values.)"""
+    def tree(values):
+        size = len(values)
+        cells = np.zeros(O.sum_tree_node_count(size), np.float32)
+        cells[:size] = np.asarray(values, np.float32)
+        O.sum_tree_setup(cells, size)
+        return cells, size
+    s3 = lambda cells, size: tuple(O.sum_tree_sample(cells, size, v) for v in (0.0, 0.5, 1.0))
+    n = 128
+    assert O.sum_tree_node_count(n) == 255
+    assert s3(*tree(np.arange(n))) == (1, 90, 127)                                  # test 1 (:50-62)
+    assert s3(*tree([0 if i < n // 2 else 1 for i in range(n)])) == (64, 96, 127)    # test 2 (:66-79)
+    assert s3(*tree([1 if i < n // 2 else 0 for i in range(n)])) == (0, 32, 63)      # test 3 (:82-95)
+    n = 80
+    assert (O.sum_tree_node_count(n) + 1) // 2 == 128                                # padded_size() (:106-110)
+    assert s3(*tree([0 if i < n // 2 else 1 for i in range(n)])) == (40, 60, 79)     # test 4 (:113-126)
+    cells, size = tree([1 if i < n // 2 else 0 for i in range(n)])
+    assert s3(cells, size) == (0, 20, 39)                                            # test 5 (:129-146)
+    O.sum_tree_set(cells, size, 39, float(cells[39]) - 1.0)                          # add(39, -1)
+    assert O.sum_tree_sample(cells, size, 1.0) == 38                                 # test 6 (:149-157)
+    O.sum_tree_set(cells, size, 38, float(cells[38]) - 1.0)                          # add(38, -1)
+    assert O.sum_tree_sample(cells, size, 1.0) == 37                                 # test 7 (:160-167)
+    O.sum_tree_set(cells, size, 38, float(cells[38]) + 1.0)                          # add(38, 1)
+    O.sum_tree_set(cells, size, 38, 0.0)                                             # set(38, 0)
+    assert O.sum_tree_sample(cells, size, 1.0) == 37                                 # test 8 (:170-180)
+    for i in range(10):                                                              # test 9 (:183-193)
+        O.sum_tree_set(cells, size, i, 0.0)
+        assert O.sum_tree_sample(cells, size, 0.0) == i + 1
+
+
 def _random_deques(rng, n_reads, stride, max_size=40):
     push, _, _ = O.hit_deque_ops()
     hits = np.zeros((n_reads, stride), np.uint64)
