@@ -499,3 +499,13 @@ def test_sw_tracebacks_kats_and_relation_to_gotoh():
             if a["sink"] == b["sink"]:
                 assert key(a) == key(b)
     assert local_differs > 0
+
+
+def test_banana_suffix_array_and_bwt_literals():
+    """The literals of nvbio-test/packedstream_test.cpp:161-202: the suffix array of BANANA (B=1, A=0, N=2) is 5 3 1 0 4 2 and its BWT
+    (the sentinel's row dropped, as saisxx_bwt writes it) reads ANNBAA -- the oracle's index construction on the same string."""
+    t = np.array([1, 0, 2, 0, 2, 0], dtype=np.uint8)
+    f = O.FMIndex(t)
+    assert f.sa[0] == 6 and f.sa[1:].tolist() == [5, 3, 1, 0, 4, 2]
+    assert "".join("ABNT"[c] for c in f.bwt) == "ANNBAA"
+    assert f.primary == 4                       # the row of the whole string: where the dropped sentinel stood
