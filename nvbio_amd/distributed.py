@@ -109,15 +109,25 @@ class CxxComm:
         self.L, self.C = lib(), C
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        if not self.L.nvbio_hip_comm_available():
-            raise RuntimeError("RCCL could not be bound (librccl.so.1)")
+        # Every rank reaches every collective below whatever happens locally: a rank that cannot bind RCCL (or rank 0 failing to make the
+        # id) says so in the exchange and ALL ranks raise together -- nobody is left waiting inside ncclCommInitRank for a peer that gave up.
         ident = (C.c_uint8 * 128)()
-        if self.rank == 0:
-            check(self.L.nvbio_hip_comm_unique_id(ident), "nvbio_hip_comm_unique_id")
-        box = [bytes(ident)]
+        problem = None
+        if not self.L.nvbio_hip_comm_available():
+            problem = "RCCL could not be bound (librccl.so.1)"
+        elif self.rank == 0:
+            err = self.L.nvbio_hip_comm_unique_id(ident)
+            if err != 0:
+                problem = "nvbio_hip_comm_unique_id failed with %d" % err
         if self.world > 1:
-            dist.broadcast_object_list(box, src=0, group=group)
-        ident = (C.c_uint8 * 128).from_buffer_copy(box[0])
+            reports = [None] * self.world
+            dist.all_gather_object(reports, (problem, bytes(ident) if self.rank == 0 else None), group=group)
+        else:
+            reports = [(problem, bytes(ident))]
+        bad = [(r, p[0]) for r, p in enumerate(reports) if p[0] is not None]
+        if bad:
+            raise RuntimeError("C++ / RCCL communicator not opened: " + "; ".join("rank %d: %s" % b for b in bad))
+        ident = (C.c_uint8 * 128).from_buffer_copy(reports[0][1])
         self.comm = C.c_void_p()
         check(self.L.nvbio_hip_comm_init_rank(C.byref(self.comm), self.world, self.rank, ident), "nvbio_hip_comm_init_rank")
 
