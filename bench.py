@@ -367,11 +367,13 @@ def e2e_sharded_leg(a, dev, rank, world, barrier, cxx_comm=None):
         prm = AL.Params(hits_stride=16, batch_size=n)
         # 16 B per read to rank 0: alignment word, position, MAPQ, read id -- from C++ over RCCL when the pre-flight found it
         gat = CxxRecordGather(cxx_comm, n * world, 4, dst=0, device=dev) if cxx_comm is not None else RecordGather(n * world, 4, dst=0, device=dev)
+        def align():
+            return AL.best_approx(fmi, None, sym, genome_words, ng, prm, names=names, packed=packed)
         def run():
-            r = AL.best_approx(fmi, None, sym, genome_words, ng, prm, names=names, packed=packed)
+            r = align()
             r["table"] = gat.gather(alignment_records(r["best"][0], r["mapq"], rank * n), concat=False)
             return r
-        run(); torch.cuda.synchronize()
+        align(); torch.cuda.synchronize()          # local warm-up only: the gather is a collective and waits for the agreement below
         state = dict(run=run, n=n, ng=ng, pos=pos, gat=gat)
     except Exception as e:          # noqa: BLE001 -- reported, and agreed on below
         err = "%s: %s" % (type(e).__name__, e)
@@ -379,6 +381,7 @@ def e2e_sharded_leg(a, dev, rank, world, barrier, cxx_comm=None):
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if int(ok.item()) == 0:
         return {"error": err or "another rank failed during set-up"}
+    state["run"](); torch.cuda.synchronize()       # warm-up of the whole step, gather included: every rank is here
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     r = state["run"]()
