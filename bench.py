@@ -358,9 +358,10 @@ def e2e_sharded_leg(a, dev, rank, world, barrier, cxx_comm=None):
         g = torch.Generator(device=dev)
         g.manual_seed(0x5EED0003)
         text = torch.randint(0, 4, (ng,), dtype=torch.uint8, generator=g, device=dev)
-        fmi = W.build_fm_index(text).with_dimer()            # the line-native index next to the reference layout
         genome_words = W._pack_chunked(text, 2, True)
         sym, pos, _ = P.make_reads(text, n, READ_LEN, seed=0x5EED0004 + rank)
+        fmi, index_desc = hbm_rich(W.build_fm_index(text), dev)     # every rank its own copy: two-symbol arrays + k-mer table + full SA as memory allows
+        state["index"] = index_desc
         del text
         packed = P.pack_read_streams(sym)
         names = SEL.pack_names(["r%d.%d" % (rank, i) for i in range(n)], dev)
@@ -374,7 +375,7 @@ def e2e_sharded_leg(a, dev, rank, world, barrier, cxx_comm=None):
             r["table"] = gat.gather(alignment_records(r["best"][0], r["mapq"], rank * n), concat=False)
             return r
         align(); torch.cuda.synchronize()          # local warm-up only: the gather is a collective and waits for the agreement below
-        state = dict(run=run, n=n, ng=ng, pos=pos, gat=gat)
+        state.update(run=run, n=n, ng=ng, pos=pos, gat=gat)
     except Exception as e:          # noqa: BLE001 -- reported, and agreed on below
         err = "%s: %s" % (type(e).__name__, e)
     ok = torch.tensor([0 if err else 1], dtype=torch.int32, device="cpu" if cpu else dev)
@@ -404,7 +405,7 @@ def e2e_sharded_leg(a, dev, rank, world, barrier, cxx_comm=None):
         gathered_ok = bool(torch.equal(part(0), own)) and all(
             bool((part(k)[:, 3] == torch.arange(k * n, (k + 1) * n, device=dev, dtype=torch.int64).to(torch.int32)).all()) for k in range(1, world))
     return {"driver": "nvbio_amd.aligner.best_approx (Aligner::best_approx: seeding passes, randomized selection, band-31 extension, reduce, MAPQ, traceback)",
-            "index": "line_native (two-symbol index attached)", "gather": True, "gather_path": "cxx_rccl" if cxx_comm is not None else "torch.distributed.gather", "gather_record_bytes": 16, "gathered_records_verified": gathered_ok,
+            "index": state.get("index"), "gather": True, "gather_path": "cxx_rccl" if cxx_comm is not None else "torch.distributed.gather", "gather_record_bytes": 16, "gathered_records_verified": gathered_ok,
             "genome_symbols": state["ng"], "reads_per_gpu": n, "n_gpus": world, "ms_per_batch": el * 1e3, "Mreads_per_s": n * world / el / 1e6,
             "aligned": float(frac[0].item()) / world, "best_at_true_position": float(frac[1].item()) / world,
             "sharding": "reads block-sharded, index replicated, no collective inside the pipeline; one gather of 16-byte alignment records to rank 0 per batch, inside the timed region"}
