@@ -86,3 +86,35 @@ def test_two_rank_shard_and_gather(n, record_bytes):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def test_cxx_shard_range_is_the_same_split(tmp_path):
+    """include/nvbio_hip/multi_device.h (hip::shard_range / shard_sizes, what DeviceGroup's ranks use) against nvbio_amd.distributed:
+    a host-only program built with g++ (the header's device-facing members are inline and not called)."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("needs g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "shard.cpp"
+    src.write_text(
+        "#include <cstdio>\n#include <cstdlib>\n#include <nvbio_hip/multi_device.h>\n"
+        "int main(int argc, char** argv) {\n"
+        "  for (int i = 1; i + 1 < argc; i += 2) {\n"
+        "    const unsigned long long n = strtoull(argv[i], 0, 10); const unsigned w = unsigned(atoi(argv[i + 1]));\n"
+        "    const std::vector<nvbio::uint64> sz = nvbio::hip::shard_sizes(n, w);\n"
+        "    for (unsigned r = 0; r < w; ++r) { const auto p = nvbio::hip::shard_range(n, r, w); printf(\"%llu %llu %llu \", (unsigned long long)p.first, (unsigned long long)p.second, (unsigned long long)sz[r]); }\n"
+        "    printf(\"\\n\");\n  }\n  return 0;\n}\n")
+    exe = tmp_path / "shard"
+    lib = os.path.join(root, "nvbio_amd", "lib")
+    cmd = ["g++", "-std=c++17", "-O1", "-I", os.path.join(root, "include"), str(src), "-o", str(exe), "-L", lib, "-lnvbio_hip", "-Wl,-rpath," + lib]
+    if not os.path.exists(os.path.join(lib, "libnvbio_hip.so")):
+        pytest.skip("libnvbio_hip.so is not built")
+    subprocess.check_call(cmd)
+    cases = [(0, 1), (1, 1), (1, 8), (7, 8), (8, 8), (9, 8), (10_000_000, 8), (200_000_000, 8), (25_000_001, 3), ((1 << 33) + 5, 7)]
+    out = subprocess.check_output([str(exe)] + [str(x) for c in cases for x in c]).decode().strip().split("\n")
+    for (n, w), line in zip(cases, out):
+        v = [int(x) for x in line.split()]
+        for r in range(w):
+            lo, hi = shard_range(n, r, w)
+            assert v[3 * r:3 * r + 3] == [lo, hi, hi - lo], (n, w, r)
