@@ -341,6 +341,77 @@ bool score_pattern_blocking(const scheme_type& scoring, const pattern_string pat
     return true;
 }
 
+// ungapped ("Hamming") scoring (hamming/hamming_inl.h:413-1270): the linear-gap sweeps with the gap terms removed and every
+// border zero -- H(i,j) = H(i-1,j-1) + S, clamped at zero for LOCAL; 16-symbol blocks, the same report order as the sweeps above.
+// TEXT_BLOCKING walks the text in blocks with a column over the pattern (no early exit), otherwise the pattern in blocks with
+// a column over the text (early exit on the block's right edge, :654-656).
+template <bool TEXT_BLOCKING, AlignmentType TYPE, typename scheme_type, typename pattern_string, typename qual_string, typename text_string, typename sink_type, typename column_type>
+NVBIO_HOST_DEVICE inline
+bool hamming_score(const scheme_type& scoring, const pattern_string pattern, const qual_string quals, const text_string text,
+                   const int32 min_score, sink_type& sink, column_type column)
+{
+    const uint32 BL = 16u;
+    const uint32 M = pattern.length(), N = text.length();
+    const uint32 OUTER = TEXT_BLOCKING ? N : M, INNER = TEXT_BLOCKING ? M : N;     // blocked-over string, column string
+    for (uint32 i = 0; i < INNER; ++i) column[i] = int16(0);
+    int32 H[BL + 1];
+    uint8 sym[BL], ql[BL];
+    for (uint32 t = 0; t < BL; ++t) { sym[t] = 0; ql[t] = 0; }
+    const uint32 padded = BL * ((OUTER + BL - 1u) / BL);
+    const uint32 end_block = padded > BL ? padded : BL;
+    for (uint32 block = 0; block + BL <= end_block; block += BL)
+    {
+        const bool last = (block + BL == end_block);
+        for (uint32 t = 0; t < BL; ++t)
+            if (block + t < OUTER)
+            {
+                if (TEXT_BLOCKING) sym[t] = uint8(text[block + t]);
+                else { sym[t] = uint8(pattern[block + t]); ql[t] = uint8(quals[block + t]); }
+            }
+        for (uint32 j = 0; j <= BL; ++j) H[j] = 0;
+        int32 best_edge = int32(-2147483647 - 1);
+        int32 carry = 0;
+        for (uint32 i = 0; i < INNER; ++i)
+        {
+            const uint8 o = TEXT_BLOCKING ? uint8(pattern[i]) : uint8(text[i]);
+            const uint8 oq = TEXT_BLOCKING ? uint8(quals[i]) : uint8(0);
+            int32 diag = carry;
+            H[0] = carry = column[i];
+            for (uint32 j = 1; j <= BL; ++j)
+            {
+                const uint8 r = TEXT_BLOCKING ? sym[j - 1] : o, q = TEXT_BLOCKING ? o : sym[j - 1], qq = TEXT_BLOCKING ? oq : ql[j - 1];
+                int32 h = diag + (r == q ? scoring.match(qq) : scoring.mismatch(r, q, qq));
+                if (TYPE == LOCAL) h = nvbio::max(h, int32(0));
+                diag = H[j];
+                H[j] = h;
+            }
+            column[i] = int16(H[BL]);
+            best_edge = nvbio::max(best_edge, H[BL]);
+            if (TYPE == LOCAL)
+            {
+                for (uint32 j = 1; j <= BL; ++j)
+                    if (!last || block + j <= OUTER) sink.report(H[j], TEXT_BLOCKING ? make_uint2(block + j, i + 1u) : make_uint2(i + 1u, block + j));
+            }
+            else if (!TEXT_BLOCKING && last && TYPE == SEMI_GLOBAL) sink.report(H[((M - 1u) & (BL - 1u)) + 1u], make_uint2(i + 1u, M));
+        }
+        if (TEXT_BLOCKING)
+        {
+            if (TYPE == SEMI_GLOBAL)         { for (uint32 j = 1; j <= BL; ++j) if (!last || block + j <= N) sink.report(H[j], make_uint2(block + j, M)); }
+            else if (TYPE == GLOBAL && last) { for (uint32 j = 1; j <= BL; ++j) if (block + j == N) sink.report(H[j], make_uint2(block + j, M)); }
+        }
+        else if (!last && int64(best_edge) + int64(M - block - BL) * scoring.match(255) < int64(min_score)) return false;
+    }
+    if (!TEXT_BLOCKING && TYPE == GLOBAL) sink.report(H[((M - 1u) & (BL - 1u)) + 1u], make_uint2(N, M));
+    return true;
+}
+
+/// the boundary column as the int16 entries the sweeps index: callers hand in a pointer to the reference's
+/// column_storage_type<aligner>::type (short2 per symbol for Gotoh, int16 otherwise) or to plain int16s
+template <typename T> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE T      column_words(T c)       { return c; }
+#if defined(__HIPCC__)
+NVBIO_FORCEINLINE NVBIO_HOST_DEVICE int16* column_words(short2* c) { return reinterpret_cast<int16*>(c); }
+#endif
+
 template <AlignmentType TYPE, typename S, typename P, typename Q, typename T, typename K, typename C>
 NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool full_score(const GotohAligner<TYPE, S, TextBlockingTag>& al, const P p, const Q q, const T t, const int32 ms, K& sink, C col)
 { return gotoh_score_text_blocking<TYPE>(al.scheme, p, q, t, ms, sink, col); }
@@ -360,6 +431,13 @@ template <AlignmentType TYPE, typename P, typename Q, typename T, typename K, ty
 NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool full_score(const EditDistanceAligner<TYPE, PatternBlockingTag>&, const P p, const Q q, const T t, const int32 ms, K& sink, C col)
 { return score_pattern_blocking<true, TYPE>(EditDistanceSWScheme(), p, q, t, ms, sink, col); }
 
+template <AlignmentType TYPE, typename S, typename P, typename Q, typename T, typename K, typename C>
+NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool full_score(const HammingDistanceAligner<TYPE, S, TextBlockingTag>& al, const P p, const Q q, const T t, const int32 ms, K& sink, C col)
+{ return hamming_score<true, TYPE>(al.scheme, p, q, t, ms, sink, col); }
+template <AlignmentType TYPE, typename S, typename P, typename Q, typename T, typename K, typename C>
+NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool full_score(const HammingDistanceAligner<TYPE, S, PatternBlockingTag>& al, const P p, const Q q, const T t, const int32 ms, K& sink, C col)
+{ return hamming_score<false, TYPE>(al.scheme, p, q, t, ms, sink, col); }
+
 /// int16 entries of boundary column an aligner needs for a (pattern, text) pair: per symbol of the string it does NOT block over
 template <typename aligner_type> struct column_entries {};
 template <AlignmentType T, typename S> struct column_entries< GotohAligner<T, S, TextBlockingTag> >          { NVBIO_HOST_DEVICE static uint32 get(uint32 M, uint32)   { return 2u * M; } };
@@ -368,6 +446,8 @@ template <AlignmentType T, typename S> struct column_entries< SmithWatermanAlign
 template <AlignmentType T, typename S> struct column_entries< SmithWatermanAligner<T, S, PatternBlockingTag> > { NVBIO_HOST_DEVICE static uint32 get(uint32, uint32 N) { return N; } };
 template <AlignmentType T> struct column_entries< EditDistanceAligner<T, TextBlockingTag> >                  { NVBIO_HOST_DEVICE static uint32 get(uint32 M, uint32)   { return M; } };
 template <AlignmentType T> struct column_entries< EditDistanceAligner<T, PatternBlockingTag> >               { NVBIO_HOST_DEVICE static uint32 get(uint32, uint32 N)   { return N; } };
+template <AlignmentType T, typename S> struct column_entries< HammingDistanceAligner<T, S, TextBlockingTag> >    { NVBIO_HOST_DEVICE static uint32 get(uint32 M, uint32) { return M; } };
+template <AlignmentType T, typename S> struct column_entries< HammingDistanceAligner<T, S, PatternBlockingTag> > { NVBIO_HOST_DEVICE static uint32 get(uint32, uint32 N) { return N; } };
 
 } // namespace priv
 
@@ -414,7 +494,7 @@ NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
 bool alignment_score(const aligner_type aligner, const pattern_string pattern, const qual_string quals, const text_string text,
                      const int32 min_score, sink_type& sink, column_type column)
 {
-    return priv::full_score(aligner, pattern, quals, text, min_score, sink, column);
+    return priv::full_score(aligner, pattern, quals, text, min_score, sink, priv::column_words(column));
 }
 /// ... with the column in local storage sized by a compile-time bound on the blocked-over string (alignment.h:510-527)
 template <uint32 MAX_LEN, typename aligner_type, typename pattern_string, typename qual_string, typename text_string, typename sink_type>

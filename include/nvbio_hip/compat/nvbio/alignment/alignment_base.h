@@ -132,8 +132,60 @@ struct HammingDistanceAligner
 };
 template <AlignmentType TYPE, typename scoring_scheme_type> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
 HammingDistanceAligner<TYPE, scoring_scheme_type> make_hamming_distance_aligner(const scoring_scheme_type& scheme) { return HammingDistanceAligner<TYPE, scoring_scheme_type>(scheme); }
+template <AlignmentType TYPE, typename scoring_scheme_type, typename algorithm_tag> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
+HammingDistanceAligner<TYPE, scoring_scheme_type, algorithm_tag> make_hamming_distance_aligner(const scoring_scheme_type& scheme) { return HammingDistanceAligner<TYPE, scoring_scheme_type, algorithm_tag>(scheme); }
+
+namespace priv { typedef nvbio::aln::EditDistanceSWScheme EditDistanceSWScheme; }       // the reference keeps it in priv (ed/ed_utils.h)
+
+/// the cell type of the boundary column a full-matrix score pass is handed (alignment/utils.h:58-64)
+template <typename aligner_type> struct column_storage_type { typedef null_type type; };
+template <AlignmentType T, typename A>             struct column_storage_type< EditDistanceAligner<T, A> >       { typedef int16 type; };
+template <AlignmentType T, typename S, typename A> struct column_storage_type< HammingDistanceAligner<T, S, A> > { typedef int16 type; };
+template <AlignmentType T, typename S, typename A> struct column_storage_type< SmithWatermanAligner<T, S, A> >   { typedef int16 type; };
+#if defined(__HIPCC__)
+template <AlignmentType T, typename S, typename A> struct column_storage_type< GotohAligner<T, S, A> >           { typedef short2 type; };
+#else
+template <AlignmentType T, typename S, typename A> struct column_storage_type< GotohAligner<T, S, A> >           { struct type { int16 x, y; }; };
+#endif
+
+/// max_pattern_gaps / max_text_gaps(aligner, min_score, pattern_len) (alignment/utils.h:136-222, utils_inl.h:36-200): how many gap
+/// symbols an alignment of a pattern_len pattern can hold and still reach min_score -- nvBowtie sizes the opposite-mate window
+/// with it (score_opposite_inl.h:139).  Start from the all-match score (match(30) per symbol), pay the opening once (affine
+/// gaps), then count extensions while the score holds; the count is capped at pattern_len and the result is "steps - 1", which
+/// wraps to 0xFFFFFFFF when the opening alone already sinks the score (kept: callers add it to a length as a signed value).
+namespace priv {
+NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 affordable_gaps(int32 score, const int32 min_score, const int32 open, const int32 step, const int32 pattern_len)
+{
+    if (score < min_score) return 0u;
+    score += open;
+    uint32 n = 0;
+    for (; score >= min_score && n < uint32(pattern_len); ++n) score += step;
+    return n - 1u;
+}
+} // namespace priv
+template <AlignmentType T, typename A> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
+uint32 max_pattern_gaps(const EditDistanceAligner<T, A>&, const int32 min_score, const int32) { return uint32(-min_score); }
+template <AlignmentType T, typename A> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
+uint32 max_text_gaps(const EditDistanceAligner<T, A>&, const int32 min_score, const int32) { return uint32(-min_score); }
+template <AlignmentType T, typename S, typename A> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
+uint32 max_pattern_gaps(const HammingDistanceAligner<T, S, A>&, const int32, const int32) { return 0u; }
+template <AlignmentType T, typename S, typename A> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
+uint32 max_text_gaps(const HammingDistanceAligner<T, S, A>&, const int32, const int32) { return 0u; }
+template <AlignmentType T, typename S, typename A> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
+uint32 max_pattern_gaps(const SmithWatermanAligner<T, S, A>& al, const int32 min_score, const int32 pattern_len)
+{ return priv::affordable_gaps(pattern_len * al.scheme.match(30), min_score, 0, al.scheme.deletion(), pattern_len); }
+template <AlignmentType T, typename S, typename A> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
+uint32 max_text_gaps(const SmithWatermanAligner<T, S, A>& al, const int32 min_score, const int32 pattern_len)
+{ return priv::affordable_gaps(pattern_len * al.scheme.match(30), min_score, 0, al.scheme.insertion(), pattern_len); }
+template <AlignmentType T, typename S, typename A> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
+uint32 max_pattern_gaps(const GotohAligner<T, S, A>& al, const int32 min_score, const int32 pattern_len)
+{ return priv::affordable_gaps(pattern_len * al.scheme.match(30), min_score, al.scheme.pattern_gap_open(), al.scheme.pattern_gap_extension(), pattern_len); }
+template <AlignmentType T, typename S, typename A> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
+uint32 max_text_gaps(const GotohAligner<T, S, A>& al, const int32 min_score, const int32 pattern_len)
+{ return priv::affordable_gaps(pattern_len * al.scheme.match(30), min_score, al.scheme.text_gap_open(), al.scheme.text_gap_extension(), pattern_len); }
 
 template <typename T> struct transpose_aligner {};
+template <AlignmentType T, typename S, typename A> struct transpose_aligner< HammingDistanceAligner<T, S, A> > { typedef HammingDistanceAligner<T, S, typename transpose_tag<A>::type> type; };
 template <AlignmentType T, typename A> struct transpose_aligner< EditDistanceAligner<T, A> > { typedef EditDistanceAligner<T, typename transpose_tag<A>::type> type; };
 template <AlignmentType T, typename S, typename A> struct transpose_aligner< GotohAligner<T, S, A> > { typedef GotohAligner<T, S, typename transpose_tag<A>::type> type; };
 template <AlignmentType T, typename S, typename A> struct transpose_aligner< SmithWatermanAligner<T, S, A> > { typedef SmithWatermanAligner<T, S, typename transpose_tag<A>::type> type; };

@@ -52,6 +52,11 @@ typedef DeviceThreadBlockScheduler<128, 1> DeviceThreadScheduler;
 struct DeviceStagedThreadScheduler {};
 struct DeviceWarpScheduler {};
 
+/// which schedulers a batch of a given aligner runs under (batched.h:78-100): all four for the gapped aligners, all but the
+/// warp scheduler for the ungapped one
+template <typename aligner_type, typename scheduler_type> struct supports_scheduler { static const bool pred = true; };
+template <AlignmentType TYPE, typename S, typename A> struct supports_scheduler< HammingDistanceAligner<TYPE, S, A>, DeviceWarpScheduler > { static const bool pred = false; };
+
 struct hip_error : public std::runtime_error {
     int code;
     hip_error(const char* what, int c) : std::runtime_error(std::string(what) + " failed, hipError " + std::to_string(c)), code(c) {}
@@ -133,17 +138,17 @@ template <typename S> struct quality_scheme<S, std::void_t<typename S::match_cos
 template <typename A> struct tuned_aligner { static const bool ok = false; static const bool QUAL = false; };
 #if defined(NVBIO_HIP_COMPAT_TUNED)
 template <AlignmentType T, typename G> struct tuned_aligner< GotohAligner<T, SimpleGotohScheme, G> > {
-    static const bool ok = true; static const bool QUAL = false; static const int32 KIND = NVBIO_HIP_GOTOH_ALIGNER; static const bool TEXT_BLOCKING = equal<G, TextBlockingTag>::pred;
+    static const bool ok = true; static const bool QUAL = false; static const int32 KIND = NVBIO_HIP_GOTOH_ALIGNER; static const bool TEXT_BLOCKING = same_type<G, TextBlockingTag>::pred;
     static void scheme4(const GotohAligner<T, SimpleGotohScheme, G>& a, int32* v) { v[0] = a.scheme.m_match; v[1] = a.scheme.m_mismatch; v[2] = a.scheme.m_gap_open; v[3] = a.scheme.m_gap_ext; } };
 template <AlignmentType T, typename G> struct tuned_aligner< SmithWatermanAligner<T, SimpleSmithWatermanScheme, G> > {
-    static const bool ok = true; static const bool QUAL = false; static const int32 KIND = NVBIO_HIP_SW_ALIGNER; static const bool TEXT_BLOCKING = equal<G, TextBlockingTag>::pred;
+    static const bool ok = true; static const bool QUAL = false; static const int32 KIND = NVBIO_HIP_SW_ALIGNER; static const bool TEXT_BLOCKING = same_type<G, TextBlockingTag>::pred;
     static void scheme4(const SmithWatermanAligner<T, SimpleSmithWatermanScheme, G>& a, int32* v) { v[0] = a.scheme.m_match; v[1] = a.scheme.m_mismatch; v[2] = a.scheme.m_deletion; v[3] = a.scheme.m_insertion; } };
 template <AlignmentType T, typename G> struct tuned_aligner< EditDistanceAligner<T, G> > {
-    static const bool ok = true; static const bool QUAL = false; static const int32 KIND = NVBIO_HIP_SW_ALIGNER; static const bool TEXT_BLOCKING = equal<G, TextBlockingTag>::pred;
+    static const bool ok = true; static const bool QUAL = false; static const int32 KIND = NVBIO_HIP_SW_ALIGNER; static const bool TEXT_BLOCKING = same_type<G, TextBlockingTag>::pred;
     static void scheme4(const EditDistanceAligner<T, G>&, int32* v) { v[0] = 0; v[1] = -1; v[2] = -1; v[3] = -1; } };
 /// a Gotoh aligner over a scheme of nvBowtie's concept: its 256 mismatch penalties are tabulated on the host
 template <AlignmentType T, typename S, typename G> struct tuned_aligner< GotohAligner<T, S, G> > {
-    static const bool ok = quality_scheme<S>::value; static const bool QUAL = true; static const int32 KIND = NVBIO_HIP_GOTOH_ALIGNER; static const bool TEXT_BLOCKING = equal<G, TextBlockingTag>::pred;
+    static const bool ok = quality_scheme<S>::value; static const bool QUAL = true; static const int32 KIND = NVBIO_HIP_GOTOH_ALIGNER; static const bool TEXT_BLOCKING = same_type<G, TextBlockingTag>::pred;
     /// false when the scheme's values do not follow the concept (a match bonus that depends on the quality, a substitution score
     /// that depends on more than (equal?, quality)): such a stream runs on the generic lane
     static bool table(const GotohAligner<T, S, G>& a, nvbio_hip_gotoh_qual_scheme& q)
@@ -801,9 +806,9 @@ struct BatchedBandedAlignmentTraceback
                )
     {
 #if defined(__HIPCC__)
-        dispatch(stream, hip_stream, std::integral_constant<bool, equal<algorithm_type, HostThreadScheduler>::pred>());
+        dispatch(stream, hip_stream, std::integral_constant<bool, same_type<algorithm_type, HostThreadScheduler>::pred>());
 #else
-        static_assert(equal<algorithm_type, HostThreadScheduler>::pred, "the device schedulers need a translation unit compiled by hipcc");
+        static_assert(same_type<algorithm_type, HostThreadScheduler>::pred, "the device schedulers need a translation unit compiled by hipcc");
         m_run.run_host(stream);
 #endif
     }
@@ -827,9 +832,9 @@ struct BatchedAlignmentTraceback
                )
     {
 #if defined(__HIPCC__)
-        dispatch(stream, hip_stream, std::integral_constant<bool, equal<algorithm_type, HostThreadScheduler>::pred>());
+        dispatch(stream, hip_stream, std::integral_constant<bool, same_type<algorithm_type, HostThreadScheduler>::pred>());
 #else
-        static_assert(equal<algorithm_type, HostThreadScheduler>::pred, "the device schedulers need a translation unit compiled by hipcc");
+        static_assert(same_type<algorithm_type, HostThreadScheduler>::pred, "the device schedulers need a translation unit compiled by hipcc");
         m_run.run_host(stream);
 #endif
     }
@@ -883,7 +888,7 @@ void batch_banded_alignment_score(const aligner_type aligner, const pattern_set_
     BatchedBandedAlignmentScore<BAND_LEN, stream_type, scheduler_type> batch;
     batch.enact(stream_type(aligner, patterns.size(), patterns, texts, sinks, max_pattern_length, max_text_length));
 #if defined(__HIPCC__)
-    if (!equal<scheduler_type, HostThreadScheduler>::pred) priv::check(hipStreamSynchronize(0), "hipStreamSynchronize");    // the batch object's buffers die here
+    if (!same_type<scheduler_type, HostThreadScheduler>::pred) priv::check(hipStreamSynchronize(0), "hipStreamSynchronize");    // the batch object's buffers die here
 #endif
 }
 /// batch_alignment_score(aligner, patterns, texts, sinks, scheduler, maxP, maxT)   (batched.h:160-190)
@@ -895,7 +900,7 @@ void batch_alignment_score(const aligner_type aligner, const pattern_set_type pa
     BatchedAlignmentScore<stream_type, scheduler_type> batch;
     batch.enact(stream_type(aligner, patterns.size(), patterns, texts, sinks, max_pattern_length, max_text_length));
 #if defined(__HIPCC__)
-    if (!equal<scheduler_type, HostThreadScheduler>::pred) priv::check(hipStreamSynchronize(0), "hipStreamSynchronize");
+    if (!same_type<scheduler_type, HostThreadScheduler>::pred) priv::check(hipStreamSynchronize(0), "hipStreamSynchronize");
 #endif
 }
 

@@ -288,5 +288,45 @@ NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint64 full_traceback_scratch(const uint32 m
 { return full_traceback_flag_bytes(maxP, maxT) + full_traceback_row_bytes(maxP) + full_traceback_column_bytes(maxT); }
 
 } // namespace priv
+
+// ---------------------------------------------------------------------------------------- public per-thread functions
+// The storage-less forms (banded_inl.h:450-489, alignment_inl.h:482-560): the reference sizes checkpoint + sub-matrix scratch
+// from its template bounds and keeps it in local memory; here the scratch is the dense flag matrix of the generic tracebacks
+// above -- MAX_PATTERN_LEN x BAND_LEN (banded) or MAX_PATTERN_LEN x MAX_TEXT_LEN (full) bytes -- taken from the heap in host
+// code and from the lane's private memory in device code (CHECKPOINTS is accepted and unused: nothing is recomputed).
+namespace priv {
+template <typename T, uint64 N> struct scratch
+{
+#if defined(NVBIO_DEVICE_COMPILATION)
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE T* get() { return m; }
+    T m[N];
+#else
+    scratch() : m(new T[N]) {}
+    ~scratch() { delete[] m; }
+    T* get() { return m; }
+    T* m;
+#endif
+};
+} // namespace priv
+
+template <uint32 BAND_LEN, uint32 MAX_PATTERN_LEN, uint32 CHECKPOINTS, typename aligner_type, typename pattern_string, typename qual_string, typename text_string, typename backtracer_type>
+NVBIO_HOST_DEVICE inline
+Alignment<int32> banded_alignment_traceback(const aligner_type aligner, const pattern_string pattern, const qual_string quals, const text_string text,
+                                            const int32 /*min_score*/, backtracer_type& backtracer)
+{
+    priv::scratch<uint8, uint64(MAX_PATTERN_LEN) * BAND_LEN> flags;
+    return priv::banded_traceback<BAND_LEN>(aligner, pattern, quals, text, backtracer, flags.get());
+}
+template <uint32 MAX_PATTERN_LEN, uint32 MAX_TEXT_LEN, uint32 CHECKPOINTS, typename aligner_type, typename pattern_string, typename qual_string, typename text_string, typename backtracer_type>
+NVBIO_HOST_DEVICE inline
+Alignment<int32> alignment_traceback(const aligner_type aligner, const pattern_string pattern, const qual_string quals, const text_string text,
+                                     const int32 /*min_score*/, backtracer_type& backtracer)
+{
+    priv::scratch<uint8, uint64(MAX_PATTERN_LEN) * MAX_TEXT_LEN> flags;
+    priv::scratch<int32, 2ull * (MAX_PATTERN_LEN + 1u)>          rows;
+    priv::scratch<int16, 2ull * MAX_TEXT_LEN + 8u>               column;
+    return priv::matrix_traceback(aligner, pattern, quals, text, backtracer, flags.get(), rows.get(), column.get());
+}
+
 } // namespace aln
 } // namespace nvbio

@@ -3,6 +3,7 @@
 // wrapper only forwards (same values, same interface).
 #pragma once
 #include "types.h"
+#include "iterator.h"
 
 namespace nvbio {
 

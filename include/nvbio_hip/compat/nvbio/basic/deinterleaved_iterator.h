@@ -5,18 +5,9 @@
 // (nvbio/io/fmindex/fmindex.h:159-174).
 #pragma once
 #include "types.h"
+#include "iterator.h"
 
 namespace nvbio {
-
-namespace priv {
-template <typename V> struct vec_comp { typedef V type; NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static V get(const V& v, uint32) { return v; } static const uint32 N = 1; };
-template <> struct vec_comp<uint4> { typedef uint32 type; static const uint32 N = 4;
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static uint32 get(const uint4& v, const uint32 k) { return k <= 1u ? (k == 0u ? v.x : v.y) : (k == 2u ? v.z : v.w); } };
-template <> struct vec_comp<uint2> { typedef uint32 type; static const uint32 N = 2;
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static uint32 get(const uint2& v, const uint32 k) { return k == 0u ? v.x : v.y; } };
-template <> struct vec_comp<ulonglong4> { typedef uint64 type; static const uint32 N = 4;
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static uint64 get(const ulonglong4& v, const uint32 k) { return k <= 1u ? (k == 0u ? v.x : v.y) : (k == 2u ? v.z : v.w); } };
-} // namespace priv
 
 template <uint32 STRIDE, uint32 WHICH, typename BaseIterator>
 struct deinterleaved_iterator

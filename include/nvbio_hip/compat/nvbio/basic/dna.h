@@ -19,4 +19,12 @@ template <typename SymbolIterator>
 NVBIO_HOST_DEVICE inline void dna_to_string(const SymbolIterator begin, const SymbolIterator end, char* string)
 { uint32 i = 0; for (SymbolIterator it = begin; it != end; ++it) string[i++] = dna_to_char(*it); string[i] = '\0'; }
 
+/// ASCII -> DNA symbols, for a [begin, end) range or a NUL-terminated string (dna.h:165-190)
+template <typename SymbolIterator>
+NVBIO_HOST_DEVICE inline void string_to_dna(const char* begin, const char* end, SymbolIterator symbols)
+{ for (uint32 i = 0; begin + i != end; ++i) symbols[i] = char_to_dna(begin[i]); }
+template <typename SymbolIterator>
+NVBIO_HOST_DEVICE inline void string_to_dna(const char* begin, SymbolIterator symbols)
+{ for (uint32 i = 0; begin[i] != '\0'; ++i) symbols[i] = char_to_dna(begin[i]); }
+
 } // namespace nvbio

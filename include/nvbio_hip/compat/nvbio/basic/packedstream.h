@@ -7,6 +7,8 @@
 // sw-benchmark's references 2-bit LE).
 #pragma once
 #include "types.h"
+#include "numbers.h"
+#include "iterator.h"
 // <endian.h> defines BIG_ENDIAN as a macro; the reference drops it (packedstream.h:38-40) because PackedStream has a member of that name
 #if defined(BIG_ENDIAN)
 #undef BIG_ENDIAN
@@ -30,7 +32,9 @@ struct PackedStream
     typedef typename unsigned_type<IndexType>::type                          index_type;
     typedef typename signed_type<IndexType>::type                            sindex_type;
     typedef typename std::iterator_traits<InputStream>::value_type           storage_type;
-    static const uint32 WORD_SIZE         = uint32(8u * sizeof(storage_type));
+    typedef priv::vec_comp<storage_type>                                     storage_comp;        ///< uint4 / uint2 storage is seen as its scalar words
+    typedef typename storage_comp::type                                      word_type;
+    static const uint32 WORD_SIZE         = uint32(8u * sizeof(word_type));
     static const uint32 SYMBOLS_PER_WORD  = WORD_SIZE / SYMBOL_SIZE_T;
 
     typedef InputStream                      stream_type;
@@ -57,19 +61,31 @@ struct PackedStream
     NVBIO_FORCEINLINE NVBIO_HOST_DEVICE Symbol get(const index_type i) const
     {
         const index_type s = m_index + i;
-        const storage_type w = m_stream[s / SYMBOLS_PER_WORD];
+        const word_type w = word(s / SYMBOLS_PER_WORD);
         const uint32 k = uint32(s % SYMBOLS_PER_WORD);
         const uint32 sh = BIG_ENDIAN_T ? (WORD_SIZE - SYMBOL_SIZE_T * (k + 1u)) : (SYMBOL_SIZE_T * k);
-        return Symbol((w >> sh) & storage_type(SYMBOL_MASK));
+        return Symbol((w >> sh) & word_type(SYMBOL_MASK));
     }
     NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void set(const index_type i, const Symbol v)
     {
         const index_type s = m_index + i;
         const uint32 k = uint32(s % SYMBOLS_PER_WORD);
         const uint32 sh = BIG_ENDIAN_T ? (WORD_SIZE - SYMBOL_SIZE_T * (k + 1u)) : (SYMBOL_SIZE_T * k);
-        storage_type w = m_stream[s / SYMBOLS_PER_WORD];
-        w = (w & ~(storage_type(SYMBOL_MASK) << sh)) | (storage_type(uint32(v) & SYMBOL_MASK) << sh);
-        m_stream[s / SYMBOLS_PER_WORD] = w;
+        word_type w = word(s / SYMBOLS_PER_WORD);
+        w = (w & ~(word_type(SYMBOL_MASK) << sh)) | (word_type(uint32(v) & SYMBOL_MASK) << sh);
+        set_word(s / SYMBOLS_PER_WORD, w);
+    }
+    /// scalar word j of the underlying storage (absolute: the stream's own symbol offset is not applied)
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE word_type word(const index_type j) const
+    {
+        if (storage_comp::N == 1u) return storage_comp::get(m_stream[j], 0u);
+        return storage_comp::get(m_stream[j / storage_comp::N], uint32(j % storage_comp::N));
+    }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void set_word(const index_type j, const word_type w)
+    {
+        storage_type e = m_stream[j / storage_comp::N];
+        storage_comp::put(e, uint32(j % storage_comp::N), w);
+        m_stream[j / storage_comp::N] = e;
     }
     NVBIO_FORCEINLINE NVBIO_HOST_DEVICE Symbol get() const { return get(0); }
     NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void   set(const Symbol v) { set(0, v); }

@@ -26,6 +26,7 @@
 #include <stddef.h>
 #include <iterator>
 #include <limits>
+#include <new>
 
 namespace nvbio {
 
@@ -76,8 +77,15 @@ template <> struct unsigned_type<int32>  { typedef uint32 type; };
 template <> struct unsigned_type<uint64> { typedef uint64 type; };
 template <> struct unsigned_type<int64>  { typedef uint64 type; };
 
-template <typename A, typename B> struct equal { static const bool pred = false; };
-template <typename A>             struct equal<A, A> { static const bool pred = true; };
+/// same_type<A,B>::pred and equal<A,B>()   (nvbio/basic/types.h:222-230)
+template <typename A, typename B> struct same_type { static const bool pred = false; };
+template <typename A>             struct same_type<A, A> { static const bool pred = true; };
+template <typename A, typename B> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool equal() { return same_type<A, B>::pred; }
+/// a rounded up to a multiple of the power of two N   (types.h:283)
+template <uint32 N, typename I> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE I align(const I a) { return N > 1u ? I((a + I(N - 1u)) & ~I(N - 1u)) : a; }
+/// binary_switch / if_true selectors used in template signatures
+template <bool B, typename T, typename F> struct if_true { typedef T type; };
+template <typename T, typename F> struct if_true<false, T, F> { typedef F type; };
 
 /// Field_traits<T>::min() / max() with the reference's values (numbers.h:795-850): the 32- and 64-bit signed extremes are
 /// +-2^30 and +-2^62, not the type limits -- BestSink starts at -2^30 and streams use it as "no threshold"
@@ -98,6 +106,23 @@ template <typename T> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE T min3(const T a, cons
 NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 divide_ri(const uint32 a, const uint32 b) { return (a + b - 1u) / b; }
 NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 popc(const uint32 x) { return uint32(__builtin_popcount(x)); }
 NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 popc(const uint64 x) { return uint32(__builtin_popcountll(x)); }
+
+namespace priv {
+/// the scalar words of a (possibly vector-valued) storage element: uint4 -> 4 x uint32, ulonglong2 -> 2 x uint64, T -> T.
+/// PackedStream, deinterleaved_iterator and the rank dictionary see every word iterator through this.
+template <typename V> struct vec_comp { typedef V type; static const uint32 N = 1;
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static V get(const V& v, uint32) { return v; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static void put(V& v, uint32, const V x) { v = x; } };
+#define NVBIO_HIP_VEC_COMP2(V, T) template <> struct vec_comp<V> { typedef T type; static const uint32 N = 2; \
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static T get(const V& v, const uint32 k) { return k == 0u ? v.x : v.y; } \
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static void put(V& v, const uint32 k, const T x) { if (k == 0u) v.x = x; else v.y = x; } };
+#define NVBIO_HIP_VEC_COMP4(V, T) template <> struct vec_comp<V> { typedef T type; static const uint32 N = 4; \
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static T get(const V& v, const uint32 k) { return k <= 1u ? (k == 0u ? v.x : v.y) : (k == 2u ? v.z : v.w); } \
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static void put(V& v, const uint32 k, const T x) { if (k == 0u) v.x = x; else if (k == 1u) v.y = x; else if (k == 2u) v.z = x; else v.w = x; } };
+NVBIO_HIP_VEC_COMP2(uint2, uint32) NVBIO_HIP_VEC_COMP4(uint4, uint32) NVBIO_HIP_VEC_COMP2(ulonglong2, uint64) NVBIO_HIP_VEC_COMP4(ulonglong4, uint64)
+#undef NVBIO_HIP_VEC_COMP2
+#undef NVBIO_HIP_VEC_COMP4
+} // namespace priv
 
 /// string_traits<Iterator>::value_type
 template <typename T> struct string_traits { typedef typename T::value_type value_type; typedef uint32 index_type; };

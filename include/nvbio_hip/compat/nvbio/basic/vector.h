@@ -35,6 +35,22 @@ struct vector<device_tag, T> : public thrust::device_vector<T>
     template <typename OtherVector> vector& operator=(const OtherVector& v) { base_type::operator=(v); return *this; }
 };
 
+namespace cuda {
+/// resize-and-copy between thrust vectors of either system (nvbio/basic/vector.h:44-69)
+template <typename TTargetVector, typename TSourceVector>
+inline void thrust_copy_vector(TTargetVector& target, TSourceVector& source)
+{
+    target.resize(source.size());
+    thrust::copy(source.begin(), source.end(), target.begin());
+}
+template <typename TTargetVector, typename TSourceVector>
+inline void thrust_copy_vector(TTargetVector& target, TSourceVector& source, uint32 count)
+{
+    target.resize(count);
+    thrust::copy(source.begin(), source.begin() + count, target.begin());
+}
+} // namespace cuda
+
 template <typename T> inline T*       raw_pointer(thrust::device_vector<T>& v)       { return v.empty() ? (T*)0 : thrust::raw_pointer_cast(&v.front()); }
 template <typename T> inline const T* raw_pointer(const thrust::device_vector<T>& v) { return v.empty() ? (const T*)0 : thrust::raw_pointer_cast(&v.front()); }
 template <typename T> inline T*       raw_pointer(thrust::host_vector<T>& v)         { return v.empty() ? (T*)0 : &v.front(); }

@@ -21,6 +21,8 @@ struct vector_view
 
     NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void      resize(const uint32 sz) { m_size = sz; }
     NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void      clear() { m_size = 0; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void      push_back(const value_type& v) { m_vec[m_size++] = v; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void      pop_back() { --m_size; }
     NVBIO_FORCEINLINE NVBIO_HOST_DEVICE IndexType size() const { return m_size; }
     NVBIO_FORCEINLINE NVBIO_HOST_DEVICE IndexType length() const { return m_size; }
     NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool      empty() const { return m_size == 0; }

@@ -138,7 +138,7 @@ struct production_layout< fm_index< rank_dictionary<2, 64, PackedStream<deinterl
                       SSA_index_multiple_context<K, SI>, L> index_type;
     typedef typename index_type::L2_iterator L2_iterator;
     static const bool ok = uint4_pointer<B0>::ok && uint4_pointer<B1>::ok && nvbio::priv::word_pointer<SI>::ok && l2_pointer<L2_iterator>::ok &&
-                           (K & (K - 1u)) == 0u && equal<typename index_type::index_type, uint32>::pred;
+                           (K & (K - 1u)) == 0u && same_type<typename index_type::index_type, uint32>::pred;
 #if defined(NVBIO_HIP_COMPAT_FILTER_TUNED)
     /// fill the C-ABI description; false when the two halves are not one interleaved array starting at its first record
     static bool describe(const index_type& f, nvbio_hip_fmindex& m)

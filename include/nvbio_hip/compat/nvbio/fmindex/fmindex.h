@@ -8,6 +8,7 @@
 // nvBowtie's own match_range, mapping_inl.h:90.)
 #pragma once
 #include "rank_dictionary.h"
+
 #include "ssa.h"
 
 namespace nvbio {
@@ -15,7 +16,7 @@ namespace nvbio {
 template <typename A, typename B, typename T, typename F> struct if_equal { typedef F type; };
 template <typename A, typename T, typename F> struct if_equal<A, A, T, F> { typedef T type; };
 
-template <typename TRankDictionary, typename TSuffixArray, typename TL2 = null_type>
+template <typename TRankDictionary, typename TSuffixArray, typename TL2>
 struct fm_index
 {
     typedef TRankDictionary                         rank_dictionary_type;
@@ -78,6 +79,43 @@ typename R::vec4_type rank4(const NVBIO_FMI& fmi, typename NVBIO_FMI::index_type
     return rank4(fmi.m_rank_dict, k);
 }
 
+/// ... of both ends of a range, the form nvBowtie's 1-mismatch map<> steps with (fmindex_inl.h:138-186, mapping_inl.h:178).
+/// The '$' adjustments are applied per end and the two ends go to the dictionary together, so that on the production layout
+/// they share one 32-byte record when they fall in the same block.
+NVBIO_FMI_T NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
+void rank4(const NVBIO_FMI& fmi, typename NVBIO_FMI::range_type range, typename R::vec4_type* outl, typename R::vec4_type* outh)
+{
+    typedef typename NVBIO_FMI::index_type index_type;
+    if (range.x == range.y) { *outl = rank4(fmi, range.x); *outh = *outl; return; }
+    if (range.x == index_type(-1) || range.y == fmi.length() || range.y == index_type(-1) || range.x == fmi.length())
+    { *outl = rank4(fmi, range.x); *outh = rank4(fmi, range.y); return; }
+    if (range.x >= fmi.primary()) --range.x;
+    if (range.y >= fmi.primary()) --range.y;
+    rank4(fmi.m_rank_dict, range, outl, outh);
+}
+/// every symbol of the alphabet (fmindex_inl.h:188-262).  The reference's single-ended form falls through its k == -1 and
+/// k == length branches into the dictionary query (:208-222, reading out of bounds); here those branches return.
+NVBIO_FMI_T NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
+void rank_all(const NVBIO_FMI& fmi, typename NVBIO_FMI::index_type k, typename NVBIO_FMI::vector_type* out)
+{
+    typedef typename NVBIO_FMI::index_type index_type;
+    if (k == index_type(-1)) { for (uint32 c = 0; c < fmi.symbol_count(); ++c) (*out)[c] = 0; return; }
+    if (k == fmi.length())   { for (uint32 c = 0; c < fmi.symbol_count(); ++c) (*out)[c] = fmi.count(c); return; }
+    if (k >= fmi.primary()) --k;
+    rank_all(fmi.m_rank_dict, k, out);
+}
+NVBIO_FMI_T NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
+void rank_all(const NVBIO_FMI& fmi, typename NVBIO_FMI::range_type range, typename NVBIO_FMI::vector_type* outl, typename NVBIO_FMI::vector_type* outh)
+{
+    typedef typename NVBIO_FMI::index_type index_type;
+    if (range.x == range.y) { rank_all(fmi, range.x, outl); *outh = *outl; return; }
+    if (range.x == index_type(-1) || range.y == fmi.length() || range.y == index_type(-1) || range.x == fmi.length())
+    { rank_all(fmi, range.x, outl); rank_all(fmi, range.y, outh); return; }
+    if (range.x >= fmi.primary()) --range.x;
+    if (range.y >= fmi.primary()) --range.y;
+    rank_all(fmi.m_rank_dict, range, outl, outh);
+}
+
 /// backward search from a given range   (fmindex_inl.h:307-341)
 template <typename R, typename S, typename L, typename Iterator> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
 typename NVBIO_FMI::range_type match(const NVBIO_FMI& fmi, const Iterator pattern, const uint32 pattern_len, const typename NVBIO_FMI::range_type in_range)
@@ -128,6 +166,15 @@ typename NVBIO_FMI::index_type basic_inv_psi(const NVBIO_FMI& fmi, const typenam
     return fmi.L2(c) + rank(fmi.m_rank_dict, k, uint32(c));
 }
 
+/// LF-walk until the suffix array knows the row: (row, steps)   (fmindex_inl.h:416-456)
+NVBIO_FMI_T NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
+typename NVBIO_FMI::range_type inv_psi(const NVBIO_FMI& fmi, const typename NVBIO_FMI::index_type i)
+{
+    typedef typename NVBIO_FMI::index_type index_type;
+    index_type j = i, t = 0, suffix;
+    while (!fmi.m_sa.fetch(j, suffix)) { j = basic_inv_psi(fmi, j); ++t; }
+    return make_vector(j, t);
+}
 /// LF-walk to the next sampled row: (row, steps)   (fmindex_inl.h:511-545)
 NVBIO_FMI_T NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
 typename NVBIO_FMI::range_type locate_ssa_iterator(const NVBIO_FMI& fmi, const typename NVBIO_FMI::index_type i)

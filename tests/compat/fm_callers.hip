@@ -4,6 +4,7 @@
 // over 32- and 64-bit indices, with separate bwt / occ arrays and with the interleaved uint4 production layout seen
 // through deinterleaved_iterator (nvbio/io/fmindex/fmindex.h:159-174).  Compiled with `hipcc -I include/nvbio_hip/compat`.
 #include <nvbio/basic/types.h>
+#include <nvbio/basic/numbers.h>
 #include <nvbio/basic/cached_iterator.h>
 #include <nvbio/basic/packedstream.h>
 #include <nvbio/basic/deinterleaved_iterator.h>
@@ -54,6 +55,78 @@ __global__ void rank_kernel(const uint32 n, const FMIndexType fmi, const typenam
     // the range form resolves both ends like two point queries
     const typename FMIndexType::range_type rr = rank(fmi, make_vector(index_type(rows[q] - 1), rows[q]), symbols[q]);
     if (rr.y != out[q] || rr.x != rank(fmi, index_type(rows[q] - 1), symbols[q])) out[q] = index_type(-7);
+}
+
+// the range forms a caller of nvBowtie's shape uses (mapping_inl.h:83-97, 128-220): rank4 / rank_all of both ends of an SA range,
+// read back with comp(); and a one-mismatch seed search built on them -- exact over query[0, len1), one substitution allowed in
+// query[len1, len2), walking the query front to back (each symbol is PREPENDED to the matched string).  Slot 0 of a query's
+// output holds the exact range, slot 1 + 3 * (i - len1) + k the range with position i replaced by the k-th other symbol; (1, 0) = none.
+template <typename FMIndexType>
+__global__ void rank4_range_kernel(const uint32 n, const FMIndexType fmi, const typename FMIndexType::index_type* lo_rows, const typename FMIndexType::index_type* hi_rows,
+                                   typename FMIndexType::index_type* out_lo, typename FMIndexType::index_type* out_hi, uint32* agree)
+{
+    typedef typename FMIndexType::index_type                        index_type;
+    typedef typename FMIndexType::rank_dictionary_type::vec4_type   vec4_type;
+    const uint32 q = threadIdx.x + blockIdx.x * blockDim.x;
+    if (q >= n) return;
+    vec4_type lo, hi;
+    rank4(fmi, make_vector(lo_rows[q], hi_rows[q]), &lo, &hi);
+    for (uint32 c = 0; c < 4u; ++c) { out_lo[4 * q + c] = comp(lo, c); out_hi[4 * q + c] = comp(hi, c); }
+    // rank_all must say the same, and each end must equal its point query
+    typename FMIndexType::vector_type al, ah;
+    rank_all(fmi, make_vector(lo_rows[q], hi_rows[q]), &al, &ah);
+    const vec4_type pl = rank4(fmi, lo_rows[q]), ph = rank4(fmi, hi_rows[q]);
+    bool ok = true;
+    for (uint32 c = 0; c < 4u; ++c)
+        ok = ok && al[c] == comp(lo, c) && ah[c] == comp(hi, c) && comp(pl, c) == comp(lo, c) && comp(ph, c) == comp(hi, c)
+                && rank(fmi, make_vector(lo_rows[q], hi_rows[q]), uint8(c)).x == comp(lo, c) && rank(fmi, make_vector(lo_rows[q], hi_rows[q]), uint8(c)).y == comp(hi, c);
+    agree[q] = ok ? 1u : 0u;
+}
+
+template <typename FMIndexType, typename Query>
+NVBIO_FORCEINLINE NVBIO_DEVICE uint2 extend_exact(const FMIndexType& fmi, uint2 range, const Query query, const uint32 begin, const uint32 end)
+{
+    for (uint32 i = begin; i < end && range.x <= range.y; ++i)
+    {
+        const uint8 c = query[i];
+        if (c > 3) return make_uint2(1u, 0u);
+        const uint2 r = rank(fmi, make_uint2(range.x - 1u, range.y), c);
+        range = make_uint2(fmi.L2(c) + r.x + 1u, fmi.L2(c) + r.y);
+    }
+    return range;
+}
+template <typename FMIndexType>
+__global__ void one_mismatch_kernel(const uint32 n_queries, const uint32 len1, const uint32 len2, const uint32* genome_words, const FMIndexType fmi,
+                                    const uint32* starts, uint32* out_ranges)
+{
+    const uint32 q = threadIdx.x + blockIdx.x * blockDim.x;
+    if (q >= n_queries) return;
+    typedef PackedStream<const uint32*, uint8, 2, true> genome_string;
+    const genome_string query = genome_string(genome_words) + starts[q];
+    const uint32 slots = 1u + 3u * (len2 - len1);
+    uint32* out = out_ranges + 2ull * slots * q;
+    for (uint32 s = 0; s < slots; ++s) { out[2 * s] = 1u; out[2 * s + 1] = 0u; }
+
+    uint2 base = extend_exact(fmi, make_uint2(0u, fmi.length()), query, 0u, len1);
+    for (uint32 i = len1; i < len2 && base.x <= base.y; ++i)
+    {
+        const uint8 c = query[i];
+        uint4 lo, hi;
+        rank4(fmi, make_uint2(base.x - 1u, base.y), &lo, &hi);
+        uint32 k = 0;
+        for (uint8 sub = 0; sub < 4; ++sub)
+        {
+            if (sub == c) continue;
+            if (comp(hi, sub) > comp(lo, sub))
+            {
+                const uint2 r = extend_exact(fmi, make_uint2(fmi.L2(sub) + comp(lo, sub) + 1u, fmi.L2(sub) + comp(hi, sub)), query, i + 1u, len2);
+                if (r.x <= r.y) { out[2 * (1u + 3u * (i - len1) + k)] = r.x; out[2 * (1u + 3u * (i - len1) + k) + 1] = r.y; }
+            }
+            ++k;
+        }
+        base = make_uint2(fmi.L2(c) + comp(lo, c) + 1u, fmi.L2(c) + comp(hi, c));
+    }
+    if (base.x <= base.y) { out[0] = base.x; out[1] = base.y; }
 }
 
 // separate arrays, as the reference's synthetic tests build them (fmindex_test.cu:418-600)
@@ -123,6 +196,39 @@ API int compat_fm_rank(int layout, unsigned long long n, unsigned long long prim
     if (layout == 1) return run_rank< SeparateLayout<uint64>, uint64 >(uint64(n), uint64(primary), (const uint64*)L2, bwt, occ, count_table, n_queries, (const uint64*)rows, symbols, (uint64*)out, (uint64*)out4);
     if (layout == 2) return run_rank< InterleavedLayout, uint32 >(uint32(n), uint32(primary), (const uint32*)L2, bwt, occ, count_table, n_queries, (const uint32*)rows, symbols, (uint32*)out, (uint32*)out4);
     return -1;
+}
+
+template <typename Layout, typename index_type>
+static int run_rank4_range(index_type n, index_type primary, const index_type* L2, const void* bwt, const void* occ, const uint32* count_table,
+                           uint32 n_queries, const index_type* lo_rows, const index_type* hi_rows, index_type* out_lo, index_type* out_hi, uint32* agree)
+{
+    const typename Layout::fm_index_type fmi = Layout::make(n, primary, L2, bwt, occ, count_table, (const index_type*)NULL);
+    hipLaunchKernelGGL((rank4_range_kernel<typename Layout::fm_index_type>), dim3((n_queries + 127u) / 128u), dim3(128), 0, 0, n_queries, fmi, lo_rows, hi_rows, out_lo, out_hi, agree);
+    return int(hipDeviceSynchronize());
+}
+API int compat_fm_rank4_range(int layout, unsigned long long n, unsigned long long primary, const void* L2, const void* bwt, const void* occ, const unsigned* count_table,
+                              unsigned n_queries, const void* lo_rows, const void* hi_rows, void* out_lo, void* out_hi, unsigned* agree)
+{
+    if (layout == 0) return run_rank4_range< SeparateLayout<uint32>, uint32 >(uint32(n), uint32(primary), (const uint32*)L2, bwt, occ, count_table, n_queries, (const uint32*)lo_rows, (const uint32*)hi_rows, (uint32*)out_lo, (uint32*)out_hi, agree);
+    if (layout == 1) return run_rank4_range< SeparateLayout<uint64>, uint64 >(uint64(n), uint64(primary), (const uint64*)L2, bwt, occ, count_table, n_queries, (const uint64*)lo_rows, (const uint64*)hi_rows, (uint64*)out_lo, (uint64*)out_hi, agree);
+    if (layout == 2) return run_rank4_range< InterleavedLayout, uint32 >(uint32(n), uint32(primary), (const uint32*)L2, bwt, occ, count_table, n_queries, (const uint32*)lo_rows, (const uint32*)hi_rows, (uint32*)out_lo, (uint32*)out_hi, agree);
+    return -1;
+}
+API int compat_fm_one_mismatch(int layout, unsigned n, unsigned primary, const unsigned* L2, const void* bwt, const void* occ, const unsigned* count_table,
+                               unsigned n_queries, unsigned len1, unsigned len2, const unsigned* genome_words, const unsigned* starts, unsigned* out_ranges)
+{
+    if (layout == 0)
+    {
+        const SeparateLayout<uint32>::fm_index_type fmi = SeparateLayout<uint32>::make(n, primary, L2, bwt, occ, count_table, (const uint32*)NULL);
+        hipLaunchKernelGGL((one_mismatch_kernel<SeparateLayout<uint32>::fm_index_type>), dim3((n_queries + 127u) / 128u), dim3(128), 0, 0, n_queries, len1, len2, genome_words, fmi, starts, out_ranges);
+    }
+    else if (layout == 2)
+    {
+        const InterleavedLayout::fm_index_type fmi = InterleavedLayout::make(n, primary, L2, bwt, occ, count_table, (const uint32*)NULL);
+        hipLaunchKernelGGL((one_mismatch_kernel<InterleavedLayout::fm_index_type>), dim3((n_queries + 127u) / 128u), dim3(128), 0, 0, n_queries, len1, len2, genome_words, fmi, starts, out_ranges);
+    }
+    else return -1;
+    return int(hipDeviceSynchronize());
 }
 
 // the same templates on the host (fmindex_test.cu:376-413 runs its cpu alignment loop this way)

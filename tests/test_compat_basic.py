@@ -1,0 +1,85 @@
+"""CPU suite for the small building blocks the round-4 boundary work added to the drop-in template layer
+(include/nvbio_hip/compat): priority_deque, the range forms of rank4 / rank_all with comp(), max_text_gaps -- host-compiled
+(tests/compat/host_basic.cpp, g++) -- and the reference's own rank test (nvbio-test/rank_test.cu compiled as it lies against the
+layer, oracle/_ref/ref_rank_test, built where /root/reference exists)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "tests", "compat", "libhost_basic.so")
+
+
+@pytest.fixture(scope="module")
+def hb():
+    assert os.path.exists(LIB), "build with python -c 'import __graft_entry__ as g; g.build()'"
+    return C.CDLL(LIB)
+
+
+def p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_priority_deque_replays_the_reference_heap(hb):
+    """33 k push / pop_top / pop_bottom operations recorded from the reference's compiled interval_heap.h: the drop-in
+    priority_deque holds the same array after every one (which of several equal-sized hits surfaces first included)."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "hit_deque_vectors.npz"))
+    arrs = [np.ascontiguousarray(z[k]) for k in ("ops", "vals", "caps", "sizes", "states", "case_start")]
+    assert hb.replay(*[p(a) for a in arrs], C.c_int(len(arrs[5]) - 1)) == 0
+
+
+def test_range_rank4_rank_all_on_host(hb):
+    rng = np.random.default_rng(23)
+    n = 20011
+    text = rng.integers(0, 4, n, dtype=np.uint8)
+    host = O.FMIndex(text)
+    nb = (n + 63) // 64 + 1
+    occ = np.zeros(nb * 4, dtype=np.uint32)
+    cum = np.zeros((n + 1, 4), dtype=np.int64)
+    for c in range(4):
+        cum[1:, c] = np.cumsum(host.bwt == c)
+    for k in range(nb):
+        occ[4 * k: 4 * k + 4] = cum[min(64 * k, n)]
+    bw = np.concatenate([O.pack(host.bwt, 2, True, pad_words=0), np.zeros(8, np.uint32)])
+    pr = host.primary
+    lo = rng.integers(0, n + 1, 20000).astype(np.int64)
+    hi = np.minimum(n, lo + rng.choice([0, 1, 5, 40, 63, 64, 200, 5000], lo.size))
+    lo = np.concatenate([lo, [-1, -1, 0, pr - 1, pr, pr - 1, n - 1, n, 62, 63, -1]]).astype(np.uint32)
+    hi = np.concatenate([hi, [n, 0, 0, pr, pr, pr + 1, n, n, 63, 64, pr]]).astype(np.uint32)
+    out_lo, out_hi = np.zeros((lo.size, 4), np.uint32), np.zeros((lo.size, 4), np.uint32)
+    L2 = host.L2.astype(np.uint32)
+    bad = hb.rank_ranges(C.c_uint32(n), C.c_uint32(pr), p(L2), p(bw), p(occ), C.c_uint32(lo.size), p(lo), p(hi), p(out_lo), p(out_hi))
+    assert bad == 0
+    assert (out_lo == host.rank4(lo)).all() and (out_hi == host.rank4(hi)).all()
+
+
+def test_max_gaps():
+    hb = C.CDLL(LIB)
+    out = np.zeros(3, np.uint32)
+    # nvBowtie local defaults: match 2, gap open 5+3, ext 3 (stored negative); 150-bp mate, min_score 20 + 8 ln(150) = 60
+    hb.gaps(2, -8, -3, 60, 150, p(out))
+    # 300 - 8 = 292; extensions while score >= 60: 292, 289, ... -> n = 78 steps, result n - 1
+    score, k = 300 - 8, 0
+    while score >= 60 and k < 150:
+        score -= 3; k += 1
+    assert out[0] == k - 1 and out[1] == k - 1
+    hb.gaps(2, -8, -3, 295, 150, p(out))
+    assert out[0] == 0xFFFFFFFF            # the opening alone sinks the score: "steps - 1" wraps (utils_inl.h:176-200)
+    hb.gaps(2, -8, -3, 301, 150, p(out))
+    assert out[0] == 0
+    hb.gaps(2, -8, -3, -7, 150, p(out))
+    assert out[2] == 7                      # edit distance: -min_score
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_rank_test")), reason="oracle/_ref/ref_rank_test not built (needs /root/reference)")
+def test_reference_rank_test_passes_on_the_drop_in_layer():
+    """nvbio-test/rank_test.cu (whole TU, compiled as it lies with -I include/nvbio_hip/compat): rank() and rank_all() at every
+    position of a random text against running counts, for uint32 / uint4 / uint64 dictionaries (rank_test.cu:55-232)."""
+    r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "ref_rank_test"), "-length", "200"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-400:]
+    assert "rank test... done" in r.stderr and "mismatch" not in r.stderr

@@ -23,6 +23,8 @@ def fm():
     L.compat_fm_search.argtypes = [i32, u64, u64, vp, vp, vp, vp, vp, u32, u32, vp, vp, vp, vp, vp]
     L.compat_fm_rank.argtypes = [i32, u64, u64, vp, vp, vp, vp, u32, vp, vp, vp, vp]
     L.compat_fm_search_host.argtypes = [u32, u32, vp, vp, vp, vp, u32, u32, vp, vp, vp, vp]
+    L.compat_fm_rank4_range.argtypes = [i32, u64, u64, vp, vp, vp, vp, u32, vp, vp, vp, vp, vp]
+    L.compat_fm_one_mismatch.argtypes = [i32, u32, u32, vp, vp, vp, vp, u32, u32, u32, vp, vp, vp]
     return L
 
 
@@ -138,3 +140,88 @@ def test_caller_kernel_rank(fm, index, layout):
     assert fm.compat_fm_rank(layout, n, d["host"].primary, vp(L2), vp(bwt), vp(occ), vp(ct), rows.size, vp(r), vp(s), vp(out), vp(out4)) == 0
     assert (out.cpu().numpy().view(dt) == exp.astype(dt)).all()
     assert (out4.cpu().numpy().view(dt) == exp4.astype(dt)).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", [0, 1, 2], ids=["separate32", "separate64", "interleaved_uint4"])
+def test_caller_kernel_range_rank4_and_rank_all(fm, index, layout):
+    """rank4(fmi, (l, r), &lo, &hi) / rank_all(fmi, (l, r), ...) / comp() -- the forms nvBowtie's map<> steps with
+    (fmindex.h:451-500, numbers.h:239-290) -- per end against the oracle's rank4, on ranges inside one block, across blocks, around
+    `primary`, and with the l == -1 / r == n ends of the first search step."""
+    import torch
+    d = index
+    rng = np.random.default_rng(19)
+    n, pr = d["n"], d["host"].primary
+    lo = rng.integers(0, n + 1, 40000).astype(np.int64)
+    hi = np.minimum(n, lo + rng.choice([0, 1, 5, 40, 63, 64, 200, 5000], lo.size))
+    extra_lo = np.array([-1, -1, 0, pr - 1, pr, pr - 1, n - 1, n, 62, 63, -1], np.int64)
+    extra_hi = np.array([n, 0, 0, pr, pr, pr + 1, n, n, 63, 64, pr], np.int64)
+    lo, hi = np.concatenate([lo, extra_lo]), np.concatenate([hi, extra_hi])
+    dt = np.uint64 if layout == 1 else np.uint32
+    exp_lo, exp_hi = d["host"].rank4(lo.astype(np.uint32)), d["host"].rank4(hi.astype(np.uint32))
+    sfx = "64" if layout == 1 else "32"
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64 if a.dtype == np.uint64 else np.int32 if a.dtype == np.uint32 else a.dtype)).cuda()
+    L2 = dev(d["L2_" + sfx])
+    if layout == 2:
+        bwt, occ = dev(d["host"].bwt_occ), None
+    else:
+        bwt, occ = dev(d["bwt" + sfx]), dev(d["occ" + sfx])
+    ct = dev(d["count_table"])
+    lo_d, hi_d = dev(lo.astype(np.int64).astype(dt) if layout == 1 else lo.astype(np.uint32)), dev(hi.astype(dt))
+    tdt = torch.int64 if layout == 1 else torch.int32
+    out_lo = torch.zeros((lo.size, 4), dtype=tdt, device="cuda")
+    out_hi = torch.zeros((lo.size, 4), dtype=tdt, device="cuda")
+    agree = torch.zeros(lo.size, dtype=torch.int32, device="cuda")
+    vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    assert fm.compat_fm_rank4_range(layout, n, pr, vp(L2), vp(bwt), vp(occ), vp(ct), lo.size, vp(lo_d), vp(hi_d), vp(out_lo), vp(out_hi), vp(agree)) == 0
+    assert (out_lo.cpu().numpy().view(dt) == exp_lo.astype(dt)).all()
+    assert (out_hi.cpu().numpy().view(dt) == exp_hi.astype(dt)).all()
+    assert int(agree.sum()) == lo.size
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", [0, 2], ids=["separate32", "interleaved_uint4"])
+@pytest.mark.parametrize("len1,len2", [(10, 22), (0, 12), (16, 20)])
+def test_caller_kernel_one_mismatch_search(fm, index, layout, len1, len2):
+    """A caller of the shape of nvBowtie's map<> (mapping_inl.h:128-220) through the drop-in templates: exact over the first len1
+    symbols, one substitution in the rest, stepping with the range rank4 + comp().  Expected: the oracle's match() of every
+    substituted query, which reaches the same SA range by plain backward search."""
+    import torch
+    d = index
+    rng = np.random.default_rng(100 * len1 + len2 + layout)
+    nq = 1500
+    starts = rng.integers(0, d["n"] - len2 + 1, nq).astype(np.uint32)
+    starts[:3] = [0, 2000, 2301]
+    slots = 1 + 3 * (len2 - len1)
+    # query[i] is prepended at step i: the string searched for is the query reversed
+    pats, where = [], []
+    for q, s in enumerate(starts):
+        qu = d["text"][s:s + len2]
+        pats.append(qu[::-1].copy()); where.append((q, 0))
+        for i in range(len1, len2):
+            k = 0
+            for sub in range(4):
+                if sub == qu[i]:
+                    continue
+                v = qu.copy(); v[i] = sub
+                pats.append(v[::-1].copy()); where.append((q, 1 + 3 * (i - len1) + k))
+                k += 1
+    got_exp = d["host"].match(O.StringSet.from_lists(pats, 2, True))
+    exp = np.zeros((nq, slots, 2), np.uint32)
+    exp[:, :, 0] = 1
+    for (q, s), r in zip(where, got_exp):
+        if r[0] <= r[1]:
+            exp[q, s] = r
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32 if a.dtype == np.uint32 else a.dtype)).cuda()
+    L2 = dev(d["L2_32"])
+    if layout == 2:
+        bwt, occ = dev(d["host"].bwt_occ), None
+    else:
+        bwt, occ = dev(d["bwt32"]), dev(d["occ32"])
+    ct, st, genome = dev(d["count_table"]), dev(starts), dev(d["genome32"])
+    out = torch.zeros((nq, slots, 2), dtype=torch.int32, device="cuda")
+    vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    assert fm.compat_fm_one_mismatch(layout, d["n"], d["host"].primary, vp(L2), vp(bwt), vp(occ), vp(ct), nq, len1, len2, vp(genome), vp(st), vp(out)) == 0
+    got = out.cpu().numpy().view(np.uint32)
+    assert (got == exp).all()
+    assert (exp[:, 1:, 0] <= exp[:, 1:, 1]).sum() > nq // 4        # the substitution branch really fired
