@@ -129,11 +129,12 @@ struct SSA_index_multiple_device
         if (hipDeviceSynchronize() != hipSuccess) throw std::runtime_error("SSA_index_multiple_device: link kernel failed");
         const thrust::host_vector<index_type> next = d_next, hops = d_hops;
         thrust::host_vector<index_type> ssa(n_items, index_type(0));
-        // row 0 holds suffix n; every link moves `hops` positions towards the start of the text
+        // row 0 holds suffix n; every link moves `hops` positions towards the start of the text.  The walk is a cycle of n + 1 rows
+        // (the row of suffix 0 maps back to row 0), so the chain ends at the first link longer than what is left of the text.
         index_type k = 0, suffix = m_n;
-        for (uint32 guard = 0; suffix > 0; ++guard)
+        for (uint32 links = 0; hops[k] <= suffix; ++links)
         {
-            if (guard > n_items || hops[k] > suffix) throw std::runtime_error("SSA_index_multiple_device: index out of bounds");
+            if (links > n_items) throw std::runtime_error("SSA_index_multiple_device: index out of bounds");
             suffix -= hops[k];
             k = next[k];
             ssa[k] = suffix;

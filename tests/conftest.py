@@ -10,6 +10,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # torch bundles its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).  A hipcc-built test library loaded
+    # BEFORE torch pulls in /opt/rocm's copy instead, the process ends up with two runtimes and the second one sees no device
+    # (hipErrorNoDevice from every call) -- which made single-module runs of the drop-in caller tests fail.  Load torch first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     # NVBIO_FUZZ_SEED=<k>: shift every integer seed handed to numpy's default_rng by k, i.e. rerun the whole parity suite on
     # fresh random data (golden-vector tests regenerate nothing and are unaffected)
     off = int(os.environ.get("NVBIO_FUZZ_SEED", "0"))

@@ -181,7 +181,7 @@ def test_caller_kernel_range_rank4_and_rank_all(fm, index, layout):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("layout", [0, 2], ids=["separate32", "interleaved_uint4"])
-@pytest.mark.parametrize("len1,len2", [(10, 22), (0, 12), (16, 20)])
+@pytest.mark.parametrize("len1,len2", [(10, 22), (0, 8), (4, 9)])
 def test_caller_kernel_one_mismatch_search(fm, index, layout, len1, len2):
     """A caller of the shape of nvBowtie's map<> (mapping_inl.h:128-220) through the drop-in templates: exact over the first len1
     symbols, one substitution in the rest, stepping with the range rank4 + comp().  Expected: the oracle's match() of every
@@ -224,4 +224,5 @@ def test_caller_kernel_one_mismatch_search(fm, index, layout, len1, len2):
     assert fm.compat_fm_one_mismatch(layout, d["n"], d["host"].primary, vp(L2), vp(bwt), vp(occ), vp(ct), nq, len1, len2, vp(genome), vp(st), vp(out)) == 0
     got = out.cpu().numpy().view(np.uint32)
     assert (got == exp).all()
-    assert (exp[:, 1:, 0] <= exp[:, 1:, 1]).sum() > nq // 4        # the substitution branch really fired
+    if len2 < 10:
+        assert (exp[:, 1:, 0] <= exp[:, 1:, 1]).sum() > nq                 # the substitution branch really fired (8- and 9-mers of a 60 k text)
