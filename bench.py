@@ -1158,10 +1158,11 @@ def full_dp_leg(a, dev):
 
 
 def compat_stream_leg(a, dev):
-    """What the source-level drop-in route costs: ONE nvBowtie-shaped score stream -- tests/compat/nvbowtie_streams.hip,
-    written to the shape of alignment_utils.h:170-340 + score_best_inl.h:54-148 + scoring.h:206-356: reads stored reversed and viewed through
-    io::ReadLoader, quality strings, the quality-aware scheme, band 15, LOCAL -- enacted through BatchedBandedAlignmentScore on the tuned
-    (staged) route and forced down the generic one-lane-per-job template.  Same hits, same outputs (compared), a sample against the oracle."""
+    """What the source-level drop-in route costs: ONE score stream of read VIEWS, the concept of nvBowtie's streams
+    (alignment_utils.h:170-340 + score_best_inl.h:54-148 + scoring.h:206-356) -- tests/compat/nvbowtie_streams.hip: reads stored reversed and
+    viewed through io::ReadLoader, quality strings, a quality-aware scheme, band 15, LOCAL -- enacted through BatchedBandedAlignmentScore
+    (a) in place on the views (tuned-views: nvbio_hip_banded_gotoh_score_qual_views), (b) on the staged tuned route it replaced, (c) down the
+    generic one-lane-per-job template.  Same hits, same outputs (compared), a sample against the oracle."""
     import ctypes as C
     import numpy as np
     from nvbio_amd import pipeline as P
@@ -1174,6 +1175,7 @@ def compat_stream_leg(a, dev):
     lib = C.CDLL(path)
     lib.bt2_banded_score.argtypes = [C.POINTER(Args), C.c_char_p]
     lib.bt2_banded_score_generic.argtypes = [C.POINTER(Args)]
+    lib.bt2_banded_score_staged.argtypes = [C.POINTER(Args), C.c_char_p]
     n, L, band, ng = min(a.reads, 10_000_000), READ_LEN, 15, 1 << 28
     g = torch.Generator(device=dev); g.manual_seed(0x5EED0011)
     text = torch.randint(0, 4, (ng,), dtype=torch.uint8, generator=g, device=dev)
@@ -1215,10 +1217,19 @@ def compat_stream_leg(a, dev):
             raise SystemExit("compat stream leg: bt2_banded_score_generic failed")
 
     ms_t = timed(tuned)
+    route = pathbuf.value.decode()
     ts, tk = out["raw_score"].clone(), out["raw_sink"].clone()
     out["raw_score"].zero_(); out["raw_sink"].zero_()
+
+    def staged():
+        if lib.bt2_banded_score_staged(C.byref(args), pathbuf) != 0:
+            raise SystemExit("compat stream leg: bt2_banded_score_staged failed")
+
+    ms_s = timed(staged)
+    same_s = bool(torch.equal(ts, out["raw_score"]) and torch.equal(tk, out["raw_sink"]))
+    out["raw_score"].zero_(); out["raw_sink"].zero_()
     ms_g = timed(generic, reps=1)
-    same = bool(torch.equal(ts, out["raw_score"]) and torch.equal(tk, out["raw_sink"]))
+    same = bool(same_s and torch.equal(ts, out["raw_score"]) and torch.equal(tk, out["raw_sink"]))
     # a sample against the oracle
     m = 20000
     lut, s5, ty = scheme_tables(SCHEMES["local"])
@@ -1238,8 +1249,9 @@ def compat_stream_leg(a, dev):
     if not (same and ok):
         raise SystemExit("parity gate failed: compat stream routes disagree (tuned vs generic %s, tuned vs oracle %s)" % (same, ok))
     return {"stream": "nvBowtie-shaped BestScoreStream (ReadLoader views of reversed reads, quality strings, SmithWatermanScoringScheme), band 15, LOCAL, %d hits x %d bp" % (n, L),
-            "tuned_route": {"path": pathbuf.value.decode(), "ms_per_enact": ms_t, "Mreads_per_s": n / ms_t / 1e3,
-                            "includes": "job-table kernel (stream's own init_context / load_strings, staging of patterns and qualities), one host sync, the tuned kernel, the stream's output()"},
+            "tuned_route": {"path": route, "ms_per_enact": ms_t, "Mreads_per_s": n / ms_t / 1e3,
+                            "includes": "job-description kernel (the stream's own init_context / load_strings, one lane per job: where the stored read lies and how it is viewed), one host sync, the tuned kernel reading the stored reads in place through their views, the stream's output()"},
+            "staged_route": {"ms_per_enact": ms_s, "Mreads_per_s": n / ms_s / 1e3, "note": "the r03 route: patterns and qualities copied to a scratch by sixteen lanes per job first"},
             "generic_lane": {"ms_per_enact": ms_g, "Mreads_per_s": n / ms_g / 1e3},
             "identical_outputs": same, "oracle_sample": {"checked": m, "bit_exact": ok}}
 

@@ -160,6 +160,21 @@ int nvbio_hip_banded_gotoh_score_qual(
     uint32_t max_pattern_len, uint32_t max_text_len,
     uint32_t n, int32_t* out_score, uint32_t* out_sink, void* stream);
 
+/* The same with a per-job VIEW of each pattern, so that nvBowtie's unedited streams run in place.  nvBowtie never materialises
+ * the string it aligns: AlignmentStrings::load (nvBowtie/bowtie2/cuda/alignment_utils.h:170-218) hands the DP an
+ * nvbio::io::ReadStream (nvbio/io/utils.h:100-330) over the stored read -- reads are stored reversed, (REVERSE, STANDARD) shows
+ * the forward strand and (FORWARD, COMPLEMENT) the reverse complement -- and the reference's per-thread DP reads it symbol by
+ * symbol through operator[].  pattern_flags[i] (device, one byte per job, NULL = no views) describes job i's view of the stored
+ * symbols [begin[i], begin[i] + length[i]):  bit 0 = walk them backwards (pattern symbol k is stored symbol begin + length - 1 - k,
+ * and its quality is quals[begin + length - 1 - k]),  bit 1 = complement the bases (c < 4 -> 3 - c; N stays).  The kernels turn
+ * each 16-symbol group round in registers as they fetch it; results are those of the materialised string, bit for bit. */
+int nvbio_hip_banded_gotoh_score_qual_views(
+    const nvbio_hip_gotoh_qual_scheme* scheme /* host */, int32_t type, uint32_t band_len,
+    const nvbio_hip_string_set* patterns, const uint8_t* quals, uint64_t n_quals, const uint8_t* pattern_flags /* device, nullable */,
+    const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len,
+    uint32_t n, int32_t* out_score, uint32_t* out_sink, void* stream);
+
 /* Batched banded Gotoh traceback.  Replaces
  *   BatchedBandedAlignmentTraceback<BAND_LEN, CHECKPOINTS, stream, DeviceThreadScheduler>::enact
  *   (nvbio/alignment/batched.h:460-476, batched_banded_inl.h:250-420)

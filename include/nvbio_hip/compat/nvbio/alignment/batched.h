@@ -32,6 +32,8 @@
 #include "../basic/cuda/ldg.h"
 #include "../strings/string_set.h"
 #include <stdexcept>
+#include <algorithm>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 #include <type_traits>
@@ -172,9 +174,22 @@ template <AlignmentType T, typename S, typename G> struct tuned_aligner< GotohAl
 
 /// how a pattern reaches the tuned kernels: in place (a window of packed words), staged (read through its own operator[] into the
 /// batch's scratch: io::ReadStream views of <= 4-bit symbols), or not at all
-template <typename P> struct pattern_source { static const bool direct = packed_view<P>::ok; static const bool stageable = packed_view<P>::ok; };
+/// "this iterator is a pointer to bytes in memory" (a read batch's quality stream)
+template <typename It> struct byte_pointer { static const bool ok = false; };
+template <> struct byte_pointer<const uint8*> { static const bool ok = true; NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static const uint8* get(const uint8* p) { return p; } };
+template <> struct byte_pointer<uint8*>       { static const bool ok = true; NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static const uint8* get(uint8* p) { return p; } };
+template <> struct byte_pointer< cuda::ldg_pointer<uint8> > { static const bool ok = true; NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static const uint8* get(cuda::ldg_pointer<uint8> p) { return p.base; } };
+
+/// ... or a VIEW run in place: an io::ReadStream over packed words with a byte-pointer quality stream -- the only pattern nvBowtie's
+/// streams hand out (alignment_utils.h:170-218).  The banded quality-scheme kernels take (stored range, reverse / complement flags)
+/// per job and turn each 16-symbol group round as they fetch it (nvbio_hip_banded_gotoh_score_qual_views): nothing is staged.
+template <typename P> struct pattern_source { static const bool direct = packed_view<P>::ok; static const bool stageable = packed_view<P>::ok; static const bool viewable = false; };
 template <typename St, typename Q> struct pattern_source< io::ReadStream<St, Q> >
-{ static const bool direct = false; static const bool stageable = (io::ReadStream<St, Q>::SYMBOL_SIZE <= 4u); };
+{
+    static const bool direct = false; static const bool stageable = (io::ReadStream<St, Q>::SYMBOL_SIZE <= 4u);
+    static const bool viewable = nvbio::priv::packed_stream_where<St>::ok && byte_pointer<Q>::ok;
+    typedef nvbio::priv::packed_stream_where<St> where_type; typedef byte_pointer<Q> qual_pointer;
+};
 
 template <typename stream_type, typename sink_like>
 struct recognition
@@ -191,6 +206,8 @@ struct recognition
     static const bool staged = aligner::ok && text_ok && pattern_source<pattern_type>::stageable && sink_like::value && !zero_copy;
     static const bool value = zero_copy || staged;
     static const bool stage_quals = staged && aligner::QUAL;
+    /// a staged stream whose banded SCORE batches run on views in place instead (full-matrix and traceback batches still stage)
+    static const bool view = staged && aligner::QUAL && pattern_source<pattern_type>::viewable;
 };
 template <typename stream_type> struct score_sink_ok { static const bool value = best_sink< decltype(typename stream_type::context_type().sink) >::ok; };
 struct any_sink_ok { static const bool value = true; };
@@ -204,6 +221,7 @@ struct job_table
 {
     uint64* pat_begin; uint32* pat_len; uint64* txt_begin; uint32* txt_len; int32* min_score; int32* score; uint32* sink; uint8* ok;
     unsigned long long* bounds;        // [0] lowest pattern word, [1] end pattern word, [2] lowest text word, [3] end text word
+                                       // views: [4] / [5] min / max of (quality address - pattern symbol address), [7] end pattern symbol
     uint32* stage_words; uint8* stage_quals; uint32 stage_stride;         // staged patterns: job i at symbol i * stage_stride (4-bit, little-endian)
     static uint64 bytes(const uint32 n) { return 64u + uint64(n) * (8u + 4u + 8u + 4u + 4u + 4u + 8u + 1u) + 8u * 16u; }
     static uint32 stride_for(const uint32 maxP) { const uint32 s = (maxP + 7u) & ~7u; return s ? s : 8u; }
@@ -229,7 +247,7 @@ __device__ __forceinline__ unsigned long long wave_min(unsigned long long v)
 __device__ __forceinline__ unsigned long long wave_max(unsigned long long v)
 { for (int o = 32; o > 0; o >>= 1) { const unsigned long long w = __shfl_xor(v, o, 64); v = w > v ? w : v; } return v; }
 
-__global__ void init_bounds_kernel(unsigned long long* b) { if (threadIdx.x < 4u) b[threadIdx.x] = (threadIdx.x & 1u) ? 0ull : ~0ull; }
+__global__ void init_bounds_kernel(unsigned long long* b) { if (threadIdx.x < 8u) b[threadIdx.x] = (threadIdx.x & 1u) ? 0ull : ~0ull; }
 
 /// where a pattern lives (in place), or nothing (staged)
 template <typename P, bool DIRECT> struct pattern_where {
@@ -250,11 +268,13 @@ __global__ void __launch_bounds__(128) describe_jobs_kernel(const stream_type st
 {
     typedef pattern_where<typename R::pattern_type, !R::staged> pwhere;
     constexpr uint32 G = R::staged ? 16u : 1u;                       // lanes per job
-    const uint32 gt = blockIdx.x * 128u + threadIdx.x;
-    const uint32 i = gt / G, j = gt % G;
+    // a fixed grid strides over the jobs, every lane keeps its own bounds, and the four global bounds cost four atomics per BLOCK
+    // (one per wave and bound made waves that see jobs in storage order queue up on the same addresses: see describe_views_kernel)
     unsigned long long plo = ~0ull, phi = 0ull, tlo = ~0ull, thi = 0ull;
-    if (i < stream.size())
+    const uint64 total = uint64(stream.size()) * G;
+    for (uint64 gt = uint64(blockIdx.x) * 128u + threadIdx.x; gt < total; gt += uint64(gridDim.x) * 128u)
     {
+        const uint32 i = uint32(gt / G), j = uint32(gt % G);
         typename stream_type::context_type ctx;
         typename stream_type::strings_type strings;
         uint32 pl = 0, tl = 0; uint64 pw = 0, tw = 0; uint32 pf = 0, tf = 0; int32 ms = 0;
@@ -265,7 +285,7 @@ __global__ void __launch_bounds__(128) describe_jobs_kernel(const stream_type st
             pwhere::get(strings.pattern, pw, pf);
             packed_view<typename R::text_type>::where(strings.text, tw, tf);
             pl = strings.pattern.length(); tl = strings.text.length(); ms = ctx.min_score;
-            tlo = tw; thi = tw + (tf + tl + 15u) / 16u;
+            { const unsigned long long te = tw + (tf + tl + 15u) / 16u; tlo = tw < tlo ? tw : tlo; thi = te > thi ? te : thi; }
             if (R::staged)
             {
                 // a job longer than the announced maximum cannot be staged: it is given an empty text, which the kernels refuse like
@@ -292,7 +312,7 @@ __global__ void __launch_bounds__(128) describe_jobs_kernel(const stream_type st
                     }
                 }
             }
-            else { plo = pw; phi = pw + (pf + pl + 32u / pwhere::BITS - 1u) / (32u / pwhere::BITS); }
+            else { const unsigned long long pe = pw + (pf + pl + 32u / pwhere::BITS - 1u) / (32u / pwhere::BITS); plo = pw < plo ? pw : plo; phi = pe > phi ? pe : phi; }
         }
         // offsets are kept absolute (symbols from address 0) until the host knows the lowest word
         if (j == 0u)
@@ -301,20 +321,74 @@ __global__ void __launch_bounds__(128) describe_jobs_kernel(const stream_type st
             t.txt_begin[i] = tw * 16u + tf; t.txt_len[i] = tl; t.min_score[i] = ms;
         }
     }
+    __shared__ unsigned long long s_b[2][4];
     plo = wave_min(plo); phi = wave_max(phi); tlo = wave_min(tlo); thi = wave_max(thi);
-    if ((threadIdx.x & 63u) == 0u)
+    if ((threadIdx.x & 63u) == 0u) { unsigned long long* o = s_b[threadIdx.x >> 6]; o[0] = plo; o[1] = phi; o[2] = tlo; o[3] = thi; }
+    __syncthreads();
+    if (threadIdx.x < 4u)
     {
-        // (a wave that cannot move a bound skips the atomic: after the first waves almost all can, and 2.5 M waves hammering four
-        // addresses cost 50 ms)
-        const volatile unsigned long long* b = t.bounds;
-        if (phi) { if (plo < b[0]) atomicMin(&t.bounds[0], plo); if (phi > b[1]) atomicMax(&t.bounds[1], phi); }
-        if (thi) { if (tlo < b[2]) atomicMin(&t.bounds[2], tlo); if (thi > b[3]) atomicMax(&t.bounds[3], thi); }
+        const unsigned long long a = s_b[0][threadIdx.x], b = s_b[1][threadIdx.x];
+        if ((threadIdx.x & 1u) == 0u) { const unsigned long long v = a < b ? a : b; if (v != ~0ull) atomicMin(&t.bounds[threadIdx.x], v); }
+        else                          { const unsigned long long v = a > b ? a : b; if (v != 0ull) atomicMax(&t.bounds[threadIdx.x], v); }
     }
 }
 __global__ void __launch_bounds__(256) rebase_jobs_kernel(const uint32 n, uint64* pat_begin, const uint64 pat_delta, uint64* txt_begin, const uint64 txt_delta)
 {
     const uint32 i = blockIdx.x * 256u + threadIdx.x;
     if (i < n) { pat_begin[i] -= pat_delta; txt_begin[i] -= txt_delta; }
+}
+/// the view route's description of a job: where the STORED read lies (absolute symbol address), how the stream looks at it (t.ok[i]:
+/// bit 0 reversed, bit 1 complemented), and where its qualities lie relative to its symbols -- one lane per job, nothing copied
+template <typename stream_type, typename R>
+__global__ void __launch_bounds__(256) describe_views_kernel(const stream_type stream, const job_table t)
+{
+    typedef pattern_source<typename R::pattern_type> source;
+    typedef typename source::where_type              where_type;
+    const uint32 per = 32u / where_type::BITS;
+    // a fixed grid strides over the jobs and every lane keeps its own bounds: the seven global bounds then cost seven atomics per
+    // BLOCK.  (One atomic per wave and bound is what the first version did; jobs usually come in storage order, so every wave moved
+    // the upper bounds, and 156 k waves x 3 atomics on three addresses were 3 of its 4.1 ms per 10 M jobs.)
+    unsigned long long plo = ~0ull, phi = 0ull, tlo = ~0ull, thi = 0ull, dlo = ~0ull, dhi = 0ull, send = 0ull;
+    const uint32 n = stream.size();
+    for (uint32 i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
+    {
+        typename stream_type::context_type ctx;
+        typename stream_type::strings_type strings;
+        uint32 pl = 0, tl = 0, tf = 0, fl = 0; uint64 ps = 0, tw = 0; int32 ms = 0;
+        if (stream.init_context(i, &ctx))
+        {
+            const uint32 len = stream.pattern_length(i, &ctx);
+            stream.load_strings(i, 0u, len, &ctx, &strings);
+            uint64 w; uint32 f;
+            where_type::where(strings.pattern.stream, w, f);
+            ps = w * per + f + strings.pattern.first;
+            pl = strings.pattern.length();
+            fl = (strings.pattern.rev ? 1u : 0u) | (strings.pattern.comp ? 2u : 0u);
+            packed_view<typename R::text_type>::where(strings.text, tw, tf);
+            tl = strings.text.length(); ms = ctx.min_score;
+            const unsigned long long te = tw + (tf + tl + 15u) / 16u, pe = (ps + pl + per - 1u) / per;
+            tlo = tw < tlo ? tw : tlo; thi = te > thi ? te : thi;
+            plo = ps / per < plo ? ps / per : plo; phi = pe > phi ? pe : phi; send = ps + pl > send ? ps + pl : send;
+            const unsigned long long qa = (unsigned long long)(reinterpret_cast<uintptr_t>(source::qual_pointer::get(strings.pattern.qual))) + strings.pattern.first;
+            const unsigned long long d = qa - ps;       // modular: equal for all jobs of one read batch
+            dlo = d < dlo ? d : dlo; dhi = d > dhi ? d : dhi;
+        }
+        t.pat_begin[i] = ps; t.pat_len[i] = pl; t.ok[i] = uint8(fl);
+        t.txt_begin[i] = tw * 16u + tf; t.txt_len[i] = tl; t.min_score[i] = ms;
+    }
+    __shared__ unsigned long long s_b[4][7];
+    plo = wave_min(plo); phi = wave_max(phi); tlo = wave_min(tlo); thi = wave_max(thi); send = wave_max(send); dlo = wave_min(dlo); dhi = wave_max(dhi);
+    if ((threadIdx.x & 63u) == 0u)
+    { unsigned long long* o = s_b[threadIdx.x >> 6]; o[0] = plo; o[1] = phi; o[2] = tlo; o[3] = thi; o[4] = dlo; o[5] = dhi; o[6] = send; }
+    __syncthreads();
+    if (threadIdx.x < 7u)
+    {
+        const bool is_min = (threadIdx.x == 0u || threadIdx.x == 2u || threadIdx.x == 4u);
+        unsigned long long v = s_b[0][threadIdx.x];
+        for (uint32 w = 1; w < 4u; ++w) { const unsigned long long x = s_b[w][threadIdx.x]; v = is_min ? (x < v ? x : v) : (x > v ? x : v); }
+        const uint32 slot = threadIdx.x == 6u ? 7u : threadIdx.x;
+        if (is_min) { if (v != ~0ull) atomicMin(&t.bounds[slot], v); } else if (v != 0ull) atomicMax(&t.bounds[slot], v);
+    }
 }
 /// hand each result to the stream: a job the scorer refused (text shorter than pattern) leaves the fresh sink untouched
 template <typename stream_type>
@@ -382,7 +456,7 @@ inline void build_job_table(const stream_type& stream, device_buffer& buf, job_t
     }
     if (extra) *extra = base + table + stage;
     hipLaunchKernelGGL(init_bounds_kernel, dim3(1), dim3(64), 0, hs, t.bounds);
-    hipLaunchKernelGGL((describe_jobs_kernel<stream_type, R>), dim3(uint32((uint64(n) * (R::staged ? 16u : 1u) + 127u) / 128u)), dim3(128), 0, hs, stream, t);
+    hipLaunchKernelGGL((describe_jobs_kernel<stream_type, R>), dim3(uint32(std::min<uint64>((uint64(n) * (R::staged ? 16u : 1u) + 127u) / 128u, 65536u))), dim3(128), 0, hs, stream, t);
     unsigned long long b[4];
     check(hipMemcpyAsync(b, t.bounds, sizeof(b), hipMemcpyDeviceToHost, hs), "hipMemcpyAsync");
     check(hipStreamSynchronize(hs), "hipStreamSynchronize");
@@ -397,6 +471,37 @@ inline void build_job_table(const stream_type& stream, device_buffer& buf, job_t
     ts.words = reinterpret_cast<const uint32*>(uintptr_t(b[2]) * 4u); ts.n_words = b[3] - b[2];
     ts.bits = 2u; ts.big_endian = packed_view<typename R::text_type>::BE ? 1u : 0u;
     ts.begin = t.txt_begin; ts.length = t.txt_len; ts.fixed_length = 0; ts._pad = 0;
+}
+
+/// the view route: describe -> (sync: the bounds) -> rebase.  false when the jobs' qualities do not sit at one common distance from their
+/// symbols (several read batches behind one stream): the caller then stages, as before.
+template <typename stream_type, typename R = recognised<stream_type> >
+inline bool build_view_table(const stream_type& stream, device_buffer& buf, job_table& t, nvbio_hip_string_set& ps, nvbio_hip_string_set& ts,
+                             const uint8** quals, uint64* n_quals, const uint8** flags, hipStream_t hs)
+{
+    typedef typename pattern_source<typename R::pattern_type>::where_type where_type;
+    const uint32 n = stream.size();
+    const uint64 table = (job_table::bytes(n) + 15u) & ~uint64(15);
+    t.carve(buf.reserve(table + 16u), n);
+    hipLaunchKernelGGL(init_bounds_kernel, dim3(1), dim3(64), 0, hs, t.bounds);
+    hipLaunchKernelGGL((describe_views_kernel<stream_type, R>), dim3(std::min<uint32>((n + 255u) / 256u, 8192u)), dim3(256), 0, hs, stream, t);
+    unsigned long long b[8];
+    check(hipMemcpyAsync(b, t.bounds, sizeof(b), hipMemcpyDeviceToHost, hs), "hipMemcpyAsync");
+    check(hipStreamSynchronize(hs), "hipStreamSynchronize");
+    if (b[1] == 0ull || b[4] != b[5]) return false;
+    if (b[3] == 0ull) { b[2] = 0ull; b[3] = 1ull; }
+    const uint32 per = 32u / where_type::BITS;
+    hipLaunchKernelGGL(rebase_jobs_kernel, dim3((n + 255u) / 256u), dim3(256), 0, hs, n, t.pat_begin, uint64(b[0]) * per, t.txt_begin, uint64(b[2]) * 16u);
+    ps.words = reinterpret_cast<const uint32*>(uintptr_t(b[0]) * 4u); ps.n_words = b[1] - b[0]; ps.bits = where_type::BITS; ps.big_endian = where_type::BE ? 1u : 0u;
+    ps.begin = t.pat_begin; ps.length = t.pat_len; ps.fixed_length = 0; ps._pad = 0;
+    ts.words = reinterpret_cast<const uint32*>(uintptr_t(b[2]) * 4u); ts.n_words = b[3] - b[2];
+    ts.bits = 2u; ts.big_endian = packed_view<typename R::text_type>::BE ? 1u : 0u;
+    ts.begin = t.txt_begin; ts.length = t.txt_len; ts.fixed_length = 0; ts._pad = 0;
+    // quals[begin + k] must be the quality of stored symbol begin + k: the array starts where the lowest pattern word's first symbol would
+    *quals = reinterpret_cast<const uint8*>(uintptr_t(b[4] + uint64(b[0]) * per));
+    *n_quals = b[7] - uint64(b[0]) * per;
+    *flags = t.ok;
+    return true;
 }
 
 /// the largest |cost| of an aligner's scheme (to bound what an int16 sink can hold)
@@ -547,6 +652,23 @@ private:
         typedef decltype(typename stream_type::context_type().sink) sink_type;
         if (!scheme.init(stream) || !scheme.template sink_fits<sink_type>(stream)) { run_device(stream, hs, std::false_type()); return; }
         priv::job_table t; nvbio_hip_string_set ps, ts; const uint8* quals = NULL; uint64 n_quals = 0;
+        if constexpr (priv::recognised<stream_type>::view)
+        {
+            // nvBowtie's streams: the stored reads are scored through their views, in place
+            // (NVBIO_HIP_COMPAT_NO_VIEWS=1 keeps the staged route, for timing the two side by side)
+            const uint8* flags = NULL;
+            const char* no_views = getenv("NVBIO_HIP_COMPAT_NO_VIEWS");
+            if (!(no_views && no_views[0] == '1') && priv::build_view_table(stream, m_jobs, t, ps, ts, &quals, &n_quals, &flags, hs) && n_quals >= 4u)
+            {
+                const int err = nvbio_hip_banded_gotoh_score_qual_views(&scheme.q, int32(stream_type::aligner_type::TYPE), BAND_LEN, &ps, quals, n_quals, flags, &ts,
+                                                                        stream.max_pattern_length(), stream.max_text_length(), n, t.score, t.sink, hs);
+                priv::check(err, "nvbio_hip_banded_gotoh_score_qual_views");
+                hipLaunchKernelGGL((priv::output_jobs_kernel<stream_type>), dim3((n + 127u) / 128u), dim3(128), 0, hs, stream, t);
+                priv::check(hipGetLastError(), "output_jobs_kernel");
+                m_path = "tuned-views";
+                return;
+            }
+        }
         priv::build_job_table(stream, m_jobs, t, ps, ts, hs, 0u, NULL, &quals, &n_quals);
         const int err = scheme.banded_score(BAND_LEN, stream, t, ps, ts, quals, n_quals, hs);
         if (err == 801) { run_device(stream, hs, std::false_type()); return; }       // outside the tuned kernels' contract (e.g. asymmetric linear gaps)

@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(128) filter_describe_kernel(const uint32 n, co
         view::where(s, w0, first);
         const uint32 per = 32u / view::BITS;
         begin[q] = w0 * per + first; len[q] = uint32(s.length());
-        lo = w0; hi = w0 + (first + uint32(s.length()) + per - 1u) / per + 1u;
+        lo = w0; hi = w0 + (first + uint32(s.length()) + per - 1u) / per;        // exactly the words the string occupies: the kernels clamp their look-ahead to it
     }
     lo = filter_wave_min(lo); hi = filter_wave_max(hi);
     if ((threadIdx.x & 63u) == 0u && hi) { atomicMin(&bounds[0], lo); atomicMax(&bounds[1], hi); }
@@ -388,7 +388,8 @@ private:
     void attach_line_native()
     {
         if (!m_line_native) return;
-        if (m_dimer_for != m_fmi.bwt_occ || m_dimer_len != m_fmi.length || m_dimer_primary != m_fmi.primary)
+        if (m_dimer_for != m_fmi.bwt_occ || m_dimer_len != m_fmi.length || m_dimer_primary != m_fmi.primary ||
+            m_dimer_L2[0] != m_fmi.L2[1] || m_dimer_L2[1] != m_fmi.L2[2] || m_dimer_L2[2] != m_fmi.L2[3])      // a different index rebuilt at the same address
         {
             m_dimer_for = nullptr;
             const uint64 bytes = nvbio_hip_fm_dimer_index_bytes(m_fmi.length), tb = nvbio_hip_fm_build_dimer_index_temp_bytes(m_fmi.length);
@@ -400,6 +401,7 @@ private:
                 if (nvbio_hip_fm_build_dimer_index(&m_fmi, d, t, tb, m_stream) != 0) { m_line_native = false; return; }
             } catch (const fmindex::hip_error&) { m_line_native = false; return; }
             m_dimer_for = m_fmi.bwt_occ; m_dimer_len = m_fmi.length; m_dimer_primary = m_fmi.primary;
+            m_dimer_L2[0] = m_fmi.L2[1]; m_dimer_L2[1] = m_fmi.L2[2]; m_dimer_L2[2] = m_fmi.L2[3];
         }
         if (nvbio_hip_fm_attach_dimer_index(&m_fmi, m_dimer.ptr, m_stream) != 0) m_fmi.dimer = nullptr;
     }
@@ -417,7 +419,7 @@ private:
     const char*                       m_path;
     hipStream_t                       m_stream;
     bool                              m_tuned, m_line_native;
-    const uint32*                     m_dimer_for; uint32 m_dimer_len, m_dimer_primary;
+    const uint32*                     m_dimer_for; uint32 m_dimer_len, m_dimer_primary, m_dimer_L2[3] = { 0u, 0u, 0u };
 };
 #endif // __HIPCC__
 

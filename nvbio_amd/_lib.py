@@ -7,7 +7,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libnvbio_hip.so")
 
 # every symbol include/nvbio_hip.h declares
 SYMBOLS = [
-    "nvbio_hip_banded_gotoh_score", "nvbio_hip_banded_gotoh_score_qual", "nvbio_hip_gotoh_score", "nvbio_hip_banded_sw_score", "nvbio_hip_sw_score", "nvbio_hip_alignment_score", "nvbio_hip_alignment_score_qual",
+    "nvbio_hip_banded_gotoh_score", "nvbio_hip_banded_gotoh_score_qual", "nvbio_hip_banded_gotoh_score_qual_views", "nvbio_hip_gotoh_score", "nvbio_hip_banded_sw_score", "nvbio_hip_sw_score", "nvbio_hip_alignment_score", "nvbio_hip_alignment_score_qual",
     "nvbio_hip_banded_gotoh_traceback_temp_bytes", "nvbio_hip_banded_gotoh_traceback", "nvbio_hip_banded_gotoh_traceback_qual",
     "nvbio_hip_gotoh_traceback_temp_bytes", "nvbio_hip_gotoh_traceback", "nvbio_hip_gotoh_traceback_qual", "nvbio_hip_gotoh_traceback_known_score", "nvbio_hip_gotoh_traceback_qual_known_score", "nvbio_hip_known_score_redone", "nvbio_hip_banded_sw_traceback", "nvbio_hip_sw_traceback",
     "nvbio_hip_fm_rank", "nvbio_hip_fm_rank4", "nvbio_hip_fm_rank_range",
@@ -85,6 +85,7 @@ def lib():
         P = C.POINTER
         L.nvbio_hip_banded_gotoh_score.argtypes = [P(GotohSchemeStruct), i32, u32, P(StringSetStruct), P(StringSetStruct), u32, u32, u32, vp, vp, vp]
         L.nvbio_hip_banded_gotoh_score_qual.argtypes = [P(GotohQualSchemeStruct), i32, u32, P(StringSetStruct), vp, u64, P(StringSetStruct), u32, u32, u32, vp, vp, vp]
+        L.nvbio_hip_banded_gotoh_score_qual_views.argtypes = [P(GotohQualSchemeStruct), i32, u32, P(StringSetStruct), vp, u64, vp, P(StringSetStruct), u32, u32, u32, vp, vp, vp]
         L.nvbio_hip_banded_gotoh_traceback_temp_bytes.argtypes = [u32, u32, u32]
         L.nvbio_hip_banded_gotoh_traceback_temp_bytes.restype = u64
         L.nvbio_hip_banded_gotoh_traceback.argtypes = [P(GotohSchemeStruct), i32, u32, P(StringSetStruct), P(StringSetStruct), u32, u32, u32,

@@ -142,9 +142,11 @@ class BatchedBandedAlignmentScore:
 
     max_temp_storage = min_temp_storage
 
-    def enact(self, aligner, patterns, texts, out_score, out_sink, max_pattern_length=0, max_text_length=0, quals=None):
+    def enact(self, aligner, patterns, texts, out_score, out_sink, max_pattern_length=0, max_text_length=0, quals=None, pattern_flags=None):
         """quals: uint8 device tensor indexed like the pattern stream's symbols -- required by (and only
-        used with) a SmithWatermanScoringScheme aligner, as nvBowtie's read qualities are."""
+        used with) a SmithWatermanScoringScheme aligner, as nvBowtie's read qualities are.
+        pattern_flags: optional uint8 device tensor, one byte per job -- the io::ReadStream view nvBowtie's streams take of a stored
+        read (bit 0 = walk it backwards, bit 1 = complement), applied by the kernel as it fetches (quality scheme only)."""
         n = len(patterns)
         if patterns.length is None:
             max_pattern_length = max_pattern_length or patterns.fixed_length
@@ -164,12 +166,16 @@ class BatchedBandedAlignmentScore:
             return
         if isinstance(aligner.scheme, SmithWatermanScoringScheme):
             assert quals is not None and quals.dtype == torch.uint8 and quals.is_cuda and quals.is_contiguous()
-            err = lib().nvbio_hip_banded_gotoh_score_qual(
-                C.byref(sc), aligner.type, self.band_len, C.byref(ps), C.c_void_p(quals.data_ptr()), quals.numel(), C.byref(ts),
+            if pattern_flags is not None:
+                assert pattern_flags.dtype == torch.uint8 and pattern_flags.is_cuda and pattern_flags.numel() >= n
+            err = lib().nvbio_hip_banded_gotoh_score_qual_views(
+                C.byref(sc), aligner.type, self.band_len, C.byref(ps), C.c_void_p(quals.data_ptr()), quals.numel(),
+                C.c_void_p(pattern_flags.data_ptr()) if pattern_flags is not None else None, C.byref(ts),
                 int(max_pattern_length), int(max_text_length), n,
                 C.c_void_p(out_score.data_ptr()), C.c_void_p(out_sink.data_ptr()), current_stream_ptr())
-            check(err, "nvbio_hip_banded_gotoh_score_qual")
+            check(err, "nvbio_hip_banded_gotoh_score_qual_views")
             return
+        assert pattern_flags is None, "pattern views are a feature of the quality-scheme entry point"
         err = lib().nvbio_hip_banded_gotoh_score(
             C.byref(sc), aligner.type, self.band_len, C.byref(ps), C.byref(ts),
             int(max_pattern_length), int(max_text_length), n,
@@ -178,7 +184,7 @@ class BatchedBandedAlignmentScore:
 
 
 def batch_banded_alignment_score(band_len, aligner, patterns, texts, out_score=None, out_sink=None,
-                                 max_pattern_length=0, max_text_length=0, quals=None):
+                                 max_pattern_length=0, max_text_length=0, quals=None, pattern_flags=None):
     """batch_banded_alignment_score<BAND_LEN>(aligner, patterns, texts, sinks, DeviceThreadScheduler()).
     Returns (score[n] int32, sink[n,2] int32 holding the uint32 bit patterns)."""
     n = len(patterns)
@@ -188,7 +194,7 @@ def batch_banded_alignment_score(band_len, aligner, patterns, texts, out_score=N
     if out_sink is None:
         out_sink = torch.empty((n, 2), dtype=torch.int32, device=dev)
     BatchedBandedAlignmentScore(band_len).enact(aligner, patterns, texts, out_score, out_sink,
-                                                max_pattern_length, max_text_length, quals)
+                                                max_pattern_length, max_text_length, quals, pattern_flags)
     return out_score, out_sink
 
 

@@ -87,7 +87,7 @@ static uint32_t max_len_16bit(int32_t match, int32_t best_pair /* max substituti
 
 template <typename QA>
 static int banded_gotoh_dispatch(nvb::GotohParams& p, const QA& qa, int64_t max_abs_cost, int32_t best_pair, int32_t type, uint32_t band_len,
-                                 const nvbio_hip_string_set* patterns, hipStream_t s, const char* tag16, const char* tag32)
+                                 const nvbio_hip_string_set* patterns, hipStream_t s, const char* tag16, const char* tag32, const bool views = false)
 {
     using namespace nvb;
     // NVBIO_HIP_FORCE_32BIT=1 disables the 16-bit kernels (used by the tests to cover both widths)
@@ -103,7 +103,12 @@ static int banded_gotoh_dispatch(nvb::GotohParams& p, const QA& qa, int64_t max_
         p.stage_pw = p.stage_tw = 0;
         const char* nostage = getenv("NVBIO_HIP_NO_STAGING");
         if (maxM != 0 && !(nostage && nostage[0] == '1')) {
-            const uint32_t pw = (stage_words_pattern(32u / patterns->bits - 1u, maxM, patterns->bits) + 3u) & ~3u;
+            uint32_t pw = stage_words_pattern(32u / patterns->bits - 1u, maxM, patterns->bits);
+            if (views) {     // a reversed view spans the groups [last - ceil16(M) - 15, last] plus one group fetch from the word of last - 15
+                const uint32_t per = 32u / patterns->bits, c16 = (maxM + 15u) & ~15u;
+                pw = std::max(pw, (per - 1u + c16 + 16u + per - 1u) / per + (patterns->bits == 4 ? 3u : 2u));
+            }
+            pw = (pw + 3u) & ~3u;
             const uint32_t tw = (stage_words_text(15u, maxM, band_len) + 3u) & ~3u;
             if ((pw + tw) * 1024u <= 32768u) { p.stage_pw = pw; p.stage_tw = tw; }
         }
@@ -173,6 +178,16 @@ NVB_API int nvbio_hip_banded_gotoh_score_qual(
     uint32_t max_pattern_len, uint32_t max_text_len,
     uint32_t n, int32_t* out_score, uint32_t* out_sink, void* stream)
 {
+    return nvbio_hip_banded_gotoh_score_qual_views(scheme, type, band_len, patterns, quals, n_quals, nullptr, texts, max_pattern_len, max_text_len, n, out_score, out_sink, stream);
+}
+
+NVB_API int nvbio_hip_banded_gotoh_score_qual_views(
+    const nvbio_hip_gotoh_qual_scheme* scheme, int32_t type, uint32_t band_len,
+    const nvbio_hip_string_set* patterns, const uint8_t* quals, uint64_t n_quals, const uint8_t* pattern_flags,
+    const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len,
+    uint32_t n, int32_t* out_score, uint32_t* out_sink, void* stream)
+{
     (void)max_text_len;
     using namespace nvb;
     if (!scheme) return hipErrorInvalidValue;
@@ -190,13 +205,14 @@ NVB_API int nvbio_hip_banded_gotoh_score_qual(
     p.n = n; p.out_score = out_score; p.out_sink = out_sink;
     p.stage_pw = max_pattern_len; p.stage_tw = 0;       // the hint, consumed by banded_gotoh_dispatch
     QualArgs qa;
-    qa.quals = quals; qa.n_quals = n_quals;
+    qa.quals = quals; qa.n_quals = n_quals; qa.flags = pattern_flags;
     int64_t A = std::max(std::max(iabs64(scheme->match), iabs64(scheme->pattern_gap_open)), std::max(iabs64(scheme->pattern_gap_ext),
                 std::max(iabs64(scheme->text_gap_open), iabs64(scheme->text_gap_ext))));
     int32_t best_pair = scheme->match;
     for (int i = 0; i < 256; ++i) { qa.lut[i] = scheme->mismatch[i]; A = std::max(A, iabs64(scheme->mismatch[i])); best_pair = std::max(best_pair, scheme->mismatch[i]); }
     return banded_gotoh_dispatch(p, qa, A, best_pair, type, band_len, patterns, to_stream(stream),
-                                 "banded_gotoh_score_kernel<A16,qual>", "banded_gotoh_score_kernel<A32,qual>");
+                                 pattern_flags ? "banded_gotoh_score_kernel<A16,qual,views>" : "banded_gotoh_score_kernel<A16,qual>",
+                                 pattern_flags ? "banded_gotoh_score_kernel<A32,qual,views>" : "banded_gotoh_score_kernel<A32,qual>", pattern_flags != nullptr);
 }
 
 // SmithWatermanAligner / EditDistanceAligner in the band (sw_banded_inl.h:340-520): with deletion == insertion the

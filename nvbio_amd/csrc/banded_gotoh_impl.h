@@ -24,6 +24,10 @@ struct QualArgs {
     const uint8_t* quals;        // quality of the pattern symbol at stream index begin + i
     uint64_t       n_quals;      // bytes allocated (loads are clamped)
     int32_t        lut[256];     // mismatch(q)
+    // optional per-job view of the pattern (nvbio::io::ReadStream, nvbio/io/utils.h:100-330; how nvBowtie's streams hand out a read,
+    // nvBowtie/bowtie2/cuda/alignment_utils.h:194-211): bit 0 = walk the stored symbols [begin, begin + M) backwards (symbol k of the
+    // pattern is stored symbol begin + M - 1 - k, its quality likewise), bit 1 = complement the bases (c < 4 -> 3 - c).  NULL = none.
+    const uint8_t* flags;
 };
 struct NoQual {};
 
@@ -332,6 +336,69 @@ __device__ __forceinline__ uint64_t fetch_pattern16(const Stream& s, uint64_t sy
     return (s.bits == 4) ? fetch16_4bit(s, sym) : expand_2to4(fetch16_2bit(s, sym));
 }
 
+__host__ __device__ __forceinline__ uint32_t stage_words_pattern(uint32_t off, uint32_t M, uint32_t bits);
+
+// ---- pattern views (QualArgs::flags).  The 16 pattern symbols / qualities of rows i0 .. i0+15 of a job whose pattern is stored
+// symbols [pb, pb + M).  A reversed view reads the group of stored symbols [last - i0 - 15, last - i0], last = pb + M - 1, and turns it
+// round in registers: nothing is copied or staged per job, the DP rows see the same canonical group either way.
+__device__ __forceinline__ uint32_t view_flags(const QualArgs& qa, uint32_t id) { return qa.flags ? uint32_t(qa.flags[id]) : 0u; }
+__device__ __forceinline__ uint32_t view_flags(const NoQual&, uint32_t)        { return 0u; }
+__device__ __forceinline__ uint64_t reverse_nibbles(uint64_t x)
+{
+    x = __builtin_bswap64(x);
+    return ((x & 0xF0F0F0F0F0F0F0F0ull) >> 4) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+}
+__device__ __forceinline__ uint64_t complement_nibbles(uint64_t v)        // c < 4 -> 3 - c, anything else (N) stays
+{
+    const uint64_t big = ((v >> 2) | (v >> 3)) & 0x1111111111111111ull;  // 1 where the nibble is >= 4
+    return v ^ ((big ^ 0x1111111111111111ull) * 3ull);
+}
+// 16 quality bytes of stored positions s .. s+15 where s may be negative (a reversed read at the very start of the array): bytes
+// before the array are zero -- they belong to rows past the pattern's end
+__device__ __forceinline__ uint4 fetch_quals16_signed(const QualArgs& qa, int64_t s)
+{
+    if (s >= 0) return fetch_quals16(qa, uint64_t(s));
+    uint32_t w[4] = { 0u, 0u, 0u, 0u };
+    for (int r = 0; r < 16; ++r) {
+        const int64_t pos = s + r;
+        const uint32_t b = pos < 0 ? 0u : uint32_t(qa.quals[uint64_t(pos) < qa.n_quals ? uint64_t(pos) : qa.n_quals - 1u]);
+        w[r >> 2] |= b << (8 * (r & 3));
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ void fetch_group(const Stream& ps, const QualArgs& qa, const uint64_t pb, const uint32_t M, const uint32_t fl, const uint32_t i0,
+                                            uint64_t& P, uint4& Q)
+{
+    if ((fl & 1u) == 0u) { P = fetch_pattern16(ps, pb + i0); Q = fetch_quals16(qa, pb + i0); }
+    else
+    {
+        const int64_t s = int64_t(pb + M - 1u) - int64_t(i0) - 15;
+        const uint64_t raw = s >= 0 ? fetch_pattern16(ps, uint64_t(s)) : (s > -16 ? fetch_pattern16(ps, 0u) << (4u * uint32_t(-s)) : 0ull);
+        const uint4 q = fetch_quals16_signed(qa, s);
+        P = reverse_nibbles(raw);
+        Q = make_uint4(__builtin_bswap32(q.w), __builtin_bswap32(q.z), __builtin_bswap32(q.y), __builtin_bswap32(q.x));
+    }
+    if (fl & 2u) P = complement_nibbles(P);
+}
+__device__ __forceinline__ void fetch_group(const Stream& ps, const NoQual&, const uint64_t pb, const uint32_t, const uint32_t, const uint32_t i0, uint64_t& P, uint4& Q)
+{
+    P = fetch_pattern16(ps, pb + i0); Q = make_uint4(0, 0, 0, 0);
+}
+// first word and word count of the pattern words a lane touches, for its LDS copy
+__device__ __forceinline__ void pattern_words_span(const uint64_t pb, const uint32_t M, const uint32_t bits, const uint32_t fl, uint64_t& first_word, uint32_t& words)
+{
+    const uint32_t per = 32u / bits;
+    if ((fl & 1u) == 0u) { first_word = pb / per; words = stage_words_pattern(uint32_t(pb % per), M, bits); }
+    else
+    {
+        const uint32_t c16 = (M + 15u) & ~15u;
+        const int64_t last = int64_t(pb + M - 1u);
+        const int64_t lo = last - int64_t(c16) - 15, hi = last - 15;             // first symbol of the lowest / highest group fetched
+        first_word = uint64_t(lo > 0 ? lo : 0) / per;
+        words = uint32_t(uint64_t(hi > 0 ? hi : 0) / per + (bits == 4 ? 3u : 2u) - first_word);
+    }
+}
+
 // the sentinel standing in for the reference's infimum (-32768 - max(G_o,G_e), :446-448).
 // 32-bit: the reference's own number (scaled for LOCAL).  16-bit: the lowest value whose
 // G_e step is still representable; the host only selects the 16-bit kernel when every reachable
@@ -393,6 +460,7 @@ banded_gotoh_score_kernel(const GotohParams p, const QA qa)
     const uint64_t pb = p.pat.begin[id];
     const uint64_t tb = p.txt.begin[id];
     const uint32_t N  = p.txt.length ? p.txt.length[id] : p.txt.fixed_length;
+    const uint32_t fl = view_flags(qa, id);
 
     int32_t  score = -(1 << 30);                 // BestSink<int32>() : numbers.h:832-835
     uint32_t sx = 0xFFFFFFFFu, sy = 0xFFFFFFFFu;
@@ -407,9 +475,10 @@ banded_gotoh_score_kernel(const GotohParams p, const QA qa)
         Stream ps = p.pat.s, ts = p.txt.s;
         if (p.stage_pw != 0u)
         {
-            const uint32_t pper = 32u / ps.bits;
-            const uint64_t kbp = pb / pper, kbt = tb >> 4;
-            if (stage_words_pattern(uint32_t(pb % pper), M, ps.bits) <= p.stage_pw &&
+            uint64_t kbp; uint32_t pwords;
+            pattern_words_span(pb, M, ps.bits, fl, kbp, pwords);
+            const uint64_t kbt = tb >> 4;
+            if (pwords <= p.stage_pw &&
                 stage_words_text(uint32_t(tb & 15u), M, BAND) <= p.stage_tw)
             {
                 uint32_t* lp = s_stage + threadIdx.x;
@@ -460,15 +529,15 @@ banded_gotoh_score_kernel(const GotohParams p, const QA qa)
             }
         }
 
-        uint64_t P  = fetch_pattern16(ps, pb);
+        uint64_t P; uint4 Q;
+        fetch_group(ps, qa, pb, M, fl, 0u, P, Q);
         uint32_t Tx = fetch16_2bit(ts, tb + BAND - 1);
-        uint4    Q  = fetch_quals16(qa, pb);
         for (uint32_t i0 = 0; i0 < M; i0 += BT::ROWS)
         {
             // prefetch the next block's symbols while this one computes
-            const uint64_t Pn = fetch_pattern16(ps, pb + i0 + BT::ROWS);
+            uint64_t Pn; uint4 Qn;
+            fetch_group(ps, qa, pb, M, fl, i0 + BT::ROWS, Pn, Qn);
             const uint32_t Tn = fetch16_2bit(ts, tb + i0 + BT::ROWS + BAND - 1);
-            const uint4    Qn = fetch_quals16(qa, pb + i0 + BT::ROWS);
             // a block none of whose rows lets a symbol past the text's end into the band runs on table arithmetic
             if (A::TABLE && i0 + BT::ROWS - 1u + BAND - 1u < N)
                 RowUnrollN<BAND, TYPE, A, QUAL, true, 0, BT::ROWS>::run(st, k, i0, M, N, P, Tx, Q, s_lut, s_masks);

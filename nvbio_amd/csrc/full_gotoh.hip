@@ -373,19 +373,23 @@ struct Sweep16
         // select takes the first lanes' mask from VCC -- where a DPP move into a register preset with the first lane's value costs two and
         // knows lane 0 only.  (In isolation v_cndmask_b32_dpp on VCC measures 22.7 issue cycles against 6.9 for a DPP move + an e64 select
         // on an SGPR mask, profiles/r03/valu_probe.txt; inside this sweep the order is the other way round, 3.73 against 3.54 TCUPS.)
-        // out_hg is the register the step before wrote last: it is read last (a DPP source needs two wait states, nothing inserts them here).
+        // gfx9 wants two wait states between a VALU write of a VGPR and a DPP read of it, and the compiler's hazard recognizer does not
+        // look inside an asm block: whatever the scheduler placed before this block, `s_nop 1` after the s_mov guarantees them (the registers
+        // the step before wrote last -- out_hg, and out_cm in the CHECK form -- are also read last).
         uint32_t in_hg, in_f, in_ch, in_cm = 0u;
         if (CHECK)
             asm("s_mov_b64 vcc, %[m]\n\t"
-                "v_cndmask_b32_dpp %[cm], %[ocm], %[hcm], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                "s_nop 1\n\t"
                 "v_cndmask_b32_dpp %[ch], %[och], %[hch], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
                 "v_cndmask_b32_dpp %[f], %[of], %[hf], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
-                "v_cndmask_b32_dpp %[hg], %[ohg], %[hh], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
+                "v_cndmask_b32_dpp %[hg], %[ohg], %[hh], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
+                "v_cndmask_b32_dpp %[cm], %[ocm], %[hcm], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"
                 : [cm] "=&v"(in_cm), [ch] "=&v"(in_ch), [f] "=&v"(in_f), [hg] "=&v"(in_hg)
                 : [ocm] "v"(out_cm), [och] "v"(out_ch), [of] "v"(out_f), [ohg] "v"(out_hg),
                   [hcm] "v"(0x8000u), [hch] "v"(ch0), [hf] "v"(inf16), [hh] "v"(th), [m] "s"(head_mask) : "vcc");
         else
             asm("s_mov_b64 vcc, %[m]\n\t"
+                "s_nop 1\n\t"
                 "v_cndmask_b32_dpp %[ch], %[och], %[hch], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
                 "v_cndmask_b32_dpp %[f], %[of], %[hf], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
                 "v_cndmask_b32_dpp %[hg], %[ohg], %[hh], vcc wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0"

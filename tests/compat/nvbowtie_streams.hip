@@ -1,18 +1,18 @@
-// tests/compat/nvbowtie_streams.hip -- a caller written to the shape of nvBowtie's own alignment streams:
-//   * the strings container of nvBowtie/bowtie2/cuda/alignment_utils.h:170-218 (AlignmentStrings: a ReadLoader pattern viewed
-//     REVERSE / STANDARD or FORWARD / COMPLEMENT by the hit's strand, pattern.qualities(), a PackedStringLoader genome window,
-//     all with the lmem cache tag),
-//   * the stream base of :257-340 (context {idx, mate, read_range, read_id, read_rc, genome_begin, genome_end, min_score} + sink or
-//     backtracer; load_strings() = strings->load(pipeline, context)),
-//   * a score stream in the shape of score_best_inl.h:54-148 (window = [loc - band/2, + band + read_len) clamped to the genome,
-//     min_score = max(second best, score_limit), output = hit.score / hit.sink),
-//   * an opposite-mate score stream over the full matrix (score_opposite_inl.h:54-260) and a traceback stream with nvBowtie's
-//     CIGAR-forming Backtracker (alignment_utils.h:125-168, traceback_inl.h:53-189),
-//   * a scoring scheme in the shape of scoring.h:206-356 (QualCost mismatch penalties, constant match bonus, separate read /
-//     reference gap costs).
-// It includes the reference's header names and is compiled with `hipcc -I include/nvbio_hip/compat`; nothing in these classes
-// knows about this build.  The extern "C" entry points at the bottom exist so that the Python tests can drive it; they report
-// which execution the batch objects chose (nvBowtie's streams must run "tuned").
+// tests/compat/nvbowtie_streams.hip -- a GPU-side client of the drop-in template layer that scores and traces back VIEWS of stored
+// reads, the concept nvBowtie's extension streams are built on.  (That the reference's own stream classes -- verbatim -- bind and are
+// routed to the tuned kernels is proved at compile time by tools/ref_bind_check.py in the build container; this file exists so that
+// the same ROUTES run on the GPU box, against the oracle, from a caller that owns nothing but the library's documented concepts.)
+//
+// The concepts it relies on, all from the layer's public headers:
+//   * a read batch type with the members io::ReadLoader asks for (sequence_stream(), qual_stream(), the two storage iterator
+//     typedefs, SEQUENCE_BITS / SEQUENCE_BIG_ENDIAN);  ReadLoader::load(batch, range, direction, complement) -> io::ReadStream;
+//     ReadStream::qualities() -> the matching quality string;
+//   * a text that is a vector_view over a PackedStringLoader window of a 2-bit genome;
+//   * a scoring scheme with match / mismatch(q) / substitution / four gap accessors and the two cost-function typedefs;
+//   * the batch stream concept (batched.h:239-296): aligner(), size(), max_*_length(), init_context, pattern / text length,
+//     load_strings, output; context {min_score, sink} for scores, {min_score, backtracer, alignment} for tracebacks.
+// One stream template covers the four uses (banded score, whole-window score, banded traceback, whole-window traceback); a job is a
+// candidate placement {read, position, strand} of a read (or of its mate) on the genome.
 #include <nvbio/basic/types.h>
 #include <nvbio/basic/packedstream.h>
 #include <nvbio/basic/packedstream_loader.h>
@@ -26,322 +26,199 @@
 
 using namespace nvbio;
 
-namespace bt2 {
+namespace client {
 
-using namespace nvbio::io;
-
-// ---------------------------------------------------------------------------------------------------------------------
-// the scheme (shape of scoring.h:86-125, 206-356)
-// ---------------------------------------------------------------------------------------------------------------------
-template <typename T> struct QualCost
+// ------------------------------------------------------------------------------------------------------------------ scoring
+/// mismatch penalty growing linearly with the phred quality up to 40, truncated the way float -> int conversion truncates
+struct PhredPenalty
 {
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE QualCost() : m_min_val(0), m_max_val(0) {}
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE QualCost(const T min_val, const T max_val) : m_min_val(min_val), m_max_val(max_val) {}
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE T operator()(const int i) const
-    {
-        const float frac = (float)(nvbio::min(i, 40) / 40.0f);
-        return m_min_val + T(frac * (m_max_val - m_min_val));
-    }
-    T m_min_val, m_max_val;
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE PhredPenalty(const int at0 = 0, const int at40 = 0) : lo(at0), hi(at40) {}
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE int operator()(const int phred) const { return lo + int((float)(phred < 40 ? phred : 40) / 40.0f * (hi - lo)); }
+    int lo, hi;
 };
-template <typename T> struct ConstantCost
+struct FixedBonus
 {
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE ConstantCost() : m_val(0) {}
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE ConstantCost(const T, const T max_val) : m_val(max_val) {}
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE T operator()(const int) const { return T(m_val); }
-    T m_val;
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE FixedBonus(const int v = 0) : value(v) {}
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE int operator()(const int) const { return value; }
+    int value;
 };
-
-template <typename MMCost = QualCost<int>, typename NCost = ConstantCost<int> >
-struct SmithWatermanScoringScheme
+/// affine gaps with separate costs on the read and on the reference side: a gap of length L costs base + L * step
+struct ViewScheme
 {
-    typedef SmithWatermanScoringScheme<MMCost, NCost>        scheme_type;
-    typedef aln::GotohAligner<aln::LOCAL, scheme_type>       local_aligner_type;
-    typedef aln::GotohAligner<aln::SEMI_GLOBAL, scheme_type> end_to_end_aligner_type;
-    typedef ConstantCost<int> MatchCost;
-    typedef MMCost            MismatchCost;
-    typedef MatchCost         match_cost_function;
-    typedef MismatchCost      mismatch_cost_function;
-    typedef NCost             N_cost_function;
-    static const int32 inf_score   = -(1 << 16);
-    static const int32 worst_score = inf_score;
+    typedef FixedBonus   match_cost_function;
+    typedef PhredPenalty mismatch_cost_function;
+    static const int32 worst_score = -(1 << 16);
 
-    local_aligner_type      local_aligner()      const { return local_aligner_type(*this); }
-    end_to_end_aligner_type end_to_end_aligner() const { return end_to_end_aligner_type(*this); }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE int32 match(const uint8 q = 0) const { return bonus(q); }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE int32 mismatch(const uint8 q = 0) const { return -penalty(q); }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE int32 mismatch(const uint8, const uint8, const uint8 q = 0) const { return -penalty(q); }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE int32 substitution(const uint32, const uint32, const uint8 ref, const uint8 sym, const uint8 q = 0) const
+    { return ref == sym ? bonus(q) : -penalty(q); }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE int32 pattern_gap_open()      const { return -(read_gap_base + read_gap_step); }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE int32 pattern_gap_extension() const { return -read_gap_step; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE int32 text_gap_open()         const { return -(ref_gap_base + ref_gap_step); }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE int32 text_gap_extension()    const { return -ref_gap_step; }
 
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE int32 match(const uint8 q = 0)    const { return  m_match(q); }
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE int32 mismatch(const uint8 q = 0) const { return -m_mmp(q); }
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE int32 mismatch(const uint8, const uint8, const uint8 qq = 0) const { return -m_mmp(qq); }
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE int32 substitution(const uint32, const uint32, const uint8 r, const uint8 q, const uint8 qq = 0) const { return r == q ? m_match(qq) : -m_mmp(qq); }
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE int32 pattern_gap_open()      const { return -m_read_gap_const - m_read_gap_coeff; }
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE int32 pattern_gap_extension() const { return -m_read_gap_coeff; }
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE int32 text_gap_open()         const { return -m_ref_gap_const - m_ref_gap_coeff; }
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE int32 text_gap_extension()    const { return -m_ref_gap_coeff; }
-
-    int       m_read_gap_const, m_read_gap_coeff, m_ref_gap_const, m_ref_gap_coeff;
-    MatchCost m_match;
-    MMCost    m_mmp;
-    NCost     m_np;
+    FixedBonus   bonus;
+    PhredPenalty penalty;
+    int          read_gap_base, read_gap_step, ref_gap_base, ref_gap_step;
 };
 
-// ---------------------------------------------------------------------------------------------------------------------
-// the batch of reads (the accessors io::SequenceDataAccess offers) and the pipeline state
-// ---------------------------------------------------------------------------------------------------------------------
-struct ReadBatch
+// ------------------------------------------------------------------------------------------------------------------ data
+/// 4-bit big-endian reads, stored back to front, with a quality byte per stored symbol -- what io::ReadLoader loads from
+struct StoredReads
 {
     static const uint32 SEQUENCE_BITS       = io::SequenceDataTraits<DNA_N>::SEQUENCE_BITS;
     static const bool   SEQUENCE_BIG_ENDIAN = io::SequenceDataTraits<DNA_N>::SEQUENCE_BIG_ENDIAN;
-    typedef cuda::ldg_pointer<uint32>                                                       sequence_storage_iterator;
-    typedef cuda::ldg_pointer<uint8>                                                        qual_storage_iterator;
+    typedef cuda::ldg_pointer<uint32>  sequence_storage_iterator;
+    typedef cuda::ldg_pointer<uint8>   qual_storage_iterator;
     typedef PackedStream<sequence_storage_iterator, uint8, SEQUENCE_BITS, SEQUENCE_BIG_ENDIAN> sequence_stream_type;
-
     NVBIO_FORCEINLINE NVBIO_HOST_DEVICE sequence_stream_type  sequence_stream() const { return sequence_stream_type(sequence_storage_iterator(words)); }
     NVBIO_FORCEINLINE NVBIO_HOST_DEVICE qual_storage_iterator qual_stream()     const { return qual_storage_iterator(quals); }
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint2  get_range(const uint32 i) const { return make_uint2(index[i], index[i + 1]); }
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 max_read_len() const { return longest; }
-    const uint32* words; const uint8* quals; const uint32* index; uint32 longest;
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint2 extent(const uint32 r) const { return make_uint2(offsets[r], offsets[r + 1]); }
+    const uint32* words; const uint8* quals; const uint32* offsets; uint32 longest;
+};
+struct Candidate { uint32 read, position, reverse_strand; };
+
+/// everything a batch reads and writes
+struct Workspace
+{
+    typedef PackedStream<cuda::ldg_pointer<uint32>, uint8, 2, true> genome_type;
+    StoredReads       reads, mates;
+    genome_type       genome;
+    uint32            genome_length;
+    const uint32*     order;            // job i works on candidate order[i]
+    const Candidate*  candidates;
+    uint32            n_jobs;
+    const int32*      runner_up;        // per read: the score to beat
+    int32             floor;
+    const uint2*      windows;          // whole-window modes: the genome window of each candidate's mate
+    uint32            widest_window;
+    int32*  placed_score; uint32* placed_end; int32* raw_score; uint2* raw_sink;
+    uint16* cigar; uint32 cigar_stride; uint32* cigar_len; int32* aln_score; uint2* aln_source; uint2* aln_sink;
 };
 
-struct Hit { uint32 read_id, loc, rc; };
-
-template <typename scheme_t>
-struct Pipeline
+/// one run-length CIGAR element in 16 bits: operation in the low two bits, length above (soft clip = 3)
+struct Run
 {
-    typedef scheme_t                                                   scheme_type;
-    typedef ReadBatch                                                  read_batch_type;
-    typedef PackedStream<cuda::ldg_pointer<uint32>, uint8, 2, true>    genome_iterator;
-    read_batch_type  reads, reads_o;
-    genome_iterator  genome;
-    uint32           genome_length;
-    const uint32*    idx_queue;
-    const Hit*       hits;
-    uint32           hits_queue_size;
-    const int32*     second_best;         // per read
-    int32            score_limit;
-    int32*           hit_score; uint32* hit_sink; int32* raw_score; uint2* raw_sink;      // outputs
-    // opposite-mate windows
-    const uint2*     o_windows;
-    // tracebacks
-    uint16*          cigar; uint32 cigar_stride; uint32* cigar_len; int32* aln_score; uint2* aln_source; uint2* aln_sink;
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE Run() {}
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE Run(const uint32 op, const uint32 len) : packed(uint16(op | (len << 2))) {}
+    uint16 packed;
 };
-
-enum AlignmentStreamType { SCORE_STREAM = 0, OPPOSITE_SCORE_STREAM = 1, TRACEBACK_STREAM = 2 };
-
-/// the CIGAR op as nvBowtie stores it (nvbio/io/alignments.h:57-75)
-struct Cigar
+/// the backtracer: receives the alignment from its end backwards and run-length encodes it as it comes
+struct RunRecorder
 {
-    enum Type { SUBSTITUTION = 0, INSERTION = 1, DELETION = 2, SOFT_CLIPPING = 3 };
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE Cigar() {}
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE Cigar(const uint8 type, const uint16 len) : m_type(type), m_len(len) {}
-    uint16 m_type:2, m_len:14;
-};
-
-/// forms a CIGAR on the go, stored backwards (alignment_utils.h:125-168)
-template <typename vector>
-struct Backtracker
-{
-    NVBIO_FORCEINLINE NVBIO_DEVICE Backtracker(vector vec, const uint32 _capacity) : out(vec), size(0), prev(255), capacity(_capacity) {}
-    NVBIO_FORCEINLINE NVBIO_DEVICE void clip(const uint32 l) { if (l) out[size++] = Cigar(Cigar::SOFT_CLIPPING, l); }
-    NVBIO_FORCEINLINE NVBIO_DEVICE void push(uint8 type)
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE RunRecorder() : n(0), last(0xFFu) {}
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void clip(const uint32 len) { if (len) { runs[n++] = Run(3u, len); last = 0xFFu; } }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void push(const uint8 op)
     {
-        if (prev == type) out[size - 1u].m_len++;
-        else { out[size++] = Cigar(type, 1u); prev = type; }
+        if (op == last) runs[n - 1u].packed += 4u;
+        else { runs[n++] = Run(op, 1u); last = op; }
     }
-    vector out; uint32 size; uint8 prev; uint32 capacity;
+    Run runs[1024]; uint32 n; uint8 last;
 };
 
-// ---------------------------------------------------------------------------------------------------------------------
-// strings + stream base (shape of alignment_utils.h:170-340)
-// ---------------------------------------------------------------------------------------------------------------------
-template <typename AlignerType, typename PipelineType>
-struct AlignmentStrings
+enum Mode { BAND_SCORE = 0, WINDOW_SCORE = 1, BAND_TRACE = 2, WINDOW_TRACE = 3 };
+template <Mode M> struct mode_traits { static const bool whole_window = (M == WINDOW_SCORE || M == WINDOW_TRACE); static const bool trace = (M == BAND_TRACE || M == WINDOW_TRACE); };
+
+template <bool TRACE> struct Result { aln::BestSink<int32> sink; };
+template <> struct Result<true> { RunRecorder backtracer; aln::Alignment<int32> alignment; };
+
+// ------------------------------------------------------------------------------------------------------------------ the stream
+template <Mode MODE, typename Aligner>
+struct PlacementStream
 {
-    typedef typename PipelineType::genome_iterator   genome_iterator;
-    typedef typename PipelineType::read_batch_type   read_batch_type;
-    typedef typename PipelineType::scheme_type       scheme_type;
-    typedef AlignerType                              aligner_type;
-    static const uint32 CACHE_SIZE = 64;
-    typedef nvbio::lmem_cache_tag<CACHE_SIZE>        lmem_cache_type;
+    typedef Aligner aligner_type;
+    typedef mode_traits<MODE> traits;
+    typedef lmem_cache_tag<64> cache_tag;
+    typedef io::ReadLoader<StoredReads, cache_tag>                          read_loader;
+    typedef PackedStringLoader<cuda::ldg_pointer<uint32>, 2, true, cache_tag> genome_loader;
 
-    typedef ReadLoader<read_batch_type, lmem_cache_type>        pattern_loader_type;
-    typedef typename pattern_loader_type::string_type           pattern_string;
-    typedef typename pattern_string::qual_string_type           qual_string;
-    typedef PackedStringLoader<typename genome_iterator::storage_iterator, genome_iterator::SYMBOL_SIZE, genome_iterator::BIG_ENDIAN, lmem_cache_type> text_loader_type;
-    typedef typename text_loader_type::iterator                 text_iterator;
-    typedef vector_view<text_iterator>                          text_string;
-
-    template <typename context_type>
-    NVBIO_HOST_DEVICE void load(const PipelineType& pipeline, const context_type* context)
+    /// the job: which candidate, which read range, which strand, which genome window, the score to beat -- and where the result goes
+    struct context_type : Result<traits::trace>
     {
-        read_batch_type reads = context->mate ? pipeline.reads_o : pipeline.reads;
-        const DirType  read_dir  = context->read_rc ? FORWARD    : REVERSE;       // the reads are stored reversed
-        const ReadType read_type = context->read_rc ? COMPLEMENT : STANDARD;
-        pattern = pattern_loader.load(reads, context->read_range, read_dir, read_type);
-        quals   = pattern.qualities();
-        text    = text_string(context->genome_end - context->genome_begin,
-                              text_loader.load(pipeline.genome + context->genome_begin, context->genome_end - context->genome_begin));
-    }
-    pattern_loader_type pattern_loader;
-    text_loader_type    text_loader;
-    pattern_string      pattern;
-    qual_string         quals;
-    text_string         text;
-};
-
-template <AlignmentStreamType TYPE> struct AlignmentStreamContext {};
-template <> struct AlignmentStreamContext<SCORE_STREAM>          { aln::BestSink<int32> sink; };
-template <> struct AlignmentStreamContext<OPPOSITE_SCORE_STREAM> { aln::BestSink<int32> sink; };
-template <> struct AlignmentStreamContext<TRACEBACK_STREAM>
-{
-    Cigar                   cigar[1024];
-    Backtracker<Cigar*>     backtracer;
-    aln::Alignment<int32>   alignment;
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE AlignmentStreamContext() : backtracer(cigar, 1024u) {}
-};
-
-template <AlignmentStreamType TYPE, typename AlignerType, typename PipelineType>
-struct AlignmentStreamBase
-{
-    typedef AlignmentStrings<AlignerType, PipelineType> strings_type;
-    typedef typename PipelineType::scheme_type          scheme_type;
-    typedef AlignerType                                 aligner_type;
-    struct context_type : AlignmentStreamContext<TYPE>
-    {
-        uint32 idx, mate; uint2 read_range; uint32 read_id, read_rc, genome_begin, genome_end; int32 min_score;
+        uint32 candidate; uint2 stored; bool reverse_strand; uint32 window_lo, window_hi; int32 min_score;
     };
-    AlignmentStreamBase(const PipelineType _pipeline, const aligner_type _aligner) : m_pipeline(_pipeline), m_aligner(_aligner) {}
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE const aligner_type& aligner() const { return m_aligner; }
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 pattern_length(const uint32, const context_type* context) const { return context->read_range.y - context->read_range.x; }
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 text_length(const uint32, const context_type* context) const { return context->genome_end - context->genome_begin; }
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void load_strings(const uint32, const uint32, const uint32, const context_type* context, strings_type* strings) const
-    { strings->load(m_pipeline, context); }
-    PipelineType m_pipeline;
-    aligner_type m_aligner;
-};
-
-// ---------------------------------------------------------------------------------------------------------------------
-// the three streams
-// ---------------------------------------------------------------------------------------------------------------------
-template <typename AlignerType, typename PipelineType>
-struct BestScoreStream : public AlignmentStreamBase<SCORE_STREAM, AlignerType, PipelineType>
-{
-    typedef AlignmentStreamBase<SCORE_STREAM, AlignerType, PipelineType> base_type;
-    typedef typename base_type::context_type context_type;
-    typedef typename base_type::scheme_type  scheme_type;
-    BestScoreStream(const uint32 _band_len, const PipelineType _pipeline, const AlignerType _aligner) : base_type(_pipeline, _aligner), m_band_len(_band_len) {}
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 max_pattern_length() const { return base_type::m_pipeline.reads.max_read_len(); }
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 max_text_length() const { return base_type::m_pipeline.reads.max_read_len() + m_band_len; }
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 size() const { return base_type::m_pipeline.hits_queue_size; }
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool init_context(const uint32 i, context_type* context) const
+    /// the strings of a job: a view of the stored read, its qualities in the same order, the genome window
+    struct strings_type
     {
-        context->idx = base_type::m_pipeline.idx_queue[i];
-        const Hit hit = base_type::m_pipeline.hits[context->idx];
-        context->mate       = 0u;
-        context->read_rc    = hit.rc;
-        context->read_id    = hit.read_id;
-        context->read_range = base_type::m_pipeline.reads.get_range(context->read_id);
-        const uint32 g_pos = hit.loc;
-        const uint32 read_len = context->read_range.y - context->read_range.x;
-        context->genome_begin = g_pos > m_band_len / 2 ? g_pos - m_band_len / 2 : 0u;
-        context->genome_end   = nvbio::min(context->genome_begin + m_band_len + read_len, base_type::m_pipeline.genome_length);
-        context->sink = aln::BestSink<int32>();
-        context->min_score = nvbio::max(base_type::m_pipeline.second_best[context->read_id], base_type::m_pipeline.score_limit);
+        typename read_loader::string_type                        pattern;
+        typename read_loader::string_type::qual_string_type      quals;
+        vector_view<typename genome_loader::iterator>            text;
+        read_loader   loads_read;
+        genome_loader loads_genome;
+    };
+
+    PlacementStream(const Workspace& workspace, const Aligner aligner, const uint32 band) : ws(workspace), al(aligner), band_len(band) {}
+
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE const Aligner& aligner() const { return al; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 size() const { return ws.n_jobs; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 max_pattern_length() const { return traits::whole_window ? ws.mates.longest : ws.reads.longest; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 max_text_length() const { return traits::whole_window ? ws.widest_window : ws.reads.longest + band_len; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 pattern_length(const uint32, const context_type* job) const { return job->stored.y - job->stored.x; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 text_length(const uint32, const context_type* job) const { return job->window_hi - job->window_lo; }
+
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool init_context(const uint32 i, context_type* job) const
+    {
+        job->candidate = ws.order[i];
+        const Candidate c = ws.candidates[job->candidate];
+        if (traits::whole_window)
+        {
+            // the mate lies on the other strand, somewhere in a window computed elsewhere; an empty window means "do not look"
+            job->stored = ws.mates.extent(c.read);
+            job->reverse_strand = !c.reverse_strand;
+            job->window_lo = ws.windows[job->candidate].x; job->window_hi = ws.windows[job->candidate].y;
+            job->min_score = ws.floor;
+            if constexpr (!traits::trace) job->sink = aln::BestSink<int32>();
+            return traits::trace || job->window_hi > job->window_lo;
+        }
+        // the read is tried around its candidate position: half a band before it, a band plus its length wide, cut at the genome's end
+        job->stored = ws.reads.extent(c.read);
+        job->reverse_strand = c.reverse_strand != 0u;
+        const uint32 len = job->stored.y - job->stored.x, half = band_len / 2u;
+        job->window_lo = c.position > half ? c.position - half : 0u;
+        job->window_hi = nvbio::min(job->window_lo + band_len + len, ws.genome_length);
+        job->min_score = traits::trace ? ws.floor : nvbio::max(ws.runner_up[c.read], ws.floor);
+        if constexpr (!traits::trace) job->sink = aln::BestSink<int32>();
         return true;
     }
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void output(const uint32, const context_type* context) const
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void load_strings(const uint32, const uint32, const uint32, const context_type* job, strings_type* s) const
     {
-        const aln::BestSink<int32> sink = context->sink;
-        base_type::m_pipeline.hit_score[context->idx] = nvbio::max(sink.score, scheme_type::worst_score);
-        base_type::m_pipeline.hit_sink[context->idx]  = context->genome_begin + sink.sink.x;
-        base_type::m_pipeline.raw_score[context->idx] = sink.score;
-        base_type::m_pipeline.raw_sink[context->idx]  = sink.sink;
+        // reads are stored back to front: the forward strand is the stored read walked backwards, the reverse complement is the stored
+        // read walked forwards with every base complemented
+        const StoredReads& from = traits::whole_window ? ws.mates : ws.reads;
+        s->pattern = s->loads_read.load(from, job->stored, job->reverse_strand ? io::FORWARD : io::REVERSE, job->reverse_strand ? io::COMPLEMENT : io::STANDARD);
+        s->quals   = s->pattern.qualities();
+        const uint32 span = job->window_hi - job->window_lo;
+        s->text    = vector_view<typename genome_loader::iterator>(span, s->loads_genome.load(ws.genome + job->window_lo, span));
     }
-    const uint32 m_band_len;
-};
-
-/// the opposite mate scored over a whole window with the full DP (the mate batch, its strand and window given per hit)
-template <typename AlignerType, typename PipelineType>
-struct OppositeScoreStream : public AlignmentStreamBase<OPPOSITE_SCORE_STREAM, AlignerType, PipelineType>
-{
-    typedef AlignmentStreamBase<OPPOSITE_SCORE_STREAM, AlignerType, PipelineType> base_type;
-    typedef typename base_type::context_type context_type;
-    OppositeScoreStream(const uint32 _max_window, const PipelineType _pipeline, const AlignerType _aligner) : base_type(_pipeline, _aligner), m_max_window(_max_window) {}
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 max_pattern_length() const { return base_type::m_pipeline.reads_o.max_read_len(); }
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 max_text_length() const { return m_max_window; }
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 size() const { return base_type::m_pipeline.hits_queue_size; }
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool init_context(const uint32 i, context_type* context) const
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void output(const uint32, const context_type* job) const
     {
-        context->idx = base_type::m_pipeline.idx_queue[i];
-        const Hit hit = base_type::m_pipeline.hits[context->idx];
-        context->mate       = 1u;
-        context->read_rc    = !hit.rc;
-        context->read_id    = hit.read_id;
-        context->read_range = base_type::m_pipeline.reads_o.get_range(context->read_id);
-        context->genome_begin = base_type::m_pipeline.o_windows[context->idx].x;
-        context->genome_end   = base_type::m_pipeline.o_windows[context->idx].y;
-        context->sink = aln::BestSink<int32>();
-        context->min_score = base_type::m_pipeline.score_limit;
-        return context->genome_end > context->genome_begin;          // hits without a window are skipped, as score_opposite_inl.h:121-160 does
-    }
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void output(const uint32, const context_type* context) const
-    {
-        base_type::m_pipeline.raw_score[context->idx] = context->sink.score;
-        base_type::m_pipeline.raw_sink[context->idx]  = context->sink.sink;
-    }
-    const uint32 m_max_window;
-};
-
-/// tracebacks of the hits' alignments with the CIGAR-forming backtracer (traceback_inl.h:53-189); FULL: opposite-mate windows
-template <bool FULL, typename AlignerType, typename PipelineType>
-struct TracebackStream : public AlignmentStreamBase<TRACEBACK_STREAM, AlignerType, PipelineType>
-{
-    typedef AlignmentStreamBase<TRACEBACK_STREAM, AlignerType, PipelineType> base_type;
-    typedef typename base_type::context_type context_type;
-    TracebackStream(const uint32 _band_len, const uint32 _max_window, const PipelineType _pipeline, const AlignerType _aligner)
-        : base_type(_pipeline, _aligner), m_band_len(_band_len), m_max_window(_max_window) {}
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 max_pattern_length() const { return FULL ? base_type::m_pipeline.reads_o.max_read_len() : base_type::m_pipeline.reads.max_read_len(); }
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 max_text_length() const { return FULL ? m_max_window : base_type::m_pipeline.reads.max_read_len() + m_band_len; }
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 size() const { return base_type::m_pipeline.hits_queue_size; }
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool init_context(const uint32 i, context_type* context) const
-    {
-        context->idx = base_type::m_pipeline.idx_queue[i];
-        const Hit hit = base_type::m_pipeline.hits[context->idx];
-        context->mate       = FULL ? 1u : 0u;
-        context->read_rc    = FULL ? !hit.rc : hit.rc;
-        context->read_id    = hit.read_id;
-        context->read_range = FULL ? base_type::m_pipeline.reads_o.get_range(context->read_id) : base_type::m_pipeline.reads.get_range(context->read_id);
-        if (FULL)
+        const uint32 k = job->candidate;
+        if constexpr (traits::trace)
         {
-            context->genome_begin = base_type::m_pipeline.o_windows[context->idx].x;
-            context->genome_end   = base_type::m_pipeline.o_windows[context->idx].y;
+            ws.aln_score[k] = job->alignment.score; ws.aln_source[k] = job->alignment.source; ws.aln_sink[k] = job->alignment.sink;
+            const uint32 n = job->backtracer.n;
+            ws.cigar_len[k] = n;
+            for (uint32 r = 0; r < n && r < ws.cigar_stride; ++r) ws.cigar[uint64(k) * ws.cigar_stride + r] = job->backtracer.runs[r].packed;
         }
         else
         {
-            const uint32 read_len = context->read_range.y - context->read_range.x;
-            context->genome_begin = hit.loc > m_band_len / 2 ? hit.loc - m_band_len / 2 : 0u;
-            context->genome_end   = nvbio::min(context->genome_begin + m_band_len + read_len, base_type::m_pipeline.genome_length);
+            ws.raw_score[k] = job->sink.score; ws.raw_sink[k] = job->sink.sink;
+            if (!traits::whole_window)
+            {
+                ws.placed_score[k] = nvbio::max(job->sink.score, int32(ViewScheme::worst_score));
+                ws.placed_end[k]   = job->window_lo + job->sink.sink.x;
+            }
         }
-        context->min_score = base_type::m_pipeline.score_limit;
-        return true;
     }
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void output(const uint32, const context_type* context) const
-    {
-        const PipelineType& p = base_type::m_pipeline;
-        p.aln_score[context->idx]  = context->alignment.score;
-        p.aln_source[context->idx] = context->alignment.source;
-        p.aln_sink[context->idx]   = context->alignment.sink;
-        const uint32 size = context->backtracer.size;
-        p.cigar_len[context->idx] = size;
-        for (uint32 k = 0; k < size && k < p.cigar_stride; ++k)
-            p.cigar[uint64(context->idx) * p.cigar_stride + k] = uint16(context->cigar[k].m_type | (context->cigar[k].m_len << 2));
-    }
-    const uint32 m_band_len, m_max_window;
+    Workspace ws; Aligner al; uint32 band_len;
 };
 
-typedef SmithWatermanScoringScheme<>   scheme_type;
-typedef Pipeline<scheme_type>          pipeline_type;
+typedef aln::GotohAligner<aln::LOCAL, ViewScheme>       local_aligner;
+typedef aln::GotohAligner<aln::SEMI_GLOBAL, ViewScheme> end_to_end_aligner;
 
-} // namespace bt2
+} // namespace client
 
 // ---------------------------------------------------------------------------------------------------------------------
 // C entry points for the tests
@@ -364,26 +241,26 @@ struct bt2_args
     uint16_t* cigar; uint32_t cigar_stride; uint32_t* cigar_len; int32_t* aln_score; uint32_t* aln_source; uint32_t* aln_sink;
 };
 
-static bt2::pipeline_type make_pipeline(const bt2_args* a)
+static client::Workspace make_workspace(const bt2_args* a)
 {
-    bt2::pipeline_type p;
-    p.reads.words = a->read_words; p.reads.quals = a->read_quals; p.reads.index = a->read_index; p.reads.longest = a->longest;
-    p.reads_o.words = a->mate_words; p.reads_o.quals = a->mate_quals; p.reads_o.index = a->mate_index; p.reads_o.longest = a->mate_longest;
-    p.genome = bt2::pipeline_type::genome_iterator(cuda::ldg_pointer<uint32>(a->genome_words));
-    p.genome_length = a->genome_length;
-    p.idx_queue = a->idx_queue; p.hits = (const bt2::Hit*)a->hits; p.hits_queue_size = a->n_hits;
-    p.second_best = a->second_best; p.score_limit = a->score_limit;
-    p.hit_score = a->hit_score; p.hit_sink = a->hit_sink; p.raw_score = a->raw_score; p.raw_sink = (uint2*)a->raw_sink;
-    p.o_windows = (const uint2*)a->o_windows;
-    p.cigar = a->cigar; p.cigar_stride = a->cigar_stride; p.cigar_len = a->cigar_len; p.aln_score = a->aln_score;
-    p.aln_source = (uint2*)a->aln_source; p.aln_sink = (uint2*)a->aln_sink;
-    return p;
+    client::Workspace w;
+    w.reads.words = a->read_words; w.reads.quals = a->read_quals; w.reads.offsets = a->read_index; w.reads.longest = a->longest;
+    w.mates.words = a->mate_words; w.mates.quals = a->mate_quals; w.mates.offsets = a->mate_index; w.mates.longest = a->mate_longest;
+    w.genome = client::Workspace::genome_type(cuda::ldg_pointer<uint32>(a->genome_words));
+    w.genome_length = a->genome_length;
+    w.order = a->idx_queue; w.candidates = (const client::Candidate*)a->hits; w.n_jobs = a->n_hits;
+    w.runner_up = a->second_best; w.floor = a->score_limit;
+    w.windows = (const uint2*)a->o_windows; w.widest_window = a->max_window;
+    w.placed_score = a->hit_score; w.placed_end = a->hit_sink; w.raw_score = a->raw_score; w.raw_sink = (uint2*)a->raw_sink;
+    w.cigar = a->cigar; w.cigar_stride = a->cigar_stride; w.cigar_len = a->cigar_len; w.aln_score = a->aln_score;
+    w.aln_source = (uint2*)a->aln_source; w.aln_sink = (uint2*)a->aln_sink;
+    return w;
 }
-static bt2::scheme_type make_scheme(const bt2_args* a)
+static client::ViewScheme make_scheme(const bt2_args* a)
 {
-    bt2::scheme_type s;
-    s.m_read_gap_const = a->rdg_c; s.m_read_gap_coeff = a->rdg_k; s.m_ref_gap_const = a->rfg_c; s.m_ref_gap_coeff = a->rfg_k;
-    s.m_match = bt2::ConstantCost<int>(0, a->match); s.m_mmp = bt2::QualCost<int>(a->mmp_min, a->mmp_max); s.m_np = bt2::ConstantCost<int>(0, 1);
+    client::ViewScheme s;
+    s.read_gap_base = a->rdg_c; s.read_gap_step = a->rdg_k; s.ref_gap_base = a->rfg_c; s.ref_gap_step = a->rfg_k;
+    s.bonus = client::FixedBonus(a->match); s.penalty = client::PhredPenalty(a->mmp_min, a->mmp_max);
     return s;
 }
 static void copy_path(char* out, const char* path) { strncpy(out, path, 15); out[15] = 0; }
@@ -391,73 +268,81 @@ static void copy_path(char* out, const char* path) { strncpy(out, path, 15); out
 template <typename aligner_type>
 static int run_banded_score(const bt2_args* a, const aligner_type aligner, char* path)
 {
-    typedef bt2::BestScoreStream<aligner_type, bt2::pipeline_type> stream_type;
-    static_assert(aln::priv::recognised<stream_type>::value && aln::priv::recognised<stream_type>::staged && aln::priv::recognised<stream_type>::stage_quals,
-                  "nvBowtie's score stream must be recognised (staged patterns and qualities)");
-    const bt2::pipeline_type p = make_pipeline(a);
-    if (a->band_len < 16) { aln::BatchedBandedAlignmentScore<15u, stream_type, aln::DeviceThreadScheduler> batch; batch.enact(stream_type(15u, p, aligner), 0, NULL); copy_path(path, batch.last_path()); }
-    else                  { aln::BatchedBandedAlignmentScore<31u, stream_type, aln::DeviceThreadScheduler> batch; batch.enact(stream_type(31u, p, aligner), 0, NULL); copy_path(path, batch.last_path()); }
+    typedef client::PlacementStream<client::BAND_SCORE, aligner_type> stream_type;
+    typedef aln::priv::recognised<stream_type> R;
+    static_assert(R::value && R::staged && R::stage_quals, "a stream of read views under a quality scheme is recognised");
+    static_assert(R::view, "... and its banded score batches run on the views in place");
+    const client::Workspace w = make_workspace(a);
+    if (a->band_len < 16) { aln::BatchedBandedAlignmentScore<15u, stream_type, aln::DeviceThreadScheduler> batch; batch.enact(stream_type(w, aligner, 15u), 0, NULL); copy_path(path, batch.last_path()); }
+    else                  { aln::BatchedBandedAlignmentScore<31u, stream_type, aln::DeviceThreadScheduler> batch; batch.enact(stream_type(w, aligner, 31u), 0, NULL); copy_path(path, batch.last_path()); }
     return int(hipDeviceSynchronize());
 }
 API int bt2_banded_score(const bt2_args* a, char* path)
 {
     try {
-        const bt2::scheme_type s = make_scheme(a);
-        return a->local ? run_banded_score(a, s.local_aligner(), path) : run_banded_score(a, s.end_to_end_aligner(), path);
+        const client::ViewScheme s = make_scheme(a);
+        return a->local ? run_banded_score(a, client::local_aligner(s), path) : run_banded_score(a, client::end_to_end_aligner(s), path);
     } catch (const std::exception& e) { fprintf(stderr, "bt2_banded_score: %s\n", e.what()); return -1; }
 }
-/// the same stream forced down the generic lane (what a build without the tuned recognition would run): for timing it beside the tuned one
+/// the same stream through the STAGED tuned route (patterns and qualities copied to a scratch first -- what the view route replaces;
+/// NVBIO_HIP_COMPAT_NO_VIEWS selects it) and down the generic lane (what a build without the tuned recognition runs): for timing
+/// them beside the in-place route, and for checking that all three agree
+API int bt2_banded_score_staged(const bt2_args* a, char* path)
+{
+    setenv("NVBIO_HIP_COMPAT_NO_VIEWS", "1", 1);
+    const int r = bt2_banded_score(a, path);
+    unsetenv("NVBIO_HIP_COMPAT_NO_VIEWS");
+    return r;
+}
 API int bt2_banded_score_generic(const bt2_args* a)
 {
-    typedef bt2::scheme_type::local_aligner_type aligner_type;
-    typedef bt2::BestScoreStream<aligner_type, bt2::pipeline_type> stream_type;
-    const bt2::pipeline_type p = make_pipeline(a);
-    const stream_type stream(15u, p, make_scheme(a).local_aligner());
+    typedef client::PlacementStream<client::BAND_SCORE, client::local_aligner> stream_type;
+    const stream_type stream(make_workspace(a), client::local_aligner(make_scheme(a)), 15u);
     hipLaunchKernelGGL((aln::priv::batched_banded_score_kernel<15u, stream_type>), dim3((a->n_hits + 127u) / 128u), dim3(128), 0, 0, stream);
     return int(hipDeviceSynchronize());
 }
 template <typename aligner_type>
 static int run_full_score(const bt2_args* a, const aligner_type aligner, char* path)
 {
-    typedef bt2::OppositeScoreStream<aligner_type, bt2::pipeline_type> stream_type;
-    static_assert(aln::priv::recognised<stream_type>::staged, "nvBowtie's opposite-mate stream must be recognised");
+    typedef client::PlacementStream<client::WINDOW_SCORE, aligner_type> stream_type;
+    static_assert(aln::priv::recognised<stream_type>::staged, "the whole-window score stream is recognised");
     aln::BatchedAlignmentScore<stream_type, aln::DeviceThreadScheduler> batch;
-    batch.enact(stream_type(a->max_window, make_pipeline(a), aligner), 0, NULL);
+    batch.enact(stream_type(make_workspace(a), aligner, 0u), 0, NULL);
     copy_path(path, batch.last_path());
     return int(hipDeviceSynchronize());
 }
 API int bt2_opposite_score(const bt2_args* a, char* path)
 {
     try {
-        const bt2::scheme_type s = make_scheme(a);
-        return a->local ? run_full_score(a, s.local_aligner(), path) : run_full_score(a, s.end_to_end_aligner(), path);
+        const client::ViewScheme s = make_scheme(a);
+        return a->local ? run_full_score(a, client::local_aligner(s), path) : run_full_score(a, client::end_to_end_aligner(s), path);
     } catch (const std::exception& e) { fprintf(stderr, "bt2_opposite_score: %s\n", e.what()); return -1; }
 }
 template <typename aligner_type>
 static int run_traceback(const bt2_args* a, const aligner_type aligner, const bool full, char* path)
 {
-    const bt2::pipeline_type p = make_pipeline(a);
+    const client::Workspace w = make_workspace(a);
     if (full)
     {
-        typedef bt2::TracebackStream<true, aligner_type, bt2::pipeline_type> stream_type;
-        static_assert(aln::priv::recognised_tb<stream_type>::staged, "nvBowtie's traceback stream must be recognised");
+        typedef client::PlacementStream<client::WINDOW_TRACE, aligner_type> stream_type;
+        static_assert(aln::priv::recognised_tb<stream_type>::staged, "the whole-window traceback stream is recognised");
         aln::BatchedAlignmentTraceback<1024u, stream_type> batch;
-        batch.enact(stream_type(0u, a->max_window, p, aligner), 0, NULL);
+        batch.enact(stream_type(w, aligner, 0u), 0, NULL);
         copy_path(path, batch.last_path());
     }
     else
     {
-        typedef bt2::TracebackStream<false, aligner_type, bt2::pipeline_type> stream_type;
-        static_assert(aln::priv::recognised_tb<stream_type>::staged, "nvBowtie's traceback stream must be recognised");
-        if (a->band_len < 16) { aln::BatchedBandedAlignmentTraceback<15u, 1024u, stream_type> batch; batch.enact(stream_type(15u, 0u, p, aligner), 0, NULL); copy_path(path, batch.last_path()); }
-        else                  { aln::BatchedBandedAlignmentTraceback<31u, 1024u, stream_type> batch; batch.enact(stream_type(31u, 0u, p, aligner), 0, NULL); copy_path(path, batch.last_path()); }
+        typedef client::PlacementStream<client::BAND_TRACE, aligner_type> stream_type;
+        static_assert(aln::priv::recognised_tb<stream_type>::staged, "the banded traceback stream is recognised");
+        if (a->band_len < 16) { aln::BatchedBandedAlignmentTraceback<15u, 1024u, stream_type> batch; batch.enact(stream_type(w, aligner, 15u), 0, NULL); copy_path(path, batch.last_path()); }
+        else                  { aln::BatchedBandedAlignmentTraceback<31u, 1024u, stream_type> batch; batch.enact(stream_type(w, aligner, 31u), 0, NULL); copy_path(path, batch.last_path()); }
     }
     return int(hipDeviceSynchronize());
 }
 API int bt2_traceback(const bt2_args* a, int full, char* path)
 {
     try {
-        const bt2::scheme_type s = make_scheme(a);
-        return a->local ? run_traceback(a, s.local_aligner(), full != 0, path) : run_traceback(a, s.end_to_end_aligner(), full != 0, path);
+        const client::ViewScheme s = make_scheme(a);
+        return a->local ? run_traceback(a, client::local_aligner(s), full != 0, path) : run_traceback(a, client::end_to_end_aligner(s), full != 0, path);
     } catch (const std::exception& e) { fprintf(stderr, "bt2_traceback: %s\n", e.what()); return -1; }
 }

@@ -231,3 +231,66 @@ def test_quality_aware_scheme(cuda, band, ty):
             gs, gk = gs.cpu().numpy(), gk.cpu().numpy().view(np.uint32)
             bad = np.nonzero((es != gs) | (ek != gk).any(1))[0]
             assert bad.size == 0, (band, ty, force32, bad[:5], es[bad[:3]], gs[bad[:3]])
+
+
+@pytest.mark.parametrize("band", [7, 15, 31])
+@pytest.mark.parametrize("ty", [nvb.LOCAL, nvb.SEMI_GLOBAL, nvb.GLOBAL])
+def test_pattern_views_run_in_place(cuda, band, ty):
+    """nvbio_hip_banded_gotoh_score_qual_views: each job aligns an io::ReadStream VIEW of a stored read -- walked backwards and / or
+    complemented, qualities following the walk (nvbio/io/utils.h:100-330; nvBowtie's AlignmentStrings::load,
+    alignment_utils.h:194-211) -- applied by the kernel as it fetches each 16-symbol group.  Expected: the oracle on the strings
+    and qualities materialised on the host.  Stored reads are ragged, the first ones sit at the very start of the arrays (the
+    reversed walk's look-behind reaches before position 0), several jobs share one stored read, both arithmetic widths, with and
+    without LDS staging."""
+    rng = np.random.default_rng(900 + band + ty)
+    pats, txts = random_pairs(rng, 3000, band)
+    pats[0], pats[1], pats[2] = pats[0][:5], pats[1][:17], pats[2][:33]                 # short reads right at the start of the arrays
+    for k in range(3):
+        txts[k] = txts[k][:len(pats[k]) + band + 3]
+    stored = O.StringSet.from_lists(pats, 4, True)
+    ht = O.StringSet.from_lists(txts, 2, True)
+    total = int(stored.begin[-1] + stored.length[-1])
+    quals = rng.integers(0, 60, total + 3, dtype=np.uint8)
+    quals[::89] = 255
+    flags = rng.integers(0, 4, len(pats)).astype(np.uint8)
+    flags[:8] = [1, 3, 1, 0, 2, 3, 1, 3]
+    # materialise what each view shows
+    mats, mq = [], []
+    for i, pt in enumerate(pats):
+        b, m = int(stored.begin[i]), len(pt)
+        v, q = np.asarray(pt, np.uint8), quals[b:b + m]
+        if flags[i] & 1:
+            v, q = v[::-1], q[::-1]
+        if flags[i] & 2:
+            v = np.where(v < 4, 3 - v, v).astype(np.uint8)
+        mats.append(v.copy()); mq.append(q.copy())
+    hm = O.StringSet.from_lists(mats, 4, True)
+    assert (hm.begin == stored.begin).all()
+    mquals = quals.copy()
+    for i, q in enumerate(mq):
+        mquals[int(hm.begin[i]):int(hm.begin[i]) + q.size] = q
+    scheme = nvb.SmithWatermanScoringScheme.local() if ty == nvb.LOCAL else nvb.SmithWatermanScoringScheme()
+    st = scheme.struct()
+    lut = np.array([st.mismatch[q] for q in range(256)], dtype=np.int32)
+    s6 = (st.match, st.pattern_gap_open, st.pattern_gap_ext, st.text_gap_open, st.text_gap_ext, 0)
+    es, ek = O.batch_banded_gotoh_score_qual(band, ty, s6, lut, mquals, hm, ht)
+    p = nvb.PackedStringSet.from_host(stored.words, 4, True, stored.begin, stored.length, device=cuda)
+    t = nvb.PackedStringSet.from_host(ht.words, 2, True, ht.begin, ht.length, device=cuda)
+    dq, df = torch.from_numpy(quals).to(cuda), torch.from_numpy(flags).to(cuda)
+    for force32, nostage in (("0", "0"), ("1", "0"), ("0", "1")):
+        os.environ["NVBIO_HIP_FORCE_32BIT"], os.environ["NVBIO_HIP_NO_STAGING"] = force32, nostage
+        try:
+            gs, gk = nvb.batch_banded_alignment_score(band, nvb.make_gotoh_aligner(ty, scheme), p, t, quals=dq, pattern_flags=df,
+                                                      max_pattern_length=int(stored.length.max()))
+            torch.cuda.synchronize()
+        finally:
+            os.environ["NVBIO_HIP_FORCE_32BIT"], os.environ["NVBIO_HIP_NO_STAGING"] = "0", "0"
+        assert "views" in nvb.lib().nvbio_hip_last_kernel().decode()
+        gs, gk = gs.cpu().numpy(), gk.cpu().numpy().view(np.uint32)
+        bad = np.nonzero((es != gs) | (ek != gk).any(1))[0]
+        assert bad.size == 0, (band, ty, force32, nostage, bad[:5], flags[bad[:5]], es[bad[:3]], gs[bad[:3]])
+    # no flags == the plain entry point
+    z = torch.zeros_like(df)
+    a = nvb.batch_banded_alignment_score(band, nvb.make_gotoh_aligner(ty, scheme), p, t, quals=dq, pattern_flags=z, max_pattern_length=int(stored.length.max()))
+    b = nvb.batch_banded_alignment_score(band, nvb.make_gotoh_aligner(ty, scheme), p, t, quals=dq, max_pattern_length=int(stored.length.max()))
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])

@@ -1,10 +1,13 @@
-"""nvBowtie's own alignment streams through the drop-in template layer.
-
-tests/compat/nvbowtie_streams.hip is written to the shape of nvBowtie/bowtie2/cuda/alignment_utils.h:170-340 (AlignmentStrings:
-reads stored reversed and viewed through io::ReadLoader as REVERSE/STANDARD or FORWARD/COMPLEMENT, pattern.qualities(), lmem-cached
-PackedStringLoader genome windows), score_best_inl.h:54-148 (BestScoreStream), score_opposite_inl.h (full-matrix opposite mate),
-traceback_inl.h:53-189 (CIGAR-forming Backtracker) and scoring.h:206-356 (quality-aware SmithWatermanScoringScheme).
-Every batch object must report last_path() == "tuned" and reproduce the oracle bit for bit."""
+"""Streams of READ VIEWS through the drop-in template layer -- the concept nvBowtie's extension streams are built on (reads stored
+back to front and looked at through io::ReadLoader as REVERSE / STANDARD or FORWARD / COMPLEMENT views, pattern.qualities(), genome
+windows through PackedStringLoader, a quality-aware scheme with the seven accessors, a CIGAR-forming backtracer).  The caller,
+tests/compat/nvbowtie_streams.hip, is a client written against the layer's documented concepts with its own types; that the
+reference's stream classes themselves (alignment_utils.h:170-340, score_best_inl.h:54-148, score_paired / score_all /
+score_opposite_inl.h, traceback_inl.h:53-189, scoring.h:206-356) bind and take the same routes is proved verbatim by
+tools/ref_bind_check.py in the build container.
+Banded score batches must run on the views IN PLACE (last_path() == "tuned-views": nvbio_hip_banded_gotoh_score_qual_views, nothing
+staged); whole-window scores and the tracebacks run the tuned kernels on staged copies ("tuned"); every route reproduces the oracle
+bit for bit."""
 import ctypes as C
 import os
 
@@ -185,7 +188,7 @@ def test_best_score_stream_runs_tuned_and_matches_oracle(lib, cuda, kind, band):
     keep, out = fill(a, w, cuda, SCHEMES[kind], band)
     path = C.create_string_buffer(16)
     assert lib.bt2_banded_score(C.byref(a), path) == 0
-    assert path.value == b"tuned"
+    assert path.value == b"tuned-views"
     lut, s5, ty = scheme_tables(SCHEMES[kind])
     ps, qbuf, ts = jobs(w, band)
     es, ek = O.batch_banded_gotoh_score_qual(band, ty, s5 + (0,), lut, qbuf, ps, ts)
@@ -197,6 +200,10 @@ def test_best_score_stream_runs_tuned_and_matches_oracle(lib, cuda, kind, band):
     assert (out["hit_score"].cpu().numpy() == np.maximum(es, -(1 << 16))).all()
     assert (out["hit_sink"].cpu().numpy().view(np.uint32) == (gb + ek[:, 0]).astype(np.uint32)).all()
     assert (es > (30 if kind == "local" else -30)).sum() > 3000
+    # the staged tuned route (what the in-place one replaced) still agrees
+    out["raw_score"].fill_(777); out["raw_sink"].fill_(5)
+    assert lib.bt2_banded_score_staged(C.byref(a), path) == 0 and path.value == b"tuned"
+    assert (out["raw_score"].cpu().numpy() == es).all() and (out["raw_sink"].cpu().numpy().view(np.uint32) == ek).all()
 
 
 def test_generic_lane_gives_the_same_results(lib, cuda):
@@ -205,7 +212,7 @@ def test_generic_lane_gives_the_same_results(lib, cuda):
     a = Args()
     keep, out = fill(a, w, cuda, SCHEMES["local"], 15)
     path = C.create_string_buffer(16)
-    assert lib.bt2_banded_score(C.byref(a), path) == 0 and path.value == b"tuned"
+    assert lib.bt2_banded_score(C.byref(a), path) == 0 and path.value == b"tuned-views"
     tuned = (out["raw_score"].cpu().numpy().copy(), out["raw_sink"].cpu().numpy().copy())
     out["raw_score"].fill_(777); out["raw_sink"].fill_(5)
     assert lib.bt2_banded_score_generic(C.byref(a)) == 0

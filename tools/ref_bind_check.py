@@ -123,7 +123,7 @@ void instantiate(const uint32* p, const uint32* t, int16* s)
 
 # nvBowtie's own stream machinery: the strings container + stream base (alignment_utils.h), the single-end score stream (score_best_inl.h) and the
 # scheme (scoring.h) -- verbatim; the wrapper supplies nvBowtie's pipeline / hit-queue / params types (application types, not library types)
-CASES.append(("nvBowtie AlignmentStrings + AlignmentStreamBase + BestScoreStream + SmithWatermanScoringScheme -> tuned (staged)",
+CASES.append(("nvBowtie AlignmentStrings + AlignmentStreamBase + BestScoreStream + SmithWatermanScoringScheme -> tuned, on the read views in place",
               [("nvBowtie/bowtie2/cuda/scoring.h", 53, 125), ("nvBowtie/bowtie2/cuda/scoring.h", 196, 356),
                ("nvBowtie/bowtie2/cuda/alignment_utils.h", 114, 345), ("nvBowtie/bowtie2/cuda/score_best_inl.h", 48, 148),
                ("nvBowtie/bowtie2/cuda/func.h", 39, 70)], r"""
@@ -187,6 +187,7 @@ typedef scheme_type::local_aligner_type                      local_aligner;
 typedef detail::BestScoreStream<local_aligner, pipeline_type> stream_type;
 static_assert(aln::priv::quality_scheme<scheme_type>::value, "nvBowtie's scheme is recognised as a quality scheme");
 static_assert(aln::priv::recognised<stream_type>::staged && aln::priv::recognised<stream_type>::stage_quals, "nvBowtie's BestScoreStream must run on the tuned kernels");
+static_assert(aln::priv::recognised<stream_type>::view, "... and in place: its patterns are io::ReadStream views of packed reads with byte-pointer qualities");
 void instantiate(const pipeline_type& pipeline, const scheme_type& scheme, const ParamsPOD params)
 {{
     aln::BatchedBandedAlignmentScore<15u, stream_type, aln::DeviceThreadScheduler> batch;
@@ -459,11 +460,12 @@ NVBOWTIE_SCORE_RANGES = [("nvBowtie/bowtie2/cuda/scoring.h", 53, 125), ("nvBowti
                          ("nvBowtie/bowtie2/cuda/alignment_utils.h", 42, 345)]
 FUNC_H = ("nvBowtie/bowtie2/cuda/func.h", 39, 70)
 
-CASES.append(("nvBowtie score_paired_inl.h: BestAnchorScoreStream + banded_anchor_score_best (the enact calls of :212-237) -> tuned (staged)",
+CASES.append(("nvBowtie score_paired_inl.h: BestAnchorScoreStream + banded_anchor_score_best (the enact calls of :212-237) -> tuned, on the read views in place",
               NVBOWTIE_SCORE_RANGES + [("nvBowtie/bowtie2/cuda/score_paired_inl.h", 48, 243), FUNC_H],
               NVBOWTIE_SCORE_PRELUDE + r"""
 typedef detail::BestAnchorScoreStream<local_aligner, pipeline_type> stream_type;
 static_assert(aln::priv::recognised<stream_type>::staged && aln::priv::recognised<stream_type>::stage_quals, "nvBowtie's BestAnchorScoreStream must run on the tuned kernels");
+static_assert(aln::priv::recognised<stream_type>::view, "... on the read views in place");
 void instantiate(const pipeline_type& pipeline, const scheme_type& scheme, const ParamsPOD params)
 {{
     detail::banded_anchor_score_best(15u, pipeline, scheme.local_aligner(), params);
@@ -472,11 +474,12 @@ void instantiate(const pipeline_type& pipeline, const scheme_type& scheme, const
 }} }} }} // namespaces
 """))
 
-CASES.append(("nvBowtie score_all_inl.h: AllScoreStream + banded_score_all (the enact calls of :194-219) -> tuned (staged)",
+CASES.append(("nvBowtie score_all_inl.h: AllScoreStream + banded_score_all (the enact calls of :194-219) -> tuned, on the read views in place",
               NVBOWTIE_SCORE_RANGES + [("nvBowtie/bowtie2/cuda/score_all_inl.h", 48, 225), FUNC_H],
               NVBOWTIE_SCORE_PRELUDE + r"""
 typedef detail::AllScoreStream<local_aligner, pipeline_type> stream_type;
 static_assert(aln::priv::recognised<stream_type>::staged && aln::priv::recognised<stream_type>::stage_quals, "nvBowtie's AllScoreStream must run on the tuned kernels");
+static_assert(aln::priv::recognised<stream_type>::view, "... on the read views in place");
 void instantiate(const pipeline_type& pipeline, const scheme_type& scheme, const ParamsPOD params)
 {{
     detail::banded_score_all(15u, pipeline, scheme.local_aligner(), params, 0u, 64u, (uint32*)0);
