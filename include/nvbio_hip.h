@@ -832,6 +832,22 @@ int nvbio_hip_comm_init_all(void** comms, int n_devices, const int* devices /* n
 int nvbio_hip_comm_destroy(void* comm);
 int nvbio_hip_comm_rank(void* comm, int* rank, int* world);
 int nvbio_hip_gather_records(void* comm, const void* send, const uint64_t* counts, uint32_t record_bytes, void* recv /* root only */, int root, void* stream);
+/* after a local failure: unblock the peers waiting on this communicator (ncclCommAbort); it is unusable afterwards */
+int nvbio_hip_comm_abort(void* comm);
+/* The transport seam under nvbio_hip_gather_records.  The gather is a plan of sends / receives / one copy (nvbio_hip/gather_plan.h)
+ * executed through these five operations; the default table is RCCL.  Installing another table (NULL restores RCCL) lets the CPU suite
+ * run the plan over host memory at worlds of 2..8, and lets a deployment without RCCL keep the entry point.  `comm` is whatever the
+ * table's owner made it; every function returns 0 or an error code. */
+typedef struct nvbio_hip_comm_transport {
+    int (*rank)(void* comm, int* rank, int* world);
+    int (*group_start)(void* comm);
+    int (*group_end)(void* comm);
+    int (*send)(void* comm, const void* buf, uint64_t bytes, int peer, void* stream);
+    int (*recv)(void* comm, void* buf, uint64_t bytes, int peer, void* stream);
+    int (*copy)(void* comm, void* dst, const void* src, uint64_t bytes, void* stream);
+    int (*abort)(void* comm);
+} nvbio_hip_comm_transport;
+void nvbio_hip_comm_set_transport(const nvbio_hip_comm_transport* transport);
 
 /* Library / device introspection (host). */
 int         nvbio_hip_abi_version(void);

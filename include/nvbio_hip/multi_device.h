@@ -13,7 +13,10 @@
 //                                  RCCL ncclSend / ncclRecv (nvbio_hip_gather_records).
 // Everything inside a rank -- index, Aligner, streams -- is what a single-GPU run uses.
 #pragma once
+#include <atomic>
 #include <functional>
+#include <string>
+#include <stdexcept>
 #include <thread>
 #include <vector>
 #include "types.h"
@@ -24,6 +27,7 @@ namespace hip {
 /// rank `rank` of `world` owns items [first, second) of n_total (nvbio_amd/distributed.py: shard_range -- the same split)
 inline std::pair<uint64, uint64> shard_range(const uint64 n_total, const uint32 rank, const uint32 world)
 {
+    if (world == 0u) return std::make_pair(uint64(0), uint64(0));
     const uint64 per = (n_total + world - 1u) / world;
     const uint64 lo = std::min<uint64>(n_total, uint64(rank) * per);
     return std::make_pair(lo, std::min<uint64>(n_total, lo + per));
@@ -56,8 +60,8 @@ struct DeviceGroup
         }
     };
 
-    DeviceGroup() {}
-    ~DeviceGroup() { for (size_t i = 0; i < m_ranks.size(); ++i) if (m_ranks[i].comm) (void)nvbio_hip_comm_destroy(m_ranks[i].comm); }
+    DeviceGroup() : m_owns_comms(true) {}
+    ~DeviceGroup() { if (m_owns_comms) for (size_t i = 0; i < m_ranks.size(); ++i) if (m_ranks[i].comm) (void)nvbio_hip_comm_destroy(m_ranks[i].comm); }
     DeviceGroup(const DeviceGroup&) = delete;
     DeviceGroup& operator=(const DeviceGroup&) = delete;
 
@@ -86,27 +90,50 @@ struct DeviceGroup
         g.m_ranks.assign(1, r);
     }
 
+    /// ranks over communicators made elsewhere (one per local rank, all of one world); devices[i] < 0 = do not bind a device (hosts
+    /// without one: the CPU suite runs the group over a host-memory transport, nvbio_hip_comm_set_transport).  The group does not own
+    /// these communicators.
+    static void from_comms(DeviceGroup& g, const std::vector<void*>& comms, const std::vector<int>& devices)
+    {
+        g.m_ranks.resize(comms.size());
+        for (size_t i = 0; i < comms.size(); ++i) { Rank r = { uint32(i), uint32(comms.size()), devices[i], comms[i] }; g.m_ranks[i] = r; }
+        g.m_owns_comms = false;
+    }
+
     size_t size() const { return m_ranks.size(); }
     const Rank& operator[](const size_t i) const { return m_ranks[i]; }
 
     /// run `body` once per local rank: on its own host thread bound to its device when this group holds several (compute_thread.cu:95:
-    /// cudaSetDevice per thread), inline otherwise.  The first exception of any thread is rethrown after all have joined.
+    /// cudaSetDevice per thread), inline otherwise.  The first exception of any thread is rethrown after all have joined.  A rank that
+    /// fails never reaches the collective its peers are waiting in, so the failing thread ABORTS every communicator of the group
+    /// (ncclCommAbort): the peers' pending receives return an error, their threads end, and the caller gets the original exception
+    /// instead of a hang.
     void run(const std::function<void(const Rank&)>& body) const
     {
         if (m_ranks.size() == 1u) { body(m_ranks[0]); return; }
         std::vector<std::thread> threads;
         std::vector<std::string> errors(m_ranks.size());
+        std::atomic<int> first_failed(-1);
+        auto fail = [&](const size_t i, const char* what) {
+            errors[i] = (what && what[0]) ? what : "error";
+            int expected = -1;
+            if (first_failed.compare_exchange_strong(expected, int(i)))
+                for (size_t k = 0; k < m_ranks.size(); ++k) if (m_ranks[k].comm) (void)nvbio_hip_comm_abort(m_ranks[k].comm);
+        };
         for (size_t i = 0; i < m_ranks.size(); ++i)
             threads.emplace_back([&, i] {
-                try { hip_check(nvbio_hip_set_device(m_ranks[i].device), "nvbio_hip_set_device"); body(m_ranks[i]); }
-                catch (const std::exception& e) { errors[i] = e.what(); if (errors[i].empty()) errors[i] = "error"; }
+                try { if (m_ranks[i].device >= 0) hip_check(nvbio_hip_set_device(m_ranks[i].device), "nvbio_hip_set_device"); body(m_ranks[i]); }
+                catch (const std::exception& e) { fail(i, e.what()); }
+                catch (...) { fail(i, "unknown exception"); }
             });
         for (size_t i = 0; i < threads.size(); ++i) threads[i].join();
-        for (size_t i = 0; i < errors.size(); ++i) if (!errors[i].empty()) throw std::runtime_error("rank " + std::to_string(i) + ": " + errors[i]);
+        const int f = first_failed.load();
+        if (f >= 0) throw std::runtime_error("rank " + std::to_string(f) + ": " + errors[size_t(f)]);
     }
 
 private:
     std::vector<Rank> m_ranks;
+    bool              m_owns_comms;
 };
 
 } // namespace hip

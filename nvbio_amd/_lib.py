@@ -32,7 +32,7 @@ SYMBOLS = [
     "nvbio_hip_stream_synchronize", "nvbio_hip_stream_create", "nvbio_hip_stream_create_with_cu_mask", "nvbio_hip_stream_destroy", "nvbio_hip_device_cu_count",
     "nvbio_hip_set_seeding_grid_limit", "nvbio_hip_get_seeding_grid_limit",
     "nvbio_hip_comm_available", "nvbio_hip_device_count", "nvbio_hip_set_device", "nvbio_hip_get_device", "nvbio_hip_comm_unique_id", "nvbio_hip_comm_init_rank",
-    "nvbio_hip_comm_init_all", "nvbio_hip_comm_destroy", "nvbio_hip_comm_rank", "nvbio_hip_gather_records",
+    "nvbio_hip_comm_init_all", "nvbio_hip_comm_destroy", "nvbio_hip_comm_rank", "nvbio_hip_gather_records", "nvbio_hip_comm_abort", "nvbio_hip_comm_set_transport",
     "nvbio_hip_abi_version", "nvbio_hip_arch", "nvbio_hip_last_kernel",
 ]
 

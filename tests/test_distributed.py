@@ -118,3 +118,17 @@ def test_cxx_shard_range_is_the_same_split(tmp_path):
         for r in range(w):
             lo, hi = shard_range(n, r, w)
             assert v[3 * r:3 * r + 3] == [lo, hi, hi - lo], (n, w, r)
+
+
+def test_cxx_record_gather_and_device_group_over_a_host_transport():
+    """The C++ side of the path's only collective without a multi-GPU node: nvbio_hip_gather_records (the plan of
+    include/nvbio_hip/gather_plan.h) and hip::DeviceGroup -- one host thread per rank -- over a host-memory transport installed through
+    nvbio_hip_comm_set_transport (tests/cxx/comm_plan_test.cpp): worlds of 2, 3, 5, 8; even, ragged, empty and one-rank-only shards;
+    1 / 4 / 8-word records; several roots; shard_sizes() of ragged totals.  The root's buffer must hold every rank's records in rank
+    order and global read order (a swapped offset or rank fails it), grouped receives must not deadlock against the sends, and a rank
+    that throws before the collective must surface as an exception instead of a hang (DeviceGroup aborts the communicators)."""
+    import ctypes
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "tests", "cxx", "libcomm_plan_test.so")
+    assert os.path.exists(path), "build with python -c 'import __graft_entry__ as g; g.build()'"
+    assert ctypes.CDLL(path).comm_plan_selftest() == 0
