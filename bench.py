@@ -554,13 +554,13 @@ def e2e_leg(a, dev, fmi, text):
                 idx, desc = hbm_rich(fmi, dev)
             else:
                 idx, desc = fmi.with_dimer(), {"line_native": True, "ktab_k": 0, "sa_int": fmi.sa_int}
-            serial, sb, sm = cxx_pipelined(dev, idx, inputs, genome_words, ng, names, prm, 1, 0, False)
+            serial, sb, sm = cxx_pipelined(dev, idx, inputs, genome_words, ng, names, prm, 1)
             entry = {"index": desc, "serial": serial}
             if sb is not None:
                 loc = [(x[0] >> 32) & 0xFFFFFFFF for x in sb]
                 entry["aligned"] = sum(int((l != 0xFFFFFFFF).sum().item()) for l in loc) / tot
                 entry["best_at_true_position"] = sum(int(((l != 0xFFFFFFFF) & ((l - t).abs() <= 2)).sum().item()) for l, t in zip(loc, truth)) / tot
-                co, cb, cm = cxx_pipelined(dev, idx, inputs, genome_words, ng, names, prm, 2, 0, False)
+                co, cb, cm = cxx_pipelined(dev, idx, inputs, genome_words, ng, names, prm, 2)
                 if cb is not None:
                     co["identical_to_serial"] = all(torch.equal(x, y) for x, y in zip(cb, sb)) and all(torch.equal(x, y) for x, y in zip(cm, sm))
                 entry["two_batches_in_flight"] = co
@@ -647,7 +647,7 @@ def config5_share_leg(a, dev, fmi, text, genome_words, ng, names, prm, batch_pai
     out = {"pairs": n * nb, "batches": nb, "pairs_per_batch": n, "read_len": L, "index": desc,
            "driver": "nvbio::bowtie2::cuda::Aligner::best_approx(PairedReadBatch) (C++, include/nvbio_hip/aligner.h)", "pair_record_bytes": 32}
     ref = None
-    for key, workers, limit, token in (("serial", 1, 0, 0), ("two_batches_in_flight", 2, 0, 0)):
+    for key, workers in (("serial", 1), ("two_batches_in_flight", 2)):
         ms, stats = (C.c_double * 1)(), (C.c_uint64 * 2)()
         torch.cuda.synchronize()
         torch.cuda.empty_cache()               # the C++ drivers allocate their own workspaces: hand them what torch's allocator has cached
@@ -656,12 +656,12 @@ def config5_share_leg(a, dev, fmi, text, genome_words, ng, names, prm, batch_pai
             u64x2([pk0[0][0].words.numel(), pk0[1][0].words.numel()]), u64x2([pk0[0][1].numel(), pk0[1][1].numel()]),
             vp(quals), C.c_uint64(quals.numel()), vp(arena), vp(nidx), C.c_uint64(keep[0][1].numel()), C.c_uint64(mate_offset), vp(both_q), C.c_uint64(both_q.numel()),
             vp(genome_words), C.c_uint64(genome_words.numel()), C.c_uint32(ng), C.byref(sp), C.byref(pp),
-            C.c_uint32(workers), C.c_uint32(limit), ms, rec_ptrs, stats, C.c_uint32(token))
+            C.c_uint32(workers), ms, rec_ptrs, stats)
         torch.cuda.synchronize()
         if rc != 0:
             out[key] = {"error": "nvbio_aligner_best_approx_paired_pipelined returned %d" % rc}
             continue
-        out[key] = {"host_threads": workers, "seeding_grid_limit": limit, "seeding_token": bool(token), "ms_total": ms[0], "Mpairs_per_s": n * nb / ms[0] / 1e3,
+        out[key] = {"host_threads": workers, "ms_total": ms[0], "Mpairs_per_s": n * nb / ms[0] / 1e3,
                     "ms_per_batch": ms[0] / nb, "anchor_extensions": int(stats[0])}
         if ref is None:
             ref = [t.clone() for t in records]
@@ -803,9 +803,9 @@ def cxx_driver_leg(a, dev, idx, sym, packed, genome_words, ng, names, prm, ref_b
             "identical_to_python_driver": bool(torch.equal(best, ref_best) and torch.equal(mapq, ref_mapq))}
 
 
-def cxx_pipelined(dev, idx, batches, genome_words, ng, names, prm, workers, limit, token, reps=2):
+def cxx_pipelined(dev, idx, batches, genome_words, ng, names, prm, workers, reps=2):
     """`len(batches)` batches of reads through the C++ single-end driver with `workers` host threads / HIP streams sharing the device
-    (tests/cxx/aligner_shim.cpp: nvbio_aligner_best_approx_pipelined; include/nvbio_hip/aligner.h: Aligner::seeding_token).
+    (tests/cxx/aligner_shim.cpp: nvbio_aligner_best_approx_pipelined).
     batches: [pack_read_streams(sym), ...].  Returns (dict, bests, mapqs)."""
     import ctypes as C
     shim = C.CDLL(os.path.join(ROOT, "tests", "cxx", "libaligner_shim.so"))
@@ -827,11 +827,11 @@ def cxx_pipelined(dev, idx, batches, genome_words, ng, names, prm, workers, limi
         ptrs([b[0].words for b in batches]), C.c_uint64(batches[0][0].words.numel()), ptrs([b[0].begin for b in batches]),
         ptrs([b[1] for b in batches]), C.c_uint64(batches[0][1].numel()), vp(quals), C.c_uint64(quals.numel()), vp(arena), vp(nidx),
         vp(genome_words), C.c_uint64(genome_words.numel()), C.c_uint32(ng), C.byref(sp),
-        C.c_uint32(workers), C.c_uint32(limit), C.c_uint32(reps), ms, ptrs(best), ptrs(mapq), C.c_uint32(1 if token else 0), C.c_uint32(0), C.c_uint32(1), C.c_uint32(0))
+        C.c_uint32(workers), C.c_uint32(reps), ms, ptrs(best), ptrs(mapq))
     torch.cuda.synchronize()
     if rc != 0:
         return {"error": "nvbio_aligner_best_approx_pipelined returned %d" % rc}, None, None
-    return {"host_threads": workers, "seeding_grid_limit": limit, "seeding_token": bool(token), "ms_total": ms[0], "Mreads_per_s": n * nb / ms[0] / 1e3}, best, mapq
+    return {"host_threads": workers, "ms_total": ms[0], "Mreads_per_s": n * nb / ms[0] / 1e3}, best, mapq
 
 
 def hbm_rich(fmi, dev):
@@ -881,6 +881,10 @@ def rank_leg(a, dev, fmi):
         res["traffic_frac_of_hbm_peak"] = res["traffic_GBs"] / HBM_PEAK_GBS
     res["random_lines_per_s_G"] = q / (ms * 1e-3) / 1e9
     res["random_line_limit_G"] = 53.0          # tools/gather_probe.hip (profiles/r01/gather_probe.txt): the chip's random 128-B line rate
+    # how to read `frac`: a point query needs 32 bytes of the 128-byte line the fabric moves for it, and the kernel issues those lines at
+    # request_rate_frac of the rate the chip sustains for random lines -- frac = useful_fraction_of_line x (moved bytes / HBM peak)
+    res["useful_fraction_of_line"] = 32.0 / 128.0
+    res["request_rate_frac"] = res["random_lines_per_s_G"] / res["random_line_limit_G"]
     res["order"] = "shuffled"
     res["note"] = ("uniform random point queries, shuffled: one 128-B fabric request per query is the floor (~53 G/s on this chip), so 40 "
                    "algorithmic bytes per query cannot exceed ~0.27 of HBM peak in this order; `sorted_order` is the same query set sorted by row, the "

@@ -257,7 +257,9 @@ int nvbio_hip_gotoh_traceback_qual(
  * count; nvbio_hip_known_score_redone() totals it).  Under a TRUE premise the result is the plain form's in every case, ties included: a
  * tied cell the cropped DP visits first lies off the last row, fails the check, and the job is traced again.  Not detectable under a
  * FALSE premise: a window whose plain-order best alignment (of score known_score, or better in the dropped rows) is not the one the kept
- * rows hold with exactly known_score ending at the last row -- the caller then gets that other alignment.  GLOBAL: same as the plain forms. */
+ * rows hold with exactly known_score ending at the last row -- the caller then gets that other alignment.  GLOBAL: same as the plain forms.
+ * Unlike the plain forms, these two BLOCK the host: the per-job check is read back (one device-to-host copy and a synchronisation of
+ * `stream`), and a batch with failed checks allocates and frees a redo buffer before returning. */
 int nvbio_hip_gotoh_traceback_known_score(
     const nvbio_hip_gotoh_scheme* scheme /* host */, int32_t type,
     const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts, const int32_t* known_score,
@@ -798,19 +800,15 @@ int nvbio_hip_memcpy(void* dst, const void* src, uint64_t bytes, int kind, void*
 int nvbio_hip_memset(void* dst, int value, uint64_t bytes, void* stream);
 int nvbio_hip_stream_synchronize(void* stream);
 
-/* Streams and co-scheduling.  The reference runs one host thread per device on its default stream (nvBowtie.cpp:809-864,
- * compute_thread.cu:74-117).  An MI355X is better served by SEVERAL batches in flight on one device: seeding (map / locate) is bound by
- * the fabric's random-line rate with idle VALUs, extension / selection / traceback are VALU-bound with an idle fabric.  A driver object
- * per host thread, each on its own non-blocking stream (every nvbio_hip_* entry takes the stream), lets the two kinds overlap;
- * nvbio_hip_set_seeding_grid_limit(blocks) caps the grid of the seeding kernels (they become grid-stride loops over their reads), so
- * that they leave wave slots, registers and LDS of every CU to the other stream's kernels.  Process-wide, 0 = no limit (the default).
- * Results never depend on any of this. */
+/* Streams.  The reference runs one host thread per device on its default stream (nvBowtie.cpp:809-864, compute_thread.cu:74-117).
+ * Every nvbio_hip_* entry takes the stream its work is queued on, so a driver object per host thread, each on its own non-blocking
+ * stream, keeps several batches in flight on one device: one batch's fabric-bound seeding (map / locate: random 128-byte lines, idle
+ * VALUs) overlaps another's VALU-bound extension / selection / traceback (+7-10 % measured, profiles/r03/cosched_two_streams.txt).
+ * (Round 3 also exported a CU-masked stream, a grid cap for the seeding kernels and a seeding token; none of them beat two plain
+ * streams in any measured configuration -- a saturated fabric taxes co-resident VALU kernels whichever CUs they sit on,
+ * profiles/r03/cosched_cu_mask.txt, cosched_token_grid_limit.txt -- and they were removed.)  Results never depend on any of this. */
 int nvbio_hip_stream_create(void** stream, uint32_t non_blocking);
-int nvbio_hip_stream_create_with_cu_mask(void** stream, const uint32_t* mask, uint32_t n_words);
 int nvbio_hip_stream_destroy(void* stream);
-int nvbio_hip_device_cu_count(void);
-void     nvbio_hip_set_seeding_grid_limit(uint32_t blocks);
-uint32_t nvbio_hip_get_seeding_grid_limit(void);
 
 /* Multi-GPU.  The reference runs one host thread per device over a replicated index, all writing into one shared
  * output (nvBowtie/nvBowtie.cpp:809-864, bowtie2/cuda/compute_thread.cu:74-117): no collective.  Here every device aligns a contiguous
@@ -848,6 +846,15 @@ typedef struct nvbio_hip_comm_transport {
     int (*abort)(void* comm);
 } nvbio_hip_comm_transport;
 void nvbio_hip_comm_set_transport(const nvbio_hip_comm_transport* transport);
+
+/* Test switches.  A few environment variables select alternative executions of the same results, for the parity suite to cover both
+ * (NVBIO_HIP_FORCE_32BIT, NVBIO_HIP_NO_STAGING, NVBIO_HIP_FULL_GENERIC, NVBIO_HIP_FULL_SINGLE_JOB, NVBIO_HIP_ED_SWEEP,
+ * NVBIO_HIP_SELECT_LANES, NVBIO_HIP_TRACEBACK_LANES).  They are read with getenv at every call so that one process can flip them between
+ * calls; getenv is not safe against a concurrent setenv, so change them only while no other thread is inside a library call.  Production
+ * code leaves them unset.
+ * Memory helpers: nvbio_hip_device_free synchronises the DEVICE (hipFree's contract: the block may be in use by any stream) and frees on
+ * the calling thread's current device -- call it from a thread bound to the device the block lives on, and keep per-batch storage in a
+ * hip::device_arena (include/nvbio_hip/types.h), which never comes through here. */
 
 /* Library / device introspection (host). */
 int         nvbio_hip_abi_version(void);

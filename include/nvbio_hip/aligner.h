@@ -109,27 +109,15 @@ struct Aligner
 
     hip::device_arena                 workspace;                 // the per-batch queues and temporaries of the best-mapping drivers
 
-    /// Several Aligner objects, one per host thread and HIP stream, may share one device (include/nvbio_hip.h, "Streams and
-    /// co-scheduling"): seeding (map / locate) is bound by the fabric's random-line rate with idle VALUs, everything else is VALU-bound
-    /// with an idle fabric.  Two seeding kernels resident at once only share the line rate (measured: both slow down ~1.8x,
-    /// profiles/r03/cosched_trace.txt); what pays is ONE batch seeding while the others extend.  Aligners that are given the same token
-    /// take it around their seeding kernels (and wait for them inside), so at most one of them is in a fabric-bound stage at a time.
-    std::mutex*                       seeding_token;
-    /// optional: a second stream for the seeding kernels alone (e.g. one created with a CU mask, nvbio_hip_stream_create_with_cu_mask, so
-    /// that seeding occupies a fixed slice of the chip and leaves the rest to the other batches' kernels); the hand-over is host-side
-    void*                             seeding_stream;
-
-    Aligner() : BATCH_SIZE(0), SCORING_BATCH(0), cigar_stride(64), mds_stride(256), n_alignments(0), seeding_token(nullptr), seeding_stream(nullptr) {}
+    /// Several Aligner objects, one per host thread and HIP stream, may share one device (include/nvbio_hip.h, "Streams"): seeding
+    /// (map / locate) is bound by the fabric's random-line rate with idle VALUs, everything else is VALU-bound with an idle fabric, so two
+    /// batches in flight overlap the two kinds (+7-10 %).  Nothing else is needed for that: the seeding stages are queued on the batch's own
+    /// stream like every other stage (a token that serialised the seeding stages of co-resident Aligners, and a CU-masked seeding stream,
+    /// were tried in round 3 and removed -- neither beat plain streams).
+    Aligner() : BATCH_SIZE(0), SCORING_BATCH(0), cigar_stride(64), mds_stride(256), n_alignments(0) {}
 
     /// run a seeding stage: f(stream) queues its kernels on the stream it is given
-    template <typename F> void fabric_bound(void* hip_stream, F f)
-    {
-        if (!seeding_token && !seeding_stream) { f(hip_stream); return; }
-        if (seeding_stream) hip::synchronize(hip_stream);               // what the stage reads has been produced
-        void* s = seeding_stream ? seeding_stream : hip_stream;
-        if (seeding_token) { std::lock_guard<std::mutex> guard(*seeding_token); f(s); hip::synchronize(s); }
-        else               { f(s); hip::synchronize(s); }
-    }
+    template <typename F> void fabric_bound(void* hip_stream, F f) { f(hip_stream); }
 
     /// Aligner::band_length (aligner.h:165-174)
     static uint32 band_length(const uint32 max_dist)

@@ -29,8 +29,7 @@ SYMBOLS = [
     "nvbio_hip_fm_filter_temp_bytes", "nvbio_hip_fm_filter_rank", "nvbio_hip_fm_filter_locate",
     "nvbio_hip_build_bwt_occ_temp_bytes", "nvbio_hip_build_bwt_occ",
     "nvbio_hip_device_malloc", "nvbio_hip_device_free", "nvbio_hip_memcpy", "nvbio_hip_memset",
-    "nvbio_hip_stream_synchronize", "nvbio_hip_stream_create", "nvbio_hip_stream_create_with_cu_mask", "nvbio_hip_stream_destroy", "nvbio_hip_device_cu_count",
-    "nvbio_hip_set_seeding_grid_limit", "nvbio_hip_get_seeding_grid_limit",
+    "nvbio_hip_stream_synchronize", "nvbio_hip_stream_create", "nvbio_hip_stream_destroy",
     "nvbio_hip_comm_available", "nvbio_hip_device_count", "nvbio_hip_set_device", "nvbio_hip_get_device", "nvbio_hip_comm_unique_id", "nvbio_hip_comm_init_rank",
     "nvbio_hip_comm_init_all", "nvbio_hip_comm_destroy", "nvbio_hip_comm_rank", "nvbio_hip_gather_records", "nvbio_hip_comm_abort", "nvbio_hip_comm_set_transport",
     "nvbio_hip_abi_version", "nvbio_hip_arch", "nvbio_hip_last_kernel",
@@ -191,8 +190,6 @@ def lib():
         L.nvbio_hip_build_bwt_occ_temp_bytes.argtypes = [u32]
         L.nvbio_hip_build_bwt_occ_temp_bytes.restype = u64
         L.nvbio_hip_build_bwt_occ.argtypes = [u32, vp, vp, vp, vp, u64, vp]
-        L.nvbio_hip_set_seeding_grid_limit.argtypes = [u32]; L.nvbio_hip_set_seeding_grid_limit.restype = None
-        L.nvbio_hip_get_seeding_grid_limit.argtypes = []; L.nvbio_hip_get_seeding_grid_limit.restype = u32
         L.nvbio_hip_comm_unique_id.argtypes = [vp]
         L.nvbio_hip_comm_init_rank.argtypes = [P(vp), C.c_int, C.c_int, vp]
         L.nvbio_hip_comm_init_all.argtypes = [vp, C.c_int, vp]

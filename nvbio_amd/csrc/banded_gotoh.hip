@@ -277,17 +277,11 @@ NVB_API int nvbio_hip_device_free(void* ptr)
     if (hipGetDevice(&dev) == hipSuccess && nvb::private_pool(dev)) return hipFreeAsync(ptr, nullptr);
     return hipFree(ptr);
 }
-// ---- streams and co-scheduling for the C++ host layer (which has no HIP headers).  The reference's drivers run on the default stream of
-// one host thread per device (nvBowtie.cpp:809-864); here one device serves several batches at once: a driver object per host thread,
-// each on its own non-blocking stream, so that one batch's fabric-bound seeding overlaps another's VALU-bound extension.
+// ---- streams for the C++ host layer (which has no HIP headers).  The reference's drivers run on the default stream of one host thread
+// per device (nvBowtie.cpp:809-864); here one device serves several batches at once: a driver object per host thread, each on its own
+// non-blocking stream, so that one batch's fabric-bound seeding overlaps another's VALU-bound extension.
 namespace nvb {
-static std::atomic<uint32_t> g_seeding_grid_limit{0};
-uint32_t seeding_grid(uint64_t n_items)
-{
-    const uint64_t blocks = (n_items + 255u) / 256u;
-    const uint32_t lim = g_seeding_grid_limit.load(std::memory_order_relaxed);
-    return uint32_t(lim != 0u && blocks > lim ? lim : blocks);
-}
+uint32_t seeding_grid(uint64_t n_items) { return uint32_t((n_items + 255u) / 256u); }
 } // namespace nvb
 NVB_API int nvbio_hip_stream_create(void** stream, uint32_t non_blocking)
 {
@@ -297,24 +291,7 @@ NVB_API int nvbio_hip_stream_create(void** stream, uint32_t non_blocking)
     *stream = s;
     return e;
 }
-/* a stream whose kernels run only on the compute units set in `mask` (bit k of word k / 32 = CU k) */
-NVB_API int nvbio_hip_stream_create_with_cu_mask(void** stream, const uint32_t* mask, uint32_t n_words)
-{
-    if (!stream || !mask || n_words == 0) return hipErrorInvalidValue;
-    hipStream_t s = nullptr;
-    const hipError_t e = hipExtStreamCreateWithCUMask(&s, n_words, mask);
-    *stream = s;
-    return e;
-}
 NVB_API int nvbio_hip_stream_destroy(void* stream) { return stream ? hipStreamDestroy(nvb::to_stream(stream)) : hipSuccess; }
-NVB_API int nvbio_hip_device_cu_count(void)
-{
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    return n;
-}
-NVB_API void     nvbio_hip_set_seeding_grid_limit(uint32_t blocks) { nvb::g_seeding_grid_limit.store(blocks, std::memory_order_relaxed); }
-NVB_API uint32_t nvbio_hip_get_seeding_grid_limit(void) { return nvb::g_seeding_grid_limit.load(std::memory_order_relaxed); }
 
 NVB_API int nvbio_hip_memcpy(void* dst, const void* src, uint64_t bytes, int kind, void* stream)
 {

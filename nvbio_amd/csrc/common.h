@@ -122,7 +122,7 @@ inline StringSet make_string_set(const nvbio_hip_string_set* h)
 
 inline hipStream_t to_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
-// blocks a seeding kernel (map / locate: fabric-bound, their VALUs idle) may occupy: nvbio_hip_set_seeding_grid_limit (0 = no limit)
+// blocks of a seeding kernel (map / locate) over n_items reads or rows, 256 lanes each
 uint32_t seeding_grid(uint64_t n_items);
 
 } // namespace nvb

@@ -149,7 +149,7 @@ map_exact_one(const uint32_t id, const Fmi& f, const StringSet& reads, const uin
     out_counts[read_id] = nh;
     if (out_reseed) out_reseed[id] = (range_count == 0u || range_sum >= p.rep_seeds * range_count) ? 1 : 0;
 }
-// grid-stride: the launch may be limited to fewer blocks than reads / 256 (nvbio_hip_set_seeding_grid_limit), so that this
+// grid-stride (a launch may hold fewer blocks than reads / 256), so that this
 // fabric-bound kernel leaves wave slots and registers of every CU to a VALU-bound kernel of another stream
 __global__ void __launch_bounds__(256)
 map_exact_kernel(const Fmi f, const StringSet reads, const uint32_t* __restrict__ in_queue, uint32_t n,

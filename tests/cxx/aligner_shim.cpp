@@ -137,7 +137,7 @@ int nvbio_aligner_best_approx_timed(const nvbio_hip_fmindex* fmi, const nvbio_hi
 // Co-scheduling probe / pipelined driver (bench.py's config-4 leg, tools/cosched_probe.py): `n_batches` batches through the single-end
 // driver with `n_workers` host threads, each owning one Aligner and one non-blocking HIP stream (worker w takes batches w, w + n_workers,
 // ...), the way the reference runs one host thread per device -- here several per device, so that one batch's fabric-bound seeding
-// overlaps another's VALU-bound extension.  seeding_grid_limit: nvbio_hip_set_seeding_grid_limit for the run (0 = none).
+// overlaps another's VALU-bound extension.
 // batch b's reads: d_rev_words[b] / d_rev_begin[b] / d_fwrc_words[b] (device pointers, one set per batch).
 // out_wall_ms = wall time of all batches between two device synchronisations (after one untimed warm-up pass that sizes every worker's
 // workspace); d_best[b] (device, 2n) / d_mapq[b] receive every batch's results.
@@ -149,10 +149,8 @@ int nvbio_aligner_best_approx_pipelined(const nvbio_hip_fmindex* fmi, const nvbi
                                         const uint32_t* const* d_fwrc_words, uint64_t fwrc_n_words, const uint8_t* d_quals, uint64_t n_quals,
                                         const char* d_names, const uint32_t* d_names_idx,
                                         const uint32_t* d_genome_words, uint64_t genome_n_words, uint32_t genome_len, const shim_params* sp,
-                                        uint32_t n_workers, uint32_t seeding_grid_limit, uint32_t reps, double* out_wall_ms,
-                                        uint64_t* const* d_best, uint8_t* const* d_mapq, uint32_t seeding_token /* 1: the workers take turns in their seeding stages */,
-                                        uint32_t seeding_cus /* > 0: seeding kernels on a CU-masked stream of this many CUs */, uint32_t cu_stride /* 1 = the first CUs, k = every k-th */,
-                                        uint32_t mask_compute /* 1: the other kernels on the complement */)
+                                        uint32_t n_workers, uint32_t reps, double* out_wall_ms,
+                                        uint64_t* const* d_best, uint8_t* const* d_mapq)
 {
     try {
         Params params;
@@ -169,31 +167,13 @@ int nvbio_aligner_best_approx_pipelined(const nvbio_hip_fmindex* fmi, const nvbi
         fm_index_device f, rf; f.m = *fmi; rf.m = rfmi ? *rfmi : *fmi;
         if (n_workers == 0) n_workers = 1;
 
-        std::mutex token;
-        const uint32_t old_limit = nvbio_hip_get_seeding_grid_limit();
-        nvbio_hip_set_seeding_grid_limit(seeding_grid_limit);
         std::vector<Aligner*> aligners(n_workers, nullptr);
-        std::vector<void*>    streams(n_workers, nullptr), seed_streams(n_workers, nullptr);
+        std::vector<void*>    streams(n_workers, nullptr);
         for (uint32_t w = 0; w < n_workers; ++w)
         {
             aligners[w] = new Aligner();
             aligners[w]->init(std::max(sp->batch_size, n), sp->batch_size);
-            if (seeding_cus)
-            {
-                const uint32_t n_cu = uint32_t(nvbio_hip_device_cu_count()), words = (n_cu + 31u) / 32u;
-                std::vector<uint32_t> seed_mask(words, 0u), rest_mask(words, 0u);
-                uint32_t taken = 0;
-                for (uint32_t c = 0; c < n_cu; ++c)
-                {
-                    const bool pick = taken < seeding_cus && (c % (cu_stride ? cu_stride : 1u)) == 0u;
-                    if (pick) { seed_mask[c / 32u] |= 1u << (c % 32u); ++taken; } else rest_mask[c / 32u] |= 1u << (c % 32u);
-                }
-                hip_check(nvbio_hip_stream_create_with_cu_mask(&seed_streams[w], seed_mask.data(), words), "nvbio_hip_stream_create_with_cu_mask");
-                aligners[w]->seeding_stream = seed_streams[w];
-                if (mask_compute) hip_check(nvbio_hip_stream_create_with_cu_mask(&streams[w], rest_mask.data(), words), "nvbio_hip_stream_create_with_cu_mask");
-            }
-            if (!streams[w] && (n_workers > 1 || seeding_cus)) hip_check(nvbio_hip_stream_create(&streams[w], 1u), "nvbio_hip_stream_create");
-            if (n_workers > 1 && seeding_token) aligners[w]->seeding_token = &token;
+            if (n_workers > 1) hip_check(nvbio_hip_stream_create(&streams[w], 1u), "nvbio_hip_stream_create");
         }
         std::vector<int> failed(n_workers, 0);
         auto worker = [&](const uint32_t w)
@@ -234,8 +214,7 @@ int nvbio_aligner_best_approx_pipelined(const nvbio_hip_fmindex* fmi, const nvbi
             total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
         out_wall_ms[0] = reps ? total / reps : 0.0;
-        for (uint32_t w = 0; w < n_workers; ++w) { delete aligners[w]; if (streams[w]) nvbio_hip_stream_destroy(streams[w]); if (seed_streams[w]) nvbio_hip_stream_destroy(seed_streams[w]); }
-        nvbio_hip_set_seeding_grid_limit(old_limit);
+        for (uint32_t w = 0; w < n_workers; ++w) { delete aligners[w]; if (streams[w]) nvbio_hip_stream_destroy(streams[w]); }
         for (uint32_t w = 0; w < n_workers; ++w) if (failed[w]) return 1;
         return 0;
     } catch (const std::exception& e) { fprintf(stderr, "aligner_shim: %s\n", e.what()); return 1; }
@@ -370,8 +349,7 @@ int nvbio_aligner_best_approx_paired_pipelined(const nvbio_hip_fmindex* fmi, con
                                                const uint8_t* d_quals, uint64_t n_quals, const char* d_names, const uint32_t* d_names_idx,
                                                uint64_t both_n_words, uint64_t mate_offset, const uint8_t* d_both_quals, uint64_t both_n_quals,
                                                const uint32_t* d_genome_words, uint64_t genome_n_words, uint32_t genome_len, const shim_params* sp, const shim_pe_params* pp,
-                                               uint32_t n_workers, uint32_t seeding_grid_limit, double* out_wall_ms, uint64_t* const* d_records, uint64_t* h_stats /* extensions, rounds */,
-                                               uint32_t seeding_token)
+                                               uint32_t n_workers, double* out_wall_ms, uint64_t* const* d_records, uint64_t* h_stats /* extensions, rounds */)
 {
     try {
         Params params;
@@ -390,9 +368,6 @@ int nvbio_aligner_best_approx_paired_pipelined(const nvbio_hip_fmindex* fmi, con
         const ScoreLimits limits(sp->match, SimpleFunc(SimpleFunc::Type(sp->score_min_type), sp->score_min_k, sp->score_min_m));
         fm_index_device f, rf; f.m = *fmi; rf.m = rfmi ? *rfmi : *fmi;
         if (n_workers == 0) n_workers = 1;
-        std::mutex token;
-        const uint32_t old_limit = nvbio_hip_get_seeding_grid_limit();
-        nvbio_hip_set_seeding_grid_limit(seeding_grid_limit);
         std::vector<Aligner*> aligners(n_workers, nullptr);
         std::vector<void*>    streams(n_workers, nullptr);
         for (uint32_t w = 0; w < n_workers; ++w)
@@ -401,7 +376,6 @@ int nvbio_aligner_best_approx_paired_pipelined(const nvbio_hip_fmindex* fmi, con
             aligners[w]->init(std::max(sp->batch_size, n), sp->batch_size);
             aligners[w]->init_paired();
             if (n_workers > 1) hip_check(nvbio_hip_stream_create(&streams[w], 1u), "nvbio_hip_stream_create");
-            if (n_workers > 1 && seeding_token) aligners[w]->seeding_token = &token;
         }
         std::vector<int> failed(n_workers, 0);
         std::vector<uint64_t> ext(n_workers, 0), rounds(n_workers, 0);
@@ -449,7 +423,6 @@ int nvbio_aligner_best_approx_paired_pipelined(const nvbio_hip_fmindex* fmi, con
         out_wall_ms[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         h_stats[0] = h_stats[1] = 0;
         for (uint32_t w = 0; w < n_workers; ++w) { h_stats[0] += ext[w]; h_stats[1] += rounds[w]; delete aligners[w]; if (streams[w]) nvbio_hip_stream_destroy(streams[w]); }
-        nvbio_hip_set_seeding_grid_limit(old_limit);
         for (uint32_t w = 0; w < n_workers; ++w) if (failed[w]) return 1;
         return 0;
     } catch (const std::exception& e) { fprintf(stderr, "aligner_shim: %s\n", e.what()); return 1; }

@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
-"""Co-scheduling probe: BASELINE config 4's batches through the C++ single-end driver with 1..3 host threads / HIP
-streams per device and a grid limit on the fabric-bound seeding kernels, on the lean (line-native) and the HBM-rich index.
+"""Batch probe: BASELINE config 4's batches through the C++ single-end driver with 1..3 host threads / HIP streams per device, on the lean
+(line-native) and the HBM-rich index flavours.  The command rocprofv3 traces / counter passes of the end-to-end stages are taken under
+(`rocprofv3 --kernel-trace --stats -- python tools/batch_probe.py ...`).  (Round 3's tools/cosched_probe.py, minus the CU-mask / grid-limit /
+seeding-token knobs that were removed from the library.)
 
-    python tools/cosched_probe.py [--genome 3e9] [--reads 10000000] [--batches 6] [--configs 1:0,2:0,2:1024,2:2048,2:4096,3:2048]
+    python tools/batch_probe.py [--genome 3e9] [--reads 10000000] [--batches 6] [--workers 1,2]
 
-Prints one JSON line: per index flavour and (workers, seeding grid limit) the wall time of all batches, M reads/s, and whether every
-batch's bests / MAPQs equal the serial run's."""
+Prints one JSON line: per index flavour and worker count the wall time of all batches, M reads/s, and whether every batch's bests / MAPQs
+equal the serial run's."""
 import argparse
 import ctypes as C
 import json
@@ -27,7 +29,7 @@ def main():
     ap.add_argument("--reads", type=int, default=10_000_000)
     ap.add_argument("--batches", type=int, default=6)
     ap.add_argument("--reps", type=int, default=2)
-    ap.add_argument("--configs", default="1:0:0,2:0:0,2:0:1,2:1024:1,2:2048:1,3:1024:1", help="workers:seeding grid limit:seeding token")
+    ap.add_argument("--workers", default="1,2", help="host threads / streams sharing the device, one run per entry")
     ap.add_argument("--indices", default="line_native,hbm_rich")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -53,7 +55,7 @@ def main():
     arena, nidx = names
     vp = lambda t: C.c_void_p(t.data_ptr())
     ptrs = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
-    out = {"genome_symbols": ng, "reads_per_batch": n, "batches": a.batches, "cu_count": int(nvb.lib().nvbio_hip_device_cu_count())}
+    out = {"genome_symbols": ng, "reads_per_batch": n, "batches": a.batches}
     for flavour in a.indices.split(","):
         idx = fmi.with_dimer()
         if flavour == "hbm_rich":
@@ -69,8 +71,8 @@ def main():
         mapq = [torch.zeros(n, dtype=torch.uint8, device=dev) for _ in range(a.batches)]
         ref = None
         res = {}
-        for cfg in a.configs.split(","):
-            workers, limit, token, scus, stride, mcomp = ([int(x) for x in cfg.split(":")] + [0, 0, 0, 0])[:6]
+        for cfg in a.workers.split(","):
+            workers = int(cfg)
             for t in best:
                 t.zero_()
             ms = (C.c_double * 1)()
@@ -80,7 +82,7 @@ def main():
                 ptrs([b[0].words for b in batches]), C.c_uint64(batches[0][0].words.numel()), ptrs([b[0].begin for b in batches]),
                 ptrs([b[1] for b in batches]), C.c_uint64(batches[0][1].numel()), vp(quals), C.c_uint64(quals.numel()), vp(arena), vp(nidx),
                 vp(genome_words), C.c_uint64(genome_words.numel()), C.c_uint32(ng), C.byref(sp),
-                C.c_uint32(workers), C.c_uint32(limit), C.c_uint32(a.reps), ms, ptrs(best), ptrs(mapq), C.c_uint32(token), C.c_uint32(scus), C.c_uint32(stride or 1), C.c_uint32(mcomp))
+                C.c_uint32(workers), C.c_uint32(a.reps), ms, ptrs(best), ptrs(mapq))
             torch.cuda.synchronize()
             if rc != 0:
                 res[cfg] = {"error": rc}
@@ -88,7 +90,7 @@ def main():
             if ref is None:
                 ref = ([t.clone() for t in best], [t.clone() for t in mapq])
             same = all(torch.equal(x, y) for x, y in zip(best, ref[0])) and all(torch.equal(x, y) for x, y in zip(mapq, ref[1]))
-            res[cfg] = {"workers": workers, "seeding_grid_limit": limit, "seeding_token": bool(token), "seeding_cus": scus, "cu_stride": stride, "compute_on_complement": bool(mcomp), "ms_total": ms[0], "Mreads_per_s": n * a.batches / ms[0] / 1e3, "identical_to_serial": bool(same)}
+            res[cfg] = {"workers": workers, "ms_total": ms[0], "Mreads_per_s": n * a.batches / ms[0] / 1e3, "identical_to_serial": bool(same)}
             sys.stderr.write("%s %s %s\n" % (flavour, cfg, json.dumps(res[cfg])))
         out[flavour] = res
         del idx, best, mapq, ref

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Concurrency inside a rocprofv3 --kernel-trace CSV: from the first dispatch of a marker kernel on, how long 0 / 1 / 2+ kernels were
 resident at once, the summed kernel time against the wall time, and each kernel's mean duration -- to see whether two batches in
-flight (tools/cosched_probe.py) actually overlap the fabric-bound seeding kernels with the VALU-bound extension kernels.
+flight (tools/batch_probe.py) actually overlap the fabric-bound seeding kernels with the VALU-bound extension kernels.
 usage: python tools/overlap_trace.py <kernel_trace.csv> [marker_substring]"""
 import csv
 import sys
