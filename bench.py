@@ -54,6 +54,23 @@ def measured_counter(kernel, key):
         return None
 
 
+def dp_counters(kernel):
+    """The two DP-path counters north_star names -- L2 hit rate and LDS bank conflicts -- from the committed PMC passes of this command
+    (profiles/traffic.json, taken on the round's final code): TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum); SQ_LDS_BANK_CONFLICT (extra cycles)
+    over SQ_LDS_IDX_ACTIVE (all LDS-array cycles).  None if the pass is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            pm = json.load(f).get(kernel, {})
+    except Exception:
+        return None
+    if pm.get("l2_hit") is None or pm.get("lds_idx_active_cycles") is None:
+        return None
+    return {"l2_hit": pm["l2_hit"], "l2_miss": pm["l2_miss"], "l2_hit_rate": pm["l2_hit"] / max(pm["l2_hit"] + pm["l2_miss"], 1),
+            "lds_bank_conflict_cycles": pm["lds_bank_conflict_cycles"], "lds_active_cycles": pm["lds_idx_active_cycles"],
+            "lds_bank_conflict_frac": pm["lds_bank_conflict_cycles"] / max(pm["lds_idx_active_cycles"], 1),
+            "source": pm.get("counters_source")}
+
+
 def physical_cores():
     """Physical cores of the host (distinct (package, core) pairs in /proc/cpuinfo), None if it cannot be read."""
     try:
@@ -308,6 +325,7 @@ def main():
             roofline["executed"] = {"valu_lane_ops_per_cell": iv * 64.0 / iv_reads / CELLS_PER_ALN, "nominal_ops_per_cell": NOMINAL_OPS_PER_CELL,
                                     "achieved": iv / iv_reads * n * 64 / kt / 1e12, "unit": "T lane-op/s",
                                     "frac": iv / iv_reads * n * 64 / kt / 1e12 / VALU_PEAK_TOPS, "source": "SQ_INSTS_VALU, profiles/traffic.json"}
+        roofline["counters"] = dp_counters("banded_gotoh_score_kernel")
         if a32_ms is not None:
             roofline["a32"] = {"kernel": "banded_gotoh_score_kernel<15,LOCAL,A32>", "kernel_ms": a32_ms, "gcups": n * CELLS_PER_ALN / (a32_ms * 1e-3) / 1e9,
                                "reads_per_s": n / (a32_ms * 1e-3), "frac": n * CELLS_PER_ALN * NOMINAL_OPS_PER_CELL / (a32_ms * 1e-3) / 1e12 / VALU_PEAK_TOPS,
@@ -1144,6 +1162,7 @@ def full_dp_leg(a, dev):
             per_cell = pm["insts_valu_per_launch"] * 64.0 / pm["cells_per_launch"]
             roof["executed"] = {"valu_lane_ops_per_cell": per_cell, "achieved": per_cell * cells / (ms * 1e-3) / 1e12,
                                 "frac": per_cell * cells / (ms * 1e-3) / 1e12 / VALU_PEAK_TOPS, "source": "SQ_INSTS_VALU, profiles/traffic.json"}
+        roof["counters"] = dp_counters("full_gotoh_score_kernel<%s>" % name)
         res[name]["roofline"] = roof
     # sw-benchmark's second leg (sw-benchmark.cu:641-657): the same reads, edit distance, SEMI_GLOBAL -- on the bit-vector kernel; "GCUPS" is
     # sw-benchmark's figure (matrix cells / time) although no matrix is filled
