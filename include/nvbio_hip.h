@@ -479,14 +479,18 @@ int nvbio_hip_score_reduce(uint32_t n_active, const uint32_t* read_ids /* nullab
  * hits[read_id * hits_stride] in the array order of its priority_deque (interval heap, nvbio/basic/interval_heap.h;
  * slot 0 = a largest range, top() = slot 1, or slot 0 when alone), hit_counts[read_id] is the deque size.  The
  * probability tree of the randomized selection (SumTree<float*>, nvbio/basic/sum_tree.h) of read r lives at
- * probs[r * probs_stride], probs_stride >= nvbio_hip_sum_tree_node_count(hits_stride).
+ * probs[r * probs_stride] as its LEAVES: leaf i (i < hit_counts[r]) at probs[r * probs_stride + i].  Every other node of a SumTree is
+ * the float sum of its two children, so the kernels rebuild them on chip -- bit for bit the values the reference keeps in memory -- and
+ * a pick that exhausts a hit writes one zero instead of a leaf and four ancestors (the stage is bound by the lines it moves).
+ * probs_stride >= hits_stride (a multiple of 4 lets the kernels use 16-byte accesses); rows wider than 32 hit slots are handled one
+ * lane per read with the sums in the row itself, as scratch: probs_stride >= nvbio_hip_sum_tree_node_count(hits_stride) there.
  * Active reads are packed_read words (defs.h:152-162: read_id:31, top_flag:1); a selected hit is {read_id, loc, seed}
  * with seed a packed_seed word (defs.h:171-181: pos_in_read:12, index_dir:1, rc:1, top_flag:1).
  * Floating point: single precision, every operation rounded separately (the host-compiled arithmetic). */
 uint32_t nvbio_hip_sum_tree_node_count(uint32_t size);
 /* select_init_kernel (select.cu:36-103): trys[r] = max_effort_init (if trys); when randomized, rseeds[r] = hash of the
  * read's name (names NUL-terminated in read_names at read_names_idx[r]; with read_names NULL rseeds is left as the
- * caller set it), probs = 1 / range_size^2 per hit (the first 0 if top_seed) and the tree sums. */
+ * caller set it), probs = the leaves: 1 / range_size^2 per hit (the first 0 if top_seed). */
 int nvbio_hip_select_init(uint32_t n_reads, const char* read_names, const uint32_t* read_names_idx,
                           const uint64_t* hits, uint32_t hits_stride, const uint32_t* hit_counts,
                           float* probs, uint32_t probs_stride, uint32_t* trys /* nullable */, uint32_t* rseeds,

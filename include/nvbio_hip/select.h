@@ -35,15 +35,15 @@ struct SelectParamsPOD
 };
 
 /// The device-side state the selection stage adds to the hit deques: the pipeline's trys / rseeds and the deques'
-/// probability trees (SeedHitDequeArray::m_probs).  Read r's tree is probs[r * probs_stride ..).
+/// probability trees (SeedHitDequeArray::m_probs).  Read r's tree is probs[r * probs_stride ..): its LEAVES only -- the selection kernels
+/// rebuild the sums above them on chip (nvbio_amd/csrc/select.hip), so a 16-slot deque's row is 64 bytes instead of two 128-byte lines.
 struct SelectState
 {
     SelectState(const uint32 n_reads, const uint32 hits_stride) :
-        probs_stride(row_pitch(nvbio_hip_sum_tree_node_count(hits_stride))), probs(size_t(n_reads) * row_pitch(nvbio_hip_sum_tree_node_count(hits_stride))),
+        probs_stride(row_pitch(hits_stride)), probs(size_t(n_reads) * row_pitch(hits_stride)),
         trys(n_reads), rseeds(n_reads) {}
-    /// A tree row starts on a 128-byte line: the 31 nodes of a 16-hit deque then sit in ONE line instead of straddling two (the selection
-    /// stage is bound by the lines it moves, profiles/r03/select_coop.txt); larger trees are padded to whole lines alike.
-    static uint32 row_pitch(const uint32 nodes) { return (nodes + 31u) & ~31u; }
+    /// floats per row: the hit slots rounded to 16-byte pieces (vector loads); rows wider than 32 slots keep room for the sums too, as scratch
+    static uint32 row_pitch(const uint32 hits_stride) { return hits_stride <= 32u ? ((hits_stride + 3u) & ~3u) : ((nvbio_hip_sum_tree_node_count(hits_stride) + 31u) & ~31u); }
     uint32 probs_stride;
     hip::device_vector<float>  probs;
     hip::device_vector<uint32> trys, rseeds;

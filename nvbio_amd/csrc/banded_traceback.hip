@@ -144,7 +144,12 @@ __global__ __launch_bounds__(256) void banded_gotoh_traceback_kernel(const Trace
             }
 #pragma unroll
             for (uint32_t k = 0; k < W; ++k)
-                __builtin_nontemporal_store(row.w[k], p.flags + (uint64_t(i) * W + k) * p.n + slot);
+                // A PLAIN store.  This was a nontemporal store (the flags are written once and read once, much later): with it the C++ suite's
+                // band-7 LOCAL batch came back with a different -- equally scored -- traceback for one job in about one run of six (round 4: 5 of
+                // 28 runs of tests/cxx/nvbio_hip_test -aln; 0 of 24 with this store; the Python suite on torch-allocated scratch never showed it).
+                // The walk below re-reads these words from the same lane; an `nt` store is not ordered against that later load the way a normal
+                // store is on this path.  Bit-exactness is the contract, the stream hint was worth < 2 % of this kernel.
+                p.flags[(uint64_t(i) * W + k) * p.n + slot] = row.w[k];
         }
         if (TYPE == NVBIO_HIP_GLOBAL)
             report(H[BAND - 1], M + BAND - 1, M);

@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(256) full_gotoh_traceback_kernel(const FullTbP
             p.column[uint64_t(i) * n + slot] = (uint32_t(H_band[BL]) & 0xFFFFu) | (uint32_t(E) << 16);     // make_vector<short> (:565)
             #pragma unroll
             for (uint32_t w8 = 0; w8 < BL / 8u; ++w8)
-                __builtin_nontemporal_store(word[w8], p.flags + (uint64_t(blk * (BL / 8u) + w8) * p.max_text_len + i) * n + slot);
+                p.flags[(uint64_t(blk * (BL / 8u) + w8) * p.max_text_len + i) * n + slot] = word[w8];      // plain store: see banded_traceback.hip
             if (TYPE == NVBIO_HIP_SEMI_GLOBAL && last)
             {
                 // save_boundary -> save_Mth: H[i][M] (utils_inl.h:206-226,279-299)

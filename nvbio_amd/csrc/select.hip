@@ -27,12 +27,25 @@ namespace nvb {
 __device__ __forceinline__ uint32_t ilog2(uint32_t n) { return 31u - uint32_t(__clz(int(n | 1u))); }       // nvbio::log2 (floor; log2(0) = 0)
 __device__ __forceinline__ uint32_t st_padded(const uint32_t size) { const uint32_t l = ilog2(size); return (1u << l) < size ? 1u << (l + 1u) : 1u << l; }
 
-struct SumTree
+// Where a tree's nodes live.  HBM holds only the LEAVES of a read's tree (leaf i at probs[r * probs_stride + i], i < the read's hit count):
+// every internal node of a SumTree is the float sum of its two children, left + right (setup() builds it so, set() keeps it so), i.e. a
+// function of the leaves -- so a selection call loads the leaves, rebuilds the sums on chip (the same pairwise adds, the same values bit for
+// bit) and writes back the one leaf a pick zeroes.  The reference keeps all 2 * padded - 1 nodes in memory (SeedHitDequeArray::m_probs)
+// and rewrites a zeroed leaf's ancestors; at 10 M reads that is the second 128-byte line of every read on every call and four more writes
+// per exhausted hit (profiles/r03/select_coop.txt: the stage is bound by exactly those lines).
+//   RowCells   nodes in a row of global memory (wide rows: hits_stride > 32; the row needs room for all the nodes, internal ones are scratch)
+//   LdsCells   nodes in LDS, lane-interleaved (node i of this lane at s_tree[i * 256 + lane]: conflict-free)
+struct RowCells { float* p; __device__ __forceinline__ float& operator[](const uint32_t i) const { return p[i]; } };
+struct LdsCells { float* p; __device__ __forceinline__ float& operator[](const uint32_t i) const { return p[i * 256u]; } };
+
+template <typename Cells>
+struct SumTreeT
 {
-    float*   c;
+    Cells    c;
     uint32_t size, padded;
-    __device__ __forceinline__ SumTree(float* cells, const uint32_t n) : c(cells), size(n), padded(st_padded(n)) {}
+    __device__ __forceinline__ SumTreeT(const Cells cells, const uint32_t n) : c(cells), size(n), padded(st_padded(n)) {}
     __device__ __forceinline__ float sum() const { return c[padded * 2u - 2u]; }
+    /// the sums above leaves that are already in place (cells [0, size)): padding leaves zeroed, then level by level
     __device__ void setup() const
     {
         for (uint32_t i = size; i < padded; ++i) c[i] = 0.0f;
@@ -112,8 +125,7 @@ select_init_kernel(uint32_t n_reads, const char* __restrict__ names, const uint3
     float* pr = probs + uint64_t(r) * probs_stride;
     const uint2* h = hits + uint64_t(r) * hits_stride;
     for (uint32_t i = 0; i < n; ++i) { const float d = __uint2float_rn(hit_delta(h[i])); pr[i] = __fdiv_rn(1.0f, __fmul_rn(d, d)); }
-    if (top_seed) pr[0] = 0.0f;
-    SumTree(pr, n).setup();
+    if (top_seed) pr[0] = 0.0f;              // the leaves are the tree (see RowCells / LdsCells above)
 }
 
 // A read's hit row and probability tree held by a group of G lanes, four hits / leaves per lane (G = 4: rows of <= 16 hits, G = 8: <= 32).
@@ -148,9 +160,8 @@ struct TreeQuad
     }
 };
 
-// The probability trees of select_init, four leaves per lane: leaf = 1 / delta^2, then the levels (SumTree::setup's adds).  A read's hit row
-// is read and its tree row written in contiguous pieces -- where one lane per read walks 16 scattered 8-byte loads and 31 scattered 4-byte
-// stores.  Same tree, bit for bit.
+// The leaves of select_init, four per lane: leaf = 1 / delta^2 (0 for the first hit under top_seed).  A read's hit row is read and its leaves
+// written in contiguous pieces -- where one lane per read walks 16 scattered 8-byte loads and 16 scattered 4-byte stores.
 template <int G>
 __global__ void __launch_bounds__(256)
 select_init_tree_kernel(uint32_t n_reads, const uint2* __restrict__ hits, uint32_t hits_stride, const uint32_t* __restrict__ counts,
@@ -158,39 +169,27 @@ select_init_tree_kernel(uint32_t n_reads, const uint2* __restrict__ hits, uint32
 {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     const uint32_t slot = t / G, j = t % G;
-    if (slot >= n_reads) return;                    // (whole groups leave together: 256 % G == 0)
+    if (slot >= n_reads) return;
     const uint32_t r = queue ? queue[slot] : slot;
     const uint32_t n = counts[r];
-    if (n == 0u) return;
-    const uint32_t padded = st_padded(n);
+    if (4u * j >= n) return;
     float* pr = probs + uint64_t(r) * probs_stride;
     const uint2* hrow = hits + uint64_t(r) * hits_stride;
-    TreeQuad<G> tq;
+    float v[4];
     #pragma unroll
     for (uint32_t q = 0; q < 4u; ++q)
     {
         const uint32_t i = 4u * j + q;
-        float v = 0.0f;
-        if (i < n) { const float dl = __uint2float_rn(hit_delta(hrow[i])); v = __fdiv_rn(1.0f, __fmul_rn(dl, dl)); }
-        if (top_seed && i == 0u) v = 0.0f;
-        tq.lf[q] = v;
-        if (i < padded) pr[i] = v;
+        v[q] = 0.0f;
+        if (i < n) { const float dl = __uint2float_rn(hit_delta(hrow[i])); v[q] = __fdiv_rn(1.0f, __fmul_rn(dl, dl)); }
+        if (top_seed && i == 0u) v[q] = 0.0f;
     }
-    tq.rebuild();
-    uint32_t base = padded;                                                          // level 1: padded / 2 nodes
-    if (2u * j      < (padded >> 1)) pr[base + 2u * j]      = tq.a;
-    if (2u * j + 1u < (padded >> 1)) pr[base + 2u * j + 1u] = tq.b;
-    base += padded >> 1;
-    if (j < (padded >> 2)) pr[base + j] = tq.c;
-    base += padded >> 2;
-    if ((j & 1u) == 0u && (j >> 1) < (padded >> 3)) pr[base + (j >> 1)] = tq.d;
-    base += padded >> 3;
-    if ((j & 3u) == 0u && (j >> 2) < (padded >> 4)) pr[base + (j >> 2)] = tq.e;
-    base += padded >> 4;
-    if (G > 4 && (j & 7u) == 0u && (j >> 3) < (padded >> 5)) pr[base + (j >> 3)] = tq.f;
+    if ((probs_stride & 3u) == 0u && 4u * j + 4u <= probs_stride) *reinterpret_cast<float4*>(pr + 4u * j) = make_float4(v[0], v[1], v[2], v[3]);
+    else { for (uint32_t q = 0; q < 4u; ++q) if (4u * j + q < n) pr[4u * j + q] = v[q]; }
 }
 
-__device__ uint32_t randomized_select(const SumTree& tree, const uint2* h, uint32_t* rseed)
+template <typename Tree>
+__device__ uint32_t randomized_select(const Tree& tree, const uint2* h, uint32_t* rseed)
 {
     uint32_t s = *rseed;
     uint32_t pick = 0u;
@@ -205,14 +204,16 @@ __device__ uint32_t randomized_select(const SumTree& tree, const uint2* h, uint3
     return pick;
 }
 
-// stage 1: every active read makes its picks into its own staging slots
-template <bool RANDOMIZED>
+// stage 1: every active read makes its picks into its own staging slots.
+// PADDED (randomized only): 0 = the tree's nodes in the read's row of global memory (wide rows), 16 / 32 = in LDS, rebuilt from the leaves
+template <bool RANDOMIZED, int PADDED>
 __global__ void __launch_bounds__(256)
 select_kernel(uint32_t n_multi, const uint32_t* __restrict__ active_in, uint32_t n_active,
               uint2* __restrict__ hits, uint32_t hits_stride, uint32_t* __restrict__ counts,
               float* __restrict__ probs, uint32_t probs_stride, uint32_t* __restrict__ rseeds, const uint32_t* __restrict__ trys,
               uint32_t* __restrict__ stage_read, uint32_t* __restrict__ stage_loc, uint32_t* __restrict__ stage_seed, uint64_t* __restrict__ key)
 {
+    __shared__ float s_tree[(RANDOMIZED && PADDED > 0) ? (2 * PADDED - 1) * 256 : 1];
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t > n_active) return;
     if (t == n_active) { key[t] = 0ull; return; }
@@ -225,7 +226,7 @@ select_kernel(uint32_t n_multi, const uint32_t* __restrict__ active_in, uint32_t
         uint2* h = hits + uint64_t(read_id) * hits_stride;
         uint32_t* out_loc = stage_loc + uint64_t(t) * n_multi;
         uint32_t* out_seed = stage_seed + uint64_t(t) * n_multi;
-        if (!RANDOMIZED)
+        if constexpr (!RANDOMIZED)
         {
             const HitDeque deque = { h };
             for (uint32_t i = 0; i < n_multi; ++i)
@@ -245,17 +246,43 @@ select_kernel(uint32_t n_multi, const uint32_t* __restrict__ active_in, uint32_t
         }
         else
         {
-            const SumTree tree(probs + uint64_t(read_id) * probs_stride, n);
-            for (uint32_t i = 0; i < n_multi; ++i)
+            float* leaves = probs + uint64_t(read_id) * probs_stride;
+            auto picks = [&](const auto& tree)
             {
-                if (tree.sum() <= 0.0f) break;                                  // (erase() here is undone by the reference's destructor)
-                if (top_flag && hit_delta(h[0]) == 0u) top_flag = 0u;
-                const uint32_t id = top_flag ? 0u : randomized_select(tree, h, &rseeds[read_id]);
-                if (hit_delta(h[id]) == 0u) { if (n_multi > 1u) continue; else break; }
-                out_loc[n_sel] = hit_pop_front(&h[id]);
-                if (hit_delta(h[id]) == 0u) tree.set(id, 0.0f);
-                out_seed[n_sel] = packed_seed_of(h[id], top_flag);
-                ++n_sel;
+                for (uint32_t i = 0; i < n_multi; ++i)
+                {
+                    if (tree.sum() <= 0.0f) break;                              // (erase() here is undone by the reference's destructor)
+                    if (top_flag && hit_delta(h[0]) == 0u) top_flag = 0u;
+                    const uint32_t id = top_flag ? 0u : randomized_select(tree, h, &rseeds[read_id]);
+                    if (hit_delta(h[id]) == 0u) { if (n_multi > 1u) continue; else break; }
+                    out_loc[n_sel] = hit_pop_front(&h[id]);
+                    if (hit_delta(h[id]) == 0u) { tree.set(id, 0.0f); leaves[id] = 0.0f; }     // on chip: the leaf and its ancestors; in memory: the leaf
+                    out_seed[n_sel] = packed_seed_of(h[id], top_flag);
+                    ++n_sel;
+                }
+            };
+            if constexpr (PADDED > 0)
+            {
+                const LdsCells cells = { s_tree + threadIdx.x };
+                const SumTreeT<LdsCells> tree(cells, n);
+                const uint32_t n4 = (n + 3u) & ~3u;
+                if ((probs_stride & 3u) == 0u && n4 <= probs_stride)
+                    for (uint32_t i = 0; i < n4; i += 4u)
+                    {
+                        const float4 v = *reinterpret_cast<const float4*>(leaves + i);
+                        cells[i] = v.x; cells[i + 1u] = i + 1u < n ? v.y : 0.0f; cells[i + 2u] = i + 2u < n ? v.z : 0.0f; cells[i + 3u] = i + 3u < n ? v.w : 0.0f;
+                    }
+                else
+                    for (uint32_t i = 0; i < n; ++i) cells[i] = leaves[i];
+                tree.setup();
+                picks(tree);
+            }
+            else
+            {
+                const RowCells cells = { leaves };
+                const SumTreeT<RowCells> tree(cells, n);
+                tree.setup();                                                    // the row's internal nodes are scratch: rebuilt on entry
+                picks(tree);
             }
         }
     }
@@ -302,7 +329,7 @@ select_rand_quad_kernel(uint32_t n_multi, const uint32_t* __restrict__ active_in
             const uint32_t i = 4u * j + q;
             const uint2 h = (i < n) ? hrow[i] : make_uint2(0u, 0u);
             hx[q] = h.x; hy[q] = h.y;
-            tq.lf[q] = (i < padded) ? pr[i] : 0.0f;
+            tq.lf[q] = (i < n) ? pr[i] : 0.0f;
         }
         // delta of hit i (the same i in every lane of the group)
         auto delta_of = [&](const uint32_t i) -> uint32_t {
@@ -367,15 +394,7 @@ select_rand_quad_kernel(uint32_t n_multi, const uint32_t* __restrict__ active_in
                     pr[id] = 0.0f;
                 }
             }
-            if (dsel == 1u)
-            {
-                tq.rebuild();
-                if (j == (id >> 2))                                                    // ... then its ancestors, level by level
-                {
-                    uint32_t base = padded;
-                    for (uint32_t k = 1u; k <= lg; ++k) { pr[base + (id >> k)] = tq.own(k, id & 3u); base += padded >> k; }
-                }
-            }
+            if (dsel == 1u) tq.rebuild();                                              // ... its ancestors exist in registers only
             ++n_sel;
         }
         if (j == 0u && s != s_in) rseeds[read_id] = s;
@@ -538,6 +557,9 @@ NVB_API uint32_t nvbio_hip_sum_tree_node_count(uint32_t size)
     return padded * 2u - 1u;
 }
 
+// floats a read's row of `probs` needs: its leaves (one per hit slot); wide rows (> 32 slots) also hold the rebuilt sums, as scratch
+static uint32_t min_probs_stride(const uint32_t hits_stride) { return hits_stride <= 32u ? hits_stride : nvbio_hip_sum_tree_node_count(hits_stride); }
+
 static int select_init_impl(uint32_t n_reads, const uint32_t* queue, const char* read_names, const uint32_t* read_names_idx,
                             const uint64_t* hits, uint32_t hits_stride, const uint32_t* hit_counts,
                             float* probs, uint32_t probs_stride, uint32_t* trys, uint32_t* rseeds,
@@ -546,7 +568,7 @@ static int select_init_impl(uint32_t n_reads, const uint32_t* queue, const char*
     if (n_reads == 0) return hipSuccess;
     if (randomized) {
         if (!hits || !hit_counts || !probs || !rseeds || hits_stride == 0) return hipErrorInvalidValue;
-        if (probs_stride < nvbio_hip_sum_tree_node_count(hits_stride)) return hipErrorInvalidValue;
+        if (probs_stride < min_probs_stride(hits_stride)) return hipErrorInvalidValue;
         if (read_names && !read_names_idx) return hipErrorInvalidValue;
     }
     g_last_kernel = "select_init_kernel";
@@ -601,7 +623,7 @@ NVB_API int nvbio_hip_select(int32_t randomized, uint32_t n_multi, const uint32_
     if (n_multi == 0 || n_multi > 4096u) return hipErrorInvalidValue;          // the reference encodes the per-read hit index in 12 bits
     if (n_active != 0 && (!active_in || !hits || !hit_counts || !trys || !active_out || !hit_read_id || !hit_loc || !hit_seed || hits_stride == 0))
         return hipErrorInvalidValue;
-    if (randomized && n_active != 0 && (!probs || !rseeds || probs_stride < nvbio_hip_sum_tree_node_count(hits_stride))) return hipErrorInvalidValue;
+    if (randomized && n_active != 0 && (!probs || !rseeds || probs_stride < min_probs_stride(hits_stride))) return hipErrorInvalidValue;
     if (!temp || temp_bytes < nvbio_hip_select_temp_bytes(n_active, n_multi)) return hipErrorInvalidValue;
     const uint64_t n = n_active;
     uint8_t* p = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(temp) + 255u) & ~uintptr_t(255));
@@ -624,11 +646,17 @@ NVB_API int nvbio_hip_select(int32_t randomized, uint32_t n_multi, const uint32_
     else if (quad)
         hipLaunchKernelGGL(select_rand_quad_kernel<8>, grid_for((uint64_t(n) + 1u) * 8u), dim3(256), 0, s, n_multi, active_in, n_active, reinterpret_cast<uint2*>(hits), hits_stride,
                            hit_counts, probs, probs_stride, rseeds, trys, stage_read, stage_loc, stage_seed, key);
+    else if (randomized && hits_stride <= 16u)
+        hipLaunchKernelGGL((select_kernel<true, 16>), grid_for(n + 1u), dim3(256), 0, s, n_multi, active_in, n_active, reinterpret_cast<uint2*>(hits), hits_stride,
+                           hit_counts, probs, probs_stride, rseeds, trys, stage_read, stage_loc, stage_seed, key);
+    else if (randomized && hits_stride <= 32u)
+        hipLaunchKernelGGL((select_kernel<true, 32>), grid_for(n + 1u), dim3(256), 0, s, n_multi, active_in, n_active, reinterpret_cast<uint2*>(hits), hits_stride,
+                           hit_counts, probs, probs_stride, rseeds, trys, stage_read, stage_loc, stage_seed, key);
     else if (randomized)
-        hipLaunchKernelGGL(select_kernel<true>, grid_for(n + 1u), dim3(256), 0, s, n_multi, active_in, n_active, reinterpret_cast<uint2*>(hits), hits_stride,
+        hipLaunchKernelGGL((select_kernel<true, 0>), grid_for(n + 1u), dim3(256), 0, s, n_multi, active_in, n_active, reinterpret_cast<uint2*>(hits), hits_stride,
                            hit_counts, probs, probs_stride, rseeds, trys, stage_read, stage_loc, stage_seed, key);
     else
-        hipLaunchKernelGGL(select_kernel<false>, grid_for(n + 1u), dim3(256), 0, s, n_multi, active_in, n_active, reinterpret_cast<uint2*>(hits), hits_stride,
+        hipLaunchKernelGGL((select_kernel<false, 0>), grid_for(n + 1u), dim3(256), 0, s, n_multi, active_in, n_active, reinterpret_cast<uint2*>(hits), hits_stride,
                            hit_counts, probs, probs_stride, rseeds, trys, stage_read, stage_loc, stage_seed, key);
     if (hipError_t e = hipcub::DeviceScan::ExclusiveSum(p, scan_bytes, key, off, int(n_active) + 1, s)) return e;
     hipLaunchKernelGGL(select_compact_kernel, grid_for(n + 1u), dim3(256), 0, s, n_multi, n_active, key, off, stage_read, stage_loc, stage_seed,

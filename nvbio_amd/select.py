@@ -38,7 +38,8 @@ class SelectState:
         dev = hits.device
         self.hits, self.counts = hits, counts
         self.randomized = bool(randomized)
-        self.probs_stride = sum_tree_node_count(stride)
+        # a read's row holds the LEAVES of its probability tree (the sums are rebuilt on chip); rows wider than 32 hit slots also hold the sums
+        self.probs_stride = ((stride + 3) & ~3) if stride <= 32 else sum_tree_node_count(stride)
         self.probs = torch.zeros((n, self.probs_stride), dtype=torch.float32, device=dev) if randomized else None
         self.trys = torch.zeros(n, dtype=torch.int32, device=dev)
         self.rseeds = (rseeds.clone() if rseeds is not None else torch.zeros(n, dtype=torch.int32, device=dev))
