@@ -852,7 +852,7 @@ typedef struct nvbio_hip_comm_transport {
 void nvbio_hip_comm_set_transport(const nvbio_hip_comm_transport* transport);
 
 /* Test switches.  A few environment variables select alternative executions of the same results, for the parity suite to cover both
- * (NVBIO_HIP_FORCE_32BIT, NVBIO_HIP_NO_STAGING, NVBIO_HIP_FULL_GENERIC, NVBIO_HIP_FULL_SINGLE_JOB, NVBIO_HIP_ED_SWEEP,
+ * (NVBIO_HIP_FORCE_32BIT, NVBIO_HIP_NO_STAGING, NVBIO_HIP_FULL_GENERIC, NVBIO_HIP_FULL_SINGLE_JOB, NVBIO_HIP_FULL_ROWS, NVBIO_HIP_ED_SWEEP,
  * NVBIO_HIP_SELECT_LANES, NVBIO_HIP_TRACEBACK_LANES).  They are read with getenv at every call so that one process can flip them between
  * calls; getenv is not safe against a concurrent setenv, so change them only while no other thread is inside a library call.  Production
  * code leaves them unset.

@@ -700,7 +700,7 @@ full_gotoh_score_kernel(const FullParams p)
 // on the single-job sweep, segment by segment, so every result is the one full_gotoh_score_kernel produces.
 // ---------------------------------------------------------------------------------------------
 template <int TYPE, int R>
-__global__ void __launch_bounds__(256, 3)       // >= 3 waves per SIMD: left alone the SEMI_GLOBAL instance takes 176 VGPRs (2 waves); 168 + 14 spilled: +8 %
+__global__ void __launch_bounds__(256, (R <= 6 ? 3 : 2))       // R <= 6: >= 3 waves per SIMD (left alone the SEMI_GLOBAL instance takes 176 VGPRs = 2 waves; 168 + 14 spilled: +8 %); deeper lanes hold more rows and get 256 VGPRs
 full_gotoh_score_multi_kernel(const FullParams p, const uint32_t n_seg, const uint32_t seg_w)
 {
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
@@ -1032,18 +1032,29 @@ static int full_score_core(
         auto eff = [](const double lanes, const double rows, const double overhead) { return lanes / 64.0 * (28.0 * rows) / (28.0 * rows + overhead); };
         double best = eff(double((maxM + R - 1) / R), double(R), 24.0);
         uint32_t best_seg = 1u, best_r = 0u;
+        // (rows per lane: 5 / 6 with two or three jobs per wave; 8 / 10 with four -- 150-bp mates: 4 x 15 lanes x 10 rows -- which halves the
+        // per-step work that does not depend on the rows: the hand-off between lanes, the step's bookkeeping, the ramp in and out of a matrix)
+        const char* rows_env = getenv("NVBIO_HIP_FULL_ROWS");                    // test switch: 5, 6, 8, 10 = only that depth
+        const uint32_t only_r = rows_env ? uint32_t(atoi(rows_env)) : 0u;
+        const uint32_t depths[4] = { 5u, 6u, 8u, 10u };
         for (uint32_t ns = 2u; ns <= 4u; ++ns)
-            for (uint32_t r = 5u; r <= 6u; ++r)
+            for (uint32_t di = 0; di < 4u; ++di)
             {
+                const uint32_t r = depths[di];
+                if (only_r && r != only_r) continue;
                 const uint32_t usable = 64u / ns;
                 if (uint64_t(usable) * r < maxM) continue;
-                const double e = eff(double(ns * ((maxM + r - 1u) / r)), double(r), 24.0);
+                double e = eff(double(ns * ((maxM + r - 1u) / r)), double(r), 24.0);
+                // measured at 150 x 16 384 (profiles/r04/full_dp_rows.txt): ten rows per lane beat five by 7 % (SEMI_GLOBAL) and 12 % (GLOBAL) as the
+                // model says, but LOCAL's deeper lanes take 176 VGPRs (two waves per SIMD) and its per-row maxima fold more often: 0.97 of R = 5
+                if (type == NVBIO_HIP_LOCAL && r >= 8u) e *= 0.90;
                 if (e > best * 1.05) { best = e; best_seg = ns; best_r = r; }
             }
         if (best_seg > 1u && !(nomulti && nomulti[0] == '1') && uint64_t(maxN) * 64u * 8u < (1ull << 32))
         {
             g_last_kernel = "full_gotoh_score_multi_kernel<16-bit>";
-            return best_r == 5u ? launch_full_multi<5>(p, type, best_seg, s) : launch_full_multi<6>(p, type, best_seg, s);
+            switch (best_r) { case 5u: return launch_full_multi<5>(p, type, best_seg, s); case 6u: return launch_full_multi<6>(p, type, best_seg, s);
+                              case 8u: return launch_full_multi<8>(p, type, best_seg, s); default: return launch_full_multi<10>(p, type, best_seg, s); }
         }
     }
     if (fast) {

@@ -223,8 +223,15 @@ def test_several_jobs_per_wave(cuda, ty, max_m, max_n, monkeypatch):
                     es, ek, eo = O.batch_score_pattern_blocking(0, ty, scheme, hp, ht, min_score=min_score)
                 ms = torch.from_numpy(min_score).to(cuda) if min_score is not None else None
                 kernels = []
-                for single in ("0", "1"):
-                    monkeypatch.setenv("NVBIO_HIP_FULL_SINGLE_JOB", single)
+                # "0": the depth the host picks; "r8" / "r10": four jobs per wave at 8 / 10 rows per lane where the pattern fits; "1": one job per wave
+                for single in ("0", "r8", "r10", "1"):
+                    monkeypatch.setenv("NVBIO_HIP_FULL_SINGLE_JOB", "1" if single == "1" else "0")
+                    if single.startswith("r"):
+                        if max_m > 16 * int(single[1:]):
+                            continue
+                        monkeypatch.setenv("NVBIO_HIP_FULL_ROWS", single[1:])
+                    else:
+                        monkeypatch.delenv("NVBIO_HIP_FULL_ROWS", raising=False)
                     al = nvb.make_gotoh_aligner(ty, nvb.SimpleGotohScheme(*scheme), algo)
                     gs, gk, go = nvb.batch_alignment_score(al, p, t, max_m, max_n, ms)
                     torch.cuda.synchronize()
@@ -234,5 +241,6 @@ def test_several_jobs_per_wave(cuda, ty, max_m, max_n, monkeypatch):
                     bad = np.nonzero(((es != gs) | (ek != gk).any(1) | (eo != go)) & sel)[0]
                     assert bad.size == 0, "type %d scheme %s algo %d single=%s n=%d: %d mismatches; first %d: M=%d N=%d cpu (%d,%s,%d) gpu (%d,%s,%d)" % (
                         ty, scheme, algo, single, n, bad.size, bad[0], len(pats[bad[0]]), len(txts[bad[0]]), es[bad[0]], ek[bad[0]], eo[bad[0]], gs[bad[0]], gk[bad[0]], go[bad[0]])
-                assert "multi" in kernels[0] and "multi" not in kernels[1], kernels
+                assert "multi" in kernels[0] and "multi" not in kernels[-1], kernels
     monkeypatch.delenv("NVBIO_HIP_FULL_SINGLE_JOB", raising=False)
+    monkeypatch.delenv("NVBIO_HIP_FULL_ROWS", raising=False)
