@@ -744,7 +744,9 @@ int nvbio_hip_sort_hits(uint32_t n, const uint32_t* hit_read_id, const uint32_t*
 /* BowtieMapq2 / BowtieMapq3 (nvBowtie/bowtie2/cuda/mapq.h:42-330) for single-end reads:
  * out_mapq[r] from the best / second-best alignment of read r; perfect_score(len) = len * match,
  * min_score(len) = min_score_by_len[len] (the scheme's SimpleFunc tabulated by the host, scoring.h:272-281),
- * monotone = scheme.m_monotone (match bonus == 0).  Unaligned reads get 0.  version: 2 or 3. */
+ * monotone = scheme.m_monotone (match bonus == 0).  Every read is evaluated, aligned or not, as the reference's MapqFunctorSE / PE
+ * do: an unaligned read (Alignment::invalid(), score 2^17 - 1) gets the calculator's top no-second value and the reference's writers
+ * zero it (output_sam.cpp:462).  version: 2 or 3. */
 int nvbio_hip_mapq(int32_t version, int32_t match, int32_t monotone, const int32_t* min_score_by_len /* device */,
                    uint32_t n_reads, const uint64_t* best_alignments, uint32_t best_stride,
                    const uint32_t* read_len /* nullable */, uint32_t fixed_read_len, uint8_t* out_mapq, void* stream);

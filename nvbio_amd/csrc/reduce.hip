@@ -543,7 +543,6 @@ mapq_kernel(int32_t version, int32_t match, int32_t monotone, uint32_t n_reads, 
     if (r >= n_reads) return;
     const uint2 b1 = best[r], b2 = best[r + best_stride];
     const IoAln a1 = { b1.x, b1.y }, a2 = { b2.x, b2.y };
-    if (a1.align == 0xFFFFFFFFu) { out[r] = 0; return; }
     const uint32_t len = read_len ? read_len[r] : fixed_len;
     const float max_score = float(int32_t(len) * match), min_score = float(min_score_by_len[len]);
     const bool has_second = a2.align != 0xFFFFFFFFu;
@@ -560,7 +559,6 @@ mapq_paired_kernel(int32_t version, int32_t match, int32_t monotone, uint32_t n_
     if (r >= n_reads) return;
     auto ld = [](const uint2* q, uint32_t i) { const uint2 v = q[i]; IoAln a = { v.x, v.y }; return a; };
     const IoBestPairs b = { ld(best, r), ld(best, r + best_stride), ld(best_o, r), ld(best_o, r + best_stride) };
-    if (b.a1.align == 0xFFFFFFFFu) { out[r] = 0; return; }
     const bool paired = io_aln_paired(b.a1);
     const bool has_second = paired ? io_aln_paired(b.a2) : (b.a2.align != 0xFFFFFFFFu);
     const uint32_t len = read_len ? read_len[r] : fixed_len, olen = o_read_len ? o_read_len[r] : o_fixed_len;

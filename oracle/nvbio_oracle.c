@@ -2389,7 +2389,10 @@ static uint32_t mapq_v2(int32_t best_score, int has_second, int32_t second_score
     if (best_diff > 0) return (best_over >= diff * 0.5f) ? 11 : 2;
     return (best_over >= diff * 0.5f) ? 1 : 0;
 }
-/* single-end reads: out[r] = mapq(BestPairedAlignments(best of read r), read_len[r]); unaligned reads get 0.
+/* single-end reads: out[r] = mapq(BestPairedAlignments(best of read r), read_len[r]) for EVERY read, aligned or not, as
+ * MapqFunctorSE does (aligner_best_approx.h:62-76): an unaligned read carries Alignment::invalid() (score 2^17 - 1), for which the
+ * calculator returns its top no-second value; the reference's writers zero it later (output_sam.cpp:462, output_bam.cpp:317).
+ * Pinned against the reference's compiled mapq.h / functors (oracle/_ref/libref_mapq.so, tests/test_ref_mapq.py).
  * scheme: match bonus, min-score SimpleFunc (type,k,m), monotone flag (scoring.h:272-281,347) */
 ORACLE_API void oracle_mapq(int version, int32_t match, int min_type, float min_k, float min_m, int monotone,
     uint32_t n_reads, const uint64_t* best, uint32_t best_stride, const uint32_t* read_len, uint8_t* out)
@@ -2397,7 +2400,6 @@ ORACLE_API void oracle_mapq(int version, int32_t match, int min_type, float min_
     for (uint32_t r = 0; r < n_reads; ++r)
     {
         const io_aln_t a1 = { (uint32_t)best[r], (uint32_t)(best[r] >> 32) }, a2 = { (uint32_t)best[r + best_stride], (uint32_t)(best[r + best_stride] >> 32) };
-        if (!io_aln_aligned(a1)) { out[r] = 0; continue; }
         const float max_score = (float)((int32_t)read_len[r] * match), min_score = (float)simple_func(min_type, min_k, min_m, (int32_t)read_len[r]);
         out[r] = (uint8_t)(version == 3 ? mapq_v3(io_aln_score(a1), io_aln_aligned(a2), io_aln_score(a2), max_score, min_score, 0)
                                         : mapq_v2(io_aln_score(a1), io_aln_aligned(a2), io_aln_score(a2), max_score, min_score, monotone));
@@ -2591,7 +2593,6 @@ ORACLE_API void oracle_mapq_paired(int version, int32_t match, int min_type, flo
     {
         const io_best_pairs_t b = { { (uint32_t)best[r], (uint32_t)(best[r] >> 32) }, { (uint32_t)best[r + best_stride], (uint32_t)(best[r + best_stride] >> 32) },
                                     { (uint32_t)best_o[r], (uint32_t)(best_o[r] >> 32) }, { (uint32_t)best_o[r + best_stride], (uint32_t)(best_o[r + best_stride] >> 32) } };
-        if (!io_aln_aligned(b.a1)) { out[r] = 0; continue; }
         const int paired = bp_is_paired(&b);
         const int has_second = paired ? bp_has_second_paired(&b) : io_aln_aligned(b.a2);
         if (version == 3) {
