@@ -37,9 +37,7 @@
 #include <string>
 #include <vector>
 #include <type_traits>
-#if defined(_OPENMP)
-#include <omp.h>
-#endif
+#include "../basic/omp.h"
 #if defined(__HIPCC__) && !defined(NVBIO_HIP_COMPAT_NO_TUNED)
 #include "../../../../nvbio_hip.h"
 #define NVBIO_HIP_COMPAT_TUNED 1
@@ -184,9 +182,9 @@ template <> struct byte_pointer< cuda::ldg_pointer<uint8> > { static const bool 
 /// streams hand out (alignment_utils.h:170-218).  The banded quality-scheme kernels take (stored range, reverse / complement flags)
 /// per job and turn each 16-symbol group round as they fetch it (nvbio_hip_banded_gotoh_score_qual_views): nothing is staged.
 template <typename P> struct pattern_source { static const bool direct = packed_view<P>::ok; static const bool stageable = packed_view<P>::ok; static const bool viewable = false; };
-template <typename St, typename Q> struct pattern_source< io::ReadStream<St, Q> >
+template <typename St, typename Q> struct pattern_source< ReadStream<St, Q> >
 {
-    static const bool direct = false; static const bool stageable = (io::ReadStream<St, Q>::SYMBOL_SIZE <= 4u);
+    static const bool direct = false; static const bool stageable = (ReadStream<St, Q>::SYMBOL_SIZE <= 4u);
     static const bool viewable = nvbio::priv::packed_stream_where<St>::ok && byte_pointer<Q>::ok;
     typedef nvbio::priv::packed_stream_where<St> where_type; typedef byte_pointer<Q> qual_pointer;
 };

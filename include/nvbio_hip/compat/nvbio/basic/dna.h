@@ -10,6 +10,9 @@ template <Alphabet A> struct AlphabetTraits {};
 template <> struct AlphabetTraits<DNA>   { static const uint32 SYMBOL_SIZE = 2; static const uint32 SYMBOL_COUNT = 4; };
 template <> struct AlphabetTraits<DNA_N> { static const uint32 SYMBOL_SIZE = 4; static const uint32 SYMBOL_COUNT = 5; };
 
+/// symbol width of an alphabet, at run time (strings/alphabet.h: bits_per_symbol)
+NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 bits_per_symbol(const Alphabet a) { return a == DNA ? 2u : (a == DNA_N || a == DNA_IUPAC || a == RNA_N) ? 4u : a == RNA ? 2u : 8u; }
+
 NVBIO_FORCEINLINE NVBIO_HOST_DEVICE char  dna_to_char(const uint8 c) { return c == 0 ? 'A' : c == 1 ? 'C' : c == 2 ? 'G' : c == 3 ? 'T' : 'N'; }
 NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint8 char_to_dna(const char c)  { return c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u; }
 template <typename SymbolIterator>

@@ -1,0 +1,114 @@
+// compat/nvbio/fasta/fasta.h -- FASTA_inc_reader / FASTA_reader (nvbio/fasta/fasta.h:40-150, fasta_inl.h): the incremental FASTA
+// parsers callers such as sw-benchmark.cu:530-555 use to stream a reference into their own packers.  Plain or gzip input (zlib is
+// what the reference reads through as well: link with -lz).
+#pragma once
+#include "../basic/types.h"
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include <zlib.h>
+
+namespace nvbio {
+
+namespace priv {
+/// a buffered byte source over a (possibly gzip-compressed) file; 255 marks the end, as in the reference's readers
+struct byte_source
+{
+    byte_source(const char* name, const uint32 buffer_size) : m_file(gzopen(name, "r")), m_buffer(buffer_size ? buffer_size : 1u), m_fill(0), m_pos(0)
+    { if (m_file) gzbuffer(m_file, buffer_size ? buffer_size : 8192u); }
+    ~byte_source() { if (m_file) gzclose(m_file); }
+    byte_source(const byte_source&) = delete;
+    byte_source& operator=(const byte_source&) = delete;
+    bool  valid() const { return m_file != NULL; }
+    uint8 get()
+    {
+        if (m_pos >= m_fill) { const int got = gzread(m_file, m_buffer.data(), unsigned(m_buffer.size())); m_fill = got > 0 ? uint32(got) : 0u; m_pos = 0; }
+        return m_pos < m_fill ? m_buffer[m_pos++] : uint8(255u);
+    }
+    void  unget() { if (m_pos) --m_pos; }
+    void  rewind() { if (m_file) gzrewind(m_file); m_fill = m_pos = 0; }
+    gzFile             m_file;
+    std::vector<uint8> m_buffer;
+    uint32             m_fill, m_pos;
+};
+} // namespace priv
+
+/// character-at-a-time FASTA parser.  Writer: begin_read(), end_read(), id(c) per name character (then '\0'), read(c) per base.
+struct FASTA_inc_reader
+{
+    FASTA_inc_reader(const char* filename, const uint32 buffer_size = 64536u) : m_src(filename, buffer_size) {}
+    bool  valid() const { return m_src.valid(); }
+    uint8 get() { return m_src.get(); }
+
+    /// parse up to n_reads records; returns the number of records started.  As in the reference (fasta_inl.h:88-126), the call
+    /// returns as soon as the header of a SECOND record is met -- `while (fasta.read(1024, w) == 1024);` therefore streams the first
+    /// record of a file and stops, which is how sw-benchmark.cu reads its reference -- and only un-reads that '>' when n_reads
+    /// records were reached.
+    template <typename Writer>
+    uint32 read(const uint32 n_reads, Writer& writer)
+    {
+        uint32 n = 0;
+        bool in_record = false;
+        writer.begin_read();
+        for (uint8 c = get(); c != 255u; c = get())
+        {
+            if (c == '>')
+            {
+                if (in_record)
+                {
+                    writer.end_read();
+                    writer.begin_read();
+                    if (n == n_reads) m_src.unget();
+                    return n;
+                }
+                ++n;
+                for (c = get(); c != ' ' && c != '\n' && c != 255u; c = get()) writer.id(c);
+                writer.id('\0');
+                while (c != '\n' && c != 255u) c = get();
+                in_record = true;
+            }
+            if (in_record && c != '\n' && c != ' ' && c != '\r') writer.read(c);
+        }
+        writer.end_read();
+        return n;
+    }
+private:
+    priv::byte_source m_src;
+};
+
+/// record-at-a-time FASTA parser.  Writer: push_back(const char* id, uint32 read_len, const uint8* bases).
+struct FASTA_reader
+{
+    FASTA_reader(const char* filename, const uint32 buffer_size = 64536u) : m_src(filename, buffer_size) {}
+    bool  valid() const { return m_src.valid(); }
+    uint8 get() { return m_src.get(); }
+    void  rewind() { m_src.rewind(); }
+
+    template <typename Writer>
+    uint32 read(const uint32 n_reads, Writer& writer)
+    {
+        uint32 n = 0;
+        while (n < n_reads)
+        {
+            uint8 c = get();
+            while (c != '>' && c != 255u) c = get();        // find the next header
+            if (c == 255u) break;
+            m_id.clear(); m_read.clear();
+            for (c = get(); c != ' ' && c != '\n' && c != 255u; c = get()) m_id.push_back(char(c));
+            m_id.push_back('\0');
+            while (c != '\n' && c != 255u) c = get();
+            for (c = get(); c != '>' && c != 255u; c = get())
+                if (c != '\n' && c != ' ' && c != '\r') m_read.push_back(c);
+            if (c == '>') m_src.unget();
+            writer.push_back(m_id.data(), uint32(m_read.size()), m_read.data());
+            ++n;
+        }
+        return n;
+    }
+private:
+    priv::byte_source  m_src;
+    std::vector<char>  m_id;
+    std::vector<uint8> m_read;
+};
+
+} // namespace nvbio

@@ -1,2 +1,476 @@
+// compat/nvbio/io/sequence/sequence.h -- the read / reference containers either side of the hot path (nvbio/io/sequence/sequence.h,
+// sequence_access.h, sequence_encoder.h): SequenceDataInfo, the storage-less views, SequenceDataHost / Device,
+// SequenceDataAccess<ALPHABET>, the batch encoder, and FASTQ / FASTA input streams behind open_sequence_file() -- what
+// sw-benchmark.cu:513-575 and nvBowtie.cpp:573-600 drive.  Layout as the reference's: symbols packed big-endian at the alphabet's width
+// into one uint32 stream with NO padding between sequences, `sequence_index` = n + 1 symbol offsets, one phred byte per symbol, names as
+// NUL-terminated strings with their own n + 1 byte offsets.  The device flavour needs hipcc (rocThrust vectors); everything else is host C++.
 #pragma once
 #include "sequence_traits.h"
+#include "../../basic/packedstream.h"
+#include "../../basic/vector_view.h"
+#include "../../basic/vector.h"
+#include "../../strings/string_set.h"
+#include "../../fasta/fasta.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace nvbio {
+namespace io {
+
+enum QualityEncoding  { Phred = 0, Phred33 = 1, Phred64 = 2, Solexa = 3 };
+enum SequenceEncoding { FORWARD = 0x0001, REVERSE = 0x0002, FORWARD_COMPLEMENT = 0x0004, REVERSE_COMPLEMENT = 0x0008 };
+enum SequenceFlags    { SEQUENCE_DATA = 0x0001, SEQUENCE_QUALS = 0x0002, SEQUENCE_NAMES = 0x0004 };
+
+/// the counts every flavour of sequence data carries (sequence.h:201-242)
+struct SequenceDataInfo
+{
+    NVBIO_HOST_DEVICE SequenceDataInfo() : m_alphabet(PROTEIN), m_n_seqs(0), m_name_stream_len(0), m_sequence_stream_len(0), m_sequence_stream_words(0),
+        m_has_qualities(0), m_min_sequence_len(uint32(-1)), m_max_sequence_len(0), m_avg_sequence_len(0) {}
+
+    NVBIO_HOST_DEVICE Alphabet alphabet()         const { return m_alphabet; }
+    NVBIO_HOST_DEVICE uint32   size()             const { return m_n_seqs; }
+    NVBIO_HOST_DEVICE uint32   bps()              const { return m_sequence_stream_len; }
+    NVBIO_HOST_DEVICE uint32   words()            const { return m_sequence_stream_words; }
+    NVBIO_HOST_DEVICE uint32   qs()               const { return m_has_qualities ? m_sequence_stream_len : 0u; }
+    NVBIO_HOST_DEVICE uint32   name_stream_len()  const { return m_name_stream_len; }
+    NVBIO_HOST_DEVICE bool     has_qualities()    const { return m_has_qualities != 0; }
+    NVBIO_HOST_DEVICE uint32   max_sequence_len() const { return m_max_sequence_len; }
+    NVBIO_HOST_DEVICE uint32   min_sequence_len() const { return m_min_sequence_len; }
+    NVBIO_HOST_DEVICE uint32   avg_sequence_len() const { return m_avg_sequence_len; }
+
+    Alphabet m_alphabet;
+    uint32   m_n_seqs, m_name_stream_len, m_sequence_stream_len, m_sequence_stream_words, m_has_qualities;
+    uint32   m_min_sequence_len, m_max_sequence_len, m_avg_sequence_len;
+};
+NVBIO_HOST_DEVICE inline bool operator==(const SequenceDataInfo& a, const SequenceDataInfo& b)
+{
+    return a.m_alphabet == b.m_alphabet && a.m_n_seqs == b.m_n_seqs && a.m_name_stream_len == b.m_name_stream_len && a.m_sequence_stream_len == b.m_sequence_stream_len &&
+           a.m_sequence_stream_words == b.m_sequence_stream_words && a.m_has_qualities == b.m_has_qualities && a.m_min_sequence_len == b.m_min_sequence_len &&
+           a.m_max_sequence_len == b.m_max_sequence_len && a.m_avg_sequence_len == b.m_avg_sequence_len;
+}
+NVBIO_HOST_DEVICE inline bool operator!=(const SequenceDataInfo& a, const SequenceDataInfo& b) { return !(a == b); }
+
+namespace priv {
+template <typename It> struct const_iterator_of             { typedef It type; };
+template <typename T>  struct const_iterator_of<T*>         { typedef const T* type; };
+} // namespace priv
+
+/// a storage-less view: the counts plus five iterators (sequence.h:296-400)
+template <typename IndexIterator = uint32*, typename SequenceStorageIterator = uint32*, typename QualStorageIterator = char*, typename NameStorageIterator = char*>
+struct SequenceDataViewCore : public SequenceDataInfo
+{
+    typedef IndexIterator            index_iterator;
+    typedef SequenceStorageIterator  sequence_storage_iterator;
+    typedef QualStorageIterator      qual_storage_iterator;
+    typedef NameStorageIterator      name_storage_iterator;
+    typedef typename priv::const_iterator_of<IndexIterator>::type            const_index_iterator;
+    typedef typename priv::const_iterator_of<SequenceStorageIterator>::type  const_sequence_storage_iterator;
+    typedef typename priv::const_iterator_of<QualStorageIterator>::type      const_qual_storage_iterator;
+    typedef typename priv::const_iterator_of<NameStorageIterator>::type      const_name_storage_iterator;
+
+    NVBIO_HOST_DEVICE SequenceDataViewCore() : m_name_stream(), m_name_index(), m_sequence_stream(), m_sequence_index(), m_qual_stream() {}
+    NVBIO_HOST_DEVICE SequenceDataViewCore(const SequenceDataInfo& info, const SequenceStorageIterator sequence_stream, const IndexIterator sequence_index,
+                                           const QualStorageIterator qual_stream, const NameStorageIterator name_stream, const IndexIterator name_index)
+        : SequenceDataInfo(info), m_name_stream(name_stream), m_name_index(name_index), m_sequence_stream(sequence_stream), m_sequence_index(sequence_index), m_qual_stream(qual_stream) {}
+    template <typename I, typename S, typename Q, typename N>
+    NVBIO_HOST_DEVICE SequenceDataViewCore(const SequenceDataViewCore<I, S, Q, N>& in)
+        : SequenceDataInfo(in), m_name_stream(NameStorageIterator(in.m_name_stream)), m_name_index(IndexIterator(in.m_name_index)),
+          m_sequence_stream(SequenceStorageIterator(in.m_sequence_stream)), m_sequence_index(IndexIterator(in.m_sequence_index)), m_qual_stream(QualStorageIterator(in.m_qual_stream)) {}
+
+    NVBIO_HOST_DEVICE index_iterator                  name_index()             { return m_name_index; }
+    NVBIO_HOST_DEVICE index_iterator                  sequence_index()         { return m_sequence_index; }
+    NVBIO_HOST_DEVICE name_storage_iterator           name_stream()            { return m_name_stream; }
+    NVBIO_HOST_DEVICE sequence_storage_iterator       sequence_storage()       { return m_sequence_stream; }
+    NVBIO_HOST_DEVICE qual_storage_iterator           qual_stream()            { return m_qual_stream; }
+    NVBIO_HOST_DEVICE const_index_iterator            name_index()       const { return m_name_index; }
+    NVBIO_HOST_DEVICE const_index_iterator            sequence_index()   const { return m_sequence_index; }
+    NVBIO_HOST_DEVICE const_name_storage_iterator     name_stream()      const { return m_name_stream; }
+    NVBIO_HOST_DEVICE const_sequence_storage_iterator sequence_storage() const { return m_sequence_stream; }
+    NVBIO_HOST_DEVICE const_qual_storage_iterator     qual_stream()      const { return m_qual_stream; }
+    NVBIO_HOST_DEVICE uint2 get_range(const uint32 i) const { return make_uint2(sequence_index()[i], sequence_index()[i + 1]); }
+
+    name_storage_iterator     m_name_stream;
+    index_iterator            m_name_index;
+    sequence_storage_iterator m_sequence_stream;
+    index_iterator            m_sequence_index;
+    qual_storage_iterator     m_qual_stream;
+};
+typedef SequenceDataViewCore<uint32*, uint32*, char*, char*>                         SequenceDataView;
+typedef SequenceDataViewCore<const uint32*, const uint32*, const char*, const char*> ConstSequenceDataView;
+
+/// the polymorphic base of the containers
+struct SequenceData : public SequenceDataInfo { virtual ~SequenceData() {} };
+
+namespace priv {
+#if defined(__HIPCC__)
+template <typename In, typename Out> inline void seq_copy(In in, const uint32 n, Out out) { thrust::copy(in, in + n, out); }
+template <typename system_tag, typename T> struct seq_vector { typedef nvbio::vector<system_tag, T> type; };
+template <typename V> inline typename V::value_type*       seq_ptr(V& v)       { return nvbio::raw_pointer(static_cast<typename V::base_type&>(v)); }
+template <typename V> inline const typename V::value_type* seq_ptr(const V& v) { return nvbio::raw_pointer(static_cast<const typename V::base_type&>(v)); }
+#else
+template <typename In, typename Out> inline void seq_copy(In in, const uint32 n, Out out) { std::copy(in, in + n, out); }
+template <typename system_tag, typename T> struct seq_vector {};                               // the device flavour needs hipcc
+template <typename T> struct seq_vector<host_tag, T> { typedef std::vector<T> type; };
+template <typename T> inline T*       seq_ptr(std::vector<T>& v)       { return v.empty() ? (T*)0 : v.data(); }
+template <typename T> inline const T* seq_ptr(const std::vector<T>& v) { return v.empty() ? (const T*)0 : v.data(); }
+#endif
+} // namespace priv
+
+/// sequence data owning its storage in host or device memory (sequence.h:436-560)
+template <typename system_tag>
+struct SequenceDataStorage : public SequenceData
+{
+    typedef SequenceDataView       plain_view_type;
+    typedef ConstSequenceDataView  const_plain_view_type;
+    typedef typename priv::seq_vector<system_tag, uint32>::type  word_vector;
+    typedef typename priv::seq_vector<system_tag, char>::type    char_vector;
+    typedef typename word_vector::iterator        index_iterator;
+    typedef typename word_vector::iterator        sequence_storage_iterator;
+    typedef typename char_vector::iterator        qual_storage_iterator;
+    typedef typename char_vector::iterator        name_storage_iterator;
+    typedef typename word_vector::const_iterator  const_index_iterator;
+    typedef typename word_vector::const_iterator  const_sequence_storage_iterator;
+    typedef typename char_vector::const_iterator  const_qual_storage_iterator;
+    typedef typename char_vector::const_iterator  const_name_storage_iterator;
+
+    SequenceDataStorage() {}
+    template <typename other_tag> SequenceDataStorage(const SequenceDataStorage<other_tag>& other) { *this = other; }
+    SequenceDataStorage(const SequenceDataStorage& other) : SequenceData() { *this = other; }
+    template <typename I, typename S, typename Q, typename N> SequenceDataStorage(const SequenceDataViewCore<I, S, Q, N>& other) { *this = other; }
+
+    SequenceDataStorage& operator=(const SequenceDataStorage& other) { return this->template assign_storage<system_tag>(other); }
+    template <typename other_tag> SequenceDataStorage& operator=(const SequenceDataStorage<other_tag>& other) { return this->template assign_storage<other_tag>(other); }
+
+    /// copy out of a view over HOST memory (raw pointers are host pointers to thrust, as in the reference's thrust::copy calls, sequence.h:510-520)
+    template <typename I, typename S, typename Q, typename N>
+    SequenceDataStorage& operator=(const SequenceDataViewCore<I, S, Q, N>& other)
+    {
+        this->SequenceDataInfo::operator=(other);
+        m_sequence_vec.resize(m_sequence_stream_words); m_sequence_index_vec.resize(m_n_seqs + 1u);
+        m_name_vec.resize(m_name_stream_len);           m_name_index_vec.resize(m_n_seqs + 1u);
+        m_qual_vec.resize(m_has_qualities ? m_sequence_stream_len : 0u);
+        priv::seq_copy(other.sequence_storage(), m_sequence_stream_words, m_sequence_vec.begin());
+        priv::seq_copy(other.sequence_index(),   m_n_seqs + 1u,           m_sequence_index_vec.begin());
+        priv::seq_copy(other.name_stream(),      m_name_stream_len,       m_name_vec.begin());
+        priv::seq_copy(other.name_index(),       m_n_seqs + 1u,           m_name_index_vec.begin());
+        if (m_has_qualities) priv::seq_copy(other.qual_stream(), m_sequence_stream_len, m_qual_vec.begin());
+        return *this;
+    }
+
+    operator plain_view_type()
+    { return plain_view_type(*this, priv::seq_ptr(m_sequence_vec), priv::seq_ptr(m_sequence_index_vec), priv::seq_ptr(m_qual_vec), priv::seq_ptr(m_name_vec), priv::seq_ptr(m_name_index_vec)); }
+    operator const_plain_view_type() const
+    { return const_plain_view_type(*this, priv::seq_ptr(m_sequence_vec), priv::seq_ptr(m_sequence_index_vec), priv::seq_ptr(m_qual_vec), priv::seq_ptr(m_name_vec), priv::seq_ptr(m_name_index_vec)); }
+
+    /// room for n_seqs sequences of n_bps symbols in total
+    void reserve(const uint32 n_seqs, const uint32 n_bps)
+    {
+        const uint32 per_word = 32u / bits_per_symbol(m_alphabet);
+        m_sequence_index_vec.reserve(n_seqs + 1u); m_sequence_vec.reserve((n_bps + per_word - 1u) / per_word);
+        m_qual_vec.reserve(n_bps); m_name_index_vec.reserve(n_seqs + 1u);
+    }
+
+    index_iterator                  name_index()             { return m_name_index_vec.begin(); }
+    index_iterator                  sequence_index()         { return m_sequence_index_vec.begin(); }
+    name_storage_iterator           name_stream()            { return m_name_vec.begin(); }
+    sequence_storage_iterator       sequence_storage()       { return m_sequence_vec.begin(); }
+    qual_storage_iterator           qual_stream()            { return m_qual_vec.begin(); }
+    const_index_iterator            name_index()       const { return m_name_index_vec.begin(); }
+    const_index_iterator            sequence_index()   const { return m_sequence_index_vec.begin(); }
+    const_name_storage_iterator     name_stream()      const { return m_name_vec.begin(); }
+    const_sequence_storage_iterator sequence_storage() const { return m_sequence_vec.begin(); }
+    const_qual_storage_iterator     qual_stream()      const { return m_qual_vec.begin(); }
+
+    word_vector m_sequence_vec;
+    word_vector m_sequence_index_vec;
+    char_vector m_qual_vec;
+    char_vector m_name_vec;
+    word_vector m_name_index_vec;
+
+private:
+    template <typename other_tag>
+    SequenceDataStorage& assign_storage(const SequenceDataStorage<other_tag>& other)
+    {
+        this->SequenceDataInfo::operator=(other);
+        m_sequence_vec = other.m_sequence_vec; m_sequence_index_vec = other.m_sequence_index_vec;
+        m_qual_vec = other.m_qual_vec; m_name_vec = other.m_name_vec; m_name_index_vec = other.m_name_index_vec;
+        return *this;
+    }
+};
+typedef SequenceDataStorage<host_tag>   SequenceDataHost;
+typedef SequenceDataStorage<device_tag> SequenceDataDevice;
+
+} // namespace io
+
+template <typename system_tag> inline io::SequenceDataView      plain_view(io::SequenceDataStorage<system_tag>& data)       { return io::SequenceDataView(data); }
+template <typename system_tag> inline io::ConstSequenceDataView plain_view(const io::SequenceDataStorage<system_tag>& data) { return io::ConstSequenceDataView(data); }
+inline io::SequenceDataView      plain_view(io::SequenceDataView& view)            { return view; }
+inline io::ConstSequenceDataView plain_view(const io::ConstSequenceDataView& view) { return view; }
+
+namespace io {
+
+/// alphabet-aware accessors over any view or container (sequence_access.h:52-180)
+template <Alphabet SEQUENCE_ALPHABET_T, typename SequenceDataT = ConstSequenceDataView>
+struct SequenceDataAccess
+{
+    static const Alphabet SEQUENCE_ALPHABET         = SEQUENCE_ALPHABET_T;
+    static const uint32   SEQUENCE_BITS             = SequenceDataTraits<SEQUENCE_ALPHABET_T>::SEQUENCE_BITS;
+    static const bool     SEQUENCE_BIG_ENDIAN       = SequenceDataTraits<SEQUENCE_ALPHABET_T>::SEQUENCE_BIG_ENDIAN;
+    static const uint32   SEQUENCE_SYMBOLS_PER_WORD = SequenceDataTraits<SEQUENCE_ALPHABET_T>::SEQUENCE_SYMBOLS_PER_WORD;
+
+    typedef typename SequenceDataT::const_index_iterator             index_iterator;
+    typedef typename SequenceDataT::const_sequence_storage_iterator  sequence_storage_iterator;
+    typedef typename SequenceDataT::const_qual_storage_iterator      qual_storage_iterator;
+    typedef typename SequenceDataT::const_name_storage_iterator      name_storage_iterator;
+    typedef SequenceDataViewCore<index_iterator, sequence_storage_iterator, qual_storage_iterator, name_storage_iterator>  sequence_reference;
+
+    typedef PackedStream<sequence_storage_iterator, uint8, SEQUENCE_BITS, SEQUENCE_BIG_ENDIAN>  sequence_stream_type;
+    typedef vector_view<sequence_stream_type>   sequence_string;
+    typedef vector_view<qual_storage_iterator>  qual_string;
+    typedef vector_view<name_storage_iterator>  name_string;
+    typedef ConcatenatedStringSet<sequence_stream_type, index_iterator>   sequence_string_set_type;
+    typedef ConcatenatedStringSet<qual_storage_iterator, index_iterator>  qual_string_set_type;
+    typedef ConcatenatedStringSet<name_storage_iterator, index_iterator>  name_string_set_type;
+
+    template <typename AnyData>
+    NVBIO_HOST_DEVICE SequenceDataAccess(const AnyData& data)
+        : m_data(data, data.sequence_storage(), data.sequence_index(), data.qual_stream(), data.name_stream(), data.name_index()) {}
+
+    NVBIO_HOST_DEVICE uint32 size()             const { return m_data.size(); }
+    NVBIO_HOST_DEVICE uint32 bps()              const { return m_data.bps(); }
+    NVBIO_HOST_DEVICE uint32 words()            const { return m_data.words(); }
+    NVBIO_HOST_DEVICE uint32 name_stream_len()  const { return m_data.name_stream_len(); }
+    NVBIO_HOST_DEVICE uint32 max_sequence_len() const { return m_data.max_sequence_len(); }
+    NVBIO_HOST_DEVICE uint32 min_sequence_len() const { return m_data.min_sequence_len(); }
+    NVBIO_HOST_DEVICE uint32 avg_sequence_len() const { return m_data.avg_sequence_len(); }
+
+    NVBIO_HOST_DEVICE index_iterator            name_index()       const { return m_data.name_index(); }
+    NVBIO_HOST_DEVICE index_iterator            sequence_index()   const { return m_data.sequence_index(); }
+    NVBIO_HOST_DEVICE name_storage_iterator     name_stream()      const { return m_data.name_stream(); }
+    NVBIO_HOST_DEVICE sequence_storage_iterator sequence_storage() const { return m_data.sequence_storage(); }
+    NVBIO_HOST_DEVICE qual_storage_iterator     qual_stream()      const { return m_data.qual_stream(); }
+
+    NVBIO_HOST_DEVICE uint2 get_range(const uint32 i) const { return make_uint2(sequence_index()[i], sequence_index()[i + 1]); }
+    NVBIO_HOST_DEVICE sequence_stream_type sequence_stream() const { return sequence_stream_type(sequence_storage()); }
+    NVBIO_HOST_DEVICE sequence_string_set_type sequence_string_set() const { return sequence_string_set_type(size(), sequence_stream(), sequence_index()); }
+    NVBIO_HOST_DEVICE qual_string_set_type     qual_string_set()     const { return qual_string_set_type(size(), qual_stream(), sequence_index()); }
+    NVBIO_HOST_DEVICE name_string_set_type     name_string_set()     const { return name_string_set_type(size(), name_stream(), name_index()); }
+    NVBIO_HOST_DEVICE sequence_string get_read(const uint32 i) const { const uint2 r = get_range(i); return sequence_string(r.y - r.x, sequence_stream() + r.x); }
+    NVBIO_HOST_DEVICE qual_string     get_quals(const uint32 i) const { const uint2 r = get_range(i); return qual_string(r.y - r.x, qual_stream() + r.x); }
+    NVBIO_HOST_DEVICE name_string     get_name(const uint32 i) const { return name_string(name_index()[i + 1] - name_index()[i] - 1u, name_stream() + name_index()[i]); }
+
+    const sequence_reference m_data;
+};
+template <Alphabet ALPHABET, typename SequenceDataT>
+inline SequenceDataAccess<ALPHABET, SequenceDataT> make_access(const SequenceDataT& data) { return SequenceDataAccess<ALPHABET, SequenceDataT>(data); }
+
+namespace priv {
+/// ASCII base -> {A, C, G, T, N} = {0..4}; '-' -> 5 (sequence_encoder.cpp:38-60)
+inline uint8 nt4_code(const uint8 c)
+{
+    switch (c) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; case '-': return 5; default: return 4; }
+}
+/// file quality byte -> phred (sequence_encoder.cpp:64-118)
+inline uint8 phred_quality(const QualityEncoding e, const uint8 q)
+{
+    if (e == Phred33) return uint8(q - 33u);
+    if (e == Phred64) return uint8(q - 64u);
+    if (e == Solexa)  { static const uint8 low[20] = { 0, 1, 1, 1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 7, 8, 9, 10 }; return q < 20u ? low[q] : uint8(q - 10u); }
+    return q;
+}
+} // namespace priv
+
+/// appends encoded sequences to a SequenceDataHost (sequence_encoder.h:47-140, sequence_encoder.cpp:265-420)
+struct SequenceDataEncoder
+{
+    enum StrandOp { NO_OP = 0x0000, REVERSE_OP = 0x0001, COMPLEMENT_OP = 0x0002, REVERSE_COMPLEMENT_OP = 0x0003 };
+
+    SequenceDataEncoder(const Alphabet alphabet, SequenceDataHost* data, const bool append = false) : m_alphabet(alphabet), m_data(data), m_append(append) {}
+    virtual ~SequenceDataEncoder() {}
+
+    virtual void reserve(const uint32 n_seqs, const uint32 n_bps) { m_data->reserve(n_seqs, n_bps); }
+
+    /// start a batch: empty the container unless appending
+    virtual void begin_batch()
+    {
+        if (m_append && m_data->m_sequence_index_vec.size() > 0) return;
+        static_cast<SequenceDataInfo&>(*m_data) = SequenceDataInfo();
+        m_data->m_alphabet = m_alphabet; m_data->m_has_qualities = 1u;
+        m_data->m_sequence_vec.clear(); m_data->m_qual_vec.clear(); m_data->m_name_vec.clear();
+        m_data->m_sequence_index_vec.assign(1, 0u); m_data->m_name_index_vec.assign(1, 0u);
+    }
+
+    /// append one sequence: trimmed by trim5 / trim3, truncated to max_sequence_len, optionally reversed and / or complemented
+    virtual void push_back(const uint32 in_len, const char* name, const uint8* base_pairs, const uint8* quality, const QualityEncoding quality_encoding,
+                           const uint32 max_sequence_len, const uint32 trim3, const uint32 trim5, const StrandOp op)
+    {
+        const uint32 trimmed = in_len > trim3 + trim5 ? in_len - trim3 - trim5 : 0u;
+        const uint32 len = std::min(trimmed, max_sequence_len);
+        base_pairs += trim5; if (quality) quality += trim5;
+        const uint32 bits = bits_per_symbol(m_alphabet), per_word = 32u / bits, begin = m_data->m_sequence_stream_len, end = begin + len;
+        m_data->m_sequence_vec.resize((end + per_word - 1u) / per_word, 0u);
+        m_data->m_qual_vec.resize(end);
+        uint32* words = priv::seq_ptr(m_data->m_sequence_vec);
+        for (uint32 i = 0; i < len; ++i)
+        {
+            const uint32 src = (op & REVERSE_OP) ? len - 1u - i : i;
+            uint32 s;
+            if (m_alphabet == DNA || m_alphabet == DNA_N)
+            {
+                s = priv::nt4_code(base_pairs[src]);
+                if (op & COMPLEMENT_OP) s = s < 4u ? 3u - s : 4u;
+            }
+            else s = base_pairs[src];
+            const uint32 pos = begin + i, shift = 32u - bits - (pos % per_word) * bits;          // big-endian inside the word
+            words[pos / per_word] = (words[pos / per_word] & ~(((1u << bits) - 1u) << shift)) | ((s & ((1u << bits) - 1u)) << shift);
+            m_data->m_qual_vec[pos] = quality ? char(priv::phred_quality(quality_encoding, quality[src])) : char(0);
+        }
+        m_data->m_n_seqs++;
+        m_data->m_sequence_stream_len = end;
+        m_data->m_sequence_stream_words = (end + per_word - 1u) / per_word;
+        m_data->m_sequence_index_vec.push_back(end);
+        m_data->m_min_sequence_len = std::min(m_data->m_min_sequence_len, len);
+        m_data->m_max_sequence_len = std::max(m_data->m_max_sequence_len, len);
+        const size_t name_len = strlen(name);
+        m_data->m_name_vec.insert(m_data->m_name_vec.end(), name, name + name_len + 1u);
+        m_data->m_name_stream_len = uint32(m_data->m_name_vec.size());
+        m_data->m_name_index_vec.push_back(m_data->m_name_stream_len);
+    }
+
+    virtual void end_batch()
+    { m_data->m_avg_sequence_len = m_data->m_n_seqs ? uint32(ceilf(float(m_data->m_sequence_stream_len) / float(m_data->m_n_seqs))) : 0u; }
+
+    const SequenceDataInfo* info() const { return m_data; }
+    Alphabet alphabet() const { return m_alphabet; }
+
+private:
+    Alphabet          m_alphabet;
+    SequenceDataHost* m_data;
+    bool              m_append;
+};
+inline SequenceDataEncoder* create_encoder(const Alphabet alphabet, SequenceDataHost* data) { return new SequenceDataEncoder(alphabet, data); }
+
+/// a source of sequence batches
+struct SequenceDataInputStream
+{
+    virtual ~SequenceDataInputStream() {}
+    /// load up to batch_size sequences / batch_bps symbols through the encoder; returns the number loaded
+    virtual int  next(SequenceDataEncoder* encoder, const uint32 batch_size, const uint32 batch_bps = uint32(-1)) = 0;
+    virtual bool is_ok() = 0;
+    virtual bool rewind() { return false; }
+};
+typedef SequenceDataInputStream SequenceDataStream;
+
+/// the next batch of a stream into `data`, encoded over `alphabet` (sequence_encoder.cpp:455-500)
+inline int next(const Alphabet alphabet, SequenceDataHost* data, SequenceDataInputStream* stream, const uint32 batch_size, const uint32 batch_bps = uint32(-1))
+{
+    SequenceDataEncoder encoder(alphabet, data);
+    return stream->next(&encoder, batch_size, batch_bps);
+}
+
+namespace priv {
+/// FASTQ ('@') and FASTA ('>') text, plain or gzip, record after record (sequence_fastq.cpp:60-300, sequence_fasta.cpp)
+struct TextSequenceFile : public SequenceDataInputStream
+{
+    TextSequenceFile(const char* name, const QualityEncoding qualities, const uint32 max_seqs, const uint32 max_sequence_len, const SequenceEncoding flags,
+                     const uint32 trim3, const uint32 trim5)
+        : m_src(name, 1u << 16), m_qualities(qualities), m_max_seqs(max_seqs), m_max_len(max_sequence_len), m_flags(flags), m_trim3(trim3), m_trim5(trim5), m_loaded(0), m_ok(m_src.valid()), m_eof(false) {}
+
+    bool is_ok() { return m_ok; }
+    bool rewind() { m_src.rewind(); m_loaded = 0; m_eof = false; return true; }
+
+    int next(SequenceDataEncoder* encoder, const uint32 batch_size, const uint32 batch_bps = uint32(-1))
+    {
+        const uint32 want = std::min(m_max_seqs - m_loaded, batch_size);
+        if (!m_ok || want == 0u) return 0;
+        encoder->begin_batch();
+        { const uint32 n = std::min(want, 1u << 20); encoder->reserve(n, batch_bps == uint32(-1) ? n * 100u : std::min(batch_bps, 1u << 28)); }
+        const SequenceDataInfo* info = encoder->info();
+        while (info->size() < want && info->bps() < batch_bps && !m_eof)
+            if (!read_record(encoder)) break;
+        m_loaded += info->size();
+        encoder->end_batch();
+        return int(info->size());
+    }
+
+private:
+    // one record -> one sequence per strand requested, in the order FORWARD, REVERSE, FORWARD_COMPLEMENT, REVERSE_COMPLEMENT
+    bool read_record(SequenceDataEncoder* encoder)
+    {
+        uint8 c = m_src.get();
+        while (c != 255u && c <= 31u) c = m_src.get();                              // blank lines between records
+        if (c == 255u) { m_eof = true; return false; }
+        if (c != '@' && c != '>') { m_ok = false; fprintf(stderr, "sequence file: parsing error (record starts with '%c')\n", c); return false; }
+        const bool fastq = (c == '@');
+        m_name.clear(); m_bp.clear(); m_q.clear();
+        for (c = m_src.get(); c != '\n' && c != 255u; c = m_src.get()) if (c != '\r') m_name.push_back(char(c));
+        m_name.push_back('\0');
+        if (fastq)
+        {
+            for (c = m_src.get(); c != '+' && c != 255u; c = m_src.get()) if (c >= 0x21 && c <= 0x7E) m_bp.push_back(c);
+            if (c == 255u) { m_ok = false; fprintf(stderr, "FASTQ loader: incomplete read \"%s\"\n", m_name.data()); return false; }
+            for (c = m_src.get(); c != '\n' && c != 255u; c = m_src.get()) {}
+            while (m_q.size() < m_bp.size()) { c = m_src.get(); if (c == 255u) break; if (c >= 0x21 && c <= 0x7E) m_q.push_back(c); }
+            if (m_q.size() < m_bp.size()) { m_ok = false; fprintf(stderr, "FASTQ loader: incomplete read \"%s\"\n", m_name.data()); return false; }
+        }
+        else
+        {
+            for (c = m_src.get(); c != '>' && c != 255u; c = m_src.get()) if (c >= 0x21 && c <= 0x7E) m_bp.push_back(c);
+            if (c == '>') m_src.unget();
+            m_q.assign(m_bp.size(), uint8(50u));       // FASTA carries no qualities: the byte 50 goes through the quality encoding (sequence_fasta.cpp:60-61)
+        }
+        if (m_bp.empty()) return true;                                                    // (an empty record contributes nothing)
+        const uint32 len = uint32(m_bp.size());
+        if (m_flags & FORWARD)            encoder->push_back(len, m_name.data(), m_bp.data(), m_q.data(), m_qualities, m_max_len, m_trim3, m_trim5, SequenceDataEncoder::NO_OP);
+        if (m_flags & REVERSE)            encoder->push_back(len, m_name.data(), m_bp.data(), m_q.data(), m_qualities, m_max_len, m_trim3, m_trim5, SequenceDataEncoder::REVERSE_OP);
+        if (m_flags & FORWARD_COMPLEMENT) encoder->push_back(len, m_name.data(), m_bp.data(), m_q.data(), m_qualities, m_max_len, m_trim3, m_trim5, SequenceDataEncoder::COMPLEMENT_OP);
+        if (m_flags & REVERSE_COMPLEMENT) encoder->push_back(len, m_name.data(), m_bp.data(), m_q.data(), m_qualities, m_max_len, m_trim3, m_trim5, SequenceDataEncoder::REVERSE_COMPLEMENT_OP);
+        return true;
+    }
+
+    nvbio::priv::byte_source m_src;
+    QualityEncoding    m_qualities;
+    uint32             m_max_seqs, m_max_len;
+    SequenceEncoding   m_flags;
+    uint32             m_trim3, m_trim5, m_loaded;
+    bool               m_ok, m_eof;
+    std::vector<char>  m_name;
+    std::vector<uint8> m_bp, m_q;
+};
+} // namespace priv
+
+/// open a FASTQ / FASTA file (plain or .gz; the record marker decides the format).  NULL when the file cannot be opened.
+/// The reference's factory also opens .txt / .sam / .bam / .pac inputs (sequence_priv.cpp:84-220); those are not read here.
+inline SequenceDataInputStream* open_sequence_file(const char* sequence_file_name, const QualityEncoding qualities = Phred33, const uint32 max_seqs = uint32(-1),
+                                                   const uint32 max_sequence_len = uint32(-1), const SequenceEncoding flags = FORWARD, const uint32 trim3 = 0, const uint32 trim5 = 0)
+{
+    priv::TextSequenceFile* f = new priv::TextSequenceFile(sequence_file_name, qualities, max_seqs, max_sequence_len, flags, trim3, trim5);
+    if (!f->is_ok()) { delete f; return NULL; }
+    return f;
+}
+
+/// load a whole file into `sequence_data`
+inline bool load_sequence_file(const Alphabet alphabet, SequenceDataHost* sequence_data, const char* sequence_file_name,
+                               const SequenceFlags load_flags = SequenceFlags(SEQUENCE_DATA | SEQUENCE_QUALS | SEQUENCE_NAMES), const QualityEncoding qualities = Phred33)
+{
+    (void)load_flags;
+    SequenceDataInputStream* f = open_sequence_file(sequence_file_name, qualities);
+    if (f == NULL) return false;
+    const int n = next(alphabet, sequence_data, f, uint32(-1), uint32(-1));
+    const bool ok = f->is_ok() && n >= 0;
+    delete f;
+    return ok;
+}
+inline SequenceDataHost* load_sequence_file(const Alphabet alphabet, const char* sequence_file_name,
+                                            const SequenceFlags load_flags = SequenceFlags(SEQUENCE_DATA | SEQUENCE_QUALS | SEQUENCE_NAMES), const QualityEncoding qualities = Phred33)
+{
+    SequenceDataHost* data = new SequenceDataHost();
+    if (!load_sequence_file(alphabet, data, sequence_file_name, load_flags, qualities)) { delete data; return NULL; }
+    return data;
+}
+
+} // namespace io
+} // namespace nvbio

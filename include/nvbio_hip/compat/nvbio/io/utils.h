@@ -15,7 +15,8 @@
 #include "../basic/vector_view.h"
 
 namespace nvbio {
-namespace io {
+
+// (the reference declares everything in this header in namespace nvbio, not nvbio::io: utils.h:37-347)
 
 enum ReadType { STANDARD = 0u, COMPLEMENT = 1u };
 enum DirType  { FORWARD  = 0u, REVERSE    = 1u };
@@ -127,9 +128,7 @@ struct SequenceStreamLoader
     loader_type loader;
 };
 
-} // namespace io
-
-template <typename S, typename Q> struct string_traits< io::ReadStream<S, Q> > { typedef typename io::ReadStream<S, Q>::value_type value_type; typedef uint32 index_type; };
-template <typename R> struct string_traits< io::ReadStreamQualities<R> > { typedef uint8 value_type; typedef uint32 index_type; };
+template <typename S, typename Q> struct string_traits< ReadStream<S, Q> > { typedef typename ReadStream<S, Q>::value_type value_type; typedef uint32 index_type; };
+template <typename R> struct string_traits< ReadStreamQualities<R> > { typedef uint8 value_type; typedef uint32 index_type; };
 
 } // namespace nvbio

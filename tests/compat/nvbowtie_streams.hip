@@ -131,7 +131,7 @@ struct PlacementStream
     typedef Aligner aligner_type;
     typedef mode_traits<MODE> traits;
     typedef lmem_cache_tag<64> cache_tag;
-    typedef io::ReadLoader<StoredReads, cache_tag>                          read_loader;
+    typedef ReadLoader<StoredReads, cache_tag>                          read_loader;
     typedef PackedStringLoader<cuda::ldg_pointer<uint32>, 2, true, cache_tag> genome_loader;
 
     /// the job: which candidate, which read range, which strand, which genome window, the score to beat -- and where the result goes
@@ -187,7 +187,7 @@ struct PlacementStream
         // reads are stored back to front: the forward strand is the stored read walked backwards, the reverse complement is the stored
         // read walked forwards with every base complemented
         const StoredReads& from = traits::whole_window ? ws.mates : ws.reads;
-        s->pattern = s->loads_read.load(from, job->stored, job->reverse_strand ? io::FORWARD : io::REVERSE, job->reverse_strand ? io::COMPLEMENT : io::STANDARD);
+        s->pattern = s->loads_read.load(from, job->stored, job->reverse_strand ? FORWARD : REVERSE, job->reverse_strand ? COMPLEMENT : STANDARD);
         s->quals   = s->pattern.qualities();
         const uint32 span = job->window_hi - job->window_lo;
         s->text    = vector_view<typename genome_loader::iterator>(span, s->loads_genome.load(ws.genome + job->window_lo, span));

@@ -142,7 +142,6 @@ CASES.append(("nvBowtie AlignmentStrings + AlignmentStreamBase + BestScoreStream
 #define NVBIO_CUDA_DEBUG_PRINT_IF(...)
 #define DP_REPORT_MULTIPLE 0
 namespace nvbio {{ namespace bowtie2 {{ namespace cuda {{
-using namespace nvbio::io;
 // ---- nvBowtie/bowtie2/cuda/func.h, SimpleFunc (verbatim)
 {4}
 // ---- application-side types of nvBowtie the verbatim ranges refer to (params.h, pipeline_states.h, scoring_queues.h)
@@ -219,7 +218,6 @@ CASES.append(("nvBowtie BestTracebackStream + Backtracker (CIGAR-forming, 1024-e
 #define MAXIMUM_READ_LENGTH 512
 #define MAXIMUM_INSERT_LENGTH 1024
 namespace nvbio {{ namespace bowtie2 {{ namespace cuda {{
-using namespace nvbio::io;
 {4}
 // ---- application-side types of nvBowtie the verbatim ranges refer to (params.h, defs.h, pipeline_states.h, the CIGAR arena)
 enum MateType {{ AnchorMate = 0, OppositeMate = 1 }};
@@ -289,7 +287,6 @@ CASES.append(("nvBowtie mapping_inl.h: check_N, match_range, store_deque, 1-mism
               [("nvBowtie/bowtie2/cuda/seed_hit.h", 47, 245), ("nvBowtie/bowtie2/cuda/utils.h", 51, 53), ("nvBowtie/bowtie2/cuda/mapping_inl.h", 60, 505)],
               NVBOWTIE_APP_PRELUDE + r"""
 namespace nvbio {{ namespace bowtie2 {{ namespace cuda {{
-using namespace nvbio::io;
 enum {{ BLOCKDIM = 96 }};                                                                       // nvBowtie defs.h:89
 // ---- nvBowtie/bowtie2/cuda/seed_hit.h, SeedHit + hit_compare (verbatim)
 {0}
@@ -360,7 +357,6 @@ CASES.append(("nvBowtie locate_inl.h: locate / locate_init / locate_lookup (same
               NVBOWTIE_APP_PRELUDE + r"""
 #define NVBIO_CUDA_ASSERT_IF(...)
 namespace nvbio {{ namespace bowtie2 {{ namespace cuda {{
-using namespace nvbio::io;
 enum {{ BLOCKDIM = 96 }};
 // ---- application-side types (scoring_queues.h: the hit queues a locate kernel rewrites in place; params.h)
 struct ParamsPOD {{ uint32 dummy; }};
@@ -407,7 +403,6 @@ NVBOWTIE_SCORE_PRELUDE = r"""
 #define NVBIO_CUDA_ASSERT_IF(...)
 #define DP_REPORT_MULTIPLE 0
 namespace nvbio {{ namespace bowtie2 {{ namespace cuda {{
-using namespace nvbio::io;
 // ---- nvBowtie/bowtie2/cuda/func.h, SimpleFunc (verbatim)
 {4}
 // ---- application-side types of nvBowtie the verbatim ranges refer to (params.h, pipeline_states.h, scoring_queues.h)
@@ -517,6 +512,23 @@ WHOLE.append(dict(name="nvbio-test/fmindex_test.cu:56-717 (everything but the fi
                   tu=None, install="ref_fmindex_test", ranges=[("nvbio-test/fmindex_test.cu", 56, 717)],
                   wrapper="#include <nvbio/basic/omp.h>\n#include <stdio.h>\n#include <stdlib.h>\n#include <string.h>\n#include <vector>\n#include <algorithm>\n#include <nvbio/basic/timer.h>\n#include <nvbio/basic/console.h>\n#include <nvbio/basic/dna.h>\n#include <nvbio/basic/cached_iterator.h>\n#include <nvbio/basic/packedstream.h>\n#include <nvbio/basic/deinterleaved_iterator.h>\n#include <nvbio/basic/cuda/ldg.h>\n#include <nvbio/fmindex/bwt.h>\n#include <nvbio/fmindex/ssa.h>\n#include <nvbio/fmindex/fmindex.h>\n{0}\nint main(int argc, char** argv)\n{\n    const uint32 len = argc > 1 ? atoi(argv[1]) : 100000, q = argc > 2 ? atoi(argv[2]) : 10000;\n    synthetic_test<uint32>(len, q);\n    synthetic_test<uint64>(len, q);\n    fprintf(stderr, \"fmindex synthetic test... done\\n\");\n    return 0;\n}\n",
                   main=None, run=["20000", "2000"], expect="cpu alignment... done", may_abort=True))
+WHOLE.append(dict(name="sw-benchmark/sw-benchmark.cu, whole TU -- the program BASELINE's headline numbers come from -- compiled as it lies and linked (FASTQ reads + FASTA reference through the drop-in io::open_sequence_file / FASTA_inc_reader, AlignmentStream on the tuned kernels, its own per-thread kernel on the generic lane code); RUN here up to the first device allocation, on the GPU box from oracle/_ref/ to its own GCUPS printout",
+                  tu="sw-benchmark/sw-benchmark.cu", install="ref_sw_benchmark", main=None, files="sw", run=["{reads}", "{ref}"], expect="reading reference file \"{ref}\"... done (3000 bps)", may_abort=True))
+
+
+def sw_benchmark_files(tmp):
+    """a 3 000-bp FASTA reference and 64 FASTQ reads cut from it, for the host part of the sw-benchmark run"""
+    import random
+    rnd = random.Random(7)
+    ref = "".join(rnd.choice("ACGT") for _ in range(3000))
+    ref_name, reads_name = os.path.join(tmp, "ref.fa"), os.path.join(tmp, "reads.fq")
+    with open(ref_name, "w") as f:
+        f.write(">chr1 synthetic\n" + "\n".join(ref[i:i + 70] for i in range(0, len(ref), 70)) + "\n")
+    with open(reads_name, "w") as f:
+        for i in range(64):
+            p = rnd.randrange(0, 2900)
+            f.write("@read%d\n%s\n+\n%s\n" % (i, ref[p:p + 100], "I" * 100))
+    return dict(reads=reads_name, ref=ref_name)
 
 
 def whole_cases(tmp, out, only, install=False):
@@ -554,16 +566,20 @@ def whole_cases(tmp, out, only, install=False):
             srcs += ["-x", "hip", m]
         t0 = time.time()
         r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-std=c++17", "-O2", "-fopenmp", "-include", port] + srcs +
-                           ["-I" + COMPAT, "-I" + inc, "-L" + os.path.join(ROOT, "nvbio_amd", "lib"), "-lnvbio_hip",
+                           ["-I" + COMPAT, "-I" + inc, "-L" + os.path.join(ROOT, "nvbio_amd", "lib"), "-lnvbio_hip", "-lz",
                             "-Wl,-rpath,$ORIGIN/../../nvbio_amd/lib", "-o", exe], capture_output=True, text=True)
         ok = r.returncode == 0
         ran = ""
         if ok and c.get("run") is not None:
-            rr = subprocess.run([exe] + c["run"], capture_output=True, text=True, timeout=600,
+            subst = sw_benchmark_files(tmp) if c.get("files") == "sw" else {}
+            run_args = [a.format(**subst) for a in c["run"]]
+            expect = c["expect"].format(**subst) if subst else c["expect"]
+            rr = subprocess.run([exe] + run_args, capture_output=True, text=True, timeout=600,
                                 env=dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "nvbio_amd", "lib") + ":" + os.environ.get("LD_LIBRARY_PATH", "")))
             text = (rr.stdout + rr.stderr).replace("\r", "\n")
-            good = c["expect"] in text and (rr.returncode == 0 or c.get("may_abort"))
-            ran = "ran `%s`: %s (exit %d%s)" % (" ".join([os.path.basename(exe)] + c["run"]), "reached \"%s\"" % c["expect"] if good else "DID NOT reach \"%s\"" % c["expect"],
+            good = expect in text and (rr.returncode == 0 or c.get("may_abort"))
+            shown = expect.replace(tmp, "<tmp>")
+            ran = "ran `%s`: %s (exit %d%s)" % (" ".join([os.path.basename(exe)] + [a.replace(tmp, "<tmp>") for a in run_args]), "reached \"%s\"" % shown if good else "DID NOT reach \"%s\"" % shown,
                                                rr.returncode, "; stops where the first device allocation needs a GPU" if c.get("may_abort") and rr.returncode != 0 else "")
             ok = ok and good
         failed += 0 if ok else 1
