@@ -213,6 +213,86 @@ struct any_sink_ok { static const bool value = true; };
 template <typename stream_type> struct recognised    : recognition<stream_type, score_sink_ok<stream_type> > {};
 template <typename stream_type> struct recognised_tb : recognition<stream_type, any_sink_ok> {};
 
+/// The longest pattern and text of a batch.  The stream concept offers max_pattern_length() / max_text_length() (batched.h:252-256), and a
+/// stream of plain packed strings is taken at its word.  nvBowtie's own streams are not: their max_pattern_length() names a member its
+/// read batch does not have (score_best_inl.h:80) and only compiles in the reference because DeviceThreadScheduler never instantiates it.
+/// For every stream that is not `zero_copy` the two lengths are therefore MEASURED -- one light pass over init_context / pattern_length /
+/// text_length -- and published for the duration of the enact() call through limits_scope; code below reads them with maxP_of / maxT_of.
+struct stream_limits { const void* stream; uint32 maxP, maxT; };
+inline stream_limits& current_limits() { static thread_local stream_limits l = { NULL, 0u, 0u }; return l; }
+template <typename stream_type> inline uint32 maxP_of(const stream_type& s) { const stream_limits& l = current_limits(); if (l.stream != &s) throw std::logic_error("batched: stream limits read outside an enact() scope"); return l.maxP; }
+template <typename stream_type> inline uint32 maxT_of(const stream_type& s) { const stream_limits& l = current_limits(); if (l.stream != &s) throw std::logic_error("batched: stream limits read outside an enact() scope"); return l.maxT; }
+
+template <typename stream_type>
+NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void job_lengths(const stream_type& stream, const uint32 i, uint32& pl, uint32& tl)
+{
+    typename stream_type::context_type ctx;
+    pl = tl = 0;
+    if (stream.init_context(i, &ctx)) { pl = stream.pattern_length(i, &ctx); tl = stream.text_length(i, &ctx); }
+}
+#if defined(__HIPCC__)
+template <typename stream_type>
+__global__ void __launch_bounds__(256) measure_limits_kernel(const stream_type stream, uint32* out)
+{
+    __shared__ uint32 s_p, s_t;
+    if (threadIdx.x == 0) { s_p = 0; s_t = 0; }
+    __syncthreads();
+    uint32 mp = 0, mt = 0;
+    const uint32 n = stream.size();
+    for (uint64 i = uint64(blockIdx.x) * 256u + threadIdx.x; i < n; i += uint64(gridDim.x) * 256u)
+    {
+        uint32 pl, tl; job_lengths(stream, uint32(i), pl, tl);
+        mp = pl > mp ? pl : mp; mt = tl > mt ? tl : mt;
+    }
+    atomicMax(&s_p, mp); atomicMax(&s_t, mt);
+    __syncthreads();
+    if (threadIdx.x == 0) { atomicMax(out, s_p); atomicMax(out + 1, s_t); }
+}
+#endif
+template <typename stream_type, bool TRUSTED> struct limits_reader
+{ static void read(const stream_type& s, uint32& p, uint32& t) { p = s.max_pattern_length(); t = s.max_text_length(); } };
+template <typename stream_type> struct limits_reader<stream_type, false> { static void read(const stream_type&, uint32& p, uint32& t) { p = t = 0; } };
+
+template <typename stream_type>
+struct limits_scope
+{
+    static const bool trusted = recognised_tb<stream_type>::zero_copy;
+    /// host streams: walk the jobs
+    limits_scope(const stream_type& s) : m_saved(current_limits())
+    {
+        uint32 p = 0, t = 0;
+        if (trusted) limits_reader<stream_type, trusted>::read(s, p, t);
+        else
+        {
+            const int64 n = int64(s.size());
+            #pragma omp parallel for reduction(max : p, t) schedule(static)
+            for (int64 i = 0; i < n; ++i) { uint32 pl, tl; job_lengths(s, uint32(i), pl, tl); p = pl > p ? pl : p; t = tl > t ? tl : t; }
+        }
+        const stream_limits l = { &s, p, t }; current_limits() = l;
+    }
+#if defined(__HIPCC__)
+    /// device streams: one reduction kernel (and a synchronization: the lengths size the launches that follow)
+    limits_scope(const stream_type& s, hipStream_t hs) : m_saved(current_limits())
+    {
+        static thread_local device_buffer scratch;
+        uint32 v[2] = { 0u, 0u };
+        if (trusted) limits_reader<stream_type, trusted>::read(s, v[0], v[1]);
+        else if (s.size())
+        {
+            uint32* d = reinterpret_cast<uint32*>(scratch.reserve(64u));
+            check(hipMemsetAsync(d, 0, 8u, hs), "hipMemsetAsync");
+            const uint32 blocks = uint32(std::min<uint64>((uint64(s.size()) + 255u) / 256u, 4096u));
+            hipLaunchKernelGGL((measure_limits_kernel<stream_type>), dim3(blocks), dim3(256), 0, hs, s, d);
+            check(hipMemcpyAsync(v, d, 8u, hipMemcpyDeviceToHost, hs), "hipMemcpyAsync");
+            check(hipStreamSynchronize(hs), "hipStreamSynchronize");
+        }
+        const stream_limits l = { &s, v[0], v[1] }; current_limits() = l;
+    }
+#endif
+    ~limits_scope() { current_limits() = m_saved; }
+    stream_limits m_saved;
+};
+
 #if defined(NVBIO_HIP_COMPAT_TUNED)
 /// the job table the tuned kernels consume (structure of arrays in one device buffer)
 struct job_table
@@ -245,7 +325,7 @@ __device__ __forceinline__ unsigned long long wave_min(unsigned long long v)
 __device__ __forceinline__ unsigned long long wave_max(unsigned long long v)
 { for (int o = 32; o > 0; o >>= 1) { const unsigned long long w = __shfl_xor(v, o, 64); v = w > v ? w : v; } return v; }
 
-__global__ void init_bounds_kernel(unsigned long long* b) { if (threadIdx.x < 8u) b[threadIdx.x] = (threadIdx.x & 1u) ? 0ull : ~0ull; }
+static __global__ void init_bounds_kernel(unsigned long long* b) { if (threadIdx.x < 8u) b[threadIdx.x] = (threadIdx.x & 1u) ? 0ull : ~0ull; }
 
 /// where a pattern lives (in place), or nothing (staged)
 template <typename P, bool DIRECT> struct pattern_where {
@@ -330,7 +410,7 @@ __global__ void __launch_bounds__(128) describe_jobs_kernel(const stream_type st
         else                          { const unsigned long long v = a > b ? a : b; if (v != 0ull) atomicMax(&t.bounds[threadIdx.x], v); }
     }
 }
-__global__ void __launch_bounds__(256) rebase_jobs_kernel(const uint32 n, uint64* pat_begin, const uint64 pat_delta, uint64* txt_begin, const uint64 txt_delta)
+static __global__ void __launch_bounds__(256) rebase_jobs_kernel(const uint32 n, uint64* pat_begin, const uint64 pat_delta, uint64* txt_begin, const uint64 txt_delta)
 {
     const uint32 i = blockIdx.x * 256u + threadIdx.x;
     if (i < n) { pat_begin[i] -= pat_delta; txt_begin[i] -= txt_delta; }
@@ -438,7 +518,7 @@ inline void build_job_table(const stream_type& stream, device_buffer& buf, job_t
                             const uint64 extra_bytes = 0, uint8** extra = NULL, const uint8** quals = NULL, uint64* n_quals = NULL)
 {
     const uint32 n = stream.size();
-    const uint32 maxP = stream.max_pattern_length();
+    const uint32 maxP = maxP_of(stream);
     const uint64 table = (job_table::bytes(n) + 15u) & ~uint64(15);
     const uint64 stage = R::staged ? ((job_table::stage_bytes(n, maxP, R::stage_quals) + 15u) & ~uint64(15)) : 0u;
     uint8* base = buf.reserve(table + stage + extra_bytes + 16u);
@@ -540,12 +620,12 @@ struct tuned_scheme
     /// an int16 sink holds every score of the batch (the reference narrows each reported score to the sink's type)
     template <typename sink_type>
     bool sink_fits(const stream_type& stream) const
-    { return !best_sink<sink_type>::narrow || (int64(stream.max_pattern_length()) + stream.max_text_length() + 2) * A < 32000; }
+    { return !best_sink<sink_type>::narrow || (int64(maxP_of(stream)) + maxT_of(stream) + 2) * A < 32000; }
 
     int banded_score(const uint32 band, const stream_type& stream, const job_table& t, const nvbio_hip_string_set& ps, const nvbio_hip_string_set& ts,
                      const uint8* quals, const uint64 n_quals, hipStream_t hs) const
     {
-        const uint32 n = stream.size(), maxP = stream.max_pattern_length(), maxT = stream.max_text_length();
+        const uint32 n = stream.size(), maxP = maxP_of(stream), maxT = maxT_of(stream);
         if constexpr (TA::QUAL) return nvbio_hip_banded_gotoh_score_qual(&q, int32(aligner_type::TYPE), band, &ps, quals, n_quals, &ts, maxP, maxT, n, t.score, t.sink, hs);
         else if (TA::KIND == NVBIO_HIP_GOTOH_ALIGNER) { const nvbio_hip_gotoh_scheme g = { sc[0], sc[1], sc[2], sc[3] };
             return nvbio_hip_banded_gotoh_score(&g, int32(aligner_type::TYPE), band, &ps, &ts, maxP, maxT, n, t.score, t.sink, hs); }
@@ -555,7 +635,7 @@ struct tuned_scheme
     int full_score(const stream_type& stream, const job_table& t, const nvbio_hip_string_set& ps, const nvbio_hip_string_set& ts,
                    const uint8* quals, const uint64 n_quals, hipStream_t hs) const
     {
-        const uint32 n = stream.size(), maxP = stream.max_pattern_length(), maxT = stream.max_text_length();
+        const uint32 n = stream.size(), maxP = maxP_of(stream), maxT = maxT_of(stream);
         const int32 algo = TA::TEXT_BLOCKING ? NVBIO_HIP_TEXT_BLOCKING : NVBIO_HIP_PATTERN_BLOCKING;
         if constexpr (TA::QUAL) return nvbio_hip_alignment_score_qual(&q, algo, int32(aligner_type::TYPE), &ps, quals, n_quals, &ts, maxP, maxT, t.min_score, n, t.score, t.sink, t.ok, hs);
         else return nvbio_hip_alignment_score(TA::KIND, algo, sc, int32(aligner_type::TYPE), &ps, &ts, maxP, maxT, t.min_score, n, t.score, t.sink, t.ok, hs);
@@ -564,7 +644,7 @@ struct tuned_scheme
     int traceback(const uint32 band, const stream_type& stream, const job_table& t, const nvbio_hip_string_set& ps, const nvbio_hip_string_set& ts,
                   const uint8* quals, const uint64 n_quals, uint32* source, uint16* cigar, const uint32 stride, uint32* cigar_len, uint8* temp, const uint64 tb, hipStream_t hs) const
     {
-        const uint32 n = stream.size(), maxP = stream.max_pattern_length(), maxT = stream.max_text_length();
+        const uint32 n = stream.size(), maxP = maxP_of(stream), maxT = maxT_of(stream);
         const int32 ty = int32(aligner_type::TYPE);
         if constexpr (TA::QUAL)
             return band ? nvbio_hip_banded_gotoh_traceback_qual(&q, ty, band, &ps, quals, n_quals, &ts, maxP, maxT, n, t.score, t.sink, source, cigar, stride, cigar_len, temp, tb, hs)
@@ -617,6 +697,7 @@ private:
 #if defined(__HIPCC__)
         const uint32 n = stream.size();
         if (n == 0) return;
+        const priv::limits_scope<stream_type> limits(stream, hs);
         run_device(stream, hs, std::integral_constant<bool, priv::recognised<stream_type>::value && priv::tuned_band<BAND_LEN>::value>());
 #else
         static_assert(sizeof(any_device_scheduler) == 0, "the device schedulers need a translation unit compiled by hipcc");
@@ -659,7 +740,7 @@ private:
             if (!(no_views && no_views[0] == '1') && priv::build_view_table(stream, m_jobs, t, ps, ts, &quals, &n_quals, &flags, hs) && n_quals >= 4u)
             {
                 const int err = nvbio_hip_banded_gotoh_score_qual_views(&scheme.q, int32(stream_type::aligner_type::TYPE), BAND_LEN, &ps, quals, n_quals, flags, &ts,
-                                                                        stream.max_pattern_length(), stream.max_text_length(), n, t.score, t.sink, hs);
+                                                                        priv::maxP_of(stream), priv::maxT_of(stream), n, t.score, t.sink, hs);
                 priv::check(err, "nvbio_hip_banded_gotoh_score_qual_views");
                 hipLaunchKernelGGL((priv::output_jobs_kernel<stream_type>), dim3((n + 127u) / 128u), dim3(128), 0, hs, stream, t);
                 priv::check(hipGetLastError(), "output_jobs_kernel");
@@ -719,7 +800,8 @@ private:
              )
     {
         const int64 n = int64(stream.size());
-        const uint64 stride = column_stride(stream.max_pattern_length(), stream.max_text_length());
+        const priv::limits_scope<stream_type> limits(stream);
+        const uint64 stride = column_stride(priv::maxP_of(stream), priv::maxT_of(stream));
         #pragma omp parallel
         {
             std::vector<int16> column(stride + 8u);
@@ -737,6 +819,7 @@ private:
     {
 #if defined(__HIPCC__)
         if (stream.size() == 0) return;
+        const priv::limits_scope<stream_type> limits(stream, hs);
         run_device(stream, temp_size, temp, hs, std::integral_constant<bool, priv::recognised<stream_type>::value>());
 #else
         static_assert(sizeof(any_device_scheduler) == 0, "the device schedulers need a translation unit compiled by hipcc");
@@ -746,7 +829,7 @@ private:
     void run_device(const stream_type& stream, uint64 temp_size, uint8* temp, hipStream_t hs, std::false_type)
     {
         const uint32 n = stream.size();
-        const uint64 stride = column_stride(stream.max_pattern_length(), stream.max_text_length());
+        const uint64 stride = column_stride(priv::maxP_of(stream), priv::maxT_of(stream));
         const uint64 need = uint64(n) * stride * sizeof(int16);
         if (temp == NULL || temp_size < need) temp = m_columns.reserve(need);          // batched_inl.h:402-408: allocate when the caller gave none
         hipLaunchKernelGGL((priv::batched_full_score_kernel<stream_type>), dim3((n + 127u) / 128u), dim3(128), 0, hs, stream, reinterpret_cast<int16*>(temp), stride);
@@ -760,7 +843,7 @@ private:
         priv::tuned_scheme<stream_type> scheme;
         typedef decltype(typename stream_type::context_type().sink) sink_type;
         // the tuned sweep keeps <= 1024 rows in a wave
-        if (stream.max_pattern_length() > 1024u || !scheme.init(stream) || !scheme.template sink_fits<sink_type>(stream)) { run_device(stream, temp_size, temp, hs, std::false_type()); return; }
+        if (priv::maxP_of(stream) > 1024u || !scheme.init(stream) || !scheme.template sink_fits<sink_type>(stream)) { run_device(stream, temp_size, temp, hs, std::false_type()); return; }
         priv::job_table t; nvbio_hip_string_set ps, ts; const uint8* quals = NULL; uint64 n_quals = 0;
         priv::build_job_table(stream, m_jobs, t, ps, ts, hs, 0u, NULL, &quals, &n_quals);
         const int err = scheme.full_score(stream, t, ps, ts, quals, n_quals, hs);
@@ -844,7 +927,8 @@ struct traceback_runner
     {
         stream_type stream(in_stream);
         const int64 n = int64(stream.size());
-        const uint32 maxP = stream.max_pattern_length(), maxT = stream.max_text_length();
+        const limits_scope<stream_type> limits(stream);
+        const uint32 maxP = maxP_of(stream), maxT = maxT_of(stream);
         const uint64 bytes = BAND_LEN ? banded_traceback_scratch(BAND_LEN ? BAND_LEN : 1u, maxP) : full_traceback_scratch(maxP, maxT);
         #pragma omp parallel
         {
@@ -858,11 +942,12 @@ struct traceback_runner
     void run(const stream_type& stream, hipStream_t hs)
     {
         if (stream.size() == 0) return;
+        const limits_scope<stream_type> limits(stream, hs);
         run_device(stream, hs, std::integral_constant<bool, recognised_tb<stream_type>::value && (BAND_LEN == 0u || tuned_band<BAND_LEN ? BAND_LEN : 3u>::value)>());
     }
     void run_device(const stream_type& stream, hipStream_t hs, std::false_type)
     {
-        const uint32 n = stream.size(), maxP = stream.max_pattern_length(), maxT = stream.max_text_length();
+        const uint32 n = stream.size(), maxP = maxP_of(stream), maxT = maxT_of(stream);
         const uint64 stride = BAND_LEN ? banded_traceback_scratch(BAND_LEN ? BAND_LEN : 1u, maxP) : full_traceback_scratch(maxP, maxT);
         uint8* scratch = m_temp.reserve(uint64(n) * stride + 16u);
         launch_generic(stream, scratch, stride, maxP, maxT, hs, std::integral_constant<bool, BAND_LEN != 0u>());
@@ -879,7 +964,7 @@ struct traceback_runner
 #if defined(NVBIO_HIP_COMPAT_TUNED)
         const uint32 n = stream.size();
         const uint32 band = BAND_LEN;
-        const uint32 maxP = stream.max_pattern_length(), maxT = stream.max_text_length();
+        const uint32 maxP = maxP_of(stream), maxT = maxT_of(stream);
         tuned_scheme<stream_type> scheme;
         if (!scheme.init(stream)) { run_device(stream, hs, std::false_type()); return; }
         const uint32 stride = band ? maxP + band + 4u : maxP + maxT + 4u;          // run-length words never exceed the walk's length

@@ -2,6 +2,8 @@
 // (nvbio/basic/cuda/pingpong_queues.h): a kernel reads in_queue[0, in_size) and appends to out_queue through *out_size.
 #pragma once
 #include "../types.h"
+#include "arch.h"
+#include "../thrust_view.h"
 #if defined(__HIPCC__)
 #include <thrust/device_vector.h>
 #endif
@@ -56,4 +58,10 @@ struct PingPongQueues
 #endif
 
 } // namespace cuda
+
+#if defined(__HIPCC__)
+template <typename T> inline cuda::PingPongQueuesView<T> device_view(cuda::PingPongQueues<T>& queues) { return queues.device_view(); }
+template <typename T> inline cuda::PingPongQueuesView<T> plain_view(cuda::PingPongQueues<T>& queues)  { return queues.device_view(); }
+#endif
+
 } // namespace nvbio

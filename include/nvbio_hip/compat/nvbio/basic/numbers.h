@@ -8,6 +8,12 @@
 
 namespace nvbio {
 
+#if defined(__HIPCC__)
+/// lane and warp of a thread in the reference's 32-lane terms (numbers.h:64-65; see cuda/arch.h on virtual warps)
+NVBIO_FORCEINLINE __device__ uint32 warp_tid() { return threadIdx.x & 31u; }
+NVBIO_FORCEINLINE __device__ uint32 warp_id()  { return threadIdx.x >> 5; }
+#endif
+
 namespace util {
 
 template <uint32 N> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 lo_bits() { return N >= 32u ? 0xFFFFFFFFu : (1u << (N & 31u)) - 1u; }
@@ -104,5 +110,77 @@ template <typename T, typename R> struct cast_functor
     typedef T argument_type; typedef R result_type;
     NVBIO_FORCEINLINE NVBIO_HOST_DEVICE R operator()(const T v) const { return R(v); }
 };
+
+/// the top bits of a 32-bit word as a narrower key (numbers.h:1064-1103): what nvBowtie sorts its hits by
+template <typename T, typename U> struct hi_bits_functor {};
+template <> struct hi_bits_functor<uint8, uint32>  { typedef uint32 argument_type; typedef uint8  result_type; NVBIO_FORCEINLINE NVBIO_HOST_DEVICE result_type operator()(const argument_type op) const { return result_type(op >> 24u); } };
+template <> struct hi_bits_functor<uint16, uint32> { typedef uint32 argument_type; typedef uint16 result_type; NVBIO_FORCEINLINE NVBIO_HOST_DEVICE result_type operator()(const argument_type op) const { return result_type(op >> 16u); } };
+template <> struct hi_bits_functor<uint32, uint32> { typedef uint32 argument_type; typedef uint32 result_type; NVBIO_FORCEINLINE NVBIO_HOST_DEVICE result_type operator()(const argument_type op) const { return op; } };
+
+/// the small functor vocabulary handed to transform / reduce / copy_if (numbers.h:920-1380)
+struct add_functor { template <typename T> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE T operator()(const T a, const T b) const { return a + b; } };
+struct min_functor { template <typename T> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE T operator()(const T a, const T b) const { return a < b ? a : b; } };
+struct max_functor { template <typename T> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE T operator()(const T a, const T b) const { return a > b ? a : b; } };
+#define NVBIO_HIP_UNARY_TEST(name, expr)                                                                                     \
+    template <typename T> struct name { typedef T argument_type; typedef bool result_type;                                    \
+        NVBIO_FORCEINLINE NVBIO_HOST_DEVICE result_type operator()(const T op) const { return expr; } };
+NVBIO_HIP_UNARY_TEST(is_true_functor,  op ? true : false)
+NVBIO_HIP_UNARY_TEST(is_false_functor, op ? false : true)
+#undef NVBIO_HIP_UNARY_TEST
+#define NVBIO_HIP_BOUND_TEST(name, cmp)                                                                                      \
+    template <typename T> struct name { typedef T argument_type; typedef bool result_type;                                    \
+        NVBIO_FORCEINLINE NVBIO_HOST_DEVICE name(const T k) : m_k(k) {}                                                       \
+        NVBIO_FORCEINLINE NVBIO_HOST_DEVICE result_type operator()(const T op) const { return op cmp m_k; }                   \
+        const T m_k; };
+NVBIO_HIP_BOUND_TEST(equal_to_functor, ==)
+NVBIO_HIP_BOUND_TEST(not_equal_to_functor, !=)
+#undef NVBIO_HIP_BOUND_TEST
+#define NVBIO_HIP_BINARY_TEST(name, cmp)                                                                                     \
+    template <typename T> struct name { typedef T first_argument_type; typedef T second_argument_type; typedef bool result_type; \
+        NVBIO_FORCEINLINE NVBIO_HOST_DEVICE result_type operator()(const T a, const T b) const { return a cmp b; } };
+NVBIO_HIP_BINARY_TEST(equal_functor, ==)
+NVBIO_HIP_BINARY_TEST(not_equal_functor, !=)
+#undef NVBIO_HIP_BINARY_TEST
+/// op -> perm[op]
+template <typename Iterator, typename index_type = uint32>
+struct gather_functor
+{
+    typedef index_type argument_type; typedef typename std::iterator_traits<Iterator>::value_type result_type;
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE gather_functor(const Iterator perm) : m_perm(perm) {}
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE result_type operator()(const argument_type op) const { return m_perm[op]; }
+    Iterator m_perm;
+};
+template <typename Iterator> inline gather_functor<Iterator> make_gather_functor(const Iterator perm) { return gather_functor<Iterator>(perm); }
+/// op -> fun2(fun1(op))
+template <typename Functor2, typename Functor1>
+struct composition_functor
+{
+    typedef typename Functor1::argument_type argument_type; typedef typename Functor2::result_type result_type;
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE composition_functor(const Functor2 fun2, const Functor1 fun1) : m_fun1(fun1), m_fun2(fun2) {}
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE result_type operator()(const argument_type op) const { return m_fun2(m_fun1(op)); }
+    Functor1 m_fun1; Functor2 m_fun2;
+};
+template <typename Functor2, typename Functor1>
+inline composition_functor<Functor2, Functor1> make_composition_functor(const Functor2 fun2, const Functor1 fun1) { return composition_functor<Functor2, Functor1>(fun2, fun1); }
+/// a binary functor with its first / second argument fixed
+template <typename Functor>
+struct bind_first_functor
+{
+    typedef typename Functor::second_argument_type argument_type; typedef typename Functor::first_argument_type const_type; typedef typename Functor::result_type result_type;
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bind_first_functor(const const_type c) : m_fun(), m_c(c) {}
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bind_first_functor(const Functor fun, const const_type c) : m_fun(fun), m_c(c) {}
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE result_type operator()(const argument_type op) const { return m_fun(m_c, op); }
+    Functor m_fun; const_type m_c;
+};
+template <typename Functor>
+struct bind_second_functor
+{
+    typedef typename Functor::first_argument_type argument_type; typedef typename Functor::second_argument_type const_type; typedef typename Functor::result_type result_type;
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bind_second_functor(const const_type c) : m_fun(), m_c(c) {}
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bind_second_functor(const Functor fun, const const_type c) : m_fun(fun), m_c(c) {}
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE result_type operator()(const argument_type op) const { return m_fun(op, m_c); }
+    Functor m_fun; const_type m_c;
+};
+template <typename T> struct negate_functor { typedef T argument_type; typedef T result_type; NVBIO_FORCEINLINE NVBIO_HOST_DEVICE T operator()(const T op) const { return -op; } };
 
 } // namespace nvbio

@@ -7,6 +7,7 @@
 // sw-benchmark's references 2-bit LE).
 #pragma once
 #include "types.h"
+#include "strided_iterator.h"     // (the reference's packedstream.h brings it in, and callers rely on that: persist.cu:215)
 #include "numbers.h"
 #include "iterator.h"
 // <endian.h> defines BIG_ENDIAN as a macro; the reference drops it (packedstream.h:38-40) because PackedStream has a member of that name
@@ -138,6 +139,21 @@ template <typename I, typename S, uint32 B, bool E, typename X>
 struct stream_traits< PackedStream<I, S, B, E, X> > { typedef X index_type; typedef S symbol_type; static const uint32 SYMBOL_SIZE = B; static const uint32 SYMBOL_COUNT = 1u << B; };
 template <typename I, typename S, uint32 B, bool E, typename X>
 struct string_traits< PackedStream<I, S, B, E, X> > { typedef S value_type; typedef X index_type; };
+
+/// an iterator over uint4 words read as a stream of uint32 components (packedstream.h:610-635)
+template <typename IteratorType>
+struct uint4_as_uint32_iterator
+{
+    typedef uint32                                                          value_type;
+    typedef value_type*                                                     pointer;
+    typedef value_type                                                      reference;
+    typedef typename std::iterator_traits<IteratorType>::difference_type    difference_type;
+    typedef typename std::iterator_traits<IteratorType>::iterator_category  iterator_category;
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint4_as_uint32_iterator() {}
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint4_as_uint32_iterator(const IteratorType it) : m_it(it) {}
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE value_type operator[](const uint32 i) const { const uint4 w = m_it[i >> 2]; const uint32 c = i & 3u; return c == 0 ? w.x : c == 1 ? w.y : c == 2 ? w.z : w.w; }
+    IteratorType m_it;
+};
 
 /// pack a symbol range into a stream (assign(), packedstream_inl.h)
 template <typename InputIterator, typename I, typename S, uint32 B, bool E, typename X>

@@ -27,6 +27,10 @@ struct priority_deque
     NVBIO_FORCEINLINE NVBIO_HOST_DEVICE explicit priority_deque(const Compare& comp = Compare(), const Sequence& seq = Sequence()) : m_seq(seq), m_comp(comp) { heapify(); }
     /// over a container that already is an interval heap (constructed == true), or any content otherwise
     NVBIO_FORCEINLINE NVBIO_HOST_DEVICE priority_deque(const Sequence& seq, const bool constructed = false) : m_seq(seq) { if (!constructed) heapify(); }
+    /// the tag form of the same: priority_deque(seq, priority_deque::CONSTRUCTED) never touches the container (priority_deque.h:173,194-196) --
+    /// which is what lets it wrap a read-only view of a stored heap
+    enum Constructed { CONSTRUCTED };
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE priority_deque(const Sequence& seq, const Constructed) : m_seq(seq) {}
 
     NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool      empty() const { return m_seq.empty(); }
     NVBIO_FORCEINLINE NVBIO_HOST_DEVICE size_type size()  const { return size_type(m_seq.size()); }
@@ -45,6 +49,7 @@ struct priority_deque
         const int n = int(size());
         if ((n - 1) & 1) leaf_upper(n, n - 1); else leaf_lower(n, n - 1);
     }
+    NVBIO_HOST_DEVICE void pop() { pop_top(); }          // std::priority_queue's name for it (priority_deque.h:225)
     NVBIO_HOST_DEVICE void pop_top()
     {
         const int n = int(size());

@@ -6,15 +6,17 @@
 
 namespace nvbio {
 
-template <typename T>
+/// (the reference's second parameter names the counter type, e.g. SharedPointer<Impl, AtomicInt32> for pointers shared across
+/// threads; std::shared_ptr's count is atomic already, so it is accepted and ignored)
+template <typename T, typename CounterT = long>
 struct SharedPointer : public std::shared_ptr<T>
 {
     typedef std::shared_ptr<T> base_type;
     SharedPointer() {}
     template <typename U> explicit SharedPointer(U* p) : base_type(p) {}
     template <typename U, typename D> SharedPointer(U* p, D d) : base_type(p, d) {}
-    template <typename U> SharedPointer(const SharedPointer<U>& o) : base_type(static_cast<const std::shared_ptr<U>&>(o)) {}
-    template <typename U> SharedPointer& operator=(const SharedPointer<U>& o) { base_type::operator=(static_cast<const std::shared_ptr<U>&>(o)); return *this; }
+    template <typename U, typename C> SharedPointer(const SharedPointer<U, C>& o) : base_type(static_cast<const std::shared_ptr<U>&>(o)) {}
+    template <typename U, typename C> SharedPointer& operator=(const SharedPointer<U, C>& o) { base_type::operator=(static_cast<const std::shared_ptr<U>&>(o)); return *this; }
     SharedPointer& operator=(T* p) { base_type::reset(p); return *this; }
 };
 

@@ -20,8 +20,15 @@
 #endif
 #define NVBIO_CUDA_DEBUG_ASSERT(...)
 #define NVBIO_CUDA_ASSERT(...)
+#define NVBIO_CUDA_ASSERT_IF(...)
+#define NVBIO_CUDA_DEBUG_STATEMENT(x)
+#define NVBIO_CUDA_DEBUG_PRINT(...)
+#define NVBIO_CUDA_DEBUG_PRINT_IF(...)
+#define NVBIO_CUDA_DEBUG_CHECK_IF(...)
+#define NVBIO_CUDA_DEBUG_SELECT(debug_val, normal_val) (normal_val)
 #define NVBIO_VAR_UNUSED __attribute__((unused))
 
+#include "version.h"
 #include <stdint.h>
 #include <stddef.h>
 #include <iterator>
@@ -77,6 +84,33 @@ template <> struct unsigned_type<int32>  { typedef uint32 type; };
 template <> struct unsigned_type<uint64> { typedef uint64 type; };
 template <> struct unsigned_type<int64>  { typedef uint64 type; };
 
+/// to_const / reference_subtype / device_view_subtype / plain_view_subtype (types.h:168-204): the view a container hands to kernels
+template <typename T> struct to_const           { typedef T type; };
+template <typename T> struct to_const<T&>       { typedef const T& type; };
+template <typename T> struct to_const<T*>       { typedef const T* type; };
+template <typename T> struct to_const<const T&> { typedef const T& type; };
+template <typename T> struct to_const<const T*> { typedef const T* type; };
+template <typename T> struct reference_subtype            { typedef typename T::reference type; };
+template <typename T> struct reference_subtype<T*>        { typedef T&                    type; };
+template <typename T> struct reference_subtype<const T*>  { typedef const T&              type; };
+template <>           struct reference_subtype<null_type> { typedef null_type             type; };
+template <typename T> struct device_view_subtype            { typedef typename T::device_view_type type; };
+template <>           struct device_view_subtype<null_type> { typedef null_type type; };
+template <typename T> struct device_view_subtype<const T*>  { typedef const T*  type; };
+template <typename T> struct device_view_subtype<T*>        { typedef T*        type; };
+template <typename T> struct plain_view_subtype            { typedef typename T::plain_view_type       type; };
+template <typename T> struct plain_view_subtype<const T>   { typedef typename T::const_plain_view_type type; };
+template <>           struct plain_view_subtype<null_type> { typedef null_type type; };
+template <typename T> struct plain_view_subtype<const T*>  { typedef const T*  type; };
+template <typename T> struct plain_view_subtype<T*>        { typedef T*        type; };
+/// reinterpret the bits of a value as another type of the same size (types.h: binary_cast)
+template <typename Out, typename In>
+NVBIO_FORCEINLINE NVBIO_HOST_DEVICE Out binary_cast(const In in)
+{
+    static_assert(sizeof(Out) == sizeof(In), "binary_cast between types of different sizes");
+    Out out; __builtin_memcpy(&out, &in, sizeof(Out)); return out;
+}
+
 /// same_type<A,B>::pred and equal<A,B>()   (nvbio/basic/types.h:222-230)
 template <typename A, typename B> struct same_type { static const bool pred = false; };
 template <typename A>             struct same_type<A, A> { static const bool pred = true; };
@@ -84,6 +118,8 @@ template <typename A, typename B> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool equal
 /// a rounded up to a multiple of the power of two N   (types.h:283)
 template <uint32 N, typename I> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE I align(const I a) { return N > 1u ? I((a + I(N - 1u)) & ~I(N - 1u)) : a; }
 /// binary_switch / if_true selectors used in template signatures
+template <typename A, typename B, uint32 N> struct binary_switch { typedef B type; };
+template <typename A, typename B> struct binary_switch<A, B, 0> { typedef A type; };
 template <bool B, typename T, typename F> struct if_true { typedef T type; };
 template <typename T, typename F> struct if_true<false, T, F> { typedef F type; };
 

@@ -15,6 +15,12 @@ struct vector_view
     typedef value_type                                              const_reference;
     typedef IndexType                                               index_type;
     typedef IndexType                                               size_type;
+    typedef typename std::iterator_traits<Iterator>::pointer         pointer;
+    typedef typename std::iterator_traits<Iterator>::difference_type difference_type;
+    typedef std::random_access_iterator_tag                         iterator_category;
+    typedef Iterator                                                forward_iterator;
+    typedef vector_view<Iterator, IndexType>                        plain_view_type;
+    typedef vector_view<Iterator, IndexType>                        const_plain_view_type;
 
     NVBIO_FORCEINLINE NVBIO_HOST_DEVICE vector_view() : m_size(0) {}
     NVBIO_FORCEINLINE NVBIO_HOST_DEVICE vector_view(const IndexType size, Iterator vec) : m_size(size), m_vec(vec) {}
@@ -35,6 +41,8 @@ struct vector_view
     NVBIO_FORCEINLINE NVBIO_HOST_DEVICE Iterator begin() const { return m_vec; }
     NVBIO_FORCEINLINE NVBIO_HOST_DEVICE Iterator end()   const { return m_vec + m_size; }
     NVBIO_FORCEINLINE NVBIO_HOST_DEVICE Iterator base()  const { return m_vec; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE reference operator*() const { return *m_vec; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE operator Iterator() const { return m_vec; }            // a view decays to its iterator (vector_view.h:199)
 
     IndexType m_size;
     Iterator  m_vec;
@@ -42,6 +50,10 @@ struct vector_view
 
 template <typename Iterator, typename I> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 length(const vector_view<Iterator, I>& v) { return uint32(v.length()); }
 template <typename T> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 length(const T& s) { return uint32(s.length()); }
+template <typename T>             NVBIO_FORCEINLINE NVBIO_HOST_DEVICE T raw_pointer(const vector_view<T>& v) { return v.base(); }
+template <typename T, typename I> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE T begin(const vector_view<T, I>& v) { return v.begin(); }
+template <typename T> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE T*       begin(T* v)       { return v; }
+template <typename T> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE const T* begin(const T* v) { return v; }
 template <typename Iterator, typename I> struct string_traits< vector_view<Iterator, I> > {
     typedef typename vector_view<Iterator, I>::value_type value_type; typedef I index_type;
 };

@@ -164,7 +164,7 @@ __device__ __forceinline__ unsigned long long filter_wave_min(unsigned long long
 __device__ __forceinline__ unsigned long long filter_wave_max(unsigned long long v)
 { for (int o = 32; o > 0; o >>= 1) { const unsigned long long w = __shfl_xor(v, o, 64); v = w > v ? w : v; } return v; }
 
-__global__ void filter_init_bounds_kernel(unsigned long long* b) { if (threadIdx.x < 2u) b[threadIdx.x] = threadIdx.x ? 0ull : ~0ull; }
+static __global__ void filter_init_bounds_kernel(unsigned long long* b) { if (threadIdx.x < 2u) b[threadIdx.x] = threadIdx.x ? 0ull : ~0ull; }
 /// where each string of the set lives: absolute symbol offset (from address 0), length; lowest / highest word over the set
 template <typename string_set_type>
 __global__ void __launch_bounds__(128) filter_describe_kernel(const uint32 n, const string_set_type string_set, uint64* begin, uint32* len, unsigned long long* bounds)
@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(128) filter_describe_kernel(const uint32 n, co
     lo = filter_wave_min(lo); hi = filter_wave_max(hi);
     if ((threadIdx.x & 63u) == 0u && hi) { atomicMin(&bounds[0], lo); atomicMax(&bounds[1], hi); }
 }
-__global__ void __launch_bounds__(256) filter_rebase_kernel(const uint32 n, uint64* begin, const uint64 delta)
+static __global__ void __launch_bounds__(256) filter_rebase_kernel(const uint32 n, uint64* begin, const uint64 delta)
 {
     const uint32 q = blockIdx.x * 256u + threadIdx.x;
     if (q < n) begin[q] -= delta;

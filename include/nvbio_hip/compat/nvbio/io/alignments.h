@@ -6,6 +6,7 @@
 // can be handed to the C-ABI reduction / MAPQ entry points as uint64 words.
 #pragma once
 #include "../basic/types.h"
+#include "../basic/pod.h"
 
 namespace nvbio {
 namespace io {
@@ -117,8 +118,67 @@ struct BestPairedAlignments
     template <uint32 I> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool   is_aligned() const { return I == 0 ? m_a1.is_aligned() : m_a2.is_aligned(); }
     template <uint32 I> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool   is_rc() const { return I == 0 ? m_a1.is_rc() : m_a2.is_rc(); }
     template <uint32 I> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool   is_opposite_rc() const { return I == 0 ? m_o1.is_rc() : m_o2.is_rc(); }
+    template <uint32 I> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 anchor_mate()    const { return I == 0 ? m_a1.mate()  : m_a2.mate(); }
+    template <uint32 I> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 opposite_mate()  const { return I == 0 ? m_o1.mate()  : m_o2.mate(); }
+    template <uint32 I> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE int32  anchor_score()   const { return I == 0 ? m_a1.score() : m_a2.score(); }
+    template <uint32 I> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 anchor_ed()      const { return I == 0 ? m_a1.ed()    : m_a2.ed(); }
+    template <uint32 I> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE int32  opposite_score() const { return I == 0 ? m_o1.score() : m_o2.score(); }
+    template <uint32 I> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 opposite_ed()    const { return I == 0 ? m_o1.ed()    : m_o2.ed(); }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE BestAlignments anchor()   const { return BestAlignments(m_a1, m_a2); }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE BestAlignments opposite() const { return BestAlignments(m_o1, m_o2); }
+    /// the best and second-best slots of read file `m`, whichever side holds them
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE BestAlignments mate(const uint32 m) const { return BestAlignments(m == m_a1.mate() ? m_a1 : m_o1, m == m_a2.mate() ? m_a2 : m_o2); }
     Alignment m_a1, m_a2, m_o1, m_o2;
 };
 
+/// predicates over the records, for thrust-style counting and partitioning (alignments.h:345-420)
+struct has_second          { NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool operator()(const BestAlignments& b) { return b.has_second(); }
+                             NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool operator()(const BestPairedAlignments& b) { return b.has_second(); } };
+struct has_second_paired   { NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool operator()(const BestAlignments& b) { return b.has_second() && b.alignment<1>().is_paired(); }
+                             NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool operator()(const BestPairedAlignments& b) { return b.has_second_paired(); } };
+struct has_second_unpaired { NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool operator()(const BestAlignments& b) { return b.has_second() && b.alignment<1>().is_unpaired(); }
+                             NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool operator()(const BestPairedAlignments& b) { return b.has_second_unpaired(); } };
+#define NVBIO_HIP_ALIGNMENT_PREDICATE(name, test)                                                                            \
+    struct name { NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool operator()(const BestAlignments& b) { const Alignment& a = b.alignment<0>(); return test; } \
+                  NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool operator()(const Alignment& a) { return test; } };
+NVBIO_HIP_ALIGNMENT_PREDICATE(is_paired,         a.is_paired())
+NVBIO_HIP_ALIGNMENT_PREDICATE(is_unpaired,       a.is_unpaired())
+NVBIO_HIP_ALIGNMENT_PREDICATE(is_concordant,     a.is_concordant())
+NVBIO_HIP_ALIGNMENT_PREDICATE(is_discordant,     a.is_discordant())
+NVBIO_HIP_ALIGNMENT_PREDICATE(is_not_concordant, a.is_concordant() == false)      // unpaired or discordant
+NVBIO_HIP_ALIGNMENT_PREDICATE(is_aligned,        a.is_aligned())
+#undef NVBIO_HIP_ALIGNMENT_PREDICATE
+
+/// are two placements different?  Same strand and within `dist` of each other = the same placement (alignments_inl.h:34-136).
+/// The Alignment / PairedAlignments forms compare END positions (alignment() + sink()): valid while the records still hold DP sinks.
+NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool distinct_alignments(const uint32 pos1, const bool rc1, const uint32 pos2, const bool rc2, const uint32 dist)
+{
+    if (rc1 != rc2) return true;
+    const uint32 lo = pos2 - (pos2 < dist ? pos2 : dist);
+    return !(pos1 >= lo && pos1 <= pos2 + dist);
+}
+NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool distinct_alignments(const uint32 apos1, const uint32 opos1, const bool arc1, const bool orc1,
+                                                             const uint32 apos2, const uint32 opos2, const bool arc2, const bool orc2)
+{ return arc1 != arc2 || orc1 != orc2 || apos1 != apos2 || opos1 != opos2; }
+NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool distinct_alignments(const uint32 apos1, const uint32 opos1, const bool arc1, const bool orc1,
+                                                             const uint32 apos2, const uint32 opos2, const bool arc2, const bool orc2, const uint32 dist)
+{ return distinct_alignments(apos1, arc1, apos2, arc2, dist) || distinct_alignments(opos1, orc1, opos2, orc2, dist); }
+NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool distinct_alignments(const Alignment& p1, const Alignment& p2, const uint32 dist = 1)
+{ return distinct_alignments(p1.alignment() + p1.sink(), p1.is_rc(), p2.alignment() + p2.sink(), p2.is_rc(), dist); }
+NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool distinct_alignments(const PairedAlignments& p1, const PairedAlignments& p2)
+{
+    const Alignment a1 = p1.mate(0), o1 = p1.mate(1), a2 = p2.mate(0), o2 = p2.mate(1);
+    return distinct_alignments(a1.alignment() + a1.sink(), o1.alignment() + o1.sink(), a1.is_rc(), o1.is_rc(), a2.alignment() + a2.sink(), o2.alignment() + o2.sink(), a2.is_rc(), o2.is_rc());
+}
+NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool distinct_alignments(const PairedAlignments& p1, const PairedAlignments& p2, const uint32 dist)
+{
+    const Alignment a1 = p1.mate(0), o1 = p1.mate(1), a2 = p2.mate(0), o2 = p2.mate(1);
+    return distinct_alignments(a1.alignment() + a1.sink(), o1.alignment() + o1.sink(), a1.is_rc(), o1.is_rc(), a2.alignment() + a2.sink(), o2.alignment() + o2.sink(), a2.is_rc(), o2.is_rc(), dist);
+}
+
 } // namespace io
+
+template <> struct pod_type<io::Alignment>      { typedef uint2 type; };
+template <> struct pod_type<io::BestAlignments> { typedef uint4 type; };
+
 } // namespace nvbio

@@ -9,8 +9,10 @@
 #include "../../basic/packedstream.h"
 #include "../../basic/vector_view.h"
 #include "../../basic/vector.h"
+#include "../../basic/cuda/ldg.h"
 #include "../../strings/string_set.h"
 #include "../../fasta/fasta.h"
+#include "../../basic/console.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -100,9 +102,17 @@ struct SequenceDataViewCore : public SequenceDataInfo
 };
 typedef SequenceDataViewCore<uint32*, uint32*, char*, char*>                         SequenceDataView;
 typedef SequenceDataViewCore<const uint32*, const uint32*, const char*, const char*> ConstSequenceDataView;
+typedef SequenceDataViewCore<cuda::ldg_pointer<uint32>, cuda::ldg_pointer<uint32>, const char*, const char*> LdgSequenceDataView;
 
-/// the polymorphic base of the containers
-struct SequenceData : public SequenceDataInfo { virtual ~SequenceData() {} };
+/// the polymorphic base of the containers: whatever holds the storage can be looked at through a plain view (sequence.h:414-430)
+struct SequenceData : public SequenceDataInfo
+{
+    typedef SequenceDataView       plain_view_type;
+    typedef ConstSequenceDataView  const_plain_view_type;
+    virtual ~SequenceData() {}
+    virtual operator plain_view_type()             { return plain_view_type(); }
+    virtual operator const_plain_view_type() const { return const_plain_view_type(); }
+};
 
 namespace priv {
 #if defined(__HIPCC__)
@@ -139,6 +149,12 @@ struct SequenceDataStorage : public SequenceData
     SequenceDataStorage() {}
     template <typename other_tag> SequenceDataStorage(const SequenceDataStorage<other_tag>& other) { *this = other; }
     SequenceDataStorage(const SequenceDataStorage& other) : SequenceData() { *this = other; }
+    /// from any container behind the base class: host-side data (loaded or mapped) is seen through its plain view
+    SequenceDataStorage(const SequenceData& other)
+    {
+        if (const SequenceDataStorage* same = dynamic_cast<const SequenceDataStorage*>(&other)) *this = *same;
+        else *this = static_cast<const_plain_view_type>(other);
+    }
     template <typename I, typename S, typename Q, typename N> SequenceDataStorage(const SequenceDataViewCore<I, S, Q, N>& other) { *this = other; }
 
     SequenceDataStorage& operator=(const SequenceDataStorage& other) { return this->template assign_storage<system_tag>(other); }
@@ -160,9 +176,9 @@ struct SequenceDataStorage : public SequenceData
         return *this;
     }
 
-    operator plain_view_type()
+    virtual operator plain_view_type()
     { return plain_view_type(*this, priv::seq_ptr(m_sequence_vec), priv::seq_ptr(m_sequence_index_vec), priv::seq_ptr(m_qual_vec), priv::seq_ptr(m_name_vec), priv::seq_ptr(m_name_index_vec)); }
-    operator const_plain_view_type() const
+    virtual operator const_plain_view_type() const
     { return const_plain_view_type(*this, priv::seq_ptr(m_sequence_vec), priv::seq_ptr(m_sequence_index_vec), priv::seq_ptr(m_qual_vec), priv::seq_ptr(m_name_vec), priv::seq_ptr(m_name_index_vec)); }
 
     /// room for n_seqs sequences of n_bps symbols in total
@@ -207,6 +223,8 @@ typedef SequenceDataStorage<device_tag> SequenceDataDevice;
 
 template <typename system_tag> inline io::SequenceDataView      plain_view(io::SequenceDataStorage<system_tag>& data)       { return io::SequenceDataView(data); }
 template <typename system_tag> inline io::ConstSequenceDataView plain_view(const io::SequenceDataStorage<system_tag>& data) { return io::ConstSequenceDataView(data); }
+inline io::SequenceDataView      plain_view(io::SequenceData& data)                { return io::SequenceDataView(data); }
+inline io::ConstSequenceDataView plain_view(const io::SequenceData& data)          { return io::ConstSequenceDataView(data); }
 inline io::SequenceDataView      plain_view(io::SequenceDataView& view)            { return view; }
 inline io::ConstSequenceDataView plain_view(const io::ConstSequenceDataView& view) { return view; }
 
@@ -235,9 +253,8 @@ struct SequenceDataAccess
     typedef ConcatenatedStringSet<qual_storage_iterator, index_iterator>  qual_string_set_type;
     typedef ConcatenatedStringSet<name_storage_iterator, index_iterator>  name_string_set_type;
 
-    template <typename AnyData>
-    NVBIO_HOST_DEVICE SequenceDataAccess(const AnyData& data)
-        : m_data(data, data.sequence_storage(), data.sequence_index(), data.qual_stream(), data.name_stream(), data.name_index()) {}
+    /// (a container converts to its plain view on the way in: SequenceDataAccess<DNA_N> access( host_or_device_data ))
+    NVBIO_HOST_DEVICE SequenceDataAccess(const SequenceDataT& data) : m_data(data) {}
 
     NVBIO_HOST_DEVICE uint32 size()             const { return m_data.size(); }
     NVBIO_HOST_DEVICE uint32 bps()              const { return m_data.bps(); }
@@ -452,11 +469,93 @@ inline SequenceDataInputStream* open_sequence_file(const char* sequence_file_nam
     return f;
 }
 
-/// load a whole file into `sequence_data`
+namespace priv {
+inline bool file_exists(const std::string& name) { FILE* f = fopen(name.c_str(), "rb"); if (f) fclose(f); return f != NULL; }
+/// a BWA-style packed reference: <prefix>.ann beside <prefix>.pac or <prefix>.wpac (sequence_pac.cpp:225-245)
+inline bool is_pac_archive(const char* prefix)
+{
+    const std::string p(prefix);
+    return file_exists(p + ".ann") && (file_exists(p + ".pac") || file_exists(p + ".wpac"));
+}
+/// load it: names and sequence offsets from .ann (line 1: l_pac n_seqs seed; per sequence "gi name comment" and "offset len n_ambs"), symbols
+/// from .wpac ([uint64 length][2-bit big-endian words]) or .pac (BWA's byte-packed genome, last byte = symbols in the last data byte),
+/// re-packed at the alphabet's width; no qualities (sequence_pac.cpp:60-330, basic/bnt.cpp:83-163)
+inline bool load_pac_archive(const Alphabet alphabet, SequenceDataHost* data, const char* prefix)
+{
+    const std::string p(prefix);
+    FILE* ann = fopen((p + ".ann").c_str(), "r");
+    if (!ann) return false;
+    unsigned long long l_pac = 0; int n_seqs = 0; unsigned seed = 0;
+    if (fscanf(ann, "%llu %d %u", &l_pac, &n_seqs, &seed) != 3 || n_seqs <= 0) { fclose(ann); log_error(stderr, "loading BNS files failed\n"); return false; }
+    static_cast<SequenceDataInfo&>(*data) = SequenceDataInfo();
+    data->m_alphabet = alphabet; data->m_n_seqs = uint32(n_seqs); data->m_sequence_stream_len = uint32(l_pac); data->m_avg_sequence_len = uint32(l_pac / n_seqs);
+    data->m_sequence_index_vec.assign(1, 0u); data->m_name_index_vec.assign(1, 0u); data->m_name_vec.clear(); data->m_qual_vec.clear();
+    char line[8192];
+    (void)fgets(line, sizeof(line), ann);                                                    // rest of the first line
+    for (int i = 0; i < n_seqs; ++i)
+    {
+        if (!fgets(line, sizeof(line), ann)) { fclose(ann); log_error(stderr, "loading BNS files failed\n"); return false; }
+        char* name = strchr(line, ' ');                                                      // "gi name [comment]"
+        name = name ? name + 1 : line;
+        name[strcspn(name, " \n\r")] = 0;
+        data->m_name_vec.insert(data->m_name_vec.end(), name, name + strlen(name) + 1u);
+        data->m_name_index_vec.push_back(uint32(data->m_name_vec.size()));
+        unsigned long long offset = 0; unsigned len = 0, n_ambs = 0;
+        if (!fgets(line, sizeof(line), ann) || sscanf(line, "%llu %u %u", &offset, &len, &n_ambs) != 3) { fclose(ann); log_error(stderr, "loading BNS files failed\n"); return false; }
+        data->m_sequence_index_vec.push_back(uint32(offset + len));
+        data->m_min_sequence_len = std::min(data->m_min_sequence_len, uint32(len));
+        data->m_max_sequence_len = std::max(data->m_max_sequence_len, uint32(len));
+    }
+    fclose(ann);
+    data->m_name_stream_len = uint32(data->m_name_vec.size());
+    data->m_has_qualities = 0u;
+    const uint32 n = uint32(l_pac), bits = bits_per_symbol(alphabet), per_word = 32u / bits;
+    const uint32 seq_words = (n + per_word - 1u) / per_word, aligned_words = (seq_words + 3u) & ~3u;
+    data->m_sequence_stream_words = aligned_words;
+    data->m_sequence_vec.assign(aligned_words, 0u);
+    // the 2-bit symbols, from either file
+    std::vector<uint32> packed((size_t(n) + 15u) / 16u, 0u);
+    FILE* f = fopen((p + ".wpac").c_str(), "rb");
+    if (f)
+    {
+        uint64 len = 0;
+        const bool ok = fread(&len, sizeof(len), 1, f) == 1 && uint32(len) == n && fread(packed.data(), sizeof(uint32), packed.size(), f) == packed.size();
+        fclose(f);
+        if (!ok) { log_error(stderr, "failed reading %s.wpac\n", prefix); return false; }
+    }
+    else
+    {
+        f = fopen((p + ".pac").c_str(), "rb");
+        if (!f) { log_warning(stderr, "unable to open %s.[w]pac\n", prefix); return false; }
+        fseek(f, 0, SEEK_END);
+        const long size = ftell(f);
+        std::vector<uint8> raw(size > 0 ? size_t(size) : 0u);
+        fseek(f, 0, SEEK_SET);
+        const bool ok = size >= 2 && fread(raw.data(), 1, raw.size(), f) == raw.size();
+        fclose(f);
+        // BWA writes ceil(n / 4) data bytes, one zero byte when n is a multiple of 4, then the count byte (n % 4)
+        if (!ok || uint32(size - 1 - (raw[size - 1] == 0 ? 1 : 0)) != (n + 3u) / 4u && uint32(size - 1) != (n + 3u) / 4u)
+        { log_error(stderr, "mismatching sequence lengths in %s.pac\n", prefix); return false; }
+        for (uint32 b = 0; b < (n + 3u) / 4u; ++b) packed[b >> 2] |= uint32(raw[b]) << (24u - 8u * (b & 3u));
+    }
+    uint32* words = priv::seq_ptr(data->m_sequence_vec);
+    if (bits == 2u) std::copy(packed.begin(), packed.end(), words);
+    else
+        for (uint32 i = 0; i < n; ++i)
+        {
+            const uint32 sym = (packed[i >> 4] >> (30u - 2u * (i & 15u))) & 3u;
+            words[i / per_word] |= sym << (32u - bits - (i % per_word) * bits);
+        }
+    return true;
+}
+} // namespace priv
+
+/// load a whole file into `sequence_data`: a packed reference archive (<name>.ann + .pac / .wpac) or a FASTQ / FASTA file
 inline bool load_sequence_file(const Alphabet alphabet, SequenceDataHost* sequence_data, const char* sequence_file_name,
                                const SequenceFlags load_flags = SequenceFlags(SEQUENCE_DATA | SEQUENCE_QUALS | SEQUENCE_NAMES), const QualityEncoding qualities = Phred33)
 {
     (void)load_flags;
+    if (priv::is_pac_archive(sequence_file_name)) return priv::load_pac_archive(alphabet, sequence_data, sequence_file_name);
     SequenceDataInputStream* f = open_sequence_file(sequence_file_name, qualities);
     if (f == NULL) return false;
     const int n = next(alphabet, sequence_data, f, uint32(-1), uint32(-1));
