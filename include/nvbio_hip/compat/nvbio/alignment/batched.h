@@ -698,6 +698,7 @@ private:
         const uint32 n = stream.size();
         if (n == 0) return;
         const priv::limits_scope<stream_type> limits(stream, hs);
+        if (!priv::limits_scope<stream_type>::trusted && priv::maxP_of(stream) == 0u) { m_path = "empty"; return; }
         run_device(stream, hs, std::integral_constant<bool, priv::recognised<stream_type>::value && priv::tuned_band<BAND_LEN>::value>());
 #else
         static_assert(sizeof(any_device_scheduler) == 0, "the device schedulers need a translation unit compiled by hipcc");
@@ -820,6 +821,7 @@ private:
 #if defined(__HIPCC__)
         if (stream.size() == 0) return;
         const priv::limits_scope<stream_type> limits(stream, hs);
+        if (!priv::limits_scope<stream_type>::trusted && priv::maxP_of(stream) == 0u) { m_path = "empty"; return; }
         run_device(stream, temp_size, temp, hs, std::integral_constant<bool, priv::recognised<stream_type>::value>());
 #else
         static_assert(sizeof(any_device_scheduler) == 0, "the device schedulers need a translation unit compiled by hipcc");
@@ -943,6 +945,7 @@ struct traceback_runner
     {
         if (stream.size() == 0) return;
         const limits_scope<stream_type> limits(stream, hs);
+        if (!limits_scope<stream_type>::trusted && maxP_of(stream) == 0u) { m_path = "empty"; return; }       // measured: no job has a valid context, nothing to trace or output
         run_device(stream, hs, std::integral_constant<bool, recognised_tb<stream_type>::value && (BAND_LEN == 0u || tuned_band<BAND_LEN ? BAND_LEN : 3u>::value)>());
     }
     void run_device(const stream_type& stream, hipStream_t hs, std::false_type)
@@ -978,6 +981,8 @@ struct traceback_runner
         uint8* temp = m_temp.reserve(tb + 16u);
         const int err = scheme.traceback(band, stream, t, ps, ts, quals, n_quals, source, cigar, stride, cigar_len, temp, tb, hs);
         if (err == 801) { run_device(stream, hs, std::false_type()); return; }     // e.g. asymmetric linear gaps, values beyond int16
+        if (err != 0) fprintf(stderr, "compat traceback: err %d band %u n %u maxP %u maxT %u stride %u tb %llu quals %p n_quals %llu ps{words %p n %llu bits %u} ts{words %p n %llu}\n", err, band, n, maxP, maxT, stride,
+                              (unsigned long long)tb, (const void*)quals, (unsigned long long)n_quals, (const void*)ps.words, (unsigned long long)ps.n_words, ps.bits, (const void*)ts.words, (unsigned long long)ts.n_words);
         check(err, "nvbio_hip_*_traceback");
         hipLaunchKernelGGL((replay_tracebacks_kernel<stream_type>), dim3((n + 127u) / 128u), dim3(128), 0, hs, stream, t, source, cigar, stride, cigar_len);
         check(hipGetLastError(), "replay_tracebacks_kernel");

@@ -6,6 +6,7 @@ tools/ref_bind_check.py --install-ref-tests -> oracle/_ref/ref_*_test; built in 
                        literals, Gotoh / SW / ED score + traceback checked against the test's own reference DP (ref_sw,
                        ref_banded_sw) and CIGAR literals, then every Batched*AlignmentScore scheduler and the per-thread kernel
   ref_sw_benchmark     sw-benchmark/sw-benchmark.cu, whole TU: the reference's headline benchmark program on synthetic FASTQ / FASTA input
+  ref_nvBowtie         the whole nvBowtie application (29 TUs as they lie + contrib/crc), FASTQ + index files -> SAM
   ref_fmindex_test     nvbio-test/fmindex_test.cu:56-717: SA -> BWT -> occurrence table -> SSA (host, and built on the device from the
                        FM-index alone), match + locate on host and in its device kernel, 32- and 64-bit, separate and interleaved
 
@@ -78,3 +79,70 @@ def test_reference_sw_benchmark_runs(tmp_path):
     assert len(rows) == 4, text[-1500:]                      # Gotoh x 3 + edit distance semi-global
     assert all(float(a) > 0 and float(b) > 0 for _, a, b in rows), rows
     open(os.path.join(ROOT, "gpurun_out", "ref_sw_benchmark.log"), "w").write(text)
+
+
+def _write_reference(tmp_path, rng, n_genome, names_and_lengths):
+    """index + genome + annotation files of a synthetic reference, the way nvBWT leaves them: <prefix>.bwt / .sa / .rbwt / .rsa /
+    .wpac / .ann / .amb (made with the oracle's suffix sorting: test infrastructure)"""
+    import numpy as np
+    from nvbio_amd import io as nio
+    from oracle import pyoracle as O
+    text = rng.integers(0, 4, n_genome, dtype=np.uint8)
+    prefix = str(tmp_path / "genome")
+    nio.save_fmindex(prefix, O.FMIndex(text))
+    nio.save_fmindex(prefix, O.FMIndex(text[::-1].copy()), reverse=True)
+    nio.write_wpac(prefix + ".wpac", text.size, O.pack(text, 2, True))
+    nio.write_bns(prefix, [n for n, _ in names_and_lengths], [l for _, l in names_and_lengths])
+    return prefix, text
+
+
+def test_reference_nvbowtie_runs_end_to_end(tmp_path):
+    """nvBowtie ITSELF -- all 29 translation units of the reference's application compiled as they lie against the drop-in layer and linked
+    with libnvbio_hip.so (tools/nvbowtie_tu_check.py --link) -- aligning a FASTQ file against index files on the MI355X and writing SAM:
+    its own drivers, queues, selection, reduction and reporting code on top of this repository's templates and kernels.  Reads drawn from
+    a two-sequence synthetic reference with 3 % substitutions must come back at their origin, on the right strand, with CIGARs that consume
+    the read, in the reference's tag set."""
+    import re
+    import numpy as np
+    exe = os.path.join(REF, "ref_nvBowtie")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_nvBowtie not built (needs /root/reference in the build container)")
+    rng = np.random.default_rng(3)
+    n_genome = 200_000
+    prefix, text = _write_reference(tmp_path, rng, n_genome, [("chrA", 120_000), ("chrB", 80_000)])
+    n, L = 4000, 100
+    pos = rng.integers(0, n_genome - L, n)
+    pos = np.where((pos < 120_000) & (pos + L > 120_000), pos - L, pos)           # no read across the two sequences
+    fastq = str(tmp_path / "reads.fastq")
+    with open(fastq, "w") as f:
+        for i, p in enumerate(pos):
+            r = text[p:p + L].copy()
+            mut = rng.random(L) < 0.03
+            r[mut] = (r[mut] + 1) & 3
+            if i % 2:
+                r = (3 - r)[::-1]
+            f.write("@read%d\n%s\n+\n%s\n" % (i, "".join("ACGT"[c] for c in r), "I" * L))
+    sam = str(tmp_path / "out.sam")
+    r = subprocess.run([exe, "--file-ref", "-x", prefix, "-U", fastq, "-S", sam] + os.environ.get("NVBOWTIE_EXTRA_ARGS", "").split(), capture_output=True, text=True, timeout=900)
+    log = (r.stdout + r.stderr).replace("\r", "\n")
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    open(os.path.join(ROOT, "gpurun_out", "ref_nvbowtie.log"), "w").write(log[-20000:])
+    assert r.returncode == 0, log[-3000:]
+    lines = [ln.rstrip("\n").split("\t") for ln in open(sam) if not ln.startswith("@")]
+    header = [ln for ln in open(sam) if ln.startswith("@")]
+    assert any(h.startswith("@SQ\tSN:chrA\tLN:120000") for h in header) and any(h.startswith("@SQ\tSN:chrB\tLN:80000") for h in header)
+    assert len(lines) == n, (len(lines), log[-2000:])
+    aligned = [ln for ln in lines if not (int(ln[1]) & 4)]
+    assert len(aligned) > 0.95 * n, len(aligned)
+    good = 0
+    for ln in aligned:
+        i = int(ln[0][4:])
+        consumed = sum(int(k) for k, op in re.findall(r"(\d+)([MIDS])", ln[5]) if op in "MIS")
+        assert consumed == L == len(ln[9])
+        origin = int(pos[i])
+        chrom, off = ("chrA", origin) if origin < 120_000 else ("chrB", origin - 120_000)
+        good += (ln[2] == chrom and int(ln[3]) - 1 == off and bool(int(ln[1]) & 16) == bool(i % 2))
+        tags = set(t.split(":")[0] for t in ln[11:])
+        assert tags == {"NM", "AS", "XM", "XO", "XG", "MD"}
+    assert good > 0.97 * len(aligned), (good, len(aligned))
+    open(os.path.join(ROOT, "gpurun_out", "ref_nvbowtie_sam_head.txt"), "w").write("".join(header) + "\n".join("\t".join(ln) for ln in lines[:20]) + "\n")

@@ -12,10 +12,31 @@
 #include <thrust/detail/config.h>
 #include <thrust/device_vector.h>
 #include <thrust/host_vector.h>
+#include <thrust/copy.h>
+#include <thrust/fill.h>
+#include <thrust/sort.h>
+#include <thrust/scan.h>
+#include <thrust/reduce.h>
+#include <thrust/transform.h>
+#include <thrust/for_each.h>
+#include <thrust/binary_search.h>
+#include <thrust/merge.h>
+#include <thrust/logical.h>
+#include <thrust/iterator/counting_iterator.h>
+#include <thrust/iterator/constant_iterator.h>
+#include <thrust/iterator/transform_iterator.h>
+#include <thrust/iterator/zip_iterator.h>
+#include <rocprim/rocprim.hpp>
+#include <hipcub/hipcub.hpp>
 #if !defined(__CUDACC__)
 #define __CUDACC__ 1
 #define __CUDACC_VER_MAJOR__ 12
 #define __CUDACC_VER_MINOR__ 0
+#endif
+// ... and `#if defined(__CUDA_ARCH__) && __CUDA_ARCH__ > 0` meaning "this is the device pass" (seed_hit_deque_array_inl.h:80: without it
+// alloc_deque() compiles to `return NULL` and no seed hit is ever stored).  Same rule: defined after the toolchain's own headers.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__CUDA_ARCH__)
+#define __CUDA_ARCH__ 900
 #endif
 #define cudaSetDevice               hipSetDevice
 #define cudaGetDeviceCount          hipGetDeviceCount
