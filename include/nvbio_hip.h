@@ -687,12 +687,15 @@ int nvbio_hip_traceback_best_setup(uint32_t n, const uint32_t* idx /* nullable *
  *     out_mds_len[i] its length (bytes beyond mds_stride are counted, not stored);
  *   - the alignment best_alignments[idx ? idx[i] : i] rewritten: m_align = the text's begin, m_ed = mismatches + inserted / deleted
  *     symbols (soft clips excluded), m_score = sum over the SUBSTITUTION columns of scoring_scheme.score (scoring.h:301-311):
- *     -n_penalty when the read symbol is N, else match or mismatch_by_quality[q] (host table of -m_mmp(q)).
+ *     -n_penalty when the read symbol is N, else match or mismatch_by_quality[q] (host table of -m_mmp(q)); minus, per INSERTION run of
+ *     l read symbols, cumulative_deletion(l) = -(text_gap_open + (l - 1) text_gap_ext), and per DELETION run cumulative_insertion(l) =
+ *     -(pattern_gap_open + (l - 1) pattern_gap_ext) (traceback_inl.h:664-665).  gap_costs (host, 4 ints): pattern_gap_open, pattern_gap_ext,
+ *     text_gap_open, text_gap_ext as nvbio_hip_gotoh_qual_scheme holds them (<= 0).
  * Jobs with valid 0, no CIGAR, or a CIGAR longer than cigar_stride are skipped (out_mds_len 0, alignment untouched). */
 int nvbio_hip_finish_alignment(uint32_t n, const uint8_t* valid, const nvbio_hip_string_set* patterns, const uint8_t* quals /* nullable */, uint64_t n_quals,
                                const nvbio_hip_string_set* texts, const uint16_t* cigar, uint32_t cigar_stride, const uint32_t* cigar_len,
                                const uint32_t* cigar_source /* uint2[n] */, int32_t match, const int32_t* mismatch_by_quality /* host, 256 */, int32_t n_penalty,
-                               const uint32_t* idx /* nullable */, uint64_t* best_alignments, uint8_t* out_mds, uint32_t mds_stride, uint32_t* out_mds_len, void* stream);
+                               const int32_t* gap_costs /* host, 4 */, const uint32_t* idx /* nullable */, uint64_t* best_alignments, uint8_t* out_mds, uint32_t mds_stride, uint32_t* out_mds_len, void* stream);
 
 /* ---- all-mapping mode (Aligner::all / score_all, nvBowtie/bowtie2/cuda/aligner_all.h:47-694) ----
  * Every row of every SA range in every read's hit deque is located, de-duplicated, extended, and reported when its score reaches

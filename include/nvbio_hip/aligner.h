@@ -329,7 +329,7 @@ private:
             });
             const nvbio_hip_string_set p = patterns.abi(), t = texts.abi();
             hip_check(nvbio_hip_finish_alignment(nb, valid.data(), &p, reads.quals, reads.n_quals, &t, reinterpret_cast<const uint16*>(cigar.data() + off * cigar_stride), cigar_stride,
-                                                 cigar_len.data() + off, cigar_source.data() + 2u * off, sc.match, sc.mismatch, 1, nullptr, a,
+                                                 cigar_len.data() + off, cigar_source.data() + 2u * off, sc.match, sc.mismatch, 1, &sc.pattern_gap_open, nullptr, a,
                                                  mds.data() + off * mds_stride, mds_stride, mds_len.data() + off, hip_stream), "nvbio_hip_finish_alignment");
             hip::synchronize(hip_stream);
         }
@@ -430,7 +430,7 @@ private:
                 const nvbio_hip_gotoh_qual_scheme sc = scoring_scheme.abi();
                 const nvbio_hip_string_set p = patterns.abi(), t = texts.abi();
                 hip_check(nvbio_hip_finish_alignment(count, valid.data(), &p, reads.quals, reads.n_quals, &t, reinterpret_cast<const uint16*>(cigar.data()), cigar_stride,
-                                                     cigar_len.data(), cigar_source.data(), sc.match, sc.mismatch, 1 /* m_np = ConstantCost(1,1) */, nullptr,
+                                                     cigar_len.data(), cigar_source.data(), sc.match, sc.mismatch, 1 /* m_np = ConstantCost(1,1) */, &sc.pattern_gap_open, nullptr,
                                                      reinterpret_cast<uint64*>(best_data_dvec.data()), mds.data(), mds_stride, mds_len.data(), hip_stream),
                           "nvbio_hip_finish_alignment");
                 hip::synchronize(hip_stream);
@@ -611,7 +611,7 @@ private:
             const PackedStringSetView<2, true> texts(n_jobs, genome_words, genome_n_words, tb_txt.data(), tb_len.data(), 0u);
             const nvbio_hip_string_set p = patterns.abi(), t = texts.abi();
             hip_check(nvbio_hip_finish_alignment(n_jobs, v, &p, reads.both_quals, reads.both_n_quals, &t, reinterpret_cast<const uint16*>(cg), cigar_stride, cg_len, src,
-                                                 sc.match, sc.mismatch, 1, idx, slots, md, mds_stride, md_len, hip_stream), "nvbio_hip_finish_alignment");
+                                                 sc.match, sc.mismatch, 1, &sc.pattern_gap_open, idx, slots, md, mds_stride, md_len, hip_stream), "nvbio_hip_finish_alignment");
         };
 
         banded_tb(best, 0, valid, cigar.data(), cigar_len.data(), cigar_source.data(), cigar_sink.data(), traceback_score.data());

@@ -173,7 +173,7 @@ def lib():
         L.nvbio_hip_mark_unaligned.argtypes = [u32, vp, vp, vp, vp]
         L.nvbio_hip_copy_flagged_temp_bytes.argtypes = [u32]; L.nvbio_hip_copy_flagged_temp_bytes.restype = u64
         L.nvbio_hip_copy_flagged.argtypes = [u32, vp, vp, vp, vp, vp, u64, vp]
-        L.nvbio_hip_finish_alignment.argtypes = [u32, vp, P(StringSetStruct), vp, u64, P(StringSetStruct), vp, u32, vp, vp, i32, vp, i32, vp, vp, vp, u32, vp, vp]
+        L.nvbio_hip_finish_alignment.argtypes = [u32, vp, P(StringSetStruct), vp, u64, P(StringSetStruct), vp, u32, vp, vp, i32, vp, i32, vp, vp, vp, vp, u32, vp, vp]
         L.nvbio_hip_traceback_best_setup.argtypes = [u32, vp, vp, u32, u32, vp, vp, u32, u64, u64, i32, vp, vp, vp, vp, vp, vp]
         L.nvbio_hip_score_reduce_paired.argtypes = [u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, i32, i32, i32, vp, vp, u32, vp]
         L.nvbio_hip_opposite_mate_windows.argtypes = [u32, vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, u32, i32, vp, i32, i32, P(PeParamsStruct),

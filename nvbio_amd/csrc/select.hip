@@ -820,15 +820,15 @@ NVB_API int nvbio_hip_traceback_best_setup(uint32_t n, const uint32_t* idx, cons
 // finish_alignment_kernel (traceback_inl.h:523-722) + BestTracebackStream::finish (:177-189): one lane replays its alignment's
 // CIGAR (stored end first) over the read and its genome window and emits the MD string in nvbio's byte code (io::MDS_OP:
 // [len lo, len hi] then {MATCH, run <= 255} / {MISMATCH, read symbol} / {INSERTION | DELETION, length byte, symbols...}), the
-// edit distance (clips not counted) and the final score = scoring_scheme.score() summed over the SUBSTITUTION columns only
-// (scoring.h:301-311), then rewrites the alignment: m_align = window begin, m_ed, m_score.  A streaming pass over ~100 bytes
+// edit distance (clips not counted) and the final score = scoring_scheme.score() summed over the SUBSTITUTION columns (scoring.h:301-311)
+// minus cumulative_deletion(l) per INSERTION run and cumulative_insertion(l) per DELETION run (traceback_inl.h:664-665), then rewrites the alignment: m_align = window begin, m_ed, m_score.  A streaming pass over ~100 bytes
 // per read.  A CIGAR that overflowed its slots cannot be replayed: skipped (mds_len 0, alignment untouched).
 namespace nvb {
 
 struct FinishParams {
     uint32_t n; const uint8_t* valid; StringSet pat, txt; const uint8_t* quals; uint64_t n_quals;
     const uint16_t* cigar; uint32_t cigar_stride; const uint32_t* cigar_len; const uint2* cigar_source;
-    int32_t match, n_penalty; int32_t mismatch[256];
+    int32_t match, n_penalty; int32_t gaps[4]; int32_t mismatch[256];
     const uint32_t* idx; uint2* best; uint8_t* mds; uint32_t mds_stride; uint32_t* mds_len;
 };
 
@@ -887,6 +887,10 @@ __global__ void __launch_bounds__(256) finish_alignment_kernel(const FinishParam
                 if (t != 3u) ++ed;
             }
         }
+        // a run of l inserted read symbols costs cumulative_deletion(l) = ref_gap_const + ref_gap_coeff * l = -(text_gap_open + (l - 1) * text_gap_ext),
+        // a run of l deleted genome symbols cumulative_insertion(l), the pattern-gap twin (scoring.h:319-329; the names are crossed in the reference)
+        if (t == 1u && l)      score += p.gaps[2] + int32_t(l - 1u) * p.gaps[3];
+        else if (t == 2u && l) score += p.gaps[0] + int32_t(l - 1u) * p.gaps[1];
     }
     close_run();
     if (p.mds_stride >= 2u) { mds[0] = uint8_t(mds_len & 0xFFu); mds[1] = uint8_t(mds_len >> 8); }
@@ -901,11 +905,11 @@ __global__ void __launch_bounds__(256) finish_alignment_kernel(const FinishParam
 
 NVB_API int nvbio_hip_finish_alignment(uint32_t n, const uint8_t* valid, const nvbio_hip_string_set* patterns, const uint8_t* quals, uint64_t n_quals,
                                        const nvbio_hip_string_set* texts, const uint16_t* cigar, uint32_t cigar_stride, const uint32_t* cigar_len,
-                                       const uint32_t* cigar_source, int32_t match, const int32_t* mismatch_by_quality, int32_t n_penalty,
+                                       const uint32_t* cigar_source, int32_t match, const int32_t* mismatch_by_quality, int32_t n_penalty, const int32_t* gap_costs,
                                        const uint32_t* idx, uint64_t* best_alignments, uint8_t* out_mds, uint32_t mds_stride, uint32_t* out_mds_len, void* stream)
 {
     if (n == 0) return hipSuccess;
-    if (!valid || !patterns || !texts || !cigar || !cigar_len || !cigar_source || !mismatch_by_quality || !best_alignments || !out_mds || !out_mds_len ||
+    if (!valid || !patterns || !texts || !cigar || !cigar_len || !cigar_source || !mismatch_by_quality || !gap_costs || !best_alignments || !out_mds || !out_mds_len ||
         cigar_stride == 0 || mds_stride < 2) return hipErrorInvalidValue;
     if (!(patterns->bits == 2 || patterns->bits == 4) || texts->bits != 2) return hipErrorNotSupported;
     if (!patterns->words || !patterns->begin || !texts->words || !texts->begin) return hipErrorInvalidValue;
@@ -913,6 +917,7 @@ NVB_API int nvbio_hip_finish_alignment(uint32_t n, const uint8_t* valid, const n
     p.n = n; p.valid = valid; p.pat = make_string_set(patterns); p.txt = make_string_set(texts); p.quals = quals; p.n_quals = n_quals;
     p.cigar = cigar; p.cigar_stride = cigar_stride; p.cigar_len = cigar_len; p.cigar_source = reinterpret_cast<const uint2*>(cigar_source);
     p.match = match; p.n_penalty = n_penalty;
+    for (int i = 0; i < 4; ++i) p.gaps[i] = gap_costs[i];
     for (int i = 0; i < 256; ++i) p.mismatch[i] = mismatch_by_quality[i];
     p.idx = idx; p.best = reinterpret_cast<uint2*>(best_alignments); p.mds = out_mds; p.mds_stride = mds_stride; p.mds_len = out_mds_len;
     g_last_kernel = "finish_alignment_kernel";

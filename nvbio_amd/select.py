@@ -270,9 +270,10 @@ def finish_alignment(valid, patterns, quals, texts, cigar, cigar_len, source, sc
     mds_len = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
     st = scheme.struct()
     lut = (C.c_int32 * 256)(*[st.mismatch[q] for q in range(256)])
+    gaps = (C.c_int32 * 4)(st.pattern_gap_open, st.pattern_gap_ext, st.text_gap_open, st.text_gap_ext)
     ps, ts = patterns.struct(), texts.struct()
     check(lib().nvbio_hip_finish_alignment(n, _vp(valid), C.byref(ps), _vp(quals), quals.numel() if quals is not None else 0, C.byref(ts), _vp(cigar), cigar.shape[1],
-                                           _vp(cigar_len), _vp(source), int(scheme.m_match), lut, int(getattr(scheme, "m_n_penalty", 1)), _vp(idx), _vp(best_data),
+                                           _vp(cigar_len), _vp(source), int(scheme.m_match), lut, int(getattr(scheme, "m_n_penalty", 1)), gaps, _vp(idx), _vp(best_data),
                                            _vp(mds), mds_stride, _vp(mds_len), current_stream_ptr()), "nvbio_hip_finish_alignment")
     return mds, mds_len[:n]
 

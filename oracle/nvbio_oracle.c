@@ -2524,8 +2524,12 @@ ORACLE_API void oracle_mark_discordant(uint32_t n_reads, uint64_t* best, uint64_
 /* <= 255} / {MISMATCH, read symbol} / {INSERTION|DELETION, length byte, symbols */
 /* ...}), its edit distance (mismatches + inserted / deleted symbols, clips not   */
 /* counted) and its final score -- the sum of scoring_scheme.score() over the     */
-/* SUBSTITUTION columns only (scoring.h:301-311: N penalty if the read symbol is  */
-/* > 3, else match bonus or the quality's mismatch penalty) -- and the alignment  */
+/* SUBSTITUTION columns (scoring.h:301-311: N penalty if the read symbol is > 3,  */
+/* else match bonus or the quality's mismatch penalty) MINUS, per INSERTION run   */
+/* of l read symbols, cumulative_deletion(l) = ref_gap_const + ref_gap_coeff * l, */
+/* and per DELETION run cumulative_insertion(l) (traceback_inl.h:664-665; round 4 */
+/* found the two subtractions missing here by running nvBowtie's own compiled     */
+/* finish_alignment_kernel beside this restatement) -- and the alignment          */
 /* rewritten by BestTracebackStream::finish (:177-189): m_align = window begin,   */
 /* m_ed, m_score.  CIGAR words are stored end first.  A CIGAR that overflowed its */
 /* slots cannot be replayed: the job is skipped (mds_len 0, alignment untouched). */
@@ -2534,8 +2538,8 @@ ORACLE_API void oracle_finish_alignment(uint32_t n, const uint8_t* valid,
     const uint32_t* pw, uint32_t pbits, uint32_t pbe, const uint64_t* pbegin, const uint32_t* plen, const uint8_t* quals, uint64_t n_quals,
     const uint32_t* tw, uint32_t tbe, const uint64_t* tbegin, const uint32_t* tlen,
     const uint16_t* cigar, uint32_t cigar_stride, const uint32_t* cigar_len, const uint32_t* cigar_source /* 2n */,
-    int32_t match, const int32_t* mismatch_lut, int32_t n_penalty, const uint32_t* idx /* nullable */, uint64_t* best,
-    uint8_t* out_mds, uint32_t mds_stride, uint32_t* out_mds_len)
+    int32_t match, const int32_t* mismatch_lut, int32_t n_penalty, const int32_t* gap_costs /* pattern open, ext, text open, ext (<= 0) */,
+    const uint32_t* idx /* nullable */, uint64_t* best, uint8_t* out_mds, uint32_t mds_stride, uint32_t* out_mds_len)
 {
     for (uint32_t w = 0; w < n; ++w)
     {
@@ -2573,6 +2577,8 @@ ORACLE_API void oracle_finish_alignment(uint32_t n, const uint8_t* valid,
                     if (t != 3u) ++ed;
                 }
             }
+            if (t == 1u && l)      score += gap_costs[2] + (int32_t)(l - 1u) * gap_costs[3];      /* -cumulative_deletion(l): the reference gap (text) costs */
+            else if (t == 2u && l) score += gap_costs[0] + (int32_t)(l - 1u) * gap_costs[1];      /* -cumulative_insertion(l): the read gap (pattern) costs */
         }
         #undef MDS_PUSH
         if (mds_stride >= 2) { mds[0] = (uint8_t)(mds_len & 0xFF); mds[1] = (uint8_t)(mds_len >> 8); }

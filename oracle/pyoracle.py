@@ -764,8 +764,9 @@ def mark_discordant(best, best_o):
     lib().oracle_mark_discordant(C.c_uint32(best.shape[1]), _p(best), _p(best_o), C.c_uint32(best.shape[1]))
 
 
-def finish_alignment(valid, patterns, quals, texts, cigar, cigar_len, source, match, mismatch_lut, n_penalty, best_row, idx=None, mds_stride=256):
-    """finish_alignment_kernel over n jobs: returns (mds uint8[n, stride], mds_len uint32[n]) and rewrites best_row[idx[i] | i] in place."""
+def finish_alignment(valid, patterns, quals, texts, cigar, cigar_len, source, match, mismatch_lut, n_penalty, best_row, idx=None, mds_stride=256, gap_costs=(-8, -3, -8, -3)):
+    """finish_alignment_kernel over n jobs: returns (mds uint8[n, stride], mds_len uint32[n]) and rewrites best_row[idx[i] | i] in place.
+    gap_costs = (pattern_gap_open, pattern_gap_ext, text_gap_open, text_gap_ext) of the scheme; the default is nvBowtie's (5 + 3, 3) twice."""
     n = len(patterns)
     mds = np.zeros((max(n, 1), mds_stride), dtype=np.uint8); mds_len = np.zeros(n, dtype=np.uint32)
     cg = np.ascontiguousarray(cigar, dtype=np.uint16)
@@ -774,7 +775,7 @@ def finish_alignment(valid, patterns, quals, texts, cigar, cigar_len, source, ma
                                   _p(patterns.begin), _p(patterns.length), _p(q), C.c_uint64(q.size if q is not None else 0),
                                   _p(texts.words), C.c_uint32(texts.big_endian), _p(texts.begin), _p(texts.length),
                                   _p(cg), C.c_uint32(cg.shape[1]), _p(_u32(cigar_len)), _p(_u32(source)),
-                                  C.c_int32(match), _p(np.ascontiguousarray(mismatch_lut, dtype=np.int32)), C.c_int32(n_penalty),
+                                  C.c_int32(match), _p(np.ascontiguousarray(mismatch_lut, dtype=np.int32)), C.c_int32(n_penalty), _p(np.ascontiguousarray(gap_costs, dtype=np.int32)),
                                   _p(_u32(idx)) if idx is not None else None, _p(best_row), _p(mds), C.c_uint32(mds_stride), _p(mds_len))
     return mds, mds_len
 

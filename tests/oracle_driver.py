@@ -96,7 +96,7 @@ def best_approx(host_fmi, host_rfmi, sym, genome_words, genome_len, params, sche
         if finish:                                       # finish_alignment_best (traceback_inl.h:523-760)
             out["best_scored"] = best.copy()
             mds, mds_len = O.finish_alignment(np.ones(ids.size, np.uint8), pat, quals, txt, r["cigar"][: ids.size], r["cigar_len"], r["source"], scheme.m_match, lut, 1,
-                                              best[0], idx=ids, mds_stride=mds_stride)
+                                              best[0], idx=ids, mds_stride=mds_stride, gap_costs=(scheme.pattern_gap_open(), scheme.pattern_gap_extension(), scheme.text_gap_open(), scheme.text_gap_extension()))
             out["mds"] = np.zeros((n, mds_stride), np.uint8); out["mds"][ids] = mds[: ids.size]
             out["mds_len"] = np.zeros(n, np.uint32); out["mds_len"][ids] = mds_len
     return out
@@ -205,7 +205,7 @@ def best_approx_paired(host_fmi, host_rfmi, sym1, sym2, genome_words, genome_len
             if finish:                                   # finish_alignment_best / finish_opposite_alignment_best on this slot
                 txt = O.StringSet(genome_words, 2, True, np.array([tb0], np.uint64), np.array([tb1 - tb0], np.uint32))
                 m, ml = O.finish_alignment(np.ones(1, np.uint8), pat, quals, txt, r["cigar"][:1], r["cigar_len"], r["source"], scheme.m_match, lut, 1, data[0],
-                                           idx=np.array([i], np.uint32), mds_stride=mds_stride)
+                                           idx=np.array([i], np.uint32), mds_stride=mds_stride, gap_costs=(scheme.pattern_gap_open(), scheme.pattern_gap_extension(), scheme.text_gap_open(), scheme.text_gap_extension()))
                 res["mds"][i] = m[0]; res["mds_len"][i] = ml[0]
         return res
 
@@ -297,6 +297,6 @@ def all_mapping(host_fmi, host_rfmi, sym, genome_words, genome_len, params, sche
         r = O.batch_banded_gotoh_traceback(band, aln_type, sch6[:5], pat, txt, cigar_stride, mm_lut=lut, quals=quals)
         fin = aln.copy()
         mds, mds_len = O.finish_alignment(np.ones(m, np.uint8), pat, quals, txt, r["cigar"][:m], r["cigar_len"], r["source"], scheme.m_match, lut, 1, fin,
-                                          mds_stride=mds_stride)
+                                          mds_stride=mds_stride, gap_costs=(scheme.pattern_gap_open(), scheme.pattern_gap_extension(), scheme.text_gap_open(), scheme.text_gap_extension()))
         out.update(alignments=fin, tb=r, mds=mds[:m], mds_len=mds_len)
     return out

@@ -96,6 +96,31 @@ def _write_reference(tmp_path, rng, n_genome, names_and_lengths):
     return prefix, text
 
 
+def _simulated_run(tmp_path, seed, n, L, indel_rate=0.0):
+    """a two-sequence 200 kbp reference on disk and a FASTQ file of n reads of L bases drawn from it: 3 % substitutions, every other read
+    reverse-complemented, and with indel_rate a one- or two-base insertion or deletion in the middle of a read"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    n_genome = 200_000
+    prefix, text = _write_reference(tmp_path, rng, n_genome, [("chrA", 120_000), ("chrB", 80_000)])
+    pos = rng.integers(0, n_genome - L - 4, n)
+    pos = np.where((pos < 120_000) & (pos + L + 4 > 120_000), pos - L - 4, pos)   # no read across the two sequences
+    fastq = str(tmp_path / "reads.fastq")
+    with open(fastq, "w") as f:
+        for i, p in enumerate(pos):
+            r = text[p:p + L].copy()
+            if rng.random() < indel_rate:
+                k, g = int(rng.integers(30, 70)), int(rng.integers(1, 3))
+                if rng.random() < 0.5: r = np.concatenate([r[:k], rng.integers(0, 4, g).astype(np.uint8), r[k:]])[:L]      # insertion in the read
+                else:                  r = np.concatenate([text[p:p + k], text[p + k + g:p + L + g]])                    # deletion from the read
+            mut = rng.random(L) < 0.03
+            r[mut] = (r[mut] + 1) & 3
+            if i % 2:
+                r = (3 - r)[::-1]
+            f.write("@read%d\n%s\n+\n%s\n" % (i, "".join("ACGT"[c] for c in r), "I" * L))
+    return prefix, fastq, pos
+
+
 def test_reference_nvbowtie_runs_end_to_end(tmp_path):
     """nvBowtie ITSELF -- all 29 translation units of the reference's application compiled as they lie against the drop-in layer and linked
     with libnvbio_hip.so (tools/nvbowtie_tu_check.py --link) -- aligning a FASTQ file against index files on the MI355X and writing SAM:
@@ -107,21 +132,8 @@ def test_reference_nvbowtie_runs_end_to_end(tmp_path):
     exe = os.path.join(REF, "ref_nvBowtie")
     if not os.path.exists(exe):
         pytest.skip("oracle/_ref/ref_nvBowtie not built (needs /root/reference in the build container)")
-    rng = np.random.default_rng(3)
-    n_genome = 200_000
-    prefix, text = _write_reference(tmp_path, rng, n_genome, [("chrA", 120_000), ("chrB", 80_000)])
     n, L = 4000, 100
-    pos = rng.integers(0, n_genome - L, n)
-    pos = np.where((pos < 120_000) & (pos + L > 120_000), pos - L, pos)           # no read across the two sequences
-    fastq = str(tmp_path / "reads.fastq")
-    with open(fastq, "w") as f:
-        for i, p in enumerate(pos):
-            r = text[p:p + L].copy()
-            mut = rng.random(L) < 0.03
-            r[mut] = (r[mut] + 1) & 3
-            if i % 2:
-                r = (3 - r)[::-1]
-            f.write("@read%d\n%s\n+\n%s\n" % (i, "".join("ACGT"[c] for c in r), "I" * L))
+    prefix, fastq, pos = _simulated_run(tmp_path, 3, n, L)
     sam = str(tmp_path / "out.sam")
     r = subprocess.run([exe, "--file-ref", "-x", prefix, "-U", fastq, "-S", sam] + os.environ.get("NVBOWTIE_EXTRA_ARGS", "").split(), capture_output=True, text=True, timeout=900)
     log = (r.stdout + r.stderr).replace("\r", "\n")
@@ -146,3 +158,37 @@ def test_reference_nvbowtie_runs_end_to_end(tmp_path):
         assert tags == {"NM", "AS", "XM", "XO", "XG", "MD"}
     assert good > 0.97 * len(aligned), (good, len(aligned))
     open(os.path.join(ROOT, "gpurun_out", "ref_nvbowtie_sam_head.txt"), "w").write("".join(header) + "\n".join("\t".join(ln) for ln in lines[:20]) + "\n")
+
+
+def test_own_pipeline_equals_reference_nvbowtie(tmp_path, cuda):
+    """The strongest parity statement this repository can make: the reference's nvBowtie APPLICATION -- its own drivers, queues, selection,
+    reduction, MAPQ, traceback and finishing code, compiled unchanged on top of the drop-in layer -- and this repository's from-scratch
+    driver (nvbio_amd.aligner.best_approx over the C-ABI, tools/align_fastq.py) align the same FASTQ file against the same index files, and
+    every SAM record agrees: position, strand, MAPQ, CIGAR, sequence, and the NM / AS / XM / XO / XG / MD tags.  A quarter of the reads carry an
+    indel so that gapped alignments (where the two once disagreed on AS: the gap costs missing from finish_alignment's restatement) are compared."""
+    import io as _io
+    import sys
+    exe = os.path.join(REF, "ref_nvBowtie")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_nvBowtie not built (needs /root/reference in the build container)")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import align_fastq
+    n, L = 6000, 100
+    prefix, fastq, pos = _simulated_run(tmp_path, 17, n, L, indel_rate=0.25)
+    sam = str(tmp_path / "ref.sam")
+    r = subprocess.run([exe, "--file-ref", "-x", prefix, "-U", fastq, "-S", sam], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    ref = [ln.rstrip("\n").split("\t") for ln in open(sam) if not ln.startswith("@")]
+    buf = _io.StringIO()
+    align_fastq.main(prefix, fastq, buf, device=cuda)
+    own = [ln.split("\t") for ln in buf.getvalue().splitlines() if not ln.startswith("@")]
+    assert len(ref) == len(own) == n
+    differ = []
+    gapped = 0
+    for a, b in zip(ref, own):
+        a = list(a); a[1] = str(int(a[1]) & ~64)              # nvBowtie flags single-end reads READ_1 (output_sam.cpp:431); the example writer does not
+        gapped += ("I" in a[5] or "D" in a[5])
+        if a != b:
+            differ.append((a[:6] + a[11:], b[:6] + b[11:]))
+    assert gapped > 0.15 * n, gapped
+    assert not differ, (len(differ), differ[:3])
