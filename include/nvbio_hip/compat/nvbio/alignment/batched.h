@@ -34,6 +34,7 @@
 #include <stdexcept>
 #include <algorithm>
 #include <stdlib.h>
+#include <string.h>
 #include <string>
 #include <vector>
 #include <type_traits>
@@ -63,6 +64,22 @@ struct hip_error : public std::runtime_error {
 };
 
 namespace priv {
+/// A job's context, starting from all-zero bytes.  The reference declares its contexts uninitialised, and nvBowtie's BestAnchorScoreStream
+/// reads context->min_score before writing it (score_paired_inl.h:150: `skip = ... || (context->min_score > a_optimal_score)`): whether a
+/// hit is skipped then depends on what the register held.  This layer evaluates init_context in up to three kernels per batch (lengths,
+/// job description, output), so the three must agree: every context is built over zeroed storage, which makes that test deterministic
+/// (false, as it is for the zero a fresh CUDA local usually holds).
+template <typename C>
+struct fresh_context
+{
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE fresh_context() { for (unsigned i = 0; i < sizeof(C); ++i) raw[i] = 0; new (raw) C; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE ~fresh_context() { get().~C(); }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE C& get() { return *reinterpret_cast<C*>(raw); }
+    alignas(C) unsigned char raw[sizeof(C)];
+};
+} // namespace priv
+
+namespace priv {
 
 inline void check(const int err, const char* what) { if (err != 0) throw hip_error(what, err); }
 
@@ -70,7 +87,7 @@ inline void check(const int err, const char* what) { if (err != 0) throw hip_err
 template <uint32 BAND_LEN, typename stream_type>
 NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void banded_job(const stream_type& stream, const uint32 i)
 {
-    typename stream_type::context_type ctx;
+    priv::fresh_context<typename stream_type::context_type> ctx_storage; typename stream_type::context_type& ctx = ctx_storage.get();
     typename stream_type::strings_type strings;
     if (!stream.init_context(i, &ctx)) return;
     const uint32 len = stream.pattern_length(i, &ctx);
@@ -81,7 +98,7 @@ NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void banded_job(const stream_type& stream, c
 template <typename stream_type>
 NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void full_job(const stream_type& stream, const uint32 i, int16* column)
 {
-    typename stream_type::context_type ctx;
+    priv::fresh_context<typename stream_type::context_type> ctx_storage; typename stream_type::context_type& ctx = ctx_storage.get();
     typename stream_type::strings_type strings;
     if (!stream.init_context(i, &ctx)) return;
     const uint32 len = stream.pattern_length(i, &ctx);
@@ -218,6 +235,8 @@ template <typename stream_type> struct recognised_tb : recognition<stream_type, 
 /// read batch does not have (score_best_inl.h:80) and only compiles in the reference because DeviceThreadScheduler never instantiates it.
 /// For every stream that is not `zero_copy` the two lengths are therefore MEASURED -- one light pass over init_context / pattern_length /
 /// text_length -- and published for the duration of the enact() call through limits_scope; code below reads them with maxP_of / maxT_of.
+/// NVBIO_HIP_COMPAT_GENERIC=<names> (test switch): run the named batch classes -- "banded", "full", "traceback" -- on the generic lane code
+inline bool forced_generic(const char* name) { const char* e = getenv("NVBIO_HIP_COMPAT_GENERIC"); return e && strstr(e, name) != NULL; }
 struct stream_limits { const void* stream; uint32 maxP, maxT; };
 inline stream_limits& current_limits() { static thread_local stream_limits l = { NULL, 0u, 0u }; return l; }
 template <typename stream_type> inline uint32 maxP_of(const stream_type& s) { const stream_limits& l = current_limits(); if (l.stream != &s) throw std::logic_error("batched: stream limits read outside an enact() scope"); return l.maxP; }
@@ -226,7 +245,7 @@ template <typename stream_type> inline uint32 maxT_of(const stream_type& s) { co
 template <typename stream_type>
 NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void job_lengths(const stream_type& stream, const uint32 i, uint32& pl, uint32& tl)
 {
-    typename stream_type::context_type ctx;
+    priv::fresh_context<typename stream_type::context_type> ctx_storage; typename stream_type::context_type& ctx = ctx_storage.get();
     pl = tl = 0;
     if (stream.init_context(i, &ctx)) { pl = stream.pattern_length(i, &ctx); tl = stream.text_length(i, &ctx); }
 }
@@ -353,7 +372,7 @@ __global__ void __launch_bounds__(128) describe_jobs_kernel(const stream_type st
     for (uint64 gt = uint64(blockIdx.x) * 128u + threadIdx.x; gt < total; gt += uint64(gridDim.x) * 128u)
     {
         const uint32 i = uint32(gt / G), j = uint32(gt % G);
-        typename stream_type::context_type ctx;
+        priv::fresh_context<typename stream_type::context_type> ctx_storage; typename stream_type::context_type& ctx = ctx_storage.get();
         typename stream_type::strings_type strings;
         uint32 pl = 0, tl = 0; uint64 pw = 0, tw = 0; uint32 pf = 0, tf = 0; int32 ms = 0;
         if (stream.init_context(i, &ctx))
@@ -430,7 +449,7 @@ __global__ void __launch_bounds__(256) describe_views_kernel(const stream_type s
     const uint32 n = stream.size();
     for (uint32 i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
     {
-        typename stream_type::context_type ctx;
+        priv::fresh_context<typename stream_type::context_type> ctx_storage; typename stream_type::context_type& ctx = ctx_storage.get();
         typename stream_type::strings_type strings;
         uint32 pl = 0, tl = 0, tf = 0, fl = 0; uint64 ps = 0, tw = 0; int32 ms = 0;
         if (stream.init_context(i, &ctx))
@@ -474,7 +493,7 @@ __global__ void __launch_bounds__(128) output_jobs_kernel(const stream_type stre
 {
     const uint32 i = blockIdx.x * 128u + threadIdx.x;
     if (i >= stream.size()) return;
-    typename stream_type::context_type ctx;
+    priv::fresh_context<typename stream_type::context_type> ctx_storage; typename stream_type::context_type& ctx = ctx_storage.get();
     if (!stream.init_context(i, &ctx)) return;
     const uint2 k = make_uint2(t.sink[2u * i], t.sink[2u * i + 1u]);
     if (!(k.x == 0xFFFFFFFFu && k.y == 0xFFFFFFFFu)) { ctx.sink.score = t.score[i]; ctx.sink.sink = k; }
@@ -490,7 +509,7 @@ __global__ void __launch_bounds__(128) replay_tracebacks_kernel(stream_type stre
 {
     const uint32 i = blockIdx.x * 128u + threadIdx.x;
     if (i >= stream.size()) return;
-    typename stream_type::context_type ctx;
+    priv::fresh_context<typename stream_type::context_type> ctx_storage; typename stream_type::context_type& ctx = ctx_storage.get();
     if (!stream.init_context(i, &ctx)) { stream.output(i, &ctx); return; }
     const uint2 snk = make_uint2(t.sink[2u * i], t.sink[2u * i + 1u]), src = make_uint2(source[2u * i], source[2u * i + 1u]);
     if (snk.x == 0xFFFFFFFFu || snk.y == 0xFFFFFFFFu)
@@ -699,6 +718,7 @@ private:
         if (n == 0) return;
         const priv::limits_scope<stream_type> limits(stream, hs);
         if (!priv::limits_scope<stream_type>::trusted && priv::maxP_of(stream) == 0u) { m_path = "empty"; return; }
+        if (priv::forced_generic("banded")) { run_device(stream, hs, std::false_type()); return; }
         run_device(stream, hs, std::integral_constant<bool, priv::recognised<stream_type>::value && priv::tuned_band<BAND_LEN>::value>());
 #else
         static_assert(sizeof(any_device_scheduler) == 0, "the device schedulers need a translation unit compiled by hipcc");
@@ -750,8 +770,12 @@ private:
             }
         }
         priv::build_job_table(stream, m_jobs, t, ps, ts, hs, 0u, NULL, &quals, &n_quals);
+        if (ts.words == NULL || ps.words == NULL) { run_device(stream, hs, std::false_type()); return; }      // no job with a text: nothing for the tuned kernels to read
         const int err = scheme.banded_score(BAND_LEN, stream, t, ps, ts, quals, n_quals, hs);
         if (err == 801) { run_device(stream, hs, std::false_type()); return; }       // outside the tuned kernels' contract (e.g. asymmetric linear gaps)
+        if (err != 0) fprintf(stderr, "compat banded score: err %d band %u n %u maxP %u maxT %u quals %p n_quals %llu ps{words %p n %llu bits %u begin %p len %p} ts{words %p n %llu begin %p len %p}\n", err, BAND_LEN, n,
+                              priv::maxP_of(stream), priv::maxT_of(stream), (const void*)quals, (unsigned long long)n_quals, (const void*)ps.words, (unsigned long long)ps.n_words, ps.bits, (const void*)ps.begin, (const void*)ps.length,
+                              (const void*)ts.words, (unsigned long long)ts.n_words, (const void*)ts.begin, (const void*)ts.length);
         priv::check(err, "nvbio_hip_banded_score");
         hipLaunchKernelGGL((priv::output_jobs_kernel<stream_type>), dim3((n + 127u) / 128u), dim3(128), 0, hs, stream, t);
         priv::check(hipGetLastError(), "output_jobs_kernel");
@@ -822,6 +846,7 @@ private:
         if (stream.size() == 0) return;
         const priv::limits_scope<stream_type> limits(stream, hs);
         if (!priv::limits_scope<stream_type>::trusted && priv::maxP_of(stream) == 0u) { m_path = "empty"; return; }
+        if (priv::forced_generic("full")) { run_device(stream, temp_size, temp, hs, std::false_type()); return; }
         run_device(stream, temp_size, temp, hs, std::integral_constant<bool, priv::recognised<stream_type>::value>());
 #else
         static_assert(sizeof(any_device_scheduler) == 0, "the device schedulers need a translation unit compiled by hipcc");
@@ -848,6 +873,7 @@ private:
         if (priv::maxP_of(stream) > 1024u || !scheme.init(stream) || !scheme.template sink_fits<sink_type>(stream)) { run_device(stream, temp_size, temp, hs, std::false_type()); return; }
         priv::job_table t; nvbio_hip_string_set ps, ts; const uint8* quals = NULL; uint64 n_quals = 0;
         priv::build_job_table(stream, m_jobs, t, ps, ts, hs, 0u, NULL, &quals, &n_quals);
+        if (ts.words == NULL || ps.words == NULL) { run_device(stream, temp_size, temp, hs, std::false_type()); return; }
         const int err = scheme.full_score(stream, t, ps, ts, quals, n_quals, hs);
         if (err == 801) { run_device(stream, temp_size, temp, hs, std::false_type()); return; }
         priv::check(err, "nvbio_hip_alignment_score");
@@ -880,7 +906,7 @@ namespace priv {
 template <uint32 BAND_LEN, typename stream_type>
 NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void banded_traceback_job(stream_type& stream, const uint32 i, uint8* flags)
 {
-    typename stream_type::context_type ctx;
+    priv::fresh_context<typename stream_type::context_type> ctx_storage; typename stream_type::context_type& ctx = ctx_storage.get();
     typename stream_type::strings_type strings;
     if (!stream.init_context(i, &ctx)) { stream.output(i, &ctx); return; }          // batched_banded_inl.h:262-268: declined jobs are output as they are
     const uint32 len = stream.pattern_length(i, &ctx);
@@ -891,7 +917,7 @@ NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void banded_traceback_job(stream_type& strea
 template <typename stream_type>
 NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void full_traceback_job(stream_type& stream, const uint32 i, uint8* scratch, const uint32 maxP, const uint32 maxT)
 {
-    typename stream_type::context_type ctx;
+    priv::fresh_context<typename stream_type::context_type> ctx_storage; typename stream_type::context_type& ctx = ctx_storage.get();
     typename stream_type::strings_type strings;
     if (!stream.init_context(i, &ctx)) { stream.output(i, &ctx); return; }
     const uint32 len = stream.pattern_length(i, &ctx);
@@ -946,6 +972,7 @@ struct traceback_runner
         if (stream.size() == 0) return;
         const limits_scope<stream_type> limits(stream, hs);
         if (!limits_scope<stream_type>::trusted && maxP_of(stream) == 0u) { m_path = "empty"; return; }       // measured: no job has a valid context, nothing to trace or output
+        if (forced_generic("traceback")) { run_device(stream, hs, std::false_type()); return; }
         run_device(stream, hs, std::integral_constant<bool, recognised_tb<stream_type>::value && (BAND_LEN == 0u || tuned_band<BAND_LEN ? BAND_LEN : 3u>::value)>());
     }
     void run_device(const stream_type& stream, hipStream_t hs, std::false_type)
@@ -974,6 +1001,7 @@ struct traceback_runner
         const uint64 extra = uint64(n) * (8u + 4u + uint64(stride) * 2u) + 64u;
         job_table t; nvbio_hip_string_set ps, ts; uint8* x = NULL; const uint8* quals = NULL; uint64 n_quals = 0;
         build_job_table<stream_type, recognised_tb<stream_type> >(stream, m_jobs, t, ps, ts, hs, extra, &x, &quals, &n_quals);
+        if (ts.words == NULL || ps.words == NULL) { run_device(stream, hs, std::false_type()); return; }
         uint32* source = reinterpret_cast<uint32*>(x);
         uint32* cigar_len = source + 2u * uint64(n);
         uint16* cigar = reinterpret_cast<uint16*>(cigar_len + n);

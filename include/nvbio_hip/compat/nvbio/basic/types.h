@@ -23,7 +23,17 @@
 #define NVBIO_CUDA_ASSERT_IF(...)
 #define NVBIO_CUDA_DEBUG_STATEMENT(x)
 #define NVBIO_CUDA_DEBUG_PRINT(...)
+#if defined(NVBIO_HIP_COMPAT_DEBUG_TEXT)
+/* diagnosis builds: print the FORMAT TEXT of the application's debug statements when their condition holds (the arguments are not evaluated:
+ * several of nvBowtie's own debug lines do not compile, reduce_inl.h:186) */
+#define NVBIO_HIP_FIRST_ARG(fmt, ...) fmt
+#define NVBIO_CUDA_DEBUG_PRINT_IF(cond, ...) if (cond) printf("%s", NVBIO_HIP_FIRST_ARG(__VA_ARGS__, ""))
+#elif defined(NVBIO_HIP_COMPAT_DEBUG_FULL)
+/* ... or, for translation units whose debug statements do compile, the statements themselves */
+#define NVBIO_CUDA_DEBUG_PRINT_IF(cond, ...) if (cond) printf(__VA_ARGS__)
+#else
 #define NVBIO_CUDA_DEBUG_PRINT_IF(...)
+#endif
 #define NVBIO_CUDA_DEBUG_CHECK_IF(...)
 #define NVBIO_CUDA_DEBUG_SELECT(debug_val, normal_val) (normal_val)
 #define NVBIO_VAR_UNUSED __attribute__((unused))

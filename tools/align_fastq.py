@@ -51,7 +51,7 @@ class Reference:
         return self.names[k], p
 
 
-def main(prefix, fastq, out=sys.stdout, device="cuda", ref_name="ref"):
+def main(prefix, fastq, out=sys.stdout, device="cuda", ref_name="ref", **param_overrides):
     data = nio.FMIndexDataDevice(prefix, flags=nio.FORWARD | nio.SA, device=device)
     n_genome, g_words = nio.load_genome(prefix)
     genome_words = torch.from_numpy(np.concatenate([g_words, np.zeros(8, np.uint32)]).view(np.int32)).to(device)
@@ -61,7 +61,7 @@ def main(prefix, fastq, out=sys.stdout, device="cuda", ref_name="ref"):
         raise SystemExit("align_fastq: no reads")
     index = np.asarray(reads.sequence_index, dtype=np.int64)
     batch = A.ReadBatch.from_ragged(torch.from_numpy(reads.symbols).to(device), torch.from_numpy(index).to(device), torch.from_numpy(reads.quals).to(device))
-    params = A.Params(hits_stride=32)
+    params = A.Params(hits_stride=32, **param_overrides)        # e.g. local=True = nvBowtie --local
     r = A.best_approx(data.index(), None, batch, genome_words, n_genome, params, names=list(reads.names), cigar_stride=64, finish=True)
     torch.cuda.synchronize()
     best = r["best"].cpu().numpy().view(np.uint64)            # finished: m_align = the traceback window's begin, m_ed, final score

@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""Run the reference's own nvBowtie (oracle/_ref/ref_nvBowtie: its application sources compiled unchanged on the drop-in layer,
+tools/nvbowtie_tu_check.py --link) and this repository's from-scratch drivers (tools/align_fastq.py over the C-ABI) on the same simulated
+input, and compare their SAM records field by field.  GPU box only.
+
+    python tools/nvbowtie_compare.py [--mode se|local|all|paired] [--reads N] [--seed S] [--indels RATE]
+"""
+import argparse
+import io as _io
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def write_reference(tmp, rng, n_genome, seqs):
+    from nvbio_amd import io as nio
+    from oracle import pyoracle as O
+    text = rng.integers(0, 4, n_genome, dtype=np.uint8)
+    prefix = os.path.join(tmp, "genome")
+    nio.save_fmindex(prefix, O.FMIndex(text))
+    nio.save_fmindex(prefix, O.FMIndex(text[::-1].copy()), reverse=True)
+    nio.write_wpac(prefix + ".wpac", text.size, O.pack(text, 2, True))
+    nio.write_bns(prefix, [n for n, _ in seqs], [l for _, l in seqs])
+    return prefix, text
+
+
+def mutate(rng, r, rate):
+    mut = rng.random(r.size) < rate
+    r = r.copy(); r[mut] = (r[mut] + 1) & 3
+    return r
+
+
+def write_fastq(path, reads, tag, qual="I"):
+    with open(path, "w") as f:
+        for i, r in enumerate(reads):
+            f.write("@%s%d\n%s\n+\n%s\n" % (tag, i, "".join("ACGT"[c] for c in r), qual * len(r)))
+
+
+def records(text):
+    return [ln.rstrip("\n").split("\t") for ln in text.splitlines() if ln and not ln.startswith("@")]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="se", choices=["se", "local", "all", "paired"])
+    ap.add_argument("--reads", type=int, default=4000)
+    ap.add_argument("--seed", type=int, default=5)
+    ap.add_argument("--indels", type=float, default=0.2)
+    ap.add_argument("--show", type=int, default=4)
+    args = ap.parse_args()
+    import torch
+    import align_fastq
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_nvBowtie")
+    rng = np.random.default_rng(args.seed)
+    tmp = tempfile.mkdtemp(prefix="nvbcmp_")
+    n_genome, L, n = 200_000, 100, args.reads
+    prefix, text = write_reference(tmp, rng, n_genome, [("chrA", 120_000), ("chrB", 80_000)])
+    if args.mode == "all":                                   # some repeats, so that reads have several placements
+        pass
+    dev = torch.device("cuda:0")
+    sam = os.path.join(tmp, "ref.sam")
+    buf = _io.StringIO()
+    if args.mode == "paired":
+        frag = rng.integers(200, 400, n)
+        pos = rng.integers(0, 120_000 - 420, n) + np.where(rng.random(n) < 0.4, 120_000, 0) * 0
+        m1 = [mutate(rng, text[p:p + L], 0.02) for p in pos]
+        m2 = [mutate(rng, (3 - text[p + f - L:p + f])[::-1], 0.02) for p, f in zip(pos, frag)]
+        f1, f2 = os.path.join(tmp, "m1.fastq"), os.path.join(tmp, "m2.fastq")
+        write_fastq(f1, m1, "pair", "?"); write_fastq(f2, m2, "pair", "?")       # Q30 throughout: the Python paired driver takes one quality value
+        cmd = [exe, "--file-ref", "-x", prefix, "-1", f1, "-2", f2, "-S", sam]
+        own = lambda: align_fastq.main_paired(prefix, f1, f2, buf, device=dev)
+    else:
+        pos = rng.integers(0, n_genome - L - 4, n)
+        pos = np.where((pos < 120_000) & (pos + L + 4 > 120_000), pos - L - 4, pos)
+        reads = []
+        for i, p in enumerate(pos):
+            r = text[p:p + L].copy()
+            if rng.random() < args.indels:
+                k, g = int(rng.integers(30, 70)), int(rng.integers(1, 3))
+                r = np.concatenate([r[:k], rng.integers(0, 4, g).astype(np.uint8), r[k:]])[:L] if rng.random() < 0.5 else np.concatenate([text[p:p + k], text[p + k + g:p + L + g]])
+            r = mutate(rng, r, 0.03)
+            reads.append((3 - r)[::-1] if i % 2 else r)
+        fq = os.path.join(tmp, "reads.fastq")
+        write_fastq(fq, reads, "read")
+        cmd = [exe, "--file-ref", "-x", prefix, "-U", fq, "-S", sam] + (["--local"] if args.mode == "local" else ["--all"] if args.mode == "all" else [])
+        if args.mode == "all":
+            own = lambda: align_fastq.main_all(prefix, fq, buf, device=dev)
+        elif args.mode == "local":
+            import nvbio_amd as nvb
+            own = lambda: align_fastq.main(prefix, fq, buf, device=dev, local=True)
+        else:
+            own = lambda: align_fastq.main(prefix, fq, buf, device=dev)
+    cmd += os.environ.get("NVBOWTIE_EXTRA_ARGS", "").split()
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if os.environ.get("NVBOWTIE_EXTRA_ARGS"):
+        print((r.stdout + r.stderr)[-6000:])
+    if r.returncode != 0:
+        print((r.stdout + r.stderr)[-3000:]); return 1
+    ref = records(open(sam).read())
+    own()
+    mine = records(buf.getvalue())
+    print("mode %s: reference %d records, own %d records" % (args.mode, len(ref), len(mine)))
+    if args.mode == "all":
+        key = lambda a: (a[0], a[2], int(a[3]), int(a[1]) & 16)
+        ref.sort(key=key); mine.sort(key=key)
+    same, shown = 0, 0
+    for a, b in zip(ref, mine):
+        a = list(a)
+        if args.mode != "paired":
+            a[1] = str(int(a[1]) & ~64)
+        if a == b:
+            same += 1
+        elif shown < args.show:
+            shown += 1
+            d = [i for i in range(min(len(a), len(b))) if a[i] != b[i]]
+            print("  differ in fields", d, "\n    ref:", a[:9] + a[11:], "\n    own:", b[:9] + b[11:])
+    print("identical records: %d of %d" % (same, max(len(ref), len(mine))))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -52,7 +52,7 @@ def main():
         t0 = time.time()
         obj = os.path.join(tmp, os.path.basename(tu) + ".o")
         r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-std=c++17", "-O2" if args.link else "-O1", "-fopenmp", "-w", "-include", os.path.join(ROOT, "tools", "port_cuda_calls.h"),
-                            "-x", "hip", "-c", tu, "-I" + os.path.join(ROOT, "include", "nvbio_hip", "compat"), "-I" + tmp, "-I" + os.path.join(ROOT, "tools", "port"), "-o", obj], capture_output=True, text=True)
+                            "-x", "hip", "-c", tu] + (["-DNVBIO_HIP_COMPAT_DEBUG_TEXT"] if os.environ.get("NVBOWTIE_DEBUG_BUILD") and (os.path.basename(tu) == "reduce.cu" or os.path.basename(tu).startswith("aligner_")) else ["-DNVBIO_HIP_COMPAT_DEBUG_FULL"] if os.environ.get("NVBOWTIE_DEBUG_BUILD") else []) + os.environ.get("NVBOWTIE_EXTRA_FLAGS", "").split() + [ "-I" + os.path.join(ROOT, "include", "nvbio_hip", "compat"), "-I" + tmp, "-I" + os.path.join(ROOT, "tools", "port"), "-o", obj], capture_output=True, text=True)
         errs = [l.replace(tmp + "/", "").replace(ROOT + "/", "") for l in r.stderr.splitlines() if "error:" in l or "fatal error" in l]
         return tu, r.returncode == 0, errs, time.time() - t0
 
