@@ -30,6 +30,15 @@ struct Params : public ParamsPOD
     SelectParamsPOD select;
     uint32 max_dist; AlignmentTypeMode alignment_type; bool no_multi_hits, fw, rc; uint32 hits_stride;
     bool   finish_alignments;      ///< run finish_alignment_best (MD strings, edit distances, final scores) as the reference always does
+
+    /// switch between end-to-end and local alignment the way nvBowtie's option parser does (params.cpp:156-160): the alignment type
+    /// also moves the seeding defaults -- 22-bp seeds every 1 + 1.15 sqrt(L) end-to-end, 20-bp seeds every 1 + 0.75 sqrt(L) local
+    void set_alignment_type(const AlignmentTypeMode type)
+    {
+        alignment_type = type;
+        seed_len  = type == LocalAlignment ? 20u : 22u;
+        seed_freq = SimpleFunc(SimpleFunc::SqrtFunc, 1.0f, type == LocalAlignment ? 0.75f : 1.15f);
+    }
 };
 
 /// per-stage device times (the reference's stats.map / select / locate / score ... timers, aligner_best_approx.h): off by default,

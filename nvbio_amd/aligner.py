@@ -57,6 +57,11 @@ class Params:
             if not hasattr(self, k):
                 raise TypeError("unknown parameter %s" % k)
             setattr(self, k, v)
+        if self.local:                                 # --local moves the seeding defaults (params.cpp:156-160): 20-bp seeds every 1 + 0.75 sqrt(L)
+            if "seed_len" not in kw:
+                self.seed_len = 20
+            if "seed_freq" not in kw:
+                self.seed_freq = (mapping.SQRT_FUNC, 1.0, 0.75)
         self.max_effort_init = max(self.max_effort_init, self.max_effort)      # params.cpp:197-198
         self.max_ext = max(self.max_ext, self.max_effort)
 

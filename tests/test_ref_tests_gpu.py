@@ -192,3 +192,19 @@ def test_own_pipeline_equals_reference_nvbowtie(tmp_path, cuda):
             differ.append((a[:6] + a[11:], b[:6] + b[11:]))
     assert gapped > 0.15 * n, gapped
     assert not differ, (len(differ), differ[:3])
+
+
+@pytest.mark.parametrize("mode", ["local", "all", "paired"])
+def test_own_drivers_equal_reference_nvbowtie_in_every_mode(mode, cuda):
+    """The same comparison for nvBowtie --local, --all and paired-end (-1 / -2, FR, 200-400 bp fragments): tools/nvbowtie_compare.py runs the
+    reference's application and this repository's driver of that mode (best_approx with local=True, all_mapping, best_approx_paired) on
+    one simulated input and compares the SAM records; all of them must be identical."""
+    import argparse
+    import sys
+    if not os.path.exists(os.path.join(REF, "ref_nvBowtie")):
+        pytest.skip("oracle/_ref/ref_nvBowtie not built (needs /root/reference in the build container)")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import nvbowtie_compare
+    same, n_ref, n_own = nvbowtie_compare.compare(argparse.Namespace(mode=mode, reads=3000, seed=23, indels=0.2, show=3))
+    assert n_ref == n_own and n_ref >= 3000
+    assert same == n_ref, (mode, same, n_ref)

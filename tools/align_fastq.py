@@ -17,6 +17,8 @@ import torch
 import nvbio_amd as nvb
 from nvbio_amd import io as nio, aligner as A
 
+last_stats = None
+
 
 def _rname_pos(ref, pos):
     """(RNAME, 1-based POS) of a genome coordinate"""
@@ -64,6 +66,8 @@ def main(prefix, fastq, out=sys.stdout, device="cuda", ref_name="ref", **param_o
     params = A.Params(hits_stride=32, **param_overrides)        # e.g. local=True = nvBowtie --local
     r = A.best_approx(data.index(), None, batch, genome_words, n_genome, params, names=list(reads.names), cigar_stride=64, finish=True)
     torch.cuda.synchronize()
+    global last_stats
+    last_stats = dict((k, v) for k, v in r["stats"].items() if k != "ms")          # seeding passes, queue sizes, extension rounds
     best = r["best"].cpu().numpy().view(np.uint64)            # finished: m_align = the traceback window's begin, m_ed, final score
     mapq, cig, clen = r["mapq"].cpu().numpy(), r["cigar"].cpu().numpy().view(np.uint16), r["cigar_len"].cpu().numpy()
     source, mds = r["source"].cpu().numpy(), r["mds"].cpu().numpy()

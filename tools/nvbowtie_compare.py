@@ -54,6 +54,12 @@ def main():
     ap.add_argument("--indels", type=float, default=0.2)
     ap.add_argument("--show", type=int, default=4)
     args = ap.parse_args()
+    same, n_ref, n_own = compare(args)
+    return 0 if same == max(n_ref, n_own) and n_ref else 1
+
+
+def compare(args):
+    """-> (identical records, reference records, own records)"""
     import torch
     import align_fastq
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_nvBowtie")
@@ -88,7 +94,8 @@ def main():
             reads.append((3 - r)[::-1] if i % 2 else r)
         fq = os.path.join(tmp, "reads.fastq")
         write_fastq(fq, reads, "read")
-        cmd = [exe, "--file-ref", "-x", prefix, "-U", fq, "-S", sam] + (["--local"] if args.mode == "local" else ["--all"] if args.mode == "all" else [])
+        # (mode flags go first: nvBowtie reads argv[i + 1] after an option it does not know, nvBowtie.cpp:343)
+        cmd = [exe] + (["--local"] if args.mode == "local" else ["--all"] if args.mode == "all" else []) + ["--file-ref", "-x", prefix, "-U", fq, "-S", sam]
         if args.mode == "all":
             own = lambda: align_fastq.main_all(prefix, fq, buf, device=dev)
         elif args.mode == "local":
@@ -101,10 +108,12 @@ def main():
     if os.environ.get("NVBOWTIE_EXTRA_ARGS"):
         print((r.stdout + r.stderr)[-6000:])
     if r.returncode != 0:
-        print((r.stdout + r.stderr)[-3000:]); return 1
+        print((r.stdout + r.stderr)[-3000:]); return 0, 0, 0
     ref = records(open(sam).read())
     own()
     mine = records(buf.getvalue())
+    if os.environ.get("OWN_STATS") and hasattr(align_fastq, "last_stats"):
+        print("own driver stats:", align_fastq.last_stats)
     print("mode %s: reference %d records, own %d records" % (args.mode, len(ref), len(mine)))
     if args.mode == "all":
         key = lambda a: (a[0], a[2], int(a[3]), int(a[1]) & 16)
@@ -121,7 +130,7 @@ def main():
             d = [i for i in range(min(len(a), len(b))) if a[i] != b[i]]
             print("  differ in fields", d, "\n    ref:", a[:9] + a[11:], "\n    own:", b[:9] + b[11:])
     print("identical records: %d of %d" % (same, max(len(ref), len(mine))))
-    return 0
+    return same, len(ref), len(mine)
 
 
 if __name__ == "__main__":
