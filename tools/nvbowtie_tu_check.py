@@ -86,9 +86,10 @@ def main():
     if not args.only:
         os.makedirs(os.path.dirname(args.log), exist_ok=True)
         open(args.log, "w").write(text)
+    failed = ok_n != len(tus) or (args.link and not args.only and not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_nvBowtie")))
     print(text)
     subprocess.run(["rm", "-rf", tmp])
-    return 0
+    return 1 if failed else 0
 
 
 if __name__ == "__main__":
