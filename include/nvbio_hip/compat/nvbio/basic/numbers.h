@@ -10,8 +10,17 @@ namespace nvbio {
 
 #if defined(__HIPCC__)
 /// lane and warp of a thread in the reference's 32-lane terms (numbers.h:64-65; see cuda/arch.h on virtual warps)
-NVBIO_FORCEINLINE __device__ uint32 warp_tid() { return threadIdx.x & 31u; }
-NVBIO_FORCEINLINE __device__ uint32 warp_id()  { return threadIdx.x >> 5; }
+/// warp_tid() converts to uint32 everywhere, with one extra: `n - warp_tid()` keeps its type, and a 32-bit mask shifted by such a difference
+/// follows CUDA's rule -- a shift by 32 or more gives 0 -- where C++ leaves it undefined and gfx950 would shift by (n & 31).  nvBowtie's
+/// warp-aggregated queue allocation elects its leader with `__popc( mask << (32u - warp_tid()) ) == 0` (nvBowtie/bowtie2/cuda/utils.h:62):
+/// lane 0 shifts by 32 and must see 0.
+struct warp_lane  { uint32 v; NVBIO_FORCEINLINE NVBIO_HOST_DEVICE operator uint32() const { return v; } };
+struct warp_shift { uint32 v; NVBIO_FORCEINLINE NVBIO_HOST_DEVICE operator uint32() const { return v; } };
+template <typename T> NVBIO_FORCEINLINE NVBIO_HOST_DEVICE warp_shift operator-(const T a, const warp_lane b) { const warp_shift s = { uint32(a) - b.v }; return s; }
+NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 operator<<(const uint32 m, const warp_shift s) { return s.v >= 32u ? 0u : (m << s.v); }
+NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 operator>>(const uint32 m, const warp_shift s) { return s.v >= 32u ? 0u : (m >> s.v); }
+NVBIO_FORCEINLINE __device__ warp_lane warp_tid() { const warp_lane l = { threadIdx.x & 31u }; return l; }
+NVBIO_FORCEINLINE __device__ uint32    warp_id()  { return threadIdx.x >> 5; }
 #endif
 
 namespace util {

@@ -208,3 +208,19 @@ def test_own_drivers_equal_reference_nvbowtie_in_every_mode(mode, cuda):
     same, n_ref, n_own = nvbowtie_compare.compare(argparse.Namespace(mode=mode, reads=3000, seed=23, indels=0.2, show=3))
     assert n_ref == n_own and n_ref >= 3000
     assert same == n_ref, (mode, same, n_ref)
+
+
+def test_own_driver_equals_reference_nvbowtie_above_half_a_batch(cuda):
+    """More than BATCH_SIZE / 2 reads in flight: nvBowtie then selects ONE hit per read and round through its warp-aggregated queue allocation
+    (`alloc()`, utils.h:58-71: a ballot, a leader elected by `mask << (32 - warp_tid())` -- a shift by 32 for lane 0, which CUDA defines as 0
+    and the drop-in layer's warp_tid() type reproduces --, a broadcast through a per-warp shared slot), on 32-lane virtual warps.  600 000
+    reads, end to end; every SAM record equal to the from-scratch driver's."""
+    import argparse
+    import sys
+    if not os.path.exists(os.path.join(REF, "ref_nvBowtie")):
+        pytest.skip("oracle/_ref/ref_nvBowtie not built (needs /root/reference in the build container)")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import nvbowtie_compare
+    same, n_ref, n_own = nvbowtie_compare.compare(argparse.Namespace(mode="se", reads=600_000, seed=31, indels=0.1, show=3))
+    assert n_ref == n_own == 600_000
+    assert same == n_ref, (same, n_ref)
