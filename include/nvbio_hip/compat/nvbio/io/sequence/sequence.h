@@ -15,6 +15,7 @@
 #include "../../basic/console.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -120,7 +121,31 @@ template <typename In, typename Out> inline void seq_copy(In in, const uint32 n,
 template <typename system_tag, typename T> struct seq_vector { typedef nvbio::vector<system_tag, T> type; };
 template <typename V> inline typename V::value_type*       seq_ptr(V& v)       { return nvbio::raw_pointer(static_cast<typename V::base_type&>(v)); }
 template <typename V> inline const typename V::value_type* seq_ptr(const V& v) { return nvbio::raw_pointer(static_cast<const typename V::base_type&>(v)); }
+/// A 2-bit DNA stream in device memory is a reference genome, and its users address it with 32-bit coordinates they do not always
+/// keep inside it: nvBowtie's locate stage stores `SA position - offset of the seed in the read` (locate_inl.h:142,204), which wraps
+/// below zero for a read with an insertion lying over the first bases of the genome, and the scoring streams then load a window at
+/// that coordinate (score_best_inl.h:111-115, alignment_utils.h:216-218) -- a read ~1 GiB past the stream.  On the hardware the
+/// reference was written for such a read lands in some other mapped allocation and the garbage scores below the threshold; here it
+/// is a memory fault that ends the process.  With 288 GB of HBM the robust answer is cheap: reserve the stream's allocation so that
+/// EVERY 32-bit coordinate (2^32 symbols = 2^28 words = 1 GiB, plus a window of slack) is addressable, and zero the tail, so a wrapped
+/// window reads as poly-A and fails the score test deterministically.  NVBIO_HIP_COMPAT_NO_COORD_COVER=1 switches it off.
+template <typename system_tag> struct coordinate_cover { template <typename V> static void apply(V&, const uint32) {} };
+template <> struct coordinate_cover<device_tag>
+{
+    template <typename V> static void apply(V& v, const uint32 alphabet)
+    {
+        if (alphabet != uint32(DNA) || v.empty()) return;
+        const char* off = getenv("NVBIO_HIP_COMPAT_NO_COORD_COVER");
+        if (off && off[0] == '1') return;
+        const size_t all = (size_t(1) << 28) + 1024u;
+        if (v.capacity() >= all) return;
+        const size_t n = v.size();
+        v.reserve(all);
+        (void)hipMemset(nvbio::raw_pointer(static_cast<typename V::base_type&>(v)) + n, 0, (all - n) * sizeof(uint32));
+    }
+};
 #else
+template <typename system_tag> struct coordinate_cover { template <typename V> static void apply(V&, const uint32) {} };
 template <typename In, typename Out> inline void seq_copy(In in, const uint32 n, Out out) { std::copy(in, in + n, out); }
 template <typename system_tag, typename T> struct seq_vector {};                               // the device flavour needs hipcc
 template <typename T> struct seq_vector<host_tag, T> { typedef std::vector<T> type; };
@@ -173,6 +198,7 @@ struct SequenceDataStorage : public SequenceData
         priv::seq_copy(other.name_stream(),      m_name_stream_len,       m_name_vec.begin());
         priv::seq_copy(other.name_index(),       m_n_seqs + 1u,           m_name_index_vec.begin());
         if (m_has_qualities) priv::seq_copy(other.qual_stream(), m_sequence_stream_len, m_qual_vec.begin());
+        priv::coordinate_cover<system_tag>::apply(m_sequence_vec, uint32(m_alphabet));
         return *this;
     }
 
@@ -213,6 +239,7 @@ private:
         this->SequenceDataInfo::operator=(other);
         m_sequence_vec = other.m_sequence_vec; m_sequence_index_vec = other.m_sequence_index_vec;
         m_qual_vec = other.m_qual_vec; m_name_vec = other.m_name_vec; m_name_index_vec = other.m_name_index_vec;
+        priv::coordinate_cover<system_tag>::apply(m_sequence_vec, uint32(m_alphabet));
         return *this;
     }
 };
