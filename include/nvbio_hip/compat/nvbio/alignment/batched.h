@@ -193,6 +193,10 @@ template <AlignmentType T, typename S, typename G> struct tuned_aligner< GotohAl
 template <typename It> struct byte_pointer { static const bool ok = false; };
 template <> struct byte_pointer<const uint8*> { static const bool ok = true; NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static const uint8* get(const uint8* p) { return p; } };
 template <> struct byte_pointer<uint8*>       { static const bool ok = true; NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static const uint8* get(uint8* p) { return p; } };
+/// (the io layer keeps qualities as `char`: SequenceDataViewCore<..., const char*, ...>, io/sequence/sequence.h)
+template <> struct byte_pointer<const char*>  { static const bool ok = true; NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static const uint8* get(const char* p) { return reinterpret_cast<const uint8*>(p); } };
+template <> struct byte_pointer<char*>        { static const bool ok = true; NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static const uint8* get(char* p) { return reinterpret_cast<const uint8*>(p); } };
+template <> struct byte_pointer< cuda::ldg_pointer<char> >  { static const bool ok = true; NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static const uint8* get(cuda::ldg_pointer<char> p) { return reinterpret_cast<const uint8*>(p.base); } };
 template <> struct byte_pointer< cuda::ldg_pointer<uint8> > { static const bool ok = true; NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static const uint8* get(cuda::ldg_pointer<uint8> p) { return p.base; } };
 
 /// ... or a VIEW run in place: an io::ReadStream over packed words with a byte-pointer quality stream -- the only pattern nvBowtie's
@@ -360,11 +364,16 @@ template <typename P> struct pattern_where<P, false> {
 /// per job writes 38 scattered words per 100-bp read and is bound by exactly that: 12 of 14.7 ms per 10 M jobs).  Every one of the sixteen
 /// evaluates the stream's context -- the same addresses in all of them, so no more lines move; the views a stream hands out may point into
 /// the lane's own context (nvBowtie's loaders cache words there), so they cannot be passed between lanes.
+template <typename stream_type, typename R> struct describe_lanes
+{ static const uint32 value = R::staged ? (sizeof(typename stream_type::context_type) > 1024u ? 2u : 16u) : 1u; };
 template <typename stream_type, typename R>
 __global__ void __launch_bounds__(128) describe_jobs_kernel(const stream_type stream, const job_table t)
 {
     typedef pattern_where<typename R::pattern_type, !R::staged> pwhere;
-    constexpr uint32 G = R::staged ? 16u : 1u;                       // lanes per job
+    // lanes per job.  Every lane of a job evaluates its own zeroed context: with a traceback stream's 4 KB context (nvBowtie keeps a
+    // cigar[1024] in it, alignment_utils.h:252-258) sixteen lanes zeroed 64 KB of scratch per job -- 7.3 ms per 1 M jobs, more than
+    // the traceback itself -- so large contexts are shared by two lanes only
+    constexpr uint32 G = priv::describe_lanes<stream_type, R>::value;
     // a fixed grid strides over the jobs, every lane keeps its own bounds, and the four global bounds cost four atomics per BLOCK
     // (one per wave and bound made waves that see jobs in storage order queue up on the same addresses: see describe_views_kernel)
     unsigned long long plo = ~0ull, phi = 0ull, tlo = ~0ull, thi = 0ull;
@@ -553,7 +562,7 @@ inline void build_job_table(const stream_type& stream, device_buffer& buf, job_t
     }
     if (extra) *extra = base + table + stage;
     hipLaunchKernelGGL(init_bounds_kernel, dim3(1), dim3(64), 0, hs, t.bounds);
-    hipLaunchKernelGGL((describe_jobs_kernel<stream_type, R>), dim3(uint32(std::min<uint64>((uint64(n) * (R::staged ? 16u : 1u) + 127u) / 128u, 65536u))), dim3(128), 0, hs, stream, t);
+    hipLaunchKernelGGL((describe_jobs_kernel<stream_type, R>), dim3(uint32(std::min<uint64>((uint64(n) * describe_lanes<stream_type, R>::value + 127u) / 128u, 65536u))), dim3(128), 0, hs, stream, t);
     unsigned long long b[4];
     check(hipMemcpyAsync(b, t.bounds, sizeof(b), hipMemcpyDeviceToHost, hs), "hipMemcpyAsync");
     check(hipStreamSynchronize(hs), "hipStreamSynchronize");

@@ -2,6 +2,8 @@
 // parsers callers such as sw-benchmark.cu:530-555 use to stream a reference into their own packers.  Plain or gzip input (zlib is
 // what the reference reads through as well: link with -lz).
 #pragma once
+#include <algorithm>
+#include <cstring>
 #include "../basic/types.h"
 #include <stdio.h>
 #include <string>
@@ -26,6 +28,19 @@ struct byte_source
         return m_pos < m_fill ? m_buffer[m_pos++] : uint8(255u);
     }
     void  unget() { if (m_pos) --m_pos; }
+    /// up to n raw bytes (what get() has buffered first); 0 at the end of the file
+    size_t read(uint8* out, const size_t n)
+    {
+        size_t done = 0;
+        if (m_pos < m_fill) { done = std::min<size_t>(n, m_fill - m_pos); memcpy(out, m_buffer.data() + m_pos, done); m_pos += uint32(done); }
+        while (done < n)
+        {
+            const int got = gzread(m_file, out + done, unsigned(std::min<size_t>(n - done, size_t(1) << 30)));
+            if (got <= 0) break;
+            done += size_t(got);
+        }
+        return done;
+    }
     void  rewind() { if (m_file) gzrewind(m_file); m_fill = m_pos = 0; }
     gzFile             m_file;
     std::vector<uint8> m_buffer;

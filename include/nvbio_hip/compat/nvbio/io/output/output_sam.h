@@ -9,8 +9,10 @@
 #include "../../basic/threads.h"
 #include "../../basic/timer.h"
 #include "../../basic/dna.h"
+#include "../../basic/omp.h"
 #include <algorithm>
 #include <string>
+#include <vector>
 
 namespace nvbio {
 namespace io {
@@ -96,9 +98,17 @@ struct SamOutput : public OutputFile
         {
             ScopedTimer<float> timer(&seconds);
             ScopedLock hold(&mutex);
-            std::string text;
-            for (uint32 c = 0; c < batch.count; ++c) record(get(batch, c), AlignmentData::invalid(), text);
-            fwrite(text.data(), 1, text.size(), fp);
+            // the records of a batch are independent: every OpenMP thread formats a contiguous share, the shares are written in order
+            const size_t n_threads = size_t(usable_omp_threads());
+            std::vector<std::string> text(n_threads);
+            #pragma omp parallel num_threads(int(text.size()))
+            {
+                const uint32 t = uint32(omp_get_thread_num()), nt = uint32(omp_get_num_threads());
+                const uint32 lo = uint32(uint64(batch.count) * t / nt), hi = uint32(uint64(batch.count) * (t + 1u) / nt);
+                text[t].reserve(size_t(hi - lo) * 320u);
+                for (uint32 c = lo; c < hi; ++c) record(get(batch, c), AlignmentData::invalid(), text[t]);
+            }
+            for (size_t t = 0; t < text.size(); ++t) fwrite(text[t].data(), 1, text[t].size(), fp);
         }
         iostats.n_reads += batch.count;
         iostats.output_process_timings.add(batch.count, seconds);
@@ -109,14 +119,21 @@ struct SamOutput : public OutputFile
         {
             ScopedTimer<float> timer(&seconds);
             ScopedLock hold(&mutex);
-            std::string text;
-            for (uint32 c = 0; c < batch.count; ++c)
+            const size_t n_threads = size_t(usable_omp_threads());
+            std::vector<std::string> text(n_threads);
+            #pragma omp parallel num_threads(int(text.size()))
             {
-                const AlignmentData anchor = get_anchor_mate(batch, c), opposite = get_opposite_mate(batch, c);
-                record(anchor, opposite, text);
-                record(opposite, anchor, text);
+                const uint32 t = uint32(omp_get_thread_num()), nt = uint32(omp_get_num_threads());
+                const uint32 lo = uint32(uint64(batch.count) * t / nt), hi = uint32(uint64(batch.count) * (t + 1u) / nt);
+                text[t].reserve(size_t(hi - lo) * 800u);
+                for (uint32 c = lo; c < hi; ++c)
+                {
+                    const AlignmentData anchor = get_anchor_mate(batch, c), opposite = get_opposite_mate(batch, c);
+                    record(anchor, opposite, text[t]);
+                    record(opposite, anchor, text[t]);
+                }
             }
-            fwrite(text.data(), 1, text.size(), fp);
+            for (size_t t = 0; t < text.size(); ++t) fwrite(text[t].data(), 1, text[t].size(), fp);
         }
         iostats.n_reads += batch.count;
         iostats.output_process_timings.add(batch.count, seconds);
@@ -126,6 +143,10 @@ struct SamOutput : public OutputFile
 private:
     uint32 sequence_of(const uint32 pos) const { return uint32(std::upper_bound(bnt.sequence_index, bnt.sequence_index + bnt.n_seqs, pos) - bnt.sequence_index) - 1u; }
 
+    /// decimal text without a temporary string
+    static void put(std::string& o, uint32 v) { char b[12]; int n = 0; do { b[n++] = char('0' + v % 10u); v /= 10u; } while (v); while (n) o.push_back(b[--n]); }
+    static void put(std::string& o, const int32 v) { if (v < 0) { o.push_back('-'); put(o, uint32(-int64(v))); } else put(o, uint32(v)); }
+
     /// "3M1D7M" from the stored (reversed) operation list; returns the read bases it consumes
     static uint32 cigar_text(const AlignmentData& a, std::string& out)
     {
@@ -133,7 +154,7 @@ private:
         for (uint32 i = a.cigar_len; i-- > 0;)
         {
             const Cigar& op = a.cigar[i];
-            out += std::to_string(uint32(op.m_len)); out += "MIDS"[op.m_type];
+            put(out, uint32(op.m_len)); out += "MIDS"[op.m_type];
             if (op.m_type != Cigar::DELETION) consumed += op.m_len;
         }
         return consumed;
@@ -149,7 +170,7 @@ private:
         do
         {
             const uint8 op = p[i++];
-            if (op == MDS_MATCH)         { uint8 run = p[i++]; while (i < end && p[i] == MDS_MATCH) run = uint8(run + p[i++]); md += std::to_string(uint32(run)); }
+            if (op == MDS_MATCH)         { uint8 run = p[i++]; while (i < end && p[i] == MDS_MATCH) run = uint8(run + p[i++]); put(md, uint32(run)); }
             else if (op == MDS_MISMATCH) { md += dna_to_char(p[i++]); ++mm; }
             else if (op == MDS_INSERTION){ const uint8 l = p[i++]; i += l; ++gapo; gape += l - 1u; }
             else if (op == MDS_DELETION) { const uint8 l = p[i++]; md += '^'; for (uint8 k = 0; k < l; ++k) md += dna_to_char(p[i++]); md += '0'; ++gapo; gape += l - 1u; }
@@ -158,20 +179,27 @@ private:
     /// append the SAM line of `a` (whose mate, for pairs, is `mate`)
     void record(const AlignmentData& a, const AlignmentData& mate, std::string& out)
     {
-        std::string seq(a.read_len, 'N'), qual(a.read_len, '!');
+        // the read as the file had it (or its reverse complement), and its qualities, as text
         const bool rc = a.aln->is_rc();
-        for (uint32 i = 0; i < a.read_len; ++i)
+        auto put_read = [&](std::string& o)
         {
-            const uint32 src = rc ? i : a.read_len - 1u - i;
-            const uint8 s = a.read_data[src];
-            seq[i]  = dna_to_char(rc ? (s < 4 ? uint8(3u - s) : uint8(4)) : s);
-            qual[i] = char(a.qual[src] + 33);
-        }
+            const size_t at = o.size();
+            o.resize(at + 2u * size_t(a.read_len) + 1u);
+            char* seq = &o[at]; char* qual = seq + a.read_len + 1u;
+            for (uint32 i = 0; i < a.read_len; ++i)
+            {
+                const uint32 src = rc ? i : a.read_len - 1u - i;
+                const uint8 s = a.read_data[src];
+                seq[i]  = dna_to_char(rc ? (s < 4 ? uint8(3u - s) : uint8(4)) : s);
+                qual[i] = char(a.qual[src] + 33);
+            }
+            seq[a.read_len] = '\t';
+        };
         uint32 mapq = a.mapq;
         out += a.read_name;
         if (!(a.aln->is_aligned() || int(mapq) < mapq_filter))
         {
-            out += "\t4\t*\t0\t0\t*\t*\t0\t0\t"; out += seq; out += '\t'; out += qual; out += '\n';
+            out += "\t4\t*\t0\t0\t*\t*\t0\t0\t"; put_read(out); out += '\n';
             return;
         }
         uint32 flags = (a.aln->mate() ? SAM_FLAGS_READ_2 : SAM_FLAGS_READ_1) | (rc ? SAM_FLAGS_REVERSE : 0u);
@@ -209,20 +237,20 @@ private:
         }
         std::string md; uint32 mm, gapo, gape;
         md_text(a, md, mm, gapo, gape);
-        out += '\t'; out += std::to_string(flags);
+        out += '\t'; put(out, flags);
         out += '\t'; out += bnt.names + bnt.names_index[seq_id];
-        out += '\t'; out += std::to_string(a.cigar_pos - bnt.sequence_index[seq_id] + 1u);
-        out += '\t'; out += std::to_string(mapq);
+        out += '\t'; put(out, uint32(a.cigar_pos - bnt.sequence_index[seq_id] + 1u));
+        out += '\t'; put(out, mapq);
         out += '\t'; out += cigar;
         out += '\t'; out += rnext;
-        out += '\t'; out += std::to_string(pnext);
-        out += '\t'; out += std::to_string(tlen);
-        out += '\t'; out += seq; out += '\t'; out += qual;
-        out += "\tNM:i:"; out += std::to_string(a.aln->ed());
-        out += "\tAS:i:"; out += std::to_string(a.aln->score());
-        out += "\tXM:i:"; out += std::to_string(mm);
-        out += "\tXO:i:"; out += std::to_string(gapo);
-        out += "\tXG:i:"; out += std::to_string(gape);
+        out += '\t'; put(out, pnext);
+        out += '\t'; put(out, tlen);
+        out += '\t'; put_read(out);
+        out += "\tNM:i:"; put(out, uint32(a.aln->ed()));
+        out += "\tAS:i:"; put(out, int32(a.aln->score()));
+        out += "\tXM:i:"; put(out, mm);
+        out += "\tXO:i:"; put(out, gapo);
+        out += "\tXG:i:"; put(out, gape);
         out += "\tMD:Z:"; out += md.empty() ? std::string("*") : md;
         out += '\n';
     }

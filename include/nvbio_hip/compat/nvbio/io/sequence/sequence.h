@@ -13,11 +13,13 @@
 #include "../../strings/string_set.h"
 #include "../../fasta/fasta.h"
 #include "../../basic/console.h"
+#include "../../basic/omp.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <typeinfo>
 #include <vector>
 
 namespace nvbio {
@@ -387,6 +389,115 @@ struct SequenceDataEncoder
     virtual void end_batch()
     { m_data->m_avg_sequence_len = m_data->m_n_seqs ? uint32(ceilf(float(m_data->m_sequence_stream_len) / float(m_data->m_n_seqs))) : 0u; }
 
+    /// one parsed record of a text file
+    struct TextRecord { const char* name; const uint8* bases; const uint8* quals; uint32 name_len, len; };
+    /// append a whole batch of records, each once per strand operation in `ops`, exactly as the push_back calls would -- but the
+    /// packing of the symbols and the quality conversion are spread over the OpenMP threads (the text scanner feeding this runs at
+    /// ~10 M records/s; one thread packing symbol by symbol ran at 1.2 M).  Sequences of different threads may share a word: words
+    /// are OR-ed atomically into zero-initialised storage.
+    void push_back_batch(const std::vector<TextRecord>& records, const QualityEncoding quality_encoding,
+                         const uint32 max_sequence_len, const uint32 trim3, const uint32 trim5, const StrandOp* ops, const uint32 n_ops)
+    {
+        const size_t n = records.size() * n_ops;
+        if (n == 0) return;
+        const uint32 bits = bits_per_symbol(m_alphabet), per_word = 32u / bits, mask = (1u << bits) - 1u;
+        const bool dna = (m_alphabet == DNA || m_alphabet == DNA_N);
+        const uint32 first = m_data->m_n_seqs;
+        m_data->m_sequence_index_vec.resize(first + n + 1u);
+        m_data->m_name_index_vec.resize(first + n + 1u);
+        uint32* index = priv::seq_ptr(m_data->m_sequence_index_vec);
+        uint32* nindex = priv::seq_ptr(m_data->m_name_index_vec);
+        uint32 end = m_data->m_sequence_stream_len, min_len = m_data->m_min_sequence_len, max_len = m_data->m_max_sequence_len;
+        size_t name_bytes = m_data->m_name_vec.size();
+        for (size_t r = 0; r < records.size(); ++r)
+        {
+            const uint32 in_len = records[r].len, trimmed = in_len > trim3 + trim5 ? in_len - trim3 - trim5 : 0u, len = std::min(trimmed, max_sequence_len);
+            const size_t name_len = size_t(records[r].name_len) + 1u;
+            for (uint32 o = 0; o < n_ops; ++o)
+            {
+                end += len; name_bytes += name_len;
+                index[first + r * n_ops + o + 1u] = end; nindex[first + r * n_ops + o + 1u] = uint32(name_bytes);
+            }
+            min_len = std::min(min_len, len); max_len = std::max(max_len, len);
+        }
+        m_data->m_sequence_vec.resize((end + per_word - 1u) / per_word, 0u);
+        m_data->m_qual_vec.resize(end);
+        m_data->m_name_vec.resize(name_bytes);
+        uint32* words = priv::seq_ptr(m_data->m_sequence_vec);
+        char*   qout  = priv::seq_ptr(m_data->m_qual_vec);
+        char*   nout  = priv::seq_ptr(m_data->m_name_vec);
+        uint8 phred[256], code[2][256];                 // file byte -> phred; file byte -> symbol, plain and complemented
+        for (uint32 q = 0; q < 256u; ++q)
+        {
+            phred[q] = priv::phred_quality(quality_encoding, uint8(q));
+            const uint32 c = dna ? priv::nt4_code(uint8(q)) : q;
+            code[0][q] = uint8(c & mask); code[1][q] = uint8((dna ? (c < 4u ? 3u - c : 4u) : c) & mask);
+        }
+        const uint32 word_shift = per_word == 16u ? 4u : per_word == 8u ? 3u : per_word == 4u ? 2u : 0u;
+        const int64 n_records = int64(records.size());
+        #pragma omp parallel for schedule(static) num_threads(usable_omp_threads())
+        for (int64 r = 0; r < n_records; ++r)
+        {
+            const uint8* bp = records[r].bases + trim5;
+            const uint8* qp = records[r].quals ? records[r].quals + trim5 : NULL;
+            for (uint32 o = 0; o < n_ops; ++o)
+            {
+                const size_t  e = first + size_t(r) * n_ops + o;
+                const uint32  begin = index[e], len = index[e + 1u] - begin;
+                const StrandOp op = ops[o];
+                const uint8* lut = code[(op & COMPLEMENT_OP) ? 1 : 0];
+                const bool   rev = (op & REVERSE_OP) != 0;
+                const ptrdiff_t step = rev ? -1 : 1;
+                // qualities
+                if (qp) { const uint8* q = rev ? qp + len - 1u : qp; char* o_ = qout + begin; for (uint32 i = 0; i < len; ++i, q += step) o_[i] = char(phred[*q]); }
+                else if (len) memset(qout + begin, 0, len);
+                // symbols: big-endian inside the word.  The words a sequence shares with its neighbours (its first and last, unless it
+                // starts / ends on a word boundary) are OR-ed atomically; the ones it owns are stored
+                const uint8* b_ = rev ? bp + len - 1u : bp;
+                uint32 i = 0, pos = begin;
+                if (word_shift)
+                {
+                    if (pos & (per_word - 1u))
+                    {
+                        uint32 acc = 0;
+                        for (; i < len && (pos & (per_word - 1u)); ++i, ++pos, b_ += step) acc |= uint32(lut[*b_]) << (32u - bits - (pos & (per_word - 1u)) * bits);
+                        __atomic_fetch_or(&words[(pos - 1u) >> word_shift], acc, __ATOMIC_RELAXED);
+                    }
+                    for (; i + per_word <= len; i += per_word, pos += per_word)
+                    {
+                        uint32 acc = 0;
+                        for (uint32 k = 0; k < per_word; ++k, b_ += step) acc |= uint32(lut[*b_]) << (32u - bits - k * bits);
+                        words[pos >> word_shift] = acc;
+                    }
+                    if (i < len)
+                    {
+                        uint32 acc = 0;
+                        for (; i < len; ++i, ++pos, b_ += step) acc |= uint32(lut[*b_]) << (32u - bits - (pos & (per_word - 1u)) * bits);
+                        __atomic_fetch_or(&words[(pos - 1u) >> word_shift], acc, __ATOMIC_RELAXED);
+                    }
+                }
+                else
+                {
+                    uint32 acc = 0;
+                    for (; i < len; ++i, ++pos, b_ += step)
+                    {
+                        const uint32 slot = pos % per_word;
+                        acc |= uint32(lut[*b_]) << (32u - bits - slot * bits);
+                        if (slot == per_word - 1u || i == len - 1u) { __atomic_fetch_or(&words[pos / per_word], acc, __ATOMIC_RELAXED); acc = 0; }
+                    }
+                }
+                memcpy(nout + nindex[e], records[r].name, records[r].name_len); nout[nindex[e] + records[r].name_len] = '\0';
+            }
+        }
+        m_data->m_n_seqs += uint32(n);
+        m_data->m_sequence_stream_len = end;
+        m_data->m_sequence_stream_words = (end + per_word - 1u) / per_word;
+        m_data->m_min_sequence_len = min_len; m_data->m_max_sequence_len = max_len;
+        m_data->m_name_stream_len = uint32(name_bytes);
+    }
+    /// true when push_back_batch() may stand in for push_back(): the encoder is this class itself, not a caller's subclass of it
+    bool is_plain() const { return typeid(*this) == typeid(SequenceDataEncoder); }
+
     const SequenceDataInfo* info() const { return m_data; }
     Alphabet alphabet() const { return m_alphabet; }
 
@@ -416,15 +527,25 @@ inline int next(const Alphabet alphabet, SequenceDataHost* data, SequenceDataInp
 }
 
 namespace priv {
-/// FASTQ ('@') and FASTA ('>') text, plain or gzip, record after record (sequence_fastq.cpp:60-300, sequence_fasta.cpp)
+/// FASTQ ('@') and FASTA ('>') text, plain or gzip (sequence_fastq.cpp:60-300, sequence_fasta.cpp).  The grammar, as the reference's
+/// character loop has it: bytes <= 31 are skipped before a record marker; the rest of the marker's line is the name ('\r' dropped);
+/// FASTQ bases are the characters '!'..'~' up to a '+', the rest of that line is ignored, and as many '!'..'~' characters as there were
+/// bases are the qualities, over however many lines; FASTA bases run to the next line that starts with '>', every base with the
+/// quality byte 50.  A record without bases contributes nothing.
+///
+/// The file is read in blocks and cut into lines with memchr; a record whose bases and qualities each sit on one clean line -- every
+/// record of an ordinary file -- is handed on as pointers into the block, anything else is normalised into a side buffer first.  With
+/// the plain encoder a whole batch of records is then packed by all OpenMP threads at once (SequenceDataEncoder::push_back_batch);
+/// a caller's own encoder subclass gets the same records one push_back at a time.
 struct TextSequenceFile : public SequenceDataInputStream
 {
     TextSequenceFile(const char* name, const QualityEncoding qualities, const uint32 max_seqs, const uint32 max_sequence_len, const SequenceEncoding flags,
                      const uint32 trim3, const uint32 trim5)
-        : m_src(name, 1u << 16), m_qualities(qualities), m_max_seqs(max_seqs), m_max_len(max_sequence_len), m_flags(flags), m_trim3(trim3), m_trim5(trim5), m_loaded(0), m_ok(m_src.valid()), m_eof(false) {}
+        : m_src(name, 1u << 16), m_qualities(qualities), m_max_seqs(max_seqs), m_max_len(max_sequence_len), m_flags(flags), m_trim3(trim3), m_trim5(trim5), m_loaded(0),
+          m_ok(m_src.valid()), m_eof(false), m_cur(0), m_raw_eof(false) {}
 
     bool is_ok() { return m_ok; }
-    bool rewind() { m_src.rewind(); m_loaded = 0; m_eof = false; return true; }
+    bool rewind() { m_src.rewind(); m_loaded = 0; m_eof = false; m_raw.clear(); m_cur = 0; m_raw_eof = false; return true; }
 
     int next(SequenceDataEncoder* encoder, const uint32 batch_size, const uint32 batch_bps = uint32(-1))
     {
@@ -432,46 +553,162 @@ struct TextSequenceFile : public SequenceDataInputStream
         if (!m_ok || want == 0u) return 0;
         encoder->begin_batch();
         { const uint32 n = std::min(want, 1u << 20); encoder->reserve(n, batch_bps == uint32(-1) ? n * 100u : std::min(batch_bps, 1u << 28)); }
+        SequenceDataEncoder::StrandOp ops[4]; uint32 n_ops = 0;              // one sequence per strand requested, in this order
+        if (m_flags & FORWARD)            ops[n_ops++] = SequenceDataEncoder::NO_OP;
+        if (m_flags & REVERSE)            ops[n_ops++] = SequenceDataEncoder::REVERSE_OP;
+        if (m_flags & FORWARD_COMPLEMENT) ops[n_ops++] = SequenceDataEncoder::COMPLEMENT_OP;
+        if (m_flags & REVERSE_COMPLEMENT) ops[n_ops++] = SequenceDataEncoder::REVERSE_COMPLEMENT_OP;
         const SequenceDataInfo* info = encoder->info();
-        while (info->size() < want && info->bps() < batch_bps && !m_eof)
-            if (!read_record(encoder)) break;
+        // what the last batch consumed of the block goes; what it did not is the start of this one
+        if (m_cur) { m_raw.erase(m_raw.begin(), m_raw.begin() + std::min(m_cur, m_raw.size())); m_cur = 0; }
+        m_scan.clear(); m_extra.clear();
+        // the stop rule of a record-at-a-time loop: enough sequences, or enough symbols, counted as they are appended
+        uint64 n_seqs = info->size(), n_bps = info->bps();
+        while (n_ops && n_seqs < want && n_bps < batch_bps && !m_eof)
+        {
+            Scan rec;
+            if (!scan_record(rec)) break;
+            if (rec.len == 0u) continue;
+            m_scan.push_back(rec);
+            const uint32 trimmed = rec.len > m_trim3 + m_trim5 ? rec.len - m_trim3 - m_trim5 : 0u;
+            n_seqs += n_ops; n_bps += uint64(std::min(trimmed, m_max_len)) * n_ops;
+        }
+        // (the block and the side buffer stop growing here: offsets become pointers)
+        m_records.resize(m_scan.size());
+        for (size_t i = 0; i < m_scan.size(); ++i)
+        {
+            const Scan& r = m_scan[i];
+            SequenceDataEncoder::TextRecord& t = m_records[i];
+            t.name = reinterpret_cast<const char*>(at(r.name)); t.bases = at(r.bases); t.quals = at(r.quals); t.name_len = r.name_len; t.len = r.len;
+        }
+        if (encoder->is_plain()) encoder->push_back_batch(m_records, m_qualities, m_max_len, m_trim3, m_trim5, ops, n_ops);
+        else
+        {
+            std::string name;
+            for (size_t i = 0; i < m_records.size(); ++i)
+            {
+                const SequenceDataEncoder::TextRecord& t = m_records[i];
+                name.assign(t.name, t.name_len);
+                for (uint32 o = 0; o < n_ops; ++o) encoder->push_back(t.len, name.c_str(), t.bases, t.quals, m_qualities, m_max_len, m_trim3, m_trim5, ops[o]);
+            }
+        }
         m_loaded += info->size();
         encoder->end_batch();
         return int(info->size());
     }
 
 private:
-    // one record -> one sequence per strand requested, in the order FORWARD, REVERSE, FORWARD_COMPLEMENT, REVERSE_COMPLEMENT
-    bool read_record(SequenceDataEncoder* encoder)
+    static const uint64 IN_EXTRA = uint64(1) << 63;
+    struct Scan { uint64 name, bases, quals; uint32 name_len, len; };       // offsets into the block, or (IN_EXTRA) the side buffer
+
+    const uint8* at(const uint64 off) const { return (off & IN_EXTRA) ? m_extra.data() + (off & ~IN_EXTRA) : m_raw.data() + off; }
+    static bool clean(const uint8* p, const size_t n) { uint32 bad = 0; for (size_t i = 0; i < n; ++i) bad |= uint32(uint8(p[i] - 0x21u) > 0x5Du); return bad == 0u; }
+    void append_printable(const size_t b, const size_t e) { for (size_t i = b; i < e; ++i) if (m_raw[i] >= 0x21u && m_raw[i] <= 0x7Eu) m_extra.push_back(m_raw[i]); }
+
+    /// more of the file into the block
+    bool fill()
     {
-        uint8 c = m_src.get();
-        while (c != 255u && c <= 31u) c = m_src.get();                              // blank lines between records
-        if (c == 255u) { m_eof = true; return false; }
-        if (c != '@' && c != '>') { m_ok = false; fprintf(stderr, "sequence file: parsing error (record starts with '%c')\n", c); return false; }
-        const bool fastq = (c == '@');
-        m_name.clear(); m_bp.clear(); m_q.clear();
-        for (c = m_src.get(); c != '\n' && c != 255u; c = m_src.get()) if (c != '\r') m_name.push_back(char(c));
-        m_name.push_back('\0');
-        if (fastq)
+        if (m_raw_eof) return false;
+        const size_t chunk = size_t(4) << 20, old = m_raw.size();
+        m_raw.resize(old + chunk);
+        const size_t got = m_src.read(m_raw.data() + old, chunk);
+        m_raw.resize(old + got);
+        if (got == 0) m_raw_eof = true;
+        return got > 0;
+    }
+    /// the next line [b, e) of the block, without its line end ('\n' or "\r\n"); false when the file is exhausted
+    bool line(size_t& b, size_t& e)
+    {
+        size_t from = m_cur;
+        for (;;)
         {
-            for (c = m_src.get(); c != '+' && c != 255u; c = m_src.get()) if (c >= 0x21 && c <= 0x7E) m_bp.push_back(c);
-            if (c == 255u) { m_ok = false; fprintf(stderr, "FASTQ loader: incomplete read \"%s\"\n", m_name.data()); return false; }
-            for (c = m_src.get(); c != '\n' && c != 255u; c = m_src.get()) {}
-            while (m_q.size() < m_bp.size()) { c = m_src.get(); if (c == 255u) break; if (c >= 0x21 && c <= 0x7E) m_q.push_back(c); }
-            if (m_q.size() < m_bp.size()) { m_ok = false; fprintf(stderr, "FASTQ loader: incomplete read \"%s\"\n", m_name.data()); return false; }
+            const void* nl = from < m_raw.size() ? memchr(m_raw.data() + from, '\n', m_raw.size() - from) : NULL;
+            if (nl) { b = m_cur; e = size_t(static_cast<const uint8*>(nl) - m_raw.data()); m_cur = e + 1u; break; }
+            from = m_raw.size();
+            if (!fill())
+            {
+                if (m_cur >= m_raw.size()) return false;
+                b = m_cur; e = m_raw.size(); m_cur = e; break;                // a last line without a line end
+            }
         }
-        else
+        if (e > b && m_raw[e - 1u] == '\r') --e;
+        return true;
+    }
+    bool fail(const char* what, const Scan& rec)
+    {
+        m_ok = false;
+        fprintf(stderr, "sequence file: %s in record \"%.*s\"\n", what, int(rec.name_len), reinterpret_cast<const char*>(at(rec.name)));
+        return false;
+    }
+
+    bool scan_record(Scan& rec)
+    {
+        size_t b = 0, e = 0, s = 0;
+        for (;;)                                                               // blank lines between records
         {
-            for (c = m_src.get(); c != '>' && c != 255u; c = m_src.get()) if (c >= 0x21 && c <= 0x7E) m_bp.push_back(c);
-            if (c == '>') m_src.unget();
-            m_q.assign(m_bp.size(), uint8(50u));       // FASTA carries no qualities: the byte 50 goes through the quality encoding (sequence_fasta.cpp:60-61)
+            if (!line(b, e)) { m_eof = true; return false; }
+            for (s = b; s < e && m_raw[s] <= 31u; ++s) {}
+            if (s < e) break;
         }
-        if (m_bp.empty()) return true;                                                    // (an empty record contributes nothing)
-        const uint32 len = uint32(m_bp.size());
-        if (m_flags & FORWARD)            encoder->push_back(len, m_name.data(), m_bp.data(), m_q.data(), m_qualities, m_max_len, m_trim3, m_trim5, SequenceDataEncoder::NO_OP);
-        if (m_flags & REVERSE)            encoder->push_back(len, m_name.data(), m_bp.data(), m_q.data(), m_qualities, m_max_len, m_trim3, m_trim5, SequenceDataEncoder::REVERSE_OP);
-        if (m_flags & FORWARD_COMPLEMENT) encoder->push_back(len, m_name.data(), m_bp.data(), m_q.data(), m_qualities, m_max_len, m_trim3, m_trim5, SequenceDataEncoder::COMPLEMENT_OP);
-        if (m_flags & REVERSE_COMPLEMENT) encoder->push_back(len, m_name.data(), m_bp.data(), m_q.data(), m_qualities, m_max_len, m_trim3, m_trim5, SequenceDataEncoder::REVERSE_COMPLEMENT_OP);
+        const uint8 marker = m_raw[s];
+        if (marker != '@' && marker != '>') { m_ok = false; fprintf(stderr, "sequence file: parsing error (record starts with '%c')\n", marker); return false; }
+        rec.name = s + 1u; rec.name_len = uint32(e - s - 1u); rec.len = 0; rec.bases = rec.quals = 0;
+        if (rec.name_len && memchr(m_raw.data() + s + 1u, '\r', rec.name_len))
+        {
+            rec.name = IN_EXTRA | m_extra.size();
+            for (size_t i = s + 1u; i < e; ++i) if (m_raw[i] != '\r') m_extra.push_back(m_raw[i]);
+            rec.name_len = uint32(m_extra.size() - (rec.name & ~IN_EXTRA));
+        }
+        if (marker == '>')
+        {
+            rec.bases = IN_EXTRA | m_extra.size();
+            for (;;)
+            {
+                const size_t before = m_cur;
+                if (!line(b, e)) break;
+                if (e > b && m_raw[b] == '>') { m_cur = before; break; }       // the next record's marker: not ours
+                append_printable(b, e);
+            }
+            rec.len = uint32(m_extra.size() - (rec.bases & ~IN_EXTRA));
+            rec.quals = IN_EXTRA | m_extra.size();
+            m_extra.insert(m_extra.end(), rec.len, uint8(50u));               // FASTA carries no qualities: the byte 50 goes through the quality encoding (sequence_fasta.cpp:60-61)
+            return true;
+        }
+        // FASTQ bases: up to the first '+'
+        bool direct = true; size_t first_b = 0, first_e = 0; uint32 lines = 0;
+        for (;;)
+        {
+            if (!line(b, e)) return fail("incomplete read", rec);
+            const void* plus = e > b ? memchr(m_raw.data() + b, '+', e - b) : NULL;
+            const size_t stop = plus ? size_t(static_cast<const uint8*>(plus) - m_raw.data()) : e;
+            if (stop > b)
+            {
+                if (lines == 0 && clean(m_raw.data() + b, stop - b)) { first_b = b; first_e = stop; }
+                else
+                {
+                    if (direct) { direct = false; rec.bases = IN_EXTRA | m_extra.size(); if (lines) append_printable(first_b, first_e); }
+                    append_printable(b, stop);
+                }
+                ++lines;
+            }
+            if (plus) break;
+        }
+        if (direct) { rec.bases = first_b; rec.len = uint32(first_e - first_b); }
+        else rec.len = uint32(m_extra.size() - (rec.bases & ~IN_EXTRA));
+        // FASTQ qualities: as many printable characters as bases
+        uint32 have = 0; direct = true; lines = 0;
+        while (have < rec.len)
+        {
+            if (!line(b, e)) return fail("incomplete read", rec);
+            if (e == b) continue;
+            if (lines == 0 && e - b == rec.len && clean(m_raw.data() + b, e - b)) { rec.quals = b; have = rec.len; break; }
+            if (direct) { direct = false; rec.quals = IN_EXTRA | m_extra.size(); }
+            append_printable(b, e);
+            have = uint32(m_extra.size() - (rec.quals & ~IN_EXTRA));
+            ++lines;
+        }
+        // (the character loop takes exactly rec.len quality characters and trips over the rest of the line at the next record)
+        if (have > rec.len) return fail("more qualities than bases", rec);
         return true;
     }
 
@@ -481,8 +718,11 @@ private:
     SequenceEncoding   m_flags;
     uint32             m_trim3, m_trim5, m_loaded;
     bool               m_ok, m_eof;
-    std::vector<char>  m_name;
-    std::vector<uint8> m_bp, m_q;
+    std::vector<uint8> m_raw, m_extra;          // the block being cut into records; the normalised irregular ones
+    size_t             m_cur;                   // first unconsumed byte of the block
+    bool               m_raw_eof;
+    std::vector<Scan>  m_scan;
+    std::vector<SequenceDataEncoder::TextRecord> m_records;
 };
 } // namespace priv
 

@@ -65,3 +65,40 @@ extern "C" void gaps(int match, int open, int ext, int min_score, int len, uint3
     out[1] = aln::max_pattern_gaps(aln::make_gotoh_aligner<aln::LOCAL>(g), min_score, len);
     out[2] = aln::max_text_gaps(aln::make_edit_distance_aligner<aln::SEMI_GLOBAL>(), min_score, len);
 }
+
+// ---- the text sequence loader (io/sequence/sequence.h): batch form (the plain encoder) and record-at-a-time form (any subclass) ----
+#include <nvbio/io/sequence/sequence.h>
+#include <memory>
+namespace {
+struct RecordwiseEncoder : nvbio::io::SequenceDataEncoder
+{
+    RecordwiseEncoder(const nvbio::Alphabet a, nvbio::io::SequenceDataHost* d) : nvbio::io::SequenceDataEncoder(a, d) {}
+};
+}
+/// load `path` in batches of `batch_size`; symbols / qualities / names ('\0'-separated) / index of all batches are concatenated.
+/// returns the number of sequences, or -1 when a capacity is exceeded, -2 when the file does not open
+extern "C" int load_reads(const char* path, uint32 flags, uint32 qenc, uint32 max_len, uint32 trim3, uint32 trim5, uint32 batch_size, int recordwise,
+                          uint32* index, uint8* symbols, uint8* quals, char* names, uint32 cap_seqs, uint32 cap_syms, uint32 cap_names, uint32* info)
+{
+    std::unique_ptr<io::SequenceDataInputStream> f(io::open_sequence_file(path, io::QualityEncoding(qenc), uint32(-1), max_len, io::SequenceEncoding(flags), trim3, trim5));
+    if (!f) return -2;
+    uint32 n = 0, syms = 0, name_bytes = 0;
+    index[0] = 0;
+    for (;;)
+    {
+        io::SequenceDataHost data;
+        int got;
+        if (recordwise) { RecordwiseEncoder enc(DNA_N, &data); got = f->next(&enc, batch_size); }
+        else got = io::next(DNA_N, &data, f.get(), batch_size);
+        if (got <= 0) break;
+        const io::SequenceDataAccess<DNA_N> access(data);
+        if (n + data.size() > cap_seqs || syms + data.bps() > cap_syms || name_bytes + data.m_name_stream_len > cap_names) return -1;
+        for (uint32 i = 0; i < data.bps(); ++i) { symbols[syms + i] = access.sequence_stream()[i]; quals[syms + i] = uint8(access.qual_stream()[i]); }
+        for (uint32 i = 0; i < data.size(); ++i) index[n + i + 1] = syms + access.sequence_index()[i + 1];
+        for (uint32 i = 0; i < data.m_name_stream_len; ++i) names[name_bytes + i] = access.name_stream()[i];
+        info[0] = data.min_sequence_len(); info[1] = data.max_sequence_len(); info[2] = data.avg_sequence_len();
+        n += data.size(); syms += data.bps(); name_bytes += data.m_name_stream_len;
+    }
+    info[3] = name_bytes; info[4] = f->is_ok() ? 1u : 0u;
+    return int(n);
+}

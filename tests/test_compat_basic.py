@@ -83,3 +83,66 @@ def test_reference_rank_test_passes_on_the_drop_in_layer():
     r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "ref_rank_test"), "-length", "200"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-400:]
     assert "rank test... done" in r.stderr and "mismatch" not in r.stderr
+
+
+def _load_reads(hb, path, flags, qenc=1, max_len=0xFFFFFFFF, trim3=0, trim5=0, batch=1 << 20, recordwise=0, cap=1 << 22):
+    index = np.zeros(200001, np.uint32); syms = np.zeros(cap, np.uint8); quals = np.zeros(cap, np.uint8)
+    names = np.zeros(cap, np.uint8); info = np.zeros(8, np.uint32)
+    n = hb.load_reads(str(path).encode(), C.c_uint32(flags), C.c_uint32(qenc), C.c_uint32(max_len), C.c_uint32(trim3), C.c_uint32(trim5),
+                      C.c_uint32(batch), C.c_int(recordwise), p(index), p(syms), p(quals), p(names), C.c_uint32(index.size - 1), C.c_uint32(cap),
+                      C.c_uint32(cap), p(info))
+    assert n >= 0, n
+    total = int(index[n])
+    nm = bytes(names[:int(info[3])]).split(b"\0")[:-1] if info[3] else []
+    return n, index[:n + 1].copy(), syms[:total].copy(), quals[:total].copy(), nm, info
+
+
+@pytest.mark.parametrize("flags", [1, 2, 1 | 8, 1 | 2 | 4 | 8])
+def test_text_sequence_loader_batch_and_record_forms(hb, tmp_path, flags):
+    """The drop-in FASTQ loader (compat/nvbio/io/sequence/sequence.h): its batch form -- lines parsed into flat arrays, symbols packed
+    by all OpenMP threads -- and its record-at-a-time form give the same SequenceData, which is the one nvbio_amd.io.read_fastq
+    (the restatement of sequence_encoder.cpp checked in test_io_formats.py) builds; several batches, ragged lengths, N, lower case."""
+    from nvbio_amd import io as nio
+    rng = np.random.default_rng(77 + flags)
+    n = 3000
+    lens = rng.integers(1, 160, n)
+    fq = tmp_path / "r.fastq"
+    with open(fq, "wb") as f:
+        for i in range(n):
+            s = rng.choice(np.frombuffer(b"ACGTNacgt", np.uint8), lens[i]).tobytes()
+            q = rng.integers(33, 74, lens[i]).astype(np.uint8).tobytes()
+            f.write(b"@read%d\n%s\n+\n%s\n" % (i, s, q))
+    want = nio.read_fastq(str(fq), flags=flags)
+    for recordwise in (0, 1):
+        for batch in (1 << 20, 257):
+            got_n, index, syms, quals, names, info = _load_reads(hb, fq, flags, batch=batch, recordwise=recordwise)
+            assert got_n == want.size() and (index == want.sequence_index).all()
+            assert (syms == want.symbols).all() and (quals == want.quals).all()
+            per = bin(flags).count("1")
+            assert names == [("read%d" % (i // per)).encode() for i in range(got_n)]
+            assert info[4] == 1
+    # trimming and truncation are applied per strand copy, before the strand operation
+    t_n, t_index, t_syms, t_quals, _, _ = _load_reads(hb, fq, flags, trim3=3, trim5=2, max_len=50)
+    r_n, r_index, r_syms, r_quals, _, _ = _load_reads(hb, fq, flags, trim3=3, trim5=2, max_len=50, recordwise=1)
+    assert t_n == r_n and (t_index == r_index).all() and (t_syms == r_syms).all() and (t_quals == r_quals).all()
+    fwd = nio.read_fastq(str(fq), flags=1)
+    if flags == 1:
+        for i in (0, 1, 2, n - 1):
+            b, e = int(fwd.sequence_index[i]), int(fwd.sequence_index[i + 1])
+            keep = min(max(e - b - 5, 0), 50)
+            assert (t_syms[t_index[i]:t_index[i + 1]] == fwd.symbols[b + 2:b + 2 + keep]).all()
+
+
+def test_text_sequence_loader_tolerates_line_breaks_and_blank_lines(hb, tmp_path):
+    """CR LF line ends, records wrapped over several lines, blank lines between records, a FASTA record: both forms agree with the
+    plain 4-line text"""
+    plain = tmp_path / "p.fastq"; odd = tmp_path / "o.fastq"
+    plain.write_bytes(b"@a x\nACGTACGTAC\n+\nIIIIIIIIII\n@b\nTTNNA\n+\n#####\n@c\nG\n+\n5\n")
+    odd.write_bytes(b"@a x\r\nACGTA\r\nCGTAC\r\n+a x\r\nIIIII\r\nIIIII\r\n\r\n\n@b\nTTNNA\n+\n#####\n\n@c\nG\n+\n5")
+    ref = _load_reads(hb, plain, 2)
+    for recordwise in (0, 1):
+        got = _load_reads(hb, odd, 2, recordwise=recordwise)
+        assert got[0] == ref[0] == 3 and all((a == b).all() for a, b in zip(got[1:4], ref[1:4])) and got[4] == ref[4] == [b"a x", b"b", b"c"]
+    bad = tmp_path / "bad.fastq"; bad.write_bytes(b"@x\nACGT\n+\nII\n")
+    for recordwise in (0, 1):
+        assert _load_reads(hb, bad, 1, recordwise=recordwise)[5][4] == 0          # is_ok() turns false: incomplete read

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--genome", type=int, default=4_000_000)
     ap.add_argument("--reads", type=int, default=1_000_000)
     ap.add_argument("--extra", default="")
+    ap.add_argument("--wrap", default="", help="a command prefix to run nvBowtie under, e.g. 'rocprofv3 --kernel-trace --stats -d /tmp/p -o n --'")
     args = ap.parse_args()
     from nvbio_amd import io as nio
     from oracle import pyoracle as O
@@ -51,7 +52,7 @@ def main():
             f.write(b"@r%d\n" % i); f.write(seq[i].tobytes()); f.write(b"\n+\n"); f.write(qual); f.write(b"\n")
     print("fastq written in %.1f s" % (time.time() - t0))
     sam = os.path.join(tmp, "out.sam")
-    cmd = [os.path.join(ROOT, "oracle", "_ref", "ref_nvBowtie")] + args.extra.split() + ["--file-ref", "-x", prefix, "-U", fq, "-S", sam]
+    cmd = args.wrap.split() + [os.path.join(ROOT, "oracle", "_ref", "ref_nvBowtie")] + args.extra.split() + ["--file-ref", "-x", prefix, "-U", fq, "-S", sam]
     t0 = time.time()
     r = subprocess.run(cmd, capture_output=True, text=True)
     dt = time.time() - t0
