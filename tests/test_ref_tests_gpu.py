@@ -210,8 +210,30 @@ def test_own_drivers_equal_reference_nvbowtie_in_every_mode(mode, cuda):
     assert same == n_ref, (mode, same, n_ref)
 
 
+@pytest.mark.parametrize("case", [dict(mode="se", quals="random", seed=41), dict(mode="local", quals="random", len=250, seed=42),
+                                  dict(mode="se", ns=0.01, len=150, seed=43), dict(mode="se", len=50, seed=45),
+                                  dict(mode="all", quals="random", ns=0.005, seed=46)],
+                         ids=["se-random-quals", "local-250bp-random-quals", "se-150bp-with-N", "se-50bp", "all-random-quals-with-N"])
+def test_own_drivers_equal_reference_nvbowtie_on_varied_reads(case, cuda):
+    """Per-base qualities drawn from phred 2 .. 40 (nvBowtie's mismatch penalty depends on them, scoring.h:206-356), reads with N, read
+    lengths 50 / 150 / 250: still every SAM record of the reference's application equals the from-scratch driver's."""
+    import argparse
+    import sys
+    if not os.path.exists(os.path.join(REF, "ref_nvBowtie")):
+        pytest.skip("oracle/_ref/ref_nvBowtie not built (needs /root/reference in the build container)")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import nvbowtie_compare
+    args = dict(mode="se", reads=3000, seed=5, indels=0.2, show=3, len=100, ns=0.0, quals="I"); args.update(case)
+    same, n_ref, n_own = nvbowtie_compare.compare(argparse.Namespace(**args))
+    assert n_ref == n_own and n_ref >= 3000
+    assert same == n_ref, (case, same, n_ref)
+
+
 def test_own_driver_equals_reference_nvbowtie_above_half_a_batch(cuda):
-    """More than BATCH_SIZE / 2 reads in flight: nvBowtie then selects ONE hit per read and round through its warp-aggregated queue allocation
+    """More than BATCH_SIZE / 2 reads in flight (and, with this seed, reads with an insertion over the first bases of the genome: their
+    seed hits locate below zero, `SA position - offset in the read` wraps, and nvBowtie loads a scoring window ~1 GiB past the reference
+    stream -- io::SequenceDataDevice covers every 32-bit coordinate for that, compat/nvbio/io/sequence/sequence.h: coordinate_cover).
+    More than BATCH_SIZE / 2 reads in flight: nvBowtie then selects ONE hit per read and round through its warp-aggregated queue allocation
     (`alloc()`, utils.h:58-71: a ballot, a leader elected by `mask << (32 - warp_tid())` -- a shift by 32 for lane 0, which CUDA defines as 0
     and the drop-in layer's warp_tid() type reproduces --, a broadcast through a per-warp shared slot), on 32-lane virtual warps.  600 000
     reads, end to end; every SAM record equal to the from-scratch driver's."""

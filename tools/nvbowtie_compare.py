@@ -36,10 +36,12 @@ def mutate(rng, r, rate):
     return r
 
 
-def write_fastq(path, reads, tag, qual="I"):
+def write_fastq(path, reads, tag, qual="I", rng=None):
+    """qual: one character for every base, or "random" (with rng): phred 2 .. 40 drawn per base"""
     with open(path, "w") as f:
         for i, r in enumerate(reads):
-            f.write("@%s%d\n%s\n+\n%s\n" % (tag, i, "".join("ACGT"[c] for c in r), qual * len(r)))
+            q = qual * len(r) if qual != "random" else "".join(chr(33 + int(v)) for v in rng.integers(2, 41, len(r)))
+            f.write("@%s%d\n%s\n+\n%s\n" % (tag, i, "".join("ACGTN"[c] for c in r), q))
 
 
 def records(text):
@@ -53,6 +55,9 @@ def main():
     ap.add_argument("--seed", type=int, default=5)
     ap.add_argument("--indels", type=float, default=0.2)
     ap.add_argument("--show", type=int, default=4)
+    ap.add_argument("--len", type=int, default=100, help="read length (single-end modes)")
+    ap.add_argument("--ns", type=float, default=0.0, help="fraction of read bases replaced by N (single-end modes)")
+    ap.add_argument("--quals", default="I", help="one quality character for all bases, or 'random' (single-end modes)")
     args = ap.parse_args()
     same, n_ref, n_own = compare(args)
     return 0 if same == max(n_ref, n_own) and n_ref else 1
@@ -65,7 +70,7 @@ def compare(args):
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_nvBowtie")
     rng = np.random.default_rng(args.seed)
     tmp = tempfile.mkdtemp(prefix="nvbcmp_")
-    n_genome, L, n = 200_000, 100, args.reads
+    n_genome, L, n = 200_000, (getattr(args, "len", 100) if args.mode != "paired" else 100), args.reads
     prefix, text = write_reference(tmp, rng, n_genome, [("chrA", 120_000), ("chrB", 80_000)])
     if args.mode == "all":                                   # some repeats, so that reads have several placements
         pass
@@ -88,12 +93,15 @@ def compare(args):
         for i, p in enumerate(pos):
             r = text[p:p + L].copy()
             if rng.random() < args.indels:
-                k, g = int(rng.integers(30, 70)), int(rng.integers(1, 3))
+                k, g = int(rng.integers(3 * L // 10, 7 * L // 10)), int(rng.integers(1, 3))
                 r = np.concatenate([r[:k], rng.integers(0, 4, g).astype(np.uint8), r[k:]])[:L] if rng.random() < 0.5 else np.concatenate([text[p:p + k], text[p + k + g:p + L + g]])
             r = mutate(rng, r, 0.03)
-            reads.append((3 - r)[::-1] if i % 2 else r)
+            r = (3 - r)[::-1] if i % 2 else r
+            if getattr(args, "ns", 0.0) > 0.0:
+                r = np.where(rng.random(r.size) < args.ns, 4, r).astype(np.uint8)
+            reads.append(r)
         fq = os.path.join(tmp, "reads.fastq")
-        write_fastq(fq, reads, "read")
+        write_fastq(fq, reads, "read", getattr(args, "quals", "I"), rng)
         # (mode flags go first: nvBowtie reads argv[i + 1] after an option it does not know, nvBowtie.cpp:343)
         cmd = [exe] + (["--local"] if args.mode == "local" else ["--all"] if args.mode == "all" else []) + ["--file-ref", "-x", prefix, "-U", fq, "-S", sam]
         if args.mode == "all":
