@@ -241,8 +241,8 @@ def best_approx(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=No
 # paired-end: Aligner::best_approx / best_approx_score of aligner_best_approx_paired.h (:95-453, :455-700)
 # ------------------------------------------------------------------------------------------------------------------
 def best_approx_score_paired(fmi, rfmi, state, seed_queue, anchor, best, best_o, a_words, o_words, n_reads, read_len, genome_words, genome_len,
-                             scheme, banded_aligner, full_aligner, quals, table, params, band_len, stats, memo):
-    """The extension rounds of one seeding pass of one anchor mate: select, locate, anchor_score_best, opposite_score_best over the
+                             scheme, banded_aligner, full_aligner, quals, table, params, band_len, stats, memo, o_quals=None):
+    """The extension rounds of one seeding pass of one anchor mate (`quals`: the anchor mate's quality stream, `o_quals`: the opposite mate's): select, locate, anchor_score_best, opposite_score_best over the
     hits whose anchor scored, score_reduce_paired with the give-up counters."""
     L = read_len
     active = seed_queue.to(torch.int32)
@@ -282,7 +282,7 @@ def best_approx_score_paired(fmi, rfmi, state, seed_queue, anchor, best, best_o,
                 o_txt = PackedStringSet(genome_words, 2, True, ob.contiguous(), (oe - ob).to(torch.int32).contiguous(), 0)
                 o_ms = ow["min_score"][idx].contiguous()
                 max_n = int(params.max_frag_len) + L
-                s_o, k_o, _ = batch_alignment_score(full_aligner, o_pat, o_txt, L, max_n, o_ms, quals=quals)
+                s_o, k_o, _ = batch_alignment_score(full_aligner, o_pat, o_txt, L, max_n, o_ms, quals=quals if o_quals is None else o_quals)
             else:
                 s_o = torch.empty(0, dtype=torch.int32, device=loc.device); k_o = torch.empty((0, 2), dtype=torch.int32, device=loc.device)
             o_score, o_score2, o_loc, o_sink, o_sink2 = sel.opposite_score_finish(idx.to(torch.int32), s_o, k_o, ow["min_score"], ow["genome_begin"],
@@ -298,8 +298,9 @@ def best_approx_score_paired(fmi, rfmi, state, seed_queue, anchor, best, best_o,
 
 
 def best_approx_paired(fmi, rfmi, sym1, sym2, genome_words, genome_len, params=None, scheme=None, names=None, qual_value=30, traceback=True,
-                       cigar_stride=64, stage_times=False, finish=False, mds_stride=256):
-    """Aligner::best_approx for read pairs (equal-length mates sym1 / sym2, uint8 [n, L]).  Returns dict(best, best_o int64[2,n]
+                       cigar_stride=64, stage_times=False, finish=False, mds_stride=256, quals1=None, quals2=None):
+    """Aligner::best_approx for read pairs (equal-length mates sym1 / sym2, uint8 [n, L]; quals1 / quals2: their phred qualities, uint8
+    [n, L], or None for `qual_value` throughout).  Returns dict(best, best_o int64[2,n]
     io::Alignment words of the anchor / opposite slots, mapq1, mapq2 uint8[n], and with traceback per slot set ("1" = best_data,
     "2" = best_data_o): cigar, cigar_len, source, sink; stats)."""
     from .pipeline import pack_read_streams
@@ -313,7 +314,7 @@ def best_approx_paired(fmi, rfmi, sym1, sym2, genome_words, genome_len, params=N
     full_aligner = make_gotoh_aligner(aln_type, scheme, PATTERN_BLOCKING)            # nvBowtie's aligners carry the default tag
     band_len = band_length(params.max_dist)
     packed = [pack_read_streams(sym1), pack_read_streams(sym2)]                       # per mate: (reversed reads, fw + rc words)
-    quals = torch.full((2 * n * L + 8,), qual_value, dtype=torch.uint8, device=dev)
+    mate_quals = [_qual_stream(n, L, qual_value, quals1, dev), _qual_stream(n, L, qual_value, quals2, dev)]   # laid out like each mate's fw + rc words
     if not params.randomized:
         name_arena = None
     elif isinstance(names, tuple):
@@ -345,7 +346,7 @@ def best_approx_paired(fmi, rfmi, sym1, sym2, genome_words, genome_len, params=N
             with _Stage(stats, "select_init"):
                 state = sel.SelectState(hits, counts, name_arena, params.max_effort_init, params.randomized, params.top_seed)
             best_approx_score_paired(fmi, rfmi, state, seed_queue, anchor, best, best_o, a_words, o_words, n, L, genome_words, genome_len, scheme,
-                                     banded_aligner, full_aligner, quals, table, params, band_len, stats, memo)
+                                     banded_aligner, full_aligner, mate_quals[anchor], table, params, band_len, stats, memo, o_quals=mate_quals[1 - anchor])
             seed_queue = seed_queue[reseed != 0]                                      # copy_flagged (no mark_unaligned in the paired driver)
     if params.pe_discordant:
         sel.mark_discordant(best, best_o)
@@ -357,7 +358,8 @@ def best_approx_paired(fmi, rfmi, sym1, sym2, genome_words, genome_len, params=N
         # both mates' fw + rc patterns in one stream: a traceback picks its read by the alignment's mate bit (traceback_inl.h:117-120)
         mate_words = torch.cat([packed[0][1], packed[1][1]])
         mate_offset = int(packed[0][1].numel()) * 8
-        tq = torch.full((mate_offset + 2 * n * L + 8,), qual_value, dtype=torch.uint8, device=dev)
+        tq = torch.zeros(mate_offset + 2 * n * L + 8, dtype=torch.uint8, device=dev)
+        tq[: 2 * n * L] = mate_quals[0][: 2 * n * L]; tq[mate_offset: mate_offset + 2 * n * L] = mate_quals[1][: 2 * n * L]
         sets = lambda pb, tbeg, tlen: (PackedStringSet(mate_words, 4, True, pb, None, L), PackedStringSet(genome_words, 2, True, tbeg, tlen, 0))
         with _Stage(stats, "traceback"):
             # banded_traceback_best over the anchor slots (every aligned entry)

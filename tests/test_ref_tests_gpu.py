@@ -212,8 +212,8 @@ def test_own_drivers_equal_reference_nvbowtie_in_every_mode(mode, cuda):
 
 @pytest.mark.parametrize("case", [dict(mode="se", quals="random", seed=41), dict(mode="local", quals="random", len=250, seed=42),
                                   dict(mode="se", ns=0.01, len=150, seed=43), dict(mode="se", len=50, seed=45),
-                                  dict(mode="all", quals="random", ns=0.005, seed=46)],
-                         ids=["se-random-quals", "local-250bp-random-quals", "se-150bp-with-N", "se-50bp", "all-random-quals-with-N"])
+                                  dict(mode="all", quals="random", ns=0.005, seed=46), dict(mode="paired", quals="random", seed=51)],
+                         ids=["se-random-quals", "local-250bp-random-quals", "se-150bp-with-N", "se-50bp", "all-random-quals-with-N", "paired-random-quals"])
 def test_own_drivers_equal_reference_nvbowtie_on_varied_reads(case, cuda):
     """Per-base qualities drawn from phred 2 .. 40 (nvBowtie's mismatch penalty depends on them, scoring.h:206-356), reads with N, read
     lengths 50 / 150 / 250: still every SAM record of the reference's application equals the from-scratch driver's."""

@@ -138,7 +138,8 @@ def main_paired(prefix, fastq1, fastq2, out=sys.stdout, device="cuda", ref_name=
     L = int(lens[0])
     mats = [torch.from_numpy(r.symbols.reshape(n, L)).to(device) for r in (r1, r2)]
     params = A.Params(hits_stride=32, **param_overrides)
-    r = A.best_approx_paired(data.index(), None, mats[0], mats[1], genome_words, n_genome, params, names=list(r1.names), finish=True)
+    quals = [torch.from_numpy(r.quals.reshape(n, L)).to(device) for r in (r1, r2)]
+    r = A.best_approx_paired(data.index(), None, mats[0], mats[1], genome_words, n_genome, params, names=list(r1.names), finish=True, quals1=quals[0], quals2=quals[1])
     torch.cuda.synchronize()
     slots = []
     for key_best, key_tb, key_mds, key_mapq in (("best", "tb1", "mds1", "mapq1"), ("best_o", "tb2", "mds2", "mapq2")):

@@ -83,7 +83,8 @@ def compare(args):
         m1 = [mutate(rng, text[p:p + L], 0.02) for p in pos]
         m2 = [mutate(rng, (3 - text[p + f - L:p + f])[::-1], 0.02) for p, f in zip(pos, frag)]
         f1, f2 = os.path.join(tmp, "m1.fastq"), os.path.join(tmp, "m2.fastq")
-        write_fastq(f1, m1, "pair", "?"); write_fastq(f2, m2, "pair", "?")       # Q30 throughout: the Python paired driver takes one quality value
+        q = getattr(args, "quals", "I")
+        write_fastq(f1, m1, "pair", q, rng); write_fastq(f2, m2, "pair", q, rng)
         cmd = [exe, "--file-ref", "-x", prefix, "-1", f1, "-2", f2, "-S", sam]
         own = lambda: align_fastq.main_paired(prefix, f1, f2, buf, device=dev)
     else:
