@@ -89,7 +89,7 @@ NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void banded_job(const stream_type& stream, c
 {
     priv::fresh_context<typename stream_type::context_type> ctx_storage; typename stream_type::context_type& ctx = ctx_storage.get();
     typename stream_type::strings_type strings;
-    if (!stream.init_context(i, &ctx)) return;
+    if (!stream.init_context(i, &ctx)) { stream.output(i, &ctx); return; }      // a declined job is still output, as init_context left it (batched_banded_inl.h:53-75, batched_inl.h:58-63)
     const uint32 len = stream.pattern_length(i, &ctx);
     stream.load_strings(i, 0u, len, &ctx, &strings);
     banded_alignment_score<BAND_LEN>(stream.aligner(), strings.pattern, strings.quals, strings.text, ctx.min_score, ctx.sink);
@@ -100,7 +100,7 @@ NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void full_job(const stream_type& stream, con
 {
     priv::fresh_context<typename stream_type::context_type> ctx_storage; typename stream_type::context_type& ctx = ctx_storage.get();
     typename stream_type::strings_type strings;
-    if (!stream.init_context(i, &ctx)) return;
+    if (!stream.init_context(i, &ctx)) { stream.output(i, &ctx); return; }      // a declined job is still output, as init_context left it (batched_banded_inl.h:53-75, batched_inl.h:58-63)
     const uint32 len = stream.pattern_length(i, &ctx);
     stream.load_strings(i, 0u, len, &ctx, &strings);
     alignment_score(stream.aligner(), strings.pattern, strings.quals, strings.text, ctx.min_score, ctx.sink, column);
@@ -503,7 +503,7 @@ __global__ void __launch_bounds__(128) output_jobs_kernel(const stream_type stre
     const uint32 i = blockIdx.x * 128u + threadIdx.x;
     if (i >= stream.size()) return;
     priv::fresh_context<typename stream_type::context_type> ctx_storage; typename stream_type::context_type& ctx = ctx_storage.get();
-    if (!stream.init_context(i, &ctx)) return;
+    if (!stream.init_context(i, &ctx)) { stream.output(i, &ctx); return; }      // a declined job is still output, as init_context left it (batched_banded_inl.h:53-75, batched_inl.h:58-63)
     const uint2 k = make_uint2(t.sink[2u * i], t.sink[2u * i + 1u]);
     if (!(k.x == 0xFFFFFFFFu && k.y == 0xFFFFFFFFu)) { ctx.sink.score = t.score[i]; ctx.sink.sink = k; }
     stream.output(i, &ctx);

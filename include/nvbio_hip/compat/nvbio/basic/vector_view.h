@@ -5,6 +5,15 @@
 
 namespace nvbio {
 
+namespace priv {
+/// what a const view hands out: `const T&` into the storage when the iterator refers to real objects (vector_view.h:96: to_const<reference>
+/// -- nvBowtie's non-randomized selection keeps `&deque.top()` and pops SA rows off that hit in place, select_inl.h:108-127, so a copy
+/// here is a dangling pointer there), the value where the iterator's reference is a proxy (packed streams)
+template <typename R, typename V> struct view_const_reference            { typedef V        type; };
+template <typename T, typename V> struct view_const_reference<T&, V>       { typedef const T& type; };
+template <typename T, typename V> struct view_const_reference<const T&, V> { typedef const T& type; };
+} // namespace priv
+
 template <typename Iterator, typename IndexType = uint32>
 struct vector_view
 {
@@ -12,7 +21,7 @@ struct vector_view
     typedef Iterator                                                const_iterator;
     typedef typename std::iterator_traits<Iterator>::value_type     value_type;
     typedef typename std::iterator_traits<Iterator>::reference      reference;
-    typedef value_type                                              const_reference;
+    typedef typename priv::view_const_reference<reference, value_type>::type const_reference;
     typedef IndexType                                               index_type;
     typedef IndexType                                               size_type;
     typedef typename std::iterator_traits<Iterator>::pointer         pointer;

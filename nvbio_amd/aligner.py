@@ -440,7 +440,8 @@ def all_mapping(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=No
             raise ValueError("all_mapping: the reference's seed cap (%d) would drop seeds of %d-bp reads; this seeding interval is not supported" % (max_seeds, l))
     with _Stage(stats, "map"):
         hits, counts, _ = mapping.map_seeds(fmi, rfmi, batch.reversed, mp, L, allow_sub=params.allow_sub, subseed_len=params.subseed_len, retry=0,
-                                            fw=params.fw, rc=params.rc, in_queue=None, hits_stride=hits_stride)
+                                            fw=params.fw, rc=params.rc, in_queue=None, hits_stride=hits_stride,
+                                            algorithm=mapping.APPROX_MAPPING if params.allow_sub else mapping.EXACT_MAPPING)
     empty = dict(read_id=torch.zeros(0, dtype=torch.int32, device=dev), alignments=torch.zeros(0, dtype=torch.int64, device=dev),
                  alignments_scored=torch.zeros(0, dtype=torch.int64, device=dev), stats=stats)
     # scans (thrust::inclusive_scan in the reference) and the range sizes

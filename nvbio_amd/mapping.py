@@ -59,12 +59,13 @@ def map_exact(fmi, reads, params, max_read_len, retry=0, fw=True, rc=True, in_qu
 EXACT_MAPPING, APPROX_MAPPING, CASE_PRUNING_MAPPING = 0, 1, 2      # MappingAlgorithm (mapping_inl.h:118-123)
 
 
-def map_seeds(fmi, rfmi, reads, params, max_read_len, allow_sub=0, subseed_len=0, retry=0, fw=True, rc=True, in_queue=None, hits_stride=64):
+def map_seeds(fmi, rfmi, reads, params, max_read_len, allow_sub=0, subseed_len=0, retry=0, fw=True, rc=True, in_queue=None, hits_stride=64, algorithm=None):
     """nvBowtie's map() with the algorithm choice of map_t (mapping_inl.h:809-843): allow_sub == 0 -> exact;
     allow_sub and subseed_len == 0 -> case pruning (uses rfmi, the index of the reversed genome);
     allow_sub and subseed_len > 0 -> exact subseed + one mismatch in the rest.  Returns (hits, counts, reseed)
     as map_exact does; index_dir = 1 marks hits found on rfmi."""
-    algorithm = EXACT_MAPPING if not allow_sub else (CASE_PRUNING_MAPPING if subseed_len == 0 else APPROX_MAPPING)
+    if algorithm is None:             # (the all-mapping driver names its mapper itself: map_exact or map_approx, aligner_all.h:177-212)
+        algorithm = EXACT_MAPPING if not allow_sub else (CASE_PRUNING_MAPPING if subseed_len == 0 else APPROX_MAPPING)
     dev = reads.words.device
     n_reads = len(reads)
     n = in_queue.numel() if in_queue is not None else n_reads

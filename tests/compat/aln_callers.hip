@@ -112,7 +112,7 @@ struct ByteStringStream
     NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool init_context(const uint32 i, context_type* context) const
     {
         context->min_score = m_thresholds ? m_thresholds[i] : Field_traits<int32>::min();
-        return (i % 97u) != 96u;               // some jobs are declined: their outputs must stay untouched
+        return (i % 97u) != 96u;               // some jobs are declined: they are still output, with the sink as the context was built (batched_banded_inl.h:53-75)
     }
     NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void load_strings(const uint32 i, const uint32, const uint32, const context_type*, strings_type* strings) const
     {

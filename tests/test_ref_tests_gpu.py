@@ -229,6 +229,38 @@ def test_own_drivers_equal_reference_nvbowtie_on_varied_reads(case, cuda):
     assert same == n_ref, (case, same, n_ref)
 
 
+@pytest.mark.parametrize("case", [dict(mode="se", extra="-N 1", own="allow_sub=1", seed=61),
+                                  dict(mode="se", extra="-L 18 -D 20 -R 3", own="seed_len=18,max_effort=20,max_reseed=3", seed=62),
+                                  dict(mode="local", extra="-N 1 -L 16", own="allow_sub=1,seed_len=16", seed=63),
+                                  dict(mode="paired", extra="-I 250 -X 380", own="min_frag_len=250,max_frag_len=380", seed=64, reads=10000),
+                                  dict(mode="paired", extra="--no-mixed", own="pe_unpaired=False", seed=65),
+                                  dict(mode="paired", extra="--no-discordant", own="pe_discordant=False", seed=66),
+                                  dict(mode="se", extra="--no-rand", own="randomized=False", seed=67),
+                                  dict(mode="se", extra="--no-rand --no-multi-hits 1", own="randomized=False,no_multi_hits=True", seed=67),
+                                  dict(mode="paired", extra="--no-rand", own="randomized=False", seed=70, reads=5000),
+                                  dict(mode="se", extra="--nofw", own="fw=False", seed=68),
+                                  dict(mode="all", extra="-N 1", own="allow_sub=1", seed=69)],
+                         ids=["se-N1", "se-L18-D20-R3", "local-N1-L16", "paired-I250-X380", "paired-no-mixed", "paired-no-discordant", "se-no-rand",
+                              "se-no-rand-single-hit", "paired-no-rand", "se-nofw", "all-N1"])
+def test_own_drivers_equal_reference_nvbowtie_under_its_options(case, cuda):
+    """nvBowtie's command-line options against the same settings of this repository's drivers: one mismatch in the seed (-N 1: the
+    case-pruning mapper in the best modes, the approximate mapper in --all, aligner_all.h:177-212), seed length / effort / re-seeding,
+    insert-size limits (-I / -X: here a mate starts exactly at the edge of the opposite-mate window for 1 fragment length in 200, which is
+    where a declined anchor job must still be OUTPUT -- batched_banded_inl.h:53-75 -- or the skipped hit keeps a stale score),
+    --no-mixed, --no-discordant, the non-randomized selection (--no-rand: nvBowtie pops SA rows off `&deque.top()` in place, so a const
+    vector_view must hand out references, vector_view.h:96), --nofw.  Every SAM record identical."""
+    import argparse
+    import sys
+    if not os.path.exists(os.path.join(REF, "ref_nvBowtie")):
+        pytest.skip("oracle/_ref/ref_nvBowtie not built (needs /root/reference in the build container)")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import nvbowtie_compare
+    args = dict(mode="se", reads=3000, seed=5, indels=0.2, show=3, len=100, ns=0.0, quals="I", extra="", own=""); args.update(case)
+    same, n_ref, n_own = nvbowtie_compare.compare(argparse.Namespace(**args))
+    assert n_ref == n_own and n_ref >= args["reads"]
+    assert same == n_ref, (case, same, n_ref)
+
+
 def test_own_driver_equals_reference_nvbowtie_above_half_a_batch(cuda):
     """More than BATCH_SIZE / 2 reads in flight (and, with this seed, reads with an insertion over the first bases of the genome: their
     seed hits locate below zero, `SA position - offset in the read` wraps, and nvBowtie loads a scoring window ~1 GiB past the reference

@@ -54,7 +54,8 @@ class Reference:
 
 
 def main(prefix, fastq, out=sys.stdout, device="cuda", ref_name="ref", **param_overrides):
-    data = nio.FMIndexDataDevice(prefix, flags=nio.FORWARD | nio.SA, device=device)
+    # (the 1-mismatch mappers search the reverse index too, mapping_inl.h:128-220: -N 1 needs <prefix>.rbwt)
+    data = nio.FMIndexDataDevice(prefix, flags=nio.FORWARD | nio.SA | (nio.REVERSE if param_overrides.get("allow_sub") else 0), device=device)
     n_genome, g_words = nio.load_genome(prefix)
     genome_words = torch.from_numpy(np.concatenate([g_words, np.zeros(8, np.uint32)]).view(np.int32)).to(device)
     reads = nio.read_fastq(fastq)
@@ -64,7 +65,7 @@ def main(prefix, fastq, out=sys.stdout, device="cuda", ref_name="ref", **param_o
     index = np.asarray(reads.sequence_index, dtype=np.int64)
     batch = A.ReadBatch.from_ragged(torch.from_numpy(reads.symbols).to(device), torch.from_numpy(index).to(device), torch.from_numpy(reads.quals).to(device))
     params = A.Params(hits_stride=32, **param_overrides)        # e.g. local=True = nvBowtie --local
-    r = A.best_approx(data.index(), None, batch, genome_words, n_genome, params, names=list(reads.names), cigar_stride=64, finish=True)
+    r = A.best_approx(data.index(), data.rindex(), batch, genome_words, n_genome, params, names=list(reads.names), cigar_stride=64, finish=True)
     torch.cuda.synchronize()
     global last_stats
     last_stats = dict((k, v) for k, v in r["stats"].items() if k != "ms")          # seeding passes, queue sizes, extension rounds
@@ -91,7 +92,8 @@ def main(prefix, fastq, out=sys.stdout, device="cuda", ref_name="ref", **param_o
 def main_all(prefix, fastq, out=sys.stdout, device="cuda", ref_name="ref", **param_overrides):
     """All-mapping flow (nvBowtie --all = Aligner::all): one SAM record per accepted alignment of every read (MAPQ 255, as the reference fills
     it, aligner_all.h:82), no record for reads without one.  Needs the reverse index too when one-mismatch seeds are asked for."""
-    data = nio.FMIndexDataDevice(prefix, flags=nio.FORWARD | nio.SA, device=device)
+    # (the 1-mismatch mappers search the reverse index too, mapping_inl.h:128-220: -N 1 needs <prefix>.rbwt)
+    data = nio.FMIndexDataDevice(prefix, flags=nio.FORWARD | nio.SA | (nio.REVERSE if param_overrides.get("allow_sub") else 0), device=device)
     n_genome, g_words = nio.load_genome(prefix)
     genome_words = torch.from_numpy(np.concatenate([g_words, np.zeros(8, np.uint32)]).view(np.int32)).to(device)
     reads = nio.read_fastq(fastq)
@@ -100,7 +102,7 @@ def main_all(prefix, fastq, out=sys.stdout, device="cuda", ref_name="ref", **par
     index = np.asarray(reads.sequence_index, dtype=np.int64)
     batch = A.ReadBatch.from_ragged(torch.from_numpy(reads.symbols).to(device), torch.from_numpy(index).to(device), torch.from_numpy(reads.quals).to(device))
     ref = Reference(prefix, n_genome, ref_name)
-    r = A.all_mapping(data.index(), None, batch, genome_words, n_genome, A.Params(hits_stride=32, **param_overrides), cigar_stride=64,
+    r = A.all_mapping(data.index(), data.rindex(), batch, genome_words, n_genome, A.Params(hits_stride=32, **param_overrides), cigar_stride=64,
                       sequence_index=ref.index)                       # seeds straddling two sequences are dropped (mark_straddling)
     torch.cuda.synchronize()
     out.write(ref.header())
@@ -127,7 +129,8 @@ def main_paired(prefix, fastq1, fastq2, out=sys.stdout, device="cuda", ref_name=
     aligner_best_approx_paired.h) with SamOutput's paired fields (output_sam.cpp:372-520): flags READ_1 / READ_2 by the alignment's mate, REVERSE,
     PAIRED, PROPER_PAIR when the mate's alignment is concordant, MATE_UNMAPPED, MATE_REVERSE; RNEXT '=', PNEXT, TLEN = span of the two alignments,
     negative for the rightmost one; unaligned reads carry the UNMAPPED flag alone, as the reference writes them."""
-    data = nio.FMIndexDataDevice(prefix, flags=nio.FORWARD | nio.SA, device=device)
+    # (the 1-mismatch mappers search the reverse index too, mapping_inl.h:128-220: -N 1 needs <prefix>.rbwt)
+    data = nio.FMIndexDataDevice(prefix, flags=nio.FORWARD | nio.SA | (nio.REVERSE if param_overrides.get("allow_sub") else 0), device=device)
     n_genome, g_words = nio.load_genome(prefix)
     genome_words = torch.from_numpy(np.concatenate([g_words, np.zeros(8, np.uint32)]).view(np.int32)).to(device)
     r1, r2 = nio.read_fastq(fastq1), nio.read_fastq(fastq2)
@@ -139,7 +142,7 @@ def main_paired(prefix, fastq1, fastq2, out=sys.stdout, device="cuda", ref_name=
     mats = [torch.from_numpy(r.symbols.reshape(n, L)).to(device) for r in (r1, r2)]
     params = A.Params(hits_stride=32, **param_overrides)
     quals = [torch.from_numpy(r.quals.reshape(n, L)).to(device) for r in (r1, r2)]
-    r = A.best_approx_paired(data.index(), None, mats[0], mats[1], genome_words, n_genome, params, names=list(r1.names), finish=True, quals1=quals[0], quals2=quals[1])
+    r = A.best_approx_paired(data.index(), data.rindex(), mats[0], mats[1], genome_words, n_genome, params, names=list(r1.names), finish=True, quals1=quals[0], quals2=quals[1])
     torch.cuda.synchronize()
     slots = []
     for key_best, key_tb, key_mds, key_mapq in (("best", "tb1", "mds1", "mapq1"), ("best_o", "tb2", "mds2", "mapq2")):
@@ -162,18 +165,23 @@ def main_paired(prefix, fastq1, fastq2, out=sys.stdout, device="cuda", ref_name=
         f = [fields(slots[0], i), fields(slots[1], i)]
         for k in (0, 1):
             a, m = f[k], f[1 - k]
-            mate = a["mate"] if a else k                              # an unaligned slot k holds mate k
+            # SamOutput reads the strand and mate bits of a slot's io::Alignment word whether or not it holds an alignment
+            # (output_sam.cpp:389-418, 438-452; get_anchor_mate / get_opposite_mate, output_priv.h): an unaligned read is printed on
+            # the strand its word names, and its mate's MATE_REVERSE flag follows that bit too
+            w_k, w_m = int(slots[k]["best"][i] & 0xFFFFFFFF), int(slots[1 - k]["best"][i] & 0xFFFFFFFF)
+            mate = (w_k >> 29) & 1
             rd = reads[mate]
             seq, qual = rd.symbols[i * L:(i + 1) * L], rd.quals[i * L:(i + 1) * L]
             if a is None:
-                out.write("%s\t4\t*\t0\t0\t*\t*\t0\t0\t%s\t%s\n" % (rd.names[i], "".join("ACGTN"[c] for c in seq), "".join(chr(int(q) + 33) for q in qual)))
+                s, q = (np.where(seq < 4, 3 - seq, 4)[::-1], qual[::-1]) if (w_k >> 28) & 1 else (seq, qual)
+                out.write("%s\t4\t*\t0\t0\t*\t*\t0\t0\t%s\t%s\n" % (rd.names[i], "".join("ACGTN"[c] for c in s), "".join(chr(int(x) + 33) for x in q)))
                 continue
             flags = (0x80 if a["mate"] else 0x40) | (0x10 if a["rc"] else 0) | 0x1
             if m is not None and m["concordant"]:
                 flags |= 0x2
             if m is None:
                 flags |= 0x8
-            elif m["rc"]:
+            if (w_m >> 28) & 1:
                 flags |= 0x20
             rname, lpos = ref.locate(a["pos"])
             if m is not None:

@@ -57,7 +57,9 @@ def main():
     ap.add_argument("--show", type=int, default=4)
     ap.add_argument("--len", type=int, default=100, help="read length (single-end modes)")
     ap.add_argument("--ns", type=float, default=0.0, help="fraction of read bases replaced by N (single-end modes)")
-    ap.add_argument("--quals", default="I", help="one quality character for all bases, or 'random' (single-end modes)")
+    ap.add_argument("--quals", default="I", help="one quality character for all bases, or 'random'")
+    ap.add_argument("--extra", default="", help="further nvBowtie options, e.g. '-N 1 -L 18'")
+    ap.add_argument("--own", default="", help="the same settings for this repository's driver: comma-separated Params fields, e.g. 'allow_sub=1,seed_len=18'")
     args = ap.parse_args()
     same, n_ref, n_own = compare(args)
     return 0 if same == max(n_ref, n_own) and n_ref else 1
@@ -70,6 +72,11 @@ def compare(args):
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_nvBowtie")
     rng = np.random.default_rng(args.seed)
     tmp = tempfile.mkdtemp(prefix="nvbcmp_")
+    overrides = {}
+    for kv in filter(None, getattr(args, "own", "").split(",")):
+        k, v = kv.split("=")
+        overrides[k] = (v == "True") if v in ("True", "False") else int(v)
+    extra = getattr(args, "extra", "").split()
     n_genome, L, n = 200_000, (getattr(args, "len", 100) if args.mode != "paired" else 100), args.reads
     prefix, text = write_reference(tmp, rng, n_genome, [("chrA", 120_000), ("chrB", 80_000)])
     if args.mode == "all":                                   # some repeats, so that reads have several placements
@@ -85,8 +92,8 @@ def compare(args):
         f1, f2 = os.path.join(tmp, "m1.fastq"), os.path.join(tmp, "m2.fastq")
         q = getattr(args, "quals", "I")
         write_fastq(f1, m1, "pair", q, rng); write_fastq(f2, m2, "pair", q, rng)
-        cmd = [exe, "--file-ref", "-x", prefix, "-1", f1, "-2", f2, "-S", sam]
-        own = lambda: align_fastq.main_paired(prefix, f1, f2, buf, device=dev)
+        cmd = [exe] + extra + ["--file-ref", "-x", prefix, "-1", f1, "-2", f2, "-S", sam]
+        own = lambda: align_fastq.main_paired(prefix, f1, f2, buf, device=dev, **overrides)
     else:
         pos = rng.integers(0, n_genome - L - 4, n)
         pos = np.where((pos < 120_000) & (pos + L + 4 > 120_000), pos - L - 4, pos)
@@ -104,18 +111,18 @@ def compare(args):
         fq = os.path.join(tmp, "reads.fastq")
         write_fastq(fq, reads, "read", getattr(args, "quals", "I"), rng)
         # (mode flags go first: nvBowtie reads argv[i + 1] after an option it does not know, nvBowtie.cpp:343)
-        cmd = [exe] + (["--local"] if args.mode == "local" else ["--all"] if args.mode == "all" else []) + ["--file-ref", "-x", prefix, "-U", fq, "-S", sam]
+        cmd = [exe] + (["--local"] if args.mode == "local" else ["--all"] if args.mode == "all" else []) + extra + ["--file-ref", "-x", prefix, "-U", fq, "-S", sam]
         if args.mode == "all":
-            own = lambda: align_fastq.main_all(prefix, fq, buf, device=dev)
+            own = lambda: align_fastq.main_all(prefix, fq, buf, device=dev, **overrides)
         elif args.mode == "local":
-            import nvbio_amd as nvb
-            own = lambda: align_fastq.main(prefix, fq, buf, device=dev, local=True)
+            own = lambda: align_fastq.main(prefix, fq, buf, device=dev, local=True, **overrides)
         else:
-            own = lambda: align_fastq.main(prefix, fq, buf, device=dev)
+            own = lambda: align_fastq.main(prefix, fq, buf, device=dev, **overrides)
     cmd += os.environ.get("NVBOWTIE_EXTRA_ARGS", "").split()
     r = subprocess.run(cmd, capture_output=True, text=True)
-    if os.environ.get("NVBOWTIE_EXTRA_ARGS"):
-        print((r.stdout + r.stderr)[-6000:])
+    if os.environ.get("NVBOWTIE_EXTRA_ARGS"):          # (a debug build's device-side prints: everything that is not a log line)
+        print("\n".join(ln for ln in (r.stdout + r.stderr).replace("\r", "\n").splitlines()
+                        if ln.strip() and not ln.startswith(("stats", "verbose", "info", "visible", "debug", "warning", "[0]")))[-20000:])
     if r.returncode != 0:
         print((r.stdout + r.stderr)[-3000:]); return 0, 0, 0
     ref = records(open(sam).read())
@@ -138,6 +145,9 @@ def compare(args):
             shown += 1
             d = [i for i in range(min(len(a), len(b))) if a[i] != b[i]]
             print("  differ in fields", d, "\n    ref:", a[:9] + a[11:], "\n    own:", b[:9] + b[11:])
+            if args.mode == "paired":
+                k = int(a[0][4:])
+                print("    simulated: mate 1 at %d, fragment %d" % (pos[k] + 1, frag[k]))
     print("identical records: %d of %d" % (same, max(len(ref), len(mine))))
     return same, len(ref), len(mine)
 
