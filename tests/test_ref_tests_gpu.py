@@ -239,9 +239,18 @@ def test_own_drivers_equal_reference_nvbowtie_on_varied_reads(case, cuda):
                                   dict(mode="se", extra="--no-rand --no-multi-hits 1", own="randomized=False,no_multi_hits=True", seed=67),
                                   dict(mode="paired", extra="--no-rand", own="randomized=False", seed=70, reads=5000),
                                   dict(mode="se", extra="--nofw", own="fw=False", seed=68),
-                                  dict(mode="all", extra="-N 1", own="allow_sub=1", seed=69)],
+                                  dict(mode="all", extra="-N 1", own="allow_sub=1", seed=69),
+                                  dict(mode="se", extra="--top 1", own="top_seed=1", seed=81),
+                                  dict(mode="se", extra="--max-dist 7", own="max_dist=7", seed=82),
+                                  dict(mode="se", extra="--max-hits 20 --min-ext 10 --max-ext 40", own="max_hits=20,min_ext=10,max_ext=40", seed=83),
+                                  dict(mode="se", extra="-N 1 --subseed-len 10", own="allow_sub=1,subseed_len=10", seed=84),
+                                  dict(mode="paired", extra="--no-overlap", own="pe_overlap=False", seed=85),
+                                  dict(mode="paired", extra="--ff", own="pe_policy=0", seed=86),
+                                  dict(mode="paired", extra="--top 1 -N 1", own="top_seed=1,allow_sub=1", seed=88),
+                                  dict(mode="se", extra="--rep-seeds 5 -R 4", own="rep_seeds=5,max_reseed=4", seed=89)],
                          ids=["se-N1", "se-L18-D20-R3", "local-N1-L16", "paired-I250-X380", "paired-no-mixed", "paired-no-discordant", "se-no-rand",
-                              "se-no-rand-single-hit", "paired-no-rand", "se-nofw", "all-N1"])
+                              "se-no-rand-single-hit", "paired-no-rand", "se-nofw", "all-N1", "se-top", "se-max-dist-7", "se-max-hits-ext", "se-N1-subseed",
+                              "paired-no-overlap", "paired-ff", "paired-top-N1", "se-rep-seeds"])
 def test_own_drivers_equal_reference_nvbowtie_under_its_options(case, cuda):
     """nvBowtie's command-line options against the same settings of this repository's drivers: one mismatch in the seed (-N 1: the
     case-pruning mapper in the best modes, the approximate mapper in --all, aligner_all.h:177-212), seed length / effort / re-seeding,
