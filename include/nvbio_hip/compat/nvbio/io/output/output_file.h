@@ -1,6 +1,6 @@
 // compat/nvbio/io/output/output_file.h -- where an aligner sends its results (nvbio/io/output/output_file.h:75-164, output_file.cpp):
 // OutputFile is the null sink and the base class; OutputFile::open() picks the writer from the file name.  This layer writes SAM
-// (output_sam.h); ".bam" and ".dbg" names -- BamOutput / DebugOutput in the reference -- get the SAM writer too, with a warning.
+// (output_sam.h) and BAM (output_bam.h); a ".dbg" name -- DebugOutput in the reference -- gets the SAM writer, with a warning.
 #pragma once
 #include "output_types.h"
 #include "output_stats.h"
@@ -53,6 +53,7 @@ public:
 } // namespace nvbio
 
 #include "output_sam.h"
+#include "output_bam.h"
 
 namespace nvbio {
 namespace io {
@@ -66,7 +67,8 @@ inline OutputFile* OutputFile::open(const char* file_name, AlignmentType aln_typ
     if (strcmp(file_name, "/dev/null") == 0) return new priv::NullOutput(file_name, aln_type, bnt);
     const char* ext = len >= 4 ? file_name + len - 4 : "";
     if (strcmp(ext, ".sam") == 0) return new SamOutput(file_name, aln_type, bnt);
-    if (strcmp(ext, ".bam") == 0 || strcmp(ext, ".dbg") == 0) log_warning(stderr, "%s output is not written by this layer; writing SAM text to %s\n", ext + 1, file_name);
+    if (strcmp(ext, ".bam") == 0) return new BamOutput(file_name, aln_type, bnt);
+    if (strcmp(ext, ".dbg") == 0) log_warning(stderr, "%s output is not written by this layer; writing SAM text to %s\n", ext + 1, file_name);
     else                                                     log_warning(stderr, "could not determine file type for %s; guessing SAM\n", file_name);
     return new SamOutput(file_name, aln_type, bnt);
 }

@@ -441,10 +441,12 @@ def read_bam(path):
             key, ty = raw[p:p + 2].decode(), chr(raw[p + 2]); p += 3
             if ty == "Z":
                 e = raw.index(b"\0", p); tags[key] = raw[p:e].decode(); p = e + 1
-            elif ty == "I":
-                tags[key] = struct.unpack_from("<I", raw, p)[0]; p += 4
-            else:
-                tags[key] = raw[p]; p += 1
+            elif ty in "Ii":
+                tags[key] = struct.unpack_from("<I" if ty == "I" else "<i", raw, p)[0]; p += 4
+            elif ty in "Ss":
+                tags[key] = struct.unpack_from("<H" if ty == "S" else "<h", raw, p)[0]; p += 2
+            else:                                           # C / c
+                tags[key] = raw[p] if ty == "C" else struct.unpack_from("<b", raw, p)[0]; p += 1
         recs.append(dict(name=name, flag=flag, ref=rid, pos=pos + 1, mapq=mapq, cigar=cig or "*", next_ref=nid, pnext=npos + 1, tlen=tlen, seq=seq, qual=qual, tags=tags))
         o += bs
     return text, refs, recs

@@ -210,6 +210,72 @@ def test_own_drivers_equal_reference_nvbowtie_in_every_mode(mode, cuda):
     assert same == n_ref, (mode, same, n_ref)
 
 
+@pytest.mark.parametrize("paired", [False, True], ids=["single-end", "paired-end"])
+def test_reference_nvbowtie_writes_bam(tmp_path, paired):
+    """`-S out.bam`: the drop-in layer's BamOutput (compat/nvbio/io/output/output_bam.h: BGZF blocks of binary records in BamOutput's
+    layout, output_bam.cpp:234-519) against the SAM text of the same run, field by field -- name, flags, reference, position, MAPQ,
+    CIGAR, mate fields, TLEN, bases, qualities, the NM / AS / XM / XO / XG / MD tags; the file must read back as a gzip stream that
+    ends with the BGZF end-of-file block."""
+    import numpy as np
+    from nvbio_amd import io as nio
+    exe = os.path.join(REF, "ref_nvBowtie")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_nvBowtie not built (needs /root/reference in the build container)")
+    n, L = 3000, 100
+    if paired:
+        rng = np.random.default_rng(12)
+        prefix, text = _write_reference(tmp_path, rng, 200_000, [("chrA", 120_000), ("chrB", 80_000)])
+        frag = rng.integers(200, 400, n); pos = rng.integers(120_000, 200_000 - 420, n)          # on the SECOND sequence: next_refID must name it
+        files = []
+        for k in (0, 1):
+            path = str(tmp_path / ("m%d.fastq" % k))
+            with open(path, "w") as f:
+                for i in range(n):
+                    r = text[pos[i]:pos[i] + L] if k == 0 else (3 - text[pos[i] + frag[i] - L:pos[i] + frag[i]])[::-1]
+                    r = r.copy(); mut = rng.random(L) < 0.02; r[mut] = (r[mut] + 1) & 3
+                    if i % 50 == 7 and k == 1:
+                        r = rng.integers(0, 4, L).astype(np.uint8)                                 # a mate that aligns nowhere
+                    f.write("@pair%d\n%s\n+\n%s\n" % (i, "".join("ACGT"[c] for c in r), "".join(chr(33 + int(q)) for q in rng.integers(2, 41, L))))
+            files.append(path)
+        inputs = ["-1", files[0], "-2", files[1]]
+    else:
+        prefix, fastq, _ = _simulated_run(tmp_path, 9, n, L, indel_rate=0.3)
+        inputs = ["-U", fastq]
+    outs = {}
+    for ext in ("sam", "bam"):
+        out = str(tmp_path / ("out." + ext))
+        r = subprocess.run([exe, "--file-ref", "-x", prefix] + inputs + ["-S", out], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        outs[ext] = out
+    sam = [ln.rstrip("\n").split("\t") for ln in open(outs["sam"]) if not ln.startswith("@")]
+    raw = open(outs["bam"], "rb").read()
+    assert raw[:4] == b"\x1f\x8b\x08\x04" and raw[-28:] == bytes([0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 0x42, 0x43, 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+    text_h, refs, recs = nio.read_bam(outs["bam"])
+    assert refs == [("chrA", 120_000), ("chrB", 80_000)] and text_h.startswith("@HD\tVN:1.3\n") and "@PG\tID:" in text_h
+    assert len(recs) == len(sam) == (2 * n if paired else n)
+    names = [r_[0] for r_ in refs]
+    n_mapped = n_gapped = 0
+    for s_, b in zip(sam, recs):
+        flag = int(s_[1])
+        assert b["name"] == s_[0] and b["seq"] == s_[9] and b["qual"] == s_[10]
+        if flag & 4:
+            # SamOutput prints an unmapped read with the flag 4 alone; BamOutput likewise
+            assert b["flag"] == 4 and b["ref"] == -1 and b["pos"] == 0 and b["cigar"] == "*" and b["next_ref"] == -1 and not b["tags"]
+            continue
+        n_mapped += 1
+        assert b["flag"] == flag and names[b["ref"]] == s_[2] and b["pos"] == int(s_[3]) and b["mapq"] == int(s_[4]) and b["cigar"] == s_[5]
+        n_gapped += ("I" in s_[5]) or ("D" in s_[5])
+        if paired:
+            assert (names[b["next_ref"]] == s_[2] if s_[6] == "=" else names[b["next_ref"]] == s_[6]) and b["pnext"] == int(s_[7]) and b["tlen"] == int(s_[8])
+        else:
+            assert b["next_ref"] == -1 and b["pnext"] == 0 and b["tlen"] == 0          # SamOutput prints '*' 0 0
+        tags = dict((t.split(":")[0], t.split(":", 2)[2]) for t in s_[11:])
+        assert {k: str(v) for k, v in b["tags"].items()} == tags
+    assert n_mapped > 0.95 * len(sam) * (0.98 if paired else 1.0)
+    if not paired:
+        assert n_gapped > 100
+
+
 @pytest.mark.parametrize("case", [dict(mode="se", quals="random", seed=41), dict(mode="local", quals="random", len=250, seed=42),
                                   dict(mode="se", ns=0.01, len=150, seed=43), dict(mode="se", len=50, seed=45),
                                   dict(mode="all", quals="random", ns=0.005, seed=46), dict(mode="paired", quals="random", seed=51)],
