@@ -279,8 +279,8 @@ __device__ __forceinline__ uint32_t min16u(uint32_t a, uint32_t b) { uint32_t r;
 // matrix (H(-1, c) + G_o, F = infimum, the text symbol of column c of ITS job, an empty column maximum), every other lane what the lane
 // above computed one step ago.  Everything a job owns (M, Ncols, lane_last, klast ...) is a per-lane value, and the loop bounds are the
 // wave's maxima / minima.
-template <int TYPE, int R, bool CHECK, bool PBX = false, bool MULTI = false>      // PBX: keep every row's maximum over the text (pattern-blocking early exit, non-LOCAL types)
-struct Sweep16
+template <int TYPE, int R, bool CHECK, bool PBX = false, bool MULTI = false, bool BKL = false>      // PBX: keep every row's maximum over the text (pattern-blocking early exit, non-LOCAL types)
+struct Sweep16                                                                                     // BKL: LOCAL's per-row records live in LDS (bkl), not in registers
 {
     const FullParams& p;
     uint32_t lane, lane_last, klast, M, Ncols, Nfull;
@@ -290,7 +290,12 @@ struct Sweep16
     uint32_t go, ge, rge, inf16, init_above_g;
     uint32_t tlo[R], thi[R];              // per-row substitution table: four 16-bit entries, scores pre-biased by -G_o (cell16)
     uint64_t tb;
-    uint32_t q[R], HLG[R], E[R], bestk[R], rmax[PBX ? R : 1];
+    uint32_t q[R], HLG[R], E[R], bestk[BKL ? 1 : R], rmax[PBX ? R : 1];
+    // BKL: bestk[k] of this lane at bkl[k * 64 + wlane].  The records are touched once per 16 steps (fold) and at the end, so LDS costs
+    // nothing measurable -- and ten rows per lane of LOCAL then fit 168 VGPRs, i.e. three waves per SIMD instead of two
+    uint32_t* bkl;
+    __device__ __forceinline__ uint32_t get_bk(const int k) const { return BKL ? bkl[k * 64 + int(wlane)] : bestk[BKL ? 0 : k]; }
+    __device__ __forceinline__ void     set_bk(const int k, const uint32_t v) { if (BKL) bkl[k * 64 + int(wlane)] = v; else bestk[BKL ? 0 : k] = v; }
     // LOCAL carries every value x16 (the host admits LOCAL only below 2048) so that "score, then later column" is one 16-bit maximum:
     // bk16 = max over the current group of 16 steps of H*16 + (step & 15); the groups are folded into bestk = score << 20 | column
     // at wave-uniform times.  (The 32-bit form, (h << 20 | c) and v_max_u32 per cell, cost 8.6 issue cycles of a cell's 36; this costs 4.6.)
@@ -331,7 +336,7 @@ struct Sweep16
             tlo[k] = (q[k] == 0u ? sM : sXr) | ((q[k] == 1u ? sM : sXr) << 16);
             thi[k] = (q[k] == 2u ? sM : sXr) | ((q[k] == 3u ? sM : sXr) << 16);
             E[k]   = c16((TYPE == NVBIO_HIP_LOCAL) ? 0 : infimum);
-            bestk[k] = 0u;
+            set_bk(k, 0u);
             if (TYPE == NVBIO_HIP_LOCAL) bk16[k] = 0x8000u;
             if (PBX) rmax[k] = 0x8000u;
             if (CHECK) lim[k] = (uint32_t(k) <= kl) ? 0x7FFFu : 0x8000u;
@@ -456,7 +461,8 @@ struct Sweep16
             {
                 const uint32_t t = bk16[k];
                 const uint32_t cand = ((t >> 4) << 20) | ((base + (t & 15u) - lane) & 0xFFFFFu);
-                bestk[k] = (t != 0x8000u) ? max(bestk[k], cand) : bestk[k];      // 0x8000: the lane sat outside the matrix for the whole group
+                if (BKL) { if (t != 0x8000u) { const uint32_t b0 = get_bk(k); if (cand > b0) set_bk(k, cand); } }
+                else bestk[BKL ? 0 : k] = (t != 0x8000u) ? max(bestk[BKL ? 0 : k], cand) : bestk[BKL ? 0 : k];      // 0x8000: the lane sat outside the matrix for the whole group
                 bk16[k] = 0x8000u;
             }
         }
@@ -530,7 +536,7 @@ struct Sweep16
                 const uint32_t r = lane * R + k;
                 if (uint32_t(k) < nvalid && ((r + 1u) & (BLK - 1u)) == 0u && r + 1u < M)
                 {
-                    const int32_t rm = (TYPE == NVBIO_HIP_LOCAL) ? int32_t(bestk[k] >> 20) : int32_t(int16_t(rmax[PBX ? k : 0]));
+                    const int32_t rm = (TYPE == NVBIO_HIP_LOCAL) ? int32_t(get_bk(k) >> 20) : int32_t(int16_t(rmax[PBX ? k : 0]));
                     if (rm + int32_t(M - (r + 1u)) * p.match < min_score) first = min(first, r);
                 }
             }
@@ -546,7 +552,7 @@ struct Sweep16
             for (int k = 0; k < R; ++k)
             {
                 if (uint32_t(k) < nvalid && Ncols > 0u) {
-                    const uint32_t hh = bestk[k] >> 20, cc = bestk[k] & 0xFFFFFu, r = lane * R + k;
+                    const uint32_t bkk = get_bk(k), hh = bkk >> 20, cc = bkk & 0xFFFFFu, r = lane * R + k;
                     // text blocking: block of columns -> row -> column in block; pattern blocking: block of rows -> column -> row in block
                     const uint32_t key = PB ? (((r >> BS) << (20u + BS)) | (cc << BS) | (r & (BLK - 1u)))
                                             : ((cc >> BS) * KM + r * BLK + (cc & (BLK - 1u)));
@@ -583,11 +589,12 @@ struct Sweep16
     }
 };
 
-template <int TYPE, int R, bool CHECK>
+template <int TYPE, int R, bool CHECK, bool BKL = false>
 __device__ __forceinline__ SweepResult sweep16(const FullParams& p, const uint64_t pb, const uint64_t tb,
-                                               const uint32_t M, const uint32_t Ncols, const uint32_t Nfull, const int32_t min_score)
+                                               const uint32_t M, const uint32_t Ncols, const uint32_t Nfull, const int32_t min_score, uint32_t* bkl = nullptr)
 {
-    Sweep16<TYPE, R, CHECK> sw(p);
+    Sweep16<TYPE, R, CHECK, false, false, BKL> sw(p);
+    sw.bkl = bkl;
     sw.init(pb, tb, M, Ncols, Nfull, min_score);
     return sw.run();
 }
@@ -700,9 +707,13 @@ full_gotoh_score_kernel(const FullParams p)
 // on the single-job sweep, segment by segment, so every result is the one full_gotoh_score_kernel produces.
 // ---------------------------------------------------------------------------------------------
 template <int TYPE, int R>
-__global__ void __launch_bounds__(256, (R <= 6 ? 3 : 2))       // R <= 6: >= 3 waves per SIMD (left alone the SEMI_GLOBAL instance takes 176 VGPRs = 2 waves; 168 + 14 spilled: +8 %); deeper lanes hold more rows and get 256 VGPRs
+__global__ void __launch_bounds__(256, ((R <= 6 || (TYPE == NVBIO_HIP_LOCAL && R >= 8)) ? 3 : 2))       // R <= 6: >= 3 waves per SIMD (left alone the SEMI_GLOBAL instance takes 176 VGPRs = 2 waves; 168 + 14 spilled: +8 %); deeper lanes hold more rows and get 256 VGPRs
 full_gotoh_score_multi_kernel(const FullParams p, const uint32_t n_seg, const uint32_t seg_w)
 {
+    // LOCAL with eight or more rows per lane: the rows' records in LDS (Sweep16: BKL), which brings the instance from 176 to <= 168 VGPRs
+    constexpr bool BKL = (TYPE == NVBIO_HIP_LOCAL && R >= 8);
+    __shared__ uint32_t bk_sh[BKL ? 4 : 1][BKL ? R * 64 : 1];
+    uint32_t* const bkl = BKL ? &bk_sh[threadIdx.x >> 6][0] : nullptr;
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
     const uint32_t wl   = threadIdx.x & 63u;
     const uint32_t seg  = wl / seg_w, sl = wl - seg * seg_w;
@@ -746,7 +757,8 @@ full_gotoh_score_multi_kernel(const FullParams p, const uint32_t n_seg, const ui
     uint32_t redo = 0u, redo_arg = 0u;
     if (PB && check)
     {
-        Sweep16<TYPE, R, false, (TYPE != NVBIO_HIP_LOCAL), true> sw(p);
+        Sweep16<TYPE, R, false, (TYPE != NVBIO_HIP_LOCAL), true, BKL> sw(p);
+        sw.bkl = bkl;
         sw.init(pb, tb, Ms, Ns, Ns, min_score, seg_w, sweeps);
         sw.pb_check = true;
         const SweepResult r = sw.run();
@@ -759,8 +771,8 @@ full_gotoh_score_multi_kernel(const FullParams p, const uint32_t n_seg, const ui
     else
     {
         SweepResult r;
-        if (check) { Sweep16<TYPE, R, true,  false, true> sw(p); sw.init(pb, tb, Ms, Ns, Ns, min_score, seg_w, sweeps); r = sw.run(); }
-        else       { Sweep16<TYPE, R, false, false, true> sw(p); sw.init(pb, tb, Ms, Ns, Ns, min_score, seg_w, sweeps); r = sw.run(); }
+        if (check) { Sweep16<TYPE, R, true,  false, true, BKL> sw(p); sw.bkl = bkl; sw.init(pb, tb, Ms, Ns, Ns, min_score, seg_w, sweeps); r = sw.run(); }
+        else       { Sweep16<TYPE, R, false, false, true, BKL> sw(p); sw.bkl = bkl; sw.init(pb, tb, Ms, Ns, Ns, min_score, seg_w, sweeps); r = sw.run(); }
         if (sweeps)
         {
             if (r.exit_col != 0xFFFFFFFFu)
@@ -789,7 +801,7 @@ full_gotoh_score_multi_kernel(const FullParams p, const uint32_t n_seg, const ui
             const uint64_t gpb = (uint64_t(uint32_t(__shfl(int32_t(uint32_t(pb >> 32)), src))) << 32) | uint32_t(__shfl(int32_t(uint32_t(pb)), src));
             const uint64_t gtb = (uint64_t(uint32_t(__shfl(int32_t(uint32_t(tb >> 32)), src))) << 32) | uint32_t(__shfl(int32_t(uint32_t(tb)), src));
             const int32_t  gms = __shfl(min_score, src);
-            const SweepResult r2 = (rd == 1u) ? sweep16<TYPE, R, false>(p, gpb, gtb, arg, gN, gN, gms) : sweep16<TYPE, R, false>(p, gpb, gtb, gM, arg, gN, gms);
+            const SweepResult r2 = (rd == 1u) ? sweep16<TYPE, R, false, BKL>(p, gpb, gtb, arg, gN, gN, gms, bkl) : sweep16<TYPE, R, false, BKL>(p, gpb, gtb, gM, arg, gN, gms, bkl);
             if (seg == g) { score = r2.score; sx = r2.sx; sy = r2.sy; }
         }
     }
@@ -1045,9 +1057,10 @@ static int full_score_core(
                 const uint32_t usable = 64u / ns;
                 if (uint64_t(usable) * r < maxM) continue;
                 double e = eff(double(ns * ((maxM + r - 1u) / r)), double(r), 24.0);
-                // measured at 150 x 16 384 (profiles/r04/full_dp_rows.txt): ten rows per lane beat five by 7 % (SEMI_GLOBAL) and 12 % (GLOBAL) as the
-                // model says, but LOCAL's deeper lanes take 176 VGPRs (two waves per SIMD) and its per-row maxima fold more often: 0.97 of R = 5
-                if (type == NVBIO_HIP_LOCAL && r >= 8u) e *= 0.90;
+                // measured at 150 x 16 384 (profiles/r04/full_dp_rows.txt): ten rows per lane beat five by 7 % (SEMI_GLOBAL), 12 % (GLOBAL) and -- with
+                // LOCAL's per-row records moved to LDS, which brings its instance from 176 to 168 VGPRs = three waves per SIMD -- 4 % (LOCAL); eight
+                // rows (three jobs of 19 lanes) lose to five for every type
+                if (type == NVBIO_HIP_LOCAL && r == 8u) e *= 0.90;
                 if (e > best * 1.05) { best = e; best_seg = ns; best_r = r; }
             }
         if (best_seg > 1u && !(nomulti && nomulti[0] == '1') && uint64_t(maxN) * 64u * 8u < (1ull << 32))
