@@ -214,7 +214,7 @@ private:
         SeedHitDequeArrayDeviceView hits = { hit_data.data(), hits_stride, hit_counts.data() };
         hip_check(nvbio_hip_memset(hit_counts.data(), 0, uint64(count) * 4u, hip_stream), "nvbio_hip_memset");
         const PingPongQueuesView seed_queues = { count, d_iota.data() };
-        map(reads.reversed, fmi, rfmi, 0u, seed_queues, reseed.data(), hits, params, seed_freq.data(), params.fw, params.rc, hip_stream);
+        map_all(reads.reversed, fmi, rfmi, seed_queues, reseed.data(), hits, params, seed_freq.data(), params.fw, params.rc, hip_stream);
 
         // scan the deque sizes, gather and scan the range sizes
         uint32 n_ranges = 0;

@@ -67,7 +67,8 @@ struct ParamsPOD
 /// map(): one run of seed mapping for the reads in the input queue, with the algorithm choice of map_t
 /// (mapping_inl.h:809-843).  d_seed_freq_table: device copy of params.seed_freq_table(max_read_len).
 template <typename read_batch_type>
-inline void map(
+inline void map_with(
+    const int32                     algorithm,
     const read_batch_type&          read_batch,
     const fm_index_device&          fmi,
     const fm_index_device&          rfmi,
@@ -82,10 +83,47 @@ inline void map(
     void*                           hip_stream = nullptr)
 {
     const nvbio_hip_map_params p = { params.seed_len, params.min_read_len, params.max_hits, params.max_reseed, retry, params.rep_seeds, fw ? 1u : 0u, rc ? 1u : 0u };
-    const int32 algorithm = !params.allow_sub ? NVBIO_HIP_EXACT_MAPPING : (params.subseed_len == 0 ? NVBIO_HIP_CASE_PRUNING_MAPPING : NVBIO_HIP_APPROX_MAPPING);
     const nvbio_hip_string_set r = read_batch.abi();
     hip_check(nvbio_hip_map(algorithm, params.subseed_len, &fmi.m, &rfmi.m, &r, queues.in_queue, queues.in_size, &p, d_seed_freq_table,
                             reinterpret_cast<uint64*>(hits.hits), hits.stride, hits.counts, reseed, hip_stream), "nvbio_hip_map");
+}
+
+template <typename read_batch_type>
+inline void map(
+    const read_batch_type&          read_batch,
+    const fm_index_device&          fmi,
+    const fm_index_device&          rfmi,
+    const uint32                    retry,
+    const PingPongQueuesView        queues,
+    uint8*                          reseed,
+    SeedHitDequeArrayDeviceView     hits,
+    const ParamsPOD                 params,
+    const uint32*                   d_seed_freq_table,
+    const bool                      fw,
+    const bool                      rc,
+    void*                           hip_stream = nullptr)
+{
+    const int32 algorithm = !params.allow_sub ? NVBIO_HIP_EXACT_MAPPING : (params.subseed_len == 0 ? NVBIO_HIP_CASE_PRUNING_MAPPING : NVBIO_HIP_APPROX_MAPPING);
+    map_with(algorithm, read_batch, fmi, rfmi, retry, queues, reseed, hits, params, d_seed_freq_table, fw, rc, hip_stream);
+}
+
+/// the all-mapping driver's choice (aligner_all.h:177-212): map_exact, or -- with params.allow_sub -- map_approx with params.subseed_len
+/// exact symbols (none by default) and one mismatch in the rest of the seed; never the case-pruning mapper of the best modes
+template <typename read_batch_type>
+inline void map_all(
+    const read_batch_type&          read_batch,
+    const fm_index_device&          fmi,
+    const fm_index_device&          rfmi,
+    const PingPongQueuesView        queues,
+    uint8*                          reseed,
+    SeedHitDequeArrayDeviceView     hits,
+    const ParamsPOD                 params,
+    const uint32*                   d_seed_freq_table,
+    const bool                      fw,
+    const bool                      rc,
+    void*                           hip_stream = nullptr)
+{
+    map_with(params.allow_sub ? NVBIO_HIP_APPROX_MAPPING : NVBIO_HIP_EXACT_MAPPING, read_batch, fmi, rfmi, 0u, queues, reseed, hits, params, d_seed_freq_table, fw, rc, hip_stream);
 }
 
 } // namespace cuda

@@ -706,8 +706,13 @@ full_gotoh_score_kernel(const FullParams p)
 // fires needs a second sweep over a prefix of its rows / columns (as in full_gotoh_score_kernel): the wave then runs that job alone
 // on the single-job sweep, segment by segment, so every result is the one full_gotoh_score_kernel produces.
 // ---------------------------------------------------------------------------------------------
-template <int TYPE, int R>
-__global__ void __launch_bounds__(256, ((R <= 6 || (TYPE == NVBIO_HIP_LOCAL && R >= 8)) ? 3 : 2))       // R <= 6: >= 3 waves per SIMD (left alone the SEMI_GLOBAL instance takes 176 VGPRs = 2 waves; 168 + 14 spilled: +8 %); deeper lanes hold more rows and get 256 VGPRs
+// MODE: 0 = no min_score, 1 = min_score with text blocking (the sweep that watches the column maxima, CHECK), 2 = min_score with pattern
+// blocking (the sweep that also keeps every row's maximum, PBX).  One kernel per job shape because a kernel's register allocation is the
+// maximum over the sweeps compiled into it: with all three inside, every instance carried the CHECK sweep's budget (SEMI_GLOBAL at ten rows
+// per lane: 256 VGPRs, two waves per SIMD); apart, the same instance takes 84 (no min_score: five waves) / 105 (PBX: four) and only the
+// CHECK sweep keeps its 250 (capped at 168 it spills 428 bytes).  LOCAL at ten rows: 109 / 168 / 168.  profiles/r04/full_dp_rows.txt.
+template <int TYPE, int R, int MODE>
+__global__ void __launch_bounds__(256, ((R >= 8 && MODE == 1 && TYPE != NVBIO_HIP_LOCAL) ? 2 : 3))       // R <= 6: >= 3 waves per SIMD (left alone the SEMI_GLOBAL instance takes 176 VGPRs = 2 waves; 168 + 14 spilled: +8 %); deeper lanes hold more rows and get 256 VGPRs
 full_gotoh_score_multi_kernel(const FullParams p, const uint32_t n_seg, const uint32_t seg_w)
 {
     // LOCAL with eight or more rows per lane: the rows' records in LDS (Sweep16: BKL), which brings the instance from 176 to <= 168 VGPRs
@@ -755,7 +760,7 @@ full_gotoh_score_multi_kernel(const FullParams p, const uint32_t n_seg, const ui
     const uint32_t Ms = sweeps ? M : 1u, Ns = sweeps ? N : 0u;
     // 0 = nothing more to do, 1 = sweep rows [0, arg] again (pattern blocking, LOCAL), 2 = sweep columns [0, arg] again (text blocking, LOCAL)
     uint32_t redo = 0u, redo_arg = 0u;
-    if (PB && check)
+    if constexpr (MODE == 2)
     {
         Sweep16<TYPE, R, false, (TYPE != NVBIO_HIP_LOCAL), true, BKL> sw(p);
         sw.bkl = bkl;
@@ -771,8 +776,8 @@ full_gotoh_score_multi_kernel(const FullParams p, const uint32_t n_seg, const ui
     else
     {
         SweepResult r;
-        if (check) { Sweep16<TYPE, R, true,  false, true, BKL> sw(p); sw.bkl = bkl; sw.init(pb, tb, Ms, Ns, Ns, min_score, seg_w, sweeps); r = sw.run(); }
-        else       { Sweep16<TYPE, R, false, false, true, BKL> sw(p); sw.bkl = bkl; sw.init(pb, tb, Ms, Ns, Ns, min_score, seg_w, sweeps); r = sw.run(); }
+        if constexpr (MODE == 1) { Sweep16<TYPE, R, true,  false, true, BKL> sw(p); sw.bkl = bkl; sw.init(pb, tb, Ms, Ns, Ns, min_score, seg_w, sweeps); r = sw.run(); }
+        else                     { Sweep16<TYPE, R, false, false, true, BKL> sw(p); sw.bkl = bkl; sw.init(pb, tb, Ms, Ns, Ns, min_score, seg_w, sweeps); r = sw.run(); }
         if (sweeps)
         {
             if (r.exit_col != 0xFFFFFFFFu)
@@ -819,12 +824,19 @@ static hipError_t launch_full_multi(const FullParams& p, int type, uint32_t n_se
     const uint32_t seg_w = 64u / n_seg;
     const uint64_t waves = (uint64_t(p.n) + n_seg - 1u) / n_seg;
     const dim3 grid(uint32_t((waves * 64u + 255u) / 256u)), block(256);
+    // (see the kernel: one instance per job shape, because their register budgets differ)
+    const int mode = p.min_score == nullptr ? 0 : (p.pattern_blocking != 0u ? 2 : 1);
+    #define NVB_LAUNCH_MULTI(T) do { \
+        if (mode == 2)      hipLaunchKernelGGL((full_gotoh_score_multi_kernel<T, R, 2>), grid, block, 0, s, p, n_seg, seg_w); \
+        else if (mode == 1) hipLaunchKernelGGL((full_gotoh_score_multi_kernel<T, R, 1>), grid, block, 0, s, p, n_seg, seg_w); \
+        else                hipLaunchKernelGGL((full_gotoh_score_multi_kernel<T, R, 0>), grid, block, 0, s, p, n_seg, seg_w); } while (0)
     switch (type) {
-    case NVBIO_HIP_LOCAL:       hipLaunchKernelGGL((full_gotoh_score_multi_kernel<NVBIO_HIP_LOCAL, R>),       grid, block, 0, s, p, n_seg, seg_w); break;
-    case NVBIO_HIP_SEMI_GLOBAL: hipLaunchKernelGGL((full_gotoh_score_multi_kernel<NVBIO_HIP_SEMI_GLOBAL, R>), grid, block, 0, s, p, n_seg, seg_w); break;
-    case NVBIO_HIP_GLOBAL:      hipLaunchKernelGGL((full_gotoh_score_multi_kernel<NVBIO_HIP_GLOBAL, R>),      grid, block, 0, s, p, n_seg, seg_w); break;
+    case NVBIO_HIP_LOCAL:       NVB_LAUNCH_MULTI(NVBIO_HIP_LOCAL); break;
+    case NVBIO_HIP_SEMI_GLOBAL: NVB_LAUNCH_MULTI(NVBIO_HIP_SEMI_GLOBAL); break;
+    case NVBIO_HIP_GLOBAL:      NVB_LAUNCH_MULTI(NVBIO_HIP_GLOBAL); break;
     default: return hipErrorInvalidValue;
     }
+    #undef NVB_LAUNCH_MULTI
     return hipGetLastError();
 }
 

@@ -238,7 +238,7 @@ def all_mapping(host_fmi, host_rfmi, sym, genome_words, genome_len, params, sche
     mp = params.mapping_params()
     sf = mp.seed_freq_table(L, "cpu").numpy().view(np.uint32)
     stride = params.hits_stride or min(params.max_hits, 128)
-    algorithm = 0 if not params.allow_sub else (2 if params.subseed_len == 0 else 1)
+    algorithm = 1 if params.allow_sub else 0          # map_exact or map_approx -- never case pruning (aligner_all.h:177-212)
     pd = dict(seed_len=mp.seed_len, min_read_len=mp.min_read_len, max_hits=mp.max_hits, max_reseed=mp.max_reseed, retry=0,
               rep_seeds=mp.rep_seeds, fw=int(params.fw), rc=int(params.rc))
     hits, counts, _ = O.map_seeds(algorithm, params.subseed_len, host_fmi, host_rfmi, reads_rev, pd, sf, stride)

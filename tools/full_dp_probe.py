@@ -3,6 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, nvbio_amd as nvb
 from nvbio_amd import workloads as W
 dev = "cuda"
+TYPE = nvb.SEMI_GLOBAL if "semi" in sys.argv[1:] else nvb.GLOBAL if "global" in sys.argv[1:] else nvb.LOCAL      # python tools/full_dp_probe.py [semi|global]
 def timed(fn, reps=3):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -17,11 +18,11 @@ for nw, wl in ((1_000_000, 650), (200_000, 650), (100_000, 4096)):
     mate = win.gather(1, off.unsqueeze(1) + torch.arange(150, device=dev).unsqueeze(0))
     mp_ = nvb.PackedStringSet(W._pack_chunked(mate.reshape(-1), 4, True), 4, True, torch.arange(nw, dtype=torch.int64, device=dev) * 150, None, 150)
     wt = nvb.PackedStringSet(W._pack_chunked(win.reshape(-1), 2, True), 2, True, torch.arange(nw, dtype=torch.int64, device=dev) * wl, None, wl)
-    msc = torch.full((nw,), 100, dtype=torch.int32, device=dev)
+    msc = torch.full((nw,), 100 if TYPE == nvb.LOCAL else -90, dtype=torch.int32, device=dev)
     for scheme in ((2, -6, -8, -3), (2, -1, -2, -1)):
         for algo in (nvb.TEXT_BLOCKING, nvb.PATTERN_BLOCKING):
-            al = nvb.make_gotoh_aligner(nvb.LOCAL, nvb.SimpleGotohScheme(*scheme), algo)
-            for ms_t, nm in ((None, "no min_score"), (msc, "min_score=100")):
+            al = nvb.make_gotoh_aligner(TYPE, nvb.SimpleGotohScheme(*scheme), algo)
+            for ms_t, nm in ((None, "no min_score"), (msc, "min_score=%d" % int(msc[0]))):
                 ms = timed(lambda: nvb.batch_alignment_score(al, mp_, wt, 150, wl, ms_t))
                 print("n %7d N %4d scheme %s algo %d %-13s: %7.2f ms %6.0f GCUPS [%s]" % (nw, wl, scheme, algo, nm, ms, nw * 150 * wl / ms / 1e6, nvb.lib().nvbio_hip_last_kernel().decode()))
     del win, mate, mp_, wt
