@@ -278,20 +278,26 @@ def test_reference_nvbowtie_writes_bam(tmp_path, paired):
 
 @pytest.mark.parametrize("case", [dict(mode="se", quals="random", seed=41), dict(mode="local", quals="random", len=250, seed=42),
                                   dict(mode="se", ns=0.01, len=150, seed=43), dict(mode="se", len=50, seed=45),
-                                  dict(mode="all", quals="random", ns=0.005, seed=46), dict(mode="paired", quals="random", seed=51)],
-                         ids=["se-random-quals", "local-250bp-random-quals", "se-150bp-with-N", "se-50bp", "all-random-quals-with-N", "paired-random-quals"])
+                                  dict(mode="all", quals="random", ns=0.005, seed=46), dict(mode="paired", quals="random", seed=51),
+                                  dict(mode="se", repeats=0.6, quals="random", seed=109, reads=10000), dict(mode="paired", repeats=0.6, seed=110, reads=5000),
+                                  dict(mode="all", repeats=0.6, seed=107), dict(mode="all", repeats=0.6, seed=108, extra="-N 1", own="allow_sub=1"),
+                                  dict(mode="local", repeats=0.6, seed=111, extra="--no-rand", own="randomized=False", reads=10000)],
+                         ids=["se-random-quals", "local-250bp-random-quals", "se-150bp-with-N", "se-50bp", "all-random-quals-with-N", "paired-random-quals",
+                              "se-repeats", "paired-repeats", "all-repeats", "all-repeats-N1", "local-repeats-no-rand"])
 def test_own_drivers_equal_reference_nvbowtie_on_varied_reads(case, cuda):
     """Per-base qualities drawn from phred 2 .. 40 (nvBowtie's mismatch penalty depends on them, scoring.h:206-356), reads with N, read
-    lengths 50 / 150 / 250: still every SAM record of the reference's application equals the from-scratch driver's."""
+    lengths 50 / 150 / 250, and genomes 60 % covered by 1 %-diverged copies of six repeat families (several placements per read: second-best
+    scores, low MAPQ, randomized choice among equals, 5 placements per read on average in --all): still every SAM record of the reference's
+    application equals the from-scratch driver's."""
     import argparse
     import sys
     if not os.path.exists(os.path.join(REF, "ref_nvBowtie")):
         pytest.skip("oracle/_ref/ref_nvBowtie not built (needs /root/reference in the build container)")
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import nvbowtie_compare
-    args = dict(mode="se", reads=3000, seed=5, indels=0.2, show=3, len=100, ns=0.0, quals="I"); args.update(case)
+    args = dict(mode="se", reads=3000, seed=5, indels=0.2, show=3, len=100, ns=0.0, quals="I", repeats=0.0, extra="", own=""); args.update(case)
     same, n_ref, n_own = nvbowtie_compare.compare(argparse.Namespace(**args))
-    assert n_ref == n_own and n_ref >= 3000
+    assert n_ref == n_own and n_ref >= args["reads"]
     assert same == n_ref, (case, same, n_ref)
 
 
@@ -330,7 +336,7 @@ def test_own_drivers_equal_reference_nvbowtie_under_its_options(case, cuda):
         pytest.skip("oracle/_ref/ref_nvBowtie not built (needs /root/reference in the build container)")
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import nvbowtie_compare
-    args = dict(mode="se", reads=3000, seed=5, indels=0.2, show=3, len=100, ns=0.0, quals="I", extra="", own=""); args.update(case)
+    args = dict(mode="se", reads=3000, seed=5, indels=0.2, show=3, len=100, ns=0.0, quals="I", repeats=0.0, extra="", own=""); args.update(case)
     same, n_ref, n_own = nvbowtie_compare.compare(argparse.Namespace(**args))
     assert n_ref == n_own and n_ref >= args["reads"]
     assert same == n_ref, (case, same, n_ref)

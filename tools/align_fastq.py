@@ -26,6 +26,11 @@ def _rname_pos(ref, pos):
     return name, p + 1
 
 
+def cigar_ref_length(words, length):
+    """reference symbols an alignment spans: its M and D operations"""
+    return sum((int(w) & 0xFFFF) >> 2 for w in words[:length] if (int(w) & 3) in (0, 2))
+
+
 def cigar_string(words, length):
     """io::Cigar words are stored end-first; SAM wants them start-first"""
     ops = [(int(w) & 3, (int(w) & 0xFFFF) >> 2) for w in words[:length]][::-1]
@@ -44,6 +49,13 @@ class Reference:
     def header(self):
         return "@HD\tVN:1.0\tSO:unsorted\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (nm, self.index[k + 1] - self.index[k]) for k, nm in enumerate(self.names)) + \
                "@PG\tID:nvbio_amd\tPN:nvbio_amd\n"
+
+    def bridges(self, pos, ref_len):
+        """an alignment that runs over the end of its reference sequence: SamOutput flags it UNMAPPED with mapping quality 0 and still
+        prints it in full (output_sam.cpp:454-462)"""
+        import bisect
+        k = bisect.bisect_right(list(self.index), pos) - 1
+        return pos + ref_len > int(self.index[k + 1])
 
     def locate(self, pos):
         """genome coordinate -> (RNAME, 0-based coordinate inside that sequence)"""
@@ -84,8 +96,9 @@ def main(prefix, fastq, out=sys.stdout, device="cuda", ref_name="ref", **param_o
         score, ed = ((w >> 1) & 0x1FFFF) * (-1 if w & 1 else 1), (w >> 18) & 0x3FF
         s, q = (np.where(seq < 4, 3 - seq, 4)[::-1], qual[::-1]) if rc else (seq, qual)
         md, mm, gapo, gape = nio.sam_md_string(mds[i])
+        over = ref.bridges(pos + int(source[i, 0]), cigar_ref_length(cig[i], int(clen[i])))
         out.write("%s\t%d\t%s\t%d\t%d\t%s\t*\t0\t0\t%s\t%s\tNM:i:%d\tAS:i:%d\tXM:i:%d\tXO:i:%d\tXG:i:%d\tMD:Z:%s\n" % (
-            reads.names[i], 16 if rc else 0, *_rname_pos(ref, pos + int(source[i, 0])), int(mapq[i]), cigar_string(cig[i], int(clen[i])),
+            reads.names[i], (16 if rc else 0) | (4 if over else 0), *_rname_pos(ref, pos + int(source[i, 0])), 0 if over else int(mapq[i]), cigar_string(cig[i], int(clen[i])),
             "".join("ACGTN"[c] for c in s), "".join(chr(int(x) + 33) for x in q), ed, score, mm, gapo, gape, md or "*"))
 
 
@@ -119,8 +132,9 @@ def main_all(prefix, fastq, out=sys.stdout, device="cuda", ref_name="ref", **par
         score, ed = ((w >> 1) & 0x1FFFF) * (-1 if w & 1 else 1), (w >> 18) & 0x3FF
         s, q = (np.where(seq < 4, 3 - seq, 4)[::-1], qual[::-1]) if rc else (seq, qual)
         md, mm, gapo, gape = nio.sam_md_string(mds[k])
-        out.write("%s\t%d\t%s\t%d\t255\t%s\t*\t0\t0\t%s\t%s\tNM:i:%d\tAS:i:%d\tXM:i:%d\tXO:i:%d\tXG:i:%d\tMD:Z:%s\n" % (
-            reads.names[i], 16 if rc else 0, *_rname_pos(ref, pos + int(source[k, 0])), cigar_string(cig[k], int(clen[k])),
+        over = ref.bridges(pos + int(source[k, 0]), cigar_ref_length(cig[k], int(clen[k])))
+        out.write("%s\t%d\t%s\t%d\t%d\t%s\t*\t0\t0\t%s\t%s\tNM:i:%d\tAS:i:%d\tXM:i:%d\tXO:i:%d\tXG:i:%d\tMD:Z:%s\n" % (
+            reads.names[i], (16 if rc else 0) | (4 if over else 0), *_rname_pos(ref, pos + int(source[k, 0])), 0 if over else 255, cigar_string(cig[k], int(clen[k])),
             "".join("ACGTN"[c] for c in s), "".join(chr(int(x) + 33) for x in q), ed, score, mm, gapo, gape, md or "*"))
 
 
@@ -184,6 +198,9 @@ def main_paired(prefix, fastq1, fastq2, out=sys.stdout, device="cuda", ref_name=
             if (w_m >> 28) & 1:
                 flags |= 0x20
             rname, lpos = ref.locate(a["pos"])
+            over = ref.bridges(a["pos"], a["ref_len"])
+            if over:
+                flags |= 0x4
             if m is not None:
                 m_rname, m_lpos = ref.locate(m["pos"])
                 rnext = "=" if m_rname == rname else m_rname
@@ -200,7 +217,7 @@ def main_paired(prefix, fastq1, fastq2, out=sys.stdout, device="cuda", ref_name=
             s, q = (np.where(seq < 4, 3 - seq, 4)[::-1], qual[::-1]) if a["rc"] else (seq, qual)
             md, mm, gapo, gape = nio.sam_md_string(slots[k]["mds"][i])
             out.write("%s\t%d\t%s\t%d\t%d\t%s\t%s\t%d\t%d\t%s\t%s\tNM:i:%d\tAS:i:%d\tXM:i:%d\tXO:i:%d\tXG:i:%d\tMD:Z:%s\n" % (
-                rd.names[i], flags, rname, lpos + 1, int(slots[k]["mapq"][i]), cigar_string(slots[k]["cigar"][i], int(slots[k]["clen"][i])), rnext, pnext, tlen,
+                rd.names[i], flags, rname, lpos + 1, 0 if over else int(slots[k]["mapq"][i]), cigar_string(slots[k]["cigar"][i], int(slots[k]["clen"][i])), rnext, pnext, tlen,
                 "".join("ACGTN"[c] for c in s), "".join(chr(int(x) + 33) for x in q), ed, score, mm, gapo, gape, md or "*"))
 
 
