@@ -609,7 +609,8 @@ __device__ __forceinline__ SweepResult sweep16_pb(const FullParams& p, const uin
     return sw.run();
 }
 
-template <int TYPE, int R, bool TRUNC, bool FAST>
+// MODE (FAST only; see full_gotoh_score_multi_kernel): 0 = no min_score, 1 = min_score with text blocking, 2 = min_score with pattern blocking
+template <int TYPE, int R, bool TRUNC, bool FAST, int MODE = 0>
 __global__ void __launch_bounds__(256)
 full_gotoh_score_kernel(const FullParams p)
 {
@@ -641,7 +642,7 @@ full_gotoh_score_kernel(const FullParams p)
             if (TYPE == NVBIO_HIP_GLOBAL)      { score = p.row_go + p.row_ge * int32_t(N - 1u); sx = N; sy = 0u; }
         }
     }
-    else if (FAST && p.pattern_blocking != 0u && check)
+    else if constexpr (FAST && MODE == 2)
     {
         // PatternBlockingTag with a min_score: the exit test runs per block of pattern rows (gotoh_inl.h:826-830)
         const uint32_t BLK = 1u << p.blk_log2;
@@ -666,9 +667,10 @@ full_gotoh_score_kernel(const FullParams p)
     }
     else
     {
-        SweepResult r = FAST ? (check ? sweep16<TYPE, R, true>(p, pb, tb, M, N, N, min_score)
-                                      : sweep16<TYPE, R, false>(p, pb, tb, M, N, N, min_score))
-                             : sweep<TYPE, R, TRUNC>(p, pb, tb, M, N, N, check, min_score);
+        SweepResult r;
+        if constexpr (!FAST)          r = sweep<TYPE, R, TRUNC>(p, pb, tb, M, N, N, check, min_score);
+        else if constexpr (MODE == 1) r = sweep16<TYPE, R, true>(p, pb, tb, M, N, N, min_score);
+        else                          r = sweep16<TYPE, R, false>(p, pb, tb, M, N, N, min_score);
         if (r.exit_col != 0xFFFFFFFFu)
         {
             // the reference returned false after this block: its sink saw columns [0, exit_col] only
@@ -844,12 +846,21 @@ template <int R, bool TRUNC, bool FAST>
 static hipError_t launch_full(const FullParams& p, int type, hipStream_t s)
 {
     const dim3 grid((uint64_t(p.n) * 64u + 255u) / 256u), block(256);
+    // (the 16-bit sweep: one kernel per job shape, as for the multi-job kernel; the 32-bit sweep decides at run time)
+    const int mode = !FAST ? 0 : (p.min_score == nullptr ? 0 : (p.pattern_blocking != 0u ? 2 : 1));
+    #define NVB_LAUNCH_FULL(T) do { \
+        if constexpr (FAST) { \
+            if (mode == 2)      hipLaunchKernelGGL((full_gotoh_score_kernel<T, R, TRUNC, FAST, 2>), grid, block, 0, s, p); \
+            else if (mode == 1) hipLaunchKernelGGL((full_gotoh_score_kernel<T, R, TRUNC, FAST, 1>), grid, block, 0, s, p); \
+            else                hipLaunchKernelGGL((full_gotoh_score_kernel<T, R, TRUNC, FAST, 0>), grid, block, 0, s, p); \
+        } else                  hipLaunchKernelGGL((full_gotoh_score_kernel<T, R, TRUNC, FAST, 0>), grid, block, 0, s, p); } while (0)
     switch (type) {
-    case NVBIO_HIP_GLOBAL:      hipLaunchKernelGGL((full_gotoh_score_kernel<NVBIO_HIP_GLOBAL, R, TRUNC, FAST>),      grid, block, 0, s, p); break;
-    case NVBIO_HIP_LOCAL:       hipLaunchKernelGGL((full_gotoh_score_kernel<NVBIO_HIP_LOCAL, R, TRUNC, FAST>),       grid, block, 0, s, p); break;
-    case NVBIO_HIP_SEMI_GLOBAL: hipLaunchKernelGGL((full_gotoh_score_kernel<NVBIO_HIP_SEMI_GLOBAL, R, TRUNC, FAST>), grid, block, 0, s, p); break;
+    case NVBIO_HIP_GLOBAL:      NVB_LAUNCH_FULL(NVBIO_HIP_GLOBAL); break;
+    case NVBIO_HIP_LOCAL:       NVB_LAUNCH_FULL(NVBIO_HIP_LOCAL); break;
+    case NVBIO_HIP_SEMI_GLOBAL: NVB_LAUNCH_FULL(NVBIO_HIP_SEMI_GLOBAL); break;
     default: return hipErrorInvalidValue;
     }
+    #undef NVB_LAUNCH_FULL
     return hipGetLastError();
 }
 
