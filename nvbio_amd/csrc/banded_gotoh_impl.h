@@ -436,8 +436,10 @@ template <typename A> __device__ __forceinline__ void fill_lut(typename A::T* lu
 }
 template <typename A> __device__ __forceinline__ void fill_lut(typename A::T*, const NoQual&, int32_t, int) {}
 
+// band 31 with per-base qualities (nvBowtie's default band: max_dist 15) takes 173-189 VGPRs when left alone -- two waves per SIMD, a few
+// registers over the 168 that allow three; the bound makes the compiler fit them
 template <int BAND, int TYPE, typename A, typename QA>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, (BAND == 31 ? 3 : 1))
 banded_gotoh_score_kernel(const GotohParams p, const QA qa)
 {
     typedef BandTraits<BAND> BT;

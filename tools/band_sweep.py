@@ -1,4 +1,6 @@
 """Throughput of the banded score kernel across bands / schemes / read lengths (GCUPS)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, nvbio_amd as nvb
 from nvbio_amd import workloads as W
 dev = "cuda"
@@ -9,7 +11,9 @@ def timed(fn, reps=5):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-for L, band in ((100, 7), (100, 5), (100, 3), (250, 31)):
+import sys
+CASES = ((100, 31), (150, 31)) if "b31" in sys.argv[1:] else ((100, 7), (100, 5), (100, 3), (250, 31))
+for L, band in CASES:
     n = 4_000_000
     p, t = W.make_sw_batch(n, L, L + max(band, 15), seed=3, device=dev)
     sc = torch.empty(n, dtype=torch.int32, device=dev); sk = torch.empty((n, 2), dtype=torch.int32, device=dev)
