@@ -324,6 +324,11 @@ struct job_table
     unsigned long long* bounds;        // [0] lowest pattern word, [1] end pattern word, [2] lowest text word, [3] end text word
                                        // views: [4] / [5] min / max of (quality address - pattern symbol address), [7] end pattern symbol
     uint32* stage_words; uint8* stage_quals; uint32 stage_stride;         // staged patterns: job i at symbol i * stage_stride (4-bit, little-endian)
+    // set by the host after the description pass: no job's min_score can ever bind (all <= -2^29; bounds[5] holds their maximum, biased by 2^31).
+    // A stream that does not use thresholds says so with Field_traits<int32>::min() in every context (sw-benchmark.cu:204-215, batched_inl.h:944);
+    // the full-matrix kernels then run their plain sweep instead of the one that watches the column maxima (12.2 instead of 16.2 ms for
+    // sw-benchmark's LOCAL batch)
+    bool    no_thresholds;
     static uint64 bytes(const uint32 n) { return 64u + uint64(n) * (8u + 4u + 8u + 4u + 4u + 4u + 8u + 1u) + 8u * 16u; }
     static uint32 stride_for(const uint32 maxP) { const uint32 s = (maxP + 7u) & ~7u; return s ? s : 8u; }
     static uint64 stage_bytes(const uint32 n, const uint32 maxP, const bool quals)
@@ -339,7 +344,7 @@ struct job_table
         min_score = reinterpret_cast<int32*>(p);  p += uint64(n) * 4u;
         score     = reinterpret_cast<int32*>(p);  p += uint64(n) * 4u;
         ok        = p;
-        stage_words = nullptr; stage_quals = nullptr; stage_stride = 0;
+        stage_words = nullptr; stage_quals = nullptr; stage_stride = 0; no_thresholds = false;
     }
 };
 
@@ -376,7 +381,7 @@ __global__ void __launch_bounds__(128) describe_jobs_kernel(const stream_type st
     constexpr uint32 G = priv::describe_lanes<stream_type, R>::value;
     // a fixed grid strides over the jobs, every lane keeps its own bounds, and the four global bounds cost four atomics per BLOCK
     // (one per wave and bound made waves that see jobs in storage order queue up on the same addresses: see describe_views_kernel)
-    unsigned long long plo = ~0ull, phi = 0ull, tlo = ~0ull, thi = 0ull;
+    unsigned long long plo = ~0ull, phi = 0ull, tlo = ~0ull, thi = 0ull, mshi = 0ull;
     const uint64 total = uint64(stream.size()) * G;
     for (uint64 gt = uint64(blockIdx.x) * 128u + threadIdx.x; gt < total; gt += uint64(gridDim.x) * 128u)
     {
@@ -391,6 +396,7 @@ __global__ void __launch_bounds__(128) describe_jobs_kernel(const stream_type st
             pwhere::get(strings.pattern, pw, pf);
             packed_view<typename R::text_type>::where(strings.text, tw, tf);
             pl = strings.pattern.length(); tl = strings.text.length(); ms = ctx.min_score;
+            { const unsigned long long mb = static_cast<unsigned long long>(static_cast<long long>(ms) + (1ll << 31)); mshi = mb > mshi ? mb : mshi; }
             { const unsigned long long te = tw + (tf + tl + 15u) / 16u; tlo = tw < tlo ? tw : tlo; thi = te > thi ? te : thi; }
             if (R::staged)
             {
@@ -427,9 +433,9 @@ __global__ void __launch_bounds__(128) describe_jobs_kernel(const stream_type st
             t.txt_begin[i] = tw * 16u + tf; t.txt_len[i] = tl; t.min_score[i] = ms;
         }
     }
-    __shared__ unsigned long long s_b[2][4];
-    plo = wave_min(plo); phi = wave_max(phi); tlo = wave_min(tlo); thi = wave_max(thi);
-    if ((threadIdx.x & 63u) == 0u) { unsigned long long* o = s_b[threadIdx.x >> 6]; o[0] = plo; o[1] = phi; o[2] = tlo; o[3] = thi; }
+    __shared__ unsigned long long s_b[2][5];
+    plo = wave_min(plo); phi = wave_max(phi); tlo = wave_min(tlo); thi = wave_max(thi); mshi = wave_max(mshi);
+    if ((threadIdx.x & 63u) == 0u) { unsigned long long* o = s_b[threadIdx.x >> 6]; o[0] = plo; o[1] = phi; o[2] = tlo; o[3] = thi; o[4] = mshi; }
     __syncthreads();
     if (threadIdx.x < 4u)
     {
@@ -437,6 +443,8 @@ __global__ void __launch_bounds__(128) describe_jobs_kernel(const stream_type st
         if ((threadIdx.x & 1u) == 0u) { const unsigned long long v = a < b ? a : b; if (v != ~0ull) atomicMin(&t.bounds[threadIdx.x], v); }
         else                          { const unsigned long long v = a > b ? a : b; if (v != 0ull) atomicMax(&t.bounds[threadIdx.x], v); }
     }
+    else if (threadIdx.x == 4u)
+    { const unsigned long long a = s_b[0][4], b = s_b[1][4], v = a > b ? a : b; if (v != 0ull) atomicMax(&t.bounds[5], v); }      // [5]: the largest min_score, biased by 2^31
 }
 static __global__ void __launch_bounds__(256) rebase_jobs_kernel(const uint32 n, uint64* pat_begin, const uint64 pat_delta, uint64* txt_begin, const uint64 txt_delta)
 {
@@ -563,9 +571,10 @@ inline void build_job_table(const stream_type& stream, device_buffer& buf, job_t
     if (extra) *extra = base + table + stage;
     hipLaunchKernelGGL(init_bounds_kernel, dim3(1), dim3(64), 0, hs, t.bounds);
     hipLaunchKernelGGL((describe_jobs_kernel<stream_type, R>), dim3(uint32(std::min<uint64>((uint64(n) * describe_lanes<stream_type, R>::value + 127u) / 128u, 65536u))), dim3(128), 0, hs, stream, t);
-    unsigned long long b[4];
+    unsigned long long b[6];
     check(hipMemcpyAsync(b, t.bounds, sizeof(b), hipMemcpyDeviceToHost, hs), "hipMemcpyAsync");
     check(hipStreamSynchronize(hs), "hipStreamSynchronize");
+    t.no_thresholds = (b[5] != 0ull) && static_cast<long long>(b[5]) - (1ll << 31) <= -(1ll << 29);
     if (b[1] == 0ull) { b[0] = 0ull; b[1] = 1ull; }          // no job has a pattern / text: any valid range will do
     if (b[3] == 0ull) { b[2] = 0ull; b[3] = 1ull; }
     typedef pattern_where<typename R::pattern_type, !R::staged> pwhere;
@@ -665,8 +674,10 @@ struct tuned_scheme
     {
         const uint32 n = stream.size(), maxP = maxP_of(stream), maxT = maxT_of(stream);
         const int32 algo = TA::TEXT_BLOCKING ? NVBIO_HIP_TEXT_BLOCKING : NVBIO_HIP_PATTERN_BLOCKING;
-        if constexpr (TA::QUAL) return nvbio_hip_alignment_score_qual(&q, algo, int32(aligner_type::TYPE), &ps, quals, n_quals, &ts, maxP, maxT, t.min_score, n, t.score, t.sink, t.ok, hs);
-        else return nvbio_hip_alignment_score(TA::KIND, algo, sc, int32(aligner_type::TYPE), &ps, &ts, maxP, maxT, t.min_score, n, t.score, t.sink, t.ok, hs);
+        // thresholds that can never bind are not passed on (a non-negative match score: with a negative one even -2^30 takes part in the
+        // reference's exit test for empty patterns, gotoh_inl.h:1203-1207)
+        if constexpr (TA::QUAL) return nvbio_hip_alignment_score_qual(&q, algo, int32(aligner_type::TYPE), &ps, quals, n_quals, &ts, maxP, maxT, (t.no_thresholds && q.match >= 0) ? nullptr : t.min_score, n, t.score, t.sink, t.ok, hs);
+        else return nvbio_hip_alignment_score(TA::KIND, algo, sc, int32(aligner_type::TYPE), &ps, &ts, maxP, maxT, (t.no_thresholds && sc[0] >= 0) ? nullptr : t.min_score, n, t.score, t.sink, t.ok, hs);
     }
     /// band == 0: full matrix
     int traceback(const uint32 band, const stream_type& stream, const job_table& t, const nvbio_hip_string_set& ps, const nvbio_hip_string_set& ts,
