@@ -122,19 +122,50 @@ __global__ void __launch_bounds__(128) batched_full_score_kernel(const stream_ty
 }
 
 /// a growable device buffer owned by a batch object (the reference keeps a thrust::device_vector<uint8> there)
+/// a batch object's scratch (job tables, staged strings, boundary columns).  Callers make a fresh batch object per call (sw-benchmark.cu:373-378,
+/// nvBowtie's score / traceback functions), and a plain hipMalloc costs ~4 ms here -- a third of sw-benchmark's timed enact() -- so the
+/// blocks come from the library's private stream-ordered pool (nvbio_hip_device_malloc: hipMalloc / hipFree semantics, freed blocks kept)
 struct device_buffer
 {
     device_buffer() : ptr(nullptr), bytes(0) {}
-    ~device_buffer() { if (ptr) (void)hipFree(ptr); }
+    ~device_buffer() { release(); }
     device_buffer(const device_buffer&) = delete;
     device_buffer& operator=(const device_buffer&) = delete;
     uint8* reserve(const uint64 n)
     {
-        if (n > bytes) { if (ptr) (void)hipFree(ptr); ptr = nullptr; bytes = 0; check(hipMalloc(reinterpret_cast<void**>(&ptr), n), "hipMalloc"); bytes = n; }
+        if (n > bytes)
+        {
+            release();
+#if defined(NVBIO_HIP_COMPAT_TUNED)
+            void* p = nullptr; check(nvbio_hip_device_malloc(&p, n), "nvbio_hip_device_malloc"); ptr = static_cast<uint8*>(p);
+#else
+            check(hipMalloc(reinterpret_cast<void**>(&ptr), n), "hipMalloc");
+#endif
+            bytes = n;
+        }
         return ptr;
+    }
+    void release()
+    {
+        if (!ptr) return;
+#if defined(NVBIO_HIP_COMPAT_TUNED)
+        (void)nvbio_hip_device_free(ptr);
+#else
+        (void)hipFree(ptr);
+#endif
+        ptr = nullptr; bytes = 0;
     }
     uint8* ptr; uint64 bytes;
 };
+/// a few words of PINNED host memory per host thread, for the small read-backs between a batch's kernels (bounds, limits): hipMemcpyAsync
+/// into pageable memory took 4.5 ms per call on the GPU box (a third of sw-benchmark's timed enact()); into pinned memory it is a DMA
+inline unsigned long long* pinned_words()
+{
+    struct holder { unsigned long long* p; holder() : p(nullptr) { if (hipHostMalloc(reinterpret_cast<void**>(&p), 128u, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = nullptr; } }
+                    ~holder() { if (p) (void)hipHostFree(p); } };
+    static thread_local holder h;
+    return h.p;
+}
 #endif
 
 // ---------------------------------------------------------------------------------------- stream recognition
@@ -306,8 +337,11 @@ struct limits_scope
             check(hipMemsetAsync(d, 0, 8u, hs), "hipMemsetAsync");
             const uint32 blocks = uint32(std::min<uint64>((uint64(s.size()) + 255u) / 256u, 4096u));
             hipLaunchKernelGGL((measure_limits_kernel<stream_type>), dim3(blocks), dim3(256), 0, hs, s, d);
-            check(hipMemcpyAsync(v, d, 8u, hipMemcpyDeviceToHost, hs), "hipMemcpyAsync");
+            unsigned long long* pin = pinned_words();
+            void* dst = pin ? static_cast<void*>(pin) : static_cast<void*>(v);
+            check(hipMemcpyAsync(dst, d, 8u, hipMemcpyDeviceToHost, hs), "hipMemcpyAsync");
             check(hipStreamSynchronize(hs), "hipStreamSynchronize");
+            if (pin) memcpy(v, pin, 8u);
         }
         const stream_limits l = { &s, v[0], v[1] }; current_limits() = l;
     }
@@ -572,8 +606,10 @@ inline void build_job_table(const stream_type& stream, device_buffer& buf, job_t
     hipLaunchKernelGGL(init_bounds_kernel, dim3(1), dim3(64), 0, hs, t.bounds);
     hipLaunchKernelGGL((describe_jobs_kernel<stream_type, R>), dim3(uint32(std::min<uint64>((uint64(n) * describe_lanes<stream_type, R>::value + 127u) / 128u, 65536u))), dim3(128), 0, hs, stream, t);
     unsigned long long b[6];
-    check(hipMemcpyAsync(b, t.bounds, sizeof(b), hipMemcpyDeviceToHost, hs), "hipMemcpyAsync");
-    check(hipStreamSynchronize(hs), "hipStreamSynchronize");
+    { unsigned long long* pin = pinned_words();
+      check(hipMemcpyAsync(pin ? pin : b, t.bounds, sizeof(b), hipMemcpyDeviceToHost, hs), "hipMemcpyAsync");
+      check(hipStreamSynchronize(hs), "hipStreamSynchronize");
+      if (pin) memcpy(b, pin, sizeof(b)); }
     t.no_thresholds = (b[5] != 0ull) && static_cast<long long>(b[5]) - (1ll << 31) <= -(1ll << 29);
     if (b[1] == 0ull) { b[0] = 0ull; b[1] = 1ull; }          // no job has a pattern / text: any valid range will do
     if (b[3] == 0ull) { b[2] = 0ull; b[3] = 1ull; }
@@ -601,8 +637,10 @@ inline bool build_view_table(const stream_type& stream, device_buffer& buf, job_
     hipLaunchKernelGGL(init_bounds_kernel, dim3(1), dim3(64), 0, hs, t.bounds);
     hipLaunchKernelGGL((describe_views_kernel<stream_type, R>), dim3(std::min<uint32>((n + 255u) / 256u, 8192u)), dim3(256), 0, hs, stream, t);
     unsigned long long b[8];
-    check(hipMemcpyAsync(b, t.bounds, sizeof(b), hipMemcpyDeviceToHost, hs), "hipMemcpyAsync");
-    check(hipStreamSynchronize(hs), "hipStreamSynchronize");
+    { unsigned long long* pin = pinned_words();
+      check(hipMemcpyAsync(pin ? pin : b, t.bounds, sizeof(b), hipMemcpyDeviceToHost, hs), "hipMemcpyAsync");
+      check(hipStreamSynchronize(hs), "hipStreamSynchronize");
+      if (pin) memcpy(b, pin, sizeof(b)); }
     if (b[1] == 0ull || b[4] != b[5]) return false;
     if (b[3] == 0ull) { b[2] = 0ull; b[3] = 1ull; }
     const uint32 per = 32u / where_type::BITS;
