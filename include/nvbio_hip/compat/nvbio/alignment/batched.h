@@ -161,8 +161,8 @@ struct device_buffer
 /// into pageable memory took 4.5 ms per call on the GPU box (a third of sw-benchmark's timed enact()); into pinned memory it is a DMA
 inline unsigned long long* pinned_words()
 {
-    struct holder { unsigned long long* p; holder() : p(nullptr) { if (hipHostMalloc(reinterpret_cast<void**>(&p), 128u, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = nullptr; } }
-                    ~holder() { if (p) (void)hipHostFree(p); } };
+    // (never freed: a thread's 128 bytes, against a hipHostFree that could run after the runtime has shut down)
+    struct holder { unsigned long long* p; holder() : p(nullptr) { if (hipHostMalloc(reinterpret_cast<void**>(&p), 128u, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = nullptr; } } };
     static thread_local holder h;
     return h.p;
 }

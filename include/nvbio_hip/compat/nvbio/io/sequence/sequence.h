@@ -142,7 +142,8 @@ template <> struct coordinate_cover<device_tag>
         const size_t all = (size_t(1) << 28) + 1024u;
         if (v.capacity() >= all) return;
         const size_t n = v.size();
-        v.reserve(all);
+        // (a device too full for the extra GiB keeps the stream as it is: the application then runs as it would on the reference's hardware)
+        try { v.reserve(all); } catch (...) { (void)hipGetLastError(); log_warning(stderr, "reference stream: no room to cover the 32-bit coordinate space (%zu MB)\n", all * sizeof(uint32) >> 20); return; }
         (void)hipMemset(nvbio::raw_pointer(static_cast<typename V::base_type&>(v)) + n, 0, (all - n) * sizeof(uint32));
     }
 };
