@@ -28,6 +28,22 @@ struct byte_source
         return m_pos < m_fill ? m_buffer[m_pos++] : uint8(255u);
     }
     void  unget() { if (m_pos) --m_pos; }
+    /// the rest of the current line, without its '\n', appended to `out`; false at the end of the file with nothing read
+    template <typename Vec> bool get_line(Vec& out)
+    {
+        bool any = false;
+        for (;;)
+        {
+            if (m_pos >= m_fill) { const int got = gzread(m_file, m_buffer.data(), unsigned(m_buffer.size())); m_fill = got > 0 ? uint32(got) : 0u; m_pos = 0; if (m_fill == 0u) return any; }
+            const uint8* b = m_buffer.data() + m_pos;
+            const uint8* nl = static_cast<const uint8*>(memchr(b, '\n', m_fill - m_pos));
+            const uint8* e = nl ? nl : m_buffer.data() + m_fill;
+            out.insert(out.end(), b, e);
+            any = true;
+            m_pos = uint32(e - m_buffer.data()) + (nl ? 1u : 0u);
+            if (nl) return true;
+        }
+    }
     /// up to n raw bytes (what get() has buffered first); 0 at the end of the file
     size_t read(uint8* out, const size_t n)
     {

@@ -727,11 +727,124 @@ private:
 };
 } // namespace priv
 
-/// open a FASTQ / FASTA file (plain or .gz; the record marker decides the format).  NULL when the file cannot be opened.
-/// The reference's factory also opens .txt / .sam / .bam / .pac inputs (sequence_priv.cpp:84-220); those are not read here.
+namespace priv {
+/// reads out of alignment files (sequence_sam.cpp:360-495, sequence_bam.cpp:200-388): every record that is not a secondary alignment
+/// (flag 0x100) contributes its name, SEQ and QUAL; a record flagged reverse-complemented (0x10) holds the read on the other strand, so the
+/// strand operation is turned round (FORWARD: reverse-complement it back; REVERSE: complement only; ...).  SAM qualities are phred + 33, BAM
+/// qualities plain phred; BAM bases are 4-bit codes of "=ACMGRSVTWYHKDBN".  BGZF is a series of gzip members: zlib's gzread walks it.
+struct AlignmentSequenceFile : public SequenceDataInputStream
+{
+    AlignmentSequenceFile(const char* name, const bool bam, const uint32 max_seqs, const uint32 max_sequence_len, const SequenceEncoding flags, const uint32 trim3, const uint32 trim5)
+        : m_src(name, 1u << 16), m_bam(bam), m_max_seqs(max_seqs), m_max_len(max_sequence_len), m_flags(flags), m_trim3(trim3), m_trim5(trim5), m_loaded(0), m_ok(m_src.valid()), m_eof(false)
+    { if (m_ok) m_ok = skip_header(); }
+
+    bool is_ok() { return m_ok; }
+    bool rewind() { m_src.rewind(); m_loaded = 0; m_eof = false; m_ok = m_src.valid() && skip_header(); return m_ok; }
+
+    int next(SequenceDataEncoder* encoder, const uint32 batch_size, const uint32 batch_bps = uint32(-1))
+    {
+        const uint32 want = std::min(m_max_seqs - m_loaded, batch_size);
+        if (!m_ok || want == 0u) return 0;
+        encoder->begin_batch();
+        const SequenceDataInfo* info = encoder->info();
+        while (info->size() < want && info->bps() < batch_bps && !m_eof && m_ok)
+        {
+            uint32 record_flags = 0;
+            if (!(m_bam ? read_bam_record(record_flags) : read_sam_record(record_flags))) break;
+            if (record_flags & 0x100u) continue;                                      // secondary alignment
+            const bool rc = (record_flags & 0x10u) != 0u;
+            typedef SequenceDataEncoder E;
+            const QualityEncoding q = m_bam ? Phred : Phred33;
+            const uint32 len = uint32(m_bp.size());
+            if (m_flags & FORWARD)            encoder->push_back(len, m_name.c_str(), m_bp.data(), m_q.data(), q, m_max_len, m_trim3, m_trim5, rc ? E::REVERSE_COMPLEMENT_OP : E::NO_OP);
+            if (m_flags & REVERSE)            encoder->push_back(len, m_name.c_str(), m_bp.data(), m_q.data(), q, m_max_len, m_trim3, m_trim5, rc ? E::COMPLEMENT_OP : E::REVERSE_OP);
+            if (m_flags & FORWARD_COMPLEMENT) encoder->push_back(len, m_name.c_str(), m_bp.data(), m_q.data(), q, m_max_len, m_trim3, m_trim5, rc ? E::REVERSE_OP : E::COMPLEMENT_OP);
+            if (m_flags & REVERSE_COMPLEMENT) encoder->push_back(len, m_name.c_str(), m_bp.data(), m_q.data(), q, m_max_len, m_trim3, m_trim5, rc ? E::NO_OP : E::REVERSE_COMPLEMENT_OP);
+        }
+        m_loaded += info->size();
+        encoder->end_batch();
+        return int(info->size());
+    }
+
+private:
+    bool get(void* out, const size_t n) { return m_src.read(static_cast<uint8*>(out), n) == n; }
+    bool skip(size_t n) { uint8 buf[256]; while (n) { const size_t k = std::min(n, sizeof(buf)); if (!get(buf, k)) return false; n -= k; } return true; }
+    bool skip_header()
+    {
+        if (!m_bam) return true;                                                        // SAM: '@' lines are dropped as records are read
+        char magic[4]; int32 l_text = 0, n_ref = 0;
+        if (!get(magic, 4) || memcmp(magic, "BAM\1", 4) != 0 || !get(&l_text, 4) || !skip(size_t(l_text)) || !get(&n_ref, 4)) return false;
+        for (int32 i = 0; i < n_ref; ++i) { int32 l_name = 0; if (!get(&l_name, 4) || !skip(size_t(l_name) + 4u)) return false; }
+        return true;
+    }
+    bool read_sam_record(uint32& record_flags)
+    {
+        std::vector<uint8> line;
+        for (;;)
+        {
+            line.clear();
+            if (!m_src.get_line(line)) { m_eof = true; return false; }
+            while (!line.empty() && (line.back() == '\r' || line.back() == '\n')) line.pop_back();
+            if (!line.empty() && line[0] != '@') break;
+        }
+        // QNAME FLAG RNAME POS MAPQ CIGAR RNEXT PNEXT TLEN SEQ QUAL ...
+        size_t field[12]; uint32 n = 0; field[n++] = 0;
+        for (size_t i = 0; i < line.size() && n < 12u; ++i) if (line[i] == '\t') field[n++] = i + 1u;
+        if (n < 11u) { m_ok = false; fprintf(stderr, "SAM file: a record with %u fields\n", n); return false; }
+        if (n < 12u) field[n] = line.size() + 1u;
+        auto text = [&](const uint32 k) { return std::string(reinterpret_cast<const char*>(line.data()) + field[k], field[k + 1] - 1u - field[k]); };
+        m_name = text(0); record_flags = uint32(strtol(text(1).c_str(), NULL, 0));
+        const std::string seq = text(9), qual = text(10);
+        m_bp.assign(seq.begin(), seq.end());
+        if (qual == "*") m_q.assign(m_bp.size(), uint8(33u)); else m_q.assign(qual.begin(), qual.end());
+        if (m_q.size() != m_bp.size()) { m_ok = false; fprintf(stderr, "SAM file: SEQ and QUAL of \"%s\" differ in length\n", m_name.c_str()); return false; }
+        return true;
+    }
+    bool read_bam_record(uint32& record_flags)
+    {
+        int32 block_size = 0;
+        if (m_src.read(reinterpret_cast<uint8*>(&block_size), 4u) != 4u) { m_eof = true; return false; }
+        struct { int32 refID, pos; uint32 bin_mq_nl, flag_nc; int32 l_seq, next_refID, next_pos, tlen; } h;
+        if (block_size < 32 || !get(&h, 32u)) { m_ok = false; fprintf(stderr, "error processing BAM file (truncated record)\n"); return false; }
+        record_flags = h.flag_nc >> 16;
+        const uint32 l_name = h.bin_mq_nl & 0xFFu, n_cigar = h.flag_nc & 0xFFFFu, l_seq = uint32(h.l_seq);
+        const size_t body = size_t(l_name) + 4u * n_cigar + (l_seq + 1u) / 2u + l_seq;
+        if (body + 32u > size_t(block_size)) { m_ok = false; fprintf(stderr, "error processing BAM file (record sizes)\n"); return false; }
+        std::vector<char> name(l_name + 1u, '\0'); std::vector<uint8> packed((l_seq + 1u) / 2u);
+        m_q.resize(l_seq);
+        if (!get(name.data(), l_name) || !skip(4u * n_cigar) || !get(packed.data(), packed.size()) || !get(m_q.data(), l_seq) || !skip(size_t(block_size) - 32u - body))
+        { m_ok = false; fprintf(stderr, "error processing BAM file (could not fetch a record)\n"); return false; }
+        m_name = name.data();
+        m_bp.resize(l_seq);
+        for (uint32 c = 0; c < l_seq; ++c) m_bp[c] = uint8("=ACMGRSVTWYHKDBN"[(packed[c / 2u] >> ((c & 1u) ? 0u : 4u)) & 15u]);
+        for (uint32 c = 0; c < l_seq; ++c) if (m_q[c] == 0xFFu) m_q[c] = 0u;              // "no quality stored"
+        return true;
+    }
+
+    nvbio::priv::byte_source m_src;
+    bool               m_bam;
+    uint32             m_max_seqs, m_max_len;
+    SequenceEncoding   m_flags;
+    uint32             m_trim3, m_trim5, m_loaded;
+    bool               m_ok, m_eof;
+    std::string        m_name;
+    std::vector<uint8> m_bp, m_q;
+};
+inline bool has_suffix(const char* name, const char* suffix)
+{ const size_t n = strlen(name), k = strlen(suffix); return n >= k && strcmp(name + n - k, suffix) == 0; }
+} // namespace priv
+
+/// open a file of reads: FASTQ / FASTA text (plain or .gz; the record marker decides which), or the reads of a .sam / .bam file
+/// (sequence_priv.cpp:84-220 picks by extension as well).  NULL when the file cannot be opened.  (.txt and .pac inputs are not read here.)
 inline SequenceDataInputStream* open_sequence_file(const char* sequence_file_name, const QualityEncoding qualities = Phred33, const uint32 max_seqs = uint32(-1),
                                                    const uint32 max_sequence_len = uint32(-1), const SequenceEncoding flags = FORWARD, const uint32 trim3 = 0, const uint32 trim5 = 0)
 {
+    if (priv::has_suffix(sequence_file_name, ".sam") || priv::has_suffix(sequence_file_name, ".bam"))
+    {
+        priv::AlignmentSequenceFile* a = new priv::AlignmentSequenceFile(sequence_file_name, priv::has_suffix(sequence_file_name, ".bam"), max_seqs, max_sequence_len, flags, trim3, trim5);
+        if (!a->is_ok()) { delete a; return NULL; }
+        return a;
+    }
     priv::TextSequenceFile* f = new priv::TextSequenceFile(sequence_file_name, qualities, max_seqs, max_sequence_len, flags, trim3, trim5);
     if (!f->is_ok()) { delete f; return NULL; }
     return f;

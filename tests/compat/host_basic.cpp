@@ -102,3 +102,4 @@ extern "C" int load_reads(const char* path, uint32 flags, uint32 qenc, uint32 ma
     info[3] = name_bytes; info[4] = f->is_ok() ? 1u : 0u;
     return int(n);
 }
+// (load_reads above opens .sam / .bam names through the same factory: AlignmentSequenceFile)

@@ -146,3 +146,45 @@ def test_text_sequence_loader_tolerates_line_breaks_and_blank_lines(hb, tmp_path
     bad = tmp_path / "bad.fastq"; bad.write_bytes(b"@x\nACGT\n+\nII\n")
     for recordwise in (0, 1):
         assert _load_reads(hb, bad, 1, recordwise=recordwise)[5][4] == 0          # is_ok() turns false: incomplete read
+
+
+@pytest.mark.parametrize("flags", [1, 2, 1 | 2 | 4 | 8])
+def test_reads_out_of_sam_and_bam_files(hb, tmp_path, flags):
+    """open_sequence_file on a .sam / .bam name (compat AlignmentSequenceFile; sequence_sam.cpp:405-495, sequence_bam.cpp:232-388): header lines
+    and secondary alignments are skipped, a record flagged reverse-complemented is turned back per requested strand, SAM qualities are
+    phred + 33 and BAM qualities plain phred, a missing QUAL reads as phred 0.  The BAM file is the SAM text through nvbio_amd.io.sam_to_bam."""
+    from nvbio_amd import io as nio
+    rng = np.random.default_rng(5 + flags)
+    n = 500
+    recs, lines = [], ["@HD\tVN:1.3", "@SQ\tSN:chr1\tLN:100000", "@PG\tID:x"]
+    for i in range(n):
+        ln = int(rng.integers(1, 120))
+        seq = bytes(rng.choice(np.frombuffer(b"ACGTN", np.uint8), ln, p=[0.24, 0.24, 0.24, 0.24, 0.04]))
+        star = rng.random() < 0.05
+        qual = b"*" if star else bytes((33 + rng.integers(0, 41, ln)).astype(np.uint8))
+        fl = int(rng.choice([0, 16, 4, 256, 256 | 16, 1 | 64, 1 | 128 | 16]))
+        lines.append("r%d\t%d\tchr1\t%d\t30\t%dM\t*\t0\t0\t%s\t%s\tNM:i:0" % (i, fl, 1 + int(rng.integers(0, 90000)), ln, seq.decode(), qual.decode()))
+        if not fl & 256:
+            recs.append((("r%d" % i).encode(), seq, np.zeros(ln, np.uint8) if star else np.frombuffer(qual, np.uint8) - 33, bool(fl & 16)))
+    sam = tmp_path / "reads.sam"
+    sam.write_text("\n".join(lines) + "\n")
+    bam = tmp_path / "reads.bam"
+    nio.sam_to_bam(sam.read_text(), str(bam))
+    code = np.full(256, 4, np.uint8)
+    for k, c in enumerate(b"ACGT"):
+        code[c] = k; code[c + 32] = k
+    names, syms, quals, lens = [], [], [], []
+    for name, seq, q, rc in recs:
+        s = code[np.frombuffer(seq, np.uint8)]
+        comp = np.where(s < 4, 3 - s, 4).astype(np.uint8)
+        # (requested strand) -> what is stored for a forward record / for a reverse-complemented one
+        for flag, fwd, rev in ((1, (s, q), (comp[::-1], q[::-1])), (2, (s[::-1], q[::-1]), (comp, q)), (4, (comp, q), (s[::-1], q[::-1])), (8, (comp[::-1], q[::-1]), (s, q))):
+            if flags & flag:
+                a, b = rev if rc else fwd
+                names.append(name); syms.append(a); quals.append(b); lens.append(len(a))
+    for path in (sam, bam):
+        for batch in (1 << 20, 97):
+            got_n, index, gs, gq, gnames, info = _load_reads(hb, path, flags, batch=batch)
+            assert got_n == len(lens) and (np.diff(index.astype(np.int64)) == np.array(lens)).all()
+            assert (gs == np.concatenate(syms)).all() and (gq == np.concatenate(quals)).all()
+            assert gnames == names and info[4] == 1
