@@ -830,12 +830,52 @@ private:
     std::string        m_name;
     std::vector<uint8> m_bp, m_q;
 };
+/// one read per line, no names, every base with the best quality character '~' (sequence_txt.cpp:49-190); empty lines contribute nothing
+struct TxtSequenceFile : public SequenceDataInputStream
+{
+    TxtSequenceFile(const char* name, const QualityEncoding qualities, const uint32 max_seqs, const uint32 max_sequence_len, const SequenceEncoding flags, const uint32 trim3, const uint32 trim5)
+        : m_src(name, 1u << 16), m_qualities(qualities), m_max_seqs(max_seqs), m_max_len(max_sequence_len), m_flags(flags), m_trim3(trim3), m_trim5(trim5), m_loaded(0), m_eof(false) {}
+    bool is_ok() { return m_src.valid(); }
+    bool rewind() { m_src.rewind(); m_loaded = 0; m_eof = false; return true; }
+    int next(SequenceDataEncoder* encoder, const uint32 batch_size, const uint32 batch_bps = uint32(-1))
+    {
+        const uint32 want = std::min(m_max_seqs - m_loaded, batch_size);
+        if (!is_ok() || want == 0u) return 0;
+        encoder->begin_batch();
+        const SequenceDataInfo* info = encoder->info();
+        typedef SequenceDataEncoder E;
+        while (info->size() < want && info->bps() < batch_bps && !m_eof)
+        {
+            m_bp.clear();
+            if (!m_src.get_line(m_bp)) { m_eof = true; break; }
+            while (!m_bp.empty() && m_bp.back() == '\r') m_bp.pop_back();
+            if (m_bp.empty()) continue;
+            if (m_q.size() < m_bp.size()) m_q.resize(m_bp.size(), uint8('~'));
+            const uint32 len = uint32(m_bp.size());
+            if (m_flags & FORWARD)            encoder->push_back(len, "", m_bp.data(), m_q.data(), m_qualities, m_max_len, m_trim3, m_trim5, E::NO_OP);
+            if (m_flags & REVERSE)            encoder->push_back(len, "", m_bp.data(), m_q.data(), m_qualities, m_max_len, m_trim3, m_trim5, E::REVERSE_OP);
+            if (m_flags & FORWARD_COMPLEMENT) encoder->push_back(len, "", m_bp.data(), m_q.data(), m_qualities, m_max_len, m_trim3, m_trim5, E::COMPLEMENT_OP);
+            if (m_flags & REVERSE_COMPLEMENT) encoder->push_back(len, "", m_bp.data(), m_q.data(), m_qualities, m_max_len, m_trim3, m_trim5, E::REVERSE_COMPLEMENT_OP);
+        }
+        m_loaded += info->size();
+        encoder->end_batch();
+        return int(info->size());
+    }
+private:
+    nvbio::priv::byte_source m_src;
+    QualityEncoding    m_qualities;
+    uint32             m_max_seqs, m_max_len;
+    SequenceEncoding   m_flags;
+    uint32             m_trim3, m_trim5, m_loaded;
+    bool               m_eof;
+    std::vector<uint8> m_bp, m_q;
+};
 inline bool has_suffix(const char* name, const char* suffix)
 { const size_t n = strlen(name), k = strlen(suffix); return n >= k && strcmp(name + n - k, suffix) == 0; }
 } // namespace priv
 
 /// open a file of reads: FASTQ / FASTA text (plain or .gz; the record marker decides which), or the reads of a .sam / .bam file
-/// (sequence_priv.cpp:84-220 picks by extension as well).  NULL when the file cannot be opened.  (.txt and .pac inputs are not read here.)
+/// (sequence_priv.cpp:84-220 picks by extension as well), or one read per line of a .txt file.  NULL when the file cannot be opened.
 inline SequenceDataInputStream* open_sequence_file(const char* sequence_file_name, const QualityEncoding qualities = Phred33, const uint32 max_seqs = uint32(-1),
                                                    const uint32 max_sequence_len = uint32(-1), const SequenceEncoding flags = FORWARD, const uint32 trim3 = 0, const uint32 trim5 = 0)
 {
@@ -844,6 +884,12 @@ inline SequenceDataInputStream* open_sequence_file(const char* sequence_file_nam
         priv::AlignmentSequenceFile* a = new priv::AlignmentSequenceFile(sequence_file_name, priv::has_suffix(sequence_file_name, ".bam"), max_seqs, max_sequence_len, flags, trim3, trim5);
         if (!a->is_ok()) { delete a; return NULL; }
         return a;
+    }
+    if (priv::has_suffix(sequence_file_name, ".txt") || priv::has_suffix(sequence_file_name, ".txt.gz"))
+    {
+        priv::TxtSequenceFile* t = new priv::TxtSequenceFile(sequence_file_name, qualities, max_seqs, max_sequence_len, flags, trim3, trim5);
+        if (!t->is_ok()) { delete t; return NULL; }
+        return t;
     }
     priv::TextSequenceFile* f = new priv::TextSequenceFile(sequence_file_name, qualities, max_seqs, max_sequence_len, flags, trim3, trim5);
     if (!f->is_ok()) { delete f; return NULL; }

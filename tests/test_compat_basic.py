@@ -188,3 +188,21 @@ def test_reads_out_of_sam_and_bam_files(hb, tmp_path, flags):
             assert got_n == len(lens) and (np.diff(index.astype(np.int64)) == np.array(lens)).all()
             assert (gs == np.concatenate(syms)).all() and (gq == np.concatenate(quals)).all()
             assert gnames == names and info[4] == 1
+
+
+def test_reads_out_of_a_txt_file(hb, tmp_path):
+    """one read per line (sequence_txt.cpp): no names, every base with the best quality '~' (phred 93 under Phred33), empty lines skipped; plain or gzip"""
+    import gzip
+    rng = np.random.default_rng(12)
+    reads = [bytes(rng.choice(np.frombuffer(b"ACGTNacgt", np.uint8), int(rng.integers(1, 90)))) for _ in range(300)]
+    text = b"\n".join(r if i % 17 else r + b"\n" for i, r in enumerate(reads)) + b"\n"          # (some blank lines in between)
+    plain = tmp_path / "reads.txt"; plain.write_bytes(text)
+    packed = tmp_path / "reads2.txt.gz"; packed.write_bytes(gzip.compress(text))
+    code = np.full(256, 4, np.uint8)
+    for k, c in enumerate(b"ACGT"):
+        code[c] = k; code[c + 32] = k
+    want = np.concatenate([code[np.frombuffer(r, np.uint8)][::-1] for r in reads])               # io::REVERSE, as nvBowtie loads reads
+    for path in (plain, packed):
+        got_n, index, gs, gq, gnames, info = _load_reads(hb, path, 2, batch=64)
+        assert got_n == len(reads) and (np.diff(index.astype(np.int64)) == np.array([len(r) for r in reads])).all()
+        assert (gs == want).all() and (gq == 93).all() and gnames == [b""] * len(reads)
