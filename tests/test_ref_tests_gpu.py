@@ -345,8 +345,8 @@ def test_own_drivers_equal_reference_nvbowtie_under_its_options(case, cuda):
 def test_own_driver_equals_reference_nvbowtie_above_half_a_batch(cuda):
     """More than BATCH_SIZE / 2 reads in flight (and, with this seed, reads with an insertion over the first bases of the genome: their
     seed hits locate below zero, `SA position - offset in the read` wraps, and nvBowtie loads a scoring window ~1 GiB past the reference
-    stream -- io::SequenceDataDevice covers every 32-bit coordinate for that, compat/nvbio/io/sequence/sequence.h: coordinate_cover).
-    More than BATCH_SIZE / 2 reads in flight: nvBowtie then selects ONE hit per read and round through its warp-aggregated queue allocation
+    stream -- io::SequenceDataDevice covers every 32-bit coordinate for that, compat/nvbio/io/sequence/sequence.h: coordinate_cover):
+    nvBowtie then selects ONE hit per read and round through its warp-aggregated queue allocation
     (`alloc()`, utils.h:58-71: a ballot, a leader elected by `mask << (32 - warp_tid())` -- a shift by 32 for lane 0, which CUDA defines as 0
     and the drop-in layer's warp_tid() type reproduces --, a broadcast through a per-warp shared slot), on 32-lane virtual warps.  600 000
     reads, end to end; every SAM record equal to the from-scratch driver's."""
