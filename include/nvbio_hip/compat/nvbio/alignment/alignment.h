@@ -134,6 +134,80 @@ template <uint32 BAND_LEN, AlignmentType TYPE, typename A, typename P, typename 
 NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool banded_score(const EditDistanceAligner<TYPE, A>&, const P p, const Q q, const T t, K& sink)
 { return banded_sw_score<BAND_LEN, TYPE>(EditDistanceSWScheme(), p, q, t, sink); }
 
+// ------------------------------------------------------------------ banded, bit-vector edit distance (MyersTag)
+// EditDistanceAligner<TYPE, MyersTag<A>> selects Hyyro's banded form of Myers' bit-vector algorithm (myers_banded_inl.h:236-291 with no
+// pre-loaded pattern symbols): one 32-bit word holds the vertical deltas of the BAND_LEN cells of a column, the band slides one pattern
+// row per text column while the pattern lasts ("diagonal" columns: the tracked cell is the band's lowest), then stays put ("horizontal"
+// columns: the tracked cell is the pattern's last row).  What distinguishes its results from the banded DP above, all kept:
+//   * the threshold is taken as int16 (a -2^30 "no threshold" becomes 0: only exact occurrences report);
+//   * scores are reported only from the horizontal columns, in text order (a BestSink keeps the last of equal scores);
+//   * a text as long as the pattern reads delta bit BAND_LEN of the horizontal word in its single horizontal column.
+template <uint32 ALPHABET_SIZE>
+struct symbol_masks
+{
+    uint32 eq[ALPHABET_SIZE];
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE symbol_masks() { for (uint32 c = 0; c < ALPHABET_SIZE; ++c) eq[c] = 0u; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static uint32 slot(const uint8 c) { return (ALPHABET_SIZE & (ALPHABET_SIZE - 1u)) ? uint32(c) : uint32(c) & (ALPHABET_SIZE - 1u); }
+    /// the band moves down one pattern row: every mask loses its top row, `c` enters at the bottom (bit `bit`)
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void slide() { for (uint32 c = 0; c < ALPHABET_SIZE; ++c) eq[c] >>= 1; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void enter(const uint8 c, const uint32 bit)
+    { const uint32 k = slot(c); for (uint32 a = 0; a < ALPHABET_SIZE; ++a) eq[a] |= (a == k) ? bit : 0u; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 of(const uint8 c) const
+    { const uint32 k = slot(c); uint32 r = 0u; for (uint32 a = 0; a < ALPHABET_SIZE; ++a) r = (a == k) ? eq[a] : r; return r; }
+};
+/// one text column of the band: vertical deltas (plus / minus) in, out one row lower; returns the diagonal-zero and horizontal words
+struct band_deltas
+{
+    uint32 plus, minus;
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE band_deltas() : plus(0xFFFFFFFFu), minus(0u) {}
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void column(const uint32 eq, uint32& d0, uint32& h_plus, uint32& h_minus)
+    {
+        const uint32 x = eq | minus;
+        d0      = ((plus + (x & plus)) ^ plus) | x;
+        h_minus = plus & d0;
+        h_plus  = minus | ~(plus | d0);
+        const uint32 up = d0 >> 1;
+        minus = up & h_plus;
+        plus  = h_minus | ~(up | h_plus);
+    }
+};
+template <uint32 BAND_LEN, AlignmentType TYPE, uint32 ALPHABET_SIZE, typename pattern_string, typename text_string, typename sink_type>
+NVBIO_HOST_DEVICE inline
+bool banded_bitvector_score(const pattern_string pattern, const text_string text, const int16 min_score, sink_type& sink)
+{
+    const uint32 M = pattern.length(), N = text.length();
+    if (N < M) return false;
+    symbol_masks<ALPHABET_SIZE> masks;
+    band_deltas v;
+    int32 score = 0;
+    const uint32 bottom = 1u << (BAND_LEN - 1u);
+    const uint32 n_diag = nvbio::min(N - 1u, M);
+    uint32 d0, hp, hn;
+    for (uint32 i = 0; i < n_diag; ++i)
+    {
+        masks.slide(); masks.enter(uint8(pattern[i]), bottom);
+        v.column(masks.of(uint8(text[i])), d0, hp, hn);
+        score -= (d0 & bottom) ? 0 : 1;
+    }
+    int32 row = int32(BAND_LEN - 1u + M - n_diag);            // bit of the pattern's last row in the column about to be computed
+    for (uint32 i = n_diag; i < N && row >= 0; ++i, --row)
+    {
+        masks.slide();
+        v.column(masks.of(uint8(text[i])), d0, hp, hn);
+        score -= int32((hp >> row) & 1u) - int32((hn >> row) & 1u);
+        if (TYPE == SEMI_GLOBAL && score >= min_score) sink.report(score, make_uint2(i + 1u, M));
+    }
+    if (TYPE == GLOBAL && score >= min_score) sink.report(score, make_uint2(N, M));
+    return true;
+}
+template <uint32 BAND_LEN, AlignmentType TYPE, uint32 A, typename P, typename Q, typename T, typename K>
+NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool banded_score(const EditDistanceAligner<TYPE, MyersTag<A> >&, const P p, const Q, const T t, const int32 min_score, K& sink)
+{ return banded_bitvector_score<BAND_LEN, TYPE, A>(p, t, int16(min_score), sink); }
+/// every other aligner: the whole-pattern banded DP has no use for the threshold
+template <uint32 BAND_LEN, typename aligner_type, typename P, typename Q, typename T, typename K>
+NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool banded_score(const aligner_type& al, const P p, const Q q, const T t, const int32, K& sink)
+{ return banded_score<BAND_LEN>(al, p, q, t, sink); }
+
 // ------------------------------------------------------------------ full matrix
 // One template covers the four sweeps.  `outer` is the string walked in blocks of BL symbols (the text for
 // TextBlockingTag, the pattern for PatternBlockingTag), `inner` the other one; the boundary between consecutive blocks
@@ -453,14 +527,13 @@ template <AlignmentType T, typename S> struct column_entries< HammingDistanceAli
 
 // ---------------------------------------------------------------------------------------- public per-thread functions
 /// banded_alignment_score<BAND_LEN>(aligner, pattern, quals, text, min_score, sink)   (alignment.h:257-272).
-/// min_score only matters to the reference's windowed (staged) form; a whole-pattern banded score ignores it.
+/// min_score only matters to the reference's windowed (staged) form and to the bit-vector edit distance; the whole-pattern banded DP ignores it.
 template <uint32 BAND_LEN, typename aligner_type, typename pattern_string, typename qual_string, typename text_string, typename sink_type>
 NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
 bool banded_alignment_score(const aligner_type aligner, const pattern_string pattern, const qual_string quals, const text_string text,
                             const int32 min_score, sink_type& sink)
 {
-    (void)min_score;
-    return priv::banded_score<BAND_LEN>(aligner, pattern, quals, text, sink);
+    return priv::banded_score<BAND_LEN>(aligner, pattern, quals, text, min_score, sink);
 }
 /// ... without qualities (alignment.h:284-298)
 template <uint32 BAND_LEN, typename aligner_type, typename pattern_string, typename text_string, typename sink_type>

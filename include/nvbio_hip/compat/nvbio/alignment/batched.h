@@ -194,6 +194,9 @@ template <AlignmentType T, typename G> struct tuned_aligner< SmithWatermanAligne
 template <AlignmentType T, typename G> struct tuned_aligner< EditDistanceAligner<T, G> > {
     static const bool ok = true; static const bool QUAL = false; static const int32 KIND = NVBIO_HIP_SW_ALIGNER; static const bool TEXT_BLOCKING = same_type<G, TextBlockingTag>::pred;
     static void scheme4(const EditDistanceAligner<T, G>&, int32* v) { v[0] = 0; v[1] = -1; v[2] = -1; v[3] = -1; } };
+/// the bit-vector edit distance is its own algorithm with its own reporting rules (alignment.h: banded_bitvector_score), not the DP the
+/// tuned kernels run: such streams take the generic lane
+template <AlignmentType T, uint32 N> struct tuned_aligner< EditDistanceAligner<T, MyersTag<N> > > { static const bool ok = false; static const bool QUAL = false; };
 /// a Gotoh aligner over a scheme of nvBowtie's concept: its 256 mismatch penalties are tabulated on the host
 template <AlignmentType T, typename S, typename G> struct tuned_aligner< GotohAligner<T, S, G> > {
     static const bool ok = quality_scheme<S>::value; static const bool QUAL = true; static const int32 KIND = NVBIO_HIP_GOTOH_ALIGNER; static const bool TEXT_BLOCKING = same_type<G, TextBlockingTag>::pred;

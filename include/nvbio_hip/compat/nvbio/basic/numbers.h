@@ -171,6 +171,15 @@ struct composition_functor
 };
 template <typename Functor2, typename Functor1>
 inline composition_functor<Functor2, Functor1> make_composition_functor(const Functor2 fun2, const Functor1 fun1) { return composition_functor<Functor2, Functor1>(fun2, fun1); }
+/// v -> component c of the vector v (x, y, z, w = 0 .. 3)
+template <typename T>
+struct component_functor
+{
+    typedef T argument_type; typedef typename priv::vec_comp<T>::type result_type;
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE component_functor(const uint32 c) : m_c(c) {}
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE result_type operator()(const argument_type op) const { return priv::vec_comp<T>::get(op, m_c); }
+    uint32 m_c;
+};
 /// a binary functor with its first / second argument fixed
 template <typename Functor>
 struct bind_first_functor

@@ -20,6 +20,7 @@
 #include "../basic/packed_view.h"
 #include "../basic/deinterleaved_iterator.h"
 #include "../basic/vector.h"
+#include "../basic/cuda/primitives.h"
 #include "../strings/string_set.h"
 #include <stdexcept>
 #include <string>

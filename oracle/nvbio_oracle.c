@@ -952,6 +952,77 @@ ORACLE_API void oracle_batch_sw_score(
     }
 }
 
+/* ------------------------------------------------------------------------ */
+/* Banded bit-vector edit distance: EditDistanceAligner<TYPE, MyersTag<A>>      */
+/* banded_myers<BAND_WIDTH, C = 0, TYPE, ALPHABET_SIZE> (alignment/myers/myers_banded_inl.h:236-291, reached through */
+/* banded_alignment_score :306-329), with MyersBitVectors<A> :44-196, diagonal_column :198-212, horizontal_column :214-228. */
+/* The threshold parameter is an int16 (:243): the caller's int32 is narrowed on the way in, and the sink's score type */
+/* narrows the reported distance (BestSink<int16> in examples/fmmap/fmmap.cu:306; sink_bits says which).  A = 5 leaves the */
+/* fifth vector uninitialised in the reference (:160-165 clears four); texts of the callers here hold symbols 0..3, so it is */
+/* never read -- zero here.                                                                                                  */
+/* ------------------------------------------------------------------------ */
+static inline uint32_t myers_slot(uint32_t A, uint32_t c) { return A == 4 ? (c & 3u) : A == 2 ? (c & 1u) : c; }
+static int banded_myers_x(uint32_t BW, int type, uint32_t A,
+    const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, uint64_t pat_begin, uint32_t pattern_len,
+    const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, uint64_t txt_begin, uint32_t text_len,
+    int32_t min_score32, best_sink_t* sink)
+{
+    const int16_t min_score = (int16_t)min_score32;                        /* :243 */
+    if (text_len < pattern_len) return 0;                                  /* :250-251 */
+    uint32_t B[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    uint32_t VP = 0xFFFFFFFFu, VN = 0u;                                    /* :255-256 */
+    int dist = 0;                                                          /* :258, C = 0 */
+    const uint32_t last = (text_len - 1u < pattern_len) ? text_len - 1u : pattern_len;     /* :266 */
+    for (uint32_t i = 0; i < last; ++i)                                    /* phase 1 (diagonal) :267-274 */
+    {
+        for (uint32_t c = 0; c < A; ++c) B[c] >>= 1;
+        B[myers_slot(A, ps_get(pat_w, pat_bits, pat_be, pat_begin + i))] |= 1u << (BW - 1);
+        const uint32_t Bc = B[myers_slot(A, ps_get(txt_w, txt_bits, txt_be, txt_begin + i))];
+        uint32_t X = Bc | VN;                                              /* diagonal_column :200-211 */
+        const uint32_t D0 = ((VP + (X & VP)) ^ VP) | X;
+        const uint32_t HN = VP & D0;
+        const uint32_t HP = VN | ~(VP | D0);
+        X = D0 >> 1; VN = X & HP; VP = HN | ~(X | HP);
+        dist -= 1 - (int)((D0 >> (BW - 1)) & 1u);
+    }
+    int s = (int)(BW - 1u + pattern_len - last);                           /* :277, C = 0 */
+    for (uint32_t i = last; i < text_len && s >= 0; ++i)                   /* phase 2 (horizontal) :278-289 */
+    {
+        for (uint32_t c = 0; c < A; ++c) B[c] >>= 1;
+        const uint32_t Bc = B[myers_slot(A, ps_get(txt_w, txt_bits, txt_be, txt_begin + i))];
+        uint32_t X = Bc | VN;                                              /* horizontal_column :216-227 */
+        const uint32_t D0 = ((VP + (X & VP)) ^ VP) | X;
+        const uint32_t HN = VP & D0;
+        const uint32_t HP = VN | ~(VP | D0);
+        X = D0 >> 1; VN = X & HP; VP = HN | ~(X | HP);
+        dist -= (int)((HP >> s) & 1u) - (int)((HN >> s) & 1u);
+        if (type == ALN_SEMI_GLOBAL && dist >= min_score) sink_report(sink, dist, i + 1, pattern_len);
+        --s;
+    }
+    if (type == ALN_GLOBAL && dist >= min_score) sink_report(sink, dist, text_len, pattern_len);
+    return 1;
+}
+/* BatchedBandedAlignmentScore over the bit-vector edit-distance aligner; sink_bits = 16 narrows the sink as BestSink<int16> does
+ * (initial score -32768, sink_inl.h:38-46 over Field_traits<int16>::min()) */
+ORACLE_API void oracle_batch_banded_myers_score(
+    uint32_t band, int type, uint32_t alphabet, int32_t min_score, uint32_t sink_bits,
+    const uint32_t* pat_w, uint32_t pat_bits, uint32_t pat_be, const uint64_t* pat_begin, const uint32_t* pat_len,
+    const uint32_t* txt_w, uint32_t txt_bits, uint32_t txt_be, const uint64_t* txt_begin, const uint32_t* txt_len,
+    uint32_t n, int32_t* out_score, uint32_t* out_sink, int n_threads)
+{
+#if defined(_OPENMP)
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+    #pragma omp parallel for schedule(dynamic, 16)
+#endif
+    for (int64_t i = 0; i < (int64_t)n; ++i)
+    {
+        best_sink_t s; sink_init(&s);
+        if (sink_bits == 16) s.score = -32768;
+        banded_myers_x(band, type, alphabet, pat_w, pat_bits, pat_be, pat_begin[i], pat_len[i], txt_w, txt_bits, txt_be, txt_begin[i], txt_len[i], min_score, &s);
+        out_score[i] = s.score; out_sink[2 * i] = s.sink_x; out_sink[2 * i + 1] = s.sink_y;
+    }
+}
+
 /* ref_sw for the Gotoh aligner: nvbio-test/alignment_test_utils.h:536-624, the independent
  * full-matrix checker the reference's alignment test compares alignment_score() with
  * (alignment_test.cu:247-265).  i runs over the text, j over the pattern. */

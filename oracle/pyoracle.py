@@ -378,6 +378,20 @@ def batch_sw_score(band, aln_type, scheme, patterns, texts, n_threads=0):
     return score, sink
 
 
+def batch_banded_myers_score(band, aln_type, alphabet, patterns, texts, min_score=-(1 << 30), sink_bits=32, n_threads=0):
+    """EditDistanceAligner<TYPE, MyersTag<alphabet>> through BatchedBandedAlignmentScore<band>: the banded bit-vector edit distance
+    (myers_banded_inl.h:236-291).  min_score is narrowed to int16 as the reference's signature does; sink_bits = 16 = BestSink<int16>."""
+    n = len(patterns)
+    score = np.empty(n, dtype=np.int32)
+    sink = np.empty((n, 2), dtype=np.uint32)
+    lib().oracle_batch_banded_myers_score(
+        C.c_uint32(band), C.c_int(aln_type), C.c_uint32(alphabet), C.c_int32(min_score), C.c_uint32(sink_bits),
+        _p(patterns.words), C.c_uint32(patterns.bits), C.c_uint32(patterns.big_endian), _p(patterns.begin), _p(patterns.length),
+        _p(texts.words), C.c_uint32(texts.bits), C.c_uint32(texts.big_endian), _p(texts.begin), _p(texts.length),
+        C.c_uint32(n), _p(score), _p(sink), C.c_int(n_threads))
+    return score, sink
+
+
 def batch_gotoh_score_qual(algorithm, aln_type, scheme5, mm_lut, quals, patterns, texts, min_score=None, n_threads=0):
     """Full-matrix Gotoh score with nvBowtie's quality-aware scheme: scheme5 = (match, pattern_gap_open, pattern_gap_ext,
     text_gap_open, text_gap_ext); algorithm 0 = pattern blocking, 1 = text blocking -> (score, sink, ok)."""

@@ -103,3 +103,52 @@ extern "C" int load_reads(const char* path, uint32 flags, uint32 qenc, uint32 ma
     return int(n);
 }
 // (load_reads above opens .sam / .bam names through the same factory: AlignmentSequenceFile)
+
+// ---- the bit-vector banded edit distance (alignment.h: EditDistanceAligner<TYPE, MyersTag<A>>) and infix sets (strings/infix.h) ----
+#include <nvbio/alignment/alignment.h>
+#include <nvbio/strings/infix.h>
+#include <nvbio/basic/packedstream.h>
+/// n jobs: pattern i = symbols [pb[i], pb[i] + pl[i]) of the byte string `pat`, text i likewise; band 31 / 15, alphabet 5 / 4.  A job is run
+/// through an InfixSet over each string (the form examples/fmmap/fmmap.cu:337-345 hands its strings over in)
+template <uint32 BAND, aln::AlignmentType TYPE, uint32 A, typename sink_t>
+static void myers_jobs(const uint8* pat, const uint8* txt, const uint2* pc, const uint2* tc, uint32 n, int32 min_score, int32* score, uint32* sink)
+{
+    const InfixSet<const uint8*, const uint2*> patterns(n, pat, pc), texts(n, txt, tc);
+    for (uint32 i = 0; i < n; ++i)
+    {
+        sink_t s;
+        aln::banded_alignment_score<BAND>(aln::make_edit_distance_aligner<TYPE, aln::MyersTag<A> >(), patterns[i], texts[i], min_score, s);
+        score[i] = s.score; sink[2 * i] = s.sink.x; sink[2 * i + 1] = s.sink.y;
+    }
+}
+extern "C" int banded_myers(uint32 band, int type, uint32 alphabet, int sink_bits, const uint8* pat, const uint8* txt, const uint32* pc, const uint32* tc, uint32 n,
+                            int32 min_score, int32* score, uint32* sink)
+{
+    const uint2* p2 = reinterpret_cast<const uint2*>(pc); const uint2* t2 = reinterpret_cast<const uint2*>(tc);
+#define MYERS_CASE(B, T, AL, S) if (band == B && type == int(T) && alphabet == AL && sink_bits == int(8 * sizeof(S::score_type))) { myers_jobs<B, T, AL, S>(pat, txt, p2, t2, n, min_score, score, sink); return 0; }
+    MYERS_CASE(31u, aln::SEMI_GLOBAL, 5u, aln::BestSink<int16>)
+    MYERS_CASE(31u, aln::SEMI_GLOBAL, 5u, aln::BestSink<int32>)
+    MYERS_CASE(31u, aln::GLOBAL, 5u, aln::BestSink<int32>)
+    MYERS_CASE(15u, aln::SEMI_GLOBAL, 4u, aln::BestSink<int32>)
+    MYERS_CASE(15u, aln::GLOBAL, 4u, aln::BestSink<int32>)
+    MYERS_CASE(7u, aln::SEMI_GLOBAL, 2u, aln::BestSink<int32>)
+#undef MYERS_CASE
+    return -1;
+}
+/// infixes of a string set: out[k] = symbols of infix k, concatenated; returns the total
+extern "C" uint32 read_set_infixes(const uint32* words, const uint32* offsets, uint32 n_strings, const uint32* coords4, uint32 n_infixes, uint8* out, uint32* ids)
+{
+    typedef PackedStream<const uint32*, uint8, 4, true> stream_type;
+    typedef ConcatenatedStringSet<stream_type, const uint32*> set_type;
+    const set_type set(n_strings, stream_type(words), offsets);
+    const InfixSet<set_type, const string_set_infix_coord_type*> infixes(n_infixes, set, reinterpret_cast<const string_set_infix_coord_type*>(coords4));
+    uint32 total = 0;
+    for (uint32 k = 0; k < infixes.size(); ++k)
+    {
+        const InfixSet<set_type, const string_set_infix_coord_type*>::string_type s = infixes[k];
+        ids[k] = string_id(s);
+        if (length(s) != infix_end(s) - infix_begin(s) || s.begin()[0] != s[0]) return uint32(-1);
+        for (uint32 i = 0; i < length(s); ++i) out[total++] = s[i];
+    }
+    return total;
+}

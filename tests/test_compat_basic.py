@@ -206,3 +206,64 @@ def test_reads_out_of_a_txt_file(hb, tmp_path):
         got_n, index, gs, gq, gnames, info = _load_reads(hb, path, 2, batch=64)
         assert got_n == len(reads) and (np.diff(index.astype(np.int64)) == np.array([len(r) for r in reads])).all()
         assert (gs == want).all() and (gq == 93).all() and gnames == [b""] * len(reads)
+
+
+MYERS_CASES = [(31, O.SEMI_GLOBAL, 5, 16, 0), (31, O.SEMI_GLOBAL, 5, 16, -(1 << 30)), (31, O.SEMI_GLOBAL, 5, 32, -12), (31, O.GLOBAL, 5, 32, -40),
+               (15, O.SEMI_GLOBAL, 4, 32, -9), (15, O.GLOBAL, 4, 32, -100), (7, O.SEMI_GLOBAL, 2, 32, -6)]
+
+
+@pytest.mark.parametrize("band,aln_type,alphabet,sink_bits,min_score", MYERS_CASES)
+def test_banded_bitvector_edit_distance(hb, band, aln_type, alphabet, sink_bits, min_score):
+    """EditDistanceAligner<TYPE, MyersTag<A>> under banded_alignment_score: the drop-in layer's bit-vector band against the oracle's restatement
+    of myers_banded_inl.h:236-291 -- distances, sink positions, the int16 threshold (a -2^30 'none' becomes 0), texts no longer than the
+    pattern, texts shorter (declined), patterns shorter than the band.  Strings are read through InfixSets over one byte string."""
+    rng = np.random.default_rng(band * 131 + alphabet)
+    pats, txts = [], []
+    for k in range(3000):
+        pl = int(rng.integers(1, 90))
+        tl = pl + int(rng.integers(-2, band + 6))
+        hi = 2 if alphabet == 2 else 4
+        t = rng.integers(0, hi, max(tl, 0)).astype(np.uint8)
+        off = int(rng.integers(0, max(1, min(band, tl - pl + 1)))) if tl >= pl else 0
+        q = list(t[off:off + pl]) if tl >= pl else list(rng.integers(0, hi, pl))
+        q += list(rng.integers(0, hi, pl - len(q)))
+        for _ in range(int(rng.integers(0, 6))):
+            at, r = int(rng.integers(0, len(q))), rng.random()
+            if r < 0.5:
+                q[at] = (q[at] + 1) % hi
+            elif r < 0.75 and len(q) > 1:
+                del q[at]
+            else:
+                q.insert(at, int(rng.integers(0, hi)))
+        q = np.array(q, dtype=np.uint8)
+        if alphabet == 5 and rng.random() < 0.2:
+            q[int(rng.integers(0, q.size))] = 4                    # an N in the read
+        pats.append(q); txts.append(t)
+    ps, ts = O.StringSet.from_lists(pats, 8, False), O.StringSet.from_lists(txts, 8, False)
+    es, ek = O.batch_banded_myers_score(band, aln_type, alphabet, ps, ts, min_score=min_score, sink_bits=sink_bits)
+    pat, txt = np.concatenate(pats), np.concatenate(txts + [np.zeros(1, np.uint8)])
+    pc = np.stack([ps.begin, ps.begin + ps.length], 1).astype(np.uint32)
+    tc = np.stack([ts.begin, ts.begin + ts.length], 1).astype(np.uint32)
+    score, sink = np.zeros(len(pats), np.int32), np.zeros((len(pats), 2), np.uint32)
+    assert hb.banded_myers(C.c_uint32(band), C.c_int(aln_type), C.c_uint32(alphabet), C.c_int(sink_bits), p(pat), p(txt), p(pc), p(tc), C.c_uint32(len(pats)),
+                           C.c_int32(min_score), p(score), p(sink)) == 0
+    assert (score == es).all() and (sink == ek).all()
+    reported = (ek[:, 0] != 0xFFFFFFFF)
+    assert reported.any() and (~reported).any()
+    if min_score <= -(1 << 30):                                      # the threshold the batch functions pass: exact occurrences only
+        assert (es[reported] == 0).all()
+
+
+def test_infix_set_over_a_packed_string_set(hb):
+    rng = np.random.default_rng(77)
+    reads = [rng.integers(0, 5, int(rng.integers(30, 120))).astype(np.uint8) for _ in range(200)]
+    hs = O.StringSet.from_lists(reads, 4, True)
+    offsets = np.concatenate([hs.begin, [hs.begin[-1] + hs.length[-1]]]).astype(np.uint32)
+    coords, want = [], []
+    for k in range(1000):
+        r = int(rng.integers(0, len(reads))); b = int(rng.integers(0, len(reads[r]) - 22)); e = b + int(rng.integers(1, 23))
+        coords.append((r, b, e, 0)); want.append(reads[r][b:e])
+    coords = np.array(coords, dtype=np.uint32)
+    out, ids = np.zeros(sum(len(w) for w in want), np.uint8), np.zeros(len(want), np.uint32)
+    n = hb.read_set_infixes(p(hs.words), p(offsets), C.c_uint32(len(reads)), p(coords), C.c_uint32(len(want)), p(out), p(ids))
+    assert n == out.size and (out == np.concatenate(want)).all() and (ids == coords[:, 0]).all()

@@ -7,6 +7,7 @@ tools/ref_bind_check.py --install-ref-tests -> oracle/_ref/ref_*_test; built in 
                        ref_banded_sw) and CIGAR literals, then every Batched*AlignmentScore scheduler and the per-thread kernel
   ref_sw_benchmark     sw-benchmark/sw-benchmark.cu, whole TU: the reference's headline benchmark program on synthetic FASTQ / FASTA input
   ref_nvBowtie         the whole nvBowtie application (29 TUs as they lie + contrib/crc), FASTQ + index files -> SAM
+  ref_fmmap            examples/fmmap/fmmap.cu, whole TU: FM-index filter over infix seed sets + banded bit-vector edit distance, against the oracle
   ref_fmindex_test     nvbio-test/fmindex_test.cu:56-717: SA -> BWT -> occurrence table -> SSA (host, and built on the device from the
                        FM-index alone), match + locate on host and in its device kernel, 32- and 64-bit, separate and interleaved
 
@@ -95,6 +96,74 @@ def _write_reference(tmp_path, rng, n_genome, names_and_lengths):
     nio.write_bns(prefix, [n for n, _ in names_and_lengths], [l for _, l in names_and_lengths])
     return prefix, text
 
+
+
+def test_reference_fmmap_runs_and_matches_the_oracle(tmp_path):
+    """examples/fmmap/fmmap.cu, whole TU as it lies (SURVEY 8(b)'s caller list): reads in both strands -> seeds every 10 bp as an InfixSet over the
+    packed read set -> FMIndexFilterDevice::rank / locate -> diagonals -> windows -> batch_banded_alignment_score<31> with the bit-vector
+    edit-distance aligner into BestSink<int16> -> best per read.  Its own 'aligned % reads' line must equal the same pipeline run through the CPU
+    oracle (FM-index match + locate, banded bit-vector distance with the reference's int16 threshold: the batch function's 'no threshold' -2^30
+    narrows to 0, so only windows holding the read exactly report a score -- myers_banded_inl.h:243, batched_inl.h:946)."""
+    import re
+    import numpy as np
+    from oracle import pyoracle as O
+    exe = os.path.join(REF, "ref_fmmap")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_fmmap not built (needs /root/reference in the build container)")
+    rng = np.random.default_rng(41)
+    n_genome, n, L = 200_000, 4000, 100
+    prefix, text = _write_reference(tmp_path, rng, n_genome, [("chrA", 120_000), ("chrB", 80_000)])
+    pos = rng.integers(300, n_genome - L - 300, n)
+    reads = []
+    for i, q in enumerate(pos):
+        r = text[q:q + L].copy()
+        if i % 3:                                                  # a third of the reads are exact copies
+            m = rng.random(L) < 0.01; r[m] = (r[m] + 1) & 3
+        if i % 7 == 0:
+            r[int(rng.integers(0, L))] = 4                         # an N
+        reads.append((3 - r)[::-1] if i % 2 and r.max() < 4 else r)
+    fastq = str(tmp_path / "reads.fastq")
+    with open(fastq, "w") as f:
+        for i, r in enumerate(reads):
+            f.write("@read%d\n%s\n+\n%s\n" % (i, "".join("ACGTN"[c] for c in r), "I" * L))
+    r = subprocess.run([exe, prefix, fastq], capture_output=True, text=True, timeout=900)
+    out = (r.stdout + r.stderr).replace("\r", "\n")
+    assert r.returncode == 0, out[-2000:]
+    m = re.findall(r"aligned\s+([0-9.]+) % reads", out)
+    assert m, out[-2000:]
+    occ = re.findall(r"occurrences\s+:\s+([0-9.]+) B", out)
+    # ---- the same pipeline on the CPU oracle
+    host = O.FMIndex(text)
+    both = []
+    for r_ in reads:                                               # io::FORWARD | io::REVERSE_COMPLEMENT: strings 2i and 2i + 1 (N stays N)
+        both.append(r_); both.append(np.where(r_ < 4, 3 - r_, 4)[::-1].astype(np.uint8))
+    seeds, owner, offs = [], [], []
+    for sid, s in enumerate(both):
+        for b in range(0, L - 22 + 1, 10):
+            seeds.append(s[b:b + 22]); owner.append(sid); offs.append(b)
+    ranges = host.match(O.StringSet.from_lists(seeds, 4, True))
+    pats, txts, who = [], [], []
+    n_hits = 0
+    for k, (lo, hi) in enumerate(ranges):
+        if lo > hi:
+            continue
+        rows = np.arange(lo, hi + 1, dtype=np.uint32)
+        n_hits += rows.size
+        for tp in host.locate(rows):
+            diag = int(tp) - offs[k]
+            gb = diag - 15 if diag > 15 else 0
+            ge = min(gb + L + 31, n_genome)
+            pats.append(both[owner[k]]); txts.append(text[gb:ge]); who.append(owner[k] // 2)
+    score, _ = O.batch_banded_myers_score(31, O.SEMI_GLOBAL, 5, O.StringSet.from_lists(pats, 4, True), O.StringSet.from_lists(txts, 2, True), sink_bits=16)
+    best = np.full(n, -32768, np.int64)
+    np.maximum.at(best, np.array(who), score)
+    expected = 100.0 * float((best >= -20).sum()) / n
+    assert 20.0 < expected < 60.0
+    assert abs(float(m[-1]) - expected) < 0.006, (m[-1], expected)
+    if occ:
+        assert abs(float(occ[-1]) - n_hits * 1e-9) < 1.1e-3
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    open(os.path.join(ROOT, "gpurun_out", "ref_fmmap.log"), "w").write(out + "\noracle: %.4f %% of %d reads aligned, %d seed hits\n" % (expected, n, n_hits))
 
 def _simulated_run(tmp_path, seed, n, L, indel_rate=0.0):
     """a two-sequence 200 kbp reference on disk and a FASTQ file of n reads of L bases drawn from it: 3 % substitutions, every other read

@@ -494,6 +494,32 @@ void instantiate(const pipeline_type& pipeline, const scheme_type& scheme, const
 }} }} }} // namespaces
 """))
 
+CASES.append(("examples/fmmap/fmmap.cu: Pipeline (FMIndexFilterDevice over io::FMIndexDataDevice::fm_index_type), hit_to_diagonal, extract_seeds -> the filter's tuned route, seeds in place",
+              [("examples/fmmap/fmmap.cu", 87, 149)], r"""
+#include <nvbio/basic/vector.h>
+#include <nvbio/basic/shared_pointer.h>
+#include <nvbio/basic/dna.h>
+#include <nvbio/strings/string_set.h>
+#include <nvbio/strings/infix.h>
+#include <nvbio/strings/seeds.h>
+#include <nvbio/fmindex/filter.h>
+#include <nvbio/io/sequence/sequence.h>
+#include <nvbio/io/fmindex/fmindex.h>
+using namespace nvbio;
+struct Params {{ uint32 seed_len; uint32 seed_intv; uint32 merge_intv; }};
+{0}
+typedef io::SequenceDataAccess<DNA_N>::sequence_string_set_type read_string_set_type;
+typedef InfixSet<read_string_set_type, const string_set_infix_coord_type*> seed_string_set_type;
+static_assert(fmindex::production_layout<Pipeline::fm_index_type>::ok, "io::FMIndexDataDevice's index is the production layout: FMIndexFilterDevice runs the gfx950 kernels on it");
+static_assert(nvbio::priv::packed_view<seed_string_set_type::string_type>::ok && nvbio::priv::packed_view<seed_string_set_type::string_type>::BITS == 4u,
+              "a seed cut out of the packed read set is a window of packed words: ranked in place");
+seed_string_set_type instantiate(const io::SequenceDataDevice& reads, nvbio::vector<device_tag, string_set_infix_coord_type>& coords)
+{{
+    const io::SequenceDataAccess<DNA_N> access(reads);
+    return extract_seeds(access.sequence_string_set(), 22u, 10u, coords);
+}}
+"""))
+
 # ------------------------------------------------------------------------------------------------------------------------------
 # whole translation units of the reference's own test suite: compiled AS THEY LIE (hipcc -x hip <path under /root/reference>),
 # linked against libnvbio_hip.so with a two-line main, and -- where the test is host code -- RUN here.  The only thing added on
@@ -515,6 +541,10 @@ WHOLE.append(dict(name="nvbio-test/fmindex_test.cu:56-717 (everything but the fi
 WHOLE.append(dict(name="sw-benchmark/sw-benchmark.cu, whole TU -- the program BASELINE's headline numbers come from -- compiled as it lies and linked (FASTQ reads + FASTA reference through the drop-in io::open_sequence_file / FASTA_inc_reader, AlignmentStream on the tuned kernels, its own per-thread kernel on the generic lane code); RUN here up to the first device allocation, on the GPU box from oracle/_ref/ to its own GCUPS printout",
                   tu="sw-benchmark/sw-benchmark.cu", install="ref_sw_benchmark", main=None, files="sw", run=["{reads}", "{ref}"], expect="reading reference file \"{ref}\"... done (3000 bps)", may_abort=True))
 
+WHOLE.append(dict(name="examples/fmmap/fmmap.cu, whole TU (+ its util.h in place) -- FMIndexFilterDevice::rank / locate over an InfixSet of seeds cut from the read string-set (strings/infix.h, strings/seeds.h), "
+                       "SparseStringSet windows into batch_banded_alignment_score<31> with the bit-vector edit-distance aligner and BestSink<int16>, cuda::reduce_by_key / cuda::reduce -- compiled as it lies and linked; "
+                       "RUN here through the index and reference loaders, on the GPU box from oracle/_ref/ to its own 'aligned % reads' line",
+                  tu="examples/fmmap/fmmap.cu", install="ref_fmmap", main=None, files="fmmap", run=["{index}", "{reads}"], expect="FMIndexData: loading... done", may_abort=True))
 
 def sw_benchmark_files(tmp):
     """a 3 000-bp FASTA reference and 64 FASTQ reads cut from it, for the host part of the sw-benchmark run"""
@@ -530,6 +560,25 @@ def sw_benchmark_files(tmp):
             f.write("@read%d\n%s\n+\n%s\n" % (i, ref[p:p + 100], "I" * 100))
     return dict(reads=reads_name, ref=ref_name)
 
+
+
+def fmmap_files(tmp):
+    """a 50-kbp index (.bwt / .sa / .wpac / .ann / .amb through nvbio_amd.io's writers) and 32 reads cut from it, for the host part of the fmmap run"""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from nvbio_amd import io as nio
+    from oracle import pyoracle as O
+    rng = np.random.default_rng(5)
+    text = rng.integers(0, 4, 50_000, dtype=np.uint8)
+    prefix = os.path.join(tmp, "fmmap_genome")
+    nio.save_fmindex(prefix, O.FMIndex(text))
+    nio.write_wpac(prefix + ".wpac", text.size, O.pack(text, 2, True)); nio.write_bns(prefix, ["chr1"], [text.size])
+    reads_name = os.path.join(tmp, "fmmap_reads.fq")
+    with open(reads_name, "w") as f:
+        for i in range(32):
+            q = int(rng.integers(200, 49_000))
+            f.write("@read%d\n%s\n+\n%s\n" % (i, "".join("ACGT"[c] for c in text[q:q + 100]), "I" * 100))
+    return dict(index=prefix, reads=reads_name)
 
 def whole_cases(tmp, out, only, install=False):
     """compile + link (+ run) the whole-TU cases; returns the number of failures"""
@@ -571,7 +620,7 @@ def whole_cases(tmp, out, only, install=False):
         ok = r.returncode == 0
         ran = ""
         if ok and c.get("run") is not None:
-            subst = sw_benchmark_files(tmp) if c.get("files") == "sw" else {}
+            subst = sw_benchmark_files(tmp) if c.get("files") == "sw" else fmmap_files(tmp) if c.get("files") == "fmmap" else {}
             run_args = [a.format(**subst) for a in c["run"]]
             expect = c["expect"].format(**subst) if subst else c["expect"]
             rr = subprocess.run([exe] + run_args, capture_output=True, text=True, timeout=600,
@@ -601,7 +650,7 @@ def whole_cases(tmp, out, only, install=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--keep", action="store_true", help="keep the temporary TUs (for debugging; they hold reference text, do not commit them)")
-    ap.add_argument("--log", default=os.path.join(ROOT, "profiles", "r04", "ref_bind_check.log"))
+    ap.add_argument("--log", default=os.path.join(ROOT, "profiles", "r05", "ref_bind_check.log"))
     ap.add_argument("--only", type=int, nargs="*", help="run only these case numbers")
     ap.add_argument("--install-ref-tests", action="store_true",
                     help="also copy the whole-TU binaries to oracle/_ref/ (git-ignored; they travel to the GPU box, where tests/test_ref_tests_gpu.py runs them)")
