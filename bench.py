@@ -284,13 +284,13 @@ def main():
     # the same launch on the all-int32 kernel (what runs when the host cannot prove the 16-bit form exact)
     a32_ms = None
     if rank == 0 and world == 1:
-        os.environ["NVBIO_HIP_FORCE_32BIT"] = "1"
+        nvb.set_test_switch("NVBIO_HIP_FORCE_32BIT", "1")
         launch(outs[1]); torch.cuda.synchronize()
         ev32 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
         for e0, e1 in ev32:
             e0.record(); launch(outs[1]); e1.record()
         torch.cuda.synchronize()
-        del os.environ["NVBIO_HIP_FORCE_32BIT"]
+        nvb.set_test_switch("NVBIO_HIP_FORCE_32BIT", 0)
         a32_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev32) / len(ev32)
         a32_same = bool(torch.equal(outs[1][0], outs[0][0]) and torch.equal(outs[1][1], outs[0][1]))
     if gather_on and cxx_g is not None:

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define NVBIO_HIP_ABI_VERSION 1
+#define NVBIO_HIP_ABI_VERSION 2
 
 /* nvbio::aln::AlignmentType (nvbio/alignment/alignment_base.h:54) */
 enum { NVBIO_HIP_GLOBAL = 0, NVBIO_HIP_LOCAL = 1, NVBIO_HIP_SEMI_GLOBAL = 2 };
@@ -856,14 +856,18 @@ typedef struct nvbio_hip_comm_transport {
 } nvbio_hip_comm_transport;
 void nvbio_hip_comm_set_transport(const nvbio_hip_comm_transport* transport);
 
-/* Test switches.  A few environment variables select alternative executions of the same results, for the parity suite to cover both
+/* Test switches.  A few named integers select alternative executions of the same results, for the parity suite to cover both
  * (NVBIO_HIP_FORCE_32BIT, NVBIO_HIP_NO_STAGING, NVBIO_HIP_FULL_GENERIC, NVBIO_HIP_FULL_SINGLE_JOB, NVBIO_HIP_FULL_ROWS, NVBIO_HIP_ED_SWEEP,
- * NVBIO_HIP_SELECT_LANES, NVBIO_HIP_TRACEBACK_LANES).  They are read with getenv at every call so that one process can flip them between
- * calls; getenv is not safe against a concurrent setenv, so change them only while no other thread is inside a library call.  Production
- * code leaves them unset.
- * Memory helpers: nvbio_hip_device_free synchronises the DEVICE (hipFree's contract: the block may be in use by any stream) and frees on
- * the calling thread's current device -- call it from a thread bound to the device the block lives on, and keep per-batch storage in a
- * hip::device_arena (include/nvbio_hip/types.h), which never comes through here. */
+ * NVBIO_HIP_SELECT_LANES, NVBIO_HIP_TRACEBACK_LANES).  Each is seeded ONCE per process from the environment variable of the same name and
+ * changed afterwards only through nvbio_hip_set_test_switch (atomic; safe while other threads are inside library calls -- a call in flight
+ * uses the value it read when it started).  0 = the default execution.  Production code leaves them alone. */
+int nvbio_hip_set_test_switch(const char* name, int value);     /* hipErrorInvalidValue for an unknown name */
+int nvbio_hip_get_test_switch(const char* name);                /* -1 for an unknown name */
+/* Memory helpers: nvbio_hip_device_malloc / nvbio_hip_device_free take blocks from a private pool of the calling thread's current device.
+ * nvbio_hip_device_free does not stop the host: the block returns to the pool after everything queued so far on the legacy default stream
+ * (hence on every blocking stream) and on the streams made by nvbio_hip_stream_create has finished (a fence stream waits on an event per
+ * stream).  Work on a non-blocking stream created elsewhere is not fenced -- synchronise it first.  Call it from a thread bound to the device
+ * the block lives on; per-batch storage lives in a hip::device_arena (include/nvbio_hip/types.h) and never comes through here. */
 
 /* Library / device introspection (host). */
 int         nvbio_hip_abi_version(void);

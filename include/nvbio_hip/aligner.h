@@ -123,7 +123,7 @@ struct Aligner
     /// batches in flight overlap the two kinds (+7-10 %).  Nothing else is needed for that: the seeding stages are queued on the batch's own
     /// stream like every other stage (a token that serialised the seeding stages of co-resident Aligners, and a CU-masked seeding stream,
     /// were tried in round 3 and removed -- neither beat plain streams).
-    Aligner() : BATCH_SIZE(0), SCORING_BATCH(0), cigar_stride(64), mds_stride(256), n_alignments(0) {}
+    Aligner() : BATCH_SIZE(0), SCORING_BATCH(0), cigar_stride(64), mds_stride(256), n_alignments(0) { check_abi(); }
 
     /// run a seeding stage: f(stream) queues its kernels on the stream it is given
     template <typename F> void fabric_bound(void* hip_stream, F f) { f(hip_stream); }

@@ -60,8 +60,9 @@ struct DeviceGroup
         }
     };
 
-    DeviceGroup() : m_owns_comms(true) {}
-    ~DeviceGroup() { if (m_owns_comms) for (size_t i = 0; i < m_ranks.size(); ++i) if (m_ranks[i].comm) (void)nvbio_hip_comm_destroy(m_ranks[i].comm); }
+    DeviceGroup() : m_owns_comms(true), m_aborted(false) { check_abi(); }
+    /// (an aborted communicator is already released -- ncclCommAbort frees it --, so the failure path of run() must not destroy it again)
+    ~DeviceGroup() { if (m_owns_comms && !m_aborted.load()) for (size_t i = 0; i < m_ranks.size(); ++i) if (m_ranks[i].comm) (void)nvbio_hip_comm_destroy(m_ranks[i].comm); }
     DeviceGroup(const DeviceGroup&) = delete;
     DeviceGroup& operator=(const DeviceGroup&) = delete;
 
@@ -118,7 +119,10 @@ struct DeviceGroup
             errors[i] = (what && what[0]) ? what : "error";
             int expected = -1;
             if (first_failed.compare_exchange_strong(expected, int(i)))
+            {
+                m_aborted.store(true);
                 for (size_t k = 0; k < m_ranks.size(); ++k) if (m_ranks[k].comm) (void)nvbio_hip_comm_abort(m_ranks[k].comm);
+            }
         };
         for (size_t i = 0; i < m_ranks.size(); ++i)
             threads.emplace_back([&, i] {
@@ -134,6 +138,7 @@ struct DeviceGroup
 private:
     std::vector<Rank> m_ranks;
     bool              m_owns_comms;
+    mutable std::atomic<bool> m_aborted;      ///< run() aborted (= released) the communicators: the group is dead, nothing left to destroy
 };
 
 } // namespace hip

@@ -1,0 +1,170 @@
+// nvbio_hip/sam.h -- SAM records of the single-end best-mapping driver's results (host side, after the batch came back):
+// the mandatory fields and the tags SamOutput writes for an aligned read (nvbio/io/output/output_sam.cpp:316-366: NM, AS, XM, XO,
+// XG, MD), its conventions kept -- an unaligned read is flag 4 with '*' fields and the read as loaded; an alignment that runs over the
+// end of its reference sequence is printed in full with the UNMAPPED flag and mapping quality 0 (:454-462); MD / XM / XO / XG come
+// from the byte-coded MDS finish_alignment leaves (generate_md_string :233-314, its uint8 run counter included).
+// Records are formatted by all OpenMP threads into per-thread buffers and written in read order.
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <algorithm>
+#if defined(_OPENMP)
+#include <omp.h>
+#endif
+
+namespace nvbio {
+namespace io {
+
+/// the reference's sequences: names and n + 1 offsets into the concatenated genome (<prefix>.ann, or one sequence)
+struct SamReference
+{
+    std::vector<std::string> names;
+    std::vector<uint64_t>    index;
+    uint32_t sequence_of(const uint64_t pos) const
+    {
+        const uint32_t k = uint32_t(std::upper_bound(index.begin(), index.end(), pos) - index.begin());
+        return k == 0u ? 0u : std::min<uint32_t>(k - 1u, uint32_t(names.size()) - 1u);
+    }
+    std::string header(const char* program = "nvbio_amd") const
+    {
+        std::string h = "@HD\tVN:1.0\tSO:unsorted\n";
+        for (size_t k = 0; k < names.size(); ++k) h += "@SQ\tSN:" + names[k] + "\tLN:" + std::to_string(index[k + 1] - index[k]) + "\n";
+        h += std::string("@PG\tID:") + program + "\tPN:" + program + "\n";
+        return h;
+    }
+};
+
+/// what Aligner::best_approx (finish = true) returns for a batch, on the host
+struct SamBatchSE
+{
+    uint32_t        n;
+    const char*     names;        const uint32_t* names_index;      ///< n + 1 offsets, each name 0-terminated inside its slot
+    const uint8_t*  symbols;      const uint64_t* read_index;       ///< forward reads, one symbol (0..4) per byte; n + 1 offsets
+    const uint8_t*  quals;                                          ///< phred, same offsets
+    const uint64_t* best;                                           ///< io::Alignment words of the best alignment: low = flags / score / ed, high = position
+    const uint8_t*  mapq;
+    const uint16_t* cigar;        uint32_t cigar_stride;            ///< io::Cigar words, end first
+    const uint32_t* cigar_len;
+    const uint32_t* source;                                         ///< (x, y) per read: where in the traceback window the alignment starts
+    const uint8_t*  mds;          uint32_t mds_stride;
+};
+
+namespace priv {
+inline void put_uint(std::string& s, uint64_t v) { char b[24]; int k = 24; do { b[--k] = char('0' + v % 10u); v /= 10u; } while (v); s.append(b + k, size_t(24 - k)); }
+inline void put_int(std::string& s, int64_t v) { if (v < 0) { s.push_back('-'); put_uint(s, uint64_t(-v)); } else put_uint(s, uint64_t(v)); }
+
+/// MD:Z text and the mismatch / gap-open / gap-extension counters of one MDS
+inline void md_string(const uint8_t* mds, std::string& md, int32_t& mm, int32_t& gapo, int32_t& gape)      // (int32 counters, output_sam.h:83-85)
+{
+    static const char dna[] = "ACGTN";
+    const uint32_t n = uint32_t(mds[0]) | (uint32_t(mds[1]) << 8);
+    mm = gapo = gape = 0;
+    uint32_t i = 2u;
+    while (i < n)
+    {
+        const uint32_t op = mds[i++];
+        if (op == 0u)
+        {
+            uint32_t run = mds[i++];
+            while (i < n && mds[i] == 0u) { run = (run + mds[i]) & 0xFFu; ++i; }      // the reference's byte counter walks over the next MATCH token's op byte
+            put_uint(md, run);
+        }
+        else if (op == 1u) { md.push_back(dna[std::min<uint32_t>(mds[i], 4u)]); ++i; ++mm; }
+        else if (op == 2u) { const uint32_t l = mds[i]; i += 1u + l; ++gapo; gape += int32_t(l) - 1; }
+        else if (op == 3u)
+        {
+            const uint32_t l = mds[i++];
+            md.push_back('^');
+            for (uint32_t k = 0; k < l; ++k) md.push_back(dna[std::min<uint32_t>(mds[i + k], 4u)]);
+            md.push_back('0');
+            i += l; ++gapo; gape += int32_t(l) - 1;
+        }
+    }
+}
+
+inline void se_record(const SamBatchSE& b, const SamReference& ref, const uint32_t i, const uint32_t extra_flags, std::string& out, std::string& md)
+{
+    static const char dna[] = "ACGTN";
+    const uint32_t w   = uint32_t(b.best[i] & 0xFFFFFFFFull);
+    const uint32_t pos = uint32_t(b.best[i] >> 32);
+    const uint8_t* seq = b.symbols + b.read_index[i];
+    const uint8_t* ql  = b.quals + b.read_index[i];
+    const uint32_t L   = uint32_t(b.read_index[i + 1] - b.read_index[i]);
+    out.append(b.names + b.names_index[i]);
+    if (pos == 0xFFFFFFFFu)
+    {
+        out.push_back('\t'); put_uint(out, 4u | extra_flags); out.append("\t*\t0\t0\t*\t*\t0\t0\t");
+        for (uint32_t k = 0; k < L; ++k) out.push_back(dna[std::min<uint32_t>(seq[k], 4u)]);
+        out.push_back('\t');
+        for (uint32_t k = 0; k < L; ++k) out.push_back(char(ql[k] + 33));
+        out.push_back('\n');
+        return;
+    }
+    const bool     rc    = (w >> 28) & 1u;
+    const int32_t  score = int32_t((w >> 1) & 0x1FFFFu) * ((w & 1u) ? -1 : 1);
+    const uint32_t ed    = (w >> 18) & 0x3FFu;
+    const uint16_t* cg   = b.cigar + uint64_t(i) * b.cigar_stride;
+    const uint32_t  cl   = b.cigar_len[i];
+    uint64_t ref_len = 0;
+    for (uint32_t k = 0; k < cl; ++k) { const uint32_t t = cg[k] & 3u; if (t == 0u || t == 2u) ref_len += cg[k] >> 2; }
+    const uint64_t at   = uint64_t(pos) + b.source[2u * i];
+    const uint32_t sq   = ref.sequence_of(at);
+    const bool     over = at + ref_len > ref.index[sq + 1];
+    out.push_back('\t'); put_uint(out, (rc ? 16u : 0u) | (over ? 4u : 0u) | extra_flags);
+    out.push_back('\t'); out.append(ref.names[sq]);
+    out.push_back('\t'); put_uint(out, at - ref.index[sq] + 1u);
+    out.push_back('\t'); put_uint(out, over ? 0u : b.mapq[i]);
+    out.push_back('\t');
+    if (cl == 0u) out.push_back('*');
+    for (uint32_t k = cl; k-- > 0u;) { put_uint(out, cg[k] >> 2); out.push_back("MIDS"[cg[k] & 3u]); }
+    out.append("\t*\t0\t0\t");
+    if (rc) { for (uint32_t k = L; k-- > 0u;) out.push_back(seq[k] < 4u ? dna[3u - seq[k]] : 'N'); }
+    else    { for (uint32_t k = 0; k < L; ++k) out.push_back(dna[std::min<uint32_t>(seq[k], 4u)]); }
+    out.push_back('\t');
+    if (rc) { for (uint32_t k = L; k-- > 0u;) out.push_back(char(ql[k] + 33)); }
+    else    { for (uint32_t k = 0; k < L; ++k) out.push_back(char(ql[k] + 33)); }
+    int32_t mm, gapo, gape;
+    md.clear();
+    md_string(b.mds + uint64_t(i) * b.mds_stride, md, mm, gapo, gape);
+    out.append("\tNM:i:"); put_uint(out, ed);
+    out.append("\tAS:i:"); put_int(out, score);
+    out.append("\tXM:i:"); put_int(out, mm);
+    out.append("\tXO:i:"); put_int(out, gapo);
+    out.append("\tXG:i:"); put_int(out, gape);
+    out.append("\tMD:Z:"); if (md.empty()) out.push_back('*'); else out.append(md);
+    out.push_back('\n');
+}
+} // namespace priv
+
+/// append the batch's records to `f`; extra_flags are OR-ed into every FLAG (SamOutput marks single-end reads READ_1 = 64 too)
+inline bool write_sam_se(FILE* f, const SamBatchSE& batch, const SamReference& ref, const uint32_t extra_flags = 0u)
+{
+#if defined(_OPENMP)
+    const int n_threads = std::max(1, omp_get_max_threads());
+#else
+    const int n_threads = 1;
+#endif
+    const uint32_t chunk = 16384u;
+    bool ok = true;
+    for (uint64_t base = 0; base < batch.n && ok; base += uint64_t(chunk) * uint64_t(n_threads))
+    {
+        std::vector<std::string> bufs; bufs.resize(size_t(n_threads));
+        #pragma omp parallel for schedule(static, 1) num_threads(n_threads)
+        for (int t = 0; t < n_threads; ++t)
+        {
+            const uint64_t lo = base + uint64_t(t) * chunk, hi = std::min<uint64_t>(lo + chunk, batch.n);
+            std::string md;
+            bufs[size_t(t)].reserve(size_t(chunk) * 320u);
+            for (uint64_t i = lo; i < hi; ++i) priv::se_record(batch, ref, uint32_t(i), extra_flags, bufs[size_t(t)], md);
+        }
+        for (int t = 0; t < n_threads && ok; ++t)
+            ok = bufs[size_t(t)].empty() || fwrite(bufs[size_t(t)].data(), 1, bufs[size_t(t)].size(), f) == bufs[size_t(t)].size();
+    }
+    return ok;
+}
+
+} // namespace io
+} // namespace nvbio

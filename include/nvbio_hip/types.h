@@ -42,6 +42,13 @@ struct hip_error : public std::runtime_error {
     hip_error(const char* what, int c) : std::runtime_error(std::string(what) + " failed, hipError " + std::to_string(c)), code(c) {}
 };
 inline void hip_check(int err, const char* what) { if (err != 0) throw hip_error(what, err); }
+/// the library this translation unit was compiled against: argument lists changed between ABI versions, so a wrapper built against one
+/// header must not call a library of another (checked once, by the first driver object / device group / arena that is made)
+inline void check_abi()
+{
+    static const int have = nvbio_hip_abi_version();
+    if (have != NVBIO_HIP_ABI_VERSION) throw hip_error(("libnvbio_hip.so has ABI version " + std::to_string(have) + ", these headers are version " + std::to_string(NVBIO_HIP_ABI_VERSION) + ": nvbio_hip_abi_version()").c_str(), have);
+}
 /// a failed allocation says how much was asked for (an out-of-memory report without the size is useless to whoever sizes the batches)
 inline void hip_check_alloc(int err, unsigned long long bytes) { if (err != 0) throw hip_error(("nvbio_hip_device_malloc(" + std::to_string(bytes) + " bytes)").c_str(), err); }
 

@@ -6,7 +6,7 @@ that ABI which mirrors the reference's names (nvbio::aln / nvbio::fm_index /
 FMIndexFilter) and uses torch only for device memory and streams.  There is no
 CPU fallback: importing the package without the built library raises.
 """
-from ._lib import lib, LIB_PATH, check  # noqa: F401
+from ._lib import lib, LIB_PATH, check, set_test_switch, test_switch  # noqa: F401
 from .strings import PackedStringSet, pack_symbols  # noqa: F401
 from .alignment import (GLOBAL, LOCAL, SEMI_GLOBAL, PATTERN_BLOCKING, TEXT_BLOCKING, SimpleGotohScheme, SmithWatermanScoringScheme, GotohAligner,  # noqa: F401
                         make_gotoh_aligner, BatchedBandedAlignmentScore, batch_banded_alignment_score,

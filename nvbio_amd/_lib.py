@@ -32,7 +32,7 @@ SYMBOLS = [
     "nvbio_hip_stream_synchronize", "nvbio_hip_stream_create", "nvbio_hip_stream_destroy",
     "nvbio_hip_comm_available", "nvbio_hip_device_count", "nvbio_hip_set_device", "nvbio_hip_get_device", "nvbio_hip_comm_unique_id", "nvbio_hip_comm_init_rank",
     "nvbio_hip_comm_init_all", "nvbio_hip_comm_destroy", "nvbio_hip_comm_rank", "nvbio_hip_gather_records", "nvbio_hip_comm_abort", "nvbio_hip_comm_set_transport",
-    "nvbio_hip_abi_version", "nvbio_hip_arch", "nvbio_hip_last_kernel",
+    "nvbio_hip_abi_version", "nvbio_hip_arch", "nvbio_hip_last_kernel", "nvbio_hip_set_test_switch", "nvbio_hip_get_test_switch",
 ]
 
 
@@ -198,6 +198,10 @@ def lib():
         L.nvbio_hip_gather_records.argtypes = [vp, vp, vp, u32, vp, C.c_int, vp]
         L.nvbio_hip_set_device.argtypes = [C.c_int]
         L.nvbio_hip_abi_version.restype = C.c_int
+        L.nvbio_hip_set_test_switch.argtypes = [C.c_char_p, C.c_int]
+        L.nvbio_hip_get_test_switch.argtypes = [C.c_char_p]
+        if L.nvbio_hip_abi_version() != 2:
+            raise RuntimeError("nvbio_amd: lib/libnvbio_hip.so has ABI version %d, this package needs 2 -- rebuild it (python -m nvbio_amd.build)" % L.nvbio_hip_abi_version())
         L.nvbio_hip_arch.restype = C.c_char_p
         L.nvbio_hip_last_kernel.restype = C.c_char_p
         _lib = L
@@ -207,6 +211,28 @@ def lib():
 def check(err, what):
     if err != 0:
         raise RuntimeError("nvbio_amd: %s failed with hipError %d" % (what, err))
+
+
+def set_test_switch(name, value):
+    """One of the library's test switches (include/nvbio_hip.h, 'Test switches'): an integer, 0 = the default execution.  The switches are seeded
+    once from the environment and changed only through this call afterwards."""
+    check(lib().nvbio_hip_set_test_switch(name.encode(), int(value)), "nvbio_hip_set_test_switch(%s)" % name)
+
+
+class test_switch:
+    """with test_switch("NVBIO_HIP_FORCE_32BIT", 1): ...   -- the switch is restored on exit"""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, int(value)
+
+    def __enter__(self):
+        self.saved = lib().nvbio_hip_get_test_switch(self.name.encode())
+        set_test_switch(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_test_switch(self.name, self.saved)
+        return False
 
 
 def current_stream_ptr():

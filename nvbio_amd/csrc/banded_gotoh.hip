@@ -39,6 +39,10 @@
 #include "banded_gotoh_impl.h"
 #include <mutex>
 #include <atomic>
+#include <vector>
+#include <algorithm>
+#include <cstring>
+#include <cstdlib>
 
 namespace nvb {
 
@@ -91,8 +95,7 @@ static int banded_gotoh_dispatch(nvb::GotohParams& p, const QA& qa, int64_t max_
 {
     using namespace nvb;
     // NVBIO_HIP_FORCE_32BIT=1 disables the 16-bit kernels (used by the tests to cover both widths)
-    const char* force32 = getenv("NVBIO_HIP_FORCE_32BIT");
-    const uint32_t lim16 = (force32 && force32[0] == '1') ? 0u
+    const uint32_t lim16 = test_switch(SW_FORCE_32BIT) == 1 ? 0u
                          : max_len_16bit(p.match, best_pair, max_abs_cost, std::max(p.gap_open, p.txt_gap_open), std::max(p.gap_ext, p.txt_gap_ext), type, band_len);
     const bool fixed = (patterns->length == nullptr);
     hipError_t e = hipSuccess;
@@ -101,8 +104,7 @@ static int banded_gotoh_dispatch(nvb::GotohParams& p, const QA& qa, int64_t max_
     {
         const uint32_t maxM = fixed ? patterns->fixed_length : p.stage_pw /* carries the hint */;
         p.stage_pw = p.stage_tw = 0;
-        const char* nostage = getenv("NVBIO_HIP_NO_STAGING");
-        if (maxM != 0 && !(nostage && nostage[0] == '1')) {
+        if (maxM != 0 && test_switch(SW_NO_STAGING) != 1) {
             uint32_t pw = stage_words_pattern(32u / patterns->bits - 1u, maxM, patterns->bits);
             if (views) {     // a reversed view spans the groups [last - ceil16(M) - 15, last] plus one group fetch from the word of last - 15
                 const uint32_t per = 32u / patterns->bits, c16 = (maxM + 15u) & ~15u;
@@ -269,13 +271,43 @@ NVB_API int nvbio_hip_device_malloc(void** ptr, uint64_t bytes)
     if (hipError_t e = hipMallocFromPoolAsync(ptr, bytes ? bytes : 1, pool, nullptr)) return e;
     return hipStreamSynchronize(nullptr);          // like hipMalloc: the block is usable from every stream on return
 }
+// nvbio_hip_device_free keeps hipFree's contract for the streams this library knows -- the legacy default stream (and through it every blocking
+// stream) and the streams made by nvbio_hip_stream_create -- WITHOUT stopping the host: a fence stream waits on an event recorded in each of
+// them, and the block goes back to the pool in that fence stream's order.  The calling thread returns at once; another driver thread's batch in
+// flight is not waited for.  (Work queued on a non-blocking stream created elsewhere is not fenced: synchronise such a stream before freeing.)
+namespace nvb {
+static std::mutex g_streams_mtx;
+static std::vector<hipStream_t> g_streams[64];
+static hipStream_t g_fence[64] = {};
+static void register_stream(int dev, hipStream_t s) { if (dev >= 0 && dev < 64) { std::lock_guard<std::mutex> lock(g_streams_mtx); g_streams[dev].push_back(s); } }
+static void forget_stream(hipStream_t s)
+{
+    std::lock_guard<std::mutex> lock(g_streams_mtx);
+    for (auto& v : g_streams) v.erase(std::remove(v.begin(), v.end(), s), v.end());
+}
+} // namespace nvb
 NVB_API int nvbio_hip_device_free(void* ptr)
 {
     if (!ptr) return hipSuccess;
-    if (hipError_t e = hipDeviceSynchronize()) return e;     // hipFree's implicit synchronisation: no stream still uses the block
     int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && nvb::private_pool(dev)) return hipFreeAsync(ptr, nullptr);
-    return hipFree(ptr);
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !nvb::private_pool(dev)) {
+        if (hipError_t e = hipDeviceSynchronize()) return e;
+        return hipFree(ptr);
+    }
+    std::lock_guard<std::mutex> lock(nvb::g_streams_mtx);
+    hipStream_t& fence = nvb::g_fence[dev];
+    if (!fence) { if (hipError_t e = hipStreamCreateWithFlags(&fence, hipStreamNonBlocking)) { fence = nullptr; return e; } }
+    auto wait_on = [&](hipStream_t s) -> hipError_t {
+        hipEvent_t ev = nullptr;
+        if (hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) return e;
+        hipError_t e = hipEventRecord(ev, s);
+        if (e == hipSuccess) e = hipStreamWaitEvent(fence, ev, 0);
+        (void)hipEventDestroy(ev);                     // released by the runtime once it has completed
+        return e;
+    };
+    if (hipError_t e = wait_on(nullptr)) return e;
+    for (hipStream_t s : nvb::g_streams[dev]) if (hipError_t e = wait_on(s)) return e;
+    return hipFreeAsync(ptr, fence);
 }
 // ---- streams for the C++ host layer (which has no HIP headers).  The reference's drivers run on the default stream of one host thread
 // per device (nvBowtie.cpp:809-864); here one device serves several batches at once: a driver object per host thread, each on its own
@@ -289,9 +321,43 @@ NVB_API int nvbio_hip_stream_create(void** stream, uint32_t non_blocking)
     hipStream_t s = nullptr;
     const hipError_t e = hipStreamCreateWithFlags(&s, non_blocking ? hipStreamNonBlocking : hipStreamDefault);
     *stream = s;
+    int dev = 0;
+    if (e == hipSuccess && hipGetDevice(&dev) == hipSuccess) nvb::register_stream(dev, s);
     return e;
 }
-NVB_API int nvbio_hip_stream_destroy(void* stream) { return stream ? hipStreamDestroy(nvb::to_stream(stream)) : hipSuccess; }
+NVB_API int nvbio_hip_stream_destroy(void* stream)
+{
+    if (!stream) return hipSuccess;
+    nvb::forget_stream(nvb::to_stream(stream));
+    return hipStreamDestroy(nvb::to_stream(stream));
+}
+
+// ---- test switches
+namespace nvb {
+static std::atomic<int> g_switch[SW_COUNT];
+static const char* const g_switch_name[SW_COUNT] = { "NVBIO_HIP_FORCE_32BIT", "NVBIO_HIP_NO_STAGING", "NVBIO_HIP_FULL_GENERIC", "NVBIO_HIP_ED_SWEEP",
+                                                     "NVBIO_HIP_FULL_SINGLE_JOB", "NVBIO_HIP_FULL_ROWS", "NVBIO_HIP_TRACEBACK_LANES", "NVBIO_HIP_SELECT_LANES" };
+static void seed_switches()
+{
+    static std::once_flag once;
+    std::call_once(once, [] { for (int k = 0; k < SW_COUNT; ++k) { const char* e = getenv(g_switch_name[k]); g_switch[k].store(e ? atoi(e) : 0, std::memory_order_relaxed); } });
+}
+int test_switch(TestSwitch which) { seed_switches(); return g_switch[which].load(std::memory_order_relaxed); }
+} // namespace nvb
+NVB_API int nvbio_hip_set_test_switch(const char* name, int value)
+{
+    if (!name) return hipErrorInvalidValue;
+    nvb::seed_switches();
+    for (int k = 0; k < nvb::SW_COUNT; ++k)
+        if (strcmp(name, nvb::g_switch_name[k]) == 0) { nvb::g_switch[k].store(value, std::memory_order_relaxed); return hipSuccess; }
+    return hipErrorInvalidValue;
+}
+NVB_API int nvbio_hip_get_test_switch(const char* name)
+{
+    if (!name) return -1;
+    for (int k = 0; k < nvb::SW_COUNT; ++k) if (strcmp(name, nvb::g_switch_name[k]) == 0) return nvb::test_switch(nvb::TestSwitch(k));
+    return -1;
+}
 
 NVB_API int nvbio_hip_memcpy(void* dst, const void* src, uint64_t bytes, int kind, void* stream)
 {

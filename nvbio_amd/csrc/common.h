@@ -11,6 +11,12 @@ namespace nvb {
 // thread-local name of the last kernel variant launched (introspection for tests/bench)
 extern thread_local const char* g_last_kernel;
 
+// Test switches (include/nvbio_hip.h, "Test switches"): alternative executions of the same results.  Each is an atomic int, seeded ONCE
+// from the environment variable of the same name (std::call_once) and changed afterwards only through nvbio_hip_set_test_switch --
+// no getenv on the launch paths, which run on several driver threads at a time.
+enum TestSwitch { SW_FORCE_32BIT = 0, SW_NO_STAGING, SW_FULL_GENERIC, SW_ED_SWEEP, SW_FULL_SINGLE_JOB, SW_FULL_ROWS, SW_TRACEBACK_LANES, SW_SELECT_LANES, SW_COUNT };
+int test_switch(TestSwitch which);       // the switch's integer value; 0 = default execution
+
 // ---------------------------------------------------------------------------
 // Packed-stream decoding.  The reference addresses symbols one at a time through
 // PackedStream (nvbio/basic/packedstream_inl.h:336-400).  Here a thread pulls a

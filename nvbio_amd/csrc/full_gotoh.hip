@@ -1040,15 +1040,13 @@ static int full_score_core(
     g_last_kernel = "full_gotoh_score_kernel";
     const int R = maxM <= 64u ? 1 : maxM <= 128u ? 2 : maxM <= 192u ? 3 : maxM <= 256u ? 4 : maxM <= 512u ? 8 : 16;
     // the 16-bit sweep needs: values inside int16 (= !trunc), LOCAL scores < 2048 and columns < 2^20 for its packed row maxima
-    const char* nofast = getenv("NVBIO_HIP_FULL_GENERIC");
     // (LOCAL runs x16: scores below 2048 and every cost below 2048 / 3 keep H, E, F, H + G_o and the diagonal sum inside int16)
     const bool fast = !trunc && maxN < (1u << 20) && (type != NVBIO_HIP_LOCAL || (scheme->match >= 0 && int64_t(maxM) * best_pair < 2048 && A * 3 < 2000))
-                      && !(nofast && nofast[0] == '1');
+                      && test_switch(SW_FULL_GENERIC) != 1;
     // edit distance, no min_score, non-LOCAL: the bit-vector kernel (NVBIO_HIP_ED_SWEEP=1 keeps the sweep, for the tests)
     {
-        const char* sweep_ed = getenv("NVBIO_HIP_ED_SWEEP");
         const bool ed = !qual && blk_log2 == 4u && scheme->match == 0 && scheme->mismatch == -1 && scheme->gap_open == -1 && scheme->gap_ext == -1;
-        if (ed && !trunc && type != NVBIO_HIP_LOCAL && min_score == nullptr && maxM <= 512u && !(sweep_ed && sweep_ed[0] == '1'))
+        if (ed && !trunc && type != NVBIO_HIP_LOCAL && min_score == nullptr && maxM <= 512u && test_switch(SW_ED_SWEEP) != 1)
         {
             g_last_kernel = "edit_distance_bitvector_kernel";
             const uint32_t words = (maxM + 63u) / 64u;
@@ -1063,14 +1061,13 @@ static int full_score_core(
     {
         // several jobs per wave when that keeps more lanes busy: n_seg segments of 64 / n_seg lanes, R = 5 or 6 rows per lane.
         // Estimated cell throughput: busy lanes x (cell work) / (cell work + per-step overhead).
-        const char* nomulti = getenv("NVBIO_HIP_FULL_SINGLE_JOB");
+        const bool nomulti = test_switch(SW_FULL_SINGLE_JOB) == 1;
         auto eff = [](const double lanes, const double rows, const double overhead) { return lanes / 64.0 * (28.0 * rows) / (28.0 * rows + overhead); };
         double best = eff(double((maxM + R - 1) / R), double(R), 24.0);
         uint32_t best_seg = 1u, best_r = 0u;
         // (rows per lane: 5 / 6 with two or three jobs per wave; 8 / 10 with four -- 150-bp mates: 4 x 15 lanes x 10 rows -- which halves the
         // per-step work that does not depend on the rows: the hand-off between lanes, the step's bookkeeping, the ramp in and out of a matrix)
-        const char* rows_env = getenv("NVBIO_HIP_FULL_ROWS");                    // test switch: 5, 6, 8, 10 = only that depth
-        const uint32_t only_r = rows_env ? uint32_t(atoi(rows_env)) : 0u;
+        const uint32_t only_r = uint32_t(std::max(0, test_switch(SW_FULL_ROWS)));     // test switch: 5, 6, 8, 10 = only that depth
         const uint32_t depths[4] = { 5u, 6u, 8u, 10u };
         for (uint32_t ns = 2u; ns <= 4u; ++ns)
             for (uint32_t di = 0; di < 4u; ++di)
@@ -1086,7 +1083,7 @@ static int full_score_core(
                 if (type == NVBIO_HIP_LOCAL && r == 8u) e *= 0.90;
                 if (e > best * 1.05) { best = e; best_seg = ns; best_r = r; }
             }
-        if (best_seg > 1u && !(nomulti && nomulti[0] == '1') && uint64_t(maxN) * 64u * 8u < (1ull << 32))
+        if (best_seg > 1u && !nomulti && uint64_t(maxN) * 64u * 8u < (1ull << 32))
         {
             g_last_kernel = "full_gotoh_score_multi_kernel<16-bit>";
             switch (best_r) { case 5u: return launch_full_multi<5>(p, type, best_seg, s); case 6u: return launch_full_multi<6>(p, type, best_seg, s);

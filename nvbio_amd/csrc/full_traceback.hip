@@ -628,8 +628,7 @@ static int full_traceback_core(
     }
     // one job per wave segment when its blocks fit a wave (patterns to 64 blocks); NVBIO_HIP_TRACEBACK_LANES=1 keeps one job per lane
     const uint32_t nb = std::max(1u, (maxM + block_len - 1u) / block_len);
-    const char* lanes = getenv("NVBIO_HIP_TRACEBACK_LANES");
-    if (nb <= 64u && !(lanes && lanes[0] == '1'))
+    if (nb <= 64u && test_switch(SW_TRACEBACK_LANES) != 1)
     {
         const uint64_t blocks8 = 2u * std::max<uint64_t>(1u, (uint64_t(maxM) + 15u) / 16u);
         const uint64_t region = (blocks8 + 1u) * uint64_t(maxN) + blocks8 * blocks8;          // dwords per job (temp_bytes above)

@@ -573,8 +573,7 @@ static int select_init_impl(uint32_t n_reads, const uint32_t* queue, const char*
     }
     g_last_kernel = "select_init_kernel";
     // trees: 4 or 8 lanes per read (four leaves each) when a read's hit slots fit, one lane per read otherwise
-    const char* lanes = getenv("NVBIO_HIP_SELECT_LANES");                  // =1: one lane per read
-    const bool one_lane = lanes && lanes[0] == '1';
+    const bool one_lane = test_switch(SW_SELECT_LANES) == 1;             // NVBIO_HIP_SELECT_LANES = 1: one lane per read
     const int G = (!randomized || one_lane) ? 0 : hits_stride <= 16u ? 4 : hits_stride <= 32u ? 8 : 0;
     hipLaunchKernelGGL(select_init_kernel, grid_for(n_reads), dim3(256), 0, to_stream(stream), n_reads, read_names, read_names_idx,
                        reinterpret_cast<const uint2*>(hits), hits_stride, hit_counts, probs, probs_stride, trys, rseeds, max_effort_init,
@@ -638,8 +637,7 @@ NVB_API int nvbio_hip_select(int32_t randomized, uint32_t n_multi, const uint32_
     // One lane per read is the default: the stage moves every active read's hit row and tree row in and out of HBM once per call and
     // sits near that floor; the four-leaves-per-lane form (NVBIO_HIP_SELECT_LANES=4, same results) measured slower on config 4
     // (profiles/r03/select_coop.txt).
-    const char* lanes = getenv("NVBIO_HIP_SELECT_LANES");
-    const bool quad = randomized && hits_stride <= 32u && lanes && lanes[0] == '4';
+    const bool quad = randomized && hits_stride <= 32u && test_switch(SW_SELECT_LANES) == 4;
     if (quad && hits_stride <= 16u)
         hipLaunchKernelGGL(select_rand_quad_kernel<4>, grid_for((uint64_t(n) + 1u) * 4u), dim3(256), 0, s, n_multi, active_in, n_active, reinterpret_cast<uint2*>(hits), hits_stride,
                            hit_counts, probs, probs_stride, rseeds, trys, stage_read, stage_loc, stage_seed, key);

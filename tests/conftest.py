@@ -32,3 +32,14 @@ def cuda():
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but no GPU is visible (no CPU fallback exists)")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _default_test_switches():
+    """every test starts and ends on the library's default executions (the switches are process-wide integers, include/nvbio_hip.h)"""
+    yield
+    mod = sys.modules.get("nvbio_amd._lib")
+    if mod is not None and getattr(mod, "_lib", None) is not None:
+        for name in ("NVBIO_HIP_FORCE_32BIT", "NVBIO_HIP_NO_STAGING", "NVBIO_HIP_FULL_GENERIC", "NVBIO_HIP_ED_SWEEP", "NVBIO_HIP_FULL_SINGLE_JOB",
+                     "NVBIO_HIP_FULL_ROWS", "NVBIO_HIP_TRACEBACK_LANES", "NVBIO_HIP_SELECT_LANES"):
+            mod._lib.nvbio_hip_set_test_switch(name.encode(), 0)

@@ -514,3 +514,23 @@ int nvbio_multi_device_selftest(uint32_t n_devices, uint64_t n_total, uint32_t r
         return 0;
     } catch (const std::exception& e) { fprintf(stderr, "nvbio_multi_device_selftest: %s\n", e.what()); return 1; }
 }
+
+// ---- the host layer's SAM writer (include/nvbio_hip/sam.h) for the Python tools: tools/align_fastq.py, tools/nvbowtie_3gbp.py ----
+#include <nvbio_hip/sam.h>
+extern "C" __attribute__((visibility("default")))
+int nvbio_write_sam_se(const char* path, int append, int with_header, uint32_t extra_flags, uint32_t n, const char* names, const uint32_t* names_index,
+                       const uint8_t* symbols, const uint64_t* read_index, const uint8_t* quals, const uint64_t* best, const uint8_t* mapq,
+                       const uint16_t* cigar, uint32_t cigar_stride, const uint32_t* cigar_len, const uint32_t* source, const uint8_t* mds, uint32_t mds_stride,
+                       uint32_t n_seqs, const char* const* seq_names, const uint64_t* seq_index)
+{
+    io::SamReference ref;
+    for (uint32_t k = 0; k < n_seqs; ++k) ref.names.push_back(seq_names[k]);
+    ref.index.assign(seq_index, seq_index + n_seqs + 1u);
+    FILE* f = fopen(path, append ? "ab" : "wb");
+    if (!f) return 1;
+    bool ok = true;
+    if (with_header) { const std::string h = ref.header(); ok = fwrite(h.data(), 1, h.size(), f) == h.size(); }
+    const io::SamBatchSE b = { n, names, names_index, symbols, read_index, quals, best, mapq, cigar, cigar_stride, cigar_len, source, mds, mds_stride };
+    ok = ok && io::write_sam_se(f, b, ref, extra_flags);
+    return (fclose(f) == 0 && ok) ? 0 : 2;
+}

@@ -24,7 +24,7 @@ def test_library_exports_every_symbol():
     L = ctypes.CDLL(nvbio_amd.LIB_PATH)
     for s in declared_symbols():
         assert hasattr(L, s), s
-    assert nvbio_amd.lib().nvbio_hip_abi_version() == 1
+    assert nvbio_amd.lib().nvbio_hip_abi_version() == 2
     assert nvbio_amd.lib().nvbio_hip_arch() == b"gfx950"
 
 

@@ -32,7 +32,7 @@ def run_gpu(band, ty, scheme, hp, ht, dev, force32=False):
     too small, so staged lanes, unstaged launches and per-lane fall-backs are all exercised."""
     p = nvb.PackedStringSet.from_host(hp.words, hp.bits, hp.big_endian, hp.begin, hp.length, device=dev)
     t = nvb.PackedStringSet.from_host(ht.words, ht.bits, ht.big_endian, ht.begin, ht.length, device=dev)
-    os.environ["NVBIO_HIP_FORCE_32BIT"] = "1" if force32 else "0"
+    nvb.set_test_switch("NVBIO_HIP_FORCE_32BIT", "1" if force32 else "0")
     maxlen = int(hp.length.max()) if hp.length.size else 0
     _hint_cycle[0] += 1
     hint = (0, maxlen, max(maxlen // 2, 1))[_hint_cycle[0] % 3]
@@ -41,7 +41,7 @@ def run_gpu(band, ty, scheme, hp, ht, dev, force32=False):
                                                        max_pattern_length=hint)
         torch.cuda.synchronize()
     finally:
-        os.environ["NVBIO_HIP_FORCE_32BIT"] = "0"
+        nvb.set_test_switch("NVBIO_HIP_FORCE_32BIT", "0")
     return score.cpu().numpy(), sink.cpu().numpy().view(np.uint32)
 
 
@@ -222,12 +222,12 @@ def test_quality_aware_scheme(cuda, band, ty):
         t = nvb.PackedStringSet.from_host(ht.words, 2, True, ht.begin, ht.length, device=cuda)
         dq = torch.from_numpy(quals).to(cuda)
         for force32 in ("0", "1"):
-            os.environ["NVBIO_HIP_FORCE_32BIT"] = force32
+            nvb.set_test_switch("NVBIO_HIP_FORCE_32BIT", force32)
             try:
                 gs, gk = nvb.batch_banded_alignment_score(band, nvb.make_gotoh_aligner(ty, scheme), p, t, quals=dq)
                 torch.cuda.synchronize()
             finally:
-                os.environ["NVBIO_HIP_FORCE_32BIT"] = "0"
+                nvb.set_test_switch("NVBIO_HIP_FORCE_32BIT", "0")
             gs, gk = gs.cpu().numpy(), gk.cpu().numpy().view(np.uint32)
             bad = np.nonzero((es != gs) | (ek != gk).any(1))[0]
             assert bad.size == 0, (band, ty, force32, bad[:5], es[bad[:3]], gs[bad[:3]])
@@ -278,13 +278,13 @@ def test_pattern_views_run_in_place(cuda, band, ty):
     t = nvb.PackedStringSet.from_host(ht.words, 2, True, ht.begin, ht.length, device=cuda)
     dq, df = torch.from_numpy(quals).to(cuda), torch.from_numpy(flags).to(cuda)
     for force32, nostage in (("0", "0"), ("1", "0"), ("0", "1")):
-        os.environ["NVBIO_HIP_FORCE_32BIT"], os.environ["NVBIO_HIP_NO_STAGING"] = force32, nostage
+        nvb.set_test_switch("NVBIO_HIP_FORCE_32BIT", force32); nvb.set_test_switch("NVBIO_HIP_NO_STAGING", nostage)
         try:
             gs, gk = nvb.batch_banded_alignment_score(band, nvb.make_gotoh_aligner(ty, scheme), p, t, quals=dq, pattern_flags=df,
                                                       max_pattern_length=int(stored.length.max()))
             torch.cuda.synchronize()
         finally:
-            os.environ["NVBIO_HIP_FORCE_32BIT"], os.environ["NVBIO_HIP_NO_STAGING"] = "0", "0"
+            nvb.set_test_switch("NVBIO_HIP_FORCE_32BIT", "0"); nvb.set_test_switch("NVBIO_HIP_NO_STAGING", "0")
         assert "views" in nvb.lib().nvbio_hip_last_kernel().decode()
         gs, gk = gs.cpu().numpy(), gk.cpu().numpy().view(np.uint32)
         bad = np.nonzero((es != gs) | (ek != gk).any(1))[0]

@@ -26,12 +26,12 @@ def run(ty, scheme, pats, txts, dev, min_score=None, maxM=None, maxN=None, pbits
     maxM = maxM or max(1, max(len(x) for x in pats))
     maxN = maxN or max(1, max(len(x) for x in txts))
     for generic in ("0", "1"):          # the 16-bit systolic sweep (when eligible) and the generic 32-bit one
-        os.environ["NVBIO_HIP_FULL_GENERIC"] = generic
+        nvb.set_test_switch("NVBIO_HIP_FULL_GENERIC", generic)
         try:
             gs, gk, go = nvb.batch_alignment_score(nvb.make_gotoh_aligner(ty, nvb.SimpleGotohScheme(*scheme)), p, t, maxM, maxN, ms)
             torch.cuda.synchronize()
         finally:
-            os.environ["NVBIO_HIP_FULL_GENERIC"] = "0"
+            nvb.set_test_switch("NVBIO_HIP_FULL_GENERIC", "0")
         gs, gk, go = gs.cpu().numpy(), gk.cpu().numpy().view(np.uint32), go.cpu().numpy()
         bad = np.nonzero((es != gs) | (ek != gk).any(1) | (eo != go))[0]
         assert bad.size == 0, "type %d scheme %s generic=%s: %d mismatches; first %d: M=%d N=%d cpu (%d,%s,%d) gpu (%d,%s,%d)" % (
@@ -225,13 +225,13 @@ def test_several_jobs_per_wave(cuda, ty, max_m, max_n, monkeypatch):
                 kernels = []
                 # "0": the depth the host picks; "r8" / "r10": four jobs per wave at 8 / 10 rows per lane where the pattern fits; "1": one job per wave
                 for single in ("0", "r8", "r10", "1"):
-                    monkeypatch.setenv("NVBIO_HIP_FULL_SINGLE_JOB", "1" if single == "1" else "0")
+                    nvb.set_test_switch("NVBIO_HIP_FULL_SINGLE_JOB", "1" if single == "1" else "0")
                     if single.startswith("r"):
                         if max_m > 16 * int(single[1:]):
                             continue
-                        monkeypatch.setenv("NVBIO_HIP_FULL_ROWS", single[1:])
+                        nvb.set_test_switch("NVBIO_HIP_FULL_ROWS", single[1:])
                     else:
-                        monkeypatch.delenv("NVBIO_HIP_FULL_ROWS", raising=False)
+                        nvb.set_test_switch("NVBIO_HIP_FULL_ROWS", 0)
                     al = nvb.make_gotoh_aligner(ty, nvb.SimpleGotohScheme(*scheme), algo)
                     gs, gk, go = nvb.batch_alignment_score(al, p, t, max_m, max_n, ms)
                     torch.cuda.synchronize()
@@ -242,5 +242,5 @@ def test_several_jobs_per_wave(cuda, ty, max_m, max_n, monkeypatch):
                     assert bad.size == 0, "type %d scheme %s algo %d single=%s n=%d: %d mismatches; first %d: M=%d N=%d cpu (%d,%s,%d) gpu (%d,%s,%d)" % (
                         ty, scheme, algo, single, n, bad.size, bad[0], len(pats[bad[0]]), len(txts[bad[0]]), es[bad[0]], ek[bad[0]], eo[bad[0]], gs[bad[0]], gk[bad[0]], go[bad[0]])
                 assert "multi" in kernels[0] and "multi" not in kernels[-1], kernels
-    monkeypatch.delenv("NVBIO_HIP_FULL_SINGLE_JOB", raising=False)
-    monkeypatch.delenv("NVBIO_HIP_FULL_ROWS", raising=False)
+    nvb.set_test_switch("NVBIO_HIP_FULL_SINGLE_JOB", 0)
+    nvb.set_test_switch("NVBIO_HIP_FULL_ROWS", 0)

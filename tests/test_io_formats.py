@@ -350,3 +350,65 @@ def test_bam_round_trip(tmp_path):
         o += 4 + bs
     assert o == len(raw)
     assert open(path, "rb").read()[-28:] == bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")      # the BGZF end-of-file block
+
+
+def test_native_sam_writer_equals_the_python_one(tmp_path):
+    """include/nvbio_hip/sam.h (the C++ host layer's SAM records: what a run of millions of reads is written with) against the Python
+    formatter of tools/align_fastq.py on synthetic driver output: unaligned reads, both strands, reads with N, CIGARs with every operation,
+    MDS streams with mismatches / insertions / deletions / 255+ match runs, alignments that bridge two reference sequences, READ_1 as an
+    extra flag.  (The Python formatter is the one the nvBowtie-equality tests validated record by record.)"""
+    import io as _io
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import align_fastq as AF
+    rng = np.random.default_rng(5)
+    n = 3000
+    lens = rng.integers(30, 160, n)
+    index = np.zeros(n + 1, np.int64); index[1:] = np.cumsum(lens)
+    symbols = rng.integers(0, 4, int(index[-1])).astype(np.uint8)
+    symbols[rng.random(symbols.size) < 0.01] = 4
+    quals = rng.integers(2, 41, int(index[-1])).astype(np.uint8)
+    names = ["read_%d/x" % i for i in range(n)]
+    nio.write_bns(str(tmp_path / "g"), ["chrA", "chrB", "chrC"], [5000, 300, 4700])
+
+    class Ref(AF.Reference):
+        pass
+    ref = Ref(str(tmp_path / "g"), 10_000, "ref")
+    best = np.zeros((2, n), np.uint64)
+    mapq = rng.integers(0, 43, n).astype(np.uint8)
+    cig = np.zeros((n, 64), np.uint16); clen = np.zeros(n, np.uint32)
+    source = np.zeros((n, 2), np.uint32); mds = np.zeros((n, 256), np.uint8)
+    for i in range(n):
+        if i % 11 == 0:
+            best[0, i] = (0xFFFFFFFF << 32) | (int(rng.integers(0, 4)) << 28)
+            continue
+        pos = int(rng.integers(0, 9_900))
+        score = int(rng.integers(-300, 301))
+        w = (1 if score < 0 else 0) | (abs(score) << 1) | (int(rng.integers(0, 40)) << 18) | (int(rng.integers(0, 2)) << 28)
+        best[0, i] = (pos << 32) | w
+        k = int(rng.integers(1, 9))
+        ops = rng.integers(0, 4, k); ops[0] = 0
+        for j in range(k):
+            cig[i, j] = int(ops[j]) | (int(rng.integers(1, 200)) << 2)
+        clen[i] = k
+        source[i] = (int(rng.integers(0, 20)), int(rng.integers(0, 5)))
+        toks = []
+        for _ in range(int(rng.integers(1, 12))):
+            op = int(rng.choice([0, 0, 0, 1, 2, 3]))
+            if op == 0:
+                toks += [0, int(rng.choice([1, 17, 200, 255]))]
+            elif op == 1:
+                toks += [1, int(rng.integers(0, 5))]
+            else:
+                l = int(rng.integers(1, 5)); toks += [op, l] + [int(x) for x in rng.integers(0, 5, l)]
+        total = 2 + len(toks)
+        mds[i, 0], mds[i, 1] = total & 0xFF, total >> 8
+        mds[i, 2:total] = toks
+    for flags in (0, 64):
+        buf = _io.StringIO()
+        AF.write_records_se(buf, ref, names, symbols, index, quals, best, mapq, cig, clen, source, mds, extra_flags=flags)
+        path = str(tmp_path / ("native_%d.sam" % flags))
+        AF.write_records_se_native(path, ref, names, symbols, index, quals, best, mapq, cig, clen, source, mds, extra_flags=flags)
+        text = open(path).read()
+        assert text == ref.header() + buf.getvalue()
+    assert "\t4\t" in text or "\t68\t" in text

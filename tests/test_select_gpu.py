@@ -76,7 +76,7 @@ def test_select_rounds_match_oracle(cuda, randomized, n_multi, top_seed, stride)
 def test_select_lane_forms_match_oracle(cuda, monkeypatch, lanes, n_multi, stride):
     """NVBIO_HIP_SELECT_LANES=1: select_init and select with one lane per read; =4: the randomized select with a read's row and tree
     in 4 / 8 lanes, four leaves each.  Same picks and state as the oracle either way."""
-    monkeypatch.setenv("NVBIO_HIP_SELECT_LANES", lanes)
+    nvb.set_test_switch("NVBIO_HIP_SELECT_LANES", lanes)
     _select_rounds(cuda, True, n_multi, 1, stride)
 
 

@@ -66,12 +66,12 @@ def test_full_matrix(cuda, ty):
     for scheme in SCHEMES:
         es, ek = O.batch_sw_score(0, ty, scheme, hp, ht)
         for generic in ("0", "1"):
-            os.environ["NVBIO_HIP_FULL_GENERIC"] = generic
+            nvb.set_test_switch("NVBIO_HIP_FULL_GENERIC", generic)
             try:
                 gs, gk, go = nvb.batch_alignment_score(aligner_for(ty, scheme), to_dev(hp, cuda), to_dev(ht, cuda), 200, 400)
                 torch.cuda.synchronize()
             finally:
-                os.environ["NVBIO_HIP_FULL_GENERIC"] = "0"
+                nvb.set_test_switch("NVBIO_HIP_FULL_GENERIC", "0")
             gs, gk = gs.cpu().numpy(), gk.cpu().numpy().view(np.uint32)
             bad = np.nonzero((es != gs) | (ek != gk).any(1))[0]
             assert bad.size == 0, (ty, scheme, generic, bad[:5], es[bad[:3]], gs[bad[:3]], ek[bad[:3]], gk[bad[:3]])
@@ -143,13 +143,13 @@ def test_edit_distance_bitvector_kernel(cuda, ty, algorithm):
         al = nvb.make_edit_distance_aligner(ty, tag)
         dp, dt = to_dev(hp, cuda), to_dev(ht, cuda)
         for sweep in ("0", "1"):
-            os.environ["NVBIO_HIP_ED_SWEEP"] = sweep
+            nvb.set_test_switch("NVBIO_HIP_ED_SWEEP", sweep)
             try:
                 gs, gk, go = nvb.batch_alignment_score(al, dp, dt, max_m, max_n)
                 torch.cuda.synchronize()
                 kernel = lib().nvbio_hip_last_kernel()
             finally:
-                os.environ["NVBIO_HIP_ED_SWEEP"] = "0"
+                nvb.set_test_switch("NVBIO_HIP_ED_SWEEP", "0")
             assert (b"edit_distance_bitvector" in kernel) == (sweep == "0"), kernel
             gs, gk = gs.cpu().numpy(), gk.cpu().numpy().view(np.uint32)
             # (an empty pattern makes the reference's pattern-blocking pass read uninitialised cells: there the two kernels are only

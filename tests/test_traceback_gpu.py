@@ -135,9 +135,9 @@ def tb_kernel(request, monkeypatch):
     """Both executions of the full-matrix traceback: one job per wave segment (the default where a job's pattern blocks fit a wave)
     and one job per lane (NVBIO_HIP_TRACEBACK_LANES=1; what longer patterns get)."""
     if request.param == "lanes":
-        monkeypatch.setenv("NVBIO_HIP_TRACEBACK_LANES", "1")
+        nvb.set_test_switch("NVBIO_HIP_TRACEBACK_LANES", "1")
     else:
-        monkeypatch.delenv("NVBIO_HIP_TRACEBACK_LANES", raising=False)
+        nvb.set_test_switch("NVBIO_HIP_TRACEBACK_LANES", 0)
     return request.param
 
 

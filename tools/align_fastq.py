@@ -86,11 +86,17 @@ def main(prefix, fastq, out=sys.stdout, device="cuda", ref_name="ref", **param_o
     source, mds = r["source"].cpu().numpy(), r["mds"].cpu().numpy()
     ref = Reference(prefix, n_genome, ref_name)
     out.write(ref.header())
-    for i in range(n):
+    write_records_se(out, ref, reads.names, reads.symbols, index, reads.quals, best, mapq, cig, clen, source, mds)
+
+
+def write_records_se(out, ref, names, symbols, index, quals, best, mapq, cig, clen, source, mds, extra_flags=0):
+    """One SAM record per read from the arrays Aligner::best_approx (finish = True) returns (the Python spelling; write_records_se_native
+    is the C++ host layer's, include/nvbio_hip/sam.h)"""
+    for i in range(len(index) - 1):
         w, pos = int(best[0, i] & 0xFFFFFFFF), int(best[0, i] >> 32)
-        seq, qual = reads.symbols[index[i]:index[i + 1]], reads.quals[index[i]:index[i + 1]]
+        seq, qual = symbols[index[i]:index[i + 1]], quals[index[i]:index[i + 1]]
         if pos == 0xFFFFFFFF:
-            out.write("%s\t4\t*\t0\t0\t*\t*\t0\t0\t%s\t%s\n" % (reads.names[i], "".join("ACGTN"[c] for c in seq), "".join(chr(int(q) + 33) for q in qual)))
+            out.write("%s\t%d\t*\t0\t0\t*\t*\t0\t0\t%s\t%s\n" % (names[i], 4 | extra_flags, "".join("ACGTN"[c] for c in seq), "".join(chr(int(q) + 33) for q in qual)))
             continue
         rc = (w >> 28) & 1
         score, ed = ((w >> 1) & 0x1FFFF) * (-1 if w & 1 else 1), (w >> 18) & 0x3FF
@@ -98,8 +104,35 @@ def main(prefix, fastq, out=sys.stdout, device="cuda", ref_name="ref", **param_o
         md, mm, gapo, gape = nio.sam_md_string(mds[i])
         over = ref.bridges(pos + int(source[i, 0]), cigar_ref_length(cig[i], int(clen[i])))
         out.write("%s\t%d\t%s\t%d\t%d\t%s\t*\t0\t0\t%s\t%s\tNM:i:%d\tAS:i:%d\tXM:i:%d\tXO:i:%d\tXG:i:%d\tMD:Z:%s\n" % (
-            reads.names[i], (16 if rc else 0) | (4 if over else 0), *_rname_pos(ref, pos + int(source[i, 0])), 0 if over else int(mapq[i]), cigar_string(cig[i], int(clen[i])),
+            names[i], (16 if rc else 0) | (4 if over else 0) | extra_flags, *_rname_pos(ref, pos + int(source[i, 0])), 0 if over else int(mapq[i]), cigar_string(cig[i], int(clen[i])),
             "".join("ACGTN"[c] for c in s), "".join(chr(int(x) + 33) for x in q), ed, score, mm, gapo, gape, md or "*"))
+
+
+def write_records_se_native(path, ref, names, symbols, index, quals, best, mapq, cig, clen, source, mds, extra_flags=0, append=False, header=True):
+    """The same records through the C++ host layer's writer (include/nvbio_hip/sam.h: all host threads format, written in read order) --
+    what a run of millions of reads uses.  `names`: a list of str, or (bytes buffer of 0-terminated names, uint32 offsets)."""
+    import ctypes as C
+    import os
+    lib = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "cxx", "libaligner_shim.so"))
+    if isinstance(names, tuple):
+        name_buf, name_idx = names
+    else:
+        enc = [nm.encode() + b"\0" for nm in names]
+        name_idx = np.zeros(len(enc) + 1, np.uint32); name_idx[1:] = np.cumsum([len(e) for e in enc])
+        name_buf = np.frombuffer(b"".join(enc), dtype=np.uint8)
+    arr = lambda a, t: np.ascontiguousarray(a, dtype=t)
+    symbols, quals, index = arr(symbols, np.uint8), arr(quals, np.uint8), arr(index, np.uint64)
+    best, mapq, cig, clen = arr(best[0] if np.ndim(best) == 2 else best, np.uint64), arr(mapq, np.uint8), arr(cig, np.uint16), arr(clen, np.uint32)
+    source, mds, name_buf, name_idx = arr(source, np.uint32), arr(mds, np.uint8), arr(name_buf, np.uint8), arr(name_idx, np.uint32)
+    seq_names = (C.c_char_p * len(ref.names))(*[nm.encode() for nm in ref.names])
+    seq_index = arr(ref.index, np.uint64)
+    pv = lambda a: a.ctypes.data_as(C.c_void_p)
+    n = index.size - 1
+    rc = lib.nvbio_write_sam_se(path.encode(), C.c_int(1 if append else 0), C.c_int(1 if header else 0), C.c_uint32(extra_flags), C.c_uint32(n), pv(name_buf), pv(name_idx),
+                                pv(symbols), pv(index), pv(quals), pv(best), pv(mapq), pv(cig), C.c_uint32(cig.shape[1]), pv(clen), pv(source), pv(mds), C.c_uint32(mds.shape[1]),
+                                C.c_uint32(len(ref.names)), seq_names, pv(seq_index))
+    if rc != 0:
+        raise IOError("nvbio_write_sam_se(%s) failed: %d" % (path, rc))
 
 
 def main_all(prefix, fastq, out=sys.stdout, device="cuda", ref_name="ref", **param_overrides):

@@ -1,0 +1,291 @@
+#!/usr/bin/env python3
+"""BASELINE config 4 through the reference's own application: the unchanged nvBowtie (oracle/_ref/ref_nvBowtie: its 29 translation units compiled
+as they lie on the drop-in layer, linked with libnvbio_hip.so) and this repository's from-scratch driver (nvbio_amd.aligner.best_approx =
+Aligner::best_approx) on the SAME 3 Gbp index files and the same FASTQ reads, every SAM record compared.  GPU box only.
+
+  * a synthetic genome is drawn on the device (i.i.d. bases; with --repeats a fraction of it is overwritten by diverged copies of a few repeat
+    families, the largest with millions of copies, so that seeds reach SA ranges of 2^20 rows and more: SeedHit::range_delta's 20 bits,
+    nvBowtie/bowtie2/cuda/seed_hit.h), cut into 24 sequences;
+  * forward and reverse FM-indices are built on the device (nvbio_amd.workloads.build_fm_index: prefix doubling) and written as
+    <prefix>.bwt/.sa/.rbwt/.rsa/.wpac/.ann/.amb -- the files nvBWT leaves;
+  * reads: 100 bp, 3 % substitutions, a fifth with a 1-2 bp indel, one in a hundred with an N, every other one reverse-complemented, per-base
+    phred 2..40, written as FASTQ;
+  * ref_nvBowtie --file-ref -x <prefix> -U reads.fastq -S ref.sam, then the own driver on the same arrays -> own.sam through the C++ host layer's
+    SAM writer (include/nvbio_hip/sam.h); the records are compared byte for byte (SamOutput's READ_1 flag on single-end reads aside).
+
+    python tools/nvbowtie_3gbp.py [--genome 3e9] [--reads 5000000] [--repeats 0.6] [--profile DIR] [--json OUT]
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+# (length, share of the repeat budget, divergence of a copy from its family's consensus)
+FAMILIES = [(200, 1.0 / 3.0, 0.01), (1500, 1.0 / 3.0, 0.01), (5000, 1.0 / 3.0, 0.015)]
+
+
+def make_genome(n, repeats, seed, dev):
+    """uint8 symbol tensor of length n.  Repeat copies sit on a grid of their family's length (no two copies of a family overlap), families are
+    laid down one after the other: the result is a deterministic function of (n, repeats, seed)."""
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    text = torch.empty(n, dtype=torch.uint8, device=dev)
+    for s in range(0, n, 1 << 28):
+        e = min(n, s + (1 << 28))
+        text[s:e] = torch.randint(0, 4, (e - s,), dtype=torch.uint8, generator=g, device=dev)
+    placed = []
+    for L, share, div in FAMILIES:
+        copies = int(repeats * share * n / L)
+        if copies == 0:
+            continue
+        consensus = torch.randint(0, 4, (L,), dtype=torch.uint8, generator=g, device=dev)
+        slots = torch.randperm(n // L, generator=g, device=dev)[:copies]
+        for c0 in range(0, copies, 1 << 18):
+            sl = slots[c0:c0 + (1 << 18)]
+            idx = (sl * L).unsqueeze(1) + torch.arange(L, device=dev).unsqueeze(0)
+            vals = consensus.unsqueeze(0).expand(sl.numel(), L)
+            mut = torch.rand((sl.numel(), L), generator=g, device=dev) < div
+            shift = torch.randint(1, 4, (sl.numel(), L), dtype=torch.uint8, generator=g, device=dev)
+            text[idx.reshape(-1)] = torch.where(mut, (vals + shift) & 3, vals).reshape(-1)
+        placed.append((L, copies))
+    return text, placed
+
+
+def save_index(prefix, fmi, reverse):
+    """FMIndexDevice -> <prefix>.bwt/.sa (or .rbwt/.rsa), nvBWT's layout (nvbio_amd.io.write_bwt / write_sa)"""
+    from nvbio_amd import io as nio
+    n = fmi.length
+    words = fmi.bwt_occ.view(-1, 8)[:, :4].contiguous().view(-1).cpu().numpy().view(np.uint32)
+    cum = np.array(fmi.L2[1:5], dtype=np.uint32)
+    nio.write_bwt(prefix + (".rbwt" if reverse else ".bwt"), fmi.primary, cum, words, n)
+    nio.write_sa(prefix + (".rsa" if reverse else ".sa"), fmi.primary, cum, fmi.ssa.cpu().numpy().view(np.uint32), n, fmi.sa_int)
+
+
+def make_reads(text, n_reads, L, seed, seq_bounds, dev):
+    """-> (symbols uint8 [n, L] as they appear in the FASTQ file, phred uint8 [n, L]).  No read crosses a sequence boundary."""
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    n = text.numel()
+    pos = torch.randint(0, n - L - 8, (n_reads,), generator=g, device=dev)
+    b = torch.tensor(seq_bounds[1:-1], dtype=torch.int64, device=dev)
+    if b.numel():
+        k = torch.searchsorted(b, pos + L + 8, right=False)                 # boundaries below the window's end; the last of them may lie inside it
+        kb = b[torch.clamp(k - 1, min=0)]
+        cross = (k > 0) & (kb > pos)
+        pos = torch.where(cross, kb - L - 8, pos)
+    idx = pos.unsqueeze(1) + torch.arange(L + 4, device=dev).unsqueeze(0)
+    win = text[idx]                                                           # L + 4 symbols: room for a deletion
+    # a fifth of the reads carry a 1-2 bp indel at 30-70 % of their length
+    r = torch.rand(n_reads, generator=g, device=dev)
+    at = torch.randint(3 * L // 10, 7 * L // 10, (n_reads,), generator=g, device=dev)
+    gl = torch.randint(1, 3, (n_reads,), generator=g, device=dev)
+    col = torch.arange(L, device=dev).unsqueeze(0)
+    dele, ins = (r < 0.1).unsqueeze(1), ((r >= 0.1) & (r < 0.2)).unsqueeze(1)
+    src = torch.where(dele & (col >= at.unsqueeze(1)), col + gl.unsqueeze(1), col)                      # deletion: skip gl reference symbols
+    src = torch.where(ins & (col >= (at + gl).unsqueeze(1)), col - gl.unsqueeze(1), src)                # insertion: gl new symbols, the rest shifted
+    sym = torch.gather(win, 1, src)
+    rnd = torch.randint(0, 4, (n_reads, L), dtype=torch.uint8, generator=g, device=dev)
+    sym = torch.where(ins & (col >= at.unsqueeze(1)) & (col < (at + gl).unsqueeze(1)), rnd, sym)
+    mut = torch.rand((n_reads, L), generator=g, device=dev) < 0.03
+    sym = torch.where(mut, (sym + 1 + (rnd % 3)) & 3, sym)
+    rc = (torch.arange(n_reads, device=dev) & 1).bool().unsqueeze(1)
+    sym = torch.where(rc, (3 - sym).flip(1), sym)
+    hasn = torch.rand(n_reads, generator=g, device=dev) < 0.01
+    npos = torch.randint(0, L, (n_reads,), generator=g, device=dev)
+    sym = torch.where(hasn.unsqueeze(1) & (col == npos.unsqueeze(1)), torch.full_like(sym, 4), sym)
+    qual = torch.randint(2, 41, (n_reads, L), dtype=torch.uint8, generator=g, device=dev)
+    return sym.contiguous(), qual.contiguous(), pos
+
+
+def write_fastq(path, sym, qual, digits=8):
+    """@r<8 digits>, sequence, +, phred+33: built as one byte matrix on the device"""
+    n, L = sym.shape
+    dev = sym.device
+    rec = torch.empty((n, 2 + digits + 1 + L + 3 + L + 1), dtype=torch.uint8, device=dev)
+    rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
+    ids = torch.arange(n, device=dev)
+    for d in range(digits):
+        rec[:, 2 + d] = ((ids // (10 ** (digits - 1 - d))) % 10 + ord("0")).to(torch.uint8)
+    o = 2 + digits
+    rec[:, o] = ord("\n")
+    lut = torch.tensor(list(b"ACGTN"), dtype=torch.uint8, device=dev)
+    rec[:, o + 1:o + 1 + L] = lut[sym.long()]
+    rec[:, o + 1 + L] = ord("\n"); rec[:, o + 2 + L] = ord("+"); rec[:, o + 3 + L] = ord("\n")
+    rec[:, o + 4 + L:o + 4 + 2 * L] = qual + 33
+    rec[:, o + 4 + 2 * L] = ord("\n")
+    rec.cpu().numpy().tofile(path)
+
+
+def own_driver(prefix, sym, qual, sam_path, dev, batch_reads, digits=8, timings=None):
+    """this repository's driver over the same reads, batch by batch -> own.sam"""
+    import align_fastq as AF
+    from nvbio_amd import io as nio, aligner as A
+    t0 = time.time()
+    data = nio.FMIndexDataDevice(prefix, flags=nio.FORWARD | nio.SA, device=dev)
+    n_genome, g_words = nio.load_genome(prefix)
+    genome_words = torch.from_numpy(np.concatenate([g_words, np.zeros(8, np.uint32)]).view(np.int32)).to(dev)
+    ref = AF.Reference(prefix, n_genome, "ref")
+    torch.cuda.synchronize()
+    t_load = time.time() - t0
+    n, L = sym.shape
+    params = A.Params(hits_stride=32)
+    t_align, t_write, stats = 0.0, 0.0, []
+    for s in range(0, n, batch_reads):
+        e = min(n, s + batch_reads)
+        m = e - s
+        names = ["r%0*d" % (digits, i) for i in range(s, e)]
+        index = torch.arange(0, (m + 1) * L, L, dtype=torch.int64, device=dev)
+        batch = A.ReadBatch.from_ragged(sym[s:e].reshape(-1), index, qual[s:e].reshape(-1))
+        torch.cuda.synchronize(); t1 = time.time()
+        r = A.best_approx(data.index(), data.rindex(), batch, genome_words, n_genome, params, names=names, cigar_stride=64, finish=True)
+        torch.cuda.synchronize(); t_align += time.time() - t1
+        stats.append(dict((k, v) for k, v in r["stats"].items() if k != "ms"))
+        t1 = time.time()
+        name_buf = np.frombuffer(("\0".join(names) + "\0").encode(), dtype=np.uint8)
+        name_idx = np.arange(0, (m + 1) * (digits + 2), digits + 2, dtype=np.uint32)
+        AF.write_records_se_native(sam_path, ref, (name_buf, name_idx), sym[s:e].reshape(-1).cpu().numpy(), index.cpu().numpy(), qual[s:e].reshape(-1).cpu().numpy(),
+                                   r["best"].cpu().numpy().view(np.uint64), r["mapq"].cpu().numpy(), r["cigar"].cpu().numpy().view(np.uint16), r["cigar_len"].cpu().numpy(),
+                                   r["source"].cpu().numpy(), r["mds"].cpu().numpy(), extra_flags=64, append=s > 0, header=s == 0)
+        t_write += time.time() - t1
+        del r, batch
+    if timings is not None:
+        timings.update(own_load_s=t_load, own_align_s=t_align, own_write_s=t_write, own_reads_per_s=n / t_align, own_batches=len(stats), own_stats_first_batch=stats[0])
+
+
+def compare_sam(ref_path, own_path, show=5):
+    """-> (records of the reference, of the own driver, identical ones); byte comparison first, line by line only when that fails"""
+    def body(path):
+        raw = np.fromfile(path, dtype=np.uint8)
+        at = 0
+        while at < raw.size and raw[at] == ord("@"):                           # header lines
+            nl = int(np.flatnonzero(raw[at:at + (1 << 20)] == 10)[0])
+            at += nl + 1
+        return raw[at:]
+    a, b = body(ref_path), body(own_path)
+    n_a, n_b = int((a == 10).sum()), int((b == 10).sum())
+    if a.size == b.size and bool((a == b).all()):
+        return n_a, n_b, n_a, []
+    la, lb = a.tobytes().split(b"\n"), b.tobytes().split(b"\n")
+    same, diffs = 0, []
+    for x, y in zip(la, lb):
+        if x == y:
+            same += 1 if x else 0
+        elif len(diffs) < show:
+            fx, fy = x.split(b"\t"), y.split(b"\t")
+            d = [i for i in range(min(len(fx), len(fy))) if fx[i] != fy[i]]
+            diffs.append(dict(fields=d, ref=[f.decode() for f in fx[:9] + fx[11:]], own=[f.decode() for f in fy[:9] + fy[11:]]))
+    return n_a, n_b, same, diffs
+
+
+def run(genome=3_000_000_000, reads=5_000_000, repeats=0.6, seed=0x5EED0009, batch_reads=1_000_000, profile=None, workdir=None, keep=False, extra=(), threads_test=False):
+    from nvbio_amd import workloads as W, io as nio
+    dev = torch.device("cuda:0")
+    out = dict(genome=genome, reads=reads, repeats=repeats, read_len=100)
+    tmp = workdir or tempfile.mkdtemp(prefix="nvb3g_")
+    prefix = os.path.join(tmp, "genome")
+    t0 = time.time()
+    text, placed = make_genome(genome, repeats, seed, dev)
+    out["repeat_families"] = [dict(length=L, copies=c) for L, c in placed]
+    torch.cuda.synchronize(); out["genome_s"] = time.time() - t0
+    n_seq = 24
+    lens = [genome // n_seq] * (n_seq - 1); lens.append(genome - sum(lens))
+    bounds = [0] + list(np.cumsum(lens))
+    t0 = time.time()
+    fmi = W.build_fm_index(text)
+    torch.cuda.synchronize(); out["index_build_s"] = time.time() - t0
+    t0 = time.time()
+    save_index(prefix, fmi, False)
+    del fmi
+    rfmi = W.build_fm_index(text.flip(0).contiguous())
+    torch.cuda.synchronize(); out["rindex_build_s"] = time.time() - t0
+    save_index(prefix, rfmi, True)
+    del rfmi
+    from nvbio_amd.strings import pack_symbols
+    gw = torch.cat([pack_symbols(text[s:s + (1 << 30)], 2, True, pad_words=0) for s in range(0, genome, 1 << 30)])
+    nio.write_wpac(prefix + ".wpac", genome, gw.cpu().numpy().view(np.uint32)); del gw
+    nio.write_bns(prefix, ["chr%d" % (k + 1) for k in range(n_seq)], lens)
+    out["files_s"] = time.time() - t0
+    sym, qual, pos = make_reads(text, reads, 100, seed + 1, bounds, dev)
+    del text
+    torch.cuda.empty_cache()
+    fq = os.path.join(tmp, "reads.fastq")
+    write_fastq(fq, sym, qual)
+    out["index_files_GB"] = sum(os.path.getsize(prefix + e) for e in (".bwt", ".sa", ".rbwt", ".rsa", ".wpac")) / 1e9
+    # ---- the reference's application
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_nvBowtie")
+    ref_sam = os.path.join(tmp, "ref.sam")
+    cmd = [exe] + list(extra) + ["--file-ref", "-x", prefix, "-U", fq, "-S", ref_sam]
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    out["nvbowtie_wall_s"] = time.time() - t0
+    log = (r.stdout + r.stderr).replace("\r", "\n")
+    out["nvbowtie_exit"] = r.returncode
+    out["nvbowtie_log_tail"] = [l for l in log.splitlines() if l.strip()][-60:]
+    out["nvbowtie_reads_per_s_incl_io"] = reads / out["nvbowtie_wall_s"]
+    if r.returncode != 0:
+        return out, log
+    # ---- this repository's driver
+    own_sam = os.path.join(tmp, "own.sam")
+    own_driver(prefix, sym, qual, own_sam, dev, batch_reads, timings=out)
+    t0 = time.time()
+    n_ref, n_own, same, diffs = compare_sam(ref_sam, own_sam)
+    out.update(records_ref=n_ref, records_own=n_own, identical=same, first_differences=diffs, compare_s=time.time() - t0)
+    # aligned share and wide SA ranges seen, from the reference's SAM
+    flags = np.loadtxt(ref_sam, dtype=np.int64, comments="@", usecols=(1,), delimiter="\t", max_rows=200_000)
+    out["aligned_share_first_200k"] = float(((flags & 4) == 0).mean())
+    if threads_test:
+        # nvBowtie's multi-device mode on one GPU: two compute threads, shared input thread, mutexed output (nvBowtie.cpp:809-864)
+        mt_sam = os.path.join(tmp, "ref_mt.sam")
+        t0 = time.time()
+        r2 = subprocess.run([exe] + list(extra) + ["--device", "0", "--device", "0", "--file-ref", "-x", prefix, "-U", fq, "-S", mt_sam], capture_output=True, text=True)
+        out["nvbowtie_two_threads_wall_s"] = time.time() - t0
+        out["nvbowtie_two_threads_exit"] = r2.returncode
+        if r2.returncode == 0:
+            a = sorted(l for l in open(ref_sam, "rb").read().split(b"\n") if l and not l.startswith(b"@"))
+            b = sorted(l for l in open(mt_sam, "rb").read().split(b"\n") if l and not l.startswith(b"@"))
+            out["two_threads_same_multiset"] = a == b
+        else:
+            out["two_threads_log_tail"] = (r2.stdout + r2.stderr).replace("\r", "\n")[-1500:]
+    if profile:
+        os.makedirs(profile, exist_ok=True)
+        pr = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "-d", profile, "-o", "ref_nvbowtie_3gbp", "--"] + cmd[:-1] + [os.path.join(tmp, "prof.sam")],
+                            capture_output=True, text=True, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp")
+        out["profile_exit"] = pr.returncode
+    if not keep and workdir is None:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out, log
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--genome", type=float, default=3e9)
+    ap.add_argument("--reads", type=int, default=5_000_000)
+    ap.add_argument("--repeats", type=float, default=0.6)
+    ap.add_argument("--batch-reads", type=int, default=1_000_000)
+    ap.add_argument("--profile", default=None, help="directory for a second nvBowtie run under rocprofv3 --kernel-trace --stats")
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--log", default=None, help="where to keep nvBowtie's own log")
+    ap.add_argument("--two-threads", action="store_true", help="also run nvBowtie with --device 0 --device 0 and compare the records as a multiset")
+    ap.add_argument("--extra", default="")
+    a = ap.parse_args()
+    out, log = run(int(a.genome), a.reads, a.repeats, batch_reads=a.batch_reads, profile=a.profile, extra=a.extra.split(), threads_test=a.two_threads)
+    if a.log:
+        open(a.log, "w").write(log)
+    text = json.dumps(out, indent=1, default=str)
+    if a.json:
+        open(a.json, "w").write(text)
+    print(text)
+    ok = out.get("nvbowtie_exit") == 0 and out.get("identical") == out.get("records_ref") == out.get("records_own") == a.reads
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

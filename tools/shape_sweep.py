@@ -16,10 +16,10 @@ for L, band in ((100, 15), (150, 31)):
     sc = torch.empty(n, dtype=torch.int32, device=dev); sk = torch.empty((n, 2), dtype=torch.int32, device=dev)
     b = nvb.BatchedBandedAlignmentScore(band)
     for force in ("0", "1"):
-        os.environ["NVBIO_HIP_FORCE_32BIT"] = force
+        nvb.set_test_switch("NVBIO_HIP_FORCE_32BIT", force)
         ms = timed(lambda: b.enact(al, p, t, sc, sk))
         print("banded L %3d band %2d force32=%s fixed : %6.2f ms %7.0f GCUPS [%s]" % (L, band, force, ms, n * L * band / ms / 1e6, nvb.lib().nvbio_hip_last_kernel().decode()))
-    os.environ["NVBIO_HIP_FORCE_32BIT"] = "0"
+    nvb.set_test_switch("NVBIO_HIP_FORCE_32BIT", "0")
     # ragged: the same strings with explicit length arrays (+ max_pattern_length hint, and without)
     pr = nvb.PackedStringSet(p.words, 4, True, p.begin, torch.full((n,), L, dtype=torch.int32, device=dev), 0)
     tr = nvb.PackedStringSet(t.words, 2, False, t.begin, torch.full((n,), L + band, dtype=torch.int32, device=dev), 0)
