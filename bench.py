@@ -40,7 +40,8 @@ READ_LEN, REF_LEN, BAND = 100, 150, 15
 SCHEME = (2, -1, -2, -1)
 # algorithmic figures per alignment
 CELLS_PER_ALN = READ_LEN * BAND                    # 1500 band cells
-NOMINAL_OPS_PER_CELL = 14                          # reference recurrence, int ops per cell
+NOMINAL_OPS_PER_CELL = 14                          # reference recurrence, int ops per cell (LOCAL, the headline's type)
+FULL_NOMINAL_OPS_PER_CELL = {"local": 14, "semi_global": 12, "global": 11}   # the same recurrence per alignment type
 BYTES_PER_ALN = 50 + 29 + 12 + 8                   # packed read + text window + sink record + offsets = 99 B
 RANK_BYTES_PER_QUERY = 40                          # 32 B record + 4 B query + 4 B result
 
@@ -83,6 +84,11 @@ def physical_cores():
         return len(pairs) or None
     except OSError:
         return None
+
+
+def counters_round(kernel):
+    """which round's PMC pass a replayed counter of profiles/traffic.json was taken in (every entry carries it)"""
+    return measured_counter(kernel, "round")
 
 
 def measured_traffic(kernel):
@@ -312,6 +318,7 @@ def main():
             "unit": "Tint-op/s",
             "frac": n * CELLS_PER_ALN * NOMINAL_OPS_PER_CELL / kt / 1e12 / VALU_PEAK_TOPS,
             "traffic": measured_traffic("banded_gotoh_score_kernel"),
+            "traffic_round": counters_round("banded_gotoh_score_kernel"),      # the round whose PMC pass the replayed counters come from
             "kernel_ms": kern_ms,
             "gcups": n * CELLS_PER_ALN / kt / 1e9,
             "hbm_GBs": n * BYTES_PER_ALN / kt / 1e9,
@@ -889,7 +896,7 @@ def rank_leg(a, dev, fmi):
     gbs = q * RANK_BYTES_PER_QUERY / (ms * 1e-3) / 1e9
     traffic = measured_traffic("fm_rank_kernel")
     res = {"kernel": "fm_rank_kernel", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": ms, "queries": q, "index_symbols": ng,
+           "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_round": counters_round("fm_rank_kernel"), "kernel_ms": ms, "queries": q, "index_symbols": ng,
            "index_bytes": int(bwt_occ.numel()) * 4, "Mqueries_per_s": q / (ms * 1e-3) / 1e6}
     if traffic:
         # what the memory system actually moved (PMC, profiles/traffic.json, measured at the default query count): every query
@@ -923,7 +930,7 @@ def rank_leg(a, dev, fmi):
     gbs_s = q * RANK_BYTES_PER_QUERY / (ms_s * 1e-3) / 1e9
     sorted_traffic = measured_traffic("fm_rank_kernel_sorted")
     res["sorted_order"] = {"kernel_ms": ms_s, "algorithmic_GBs": gbs_s, "Mqueries_per_s": q / (ms_s * 1e-3) / 1e6, "identical_to_shuffled": True,
-                           "traffic": sorted_traffic,
+                           "traffic": sorted_traffic, "traffic_round": counters_round("fm_rank_kernel_sorted"),
                            "note": "NOT a roofline figure: ~11 consecutive queries share a 128-B line and L2 serves the repeats, so algorithmic bytes (40 per query) over "
                                    "time can pass the HBM peak; `traffic` is what the fabric moved for this order (TCC_EA0_RDREQ pass, profiles/traffic.json), "
                                    "null until that pass has been taken"}
@@ -1083,10 +1090,12 @@ def seed_leg(a, dev, fmi, text, build_s):
     if rq is not None:
         line_native["match"]["traffic"] = int(a.seeds * (rq * 128 + 8))
         line_native["match"]["traffic_over_algorithmic"] = (rq * 128 + 8) / bytes_per_seed
+        line_native["match"]["traffic_round"] = counters_round("fm_match_kernel<line_native>")
     rq = measured_counter("fm_locate_kernel<line_native>", "rdreq_128B_per_row")
     if rq is not None:
         line_native["locate"]["traffic"] = int(rows.numel() * (rq * 128 + 4))
         line_native["locate"]["traffic_over_algorithmic"] = (rq * 128 + 4) / bytes_per_loc
+        line_native["locate"]["traffic_round"] = counters_round("fm_locate_kernel<line_native>")
     # the line-native figures priced in the SAME algorithmic bytes (what the reference's walk would touch): the index does the
     # job in fewer, fuller lines, so the fraction says how close the seeding stage is to what 8 TB/s could do for that walk
     for leg, nunits, bpu in (("match", a.seeds, bytes_per_seed), ("locate", rows.numel(), bytes_per_loc)):
@@ -1149,10 +1158,14 @@ def full_dp_leg(a, dev):
             raise SystemExit("parity gate failed: full-matrix Gotoh differs from the oracle")
         res[name] = {"kernel_ms": ms, "GCUPS": n * L * N / (ms * 1e-3) / 1e9, "Mreads_per_s": n / (ms * 1e-3) / 1e6, "parity_checked": m, "bit_exact": ok,
                      "kernel": nvb.lib().nvbio_hip_last_kernel().decode()}
-        # the same accounting as the headline: cells x 14 nominal ops against the VALU lane-op peak, and the executed count of the committed PMC pass
+        # roofline of the full-matrix sweep: integer-VALU issue.  `frac` is the EXECUTED lane-op rate (SQ_INSTS_VALU x 64 of the committed PMC pass
+        # of this command, per cell, x the cells of this run) against the VALU lane-op peak -- a fraction of what the SIMDs can issue, never above 1.
+        # The nominal figure beside it counts the reference recurrence per alignment type (F, E, H: 6 adds + 3 max, substitution compare + select = 11
+        # for GLOBAL; + the last-row report for SEMI_GLOBAL = 12; + max(.,0) and the sink compare / update for LOCAL = 14).
         cells = float(n) * L * N
-        roof = {"bound": "valu", "achieved": cells * NOMINAL_OPS_PER_CELL / (ms * 1e-3) / 1e12, "peak": VALU_PEAK_TOPS, "unit": "T lane-op/s",
-                "frac": cells * NOMINAL_OPS_PER_CELL / (ms * 1e-3) / 1e12 / VALU_PEAK_TOPS}
+        nominal = FULL_NOMINAL_OPS_PER_CELL[name]
+        roof = {"bound": "valu", "peak": VALU_PEAK_TOPS, "unit": "T lane-op/s",
+                "nominal": {"ops_per_cell": nominal, "achieved": cells * nominal / (ms * 1e-3) / 1e12, "frac": cells * nominal / (ms * 1e-3) / 1e12 / VALU_PEAK_TOPS}}
         try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                 pm = json.load(f).get("full_gotoh_score_kernel<%s>" % name)
@@ -1160,8 +1173,10 @@ def full_dp_leg(a, dev):
             pm = None
         if pm and pm.get("insts_valu_per_launch") and pm.get("cells_per_launch"):
             per_cell = pm["insts_valu_per_launch"] * 64.0 / pm["cells_per_launch"]
-            roof["executed"] = {"valu_lane_ops_per_cell": per_cell, "achieved": per_cell * cells / (ms * 1e-3) / 1e12,
-                                "frac": per_cell * cells / (ms * 1e-3) / 1e12 / VALU_PEAK_TOPS, "source": "SQ_INSTS_VALU, profiles/traffic.json"}
+            roof.update({"achieved": per_cell * cells / (ms * 1e-3) / 1e12, "frac": per_cell * cells / (ms * 1e-3) / 1e12 / VALU_PEAK_TOPS,
+                         "executed_lane_ops_per_cell": per_cell, "source": "SQ_INSTS_VALU, profiles/traffic.json", "counters_round": pm.get("round")})
+        else:
+            roof.update({"achieved": roof["nominal"]["achieved"], "frac": roof["nominal"]["frac"], "source": "nominal op count (no PMC pass committed)"})
         roof["counters"] = dp_counters("full_gotoh_score_kernel<%s>" % name)
         res[name]["roofline"] = roof
     # sw-benchmark's second leg (sw-benchmark.cu:641-657): the same reads, edit distance, SEMI_GLOBAL -- on the bit-vector kernel; "GCUPS" is
