@@ -8,7 +8,7 @@
 // nvBowtie's own match_range, mapping_inl.h:90.)
 #pragma once
 #include "rank_dictionary.h"
-
+#include "line_native.h"
 #include "ssa.h"
 
 namespace nvbio {
@@ -42,15 +42,47 @@ struct fm_index
                                                  const TRankDictionary rank_dict, const TSuffixArray sa)
         : m_length(length), m_primary(primary), m_L2(L2), m_rank_dict(rank_dict), m_sa(sa) {}
 
+    /// the line-native index of this FM-index in device memory (line_native.h; io::FMIndexDataDevice attaches it): the per-thread device
+    /// functions below then read one 128-byte record per step end instead of the 32-byte records of the reference layout
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void set_line_native(const uint32* base) { m_side.base = base; }
+
     index_type      m_length;
     index_type      m_primary;
     L2_iterator     m_L2;
     TRankDictionary m_rank_dict;
     TSuffixArray    m_sa;
+    priv::native_side<index_type> m_side;
 };
 
 #define NVBIO_FMI_T template <typename R, typename S, typename L>
 #define NVBIO_FMI   fm_index<R, S, L>
+
+#if defined(__HIPCC__)
+namespace priv {
+/// rank over both ends of a range on the line-native records: the step kept by the previous call, or one or two fresh lines
+template <typename F, typename side_type, typename range_type>
+NVBIO_FORCEINLINE __device__ range_type native_rank(const F&, const side_type&, const range_type range, const uint8) { return range; }     // (never attached)
+template <typename F>
+NVBIO_FORCEINLINE __device__ uint2 native_rank(const F& fmi, const native_side<uint32>& side, const uint2 range, const uint8 c)
+{
+    const uint32 L2c = fmi.L2(c);
+    uint2 out;
+    if (side.kept(range.x, range.y, c, L2c, out)) return out;
+    return side.step(range.x, range.y, c, L2c);
+}
+template <typename sa_type> struct native_sampled
+{
+    NVBIO_FORCEINLINE __device__ native_sampled(const sa_type& sa) : m_sa(sa) {}
+    NVBIO_FORCEINLINE __device__ bool operator()(const uint32 row) const { return m_sa.has(row); }
+    const sa_type& m_sa;
+};
+template <typename F, typename side_type, typename index_type>
+NVBIO_FORCEINLINE __device__ void native_locate_step(const F&, const side_type&, index_type&, index_type&) {}
+template <typename F>
+NVBIO_FORCEINLINE __device__ void native_locate_step(const F& fmi, const native_side<uint32>& side, uint32& j, uint32& t)
+{ side.locate_step(j, t, native_sampled<typename F::suffix_array_type>(fmi.m_sa)); }
+} // namespace priv
+#endif
 
 /// occurrences of c in BWT rows [0, k]   (fmindex_inl.h:36-57)
 NVBIO_FMI_T NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
@@ -66,6 +98,9 @@ typename NVBIO_FMI::index_type rank(const NVBIO_FMI& fmi, typename NVBIO_FMI::in
 NVBIO_FMI_T NVBIO_FORCEINLINE NVBIO_HOST_DEVICE
 typename NVBIO_FMI::range_type rank(const NVBIO_FMI& fmi, typename NVBIO_FMI::range_type range, uint8 c)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (fmi.m_side.attached()) return priv::native_rank(fmi, fmi.m_side, range, c);
+#endif
     return make_vector(rank(fmi, range.x, c), rank(fmi, range.y, c));
 }
 /// all four symbols at once   (fmindex_inl.h:111-135)
@@ -181,6 +216,13 @@ typename NVBIO_FMI::range_type locate_ssa_iterator(const NVBIO_FMI& fmi, const t
 {
     typedef typename NVBIO_FMI::index_type index_type;
     index_type j = i, t = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (fmi.m_side.attached())
+    {
+        while (!fmi.m_sa.has(j)) priv::native_locate_step(fmi, fmi.m_side, j, t);        // up to two text positions per record
+        return make_vector(j, t);
+    }
+#endif
     while (!fmi.m_sa.has(j)) { j = basic_inv_psi(fmi, j); ++t; }
     return make_vector(j, t);
 }

@@ -16,9 +16,14 @@
 #include "../../fmindex/ssa.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <algorithm>
 #include <string>
 #include <vector>
+#if defined(__HIPCC__) && !defined(NVBIO_HIP_COMPAT_NO_TUNED)
+#include "../../../../../nvbio_hip.h"
+#define NVBIO_HIP_COMPAT_IO_TUNED 1
+#endif
 
 namespace nvbio {
 namespace io {
@@ -239,8 +244,21 @@ struct FMIndexDataDevice : public FMIndexData
             if ((flags & FORWARD) && host_data.has_ssa())  { upload(m_ssa_vec,  host_data.m_ssa.m_ssa,  n_sa); m_ssa  = FMIndexDataCore::ssa_type(nvbio::raw_pointer(m_ssa_vec)); }
             if ((flags & REVERSE) && host_data.has_rssa()) { upload(m_rssa_vec, host_data.m_rssa.m_ssa, n_sa); m_rssa = FMIndexDataCore::ssa_type(nvbio::raw_pointer(m_rssa_vec)); }
         }
+        // the line-native records of each index loaded (fmindex/line_native.h): 3.7 bytes per SA row of the 288 GB, built on the device from the
+        // arrays just uploaded; index() / rindex() carry their address.  NVBIO_HIP_COMPAT_LINE_NATIVE=0 keeps the reference layout alone.
+        m_native = m_rnative = NULL;
+#if defined(NVBIO_HIP_COMPAT_IO_TUNED)
+        const char* off = getenv("NVBIO_HIP_COMPAT_LINE_NATIVE");
+        if (!(off && off[0] == '0'))
+        {
+            if (m_bwt_occ)  m_native  = build_line_native(m_native_vec,  m_bwt_occ,  m_primary,  m_ssa.m_ssa,  host_data.m_L2);
+            if (m_rbwt_occ) m_rnative = build_line_native(m_rnative_vec, m_rbwt_occ, m_rprimary, m_rssa.m_ssa, host_data.m_L2);
+        }
+#endif
     }
     uint64 allocated() const { return m_allocated; }
+    const uint32* line_native()  const { return m_native; }       ///< device memory, NULL = not built
+    const uint32* rline_native() const { return m_rnative; }
 
     occ_type  occ_iterator()  const { return occ_type(bwt_occ_type(reinterpret_cast<const uint4*>(bwt_occ()))); }
     occ_type  rocc_iterator() const { return occ_type(bwt_occ_type(reinterpret_cast<const uint4*>(rbwt_occ()))); }
@@ -252,12 +270,39 @@ struct FMIndexDataDevice : public FMIndexData
 
     rank_dict_type rank_dict()  const { return rank_dict_type(bwt_stream_type(bwt_iterator()),  occ_iterator(),  count_table_iterator()); }
     rank_dict_type rrank_dict() const { return rank_dict_type(bwt_stream_type(rbwt_iterator()), rocc_iterator(), count_table_iterator()); }
-    fm_index_type  index()  const { return fm_index_type(length(), primary(),  L2(), rank_dict(),  ssa_iterator()); }
-    fm_index_type  rindex() const { return fm_index_type(length(), rprimary(), L2(), rrank_dict(), rssa_iterator()); }
+    fm_index_type  index()  const { fm_index_type f(length(), primary(),  L2(), rank_dict(),  ssa_iterator());  f.set_line_native(m_native);  return f; }
+    fm_index_type  rindex() const { fm_index_type f(length(), rprimary(), L2(), rrank_dict(), rssa_iterator()); f.set_line_native(m_rnative); return f; }
     partial_fm_index_type partial_index()  const { return partial_fm_index_type(length(), primary(),  L2(), rank_dict(),  null_type()); }
     partial_fm_index_type rpartial_index() const { return partial_fm_index_type(length(), rprimary(), L2(), rrank_dict(), null_type()); }
 
 private:
+#if defined(NVBIO_HIP_COMPAT_IO_TUNED)
+    /// nvbio_hip_fm_build_dimer_index over one uploaded index; NULL (and a warning) when the device cannot spare the room or the build fails
+    const uint32* build_line_native(nvbio::vector<device_tag, uint32>& store, const uint32* bwt_occ, const uint32 primary, const uint32* ssa, const uint32* host_L2)
+    {
+        nvbio_hip_fmindex m;
+        memset(&m, 0, sizeof(m));
+        m.length = m_seq_length; m.primary = primary; m.sa_int = SA_INT;
+        for (int i = 0; i < 5; ++i) m.L2[i] = host_L2[i];
+        m.bwt_occ = bwt_occ; m.ssa = ssa;
+        const uint64 bytes = nvbio_hip_fm_dimer_index_bytes(m_seq_length), tb = nvbio_hip_fm_build_dimer_index_temp_bytes(m_seq_length);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || uint64(free_b) < 2u * (bytes + tb))
+        { (void)hipGetLastError(); log_warning(stderr, "FMIndexDataDevice: no room for the line-native index (%.1f GB), staying on the reference layout\n", float(bytes) * 1.0e-9f); return NULL; }
+        try
+        {
+            store.resize(size_t(bytes / 4u) + 64u);
+            nvbio::vector<device_tag, uint8> temp(size_t(tb) + 16u);
+            uint32* base = nvbio::raw_pointer(store);
+            base += ((128u - uint32(uintptr_t(base) & 127u)) & 127u) / 4u;
+            if (nvbio_hip_fm_build_dimer_index(&m, base, nvbio::raw_pointer(temp), tb, 0) != 0 || hipStreamSynchronize(0) != hipSuccess)
+            { (void)hipGetLastError(); store.clear(); log_warning(stderr, "FMIndexDataDevice: building the line-native index failed, staying on the reference layout\n"); return NULL; }
+            m_allocated += bytes;
+            return base;
+        }
+        catch (...) { (void)hipGetLastError(); store.clear(); return NULL; }
+    }
+#endif
     void upload(nvbio::vector<device_tag, uint32>& dst, const uint32* src, const size_t n)
     {
         dst.resize(n);
@@ -265,7 +310,9 @@ private:
         m_allocated += uint64(n) * sizeof(uint32);
     }
     uint64                             m_allocated;
-    nvbio::vector<device_tag, uint32>  m_bwt_occ_vec, m_rbwt_occ_vec, m_ssa_vec, m_rssa_vec, m_count_table_vec, m_L2_vec;
+    nvbio::vector<device_tag, uint32>  m_bwt_occ_vec, m_rbwt_occ_vec, m_ssa_vec, m_rssa_vec, m_count_table_vec, m_L2_vec, m_native_vec, m_rnative_vec;
+    const uint32*                      m_native;
+    const uint32*                      m_rnative;
 };
 
 inline void init_ssa(const FMIndexDataDevice& driver_data, FMIndexDataDevice::ssa_storage_type& ssa, FMIndexDataDevice::ssa_storage_type& rssa)

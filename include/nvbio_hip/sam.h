@@ -96,7 +96,7 @@ inline void se_record(const SamBatchSE& b, const SamReference& ref, const uint32
     out.append(b.names + b.names_index[i]);
     if (pos == 0xFFFFFFFFu)
     {
-        out.push_back('\t'); put_uint(out, 4u | extra_flags); out.append("\t*\t0\t0\t*\t*\t0\t0\t");
+        out.append("\t4\t*\t0\t0\t*\t*\t0\t0\t");                 // (UNMAPPED alone, output_sam.cpp:427)
         for (uint32_t k = 0; k < L; ++k) out.push_back(dna[std::min<uint32_t>(seq[k], 4u)]);
         out.push_back('\t');
         for (uint32_t k = 0; k < L; ++k) out.push_back(char(ql[k] + 33));
@@ -139,7 +139,7 @@ inline void se_record(const SamBatchSE& b, const SamReference& ref, const uint32
 }
 } // namespace priv
 
-/// append the batch's records to `f`; extra_flags are OR-ed into every FLAG (SamOutput marks single-end reads READ_1 = 64 too)
+/// append the batch's records to `f`; extra_flags are OR-ed into the FLAG of every aligned read (SamOutput marks single-end alignments READ_1 = 64 too)
 inline bool write_sam_se(FILE* f, const SamBatchSE& batch, const SamReference& ref, const uint32_t extra_flags = 0u)
 {
 #if defined(_OPENMP)

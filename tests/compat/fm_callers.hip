@@ -247,3 +247,90 @@ API int compat_fm_search_host(unsigned n, unsigned primary, const unsigned* L2, 
     }
     return 0;
 }
+
+// ---- the line-native records under the per-thread functions (fmindex/line_native.h): the same walks on an index with and without them ----
+// A walk in the shape of nvBowtie's match_range (mapping_inl.h:83-97): the index is held BY VALUE for the length of the loop, one
+// rank(index, (x - 1, y), c) per symbol, front to back; every raw pair of counts it gets is written out.
+template <typename FMType, typename Query>
+__device__ uint2 traced_walk(uint2 range, const FMType index, const Query query, const uint32 begin, const uint32 end, uint32* trace)
+{
+    for (uint32 i = begin; i < end && range.x <= range.y; ++i)
+    {
+        const uint8 c = query[i];
+        const uint2 cnts = rank(index, make_uint2(range.x - 1u, range.y), c);
+        trace[2u * i] = cnts.x; trace[2u * i + 1u] = cnts.y;
+        range.x = index.L2(c) + cnts.x + 1u;
+        range.y = index.L2(c) + cnts.y;
+    }
+    return range;
+}
+/// mode 0: one walk per lane; mode 1: two walks INTERLEAVED on one index object (each call finds the other walk's kept step); mode 2: after every
+/// step the same query is asked again (a kept step must not answer a repeated range wrongly); rows: locate_ssa_iterator + lookup
+template <typename FMIndexType>
+__global__ void native_walk_kernel(const uint32 n_queries, const uint32 query_len, const uint32* genome_words, const FMIndexType fmi, const uint32 mode,
+                                   const uint32* starts, uint32* ranges, uint32* trace, const uint32 n_rows, const uint32* rows, uint32* iterators, uint32* positions)
+{
+    const uint32 q = threadIdx.x + blockIdx.x * blockDim.x;
+    typedef PackedStream<const uint32*, uint8, 2, true> genome_string;
+    const genome_string genome(genome_words);
+    if (q < n_queries)
+    {
+        uint32* tr = trace + uint64(q) * 2u * query_len;
+        for (uint32 i = 0; i < 2u * query_len; ++i) tr[i] = 0xFFFFFFFFu;
+        uint2 range = make_uint2(0u, fmi.length());
+        if (mode == 0u) range = traced_walk(range, fmi, genome + starts[q], 0u, query_len, tr);
+        else if (mode == 1u)
+        {
+            const FMIndexType index = fmi;
+            const genome_string a = genome + starts[q], b = genome + starts[(q + 1u) % n_queries];
+            uint2 other = range;
+            for (uint32 i = 0; i < query_len && range.x <= range.y; ++i)
+            {
+                const uint8 c = a[i];
+                const uint2 cnts = rank(index, make_uint2(range.x - 1u, range.y), c);
+                tr[2u * i] = cnts.x; tr[2u * i + 1u] = cnts.y;
+                range.x = index.L2(c) + cnts.x + 1u; range.y = index.L2(c) + cnts.y;
+                if (other.x <= other.y)
+                {
+                    const uint8 d = b[i];
+                    const uint2 o = rank(index, make_uint2(other.x - 1u, other.y), d);
+                    other.x = index.L2(d) + o.x + 1u; other.y = index.L2(d) + o.y;
+                }
+            }
+        }
+        else
+        {
+            const FMIndexType index = fmi;
+            const genome_string a = genome + starts[q];
+            for (uint32 i = 0; i < query_len && range.x <= range.y; ++i)
+            {
+                const uint8 c = a[i];
+                const uint2 cnts = rank(index, make_uint2(range.x - 1u, range.y), c);
+                const uint2 again = rank(index, make_uint2(range.x - 1u, range.y), uint8((c + 1u) & 3u));     // same range, another symbol
+                const uint2 once_more = rank(index, make_uint2(range.x - 1u, range.y), c);
+                tr[2u * i] = cnts.x; tr[2u * i + 1u] = (once_more.x == cnts.x && once_more.y == cnts.y) ? cnts.y : 0xDEADBEEFu;
+                (void)again;
+                range.x = index.L2(c) + cnts.x + 1u; range.y = index.L2(c) + cnts.y;
+            }
+        }
+        ranges[2u * q] = range.x; ranges[2u * q + 1u] = range.y;
+    }
+    if (q < n_rows)
+    {
+        const uint2 it = locate_ssa_iterator(fmi, rows[q]);
+        iterators[2u * q] = it.x; iterators[2u * q + 1u] = it.y;
+        positions[q] = lookup_ssa_iterator(fmi, it);
+    }
+}
+API int compat_fm_native_walk(unsigned n, unsigned primary, const unsigned* L2, const void* bwt_occ, const unsigned* count_table, const unsigned* ssa,
+                              const unsigned* line_native /* NULL = reference layout */, unsigned mode, unsigned n_queries, unsigned query_len,
+                              const unsigned* genome_words, const unsigned* starts, unsigned* ranges, unsigned* trace, unsigned n_rows, const unsigned* rows,
+                              unsigned* iterators, unsigned* positions)
+{
+    InterleavedLayout::fm_index_type fmi = InterleavedLayout::make(n, primary, L2, bwt_occ, NULL, count_table, ssa);
+    fmi.set_line_native(line_native);
+    const uint32 m = n_queries > n_rows ? n_queries : n_rows;
+    hipLaunchKernelGGL((native_walk_kernel<InterleavedLayout::fm_index_type>), dim3((m + 127u) / 128u), dim3(128), 0, 0, n_queries, query_len, genome_words, fmi, mode,
+                       starts, ranges, trace, n_rows, rows, iterators, positions);
+    return int(hipDeviceSynchronize());
+}

@@ -226,3 +226,58 @@ def test_caller_kernel_one_mismatch_search(fm, index, layout, len1, len2):
     assert (got == exp).all()
     if len2 < 10:
         assert (exp[:, 1:, 0] <= exp[:, 1:, 1]).sum() > nq                 # the substitution branch really fired (8- and 9-mers of a 60 k text)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["one_walk", "two_walks_interleaved", "repeated_queries"])
+def test_line_native_records_under_the_per_thread_functions(fm, mode):
+    """fmindex/line_native.h: the same caller kernel -- a walk in the shape of nvBowtie's match_range (one rank(index, (x - 1, y), c) per symbol on an
+    index held by value) and locate_ssa_iterator / lookup_ssa_iterator over random rows -- on the production-layout fm_index WITH the line-native
+    records attached and WITHOUT them: every raw pair of counts of every step, every final range (emptied ones included), every iterator and every
+    position must be identical, and equal the oracle's.  Mode 1 interleaves two searches on one index object and mode 2 repeats queries, so that the
+    step a call keeps for its successor is found by calls it was not meant for.  The genome has exact and diverged repeats (long non-empty walks)."""
+    import torch
+    import nvbio_amd as nvb
+    fm.compat_fm_native_walk.argtypes = [C.c_uint32, C.c_uint32] + [C.c_void_p] * 5 + [C.c_uint32] * 3 + [C.c_void_p] * 4 + [C.c_uint32] + [C.c_void_p] * 3
+    rng = np.random.default_rng(91)
+    n = 300_007
+    text = rng.integers(0, 4, n, dtype=np.uint8)
+    fam = rng.integers(0, 4, 700, dtype=np.uint8)
+    for k in range(120):
+        at = int(rng.integers(0, n - 800)); c = fam.copy(); m = rng.random(c.size) < 0.01; c[m] = (c[m] + 1) & 3
+        text[at:at + c.size] = c
+    text[5000:5900] = np.tile(np.array([2, 0, 0, 3], np.uint8), 225)
+    host = O.FMIndex(text)
+    dev = torch.device("cuda:0")
+    fmi = nvb.FMIndexDevice.from_host(host, dev).with_dimer()
+    qlen, nq, nrows = 40, 30000, 50000
+    # the walk consumes query[0] first and PREPENDS every symbol: it searches for the reversed query.  Queries are therefore slices of the reversed
+    # genome (their reversals occur: walks that stay non-empty), followed by a stretch of unrelated random symbols (walks that run empty)
+    source = np.concatenate([text[::-1], rng.integers(0, 4, 60_000, dtype=np.uint8)])
+    starts = rng.integers(0, source.size - qlen, nq).astype(np.uint32)
+    starts[:3] = [0, n - qlen, n - 5900]
+    gw = np.concatenate([O.pack(source, 2, True, pad_words=0), np.zeros(8, np.uint32)])
+    rows = rng.integers(0, n + 1, nrows).astype(np.uint32)
+    rows[:4] = [0, n, host.primary, max(host.primary - 1, 0)]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
+    d_L2, d_ct, d_gw, d_st, d_rows = t(host.L2.astype(np.uint32)), t(np.zeros(256, np.uint32)), t(gw), t(starts), t(rows)
+    vp = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
+    outs = []
+    for native in (None, fmi.dimer):
+        ranges = torch.zeros((nq, 2), dtype=torch.int32, device=dev)
+        trace = torch.zeros((nq, 2 * qlen), dtype=torch.int32, device=dev)
+        its = torch.zeros((nrows, 2), dtype=torch.int32, device=dev)
+        posn = torch.zeros(nrows, dtype=torch.int32, device=dev)
+        assert fm.compat_fm_native_walk(n, host.primary, vp(d_L2), vp(fmi.bwt_occ), vp(d_ct), vp(fmi.ssa), vp(native), mode, nq, qlen, vp(d_gw), vp(d_st),
+                                        vp(ranges), vp(trace), nrows, vp(d_rows), vp(its), vp(posn)) == 0
+        outs.append([x.cpu().numpy().view(np.uint32) for x in (ranges, trace, its, posn)])
+    for a, b, what in zip(outs[0], outs[1], ("ranges", "step counts", "ssa iterators", "positions")):
+        assert (a == b).all(), "%s differ between the reference layout and the line-native records (%d of %d)" % (what, int((a != b).sum()), a.size)
+    assert not (outs[1][1] == 0xDEADBEEF).any()
+    # against the oracle: the walk consumes query[0] first, i.e. it is a backward search for the reversed slice
+    pats = [source[s:s + qlen][::-1] for s in starts]
+    exp = host.match(O.StringSet.from_lists(pats, 2, True))
+    assert (outs[1][0] == exp).all()
+    assert (outs[1][3] == host.locate(rows)).all()
+    emptied = int((exp[:, 0] > exp[:, 1]).sum())
+    assert 0 < emptied < nq

@@ -96,7 +96,7 @@ def write_records_se(out, ref, names, symbols, index, quals, best, mapq, cig, cl
         w, pos = int(best[0, i] & 0xFFFFFFFF), int(best[0, i] >> 32)
         seq, qual = symbols[index[i]:index[i + 1]], quals[index[i]:index[i + 1]]
         if pos == 0xFFFFFFFF:
-            out.write("%s\t%d\t*\t0\t0\t*\t*\t0\t0\t%s\t%s\n" % (names[i], 4 | extra_flags, "".join("ACGTN"[c] for c in seq), "".join(chr(int(q) + 33) for q in qual)))
+            out.write("%s\t4\t*\t0\t0\t*\t*\t0\t0\t%s\t%s\n" % (names[i], "".join("ACGTN"[c] for c in seq), "".join(chr(int(q) + 33) for q in qual)))
             continue
         rc = (w >> 28) & 1
         score, ed = ((w >> 1) & 0x1FFFF) * (-1 if w & 1 else 1), (w >> 18) & 0x3FF

@@ -160,7 +160,7 @@ def own_driver(prefix, sym, qual, sam_path, dev, batch_reads, digits=8, timings=
 
 
 def compare_sam(ref_path, own_path, show=5):
-    """-> (records of the reference, of the own driver, identical ones); byte comparison first, line by line only when that fails"""
+    """-> (records of the reference, of the own driver, identical ones, examples, categories); byte comparison first, line by line only when that fails"""
     def body(path):
         raw = np.fromfile(path, dtype=np.uint8)
         at = 0
@@ -171,23 +171,49 @@ def compare_sam(ref_path, own_path, show=5):
     a, b = body(ref_path), body(own_path)
     n_a, n_b = int((a == 10).sum()), int((b == 10).sum())
     if a.size == b.size and bool((a == b).all()):
-        return n_a, n_b, n_a, []
+        return n_a, n_b, n_a, [], {}
     la, lb = a.tobytes().split(b"\n"), b.tobytes().split(b"\n")
-    same, diffs = 0, []
+    same, diffs, cats = 0, [], {}
     for x, y in zip(la, lb):
         if x == y:
             same += 1 if x else 0
-        elif len(diffs) < show:
-            fx, fy = x.split(b"\t"), y.split(b"\t")
-            d = [i for i in range(min(len(fx), len(fy))) if fx[i] != fy[i]]
-            diffs.append(dict(fields=d, ref=[f.decode() for f in fx[:9] + fx[11:]], own=[f.decode() for f in fy[:9] + fy[11:]]))
-    return n_a, n_b, same, diffs
+            continue
+        fx, fy = x.split(b"\t"), y.split(b"\t")
+        d = [i for i in range(min(len(fx), len(fy))) if fx[i] != fy[i]]
+        ua, ub = (int(fx[1]) & 4) != 0, (int(fy[1]) & 4) != 0
+        if ua != ub:
+            cat = "aligned_vs_unaligned"
+        elif len(fx) > 12 and len(fy) > 12 and fx[12] != fy[12]:
+            cat = "different_score"                                            # AS:i differs
+        elif fx[4] != fy[4]:
+            cat = "same_score_different_mapq"
+        elif fx[2] != fy[2] or fx[3] != fy[3]:
+            cat = "same_score_and_mapq_other_placement"
+        else:
+            cat = "other_fields_%s" % ",".join(map(str, d))
+        cats[cat] = cats.get(cat, 0) + 1
+        if len(diffs) < show or (cats[cat] <= 3 and len(diffs) < 4 * show):
+            diffs.append(dict(category=cat, fields=d, ref=[f.decode() for f in fx[:9] + fx[11:]], own=[f.decode() for f in fy[:9] + fy[11:]]))
+    return n_a, n_b, same, diffs, cats
 
 
-def run(genome=3_000_000_000, reads=5_000_000, repeats=0.6, seed=0x5EED0009, batch_reads=1_000_000, profile=None, workdir=None, keep=False, extra=(), threads_test=False):
+def multiset_difference(path_a, path_b, show=6):
+    """records (header aside) of two SAM files as multisets -> (only in a, only in b, examples)"""
+    from collections import Counter
+    ca = Counter(l for l in open(path_a, "rb").read().split(b"\n") if l and not l.startswith(b"@"))
+    cb = Counter(l for l in open(path_b, "rb").read().split(b"\n") if l and not l.startswith(b"@"))
+    only_a, only_b = ca - cb, cb - ca
+    ex = [[f.decode() for f in l.split(b"\t")[:9] + l.split(b"\t")[11:]] for l in sorted(only_a)[:show]]
+    exb = [[f.decode() for f in l.split(b"\t")[:9] + l.split(b"\t")[11:]] for l in sorted(only_b)[:show]]
+    return sum(only_a.values()), sum(only_b.values()), ex, exb
+
+
+def run(genome=3_000_000_000, reads=5_000_000, repeats=0.6, seed=0x5EED0009, batch_reads=1_000_000, profile=None, workdir=None, keep=False, extra=(), threads_test=False, rerun=False):
     from nvbio_amd import workloads as W, io as nio
     dev = torch.device("cuda:0")
     out = dict(genome=genome, reads=reads, repeats=repeats, read_len=100)
+    if workdir:
+        os.makedirs(workdir, exist_ok=True)
     tmp = workdir or tempfile.mkdtemp(prefix="nvb3g_")
     prefix = os.path.join(tmp, "genome")
     t0 = time.time()
@@ -235,8 +261,15 @@ def run(genome=3_000_000_000, reads=5_000_000, repeats=0.6, seed=0x5EED0009, bat
     own_sam = os.path.join(tmp, "own.sam")
     own_driver(prefix, sym, qual, own_sam, dev, batch_reads, timings=out)
     t0 = time.time()
-    n_ref, n_own, same, diffs = compare_sam(ref_sam, own_sam)
-    out.update(records_ref=n_ref, records_own=n_own, identical=same, first_differences=diffs, compare_s=time.time() - t0)
+    n_ref, n_own, same, diffs, cats = compare_sam(ref_sam, own_sam)
+    out.update(records_ref=n_ref, records_own=n_own, identical=same, difference_categories=cats, first_differences=diffs, compare_s=time.time() - t0)
+    if rerun:
+        # the reference's application against itself: a second run on the same files
+        again = os.path.join(tmp, "ref2.sam")
+        r3 = subprocess.run(cmd[:-1] + [again], capture_output=True, text=True)
+        if r3.returncode == 0:
+            oa, ob, ex, exb = multiset_difference(ref_sam, again)
+            out["nvbowtie_rerun"] = dict(only_first=oa, only_second=ob, examples_first=ex, examples_second=exb)
     # aligned share and wide SA ranges seen, from the reference's SAM
     flags = []
     with open(ref_sam, "rb") as f:
@@ -254,12 +287,13 @@ def run(genome=3_000_000_000, reads=5_000_000, repeats=0.6, seed=0x5EED0009, bat
         out["nvbowtie_two_threads_wall_s"] = time.time() - t0
         out["nvbowtie_two_threads_exit"] = r2.returncode
         if r2.returncode == 0:
-            a = sorted(l for l in open(ref_sam, "rb").read().split(b"\n") if l and not l.startswith(b"@"))
-            b = sorted(l for l in open(mt_sam, "rb").read().split(b"\n") if l and not l.startswith(b"@"))
-            out["two_threads_same_multiset"] = a == b
+            oa, ob, ex, exb = multiset_difference(ref_sam, mt_sam)
+            out["two_threads_same_multiset"] = (oa == 0 and ob == 0)
+            out["two_threads_difference"] = dict(only_single=oa, only_two_threads=ob, examples_single=ex, examples_two_threads=exb)
         else:
             out["two_threads_log_tail"] = (r2.stdout + r2.stderr).replace("\r", "\n")[-1500:]
     if profile:
+        profile = os.path.abspath(profile)
         os.makedirs(profile, exist_ok=True)
         pr = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "-d", profile, "-o", "ref_nvbowtie_3gbp", "--"] + cmd[:-1] + [os.path.join(tmp, "prof.sam")],
                             capture_output=True, text=True, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp")
@@ -281,8 +315,13 @@ def main():
     ap.add_argument("--log", default=None, help="where to keep nvBowtie's own log")
     ap.add_argument("--two-threads", action="store_true", help="also run nvBowtie with --device 0 --device 0 and compare the records as a multiset")
     ap.add_argument("--extra", default="")
+    ap.add_argument("--rerun", action="store_true", help="run nvBowtie a second time and compare its two outputs")
+    ap.add_argument("--keep", default=None, help="work in this directory and keep the files")
     a = ap.parse_args()
-    out, log = run(int(a.genome), a.reads, a.repeats, batch_reads=a.batch_reads, profile=a.profile, extra=a.extra.split(), threads_test=a.two_threads)
+    out, log = run(int(a.genome), a.reads, a.repeats, batch_reads=a.batch_reads, profile=a.profile, extra=a.extra.split(), threads_test=a.two_threads, rerun=a.rerun,
+                   workdir=a.keep)
+    if a.keep:
+        os.makedirs(a.keep, exist_ok=True)
     if a.log:
         open(a.log, "w").write(log)
     text = json.dumps(out, indent=1, default=str)
