@@ -110,7 +110,7 @@ def parse():
     ap.add_argument("--genome", type=float, default=3.0e9, help="synthetic genome length of the FM-index legs (a true index is built on the device)")
     ap.add_argument("--rank-queries", type=int, default=1 << 28)
     ap.add_argument("--no-rank", action="store_true")
-    ap.add_argument("--only", choices=["dp", "rank", "seed", "e2e", "full", "extras", "compat"], default=None, help="profiling aid: run just one leg, print its object")
+    ap.add_argument("--only", choices=["dp", "rank", "seed", "e2e", "full", "extras", "compat", "refapp"], default=None, help="profiling aid: run just one leg, print its object")
     ap.add_argument("--seeds", type=int, default=50_000_000)
     ap.add_argument("--pairs", type=int, default=500_000, help="read pairs of the paired-end driver leg inside the e2e leg (0 = skip)")
     ap.add_argument("--share-pairs", type=int, default=25_000_000, help="config 5 at one GPU's share of 200 M pairs over 8 GPUs (0 = skip); runs in batches of --pairs")
@@ -122,6 +122,8 @@ def parse():
     ap.add_argument("--e2e-reads", type=int, default=10_000_000, help="reads per batch of the end-to-end seed+locate+extend leg")
     ap.add_argument("--e2e-batches", type=int, default=5, help="batches of the full-size run of BASELINE config 4 (5 x 10 M = 50 M reads)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-ref-app", action="store_true", help="skip the leg that runs the reference's own nvBowtie binary (oracle/_ref/ref_nvBowtie) at config-4 size")
+    ap.add_argument("--ref-app-reads", type=int, default=5_000_000)
     ap.add_argument("--cpu-sample", type=int, default=10_000_000)
     return ap.parse_args()
 
@@ -170,8 +172,11 @@ def main():
         a.no_e2e = a.only != "e2e"
         print(json.dumps(fm_legs(a, dev)))
         return
+    if a.only == "refapp":
+        print(json.dumps({"ref_nvbowtie_leg": ref_nvbowtie_leg(a, dev)}))
+        return
     if a.only == "dp":
-        a.no_rank = a.no_cpu = a.no_seed = a.no_e2e = a.no_full = True
+        a.no_rank = a.no_cpu = a.no_seed = a.no_e2e = a.no_full = a.no_ref_app = True
 
     # ---------------------------------------------------------------- inputs (resident before timing)
     n = a.reads
@@ -354,6 +359,9 @@ def main():
     if rank == 0 and world == 1 and not a.no_full:
         out["full_dp_leg"] = full_dp_leg(a, dev)
         out["compat_stream_leg"] = compat_stream_leg(a, dev)
+    if rank == 0 and world == 1 and not a.no_ref_app:
+        torch.cuda.empty_cache()
+        out["ref_nvbowtie_leg"] = ref_nvbowtie_leg(a, dev)
     if rank == 0 and world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_leg(a, *W.make_sw_batch(min(n, a.cpu_sample), READ_LEN, REF_LEN, seed=0x5EED0002, device=dev))
     # ---------------------------------------------------------------- nvBowtie end to end, sharded (N > 1): BASELINE config 4's "1 vs 8 GPU shard"
@@ -367,6 +375,35 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def ref_nvbowtie_leg(a, dev):
+    """BASELINE config 4 through the REFERENCE'S OWN APPLICATION: nvBowtie's 29 translation units compiled as they lie on the drop-in layer and linked
+    with libnvbio_hip.so (oracle/_ref/ref_nvBowtie, built where /root/reference exists) -- a caller of the product, not a checker -- on a 3 Gbp
+    repeat-rich synthetic genome written as .bwt/.sa/.rbwt/.rsa/.wpac/.ann/.amb and a FASTQ file, beside this repository's driver on the same files
+    (tools/nvbowtie_3gbp.py).  Reports nvBowtie's own per-stage device seconds and whether every SAM record of the two is identical."""
+    import re
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_nvBowtie")
+    if not os.path.exists(exe):
+        return {"skipped": "oracle/_ref/ref_nvBowtie is not built (needs /root/reference in the build container)"}
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import nvbowtie_3gbp as T
+        res, log = T.run(int(a.genome), a.ref_app_reads, 0.6)
+    except Exception as e:      # noqa: BLE001
+        return {"error": repr(e)[:500]}
+    stages = {}
+    for name, secs, dev_s in re.findall(r"stats\s+: \[0\]\s+(\w[\w ]*?)\s+: ([0-9.]+) sec \(.*?([0-9.]+) device sec\)", log.replace("\r", "\n")):
+        stages[name.strip()] = {"wall_s": float(secs), "device_ms": float(dev_s) * 1e3}
+    total = re.findall(r"stats\s+: \[0\]\s+total\s+: ([0-9.]+) sec", log)
+    out = {"genome": res.get("genome"), "repeats": res.get("repeats"), "reads": res.get("reads"), "index_files_GB": res.get("index_files_GB"),
+           "nvbowtie": {"exit": res.get("nvbowtie_exit"), "wall_s_incl_index_load_and_io": res.get("nvbowtie_wall_s"),
+                        "align_s": float(total[0]) if total else None, "reads_per_s": (res.get("reads") / float(total[0])) if total else None,
+                        "stages": stages, "line_native_records": os.environ.get("NVBIO_HIP_COMPAT_LINE_NATIVE", "1") != "0"},
+           "own_driver": {"align_s": res.get("own_align_s"), "reads_per_s": res.get("own_reads_per_s"), "batches": res.get("own_batches"), "sam_write_s": res.get("own_write_s")},
+           "records": res.get("records_ref"), "identical_records": res.get("identical"), "difference_categories": res.get("difference_categories"),
+           "every_record_identical": res.get("identical") is not None and res.get("identical") == res.get("records_ref") == res.get("records_own")}
+    return out
 
 
 def e2e_sharded_leg(a, dev, rank, world, barrier, cxx_comm=None):

@@ -428,3 +428,25 @@ def test_own_driver_equals_reference_nvbowtie_above_half_a_batch(cuda):
     same, n_ref, n_own = nvbowtie_compare.compare(argparse.Namespace(mode="se", reads=600_000, seed=31, indels=0.1, show=3))
     assert n_ref == n_own == 600_000
     assert same == n_ref, (same, n_ref)
+
+
+def test_reference_nvbowtie_equals_own_driver_at_3gbp():
+    """BASELINE config 4 as written -- a 3 Gbp index -- through the reference's own application: a repeat-rich synthetic genome (60 % of it diverged
+    copies of three repeat families, the largest with three million copies: SA ranges beyond 2^20 rows, rows above 2^31, MAPQ across its whole
+    range), its forward and reverse FM-indices written as the files nvBWT leaves, 5 M reads as FASTQ; the unchanged nvBowtie binary and this
+    repository's driver (same batches of 1024 K reads) must print the same SAM record for every read (tools/nvbowtie_3gbp.py)."""
+    import sys
+    exe = os.path.join(REF, "ref_nvBowtie")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_nvBowtie not built (needs /root/reference in the build container)")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import json
+    import nvbowtie_3gbp as T
+    out, log = T.run(3_000_000_000, 5_000_000, 0.6)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "nvbowtie_3gbp.json"), "w"), indent=1, default=str)
+    open(os.path.join(ROOT, "gpurun_out", "nvbowtie_3gbp.log"), "w").write(log)
+    assert out["nvbowtie_exit"] == 0, log[-2000:]
+    assert out["records_ref"] == out["records_own"] == 5_000_000
+    assert out["identical"] == 5_000_000, (out["difference_categories"], out["first_differences"][:3])
+    assert out["aligned_share_first_200k"] > 0.9

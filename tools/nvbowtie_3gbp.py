@@ -208,7 +208,7 @@ def multiset_difference(path_a, path_b, show=6):
     return sum(only_a.values()), sum(only_b.values()), ex, exb
 
 
-def run(genome=3_000_000_000, reads=5_000_000, repeats=0.6, seed=0x5EED0009, batch_reads=1_000_000, profile=None, workdir=None, keep=False, extra=(), threads_test=False, rerun=False):
+def run(genome=3_000_000_000, reads=5_000_000, repeats=0.6, seed=0x5EED0009, batch_reads=1 << 20, profile=None, workdir=None, keep=False, extra=(), threads_test=False, rerun=False):
     from nvbio_amd import workloads as W, io as nio
     dev = torch.device("cuda:0")
     out = dict(genome=genome, reads=reads, repeats=repeats, read_len=100)
@@ -309,7 +309,7 @@ def main():
     ap.add_argument("--genome", type=float, default=3e9)
     ap.add_argument("--reads", type=int, default=5_000_000)
     ap.add_argument("--repeats", type=float, default=0.6)
-    ap.add_argument("--batch-reads", type=int, default=1_000_000)
+    ap.add_argument("--batch-reads", type=int, default=1 << 20, help="reads per batch of the own driver: nvBowtie's default batch (1024 K reads), because the hits-per-read rule of both drivers reasons with the batch")
     ap.add_argument("--profile", default=None, help="directory for a second nvBowtie run under rocprofv3 --kernel-trace --stats")
     ap.add_argument("--json", default=None)
     ap.add_argument("--log", default=None, help="where to keep nvBowtie's own log")
