@@ -210,9 +210,16 @@ def main():
 
         flag = 1
         try:
-            if not on_nccl or os.environ.get("NVBIO_BENCH_TORCH_GATHER") == "1":
+            host_transport = os.environ.get("NVBIO_BENCH_HOST_TRANSPORT") == "1"
+            if host_transport:
+                # the production C++ gather with only ncclSend / ncclRecv replaced (nvbio_hip_comm_set_transport: gloo carries the bytes): what two
+                # ranks sharing one device -- where RCCL refuses to open -- can exercise of the N > 1 path (tests/test_bench_multirank_gpu.py)
+                from nvbio_amd.distributed import HostTransportComm
+                cxx_comm = HostTransportComm()
+            elif not on_nccl or os.environ.get("NVBIO_BENCH_TORCH_GATHER") == "1":
                 raise RuntimeError("C++ gather needs one device per rank")
-            cxx_comm = CxxComm()
+            else:
+                cxx_comm = CxxComm()
             pg = CxxRecordGather(cxx_comm, world * 4, 1, dst=0, device=dev)
             pg.gather(torch.full((4, 1), rank, dtype=torch.int32, device=dev))
             torch.cuda.synchronize()
@@ -222,7 +229,8 @@ def main():
             sys.stderr.write("bench: C++ / RCCL gather unavailable on rank %d (%s); trying torch.distributed\n" % (rank, e))
             flag = 0
         if agree(flag):
-            gather_path = "cxx_rccl (nvbio_hip_gather_records: grouped ncclSend/ncclRecv from C++)"
+            gather_path = ("cxx_host_transport (nvbio_hip_gather_records over a gloo-backed transport table)" if os.environ.get("NVBIO_BENCH_HOST_TRANSPORT") == "1"
+                           else "cxx_rccl (nvbio_hip_gather_records: grouped ncclSend/ncclRecv from C++)")
             cxx_g = [CxxRecordGather(cxx_comm, n * world, 1, dst=0, device=dev) for _ in range(2)]
         else:
             cxx_comm = None

@@ -755,7 +755,10 @@ int nvbio_hip_mapq(int32_t version, int32_t match, int32_t monotone, const int32
                    const uint32_t* read_len /* nullable */, uint32_t fixed_read_len, uint8_t* out_mapq, void* stream);
 
 /* The same calculators over BestPairedAlignments(anchor pair, opposite pair) (mapq.h:56-58, 156-166): when the best alignment
- * is paired, scores and the score range are the sums over both mates (version 2) / the quality is 44 (version 3). */
+ * is paired, scores and the score range are the sums over both mates (version 2) / the quality is 44 (version 3).  As for single-end
+ * reads, an UNALIGNED mate is evaluated too and does not get 0 here (the reference's functors do the same; its writers print 0 for a read
+ * they flag unmapped, output_sam.cpp:462): a consumer that wants "unaligned = 0" zeroes it itself, as this repository's SAM writers do
+ * (include/nvbio_hip/sam.h, tools/align_fastq.py; tests/test_io_formats.py checks the records of unaligned reads). */
 int nvbio_hip_mapq_paired(int32_t version, int32_t match, int32_t monotone, const int32_t* min_score_by_len /* device */,
                           uint32_t n_reads, const uint64_t* best_alignments, const uint64_t* best_alignments_o, uint32_t best_stride,
                           const uint32_t* read_len /* nullable */, const uint32_t* o_read_len /* nullable */,

@@ -237,4 +237,6 @@ class test_switch:
 
 def current_stream_ptr():
     import torch
+    if not torch.cuda.is_available():
+        return C.c_void_p(0)          # host-only use of the transport seam (the CPU suite's gather over host memory)
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)

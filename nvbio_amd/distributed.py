@@ -137,6 +137,99 @@ class CxxComm:
             self.comm = None
 
 
+class HostTransportComm:
+    """CxxComm's interface where RCCL cannot serve -- two ranks sharing one device (tests/test_bench_multirank_gpu.py), or no device at all
+    (the CPU suite): the transport seam of the C-ABI (nvbio_hip_comm_set_transport) is filled with functions that carry the bytes through
+    torch.distributed's gloo group, staged through host memory.  Everything above the seam -- nvbio_hip_gather_records, the gather plan, the
+    record tables of CxxRecordGather, bench.py's double-buffered gather -- is the code a multi-GPU node runs; only ncclSend / ncclRecv
+    themselves are replaced.  One per process (the transport table is process-wide)."""
+
+    def __init__(self, group=None):
+        import ctypes as C
+        from ._lib import lib
+        self.L, self.C, self.group = lib(), C, group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.on_device = torch.cuda.is_available()
+        self._queued = None            # receives posted inside a group, executed at its end (NCCL's group semantics)
+        vp, u64, ci = C.c_void_p, C.c_uint64, C.c_int
+        F = C.CFUNCTYPE
+
+        def guard(fn):
+            def wrapped(*a):
+                try:
+                    return fn(*a) or 0
+                except Exception as e:      # noqa: BLE001 -- an exception must not unwind through the C caller
+                    import sys
+                    sys.stderr.write("HostTransportComm: %r\n" % (e,))
+                    return 999
+            return wrapped
+
+        def f_rank(comm, r, w):
+            r[0], w[0] = self.rank, self.world
+
+        def f_start(comm):
+            self._queued = []
+
+        def f_end(comm):
+            q, self._queued = self._queued or [], None
+            for buf, nbytes, peer, stream in q:
+                self._recv_now(buf, nbytes, peer, stream)
+
+        def f_send(comm, buf, nbytes, peer, stream):
+            host = torch.empty(int(nbytes), dtype=torch.uint8)
+            self._copy(host.data_ptr(), buf, nbytes, 2, stream)
+            dist.send(host, dst=self._global(peer), group=self.group)
+
+        def f_recv(comm, buf, nbytes, peer, stream):
+            if self._queued is not None:
+                self._queued.append((buf, nbytes, peer, stream))
+            else:
+                self._recv_now(buf, nbytes, peer, stream)
+
+        def f_copy(comm, dst, src, nbytes, stream):
+            self._copy(dst, src, nbytes, 3, stream)
+
+        def f_abort(comm):
+            pass
+
+        self._types = (F(ci, vp, C.POINTER(ci), C.POINTER(ci)), F(ci, vp), F(ci, vp), F(ci, vp, vp, u64, ci, vp), F(ci, vp, vp, u64, ci, vp),
+                       F(ci, vp, vp, vp, u64, vp), F(ci, vp))
+        fns = (f_rank, f_start, f_end, f_send, f_recv, f_copy, f_abort)
+        self._callbacks = [t(guard(f)) for t, f in zip(self._types, fns)]           # kept alive for as long as the table is installed
+
+        class Table(C.Structure):
+            _fields_ = [(n, t) for n, t in zip(("rank", "group_start", "group_end", "send", "recv", "copy", "abort"), self._types)]
+        self._table = Table(*self._callbacks)
+        self.L.nvbio_hip_comm_set_transport.argtypes = [C.c_void_p]
+        self.L.nvbio_hip_comm_set_transport(C.byref(self._table))
+        self._token = C.c_int(self.rank)
+        self.comm = C.cast(C.pointer(self._token), C.c_void_p)                      # any non-null handle: the table's functions ignore it
+
+    def _global(self, peer):
+        return dist.get_global_rank(self.group, peer) if self.group is not None else peer
+
+    def _copy(self, dst, src, nbytes, kind, stream):
+        """kind: 1 host -> device, 2 device -> host, 3 device -> device (nvbio_hip_memcpy's); plain memmove without a device"""
+        if nbytes == 0:
+            return
+        if not self.on_device:
+            self.C.memmove(dst, src, int(nbytes)); return
+        from ._lib import check
+        check(self.L.nvbio_hip_memcpy(self.C.c_void_p(dst), self.C.c_void_p(src), self.C.c_uint64(nbytes), kind, self.C.c_void_p(stream)), "nvbio_hip_memcpy")
+        check(self.L.nvbio_hip_stream_synchronize(self.C.c_void_p(stream)), "nvbio_hip_stream_synchronize")
+
+    def _recv_now(self, buf, nbytes, peer, stream):
+        host = torch.empty(int(nbytes), dtype=torch.uint8)
+        dist.recv(host, src=self._global(peer), group=self.group)
+        self._copy(buf, host.data_ptr(), nbytes, 1, stream)
+
+    def close(self):
+        if self.comm:
+            self.L.nvbio_hip_comm_set_transport(None)
+            self.comm = None
+
+
 class CxxRecordGather:
     """RecordGather's interface over nvbio_hip_gather_records (grouped ncclSend / ncclRecv issued from C++ on the caller's current HIP
     stream): int32 records [n_r, width] from every rank to `dst`, in rank order, into ONE contiguous [n_total, width] table on the root."""

@@ -21,8 +21,14 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def test_two_ranks_share_one_gpu_through_the_whole_bench():
+@pytest.mark.parametrize("route", ["torch_fallback", "cxx_host_transport"])
+def test_two_ranks_share_one_gpu_through_the_whole_bench(route):
+    """route = cxx_host_transport: the C++ gather (nvbio_hip_gather_records, CxxRecordGather's tables, the e2e leg's record gather through
+    DeviceGroup's entry point) runs between the two processes with only ncclSend / ncclRecv swapped for gloo -- what is left unexercised on a
+    multi-GPU node is RCCL itself; route = torch_fallback: the C++ route declines and every rank falls back together."""
     env = dict(os.environ, NVBIO_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    if route == "cxx_host_transport":
+        env["NVBIO_BENCH_HOST_TRANSPORT"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--reads", "300000",
            "--genome", "4e6", "--e2e-reads", "40000"]
@@ -32,7 +38,8 @@ def test_two_ranks_share_one_gpu_through_the_whole_bench():
     assert len(lines) == 1, r.stdout[-2000:]                       # rank 0 prints ONE line
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "weak"
-    assert out["config"]["gather"] is True and out["config"]["gather_path"] == "torch.distributed.gather"
+    assert out["config"]["gather"] is True
+    assert out["config"]["gather_path"] == "torch.distributed.gather" if route == "torch_fallback" else out["config"]["gather_path"].startswith("cxx_host_transport")
     assert out["parity"]["bit_exact"] is True
     assert out["value"] > 0 and abs(out["value"] - 2 * 300000 * 4 / (out["ms_per_step"] * 4e-3)) / out["value"] < 1e-6
     leg = out["e2e_sharded_leg"]
@@ -40,5 +47,5 @@ def test_two_ranks_share_one_gpu_through_the_whole_bench():
     assert leg["n_gpus"] == 2 and leg["gather"] is True and leg["gathered_records_verified"] is True
     assert leg["aligned"] > 0.9 and leg["best_at_true_position"] > 0.8
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "bench_two_ranks_one_gpu.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "bench_two_ranks_one_gpu_%s.json" % route), "w") as f:
         f.write(lines[0] + "\n")
