@@ -196,7 +196,7 @@ static const char* full_bytes(const aligner_type aligner, const Args& a, const b
     return run< aln::BatchedAlignmentScore<stream_type, scheduler> >(stream, device);
 }
 
-// kind: 0 Gotoh, 1 Smith-Waterman, 2 edit distance, 3 Gotoh with the user-defined PhredGotohScheme
+// kind: 0 Gotoh, 1 Smith-Waterman, 2 edit distance, 3 Gotoh with the user-defined PhredGotohScheme, 4 the bit-vector banded edit distance (MyersTag<5>)
 template <typename F> static const char* with_type(const int type, F f)
 {
     if (type == 0) return f(std::integral_constant<aln::AlignmentType, aln::GLOBAL>());
@@ -224,6 +224,7 @@ API int compat_banded_score(int strings, int where, int kind, int type, int band
                         if (kind == 0) return banded_packed<B, aln::DeviceThreadScheduler>(aln::make_gotoh_aligner<TYPE>(g), a, true); \
                         if (kind == 1) return banded_packed<B, aln::DeviceThreadScheduler>(aln::make_smith_waterman_aligner<TYPE>(w), a, true); \
                         if (kind == 2) return banded_packed<B, aln::DeviceThreadScheduler>(aln::make_edit_distance_aligner<TYPE>(), a, true); \
+                        if (kind == 4) return banded_packed<B, aln::DeviceThreadScheduler>(aln::make_edit_distance_aligner<TYPE, aln::MyersTag<5> >(), a, true); \
                     } \
                     if (strings == 0 && where == 1 && kind == 0) return banded_packed<B, aln::HostThreadScheduler>(aln::make_gotoh_aligner<TYPE>(g), a, false); \
                     if (strings == 1 && where == 0) { \
@@ -231,6 +232,7 @@ API int compat_banded_score(int strings, int where, int kind, int type, int band
                         if (kind == 1) return banded_bytes<B, aln::DeviceThreadScheduler, aln::Best2Sink<int32> >(aln::make_smith_waterman_aligner<TYPE>(w), a, true); \
                         if (kind == 2) return banded_bytes<B, aln::DeviceThreadScheduler, aln::BestSink<int32> >(aln::make_edit_distance_aligner<TYPE>(), a, true); \
                         if (kind == 3) return banded_bytes<B, aln::DeviceThreadScheduler, aln::BestSink<int32> >(aln::make_gotoh_aligner<TYPE>(PhredGotohScheme()), a, true); \
+                        if (kind == 4) return banded_bytes<B, aln::DeviceThreadScheduler, aln::BestSink<int32> >(aln::make_edit_distance_aligner<TYPE, aln::MyersTag<5> >(), a, true); \
                     } \
                     if (strings == 1 && where == 1 && kind == 1) return banded_bytes<B, aln::HostThreadScheduler, aln::BestSink<int32> >(aln::make_smith_waterman_aligner<TYPE>(w), a, false); \
                 }

@@ -130,6 +130,43 @@ def test_packed_stream_runs_on_the_tuned_kernels(callers, typ, kind, scheme, ban
     assert (es == -(1 << 30)).sum() > 10          # refused jobs reach output() with the untouched sink
 
 
+@pytest.mark.parametrize("typ", [GLOBAL, SEMI])
+@pytest.mark.parametrize("packed", [True, False], ids=["packed", "bytes"])
+@pytest.mark.parametrize("band", [15, 31])
+def test_banded_bitvector_edit_distance_on_the_device(callers, typ, packed, band):
+    """EditDistanceAligner<TYPE, MyersTag<5>> through BatchedBandedAlignmentScore on the device (what examples/fmmap/fmmap.cu:359-367 calls): the
+    generic lanes run the banded bit-vector algorithm of alignment.h, against the oracle's restatement of myers_banded_inl.h.  The stream's
+    'no threshold' -2^30 narrows to an int16 0: only windows that hold the read exactly report -- reads with an N never do."""
+    rng = np.random.default_rng(40 + band + typ)
+    reads, quals, wins = [], [], []
+    for i in range(3000):
+        L = int(rng.integers(1, 140))
+        W = L + band if typ == GLOBAL else L + band + int(rng.integers(0, 9))
+        w = rng.integers(0, 4, W, dtype=np.uint8)
+        off = int(rng.integers(0, band))
+        r = w[off:off + L].copy()
+        if i % 3 == 0:
+            m = rng.random(L) < 0.03; r[m] = (r[m] + 1) & 3
+        if i % 5 == 0:
+            r[int(rng.integers(0, L))] = 4
+        if i % 41 == 40 and L > 3:
+            w = w[:L - 1]
+        reads.append(r); quals.append(np.zeros(L, np.uint8)); wins.append(w)
+    b = Batch(reads, quals, wins, packed=packed, on_device=True)
+    path = run_banded(callers, b, 0 if packed else 1, 0, 4, typ, band, (0, -1, -1, -1))
+    assert path == "generic"
+    es, ek = O.batch_banded_myers_score(band, typ, 5, b.hr, b.hw)
+    if not packed:                                   # (the byte-string stream of the test declines every 97th job: it is output as its context was built)
+        declined = (np.arange(b.n) % 97) == 96
+        es[declined] = -(1 << 30); ek[declined] = 0xFFFFFFFF
+    gs, gk = b.results()
+    assert (gs == es).all() and (gk == ek).all()
+    reported = es > -(1 << 30)
+    assert reported.sum() > 300 and (es[reported] == 0).all()
+    has_n = np.array([bool((r == 4).any()) for r in reads])
+    assert not reported[has_n].any()
+
+
 def test_packed_stream_outside_the_tuned_contract_falls_to_the_generic_lanes(callers):
     reads, quals, wins = make_jobs(7, 2000, band=15)
     b = Batch(reads, quals, wins, packed=True, on_device=True)

@@ -157,6 +157,10 @@ def test_reference_fmmap_runs_and_matches_the_oracle(tmp_path):
     score, _ = O.batch_banded_myers_score(31, O.SEMI_GLOBAL, 5, O.StringSet.from_lists(pats, 4, True), O.StringSet.from_lists(txts, 2, True), sink_bits=16)
     best = np.full(n, -32768, np.int64)
     np.maximum.at(best, np.array(who), score)
+    # (the program hands update_scores the HIT count, not the segment count reduce_by_key returns (fmmap.cu:376-393): the tail of its zero-initialised
+    # out_reads / out_scores vectors is folded in too, i.e. read 0 of a batch always ends with a score of at least 0 once a read has two hits)
+    if n_hits > len(set(who)):
+        best[0] = max(best[0], 0)
     expected = 100.0 * float((best >= -20).sum()) / n
     assert 20.0 < expected < 60.0
     assert abs(float(m[-1]) - expected) < 0.006, (m[-1], expected)
