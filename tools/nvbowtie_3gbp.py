@@ -123,7 +123,7 @@ def write_fastq(path, sym, qual, digits=8):
     rec.cpu().numpy().tofile(path)
 
 
-def own_driver(prefix, sym, qual, sam_path, dev, batch_reads, digits=8, timings=None):
+def own_driver(prefix, sym, qual, sam_path, dev, batch_reads, digits=8, timings=None, overrides=None):
     """this repository's driver over the same reads, batch by batch -> own.sam"""
     import align_fastq as AF
     from nvbio_amd import io as nio, aligner as A
@@ -135,7 +135,7 @@ def own_driver(prefix, sym, qual, sam_path, dev, batch_reads, digits=8, timings=
     torch.cuda.synchronize()
     t_load = time.time() - t0
     n, L = sym.shape
-    params = A.Params(hits_stride=32)
+    params = A.Params(hits_stride=32, **(overrides or {}))
     t_align, t_write, stats = 0.0, 0.0, []
     for s in range(0, n, batch_reads):
         e = min(n, s + batch_reads)
@@ -208,7 +208,7 @@ def multiset_difference(path_a, path_b, show=6):
     return sum(only_a.values()), sum(only_b.values()), ex, exb
 
 
-def run(genome=3_000_000_000, reads=5_000_000, repeats=0.6, seed=0x5EED0009, batch_reads=1 << 20, profile=None, workdir=None, keep=False, extra=(), threads_test=False, rerun=False):
+def run(genome=3_000_000_000, reads=5_000_000, repeats=0.6, seed=0x5EED0009, batch_reads=1 << 20, profile=None, workdir=None, keep=False, extra=(), threads_test=False, rerun=False, own_overrides=None):
     from nvbio_amd import workloads as W, io as nio
     dev = torch.device("cuda:0")
     out = dict(genome=genome, reads=reads, repeats=repeats, read_len=100)
@@ -259,7 +259,7 @@ def run(genome=3_000_000_000, reads=5_000_000, repeats=0.6, seed=0x5EED0009, bat
         return out, log
     # ---- this repository's driver
     own_sam = os.path.join(tmp, "own.sam")
-    own_driver(prefix, sym, qual, own_sam, dev, batch_reads, timings=out)
+    own_driver(prefix, sym, qual, own_sam, dev, batch_reads, timings=out, overrides=own_overrides)
     t0 = time.time()
     n_ref, n_own, same, diffs, cats = compare_sam(ref_sam, own_sam)
     out.update(records_ref=n_ref, records_own=n_own, identical=same, difference_categories=cats, first_differences=diffs, compare_s=time.time() - t0)
@@ -295,7 +295,7 @@ def run(genome=3_000_000_000, reads=5_000_000, repeats=0.6, seed=0x5EED0009, bat
     if profile:
         profile = os.path.abspath(profile)
         os.makedirs(profile, exist_ok=True)
-        pr = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "-d", profile, "-o", "ref_nvbowtie_3gbp", "--"] + cmd[:-1] + [os.path.join(tmp, "prof.sam")],
+        pr = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", profile, "-o", "ref_nvbowtie_3gbp", "--"] + cmd[:-1] + [os.path.join(tmp, "prof.sam")],
                             capture_output=True, text=True, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp")
         out["profile_exit"] = pr.returncode
     if not keep and workdir is None:
@@ -315,11 +315,16 @@ def main():
     ap.add_argument("--log", default=None, help="where to keep nvBowtie's own log")
     ap.add_argument("--two-threads", action="store_true", help="also run nvBowtie with --device 0 --device 0 and compare the records as a multiset")
     ap.add_argument("--extra", default="")
+    ap.add_argument("--own", default="", help="the same settings for this repository's driver: comma-separated Params fields, e.g. 'no_multi_hits=True'")
     ap.add_argument("--rerun", action="store_true", help="run nvBowtie a second time and compare its two outputs")
     ap.add_argument("--keep", default=None, help="work in this directory and keep the files")
     a = ap.parse_args()
+    overrides = {}
+    for kv in filter(None, a.own.split(",")):
+        k, v = kv.split("=")
+        overrides[k] = (v == "True") if v in ("True", "False") else int(v)
     out, log = run(int(a.genome), a.reads, a.repeats, batch_reads=a.batch_reads, profile=a.profile, extra=a.extra.split(), threads_test=a.two_threads, rerun=a.rerun,
-                   workdir=a.keep)
+                   workdir=a.keep, own_overrides=overrides)
     if a.keep:
         os.makedirs(a.keep, exist_ok=True)
     if a.log:
