@@ -290,9 +290,11 @@ NVB_API int nvbio_hip_device_free(void* ptr)
 {
     if (!ptr) return hipSuccess;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64 || !nvb::private_pool(dev)) {
+    static const bool sync_free = [] { const char* e = getenv("NVBIO_HIP_SYNC_FREE"); return e && e[0] == '1'; }();     // debugging aid: hipFree's blocking form
+    const bool have_dev = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+    if (sync_free || !have_dev || !nvb::private_pool(dev)) {
         if (hipError_t e = hipDeviceSynchronize()) return e;
-        return hipFree(ptr);
+        return (have_dev && nvb::private_pool(dev)) ? hipFreeAsync(ptr, nullptr) : hipFree(ptr);
     }
     std::lock_guard<std::mutex> lock(nvb::g_streams_mtx);
     hipStream_t& fence = nvb::g_fence[dev];

@@ -162,7 +162,7 @@ def test_banded_bitvector_edit_distance_on_the_device(callers, typ, packed, band
     gs, gk = b.results()
     assert (gs == es).all() and (gk == ek).all()
     reported = es > -(1 << 30)
-    assert reported.sum() > 300 and (es[reported] == 0).all()
+    assert reported.sum() > (300 if typ == SEMI else 20) and (es[reported] == 0).all()          # (GLOBAL: only a read sitting on the band's last diagonal ends at distance 0)
     has_n = np.array([bool((r == 4).any()) for r in reads])
     assert not reported[has_n].any()
 

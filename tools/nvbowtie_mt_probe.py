@@ -14,6 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def records(path):
     d = {}
+    if path is None or not os.path.exists(path):
+        return d
     for l in open(path, "rb").read().split(b"\n"):
         if l and not l.startswith(b"@"):
             d[l.split(b"\t", 1)[0]] = l
@@ -22,6 +24,7 @@ def records(path):
 
 def main():
     W = sys.argv[1]
+    extra_env = dict(kv.split("=") for kv in sys.argv[2:])
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_nvBowtie")
     rec = 215                                                          # bytes of one FASTQ record of tools/nvbowtie_3gbp.py
     b0, b1 = 1 << 20, 2 << 20
@@ -31,14 +34,22 @@ def main():
     out = {}
 
     def run(tag, args):
-        r = subprocess.run([exe] + args + ["--file-ref", "-x", os.path.join(W, "genome"), "-S", os.path.join(W, tag + ".sam")], capture_output=True, text=True)
-        out[tag + "_exit"] = r.returncode
+        try:
+            r = subprocess.run([exe] + args + ["--file-ref", "-x", os.path.join(W, "genome"), "-S", os.path.join(W, tag + ".sam")], capture_output=True, text=True, timeout=90,
+                               env=dict(os.environ, **extra_env))
+            out[tag + "_exit"] = r.returncode
+        except subprocess.TimeoutExpired as e:
+            out[tag + "_exit"] = "HUNG (90 s)"
+            txt = lambda x: x.decode(errors="replace") if isinstance(x, bytes) else (x or "")
+            out[tag + "_log_tail"] = (txt(e.stdout) + txt(e.stderr)).replace("\r", "\n")[-1500:]
+            return None
         return os.path.join(W, tag + ".sam")
 
     alone = records(run("b1_alone", ["-U", os.path.join(W, "batch1.fastq")]))
     full = records(os.path.join(W, "ref.sam"))
     mt1 = records(run("mt_a", ["--device", "0", "--device", "0", "-U", os.path.join(W, "reads.fastq")]))
     mt2 = records(run("mt_b", ["--device", "0", "--device", "0", "-U", os.path.join(W, "reads.fastq")]))
+    print(json.dumps(out), file=sys.stderr, flush=True)
     own = records(os.path.join(W, "own.sam")) if os.path.exists(os.path.join(W, "own.sam")) else {}
     names = list(alone.keys())
     out["batch1_reads"] = len(names)
