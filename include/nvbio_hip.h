@@ -868,8 +868,8 @@ int nvbio_hip_set_test_switch(const char* name, int value);     /* hipErrorInval
 int nvbio_hip_get_test_switch(const char* name);                /* -1 for an unknown name */
 /* Memory helpers: nvbio_hip_device_malloc / nvbio_hip_device_free take blocks from a private pool of the calling thread's current device.
  * nvbio_hip_device_free does not stop the host: the block returns to the pool after everything queued so far on the legacy default stream
- * (hence on every blocking stream) and on the streams made by nvbio_hip_stream_create has finished (a fence stream waits on an event per
- * stream).  Work on a non-blocking stream created elsewhere is not fenced -- synchronise it first.  Call it from a thread bound to the device
+ * (hence on every blocking stream) and on the streams made by nvbio_hip_stream_create has finished (it is parked with an event per
+ * stream and reclaimed at a later malloc / free).  Work on a non-blocking stream created elsewhere is not covered -- synchronise it first.  Call it from a thread bound to the device
  * the block lives on; per-batch storage lives in a hip::device_arena (include/nvbio_hip/types.h) and never comes through here. */
 
 /* Library / device introspection (host). */

@@ -40,6 +40,7 @@
 #include <mutex>
 #include <atomic>
 #include <vector>
+#include <deque>
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>
@@ -261,6 +262,46 @@ static hipMemPool_t private_pool(int dev)
     return pools[dev];
 }
 } // namespace nvb
+// nvbio_hip_device_free keeps hipFree's contract for the streams this library knows -- the legacy default stream (and through it every blocking
+// stream) and the streams made by nvbio_hip_stream_create -- WITHOUT stopping the host: the block is parked with one event recorded in each of
+// those streams and goes back to the pool (on the default stream, by which time nothing uses it) once every event has completed; the parked
+// blocks are polled at the next malloc / free.  The calling thread returns at once; another driver thread's batch in flight is not waited for.
+// Nothing is ever freed on, or waited for by, a stream other than the default one: the pool sees plain same-stream alloc / free traffic.
+// (Work queued on a non-blocking stream created elsewhere is not covered: synchronise such a stream before freeing.  More than 512 parked
+// blocks: the oldest is waited for.)
+namespace nvb {
+static std::mutex g_streams_mtx;
+static std::vector<hipStream_t> g_streams[64];
+struct ParkedBlock { void* ptr; std::vector<hipEvent_t> events; };
+static std::deque<ParkedBlock> g_parked[64];
+static void register_stream(int dev, hipStream_t s) { if (dev >= 0 && dev < 64) { std::lock_guard<std::mutex> lock(g_streams_mtx); g_streams[dev].push_back(s); } }
+static void forget_stream(hipStream_t s)
+{
+    std::lock_guard<std::mutex> lock(g_streams_mtx);
+    for (auto& v : g_streams) v.erase(std::remove(v.begin(), v.end(), s), v.end());
+}
+// (g_streams_mtx held)  return every parked block whose events have all completed; wait_oldest: block on the first one that has not
+static void reclaim_parked(int dev, bool wait_oldest)
+{
+    std::deque<ParkedBlock>& q = g_parked[dev];
+    while (!q.empty())
+    {
+        ParkedBlock& b = q.front();
+        bool done = true;
+        for (hipEvent_t ev : b.events)
+        {
+            hipError_t e = hipEventQuery(ev);
+            if (e == hipErrorNotReady && wait_oldest) e = hipEventSynchronize(ev);
+            if (e == hipErrorNotReady) { (void)hipGetLastError(); done = false; break; }
+        }
+        if (!done) break;
+        for (hipEvent_t ev : b.events) (void)hipEventDestroy(ev);
+        (void)hipFreeAsync(b.ptr, nullptr);
+        q.pop_front();
+        wait_oldest = false;
+    }
+}
+} // namespace nvb
 NVB_API int nvbio_hip_device_malloc(void** ptr, uint64_t bytes)
 {
     if (!ptr) return hipErrorInvalidValue;
@@ -268,24 +309,10 @@ NVB_API int nvbio_hip_device_malloc(void** ptr, uint64_t bytes)
     if (hipError_t e = hipGetDevice(&dev)) return e;
     hipMemPool_t pool = nvb::private_pool(dev);
     if (!pool) return hipMalloc(ptr, bytes ? bytes : 1);
+    if (dev >= 0 && dev < 64) { std::lock_guard<std::mutex> lock(nvb::g_streams_mtx); nvb::reclaim_parked(dev, false); }
     if (hipError_t e = hipMallocFromPoolAsync(ptr, bytes ? bytes : 1, pool, nullptr)) return e;
     return hipStreamSynchronize(nullptr);          // like hipMalloc: the block is usable from every stream on return
 }
-// nvbio_hip_device_free keeps hipFree's contract for the streams this library knows -- the legacy default stream (and through it every blocking
-// stream) and the streams made by nvbio_hip_stream_create -- WITHOUT stopping the host: a fence stream waits on an event recorded in each of
-// them, and the block goes back to the pool in that fence stream's order.  The calling thread returns at once; another driver thread's batch in
-// flight is not waited for.  (Work queued on a non-blocking stream created elsewhere is not fenced: synchronise such a stream before freeing.)
-namespace nvb {
-static std::mutex g_streams_mtx;
-static std::vector<hipStream_t> g_streams[64];
-static hipStream_t g_fence[64] = {};
-static void register_stream(int dev, hipStream_t s) { if (dev >= 0 && dev < 64) { std::lock_guard<std::mutex> lock(g_streams_mtx); g_streams[dev].push_back(s); } }
-static void forget_stream(hipStream_t s)
-{
-    std::lock_guard<std::mutex> lock(g_streams_mtx);
-    for (auto& v : g_streams) v.erase(std::remove(v.begin(), v.end(), s), v.end());
-}
-} // namespace nvb
 NVB_API int nvbio_hip_device_free(void* ptr)
 {
     if (!ptr) return hipSuccess;
@@ -297,19 +324,26 @@ NVB_API int nvbio_hip_device_free(void* ptr)
         return (have_dev && nvb::private_pool(dev)) ? hipFreeAsync(ptr, nullptr) : hipFree(ptr);
     }
     std::lock_guard<std::mutex> lock(nvb::g_streams_mtx);
-    hipStream_t& fence = nvb::g_fence[dev];
-    if (!fence) { if (hipError_t e = hipStreamCreateWithFlags(&fence, hipStreamNonBlocking)) { fence = nullptr; return e; } }
-    auto wait_on = [&](hipStream_t s) -> hipError_t {
+    nvb::reclaim_parked(dev, nvb::g_parked[dev].size() >= 512u);
+    nvb::ParkedBlock b; b.ptr = ptr;
+    auto mark = [&](hipStream_t s) -> hipError_t {
         hipEvent_t ev = nullptr;
         if (hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) return e;
-        hipError_t e = hipEventRecord(ev, s);
-        if (e == hipSuccess) e = hipStreamWaitEvent(fence, ev, 0);
-        (void)hipEventDestroy(ev);                     // released by the runtime once it has completed
-        return e;
+        if (hipError_t e = hipEventRecord(ev, s)) { (void)hipEventDestroy(ev); return e; }
+        b.events.push_back(ev);
+        return hipSuccess;
     };
-    if (hipError_t e = wait_on(nullptr)) return e;
-    for (hipStream_t s : nvb::g_streams[dev]) if (hipError_t e = wait_on(s)) return e;
-    return hipFreeAsync(ptr, fence);
+    hipError_t e = mark(nullptr);
+    for (size_t k = 0; e == hipSuccess && k < nvb::g_streams[dev].size(); ++k) e = mark(nvb::g_streams[dev][k]);
+    if (e != hipSuccess)
+    {   // could not mark a stream: fall back to the blocking form for this block
+        for (hipEvent_t ev : b.events) (void)hipEventDestroy(ev);
+        (void)hipGetLastError();
+        if (hipError_t es = hipDeviceSynchronize()) return es;
+        return hipFreeAsync(ptr, nullptr);
+    }
+    nvb::g_parked[dev].push_back(std::move(b));
+    return hipSuccess;
 }
 // ---- streams for the C++ host layer (which has no HIP headers).  The reference's drivers run on the default stream of one host thread
 // per device (nvBowtie.cpp:809-864); here one device serves several batches at once: a driver object per host thread, each on its own
