@@ -152,3 +152,34 @@ extern "C" uint32 read_set_infixes(const uint32* words, const uint32* offsets, u
     }
     return total;
 }
+
+// ---- the randomized hit selection the way nvBowtie's kernels run it over the drop-in SumTree (select.cu:86-102, select_inl.h:146-175, 200-252):
+//      leaves 1 / delta^2, LCG draws, sample(), pop_front, zero an emptied hit's leaf -- the picks of `rounds` rounds for one read
+#include <nvbio/basic/sum_tree.h>
+extern "C" uint32 sum_tree_picks(uint32 n_hits, const uint32* begins, uint32* deltas /* 20-bit, modified */, uint32 rseed, uint32 rounds, float* cells /* node_count(n_hits) */,
+                                 uint32* out_rows, uint32* out_hit)
+{
+    typedef SumTree<float*> ProbTree;
+    std::vector<uint32> begin(begins, begins + n_hits);
+    for (uint32 i = 0; i < n_hits; ++i) cells[i] = 1.0f / (float(deltas[i]) * float(deltas[i]));
+    ProbTree tree(n_hits ? n_hits : 1u, cells);
+    tree.setup();
+    uint32 made = 0;
+    for (uint32 r = 0; r < rounds; ++r)
+    {
+        if (tree.sum() <= 0.0f) break;
+        uint32 hit_id = 0; bool found = false;
+        for (uint32 i = 0; i < 10 && !found; ++i)
+        {
+            rseed = 1664525u * rseed + 1013904223u;
+            const float rf = float(rseed) / float(0xFFFFFFFFu);
+            const uint32 id = sample(tree, rf);
+            if (deltas[id] != 0u) { hit_id = id; found = true; }
+        }
+        if (deltas[hit_id] == 0u) break;
+        out_rows[made] = begin[hit_id]++; out_hit[made] = hit_id; ++made;
+        deltas[hit_id] = (deltas[hit_id] - 1u) & 0xFFFFFu;
+        if (deltas[hit_id] == 0u) tree.set(hit_id, 0.0f);
+    }
+    return made;
+}

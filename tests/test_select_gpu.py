@@ -70,6 +70,14 @@ def test_select_rounds_match_oracle(cuda, randomized, n_multi, top_seed, stride)
     _select_rounds(cuda, randomized, n_multi, top_seed, stride)
 
 
+@pytest.mark.parametrize("n_multi", [1, 4])
+@pytest.mark.parametrize("stride", [16, 32, 40])
+def test_select_rounds_over_wide_ranges_match_oracle(cuda, n_multi, stride):
+    """The same rounds over deques as a repeat-rich 3 Gbp index fills them: ranges from one row to 2^20 - 1 rows in one deque, i.e. leaves
+    twelve orders of magnitude apart -- where the float arithmetic of sample() decides among the wide ranges only after the narrow ones ran out."""
+    _select_rounds(cuda, True, n_multi, 0, stride, wide=True, max_rounds=60)
+
+
 @pytest.mark.parametrize("lanes", ["1", "4"])
 @pytest.mark.parametrize("n_multi", [1, 4])
 @pytest.mark.parametrize("stride", [8, 16, 32])
@@ -89,10 +97,28 @@ def _leaves_match(g_probs, e_probs, counts):
     return bool((g[:, :w][mask] == e[:, :w][mask]).all())
 
 
-def _select_rounds(cuda, randomized, n_multi, top_seed, stride):
+def _wide_deques(rng, n_reads, stride):
+    """deques the way a repeat-rich 3 Gbp index fills them: SA ranges from 1 row to the 20 bits a SeedHit keeps (leaves 1 / delta^2 from 1 down to 1e-12)"""
+    push, _, _ = O.hit_deque_ops()
+    hits = np.zeros((n_reads, stride), np.uint64)
+    counts = np.zeros(n_reads, np.uint32)
+    for r in range(n_reads):
+        k = int(rng.integers(1, min(stride, 14) + 1))
+        for j in range(k):
+            kind = int(rng.integers(0, 4))
+            size = int(rng.integers(1, 40)) if kind == 0 else int(rng.integers(300, 5000)) if kind == 1 else int(rng.integers(100_000, 1 << 20))
+            begin = int(rng.integers(0, 3_000_000_000 - (1 << 21)))
+            flags = (int(rng.integers(0, 1 << 10)) << 20) | (int(rng.integers(0, 4)) << 30)
+            hits[r, j] = np.uint64(((size | flags) << 32) | begin)
+            push(hits[r], j + 1)
+        counts[r] = k
+    return hits, counts
+
+
+def _select_rounds(cuda, randomized, n_multi, top_seed, stride, wide=False, max_rounds=2000):
     rng = np.random.default_rng(40 + n_multi + 2 * top_seed + 100 * stride)
     n = 3000
-    hits, counts = _random_deques(rng, n, stride, max_size=min(stride, 16))
+    hits, counts = _wide_deques(rng, n, stride) if wide else _random_deques(rng, n, stride, max_size=min(stride, 16))
     names = ["r%d/%d" % (i, i * 7919 % 13) for i in range(n)]
     arena, idx = O.pack_names(names)
     e_probs, e_trys, e_rseeds = O.select_init(hits, counts, arena, idx, 15, randomized, top_seed)
@@ -121,6 +147,8 @@ def _select_rounds(cuda, randomized, n_multi, top_seed, stride):
         if randomized:
             assert (u(st.rseeds) == e_rseeds).all() and _leaves_match(st.probs, e_probs, counts)
         rounds += 1; total += e_loc.size
+        if wide and rounds >= max_rounds:
+            break
         assert rounds < 2000
     assert rounds > 3 and total > n
 

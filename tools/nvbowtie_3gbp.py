@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 FAMILIES = [(200, 1.0 / 3.0, 0.01), (1500, 1.0 / 3.0, 0.01), (5000, 1.0 / 3.0, 0.015)]
 
 
-def make_genome(n, repeats, seed, dev):
+def make_genome(n, repeats, seed, dev, families=None):
     """uint8 symbol tensor of length n.  Repeat copies sit on a grid of their family's length (no two copies of a family overlap), families are
     laid down one after the other: the result is a deterministic function of (n, repeats, seed)."""
     g = torch.Generator(device=dev); g.manual_seed(seed)
@@ -42,7 +42,7 @@ def make_genome(n, repeats, seed, dev):
         e = min(n, s + (1 << 28))
         text[s:e] = torch.randint(0, 4, (e - s,), dtype=torch.uint8, generator=g, device=dev)
     placed = []
-    for L, share, div in FAMILIES:
+    for L, share, div in (families or FAMILIES):
         copies = int(repeats * share * n / L)
         if copies == 0:
             continue
@@ -208,7 +208,7 @@ def multiset_difference(path_a, path_b, show=6):
     return sum(only_a.values()), sum(only_b.values()), ex, exb
 
 
-def run(genome=3_000_000_000, reads=5_000_000, repeats=0.6, seed=0x5EED0009, batch_reads=1 << 20, profile=None, workdir=None, keep=False, extra=(), threads_test=False, rerun=False, own_overrides=None):
+def run(genome=3_000_000_000, reads=5_000_000, repeats=0.6, seed=0x5EED0009, batch_reads=1 << 20, profile=None, workdir=None, keep=False, extra=(), threads_test=False, rerun=False, own_overrides=None, families=None):
     from nvbio_amd import workloads as W, io as nio
     dev = torch.device("cuda:0")
     out = dict(genome=genome, reads=reads, repeats=repeats, read_len=100)
@@ -217,7 +217,7 @@ def run(genome=3_000_000_000, reads=5_000_000, repeats=0.6, seed=0x5EED0009, bat
     tmp = workdir or tempfile.mkdtemp(prefix="nvb3g_")
     prefix = os.path.join(tmp, "genome")
     t0 = time.time()
-    text, placed = make_genome(genome, repeats, seed, dev)
+    text, placed = make_genome(genome, repeats, seed, dev, families)
     out["repeat_families"] = [dict(length=L, copies=c) for L, c in placed]
     torch.cuda.synchronize(); out["genome_s"] = time.time() - t0
     n_seq = 24
@@ -315,6 +315,7 @@ def main():
     ap.add_argument("--log", default=None, help="where to keep nvBowtie's own log")
     ap.add_argument("--two-threads", action="store_true", help="also run nvBowtie with --device 0 --device 0 and compare the records as a multiset")
     ap.add_argument("--extra", default="")
+    ap.add_argument("--families", default="", help="repeat families as length:share:divergence,... (shares of the --repeats budget; default 200:1/3:0.01,1500:1/3:0.01,5000:1/3:0.015)")
     ap.add_argument("--own", default="", help="the same settings for this repository's driver: comma-separated Params fields, e.g. 'no_multi_hits=True'")
     ap.add_argument("--rerun", action="store_true", help="run nvBowtie a second time and compare its two outputs")
     ap.add_argument("--keep", default=None, help="work in this directory and keep the files")
@@ -324,7 +325,8 @@ def main():
         k, v = kv.split("=")
         overrides[k] = (v == "True") if v in ("True", "False") else int(v)
     out, log = run(int(a.genome), a.reads, a.repeats, batch_reads=a.batch_reads, profile=a.profile, extra=a.extra.split(), threads_test=a.two_threads, rerun=a.rerun,
-                   workdir=a.keep, own_overrides=overrides)
+                   workdir=a.keep, own_overrides=overrides,
+                   families=[(int(f.split(":")[0]), float(f.split(":")[1]), float(f.split(":")[2])) for f in a.families.split(",")] if a.families else None)
     if a.keep:
         os.makedirs(a.keep, exist_ok=True)
     if a.log:
