@@ -84,6 +84,9 @@ def hits_per_read(n_active, n_ext, params):
     return 1
 
 
+TRACE = None        # {"read": id in the batch, "events": []} to record one read's picks
+
+
 def best_approx_score(fmi, rfmi, state, seed_queue, best, batch, genome_words, genome_len, aligner, params, band_len, stats, best_sink=None):
     """Aligner::best_approx_score: the extension rounds of one seeding pass (`state` = select_init's output)."""
     active = seed_queue.to(torch.int32)                                   # pack_read(params.top_seed), defs.h:185-205
@@ -98,6 +101,10 @@ def best_approx_score(fmi, rfmi, state, seed_queue, best, batch, genome_words, g
             break
         if loc.numel() == 0:
             continue
+        traced = None
+        if TRACE is not None:                   # debugging aid: the SA rows picked for one read, round by round (tools/nvbowtie_subset_probe.py)
+            traced = (rid == TRACE["read"]).nonzero().flatten()
+            rows = loc[traced].cpu().tolist()
         with _Stage(stats, "locate"):
             sel.locate_hits(fmi, rfmi, loc, seed)
         with _Stage(stats, "score"):
@@ -117,6 +124,9 @@ def best_approx_score(fmi, rfmi, state, seed_queue, best, batch, genome_words, g
         with _Stage(stats, "reduce"):
             sel.score_reduce_best_approx(best, state, active, hit_begin, score, loc, seed, WORST_SCORE, n_ext, params.min_ext, params.max_ext,
                                          params.max_effort, fixed_read_len=batch.fixed_len, read_len=batch.read_len, hit_sink=hit_sink, best_sink=best_sink)
+        if traced is not None and traced.numel():
+            TRACE["events"].append(dict(n_ext=n_ext, sa_rows=[r & 0xFFFFFFFF for r in rows], seeds=[x & 0xFFFFFFFF for x in seed[traced].cpu().tolist()],
+                                        positions=[x & 0xFFFFFFFF for x in loc[traced].cpu().tolist()], scores=score[traced].cpu().tolist()))
         stats["extensions"] += int(loc.numel()); stats["rounds"] += 1
         n_ext += n_multi
 
@@ -258,6 +268,10 @@ def best_approx_score_paired(fmi, rfmi, state, seed_queue, anchor, best, best_o,
             break
         if loc.numel() == 0:
             continue
+        traced = None
+        if TRACE is not None:                   # debugging aid: the SA rows picked for one read, round by round (tools/nvbowtie_subset_probe.py)
+            traced = (rid == TRACE["read"]).nonzero().flatten()
+            rows = loc[traced].cpu().tolist()
         with _Stage(stats, "locate"):
             sel.locate_hits(fmi, rfmi, loc, seed)
         with _Stage(stats, "anchor_score"):
@@ -292,6 +306,9 @@ def best_approx_score_paired(fmi, rfmi, state, seed_queue, anchor, best, best_o,
             sel.score_reduce_paired_best_approx(best, best_o, state, active, hit_begin, loc, hit_sink, hit_score, seed, o_loc, o_sink, o_sink2, o_score, o_score2,
                                                 anchor, params.pe_policy, params.pe_unpaired, WORST_SCORE, n_ext, params.min_ext, params.max_ext,
                                                 params.max_effort, L)
+        if traced is not None and traced.numel():
+            TRACE["events"].append(dict(n_ext=n_ext, sa_rows=[r & 0xFFFFFFFF for r in rows], seeds=[x & 0xFFFFFFFF for x in seed[traced].cpu().tolist()],
+                                        positions=[x & 0xFFFFFFFF for x in loc[traced].cpu().tolist()], scores=score[traced].cpu().tolist()))
         stats["extensions"] += int(loc.numel()); stats["rounds"] += 1
         n_ext += n_multi
     stats["opposite_extensions"] += int(n_valid_dev)
