@@ -5,7 +5,7 @@
 // An interval heap in array form: slots 2k / 2k+1 hold the lower / upper bound of node k; slot 0 is a minimum under Compare
 // (bottom()), slot 1 -- slot 0 when alone -- a maximum (top()).  Which of several equivalent elements surfaces first depends on
 // the exchanges made, and nvBowtie's selection stage samples the array slots directly, so the exchange sequence is the
-// reference's (interval_heap.h:195-260, 389-533), element for element -- the same restatement the device kernels carry for
+// reference's (interval_heap.h:195-260, 356-533), element for element -- the same restatement the device kernels carry for
 // SeedHit words (nvbio_amd/csrc/hit_deque.h), pinned by replaying operation programs recorded from the reference's compiled
 // heap (tests/golden/hit_deque_vectors.npz).
 #pragma once
@@ -67,15 +67,29 @@ struct priority_deque
 private:
     NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool before(const int i, const int j) { return m_comp(m_seq[i], m_seq[j]); }
     NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void swap_slots(const int i, const int j) { const Type t = m_seq[i]; m_seq[i] = m_seq[j]; m_seq[j] = t; }
+    /// the bottom-up construction (make_interval_heap, interval_heap.h:356-384): node pairs from the last one to the first, each put in order and
+    /// sifted down inside its own subtree (`stop` = the slot below which the way back up ends).  nvBowtie runs it on every hits[read_id] its
+    /// selection kernels take -- SeedHitDequeArrayDeviceView::get_deque() passes constructed = false (seed_hit_deque_array_inl.h:104-109) -- over hits
+    /// whose ranges shrank since the last round, so the arrangement it leaves is part of the results.
     NVBIO_HOST_DEVICE void heapify()
     {
-        // re-insert the elements one by one over the same storage
         const int n = int(size());
-        for (int k = 1; k <= n; ++k) { if ((k - 1) & 1) leaf_upper(k, k - 1); else leaf_lower(k, k - 1); }
+        if (n <= 1) return;
+        const int end_parent = n / 2 - 1;
+        int i = n ^ (n & 1);
+        do
+        {
+            i -= 2;
+            const int stop = (i <= end_parent) ? (i * 2 + 2) : n;
+            if (before(i + 1, i)) swap_slots(i + 1, i);
+            sift_down(n, i + 1, false, stop);
+            sift_down(n, i, true, stop);
+        }
+        while (i >= 2);
     }
-    NVBIO_HOST_DEVICE void sift_up(int i, const bool lower)
+    NVBIO_HOST_DEVICE void sift_up(int i, const bool lower, const int stop = 2)
     {
-        while (i >= 2)
+        while (i >= stop)
         {
             const int parent = ((i / 2 - 1) | 1) ^ (lower ? 1 : 0);
             if (!(lower ? before(i, parent) : before(parent, i))) break;
@@ -84,20 +98,20 @@ private:
         }
     }
     /// slot i, on the upper side of a leaf of an n-element heap, may be out of place
-    NVBIO_HOST_DEVICE void leaf_upper(const int n, const int i)
+    NVBIO_HOST_DEVICE void leaf_upper(const int n, const int i, const int stop = 2)
     {
         const int co = (i * 2 < n) ? i * 2 : (i ^ 1);
-        if (before(i, co)) { swap_slots(i, co); sift_up(co, true); }
-        else sift_up(i, false);
+        if (before(i, co)) { swap_slots(i, co); sift_up(co, true, stop); }
+        else sift_up(i, false, stop);
     }
-    NVBIO_HOST_DEVICE void leaf_lower(const int n, const int i)
+    NVBIO_HOST_DEVICE void leaf_lower(const int n, const int i, const int stop = 2)
     {
         int co = i | 1;
         if (co >= n) { if (co == 1) return; co = (co / 2 - 1) | 1; }
-        if (before(co, i)) { swap_slots(i, co); sift_up(co, false); }
-        else sift_up(i, true);
+        if (before(co, i)) { swap_slots(i, co); sift_up(co, false, stop); }
+        else sift_up(i, true, stop);
     }
-    NVBIO_HOST_DEVICE void sift_down(const int n, int i, const bool lower)
+    NVBIO_HOST_DEVICE void sift_down(const int n, int i, const bool lower, const int stop = 2)
     {
         const int end_parent = n / 2 - ((lower && (n & 3) == 0) ? 2 : 1);
         while (i < end_parent)
@@ -116,14 +130,14 @@ private:
                 {
                     ++child;
                     swap_slots(i, child);
-                    leaf_lower(n, child);
+                    leaf_lower(n, child, stop);
                     return;
                 }
                 swap_slots(i, child);
                 i = child;
             }
         }
-        if (lower) leaf_lower(n, i); else leaf_upper(n, i);
+        if (lower) leaf_lower(n, i, stop); else leaf_upper(n, i, stop);
     }
 
     Sequence m_seq;

@@ -3,7 +3,7 @@
 //
 // Replaces priority_deque<SeedHit, vector_view<SeedHit*>, hit_compare> (nvbio/basic/priority_deque.h:329-421,
 // nvBowtie/bowtie2/cuda/seed_hit_deque_array.h:175-354) over the interval heap of nvbio/basic/interval_heap.h
-// (:195-260, :389-533) with hit_compare = "larger range first" (seed_hit.h:235-244): even slots are interval
+// (:195-260, :356-533) with hit_compare = "larger range first" (seed_hit.h:235-244): even slots are interval
 // lower bounds, odd slots upper bounds; slot 0 holds a hit of largest range (what pop_bottom drops when the
 // deque is full), slot 1 (slot 0 when alone) a hit of smallest range (top(): what the selection stage
 // extends first).  The array order decides which of several equal-sized hits is met first -- by top() and by
@@ -22,29 +22,29 @@ struct HitDeque
     __device__ __forceinline__ static bool before(const uint2 f, const uint2 s) { return (f.y & 0xFFFFFu) > (s.y & 0xFFFFFu); }
     __device__ __forceinline__ void swap(const int i, const int j) const { const uint2 t = a[i]; a[i] = a[j]; a[j] = t; }
 
-    __device__ void sift_up(int i, const bool lower) const
+    __device__ void sift_up(int i, const bool lower, const int stop = 2) const
     {
-        while (i >= 2) {
+        while (i >= stop) {
             const int parent = ((i / 2 - 1) | 1) ^ (lower ? 1 : 0);
             if (!(lower ? before(a[i], a[parent]) : before(a[parent], a[i]))) break;
             swap(i, parent);
             i = parent;
         }
     }
-    __device__ void leaf_upper(const int n, const int i) const
+    __device__ void leaf_upper(const int n, const int i, const int stop = 2) const
     {
         const int co = (i * 2 < n) ? i * 2 : (i ^ 1);
-        if (before(a[i], a[co])) { swap(i, co); sift_up(co, true); }
-        else sift_up(i, false);
+        if (before(a[i], a[co])) { swap(i, co); sift_up(co, true, stop); }
+        else sift_up(i, false, stop);
     }
-    __device__ void leaf_lower(const int n, const int i) const
+    __device__ void leaf_lower(const int n, const int i, const int stop = 2) const
     {
         int co = i | 1;
         if (co >= n) { if (co == 1) return; co = (co / 2 - 1) | 1; }
-        if (before(a[co], a[i])) { swap(i, co); sift_up(co, false); }
-        else sift_up(i, true);
+        if (before(a[co], a[i])) { swap(i, co); sift_up(co, false, stop); }
+        else sift_up(i, true, stop);
     }
-    __device__ void sift_down(const int n, int i, const bool lower) const
+    __device__ void sift_down(const int n, int i, const bool lower, const int stop = 2) const
     {
         const int end_parent = n / 2 - ((lower && (n & 3) == 0) ? 2 : 1);
         while (i < end_parent) {
@@ -59,14 +59,31 @@ struct HitDeque
                 if (!lower && child + 1 < n && before(a[child], a[child + 1])) {
                     ++child;
                     swap(i, child);
-                    leaf_lower(n, child);
+                    leaf_lower(n, child, stop);
                     return;
                 }
                 swap(i, child);
                 i = child;
             }
         }
-        if (lower) leaf_lower(n, i); else leaf_upper(n, i);
+        if (lower) leaf_lower(n, i, stop); else leaf_upper(n, i, stop);
+    }
+    // The bottom-up construction (make_interval_heap, interval_heap.h:356-384).  The reference's selection kernels run it every time they take
+    // hits[read_id]: SeedHitDequeArrayDeviceView::get_deque(read_id, build_heap = false) hands that false to priority_deque(seq, constructed)
+    // (seed_hit_deque_array_inl.h:104-109, priority_deque.h:320-325).  The ranges shrank since the last round, equal sizes are common, and the
+    // probability-tree leaves do not move with the hits -- so the arrangement this leaves decides later picks, and every exchange is kept.
+    __device__ void make(const int n) const
+    {
+        if (n <= 1) return;
+        const int end_parent = n / 2 - 1;
+        int i = n ^ (n & 1);
+        do {
+            i -= 2;
+            const int stop = (i <= end_parent) ? (i * 2 + 2) : n;
+            if (before(a[i + 1], a[i])) swap(i + 1, i);
+            sift_down(n, i + 1, false, stop);
+            sift_down(n, i, true, stop);
+        } while (i >= 2);
     }
     // a[n-1] holds the new hit (priority_deque::push)
     __device__ void push(const int n) const { if ((n - 1) & 1) leaf_upper(n, n - 1); else leaf_lower(n, n - 1); }

@@ -226,9 +226,10 @@ select_kernel(uint32_t n_multi, const uint32_t* __restrict__ active_in, uint32_t
         uint2* h = hits + uint64_t(read_id) * hits_stride;
         uint32_t* out_loc = stage_loc + uint64_t(t) * n_multi;
         uint32_t* out_seed = stage_seed + uint64_t(t) * n_multi;
+        const HitDeque deque = { h };
+        deque.make(int(n));                                                     // hits[ read_id ] rebuilds the heap (hit_deque.h)
         if constexpr (!RANDOMIZED)
         {
-            const HitDeque deque = { h };
             for (uint32_t i = 0; i < n_multi; ++i)
             {
                 uint32_t top = uint32_t(deque.top(int(n)));
@@ -321,6 +322,8 @@ select_rand_quad_kernel(uint32_t n_multi, const uint32_t* __restrict__ active_in
         uint2* hrow = hits + uint64_t(read_id) * hits_stride;
         float* pr = probs + uint64_t(read_id) * probs_stride;
         const uint32_t padded = st_padded(n), lg = ilog2(padded);
+        if (j == 0u) { const HitDeque deque = { hrow }; deque.make(int(n)); }          // hits[ read_id ] rebuilds the heap; the group's lanes
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                         // are in one wavefront and read the row after it
         uint32_t hx[4], hy[4];
         TreeQuad<G> tq;
         #pragma unroll
@@ -512,7 +515,7 @@ score_best_setup_kernel(uint32_t n, const uint32_t* __restrict__ hit_read_id, co
 }
 
 // one lane per program of deque operations (0 push with the mappers' "full: pop_bottom first" rule, 1 pop_top,
-// 2 pop_bottom), the deque's array written out after every operation: lets a test replay the programs recorded
+// 2 pop_bottom, 3 shrink the range in slot val & 2^32-1 to val >> 32 in place, 4 rebuild the heap), the deque's array written out after every operation: lets a test replay the programs recorded
 // from the reference's heap (tests/golden/hit_deque_vectors.npz) through the device implementation
 __global__ void __launch_bounds__(64)
 hit_deque_replay_kernel(uint32_t n_cases, const uint32_t* __restrict__ case_start, const uint8_t* __restrict__ ops, const uint64_t* __restrict__ vals,
@@ -532,7 +535,9 @@ hit_deque_replay_kernel(uint32_t n_cases, const uint32_t* __restrict__ case_star
             d.push(n);
         }
         else if (ops[i] == 1u) { d.pop_top(n); --n; }
-        else { d.pop_bottom(n); --n; }
+        else if (ops[i] == 2u) { d.pop_bottom(n); --n; }
+        else if (ops[i] == 3u) { uint2& w = d.a[uint32_t(vals[i])]; w.y = (w.y & ~0xFFFFFu) | (uint32_t(vals[i] >> 32) & 0xFFFFFu); }
+        else d.make(n);
         for (int k = 0; k < n; ++k) out_states[o++] = (uint64_t(d.a[k].y) << 32) | d.a[k].x;
     }
 }

@@ -1700,6 +1700,24 @@ static void ih_pop_top(uint64_t* a, long n)
     hit_swap(a, 1, n - 1);
     ih_sift_down(a, n - 1, 1, 0, 2);
 }
+/* make_interval_heap (interval_heap.h:356-384): what priority_deque(seq, constructed = false) runs (priority_deque.h:320-325) -- and
+ * SeedHitDequeArrayDeviceView::get_deque(read_id, build_heap = false) passes that false as `constructed`
+ * (seed_hit_deque_array_inl.h:104-109), so EVERY hits[read_id] the selection kernels take rebuilds the read's heap by the hits'
+ * current range sizes: the hits change slots between rounds while the probability-tree leaves stay where select_init put them. */
+static void ih_make(uint64_t* a, long n)
+{
+    if (n <= 1) return;
+    const long end_parent = n / 2 - 1;
+    long i = n ^ (n & 1);                          /* a trailing singleton interval is skipped */
+    do {
+        i -= 2;
+        const long stop = (i <= end_parent) ? (i * 2 + 2) : n;
+        if (hit_before(a[i + 1], a[i])) hit_swap(a, i + 1, i);
+        ih_sift_down(a, n, i + 1, 0, stop);
+        ih_sift_down(a, n, i, 1, stop);
+    } while (i >= 2);
+}
+ORACLE_API void oracle_hit_deque_make(uint64_t* a, uint32_t n)       { ih_make(a, n); }
 ORACLE_API void oracle_hit_deque_push(uint64_t* a, uint32_t n)       { ih_push(a, n); }
 ORACLE_API void oracle_hit_deque_pop_bottom(uint64_t* a, uint32_t n) { ih_pop_bottom(a, n); }
 ORACLE_API void oracle_hit_deque_pop_top(uint64_t* a, uint32_t n)    { ih_pop_top(a, n); }
@@ -2097,6 +2115,7 @@ ORACLE_API void oracle_select(int randomized, uint32_t n_multi, const uint32_t* 
         if (n == 0) continue;
         uint64_t* h = hits + (uint64_t)read_id * hits_stride;
         const uint64_t first = n_hits;
+        ih_make(h, n);                                                         /* hits[ read_id ] (select_inl.h:102,212,318,519) */
         if (!randomized)
         {
             /* select_kernel (:74-137) and select_multi_kernel (:281-480): walk the deque from its top */

@@ -664,6 +664,11 @@ def hit_deque_ops(lib_handle=None):
     return mk(L.oracle_hit_deque_push), mk(L.oracle_hit_deque_pop_bottom), mk(L.oracle_hit_deque_pop_top)
 
 
+def hit_deque_make(a, n):
+    """make_interval_heap over a[:n] in place (what priority_deque(seq, constructed=False) runs)."""
+    lib().oracle_hit_deque_make(_p(a), C.c_uint32(n))
+
+
 def sum_tree_node_count(size):
     lib().oracle_sum_tree_node_count.restype = C.c_uint32
     return int(lib().oracle_sum_tree_node_count(C.c_uint32(size)))

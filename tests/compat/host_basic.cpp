@@ -20,7 +20,10 @@ extern "C" int replay(const uint8_t* ops, const uint64_t* vals, const uint32_t* 
         for (uint32 k = case_start[c]; k < case_start[c + 1]; ++k)
         {
             if (ops[k] == 0) { if (dq.size() == caps[k]) dq.pop_bottom(); dq.push(vals[k]); }
-            else if (ops[k] == 1) dq.pop_top(); else dq.pop_bottom();
+            else if (ops[k] == 1) dq.pop_top();
+            else if (ops[k] == 2) dq.pop_bottom();
+            else if (ops[k] == 3) { uint64& w = store[uint32(vals[k])]; w = (w & ~(uint64(0xFFFFFu) << 32)) | ((vals[k] >> 32) << 32); }     // a range shrinks in place
+            else dq = priority_deque<uint64, vec, cmp>(vec(dq.size(), store), false);                                                      // taken again, as hits[read_id] is: rebuilt
             if (dq.size() != sizes[k]) return -(int)k - 1;
             for (uint32 i = 0; i < sizes[k]; ++i) if (store[i] != states[pos + i]) return -(int)k - 1;
             pos += sizes[k];

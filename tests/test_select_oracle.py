@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REF_SO = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "libref_hit_deque.so")
 
 
-def replay(push, pop_bottom, pop_top, G, check):
+def replay(push, pop_bottom, pop_top, G, check, make=O.hit_deque_make):
     ops, vals, caps, sizes, states, cs = (G[k] for k in ("ops", "vals", "caps", "sizes", "states", "case_start"))
     off = 0
     for c in range(cs.size - 1):
@@ -27,8 +27,13 @@ def replay(push, pop_bottom, pop_top, G, check):
                 push(a, n)
             elif ops[i] == 1:
                 pop_top(a, n); n -= 1
-            else:
+            elif ops[i] == 2:
                 pop_bottom(a, n); n -= 1
+            elif ops[i] == 3:                      # a selection shrinks the range of the hit in one slot, in place
+                slot, size = int(vals[i]) & 0xFFFFFFFF, int(vals[i]) >> 32
+                a[slot] = np.uint64((int(a[slot]) & ~(0xFFFFF << 32)) | (size << 32))
+            else:                                  # hits[read_id] of the next selection round: the heap is rebuilt
+                make(a, n)
             assert n == sizes[i]
             check(a[:n], states[off:off + n], c, i)
             off += n
@@ -37,7 +42,8 @@ def replay(push, pop_bottom, pop_top, G, check):
 
 def test_hit_deque_matches_reference_vectors():
     """The golden programs were run through the reference's interval_heap.h (tests/golden/make_hit_deque_vectors.py): after
-    every push / pop_top / pop_bottom the restated heap holds the same array, ties included."""
+    every push / pop_top / pop_bottom -- and every rebuild over hits whose ranges shrank in place, the selection kernels'
+    make_interval_heap -- the restated heap holds the same array, ties included."""
     G = np.load(os.path.join(HERE, "golden", "hit_deque_vectors.npz"))
     push, pop_bottom, pop_top = O.hit_deque_ops()
 
@@ -64,11 +70,24 @@ def test_hit_deque_matches_reference_build_live():
                 v = (int(rng.integers(1, maxsz)) << 32) | int(rng.integers(0, 1 << 32))
                 a[n] = v; b[n] = v; n += 1
                 push(a, n); ref.ref_hit_deque_push(b.ctypes.data_as(P), n)
-            elif u < 0.8:
+            elif u < 0.7:
                 pop_top(a, n); ref.ref_hit_deque_pop_top(b.ctypes.data_as(P), n); n -= 1
-            else:
+            elif u < 0.8:
                 pop_bottom(a, n); ref.ref_hit_deque_pop_bottom(b.ctypes.data_as(P), n); n -= 1
+            else:                                  # a selection round: some ranges shrink in place, then the heap is rebuilt
+                for slot in rng.integers(0, n, int(rng.integers(0, 4))):
+                    size = (int(a[slot]) >> 32) & 0xFFFFF
+                    size = int(rng.integers(0, size + 1))
+                    a[slot] = b[slot] = np.uint64((int(a[slot]) & ~(0xFFFFF << 32)) | (size << 32))
+                O.hit_deque_make(a, n); ref.ref_hit_deque_make(b.ctypes.data_as(P), n)
             assert (a[:n] == b[:n]).all() and ref.ref_hit_deque_is_heap(b.ctypes.data_as(P), n)
+    # and over arbitrary arrays
+    for trial in range(3000):
+        n = int(rng.integers(0, 64)); maxsz = int(rng.choice([2, 3, 8, 1000]))
+        a = ((rng.integers(0, maxsz, 64).astype(np.uint64) << np.uint64(32)) | rng.integers(0, 1 << 32, 64).astype(np.uint64))
+        b = a.copy()
+        O.hit_deque_make(a, n); ref.ref_hit_deque_make(b.ctypes.data_as(P), n)
+        assert (a == b).all() and ref.ref_hit_deque_is_heap(b.ctypes.data_as(P), n)
 
 
 def test_hit_deque_order_properties():
