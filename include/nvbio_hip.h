@@ -867,9 +867,10 @@ void nvbio_hip_comm_set_transport(const nvbio_hip_comm_transport* transport);
 int nvbio_hip_set_test_switch(const char* name, int value);     /* hipErrorInvalidValue for an unknown name */
 int nvbio_hip_get_test_switch(const char* name);                /* -1 for an unknown name */
 /* Memory helpers: nvbio_hip_device_malloc / nvbio_hip_device_free take blocks from a private pool of the calling thread's current device.
- * nvbio_hip_device_free does not stop the host: the block returns to the pool after everything queued so far on the legacy default stream
- * (hence on every blocking stream) and on the streams made by nvbio_hip_stream_create has finished (it is parked with an event per
- * stream and reclaimed at a later malloc / free).  Work on a non-blocking stream created elsewhere is not covered -- synchronise it first.  Call it from a thread bound to the device
+ * nvbio_hip_device_free does not stop the host: the block returns to the pool in the legacy default stream's order (a stream-ordered free),
+ * behind a device-side wait for what the streams made by nvbio_hip_stream_create hold at that point; the pool only serves default-stream
+ * requests, and nvbio_hip_device_malloc returns after the default stream has drained, so the next owner never overlaps the previous one's work.
+ * Work on a non-blocking stream created elsewhere is not covered -- synchronise it first.  Call it from a thread bound to the device
  * the block lives on; per-batch storage lives in a hip::device_arena (include/nvbio_hip/types.h) and never comes through here. */
 
 /* Library / device introspection (host). */

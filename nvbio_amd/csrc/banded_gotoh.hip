@@ -40,7 +40,6 @@
 #include <mutex>
 #include <atomic>
 #include <vector>
-#include <deque>
 #include <algorithm>
 #include <cstring>
 #include <cstdlib>
@@ -272,34 +271,11 @@ static hipMemPool_t private_pool(int dev)
 namespace nvb {
 static std::mutex g_streams_mtx;
 static std::vector<hipStream_t> g_streams[64];
-struct ParkedBlock { void* ptr; std::vector<hipEvent_t> events; };
-static std::deque<ParkedBlock> g_parked[64];
 static void register_stream(int dev, hipStream_t s) { if (dev >= 0 && dev < 64) { std::lock_guard<std::mutex> lock(g_streams_mtx); g_streams[dev].push_back(s); } }
 static void forget_stream(hipStream_t s)
 {
     std::lock_guard<std::mutex> lock(g_streams_mtx);
     for (auto& v : g_streams) v.erase(std::remove(v.begin(), v.end(), s), v.end());
-}
-// (g_streams_mtx held)  return every parked block whose events have all completed; wait_oldest: block on the first one that has not
-static void reclaim_parked(int dev, bool wait_oldest)
-{
-    std::deque<ParkedBlock>& q = g_parked[dev];
-    while (!q.empty())
-    {
-        ParkedBlock& b = q.front();
-        bool done = true;
-        for (hipEvent_t ev : b.events)
-        {
-            hipError_t e = hipEventQuery(ev);
-            if (e == hipErrorNotReady && wait_oldest) e = hipEventSynchronize(ev);
-            if (e == hipErrorNotReady) { (void)hipGetLastError(); done = false; break; }
-        }
-        if (!done) break;
-        for (hipEvent_t ev : b.events) (void)hipEventDestroy(ev);
-        (void)hipFreeAsync(b.ptr, nullptr);
-        q.pop_front();
-        wait_oldest = false;
-    }
 }
 } // namespace nvb
 NVB_API int nvbio_hip_device_malloc(void** ptr, uint64_t bytes)
@@ -309,7 +285,6 @@ NVB_API int nvbio_hip_device_malloc(void** ptr, uint64_t bytes)
     if (hipError_t e = hipGetDevice(&dev)) return e;
     hipMemPool_t pool = nvb::private_pool(dev);
     if (!pool) return hipMalloc(ptr, bytes ? bytes : 1);
-    if (dev >= 0 && dev < 64) { std::lock_guard<std::mutex> lock(nvb::g_streams_mtx); nvb::reclaim_parked(dev, false); }
     if (hipError_t e = hipMallocFromPoolAsync(ptr, bytes ? bytes : 1, pool, nullptr)) return e;
     return hipStreamSynchronize(nullptr);          // like hipMalloc: the block is usable from every stream on return
 }
@@ -323,27 +298,28 @@ NVB_API int nvbio_hip_device_free(void* ptr)
         if (hipError_t e = hipDeviceSynchronize()) return e;
         return (have_dev && nvb::private_pool(dev)) ? hipFreeAsync(ptr, nullptr) : hipFree(ptr);
     }
+    // Stream-ordered: the block goes back to the pool in the default stream's order, and the pool only ever serves default-stream requests
+    // (nvbio_hip_device_malloc), so whoever gets it next is ordered behind everything the default stream held at this point -- the host does
+    // not wait.  Work on the library's own non-blocking streams is not ordered with the default stream: the free is put behind one event per
+    // such stream (a wait executed by the device).  A program that only uses the default stream -- the reference's applications -- pays one
+    // hipFreeAsync.  (A form that parked blocks on the host and polled events did not survive the unchanged nvBowtie at 3 Gbp:
+    // profiles/r05/device_free_forms.txt.)
     std::lock_guard<std::mutex> lock(nvb::g_streams_mtx);
-    nvb::reclaim_parked(dev, nvb::g_parked[dev].size() >= 512u);
-    nvb::ParkedBlock b; b.ptr = ptr;
-    auto mark = [&](hipStream_t s) -> hipError_t {
+    for (hipStream_t s : nvb::g_streams[dev])
+    {
         hipEvent_t ev = nullptr;
-        if (hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) return e;
-        if (hipError_t e = hipEventRecord(ev, s)) { (void)hipEventDestroy(ev); return e; }
-        b.events.push_back(ev);
-        return hipSuccess;
-    };
-    hipError_t e = mark(nullptr);
-    for (size_t k = 0; e == hipSuccess && k < nvb::g_streams[dev].size(); ++k) e = mark(nvb::g_streams[dev][k]);
-    if (e != hipSuccess)
-    {   // could not mark a stream: fall back to the blocking form for this block
-        for (hipEvent_t ev : b.events) (void)hipEventDestroy(ev);
-        (void)hipGetLastError();
-        if (hipError_t es = hipDeviceSynchronize()) return es;
-        return hipFreeAsync(ptr, nullptr);
+        hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(ev, s);
+        if (e == hipSuccess) e = hipStreamWaitEvent(nullptr, ev, 0);
+        if (ev) (void)hipEventDestroy(ev);               // (released by the runtime once the wait has been through)
+        if (e != hipSuccess)
+        {   // could not order behind this stream: the blocking form for this block
+            (void)hipGetLastError();
+            if (hipError_t es = hipDeviceSynchronize()) return es;
+            break;
+        }
     }
-    nvb::g_parked[dev].push_back(std::move(b));
-    return hipSuccess;
+    return hipFreeAsync(ptr, nullptr);
 }
 // ---- streams for the C++ host layer (which has no HIP headers).  The reference's drivers run on the default stream of one host thread
 // per device (nvBowtie.cpp:809-864); here one device serves several batches at once: a driver object per host thread, each on its own

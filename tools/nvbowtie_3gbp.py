@@ -174,7 +174,7 @@ def compare_sam(ref_path, own_path, show=5):
         return n_a, n_b, n_a, [], {}
     la, lb = a.tobytes().split(b"\n"), b.tobytes().split(b"\n")
     same, diffs, cats = 0, [], {}
-    for x, y in zip(la, lb):
+    for k, (x, y) in enumerate(zip(la, lb)):
         if x == y:
             same += 1 if x else 0
             continue
@@ -192,6 +192,7 @@ def compare_sam(ref_path, own_path, show=5):
         else:
             cat = "other_fields_%s" % ",".join(map(str, d))
         cats[cat] = cats.get(cat, 0) + 1
+        cats["in_batch_%d" % (k >> 20)] = cats.get("in_batch_%d" % (k >> 20), 0) + 1
         if len(diffs) < show or (cats[cat] <= 3 and len(diffs) < 4 * show):
             diffs.append(dict(category=cat, fields=d, ref=[f.decode() for f in fx[:9] + fx[11:]], own=[f.decode() for f in fy[:9] + fy[11:]]))
     return n_a, n_b, same, diffs, cats
