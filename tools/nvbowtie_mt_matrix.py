@@ -32,11 +32,15 @@ def main():
     st = run("st", False, {})
     st2 = run("st2", False, {})
     out["single_thread_repeatable"] = (st == st2) if not isinstance(st, str) else st
+    quick = [("default", {}), ("default_again", {}), ("launch_blocking", {"HIP_LAUNCH_BLOCKING": "1"}), ("launch_blocking_again", {"HIP_LAUNCH_BLOCKING": "1"}),
+             ("serialized", {"AMD_SERIALIZE_KERNEL": "3", "AMD_SERIALIZE_COPY": "3"}), ("sync_free", {"NVBIO_HIP_SYNC_FREE": "1"})]
     cases = [("default", {}), ("default_again", {}), ("sync_free", {"NVBIO_HIP_SYNC_FREE": "1"}), ("no_line_native", {"NVBIO_HIP_COMPAT_LINE_NATIVE": "0"}),
              ("generic_lanes", {"NVBIO_HIP_COMPAT_GENERIC": "banded,full,traceback"}), ("no_views", {"NVBIO_HIP_COMPAT_NO_VIEWS": "1"}),
              ("sync_free+generic", {"NVBIO_HIP_SYNC_FREE": "1", "NVBIO_HIP_COMPAT_GENERIC": "banded,full,traceback"}),
              ("sync_free+no_line_native", {"NVBIO_HIP_SYNC_FREE": "1", "NVBIO_HIP_COMPAT_LINE_NATIVE": "0"}),
              ("all_off", {"NVBIO_HIP_SYNC_FREE": "1", "NVBIO_HIP_COMPAT_LINE_NATIVE": "0", "NVBIO_HIP_COMPAT_GENERIC": "banded,full,traceback"})]
+    if os.environ.get("MT_MATRIX_QUICK"):
+        cases = quick
     for tag, env in cases:
         ref = st
         if "GENERIC" in "".join(env) or "NO_VIEWS" in "".join(env):
