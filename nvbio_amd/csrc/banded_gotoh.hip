@@ -38,6 +38,7 @@
 //
 #include "banded_gotoh_impl.h"
 #include <mutex>
+#include <unordered_map>
 #include <atomic>
 #include <vector>
 #include <algorithm>
@@ -231,18 +232,51 @@ NVB_API int nvbio_hip_banded_sw_score(
     return nvbio_hip_banded_gotoh_score(&g, type, band_len, patterns, texts, max_pattern_len, max_text_len, n, out_score, out_sink, stream);
 }
 
-// Device memory for the C++ host layer's containers.  A private, per-device stream-ordered pool (the device's default pool and
-// its attributes are left alone: this library shares its process with torch's allocator in bench.py) with a bounded release
-// threshold, so freed blocks above 256 MiB go back to the driver.  nvbio_hip_device_free keeps hipFree's contract -- the block
-// may be in use by ANY stream of the device until the call returns, so the device is synchronised before the block re-enters the
-// pool; a driver's per-batch working set lives in a hip::device_arena (include/nvbio_hip/types.h) and never comes through here.
+// Device memory for the C++ host layer's containers and the drop-in layer's vectors: hipMalloc'ed blocks kept in a per-device cache.
+//
+// Rounds 1-4 took them from a private hipMemPool (hipMallocFromPoolAsync / hipFreeAsync on the legacy default stream).  Under the reference's
+// own multi-threaded mode -- nvBowtie --device 0 --device 0: two compute threads, each with its own Aligner, both on the default stream of one
+// device -- that pool loses the contents of live blocks: a ~2 MB stretch of one thread's traceback scratch reads back as zeros while the other
+// thread allocates and frees (profiles/r05/two_threads_pool.txt: 0 of 9 runs differ from the single-thread run with plain hipMalloc / hipFree,
+// 2 of 3 with the pool; no two live blocks ever overlapped, a mutex around every pool call, kernel / copy serialisation and a blocking free all
+// left it in place).  So the pool is gone: a freed block goes on a free list, a request takes the smallest listed block of at least its size
+// (and at most twice it) or calls hipMalloc.
+//   free    does not stop the host.  Work that used the block was queued before the call -- on the default stream, a blocking stream, or a
+//           stream made by nvbio_hip_stream_create; for each of the latter the default stream is made to wait (hipStreamWaitEvent) for what
+//           that stream holds now.
+//   malloc  returns after hipStreamSynchronize(default stream), as it always did (hipMalloc's contract: usable from every stream): everything
+//           queued before the block was freed -- the waits included -- has finished by then, whichever thread freed it.
+// Blocks stay cached up to NVBIO_HIP_POOL_KEEP_MB (default 8192) per device, least recently freed first out (hipFree).  A driver's per-batch
+// working set lives in a hip::device_arena (include/nvbio_hip/types.h) and comes through here once.
 namespace nvb {
-static hipMemPool_t private_pool(int dev)
+static std::mutex g_streams_mtx;
+static std::vector<hipStream_t> g_streams[64];
+static void register_stream(int dev, hipStream_t s) { if (dev >= 0 && dev < 64) { std::lock_guard<std::mutex> lock(g_streams_mtx); g_streams[dev].push_back(s); } }
+static void forget_stream(hipStream_t s)
+{
+    std::lock_guard<std::mutex> lock(g_streams_mtx);
+    for (auto& v : g_streams) v.erase(std::remove(v.begin(), v.end(), s), v.end());
+}
+
+struct CachedBlock { void* ptr; uint64_t bytes; uint64_t stamp; };
+struct BlockCache
+{
+    std::mutex mtx;
+    std::vector<CachedBlock> idle;                       // freed, ready to be handed out again
+    std::unordered_map<void*, uint64_t> live;            // handed out: size
+    uint64_t idle_bytes = 0, clock = 0;
+};
+static BlockCache g_cache[64];
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static uint64_t cache_keep_bytes() { static const uint64_t keep = uint64_t(std::max(0, env_int("NVBIO_HIP_POOL_KEEP_MB", 8192))) << 20; return keep; }
+// the rounds 1-4 allocator, kept for reproducing what it does under two host threads: NVBIO_HIP_ROCM_POOL=1
+static hipMemPool_t rocm_pool(int dev)
 {
     static std::mutex mtx;
     static hipMemPool_t pools[64] = {};
     static bool tried[64] = {};
-    if (dev < 0 || dev >= 64) return nullptr;
+    static const bool use = env_int("NVBIO_HIP_ROCM_POOL", 0) == 1;
+    if (!use || dev < 0 || dev >= 64) return nullptr;
     std::lock_guard<std::mutex> lock(mtx);
     if (!tried[dev]) {
         tried[dev] = true;
@@ -260,22 +294,16 @@ static hipMemPool_t private_pool(int dev)
     }
     return pools[dev];
 }
-} // namespace nvb
-// nvbio_hip_device_free keeps hipFree's contract for the streams this library knows -- the legacy default stream (and through it every blocking
-// stream) and the streams made by nvbio_hip_stream_create -- WITHOUT stopping the host: the block is parked with one event recorded in each of
-// those streams and goes back to the pool (on the default stream, by which time nothing uses it) once every event has completed; the parked
-// blocks are polled at the next malloc / free.  The calling thread returns at once; another driver thread's batch in flight is not waited for.
-// Nothing is ever freed on, or waited for by, a stream other than the default one: the pool sees plain same-stream alloc / free traffic.
-// (Work queued on a non-blocking stream created elsewhere is not covered: synchronise such a stream before freeing.  More than 512 parked
-// blocks: the oldest is waited for.)
-namespace nvb {
-static std::mutex g_streams_mtx;
-static std::vector<hipStream_t> g_streams[64];
-static void register_stream(int dev, hipStream_t s) { if (dev >= 0 && dev < 64) { std::lock_guard<std::mutex> lock(g_streams_mtx); g_streams[dev].push_back(s); } }
-static void forget_stream(hipStream_t s)
+static void drop_idle(BlockCache& c, std::vector<void*>& victims, uint64_t keep)          // (c.mtx held) least recently freed first
 {
-    std::lock_guard<std::mutex> lock(g_streams_mtx);
-    for (auto& v : g_streams) v.erase(std::remove(v.begin(), v.end(), s), v.end());
+    while (c.idle_bytes > keep && !c.idle.empty())
+    {
+        size_t k = 0;
+        for (size_t j = 1; j < c.idle.size(); ++j) if (c.idle[j].stamp < c.idle[k].stamp) k = j;
+        victims.push_back(c.idle[k].ptr);
+        c.idle_bytes -= c.idle[k].bytes;
+        c.idle[k] = c.idle.back(); c.idle.pop_back();
+    }
 }
 } // namespace nvb
 NVB_API int nvbio_hip_device_malloc(void** ptr, uint64_t bytes)
@@ -283,43 +311,95 @@ NVB_API int nvbio_hip_device_malloc(void** ptr, uint64_t bytes)
     if (!ptr) return hipErrorInvalidValue;
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev)) return e;
-    hipMemPool_t pool = nvb::private_pool(dev);
-    if (!pool) return hipMalloc(ptr, bytes ? bytes : 1);
-    if (hipError_t e = hipMallocFromPoolAsync(ptr, bytes ? bytes : 1, pool, nullptr)) return e;
+    if (dev < 0 || dev >= 64) return hipMalloc(ptr, bytes ? bytes : 1);
+    if (hipMemPool_t pool = nvb::rocm_pool(dev))
+    {
+        if (hipError_t e = hipMallocFromPoolAsync(ptr, bytes ? bytes : 1, pool, nullptr)) return e;
+        return hipStreamSynchronize(nullptr);
+    }
+    const uint64_t n = ((bytes ? bytes : 1) + 511ull) & ~511ull;
+    nvb::BlockCache& c = nvb::g_cache[dev];
+    void* p = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(c.mtx);
+        size_t best = c.idle.size();
+        for (size_t k = 0; k < c.idle.size(); ++k)
+            if (c.idle[k].bytes >= n && c.idle[k].bytes <= 2u * n && (best == c.idle.size() || c.idle[k].bytes < c.idle[best].bytes)) best = k;
+        if (best != c.idle.size())
+        {
+            p = c.idle[best].ptr;
+            c.live[p] = c.idle[best].bytes;
+            c.idle_bytes -= c.idle[best].bytes;
+            c.idle[best] = c.idle.back(); c.idle.pop_back();
+        }
+    }
+    if (!p)
+    {
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess)
+        {   // out of memory with blocks sitting idle: give them back and ask again
+            (void)hipGetLastError();
+            std::vector<void*> victims;
+            { std::lock_guard<std::mutex> lock(c.mtx); nvb::drop_idle(c, victims, 0); }
+            for (void* v : victims) (void)hipFree(v);
+            e = hipMalloc(&p, n);
+            if (e != hipSuccess) return e;
+        }
+        std::lock_guard<std::mutex> lock(c.mtx);
+        c.live[p] = n;
+    }
+    *ptr = p;
+    // NVBIO_HIP_POISON_ALLOC=<byte> (debugging aid, read once): every block handed out is filled with that byte, so a caller that reads storage
+    // it never wrote gives results that change with the byte
+    static const int poison = nvb::env_int("NVBIO_HIP_POISON_ALLOC", -1);
+    if (poison >= 0) (void)hipMemsetAsync(p, poison & 255, bytes ? bytes : 1, nullptr);
     return hipStreamSynchronize(nullptr);          // like hipMalloc: the block is usable from every stream on return
 }
 NVB_API int nvbio_hip_device_free(void* ptr)
 {
     if (!ptr) return hipSuccess;
     int dev = 0;
-    static const bool sync_free = [] { const char* e = getenv("NVBIO_HIP_SYNC_FREE"); return e && e[0] == '1'; }();     // debugging aid: hipFree's blocking form
+    static const bool sync_free = nvb::env_int("NVBIO_HIP_SYNC_FREE", 0) == 1;     // debugging aid: hipFree's blocking form
     const bool have_dev = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
-    if (sync_free || !have_dev || !nvb::private_pool(dev)) {
-        if (hipError_t e = hipDeviceSynchronize()) return e;
-        return (have_dev && nvb::private_pool(dev)) ? hipFreeAsync(ptr, nullptr) : hipFree(ptr);
-    }
-    // Stream-ordered: the block goes back to the pool in the default stream's order, and the pool only ever serves default-stream requests
-    // (nvbio_hip_device_malloc), so whoever gets it next is ordered behind everything the default stream held at this point -- the host does
-    // not wait.  Work on the library's own non-blocking streams is not ordered with the default stream: the free is put behind one event per
-    // such stream (a wait executed by the device).  A program that only uses the default stream -- the reference's applications -- pays one
-    // hipFreeAsync.  (A form that parked blocks on the host and polled events did not survive the unchanged nvBowtie at 3 Gbp:
-    // profiles/r05/device_free_forms.txt.)
-    std::lock_guard<std::mutex> lock(nvb::g_streams_mtx);
-    for (hipStream_t s : nvb::g_streams[dev])
+    if (!have_dev) { if (hipError_t e = hipDeviceSynchronize()) return e; return hipFree(ptr); }
+    if (sync_free) { if (hipError_t e = hipDeviceSynchronize()) return e; }
+    else
     {
-        hipEvent_t ev = nullptr;
-        hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventRecord(ev, s);
-        if (e == hipSuccess) e = hipStreamWaitEvent(nullptr, ev, 0);
-        if (ev) (void)hipEventDestroy(ev);               // (released by the runtime once the wait has been through)
-        if (e != hipSuccess)
-        {   // could not order behind this stream: the blocking form for this block
-            (void)hipGetLastError();
-            if (hipError_t es = hipDeviceSynchronize()) return es;
-            break;
+        // the library's own non-blocking streams are not ordered with the default stream: put it behind what each of them holds now
+        std::lock_guard<std::mutex> lock(nvb::g_streams_mtx);
+        for (hipStream_t s : nvb::g_streams[dev])
+        {
+            hipEvent_t ev = nullptr;
+            hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventRecord(ev, s);
+            if (e == hipSuccess) e = hipStreamWaitEvent(nullptr, ev, 0);
+            if (ev) (void)hipEventDestroy(ev);               // (released by the runtime once the wait has been through)
+            if (e != hipSuccess)
+            {   // could not order behind this stream: the blocking form for this block
+                (void)hipGetLastError();
+                if (hipError_t es = hipDeviceSynchronize()) return es;
+                break;
+            }
         }
     }
-    return hipFreeAsync(ptr, nullptr);
+    if (nvb::rocm_pool(dev)) return hipFreeAsync(ptr, nullptr);
+    nvb::BlockCache& c = nvb::g_cache[dev];
+    std::vector<void*> victims;
+    {
+        std::lock_guard<std::mutex> lock(c.mtx);
+        auto it = c.live.find(ptr);
+        if (it == c.live.end()) victims.push_back(ptr);      // not from here (or freed twice): hipFree says which
+        else
+        {
+            c.idle.push_back(nvb::CachedBlock{ ptr, it->second, ++c.clock });
+            c.idle_bytes += it->second;
+            c.live.erase(it);
+            nvb::drop_idle(c, victims, nvb::cache_keep_bytes());
+        }
+    }
+    hipError_t r = hipSuccess;
+    for (void* v : victims) { const hipError_t e = hipFree(v); if (e != hipSuccess) r = e; }      // (hipFree waits for the device itself)
+    return r;
 }
 // ---- streams for the C++ host layer (which has no HIP headers).  The reference's drivers run on the default stream of one host thread
 // per device (nvBowtie.cpp:809-864); here one device serves several batches at once: a driver object per host thread, each on its own

@@ -434,6 +434,25 @@ def test_own_driver_equals_reference_nvbowtie_above_half_a_batch(cuda):
     assert same == n_ref, (same, n_ref)
 
 
+@pytest.mark.parametrize("mode,reads", [("se", 300_000), ("paired", 120_000)], ids=["single-end", "paired-end"])
+def test_reference_nvbowtie_with_two_compute_threads(mode, reads, cuda):
+    """nvBowtie's multi-device mode pointed twice at the one GPU (`--device 0 --device 0`: two compute threads, each with its own Aligner, one
+    input thread, one mutexed output file; nvBowtie.cpp:809-864, paired-end :638-703), batches of 16 K reads so that both threads get many:
+    every read's record must be the one the single-thread run prints (itself held to the from-scratch drivers by the tests above), on each of
+    three runs.  (Rounds 1-4 served the drop-in layer's vectors from a hipMemPool; under two threads live blocks lost their contents and two
+    runs in three printed a few hundred different records -- profiles/r05/two_threads_pool.txt.)"""
+    import argparse
+    import sys
+    if not os.path.exists(os.path.join(REF, "ref_nvBowtie")):
+        pytest.skip("oracle/_ref/ref_nvBowtie not built (needs /root/reference in the build container)")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import nvbowtie_compare
+    args = dict(mode=mode, reads=reads, seed=71, indels=0.3, show=3, len=100, ns=0.0, quals="random", repeats=0.0, extra="--batch-size 16", own="")
+    n, same = nvbowtie_compare.two_threads(argparse.Namespace(**args), repeats=3)
+    assert n >= reads
+    assert same == [n, n, n], (mode, n, same)
+
+
 def test_reference_nvbowtie_equals_own_driver_at_3gbp():
     """BASELINE config 4 as written -- a 3 Gbp index -- through the reference's own application: a repeat-rich synthetic genome (60 % of it diverged
     copies of three repeat families, the largest with three million copies: SA ranges beyond 2^20 rows, rows above 2^31, MAPQ across its whole

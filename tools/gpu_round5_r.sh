@@ -1,0 +1,8 @@
+set -x
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+W=/tmp/wmt
+timeout 200 python tools/nvbowtie_3gbp.py --genome 1e8 --reads 1000000 --keep $W --json gpurun_out/nvb_1e8.json --log gpurun_out/nvb_1e8.log > gpurun_out/nvb_1e8.out 2>&1
+timeout 900 python tools/nvbowtie_guard_probe.py $W > gpurun_out/guard_probe.json 2> gpurun_out/guard_probe.err
+cut -c1-330 gpurun_out/guard_probe.err | head -120

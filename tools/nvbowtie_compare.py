@@ -81,8 +81,32 @@ def main():
     return 0 if same == max(n_ref, n_own) and n_ref else 1
 
 
-def compare(args):
-    """-> (identical records, reference records, own records)"""
+def two_threads(args, repeats=2):
+    """nvBowtie with two compute threads on the one GPU (`--device 0 --device 0`) against its own single-thread run on the same files, read by read
+    -> (records of the single-thread run, [records of each two-thread run that equal them])"""
+    cmd, _, _, sam = prepare(args)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        print((r.stdout + r.stderr)[-3000:]); return 0, []
+    key = lambda a: (a[0], int(a[1]) & 0xC0)
+    single = sorted(records(open(sam).read()), key=key)
+    same = []
+    for k in range(repeats):
+        r = subprocess.run(cmd[:1] + ["--device", "0", "--device", "0"] + cmd[1:], capture_output=True, text=True, timeout=150)
+        if r.returncode != 0:
+            print((r.stdout + r.stderr)[-3000:]); same.append(-1); continue
+        two = sorted(records(open(sam).read()), key=key)
+        same.append(sum(1 for a, b in zip(single, two) if a == b) if len(two) == len(single) else -len(two))
+        shown = 0
+        for a, b in zip(single, two):
+            if a != b and shown < args.show:
+                shown += 1
+                print("  run %d:\n    one thread : %s\n    two threads: %s" % (k, a[:9] + a[11:], b[:9] + b[11:]))
+    return len(single), same
+
+
+def prepare(args):
+    """writes the reference files and the reads of a case -> (nvBowtie command, this repository's driver as a callable, its output buffer, nvBowtie's SAM path)"""
     import torch
     import align_fastq
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_nvBowtie")
@@ -135,6 +159,14 @@ def compare(args):
         else:
             own = lambda: align_fastq.main(prefix, fq, buf, device=dev, **overrides)
     cmd += os.environ.get("NVBOWTIE_EXTRA_ARGS", "").split()
+    return cmd, own, buf, sam
+
+
+def compare(args):
+    """-> (identical records, reference records, own records)"""
+    cmd, own, buf, sam = prepare(args)
+    import align_fastq
+    extra = getattr(args, "extra", "").split()
     r = subprocess.run(cmd, capture_output=True, text=True)
     if os.environ.get("NVBOWTIE_EXTRA_ARGS"):          # (a debug build's device-side prints: everything that is not a log line)
         print("\n".join(ln for ln in (r.stdout + r.stderr).replace("\r", "\n").splitlines()
