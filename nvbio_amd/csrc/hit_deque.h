@@ -15,12 +15,30 @@
 
 namespace nvb {
 
-struct HitDeque
+// where the heap's elements live: SeedHit words in a read's arena row, or -- for rebuilding a heap on chip (select.hip) -- one key per hit,
+// (range size << 8 | slot), in LDS, lane-interleaved
+struct RowHits
 {
-    uint2* a;
-
+    typedef uint2 value_type;
+    uint2* p;
+    __device__ __forceinline__ uint2& operator[](const int i) const { return p[i]; }
     __device__ __forceinline__ static bool before(const uint2 f, const uint2 s) { return (f.y & 0xFFFFFu) > (s.y & 0xFFFFFu); }
-    __device__ __forceinline__ void swap(const int i, const int j) const { const uint2 t = a[i]; a[i] = a[j]; a[j] = t; }
+};
+struct LdsKeys
+{
+    typedef uint32_t value_type;
+    uint32_t* p;
+    __device__ __forceinline__ uint32_t& operator[](const int i) const { return p[i * 256]; }
+    __device__ __forceinline__ static bool before(const uint32_t f, const uint32_t s) { return (f >> 8) > (s >> 8); }
+};
+
+template <typename Cells>
+struct HitDequeT
+{
+    Cells a;
+
+    __device__ __forceinline__ static bool before(const typename Cells::value_type f, const typename Cells::value_type s) { return Cells::before(f, s); }
+    __device__ __forceinline__ void swap(const int i, const int j) const { const typename Cells::value_type t = a[i]; a[i] = a[j]; a[j] = t; }
 
     __device__ void sift_up(int i, const bool lower, const int stop = 2) const
     {
@@ -92,5 +110,6 @@ struct HitDeque
     __device__ void pop_top(const int n) const { if (n <= 2) return; swap(1, n - 1); sift_down(n - 1, 1, false); }
     __device__ __forceinline__ int top(const int n) const { return n == 1 ? 0 : 1; }
 };
+typedef HitDequeT<RowHits> HitDeque;
 
 } // namespace nvb
