@@ -30,48 +30,31 @@ def main():
             r = subprocess.run([exe] + (["--device", "0", "--device", "0"] if mt else []) + base_cmd + ["-S", sam], capture_output=True, text=True, timeout=60, env=dict(os.environ, **env))
         except subprocess.TimeoutExpired:
             return None
-        notes = [l for l in r.stderr.splitlines() if "overlaps live block" in l or "not a live block" in l]
-        if notes:
-            print(tag, "pool check:", len(notes), notes[:3], file=sys.stderr, flush=True)
         return records(sam) if r.returncode == 0 else None
 
     st = run("st", False, {})
     out = {}
-    cases = [("mt", {}), ("mt_again", {}), ("mt_omp1", {"OMP_NUM_THREADS": "1"}), ("mt_omp1_again", {"OMP_NUM_THREADS": "1"}),
-             ("mt_serialized_omp1", {"OMP_NUM_THREADS": "1", "AMD_SERIALIZE_KERNEL": "3", "AMD_SERIALIZE_COPY": "3"}),
-             ("mt_no_tuned", {"NVBIO_HIP_COMPAT_GENERIC": "banded,full,traceback", "NVBIO_HIP_COMPAT_LINE_NATIVE": "0"})]
-    if os.environ.get("MT_EXAMPLES_CASES") == "pool":
-        keep = {"NVBIO_HIP_POOL_KEEP_MB": "100000"}
-        gen = {"NVBIO_HIP_COMPAT_GENERIC": "banded,full,traceback"}
-        cases = [("mt_keep", keep), ("mt_keep_2", keep), ("mt_keep_3", keep), ("mt_keep_generic", dict(keep, **gen)), ("mt_keep_generic_2", dict(keep, **gen)),
-                 ("mt_generic", gen), ("mt_generic_2", gen), ("mt_generic_syncfree", dict(gen, NVBIO_HIP_SYNC_FREE="1")), ("mt_keep_generic_syncfree", dict(keep, NVBIO_HIP_SYNC_FREE="1", **gen)),
-                 ("mt_hwq1_generic", dict(gen, GPU_MAX_HW_QUEUES="1")), ("mt_hwq1_generic_2", dict(gen, GPU_MAX_HW_QUEUES="1")),
-                 ("mt_serialized_generic", dict(gen, AMD_SERIALIZE_KERNEL="3", AMD_SERIALIZE_COPY="3")), ("mt_serialized_generic_2", dict(gen, AMD_SERIALIZE_KERNEL="3", AMD_SERIALIZE_COPY="3"))]
-    if os.environ.get("MT_EXAMPLES_CASES") == "two_processes":
+    gen = {"NVBIO_HIP_COMPAT_GENERIC": "banded,full,traceback"}
+    pool = {"NVBIO_HIP_ROCM_POOL": "1"}                    # the hipMemPool of rounds 1-4 (csrc/banded_gotoh.hip): what every case but "final" was about
+    which = os.environ.get("MT_EXAMPLES_CASES", "final")
+    if which == "two_processes":
         # two single-thread processes side by side on the one GPU: does a neighbour on the device (not in the process) do it?
         import threading
         for rep in range(3):
             res = [None, None]
             def go(j):
-                res[j] = run("proc%d_%d" % (rep, j), False, {})
+                res[j] = run("proc%d_%d" % (rep, j), False, pool)
             th = [threading.Thread(target=go, args=(j,)) for j in range(2)]
             [t.start() for t in th]; [t.join() for t in th]
             out["two_processes_%d" % rep] = [None if r is None else sum(1 for k, a in st.items() if r.get(k) != a) for r in res]
-        cases = [("mt_generic_a", {"NVBIO_HIP_COMPAT_GENERIC": "banded,full,traceback"}), ("mt_generic_b", {"NVBIO_HIP_COMPAT_GENERIC": "banded,full,traceback"}),
-                 ("mt_generic_c", {"NVBIO_HIP_COMPAT_GENERIC": "banded,full,traceback"}), ("mt_a", {}), ("mt_b", {}), ("mt_c", {})]
-    if os.environ.get("MT_EXAMPLES_CASES") == "nopool":
-        gen = {"NVBIO_HIP_COMPAT_GENERIC": "banded,full,traceback"}
-        np_ = dict(gen, NVBIO_HIP_NO_POOL="1")
-        cases = [("mt_nopool_generic_%d" % k, np_) for k in range(6)] + [("mt_pool_generic_%d" % k, gen) for k in range(3)] + [("mt_nopool_%d" % k, {"NVBIO_HIP_NO_POOL": "1"}) for k in range(3)]
-    if os.environ.get("MT_EXAMPLES_CASES") == "final":
-        gen = {"NVBIO_HIP_COMPAT_GENERIC": "banded,full,traceback"}
+        cases = []
+    elif which == "serialized":
+        ser = dict(pool, AMD_SERIALIZE_KERNEL="3", AMD_SERIALIZE_COPY="3")
+        cases = [("pool_generic_serialized_%d" % k, dict(gen, **ser)) for k in range(2)] + [("pool_generic_one_hw_queue_%d" % k, dict(gen, GPU_MAX_HW_QUEUES="1", **pool)) for k in range(2)] + \
+                [("pool_generic_blocking_free_%d" % k, dict(gen, NVBIO_HIP_SYNC_FREE="1", **pool)) for k in range(2)] + [("pool_one_omp_thread_%d" % k, dict(pool, OMP_NUM_THREADS="1")) for k in range(2)]
+    else:
         cases = [("two_threads_generic_%d" % k, gen) for k in range(4)] + [("two_threads_%d" % k, {}) for k in range(4)] + \
-                [("two_threads_generic_rocm_pool_%d" % k, dict(gen, NVBIO_HIP_ROCM_POOL="1")) for k in range(3)]
-    if os.environ.get("MT_EXAMPLES_CASES") == "lock":
-        gen = {"NVBIO_HIP_COMPAT_GENERIC": "banded,full,traceback"}
-        cases = [("mt_check_generic", dict(gen, NVBIO_HIP_POOL_CHECK="1")), ("mt_check_generic_2", dict(gen, NVBIO_HIP_POOL_CHECK="1")),
-                 ("mt_lock_generic", dict(gen, NVBIO_HIP_POOL_LOCK="1")), ("mt_lock_generic_2", dict(gen, NVBIO_HIP_POOL_LOCK="1")), ("mt_lock_generic_3", dict(gen, NVBIO_HIP_POOL_LOCK="1")),
-                 ("mt_lock_generic_4", dict(gen, NVBIO_HIP_POOL_LOCK="1")), ("mt_lock", dict(NVBIO_HIP_POOL_LOCK="1")), ("mt_lock_2", dict(NVBIO_HIP_POOL_LOCK="1"))]
+                [("two_threads_generic_rocm_pool_%d" % k, dict(gen, **pool)) for k in range(3)]
     for tag, env in cases:
         mt = run(tag, True, env)
         if mt is None or st is None:
