@@ -866,10 +866,13 @@ void nvbio_hip_comm_set_transport(const nvbio_hip_comm_transport* transport);
  * uses the value it read when it started).  0 = the default execution.  Production code leaves them alone. */
 int nvbio_hip_set_test_switch(const char* name, int value);     /* hipErrorInvalidValue for an unknown name */
 int nvbio_hip_get_test_switch(const char* name);                /* -1 for an unknown name */
-/* Memory helpers: nvbio_hip_device_malloc / nvbio_hip_device_free take blocks from a private pool of the calling thread's current device.
- * nvbio_hip_device_free does not stop the host: the block returns to the pool in the legacy default stream's order (a stream-ordered free),
- * behind a device-side wait for what the streams made by nvbio_hip_stream_create hold at that point; the pool only serves default-stream
- * requests, and nvbio_hip_device_malloc returns after the default stream has drained, so the next owner never overlaps the previous one's work.
+/* Memory helpers: nvbio_hip_device_malloc / nvbio_hip_device_free hand out hipMalloc'ed blocks kept in a per-device cache of the library's own
+ * (a freed block is listed and reused for a request of at least half its size; up to NVBIO_HIP_POOL_KEEP_MB = 8192 MB stay listed).  Not a
+ * hipMemPool: under two host threads on one device -- the reference's nvBowtie --device 0 --device 0 -- ROCm 7.0's pool loses the contents
+ * of live blocks (profiles/r05/two_threads_pool.txt).  nvbio_hip_device_free does not stop the host: work that used the block was queued before
+ * the call, on the default stream, a blocking stream or a stream made by nvbio_hip_stream_create -- the default stream is put behind what each
+ * of the latter holds now (hipStreamWaitEvent) --, and nvbio_hip_device_malloc returns after the default stream has drained (hipMalloc's
+ * contract: the block is usable from every stream), so the next owner never overlaps the previous one's work, whichever thread it is.
  * Work on a non-blocking stream created elsewhere is not covered -- synchronise it first.  Call it from a thread bound to the device
  * the block lives on; per-batch storage lives in a hip::device_arena (include/nvbio_hip/types.h) and never comes through here. */
 

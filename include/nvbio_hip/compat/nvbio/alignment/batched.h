@@ -124,7 +124,8 @@ __global__ void __launch_bounds__(128) batched_full_score_kernel(const stream_ty
 /// a growable device buffer owned by a batch object (the reference keeps a thrust::device_vector<uint8> there)
 /// a batch object's scratch (job tables, staged strings, boundary columns).  Callers make a fresh batch object per call (sw-benchmark.cu:373-378,
 /// nvBowtie's score / traceback functions), and a plain hipMalloc costs ~4 ms here -- a third of sw-benchmark's timed enact() -- so the
-/// blocks come from the library's private stream-ordered pool (nvbio_hip_device_malloc: hipMalloc / hipFree semantics, freed blocks kept)
+/// blocks come from the library's block cache (nvbio_hip_device_malloc: hipMalloc / hipFree semantics, freed blocks kept; the free does not stop the host,
+/// which matters here: the batch object dies -- and frees its scratch -- right after enact() returns, with its kernels still queued)
 struct device_buffer
 {
     device_buffer() : ptr(nullptr), bytes(0) {}

@@ -56,8 +56,8 @@ namespace hip {
 
 /// A grow-only device arena for a driver's per-batch working set.  The reference's Aligner allocates its queues once in
 /// init(); a driver written with scoped vectors would instead allocate and free gigabytes per batch (a 10 M-read batch needs
-/// a 16 GB traceback buffer), and neither hipMalloc (~0.1 s per GB-sized block) nor the stream-ordered pool (which splits the
-/// big block among the small requests of the next batch) makes that cheap.  Vectors built while an arena_scope is active take
+/// a 16 GB traceback buffer), and neither hipMalloc (~0.1 s per GB-sized block) nor a cache of freed blocks (which hands
+/// the big block to the first smaller request of the next batch, or keeps gigabytes idle) makes that cheap.  Vectors built while an arena_scope is active take
 /// their storage from the arena and never free it; reset() rewinds, and after the first batch the arena is one block.
 struct device_arena
 {
