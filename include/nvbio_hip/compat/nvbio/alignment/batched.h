@@ -654,7 +654,11 @@ inline bool build_view_table(const stream_type& stream, device_buffer& buf, job_
     ts.words = reinterpret_cast<const uint32*>(uintptr_t(b[2]) * 4u); ts.n_words = b[3] - b[2];
     ts.bits = 2u; ts.big_endian = packed_view<typename R::text_type>::BE ? 1u : 0u;
     ts.begin = t.txt_begin; ts.length = t.txt_len; ts.fixed_length = 0; ts._pad = 0;
-    // quals[begin + k] must be the quality of stored symbol begin + k: the array starts where the lowest pattern word's first symbol would
+    // quals[begin + k] must be the quality of stored symbol begin + k: the array starts where the lowest pattern word's first symbol would.
+    // That address is never below the caller's quality storage: a quality string runs parallel to its symbol stream from symbol 0 (b[4] ==
+    // b[5]: one offset for every job), symbol 0 opens a word, so the first symbol of ANY word of the stream has a quality byte -- when the
+    // lowest read starts mid-word the bytes in front of it are an earlier read's.  Positions below the array (a reversed read at symbol 0)
+    // are never fetched: fetch_quals16_signed supplies zeros for them (csrc/banded_gotoh_impl.h).
     *quals = reinterpret_cast<const uint8*>(uintptr_t(b[4] + uint64(b[0]) * per));
     *n_quals = b[7] - uint64(b[0]) * per;
     *flags = t.ok;
