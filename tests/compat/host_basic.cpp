@@ -1,4 +1,5 @@
 // tests/compat/host_basic.cpp -- host-compiled (g++, no HIP) callers of the small building blocks of the drop-in layer:
+//   heapify_arrays priority_deque(seq, false) over arbitrary arrays
 //   replay        priority_deque<uint64, vector_view<uint64*>, cmp> driven by operation programs recorded from the REFERENCE's
 //                 compiled interval heap (tests/golden/hit_deque_vectors.npz), array state compared after every operation
 //   rank_ranges   rank_dictionary / fm_index range forms (rank4, rank_all, comp) over separate uint32 arrays and over uint4 arrays
@@ -30,6 +31,14 @@ extern "C" int replay(const uint8_t* ops, const uint64_t* vals, const uint32_t* 
         }
     }
     return 0;
+}
+
+// priority_deque(seq, constructed = false) over arbitrary arrays: what it leaves (the reference's make_interval_heap)
+extern "C" void heapify_arrays(uint64_t* data, const uint32_t* sizes, int n_cases, uint32_t stride)
+{
+    typedef vector_view<uint64*> vec;
+    for (int c = 0; c < n_cases; ++c)
+        priority_deque<uint64, vec, cmp> dq(vec(sizes[c], reinterpret_cast<uint64*>(data) + uint64(c) * stride), false);
 }
 
 #include <nvbio/basic/numbers.h>

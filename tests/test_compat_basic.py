@@ -33,6 +33,30 @@ def test_priority_deque_replays_the_reference_heap(hb):
     assert hb.replay(*[p(a) for a in arrs], C.c_int(len(arrs[5]) - 1)) == 0
 
 
+def test_priority_deque_builds_the_reference_heap_over_any_array(hb):
+    """priority_deque(seq, constructed = false) -- what nvBowtie's selection kernels construct at every round over hits whose ranges shrank in
+    place -- leaves the arrangement the reference's make_interval_heap leaves: 4 000 arrays of 0..63 words, few distinct range sizes (ties decide
+    everything), against the oracle's restatement and, where oracle/_ref is built, the reference header itself."""
+    rng = np.random.default_rng(911)
+    n_cases, stride = 4000, 64
+    sizes = rng.integers(0, 64, n_cases).astype(np.uint32)
+    maxsz = rng.choice([2, 3, 5, 16, 1 << 19], n_cases)
+    data = ((rng.integers(0, 1 << 30, (n_cases, stride)) % maxsz[:, None]).astype(np.uint64) << np.uint64(32)) | rng.integers(0, 1 << 32, (n_cases, stride)).astype(np.uint64)
+    data = np.ascontiguousarray(data)
+    want = data.copy()
+    for c in range(n_cases):
+        O.hit_deque_make(want[c], int(sizes[c]))
+    ref_so = os.path.join(ROOT, "oracle", "_ref", "libref_hit_deque.so")
+    if os.path.exists(ref_so):
+        ref = C.CDLL(ref_so)
+        again = data.copy()
+        for c in range(n_cases):
+            ref.ref_hit_deque_make(again[c].ctypes.data_as(C.POINTER(C.c_uint64)), C.c_uint32(int(sizes[c])))
+        assert (again == want).all()
+    hb.heapify_arrays(p(data), p(sizes), C.c_int(n_cases), C.c_uint32(stride))
+    assert (data == want).all()
+
+
 def test_range_rank4_rank_all_on_host(hb):
     rng = np.random.default_rng(23)
     n = 20011
