@@ -122,7 +122,8 @@ def parse():
     ap.add_argument("--e2e-reads", type=int, default=10_000_000, help="reads per batch of the end-to-end seed+locate+extend leg")
     ap.add_argument("--e2e-batches", type=int, default=5, help="batches of the full-size run of BASELINE config 4 (5 x 10 M = 50 M reads)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-ref-app", action="store_true", help="skip the leg that runs the reference's own nvBowtie binary (oracle/_ref/ref_nvBowtie) at config-4 size")
+    ap.add_argument("--ref-app", action="store_true", help="also run the leg that runs the reference's own nvBowtie binary (oracle/_ref/ref_nvBowtie) at config-4 size: writes 3.75 GB of index files, ~40 s; opt-in")
+    ap.add_argument("--legs-file", default=None, help="where the full per-leg objects go (default: gpurun_out/bench_legs.json if that directory exists, else ./bench_legs.json)")
     ap.add_argument("--ref-app-reads", type=int, default=5_000_000)
     ap.add_argument("--cpu-sample", type=int, default=10_000_000)
     return ap.parse_args()
@@ -176,7 +177,7 @@ def main():
         print(json.dumps({"ref_nvbowtie_leg": ref_nvbowtie_leg(a, dev)}))
         return
     if a.only == "dp":
-        a.no_rank = a.no_cpu = a.no_seed = a.no_e2e = a.no_full = a.no_ref_app = True
+        a.no_rank = a.no_cpu = a.no_seed = a.no_e2e = a.no_full = True; a.ref_app = False
 
     # ---------------------------------------------------------------- inputs (resident before timing)
     n = a.reads
@@ -367,7 +368,7 @@ def main():
     if rank == 0 and world == 1 and not a.no_full:
         out["full_dp_leg"] = full_dp_leg(a, dev)
         out["compat_stream_leg"] = compat_stream_leg(a, dev)
-    if rank == 0 and world == 1 and not a.no_ref_app:
+    if rank == 0 and world == 1 and a.ref_app:
         torch.cuda.empty_cache()
         out["ref_nvbowtie_leg"] = ref_nvbowtie_leg(a, dev)
     if rank == 0 and world == 1 and not a.no_cpu:
@@ -380,9 +381,28 @@ def main():
         if rank == 0:
             out["e2e_sharded_leg"] = leg
     if rank == 0:
-        print(json.dumps(out))
+        emit(out, a.legs_file)
     if world > 1:
         dist.destroy_process_group()
+
+
+def emit(out, legs_file=None):
+    """Every leg on its own stdout line and in the legs file; then the compact headline (benchlib/headline.py: < 4 KB, the contract's keys
+    + roofline + rank_roofline + cpu_baseline + parity) as the LAST line -- the one the driver parses."""
+    from benchlib import headline as H
+    if legs_file is None:
+        d = os.path.join(ROOT, "gpurun_out")
+        legs_file = os.path.join(d, "bench_legs.json") if os.path.isdir(d) else os.path.join(os.getcwd(), "bench_legs.json")
+    try:
+        with open(legs_file, "w") as f:
+            json.dump(out, f, indent=1)
+        shown = os.path.relpath(legs_file, ROOT) if legs_file.startswith(ROOT) else legs_file
+    except OSError as e:
+        sys.stderr.write("bench: could not write %s (%s)\n" % (legs_file, e))
+        shown = None
+    for line in H.leg_lines(out):
+        print(line)
+    print(H.headline_line(out, shown), flush=True)
 
 
 def ref_nvbowtie_leg(a, dev):

@@ -102,7 +102,7 @@ def best_approx_score(fmi, rfmi, state, seed_queue, best, batch, genome_words, g
         if loc.numel() == 0:
             continue
         traced = None
-        if TRACE is not None:                   # debugging aid: the SA rows picked for one read, round by round (tools/nvbowtie_subset_probe.py)
+        if TRACE is not None:                   # debugging aid: the SA rows picked for one read, round by round
             traced = (rid == TRACE["read"]).nonzero().flatten()
             rows = loc[traced].cpu().tolist()
         with _Stage(stats, "locate"):
@@ -269,7 +269,7 @@ def best_approx_score_paired(fmi, rfmi, state, seed_queue, anchor, best, best_o,
         if loc.numel() == 0:
             continue
         traced = None
-        if TRACE is not None:                   # debugging aid: the SA rows picked for one read, round by round (tools/nvbowtie_subset_probe.py)
+        if TRACE is not None:                   # debugging aid: the SA rows picked for one read, round by round
             traced = (rid == TRACE["read"]).nonzero().flatten()
             rows = loc[traced].cpu().tolist()
         with _Stage(stats, "locate"):
