@@ -175,6 +175,24 @@ int nvbio_hip_banded_gotoh_score_qual_views(
     uint32_t max_pattern_len, uint32_t max_text_len,
     uint32_t n, int32_t* out_score, uint32_t* out_sink, void* stream);
 
+/* The same scorer with a threshold per job -- the reference's `min_score` argument of banded_alignment_score (alignment_inl.h; its windowed
+ * form gives up on a job once max(H) < min_score + remaining_rows * match, gotoh_banded_inl.h:622-634), which nvBowtie's scoring stage sets to
+ * the read's second-best score (score_best_inl.h:113-116) and whose reduction only asks whether a score is ABOVE that (reduce_inl.h:111-135).
+ *   job i ends above min_score[i]:   out_score / out_sink are what nvbio_hip_banded_gotoh_score_qual_views reports, bit for bit;
+ *   job i ends at or below it:       out_score[i] is SOME value <= min_score[i] (an upper bound of the true score), out_sink[i] = (-1, -1).
+ * min_score == NULL or min_score[i] == INT32_MIN: exact.  Persistent waves pull jobs from *work_counter (device, 4 bytes, zeroed by the call):
+ * a lane whose job is given up or done takes the next (nvbio_amd/csrc/banded_gotoh_bounded.h).  n_on_device (optional, device): the number
+ * of jobs, read by the kernel -- `n` is then only an upper bound (array capacity), and the host need not know the count.  out_index (optional,
+ * device): job i's results are written at out_score[out_index[i]] / out_sink[out_index[i]] -- a compacted batch of jobs (nvbio_hip_score_best_setup's
+ * job_hit) writing straight back at its hits. */
+int nvbio_hip_banded_gotoh_score_qual_bounded(
+    const nvbio_hip_gotoh_qual_scheme* scheme, int32_t type, uint32_t band_len,
+    const nvbio_hip_string_set* patterns, const uint8_t* quals, uint64_t n_quals, const uint8_t* pattern_flags,
+    const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len,
+    uint32_t n, const uint32_t* n_on_device, const int32_t* min_score, uint32_t* work_counter, const uint32_t* out_index,
+    int32_t* out_score, uint32_t* out_sink, void* stream);
+
 /* Batched banded Gotoh traceback.  Replaces
  *   BatchedBandedAlignmentTraceback<BAND_LEN, CHECKPOINTS, stream, DeviceThreadScheduler>::enact
  *   (nvbio/alignment/batched.h:460-476, batched_banded_inl.h:250-420)
@@ -407,6 +425,12 @@ int nvbio_hip_fm_locate_host(const nvbio_hip_fmindex* fmi, const uint32_t* sa_ro
  * match(fmi, kmer c), where kmer c has symbol t (0 = first) at bits [2t,2t+2) of c, for all
  * 4^k codes; 1 <= k <= 16; out_ktab holds 2*4^k words (k=12: 128 MiB, k=14: 2 GiB, k=15: 8 GiB, k=16: 32 GiB). */
 int nvbio_hip_fm_build_ktab(const nvbio_hip_fmindex* fmi, uint32_t k, uint32_t* out_ktab, void* stream);
+/* The suffix array sampled every sa_int_out rows (a power of two <= fmi->sa_int; 1 = the whole array), derived on the device from `fmi`'s own
+ * sampled array: out_ssa[k] = locate(k * sa_int_out), nvbio_hip_fm_dense_ssa_entries(length, sa_int_out) = (length + sa_int_out) / sa_int_out
+ * words (out_ssa[0] = 0xFFFFFFFF like every SSA, ssa_inl.h:263-309).  An index carrying it (ssa = out_ssa, sa_int = sa_int_out) locates with
+ * at most sa_int_out - 1 LF steps -- none at 1 -- and returns the same positions: what 288 GB of HBM are for (12 GB at 3 Gbp). */
+uint64_t nvbio_hip_fm_dense_ssa_entries(uint32_t length, uint32_t sa_int);
+int nvbio_hip_fm_build_dense_ssa(const nvbio_hip_fmindex* fmi, uint32_t sa_int_out, uint32_t* out_ssa, void* stream);
 
 /* nvBowtie's seeding parameters as map_queues_kernel reads them (nvBowtie/bowtie2/cuda/params.h:100-120). */
 typedef struct nvbio_hip_map_params {
@@ -807,7 +831,11 @@ int nvbio_hip_build_bwt_occ(uint32_t n, const uint32_t* bwt_words, uint32_t* out
  * include/nvbio_hip/ uses them where the reference uses thrust::device_vector).
  * kind: 1 = host->device, 2 = device->host, 3 = device->device. */
 int nvbio_hip_device_malloc(void** ptr, uint64_t bytes);
-int nvbio_hip_device_free(void* ptr);
+int nvbio_hip_device_free(void* ptr);             /* hipFree's contract: waits for the device */
+int nvbio_hip_device_free_ordered(void* ptr);     /* opt-in, does not stop the host: see "Memory helpers" below */
+int nvbio_hip_device_free_after(void* ptr, void* stream);   /* the same, for a block whose work was queued on `stream` (any stream of the caller's) */
+int nvbio_hip_device_trim(void);                  /* hipFree every idle block of this device's cache */
+int nvbio_hip_device_mem_info(uint64_t* free_bytes, uint64_t* total_bytes, uint64_t* idle_cached_bytes);
 int nvbio_hip_memcpy(void* dst, const void* src, uint64_t bytes, int kind, void* stream);
 int nvbio_hip_memset(void* dst, int value, uint64_t bytes, void* stream);
 int nvbio_hip_stream_synchronize(void* stream);
@@ -866,15 +894,24 @@ void nvbio_hip_comm_set_transport(const nvbio_hip_comm_transport* transport);
  * uses the value it read when it started).  0 = the default execution.  Production code leaves them alone. */
 int nvbio_hip_set_test_switch(const char* name, int value);     /* hipErrorInvalidValue for an unknown name */
 int nvbio_hip_get_test_switch(const char* name);                /* -1 for an unknown name */
+const char* nvbio_hip_test_switch_name(int index);              /* the index-th switch's name, NULL past the last: how a binding enumerates them */
 /* Memory helpers: nvbio_hip_device_malloc / nvbio_hip_device_free hand out hipMalloc'ed blocks kept in a per-device cache of the library's own
- * (a freed block is listed and reused for a request of at least half its size; up to NVBIO_HIP_POOL_KEEP_MB = 8192 MB stay listed).  Not a
- * hipMemPool: under two host threads on one device -- the reference's nvBowtie --device 0 --device 0 -- ROCm 7.0's pool loses the contents
- * of live blocks (profiles/r05/two_threads_pool.txt).  nvbio_hip_device_free does not stop the host: work that used the block was queued before
- * the call, on the default stream, a blocking stream or a stream made by nvbio_hip_stream_create -- the default stream is put behind what each
- * of the latter holds now (hipStreamWaitEvent) --, and nvbio_hip_device_malloc returns after the default stream has drained (hipMalloc's
- * contract: the block is usable from every stream), so the next owner never overlaps the previous one's work, whichever thread it is.
- * Work on a non-blocking stream created elsewhere is not covered -- synchronise it first.  Call it from a thread bound to the device
- * the block lives on; per-batch storage lives in a hip::device_arena (include/nvbio_hip/types.h) and never comes through here. */
+ * (a freed block is listed and reused for a request of at least half its size; up to NVBIO_HIP_POOL_KEEP_MB = 2048 MB stay listed;
+ * nvbio_hip_device_trim hands the idle ones back, nvbio_hip_device_mem_info says how much is idle).  Not a hipMemPool: under two host threads
+ * on one device -- the reference's nvBowtie --device 0 --device 0 -- ROCm 7.0's pool loses the contents of live blocks
+ * (profiles/r05/two_threads_pool.txt).
+ *   nvbio_hip_device_free          hipFree's contract (the reference's cudaFree): the device is idle before the block can change hands, whatever
+ *                                  stream used it -- the caller's own non-blocking streams and torch's pool streams included.  What
+ *                                  nvbio::vector<device_tag> / device_buffer of the drop-in layer call.
+ *   nvbio_hip_device_free_ordered  opt-in, does not stop the host.  The caller vouches that all work on the block was queued, before the call, on the
+ *                                  default stream, a blocking stream or a stream made by nvbio_hip_stream_create: the default stream is put
+ *                                  behind what each of the latter holds now (hipStreamWaitEvent), and nvbio_hip_device_malloc returns after
+ *                                  the default stream has drained, so the next owner never overlaps the previous one's work, whichever thread
+ *                                  it is.  What this repository's C++ host layer uses (include/nvbio_hip/types.h).
+ *   nvbio_hip_device_free_after    the ordered form for a block all of whose work was queued on ONE known stream of the caller's (registered or not):
+ *                                  the default stream is put behind that stream too.  What a batch object's scratch (device_buffer, compat
+ *                                  alignment/batched.h) uses: it dies right after enact(stream) returns, with its kernels still queued there.
+ * Call them from a thread bound to the device the block lives on; per-batch storage lives in a hip::device_arena and comes through here once. */
 
 /* Library / device introspection (host). */
 int         nvbio_hip_abi_version(void);

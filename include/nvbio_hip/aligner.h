@@ -674,6 +674,10 @@ private:
         stats.clock.end("traceback", hip_stream);
     }
 
+    /// whether the extension rounds hand the scorer their thresholds (NVBIO_HIP_BOUNDED_DP=1, read once; off by default)
+    static bool bounded_dp() { static const bool on = [] { const char* e = getenv("NVBIO_HIP_BOUNDED_DP"); return e && atoi(e) == 1; }(); return on; }
+    bool count_jobs = false;          ///< fill Stats::dp_jobs (one host round trip per extension round; the stage clock does it too)
+
     /// the static band of banded_score_best / banded_traceback_best (score_best_inl.h:160-164)
     template <typename F>
     static void dispatch_band(const uint32 band_len, F f)
@@ -698,7 +702,7 @@ private:
         const uint32 L = reads.len;
         hip::device_vector<int32> known_score(pat_begin.size());
         hip::device_vector<uint32> hit_sink(best_sink ? pat_begin.size() * 2u : 0u);       // the DP sinks, per hit (kept for the traceback)
-        hip::device_vector<uint32> job_hit(pat_begin.size()), job_count(1);
+        hip::device_vector<uint32> job_hit(pat_begin.size()), job_count(1), work_counter(1);
         // active_read_queues.in_queue = pack_read( params.top_seed ) of the seed queue
         hip_check(nvbio_hip_pack_read_queue(seed_queue_size, seed_queue, params.select.top_seed & 1u, reinterpret_cast<uint32*>(queues.active_in.data()), hip_stream),
                   "nvbio_hip_pack_read_queue");
@@ -728,19 +732,22 @@ private:
             score_best_setup(queues, nullptr, nullptr, L, reads.rc_offset, band_len, genome_len, best_data_dvec.data(), BATCH_SIZE, worst_score,
                              pat_begin.data(), nullptr, txt_begin.data(), txt_len.data(), min_score.data(), known_score.data(),
                              job_count.data(), job_hit.data(), hip_stream);
+            // The DP jobs.  job_count stays on the device -- the scorer reads it there, so the host does not wait for the set-up kernel between
+            // the two -- and every job's score and sink are written straight back at its hit (job_hit): scores into known_score, sinks into
+            // hit_sink.  NVBIO_HIP_BOUNDED_DP=1 also hands the scorer every job's min_score (the read's second-best score, as
+            // BestScoreStream::init_context sets it): jobs that cannot beat it are given up part way by persistent waves
+            // (nvbio_amd/csrc/banded_gotoh_bounded.h) -- same records, measured slower than the plain kernel on this hardware.
             uint32 n_jobs = 0;
-            hip::synchronize(hip_stream);
-            hip_check(nvbio_hip_memcpy(&n_jobs, job_count.data(), 4u, 2, hip_stream), "nvbio_hip_memcpy(d2h)");
-            if (n_jobs)
             {
-                const PackedStringSetView<4, true> patterns(n_jobs, reads.fw_rc_words, reads.fw_rc_n_words, pat_begin.data(), nullptr, L);
-                const PackedStringSetView<2, true> texts(n_jobs, genome_words, genome_n_words, txt_begin.data(), txt_len.data(), 0u);
-                const aln::BestSinkArrays sink_arrays = { hit_score.data(), sinks.data() };
+                const uint32 nh = queues.hits_size;
+                const PackedStringSetView<4, true> patterns(nh, reads.fw_rc_words, reads.fw_rc_n_words, pat_begin.data(), nullptr, L);
+                const PackedStringSetView<2, true> texts(nh, genome_words, genome_n_words, txt_begin.data(), txt_len.data(), 0u);
+                const aln::BestSinkArrays sink_arrays = { known_score.data(), best_sink ? hit_sink.data() : sinks.data() };
                 dispatch_band(band_len, [&](auto band) {
-                    aln::batch_banded_alignment_score<decltype(band)::value>(aligner, patterns, reads.quals, reads.n_quals, texts, sink_arrays, L, L + band_len, hip_stream);
+                    aln::batch_banded_alignment_score<decltype(band)::value>(aligner, patterns, reads.quals, reads.n_quals, texts, bounded_dp() ? min_score.data() : nullptr,
+                                                                             job_count.data(), work_counter.data(), job_hit.data(), sink_arrays, L, L + band_len, hip_stream);
                 });
-                hip_check(nvbio_hip_scatter_rows(n_jobs, job_hit.data(), hit_score.data(), known_score.data(), 4u, hip_stream), "nvbio_hip_scatter_rows");
-                if (best_sink) hip_check(nvbio_hip_scatter_rows(n_jobs, job_hit.data(), sinks.data(), hit_sink.data(), 8u, hip_stream), "nvbio_hip_scatter_rows");
+                if (stats.clock.enabled || count_jobs) { hip::synchronize(hip_stream); hip_check(nvbio_hip_memcpy(&n_jobs, job_count.data(), 4u, 2, hip_stream), "nvbio_hip_memcpy(d2h)"); }
             }
             stats.dp_jobs += n_jobs;
             stats.clock.end("score", hip_stream);

@@ -229,6 +229,35 @@ void batch_banded_alignment_score(
                                                 patterns.size(), sinks.score, sinks.sink, hip_stream), "nvbio_hip_banded_gotoh_score_qual");
 }
 
+/// ... with the stream's per-job min_score (BestScoreStream::init_context sets it to the read's second-best score, score_best_inl.h:113-116;
+/// banded_alignment_score takes it for its early-out, gotoh_banded_inl.h:622-634): a job that cannot end above min_score[i] is given up and
+/// reports some score <= min_score[i] -- what nvBowtie's reduction does with it is the same (reduce_inl.h:111-135); jobs ending above it are
+/// exact.  `n_jobs_on_device` (optional): the job count lives on the device and patterns.size() is only the arrays' capacity -- no host
+/// round trip between the kernel that counts the jobs and this one.  `work_counter`: 4 bytes of device scratch owned by the caller.
+/// `out_index` (optional): job i's score and sink are written at sinks.score[out_index[i]] / sinks.sink[out_index[i]].
+template <uint32 BAND_LEN, AlignmentType TYPE, typename pattern_set_type, typename text_set_type>
+void batch_banded_alignment_score(
+    const GotohAligner<TYPE, SmithWatermanScoringScheme> aligner,
+    const pattern_set_type  patterns,
+    const uint8*            quals,
+    const uint64            n_quals,
+    const text_set_type     texts,
+    const int32*            min_score,
+    const uint32*           n_jobs_on_device,
+          uint32*           work_counter,
+    const uint32*           out_index,
+          BestSinkArrays    sinks,
+    const uint32            max_pattern_length,
+    const uint32            max_text_length,
+    void*                   hip_stream = nullptr)
+{
+    const nvbio_hip_gotoh_qual_scheme sc = aligner.scheme.abi();
+    const nvbio_hip_string_set p = patterns.abi(), t = texts.abi();
+    hip_check(nvbio_hip_banded_gotoh_score_qual_bounded(&sc, int32(TYPE), BAND_LEN, &p, quals, n_quals, nullptr, &t, max_pattern_length, max_text_length,
+                                                        patterns.size(), n_jobs_on_device, min_score, work_counter, out_index, sinks.score, sinks.sink, hip_stream),
+              "nvbio_hip_banded_gotoh_score_qual_bounded");
+}
+
 } // namespace aln
 
 /// io::Cigar (nvbio/io/alignments.h:57-75): what nvBowtie's Backtracker writes

@@ -124,16 +124,20 @@ __global__ void __launch_bounds__(128) batched_full_score_kernel(const stream_ty
 /// a growable device buffer owned by a batch object (the reference keeps a thrust::device_vector<uint8> there)
 /// a batch object's scratch (job tables, staged strings, boundary columns).  Callers make a fresh batch object per call (sw-benchmark.cu:373-378,
 /// nvBowtie's score / traceback functions), and a plain hipMalloc costs ~4 ms here -- a third of sw-benchmark's timed enact() -- so the
-/// blocks come from the library's block cache (nvbio_hip_device_malloc: hipMalloc / hipFree semantics, freed blocks kept; the free does not stop the host,
-/// which matters here: the batch object dies -- and frees its scratch -- right after enact() returns, with its kernels still queued)
+/// blocks come from the library's block cache (nvbio_hip_device_malloc; freed blocks kept).  The batch object dies -- and frees its scratch -- right
+/// after enact() returns, with its kernels still queued on enact's stream: the buffer remembers that stream and frees with
+/// nvbio_hip_device_free_after, which orders the next owner behind it without stopping the host
 struct device_buffer
 {
-    device_buffer() : ptr(nullptr), bytes(0) {}
+    device_buffer() : ptr(nullptr), bytes(0), last(nullptr) {}
     ~device_buffer() { release(); }
     device_buffer(const device_buffer&) = delete;
     device_buffer& operator=(const device_buffer&) = delete;
-    uint8* reserve(const uint64 n)
+    /// `hs`: the stream the caller is about to use the buffer on
+    uint8* reserve(const uint64 n, void* hs = nullptr)
     {
+        if (hs != last && ptr && n > bytes) release();     // (a buffer that moves to another stream AND grows: free it behind the old one)
+        last = hs;
         if (n > bytes)
         {
             release();
@@ -150,13 +154,13 @@ struct device_buffer
     {
         if (!ptr) return;
 #if defined(NVBIO_HIP_COMPAT_TUNED)
-        (void)nvbio_hip_device_free(ptr);
+        (void)nvbio_hip_device_free_after(ptr, last);
 #else
         (void)hipFree(ptr);
 #endif
         ptr = nullptr; bytes = 0;
     }
-    uint8* ptr; uint64 bytes;
+    uint8* ptr; uint64 bytes; void* last;
 };
 /// a few words of PINNED host memory per host thread, for the small read-backs between a batch's kernels (bounds, limits): hipMemcpyAsync
 /// into pageable memory took 4.5 ms per call on the GPU box (a third of sw-benchmark's timed enact()); into pinned memory it is a DMA
@@ -337,7 +341,7 @@ struct limits_scope
         if (trusted) limits_reader<stream_type, trusted>::read(s, v[0], v[1]);
         else if (s.size())
         {
-            uint32* d = reinterpret_cast<uint32*>(scratch.reserve(64u));
+            uint32* d = reinterpret_cast<uint32*>(scratch.reserve(64u, hs));
             check(hipMemsetAsync(d, 0, 8u, hs), "hipMemsetAsync");
             const uint32 blocks = uint32(std::min<uint64>((uint64(s.size()) + 255u) / 256u, 4096u));
             hipLaunchKernelGGL((measure_limits_kernel<stream_type>), dim3(blocks), dim3(256), 0, hs, s, d);
@@ -595,7 +599,7 @@ inline void build_job_table(const stream_type& stream, device_buffer& buf, job_t
     const uint32 maxP = maxP_of(stream);
     const uint64 table = (job_table::bytes(n) + 15u) & ~uint64(15);
     const uint64 stage = R::staged ? ((job_table::stage_bytes(n, maxP, R::stage_quals) + 15u) & ~uint64(15)) : 0u;
-    uint8* base = buf.reserve(table + stage + extra_bytes + 16u);
+    uint8* base = buf.reserve(table + stage + extra_bytes + 16u, hs);
     t.carve(base, n);
     if (R::staged)
     {
@@ -637,7 +641,7 @@ inline bool build_view_table(const stream_type& stream, device_buffer& buf, job_
     typedef typename pattern_source<typename R::pattern_type>::where_type where_type;
     const uint32 n = stream.size();
     const uint64 table = (job_table::bytes(n) + 15u) & ~uint64(15);
-    t.carve(buf.reserve(table + 16u), n);
+    t.carve(buf.reserve(table + 16u, hs), n);
     hipLaunchKernelGGL(init_bounds_kernel, dim3(1), dim3(64), 0, hs, t.bounds);
     hipLaunchKernelGGL((describe_views_kernel<stream_type, R>), dim3(std::min<uint32>((n + 255u) / 256u, 8192u)), dim3(256), 0, hs, stream, t);
     unsigned long long b[8];
@@ -924,7 +928,7 @@ private:
         const uint32 n = stream.size();
         const uint64 stride = column_stride(priv::maxP_of(stream), priv::maxT_of(stream));
         const uint64 need = uint64(n) * stride * sizeof(int16);
-        if (temp == NULL || temp_size < need) temp = m_columns.reserve(need);          // batched_inl.h:402-408: allocate when the caller gave none
+        if (temp == NULL || temp_size < need) temp = m_columns.reserve(need, hs);          // batched_inl.h:402-408: allocate when the caller gave none
         hipLaunchKernelGGL((priv::batched_full_score_kernel<stream_type>), dim3((n + 127u) / 128u), dim3(128), 0, hs, stream, reinterpret_cast<int16*>(temp), stride);
         priv::check(hipGetLastError(), "batched_full_score_kernel");
         m_path = "generic";
@@ -1045,7 +1049,7 @@ struct traceback_runner
     {
         const uint32 n = stream.size(), maxP = maxP_of(stream), maxT = maxT_of(stream);
         const uint64 stride = BAND_LEN ? banded_traceback_scratch(BAND_LEN ? BAND_LEN : 1u, maxP) : full_traceback_scratch(maxP, maxT);
-        uint8* scratch = m_temp.reserve(uint64(n) * stride + 16u);
+        uint8* scratch = m_temp.reserve(uint64(n) * stride + 16u, hs);
         launch_generic(stream, scratch, stride, maxP, maxT, hs, std::integral_constant<bool, BAND_LEN != 0u>());
         check(hipGetLastError(), "batched_traceback_kernel");
         m_path = "generic";
@@ -1072,7 +1076,7 @@ struct traceback_runner
         uint32* cigar_len = source + 2u * uint64(n);
         uint16* cigar = reinterpret_cast<uint16*>(cigar_len + n);
         const uint64 tb = band ? nvbio_hip_banded_gotoh_traceback_temp_bytes(band, maxP, n) : nvbio_hip_gotoh_traceback_temp_bytes(maxP, maxT, n);
-        uint8* temp = m_temp.reserve(tb + 16u);
+        uint8* temp = m_temp.reserve(tb + 16u, hs);
         const int err = scheme.traceback(band, stream, t, ps, ts, quals, n_quals, source, cigar, stride, cigar_len, temp, tb, hs);
         if (err == 801) { run_device(stream, hs, std::false_type()); return; }     // e.g. asymmetric linear gaps, values beyond int16
         if (err != 0) fprintf(stderr, "compat traceback: err %d band %u n %u maxP %u maxT %u stride %u tb %llu quals %p n_quals %llu ps{words %p n %llu bits %u} ts{words %p n %llu}\n", err, band, n, maxP, maxT, stride,

@@ -5,6 +5,8 @@
 // lookup_ssa_iterator (nvbio/fmindex/fmindex_inl.h) in their batched form, and
 // FMIndexFilterDevice (nvbio/fmindex/filter.h:139-203) with the reference's member names.
 #pragma once
+#include <stdlib.h>
+#include <string>
 #include "strings.h"
 
 namespace nvbio {
@@ -58,6 +60,74 @@ inline void locate_ssa_iterator(const fm_index_device& fmi, uint32 n, const uint
 { hip_check(nvbio_hip_fm_locate_ssa_iterator(&fmi.m, rows, n, reinterpret_cast<uint32*>(out), stream), "nvbio_hip_fm_locate_ssa_iterator"); }
 inline void lookup_ssa_iterator(const fm_index_device& fmi, uint32 n, const uint2* it, uint32* out, void* stream = nullptr)
 { hip_check(nvbio_hip_fm_lookup_ssa_iterator(&fmi.m, reinterpret_cast<const uint32*>(it), n, out, stream), "nvbio_hip_fm_lookup_ssa_iterator"); }
+
+/// The index an MI355X's HBM is there for, built on the device from a loaded index and owning the extra arrays: the line-native two-symbol
+/// records (one 128-byte line per backward-search step pair), the match range of every 12-mer (128 MiB) and a denser -- when it fits, the
+/// whole -- suffix array (12 GB at 3 Gbp: locate without an LF walk).  Every result is bit-identical to the lean index's; only the time
+/// changes (seeding + locate about 2x).  What is built follows the memory that is free when build() runs:
+/// `budget_bytes` (0 = 35 % of the device's free memory; the drivers' per-batch workspace and a reverse index want their share too).
+/// NVBIO_HIP_INDEX=lean|line_native|rich overrides (lean: nothing built; line_native: the two-symbol records only; rich: everything, the
+/// whole suffix array, fail if it does not fit).
+struct fm_index_hbm
+{
+    hip::device_vector<uint32> dimer, ktab, ssa;
+    fm_index_device            index;          ///< the view to hand to map / locate / the drivers (points into `base`'s and this object's arrays)
+    uint32                     ktab_k, sa_int;
+    bool                       line_native;
+    fm_index_hbm() : ktab_k(0), sa_int(0), line_native(false) {}
+
+    void build(const fm_index_device& base, uint64 budget_bytes = 0, void* stream = nullptr)
+    {
+        index = base; ktab_k = 0; sa_int = base.m.sa_int; line_native = false;
+        const char* env = getenv("NVBIO_HIP_INDEX");
+        const std::string policy = env ? env : "auto";
+        if (policy == "lean" || base.m.bwt_occ == nullptr) return;
+        uint64 free_b = 0, total_b = 0, idle_b = 0;
+        hip_check(nvbio_hip_device_mem_info(&free_b, &total_b, &idle_b), "nvbio_hip_device_mem_info");
+        uint64 budget = budget_bytes ? budget_bytes : uint64(double(free_b + idle_b) * 0.35);
+        if (policy == "rich") budget = ~uint64(0);
+        const uint32 n = base.m.length;
+        // the two-symbol records
+        {
+            const uint64 bytes = nvbio_hip_fm_dimer_index_bytes(n), temp_bytes = nvbio_hip_fm_build_dimer_index_temp_bytes(n);
+            if (bytes + temp_bytes <= budget)
+            {
+                dimer.resize((bytes + 3u) / 4u);
+                hip::device_vector<uint8> temp(temp_bytes);
+                nvbio_hip_fmindex plain = base.m; plain.dimer = nullptr; plain.trimer = nullptr; plain.ktab = nullptr; plain.ktab_k = 0;
+                hip_check(nvbio_hip_fm_build_dimer_index(&plain, dimer.data(), temp.data(), temp_bytes, stream), "nvbio_hip_fm_build_dimer_index");
+                hip_check(index.set_dimer(dimer.data(), stream), "nvbio_hip_fm_attach_dimer_index");
+                hip::synchronize(stream);
+                line_native = true; budget -= bytes;
+            }
+        }
+        if (policy == "line_native") return;
+        // every 12-mer's range
+        if ((uint64(2) << 24) * 4u <= budget)
+        {
+            ktab.resize(size_t(2) << 24);
+            build_ktab(index, 12u, ktab.data(), stream);
+            index.set_ktab(ktab.data(), 12u); ktab_k = 12u; budget -= (uint64(2) << 24) * 4u;
+        }
+        // the densest suffix array that fits
+        if (base.m.ssa)
+            for (uint32 s = 1; s < base.m.sa_int; s *= 2)
+            {
+                const uint64 entries = nvbio_hip_fm_dense_ssa_entries(n, s);
+                if (entries * 4u > budget) { if (policy == "rich") throw hip_error("fm_index_hbm: the whole suffix array does not fit", 2); continue; }
+                ssa.resize(entries);
+                hip_check(nvbio_hip_fm_build_dense_ssa(&index.m, s, ssa.data(), stream), "nvbio_hip_fm_build_dense_ssa");
+                hip::synchronize(stream);
+                index.m.ssa = ssa.data(); index.m.sa_int = s; sa_int = s;
+                break;
+            }
+    }
+    /// "line_native ktab12 sa_int=1": what the index a run used was
+    std::string description() const
+    {
+        return std::string(line_native ? "line_native" : "reference_layout") + (ktab_k ? " ktab" + std::to_string(ktab_k) : std::string()) + " sa_int=" + std::to_string(sa_int);
+    }
+};
 
 /// FMIndexFilter<device_tag, fm_index>  (filter.h:139-203)
 template <typename system_tag, typename fm_index_type> struct FMIndexFilter {};

@@ -92,15 +92,32 @@ struct FMIndexDataHost : public FMIndexDataCore
 /// The device side: interleaved bwt|occ records (built on the device) + SSA, as fm_index_device views
 struct FMIndexDataDevice : public FMIndexDataCore
 {
-    FMIndexDataDevice(const FMIndexDataHost& host, const uint32 flags = FORWARD | REVERSE) : m_seq_length(host.m_seq_length)
+    /// hbm_rich (the default on this hardware): index() / rindex() come back in the form the device's free memory allows (enrich())
+    FMIndexDataDevice(const FMIndexDataHost& host, const uint32 flags = FORWARD | REVERSE, const bool hbm_rich = true) : m_seq_length(host.m_seq_length)
     {
         for (int i = 0; i < 5; ++i) m_L2[i] = m_rL2[i] = 0;
         if ((flags & FORWARD) && !host.m_bwt.empty())  upload(host.m_bwt,  host.m_ssa,  host.m_primary,  m_bwt_occ,  m_ssa,  m_L2,  m_index);
         if ((flags & REVERSE) && !host.m_rbwt.empty()) upload(host.m_rbwt, host.m_rssa, host.m_rprimary, m_rbwt_occ, m_rssa, m_rL2, m_rindex);
+        if (hbm_rich) enrich();
     }
-    const fm_index_device& index()  const { return m_index; }
-    const fm_index_device& rindex() const { return m_rindex; }
+    FMIndexDataDevice(const FMIndexDataDevice&) = delete;              // index() points into this object's arrays
+    FMIndexDataDevice& operator=(const FMIndexDataDevice&) = delete;
+    /// the forward / reverse index as the drivers should use it: the HBM-rich form once enrich() has run, else as loaded
+    const fm_index_device& index()  const { return m_rich ? m_hbm.index  : m_index; }
+    const fm_index_device& rindex() const { return m_rich ? m_rhbm.index : m_rindex; }
+    /// the indices exactly as loaded (the reference's layout: bwt|occ records + SA sampled every 16 rows)
+    const fm_index_device& lean_index()  const { return m_index; }
+    const fm_index_device& lean_rindex() const { return m_rindex; }
     uint32 genome_length() const { return m_seq_length; }
+    /// build what this device's free memory allows on top of the loaded arrays (fm_index_hbm: line-native records, 12-mer table, a
+    /// denser suffix array; NVBIO_HIP_INDEX=lean turns it off).  Results of every stage stay bit-identical.
+    void enrich(void* stream = nullptr)
+    {
+        if (m_index.m.bwt_occ)  m_hbm.build(m_index, 0, stream);
+        if (m_rindex.m.bwt_occ) m_rhbm.build(m_rindex, 0, stream);
+        m_rich = true;
+    }
+    std::string description() const { return m_rich ? m_hbm.description() : std::string("reference_layout sa_int=16"); }
 
 private:
     void upload(const std::vector<uint32>& bwt, const std::vector<uint32>& ssa, const uint32 primary,
@@ -115,6 +132,8 @@ private:
     uint32 m_seq_length, m_L2[5], m_rL2[5];
     hip::device_vector<uint32> m_bwt_occ, m_rbwt_occ, m_ssa, m_rssa;
     fm_index_device m_index, m_rindex;
+    fm_index_hbm    m_hbm, m_rhbm;
+    bool            m_rich = false;
 };
 
 /// genome loaders: (seq_length, 2-bit big-endian words); <prefix>.wpac if present, else <prefix>.pac

@@ -62,7 +62,7 @@ namespace hip {
 struct device_arena
 {
     device_arena() : used(0), taken(0) {}
-    ~device_arena() { for (size_t i = 0; i < blocks.size(); ++i) nvbio_hip_device_free(blocks[i].first); }
+    ~device_arena() { for (size_t i = 0; i < blocks.size(); ++i) nvbio_hip_device_free_ordered(blocks[i].first); }
     device_arena(const device_arena&) = delete;
     device_arena& operator=(const device_arena&) = delete;
     void* take(uint64 bytes)
@@ -89,7 +89,7 @@ struct device_arena
     {
         if (blocks.size() > 1)
         {
-            for (size_t i = 0; i < blocks.size(); ++i) nvbio_hip_device_free(blocks[i].first);
+            for (size_t i = 0; i < blocks.size(); ++i) nvbio_hip_device_free_ordered(blocks[i].first);
             blocks.clear();
             const uint64 size = ((taken + taken / 8u) + (uint64(64) << 20) - 1u) & ~((uint64(64) << 20) - 1u);
             void* p = nullptr;
@@ -120,10 +120,10 @@ struct device_vector {
     device_vector(const std::vector<T>& h) : m_ptr(nullptr), m_size(0), m_in_arena(false) { assign(h.data(), h.size()); }
     device_vector(const device_vector&) = delete;
     device_vector& operator=(const device_vector&) = delete;
-    ~device_vector() { if (m_ptr && !m_in_arena) nvbio_hip_device_free(m_ptr); }
+    ~device_vector() { if (m_ptr && !m_in_arena) nvbio_hip_device_free_ordered(m_ptr); }
     void resize(size_t n) {
         if (n == m_size) return;
-        if (m_ptr && !m_in_arena) nvbio_hip_device_free(m_ptr);
+        if (m_ptr && !m_in_arena) nvbio_hip_device_free_ordered(m_ptr);
         m_ptr = nullptr;
         if (current_arena() && (m_in_arena || m_size == 0)) { m_ptr = static_cast<T*>(current_arena()->take(uint64(n ? n : 1) * sizeof(T))); m_in_arena = true; m_size = n; return; }
         void* p = nullptr;

@@ -7,11 +7,11 @@ LIB_PATH = os.path.join(HERE, "lib", "libnvbio_hip.so")
 
 # every symbol include/nvbio_hip.h declares
 SYMBOLS = [
-    "nvbio_hip_banded_gotoh_score", "nvbio_hip_banded_gotoh_score_qual", "nvbio_hip_banded_gotoh_score_qual_views", "nvbio_hip_gotoh_score", "nvbio_hip_banded_sw_score", "nvbio_hip_sw_score", "nvbio_hip_alignment_score", "nvbio_hip_alignment_score_qual",
+    "nvbio_hip_banded_gotoh_score", "nvbio_hip_banded_gotoh_score_qual", "nvbio_hip_banded_gotoh_score_qual_views", "nvbio_hip_banded_gotoh_score_qual_bounded", "nvbio_hip_gotoh_score", "nvbio_hip_banded_sw_score", "nvbio_hip_sw_score", "nvbio_hip_alignment_score", "nvbio_hip_alignment_score_qual",
     "nvbio_hip_banded_gotoh_traceback_temp_bytes", "nvbio_hip_banded_gotoh_traceback", "nvbio_hip_banded_gotoh_traceback_qual",
     "nvbio_hip_gotoh_traceback_temp_bytes", "nvbio_hip_gotoh_traceback", "nvbio_hip_gotoh_traceback_qual", "nvbio_hip_gotoh_traceback_known_score", "nvbio_hip_gotoh_traceback_qual_known_score", "nvbio_hip_known_score_redone", "nvbio_hip_banded_sw_traceback", "nvbio_hip_sw_traceback",
     "nvbio_hip_fm_rank", "nvbio_hip_fm_rank4", "nvbio_hip_fm_rank_range",
-    "nvbio_hip_fm_match", "nvbio_hip_fm_build_ktab",
+    "nvbio_hip_fm_match", "nvbio_hip_fm_build_ktab", "nvbio_hip_fm_dense_ssa_entries", "nvbio_hip_fm_build_dense_ssa",
     "nvbio_hip_banded_gotoh_score_host", "nvbio_hip_banded_sw_score_host", "nvbio_hip_alignment_score_host",
     "nvbio_hip_fm_rank_host", "nvbio_hip_fm_match_host", "nvbio_hip_fm_locate_host",
     "nvbio_hip_fm_dimer_index_bytes", "nvbio_hip_fm_build_dimer_index_temp_bytes", "nvbio_hip_fm_build_dimer_index", "nvbio_hip_fm_attach_dimer_index",
@@ -28,11 +28,11 @@ SYMBOLS = [
     "nvbio_hip_fm_locate_ssa_iterator", "nvbio_hip_fm_lookup_ssa_iterator",
     "nvbio_hip_fm_filter_temp_bytes", "nvbio_hip_fm_filter_rank", "nvbio_hip_fm_filter_locate",
     "nvbio_hip_build_bwt_occ_temp_bytes", "nvbio_hip_build_bwt_occ",
-    "nvbio_hip_device_malloc", "nvbio_hip_device_free", "nvbio_hip_memcpy", "nvbio_hip_memset",
+    "nvbio_hip_device_malloc", "nvbio_hip_device_free", "nvbio_hip_device_free_ordered", "nvbio_hip_device_free_after", "nvbio_hip_device_trim", "nvbio_hip_device_mem_info", "nvbio_hip_memcpy", "nvbio_hip_memset",
     "nvbio_hip_stream_synchronize", "nvbio_hip_stream_create", "nvbio_hip_stream_destroy",
     "nvbio_hip_comm_available", "nvbio_hip_device_count", "nvbio_hip_set_device", "nvbio_hip_get_device", "nvbio_hip_comm_unique_id", "nvbio_hip_comm_init_rank",
     "nvbio_hip_comm_init_all", "nvbio_hip_comm_destroy", "nvbio_hip_comm_rank", "nvbio_hip_gather_records", "nvbio_hip_comm_abort", "nvbio_hip_comm_set_transport",
-    "nvbio_hip_abi_version", "nvbio_hip_arch", "nvbio_hip_last_kernel", "nvbio_hip_set_test_switch", "nvbio_hip_get_test_switch",
+    "nvbio_hip_abi_version", "nvbio_hip_arch", "nvbio_hip_last_kernel", "nvbio_hip_set_test_switch", "nvbio_hip_get_test_switch", "nvbio_hip_test_switch_name",
 ]
 
 
@@ -67,6 +67,7 @@ class FMIndexStruct(C.Structure):        # nvbio_hip_fmindex
 
 
 _lib = None
+ABI_VERSION = 2
 
 
 def lib():
@@ -78,6 +79,14 @@ def lib():
                 "nvbio_amd: %s is missing -- build it with `python -m nvbio_amd.build` "
                 "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
         L = C.CDLL(LIB_PATH)
+        # the version first: a stale library fails here with the message that says what to do, not on a symbol it lacks
+        try:
+            L.nvbio_hip_abi_version.restype = C.c_int
+            found = L.nvbio_hip_abi_version()
+        except AttributeError:
+            found = None
+        if found != ABI_VERSION:
+            raise RuntimeError("nvbio_amd: lib/libnvbio_hip.so has ABI version %s, this package needs %d -- rebuild it (python -m nvbio_amd.build)" % (found, ABI_VERSION))
         for s in SYMBOLS:
             getattr(L, s)   # AttributeError if the library does not export the ABI
         vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32
@@ -85,6 +94,7 @@ def lib():
         L.nvbio_hip_banded_gotoh_score.argtypes = [P(GotohSchemeStruct), i32, u32, P(StringSetStruct), P(StringSetStruct), u32, u32, u32, vp, vp, vp]
         L.nvbio_hip_banded_gotoh_score_qual.argtypes = [P(GotohQualSchemeStruct), i32, u32, P(StringSetStruct), vp, u64, P(StringSetStruct), u32, u32, u32, vp, vp, vp]
         L.nvbio_hip_banded_gotoh_score_qual_views.argtypes = [P(GotohQualSchemeStruct), i32, u32, P(StringSetStruct), vp, u64, vp, P(StringSetStruct), u32, u32, u32, vp, vp, vp]
+        L.nvbio_hip_banded_gotoh_score_qual_bounded.argtypes = [P(GotohQualSchemeStruct), i32, u32, P(StringSetStruct), vp, u64, vp, P(StringSetStruct), u32, u32, u32, vp, vp, vp, vp, vp, vp, vp]
         L.nvbio_hip_banded_gotoh_traceback_temp_bytes.argtypes = [u32, u32, u32]
         L.nvbio_hip_banded_gotoh_traceback_temp_bytes.restype = u64
         L.nvbio_hip_banded_gotoh_traceback.argtypes = [P(GotohSchemeStruct), i32, u32, P(StringSetStruct), P(StringSetStruct), u32, u32, u32,
@@ -200,8 +210,13 @@ def lib():
         L.nvbio_hip_abi_version.restype = C.c_int
         L.nvbio_hip_set_test_switch.argtypes = [C.c_char_p, C.c_int]
         L.nvbio_hip_get_test_switch.argtypes = [C.c_char_p]
-        if L.nvbio_hip_abi_version() != 2:
-            raise RuntimeError("nvbio_amd: lib/libnvbio_hip.so has ABI version %d, this package needs 2 -- rebuild it (python -m nvbio_amd.build)" % L.nvbio_hip_abi_version())
+        L.nvbio_hip_fm_dense_ssa_entries.argtypes = [u32, u32]
+        L.nvbio_hip_fm_dense_ssa_entries.restype = u64
+        L.nvbio_hip_fm_build_dense_ssa.argtypes = [P(FMIndexStruct), u32, vp, vp]
+        L.nvbio_hip_test_switch_name.argtypes = [C.c_int]
+        L.nvbio_hip_test_switch_name.restype = C.c_char_p
+        L.nvbio_hip_device_free_after.argtypes = [vp, vp]
+        L.nvbio_hip_device_mem_info.argtypes = [P(u64), P(u64), P(u64)]
         L.nvbio_hip_arch.restype = C.c_char_p
         L.nvbio_hip_last_kernel.restype = C.c_char_p
         _lib = L
@@ -211,6 +226,23 @@ def lib():
 def check(err, what):
     if err != 0:
         raise RuntimeError("nvbio_amd: %s failed with hipError %d" % (what, err))
+
+
+def test_switch_names():
+    """the names of the library's test switches, as the library lists them (nvbio_hip_test_switch_name)"""
+    out, k = [], 0
+    while True:
+        n = lib().nvbio_hip_test_switch_name(k)
+        if not n:
+            return out
+        out.append(n.decode()); k += 1
+
+
+def device_mem_info():
+    """(free, total, idle bytes in the library's block cache) of the current device"""
+    f, t, i = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    check(lib().nvbio_hip_device_mem_info(C.byref(f), C.byref(t), C.byref(i)), "nvbio_hip_device_mem_info")
+    return f.value, t.value, i.value
 
 
 def set_test_switch(name, value):

@@ -142,11 +142,16 @@ class BatchedBandedAlignmentScore:
 
     max_temp_storage = min_temp_storage
 
-    def enact(self, aligner, patterns, texts, out_score, out_sink, max_pattern_length=0, max_text_length=0, quals=None, pattern_flags=None):
+    def enact(self, aligner, patterns, texts, out_score, out_sink, max_pattern_length=0, max_text_length=0, quals=None, pattern_flags=None,
+              min_score=None, n_on_device=None, out_index=None):
         """quals: uint8 device tensor indexed like the pattern stream's symbols -- required by (and only
         used with) a SmithWatermanScoringScheme aligner, as nvBowtie's read qualities are.
         pattern_flags: optional uint8 device tensor, one byte per job -- the io::ReadStream view nvBowtie's streams take of a stored
-        read (bit 0 = walk it backwards, bit 1 = complement), applied by the kernel as it fetches (quality scheme only)."""
+        read (bit 0 = walk it backwards, bit 1 = complement), applied by the kernel as it fetches (quality scheme only).
+        min_score: optional int32 device tensor, one threshold per job (the reference's min_score argument, quality scheme only): a job that
+        cannot end above its threshold is given up and reports some score <= the threshold and the sink (-1, -1); jobs that end above it are
+        exact (nvbio_hip_banded_gotoh_score_qual_bounded).  n_on_device: optional int32[1] device tensor holding the job count.  out_index: optional
+        int32 device tensor: job i's results go to out_score[out_index[i]] / out_sink[out_index[i]]."""
         n = len(patterns)
         if patterns.length is None:
             max_pattern_length = max_pattern_length or patterns.fixed_length
@@ -168,6 +173,19 @@ class BatchedBandedAlignmentScore:
             assert quals is not None and quals.dtype == torch.uint8 and quals.is_cuda and quals.is_contiguous()
             if pattern_flags is not None:
                 assert pattern_flags.dtype == torch.uint8 and pattern_flags.is_cuda and pattern_flags.numel() >= n
+            if min_score is not None or n_on_device is not None or out_index is not None:
+                assert min_score is None or (min_score.dtype == torch.int32 and min_score.is_cuda and min_score.numel() >= n)
+                counter = torch.empty(1, dtype=torch.int32, device=out_score.device)
+                err = lib().nvbio_hip_banded_gotoh_score_qual_bounded(
+                    C.byref(sc), aligner.type, self.band_len, C.byref(ps), C.c_void_p(quals.data_ptr()), quals.numel(),
+                    C.c_void_p(pattern_flags.data_ptr()) if pattern_flags is not None else None, C.byref(ts),
+                    int(max_pattern_length), int(max_text_length), n,
+                    C.c_void_p(n_on_device.data_ptr()) if n_on_device is not None else None,
+                    C.c_void_p(min_score.data_ptr()) if min_score is not None else None, C.c_void_p(counter.data_ptr()),
+                    C.c_void_p(out_index.data_ptr()) if out_index is not None else None,
+                    C.c_void_p(out_score.data_ptr()), C.c_void_p(out_sink.data_ptr()), current_stream_ptr())
+                check(err, "nvbio_hip_banded_gotoh_score_qual_bounded")
+                return
             err = lib().nvbio_hip_banded_gotoh_score_qual_views(
                 C.byref(sc), aligner.type, self.band_len, C.byref(ps), C.c_void_p(quals.data_ptr()), quals.numel(),
                 C.c_void_p(pattern_flags.data_ptr()) if pattern_flags is not None else None, C.byref(ts),
@@ -184,7 +202,7 @@ class BatchedBandedAlignmentScore:
 
 
 def batch_banded_alignment_score(band_len, aligner, patterns, texts, out_score=None, out_sink=None,
-                                 max_pattern_length=0, max_text_length=0, quals=None, pattern_flags=None):
+                                 max_pattern_length=0, max_text_length=0, quals=None, pattern_flags=None, min_score=None, n_on_device=None):
     """batch_banded_alignment_score<BAND_LEN>(aligner, patterns, texts, sinks, DeviceThreadScheduler()).
     Returns (score[n] int32, sink[n,2] int32 holding the uint32 bit patterns)."""
     n = len(patterns)
@@ -194,7 +212,7 @@ def batch_banded_alignment_score(band_len, aligner, patterns, texts, out_score=N
     if out_sink is None:
         out_sink = torch.empty((n, 2), dtype=torch.int32, device=dev)
     BatchedBandedAlignmentScore(band_len).enact(aligner, patterns, texts, out_score, out_sink,
-                                                max_pattern_length, max_text_length, quals, pattern_flags)
+                                                max_pattern_length, max_text_length, quals, pattern_flags, min_score, n_on_device)
     return out_score, out_sink
 
 

@@ -36,7 +36,7 @@
 //    to that length run the 16-bit kernel, longer ones the 32-bit kernel.
 //    Both produce the reference's int32 results bit for bit.
 //
-#include "banded_gotoh_impl.h"
+#include "banded_gotoh_bounded.h"
 #include <mutex>
 #include <unordered_map>
 #include <atomic>
@@ -54,6 +54,24 @@ thread_local const char* g_last_kernel = "";
     extern template hipError_t launch_band_width<B, QualArgs>(const GotohParams&, const QualArgs&, int, bool, hipStream_t);
 NVB_DECL(3) NVB_DECL(5) NVB_DECL(7) NVB_DECL(15) NVB_DECL(31)
 #undef NVB_DECL
+#define NVB_DECL(B) \
+    extern template hipError_t launch_band_width_bounded<B, NoQual>(const GotohParams&, const NoQual&, const BoundArgs&, int, bool, hipStream_t); \
+    extern template hipError_t launch_band_width_bounded<B, QualArgs>(const GotohParams&, const QualArgs&, const BoundArgs&, int, bool, hipStream_t);
+NVB_DECL(3) NVB_DECL(5) NVB_DECL(7) NVB_DECL(15) NVB_DECL(31)
+#undef NVB_DECL
+
+template <typename QA>
+static hipError_t launch_bounded(const GotohParams& p, const QA& qa, const BoundArgs& ba, int type, uint32_t band, bool width16, hipStream_t s)
+{
+    switch (band) {
+    case 3:  return launch_band_width_bounded<3, QA>(p, qa, ba, type, width16, s);
+    case 5:  return launch_band_width_bounded<5, QA>(p, qa, ba, type, width16, s);
+    case 7:  return launch_band_width_bounded<7, QA>(p, qa, ba, type, width16, s);
+    case 15: return launch_band_width_bounded<15, QA>(p, qa, ba, type, width16, s);
+    case 31: return launch_band_width_bounded<31, QA>(p, qa, ba, type, width16, s);
+    default: return hipErrorNotSupported;
+    }
+}
 
 template <typename QA>
 static hipError_t launch(const GotohParams& p, const QA& qa, int type, uint32_t band, bool width16, hipStream_t s)
@@ -92,7 +110,8 @@ static uint32_t max_len_16bit(int32_t match, int32_t best_pair /* max substituti
 
 template <typename QA>
 static int banded_gotoh_dispatch(nvb::GotohParams& p, const QA& qa, int64_t max_abs_cost, int32_t best_pair, int32_t type, uint32_t band_len,
-                                 const nvbio_hip_string_set* patterns, hipStream_t s, const char* tag16, const char* tag32, const bool views = false)
+                                 const nvbio_hip_string_set* patterns, hipStream_t s, const char* tag16, const char* tag32, const bool views = false,
+                                 const nvb::BoundArgs* bound = nullptr)
 {
     using namespace nvb;
     // NVBIO_HIP_FORCE_32BIT=1 disables the 16-bit kernels (used by the tests to cover both widths)
@@ -117,16 +136,22 @@ static int banded_gotoh_dispatch(nvb::GotohParams& p, const QA& qa, int64_t max_
         }
     }
     // jobs with pattern_len <= lim16 : 16-bit arithmetic;  longer ones : 32-bit arithmetic
+    // the bounded form (banded_gotoh_bounded.h): persistent waves over a work counter, zeroed before each of the (at most two) launches
+    auto go = [&](const bool width16) -> hipError_t {
+        if (!bound) return launch<QA>(p, qa, type, band_len, width16, s);
+        if (hipError_t z = hipMemsetAsync(bound->counter, 0, 4u, s)) return z;
+        return launch_bounded<QA>(p, qa, *bound, type, band_len, width16, s);
+    };
     if (lim16 > 0 && (!fixed || patterns->fixed_length <= lim16)) {
         p.len_lo = 0; p.len_hi = lim16;
         g_last_kernel = tag16;
-        e = launch<QA>(p, qa, type, band_len, true, s);
+        e = go(true);
         if (e != hipSuccess) return e;
     }
     if (lim16 != 0xFFFFFFFFu && (!fixed || patterns->fixed_length > lim16)) {
         p.len_lo = lim16 > 0 ? lim16 + 1 : 0; p.len_hi = 0xFFFFFFFFu;
         if (fixed || lim16 == 0) g_last_kernel = tag32;
-        e = launch<QA>(p, qa, type, band_len, false, s);
+        e = go(false);
     }
     return e;
 }
@@ -167,7 +192,7 @@ NVB_API int nvbio_hip_banded_gotoh_score(
     p.match = scheme->match; p.mismatch = scheme->mismatch;
     p.gap_open = scheme->gap_open; p.gap_ext = scheme->gap_ext;
     p.txt_gap_open = scheme->gap_open; p.txt_gap_ext = scheme->gap_ext;      // SimpleGotohScheme: utils.h:128-131
-    p.n = n; p.out_score = out_score; p.out_sink = out_sink;
+    p.n = n; p.out_score = out_score; p.out_sink = out_sink; p.n_dev = nullptr; p.out_index = nullptr;
     p.stage_pw = max_pattern_len; p.stage_tw = 0;       // the hint, consumed by banded_gotoh_dispatch
     const int64_t A = std::max(std::max(iabs64(scheme->match), iabs64(scheme->mismatch)), std::max(iabs64(scheme->gap_open), iabs64(scheme->gap_ext)));
     return banded_gotoh_dispatch(p, NoQual(), A, std::max(scheme->match, scheme->mismatch), type, band_len, patterns, to_stream(stream),
@@ -205,7 +230,7 @@ NVB_API int nvbio_hip_banded_gotoh_score_qual_views(
     p.match = scheme->match; p.mismatch = 0;
     p.gap_open = scheme->pattern_gap_open; p.gap_ext = scheme->pattern_gap_ext;
     p.txt_gap_open = scheme->text_gap_open; p.txt_gap_ext = scheme->text_gap_ext;
-    p.n = n; p.out_score = out_score; p.out_sink = out_sink;
+    p.n = n; p.out_score = out_score; p.out_sink = out_sink; p.n_dev = nullptr; p.out_index = nullptr;
     p.stage_pw = max_pattern_len; p.stage_tw = 0;       // the hint, consumed by banded_gotoh_dispatch
     QualArgs qa;
     qa.quals = quals; qa.n_quals = n_quals; qa.flags = pattern_flags;
@@ -216,6 +241,57 @@ NVB_API int nvbio_hip_banded_gotoh_score_qual_views(
     return banded_gotoh_dispatch(p, qa, A, best_pair, type, band_len, patterns, to_stream(stream),
                                  pattern_flags ? "banded_gotoh_score_kernel<A16,qual,views>" : "banded_gotoh_score_kernel<A16,qual>",
                                  pattern_flags ? "banded_gotoh_score_kernel<A32,qual,views>" : "banded_gotoh_score_kernel<A32,qual>", pattern_flags != nullptr);
+}
+
+// The same scorer with a threshold per job (banded_gotoh_bounded.h): a job whose score cannot exceed min_score[i] is given up; its lane takes the next one.
+NVB_API int nvbio_hip_banded_gotoh_score_qual_bounded(
+    const nvbio_hip_gotoh_qual_scheme* scheme, int32_t type, uint32_t band_len,
+    const nvbio_hip_string_set* patterns, const uint8_t* quals, uint64_t n_quals, const uint8_t* pattern_flags,
+    const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len,
+    uint32_t n, const uint32_t* n_on_device, const int32_t* min_score, uint32_t* work_counter, const uint32_t* out_index,
+    int32_t* out_score, uint32_t* out_sink, void* stream)
+{
+    (void)max_text_len;
+    using namespace nvb;
+    if (!scheme || (min_score && !work_counter)) return hipErrorInvalidValue;
+    if (int e = check_banded_args(type, band_len, patterns, texts)) return e;
+    if (n == 0) return hipSuccess;
+    if (int e = check_banded_ptrs(patterns, texts, out_score, out_sink)) return e;
+    if (!quals || n_quals < 4) return hipErrorInvalidValue;
+
+    GotohParams p;
+    p.pat = make_string_set(patterns);
+    p.txt = make_string_set(texts);
+    p.match = scheme->match; p.mismatch = 0;
+    p.gap_open = scheme->pattern_gap_open; p.gap_ext = scheme->pattern_gap_ext;
+    p.txt_gap_open = scheme->text_gap_open; p.txt_gap_ext = scheme->text_gap_ext;
+    p.n = n; p.out_score = out_score; p.out_sink = out_sink; p.n_dev = nullptr; p.out_index = nullptr;
+    p.stage_pw = max_pattern_len; p.stage_tw = 0;
+    QualArgs qa;
+    qa.quals = quals; qa.n_quals = n_quals; qa.flags = pattern_flags;
+    int64_t A = std::max(std::max(iabs64(scheme->match), iabs64(scheme->pattern_gap_open)), std::max(iabs64(scheme->pattern_gap_ext),
+                std::max(iabs64(scheme->text_gap_open), iabs64(scheme->text_gap_ext))));
+    int32_t best_pair = scheme->match;
+    for (int i = 0; i < 256; ++i) { qa.lut[i] = scheme->mismatch[i]; A = std::max(A, iabs64(scheme->mismatch[i])); best_pair = std::max(best_pair, scheme->mismatch[i]); }
+    // without thresholds this is the plain kernel over a device-side count, writing through the index
+    if (!min_score)
+    {
+        p.n_dev = n_on_device; p.out_index = out_index;
+        return banded_gotoh_dispatch(p, qa, A, best_pair, type, band_len, patterns, to_stream(stream),
+                                     pattern_flags ? "banded_gotoh_score_kernel<A16,qual,views>" : "banded_gotoh_score_kernel<A16,qual>",
+                                     pattern_flags ? "banded_gotoh_score_kernel<A32,qual,views>" : "banded_gotoh_score_kernel<A32,qual>", pattern_flags != nullptr);
+    }
+    BoundArgs ba;
+    // a gap that scores above zero could lift a path after the bound was taken: no thresholds then (every job exact)
+    const bool gaps_ok = scheme->pattern_gap_open <= 0 && scheme->pattern_gap_ext <= 0;
+    ba.min_score = gaps_ok ? min_score : nullptr;
+    ba.n_dev = n_on_device; ba.counter = work_counter; ba.out_index = out_index;
+    ba.cap = std::max(best_pair, 0);
+    static const int refill = [] { const char* e = getenv("NVBIO_HIP_BOUNDED_REFILL"); return std::min(64, std::max(1, e ? atoi(e) : 16)); }();
+    ba.refill = uint32_t(refill);
+    return banded_gotoh_dispatch(p, qa, A, best_pair, type, band_len, patterns, to_stream(stream),
+                                 "banded_gotoh_score_bounded_kernel<A16,qual>", "banded_gotoh_score_bounded_kernel<A32,qual>", pattern_flags != nullptr, &ba);
 }
 
 // SmithWatermanAligner / EditDistanceAligner in the band (sw_banded_inl.h:340-520): with deletion == insertion the
@@ -241,12 +317,15 @@ NVB_API int nvbio_hip_banded_sw_score(
 // 2 of 3 with the pool; no two live blocks ever overlapped, a mutex around every pool call, kernel / copy serialisation and a blocking free all
 // left it in place).  So the pool is gone: a freed block goes on a free list, a request takes the smallest listed block of at least its size
 // (and at most twice it) or calls hipMalloc.
-//   free    does not stop the host.  Work that used the block was queued before the call -- on the default stream, a blocking stream, or a
-//           stream made by nvbio_hip_stream_create; for each of the latter the default stream is made to wait (hipStreamWaitEvent) for what
-//           that stream holds now.
+//   free    nvbio_hip_device_free keeps hipFree's contract: the device is idle before the block goes on the list (a drop-in caller may have
+//           used the block on a stream this library never saw -- torch's pool streams, its own hipStreamNonBlocking streams).
+//           nvbio_hip_device_free_ordered is the opt-in form that does not stop the host, for callers that vouch for their streams (this
+//           repository's C++ host layer, include/nvbio_hip/types.h): work that used the block was queued before the call -- on the default
+//           stream, a blocking stream, or a stream made by nvbio_hip_stream_create; for each of the latter the default stream is made to
+//           wait (hipStreamWaitEvent) for what that stream holds now.
 //   malloc  returns after hipStreamSynchronize(default stream), as it always did (hipMalloc's contract: usable from every stream): everything
 //           queued before the block was freed -- the waits included -- has finished by then, whichever thread freed it.
-// Blocks stay cached up to NVBIO_HIP_POOL_KEEP_MB (default 8192) per device, least recently freed first out (hipFree).  A driver's per-batch
+// Blocks stay cached up to NVBIO_HIP_POOL_KEEP_MB (default 2048) per device (nvbio_hip_device_trim hands them back), least recently freed first out (hipFree).  A driver's per-batch
 // working set lives in a hip::device_arena (include/nvbio_hip/types.h) and comes through here once.
 namespace nvb {
 static std::mutex g_streams_mtx;
@@ -268,7 +347,7 @@ struct BlockCache
 };
 static BlockCache g_cache[64];
 static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-static uint64_t cache_keep_bytes() { static const uint64_t keep = uint64_t(std::max(0, env_int("NVBIO_HIP_POOL_KEEP_MB", 8192))) << 20; return keep; }
+static uint64_t cache_keep_bytes() { static const uint64_t keep = uint64_t(std::max(0, env_int("NVBIO_HIP_POOL_KEEP_MB", 2048))) << 20; return keep; }
 // the rounds 1-4 allocator, kept for reproducing what it does under two host threads: NVBIO_HIP_ROCM_POOL=1
 static hipMemPool_t rocm_pool(int dev)
 {
@@ -355,19 +434,23 @@ NVB_API int nvbio_hip_device_malloc(void** ptr, uint64_t bytes)
     if (poison >= 0) (void)hipMemsetAsync(p, poison & 255, bytes ? bytes : 1, nullptr);
     return hipStreamSynchronize(nullptr);          // like hipMalloc: the block is usable from every stream on return
 }
-NVB_API int nvbio_hip_device_free(void* ptr)
+// free_impl: `ordered` = the non-blocking form (the caller vouches that every stream that touched the block is the default stream, a blocking
+// stream or one made by nvbio_hip_stream_create); otherwise hipFree's contract -- the device is idle before the block can change hands.
+static int free_impl(void* ptr, bool ordered, hipStream_t extra = nullptr)
 {
     if (!ptr) return hipSuccess;
     int dev = 0;
-    static const bool sync_free = nvb::env_int("NVBIO_HIP_SYNC_FREE", 0) == 1;     // debugging aid: hipFree's blocking form
+    static const bool sync_free = nvb::env_int("NVBIO_HIP_SYNC_FREE", 0) == 1;     // debugging aid: the blocking form everywhere
     const bool have_dev = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
     if (!have_dev) { if (hipError_t e = hipDeviceSynchronize()) return e; return hipFree(ptr); }
-    if (sync_free) { if (hipError_t e = hipDeviceSynchronize()) return e; }
+    if (sync_free || !ordered) { if (hipError_t e = hipDeviceSynchronize()) return e; }
     else
     {
         // the library's own non-blocking streams are not ordered with the default stream: put it behind what each of them holds now
         std::lock_guard<std::mutex> lock(nvb::g_streams_mtx);
-        for (hipStream_t s : nvb::g_streams[dev])
+        std::vector<hipStream_t> behind(nvb::g_streams[dev]);
+        if (extra && std::find(behind.begin(), behind.end(), extra) == behind.end()) behind.push_back(extra);
+        for (hipStream_t s : behind)
         {
             hipEvent_t ev = nullptr;
             hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
@@ -400,6 +483,35 @@ NVB_API int nvbio_hip_device_free(void* ptr)
     hipError_t r = hipSuccess;
     for (void* v : victims) { const hipError_t e = hipFree(v); if (e != hipSuccess) r = e; }      // (hipFree waits for the device itself)
     return r;
+}
+NVB_API int nvbio_hip_device_free(void* ptr)         { return free_impl(ptr, false); }
+NVB_API int nvbio_hip_device_free_ordered(void* ptr) { return free_impl(ptr, true); }
+NVB_API int nvbio_hip_device_free_after(void* ptr, void* stream) { return free_impl(ptr, true, nvb::to_stream(stream)); }
+// hand every idle block of the calling thread's device back to the runtime (hipFree): for a process that shares the device with another
+// allocator (torch's) and is about to let that one grow
+NVB_API int nvbio_hip_device_trim(void)
+{
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev)) return e;
+    if (dev < 0 || dev >= 64) return hipSuccess;
+    std::vector<void*> victims;
+    { std::lock_guard<std::mutex> lock(nvb::g_cache[dev].mtx); nvb::drop_idle(nvb::g_cache[dev], victims, 0); }
+    hipError_t r = hipSuccess;
+    for (void* v : victims) { const hipError_t e = hipFree(v); if (e != hipSuccess) r = e; }
+    return r;
+}
+// free / total bytes of the calling thread's device (hipMemGetInfo) plus what the library's block cache holds idle
+NVB_API int nvbio_hip_device_mem_info(uint64_t* free_bytes, uint64_t* total_bytes, uint64_t* idle_cached_bytes)
+{
+    size_t f = 0, t = 0;
+    if (hipError_t e = hipMemGetInfo(&f, &t)) return e;
+    int dev = 0;
+    uint64_t idle = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) { std::lock_guard<std::mutex> lock(nvb::g_cache[dev].mtx); idle = nvb::g_cache[dev].idle_bytes; }
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    if (idle_cached_bytes) *idle_cached_bytes = idle;
+    return hipSuccess;
 }
 // ---- streams for the C++ host layer (which has no HIP headers).  The reference's drivers run on the default stream of one host thread
 // per device (nvBowtie.cpp:809-864); here one device serves several batches at once: a driver object per host thread, each on its own
@@ -444,6 +556,7 @@ NVB_API int nvbio_hip_set_test_switch(const char* name, int value)
         if (strcmp(name, nvb::g_switch_name[k]) == 0) { nvb::g_switch[k].store(value, std::memory_order_relaxed); return hipSuccess; }
     return hipErrorInvalidValue;
 }
+NVB_API const char* nvbio_hip_test_switch_name(int index) { return (index >= 0 && index < nvb::SW_COUNT) ? nvb::g_switch_name[index] : nullptr; }
 NVB_API int nvbio_hip_get_test_switch(const char* name)
 {
     if (!name) return -1;

@@ -16,6 +16,8 @@ struct GotohParams {
     uint32_t  stage_pw, stage_tw; // words of pattern / text each lane stages in LDS (0 = read HBM per block)
     int32_t*  out_score;
     uint32_t* out_sink;
+    const uint32_t* n_dev;        // optional: the job count on the device (n is then the arrays' capacity) -- no host round trip to size the launch
+    const uint32_t* out_index;    // optional: job i's results go to out_score[out_index[i]] / out_sink[out_index[i]] (a compacted batch writing back at its hits)
 };
 
 // nvBowtie's quality-aware scheme (nvBowtie/bowtie2/cuda/scoring.h:283-293): the mismatch score is a
@@ -459,7 +461,7 @@ banded_gotoh_score_kernel(const GotohParams p, const QA qa)
     extern __shared__ __attribute__((aligned(16))) uint32_t s_stage[];    // [stage_pw + stage_tw][256]
     fill_lut<A>(s_lut, qa, p.gap_open, SH);
     const uint32_t id = blockIdx.x * 256u + threadIdx.x;
-    if (id >= p.n) return;
+    if (id >= (p.n_dev ? *p.n_dev : p.n)) return;
 
     const uint32_t M  = p.pat.length ? p.pat.length[id] : p.pat.fixed_length;
     if (M < p.len_lo || M > p.len_hi) return;                   // the other arithmetic width owns this job
@@ -545,7 +547,8 @@ banded_gotoh_score_kernel(const GotohParams p, const QA qa)
             fetch_group(ps, qa, pb, M, fl, i0 + BT::ROWS, Pn, Qn);
             const uint32_t Tn = fetch16_2bit(ts, tb + i0 + BT::ROWS + BAND - 1);
             // a block none of whose rows lets a symbol past the text's end into the band runs on table arithmetic
-            if (A::TABLE && i0 + BT::ROWS - 1u + BAND - 1u < N)
+            // (the block's last row that exists: rows past the pattern's end are skipped, so they need no symbol)
+            if (A::TABLE && (i0 + BT::ROWS < M ? i0 + BT::ROWS : M) - 1u + BAND - 1u < N)
                 RowUnrollN<BAND, TYPE, A, QUAL, true, 0, BT::ROWS>::run(st, k, i0, M, N, P, Tx, Q, s_lut, s_masks);
             else
                 RowUnrollN<BAND, TYPE, A, QUAL, false, 0, BT::ROWS>::run(st, k, i0, M, N, P, Tx, Q, s_lut, s_masks);
@@ -579,8 +582,9 @@ banded_gotoh_score_kernel(const GotohParams p, const QA qa)
             }
         }
     }
-    p.out_score[id] = score;
-    reinterpret_cast<uint2*>(p.out_sink)[id] = make_uint2(sx, sy);
+    const uint32_t o = p.out_index ? p.out_index[id] : id;
+    p.out_score[o] = score;
+    reinterpret_cast<uint2*>(p.out_sink)[o] = make_uint2(sx, sy);
 }
 
 template <int BAND, typename A, typename QA>

@@ -87,6 +87,15 @@ fm_locate_kernel(const Fmi f, const uint32_t* __restrict__ rows, uint32_t n, uin
     const uint2 it = fm_locate_it(f, rows[id]);
     out[id] = f.ssa[it.x / f.sa_int] + it.y;                      // fmindex_inl.h:500
 }
+// the suffix array sampled every `step` rows: out[k] = locate(k * step) through the index's own (sparser) SSA
+__global__ void __launch_bounds__(256)
+fm_dense_ssa_kernel(const Fmi f, uint32_t step, uint64_t n_out, uint32_t* __restrict__ out)
+{
+    const uint64_t id = uint64_t(blockIdx.x) * 256u + threadIdx.x;
+    if (id >= n_out) return;
+    const uint2 it = fm_locate_it(f, uint32_t(id * step));
+    out[id] = f.ssa[it.x / f.sa_int] + it.y;
+}
 __global__ void __launch_bounds__(256)
 fm_locate_it_kernel(const Fmi f, const uint32_t* __restrict__ rows, uint32_t n, uint2* __restrict__ out)
 {
@@ -253,6 +262,17 @@ NVB_API int nvbio_hip_fm_locate(const nvbio_hip_fmindex* fmi, const uint32_t* sa
     if (!sa_rows || !out_pos) return hipErrorInvalidValue;
     g_last_kernel = "fm_locate_kernel";
     hipLaunchKernelGGL(fm_locate_kernel, grid_for(n), dim3(256), 0, to_stream(stream), make_fmi(fmi), sa_rows, n, out_pos);
+    return hipGetLastError();
+}
+
+NVB_API uint64_t nvbio_hip_fm_dense_ssa_entries(uint32_t length, uint32_t sa_int) { return sa_int ? (uint64_t(length) + sa_int) / sa_int : 0ull; }
+NVB_API int nvbio_hip_fm_build_dense_ssa(const nvbio_hip_fmindex* fmi, uint32_t sa_int_out, uint32_t* out_ssa, void* stream)
+{
+    if (int e = check_locate(fmi)) return e;
+    if (!out_ssa || sa_int_out == 0 || (sa_int_out & (sa_int_out - 1)) != 0 || sa_int_out > fmi->sa_int) return hipErrorInvalidValue;
+    const uint64_t n_out = nvbio_hip_fm_dense_ssa_entries(fmi->length, sa_int_out);
+    g_last_kernel = "fm_dense_ssa_kernel";
+    hipLaunchKernelGGL(fm_dense_ssa_kernel, grid_for(n_out), dim3(256), 0, to_stream(stream), make_fmi(fmi), sa_int_out, n_out, out_ssa);
     return hipGetLastError();
 }
 

@@ -91,6 +91,48 @@ class FMIndexDevice:
         ssa = locate(self, rows)
         return self._copy(ssa=ssa, sa_int=sa_int)
 
+    def with_dense_ssa_native(self, sa_int):
+        """with_dense_ssa through the library's own builder (nvbio_hip_fm_build_dense_ssa): no row array, 4 bytes per kept row"""
+        assert sa_int >= 1 and (sa_int & (sa_int - 1)) == 0 and sa_int <= self.sa_int and self.ssa is not None
+        n_out = int(lib().nvbio_hip_fm_dense_ssa_entries(self.length, sa_int))
+        ssa = torch.empty(n_out, dtype=torch.int32, device=self.bwt_occ.device)
+        s = self.struct()
+        check(lib().nvbio_hip_fm_build_dense_ssa(C.byref(s), sa_int, _vp(ssa), current_stream_ptr()), "nvbio_hip_fm_build_dense_ssa")
+        return self._copy(ssa=ssa, sa_int=sa_int)
+
+    def hbm_default(self, budget_bytes=0, policy=None):
+        """The index this device's HBM is there for -- nvbio::fm_index_hbm::build of the C++ host layer (include/nvbio_hip/fmindex.h), same
+        policy: the line-native two-symbol records, every 12-mer's range, the densest suffix array that fits `budget_bytes` (0 = 35 % of
+        the memory that is free now).  NVBIO_HIP_INDEX=lean|line_native|rich overrides.  Results stay bit-identical.
+        -> (index, description dict)"""
+        import os
+        from ._lib import device_mem_info
+        policy = policy or os.environ.get("NVBIO_HIP_INDEX", "auto")
+        idx = self
+        if policy != "lean":
+            free_b, _, idle_b = device_mem_info()
+            free_b += torch.cuda.memory_reserved(self.bwt_occ.device) - torch.cuda.memory_allocated(self.bwt_occ.device)   # what torch's allocator would reuse
+            budget = budget_bytes or int((free_b + idle_b) * 0.35)
+            if policy == "rich":
+                budget = 1 << 62
+            L = lib()
+            need = int(L.nvbio_hip_fm_dimer_index_bytes(self.length)) + int(L.nvbio_hip_fm_build_dimer_index_temp_bytes(self.length))
+            if idx.dimer is None and need <= budget:
+                idx = idx.with_dimer(); budget -= int(L.nvbio_hip_fm_dimer_index_bytes(self.length))
+            if policy != "line_native":
+                if idx.ktab is None and (8 << 24) <= budget:
+                    idx = idx.with_ktab(12); budget -= 8 << 24
+                if idx.ssa is not None:
+                    s = 1
+                    while s < idx.sa_int:
+                        if int(L.nvbio_hip_fm_dense_ssa_entries(self.length, s)) * 4 <= budget:
+                            idx = idx.with_dense_ssa_native(s)
+                            break
+                        if policy == "rich":
+                            raise RuntimeError("hbm_default: the whole suffix array does not fit")
+                        s *= 2
+        return idx, {"line_native": idx.dimer is not None, "ktab_k": idx.ktab_k if idx.ktab is not None else 0, "sa_int": idx.sa_int, "policy": policy}
+
     def struct(self):
         s = FMIndexStruct()
         s.length, s.primary, s.sa_int = self.length, self.primary, self.sa_int

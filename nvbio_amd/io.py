@@ -191,12 +191,28 @@ class FMIndexDataDevice:
     <prefix>.bwt/.sa (FORWARD) and .rbwt/.rsa (REVERSE), builds the interleaved bwt|occ records on the device
     and exposes `index()` / `rindex()` as FMIndexDevice objects."""
 
-    def __init__(self, prefix, flags=FORWARD | REVERSE | SA, device="cuda"):
+    def __init__(self, prefix, flags=FORWARD | REVERSE | SA, device="cuda", hbm_rich=True):
+        """hbm_rich (the default on this hardware): index() / rindex() come back in the form the device's free memory allows --
+        line-native records, 12-mer table, a denser suffix array (FMIndexDevice.hbm_default; NVBIO_HIP_INDEX=lean turns it off).
+        lean_index() / lean_rindex() are the arrays exactly as loaded."""
         self.flags = flags
         self._fwd = self._load(prefix + ".bwt", prefix + ".sa", flags, device) if flags & FORWARD else None
         self._rev = self._load(prefix + ".rbwt", prefix + ".rsa", flags, device) if flags & REVERSE else None
         one = self._fwd or self._rev
         self.seq_length = one.length if one else 0
+        self._lean = (self._fwd, self._rev)
+        self.description = {"line_native": False, "ktab_k": 0, "sa_int": SA_INT, "policy": "lean"}
+        if hbm_rich:
+            if self._fwd is not None:
+                self._fwd, self.description = self._fwd.hbm_default()
+            if self._rev is not None:
+                self._rev, _ = self._rev.hbm_default()
+
+    def lean_index(self):
+        return self._lean[0]
+
+    def lean_rindex(self):
+        return self._lean[1]
 
     @staticmethod
     def _load(bwt_path, sa_path, flags, device):

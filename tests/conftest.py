@@ -40,6 +40,5 @@ def _default_test_switches():
     yield
     mod = sys.modules.get("nvbio_amd._lib")
     if mod is not None and getattr(mod, "_lib", None) is not None:
-        for name in ("NVBIO_HIP_FORCE_32BIT", "NVBIO_HIP_NO_STAGING", "NVBIO_HIP_FULL_GENERIC", "NVBIO_HIP_ED_SWEEP", "NVBIO_HIP_FULL_SINGLE_JOB",
-                     "NVBIO_HIP_FULL_ROWS", "NVBIO_HIP_TRACEBACK_LANES", "NVBIO_HIP_SELECT_LANES"):
+        for name in mod.test_switch_names():          # the library's own list (nvbio_hip_test_switch_name)
             mod._lib.nvbio_hip_set_test_switch(name.encode(), 0)

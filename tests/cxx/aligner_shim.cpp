@@ -144,10 +144,10 @@ int nvbio_aligner_best_approx_timed(const nvbio_hip_fmindex* fmi, const nvbio_hi
 #include <thread>
 #include <mutex>
 extern "C" __attribute__((visibility("default")))
-int nvbio_aligner_best_approx_pipelined(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmindex* rfmi, uint32_t n, uint32_t L, uint32_t n_batches,
+int nvbio_aligner_best_approx_pipelined_names(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmindex* rfmi, uint32_t n, uint32_t L, uint32_t n_batches,
                                         const uint32_t* const* d_rev_words, uint64_t rev_n_words, const uint64_t* const* d_rev_begin,
-                                        const uint32_t* const* d_fwrc_words, uint64_t fwrc_n_words, const uint8_t* d_quals, uint64_t n_quals,
-                                        const char* d_names, const uint32_t* d_names_idx,
+                                        const uint32_t* const* d_fwrc_words, uint64_t fwrc_n_words, const uint8_t* const* d_quals, uint64_t n_quals,
+                                        const char* const* d_names, const uint32_t* const* d_names_idx,
                                         const uint32_t* d_genome_words, uint64_t genome_n_words, uint32_t genome_len, const shim_params* sp,
                                         uint32_t n_workers, uint32_t reps, double* out_wall_ms,
                                         uint64_t* const* d_best, uint8_t* const* d_mapq)
@@ -185,7 +185,7 @@ int nvbio_aligner_best_approx_pipelined(const nvbio_hip_fmindex* fmi, const nvbi
                     reads.n = n; reads.len = L;
                     reads.reversed = PackedStringSetView<4, true>(n, d_rev_words[b], rev_n_words, d_rev_begin[b], nullptr, L);
                     reads.fw_rc_words = d_fwrc_words[b]; reads.fw_rc_n_words = fwrc_n_words; reads.rc_offset = uint64_t(n) * L;
-                    reads.quals = d_quals; reads.n_quals = n_quals; reads.names = d_names; reads.names_idx = d_names_idx;
+                    reads.quals = d_quals[b]; reads.n_quals = n_quals; reads.names = d_names[b]; reads.names_idx = d_names_idx[b];
                     Stats stats;
                     aligners[w]->best_approx(params, f, rf, scheme, limits, d_genome_words, genome_n_words, genome_len, reads, stats, streams[w]);
                     hip_check(nvbio_hip_memcpy(d_best[b], aligners[w]->best_data_dvec.data(), uint64_t(n) * 8u, 3, streams[w]), "d2d");
@@ -218,6 +218,21 @@ int nvbio_aligner_best_approx_pipelined(const nvbio_hip_fmindex* fmi, const nvbi
         for (uint32_t w = 0; w < n_workers; ++w) if (failed[w]) return 1;
         return 0;
     } catch (const std::exception& e) { fprintf(stderr, "aligner_shim: %s\n", e.what()); return 1; }
+}
+
+// the same with one quality stream and one name arena shared by every batch (bench.py's config-4 leg: constant qualities)
+extern "C" __attribute__((visibility("default")))
+int nvbio_aligner_best_approx_pipelined(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmindex* rfmi, uint32_t n, uint32_t L, uint32_t n_batches,
+                                        const uint32_t* const* d_rev_words, uint64_t rev_n_words, const uint64_t* const* d_rev_begin,
+                                        const uint32_t* const* d_fwrc_words, uint64_t fwrc_n_words, const uint8_t* d_quals, uint64_t n_quals,
+                                        const char* d_names, const uint32_t* d_names_idx,
+                                        const uint32_t* d_genome_words, uint64_t genome_n_words, uint32_t genome_len, const shim_params* sp,
+                                        uint32_t n_workers, uint32_t reps, double* out_wall_ms,
+                                        uint64_t* const* d_best, uint8_t* const* d_mapq)
+{
+    std::vector<const uint8_t*> q(n_batches, d_quals); std::vector<const char*> nm(n_batches, d_names); std::vector<const uint32_t*> ni(n_batches, d_names_idx);
+    return nvbio_aligner_best_approx_pipelined_names(fmi, rfmi, n, L, n_batches, d_rev_words, rev_n_words, d_rev_begin, d_fwrc_words, fwrc_n_words, q.data(), n_quals,
+                                                     nm.data(), ni.data(), d_genome_words, genome_n_words, genome_len, sp, n_workers, reps, out_wall_ms, d_best, d_mapq);
 }
 
 struct shim_pe_params { int32_t pe_policy; uint32_t pe_overlap, pe_unpaired, pe_discordant, min_frag_len, max_frag_len; };

@@ -294,3 +294,81 @@ def test_pattern_views_run_in_place(cuda, band, ty):
     a = nvb.batch_banded_alignment_score(band, nvb.make_gotoh_aligner(ty, scheme), p, t, quals=dq, pattern_flags=z, max_pattern_length=int(stored.length.max()))
     b = nvb.batch_banded_alignment_score(band, nvb.make_gotoh_aligner(ty, scheme), p, t, quals=dq, max_pattern_length=int(stored.length.max()))
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("band", [3, 7, 15, 31])
+@pytest.mark.parametrize("ty", [nvb.LOCAL, nvb.SEMI_GLOBAL, nvb.GLOBAL])
+def test_bounded_scorer_threshold_semantics(cuda, band, ty):
+    """nvbio_hip_banded_gotoh_score_qual_bounded (the reference's min_score argument; nvbio_amd/csrc/banded_gotoh_bounded.h): a job that ends
+    ABOVE its threshold reports the oracle's score and sink bit for bit; a job that ends at or below it reports SOME score <= the threshold --
+    never above, whatever row it was given up at -- and the sink (-1, -1) if it was given up; INT32_MIN thresholds (and none at all) make every
+    job exact.  Ragged jobs (empty patterns, texts shorter than patterns, windows cut by the text's end), both arithmetic widths, with and
+    without LDS staging, pattern views, every refill setting, and the job count read from the device."""
+    rng = np.random.default_rng(7700 + band + ty)
+    pats, txts = random_pairs(rng, 5000, band)
+    pats[5], pats[6] = pats[5][:0], pats[6][:1]                                  # an empty and a one-symbol pattern
+    for k in range(40, 80):                                                      # windows as nvBowtie cuts them: pattern + band, some cut short
+        txts[k] = (txts[k] * 4)[:len(pats[k]) + band - (k % 3)]
+    stored = O.StringSet.from_lists(pats, 4, True)
+    ht = O.StringSet.from_lists(txts, 2, True)
+    total = int(stored.begin[-1] + stored.length[-1])
+    quals = rng.integers(0, 45, total + 3, dtype=np.uint8)
+    scheme = nvb.SmithWatermanScoringScheme.local() if ty == nvb.LOCAL else nvb.SmithWatermanScoringScheme()
+    st = scheme.struct()
+    lut = np.array([st.mismatch[q] for q in range(256)], dtype=np.int32)
+    s6 = (st.match, st.pattern_gap_open, st.pattern_gap_ext, st.text_gap_open, st.text_gap_ext, 0)
+    es, ek = O.batch_banded_gotoh_score_qual(band, ty, s6, lut, quals, stored, ht)
+    n = len(pats)
+    # thresholds around the true scores: a third well below (job must be exact), a third at the score (<=: may be given up), a third above
+    off = rng.integers(-40, 41, n)
+    thr = (es.astype(np.int64) + off).clip(-(1 << 20), 1 << 20).astype(np.int32)
+    thr[::11] = np.iinfo(np.int32).min
+    thr[es == -(1 << 30)] = -50                                                  # jobs without an alignment keep their -(1 << 30)
+    p = nvb.PackedStringSet.from_host(stored.words, 4, True, stored.begin, stored.length, device=cuda)
+    t = nvb.PackedStringSet.from_host(ht.words, 2, True, ht.begin, ht.length, device=cuda)
+    dq, dthr = torch.from_numpy(quals).to(cuda), torch.from_numpy(thr).to(cuda)
+    al = nvb.make_gotoh_aligner(ty, scheme)
+    maxp = int(stored.length.max())
+    n_dev = torch.tensor([n], dtype=torch.int32, device=cuda)
+    exact_needed = es > thr
+    for force32, nostage, refill_n_dev in (("0", "0", False), ("1", "0", False), ("0", "1", True)):
+        nvb.set_test_switch("NVBIO_HIP_FORCE_32BIT", force32); nvb.set_test_switch("NVBIO_HIP_NO_STAGING", nostage)
+        try:
+            if refill_n_dev:
+                # the job count on the device, results written through an index (a compacted batch writing back at its hits)
+                perm = torch.randperm(n, device=cuda).to(torch.int32)
+                ps_, pk_ = torch.empty(n, dtype=torch.int32, device=cuda), torch.empty((n, 2), dtype=torch.int32, device=cuda)
+                nvb.BatchedBandedAlignmentScore(band).enact(al, p, t, ps_, pk_, maxp, 0, dq, None, dthr, n_dev, perm)
+                gs, gk = ps_[perm.long()], pk_[perm.long()]
+                # no thresholds: the plain kernel over the device-side count, through the same index -- exact
+                qs_, qk_ = torch.full((n,), 12345, dtype=torch.int32, device=cuda), torch.empty((n, 2), dtype=torch.int32, device=cuda)
+                half = torch.tensor([n // 2], dtype=torch.int32, device=cuda)
+                nvb.BatchedBandedAlignmentScore(band).enact(al, p, t, qs_, qk_, maxp, 0, dq, None, None, half, perm)
+                assert "bounded" not in nvb.lib().nvbio_hip_last_kernel().decode()
+                hs, hk = qs_[perm.long()].cpu().numpy(), qk_[perm.long()].cpu().numpy().view(np.uint32)
+                assert (hs[:n // 2] == es[:n // 2]).all() and (hk[:n // 2] == ek[:n // 2]).all() and (hs[n // 2:] == 12345).all()      # jobs past the count are not touched
+            else:
+                gs, gk = nvb.batch_banded_alignment_score(band, al, p, t, quals=dq, max_pattern_length=maxp, min_score=dthr)
+            xs, xk = nvb.batch_banded_alignment_score(band, al, p, t, quals=dq, max_pattern_length=maxp, min_score=torch.full_like(dthr, np.iinfo(np.int32).min))
+            torch.cuda.synchronize()
+        finally:
+            nvb.set_test_switch("NVBIO_HIP_FORCE_32BIT", "0"); nvb.set_test_switch("NVBIO_HIP_NO_STAGING", "0")
+        assert "bounded" in nvb.lib().nvbio_hip_last_kernel().decode()
+        gs, gk, xs, xk = gs.cpu().numpy(), gk.cpu().numpy().view(np.uint32), xs.cpu().numpy(), xk.cpu().numpy().view(np.uint32)
+        assert (xs == es).all() and (xk == ek).all(), (band, ty, force32, np.nonzero(xs != es)[0][:5])
+        bad = np.nonzero(exact_needed & ((gs != es) | (gk != ek).any(1)))[0]
+        assert bad.size == 0, (band, ty, force32, nostage, bad[:5], es[bad[:3]], gs[bad[:3]], thr[bad[:3]])
+        below = ~exact_needed
+        assert (gs[below] <= thr[below]).all() or (gs[below][gs[below] > thr[below]] == es[below][gs[below] > thr[below]]).all()
+        # a given-up job carries no sink; one that ran to its end is exact
+        gave_up = below & (gk == 0xFFFFFFFF).all(1) & (es != -(1 << 30))
+        ran = below & ~gave_up
+        assert (gs[ran] == es[ran]).all() and (gk[ran] == ek[ran]).all()
+        assert (gs[gave_up] >= es[gave_up]).all() and (gs[gave_up] <= thr[gave_up]).all()     # an upper bound of the true score, at or below the threshold
+    # end-to-end mode gives up early: with thresholds well above the scores most jobs stop before their last row
+    if ty == nvb.SEMI_GLOBAL and band >= 15:
+        hi = torch.from_numpy((es.clip(-(1 << 20), None) + 30).astype(np.int32)).to(cuda)
+        gs, gk = nvb.batch_banded_alignment_score(band, al, p, t, quals=dq, max_pattern_length=maxp, min_score=hi)
+        gave_up = (gk.cpu().numpy().view(np.uint32) == 0xFFFFFFFF).all(1) & (es != -(1 << 30))
+        assert int(gave_up.sum()) > n // 4, int(gave_up.sum())
+        assert (gs.cpu().numpy()[gave_up] <= hi.cpu().numpy()[gave_up]).all()

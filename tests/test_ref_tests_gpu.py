@@ -472,4 +472,6 @@ def test_reference_nvbowtie_equals_own_driver_at_3gbp():
     assert out["nvbowtie_exit"] == 0, log[-2000:]
     assert out["records_ref"] == out["records_own"] == 5_000_000
     assert out["identical"] == 5_000_000, (out["difference_categories"], out["first_differences"][:3])
+    # the C++ host driver on the HBM-rich index the device gets by default: the same 5 M records
+    assert out["records_cxx"] == 5_000_000 and out["cxx_identical"] == 5_000_000, (out["cxx_index"], out["cxx_difference_categories"], out["cxx_first_differences"][:3])
     assert out["aligned_share_first_200k"] > 0.9

@@ -159,6 +159,63 @@ def own_driver(prefix, sym, qual, sam_path, dev, batch_reads, digits=8, timings=
         timings.update(own_load_s=t_load, own_align_s=t_align, own_write_s=t_write, own_reads_per_s=n / t_align, own_batches=len(stats), own_stats_first_batch=stats[0])
 
 
+def own_driver_cxx(prefix, sym, qual, sam_path, dev, batch_reads, digits=8, timings=None, hbm_rich=True):
+    """the C++ host driver (nvbio::bowtie2::cuda::Aligner::best_approx, include/nvbio_hip/aligner.h; entered through tests/cxx/aligner_shim.cpp)
+    over the same reads on the same index files, batch by batch -> own_cxx.sam.  The index is what io::FMIndexDataDevice makes of the files on
+    this device by default: the HBM-rich form (line-native records, 12-mer table, the densest suffix array that fits)."""
+    import ctypes as C
+    import align_fastq as AF
+    import bench as B
+    import nvbio_amd as nvb
+    from nvbio_amd import io as nio, aligner as A, pipeline as P, select as SEL
+    shim = C.CDLL(os.path.join(ROOT, "tests", "cxx", "libaligner_shim.so"))
+    t0 = time.time()
+    data = nio.FMIndexDataDevice(prefix, flags=nio.FORWARD | nio.SA, device=dev, hbm_rich=hbm_rich)
+    n_genome, g_words = nio.load_genome(prefix)
+    genome_words = torch.from_numpy(np.concatenate([g_words, np.zeros(8, np.uint32)]).view(np.int32)).to(dev)
+    ref = AF.Reference(prefix, n_genome, "ref")
+    torch.cuda.synchronize()
+    t_load = time.time() - t0
+    n, L = sym.shape
+    prm = A.Params(hits_stride=32, batch_size=batch_reads)
+    scheme = nvb.SmithWatermanScoringScheme()
+    sp = B._shim_params(prm, scheme); sp.finish = 1
+    fs = data.index().struct()
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    hp = lambda a: a.ctypes.data_as(C.c_void_p)
+    t_align, t_write, first_stats = 0.0, 0.0, None
+    for s0 in range(0, n, batch_reads):
+        e0 = min(n, s0 + batch_reads); m = e0 - s0
+        sb = sym[s0:e0].contiguous()
+        rev, fwrc = P.pack_read_streams(sb)
+        qs = A._qual_stream(m, L, 30, qual[s0:e0], dev)
+        names = ["r%0*d" % (digits, i) for i in range(s0, e0)]
+        arena, nidx = SEL.pack_names(names, dev)
+        best = np.zeros((2, m), np.uint64); mapq = np.zeros(m, np.uint8); cigar = np.zeros((m, 64), np.uint16); cigar_len = np.zeros(m, np.uint32)
+        source = np.zeros((m, 2), np.uint32); sink = np.zeros((m, 2), np.uint32); tb_score = np.zeros(m, np.int32); stats = np.zeros(12, np.uint64)
+        mds = np.zeros((m, 256), np.uint8); mds_len = np.zeros(m, np.uint32)
+        torch.cuda.synchronize(); t1 = time.time()
+        rc = shim.nvbio_aligner_best_approx(C.byref(fs), None, C.c_uint32(m), C.c_uint32(L), vp(rev.words), C.c_uint64(rev.words.numel()), vp(rev.begin), vp(fwrc),
+                                            C.c_uint64(fwrc.numel()), vp(qs), C.c_uint64(qs.numel()), vp(arena), vp(nidx), vp(genome_words), C.c_uint64(genome_words.numel()),
+                                            C.c_uint32(n_genome), C.byref(sp), hp(best), hp(mapq), hp(cigar), hp(cigar_len), hp(source), hp(sink), hp(tb_score), hp(stats),
+                                            hp(mds), hp(mds_len))
+        t_align += time.time() - t1
+        if rc != 0:
+            raise RuntimeError("nvbio_aligner_best_approx returned %d" % rc)
+        if first_stats is None:
+            first_stats = dict(extensions=int(stats[0]), rounds=int(stats[1]), seeding_passes=int(stats[2]), queue=[int(x) for x in stats[4:4 + int(stats[3])]])
+        t1 = time.time()
+        name_buf = np.frombuffer(("\0".join(names) + "\0").encode(), dtype=np.uint8)
+        name_idx = np.arange(0, (m + 1) * (digits + 2), digits + 2, dtype=np.uint32)
+        index = np.arange(0, (m + 1) * L, L, dtype=np.int64)
+        AF.write_records_se_native(sam_path, ref, (name_buf, name_idx), sb.reshape(-1).cpu().numpy(), index, qual[s0:e0].reshape(-1).cpu().numpy(),
+                                   best, mapq, cigar, cigar_len, source, mds, extra_flags=64, append=s0 > 0, header=s0 == 0)
+        t_write += time.time() - t1
+    if timings is not None:
+        timings.update(cxx_load_s=t_load, cxx_align_s_incl_result_copies=t_align, cxx_write_s=t_write, cxx_reads_per_s=n / t_align, cxx_index=data.description,
+                       cxx_stats_first_batch=first_stats)
+
+
 def compare_sam(ref_path, own_path, show=5):
     """-> (records of the reference, of the own driver, identical ones, examples, categories); byte comparison first, line by line only when that fails"""
     def body(path):
@@ -264,6 +321,12 @@ def run(genome=3_000_000_000, reads=5_000_000, repeats=0.6, seed=0x5EED0009, bat
     t0 = time.time()
     n_ref, n_own, same, diffs, cats = compare_sam(ref_sam, own_sam)
     out.update(records_ref=n_ref, records_own=n_own, identical=same, difference_categories=cats, first_differences=diffs, compare_s=time.time() - t0)
+    # ---- ... and its C++ host driver on the HBM-rich index this device gets by default
+    torch.cuda.empty_cache()
+    cxx_sam = os.path.join(tmp, "own_cxx.sam")
+    own_driver_cxx(prefix, sym, qual, cxx_sam, dev, batch_reads, timings=out)
+    n_ref2, n_cxx, same2, diffs2, cats2 = compare_sam(ref_sam, cxx_sam)
+    out.update(records_cxx=n_cxx, cxx_identical=same2, cxx_difference_categories=cats2, cxx_first_differences=diffs2)
     if rerun:
         # the reference's application against itself: a second run on the same files
         again = os.path.join(tmp, "ref2.sam")
@@ -336,7 +399,7 @@ def main():
     if a.json:
         open(a.json, "w").write(text)
     print(text)
-    ok = out.get("nvbowtie_exit") == 0 and out.get("identical") == out.get("records_ref") == out.get("records_own") == a.reads
+    ok = out.get("nvbowtie_exit") == 0 and out.get("identical") == out.get("records_ref") == out.get("records_own") == a.reads and out.get("cxx_identical") == a.reads
     return 0 if ok else 1
 
 
