@@ -110,7 +110,7 @@ def parse():
     ap.add_argument("--genome", type=float, default=3.0e9, help="synthetic genome length of the FM-index legs (a true index is built on the device)")
     ap.add_argument("--rank-queries", type=int, default=1 << 28)
     ap.add_argument("--no-rank", action="store_true")
-    ap.add_argument("--only", choices=["dp", "rank", "seed", "e2e", "full", "extras", "compat", "refapp"], default=None, help="profiling aid: run just one leg, print its object")
+    ap.add_argument("--only", choices=["dp", "rank", "seed", "e2e", "full", "extras", "compat", "refapp", "repeats"], default=None, help="profiling aid: run just one leg, print its object")
     ap.add_argument("--seeds", type=int, default=50_000_000)
     ap.add_argument("--pairs", type=int, default=500_000, help="read pairs of the paired-end driver leg inside the e2e leg (0 = skip)")
     ap.add_argument("--share-pairs", type=int, default=25_000_000, help="config 5 at one GPU's share of 200 M pairs over 8 GPUs (0 = skip); runs in batches of --pairs")
@@ -123,6 +123,8 @@ def parse():
     ap.add_argument("--e2e-batches", type=int, default=5, help="batches of the full-size run of BASELINE config 4 (5 x 10 M = 50 M reads)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--ref-app", action="store_true", help="also run the leg that runs the reference's own nvBowtie binary (oracle/_ref/ref_nvBowtie) at config-4 size: writes 3.75 GB of index files, ~40 s; opt-in")
+    ap.add_argument("--no-repeat-rich", action="store_true", help="skip the single-end driver on the repeat-rich 3 Gbp genome (a second genome and index: ~25 s)")
+    ap.add_argument("--repeat-rich-reads", type=int, default=5_000_000)
     ap.add_argument("--legs-file", default=None, help="where the full per-leg objects go (default: gpurun_out/bench_legs.json if that directory exists, else ./bench_legs.json)")
     ap.add_argument("--ref-app-reads", type=int, default=5_000_000)
     ap.add_argument("--cpu-sample", type=int, default=10_000_000)
@@ -173,11 +175,14 @@ def main():
         a.no_e2e = a.only != "e2e"
         print(json.dumps(fm_legs(a, dev)))
         return
+    if a.only == "repeats":
+        print(json.dumps({"repeat_rich": repeat_rich_leg(a, dev)}))
+        return
     if a.only == "refapp":
         print(json.dumps({"ref_nvbowtie_leg": ref_nvbowtie_leg(a, dev)}))
         return
     if a.only == "dp":
-        a.no_rank = a.no_cpu = a.no_seed = a.no_e2e = a.no_full = True; a.ref_app = False
+        a.no_rank = a.no_cpu = a.no_seed = a.no_e2e = a.no_full = a.no_repeat_rich = True; a.ref_app = False
 
     # ---------------------------------------------------------------- inputs (resident before timing)
     n = a.reads
@@ -368,6 +373,10 @@ def main():
     if rank == 0 and world == 1 and not a.no_full:
         out["full_dp_leg"] = full_dp_leg(a, dev)
         out["compat_stream_leg"] = compat_stream_leg(a, dev)
+    if rank == 0 and world == 1 and not a.no_e2e and not a.no_repeat_rich:
+        torch.cuda.empty_cache()
+        nvb.lib().nvbio_hip_device_trim()
+        out.setdefault("e2e_leg", {})["repeat_rich"] = repeat_rich_leg(a, dev)
     if rank == 0 and world == 1 and a.ref_app:
         torch.cuda.empty_cache()
         out["ref_nvbowtie_leg"] = ref_nvbowtie_leg(a, dev)
@@ -403,6 +412,26 @@ def emit(out, legs_file=None):
     for line in H.leg_lines(out):
         print(line)
     print(H.headline_line(out, shown), flush=True)
+
+
+def repeat_rich_leg(a, dev):
+    """BASELINE config 4 on a genome that looks like one: the repeat-rich 3 Gbp genome of tools/nvbowtie_3gbp.py (60 % of it diverged copies of three
+    repeat families, the largest with three million copies) -- the genome on which every SAM record of this driver is held to the unchanged
+    nvBowtie's (tests/test_ref_tests_gpu.py) -- through the C++ single-end driver in nvBowtie's own batches of 1024 K reads (the hits-per-read
+    rule of both drivers reasons with the batch), on the index the loaders build by default (FMIndexDevice.hbm_default), one batch at a time
+    and two in flight; every batch's (best, mapq) compared with the same driver on the reference-layout index.  Where a batch's time goes:
+    `one_batch.stage_ms_with_syncs`; the i.i.d. genome of `config4_full_size` takes 8-10 extension rounds per batch, this one 113."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import own_driver_3gbp as T
+        r = T.measure(int(a.genome), a.repeat_rich_reads, 1 << 20, 0.6, "default", (1, 2), check=False, stage_clock=True, reps=2, lean_check=True)
+    except Exception as e:      # noqa: BLE001
+        return {"error": repr(e)[:500]}
+    return {"genome": r["genome"], "repeats": r["repeats"], "repeat_families": r["repeat_families"], "reads": r["reads_aligned"], "batch_reads": r["batch"], "driver": r["driver"],
+            "index": r["index_built"], "one_batch": r.get("one_batch"), "serial": r["pipelined"].get("1"), "two_batches_in_flight": r["pipelined"].get("2"),
+            "Mreads_per_s": r["Mreads_per_s"], "rounds": (r.get("one_batch") or {}).get("rounds"), "extensions": (r.get("one_batch") or {}).get("extensions"),
+            "identical_to_reference_layout": r.get("identical_to_reference_layout"),
+            "identical_to_reference_driver": "every SAM record of this driver on this genome equals the unchanged nvBowtie's: tests/test_ref_tests_gpu.py::test_reference_nvbowtie_equals_own_driver_at_3gbp (python bench.py --ref-app reruns it here)"}
 
 
 def ref_nvbowtie_leg(a, dev):
@@ -639,9 +668,12 @@ def e2e_leg(a, dev, fmi, text):
             del symb
         tot = n * a.e2e_batches
         c4 = {"reads": tot, "batches": a.e2e_batches, "driver": "nvbio::bowtie2::cuda::Aligner::best_approx (C++, include/nvbio_hip/aligner.h)"}
-        for flavour in ("hbm_rich", "line_native"):
-            if flavour == "hbm_rich":
+        ref_results = None
+        for flavour in ("reference_layout", "default", "line_native"):
+            if flavour == "default":                   # what the loaders build on this device when nothing is said (FMIndexDevice.hbm_default / nvbio::fm_index_hbm)
                 idx, desc = hbm_rich(fmi, dev)
+            elif flavour == "reference_layout":
+                idx, desc = fmi, {"line_native": False, "ktab_k": 0, "sa_int": fmi.sa_int}
             else:
                 idx, desc = fmi.with_dimer(), {"line_native": True, "ktab_k": 0, "sa_int": fmi.sa_int}
             serial, sb, sm = cxx_pipelined(dev, idx, inputs, genome_words, ng, names, prm, 1)
@@ -655,11 +687,16 @@ def e2e_leg(a, dev, fmi, text):
                     co["identical_to_serial"] = all(torch.equal(x, y) for x, y in zip(cb, sb)) and all(torch.equal(x, y) for x, y in zip(cm, sm))
                 entry["two_batches_in_flight"] = co
                 del cb, cm
+                if flavour == "reference_layout":
+                    ref_results = (sb, sm)
+                elif ref_results is not None:
+                    entry["identical_to_reference_layout"] = all(torch.equal(x, y) for x, y in zip(sb, ref_results[0])) and all(torch.equal(x, y) for x, y in zip(sm, ref_results[1]))
+            entry["Mreads_per_s"] = max([v.get("Mreads_per_s", 0.0) for v in (entry.get("serial", {}), entry.get("two_batches_in_flight", {}))])
             c4[flavour] = entry
             del idx, sb, sm
             torch.cuda.empty_cache()
-        best_rate = max([v.get("Mreads_per_s", 0.0) for f in ("hbm_rich", "line_native") for v in (c4[f].get("serial", {}), c4[f].get("two_batches_in_flight", {}))])
-        c4["Mreads_per_s"] = best_rate
+        c4["Mreads_per_s"] = c4["default"]["Mreads_per_s"]              # the figure of the index a user gets by default
+        del ref_results
         res["config4_full_size"] = c4
         del inputs, truth
     # BASELINE config 5's shape in the default run: nvBowtie's paired-end driver (2 x 150 bp FR pairs, --local: 20-bp seeds, LOCAL band 31
@@ -925,15 +962,14 @@ def cxx_pipelined(dev, idx, batches, genome_words, ng, names, prm, workers, reps
 
 
 def hbm_rich(fmi, dev):
-    """The index the 288 GB of an MI355X are there for: the line-native two-symbol arrays, the match range of every 16-mer (34 GB; every
-    15-mer, 8.6 GB, below 120 GB free) and the full suffix array (sa_int = 1, 12 GB at 3 Gbp) -- every result stays bit-identical (checked
-    by the callers).  Falls back to k = 12 / sa_int = 4 when less than 64 GB are free."""
+    """The index the loaders build on this device when nothing is said -- the library's own policy (nvbio_amd.fmindex.FMIndexDevice.hbm_default =
+    nvbio::fm_index_hbm::build of the C++ host layer): line-native two-symbol records, the densest suffix array and the largest k-mer table that fit
+    35 % of the free memory (3 Gbp on a 288 GB MI355X: the whole suffix array, 12 GB, and every 16-mer's range, 34 GB).  Results stay bit-identical
+    (checked by the callers)."""
     torch.cuda.empty_cache()                   # (what torch's allocator has cached counts as free)
-    free_b, _ = torch.cuda.mem_get_info(dev)
-    big = free_b > (64 << 30) and fmi.length > (1 << 28)
-    k, sa = (16 if free_b > (120 << 30) else 15, 1) if big else (12, 1 if free_b > (24 << 30) else 4)
-    idx = fmi.with_dimer().with_ktab(k).with_dense_ssa(sa)
-    desc = {"line_native": True, "ktab_k": k, "ktab_bytes": (4 ** k) * 8, "sa_int": sa, "ssa_bytes": int(idx.ssa.numel()) * 4, "dimer_bytes": int(idx.dimer.numel()) * 4}
+    idx, desc = fmi.hbm_default()
+    desc = dict(desc, ktab_bytes=(4 ** desc["ktab_k"]) * 8 if desc["ktab_k"] else 0, ssa_bytes=int(idx.ssa.numel()) * 4 if idx.ssa is not None else 0,
+                dimer_bytes=int(idx.dimer.numel()) * 4 if idx.dimer is not None else 0)
     return idx, desc
 
 

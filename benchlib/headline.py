@@ -84,7 +84,7 @@ def compact_e2e(e):
             out["config4_default"] = _pick(d, ("Mreads_per_s", "identical_to_reference_layout"))
     rr = e.get("repeat_rich")
     if isinstance(rr, dict):
-        out["repeat_rich"] = _pick(rr, ("Mreads_per_s", "reads", "rounds", "extensions", "identical_to_reference_driver"))
+        out["repeat_rich"] = _pick(rr, ("Mreads_per_s", "reads", "batch_reads", "rounds", "extensions", "identical_to_reference_layout"))
     c5 = e.get("config5_per_gpu_share")
     if isinstance(c5, dict):
         out["config5_share"] = {k: _num((c5.get(k) or {}).get("Mpairs_per_s")) for k in ("serial", "two_batches_in_flight") if isinstance(c5.get(k), dict)}

@@ -62,8 +62,8 @@ inline void lookup_ssa_iterator(const fm_index_device& fmi, uint32 n, const uint
 { hip_check(nvbio_hip_fm_lookup_ssa_iterator(&fmi.m, reinterpret_cast<const uint32*>(it), n, out, stream), "nvbio_hip_fm_lookup_ssa_iterator"); }
 
 /// The index an MI355X's HBM is there for, built on the device from a loaded index and owning the extra arrays: the line-native two-symbol
-/// records (one 128-byte line per backward-search step pair), the match range of every 12-mer (128 MiB) and a denser -- when it fits, the
-/// whole -- suffix array (12 GB at 3 Gbp: locate without an LF walk).  Every result is bit-identical to the lean index's; only the time
+/// records (one 128-byte line per backward-search step pair), a denser -- when it fits, the whole -- suffix array (12 GB at 3 Gbp: locate
+/// without an LF walk) and the match range of every k-mer for the largest k that fits (k = 16: 34 GB, 6 search steps left of a 22-mer's 22).  Every result is bit-identical to the lean index's; only the time
 /// changes (seeding + locate about 2x).  What is built follows the memory that is free when build() runs:
 /// `budget_bytes` (0 = 35 % of the device's free memory; the drivers' per-batch workspace and a reverse index want their share too).
 /// NVBIO_HIP_INDEX=lean|line_native|rich overrides (lean: nothing built; line_native: the two-symbol records only; rich: everything, the
@@ -102,14 +102,7 @@ struct fm_index_hbm
             }
         }
         if (policy == "line_native") return;
-        // every 12-mer's range
-        if ((uint64(2) << 24) * 4u <= budget)
-        {
-            ktab.resize(size_t(2) << 24);
-            build_ktab(index, 12u, ktab.data(), stream);
-            index.set_ktab(ktab.data(), 12u); ktab_k = 12u; budget -= (uint64(2) << 24) * 4u;
-        }
-        // the densest suffix array that fits
+        // the densest suffix array that fits (locate without an LF walk at 1): the most valuable of the extras, so it is sized first
         if (base.m.ssa)
             for (uint32 s = 1; s < base.m.sa_int; s *= 2)
             {
@@ -118,9 +111,23 @@ struct fm_index_hbm
                 ssa.resize(entries);
                 hip_check(nvbio_hip_fm_build_dense_ssa(&index.m, s, ssa.data(), stream), "nvbio_hip_fm_build_dense_ssa");
                 hip::synchronize(stream);
-                index.m.ssa = ssa.data(); index.m.sa_int = s; sa_int = s;
+                index.m.ssa = ssa.data(); index.m.sa_int = s; sa_int = s; budget -= entries * 4u;
                 break;
             }
+        // the match range of every k-mer, the largest k that fits and that the text can fill (4^k <= ~4 x length): 16 -> 34 GB, 15 -> 8.6 GB, 12 -> 128 MB
+        {
+            uint32 kmax = 8u;
+            while (kmax < 16u && (uint64(1) << (2u * kmax)) < uint64(n)) ++kmax;
+            for (uint32 k = kmax; k >= 8u; --k)
+            {
+                const uint64 bytes = (uint64(2) << (2u * k)) * 4u;
+                if (bytes > budget) continue;
+                ktab.resize(size_t(2) << (2u * k));
+                build_ktab(index, k, ktab.data(), stream);
+                index.set_ktab(ktab.data(), k); ktab_k = k; budget -= bytes;
+                break;
+            }
+        }
     }
     /// "line_native ktab12 sa_int=1": what the index a run used was
     std::string description() const

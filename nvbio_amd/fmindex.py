@@ -102,7 +102,7 @@ class FMIndexDevice:
 
     def hbm_default(self, budget_bytes=0, policy=None):
         """The index this device's HBM is there for -- nvbio::fm_index_hbm::build of the C++ host layer (include/nvbio_hip/fmindex.h), same
-        policy: the line-native two-symbol records, every 12-mer's range, the densest suffix array that fits `budget_bytes` (0 = 35 % of
+        policy: the line-native two-symbol records, the densest suffix array and the largest k-mer table that fit `budget_bytes` (0 = 35 % of
         the memory that is free now).  NVBIO_HIP_INDEX=lean|line_native|rich overrides.  Results stay bit-identical.
         -> (index, description dict)"""
         import os
@@ -120,17 +120,24 @@ class FMIndexDevice:
             if idx.dimer is None and need <= budget:
                 idx = idx.with_dimer(); budget -= int(L.nvbio_hip_fm_dimer_index_bytes(self.length))
             if policy != "line_native":
-                if idx.ktab is None and (8 << 24) <= budget:
-                    idx = idx.with_ktab(12); budget -= 8 << 24
-                if idx.ssa is not None:
+                if idx.ssa is not None:                  # the densest suffix array that fits, sized first
                     s = 1
                     while s < idx.sa_int:
-                        if int(L.nvbio_hip_fm_dense_ssa_entries(self.length, s)) * 4 <= budget:
-                            idx = idx.with_dense_ssa_native(s)
+                        need = int(L.nvbio_hip_fm_dense_ssa_entries(self.length, s)) * 4
+                        if need <= budget:
+                            idx = idx.with_dense_ssa_native(s); budget -= need
                             break
                         if policy == "rich":
                             raise RuntimeError("hbm_default: the whole suffix array does not fit")
                         s *= 2
+                if idx.ktab is None:                     # every k-mer's range, the largest k that fits and that the text can fill
+                    kmax = 8
+                    while kmax < 16 and (1 << (2 * kmax)) < self.length:
+                        kmax += 1
+                    for k in range(kmax, 7, -1):
+                        if (8 << (2 * k)) <= budget:
+                            idx = idx.with_ktab(k); budget -= 8 << (2 * k)
+                            break
         return idx, {"line_native": idx.dimer is not None, "ktab_k": idx.ktab_k if idx.ktab is not None else 0, "sa_int": idx.sa_int, "policy": policy}
 
     def struct(self):

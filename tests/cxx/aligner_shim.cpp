@@ -129,7 +129,7 @@ int nvbio_aligner_best_approx_timed(const nvbio_hip_fmindex* fmi, const nvbio_hi
         hip_check(nvbio_hip_memcpy(d_best + n, aligner.best_data_dvec.data() + aligner.BATCH_SIZE, uint64_t(n) * 8u, 3, nullptr), "d2d");
         hip_check(nvbio_hip_memcpy(d_mapq, aligner.mapq_dvec.data(), n, 3, nullptr), "d2d");
         hip::synchronize();
-        h_stats[0] = stats.extensions; h_stats[1] = stats.rounds; h_stats[2] = stats.seeding_passes; h_stats[3] = stats.dp_jobs;
+        h_stats[0] = stats.extensions; h_stats[1] = stats.rounds; h_stats[2] = stats.seeding_passes; h_stats[3] = timed.dp_jobs;      // (the DP jobs are only counted under the stage clock)
         return 0;
     } catch (const std::exception& e) { fprintf(stderr, "aligner_shim: %s\n", e.what()); return 1; }
 }

@@ -107,6 +107,110 @@ def death_probe(fmi, genome_words, ng, sym, qual, prm, dev, rows=(20, 40, 60, 80
     return tally
 
 
+def measure(genome=3_000_000_000, reads=5_000_000, batch=1 << 20, repeats=0.6, index="default", workers=(1, 2), check=False, stage_clock=True, reps=2,
+            probe=False, verbose=False, lean_check=False):
+    """-> dict.  check: batch 0's (best, mapq) against the Python driver's; lean_check: every batch's against the same C++ driver on the index in
+    the reference's layout (bwt|occ records, SA every 16 rows)."""
+    import bench as B
+    from nvbio_amd import aligner as A, select as SEL
+    import nvbio_amd as nvb
+    dev = torch.device("cuda:0")
+    t0 = time.time()
+    fmi, genome_words, sym, qual, placed, index_desc = setup(int(genome), reads, repeats, 0x5EED0009, dev, "reference" if lean_check else index)
+    lean = fmi
+    if lean_check:
+        index_desc = {"line_native": False, "ktab_k": 0, "sa_int": fmi.sa_int, "policy": "lean"}
+        if index == "line_native":
+            fmi = lean.with_dimer(); index_desc["line_native"] = True
+        elif index == "default":
+            fmi, index_desc = lean.hbm_default()
+    torch.cuda.synchronize()
+    out = dict(genome=int(genome), reads=reads, batch=batch, repeats=repeats, index=index, index_built=index_desc, setup_s=time.time() - t0,
+               repeat_families=[dict(length=L, copies=c) for L, c in placed], driver="nvbio::bowtie2::cuda::Aligner::best_approx (C++, include/nvbio_hip/aligner.h)")
+    n, L = sym.shape
+    batches = pack_batches(sym, qual, batch, dev)
+    nb = len(batches)
+    prm = A.Params(hits_stride=32, batch_size=batch)
+    scheme = nvb.SmithWatermanScoringScheme()
+    sp = B._shim_params(prm, scheme)
+    sp.finish = 0 if (check or lean_check) else 1        # finish_alignment rewrites best_data (window begin, final score): the comparisons are of the extension-stage words
+    shim = shim_lib()
+    fs = fmi.struct()
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    ptrs = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    ng = int(genome)
+    # every batch uses its own names r%08d (the randomized selection is seeded by them)
+    name_arenas = [SEL.pack_names(["r%08d" % i for i in range(b[3], b[3] + batch)], dev) for b in batches]
+
+    # ---- one batch with the stage clock
+    if stage_clock:
+        rev, fwrc, qs, s0 = batches[0]
+        best = torch.zeros((2, batch), dtype=torch.int64, device=dev); mapq = torch.zeros(batch, dtype=torch.uint8, device=dev)
+        ms, stage, stats = (C.c_double * 1)(), (C.c_double * 9)(), (C.c_uint64 * 4)()
+        torch.cuda.synchronize(); torch.cuda.empty_cache()
+        rc = shim.nvbio_aligner_best_approx_timed(C.byref(fs), None, C.c_uint32(batch), C.c_uint32(L), vp(rev.words), C.c_uint64(rev.words.numel()), vp(rev.begin),
+                                                  vp(fwrc), C.c_uint64(fwrc.numel()), vp(qs), C.c_uint64(qs.numel()), vp(name_arenas[0][0]), vp(name_arenas[0][1]),
+                                                  vp(genome_words), C.c_uint64(genome_words.numel()), C.c_uint32(ng), C.byref(sp), C.c_uint32(reps), ms, stage, vp(best), vp(mapq), stats)
+        assert rc == 0
+        loc = (best[0] >> 32) & 0xFFFFFFFF
+        out["one_batch"] = dict(ms_per_batch=ms[0], Mreads_per_s=batch / ms[0] / 1e3, extensions=int(stats[0]), rounds=int(stats[1]), seeding_passes=int(stats[2]),
+                                dp_jobs=int(stats[3]), aligned=float((loc != 0xFFFFFFFF).float().mean().item()),
+                                stage_ms_with_syncs={k: round(stage[i], 3) for i, k in enumerate(STAGES)}, stage_ms_sum=round(sum(stage), 3))
+        if check:
+            index_t = torch.arange(0, (batch + 1) * L, L, dtype=torch.int64, device=dev)
+            rb = A.ReadBatch.from_ragged(sym[:batch].reshape(-1), index_t, qual[:batch].reshape(-1))
+            t1 = time.time()
+            r = A.best_approx(fmi, None, rb, genome_words, ng, prm, names=["r%08d" % i for i in range(batch)], cigar_stride=64, finish=False)
+            torch.cuda.synchronize()
+            out["python_driver"] = dict(s_per_batch=time.time() - t1, extensions=r["stats"]["extensions"], rounds=r["stats"]["rounds"],
+                                        identical_best=bool(torch.equal(r["best"], best)), identical_mapq=bool(torch.equal(r["mapq"], mapq)))
+            del r, rb
+        if verbose:
+            print(json.dumps(out["one_batch"]), flush=True)
+
+    if probe:
+        out["death_probe"] = death_probe(fmi, genome_words, ng, sym[:batch], qual[:batch], prm, dev)
+        if verbose:
+            print(json.dumps(out["death_probe"]), flush=True)
+
+    # ---- all batches, w in flight (every batch with its own qualities and names)
+    def run_all(fstruct, w, r):
+        best = [torch.zeros((2, batch), dtype=torch.int64, device=dev) for _ in range(nb)]
+        mapq = [torch.zeros(batch, dtype=torch.uint8, device=dev) for _ in range(nb)]
+        ms = (C.c_double * 1)()
+        torch.cuda.synchronize(); torch.cuda.empty_cache()
+        rc = shim.nvbio_aligner_best_approx_pipelined_names(
+            C.byref(fstruct), None, C.c_uint32(batch), C.c_uint32(L), C.c_uint32(nb),
+            ptrs([b[0].words for b in batches]), C.c_uint64(batches[0][0].words.numel()), ptrs([b[0].begin for b in batches]),
+            ptrs([b[1] for b in batches]), C.c_uint64(batches[0][1].numel()),
+            ptrs([b[2] for b in batches]), C.c_uint64(batches[0][2].numel()), ptrs([x[0] for x in name_arenas]), ptrs([x[1] for x in name_arenas]),
+            vp(genome_words), C.c_uint64(genome_words.numel()), C.c_uint32(ng), C.byref(sp), C.c_uint32(w), C.c_uint32(r), ms, ptrs(best), ptrs(mapq))
+        torch.cuda.synchronize()
+        assert rc == 0
+        return ms[0], best, mapq
+
+    out["pipelined"] = {}
+    first = None
+    for w in workers:
+        ms, best, mapq = run_all(fs, w, reps)
+        loc = [(x[0] >> 32) & 0xFFFFFFFF for x in best]
+        out["pipelined"][str(w)] = dict(host_threads=w, ms_total=ms, Mreads_per_s=batch * nb / ms / 1e3,
+                                        aligned=sum(int((l != 0xFFFFFFFF).sum().item()) for l in loc) / (batch * nb))
+        if first is None:
+            first = (best, mapq)
+        else:
+            out["pipelined"][str(w)]["identical_to_serial"] = all(torch.equal(x, y) for x, y in zip(best, first[0])) and all(torch.equal(x, y) for x, y in zip(mapq, first[1]))
+        if verbose:
+            print(json.dumps({("workers_%d" % w): out["pipelined"][str(w)]}), flush=True)
+    out["reads_aligned"] = batch * nb
+    out["Mreads_per_s"] = max(v["Mreads_per_s"] for v in out["pipelined"].values()) if out["pipelined"] else None
+    if lean_check and first is not None:
+        ls = lean.struct()
+        _, lb, lm = run_all(ls, 1, 1)
+        out["identical_to_reference_layout"] = all(torch.equal(x, y) for x, y in zip(lb, first[0])) and all(torch.equal(x, y) for x, y in zip(lm, first[1]))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--genome", type=float, default=3e9)
@@ -116,89 +220,14 @@ def main():
     ap.add_argument("--index", default="default", choices=["reference", "line_native", "default"], help="default: FMIndexDevice.hbm_default(), what the loaders build on this device")
     ap.add_argument("--workers", default="1,2,4")
     ap.add_argument("--check", action="store_true", help="compare batch 0's (best, mapq) with the Python driver's")
+    ap.add_argument("--lean-check", action="store_true", help="compare every batch with the same driver on the index in the reference's layout")
     ap.add_argument("--no-stage-clock", action="store_true")
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--json", default=None)
     ap.add_argument("--death-probe", action="store_true", help="Python driver on batch 0 with every DP job also scored over its first K rows: how early jobs fall to or below their min_score")
     a = ap.parse_args()
-    import bench as B
-    from nvbio_amd import aligner as A, select as SEL
-    import nvbio_amd as nvb
-    dev = torch.device("cuda:0")
-    t0 = time.time()
-    fmi, genome_words, sym, qual, placed, index_desc = setup(int(a.genome), a.reads, a.repeats, 0x5EED0009, dev, a.index)
-    torch.cuda.synchronize()
-    out = dict(genome=int(a.genome), reads=a.reads, batch=a.batch, repeats=a.repeats, index=a.index, index_built=index_desc, setup_s=time.time() - t0,
-               repeat_families=[dict(length=L, copies=c) for L, c in placed])
-    n, L = sym.shape
-    batches = pack_batches(sym, qual, a.batch, dev)
-    nb = len(batches)
-    prm = A.Params(hits_stride=32, batch_size=a.batch)
-    scheme = nvb.SmithWatermanScoringScheme()
-    sp = B._shim_params(prm, scheme)
-    sp.finish = 0 if a.check else 1        # finish_alignment rewrites best_data (window begin, final score): the comparison is of the extension-stage words
-    shim = shim_lib()
-    fs = fmi.struct()
-    vp = lambda t: C.c_void_p(t.data_ptr())
-    ptrs = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
-    ng = int(a.genome)
-    # every batch uses its own names r%08d (the randomized selection is seeded by them)
-    name_arenas = [SEL.pack_names(["r%08d" % i for i in range(b[3], b[3] + a.batch)], dev) for b in batches]
-
-    # ---- one batch with the stage clock
-    if not a.no_stage_clock:
-        rev, fwrc, qs, s0 = batches[0]
-        best = torch.zeros((2, a.batch), dtype=torch.int64, device=dev); mapq = torch.zeros(a.batch, dtype=torch.uint8, device=dev)
-        ms, stage, stats = (C.c_double * 1)(), (C.c_double * 9)(), (C.c_uint64 * 4)()
-        torch.cuda.synchronize(); torch.cuda.empty_cache()
-        rc = shim.nvbio_aligner_best_approx_timed(C.byref(fs), None, C.c_uint32(a.batch), C.c_uint32(L), vp(rev.words), C.c_uint64(rev.words.numel()), vp(rev.begin),
-                                                  vp(fwrc), C.c_uint64(fwrc.numel()), vp(qs), C.c_uint64(qs.numel()), vp(name_arenas[0][0]), vp(name_arenas[0][1]),
-                                                  vp(genome_words), C.c_uint64(genome_words.numel()), C.c_uint32(ng), C.byref(sp), C.c_uint32(a.reps), ms, stage, vp(best), vp(mapq), stats)
-        assert rc == 0
-        loc = (best[0] >> 32) & 0xFFFFFFFF
-        out["one_batch"] = dict(ms_per_batch=ms[0], Mreads_per_s=a.batch / ms[0] / 1e3, extensions=int(stats[0]), rounds=int(stats[1]), seeding_passes=int(stats[2]),
-                                dp_jobs=int(stats[3]), aligned=float((loc != 0xFFFFFFFF).float().mean().item()),
-                                stage_ms_with_syncs={k: round(stage[i], 3) for i, k in enumerate(STAGES)}, stage_ms_sum=round(sum(stage), 3))
-        if a.check:
-            index = torch.arange(0, (a.batch + 1) * L, L, dtype=torch.int64, device=dev)
-            rb = A.ReadBatch.from_ragged(sym[:a.batch].reshape(-1), index, qual[:a.batch].reshape(-1))
-            t1 = time.time()
-            r = A.best_approx(fmi, None, rb, genome_words, ng, prm, names=["r%08d" % i for i in range(a.batch)], cigar_stride=64, finish=False)
-            torch.cuda.synchronize()
-            out["python_driver"] = dict(s_per_batch=time.time() - t1, extensions=r["stats"]["extensions"], rounds=r["stats"]["rounds"],
-                                        identical_best=bool(torch.equal(r["best"], best)), identical_mapq=bool(torch.equal(r["mapq"], mapq)))
-            del r, rb
-        print(json.dumps(out["one_batch"]), flush=True)
-
-    if a.death_probe:
-        out["death_probe"] = death_probe(fmi, genome_words, ng, sym[:a.batch], qual[:a.batch], prm, dev)
-        print(json.dumps(out["death_probe"]), flush=True)
-
-    # ---- all batches, w in flight.  The pipelined entry shares one name arena across batches; to keep every batch's own names the
-    # runs below go batch by batch when names differ -> use the shim's per-batch name pointers if it has them
-    has_names = hasattr(shim, "nvbio_aligner_best_approx_pipelined_names")
-    out["pipelined"] = {}
-    for w in [int(x) for x in a.workers.split(",") if x]:
-        best = [torch.zeros((2, a.batch), dtype=torch.int64, device=dev) for _ in range(nb)]
-        mapq = [torch.zeros(a.batch, dtype=torch.uint8, device=dev) for _ in range(nb)]
-        ms = (C.c_double * 1)()
-        torch.cuda.synchronize(); torch.cuda.empty_cache()
-        fn = shim.nvbio_aligner_best_approx_pipelined_names if has_names else shim.nvbio_aligner_best_approx_pipelined
-        args = [C.byref(fs), None, C.c_uint32(a.batch), C.c_uint32(L), C.c_uint32(nb),
-                ptrs([b[0].words for b in batches]), C.c_uint64(batches[0][0].words.numel()), ptrs([b[0].begin for b in batches]),
-                ptrs([b[1] for b in batches]), C.c_uint64(batches[0][1].numel())]
-        if has_names:
-            args += [ptrs([b[2] for b in batches]), C.c_uint64(batches[0][2].numel()), ptrs([x[0] for x in name_arenas]), ptrs([x[1] for x in name_arenas])]
-        else:
-            args += [vp(batches[0][2]), C.c_uint64(batches[0][2].numel()), vp(name_arenas[0][0]), vp(name_arenas[0][1])]
-        args += [vp(genome_words), C.c_uint64(genome_words.numel()), C.c_uint32(ng), C.byref(sp), C.c_uint32(w), C.c_uint32(a.reps), ms, ptrs(best), ptrs(mapq)]
-        rc = fn(*args)
-        torch.cuda.synchronize()
-        assert rc == 0
-        loc = [(x[0] >> 32) & 0xFFFFFFFF for x in best]
-        out["pipelined"][str(w)] = dict(host_threads=w, ms_total=ms[0], Mreads_per_s=a.batch * nb / ms[0] / 1e3,
-                                        aligned=sum(int((l != 0xFFFFFFFF).sum().item()) for l in loc) / (a.batch * nb))
-        print(json.dumps({("workers_%d" % w): out["pipelined"][str(w)]}), flush=True)
+    out = measure(int(a.genome), a.reads, a.batch, a.repeats, a.index, [int(x) for x in a.workers.split(",") if x], a.check, not a.no_stage_clock, a.reps, a.death_probe,
+                  verbose=True, lean_check=a.lean_check)
     text = json.dumps(out, indent=1)
     if a.json:
         os.makedirs(os.path.dirname(os.path.abspath(a.json)), exist_ok=True)
