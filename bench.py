@@ -204,7 +204,7 @@ def main():
     # (nvbio_hip_gather_records; include/nvbio_hip/multi_device.h), its communicator opened from a unique id that torch.distributed
     # only ships.  Second choice: torch.distributed.gather.  Every rank tries on tiny buffers first and all agree on the outcome, so a
     # backend that cannot do it is found here -- the run then continues ("gather_path" says how) instead of dying mid-measurement.
-    gather_on, gather_path, cxx_comm, cxx_g = world > 1, None, None, None
+    gather_on, gather_path, cxx_comm, cxx_g, ranks_seen = world > 1, None, None, None, 0
     if world > 1:
         from nvbio_amd.distributed import CxxComm, CxxRecordGather, pack_result_records
         on_nccl = dist.get_backend() == "nccl"
@@ -229,8 +229,10 @@ def main():
             pg = CxxRecordGather(cxx_comm, world * 4, 1, dst=0, device=dev)
             pg.gather(torch.full((4, 1), rank, dtype=torch.int32, device=dev))
             torch.cuda.synchronize()
-            if rank == 0 and not all(bool((pg.shard(r) == r).all()) for r in range(world)):
-                raise RuntimeError("C++ gather returned wrong records")
+            if rank == 0:
+                ranks_seen = sum(1 for r in range(world) if bool((pg.shard(r) == r).all()))      # ranks whose probe records arrived intact through the C++ gather
+                if ranks_seen != world:
+                    raise RuntimeError("C++ gather returned wrong records (%d of %d ranks seen)" % (ranks_seen, world))
         except Exception as e:     # noqa: BLE001
             sys.stderr.write("bench: C++ / RCCL gather unavailable on rank %d (%s); trying torch.distributed\n" % (rank, e))
             flag = 0
@@ -240,6 +242,7 @@ def main():
             cxx_g = [CxxRecordGather(cxx_comm, n * world, 1, dst=0, device=dev) for _ in range(2)]
         else:
             cxx_comm = None
+            ranks_seen = 0
             flag = 1
             try:
                 probe = ResultGather(world * 4, dst=0, device=dev, record_bytes=4)
@@ -301,8 +304,12 @@ def main():
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
+    per_rank_ms = None
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        every = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(every, tt)                                   # each rank's own clock, for the line; the job's time is their maximum
+        per_rank_ms = [float(x.item()) / a.steps * 1e3 for x in every]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(a.steps, 1)
@@ -361,7 +368,8 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int16", "data": "synthetic",
             "config": {"workload": "nvbio::aln batched banded SW (configs[1]): %d x 100 bp reads vs 150 bp windows per GPU, band=15, LOCAL Gotoh (2,-1,-2,-1)" % n,
-                       "reads_per_gpu": n, "read_len": READ_LEN, "band": BAND, "type": "LOCAL", "parallelism": "read-shard x%d, gather to rank 0" % world, "gather": bool(gather_on) if world > 1 else None, "gather_path": gather_path},
+                       "reads_per_gpu": n, "read_len": READ_LEN, "band": BAND, "type": "LOCAL", "parallelism": "read-shard x%d, gather to rank 0" % world, "gather": bool(gather_on) if world > 1 else None, "gather_path": gather_path,
+                       "rccl_ranks_seen": ranks_seen if world > 1 else None, "per_rank_ms_per_step": per_rank_ms},
             "roofline": roofline, "parity": parity,
         }
 

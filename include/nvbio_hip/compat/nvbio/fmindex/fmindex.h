@@ -45,6 +45,9 @@ struct fm_index
     /// the line-native index of this FM-index in device memory (line_native.h; io::FMIndexDataDevice attaches it): the per-thread device
     /// functions below then read one 128-byte record per step end instead of the 32-byte records of the reference layout
     NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void set_line_native(const uint32* base) { m_side.base = base; }
+    /// the whole suffix array of this FM-index in device memory (line_native.h: full_sa; io::FMIndexDataDevice builds and attaches it when the
+    /// device has the room): locate_ssa_iterator becomes one load, the positions stay what the sampled array gives
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void set_full_sa(const uint32* sa) { m_side.full_sa = sa; }
 
     index_type      m_length;
     index_type      m_primary;
@@ -70,6 +73,9 @@ NVBIO_FORCEINLINE __device__ uint2 native_rank(const F& fmi, const native_side<u
     if (side.kept(range.x, range.y, c, L2c, out)) return out;
     return side.step(range.x, range.y, c, L2c);
 }
+/// the attached whole suffix array, NULL for index types that cannot carry one
+template <typename side_type> NVBIO_FORCEINLINE __device__ const uint32* full_sa_of(const side_type&) { return NULL; }
+NVBIO_FORCEINLINE __device__ const uint32* full_sa_of(const native_side<uint32>& side) { return side.full_sa; }
 template <typename sa_type> struct native_sampled
 {
     NVBIO_FORCEINLINE __device__ native_sampled(const sa_type& sa) : m_sa(sa) {}
@@ -217,6 +223,7 @@ typename NVBIO_FMI::range_type locate_ssa_iterator(const NVBIO_FMI& fmi, const t
     typedef typename NVBIO_FMI::index_type index_type;
     index_type j = i, t = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
+    if (priv::full_sa_of(fmi.m_side)) return make_vector(index_type(0), index_type(priv::full_sa_of(fmi.m_side)[i] + 1u));      // (0, SA[i] + 1): ssa[0] = -1
     if (fmi.m_side.attached())
     {
         while (!fmi.m_sa.has(j)) priv::native_locate_step(fmi, fmi.m_side, j, t);        // up to two text positions per record

@@ -75,15 +75,30 @@ template <> struct native_side<uint32>
 {
     static const uint32 NONE = 0xFFFFFFFEu;      // no caller passes -2 as a range end
 
-    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE native_side() : base(NULL), next_lo(NONE), next_hi(NONE) {}
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE native_side() : base(NULL), full_sa(NULL), next_lo(NONE), next_hi(NONE) {}
     NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool attached() const { return base != NULL; }
 
     const uint32* base;                  ///< header line of the line-native buffer (device memory); NULL = reference layout only
-    // the step kept for the next call: rank(fmi, (next_lo, next_hi), a) = (keep_lo[a] - L2[a], keep_hi[a] - L2[a]) wherever keep_lo[a] < keep_hi[a]
+    /// the whole suffix array in device memory (full_sa[row] = SA[row], full_sa[0] = 0xFFFFFFFF like ssa[0]; NULL = none): 4 bytes per row of the
+    /// 288 GB (12 GB at 3 Gbp).  locate_ssa_iterator then answers with the iterator (0, SA[row] + 1) -- row 0 is sampled and holds -1, so
+    /// lookup_ssa_iterator returns ssa[0] + SA[row] + 1 = SA[row], the value the LF walk to any other sampled row would have produced
+    const uint32* full_sa;
+    // the step kept for the next call: rank(fmi, (next_lo, next_hi), a) = (keep_lo[a] - L2[a], keep_hi[a] - L2[a]) wherever keep_lo[a] < keep_hi[a].
+    // The reference's fm_index is a read-only view that several threads may share (in __shared__ memory, behind a pointer, in a struct a block
+    // holds); this cache is written by rank(const fm_index&, ...).  It is therefore used ONLY when the object is the calling lane's own -- in
+    // private memory, i.e. a by-value copy in registers / scratch, which is how nvBowtie's kernels hold theirs (thread_private()): an fm_index
+    // in LDS or global memory never has these fields read or written, and every rank() on it reads its lines afresh.
     mutable uint32 next_lo, next_hi;
     mutable uint32 keep_lo[4], keep_hi[4];
 
 #if defined(__HIPCC__)
+    /// whether this object lives in the calling lane's private memory (folds to a constant wherever the compiler knows the object's address space,
+    /// which it does for every by-value copy; a run-time aperture test for an object reached through a generic pointer)
+#if defined(__HIP_DEVICE_COMPILE__)
+    NVBIO_FORCEINLINE __device__ bool thread_private() const { return __builtin_amdgcn_is_private(static_cast<const void*>(this)); }
+#else
+    NVBIO_FORCEINLINE __device__ bool thread_private() const { return false; }          // (the host pass of a HIP translation unit only parses this)
+#endif
     NVBIO_FORCEINLINE __device__ uint32 primary() const { return base[2]; }
     NVBIO_FORCEINLINE __device__ uint32 p1()      const { return base[3]; }
     NVBIO_FORCEINLINE __device__ uint32 fill1()   const { return base[4]; }
@@ -106,13 +121,16 @@ template <> struct native_side<uint32>
         const uint32 c0 = t + r0.kb.x + r0.kb.y + r0.kb.z + r0.kb.w + r0.count_b(c, w0) - ((c == 0u && e0 > pr) ? 1u : 0u);
         const uint32 c1 = t + r1.kb.x + r1.kb.y + r1.kb.z + r1.kb.w + r1.count_b(c, w1) - ((c == 0u && e1 > pr) ? 1u : 0u);
         // the range this step produces is [L2c + c0 + 1, L2c + c1]: the caller's next query, if it goes on, is (L2c + c0, L2c + c1)
-        next_lo = L2c + c0; next_hi = L2c + c1;
-        #pragma unroll
-        for (uint32 a = 0; a < 4u; ++a)
+        if (thread_private())
         {
-            const uint32 v = a * 4u + c;
-            keep_lo[a] = native_pick(r0.kb, a) + r0.count_ab(v, w0) - filler(e0, v);
-            keep_hi[a] = native_pick(r1.kb, a) + r1.count_ab(v, w1) - filler(e1, v);
+            next_lo = L2c + c0; next_hi = L2c + c1;
+            #pragma unroll
+            for (uint32 a = 0; a < 4u; ++a)
+            {
+                const uint32 v = a * 4u + c;
+                keep_lo[a] = native_pick(r0.kb, a) + r0.count_ab(v, w0) - filler(e0, v);
+                keep_hi[a] = native_pick(r1.kb, a) + r1.count_ab(v, w1) - filler(e1, v);
+            }
         }
         return make_uint2(c0, c1);
     }
@@ -120,6 +138,7 @@ template <> struct native_side<uint32>
     /// counts the reference returns, fmindex_dimer.h)
     NVBIO_FORCEINLINE __device__ bool kept(const uint32 lo, const uint32 hi, const uint32 a, const uint32 L2a, uint2& out) const
     {
+        if (!thread_private()) return false;                     // a shared object: nothing was kept, nothing is read
         if (lo != next_lo || hi != next_hi) return false;
         const uint32 k0 = a <= 1u ? (a == 0u ? keep_lo[0] : keep_lo[1]) : (a == 2u ? keep_lo[2] : keep_lo[3]);
         const uint32 k1 = a <= 1u ? (a == 0u ? keep_hi[0] : keep_hi[1]) : (a == 2u ? keep_hi[2] : keep_hi[3]);

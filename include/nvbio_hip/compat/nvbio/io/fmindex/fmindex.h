@@ -247,12 +247,21 @@ struct FMIndexDataDevice : public FMIndexData
         // the line-native records of each index loaded (fmindex/line_native.h): 3.7 bytes per SA row of the 288 GB, built on the device from the
         // arrays just uploaded; index() / rindex() carry their address.  NVBIO_HIP_COMPAT_LINE_NATIVE=0 keeps the reference layout alone.
         m_native = m_rnative = NULL;
+        m_full_sa = m_rfull_sa = NULL;
 #if defined(NVBIO_HIP_COMPAT_IO_TUNED)
         const char* off = getenv("NVBIO_HIP_COMPAT_LINE_NATIVE");
         if (!(off && off[0] == '0'))
         {
             if (m_bwt_occ)  m_native  = build_line_native(m_native_vec,  m_bwt_occ,  m_primary,  m_ssa.m_ssa,  host_data.m_L2);
             if (m_rbwt_occ) m_rnative = build_line_native(m_rnative_vec, m_rbwt_occ, m_rprimary, m_rssa.m_ssa, host_data.m_L2);
+        }
+        // ... and the whole suffix array of each index that came with a sampled one (4 bytes per row: 12 GB at 3 Gbp), when a third of the free memory
+        // holds it: locate_ssa_iterator is then one load instead of an LF walk of ~15 steps.  NVBIO_HIP_COMPAT_FULL_SA=0 keeps the sampled array alone.
+        const char* fsa = getenv("NVBIO_HIP_COMPAT_FULL_SA");
+        if (!(fsa && fsa[0] == '0'))
+        {
+            if (m_bwt_occ  && m_ssa.m_ssa)  m_full_sa  = build_full_sa(m_full_sa_vec,  m_bwt_occ,  m_primary,  m_ssa.m_ssa,  host_data.m_L2, m_native);
+            if (m_rbwt_occ && m_rssa.m_ssa) m_rfull_sa = build_full_sa(m_rfull_sa_vec, m_rbwt_occ, m_rprimary, m_rssa.m_ssa, host_data.m_L2, m_rnative);
         }
 #endif
     }
@@ -270,8 +279,10 @@ struct FMIndexDataDevice : public FMIndexData
 
     rank_dict_type rank_dict()  const { return rank_dict_type(bwt_stream_type(bwt_iterator()),  occ_iterator(),  count_table_iterator()); }
     rank_dict_type rrank_dict() const { return rank_dict_type(bwt_stream_type(rbwt_iterator()), rocc_iterator(), count_table_iterator()); }
-    fm_index_type  index()  const { fm_index_type f(length(), primary(),  L2(), rank_dict(),  ssa_iterator());  f.set_line_native(m_native);  return f; }
-    fm_index_type  rindex() const { fm_index_type f(length(), rprimary(), L2(), rrank_dict(), rssa_iterator()); f.set_line_native(m_rnative); return f; }
+    fm_index_type  index()  const { fm_index_type f(length(), primary(),  L2(), rank_dict(),  ssa_iterator());  f.set_line_native(m_native);  f.set_full_sa(m_full_sa);  return f; }
+    fm_index_type  rindex() const { fm_index_type f(length(), rprimary(), L2(), rrank_dict(), rssa_iterator()); f.set_line_native(m_rnative); f.set_full_sa(m_rfull_sa); return f; }
+    const uint32* full_sa()  const { return m_full_sa; }          ///< device memory, NULL = not built
+    const uint32* rfull_sa() const { return m_rfull_sa; }
     partial_fm_index_type partial_index()  const { return partial_fm_index_type(length(), primary(),  L2(), rank_dict(),  null_type()); }
     partial_fm_index_type rpartial_index() const { return partial_fm_index_type(length(), rprimary(), L2(), rrank_dict(), null_type()); }
 
@@ -302,6 +313,29 @@ private:
         }
         catch (...) { (void)hipGetLastError(); store.clear(); return NULL; }
     }
+    /// nvbio_hip_fm_build_dense_ssa(sa_int = 1) over one uploaded index; NULL when the device cannot spare the room or the build fails
+    const uint32* build_full_sa(nvbio::vector<device_tag, uint32>& store, const uint32* bwt_occ, const uint32 primary, const uint32* ssa, const uint32* host_L2, const uint32* native)
+    {
+        nvbio_hip_fmindex m;
+        memset(&m, 0, sizeof(m));
+        m.length = m_seq_length; m.primary = primary; m.sa_int = SA_INT;
+        for (int i = 0; i < 5; ++i) m.L2[i] = host_L2[i];
+        m.bwt_occ = bwt_occ; m.ssa = ssa;
+        if (native && nvbio_hip_fm_attach_dimer_index(&m, native, 0) != 0) { (void)hipGetLastError(); m.dimer = NULL; }      // (the walk that fills the array goes two positions per line with it)
+        const uint64 bytes = nvbio_hip_fm_dense_ssa_entries(m_seq_length, 1u) * 4u;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || uint64(free_b) < 3u * bytes) { (void)hipGetLastError(); return NULL; }
+        try
+        {
+            store.resize(size_t(bytes / 4u));
+            uint32* out = nvbio::raw_pointer(store);
+            if (nvbio_hip_fm_build_dense_ssa(&m, 1u, out, 0) != 0 || hipStreamSynchronize(0) != hipSuccess)
+            { (void)hipGetLastError(); store.clear(); log_warning(stderr, "FMIndexDataDevice: building the whole suffix array failed, staying on the sampled one\n"); return NULL; }
+            m_allocated += bytes;
+            return out;
+        }
+        catch (...) { (void)hipGetLastError(); store.clear(); return NULL; }
+    }
 #endif
     void upload(nvbio::vector<device_tag, uint32>& dst, const uint32* src, const size_t n)
     {
@@ -310,9 +344,11 @@ private:
         m_allocated += uint64(n) * sizeof(uint32);
     }
     uint64                             m_allocated;
-    nvbio::vector<device_tag, uint32>  m_bwt_occ_vec, m_rbwt_occ_vec, m_ssa_vec, m_rssa_vec, m_count_table_vec, m_L2_vec, m_native_vec, m_rnative_vec;
+    nvbio::vector<device_tag, uint32>  m_bwt_occ_vec, m_rbwt_occ_vec, m_ssa_vec, m_rssa_vec, m_count_table_vec, m_L2_vec, m_native_vec, m_rnative_vec, m_full_sa_vec, m_rfull_sa_vec;
     const uint32*                      m_native;
     const uint32*                      m_rnative;
+    const uint32*                      m_full_sa;
+    const uint32*                      m_rfull_sa;
 };
 
 inline void init_ssa(const FMIndexDataDevice& driver_data, FMIndexDataDevice::ssa_storage_type& ssa, FMIndexDataDevice::ssa_storage_type& rssa)

@@ -265,15 +265,46 @@ __device__ uint2 traced_walk(uint2 range, const FMType index, const Query query,
     return range;
 }
 /// mode 0: one walk per lane; mode 1: two walks INTERLEAVED on one index object (each call finds the other walk's kept step); mode 2: after every
-/// step the same query is asked again (a kept step must not answer a repeated range wrongly); rows: locate_ssa_iterator + lookup
+/// step the same query is asked again (a kept step must not answer a repeated range wrongly); mode 3: ONE index object in __shared__ memory walked
+/// by every lane of the block at once; mode 4: one object in global memory behind a pointer, walked by every lane of the grid (the reference's
+/// fm_index is a read-only view: a shared object must answer as a private copy does, whatever the other lanes ask of it meanwhile);
+/// rows: locate_ssa_iterator + lookup
+template <typename FMIndexType, typename Query>
+__device__ uint2 traced_walk_shared(uint2 range, const FMIndexType* index, const Query query, const uint32 end, uint32* trace)
+{
+    for (uint32 i = 0; i < end && range.x <= range.y; ++i)
+    {
+        const uint8 c = query[i];
+        const uint2 cnts = rank(*index, make_uint2(range.x - 1u, range.y), c);          // *index: the one object every lane uses
+        trace[2u * i] = cnts.x; trace[2u * i + 1u] = cnts.y;
+        range.x = index->L2(c) + cnts.x + 1u;
+        range.y = index->L2(c) + cnts.y;
+    }
+    return range;
+}
 template <typename FMIndexType>
 __global__ void native_walk_kernel(const uint32 n_queries, const uint32 query_len, const uint32* genome_words, const FMIndexType fmi, const uint32 mode,
-                                   const uint32* starts, uint32* ranges, uint32* trace, const uint32 n_rows, const uint32* rows, uint32* iterators, uint32* positions)
+                                   const uint32* starts, uint32* ranges, uint32* trace, const uint32 n_rows, const uint32* rows, uint32* iterators, uint32* positions,
+                                   FMIndexType* global_index)
 {
     const uint32 q = threadIdx.x + blockIdx.x * blockDim.x;
     typedef PackedStream<const uint32*, uint8, 2, true> genome_string;
     const genome_string genome(genome_words);
-    if (q < n_queries)
+    __shared__ unsigned char s_index_bytes[sizeof(FMIndexType)] __attribute__((aligned(16)));
+    FMIndexType* s_index = reinterpret_cast<FMIndexType*>(s_index_bytes);
+    if (mode == 3u)
+    {
+        if (threadIdx.x == 0u) *s_index = fmi;
+        __syncthreads();
+    }
+    if (q < n_queries && (mode == 3u || mode == 4u))
+    {
+        uint32* tr = trace + uint64(q) * 2u * query_len;
+        for (uint32 i = 0; i < 2u * query_len; ++i) tr[i] = 0xFFFFFFFFu;
+        const uint2 range = traced_walk_shared(make_uint2(0u, fmi.length()), mode == 3u ? s_index : global_index, genome + starts[q], query_len, tr);
+        ranges[2u * q] = range.x; ranges[2u * q + 1u] = range.y;
+    }
+    else if (q < n_queries)
     {
         uint32* tr = trace + uint64(q) * 2u * query_len;
         for (uint32 i = 0; i < 2u * query_len; ++i) tr[i] = 0xFFFFFFFFu;
@@ -330,7 +361,12 @@ API int compat_fm_native_walk(unsigned n, unsigned primary, const unsigned* L2, 
     InterleavedLayout::fm_index_type fmi = InterleavedLayout::make(n, primary, L2, bwt_occ, NULL, count_table, ssa);
     fmi.set_line_native(line_native);
     const uint32 m = n_queries > n_rows ? n_queries : n_rows;
+    InterleavedLayout::fm_index_type* d_index = NULL;              // mode 4: the object itself in device memory
+    if (hipMalloc(reinterpret_cast<void**>(&d_index), sizeof(fmi)) != hipSuccess) return 2;
+    if (hipMemcpy(d_index, &fmi, sizeof(fmi), hipMemcpyHostToDevice) != hipSuccess) return 2;
     hipLaunchKernelGGL((native_walk_kernel<InterleavedLayout::fm_index_type>), dim3((m + 127u) / 128u), dim3(128), 0, 0, n_queries, query_len, genome_words, fmi, mode,
-                       starts, ranges, trace, n_rows, rows, iterators, positions);
-    return int(hipDeviceSynchronize());
+                       starts, ranges, trace, n_rows, rows, iterators, positions, d_index);
+    const int e = int(hipDeviceSynchronize());
+    (void)hipFree(d_index);
+    return e;
 }

@@ -247,7 +247,7 @@ static int paired_impl(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmindex* rf
                                      const uint32_t* d_genome_words, uint64_t genome_n_words, uint32_t genome_len, const shim_params* sp, const shim_pe_params* pp,
                                      uint64_t* const* h_best, uint8_t* const* h_mapq, uint16_t* const* h_cigar, uint32_t* const* h_cigar_len, uint32_t* const* h_source,
                                      uint32_t* const* h_sink, uint8_t* const* h_mds, uint32_t* const* h_mds_len, uint64_t* h_stats,
-                                     uint32_t reps, double* out_ms, double* out_stage_ms /* 10 */)
+                                     uint32_t reps, double* out_ms, double* out_stage_ms /* 10 */, const uint8_t* const* d_mate_quals = nullptr /* 2: each mate's own stream */)
 {
     try {
         Params params;
@@ -273,7 +273,7 @@ static int paired_impl(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmindex* rf
             b.n = n; b.len = L;
             b.reversed = PackedStringSetView<4, true>(n, d_rev_words[m], rev_n_words[m], d_rev_begin[m], nullptr, L);
             b.fw_rc_words = d_fwrc_words[m]; b.fw_rc_n_words = fwrc_n_words[m]; b.rc_offset = uint64_t(n) * L;
-            b.quals = d_quals; b.n_quals = n_quals; b.names = d_names; b.names_idx = d_names_idx;
+            b.quals = d_mate_quals ? d_mate_quals[m] : d_quals; b.n_quals = n_quals; b.names = d_names; b.names_idx = d_names_idx;
         }
         reads.both_words = d_both_words; reads.both_n_words = both_n_words; reads.mate_offset = mate_offset;
         reads.both_quals = d_both_quals; reads.both_n_quals = both_n_quals;
@@ -336,6 +336,24 @@ int nvbio_aligner_best_approx_paired(const nvbio_hip_fmindex* fmi, const nvbio_h
     return paired_impl(fmi, rfmi, n, L, d_rev_words, rev_n_words, d_rev_begin, d_fwrc_words, fwrc_n_words, d_quals, n_quals, d_names, d_names_idx, d_both_words, both_n_words,
                        mate_offset, d_both_quals, both_n_quals, d_genome_words, genome_n_words, genome_len, sp, pp, h_best, h_mapq, h_cigar, h_cigar_len, h_source, h_sink,
                        h_mds, h_mds_len, h_stats, 0u, nullptr, nullptr);
+}
+// ... with each mate's own quality stream (fw + rc order, n_quals bytes each); d_both_quals holds mate m's at m * mate_offset
+extern "C" __attribute__((visibility("default")))
+int nvbio_aligner_best_approx_paired_quals(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmindex* rfmi, uint32_t n, uint32_t L,
+                                     const uint32_t* const* d_rev_words, const uint64_t* rev_n_words, const uint64_t* const* d_rev_begin,
+                                     const uint32_t* const* d_fwrc_words, const uint64_t* fwrc_n_words, const uint8_t* const* d_mate_quals, uint64_t n_quals,
+                                     const char* d_names, const uint32_t* d_names_idx,
+                                     const uint32_t* d_both_words, uint64_t both_n_words, uint64_t mate_offset, const uint8_t* d_both_quals, uint64_t both_n_quals,
+                                     const uint32_t* d_genome_words, uint64_t genome_n_words, uint32_t genome_len, const shim_params* sp, const shim_pe_params* pp,
+                                     uint64_t* const* h_best, uint8_t* const* h_mapq, uint16_t* const* h_cigar, uint32_t* const* h_cigar_len, uint32_t* const* h_source,
+                                     uint32_t* const* h_sink, uint8_t* const* h_mds, uint32_t* const* h_mds_len, uint64_t* h_stats, double* out_ms)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = paired_impl(fmi, rfmi, n, L, d_rev_words, rev_n_words, d_rev_begin, d_fwrc_words, fwrc_n_words, d_mate_quals[0], n_quals, d_names, d_names_idx, d_both_words, both_n_words,
+                       mate_offset, d_both_quals, both_n_quals, d_genome_words, genome_n_words, genome_len, sp, pp, h_best, h_mapq, h_cigar, h_cigar_len, h_source, h_sink,
+                       h_mds, h_mds_len, h_stats, 0u, nullptr, nullptr, d_mate_quals);
+    if (out_ms) out_ms[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
 }
 // the same driver on the wall clock (bench.py: e2e_leg.config5_shape_paired_end.cxx): mean of `reps` batches with one Aligner object,
 // stage times from one more; only the best alignments of both slot sets come back (host, 2n words each)
@@ -547,5 +565,31 @@ int nvbio_write_sam_se(const char* path, int append, int with_header, uint32_t e
     if (with_header) { const std::string h = ref.header(); ok = fwrite(h.data(), 1, h.size(), f) == h.size(); }
     const io::SamBatchSE b = { n, names, names_index, symbols, read_index, quals, best, mapq, cigar, cigar_stride, cigar_len, source, mds, mds_stride };
     ok = ok && io::write_sam_se(f, b, ref, extra_flags);
+    return (fclose(f) == 0 && ok) ? 0 : 2;
+}
+
+// the paired-end twin: two slot sets of host arrays (anchor, opposite) -> two SAM records per pair
+extern "C" __attribute__((visibility("default")))
+int nvbio_write_sam_pe(const char* path, int append, int with_header, uint32_t n, uint32_t len, const char* names, const uint32_t* names_index,
+                       const uint8_t* const* symbols /* 2 */, const uint8_t* const* quals /* 2 */,
+                       const uint64_t* const* best /* 2 */, const uint8_t* const* mapq, const uint16_t* const* cigar, uint32_t cigar_stride, const uint32_t* const* cigar_len,
+                       const uint32_t* const* source, const uint8_t* const* mds, uint32_t mds_stride,
+                       uint32_t n_seqs, const char* const* seq_names, const uint64_t* seq_index)
+{
+    io::SamReference ref;
+    for (uint32_t k = 0; k < n_seqs; ++k) ref.names.push_back(seq_names[k]);
+    ref.index.assign(seq_index, seq_index + n_seqs + 1u);
+    FILE* f = fopen(path, append ? "ab" : "wb");
+    if (!f) return 1;
+    bool ok = true;
+    if (with_header) { const std::string h = ref.header(); ok = fwrite(h.data(), 1, h.size(), f) == h.size(); }
+    io::SamBatchPE b;
+    b.n = n; b.len = len; b.names = names; b.names_index = names_index; b.cigar_stride = cigar_stride; b.mds_stride = mds_stride;
+    for (int k = 0; k < 2; ++k)
+    {
+        b.symbols[k] = symbols[k]; b.quals[k] = quals[k];
+        b.slot[k].best = best[k]; b.slot[k].mapq = mapq[k]; b.slot[k].cigar = cigar[k]; b.slot[k].cigar_len = cigar_len[k]; b.slot[k].source = source[k]; b.slot[k].mds = mds[k];
+    }
+    ok = ok && io::write_sam_pe(f, b, ref);
     return (fclose(f) == 0 && ok) ? 0 : 2;
 }

@@ -35,17 +35,24 @@ def test_two_ranks_share_one_gpu_through_the_whole_bench(route):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]                       # rank 0 prints ONE line
-    out = json.loads(lines[0])
+    # rank 0 prints the legs, one line each, then the headline as the LAST line (the one the driver parses: < 4 KB, benchlib/headline.py)
+    out = json.loads(lines[-1])
+    assert len(lines[-1].encode()) < 4096 and "leg" not in out
+    legs = {d["leg"]: d["data"] for d in map(json.loads, lines[:-1])}
+    assert all(k in out for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "parity"))
     assert out["n_gpus"] == 2 and out["steps"] == 4 and out["scaling"] == "weak"
+    assert len(out["config"]["per_rank_ms_per_step"]) == 2 and all(x > 0 for x in out["config"]["per_rank_ms_per_step"])
+    assert abs(max(out["config"]["per_rank_ms_per_step"]) - out["ms_per_step"]) / out["ms_per_step"] < 1e-6        # the maximum over ranks
+    assert out["config"]["rccl_ranks_seen"] == (0 if route == "torch_fallback" else 2)                              # ranks whose records came through the C++ gather
     assert out["config"]["gather"] is True
     assert out["config"]["gather_path"] == "torch.distributed.gather" if route == "torch_fallback" else out["config"]["gather_path"].startswith("cxx_host_transport")
     assert out["parity"]["bit_exact"] is True
     assert out["value"] > 0 and abs(out["value"] - 2 * 300000 * 4 / (out["ms_per_step"] * 4e-3)) / out["value"] < 1e-6
-    leg = out["e2e_sharded_leg"]
+    leg = legs["e2e_sharded_leg"]
     assert "error" not in leg, leg
+    assert out["e2e_sharded"]["Mreads_per_s"] > 0
     assert leg["n_gpus"] == 2 and leg["gather"] is True and leg["gathered_records_verified"] is True
     assert leg["aligned"] > 0.9 and leg["best_at_true_position"] > 0.8
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "bench_two_ranks_one_gpu_%s.json" % route), "w") as f:
-        f.write(lines[0] + "\n")
+        f.write(lines[-1] + "\n")

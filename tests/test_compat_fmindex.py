@@ -229,13 +229,16 @@ def test_caller_kernel_one_mismatch_search(fm, index, layout, len1, len2):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", [0, 1, 2], ids=["one_walk", "two_walks_interleaved", "repeated_queries"])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4], ids=["one_walk", "two_walks_interleaved", "repeated_queries", "one_index_in_shared_memory", "one_index_behind_a_pointer"])
 def test_line_native_records_under_the_per_thread_functions(fm, mode):
     """fmindex/line_native.h: the same caller kernel -- a walk in the shape of nvBowtie's match_range (one rank(index, (x - 1, y), c) per symbol on an
     index held by value) and locate_ssa_iterator / lookup_ssa_iterator over random rows -- on the production-layout fm_index WITH the line-native
     records attached and WITHOUT them: every raw pair of counts of every step, every final range (emptied ones included), every iterator and every
     position must be identical, and equal the oracle's.  Mode 1 interleaves two searches on one index object and mode 2 repeats queries, so that the
-    step a call keeps for its successor is found by calls it was not meant for.  The genome has exact and diverged repeats (long non-empty walks)."""
+    step a call keeps for its successor is found by calls it was not meant for.  Modes 3 and 4 put ONE fm_index object in __shared__ / global memory and
+    let every lane of the block / grid walk it at once -- the reference's fm_index is a read-only view, so a shared object must answer exactly as a
+    private copy does (the kept step is only ever used on an object in the lane's private memory, line_native.h: thread_private()).
+    The genome has exact and diverged repeats (long non-empty walks)."""
     import torch
     import nvbio_amd as nvb
     fm.compat_fm_native_walk.argtypes = [C.c_uint32, C.c_uint32] + [C.c_void_p] * 5 + [C.c_uint32] * 3 + [C.c_void_p] * 4 + [C.c_uint32] + [C.c_void_p] * 3

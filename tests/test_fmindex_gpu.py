@@ -379,6 +379,71 @@ def test_full_size_match_and_locate(cuda, genome_3gbp, flavour):
     torch.cuda.empty_cache()
 
 
+def test_config3_at_50m_seeds(cuda, genome_3gbp):
+    """BASELINE config 3 as written: 50 M 22-bp exact seeds on the 3 Gbp index -- match + locate on the index the loaders build by default
+    (FMIndexDevice.hbm_default) and on the reference layout.  A sample of 1.2 M seeds spread over the 50 M goes against the oracle on a host copy;
+    all 50 M are held to the properties the domain offers: the two layouts agree range for range and position for position; a seed drawn from the
+    genome is found (non-empty range) and the text at EVERY located position spells the seed (what the reference's own test checks on a sample,
+    fmindex_test.cu:636-657, here on all ~45 M located rows by a packed compare on the device); a range's first row locates to a position whose
+    22-mer is the smallest suffix carrying the seed, so locating the LAST row of the range must spell the seed too."""
+    text, fmi, host = genome_3gbp
+    n = 50_000_000
+    seeds = W.make_seeds(text, n, 22)
+    rich, desc = fmi.hbm_default()
+    assert desc["line_native"] and desc["sa_int"] < 16
+    r_lean = nvb.match(fmi, seeds)
+    r_rich = nvb.match(rich, seeds)
+    assert torch.equal(r_lean, r_rich)
+    lo, hi = r_lean[:, 0].to(torch.int64) & 0xFFFFFFFF, r_lean[:, 1].to(torch.int64) & 0xFFFFFFFF
+    found = lo <= hi
+    share = float(found.float().mean().item())
+    assert 0.85 < share < 0.95, share                                   # 90 % of the seeds are drawn from the genome, the rest are random 22-mers
+    rows_first = r_lean[:, 0][found].contiguous()
+    rows_last = r_lean[:, 1][found].contiguous()
+    p_lean = nvb.locate(fmi, rows_first)
+    p_rich = nvb.locate(rich, rows_first)
+    assert torch.equal(p_lean, p_rich)
+    p_last = nvb.locate(rich, rows_last)
+    # the text at every located position is the seed: compare 22 symbols as a packed 44-bit integer, in chunks
+    sym = seeds.words          # packed 2-bit big-endian words; decode the seeds on the device the same way the text is packed
+    idx_found = torch.nonzero(found).squeeze(1)
+    begin = seeds.begin[idx_found]
+    def spell(words, big_endian_bits2, start):           # 22 symbols from symbol offset `start` of a 2-bit big-endian word stream -> int64
+        out = torch.zeros_like(start)
+        for k in range(22):
+            s = start + k
+            w = words[(s >> 4)].to(torch.int64) & 0xFFFFFFFF
+            out = (out << 2) | ((w >> (30 - 2 * (s & 15))) & 3)
+        return out
+    assert seeds.bits == 2 and seeds.big_endian
+    chunk = 1 << 23
+    ar = torch.arange(22, device=cuda)
+    for s0 in range(0, idx_found.numel(), chunk):
+        e0 = min(idx_found.numel(), s0 + chunk)
+        want = spell(seeds.words, True, begin[s0:e0])
+        for p in (p_lean[s0:e0], p_last[s0:e0]):
+            q = (p.to(torch.int64) & 0xFFFFFFFF)
+            t = text[q.unsqueeze(1) + ar.unsqueeze(0)].to(torch.int64)
+            got = torch.zeros(e0 - s0, dtype=torch.int64, device=cuda)
+            for k in range(22):
+                got = (got << 2) | t[:, k]
+            assert torch.equal(got, want)
+    # the sample against the oracle
+    step = n // 1_200_000
+    pick = torch.arange(0, n, step, device=cuda)[:1_200_000]
+    sub = nvb.PackedStringSet(seeds.words, 2, True, seeds.begin[pick].contiguous(), None, 22)
+    exp = host.match(O.StringSet.from_device(sub), n_threads=0)
+    got = u32(r_lean[pick])
+    assert (got == exp).all()
+    ok = exp[:, 0] <= exp[:, 1]
+    epos = host.locate(exp[ok, 0], n_threads=0)
+    pos_all = torch.full((n,), -1, dtype=torch.int32, device=cuda)
+    pos_all[idx_found] = p_lean
+    assert (u32(pos_all[pick][torch.from_numpy(ok).to(cuda)]) == epos).all()
+    del rich
+    torch.cuda.empty_cache()
+
+
 # ------------------------------------------------------------------ three symbols per step
 def test_trimer_arrays_equal_model(cuda, index):
     from tests import dimer_model as DM

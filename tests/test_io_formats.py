@@ -73,11 +73,16 @@ def test_index_round_trip_through_files(tmp_path, cuda):
     nio.save_fmindex(prefix, h)
     nio.save_fmindex(prefix, rh, reverse=True)
     data = nio.FMIndexDataDevice(prefix, device=cuda)
-    for loaded, host in ((data.index(), h), (data.rindex(), rh)):
+    # the arrays exactly as the files hold them (lean_index), and the index the loader hands out by default on this device: the same arrays plus the
+    # line-native records, a k-mer table and the whole suffix array (every SA row, checked against the oracle's)
+    for loaded, rich, host in ((data.lean_index(), data.index(), h), (data.lean_rindex(), data.rindex(), rh)):
         assert (loaded.length, loaded.primary) == (host.length, host.primary)
         assert loaded.L2 == [int(x) for x in host.L2]
         assert (loaded.bwt_occ.cpu().numpy().view(np.uint32) == host.bwt_occ).all()
         assert (loaded.ssa.cpu().numpy().view(np.uint32) == host.ssa).all()
+        assert rich.dimer is not None and rich.ktab is not None and rich.sa_int == 1
+        assert (rich.ssa.cpu().numpy().view(np.uint32) == host.locate(np.arange(host.length + 1, dtype=np.uint32))).all()
+    assert data.description["sa_int"] == 1 and data.description["line_native"]
     seeds = [text[i:i + 20] for i in rng.integers(0, text.size - 20, 500)]
     hs = O.StringSet.from_lists(seeds, 2, True)
     ds = nvb.PackedStringSet.from_host(hs.words, 2, True, hs.begin, hs.length, device=cuda)

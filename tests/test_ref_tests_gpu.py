@@ -475,3 +475,26 @@ def test_reference_nvbowtie_equals_own_driver_at_3gbp():
     # the C++ host driver on the HBM-rich index the device gets by default: the same 5 M records
     assert out["records_cxx"] == 5_000_000 and out["cxx_identical"] == 5_000_000, (out["cxx_index"], out["cxx_difference_categories"], out["cxx_first_differences"][:3])
     assert out["aligned_share_first_200k"] > 0.9
+
+
+def test_reference_nvbowtie_equals_own_paired_driver_at_3gbp():
+    """BASELINE config 5 as written, at one device and one batch: paired-end 2 x 150 bp, --local (LOCAL Gotoh, band 31), on the 3 Gbp repeat-rich index
+    files, 1024 K pairs (nvBowtie's batch) with per-base qualities, indels and Ns: the unchanged nvBowtie (-1 / -2) and the C++ paired-end driver
+    (Aligner::best_approx over a PairedReadBatch, on the HBM-rich index the loaders build by default) must print the same two SAM records for every
+    pair -- flags, positions, MAPQ, CIGAR, RNEXT / PNEXT / TLEN, NM / AS / XM / XO / XG / MD (tools/nvbowtie_3gbp.py run_paired; the records come out of
+    the host layer's paired SAM writer, include/nvbio_hip/sam.h)."""
+    import sys
+    exe = os.path.join(REF, "ref_nvBowtie")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_nvBowtie not built (needs /root/reference in the build container)")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import json
+    import nvbowtie_3gbp as T
+    pairs = 1 << 20
+    out, log = T.run_paired(3_000_000_000, pairs, 0.6)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "nvbowtie_3gbp_paired.json"), "w"), indent=1, default=str)
+    open(os.path.join(ROOT, "gpurun_out", "nvbowtie_3gbp_paired.log"), "w").write(log)
+    assert out["nvbowtie_exit"] == 0, log[-2000:]
+    assert out["records_ref"] == out["records_own"] == 2 * pairs
+    assert out["identical"] == 2 * pairs, (out["difference_categories"], out["first_differences"][:3])

@@ -104,12 +104,12 @@ def make_reads(text, n_reads, L, seed, seq_bounds, dev):
     return sym.contiguous(), qual.contiguous(), pos
 
 
-def write_fastq(path, sym, qual, digits=8):
+def write_fastq(path, sym, qual, digits=8, tag="r"):
     """@r<8 digits>, sequence, +, phred+33: built as one byte matrix on the device"""
     n, L = sym.shape
     dev = sym.device
     rec = torch.empty((n, 2 + digits + 1 + L + 3 + L + 1), dtype=torch.uint8, device=dev)
-    rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
+    rec[:, 0] = ord("@"); rec[:, 1] = ord(tag)
     ids = torch.arange(n, device=dev)
     for d in range(digits):
         rec[:, 2 + d] = ((ids // (10 ** (digits - 1 - d))) % 10 + ord("0")).to(torch.uint8)
@@ -157,6 +157,190 @@ def own_driver(prefix, sym, qual, sam_path, dev, batch_reads, digits=8, timings=
         del r, batch
     if timings is not None:
         timings.update(own_load_s=t_load, own_align_s=t_align, own_write_s=t_write, own_reads_per_s=n / t_align, own_batches=len(stats), own_stats_first_batch=stats[0])
+
+
+def make_pairs(text, n_pairs, L, seed, seq_bounds, dev, frag=(250, 450)):
+    """FR pairs with per-base qualities: mate 1 = the fragment's first L bases, mate 2 = the reverse complement of its last L; half of the fragments come
+    from the reverse strand; 3 % substitutions, a tenth of the mates with a 1-2 bp indel, one mate in a hundred with an N.  No fragment crosses a sequence
+    boundary.  -> (sym1, sym2, qual1, qual2) uint8 [n, L]"""
+    g = torch.Generator(device=dev); g.manual_seed(seed)
+    n = text.numel()
+    flen = torch.randint(frag[0], frag[1] + 1, (n_pairs,), generator=g, device=dev)
+    pos = torch.randint(0, n - frag[1] - 16, (n_pairs,), generator=g, device=dev)
+    b = torch.tensor(seq_bounds[1:-1], dtype=torch.int64, device=dev)
+    if b.numel():
+        k = torch.searchsorted(b, pos + flen + 8, right=False)
+        kb = b[torch.clamp(k - 1, min=0)]
+        cross = (k > 0) & (kb > pos)
+        pos = torch.where(cross, kb - flen - 8, pos)
+
+    def mate(start, rc, salt):
+        idx = start.unsqueeze(1) + torch.arange(L + 4, device=dev).unsqueeze(0)
+        win = text[idx]
+        r = torch.rand(n_pairs, generator=g, device=dev)
+        at = torch.randint(3 * L // 10, 7 * L // 10, (n_pairs,), generator=g, device=dev)
+        gl = torch.randint(1, 3, (n_pairs,), generator=g, device=dev)
+        col = torch.arange(L, device=dev).unsqueeze(0)
+        dele, ins = (r < 0.05).unsqueeze(1), ((r >= 0.05) & (r < 0.1)).unsqueeze(1)
+        src = torch.where(dele & (col >= at.unsqueeze(1)), col + gl.unsqueeze(1), col)
+        src = torch.where(ins & (col >= (at + gl).unsqueeze(1)), col - gl.unsqueeze(1), src)
+        sym = torch.gather(win, 1, src)
+        rnd = torch.randint(0, 4, (n_pairs, L), dtype=torch.uint8, generator=g, device=dev)
+        sym = torch.where(ins & (col >= at.unsqueeze(1)) & (col < (at + gl).unsqueeze(1)), rnd, sym)
+        mut = torch.rand((n_pairs, L), generator=g, device=dev) < 0.03
+        sym = torch.where(mut, (sym + 1 + (rnd % 3)) & 3, sym)
+        if rc:
+            sym = (3 - sym).flip(1)
+        hasn = torch.rand(n_pairs, generator=g, device=dev) < 0.01
+        npos = torch.randint(0, L, (n_pairs,), generator=g, device=dev)
+        sym = torch.where(hasn.unsqueeze(1) & (col == npos.unsqueeze(1)), torch.full_like(sym, 4), sym)
+        q = torch.randint(2, 41, (n_pairs, L), dtype=torch.uint8, generator=g, device=dev)
+        return sym.contiguous(), q.contiguous()
+    m1, q1 = mate(pos, False, 0)
+    m2, q2 = mate(pos + flen - L - 2, True, 1)              # (the window is L + 4 wide: the mate's last base sits near the fragment's end)
+    swap = (torch.rand(n_pairs, generator=g, device=dev) < 0.5).unsqueeze(1)
+    return (torch.where(swap, m2, m1).contiguous(), torch.where(swap, m1, m2).contiguous(), torch.where(swap, q2, q1).contiguous(), torch.where(swap, q1, q2).contiguous())
+
+
+def own_driver_cxx_paired(prefix, s1, s2, q1, q2, sam_path, dev, batch_pairs, digits=8, timings=None, local=True):
+    """the C++ paired-end driver (Aligner::best_approx over a PairedReadBatch) over the same pairs on the same index files -> own_pe.sam through
+    the host layer's paired SAM writer (include/nvbio_hip/sam.h: write_sam_pe)"""
+    import ctypes as C
+    import align_fastq as AF
+    import bench as B
+    import nvbio_amd as nvb
+    from nvbio_amd import io as nio, aligner as A, pipeline as P, select as SEL
+    shim = C.CDLL(os.path.join(ROOT, "tests", "cxx", "libaligner_shim.so"))
+    t0 = time.time()
+    data = nio.FMIndexDataDevice(prefix, flags=nio.FORWARD | nio.SA, device=dev)
+    n_genome, g_words = nio.load_genome(prefix)
+    genome_words = torch.from_numpy(np.concatenate([g_words, np.zeros(8, np.uint32)]).view(np.int32)).to(dev)
+    ref = AF.Reference(prefix, n_genome, "ref")
+    torch.cuda.synchronize()
+    t_load = time.time() - t0
+    n, L = s1.shape
+    prm = A.Params(hits_stride=32, batch_size=batch_pairs, local=local)
+    scheme = nvb.SmithWatermanScoringScheme.local() if local else nvb.SmithWatermanScoringScheme()
+    sp = B._shim_params(prm, scheme); sp.finish = 1
+
+    class ShimPeParams(C.Structure):
+        _fields_ = [("pe_policy", C.c_int32)] + [(k, C.c_uint32) for k in ("pe_overlap", "pe_unpaired", "pe_discordant", "min_frag_len", "max_frag_len")]
+    pp = ShimPeParams(prm.pe_policy, int(prm.pe_overlap), int(prm.pe_unpaired), int(prm.pe_discordant), prm.min_frag_len, prm.max_frag_len)
+    fs = data.index().struct()
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    pair_ptrs = lambda ts: (C.c_void_p * 2)(*[t.data_ptr() for t in ts])
+    pair_host = lambda arrs: (C.c_void_p * 2)(*[a.ctypes.data for a in arrs])
+    u64x2 = lambda v: (C.c_uint64 * 2)(*v)
+    t_align, t_write, first_stats = 0.0, 0.0, None
+    seq_names = (C.c_char_p * len(ref.names))(*[nm.encode() for nm in ref.names])
+    seq_index = np.ascontiguousarray(ref.index, dtype=np.uint64)
+    for b0 in range(0, n, batch_pairs):
+        e0 = min(n, b0 + batch_pairs); m = e0 - b0
+        mates = [s1[b0:e0].contiguous(), s2[b0:e0].contiguous()]
+        mq = [q1[b0:e0].contiguous(), q2[b0:e0].contiguous()]
+        packed = [P.pack_read_streams(x) for x in mates]
+        qs = [A._qual_stream(m, L, 30, x, dev) for x in mq]
+        both = torch.cat([packed[0][1], packed[1][1]]); mate_offset = packed[0][1].numel() * 8
+        both_q = torch.zeros(mate_offset + 2 * m * L + 8, dtype=torch.uint8, device=dev)
+        both_q[:qs[0].numel()] = qs[0]; both_q[mate_offset:mate_offset + qs[1].numel()] = qs[1]
+        names = ["p%0*d" % (digits, i) for i in range(b0, e0)]
+        arena, nidx = SEL.pack_names(names, dev)
+        out = dict(best=[np.zeros((2, m), np.uint64) for _ in range(2)], mapq=[np.zeros(m, np.uint8) for _ in range(2)], cigar=[np.zeros((m, 64), np.uint16) for _ in range(2)],
+                   cigar_len=[np.zeros(m, np.uint32) for _ in range(2)], source=[np.zeros((m, 2), np.uint32) for _ in range(2)], sink=[np.zeros((m, 2), np.uint32) for _ in range(2)],
+                   mds=[np.zeros((m, 256), np.uint8) for _ in range(2)], mds_len=[np.zeros(m, np.uint32) for _ in range(2)])
+        stats = np.zeros(12, np.uint64)
+        ms = (C.c_double * 1)()
+        torch.cuda.synchronize(); t1 = time.time()
+        rc = shim.nvbio_aligner_best_approx_paired_quals(
+            C.byref(fs), None, C.c_uint32(m), C.c_uint32(L),
+            pair_ptrs([packed[0][0].words, packed[1][0].words]), u64x2([packed[0][0].words.numel(), packed[1][0].words.numel()]), pair_ptrs([packed[0][0].begin, packed[1][0].begin]),
+            pair_ptrs([packed[0][1], packed[1][1]]), u64x2([packed[0][1].numel(), packed[1][1].numel()]), pair_ptrs(qs), C.c_uint64(qs[0].numel()), vp(arena), vp(nidx),
+            vp(both), C.c_uint64(both.numel()), C.c_uint64(mate_offset), vp(both_q), C.c_uint64(both_q.numel()),
+            vp(genome_words), C.c_uint64(genome_words.numel()), C.c_uint32(n_genome), C.byref(sp), C.byref(pp),
+            pair_host(out["best"]), pair_host(out["mapq"]), pair_host(out["cigar"]), pair_host(out["cigar_len"]), pair_host(out["source"]), pair_host(out["sink"]),
+            pair_host(out["mds"]), pair_host(out["mds_len"]), stats.ctypes.data_as(C.c_void_p), ms)
+        t_align += time.time() - t1
+        if rc != 0:
+            raise RuntimeError("nvbio_aligner_best_approx_paired_quals returned %d" % rc)
+        if first_stats is None:
+            first_stats = dict(anchor_extensions=int(stats[0]), rounds=int(stats[1]), seeding_passes=int(stats[2]))
+        t1 = time.time()
+        name_buf = np.frombuffer(("\0".join(names) + "\0").encode(), dtype=np.uint8)
+        name_idx = np.arange(0, (m + 1) * (digits + 2), digits + 2, dtype=np.uint32)
+        hs = [x.cpu().numpy() for x in mates]; hq = [x.cpu().numpy() for x in mq]
+        best0 = [np.ascontiguousarray(x[0]) for x in out["best"]]
+        pv = lambda a: a.ctypes.data_as(C.c_void_p)
+        rc = shim.nvbio_write_sam_pe(sam_path.encode(), C.c_int(1 if b0 > 0 else 0), C.c_int(1 if b0 == 0 else 0), C.c_uint32(m), C.c_uint32(L), pv(name_buf), pv(name_idx),
+                                     pair_host(hs), pair_host(hq), pair_host(best0), pair_host(out["mapq"]), pair_host(out["cigar"]), C.c_uint32(64), pair_host(out["cigar_len"]),
+                                     pair_host(out["source"]), pair_host(out["mds"]), C.c_uint32(256), C.c_uint32(len(ref.names)), seq_names, pv(seq_index))
+        if rc != 0:
+            raise IOError("nvbio_write_sam_pe failed: %d" % rc)
+        t_write += time.time() - t1
+    if timings is not None:
+        timings.update(cxx_load_s=t_load, cxx_align_s_incl_result_copies=t_align, cxx_write_s=t_write, cxx_pairs_per_s=n / t_align, cxx_index=data.description, cxx_stats_first_batch=first_stats)
+
+
+def build_files(tmp, genome, repeats, seed, dev, families=None, out=None):
+    """the synthetic genome, its forward / reverse index files and the BWA-style reference files under <tmp>/genome -> (prefix, text, sequence bounds)"""
+    from nvbio_amd import workloads as W, io as nio
+    from nvbio_amd.strings import pack_symbols
+    out = out if out is not None else {}
+    prefix = os.path.join(tmp, "genome")
+    t0 = time.time()
+    text, placed = make_genome(genome, repeats, seed, dev, families)
+    out["repeat_families"] = [dict(length=L, copies=c) for L, c in placed]
+    n_seq = 24
+    lens = [genome // n_seq] * (n_seq - 1); lens.append(genome - sum(lens))
+    bounds = [0] + [int(x) for x in np.cumsum(lens)]
+    fmi = W.build_fm_index(text)
+    save_index(prefix, fmi, False)
+    del fmi
+    rfmi = W.build_fm_index(text.flip(0).contiguous())
+    save_index(prefix, rfmi, True)
+    del rfmi
+    gw = torch.cat([pack_symbols(text[s:s + (1 << 30)], 2, True, pad_words=0) for s in range(0, genome, 1 << 30)])
+    nio.write_wpac(prefix + ".wpac", genome, gw.cpu().numpy().view(np.uint32)); del gw
+    nio.write_bns(prefix, ["chr%d" % (k + 1) for k in range(n_seq)], lens)
+    torch.cuda.synchronize(); out["files_s"] = time.time() - t0
+    out["index_files_GB"] = sum(os.path.getsize(prefix + e) for e in (".bwt", ".sa", ".rbwt", ".rsa", ".wpac")) / 1e9
+    return prefix, text, bounds
+
+
+def run_paired(genome=3_000_000_000, pairs=1 << 20, repeats=0.6, seed=0x5EED0019, batch_pairs=1 << 20, read_len=150, workdir=None, keep=False, extra=("--local",)):
+    """BASELINE config 5's shape at its index size: 2 x 150 bp FR pairs, --local (LOCAL Gotoh, band 31 from the default max_dist 15), on the 3 Gbp index
+    files: the unchanged nvBowtie (-1 / -2) and the C++ paired-end driver on the same files and reads, every SAM record compared."""
+    dev = torch.device("cuda:0")
+    out = dict(genome=genome, pairs=pairs, repeats=repeats, read_len=read_len, mode=" ".join(extra))
+    if workdir:
+        os.makedirs(workdir, exist_ok=True)
+    tmp = workdir or tempfile.mkdtemp(prefix="nvb3gpe_")
+    try:
+        prefix, text, bounds = build_files(tmp, genome, repeats, seed, dev, out=out)
+        s1, s2, q1, q2 = make_pairs(text, pairs, read_len, seed + 1, bounds, dev)
+        del text
+        torch.cuda.empty_cache()
+        f1, f2 = os.path.join(tmp, "m1.fastq"), os.path.join(tmp, "m2.fastq")
+        write_fastq(f1, s1, q1, tag="p"); write_fastq(f2, s2, q2, tag="p")
+        exe = os.path.join(ROOT, "oracle", "_ref", "ref_nvBowtie")
+        ref_sam = os.path.join(tmp, "ref_pe.sam")
+        cmd = [exe] + list(extra) + ["--file-ref", "-x", prefix, "-1", f1, "-2", f2, "-S", ref_sam]
+        t0 = time.time()
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        out["nvbowtie_wall_s"] = time.time() - t0
+        log = (r.stdout + r.stderr).replace("\r", "\n")
+        out["nvbowtie_exit"] = r.returncode
+        out["nvbowtie_log_tail"] = [l for l in log.splitlines() if l.strip()][-40:]
+        if r.returncode != 0:
+            return out, log
+        own_sam = os.path.join(tmp, "own_pe.sam")
+        own_driver_cxx_paired(prefix, s1, s2, q1, q2, own_sam, dev, batch_pairs, timings=out, local="--local" in extra)
+        n_ref, n_own, same, diffs, cats = compare_sam(ref_sam, own_sam)
+        out.update(records_ref=n_ref, records_own=n_own, identical=same, difference_categories=cats, first_differences=diffs)
+        return out, log
+    finally:
+        if not keep and workdir is None:
+            import shutil
+            shutil.rmtree(tmp, ignore_errors=True)
 
 
 def own_driver_cxx(prefix, sym, qual, sam_path, dev, batch_reads, digits=8, timings=None, hbm_rich=True):
@@ -273,6 +457,16 @@ def run(genome=3_000_000_000, reads=5_000_000, repeats=0.6, seed=0x5EED0009, bat
     if workdir:
         os.makedirs(workdir, exist_ok=True)
     tmp = workdir or tempfile.mkdtemp(prefix="nvb3g_")
+    try:
+        return _run(tmp, genome, reads, repeats, seed, batch_reads, profile, extra, threads_test, rerun, own_overrides, families, out, dev)
+    finally:
+        if not keep and workdir is None:          # on every path: the directory holds 4 GB of index files
+            import shutil
+            shutil.rmtree(tmp, ignore_errors=True)
+
+
+def _run(tmp, genome, reads, repeats, seed, batch_reads, profile, extra, threads_test, rerun, own_overrides, families, out, dev):
+    from nvbio_amd import workloads as W, io as nio
     prefix = os.path.join(tmp, "genome")
     t0 = time.time()
     text, placed = make_genome(genome, repeats, seed, dev, families)
@@ -362,9 +556,6 @@ def run(genome=3_000_000_000, reads=5_000_000, repeats=0.6, seed=0x5EED0009, bat
         pr = subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", profile, "-o", "ref_nvbowtie_3gbp", "--"] + cmd[:-1] + [os.path.join(tmp, "prof.sam")],
                             capture_output=True, text=True, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp")
         out["profile_exit"] = pr.returncode
-    if not keep and workdir is None:
-        import shutil
-        shutil.rmtree(tmp, ignore_errors=True)
     return out, log
 
 
@@ -383,7 +574,17 @@ def main():
     ap.add_argument("--own", default="", help="the same settings for this repository's driver: comma-separated Params fields, e.g. 'no_multi_hits=True'")
     ap.add_argument("--rerun", action="store_true", help="run nvBowtie a second time and compare its two outputs")
     ap.add_argument("--keep", default=None, help="work in this directory and keep the files")
+    ap.add_argument("--paired", type=int, default=0, help="run the paired-end comparison instead (config 5's shape: 2 x 150 bp, --local) with this many pairs")
     a = ap.parse_args()
+    if a.paired:
+        out, log = run_paired(int(a.genome), a.paired, a.repeats, workdir=a.keep)
+        if a.log:
+            open(a.log, "w").write(log)
+        text = json.dumps(out, indent=1, default=str)
+        if a.json:
+            open(a.json, "w").write(text)
+        print(text)
+        return 0 if out.get("nvbowtie_exit") == 0 and out.get("identical") == out.get("records_ref") == out.get("records_own") == 2 * a.paired else 1
     overrides = {}
     for kv in filter(None, a.own.split(",")):
         k, v = kv.split("=")
