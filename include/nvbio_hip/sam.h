@@ -58,7 +58,7 @@ inline void put_int(std::string& s, int64_t v) { if (v < 0) { s.push_back('-'); 
 
 /// MD:Z text and the mismatch / gap-open / gap-extension counters of one MDS
 /// `stride`: the bytes the row owns.  The 16-bit length in mds[0..1] is what finish_alignment meant to write; a string longer than the row was cut
-/// there, so the walk stops at min(length, stride) and every operand is read inside it (a token cut in half ends the string).  Returns false
+/// there, so the walk stops at min(length, stride) and no operand is read outside the row (a token cut by the row's end ends the string).  Returns false
 /// when the row was too short for its string: the caller prints MD:Z:* for that record rather than half a string.
 inline bool md_string(const uint8_t* mds, const uint32_t stride, std::string& md, int32_t& mm, int32_t& gapo, int32_t& gape)      // (int32 counters, output_sam.h:83-85)
 {
@@ -70,7 +70,7 @@ inline bool md_string(const uint8_t* mds, const uint32_t stride, std::string& md
     while (i < n)
     {
         const uint32_t op = mds[i++];
-        if (i >= n) break;                                                            // an op byte without its operand: cut
+        if (i >= stride) break;                                                       // an operand would lie outside the row: cut (inside the row the walk is the reference's, the byte past the length included)
         if (op == 0u)
         {
             uint32_t run = mds[i++];
@@ -83,7 +83,7 @@ inline bool md_string(const uint8_t* mds, const uint32_t stride, std::string& md
         {
             const uint32_t l = mds[i++];
             md.push_back('^');
-            for (uint32_t k = 0; k < l && i + k < n; ++k) md.push_back(dna[std::min<uint32_t>(mds[i + k], 4u)]);
+            for (uint32_t k = 0; k < l && i + k < stride; ++k) md.push_back(dna[std::min<uint32_t>(mds[i + k], 4u)]);
             md.push_back('0');
             i += l; ++gapo; gape += int32_t(l) - 1;
         }

@@ -417,3 +417,38 @@ def test_native_sam_writer_equals_the_python_one(tmp_path):
         text = open(path).read()
         assert text == ref.header() + buf.getvalue()
     assert "\t4\t" in text or "\t68\t" in text
+
+
+def test_native_sam_writer_stays_inside_short_rows(tmp_path):
+    """A CIGAR or MD string longer than its row (cigar_len > cigar_stride, the MDS length field > mds_stride: a long read with many edits against short
+    strides) was cut at the row's end by the stage that wrote it; the writer must not walk into the next read's row (include/nvbio_hip/sam.h): the
+    CIGAR is printed up to the row's end, the MD field of a cut string is '*', and the neighbours' records are untouched."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import align_fastq as AF
+    nio.write_bns(str(tmp_path / "g"), ["chrA"], [10_000])
+    ref = AF.Reference(str(tmp_path / "g"), 10_000, "ref")
+    n, L = 3, 20
+    index = np.arange(0, (n + 1) * L, L, dtype=np.int64)
+    symbols = np.tile(np.array([0, 1, 2, 3], np.uint8), n * L // 4)
+    quals = np.full(n * L, 30, np.uint8)
+    names = ["a", "b", "c"]
+    best = np.zeros((2, n), np.uint64)
+    for i in range(n):
+        best[0, i] = ((100 + 50 * i) << 32) | (10 << 1)
+    mapq = np.full(n, 42, np.uint8)
+    cig = np.zeros((n, 4), np.uint16); clen = np.array([2, 9, 2], np.uint32)            # read b claims 9 ops in a row of 4
+    for i in range(n):
+        cig[i] = [0 | (5 << 2), 0 | (7 << 2), 0 | (3 << 2), 0 | (5 << 2)]
+    source = np.zeros((n, 2), np.uint32)
+    mds = np.zeros((n, 8), np.uint8)
+    mds[0, :4] = [4, 0, 0, 20]                                                              # "20"
+    mds[1, :8] = [44, 1, 0, 9, 1, 2, 0, 9]                                                  # claims 300 bytes in a row of 8
+    mds[2, :6] = [6, 0, 0, 12, 1, 3]                                                        # "12T"
+    path = str(tmp_path / "short_rows.sam")
+    AF.write_records_se_native(path, ref, names, symbols, index, quals, best, mapq, cig, clen, source, mds)
+    recs = [l.split("\t") for l in open(path).read().splitlines() if not l.startswith("@")]
+    assert [r[0] for r in recs] == names
+    assert recs[0][5] == "7M5M" and recs[0][-1] == "MD:Z:20"
+    assert recs[1][5] == "5M3M7M5M" and recs[1][-1] == "MD:Z:*"                           # the four ops of its own row, no more; a cut MD string is not printed
+    assert recs[2][5] == "7M5M" and recs[2][-1] == "MD:Z:12T"
