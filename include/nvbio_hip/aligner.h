@@ -676,6 +676,8 @@ private:
 
     /// whether the extension rounds hand the scorer their thresholds (NVBIO_HIP_BOUNDED_DP=1, read once; off by default)
     static bool bounded_dp() { static const bool on = [] { const char* e = getenv("NVBIO_HIP_BOUNDED_DP"); return e && atoi(e) == 1; }(); return on; }
+    /// NVBIO_HIP_TRACE_ROUNDS=1 (read once): one line per extension round on stderr -- the queue sizes the hits-per-read rule saw
+    static bool trace_rounds() { static const bool on = [] { const char* e = getenv("NVBIO_HIP_TRACE_ROUNDS"); return e && atoi(e) == 1; }(); return on; }
     bool count_jobs = false;          ///< fill Stats::dp_jobs (one host round trip per extension round; the stage clock does it too)
 
     /// the static band of banded_score_best / banded_traceback_best (score_best_inl.h:160-164)
@@ -720,7 +722,9 @@ private:
             if (queues.in_size <= SCORING_BATCH / 2 && !params.no_multi_hits)
                 n_hits_per_read = std::min(SCORING_BATCH / queues.in_size, std::min(4096u, params.select.max_ext - n_ext));
 
+            const uint32 in_before = queues.in_size;
             stats.clock.run("select", hip_stream, [&] { select(hits, state, queues, n_hits_per_read, params.select, hip_stream); });
+            if (trace_rounds()) fprintf(stderr, "round %u: n_ext %u, active in %u -> out %u, hits per read %u, hits %u\n", stats.rounds, n_ext, in_before, queues.in_size, n_hits_per_read, queues.hits_size);
             if (queues.in_size == 0) break;
             if (queues.hits_size == 0) continue;
             stats.clock.run("locate", hip_stream, [&] { fabric_bound(hip_stream, [&](void* ss) { locate(fmi, rfmi, queues, ss); }); });

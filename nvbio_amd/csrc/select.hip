@@ -19,6 +19,7 @@
 #include "fmindex_device.h"
 #include "hit_deque.h"
 #include <hipcub/hipcub.hpp>
+#include <mutex>
 #include <limits.h>
 #include <stdlib.h>
 
@@ -204,6 +205,36 @@ __device__ uint32_t randomized_select(const Tree& tree, const uint2* h, uint32_t
     return pick;
 }
 
+// ---- make() by table.  HitDequeT::make() is a comparison sort-like procedure: what it does to a row depends only on how the hits' range sizes
+// compare, never on their values.  A row whose range sizes take at most TWO distinct values -- the common case: a read's seeds are unique in the
+// genome (all sizes 1), then some of them are used up (size 0) -- is therefore one of 2^n patterns ("which hits hold the larger value"), and the
+// arrangement make() leaves is a fixed permutation per (n, pattern).  The table holds it for every n <= 16: entry (2^n - 2 + pattern) = sixteen
+// nibbles, nibble k = the slot whose hit make() moves to slot k.  Built once per device by running make() itself over every pattern (1 MB), so a
+// looked-up arrangement IS make()'s.  A selection call then replaces the ~n log n dependent LDS exchanges of the construction by one 8-byte load
+// and the moves it names (usually none).  Rows with three or more distinct sizes, or more than 16 hits, run make() as before.
+struct LocalKeys
+{
+    typedef uint32_t value_type;
+    uint32_t* p;
+    __device__ __forceinline__ uint32_t& operator[](const int i) const { return p[i]; }
+    __device__ __forceinline__ static bool before(const uint32_t f, const uint32_t s) { return (f >> 8) > (s >> 8); }
+};
+__global__ void __launch_bounds__(256)
+select_make_table_kernel(uint64_t* __restrict__ table)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= (1u << 17) - 2u) return;
+    const uint32_t n = 31u - uint32_t(__clz(int(t + 2u)));          // 2^n - 2 <= t < 2^(n+1) - 2
+    const uint32_t pattern = t - ((1u << n) - 2u);
+    uint32_t keys[16];
+    for (uint32_t i = 0; i < 16u; ++i) keys[i] = (((pattern >> i) & 1u) << 8) | i;
+    const HitDequeT<LocalKeys> d = { { keys } };
+    d.make(int(n));
+    uint64_t perm = 0;
+    for (uint32_t k = 0; k < 16u; ++k) perm |= uint64_t(k < n ? (keys[k] & 255u) : k) << (4u * k);
+    table[t] = perm;
+}
+
 // stage 1: every active read makes its picks into its own staging slots.
 // PADDED (randomized only): 0 = the tree's nodes in the read's row of global memory (wide rows), 16 / 32 = in LDS, rebuilt from the leaves
 template <bool RANDOMIZED, int PADDED>
@@ -211,7 +242,8 @@ __global__ void __launch_bounds__(256)
 select_kernel(uint32_t n_multi, const uint32_t* __restrict__ active_in, uint32_t n_active,
               uint2* __restrict__ hits, uint32_t hits_stride, uint32_t* __restrict__ counts,
               float* __restrict__ probs, uint32_t probs_stride, uint32_t* __restrict__ rseeds, const uint32_t* __restrict__ trys,
-              uint32_t* __restrict__ stage_read, uint32_t* __restrict__ stage_loc, uint32_t* __restrict__ stage_seed, uint64_t* __restrict__ key)
+              uint32_t* __restrict__ stage_read, uint32_t* __restrict__ stage_loc, uint32_t* __restrict__ stage_seed, uint64_t* __restrict__ key,
+              const uint64_t* __restrict__ make_table)
 {
     __shared__ float s_tree[(RANDOMIZED && PADDED > 0) ? (2 * PADDED - 1) * 256 : 1];
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
@@ -227,13 +259,73 @@ select_kernel(uint32_t n_multi, const uint32_t* __restrict__ active_in, uint32_t
         uint32_t* out_loc = stage_loc + uint64_t(t) * n_multi;
         uint32_t* out_seed = stage_seed + uint64_t(t) * n_multi;
         const HitDeque deque = { h };
-        // hits[ read_id ] rebuilds the heap (hit_deque.h: make()).  Nearly always that leaves the row as it is -- a valid heap only changes where a
-        // hit ties with one below it -- so, for rows that fit, the construction runs on one key per hit (range size, slot) in LDS (the tree's
-        // cells, not yet loaded) and only the hits it moved are moved in memory, cycle by cycle; in global memory it made this stage three times
-        // as long (12.5 instead of 4 ms per 10 M reads).
+        // hits[ read_id ] rebuilds the heap (hit_deque.h: make()).  For rows that fit the tree's LDS cells (not yet loaded) the construction never
+        // touches memory exchange by exchange:
+        //   * a row of <= 16 hits is read ONCE into registers (eight 16-byte loads, independent of each other);
+        //   * its arrangement is looked up (at most two distinct range sizes: select_make_table_kernel) or built by make() on one key per hit in LDS;
+        //   * the arrangement is a permutation of <= 16 slots held in one 64-bit register; the row goes through the LDS cells once (x words, then
+        //     y words) and comes back permuted, and only the slots that changed are stored -- independent stores.
+        // Round 5 moved the hits in global memory cycle by cycle -- h[j] = h[src] with the next step waiting for the store: a chain of ~n memory
+        // round trips per read, and with equal range sizes (a read whose seeds are unique) make() moves every hit at every round.  That chain, not
+        // the construction, was the stage's 12.5 ms per 10 M reads (the table alone changed nothing).  Rows of 17 .. 32 hits keep the old form.
+        // rows of <= 16 hits live in registers from here to the end of the call: hx / hy, `dirty` = the slots to store back
+        uint32_t hx[16], hy[16];
+        uint32_t dirty = 0u;
+        bool in_regs = false;
         if constexpr (PADDED > 0)
         {
-            const LdsKeys keys = { reinterpret_cast<uint32_t*>(s_tree) + threadIdx.x };
+            uint32_t* cell = reinterpret_cast<uint32_t*>(s_tree) + threadIdx.x;          // this lane's cells: cell[i * 256]
+            const LdsKeys keys = { cell };
+            if (n <= 16u && (hits_stride & 1u) == 0u)
+            {
+                in_regs = true;
+                #pragma unroll
+                for (uint32_t i = 0; i < 16u; i += 2u)
+                {
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if (i < n) v = *reinterpret_cast<const uint4*>(h + i);
+                    hx[i] = v.x; hy[i] = v.y; hx[i + 1u] = v.z; hy[i + 1u] = v.w;
+                }
+                // at most two distinct range sizes?
+                uint32_t dmin = 0xFFFFFFFFu, dmax = 0u;
+                #pragma unroll
+                for (uint32_t i = 0; i < 16u; ++i)
+                    if (i < n) { const uint32_t d = hy[i] & 0xFFFFFu; dmin = d < dmin ? d : dmin; dmax = d > dmax ? d : dmax; }
+                uint32_t pattern = 0u; bool two = make_table != nullptr;
+                #pragma unroll
+                for (uint32_t i = 0; i < 16u; ++i)
+                    if (i < n) { const uint32_t d = hy[i] & 0xFFFFFu; two = two && (d == dmin || d == dmax); pattern |= ((d == dmax && dmax != dmin) ? 1u : 0u) << i; }
+                uint64_t perm;
+                if (two) perm = make_table[((1u << n) - 2u) + pattern];
+                else
+                {
+                    #pragma unroll
+                    for (uint32_t i = 0; i < 16u; ++i) if (i < n) keys[int(i)] = ((hy[i] & 0xFFFFFu) << 8) | i;
+                    const HitDequeT<LdsKeys> kd = { keys };
+                    kd.make(int(n));
+                    perm = 0xFEDCBA9876543210ull;
+                    #pragma unroll
+                    for (uint32_t k = 0; k < 16u; ++k) if (k < n) perm = (perm & ~(15ull << (4u * k))) | (uint64_t(keys[int(k)] & 15u) << (4u * k));
+                }
+                if (perm != 0xFEDCBA9876543210ull)
+                {
+                    // slot k takes what was in slot (perm >> 4k) & 15
+                    uint32_t nx[16], ny[16];
+                    #pragma unroll
+                    for (uint32_t i = 0; i < 16u; ++i) if (i < n) cell[i * 256u] = hx[i];
+                    #pragma unroll
+                    for (uint32_t k = 0; k < 16u; ++k) nx[k] = k < n ? cell[(uint32_t(perm >> (4u * k)) & 15u) * 256u] : 0u;
+                    #pragma unroll
+                    for (uint32_t i = 0; i < 16u; ++i) if (i < n) cell[i * 256u] = hy[i];
+                    #pragma unroll
+                    for (uint32_t k = 0; k < 16u; ++k) ny[k] = k < n ? cell[(uint32_t(perm >> (4u * k)) & 15u) * 256u] : 0u;
+                    #pragma unroll
+                    for (uint32_t k = 0; k < 16u; ++k)
+                        if (k < n && (uint32_t(perm >> (4u * k)) & 15u) != k) { hx[k] = nx[k]; hy[k] = ny[k]; dirty |= 1u << k; }
+                }
+            }
+            else
+            {
             if ((hits_stride & 1u) == 0u)
                 for (uint32_t i = 0; i < n; i += 2u)
                 {
@@ -258,6 +350,7 @@ select_kernel(uint32_t n_multi, const uint32_t* __restrict__ active_in, uint32_t
                     h[j] = h[src];
                     j = src;
                 }
+            }
             }
         }
         else deque.make(int(n));
@@ -309,7 +402,53 @@ select_kernel(uint32_t n_multi, const uint32_t* __restrict__ active_in, uint32_t
                 else
                     for (uint32_t i = 0; i < n; ++i) cells[i] = leaves[i];
                 tree.setup();
-                picks(tree);
+                if (!in_regs) picks(tree);
+                else
+                {
+                    // the same picks on the row in registers: a hit is looked up / popped by a 16-way select instead of a load of h[id] -- with several
+                    // picks per read (the multi-hit rounds) those loads missed L2 again and again (128 fabric reads per read at 20 picks per read,
+                    // profiles/r06/pmc_select.txt); the LCG state stays in a register; the slots that changed are stored once, at the end
+                    auto y_at = [&](const uint32_t id) { uint32_t r = 0u;
+                        #pragma unroll
+                        for (uint32_t i = 0; i < 16u; ++i) r = (i == id) ? hy[i] : r;
+                        return r; };
+                    auto x_at = [&](const uint32_t id) { uint32_t r = 0u;
+                        #pragma unroll
+                        for (uint32_t i = 0; i < 16u; ++i) r = (i == id) ? hx[i] : r;
+                        return r; };
+                    uint32_t sd = rseeds[read_id];
+                    const uint32_t sd_in = sd;
+                    bool drew = false;
+                    for (uint32_t i = 0; i < n_multi; ++i)
+                    {
+                        if (tree.sum() <= 0.0f) break;
+                        if (top_flag && (hy[0] & 0xFFFFFu) == 0u) top_flag = 0u;
+                        uint32_t id = 0u;
+                        if (!top_flag)
+                        {
+                            bool found = false;                                     // randomized_select
+                            for (uint32_t tr = 0; tr < 10u && !found; ++tr) {
+                                sd = 1664525u * sd + 1013904223u;
+                                const float rf = __fdiv_rn(__uint2float_rn(sd), 4294967296.0f);
+                                const uint32_t cand = tree.sample(rf);
+                                if ((y_at(cand) & 0xFFFFFu) != 0u) { id = cand; found = true; }
+                            }
+                            drew = true;
+                        }
+                        const uint32_t y = y_at(id);
+                        if ((y & 0xFFFFFu) == 0u) { if (n_multi > 1u) continue; else break; }
+                        const uint32_t x = x_at(id);
+                        const uint32_t y1 = (y & ~0xFFFFFu) | ((y - 1u) & 0xFFFFFu);            // pop_front
+                        #pragma unroll
+                        for (uint32_t k = 0; k < 16u; ++k) if (k == id) { hx[k] = x + 1u; hy[k] = y1; }
+                        dirty |= 1u << id;
+                        out_loc[n_sel] = x;
+                        if ((y1 & 0xFFFFFu) == 0u) { tree.set(id, 0.0f); leaves[id] = 0.0f; }
+                        out_seed[n_sel] = packed_seed_of(make_uint2(x + 1u, y1), top_flag);
+                        ++n_sel;
+                    }
+                    if (drew || sd != sd_in) rseeds[read_id] = sd;
+                }
             }
             else
             {
@@ -318,6 +457,11 @@ select_kernel(uint32_t n_multi, const uint32_t* __restrict__ active_in, uint32_t
                 tree.setup();                                                    // the row's internal nodes are scratch: rebuilt on entry
                 picks(tree);
             }
+        }
+        if (in_regs && dirty != 0u)
+        {
+            #pragma unroll
+            for (uint32_t k = 0; k < 16u; ++k) if ((dirty >> k) & 1u) h[k] = make_uint2(hx[k], hy[k]);
         }
     }
     stage_read[t] = read_id | (top_flag << 31);
@@ -650,6 +794,28 @@ NVB_API uint64_t nvbio_hip_select_temp_bytes(uint32_t n_active, uint32_t n_multi
     return 2u * align256(n * m * 4u) + align256(n * 4u) + 2u * align256((n + 1u) * 8u) + align256(select_scan_bytes(n_active)) + 256u;
 }
 
+namespace nvb {
+// the table of make() arrangements of the calling thread's device, built on first use (1 MB; never freed)
+static const uint64_t* select_make_table(hipStream_t s)
+{
+    static std::mutex mtx;
+    static uint64_t* tables[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mtx);
+    if (!tables[dev])
+    {
+        uint64_t* t = nullptr;
+        const uint32_t entries = (1u << 17) - 2u;
+        if (hipMalloc(reinterpret_cast<void**>(&t), uint64_t(entries) * 8u) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        hipLaunchKernelGGL(select_make_table_kernel, dim3((entries + 255u) / 256u), dim3(256), 0, s, t);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(t); return nullptr; }   // every stream may use it from here on
+        tables[dev] = t;
+    }
+    return tables[dev];
+}
+} // namespace nvb
+
 NVB_API int nvbio_hip_select(int32_t randomized, uint32_t n_multi, const uint32_t* active_in, uint32_t n_active,
                              uint64_t* hits, uint32_t hits_stride, uint32_t* hit_counts,
                              float* probs, uint32_t probs_stride, uint32_t* rseeds, const uint32_t* trys,
@@ -676,6 +842,8 @@ NVB_API int nvbio_hip_select(int32_t randomized, uint32_t n_multi, const uint32_
     // sits near that floor; the four-leaves-per-lane form (NVBIO_HIP_SELECT_LANES=4, same results) measured slower on config 4
     // (profiles/r03/select_coop.txt).
     const bool quad = randomized && hits_stride <= 32u && test_switch(SW_SELECT_LANES) == 4;
+    // make() by table (see select_make_table_kernel): NVBIO_HIP_SELECT_LANES=2 runs without it (same results; the parity suite covers both)
+    const uint64_t* table = (randomized && hits_stride <= 32u && test_switch(SW_SELECT_LANES) != 2) ? select_make_table(s) : nullptr;
     if (quad && hits_stride <= 16u)
         hipLaunchKernelGGL(select_rand_quad_kernel<4>, grid_for((uint64_t(n) + 1u) * 4u), dim3(256), 0, s, n_multi, active_in, n_active, reinterpret_cast<uint2*>(hits), hits_stride,
                            hit_counts, probs, probs_stride, rseeds, trys, stage_read, stage_loc, stage_seed, key);
@@ -684,16 +852,16 @@ NVB_API int nvbio_hip_select(int32_t randomized, uint32_t n_multi, const uint32_
                            hit_counts, probs, probs_stride, rseeds, trys, stage_read, stage_loc, stage_seed, key);
     else if (randomized && hits_stride <= 16u)
         hipLaunchKernelGGL((select_kernel<true, 16>), grid_for(n + 1u), dim3(256), 0, s, n_multi, active_in, n_active, reinterpret_cast<uint2*>(hits), hits_stride,
-                           hit_counts, probs, probs_stride, rseeds, trys, stage_read, stage_loc, stage_seed, key);
+                           hit_counts, probs, probs_stride, rseeds, trys, stage_read, stage_loc, stage_seed, key, table);
     else if (randomized && hits_stride <= 32u)
         hipLaunchKernelGGL((select_kernel<true, 32>), grid_for(n + 1u), dim3(256), 0, s, n_multi, active_in, n_active, reinterpret_cast<uint2*>(hits), hits_stride,
-                           hit_counts, probs, probs_stride, rseeds, trys, stage_read, stage_loc, stage_seed, key);
+                           hit_counts, probs, probs_stride, rseeds, trys, stage_read, stage_loc, stage_seed, key, table);
     else if (randomized)
         hipLaunchKernelGGL((select_kernel<true, 0>), grid_for(n + 1u), dim3(256), 0, s, n_multi, active_in, n_active, reinterpret_cast<uint2*>(hits), hits_stride,
-                           hit_counts, probs, probs_stride, rseeds, trys, stage_read, stage_loc, stage_seed, key);
+                           hit_counts, probs, probs_stride, rseeds, trys, stage_read, stage_loc, stage_seed, key, nullptr);
     else
         hipLaunchKernelGGL((select_kernel<false, 0>), grid_for(n + 1u), dim3(256), 0, s, n_multi, active_in, n_active, reinterpret_cast<uint2*>(hits), hits_stride,
-                           hit_counts, probs, probs_stride, rseeds, trys, stage_read, stage_loc, stage_seed, key);
+                           hit_counts, probs, probs_stride, rseeds, trys, stage_read, stage_loc, stage_seed, key, nullptr);
     if (hipError_t e = hipcub::DeviceScan::ExclusiveSum(p, scan_bytes, key, off, int(n_active) + 1, s)) return e;
     hipLaunchKernelGGL(select_compact_kernel, grid_for(n + 1u), dim3(256), 0, s, n_multi, n_active, key, off, stage_read, stage_loc, stage_seed,
                        active_out, hit_begin, hit_read_id, hit_loc, hit_seed, out_sizes);

@@ -78,14 +78,44 @@ def test_select_rounds_over_wide_ranges_match_oracle(cuda, n_multi, stride):
     _select_rounds(cuda, True, n_multi, 0, stride, wide=True, max_rounds=60)
 
 
-@pytest.mark.parametrize("lanes", ["1", "4"])
+@pytest.mark.parametrize("lanes", ["1", "2", "4"])
 @pytest.mark.parametrize("n_multi", [1, 4])
 @pytest.mark.parametrize("stride", [8, 16, 32])
 def test_select_lane_forms_match_oracle(cuda, monkeypatch, lanes, n_multi, stride):
     """NVBIO_HIP_SELECT_LANES=1: select_init and select with one lane per read; =4: the randomized select with a read's row and tree
-    in 4 / 8 lanes, four leaves each.  Same picks and state as the oracle either way."""
+    in 4 / 8 lanes, four leaves each; =2: one lane per read WITHOUT the table of make() arrangements (every row rebuilds its heap exchange by
+    exchange; the default looks the arrangement of rows with at most two distinct range sizes up).  Same picks and state as the oracle every way."""
     nvb.set_test_switch("NVBIO_HIP_SELECT_LANES", lanes)
     _select_rounds(cuda, True, n_multi, 1, stride)
+
+
+def _two_size_deques(rng, n_reads, stride, sizes):
+    """deques as the mappers push them, every hit's range size drawn from `sizes` (one or two values): the rows the make() table serves"""
+    push, _, _ = O.hit_deque_ops()
+    hits = np.zeros((n_reads, stride), np.uint64)
+    counts = np.zeros(n_reads, np.uint32)
+    for r in range(n_reads):
+        k = int(rng.integers(0, min(stride, 16) + 1)) if r % 9 else 0
+        for j in range(k):
+            size = int(sizes[int(rng.integers(0, len(sizes)))])
+            begin = int(rng.integers(0, 1 << 30))
+            flags = (int(rng.integers(0, 1 << 10)) << 20) | (int(rng.integers(0, 4)) << 30)
+            hits[r, j] = np.uint64(((size | flags) << 32) | begin)
+            push(hits[r], j + 1)
+        counts[r] = k
+    return hits, counts
+
+
+@pytest.mark.parametrize("sizes", [(1,), (1, 2), (1, 3), (2, 900_000), (7, 7)], ids=["unique_seeds", "one_two", "one_three", "far_apart", "all_equal"])
+@pytest.mark.parametrize("n_multi", [1, 4])
+@pytest.mark.parametrize("stride", [16, 32])
+def test_select_rounds_on_rows_the_make_table_serves(cuda, sizes, n_multi, stride):
+    """Rows whose range sizes take one or two values -- a read's seeds unique in the genome, then some used up -- have their heap arrangement looked up
+    (select_make_table_kernel) instead of rebuilt exchange by exchange: selection rounds to exhaustion against the oracle's replay of the
+    reference's interval heap, every round's picks and every hit row slot for slot (rows drift out of the table's reach as ranges shrink to a
+    third value and back in as they run out; top_seed on, so the first pick is the row's slot 0)."""
+    _select_rounds(cuda, True, n_multi, 1, stride, two_sizes=sizes)
+    _select_rounds(cuda, True, n_multi, 0, stride, two_sizes=sizes)
 
 
 def _leaves_match(g_probs, e_probs, counts):
@@ -115,10 +145,13 @@ def _wide_deques(rng, n_reads, stride):
     return hits, counts
 
 
-def _select_rounds(cuda, randomized, n_multi, top_seed, stride, wide=False, max_rounds=2000):
+def _select_rounds(cuda, randomized, n_multi, top_seed, stride, wide=False, max_rounds=2000, two_sizes=None):
     rng = np.random.default_rng(40 + n_multi + 2 * top_seed + 100 * stride)
     n = 3000
-    hits, counts = _wide_deques(rng, n, stride) if wide else _random_deques(rng, n, stride, max_size=min(stride, 16))
+    if two_sizes is not None:
+        hits, counts = _two_size_deques(rng, n, stride, two_sizes)
+    else:
+        hits, counts = _wide_deques(rng, n, stride) if wide else _random_deques(rng, n, stride, max_size=min(stride, 16))
     names = ["r%d/%d" % (i, i * 7919 % 13) for i in range(n)]
     arena, idx = O.pack_names(names)
     e_probs, e_trys, e_rseeds = O.select_init(hits, counts, arena, idx, 15, randomized, top_seed)
@@ -147,7 +180,7 @@ def _select_rounds(cuda, randomized, n_multi, top_seed, stride, wide=False, max_
         if randomized:
             assert (u(st.rseeds) == e_rseeds).all() and _leaves_match(st.probs, e_probs, counts)
         rounds += 1; total += e_loc.size
-        if wide and rounds >= max_rounds:
+        if (wide or two_sizes is not None) and rounds >= max_rounds:
             break
         assert rounds < 2000
     assert rounds > 3 and total > n
