@@ -268,60 +268,65 @@ select_kernel(uint32_t n_multi, const uint32_t* __restrict__ active_in, uint32_t
         // Round 5 moved the hits in global memory cycle by cycle -- h[j] = h[src] with the next step waiting for the store: a chain of ~n memory
         // round trips per read, and with equal range sizes (a read whose seeds are unique) make() moves every hit at every round.  That chain, not
         // the construction, was the stage's 12.5 ms per 10 M reads (the table alone changed nothing).  Rows of 17 .. 32 hits keep the old form.
-        // rows of <= 16 hits live in registers from here to the end of the call: hx / hy, `dirty` = the slots to store back
-        uint32_t hx[16], hy[16];
+        // rows of <= RMAX = 16 hits live in registers from here to the end of the call: hx / hy, `dirty` = the slots to store back
+        constexpr uint32_t RMAX = 16u;       // (32 registers of row per lane; at 32 hits per row the 32-way selects cost more than the loads they replace: measured, profiles/r06/README.md)
+        uint32_t hx[RMAX], hy[RMAX];
         uint32_t dirty = 0u;
         bool in_regs = false;
         if constexpr (PADDED > 0)
         {
             uint32_t* cell = reinterpret_cast<uint32_t*>(s_tree) + threadIdx.x;          // this lane's cells: cell[i * 256]
             const LdsKeys keys = { cell };
-            if (n <= 16u && (hits_stride & 1u) == 0u)
+            if (n <= RMAX && (hits_stride & 1u) == 0u)
             {
                 in_regs = true;
                 #pragma unroll
-                for (uint32_t i = 0; i < 16u; i += 2u)
+                for (uint32_t i = 0; i < RMAX; i += 2u)
                 {
                     uint4 v = make_uint4(0u, 0u, 0u, 0u);
                     if (i < n) v = *reinterpret_cast<const uint4*>(h + i);
                     hx[i] = v.x; hy[i] = v.y; hx[i + 1u] = v.z; hy[i + 1u] = v.w;
                 }
-                // at most two distinct range sizes?
+                // at most two distinct range sizes (and a row the table covers)?
                 uint32_t dmin = 0xFFFFFFFFu, dmax = 0u;
                 #pragma unroll
-                for (uint32_t i = 0; i < 16u; ++i)
+                for (uint32_t i = 0; i < RMAX; ++i)
                     if (i < n) { const uint32_t d = hy[i] & 0xFFFFFu; dmin = d < dmin ? d : dmin; dmax = d > dmax ? d : dmax; }
-                uint32_t pattern = 0u; bool two = make_table != nullptr;
+                uint32_t pattern = 0u; bool two = make_table != nullptr && n <= 16u;
                 #pragma unroll
-                for (uint32_t i = 0; i < 16u; ++i)
+                for (uint32_t i = 0; i < 16u && i < RMAX; ++i)
                     if (i < n) { const uint32_t d = hy[i] & 0xFFFFFu; two = two && (d == dmin || d == dmax); pattern |= ((d == dmax && dmax != dmin) ? 1u : 0u) << i; }
-                uint64_t perm;
-                if (two) perm = make_table[((1u << n) - 2u) + pattern];
+                uint32_t src[RMAX];                                                  // slot k takes what was in slot src[k]
+                bool moved = false;
+                if (two)
+                {
+                    const uint64_t perm = make_table[((1u << n) - 2u) + pattern];
+                    #pragma unroll
+                    for (uint32_t k = 0; k < RMAX; ++k) { src[k] = (k < 16u && k < n) ? (uint32_t(perm >> (4u * (k & 15u))) & 15u) : k; moved = moved || src[k] != k; }
+                }
                 else
                 {
                     #pragma unroll
-                    for (uint32_t i = 0; i < 16u; ++i) if (i < n) keys[int(i)] = ((hy[i] & 0xFFFFFu) << 8) | i;
+                    for (uint32_t i = 0; i < RMAX; ++i) if (i < n) keys[int(i)] = ((hy[i] & 0xFFFFFu) << 8) | i;
                     const HitDequeT<LdsKeys> kd = { keys };
                     kd.make(int(n));
-                    perm = 0xFEDCBA9876543210ull;
                     #pragma unroll
-                    for (uint32_t k = 0; k < 16u; ++k) if (k < n) perm = (perm & ~(15ull << (4u * k))) | (uint64_t(keys[int(k)] & 15u) << (4u * k));
+                    for (uint32_t k = 0; k < RMAX; ++k) { src[k] = k < n ? (keys[int(k)] & 255u) : k; moved = moved || src[k] != k; }
                 }
-                if (perm != 0xFEDCBA9876543210ull)
+                if (moved)
                 {
-                    // slot k takes what was in slot (perm >> 4k) & 15
-                    uint32_t nx[16], ny[16];
+                    uint32_t nx[RMAX], ny[RMAX];
                     #pragma unroll
-                    for (uint32_t i = 0; i < 16u; ++i) if (i < n) cell[i * 256u] = hx[i];
+                    for (uint32_t i = 0; i < RMAX; ++i) if (i < n) cell[i * 256u] = hx[i];
                     #pragma unroll
-                    for (uint32_t k = 0; k < 16u; ++k) nx[k] = k < n ? cell[(uint32_t(perm >> (4u * k)) & 15u) * 256u] : 0u;
+                    for (uint32_t k = 0; k < RMAX; ++k) nx[k] = k < n ? cell[src[k] * 256u] : 0u;
                     #pragma unroll
-                    for (uint32_t i = 0; i < 16u; ++i) if (i < n) cell[i * 256u] = hy[i];
+                    for (uint32_t i = 0; i < RMAX; ++i) if (i < n) cell[i * 256u] = hy[i];
                     #pragma unroll
-                    for (uint32_t k = 0; k < 16u; ++k) ny[k] = k < n ? cell[(uint32_t(perm >> (4u * k)) & 15u) * 256u] : 0u;
+                    for (uint32_t k = 0; k < RMAX; ++k) ny[k] = k < n ? cell[src[k] * 256u] : 0u;
                     #pragma unroll
-                    for (uint32_t k = 0; k < 16u; ++k)
-                        if (k < n && (uint32_t(perm >> (4u * k)) & 15u) != k) { hx[k] = nx[k]; hy[k] = ny[k]; dirty |= 1u << k; }
+                    for (uint32_t k = 0; k < RMAX; ++k)
+                        if (k < n && src[k] != k) { hx[k] = nx[k]; hy[k] = ny[k]; dirty |= 1u << k; }
                 }
             }
             else
@@ -405,16 +410,16 @@ select_kernel(uint32_t n_multi, const uint32_t* __restrict__ active_in, uint32_t
                 if (!in_regs) picks(tree);
                 else
                 {
-                    // the same picks on the row in registers: a hit is looked up / popped by a 16-way select instead of a load of h[id] -- with several
+                    // the same picks on the row in registers: a hit is looked up / popped by an RMAX-way select instead of a load of h[id] -- with several
                     // picks per read (the multi-hit rounds) those loads missed L2 again and again (128 fabric reads per read at 20 picks per read,
                     // profiles/r06/pmc_select.txt); the LCG state stays in a register; the slots that changed are stored once, at the end
                     auto y_at = [&](const uint32_t id) { uint32_t r = 0u;
                         #pragma unroll
-                        for (uint32_t i = 0; i < 16u; ++i) r = (i == id) ? hy[i] : r;
+                        for (uint32_t i = 0; i < RMAX; ++i) r = (i == id) ? hy[i] : r;
                         return r; };
                     auto x_at = [&](const uint32_t id) { uint32_t r = 0u;
                         #pragma unroll
-                        for (uint32_t i = 0; i < 16u; ++i) r = (i == id) ? hx[i] : r;
+                        for (uint32_t i = 0; i < RMAX; ++i) r = (i == id) ? hx[i] : r;
                         return r; };
                     uint32_t sd = rseeds[read_id];
                     const uint32_t sd_in = sd;
@@ -440,7 +445,7 @@ select_kernel(uint32_t n_multi, const uint32_t* __restrict__ active_in, uint32_t
                         const uint32_t x = x_at(id);
                         const uint32_t y1 = (y & ~0xFFFFFu) | ((y - 1u) & 0xFFFFFu);            // pop_front
                         #pragma unroll
-                        for (uint32_t k = 0; k < 16u; ++k) if (k == id) { hx[k] = x + 1u; hy[k] = y1; }
+                        for (uint32_t k = 0; k < RMAX; ++k) if (k == id) { hx[k] = x + 1u; hy[k] = y1; }
                         dirty |= 1u << id;
                         out_loc[n_sel] = x;
                         if ((y1 & 0xFFFFFu) == 0u) { tree.set(id, 0.0f); leaves[id] = 0.0f; }
@@ -461,7 +466,7 @@ select_kernel(uint32_t n_multi, const uint32_t* __restrict__ active_in, uint32_t
         if (in_regs && dirty != 0u)
         {
             #pragma unroll
-            for (uint32_t k = 0; k < 16u; ++k) if ((dirty >> k) & 1u) h[k] = make_uint2(hx[k], hy[k]);
+            for (uint32_t k = 0; k < RMAX; ++k) if ((dirty >> k) & 1u) h[k] = make_uint2(hx[k], hy[k]);
         }
     }
     stage_read[t] = read_id | (top_flag << 31);
