@@ -175,6 +175,22 @@ int nvbio_hip_banded_gotoh_score_qual_views(
     uint32_t max_pattern_len, uint32_t max_text_len,
     uint32_t n, int32_t* out_score, uint32_t* out_sink, void* stream);
 
+/* The same scorer with ONE WAVE PER JOB (nvbio_amd/csrc/banded_gotoh_wave.hip): lane j of a wave owns band cell j and the wave sweeps the
+ * anti-diagonals 2 i + j = w -- 2 M + BAND steps instead of M * BAND cells in sequence.  For batches too small to fill the chip (a few
+ * thousand jobs: nvBowtie's extension rounds after the first), where the lane-per-job kernel takes as long as one job's cells in sequence
+ * whatever the batch size.  Same results bit for bit.  Job k (k < n, or < *n_on_device when given) is job_index[k] of the string sets
+ * (job_index == NULL: k itself) and writes out_score / out_sink at that index -- a list of live jobs run in place -- or, with out_index, at
+ * out_index[that index].  gate (device, optional): the launch does nothing unless *gate <= gate_limit -- the lane-per-job entry below takes the same
+ * pair and runs when *gate > gate_limit, so a driver queues both and the device picks the form that suits the batch, with no host round trip.
+ * Patterns up to 512 symbols (hipErrorNotSupported beyond; max_pattern_len announces the longest of a ragged set); no pattern views. */
+int nvbio_hip_banded_gotoh_score_qual_wave(
+    const nvbio_hip_gotoh_qual_scheme* scheme, int32_t type, uint32_t band_len,
+    const nvbio_hip_string_set* patterns, const uint8_t* quals /* nullable: mismatch[0] throughout */, uint64_t n_quals,
+    const nvbio_hip_string_set* texts, uint32_t max_pattern_len,
+    uint32_t n, const uint32_t* n_on_device /* nullable */, const uint32_t* job_index /* nullable */, const uint32_t* out_index /* nullable */,
+    const uint32_t* gate /* nullable */, uint32_t gate_limit,
+    int32_t* out_score, uint32_t* out_sink, void* stream);
+
 /* The same scorer with a threshold per job -- the reference's `min_score` argument of banded_alignment_score (alignment_inl.h; its windowed
  * form gives up on a job once max(H) < min_score + remaining_rows * match, gotoh_banded_inl.h:622-634), which nvBowtie's scoring stage sets to
  * the read's second-best score (score_best_inl.h:113-116) and whose reduction only asks whether a score is ABOVE that (reduce_inl.h:111-135).
@@ -184,13 +200,15 @@ int nvbio_hip_banded_gotoh_score_qual_views(
  * a lane whose job is given up or done takes the next (nvbio_amd/csrc/banded_gotoh_bounded.h).  n_on_device (optional, device): the number
  * of jobs, read by the kernel -- `n` is then only an upper bound (array capacity), and the host need not know the count.  out_index (optional,
  * device): job i's results are written at out_score[out_index[i]] / out_sink[out_index[i]] -- a compacted batch of jobs (nvbio_hip_score_best_setup's
- * job_hit) writing straight back at its hits. */
+ * job_hit) writing straight back at its hits.  gate / gate_limit (min_score == NULL only): the launch does nothing unless *gate > gate_limit (see
+ * nvbio_hip_banded_gotoh_score_qual_wave). */
 int nvbio_hip_banded_gotoh_score_qual_bounded(
     const nvbio_hip_gotoh_qual_scheme* scheme, int32_t type, uint32_t band_len,
     const nvbio_hip_string_set* patterns, const uint8_t* quals, uint64_t n_quals, const uint8_t* pattern_flags,
     const nvbio_hip_string_set* texts,
     uint32_t max_pattern_len, uint32_t max_text_len,
     uint32_t n, const uint32_t* n_on_device, const int32_t* min_score, uint32_t* work_counter, const uint32_t* out_index,
+    const uint32_t* gate /* nullable; with min_score == NULL only */, uint32_t gate_limit,
     int32_t* out_score, uint32_t* out_sink, void* stream);
 
 /* Batched banded Gotoh traceback.  Replaces
@@ -323,6 +341,18 @@ int nvbio_hip_alignment_score_qual(
     const nvbio_hip_string_set* patterns, const uint8_t* quals, uint64_t n_quals, const nvbio_hip_string_set* texts,
     uint32_t max_pattern_len, uint32_t max_text_len, const int32_t* min_score /* device, nullable */,
     uint32_t n, int32_t* out_score, uint32_t* out_sink, uint8_t* out_ok /* nullable */, void* stream);
+
+/* ... with job control, for batches whose size only the device knows.  wave_form = 0: the same dispatch, run only when *gate > gate_limit
+ * (gate == NULL: always).  wave_form = 1: ONE job per wave (64 lanes x ceil(M / 64) rows: the shortest sweep a job can have) over a list --
+ * entry k < *n_on_device is job job_index[k] of the arrays and writes its outputs there -- run only when *gate <= gate_limit.  A driver queues
+ * both with the same gate (the count of live jobs): many jobs take the throughput kernels, a few take the low-latency form, and the host never
+ * waits for the count.  16-bit sweep only (801 otherwise). */
+int nvbio_hip_alignment_score_qual_jobs(
+    const nvbio_hip_gotoh_qual_scheme* scheme /* host */, int32_t algorithm, int32_t type,
+    const nvbio_hip_string_set* patterns, const uint8_t* quals, uint64_t n_quals, const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len, const int32_t* min_score /* device, nullable */,
+    uint32_t n, const uint32_t* n_on_device, const uint32_t* job_index, const uint32_t* gate, uint32_t gate_limit, int32_t wave_form,
+    int32_t* out_score, uint32_t* out_sink, uint8_t* out_ok /* nullable */, void* stream);
 
 /* nvbio::fm_index<rank_dictionary<2,64,PackedStream<.,uint8,2,true>,.,.>, SSA_index_multiple_context<SA_INT>, const uint32*>
  * (nvbio/fmindex/fmindex.h:341-387) in the production interleaved layout
@@ -658,6 +688,24 @@ int nvbio_hip_score_reduce_paired_best_approx(uint32_t n_active, const uint32_t*
     const uint32_t* read_len /* nullable */, uint32_t fixed_read_len, uint32_t anchor, int32_t pe_policy, int32_t pe_unpaired, int32_t score_limit,
     uint64_t* best_alignments, uint64_t* best_alignments_o, uint32_t best_stride,
     uint32_t* trys, uint32_t* hit_counts, uint32_t n_ext, uint32_t min_ext, uint32_t max_ext, uint32_t max_effort, void* stream);
+/* The anchor memo (optional, a pure saving).  The anchor's banded DP is a pure function of (pair, which mate, strand, window); the reference's skip test
+ * (aligner_best_approx_paired.h: BestAnchorScoreStream::init_context compares a hit's position with the recorded alignments' window begins) almost
+ * never fires, so every seed of a read that points at the placement the read already tried pays the DP again and absorbs the identical score.
+ * memo: 6 words per pair, zero-initialised by the caller, holding the last job {window begin, strand, mate} and its raw score and sink.
+ *   anchor_memo_mark (after anchor_score_setup, before the DP): text_len_out[i] = text_len[i], or 0 for a hit whose job equals the pair's entry
+ *     (from_memo[i] = 1) or the job of the hit before it in this round (from_memo[i] = 2): the scorer's lane returns at once on an empty text.
+ *     text_len_out must not alias text_len (the update reads the set-up lengths).  live_count / live_idx (optional): the hits left with a window,
+ *     counted and listed on the device -- the job_index / gate of nvbio_hip_banded_gotoh_score_qual_wave for rounds that hold only a few.
+ *   anchor_score_finish_memo: nvbio_hip_anchor_score_finish, a marked hit taking its raw score and sink from the entry / the hit it repeats.
+ *   anchor_memo_update (after the finish): per active read, the last hit of the round that had a window becomes the pair's entry.
+ * Every output equals what re-running the DP gives. */
+int nvbio_hip_anchor_memo_mark(uint32_t n_hits, const uint32_t* hit_read_id, const uint32_t* hit_seed, const uint64_t* text_begin, const uint32_t* text_len,
+    uint32_t anchor, const uint32_t* memo, uint8_t* from_memo, uint32_t* text_len_out,
+    uint32_t* live_count /* nullable; device, zeroed by the call */, uint32_t* live_idx /* nullable with it: the hits that still need their DP */, void* stream);
+int nvbio_hip_anchor_score_finish_memo(uint32_t n_hits, const int32_t* raw_score, const uint32_t* raw_sink, const uint64_t* text_begin, const int32_t* min_score,
+    int32_t worst_score, const uint8_t* from_memo, const uint32_t* hit_read_id, const uint32_t* memo, int32_t* hit_score, uint32_t* hit_sink, void* stream);
+int nvbio_hip_anchor_memo_update(uint32_t n_active, const uint32_t* active_reads, const uint64_t* hit_begin, const uint32_t* hit_read_id, const uint32_t* hit_seed,
+    const uint64_t* text_begin, const uint32_t* text_len_setup, const uint8_t* from_memo, const int32_t* raw_score, const uint32_t* raw_sink, uint32_t anchor, uint32_t* memo, void* stream);
 /* The opposite-mate memo (optional, a pure saving).  The opposite mate's DP is a pure function of (pair, opposite strand, window,
  * threshold); the reference re-runs it for every anchor hit landing on a placement it already tried and absorbs the identical result
  * (in the second anchor pass that is every seed of every read).  memo: 6 words per pair, zero-initialised by the caller, holding the
@@ -667,6 +715,9 @@ int nvbio_hip_score_reduce_paired_best_approx(uint32_t n_active, const uint32_t*
  *     hits alone (with the valid_idx form, pass only the hits with valid == 1).
  *   opposite_memo_update (after opposite_score_finish): per active read, the last hit with valid == 1 becomes the pair's entry.
  * Every output equals what re-running the DP gives; hits of one pair in the SAME round are not matched against each other. */
+/* idx[0 .. *count) = the indices i < n with flags[i] == value (in no particular order); count is zeroed by the call.  The list of jobs a round
+ * still has to score, for the job_index forms of the scorers. */
+int nvbio_hip_list_flagged(uint32_t n, const uint8_t* flags, uint32_t value, uint32_t* count, uint32_t* idx, void* stream);
 int nvbio_hip_opposite_memo_lookup(uint32_t n_hits, const uint32_t* hit_read_id, uint8_t* valid, const uint8_t* read_rc, const uint32_t* genome_begin,
     const uint32_t* genome_end, const int32_t* min_score, uint32_t anchor, const uint32_t* memo, int32_t worst_score,
     int32_t* opposite_score, int32_t* opposite_score2, uint32_t* opposite_loc, uint32_t* opposite_sink, uint32_t* opposite_sink2,

@@ -488,6 +488,10 @@ private:
         const nvbio_hip_pe_params pp = { pe.pe_policy, int32(pe.min_frag_len), int32(pe.max_frag_len), pe.pe_overlap ? 1 : 0, worst_score, 0u, genome_len };
         hip::device_vector<uint32> memo(size_t(count) * 6u);                  // the opposite-mate memo, empty
         hip_check(nvbio_hip_memset(memo.data(), 0, uint64(count) * 24u, hip_stream), "nvbio_hip_memset");
+        hip::device_vector<uint32> a_memo(size_t(count) * 6u);                // the anchor memo, empty (nvbio_hip.h: an anchor DP already run is not run again)
+        hip_check(nvbio_hip_memset(a_memo.data(), 0, uint64(count) * 24u, hip_stream), "nvbio_hip_memset");
+        hip::device_vector<uint8>  a_from_memo(max_hits_per_round);
+        hip::device_vector<uint32> a_txt_len(max_hits_per_round), a_live_idx(max_hits_per_round), a_live_count(1);
 
         for (uint32 anchor = 0; anchor < 2; ++anchor)
         {
@@ -533,16 +537,29 @@ private:
                     hip_check(nvbio_hip_anchor_score_setup(nh, queues.hit_read_id.data(), queues.hit_loc.data(), hit_seed, nullptr, nullptr, nullptr, L, L, a_reads.rc_offset,
                                                            band_len, genome_len, best, best_o, BATCH_SIZE, sc.match, min_score_table.data(), worst_score, anchor,
                                                            pat_begin.data(), nullptr, txt_begin.data(), txt_len.data(), min_score.data(), hip_stream), "nvbio_hip_anchor_score_setup");
+                    hip_check(nvbio_hip_anchor_memo_mark(nh, queues.hit_read_id.data(), hit_seed, txt_begin.data(), txt_len.data(), anchor, a_memo.data(), a_from_memo.data(),
+                                                         a_txt_len.data(), a_live_count.data(), a_live_idx.data(), hip_stream), "nvbio_hip_anchor_memo_mark");
                     {
+                        // the hits left with a window: one lane per job over all hits when there are many (the answered ones return at once), one wave per
+                        // job over their list when there are few -- both queued, the device runs the one the count calls for
                         const PackedStringSetView<4, true> patterns(nh, a_reads.fw_rc_words, a_reads.fw_rc_n_words, pat_begin.data(), nullptr, L);
-                        const PackedStringSetView<2, true> texts(nh, genome_words, genome_n_words, txt_begin.data(), txt_len.data(), 0u);
-                        const aln::BestSinkArrays sink_arrays = { raw_score.data(), sinks.data() };
-                        dispatch_band(band_len, [&](auto band) {
-                            aln::batch_banded_alignment_score<decltype(band)::value>(aligner, patterns, a_reads.quals, a_reads.n_quals, texts, sink_arrays, L, L + band_len, hip_stream);
-                        });
+                        const PackedStringSetView<2, true> texts(nh, genome_words, genome_n_words, txt_begin.data(), a_txt_len.data(), 0u);
+                        const nvbio_hip_string_set ap = patterns.abi(), at = texts.abi();
+                        const uint32 wave_up_to = L <= 512u ? wave_form_up_to() : 0u;
+                        const uint32 bl = band_len < 4 ? 3u : band_len < 8 ? 7u : band_len < 16 ? 15u : 31u;
+                        hip_check(nvbio_hip_banded_gotoh_score_qual_bounded(&sc, int32(TYPE), bl, &ap, a_reads.quals, a_reads.n_quals, nullptr, &at, L, L + band_len, nh, nullptr, nullptr,
+                                                                            nullptr, nullptr, wave_up_to ? a_live_count.data() : nullptr, wave_up_to, raw_score.data(), sinks.data(), hip_stream),
+                                  "nvbio_hip_banded_gotoh_score_qual_bounded");
+                        if (wave_up_to)
+                            hip_check(nvbio_hip_banded_gotoh_score_qual_wave(&sc, int32(TYPE), bl, &ap, a_reads.quals, a_reads.n_quals, &at, L, std::min(nh, wave_up_to), a_live_count.data(),
+                                                                             a_live_idx.data(), nullptr, a_live_count.data(), wave_up_to, raw_score.data(), sinks.data(), hip_stream),
+                                      "nvbio_hip_banded_gotoh_score_qual_wave");
                     }
-                    hip_check(nvbio_hip_anchor_score_finish(nh, raw_score.data(), sinks.data(), txt_begin.data(), min_score.data(), worst_score, hit_score.data(), hit_sink.data(), hip_stream),
-                              "nvbio_hip_anchor_score_finish");
+                    hip_check(nvbio_hip_anchor_score_finish_memo(nh, raw_score.data(), sinks.data(), txt_begin.data(), min_score.data(), worst_score, a_from_memo.data(),
+                                                                 queues.hit_read_id.data(), a_memo.data(), hit_score.data(), hit_sink.data(), hip_stream), "nvbio_hip_anchor_score_finish_memo");
+                    hip_check(nvbio_hip_anchor_memo_update(queues.in_size, reinterpret_cast<const uint32*>(queues.active_in.data()), queues.hit_begin.data(), queues.hit_read_id.data(), hit_seed,
+                                                           txt_begin.data(), txt_len.data(), a_from_memo.data(), raw_score.data(), sinks.data(), anchor, a_memo.data(), hip_stream),
+                              "nvbio_hip_anchor_memo_update");
                     stats.clock.end("anchor_score", hip_stream);
 
                     // opposite_score_best over the hits whose anchor scored: every hit gets a job, the invalid ones an empty text
@@ -556,11 +573,25 @@ private:
                                                              memo.data(), worst_score, o_score.data(), o_score2.data(), o_loc.data(), o_sink.data(), o_sink2.data(), txt_len.data(),
                                                              hip_stream), "nvbio_hip_opposite_memo_lookup");
                     {
+                        // the windows left to score (valid == 1 after the memo): the throughput kernels over all hits when there are many, one job per
+                        // wave over their list when there are few -- both queued, the device runs the one the count calls for (nvbio_hip.h)
                         const PackedStringSetView<4, true> patterns(nh, o_reads.fw_rc_words, o_reads.fw_rc_n_words, pat_begin.data(), nullptr, L);
                         const PackedStringSetView<2, true> texts(nh, genome_words, genome_n_words, txt_begin.data(), txt_len.data(), 0u);
                         const nvbio_hip_string_set p = patterns.abi(), t = texts.abi();
-                        hip_check(nvbio_hip_alignment_score_qual(&sc, NVBIO_HIP_PATTERN_BLOCKING, int32(TYPE), &p, o_reads.quals, o_reads.n_quals, &t, L, pe.max_frag_len + L,
-                                                                 min_score.data(), nh, raw_score.data(), sinks.data(), nullptr, hip_stream), "nvbio_hip_alignment_score_qual");
+                        const uint32 wave_up_to = wave_form_up_to() / 4u;
+                        if (wave_up_to)
+                        {
+                            hip_check(nvbio_hip_list_flagged(nh, o_valid.data(), 1u, a_live_count.data(), a_live_idx.data(), hip_stream), "nvbio_hip_list_flagged");
+                            hip_check(nvbio_hip_alignment_score_qual_jobs(&sc, NVBIO_HIP_PATTERN_BLOCKING, int32(TYPE), &p, o_reads.quals, o_reads.n_quals, &t, L, pe.max_frag_len + L,
+                                                                          min_score.data(), nh, nullptr, nullptr, a_live_count.data(), wave_up_to, 0, raw_score.data(), sinks.data(), nullptr,
+                                                                          hip_stream), "nvbio_hip_alignment_score_qual_jobs");
+                            hip_check(nvbio_hip_alignment_score_qual_jobs(&sc, NVBIO_HIP_PATTERN_BLOCKING, int32(TYPE), &p, o_reads.quals, o_reads.n_quals, &t, L, pe.max_frag_len + L,
+                                                                          min_score.data(), std::min(nh, wave_up_to), a_live_count.data(), a_live_idx.data(), a_live_count.data(), wave_up_to, 1,
+                                                                          raw_score.data(), sinks.data(), nullptr, hip_stream), "nvbio_hip_alignment_score_qual_jobs");
+                        }
+                        else
+                            hip_check(nvbio_hip_alignment_score_qual(&sc, NVBIO_HIP_PATTERN_BLOCKING, int32(TYPE), &p, o_reads.quals, o_reads.n_quals, &t, L, pe.max_frag_len + L,
+                                                                     min_score.data(), nh, raw_score.data(), sinks.data(), nullptr, hip_stream), "nvbio_hip_alignment_score_qual");
                     }
                     hip_check(nvbio_hip_opposite_score_finish(nh, nullptr, o_valid.data(), raw_score.data(), sinks.data(), min_score.data(), o_gbegin.data(), worst_score,
                                                               o_score.data(), o_score2.data(), o_loc.data(), o_sink.data(), o_sink2.data(), hip_stream), "nvbio_hip_opposite_score_finish");
@@ -676,6 +707,9 @@ private:
 
     /// whether the extension rounds hand the scorer their thresholds (NVBIO_HIP_BOUNDED_DP=1, read once; off by default)
     static bool bounded_dp() { static const bool on = [] { const char* e = getenv("NVBIO_HIP_BOUNDED_DP"); return e && atoi(e) == 1; }(); return on; }
+    /// the largest batch of DP jobs that runs one wave per job (banded_gotoh_wave.hip) instead of one lane per job: NVBIO_HIP_WAVE_JOBS (read once;
+    /// default 24576, 0 = never).  A round's jobs are counted on the device and the device picks the form (alignment.h).
+    static uint32 wave_form_up_to() { static const uint32 v = [] { const char* e = getenv("NVBIO_HIP_WAVE_JOBS"); return e ? uint32(atoi(e)) : 24576u; }(); return v; }
     /// NVBIO_HIP_TRACE_ROUNDS=1 (read once): one line per extension round on stderr -- the queue sizes the hits-per-read rule saw
     static bool trace_rounds() { static const bool on = [] { const char* e = getenv("NVBIO_HIP_TRACE_ROUNDS"); return e && atoi(e) == 1; }(); return on; }
     bool count_jobs = false;          ///< fill Stats::dp_jobs (one host round trip per extension round; the stage clock does it too)
@@ -749,7 +783,8 @@ private:
                 const aln::BestSinkArrays sink_arrays = { known_score.data(), best_sink ? hit_sink.data() : sinks.data() };
                 dispatch_band(band_len, [&](auto band) {
                     aln::batch_banded_alignment_score<decltype(band)::value>(aligner, patterns, reads.quals, reads.n_quals, texts, bounded_dp() ? min_score.data() : nullptr,
-                                                                             job_count.data(), work_counter.data(), job_hit.data(), sink_arrays, L, L + band_len, hip_stream);
+                                                                             job_count.data(), work_counter.data(), job_hit.data(), sink_arrays, L, L + band_len, hip_stream,
+                                                                             wave_form_up_to());
                 });
                 if (stats.clock.enabled || count_jobs) { hip::synchronize(hip_stream); hip_check(nvbio_hip_memcpy(&n_jobs, job_count.data(), 4u, 2, hip_stream), "nvbio_hip_memcpy(d2h)"); }
             }

@@ -10,6 +10,7 @@
 // Work is done by nvbio_hip_banded_gotoh_score (include/nvbio_hip.h); like the reference's
 // enact(), calls are asynchronous on the current (null) stream and return nothing.
 #pragma once
+#include <algorithm>
 #include "strings.h"
 
 namespace nvbio {
@@ -249,13 +250,22 @@ void batch_banded_alignment_score(
           BestSinkArrays    sinks,
     const uint32            max_pattern_length,
     const uint32            max_text_length,
-    void*                   hip_stream = nullptr)
+    void*                   hip_stream = nullptr,
+    const uint32            wave_form_up_to = 0u)
 {
     const nvbio_hip_gotoh_qual_scheme sc = aligner.scheme.abi();
     const nvbio_hip_string_set p = patterns.abi(), t = texts.abi();
+    // wave_form_up_to (needs the count on the device, no thresholds, patterns the wave kernel takes): both forms are queued, the device runs the
+    // wave-per-job sweep when the batch holds at most that many jobs and the lane-per-job kernel otherwise
+    const bool both = wave_form_up_to != 0u && n_jobs_on_device != nullptr && min_score == nullptr && max_pattern_length != 0u && max_pattern_length <= 512u;
     hip_check(nvbio_hip_banded_gotoh_score_qual_bounded(&sc, int32(TYPE), BAND_LEN, &p, quals, n_quals, nullptr, &t, max_pattern_length, max_text_length,
-                                                        patterns.size(), n_jobs_on_device, min_score, work_counter, out_index, sinks.score, sinks.sink, hip_stream),
+                                                        patterns.size(), n_jobs_on_device, min_score, work_counter, out_index, both ? n_jobs_on_device : nullptr, wave_form_up_to,
+                                                        sinks.score, sinks.sink, hip_stream),
               "nvbio_hip_banded_gotoh_score_qual_bounded");
+    if (both)
+        hip_check(nvbio_hip_banded_gotoh_score_qual_wave(&sc, int32(TYPE), BAND_LEN, &p, quals, n_quals, &t, max_pattern_length, std::min<uint32>(patterns.size(), wave_form_up_to),
+                                                         n_jobs_on_device, nullptr, out_index, n_jobs_on_device, wave_form_up_to, sinks.score, sinks.sink, hip_stream),
+                  "nvbio_hip_banded_gotoh_score_qual_wave");
 }
 
 } // namespace aln

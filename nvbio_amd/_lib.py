@@ -7,7 +7,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libnvbio_hip.so")
 
 # every symbol include/nvbio_hip.h declares
 SYMBOLS = [
-    "nvbio_hip_banded_gotoh_score", "nvbio_hip_banded_gotoh_score_qual", "nvbio_hip_banded_gotoh_score_qual_views", "nvbio_hip_banded_gotoh_score_qual_bounded", "nvbio_hip_gotoh_score", "nvbio_hip_banded_sw_score", "nvbio_hip_sw_score", "nvbio_hip_alignment_score", "nvbio_hip_alignment_score_qual",
+    "nvbio_hip_banded_gotoh_score", "nvbio_hip_banded_gotoh_score_qual", "nvbio_hip_banded_gotoh_score_qual_views", "nvbio_hip_banded_gotoh_score_qual_bounded", "nvbio_hip_banded_gotoh_score_qual_wave", "nvbio_hip_gotoh_score", "nvbio_hip_banded_sw_score", "nvbio_hip_sw_score", "nvbio_hip_alignment_score", "nvbio_hip_alignment_score_qual", "nvbio_hip_alignment_score_qual_jobs",
     "nvbio_hip_banded_gotoh_traceback_temp_bytes", "nvbio_hip_banded_gotoh_traceback", "nvbio_hip_banded_gotoh_traceback_qual",
     "nvbio_hip_gotoh_traceback_temp_bytes", "nvbio_hip_gotoh_traceback", "nvbio_hip_gotoh_traceback_qual", "nvbio_hip_gotoh_traceback_known_score", "nvbio_hip_gotoh_traceback_qual_known_score", "nvbio_hip_known_score_redone", "nvbio_hip_banded_sw_traceback", "nvbio_hip_sw_traceback",
     "nvbio_hip_fm_rank", "nvbio_hip_fm_rank4", "nvbio_hip_fm_rank_range",
@@ -19,12 +19,12 @@ SYMBOLS = [
     "nvbio_hip_alignment_invalid", "nvbio_hip_init_alignments", "nvbio_hip_score_reduce", "nvbio_hip_score_reduce_paired", "nvbio_hip_opposite_mate_windows", "nvbio_hip_mapq", "nvbio_hip_mapq_paired", "nvbio_hip_fm_locate",
     "nvbio_hip_sum_tree_node_count", "nvbio_hip_select_init", "nvbio_hip_select_init_queued", "nvbio_hip_select_temp_bytes", "nvbio_hip_select", "nvbio_hip_locate_hits", "nvbio_hip_hit_deque_replay",
     "nvbio_hip_score_best_setup", "nvbio_hip_score_reduce_best_approx",
-    "nvbio_hip_anchor_score_setup", "nvbio_hip_anchor_score_finish", "nvbio_hip_opposite_score_setup", "nvbio_hip_opposite_score_finish",
+    "nvbio_hip_anchor_score_setup", "nvbio_hip_anchor_score_finish", "nvbio_hip_anchor_memo_mark", "nvbio_hip_anchor_score_finish_memo", "nvbio_hip_anchor_memo_update", "nvbio_hip_opposite_score_setup", "nvbio_hip_opposite_score_finish",
     "nvbio_hip_score_reduce_paired_best_approx", "nvbio_hip_mark_discordant",
     "nvbio_hip_pack_read_queue", "nvbio_hip_mark_unaligned", "nvbio_hip_copy_flagged_temp_bytes", "nvbio_hip_copy_flagged", "nvbio_hip_traceback_best_setup", "nvbio_hip_finish_alignment", "nvbio_hip_scatter_rows",
     "nvbio_hip_gather_ranges", "nvbio_hip_select_all", "nvbio_hip_mark_straddling", "nvbio_hip_score_all_setup", "nvbio_hip_score_all_output",
     "nvbio_hip_traceback_all_setup", "nvbio_hip_all_mapping_temp_bytes", "nvbio_hip_inclusive_scan_u32", "nvbio_hip_inclusive_scan_u64", "nvbio_hip_sort_hi_bits",
-    "nvbio_hip_sort_hits", "nvbio_hip_gather_rows", "nvbio_hip_opposite_memo_lookup", "nvbio_hip_opposite_memo_update", "nvbio_hip_traceback_best_known", "nvbio_hip_banded_gotoh_traceback_qual_known",
+    "nvbio_hip_sort_hits", "nvbio_hip_gather_rows", "nvbio_hip_list_flagged", "nvbio_hip_opposite_memo_lookup", "nvbio_hip_opposite_memo_update", "nvbio_hip_traceback_best_known", "nvbio_hip_banded_gotoh_traceback_qual_known",
     "nvbio_hip_fm_locate_ssa_iterator", "nvbio_hip_fm_lookup_ssa_iterator",
     "nvbio_hip_fm_filter_temp_bytes", "nvbio_hip_fm_filter_rank", "nvbio_hip_fm_filter_locate",
     "nvbio_hip_build_bwt_occ_temp_bytes", "nvbio_hip_build_bwt_occ",
@@ -94,7 +94,8 @@ def lib():
         L.nvbio_hip_banded_gotoh_score.argtypes = [P(GotohSchemeStruct), i32, u32, P(StringSetStruct), P(StringSetStruct), u32, u32, u32, vp, vp, vp]
         L.nvbio_hip_banded_gotoh_score_qual.argtypes = [P(GotohQualSchemeStruct), i32, u32, P(StringSetStruct), vp, u64, P(StringSetStruct), u32, u32, u32, vp, vp, vp]
         L.nvbio_hip_banded_gotoh_score_qual_views.argtypes = [P(GotohQualSchemeStruct), i32, u32, P(StringSetStruct), vp, u64, vp, P(StringSetStruct), u32, u32, u32, vp, vp, vp]
-        L.nvbio_hip_banded_gotoh_score_qual_bounded.argtypes = [P(GotohQualSchemeStruct), i32, u32, P(StringSetStruct), vp, u64, vp, P(StringSetStruct), u32, u32, u32, vp, vp, vp, vp, vp, vp, vp]
+        L.nvbio_hip_banded_gotoh_score_qual_bounded.argtypes = [P(GotohQualSchemeStruct), i32, u32, P(StringSetStruct), vp, u64, vp, P(StringSetStruct), u32, u32, u32, vp, vp, vp, vp, vp, u32, vp, vp, vp]
+        L.nvbio_hip_banded_gotoh_score_qual_wave.argtypes = [P(GotohQualSchemeStruct), i32, u32, P(StringSetStruct), vp, u64, P(StringSetStruct), u32, u32, vp, vp, vp, vp, u32, vp, vp, vp]
         L.nvbio_hip_banded_gotoh_traceback_temp_bytes.argtypes = [u32, u32, u32]
         L.nvbio_hip_banded_gotoh_traceback_temp_bytes.restype = u64
         L.nvbio_hip_banded_gotoh_traceback.argtypes = [P(GotohSchemeStruct), i32, u32, P(StringSetStruct), P(StringSetStruct), u32, u32, u32,

@@ -182,7 +182,7 @@ class BatchedBandedAlignmentScore:
                     int(max_pattern_length), int(max_text_length), n,
                     C.c_void_p(n_on_device.data_ptr()) if n_on_device is not None else None,
                     C.c_void_p(min_score.data_ptr()) if min_score is not None else None, C.c_void_p(counter.data_ptr()),
-                    C.c_void_p(out_index.data_ptr()) if out_index is not None else None,
+                    C.c_void_p(out_index.data_ptr()) if out_index is not None else None, None, 0,
                     C.c_void_p(out_score.data_ptr()), C.c_void_p(out_sink.data_ptr()), current_stream_ptr())
                 check(err, "nvbio_hip_banded_gotoh_score_qual_bounded")
                 return
@@ -199,6 +199,28 @@ class BatchedBandedAlignmentScore:
             int(max_pattern_length), int(max_text_length), n,
             C.c_void_p(out_score.data_ptr()), C.c_void_p(out_sink.data_ptr()), current_stream_ptr())
         check(err, "nvbio_hip_banded_gotoh_score")
+
+
+def batch_banded_alignment_score_wave(band_len, aligner, patterns, texts, quals, out_score=None, out_sink=None, max_pattern_length=0, job_index=None, n_on_device=None):
+    """The quality-scheme banded scorer with one wave per job (nvbio_hip_banded_gotoh_score_qual_wave): the anti-diagonal sweep, for small batches.
+    job_index: optional int32 device tensor -- job k is job_index[k] of the string sets and writes its outputs there (len(job_index) jobs run)."""
+    n_sets = len(patterns)
+    dev = patterns.words.device
+    if out_score is None:
+        out_score = torch.empty(n_sets, dtype=torch.int32, device=dev)
+    if out_sink is None:
+        out_sink = torch.empty((n_sets, 2), dtype=torch.int32, device=dev)
+    n = int(job_index.numel()) if job_index is not None else n_sets
+    sc = aligner.scheme.struct()
+    ps, ts = patterns.struct(), texts.struct()
+    if patterns.length is None:
+        max_pattern_length = max_pattern_length or patterns.fixed_length
+    check(lib().nvbio_hip_banded_gotoh_score_qual_wave(
+        C.byref(sc), aligner.type, band_len, C.byref(ps), C.c_void_p(quals.data_ptr()) if quals is not None else None, quals.numel() if quals is not None else 0,
+        C.byref(ts), int(max_pattern_length), n, C.c_void_p(n_on_device.data_ptr()) if n_on_device is not None else None,
+        C.c_void_p(job_index.data_ptr()) if job_index is not None else None, None, None, 0,
+        C.c_void_p(out_score.data_ptr()), C.c_void_p(out_sink.data_ptr()), current_stream_ptr()), "nvbio_hip_banded_gotoh_score_qual_wave")
+    return out_score, out_sink
 
 
 def batch_banded_alignment_score(band_len, aligner, patterns, texts, out_score=None, out_sink=None,

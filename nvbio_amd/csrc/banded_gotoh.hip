@@ -192,7 +192,7 @@ NVB_API int nvbio_hip_banded_gotoh_score(
     p.match = scheme->match; p.mismatch = scheme->mismatch;
     p.gap_open = scheme->gap_open; p.gap_ext = scheme->gap_ext;
     p.txt_gap_open = scheme->gap_open; p.txt_gap_ext = scheme->gap_ext;      // SimpleGotohScheme: utils.h:128-131
-    p.n = n; p.out_score = out_score; p.out_sink = out_sink; p.n_dev = nullptr; p.out_index = nullptr;
+    p.n = n; p.out_score = out_score; p.out_sink = out_sink; p.n_dev = nullptr; p.out_index = nullptr; p.gate = nullptr; p.gate_limit = 0;
     p.stage_pw = max_pattern_len; p.stage_tw = 0;       // the hint, consumed by banded_gotoh_dispatch
     const int64_t A = std::max(std::max(iabs64(scheme->match), iabs64(scheme->mismatch)), std::max(iabs64(scheme->gap_open), iabs64(scheme->gap_ext)));
     return banded_gotoh_dispatch(p, NoQual(), A, std::max(scheme->match, scheme->mismatch), type, band_len, patterns, to_stream(stream),
@@ -230,7 +230,7 @@ NVB_API int nvbio_hip_banded_gotoh_score_qual_views(
     p.match = scheme->match; p.mismatch = 0;
     p.gap_open = scheme->pattern_gap_open; p.gap_ext = scheme->pattern_gap_ext;
     p.txt_gap_open = scheme->text_gap_open; p.txt_gap_ext = scheme->text_gap_ext;
-    p.n = n; p.out_score = out_score; p.out_sink = out_sink; p.n_dev = nullptr; p.out_index = nullptr;
+    p.n = n; p.out_score = out_score; p.out_sink = out_sink; p.n_dev = nullptr; p.out_index = nullptr; p.gate = nullptr; p.gate_limit = 0;
     p.stage_pw = max_pattern_len; p.stage_tw = 0;       // the hint, consumed by banded_gotoh_dispatch
     QualArgs qa;
     qa.quals = quals; qa.n_quals = n_quals; qa.flags = pattern_flags;
@@ -250,11 +250,12 @@ NVB_API int nvbio_hip_banded_gotoh_score_qual_bounded(
     const nvbio_hip_string_set* texts,
     uint32_t max_pattern_len, uint32_t max_text_len,
     uint32_t n, const uint32_t* n_on_device, const int32_t* min_score, uint32_t* work_counter, const uint32_t* out_index,
+    const uint32_t* gate, uint32_t gate_limit,
     int32_t* out_score, uint32_t* out_sink, void* stream)
 {
     (void)max_text_len;
     using namespace nvb;
-    if (!scheme || (min_score && !work_counter)) return hipErrorInvalidValue;
+    if (!scheme || (min_score && !work_counter) || (min_score && gate)) return hipErrorInvalidValue;
     if (int e = check_banded_args(type, band_len, patterns, texts)) return e;
     if (n == 0) return hipSuccess;
     if (int e = check_banded_ptrs(patterns, texts, out_score, out_sink)) return e;
@@ -266,7 +267,7 @@ NVB_API int nvbio_hip_banded_gotoh_score_qual_bounded(
     p.match = scheme->match; p.mismatch = 0;
     p.gap_open = scheme->pattern_gap_open; p.gap_ext = scheme->pattern_gap_ext;
     p.txt_gap_open = scheme->text_gap_open; p.txt_gap_ext = scheme->text_gap_ext;
-    p.n = n; p.out_score = out_score; p.out_sink = out_sink; p.n_dev = nullptr; p.out_index = nullptr;
+    p.n = n; p.out_score = out_score; p.out_sink = out_sink; p.n_dev = nullptr; p.out_index = nullptr; p.gate = nullptr; p.gate_limit = 0;
     p.stage_pw = max_pattern_len; p.stage_tw = 0;
     QualArgs qa;
     qa.quals = quals; qa.n_quals = n_quals; qa.flags = pattern_flags;
@@ -277,7 +278,7 @@ NVB_API int nvbio_hip_banded_gotoh_score_qual_bounded(
     // without thresholds this is the plain kernel over a device-side count, writing through the index
     if (!min_score)
     {
-        p.n_dev = n_on_device; p.out_index = out_index;
+        p.n_dev = n_on_device; p.out_index = out_index; p.gate = gate; p.gate_limit = gate_limit;
         return banded_gotoh_dispatch(p, qa, A, best_pair, type, band_len, patterns, to_stream(stream),
                                      pattern_flags ? "banded_gotoh_score_kernel<A16,qual,views>" : "banded_gotoh_score_kernel<A16,qual>",
                                      pattern_flags ? "banded_gotoh_score_kernel<A32,qual,views>" : "banded_gotoh_score_kernel<A32,qual>", pattern_flags != nullptr);

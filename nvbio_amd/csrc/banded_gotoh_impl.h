@@ -18,6 +18,8 @@ struct GotohParams {
     uint32_t* out_sink;
     const uint32_t* n_dev;        // optional: the job count on the device (n is then the arrays' capacity) -- no host round trip to size the launch
     const uint32_t* out_index;    // optional: job i's results go to out_score[out_index[i]] / out_sink[out_index[i]] (a compacted batch writing back at its hits)
+    const uint32_t* gate;         // optional: the launch does nothing unless *gate > gate_limit (a device-side choice between this kernel and the
+    uint32_t        gate_limit;   //           wave-per-job kernel, which runs when *gate <= gate_limit: no host round trip to pick one)
 };
 
 // nvBowtie's quality-aware scheme (nvBowtie/bowtie2/cuda/scoring.h:283-293): the mismatch score is a
@@ -462,6 +464,7 @@ banded_gotoh_score_kernel(const GotohParams p, const QA qa)
     fill_lut<A>(s_lut, qa, p.gap_open, SH);
     const uint32_t id = blockIdx.x * 256u + threadIdx.x;
     if (id >= (p.n_dev ? *p.n_dev : p.n)) return;
+    if (p.gate && *p.gate <= p.gate_limit) return;
 
     const uint32_t M  = p.pat.length ? p.pat.length[id] : p.pat.fixed_length;
     if (M < p.len_lo || M > p.len_hi) return;                   // the other arithmetic width owns this job

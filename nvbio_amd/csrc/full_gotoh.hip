@@ -50,7 +50,13 @@ struct FullParams {
     // gap costs of the two boundary lines (they are the text / pattern gap costs, which line gets which depends on the tag)
     int32_t        col_go, col_ge;     // column before the text:  H(r, -1) = col_go + col_ge * r      (non-LOCAL)
     int32_t        row_go, row_ge;     // row above the pattern:   H(-1, c) = row_go + row_ge * c      (GLOBAL)
+    // job control (nvbio_hip_alignment_score_qual_jobs): the count on the device, a list of jobs run in place, a device-side gate
+    const uint32_t* n_dev;             // nullable: the number of jobs (of list entries, with job_index)
+    const uint32_t* job_index;         // nullable: entry k is job job_index[k] of the arrays (one-job-per-wave kernel only)
+    const uint32_t* gate;              // nullable: the launch runs iff (*gate > gate_limit) == gate_above
+    uint32_t        gate_limit, gate_above;
 };
+__device__ __forceinline__ bool gate_closed(const FullParams& p) { return p.gate != nullptr && ((*p.gate > p.gate_limit) != (p.gate_above != 0u)); }
 
 __device__ __forceinline__ int32_t dpp_shr1(int32_t first_lane_value, int32_t x)
 {
@@ -614,9 +620,10 @@ template <int TYPE, int R, bool TRUNC, bool FAST, int MODE = 0>
 __global__ void __launch_bounds__(256)
 full_gotoh_score_kernel(const FullParams p)
 {
-    const uint32_t job  = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    const uint32_t entry = (blockIdx.x * 256u + threadIdx.x) >> 6;
     const uint32_t lane = threadIdx.x & 63u;
-    if (job >= p.n) return;
+    if (entry >= (p.n_dev ? *p.n_dev : p.n) || gate_closed(p)) return;
+    const uint32_t job  = p.job_index ? p.job_index[entry] : entry;
     const uint32_t M  = p.pat.length ? p.pat.length[job] : p.pat.fixed_length;
     const uint32_t N  = p.txt.length ? p.txt.length[job] : p.txt.fixed_length;
     const uint64_t pb = p.pat.begin[job], tb = p.txt.begin[job];
@@ -726,7 +733,7 @@ full_gotoh_score_multi_kernel(const FullParams p, const uint32_t n_seg, const ui
     const uint32_t seg  = wl / seg_w, sl = wl - seg * seg_w;
     const uint32_t job  = wave * n_seg + seg;
     const bool has_job  = seg < n_seg && job < p.n;
-    if (wave * n_seg >= p.n) return;
+    if (wave * n_seg >= p.n || gate_closed(p)) return;
 
     const uint32_t M  = has_job ? (p.pat.length ? p.pat.length[job] : p.pat.fixed_length) : 0u;
     const uint32_t N  = has_job ? (p.txt.length ? p.txt.length[job] : p.txt.fixed_length) : 0u;
@@ -976,11 +983,13 @@ using namespace nvb;
 
 struct QualPart { const uint8_t* quals; uint64_t n_quals; const int32_t* mismatch; int32_t text_gap_open, text_gap_ext; };
 
+struct FullJobs { const uint32_t* n_dev; const uint32_t* job_index; const uint32_t* gate; uint32_t gate_limit; int wave_form; };
+
 static int full_score_core(
     const nvbio_hip_gotoh_scheme* scheme, const QualPart* qual, int32_t type, uint32_t blk_log2, uint32_t pattern_blocking,
     const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts,
     uint32_t max_pattern_len, uint32_t max_text_len, const int32_t* min_score,
-    uint32_t n, int32_t* out_score, uint32_t* out_sink, uint8_t* out_ok, void* stream)
+    uint32_t n, int32_t* out_score, uint32_t* out_sink, uint8_t* out_ok, void* stream, const FullJobs* jobs = nullptr)
 {
     if (!scheme || !patterns || !texts) return hipErrorInvalidValue;
     if (type < 0 || type > 2) return hipErrorInvalidValue;
@@ -998,6 +1007,12 @@ static int full_score_core(
     p.pat = make_string_set(patterns); p.txt = make_string_set(texts);
     p.match = scheme->match; p.mismatch = scheme->mismatch; p.gap_open = scheme->gap_open; p.gap_ext = scheme->gap_ext;
     p.min_score = min_score; p.n = n; p.out_score = out_score; p.out_sink = out_sink; p.out_ok = out_ok;
+    p.n_dev = nullptr; p.job_index = nullptr; p.gate = nullptr; p.gate_limit = 0u; p.gate_above = 1u;
+    if (jobs)
+    {
+        if (jobs->wave_form) { p.n_dev = jobs->n_dev; p.job_index = jobs->job_index; }       // (the throughput dispatch walks the arrays as they are)
+        p.gate = jobs->gate; p.gate_limit = jobs->gate_limit; p.gate_above = jobs->wave_form ? 0u : 1u;
+    }
     p.blk_log2 = blk_log2; p.pattern_blocking = pattern_blocking;
     p.max_m = maxM; p.max_n = maxN;
     p.quals = qual ? qual->quals : nullptr; p.n_quals = qual ? qual->n_quals : 0;
@@ -1046,7 +1061,7 @@ static int full_score_core(
     // edit distance, no min_score, non-LOCAL: the bit-vector kernel (NVBIO_HIP_ED_SWEEP=1 keeps the sweep, for the tests)
     {
         const bool ed = !qual && blk_log2 == 4u && scheme->match == 0 && scheme->mismatch == -1 && scheme->gap_open == -1 && scheme->gap_ext == -1;
-        if (ed && !trunc && type != NVBIO_HIP_LOCAL && min_score == nullptr && maxM <= 512u && test_switch(SW_ED_SWEEP) != 1)
+        if (ed && !trunc && type != NVBIO_HIP_LOCAL && min_score == nullptr && maxM <= 512u && test_switch(SW_ED_SWEEP) != 1 && !jobs)
         {
             g_last_kernel = "edit_distance_bitvector_kernel";
             const uint32_t words = (maxM + 63u) / 64u;
@@ -1061,7 +1076,7 @@ static int full_score_core(
     {
         // several jobs per wave when that keeps more lanes busy: n_seg segments of 64 / n_seg lanes, R = 5 or 6 rows per lane.
         // Estimated cell throughput: busy lanes x (cell work) / (cell work + per-step overhead).
-        const bool nomulti = test_switch(SW_FULL_SINGLE_JOB) == 1;
+        const bool nomulti = test_switch(SW_FULL_SINGLE_JOB) == 1 || (jobs && jobs->wave_form);
         auto eff = [](const double lanes, const double rows, const double overhead) { return lanes / 64.0 * (28.0 * rows) / (28.0 * rows + overhead); };
         double best = eff(double((maxM + R - 1) / R), double(R), 24.0);
         uint32_t best_seg = 1u, best_r = 0u;
@@ -1090,6 +1105,7 @@ static int full_score_core(
                               case 8u: return launch_full_multi<8>(p, type, best_seg, s); default: return launch_full_multi<10>(p, type, best_seg, s); }
         }
     }
+    if (jobs && jobs->wave_form && !fast) return hipErrorNotSupported;         // the job list is a feature of the 16-bit one-job-per-wave sweep
     if (fast) {
         g_last_kernel = "full_gotoh_score_kernel<16-bit>";
         switch (R) { case 1: return launch_full<1, false, true>(p, type, s); case 2: return launch_full<2, false, true>(p, type, s);
@@ -1172,4 +1188,24 @@ NVB_API int nvbio_hip_alignment_score_qual(
     const nvbio_hip_gotoh_scheme g = { scheme->match, worst, scheme->pattern_gap_open, scheme->pattern_gap_ext };
     const QualPart q = { quals, n_quals, scheme->mismatch, scheme->text_gap_open, scheme->text_gap_ext };
     return full_score_core(&g, &q, type, 3u, algorithm == 0 ? 1u : 0u, patterns, texts, max_pattern_len, max_text_len, min_score, n, out_score, out_sink, out_ok, stream);
+}
+
+// ... with job control: the throughput dispatch behind a device-side gate (wave_form = 0: runs when *gate > gate_limit), or one job per wave over a
+// list of jobs (wave_form = 1: entries [0, *n_on_device) of job_index, run when *gate <= gate_limit) -- see nvbio_hip.h
+NVB_API int nvbio_hip_alignment_score_qual_jobs(
+    const nvbio_hip_gotoh_qual_scheme* scheme, int32_t algorithm, int32_t type,
+    const nvbio_hip_string_set* patterns, const uint8_t* quals, uint64_t n_quals, const nvbio_hip_string_set* texts,
+    uint32_t max_pattern_len, uint32_t max_text_len, const int32_t* min_score,
+    uint32_t n, const uint32_t* n_on_device, const uint32_t* job_index, const uint32_t* gate, uint32_t gate_limit, int32_t wave_form,
+    int32_t* out_score, uint32_t* out_sink, uint8_t* out_ok, void* stream)
+{
+    if (!scheme || algorithm < 0 || algorithm > 1) return hipErrorInvalidValue;
+    if (n != 0 && (!quals || n_quals == 0)) return hipErrorInvalidValue;
+    if (wave_form && (!n_on_device || !job_index)) return hipErrorInvalidValue;
+    int32_t worst = 0;
+    for (int i = 0; i < 256; ++i) worst = std::min(worst, scheme->mismatch[i]);
+    const nvbio_hip_gotoh_scheme g = { scheme->match, worst, scheme->pattern_gap_open, scheme->pattern_gap_ext };
+    const QualPart q = { quals, n_quals, scheme->mismatch, scheme->text_gap_open, scheme->text_gap_ext };
+    const FullJobs j = { n_on_device, job_index, gate, gate_limit, wave_form ? 1 : 0 };
+    return full_score_core(&g, &q, type, 3u, algorithm == 0 ? 1u : 0u, patterns, texts, max_pattern_len, max_text_len, min_score, n, out_score, out_sink, out_ok, stream, &j);
 }

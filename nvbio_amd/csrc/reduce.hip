@@ -336,6 +336,111 @@ opposite_score_finish_kernel(uint32_t n_valid, const uint32_t* __restrict__ idx,
     o_sink2[h] = gb;
 }
 
+// ------------------------------------------------------------------ anchor memo
+// The anchor's banded DP is a pure function of (pair, which mate, strand, window).  The reference's skip test (anchor_score_setup above)
+// compares a hit's position with the recorded alignments' *window* begins and so almost never fires: every seed of a read that points at
+// the placement the read already tried -- a dozen per read on a unique genome -- pays the DP again and gets the identical score (measured:
+// 7.7 M anchor DPs per 500 k pairs where ~1.5 M are distinct, bench config 5).  One entry per pair remembers the last scored job
+// {window begin, strand, mate} and its raw outputs; a later hit with the same job is answered from it.
+//   mark    (after anchor_score_setup, before the DP): a hit whose job is the pair's entry, or the job of the hit just before it in the same
+//           round, gets an empty text (its lane of the scorer returns at once) and from_memo[i] = 1 (entry) / 2 (same as hit i - 1)
+//   finish  the reference's output step, taking a marked hit's raw score and sink from where they are
+//   update  per active read, the last hit of the round becomes the pair's entry
+// memo: 6 words per pair {window begin, 1 | strand << 1 | mate << 2, raw score, sink.x, sink.y, -}, zero-initialised by the caller.
+__global__ void __launch_bounds__(256)
+anchor_memo_mark_kernel(uint32_t n_hits, const uint32_t* __restrict__ hit_read_id, const uint32_t* __restrict__ hit_seed, const uint64_t* __restrict__ text_begin,
+                        const uint32_t* __restrict__ text_len_in, uint32_t anchor, const uint32_t* __restrict__ memo, uint8_t* __restrict__ from_memo,
+                        uint32_t* __restrict__ text_len_out, uint32_t* __restrict__ live_count, uint32_t* __restrict__ live_idx)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    __shared__ uint32_t wave_live[4], block_base;
+    uint8_t f = 0u;
+    const uint32_t tl = i < n_hits ? text_len_in[i] : 0u;
+    if (i < n_hits && tl != 0u)
+    {
+        const uint32_t r = hit_read_id[i], rc = (hit_seed[i] >> 13) & 1u, gb = uint32_t(text_begin[i]);
+        // the hit before this one in the round: same pair, same strand, same window, and scored (not skipped)
+        if (i > 0u && hit_read_id[i - 1u] == r && ((hit_seed[i - 1u] >> 13) & 1u) == rc && uint32_t(text_begin[i - 1u]) == gb && text_len_in[i - 1u] != 0u) f = 2u;
+        else
+        {
+            const uint32_t* m = memo + uint64_t(r) * 6u;
+            if (m[1] == (1u | (rc << 1) | (anchor << 2)) && m[0] == gb) f = 1u;
+        }
+    }
+    if (i < n_hits) { from_memo[i] = f; text_len_out[i] = f ? 0u : tl; }
+    // the hits that still need their DP, as a list (one atomic per block): what the wave-per-job scorer runs when there are few of them
+    if (live_count)
+    {
+        const bool live = i < n_hits && tl != 0u && f == 0u;
+        const uint64_t m = __ballot(live);
+        const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+        if (lane == 0u) wave_live[wv] = uint32_t(__popcll(m));
+        __syncthreads();
+        if (threadIdx.x == 0u) { const uint32_t tot = wave_live[0] + wave_live[1] + wave_live[2] + wave_live[3]; block_base = tot ? atomicAdd(live_count, tot) : 0u; }
+        __syncthreads();
+        uint32_t base = block_base;
+        for (uint32_t k = 0; k < wv; ++k) base += wave_live[k];
+        if (live) live_idx[base + uint32_t(__popcll(m & ((1ull << lane) - 1ull)))] = i;
+    }
+}
+// the raw (score, sink) of hit i: from the scorer, the memo, or the hit it repeats
+__device__ __forceinline__ void anchor_raw(uint32_t i, const uint8_t* __restrict__ from_memo, const uint32_t* __restrict__ hit_read_id, const uint32_t* __restrict__ memo,
+                                           const int32_t* __restrict__ raw_score, const uint2* __restrict__ raw_sink, int32_t& s, uint2& k)
+{
+    while (from_memo[i] == 2u) --i;                    // (a run of repeats ends at the hit that was scored, or answered from the entry)
+    if (from_memo[i] == 1u) { const uint32_t* m = memo + uint64_t(hit_read_id[i]) * 6u; s = int32_t(m[2]); k = make_uint2(m[3], m[4]); }
+    else { s = raw_score[i]; k = raw_sink[i]; }
+}
+__global__ void __launch_bounds__(256)
+anchor_score_finish_memo_kernel(uint32_t n, const int32_t* __restrict__ raw_score, const uint2* __restrict__ raw_sink, const uint64_t* __restrict__ text_begin,
+                                const int32_t* __restrict__ min_score, int32_t worst_score, const uint8_t* __restrict__ from_memo,
+                                const uint32_t* __restrict__ hit_read_id, const uint32_t* __restrict__ memo, int32_t* __restrict__ hit_score, uint32_t* __restrict__ hit_sink)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    int32_t s; uint2 k;
+    anchor_raw(i, from_memo, hit_read_id, memo, raw_score, raw_sink, s, k);
+    hit_score[i] = s >= min_score[i] ? s : worst_score;
+    hit_sink[i] = uint32_t(text_begin[i]) + k.x;
+}
+__global__ void __launch_bounds__(256)
+anchor_memo_update_kernel(uint32_t n_active, const uint32_t* __restrict__ active, const uint64_t* __restrict__ hit_begin, const uint32_t* __restrict__ hit_read_id,
+                          const uint32_t* __restrict__ hit_seed, const uint64_t* __restrict__ text_begin, const uint32_t* __restrict__ text_len_setup,
+                          const uint8_t* __restrict__ from_memo, const int32_t* __restrict__ raw_score, const uint2* __restrict__ raw_sink, uint32_t anchor,
+                          uint32_t* __restrict__ memo)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_active) return;
+    uint32_t* m = memo + uint64_t(active[t] & 0x7FFFFFFFu) * 6u;
+    for (uint64_t i = hit_begin[t + 1]; i > hit_begin[t]; --i)            // the last hit of the round that had a window
+    {
+        const uint32_t h = uint32_t(i - 1u);
+        if (text_len_setup[h] == 0u) continue;
+        int32_t s; uint2 k;
+        anchor_raw(h, from_memo, hit_read_id, memo, raw_score, raw_sink, s, k);      // (reads the entry before it is overwritten below: one lane per pair)
+        m[0] = uint32_t(text_begin[h]); m[1] = 1u | (((hit_seed[h] >> 13) & 1u) << 1) | (anchor << 2); m[2] = uint32_t(s); m[3] = k.x; m[4] = k.y;
+        break;
+    }
+}
+
+// the indices i < n with flags[i] == value, listed in idx (block by block: the order inside the list is not the index order), counted in *count
+__global__ void __launch_bounds__(256)
+list_flagged_kernel(uint32_t n, const uint8_t* __restrict__ flags, uint32_t value, uint32_t* __restrict__ count, uint32_t* __restrict__ idx)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    __shared__ uint32_t wave_n[4], block_base;
+    const bool hit = i < n && uint32_t(flags[i]) == value;
+    const uint64_t m = __ballot(hit);
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    if (lane == 0u) wave_n[wv] = uint32_t(__popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0u) { const uint32_t tot = wave_n[0] + wave_n[1] + wave_n[2] + wave_n[3]; block_base = tot ? atomicAdd(count, tot) : 0u; }
+    __syncthreads();
+    uint32_t base = block_base;
+    for (uint32_t k = 0; k < wv; ++k) base += wave_n[k];
+    if (hit) idx[base + uint32_t(__popcll(m & ((1ull << lane) - 1ull)))] = i;
+}
+
 // ------------------------------------------------------------------ opposite-mate memo
 // The opposite mate's DP is a pure function of (pair, opposite strand, window, threshold).  The reference re-runs it for every
 // anchor hit that lands on a placement it has already tried -- in the second anchor pass that is every seed of every read, because
@@ -737,6 +842,39 @@ NVB_API int nvbio_hip_anchor_score_finish(uint32_t n_hits, const int32_t* raw_sc
     return hipGetLastError();
 }
 
+NVB_API int nvbio_hip_anchor_memo_mark(uint32_t n_hits, const uint32_t* hit_read_id, const uint32_t* hit_seed, const uint64_t* text_begin, const uint32_t* text_len,
+    uint32_t anchor, const uint32_t* memo, uint8_t* from_memo, uint32_t* text_len_out, uint32_t* live_count, uint32_t* live_idx, void* stream)
+{
+    if ((live_count != nullptr) != (live_idx != nullptr)) return hipErrorInvalidValue;
+    if (live_count) { const hipError_t e = hipMemsetAsync(live_count, 0, sizeof(uint32_t), to_stream(stream)); if (e != hipSuccess) return e; }
+    if (n_hits == 0) return hipSuccess;
+    if (!hit_read_id || !hit_seed || !text_begin || !text_len || anchor > 1u || !memo || !from_memo || !text_len_out || text_len_out == text_len) return hipErrorInvalidValue;
+    g_last_kernel = "anchor_memo_mark_kernel";
+    hipLaunchKernelGGL(anchor_memo_mark_kernel, dim3((n_hits + 255u) / 256u), dim3(256), 0, to_stream(stream), n_hits, hit_read_id, hit_seed, text_begin, text_len, anchor, memo,
+                       from_memo, text_len_out, live_count, live_idx);
+    return hipGetLastError();
+}
+NVB_API int nvbio_hip_anchor_score_finish_memo(uint32_t n_hits, const int32_t* raw_score, const uint32_t* raw_sink, const uint64_t* text_begin, const int32_t* min_score,
+    int32_t worst_score, const uint8_t* from_memo, const uint32_t* hit_read_id, const uint32_t* memo, int32_t* hit_score, uint32_t* hit_sink, void* stream)
+{
+    if (n_hits == 0) return hipSuccess;
+    if (!raw_score || !raw_sink || !text_begin || !min_score || !from_memo || !hit_read_id || !memo || !hit_score || !hit_sink) return hipErrorInvalidValue;
+    g_last_kernel = "anchor_score_finish_memo_kernel";
+    hipLaunchKernelGGL(anchor_score_finish_memo_kernel, dim3((n_hits + 255u) / 256u), dim3(256), 0, to_stream(stream), n_hits, raw_score, reinterpret_cast<const uint2*>(raw_sink),
+                       text_begin, min_score, worst_score, from_memo, hit_read_id, memo, hit_score, hit_sink);
+    return hipGetLastError();
+}
+NVB_API int nvbio_hip_anchor_memo_update(uint32_t n_active, const uint32_t* active_reads, const uint64_t* hit_begin, const uint32_t* hit_read_id, const uint32_t* hit_seed,
+    const uint64_t* text_begin, const uint32_t* text_len_setup, const uint8_t* from_memo, const int32_t* raw_score, const uint32_t* raw_sink, uint32_t anchor, uint32_t* memo, void* stream)
+{
+    if (n_active == 0) return hipSuccess;
+    if (!active_reads || !hit_begin || !hit_read_id || !hit_seed || !text_begin || !text_len_setup || !from_memo || !raw_score || !raw_sink || anchor > 1u || !memo) return hipErrorInvalidValue;
+    g_last_kernel = "anchor_memo_update_kernel";
+    hipLaunchKernelGGL(anchor_memo_update_kernel, dim3((n_active + 255u) / 256u), dim3(256), 0, to_stream(stream), n_active, active_reads, hit_begin, hit_read_id, hit_seed, text_begin,
+                       text_len_setup, from_memo, raw_score, reinterpret_cast<const uint2*>(raw_sink), anchor, memo);
+    return hipGetLastError();
+}
+
 NVB_API int nvbio_hip_opposite_score_setup(uint32_t n_hits, const uint32_t* hit_read_id, const uint32_t* hit_seed, const uint32_t* hit_loc, const int32_t* hit_score,
     int32_t worst_score, const uint32_t* a_read_len, const uint32_t* o_read_len, uint32_t a_fixed_len, uint32_t o_fixed_len,
     const uint64_t* best_alignments, const uint64_t* best_alignments_o, uint32_t best_stride,
@@ -770,6 +908,17 @@ NVB_API int nvbio_hip_opposite_score_finish(uint32_t n_valid, const uint32_t* va
     g_last_kernel = "opposite_score_finish_kernel";
     hipLaunchKernelGGL(opposite_score_finish_kernel, dim3((n_valid + 255u) / 256u), dim3(256), 0, to_stream(stream), n_valid, valid_idx, raw_score,
                        reinterpret_cast<const uint2*>(raw_sink), min_score, genome_begin, worst_score, valid_idx ? nullptr : valid_flags, opposite_score, opposite_score2, opposite_loc, opposite_sink, opposite_sink2);
+    return hipGetLastError();
+}
+
+NVB_API int nvbio_hip_list_flagged(uint32_t n, const uint8_t* flags, uint32_t value, uint32_t* count, uint32_t* idx, void* stream)
+{
+    if (!count || !idx) return hipErrorInvalidValue;
+    if (hipError_t e = hipMemsetAsync(count, 0, sizeof(uint32_t), to_stream(stream))) return e;
+    if (n == 0) return hipSuccess;
+    if (!flags) return hipErrorInvalidValue;
+    g_last_kernel = "list_flagged_kernel";
+    hipLaunchKernelGGL(list_flagged_kernel, dim3((n + 255u) / 256u), dim3(256), 0, to_stream(stream), n, flags, value, count, idx);
     return hipGetLastError();
 }
 

@@ -372,3 +372,55 @@ def test_bounded_scorer_threshold_semantics(cuda, band, ty):
         gave_up = (gk.cpu().numpy().view(np.uint32) == 0xFFFFFFFF).all(1) & (es != -(1 << 30))
         assert int(gave_up.sum()) > n // 4, int(gave_up.sum())
         assert (gs.cpu().numpy()[gave_up] <= hi.cpu().numpy()[gave_up]).all()
+
+
+@pytest.mark.parametrize("band", [3, 5, 7, 15, 31])
+@pytest.mark.parametrize("ty", [nvb.LOCAL, nvb.SEMI_GLOBAL, nvb.GLOBAL])
+def test_wave_kernel_equals_lane_kernel(cuda, band, ty):
+    """nvbio_hip_banded_gotoh_score_qual_wave (one wave per job, the anti-diagonal sweep; nvbio_amd/csrc/banded_gotoh_wave.hip) against the oracle and the
+    lane-per-job kernel: ragged jobs (an empty and a one-symbol pattern, texts shorter than their patterns, windows cut by the text's end so that symbols
+    past it enter the band -- the reference's 2-bit cache quirk at band 31 --, texts shorter than the band), nvBowtie's end-to-end and local schemes
+    and a scheme with unequal gap costs on the two strings, scores and sinks bit for bit; then a compacted list of jobs run in place through job_index
+    with the count on the device (the other jobs' outputs untouched)."""
+    from nvbio_amd.alignment import batch_banded_alignment_score_wave
+    rng = np.random.default_rng(8800 + band + ty)
+    pats, txts = random_pairs(rng, 3000, band)
+    pats[5], pats[6] = pats[5][:0], pats[6][:1]
+    for k in range(40, 120):
+        txts[k] = (txts[k] * 4)[:len(pats[k]) + band - (k % 4)]
+    for k in range(120, 140):                                                    # texts shorter than the band
+        pats[k] = pats[k][:int(rng.integers(1, 6))]; txts[k] = (txts[k] * 2)[:len(pats[k]) + int(rng.integers(0, 4))]
+    stored = O.StringSet.from_lists(pats, 4, True)
+    ht = O.StringSet.from_lists(txts, 2, True)
+    total = int(stored.begin[-1] + stored.length[-1])
+    quals = rng.integers(0, 50, total + 3, dtype=np.uint8)
+    p = nvb.PackedStringSet.from_host(stored.words, 4, True, stored.begin, stored.length, device=cuda)
+    t = nvb.PackedStringSet.from_host(ht.words, 2, True, ht.begin, ht.length, device=cuda)
+    dq = torch.from_numpy(quals).to(cuda)
+    maxp = int(stored.length.max())
+    n = len(pats)
+    for scheme in (nvb.SmithWatermanScoringScheme.local() if ty == nvb.LOCAL else nvb.SmithWatermanScoringScheme(),
+                   nvb.SmithWatermanScoringScheme(match=1 if ty == nvb.LOCAL else 0, mmp_min=1, mmp_max=9, read_gap_const=4, read_gap_coeff=2, ref_gap_const=7, ref_gap_coeff=1)):
+        st = scheme.struct()
+        lut = np.array([st.mismatch[q] for q in range(256)], dtype=np.int32)
+        s6 = (st.match, st.pattern_gap_open, st.pattern_gap_ext, st.text_gap_open, st.text_gap_ext, 0)
+        es, ek = O.batch_banded_gotoh_score_qual(band, ty, s6, lut, quals, stored, ht)
+        al = nvb.make_gotoh_aligner(ty, scheme)
+        ls, lk = nvb.batch_banded_alignment_score(band, al, p, t, quals=dq, max_pattern_length=maxp)
+        ws, wk = batch_banded_alignment_score_wave(band, al, p, t, dq, max_pattern_length=maxp)
+        torch.cuda.synchronize()
+        assert nvb.lib().nvbio_hip_last_kernel().decode() == "banded_gotoh_wave_kernel"
+        ws_, wk_ = ws.cpu().numpy(), wk.cpu().numpy().view(np.uint32)
+        bad = np.nonzero((ws_ != es) | (wk_ != ek).any(1))[0]
+        assert bad.size == 0, (band, ty, bad[:6], es[bad[:4]], ws_[bad[:4]], ek[bad[:4]], wk_[bad[:4]], [len(pats[b]) for b in bad[:4]], [len(txts[b]) for b in bad[:4]])
+        assert torch.equal(ws, ls) and torch.equal(wk, lk)
+        # a compacted list, the count on the device
+        pick = torch.from_numpy(np.sort(rng.choice(n, 700, replace=False)).astype(np.int32)).to(cuda)
+        os_, ok_ = torch.full((n,), 777, dtype=torch.int32, device=cuda), torch.full((n, 2), 5, dtype=torch.int32, device=cuda)
+        cnt = torch.tensor([600], dtype=torch.int32, device=cuda)
+        batch_banded_alignment_score_wave(band, al, p, t, dq, out_score=os_, out_sink=ok_, max_pattern_length=maxp, job_index=pick, n_on_device=cnt)
+        torch.cuda.synchronize()
+        done = pick[:600].long()
+        assert torch.equal(os_[done], ls[done]) and torch.equal(ok_[done], lk[done])
+        rest = torch.ones(n, dtype=torch.bool, device=cuda); rest[done] = False
+        assert bool((os_[rest] == 777).all()) and bool((ok_[rest] == 5).all())
