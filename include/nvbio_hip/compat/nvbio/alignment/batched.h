@@ -842,7 +842,7 @@ private:
         priv::build_job_table(stream, m_jobs, t, ps, ts, hs, 0u, NULL, &quals, &n_quals);
         if (ts.words == NULL || ps.words == NULL) { run_device(stream, hs, std::false_type()); return; }      // no job with a text: nothing for the tuned kernels to read
         const int err = scheme.banded_score(BAND_LEN, stream, t, ps, ts, quals, n_quals, hs);
-        if (err == 801) { run_device(stream, hs, std::false_type()); return; }       // outside the tuned kernels' contract (e.g. asymmetric linear gaps)
+        if (err == 801) { run_device(stream, hs, std::false_type()); return; }       // outside the tuned kernels' contract (a band they are not instantiated for is caught above; this is the belt to that)
         if (err != 0) fprintf(stderr, "compat banded score: err %d band %u n %u maxP %u maxT %u quals %p n_quals %llu ps{words %p n %llu bits %u begin %p len %p} ts{words %p n %llu begin %p len %p}\n", err, BAND_LEN, n,
                               priv::maxP_of(stream), priv::maxT_of(stream), (const void*)quals, (unsigned long long)n_quals, (const void*)ps.words, (unsigned long long)ps.n_words, ps.bits, (const void*)ps.begin, (const void*)ps.length,
                               (const void*)ts.words, (unsigned long long)ts.n_words, (const void*)ts.begin, (const void*)ts.length);
@@ -939,8 +939,8 @@ private:
         const uint32 n = stream.size();
         priv::tuned_scheme<stream_type> scheme;
         typedef decltype(typename stream_type::context_type().sink) sink_type;
-        // the tuned sweep keeps <= 1024 rows in a wave
-        if (priv::maxP_of(stream) > 1024u || !scheme.init(stream) || !scheme.template sink_fits<sink_type>(stream)) { run_device(stream, temp_size, temp, hs, std::false_type()); return; }
+        // (patterns beyond the 1 024 rows a wave holds run in stripes: csrc/full_gotoh_striped.hip)
+        if (!scheme.init(stream) || !scheme.template sink_fits<sink_type>(stream)) { run_device(stream, temp_size, temp, hs, std::false_type()); return; }
         priv::job_table t; nvbio_hip_string_set ps, ts; const uint8* quals = NULL; uint64 n_quals = 0;
         priv::build_job_table(stream, m_jobs, t, ps, ts, hs, 0u, NULL, &quals, &n_quals);
         if (ts.words == NULL || ps.words == NULL) { run_device(stream, temp_size, temp, hs, std::false_type()); return; }
@@ -1078,7 +1078,7 @@ struct traceback_runner
         const uint64 tb = band ? nvbio_hip_banded_gotoh_traceback_temp_bytes(band, maxP, n) : nvbio_hip_gotoh_traceback_temp_bytes(maxP, maxT, n);
         uint8* temp = m_temp.reserve(tb + 16u, hs);
         const int err = scheme.traceback(band, stream, t, ps, ts, quals, n_quals, source, cigar, stride, cigar_len, temp, tb, hs);
-        if (err == 801) { run_device(stream, hs, std::false_type()); return; }     // e.g. asymmetric linear gaps, values beyond int16
+        if (err == 801) { run_device(stream, hs, std::false_type()); return; }     // e.g. asymmetric linear gaps (scores run tuned, tracebacks do not), 8-bit patterns, values beyond int16
         if (err != 0) fprintf(stderr, "compat traceback: err %d band %u n %u maxP %u maxT %u stride %u tb %llu quals %p n_quals %llu ps{words %p n %llu bits %u} ts{words %p n %llu}\n", err, band, n, maxP, maxT, stride,
                               (unsigned long long)tb, (const void*)quals, (unsigned long long)n_quals, (const void*)ps.words, (unsigned long long)ps.n_words, ps.bits, (const void*)ts.words, (unsigned long long)ts.n_words);
         check(err, "nvbio_hip_*_traceback");

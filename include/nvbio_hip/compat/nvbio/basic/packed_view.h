@@ -48,5 +48,26 @@ struct packed_view< vector_view< PackedStream<I, uint8, B, E, X>, VI > >
     NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static void where(const view_type& v, uint64& word0, uint32& first) { stream_where::where(v.begin(), word0, first); }
 };
 
+/// ... and a string of BYTES in memory (vector_view<const uint8*>, what the reference's own tests align: nvbio-test/alignment_test.cu:242-335):
+/// an 8-bit little-endian "packed" stream whose first word is the one holding the first byte.  The tuned kernels take such PATTERNS
+/// (nvbio_hip.h: bits == 8); texts stay 2-bit.
+template <typename It> struct byte_string_pointer { static const bool ok = false; };
+template <> struct byte_string_pointer<const uint8*> { static const bool ok = true; NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static const uint8* get(const uint8* p) { return p; } };
+template <> struct byte_string_pointer<uint8*>       { static const bool ok = true; NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static const uint8* get(uint8* p) { return p; } };
+template <> struct byte_string_pointer< cuda::ldg_pointer<uint8> > { static const bool ok = true; NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static const uint8* get(cuda::ldg_pointer<uint8> p) { return p.base; } };
+template <typename I, typename VI>
+struct packed_view< vector_view<I, VI> >
+{
+    static const bool   ok   = byte_string_pointer<I>::ok;
+    static const uint32 BITS = 8u;
+    static const bool   BE   = false;
+    typedef vector_view<I, VI> view_type;
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE static void where(const view_type& v, uint64& word0, uint32& first)
+    {
+        const uintptr_t a = reinterpret_cast<uintptr_t>(byte_string_pointer<I>::get(v.begin()));
+        word0 = uint64(a) / 4u; first = uint32(a & 3u);
+    }
+};
+
 } // namespace priv
 } // namespace nvbio

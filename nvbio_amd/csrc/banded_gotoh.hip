@@ -54,6 +54,9 @@ thread_local const char* g_last_kernel = "";
     extern template hipError_t launch_band_width<B, QualArgs>(const GotohParams&, const QualArgs&, int, bool, hipStream_t);
 NVB_DECL(3) NVB_DECL(5) NVB_DECL(7) NVB_DECL(15) NVB_DECL(31)
 #undef NVB_DECL
+#define NVB_DECL(B) extern template hipError_t launch_band_width_asym<B>(const GotohParams&, int, bool, hipStream_t);
+NVB_DECL(3) NVB_DECL(5) NVB_DECL(7) NVB_DECL(15) NVB_DECL(31)
+#undef NVB_DECL
 #define NVB_DECL(B) \
     extern template hipError_t launch_band_width_bounded<B, NoQual>(const GotohParams&, const NoQual&, const BoundArgs&, int, bool, hipStream_t); \
     extern template hipError_t launch_band_width_bounded<B, QualArgs>(const GotohParams&, const QualArgs&, const BoundArgs&, int, bool, hipStream_t);
@@ -69,6 +72,18 @@ static hipError_t launch_bounded(const GotohParams& p, const QA& qa, const Bound
     case 7:  return launch_band_width_bounded<7, QA>(p, qa, ba, type, width16, s);
     case 15: return launch_band_width_bounded<15, QA>(p, qa, ba, type, width16, s);
     case 31: return launch_band_width_bounded<31, QA>(p, qa, ba, type, width16, s);
+    default: return hipErrorNotSupported;
+    }
+}
+
+static hipError_t launch_asym(const GotohParams& p, int type, uint32_t band, bool width16, hipStream_t s)
+{
+    switch (band) {
+    case 3:  return launch_band_width_asym<3>(p, type, width16, s);
+    case 5:  return launch_band_width_asym<5>(p, type, width16, s);
+    case 7:  return launch_band_width_asym<7>(p, type, width16, s);
+    case 15: return launch_band_width_asym<15>(p, type, width16, s);
+    case 31: return launch_band_width_asym<31>(p, type, width16, s);
     default: return hipErrorNotSupported;
     }
 }
@@ -111,7 +126,7 @@ static uint32_t max_len_16bit(int32_t match, int32_t best_pair /* max substituti
 template <typename QA>
 static int banded_gotoh_dispatch(nvb::GotohParams& p, const QA& qa, int64_t max_abs_cost, int32_t best_pair, int32_t type, uint32_t band_len,
                                  const nvbio_hip_string_set* patterns, hipStream_t s, const char* tag16, const char* tag32, const bool views = false,
-                                 const nvb::BoundArgs* bound = nullptr)
+                                 const nvb::BoundArgs* bound = nullptr, const bool asym = false)
 {
     using namespace nvb;
     // NVBIO_HIP_FORCE_32BIT=1 disables the 16-bit kernels (used by the tests to cover both widths)
@@ -138,6 +153,7 @@ static int banded_gotoh_dispatch(nvb::GotohParams& p, const QA& qa, int64_t max_
     // jobs with pattern_len <= lim16 : 16-bit arithmetic;  longer ones : 32-bit arithmetic
     // the bounded form (banded_gotoh_bounded.h): persistent waves over a work counter, zeroed before each of the (at most two) launches
     auto go = [&](const bool width16) -> hipError_t {
+        if (asym)   return launch_asym(p, type, band_len, width16, s);
         if (!bound) return launch<QA>(p, qa, type, band_len, width16, s);
         if (hipError_t z = hipMemsetAsync(bound->counter, 0, 4u, s)) return z;
         return launch_bounded<QA>(p, qa, *bound, type, band_len, width16, s);
@@ -160,7 +176,7 @@ static int check_banded_args(int32_t type, uint32_t band_len, const nvbio_hip_st
 {
     if (!patterns || !texts) return hipErrorInvalidValue;
     if (type < 0 || type > 2) return hipErrorInvalidValue;
-    if (!(patterns->bits == 2 || patterns->bits == 4) || texts->bits != 2) return hipErrorNotSupported;
+    if (!(patterns->bits == 2 || patterns->bits == 4 || patterns->bits == 8) || texts->bits != 2) return hipErrorNotSupported;
     if (!(band_len == 3 || band_len == 5 || band_len == 7 || band_len == 15 || band_len == 31)) return hipErrorNotSupported;
     return hipSuccess;
 }
@@ -223,6 +239,7 @@ NVB_API int nvbio_hip_banded_gotoh_score_qual_views(
     if (n == 0) return hipSuccess;
     if (int e = check_banded_ptrs(patterns, texts, out_score, out_sink)) return e;
     if (!quals || n_quals < 4) return hipErrorInvalidValue;
+    if (pattern_flags && patterns->bits == 8u) return hipErrorNotSupported;      // reversed / complemented views are a feature of the packed read streams
 
     GotohParams p;
     p.pat = make_string_set(patterns);
@@ -260,6 +277,7 @@ NVB_API int nvbio_hip_banded_gotoh_score_qual_bounded(
     if (n == 0) return hipSuccess;
     if (int e = check_banded_ptrs(patterns, texts, out_score, out_sink)) return e;
     if (!quals || n_quals < 4) return hipErrorInvalidValue;
+    if (pattern_flags && patterns->bits == 8u) return hipErrorNotSupported;      // reversed / complemented views are a feature of the packed read streams
 
     GotohParams p;
     p.pat = make_string_set(patterns);
@@ -304,9 +322,30 @@ NVB_API int nvbio_hip_banded_sw_score(
     uint32_t n, int32_t* out_score, uint32_t* out_sink, void* stream)
 {
     if (!scheme) return hipErrorInvalidValue;
-    if (scheme->deletion != scheme->insertion) return hipErrorNotSupported;
-    const nvbio_hip_gotoh_scheme g = { scheme->match, scheme->mismatch, scheme->deletion, scheme->deletion };
-    return nvbio_hip_banded_gotoh_score(&g, type, band_len, patterns, texts, max_pattern_len, max_text_len, n, out_score, out_sink, stream);
+    if (scheme->deletion == scheme->insertion)
+    {
+        const nvbio_hip_gotoh_scheme g = { scheme->match, scheme->mismatch, scheme->deletion, scheme->deletion };
+        return nvbio_hip_banded_gotoh_score(&g, type, band_len, patterns, texts, max_pattern_len, max_text_len, n, out_score, out_sink, stream);
+    }
+    // deletion != insertion: the move from the previous row (band[j+1] + G, :413 / :432) costs `deletion`, the move along the row
+    // (band[j-1] + I, :433 / :459) `insertion`, row zero of a GLOBAL alignment j * deletion (:53) -- the kernels' asymmetric instances
+    (void)max_text_len;
+    using namespace nvb;
+    if (int e = check_banded_args(type, band_len, patterns, texts)) return e;
+    if (n == 0) return hipSuccess;
+    if (int e = check_banded_ptrs(patterns, texts, out_score, out_sink)) return e;
+    GotohParams p;
+    p.pat = make_string_set(patterns);
+    p.txt = make_string_set(texts);
+    p.match = scheme->match; p.mismatch = scheme->mismatch;
+    p.gap_open = p.gap_ext = scheme->insertion;
+    p.f_gap_open = p.f_gap_ext = scheme->deletion;
+    p.txt_gap_open = p.txt_gap_ext = scheme->deletion;
+    p.n = n; p.out_score = out_score; p.out_sink = out_sink; p.n_dev = nullptr; p.out_index = nullptr; p.gate = nullptr; p.gate_limit = 0;
+    p.stage_pw = max_pattern_len; p.stage_tw = 0;
+    const int64_t A = std::max(std::max(iabs64(scheme->match), iabs64(scheme->mismatch)), std::max(iabs64(scheme->deletion), iabs64(scheme->insertion)));
+    return banded_gotoh_dispatch(p, NoQual(), A, std::max(scheme->match, scheme->mismatch), type, band_len, patterns, to_stream(stream),
+                                 "banded_gotoh_score_kernel<A16X>", "banded_gotoh_score_kernel<A32X>", false, nullptr, true);
 }
 
 // Device memory for the C++ host layer's containers and the drop-in layer's vectors: hipMalloc'ed blocks kept in a per-device cache.

@@ -1,0 +1,3 @@
+// explicit instantiation: band 3, direction-dependent gap costs (A16X / A32X)
+#include "banded_gotoh_impl.h"
+namespace nvb { template hipError_t launch_band_width_asym<3>(const GotohParams&, int, bool, hipStream_t); }

@@ -63,7 +63,7 @@ banded_gotoh_score_bounded_kernel(const GotohParams p, const QA qa, const BoundA
     const uint64_t below = (1ull << lane) - 1ull;
 
     DPConsts<A> k;
-    k.Go = A::cnst(p.gap_open * (1 << SH)); k.Ge = A::cnst(p.gap_ext * (1 << SH));
+    k.Go = A::cnst(p.gap_open * (1 << SH)); k.Ge = A::cnst(p.gap_ext * (1 << SH)); k.GeF = k.dF = A::cnst(0); k.bytes = false;
     k.sM = A::cnst((p.match - p.gap_open) * (1 << SH)); k.sX = A::cnst((p.mismatch - p.gap_open) * (1 << SH));
     k.inf = Sentinel<A>::get(p.gap_open, p.gap_ext, p.txt_gap_open, p.txt_gap_ext, SH);
     k.sMM = (uint32_t(k.sM) & 0xFFFFu) * 0x10001u; k.sXX = (uint32_t(k.sX) & 0xFFFFu) * 0x10001u;

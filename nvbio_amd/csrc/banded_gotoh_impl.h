@@ -11,6 +11,8 @@ struct GotohParams {
     StringSet pat, txt;
     int32_t   match, mismatch, gap_open, gap_ext;   // gap_* = the scheme's pattern_gap_open / _extension
     int32_t   txt_gap_open, txt_gap_ext;            // text_gap_* : GLOBAL row-zero init and the infimum only
+    int32_t   f_gap_open, f_gap_ext;                // the asymmetric instances (A16X / A32X) only: the costs of the move from the previous row (F);
+                                                    // gap_* are then the costs of the move along the row (E).  Linear SW gaps: open == ext
     uint32_t  n;
     uint32_t  len_lo, len_hi;     // this launch handles jobs with len_lo <= pattern_len <= len_hi
     uint32_t  stage_pw, stage_tw; // words of pattern / text each lane stages in LDS (0 = read HBM per block)
@@ -51,6 +53,7 @@ template <int BAND> struct BandTraits {
 // ---------------------------------------------------------------------------
 struct A32 {
     typedef int32_t T;
+    static constexpr bool ASYM = false;      // one pair of gap costs for both directions (the Gotoh schemes)
     static __device__ __forceinline__ T   add(T a, T b)        { return a + b; }
     static __device__ __forceinline__ T   mx(T a, T b)         { return max(a, b); }
     static __device__ __forceinline__ T   mx3(T a, T b, T c)   { return max(max(a, b), c); }
@@ -70,7 +73,7 @@ struct A32 {
     template <int TYPE, int J, bool FAST>
     static __device__ __forceinline__ void cell(T& Fj, const T Fnext, const T HGnext, T& HGj, T& E, T& rowkey,
                                                 const uint32_t g, const uint32_t q, const T Go, const T Ge, const T sM, const T sX,
-                                                const uint32_t, const uint32_t)
+                                                const uint32_t, const uint32_t, const T = 0, const T = 0)
     {
         Fj = max(Fnext + Ge, HGnext);
         const T diag = HGj + (g == q ? sM : sX);
@@ -82,6 +85,7 @@ struct A32 {
 };
 struct A16 {
     typedef uint32_t T;
+    static constexpr bool ASYM = false;
     static __device__ __forceinline__ T add(T a, T b)      { T r; asm("v_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
     static __device__ __forceinline__ T mx(T a, T b)       { T r; asm("v_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
     static __device__ __forceinline__ T mx3(T a, T b, T c) { return mx(mx(a, b), c); }
@@ -107,7 +111,7 @@ struct A16 {
     template <int TYPE, int J, bool FAST>
     static __device__ __forceinline__ void cell(T& Fj, const T Fnext, const T HGnext, T& HGj, T& E, T& rowkey,
                                                 const uint32_t g, const uint32_t q, const T Go, const T Ge, const T sM, const T sX,
-                                                const uint32_t tlo, const uint32_t thi)
+                                                const uint32_t tlo, const uint32_t thi, const T = 0, const T = 0)
     {
         T d, h, e2;
         if (FAST && TYPE == NVBIO_HIP_LOCAL)
@@ -172,6 +176,31 @@ struct A16 {
     static __device__ __forceinline__ T min_value()        { return 0x8000u; }
 };
 
+// Direction-dependent gap costs: SmithWatermanAligner with deletion != insertion (sw_banded_inl.h:378-379, :413, :432-433 -- the move from
+// the previous row costs `deletion`, the move along the row `insertion`).  The same cell with F taking its own pair of costs:
+//   F = max(F' + GeF, H' + GoF) = max(F' + GeF, HG' + dF),  dF = GoF - Go      (HG = H + Go serves E and the diagonal as before)
+// one more add per cell than the symmetric block, left to the compiler's scheduler (the primitive ops are the same 16-bit / 32-bit ones).
+template <typename Base>
+struct Asym : Base {
+    typedef typename Base::T T;
+    static constexpr bool ASYM = true;
+    template <int TYPE, int J, bool FAST>
+    static __device__ __forceinline__ void cell(T& Fj, const T Fnext, const T HGnext, T& HGj, T& E, T& rowkey,
+                                                const uint32_t g, const uint32_t q, const T Go, const T Ge, const T sM, const T sX,
+                                                const uint32_t tlo, const uint32_t thi, const T GeF, const T dF)
+    {
+        const T sub = (FAST && Base::TABLE) ? Base::subst(tlo, thi, g) : (g == q ? sM : sX);
+        Fj = Base::mx(Base::add(Fnext, GeF), Base::add(HGnext, dF));
+        const T diag = Base::add(HGj, sub);
+        T hi = Base::mx(Base::mx(Fj, E), diag);
+        if (TYPE == NVBIO_HIP_LOCAL) { hi = Base::clamp0(hi); rowkey = Base::mx(rowkey, Base::template key<J>(hi)); }
+        HGj = Base::add(hi, Go);
+        E = Base::mx(Base::add(E, Ge), HGj);
+    }
+};
+typedef Asym<A32> A32X;
+typedef Asym<A16> A16X;
+
 template <int BAND, typename A>
 struct DPState {
     typename A::T HG[BAND];                  // (H + G_o) of the previous row  [x32 for LOCAL]
@@ -184,6 +213,8 @@ struct DPState {
 template <typename A>
 struct DPConsts {
     typename A::T Go, Ge, sM, sX, inf;       // sM/sX = match/mismatch - G_o ; inf = the infimum sentinel
+    typename A::T GeF, dF;                   // A::ASYM: F's extension cost and (F's opening cost - G_o)
+    bool bytes;                              // the patterns are 8-bit strings
     uint32_t sMM, sXX;                       // table arithmetic: sM / sX in both halves of a dword
 };
 
@@ -197,7 +228,7 @@ struct CellLoop {
         const uint32_t g = st.tc[BT::RING ? ((R + J) & 15) : J];
         if (!BT::RING) st.tc[J - 1] = g;                                   // :542
         const T fnext = (J + 1 == BAND - 1) ? k.inf : st.F[J + 1 < BAND - 1 ? J + 1 : 0];
-        A::template cell<TYPE, J, FAST>(st.F[J], fnext, st.HG[J + 1], st.HG[J], E, rowkey, g, q, k.Go, k.Ge, k.sM, sX, tlo, thi);
+        A::template cell<TYPE, J, FAST>(st.F[J], fnext, st.HG[J + 1], st.HG[J], E, rowkey, g, q, k.Go, k.Ge, k.sM, sX, tlo, thi, k.GeF, k.dF);
         CellLoop<BAND, TYPE, A, FAST, R, J + 1, END>::run(st, k, sX, E, rowkey, q, tlo, thi);
     }
 };
@@ -221,8 +252,8 @@ __device__ __forceinline__ void dp_row(DPState<BAND, A>& st, const DPConsts<A>& 
 
     // j == 0  (gotoh_banded_inl.h:483-517)
     {
-        const T fnext = A::add((1 == BAND - 1) ? k.inf : st.F[1 < BAND - 1 ? 1 : 0], k.Ge);
-        st.F[0] = A::mx(fnext, st.HG[1]);
+        const T fnext = A::add((1 == BAND - 1) ? k.inf : st.F[1 < BAND - 1 ? 1 : 0], A::ASYM ? k.GeF : k.Ge);
+        st.F[0] = A::mx(fnext, A::ASYM ? A::add(st.HG[1], k.dF) : st.HG[1]);
         const uint32_t g = st.tc[BT::RING ? (R & 15) : 0];
         const T diag = A::add(st.HG[0], FAST ? A::subst(tlo, thi, g) : (g == q ? k.sM : sX));
         T hi = A::mx(st.F[0], diag);
@@ -248,7 +279,7 @@ __device__ __forceinline__ void dp_row(DPState<BAND, A>& st, const DPConsts<A>& 
         // F[BAND-1] is `infimum` at every row (:586), so the cell next to the band edge sees it as F[j+1]
         const T fnext = (j + 1 == BAND - 1) ? k.inf : st.F[j + 1 < BAND - 1 ? j + 1 : 0];
         switch (j) {   // the sink key's column is an instruction constant
-            #define NVB_CELL(J) case J: A::template cell<TYPE, J, FAST>(st.F[j], fnext, st.HG[j + 1], st.HG[j], E, rowkey, g, q, k.Go, k.Ge, k.sM, sX, tlo, thi); break;
+            #define NVB_CELL(J) case J: A::template cell<TYPE, J, FAST>(st.F[j], fnext, st.HG[j + 1], st.HG[j], E, rowkey, g, q, k.Go, k.Ge, k.sM, sX, tlo, thi, k.GeF, k.dF); break;
             NVB_CELL(1) NVB_CELL(2) NVB_CELL(3) NVB_CELL(4) NVB_CELL(5) NVB_CELL(6) NVB_CELL(7) NVB_CELL(8) NVB_CELL(9) NVB_CELL(10)
             NVB_CELL(11) NVB_CELL(12) NVB_CELL(13) NVB_CELL(14)
             #undef NVB_CELL
@@ -309,7 +340,8 @@ struct RowUnrollN {
                 tlo = (k.sMM & m.x) | (xx & ~m.x);
                 thi = (k.sMM & m.y) | (xx & ~m.y);
             }
-            dp_row<BAND, TYPE, A, FAST, R>(st, k, sX, i, FAST ? 0u : A::enc(qr), g, g_store, tlo, thi);
+            // (an 8-bit pattern's byte 255 arrives as code 15, fetch16_8bit: it equals a text position past the end, and nothing else)
+            dp_row<BAND, TYPE, A, FAST, R>(st, k, sX, i, FAST ? 0u : ((k.bytes && qr == 15u) ? A::enc_none() : A::enc(qr)), g, g_store, tlo, thi);
         }
         RowUnrollN<BAND, TYPE, A, QUAL, FAST, R + 1, END>::run(st, k, i0, M, N, P, T, Q, lut, masks);
     }
@@ -337,7 +369,7 @@ __device__ __forceinline__ uint4 fetch_quals16(const NoQual&, uint64_t) { return
 
 __device__ __forceinline__ uint64_t fetch_pattern16(const Stream& s, uint64_t sym)
 {
-    return (s.bits == 4) ? fetch16_4bit(s, sym) : expand_2to4(fetch16_2bit(s, sym));
+    return (s.bits == 4) ? fetch16_4bit(s, sym) : (s.bits == 8) ? fetch16_8bit(s, sym) : expand_2to4(fetch16_2bit(s, sym));
 }
 
 __host__ __device__ __forceinline__ uint32_t stage_words_pattern(uint32_t off, uint32_t M, uint32_t bits);
@@ -415,6 +447,8 @@ template <> struct Sentinel<A32> {
 template <> struct Sentinel<A16> {   // infimum + G_e == -32768 exactly: the add cannot wrap
     static __device__ __forceinline__ uint32_t get(int32_t, int32_t Ge, int32_t, int32_t, int sh) { return A16::cnst(-32768 - Ge * (1 << sh)); }
 };
+template <> struct Sentinel<A32X> : Sentinel<A32> {};
+template <> struct Sentinel<A16X> : Sentinel<A16> {};      // (the caller passes F's extension cost: the only step ever added to the sentinel)
 
 // Words a lane touches over the whole DP: the last 16-symbol group fetched starts at ceil16(M) (the
 // prefetch past the last block) for the pattern and at ceil16(M) + BAND - 1 for the text; a group
@@ -422,7 +456,7 @@ template <> struct Sentinel<A16> {   // infimum + G_e == -32768 exactly: the add
 __host__ __device__ __forceinline__ uint32_t stage_words_pattern(uint32_t off, uint32_t M, uint32_t bits)
 {
     const uint32_t c16 = (M + 15u) & ~15u;
-    return ((off + c16 + (bits == 4 ? 24u : 32u)) * bits + 31u) / 32u;
+    return ((off + c16 + (bits == 4 ? 24u : bits == 8 ? 20u : 32u)) * bits + 31u) / 32u;
 }
 __host__ __device__ __forceinline__ uint32_t stage_words_text(uint32_t off, uint32_t M, uint32_t band)
 {
@@ -514,7 +548,9 @@ banded_gotoh_score_kernel(const GotohParams p, const QA qa)
         DPConsts<A> k;
         k.Go = A::cnst(p.gap_open * (1 << SH)); k.Ge = A::cnst(p.gap_ext * (1 << SH));
         k.sM = A::cnst((p.match - p.gap_open) * (1 << SH)); k.sX = A::cnst((p.mismatch - p.gap_open) * (1 << SH));
-        k.inf = Sentinel<A>::get(p.gap_open, p.gap_ext, p.txt_gap_open, p.txt_gap_ext, SH);
+        k.inf = Sentinel<A>::get(p.gap_open, A::ASYM ? p.f_gap_ext : p.gap_ext, p.txt_gap_open, p.txt_gap_ext, SH);
+        k.GeF = A::cnst((A::ASYM ? p.f_gap_ext : 0) * (1 << SH)); k.dF = A::cnst((A::ASYM ? p.f_gap_open - p.gap_open : 0) * (1 << SH));
+        k.bytes = (p.pat.s.bits == 8u);
         k.sMM = (uint32_t(k.sM) & 0xFFFFu) * 0x10001u; k.sXX = (uint32_t(k.sX) & 0xFFFFu) * 0x10001u;
         const T infimum = k.inf;
 
@@ -610,6 +646,13 @@ template <int BAND, typename QA>
 hipError_t launch_band_width(const GotohParams& p, const QA& qa, int type, bool width16, hipStream_t s)
 {
     return width16 ? launch_band<BAND, A16, QA>(p, qa, type, s) : launch_band<BAND, A32, QA>(p, qa, type, s);
+}
+
+// the asymmetric instances: no qualities (SimpleSmithWatermanScheme)
+template <int BAND>
+hipError_t launch_band_width_asym(const GotohParams& p, int type, bool width16, hipStream_t s)
+{
+    return width16 ? launch_band<BAND, A16X, NoQual>(p, NoQual(), type, s) : launch_band<BAND, A32X, NoQual>(p, NoQual(), type, s);
 }
 
 } // namespace nvb

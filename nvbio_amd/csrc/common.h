@@ -85,6 +85,32 @@ __device__ __forceinline__ uint64_t fetch16_4bit(const Stream& s, uint64_t sym)
     const uint32_t lo = funnel(w0, w1, sh), hi = funnel(w1, w2, sh);
     return (uint64_t(hi) << 32) | lo;
 }
+// 16 symbols of an 8-bit stream as 16 nibbles.  The text is 2-bit, so all that matters of a pattern byte is WHICH text symbol it
+// equals, if any: 0..3 stay, 255 -- the value the reference compares a text position past the end as (gotoh_banded_inl.h:580) --
+// becomes 15, any other byte 4 (equal to nothing)
+__device__ __forceinline__ uint64_t fetch16_8bit(const Stream& s, uint64_t sym)
+{
+    const uint64_t k  = sym >> 2;
+    const uint32_t sh = (uint32_t(sym) & 3u) << 3;
+    uint32_t w[5];
+    #pragma unroll
+    for (int i = 0; i < 5; ++i) { w[i] = ld_word(s, k + i); if (s.big_endian) w[i] = __builtin_bswap32(w[i]); }
+    uint64_t out = 0;
+    #pragma unroll
+    for (int i = 0; i < 4; ++i)
+    {
+        const uint32_t b = funnel(w[i], w[i + 1], sh);
+        const uint32_t t = b & 0xFCFCFCFCu;                                                    // bits that make a byte >= 4
+        const uint32_t big = ((((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t) & 0x80808080u) >> 7;      // 0x01 per byte >= 4
+        const uint32_t n = ~b;
+        const uint32_t ff = ((((n & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | n) & 0x80808080u) >> 7;       // 0x01 per byte != 255
+        uint32_t v = ((b & 0x03030303u) & ~(big * 3u)) | (big << 2) | ((big & ~ff) * 15u);     // 255: 4 | 15 = 15
+        v = (v | (v >> 4)) & 0x00FF00FFu;
+        v = (v | (v >> 8)) & 0x0000FFFFu;
+        out |= uint64_t(v) << (16 * i);
+    }
+    return out;
+}
 // spread 16 2-bit symbols to 16 nibbles
 __device__ __forceinline__ uint64_t expand_2to4(uint32_t v)
 {
@@ -108,6 +134,17 @@ __device__ __forceinline__ uint32_t get_symbol(const Stream& s, uint64_t sym)
         const uint32_t w = ld_word(s, sym >> 2), k = uint32_t(sym) & 3u;
         return (w >> (s.big_endian ? 24u - 8u * k : 8u * k)) & 255u;
     }
+}
+
+// A pattern with no rows under the text-blocking exit test (gotoh_inl.h:1203-1214): the column maximum stays at its initial value, so
+// after each block of BLK text columns that is not the last one the test reads -2^30 + missing_cols * match < min_score.  Returns the
+// first block that fires (the sink saw the row above the matrix up to that block's end), 0xFFFFFFFF if none does.
+__host__ __device__ inline uint32_t empty_pattern_exit_block(uint32_t N, uint32_t BLK, int32_t match, int32_t min_score)
+{
+    const uint32_t nb = BLK * ((N + BLK - 1u) / BLK), end_block = nb > BLK ? nb : BLK;
+    for (uint32_t block = 0; block + BLK < end_block; block += BLK)
+        if (-(1 << 30) + int32_t(N - block - BLK) * match < min_score) return block;
+    return 0xFFFFFFFFu;
 }
 
 struct StringSet {

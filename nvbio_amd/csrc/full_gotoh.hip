@@ -28,8 +28,10 @@
 //    (:1212-1214): the column maximum flows down the lanes with the data; when the test fires the
 //    wave recomputes the prefix it covers, so the sink holds exactly what the reference's holds.
 #include "common.h"
+#include "full_gotoh_striped.h"
 #include <algorithm>
 #include <stdlib.h>
+#include <string.h>
 
 namespace nvb {
 
@@ -640,10 +642,9 @@ full_gotoh_score_kernel(const FullParams p)
     else if (M == 0u)
     {
         // no rows: only the row above the matrix is ever reported (:1203-1207, :1404-1421)
-        const uint32_t nb = 8u * ((N + 7u) / 8u);
-        const bool has_full_block = nb > 8u;
-        const bool exits = check && has_full_block && (-(1 << 30) + int32_t(N - 8u) * p.match < min_score);
-        if (exits) { ok = 0u; if (TYPE == NVBIO_HIP_SEMI_GLOBAL) { score = 0; sx = 8u; sy = 0u; } }
+        const uint32_t xb = check ? empty_pattern_exit_block(N, 8u, p.match, min_score) : 0xFFFFFFFFu;
+        const bool exits = xb != 0xFFFFFFFFu;
+        if (exits) { ok = 0u; if (TYPE == NVBIO_HIP_SEMI_GLOBAL) { score = 0; sx = xb + 8u; sy = 0u; } }
         else if (N > 0u) {
             if (TYPE == NVBIO_HIP_SEMI_GLOBAL) { score = 0; sx = N; sy = 0u; }
             if (TYPE == NVBIO_HIP_GLOBAL)      { score = p.row_go + p.row_ge * int32_t(N - 1u); sx = N; sy = 0u; }
@@ -751,9 +752,9 @@ full_gotoh_score_multi_kernel(const FullParams p, const uint32_t n_seg, const ui
         else if (M == 0u)
         {
             swept = false;
-            const uint32_t nb = 8u * ((N + 7u) / 8u);
-            const bool exits = check && nb > 8u && (-(1 << 30) + int32_t(N - 8u) * p.match < min_score);
-            if (exits) { ok = 0u; if (TYPE == NVBIO_HIP_SEMI_GLOBAL) { score = 0; sx = 8u; sy = 0u; } }
+            const uint32_t xb = check ? empty_pattern_exit_block(N, 8u, p.match, min_score) : 0xFFFFFFFFu;
+            const bool exits = xb != 0xFFFFFFFFu;
+            if (exits) { ok = 0u; if (TYPE == NVBIO_HIP_SEMI_GLOBAL) { score = 0; sx = xb + 8u; sy = 0u; } }
             else if (N > 0u && TYPE == NVBIO_HIP_SEMI_GLOBAL) { score = 0; sx = N; sy = 0u; }
             else if (N > 0u && TYPE == NVBIO_HIP_GLOBAL)      { score = p.row_go + p.row_ge * int32_t(N - 1u); sx = N; sy = 0u; }
         }
@@ -981,6 +982,40 @@ static hipError_t launch_ed(const FullParams& p, int type, hipStream_t s)
 
 using namespace nvb;
 
+// SimpleSmithWatermanScheme with deletion != insertion, full matrix (sw_inl.h:881-1222 text blocking, :417-760 pattern blocking): the move
+// along the text costs `deletion`, the move down the pattern `insertion`; the column before the text is insertion * (r + 1), the row
+// above the pattern deletion * (c + 1).  On the striped sweep, whatever the pattern length.
+static int sw_asym_score(const nvbio_hip_sw_scheme* sw, int32_t type, uint32_t pattern_blocking,
+                         const nvbio_hip_string_set* patterns, const nvbio_hip_string_set* texts, uint32_t max_pattern_len, uint32_t max_text_len,
+                         uint32_t n, int32_t* out_score, uint32_t* out_sink, uint8_t* out_ok, void* stream)
+{
+    if (!patterns || !texts) return hipErrorInvalidValue;
+    if (type < 0 || type > 2) return hipErrorInvalidValue;
+    if (!(patterns->bits == 2 || patterns->bits == 4 || patterns->bits == 8) || texts->bits != 2) return hipErrorNotSupported;
+    if (n == 0) return hipSuccess;
+    if (!out_score || !out_sink || !patterns->words || !texts->words || !patterns->begin || !texts->begin ||
+        patterns->n_words == 0 || texts->n_words == 0) return hipErrorInvalidValue;
+    const uint32_t maxM = patterns->length ? max_pattern_len : patterns->fixed_length;
+    const uint32_t maxN = texts->length ? max_text_len : texts->fixed_length;
+    if (maxM == 0 || maxN == 0) return hipErrorNotSupported;
+    auto iabs = [](int32_t v) { return v < 0 ? -int64_t(v) : int64_t(v); };
+    const int64_t A = std::max(std::max(iabs(sw->match), iabs(sw->mismatch)), std::max(iabs(sw->deletion), iabs(sw->insertion)));
+    const int64_t span = (type == NVBIO_HIP_GLOBAL) ? int64_t(maxM) + maxN + 4 : int64_t(maxM) + 4;
+    const bool inside16 = sw->deletion <= 0 && sw->insertion <= 0 && span * A < 30000;
+    // pattern blocking keeps its int16 line over the text, which the sweep does not model: admitted while no value can leave int16
+    if (pattern_blocking && !inside16) return hipErrorNotSupported;
+    StripeParams sp;
+    sp.pat = make_string_set(patterns); sp.txt = make_string_set(texts);
+    sp.match = sw->match; sp.mismatch = sw->mismatch;
+    sp.e_go = sp.e_ge = sw->deletion; sp.f_go = sp.f_ge = sw->insertion;
+    sp.col_go = sp.col_ge = sw->insertion; sp.row_go = sp.row_ge = sw->deletion;
+    sp.infimum = -32768 - std::min(std::min(sw->deletion, sw->insertion), 0);
+    sp.linear = 1u; sp.trunc = pattern_blocking ? 0u : 1u; sp.blk_log2 = 4u; sp.pattern_blocking = pattern_blocking;
+    sp.min_score = nullptr; sp.n = n; sp.out_score = out_score; sp.out_sink = out_sink; sp.out_ok = out_ok; sp.max_n = maxN;
+    g_last_kernel = "full_gotoh_striped_kernel<sw,asymmetric>";
+    return launch_striped(sp, type, maxM, to_stream(stream));
+}
+
 struct QualPart { const uint8_t* quals; uint64_t n_quals; const int32_t* mismatch; int32_t text_gap_open, text_gap_ext; };
 
 struct FullJobs { const uint32_t* n_dev; const uint32_t* job_index; const uint32_t* gate; uint32_t gate_limit; int wave_form; };
@@ -993,15 +1028,16 @@ static int full_score_core(
 {
     if (!scheme || !patterns || !texts) return hipErrorInvalidValue;
     if (type < 0 || type > 2) return hipErrorInvalidValue;
-    if (!(patterns->bits == 2 || patterns->bits == 4) || texts->bits != 2) return hipErrorNotSupported;
+    if (!(patterns->bits == 2 || patterns->bits == 4 || patterns->bits == 8) || texts->bits != 2) return hipErrorNotSupported;
     if (n == 0) return hipSuccess;
     if (!out_score || !out_sink || !patterns->words || !texts->words || !patterns->begin || !texts->begin ||
         patterns->n_words == 0 || texts->n_words == 0) return hipErrorInvalidValue;
     // the systolic mapping holds the whole pattern in one wave's registers: the caller states its bound
     const uint32_t maxM = patterns->length ? max_pattern_len : patterns->fixed_length;
     const uint32_t maxN = texts->length ? max_text_len : texts->fixed_length;
-    if (maxM == 0 || maxM > 1024u) return hipErrorNotSupported;        // 64 lanes x 16 rows
-    if (maxN == 0 || uint64_t(maxN) * 64u * (maxM <= 512u ? 8u : 16u) >= (1ull << 32)) return hipErrorNotSupported;    // LOCAL order keys are 32-bit
+    if (maxM == 0 || maxN == 0) return hipErrorNotSupported;
+    const bool striped = maxM > 1024u;                                  // beyond 64 lanes x 16 rows: stripes of 1 024 rows (full_gotoh_striped.hip)
+    if (!striped && uint64_t(maxN) * 64u * (maxM <= 512u ? 8u : 16u) >= (1ull << 32)) return hipErrorNotSupported;    // LOCAL order keys are 32-bit
 
     FullParams p;
     p.pat = make_string_set(patterns); p.txt = make_string_set(texts);
@@ -1048,6 +1084,21 @@ static int full_score_core(
         const int64_t high = int64_t(maxM) * std::max<int64_t>(0, std::max(scheme->match, scheme->mismatch)) + worst_sub + 8;
         if (low < 32000 && high < 32000) trunc = false;
     }
+    if (striped)
+    {
+        // what the striped sweep does not model: qualities, job lists, and -- for pattern blocking -- thresholds and values beyond int16
+        if (qual || jobs) return hipErrorNotSupported;
+        if (pattern_blocking && (min_score != nullptr || trunc)) return hipErrorNotSupported;
+        StripeParams sp;
+        sp.pat = p.pat; sp.txt = p.txt; sp.match = p.match; sp.mismatch = p.mismatch;
+        sp.e_go = sp.f_go = p.gap_open; sp.e_ge = sp.f_ge = p.gap_ext;
+        sp.col_go = p.col_go; sp.col_ge = p.col_ge; sp.row_go = p.row_go; sp.row_ge = p.row_ge;
+        sp.infimum = -32768 - std::min(p.gap_open, p.gap_ext);
+        sp.linear = (blk_log2 == 4u) ? 1u : 0u; sp.trunc = trunc ? 1u : 0u; sp.blk_log2 = blk_log2; sp.pattern_blocking = pattern_blocking;
+        sp.min_score = min_score; sp.n = n; sp.out_score = out_score; sp.out_sink = out_sink; sp.out_ok = out_ok; sp.max_n = maxN;
+        g_last_kernel = "full_gotoh_striped_kernel";
+        return launch_striped(sp, type, maxM, to_stream(stream));
+    }
     // the largest score one aligned pair can add: LOCAL's H is bounded by M times it, not by M * match
     int32_t best_pair = std::max(scheme->match, scheme->mismatch);
     if (qual) for (int i = 0; i < 256; ++i) best_pair = std::max(best_pair, qual->mismatch[i]);
@@ -1061,7 +1112,7 @@ static int full_score_core(
     // edit distance, no min_score, non-LOCAL: the bit-vector kernel (NVBIO_HIP_ED_SWEEP=1 keeps the sweep, for the tests)
     {
         const bool ed = !qual && blk_log2 == 4u && scheme->match == 0 && scheme->mismatch == -1 && scheme->gap_open == -1 && scheme->gap_ext == -1;
-        if (ed && !trunc && type != NVBIO_HIP_LOCAL && min_score == nullptr && maxM <= 512u && test_switch(SW_ED_SWEEP) != 1 && !jobs)
+        if (ed && !trunc && type != NVBIO_HIP_LOCAL && min_score == nullptr && maxM <= 512u && test_switch(SW_ED_SWEEP) != 1 && !jobs && patterns->bits != 8u)
         {
             g_last_kernel = "edit_distance_bitvector_kernel";
             const uint32_t words = (maxM + 63u) / 64u;
@@ -1148,10 +1199,11 @@ NVB_API int nvbio_hip_sw_score(
     uint32_t n, int32_t* out_score, uint32_t* out_sink, void* stream)
 {
     if (!scheme) return hipErrorInvalidValue;
-    if (scheme->deletion != scheme->insertion) return hipErrorNotSupported;
+    if (scheme->deletion != scheme->insertion)
+        return sw_asym_score(scheme, type, 0u, patterns, texts, max_pattern_len, max_text_len, n, out_score, out_sink, nullptr, stream);
     const nvbio_hip_gotoh_scheme g = { scheme->match, scheme->mismatch, scheme->deletion, scheme->deletion };
     const int e = full_score_core(&g, nullptr, type, 4u, 0u, patterns, texts, max_pattern_len, max_text_len, nullptr, n, out_score, out_sink, nullptr, stream);
-    if (e == hipSuccess && n && g_last_kernel[0] != 'e') g_last_kernel = "full_gotoh_score_kernel<16-bit,sw>";       // ('e': the edit-distance kernel ran)
+    if (e == hipSuccess && n && g_last_kernel[0] != 'e' && !strstr(g_last_kernel, "striped")) g_last_kernel = "full_gotoh_score_kernel<16-bit,sw>";       // ('e': the edit-distance kernel ran)
     return e;
 }
 
@@ -1164,7 +1216,15 @@ NVB_API int nvbio_hip_alignment_score(
     uint32_t n, int32_t* out_score, uint32_t* out_sink, uint8_t* out_ok, void* stream)
 {
     if (!scheme4 || aligner < 0 || aligner > 1 || algorithm < 0 || algorithm > 1) return hipErrorInvalidValue;
-    if (aligner == 1 && scheme4[2] != scheme4[3]) return hipErrorNotSupported;         // deletion != insertion
+    if (aligner == 1 && scheme4[2] != scheme4[3])         // deletion != insertion
+    {
+        // pattern blocking tests min_score after each block of rows: only thresholds that cannot bind are admitted (NULL)
+        if (algorithm == 0 && min_score != nullptr) return hipErrorNotSupported;
+        const nvbio_hip_sw_scheme w = { scheme4[0], scheme4[1], scheme4[2], scheme4[3] };
+        const int e = sw_asym_score(&w, type, algorithm == 0 ? 1u : 0u, patterns, texts, max_pattern_len, max_text_len, n, out_score, out_sink, nullptr, stream);
+        if (e == hipSuccess && n && out_ok) return hipMemsetAsync(out_ok, 1, n, to_stream(stream));
+        return e;
+    }
     const nvbio_hip_gotoh_scheme g = { scheme4[0], scheme4[1], scheme4[2], aligner == 1 ? scheme4[2] : scheme4[3] };
     if (algorithm == 1 && aligner == 1) min_score = nullptr;                            // the text-blocking SW form never exits early
     const int e = full_score_core(&g, nullptr, type, aligner == 1 ? 4u : 3u, algorithm == 0 ? 1u : 0u, patterns, texts, max_pattern_len, max_text_len,

@@ -132,6 +132,48 @@ struct ByteStringStream
     const int32* m_thresholds; int32* m_scores; uint2* m_sinks;
 };
 
+// ---------------------------------------------------------------------------------------------------------------------
+// stream 3: patterns as plain bytes next to a packed 2-bit reference -- an 8-bit pattern string in place (nvbio_hip.h: bits == 8)
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename t_aligner_type>
+struct BytePatternStream
+{
+    typedef t_aligner_type aligner_type;
+    typedef cuda::ldg_pointer<uint32> word_iterator;
+    typedef PackedStringLoader<word_iterator, 2, false, uncached_tag> window_loader_type;
+    typedef vector_view<const uint8*>                           read_string;
+    typedef vector_view<typename window_loader_type::iterator>  window_string;
+    struct context_type { int32 min_score; aln::BestSink<int32> sink; };
+    struct strings_type { window_loader_type window_loader; read_string pattern; aln::trivial_quality_string quals; window_string text; };
+
+    BytePatternStream(aligner_type aligner, uint32 count, const uint32* read_offsets, const uint8* reads, uint32 longest_read,
+                      const uint32* window_offsets, const uint32* window_words, uint32 longest_window, const int32* thresholds, int32* scores, uint2* sinks)
+        : m_aligner(aligner), m_count(count), m_read_offsets(read_offsets), m_reads(reads), m_longest_read(longest_read),
+          m_window_offsets(window_offsets), m_windows(word_iterator(window_words)), m_longest_window(longest_window), m_thresholds(thresholds), m_scores(scores), m_sinks(sinks) {}
+
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE const aligner_type& aligner() const { return m_aligner; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 max_pattern_length() const { return m_longest_read; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 max_text_length() const { return m_longest_window; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 size() const { return m_count; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 pattern_length(const uint32 i, context_type*) const { return m_read_offsets[i + 1] - m_read_offsets[i]; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE uint32 text_length(const uint32 i, context_type*) const { return m_window_offsets[i + 1] - m_window_offsets[i]; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE bool init_context(const uint32 i, context_type* context) const
+    { context->min_score = m_thresholds ? m_thresholds[i] : Field_traits<int32>::min(); return true; }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void load_strings(const uint32 i, const uint32 window_begin, const uint32 window_end, const context_type*, strings_type* strings) const
+    {
+        const uint32 r0 = m_read_offsets[i],   rn = m_read_offsets[i + 1] - r0;
+        const uint32 w0 = m_window_offsets[i], wn = m_window_offsets[i + 1] - w0;
+        strings->text    = window_string(wn, strings->window_loader.load(m_windows + w0, wn, make_uint2(window_begin, window_end), false));
+        strings->pattern = read_string(rn, m_reads + r0);
+    }
+    NVBIO_FORCEINLINE NVBIO_HOST_DEVICE void output(const uint32 i, const context_type* context) const { m_scores[i] = context->sink.score; m_sinks[i] = context->sink.sink; }
+
+    aligner_type m_aligner; uint32 m_count;
+    const uint32* m_read_offsets; const uint8* m_reads; uint32 m_longest_read;
+    const uint32* m_window_offsets; typename window_loader_type::input_iterator m_windows; uint32 m_longest_window;
+    const int32* m_thresholds; int32* m_scores; uint2* m_sinks;
+};
+
 // a user-defined Gotoh scoring scheme: quality-dependent mismatches, different gap costs on the two strings
 struct PhredGotohScheme
 {
@@ -196,6 +238,21 @@ static const char* full_bytes(const aligner_type aligner, const Args& a, const b
     return run< aln::BatchedAlignmentScore<stream_type, scheduler> >(stream, device);
 }
 
+template <uint32 BAND, typename aligner_type>
+static const char* banded_byte_patterns(const aligner_type aligner, const Args& a)
+{
+    typedef BytePatternStream<aligner_type> stream_type;
+    const stream_type stream(aligner, a.n, a.read_offsets, (const uint8*)a.reads, a.longest_read, a.window_offsets, (const uint32*)a.windows, a.longest_window, a.thresholds, a.scores, a.sinks);
+    return run< aln::BatchedBandedAlignmentScore<BAND, stream_type, aln::DeviceThreadScheduler> >(stream, true);
+}
+template <typename aligner_type>
+static const char* full_byte_patterns(const aligner_type aligner, const Args& a)
+{
+    typedef BytePatternStream<aligner_type> stream_type;
+    const stream_type stream(aligner, a.n, a.read_offsets, (const uint8*)a.reads, a.longest_read, a.window_offsets, (const uint32*)a.windows, a.longest_window, a.thresholds, a.scores, a.sinks);
+    return run< aln::BatchedAlignmentScore<stream_type, aln::DeviceThreadScheduler> >(stream, true);
+}
+
 // kind: 0 Gotoh, 1 Smith-Waterman, 2 edit distance, 3 Gotoh with the user-defined PhredGotohScheme, 4 the bit-vector banded edit distance (MyersTag<5>)
 template <typename F> static const char* with_type(const int type, F f)
 {
@@ -206,7 +263,7 @@ template <typename F> static const char* with_type(const int type, F f)
 
 #define API extern "C" __attribute__((visibility("default")))
 
-// strings: 0 = packed words (reads 4-bit BE, windows 2-bit LE), 1 = bytes;  where: 0 = device pointers + DeviceThreadScheduler, 1 = host pointers + HostThreadScheduler
+// strings: 0 = packed words (reads 4-bit BE, windows 2-bit LE), 1 = bytes, 2 = byte patterns next to packed 2-bit windows (device only);  where: 0 = device pointers + DeviceThreadScheduler, 1 = host pointers + HostThreadScheduler
 API int compat_banded_score(int strings, int where, int kind, int type, int band, const int* sc, unsigned n,
                             const unsigned* read_offsets, const void* reads, const unsigned char* quals, unsigned longest_read,
                             const unsigned* window_offsets, const void* windows, unsigned longest_window, int* scores, unsigned* sinks, char* path /* 16 bytes */)
@@ -235,6 +292,10 @@ API int compat_banded_score(int strings, int where, int kind, int type, int band
                         if (kind == 4) return banded_bytes<B, aln::DeviceThreadScheduler, aln::BestSink<int32> >(aln::make_edit_distance_aligner<TYPE, aln::MyersTag<5> >(), a, true); \
                     } \
                     if (strings == 1 && where == 1 && kind == 1) return banded_bytes<B, aln::HostThreadScheduler, aln::BestSink<int32> >(aln::make_smith_waterman_aligner<TYPE>(w), a, false); \
+                    if (strings == 2 && where == 0) { \
+                        if (kind == 0) return banded_byte_patterns<B>(aln::make_gotoh_aligner<TYPE>(g), a); \
+                        if (kind == 1) return banded_byte_patterns<B>(aln::make_smith_waterman_aligner<TYPE>(w), a); \
+                    } \
                 }
             CASE(15) CASE(31) CASE(9)
             #undef CASE
@@ -271,7 +332,11 @@ API int compat_full_score(int strings, int where, int kind, int type, int tag, c
                     if (kind == 1) return full_bytes<aln::DeviceThreadScheduler>(aln::make_smith_waterman_aligner<TYPE, TAG>(w), a, true); \
                     if (kind == 3) return full_bytes<aln::DeviceThreadScheduler>(aln::make_gotoh_aligner<TYPE, TAG>(PhredGotohScheme()), a, true); \
                 } \
-                if (strings == 1 && where == 1 && kind == 1) return full_bytes<aln::HostThreadScheduler>(aln::make_smith_waterman_aligner<TYPE, TAG>(w), a, false);
+                if (strings == 1 && where == 1 && kind == 1) return full_bytes<aln::HostThreadScheduler>(aln::make_smith_waterman_aligner<TYPE, TAG>(w), a, false); \
+                if (strings == 2 && where == 0) { \
+                    if (kind == 0) return full_byte_patterns(aln::make_gotoh_aligner<TYPE, TAG>(g), a); \
+                    if (kind == 1) return full_byte_patterns(aln::make_smith_waterman_aligner<TYPE, TAG>(w), a); \
+                }
             if (tag == 0) { TAGGED(aln::PatternBlockingTag) } else { TAGGED(aln::TextBlockingTag) }
             #undef TAGGED
             return (const char*)NULL;

@@ -43,9 +43,13 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     ps.bits, ts.bits = 4, 2
     # null outputs -> hipErrorInvalidValue (1); nothing is launched
     assert L.nvbio_hip_banded_gotoh_score(ctypes.byref(sc), 1, 15, ctypes.byref(ps), ctypes.byref(ts), 0, 0, 10, None, None, None) == 1
-    # an 8-bit stream is outside the ABI's contract -> hipErrorNotSupported (801)
-    ps.bits = 8
+    # an 8-bit TEXT stream (or a 3-bit pattern stream) is outside the ABI's contract -> hipErrorNotSupported (801); 8-bit patterns are inside it
+    ps.bits = 3
     assert L.nvbio_hip_banded_gotoh_score(ctypes.byref(sc), 1, 15, ctypes.byref(ps), ctypes.byref(ts), 0, 0, 10, None, None, None) == 801
+    ps.bits, ts.bits = 8, 8
+    assert L.nvbio_hip_banded_gotoh_score(ctypes.byref(sc), 1, 15, ctypes.byref(ps), ctypes.byref(ts), 0, 0, 10, None, None, None) == 801
+    ts.bits = 2
+    assert L.nvbio_hip_banded_gotoh_score(ctypes.byref(sc), 1, 15, ctypes.byref(ps), ctypes.byref(ts), 0, 0, 10, None, None, None) == 1
     # an empty batch is legal
     ps.bits = 4
     assert L.nvbio_hip_banded_gotoh_score(ctypes.byref(sc), 1, 15, ctypes.byref(ps), ctypes.byref(ts), 0, 0, 0, None, None, None) == 0

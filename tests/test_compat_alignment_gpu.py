@@ -167,14 +167,87 @@ def test_banded_bitvector_edit_distance_on_the_device(callers, typ, packed, band
     assert not reported[has_n].any()
 
 
-def test_packed_stream_outside_the_tuned_contract_falls_to_the_generic_lanes(callers):
+def test_asymmetric_linear_gaps_run_on_the_tuned_kernels(callers):
+    """deletion != insertion (alignment/utils.h:92-109): banded and full matrix, both tags -- refused by the tuned kernels until round 6"""
     reads, quals, wins = make_jobs(7, 2000, band=15)
     b = Batch(reads, quals, wins, packed=True, on_device=True)
-    # asymmetric linear gap costs: the tuned kernels refuse them, the generic templates compute them
-    assert run_banded(callers, b, 0, 0, 1, LOCAL, 15, (2, -2, -4, -1)) == "generic"
-    es, ek = O.batch_sw_score(15, LOCAL, (2, -2, -4, -1), b.hr, b.hw)
-    gs, gk = b.results()
-    assert (gs == es).all() and (gk == ek).all()
+    for typ in (GLOBAL, LOCAL, SEMI):
+        assert run_banded(callers, b, 0, 0, 1, typ, 15, (2, -2, -4, -1)) == "tuned"
+        es, ek = O.batch_sw_score(15, typ, (2, -2, -4, -1), b.hr, b.hw)
+        gs, gk = b.results()
+        assert (gs == es).all() and (gk == ek).all()
+    reads, quals, wins = make_jobs(8, 900, max_read=120, full=True, short_text_every=10 ** 9)
+    reads = [r if len(r) else np.array([1], np.uint8) for r in reads]
+    quals = [q if len(q) else np.array([0], np.uint8) for q in quals]
+    b = Batch(reads, quals, wins, packed=True, on_device=True)
+    for typ in (GLOBAL, LOCAL, SEMI):
+        for tag in (0, 1):
+            assert run_full(callers, b, 0, 0, 1, typ, tag, (2, -2, -4, -1), None) == "tuned"
+            es, ek = expect_full(b, 1, typ, tag, (2, -2, -4, -1), None)
+            gs, gk = b.results()
+            assert (gs == es).all() and (gk == ek).all(), (typ, tag)
+
+
+class BytePatternBatch(Batch):
+    """patterns as bytes (symbols no 2-bit text symbol equals among them, 255 included), windows packed 2 bits per base"""
+    def __init__(self, reads, quals, wins):
+        Batch.__init__(self, [r & 3 for r in reads], quals, wins, packed=True, on_device=True)
+        cat_r = np.concatenate(reads + [np.zeros(8, np.uint8)])
+        self.hr = O.StringSet(np.frombuffer(np.concatenate([cat_r, np.zeros(-cat_r.size % 4, np.uint8)]).tobytes(), dtype=np.uint32), 8, False,
+                              self.ro[:-1].astype(np.uint64), np.diff(self.ro))
+        self.t["r"] = dev(cat_r)
+
+
+@pytest.mark.parametrize("typ", [GLOBAL, LOCAL, SEMI])
+def test_byte_patterns_over_a_packed_reference_run_in_place(callers, typ):
+    """vector_view<const uint8*> patterns: an 8-bit string set behind the C-ABI, nothing staged"""
+    rng = np.random.default_rng(900 + typ)
+    for band in (15, 31):
+        reads, quals, wins = make_jobs(910 + band + typ, 2500, band=band)
+        for r in reads:
+            odd = rng.random(r.size) < 0.03
+            r[odd] = rng.choice(np.array([4, 9, 16, 77, 200, 255], np.uint8), int(odd.sum()))
+        b = BytePatternBatch(reads, quals, wins)
+        for kind, scheme in ((0, (2, -1, -2, -1)), (1, (2, -2, -4, -1))):
+            assert run_banded(callers, b, 2, 0, kind, typ, band, scheme) == "tuned"
+            es, ek = expect_banded(b, kind, typ, band, scheme)
+            gs, gk = b.results()
+            assert (gs == es).all() and (gk == ek).all(), (band, kind)
+    reads, quals, wins = make_jobs(950 + typ, 900, max_read=120, full=True, short_text_every=10 ** 9)
+    reads = [r if len(r) else np.array([1], np.uint8) for r in reads]
+    quals = [q if len(q) else np.array([0], np.uint8) for q in quals]
+    for r in reads:
+        odd = rng.random(r.size) < 0.03
+        r[odd] = rng.choice(np.array([4, 9, 16, 77, 200, 255], np.uint8), int(odd.sum()))
+    b = BytePatternBatch(reads, quals, wins)
+    for tag in (0, 1):
+        for kind, scheme in ((0, (2, -1, -2, -1)), (1, (2, -2, -3, -3))):
+            assert run_full(callers, b, 2, 0, kind, typ, tag, scheme, None) == "tuned"
+            es, ek = expect_full(b, kind, typ, tag, scheme, None)
+            gs, gk = b.results()
+            assert (gs == es).all() and (gk == ek).all(), (tag, kind)
+
+
+@pytest.mark.parametrize("typ", [GLOBAL, LOCAL, SEMI])
+def test_full_matrix_patterns_beyond_1024_rows_stay_on_the_tuned_route(callers, typ):
+    rng = np.random.default_rng(990 + typ)
+    reads, quals, wins = [], [], []
+    for i in range(40):
+        L = int(rng.integers(800, 2600))
+        w = rng.integers(0, 4, int(rng.integers(L, L + 900)), dtype=np.uint8)
+        r = w[:L].copy()
+        m = rng.random(L) < 0.05; r[m] = rng.integers(0, 4, int(m.sum()))
+        reads.append(r); quals.append(np.zeros(L, np.uint8)); wins.append(w)
+    b = Batch(reads, quals, wins, packed=True, on_device=True)
+    th = np.where(rng.random(b.n) < 0.5, -(1 << 30), rng.integers(-40, 3000, b.n)).astype(np.int32)
+    for kind, scheme, tag, thresholds in ((0, (2, -1, -2, -1), 1, th), (0, (2, -1, -2, -1), 0, None), (1, (2, -2, -3, -3), 1, None), (2, None, 1, None)):
+        assert run_full(callers, b, 0, 0, kind, typ, tag, scheme or (0, -1, -1, -1), thresholds) == "tuned"
+        es, ek = expect_full(b, kind, typ, tag, scheme, thresholds)
+        gs, gk = b.results()
+        assert (gs == es).all() and (gk == ek).all(), (kind, tag)
+
+
+def test_packed_stream_outside_the_tuned_contract_falls_to_the_generic_lanes(callers):
     # a band the tuned kernels are not instantiated for
     for typ in (GLOBAL, LOCAL, SEMI):
         reads, quals, wins = make_jobs(9 + typ, 1500, band=9)
@@ -268,9 +341,9 @@ def test_full_matrix_generic_lanes(callers, typ, tag, kind, scheme):
 
 
 def test_full_matrix_long_patterns_and_host(callers):
-    """patterns to 1024 symbols run on the tuned sweep (16 rows per lane), longer ones on the generic lanes; HostThreadScheduler on the host"""
+    """patterns to 1024 symbols run on the register-resident sweep (16 rows per lane), longer ones on the striped one; HostThreadScheduler on the host"""
     rng = np.random.default_rng(8)
-    for lo, hi, path in ((400, 900, "tuned"), (1030, 1300, "generic")):
+    for lo, hi, path in ((400, 900, "tuned"), (1030, 1300, "tuned")):
         reads = [rng.integers(0, 4, int(rng.integers(lo, hi)), dtype=np.uint8) for _ in range(60)]
         wins = [np.concatenate([rng.integers(0, 4, 30, dtype=np.uint8), r, rng.integers(0, 4, 30, dtype=np.uint8)]) for r in reads]
         quals = [np.zeros(len(r), np.uint8) for r in reads]

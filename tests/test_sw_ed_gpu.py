@@ -101,13 +101,14 @@ def test_sw_benchmark_edit_distance_leg(cuda):
     assert es.max() <= 0 and es.min() < -2
 
 
-def test_asymmetric_costs_are_refused(cuda):
+def test_asymmetric_costs_run_on_the_tuned_kernels(cuda):
+    """deletion != insertion was refused until round 6 (tests/test_tuned_edges_gpu.py holds the parity tests)"""
     hp, ht = O.StringSet.from_lists([np.zeros(10, np.uint8)], 4, True), O.StringSet.from_lists([np.zeros(30, np.uint8)], 2, True)
     al = nvb.make_smith_waterman_aligner(nvb.LOCAL, nvb.SimpleSmithWatermanScheme(2, -1, -2, -1))
-    with pytest.raises(RuntimeError):
-        nvb.batch_banded_alignment_score(15, al, to_dev(hp, cuda), to_dev(ht, cuda))
-    with pytest.raises(RuntimeError):
-        nvb.batch_alignment_score(al, to_dev(hp, cuda), to_dev(ht, cuda), 10, 30)
+    gs, _ = nvb.batch_banded_alignment_score(15, al, to_dev(hp, cuda), to_dev(ht, cuda))
+    assert gs.cpu().tolist() == [20]
+    gs, _, _ = nvb.batch_alignment_score(al, to_dev(hp, cuda), to_dev(ht, cuda), 10, 30)
+    assert gs.cpu().tolist() == [20]
 
 
 @pytest.mark.parametrize("ty", [nvb.GLOBAL, nvb.SEMI_GLOBAL])
