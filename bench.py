@@ -857,10 +857,10 @@ def _shim_params(p, scheme):
                                               "max_hits", "allow_sub", "subseed_len", "seed_len", "seed_freq_type", "min_read_len", "max_dist", "no_multi_hits",
                                               "batch_size", "hits_stride")] + \
                    [("seed_freq_k", C.c_float), ("seed_freq_m", C.c_float), ("match", C.c_int32), ("score_min_type", C.c_int32),
-                    ("score_min_k", C.c_float), ("score_min_m", C.c_float), ("finish", C.c_uint32)]
+                    ("score_min_k", C.c_float), ("score_min_m", C.c_float), ("finish", C.c_uint32), ("edit_distance", C.c_uint32)]
     return ShimParams(int(p.local), int(p.randomized), p.top_seed, p.max_effort_init, p.max_effort, p.min_ext, p.max_ext, p.max_reseed, p.rep_seeds, p.max_hits,
                       p.allow_sub, p.subseed_len, p.seed_len, p.seed_freq[0], p.min_read_len, p.max_dist, int(p.no_multi_hits), p.batch_size, p.hits_stride or 0,
-                      p.seed_freq[1], p.seed_freq[2], scheme.m_match, scheme.m_score_min[0], scheme.m_score_min[1], scheme.m_score_min[2], 0)
+                      p.seed_freq[1], p.seed_freq[2], scheme.m_match, scheme.m_score_min[0], scheme.m_score_min[1], scheme.m_score_min[2], 0, 1 if getattr(p, "scoring_mode", "sw") == "ed" else 0)
 
 
 def cxx_paired_leg(dev, idx, s1, s2, genome_words, ng, names, prm, ref_best0):

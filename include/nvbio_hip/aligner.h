@@ -22,14 +22,23 @@ namespace bowtie2 {
 namespace cuda {
 
 enum AlignmentTypeMode { EndToEndAlignment = 0, LocalAlignment = 1 };           // params.h
+enum ScoringMode       { EditDistanceMode = 0, SmithWatermanMode = 1 };         // params.h:47-51
 
 /// the fields of nvBowtie's Params the driver reads, with its defaults (params.cpp:116-197)
 struct Params : public ParamsPOD
 {
-    Params() : max_dist(15), alignment_type(EndToEndAlignment), no_multi_hits(false), fw(true), rc(true), hits_stride(0), finish_alignments(true) {}
+    Params() : max_dist(15), alignment_type(EndToEndAlignment), no_multi_hits(false), fw(true), rc(true), hits_stride(0), finish_alignments(true),
+               scoring_mode(SmithWatermanMode) {}
     SelectParamsPOD select;
     uint32 max_dist; AlignmentTypeMode alignment_type; bool no_multi_hits, fw, rc; uint32 hits_stride;
     bool   finish_alignments;      ///< run finish_alignment_best (MD strings, edit distances, final scores) as the reference always does
+    /// --scoring ed|sw (params.cpp:117, compute_thread.cu:296): in edit-distance mode hits are extended, reduced and traced with the
+    /// edit-distance aligner against score-min = -max_dist (params.cpp:203-204); MAPQ and the final scores of finish_alignment still come
+    /// from the Smith-Waterman scheme the caller passes (aligner_best_approx.h:294-296, traceback.cu:146-160), as in the reference
+    ScoringMode scoring_mode;
+    /// the search scheme and thresholds of the mode
+    aln::SmithWatermanScoringScheme search_scheme(const aln::SmithWatermanScoringScheme& sw) const { return scoring_mode == EditDistanceMode ? aln::SmithWatermanScoringScheme::edit_distance() : sw; }
+    ScoreLimits search_limits(const ScoreLimits& sw) const { return scoring_mode == EditDistanceMode ? ScoreLimits(0, SimpleFunc(SimpleFunc::LinearFunc, -float(max_dist), 0.0f)) : sw; }
 
     /// switch between end-to-end and local alignment the way nvBowtie's option parser does (params.cpp:156-160): the alignment type
     /// also moves the seeding defaults -- 22-bp seeds every 1 + 1.15 sqrt(L) end-to-end, 20-bp seeds every 1 + 0.75 sqrt(L) local
@@ -352,12 +361,17 @@ private:
         const uint32 count = reads.n, L = reads.len;
         const uint32 band_len = band_length(params.max_dist);
         const uint32 hits_stride = params.hits_stride ? params.hits_stride : std::min(params.max_hits, 128u);
-        const aln::GotohAligner<TYPE, aln::SmithWatermanScoringScheme> aligner(scoring_scheme);
+        // the scheme hits are extended with: the caller's, or the edit-distance costs (Params::scoring_mode)
+        const bool ed_mode = params.scoring_mode == EditDistanceMode;
+        const aln::SmithWatermanScoringScheme search_scheme = params.search_scheme(scoring_scheme);
+        const ScoreLimits search_limits = params.search_limits(limits);
+        const aln::GotohAligner<TYPE, aln::SmithWatermanScoringScheme> aligner(search_scheme);
         hip::synchronize(hip_stream);                                   // nothing of the previous batch may still read the workspace
         const hip::arena_scope scope(workspace);                        // every vector below lives in the Aligner's workspace
 
         // initialize best-alignments with the threshold score
-        hip::device_vector<int32> min_score_table(limits.min_score_table(L));
+        hip::device_vector<int32> min_score_table(search_limits.min_score_table(L));
+        hip::device_vector<int32> mapq_score_table(limits.min_score_table(L));        // MAPQ reads the Smith-Waterman scheme in either mode
         init_alignments(count, nullptr, L, min_score_table.data(), best_data_dvec.data(), BATCH_SIZE, 0u, hip_stream);
 
         // the seed queue, hit deques, selection state and scoring queues of the pipeline
@@ -404,7 +418,7 @@ private:
         }
 
         // compute mapq (BowtieMapq2)
-        stats.clock.run("mapq", hip_stream, [&] { mapq(2, limits, min_score_table.data(), count, best_data_dvec.data(), BATCH_SIZE, nullptr, L, mapq_dvec.data(), hip_stream); });
+        stats.clock.run("mapq", hip_stream, [&] { mapq(2, limits, mapq_score_table.data(), count, best_data_dvec.data(), BATCH_SIZE, nullptr, L, mapq_dvec.data(), hip_stream); });
 
         // banded_traceback_best over every read (unaligned ones get an empty window and no CIGAR)
         stats.clock.begin("traceback", hip_stream);
@@ -422,6 +436,18 @@ private:
             const aln::CigarArrays     cigars     = { cigar.data(), cigar_stride, cigar_len.data() };
             hip_check(nvbio_hip_traceback_best_known(count, nullptr, reinterpret_cast<const uint64*>(best_data_dvec.data()), best_sink.data(), traceback_score.data(),
                                                      cigar_sink.data(), hip_stream), "nvbio_hip_traceback_best_known");
+            if (ed_mode)
+            {
+                // the edit-distance aligner's own walk (sw_banded_inl.h:405-470: among equal moves it does not choose as the Gotoh walk does)
+                const nvbio_hip_sw_scheme w = { 0, -1, -1, -1 };
+                const nvbio_hip_string_set p = patterns.abi(), t = texts.abi();
+                hip::device_vector<uint8> temp(nvbio_hip_banded_gotoh_traceback_temp_bytes(band_len, L, count));
+                hip_check(nvbio_hip_banded_sw_traceback(&w, int32(TYPE), band_len, &p, &t, L, L + band_len, count, traceback_score.data(), cigar_sink.data(), cigar_source.data(),
+                                                        reinterpret_cast<uint16*>(cigar.data()), cigar_stride, cigar_len.data(), temp.data(), temp.size(), hip_stream),
+                          "nvbio_hip_banded_sw_traceback");
+                hip::synchronize(hip_stream);
+            }
+            else
             dispatch_band(band_len, [&](auto band) {
                 typedef aln::PackedTracebackStream<aln::GotohAligner<TYPE, aln::SmithWatermanScoringScheme>, PackedStringSetView<4, true>, PackedStringSetView<2, true> > stream_type;
                 const stream_type stream(aligner, patterns, texts, alignments, cigars, L, L + band_len, reads.quals, reads.n_quals);
@@ -457,14 +483,19 @@ private:
         const uint32 count = reads.mate[0].n, L = reads.mate[0].len;
         const uint32 band_len = band_length(params.max_dist);
         const uint32 hits_stride = params.hits_stride ? params.hits_stride : std::min(params.max_hits, 128u);
-        const aln::GotohAligner<TYPE, aln::SmithWatermanScoringScheme> aligner(scoring_scheme);
-        const nvbio_hip_gotoh_qual_scheme sc = scoring_scheme.abi();
+        // the scheme hits are extended with (Params::scoring_mode): `sc`; the scheme of MAPQ and finish_alignment is the caller's: `fsc`
+        const bool ed_mode = params.scoring_mode == EditDistanceMode;
+        const aln::SmithWatermanScoringScheme search_scheme = params.search_scheme(scoring_scheme);
+        const ScoreLimits search_limits = params.search_limits(limits);
+        const aln::GotohAligner<TYPE, aln::SmithWatermanScoringScheme> aligner(search_scheme);
+        const nvbio_hip_gotoh_qual_scheme sc = search_scheme.abi(), fsc = scoring_scheme.abi();
+        const nvbio_hip_sw_scheme ed_costs = { 0, -1, -1, -1 };
         uint64* best   = reinterpret_cast<uint64*>(best_data_dvec.data());
         uint64* best_o = reinterpret_cast<uint64*>(best_data_dvec_o.data());
         hip::synchronize(hip_stream);
         const hip::arena_scope scope(workspace);                        // the per-batch vectors below live in the Aligner's workspace
 
-        hip::device_vector<int32> min_score_table(limits.min_score_table(L));
+        hip::device_vector<int32> min_score_table(search_limits.min_score_table(L)), mapq_score_table(limits.min_score_table(L));
         init_alignments(count, nullptr, L, min_score_table.data(), best_data_dvec.data(),   BATCH_SIZE, 0u, hip_stream);
         init_alignments(count, nullptr, L, min_score_table.data(), best_data_dvec_o.data(), BATCH_SIZE, 1u, hip_stream);
 
@@ -624,7 +655,7 @@ private:
         if (pe.pe_discordant)
             hip_check(nvbio_hip_mark_discordant(count, best, best_o, BATCH_SIZE, hip_stream), "nvbio_hip_mark_discordant");
         // mate 1's MAPQ functor
-        hip_check(nvbio_hip_mapq_paired(2, limits.match, limits.monotone ? 1 : 0, min_score_table.data(), count, best, best_o, BATCH_SIZE, nullptr, nullptr, L, L,
+        hip_check(nvbio_hip_mapq_paired(2, limits.match, limits.monotone ? 1 : 0, mapq_score_table.data(), count, best, best_o, BATCH_SIZE, nullptr, nullptr, L, L,
                                         mapq_dvec.data(), hip_stream), "nvbio_hip_mapq_paired");
 
         // tracebacks + finish: anchor slots (banded), opposite slots (full matrix for the concordant ones, banded for the others)
@@ -641,6 +672,10 @@ private:
             const PackedStringSetView<2, true> texts(count, genome_words, genome_n_words, tb_txt.data(), tb_len.data(), 0u);
             const nvbio_hip_string_set p = patterns.abi(), t = texts.abi();
             hip::device_vector<uint8> temp(nvbio_hip_banded_gotoh_traceback_temp_bytes(band_len < 4 ? 3u : band_len < 8 ? 7u : band_len < 16 ? 15u : 31u, L, count));
+            if (ed_mode)      // the edit-distance aligner's own walk (sw_banded_inl.h:405-470)
+                hip_check(nvbio_hip_banded_sw_traceback(&ed_costs, int32(TYPE), band_len < 4 ? 3u : band_len < 8 ? 7u : band_len < 16 ? 15u : 31u, &p, &t, L, L + band_len, count, score, snk, src,
+                                                        reinterpret_cast<uint16*>(cg), cigar_stride, cg_len, temp.data(), temp.size(), hip_stream), "nvbio_hip_banded_sw_traceback");
+            else
             hip_check(nvbio_hip_banded_gotoh_traceback_qual(&sc, int32(TYPE), band_len < 4 ? 3u : band_len < 8 ? 7u : band_len < 16 ? 15u : 31u, &p, reads.both_quals, reads.both_n_quals, &t,
                                                             L, L + band_len, count, score, snk, src, reinterpret_cast<uint16*>(cg), cigar_stride, cg_len, temp.data(), temp.size(), hip_stream),
                       "nvbio_hip_banded_gotoh_traceback_qual");
@@ -651,13 +686,13 @@ private:
             const PackedStringSetView<2, true> texts(n_jobs, genome_words, genome_n_words, tb_txt.data(), tb_len.data(), 0u);
             const nvbio_hip_string_set p = patterns.abi(), t = texts.abi();
             hip_check(nvbio_hip_finish_alignment(n_jobs, v, &p, reads.both_quals, reads.both_n_quals, &t, reinterpret_cast<const uint16*>(cg), cigar_stride, cg_len, src,
-                                                 sc.match, sc.mismatch, 1, &sc.pattern_gap_open, idx, slots, md, mds_stride, md_len, hip_stream), "nvbio_hip_finish_alignment");
+                                                 fsc.match, fsc.mismatch, 1, &fsc.pattern_gap_open, idx, slots, md, mds_stride, md_len, hip_stream), "nvbio_hip_finish_alignment");
         };
 
         banded_tb(best, 0, valid, cigar.data(), cigar_len.data(), cigar_source.data(), cigar_sink.data(), traceback_score.data());
         if (params.finish_alignments) finish(count, valid.data(), nullptr, best, cigar.data(), cigar_len.data(), cigar_source.data(), mds.data(), mds_len.data());
         // mate 2's MAPQ functor: after the anchor slots were finished, before the opposite ones are (:308-323)
-        hip_check(nvbio_hip_mapq_paired(2, limits.match, limits.monotone ? 1 : 0, min_score_table.data(), count, best_o, best, BATCH_SIZE, nullptr, nullptr, L, L,
+        hip_check(nvbio_hip_mapq_paired(2, limits.match, limits.monotone ? 1 : 0, mapq_score_table.data(), count, best_o, best, BATCH_SIZE, nullptr, nullptr, L, L,
                                         mapq_dvec_o.data(), hip_stream), "nvbio_hip_mapq_paired");
 
         // which opposite slots are concordant (their tracebacks run over the full matrix of [alignment, alignment + sink))
@@ -685,6 +720,10 @@ private:
             // each window ends at the sink of the scoring pass whose score the slot holds: the rows no alignment of that score can reach are dropped
             hip::device_vector<int32> known(n_conc);
             hip_check(nvbio_hip_traceback_best_known(n_conc, idx_c.data(), best_o, nullptr, known.data(), nullptr, hip_stream), "nvbio_hip_traceback_best_known");
+            if (ed_mode)      // (sw_inl.h:1660-1700)
+                hip_check(nvbio_hip_sw_traceback(&ed_costs, int32(TYPE), &p, &t, L, 1024u, n_conc, score.data(), snk.data(), src.data(), reinterpret_cast<uint16*>(cg.data()), cigar_stride,
+                                                 cg_len.data(), temp.data(), temp.size(), hip_stream), "nvbio_hip_sw_traceback");
+            else
             hip_check(nvbio_hip_gotoh_traceback_qual_known_score(&sc, int32(TYPE), &p, reads.both_quals, reads.both_n_quals, &t, known.data(), L, 1024u, n_conc, score.data(), snk.data(),
                                                                  src.data(), reinterpret_cast<uint16*>(cg.data()), cigar_stride, cg_len.data(), temp.data(), temp.size(), hip_stream),
                       "nvbio_hip_gotoh_traceback_qual_known_score");

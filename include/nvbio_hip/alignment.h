@@ -58,6 +58,11 @@ struct SmithWatermanScoringScheme
     SmithWatermanScoringScheme() : m_read_gap_const(5), m_read_gap_coeff(3), m_ref_gap_const(5), m_ref_gap_coeff(3),
                                    m_match(0), m_mmp_min(2), m_mmp_max(6), m_mmp_constant(false) {}
     static SmithWatermanScoringScheme local() { SmithWatermanScoringScheme s; s.m_match = 2; return s; }
+    /// the costs of EditDistanceAligner (ed_utils.h:44-51: match 0, everything else -1) in this scheme's terms: with them the Gotoh
+    /// recurrences are the linear-gap ones cell for cell (gap open == gap extension, so H >= E, F), which is how the drivers' scoring
+    /// stages run nvBowtie's edit-distance mode (EditDistanceScoringScheme, scoring.h:133-200) on the quality-scheme kernels
+    static SmithWatermanScoringScheme edit_distance()
+    { SmithWatermanScoringScheme s; s.m_read_gap_const = s.m_ref_gap_const = 0; s.m_read_gap_coeff = s.m_ref_gap_coeff = 1; s.m_match = 0; s.m_mmp_min = s.m_mmp_max = 1; s.m_mmp_constant = true; return s; }
 
     /// QualCost<int>::operator() (scoring.h:96-100), single precision with truncation as written there
     int32 mmp(const int q) const {

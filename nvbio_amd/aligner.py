@@ -13,7 +13,7 @@ falls back to the CPU."""
 import torch
 
 from . import mapping, reduce, select as sel
-from .alignment import (make_gotoh_aligner, SmithWatermanScoringScheme, SEMI_GLOBAL, LOCAL, PATTERN_BLOCKING, batch_banded_alignment_score,
+from .alignment import (make_gotoh_aligner, make_edit_distance_aligner, SmithWatermanScoringScheme, SEMI_GLOBAL, LOCAL, PATTERN_BLOCKING, batch_banded_alignment_score,
                         batch_banded_alignment_traceback, batch_alignment_score, batch_alignment_traceback)
 from .strings import PackedStringSet
 
@@ -48,6 +48,7 @@ class Params:
         self.randomized, self.top_seed, self.no_multi_hits = True, 0, False
         self.seed_len, self.seed_freq, self.min_read_len = 22, (mapping.SQRT_FUNC, 1.0, 1.15), 12
         self.local = False
+        self.scoring_mode = "sw"                       # --scoring sw|ed (params.cpp:117): "ed" extends, reduces and traces hits with the edit-distance aligner
         self.fw, self.rc = True, True
         # paired-end (params.cpp:165-172; io::PE_POLICY_FR)
         self.pe_policy, self.pe_overlap, self.pe_unpaired, self.pe_discordant, self.min_frag_len, self.max_frag_len = 1, True, True, True, 0, 500
@@ -188,6 +189,10 @@ def best_approx(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=No
     n, L = batch.n, batch.max_len                                                    # L: the longest read
     dev = batch.fw_rc_words.device
     scheme = scheme or (SmithWatermanScoringScheme.local() if params.local else SmithWatermanScoringScheme())
+    # edit-distance mode (compute_thread.cu:296, scoring.h:133-200): hits are extended and reduced against the edit-distance costs and
+    # score-min = -max_dist; MAPQ and finish_alignment's final scores still read the Smith-Waterman scheme (aligner_best_approx.h:294-296, :358)
+    ed_mode = params.scoring_mode == "ed"
+    final_scheme, scheme = scheme, (SmithWatermanScoringScheme.edit_distance(params.max_dist) if ed_mode else scheme)
     aligner = make_gotoh_aligner(LOCAL if params.local else SEMI_GLOBAL, scheme)
     band_len = band_length(params.max_dist)
     reads_rev, reads_fw_rc, quals = batch.reversed, batch.fw_rc_words, batch.quals
@@ -220,7 +225,7 @@ def best_approx(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=No
         sel.mark_unaligned(seed_queue, best, reseed)                               # aligner_init.cu:421-444
         seed_queue = sel.copy_flagged(seed_queue, reseed)                          # aligner_best_approx.h:273-283
     with _Stage(stats, "mapq"):
-        mapq = reduce.mapq(best, scheme, read_len=batch.read_len, fixed_read_len=batch.fixed_len, max_read_len=L)
+        mapq = reduce.mapq(best, final_scheme, read_len=batch.read_len, fixed_read_len=batch.fixed_len, max_read_len=L)
     out = dict(best=best.data, mapq=mapq, dp_jobs=stats.pop("dp_jobs", 0), stats=stats)    # (dp_jobs: the extensions that needed a DP)
     if traceback:
         # banded_traceback_best (traceback_inl.h:104-136) over every read; unaligned reads get an empty window, fail at once and
@@ -233,8 +238,12 @@ def best_approx(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=No
                 valid, pb, tbeg, tlen, plen = sel.traceback_best_setup(best.data, n, band_len, genome_len, 0, batch.rc_offset, read_begin=batch.read_begin,
                                                                       read_len=batch.read_len)
             pat, txt = PackedStringSet(reads_fw_rc, 4, True, pb, plen, batch.fixed_len), PackedStringSet(genome_words, 2, True, tbeg, tlen, 0)
-            tb = batch_banded_alignment_traceback(band_len, aligner, pat, txt, max_pattern_length=L, quals=quals, cigar_stride=cigar_stride,
-                                                  known=sel.traceback_best_known(best.data, best_sink, n))
+            if ed_mode:       # the edit-distance aligner's own walk (sw_banded_inl.h:405-470): among equal moves it does not choose as the Gotoh walk does
+                tb = batch_banded_alignment_traceback(band_len, make_edit_distance_aligner(LOCAL if params.local else SEMI_GLOBAL), pat, txt, max_pattern_length=L,
+                                                      max_text_length=L + band_len, cigar_stride=cigar_stride)
+            else:
+                tb = batch_banded_alignment_traceback(band_len, aligner, pat, txt, max_pattern_length=L, quals=quals, cigar_stride=cigar_stride,
+                                                      known=sel.traceback_best_known(best.data, best_sink, n))
         out.update(cigar=tb["cigar"], cigar_len=tb["cigar_len"], source=tb["source"], sink=tb["sink"], tb_score=tb["score"],
                    aligned_ids=torch.nonzero(best.is_aligned(0)).squeeze(1))
         if finish:
@@ -242,7 +251,7 @@ def best_approx(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=No
             # reference hands to its output stage (m_align = window begin), the extension-stage words stay in out["best_scored"]
             out["best_scored"] = best.data.clone()
             with _Stage(stats, "finish"):
-                out["mds"], out["mds_len"] = sel.finish_alignment(valid, pat, quals, txt, tb["cigar"], tb["cigar_len"], tb["source"], scheme, best.data,
+                out["mds"], out["mds_len"] = sel.finish_alignment(valid, pat, quals, txt, tb["cigar"], tb["cigar_len"], tb["source"], final_scheme, best.data,
                                                                   mds_stride=mds_stride)
     return out
 
@@ -327,8 +336,14 @@ def best_approx_paired(fmi, rfmi, sym1, sym2, genome_words, genome_len, params=N
     dev = sym1.device
     scheme = scheme or (SmithWatermanScoringScheme.local() if params.local else SmithWatermanScoringScheme())
     aln_type = LOCAL if params.local else SEMI_GLOBAL
+    # edit-distance mode: hits are extended against the edit-distance costs and score-min = -max_dist and traced with the edit-distance
+    # aligner's own walks; MAPQ and finish_alignment read the Smith-Waterman scheme (see best_approx)
+    ed_mode = params.scoring_mode == "ed"
+    final_scheme, scheme = scheme, (SmithWatermanScoringScheme.edit_distance(params.max_dist) if ed_mode else scheme)
     banded_aligner = make_gotoh_aligner(aln_type, scheme)
     full_aligner = make_gotoh_aligner(aln_type, scheme, PATTERN_BLOCKING)            # nvBowtie's aligners carry the default tag
+    tb_banded = make_edit_distance_aligner(aln_type) if ed_mode else banded_aligner
+    tb_full = make_edit_distance_aligner(aln_type, PATTERN_BLOCKING) if ed_mode else full_aligner
     band_len = band_length(params.max_dist)
     packed = [pack_read_streams(sym1), pack_read_streams(sym2)]                       # per mate: (reversed reads, fw + rc words)
     mate_quals = [_qual_stream(n, L, qual_value, quals1, dev), _qual_stream(n, L, qual_value, quals2, dev)]   # laid out like each mate's fw + rc words
@@ -368,8 +383,8 @@ def best_approx_paired(fmi, rfmi, sym1, sym2, genome_words, genome_len, params=N
     if params.pe_discordant:
         sel.mark_discordant(best, best_o)
     with _Stage(stats, "mapq"):
-        mapq1 = reduce.mapq_paired(best, best_o, scheme, fixed_read_len=L, o_fixed_read_len=L)      # MapqFunctorPE(mate 0)
-        mapq2 = reduce.mapq_paired(best_o, best, scheme, fixed_read_len=L, o_fixed_read_len=L)      # MapqFunctorPE(mate 1)
+        mapq1 = reduce.mapq_paired(best, best_o, final_scheme, fixed_read_len=L, o_fixed_read_len=L)      # MapqFunctorPE(mate 0)
+        mapq2 = reduce.mapq_paired(best_o, best, final_scheme, fixed_read_len=L, o_fixed_read_len=L)      # MapqFunctorPE(mate 1)
     out = dict(best=best.data, best_o=best_o.data, mapq1=mapq1, mapq2=mapq2, opposite_dp_jobs=stats.pop("opposite_dp_jobs", 0), stats=stats)
     if traceback:
         # both mates' fw + rc patterns in one stream: a traceback picks its read by the alignment's mate bit (traceback_inl.h:117-120)
@@ -383,7 +398,7 @@ def best_approx_paired(fmi, rfmi, sym1, sym2, genome_words, genome_len, params=N
             with _Stage(stats, "traceback.anchor"):
                 v1, pb, tbeg, tlen = sel.traceback_best_setup(best.data, n, band_len, genome_len, L, n * L, mate_offset, want=0)
                 pat1, txt1 = sets(pb, tbeg, tlen)
-                tb1 = batch_banded_alignment_traceback(band_len, banded_aligner, pat1, txt1, quals=tq, cigar_stride=cigar_stride)
+                tb1 = batch_banded_alignment_traceback(band_len, tb_banded, pat1, txt1, quals=tq, cigar_stride=cigar_stride)
             # the opposite slots: opposite_traceback_best (full matrix over [alignment, alignment + sink)) for the concordant ones,
             # banded_traceback_best for the other aligned ones
             w_o = best_o.data[0]
@@ -392,7 +407,7 @@ def best_approx_paired(fmi, rfmi, sym1, sym2, genome_words, genome_len, params=N
             with _Stage(stats, "traceback.opposite_banded"):
                 vu, pb, tbeg, tlen = sel.traceback_best_setup(best_o.data, n, band_len, genome_len, L, n * L, mate_offset, want=2)
                 pat_u, txt_u = sets(pb, tbeg, tlen)
-                tb_u = batch_banded_alignment_traceback(band_len, banded_aligner, pat_u, txt_u, quals=tq, cigar_stride=cigar_stride)
+                tb_u = batch_banded_alignment_traceback(band_len, tb_banded, pat_u, txt_u, quals=tq, cigar_stride=cigar_stride)
             if ids_c.numel():
                 with _Stage(stats, "traceback.opposite_full"):
                     vc, pb, tbeg, tlen = sel.traceback_best_setup(best_o.data, n, band_len, genome_len, L, n * L, mate_offset, want=1, idx=ids_c)
@@ -400,17 +415,17 @@ def best_approx_paired(fmi, rfmi, sym1, sym2, genome_words, genome_len, params=N
                     # these windows end at the sink of the opposite-mate scoring pass, whose score the slot holds: the traceback drops
                     # the rows of the window no alignment with that score can reach
                     known = sel.traceback_best_known(best_o.data, None, n, idx=ids_c)[0]
-                    tb_c = batch_alignment_traceback(full_aligner, pat_c, txt_c, L, 1024, cigar_stride=cigar_stride, quals=tq, known_score=known)
+                    tb_c = batch_alignment_traceback(tb_full, pat_c, txt_c, L, 1024, cigar_stride=cigar_stride, quals=tq, known_score=None if ed_mode else known)
         if finish:
             out["best_scored"], out["best_o_scored"] = best.data.clone(), best_o.data.clone()
             with _Stage(stats, "finish"):
-                out["mds1"], out["mds1_len"] = sel.finish_alignment(v1, pat1, tq, txt1, tb1["cigar"], tb1["cigar_len"], tb1["source"], scheme, best.data, mds_stride=mds_stride)
+                out["mds1"], out["mds1_len"] = sel.finish_alignment(v1, pat1, tq, txt1, tb1["cigar"], tb1["cigar_len"], tb1["source"], final_scheme, best.data, mds_stride=mds_stride)
                 # the reference evaluates mate 2's MAPQ functor here, after the anchor slots were finished and before the opposite ones
                 # are (aligner_best_approx_paired.h:308-323)
-                out["mapq2"] = reduce.mapq_paired(best_o, best, scheme, fixed_read_len=L, o_fixed_read_len=L)
-                mds2, mds2_len = sel.finish_alignment(vu, pat_u, tq, txt_u, tb_u["cigar"], tb_u["cigar_len"], tb_u["source"], scheme, best_o.data, mds_stride=mds_stride)
+                out["mapq2"] = reduce.mapq_paired(best_o, best, final_scheme, fixed_read_len=L, o_fixed_read_len=L)
+                mds2, mds2_len = sel.finish_alignment(vu, pat_u, tq, txt_u, tb_u["cigar"], tb_u["cigar_len"], tb_u["source"], final_scheme, best_o.data, mds_stride=mds_stride)
                 if ids_c.numel():
-                    mc, mc_len = sel.finish_alignment(vc, pat_c, tq, txt_c, tb_c["cigar"], tb_c["cigar_len"], tb_c["source"], scheme, best_o.data, idx=ids_c,
+                    mc, mc_len = sel.finish_alignment(vc, pat_c, tq, txt_c, tb_c["cigar"], tb_c["cigar_len"], tb_c["source"], final_scheme, best_o.data, idx=ids_c,
                                                       mds_stride=mds_stride)
                     k = ids_c.to(torch.int64)
                     mds2[k] = mc[: k.numel()]; mds2_len[k] = mc_len

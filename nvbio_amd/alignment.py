@@ -44,6 +44,14 @@ class SmithWatermanScoringScheme:
         """SmithWatermanScoringScheme::local() (scoring_inl.h:81-101): match 2, score-min = log, 0 + 10 ln(len)"""
         return SmithWatermanScoringScheme(match=2, score_min=(1, 0.0, 10.0))
 
+    @staticmethod
+    def edit_distance(max_dist=15):
+        """EditDistanceAligner's costs (ed_utils.h:44-51: match 0, everything else -1) in this scheme's terms, with nvBowtie's edit-distance
+        threshold score-min = -max_dist (params.cpp:203-204): with them the Gotoh recurrences are the linear-gap ones cell for cell (gap
+        open == gap extension, so H >= E, F), which is how the drivers' scoring stages run --scoring ed on the quality-scheme kernels"""
+        return SmithWatermanScoringScheme(match=0, mmp_min=1, mmp_max=1, read_gap_const=0, read_gap_coeff=1, ref_gap_const=0, ref_gap_coeff=1,
+                                          mm_cost="constant", score_min=(0, -float(max_dist), 0.0))
+
     def perfect_score(self, read_len):                             # scoring.h:281
         return int(read_len) * self.m_match
 

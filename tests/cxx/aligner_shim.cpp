@@ -16,6 +16,7 @@ struct shim_params
     float    seed_freq_k, seed_freq_m;
     int32_t  match, score_min_type; float score_min_k, score_min_m;
     uint32_t finish;
+    uint32_t edit_distance;        // 1: --scoring ed (params.h:47-51), 0: Smith-Waterman
 };
 
 extern "C" __attribute__((visibility("default")))
@@ -36,7 +37,7 @@ int nvbio_aligner_best_approx(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmin
         params.select.randomized = sp->randomized != 0; params.select.top_seed = sp->top_seed; params.select.max_effort_init = sp->max_effort_init;
         params.select.max_effort = sp->max_effort; params.select.min_ext = sp->min_ext; params.select.max_ext = sp->max_ext;
         params.max_dist = sp->max_dist; params.alignment_type = sp->local ? LocalAlignment : EndToEndAlignment;
-        params.no_multi_hits = sp->no_multi_hits != 0; params.hits_stride = sp->hits_stride; params.finish_alignments = sp->finish != 0;
+        params.no_multi_hits = sp->no_multi_hits != 0; params.hits_stride = sp->hits_stride; params.finish_alignments = sp->finish != 0; params.scoring_mode = sp->edit_distance ? EditDistanceMode : SmithWatermanMode;
 
         aln::SmithWatermanScoringScheme scheme = sp->local ? aln::SmithWatermanScoringScheme::local() : aln::SmithWatermanScoringScheme();
         scheme.m_match = sp->match;
@@ -90,7 +91,7 @@ int nvbio_aligner_best_approx_timed(const nvbio_hip_fmindex* fmi, const nvbio_hi
         params.select.randomized = sp->randomized != 0; params.select.top_seed = sp->top_seed; params.select.max_effort_init = sp->max_effort_init;
         params.select.max_effort = sp->max_effort; params.select.min_ext = sp->min_ext; params.select.max_ext = sp->max_ext;
         params.max_dist = sp->max_dist; params.alignment_type = sp->local ? LocalAlignment : EndToEndAlignment;
-        params.no_multi_hits = sp->no_multi_hits != 0; params.hits_stride = sp->hits_stride; params.finish_alignments = sp->finish != 0;
+        params.no_multi_hits = sp->no_multi_hits != 0; params.hits_stride = sp->hits_stride; params.finish_alignments = sp->finish != 0; params.scoring_mode = sp->edit_distance ? EditDistanceMode : SmithWatermanMode;
         aln::SmithWatermanScoringScheme scheme = sp->local ? aln::SmithWatermanScoringScheme::local() : aln::SmithWatermanScoringScheme();
         scheme.m_match = sp->match;
         const ScoreLimits limits(sp->match, SimpleFunc(SimpleFunc::Type(sp->score_min_type), sp->score_min_k, sp->score_min_m));
@@ -160,7 +161,7 @@ int nvbio_aligner_best_approx_pipelined_names(const nvbio_hip_fmindex* fmi, cons
         params.select.randomized = sp->randomized != 0; params.select.top_seed = sp->top_seed; params.select.max_effort_init = sp->max_effort_init;
         params.select.max_effort = sp->max_effort; params.select.min_ext = sp->min_ext; params.select.max_ext = sp->max_ext;
         params.max_dist = sp->max_dist; params.alignment_type = sp->local ? LocalAlignment : EndToEndAlignment;
-        params.no_multi_hits = sp->no_multi_hits != 0; params.hits_stride = sp->hits_stride; params.finish_alignments = sp->finish != 0;
+        params.no_multi_hits = sp->no_multi_hits != 0; params.hits_stride = sp->hits_stride; params.finish_alignments = sp->finish != 0; params.scoring_mode = sp->edit_distance ? EditDistanceMode : SmithWatermanMode;
         aln::SmithWatermanScoringScheme scheme = sp->local ? aln::SmithWatermanScoringScheme::local() : aln::SmithWatermanScoringScheme();
         scheme.m_match = sp->match;
         const ScoreLimits limits(sp->match, SimpleFunc(SimpleFunc::Type(sp->score_min_type), sp->score_min_k, sp->score_min_m));
@@ -257,7 +258,7 @@ static int paired_impl(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmindex* rf
         params.select.randomized = sp->randomized != 0; params.select.top_seed = sp->top_seed; params.select.max_effort_init = sp->max_effort_init;
         params.select.max_effort = sp->max_effort; params.select.min_ext = sp->min_ext; params.select.max_ext = sp->max_ext;
         params.max_dist = sp->max_dist; params.alignment_type = sp->local ? LocalAlignment : EndToEndAlignment;
-        params.no_multi_hits = sp->no_multi_hits != 0; params.hits_stride = sp->hits_stride; params.finish_alignments = sp->finish != 0;
+        params.no_multi_hits = sp->no_multi_hits != 0; params.hits_stride = sp->hits_stride; params.finish_alignments = sp->finish != 0; params.scoring_mode = sp->edit_distance ? EditDistanceMode : SmithWatermanMode;
         PairedParams pe;
         pe.pe_policy = pp->pe_policy; pe.pe_overlap = pp->pe_overlap != 0; pe.pe_unpaired = pp->pe_unpaired != 0; pe.pe_discordant = pp->pe_discordant != 0;
         pe.min_frag_len = pp->min_frag_len; pe.max_frag_len = pp->max_frag_len;
@@ -392,7 +393,7 @@ int nvbio_aligner_best_approx_paired_pipelined(const nvbio_hip_fmindex* fmi, con
         params.select.randomized = sp->randomized != 0; params.select.top_seed = sp->top_seed; params.select.max_effort_init = sp->max_effort_init;
         params.select.max_effort = sp->max_effort; params.select.min_ext = sp->min_ext; params.select.max_ext = sp->max_ext;
         params.max_dist = sp->max_dist; params.alignment_type = sp->local ? LocalAlignment : EndToEndAlignment;
-        params.no_multi_hits = sp->no_multi_hits != 0; params.hits_stride = sp->hits_stride; params.finish_alignments = sp->finish != 0;
+        params.no_multi_hits = sp->no_multi_hits != 0; params.hits_stride = sp->hits_stride; params.finish_alignments = sp->finish != 0; params.scoring_mode = sp->edit_distance ? EditDistanceMode : SmithWatermanMode;
         PairedParams pe;
         pe.pe_policy = pp->pe_policy; pe.pe_overlap = pp->pe_overlap != 0; pe.pe_unpaired = pp->pe_unpaired != 0; pe.pe_discordant = pp->pe_discordant != 0;
         pe.min_frag_len = pp->min_frag_len; pe.max_frag_len = pp->max_frag_len;

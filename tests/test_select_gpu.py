@@ -470,7 +470,7 @@ class _ShimParams(_C.Structure):
                                            "max_hits", "allow_sub", "subseed_len", "seed_len", "seed_freq_type", "min_read_len", "max_dist", "no_multi_hits",
                                            "batch_size", "hits_stride")] + \
                [("seed_freq_k", _C.c_float), ("seed_freq_m", _C.c_float), ("match", _C.c_int32), ("score_min_type", _C.c_int32),
-                ("score_min_k", _C.c_float), ("score_min_m", _C.c_float), ("finish", _C.c_uint32)]
+                ("score_min_k", _C.c_float), ("score_min_m", _C.c_float), ("finish", _C.c_uint32), ("edit_distance", _C.c_uint32)]
 
 
 @pytest.mark.parametrize("config", ["default", "no_rand", "one_hit_rounds", "multi_rounds", "one_mismatch_seeds", "local", "low_effort", "finish"])
@@ -529,6 +529,61 @@ def test_cxx_aligner_driver_matches_oracle(cuda, config):
     assert (source[ids] == tb["source"]).all() and (sink[ids] == tb["sink"]).all() and (tb_score[ids] == tb["score"]).all()
     rest = ~np.isin(np.arange(n), ids)
     assert (cigar_len[rest] == 0).all() and (source[rest] == 0xFFFFFFFF).all()
+
+
+@pytest.mark.parametrize("max_dist", [15, 7])
+def test_cxx_aligner_driver_in_edit_distance_mode_equals_the_python_driver(cuda, max_dist):
+    """--scoring ed (params.h:47-51, compute_thread.cu:296): both from-scratch drivers extend, reduce and trace with the edit-distance
+    aligner against score-min = -max_dist, and give MAPQ and the final scores from the Smith-Waterman scheme.  The Python driver is held
+    to the unchanged nvBowtie by tests/test_ref_tests_gpu.py (--scoring ed); here the C++ driver is held to the Python one."""
+    import ctypes as C
+    shim = C.CDLL(os.path.join(HERE, "cxx", "libaligner_shim.so"))
+    rng = np.random.default_rng(321 + max_dist)
+    text = _small_index(rng)
+    host, rhost = O.FMIndex(text), O.FMIndex(text[::-1].copy())
+    fmi, rfmi = nvb.FMIndexDevice.from_host(host, cuda), nvb.FMIndexDevice.from_host(rhost, cuda)
+    n, L = 1500, 100
+    sym, pos = _reads(rng, text, n, L)
+    names = ["sim.%d" % i for i in range(n)]
+    params = A.Params(scoring_mode="ed", max_dist=max_dist)
+    scheme = nvb.SmithWatermanScoringScheme()
+    gw = W._pack_chunked(torch.from_numpy(text), 2, True)
+    d_sym = torch.from_numpy(sym).to(cuda)
+    d_gw = gw.to(cuda)
+    e = A.best_approx(fmi, rfmi, d_sym, d_gw, text.size, params, scheme, names, finish=True, cigar_stride=64)
+    sw = A.best_approx(fmi, rfmi, d_sym, d_gw, text.size, A.Params(max_dist=max_dist), scheme, names, finish=True, cigar_stride=64)
+    reads_rev, fwrc = P.pack_read_streams(d_sym)
+    quals = torch.full((2 * n * L + 8,), 30, dtype=torch.uint8, device=cuda)
+    arena, idx = S.pack_names(names, cuda)
+    sp = _ShimParams(int(params.local), int(params.randomized), params.top_seed, params.max_effort_init, params.max_effort, params.min_ext, params.max_ext,
+                     params.max_reseed, params.rep_seeds, params.max_hits, params.allow_sub, params.subseed_len, params.seed_len, params.seed_freq[0],
+                     params.min_read_len, params.max_dist, int(params.no_multi_hits), params.batch_size, params.hits_stride or 0,
+                     params.seed_freq[1], params.seed_freq[2], scheme.m_match, scheme.m_score_min[0], scheme.m_score_min[1], scheme.m_score_min[2], 1, 1)
+    mds = np.zeros((n, 256), np.uint8); mds_len = np.zeros(n, np.uint32)
+    best = np.zeros((2, n), np.uint64); mapq = np.zeros(n, np.uint8); cigar = np.zeros((n, 64), np.uint16); cigar_len = np.zeros(n, np.uint32)
+    source = np.zeros((n, 2), np.uint32); sink = np.zeros((n, 2), np.uint32); tb_score = np.zeros(n, np.int32); stats = np.zeros(12, np.uint64)
+    fs, rs = fmi.struct(), rfmi.struct()
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    hp = lambda a: a.ctypes.data_as(C.c_void_p)
+    torch.cuda.synchronize()
+    rc = shim.nvbio_aligner_best_approx(C.byref(fs), C.byref(rs), C.c_uint32(n), C.c_uint32(L), vp(reads_rev.words), C.c_uint64(reads_rev.words.numel()),
+                                        vp(reads_rev.begin), vp(fwrc), C.c_uint64(fwrc.numel()), vp(quals), C.c_uint64(quals.numel()), vp(arena), vp(idx),
+                                        vp(d_gw), C.c_uint64(d_gw.numel()), C.c_uint32(text.size), C.byref(sp),
+                                        hp(best), hp(mapq), hp(cigar), hp(cigar_len), hp(source), hp(sink), hp(tb_score), hp(stats), hp(mds), hp(mds_len))
+    assert rc == 0
+    eb = e["best"].cpu().numpy().view(np.uint64)
+    assert (best == eb).all() and (mapq == e["mapq"].cpu().numpy()).all()
+    ids = e["aligned_ids"].cpu().numpy()
+    assert ids.size > n // 2
+    assert (cigar_len[ids] == e["cigar_len"].cpu().numpy().view(np.uint32)[ids]).all()
+    assert (cigar[ids] == e["cigar"].cpu().numpy().view(np.uint16)[ids]).all()
+    assert (source[ids] == e["source"].cpu().numpy().view(np.uint32)[ids]).all()
+    assert (mds_len[ids] == e["mds_len"].cpu().numpy().view(np.uint32)[ids]).all()
+    # the mode matters: the two modes accept different reads (max_dist edits against score-min = -0.6 - 0.6 L)
+    sb = sw["best"].cpu().numpy().view(np.uint64)
+    aligned_ed = (eb[0] >> np.uint64(32)) != np.uint64(0xFFFFFFFF)
+    aligned_sw = (sb[0] >> np.uint64(32)) != np.uint64(0xFFFFFFFF)
+    assert (aligned_ed != aligned_sw).any() and (eb != sb).any()
 
 
 @pytest.mark.parametrize("config", ["default", "local", "one_mismatch_seeds"])
@@ -692,3 +747,65 @@ def test_cxx_paired_aligner_driver_matches_oracle(cuda, config):
             assert (out["mds_len"][slot] == e[key]["mds_len"]).all(), key
             m = np.arange(256)[None, :] < np.minimum(e[key]["mds_len"], 256)[:, None]
             assert ((out["mds"][slot] == e[key]["mds"]) | ~m).all(), key
+
+
+def test_cxx_paired_driver_in_edit_distance_mode_equals_the_python_driver(cuda):
+    """--scoring ed for read pairs: anchor and opposite mates extended against the edit-distance costs and score-min = -max_dist, traced with
+    the edit-distance aligner's banded and full-matrix walks, MAPQ and final scores from the Smith-Waterman scheme -- the C++ driver against
+    the Python one (which tests/test_ref_tests_gpu.py holds to the unchanged nvBowtie --scoring ed)."""
+    import ctypes as C
+    shim = C.CDLL(os.path.join(HERE, "cxx", "libaligner_shim.so"))
+    rng = np.random.default_rng(4321)
+    text = _small_index(rng, 1 << 17)
+    host, rhost = O.FMIndex(text), O.FMIndex(text[::-1].copy())
+    fmi, rfmi = nvb.FMIndexDevice.from_host(host, cuda), nvb.FMIndexDevice.from_host(rhost, cuda)
+    n, L = 900, 100
+    s1, s2, pos, flen = _pairs(rng, text, n, L)
+    names = ["pair.%d" % i for i in range(n)]
+    params = A.Params(scoring_mode="ed")
+    scheme = nvb.SmithWatermanScoringScheme()
+    gw = W._pack_chunked(torch.from_numpy(text), 2, True)
+    d1, d2, d_gw = torch.from_numpy(s1).to(cuda), torch.from_numpy(s2).to(cuda), gw.to(cuda)
+    e = A.best_approx_paired(fmi, rfmi, d1, d2, d_gw, text.size, params, scheme, names, finish=True)
+    sw = A.best_approx_paired(fmi, rfmi, d1, d2, d_gw, text.size, A.Params(), scheme, names, finish=True)
+    packed = [P.pack_read_streams(x) for x in (d1, d2)]
+    quals = torch.full((2 * n * L + 8,), 30, dtype=torch.uint8, device=cuda)
+    both = torch.cat([packed[0][1], packed[1][1]]); mate_offset = packed[0][1].numel() * 8
+    both_q = torch.full((mate_offset + 2 * n * L + 8,), 30, dtype=torch.uint8, device=cuda)
+    arena, idx = S.pack_names(names, cuda)
+    sp = _ShimParams(int(params.local), int(params.randomized), params.top_seed, params.max_effort_init, params.max_effort, params.min_ext, params.max_ext,
+                     params.max_reseed, params.rep_seeds, params.max_hits, params.allow_sub, params.subseed_len, params.seed_len, params.seed_freq[0],
+                     params.min_read_len, params.max_dist, int(params.no_multi_hits), params.batch_size, params.hits_stride or 0,
+                     params.seed_freq[1], params.seed_freq[2], scheme.m_match, scheme.m_score_min[0], scheme.m_score_min[1], scheme.m_score_min[2], 1, 1)
+    pp = _ShimPeParams(params.pe_policy, int(params.pe_overlap), int(params.pe_unpaired), int(params.pe_discordant), params.min_frag_len, params.max_frag_len)
+    out = dict(best=[np.zeros((2, n), np.uint64) for _ in range(2)], mapq=[np.zeros(n, np.uint8) for _ in range(2)], cigar=[np.zeros((n, 64), np.uint16) for _ in range(2)],
+               cigar_len=[np.zeros(n, np.uint32) for _ in range(2)], source=[np.zeros((n, 2), np.uint32) for _ in range(2)], sink=[np.zeros((n, 2), np.uint32) for _ in range(2)],
+               mds=[np.zeros((n, 256), np.uint8) for _ in range(2)], mds_len=[np.zeros(n, np.uint32) for _ in range(2)])
+    stats = np.zeros(12, np.uint64)
+    pair_ptrs = lambda ts: (C.c_void_p * 2)(*[t.data_ptr() for t in ts])
+    pair_host = lambda arrs: (C.c_void_p * 2)(*[a.ctypes.data for a in arrs])
+    u64x2 = lambda v: (C.c_uint64 * 2)(*v)
+    fs, rs = fmi.struct(), rfmi.struct()
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    torch.cuda.synchronize()
+    rc = shim.nvbio_aligner_best_approx_paired(
+        C.byref(fs), C.byref(rs), C.c_uint32(n), C.c_uint32(L),
+        pair_ptrs([packed[0][0].words, packed[1][0].words]), u64x2([packed[0][0].words.numel(), packed[1][0].words.numel()]), pair_ptrs([packed[0][0].begin, packed[1][0].begin]),
+        pair_ptrs([packed[0][1], packed[1][1]]), u64x2([packed[0][1].numel(), packed[1][1].numel()]), vp(quals), C.c_uint64(quals.numel()), vp(arena), vp(idx),
+        vp(both), C.c_uint64(both.numel()), C.c_uint64(mate_offset), vp(both_q), C.c_uint64(both_q.numel()),
+        vp(d_gw), C.c_uint64(d_gw.numel()), C.c_uint32(text.size), C.byref(sp), C.byref(pp),
+        pair_host(out["best"]), pair_host(out["mapq"]), pair_host(out["cigar"]), pair_host(out["cigar_len"]), pair_host(out["source"]), pair_host(out["sink"]),
+        pair_host(out["mds"]), pair_host(out["mds_len"]), stats.ctypes.data_as(C.c_void_p))
+    assert rc == 0
+    u64 = lambda t: t.cpu().numpy().view(np.uint64)
+    assert (out["best"][0] == u64(e["best"])).all() and (out["best"][1] == u64(e["best_o"])).all()
+    assert (out["mapq"][0] == e["mapq1"].cpu().numpy()).all() and (out["mapq"][1] == e["mapq2"].cpu().numpy()).all()
+    for slot, key, md in ((0, "tb1", "mds1"), (1, "tb2", "mds2")):
+        assert (out["cigar_len"][slot] == e[key]["cigar_len"].cpu().numpy().view(np.uint32)).all(), key
+        assert (out["cigar"][slot] == e[key]["cigar"].cpu().numpy().view(np.uint16)).all(), key
+        assert (out["source"][slot] == e[key]["source"].cpu().numpy().view(np.uint32)).all(), key
+        assert (out["mds_len"][slot] == e[md + "_len"].cpu().numpy().view(np.uint32)).all(), md
+    b = u64(e["best"])[0]
+    paired = ((b >> np.uint64(30)) & np.uint64(1)) != 0
+    assert paired.mean() > 0.5                                        # most pairs come back paired in this mode too
+    assert (u64(e["best"]) != u64(sw["best"])).any()                  # ... and the mode is not the Smith-Waterman one

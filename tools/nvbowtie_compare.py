@@ -115,7 +115,7 @@ def prepare(args):
     overrides = {}
     for kv in filter(None, getattr(args, "own", "").split(",")):
         k, v = kv.split("=")
-        overrides[k] = (v == "True") if v in ("True", "False") else int(v)
+        overrides[k] = (v == "True") if v in ("True", "False") else (int(v) if v.lstrip("-").isdigit() else v)
     extra = getattr(args, "extra", "").split()
     n_genome, L, n = 200_000, (getattr(args, "len", 100) if args.mode != "paired" else 100), args.reads
     prefix, text = write_reference(tmp, rng, n_genome, [("chrA", 120_000), ("chrB", 80_000)], getattr(args, "repeats", 0.0))
