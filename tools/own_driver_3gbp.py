@@ -107,6 +107,35 @@ def death_probe(fmi, genome_words, ng, sym, qual, prm, dev, rows=(20, 40, 60, 80
     return tally
 
 
+def duplicate_probe(fmi, genome_words, ng, sym, qual, prm, dev):
+    """The Python driver on one batch, recording every DP job's (pattern begin = read and strand, window begin): how many of a batch's DP
+    jobs repeat a job the same read already ran (several seeds of a read point at one placement: same diagonal, same window)."""
+    from nvbio_amd import aligner as A, select as SEL
+    n, L = sym.shape
+    keys, per_round = [], []
+    real_setup = SEL.score_best_setup
+
+    def setup(*args, **kw):
+        r = real_setup(*args, **kw)
+        pb, tb, tl = r[0], r[2], r[3]
+        live = tl != 0
+        k = (pb[live].to(torch.int64) << 33) | (tb[live].to(torch.int64) & 0x1FFFFFFFF)
+        keys.append(k)
+        per_round.append((int(k.numel()), int(torch.unique(k).numel())))
+        return r
+
+    SEL.score_best_setup = setup
+    try:
+        index = torch.arange(0, (n + 1) * L, L, dtype=torch.int64, device=dev)
+        rb = A.ReadBatch.from_ragged(sym.reshape(-1), index, qual.reshape(-1))
+        A.best_approx(fmi, None, rb, genome_words, ng, prm, names=["r%08d" % i for i in range(n)], cigar_stride=64, finish=False)
+    finally:
+        SEL.score_best_setup = real_setup
+    allk = torch.cat(keys)
+    return dict(jobs=int(allk.numel()), distinct=int(torch.unique(allk).numel()), distinct_within_rounds=sum(u for _, u in per_round), rounds=len(per_round),
+                per_round_sample=per_round[:12] + per_round[12::10])
+
+
 def measure(genome=3_000_000_000, reads=5_000_000, batch=1 << 20, repeats=0.6, index="default", workers=(1, 2), check=False, stage_clock=True, reps=2,
             probe=False, verbose=False, lean_check=False):
     """-> dict.  check: batch 0's (best, mapq) against the Python driver's; lean_check: every batch's against the same C++ driver on the index in
@@ -168,6 +197,9 @@ def measure(genome=3_000_000_000, reads=5_000_000, batch=1 << 20, repeats=0.6, i
         if verbose:
             print(json.dumps(out["one_batch"]), flush=True)
 
+    if os.environ.get("OWN_DRIVER_DUP_PROBE"):
+        out["duplicate_probe"] = duplicate_probe(fmi, genome_words, ng, sym[:batch], qual[:batch], prm, dev)
+        print(json.dumps(out["duplicate_probe"]), flush=True)
     if probe:
         out["death_probe"] = death_probe(fmi, genome_words, ng, sym[:batch], qual[:batch], prm, dev)
         if verbose:
