@@ -201,7 +201,9 @@ private:
         const uint32 count = reads.n, L = reads.len, B = SCORING_BATCH;
         const uint32 band_len = band_length(params.max_dist);
         const uint32 hits_stride = params.hits_stride ? params.hits_stride : std::min(params.max_hits, 128u);
-        const aln::GotohAligner<TYPE, aln::SmithWatermanScoringScheme> aligner(scoring_scheme);
+        // (Params::scoring_mode: hits scored and traced with the edit-distance aligner, finished with the caller's scheme -- see best_approx_t)
+        const bool ed_mode = params.scoring_mode == EditDistanceMode;
+        const aln::GotohAligner<TYPE, aln::SmithWatermanScoringScheme> aligner(params.search_scheme(scoring_scheme));
         n_alignments = 0;
         if (count == 0) return;
 
@@ -213,7 +215,7 @@ private:
             if (L >= params.min_read_len && f > 0 && (L - std::min(params.seed_len, L)) / uint32(f) + 1u > max_seeds)
                 throw std::runtime_error("Aligner::all: the reference's seed cap would drop seeds at this seeding interval (unsupported)");
         }
-        hip::device_vector<int32>   min_score_table(limits.min_score_table(L));
+        hip::device_vector<int32>   min_score_table(params.search_limits(limits).min_score_table(L));
         std::vector<uint32> iota(std::max(count, B)); std::iota(iota.begin(), iota.end(), 0u);
         hip::device_vector<uint32>  d_iota(iota);
         hip::device_vector<SeedHit> hit_data(size_t(count) * hits_stride);
@@ -337,6 +339,18 @@ private:
             const PackedStringSetView<2, true>  texts(nb, genome_words, genome_n_words, tb_txt.data(), tb_len.data(), 0u);
             const aln::AlignmentArrays alignments = { traceback_score.data() + off, cigar_source.data() + 2u * off, cigar_sink.data() + 2u * off };
             const aln::CigarArrays     cigars     = { cigar.data() + off * cigar_stride, cigar_stride, cigar_len.data() + off };
+            if (ed_mode)
+            {
+                const nvbio_hip_sw_scheme w = { 0, -1, -1, -1 };
+                const nvbio_hip_string_set p = patterns.abi(), t = texts.abi();
+                const uint32 bl = band_len < 4 ? 3u : band_len < 8 ? 7u : band_len < 16 ? 15u : 31u;
+                hip::device_vector<uint8> temp(nvbio_hip_banded_gotoh_traceback_temp_bytes(bl, L, nb));
+                hip_check(nvbio_hip_banded_sw_traceback(&w, int32(TYPE), bl, &p, &t, L, L + band_len, nb, alignments.score, alignments.sink, alignments.source,
+                                                        reinterpret_cast<uint16*>(cigars.cigar), cigar_stride, cigars.cigar_len, temp.data(), temp.size(), hip_stream),
+                          "nvbio_hip_banded_sw_traceback");
+                hip::synchronize(hip_stream);
+            }
+            else
             dispatch_band(band_len, [&](auto band) {
                 typedef aln::PackedTracebackStream<aln::GotohAligner<TYPE, aln::SmithWatermanScoringScheme>, PackedStringSetView<4, true>, PackedStringSetView<2, true> > stream_type;
                 const stream_type stream(aligner, patterns, texts, alignments, cigars, L, L + band_len, reads.quals, reads.n_quals);

@@ -454,6 +454,8 @@ def all_mapping(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=No
     n, L = batch.n, batch.max_len
     dev = batch.fw_rc_words.device
     scheme = scheme or (SmithWatermanScoringScheme.local() if params.local else SmithWatermanScoringScheme())
+    ed_mode = params.scoring_mode == "ed"                  # all_ed (compute_thread.cu:265-278): see best_approx
+    final_scheme, scheme = scheme, (SmithWatermanScoringScheme.edit_distance(params.max_dist) if ed_mode else scheme)
     aligner = make_gotoh_aligner(LOCAL if params.local else SEMI_GLOBAL, scheme)
     band_len = band_length(params.max_dist)
     mp = params.mapping_params()
@@ -525,11 +527,15 @@ def all_mapping(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=No
                 pb, pl, tb, tl = sel.traceback_all_setup(a, r, band_len, genome_len, fixed_read_len=batch.fixed_len, read_begin=batch.read_begin,
                                                          read_len=batch.read_len, rc_offset=batch.rc_offset)
                 pat, txt = PackedStringSet(batch.fw_rc_words, 4, True, pb, pl, batch.fixed_len), PackedStringSet(genome_words, 2, True, tb, tl, 0)
-                t = batch_banded_alignment_traceback(band_len, aligner, pat, txt, max_pattern_length=L, quals=batch.quals, cigar_stride=cigar_stride,
-                                                     known=(k_score[off:off + B].contiguous(), k_sink[off:off + B].contiguous()))
+                if ed_mode:
+                    t = batch_banded_alignment_traceback(band_len, make_edit_distance_aligner(LOCAL if params.local else SEMI_GLOBAL), pat, txt, max_pattern_length=L,
+                                                         max_text_length=L + band_len, cigar_stride=cigar_stride)
+                else:
+                    t = batch_banded_alignment_traceback(band_len, aligner, pat, txt, max_pattern_length=L, quals=batch.quals, cigar_stride=cigar_stride,
+                                                         known=(k_score[off:off + B].contiguous(), k_sink[off:off + B].contiguous()))
             with _Stage(stats, "finish"):
                 valid = torch.ones(a.numel(), dtype=torch.uint8, device=dev)
-                md, mdl = sel.finish_alignment(valid, pat, batch.quals, txt, t["cigar"], t["cigar_len"], t["source"], scheme, a, mds_stride=mds_stride)
+                md, mdl = sel.finish_alignment(valid, pat, batch.quals, txt, t["cigar"], t["cigar_len"], t["source"], final_scheme, a, mds_stride=mds_stride)
             cig.append(t["cigar"][: a.numel()]); cl.append(t["cigar_len"][: a.numel()]); src.append(t["source"][: a.numel()]); snk.append(t["sink"][: a.numel()])
             mds.append(md[: a.numel()]); ml.append(mdl)
         out.update(cigar=torch.cat(cig), cigar_len=torch.cat(cl), source=torch.cat(src), sink=torch.cat(snk), mds=torch.cat(mds), mds_len=torch.cat(ml))

@@ -478,6 +478,7 @@ int nvbio_aligner_all(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmindex* rfm
         params.min_read_len = sp->min_read_len; params.max_hits = sp->max_hits; params.max_reseed = sp->max_reseed; params.rep_seeds = sp->rep_seeds;
         params.allow_sub = sp->allow_sub; params.subseed_len = sp->subseed_len;
         params.max_dist = sp->max_dist; params.alignment_type = sp->local ? LocalAlignment : EndToEndAlignment; params.hits_stride = sp->hits_stride;
+        params.scoring_mode = sp->edit_distance ? EditDistanceMode : SmithWatermanMode;
         aln::SmithWatermanScoringScheme scheme = sp->local ? aln::SmithWatermanScoringScheme::local() : aln::SmithWatermanScoringScheme();
         scheme.m_match = sp->match;
         const ScoreLimits limits(sp->match, SimpleFunc(SimpleFunc::Type(sp->score_min_type), sp->score_min_k, sp->score_min_m));
