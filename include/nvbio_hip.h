@@ -753,6 +753,13 @@ int nvbio_hip_traceback_best_setup(uint32_t n, const uint32_t* idx /* nullable *
                                    uint64_t rc_offset, uint64_t mate_offset, int32_t want,
                                    uint8_t* out_valid, uint64_t* pattern_begin, uint32_t* pattern_len /* nullable iff fixed */,
                                    uint64_t* text_begin, uint32_t* text_len, void* stream);
+/* ... for pairs whose mates have their own lengths (the reference's paired driver takes them as they come, aligner_best_approx_paired.h): mate m's
+ * reads sit at read_begin[m][r] (or r * fixed_read_len[m]) of ITS half of the pattern stream, reverse complements rc_offset[m] further; mate 1's
+ * half starts mate_offset symbols into the stream.  The entry's mate bit picks the half.  pattern_len is always written. */
+int nvbio_hip_traceback_best_setup_mates(uint32_t n, const uint32_t* idx /* nullable */, const uint64_t* best_alignments, uint32_t band_len, uint32_t genome_length,
+                                         const uint64_t* const read_begin[2] /* host array of device pointers, each nullable */, const uint32_t* const read_len[2],
+                                         const uint32_t fixed_read_len[2], const uint64_t rc_offset[2], uint64_t mate_offset, int32_t want,
+                                         uint8_t* out_valid, uint64_t* pattern_begin, uint32_t* pattern_len, uint64_t* text_begin, uint32_t* text_len, void* stream);
 
 /* finish_alignment_kernel + BestTracebackStream::finish (nvBowtie/bowtie2/cuda/traceback_inl.h:523-722, :177-189): for job i with
  * valid[i] != 0, replay its CIGAR (cigar[i * cigar_stride ..], cigar_len[i] words stored end first, first text column

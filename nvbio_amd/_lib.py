@@ -21,7 +21,7 @@ SYMBOLS = [
     "nvbio_hip_score_best_setup", "nvbio_hip_score_reduce_best_approx",
     "nvbio_hip_anchor_score_setup", "nvbio_hip_anchor_score_finish", "nvbio_hip_anchor_memo_mark", "nvbio_hip_anchor_score_finish_memo", "nvbio_hip_anchor_memo_update", "nvbio_hip_opposite_score_setup", "nvbio_hip_opposite_score_finish",
     "nvbio_hip_score_reduce_paired_best_approx", "nvbio_hip_mark_discordant",
-    "nvbio_hip_pack_read_queue", "nvbio_hip_mark_unaligned", "nvbio_hip_copy_flagged_temp_bytes", "nvbio_hip_copy_flagged", "nvbio_hip_traceback_best_setup", "nvbio_hip_finish_alignment", "nvbio_hip_scatter_rows",
+    "nvbio_hip_pack_read_queue", "nvbio_hip_mark_unaligned", "nvbio_hip_copy_flagged_temp_bytes", "nvbio_hip_copy_flagged", "nvbio_hip_traceback_best_setup", "nvbio_hip_traceback_best_setup_mates", "nvbio_hip_finish_alignment", "nvbio_hip_scatter_rows",
     "nvbio_hip_gather_ranges", "nvbio_hip_select_all", "nvbio_hip_mark_straddling", "nvbio_hip_score_all_setup", "nvbio_hip_score_all_output",
     "nvbio_hip_traceback_all_setup", "nvbio_hip_all_mapping_temp_bytes", "nvbio_hip_inclusive_scan_u32", "nvbio_hip_inclusive_scan_u64", "nvbio_hip_sort_hi_bits",
     "nvbio_hip_sort_hits", "nvbio_hip_gather_rows", "nvbio_hip_list_flagged", "nvbio_hip_opposite_memo_lookup", "nvbio_hip_opposite_memo_update", "nvbio_hip_traceback_best_known", "nvbio_hip_banded_gotoh_traceback_qual_known",
@@ -186,6 +186,8 @@ def lib():
         L.nvbio_hip_copy_flagged.argtypes = [u32, vp, vp, vp, vp, vp, u64, vp]
         L.nvbio_hip_finish_alignment.argtypes = [u32, vp, P(StringSetStruct), vp, u64, P(StringSetStruct), vp, u32, vp, vp, i32, vp, i32, vp, vp, vp, vp, u32, vp, vp]
         L.nvbio_hip_traceback_best_setup.argtypes = [u32, vp, vp, u32, u32, vp, vp, u32, u64, u64, i32, vp, vp, vp, vp, vp, vp]
+        L.nvbio_hip_traceback_best_setup_mates.argtypes = [u32, vp, vp, u32, u32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
+                                                           u64, i32, vp, vp, vp, vp, vp, vp]
         L.nvbio_hip_score_reduce_paired.argtypes = [u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, i32, i32, i32, vp, vp, u32, vp]
         L.nvbio_hip_opposite_mate_windows.argtypes = [u32, vp, vp, vp, vp, vp, vp, u32, u32, vp, vp, u32, i32, vp, i32, i32, P(PeParamsStruct),
                                                       vp, vp, vp, vp, vp, vp]

@@ -260,10 +260,15 @@ def best_approx(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=No
 # paired-end: Aligner::best_approx / best_approx_score of aligner_best_approx_paired.h (:95-453, :455-700)
 # ------------------------------------------------------------------------------------------------------------------
 def best_approx_score_paired(fmi, rfmi, state, seed_queue, anchor, best, best_o, a_words, o_words, n_reads, read_len, genome_words, genome_len,
-                             scheme, banded_aligner, full_aligner, quals, table, params, band_len, stats, memo, o_quals=None):
+                             scheme, banded_aligner, full_aligner, quals, table, params, band_len, stats, memo, o_quals=None, a_batch=None, o_batch=None):
     """The extension rounds of one seeding pass of one anchor mate (`quals`: the anchor mate's quality stream, `o_quals`: the opposite mate's): select, locate, anchor_score_best, opposite_score_best over the
     hits whose anchor scored, score_reduce_paired with the give-up counters."""
     L = read_len
+    # mates of their own lengths (a_batch / o_batch: the anchor and opposite mates' ReadBatch): per-read begins and lengths; else every read is L long
+    ragged = a_batch is not None and (a_batch.read_len is not None or o_batch.read_len is not None)
+    a_fix, o_fix = (a_batch.fixed_len, o_batch.fixed_len) if ragged else (L, L)
+    a_rc, o_rc = (a_batch.rc_offset, o_batch.rc_offset) if ragged else (n_reads * L, n_reads * L)
+    a_begin, a_len, o_begin, o_len = (a_batch.read_begin, a_batch.read_len, o_batch.read_begin, o_batch.read_len) if ragged else (None, None, None, None)
     active = seed_queue.to(torch.int32)
     if params.top_seed & 1:
         active = active | torch.tensor(-(1 << 31), dtype=torch.int32, device=active.device)
@@ -284,13 +289,16 @@ def best_approx_score_paired(fmi, rfmi, state, seed_queue, anchor, best, best_o,
         with _Stage(stats, "locate"):
             sel.locate_hits(fmi, rfmi, loc, seed)
         with _Stage(stats, "anchor_score"):
-            pb, tb, tl, ms = sel.anchor_score_setup(rid, loc, seed, best, best_o, scheme, anchor, band_len, genome_len, WORST_SCORE, L, L, n_reads * L, table)
-            raw, raw_sink = batch_banded_alignment_score(band_len, banded_aligner, PackedStringSet(a_words, 4, True, pb, None, L),
-                                                         PackedStringSet(genome_words, 2, True, tb, tl, 0), quals=quals)
+            r = sel.anchor_score_setup(rid, loc, seed, best, best_o, scheme, anchor, band_len, genome_len, WORST_SCORE, a_fix, o_fix, a_rc, table,
+                                       a_read_begin=a_begin, a_read_len=a_len, o_read_len=o_len)
+            pb, tb, tl, ms = r[:4]
+            pl = r[4] if len(r) > 4 else None
+            raw, raw_sink = batch_banded_alignment_score(band_len, banded_aligner, PackedStringSet(a_words, 4, True, pb, pl, 0 if pl is not None else L),
+                                                         PackedStringSet(genome_words, 2, True, tb, tl, 0), max_pattern_length=L, quals=quals)
             hit_score, hit_sink = sel.anchor_score_finish(raw, raw_sink, tb, ms, WORST_SCORE)
         with _Stage(stats, "opposite_score"):
-            ow = sel.opposite_score_setup(rid, seed, loc, hit_score, WORST_SCORE, best, best_o, scheme, anchor, genome_len, L, L, params.pe_policy,
-                                          params.min_frag_len, params.max_frag_len, params.pe_overlap, WORST_SCORE, table)
+            ow = sel.opposite_score_setup(rid, seed, loc, hit_score, WORST_SCORE, best, best_o, scheme, anchor, genome_len, a_fix, o_fix, params.pe_policy,
+                                          params.min_frag_len, params.max_frag_len, params.pe_overlap, WORST_SCORE, table, a_read_len=a_len, o_read_len=o_len)
             # jobs whose (window, threshold, strand) equal the pair's last scored job are answered from the memo: the reference
             # re-runs them and absorbs the identical result
             o_out = sel.opposite_outputs(int(loc.numel()), WORST_SCORE, loc.device)
@@ -301,7 +309,10 @@ def best_approx_score_paired(fmi, rfmi, state, seed_queue, anchor, best, best_o,
             if idx.numel():
                 ob = ow["genome_begin"].to(torch.int64)[idx] & 0xFFFFFFFF
                 oe = ow["genome_end"].to(torch.int64)[idx] & 0xFFFFFFFF
-                o_pat = PackedStringSet(o_words, 4, True, ((rid.to(torch.int64)[idx] & 0xFFFFFFFF) * L + ow["read_rc"].to(torch.int64)[idx] * (n_reads * L)).contiguous(), None, L)
+                r_o = rid.to(torch.int64)[idx] & 0xFFFFFFFF
+                o_first = o_begin[r_o] if o_begin is not None else r_o * o_fix
+                o_plen = o_len[r_o].contiguous() if o_len is not None else None
+                o_pat = PackedStringSet(o_words, 4, True, (o_first + ow["read_rc"].to(torch.int64)[idx] * o_rc).contiguous(), o_plen, 0 if o_plen is not None else L)
                 o_txt = PackedStringSet(genome_words, 2, True, ob.contiguous(), (oe - ob).to(torch.int32).contiguous(), 0)
                 o_ms = ow["min_score"][idx].contiguous()
                 max_n = int(params.max_frag_len) + L
@@ -314,7 +325,7 @@ def best_approx_score_paired(fmi, rfmi, state, seed_queue, anchor, best, best_o,
         with _Stage(stats, "reduce"):
             sel.score_reduce_paired_best_approx(best, best_o, state, active, hit_begin, loc, hit_sink, hit_score, seed, o_loc, o_sink, o_sink2, o_score, o_score2,
                                                 anchor, params.pe_policy, params.pe_unpaired, WORST_SCORE, n_ext, params.min_ext, params.max_ext,
-                                                params.max_effort, L)
+                                                params.max_effort, a_fix, read_len=a_len)
         if traced is not None and traced.numel():
             TRACE["events"].append(dict(n_ext=n_ext, sa_rows=[r & 0xFFFFFFFF for r in rows], seeds=[x & 0xFFFFFFFF for x in seed[traced].cpu().tolist()],
                                         positions=[x & 0xFFFFFFFF for x in loc[traced].cpu().tolist()], scores=score[traced].cpu().tolist()))
@@ -331,9 +342,17 @@ def best_approx_paired(fmi, rfmi, sym1, sym2, genome_words, genome_len, params=N
     "2" = best_data_o): cigar, cigar_len, source, sink; stats)."""
     from .pipeline import pack_read_streams
     params = params or Params()
-    n, L = sym1.shape
-    assert sym2.shape == sym1.shape
-    dev = sym1.device
+    # mates of their own lengths: two ReadBatch objects (ReadBatch.from_ragged) instead of two [n, L] matrices -- the reference's paired driver
+    # takes the mates as they come (aligner_best_approx_paired.h); L is then the longest read of either mate
+    mates = [sym1, sym2] if isinstance(sym1, ReadBatch) else None
+    if mates is not None:
+        assert isinstance(sym2, ReadBatch) and sym2.n == sym1.n
+        n, L = sym1.n, max(sym1.max_len, sym2.max_len)
+        dev = sym1.fw_rc_words.device
+    else:
+        n, L = sym1.shape
+        assert sym2.shape == sym1.shape
+        dev = sym1.device
     scheme = scheme or (SmithWatermanScoringScheme.local() if params.local else SmithWatermanScoringScheme())
     aln_type = LOCAL if params.local else SEMI_GLOBAL
     # edit-distance mode: hits are extended against the edit-distance costs and score-min = -max_dist and traced with the edit-distance
@@ -345,8 +364,13 @@ def best_approx_paired(fmi, rfmi, sym1, sym2, genome_words, genome_len, params=N
     tb_banded = make_edit_distance_aligner(aln_type) if ed_mode else banded_aligner
     tb_full = make_edit_distance_aligner(aln_type, PATTERN_BLOCKING) if ed_mode else full_aligner
     band_len = band_length(params.max_dist)
-    packed = [pack_read_streams(sym1), pack_read_streams(sym2)]                       # per mate: (reversed reads, fw + rc words)
-    mate_quals = [_qual_stream(n, L, qual_value, quals1, dev), _qual_stream(n, L, qual_value, quals2, dev)]   # laid out like each mate's fw + rc words
+    if mates is not None:
+        packed = [(m.reversed, m.fw_rc_words) for m in mates]
+        mate_quals = [m.quals for m in mates]
+    else:
+        packed = [pack_read_streams(sym1), pack_read_streams(sym2)]                       # per mate: (reversed reads, fw + rc words)
+        mate_quals = [_qual_stream(n, L, qual_value, quals1, dev), _qual_stream(n, L, qual_value, quals2, dev)]   # laid out like each mate's fw + rc words
+    mlen = (lambda m: dict(read_len=mates[m].read_len, fixed_read_len=mates[m].fixed_len)) if mates is not None else (lambda m: dict(fixed_read_len=L))
     if not params.randomized:
         name_arena = None
     elif isinstance(names, tuple):
@@ -355,8 +379,8 @@ def best_approx_paired(fmi, rfmi, sym1, sym2, genome_words, genome_len, params=N
         name_arena = sel.pack_names(names if names is not None else ["%d" % i for i in range(n)], dev)
     mp = params.mapping_params()
     table = sel._min_score_table(scheme, L, dev)
-    best = reduce.BestAlignments(n, scheme, fixed_read_len=L, device=dev, mate=0)
-    best_o = reduce.BestAlignments(n, scheme, fixed_read_len=L, device=dev, mate=1)
+    best = reduce.BestAlignments(n, scheme, max_read_len=L, device=dev, mate=0, **mlen(0))
+    best_o = reduce.BestAlignments(n, scheme, max_read_len=L, device=dev, mate=1, **mlen(1))
     hits_stride = params.hits_stride or min(params.max_hits, 128)
     stats = dict(extensions=0, opposite_extensions=0, rounds=0, seeding_passes=0, queue=[])
     if stage_times:
@@ -378,40 +402,49 @@ def best_approx_paired(fmi, rfmi, sym1, sym2, genome_words, genome_len, params=N
             with _Stage(stats, "select_init"):
                 state = sel.SelectState(hits, counts, name_arena, params.max_effort_init, params.randomized, params.top_seed)
             best_approx_score_paired(fmi, rfmi, state, seed_queue, anchor, best, best_o, a_words, o_words, n, L, genome_words, genome_len, scheme,
-                                     banded_aligner, full_aligner, mate_quals[anchor], table, params, band_len, stats, memo, o_quals=mate_quals[1 - anchor])
+                                     banded_aligner, full_aligner, mate_quals[anchor], table, params, band_len, stats, memo, o_quals=mate_quals[1 - anchor],
+                                     a_batch=mates[anchor] if mates is not None else None, o_batch=mates[1 - anchor] if mates is not None else None)
             seed_queue = seed_queue[reseed != 0]                                      # copy_flagged (no mark_unaligned in the paired driver)
     if params.pe_discordant:
         sel.mark_discordant(best, best_o)
     with _Stage(stats, "mapq"):
-        mapq1 = reduce.mapq_paired(best, best_o, final_scheme, fixed_read_len=L, o_fixed_read_len=L)      # MapqFunctorPE(mate 0)
-        mapq2 = reduce.mapq_paired(best_o, best, final_scheme, fixed_read_len=L, o_fixed_read_len=L)      # MapqFunctorPE(mate 1)
+        ml = lambda a, o: (dict(read_len=mates[a].read_len, o_read_len=mates[o].read_len, fixed_read_len=mates[a].fixed_len, o_fixed_read_len=mates[o].fixed_len, max_read_len=L)
+                           if mates is not None else dict(fixed_read_len=L, o_fixed_read_len=L))
+        mapq1 = reduce.mapq_paired(best, best_o, final_scheme, **ml(0, 1))      # MapqFunctorPE(mate 0)
+        mapq2 = reduce.mapq_paired(best_o, best, final_scheme, **ml(1, 0))      # MapqFunctorPE(mate 1)
     out = dict(best=best.data, best_o=best_o.data, mapq1=mapq1, mapq2=mapq2, opposite_dp_jobs=stats.pop("opposite_dp_jobs", 0), stats=stats)
     if traceback:
         # both mates' fw + rc patterns in one stream: a traceback picks its read by the alignment's mate bit (traceback_inl.h:117-120)
         mate_words = torch.cat([packed[0][1], packed[1][1]])
         mate_offset = int(packed[0][1].numel()) * 8
-        tq = torch.zeros(mate_offset + 2 * n * L + 8, dtype=torch.uint8, device=dev)
-        tq[: 2 * n * L] = mate_quals[0][: 2 * n * L]; tq[mate_offset: mate_offset + 2 * n * L] = mate_quals[1][: 2 * n * L]
-        sets = lambda pb, tbeg, tlen: (PackedStringSet(mate_words, 4, True, pb, None, L), PackedStringSet(genome_words, 2, True, tbeg, tlen, 0))
+        q_syms = [2 * int(m.rc_offset) for m in mates] if mates is not None else [2 * n * L, 2 * n * L]          # fw + rc quality bytes per mate
+        tq = torch.zeros(mate_offset + q_syms[1] + 8, dtype=torch.uint8, device=dev)
+        tq[: q_syms[0]] = mate_quals[0][: q_syms[0]]; tq[mate_offset: mate_offset + q_syms[1]] = mate_quals[1][: q_syms[1]]
+        sets = lambda pb, tbeg, tlen, plen=None: (PackedStringSet(mate_words, 4, True, pb, plen, 0 if plen is not None else L), PackedStringSet(genome_words, 2, True, tbeg, tlen, 0))
+
+        def tb_setup(slots, want, idx=None):
+            """-> (valid, pattern set, text set)"""
+            if mates is not None:
+                v, pb, tbeg, tlen, plen = sel.traceback_best_setup_mates(slots, n, band_len, genome_len, mates, mate_offset, want=want, idx=idx)
+                return (v,) + sets(pb, tbeg, tlen, plen)
+            v, pb, tbeg, tlen = sel.traceback_best_setup(slots, n, band_len, genome_len, L, n * L, mate_offset, want=want, idx=idx)
+            return (v,) + sets(pb, tbeg, tlen)
         with _Stage(stats, "traceback"):
             # banded_traceback_best over the anchor slots (every aligned entry)
             with _Stage(stats, "traceback.anchor"):
-                v1, pb, tbeg, tlen = sel.traceback_best_setup(best.data, n, band_len, genome_len, L, n * L, mate_offset, want=0)
-                pat1, txt1 = sets(pb, tbeg, tlen)
-                tb1 = batch_banded_alignment_traceback(band_len, tb_banded, pat1, txt1, quals=tq, cigar_stride=cigar_stride)
+                v1, pat1, txt1 = tb_setup(best.data, 0)
+                tb1 = batch_banded_alignment_traceback(band_len, tb_banded, pat1, txt1, max_pattern_length=L, quals=tq, cigar_stride=cigar_stride)
             # the opposite slots: opposite_traceback_best (full matrix over [alignment, alignment + sink)) for the concordant ones,
             # banded_traceback_best for the other aligned ones
             w_o = best_o.data[0]
             concordant = (((w_o >> 30) & 1) != 0) & (((w_o >> 31) & 1) == 0) & best_o.is_aligned(0)
             ids_c = torch.nonzero(concordant).squeeze(1).to(torch.int32)
             with _Stage(stats, "traceback.opposite_banded"):
-                vu, pb, tbeg, tlen = sel.traceback_best_setup(best_o.data, n, band_len, genome_len, L, n * L, mate_offset, want=2)
-                pat_u, txt_u = sets(pb, tbeg, tlen)
-                tb_u = batch_banded_alignment_traceback(band_len, tb_banded, pat_u, txt_u, quals=tq, cigar_stride=cigar_stride)
+                vu, pat_u, txt_u = tb_setup(best_o.data, 2)
+                tb_u = batch_banded_alignment_traceback(band_len, tb_banded, pat_u, txt_u, max_pattern_length=L, quals=tq, cigar_stride=cigar_stride)
             if ids_c.numel():
                 with _Stage(stats, "traceback.opposite_full"):
-                    vc, pb, tbeg, tlen = sel.traceback_best_setup(best_o.data, n, band_len, genome_len, L, n * L, mate_offset, want=1, idx=ids_c)
-                    pat_c, txt_c = sets(pb, tbeg, tlen)
+                    vc, pat_c, txt_c = tb_setup(best_o.data, 1, ids_c)
                     # these windows end at the sink of the opposite-mate scoring pass, whose score the slot holds: the traceback drops
                     # the rows of the window no alignment with that score can reach
                     known = sel.traceback_best_known(best_o.data, None, n, idx=ids_c)[0]
@@ -422,7 +455,7 @@ def best_approx_paired(fmi, rfmi, sym1, sym2, genome_words, genome_len, params=N
                 out["mds1"], out["mds1_len"] = sel.finish_alignment(v1, pat1, tq, txt1, tb1["cigar"], tb1["cigar_len"], tb1["source"], final_scheme, best.data, mds_stride=mds_stride)
                 # the reference evaluates mate 2's MAPQ functor here, after the anchor slots were finished and before the opposite ones
                 # are (aligner_best_approx_paired.h:308-323)
-                out["mapq2"] = reduce.mapq_paired(best_o, best, final_scheme, fixed_read_len=L, o_fixed_read_len=L)
+                out["mapq2"] = reduce.mapq_paired(best_o, best, final_scheme, **ml(1, 0))
                 mds2, mds2_len = sel.finish_alignment(vu, pat_u, tq, txt_u, tb_u["cigar"], tb_u["cigar_len"], tb_u["source"], final_scheme, best_o.data, mds_stride=mds_stride)
                 if ids_c.numel():
                     mc, mc_len = sel.finish_alignment(vc, pat_c, tq, txt_c, tb_c["cigar"], tb_c["cigar_len"], tb_c["source"], final_scheme, best_o.data, idx=ids_c,

@@ -939,6 +939,7 @@ mark_unaligned_kernel(uint32_t n_active, const uint32_t* __restrict__ active, co
 __global__ void __launch_bounds__(256)
 traceback_best_setup_kernel(uint32_t n, const uint32_t* __restrict__ idx, const uint2* __restrict__ best, uint32_t band_len, uint32_t genome_len,
                             const uint64_t* __restrict__ read_begin, const uint32_t* __restrict__ read_len, uint32_t fixed_len, uint64_t rc_offset,
+                            const uint64_t* __restrict__ read_begin1, const uint32_t* __restrict__ read_len1, uint32_t fixed_len1, uint64_t rc_offset1, int two_mates,
                             uint64_t mate_offset, int want,
                             uint8_t* __restrict__ valid, uint64_t* __restrict__ pat_begin, uint32_t* __restrict__ pat_len,
                             uint64_t* __restrict__ text_begin, uint32_t* __restrict__ text_len)
@@ -951,7 +952,9 @@ traceback_best_setup_kernel(uint32_t n, const uint32_t* __restrict__ idx, const 
     const bool concordant = ((a.x >> 30) & 1u) && !((a.x >> 31) & 1u);
     const bool ok = aligned && (want == 0 || (want == 1 ? concordant : !concordant));
     const uint32_t rc = (a.x >> 28) & 1u, mate = (a.x >> 29) & 1u, sink = (a.x >> 18) & 0x3FFu;
-    const uint32_t len = read_len ? read_len[r] : fixed_len;
+    // (two_mates: mate 1's reads have their own begins / lengths / rc offset inside their half of the stream -- mates of different lengths)
+    const bool m1 = two_mates && mate;
+    const uint32_t len = m1 ? (read_len1 ? read_len1[r] : fixed_len1) : (read_len ? read_len[r] : fixed_len);
     uint32_t gb, ge;
     if (want == 1) { gb = a.y; ge = gb + sink; }
     else { gb = a.y > band_len / 2u ? a.y - band_len / 2u : 0u; ge = gb + band_len + len; }
@@ -959,7 +962,8 @@ traceback_best_setup_kernel(uint32_t n, const uint32_t* __restrict__ idx, const 
     valid[i] = ok ? 1u : 0u;
     text_begin[i] = gb;
     text_len[i] = (ok && ge > gb) ? ge - gb : 0u;
-    pat_begin[i] = (read_begin ? read_begin[r] : uint64_t(r) * fixed_len) + (rc ? rc_offset : 0ull) + (mate ? mate_offset : 0ull);
+    pat_begin[i] = m1 ? (read_begin1 ? read_begin1[r] : uint64_t(r) * fixed_len1) + (rc ? rc_offset1 : 0ull) + mate_offset
+                      : (read_begin ? read_begin[r] : uint64_t(r) * fixed_len) + (rc ? rc_offset : 0ull) + (mate ? mate_offset : 0ull);
     if (pat_len) pat_len[i] = len;
 }
 
@@ -1020,8 +1024,26 @@ NVB_API int nvbio_hip_traceback_best_setup(uint32_t n, const uint32_t* idx, cons
     if ((!read_len && fixed_read_len == 0) || (read_len && !pattern_len)) return hipErrorInvalidValue;
     g_last_kernel = "traceback_best_setup_kernel";
     hipLaunchKernelGGL(traceback_best_setup_kernel, grid_for(n), dim3(256), 0, to_stream(stream), n, idx, reinterpret_cast<const uint2*>(best_alignments),
-                       band_len, genome_length, read_begin, read_len, fixed_read_len, rc_offset, mate_offset, int(want), out_valid, pattern_begin, pattern_len,
+                       band_len, genome_length, read_begin, read_len, fixed_read_len, rc_offset, nullptr, nullptr, 0u, 0ull, 0, mate_offset, int(want), out_valid, pattern_begin, pattern_len,
                        text_begin, text_len);
+    return hipGetLastError();
+}
+
+// ... for pairs whose mates have their own lengths: mate m's reads at read_begin[m][r] (or r * fixed_read_len[m]) of ITS half of the pattern stream, its
+// reverse complements rc_offset[m] further; mate 1's half starts mate_offset symbols into the stream
+NVB_API int nvbio_hip_traceback_best_setup_mates(uint32_t n, const uint32_t* idx, const uint64_t* best_alignments, uint32_t band_len, uint32_t genome_length,
+                                                 const uint64_t* const read_begin[2], const uint32_t* const read_len[2], const uint32_t fixed_read_len[2], const uint64_t rc_offset[2],
+                                                 uint64_t mate_offset, int32_t want, uint8_t* out_valid, uint64_t* pattern_begin, uint32_t* pattern_len, uint64_t* text_begin,
+                                                 uint32_t* text_len, void* stream)
+{
+    if (n == 0) return hipSuccess;
+    if (!best_alignments || !out_valid || !pattern_begin || !pattern_len || !text_begin || !text_len || want < 0 || want > 2) return hipErrorInvalidValue;
+    if (!read_begin || !read_len || !fixed_read_len || !rc_offset) return hipErrorInvalidValue;
+    for (int m = 0; m < 2; ++m) if (!read_len[m] && fixed_read_len[m] == 0) return hipErrorInvalidValue;
+    g_last_kernel = "traceback_best_setup_kernel";
+    hipLaunchKernelGGL(traceback_best_setup_kernel, grid_for(n), dim3(256), 0, to_stream(stream), n, idx, reinterpret_cast<const uint2*>(best_alignments),
+                       band_len, genome_length, read_begin[0], read_len[0], fixed_read_len[0], rc_offset[0], read_begin[1], read_len[1], fixed_read_len[1], rc_offset[1], 1,
+                       mate_offset, int(want), out_valid, pattern_begin, pattern_len, text_begin, text_len);
     return hipGetLastError();
 }
 

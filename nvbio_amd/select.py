@@ -137,19 +137,22 @@ def _min_score_table(scheme, max_len, dev):
 
 
 def anchor_score_setup(hit_read_id, hit_loc, hit_seed, best, best_o, scheme, anchor, band_len, genome_len, score_limit, fixed_read_len,
-                       o_fixed_read_len, rc_offset, table=None):
-    """BestAnchorScoreStream::init_context -> (pattern_begin, text_begin, text_len, min_score)."""
+                       o_fixed_read_len, rc_offset, table=None, a_read_begin=None, a_read_len=None, o_read_len=None):
+    """BestAnchorScoreStream::init_context -> (pattern_begin, text_begin, text_len, min_score); with a_read_len (mates of their own lengths:
+    a_read_begin / a_read_len of the anchor mate, o_read_len of the opposite one) also pattern_len, as a fifth value."""
     n = hit_read_id.numel()
     dev = hit_read_id.device
     table = table if table is not None else _min_score_table(scheme, max(fixed_read_len, o_fixed_read_len), dev)
     pb = torch.empty(n, dtype=torch.int64, device=dev); tb = torch.empty(n, dtype=torch.int64, device=dev)
     tl = torch.empty(n, dtype=torch.int32, device=dev); ms = torch.empty(n, dtype=torch.int32, device=dev)
-    check(lib().nvbio_hip_anchor_score_setup(n, _vp(hit_read_id), _vp(hit_loc), _vp(hit_seed), None, None, None, int(fixed_read_len), int(o_fixed_read_len),
+    pl = torch.empty(n, dtype=torch.int32, device=dev) if a_read_len is not None else None
+    check(lib().nvbio_hip_anchor_score_setup(n, _vp(hit_read_id), _vp(hit_loc), _vp(hit_seed), _vp(a_read_begin), _vp(a_read_len), _vp(o_read_len),
+                                             int(fixed_read_len), int(o_fixed_read_len),
                                              int(rc_offset), int(band_len), int(genome_len), _vp(best.data), _vp(best_o.data), best.stride,
-                                             int(scheme.m_match), _vp(table), int(score_limit), int(anchor), _vp(pb), None, _vp(tb), _vp(tl), _vp(ms),
+                                             int(scheme.m_match), _vp(table), int(score_limit), int(anchor), _vp(pb), _vp(pl), _vp(tb), _vp(tl), _vp(ms),
                                              current_stream_ptr()), "nvbio_hip_anchor_score_setup")
     table.record_stream(torch.cuda.current_stream())
-    return pb, tb, tl, ms
+    return (pb, tb, tl, ms) if pl is None else (pb, tb, tl, ms, pl)
 
 
 def anchor_score_finish(raw_score, raw_sink, text_begin, min_score, worst_score):
@@ -161,7 +164,7 @@ def anchor_score_finish(raw_score, raw_sink, text_begin, min_score, worst_score)
 
 
 def opposite_score_setup(hit_read_id, hit_seed, hit_loc, hit_score, worst_score, best, best_o, scheme, anchor, genome_len, fixed_read_len, o_fixed_read_len,
-                         pe_policy, min_frag_len, max_frag_len, pe_overlap, score_limit, table=None):
+                         pe_policy, min_frag_len, max_frag_len, pe_overlap, score_limit, table=None, a_read_len=None, o_read_len=None):
     """BestOppositeScoreStream::init_context for the hits of the opposite queue -> dict(valid, min_score, read_rc, genome_begin, genome_end)."""
     from ._lib import PeParamsStruct
     n = hit_read_id.numel()
@@ -171,7 +174,7 @@ def opposite_score_setup(hit_read_id, hit_seed, hit_loc, hit_score, worst_score,
                read_rc=torch.empty(n, dtype=torch.uint8, device=dev), genome_begin=torch.empty(n, dtype=torch.int32, device=dev),
                genome_end=torch.empty(n, dtype=torch.int32, device=dev))
     pp = PeParamsStruct(int(pe_policy), int(min_frag_len), int(max_frag_len), int(bool(pe_overlap)), int(score_limit), int(anchor), int(genome_len))
-    check(lib().nvbio_hip_opposite_score_setup(n, _vp(hit_read_id), _vp(hit_seed), _vp(hit_loc), _vp(hit_score), int(worst_score), None, None,
+    check(lib().nvbio_hip_opposite_score_setup(n, _vp(hit_read_id), _vp(hit_seed), _vp(hit_loc), _vp(hit_score), int(worst_score), _vp(a_read_len), _vp(o_read_len),
                                                int(fixed_read_len), int(o_fixed_read_len), _vp(best.data), _vp(best_o.data), best.stride,
                                                int(scheme.m_match), _vp(table), int(scheme.text_gap_open()), int(scheme.text_gap_extension()), C.byref(pp),
                                                _vp(out["valid"]), _vp(out["min_score"]), _vp(out["read_rc"]), _vp(out["genome_begin"]), _vp(out["genome_end"]),
@@ -218,9 +221,9 @@ def opposite_score_finish(valid_idx, raw_score, raw_sink, min_score, genome_begi
 
 
 def score_reduce_paired_best_approx(best, best_o, state, active, hit_begin, hit_loc, hit_sink, hit_score, hit_seed, o_loc, o_sink, o_sink2, o_score, o_score2,
-                                    anchor, pe_policy, pe_unpaired, score_limit, n_ext, min_ext, max_ext, max_effort, fixed_read_len):
+                                    anchor, pe_policy, pe_unpaired, score_limit, n_ext, min_ext, max_ext, max_effort, fixed_read_len, read_len=None):
     check(lib().nvbio_hip_score_reduce_paired_best_approx(active.numel(), _vp(active), _vp(hit_begin), _vp(hit_loc), _vp(hit_sink), _vp(hit_score), _vp(hit_seed),
-                                                          _vp(o_loc), _vp(o_sink), _vp(o_sink2), _vp(o_score), _vp(o_score2), None, int(fixed_read_len),
+                                                          _vp(o_loc), _vp(o_sink), _vp(o_sink2), _vp(o_score), _vp(o_score2), _vp(read_len), int(fixed_read_len),
                                                           int(anchor), int(pe_policy), int(bool(pe_unpaired)), int(score_limit), _vp(best.data), _vp(best_o.data),
                                                           best.stride, _vp(state.trys), _vp(state.counts), int(n_ext), int(min_ext), int(max_ext), int(max_effort),
                                                           current_stream_ptr()), "nvbio_hip_score_reduce_paired_best_approx")
@@ -245,6 +248,25 @@ def copy_flagged(values, flags):
     temp = torch.empty(tb, dtype=torch.uint8, device=dev)
     check(lib().nvbio_hip_copy_flagged(n, _vp(values), _vp(flags), _vp(out), _vp(count), _vp(temp), tb, current_stream_ptr()), "nvbio_hip_copy_flagged")
     return out[: int(count.item())]
+
+
+def traceback_best_setup_mates(best_data, n, band_len, genome_len, mates, mate_offset, want=0, idx=None):
+    """traceback_best_setup for pairs whose mates have their own lengths: mates = two ReadBatch-like objects (read_begin / read_len or fixed_len,
+    rc_offset); -> (valid, pattern_begin, text_begin, text_len, pattern_len)"""
+    import ctypes as C
+    dev = best_data.device
+    m = idx.numel() if idx is not None else n
+    valid = torch.empty(m, dtype=torch.uint8, device=dev)
+    pb = torch.empty(m, dtype=torch.int64, device=dev); tb = torch.empty(m, dtype=torch.int64, device=dev)
+    tl = torch.empty(m, dtype=torch.int32, device=dev); pl = torch.empty(m, dtype=torch.int32, device=dev)
+    ptr = lambda t: C.c_void_p(t.data_ptr() if t is not None else None)
+    rb = (C.c_void_p * 2)(ptr(mates[0].read_begin), ptr(mates[1].read_begin))
+    rl = (C.c_void_p * 2)(ptr(mates[0].read_len), ptr(mates[1].read_len))
+    fl = (C.c_uint32 * 2)(int(mates[0].fixed_len), int(mates[1].fixed_len))
+    ro = (C.c_uint64 * 2)(int(mates[0].rc_offset), int(mates[1].rc_offset))
+    check(lib().nvbio_hip_traceback_best_setup_mates(m, _vp(idx), _vp(best_data), int(band_len), int(genome_len), rb, rl, fl, ro, C.c_uint64(int(mate_offset)), int(want),
+                                                     _vp(valid), _vp(pb), _vp(pl), _vp(tb), _vp(tl), current_stream_ptr()), "nvbio_hip_traceback_best_setup_mates")
+    return valid, pb, tb, tl, pl
 
 
 def traceback_best_setup(best_data, n, band_len, genome_len, fixed_read_len, rc_offset, mate_offset=0, want=0, idx=None, read_begin=None, read_len=None):

@@ -396,10 +396,12 @@ def test_own_drivers_equal_reference_nvbowtie_on_varied_reads(case, cuda):
                                   dict(mode="se", extra="--scoring ed", own="scoring_mode=ed", seed=91),
                                   dict(mode="se", extra="--scoring ed --max-dist 7", own="scoring_mode=ed,max_dist=7", seed=92, indels=0.5),
                                   dict(mode="paired", extra="--scoring ed", own="scoring_mode=ed", seed=93, reads=6000),
-                                  dict(mode="all", extra="--scoring ed", own="scoring_mode=ed", seed=94)],
+                                  dict(mode="all", extra="--scoring ed", own="scoring_mode=ed", seed=94),
+                                  dict(mode="paired", mixed=True, seed=95, reads=8000),
+                                  dict(mode="paired", mixed=True, extra="--local", own="local=True", seed=96, reads=5000, quals="random")],
                          ids=["se-N1", "se-L18-D20-R3", "local-N1-L16", "paired-I250-X380", "paired-no-mixed", "paired-no-discordant", "se-no-rand",
                               "se-no-rand-single-hit", "paired-no-rand", "se-nofw", "all-N1", "se-top", "se-max-dist-7", "se-max-hits-ext", "se-N1-subseed",
-                              "paired-no-overlap", "paired-ff", "paired-top-N1", "se-rep-seeds", "se-edit-distance", "se-edit-distance-max-dist-7", "paired-edit-distance", "all-edit-distance"])
+                              "paired-no-overlap", "paired-ff", "paired-top-N1", "se-rep-seeds", "se-edit-distance", "se-edit-distance-max-dist-7", "paired-edit-distance", "all-edit-distance", "paired-mixed-lengths", "paired-mixed-lengths-local"])
 def test_own_drivers_equal_reference_nvbowtie_under_its_options(case, cuda):
     """nvBowtie's command-line options against the same settings of this repository's drivers: one mismatch in the seed (-N 1: the
     case-pruning mapper in the best modes, the approximate mapper in --all, aligner_all.h:177-212), seed length / effort / re-seeding,

@@ -183,13 +183,19 @@ def main_paired(prefix, fastq1, fastq2, out=sys.stdout, device="cuda", ref_name=
     r1, r2 = nio.read_fastq(fastq1), nio.read_fastq(fastq2)
     n = r1.size()
     lens = np.concatenate([np.diff(r1.sequence_index), np.diff(r2.sequence_index)])
-    if n == 0 or r2.size() != n or (lens != lens[0]).any():
-        raise SystemExit("align_fastq: the paired example needs two files with the same number of equal-length reads")
-    L = int(lens[0])
-    mats = [torch.from_numpy(r.symbols.reshape(n, L)).to(device) for r in (r1, r2)]
+    if n == 0 or r2.size() != n:
+        raise SystemExit("align_fastq: the paired example needs two files with the same number of reads")
     params = A.Params(hits_stride=32, **param_overrides)
-    quals = [torch.from_numpy(r.quals.reshape(n, L)).to(device) for r in (r1, r2)]
-    r = A.best_approx_paired(data.index(), data.rindex(), mats[0], mats[1], genome_words, n_genome, params, names=list(r1.names), finish=True, quals1=quals[0], quals2=quals[1])
+    idx = [np.asarray(r.sequence_index, dtype=np.int64) for r in (r1, r2)]
+    if (lens != lens[0]).any():
+        # mates of their own lengths: two ragged batches
+        mates = [A.ReadBatch.from_ragged(torch.from_numpy(r.symbols).to(device), torch.from_numpy(ix).to(device), torch.from_numpy(r.quals).to(device)) for r, ix in ((r1, idx[0]), (r2, idx[1]))]
+        r = A.best_approx_paired(data.index(), data.rindex(), mates[0], mates[1], genome_words, n_genome, params, names=list(r1.names), finish=True)
+    else:
+        L = int(lens[0])
+        mats = [torch.from_numpy(r.symbols.reshape(n, L)).to(device) for r in (r1, r2)]
+        quals = [torch.from_numpy(r.quals.reshape(n, L)).to(device) for r in (r1, r2)]
+        r = A.best_approx_paired(data.index(), data.rindex(), mats[0], mats[1], genome_words, n_genome, params, names=list(r1.names), finish=True, quals1=quals[0], quals2=quals[1])
     torch.cuda.synchronize()
     slots = []
     for key_best, key_tb, key_mds, key_mapq in (("best", "tb1", "mds1", "mapq1"), ("best_o", "tb2", "mds2", "mapq2")):
@@ -218,7 +224,7 @@ def main_paired(prefix, fastq1, fastq2, out=sys.stdout, device="cuda", ref_name=
             w_k, w_m = int(slots[k]["best"][i] & 0xFFFFFFFF), int(slots[1 - k]["best"][i] & 0xFFFFFFFF)
             mate = (w_k >> 29) & 1
             rd = reads[mate]
-            seq, qual = rd.symbols[i * L:(i + 1) * L], rd.quals[i * L:(i + 1) * L]
+            seq, qual = rd.symbols[idx[mate][i]:idx[mate][i + 1]], rd.quals[idx[mate][i]:idx[mate][i + 1]]
             if a is None:
                 s, q = (np.where(seq < 4, 3 - seq, 4)[::-1], qual[::-1]) if (w_k >> 28) & 1 else (seq, qual)
                 out.write("%s\t4\t*\t0\t0\t*\t*\t0\t0\t%s\t%s\n" % (rd.names[i], "".join("ACGTN"[c] for c in s), "".join(chr(int(x) + 33) for x in q)))

@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--ns", type=float, default=0.0, help="fraction of read bases replaced by N (single-end modes)")
     ap.add_argument("--quals", default="I", help="one quality character for all bases, or 'random'")
     ap.add_argument("--repeats", type=float, default=0.0, help="fraction of the genome covered by diverged copies of a few repeat families")
+    ap.add_argument("--mixed", action="store_true", help="paired mode: mates of different lengths (70 .. 130 bp each)")
     ap.add_argument("--extra", default="", help="further nvBowtie options, e.g. '-N 1 -L 18'")
     ap.add_argument("--own", default="", help="the same settings for this repository's driver: comma-separated Params fields, e.g. 'allow_sub=1,seed_len=18'")
     args = ap.parse_args()
@@ -127,8 +128,14 @@ def prepare(args):
     if args.mode == "paired":
         frag = rng.integers(200, 400, n)
         pos = rng.integers(0, 120_000 - 420, n) + np.where(rng.random(n) < 0.4, 120_000, 0) * 0
-        m1 = [mutate(rng, text[p:p + L], 0.02) for p in pos]
-        m2 = [mutate(rng, (3 - text[p + f - L:p + f])[::-1], 0.02) for p, f in zip(pos, frag)]
+        if getattr(args, "mixed", False):
+            # mates of their own lengths (70 .. 130 bp each): mate 1 from the fragment's left end, mate 2 from its right end
+            l1, l2 = rng.integers(70, 131, n), rng.integers(70, 131, n)
+            m1 = [mutate(rng, text[p:p + a], 0.02) for p, a in zip(pos, l1)]
+            m2 = [mutate(rng, (3 - text[p + f - b:p + f])[::-1], 0.02) for p, f, b in zip(pos, frag, l2)]
+        else:
+            m1 = [mutate(rng, text[p:p + L], 0.02) for p in pos]
+            m2 = [mutate(rng, (3 - text[p + f - L:p + f])[::-1], 0.02) for p, f in zip(pos, frag)]
         f1, f2 = os.path.join(tmp, "m1.fastq"), os.path.join(tmp, "m2.fastq")
         q = getattr(args, "quals", "I")
         write_fastq(f1, m1, "pair", q, rng); write_fastq(f2, m2, "pair", q, rng)
