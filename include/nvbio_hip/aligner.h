@@ -71,11 +71,17 @@ struct Stats { uint64 extensions, dp_jobs, hits, ranges, unique; uint32 rounds, 
 /// reverse complements (the extension / traceback patterns), one quality byte per pattern symbol, the read names.
 struct ReadBatch
 {
-    uint32 n, len;
+    ReadBatch() : n(0), len(0), fw_rc_words(nullptr), fw_rc_n_words(0), rc_offset(0), quals(nullptr), n_quals(0), names(nullptr), names_idx(nullptr),
+                  read_begin(nullptr), read_len(nullptr) {}
+    uint32 n, len;                  ///< len: every read's length, or -- with read_len -- the longest
     PackedStringSetView<4, true> reversed;
     const uint32* fw_rc_words; uint64 fw_rc_n_words; uint64 rc_offset;
     const uint8*  quals;       uint64 n_quals;
     const char*   names;       const uint32* names_idx;
+    /// reads of their own lengths (device arrays, NULL for an equal-length batch): read r's forward copy starts read_begin[r] symbols into
+    /// fw_rc_words and is read_len[r] long, its reverse complement rc_offset symbols further; `reversed` carries the same lengths
+    const uint64* read_begin;  const uint32* read_len;
+    uint32 fixed() const { return read_len ? 0u : len; }
 };
 
 /// the paired-end fields of Params (params.cpp:165-172; io::PairedEndPolicy FF 0, FR 1, RF 2, RR 3)
@@ -293,17 +299,19 @@ private:
             if (queue_size == 0) continue;
 
             // score_all: windows, the banded scorer, acceptance at min_score(read_len)
-            hip_check(nvbio_hip_score_all_setup(queue_size, queue.data(), hit_read.data(), hit_loc.data(), hit_seed.data(), nullptr, nullptr, L, reads.rc_offset, band_len, genome_len,
-                                                pat_begin.data(), nullptr, txt_begin.data(), txt_len.data(), hip_stream), "nvbio_hip_score_all_setup");
+            hip::device_vector<uint32> pat_len(reads.read_len ? queue_size : 0u);                 // reads of their own lengths: the jobs' pattern lengths
+            uint32* const pat_len_ptr = reads.read_len ? pat_len.data() : nullptr;
+            hip_check(nvbio_hip_score_all_setup(queue_size, queue.data(), hit_read.data(), hit_loc.data(), hit_seed.data(), reads.read_begin, reads.read_len, reads.fixed(), reads.rc_offset, band_len, genome_len,
+                                                pat_begin.data(), pat_len_ptr, txt_begin.data(), txt_len.data(), hip_stream), "nvbio_hip_score_all_setup");
             {
-                const PackedStringSetView<4, true> patterns(queue_size, reads.fw_rc_words, reads.fw_rc_n_words, pat_begin.data(), nullptr, L);
+                const PackedStringSetView<4, true> patterns(queue_size, reads.fw_rc_words, reads.fw_rc_n_words, pat_begin.data(), pat_len_ptr, reads.fixed());
                 const PackedStringSetView<2, true> texts(queue_size, genome_words, genome_n_words, txt_begin.data(), txt_len.data(), 0u);
                 const aln::BestSinkArrays sink_arrays = { hit_score.data(), sinks.data() };
                 dispatch_band(band_len, [&](auto band) {
                     aln::batch_banded_alignment_score<decltype(band)::value>(aligner, patterns, reads.quals, reads.n_quals, texts, sink_arrays, L, L + band_len, hip_stream);
                 });
             }
-            hip_check(nvbio_hip_score_all_output(queue_size, queue.data(), hit_read.data(), hit_loc.data(), hit_seed.data(), hit_score.data(), min_score_table.data(), nullptr, L,
+            hip_check(nvbio_hip_score_all_output(queue_size, queue.data(), hit_read.data(), hit_loc.data(), hit_seed.data(), hit_score.data(), min_score_table.data(), reads.read_len, reads.fixed(),
                                                  flags.data(), reinterpret_cast<uint64*>(job_aln.data()), job_read.data(), hip_stream), "nvbio_hip_score_all_output");
             hip_check(nvbio_hip_copy_flagged(queue_size, d_iota.data(), flags.data(), accepted.data(), counter.data(), flag_temp.data(), flag_temp.size(), hip_stream), "nvbio_hip_copy_flagged");
             hip::synchronize(hip_stream);
@@ -333,9 +341,11 @@ private:
         {
             const uint32 nb = uint32(std::min<uint64>(m - off, B));
             uint64* a = reinterpret_cast<uint64*>(output_alignments_dvec.data() + off);
-            hip_check(nvbio_hip_traceback_all_setup(nb, a, output_read_info_dvec.data() + off, nullptr, nullptr, L, reads.rc_offset, band_len, genome_len,
-                                                    tb_pat.data(), nullptr, tb_txt.data(), tb_len.data(), hip_stream), "nvbio_hip_traceback_all_setup");
-            const PackedStringSetView<4, true>  patterns(nb, reads.fw_rc_words, reads.fw_rc_n_words, tb_pat.data(), nullptr, L);
+            hip::device_vector<uint32> tb_plen(reads.read_len ? nb : 0u);
+            uint32* const tb_plen_ptr = reads.read_len ? tb_plen.data() : nullptr;
+            hip_check(nvbio_hip_traceback_all_setup(nb, a, output_read_info_dvec.data() + off, reads.read_begin, reads.read_len, reads.fixed(), reads.rc_offset, band_len, genome_len,
+                                                    tb_pat.data(), tb_plen_ptr, tb_txt.data(), tb_len.data(), hip_stream), "nvbio_hip_traceback_all_setup");
+            const PackedStringSetView<4, true>  patterns(nb, reads.fw_rc_words, reads.fw_rc_n_words, tb_pat.data(), tb_plen_ptr, reads.fixed());
             const PackedStringSetView<2, true>  texts(nb, genome_words, genome_n_words, tb_txt.data(), tb_len.data(), 0u);
             const aln::AlignmentArrays alignments = { traceback_score.data() + off, cigar_source.data() + 2u * off, cigar_sink.data() + 2u * off };
             const aln::CigarArrays     cigars     = { cigar.data() + off * cigar_stride, cigar_stride, cigar_len.data() + off };
@@ -386,7 +396,7 @@ private:
         // initialize best-alignments with the threshold score
         hip::device_vector<int32> min_score_table(search_limits.min_score_table(L));
         hip::device_vector<int32> mapq_score_table(limits.min_score_table(L));        // MAPQ reads the Smith-Waterman scheme in either mode
-        init_alignments(count, nullptr, L, min_score_table.data(), best_data_dvec.data(), BATCH_SIZE, 0u, hip_stream);
+        init_alignments(count, reads.read_len, reads.fixed(), min_score_table.data(), best_data_dvec.data(), BATCH_SIZE, 0u, hip_stream);
 
         // the seed queue, hit deques, selection state and scoring queues of the pipeline
         hip::device_vector<uint32> seed_queue_in(count), seed_queue_out(count), queue_count(1);
@@ -432,7 +442,7 @@ private:
         }
 
         // compute mapq (BowtieMapq2)
-        stats.clock.run("mapq", hip_stream, [&] { mapq(2, limits, mapq_score_table.data(), count, best_data_dvec.data(), BATCH_SIZE, nullptr, L, mapq_dvec.data(), hip_stream); });
+        stats.clock.run("mapq", hip_stream, [&] { mapq(2, limits, mapq_score_table.data(), count, best_data_dvec.data(), BATCH_SIZE, reads.read_len, reads.fixed(), mapq_dvec.data(), hip_stream); });
 
         // banded_traceback_best over every read (unaligned ones get an empty window and no CIGAR)
         stats.clock.begin("traceback", hip_stream);
@@ -441,10 +451,12 @@ private:
             hip::device_vector<uint64> tb_pat(count), tb_txt(count);
             hip::device_vector<uint32> tb_len(count);
             hip_check(nvbio_hip_memset(cigar.data(), 0, uint64(count) * cigar_stride * sizeof(io::Cigar), hip_stream), "nvbio_hip_memset");
-            hip_check(nvbio_hip_traceback_best_setup(count, nullptr, reinterpret_cast<const uint64*>(best_data_dvec.data()), band_len, genome_len, nullptr, nullptr, L,
-                                                     reads.rc_offset, 0u, 0, valid.data(), tb_pat.data(), nullptr, tb_txt.data(), tb_len.data(), hip_stream),
+            hip::device_vector<uint32> tb_plen(reads.read_len ? count : 0u);
+            uint32* const tb_plen_ptr = reads.read_len ? tb_plen.data() : nullptr;
+            hip_check(nvbio_hip_traceback_best_setup(count, nullptr, reinterpret_cast<const uint64*>(best_data_dvec.data()), band_len, genome_len, reads.read_begin, reads.read_len, reads.fixed(),
+                                                     reads.rc_offset, 0u, 0, valid.data(), tb_pat.data(), tb_plen_ptr, tb_txt.data(), tb_len.data(), hip_stream),
                       "nvbio_hip_traceback_best_setup");
-            const PackedStringSetView<4, true>  patterns(count, reads.fw_rc_words, reads.fw_rc_n_words, tb_pat.data(), nullptr, L);
+            const PackedStringSetView<4, true>  patterns(count, reads.fw_rc_words, reads.fw_rc_n_words, tb_pat.data(), tb_plen_ptr, reads.fixed());
             const PackedStringSetView<2, true>  texts(count, genome_words, genome_n_words, tb_txt.data(), tb_len.data(), 0u);
             const aln::AlignmentArrays alignments = { traceback_score.data(), cigar_source.data(), cigar_sink.data() };
             const aln::CigarArrays     cigars     = { cigar.data(), cigar_stride, cigar_len.data() };
@@ -494,7 +506,7 @@ private:
                               const aln::SmithWatermanScoringScheme& scoring_scheme, const ScoreLimits& limits,
                               const uint32* genome_words, const uint64 genome_n_words, const uint32 genome_len, const PairedReadBatch& reads, Stats& stats, void* hip_stream)
     {
-        const uint32 count = reads.mate[0].n, L = reads.mate[0].len;
+        const uint32 count = reads.mate[0].n, L = std::max(reads.mate[0].len, reads.mate[1].len);      // L: the longest read of either mate
         const uint32 band_len = band_length(params.max_dist);
         const uint32 hits_stride = params.hits_stride ? params.hits_stride : std::min(params.max_hits, 128u);
         // the scheme hits are extended with (Params::scoring_mode): `sc`; the scheme of MAPQ and finish_alignment is the caller's: `fsc`
@@ -510,8 +522,8 @@ private:
         const hip::arena_scope scope(workspace);                        // the per-batch vectors below live in the Aligner's workspace
 
         hip::device_vector<int32> min_score_table(search_limits.min_score_table(L)), mapq_score_table(limits.min_score_table(L));
-        init_alignments(count, nullptr, L, min_score_table.data(), best_data_dvec.data(),   BATCH_SIZE, 0u, hip_stream);
-        init_alignments(count, nullptr, L, min_score_table.data(), best_data_dvec_o.data(), BATCH_SIZE, 1u, hip_stream);
+        init_alignments(count, reads.mate[0].read_len, reads.mate[0].fixed(), min_score_table.data(), best_data_dvec.data(),   BATCH_SIZE, 0u, hip_stream);
+        init_alignments(count, reads.mate[1].read_len, reads.mate[1].fixed(), min_score_table.data(), best_data_dvec_o.data(), BATCH_SIZE, 1u, hip_stream);
 
         std::vector<uint32> iota(count); std::iota(iota.begin(), iota.end(), 0u);
         hip::device_vector<uint32>  d_iota(iota), seed_queue_in(count), seed_queue_out(count), queue_count(1);
@@ -523,6 +535,7 @@ private:
         const uint32  max_hits_per_round = std::max(SCORING_BATCH, count);
         ScoringQueues queues(count, max_hits_per_round);
         hip::device_vector<uint64> pat_begin(max_hits_per_round), txt_begin(max_hits_per_round);
+        hip::device_vector<uint32> pat_len((reads.mate[0].read_len || reads.mate[1].read_len) ? max_hits_per_round : 0u);      // mates of their own lengths: a job's pattern length
         hip::device_vector<uint32> txt_len(max_hits_per_round), sinks(size_t(max_hits_per_round) * 2u), hit_sink(max_hits_per_round);
         hip::device_vector<int32>  min_score(max_hits_per_round), raw_score(max_hits_per_round), hit_score(max_hits_per_round);
         hip::device_vector<uint8>  o_valid(max_hits_per_round), o_rc(max_hits_per_round);
@@ -579,15 +592,15 @@ private:
 
                     // anchor_score_best
                     stats.clock.begin("anchor_score", hip_stream);
-                    hip_check(nvbio_hip_anchor_score_setup(nh, queues.hit_read_id.data(), queues.hit_loc.data(), hit_seed, nullptr, nullptr, nullptr, L, L, a_reads.rc_offset,
+                    hip_check(nvbio_hip_anchor_score_setup(nh, queues.hit_read_id.data(), queues.hit_loc.data(), hit_seed, a_reads.read_begin, a_reads.read_len, o_reads.read_len, a_reads.fixed(), o_reads.fixed(), a_reads.rc_offset,
                                                            band_len, genome_len, best, best_o, BATCH_SIZE, sc.match, min_score_table.data(), worst_score, anchor,
-                                                           pat_begin.data(), nullptr, txt_begin.data(), txt_len.data(), min_score.data(), hip_stream), "nvbio_hip_anchor_score_setup");
+                                                           pat_begin.data(), a_reads.read_len ? pat_len.data() : nullptr, txt_begin.data(), txt_len.data(), min_score.data(), hip_stream), "nvbio_hip_anchor_score_setup");
                     hip_check(nvbio_hip_anchor_memo_mark(nh, queues.hit_read_id.data(), hit_seed, txt_begin.data(), txt_len.data(), anchor, a_memo.data(), a_from_memo.data(),
                                                          a_txt_len.data(), a_live_count.data(), a_live_idx.data(), hip_stream), "nvbio_hip_anchor_memo_mark");
                     {
                         // the hits left with a window: one lane per job over all hits when there are many (the answered ones return at once), one wave per
                         // job over their list when there are few -- both queued, the device runs the one the count calls for
-                        const PackedStringSetView<4, true> patterns(nh, a_reads.fw_rc_words, a_reads.fw_rc_n_words, pat_begin.data(), nullptr, L);
+                        const PackedStringSetView<4, true> patterns(nh, a_reads.fw_rc_words, a_reads.fw_rc_n_words, pat_begin.data(), a_reads.read_len ? pat_len.data() : nullptr, a_reads.fixed());
                         const PackedStringSetView<2, true> texts(nh, genome_words, genome_n_words, txt_begin.data(), a_txt_len.data(), 0u);
                         const nvbio_hip_string_set ap = patterns.abi(), at = texts.abi();
                         const uint32 wave_up_to = L <= 512u ? wave_form_up_to() : 0u;
@@ -609,10 +622,12 @@ private:
 
                     // opposite_score_best over the hits whose anchor scored: every hit gets a job, the invalid ones an empty text
                     stats.clock.begin("opposite_score", hip_stream);
-                    hip_check(nvbio_hip_opposite_score_setup(nh, queues.hit_read_id.data(), hit_seed, queues.hit_loc.data(), hit_score.data(), worst_score, nullptr, nullptr, L, L,
+                    hip_check(nvbio_hip_opposite_score_setup(nh, queues.hit_read_id.data(), hit_seed, queues.hit_loc.data(), hit_score.data(), worst_score, a_reads.read_len, o_reads.read_len, a_reads.fixed(), o_reads.fixed(),
                                                              best, best_o, BATCH_SIZE, sc.match, min_score_table.data(), sc.text_gap_open, sc.text_gap_ext, &app,
                                                              o_valid.data(), min_score.data(), o_rc.data(), o_gbegin.data(), o_gend.data(),
-                                                             nullptr, o_reads.rc_offset, pat_begin.data(), txt_begin.data(), txt_len.data(), hip_stream), "nvbio_hip_opposite_score_setup");
+                                                             o_reads.read_begin, o_reads.rc_offset, pat_begin.data(), txt_begin.data(), txt_len.data(), hip_stream), "nvbio_hip_opposite_score_setup");
+                    if (o_reads.read_len)           // mates of their own lengths: each job's pattern length is its read's
+                        hip_check(nvbio_hip_gather_rows(nh, queues.hit_read_id.data(), o_reads.read_len, pat_len.data(), 4u, hip_stream), "nvbio_hip_gather_rows");
                     // jobs equal to the pair's last scored job are answered from the memo (nvbio_hip.h: the reference re-runs them)
                     hip_check(nvbio_hip_opposite_memo_lookup(nh, queues.hit_read_id.data(), o_valid.data(), o_rc.data(), o_gbegin.data(), o_gend.data(), min_score.data(), anchor,
                                                              memo.data(), worst_score, o_score.data(), o_score2.data(), o_loc.data(), o_sink.data(), o_sink2.data(), txt_len.data(),
@@ -620,7 +635,7 @@ private:
                     {
                         // the windows left to score (valid == 1 after the memo): the throughput kernels over all hits when there are many, one job per
                         // wave over their list when there are few -- both queued, the device runs the one the count calls for (nvbio_hip.h)
-                        const PackedStringSetView<4, true> patterns(nh, o_reads.fw_rc_words, o_reads.fw_rc_n_words, pat_begin.data(), nullptr, L);
+                        const PackedStringSetView<4, true> patterns(nh, o_reads.fw_rc_words, o_reads.fw_rc_n_words, pat_begin.data(), o_reads.read_len ? pat_len.data() : nullptr, o_reads.fixed());
                         const PackedStringSetView<2, true> texts(nh, genome_words, genome_n_words, txt_begin.data(), txt_len.data(), 0u);
                         const nvbio_hip_string_set p = patterns.abi(), t = texts.abi();
                         const uint32 wave_up_to = wave_form_up_to() / 4u;
@@ -649,7 +664,7 @@ private:
                     stats.clock.begin("reduce", hip_stream);
                     hip_check(nvbio_hip_score_reduce_paired_best_approx(queues.in_size, reinterpret_cast<const uint32*>(queues.active_in.data()), queues.hit_begin.data(),
                                   queues.hit_loc.data(), hit_sink.data(), hit_score.data(), hit_seed, o_loc.data(), o_sink.data(), o_sink2.data(), o_score.data(), o_score2.data(),
-                                  nullptr, L, anchor, pe.pe_policy, pe.pe_unpaired ? 1 : 0, worst_score, best, best_o, BATCH_SIZE,
+                                  a_reads.read_len, a_reads.fixed(), anchor, pe.pe_policy, pe.pe_unpaired ? 1 : 0, worst_score, best, best_o, BATCH_SIZE,
                                   state.trys.data(), hit_counts.data(), n_ext, params.select.min_ext, params.select.max_ext, params.select.max_effort, hip_stream),
                               "nvbio_hip_score_reduce_paired_best_approx");
                     stats.clock.end("reduce", hip_stream);
@@ -669,20 +684,24 @@ private:
         if (pe.pe_discordant)
             hip_check(nvbio_hip_mark_discordant(count, best, best_o, BATCH_SIZE, hip_stream), "nvbio_hip_mark_discordant");
         // mate 1's MAPQ functor
-        hip_check(nvbio_hip_mapq_paired(2, limits.match, limits.monotone ? 1 : 0, mapq_score_table.data(), count, best, best_o, BATCH_SIZE, nullptr, nullptr, L, L,
+        hip_check(nvbio_hip_mapq_paired(2, limits.match, limits.monotone ? 1 : 0, mapq_score_table.data(), count, best, best_o, BATCH_SIZE, reads.mate[0].read_len, reads.mate[1].read_len, reads.mate[0].fixed(), reads.mate[1].fixed(),
                                         mapq_dvec.data(), hip_stream), "nvbio_hip_mapq_paired");
 
         // tracebacks + finish: anchor slots (banded), opposite slots (full matrix for the concordant ones, banded for the others)
         stats.clock.begin("traceback", hip_stream);
-        const uint64 rc_offset = reads.mate[0].rc_offset;
         hip::device_vector<uint8>  valid(count), valid_c(count);
         hip::device_vector<uint64> tb_pat(count), tb_txt(count);
-        hip::device_vector<uint32> tb_len(count), idx_c(count);
+        hip::device_vector<uint32> tb_len(count), tb_plen(count), idx_c(count);
+        // a slot's pattern comes from its mate's own half of the stream, at that mate's begins / lengths (nvbio_hip_traceback_best_setup_mates)
+        const uint64* const m_begin[2] = { reads.mate[0].read_begin, reads.mate[1].read_begin };
+        const uint32* const m_len[2]   = { reads.mate[0].read_len,   reads.mate[1].read_len };
+        const uint32        m_fixed[2] = { reads.mate[0].fixed(),    reads.mate[1].fixed() };
+        const uint64        m_rc[2]    = { reads.mate[0].rc_offset,  reads.mate[1].rc_offset };
         auto banded_tb = [&](const uint64* slots, const int32 want, hip::device_vector<uint8>& v, io::Cigar* cg, uint32* cg_len, uint32* src, uint32* snk, int32* score) {
             hip_check(nvbio_hip_memset(cg, 0, uint64(count) * cigar_stride * sizeof(io::Cigar), hip_stream), "nvbio_hip_memset");
-            hip_check(nvbio_hip_traceback_best_setup(count, nullptr, slots, band_len, genome_len, nullptr, nullptr, L, rc_offset, reads.mate_offset, want,
-                                                     v.data(), tb_pat.data(), nullptr, tb_txt.data(), tb_len.data(), hip_stream), "nvbio_hip_traceback_best_setup");
-            const PackedStringSetView<4, true> patterns(count, reads.both_words, reads.both_n_words, tb_pat.data(), nullptr, L);
+            hip_check(nvbio_hip_traceback_best_setup_mates(count, nullptr, slots, band_len, genome_len, m_begin, m_len, m_fixed, m_rc, reads.mate_offset, want,
+                                                           v.data(), tb_pat.data(), tb_plen.data(), tb_txt.data(), tb_len.data(), hip_stream), "nvbio_hip_traceback_best_setup_mates");
+            const PackedStringSetView<4, true> patterns(count, reads.both_words, reads.both_n_words, tb_pat.data(), tb_plen.data(), 0u);
             const PackedStringSetView<2, true> texts(count, genome_words, genome_n_words, tb_txt.data(), tb_len.data(), 0u);
             const nvbio_hip_string_set p = patterns.abi(), t = texts.abi();
             hip::device_vector<uint8> temp(nvbio_hip_banded_gotoh_traceback_temp_bytes(band_len < 4 ? 3u : band_len < 8 ? 7u : band_len < 16 ? 15u : 31u, L, count));
@@ -696,7 +715,7 @@ private:
             hip::synchronize(hip_stream);
         };
         auto finish = [&](const uint32 n_jobs, const uint8* v, const uint32* idx, uint64* slots, const io::Cigar* cg, const uint32* cg_len, const uint32* src, uint8* md, uint32* md_len) {
-            const PackedStringSetView<4, true> patterns(n_jobs, reads.both_words, reads.both_n_words, tb_pat.data(), nullptr, L);
+            const PackedStringSetView<4, true> patterns(n_jobs, reads.both_words, reads.both_n_words, tb_pat.data(), tb_plen.data(), 0u);
             const PackedStringSetView<2, true> texts(n_jobs, genome_words, genome_n_words, tb_txt.data(), tb_len.data(), 0u);
             const nvbio_hip_string_set p = patterns.abi(), t = texts.abi();
             hip_check(nvbio_hip_finish_alignment(n_jobs, v, &p, reads.both_quals, reads.both_n_quals, &t, reinterpret_cast<const uint16*>(cg), cigar_stride, cg_len, src,
@@ -706,12 +725,12 @@ private:
         banded_tb(best, 0, valid, cigar.data(), cigar_len.data(), cigar_source.data(), cigar_sink.data(), traceback_score.data());
         if (params.finish_alignments) finish(count, valid.data(), nullptr, best, cigar.data(), cigar_len.data(), cigar_source.data(), mds.data(), mds_len.data());
         // mate 2's MAPQ functor: after the anchor slots were finished, before the opposite ones are (:308-323)
-        hip_check(nvbio_hip_mapq_paired(2, limits.match, limits.monotone ? 1 : 0, mapq_score_table.data(), count, best_o, best, BATCH_SIZE, nullptr, nullptr, L, L,
+        hip_check(nvbio_hip_mapq_paired(2, limits.match, limits.monotone ? 1 : 0, mapq_score_table.data(), count, best_o, best, BATCH_SIZE, reads.mate[1].read_len, reads.mate[0].read_len, reads.mate[1].fixed(), reads.mate[0].fixed(),
                                         mapq_dvec_o.data(), hip_stream), "nvbio_hip_mapq_paired");
 
         // which opposite slots are concordant (their tracebacks run over the full matrix of [alignment, alignment + sink))
-        hip_check(nvbio_hip_traceback_best_setup(count, nullptr, best_o, band_len, genome_len, nullptr, nullptr, L, rc_offset, reads.mate_offset, 1,
-                                                 valid_c.data(), tb_pat.data(), nullptr, tb_txt.data(), tb_len.data(), hip_stream), "nvbio_hip_traceback_best_setup");
+        hip_check(nvbio_hip_traceback_best_setup_mates(count, nullptr, best_o, band_len, genome_len, m_begin, m_len, m_fixed, m_rc, reads.mate_offset, 1,
+                                                       valid_c.data(), tb_pat.data(), tb_plen.data(), tb_txt.data(), tb_len.data(), hip_stream), "nvbio_hip_traceback_best_setup_mates");
         hip_check(nvbio_hip_copy_flagged(count, d_iota.data(), valid_c.data(), idx_c.data(), queue_count.data(), flag_temp.data(), flag_temp.size(), hip_stream), "nvbio_hip_copy_flagged");
         hip::synchronize(hip_stream);
         const uint32 n_conc = queue_count.to_host(hip_stream)[0];
@@ -725,9 +744,9 @@ private:
             hip::device_vector<uint32>    cg_len(n_conc), src(size_t(n_conc) * 2u), snk(size_t(n_conc) * 2u), md_len(n_conc);
             hip::device_vector<int32>     score(n_conc);
             hip_check(nvbio_hip_memset(cg.data(), 0, uint64(n_conc) * cigar_stride * sizeof(io::Cigar), hip_stream), "nvbio_hip_memset");
-            hip_check(nvbio_hip_traceback_best_setup(n_conc, idx_c.data(), best_o, band_len, genome_len, nullptr, nullptr, L, rc_offset, reads.mate_offset, 1,
-                                                     v.data(), tb_pat.data(), nullptr, tb_txt.data(), tb_len.data(), hip_stream), "nvbio_hip_traceback_best_setup");
-            const PackedStringSetView<4, true> patterns(n_conc, reads.both_words, reads.both_n_words, tb_pat.data(), nullptr, L);
+            hip_check(nvbio_hip_traceback_best_setup_mates(n_conc, idx_c.data(), best_o, band_len, genome_len, m_begin, m_len, m_fixed, m_rc, reads.mate_offset, 1,
+                                                           v.data(), tb_pat.data(), tb_plen.data(), tb_txt.data(), tb_len.data(), hip_stream), "nvbio_hip_traceback_best_setup_mates");
+            const PackedStringSetView<4, true> patterns(n_conc, reads.both_words, reads.both_n_words, tb_pat.data(), tb_plen.data(), 0u);
             const PackedStringSetView<2, true> texts(n_conc, genome_words, genome_n_words, tb_txt.data(), tb_len.data(), 0u);
             const nvbio_hip_string_set p = patterns.abi(), t = texts.abi();
             hip::device_vector<uint8> temp(nvbio_hip_gotoh_traceback_temp_bytes(L, 1024u, n_conc));
@@ -792,6 +811,7 @@ private:
         hip::device_vector<int32> known_score(pat_begin.size());
         hip::device_vector<uint32> hit_sink(best_sink ? pat_begin.size() * 2u : 0u);       // the DP sinks, per hit (kept for the traceback)
         hip::device_vector<uint32> job_hit(pat_begin.size()), job_count(1), work_counter(1);
+        hip::device_vector<uint32> pat_len(reads.read_len ? pat_begin.size() : 0u);          // reads of their own lengths: the jobs' pattern lengths
         // active_read_queues.in_queue = pack_read( params.top_seed ) of the seed queue
         hip_check(nvbio_hip_pack_read_queue(seed_queue_size, seed_queue, params.select.top_seed & 1u, reinterpret_cast<uint32*>(queues.active_in.data()), hip_stream),
                   "nvbio_hip_pack_read_queue");
@@ -820,8 +840,9 @@ private:
             // score_best: BestScoreStream's windows, then the banded scorer in nvBowtie's quality-aware scheme
             // Hits at a placement the read already recorded keep the recorded score (known_score, see nvbio_hip.h); only the others
             // become DP jobs, compacted, their scores scattered back at their hits.
-            score_best_setup(queues, nullptr, nullptr, L, reads.rc_offset, band_len, genome_len, best_data_dvec.data(), BATCH_SIZE, worst_score,
-                             pat_begin.data(), nullptr, txt_begin.data(), txt_len.data(), min_score.data(), known_score.data(),
+            uint32* const pat_len_ptr = reads.read_len ? pat_len.data() : nullptr;
+            score_best_setup(queues, reads.read_begin, reads.read_len, reads.fixed(), reads.rc_offset, band_len, genome_len, best_data_dvec.data(), BATCH_SIZE, worst_score,
+                             pat_begin.data(), pat_len_ptr, txt_begin.data(), txt_len.data(), min_score.data(), known_score.data(),
                              job_count.data(), job_hit.data(), hip_stream);
             // The DP jobs.  job_count stays on the device -- the scorer reads it there, so the host does not wait for the set-up kernel between
             // the two -- and every job's score and sink are written straight back at its hit (job_hit): scores into known_score, sinks into
@@ -831,7 +852,7 @@ private:
             uint32 n_jobs = 0;
             {
                 const uint32 nh = queues.hits_size;
-                const PackedStringSetView<4, true> patterns(nh, reads.fw_rc_words, reads.fw_rc_n_words, pat_begin.data(), nullptr, L);
+                const PackedStringSetView<4, true> patterns(nh, reads.fw_rc_words, reads.fw_rc_n_words, pat_begin.data(), pat_len_ptr, reads.fixed());
                 const PackedStringSetView<2, true> texts(nh, genome_words, genome_n_words, txt_begin.data(), txt_len.data(), 0u);
                 const aln::BestSinkArrays sink_arrays = { known_score.data(), best_sink ? hit_sink.data() : sinks.data() };
                 dispatch_band(band_len, [&](auto band) {
@@ -846,7 +867,7 @@ private:
 
             // score_reduce with the give-up counters
             stats.clock.run("reduce", hip_stream, [&] {
-                score_reduce(ReduceBestApproxContext(state.trys.data(), n_ext), hits, queues, known_score.data(), nullptr, L, best_data_dvec.data(), BATCH_SIZE,
+                score_reduce(ReduceBestApproxContext(state.trys.data(), n_ext), hits, queues, known_score.data(), reads.read_len, reads.fixed(), best_data_dvec.data(), BATCH_SIZE,
                              worst_score, params.select, nullptr, hip_stream, best_sink ? hit_sink.data() : nullptr, best_sink);
             });
             stats.extensions += queues.hits_size; ++stats.rounds;

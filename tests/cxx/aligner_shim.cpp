@@ -19,6 +19,22 @@ struct shim_params
     uint32_t edit_distance;        // 1: --scoring ed (params.h:47-51), 0: Smith-Waterman
 };
 
+// Reads of their own lengths: the next nvbio_aligner_best_approx / _paired / _paired_quals call of this thread takes mate m's reads at d_read_begin[r]
+// (symbols into its forward copies, the reversed stream alike), d_read_len[r] long, reverse complements rc_offset further; L is then the
+// longest read.  d_read_len == NULL clears it.
+struct ragged_layout { const uint64_t* begin; const uint32_t* len; uint64_t rc_offset; };
+static thread_local ragged_layout g_ragged[2] = { { nullptr, nullptr, 0 }, { nullptr, nullptr, 0 } };
+extern "C" __attribute__((visibility("default")))
+void nvbio_aligner_set_ragged(int mate, const uint64_t* d_read_begin, const uint32_t* d_read_len, uint64_t rc_offset)
+{ if (mate >= 0 && mate < 2) { g_ragged[mate].begin = d_read_begin; g_ragged[mate].len = d_read_len; g_ragged[mate].rc_offset = rc_offset; } }
+static void apply_ragged(ReadBatch& b, const int mate, const uint32_t* rev_words, const uint64_t rev_n_words, const uint64_t* rev_begin)
+{
+    const ragged_layout& r = g_ragged[mate];
+    if (!r.len) return;
+    b.read_begin = r.begin; b.read_len = r.len; b.rc_offset = r.rc_offset;
+    b.reversed = PackedStringSetView<4, true>(b.n, rev_words, rev_n_words, rev_begin, r.len, 0u);
+}
+
 extern "C" __attribute__((visibility("default")))
 int nvbio_aligner_best_approx(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmindex* rfmi, uint32_t n, uint32_t L,
                               const uint32_t* d_rev_words, uint64_t rev_n_words, const uint64_t* d_rev_begin,
@@ -49,6 +65,7 @@ int nvbio_aligner_best_approx(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmin
         reads.reversed = PackedStringSetView<4, true>(n, d_rev_words, rev_n_words, d_rev_begin, nullptr, L);
         reads.fw_rc_words = d_fwrc_words; reads.fw_rc_n_words = fwrc_n_words; reads.rc_offset = uint64_t(n) * L;
         reads.quals = d_quals; reads.n_quals = n_quals; reads.names = d_names; reads.names_idx = d_names_idx;
+        apply_ragged(reads, 0, d_rev_words, rev_n_words, d_rev_begin);
 
         Aligner aligner;
         aligner.init(std::max(sp->batch_size, n), sp->batch_size);
@@ -275,6 +292,7 @@ static int paired_impl(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmindex* rf
             b.reversed = PackedStringSetView<4, true>(n, d_rev_words[m], rev_n_words[m], d_rev_begin[m], nullptr, L);
             b.fw_rc_words = d_fwrc_words[m]; b.fw_rc_n_words = fwrc_n_words[m]; b.rc_offset = uint64_t(n) * L;
             b.quals = d_mate_quals ? d_mate_quals[m] : d_quals; b.n_quals = n_quals; b.names = d_names; b.names_idx = d_names_idx;
+            apply_ragged(b, m, d_rev_words[m], rev_n_words[m], d_rev_begin[m]);
         }
         reads.both_words = d_both_words; reads.both_n_words = both_n_words; reads.mate_offset = mate_offset;
         reads.both_quals = d_both_quals; reads.both_n_quals = both_n_quals;

@@ -809,3 +809,149 @@ def test_cxx_paired_driver_in_edit_distance_mode_equals_the_python_driver(cuda):
     paired = ((b >> np.uint64(30)) & np.uint64(1)) != 0
     assert paired.mean() > 0.5                                        # most pairs come back paired in this mode too
     assert (u64(e["best"]) != u64(sw["best"])).any()                  # ... and the mode is not the Smith-Waterman one
+
+
+def _ragged_reads(rng, text, n, lo, hi):
+    """reads of lengths lo .. hi (a few substitutions, one in nine a deletion, every other one reverse-complemented) -> (flat symbols, index, flat quals)"""
+    reads, quals = [], []
+    for i in range(n):
+        L = int(rng.integers(lo, hi + 1))
+        p = int(rng.integers(0, text.size - L - 2))
+        r = text[p:p + L].copy()
+        for j in rng.integers(0, L, [0, 1, 2, 3][i % 4] * L // 60):
+            r[j] = (r[j] + 1 + rng.integers(0, 3)) & 3
+        if i % 9 == 0 and L > 40:
+            d = int(rng.integers(10, L - 10)); r = np.concatenate([r[:d], r[d + 1:], text[p + L:p + L + 1]])
+        if i % 2:
+            r = (3 - r)[::-1].copy()
+        reads.append(r.astype(np.uint8)); quals.append(rng.integers(2, 42, r.size).astype(np.uint8))
+    index = np.zeros(n + 1, np.int64); index[1:] = np.cumsum([r.size for r in reads])
+    return np.concatenate(reads), index, np.concatenate(quals)
+
+
+def test_cxx_aligner_driver_takes_reads_of_their_own_lengths(cuda):
+    """ReadBatch::read_begin / read_len (include/nvbio_hip/aligner.h): 60 .. 140-bp reads with per-base qualities through the C++ single-end driver,
+    against the Python driver on the same ragged batch (which test_best_approx_ragged_reads_matches_oracle holds to the oracle)"""
+    import ctypes as C
+    shim = C.CDLL(os.path.join(HERE, "cxx", "libaligner_shim.so"))
+    rng = np.random.default_rng(515)
+    text = _small_index(rng)
+    host, rhost = O.FMIndex(text), O.FMIndex(text[::-1].copy())
+    fmi, rfmi = nvb.FMIndexDevice.from_host(host, cuda), nvb.FMIndexDevice.from_host(rhost, cuda)
+    n = 1300
+    flat, index, fq = _ragged_reads(rng, text, n, 60, 140)
+    names = ["rag.%d" % i for i in range(n)]
+    params = A.Params()
+    scheme = nvb.SmithWatermanScoringScheme()
+    d_gw = W._pack_chunked(torch.from_numpy(text), 2, True).to(cuda)
+    rb = A.ReadBatch.from_ragged(torch.from_numpy(flat).to(cuda), torch.from_numpy(index).to(cuda), torch.from_numpy(fq).to(cuda))
+    e = A.best_approx(fmi, rfmi, rb, d_gw, text.size, params, scheme, names, finish=True, cigar_stride=64)
+    L = rb.max_len
+    arena, idx = S.pack_names(names, cuda)
+    sp = _ShimParams(int(params.local), int(params.randomized), params.top_seed, params.max_effort_init, params.max_effort, params.min_ext, params.max_ext,
+                     params.max_reseed, params.rep_seeds, params.max_hits, params.allow_sub, params.subseed_len, params.seed_len, params.seed_freq[0],
+                     params.min_read_len, params.max_dist, int(params.no_multi_hits), params.batch_size, params.hits_stride or 0,
+                     params.seed_freq[1], params.seed_freq[2], scheme.m_match, scheme.m_score_min[0], scheme.m_score_min[1], scheme.m_score_min[2], 1, 0)
+    mds = np.zeros((n, 256), np.uint8); mds_len = np.zeros(n, np.uint32)
+    best = np.zeros((2, n), np.uint64); mapq = np.zeros(n, np.uint8); cigar = np.zeros((n, 64), np.uint16); cigar_len = np.zeros(n, np.uint32)
+    source = np.zeros((n, 2), np.uint32); sink = np.zeros((n, 2), np.uint32); tb_score = np.zeros(n, np.int32); stats = np.zeros(12, np.uint64)
+    fs, rs = fmi.struct(), rfmi.struct()
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    hp = lambda a: a.ctypes.data_as(C.c_void_p)
+    shim.nvbio_aligner_set_ragged.restype = None
+    torch.cuda.synchronize()
+    shim.nvbio_aligner_set_ragged(0, vp(rb.read_begin), vp(rb.read_len), C.c_uint64(int(rb.rc_offset)))
+    try:
+        rc = shim.nvbio_aligner_best_approx(C.byref(fs), C.byref(rs), C.c_uint32(n), C.c_uint32(L), vp(rb.reversed.words), C.c_uint64(rb.reversed.words.numel()),
+                                            vp(rb.reversed.begin), vp(rb.fw_rc_words), C.c_uint64(rb.fw_rc_words.numel()), vp(rb.quals), C.c_uint64(rb.quals.numel()), vp(arena), vp(idx),
+                                            vp(d_gw), C.c_uint64(d_gw.numel()), C.c_uint32(text.size), C.byref(sp),
+                                            hp(best), hp(mapq), hp(cigar), hp(cigar_len), hp(source), hp(sink), hp(tb_score), hp(stats), hp(mds), hp(mds_len))
+    finally:
+        shim.nvbio_aligner_set_ragged(0, None, None, C.c_uint64(0))
+    assert rc == 0
+    assert (best == e["best"].cpu().numpy().view(np.uint64)).all() and (mapq == e["mapq"].cpu().numpy()).all()
+    ids = e["aligned_ids"].cpu().numpy()
+    assert ids.size > n * 3 // 4
+    assert (cigar_len[ids] == e["cigar_len"].cpu().numpy().view(np.uint32)[ids]).all() and (cigar[ids] == e["cigar"].cpu().numpy().view(np.uint16)[ids]).all()
+    assert (source[ids] == e["source"].cpu().numpy().view(np.uint32)[ids]).all() and (mds_len[ids] == e["mds_len"].cpu().numpy().view(np.uint32)[ids]).all()
+    st = e["stats"]
+    assert (int(stats[0]), int(stats[1]), int(stats[2])) == (st["extensions"], st["rounds"], st["seeding_passes"])
+
+
+def test_cxx_paired_driver_takes_mates_of_their_own_lengths(cuda):
+    """PairedReadBatch with ragged mates (70 .. 130 bp each) through the C++ paired driver, against the Python paired driver on the same batches
+    (which tests/test_ref_tests_gpu.py holds to the unchanged nvBowtie on mixed-length pairs)"""
+    import ctypes as C
+    shim = C.CDLL(os.path.join(HERE, "cxx", "libaligner_shim.so"))
+    rng = np.random.default_rng(616)
+    text = _small_index(rng, 1 << 17)
+    host, rhost = O.FMIndex(text), O.FMIndex(text[::-1].copy())
+    fmi, rfmi = nvb.FMIndexDevice.from_host(host, cuda), nvb.FMIndexDevice.from_host(rhost, cuda)
+    n = 800
+    m1, m2 = [], []
+    for i in range(n):
+        f = int(rng.integers(220, 420)); p = int(rng.integers(0, text.size - f - 2))
+        a, b = int(rng.integers(70, 131)), int(rng.integers(70, 131))
+        r1 = text[p:p + a].copy(); r2 = (3 - text[p + f - b:p + f])[::-1].copy()
+        for r in (r1, r2):
+            mut = rng.random(r.size) < 0.02; r[mut] = (r[mut] + 1) & 3
+        m1.append(r1.astype(np.uint8)); m2.append(r2.astype(np.uint8))
+    names = ["pair.%d" % i for i in range(n)]
+
+    def batch(reads):
+        index = np.zeros(n + 1, np.int64); index[1:] = np.cumsum([r.size for r in reads])
+        return A.ReadBatch.from_ragged(torch.from_numpy(np.concatenate(reads)).to(cuda), torch.from_numpy(index).to(cuda),
+                                       torch.from_numpy(rng.integers(2, 42, int(index[-1])).astype(np.uint8)).to(cuda))
+    b = [batch(m1), batch(m2)]
+    params = A.Params()
+    scheme = nvb.SmithWatermanScoringScheme()
+    d_gw = W._pack_chunked(torch.from_numpy(text), 2, True).to(cuda)
+    e = A.best_approx_paired(fmi, rfmi, b[0], b[1], d_gw, text.size, params, scheme, names, finish=True)
+    L = max(b[0].max_len, b[1].max_len)
+    both = torch.cat([b[0].fw_rc_words, b[1].fw_rc_words]); mate_offset = b[0].fw_rc_words.numel() * 8
+    both_q = torch.zeros(mate_offset + 2 * int(b[1].rc_offset) + 8, dtype=torch.uint8, device=cuda)
+    both_q[: 2 * int(b[0].rc_offset)] = b[0].quals[: 2 * int(b[0].rc_offset)]
+    both_q[mate_offset: mate_offset + 2 * int(b[1].rc_offset)] = b[1].quals[: 2 * int(b[1].rc_offset)]
+    arena, idx = S.pack_names(names, cuda)
+    sp = _ShimParams(int(params.local), int(params.randomized), params.top_seed, params.max_effort_init, params.max_effort, params.min_ext, params.max_ext,
+                     params.max_reseed, params.rep_seeds, params.max_hits, params.allow_sub, params.subseed_len, params.seed_len, params.seed_freq[0],
+                     params.min_read_len, params.max_dist, int(params.no_multi_hits), params.batch_size, params.hits_stride or 0,
+                     params.seed_freq[1], params.seed_freq[2], scheme.m_match, scheme.m_score_min[0], scheme.m_score_min[1], scheme.m_score_min[2], 1, 0)
+    pp = _ShimPeParams(params.pe_policy, int(params.pe_overlap), int(params.pe_unpaired), int(params.pe_discordant), params.min_frag_len, params.max_frag_len)
+    out = dict(best=[np.zeros((2, n), np.uint64) for _ in range(2)], mapq=[np.zeros(n, np.uint8) for _ in range(2)], cigar=[np.zeros((n, 64), np.uint16) for _ in range(2)],
+               cigar_len=[np.zeros(n, np.uint32) for _ in range(2)], source=[np.zeros((n, 2), np.uint32) for _ in range(2)], sink=[np.zeros((n, 2), np.uint32) for _ in range(2)],
+               mds=[np.zeros((n, 256), np.uint8) for _ in range(2)], mds_len=[np.zeros(n, np.uint32) for _ in range(2)])
+    stats = np.zeros(12, np.uint64)
+    pair_ptrs = lambda ts: (C.c_void_p * 2)(*[t.data_ptr() for t in ts])
+    pair_host = lambda arrs: (C.c_void_p * 2)(*[a.ctypes.data for a in arrs])
+    u64x2 = lambda v: (C.c_uint64 * 2)(*v)
+    fs, rs = fmi.struct(), rfmi.struct()
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    shim.nvbio_aligner_set_ragged.restype = None
+    torch.cuda.synchronize()
+    for m in (0, 1):
+        shim.nvbio_aligner_set_ragged(m, vp(b[m].read_begin), vp(b[m].read_len), C.c_uint64(int(b[m].rc_offset)))
+    try:
+        rc = shim.nvbio_aligner_best_approx_paired_quals(
+            C.byref(fs), C.byref(rs), C.c_uint32(n), C.c_uint32(L),
+            pair_ptrs([b[0].reversed.words, b[1].reversed.words]), u64x2([b[0].reversed.words.numel(), b[1].reversed.words.numel()]), pair_ptrs([b[0].reversed.begin, b[1].reversed.begin]),
+            pair_ptrs([b[0].fw_rc_words, b[1].fw_rc_words]), u64x2([b[0].fw_rc_words.numel(), b[1].fw_rc_words.numel()]), pair_ptrs([b[0].quals, b[1].quals]),
+            C.c_uint64(min(b[0].quals.numel(), b[1].quals.numel())), vp(arena), vp(idx),
+            vp(both), C.c_uint64(both.numel()), C.c_uint64(mate_offset), vp(both_q), C.c_uint64(both_q.numel()),
+            vp(d_gw), C.c_uint64(d_gw.numel()), C.c_uint32(text.size), C.byref(sp), C.byref(pp),
+            pair_host(out["best"]), pair_host(out["mapq"]), pair_host(out["cigar"]), pair_host(out["cigar_len"]), pair_host(out["source"]), pair_host(out["sink"]),
+            pair_host(out["mds"]), pair_host(out["mds_len"]), stats.ctypes.data_as(C.c_void_p), None)
+    finally:
+        for m in (0, 1):
+            shim.nvbio_aligner_set_ragged(m, None, None, C.c_uint64(0))
+    assert rc == 0
+    u64 = lambda t: t.cpu().numpy().view(np.uint64)
+    assert (out["best"][0] == u64(e["best"])).all() and (out["best"][1] == u64(e["best_o"])).all()
+    assert (out["mapq"][0] == e["mapq1"].cpu().numpy()).all() and (out["mapq"][1] == e["mapq2"].cpu().numpy()).all()
+    for slot, key, md in ((0, "tb1", "mds1"), (1, "tb2", "mds2")):
+        assert (out["cigar_len"][slot] == e[key]["cigar_len"].cpu().numpy().view(np.uint32)).all(), key
+        assert (out["cigar"][slot] == e[key]["cigar"].cpu().numpy().view(np.uint16)).all(), key
+        assert (out["source"][slot] == e[key]["source"].cpu().numpy().view(np.uint32)).all(), key
+        assert (out["mds_len"][slot] == e[md + "_len"].cpu().numpy().view(np.uint32)).all(), md
+    paired = ((u64(e["best"])[0] >> np.uint64(30)) & np.uint64(1)) != 0
+    assert paired.mean() > 0.7
