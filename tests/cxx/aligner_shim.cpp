@@ -506,6 +506,7 @@ int nvbio_aligner_all(const nvbio_hip_fmindex* fmi, const nvbio_hip_fmindex* rfm
         reads.reversed = PackedStringSetView<4, true>(n, d_rev_words, rev_n_words, d_rev_begin, nullptr, L);
         reads.fw_rc_words = d_fwrc_words; reads.fw_rc_n_words = fwrc_n_words; reads.rc_offset = uint64_t(n) * L;
         reads.quals = d_quals; reads.n_quals = n_quals; reads.names = nullptr; reads.names_idx = nullptr;
+        apply_ragged(reads, 0, d_rev_words, rev_n_words, d_rev_begin);
 
         Aligner aligner;
         aligner.init(std::max(sp->batch_size, n), sp->batch_size);

@@ -239,6 +239,53 @@ def test_cxx_all_mapping_driver_in_edit_distance_mode_equals_the_python_driver(c
     assert int(sw["read_id"].numel()) != m or not torch.equal(sw["alignments"], e["alignments"])          # the mode is not the Smith-Waterman one
 
 
+def test_cxx_all_mapping_driver_takes_reads_of_their_own_lengths(cuda):
+    """ReadBatch::read_begin / read_len through the C++ Aligner::all, against the Python all_mapping on the same ragged batch"""
+    import ctypes as C, os
+    from tests.test_select_gpu import _ShimParams, _ragged_reads
+    shim = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "cxx", "libaligner_shim.so"))
+    rng = np.random.default_rng(4444)
+    text = _genome(rng)
+    host, rhost = O.FMIndex(text), O.FMIndex(text[::-1].copy())
+    fmi, rfmi = nvb.FMIndexDevice.from_host(host, cuda), nvb.FMIndexDevice.from_host(rhost, cuda)
+    params = A.Params()
+    n = 500
+    flat, index, fq = _ragged_reads(rng, text, n, 60, 140)
+    scheme = nvb.SmithWatermanScoringScheme()
+    d_gw = W._pack_chunked(torch.from_numpy(text), 2, True).to(cuda)
+    rb = A.ReadBatch.from_ragged(torch.from_numpy(flat).to(cuda), torch.from_numpy(index).to(cuda), torch.from_numpy(fq).to(cuda))
+    e = A.all_mapping(fmi, rfmi, rb, d_gw, text.size, params, scheme, cigar_stride=64)
+    sp = _ShimParams(int(params.local), 0, 0, params.max_effort_init, params.max_effort, params.min_ext, params.max_ext,
+                     params.max_reseed, params.rep_seeds, params.max_hits, params.allow_sub, params.subseed_len, params.seed_len, params.seed_freq[0],
+                     params.min_read_len, params.max_dist, 0, params.batch_size, params.hits_stride or 0,
+                     params.seed_freq[1], params.seed_freq[2], scheme.m_match, scheme.m_score_min[0], scheme.m_score_min[1], scheme.m_score_min[2], 1, 0)
+    m = int(e["read_id"].numel())
+    assert m > n // 2
+    cap = m + 16
+    rid = np.zeros(cap, np.uint32); aln = np.zeros(cap, np.uint64); scored = np.zeros(cap, np.uint64); cigar = np.zeros((cap, 64), np.uint16)
+    cigar_len = np.zeros(cap, np.uint32); source = np.zeros((cap, 2), np.uint32); sink = np.zeros((cap, 2), np.uint32)
+    mds = np.zeros((cap, 256), np.uint8); mds_len = np.zeros(cap, np.uint32); stats = np.zeros(3, np.uint64); count = np.zeros(1, np.uint64)
+    si = np.asarray([0, text.size], np.uint32)
+    fs, rs = fmi.struct(), rfmi.struct()
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    hp = lambda a: a.ctypes.data_as(C.c_void_p)
+    shim.nvbio_aligner_set_ragged.restype = None
+    torch.cuda.synchronize()
+    shim.nvbio_aligner_set_ragged(0, vp(rb.read_begin), vp(rb.read_len), C.c_uint64(int(rb.rc_offset)))
+    try:
+        rc = shim.nvbio_aligner_all(C.byref(fs), C.byref(rs), C.c_uint32(n), C.c_uint32(rb.max_len), vp(rb.reversed.words), C.c_uint64(rb.reversed.words.numel()), vp(rb.reversed.begin),
+                                    vp(rb.fw_rc_words), C.c_uint64(rb.fw_rc_words.numel()), vp(rb.quals), C.c_uint64(rb.quals.numel()), vp(d_gw), C.c_uint64(d_gw.numel()), C.c_uint32(text.size),
+                                    hp(si), C.c_uint32(si.size), C.byref(sp), C.c_uint64(cap), hp(count), hp(rid), hp(aln), hp(scored), hp(cigar), hp(cigar_len), hp(source),
+                                    hp(sink), hp(mds), hp(mds_len), hp(stats))
+    finally:
+        shim.nvbio_aligner_set_ragged(0, None, None, C.c_uint64(0))
+    assert rc == 0 and int(count[0]) == m
+    u64 = lambda t: t.cpu().numpy().view(np.uint64)
+    assert (rid[:m] == e["read_id"].cpu().numpy().view(np.uint32)).all() and (scored[:m] == u64(e["alignments_scored"])).all() and (aln[:m] == u64(e["alignments"])).all()
+    assert (cigar_len[:m] == e["cigar_len"].cpu().numpy().view(np.uint32)).all() and (cigar[:m] == e["cigar"].cpu().numpy().view(np.uint16)[:m]).all()
+    assert (mds_len[:m] == e["mds_len"].cpu().numpy().view(np.uint32)).all()
+
+
 @pytest.mark.parametrize("bs", [1 << 20, 257])
 def test_all_mapping_matches_committed_vectors(cuda, bs):
     """The HIP path against the committed fixture (tests/golden/all_mapping_vectors.npz): no oracle call at run time."""
