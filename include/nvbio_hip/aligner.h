@@ -638,7 +638,7 @@ private:
                         const PackedStringSetView<4, true> patterns(nh, o_reads.fw_rc_words, o_reads.fw_rc_n_words, pat_begin.data(), o_reads.read_len ? pat_len.data() : nullptr, o_reads.fixed());
                         const PackedStringSetView<2, true> texts(nh, genome_words, genome_n_words, txt_begin.data(), txt_len.data(), 0u);
                         const nvbio_hip_string_set p = patterns.abi(), t = texts.abi();
-                        const uint32 wave_up_to = wave_form_up_to() / 4u;
+                        const uint32 wave_up_to = wave_form_full_up_to();
                         if (wave_up_to)
                         {
                             hip_check(nvbio_hip_list_flagged(nh, o_valid.data(), 1u, a_live_count.data(), a_live_idx.data(), hip_stream), "nvbio_hip_list_flagged");
@@ -782,6 +782,8 @@ private:
     /// the largest batch of DP jobs that runs one wave per job (banded_gotoh_wave.hip) instead of one lane per job: NVBIO_HIP_WAVE_JOBS (read once;
     /// default 24576, 0 = never).  A round's jobs are counted on the device and the device picks the form (alignment.h).
     static uint32 wave_form_up_to() { static const uint32 v = [] { const char* e = getenv("NVBIO_HIP_WAVE_JOBS"); return e ? uint32(atoi(e)) : 24576u; }(); return v; }
+    /// ... and the same for the opposite mate's full-matrix DP: NVBIO_HIP_WAVE_JOBS_FULL (default 6144)
+    static uint32 wave_form_full_up_to() { static const uint32 v = [] { const char* e = getenv("NVBIO_HIP_WAVE_JOBS_FULL"); return e ? uint32(atoi(e)) : 6144u; }(); return v; }
     /// NVBIO_HIP_TRACE_ROUNDS=1 (read once): one line per extension round on stderr -- the queue sizes the hits-per-read rule saw
     static bool trace_rounds() { static const bool on = [] { const char* e = getenv("NVBIO_HIP_TRACE_ROUNDS"); return e && atoi(e) == 1; }(); return on; }
     bool count_jobs = false;          ///< fill Stats::dp_jobs (one host round trip per extension round; the stage clock does it too)

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--jobs", type=int, default=4_000_000)
     ap.add_argument("--band", type=int, default=31)
     ap.add_argument("--len", type=int, default=100)
+    ap.add_argument("--wave", action="store_true", help="instead: the one-wave-per-job anti-diagonal kernel next to the lane-per-job kernel, from 256 jobs to --jobs")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     n, L, B = a.jobs, a.len, a.band
@@ -40,6 +41,22 @@ def main():
     q = torch.randint(2, 41, (n * L + 8,), dtype=torch.uint8, generator=g, device=dev)
     al = nvb.make_gotoh_aligner(nvb.SEMI_GLOBAL, nvb.SmithWatermanScoringScheme())
     s0, k0 = nvb.batch_banded_alignment_score(B, al, p, t, quals=q)
+    if a.wave:
+        # same jobs, the first m of them: latency of a small launch (what a tail round of the paired driver pays) and throughput of a large one
+        from nvbio_amd.alignment import batch_banded_alignment_score_wave
+        rows = []
+        m = 256
+        while m <= n:
+            pm = nvb.PackedStringSet(pw, 4, True, p.begin[:m].contiguous(), None, L); tm = nvb.PackedStringSet(tw, 2, True, t.begin[:m].contiguous(), None, L + B)
+            sl, kl = torch.empty(m, dtype=torch.int32, device=dev), torch.empty((m, 2), dtype=torch.int32, device=dev)
+            sw, kw = torch.empty_like(sl), torch.empty_like(kl)
+            lane = timed(lambda: nvb.batch_banded_alignment_score(B, al, pm, tm, quals=q, out_score=sl, out_sink=kl))
+            wave = timed(lambda: batch_banded_alignment_score_wave(B, al, pm, tm, q, out_score=sw, out_sink=kw))
+            rows.append(dict(jobs=m, lane_per_job_us=round(lane * 1e3, 1), wave_per_job_us=round(wave * 1e3, 1), identical=bool(torch.equal(sl, sw) and torch.equal(kl, kw)),
+                             lane_GCUPS=round(m * L * B / lane / 1e6, 1), wave_GCUPS=round(m * L * B / wave / 1e6, 1)))
+            m *= 4
+        print(json.dumps({"band": B, "len": L, "rows": rows}))
+        return
     out = {"jobs": n, "band": B, "len": L, "mean_score": float(s0.float().mean().item())}
     out["plain_ms"] = timed(lambda: nvb.batch_banded_alignment_score(B, al, p, t, quals=q, out_score=s0, out_sink=k0))
     s1, k1 = torch.empty_like(s0), torch.empty_like(k0)
