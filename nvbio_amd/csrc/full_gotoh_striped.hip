@@ -254,7 +254,7 @@ full_gotoh_striped_kernel(const StripeParams p)
 }
 
 // the lines between stripes: one block per device, grown on demand, kept (a batch of long patterns is followed by another)
-struct StripeLines { int32_t* ptr; uint64_t bytes; };
+struct StripeLines { int32_t* ptr; uint64_t bytes; hipStream_t last; bool used; };
 static thread_local StripeLines g_lines[64] = {};
 
 hipError_t launch_striped(StripeParams& p, int type, uint32_t max_m, hipStream_t s)
@@ -272,6 +272,9 @@ hipError_t launch_striped(StripeParams& p, int type, uint32_t max_m, hipStream_t
         int dev = 0;
         if (hipError_t e = hipGetDevice(&dev)) return e;
         StripeLines& L = g_lines[dev & 63];
+        // one set of lines per host thread and device: a launch on another stream than the last one waits for that one's sweep to finish
+        if (L.used && L.last != s) { if (hipError_t e = hipDeviceSynchronize()) return e; }      // (the device, not L.last: that stream may be gone)
+        L.last = s; L.used = true;
         if (L.bytes < need)
         {
             if (L.ptr) { if (hipError_t e = hipStreamSynchronize(s)) return e; nvbio_hip_device_free(L.ptr); L.ptr = nullptr; L.bytes = 0; }
