@@ -483,6 +483,22 @@ def test_reference_nvbowtie_equals_own_driver_at_3gbp():
     assert out["aligned_share_first_200k"] > 0.9
 
 
+def test_reference_nvbowtie_equals_own_drivers_at_3gbp_in_edit_distance_mode():
+    """--scoring ed at BASELINE config 4's index size: the unchanged nvBowtie and both from-scratch drivers (Params.scoring_mode = "ed" /
+    Params::scoring_mode = EditDistanceMode) on the same 3 Gbp repeat-rich files, 2 M reads: every SAM record identical"""
+    import sys
+    exe = os.path.join(REF, "ref_nvBowtie")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_nvBowtie not built (needs /root/reference in the build container)")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import nvbowtie_3gbp as T
+    out, log = T.run(3_000_000_000, 2_000_000, 0.6, extra=("--scoring", "ed"), own_overrides=dict(scoring_mode="ed"))
+    assert out["nvbowtie_exit"] == 0, log[-2000:]
+    assert out["records_ref"] == out["records_own"] == out["records_cxx"] == 2_000_000
+    assert out["identical"] == 2_000_000, (out["difference_categories"], out["first_differences"][:3])
+    assert out["cxx_identical"] == 2_000_000, (out["cxx_difference_categories"], out["cxx_first_differences"][:3])
+
+
 def test_reference_nvbowtie_equals_own_paired_driver_at_3gbp():
     """BASELINE config 5 as written, at one device and one batch: paired-end 2 x 150 bp, --local (LOCAL Gotoh, band 31), on the 3 Gbp repeat-rich index
     files, 1024 K pairs (nvBowtie's batch) with per-base qualities, indels and Ns: the unchanged nvBowtie (-1 / -2) and the C++ paired-end driver

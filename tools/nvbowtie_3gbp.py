@@ -343,7 +343,7 @@ def run_paired(genome=3_000_000_000, pairs=1 << 20, repeats=0.6, seed=0x5EED0019
             shutil.rmtree(tmp, ignore_errors=True)
 
 
-def own_driver_cxx(prefix, sym, qual, sam_path, dev, batch_reads, digits=8, timings=None, hbm_rich=True):
+def own_driver_cxx(prefix, sym, qual, sam_path, dev, batch_reads, digits=8, timings=None, hbm_rich=True, overrides=None):
     """the C++ host driver (nvbio::bowtie2::cuda::Aligner::best_approx, include/nvbio_hip/aligner.h; entered through tests/cxx/aligner_shim.cpp)
     over the same reads on the same index files, batch by batch -> own_cxx.sam.  The index is what io::FMIndexDataDevice makes of the files on
     this device by default: the HBM-rich form (line-native records, 12-mer table, the densest suffix array that fits)."""
@@ -361,7 +361,7 @@ def own_driver_cxx(prefix, sym, qual, sam_path, dev, batch_reads, digits=8, timi
     torch.cuda.synchronize()
     t_load = time.time() - t0
     n, L = sym.shape
-    prm = A.Params(hits_stride=32, batch_size=batch_reads)
+    prm = A.Params(hits_stride=32, batch_size=batch_reads, **(overrides or {}))
     scheme = nvb.SmithWatermanScoringScheme()
     sp = B._shim_params(prm, scheme); sp.finish = 1
     fs = data.index().struct()
@@ -518,7 +518,7 @@ def _run(tmp, genome, reads, repeats, seed, batch_reads, profile, extra, threads
     # ---- ... and its C++ host driver on the HBM-rich index this device gets by default
     torch.cuda.empty_cache()
     cxx_sam = os.path.join(tmp, "own_cxx.sam")
-    own_driver_cxx(prefix, sym, qual, cxx_sam, dev, batch_reads, timings=out)
+    own_driver_cxx(prefix, sym, qual, cxx_sam, dev, batch_reads, timings=out, overrides=own_overrides)
     n_ref2, n_cxx, same2, diffs2, cats2 = compare_sam(ref_sam, cxx_sam)
     out.update(records_cxx=n_cxx, cxx_identical=same2, cxx_difference_categories=cats2, cxx_first_differences=diffs2)
     if rerun:
@@ -588,7 +588,7 @@ def main():
     overrides = {}
     for kv in filter(None, a.own.split(",")):
         k, v = kv.split("=")
-        overrides[k] = (v == "True") if v in ("True", "False") else int(v)
+        overrides[k] = (v == "True") if v in ("True", "False") else (int(v) if v.lstrip("-").isdigit() else v)
     out, log = run(int(a.genome), a.reads, a.repeats, batch_reads=a.batch_reads, profile=a.profile, extra=a.extra.split(), threads_test=a.two_threads, rerun=a.rerun,
                    workdir=a.keep, own_overrides=overrides,
                    families=[(int(f.split(":")[0]), float(f.split(":")[1]), float(f.split(":")[2])) for f in a.families.split(",")] if a.families else None)
