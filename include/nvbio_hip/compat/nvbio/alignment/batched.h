@@ -358,26 +358,36 @@ struct limits_scope
     stream_limits m_saved;
 };
 
+/// the same publication for limits that were measured on the way (the view route's description pass counts them: no pass of their own)
+struct known_limits_scope
+{
+    template <typename stream_type>
+    known_limits_scope(const stream_type& s, const uint32 p, const uint32 t) : m_saved(current_limits()) { const stream_limits l = { &s, p, t }; current_limits() = l; }
+    ~known_limits_scope() { current_limits() = m_saved; }
+    stream_limits m_saved;
+};
+
 #if defined(NVBIO_HIP_COMPAT_TUNED)
 /// the job table the tuned kernels consume (structure of arrays in one device buffer)
 struct job_table
 {
     uint64* pat_begin; uint32* pat_len; uint64* txt_begin; uint32* txt_len; int32* min_score; int32* score; uint32* sink; uint8* ok;
     unsigned long long* bounds;        // [0] lowest pattern word, [1] end pattern word, [2] lowest text word, [3] end text word
-                                       // views: [4] / [5] min / max of (quality address - pattern symbol address), [7] end pattern symbol
+                                       // views: [4] / [5] min / max of (quality address - pattern symbol address), [7] end pattern symbol,
+                                       //        [9] / [11] the longest pattern / text (what limits_scope would have measured in a pass of its own)
     uint32* stage_words; uint8* stage_quals; uint32 stage_stride;         // staged patterns: job i at symbol i * stage_stride (4-bit, little-endian)
     // set by the host after the description pass: no job's min_score can ever bind (all <= -2^29; bounds[5] holds their maximum, biased by 2^31).
     // A stream that does not use thresholds says so with Field_traits<int32>::min() in every context (sw-benchmark.cu:204-215, batched_inl.h:944);
     // the full-matrix kernels then run their plain sweep instead of the one that watches the column maxima (12.2 instead of 16.2 ms for
     // sw-benchmark's LOCAL batch)
     bool    no_thresholds;
-    static uint64 bytes(const uint32 n) { return 64u + uint64(n) * (8u + 4u + 8u + 4u + 4u + 4u + 8u + 1u) + 8u * 16u; }
+    static uint64 bytes(const uint32 n) { return 128u + uint64(n) * (8u + 4u + 8u + 4u + 4u + 4u + 8u + 1u) + 8u * 16u; }
     static uint32 stride_for(const uint32 maxP) { const uint32 s = (maxP + 7u) & ~7u; return s ? s : 8u; }
     static uint64 stage_bytes(const uint32 n, const uint32 maxP, const bool quals)
     { const uint64 sym = uint64(n) * stride_for(maxP) + 64u; return sym / 2u + (quals ? sym : 0u) + 32u; }
     void carve(uint8* p, const uint32 n)
     {
-        bounds = reinterpret_cast<unsigned long long*>(p); p += 64u;
+        bounds = reinterpret_cast<unsigned long long*>(p); p += 128u;
         pat_begin = reinterpret_cast<uint64*>(p); p += uint64(n) * 8u;
         txt_begin = reinterpret_cast<uint64*>(p); p += uint64(n) * 8u;
         sink      = reinterpret_cast<uint32*>(p); p += uint64(n) * 8u;
@@ -395,7 +405,7 @@ __device__ __forceinline__ unsigned long long wave_min(unsigned long long v)
 __device__ __forceinline__ unsigned long long wave_max(unsigned long long v)
 { for (int o = 32; o > 0; o >>= 1) { const unsigned long long w = __shfl_xor(v, o, 64); v = w > v ? w : v; } return v; }
 
-static __global__ void init_bounds_kernel(unsigned long long* b) { if (threadIdx.x < 8u) b[threadIdx.x] = (threadIdx.x & 1u) ? 0ull : ~0ull; }
+static __global__ void init_bounds_kernel(unsigned long long* b) { if (threadIdx.x < 16u) b[threadIdx.x] = (threadIdx.x & 1u) ? 0ull : ~0ull; }
 
 /// where a pattern lives (in place), or nothing (staged)
 template <typename P, bool DIRECT> struct pattern_where {
@@ -504,7 +514,7 @@ __global__ void __launch_bounds__(256) describe_views_kernel(const stream_type s
     // a fixed grid strides over the jobs and every lane keeps its own bounds: the seven global bounds then cost seven atomics per
     // BLOCK.  (One atomic per wave and bound is what the first version did; jobs usually come in storage order, so every wave moved
     // the upper bounds, and 156 k waves x 3 atomics on three addresses were 3 of its 4.1 ms per 10 M jobs.)
-    unsigned long long plo = ~0ull, phi = 0ull, tlo = ~0ull, thi = 0ull, dlo = ~0ull, dhi = 0ull, send = 0ull;
+    unsigned long long plo = ~0ull, phi = 0ull, tlo = ~0ull, thi = 0ull, dlo = ~0ull, dhi = 0ull, send = 0ull, pmax = 0ull, tmax = 0ull;
     const uint32 n = stream.size();
     for (uint32 i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
     {
@@ -522,6 +532,7 @@ __global__ void __launch_bounds__(256) describe_views_kernel(const stream_type s
             fl = (strings.pattern.rev ? 1u : 0u) | (strings.pattern.comp ? 2u : 0u);
             packed_view<typename R::text_type>::where(strings.text, tw, tf);
             tl = strings.text.length(); ms = ctx.min_score;
+            pmax = pl > pmax ? pl : pmax; tmax = tl > tmax ? tl : tmax;
             const unsigned long long te = tw + (tf + tl + 15u) / 16u, pe = (ps + pl + per - 1u) / per;
             tlo = tw < tlo ? tw : tlo; thi = te > thi ? te : thi;
             plo = ps / per < plo ? ps / per : plo; phi = pe > phi ? pe : phi; send = ps + pl > send ? ps + pl : send;
@@ -532,17 +543,18 @@ __global__ void __launch_bounds__(256) describe_views_kernel(const stream_type s
         t.pat_begin[i] = ps; t.pat_len[i] = pl; t.ok[i] = uint8(fl);
         t.txt_begin[i] = tw * 16u + tf; t.txt_len[i] = tl; t.min_score[i] = ms;
     }
-    __shared__ unsigned long long s_b[4][7];
+    __shared__ unsigned long long s_b[4][9];
     plo = wave_min(plo); phi = wave_max(phi); tlo = wave_min(tlo); thi = wave_max(thi); send = wave_max(send); dlo = wave_min(dlo); dhi = wave_max(dhi);
+    pmax = wave_max(pmax); tmax = wave_max(tmax);
     if ((threadIdx.x & 63u) == 0u)
-    { unsigned long long* o = s_b[threadIdx.x >> 6]; o[0] = plo; o[1] = phi; o[2] = tlo; o[3] = thi; o[4] = dlo; o[5] = dhi; o[6] = send; }
+    { unsigned long long* o = s_b[threadIdx.x >> 6]; o[0] = plo; o[1] = phi; o[2] = tlo; o[3] = thi; o[4] = dlo; o[5] = dhi; o[6] = send; o[7] = pmax; o[8] = tmax; }
     __syncthreads();
-    if (threadIdx.x < 7u)
+    if (threadIdx.x < 9u)
     {
         const bool is_min = (threadIdx.x == 0u || threadIdx.x == 2u || threadIdx.x == 4u);
         unsigned long long v = s_b[0][threadIdx.x];
         for (uint32 w = 1; w < 4u; ++w) { const unsigned long long x = s_b[w][threadIdx.x]; v = is_min ? (x < v ? x : v) : (x > v ? x : v); }
-        const uint32 slot = threadIdx.x == 6u ? 7u : threadIdx.x;
+        const uint32 slot = threadIdx.x == 6u ? 7u : threadIdx.x == 7u ? 9u : threadIdx.x == 8u ? 11u : threadIdx.x;
         if (is_min) { if (v != ~0ull) atomicMin(&t.bounds[slot], v); } else if (v != 0ull) atomicMax(&t.bounds[slot], v);
     }
 }
@@ -636,7 +648,7 @@ inline void build_job_table(const stream_type& stream, device_buffer& buf, job_t
 /// symbols (several read batches behind one stream): the caller then stages, as before.
 template <typename stream_type, typename R = recognised<stream_type> >
 inline bool build_view_table(const stream_type& stream, device_buffer& buf, job_table& t, nvbio_hip_string_set& ps, nvbio_hip_string_set& ts,
-                             const uint8** quals, uint64* n_quals, const uint8** flags, hipStream_t hs)
+                             const uint8** quals, uint64* n_quals, const uint8** flags, hipStream_t hs, uint32* maxP = NULL, uint32* maxT = NULL)
 {
     typedef typename pattern_source<typename R::pattern_type>::where_type where_type;
     const uint32 n = stream.size();
@@ -644,11 +656,13 @@ inline bool build_view_table(const stream_type& stream, device_buffer& buf, job_
     t.carve(buf.reserve(table + 16u, hs), n);
     hipLaunchKernelGGL(init_bounds_kernel, dim3(1), dim3(64), 0, hs, t.bounds);
     hipLaunchKernelGGL((describe_views_kernel<stream_type, R>), dim3(std::min<uint32>((n + 255u) / 256u, 8192u)), dim3(256), 0, hs, stream, t);
-    unsigned long long b[8];
+    unsigned long long b[12];
     { unsigned long long* pin = pinned_words();
       check(hipMemcpyAsync(pin ? pin : b, t.bounds, sizeof(b), hipMemcpyDeviceToHost, hs), "hipMemcpyAsync");
       check(hipStreamSynchronize(hs), "hipStreamSynchronize");
       if (pin) memcpy(b, pin, sizeof(b)); }
+    if (maxP) *maxP = uint32(b[9]);
+    if (maxT) *maxT = uint32(b[11]);
     if (b[1] == 0ull || b[4] != b[5]) return false;
     if (b[3] == 0ull) { b[2] = 0ull; b[3] = 1ull; }
     const uint32 per = 32u / where_type::BITS;
@@ -786,6 +800,12 @@ private:
 #if defined(__HIPCC__)
         const uint32 n = stream.size();
         if (n == 0) return;
+#if defined(NVBIO_HIP_COMPAT_TUNED)
+        // nvBowtie's streams: the description pass of the view route measures the batch's lengths on its way, so the pass (and the host
+        // round trip) limits_scope would spend on them is not run; anything the view route declines goes the usual way below
+        if constexpr (priv::recognised<stream_type>::value && priv::recognised<stream_type>::view && priv::tuned_band<BAND_LEN>::value)
+            if (!priv::forced_generic("banded") && run_views(stream, hs)) return;
+#endif
         const priv::limits_scope<stream_type> limits(stream, hs);
         if (!priv::limits_scope<stream_type>::trusted && priv::maxP_of(stream) == 0u) { m_path = "empty"; return; }
         if (priv::forced_generic("banded")) { run_device(stream, hs, std::false_type()); return; }
@@ -814,6 +834,38 @@ private:
         priv::check(hipGetLastError(), "batched_banded_score_kernel");
         m_path = "generic";
     }
+#if defined(NVBIO_HIP_COMPAT_TUNED)
+    /// the view route on its own: the stored reads are scored through their views, in place, and the batch's lengths come out of the
+    /// description pass.  false: not taken (the scheme, the sink or the jobs' quality layout are outside it) -- nothing was output.
+    /// (NVBIO_HIP_COMPAT_NO_VIEWS=1 keeps the staged route, for timing the two side by side)
+    bool run_views(const stream_type& stream, hipStream_t hs)
+    {
+        if constexpr (priv::recognised<stream_type>::view)
+        {
+            const char* no_views = getenv("NVBIO_HIP_COMPAT_NO_VIEWS");
+            if (no_views && no_views[0] == '1') return false;
+            const uint32 n = stream.size();
+            priv::tuned_scheme<stream_type> scheme;
+            typedef decltype(typename stream_type::context_type().sink) sink_type;
+            if (!scheme.init(stream)) return false;
+            priv::job_table t; nvbio_hip_string_set ps, ts; const uint8* quals = NULL; uint64 n_quals = 0; const uint8* flags = NULL;
+            uint32 maxP = 0, maxT = 0;
+            const bool described = priv::build_view_table(stream, m_jobs, t, ps, ts, &quals, &n_quals, &flags, hs, &maxP, &maxT);
+            if (maxP == 0u) { m_path = "empty"; return true; }           // measured: no job has a valid context, nothing to score or output
+            if (!described || n_quals < 4u) return false;
+            const priv::known_limits_scope limits(stream, maxP, maxT);
+            if (!scheme.template sink_fits<sink_type>(stream)) return false;
+            const int err = nvbio_hip_banded_gotoh_score_qual_views(&scheme.q, int32(stream_type::aligner_type::TYPE), BAND_LEN, &ps, quals, n_quals, flags, &ts,
+                                                                    maxP, maxT, n, t.score, t.sink, hs);
+            priv::check(err, "nvbio_hip_banded_gotoh_score_qual_views");
+            hipLaunchKernelGGL((priv::output_jobs_kernel<stream_type>), dim3((n + 127u) / 128u), dim3(128), 0, hs, stream, t);
+            priv::check(hipGetLastError(), "output_jobs_kernel");
+            m_path = "tuned-views";
+            return true;
+        }
+        else return false;
+    }
+#endif
     void run_device(const stream_type& stream, hipStream_t hs, std::true_type)
     {
 #if defined(NVBIO_HIP_COMPAT_TUNED)
@@ -822,23 +874,6 @@ private:
         typedef decltype(typename stream_type::context_type().sink) sink_type;
         if (!scheme.init(stream) || !scheme.template sink_fits<sink_type>(stream)) { run_device(stream, hs, std::false_type()); return; }
         priv::job_table t; nvbio_hip_string_set ps, ts; const uint8* quals = NULL; uint64 n_quals = 0;
-        if constexpr (priv::recognised<stream_type>::view)
-        {
-            // nvBowtie's streams: the stored reads are scored through their views, in place
-            // (NVBIO_HIP_COMPAT_NO_VIEWS=1 keeps the staged route, for timing the two side by side)
-            const uint8* flags = NULL;
-            const char* no_views = getenv("NVBIO_HIP_COMPAT_NO_VIEWS");
-            if (!(no_views && no_views[0] == '1') && priv::build_view_table(stream, m_jobs, t, ps, ts, &quals, &n_quals, &flags, hs) && n_quals >= 4u)
-            {
-                const int err = nvbio_hip_banded_gotoh_score_qual_views(&scheme.q, int32(stream_type::aligner_type::TYPE), BAND_LEN, &ps, quals, n_quals, flags, &ts,
-                                                                        priv::maxP_of(stream), priv::maxT_of(stream), n, t.score, t.sink, hs);
-                priv::check(err, "nvbio_hip_banded_gotoh_score_qual_views");
-                hipLaunchKernelGGL((priv::output_jobs_kernel<stream_type>), dim3((n + 127u) / 128u), dim3(128), 0, hs, stream, t);
-                priv::check(hipGetLastError(), "output_jobs_kernel");
-                m_path = "tuned-views";
-                return;
-            }
-        }
         priv::build_job_table(stream, m_jobs, t, ps, ts, hs, 0u, NULL, &quals, &n_quals);
         if (ts.words == NULL || ps.words == NULL) { run_device(stream, hs, std::false_type()); return; }      // no job with a text: nothing for the tuned kernels to read
         const int err = scheme.banded_score(BAND_LEN, stream, t, ps, ts, quals, n_quals, hs);

@@ -6,6 +6,7 @@
 #pragma once
 #include "output_file.h"
 #include "output_batch.h"
+#include "output_writer.h"
 #include "../../basic/threads.h"
 #include "../../basic/timer.h"
 #include "../../basic/dna.h"
@@ -80,8 +81,9 @@ struct SamOutput : public OutputFile
         fp = _file_name ? fopen(_file_name, "wt") : stdout;
         if (fp == NULL) { log_error(stderr, "SamOutput: could not open %s for writing\n", _file_name); return; }
         if (_file_name) setvbuf(fp, NULL, _IOFBF, 1u << 20);
+        writer.open(fp);
     }
-    ~SamOutput() { if (fp && fp != stdout) fclose(fp); }
+    ~SamOutput() { close(); }
 
     void header()
     {
@@ -90,17 +92,18 @@ struct SamOutput : public OutputFile
         h += "@PG\tID:" + pg_id + "\tPN:" + pg_name + "\tVN:" + pg_version + "\tCL:\"" + pg_args + "\"\n";
         for (uint32 i = 0; i < bnt.n_seqs; ++i)
             h += std::string("@SQ\tSN:") + (bnt.names + bnt.names_index[i]) + "\tLN:" + std::to_string(bnt.sequence_index[i + 1] - bnt.sequence_index[i]) + "\n";
-        fwrite(h.data(), 1, h.size(), fp);
+        ScopedLock hold(&mutex);
+        writer.drain();
+        if (fp) fwrite(h.data(), 1, h.size(), fp);
     }
     void process(struct HostOutputBatchSE& batch)
     {
-        float seconds = 0.0f;
+        Timer timer; timer.start();
         {
-            ScopedTimer<float> timer(&seconds);
             ScopedLock hold(&mutex);
-            // the records of a batch are independent: every OpenMP thread formats a contiguous share, the shares are written in order
-            const size_t n_threads = size_t(usable_omp_threads());
-            std::vector<std::string> text(n_threads);
+            // the records of a batch are independent: every OpenMP thread formats a contiguous share; the shares go to the file in order, on
+            // the writer's thread (output_writer.h), while the caller is back at its device
+            priv::OrderedFileWriter::chunk_list text = writer.take(size_t(usable_omp_threads()));
             #pragma omp parallel num_threads(int(text.size()))
             {
                 const uint32 t = uint32(omp_get_thread_num()), nt = uint32(omp_get_num_threads());
@@ -108,19 +111,21 @@ struct SamOutput : public OutputFile
                 text[t].reserve(size_t(hi - lo) * 320u);
                 for (uint32 c = lo; c < hi; ++c) record(get(batch, c), AlignmentData::invalid(), text[t]);
             }
-            for (size_t t = 0; t < text.size(); ++t) fwrite(text[t].data(), 1, text[t].size(), fp);
+            timer.stop();
+            const float format_seconds = timer.seconds();
+            timer.start();
+            writer.push(std::move(text), format_seconds);
+            timer.stop();
+            iostats.n_reads += batch.count;
+            iostats.output_process_timings.add(batch.count, format_seconds + timer.seconds());
         }
-        iostats.n_reads += batch.count;
-        iostats.output_process_timings.add(batch.count, seconds);
     }
     void process(struct HostOutputBatchPE& batch)
     {
-        float seconds = 0.0f;
+        Timer timer; timer.start();
         {
-            ScopedTimer<float> timer(&seconds);
             ScopedLock hold(&mutex);
-            const size_t n_threads = size_t(usable_omp_threads());
-            std::vector<std::string> text(n_threads);
+            priv::OrderedFileWriter::chunk_list text = writer.take(size_t(usable_omp_threads()));
             #pragma omp parallel num_threads(int(text.size()))
             {
                 const uint32 t = uint32(omp_get_thread_num()), nt = uint32(omp_get_num_threads());
@@ -133,73 +138,90 @@ struct SamOutput : public OutputFile
                     record(opposite, anchor, text[t]);
                 }
             }
-            for (size_t t = 0; t < text.size(); ++t) fwrite(text[t].data(), 1, text[t].size(), fp);
+            timer.stop();
+            const float format_seconds = timer.seconds();
+            timer.start();
+            writer.push(std::move(text), format_seconds);
+            timer.stop();
+            iostats.n_reads += batch.count;
+            iostats.output_process_timings.add(batch.count, format_seconds + timer.seconds());
         }
-        iostats.n_reads += batch.count;
-        iostats.output_process_timings.add(batch.count, seconds);
     }
-    void close(void) { if (fp && fp != stdout) fclose(fp); fp = NULL; }
+    void close(void)
+    {
+        ScopedLock hold(&mutex);
+        writer.finish();                                  // everything handed over is in the file before it is closed
+        if (fp && fp != stdout) fclose(fp); else if (fp) fflush(fp);
+        fp = NULL; writer.open(NULL);
+    }
 
 private:
     uint32 sequence_of(const uint32 pos) const { return uint32(std::upper_bound(bnt.sequence_index, bnt.sequence_index + bnt.n_seqs, pos) - bnt.sequence_index) - 1u; }
 
-    /// decimal text without a temporary string
-    static void put(std::string& o, uint32 v) { char b[12]; int n = 0; do { b[n++] = char('0' + v % 10u); v /= 10u; } while (v); while (n) o.push_back(b[--n]); }
-    static void put(std::string& o, const int32 v) { if (v < 0) { o.push_back('-'); put(o, uint32(-int64(v))); } else put(o, uint32(v)); }
+    // text through a pointer into room the caller asked the buffer for: decimal numbers, strings, single characters
+    static char* put(char* p, uint32 v) { char b[12]; int n = 0; do { b[n++] = char('0' + v % 10u); v /= 10u; } while (v); while (n) *p++ = b[--n]; return p; }
+    static char* put(char* p, const int32 v) { if (v < 0) { *p++ = '-'; return put(p, uint32(-int64(v))); } return put(p, uint32(v)); }
+    static char* put(char* p, const char* s) { const size_t n = strlen(s); memcpy(p, s, n); return p + n; }
+    static char* tab(char* p) { *p++ = '\t'; return p; }
 
-    /// "3M1D7M" from the stored (reversed) operation list; returns the read bases it consumes
-    static uint32 cigar_text(const AlignmentData& a, std::string& out)
+    /// read bases an alignment's CIGAR consumes
+    static uint32 cigar_read_length(const AlignmentData& a)
     {
         uint32 consumed = 0;
-        for (uint32 i = a.cigar_len; i-- > 0;)
-        {
-            const Cigar& op = a.cigar[i];
-            put(out, uint32(op.m_len)); out += "MIDS"[op.m_type];
-            if (op.m_type != Cigar::DELETION) consumed += op.m_len;
-        }
+        for (uint32 i = 0; i < a.cigar_len; ++i) if (a.cigar[i].m_type != Cigar::DELETION) consumed += a.cigar[i].m_len;
         return consumed;
     }
-    /// the MD:Z value and the mismatch / gap-open / gap-extension counts of an MD program (match runs are summed as bytes, like the reference's counter)
-    static void md_text(const AlignmentData& a, std::string& md, uint32& mm, uint32& gapo, uint32& gape)
+    /// "3M1D7M" from the stored (reversed) operation list: at most 6 characters per operation
+    static char* cigar_text(const AlignmentData& a, char* p)
+    {
+        for (uint32 i = a.cigar_len; i-- > 0;) { const Cigar& op = a.cigar[i]; p = put(p, uint32(op.m_len)); *p++ = "MIDS"[op.m_type]; }
+        return p;
+    }
+    /// bytes of an MD program (0 when there is none)
+    static uint32 md_program_bytes(const AlignmentData& a) { return a.mds_vec ? (uint32(a.mds_vec[0]) | (uint32(a.mds_vec[1]) << 8)) : 0u; }
+    /// the MD:Z value and the mismatch / gap-open / gap-extension counts of an MD program (match runs are summed as bytes, like the reference's
+    /// counter); the text takes at most 2 characters per program byte
+    static char* md_text(const AlignmentData& a, char* p, uint32& mm, uint32& gapo, uint32& gape)
     {
         mm = gapo = gape = 0;
-        if (a.mds_vec == NULL) { log_warning(stderr, "  SAM: alignment %u from read %u has an empty MD string\n", a.aln_id, a.read_id); return; }
-        const uint8* p = a.mds_vec;
-        const uint32 end = uint32(p[0]) | (uint32(p[1]) << 8);
+        if (a.mds_vec == NULL) { log_warning(stderr, "  SAM: alignment %u from read %u has an empty MD string\n", a.aln_id, a.read_id); return p; }
+        const uint8* m = a.mds_vec;
+        const uint32 end = uint32(m[0]) | (uint32(m[1]) << 8);
         uint32 i = 2;
         do
         {
-            const uint8 op = p[i++];
-            if (op == MDS_MATCH)         { uint8 run = p[i++]; while (i < end && p[i] == MDS_MATCH) run = uint8(run + p[i++]); put(md, uint32(run)); }
-            else if (op == MDS_MISMATCH) { md += dna_to_char(p[i++]); ++mm; }
-            else if (op == MDS_INSERTION){ const uint8 l = p[i++]; i += l; ++gapo; gape += l - 1u; }
-            else if (op == MDS_DELETION) { const uint8 l = p[i++]; md += '^'; for (uint8 k = 0; k < l; ++k) md += dna_to_char(p[i++]); md += '0'; ++gapo; gape += l - 1u; }
+            const uint8 op = m[i++];
+            if (op == MDS_MATCH)         { uint8 run = m[i++]; while (i < end && m[i] == MDS_MATCH) run = uint8(run + m[i++]); p = put(p, uint32(run)); }
+            else if (op == MDS_MISMATCH) { *p++ = dna_to_char(m[i++]); ++mm; }
+            else if (op == MDS_INSERTION){ const uint8 l = m[i++]; i += l; ++gapo; gape += l - 1u; }
+            else if (op == MDS_DELETION) { const uint8 l = m[i++]; *p++ = '^'; for (uint8 k = 0; k < l; ++k) *p++ = dna_to_char(m[i++]); *p++ = '0'; ++gapo; gape += l - 1u; }
         } while (i < end);
+        return p;
+    }
+    /// the read as the file had it (or its reverse complement), a tab, its qualities: 2 * read_len + 1 characters
+    static char* read_text(const AlignmentData& a, const bool rc, char* seq)
+    {
+        // (4-bit codes: 0..3 = ACGT, anything else prints as N; the complement of N is N)
+        static const char fw_text[17] = "ACGTNNNNNNNNNNNN", rc_text[17] = "TGCANNNNNNNNNNNN";
+        const uint32 n = a.read_len;
+        char* qual = seq + n + 1u;
+        if (rc) for (uint32 i = 0; i < n; ++i) { seq[i] = rc_text[a.read_data[i] & 15u];          qual[i] = char(a.qual[i] + 33); }
+        else    for (uint32 i = 0; i < n; ++i) { seq[i] = fw_text[a.read_data[n - 1u - i] & 15u]; qual[i] = char(a.qual[n - 1u - i] + 33); }
+        seq[n] = '\t';
+        return qual + n;
     }
     /// append the SAM line of `a` (whose mate, for pairs, is `mate`)
-    void record(const AlignmentData& a, const AlignmentData& mate, std::string& out)
+    void record(const AlignmentData& a, const AlignmentData& mate, priv::TextBuffer& out)
     {
-        // the read as the file had it (or its reverse complement), and its qualities, as text
-        const bool rc = a.aln->is_rc();
-        auto put_read = [&](std::string& o)
-        {
-            const size_t at = o.size();
-            o.resize(at + 2u * size_t(a.read_len) + 1u);
-            char* seq = &o[at]; char* qual = seq + a.read_len + 1u;
-            for (uint32 i = 0; i < a.read_len; ++i)
-            {
-                const uint32 src = rc ? i : a.read_len - 1u - i;
-                const uint8 s = a.read_data[src];
-                seq[i]  = dna_to_char(rc ? (s < 4 ? uint8(3u - s) : uint8(4)) : s);
-                qual[i] = char(a.qual[src] + 33);
-            }
-            seq[a.read_len] = '\t';
-        };
+        const bool   rc = a.aln->is_rc();
+        const size_t name_len = strlen(a.read_name);
         uint32 mapq = a.mapq;
-        out += a.read_name;
         if (!(a.aln->is_aligned() || int(mapq) < mapq_filter))
         {
-            out += "\t4\t*\t0\t0\t*\t*\t0\t0\t"; put_read(out); out += '\n';
+            char* p = out.room(name_len + 2u * size_t(a.read_len) + 32u);
+            memcpy(p, a.read_name, name_len); p += name_len;
+            p = put(p, "\t4\t*\t0\t0\t*\t*\t0\t0\t"); p = read_text(a, rc, p); *p++ = '\n';
+            out.commit(p);
             return;
         }
         uint32 flags = (a.aln->mate() ? SAM_FLAGS_READ_2 : SAM_FLAGS_READ_1) | (rc ? SAM_FLAGS_REVERSE : 0u);
@@ -212,11 +234,9 @@ private:
         }
         const uint32 span = reference_cigar_length(a.cigar, a.cigar_len), seq_id = sequence_of(a.cigar_pos);
         if (a.cigar_pos + span > bnt.sequence_index[seq_id + 1]) { flags |= SAM_FLAGS_UNMAPPED; mapq = 0; }       // bridges two reference sequences
-        std::string cigar;
-        if (cigar_text(a, cigar) != a.read_len)
+        if (cigar_read_length(a) != a.read_len)
         {
             log_error(stderr, "SAM output : cigar length doesn't match read %u\n", a.read_id);
-            out.resize(out.size() - strlen(a.read_name));
             return;
         }
         const char* rnext = "*"; uint32 pnext = 0; int32 tlen = 0;
@@ -235,28 +255,41 @@ private:
                 }
             }
         }
-        std::string md; uint32 mm, gapo, gape;
-        md_text(a, md, mm, gapo, gape);
-        out += '\t'; put(out, flags);
-        out += '\t'; out += bnt.names + bnt.names_index[seq_id];
-        out += '\t'; put(out, uint32(a.cigar_pos - bnt.sequence_index[seq_id] + 1u));
-        out += '\t'; put(out, mapq);
-        out += '\t'; out += cigar;
-        out += '\t'; out += rnext;
-        out += '\t'; put(out, pnext);
-        out += '\t'; put(out, tlen);
-        out += '\t'; put_read(out);
-        out += "\tNM:i:"; put(out, uint32(a.aln->ed()));
-        out += "\tAS:i:"; put(out, int32(a.aln->score()));
-        out += "\tXM:i:"; put(out, mm);
-        out += "\tXO:i:"; put(out, gapo);
-        out += "\tXG:i:"; put(out, gape);
-        out += "\tMD:Z:"; out += md.empty() ? std::string("*") : md;
-        out += '\n';
+        const char*  ref_name = bnt.names + bnt.names_index[seq_id];
+        // the longest this line can get: the names, 6 characters per CIGAR operation, the read twice, 2 per MD program byte, the fixed fields
+        char* p = out.room(name_len + strlen(ref_name) + strlen(rnext) + 6u * size_t(a.cigar_len) + 2u * size_t(a.read_len) + 2u * size_t(md_program_bytes(a)) + 160u);
+        memcpy(p, a.read_name, name_len); p += name_len;
+        p = tab(p); p = put(p, flags);
+        p = tab(p); p = put(p, ref_name);
+        p = tab(p); p = put(p, uint32(a.cigar_pos - bnt.sequence_index[seq_id] + 1u));
+        p = tab(p); p = put(p, mapq);
+        p = tab(p); p = cigar_text(a, p);
+        p = tab(p); p = put(p, rnext);
+        p = tab(p); p = put(p, pnext);
+        p = tab(p); p = put(p, tlen);
+        p = tab(p); p = read_text(a, rc, p);
+        p = put(p, "\tNM:i:"); p = put(p, uint32(a.aln->ed()));
+        p = put(p, "\tAS:i:"); p = put(p, int32(a.aln->score()));
+        // the MD text is written where it goes; the counters it yields are printed in front of it
+        char  md_buf[64];
+        const uint32 md_room = 2u * md_program_bytes(a) + 2u;
+        std::vector<char> md_big;
+        char* md = md_buf;
+        if (md_room > sizeof(md_buf)) { md_big.resize(md_room); md = md_big.data(); }
+        uint32 mm, gapo, gape;
+        const char* md_end = md_text(a, md, mm, gapo, gape);
+        p = put(p, "\tXM:i:"); p = put(p, mm);
+        p = put(p, "\tXO:i:"); p = put(p, gapo);
+        p = put(p, "\tXG:i:"); p = put(p, gape);
+        p = put(p, "\tMD:Z:");
+        if (md_end == md) *p++ = '*'; else { memcpy(p, md, size_t(md_end - md)); p += md_end - md; }
+        *p++ = '\n';
+        out.commit(p);
     }
 
     FILE* fp;
     Mutex mutex;
+    priv::OrderedFileWriter writer;
 };
 
 } // namespace io

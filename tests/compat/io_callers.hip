@@ -81,17 +81,20 @@ API int write_alignments(const WriteArgs* a)
     if (out == NULL) return 1;
     out->set_program("id", "test", "0.1", "args");
     out->header();
+    // (a timing aid: NVBIO_IO_CALLERS_REPEAT=k hands the same batch to the writer k times)
+    const char* rep_env = getenv("NVBIO_IO_CALLERS_REPEAT");
+    const int   repeat  = rep_env ? std::max(atoi(rep_env), 1) : 1;
     if (a->paired)
     {
         io::HostOutputBatchPE batch; batch.count = a->n; batch.read_data[0] = &reads[0]; batch.read_data[1] = &reads[1];
         for (uint32 s = 0; s < 2u; ++s) fill(a->slots[s], a->n, batch.alignments[s], batch.cigar[s], batch.mds[s], batch.mapq[s]);
-        out->process(batch);
+        for (int r = 0; r < repeat; ++r) out->process(batch);
     }
     else
     {
         io::HostOutputBatchSE batch; batch.count = a->n; batch.read_data = &reads[0];
         fill(a->slots[0], a->n, batch.alignments, batch.cigar, batch.mds, batch.mapq);
-        out->process(batch);
+        for (int r = 0; r < repeat; ++r) out->process(batch);
     }
     out->close();
     delete out;
