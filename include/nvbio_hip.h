@@ -897,6 +897,12 @@ int nvbio_hip_device_mem_info(uint64_t* free_bytes, uint64_t* total_bytes, uint6
 int nvbio_hip_memcpy(void* dst, const void* src, uint64_t bytes, int kind, void* stream);
 int nvbio_hip_memset(void* dst, int value, uint64_t bytes, void* stream);
 int nvbio_hip_stream_synchronize(void* stream);
+int nvbio_hip_stream_query(void* stream);         /* hipStreamQuery: 0 = everything queued so far has finished, 600 (hipErrorNotReady) = not yet */
+/* Pinned host memory the device writes to through the same pointer (hipHostMalloc): where a kernel leaves the few words its host thread is
+ * waiting for -- the sizes of a selection round's queues (include/nvbio_hip/select.h) -- so that the thread reads them as they land instead of
+ * going through a stream synchronisation and a copy per round. */
+int nvbio_hip_host_malloc(void** ptr, uint64_t bytes);
+int nvbio_hip_host_free(void* ptr);
 
 /* Streams.  The reference runs one host thread per device on its default stream (nvBowtie.cpp:809-864, compute_thread.cu:74-117).
  * Every nvbio_hip_* entry takes the stream its work is queued on, so a driver object per host thread, each on its own non-blocking

@@ -55,12 +55,13 @@ struct ScoringQueues
 {
     ScoringQueues(const uint32 max_reads, const uint32 max_hits) :
         active_in(max_reads), active_out(max_reads), hit_begin(size_t(max_reads) + 1u), hit_read_id(max_hits), hit_loc(max_hits), hit_seed(max_hits),
-        sizes(2), in_size(0), hits_size(0) {}
+        sizes(2), host_sizes(2), in_size(0), hits_size(0) {}
     hip::device_vector<packed_read> active_in, active_out;
     hip::device_vector<uint64>      hit_begin;
     hip::device_vector<uint32>      hit_read_id, hit_loc;
     hip::device_vector<packed_seed> hit_seed;
     hip::device_vector<uint32>      sizes;
+    hip::pinned_words               host_sizes;       ///< where select() has the device leave a round's (in_size, hits_size) for the waiting host thread
     uint32 in_size, hits_size;
     void swap() { std::swap(active_in.m_ptr, active_out.m_ptr); std::swap(active_in.m_size, active_out.m_size); }
 };
@@ -89,13 +90,21 @@ inline void select(SeedHitDequeArrayDeviceView hits, SelectState& state, Scoring
 {
     const uint64 temp_bytes = nvbio_hip_select_temp_bytes(queues.in_size, n_hits_per_read);
     hip::device_vector<uint8> temp(temp_bytes);
+    // The two sizes decide what the host queues next.  The kernels leave them in pinned host memory and the host thread reads them as they
+    // land (hip::pinned_words): a round then costs no stream synchronisation and no copy, only the wait for the round's last kernel.  What
+    // the host queues next is ordered behind that kernel on the same stream, so nothing is read early.  NVBIO_HIP_POLL_SIZES=0 (read once)
+    // keeps the synchronise-and-copy form.
+    static const bool poll = [] { const char* e = getenv("NVBIO_HIP_POLL_SIZES"); return !(e && atoi(e) == 0); }();
+    const bool polled = poll && queues.host_sizes.ptr != nullptr;
+    if (polled) queues.host_sizes.arm();
     hip_check(nvbio_hip_select(params.randomized ? 1 : 0, n_hits_per_read, reinterpret_cast<const uint32*>(queues.active_in.data()), queues.in_size,
                                reinterpret_cast<uint64*>(hits.hits), hits.stride, hits.counts, state.probs.data(), state.probs_stride,
                                state.rseeds.data(), state.trys.data(), reinterpret_cast<uint32*>(queues.active_out.data()), queues.hit_begin.data(),
                                queues.hit_read_id.data(), queues.hit_loc.data(), reinterpret_cast<uint32*>(queues.hit_seed.data()),
-                               queues.sizes.data(), temp.data(), temp_bytes, hip_stream), "nvbio_hip_select");
-    hip_check(nvbio_hip_stream_synchronize(hip_stream), "nvbio_hip_stream_synchronize");
-    const std::vector<uint32> s = queues.sizes.to_host(hip_stream);
+                               polled ? const_cast<uint32*>(queues.host_sizes.ptr) : queues.sizes.data(), temp.data(), temp_bytes, hip_stream), "nvbio_hip_select");
+    uint32 s[2];
+    if (polled) { queues.host_sizes.wait_words(2u, hip_stream); s[0] = queues.host_sizes.ptr[0]; s[1] = queues.host_sizes.ptr[1]; }
+    else        { const std::vector<uint32> h = queues.sizes.to_host(hip_stream); s[0] = h[0]; s[1] = h[1]; }
     queues.swap();
     queues.in_size = s[0]; queues.hits_size = s[1];
 }

@@ -148,5 +148,49 @@ struct device_vector {
 
 inline void synchronize(void* stream = nullptr) { hip_check(nvbio_hip_stream_synchronize(stream), "nvbio_hip_stream_synchronize"); }
 
+/// A few words of pinned host memory a kernel writes through the same pointer: where a host thread waits for the handful of numbers that
+/// decide what it queues next (the sizes of a selection round's queues) without a stream synchronisation and a copy per round.
+/// wait_words(n): arm() set the words to a value no result takes; spin until the kernel has overwritten the first n -- looking at the
+/// stream now and then, so that a failed launch ends in an exception rather than a spin.  If the memory cannot be had (ptr == nullptr) the
+/// caller falls back to synchronise-and-copy.
+struct pinned_words
+{
+    static const uint32 unset = 0xFFFFFFFFu;
+    explicit pinned_words(const uint32 n) : ptr(nullptr), count(n)
+    {
+        void* p = nullptr;
+        if (nvbio_hip_host_malloc(&p, uint64(n) * 4u) == 0) ptr = static_cast<volatile uint32*>(p);
+    }
+    ~pinned_words() { if (ptr) nvbio_hip_host_free(const_cast<uint32*>(ptr)); }
+    pinned_words(const pinned_words&) = delete;
+    pinned_words& operator=(const pinned_words&) = delete;
+    void arm() { for (uint32 i = 0; i < count; ++i) ptr[i] = unset; }
+    void wait_words(const uint32 n, void* stream) const
+    {
+        for (uint64 spins = 1;; ++spins)
+        {
+            bool all = true;
+            for (uint32 i = 0; i < n; ++i) all = all && (ptr[i] != unset);
+            if (all) return;
+            if ((spins & 0xFFFFu) == 0u)
+            {
+                const int q = nvbio_hip_stream_query(stream);
+                if (q == 0)
+                {
+                    // the stream has drained: the words are there now, or the kernel never wrote them
+                    for (uint32 i = 0; i < n; ++i) if (ptr[i] == unset) throw std::runtime_error("pinned_words: the stream drained without the awaited words being written");
+                    return;
+                }
+                if (q != 600) hip_check(q, "nvbio_hip_stream_query");
+            }
+#if defined(__x86_64__) || defined(__i386__)
+            __builtin_ia32_pause();
+#endif
+        }
+    }
+    volatile uint32* ptr;
+    uint32           count;
+};
+
 } // namespace hip
 } // namespace nvbio

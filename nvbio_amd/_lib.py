@@ -29,7 +29,7 @@ SYMBOLS = [
     "nvbio_hip_fm_filter_temp_bytes", "nvbio_hip_fm_filter_rank", "nvbio_hip_fm_filter_locate",
     "nvbio_hip_build_bwt_occ_temp_bytes", "nvbio_hip_build_bwt_occ",
     "nvbio_hip_device_malloc", "nvbio_hip_device_free", "nvbio_hip_device_free_ordered", "nvbio_hip_device_free_after", "nvbio_hip_device_trim", "nvbio_hip_device_mem_info", "nvbio_hip_memcpy", "nvbio_hip_memset",
-    "nvbio_hip_stream_synchronize", "nvbio_hip_stream_create", "nvbio_hip_stream_destroy",
+    "nvbio_hip_stream_synchronize", "nvbio_hip_stream_query", "nvbio_hip_host_malloc", "nvbio_hip_host_free", "nvbio_hip_stream_create", "nvbio_hip_stream_destroy",
     "nvbio_hip_comm_available", "nvbio_hip_device_count", "nvbio_hip_set_device", "nvbio_hip_get_device", "nvbio_hip_comm_unique_id", "nvbio_hip_comm_init_rank",
     "nvbio_hip_comm_init_all", "nvbio_hip_comm_destroy", "nvbio_hip_comm_rank", "nvbio_hip_gather_records", "nvbio_hip_comm_abort", "nvbio_hip_comm_set_transport",
     "nvbio_hip_abi_version", "nvbio_hip_arch", "nvbio_hip_last_kernel", "nvbio_hip_set_test_switch", "nvbio_hip_get_test_switch", "nvbio_hip_test_switch_name",

@@ -614,6 +614,19 @@ NVB_API int nvbio_hip_memcpy(void* dst, const void* src, uint64_t bytes, int kin
 }
 NVB_API int nvbio_hip_memset(void* dst, int value, uint64_t bytes, void* stream) { return bytes ? hipMemsetAsync(dst, value, bytes, nvb::to_stream(stream)) : hipSuccess; }
 NVB_API int nvbio_hip_stream_synchronize(void* stream) { return hipStreamSynchronize(nvb::to_stream(stream)); }
+NVB_API int nvbio_hip_stream_query(void* stream)
+{
+    const hipError_t e = hipStreamQuery(nvb::to_stream(stream));
+    if (e == hipErrorNotReady) (void)hipGetLastError();          // "not yet" is an answer, not a sticky error
+    return e;
+}
+NVB_API int nvbio_hip_host_malloc(void** ptr, uint64_t bytes)
+{
+    if (!ptr) return hipErrorInvalidValue;
+    *ptr = nullptr;
+    return hipHostMalloc(ptr, bytes ? bytes : 1u, hipHostMallocDefault);
+}
+NVB_API int nvbio_hip_host_free(void* ptr) { return ptr ? hipHostFree(ptr) : hipSuccess; }
 
 NVB_API int         nvbio_hip_abi_version(void) { return NVBIO_HIP_ABI_VERSION; }
 NVB_API const char* nvbio_hip_arch(void)        { return "gfx950"; }
