@@ -4,7 +4,8 @@
 // process() is called by an aligner's compute thread between two batches of device work; what it needs from that thread is the
 // formatting (it reads the batch and the reads, both of which the caller overwrites right after).  The write() calls that follow only need
 // the text.  OrderedFileWriter takes the text of a batch and writes it to the file in the order the batches were handed over while the
-// caller is back at its device; at most `depth` batches wait, so the memory held is bounded and a slow disk still throttles the aligner.
+// caller is back at its device; at most `depth` batches wait (one: a batch's write is far shorter than its alignment, and every further
+// set of buffers is 300 MB of first-touch page faults), so the memory held is bounded and a slow disk still throttles the aligner.
 // The text lives in TextBuffers -- plain growable runs of bytes a formatter asks for room in once per record and then writes through a
 // pointer -- which the writer hands back when their bytes are in the file, so a batch is formatted into memory the previous batches
 // already touched (a fresh 200 MB of std::string per batch spent more time in page faults than in formatting).
@@ -61,7 +62,7 @@ class OrderedFileWriter
 public:
     typedef std::vector<TextBuffer> chunk_list;      ///< the text of one batch, in file order
 
-    OrderedFileWriter() : m_fp(NULL), m_depth(2u), m_in_flight(0u), m_stop(false), m_failed(false), m_started(false),
+    OrderedFileWriter() : m_fp(NULL), m_depth(1u), m_in_flight(0u), m_stop(false), m_failed(false), m_started(false),
                           m_batches(0u), m_bytes(0u), m_format_s(0.0), m_wait_s(0.0), m_write_s(0.0)
     {
         const char* s = getenv("NVBIO_HIP_SYNC_OUTPUT");  m_async = !(s && atoi(s) == 1);
