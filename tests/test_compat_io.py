@@ -188,3 +188,39 @@ def test_paired_end_mate_fields_sam_and_bam(lib, tmp_path):
             continue
         assert b["flag"] == int(f[1]) and names[b["ref"]] == f[2] and b["pos"] == int(f[3]) and b["cigar"] == f[5]
         assert names[b["next_ref"]] == (f[2] if f[6] == "=" else f[6]) and b["pnext"] == int(f[7]) and b["tlen"] == int(f[8])
+
+
+def test_sam_writer_thread_and_recycled_buffers(lib, tmp_path, monkeypatch):
+    """SamOutput hands a batch's text to a writer thread and formats the next batch into the buffers the previous one was written from
+    (compat/nvbio/io/output/output_writer.h): several batches through one file come out in order, byte for byte what the writes inside
+    process() (NVBIO_HIP_SYNC_OUTPUT=1) give, single-end and paired, also when a batch is larger than the buffers the first one left."""
+    rng = np.random.default_rng(92)
+    n = 700
+    reads = make_reads(rng, n, "read")
+    arr, _ = make_slot(rng, n, [0] * n, paired=False)
+    preads = [make_reads(rng, n, "pair"), make_reads(rng, n, "pair")]
+    anchor_mate = rng.integers(0, 2, n)
+    a0, _ = make_slot(rng, n, list(anchor_mate), paired=True)
+    a1, _ = make_slot(rng, n, list(1 - anchor_mate), paired=True)
+
+    def body(path):
+        text = open(path, "rb").read().split(b"\n")
+        return [ln for ln in text if ln and not ln.startswith(b"@")]
+
+    for paired, rd, slots in ((False, [reads], [arr]), (True, preads, [a0, a1])):
+        per_batch = n * (2 if paired else 1)
+        monkeypatch.delenv("NVBIO_IO_CALLERS_REPEAT", raising=False)
+        monkeypatch.setenv("NVBIO_HIP_SYNC_OUTPUT", "1")
+        one = tmp_path / ("one%d.sam" % paired)
+        run(lib, one, paired, n, rd, slots)
+        want = body(one)
+        assert len(want) == per_batch
+        for sync in ("1", "0"):
+            monkeypatch.setenv("NVBIO_HIP_SYNC_OUTPUT", sync)
+            monkeypatch.setenv("NVBIO_IO_CALLERS_REPEAT", "5")
+            many = tmp_path / ("many%d_%s.sam" % (paired, sync))
+            run(lib, many, paired, n, rd, slots)
+            got = body(many)
+            assert len(got) == 5 * per_batch
+            for k in range(5):
+                assert got[k * per_batch:(k + 1) * per_batch] == want, (paired, sync, k)
