@@ -263,14 +263,16 @@ inline bool write_records(FILE* f, const Batch& batch, Record record)
 #endif
     const uint32_t chunk = 16384u;
     bool ok = true;
+    // the threads' buffers live for the whole call: a fresh 5 MB string per thread and step is a fresh mapping whose pages fault in again
+    std::vector<std::string> bufs; bufs.resize(size_t(n_threads));
     for (uint64_t base = 0; base < batch.n && ok; base += uint64_t(chunk) * uint64_t(n_threads))
     {
-        std::vector<std::string> bufs; bufs.resize(size_t(n_threads));
         #pragma omp parallel for schedule(static, 1) num_threads(n_threads)
         for (int t = 0; t < n_threads; ++t)
         {
             const uint64_t lo = base + uint64_t(t) * chunk, hi = std::min<uint64_t>(lo + chunk, batch.n);
             std::string md;
+            bufs[size_t(t)].clear();
             bufs[size_t(t)].reserve(size_t(chunk) * 320u);
             for (uint64_t i = lo; i < hi; ++i) record(uint32_t(i), bufs[size_t(t)], md);
         }
