@@ -961,3 +961,14 @@ def test_cxx_paired_driver_takes_mates_of_their_own_lengths(cuda):
         assert (out["mds_len"][slot] == e[md + "_len"].cpu().numpy().view(np.uint32)).all(), md
     paired = ((u64(e["best"])[0] >> np.uint64(30)) & np.uint64(1)) != 0
     assert paired.mean() > 0.7
+
+
+def test_cxx_drivers_with_the_round_sizes_copied_instead_of_read_as_they_land(cuda):
+    """select() (include/nvbio_hip/select.h) has the device leave a round's queue sizes in pinned host memory and reads them there; the switch is
+    read once per process, so the synchronise-and-copy form (NVBIO_HIP_POLL_SIZES=0) runs the C++ drivers' oracle tests in a process of its own."""
+    import subprocess
+    env = dict(os.environ, NVBIO_HIP_POLL_SIZES="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "test_cxx_aligner_driver_matches_oracle or test_cxx_paired_aligner_driver_matches_oracle"],
+                       env=env, capture_output=True, text=True, timeout=1500, cwd=os.path.dirname(HERE))
+    assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-3000:], r.stderr[-1000:])
