@@ -156,12 +156,22 @@ inline void synchronize(void* stream = nullptr) { hip_check(nvbio_hip_stream_syn
 struct pinned_words
 {
     static const uint32 unset = 0xFFFFFFFFu;
+    /// (a driver makes one of these per batch: the last one a thread gave up is kept for its next -- pinning and unpinning host memory are
+    /// not cheap calls, and the second may wait for the device; the one block a thread keeps is never handed back)
     explicit pinned_words(const uint32 n) : ptr(nullptr), count(n)
     {
+        spare_slot& sp = spare();
+        if (sp.ptr && sp.count >= n) { ptr = sp.ptr; sp.ptr = nullptr; return; }
         void* p = nullptr;
         if (nvbio_hip_host_malloc(&p, uint64(n) * 4u) == 0) ptr = static_cast<volatile uint32*>(p);
     }
-    ~pinned_words() { if (ptr) nvbio_hip_host_free(const_cast<uint32*>(ptr)); }
+    ~pinned_words()
+    {
+        if (!ptr) return;
+        spare_slot& sp = spare();
+        if (sp.ptr == nullptr) { sp.ptr = ptr; sp.count = count; }
+        else nvbio_hip_host_free(const_cast<uint32*>(ptr));
+    }
     pinned_words(const pinned_words&) = delete;
     pinned_words& operator=(const pinned_words&) = delete;
     void arm() { for (uint32 i = 0; i < count; ++i) ptr[i] = unset; }
@@ -190,6 +200,9 @@ struct pinned_words
     }
     volatile uint32* ptr;
     uint32           count;
+private:
+    struct spare_slot { volatile uint32* ptr; uint32 count; };
+    static spare_slot& spare() { static thread_local spare_slot s = { nullptr, 0u }; return s; }
 };
 
 } // namespace hip
