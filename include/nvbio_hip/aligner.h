@@ -40,6 +40,27 @@ struct Params : public ParamsPOD
     aln::SmithWatermanScoringScheme search_scheme(const aln::SmithWatermanScoringScheme& sw) const { return scoring_mode == EditDistanceMode ? aln::SmithWatermanScoringScheme::edit_distance() : sw; }
     ScoreLimits search_limits(const ScoreLimits& sw) const { return scoring_mode == EditDistanceMode ? ScoreLimits(0, SimpleFunc(SimpleFunc::LinearFunc, -float(max_dist), 0.0f)) : sw; }
 
+    /// Slots of a read's hit deque when the caller names none (hits_stride == 0).  The reference's deques hold max_hits (100) ranges
+    /// (seed_hit_deque_array.h); a read of length L yields at most one range per seed and strand under exact seeding -- 2 * ((L - seed_len) /
+    /// seed_freq(L) + 1): 14 at 100 bp, 28 at 150 bp with --local -- so a row of 16 or 32 slots holds every range the reference's would, and the
+    /// selection stage works on 128- or 256-byte rows with its tree in LDS instead of 100-slot rows with the tree in memory (select.hip).
+    /// With one-mismatch seeding (allow_sub) a seed can yield several ranges: the reference's capacity stands.
+    uint32 resolved_hits_stride(const uint32 max_read_len) const
+    {
+        if (hits_stride) return hits_stride;
+        const uint32 cap = std::min(max_hits, 128u);
+        if (allow_sub) return cap;
+        uint32 most = 0;
+        for (uint32 L = std::max(min_read_len, 1u); L <= max_read_len; ++L)
+        {
+            const int32 f = seed_freq(int32(L));
+            if (f <= 0) continue;
+            most = std::max(most, 2u * ((L - std::min(seed_len, L)) / uint32(f) + 1u));
+        }
+        const uint32 rows = most <= 16u ? 16u : most <= 32u ? 32u : most;
+        return std::min(cap, rows);
+    }
+
     /// switch between end-to-end and local alignment the way nvBowtie's option parser does (params.cpp:156-160): the alignment type
     /// also moves the seeding defaults -- 22-bp seeds every 1 + 1.15 sqrt(L) end-to-end, 20-bp seeds every 1 + 0.75 sqrt(L) local
     void set_alignment_type(const AlignmentTypeMode type)
@@ -206,7 +227,7 @@ private:
     {
         const uint32 count = reads.n, L = reads.len, B = SCORING_BATCH;
         const uint32 band_len = band_length(params.max_dist);
-        const uint32 hits_stride = params.hits_stride ? params.hits_stride : std::min(params.max_hits, 128u);
+        const uint32 hits_stride = params.resolved_hits_stride(L);
         // (Params::scoring_mode: hits scored and traced with the edit-distance aligner, finished with the caller's scheme -- see best_approx_t)
         const bool ed_mode = params.scoring_mode == EditDistanceMode;
         const aln::GotohAligner<TYPE, aln::SmithWatermanScoringScheme> aligner(params.search_scheme(scoring_scheme));
@@ -384,7 +405,7 @@ private:
     {
         const uint32 count = reads.n, L = reads.len;
         const uint32 band_len = band_length(params.max_dist);
-        const uint32 hits_stride = params.hits_stride ? params.hits_stride : std::min(params.max_hits, 128u);
+        const uint32 hits_stride = params.resolved_hits_stride(L);
         // the scheme hits are extended with: the caller's, or the edit-distance costs (Params::scoring_mode)
         const bool ed_mode = params.scoring_mode == EditDistanceMode;
         const aln::SmithWatermanScoringScheme search_scheme = params.search_scheme(scoring_scheme);
@@ -508,7 +529,7 @@ private:
     {
         const uint32 count = reads.mate[0].n, L = std::max(reads.mate[0].len, reads.mate[1].len);      // L: the longest read of either mate
         const uint32 band_len = band_length(params.max_dist);
-        const uint32 hits_stride = params.hits_stride ? params.hits_stride : std::min(params.max_hits, 128u);
+        const uint32 hits_stride = params.resolved_hits_stride(L);
         // the scheme hits are extended with (Params::scoring_mode): `sc`; the scheme of MAPQ and finish_alignment is the caller's: `fsc`
         const bool ed_mode = params.scoring_mode == EditDistanceMode;
         const aln::SmithWatermanScoringScheme search_scheme = params.search_scheme(scoring_scheme);

@@ -53,7 +53,7 @@ class Params:
         # paired-end (params.cpp:165-172; io::PE_POLICY_FR)
         self.pe_policy, self.pe_overlap, self.pe_unpaired, self.pe_discordant, self.min_frag_len, self.max_frag_len = 1, True, True, True, 0, 500
         self.batch_size = 1 << 20                      # Aligner::BATCH_SIZE
-        self.hits_stride = None                        # arena slots per read (default min(max_hits, 128))
+        self.hits_stride = None                        # arena slots per read (default: resolved_hits_stride)
         for k, v in kw.items():
             if not hasattr(self, k):
                 raise TypeError("unknown parameter %s" % k)
@@ -65,6 +65,22 @@ class Params:
                 self.seed_freq = (mapping.SQRT_FUNC, 1.0, 0.75)
         self.max_effort_init = max(self.max_effort_init, self.max_effort)      # params.cpp:197-198
         self.max_ext = max(self.max_ext, self.max_effort)
+
+    def resolved_hits_stride(self, max_read_len):
+        """Slots of a read's hit deque when none are named (Params::resolved_hits_stride, include/nvbio_hip/aligner.h): the reference's capacity
+        min(max_hits, 128), or -- exact seeding, where a read yields at most one range per seed and strand -- the 16 or 32 slots that hold them all"""
+        if self.hits_stride:
+            return self.hits_stride
+        cap = min(self.max_hits, 128)
+        if self.allow_sub:
+            return cap
+        most = 0
+        for L in range(max(self.min_read_len, 1), max_read_len + 1):
+            f = mapping.simple_func(*self.seed_freq, L)
+            if f > 0:
+                most = max(most, 2 * ((L - min(self.seed_len, L)) // f + 1))
+        rows = 16 if most <= 16 else 32 if most <= 32 else most
+        return min(cap, rows)
 
     def mapping_params(self):
         return mapping.MappingParams(self.seed_len, self.seed_freq, self.min_read_len, self.max_hits, self.max_reseed, self.rep_seeds)
@@ -205,7 +221,7 @@ def best_approx(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=No
     mp = params.mapping_params()
     best = reduce.BestAlignments(n, scheme, read_len=batch.read_len, fixed_read_len=batch.fixed_len, max_read_len=L, device=dev)     # init_alignments
     seed_queue = torch.arange(n, dtype=torch.int32, device=dev)
-    hits_stride = params.hits_stride or min(params.max_hits, 128)
+    hits_stride = params.resolved_hits_stride(L)
     stats = dict(extensions=0, rounds=0, seeding_passes=0, queue=[])
     if stage_times:
         stats["ms"] = {}
@@ -381,7 +397,7 @@ def best_approx_paired(fmi, rfmi, sym1, sym2, genome_words, genome_len, params=N
     table = sel._min_score_table(scheme, L, dev)
     best = reduce.BestAlignments(n, scheme, max_read_len=L, device=dev, mate=0, **mlen(0))
     best_o = reduce.BestAlignments(n, scheme, max_read_len=L, device=dev, mate=1, **mlen(1))
-    hits_stride = params.hits_stride or min(params.max_hits, 128)
+    hits_stride = params.resolved_hits_stride(L)
     stats = dict(extensions=0, opposite_extensions=0, rounds=0, seeding_passes=0, queue=[])
     if stage_times:
         stats["ms"] = {}
@@ -492,7 +508,7 @@ def all_mapping(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=No
     aligner = make_gotoh_aligner(LOCAL if params.local else SEMI_GLOBAL, scheme)
     band_len = band_length(params.max_dist)
     mp = params.mapping_params()
-    hits_stride = params.hits_stride or min(params.max_hits, 128)
+    hits_stride = params.resolved_hits_stride(L)
     stats = dict(hits=0, ranges=0, unique=0)
     if stage_times:
         stats["ms"] = {}

@@ -287,3 +287,35 @@ def test_sam_md_string_rendering():
     assert sam_md_string(mds((0, 30), (3, 2, 1, 2), (0, 30))) == ("30^CG030", 0, 1, 1)               # deletion: '^' + symbols + '0'
     assert sam_md_string(mds((2, 3, 0, 0, 0), (0, 57))) == ("57", 0, 1, 2)                           # insertion (or soft clip): counted, not printed
     assert sam_md_string(mds((1, 4), (0, 5)))[0] == "N5"
+
+
+def test_default_hit_rows_hold_every_range_a_read_can_yield():
+    """Params.resolved_hits_stride (nvbio_amd/aligner.py; Params::resolved_hits_stride in include/nvbio_hip/aligner.h): when the caller names no
+    row size, a read's deque gets the reference's capacity min(max_hits, 128) -- or, under exact seeding, the 16 / 32 slots that hold one range per
+    seed and strand of the longest read, counted the way the mapping kernel walks the seeds (mapping_inl.h:236-262: pos += seed_freq(len) while
+    the seed fits)."""
+    from nvbio_amd import aligner as A, mapping as M
+
+    def ranges_at_most(p, length):
+        if length < p.min_read_len:
+            return 0
+        f = max(M.simple_func(*p.seed_freq, length), 0)
+        if f == 0:
+            return 0
+        sl, n, pos = min(p.seed_len, length), 0, 0
+        while pos + sl <= length:
+            n += 1; pos += f
+        return 2 * n
+
+    assert A.Params().resolved_hits_stride(100) == 16                    # 7 seeds x 2 strands
+    assert A.Params(local=True).resolved_hits_stride(150) == 32          # 14 seeds x 2 strands
+    assert A.Params(allow_sub=1).resolved_hits_stride(100) == 100        # one-mismatch seeding: several ranges per seed, the reference's capacity
+    assert A.Params(hits_stride=64).resolved_hits_stride(100) == 64      # a named size is taken as it is
+    assert A.Params(max_hits=8).resolved_hits_stride(100) == 8           # never above the reference's own cap
+    for kw in ({}, {"local": True}, {"seed_len": 12, "seed_freq": (M.LINEAR_FUNC if hasattr(M, "LINEAR_FUNC") else 0, 3.0, 0.0)}, {"min_read_len": 30}):
+        p = A.Params(**kw)
+        for longest in (20, 50, 100, 151, 250, 400):
+            rows = p.resolved_hits_stride(longest)
+            need = max(ranges_at_most(p, length) for length in range(1, longest + 1))
+            assert rows >= min(need, min(p.max_hits, 128)), (kw, longest, rows, need)
+            assert rows % 2 == 0 or rows == min(p.max_hits, 128)

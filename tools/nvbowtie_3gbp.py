@@ -135,7 +135,7 @@ def own_driver(prefix, sym, qual, sam_path, dev, batch_reads, digits=8, timings=
     torch.cuda.synchronize()
     t_load = time.time() - t0
     n, L = sym.shape
-    params = A.Params(hits_stride=32, **(overrides or {}))
+    params = A.Params(**(overrides or {}))
     t_align, t_write, stats = 0.0, 0.0, []
     for s in range(0, n, batch_reads):
         e = min(n, s + batch_reads)
@@ -219,7 +219,7 @@ def own_driver_cxx_paired(prefix, s1, s2, q1, q2, sam_path, dev, batch_pairs, di
     torch.cuda.synchronize()
     t_load = time.time() - t0
     n, L = s1.shape
-    prm = A.Params(hits_stride=32, batch_size=batch_pairs, local=local)
+    prm = A.Params(batch_size=batch_pairs, local=local)
     scheme = nvb.SmithWatermanScoringScheme.local() if local else nvb.SmithWatermanScoringScheme()
     sp = B._shim_params(prm, scheme); sp.finish = 1
 
@@ -361,7 +361,7 @@ def own_driver_cxx(prefix, sym, qual, sam_path, dev, batch_reads, digits=8, timi
     torch.cuda.synchronize()
     t_load = time.time() - t0
     n, L = sym.shape
-    prm = A.Params(hits_stride=32, batch_size=batch_reads, **(overrides or {}))
+    prm = A.Params(batch_size=batch_reads, **(overrides or {}))
     scheme = nvb.SmithWatermanScoringScheme()
     sp = B._shim_params(prm, scheme); sp.finish = 1
     fs = data.index().struct()

@@ -159,7 +159,7 @@ def measure(genome=3_000_000_000, reads=5_000_000, batch=1 << 20, repeats=0.6, i
     n, L = sym.shape
     batches = pack_batches(sym, qual, batch, dev)
     nb = len(batches)
-    prm = A.Params(hits_stride=32, batch_size=batch)
+    prm = A.Params(batch_size=batch)
     scheme = nvb.SmithWatermanScoringScheme()
     sp = B._shim_params(prm, scheme)
     sp.finish = 0 if (check or lean_check) else 1        # finish_alignment rewrites best_data (window begin, final score): the comparisons are of the extension-stage words
