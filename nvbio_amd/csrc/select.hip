@@ -635,6 +635,7 @@ locate_hits_kernel(const Fmi f, const Fmi rf, uint32_t n, uint32_t* __restrict__
     }
 }
 
+constexpr uint32_t SETUP_TILES = 4u;            // tiles of 256 hits a block of score_best_setup_kernel describes
 __global__ void __launch_bounds__(256)
 score_best_setup_kernel(uint32_t n, const uint32_t* __restrict__ hit_read_id, const uint32_t* __restrict__ hit_loc, const uint32_t* __restrict__ hit_seed,
                         const uint64_t* __restrict__ read_begin, const uint32_t* __restrict__ read_len, uint32_t fixed_len, uint64_t rc_offset,
@@ -643,57 +644,85 @@ score_best_setup_kernel(uint32_t n, const uint32_t* __restrict__ hit_read_id, co
                         uint64_t* __restrict__ text_begin, uint32_t* __restrict__ text_len, int32_t* __restrict__ min_score, int32_t* __restrict__ known_score,
                         uint32_t* __restrict__ job_count, uint32_t* __restrict__ job_hit)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    __shared__ uint32_t wave_need[4], block_base;
-    const bool live = i < n;
-    const uint32_t r = live ? hit_read_id[i] : 0u, g = live ? hit_loc[i] : 0u;
-    const uint32_t len = live ? (read_len ? read_len[r] : fixed_len) : 0u;
-    const uint32_t gb = g > band_len / 2u ? g - band_len / 2u : 0u;
-    const uint32_t sum = gb + band_len + len;
-    const uint32_t ge = sum < genome_len ? sum : genome_len;
-    // A hit at a placement the read already recorded (same strand, same start) would be scored over the very same window again, and its
-    // score is the recorded one: hand that score to the reduction instead (which usually skips the hit anyway, reduce_inl.h:111-114) and
-    // give the job an empty window.  Most seeds of a read point at one placement, so this removes most of the extension work.
-    int32_t known = INT32_MIN;
-    const uint32_t seed = live ? hit_seed[i] : 0u;
-    uint32_t w2 = 0u;
-    if (live) {
-        const uint2 a2 = best[r + best_stride];
-        w2 = a2.x;
-        if (known_score) {
-            const uint32_t rc = (seed >> 13) & 1u;
-            const uint2 a1 = best[r];
-            if (((a1.x >> 28) & 1u) == rc && a1.y == g)      { const int32_t m = int32_t((a1.x >> 1) & 0x1FFFFu); known = (a1.x & 1u) ? -m : m; }
-            else if (((a2.x >> 28) & 1u) == rc && a2.y == g) { const int32_t m = int32_t((a2.x >> 1) & 0x1FFFFu); known = (a2.x & 1u) ? -m : m; }
-            known_score[i] = known;
+    // a block describes SETUP_TILES x 256 hits: the compacted form below takes ONE slot range per block from the job counter, and with a block per
+    // 256 hits a round of 650 k hits queued 2 500 atomics on that one address -- most of the kernel's 38 us (profiles/r06); four tiles per block
+    // queue a quarter of them
+    __shared__ uint32_t wave_need[SETUP_TILES][4], block_base;
+    uint32_t r_[SETUP_TILES], seed_[SETUP_TILES], len_[SETUP_TILES], gb_[SETUP_TILES], ge_[SETUP_TILES], w2_[SETUP_TILES];
+    int32_t  known_[SETUP_TILES];
+    bool     live_[SETUP_TILES];
+    #pragma unroll
+    for (uint32_t k = 0; k < SETUP_TILES; ++k)
+    {
+        const uint32_t i = (blockIdx.x * SETUP_TILES + k) * 256u + threadIdx.x;
+        const bool live = i < n;
+        const uint32_t r = live ? hit_read_id[i] : 0u, g = live ? hit_loc[i] : 0u;
+        const uint32_t len = live ? (read_len ? read_len[r] : fixed_len) : 0u;
+        const uint32_t gb = g > band_len / 2u ? g - band_len / 2u : 0u;
+        const uint32_t sum = gb + band_len + len;
+        const uint32_t ge = sum < genome_len ? sum : genome_len;
+        // A hit at a placement the read already recorded (same strand, same start) would be scored over the very same window again, and its
+        // score is the recorded one: hand that score to the reduction instead (which usually skips the hit anyway, reduce_inl.h:111-114) and
+        // give the job an empty window.  Most seeds of a read point at one placement, so this removes most of the extension work.
+        int32_t known = INT32_MIN;
+        const uint32_t seed = live ? hit_seed[i] : 0u;
+        uint32_t w2 = 0u;
+        if (live) {
+            const uint2 a2 = best[r + best_stride];
+            w2 = a2.x;
+            if (known_score) {
+                const uint32_t rc = (seed >> 13) & 1u;
+                const uint2 a1 = best[r];
+                if (((a1.x >> 28) & 1u) == rc && a1.y == g)      { const int32_t m = int32_t((a1.x >> 1) & 0x1FFFFu); known = (a1.x & 1u) ? -m : m; }
+                else if (((a2.x >> 28) & 1u) == rc && a2.y == g) { const int32_t m = int32_t((a2.x >> 1) & 0x1FFFFu); known = (a2.x & 1u) ? -m : m; }
+                known_score[i] = known;
+            }
         }
+        r_[k] = r; seed_[k] = seed; len_[k] = len; gb_[k] = gb; ge_[k] = ge; w2_[k] = w2; known_[k] = known; live_[k] = live;
     }
     // compacted form: only the hits that still need a DP become jobs, job_hit[slot] = the hit.  One atomic per BLOCK (the waves' counts
     // meet in LDS): one per wavefront made 156 k same-address atomics per 10 M hits, which is what the kernel then waited for.  The slot
     // order varies from run to run, the scores scattered back through job_hit do not.
-    uint32_t o = i;
-    bool write = live;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint64_t mask[SETUP_TILES];
     if (job_hit) {
-        const bool need = live && known == INT32_MIN;
-        const uint64_t m = __ballot(need);
-        const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-        if (lane == 0u) wave_need[wv] = uint32_t(__popcll(m));
+        #pragma unroll
+        for (uint32_t k = 0; k < SETUP_TILES; ++k) {
+            mask[k] = __ballot(live_[k] && known_[k] == INT32_MIN);
+            if (lane == 0u) wave_need[k][wv] = uint32_t(__popcll(mask[k]));
+        }
         __syncthreads();
-        if (threadIdx.x == 0u) { const uint32_t tot = wave_need[0] + wave_need[1] + wave_need[2] + wave_need[3]; block_base = tot ? atomicAdd(job_count, tot) : 0u; }
+        if (threadIdx.x == 0u) {
+            uint32_t tot = 0u;
+            for (uint32_t k = 0; k < SETUP_TILES; ++k) tot += wave_need[k][0] + wave_need[k][1] + wave_need[k][2] + wave_need[k][3];
+            block_base = tot ? atomicAdd(job_count, tot) : 0u;
+        }
         __syncthreads();
-        uint32_t base = block_base;
-        for (uint32_t k = 0; k < wv; ++k) base += wave_need[k];
-        o = base + uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
-        write = need;
-        if (need) job_hit[o] = i;
     }
-    if (!write) return;
-    text_begin[o] = gb;
-    text_len[o] = (ge > gb && known == INT32_MIN) ? ge - gb : 0u;                // (a wrapped read start: empty window, the alignment fails)
-    pat_begin[o] = (read_begin ? read_begin[r] : uint64_t(r) * fixed_len) + (((seed >> 13) & 1u) ? rc_offset : 0ull);
-    if (pat_len) pat_len[o] = len;
-    const int32_t m2 = int32_t((w2 >> 1) & 0x1FFFFu), s2 = (w2 & 1u) ? -m2 : m2;
-    min_score[o] = s2 > score_limit ? s2 : score_limit;
+    uint32_t tile_base = job_hit ? block_base : 0u;
+    #pragma unroll
+    for (uint32_t k = 0; k < SETUP_TILES; ++k)
+    {
+        const uint32_t i = (blockIdx.x * SETUP_TILES + k) * 256u + threadIdx.x;
+        uint32_t o = i;
+        bool write = live_[k];
+        if (job_hit) {
+            const bool need = live_[k] && known_[k] == INT32_MIN;
+            uint32_t base = tile_base;
+            for (uint32_t q = 0; q < wv; ++q) base += wave_need[k][q];
+            o = base + uint32_t(__popcll(mask[k] & ((1ull << lane) - 1ull)));
+            write = need;
+            if (need) job_hit[o] = i;
+            tile_base += wave_need[k][0] + wave_need[k][1] + wave_need[k][2] + wave_need[k][3];
+        }
+        if (!write) continue;
+        text_begin[o] = gb_[k];
+        text_len[o] = (ge_[k] > gb_[k] && known_[k] == INT32_MIN) ? ge_[k] - gb_[k] : 0u;                // (a wrapped read start: empty window, the alignment fails)
+        pat_begin[o] = (read_begin ? read_begin[r_[k]] : uint64_t(r_[k]) * fixed_len) + (((seed_[k] >> 13) & 1u) ? rc_offset : 0ull);
+        if (pat_len) pat_len[o] = len_[k];
+        const int32_t m2 = int32_t((w2_[k] >> 1) & 0x1FFFFu), s2 = (w2_[k] & 1u) ? -m2 : m2;
+        min_score[o] = s2 > score_limit ? s2 : score_limit;
+    }
 }
 
 // one lane per program of deque operations (0 push with the mappers' "full: pop_bottom first" rule, 1 pop_top,
@@ -901,7 +930,7 @@ NVB_API int nvbio_hip_score_best_setup(uint32_t n_hits, const uint32_t* hit_read
     if (!read_len && fixed_read_len == 0) return hipErrorInvalidValue;
     if (read_len && !pattern_len) return hipErrorInvalidValue;
     g_last_kernel = "score_best_setup_kernel";
-    hipLaunchKernelGGL(score_best_setup_kernel, grid_for(n_hits), dim3(256), 0, to_stream(stream), n_hits, hit_read_id, hit_loc, hit_seed,
+    hipLaunchKernelGGL(score_best_setup_kernel, grid_for((uint64_t(n_hits) + SETUP_TILES - 1u) / SETUP_TILES), dim3(256), 0, to_stream(stream), n_hits, hit_read_id, hit_loc, hit_seed,
                        read_begin, read_len, fixed_read_len, rc_offset, band_len, genome_length, reinterpret_cast<const uint2*>(best_alignments),
                        best_stride, score_limit, pattern_begin, pattern_len, text_begin, text_len, min_score, known_score, job_count, job_hit);
     return hipGetLastError();

@@ -113,6 +113,8 @@ def duplicate_probe(fmi, genome_words, ng, sym, qual, prm, dev):
     from nvbio_amd import aligner as A, select as SEL
     n, L = sym.shape
     keys, per_round = [], []
+    memo = {K: torch.full((n, K), -1, dtype=torch.int64, device=dev) for K in (1, 2, 4, 8, 16)}
+    memo_hits = {K: 0 for K in memo}
     real_setup = SEL.score_best_setup
 
     def setup(*args, **kw):
@@ -122,6 +124,14 @@ def duplicate_probe(fmi, genome_words, ng, sym, qual, prm, dev):
         k = (pb[live].to(torch.int64) << 33) | (tb[live].to(torch.int64) & 0x1FFFFFFFF)
         keys.append(k)
         per_round.append((int(k.numel()), int(torch.unique(k).numel())))
+        # what a small per-read memo of scored windows would answer: K direct-mapped slots per read, looked up and refilled round by round
+        rco = int(kw.get("rc_offset") or n * L)
+        rd = (pb[live].to(torch.int64) % rco) // L
+        for K in memo:
+            slot = ((tb[live].to(torch.int64) * 0x9E3779B1) >> 12) % K
+            cell = memo[K][rd, slot]
+            memo_hits[K] += int((cell == k).sum().item())
+            memo[K][rd, slot] = k
         return r
 
     SEL.score_best_setup = setup
@@ -132,7 +142,7 @@ def duplicate_probe(fmi, genome_words, ng, sym, qual, prm, dev):
     finally:
         SEL.score_best_setup = real_setup
     allk = torch.cat(keys)
-    return dict(jobs=int(allk.numel()), distinct=int(torch.unique(allk).numel()), distinct_within_rounds=sum(u for _, u in per_round), rounds=len(per_round),
+    return dict(jobs=int(allk.numel()), distinct=int(torch.unique(allk).numel()), distinct_within_rounds=sum(u for _, u in per_round), rounds=len(per_round), memo_hits_by_slots=memo_hits,
                 per_round_sample=per_round[:12] + per_round[12::10])
 
 
