@@ -172,7 +172,7 @@ banded_gotoh_score_bounded_kernel(const GotohParams p, const QA qa, const BoundA
                     for (int j = b; j < BAND - 1 && j < b + 16; ++j)
                     {
                         const uint32_t e = A::enc((T0 >> (2 * (j - b))) & 3u);
-                        st.tc[BT::RING ? (j & 15) : j] = fresh ? e : st.tc[BT::RING ? (j & 15) : j];
+                        st.tc[BT::RING ? (j & BT::MASK) : j] = fresh ? e : st.tc[BT::RING ? (j & BT::MASK) : j];
                     }
                 }
                 uint64_t P0; uint4 Q0;
@@ -199,6 +199,7 @@ banded_gotoh_score_bounded_kernel(const GotohParams p, const QA qa, const BoundA
             else
                 RowUnrollN<BAND, TYPE, A, QUAL, false, 0, BT::ROWS>::run(st, k, i0, M, N, P, Tx, Q, s_lut, s_masks);
 #endif
+            ring_advance<BAND, A>(st);
             P = Pn; Tx = Tn; Q = Qn;
             i0 += BT::ROWS;
 

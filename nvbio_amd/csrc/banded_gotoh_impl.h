@@ -42,9 +42,15 @@ template <int BAND> struct BandTraits {
     // 2-bit PackedStream cache which truncates what it stores to 2 bits
     // (nvbio/alignment/alignment_base_inl.h:75-98, packedstream_inl.h:352-369)
     static constexpr bool QUIRK = !(BAND == 3 || BAND == 5 || BAND == 7 || BAND == 15);
-    static constexpr bool RING  = (BAND <= 16);
-    static constexpr int  ROWS  = RING ? 16 : 8;
-    static constexpr int  NTC   = RING ? 16 : BAND - 1;
+    // The band's text symbols sit in a ring of registers indexed by (row + column) & MASK: with the rows of a block unrolled every index is
+    // an instruction constant and no symbol is ever moved.  Bands up to 16 take a ring of 16 (a block of 16 rows brings it back to where it
+    // started); wider bands a ring of 32, whose halves change places after each block of 16 rows (ring_advance: sixteen v_swap_b32).  Round 6
+    // measured what the shifted array cost band 31 before: two v_mov_b32 per cell (the shift, and its copy for the lanes whose row is
+    // masked off) = 62 of a row's 343 vector instructions.
+    static constexpr bool RING  = true;
+    static constexpr int  MASK  = (BAND <= 16) ? 15 : 31;
+    static constexpr int  ROWS  = 16;
+    static constexpr int  NTC   = MASK + 1;
 };
 
 // ---------------------------------------------------------------------------
@@ -218,6 +224,19 @@ struct DPConsts {
     uint32_t sMM, sXX;                       // table arithmetic: sM / sX in both halves of a dword
 };
 
+// after a block of 16 rows: a ring of 32 has turned half way round -- its halves change places, so that the next block's row R again finds
+// column j at (R + j) & 31.  (A ring of 16 is back where it started.)
+template <int BAND, typename A>
+__device__ __forceinline__ void ring_advance(DPState<BAND, A>& st)
+{
+    if constexpr (BandTraits<BAND>::MASK == 31)
+    {
+        #pragma unroll
+        for (int k = 0; k < 16; ++k)
+            asm("v_swap_b32 %0, %1" : "+v"(st.tc[k]), "+v"(st.tc[k + 16]));
+    }
+}
+
 template <int BAND, int TYPE, typename A, bool FAST, int R, int J, int END>
 struct CellLoop {
     __device__ __forceinline__ static void run(DPState<BAND, A>& st, const DPConsts<A>& k, const typename A::T sX,
@@ -225,7 +244,7 @@ struct CellLoop {
     {
         typedef BandTraits<BAND> BT;
         typedef typename A::T T;
-        const uint32_t g = st.tc[BT::RING ? ((R + J) & 15) : J];
+        const uint32_t g = st.tc[BT::RING ? ((R + J) & BT::MASK) : J];
         if (!BT::RING) st.tc[J - 1] = g;                                   // :542
         const T fnext = (J + 1 == BAND - 1) ? k.inf : st.F[J + 1 < BAND - 1 ? J + 1 : 0];
         A::template cell<TYPE, J, FAST>(st.F[J], fnext, st.HG[J + 1], st.HG[J], E, rowkey, g, q, k.Go, k.Ge, k.sM, sX, tlo, thi, k.GeF, k.dF);
@@ -254,7 +273,7 @@ __device__ __forceinline__ void dp_row(DPState<BAND, A>& st, const DPConsts<A>& 
     {
         const T fnext = A::add((1 == BAND - 1) ? k.inf : st.F[1 < BAND - 1 ? 1 : 0], A::ASYM ? k.GeF : k.Ge);
         st.F[0] = A::mx(fnext, A::ASYM ? A::add(st.HG[1], k.dF) : st.HG[1]);
-        const uint32_t g = st.tc[BT::RING ? (R & 15) : 0];
+        const uint32_t g = st.tc[BT::RING ? (R & BT::MASK) : 0];
         const T diag = A::add(st.HG[0], FAST ? A::subst(tlo, thi, g) : (g == q ? k.sM : sX));
         T hi = A::mx(st.F[0], diag);
         if (TYPE == NVBIO_HIP_LOCAL) { hi = A::clamp0(hi); rowkey = hi; }
@@ -274,7 +293,7 @@ __device__ __forceinline__ void dp_row(DPState<BAND, A>& st, const DPConsts<A>& 
     #pragma unroll
     for (int j = 1; j < BAND - 1; ++j)
     {
-        const uint32_t g = st.tc[BT::RING ? ((R + j) & 15) : j];
+        const uint32_t g = st.tc[BT::RING ? ((R + j) & BT::MASK) : j];
         if (!BT::RING) st.tc[j - 1] = g;                                   // :542
         // F[BAND-1] is `infimum` at every row (:586), so the cell next to the band edge sees it as F[j+1]
         const T fnext = (j + 1 == BAND - 1) ? k.inf : st.F[j + 1 < BAND - 1 ? j + 1 : 0];
@@ -289,7 +308,7 @@ __device__ __forceinline__ void dp_row(DPState<BAND, A>& st, const DPConsts<A>& 
     }
     // the new text symbol enters the band (:580-581); the cached copy is what later rows see
     {
-        if (BT::RING) st.tc[(R + BAND - 1) & 15] = g_store;
+        if (BT::RING) st.tc[(R + BAND - 1) & BT::MASK] = g_store;
         else          st.tc[BAND - 2] = g_store;
     }
     // j == BAND-1  (:584-614) -- compares against the raw symbol
@@ -572,7 +591,7 @@ banded_gotoh_score_kernel(const GotohParams p, const QA qa)
                 const uint32_t T0 = fetch16_2bit(ts, tb + b);
                 #pragma unroll
                 for (int j = b; j < BAND - 1 && j < b + 16; ++j)
-                    st.tc[BT::RING ? (j & 15) : j] = A::enc((T0 >> (2 * (j - b))) & 3u);
+                    st.tc[BT::RING ? (j & BT::MASK) : j] = A::enc((T0 >> (2 * (j - b))) & 3u);
             }
         }
 
@@ -591,6 +610,7 @@ banded_gotoh_score_kernel(const GotohParams p, const QA qa)
                 RowUnrollN<BAND, TYPE, A, QUAL, true, 0, BT::ROWS>::run(st, k, i0, M, N, P, Tx, Q, s_lut, s_masks);
             else
                 RowUnrollN<BAND, TYPE, A, QUAL, false, 0, BT::ROWS>::run(st, k, i0, M, N, P, Tx, Q, s_lut, s_masks);
+            ring_advance<BAND, A>(st);
             P = Pn; Tx = Tn; Q = Qn;
         }
 
