@@ -493,10 +493,10 @@ template <typename A> __device__ __forceinline__ void fill_lut(typename A::T* lu
 }
 template <typename A> __device__ __forceinline__ void fill_lut(typename A::T*, const NoQual&, int32_t, int) {}
 
-// band 31 with per-base qualities (nvBowtie's default band: max_dist 15) takes 173-189 VGPRs when left alone -- two waves per SIMD, a few
-// registers over the 168 that allow three; the bound makes the compiler fit them (16 bytes of scratch per lane, +16-18 % measured,
-// profiles/r04/band31_occupancy.txt).  The int32 quality instances would pay 76-84 bytes of scratch for it (profiles/r05/band31_registers.txt)
-// and are left unbounded; the instances without qualities take 156-158 VGPRs either way.
+// band 31 with per-base qualities (nvBowtie's default band: max_dist 15): with the band's text symbols in an array shifted every row the 16-bit
+// instances took 173-189 VGPRs when left alone -- two waves per SIMD, a few registers over the 168 that allow three -- and this bound made the
+// compiler fit them (profiles/r04/band31_occupancy.txt).  With the ring of 32 (BandTraits) every band-31 instance takes 158-160 VGPRs and no
+// scratch; the bound stays as a statement of what the kernel is scheduled for.
 template <typename A> struct occupancy_bound { static const int b31 = 1; };
 template <> struct occupancy_bound<A16> { static const int b31 = 3; };
 template <int BAND, int TYPE, typename A, typename QA>
