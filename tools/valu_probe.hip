@@ -76,7 +76,14 @@
   X(mul_u32_u24,  "v_mul_u32_u24 %0, %0, %1") \
   X(lshl_or,      "v_lshl_or_b32 %0, %0, 3, %1") \
   X(add_lshl,     "v_add_lshl_u32 %0, %0, %1, 1") \
-  X(add3,         "v_add3_u32 %0, %0, %1, %1")
+  X(add3,         "v_add3_u32 %0, %0, %1, %1") \
+  X(add_i16_clamp,"v_add_i16 %0, %0, %1 clamp") \
+  X(sub_i16_clamp,"v_sub_i16 %0, %0, %1 clamp") \
+  X(add_u16_clamp,"v_add_u16_e64 %0, %0, %1 clamp") \
+  X(add_i16,      "v_add_i16 %0, %0, %1") \
+  X(max_i16_e64,  "v_max_i16_e64 %0, %0, %1") \
+  X(mov_b32,      "v_mov_b32 %0, %1") \
+  X(swap_b32,     "v_swap_b32 %0, %1")
 
 #define X(name, str) \
 __global__ void __launch_bounds__(256) k_##name(uint32_t* out, int iters) { \
