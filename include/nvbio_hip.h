@@ -825,6 +825,12 @@ int nvbio_hip_inclusive_scan_u64(uint32_t n, const uint64_t* in, uint64_t* out, 
 int nvbio_hip_sort_hi_bits(uint32_t n, const uint32_t* keys, uint32_t* out_idx, void* temp, uint64_t temp_bytes, void* stream);
 int nvbio_hip_sort_hits(uint32_t n, const uint32_t* hit_read_id, const uint32_t* hit_loc, const uint32_t* hit_seed, uint32_t* out_idx, uint8_t* out_first,
                         void* temp, uint64_t temp_bytes, void* stream);
+/*   sort_hits_pingpong: sort_hits, and the index Aligner::all's mark_straddling actually reads (aligner_all.h:520): `pipeline.idx_queue` is the
+ *     pointer sort_hi_bits returned (:465) -- one half of the ping-pong index buffer, which sort_64_bits (:500) has refilled and sorted through
+ *     since.  Both sorts are replayed on one pair of halves as aligner_sort.cu:37-86 makes them; out_stale[n] = what the first sort's half holds
+ *     after the second (the final index when both end in the same half, the last pass but one's otherwise). */
+int nvbio_hip_sort_hits_pingpong(uint32_t n, const uint32_t* hit_read_id, const uint32_t* hit_loc, const uint32_t* hit_seed, uint32_t* out_idx, uint8_t* out_first,
+                                 uint32_t* out_stale, void* temp, uint64_t temp_bytes, void* stream);
 
 /* BowtieMapq2 / BowtieMapq3 (nvBowtie/bowtie2/cuda/mapq.h:42-330) for single-end reads:
  * out_mapq[r] from the best / second-best alignment of read r; perfect_score(len) = len * match,

@@ -307,10 +307,11 @@ private:
             hip_check(nvbio_hip_select_all(hit_offset, hit_count, count, n_ranges, reinterpret_cast<const uint64*>(hit_data.data()), hits_stride, hit_count_scan.data(),
                                            hit_range_scan.data(), hit_loc.data(), hit_seed.data(), hit_read.data(), hip_stream), "nvbio_hip_select_all");
             // sort_hi_bits, locate, sort by (read, strand, position), dedup, straddling marks, compaction
-            hip_check(nvbio_hip_sort_hi_bits(hit_count, hit_loc.data(), idx_queue.data(), sort_temp.data(), sort_temp.size(), hip_stream), "nvbio_hip_sort_hi_bits");
             hip_check(nvbio_hip_locate_hits(&fmi.m, &rfmi.m, hit_count, hit_loc.data(), hit_seed.data(), hip_stream), "nvbio_hip_locate_hits");
-            hip_check(nvbio_hip_sort_hits(hit_count, hit_read.data(), hit_loc.data(), hit_seed.data(), sort_idx.data(), flags.data(), sort_temp.data(), sort_temp.size(), hip_stream),
-                      "nvbio_hip_sort_hits");
+            // (idx_queue: what the reference's stale `pipeline.idx_queue` holds when mark_straddling reads it -- the half of the ping-pong index buffer
+            // sort_hi_bits ended in, as sort_64_bits left it; nvbio_hip.h)
+            hip_check(nvbio_hip_sort_hits_pingpong(hit_count, hit_read.data(), hit_loc.data(), hit_seed.data(), sort_idx.data(), flags.data(), idx_queue.data(),
+                                                   sort_temp.data(), sort_temp.size(), hip_stream), "nvbio_hip_sort_hits_pingpong");
             hip_check(nvbio_hip_mark_straddling(hit_count, idx_queue.data(), uint32(sequence_index.size() - 1u), d_seq_index.data(), hit_loc.data(), params.seed_len, flags.data(), hip_stream),
                       "nvbio_hip_mark_straddling");
             hip_check(nvbio_hip_copy_flagged(hit_count, sort_idx.data(), flags.data(), queue.data(), counter.data(), flag_temp.data(), flag_temp.size(), hip_stream), "nvbio_hip_copy_flagged");

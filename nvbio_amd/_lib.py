@@ -24,7 +24,7 @@ SYMBOLS = [
     "nvbio_hip_pack_read_queue", "nvbio_hip_mark_unaligned", "nvbio_hip_copy_flagged_temp_bytes", "nvbio_hip_copy_flagged", "nvbio_hip_traceback_best_setup", "nvbio_hip_traceback_best_setup_mates", "nvbio_hip_finish_alignment", "nvbio_hip_scatter_rows",
     "nvbio_hip_gather_ranges", "nvbio_hip_select_all", "nvbio_hip_mark_straddling", "nvbio_hip_score_all_setup", "nvbio_hip_score_all_output",
     "nvbio_hip_traceback_all_setup", "nvbio_hip_all_mapping_temp_bytes", "nvbio_hip_inclusive_scan_u32", "nvbio_hip_inclusive_scan_u64", "nvbio_hip_sort_hi_bits",
-    "nvbio_hip_sort_hits", "nvbio_hip_gather_rows", "nvbio_hip_list_flagged", "nvbio_hip_opposite_memo_lookup", "nvbio_hip_opposite_memo_update", "nvbio_hip_traceback_best_known", "nvbio_hip_banded_gotoh_traceback_qual_known",
+    "nvbio_hip_sort_hits", "nvbio_hip_sort_hits_pingpong", "nvbio_hip_gather_rows", "nvbio_hip_list_flagged", "nvbio_hip_opposite_memo_lookup", "nvbio_hip_opposite_memo_update", "nvbio_hip_traceback_best_known", "nvbio_hip_banded_gotoh_traceback_qual_known",
     "nvbio_hip_fm_locate_ssa_iterator", "nvbio_hip_fm_lookup_ssa_iterator",
     "nvbio_hip_fm_filter_temp_bytes", "nvbio_hip_fm_filter_rank", "nvbio_hip_fm_filter_locate",
     "nvbio_hip_build_bwt_occ_temp_bytes", "nvbio_hip_build_bwt_occ",
@@ -177,6 +177,7 @@ def lib():
         L.nvbio_hip_inclusive_scan_u64.argtypes = [u32, vp, vp, vp, u64, vp]
         L.nvbio_hip_sort_hi_bits.argtypes = [u32, vp, vp, vp, u64, vp]
         L.nvbio_hip_sort_hits.argtypes = [u32, vp, vp, vp, vp, vp, vp, u64, vp]
+        L.nvbio_hip_sort_hits_pingpong.argtypes = [u32, vp, vp, vp, vp, vp, vp, vp, u64, vp]
         L.nvbio_hip_opposite_score_finish.argtypes = [u32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]
         L.nvbio_hip_score_reduce_paired_best_approx.argtypes = [u32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u32, u32, i32, i32, i32, vp, vp, u32, vp, vp, u32, u32, u32, u32, vp]
         L.nvbio_hip_mark_discordant.argtypes = [u32, vp, vp, u32, vp]

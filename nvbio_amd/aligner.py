@@ -544,11 +544,12 @@ def all_mapping(fmi, rfmi, sym, genome_words, genome_len, params=None, scheme=No
         with _Stage(stats, "select"):
             loc, seed, rid = sel.select_all(off, cnt, hits, count_scan, range_scan)
         with _Stage(stats, "locate"):
-            idx_queue = sel.sort_hi_bits(loc)
             sel.locate_hits(fmi, rfmi, loc, seed)
         with _Stage(stats, "sort"):
-            sidx, flags = sel.sort_hits(rid, loc, seed)                                  # SortingKeys order + first-of-run flags
-            sel.mark_straddling(idx_queue, seq_index, loc, params.seed_len, flags)
+            # SortingKeys order + first-of-run flags; mark_straddling reads the reference's stale `pipeline.idx_queue` (aligner_all.h:520): the half of
+            # the ping-pong index buffer sort_hi_bits ended in, as sort_64_bits left it -- replayed by sort_hits_pingpong
+            sidx, flags, stale = sel.sort_hits_pingpong(rid, loc, seed)
+            sel.mark_straddling(stale, seq_index, loc, params.seed_len, flags)
             q = sel.copy_flagged(sidx, flags)
         stats["unique"] += int(q.numel())
         if q.numel() == 0:

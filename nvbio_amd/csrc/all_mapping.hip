@@ -128,6 +128,11 @@ __global__ void __launch_bounds__(256) hi_bits_kernel(uint32_t n, const uint32_t
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < n) { hi[i] = keys[i] >> 16; idx[i] = i; }                                    // hi_bits_functor<uint16,uint32>
 }
+__global__ void __launch_bounds__(256) hi_bits16_kernel(uint32_t n, const uint32_t* __restrict__ keys, uint16_t* __restrict__ hi, uint32_t* __restrict__ idx)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) { hi[i] = uint16_t(keys[i] >> 16); idx[i] = i; }
+}
 // SortingKeys (aligner_all.h:229-247): loc + (read_id << 33) + (rc << 32)
 __global__ void __launch_bounds__(256) hit_keys_kernel(uint32_t n, const uint32_t* __restrict__ hit_read, const uint32_t* __restrict__ hit_loc,
                                                        const uint32_t* __restrict__ hit_seed, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx)
@@ -235,11 +240,11 @@ NVB_API uint64_t nvbio_hip_all_mapping_temp_bytes(uint32_t n)
     (void)hipcub::DeviceScan::InclusiveSum(nullptr, c, (const uint64_t*)nullptr, (uint64_t*)nullptr, int(n));
     (void)hipcub::DeviceScan::InclusiveSum(nullptr, d, (const uint32_t*)nullptr, (uint32_t*)nullptr, int(n));
     const size_t w = std::max(std::max(a, b), std::max(c, d));
-    return align256(w) + 2u * align256(uint64_t(n) * 8u) + align256(uint64_t(n) * 4u) + 256u;
+    return align256(w) + 2u * align256(uint64_t(n) * 8u) + align256(uint64_t(n) * 4u) + 2u * align256(uint64_t(n) * 4u) + 256u;      // (+ the ping-pong index halves of nvbio_hip_sort_hits_pingpong)
 }
 
 namespace {
-struct Scratch { uint8_t* work; size_t work_bytes; uint64_t* k0; uint64_t* k1; uint32_t* v0; };
+struct Scratch { uint8_t* work; size_t work_bytes; uint64_t* k0; uint64_t* k1; uint32_t* v0; uint32_t* pp0; uint32_t* pp1; };
 inline bool carve(void* temp, uint64_t temp_bytes, uint32_t n, Scratch& s)
 {
     if (!temp || temp_bytes < nvbio_hip_all_mapping_temp_bytes(n)) return false;
@@ -247,7 +252,9 @@ inline bool carve(void* temp, uint64_t temp_bytes, uint32_t n, Scratch& s)
     s.k0 = reinterpret_cast<uint64_t*>(p); p += align256(uint64_t(n) * 8u);
     s.k1 = reinterpret_cast<uint64_t*>(p); p += align256(uint64_t(n) * 8u);
     s.v0 = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(n) * 4u);
-    s.work = p; s.work_bytes = size_t(temp_bytes - 256u - 2u * align256(uint64_t(n) * 8u) - align256(uint64_t(n) * 4u));
+    s.pp0 = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(n) * 4u);
+    s.pp1 = reinterpret_cast<uint32_t*>(p); p += align256(uint64_t(n) * 4u);
+    s.work = p; s.work_bytes = size_t(temp_bytes - 256u - 2u * align256(uint64_t(n) * 8u) - 3u * align256(uint64_t(n) * 4u));
     return true;
 }
 }
@@ -292,5 +299,42 @@ NVB_API int nvbio_hip_sort_hits(uint32_t n, const uint32_t* hit_read_id, const u
     const hipError_t e = hipcub::DeviceRadixSort::SortPairs(s.work, s.work_bytes, s.k0, s.k1, s.v0, out_idx, int(n), 0, 64, to_stream(stream));   // stable
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(first_of_run_kernel, grid_for(n), dim3(256), 0, to_stream(stream), n, s.k1, out_first);
+    return hipGetLastError();
+}
+
+// Aligner::all hands mark_straddling `pipeline.idx_queue` (aligner_all.h:520): the pointer sort_hi_bits returned (:465, aligner_sort.cu:37-62), i.e.
+// one half of the ping-pong index buffer -- which sort_64_bits (:500, aligner_sort.cu:66-86) has meanwhile refilled with 0 .. n-1 and sorted through.
+// What that half holds afterwards is the final index when both sorts end in the same half, and whatever the last pass but one left when they do not:
+// decided by the sort library's pass structure for (n, key type), not by the data of the first sort.  This entry replays the two calls as the
+// reference makes them -- DoubleBuffer<uint16> / <uint32> over bits 0..16, then DoubleBuffer<uint64> / <uint32> over bits 0..64 on the SAME index
+// halves, 0 .. n-1 written into half 0 before each -- and returns, besides sort_hits' results, the half the first sort ended in: out_stale.
+NVB_API int nvbio_hip_sort_hits_pingpong(uint32_t n, const uint32_t* hit_read_id, const uint32_t* hit_loc, const uint32_t* hit_seed, uint32_t* out_idx, uint8_t* out_first,
+                                         uint32_t* out_stale, void* temp, uint64_t temp_bytes, void* stream)
+{
+    if (n == 0) return hipSuccess;
+    Scratch s;
+    if (!hit_read_id || !hit_loc || !hit_seed || !out_idx || !out_first || !out_stale || !carve(temp, temp_bytes, n, s)) return hipErrorInvalidValue;
+    hipStream_t st = to_stream(stream);
+    g_last_kernel = "hipcub::DeviceRadixSort::SortPairs";
+    // sort_hi_bits: only the half it ends in matters here (its indices are overwritten below), so any 16-bit keys do
+    uint16_t* h0 = reinterpret_cast<uint16_t*>(s.k0); uint16_t* h1 = reinterpret_cast<uint16_t*>(s.k1);
+    hipLaunchKernelGGL(hi_bits16_kernel, grid_for(n), dim3(256), 0, st, n, hit_loc, h0, s.pp0);
+    uint32_t first_half;
+    {
+        hipcub::DoubleBuffer<uint16_t> k(h0, h1);
+        hipcub::DoubleBuffer<uint32_t> v(s.pp0, s.pp1);
+        size_t bytes = s.work_bytes;
+        if (const hipError_t e = hipcub::DeviceRadixSort::SortPairs(s.work, bytes, k, v, int(n), 0, 16, st)) return e;
+        first_half = uint32_t(v.selector);
+    }
+    // sort_64_bits
+    hipLaunchKernelGGL(hit_keys_kernel, grid_for(n), dim3(256), 0, st, n, hit_read_id, hit_loc, hit_seed, s.k0, s.pp0);
+    hipcub::DoubleBuffer<uint64_t> k(s.k0, s.k1);
+    hipcub::DoubleBuffer<uint32_t> v(s.pp0, s.pp1);
+    size_t bytes = s.work_bytes;
+    if (const hipError_t e = hipcub::DeviceRadixSort::SortPairs(s.work, bytes, k, v, int(n), 0, 64, st)) return e;
+    if (const hipError_t e = hipMemcpyAsync(out_idx, v.Current(), uint64_t(n) * 4u, hipMemcpyDeviceToDevice, st)) return e;
+    if (const hipError_t e = hipMemcpyAsync(out_stale, first_half ? s.pp1 : s.pp0, uint64_t(n) * 4u, hipMemcpyDeviceToDevice, st)) return e;
+    hipLaunchKernelGGL(first_of_run_kernel, grid_for(n), dim3(256), 0, st, n, k.Current(), out_first);
     return hipGetLastError();
 }

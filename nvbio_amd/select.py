@@ -390,6 +390,18 @@ def sort_hits(hit_read_id, hit_loc, hit_seed):
     return idx, first
 
 
+def sort_hits_pingpong(hit_read_id, hit_loc, hit_seed):
+    """sort_hits + the index the reference's mark_straddling reads (aligner_all.h:520: the result pointer of sort_hi_bits, a half of the ping-pong
+    index buffer that sort_64_bits has sorted through since) -> (idx int32[n], first-of-run flags uint8[n], stale idx int32[n])."""
+    n = hit_loc.numel()
+    idx = torch.empty(n, dtype=torch.int32, device=hit_loc.device); first = torch.empty(n, dtype=torch.uint8, device=hit_loc.device)
+    stale = torch.empty(n, dtype=torch.int32, device=hit_loc.device)
+    t = _all_temp(n, hit_loc.device)
+    check(lib().nvbio_hip_sort_hits_pingpong(n, _vp(hit_read_id), _vp(hit_loc), _vp(hit_seed), _vp(idx), _vp(first), _vp(stale), _vp(t), t.numel(), current_stream_ptr()),
+          "nvbio_hip_sort_hits_pingpong")
+    return idx, first, stale
+
+
 def traceback_best_known(best_data, best_sink, n, idx=None):
     """Score and sink of every best alignment as the banded scorer reports them over the traceback's window (kept by the reduction):
     (score int32[m], sink int32[m, 2]) for batch_banded_alignment_traceback(known=...).  best_sink None: the scores alone (sink None)."""

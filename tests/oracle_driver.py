@@ -220,11 +220,16 @@ def best_approx_paired(host_fmi, host_rfmi, sym1, sym2, genome_words, genome_len
 
 
 def all_mapping(host_fmi, host_rfmi, sym, genome_words, genome_len, params, scheme, aln_type, qual_value=30, cigar_stride=64, mds_stride=256,
-                sequence_index=None, read_quals=None):
+                sequence_index=None, read_quals=None, straddle_index="sorted"):
     """Aligner::all / score_all (aligner_all.h:47-694), numpy over the oracle: one mapping pass with every seed, then all rows of all SA
     ranges in batches of params.batch_size hits -- hi-bits sort, locate, (read, strand, position) sort, de-duplication within the batch,
     straddling marks (with the reference's indexing), banded extension, acceptance at min_score(read_len), traceback, finish.  Returns
-    the accepted alignments in batch order, sorted by (read, strand, position) inside each batch."""
+    the accepted alignments in batch order, sorted by (read, strand, position) inside each batch.
+    straddle_index: which index mark_straddling reads.  The reference hands it `pipeline.idx_queue` (aligner_all.h:520), the pointer
+    sort_hi_bits returned -- a half of the ping-pong index buffer that sort_64_bits has refilled and sorted through since.  "sorted": both
+    sorts ended in the same half, the pointer sees the final (read, strand, position) index (what the radix sort of this image does at every
+    size the suites use: the reference application on the drop-in layer and nvbio_hip_sort_hits_pingpong agree on it); "locate": the
+    hi-bits index survived (the reading of rounds 4-5)."""
     band = band_length(params.max_dist)
     reads_rev, ext_words, index = pack_reads(sym)
     n, total = index.size - 1, int(index[-1])
@@ -266,7 +271,7 @@ def all_mapping(host_fmi, host_rfmi, sym, genome_words, genome_len, params, sche
         sidx = np.argsort(key, kind="stable")
         skey = key[sidx]
         flags = np.ones(cnt, bool); flags[1:] = skey[1:] != skey[:-1]
-        g = loc[idx_queue].astype(np.int64)                                            # mark_straddling: hit idx_queue[t], flag t
+        g = loc[sidx if straddle_index == "sorted" else idx_queue].astype(np.int64)     # mark_straddling: hit idx[t], flag t
         s0 = np.searchsorted(seq_index, g, side="right") - 1
         s1 = np.searchsorted(seq_index, (g + params.seed_len) & 0xFFFFFFFF, side="right") - 1
         flags[s0 != s1] = False
