@@ -12,7 +12,7 @@ def timed(fn, reps=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 import sys
-CASES = ((100, 31), (150, 31)) if "b31" in sys.argv[1:] else ((100, 7), (100, 5), (100, 3), (250, 31))
+CASES = ((100, 31), (150, 31)) if "b31" in sys.argv[1:] else ((100, 15), (150, 15)) if "b15" in sys.argv[1:] else ((100, 7), (100, 5), (100, 3), (250, 31))
 for L, band in CASES:
     n = 4_000_000
     p, t = W.make_sw_batch(n, L, L + max(band, 15), seed=3, device=dev)
