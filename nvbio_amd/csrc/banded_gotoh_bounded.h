@@ -172,7 +172,7 @@ banded_gotoh_score_bounded_kernel(const GotohParams p, const QA qa, const BoundA
                     for (int j = b; j < BAND - 1 && j < b + 16; ++j)
                     {
                         const uint32_t e = A::enc((T0 >> (2 * (j - b))) & 3u);
-                        st.tc[BT::RING ? (j & BT::MASK) : j] = fresh ? e : st.tc[BT::RING ? (j & BT::MASK) : j];
+                        st.tc[j & BT::MASK] = fresh ? e : st.tc[j & BT::MASK];
                     }
                 }
                 uint64_t P0; uint4 Q0;

@@ -47,7 +47,6 @@ template <int BAND> struct BandTraits {
     // started); wider bands a ring of 32, whose halves change places after each block of 16 rows (ring_advance: sixteen v_swap_b32).  Round 6
     // measured what the shifted array cost band 31 before: two v_mov_b32 per cell (the shift, and its copy for the lanes whose row is
     // masked off) = 62 of a row's 343 vector instructions.
-    static constexpr bool RING  = true;
     static constexpr int  MASK  = (BAND <= 16) ? 15 : 31;
     static constexpr int  ROWS  = 16;
     static constexpr int  NTC   = MASK + 1;
@@ -244,8 +243,7 @@ struct CellLoop {
     {
         typedef BandTraits<BAND> BT;
         typedef typename A::T T;
-        const uint32_t g = st.tc[BT::RING ? ((R + J) & BT::MASK) : J];
-        if (!BT::RING) st.tc[J - 1] = g;                                   // :542
+        const uint32_t g = st.tc[(R + J) & BT::MASK];                       // (:542: the reference shifts its cache here; the ring does not move)
         const T fnext = (J + 1 == BAND - 1) ? k.inf : st.F[J + 1 < BAND - 1 ? J + 1 : 0];
         A::template cell<TYPE, J, FAST>(st.F[J], fnext, st.HG[J + 1], st.HG[J], E, rowkey, g, q, k.Go, k.Ge, k.sM, sX, tlo, thi, k.GeF, k.dF);
         CellLoop<BAND, TYPE, A, FAST, R, J + 1, END>::run(st, k, sX, E, rowkey, q, tlo, thi);
@@ -273,7 +271,7 @@ __device__ __forceinline__ void dp_row(DPState<BAND, A>& st, const DPConsts<A>& 
     {
         const T fnext = A::add((1 == BAND - 1) ? k.inf : st.F[1 < BAND - 1 ? 1 : 0], A::ASYM ? k.GeF : k.Ge);
         st.F[0] = A::mx(fnext, A::ASYM ? A::add(st.HG[1], k.dF) : st.HG[1]);
-        const uint32_t g = st.tc[BT::RING ? (R & BT::MASK) : 0];
+        const uint32_t g = st.tc[R & BT::MASK];
         const T diag = A::add(st.HG[0], FAST ? A::subst(tlo, thi, g) : (g == q ? k.sM : sX));
         T hi = A::mx(st.F[0], diag);
         if (TYPE == NVBIO_HIP_LOCAL) { hi = A::clamp0(hi); rowkey = hi; }
@@ -293,8 +291,7 @@ __device__ __forceinline__ void dp_row(DPState<BAND, A>& st, const DPConsts<A>& 
     #pragma unroll
     for (int j = 1; j < BAND - 1; ++j)
     {
-        const uint32_t g = st.tc[BT::RING ? ((R + j) & BT::MASK) : j];
-        if (!BT::RING) st.tc[j - 1] = g;                                   // :542
+        const uint32_t g = st.tc[(R + j) & BT::MASK];
         // F[BAND-1] is `infimum` at every row (:586), so the cell next to the band edge sees it as F[j+1]
         const T fnext = (j + 1 == BAND - 1) ? k.inf : st.F[j + 1 < BAND - 1 ? j + 1 : 0];
         switch (j) {   // the sink key's column is an instruction constant
@@ -308,8 +305,7 @@ __device__ __forceinline__ void dp_row(DPState<BAND, A>& st, const DPConsts<A>& 
     }
     // the new text symbol enters the band (:580-581); the cached copy is what later rows see
     {
-        if (BT::RING) st.tc[(R + BAND - 1) & BT::MASK] = g_store;
-        else          st.tc[BAND - 2] = g_store;
+        st.tc[(R + BAND - 1) & BT::MASK] = g_store;
     }
     // j == BAND-1  (:584-614) -- compares against the raw symbol
     {
@@ -591,7 +587,7 @@ banded_gotoh_score_kernel(const GotohParams p, const QA qa)
                 const uint32_t T0 = fetch16_2bit(ts, tb + b);
                 #pragma unroll
                 for (int j = b; j < BAND - 1 && j < b + 16; ++j)
-                    st.tc[BT::RING ? (j & BT::MASK) : j] = A::enc((T0 >> (2 * (j - b))) & 3u);
+                    st.tc[j & BT::MASK] = A::enc((T0 >> (2 * (j - b))) & 3u);
             }
         }
 
