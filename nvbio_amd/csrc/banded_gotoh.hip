@@ -108,16 +108,20 @@ static hipError_t launch(const GotohParams& p, const QA& qa, int type, uint32_t 
 //                        keys add j < 32.  Need 32*(M*S) + 31 <= 32767 and the negative side far above the sentinel.
 //   GLOBAL/SEMI_GLOBAL:  |value| <= (M + BAND + 2) * max|cost|; need that below 15000 so that
 //                        no real value comes within a band's worth of gap steps of the sentinel.
-static uint32_t max_len_16bit(int32_t match, int32_t best_pair /* max substitution score */, int64_t A /* max |cost| */, int32_t gap_open, int32_t gap_ext, int type, uint32_t band)
+// The kernels hold row i's values plus (i + 1) |G_e| (the row frame, banded_gotoh_impl.h: A32::cell_rt): a LOCAL value reaches
+// 32 * M * (S + |G_e|) + 31, a GLOBAL / SEMI_GLOBAL one gains at most M * max|cost|.
+static uint32_t max_len_16bit(int32_t match, int32_t best_pair /* max substitution score */, int64_t A /* max |cost| */, int32_t gap_open, int32_t gap_ext, int type, uint32_t band,
+                              int32_t row_step /* |G_e| of the pattern's gaps */)
 {
     if (gap_open > 0 || gap_ext > 0) return 0;
     if (A == 0) return 0xFFFFFFFFu;
     if (type == NVBIO_HIP_LOCAL) {
         if (match < 0 || A > 100) return 0;                          // 32*4*A stays far above -32768
-        if (best_pair <= 0) return 0xFFFFFFFFu;
-        return uint32_t(1022 / best_pair);
+        const int64_t per_row = int64_t(std::max(best_pair, 0)) + row_step;
+        if (per_row <= 0) return 0xFFFFFFFFu;
+        return uint32_t(1022 / per_row);
     }
-    const int64_t lim = 15000 / A - int64_t(band) - 2;
+    const int64_t lim = (15000 / A - int64_t(band) - 2) / 2;
     return lim <= 0 ? 0u : uint32_t(lim);
 }
 
@@ -131,7 +135,8 @@ static int banded_gotoh_dispatch(nvb::GotohParams& p, const QA& qa, int64_t max_
     using namespace nvb;
     // NVBIO_HIP_FORCE_32BIT=1 disables the 16-bit kernels (used by the tests to cover both widths)
     const uint32_t lim16 = test_switch(SW_FORCE_32BIT) == 1 ? 0u
-                         : max_len_16bit(p.match, best_pair, max_abs_cost, std::max(p.gap_open, p.txt_gap_open), std::max(p.gap_ext, p.txt_gap_ext), type, band_len);
+                         : max_len_16bit(p.match, best_pair, max_abs_cost, std::max(p.gap_open, p.txt_gap_open), std::max(p.gap_ext, p.txt_gap_ext), type, band_len,
+                                         p.gap_ext < 0 ? -p.gap_ext : 0);
     const bool fixed = (patterns->length == nullptr);
     hipError_t e = hipSuccess;
     // LDS staging of each lane's words, sized from the longest pattern the caller announces

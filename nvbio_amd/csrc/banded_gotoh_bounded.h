@@ -289,7 +289,7 @@ hipError_t launch_band_bounded(const GotohParams& p, const QA& qa, const BoundAr
 template <int BAND, typename QA>
 hipError_t launch_band_width_bounded(const GotohParams& p, const QA& qa, const BoundArgs& ba, int type, bool width16, hipStream_t s)
 {
-    return width16 ? launch_band_bounded<BAND, A16, QA>(p, qa, ba, type, s) : launch_band_bounded<BAND, A32, QA>(p, qa, ba, type, s);
+    return width16 ? launch_band_bounded<BAND, A16P, QA>(p, qa, ba, type, s) : launch_band_bounded<BAND, A32P, QA>(p, qa, ba, type, s);
 }
 
 } // namespace nvb

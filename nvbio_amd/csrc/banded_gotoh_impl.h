@@ -59,6 +59,8 @@ template <int BAND> struct BandTraits {
 struct A32 {
     typedef int32_t T;
     static constexpr bool ASYM = false;      // one pair of gap costs for both directions (the Gotoh schemes)
+    static constexpr bool ROWTREND = true;   // the recurrence in the row frame (cell_rt, below)
+    static __device__ __forceinline__ T   sub(T a, T b)        { return a - b; }
     static __device__ __forceinline__ T   add(T a, T b)        { return a + b; }
     static __device__ __forceinline__ T   mx(T a, T b)         { return max(a, b); }
     static __device__ __forceinline__ T   mx3(T a, T b, T c)   { return max(max(a, b), c); }
@@ -87,10 +89,31 @@ struct A32 {
         HGj = hi + Go;
         E = max(E + Ge, HGj);
     }
+    // The same cell in the ROW FRAME.  Every value of row i is held plus (i + 1) |G_e| -- X' = X - (i + 1) G_e, the row-zero values as they
+    // are -- and the band keeps S = H' + G_o - G_e instead of H + G_o.  Moving down a row then costs F nothing:
+    //   F'(i,j) = F(i,j) - (i+1) G_e = max(F(i-1,j+1) + G_e, H(i-1,j+1) + G_o) - (i+1) G_e = max(F'(i-1,j+1), S(i-1,j+1))
+    // the diagonal keeps its pre-biased substitution score, H(i-1,j) + s - (i+1) G_e = S(i-1,j) + (s - G_o), and the gap along the row pays the
+    // step it used to pay, E'(i,j+1) = max(E'(i,j), S(i,j)) + G_e.  One add less per cell (9 -> 8 instructions, LOCAL 12 -> 11); LOCAL's floor
+    // is the row's own zero Z = (i + 1) |G_e| (one register per row), the sink key h' + j is compared inside the row as it is and loses Z once
+    // per row.  Reachable values grow by M |G_e|: max_len_16bit (banded_gotoh.hip) counts that in.
+    template <int TYPE, int J, bool FAST>
+    static __device__ __forceinline__ void cell_rt(T& Fj, const T Fnext, const T Snext, T& Sj, T& E, T& rowkey,
+                                                   const uint32_t g, const uint32_t q, const T GoE, const T Ge, const T sM, const T sX,
+                                                   const uint32_t, const uint32_t, const T Z)
+    {
+        Fj = max(Fnext, Snext);
+        const T diag = Sj + (g == q ? sM : sX);
+        T hi = max(max(Fj, E), diag);
+        if (TYPE == NVBIO_HIP_LOCAL) { hi = max(hi, Z); rowkey = max(rowkey, hi + J); }
+        Sj = hi + GoE;
+        E = max(E, Sj) + Ge;
+    }
 };
 struct A16 {
     typedef uint32_t T;
     static constexpr bool ASYM = false;
+    static constexpr bool ROWTREND = true;   // the recurrence in the row frame (A32::cell_rt has the derivation)
+    static __device__ __forceinline__ T sub(T a, T b)      { T r; asm("v_sub_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
     static __device__ __forceinline__ T add(T a, T b)      { T r; asm("v_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
     static __device__ __forceinline__ T mx(T a, T b)       { T r; asm("v_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
     static __device__ __forceinline__ T mx3(T a, T b, T c) { return mx(mx(a, b), c); }
@@ -178,8 +201,76 @@ struct A16 {
                 : [g] "v"(g), [q] "v"(q), [fn] "v"(Fnext), [ge] "v"(Ge), [sx] "v"(sX), [sm] "v"(sM), [hgn] "v"(HGnext), [go] "v"(Go)
                 : "vcc");
     }
+    // the row-frame cell (A32::cell_rt) as instruction blocks: S in `hg`, G_o - G_e in `goe`, the row's zero in `z`
+    template <int TYPE, int J, bool FAST>
+    static __device__ __forceinline__ void cell_rt(T& Fj, const T Fnext, const T Snext, T& Sj, T& E, T& rowkey,
+                                                   const uint32_t g, const uint32_t q, const T GoE, const T Ge, const T sM, const T sX,
+                                                   const uint32_t tlo, const uint32_t thi, const T Z)
+    {
+        T d, h;
+        if (FAST && TYPE == NVBIO_HIP_LOCAL)
+            asm("v_perm_b32 %[d], %[thi], %[tlo], %[g]\n\t"
+                "v_max_i16 %[f], %[fn], %[hgn]\n\t"
+                "v_add_u16 %[d], %[hg], %[d]\n\t"
+                "v_max_i16 %[h], %[f], %[e]\n\t"
+                "v_max_i16 %[h], %[h], %[d]\n\t"
+                "v_max_i16 %[h], %[h], %[z]\n\t"
+                "v_add_u16 %[hg], %[h], %[goe]\n\t"
+                "v_add_u16 %[d], %[sj], %[h]\n\t"
+                "v_max_i16 %[e], %[e], %[hg]\n\t"
+                "v_add_u16 %[e], %[e], %[ge]\n\t"
+                "v_max_i16 %[rk], %[rk], %[d]"
+                : [f] "=&v"(Fj), [d] "=&v"(d), [h] "=&v"(h), [hg] "+v"(Sj), [e] "+v"(E), [rk] "+v"(rowkey)
+                : [g] "v"(g), [tlo] "v"(tlo), [thi] "v"(thi), [fn] "v"(Fnext), [ge] "v"(Ge), [hgn] "v"(Snext), [goe] "v"(GoE), [z] "v"(Z), [sj] "I"(J));
+        else if (FAST)
+            asm("v_perm_b32 %[d], %[thi], %[tlo], %[g]\n\t"
+                "v_max_i16 %[f], %[fn], %[hgn]\n\t"
+                "v_add_u16 %[d], %[hg], %[d]\n\t"
+                "v_max_i16 %[h], %[f], %[e]\n\t"
+                "v_max_i16 %[h], %[h], %[d]\n\t"
+                "v_add_u16 %[hg], %[h], %[goe]\n\t"
+                "v_max_i16 %[e], %[e], %[hg]\n\t"
+                "v_add_u16 %[e], %[e], %[ge]"
+                : [f] "=&v"(Fj), [d] "=&v"(d), [h] "=&v"(h), [hg] "+v"(Sj), [e] "+v"(E)
+                : [g] "v"(g), [tlo] "v"(tlo), [thi] "v"(thi), [fn] "v"(Fnext), [ge] "v"(Ge), [hgn] "v"(Snext), [goe] "v"(GoE));
+        else if (TYPE == NVBIO_HIP_LOCAL)
+            asm("v_cmp_eq_u32 vcc, %[g], %[q]\n\t"
+                "v_max_i16 %[f], %[fn], %[hgn]\n\t"
+                "v_cndmask_b32 %[d], %[sx], %[sm], vcc\n\t"
+                "v_add_u16 %[d], %[hg], %[d]\n\t"
+                "v_max_i16 %[h], %[f], %[e]\n\t"
+                "v_max_i16 %[h], %[h], %[d]\n\t"
+                "v_max_i16 %[h], %[h], %[z]\n\t"
+                "v_add_u16 %[hg], %[h], %[goe]\n\t"
+                "v_add_u16 %[d], %[sj], %[h]\n\t"
+                "v_max_i16 %[e], %[e], %[hg]\n\t"
+                "v_add_u16 %[e], %[e], %[ge]\n\t"
+                "v_max_i16 %[rk], %[rk], %[d]"
+                : [f] "=&v"(Fj), [d] "=&v"(d), [h] "=&v"(h), [hg] "+v"(Sj), [e] "+v"(E), [rk] "+v"(rowkey)
+                : [g] "v"(g), [q] "v"(q), [fn] "v"(Fnext), [ge] "v"(Ge), [sx] "v"(sX), [sm] "v"(sM), [hgn] "v"(Snext), [goe] "v"(GoE), [z] "v"(Z), [sj] "I"(J)
+                : "vcc");
+        else
+            asm("v_cmp_eq_u32 vcc, %[g], %[q]\n\t"
+                "v_max_i16 %[f], %[fn], %[hgn]\n\t"
+                "v_cndmask_b32 %[d], %[sx], %[sm], vcc\n\t"
+                "v_add_u16 %[d], %[hg], %[d]\n\t"
+                "v_max_i16 %[h], %[f], %[e]\n\t"
+                "v_max_i16 %[h], %[h], %[d]\n\t"
+                "v_add_u16 %[hg], %[h], %[goe]\n\t"
+                "v_max_i16 %[e], %[e], %[hg]\n\t"
+                "v_add_u16 %[e], %[e], %[ge]"
+                : [f] "=&v"(Fj), [d] "=&v"(d), [h] "=&v"(h), [hg] "+v"(Sj), [e] "+v"(E)
+                : [g] "v"(g), [q] "v"(q), [fn] "v"(Fnext), [ge] "v"(Ge), [sx] "v"(sX), [sm] "v"(sM), [hgn] "v"(Snext), [goe] "v"(GoE)
+                : "vcc");
+    }
     static __device__ __forceinline__ T min_value()        { return 0x8000u; }
 };
+
+// The policies with the recurrence as the reference writes it (H + G_o in the band, F and E paying their step): what the bounded kernel runs
+// (banded_gotoh_bounded.h: its row bound reads the band's values as scores).
+template <typename Base> struct Plain : Base { static constexpr bool ROWTREND = false; };
+typedef Plain<A32> A32P;
+typedef Plain<A16> A16P;
 
 // Direction-dependent gap costs: SmithWatermanAligner with deletion != insertion (sw_banded_inl.h:378-379, :413, :432-433 -- the move from
 // the previous row costs `deletion`, the move along the row `insertion`).  The same cell with F taking its own pair of costs:
@@ -189,6 +280,7 @@ template <typename Base>
 struct Asym : Base {
     typedef typename Base::T T;
     static constexpr bool ASYM = true;
+    static constexpr bool ROWTREND = false;  // (F has its own costs: it would need its own frame)
     template <int TYPE, int J, bool FAST>
     static __device__ __forceinline__ void cell(T& Fj, const T Fnext, const T HGnext, T& HGj, T& E, T& rowkey,
                                                 const uint32_t g, const uint32_t q, const T Go, const T Ge, const T sM, const T sX,
@@ -213,12 +305,15 @@ struct DPState {
     uint32_t      tc[BandTraits<BAND>::NTC]; // text symbols of the band
     typename A::T bestkey;                   // LOCAL: score*32 + j of the best cell so far
     uint32_t      besti;                     //        and its row
+    typename A::T z;                         // A::ROWTREND: the row's zero, (i + 1) |G_e| (x32 for LOCAL)
+    typename A::T infrow;                    //              the reference's infimum as the previous row's frame holds it: infimum + i |G_e|
 };
 
 template <typename A>
 struct DPConsts {
     typename A::T Go, Ge, sM, sX, inf;       // sM/sX = match/mismatch - G_o ; inf = the infimum sentinel
     typename A::T GeF, dF;                   // A::ASYM: F's extension cost and (F's opening cost - G_o)
+    typename A::T GoE, Zstep;                // A::ROWTREND: G_o - G_e, |G_e|
     bool bytes;                              // the patterns are 8-bit strings
     uint32_t sMM, sXX;                       // table arithmetic: sM / sX in both halves of a dword
 };
@@ -244,8 +339,9 @@ struct CellLoop {
         typedef BandTraits<BAND> BT;
         typedef typename A::T T;
         const uint32_t g = st.tc[(R + J) & BT::MASK];                       // (:542: the reference shifts its cache here; the ring does not move)
-        const T fnext = (J + 1 == BAND - 1) ? k.inf : st.F[J + 1 < BAND - 1 ? J + 1 : 0];
-        A::template cell<TYPE, J, FAST>(st.F[J], fnext, st.HG[J + 1], st.HG[J], E, rowkey, g, q, k.Go, k.Ge, k.sM, sX, tlo, thi, k.GeF, k.dF);
+        const T fnext = (J + 1 == BAND - 1) ? (A::ROWTREND ? st.infrow : k.inf) : st.F[J + 1 < BAND - 1 ? J + 1 : 0];
+        if constexpr (A::ROWTREND) A::template cell_rt<TYPE, J, FAST>(st.F[J], fnext, st.HG[J + 1], st.HG[J], E, rowkey, g, q, k.GoE, k.Ge, k.sM, sX, tlo, thi, st.z);
+        else                       A::template cell<TYPE, J, FAST>(st.F[J], fnext, st.HG[J + 1], st.HG[J], E, rowkey, g, q, k.Go, k.Ge, k.sM, sX, tlo, thi, k.GeF, k.dF);
         CellLoop<BAND, TYPE, A, FAST, R, J + 1, END>::run(st, k, sX, E, rowkey, q, tlo, thi);
     }
 };
@@ -268,6 +364,21 @@ __device__ __forceinline__ void dp_row(DPState<BAND, A>& st, const DPConsts<A>& 
     T E;
 
     // j == 0  (gotoh_banded_inl.h:483-517)
+    if constexpr (A::ROWTREND)
+    {
+        // F[BAND-1] is the reference's infimum at every row (:586) -- a value that takes part in the maxima once scores fall below it
+        // (tests/test_banded_gpu.py::test_large_negative_scores_cross_infimum): in the previous row's frame it stands at infimum + i |G_e|
+        st.infrow = A::add(k.inf, st.z);
+        st.z = A::add(st.z, k.Zstep);                                          // this row's zero
+        st.F[0] = A::mx((1 == BAND - 1) ? st.infrow : st.F[1 < BAND - 1 ? 1 : 0], st.HG[1]);
+        const uint32_t g = st.tc[R & BT::MASK];
+        const T diag = A::add(st.HG[0], FAST ? A::subst(tlo, thi, g) : (g == q ? k.sM : sX));
+        T hi = A::mx(st.F[0], diag);
+        if (TYPE == NVBIO_HIP_LOCAL) { hi = A::mx(hi, st.z); rowkey = hi; }
+        st.HG[0] = A::add(hi, k.GoE);
+        E = A::add(st.HG[0], k.Ge);
+    }
+    else
     {
         const T fnext = A::add((1 == BAND - 1) ? k.inf : st.F[1 < BAND - 1 ? 1 : 0], A::ASYM ? k.GeF : k.Ge);
         st.F[0] = A::mx(fnext, A::ASYM ? A::add(st.HG[1], k.dF) : st.HG[1]);
@@ -293,9 +404,10 @@ __device__ __forceinline__ void dp_row(DPState<BAND, A>& st, const DPConsts<A>& 
     {
         const uint32_t g = st.tc[(R + j) & BT::MASK];
         // F[BAND-1] is `infimum` at every row (:586), so the cell next to the band edge sees it as F[j+1]
-        const T fnext = (j + 1 == BAND - 1) ? k.inf : st.F[j + 1 < BAND - 1 ? j + 1 : 0];
+        const T fnext = (j + 1 == BAND - 1) ? (A::ROWTREND ? st.infrow : k.inf) : st.F[j + 1 < BAND - 1 ? j + 1 : 0];
         switch (j) {   // the sink key's column is an instruction constant
-            #define NVB_CELL(J) case J: A::template cell<TYPE, J, FAST>(st.F[j], fnext, st.HG[j + 1], st.HG[j], E, rowkey, g, q, k.Go, k.Ge, k.sM, sX, tlo, thi, k.GeF, k.dF); break;
+            #define NVB_CELL(J) case J: if constexpr (A::ROWTREND) A::template cell_rt<TYPE, J, FAST>(st.F[j], fnext, st.HG[j + 1], st.HG[j], E, rowkey, g, q, k.GoE, k.Ge, k.sM, sX, tlo, thi, st.z); \
+                                        else                       A::template cell<TYPE, J, FAST>(st.F[j], fnext, st.HG[j + 1], st.HG[j], E, rowkey, g, q, k.Go, k.Ge, k.sM, sX, tlo, thi, k.GeF, k.dF); break;
             NVB_CELL(1) NVB_CELL(2) NVB_CELL(3) NVB_CELL(4) NVB_CELL(5) NVB_CELL(6) NVB_CELL(7) NVB_CELL(8) NVB_CELL(9) NVB_CELL(10)
             NVB_CELL(11) NVB_CELL(12) NVB_CELL(13) NVB_CELL(14)
             #undef NVB_CELL
@@ -311,13 +423,14 @@ __device__ __forceinline__ void dp_row(DPState<BAND, A>& st, const DPConsts<A>& 
     {
         const T diag = A::add(st.HG[BAND - 1], FAST ? A::subst(tlo, thi, g_new) : (g_new == q ? k.sM : sX));
         T hi = A::mx(E, diag);
-        if (TYPE == NVBIO_HIP_LOCAL) { hi = A::clamp0(hi); rowkey = A::mx(rowkey, A::template key<BAND - 1>(hi)); }
-        st.HG[BAND - 1] = A::add(hi, k.Go);
+        if (TYPE == NVBIO_HIP_LOCAL) { hi = A::ROWTREND ? A::mx(hi, st.z) : A::clamp0(hi); rowkey = A::mx(rowkey, A::template key<BAND - 1>(hi)); }
+        st.HG[BAND - 1] = A::add(hi, A::ROWTREND ? k.GoE : k.Go);
     }
     if (TYPE == NVBIO_HIP_LOCAL)
     {
         // BestSink::report uses '<=' (sink_inl.h:57-68): a later cell with an equal score wins.
-        // LOCAL keys are non-negative, so the comparison is the same in either width.
+        // LOCAL keys are non-negative, so the comparison is the same in either width.  (Row frame: the row's keys lose its zero here.)
+        if (A::ROWTREND) rowkey = A::sub(rowkey, st.z);
         const uint32_t rk = A::bits(rowkey), bk = A::bits(st.bestkey);
         const bool upd = (rk | 31u) >= bk;
         st.bestkey = upd ? rowkey : st.bestkey;
@@ -462,6 +575,8 @@ template <> struct Sentinel<A32> {
 template <> struct Sentinel<A16> {   // infimum + G_e == -32768 exactly: the add cannot wrap
     static __device__ __forceinline__ uint32_t get(int32_t, int32_t Ge, int32_t, int32_t, int sh) { return A16::cnst(-32768 - Ge * (1 << sh)); }
 };
+template <> struct Sentinel<A32P> : Sentinel<A32> {};
+template <> struct Sentinel<A16P> : Sentinel<A16> {};
 template <> struct Sentinel<A32X> : Sentinel<A32> {};
 template <> struct Sentinel<A16X> : Sentinel<A16> {};      // (the caller passes F's extension cost: the only step ever added to the sentinel)
 
@@ -565,19 +680,21 @@ banded_gotoh_score_kernel(const GotohParams p, const QA qa)
         k.sM = A::cnst((p.match - p.gap_open) * (1 << SH)); k.sX = A::cnst((p.mismatch - p.gap_open) * (1 << SH));
         k.inf = Sentinel<A>::get(p.gap_open, A::ASYM ? p.f_gap_ext : p.gap_ext, p.txt_gap_open, p.txt_gap_ext, SH);
         k.GeF = A::cnst((A::ASYM ? p.f_gap_ext : 0) * (1 << SH)); k.dF = A::cnst((A::ASYM ? p.f_gap_open - p.gap_open : 0) * (1 << SH));
+        k.GoE = A::cnst((p.gap_open - p.gap_ext) * (1 << SH)); k.Zstep = A::cnst(-p.gap_ext * (1 << SH));
+        constexpr int32_t RT = A::ROWTREND ? 1 : 0;                        // row frame: the band holds S = H + G_o - G_e, F starts below everything
         k.bytes = (p.pat.s.bits == 8u);
         k.sMM = (uint32_t(k.sM) & 0xFFFFu) * 0x10001u; k.sXX = (uint32_t(k.sX) & 0xFFFFu) * 0x10001u;
         const T infimum = k.inf;
 
         DPState<BAND, A> st;
-        // init_row_zero (:46-77), stored as H + G_o
-        st.HG[0] = k.Go;
+        // init_row_zero (:46-77), stored as H + G_o (row frame: H + G_o - G_e)
+        st.HG[0] = A::ROWTREND ? k.GoE : k.Go;
         #pragma unroll
         for (int j = 1; j < BAND; ++j)
-            st.HG[j] = A::cnst(((TYPE == NVBIO_HIP_GLOBAL ? p.txt_gap_open + (j - 1) * p.txt_gap_ext : 0) + p.gap_open) * (1 << SH));
+            st.HG[j] = A::cnst(((TYPE == NVBIO_HIP_GLOBAL ? p.txt_gap_open + (j - 1) * p.txt_gap_ext : 0) + p.gap_open - RT * p.gap_ext) * (1 << SH));
         #pragma unroll
         for (int j = 0; j < BAND - 1; ++j) st.F[j] = infimum;
-        st.bestkey = A::cnst(0); st.besti = 0;
+        st.bestkey = A::cnst(0); st.besti = 0; st.z = A::cnst(0); st.infrow = infimum;
 
         // first band of text (:441-442): symbols 0..BAND-2, no bounds check in the reference either
         {
@@ -621,7 +738,7 @@ banded_gotoh_score_kernel(const GotohParams p, const QA qa)
         }
         else if (TYPE == NVBIO_HIP_GLOBAL)
         {
-            score = A::to_int(st.HG[BAND - 1]) - p.gap_open;      // :641-642
+            score = A::to_int(st.HG[BAND - 1]) - p.gap_open + RT * int32_t(M + 1u) * p.gap_ext;      // :641-642 (row frame: out of row M-1's)
             sx = M + BAND - 1; sy = M;
         }
         else
@@ -632,7 +749,7 @@ banded_gotoh_score_kernel(const GotohParams p, const QA qa)
             #pragma unroll
             for (int j = 0; j < BAND; ++j)
             {
-                const int32_t h = A::to_int(st.HG[j]) - p.gap_open;
+                const int32_t h = A::to_int(st.HG[j]) - p.gap_open + RT * int32_t(M + 1u) * p.gap_ext;
                 if ((j == 0 || uint32_t(j) < m) && score <= h) { score = h; sx = M + j; sy = M; }
             }
         }
