@@ -349,7 +349,7 @@ def main():
             "gcups": n * CELLS_PER_ALN / kt / 1e9,
             "hbm_GBs": n * BYTES_PER_ALN / kt / 1e9,
             "hbm_frac": n * BYTES_PER_ALN / kt / 1e9 / HBM_PEAK_GBS,
-            "note": "integer DP: neither HBM nor MFMA binds it; peak = VALU lane-ops/s at 32 lanes/clk (the rate of the 16-bit ops the kernel is built from), achieved = cells x 14 nominal ops (SURVEY 8d); results are the reference's int32 scores, computed in int16 where provably exact",
+            "note": "integer DP: neither HBM nor MFMA binds it; peak = VALU lane-ops/s at 32 lanes/clk (the rate of the 16-bit ops the kernel is built from), achieved = cells x 14 nominal ops (SURVEY 8d: the reference recurrence's count); since the row-frame cell of round 6 the kernel ISSUES fewer (11 instructions per LOCAL cell + the row's set-up: `executed`), so `frac` -- the reference's operations per second over the instruction peak -- can touch 1, and `executed.frac` is the VALU issue utilisation; results are the reference's int32 scores, computed in int16 where provably exact",
         }
         # executed instructions (SQ_INSTS_VALU of the committed PMC pass, wave instructions x 64 lanes) next to the nominal-op count
         iv = measured_counter("banded_gotoh_score_kernel", "insts_valu_per_launch")
