@@ -234,6 +234,44 @@ def test_quality_aware_scheme(cuda, band, ty):
             assert bad.size == 0, (band, ty, force32, bad[:5], es[bad[:3]], gs[bad[:3]])
 
 
+@pytest.mark.parametrize("band", [15, 31])
+def test_row_frame_at_the_16_bit_limit(cuda, band):
+    """The kernels hold row i's values plus (i + 1) |G_e| (the row frame): a LOCAL value reaches 32 M (S + |G_e|) + 31, and the host sends a job
+    to the 16-bit kernel up to M = 1022 / (S + |G_e|) symbols -- 204 for nvBowtie's local scheme (match 2, gap extension 3), 340 for the
+    Gotoh scheme (2,-1,-2,-1).  Perfect reads of exactly those lengths (and one or two symbols either side) score M * match: the largest values
+    the frame can be asked to hold.  Against the oracle, and the 32-bit kernel on the same jobs."""
+    rng = np.random.default_rng(6400 + band)
+    local = nvb.SmithWatermanScoringScheme.local()
+    st = local.struct()
+    assert st.match == 2 and st.pattern_gap_ext == -3
+    pats, txts = [], []
+    for L in [202, 203, 204, 205, 206, 204, 339, 340, 341, 100]:
+        t = rng.integers(0, 4, L + 2 * band, dtype=np.uint8)
+        off = int(rng.integers(0, band))
+        pats.append(t[off:off + L].copy()); txts.append(t)
+    hp, ht = O.StringSet.from_lists(pats, 4, True), O.StringSet.from_lists(txts, 2, True)
+    total = int(hp.begin[-1] + hp.length[-1])
+    quals = np.full(total + 3, 40, np.uint8)
+    lut = np.array([st.mismatch[q] for q in range(256)], dtype=np.int32)
+    s6 = (st.match, st.pattern_gap_open, st.pattern_gap_ext, st.text_gap_open, st.text_gap_ext, 0)
+    es, ek = O.batch_banded_gotoh_score_qual(band, nvb.LOCAL, s6, lut, quals, hp, ht)
+    assert es[2] == 408 and es[7] == 680
+    p = nvb.PackedStringSet.from_host(hp.words, 4, True, hp.begin, hp.length, device=cuda)
+    t = nvb.PackedStringSet.from_host(ht.words, 2, True, ht.begin, ht.length, device=cuda)
+    dq = torch.from_numpy(quals).to(cuda)
+    for force32 in ("0", "1"):
+        nvb.set_test_switch("NVBIO_HIP_FORCE_32BIT", force32)
+        try:
+            gs, gk = nvb.batch_banded_alignment_score(band, nvb.make_gotoh_aligner(nvb.LOCAL, local), p, t, quals=dq)
+            torch.cuda.synchronize()
+        finally:
+            nvb.set_test_switch("NVBIO_HIP_FORCE_32BIT", "0")
+        assert (gs.cpu().numpy() == es).all() and (gk.cpu().numpy().view(np.uint32) == ek).all(), (band, force32, es, gs.cpu().numpy())
+    # the Gotoh scheme at its own limit
+    for ty in (nvb.LOCAL, nvb.SEMI_GLOBAL, nvb.GLOBAL):
+        check(band, ty, (2, -1, -2, -1), hp, O.StringSet.from_lists(txts, 2, False), cuda)
+
+
 @pytest.mark.parametrize("band", [7, 15, 31])
 @pytest.mark.parametrize("ty", [nvb.LOCAL, nvb.SEMI_GLOBAL, nvb.GLOBAL])
 def test_pattern_views_run_in_place(cuda, band, ty):
