@@ -121,7 +121,7 @@ static uint32_t max_len_16bit(int32_t match, int32_t best_pair /* max substituti
         if (per_row <= 0) return 0xFFFFFFFFu;
         return uint32_t(1022 / per_row);
     }
-    const int64_t lim = (15000 / A - int64_t(band) - 2) / 2;
+    const int64_t lim = (15000 / A - int64_t(band) - 2) / (row_step ? 2 : 1);
     return lim <= 0 ? 0u : uint32_t(lim);
 }
 
@@ -134,9 +134,15 @@ static int banded_gotoh_dispatch(nvb::GotohParams& p, const QA& qa, int64_t max_
 {
     using namespace nvb;
     // NVBIO_HIP_FORCE_32BIT=1 disables the 16-bit kernels (used by the tests to cover both widths)
-    const uint32_t lim16 = test_switch(SW_FORCE_32BIT) == 1 ? 0u
+    // the row-frame kernels' limit (the plain launch); the limit of the recurrence as written (asymmetric costs, the bounded form -- and LOCAL jobs
+    // between the two limits, which the plain launch hands to the A16P instance)
+    const bool rt = !asym && !bound;
+    const uint32_t lim_plain = test_switch(SW_FORCE_32BIT) == 1 ? 0u
+                             : max_len_16bit(p.match, best_pair, max_abs_cost, std::max(p.gap_open, p.txt_gap_open), std::max(p.gap_ext, p.txt_gap_ext), type, band_len, 0);
+    const uint32_t lim16 = !rt ? lim_plain : test_switch(SW_FORCE_32BIT) == 1 ? 0u
                          : max_len_16bit(p.match, best_pair, max_abs_cost, std::max(p.gap_open, p.txt_gap_open), std::max(p.gap_ext, p.txt_gap_ext), type, band_len,
                                          p.gap_ext < 0 ? -p.gap_ext : 0);
+    const uint32_t lim16p = (rt && type == NVBIO_HIP_LOCAL && lim_plain > lim16) ? lim_plain : lim16;
     const bool fixed = (patterns->length == nullptr);
     hipError_t e = hipSuccess;
     // LDS staging of each lane's words, sized from the longest pattern the caller announces
@@ -163,15 +169,23 @@ static int banded_gotoh_dispatch(nvb::GotohParams& p, const QA& qa, int64_t max_
         if (hipError_t z = hipMemsetAsync(bound->counter, 0, 4u, s)) return z;
         return launch_bounded<QA>(p, qa, *bound, type, band_len, width16, s);
     };
+    p.plain16 = 0u;
     if (lim16 > 0 && (!fixed || patterns->fixed_length <= lim16)) {
         p.len_lo = 0; p.len_hi = lim16;
         g_last_kernel = tag16;
         e = go(true);
         if (e != hipSuccess) return e;
     }
-    if (lim16 != 0xFFFFFFFFu && (!fixed || patterns->fixed_length > lim16)) {
-        p.len_lo = lim16 > 0 ? lim16 + 1 : 0; p.len_hi = 0xFFFFFFFFu;
-        if (fixed || lim16 == 0) g_last_kernel = tag32;
+    if (lim16p > lim16 && (!fixed || (patterns->fixed_length > lim16 && patterns->fixed_length <= lim16p))) {
+        p.len_lo = lim16 + 1u; p.len_hi = lim16p; p.plain16 = 1u;
+        if (fixed) g_last_kernel = tag16;
+        e = go(true);
+        p.plain16 = 0u;
+        if (e != hipSuccess) return e;
+    }
+    if (lim16p != 0xFFFFFFFFu && (!fixed || patterns->fixed_length > lim16p)) {
+        p.len_lo = lim16p > 0 ? lim16p + 1 : 0; p.len_hi = 0xFFFFFFFFu;
+        if (fixed || lim16p == 0) g_last_kernel = tag32;
         e = go(false);
     }
     return e;

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <stdlib.h>
 
+#include <type_traits>
 namespace nvb {
 
 struct GotohParams {
@@ -15,6 +16,7 @@ struct GotohParams {
                                                     // gap_* are then the costs of the move along the row (E).  Linear SW gaps: open == ext
     uint32_t  n;
     uint32_t  len_lo, len_hi;     // this launch handles jobs with len_lo <= pattern_len <= len_hi
+    uint32_t  plain16;            // the 16-bit launch runs the recurrence as the reference writes it (A16P): LOCAL jobs too long for the row frame's 16 bits
     uint32_t  stage_pw, stage_tw; // words of pattern / text each lane stages in LDS (0 = read HBM per block)
     int32_t*  out_score;
     uint32_t* out_sink;
@@ -764,6 +766,13 @@ hipError_t launch_band(const GotohParams& p, const QA& qa, int type, hipStream_t
 {
     const dim3 grid((p.n + 255u) / 256u), block(256);
     const unsigned lds_pad = (p.stage_pw + p.stage_tw) * 256u * 4u;      // the lanes' staged words
+    if constexpr (std::is_same<A, A16P>::value)                         // (instantiated for LOCAL only: the other types' row-frame limits are far out)
+    {
+        if (type != NVBIO_HIP_LOCAL) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((banded_gotoh_score_kernel<BAND, NVBIO_HIP_LOCAL, A, QA>), grid, block, lds_pad, stream, p, qa);
+        return hipGetLastError();
+    }
+    else
     switch (type) {
     case NVBIO_HIP_GLOBAL:      hipLaunchKernelGGL((banded_gotoh_score_kernel<BAND, NVBIO_HIP_GLOBAL, A, QA>),      grid, block, lds_pad, stream, p, qa); break;
     case NVBIO_HIP_LOCAL:       hipLaunchKernelGGL((banded_gotoh_score_kernel<BAND, NVBIO_HIP_LOCAL, A, QA>),       grid, block, lds_pad, stream, p, qa); break;
@@ -778,7 +787,7 @@ hipError_t launch_band(const GotohParams& p, const QA& qa, int type, hipStream_t
 template <int BAND, typename QA>
 hipError_t launch_band_width(const GotohParams& p, const QA& qa, int type, bool width16, hipStream_t s)
 {
-    return width16 ? launch_band<BAND, A16, QA>(p, qa, type, s) : launch_band<BAND, A32, QA>(p, qa, type, s);
+    return width16 ? (p.plain16 ? launch_band<BAND, A16P, QA>(p, qa, type, s) : launch_band<BAND, A16, QA>(p, qa, type, s)) : launch_band<BAND, A32, QA>(p, qa, type, s);
 }
 
 // the asymmetric instances: no qualities (SimpleSmithWatermanScheme)

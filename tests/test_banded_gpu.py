@@ -57,8 +57,8 @@ def check(band, ty, scheme, hp, ht, dev):
 
 def test_kernel_width_selection(cuda):
     """Jobs longer than the 16-bit exactness limit of their scheme go to the 32-bit kernel, per job:
-    LOCAL (2,-1,-2,-1) is exact in 16 bits up to 340 symbols (1022 / (match + |gap ext|): the kernels hold row i's values plus (i + 1) |G_e|;
-    511 before the row frame); mix lengths across both limits."""
+    LOCAL (2,-1,-2,-1) is exact in 16 bits up to 340 symbols in the row frame (1022 / (match + |gap ext|): the kernels hold row i's values plus
+    (i + 1) |G_e|) and up to 511 in the reference's own frame (the A16P instance takes the jobs in between); mix lengths across both limits."""
     rng = np.random.default_rng(42)
     pats, txts = [], []
     for L in [10, 100, 339, 340, 341, 342, 510, 511, 512, 513, 700, 1200, 30, 340, 341, 511, 512]:
