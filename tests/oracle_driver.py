@@ -227,8 +227,9 @@ def all_mapping(host_fmi, host_rfmi, sym, genome_words, genome_len, params, sche
     the accepted alignments in batch order, sorted by (read, strand, position) inside each batch.
     straddle_index: which index mark_straddling reads.  The reference hands it `pipeline.idx_queue` (aligner_all.h:520), the pointer
     sort_hi_bits returned -- a half of the ping-pong index buffer that sort_64_bits has refilled and sorted through since.  "sorted": both
-    sorts ended in the same half, the pointer sees the final (read, strand, position) index (what the radix sort of this image does at every
-    size the suites use: the reference application on the drop-in layer and nvbio_hip_sort_hits_pingpong agree on it); "locate": the
+    sorts ended in the same half, the pointer sees the final (read, strand, position) index (what the radix sort of this image does up to
+    ~10^5 hits per batch, i.e. at every size THIS numpy driver is run at; at a full batch of 2^20 hits the half holds the last pass but one,
+    which only a replay of the sorts can know: nvbio_hip_sort_hits_pingpong, held against the unchanged nvBowtie in test_ref_tests_gpu.py); "locate": the
     hi-bits index survived (the reading of rounds 4-5)."""
     band = band_length(params.max_dist)
     reads_rev, ext_words, index = pack_reads(sym)

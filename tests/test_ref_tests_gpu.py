@@ -374,6 +374,25 @@ def test_own_drivers_equal_reference_nvbowtie_on_varied_reads(case, cuda):
     assert same == n_ref, (case, same, n_ref)
 
 
+@pytest.mark.parametrize("reads", [4000, 150_000])
+def test_own_all_mapping_equals_reference_nvbowtie_with_repeats_across_sequence_boundaries(reads, cuda, monkeypatch):
+    """--all on a genome whose repeat copies may lie ACROSS sequence boundaries: the reference drops hits whose seed straddles two sequences through an
+    index it reads from a stale pointer into its sort's ping-pong buffer (aligner_all.h:520) -- the final index for small batches, the last pass
+    but one for a full batch of 2^20 hits (the 150 000-read case).  The drivers replay the two sorts on one pair of halves
+    (nvbio_hip_sort_hits_pingpong): every record the same."""
+    import argparse
+    import sys
+    if not os.path.exists(os.path.join(REF, "ref_nvBowtie")):
+        pytest.skip("oracle/_ref/ref_nvBowtie not built (needs /root/reference in the build container)")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import nvbowtie_compare
+    monkeypatch.setenv("NVBOWTIE_COMPARE_STRADDLE", "1")
+    args = dict(mode="all", reads=reads, seed=107, indels=0.2, show=3, len=100, ns=0.0, quals="I", repeats=0.6, extra="", own="")
+    same, n_ref, n_own = nvbowtie_compare.compare(argparse.Namespace(**args))
+    assert n_ref == n_own and n_ref >= reads
+    assert same == n_ref, (reads, same, n_ref)
+
+
 @pytest.mark.parametrize("case", [dict(mode="se", extra="-N 1", own="allow_sub=1", seed=61),
                                   dict(mode="se", extra="-L 18 -D 20 -R 3", own="seed_len=18,max_effort=20,max_reseed=3", seed=62),
                                   dict(mode="local", extra="-N 1 -L 16", own="allow_sub=1,seed_len=16", seed=63),
